@@ -1,0 +1,220 @@
+/*
+ * mdb_dev.h - C-ABI of the MI355X (gfx950) device layer of libmidoridb_amd.so.
+ *
+ * This is the thin boundary between the host executor (plain C, the reference's
+ * language) and the hand-written HIP kernels.  Plain pointers and sizes only; no
+ * C++ or torch types.  Every function returns MIDORIDB_OK (0) or a negative code
+ * (mdb_error.h); HIP failures map to -MIDORIDB_INTERNAL with the text available
+ * from mdb_dev_last_error().  Nothing here ever exit()s.
+ *
+ * Each operator replaces one loop of the reference's SELECT executor
+ * (reference src/engine/executor_select.c); the file:line of the code it replaces
+ * is cited per function.  All "dptr" arguments are DEVICE pointers; tables are
+ * device-resident columns:
+ *
+ *     values   : int64_t[n] (CT_INTEGER) or double[n] (CT_DOUBLE), 8 bytes per row
+ *     nullbits : uint64_t[(n+63)/64], bit (i & 63) of word (i >> 6) set  <=>  row i is NULL
+ *                (same polarity as the reference's row->null_bitmap, executor_select.c:384);
+ *                a NULL pointer means "column has no NULLs"
+ *
+ * which replaces the reference's 4 KiB row-store datablocks
+ * (reference include/primitive/row.h:15-28, datablock.h:7-13) on this path.
+ *
+ * A "tuple stream" of length n is the device analogue of the reference's early
+ * materialisation table: tuple k of a joined stream refers to base rows through
+ * row-id vectors (uint32_t[n], one per FROM table); rid == NULL means identity.
+ */
+#ifndef MDB_DEV_H
+#define MDB_DEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "mdb_error.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdb_dev_ctx mdb_dev_ctx;
+
+/* ------------------------------------------------------------------ context */
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on
+ * (e.g. the caller's current stream) or NULL for a context-owned stream. */
+int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out);
+void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx);
+int mdb_dev_ctx_set_stream(mdb_dev_ctx *ctx, void *stream);
+const char *mdb_dev_last_error(mdb_dev_ctx *ctx);
+int mdb_dev_sync(mdb_dev_ctx *ctx);
+/* Number of visible HIP devices (no context needed; <0 on error). */
+int mdb_dev_device_count(void);
+/* Pre-size the internal scratch arena (bytes).  Operators grow it on demand; growing
+ * synchronises and reallocates, so benchmarks call this (or one warm-up) first. */
+int mdb_dev_reserve(mdb_dev_ctx *ctx, size_t bytes);
+size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
+
+/* ------------------------------------------------------------------ memory */
+int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr);
+int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr);
+int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes);
+int mdb_dev_h2d(mdb_dev_ctx *ctx, void *dptr, const void *host, size_t bytes);	/* synchronous */
+int mdb_dev_d2h(mdb_dev_ctx *ctx, void *host, const void *dptr, size_t bytes);	/* synchronous */
+
+/* ------------------------------------------------------------------ profiling */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's
+ * stream; mdb_dev_prof_read() synchronises and reports per-kernel launch counts and
+ * total milliseconds since the last mdb_dev_prof_reset(). */
+#define MDB_DEV_PROF_MAX 32
+struct mdb_dev_prof_entry {
+	char name[48];
+	uint32_t launches;
+	double total_ms;
+};
+int mdb_dev_prof_enable(mdb_dev_ctx *ctx, int on);
+int mdb_dev_prof_reset(mdb_dev_ctx *ctx);
+int mdb_dev_prof_read(mdb_dev_ctx *ctx, struct mdb_dev_prof_entry *out, int cap, int *n_out);
+
+/* ------------------------------------------------------------------ scan + filter
+ *
+ * Replaces proc_where_clause() + eval_row_cond()/eval_cmp()/eval_isxnull()
+ * (reference executor_select.c:1435-1463, 1027-1074, 865-966): evaluate a boolean
+ * predicate per tuple and keep the tuples for which it is true, preserving order.
+ * Semantics kept from the reference: a comparison with a NULL operand is false
+ * (executor_select.c:557-579, 629-631); AND/OR/XOR fold left to right on plain
+ * booleans (:1041-1058); IS [NOT] NULL tests the NULL bit (:965).  Integer
+ * comparisons are full 64-bit here (the reference truncates to 32 bits - SURVEY
+ * 8a D5; identical on values in [-2^31, 2^31)).
+ *
+ * The predicate is a postfix program over a boolean stack.
+ */
+enum mdb_pred_op {
+	MDB_P_CMP_COL_CONST = 1,	/* push (col <cmp> imm); a=slot, cmp, type, imm           */
+	MDB_P_CMP_CONST_COL = 2,	/* push (imm <cmp> col)                                    */
+	MDB_P_CMP_COL_COL   = 3,	/* push (col a <cmp> col b)                                */
+	MDB_P_ISNULL        = 4,	/* push (col a IS NULL) ^ cmp  (cmp = 1 for IS NOT NULL)   */
+	MDB_P_CONST         = 5,	/* push imm != 0                                           */
+	MDB_P_AND           = 6,
+	MDB_P_OR            = 7,
+	MDB_P_XOR           = 8,
+};
+/* comparison codes = the reference's enum ast_comparison_type (include/parser/ast.h:71-84) */
+enum mdb_cmp { MDB_CMP_LT = 1, MDB_CMP_GT = 2, MDB_CMP_NE = 3, MDB_CMP_EQ = 4, MDB_CMP_LE = 5, MDB_CMP_GE = 6 };
+enum mdb_valtype { MDB_T_INT64 = 0, MDB_T_DOUBLE = 1 };
+
+struct mdb_pred_insn {
+	int32_t op;		/* enum mdb_pred_op */
+	int32_t cmp;		/* enum mdb_cmp (or negation flag for MDB_P_ISNULL) */
+	int32_t type;		/* enum mdb_valtype */
+	int32_t a, b;		/* column slots */
+	int32_t pad;
+	int64_t imm;		/* int64 value or the bits of a double */
+};
+
+#define MDB_PRED_MAX_INSNS 64
+#define MDB_PRED_MAX_SLOTS 16
+
+struct mdb_col_binding {
+	const void *values;		/* dptr: 8-byte values of the base column */
+	const uint64_t *nullbits;	/* dptr or NULL */
+	const uint32_t *rid;		/* dptr: row-id vector of the tuple stream for this column's table, or NULL = identity */
+};
+
+/* out_sel (dptr, capacity n) receives the ascending tuple positions that pass;
+ * *out_count (host) their number.  Synchronises. */
+int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns,
+		   const struct mdb_col_binding *cols, int n_cols, uint64_t n,
+		   uint32_t *out_sel, uint64_t *out_count);
+
+/* ------------------------------------------------------------------ gather / projection
+ *
+ * Replaces cpy_cols()/_merge_rows() (reference executor_select.c:340-438) and the
+ * column re-pack of proc_select_clause()/table_rem_column() (:1369-1433,
+ * src/primitive/column.c:146-243): late materialisation of one output column.
+ * dst[k] = src[idx ? idx[k] : k], NULL bits carried.  dst_nullbits may be NULL when
+ * src_nullbits is NULL. */
+int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_t *src_nullbits,
+		     const uint32_t *idx, uint64_t n, void *dst, uint64_t *dst_nullbits);
+/* dst[k] = src[idx[k]] for uint32 row-id vectors (composition of tuple streams). */
+int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
+int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n);
+
+/* ------------------------------------------------------------------ INNER JOIN (materialising)
+ *
+ * Replaces _join_nested_loop_tbl2tbl() for ON l = r (reference
+ * executor_select.c:1076-1149) and, applied twice, the intended semantics of the
+ * recursive join (:1151-1280; the reference's own tbl2mat is defective - SURVEY 8a D2).
+ *
+ * keys_l[n_l], keys_r[n_r]: 8-byte join keys (compared bit-wise; INT64 or DOUBLE bits)
+ * with optional NULL bits; a NULL key never matches (:557-579).  Output: the pairs
+ * (pos_l, pos_r) with keys_l[pos_l] == keys_r[pos_r], ordered by (pos_l, pos_r) -
+ * the reference's left-major / right-minor emission order.  *out_l / *out_r are
+ * device arrays allocated by the call (free with mdb_dev_free); *out_count their
+ * length.  Synchronises.
+ */
+int mdb_dev_join_pairs(mdb_dev_ctx *ctx,
+		       const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+		       const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+		       uint32_t **out_l, uint32_t **out_r, uint64_t *out_count);
+
+/* Cross join (FROM A, B  ==  JOIN ... ON 1=1, reference optimiser_select.c:395-464):
+ * all n_l * n_r pairs in (l, r) order, into caller buffers of that capacity. */
+int mdb_dev_cross_pairs(mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint32_t *out_l, uint32_t *out_r);
+
+/* ------------------------------------------------------------------ GROUP BY key + COUNT(*)
+ *
+ * Replaces proc_groupby_clause() + cmp_rows_col_mattbl() + inc_count_cols()
+ * (reference executor_select.c:1526-1588, 1465-1524) for one group field:
+ * groups of equal key (NULL keys form one group, :1477-1482), COUNT(*) per group.
+ * flags & MDB_ORDER_FIRST: groups come out in first-occurrence order like the
+ * reference's survivors; otherwise in unspecified order (still deterministic).
+ *
+ * out_first[g] = position of the group's first tuple, out_count[g] = COUNT(*).
+ * Caller buffers of capacity `cap` groups (n is always enough); *out_groups = G.
+ * Synchronises.
+ */
+#define MDB_ORDER_FIRST 1u
+int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
+			uint32_t flags, uint32_t *out_first, int64_t *out_count, uint64_t cap,
+			uint64_t *out_groups);
+
+/* ------------------------------------------------------------------ fused north-star pipeline
+ *
+ * SELECT l.key, COUNT(*) FROM L INNER JOIN R ON l.key = r.key GROUP BY l.key
+ * (reference tests/engine/executor_select.c:348-378; executor_select.c:1076-1149 +
+ * 1526-1588) without materialising the joined rows: per distinct non-NULL key k
+ * present on both sides, COUNT(*) = |{l: key=k}| * |{r: key=k}|.
+ *
+ * out_key[g], out_count[g] (and optionally out_first[g] = first L position of the
+ * key, may be NULL): caller buffers of capacity `cap` (n_l is always enough).
+ * With MDB_ORDER_FIRST the groups are in the reference's order (first occurrence in
+ * L-major join order).  *out_groups = G, *out_joined = number of joined rows
+ * (sum of counts).  Synchronises once at the end (to read G and J back).
+ */
+int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
+			     const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+			     const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+			     uint32_t flags,
+			     int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+			     uint64_t *out_groups, uint64_t *out_joined);
+
+/* ------------------------------------------------------------------ multi-GPU shuffle support
+ *
+ * Hash-partition a key column by destination GPU for the all-to-all exchange
+ * (SURVEY 8e): dest = hash(key) mod n_dest, NULL keys are dropped (they never
+ * join).  out_keys (capacity n) receives the keys grouped by destination, in input
+ * order within a destination; out_counts (HOST, n_dest entries) the group sizes.
+ * Synchronises.
+ */
+int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
+			      uint32_t n_dest, int64_t *out_keys, uint64_t *out_counts);
+
+/* ------------------------------------------------------------------ synthetic data (bench / tests)
+ * keys[i] = perm(i) mod modulus, perm = the bijection on [0, n) defined in
+ * include/mdb_gen.h (affine map modulo a prime with cycle walking, seeded). */
+int mdb_dev_gen_keys(mdb_dev_ctx *ctx, int64_t *keys, uint64_t n, uint64_t first_index, uint64_t domain,
+		     uint64_t seed, uint64_t modulus);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDB_DEV_H */

@@ -1,0 +1,114 @@
+/*
+ * mdb_query.h - the public C API of libmidoridb_amd.so: a drop-in for the reference's
+ * <engine/query.h> + <engine/database.h> on the SELECT path.
+ *
+ * The six entry points keep the reference's names, signatures, return conventions and
+ * ownership rules, so a program written against MidoriDB (reference README.md:39-81,
+ * tests/engine/executor_select.c) recompiles against this header unchanged:
+ *
+ *   database_open()        reference include/engine/database.h:26,  src/engine/database.c:10
+ *   database_close()       reference include/engine/database.h:32,  src/engine/database.c:30
+ *   query_execute()        reference include/engine/query.h:42,     src/engine/query.c:35
+ *   query_cur_step()       reference include/engine/query.h:44-51,  src/engine/query.c:108
+ *   query_column_int64()   reference include/engine/query.h:53-61,  src/engine/query.c:148
+ *   query_free()           reference include/engine/query.h:63-69,  src/engine/query.c:169
+ *
+ * Behind them the executor is the MI355X path (include/mdb_dev.h); there is NO CPU
+ * executor in this library: a SELECT fails with status ST_ERROR when no HIP device is
+ * usable.  Struct layouts keep the reference's field order and sizes (callers allocate
+ * struct database themselves, zero-initialised); the pointed-to objects are this
+ * library's columnar tables instead of the reference's row-store.
+ */
+#ifndef MDB_QUERY_H
+#define MDB_QUERY_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+#include <pthread.h>
+#include "mdb_error.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference include/engine/database.h:15-18 */
+struct database {
+	void *tables;			/* reference: struct hashtable *; here: the catalog */
+	pthread_mutex_t mutex;
+};
+
+/* reference include/engine/query.h:15-22 */
+enum query_output_status {
+	ST_OK_WITH_RESULTS,		/* SELECT */
+	ST_OK_EXECUTED,			/* CREATE, INSERT */
+	ST_ERROR
+};
+
+/* reference include/engine/query.h:24-28.  `table` points at the columnar result;
+ * `cursor_blk` is non-NULL once stepping has started; `cursor_offset` is the current row. */
+struct result_set {
+	void *table;
+	void *cursor_blk;
+	size_t cursor_offset;
+};
+
+struct query_output_error {
+	char message[1024];
+};
+
+/* reference include/engine/query.h:34-40 */
+struct query_output {
+	enum query_output_status status;
+	struct result_set results;
+	struct query_output_error error;
+	size_t n_rows_aff;
+};
+
+int database_open(struct database *db);
+void database_close(struct database *db);
+
+/* Executes one SQL statement (SELECT / CREATE TABLE / INSERT ... VALUES).  Never returns an
+ * error code: the returned object carries status + error.message; NULL only on allocation
+ * failure (reference src/engine/query.c:44-46, 95-105). */
+struct query_output *query_execute(struct database *db, char *query);
+
+/* MIDORIDB_ROW (4) while a row is current, MIDORIDB_OK (0) at the end - for results of ANY
+ * size (the reference's own cursor breaks past one 4 KiB datablock). */
+int query_cur_step(struct result_set *res);
+int64_t query_column_int64(struct result_set *res, int col_idx);
+void query_free(struct query_output *output);
+
+/* ------------------------------------------------------------------ extensions (not in the reference) */
+
+/* Same as query_execute() but takes the parser's output instead of SQL text: the RPN token
+ * strings of the reference grammar (src/parser/midorisql.y:517-528), one per line.  This is
+ * the seam a MidoriDB build with its own bison/flex front end binds to. */
+struct query_output *mdb_query_execute_rpn(struct database *db, const char *rpn_lines);
+
+/* The reference only has query_column_int64(); for a DOUBLE column it returns the raw bits
+ * (src/engine/query.c:162-166).  These add typed access, NULL tests and metadata. */
+double query_column_double(struct result_set *res, int col_idx);
+bool query_column_is_null(struct result_set *res, int col_idx);
+int query_column_count(struct result_set *res);
+const char *query_column_name(struct result_set *res, int col_idx);	/* "T.col" / "COUNT(*)" */
+int query_column_type(struct result_set *res, int col_idx);		/* reference enum COLUMN_TYPE values */
+uint64_t query_row_count(struct result_set *res);
+/* Whole result column at once (8-byte values, row order); NULL rows hold 0. */
+const int64_t *query_column_data(struct result_set *res, int col_idx);
+/* Device-pipeline milliseconds and joined-row count of the SELECT that produced `res`. */
+double query_exec_ms(struct result_set *res);
+uint64_t query_joined_rows(struct result_set *res);
+
+/* Bulk columnar ingest: append n rows; cols[c] = n 8-byte values for
+ * column c of the table (INT64 values or double bits), nulls[c] = n bytes (1 = NULL) or NULL. */
+int mdb_table_append_columns(struct database *db, const char *table, int ncols, uint64_t n,
+			     const int64_t *const *cols, const uint8_t *const *nulls);
+/* Fill a one-or-more-column INTEGER table with synthetic keys directly on the device (bench):
+ * column c gets perm_{seed+c}(i) mod modulus[c] (include/mdb_gen.h), i in [0, n). */
+int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint64_t seed, const uint64_t *modulus);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDB_QUERY_H */

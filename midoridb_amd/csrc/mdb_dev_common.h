@@ -1,0 +1,147 @@
+/*
+ * mdb_dev_common.h - internals shared by the HIP translation units of the device layer
+ * (context, scratch arena, launch/profiling helpers, wave64 primitives).  gfx950 only.
+ */
+#ifndef MDB_DEV_COMMON_H
+#define MDB_DEV_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <string>
+#include "mdb_dev.h"
+
+#define MDB_WAVE 64
+
+struct mdb_prof_rec {
+	int name_id;
+	hipEvent_t start, stop;
+};
+
+struct mdb_dev_ctx {
+	int device;
+	hipStream_t stream;
+	bool own_stream;
+	char err[512];
+	/* scratch arena (grow-only, bump allocated per operator) */
+	char *arena;
+	size_t arena_cap;
+	size_t arena_off;
+	/* device-side status words: [0] = leaf hash-table overflow flag, [1..] scratch */
+	uint32_t *d_status;
+	/* pinned host mirror for small read-backs */
+	uint64_t *h_pinned;
+	/* profiling */
+	bool prof_on;
+	std::vector<std::string> prof_names;
+	std::vector<mdb_prof_rec> prof_recs;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+	size_t prof_pool_used;
+};
+
+int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
+
+#define MDB_HIP(ctx, call)                                                                         \
+	do {                                                                                       \
+		hipError_t e__ = (call);                                                           \
+		if (e__ != hipSuccess)                                                             \
+			return mdb_set_err((ctx), -MIDORIDB_INTERNAL, "%s failed: %s (%s:%d)", #call, \
+					   hipGetErrorString(e__), __FILE__, __LINE__);            \
+	} while (0)
+
+/* scratch arena */
+int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes);
+void *mdb_arena_take(mdb_dev_ctx *ctx, size_t bytes);
+static inline size_t mdb_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+/* profiling hooks around one launch */
+void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name);
+void mdb_prof_end(mdb_dev_ctx *ctx);
+
+#define MDB_LAUNCH(ctx, name, kernel, grid, block, ...)                                            \
+	do {                                                                                       \
+		mdb_prof_begin((ctx), (name));                                                     \
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); \
+		mdb_prof_end((ctx));                                                               \
+		hipError_t le__ = hipGetLastError();                                               \
+		if (le__ != hipSuccess)                                                            \
+			return mdb_set_err((ctx), -MIDORIDB_INTERNAL, "launch %s failed: %s", (name), \
+					   hipGetErrorString(le__));                               \
+	} while (0)
+
+/* ------------------------------------------------------------------ device helpers */
+#ifdef __HIPCC__
+
+/* murmur3 fmix64: a bijection on 64-bit words (so the hashed value identifies the key),
+ * fmix64(0) == 0. */
+__host__ __device__ static inline uint64_t mdb_fmix64(uint64_t k)
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdULL;
+	k ^= k >> 33;
+	k *= 0xc4ceb9fe1a85ec53ULL;
+	k ^= k >> 33;
+	return k;
+}
+
+/* inverse of mdb_fmix64 (modular inverses of the two odd multipliers; x ^= x >> 33 is an involution
+ * on 64-bit words because 2*33 >= 64). */
+__host__ __device__ static inline uint64_t mdb_fmix64_inv(uint64_t k)
+{
+	k ^= k >> 33;
+	k *= 0x9cb4b2f8129337dbULL;
+	k ^= k >> 33;
+	k *= 0x4f74430c22a54005ULL;
+	k ^= k >> 33;
+	return k;
+}
+
+__device__ static inline uint32_t mdb_lane(void) { return threadIdx.x & (MDB_WAVE - 1); }
+__device__ static inline uint64_t mdb_lanemask_lt(void) { return (1ull << mdb_lane()) - 1ull; }
+
+/* inclusive scan across the 64 lanes of a wave */
+__device__ static inline uint32_t mdb_wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1) {
+		uint32_t t = __shfl_up(v, d, MDB_WAVE);
+		if ((int)mdb_lane() >= d)
+			v += t;
+	}
+	return v;
+}
+
+/* Block-wide exclusive scan of one value per thread.  blockDim.x must be a multiple of 64 and
+ * <= 1024; `tmp` is LDS scratch of at least 17 words.  Returns the exclusive prefix, *total the
+ * block sum.  Contains __syncthreads(): call from uniform control flow. */
+__device__ static inline uint32_t mdb_block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total)
+{
+	const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	uint32_t incl = mdb_wave_incl_scan(v);
+	__syncthreads();	/* protect tmp against a previous use */
+	if (mdb_lane() == MDB_WAVE - 1)
+		tmp[wave] = incl;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (uint32_t w = 0; w < nwaves; w++) {
+			uint32_t t = tmp[w];
+			tmp[w] = run;
+			run += t;
+		}
+		tmp[16] = run;
+	}
+	__syncthreads();
+	*total = tmp[16];
+	return incl - v + tmp[wave];
+}
+
+__device__ static inline bool mdb_bit_is_set(const uint64_t *bits, uint64_t i)
+{
+	return (bits[i >> 6] >> (i & 63)) & 1ull;
+}
+
+#endif /* __HIPCC__ */
+#endif /* MDB_DEV_COMMON_H */

@@ -1,0 +1,540 @@
+/*
+ * mdb_dev_core.hip - context, scratch arena, profiling, memory helpers, the exclusive-scan
+ * primitive and the small streaming kernels (gather / iota / cross pairs / synthetic keys).
+ * Hand-written HIP for gfx950 (wave64); HBM-bound byte work, no MFMA.
+ */
+#include "mdb_dev_internal.h"
+#include <stdarg.h>
+#include "mdb_gen.h"
+
+int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...)
+{
+	if (ctx) {
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+		va_end(ap);
+	}
+	return code;
+}
+
+/* ------------------------------------------------------------------ context */
+
+extern "C" int mdb_dev_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	return n;
+}
+
+extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
+{
+	if (!out)
+		return -MIDORIDB_ERROR;
+	*out = NULL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+		return -MIDORIDB_INTERNAL;
+	if (hipSetDevice(device) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	mdb_dev_ctx *ctx = new (std::nothrow) mdb_dev_ctx();
+	if (!ctx)
+		return -MIDORIDB_NOMEM;
+	ctx->device = device;
+	ctx->err[0] = 0;
+	ctx->arena = NULL;
+	ctx->arena_cap = ctx->arena_off = 0;
+	ctx->prof_on = false;
+	ctx->prof_pool_used = 0;
+	ctx->d_status = NULL;
+	ctx->h_pinned = NULL;
+	if (stream) {
+		ctx->stream = (hipStream_t)stream;
+		ctx->own_stream = false;
+	} else {
+		if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+			delete ctx;
+			return -MIDORIDB_INTERNAL;
+		}
+		ctx->own_stream = true;
+	}
+	if (hipMalloc((void **)&ctx->d_status, 64 * sizeof(uint64_t)) != hipSuccess ||
+	    hipHostMalloc((void **)&ctx->h_pinned, 1024 * sizeof(uint64_t)) != hipSuccess ||
+	    hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint64_t), ctx->stream) != hipSuccess) {
+		mdb_dev_ctx_destroy(ctx);
+		return -MIDORIDB_INTERNAL;
+	}
+	*out = ctx;
+	return MIDORIDB_OK;
+}
+
+extern "C" void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (auto &p : ctx->prof_pool) {
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+	if (ctx->arena)
+		(void)hipFree(ctx->arena);
+	if (ctx->d_status)
+		(void)hipFree(ctx->d_status);
+	if (ctx->h_pinned)
+		(void)hipHostFree(ctx->h_pinned);
+	if (ctx->own_stream)
+		(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" int mdb_dev_ctx_set_stream(mdb_dev_ctx *ctx, void *stream)
+{
+	if (!ctx)
+		return -MIDORIDB_ERROR;
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->own_stream) {
+		MDB_HIP(ctx, hipStreamDestroy(ctx->stream));
+		ctx->own_stream = false;
+	}
+	if (stream) {
+		ctx->stream = (hipStream_t)stream;
+	} else {
+		MDB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+		ctx->own_stream = true;
+	}
+	return MIDORIDB_OK;
+}
+
+extern "C" const char *mdb_dev_last_error(mdb_dev_ctx *ctx)
+{
+	return ctx ? ctx->err : "no context";
+}
+
+extern "C" int mdb_dev_sync(mdb_dev_ctx *ctx)
+{
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ arena */
+
+int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes)
+{
+	total_bytes = mdb_align_up(total_bytes) + 4096;
+	if (total_bytes > ctx->arena_cap) {
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->arena) {
+			MDB_HIP(ctx, hipFree(ctx->arena));
+			ctx->arena = NULL;
+			ctx->arena_cap = 0;
+		}
+		size_t want = total_bytes + total_bytes / 16;
+		hipError_t e = hipMalloc((void **)&ctx->arena, want);
+		if (e != hipSuccess)
+			return mdb_set_err(ctx, -MIDORIDB_NOMEM, "scratch arena of %zu bytes: %s", want, hipGetErrorString(e));
+		ctx->arena_cap = want;
+	}
+	ctx->arena_off = 0;
+	return MIDORIDB_OK;
+}
+
+void *mdb_arena_take(mdb_dev_ctx *ctx, size_t bytes)
+{
+	size_t off = ctx->arena_off;
+	bytes = mdb_align_up(bytes ? bytes : 1);
+	if (off + bytes > ctx->arena_cap) {
+		mdb_set_err(ctx, -MIDORIDB_INTERNAL, "scratch arena exhausted (%zu + %zu > %zu): sizing bug", off, bytes,
+			    ctx->arena_cap);
+		return NULL;
+	}
+	ctx->arena_off = off + bytes;
+	return ctx->arena + off;
+}
+
+extern "C" int mdb_dev_reserve(mdb_dev_ctx *ctx, size_t bytes)
+{
+	return mdb_arena_begin(ctx, bytes);
+}
+
+extern "C" size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx)
+{
+	return ctx->arena_cap;
+}
+
+/* ------------------------------------------------------------------ memory */
+
+extern "C" int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
+{
+	*dptr = NULL;
+	hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+	if (e != hipSuccess)
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr)
+{
+	if (!dptr)
+		return MIDORIDB_OK;
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MDB_HIP(ctx, hipFree(dptr));
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes)
+{
+	if (bytes)
+		MDB_HIP(ctx, hipMemsetAsync(dptr, byte, bytes, ctx->stream));
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_h2d(mdb_dev_ctx *ctx, void *dptr, const void *host, size_t bytes)
+{
+	if (bytes) {
+		MDB_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_d2h(mdb_dev_ctx *ctx, void *host, const void *dptr, size_t bytes)
+{
+	if (bytes) {
+		MDB_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ profiling */
+
+void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name)
+{
+	if (!ctx->prof_on)
+		return;
+	int id = -1;
+	for (size_t i = 0; i < ctx->prof_names.size(); i++)
+		if (ctx->prof_names[i] == name) {
+			id = (int)i;
+			break;
+		}
+	if (id < 0) {
+		ctx->prof_names.push_back(name);
+		id = (int)ctx->prof_names.size() - 1;
+	}
+	if (ctx->prof_pool_used == ctx->prof_pool.size()) {
+		hipEvent_t a, b;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+			return;
+		ctx->prof_pool.push_back(std::make_pair(a, b));
+	}
+	auto &ev = ctx->prof_pool[ctx->prof_pool_used++];
+	mdb_prof_rec r;
+	r.name_id = id;
+	r.start = ev.first;
+	r.stop = ev.second;
+	ctx->prof_recs.push_back(r);
+	(void)hipEventRecord(r.start, ctx->stream);
+}
+
+void mdb_prof_end(mdb_dev_ctx *ctx)
+{
+	if (!ctx->prof_on || ctx->prof_recs.empty())
+		return;
+	(void)hipEventRecord(ctx->prof_recs.back().stop, ctx->stream);
+}
+
+extern "C" int mdb_dev_prof_enable(mdb_dev_ctx *ctx, int on)
+{
+	ctx->prof_on = on != 0;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_prof_reset(mdb_dev_ctx *ctx)
+{
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->prof_recs.clear();
+	ctx->prof_pool_used = 0;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_prof_read(mdb_dev_ctx *ctx, struct mdb_dev_prof_entry *out, int cap, int *n_out)
+{
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	int n = (int)ctx->prof_names.size();
+	if (n > cap)
+		n = cap;
+	for (int i = 0; i < n; i++) {
+		memset(&out[i], 0, sizeof(out[i]));
+		snprintf(out[i].name, sizeof(out[i].name), "%s", ctx->prof_names[i].c_str());
+	}
+	for (auto &r : ctx->prof_recs) {
+		if (r.name_id >= n)
+			continue;
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+			out[r.name_id].launches++;
+			out[r.name_id].total_ms += ms;
+		}
+	}
+	*n_out = n;
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ exclusive scan (uint32)
+ *
+ * reduce -> spine -> apply.  Each block owns MDB_SCAN_CHUNK consecutive words (16 per thread).
+ * HBM traffic: 2 reads + 1 write of the array; it is only ever run over histogram-sized arrays
+ * (a few % of the key bytes).
+ */
+#define SCAN_THREADS 256
+#define SCAN_PER_THREAD (MDB_SCAN_CHUNK / SCAN_THREADS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *__restrict__ data, uint64_t len,
+							       uint32_t *__restrict__ block_sums)
+{
+	__shared__ uint32_t tmp[32];
+	const uint64_t base = (uint64_t)blockIdx.x * MDB_SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	uint32_t s = 0;
+	if (base + SCAN_PER_THREAD <= len) {
+		const uint4 *p = reinterpret_cast<const uint4 *>(data + base);
+#pragma unroll
+		for (int i = 0; i < SCAN_PER_THREAD / 4; i++) {
+			uint4 v = p[i];
+			s += v.x + v.y + v.z + v.w;
+		}
+	} else {
+		for (int i = 0; i < SCAN_PER_THREAD; i++)
+			if (base + i < len)
+				s += data[base + i];
+	}
+	uint32_t total;
+	(void)mdb_block_excl_scan(s, tmp, &total);
+	if (threadIdx.x == 0)
+		block_sums[blockIdx.x] = total;
+}
+
+/* single block: exclusive scan of block_sums[0..nb) in place, carry across 1024-wide sweeps */
+__global__ __launch_bounds__(1024) void k_scan_spine(uint32_t *__restrict__ block_sums, uint32_t nb)
+{
+	__shared__ uint32_t tmp[32];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nb; base += 1024) {
+		uint32_t i = base + threadIdx.x;
+		uint32_t v = i < nb ? block_sums[i] : 0;
+		uint32_t total;
+		uint32_t ex = mdb_block_excl_scan(v, tmp, &total);
+		if (i < nb)
+			block_sums[i] = carry + ex;
+		carry += total;
+	}
+	if (threadIdx.x == 0)
+		block_sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *__restrict__ data, uint64_t len,
+							      const uint32_t *__restrict__ block_sums)
+{
+	__shared__ uint32_t tmp[32];
+	const uint64_t base = (uint64_t)blockIdx.x * MDB_SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+	uint32_t v[SCAN_PER_THREAD];
+	uint32_t s = 0;
+	const bool full = base + SCAN_PER_THREAD <= len;
+	if (full) {
+		const uint4 *p = reinterpret_cast<const uint4 *>(data + base);
+#pragma unroll
+		for (int i = 0; i < SCAN_PER_THREAD / 4; i++) {
+			uint4 q = p[i];
+			v[4 * i + 0] = q.x;
+			v[4 * i + 1] = q.y;
+			v[4 * i + 2] = q.z;
+			v[4 * i + 3] = q.w;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < SCAN_PER_THREAD; i++)
+			v[i] = base + i < len ? data[base + i] : 0;
+	}
+#pragma unroll
+	for (int i = 0; i < SCAN_PER_THREAD; i++)
+		s += v[i];
+	uint32_t total;
+	uint32_t run = mdb_block_excl_scan(s, tmp, &total) + block_sums[blockIdx.x];
+#pragma unroll
+	for (int i = 0; i < SCAN_PER_THREAD; i++) {
+		uint32_t t = v[i];
+		v[i] = run;
+		run += t;
+	}
+	if (full) {
+		uint4 *p = reinterpret_cast<uint4 *>(data + base);
+#pragma unroll
+		for (int i = 0; i < SCAN_PER_THREAD / 4; i++)
+			p[i] = make_uint4(v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+	} else {
+#pragma unroll
+		for (int i = 0; i < SCAN_PER_THREAD; i++)
+			if (base + i < len)
+				data[base + i] = v[i];
+	}
+}
+
+int mdb_scan_u32_inplace(mdb_dev_ctx *ctx, uint32_t *data, uint64_t len, uint32_t *block_sums)
+{
+	if (len == 0)
+		return MIDORIDB_OK;
+	uint32_t nb = (uint32_t)((len + MDB_SCAN_CHUNK - 1) / MDB_SCAN_CHUNK);
+	MDB_LAUNCH(ctx, "scan_reduce", k_scan_reduce, nb, SCAN_THREADS, data, len, block_sums);
+	MDB_LAUNCH(ctx, "scan_spine", k_scan_spine, 1, 1024, block_sums, nb);
+	MDB_LAUNCH(ctx, "scan_apply", k_scan_apply, nb, SCAN_THREADS, data, len, block_sums);
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ gather / iota / cross pairs */
+
+#define STREAM_THREADS 256
+#define STREAM_ROUNDS 8		/* each block handles 256*8 = 2048 consecutive outputs */
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_gather64(const uint64_t *__restrict__ src,
+							     const uint64_t *__restrict__ src_null,
+							     const uint32_t *__restrict__ idx, uint64_t n,
+							     uint64_t *__restrict__ dst, uint64_t *__restrict__ dst_null)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		/* one wave covers 64 consecutive outputs per round => one NULL word per wave per round */
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		bool in = k < n;
+		uint64_t row = 0, v = 0;
+		bool isnull = false;
+		if (in) {
+			row = idx ? (uint64_t)idx[k] : k;
+			v = src[row];
+			if (src_null)
+				isnull = mdb_bit_is_set(src_null, row);
+			dst[k] = v;
+		}
+		if (dst_null) {
+			uint64_t m = __ballot(in && isnull);
+			if (mdb_lane() == 0 && (k < n))
+				dst_null[k >> 6] = m;
+		}
+	}
+}
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_gather32(const uint32_t *__restrict__ src,
+							     const uint32_t *__restrict__ idx, uint64_t n,
+							     uint32_t *__restrict__ dst)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n)
+			dst[k] = src[idx[k]];
+	}
+}
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_iota32(uint32_t *__restrict__ dst, uint64_t n)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n)
+			dst[k] = (uint32_t)k;
+	}
+}
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_cross_pairs(uint64_t n_l, uint64_t n_r, uint32_t *__restrict__ out_l,
+								uint32_t *__restrict__ out_r)
+{
+	const uint64_t total = n_l * n_r;
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < total) {
+			out_l[k] = (uint32_t)(k / n_r);
+			out_r[k] = (uint32_t)(k % n_r);
+		}
+	}
+}
+
+static inline uint32_t stream_grid(uint64_t n)
+{
+	return (uint32_t)((n + (uint64_t)STREAM_THREADS * STREAM_ROUNDS - 1) / ((uint64_t)STREAM_THREADS * STREAM_ROUNDS));
+}
+
+extern "C" int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_t *src_nullbits, const uint32_t *idx,
+				uint64_t n, void *dst, uint64_t *dst_nullbits)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (src_nullbits && !dst_nullbits)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "gather64: source has NULL bits but no destination NULL bits given");
+	MDB_LAUNCH(ctx, "gather64", k_gather64, stream_grid(n), STREAM_THREADS, (const uint64_t *)src, src_nullbits, idx, n,
+		   (uint64_t *)dst, dst_nullbits);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	MDB_LAUNCH(ctx, "gather32", k_gather32, stream_grid(n), STREAM_THREADS, src, idx, n, dst);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	MDB_LAUNCH(ctx, "iota32", k_iota32, stream_grid(n), STREAM_THREADS, dst, n);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_cross_pairs(mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint32_t *out_l, uint32_t *out_r)
+{
+	if (n_l == 0 || n_r == 0)
+		return MIDORIDB_OK;
+	if (n_l * n_r >= (1ull << 32))
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "cross join of %llu x %llu rows is too large",
+				   (unsigned long long)n_l, (unsigned long long)n_r);
+	MDB_LAUNCH(ctx, "cross_pairs", k_cross_pairs, stream_grid(n_l * n_r), STREAM_THREADS, n_l, n_r, out_l, out_r);
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ synthetic keys (include/mdb_gen.h) */
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_gen_keys(int64_t *__restrict__ keys, uint64_t n, uint64_t first,
+							      mdb_perm perm, uint64_t modulus)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n) {
+			uint64_t v = mdb_perm_apply(&perm, first + k);
+			if (modulus)
+				v %= modulus;
+			keys[k] = (int64_t)v;
+		}
+	}
+}
+
+extern "C" int mdb_dev_gen_keys(mdb_dev_ctx *ctx, int64_t *keys, uint64_t n, uint64_t first_index, uint64_t domain,
+				uint64_t seed, uint64_t modulus)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (first_index + n > domain)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "gen_keys: index range exceeds the permutation domain");
+	mdb_perm perm = mdb_perm_make(domain, seed);
+	MDB_LAUNCH(ctx, "gen_keys", k_gen_keys, stream_grid(n), STREAM_THREADS, keys, n, first_index, perm, modulus);
+	return MIDORIDB_OK;
+}

@@ -1,0 +1,281 @@
+/*
+ * mdb_dev_filter.hip - predicate filter: wavefront ballot + ordered stream compaction.
+ *
+ * Replaces the reference's WHERE pass (reference src/engine/executor_select.c:1435-1463), which
+ * walks every early-materialised row, re-resolves each operand's column by string compare
+ * (:776-789) and tombstones the rows that fail.  Here:
+ *
+ *   k_pred_bits   each lane evaluates the predicate program for one tuple; a 64-lane __ballot
+ *                 turns the wave's results into one 64-bit word of the pass bitmap (n/8 bytes),
+ *                 and the per-block pass counts are accumulated
+ *   (scan)        exclusive scan of the block counts -> output offset of every block
+ *   k_bits_to_sel re-reads only the bitmap: popcount prefix inside the block gives each passing
+ *                 tuple its output slot; tuple positions are written in ascending order
+ *
+ * so the input columns are read exactly once (coalesced when the stream is a base table) and the
+ * result order equals the reference's survivor order.
+ *
+ * NULL semantics as the reference: a comparison with a NULL operand is false (:557-579, :629-631),
+ * IS [NOT] NULL reads the NULL bit (:965), AND/OR/XOR combine plain booleans (:1041-1058).
+ */
+#include "mdb_dev_internal.h"
+
+#define FILT_THREADS 256
+#define FILT_WAVES (FILT_THREADS / MDB_WAVE)
+#define FILT_WORDS_PER_WAVE 16
+#define FILT_WORDS_PER_BLOCK (FILT_WAVES * FILT_WORDS_PER_WAVE)	/* 64 words */
+#define FILT_TUPLES_PER_BLOCK (FILT_WORDS_PER_BLOCK * 64)		/* 4096 tuples */
+
+struct pred_args {
+	mdb_pred_insn insn[MDB_PRED_MAX_INSNS];
+	mdb_col_binding cols[MDB_PRED_MAX_SLOTS];
+	int32_t n_insns;
+	int32_t pad;
+};
+
+__device__ static inline bool pred_load(const mdb_col_binding &c, uint64_t k, uint64_t *v)
+{
+	const uint64_t row = c.rid ? (uint64_t)c.rid[k] : k;
+	if (c.nullbits && mdb_bit_is_set(c.nullbits, row))
+		return false;
+	*v = reinterpret_cast<const uint64_t *>(c.values)[row];
+	return true;
+}
+
+__device__ static inline bool pred_cmp(int32_t cmp, int32_t type, uint64_t x, uint64_t y)
+{
+	if (type == MDB_T_DOUBLE) {
+		const double a = __longlong_as_double((long long)x), b = __longlong_as_double((long long)y);
+		switch (cmp) {
+		case MDB_CMP_LT: return a < b;
+		case MDB_CMP_GT: return a > b;
+		case MDB_CMP_NE: return a != b;
+		case MDB_CMP_EQ: return a == b;
+		case MDB_CMP_LE: return a <= b;
+		case MDB_CMP_GE: return a >= b;
+		}
+		return false;
+	}
+	const int64_t a = (int64_t)x, b = (int64_t)y;
+	switch (cmp) {
+	case MDB_CMP_LT: return a < b;
+	case MDB_CMP_GT: return a > b;
+	case MDB_CMP_NE: return a != b;
+	case MDB_CMP_EQ: return a == b;
+	case MDB_CMP_LE: return a <= b;
+	case MDB_CMP_GE: return a >= b;
+	}
+	return false;
+}
+
+__device__ static inline bool pred_eval(const pred_args &p, uint64_t k)
+{
+	uint64_t st = 0;	/* boolean stack, top = bit 0 */
+	for (int i = 0; i < p.n_insns; i++) {
+		const mdb_pred_insn &in = p.insn[i];
+		bool b = false;
+		uint64_t x, y;
+		switch (in.op) {
+		case MDB_P_CMP_COL_CONST:
+			b = pred_load(p.cols[in.a], k, &x) && pred_cmp(in.cmp, in.type, x, (uint64_t)in.imm);
+			st = (st << 1) | (uint64_t)b;
+			break;
+		case MDB_P_CMP_CONST_COL:
+			b = pred_load(p.cols[in.a], k, &x) && pred_cmp(in.cmp, in.type, (uint64_t)in.imm, x);
+			st = (st << 1) | (uint64_t)b;
+			break;
+		case MDB_P_CMP_COL_COL: {
+			const bool okx = pred_load(p.cols[in.a], k, &x);
+			const bool oky = pred_load(p.cols[in.b], k, &y);
+			b = okx && oky && pred_cmp(in.cmp, in.type, x, y);
+			st = (st << 1) | (uint64_t)b;
+			break;
+		}
+		case MDB_P_ISNULL:
+			b = !pred_load(p.cols[in.a], k, &x);
+			b = b != (in.cmp != 0);
+			st = (st << 1) | (uint64_t)b;
+			break;
+		case MDB_P_CONST:
+			st = (st << 1) | (uint64_t)(in.imm != 0);
+			break;
+		case MDB_P_AND:
+		case MDB_P_OR:
+		case MDB_P_XOR: {
+			const uint64_t r = st & 1, l = (st >> 1) & 1;
+			const uint64_t v = in.op == MDB_P_AND ? (l & r) : (in.op == MDB_P_OR ? (l | r) : (l ^ r));
+			st = ((st >> 2) << 1) | v;
+			break;
+		}
+		default:
+			break;
+		}
+	}
+	return st & 1;
+}
+
+/* MODE 0: general predicate program; MODE 1: "vals[k] != 0" over an int64 array */
+template <int MODE>
+__global__ __launch_bounds__(FILT_THREADS) void k_pred_bits(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
+							    uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts)
+{
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0)
+		s_cnt = 0;
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+	uint32_t cnt = 0;
+#pragma unroll 4
+	for (int r = 0; r < FILT_WORDS_PER_WAVE; r++) {
+		const uint64_t word = word0 + r;
+		const uint64_t k = (word << 6) + mdb_lane();
+		bool pass = false;
+		if (k < n)
+			pass = MODE == 1 ? (vals[k] != 0) : pred_eval(p, k);
+		const uint64_t m = __ballot(pass);
+		if ((word << 6) < n) {
+			if (mdb_lane() == 0)
+				bits[word] = m;
+			cnt += (uint32_t)__popcll(m);
+		}
+	}
+	if (mdb_lane() == 0 && cnt)
+		atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		block_counts[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(FILT_THREADS) void k_bits_to_sel(const uint64_t *__restrict__ bits, uint64_t n,
+							      const uint32_t *__restrict__ block_off, uint32_t *__restrict__ out_sel)
+{
+	__shared__ uint32_t s_woff[FILT_WORDS_PER_BLOCK];
+	const uint64_t nwords = (n + 63) >> 6;
+	const uint64_t bword0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK;
+	if (threadIdx.x < FILT_WORDS_PER_BLOCK) {	/* exactly wave 0 */
+		const uint64_t w = bword0 + threadIdx.x;
+		const uint32_t c = w < nwords ? (uint32_t)__popcll(bits[w]) : 0;
+		s_woff[threadIdx.x] = mdb_wave_incl_scan(c) - c;
+	}
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t base_off = block_off[blockIdx.x];
+	const uint64_t lt = mdb_lanemask_lt();
+#pragma unroll 4
+	for (int r = 0; r < FILT_WORDS_PER_WAVE; r++) {
+		const uint32_t wl = wave * FILT_WORDS_PER_WAVE + r;
+		const uint64_t w = bword0 + wl;
+		if (w >= nwords)
+			break;
+		const uint64_t m = bits[w];
+		if ((m >> mdb_lane()) & 1ull)
+			out_sel[base_off + s_woff[wl] + (uint32_t)__popcll(m & lt)] = (uint32_t)((w << 6) + mdb_lane());
+	}
+}
+
+static inline uint32_t filt_blocks(uint64_t n) { return (uint32_t)((n + FILT_TUPLES_PER_BLOCK - 1) / FILT_TUPLES_PER_BLOCK); }
+
+size_t mdb_filter_arena_bytes(uint64_t n)
+{
+	const uint64_t nb = filt_blocks(n) + 1;
+	return mdb_align_up(((n + 63) / 64) * 8) + mdb_align_up(nb * 4) + mdb_align_up(mdb_scan_scratch_words(nb) * 4) + 1024;
+}
+
+/* Shared tail: bitmap + block counts (arena) -> scan -> selection vector.  *d_total = device
+ * address of the number of selected tuples.  No host sync. */
+static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, const int64_t *vals, uint64_t n, uint32_t *out_sel,
+		      uint32_t **d_total)
+{
+	const uint32_t nb = filt_blocks(n);
+	uint64_t *bits = (uint64_t *)mdb_arena_take(ctx, ((n + 63) / 64) * 8);
+	uint32_t *bc = (uint32_t *)mdb_arena_take(ctx, ((size_t)nb + 1) * 4);
+	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nb + 1) * 4);
+	if (!bits || !bc || !scan_tmp)
+		return -MIDORIDB_INTERNAL;
+	MDB_HIP(ctx, hipMemsetAsync(bc + nb, 0, 4, ctx->stream));
+	if (mode == 1) {
+		pred_args empty;
+		memset(&empty, 0, sizeof(empty));
+		MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+	} else {
+		MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+	}
+	int rc = mdb_scan_u32_inplace(ctx, bc, (uint64_t)nb + 1, scan_tmp);
+	if (rc)
+		return rc;
+	MDB_LAUNCH(ctx, "filter_bits_to_sel", k_bits_to_sel, nb, FILT_THREADS, bits, n, bc, out_sel);
+	*d_total = bc + nb;
+	return MIDORIDB_OK;
+}
+
+int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint32_t *out_sel, uint32_t **d_total)
+{
+	return filter_run(ctx, 1, NULL, vals, n, out_sel, d_total);
+}
+
+extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols,
+			      int n_cols, uint64_t n, uint32_t *out_sel, uint64_t *out_count)
+{
+	*out_count = 0;
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: too many tuples");
+	if (n_insns <= 0 || n_insns > MDB_PRED_MAX_INSNS || n_cols < 0 || n_cols > MDB_PRED_MAX_SLOTS)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: predicate program too large (%d insns, %d columns)", n_insns, n_cols);
+	/* validate the program: stack discipline and slot numbers */
+	int depth = 0;
+	for (int i = 0; i < n_insns; i++) {
+		const mdb_pred_insn &in = prog[i];
+		switch (in.op) {
+		case MDB_P_CMP_COL_COL:
+			if (in.b < 0 || in.b >= n_cols)
+				return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: bad column slot");
+			/* fallthrough */
+		case MDB_P_CMP_COL_CONST:
+		case MDB_P_CMP_CONST_COL:
+		case MDB_P_ISNULL:
+			if (in.a < 0 || in.a >= n_cols)
+				return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: bad column slot");
+			depth++;
+			break;
+		case MDB_P_CONST:
+			depth++;
+			break;
+		case MDB_P_AND:
+		case MDB_P_OR:
+		case MDB_P_XOR:
+			if (depth < 2)
+				return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: malformed predicate program");
+			depth--;
+			break;
+		default:
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: unknown predicate opcode %d", in.op);
+		}
+		if (depth > 60)
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: predicate nesting too deep");
+	}
+	if (depth != 1)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: malformed predicate program");
+
+	pred_args p;
+	memset(&p, 0, sizeof(p));
+	memcpy(p.insn, prog, sizeof(mdb_pred_insn) * (size_t)n_insns);
+	if (n_cols)
+		memcpy(p.cols, cols, sizeof(mdb_col_binding) * (size_t)n_cols);
+	p.n_insns = n_insns;
+
+	int rc = mdb_arena_begin(ctx, mdb_filter_arena_bytes(n));
+	if (rc)
+		return rc;
+	uint32_t *d_total = NULL;
+	rc = filter_run(ctx, 0, &p, NULL, n, out_sel, &d_total);
+	if (rc)
+		return rc;
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_count = h[0];
+	return MIDORIDB_OK;
+}

@@ -1,0 +1,46 @@
+/*
+ * mdb_dev_internal.h - host-side entry points shared between the device-layer translation units.
+ */
+#ifndef MDB_DEV_INTERNAL_H
+#define MDB_DEV_INTERNAL_H
+
+#include "mdb_dev_common.h"
+
+/* ---- scan (mdb_dev_core.hip) ----------------------------------------------------------------
+ * In-place exclusive prefix sum over data[0..len) (uint32).  data[len-1]'s exclusive prefix is the
+ * last value written; callers that need the grand total append one zero element.  `block_sums`
+ * is scratch of mdb_scan_scratch_words(len) uint32 words. */
+#define MDB_SCAN_CHUNK 4096u
+static inline size_t mdb_scan_scratch_words(uint64_t len) { return (size_t)((len + MDB_SCAN_CHUNK - 1) / MDB_SCAN_CHUNK) + 1; }
+int mdb_scan_u32_inplace(mdb_dev_ctx *ctx, uint32_t *data, uint64_t len, uint32_t *block_sums);
+
+/* ---- radix partition (mdb_dev_partition.hip) ------------------------------------------------ */
+#define MDB_TILE 4096u		/* elements per partition tile */
+#define MDB_MAX_RADIX_BITS 9	/* up to 512-way per level */
+
+enum mdb_digit_mode {
+	MDB_DIGIT_RADIX = 0,	/* digit = bit field of the hashed key (MSD levels) */
+	MDB_DIGIT_MOD = 1,	/* digit = low32(hash) mod n_dest (multi-GPU destination) */
+};
+
+struct mdb_part_result {
+	uint64_t *hv;		/* hashed keys grouped by leaf (or original keys when inverse_out) */
+	uint32_t *rid;		/* row ids, same order (NULL when not requested) */
+	uint32_t *leaf_off;	/* nleaves + 1 offsets into hv/rid */
+	uint32_t nleaves;
+	uint32_t bits_total;
+};
+
+/* bytes of arena needed by mdb_partition_table() */
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid);
+
+/* Partition one key column into 2^(bits1+bits2) leaves by the top bits of fmix64(key), dropping
+ * NULL keys, stable (input order is kept inside a leaf).  All temporaries and outputs are carved
+ * from the arena (caller has called mdb_arena_begin with enough room).  No host sync. */
+int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
+			int bits1, int bits2, bool want_rid, mdb_part_result *out);
+
+/* choose level bits so that the average leaf holds about `target` keys */
+void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
+
+#endif /* MDB_DEV_INTERNAL_H */

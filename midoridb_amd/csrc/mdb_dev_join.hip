@@ -1,0 +1,586 @@
+/*
+ * mdb_dev_join.hip - per-leaf LDS hash build/probe kernels and the operators built on them:
+ *
+ *   mdb_dev_join_group_count  INNER JOIN + GROUP BY join key + COUNT(*), fused (north-star query)
+ *   mdb_dev_group_count       GROUP BY key + COUNT(*) over one key column
+ *   mdb_dev_join_pairs        materialising INNER JOIN, pairs in the reference's emission order
+ *
+ * After mdb_partition_table() every leaf holds all rows (of both tables) whose hashed key shares
+ * the same top bits, in original row order.  One workgroup owns one leaf: it builds an
+ * open-addressing hash table in LDS keyed by the 64-bit hashed key (fmix64 is a bijection, so
+ * equal hash <=> equal key; the value 0 = "empty slot", the single key that hashes to 0 is kept
+ * in a dedicated side slot), then streams the other side through it.  All counters are LDS
+ * atomics; global memory is read once, coalesced, and written once.
+ *
+ * Reference semantics reproduced (file:line = reference src/engine/executor_select.c):
+ *   - a NULL join key matches nothing (:557-579)            -> NULL keys were dropped at level 0
+ *   - N:M duplicates: every pair is a joined row (:1096-1141) -> COUNT = cntL * cntR per key
+ *   - GROUP BY keeps the first row of each group, in order (:1542-1583)
+ *                                                            -> groups ordered by first L position
+ *   - join output is left-major / right-minor (:1096-1141)   -> pairs ordered by (pos_l, pos_r)
+ */
+#include "mdb_dev_internal.h"
+
+/* ------------------------------------------------------------------ shared leaf helpers */
+
+#define LEAF_THREADS 512
+#define GC_SLOTS 3840u		/* group-count table: 20 B/slot -> 75 KiB, two workgroups per CU */
+#define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
+#define PJ_SLOTS 2048u		/* pairs table */
+#define PJ_TARGET 640u
+#define PJ_CHUNK 2048u		/* right-side rows staged per sweep in the emit kernel */
+
+__device__ static inline uint32_t leaf_slot(uint64_t hv, uint32_t slots)
+{
+	const uint32_t x = (uint32_t)hv * 0x9E3779B1u;
+	return (uint32_t)(((uint64_t)x * slots) >> 32);
+}
+
+/* insert-or-find hv (hv != 0); returns the slot or 0xFFFFFFFF when the table is full */
+__device__ static inline uint32_t leaf_insert(unsigned long long *keys, uint32_t slots, uint64_t hv)
+{
+	uint32_t s = leaf_slot(hv, slots);
+	for (uint32_t probe = 0; probe < slots; probe++) {
+		const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)hv);
+		if (old == 0ull || old == hv)
+			return s;
+		s = (s + 1 == slots) ? 0 : s + 1;
+	}
+	return 0xFFFFFFFFu;
+}
+
+/* find hv (hv != 0) after the build phase; 0xFFFFFFFF = absent */
+__device__ static inline uint32_t leaf_find(const unsigned long long *keys, uint32_t slots, uint64_t hv)
+{
+	uint32_t s = leaf_slot(hv, slots);
+	for (uint32_t probe = 0; probe < slots; probe++) {
+		const unsigned long long cur = keys[s];
+		if (cur == hv)
+			return s;
+		if (cur == 0ull)
+			return 0xFFFFFFFFu;
+		s = (s + 1 == slots) ? 0 : s + 1;
+	}
+	return 0xFFFFFFFFu;
+}
+
+/* ------------------------------------------------------------------ fused join + group count */
+
+struct gc_args {
+	const uint64_t *hv_l;
+	const uint32_t *rid_l;
+	const uint32_t *off_l;
+	const uint64_t *hv_r;		/* NULL: plain GROUP BY over the left stream */
+	const uint32_t *off_r;
+	int64_t *dense_cnt;		/* [n_l], zeroed: COUNT(*) written at the group's first L position */
+	unsigned long long *joined;	/* sum of all counts */
+	uint32_t *status;		/* bit 0: a leaf table overflowed */
+};
+
+template <bool HAS_R>
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
+{
+	__shared__ unsigned long long s_key[GC_SLOTS];
+	__shared__ uint32_t s_cl[GC_SLOTS];
+	__shared__ uint32_t s_cr[GC_SLOTS];
+	__shared__ uint32_t s_first[GC_SLOTS];
+	__shared__ uint32_t s_z[4];		/* the key with hash 0: [0]=cntL [1]=cntR [2]=first */
+	__shared__ unsigned long long s_sum;
+
+	const uint32_t leaf = blockIdx.x;
+	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
+	uint32_t r0 = 0, r1 = 0;
+	if (HAS_R) {
+		r0 = a.off_r[leaf];
+		r1 = a.off_r[leaf + 1];
+	}
+	if (l0 == l1 || (HAS_R && r0 == r1))
+		return;		/* no group can come out of this leaf */
+
+	for (uint32_t s = threadIdx.x; s < GC_SLOTS; s += LEAF_THREADS) {
+		s_key[s] = 0ull;
+		s_cl[s] = 0;
+		s_cr[s] = 0;
+		s_first[s] = 0xFFFFFFFFu;
+	}
+	if (threadIdx.x < 4)
+		s_z[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;
+	if (threadIdx.x == 0)
+		s_sum = 0ull;
+	__syncthreads();
+
+	/* build: left side */
+	for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
+		const uint64_t hv = a.hv_l[i];
+		const uint32_t rid = a.rid_l[i];
+		if (hv == 0) {
+			atomicAdd(&s_z[0], 1u);
+			atomicMin(&s_z[2], rid);
+		} else {
+			const uint32_t s = leaf_insert(s_key, GC_SLOTS, hv);
+			if (s == 0xFFFFFFFFu) {
+				atomicOr(a.status, 1u);
+			} else {
+				atomicAdd(&s_cl[s], 1u);
+				atomicMin(&s_first[s], rid);
+			}
+		}
+	}
+	__syncthreads();
+
+	/* probe: right side */
+	if (HAS_R) {
+		for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
+			const uint64_t hv = a.hv_r[j];
+			if (hv == 0) {
+				atomicAdd(&s_z[1], 1u);
+			} else {
+				const uint32_t s = leaf_find(s_key, GC_SLOTS, hv);
+				if (s != 0xFFFFFFFFu)
+					atomicAdd(&s_cr[s], 1u);
+			}
+		}
+		__syncthreads();
+	}
+
+	/* emit: one COUNT(*) per group at the group's first left position */
+	unsigned long long mine = 0;
+	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += LEAF_THREADS) {
+		uint32_t cl, cr, first;
+		if (s < GC_SLOTS) {
+			cl = s_cl[s];
+			cr = s_cr[s];
+			first = s_first[s];
+		} else {
+			cl = s_z[0];
+			cr = s_z[1];
+			first = s_z[2];
+		}
+		if (cl && (!HAS_R || cr)) {
+			const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
+			a.dense_cnt[first] = (int64_t)c;
+			mine += c;
+		}
+	}
+	if (mine)
+		atomicAdd(&s_sum, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_sum)
+		atomicAdd(a.joined, s_sum);
+}
+
+/* ------------------------------------------------------------------ compaction of the dense count array
+ * (implemented in mdb_dev_filter.hip: predicate "count <> 0" -> ascending positions) */
+size_t mdb_filter_arena_bytes(uint64_t n);
+int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint32_t *out_sel, uint32_t **d_total);
+
+/* ------------------------------------------------------------------ NULL-key group (plain GROUP BY only) */
+
+__global__ __launch_bounds__(256) void k_null_stats(const uint64_t *__restrict__ nullbits, uint64_t n,
+						    unsigned long long *cnt_first /* [0]=count [1]=first */)
+{
+	const uint64_t words = (n + 63) >> 6;
+	unsigned long long c = 0, first = ~0ull;
+	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t m = nullbits[w];
+		if (w == words - 1 && (n & 63))
+			m &= (1ull << (n & 63)) - 1ull;
+		if (m) {
+			c += (unsigned long long)__popcll(m);
+			const unsigned long long f = (w << 6) + (unsigned long long)(__ffsll((long long)m) - 1);
+			if (f < first)
+				first = f;
+		}
+	}
+	if (c) {
+		atomicAdd(&cnt_first[0], c);
+		atomicMin(&cnt_first[1], first);
+	}
+}
+
+__global__ void k_null_poke(const unsigned long long *cnt_first, int64_t *dense_cnt)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0 && cnt_first[0])
+		dense_cnt[cnt_first[1]] = (int64_t)cnt_first[0];
+}
+
+/* ------------------------------------------------------------------ group-count drivers */
+
+static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+			      const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group,
+			      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			      uint64_t *out_joined)
+{
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	if (n_l == 0 || (has_r && n_r == 0))
+		return MIDORIDB_OK;
+
+	int b1, b2;
+	mdb_choose_bits(n_l, GC_TARGET, &b1, &b2);
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true);
+	if (has_r)
+		need += mdb_partition_arena_bytes(n_r, b1, b2, false);
+	need += mdb_align_up(n_l * 8) + mdb_align_up(n_l * 4) + mdb_filter_arena_bytes(n_l) + 4096;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+
+	mdb_part_result pl, pr;
+	memset(&pr, 0, sizeof(pr));
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, &pl);
+	if (rc)
+		return rc;
+	if (has_r) {
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, &pr);
+		if (rc)
+			return rc;
+	}
+	int64_t *dense = (int64_t *)mdb_arena_take(ctx, n_l * 8);
+	uint32_t *sel = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
+	if (!dense || !sel)
+		return -MIDORIDB_INTERNAL;
+	/* d_status words: [0] overflow flag, [2..3] joined-row total (u64), [4..7] NULL-group stats (2 x u64) */
+	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
+	unsigned long long *d_nullst = (unsigned long long *)(ctx->d_status + 4);
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(dense, 0, n_l * 8, ctx->stream));
+
+	gc_args a;
+	a.hv_l = pl.hv;
+	a.rid_l = pl.rid;
+	a.off_l = pl.leaf_off;
+	a.hv_r = pr.hv;
+	a.off_r = pr.leaf_off;
+	a.dense_cnt = dense;
+	a.joined = d_joined;
+	a.status = ctx->d_status;
+	if (has_r) {
+		MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, pl.nleaves, LEAF_THREADS, a);
+	} else {
+		MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, pl.nleaves, LEAF_THREADS, a);
+	}
+	if (null_group && null_l) {
+		MDB_HIP(ctx, hipMemsetAsync(d_nullst + 1, 0xFF, 8, ctx->stream));
+		MDB_LAUNCH(ctx, "null_stats", k_null_stats, 256, 256, null_l, n_l, d_nullst);
+		MDB_LAUNCH(ctx, "null_poke", k_null_poke, 1, 64, d_nullst, dense);
+	}
+
+	/* order the groups by first occurrence: compact the dense array in row order */
+	uint32_t *d_total = NULL;
+	rc = mdb_filter_nonzero64(ctx, dense, n_l, sel, &d_total);
+	if (rc)
+		return rc;
+	/* read back G, J, status with one sync */
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[0], d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t G = (uint32_t)h[0];
+	const uint32_t status = (uint32_t)h[1];
+	if (status & 1u)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
+				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", GC_SLOTS);
+	if (G > cap)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
+				   (unsigned long long)cap, (unsigned long long)G);
+	if (G) {
+		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
+		if (rc)
+			return rc;
+		if (out_key) {
+			rc = mdb_dev_gather64(ctx, keys_l, NULL, sel, G, out_key, NULL);
+			if (rc)
+				return rc;
+		}
+		if (out_first)
+			MDB_HIP(ctx, hipMemcpyAsync(out_first, sel, G * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	*out_groups = G;
+	if (out_joined)
+		*out_joined = h[2];
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+					const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags,
+					int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+					uint64_t *out_groups, uint64_t *out_joined)
+{
+	(void)flags;	/* groups always come out in first-occurrence order, which satisfies both modes */
+	return group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
+				  cap, out_groups, out_joined);
+}
+
+extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,
+				   uint32_t *out_first, int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+{
+	(void)flags;
+	return group_count_common(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups,
+				  NULL);
+}
+
+/* ------------------------------------------------------------------ materialising join: count phase */
+
+struct pj_args {
+	const uint64_t *hv_l;
+	const uint32_t *rid_l;
+	const uint32_t *off_l;
+	const uint64_t *hv_r;
+	const uint32_t *rid_r;
+	const uint32_t *off_r;
+	uint32_t *match;	/* [n_l + 1]: count phase writes matches per left row; scanned into offsets */
+	uint32_t *out_l;
+	uint32_t *out_r;
+	uint32_t *status;
+	unsigned long long *total64;	/* 64-bit sum of all match counts (guards the 32-bit offsets) */
+};
+
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
+{
+	__shared__ unsigned long long s_key[PJ_SLOTS];
+	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* [PJ_SLOTS] = the key with hash 0 */
+
+	const uint32_t leaf = blockIdx.x;
+	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
+	const uint32_t r0 = a.off_r[leaf], r1 = a.off_r[leaf + 1];
+	if (l0 == l1 || r0 == r1)
+		return;
+	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+		if (s < PJ_SLOTS)
+			s_key[s] = 0ull;
+		s_cnt[s] = 0;
+	}
+	__syncthreads();
+	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
+		const uint64_t hv = a.hv_r[j];
+		uint32_t s = PJ_SLOTS;
+		if (hv != 0) {
+			s = leaf_insert(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu) {
+				atomicOr(a.status, 1u);
+				continue;
+			}
+		}
+		atomicAdd(&s_cnt[s], 1u);
+	}
+	__syncthreads();
+	unsigned long long mine = 0;
+	for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
+		const uint64_t hv = a.hv_l[i];
+		uint32_t s = PJ_SLOTS;
+		if (hv != 0)
+			s = leaf_find(s_key, PJ_SLOTS, hv);
+		if (s != 0xFFFFFFFFu) {
+			const uint32_t m = s_cnt[s];
+			if (m) {
+				a.match[a.rid_l[i]] = m;
+				mine += m;
+			}
+		}
+	}
+	if (mine)
+		atomicAdd(a.total64, mine);
+}
+
+/* ------------------------------------------------------------------ materialising join: emit phase
+ *
+ * Per leaf: table of the right side's distinct keys; the right rows are swept in chunks of
+ * PJ_CHUNK.  Inside a chunk the row ids of each key are placed contiguously (LDS counting sort by
+ * slot; ranks by comparing row ids, so every key's list is ascending = right-minor order), then
+ * every left row of the leaf copies its key's list to out[offset(left row) + matches so far].
+ */
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
+{
+	__shared__ unsigned long long s_key[PJ_SLOTS];
+	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* matches of the slot inside the current chunk */
+	__shared__ uint32_t s_start[PJ_SLOTS + 1];	/* first list position of the slot inside the chunk */
+	__shared__ uint32_t s_cur[PJ_SLOTS + 1];
+	__shared__ uint32_t s_prior[PJ_SLOTS + 1];	/* matches of the slot in earlier chunks */
+	__shared__ uint32_t s_tmp[PJ_CHUNK];
+	__shared__ uint32_t s_sorted[PJ_CHUNK];
+	__shared__ uint16_t s_eslot[PJ_CHUNK];
+	__shared__ uint32_t s_scan[32];
+
+	const uint32_t leaf = blockIdx.x;
+	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
+	const uint32_t r0 = a.off_r[leaf], r1 = a.off_r[leaf + 1];
+	if (l0 == l1 || r0 == r1)
+		return;
+	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+		if (s < PJ_SLOTS)
+			s_key[s] = 0ull;
+		s_prior[s] = 0;
+	}
+	__syncthreads();
+	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
+		const uint64_t hv = a.hv_r[j];
+		if (hv != 0 && leaf_insert(s_key, PJ_SLOTS, hv) == 0xFFFFFFFFu)
+			atomicOr(a.status, 1u);
+	}
+	__syncthreads();
+
+	constexpr uint32_t PER_T = (PJ_SLOTS + 1 + LEAF_THREADS - 1) / LEAF_THREADS;	/* slots scanned per thread */
+	for (uint32_t c0 = r0; c0 < r1; c0 += PJ_CHUNK) {
+		const uint32_t clen = (r1 - c0) < PJ_CHUNK ? (r1 - c0) : PJ_CHUNK;
+		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+			s_cnt[s] = 0;
+			s_cur[s] = 0;
+		}
+		__syncthreads();
+		/* count the chunk's rows per slot */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint64_t hv = a.hv_r[c0 + e];
+			uint32_t s = PJ_SLOTS;
+			if (hv != 0)
+				s = leaf_find(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu)
+				s = PJ_SLOTS;	/* only after an overflow, which fails the whole call anyway */
+			s_eslot[e] = (uint16_t)s;
+			atomicAdd(&s_cnt[s], 1u);
+		}
+		__syncthreads();
+		/* exclusive scan of the slot counts -> list starts */
+		{
+			uint32_t v[PER_T], sum = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < PER_T; k++) {
+				const uint32_t s = threadIdx.x * PER_T + k;
+				v[k] = s <= PJ_SLOTS ? s_cnt[s] : 0;
+				sum += v[k];
+			}
+			uint32_t total;
+			uint32_t run = mdb_block_excl_scan(sum, s_scan, &total);
+#pragma unroll
+			for (uint32_t k = 0; k < PER_T; k++) {
+				const uint32_t s = threadIdx.x * PER_T + k;
+				if (s <= PJ_SLOTS)
+					s_start[s] = run;
+				run += v[k];
+			}
+		}
+		__syncthreads();
+		/* place row ids by slot (arbitrary order inside a list) */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint32_t s = s_eslot[e];
+			const uint32_t pos = s_start[s] + atomicAdd(&s_cur[s], 1u);
+			s_tmp[pos] = a.rid_r[c0 + e];
+		}
+		__syncthreads();
+		/* rank every row id inside its list (row ids are distinct) -> ascending lists */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint32_t s = s_eslot[e];
+			const uint32_t rid = a.rid_r[c0 + e];
+			const uint32_t b = s_start[s], m = s_cnt[s];
+			uint32_t rank = 0;
+			for (uint32_t k = 0; k < m; k++)
+				rank += s_tmp[b + k] < rid;
+			s_sorted[b + rank] = rid;
+		}
+		__syncthreads();
+		/* every left row copies its key's list */
+		for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
+			const uint64_t hv = a.hv_l[i];
+			uint32_t s = PJ_SLOTS;
+			if (hv != 0)
+				s = leaf_find(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu)
+				continue;
+			const uint32_t m = s_cnt[s];
+			if (!m)
+				continue;
+			const uint32_t rid = a.rid_l[i];
+			const uint32_t base = a.match[rid] + s_prior[s];
+			const uint32_t b = s_start[s];
+			for (uint32_t k = 0; k < m; k++) {
+				a.out_l[base + k] = rid;
+				a.out_r[base + k] = s_sorted[b + k];
+			}
+		}
+		__syncthreads();
+		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS)
+			s_prior[s] += s_cnt[s];
+		__syncthreads();
+	}
+}
+
+extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
+				  uint64_t *out_count)
+{
+	*out_l = *out_r = NULL;
+	*out_count = 0;
+	if (n_l == 0 || n_r == 0)
+		return MIDORIDB_OK;
+	int b1, b2;
+	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
+	const uint64_t mlen = n_l + 1;
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true) + mdb_partition_arena_bytes(n_r, b1, b2, true) +
+		      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	mdb_part_result pl, pr;
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, &pl);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, &pr);
+	if (rc)
+		return rc;
+	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
+	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
+	if (!match || !scan_tmp)
+		return -MIDORIDB_INTERNAL;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(match, 0, mlen * 4, ctx->stream));
+
+	pj_args a;
+	a.hv_l = pl.hv;
+	a.rid_l = pl.rid;
+	a.off_l = pl.leaf_off;
+	a.hv_r = pr.hv;
+	a.rid_r = pr.rid;
+	a.off_r = pr.leaf_off;
+	a.match = match;
+	a.out_l = a.out_r = NULL;
+	a.status = ctx->d_status;
+	a.total64 = (unsigned long long *)(ctx->d_status + 2);
+	MDB_LAUNCH(ctx, "leaf_pairs_count", k_leaf_pairs_count, pl.nleaves, LEAF_THREADS, a);
+
+	/* offsets are 32-bit; the 64-bit total written by the count kernel guards against N:M blow-ups */
+	rc = mdb_scan_u32_inplace(ctx, match, mlen, scan_tmp);
+	if (rc)
+		return rc;
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[0], match + n_l, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t J = (uint32_t)h[0];
+	if ((uint32_t)h[1] & 1u)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
+				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", PJ_SLOTS);
+	if (h[2] != J)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join produces %llu rows: more than the 2^32-1 a single call can materialise",
+				   (unsigned long long)h[2]);
+	if (J == 0)
+		return MIDORIDB_OK;
+	uint32_t *ol = NULL, *orr = NULL;
+	hipError_t e1 = hipMalloc((void **)&ol, J * 4), e2 = hipMalloc((void **)&orr, J * 4);
+	if (e1 != hipSuccess || e2 != hipSuccess) {
+		if (ol)
+			(void)hipFree(ol);
+		if (orr)
+			(void)hipFree(orr);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+	}
+	a.out_l = ol;
+	a.out_r = orr;
+	MDB_LAUNCH(ctx, "leaf_pairs_emit", k_leaf_pairs_emit, pl.nleaves, LEAF_THREADS, a);
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_l = ol;
+	*out_r = orr;
+	*out_count = J;
+	return MIDORIDB_OK;
+}

@@ -1,0 +1,515 @@
+/*
+ * mdb_dev_partition.hip - stable, LDS-staged MSD radix partitioning of a key column by the top
+ * bits of fmix64(key).  This is the bandwidth-dominant stage of the join / GROUP BY pipeline.
+ *
+ * Why it exists: the reference joins by comparing every pair of rows (reference
+ * src/engine/executor_select.c:1096-1141, O(nA*nB)) and groups by comparing every pair of
+ * surviving rows (:1542-1583, O(n^2)).  Here both tables are split into 2^bits "leaves" whose
+ * build side fits one CU's LDS; equal keys always land in the same leaf, so each leaf is joined /
+ * grouped independently by one workgroup (mdb_dev_join.hip).
+ *
+ * One level = histogram -> exclusive scan -> scatter, all tile based (MDB_TILE = 4096 keys):
+ *
+ *   k_part_hist     per tile: LDS histogram of the level's digit, written digit-major
+ *   (scan)          one exclusive scan over [segment][digit][tile] gives every tile its output
+ *                   offset per digit and, as a by-product, the exact start of every child segment
+ *   k_part_scatter  per tile: wave-level peer ranking (ballot match, no atomics) gives each key a
+ *                   STABLE rank inside the tile, keys are staged sorted-by-digit in LDS, then
+ *                   written out as contiguous runs per digit (coalesced; TILE/R keys per run)
+ *
+ * Level 0 reads the raw int64 keys (+ NULL bits, NULL rows are dropped - a NULL key never joins,
+ * executor_select.c:557-579), hashes them, and attaches the row id; later levels move (hash, rid).
+ * Stability keeps the original row order inside every leaf, which the join uses to emit matches
+ * in the reference's left-major / right-minor order.
+ *
+ * Memory traffic per level and key: hist reads 8 B, scatter reads 8(+4) B and writes 8(+4) B.
+ * Blocks are mapped to tiles XCD-contiguously (blockIdx % 8 selects the XCD) so that adjacent
+ * tiles - which extend each other's output runs - meet in the same 4 MiB L2.
+ */
+#include "mdb_dev_internal.h"
+
+#define PART_THREADS 512
+#define PART_WAVES (PART_THREADS / MDB_WAVE)
+#define PART_ITEMS (MDB_TILE / PART_THREADS)		/* 8 keys per thread */
+#define PART_WAVE_SPAN (MDB_TILE / PART_WAVES)		/* 512 consecutive keys per wave */
+#define PART_MAX_R (1u << MDB_MAX_RADIX_BITS)
+#define PART_INVALID 0xFFFFFFFFu
+
+struct mdb_tile_desc {
+	uint32_t start;		/* first input element of the tile */
+	uint32_t len;		/* elements in the tile (0 = unused tile) */
+	uint32_t hbase;		/* histogram index of (segment, digit 0, this tile) */
+	uint32_t nt;		/* tiles in this tile's segment = histogram stride between digits */
+};
+
+struct mdb_level_args {
+	/* level 0 input */
+	const int64_t *keys;
+	const uint64_t *nullbits;
+	uint64_t n;
+	/* level >= 1 input */
+	const uint64_t *hv_in;
+	const uint32_t *rid_in;
+	const mdb_tile_desc *tiles;	/* NULL for level 0 (computed arithmetically) */
+	/* output */
+	uint64_t *hv_out;
+	uint32_t *rid_out;		/* NULL = row ids not wanted */
+	uint32_t *hist;			/* counts in, scanned offsets out */
+	uint32_t ntiles;		/* tiles to cover (upper bound for level >= 1) */
+	uint32_t R;			/* digits at this level */
+	uint32_t mbits;			/* bits needed to tell digits apart (ballot rounds) */
+	uint32_t shift;			/* RADIX mode: digit = (hv >> shift) & (R - 1) */
+	uint32_t mode;			/* enum mdb_digit_mode */
+	uint32_t inverse_out;		/* write fmix64^-1(hv) (= the original key) instead of hv */
+};
+
+__device__ static inline uint32_t part_digit(const mdb_level_args &a, uint64_t hv)
+{
+	if (a.mode == MDB_DIGIT_RADIX)
+		return (uint32_t)(hv >> a.shift) & (a.R - 1);
+	return (uint32_t)hv % a.R;
+}
+
+/* XCD-contiguous block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so give
+ * each XCD one contiguous run of tiles.  The grid is rounded up to a multiple of 8. */
+__device__ static inline uint32_t part_tile_of_block(void)
+{
+	const uint32_t per = gridDim.x >> 3;
+	return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+__device__ static inline mdb_tile_desc part_get_tile(const mdb_level_args &a, uint32_t t)
+{
+	mdb_tile_desc d;
+	if (t >= a.ntiles) {
+		d.start = d.len = d.hbase = d.nt = 0;
+		return d;
+	}
+	if (a.tiles)
+		return a.tiles[t];
+	const uint64_t start = (uint64_t)t * MDB_TILE;
+	d.start = (uint32_t)start;
+	d.len = start < a.n ? (uint32_t)((a.n - start) < MDB_TILE ? (a.n - start) : MDB_TILE) : 0;
+	d.hbase = t;
+	d.nt = a.ntiles;
+	return d;
+}
+
+/* Load element i of the tile: returns false for a NULL key (level 0 only). */
+template <bool LEVEL0>
+__device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t i, uint64_t *hv,
+					uint32_t *rid)
+{
+	const uint64_t g = (uint64_t)td.start + i;
+	if (LEVEL0) {
+		if (a.nullbits && mdb_bit_is_set(a.nullbits, g))
+			return false;
+		*hv = mdb_fmix64((uint64_t)a.keys[g]);
+		*rid = (uint32_t)g;
+	} else {
+		*hv = a.hv_in[g];
+		*rid = a.rid_in ? a.rid_in[g] : 0;
+	}
+	return true;
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
+{
+	__shared__ uint32_t s_h[PART_MAX_R];
+	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
+	if (td.len == 0)
+		return;
+	for (uint32_t d = threadIdx.x; d < a.R; d += PART_THREADS)
+		s_h[d] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < PART_ITEMS; r++) {
+		const uint32_t i = (uint32_t)r * PART_THREADS + threadIdx.x;
+		if (i < td.len) {
+			uint64_t hv;
+			uint32_t rid;
+			if (part_load<LEVEL0>(a, td, i, &hv, &rid))
+				atomicAdd(&s_h[part_digit(a, hv)], 1u);
+		}
+	}
+	__syncthreads();
+	for (uint32_t d = threadIdx.x; d < a.R; d += PART_THREADS)
+		a.hist[(uint64_t)td.hbase + (uint64_t)d * td.nt] = s_h[d];
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
+{
+	__shared__ uint64_t s_hv[MDB_TILE];			/* 32 KiB */
+	__shared__ uint32_t s_rid[MDB_TILE];			/* 16 KiB */
+	__shared__ uint32_t s_wcnt[PART_WAVES][PART_MAX_R];	/* 16 KiB: per-wave digit counts, then bases */
+	__shared__ uint32_t s_off[PART_MAX_R];			/* tile-local start of each digit */
+	__shared__ uint32_t s_gbase[PART_MAX_R];		/* global output start of each digit for this tile */
+	__shared__ uint32_t s_tmp[32];
+
+	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
+	if (td.len == 0)
+		return;
+	const uint32_t R = a.R;
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint64_t lt = mdb_lanemask_lt();
+
+	for (uint32_t i = threadIdx.x; i < PART_WAVES * PART_MAX_R; i += PART_THREADS)
+		(&s_wcnt[0][0])[i] = 0;
+	for (uint32_t d = threadIdx.x; d < R; d += PART_THREADS)
+		s_gbase[d] = a.hist[(uint64_t)td.hbase + (uint64_t)d * td.nt];
+
+	/* 1. load: wave w owns tile elements [w*512, w*512+512), 64 consecutive per round (coalesced) */
+	uint64_t hv[PART_ITEMS];
+	uint32_t rid[PART_ITEMS];
+	uint32_t dig[PART_ITEMS];
+	uint32_t rank[PART_ITEMS];
+#pragma unroll
+	for (int r = 0; r < PART_ITEMS; r++) {
+		const uint32_t i = wave * PART_WAVE_SPAN + (uint32_t)r * MDB_WAVE + lane;
+		bool valid = i < td.len;
+		hv[r] = 0;
+		rid[r] = 0;
+		if (valid)
+			valid = part_load<LEVEL0>(a, td, i, &hv[r], &rid[r]);
+		dig[r] = valid ? part_digit(a, hv[r]) : PART_INVALID;
+	}
+	__syncthreads();	/* s_wcnt zeroed */
+
+	/* 2. stable rank inside the wave's 512-element span: lanes with the same digit find each other
+	 *    with `mbits` ballots; the lowest such lane bumps the wave-private LDS counter. */
+	volatile uint32_t *wc = &s_wcnt[wave][0];
+#pragma unroll
+	for (int r = 0; r < PART_ITEMS; r++) {
+		const bool valid = dig[r] != PART_INVALID;
+		const uint32_t d = dig[r];
+		uint64_t peers = __ballot(valid);
+		for (uint32_t b = 0; b < a.mbits; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t before = (uint32_t)__popcll(peers & lt);
+		const uint32_t cnt = (uint32_t)__popcll(peers);
+		uint32_t prev = 0;
+		if (valid)
+			prev = wc[d];
+		if (valid && before == 0)
+			wc[d] = prev + cnt;
+		rank[r] = prev + before;
+		__builtin_amdgcn_wave_barrier();
+	}
+	__syncthreads();
+
+	/* 3. per digit: turn per-wave counts into per-wave bases, tile totals into tile offsets */
+	uint32_t total_d = 0;
+	if (threadIdx.x < R) {
+		uint32_t run = 0;
+#pragma unroll
+		for (int w = 0; w < PART_WAVES; w++) {
+			const uint32_t t = s_wcnt[w][threadIdx.x];
+			s_wcnt[w][threadIdx.x] = run;
+			run += t;
+		}
+		total_d = run;
+	}
+	uint32_t tile_total;
+	const uint32_t off_d = mdb_block_excl_scan(total_d, s_tmp, &tile_total);
+	if (threadIdx.x < R)
+		s_off[threadIdx.x] = off_d;
+	__syncthreads();
+
+	/* 4. stage the tile in LDS sorted by digit (stable) */
+#pragma unroll
+	for (int r = 0; r < PART_ITEMS; r++) {
+		if (dig[r] != PART_INVALID) {
+			const uint32_t pos = s_off[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
+			s_hv[pos] = hv[r];
+			s_rid[pos] = rid[r];
+		}
+	}
+	__syncthreads();
+
+	/* 5. write out: consecutive threads write consecutive addresses inside each digit's run */
+	for (uint32_t i = threadIdx.x; i < tile_total; i += PART_THREADS) {
+		const uint64_t h = s_hv[i];
+		const uint32_t d = part_digit(a, h);
+		const uint64_t g = (uint64_t)s_gbase[d] + (i - s_off[d]);
+		a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
+		if (a.rid_out)
+			a.rid_out[g] = s_rid[i];
+	}
+}
+
+/* ---- segment bookkeeping between levels -------------------------------------------------------
+ *
+ * After a level's scan, child segment q = (parent p, digit d) starts at scanned[tb[p]*R + d*nt_p].
+ * k_part_children writes child starts (S*R + 1 entries, last = total) and each child's tile count
+ * (S*R + 1 entries, last = 0; exclusive-scanned afterwards into the child tile bases).
+ */
+__global__ void k_part_children(const uint32_t *__restrict__ scanned, const uint32_t *__restrict__ tb, uint32_t S, uint32_t R,
+				uint32_t *__restrict__ child_start, uint32_t *__restrict__ child_ntiles)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t nq = S * R;
+	if (q > nq)
+		return;
+	auto start_of = [&](uint32_t qq) -> uint32_t {
+		if (qq >= nq)
+			return scanned[(uint64_t)tb[S] * R];	/* == grand total */
+		const uint32_t p = qq / R, d = qq % R;
+		const uint32_t ntp = tb[p + 1] - tb[p];
+		return scanned[(uint64_t)tb[p] * R + (uint64_t)d * ntp];
+	};
+	const uint32_t s0 = start_of(q);
+	child_start[q] = s0;
+	if (q == nq) {
+		child_ntiles[q] = 0;
+	} else {
+		const uint32_t s1 = start_of(q + 1);
+		child_ntiles[q] = (s1 - s0 + MDB_TILE - 1) / MDB_TILE;
+	}
+}
+
+/* tile descriptors of a level >= 1 from its segments (seg_start, tile bases tb), one thread per tile */
+__global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tb, uint32_t S, uint32_t R,
+				   mdb_tile_desc *__restrict__ tiles, uint32_t max_tiles)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= max_tiles)
+		return;
+	mdb_tile_desc d;
+	d.start = d.len = d.hbase = d.nt = 0;
+	if (t < tb[S]) {
+		/* largest p with tb[p] <= t  (tb is non-decreasing, tb[S] > t) */
+		uint32_t lo = 0, hi = S;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (tb[mid] <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		const uint32_t p = lo, tl = t - tb[p];
+		const uint32_t s0 = seg_start[p] + tl * MDB_TILE, s1 = seg_start[p + 1];
+		d.start = s0;
+		d.len = (s1 - s0) < MDB_TILE ? (s1 - s0) : MDB_TILE;
+		d.nt = tb[p + 1] - tb[p];
+		d.hbase = tb[p] * R + tl;
+	}
+	tiles[t] = d;
+}
+
+__global__ void k_part_seg0(uint32_t *seg_start, uint32_t *tb, uint32_t n, uint32_t ntiles)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		seg_start[0] = 0;
+		seg_start[1] = n;
+		tb[0] = 0;
+		tb[1] = ntiles;
+	}
+}
+
+/* ---- host orchestration ----------------------------------------------------------------------- */
+
+struct part_carver {
+	mdb_dev_ctx *ctx;
+	bool dry;
+	size_t bytes;
+	bool failed;
+	void *take(size_t b)
+	{
+		bytes += mdb_align_up(b ? b : 1);
+		if (dry)
+			return NULL;
+		void *p = mdb_arena_take(ctx, b);
+		if (!p)
+			failed = true;
+		return p;
+	}
+};
+
+void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2)
+{
+	uint64_t leaves = (n + target - 1) / target;
+	int bits = 1;
+	while (bits < 2 * MDB_MAX_RADIX_BITS && (1ull << bits) < leaves)
+		bits++;
+	if (bits <= 8) {
+		*bits1 = bits;
+		*bits2 = 0;
+	} else if (bits <= 16) {
+		*bits1 = 8;
+		*bits2 = bits - 8;
+	} else {
+		*bits1 = 9;
+		*bits2 = bits - 9;
+	}
+}
+
+static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; }
+
+static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
+			  bool want_rid, uint32_t mode, uint32_t n_dest, bool inverse_out, mdb_part_result *out)
+{
+	mdb_dev_ctx *ctx = cv.ctx;
+	const bool dry = cv.dry;
+	const int nlevels = bits2 > 0 ? 2 : 1;
+	const uint32_t Rl[2] = { mode == MDB_DIGIT_MOD ? n_dest : (1u << bits1), 1u << bits2 };
+	const uint32_t nt0 = n ? (uint32_t)((n + MDB_TILE - 1) / MDB_TILE) : 1u;
+
+	uint64_t *hv_buf[2] = { NULL, NULL };
+	uint32_t *rid_buf[2] = { NULL, NULL };
+	for (int l = 0; l < nlevels; l++) {
+		hv_buf[l] = (uint64_t *)cv.take((n ? n : 1) * 8);
+		if (want_rid)
+			rid_buf[l] = (uint32_t *)cv.take((n ? n : 1) * 4);
+	}
+
+	/* segments of the current level */
+	uint32_t S = 1;
+	uint32_t *seg_start = (uint32_t *)cv.take(2 * 4);
+	uint32_t *tb = (uint32_t *)cv.take(2 * 4);
+	if (cv.failed)
+		return -MIDORIDB_INTERNAL;
+	if (!dry)
+		MDB_LAUNCH(ctx, "part_seg0", k_part_seg0, 1, 64, seg_start, tb, (uint32_t)n, nt0);
+
+	uint32_t ntiles = nt0;
+	const mdb_tile_desc *tiles = NULL;
+	int used_bits = 0;
+	for (int l = 0; l < nlevels; l++) {
+		const uint32_t R = Rl[l];
+		const uint64_t hlen = (uint64_t)ntiles * R + 1;
+		uint32_t *hist = (uint32_t *)cv.take(hlen * 4);
+		uint32_t *scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words(hlen) * 4);
+		const uint32_t nchild = S * R;
+		uint32_t *child_start = (uint32_t *)cv.take(((size_t)nchild + 1) * 4);
+		uint32_t *child_nt = (uint32_t *)cv.take(((size_t)nchild + 1) * 4);
+		uint32_t *child_scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words((uint64_t)nchild + 1) * 4);
+		/* tile descriptors of the NEXT level (upper bound: every child adds at most one partial tile) */
+		const uint32_t next_tiles = (uint32_t)(n / MDB_TILE) + nchild + 1;
+		mdb_tile_desc *next_desc = NULL;
+		if (l + 1 < nlevels)
+			next_desc = (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
+		if (cv.failed)
+			return -MIDORIDB_INTERNAL;
+
+		if (!dry) {
+			mdb_level_args a;
+			memset(&a, 0, sizeof(a));
+			a.keys = keys;
+			a.nullbits = nullbits;
+			a.n = n;
+			a.hv_in = l ? hv_buf[l - 1] : NULL;
+			a.rid_in = l ? rid_buf[l - 1] : NULL;
+			a.tiles = tiles;
+			a.hv_out = hv_buf[l];
+			a.rid_out = rid_buf[l];
+			a.hist = hist;
+			a.ntiles = ntiles;
+			a.R = R;
+			a.mode = l == 0 ? mode : MDB_DIGIT_RADIX;
+			a.inverse_out = (inverse_out && l == nlevels - 1) ? 1u : 0u;
+			if (a.mode == MDB_DIGIT_RADIX) {
+				const int b = l == 0 ? bits1 : bits2;
+				a.shift = (uint32_t)(64 - used_bits - b);
+				a.mbits = (uint32_t)b;
+			} else {
+				uint32_t mb = 1;
+				while ((1u << mb) < R)
+					mb++;
+				a.shift = 0;
+				a.mbits = mb;
+			}
+			MDB_HIP(ctx, hipMemsetAsync(hist, 0, hlen * 4, ctx->stream));
+			if (l == 0) {
+				MDB_LAUNCH(ctx, "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
+			} else {
+				MDB_LAUNCH(ctx, "part_hist_l1", k_part_hist<false>, grid8(ntiles), PART_THREADS, a);
+			}
+			int rc = mdb_scan_u32_inplace(ctx, hist, hlen, scan_tmp);
+			if (rc)
+				return rc;
+			if (l == 0) {
+				MDB_LAUNCH(ctx, "part_scatter_l0", k_part_scatter<true>, grid8(ntiles), PART_THREADS, a);
+			} else {
+				MDB_LAUNCH(ctx, "part_scatter_l1", k_part_scatter<false>, grid8(ntiles), PART_THREADS, a);
+			}
+			MDB_LAUNCH(ctx, "part_children", k_part_children, (nchild + 1 + 255) / 256, 256, hist, tb, S, R, child_start,
+				   child_nt);
+			if (l + 1 < nlevels) {
+				rc = mdb_scan_u32_inplace(ctx, child_nt, (uint64_t)nchild + 1, child_scan_tmp);
+				if (rc)
+					return rc;
+				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles, (next_tiles + 255) / 256, 256, child_start,
+					   child_nt, nchild, Rl[l + 1], next_desc, next_tiles);
+			}
+		}
+		used_bits += (l == 0 ? bits1 : bits2);
+		seg_start = child_start;
+		tb = child_nt;
+		S = nchild;
+		tiles = next_desc;
+		ntiles = next_tiles;
+	}
+	if (out) {
+		out->hv = hv_buf[nlevels - 1];
+		out->rid = rid_buf[nlevels - 1];
+		out->leaf_off = seg_start;
+		out->nleaves = S;
+		out->bits_total = (uint32_t)used_bits;
+	}
+	return MIDORIDB_OK;
+}
+
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid)
+{
+	part_carver cv = { NULL, true, 0, false };
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, MDB_DIGIT_RADIX, 0, false, NULL);
+	return cv.bytes + 4096;
+}
+
+int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
+			bool want_rid, mdb_part_result *out)
+{
+	if (n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "table of %llu rows exceeds the 32-bit row-id limit of one GPU shard",
+				   (unsigned long long)n);
+	part_carver cv = { ctx, false, 0, false };
+	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, MDB_DIGIT_RADIX, 0, false, out);
+}
+
+/* ---- multi-GPU destination partition ------------------------------------------------------------ */
+
+extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
+					 uint32_t n_dest, int64_t *out_keys, uint64_t *out_counts)
+{
+	if (n_dest == 0 || n_dest > PART_MAX_R)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: n_dest must be in [1, %u]", PART_MAX_R);
+	if (n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: too many rows");
+	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
+	 * original keys written back through the inverse hash) */
+	part_carver dry = { NULL, true, 0, false };
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, MDB_DIGIT_MOD, n_dest, true, NULL);
+	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
+	if (rc)
+		return rc;
+	part_carver cv = { ctx, false, 0, false };
+	mdb_part_result res;
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, MDB_DIGIT_MOD, n_dest, true, &res);
+	if (rc)
+		return rc;
+	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h_off, res.leaf_off, ((size_t)n_dest + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t total = h_off[n_dest];
+	if (total)
+		MDB_HIP(ctx, hipMemcpyAsync(out_keys, res.hv, total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+	for (uint32_t d = 0; d < n_dest; d++)
+		out_counts[d] = (uint64_t)h_off[d + 1] - h_off[d];
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}

@@ -1,0 +1,189 @@
+/*
+ * mdb_host.h - internals of the host side (plain C, like the reference): SQL/RPN front end,
+ * statement plans, columnar tables with device mirrors, the executor that lowers a SELECT onto
+ * the mdb_dev_* C-ABI, and the result set behind query_cur_step()/query_column_int64().
+ */
+#ifndef MDB_HOST_H
+#define MDB_HOST_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include "mdb_error.h"
+#include "mdb_dev.h"
+#include "mdb_query.h"
+
+/* ------------------------------------------------------------------ RPN token queue
+ * Same vocabulary as the reference grammar's emit() (reference src/parser/midorisql.y:517-528,
+ * SURVEY.md Appendix A). */
+struct mdb_rpn {
+	char **tok;
+	int n, cap;
+};
+int mdb_rpn_push(struct mdb_rpn *r, const char *tok);
+void mdb_rpn_free(struct mdb_rpn *r);
+int mdb_rpn_from_text(const char *text, struct mdb_rpn *out);
+int mdb_sql_parse(const char *sql, struct mdb_rpn *out, char *err, size_t errlen);
+
+/* ------------------------------------------------------------------ catalog + columnar storage */
+#define MDB_MAX_COLS 128		/* reference TABLE_MAX_COLUMNS (include/primitive/table.h:16) */
+#define MDB_NAME_LEN 128
+
+/* numeric values of the reference's enum COLUMN_TYPE (include/primitive/column.h:17-25) */
+enum mdb_coltype {
+	MDB_CT_VARCHAR = 0,
+	MDB_CT_INTEGER = 1,
+	MDB_CT_TINYINT = 2,
+	MDB_CT_DOUBLE = 3,
+	MDB_CT_DATE = 4,
+	MDB_CT_DATETIME = 5,
+};
+
+struct mdb_column {
+	char name[MDB_NAME_LEN];
+	int type;			/* enum mdb_coltype; only the 8-byte INTEGER / DOUBLE types live on the device */
+	int64_t *data;			/* host copy, 8 bytes per row */
+	uint64_t *nullbits;		/* host NULL bits (allocated with the column), bit set = NULL */
+	uint64_t null_count;
+	/* device mirror */
+	void *d_data;
+	uint64_t *d_nullbits;		/* NULL when null_count == 0 */
+};
+
+struct mdb_table {
+	char name[MDB_NAME_LEN];
+	int ncols;
+	struct mdb_column cols[MDB_MAX_COLS];
+	uint64_t nrows, cap;
+	uint64_t generation;		/* bumped by every mutation */
+	uint64_t dev_generation;	/* generation the device mirror reflects (0 = none) */
+	uint64_t dev_rows;
+	bool device_only;		/* rows were generated on the device; there is no host copy */
+};
+
+struct mdb_catalog {
+	struct mdb_table **tables;
+	int n, cap;
+	mdb_dev_ctx *dev;		/* created lazily by the first SELECT */
+	int dev_rc;			/* sticky result of the lazy creation */
+};
+
+struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name);
+int mdb_catalog_add(struct mdb_catalog *cat, struct mdb_table *t);
+void mdb_catalog_free(struct mdb_catalog *cat);
+struct mdb_table *mdb_table_new(const char *name);
+void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev);
+int mdb_table_add_column(struct mdb_table *t, const char *name, int type);
+int mdb_table_reserve(struct mdb_table *t, uint64_t rows);
+int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen);
+int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen);
+
+/* ------------------------------------------------------------------ statement plans */
+enum mdb_expr_kind {
+	MDB_EX_NAME = 1,	/* bare column name (before resolution) */
+	MDB_EX_FIELD,		/* table.column */
+	MDB_EX_INT,
+	MDB_EX_FLOAT,
+	MDB_EX_BOOL,
+	MDB_EX_STRING,
+	MDB_EX_NULL,
+	MDB_EX_CMP,		/* op = comparison code 1..6, 2 kids */
+	MDB_EX_LOGOP,		/* op = 0 AND, 1 OR, 2 XOR (reference enum ast_logop_type), 2 kids */
+	MDB_EX_ISNULL,		/* op = negation, 1 kid */
+	MDB_EX_ISIN,		/* op = negation, kid[0] = field, rest = values */
+	MDB_EX_COUNT,		/* COUNT(*) / COUNT(x) */
+	MDB_EX_LIKE,
+	MDB_EX_ARITH,		/* + - * / % NEG: parsed, rejected by the executor like select-list math is ignored upstream */
+	MDB_EX_ALIAS,		/* alias wrapper around kid[0] */
+};
+
+struct mdb_expr {
+	int kind;
+	int op;
+	char tbl[MDB_NAME_LEN];
+	char col[MDB_NAME_LEN];
+	int64_t ival;
+	double dval;
+	struct mdb_expr **kids;
+	int nkids;
+	/* resolution (FIELD): index into the plan's FROM tables and the column index there */
+	int tbl_idx, col_idx, type;
+};
+
+struct mdb_from_tab {
+	char name[MDB_NAME_LEN];
+	char alias[MDB_NAME_LEN];
+	struct mdb_table *t;
+};
+
+/* left-deep join list: tables[0] (x) tables[1] ON on[1] (x) tables[2] ON on[2] ...; on[i] == NULL
+ * means the comma form (reference optimiser turns it into JOIN ... ON 1=1, optimiser_select.c:395-464) */
+struct mdb_select {
+	bool distinct, select_all;
+	struct mdb_expr **sel;
+	int nsel;
+	struct mdb_from_tab *tabs;
+	struct mdb_expr **on;
+	int *join_type;
+	int ntabs;
+	struct mdb_expr *where;
+	struct mdb_expr **group;
+	int ngroup;
+	bool has_having, has_orderby, has_limit;
+};
+
+struct mdb_create {
+	char name[MDB_NAME_LEN];
+	bool if_not_exists;
+	int ncols;
+	char colname[MDB_MAX_COLS][MDB_NAME_LEN];
+	int coltype[MDB_MAX_COLS];
+};
+
+struct mdb_insert {
+	char name[MDB_NAME_LEN];
+	int ncolnames;
+	char colname[MDB_MAX_COLS][MDB_NAME_LEN];
+	int ntuples, nvals;		/* nvals per tuple */
+	struct mdb_expr ***vals;	/* [ntuples][nvals] literal expressions */
+};
+
+enum mdb_stmt_kind { MDB_ST_SELECT = 1, MDB_ST_CREATE, MDB_ST_INSERT };
+
+struct mdb_stmt {
+	int kind;
+	struct mdb_select sel;
+	struct mdb_create crt;
+	struct mdb_insert ins;
+};
+
+int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, size_t errlen);
+void mdb_stmt_free(struct mdb_stmt *st);
+void mdb_expr_free(struct mdb_expr *e);
+
+/* ------------------------------------------------------------------ result set */
+struct mdb_result {
+	int ncols;
+	char (*colname)[MDB_NAME_LEN];
+	int *coltype;
+	int64_t **data;			/* host columns, 8-byte values (0 for NULL) */
+	uint64_t **nullbits;		/* host NULL bits per column or NULL */
+	uint64_t nrows;
+	double exec_ms;			/* device pipeline wall time of the SELECT that produced it */
+	uint64_t joined_rows;		/* rows produced by the join before aggregation (0 when no join) */
+};
+void mdb_result_free(struct mdb_result *r);
+
+/* ------------------------------------------------------------------ executor */
+int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, size_t errlen);
+int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_rows_aff, char *err, size_t errlen);
+int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen);
+
+/* result column order of the reference (djb2 hashtable iteration) */
+int mdb_reference_column_order(const char (*keys)[MDB_NAME_LEN], int nkeys, int *order_out);
+
+#endif /* MDB_HOST_H */

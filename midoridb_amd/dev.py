@@ -1,0 +1,276 @@
+"""Python binding of the device C-ABI (include/mdb_dev.h) for torch tensors.
+
+PyTorch is plumbing only: it owns device memory (tensor.data_ptr()) and the HIP stream the
+library launches on, and torch.distributed provides the RCCL all-to-all in bench.py.  Every
+operator below is one call through the C-ABI into hand-written HIP; nothing here computes.
+"""
+import ctypes
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+import torch
+
+from .lib import load_library
+
+MDB_ORDER_FIRST = 1
+
+# predicate opcodes / comparison codes / value types (include/mdb_dev.h)
+P_CMP_COL_CONST, P_CMP_CONST_COL, P_CMP_COL_COL, P_ISNULL, P_CONST, P_AND, P_OR, P_XOR = 1, 2, 3, 4, 5, 6, 7, 8
+CMP_LT, CMP_GT, CMP_NE, CMP_EQ, CMP_LE, CMP_GE = 1, 2, 3, 4, 5, 6
+T_INT64, T_DOUBLE = 0, 1
+
+
+class PredInsn(ctypes.Structure):
+    _fields_ = [("op", c_int32), ("cmp", c_int32), ("type", c_int32), ("a", c_int32), ("b", c_int32),
+                ("pad", c_int32), ("imm", c_int64)]
+
+
+class ColBinding(ctypes.Structure):
+    _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p)]
+
+
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", c_uint32), ("total_ms", c_double)]
+
+
+def _bind(lib):
+    if getattr(lib, "_mdb_dev_bound", False):
+        return
+    P = c_void_p
+    sig = {
+        "mdb_dev_ctx_create": ([c_int, P, POINTER(P)], c_int),
+        "mdb_dev_ctx_destroy": ([P], None),
+        "mdb_dev_ctx_set_stream": ([P, P], c_int),
+        "mdb_dev_last_error": ([P], c_char_p),
+        "mdb_dev_sync": ([P], c_int),
+        "mdb_dev_device_count": ([], c_int),
+        "mdb_dev_reserve": ([P, c_size_t], c_int),
+        "mdb_dev_arena_bytes": ([P], c_size_t),
+        "mdb_dev_alloc": ([P, c_size_t, POINTER(P)], c_int),
+        "mdb_dev_free": ([P, P], c_int),
+        "mdb_dev_memset": ([P, P, c_int, c_size_t], c_int),
+        "mdb_dev_h2d": ([P, P, P, c_size_t], c_int),
+        "mdb_dev_d2h": ([P, P, P, c_size_t], c_int),
+        "mdb_dev_prof_enable": ([P, c_int], c_int),
+        "mdb_dev_prof_reset": ([P], c_int),
+        "mdb_dev_prof_read": ([P, POINTER(ProfEntry), c_int, POINTER(c_int)], c_int),
+        "mdb_dev_filter": ([P, POINTER(PredInsn), c_int, POINTER(ColBinding), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_gather64": ([P, P, P, P, c_uint64, P, P], c_int),
+        "mdb_dev_gather32": ([P, P, P, c_uint64, P], c_int),
+        "mdb_dev_iota32": ([P, P, c_uint64], c_int),
+        "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
+        "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
+        "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
+        "mdb_dev_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, c_uint32, P, P, P, c_uint64,
+                                      POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    lib._mdb_dev_bound = True
+
+
+DEV_SYMBOLS = [
+    "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
+    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
+]
+
+
+def pack_nullbits(nulls):
+    """bool/uint8 array (1 = NULL) -> uint64 words, bit (i & 63) of word (i >> 6)."""
+    nulls = np.asarray(nulls).astype(bool)
+    n = nulls.shape[0]
+    words = (n + 63) // 64
+    padded = np.zeros(words * 64, dtype=np.uint8)
+    padded[:n] = nulls
+    return np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words).copy()
+
+
+def unpack_nullbits(words, n):
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+    return bits[:n].astype(bool)
+
+
+def _ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+class DeviceCtx:
+    """One mdb_dev_ctx bound to a torch device and (by default) torch's current stream."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        if not torch.cuda.is_available():
+            raise DeviceError("no HIP device visible: the MI355X path cannot run (there is no CPU fallback)")
+        self.lib = load_library()
+        _bind(self.lib)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if use_torch_stream else None
+        h = c_void_p()
+        rc = self.lib.mdb_dev_ctx_create(device, stream, byref(h))
+        if rc != 0:
+            raise DeviceError(f"mdb_dev_ctx_create failed with {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mdb_dev_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.mdb_dev_last_error(self.h)
+            raise DeviceError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # ---- helpers ------------------------------------------------------------------------
+    def to_dev(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        if a.dtype == np.uint64:
+            return torch.from_numpy(a.view(np.int64)).to(self.device)
+        if a.dtype == np.uint32:
+            return torch.from_numpy(a.view(np.int32)).to(self.device)
+        return torch.from_numpy(a).to(self.device)
+
+    def nullbits_dev(self, nulls):
+        if nulls is None:
+            return None
+        return self.to_dev(pack_nullbits(nulls))
+
+    def sync(self):
+        self._chk(self.lib.mdb_dev_sync(self.h), "sync")
+
+    def reserve(self, nbytes):
+        self._chk(self.lib.mdb_dev_reserve(self.h, nbytes), "reserve")
+
+    def arena_bytes(self):
+        return int(self.lib.mdb_dev_arena_bytes(self.h))
+
+    # ---- profiling ------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._chk(self.lib.mdb_dev_prof_enable(self.h, 1 if on else 0), "prof_enable")
+
+    def prof_reset(self):
+        self._chk(self.lib.mdb_dev_prof_reset(self.h), "prof_reset")
+
+    def prof_read(self):
+        buf = (ProfEntry * 64)()
+        n = c_int()
+        self._chk(self.lib.mdb_dev_prof_read(self.h, buf, 64, byref(n)), "prof_read")
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(n.value)}
+
+    # ---- operators ------------------------------------------------------------------------
+    def gen_keys(self, n, first_index, domain, seed, modulus=0):
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._chk(self.lib.mdb_dev_gen_keys(self.h, _ptr(out), n, first_index, domain, seed, modulus), "gen_keys")
+        return out
+
+    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):
+        """-> (keys[G], counts[G], first[G], joined_rows); tensors are views into `out` buffers."""
+        n_l, n_r = keys_l.numel(), keys_r.numel()
+        cap = max(n_l, 1)
+        if out is None:
+            out = (torch.empty(cap, dtype=torch.int64, device=self.device),
+                   torch.empty(cap, dtype=torch.int64, device=self.device),
+                   torch.empty(cap, dtype=torch.int32, device=self.device))
+        ok, oc, of = out
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r,
+                                                    flags, _ptr(ok), _ptr(oc), _ptr(of), cap, byref(g), byref(j)),
+                  "join_group_count")
+        G = g.value
+        return ok[:G], oc[:G], of[:G], j.value
+
+    def group_count(self, keys, nulls, flags=MDB_ORDER_FIRST):
+        n = keys.numel()
+        cap = max(n, 1)
+        of = torch.empty(cap, dtype=torch.int32, device=self.device)
+        oc = torch.empty(cap, dtype=torch.int64, device=self.device)
+        g = c_uint64()
+        self._chk(self.lib.mdb_dev_group_count(self.h, _ptr(keys), _ptr(nulls), n, flags, _ptr(of), _ptr(oc), cap, byref(g)),
+                  "group_count")
+        return of[:g.value], oc[:g.value]
+
+    def join_pairs(self, keys_l, null_l, keys_r, null_r):
+        pl, pr, cnt = c_void_p(), c_void_p(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_pairs(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), _ptr(keys_r), _ptr(null_r),
+                                              keys_r.numel(), byref(pl), byref(pr), byref(cnt)), "join_pairs")
+        J = cnt.value
+        ol = torch.empty(J, dtype=torch.int32, device=self.device)
+        orr = torch.empty(J, dtype=torch.int32, device=self.device)
+        if J:
+            # device-to-device copies out of the library-owned buffers, then release them
+            self._d2d(ol, pl, J * 4)
+            self._d2d(orr, pr, J * 4)
+            self.sync()
+        self._chk(self.lib.mdb_dev_free(self.h, pl), "free")
+        self._chk(self.lib.mdb_dev_free(self.h, pr), "free")
+        return ol, orr
+
+    def _d2d(self, dst_tensor, src_ptr, nbytes):
+        # identity gather through the library keeps everything on the context's stream
+        n32 = nbytes // 4
+        idx = torch.arange(n32, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mdb_dev_gather32(self.h, src_ptr, _ptr(idx), n32, _ptr(dst_tensor)), "gather32")
+
+    def cross_pairs(self, n_l, n_r):
+        ol = torch.empty(n_l * n_r, dtype=torch.int32, device=self.device)
+        orr = torch.empty(n_l * n_r, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mdb_dev_cross_pairs(self.h, n_l, n_r, _ptr(ol), _ptr(orr)), "cross_pairs")
+        return ol, orr
+
+    def filter(self, prog, cols, n):
+        """prog: list of (op, cmp, type, a, b, imm); cols: list of (values, nullbits, rid) tensors/None."""
+        insns = (PredInsn * max(len(prog), 1))()
+        for i, (op, cmp_, typ, a, b, imm) in enumerate(prog):
+            if typ == T_DOUBLE and isinstance(imm, float):
+                imm = int(np.float64(imm).view(np.int64))
+            insns[i] = PredInsn(op, cmp_, typ, a, b, 0, int(imm))
+        binds = (ColBinding * max(len(cols), 1))()
+        for i, (v, nb, rid) in enumerate(cols):
+            binds[i] = ColBinding(v.data_ptr(), nb.data_ptr() if nb is not None else None,
+                                  rid.data_ptr() if rid is not None else None)
+        sel = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        cnt = c_uint64()
+        self._chk(self.lib.mdb_dev_filter(self.h, insns, len(prog), binds, len(cols), n, _ptr(sel), byref(cnt)), "filter")
+        return sel[:cnt.value]
+
+    def gather64(self, src, src_null, idx, n):
+        dst = torch.empty(max(n, 1), dtype=src.dtype, device=self.device)
+        dnull = None
+        if src_null is not None:
+            dnull = torch.zeros((n + 63) // 64 or 1, dtype=torch.int64, device=self.device)
+        self._chk(self.lib.mdb_dev_gather64(self.h, _ptr(src), _ptr(src_null), _ptr(idx), n, _ptr(dst), _ptr(dnull)), "gather64")
+        return dst[:n], dnull
+
+    def gather32(self, src, idx):
+        n = idx.numel()
+        dst = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mdb_dev_gather32(self.h, _ptr(src), _ptr(idx), n, _ptr(dst)), "gather32")
+        return dst[:n]
+
+    def partition_by_dest(self, keys, nulls, n_dest, out=None):
+        n = keys.numel()
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        counts = (c_uint64 * n_dest)()
+        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, _ptr(out), counts),
+                  "partition_by_dest")
+        counts = [int(c) for c in counts]
+        return out[:sum(counts)], counts

@@ -1,0 +1,245 @@
+"""GPU parity tests of the device operators (include/mdb_dev.h) against the numpy oracle.
+
+Every call goes through the C-ABI of libmidoridb_amd.so; results must be bit-exact
+(integer / index work).  Sizes are chosen to cover: a single tile, one partition level,
+two partition levels (> 393 216 build rows), ragged tails, NULLs, duplicates (N:M), keys
+that are negative / zero (the key whose hash is 0 has a dedicated slot), and skew.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as orc
+from midoridb_amd import dev as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(rng, n, domain, null_frac=0.0, lo=0):
+    keys = rng.integers(lo, lo + max(domain, 1), size=n, dtype=np.int64)
+    nulls = None
+    if null_frac > 0:
+        nulls = rng.random(n) < null_frac
+    return keys, nulls
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+CASES_JGC = [
+    # (n_l, n_r, domain, null_frac, lo)
+    (1, 1, 1, 0.0, 0),
+    (5, 7, 3, 0.0, 0),
+    (63, 65, 10, 0.2, -5),
+    (64, 64, 64, 0.0, 0),
+    (1000, 1500, 200, 0.1, -100),
+    (4096, 4097, 5000, 0.05, 0),
+    (50_000, 70_000, 20_000, 0.01, -10_000),
+    (300_000, 300_000, 300_000, 0.0, 0),
+    (1_000_000, 1_200_000, 700_000, 0.02, -350_000),     # two partition levels
+    (2_000_000, 500_000, 3_000_000, 0.0, 0),
+]
+
+
+@pytest.mark.parametrize("n_l,n_r,domain,null_frac,lo", CASES_JGC)
+def test_join_group_count(dev, n_l, n_r, domain, null_frac, lo):
+    rng = np.random.default_rng(n_l * 31 + n_r)
+    kl, nl = _mk(rng, n_l, domain, null_frac, lo)
+    kr, nr = _mk(rng, n_r, domain, null_frac, lo)
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert j == ej
+    assert np.array_equal(_np(f).astype(np.int64), ef)
+    assert np.array_equal(_np(k), ek)
+    assert np.array_equal(_np(c), ec)
+
+
+def test_join_group_count_golden_case11(dev):
+    # reference tests/engine/executor_select.c:348-378 : A(id_a)=1,3,4 ; B(id_b)=1,1,3,3,4,NULL
+    kl = np.array([1, 3, 4], dtype=np.int64)
+    kr = np.array([1, 1, 3, 3, 4, 0], dtype=np.int64)
+    nr = np.array([0, 0, 0, 0, 0, 1], dtype=bool)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), None, dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert _np(k).tolist() == [1, 3, 4]
+    assert _np(c).tolist() == [2, 2, 1]
+    assert j == 5
+
+
+def test_join_group_count_empty_and_disjoint(dev):
+    z = dev.to_dev(np.zeros(0, dtype=np.int64))
+    a = dev.to_dev(np.arange(10, dtype=np.int64))
+    b = dev.to_dev(np.arange(100, 110, dtype=np.int64))
+    for l, r in ((z, a), (a, z), (a, b)):
+        k, c, f, j = dev.join_group_count(l, None, r, None)
+        assert k.numel() == 0 and j == 0
+
+
+def test_join_group_count_skew(dev):
+    # one hot key on both sides (N:M = 3000 x 5000) plus the zero key and int64 extremes
+    rng = np.random.default_rng(7)
+    kl = np.concatenate([np.full(3000, 42), np.zeros(10), rng.integers(-2**62, 2**62, 20_000),
+                         [np.iinfo(np.int64).min, np.iinfo(np.int64).max]]).astype(np.int64)
+    kr = np.concatenate([np.full(5000, 42), np.zeros(3), kl[3010:13010],
+                         [np.iinfo(np.int64).min]]).astype(np.int64)
+    rng.shuffle(kl)
+    rng.shuffle(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), None, dev.to_dev(kr), None)
+    assert j == ej
+    assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
+
+
+@pytest.mark.parametrize("n,domain,null_frac", [(1, 1, 0.0), (10, 3, 0.5), (65, 7, 0.3), (5000, 50, 0.1),
+                                                  (100_000, 100_000, 0.0), (1_500_000, 400_000, 0.05)])
+def test_group_count(dev, n, domain, null_frac):
+    rng = np.random.default_rng(n)
+    k, nl = _mk(rng, n, domain, null_frac, -domain // 2)
+    ef, ec = orc.group_count(k, nl)
+    f, c = dev.group_count(dev.to_dev(k), dev.nullbits_dev(nl))
+    assert np.array_equal(_np(f).astype(np.int64), ef)
+    assert np.array_equal(_np(c), ec)
+
+
+def test_group_count_golden_case10(dev):
+    # reference tests/engine/executor_select.c:318-346 : id = 1,1,3,3,4 -> (1,2)(3,2)(4,1)
+    k = np.array([1, 1, 3, 3, 4], dtype=np.int64)
+    f, c = dev.group_count(dev.to_dev(k), None)
+    assert _np(f).tolist() == [0, 2, 4] and _np(c).tolist() == [2, 2, 1]
+
+
+def test_group_count_all_null(dev):
+    k = np.zeros(100, dtype=np.int64)
+    nl = np.ones(100, dtype=bool)
+    f, c = dev.group_count(dev.to_dev(k), dev.nullbits_dev(nl))
+    assert _np(f).tolist() == [0] and _np(c).tolist() == [100]
+
+
+CASES_PAIRS = [
+    (1, 1, 1, 0.0), (3, 2, 3, 0.0), (65, 63, 9, 0.2), (2000, 3000, 500, 0.1), (40_000, 60_000, 30_000, 0.02),
+    (700_000, 900_000, 1_000_000, 0.0),   # two partition levels (900k right rows / 640 per leaf)
+]
+
+
+@pytest.mark.parametrize("n_l,n_r,domain,null_frac", CASES_PAIRS)
+def test_join_pairs(dev, n_l, n_r, domain, null_frac):
+    rng = np.random.default_rng(n_l + 3 * n_r)
+    kl, nl = _mk(rng, n_l, domain, null_frac, -3)
+    kr, nr = _mk(rng, n_r, domain, null_frac, -3)
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert l.numel() == len(el)
+    assert np.array_equal(_np(l).astype(np.int64), el)
+    assert np.array_equal(_np(r).astype(np.int64), er)
+
+
+def test_join_pairs_golden_case3(dev):
+    # reference tests/engine/executor_select.c:102-131 : A.id_a=1,2,3 ; B.id_b=1,3 -> rows (0,0),(2,1)
+    l, r = dev.join_pairs(dev.to_dev(np.array([1, 2, 3], dtype=np.int64)), None,
+                          dev.to_dev(np.array([1, 3], dtype=np.int64)), None)
+    assert _np(l).tolist() == [0, 2] and _np(r).tolist() == [0, 1]
+
+
+def test_join_pairs_heavy_duplicates(dev):
+    # one key 300 x 5000 times: exercises the chunked emit (right side > 2048 rows of one key)
+    kl = np.concatenate([np.full(300, 9), np.arange(100, 1100)]).astype(np.int64)
+    kr = np.concatenate([np.full(5000, 9), np.arange(100, 600), np.zeros(70)]).astype(np.int64)
+    rng = np.random.default_rng(3)
+    rng.shuffle(kl)
+    rng.shuffle(kr)
+    el, er = orc.join_pairs(kl, None, kr, None)
+    l, r = dev.join_pairs(dev.to_dev(kl), None, dev.to_dev(kr), None)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+def test_cross_pairs(dev):
+    l, r = dev.cross_pairs(3, 70)
+    assert _np(l).tolist() == [i for i in range(3) for _ in range(70)]
+    assert _np(r).tolist() == [j for _ in range(3) for j in range(70)]
+
+
+def test_filter_programs(dev):
+    rng = np.random.default_rng(11)
+    n = 100_003
+    a = rng.integers(-1000, 1000, n, dtype=np.int64)
+    b = rng.integers(-1000, 1000, n, dtype=np.int64)
+    x = rng.random(n)
+    na = rng.random(n) < 0.1
+    nb = rng.random(n) < 0.1
+    cols_np = [(a, na, None), (b, nb, None), (x, None, None)]
+    cols_dev = [(dev.to_dev(a), dev.nullbits_dev(na), None), (dev.to_dev(b), dev.nullbits_dev(nb), None),
+                (dev.to_dev(x), None, None)]
+    half = int(np.float64(0.5).view(np.int64))
+    progs = [
+        [(D.P_CMP_COL_CONST, D.CMP_GT, D.T_INT64, 0, 0, 500)],
+        [(D.P_CMP_CONST_COL, D.CMP_GE, D.T_INT64, 0, 0, 123), (D.P_CMP_COL_CONST, D.CMP_LT, D.T_INT64, 0, 0, 200), (D.P_AND, 0, 0, 0, 0, 0)],
+        [(D.P_CMP_COL_COL, D.CMP_EQ, D.T_INT64, 0, 1, 0)],
+        [(D.P_CMP_COL_COL, D.CMP_NE, D.T_INT64, 0, 1, 0), (D.P_ISNULL, 0, 0, 1, 0, 0), (D.P_OR, 0, 0, 0, 0, 0)],
+        [(D.P_ISNULL, 1, 0, 0, 0, 0), (D.P_CMP_COL_CONST, D.CMP_LE, D.T_DOUBLE, 2, 0, half), (D.P_XOR, 0, 0, 0, 0, 0)],
+        [(D.P_CONST, 0, 0, 0, 0, 1), (D.P_CMP_COL_CONST, D.CMP_EQ, D.T_INT64, 1, 0, -7), (D.P_AND, 0, 0, 0, 0, 0)],
+        [(D.P_CONST, 0, 0, 0, 0, 0)],
+    ]
+    for prog in progs:
+        exp = orc.filter_positions([(op, c, t, aa, bb, (np.float64(0.5) if (t == D.T_DOUBLE) else imm))
+                                    for (op, c, t, aa, bb, imm) in prog], cols_np, n)
+        got = _np(dev.filter(prog, cols_dev, n)).astype(np.int64)
+        assert np.array_equal(got, exp), prog
+
+
+def test_filter_through_rid_vector(dev):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 50, 1000, dtype=np.int64)
+    na = rng.random(1000) < 0.2
+    rid = rng.integers(0, 1000, 7777).astype(np.int32)
+    prog = [(D.P_CMP_COL_CONST, D.CMP_LT, D.T_INT64, 0, 0, 25)]
+    exp = orc.filter_positions(prog, [(a, na, rid)], len(rid))
+    got = _np(dev.filter(prog, [(dev.to_dev(a), dev.nullbits_dev(na), dev.to_dev(rid))], len(rid))).astype(np.int64)
+    assert np.array_equal(got, exp)
+
+
+def test_gather64_with_nulls(dev):
+    rng = np.random.default_rng(9)
+    src = rng.integers(-10**12, 10**12, 5000, dtype=np.int64)
+    nul = rng.random(5000) < 0.3
+    idx = rng.integers(0, 5000, 12_345).astype(np.int32)
+    out, onull = dev.gather64(dev.to_dev(src), dev.nullbits_dev(nul), dev.to_dev(idx), len(idx))
+    assert np.array_equal(_np(out), src[idx])
+    assert np.array_equal(D.unpack_nullbits(_np(onull).view(np.uint64), len(idx)), nul[idx])
+    out2, _ = dev.gather64(dev.to_dev(src), None, None, 5000)
+    assert np.array_equal(_np(out2), src)
+
+
+@pytest.mark.parametrize("n_dest", [1, 2, 4, 8])
+def test_partition_by_dest(dev, n_dest):
+    rng = np.random.default_rng(n_dest)
+    k = rng.integers(-10**9, 10**9, 200_001, dtype=np.int64)
+    nl = rng.random(len(k)) < 0.03
+    ek, ec = orc.partition_by_dest(k, nl, n_dest)
+    out, counts = dev.partition_by_dest(dev.to_dev(k), dev.nullbits_dev(nl), n_dest)
+    assert counts == ec.tolist()
+    assert np.array_equal(_np(out), ek)
+
+
+def test_gen_keys_matches_oracle(dev):
+    for (n, first, domain, seed, mod) in [(1000, 0, 1000, 42, 0), (5000, 2500, 10_000, 43, 0), (4096, 0, 4096, 44, 256)]:
+        got = _np(dev.gen_keys(n, first, domain, seed, mod))
+        assert np.array_equal(got, orc.gen_keys(n, first, domain, seed, mod))
+    full = _np(dev.gen_keys(10_000, 0, 10_000, 42, 0))
+    assert np.array_equal(np.sort(full), np.arange(10_000))
+
+
+def test_large_properties_north_star(dev):
+    """Size-independent properties at 10^7 rows per table (variant D of SURVEY 8d C3):
+    A = permutation of [0,N), B keys = permutation mod N/16  =>  G = N/16 groups of count 16,
+    J = N joined rows, groups ordered by first position, keys distinct."""
+    N = 10_000_000
+    a = dev.gen_keys(N, 0, N, 42, 0)
+    b = dev.gen_keys(N, 0, N, 43, N // 16)
+    k, c, f, j = dev.join_group_count(a, None, b, None)
+    assert j == N
+    assert k.numel() == N // 16
+    assert bool((c == 16).all())
+    assert bool((f[1:] > f[:-1]).all())
+    assert bool((a[f.long()] == k).all())
+    assert torch.unique(k).numel() == k.numel()
+    assert int(k.max()) < N // 16
