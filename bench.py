@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py - joined rows/sec of the north-star query on 1..N MI355X (contract: see DESIGN.md 6).
+
+    SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;
+
+A "step" = one pass of the whole device pipeline (hash, partition both tables, per-leaf LDS hash
+build/probe, ordered group emission) over synthetic INT64 tables that are already resident in
+HBM when the timed region starts.  N = 1: 10^8 rows per table on one GPU (BASELINE.json
+configs[2]).  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds 10^8
+rows of each table (weak scaling), keys are hash-partitioned by destination GPU, exchanged with
+one RCCL all-to-all per table over xGMI, then joined locally; no other collective is on the path.
+
+The JSON line carries `roofline` for the dominant kernel (live HIP-event timing through the
+library's per-kernel profiler) and `cpu_baseline` (the real reference executor if
+oracle/_ref/libmidori_ref.so travelled with the snapshot, else the repo's own C restatement).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per table per GPU")
+    ap.add_argument("--variant", choices=["U", "D"], default="D",
+                    help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check the result against the CPU oracle (rows <= 2e7)")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """Time the CPU path on this box's host cores on a bounded sample of the same query.
+
+    Preferred: the REAL reference executor (oracle/_ref, built in the authoring container from
+    /root/reference and shipped with the snapshot) on 2000 x 2000 rows through its own
+    ast -> semantic -> optimiser -> executor pipeline.  Fallback: oracle/cpu_naive.c ("port").
+    """
+    n = 2000
+    try:
+        from oracle import ref as refmod
+        if refmod.available():
+            db = refmod.RefDB()
+            a = np.arange(n, dtype=np.int64)
+            rng = np.random.default_rng(42)
+            db.create_int_table("A", ["id_a"])
+            db.create_int_table("B", ["id_b"])
+            db.bulk_insert("A", [rng.permutation(a)])
+            db.bulk_insert("B", [rng.permutation(a)])
+            t0 = time.perf_counter()
+            cols, rows = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;")
+            dt = time.perf_counter() - t0
+            db.close()
+            return {"value": n / dt, "unit": "joined rows/s", "cores": 1, "kind": "reference",
+                    "sample": f"north-star query, {n}x{n} unique keys, real reference executor via oracle/_ref "
+                              f"({dt:.2f} s; O(nA*nB) nested loop, {n * n / dt:.3g} row pairs/s)"}
+    except Exception as e:  # pragma: no cover - diagnostic path
+        sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
+    from oracle import cpu
+    rng = np.random.default_rng(42)
+    a = rng.permutation(np.arange(n, dtype=np.int64))
+    b = rng.permutation(np.arange(n, dtype=np.int64))
+    t0 = time.perf_counter()
+    cpu.naive_join_group_count(a, None, b, None)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "joined rows/s", "cores": 1, "kind": "port",
+            "sample": f"north-star query, {n}x{n} unique keys, oracle/cpu_naive.c nested loop ({dt:.2f} s)"}
+
+
+def cpu_hash_yardstick(rows):
+    """Multi-threaded hash join on the host (oracle/cpu_hash.c) at a bounded size, for orientation."""
+    from oracle import cpu, np_oracle as orc
+    n = min(rows, 20_000_000)
+    a = orc.gen_keys(n, 0, n, 42, 0)
+    b = orc.gen_keys(n, 0, n, 43, n // 16)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _, _, _, j = cpu.hash_join_group_count(a, None, b, None, cores)
+    dt = time.perf_counter() - t0
+    return {"value": j / dt, "unit": "joined rows/s", "cores": cores, "rows_per_table": n}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from midoridb_amd.dev import DeviceCtx
+    from midoridb_amd import shuffle
+
+    dev = DeviceCtx(local_rank)
+    n = args.rows
+    total_rows = n * world
+    mod_b = total_rows // 16 if args.variant == "D" else 0
+    # rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)
+    a = dev.gen_keys(n, rank * n, total_rows, 42, 0)
+    b = dev.gen_keys(n, rank * n, total_rows, 43, mod_b)
+    cap = int(n * 1.3) + 4096 if world > 1 else n
+    out = (torch.empty(cap, dtype=torch.int64, device=dev.device), torch.empty(cap, dtype=torch.int64, device=dev.device),
+           torch.empty(cap, dtype=torch.int32, device=dev.device))
+    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n) if world > 1 else None
+
+    def step():
+        if pipeline is None:
+            k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
+            return k.numel(), j
+        return pipeline.run(a, b, out)
+
+    for _ in range(max(args.warmup, 1) if world == 1 else args.warmup):
+        g, j = step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, j = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev.device)
+    jsum = torch.tensor([float(j)], dtype=torch.float64, device=dev.device)
+    gsum = torch.tensor([float(g)], dtype=torch.float64, device=dev.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(jsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    joined_total = int(jsum.item())
+    groups_total = int(gsum.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = joined_total / (dt / args.steps)
+
+    # ---- per-kernel profile (outside the timed region): live HIP events around every launch
+    dev.prof_enable(True)
+    dev.prof_reset()
+    prof_steps = 3
+    for _ in range(prof_steps):
+        step()
+    prof = dev.prof_read()
+    dev.prof_enable(False)
+
+    if rank == 0:
+        kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
+        # dominant kernel = the level-0/1 scatter; algorithmic bytes of one launch = every key it moves,
+        # read once (8 B hashed key [+4 B row id]) and written once
+        dom_name = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+        roof = None
+        if dom_name:
+            d = kern[dom_name]
+            launches = max(d["launches_per_step"], 1e-9)
+            avg_ms = d["ms_per_step"] / launches
+            bytes_per_launch = shuffle.algorithmic_bytes(dom_name, n, world, kern)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch}
+        # whole-pipeline view: the bytes any correct algorithm must move once
+        algo_bytes = 8 * 2 * total_rows + 16 * groups_total
+        line = {
+            "metric": "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X",
+            "value": value, "unit": "joined rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU, variant {args.variant} "
+                                   f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
+                       "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
+                       "order": "reference first-occurrence order", "parallelism": f"hash-partition x{world}"},
+            "roofline": roof,
+            "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
+                         "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "kernels": kern,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_hash"] = cpu_hash_yardstick(n)
+            except Exception as e:  # pragma: no cover
+                line["cpu_hash"] = {"error": str(e)}
+        if args.verify and n <= 20_000_000 and world == 1:
+            from oracle import cpu, np_oracle as orc
+            ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(n, 0, n, 42, 0), None, orc.gen_keys(n, 0, n, 43, mod_b),
+                                                       None, os.cpu_count() or 1)
+            k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
+            ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))
+            line["verified_vs_oracle"] = bool(ok)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,8 +39,10 @@ typedef struct mdb_dev_ctx mdb_dev_ctx;
 
 /* ------------------------------------------------------------------ context */
 
-/* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on
- * (e.g. the caller's current stream) or NULL for a context-owned stream. */
+/* Create a context on HIP device `device`.  `stream` is the hipStream_t to launch on:
+ * NULL = the device's default stream (what torch.cuda.current_stream().cuda_stream is
+ * unless the caller switched streams), MDB_STREAM_OWN = a private non-blocking stream. */
+#define MDB_STREAM_OWN ((void *)(intptr_t)-1)
 int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out);
 void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx);
 int mdb_dev_ctx_set_stream(mdb_dev_ctx *ctx, void *stream);

@@ -49,15 +49,15 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->prof_pool_used = 0;
 	ctx->d_status = NULL;
 	ctx->h_pinned = NULL;
-	if (stream) {
-		ctx->stream = (hipStream_t)stream;
-		ctx->own_stream = false;
-	} else {
+	if (stream == MDB_STREAM_OWN) {
 		if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
 			delete ctx;
 			return -MIDORIDB_INTERNAL;
 		}
 		ctx->own_stream = true;
+	} else {
+		ctx->stream = (hipStream_t)stream;	/* NULL = the device's default stream */
+		ctx->own_stream = false;
 	}
 	if (hipMalloc((void **)&ctx->d_status, 64 * sizeof(uint64_t)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->h_pinned, 1024 * sizeof(uint64_t)) != hipSuccess ||
@@ -99,11 +99,11 @@ extern "C" int mdb_dev_ctx_set_stream(mdb_dev_ctx *ctx, void *stream)
 		MDB_HIP(ctx, hipStreamDestroy(ctx->stream));
 		ctx->own_stream = false;
 	}
-	if (stream) {
-		ctx->stream = (hipStream_t)stream;
-	} else {
+	if (stream == MDB_STREAM_OWN) {
 		MDB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 		ctx->own_stream = true;
+	} else {
+		ctx->stream = (hipStream_t)stream;
 	}
 	return MIDORIDB_OK;
 }

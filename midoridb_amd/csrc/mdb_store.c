@@ -1,0 +1,267 @@
+/*
+ * mdb_store.c - catalog and columnar table storage with device mirrors.
+ *
+ * Replaces, on this path, the reference's row store (reference src/primitive/: struct table with a
+ * circular list of 4 KiB datablocks, 24-byte row header + 8-aligned payload, include/primitive/
+ * row.h:15-28): every column is one contiguous int64_t[] / double[] plus a NULL bitmap, which is
+ * exactly the layout the kernels read (include/mdb_dev.h).  INSERT appends on the host; the first
+ * SELECT after a mutation re-uploads the table (generation counter) - incremental upload is a
+ * "next" row.
+ */
+#include "mdb_host.h"
+
+struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name)
+{
+	for (int i = 0; i < cat->n; i++)
+		if (strcmp(cat->tables[i]->name, name) == 0)
+			return cat->tables[i];
+	return NULL;
+}
+
+int mdb_catalog_add(struct mdb_catalog *cat, struct mdb_table *t)
+{
+	if (cat->n == cat->cap) {
+		int nc = cat->cap ? cat->cap * 2 : 8;
+		struct mdb_table **nt = realloc(cat->tables, sizeof(*nt) * (size_t)nc);
+		if (!nt)
+			return -MIDORIDB_NOMEM;
+		cat->tables = nt;
+		cat->cap = nc;
+	}
+	cat->tables[cat->n++] = t;
+	return MIDORIDB_OK;
+}
+
+struct mdb_table *mdb_table_new(const char *name)
+{
+	struct mdb_table *t = calloc(1, sizeof(*t));
+	if (!t)
+		return NULL;
+	strncpy(t->name, name, MDB_NAME_LEN - 1);
+	t->generation = 1;
+	return t;
+}
+
+static void table_drop_device(struct mdb_table *t, mdb_dev_ctx *dev)
+{
+	for (int c = 0; c < t->ncols; c++) {
+		if (dev && t->cols[c].d_data)
+			mdb_dev_free(dev, t->cols[c].d_data);
+		if (dev && t->cols[c].d_nullbits)
+			mdb_dev_free(dev, t->cols[c].d_nullbits);
+		t->cols[c].d_data = NULL;
+		t->cols[c].d_nullbits = NULL;
+	}
+	t->dev_generation = 0;
+	t->dev_rows = 0;
+}
+
+void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev)
+{
+	if (!t)
+		return;
+	table_drop_device(t, dev);
+	for (int c = 0; c < t->ncols; c++) {
+		free(t->cols[c].data);
+		free(t->cols[c].nullbits);
+	}
+	free(t);
+}
+
+void mdb_catalog_free(struct mdb_catalog *cat)
+{
+	for (int i = 0; i < cat->n; i++)
+		mdb_table_free(cat->tables[i], cat->dev);
+	free(cat->tables);
+	if (cat->dev)
+		mdb_dev_ctx_destroy(cat->dev);
+	memset(cat, 0, sizeof(*cat));
+}
+
+int mdb_table_add_column(struct mdb_table *t, const char *name, int type)
+{
+	struct mdb_column *c;
+	if (t->ncols >= MDB_MAX_COLS)
+		return -MIDORIDB_ERROR;
+	c = &t->cols[t->ncols++];
+	memset(c, 0, sizeof(*c));
+	strncpy(c->name, name, MDB_NAME_LEN - 1);
+	c->type = type;
+	return MIDORIDB_OK;
+}
+
+int mdb_table_reserve(struct mdb_table *t, uint64_t rows)
+{
+	uint64_t ncap;
+	if (rows <= t->cap)
+		return MIDORIDB_OK;
+	ncap = t->cap ? t->cap : 64;
+	while (ncap < rows)
+		ncap *= 2;
+	for (int c = 0; c < t->ncols; c++) {
+		const uint64_t old_words = (t->cap + 63) / 64, new_words = (ncap + 63) / 64;
+		int64_t *nd = realloc(t->cols[c].data, sizeof(int64_t) * ncap);
+		uint64_t *nb;
+		if (!nd)
+			return -MIDORIDB_NOMEM;
+		t->cols[c].data = nd;
+		nb = realloc(t->cols[c].nullbits, sizeof(uint64_t) * new_words);
+		if (!nb)
+			return -MIDORIDB_NOMEM;
+		memset(nb + old_words, 0, sizeof(uint64_t) * (new_words - old_words));
+		t->cols[c].nullbits = nb;
+	}
+	t->cap = ncap;
+	return MIDORIDB_OK;
+}
+
+int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen)
+{
+	if (!cat->dev && cat->dev_rc == 0) {
+		const char *env = getenv("MIDORIDB_DEVICE");
+		int device = env ? atoi(env) : 0;
+		int n = mdb_dev_device_count();
+		if (n <= 0) {
+			cat->dev_rc = -MIDORIDB_INTERNAL;
+		} else {
+			cat->dev_rc = mdb_dev_ctx_create(device, MDB_STREAM_OWN, &cat->dev);
+		}
+	}
+	if (!cat->dev) {
+		snprintf(err, errlen,
+			 "execution phase: no usable HIP device (MI355X path only - this library has no CPU executor)\n");
+		return cat->dev_rc ? cat->dev_rc : -MIDORIDB_INTERNAL;
+	}
+	return MIDORIDB_OK;
+}
+
+int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen)
+{
+	int rc = mdb_catalog_device(cat, err, errlen);
+	if (rc)
+		return rc;
+	if (t->device_only || (t->dev_generation == t->generation && t->dev_rows == t->nrows))
+		return MIDORIDB_OK;
+	table_drop_device(t, cat->dev);
+	for (int c = 0; c < t->ncols; c++) {
+		struct mdb_column *col = &t->cols[c];
+		if (col->type != MDB_CT_INTEGER && col->type != MDB_CT_DOUBLE)
+			continue;	/* never referenced by the device path (rejected at plan time) */
+		if (t->nrows == 0)
+			continue;
+		rc = mdb_dev_alloc(cat->dev, t->nrows * 8, &col->d_data);
+		if (!rc)
+			rc = mdb_dev_h2d(cat->dev, col->d_data, col->data, t->nrows * 8);
+		if (!rc && col->null_count) {
+			rc = mdb_dev_alloc(cat->dev, ((t->nrows + 63) / 64) * 8, (void **)&col->d_nullbits);
+			if (!rc)
+				rc = mdb_dev_h2d(cat->dev, col->d_nullbits, col->nullbits, ((t->nrows + 63) / 64) * 8);
+		}
+		if (rc) {
+			snprintf(err, errlen, "execution phase: cannot mirror table '%s' on the device: %s\n", t->name,
+				 mdb_dev_last_error(cat->dev));
+			table_drop_device(t, cat->dev);
+			return rc;
+		}
+	}
+	t->dev_generation = t->generation;
+	t->dev_rows = t->nrows;
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ result column order (R3)
+ *
+ * The reference creates the result ("early_mat_tbl") columns by iterating a chained hash table of
+ * column names (reference src/engine/executor_select.c:293-322; src/datastructure/hashtable.c):
+ * djb2 over strlen+1 bytes (the NUL included, :269-281), capacity 16, doubled when count/capacity
+ * >= 0.5 after a put (:84-129; old buckets are re-inserted in bucket order, each chain from its
+ * head), list_add() inserts at the chain head (:172), iteration = buckets in order, chains from
+ * the head (:242-259).  This function replays that on the key sequence and returns, for each
+ * iteration position, the index of the key.
+ */
+static size_t djb2_with_nul(const char *s)
+{
+	size_t h = 5381;
+	size_t len = strlen(s) + 1;
+	for (size_t i = 0; i < len; i++)
+		h = ((h << 5) + h) + (size_t)(signed char)s[i];
+	return h;
+}
+
+int mdb_reference_column_order(const char (*keys)[MDB_NAME_LEN], int nkeys, int *order_out)
+{
+	size_t cap = 16;
+	int count = 0;
+	/* bucket chains as arrays, index 0 = head */
+	int *chain = calloc((size_t)nkeys * 4096 / 4096 + 1, sizeof(int));	/* placeholder to keep allocation pattern simple */
+	int **bucket;
+	int *blen;
+	int rc = MIDORIDB_OK;
+
+	free(chain);
+	bucket = calloc(cap, sizeof(int *));
+	blen = calloc(cap, sizeof(int));
+	if (!bucket || !blen)
+		return -MIDORIDB_NOMEM;
+	for (int k = 0; k < nkeys; k++) {
+		size_t b = djb2_with_nul(keys[k]) % cap;
+		int *nb = realloc(bucket[b], sizeof(int) * (size_t)(blen[b] + 1));
+		if (!nb) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		bucket[b] = nb;
+		memmove(nb + 1, nb, sizeof(int) * (size_t)blen[b]);	/* list_add: new entry becomes the head */
+		nb[0] = k;
+		blen[b]++;
+		count++;
+		if ((double)count / (double)cap >= 0.5) {
+			size_t ncap = cap * 2;
+			int **nbk = calloc(ncap, sizeof(int *));
+			int *nlen = calloc(ncap, sizeof(int));
+			if (!nbk || !nlen) {
+				free(nbk);
+				free(nlen);
+				rc = -MIDORIDB_NOMEM;
+				goto out;
+			}
+			for (size_t i = 0; i < cap; i++) {
+				for (int e = 0; e < blen[i]; e++) {	/* chain from its head */
+					int key = bucket[i][e];
+					size_t d = djb2_with_nul(keys[key]) % ncap;
+					int *x = realloc(nbk[d], sizeof(int) * (size_t)(nlen[d] + 1));
+					if (!x) {
+						rc = -MIDORIDB_NOMEM;
+						for (size_t z = 0; z < ncap; z++)
+							free(nbk[z]);
+						free(nbk);
+						free(nlen);
+						goto out;
+					}
+					nbk[d] = x;
+					memmove(x + 1, x, sizeof(int) * (size_t)nlen[d]);
+					x[0] = key;
+					nlen[d]++;
+				}
+				free(bucket[i]);
+			}
+			free(bucket);
+			free(blen);
+			bucket = nbk;
+			blen = nlen;
+			cap = ncap;
+		}
+	}
+	{
+		int pos = 0;
+		for (size_t i = 0; i < cap; i++)
+			for (int e = 0; e < blen[i]; e++)
+				order_out[pos++] = bucket[i][e];
+	}
+out:
+	for (size_t i = 0; i < cap; i++)
+		free(bucket[i]);
+	free(bucket);
+	free(blen);
+	return rc;
+}

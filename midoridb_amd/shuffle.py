@@ -1,0 +1,77 @@
+"""Multi-GPU form of the north-star pipeline: hash-partition by destination GPU -> one all-to-all
+per table over xGMI (RCCL through torch.distributed; backend "nccl" IS RCCL on ROCm) -> local
+LDS hash join + group count.  No other collective is on the data path: groups are disjoint
+across ranks because both tables are partitioned by the join key.
+
+The exchange logic is backend-neutral so the world_size-2 gloo tests on CPU run exactly this
+code with the oracle's partition/join functions plugged in instead of the device operators.
+"""
+import torch
+import torch.distributed as dist
+
+
+class KeyExchange:
+    """counts all-to-all (nGPU int64) followed by one uneven all_to_all_single of the keys."""
+
+    def __init__(self, world, device):
+        self.world = world
+        self.device = device
+
+    def exchange(self, send_keys, send_counts, recv_buf=None):
+        """send_keys: keys grouped by destination rank; send_counts: list[int] of len world.
+        Returns (recv_keys tensor, recv_counts list)."""
+        cin = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+        cout = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(cout, cin)
+        recv_counts = [int(x) for x in cout.tolist()]
+        total = sum(recv_counts)
+        if recv_buf is None or recv_buf.numel() < total:
+            recv_buf = torch.empty(max(total, 1), dtype=send_keys.dtype, device=self.device)
+        recv = recv_buf[:total]
+        dist.all_to_all_single(recv, send_keys[:sum(send_counts)], recv_counts, list(send_counts))
+        return recv, recv_counts
+
+
+class DistributedJoinGroupCount:
+    """One rank's share of  A JOIN B ON id_a = id_b GROUP BY id_a COUNT(*)  over `world` GPUs."""
+
+    def __init__(self, dev, world, rank, rows_per_rank, partition_fn=None, join_fn=None, device=None):
+        self.dev = dev
+        self.world = world
+        self.rank = rank
+        device = device if device is not None else dev.device
+        self.ex = KeyExchange(world, device)
+        cap = int(rows_per_rank * 1.3) + 4096
+        self.send_a = torch.empty(max(rows_per_rank, 1), dtype=torch.int64, device=device)
+        self.send_b = torch.empty(max(rows_per_rank, 1), dtype=torch.int64, device=device)
+        self.recv_a = torch.empty(cap, dtype=torch.int64, device=device)
+        self.recv_b = torch.empty(cap, dtype=torch.int64, device=device)
+        self.partition_fn = partition_fn or (lambda keys, out: dev.partition_by_dest(keys, None, world, out=out))
+        self.join_fn = join_fn or (lambda ka, kb, out: dev.join_group_count(ka, None, kb, None, out=out))
+
+    def run(self, a, b, out=None):
+        sa, ca = self.partition_fn(a, self.send_a)
+        sb, cb = self.partition_fn(b, self.send_b)
+        ra, _ = self.ex.exchange(sa, ca, self.recv_a)
+        rb, _ = self.ex.exchange(sb, cb, self.recv_b)
+        k, c, f, j = self.join_fn(ra, rb, out)
+        self.last = (k, c, f)
+        return k.numel() if hasattr(k, "numel") else len(k), j
+
+
+def algorithmic_bytes(kernel, n, world, kern):
+    """Algorithmic HBM bytes of ONE launch of `kernel` on tables of n rows per GPU:
+    what the launch must read once and write once, independent of how it is implemented.
+    A kernel name covers the launch for table A (carries 4-byte row ids) and for table B (keys
+    only); the figure is their average."""
+    a_key, rid = 8 * n, 4 * n
+    table = {
+        "part_hist_l0": a_key,					# read the raw keys
+        "part_hist_l1": a_key,					# read the hashed keys
+        "part_scatter_l0": ((a_key + a_key + rid) + (a_key + a_key)) / 2,	# read key, write hash (+rid)
+        "part_scatter_l1": ((2 * (a_key + rid)) + (2 * a_key)) / 2,		# move hash (+rid)
+        "leaf_join_group_count": (a_key + rid) + a_key,				# read both partitioned tables once
+        "compact_nonzero_bits": a_key,
+        "gather64": a_key,
+    }
+    return float(table.get(kernel, a_key))

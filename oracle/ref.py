@@ -1,0 +1,130 @@
+"""ref.py - TEST INFRASTRUCTURE ONLY: Python access to oracle/_ref/libmidori_ref.so, the REAL
+reference compiled from /root/reference by `make -C oracle ref` (see ref_harness.c).
+
+SQL text is turned into the parser's RPN token queue by the product's own SQL front end
+(libmidoridb_amd.so: mdb_sql_to_rpn) - the reference's flex/bison parser cannot be built here -
+and everything behind the parser seam is the unmodified reference code.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libmidori_ref.so")
+_LIB = None
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(_PATH, mode=ctypes.RTLD_LOCAL)
+        P = ctypes.c_void_p
+        L.ref_open.restype = P
+        L.ref_close.argtypes = [P]
+        L.ref_error.argtypes = [P]
+        L.ref_error.restype = ctypes.c_char_p
+        L.ref_exec_rpn.argtypes = [P, ctypes.c_char_p]
+        L.ref_exec_rpn.restype = ctypes.c_int
+        L.ref_bulk_insert.argtypes = [P, ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, P, P]
+        L.ref_bulk_insert.restype = ctypes.c_int
+        L.ref_result_ncols.argtypes = [P]
+        L.ref_result_ncols.restype = ctypes.c_int
+        L.ref_result_colname.argtypes = [P, ctypes.c_int]
+        L.ref_result_colname.restype = ctypes.c_char_p
+        L.ref_result_coltype.argtypes = [P, ctypes.c_int]
+        L.ref_result_coltype.restype = ctypes.c_int
+        L.ref_result_fetch.argtypes = [P, P, P, ctypes.c_int64]
+        L.ref_result_fetch.restype = ctypes.c_int64
+        L.ref_table_rows.argtypes = [P, ctypes.c_char_p]
+        L.ref_table_rows.restype = ctypes.c_int64
+        _LIB = L
+    return _LIB
+
+
+def sql_to_rpn(sql):
+    """SQL -> RPN lines through the product's front end (midoridb_amd/csrc/mdb_sql.c)."""
+    from midoridb_amd.lib import load_library
+    lib = load_library()
+    lib.mdb_sql_to_rpn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.mdb_sql_to_rpn.restype = ctypes.c_int
+    buf = ctypes.create_string_buffer(1 << 16)
+    err = ctypes.create_string_buffer(1024)
+    rc = lib.mdb_sql_to_rpn(sql.encode(), buf, len(buf), err, len(err))
+    if rc != 0:
+        raise ValueError(f"SQL parse error: {err.value.decode()}")
+    return buf.value.decode()
+
+
+class RefError(RuntimeError):
+    pass
+
+
+class RefDB:
+    """One reference database (struct database) driven behind its parser seam."""
+
+    def __init__(self):
+        self.L = _lib()
+        self.h = self.L.ref_open()
+        if not self.h:
+            raise RefError("ref_open failed")
+
+    def close(self):
+        if self.h:
+            self.L.ref_close(self.h)
+            self.h = None
+
+    def exec_rpn(self, rpn):
+        rc = self.L.ref_exec_rpn(self.h, rpn.encode())
+        if rc < 0:
+            raise RefError(self.L.ref_error(self.h).decode().strip())
+        return rc
+
+    def execute(self, sql):
+        """DDL/DML -> 0, SELECT -> 1 (result then available through fetch())."""
+        return self.exec_rpn(sql_to_rpn(sql))
+
+    def create_int_table(self, name, cols):
+        self.execute(f"CREATE TABLE {name} ({', '.join(c + ' INT' for c in cols)});")
+
+    def bulk_insert(self, table, cols, nulls=None):
+        """cols: list of 8-byte arrays (int64 or float64), column-major; nulls: list of bool arrays or None."""
+        ncols = len(cols)
+        n = len(cols[0]) if ncols else 0
+        vals = np.ascontiguousarray(np.stack([np.asarray(c).view(np.int64) if np.asarray(c).dtype == np.float64
+                                              else np.asarray(c, dtype=np.int64) for c in cols]))
+        nl = None
+        if nulls is not None and any(x is not None for x in nulls):
+            nl = np.ascontiguousarray(np.stack([np.zeros(n, dtype=np.uint8) if x is None else np.asarray(x, dtype=np.uint8)
+                                                for x in nulls]))
+        rc = self.L.ref_bulk_insert(self.h, table.encode(), ncols, n, vals.ctypes.data_as(ctypes.c_void_p),
+                                    nl.ctypes.data_as(ctypes.c_void_p) if nl is not None else None)
+        if rc != 0:
+            raise RefError(f"ref_bulk_insert({table}) failed: {rc}")
+
+    def fetch(self):
+        """-> (column names in physical order, values int64 [nrows, ncols], nulls bool [nrows, ncols])."""
+        nc = self.L.ref_result_ncols(self.h)
+        if nc < 0:
+            raise RefError("no result")
+        names = [self.L.ref_result_colname(self.h, i).decode() for i in range(nc)]
+        n = self.L.ref_result_fetch(self.h, None, None, 0)
+        vals = np.zeros((max(n, 1), max(nc, 1)), dtype=np.int64)
+        nulls = np.zeros((max(n, 1), max(nc, 1)), dtype=np.uint8)
+        if n:
+            self.L.ref_result_fetch(self.h, vals.ctypes.data_as(ctypes.c_void_p), nulls.ctypes.data_as(ctypes.c_void_p), n)
+        return names, vals[:n, :nc], nulls[:n, :nc].astype(bool)
+
+    def query(self, sql):
+        rc = self.execute(sql)
+        if rc != 1:
+            raise RefError("not a SELECT")
+        names, vals, nulls = self.fetch()
+        return names, [tuple(None if nulls[i, k] else int(vals[i, k]) for k in range(len(names))) for i in range(len(vals))]
+
+    def table_rows(self, name):
+        return int(self.L.ref_table_rows(self.h, name.encode()))
