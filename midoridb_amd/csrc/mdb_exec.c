@@ -1,0 +1,1038 @@
+/*
+ * mdb_exec.c - the SELECT executor: lowers a statement plan onto the device C-ABI (mdb_dev.h).
+ *
+ * This file is the MI355X replacement of executor_run_select_stmt() (reference
+ * src/engine/executor_select.c:1655-1744) and keeps its phase order:
+ *
+ *   reference phase (file:line)                        here
+ *   -------------------------------------------------  --------------------------------------------
+ *   build_cols_hashtable/build_table_scafold :267-322  result column set + order (R3), host only
+ *   proc_from_clause_table :1282-1343 (scan)           tuple stream = identity row ids (no copy)
+ *   _join_nested_loop_tbl2tbl :1076-1149               mdb_dev_join_pairs (+ residual ON filter)
+ *   _join_nested_loop_tbl2mat :1151-1232 (3-way)       the same operator applied to the joined
+ *                                                      stream (true (A x B) x C; the reference's
+ *                                                      own tbl2mat is defective)
+ *   proc_where_clause :1435-1463                       mdb_dev_filter over the stream
+ *   proc_groupby_clause :1526-1588                     mdb_dev_group_count over the gathered key
+ *   proc_select_clause :1369-1433 (projection)         mdb_dev_gather64 of the selected columns only
+ *   handle_countonly_case :1590-1653                   COUNT(*) = stream length
+ *   table_vacuum :1726                                 nothing to do (streams are always compact)
+ *
+ * plus one fused plan for the north-star shape (JOIN ... ON l = r GROUP BY that key, COUNT(*)),
+ * which never materialises the joined rows (mdb_dev_join_group_count).
+ *
+ * Early materialisation is replaced by late materialisation: a tuple stream is a set of uint32
+ * row-id vectors (one per FROM table; NULL = identity), so joins / filters / grouping move 4-byte
+ * ids and only the selected columns are gathered once at the end.
+ *
+ * The plan normalisation the reference does in its optimiser (optimiser_select.c:114-238: NAME ->
+ * fully qualified FIELDNAME, alias -> table name, SELECT * expansion) and the checks of its
+ * semantic phase that guard the executor (semantic_select.c: unknown table/column, duplicate
+ * column names across FROM tables S1, operand types S2, GROUP BY rule S4) happen in
+ * resolve_select() below.
+ */
+#include "mdb_host.h"
+#include <time.h>
+
+#define ERR(...) snprintf(err, errlen, __VA_ARGS__)
+
+/* ------------------------------------------------------------------ CREATE / INSERT (host storage) */
+
+int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, size_t errlen)
+{
+	struct mdb_table *t;
+
+	if (mdb_catalog_find(cat, c->name)) {
+		if (c->if_not_exists)
+			return MIDORIDB_OK;
+		ERR("table '%s' already exists\n", c->name);
+		return -MIDORIDB_ERROR;
+	}
+	for (int i = 0; i < c->ncols; i++) {
+		if (c->coltype[i] != MDB_CT_INTEGER && c->coltype[i] != MDB_CT_DOUBLE) {
+			ERR("column '%s': only INT/INTEGER and DOUBLE columns are supported by the MI355X path\n", c->colname[i]);
+			return -MIDORIDB_ERROR;
+		}
+		for (int k = 0; k < i; k++)
+			if (strcmp(c->colname[i], c->colname[k]) == 0) {
+				ERR("duplicate column name: '%s'\n", c->colname[i]);
+				return -MIDORIDB_ERROR;
+			}
+	}
+	t = mdb_table_new(c->name);
+	if (!t)
+		return -MIDORIDB_NOMEM;
+	for (int i = 0; i < c->ncols; i++)
+		mdb_table_add_column(t, c->colname[i], c->coltype[i]);
+	return mdb_catalog_add(cat, t);
+}
+
+int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_rows_aff, char *err, size_t errlen)
+{
+	struct mdb_table *t = mdb_catalog_find(cat, ins->name);
+	int map[MDB_MAX_COLS];
+	int rc;
+
+	if (!t) {
+		ERR("table '%s' doesn't exist\n", ins->name);
+		return -MIDORIDB_ERROR;
+	}
+	if (t->device_only) {
+		ERR("table '%s' was generated on the device and is read-only\n", ins->name);
+		return -MIDORIDB_ERROR;
+	}
+	for (int c = 0; c < t->ncols; c++)
+		map[c] = -1;
+	if (ins->ncolnames) {
+		if (ins->ncolnames != ins->nvals) {
+			ERR("column count doesn't match value count\n");
+			return -MIDORIDB_ERROR;
+		}
+		for (int k = 0; k < ins->ncolnames; k++) {
+			int found = -1;
+			for (int c = 0; c < t->ncols; c++)
+				if (strcmp(t->cols[c].name, ins->colname[k]) == 0)
+					found = c;
+			if (found < 0) {
+				ERR("no such column: '%.128s'\n", ins->colname[k]);
+				return -MIDORIDB_ERROR;
+			}
+			map[found] = k;
+		}
+	} else {
+		if (ins->nvals != t->ncols) {
+			ERR("column count doesn't match value count\n");
+			return -MIDORIDB_ERROR;
+		}
+		for (int c = 0; c < t->ncols; c++)
+			map[c] = c;
+	}
+	rc = mdb_table_reserve(t, t->nrows + (uint64_t)ins->ntuples);
+	if (rc)
+		return rc;
+	/* validate everything before touching the table */
+	for (int r = 0; r < ins->ntuples; r++)
+		for (int c = 0; c < t->ncols; c++) {
+			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
+			if (!v || v->kind == MDB_EX_NULL)
+				continue;
+			if (t->cols[c].type == MDB_CT_INTEGER && v->kind != MDB_EX_INT) {
+				ERR("val requires an INTEGER column\n");
+				return -MIDORIDB_ERROR;
+			}
+			if (t->cols[c].type == MDB_CT_DOUBLE && v->kind != MDB_EX_FLOAT) {
+				ERR("val requires a DOUBLE column\n");
+				return -MIDORIDB_ERROR;
+			}
+		}
+	for (int r = 0; r < ins->ntuples; r++) {
+		const uint64_t row = t->nrows;
+		for (int c = 0; c < t->ncols; c++) {
+			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
+			struct mdb_column *col = &t->cols[c];
+			if (!v || v->kind == MDB_EX_NULL) {
+				col->data[row] = 0;
+				col->nullbits[row >> 6] |= 1ull << (row & 63);
+				col->null_count++;
+			} else if (col->type == MDB_CT_INTEGER) {
+				col->data[row] = v->ival;
+				col->nullbits[row >> 6] &= ~(1ull << (row & 63));
+			} else {
+				memcpy(&col->data[row], &v->dval, 8);
+				col->nullbits[row >> 6] &= ~(1ull << (row & 63));
+			}
+		}
+		t->nrows++;
+	}
+	t->generation++;
+	*n_rows_aff = (size_t)ins->ntuples;
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ plan resolution */
+
+static bool field_eq(const struct mdb_expr *a, const struct mdb_expr *b)
+{
+	return a->kind == MDB_EX_FIELD && b->kind == MDB_EX_FIELD && a->tbl_idx == b->tbl_idx && a->col_idx == b->col_idx;
+}
+
+static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, size_t errlen)
+{
+	int rc;
+
+	if (!e)
+		return MIDORIDB_OK;
+	if (e->kind == MDB_EX_NAME) {
+		int ft = -1, fc = -1, hits = 0;
+		for (int t = 0; t < s->ntabs; t++)
+			for (int c = 0; c < s->tabs[t].t->ncols; c++)
+				if (strcmp(s->tabs[t].t->cols[c].name, e->col) == 0) {
+					ft = t;
+					fc = c;
+					hits++;
+				}
+		if (hits == 0) {
+			ERR("no such column: '%.128s'\n", e->col);
+			return -MIDORIDB_ERROR;
+		}
+		if (hits > 1) {
+			ERR("ambiguous column name: '%.128s'\n", e->col);
+			return -MIDORIDB_ERROR;
+		}
+		e->kind = MDB_EX_FIELD;
+		e->tbl_idx = ft;
+		e->col_idx = fc;
+		strncpy(e->tbl, s->tabs[ft].t->name, MDB_NAME_LEN - 1);
+	} else if (e->kind == MDB_EX_FIELD) {
+		int ft = -1;
+		for (int t = 0; t < s->ntabs; t++)
+			if (strcmp(s->tabs[t].alias, e->tbl) == 0 || (!s->tabs[t].alias[0] && strcmp(s->tabs[t].name, e->tbl) == 0) ||
+			    strcmp(s->tabs[t].name, e->tbl) == 0)
+				ft = t;
+		if (ft < 0) {
+			ERR("table is not part of from clause: '%.128s'\n", e->tbl);
+			return -MIDORIDB_ERROR;
+		}
+		e->tbl_idx = ft;
+		e->col_idx = -1;
+		for (int c = 0; c < s->tabs[ft].t->ncols; c++)
+			if (strcmp(s->tabs[ft].t->cols[c].name, e->col) == 0)
+				e->col_idx = c;
+		if (e->col_idx < 0) {
+			ERR("no such column: '%.128s'.'%.128s'\n", e->tbl, e->col);
+			return -MIDORIDB_ERROR;
+		}
+		strncpy(e->tbl, s->tabs[ft].t->name, MDB_NAME_LEN - 1);	/* alias -> real table name */
+	}
+	if (e->kind == MDB_EX_FIELD) {
+		e->type = s->tabs[e->tbl_idx].t->cols[e->col_idx].type;
+		if (e->type != MDB_CT_INTEGER && e->type != MDB_CT_DOUBLE) {
+			ERR("column '%s.%s': type not supported by the MI355X path\n", e->tbl, e->col);
+			return -MIDORIDB_ERROR;
+		}
+	}
+	for (int i = 0; i < e->nkids; i++)
+		if ((rc = resolve_expr(s, e->kids[i], err, errlen)))
+			return rc;
+	return MIDORIDB_OK;
+}
+
+/* predicate shape check (what the device predicate compiler accepts) */
+static int check_predicate(const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
+{
+	int rc;
+	switch (e->kind) {
+	case MDB_EX_LOGOP:
+		if ((rc = check_predicate(e->kids[0], clause, err, errlen)) || (rc = check_predicate(e->kids[1], clause, err, errlen)))
+			return rc;
+		return MIDORIDB_OK;
+	case MDB_EX_CMP: {
+		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
+		for (int i = 0; i < 2; i++) {
+			const struct mdb_expr *o = e->kids[i];
+			if (o->kind != MDB_EX_FIELD && o->kind != MDB_EX_INT && o->kind != MDB_EX_FLOAT && o->kind != MDB_EX_NULL) {
+				ERR("expressions in %s clause must compare columns with INT/DOUBLE/NULL values\n", clause);
+				return -MIDORIDB_ERROR;
+			}
+		}
+		/* operand types must match exactly (reference check_value_types_cmp, semantic_select.c:2135-2186) */
+		{
+			int tl = l->kind == MDB_EX_FIELD ? l->type : (l->kind == MDB_EX_INT ? MDB_CT_INTEGER : (l->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
+			int tr = r->kind == MDB_EX_FIELD ? r->type : (r->kind == MDB_EX_INT ? MDB_CT_INTEGER : (r->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
+			if (tl >= 0 && tr >= 0 && tl != tr) {
+				ERR("comparison operands must have the same type\n");
+				return -MIDORIDB_ERROR;
+			}
+			if ((l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL) && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
+				ERR("NULL values can only use '=' or '<>' ops\n");
+				return -MIDORIDB_ERROR;
+			}
+		}
+		return MIDORIDB_OK;
+	}
+	case MDB_EX_ISNULL:
+		if (e->kids[0]->kind != MDB_EX_FIELD) {
+			ERR("only fields are allowed in IS NULL|IS NOT NULL\n");
+			return -MIDORIDB_ERROR;
+		}
+		return MIDORIDB_OK;
+	case MDB_EX_ISIN:
+		if (e->kids[0]->kind != MDB_EX_FIELD) {
+			ERR("Fields aren't allowed on IN-clauses\n");
+			return -MIDORIDB_ERROR;
+		}
+		for (int i = 1; i < e->nkids; i++) {
+			const struct mdb_expr *v = e->kids[i];
+			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL) {
+				ERR("IN-clause can only contain raw values\n");
+				return -MIDORIDB_ERROR;
+			}
+			if ((v->kind == MDB_EX_INT && e->kids[0]->type != MDB_CT_INTEGER) ||
+			    (v->kind == MDB_EX_FLOAT && e->kids[0]->type != MDB_CT_DOUBLE)) {
+				ERR("comparison operands must have the same type\n");
+				return -MIDORIDB_ERROR;
+			}
+		}
+		return MIDORIDB_OK;
+	case MDB_EX_COUNT:
+		ERR("COUNT function can't be used in the %s-clause\n", clause);
+		return -MIDORIDB_ERROR;
+	default:
+		ERR("expressions in %s clause must be a type of comparison\n", clause);
+		return -MIDORIDB_ERROR;
+	}
+}
+
+static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, size_t errlen)
+{
+	int rc;
+
+	if (s->ntabs == 0) {
+		ERR("SELECT without FROM is not supported by the MI355X path\n");
+		return -MIDORIDB_ERROR;
+	}
+	for (int t = 0; t < s->ntabs; t++) {
+		s->tabs[t].t = mdb_catalog_find(cat, s->tabs[t].name);
+		if (!s->tabs[t].t) {
+			ERR("table doesn't exist: '%.128s'\n", s->tabs[t].name);
+			return -MIDORIDB_ERROR;
+		}
+		for (int u = 0; u < t; u++) {
+			const char *a = s->tabs[t].alias[0] ? s->tabs[t].alias : s->tabs[t].name;
+			const char *b = s->tabs[u].alias[0] ? s->tabs[u].alias : s->tabs[u].name;
+			if (strcmp(a, b) == 0) {
+				ERR("Not unique table/alias: '%.128s'\n", a);
+				return -MIDORIDB_ERROR;
+			}
+			/* S1: bare column names must be unique across all FROM tables (semantic_select.c:2470-2478) */
+			for (int c = 0; c < s->tabs[t].t->ncols; c++)
+				for (int d = 0; d < s->tabs[u].t->ncols; d++)
+					if (strcmp(s->tabs[t].t->cols[c].name, s->tabs[u].t->cols[d].name) == 0) {
+						ERR("duplicate column name: '%s'\n", s->tabs[t].t->cols[c].name);
+						return -MIDORIDB_ERROR;
+					}
+		}
+		if (s->join_type[t] != 1) {
+			ERR("only INNER JOIN is executed (the reference aborts on other join types, executor_select.c:1094)\n");
+			return -MIDORIDB_ERROR;
+		}
+	}
+	/* clauses that parse but are never executed by the reference: refuse loudly */
+	if (s->distinct || s->has_having || s->has_orderby || s->has_limit) {
+		ERR("DISTINCT / HAVING / ORDER BY / LIMIT are not executed by the reference executor and are rejected here\n");
+		return -MIDORIDB_ERROR;
+	}
+	for (int i = 0; i < s->nsel; i++) {
+		struct mdb_expr *e = s->sel[i];
+		if (e->kind == MDB_EX_COUNT) {
+			for (int k = 0; k < e->nkids; k++)
+				if ((rc = resolve_expr(s, e->kids[k], err, errlen)))
+					return rc;
+			continue;
+		}
+		if (e->kind != MDB_EX_NAME && e->kind != MDB_EX_FIELD) {
+			ERR("only columns and COUNT(*) are supported in the select list (aliases and expressions are not executed by the reference)\n");
+			return -MIDORIDB_ERROR;
+		}
+		if ((rc = resolve_expr(s, e, err, errlen)))
+			return rc;
+	}
+	for (int t = 1; t < s->ntabs; t++)
+		if (s->on[t]) {
+			if ((rc = resolve_expr(s, s->on[t], err, errlen)) || (rc = check_predicate(s->on[t], "JOIN ON", err, errlen)))
+				return rc;
+		}
+	if (s->where && ((rc = resolve_expr(s, s->where, err, errlen)) || (rc = check_predicate(s->where, "where", err, errlen))))
+		return rc;
+	if (s->ngroup > 1) {
+		ERR("GROUP BY over more than one field is outside the reference's well-defined domain (SURVEY 8a R10) and not supported\n");
+		return -MIDORIDB_ERROR;
+	}
+	for (int i = 0; i < s->ngroup; i++) {
+		if (s->group[i]->kind != MDB_EX_NAME && s->group[i]->kind != MDB_EX_FIELD) {
+			ERR("group-by clauses support only fields and aliases\n");
+			return -MIDORIDB_ERROR;
+		}
+		if ((rc = resolve_expr(s, s->group[i], err, errlen)))
+			return rc;
+	}
+	/* S4: with GROUP BY or COUNT, every plain select field must be a GROUP BY field */
+	{
+		int ncount = 0, nfield = 0;
+		for (int i = 0; i < s->nsel; i++) {
+			if (s->sel[i]->kind == MDB_EX_COUNT) {
+				ncount++;
+				continue;
+			}
+			nfield++;
+			if (s->ngroup) {
+				bool ok = false;
+				for (int g = 0; g < s->ngroup; g++)
+					ok |= field_eq(s->sel[i], s->group[g]);
+				if (!ok) {
+					ERR("SELECT list is not in GROUP BY clause: '%.128s'.'%.128s'\n", s->sel[i]->tbl, s->sel[i]->col);
+					return -MIDORIDB_ERROR;
+				}
+			}
+		}
+		if (s->select_all && (s->ngroup || ncount)) {
+			ERR("SELECT * can't be combined with GROUP BY / COUNT\n");
+			return -MIDORIDB_ERROR;
+		}
+		if (ncount && nfield && !s->ngroup) {
+			ERR("mixing fields and COUNT in the select list requires a GROUP BY clause\n");
+			return -MIDORIDB_ERROR;
+		}
+	}
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ device-side execution state */
+
+struct dbuf_list {
+	void **p;
+	int n, cap;
+};
+
+struct exec {
+	struct mdb_catalog *cat;
+	mdb_dev_ctx *dev;
+	struct mdb_select *s;
+	char *err;
+	size_t errlen;
+	struct dbuf_list bufs;
+	uint32_t *rid[MDB_MAX_COLS];	/* per FROM table: row-id vector of the current stream or NULL = identity */
+	bool have_stream;		/* false until the first table is in the stream */
+	uint64_t n;			/* stream length */
+	int64_t *d_count;		/* COUNT(*) column of the stream (after GROUP BY), device */
+	uint64_t joined_rows;
+};
+
+static int dev_fail(struct exec *x, const char *what)
+{
+	snprintf(x->err, x->errlen, "execution phase: %s: %s\n", what, mdb_dev_last_error(x->dev));
+	return -MIDORIDB_INTERNAL;
+}
+
+static int track(struct exec *x, void *p)
+{
+	if (x->bufs.n == x->bufs.cap) {
+		int nc = x->bufs.cap ? x->bufs.cap * 2 : 32;
+		void **np = realloc(x->bufs.p, sizeof(void *) * (size_t)nc);
+		if (!np)
+			return -MIDORIDB_NOMEM;
+		x->bufs.p = np;
+		x->bufs.cap = nc;
+	}
+	x->bufs.p[x->bufs.n++] = p;
+	return 0;
+}
+
+static void *dalloc(struct exec *x, size_t bytes)
+{
+	void *p = NULL;
+	if (mdb_dev_alloc(x->dev, bytes ? bytes : 8, &p))
+		return NULL;
+	if (track(x, p)) {
+		mdb_dev_free(x->dev, p);
+		return NULL;
+	}
+	return p;
+}
+
+static void free_all(struct exec *x)
+{
+	for (int i = 0; i < x->bufs.n; i++)
+		mdb_dev_free(x->dev, x->bufs.p[i]);
+	free(x->bufs.p);
+	x->bufs.p = NULL;
+	x->bufs.n = x->bufs.cap = 0;
+}
+
+/* Re-map every row-id vector of the stream through `sel` (n_new positions into the old stream). */
+static int stream_select(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
+{
+	for (int t = 0; t < ntabs_in_stream; t++) {
+		if (x->rid[t]) {
+			uint32_t *nr = dalloc(x, n_new * 4);
+			if (!nr)
+				return dev_fail(x, "allocating row ids");
+			if (n_new && mdb_dev_gather32(x->dev, x->rid[t], sel, n_new, nr))
+				return dev_fail(x, "re-mapping row ids");
+			x->rid[t] = nr;
+		} else {
+			x->rid[t] = (uint32_t *)sel;	/* identity composed with sel */
+		}
+	}
+	x->n = n_new;
+	return MIDORIDB_OK;
+}
+
+/* device pointer to a column's key/value vector for the current stream (gathered when needed) */
+static int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t **vals, const uint64_t **nulls)
+{
+	struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
+	*vals = col->d_data;
+	*nulls = col->d_nullbits;
+	if (x->rid[f->tbl_idx] && x->n) {
+		int64_t *v = dalloc(x, x->n * 8);
+		uint64_t *nb = col->d_nullbits ? dalloc(x, ((x->n + 63) / 64) * 8) : NULL;
+		if (!v || (col->d_nullbits && !nb))
+			return dev_fail(x, "allocating a key column");
+		if (mdb_dev_gather64(x->dev, col->d_data, col->d_nullbits, x->rid[f->tbl_idx], x->n, v, nb))
+			return dev_fail(x, "gathering a key column");
+		*vals = v;
+		*nulls = nb;
+	}
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ predicate compiler */
+
+struct pred_prog {
+	struct mdb_pred_insn insn[MDB_PRED_MAX_INSNS];
+	int n;
+	struct mdb_col_binding cols[MDB_PRED_MAX_SLOTS];
+	int slot_tbl[MDB_PRED_MAX_SLOTS], slot_col[MDB_PRED_MAX_SLOTS];
+	int ncols;
+};
+
+static int pred_slot(struct exec *x, struct pred_prog *p, const struct mdb_expr *f)
+{
+	struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
+	for (int i = 0; i < p->ncols; i++)
+		if (p->slot_tbl[i] == f->tbl_idx && p->slot_col[i] == f->col_idx)
+			return i;
+	if (p->ncols == MDB_PRED_MAX_SLOTS)
+		return -1;
+	p->slot_tbl[p->ncols] = f->tbl_idx;
+	p->slot_col[p->ncols] = f->col_idx;
+	p->cols[p->ncols].values = col->d_data;
+	p->cols[p->ncols].nullbits = col->d_nullbits;
+	p->cols[p->ncols].rid = x->rid[f->tbl_idx];
+	return p->ncols++;
+}
+
+static int pred_emit(struct pred_prog *p, int op, int cmp, int type, int a, int b, int64_t imm)
+{
+	struct mdb_pred_insn *in;
+	if (p->n == MDB_PRED_MAX_INSNS)
+		return -1;
+	in = &p->insn[p->n++];
+	memset(in, 0, sizeof(*in));
+	in->op = op;
+	in->cmp = cmp;
+	in->type = type;
+	in->a = a;
+	in->b = b;
+	in->imm = imm;
+	return 0;
+}
+
+static int64_t lit_bits(const struct mdb_expr *v)
+{
+	int64_t bits;
+	if (v->kind == MDB_EX_FLOAT) {
+		memcpy(&bits, &v->dval, 8);
+		return bits;
+	}
+	return v->ival;
+}
+
+static bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
+{
+	if (l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL)
+		return false;			/* executor_select.c:660-662 */
+	if (l->kind == MDB_EX_FLOAT) {
+		double a = l->dval, b = r->dval;
+		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
+	} else {
+		int64_t a = l->ival, b = r->ival;
+		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
+	}
+}
+
+static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_expr *e)
+{
+	int rc = 0, a, b;
+
+	switch (e->kind) {
+	case MDB_EX_LOGOP:
+		if ((rc = pred_compile(x, p, e->kids[0])) || (rc = pred_compile(x, p, e->kids[1])))
+			return rc;
+		return pred_emit(p, e->op == 0 ? MDB_P_AND : (e->op == 1 ? MDB_P_OR : MDB_P_XOR), 0, 0, 0, 0, 0);
+	case MDB_EX_CMP: {
+		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
+		if (l->kind == MDB_EX_FIELD && r->kind == MDB_EX_FIELD) {
+			a = pred_slot(x, p, l);
+			b = pred_slot(x, p, r);
+			if (a < 0 || b < 0)
+				return -1;
+			return pred_emit(p, MDB_P_CMP_COL_COL, e->op, l->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, b, 0);
+		}
+		if (l->kind == MDB_EX_FIELD || r->kind == MDB_EX_FIELD) {
+			const struct mdb_expr *f = l->kind == MDB_EX_FIELD ? l : r, *v = l->kind == MDB_EX_FIELD ? r : l;
+			if (v->kind == MDB_EX_NULL)	/* NULL operand: never true (executor_select.c:793-795) */
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			a = pred_slot(x, p, f);
+			if (a < 0)
+				return -1;
+			return pred_emit(p, l->kind == MDB_EX_FIELD ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
+					 f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
+		}
+		return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, const_cmp(e->op, l, r));
+	}
+	case MDB_EX_ISNULL:
+		a = pred_slot(x, p, e->kids[0]);
+		if (a < 0)
+			return -1;
+		return pred_emit(p, MDB_P_ISNULL, e->op ? 1 : 0, 0, a, 0, 0);
+	case MDB_EX_ISIN: {
+		/* x IN (v1..vk)  = (x = v1) OR ... OR (x = vk)   - SQL semantics; the reference's
+		 *                  conjunction (eval_isxin :1013-1021) is defect D3, identical for k = 1
+		 * x NOT IN (...) = (x <> v1) AND ... AND (x <> vk) - same as the reference */
+		const struct mdb_expr *f = e->kids[0];
+		a = pred_slot(x, p, f);
+		if (a < 0)
+			return -1;
+		for (int i = 1; i < e->nkids; i++) {
+			const struct mdb_expr *v = e->kids[i];
+			if (v->kind == MDB_EX_NULL)
+				rc = pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			else
+				rc = pred_emit(p, MDB_P_CMP_COL_CONST, e->op ? MDB_CMP_NE : MDB_CMP_EQ,
+					       f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
+			if (rc)
+				return rc;
+			if (i > 1 && (rc = pred_emit(p, e->op ? MDB_P_AND : MDB_P_OR, 0, 0, 0, 0, 0)))
+				return rc;
+		}
+		return 0;
+	}
+	default:
+		return -1;
+	}
+}
+
+/* filter the current stream (tables 0..ntabs-1) by predicate e */
+static int stream_filter(struct exec *x, int ntabs_in_stream, const struct mdb_expr *e)
+{
+	struct pred_prog p;
+	uint32_t *sel;
+	uint64_t m = 0;
+
+	if (x->n == 0)
+		return MIDORIDB_OK;
+	memset(&p, 0, sizeof(p));
+	if (pred_compile(x, &p, e)) {
+		snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
+			 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
+		return -MIDORIDB_ERROR;
+	}
+	sel = dalloc(x, x->n * 4);
+	if (!sel)
+		return dev_fail(x, "allocating the selection vector");
+	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, x->n, sel, &m))
+		return dev_fail(x, "filter");
+	return stream_select(x, ntabs_in_stream, sel, m);
+}
+
+/* ------------------------------------------------------------------ FROM clause */
+
+/* split an ON expression into conjuncts; pick the first "left-stream field = field of table t" as the hash key */
+static void collect_conjuncts(struct mdb_expr *e, struct mdb_expr **out, int *n, int cap)
+{
+	if (e->kind == MDB_EX_LOGOP && e->op == 0) {
+		collect_conjuncts(e->kids[0], out, n, cap);
+		collect_conjuncts(e->kids[1], out, n, cap);
+	} else if (*n < cap) {
+		out[(*n)++] = e;
+	} else {
+		*n = cap + 1;	/* overflow marker */
+	}
+}
+
+static int join_next_table(struct exec *x, int t)
+{
+	struct mdb_select *s = x->s;
+	struct mdb_table *rt = s->tabs[t].t;
+	struct mdb_expr *conj[32];
+	int nconj = 0, key = -1;
+	const struct mdb_expr *kl = NULL, *kr = NULL;
+	uint32_t *pl = NULL, *pr = NULL;
+	uint64_t J = 0;
+	int rc;
+
+	if (s->on[t]) {
+		collect_conjuncts(s->on[t], conj, &nconj, 32);
+		if (nconj > 32)
+			nconj = 0;	/* too many conjuncts: treat the whole ON as a residual predicate */
+		for (int i = 0; i < nconj && key < 0; i++) {
+			struct mdb_expr *c = conj[i];
+			if (c->kind == MDB_EX_CMP && c->op == MDB_CMP_EQ && c->kids[0]->kind == MDB_EX_FIELD && c->kids[1]->kind == MDB_EX_FIELD) {
+				struct mdb_expr *a = c->kids[0], *b = c->kids[1];
+				if (a->tbl_idx < t && b->tbl_idx == t) {
+					kl = a;
+					kr = b;
+					key = i;
+				} else if (b->tbl_idx < t && a->tbl_idx == t) {
+					kl = b;
+					kr = a;
+					key = i;
+				}
+			}
+		}
+	}
+	if (key >= 0) {
+		const int64_t *vl;
+		const uint64_t *nl;
+		struct mdb_column *rc_col = &rt->cols[kr->col_idx];
+		if ((rc = stream_column(x, kl, &vl, &nl)))
+			return rc;
+		if (x->n && rt->nrows) {
+			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, rc_col->d_data, rc_col->d_nullbits, rt->nrows, &pl, &pr, &J))
+				return dev_fail(x, "hash join");
+			if (pl && track(x, pl))
+				return -MIDORIDB_NOMEM;
+			if (pr && track(x, pr))
+				return -MIDORIDB_NOMEM;
+		}
+	} else {
+		/* no equi-join key: FROM A, B (ON 1=1) or a general ON -> all pairs, then the ON predicate */
+		const uint64_t total = x->n * rt->nrows;
+		if (total > (1ull << 28)) {
+			snprintf(x->err, x->errlen, "execution phase: cross join of %llu x %llu rows is too large (no equi-join key in the ON clause)\n",
+				 (unsigned long long)x->n, (unsigned long long)rt->nrows);
+			return -MIDORIDB_ERROR;
+		}
+		J = total;
+		if (J) {
+			pl = dalloc(x, J * 4);
+			pr = dalloc(x, J * 4);
+			if (!pl || !pr)
+				return dev_fail(x, "allocating join pairs");
+			if (mdb_dev_cross_pairs(x->dev, x->n, rt->nrows, pl, pr))
+				return dev_fail(x, "cross join");
+		}
+	}
+	/* compose the stream: earlier tables through pl, the new table = pr */
+	if ((rc = stream_select(x, t, pl, J)))
+		return rc;
+	x->rid[t] = pr;
+	x->joined_rows = J;
+	/* residual ON conjuncts (everything except the hash key), evaluated on the merged tuples */
+	if (s->on[t]) {
+		if (key < 0) {
+			if ((rc = stream_filter(x, t + 1, s->on[t])))
+				return rc;
+		} else {
+			for (int i = 0; i < nconj; i++)
+				if (i != key && (rc = stream_filter(x, t + 1, conj[i])))
+					return rc;
+		}
+		x->joined_rows = x->n;
+	}
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ result assembly */
+
+void mdb_result_free(struct mdb_result *r)
+{
+	if (!r)
+		return;
+	for (int c = 0; c < r->ncols; c++) {
+		if (r->data)
+			free(r->data[c]);
+		if (r->nullbits)
+			free(r->nullbits[c]);
+	}
+	free(r->data);
+	free(r->nullbits);
+	free(r->colname);
+	free(r->coltype);
+	free(r);
+}
+
+static double now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+/* is the plan the fused north-star shape?  returns the group field's side (0 = left key, 1 = right key) or -1 */
+static int fused_shape(struct mdb_select *s, const struct mdb_expr **kl, const struct mdb_expr **kr)
+{
+	struct mdb_expr *on;
+	if (s->ntabs != 2 || s->where || s->ngroup != 1 || !s->on[1])
+		return -1;
+	on = s->on[1];
+	if (on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
+		return -1;
+	if (on->kids[0]->tbl_idx == 0 && on->kids[1]->tbl_idx == 1) {
+		*kl = on->kids[0];
+		*kr = on->kids[1];
+	} else if (on->kids[0]->tbl_idx == 1 && on->kids[1]->tbl_idx == 0) {
+		*kl = on->kids[1];
+		*kr = on->kids[0];
+	} else {
+		return -1;
+	}
+	if ((*kl)->type != (*kr)->type)
+		return -1;
+	if (field_eq(s->group[0], *kl))
+		return 0;
+	if (field_eq(s->group[0], *kr))
+		return 1;
+	return -1;
+}
+
+int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen)
+{
+	struct exec x;
+	struct mdb_result *res = NULL;
+	char (*keys)[MDB_NAME_LEN] = NULL;
+	int *order = NULL, *key_tbl = NULL, *key_col = NULL;
+	int nkeys = 0, rc, has_count = 0;
+	double t0;
+	const struct mdb_expr *fkl = NULL, *fkr = NULL;
+	int fused;
+	int64_t *d_fused_key = NULL;
+
+	*out = NULL;
+	memset(&x, 0, sizeof(x));
+	if ((rc = resolve_select(cat, s, err, errlen)))
+		return rc;
+	if ((rc = mdb_catalog_device(cat, err, errlen)))
+		return rc;
+	for (int t = 0; t < s->ntabs; t++)
+		if ((rc = mdb_table_sync_device(cat, s->tabs[t].t, err, errlen)))
+			return rc;
+	x.cat = cat;
+	x.dev = cat->dev;
+	x.s = s;
+	x.err = err;
+	x.errlen = errlen;
+
+	/* ---- result column set in the reference's order (R3): COUNT(*) first if selected, then every column
+	 *      of every FROM table left to right; projected afterwards to the select list */
+	for (int i = 0; i < s->nsel; i++)
+		has_count |= s->sel[i]->kind == MDB_EX_COUNT;
+	{
+		int total = has_count;
+		for (int t = 0; t < s->ntabs; t++)
+			total += s->tabs[t].t->ncols;
+		keys = calloc((size_t)total, sizeof(*keys));
+		order = calloc((size_t)total, sizeof(int));
+		key_tbl = calloc((size_t)total, sizeof(int));
+		key_col = calloc((size_t)total, sizeof(int));
+		if (!keys || !order || !key_tbl || !key_col) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		if (has_count) {
+			strcpy(keys[nkeys], "COUNT(*)");
+			key_tbl[nkeys] = -1;
+			nkeys++;
+		}
+		for (int t = 0; t < s->ntabs; t++)
+			for (int c = 0; c < s->tabs[t].t->ncols; c++) {
+				snprintf(keys[nkeys], MDB_NAME_LEN, "%.60s.%.60s", s->tabs[t].t->name, s->tabs[t].t->cols[c].name);
+				key_tbl[nkeys] = t;
+				key_col[nkeys] = c;
+				nkeys++;
+			}
+		if ((rc = mdb_reference_column_order((const char (*)[MDB_NAME_LEN])keys, nkeys, order)))
+			goto out;
+	}
+
+	t0 = now_ms();
+	fused = fused_shape(s, &fkl, &fkr);
+	if (fused >= 0) {
+		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join */
+		struct mdb_table *lt = s->tabs[0].t, *rt = s->tabs[1].t;
+		struct mdb_column *lc = &lt->cols[fkl->col_idx], *rcq = &rt->cols[fkr->col_idx];
+		uint64_t cap = lt->nrows ? lt->nrows : 1, G = 0, J = 0;
+		d_fused_key = dalloc(&x, cap * 8);
+		x.d_count = dalloc(&x, cap * 8);
+		if (!d_fused_key || !x.d_count) {
+			rc = dev_fail(&x, "allocating group outputs");
+			goto out;
+		}
+		if (mdb_dev_join_group_count(x.dev, lc->d_data, lc->d_nullbits, lt->nrows, rcq->d_data, rcq->d_nullbits, rt->nrows,
+					     MDB_ORDER_FIRST, d_fused_key, x.d_count, NULL, cap, &G, &J)) {
+			rc = dev_fail(&x, "join + group count");
+			goto out;
+		}
+		x.n = G;
+		x.joined_rows = J;
+	} else {
+		/* ---- general plan */
+		x.n = s->tabs[0].t->nrows;	/* scan: identity stream over the first table */
+		for (int t = 1; t < s->ntabs; t++)
+			if ((rc = join_next_table(&x, t)))
+				goto out;
+		if (s->where && (rc = stream_filter(&x, s->ntabs, s->where)))
+			goto out;
+		if (s->ngroup == 1) {
+			const int64_t *kv;
+			const uint64_t *kn;
+			uint32_t *first;
+			uint64_t G = 0;
+			if ((rc = stream_column(&x, s->group[0], &kv, &kn)))
+				goto out;
+			first = dalloc(&x, (x.n ? x.n : 1) * 4);
+			x.d_count = dalloc(&x, (x.n ? x.n : 1) * 8);
+			if (!first || !x.d_count) {
+				rc = dev_fail(&x, "allocating group outputs");
+				goto out;
+			}
+			if (x.n && mdb_dev_group_count(x.dev, kv, kn, x.n, MDB_ORDER_FIRST, first, x.d_count, x.n, &G)) {
+				rc = dev_fail(&x, "group count");
+				goto out;
+			}
+			if ((rc = stream_select(&x, s->ntabs, first, G)))
+				goto out;
+		}
+	}
+
+	/* ---- projection + COUNT-only handling */
+	res = calloc(1, sizeof(*res));
+	if (!res) {
+		rc = -MIDORIDB_NOMEM;
+		goto out;
+	}
+	{
+		bool count_only = has_count && !s->ngroup;	/* SELECT COUNT(*) FROM ... [WHERE ...] */
+		uint64_t out_rows = count_only ? (x.n ? 1 : 0) : x.n;	/* the reference returns no row for an empty input */
+		int ncols = 0;
+		int *src = calloc((size_t)nkeys, sizeof(int));
+		if (!src) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		for (int k = 0; k < nkeys; k++) {
+			int key = order[k];
+			bool want = false;
+			if (key_tbl[key] < 0) {
+				want = true;
+			} else if (s->select_all) {
+				want = true;
+			} else {
+				for (int i = 0; i < s->nsel; i++)
+					if (s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == key_tbl[key] &&
+					    s->sel[i]->col_idx == key_col[key])
+						want = true;
+			}
+			if (want)
+				src[ncols++] = key;
+		}
+		res->ncols = ncols;
+		res->nrows = out_rows;
+		res->colname = calloc((size_t)(ncols ? ncols : 1), sizeof(*res->colname));
+		res->coltype = calloc((size_t)(ncols ? ncols : 1), sizeof(int));
+		res->data = calloc((size_t)(ncols ? ncols : 1), sizeof(int64_t *));
+		res->nullbits = calloc((size_t)(ncols ? ncols : 1), sizeof(uint64_t *));
+		if (!res->colname || !res->coltype || !res->data || !res->nullbits) {
+			free(src);
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		for (int c = 0; c < ncols; c++) {
+			int key = src[c];
+			memcpy(res->colname[c], keys[key], MDB_NAME_LEN);
+			res->data[c] = calloc((size_t)(out_rows ? out_rows : 1), 8);
+			if (!res->data[c]) {
+				free(src);
+				rc = -MIDORIDB_NOMEM;
+				goto out;
+			}
+			if (key_tbl[key] < 0) {
+				res->coltype[c] = MDB_CT_INTEGER;
+				if (count_only) {
+					if (out_rows)
+						res->data[c][0] = (int64_t)x.n;
+				} else if (out_rows) {
+					if (!x.d_count) {	/* COUNT without aggregation cannot reach here (S4) */
+						free(src);
+						ERR("execution phase: internal error\n");
+						rc = -MIDORIDB_INTERNAL;
+						goto out;
+					}
+					if (mdb_dev_d2h(x.dev, res->data[c], x.d_count, out_rows * 8)) {
+						free(src);
+						rc = dev_fail(&x, "reading COUNT(*)");
+						goto out;
+					}
+				}
+				continue;
+			}
+			{
+				struct mdb_column *col = &s->tabs[key_tbl[key]].t->cols[key_col[key]];
+				res->coltype[c] = col->type;
+				if (!out_rows || count_only)
+					continue;
+				if (fused >= 0) {
+					/* only the group key can be selected (S4); both sides hold the same value */
+					if (mdb_dev_d2h(x.dev, res->data[c], d_fused_key, out_rows * 8)) {
+						free(src);
+						rc = dev_fail(&x, "reading the group key");
+						goto out;
+					}
+					continue;
+				}
+				{
+					const uint32_t *rid = x.rid[key_tbl[key]];
+					const void *d_vals = col->d_data;
+					const uint64_t *d_nulls = col->d_nullbits;
+					if (rid) {
+						int64_t *v = dalloc(&x, out_rows * 8);
+						uint64_t *nb = col->d_nullbits ? dalloc(&x, ((out_rows + 63) / 64) * 8) : NULL;
+						if (!v || (col->d_nullbits && !nb) ||
+						    mdb_dev_gather64(x.dev, col->d_data, col->d_nullbits, rid, out_rows, v, nb)) {
+							free(src);
+							rc = dev_fail(&x, "projection gather");
+							goto out;
+						}
+						d_vals = v;
+						d_nulls = nb;
+					}
+					if (mdb_dev_d2h(x.dev, res->data[c], d_vals, out_rows * 8)) {
+						free(src);
+						rc = dev_fail(&x, "reading a result column");
+						goto out;
+					}
+					if (d_nulls) {
+						const uint64_t words = (out_rows + 63) / 64;
+						res->nullbits[c] = calloc((size_t)words, 8);
+						if (!res->nullbits[c] || mdb_dev_d2h(x.dev, res->nullbits[c], d_nulls, words * 8)) {
+							free(src);
+							rc = dev_fail(&x, "reading NULL bits");
+							goto out;
+						}
+						/* a NULL cell reads as 0 through query_column_int64(), like the reference
+						 * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
+						for (uint64_t i = 0; i < out_rows; i++)
+							if ((res->nullbits[c][i >> 6] >> (i & 63)) & 1)
+								res->data[c][i] = 0;
+					}
+				}
+			}
+		}
+		free(src);
+	}
+	res->exec_ms = now_ms() - t0;
+	res->joined_rows = x.joined_rows;
+	*out = res;
+	res = NULL;
+	rc = MIDORIDB_OK;
+out:
+	free_all(&x);
+	mdb_result_free(res);
+	free(keys);
+	free(order);
+	free(key_tbl);
+	free(key_col);
+	return rc;
+}

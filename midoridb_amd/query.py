@@ -1,0 +1,202 @@
+"""Python mirror of the reference's query API (include/mdb_query.h) over ctypes.
+
+Names and call sequence follow the reference's own tests (reference
+tests/engine/executor_select.c:47-66): database_open -> query_execute -> while
+query_cur_step(...) == MIDORIDB_ROW: query_column_int64(...) -> query_free -> database_close.
+"""
+import ctypes
+from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+from .lib import load_library
+
+MIDORIDB_OK, MIDORIDB_ERROR, MIDORIDB_INTERNAL, MIDORIDB_NOMEM, MIDORIDB_ROW = 0, 1, 2, 3, 4
+ST_OK_WITH_RESULTS, ST_OK_EXECUTED, ST_ERROR = 0, 1, 2
+
+
+class Database(Structure):
+    # struct database { void *tables; pthread_mutex_t mutex; }  (pthread_mutex_t = 40 bytes on x86-64 glibc)
+    _fields_ = [("tables", c_void_p), ("mutex", c_char * 40)]
+
+
+class ResultSet(Structure):
+    _fields_ = [("table", c_void_p), ("cursor_blk", c_void_p), ("cursor_offset", c_size_t)]
+
+
+class QueryOutputError(Structure):
+    _fields_ = [("message", c_char * 1024)]
+
+
+class QueryOutput(Structure):
+    _fields_ = [("status", c_int), ("results", ResultSet), ("error", QueryOutputError), ("n_rows_aff", c_size_t)]
+
+
+QUERY_SYMBOLS = [
+    "database_open", "database_close", "query_execute", "query_cur_step", "query_column_int64", "query_free",
+    "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
+    "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
+    "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn",
+]
+
+
+def _bind(lib):
+    if getattr(lib, "_mdb_query_bound", False):
+        return
+    PDB, PRS, PQO = POINTER(Database), POINTER(ResultSet), POINTER(QueryOutput)
+    lib.database_open.argtypes = [PDB]
+    lib.database_open.restype = c_int
+    lib.database_close.argtypes = [PDB]
+    lib.database_close.restype = None
+    lib.query_execute.argtypes = [PDB, c_char_p]
+    lib.query_execute.restype = PQO
+    lib.mdb_query_execute_rpn.argtypes = [PDB, c_char_p]
+    lib.mdb_query_execute_rpn.restype = PQO
+    lib.query_cur_step.argtypes = [PRS]
+    lib.query_cur_step.restype = c_int
+    lib.query_column_int64.argtypes = [PRS, c_int]
+    lib.query_column_int64.restype = c_int64
+    lib.query_column_double.argtypes = [PRS, c_int]
+    lib.query_column_double.restype = c_double
+    lib.query_column_is_null.argtypes = [PRS, c_int]
+    lib.query_column_is_null.restype = ctypes.c_bool
+    lib.query_column_count.argtypes = [PRS]
+    lib.query_column_count.restype = c_int
+    lib.query_column_name.argtypes = [PRS, c_int]
+    lib.query_column_name.restype = c_char_p
+    lib.query_column_type.argtypes = [PRS, c_int]
+    lib.query_column_type.restype = c_int
+    lib.query_row_count.argtypes = [PRS]
+    lib.query_row_count.restype = c_uint64
+    lib.query_column_data.argtypes = [PRS, c_int]
+    lib.query_column_data.restype = POINTER(c_int64)
+    lib.query_exec_ms.argtypes = [PRS]
+    lib.query_exec_ms.restype = c_double
+    lib.query_joined_rows.argtypes = [PRS]
+    lib.query_joined_rows.restype = c_uint64
+    lib.query_free.argtypes = [PQO]
+    lib.query_free.restype = None
+    lib.mdb_table_append_columns.argtypes = [PDB, c_char_p, c_int, c_uint64, POINTER(c_void_p), POINTER(c_void_p)]
+    lib.mdb_table_append_columns.restype = c_int
+    lib.mdb_table_generate.argtypes = [PDB, c_char_p, c_uint64, c_uint64, POINTER(c_uint64)]
+    lib.mdb_table_generate.restype = c_int
+    lib._mdb_query_bound = True
+
+
+class QueryError(RuntimeError):
+    pass
+
+
+class Result:
+    """A finished SELECT: column names (reference order), rows as tuples of int64 (NULL cells read 0,
+    exactly what query_column_int64() returns), plus NULL flags and timings."""
+
+    def __init__(self, names, types, columns, nulls, exec_ms, joined_rows):
+        self.names = names
+        self.types = types
+        self.columns = columns
+        self.nulls = nulls
+        self.exec_ms = exec_ms
+        self.joined_rows = joined_rows
+
+    @property
+    def nrows(self):
+        return len(self.columns[0]) if self.columns else 0
+
+    def rows(self):
+        return [tuple(int(c[i]) for c in self.columns) for i in range(self.nrows)]
+
+
+class DB:
+    def __init__(self):
+        self.lib = load_library()
+        _bind(self.lib)
+        self.db = Database()
+        rc = self.lib.database_open(ctypes.byref(self.db))
+        if rc != MIDORIDB_OK:
+            raise QueryError(f"database_open failed: {rc}")
+        self._open = True
+
+    def close(self):
+        if self._open:
+            self.lib.database_close(ctypes.byref(self.db))
+            self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- statements -------------------------------------------------------------------------
+    def _run(self, out):
+        if not out:
+            raise QueryError("query_execute returned NULL")
+        status = out.contents.status
+        if status == ST_ERROR:
+            msg = out.contents.error.message.decode(errors="replace")
+            self.lib.query_free(out)
+            raise QueryError(msg.strip())
+        return out, status
+
+    def execute(self, sql):
+        """CREATE / INSERT -> rows affected."""
+        out, status = self._run(self.lib.query_execute(ctypes.byref(self.db), sql.encode()))
+        n = out.contents.n_rows_aff
+        self.lib.query_free(out)
+        return n
+
+    def query(self, sql, rpn=False, step_cursor=False):
+        """SELECT -> Result.  step_cursor=True walks the result with query_cur_step()/query_column_int64()
+        exactly like the reference's tests; otherwise whole columns are copied at once."""
+        fn = self.lib.mdb_query_execute_rpn if rpn else self.lib.query_execute
+        out, status = self._run(fn(ctypes.byref(self.db), sql.encode()))
+        if status != ST_OK_WITH_RESULTS:
+            self.lib.query_free(out)
+            raise QueryError("not a SELECT")
+        rs = ctypes.byref(out.contents.results)
+        nc = self.lib.query_column_count(rs)
+        nrows = int(self.lib.query_row_count(rs))
+        names = [self.lib.query_column_name(rs, c).decode() for c in range(nc)]
+        types = [self.lib.query_column_type(rs, c) for c in range(nc)]
+        cols, nulls = [], []
+        if step_cursor:
+            cols = [[] for _ in range(nc)]
+            nulls = [[] for _ in range(nc)]
+            while self.lib.query_cur_step(rs) == MIDORIDB_ROW:
+                for c in range(nc):
+                    cols[c].append(self.lib.query_column_int64(rs, c))
+                    nulls[c].append(bool(self.lib.query_column_is_null(rs, c)))
+            cols = [np.array(c, dtype=np.int64) for c in cols]
+            nulls = [np.array(x, dtype=bool) for x in nulls]
+        else:
+            for c in range(nc):
+                p = self.lib.query_column_data(rs, c)
+                cols.append(np.ctypeslib.as_array(p, shape=(nrows,)).copy() if nrows else np.zeros(0, dtype=np.int64))
+            nulls = [None] * nc
+        res = Result(names, types, cols, nulls, float(self.lib.query_exec_ms(rs)), int(self.lib.query_joined_rows(rs)))
+        self.lib.query_free(out)
+        return res
+
+    # -- ingest -------------------------------------------------------------------------------
+    def append_columns(self, table, cols, nulls=None):
+        n = len(cols[0])
+        arrs = [np.ascontiguousarray(np.asarray(c).view(np.int64) if np.asarray(c).dtype == np.float64 else np.asarray(c, dtype=np.int64))
+                for c in cols]
+        cp = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        narrs = None
+        npp = None
+        if nulls is not None and any(x is not None for x in nulls):
+            narrs = [None if x is None else np.ascontiguousarray(x, dtype=np.uint8) for x in nulls]
+            npp = (c_void_p * len(arrs))(*[(a.ctypes.data if a is not None else None) for a in narrs])
+        rc = self.lib.mdb_table_append_columns(ctypes.byref(self.db), table.encode(), len(arrs), n, cp, npp)
+        if rc != 0:
+            raise QueryError(f"mdb_table_append_columns({table}) failed: {rc}")
+
+    def generate(self, table, n, seed, modulus=None):
+        mod = None
+        if modulus is not None:
+            mod = (c_uint64 * len(modulus))(*modulus)
+        rc = self.lib.mdb_table_generate(ctypes.byref(self.db), table.encode(), n, seed, mod)
+        if rc != 0:
+            raise QueryError(f"mdb_table_generate({table}) failed: {rc}")

@@ -123,8 +123,10 @@ class RefDB:
         rc = self.execute(sql)
         if rc != 1:
             raise RefError("not a SELECT")
-        names, vals, nulls = self.fetch()
-        return names, [tuple(None if nulls[i, k] else int(vals[i, k]) for k in range(len(names))) for i in range(len(vals))]
+        names, vals, _nulls = self.fetch()
+        # values only, as query_column_int64() would return them: the reference's NULL bitmap is not
+        # reliable in results (see ref_harness.c), a NULL cell reads as 0
+        return names, [tuple(int(vals[i, k]) for k in range(len(names))) for i in range(len(vals))]
 
     def table_rows(self, name):
         return int(self.L.ref_table_rows(self.h, name.encode()))

@@ -230,9 +230,17 @@ int64_t ref_result_fetch(void *h, int64_t *vals, uint8_t *nulls, int64_t cap_row
 					bool isnull = bit_test(r->null_bitmap, k, sizeof(r->null_bitmap));
 					int64_t v = 0;
 					size_t sp = table_calc_column_space(&t->columns[k]);
-					if (!isnull && sp == 8)
+					/* raw bytes whatever the NULL bit says, exactly like
+					 * query_column_int64() (reference src/engine/query.c:162-166): the
+					 * reference never clears the COUNT column's NULL bit
+					 * (executor_select.c:324-338) and table_rem_column() does not shift
+					 * the bitmap (src/primitive/column.c:146-211), so after a projection
+					 * the bits no longer line up with the columns.  A NULL source cell
+					 * reads as 0 because cpy_cols() skips the copy into the zeroed row
+					 * (executor_select.c:384-387). */
+					if (sp == 8)
 						memcpy(&v, r->data + off, 8);
-					else if (!isnull && sp == 1)
+					else if (sp == 1)
 						v = *(bool *)(r->data + off);
 					vals[n * t->column_count + k] = v;
 					nulls[n * t->column_count + k] = isnull;

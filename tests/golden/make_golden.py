@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by running the REAL reference (oracle/_ref/libmidori_ref.so, built
+from /root/reference by `make -C oracle ref`) on small inputs.  Run in the authoring container:
+
+    python tests/golden/make_golden.py
+
+A fixture is data only: the SQL, the input tables and the rows the reference returned
+(column names in the reference's physical result order, values as query_column_int64() would
+return them).  Every case stays inside the domain where the reference implements SQL semantics
+(SURVEY.md 8a): GROUP BY / COUNT inputs fit one 4 KiB datablock (D1), no multi-value IN (D3),
+at least one row reaches the early-materialisation table (D8), integers within int32 (D5).
+The 3-way join cases are produced by chaining two reference 2-way joins through a real
+intermediate table, because the reference's own recursive join is defective (D2).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_case(name, ddl, tables, query, source, via=None):
+    """ddl: list of CREATE statements; tables: {name: (cols list of lists, nulls list of lists or None)}."""
+    if os.environ.get("GOLDEN_TRACE"):
+        print("case", name, query, flush=True)
+    db = ref.RefDB()
+    for s in ddl:
+        db.execute(s)
+    for t, (cols, nulls) in tables.items():
+        if len(cols[0]):
+            db.bulk_insert(t, [np.array(c) for c in cols], None if nulls is None else [None if x is None else np.array(x) for x in nulls])
+    if via is not None:
+        names, rows = via(db)
+    else:
+        names, rows = db.query(query)
+    db.close()
+    return {
+        "name": name, "source": source, "ddl": ddl,
+        "tables": {t: {"cols": [[(float(v) if isinstance(v, float) else int(v)) for v in c] for c in cols],
+                       "nulls": None if nulls is None else [None if x is None else [int(b) for b in x] for x in nulls]}
+                   for t, (cols, nulls) in tables.items()},
+        "query": query, "expect": {"names": names, "rows": [list(r) for r in rows]},
+    }
+
+
+def reference_tests():
+    """The reference's own known-answer cases (tests/engine/executor_select.c), same SQL, same data."""
+    T = "reference tests/engine/executor_select.c"
+    A3 = {"A": ([[1, 2, 3], [123, 456, 789]], None), "B": ([[1, 3], [-12345, -67890]], None)}
+    ddl_ab = ["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 INT);"]
+    cases = [
+        run_case("ref_select_1", ["CREATE TABLE TEST (f1 INT);"], {"TEST": ([[123, -12345]], None)}, "SELECT * FROM TEST;", T + ":47"),
+        run_case("ref_select_2", ["CREATE TABLE A (f1 INT);", "CREATE TABLE B (f2 INT);"],
+                 {"A": ([[123, 456]], None), "B": ([[-12345, -67890]], None)}, "SELECT * FROM A, B;", T + ":71"),
+        run_case("ref_select_3", ddl_ab, A3, "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;", T + ":102"),
+        run_case("ref_select_5", ddl_ab, A3, "SELECT f1, f2 FROM A INNER JOIN B ON A.id_a = B.id_b;", T + ":168"),
+        run_case("ref_select_6", ddl_ab, A3, "SELECT f1, f2 FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f1 = 123;", T + ":197"),
+        run_case("ref_select_7", ddl_ab, A3, "SELECT f1, f2 FROM A INNER JOIN B ON A.id_a = B.id_b WHERE 123 >= f1 AND f1 < 200;", T + ":231"),
+        run_case("ref_select_9", ["CREATE TABLE A (id INT, f1 INT);"],
+                 {"A": ([[1, 2, 3, 4, 5], [1, 2, 0, 4, 0]], [None, [0, 0, 1, 0, 1]])}, "SELECT id FROM A WHERE f1 IS NULL;", T + ":292"),
+        run_case("ref_select_10", ["CREATE TABLE A (id INT, f1 INT);"],
+                 {"A": ([[1, 1, 3, 3, 4], [1, 2, 0, 4, 0]], [None, [0, 0, 1, 0, 1]])}, "SELECT id, COUNT(*) FROM A GROUP BY id;", T + ":318"),
+        run_case("ref_select_11", ["CREATE TABLE A (id_a INT);", "CREATE TABLE B (id_b INT);"],
+                 {"A": ([[1, 3, 4]], None), "B": ([[1, 1, 3, 3, 4, 0]], [[0, 0, 0, 0, 0, 1]])},
+                 "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;", T + ":348 (README example, north-star query)"),
+        run_case("ref_select_12", ["CREATE TABLE A (id INT);"], {"A": ([[1, 3, 4]], None)}, "SELECT COUNT(*) FROM A WHERE id > 1;", T + ":380"),
+        # case 8 with a single IN value (the multi-value form is reference defect D3)
+        run_case("ref_select_8_single_in", ["CREATE TABLE A (f1 INT);"], {"A": ([[1, 2, 123, 3, 126, 4, 124, 125]], None)},
+                 "SELECT f1 FROM A WHERE f1 IN (124);", T + ":265 (restricted to one IN value, D3)"),
+    ]
+    return cases
+
+
+def three_way(db_tables, ddl, name, source):
+    """(A JOIN B) JOIN C expected rows from two chained reference 2-way joins (D2 workaround)."""
+    q = "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c;"
+
+    def via(db):
+        n1, r1 = db.query("SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;")
+        # materialise A JOIN B as a real table AB with the same bare column names, in (A cols, B cols) order
+        bare = [n.split(".")[1] for n in n1]
+        db.execute("CREATE TABLE AB (" + ", ".join(c + " INT" for c in bare) + ");")
+        if r1:
+            db.bulk_insert("AB", [np.array([r[k] for r in r1]) for k in range(len(bare))])
+        n2, r2 = db.query("SELECT * FROM AB INNER JOIN C ON AB.id_a = C.id_c;")
+        # rename AB.x back to the owning table, keep the values; the direct 3-way query's column ORDER is
+        # checked separately against the djb2 emulation, so store names sorted into that order by the test
+        owner = {c: "A" for c in db_tables["A_cols"]}
+        owner.update({c: "B" for c in db_tables["B_cols"]})
+        names = [(owner[n.split(".")[1]] + "." + n.split(".")[1]) if n.startswith("AB.") else n for n in n2]
+        return names, r2
+
+    return run_case(name, ddl, db_tables["data"], q, source, via=via)
+
+
+def probes():
+    S = "reference executor behind its parser seam (oracle/_ref), probe"
+    ddl = ["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 DOUBLE);"]
+    f2 = np.array([0.5, 1.5, 2.5])
+    data = {"A": ([[1, 3, 4, 3], [10, 30, 0, 31]], [None, [0, 0, 1, 0]]), "B": ([[1, 3, 3], f2.tolist()], None)}
+
+    def rc(name, q):
+        d = {"A": data["A"], "B": ([data["B"][0][0], f2], None)}
+        c = run_case(name, ddl, d, q, S)
+        return c
+    qs = [
+        ("probe_count_empty", "SELECT COUNT(*) FROM A WHERE id_a > 100;"),
+        ("probe_where_empty", "SELECT id_a FROM A WHERE id_a > 100;"),
+        ("probe_count_all", "SELECT COUNT(*) FROM A;"),
+        ("probe_group_count_order", "SELECT f1, COUNT(*) FROM A GROUP BY f1;"),
+        ("probe_count_first", "SELECT COUNT(*), id_a FROM A GROUP BY id_a;"),
+        ("probe_double_where", "SELECT f2 FROM B WHERE f2 > 1.0;"),
+        ("probe_join_double_where", "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f2 < 2.0;"),
+        ("probe_group_by_right_key", "SELECT id_b, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_b;"),
+        ("probe_not_in", "SELECT f1 FROM A WHERE id_a NOT IN (3, 4);"),
+        ("probe_eq_null", "SELECT id_a FROM A WHERE f1 = NULL;"),
+        ("probe_const_true", "SELECT id_a FROM A WHERE 1 = 1;"),
+        ("probe_or", "SELECT id_a FROM A WHERE id_a = 3 OR f1 = 10;"),
+        ("probe_xor", "SELECT id_a FROM A WHERE id_a = 3 XOR f1 = 30;"),
+        ("probe_qualified", "SELECT A.id_a FROM A WHERE A.id_a <> 3;"),
+        ("probe_alias", "SELECT x.id_a FROM A AS x WHERE x.f1 >= 30;"),
+        ("probe_on_residual", "SELECT id_a, f1 FROM A INNER JOIN B ON A.id_a = B.id_b AND f1 > 10;"),
+        ("probe_is_not_null", "SELECT id_a FROM A WHERE f1 IS NOT NULL;"),
+        ("probe_yoda", "SELECT f1 FROM A WHERE 10 < f1;"),
+        ("probe_cross_where", "SELECT id_a, id_b FROM A, B WHERE id_a < id_b;"),
+        ("probe_on_swapped", "SELECT id_a, id_b FROM A INNER JOIN B ON B.id_b = A.id_a;"),
+    ]
+    return [rc(n, q) for n, q in qs]
+
+
+def randomized(seed, count):
+    """Random in-domain cases: tables of <= 40 rows, keys from a small domain with NULLs."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    ddl = ["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 INT);", "CREATE TABLE C (id_c INT, f3 INT);"]
+    templates = [
+        "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;",
+        "SELECT f1, f2 FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f1 > {k} AND f2 <= {m};",
+        "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;",
+        "SELECT id_b, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_b;",
+        "SELECT id_a, COUNT(*) FROM A GROUP BY id_a;",
+        "SELECT f1, COUNT(*) FROM A GROUP BY f1;",
+        "SELECT COUNT(*) FROM A WHERE f1 < {k} OR id_a = {m};",
+        "SELECT id_a, f1 FROM A WHERE f1 IS NOT NULL;",
+        "SELECT id_a FROM A WHERE f1 <> {k} XOR id_a < {m};",
+        "SELECT id_a, id_b, f2 FROM A INNER JOIN B ON A.id_a = B.id_b AND f2 > {k};",
+        "SELECT f1, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY f1;",
+        "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f1 >= {k};",
+    ]
+    for i in range(count):
+        na, nb = int(rng.integers(1, 9)), int(rng.integers(1, 9))	# <= 8 x 8 = 64 joined rows (one datablock, D1)
+        dom = int(rng.integers(2, 6))
+        a_id = rng.integers(0, dom, na)
+        b_id = rng.integers(0, dom, nb)
+        b_id[0] = a_id[0]						# at least one joined row (D8)
+        a_f = rng.integers(-50, 50, na)
+        b_f = rng.integers(-50, 50, nb)
+        b_f[0] = 49							# keeps the guaranteed pair alive under "AND f2 > k" (D8)
+        a_idn = (rng.random(na) < 0.15).astype(int)
+        a_idn[0] = 0
+        b_idn = (rng.random(nb) < 0.15).astype(int)
+        b_idn[0] = 0
+        a_fn = (rng.random(na) < 0.2).astype(int)
+        tables = {"A": ([a_id.tolist(), a_f.tolist()], [a_idn.tolist(), a_fn.tolist()]),
+                  "B": ([b_id.tolist(), b_f.tolist()], [b_idn.tolist(), None]),
+                  "C": ([[], []], None)}
+        t = templates[i % len(templates)]
+        q = t.format(k=int(rng.integers(-30, 30)), m=int(rng.integers(0, dom)))
+        if "WHERE" in q and "JOIN" not in q and "COUNT" in q:
+            pass
+        try:
+            cases.append(run_case(f"random_{seed}_{i}", ddl, tables, q, "randomised in-domain case run through oracle/_ref"))
+        except ref.RefError as e:
+            print("skip", q, e)
+    return cases
+
+
+def three_way_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    ddl = ["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 INT);", "CREATE TABLE C (id_c INT, f3 INT);"]
+    out = []
+    # the reference's own test data for the 3-way join (tests/engine/executor_select.c:133-166)
+    fixed = {"A": ([[1, 2, 3], [123, 456, 789]], None), "B": ([[1, 2, 3], [-12345, -11111, -67890]], None),
+             "C": ([[1, 3, 4], [333, 666, 999]], None)}
+    out.append(three_way({"A_cols": ["id_a", "f1"], "B_cols": ["id_b", "f2"], "data": fixed}, ddl, "ref_select_4_intended",
+                         "reference tests/engine/executor_select.c:133 (expected rows of the test; the reference itself returns only "
+                         "the first, defect D2) - produced by chaining two reference 2-way joins"))
+    for i in range(count):
+        na, nb, nc = (int(rng.integers(2, 8)) for _ in range(3))
+        dom = int(rng.integers(2, 5))
+        a, b, c = rng.integers(0, dom, na), rng.integers(0, dom, nb), rng.integers(0, dom, nc)
+        b[0] = a[0]
+        c[0] = a[0]
+        data = {"A": ([a.tolist(), rng.integers(0, 99, na).tolist()], None), "B": ([b.tolist(), rng.integers(0, 99, nb).tolist()], None),
+                "C": ([c.tolist(), rng.integers(0, 99, nc).tolist()], None)}
+        out.append(three_way({"A_cols": ["id_a", "f1"], "B_cols": ["id_b", "f2"], "data": data}, ddl, f"three_way_{seed}_{i}",
+                             "chained reference 2-way joins (D2 workaround)"))
+    return out
+
+
+def column_orders():
+    """Result column order (R3) of SELECT * over assorted schemas, straight from the reference."""
+    out = []
+    schemas = [
+        (["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 INT);"], "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;"),
+        (["CREATE TABLE T1 (a INT, b INT, c INT, d INT, e INT);", "CREATE TABLE T2 (f INT, g INT, h INT, i INT);"],
+         "SELECT * FROM T1 INNER JOIN T2 ON T1.a = T2.f;"),
+        (["CREATE TABLE orders (order_id INT, customer INT, amount INT, region INT, status INT, flag INT);",
+          "CREATE TABLE cust (cust_id INT, segment INT, country INT);"], "SELECT * FROM orders INNER JOIN cust ON orders.customer = cust.cust_id;"),
+        (["CREATE TABLE A (id_a INT, f1 INT);", "CREATE TABLE B (id_b INT, f2 INT);", "CREATE TABLE C (id_c INT, f3 INT);"],
+         "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c;"),
+        (["CREATE TABLE W (c1 INT, c2 INT, c3 INT, c4 INT, c5 INT, c6 INT, c7 INT, c8 INT, c9 INT, c10 INT, c11 INT, c12 INT);"], "SELECT * FROM W;"),
+    ]
+    for k, (ddl, q) in enumerate(schemas):
+        db = ref.RefDB()
+        tabs = {}
+        for s in ddl:
+            db.execute(s)
+            name = s.split()[2]
+            ncols = s.count(" INT")
+            db.bulk_insert(name, [np.array([7])] * ncols)
+            tabs[name] = ([[7]] * ncols, None)
+        names, rows = db.query(q)
+        db.close()
+        out.append({"name": f"column_order_{k}", "source": "reference result column order (djb2 hashtable iteration, SURVEY 8a R3)",
+                    "ddl": ddl, "tables": {t: {"cols": c, "nulls": None} for t, (c, _) in tabs.items()}, "query": q,
+                    "expect": {"names": names, "rows": [list(r) for r in rows]}})
+    return out
+
+
+def config1():
+    """BASELINE.json configs[0]: single-table SELECT + WHERE over 1M INT64 rows through the reference
+    executor (CPU).  Too large to store row by row: the fixture keeps the row count, the first and last
+    rows and a checksum (sum and xor of all returned values)."""
+    n = 1_000_000
+    db = ref.RefDB()
+    db.execute("CREATE TABLE T (v INT);")
+    db.bulk_insert("T", [np.arange(n, dtype=np.int64)])
+    q = "SELECT v FROM T WHERE v > 500000;"
+    db.execute(q)
+    names, vals, _ = db.fetch()
+    db.close()
+    col = vals[:, 0]
+    return [{"name": "config1_scan_where_1M", "source": "BASELINE.json configs[0] via oracle/_ref (reference CPU executor)",
+             "ddl": ["CREATE TABLE T (v INT);"], "generator": {"table": "T", "column": "v", "rows": n, "values": "v = i"}, "query": q,
+             "expect": {"names": names, "nrows": int(len(col)), "first": int(col[0]), "last": int(col[-1]), "sum": int(col.sum()),
+                        "xor": int(np.bitwise_xor.reduce(col))}}]
+
+
+def main():
+    if not ref.available():
+        sys.exit("oracle/_ref/libmidori_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    sets = {
+        "reference_tests.json": reference_tests(),
+        "probes.json": probes(),
+        "randomized.json": randomized(20261002, 72),
+        "three_way.json": three_way_cases(7, 8),
+        "column_order.json": column_orders(),
+        "config1.json": config1(),
+    }
+    for fn, cases in sets.items():
+        with open(os.path.join(OUT, fn), "w") as f:
+            json.dump(cases, f, indent=1)
+        print(fn, len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()
