@@ -1,0 +1,118 @@
+"""The oracle (oracle/np_oracle.py, oracle/cpu_naive.c, oracle/cpu_hash.c) pinned against the real
+reference: (1) the golden vectors the reference produced (tests/golden), (2) live runs of oracle/_ref
+on randomised inputs where the reference is correct (joins at any size, GROUP BY within one datablock)."""
+import numpy as np
+import pytest
+
+from oracle import cpu, np_oracle as orc
+from tests import golden_util as G
+
+NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
+JOIN_ALL = "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;"
+GROUP_A = "SELECT id_a, COUNT(*) FROM A GROUP BY id_a;"
+
+
+def _keys(case, t, col=0):
+    cols, nulls = G.table_arrays(case, t)
+    n = None if nulls is None or nulls[col] is None else nulls[col].astype(bool)
+    return cols[col], n
+
+
+def _cases(query):
+    return [c for c in G.all_cases("reference_tests.json", "randomized.json") if c["query"] == query]
+
+
+def test_fixture_coverage():
+    assert len(_cases(NORTH)) >= 5 and len(_cases(JOIN_ALL)) >= 5 and len(_cases(GROUP_A)) >= 5
+
+
+@pytest.mark.parametrize("case", _cases(NORTH), ids=lambda c: c["name"])
+def test_join_group_count_oracles_vs_reference_vectors(case):
+    kl, nl = _keys(case, "A")
+    kr, nr = _keys(case, "B")
+    exp = case["expect"]["rows"]
+    k, c, f, j = orc.join_group_count(kl, nl, kr, nr)
+    assert [[int(a), int(b)] for a, b in zip(k, c)] == exp
+    k2, c2, j2 = cpu.naive_join_group_count(kl, nl, kr, nr)
+    assert [[int(a), int(b)] for a, b in zip(k2, c2)] == exp and j2 == j
+    k3, c3, f3, j3 = cpu.hash_join_group_count(kl, nl, kr, nr, 3)
+    assert [[int(a), int(b)] for a, b in zip(k3, c3)] == exp and j3 == j and np.array_equal(f3, f)
+
+
+@pytest.mark.parametrize("case", _cases(JOIN_ALL), ids=lambda c: c["name"])
+def test_join_pairs_oracles_vs_reference_vectors(case):
+    kl, nl = _keys(case, "A")
+    kr, nr = _keys(case, "B")
+    a_cols, a_nulls = G.table_arrays(case, "A")
+    b_cols, b_nulls = G.table_arrays(case, "B")
+    names = case["expect"]["names"]
+    src = {"A.id_a": (a_cols[0], 0, "A"), "A.f1": (a_cols[1], 1, "A"), "B.id_b": (b_cols[0], 0, "B"), "B.f2": (b_cols[1], 1, "B")}
+    for fn in (orc.join_pairs, cpu.naive_join_pairs):
+        pl, pr = fn(kl, nl, kr, nr)
+        rows = []
+        for i, j in zip(pl, pr):
+            row = []
+            for n in names:
+                col, ci, t = src[n]
+                idx = i if t == "A" else j
+                nulls = a_nulls if t == "A" else b_nulls
+                isnull = nulls is not None and nulls[ci] is not None and nulls[ci][idx]
+                row.append(0 if isnull else int(col[idx]))	# a NULL cell reads 0 through query_column_int64()
+            rows.append(row)
+        assert rows == case["expect"]["rows"]
+
+
+@pytest.mark.parametrize("case", _cases(GROUP_A) + [c for c in G.load("reference_tests.json") if c["name"] == "ref_select_10"],
+                         ids=lambda c: c["name"])
+def test_group_count_oracles_vs_reference_vectors(case):
+    t = "A"
+    keys, nulls = _keys(case, t)
+    for fn in (orc.group_count, cpu.naive_group_count):
+        first, cnt = fn(keys, nulls)
+        rows = [[0 if (nulls is not None and nulls[i]) else int(keys[i]), int(c)] for i, c in zip(first, cnt)]
+        assert rows == case["expect"]["rows"]
+
+
+def test_oracles_agree_on_larger_random_inputs():
+    rng = np.random.default_rng(99)
+    for n_l, n_r, dom, nf in [(500, 700, 60, 0.1), (3000, 2000, 1000, 0.02), (1, 50, 2, 0.0)]:
+        kl, kr = rng.integers(-dom, dom, n_l), rng.integers(-dom, dom, n_r)
+        nl, nr = rng.random(n_l) < nf, rng.random(n_r) < nf
+        a, b = orc.join_pairs(kl, nl, kr, nr), cpu.naive_join_pairs(kl, nl, kr, nr)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        k, c, f, j = orc.join_group_count(kl, nl, kr, nr)
+        k2, c2, j2 = cpu.naive_join_group_count(kl, nl, kr, nr)
+        k3, c3, f3, j3 = cpu.hash_join_group_count(kl, nl, kr, nr, 4)
+        assert j == j2 == j3 == len(a[0])
+        assert np.array_equal(k, k2) and np.array_equal(c, c2) and np.array_equal(k, k3) and np.array_equal(c, c3) and np.array_equal(f, f3)
+        g1, g2 = orc.group_count(kl, nl), cpu.naive_group_count(kl, nl)
+        assert np.array_equal(g1[0], g2[0]) and np.array_equal(g1[1], g2[1])
+
+
+def test_join_oracle_vs_live_reference_multi_block():
+    """Joins are correct in the reference at any size: pin the oracle on inputs spanning many 4 KiB datablocks."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(5)
+    n_l, n_r = 700, 900
+    kl, kr = rng.integers(0, 300, n_l), rng.integers(0, 300, n_r)
+    nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.05
+    kr[0], nl[0], nr[0] = kl[0], False, False
+    db = ref.RefDB()
+    db.create_int_table("A", ["id_a"])
+    db.create_int_table("B", ["id_b"])
+    db.bulk_insert("A", [kl], [nl])
+    db.bulk_insert("B", [kr], [nr])
+    names, rows = db.query("SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;")
+    db.close()
+    pl, pr = orc.join_pairs(kl, nl, kr, nr)
+    assert names == ["A.id_a", "B.id_b"]
+    assert rows == [(int(kl[i]), int(kr[j])) for i, j in zip(pl, pr)]
+
+
+def test_generator_is_a_permutation_and_matches_c():
+    for n, seed in [(1, 1), (2, 2), (1000, 42), (65_537, 43)]:
+        p = orc.gen_keys(n, 0, n, seed)
+        assert np.array_equal(np.sort(p), np.arange(n))
+    assert np.array_equal(orc.gen_keys(100, 50, 1000, 7), orc.gen_keys(1000, 0, 1000, 7)[50:150])
