@@ -203,8 +203,8 @@ int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
  *
  * Hash-partition a key column by destination GPU for the all-to-all exchange
  * (SURVEY 8e): dest = hash(key) mod n_dest, NULL keys are dropped (they never
- * join).  out_keys (capacity n) receives the keys grouped by destination, in input
- * order within a destination; out_counts (HOST, n_dest entries) the group sizes.
+ * join).  out_keys (capacity n) receives the keys grouped by destination (order inside a
+ * destination is unspecified); out_counts (HOST, n_dest entries) the group sizes.
  * Synchronises.
  */
 int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,

@@ -35,10 +35,11 @@ struct mdb_part_result {
 size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid);
 
 /* Partition one key column into 2^(bits1+bits2) leaves by the top bits of fmix64(key), dropping
- * NULL keys, stable (input order is kept inside a leaf).  All temporaries and outputs are carved
- * from the arena (caller has called mdb_arena_begin with enough room).  No host sync. */
+ * NULL keys.  stable = keep input order inside every leaf (slower ballot ranking; requires want_rid),
+ * otherwise the order inside a leaf is unspecified.  All temporaries and outputs are carved from the
+ * arena (caller has called mdb_arena_begin with enough room).  No host sync. */
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			int bits1, int bits2, bool want_rid, mdb_part_result *out);
+			int bits1, int bits2, bool want_rid, bool stable, mdb_part_result *out);
 
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);

@@ -24,6 +24,7 @@
 /* ------------------------------------------------------------------ shared leaf helpers */
 
 #define LEAF_THREADS 512
+#define LEAF_BATCH 4		/* keys loaded per thread before the first is consumed */
 #define GC_SLOTS 3840u		/* group-count table: 20 B/slot -> 75 KiB, two workgroups per CU */
 #define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
 #define PJ_SLOTS 2048u		/* pairs table */
@@ -109,20 +110,38 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 		s_sum = 0ull;
 	__syncthreads();
 
-	/* build: left side */
-	for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
-		const uint64_t hv = a.hv_l[i];
-		const uint32_t rid = a.rid_l[i];
-		if (hv == 0) {
-			atomicAdd(&s_z[0], 1u);
-			atomicMin(&s_z[2], rid);
-		} else {
-			const uint32_t s = leaf_insert(s_key, GC_SLOTS, hv);
-			if (s == 0xFFFFFFFFu) {
-				atomicOr(a.status, 1u);
+	/* build: left side.  Loads are issued in batches of LEAF_BATCH per thread before any of them is
+	 * consumed, so one HBM round trip covers the whole batch (the first version loaded one key per
+	 * iteration behind the LDS atomics and was latency-bound: 70 % of wave time in s_waitcnt). */
+	for (uint32_t base = l0; base < l1; base += LEAF_THREADS * LEAF_BATCH) {
+		uint64_t hv[LEAF_BATCH];
+		uint32_t rid[LEAF_BATCH];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+			hv[u] = 0;
+			rid[u] = 0;
+			if (i < l1) {
+				hv[u] = a.hv_l[i];
+				rid[u] = a.rid_l[i];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+			if (i >= l1)
+				continue;
+			if (hv[u] == 0) {
+				atomicAdd(&s_z[0], 1u);
+				atomicMin(&s_z[2], rid[u]);
 			} else {
-				atomicAdd(&s_cl[s], 1u);
-				atomicMin(&s_first[s], rid);
+				const uint32_t s = leaf_insert(s_key, GC_SLOTS, hv[u]);
+				if (s == 0xFFFFFFFFu) {
+					atomicOr(a.status, 1u);
+				} else {
+					atomicAdd(&s_cl[s], 1u);
+					atomicMin(&s_first[s], rid[u]);
+				}
 			}
 		}
 	}
@@ -130,14 +149,25 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 
 	/* probe: right side */
 	if (HAS_R) {
-		for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
-			const uint64_t hv = a.hv_r[j];
-			if (hv == 0) {
-				atomicAdd(&s_z[1], 1u);
-			} else {
-				const uint32_t s = leaf_find(s_key, GC_SLOTS, hv);
-				if (s != 0xFFFFFFFFu)
-					atomicAdd(&s_cr[s], 1u);
+		for (uint32_t base = r0; base < r1; base += LEAF_THREADS * LEAF_BATCH) {
+			uint64_t hv[LEAF_BATCH];
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+				hv[u] = j < r1 ? a.hv_r[j] : 0;
+			}
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+				if (j >= r1)
+					continue;
+				if (hv[u] == 0) {
+					atomicAdd(&s_z[1], 1u);
+				} else {
+					const uint32_t s = leaf_find(s_key, GC_SLOTS, hv[u]);
+					if (s != 0xFFFFFFFFu)
+						atomicAdd(&s_cr[s], 1u);
+				}
 			}
 		}
 		__syncthreads();
@@ -229,11 +259,11 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 
 	mdb_part_result pl, pr;
 	memset(&pr, 0, sizeof(pr));
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, &pl);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
 	if (rc)
 		return rc;
 	if (has_r) {
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, &pr);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, &pr);
 		if (rc)
 			return rc;
 	}
@@ -523,10 +553,12 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	if (rc)
 		return rc;
 	mdb_part_result pl, pr;
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, &pl);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
 	if (rc)
 		return rc;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, &pr);
+	/* right side stable: inside a leaf its rows stay in ascending row-id order, which the chunked emit
+	 * relies on (a key's row ids in a later chunk are all larger than those of an earlier chunk) */
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, &pr);
 	if (rc)
 		return rc;
 	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);

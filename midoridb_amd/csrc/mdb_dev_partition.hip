@@ -1,5 +1,5 @@
 /*
- * mdb_dev_partition.hip - stable, LDS-staged MSD radix partitioning of a key column by the top
+ * mdb_dev_partition.hip - LDS-staged MSD radix partitioning of a key column by the top
  * bits of fmix64(key).  This is the bandwidth-dominant stage of the join / GROUP BY pipeline.
  *
  * Why it exists: the reference joins by comparing every pair of rows (reference
@@ -13,14 +13,13 @@
  *   k_part_hist     per tile: LDS histogram of the level's digit, written digit-major
  *   (scan)          one exclusive scan over [segment][digit][tile] gives every tile its output
  *                   offset per digit and, as a by-product, the exact start of every child segment
- *   k_part_scatter  per tile: wave-level peer ranking (ballot match, no atomics) gives each key a
- *                   STABLE rank inside the tile, keys are staged sorted-by-digit in LDS, then
- *                   written out as contiguous runs per digit (coalesced; TILE/R keys per run)
+ *   k_part_scatter  per tile: one LDS atomic per key gives its rank inside its digit, keys are
+ *                   staged sorted-by-digit in LDS, then written out as contiguous runs per digit
+ *                   (coalesced; TILE/R keys per run)
  *
  * Level 0 reads the raw int64 keys (+ NULL bits, NULL rows are dropped - a NULL key never joins,
  * executor_select.c:557-579), hashes them, and attaches the row id; later levels move (hash, rid).
- * Stability keeps the original row order inside every leaf, which the join uses to emit matches
- * in the reference's left-major / right-minor order.
+ * Order inside a leaf is unspecified; the consumers restore the reference's orders from the row ids.
  *
  * Memory traffic per level and key: hist reads 8 B, scatter reads 8(+4) B and writes 8(+4) B.
  * Blocks are mapped to tiles XCD-contiguously (blockIdx % 8 selects the XCD) so that adjacent
@@ -57,8 +56,8 @@ struct mdb_level_args {
 	uint32_t *hist;			/* counts in, scanned offsets out */
 	uint32_t ntiles;		/* tiles to cover (upper bound for level >= 1) */
 	uint32_t R;			/* digits at this level */
-	uint32_t mbits;			/* bits needed to tell digits apart (ballot rounds) */
 	uint32_t shift;			/* RADIX mode: digit = (hv >> shift) & (R - 1) */
+	uint32_t mbits;			/* bits needed to tell digits apart (ballot rounds of the STABLE form) */
 	uint32_t mode;			/* enum mdb_digit_mode */
 	uint32_t inverse_out;		/* write fmix64^-1(hv) (= the original key) instead of hv */
 };
@@ -138,14 +137,26 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 		a.hist[(uint64_t)td.hbase + (uint64_t)d * td.nt] = s_h[d];
 }
 
-template <bool LEVEL0>
+/*
+ * Scatter: the tile is ranked with LDS atomics (one ds_add_rtn per key returns the key's rank inside
+ * its digit), staged in LDS sorted by digit, and written out as one contiguous run per digit.
+ * Order inside a digit is arrival order, i.e. unspecified: no consumer depends on it (group order is
+ * restored from row ids with atomicMin).  STABLE = true instead ranks with wave-level ballot
+ * matching and keeps input order inside every digit; rocprofv3 showed that form issue-bound (SIMD
+ * ~100 % busy at 2.3 TB/s vs 3.7 TB/s, profiles/r01/), so it is used only where order matters: the
+ * right side of the materialising join, whose per-key row-id lists must come out ascending.
+ *
+ * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
+ * (+16 KiB for STABLE).
+ */
+template <bool LEVEL0, bool HAS_RID, bool STABLE>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
-	__shared__ uint64_t s_hv[MDB_TILE];			/* 32 KiB */
-	__shared__ uint32_t s_rid[MDB_TILE];			/* 16 KiB */
-	__shared__ uint32_t s_wcnt[PART_WAVES][PART_MAX_R];	/* 16 KiB: per-wave digit counts, then bases */
-	__shared__ uint32_t s_off[PART_MAX_R];			/* tile-local start of each digit */
-	__shared__ uint32_t s_gbase[PART_MAX_R];		/* global output start of each digit for this tile */
+	__shared__ uint64_t s_hv[MDB_TILE];
+	__shared__ uint32_t s_rid[HAS_RID ? MDB_TILE : 1];
+	__shared__ uint32_t s_cnt[PART_MAX_R];		/* per-digit counters, then tile-local digit starts */
+	__shared__ int32_t s_delta[PART_MAX_R];	/* global start of the digit's run minus its tile-local start */
+	__shared__ uint32_t s_wcnt[STABLE ? PART_WAVES * PART_MAX_R : 1];	/* STABLE: per-wave digit counts, then bases */
 	__shared__ uint32_t s_tmp[32];
 
 	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
@@ -153,21 +164,23 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		return;
 	const uint32_t R = a.R;
 	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
-	const uint64_t lt = mdb_lanemask_lt();
 
-	for (uint32_t i = threadIdx.x; i < PART_WAVES * PART_MAX_R; i += PART_THREADS)
-		(&s_wcnt[0][0])[i] = 0;
 	for (uint32_t d = threadIdx.x; d < R; d += PART_THREADS)
-		s_gbase[d] = a.hist[(uint64_t)td.hbase + (uint64_t)d * td.nt];
+		s_cnt[d] = 0;
+	if (STABLE)
+		for (uint32_t i = threadIdx.x; i < PART_WAVES * PART_MAX_R; i += PART_THREADS)
+			s_wcnt[i] = 0;
 
-	/* 1. load: wave w owns tile elements [w*512, w*512+512), 64 consecutive per round (coalesced) */
+	/* 1. load (coalesced).  STABLE: wave w owns the 512 consecutive keys [w*512, w*512+512), so that
+	 *    (wave, round, lane) order is input order; otherwise consecutive threads, consecutive keys. */
 	uint64_t hv[PART_ITEMS];
 	uint32_t rid[PART_ITEMS];
 	uint32_t dig[PART_ITEMS];
 	uint32_t rank[PART_ITEMS];
 #pragma unroll
 	for (int r = 0; r < PART_ITEMS; r++) {
-		const uint32_t i = wave * PART_WAVE_SPAN + (uint32_t)r * MDB_WAVE + lane;
+		const uint32_t i = STABLE ? wave * PART_WAVE_SPAN + (uint32_t)r * MDB_WAVE + lane
+					  : (uint32_t)r * PART_THREADS + threadIdx.x;
 		bool valid = i < td.len;
 		hv[r] = 0;
 		rid[r] = 0;
@@ -175,58 +188,74 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			valid = part_load<LEVEL0>(a, td, i, &hv[r], &rid[r]);
 		dig[r] = valid ? part_digit(a, hv[r]) : PART_INVALID;
 	}
-	__syncthreads();	/* s_wcnt zeroed */
+	__syncthreads();
 
-	/* 2. stable rank inside the wave's 512-element span: lanes with the same digit find each other
-	 *    with `mbits` ballots; the lowest such lane bumps the wave-private LDS counter. */
-	volatile uint32_t *wc = &s_wcnt[wave][0];
+	/* 2. rank inside the digit */
+	if (STABLE) {
+		/* lanes with the same digit find each other with `mbits` ballots; the lowest such lane bumps
+		 * the wave-private LDS counter: rank = keys of the digit earlier in this wave's span */
+		volatile uint32_t *wc = &s_wcnt[wave * PART_MAX_R];
+		const uint64_t lt = mdb_lanemask_lt();
 #pragma unroll
-	for (int r = 0; r < PART_ITEMS; r++) {
-		const bool valid = dig[r] != PART_INVALID;
-		const uint32_t d = dig[r];
-		uint64_t peers = __ballot(valid);
-		for (uint32_t b = 0; b < a.mbits; b++) {
-			const bool bit = (d >> b) & 1u;
-			const uint64_t m = __ballot(valid && bit);
-			peers &= bit ? m : ~m;
+		for (int r = 0; r < PART_ITEMS; r++) {
+			const bool valid = dig[r] != PART_INVALID;
+			const uint32_t d = dig[r];
+			uint64_t peers = __ballot(valid);
+			for (uint32_t b = 0; b < a.mbits; b++) {
+				const bool bit = (d >> b) & 1u;
+				const uint64_t m = __ballot(valid && bit);
+				peers &= bit ? m : ~m;
+			}
+			const uint32_t before = (uint32_t)__popcll(peers & lt);
+			const uint32_t cnt = (uint32_t)__popcll(peers);
+			uint32_t prev = 0;
+			if (valid)
+				prev = wc[d];
+			if (valid && before == 0)
+				wc[d] = prev + cnt;
+			rank[r] = prev + before;
+			__builtin_amdgcn_wave_barrier();
 		}
-		const uint32_t before = (uint32_t)__popcll(peers & lt);
-		const uint32_t cnt = (uint32_t)__popcll(peers);
-		uint32_t prev = 0;
-		if (valid)
-			prev = wc[d];
-		if (valid && before == 0)
-			wc[d] = prev + cnt;
-		rank[r] = prev + before;
-		__builtin_amdgcn_wave_barrier();
+		__syncthreads();
+		/* per digit: per-wave counts -> per-wave bases, digit total */
+		if (threadIdx.x < R) {
+			uint32_t run = 0;
+#pragma unroll
+			for (int w = 0; w < PART_WAVES; w++) {
+				const uint32_t t = s_wcnt[w * PART_MAX_R + threadIdx.x];
+				s_wcnt[w * PART_MAX_R + threadIdx.x] = run;
+				run += t;
+			}
+			s_cnt[threadIdx.x] = run;
+		}
+	} else {
+		/* one returning LDS atomic per key; order inside a digit = arrival order (unspecified) */
+#pragma unroll
+		for (int r = 0; r < PART_ITEMS; r++)
+			rank[r] = dig[r] != PART_INVALID ? atomicAdd(&s_cnt[dig[r]], 1u) : 0u;
 	}
 	__syncthreads();
 
-	/* 3. per digit: turn per-wave counts into per-wave bases, tile totals into tile offsets */
-	uint32_t total_d = 0;
-	if (threadIdx.x < R) {
-		uint32_t run = 0;
-#pragma unroll
-		for (int w = 0; w < PART_WAVES; w++) {
-			const uint32_t t = s_wcnt[w][threadIdx.x];
-			s_wcnt[w][threadIdx.x] = run;
-			run += t;
-		}
-		total_d = run;
-	}
+	/* 3. digit totals -> tile-local starts; remember where each digit's run begins globally */
+	const uint32_t total_d = threadIdx.x < R ? s_cnt[threadIdx.x] : 0u;
 	uint32_t tile_total;
 	const uint32_t off_d = mdb_block_excl_scan(total_d, s_tmp, &tile_total);
-	if (threadIdx.x < R)
-		s_off[threadIdx.x] = off_d;
+	if (threadIdx.x < R) {
+		s_cnt[threadIdx.x] = off_d;
+		s_delta[threadIdx.x] = (int32_t)(a.hist[(uint64_t)td.hbase + (uint64_t)threadIdx.x * td.nt] - off_d);
+	}
 	__syncthreads();
 
-	/* 4. stage the tile in LDS sorted by digit (stable) */
+	/* 4. stage sorted by digit */
 #pragma unroll
 	for (int r = 0; r < PART_ITEMS; r++) {
 		if (dig[r] != PART_INVALID) {
-			const uint32_t pos = s_off[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
+			uint32_t pos = s_cnt[dig[r]] + rank[r];
+			if (STABLE)
+				pos += s_wcnt[wave * PART_MAX_R + dig[r]];
 			s_hv[pos] = hv[r];
-			s_rid[pos] = rid[r];
+			if (HAS_RID)
+				s_rid[pos] = rid[r];
 		}
 	}
 	__syncthreads();
@@ -234,10 +263,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	/* 5. write out: consecutive threads write consecutive addresses inside each digit's run */
 	for (uint32_t i = threadIdx.x; i < tile_total; i += PART_THREADS) {
 		const uint64_t h = s_hv[i];
-		const uint32_t d = part_digit(a, h);
-		const uint64_t g = (uint64_t)s_gbase[d] + (i - s_off[d]);
+		const uint32_t g = (uint32_t)((int32_t)i + s_delta[part_digit(a, h)]);
 		a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
-		if (a.rid_out)
+		if (HAS_RID)
 			a.rid_out[g] = s_rid[i];
 	}
 }
@@ -351,7 +379,7 @@ void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2)
 static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; }
 
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			  bool want_rid, uint32_t mode, uint32_t n_dest, bool inverse_out, mdb_part_result *out)
+			  bool want_rid, bool stable, uint32_t mode, uint32_t n_dest, bool inverse_out, mdb_part_result *out)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -432,10 +460,18 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			int rc = mdb_scan_u32_inplace(ctx, hist, hlen, scan_tmp);
 			if (rc)
 				return rc;
-			if (l == 0) {
-				MDB_LAUNCH(ctx, "part_scatter_l0", k_part_scatter<true>, grid8(ntiles), PART_THREADS, a);
+			if (stable && l == 0) {
+				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true>), grid8(ntiles), PART_THREADS, a);
+			} else if (stable) {
+				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true>), grid8(ntiles), PART_THREADS, a);
+			} else if (l == 0 && want_rid) {
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false>), grid8(ntiles), PART_THREADS, a);
+			} else if (l == 0) {
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false>), grid8(ntiles), PART_THREADS, a);
+			} else if (want_rid) {
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else {
-				MDB_LAUNCH(ctx, "part_scatter_l1", k_part_scatter<false>, grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false>), grid8(ntiles), PART_THREADS, a);
 			}
 			MDB_LAUNCH(ctx, "part_children", k_part_children, (nchild + 1 + 255) / 256, 256, hist, tb, S, R, child_start,
 				   child_nt);
@@ -467,18 +503,20 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, MDB_DIGIT_RADIX, 0, false, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, false, MDB_DIGIT_RADIX, 0, false, NULL);
 	return cv.bytes + 4096;
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			bool want_rid, mdb_part_result *out)
+			bool want_rid, bool stable, mdb_part_result *out)
 {
 	if (n >= 0xFFFFFFFFull)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "table of %llu rows exceeds the 32-bit row-id limit of one GPU shard",
 				   (unsigned long long)n);
 	part_carver cv = { ctx, false, 0, false };
-	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, MDB_DIGIT_RADIX, 0, false, out);
+	if (stable && !want_rid)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "stable partitioning is only built with row ids");
+	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, stable, MDB_DIGIT_RADIX, 0, false, out);
 }
 
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
@@ -493,13 +531,13 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
 	 * original keys written back through the inverse hash) */
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, MDB_DIGIT_MOD, n_dest, true, NULL);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, NULL);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, MDB_DIGIT_MOD, n_dest, true, &res);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, &res);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
