@@ -42,6 +42,8 @@ def parse_args():
                     help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the result against the CPU oracle (rows <= 2e7)")
+    ap.add_argument("--force-shuffle", action="store_true",
+                    help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
 
 
@@ -98,6 +100,11 @@ def cpu_hash_yardstick(rows):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line (the JSON): everything else that native libraries print there
+    # (e.g. RCCL's version banner) is routed to stderr at the file-descriptor level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,8 +112,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_shuffle
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from midoridb_amd.dev import DeviceCtx
@@ -119,10 +128,10 @@ def main():
     # rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)
     a = dev.gen_keys(n, rank * n, total_rows, 42, 0)
     b = dev.gen_keys(n, rank * n, total_rows, 43, mod_b)
-    cap = int(n * 1.3) + 4096 if world > 1 else n
+    cap = int(n * 1.3) + 4096 if use_dist else n
     out = (torch.empty(cap, dtype=torch.int64, device=dev.device), torch.empty(cap, dtype=torch.int64, device=dev.device),
            torch.empty(cap, dtype=torch.int32, device=dev.device))
-    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n) if world > 1 else None
+    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n) if use_dist else None
 
     def step():
         if pipeline is None:
@@ -135,7 +144,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +157,7 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev.device)
     jsum = torch.tensor([float(j)], dtype=torch.float64, device=dev.device)
     gsum = torch.tensor([float(g)], dtype=torch.float64, device=dev.device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(jsum, op=dist.ReduceOp.SUM)
         dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
@@ -192,7 +201,8 @@ def main():
             "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU, variant {args.variant} "
                                    f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
                        "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
-                       "order": "reference first-occurrence order", "parallelism": f"hash-partition x{world}"},
+                       "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
+                       "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
@@ -208,13 +218,21 @@ def main():
             from oracle import cpu, np_oracle as orc
             ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(n, 0, n, 42, 0), None, orc.gen_keys(n, 0, n, 43, mod_b),
                                                        None, os.cpu_count() or 1)
-            k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
-            ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))
+            if pipeline is None:
+                k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
+                ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))
+            else:   # shuffled pipeline: same groups, order is not the reference's
+                _, jj = pipeline.run(a, b, out)
+                k, c, _ = pipeline.last
+                o1, o2 = np.argsort(k.cpu().numpy(), kind="stable"), np.argsort(ek, kind="stable")
+                ok = (jj == ej and np.array_equal(k.cpu().numpy()[o1], ek[o2]) and np.array_equal(c.cpu().numpy()[o1], ec[o2]))
             line["verified_vs_oracle"] = bool(ok)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

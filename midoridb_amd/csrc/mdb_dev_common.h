@@ -22,6 +22,7 @@ struct mdb_prof_rec {
 
 struct mdb_dev_ctx {
 	int device;
+	int num_cus;			/* compute units of the device (256 on MI355X) */
 	hipStream_t stream;
 	bool own_stream;
 	char err[512];

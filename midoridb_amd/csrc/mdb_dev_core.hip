@@ -42,6 +42,10 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	if (!ctx)
 		return -MIDORIDB_NOMEM;
 	ctx->device = device;
+	ctx->num_cus = 256;
+	(void)hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device);
+	if (ctx->num_cus <= 0)
+		ctx->num_cus = 256;
 	ctx->err[0] = 0;
 	ctx->arena = NULL;
 	ctx->arena_cap = ctx->arena_off = 0;

@@ -76,7 +76,40 @@ struct gc_args {
 	int64_t *dense_cnt;		/* [n_l], zeroed: COUNT(*) written at the group's first L position */
 	unsigned long long *joined;	/* sum of all counts */
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
+	uint32_t nleaves;
 };
+
+/*
+ * Persistent form: gridDim.x workgroups (2 per CU) walk the leaves with stride gridDim.x.  The first
+ * LEAF_BATCH keys per thread of BOTH sides of the next leaf are requested before the current leaf's
+ * results are emitted and the tables re-initialised, so the HBM round trip overlaps LDS work instead of
+ * being paid three times per leaf (offsets -> left keys -> right keys), which made the one-leaf-per-
+ * workgroup version latency-bound (70 % of wave time in s_waitcnt, profiles/r01).
+ */
+struct gc_batch {
+	uint64_t hv_l[LEAF_BATCH];
+	uint32_t rid_l[LEAF_BATCH];
+	uint64_t hv_r[LEAF_BATCH];
+};
+
+template <bool HAS_R>
+__device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, gc_batch &b)
+{
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = l0 + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+		b.hv_l[u] = 0;
+		b.rid_l[u] = 0;
+		if (i < l1) {
+			b.hv_l[u] = a.hv_l[i];
+			b.rid_l[u] = a.rid_l[i];
+		}
+		if (HAS_R) {
+			const uint32_t j = r0 + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+			b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
+		}
+	}
+}
 
 template <bool HAS_R>
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
@@ -88,109 +121,138 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 	__shared__ uint32_t s_z[4];		/* the key with hash 0: [0]=cntL [1]=cntR [2]=first */
 	__shared__ unsigned long long s_sum;
 
-	const uint32_t leaf = blockIdx.x;
-	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
-	uint32_t r0 = 0, r1 = 0;
-	if (HAS_R) {
-		r0 = a.off_r[leaf];
-		r1 = a.off_r[leaf + 1];
-	}
-	if (l0 == l1 || (HAS_R && r0 == r1))
-		return;		/* no group can come out of this leaf */
-
-	for (uint32_t s = threadIdx.x; s < GC_SLOTS; s += LEAF_THREADS) {
-		s_key[s] = 0ull;
-		s_cl[s] = 0;
-		s_cr[s] = 0;
-		s_first[s] = 0xFFFFFFFFu;
-	}
-	if (threadIdx.x < 4)
-		s_z[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;
 	if (threadIdx.x == 0)
 		s_sum = 0ull;
-	__syncthreads();
-
-	/* build: left side.  Loads are issued in batches of LEAF_BATCH per thread before any of them is
-	 * consumed, so one HBM round trip covers the whole batch (the first version loaded one key per
-	 * iteration behind the LDS atomics and was latency-bound: 70 % of wave time in s_waitcnt). */
-	for (uint32_t base = l0; base < l1; base += LEAF_THREADS * LEAF_BATCH) {
-		uint64_t hv[LEAF_BATCH];
-		uint32_t rid[LEAF_BATCH];
-#pragma unroll
-		for (int u = 0; u < LEAF_BATCH; u++) {
-			const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
-			hv[u] = 0;
-			rid[u] = 0;
-			if (i < l1) {
-				hv[u] = a.hv_l[i];
-				rid[u] = a.rid_l[i];
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < LEAF_BATCH; u++) {
-			const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
-			if (i >= l1)
-				continue;
-			if (hv[u] == 0) {
-				atomicAdd(&s_z[0], 1u);
-				atomicMin(&s_z[2], rid[u]);
-			} else {
-				const uint32_t s = leaf_insert(s_key, GC_SLOTS, hv[u]);
-				if (s == 0xFFFFFFFFu) {
-					atomicOr(a.status, 1u);
-				} else {
-					atomicAdd(&s_cl[s], 1u);
-					atomicMin(&s_first[s], rid[u]);
-				}
-			}
-		}
-	}
-	__syncthreads();
-
-	/* probe: right side */
-	if (HAS_R) {
-		for (uint32_t base = r0; base < r1; base += LEAF_THREADS * LEAF_BATCH) {
-			uint64_t hv[LEAF_BATCH];
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++) {
-				const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
-				hv[u] = j < r1 ? a.hv_r[j] : 0;
-			}
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++) {
-				const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
-				if (j >= r1)
-					continue;
-				if (hv[u] == 0) {
-					atomicAdd(&s_z[1], 1u);
-				} else {
-					const uint32_t s = leaf_find(s_key, GC_SLOTS, hv[u]);
-					if (s != 0xFFFFFFFFu)
-						atomicAdd(&s_cr[s], 1u);
-				}
-			}
-		}
-		__syncthreads();
-	}
-
-	/* emit: one COUNT(*) per group at the group's first left position */
 	unsigned long long mine = 0;
-	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += LEAF_THREADS) {
-		uint32_t cl, cr, first;
-		if (s < GC_SLOTS) {
-			cl = s_cl[s];
-			cr = s_cr[s];
-			first = s_first[s];
-		} else {
-			cl = s_z[0];
-			cr = s_z[1];
-			first = s_z[2];
+
+	uint32_t leaf = blockIdx.x;
+	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+	gc_batch b;
+	if (leaf < a.nleaves) {
+		l0 = a.off_l[leaf];
+		l1 = a.off_l[leaf + 1];
+		if (HAS_R) {
+			r0 = a.off_r[leaf];
+			r1 = a.off_r[leaf + 1];
 		}
-		if (cl && (!HAS_R || cr)) {
-			const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
-			a.dense_cnt[first] = (int64_t)c;
-			mine += c;
+		gc_prefetch<HAS_R>(a, l0, l1, r0, r1, b);
+	}
+	while (leaf < a.nleaves) {
+		const uint32_t next = leaf + gridDim.x;
+		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
+		if (next < a.nleaves) {		/* offsets of the next leaf: in flight during this leaf */
+			nl0 = a.off_l[next];
+			nl1 = a.off_l[next + 1];
+			if (HAS_R) {
+				nr0 = a.off_r[next];
+				nr1 = a.off_r[next + 1];
+			}
 		}
+		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
+		if (live) {
+			for (uint32_t s = threadIdx.x; s < GC_SLOTS; s += LEAF_THREADS) {
+				s_key[s] = 0ull;
+				s_cl[s] = 0;
+				s_cr[s] = 0;
+				s_first[s] = 0xFFFFFFFFu;
+			}
+			if (threadIdx.x < 4)
+				s_z[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;
+			__syncthreads();
+
+			/* build: left side (first batch already in registers) */
+			for (uint32_t base = l0; base < l1; base += LEAF_THREADS * LEAF_BATCH) {
+				if (base != l0) {
+#pragma unroll
+					for (int u = 0; u < LEAF_BATCH; u++) {
+						const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+						b.hv_l[u] = 0;
+						b.rid_l[u] = 0;
+						if (i < l1) {
+							b.hv_l[u] = a.hv_l[i];
+							b.rid_l[u] = a.rid_l[i];
+						}
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < LEAF_BATCH; u++) {
+					const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+					if (i >= l1)
+						continue;
+					if (b.hv_l[u] == 0) {
+						atomicAdd(&s_z[0], 1u);
+						atomicMin(&s_z[2], b.rid_l[u]);
+					} else {
+						const uint32_t s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u]);
+						if (s == 0xFFFFFFFFu) {
+							atomicOr(a.status, 1u);
+						} else {
+							atomicAdd(&s_cl[s], 1u);
+							atomicMin(&s_first[s], b.rid_l[u]);
+						}
+					}
+				}
+			}
+			__syncthreads();
+
+			/* probe: right side */
+			if (HAS_R) {
+				for (uint32_t base = r0; base < r1; base += LEAF_THREADS * LEAF_BATCH) {
+					if (base != r0) {
+#pragma unroll
+						for (int u = 0; u < LEAF_BATCH; u++) {
+							const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+							b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < LEAF_BATCH; u++) {
+						const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+						if (j >= r1)
+							continue;
+						if (b.hv_r[u] == 0) {
+							atomicAdd(&s_z[1], 1u);
+						} else {
+							const uint32_t s = leaf_find(s_key, GC_SLOTS, b.hv_r[u]);
+							if (s != 0xFFFFFFFFu)
+								atomicAdd(&s_cr[s], 1u);
+						}
+					}
+				}
+				__syncthreads();
+			}
+		}
+
+		/* request the next leaf's first batches now: they travel while this leaf is emitted */
+		if (next < a.nleaves)
+			gc_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, b);
+
+		if (live) {
+			/* emit: one COUNT(*) per group at the group's first left position */
+			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += LEAF_THREADS) {
+				uint32_t cl, cr, first;
+				if (s < GC_SLOTS) {
+					cl = s_cl[s];
+					cr = s_cr[s];
+					first = s_first[s];
+				} else {
+					cl = s_z[0];
+					cr = s_z[1];
+					first = s_z[2];
+				}
+				if (cl && (!HAS_R || cr)) {
+					const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
+					a.dense_cnt[first] = (int64_t)c;
+					mine += c;
+				}
+			}
+			__syncthreads();	/* tables are re-initialised by the next iteration */
+		}
+		leaf = next;
+		l0 = nl0;
+		l1 = nl1;
+		r0 = nr0;
+		r1 = nr1;
 	}
 	if (mine)
 		atomicAdd(&s_sum, mine);
@@ -286,10 +348,16 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	a.dense_cnt = dense;
 	a.joined = d_joined;
 	a.status = ctx->d_status;
-	if (has_r) {
-		MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, pl.nleaves, LEAF_THREADS, a);
-	} else {
-		MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, pl.nleaves, LEAF_THREADS, a);
+	a.nleaves = pl.nleaves;
+	{
+		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
+		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
+		if (has_r) {
+			MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, grid, LEAF_THREADS, a);
+		} else {
+			MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, grid, LEAF_THREADS, a);
+		}
 	}
 	if (null_group && null_l) {
 		MDB_HIP(ctx, hipMemsetAsync(d_nullst + 1, 0xFF, 8, ctx->stream));
