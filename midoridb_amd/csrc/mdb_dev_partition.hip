@@ -449,7 +449,8 @@ void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2)
 static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; }
 
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			  bool want_rid, bool stable, uint32_t mode, uint32_t n_dest, bool inverse_out, mdb_part_result *out)
+			  bool want_rid, bool stable, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
+			  mdb_part_result *out)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -460,7 +461,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
 	for (int l = 0; l < nlevels; l++) {
-		hv_buf[l] = (uint64_t *)cv.take((n ? n : 1) * 8);
+		if (l == nlevels - 1 && final_hv_out)
+			hv_buf[l] = final_hv_out;	/* last level writes straight into the caller's buffer */
+		else
+			hv_buf[l] = (uint64_t *)cv.take((n ? n : 1) * 8);
 		if (want_rid)
 			rid_buf[l] = (uint32_t *)cv.take((n ? n : 1) * 4);
 	}
@@ -573,7 +577,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, false, MDB_DIGIT_RADIX, 0, false, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, false, MDB_DIGIT_RADIX, 0, false, NULL, NULL);
 	return cv.bytes + 4096;
 }
 
@@ -588,7 +592,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "stable partitioning is only built with row ids");
 	if ((uintptr_t)keys & 15)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
-	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, stable, MDB_DIGIT_RADIX, 0, false, out);
+	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, stable, MDB_DIGIT_RADIX, 0, false, NULL, out);
 }
 
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
@@ -605,23 +609,19 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
 	 * original keys written back through the inverse hash) */
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, NULL);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, &res);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, &res);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
 	MDB_HIP(ctx, hipMemcpyAsync(h_off, res.leaf_off, ((size_t)n_dest + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint64_t total = h_off[n_dest];
-	if (total)
-		MDB_HIP(ctx, hipMemcpyAsync(out_keys, res.hv, total * 8, hipMemcpyDeviceToDevice, ctx->stream));
 	for (uint32_t d = 0; d < n_dest; d++)
 		out_counts[d] = (uint64_t)h_off[d + 1] - h_off[d];
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MIDORIDB_OK;
 }
