@@ -23,8 +23,9 @@
 
 /* ------------------------------------------------------------------ shared leaf helpers */
 
-#define LEAF_THREADS 512
-#define LEAF_BATCH 4		/* keys loaded per thread before the first is consumed */
+#define LEAF_THREADS 512		/* pairs-join leaf kernels */
+#define GC_THREADS 1024		/* group-count leaf kernel: 16 waves x 2 workgroups = 32 waves/CU hide the LDS probe latency */
+#define LEAF_BATCH 2		/* keys loaded per thread before the first is consumed */
 #define GC_SLOTS 3840u		/* group-count table: 20 B/slot -> 75 KiB, two workgroups per CU */
 #define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
 #define PJ_SLOTS 2048u		/* pairs table */
@@ -97,7 +98,7 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 {
 #pragma unroll
 	for (int u = 0; u < LEAF_BATCH; u++) {
-		const uint32_t i = l0 + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+		const uint32_t i = l0 + (uint32_t)u * GC_THREADS + threadIdx.x;
 		b.hv_l[u] = 0;
 		b.rid_l[u] = 0;
 		if (i < l1) {
@@ -105,22 +106,29 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 			b.rid_l[u] = a.rid_l[i];
 		}
 		if (HAS_R) {
-			const uint32_t j = r0 + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
 			b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
 		}
 	}
 }
 
 template <bool HAS_R>
-__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
+__global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 {
+	/* slot = hashed key (0 = empty) + packed counters (low 32 bits: left rows, high 32 bits: right rows)
+	 * + first left row id.  The tables are zeroed once; afterwards the emit pass clears exactly the slots
+	 * it reads as occupied, which halves the LDS traffic of a clear-everything-per-leaf loop. */
 	__shared__ unsigned long long s_key[GC_SLOTS];
-	__shared__ uint32_t s_cl[GC_SLOTS];
-	__shared__ uint32_t s_cr[GC_SLOTS];
-	__shared__ uint32_t s_first[GC_SLOTS];
-	__shared__ uint32_t s_z[4];		/* the key with hash 0: [0]=cntL [1]=cntR [2]=first */
+	__shared__ unsigned long long s_cnt[GC_SLOTS + 1];	/* [GC_SLOTS] = the key whose hash is 0 */
+	__shared__ uint32_t s_first[GC_SLOTS + 1];
 	__shared__ unsigned long long s_sum;
 
+	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+		if (s < GC_SLOTS)
+			s_key[s] = 0ull;
+		s_cnt[s] = 0ull;
+		s_first[s] = 0xFFFFFFFFu;
+	}
 	if (threadIdx.x == 0)
 		s_sum = 0ull;
 	unsigned long long mine = 0;
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 		}
 		gc_prefetch<HAS_R>(a, l0, l1, r0, r1, b);
 	}
+	__syncthreads();
 	while (leaf < a.nleaves) {
 		const uint32_t next = leaf + gridDim.x;
 		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
@@ -150,22 +159,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 		}
 		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
 		if (live) {
-			for (uint32_t s = threadIdx.x; s < GC_SLOTS; s += LEAF_THREADS) {
-				s_key[s] = 0ull;
-				s_cl[s] = 0;
-				s_cr[s] = 0;
-				s_first[s] = 0xFFFFFFFFu;
-			}
-			if (threadIdx.x < 4)
-				s_z[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;
-			__syncthreads();
-
 			/* build: left side (first batch already in registers) */
-			for (uint32_t base = l0; base < l1; base += LEAF_THREADS * LEAF_BATCH) {
+			for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
 				if (base != l0) {
 #pragma unroll
 					for (int u = 0; u < LEAF_BATCH; u++) {
-						const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+						const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 						b.hv_l[u] = 0;
 						b.rid_l[u] = 0;
 						if (i < l1) {
@@ -176,20 +175,17 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 				}
 #pragma unroll
 				for (int u = 0; u < LEAF_BATCH; u++) {
-					const uint32_t i = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 					if (i >= l1)
 						continue;
-					if (b.hv_l[u] == 0) {
-						atomicAdd(&s_z[0], 1u);
-						atomicMin(&s_z[2], b.rid_l[u]);
+					uint32_t s = GC_SLOTS;
+					if (b.hv_l[u] != 0)
+						s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u]);
+					if (s == 0xFFFFFFFFu) {
+						atomicOr(a.status, 1u);
 					} else {
-						const uint32_t s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u]);
-						if (s == 0xFFFFFFFFu) {
-							atomicOr(a.status, 1u);
-						} else {
-							atomicAdd(&s_cl[s], 1u);
-							atomicMin(&s_first[s], b.rid_l[u]);
-						}
+						atomicAdd(&s_cnt[s], 1ull);
+						atomicMin(&s_first[s], b.rid_l[u]);
 					}
 				}
 			}
@@ -197,26 +193,24 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 
 			/* probe: right side */
 			if (HAS_R) {
-				for (uint32_t base = r0; base < r1; base += LEAF_THREADS * LEAF_BATCH) {
+				for (uint32_t base = r0; base < r1; base += GC_THREADS * LEAF_BATCH) {
 					if (base != r0) {
 #pragma unroll
 						for (int u = 0; u < LEAF_BATCH; u++) {
-							const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+							const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 							b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
 						}
 					}
 #pragma unroll
 					for (int u = 0; u < LEAF_BATCH; u++) {
-						const uint32_t j = base + (uint32_t)u * LEAF_THREADS + threadIdx.x;
+						const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 						if (j >= r1)
 							continue;
-						if (b.hv_r[u] == 0) {
-							atomicAdd(&s_z[1], 1u);
-						} else {
-							const uint32_t s = leaf_find(s_key, GC_SLOTS, b.hv_r[u]);
-							if (s != 0xFFFFFFFFu)
-								atomicAdd(&s_cr[s], 1u);
-						}
+						uint32_t s = GC_SLOTS;
+						if (b.hv_r[u] != 0)
+							s = leaf_find(s_key, GC_SLOTS, b.hv_r[u]);
+						if (s != 0xFFFFFFFFu)
+							atomicAdd(&s_cnt[s], 1ull << 32);
 					}
 				}
 				__syncthreads();
@@ -228,25 +222,27 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_group_count(gc_args a)
 			gc_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, b);
 
 		if (live) {
-			/* emit: one COUNT(*) per group at the group's first left position */
-			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += LEAF_THREADS) {
-				uint32_t cl, cr, first;
+			/* emit one COUNT(*) per group at the group's first left position, and clear the slot */
+			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+				const unsigned long long c2 = s_cnt[s];
 				if (s < GC_SLOTS) {
-					cl = s_cl[s];
-					cr = s_cr[s];
-					first = s_first[s];
-				} else {
-					cl = s_z[0];
-					cr = s_z[1];
-					first = s_z[2];
+					if (s_key[s] == 0ull)
+						continue;
+					s_key[s] = 0ull;
+				} else if (c2 == 0ull) {
+					continue;
 				}
+				const uint32_t cl = (uint32_t)c2, cr = (uint32_t)(c2 >> 32);
+				const uint32_t first = s_first[s];
+				s_cnt[s] = 0ull;
+				s_first[s] = 0xFFFFFFFFu;
 				if (cl && (!HAS_R || cr)) {
 					const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
 					a.dense_cnt[first] = (int64_t)c;
 					mine += c;
 				}
 			}
-			__syncthreads();	/* tables are re-initialised by the next iteration */
+			__syncthreads();	/* the next leaf builds into the cleared tables */
 		}
 		leaf = next;
 		l0 = nl0;
@@ -354,9 +350,9 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
 		if (has_r) {
-			MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, grid, LEAF_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, grid, GC_THREADS, a);
 		} else {
-			MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, grid, LEAF_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, grid, GC_THREADS, a);
 		}
 	}
 	if (null_group && null_l) {
