@@ -175,6 +175,24 @@ def main():
         step()
     prof = dev.prof_read()
     dev.prof_enable(False)
+    # practical HBM ceiling of this box: device-to-device copy of one key column (read + write)
+    copy_gbs = None
+    try:
+        src = a
+        dst = torch.empty_like(a)
+        for _ in range(2):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del dst
+    except Exception:
+        pass
 
     if rank == 0:
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
@@ -189,7 +207,8 @@ def main():
             bytes_per_launch = shuffle.algorithmic_bytes(dom_name, n, world, kern)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "d2d_copy_GBs": copy_gbs,
+                    "frac_of_d2d_copy": (achieved / copy_gbs) if copy_gbs else None,
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch}
         # whole-pipeline view: the bytes any correct algorithm must move once
         algo_bytes = 8 * 2 * total_rows + 16 * groups_total

@@ -53,6 +53,9 @@ int mdb_dev_device_count(void);
 /* Pre-size the internal scratch arena (bytes).  Operators grow it on demand; growing
  * synchronises and reallocates, so benchmarks call this (or one warm-up) first. */
 int mdb_dev_reserve(mdb_dev_ctx *ctx, size_t bytes);
+/* When on, the two tables of a join are partitioned concurrently on two HIP streams.  Default off:
+ * measured on MI355X it does not shorten the single-GPU pipeline (every kernel already fills the chip). */
+int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory */

@@ -23,8 +23,11 @@ struct mdb_prof_rec {
 struct mdb_dev_ctx {
 	int device;
 	int num_cus;			/* compute units of the device (256 on MI355X) */
-	hipStream_t stream;
+	hipStream_t stream;		/* stream every operator launches on */
 	bool own_stream;
+	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
+	hipEvent_t ev_fork, ev_join;
+	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
 	char err[512];
 	/* scratch arena (grow-only, bump allocated per operator) */
 	char *arena;
@@ -56,6 +59,12 @@ int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
 int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes);
 void *mdb_arena_take(mdb_dev_ctx *ctx, size_t bytes);
 static inline size_t mdb_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+/* run the following launches on the auxiliary stream (after everything queued so far on the main
+ * stream), and come back; between the two calls ctx->stream IS the auxiliary stream */
+int mdb_aux_begin(mdb_dev_ctx *ctx, hipStream_t *saved_main);
+int mdb_aux_end(mdb_dev_ctx *ctx, hipStream_t saved_main);	/* back to the main stream; marks the end of the aux work */
+int mdb_aux_join(mdb_dev_ctx *ctx);				/* main stream waits for the marked aux work */
 
 /* profiling hooks around one launch */
 void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name);

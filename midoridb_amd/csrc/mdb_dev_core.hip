@@ -63,6 +63,15 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 		ctx->stream = (hipStream_t)stream;	/* NULL = the device's default stream */
 		ctx->own_stream = false;
 	}
+	ctx->aux_stream = NULL;
+	ctx->ev_fork = ctx->ev_join = NULL;
+	ctx->overlap = false;	/* measured: no gain on one GPU (each kernel already fills the chip), kept for the multi-GPU exchange */
+	if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+		mdb_dev_ctx_destroy(ctx);
+		return -MIDORIDB_INTERNAL;
+	}
 	if (hipMalloc((void **)&ctx->d_status, 64 * sizeof(uint64_t)) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->h_pinned, 1024 * sizeof(uint64_t)) != hipSuccess ||
 	    hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint64_t), ctx->stream) != hipSuccess) {
@@ -83,6 +92,14 @@ extern "C" void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx)
 		(void)hipEventDestroy(p.first);
 		(void)hipEventDestroy(p.second);
 	}
+	if (ctx->aux_stream) {
+		(void)hipStreamSynchronize(ctx->aux_stream);
+		(void)hipStreamDestroy(ctx->aux_stream);
+	}
+	if (ctx->ev_fork)
+		(void)hipEventDestroy(ctx->ev_fork);
+	if (ctx->ev_join)
+		(void)hipEventDestroy(ctx->ev_join);
 	if (ctx->arena)
 		(void)hipFree(ctx->arena);
 	if (ctx->d_status)
@@ -120,6 +137,43 @@ extern "C" const char *mdb_dev_last_error(mdb_dev_ctx *ctx)
 extern "C" int mdb_dev_sync(mdb_dev_ctx *ctx)
 {
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ two-stream fork / join */
+
+extern "C" int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on)
+{
+	ctx->overlap = on != 0;
+	return MIDORIDB_OK;
+}
+
+int mdb_aux_begin(mdb_dev_ctx *ctx, hipStream_t *saved_main)
+{
+	*saved_main = ctx->stream;
+	if (!ctx->overlap)
+		return MIDORIDB_OK;
+	MDB_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+	MDB_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+	ctx->stream = ctx->aux_stream;
+	return MIDORIDB_OK;
+}
+
+int mdb_aux_end(mdb_dev_ctx *ctx, hipStream_t saved_main)
+{
+	if (!ctx->overlap)
+		return MIDORIDB_OK;
+	hipStream_t aux = ctx->stream;
+	ctx->stream = saved_main;
+	MDB_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
+	return MIDORIDB_OK;
+}
+
+int mdb_aux_join(mdb_dev_ctx *ctx)
+{
+	if (!ctx->overlap)
+		return MIDORIDB_OK;
+	MDB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
 	return MIDORIDB_OK;
 }
 

@@ -317,14 +317,25 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 
 	mdb_part_result pl, pr;
 	memset(&pr, 0, sizeof(pr));
+	/* the two tables are independent until the leaf kernel: partition the right one on the auxiliary
+	 * stream so its kernels fill the tails and latency bubbles of the left one's */
+	hipStream_t main_stream = NULL;
+	if (has_r) {
+		rc = mdb_aux_begin(ctx, &main_stream);
+		if (rc)
+			return rc;
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, &pr);
+		int rc2 = mdb_aux_end(ctx, main_stream);
+		if (rc)
+			return rc;
+		if (rc2)
+			return rc2;
+	}
 	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
 	if (rc)
 		return rc;
-	if (has_r) {
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, &pr);
-		if (rc)
-			return rc;
-	}
+	if (has_r && (rc = mdb_aux_join(ctx)))	/* the leaf kernel needs both tables */
+		return rc;
 	int64_t *dense = (int64_t *)mdb_arena_take(ctx, n_l * 8);
 	uint32_t *sel = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
 	if (!dense || !sel)
@@ -617,13 +628,25 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	if (rc)
 		return rc;
 	mdb_part_result pl, pr;
+	/* right side stable: inside a leaf its rows stay in ascending row-id order, which the chunked emit
+	 * relies on (a key's row ids in a later chunk are all larger than those of an earlier chunk).
+	 * It is partitioned on the auxiliary stream, concurrently with the left table. */
+	hipStream_t main_stream = NULL;
+	rc = mdb_aux_begin(ctx, &main_stream);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, &pr);
+	{
+		int rc2 = mdb_aux_end(ctx, main_stream);
+		if (rc)
+			return rc;
+		if (rc2)
+			return rc2;
+	}
 	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
 	if (rc)
 		return rc;
-	/* right side stable: inside a leaf its rows stay in ascending row-id order, which the chunked emit
-	 * relies on (a key's row ids in a later chunk are all larger than those of an earlier chunk) */
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, &pr);
-	if (rc)
+	if ((rc = mdb_aux_join(ctx)))
 		return rc;
 	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
 	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
