@@ -26,20 +26,24 @@ enum mdb_digit_mode {
 struct mdb_part_result {
 	uint64_t *hv;		/* hashed keys grouped by leaf (or original keys when inverse_out) */
 	uint32_t *rid;		/* row ids, same order (NULL when not requested) */
-	uint32_t *leaf_off;	/* nleaves + 1 offsets into hv/rid */
+	uint32_t *leaf_off;	/* exact form: nleaves + 1 offsets into hv/rid (NULL in the fast form) */
+	uint32_t *leaf_cnt;	/* fast form: rows of each leaf, leaf i lives at [i * leaf_cap, i * leaf_cap + leaf_cnt[i]) */
+	uint32_t leaf_cap;	/* 0 = exact form */
 	uint32_t nleaves;
 	uint32_t bits_total;
 };
 
 /* bytes of arena needed by mdb_partition_table() */
-size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid);
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast);
 
 /* Partition one key column into 2^(bits1+bits2) leaves by the top bits of fmix64(key), dropping
  * NULL keys.  stable = keep input order inside every leaf (slower ballot ranking; requires want_rid),
- * otherwise the order inside a leaf is unspecified.  All temporaries and outputs are carved from the
- * arena (caller has called mdb_arena_begin with enough room).  No host sync. */
+ * otherwise the order inside a leaf is unspecified.  fast = skip the second level's histogram pass: every
+ * leaf gets a fixed-capacity region and runs are placed with atomic cursors; if a leaf overflows, bit 1 of
+ * ctx->d_status[0] is set and the caller must redo the operator with fast = false.  All temporaries and
+ * outputs are carved from the arena (caller has called mdb_arena_begin with enough room).  No host sync. */
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			int bits1, int bits2, bool want_rid, bool stable, mdb_part_result *out);
+			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out);
 
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);

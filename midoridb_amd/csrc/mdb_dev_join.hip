@@ -71,9 +71,13 @@ __device__ static inline uint32_t leaf_find(const unsigned long long *keys, uint
 struct gc_args {
 	const uint64_t *hv_l;
 	const uint32_t *rid_l;
-	const uint32_t *off_l;
+	const uint32_t *off_l;		/* exact leaf offsets, or ... */
+	const uint32_t *cnt_l;		/* ... rows per leaf of the fixed-capacity (fast) layout */
+	uint32_t cap_l;			/* 0 = exact offsets */
 	const uint64_t *hv_r;		/* NULL: plain GROUP BY over the left stream */
 	const uint32_t *off_r;
+	const uint32_t *cnt_r;
+	uint32_t cap_r;
 	int64_t *dense_cnt;		/* [n_l], zeroed: COUNT(*) written at the group's first L position */
 	unsigned long long *joined;	/* sum of all counts */
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
@@ -92,6 +96,19 @@ struct gc_batch {
 	uint32_t rid_l[LEAF_BATCH];
 	uint64_t hv_r[LEAF_BATCH];
 };
+
+__device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t *cnt, uint32_t cap, uint32_t leaf, uint32_t *b,
+					    uint32_t *e)
+{
+	if (cap) {
+		const uint32_t c = cnt[leaf];
+		*b = leaf * cap;
+		*e = *b + (c < cap ? c : cap);
+	} else {
+		*b = off[leaf];
+		*e = off[leaf + 1];
+	}
+}
 
 template <bool HAS_R>
 __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, gc_batch &b)
@@ -137,25 +154,19 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
 	gc_batch b;
 	if (leaf < a.nleaves) {
-		l0 = a.off_l[leaf];
-		l1 = a.off_l[leaf + 1];
-		if (HAS_R) {
-			r0 = a.off_r[leaf];
-			r1 = a.off_r[leaf + 1];
-		}
+		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+		if (HAS_R)
+			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
 		gc_prefetch<HAS_R>(a, l0, l1, r0, r1, b);
 	}
 	__syncthreads();
 	while (leaf < a.nleaves) {
 		const uint32_t next = leaf + gridDim.x;
 		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
-		if (next < a.nleaves) {		/* offsets of the next leaf: in flight during this leaf */
-			nl0 = a.off_l[next];
-			nl1 = a.off_l[next + 1];
-			if (HAS_R) {
-				nr0 = a.off_r[next];
-				nr1 = a.off_r[next + 1];
-			}
+		if (next < a.nleaves) {		/* range of the next leaf: in flight during this leaf */
+			gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, next, &nl0, &nl1);
+			if (HAS_R)
+				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
 		}
 		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
 		if (live) {
@@ -294,10 +305,12 @@ __global__ void k_null_poke(const unsigned long long *cnt_first, int64_t *dense_
 
 /* ------------------------------------------------------------------ group-count drivers */
 
-static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
-			      const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group,
-			      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
-			      uint64_t *out_joined)
+#define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
+
+static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
+			   int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   uint64_t *out_joined)
 {
 	*out_groups = 0;
 	if (out_joined)
@@ -307,9 +320,9 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 
 	int b1, b2;
 	mdb_choose_bits(n_l, GC_TARGET, &b1, &b2);
-	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true);
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast);
 	if (has_r)
-		need += mdb_partition_arena_bytes(n_r, b1, b2, false);
+		need += mdb_partition_arena_bytes(n_r, b1, b2, false, fast);
 	need += mdb_align_up(n_l * 8) + mdb_align_up(n_l * 4) + mdb_filter_arena_bytes(n_l) + 4096;
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
@@ -317,6 +330,9 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 
 	mdb_part_result pl, pr;
 	memset(&pr, 0, sizeof(pr));
+	/* d_status words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow),
+	 * [2..3] joined-row total (u64), [4..7] NULL-group stats (2 x u64) */
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
 	/* the two tables are independent until the leaf kernel: partition the right one on the auxiliary
 	 * stream so its kernels fill the tails and latency bubbles of the left one's */
 	hipStream_t main_stream = NULL;
@@ -324,14 +340,14 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		rc = mdb_aux_begin(ctx, &main_stream);
 		if (rc)
 			return rc;
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, &pr);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, fast, &pr);
 		int rc2 = mdb_aux_end(ctx, main_stream);
 		if (rc)
 			return rc;
 		if (rc2)
 			return rc2;
 	}
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, fast, &pl);
 	if (rc)
 		return rc;
 	if (has_r && (rc = mdb_aux_join(ctx)))	/* the leaf kernel needs both tables */
@@ -340,18 +356,20 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	uint32_t *sel = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
 	if (!dense || !sel)
 		return -MIDORIDB_INTERNAL;
-	/* d_status words: [0] overflow flag, [2..3] joined-row total (u64), [4..7] NULL-group stats (2 x u64) */
 	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
 	unsigned long long *d_nullst = (unsigned long long *)(ctx->d_status + 4);
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
 	MDB_HIP(ctx, hipMemsetAsync(dense, 0, n_l * 8, ctx->stream));
 
 	gc_args a;
 	a.hv_l = pl.hv;
 	a.rid_l = pl.rid;
 	a.off_l = pl.leaf_off;
+	a.cnt_l = pl.leaf_cnt;
+	a.cap_l = pl.leaf_cap;
 	a.hv_r = pr.hv;
 	a.off_r = pr.leaf_off;
+	a.cnt_r = pr.leaf_cnt;
+	a.cap_r = pr.leaf_cap;
 	a.dense_cnt = dense;
 	a.joined = d_joined;
 	a.status = ctx->d_status;
@@ -384,6 +402,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const uint64_t G = (uint32_t)h[0];
 	const uint32_t status = (uint32_t)h[1];
+	if (status & 2u)
+		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if (status & 1u)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
 				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", GC_SLOTS);
@@ -407,6 +427,21 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	if (out_joined)
 		*out_joined = h[2];
 	return MIDORIDB_OK;
+}
+
+static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+			      const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group,
+			      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			      uint64_t *out_joined)
+{
+	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
+	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
+	int rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, true, out_key, out_count,
+				 out_first, cap, out_groups, out_joined);
+	if (rc == GC_RETRY_EXACT)
+		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, false, out_key, out_count,
+				     out_first, cap, out_groups, out_joined);
+	return rc;
 }
 
 extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
@@ -622,7 +657,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	int b1, b2;
 	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
 	const uint64_t mlen = n_l + 1;
-	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true) + mdb_partition_arena_bytes(n_r, b1, b2, true) +
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, false) + mdb_partition_arena_bytes(n_r, b1, b2, true, false) +
 		      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
@@ -635,7 +670,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	rc = mdb_aux_begin(ctx, &main_stream);
 	if (rc)
 		return rc;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, &pr);
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, false, &pr);
 	{
 		int rc2 = mdb_aux_end(ctx, main_stream);
 		if (rc)
@@ -643,7 +678,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 		if (rc2)
 			return rc2;
 	}
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, &pl);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, false, &pl);
 	if (rc)
 		return rc;
 	if ((rc = mdb_aux_join(ctx)))

@@ -39,6 +39,7 @@ struct mdb_tile_desc {
 	uint32_t len;		/* elements in the tile (0 = unused tile) */
 	uint32_t hbase;		/* histogram index of (segment, digit 0, this tile) */
 	uint32_t nt;		/* tiles in this tile's segment = histogram stride between digits */
+	uint32_t seg;		/* index of the segment (parent partition) the tile belongs to */
 };
 
 struct mdb_level_args {
@@ -60,6 +61,10 @@ struct mdb_level_args {
 	uint32_t mbits;			/* bits needed to tell digits apart (ballot rounds of the STABLE form) */
 	uint32_t mode;			/* enum mdb_digit_mode */
 	uint32_t inverse_out;		/* write fmix64^-1(hv) (= the original key) instead of hv */
+	/* FAST (histogram-free) form: child (seg, digit) owns the fixed-capacity region [child*cap, child*cap+cap) */
+	uint32_t *cursor;		/* per child: elements placed so far (zeroed before the launch) */
+	uint32_t cap;
+	uint32_t *status;		/* bit 1 set when a child overflowed its region */
 };
 
 __device__ static inline uint32_t part_digit(const mdb_level_args &a, uint64_t hv)
@@ -81,7 +86,7 @@ __device__ static inline mdb_tile_desc part_get_tile(const mdb_level_args &a, ui
 {
 	mdb_tile_desc d;
 	if (t >= a.ntiles) {
-		d.start = d.len = d.hbase = d.nt = 0;
+		d.start = d.len = d.hbase = d.nt = d.seg = 0;
 		return d;
 	}
 	if (a.tiles)
@@ -91,6 +96,7 @@ __device__ static inline mdb_tile_desc part_get_tile(const mdb_level_args &a, ui
 	d.len = start < a.n ? (uint32_t)((a.n - start) < MDB_TILE ? (a.n - start) : MDB_TILE) : 0;
 	d.hbase = t;
 	d.nt = a.ntiles;
+	d.seg = 0;
 	return d;
 }
 
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
 	__shared__ uint64_t s_hv[MDB_TILE];
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	__shared__ uint32_t s_cnt[PART_MAX_R];		/* per-digit counters, then tile-local digit starts */
 	__shared__ int32_t s_delta[PART_MAX_R];	/* global start of the digit's run minus its tile-local start */
 	__shared__ uint32_t s_wcnt[STABLE ? PART_WAVES * PART_MAX_R : 1];	/* STABLE: per-wave digit counts, then bases */
+	__shared__ uint8_t s_ok[FAST ? PART_MAX_R : 1];			/* FAST: the digit's run fits its region */
 	__shared__ uint32_t s_tmp[32];
 
 	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
@@ -307,7 +314,19 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	const uint32_t off_d = mdb_block_excl_scan(total_d, s_tmp, &tile_total);
 	if (threadIdx.x < R) {
 		s_cnt[threadIdx.x] = off_d;
-		s_delta[threadIdx.x] = (int32_t)(a.hist[(uint64_t)td.hbase + (uint64_t)threadIdx.x * td.nt] - off_d);
+		if (FAST) {
+			/* no histogram pass: reserve the run's place in the child's fixed-capacity region with one
+			 * global atomic per (tile, digit) - ~96 tiles share a cursor, contention is negligible */
+			const uint32_t child = td.seg * R + threadIdx.x;
+			const uint32_t base = total_d ? atomicAdd(&a.cursor[child], total_d) : 0u;
+			const bool ok = base + total_d <= a.cap;
+			if (!ok)
+				atomicOr(a.status, 2u);
+			s_ok[threadIdx.x] = ok;
+			s_delta[threadIdx.x] = (int32_t)(child * a.cap + base - off_d);
+		} else {
+			s_delta[threadIdx.x] = (int32_t)(a.hist[(uint64_t)td.hbase + (uint64_t)threadIdx.x * td.nt] - off_d);
+		}
 	}
 	__syncthreads();
 
@@ -328,7 +347,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	/* 5. write out: consecutive threads write consecutive addresses inside each digit's run */
 	for (uint32_t i = threadIdx.x; i < tile_total; i += PART_THREADS) {
 		const uint64_t h = s_hv[i];
-		const uint32_t g = (uint32_t)((int32_t)i + s_delta[part_digit(a, h)]);
+		const uint32_t d = part_digit(a, h);
+		if (FAST && !s_ok[d])
+			continue;	/* overflowed child: the whole operator is re-run on the exact path */
+		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
 		a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
 		if (HAS_RID)
 			a.rid_out[g] = s_rid[i];
@@ -375,7 +397,7 @@ __global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const
 	if (t >= max_tiles)
 		return;
 	mdb_tile_desc d;
-	d.start = d.len = d.hbase = d.nt = 0;
+	d.start = d.len = d.hbase = d.nt = d.seg = 0;
 	if (t < tb[S]) {
 		/* largest p with tb[p] <= t  (tb is non-decreasing, tb[S] > t) */
 		uint32_t lo = 0, hi = S;
@@ -395,6 +417,7 @@ __global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const
 		d.len = e0 - s0;
 		d.nt = tb[p + 1] - tb[p];
 		d.hbase = tb[p] * R + tl;
+		d.seg = p;
 	}
 	tiles[t] = d;
 }
@@ -448,25 +471,42 @@ void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2)
 
 static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; }
 
+#define PART_F_STABLE 1u	/* keep input order inside every leaf (ballot ranking) */
+#define PART_F_FAST 2u		/* last level without histogram: fixed-capacity leaf regions + atomic cursors */
+
+/* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
+static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
+{
+	const uint64_t avg = (n + nleaves - 1) / nleaves;
+	return (uint32_t)(((avg + avg / 2 + 1024) + 63) & ~63ull);
+}
+
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			  bool want_rid, bool stable, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
+			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
 			  mdb_part_result *out)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
+	const bool stable = flags & PART_F_STABLE;
 	const int nlevels = bits2 > 0 ? 2 : 1;
 	const uint32_t Rl[2] = { mode == MDB_DIGIT_MOD ? n_dest : (1u << bits1), 1u << bits2 };
 	const uint32_t nt0 = n ? (uint32_t)((n + MDB_TILE - 1) / MDB_TILE) : 1u;
+	/* FAST applies to the second level only, and only while leaf * cap stays a 32-bit index */
+	const uint32_t nleaves_total = nlevels == 2 ? Rl[0] * Rl[1] : Rl[0];
+	const uint32_t fast_cap = part_fast_cap(n, nleaves_total);
+	const bool fast = (flags & PART_F_FAST) && !stable && nlevels == 2 && !final_hv_out &&
+			  (uint64_t)nleaves_total * fast_cap < 0xFFFFFFFFull;
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
 	for (int l = 0; l < nlevels; l++) {
+		const uint64_t elems = (fast && l == 1) ? (uint64_t)nleaves_total * fast_cap : (n ? n : 1);
 		if (l == nlevels - 1 && final_hv_out)
 			hv_buf[l] = final_hv_out;	/* last level writes straight into the caller's buffer */
 		else
-			hv_buf[l] = (uint64_t *)cv.take((n ? n : 1) * 8);
+			hv_buf[l] = (uint64_t *)cv.take(elems * 8);
 		if (want_rid)
-			rid_buf[l] = (uint32_t *)cv.take((n ? n : 1) * 4);
+			rid_buf[l] = (uint32_t *)cv.take(elems * 4);
 	}
 
 	/* segments of the current level */
@@ -480,13 +520,65 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 
 	uint32_t ntiles = nt0;
 	const mdb_tile_desc *tiles = NULL;
+	uint32_t *leaf_cnt = NULL;
 	int used_bits = 0;
 	for (int l = 0; l < nlevels; l++) {
 		const uint32_t R = Rl[l];
+		const uint32_t nchild = S * R;
+		const bool fast_level = fast && l == 1;
+		mdb_level_args a;
+		memset(&a, 0, sizeof(a));
+		a.keys = keys;
+		a.nullbits = nullbits;
+		a.n = n;
+		a.hv_in = l ? hv_buf[l - 1] : NULL;
+		a.rid_in = l ? rid_buf[l - 1] : NULL;
+		a.tiles = tiles;
+		a.hv_out = hv_buf[l];
+		a.rid_out = rid_buf[l];
+		a.ntiles = ntiles;
+		a.R = R;
+		a.mode = l == 0 ? mode : MDB_DIGIT_RADIX;
+		a.inverse_out = (inverse_out && l == nlevels - 1) ? 1u : 0u;
+		if (a.mode == MDB_DIGIT_RADIX) {
+			const int b = l == 0 ? bits1 : bits2;
+			a.shift = (uint32_t)(64 - used_bits - b);
+			a.mbits = (uint32_t)b;
+		} else {
+			uint32_t mb = 1;
+			while ((1u << mb) < R)
+				mb++;
+			a.shift = 0;
+			a.mbits = mb;
+		}
+
+		if (fast_level) {
+			/* histogram-free last level: one cursor per leaf, runs placed with global atomics */
+			leaf_cnt = (uint32_t *)cv.take((size_t)nchild * 4);
+			if (cv.failed)
+				return -MIDORIDB_INTERNAL;
+			if (!dry) {
+				a.cursor = leaf_cnt;
+				a.cap = fast_cap;
+				a.status = ctx->d_status;
+				MDB_HIP(ctx, hipMemsetAsync(leaf_cnt, 0, (size_t)nchild * 4, ctx->stream));
+				if (want_rid) {
+					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, true>), grid8(ntiles),
+						   PART_THREADS, a);
+				} else {
+					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
+						   PART_THREADS, a);
+				}
+			}
+			used_bits += bits2;
+			S = nchild;
+			seg_start = NULL;
+			break;
+		}
+
 		const uint64_t hlen = (uint64_t)ntiles * R + 1;
 		uint32_t *hist = (uint32_t *)cv.take(hlen * 4);
 		uint32_t *scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words(hlen) * 4);
-		const uint32_t nchild = S * R;
 		uint32_t *child_start = (uint32_t *)cv.take(((size_t)nchild + 1) * 4);
 		uint32_t *child_nt = (uint32_t *)cv.take(((size_t)nchild + 1) * 4);
 		uint32_t *child_scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words((uint64_t)nchild + 1) * 4);
@@ -499,32 +591,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			return -MIDORIDB_INTERNAL;
 
 		if (!dry) {
-			mdb_level_args a;
-			memset(&a, 0, sizeof(a));
-			a.keys = keys;
-			a.nullbits = nullbits;
-			a.n = n;
-			a.hv_in = l ? hv_buf[l - 1] : NULL;
-			a.rid_in = l ? rid_buf[l - 1] : NULL;
-			a.tiles = tiles;
-			a.hv_out = hv_buf[l];
-			a.rid_out = rid_buf[l];
 			a.hist = hist;
-			a.ntiles = ntiles;
-			a.R = R;
-			a.mode = l == 0 ? mode : MDB_DIGIT_RADIX;
-			a.inverse_out = (inverse_out && l == nlevels - 1) ? 1u : 0u;
-			if (a.mode == MDB_DIGIT_RADIX) {
-				const int b = l == 0 ? bits1 : bits2;
-				a.shift = (uint32_t)(64 - used_bits - b);
-				a.mbits = (uint32_t)b;
-			} else {
-				uint32_t mb = 1;
-				while ((1u << mb) < R)
-					mb++;
-				a.shift = 0;
-				a.mbits = mb;
-			}
 			MDB_HIP(ctx, hipMemsetAsync(hist, 0, hlen * 4, ctx->stream));
 			if (l == 0) {
 				MDB_LAUNCH(ctx, "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
@@ -535,17 +602,17 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			if (rc)
 				return rc;
 			if (stable && l == 0) {
-				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable) {
-				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0 && want_rid) {
-				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0) {
-				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (want_rid) {
-				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, false>), grid8(ntiles), PART_THREADS, a);
 			} else {
-				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, false>), grid8(ntiles), PART_THREADS, a);
 			}
 			MDB_LAUNCH(ctx, "part_children", k_part_children, (nchild + 1 + 255) / 256, 256, hist, tb, S, R, child_start,
 				   child_nt);
@@ -568,21 +635,23 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		out->hv = hv_buf[nlevels - 1];
 		out->rid = rid_buf[nlevels - 1];
 		out->leaf_off = seg_start;
+		out->leaf_cnt = leaf_cnt;
+		out->leaf_cap = fast ? fast_cap : 0;
 		out->nleaves = S;
 		out->bits_total = (uint32_t)used_bits;
 	}
 	return MIDORIDB_OK;
 }
 
-size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid)
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, false, MDB_DIGIT_RADIX, 0, false, NULL, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL);
 	return cv.bytes + 4096;
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			bool want_rid, bool stable, mdb_part_result *out)
+			bool want_rid, bool stable, bool fast, mdb_part_result *out)
 {
 	if (n >= 0xFFFFFFFFull)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "table of %llu rows exceeds the 32-bit row-id limit of one GPU shard",
@@ -592,7 +661,8 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "stable partitioning is only built with row ids");
 	if ((uintptr_t)keys & 15)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
-	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, stable, MDB_DIGIT_RADIX, 0, false, NULL, out);
+	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u),
+			      MDB_DIGIT_RADIX, 0, false, NULL, out);
 }
 
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
@@ -609,13 +679,13 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
 	 * original keys written back through the inverse hash) */
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, false, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, &res);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, &res);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;

@@ -90,6 +90,23 @@ def test_join_group_count_skew(dev):
     assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
 
 
+def test_join_group_count_skew_two_levels_falls_back_to_exact_layout(dev):
+    """A key repeated 300 000 times in a 10^6-row table overflows its fixed-capacity leaf region of the
+    histogram-free layout; the operator must notice and redo the partitioning with exact histograms."""
+    rng = np.random.default_rng(21)
+    kl = np.concatenate([np.full(300_000, 7), rng.integers(0, 10**9, 700_000)]).astype(np.int64)
+    kr = np.concatenate([np.full(200_000, 7), rng.integers(0, 10**9, 600_000), kl[300_000:500_000]]).astype(np.int64)
+    rng.shuffle(kl)
+    rng.shuffle(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), None, dev.to_dev(kr), None)
+    assert j == ej
+    assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
+    g_f, g_c = dev.group_count(dev.to_dev(kl), None)
+    e_f, e_c = orc.group_count(kl, None)
+    assert np.array_equal(_np(g_f).astype(np.int64), e_f) and np.array_equal(_np(g_c), e_c)
+
+
 @pytest.mark.parametrize("n,domain,null_frac", [(1, 1, 0.0), (10, 3, 0.5), (65, 7, 0.3), (5000, 50, 0.1),
                                                   (100_000, 100_000, 0.0), (1_500_000, 400_000, 0.05)])
 def test_group_count(dev, n, domain, null_frac):
