@@ -25,6 +25,7 @@
 
 #define LEAF_THREADS 512		/* pairs-join leaf kernels */
 #define GC_THREADS 1024		/* group-count leaf kernel: 16 waves x 2 workgroups = 32 waves/CU hide the LDS probe latency */
+#define GC_EMIT_ITERS ((GC_SLOTS + 1 + GC_THREADS - 1) / GC_THREADS)	/* table slots visited per thread */
 #define LEAF_BATCH 2		/* keys loaded per thread before the first is consumed */
 #define GC_SLOTS 3840u		/* group-count table: 20 B/slot -> 75 KiB, two workgroups per CU */
 #define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
@@ -78,7 +79,10 @@ struct gc_args {
 	const uint32_t *off_r;
 	const uint32_t *cnt_r;
 	uint32_t cap_r;
-	int64_t *dense_cnt;		/* [n_l], zeroed: COUNT(*) written at the group's first L position */
+	int64_t *dense_cnt;		/* dense mode: [n_l], zeroed: COUNT(*) written at the group's first L position */
+	unsigned long long *rec;	/* record mode: one 64-bit record per group, (first << (64 - kbits)) | COUNT(*) */
+	uint32_t *rec_count;		/* record mode: number of records written so far */
+	uint32_t kbits;			/* record mode: bits of a left row id (0 = dense mode) */
 	unsigned long long *joined;	/* sum of all counts */
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
 	uint32_t nleaves;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 	__shared__ unsigned long long s_cnt[GC_SLOTS + 1];	/* [GC_SLOTS] = the key whose hash is 0 */
 	__shared__ uint32_t s_first[GC_SLOTS + 1];
 	__shared__ unsigned long long s_sum;
+	__shared__ uint32_t s_scan[32];
 
 	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
 		if (s < GC_SLOTS)
@@ -233,8 +238,18 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			gc_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, b);
 
 		if (live) {
-			/* emit one COUNT(*) per group at the group's first left position, and clear the slot */
-			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+			/* emit one COUNT(*) per group and clear the slot.  Record mode: the groups of this leaf are
+			 * appended to one global list (a single atomic per leaf reserves the space) and ordered
+			 * afterwards by a radix sort on the first row id; dense mode: COUNT(*) is scattered to the
+			 * group's first row position (8-byte random writes, only kept as a fallback). */
+			uint64_t recv[GC_EMIT_ITERS];
+			uint32_t nrec = 0;
+#pragma unroll
+			for (int it = 0; it < GC_EMIT_ITERS; it++) {
+				const uint32_t s = threadIdx.x + (uint32_t)it * GC_THREADS;
+				recv[it] = 0;
+				if (s > GC_SLOTS)
+					continue;
 				const unsigned long long c2 = s_cnt[s];
 				if (s < GC_SLOTS) {
 					if (s_key[s] == 0ull)
@@ -249,9 +264,28 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 				s_first[s] = 0xFFFFFFFFu;
 				if (cl && (!HAS_R || cr)) {
 					const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
-					a.dense_cnt[first] = (int64_t)c;
 					mine += c;
+					if (a.kbits) {
+						if (c >> (64 - a.kbits))
+							atomicOr(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+						recv[it] = ((unsigned long long)first << (64 - a.kbits)) | c;
+						nrec++;
+					} else {
+						a.dense_cnt[first] = (int64_t)c;
+					}
 				}
+			}
+			if (a.kbits) {
+				uint32_t total;
+				uint32_t pos = mdb_block_excl_scan(nrec, s_scan, &total);
+				if (threadIdx.x == 0 && total)
+					s_scan[20] = atomicAdd(a.rec_count, total);
+				__syncthreads();
+				pos += s_scan[20];
+#pragma unroll
+				for (int it = 0; it < GC_EMIT_ITERS; it++)
+					if (recv[it])
+						a.rec[pos++] = recv[it];
 			}
 			__syncthreads();	/* the next leaf builds into the cleared tables */
 		}
@@ -303,13 +337,113 @@ __global__ void k_null_poke(const unsigned long long *cnt_first, int64_t *dense_
 		dense_cnt[cnt_first[1]] = (int64_t)cnt_first[0];
 }
 
+__global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long long *rec, uint32_t *rec_count, uint32_t kbits,
+			   uint32_t *status)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0 && cnt_first[0]) {
+		if (cnt_first[0] >> (64 - kbits))
+			atomicOr(status, 4u);
+		rec[atomicAdd(rec_count, 1u)] = (cnt_first[1] << (64 - kbits)) | cnt_first[0];
+	}
+}
+
+/* ------------------------------------------------------------------ ordering the groups by first row id
+ *
+ * The group records (first row id in the top kbits, COUNT(*) below) were radix-partitioned on the top
+ * bits of the row id, so leaf i holds exactly the records whose row id lies in [i * range, (i+1) * range),
+ * range <= ORD_RANGE.  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
+ * compacting the slots in order sorts the leaf; leaves are already in order.  This is what reproduces the
+ * reference's "survivors keep table order" (executor_select.c:1542-1583) without 8-byte random writes
+ * into a table-sized array.
+ */
+#define ORD_THREADS 1024
+#define ORD_RANGE 2048u		/* row ids per ordering leaf = 2 LDS slots per thread */
+
+struct ord_args {
+	const unsigned long long *rec;
+	const uint32_t *off;		/* exact layout: leaf offsets = output positions */
+	const uint32_t *cnt;		/* fast layout: records per leaf ... */
+	const uint32_t *out_base;	/* ... and their exclusive prefix = output positions */
+	uint32_t cap;
+	uint32_t kbits, leaf_bits;
+	uint32_t *out_first;
+	int64_t *out_count;
+};
+
+__global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
+{
+	__shared__ unsigned long long s_slot[ORD_RANGE];
+	__shared__ uint32_t s_scan[32];
+	const uint32_t leaf = blockIdx.x;
+	uint32_t b, e, base;
+	if (a.cap) {
+		const uint32_t c = a.cnt[leaf];
+		b = leaf * a.cap;
+		e = b + (c < a.cap ? c : a.cap);
+		base = a.out_base[leaf];
+	} else {
+		b = a.off[leaf];
+		e = a.off[leaf + 1];
+		base = b;
+	}
+	if (b == e)
+		return;
+	const uint32_t range_bits = a.kbits - a.leaf_bits;
+	const uint32_t range = 1u << range_bits;
+	const unsigned long long cmask = (1ull << (64 - a.kbits)) - 1ull;
+	s_slot[2 * threadIdx.x] = 0ull;
+	s_slot[2 * threadIdx.x + 1] = 0ull;
+	__syncthreads();
+	for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
+		const unsigned long long r = a.rec[i];
+		s_slot[(uint32_t)(r >> (64 - a.kbits)) & (range - 1)] = r & cmask;	/* COUNT(*) >= 1 marks the slot */
+	}
+	__syncthreads();
+	const unsigned long long c0 = s_slot[2 * threadIdx.x], c1 = s_slot[2 * threadIdx.x + 1];
+	uint32_t total;
+	uint32_t pos = base + mdb_block_excl_scan((c0 != 0) + (c1 != 0), s_scan, &total);
+	const uint32_t first0 = (leaf << range_bits) + 2 * threadIdx.x;
+	if (c0) {
+		a.out_first[pos] = first0;
+		a.out_count[pos] = (int64_t)c0;
+		pos++;
+	}
+	if (c1) {
+		a.out_first[pos] = first0 + 1;
+		a.out_count[pos] = (int64_t)c1;
+	}
+}
+
+/* bits of the ordering sort: leaves of at most ORD_RANGE row ids, at most 9 bits per level */
+static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
+{
+	uint32_t k = 1;
+	while (k < 32 && (1ull << k) < n_l)
+		k++;
+	int b = (int)k - 11;
+	if (b < 1)
+		b = 1;
+	if (b > 2 * MDB_MAX_RADIX_BITS)
+		return false;
+	*kbits = k;
+	if (b <= MDB_MAX_RADIX_BITS) {
+		*sb1 = b;
+		*sb2 = 0;
+	} else {
+		*sb1 = (b + 1) / 2;
+		*sb2 = b - *sb1;
+	}
+	return true;
+}
+
 /* ------------------------------------------------------------------ group-count drivers */
 
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
+#define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   bool want_records, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 			   uint64_t *out_joined)
 {
 	*out_groups = 0;
@@ -323,7 +457,15 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast);
 	if (has_r)
 		need += mdb_partition_arena_bytes(n_r, b1, b2, false, fast);
-	need += mdb_align_up(n_l * 8) + mdb_align_up(n_l * 4) + mdb_filter_arena_bytes(n_l) + 4096;
+	{
+		uint32_t kb = 0;
+		int s1 = 0, s2 = 0;
+		need += mdb_align_up((n_l + 1) * 8) + mdb_align_up(n_l * 4) + 4096;
+		if (want_records && order_bits(n_l, &kb, &s1, &s2))
+			need += mdb_partition_raw_arena_bytes(n_l, s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) + (((size_t)1 << (s1 + s2)) + 4096) * 8;
+		else
+			need += mdb_filter_arena_bytes(n_l);
+	}
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
@@ -352,13 +494,27 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		return rc;
 	if (has_r && (rc = mdb_aux_join(ctx)))	/* the leaf kernel needs both tables */
 		return rc;
-	int64_t *dense = (int64_t *)mdb_arena_take(ctx, n_l * 8);
+	/* ---- result ordering: record mode (sort the groups by first row id) or dense mode (fallback) */
+	uint32_t kbits = 0;
+	int sb1 = 0, sb2 = 0;
+	const bool records = want_records && order_bits(n_l, &kbits, &sb1, &sb2);
+	const uint32_t ord_range = records ? (1u << (kbits - (uint32_t)(sb1 + sb2))) : 0;
+	int64_t *dense = NULL;
+	unsigned long long *rec = NULL;
 	uint32_t *sel = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
-	if (!dense || !sel)
+	if (records) {
+		rec = (unsigned long long *)mdb_arena_take(ctx, (n_l + 1) * 8);
+	} else {
+		dense = (int64_t *)mdb_arena_take(ctx, n_l * 8);
+	}
+	if (!sel || (!rec && !dense))
 		return -MIDORIDB_INTERNAL;
+	/* d_status u32 words: [0] flags, [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
+	uint32_t *d_rec_count = ctx->d_status + 1;
 	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
 	unsigned long long *d_nullst = (unsigned long long *)(ctx->d_status + 4);
-	MDB_HIP(ctx, hipMemsetAsync(dense, 0, n_l * 8, ctx->stream));
+	if (dense)
+		MDB_HIP(ctx, hipMemsetAsync(dense, 0, n_l * 8, ctx->stream));
 
 	gc_args a;
 	a.hv_l = pl.hv;
@@ -371,6 +527,9 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	a.cnt_r = pr.leaf_cnt;
 	a.cap_r = pr.leaf_cap;
 	a.dense_cnt = dense;
+	a.rec = rec;
+	a.rec_count = d_rec_count;
+	a.kbits = records ? kbits : 0;
 	a.joined = d_joined;
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
@@ -387,30 +546,79 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	if (null_group && null_l) {
 		MDB_HIP(ctx, hipMemsetAsync(d_nullst + 1, 0xFF, 8, ctx->stream));
 		MDB_LAUNCH(ctx, "null_stats", k_null_stats, 256, 256, null_l, n_l, d_nullst);
-		MDB_LAUNCH(ctx, "null_poke", k_null_poke, 1, 64, d_nullst, dense);
+		if (records) {
+			MDB_LAUNCH(ctx, "null_rec", k_null_rec, 1, 64, d_nullst, rec, d_rec_count, kbits, ctx->d_status);
+		} else {
+			MDB_LAUNCH(ctx, "null_poke", k_null_poke, 1, 64, d_nullst, dense);
+		}
 	}
 
-	/* order the groups by first occurrence: compact the dense array in row order */
-	uint32_t *d_total = NULL;
-	rc = mdb_filter_nonzero64(ctx, dense, n_l, sel, &d_total);
-	if (rc)
-		return rc;
-	/* read back G, J, status with one sync */
 	uint64_t *h = ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(&h[0], d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint64_t G = (uint32_t)h[0];
+	uint64_t G = 0;
+	uint32_t *first_out = out_first ? out_first : sel;
+	if (records) {
+		/* G, J and the status flags come back with one sync; the sort is sized by G */
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		G = h[1] >> 32;
+	} else {
+		uint32_t *d_total = NULL;
+		rc = mdb_filter_nonzero64(ctx, dense, n_l, sel, &d_total);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemcpyAsync(&h[0], d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		G = (uint32_t)h[0];
+	}
 	const uint32_t status = (uint32_t)h[1];
+	const uint64_t joined = h[2];
 	if (status & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
+	if (status & 4u)
+		return GC_RETRY_DENSE;	/* a COUNT(*) too large to share a 64-bit record with its row id */
 	if (status & 1u)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
 				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", GC_SLOTS);
 	if (G > cap)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
-	if (G) {
+	if (G && records) {
+		mdb_part_result ps;
+		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, G, sb1, sb2, ord_range, &ps);
+		if (rc)
+			return rc;
+		ord_args oa;
+		oa.rec = (const unsigned long long *)ps.hv;
+		oa.off = ps.leaf_off;
+		oa.cnt = ps.leaf_cnt;
+		oa.cap = ps.leaf_cap;
+		oa.out_base = NULL;
+		oa.kbits = kbits;
+		oa.leaf_bits = (uint32_t)(sb1 + sb2);
+		oa.out_first = first_out;
+		oa.out_count = out_count;
+		if (ps.leaf_cap) {
+			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
+			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
+			uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
+			if (!obase || !otmp)
+				return -MIDORIDB_INTERNAL;
+			MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
+			rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
+			if (rc)
+				return rc;
+			oa.out_base = obase;
+		}
+		MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
+		if (out_key) {
+			rc = mdb_dev_gather64(ctx, keys_l, NULL, first_out, G, out_key, NULL);
+			if (rc)
+				return rc;
+		}
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
 		if (rc)
 			return rc;
@@ -425,7 +633,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	}
 	*out_groups = G;
 	if (out_joined)
-		*out_joined = h[2];
+		*out_joined = joined;
 	return MIDORIDB_OK;
 }
 
@@ -436,11 +644,18 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 {
 	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
-	int rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, true, out_key, out_count,
-				 out_first, cap, out_groups, out_joined);
-	if (rc == GC_RETRY_EXACT)
-		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, false, out_key, out_count,
-				     out_first, cap, out_groups, out_joined);
+	bool fast = true, records = true;
+	int rc;
+	for (int attempt = 0; attempt < 3; attempt++) {
+		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, out_key,
+				     out_count, out_first, cap, out_groups, out_joined);
+		if (rc == GC_RETRY_EXACT)
+			fast = false;
+		else if (rc == GC_RETRY_DENSE)
+			records = false;
+		else
+			break;
+	}
 	return rc;
 }
 

@@ -483,7 +483,7 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
-			  mdb_part_result *out)
+			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -493,7 +493,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const uint32_t nt0 = n ? (uint32_t)((n + MDB_TILE - 1) / MDB_TILE) : 1u;
 	/* FAST applies to the second level only, and only while leaf * cap stays a 32-bit index */
 	const uint32_t nleaves_total = nlevels == 2 ? Rl[0] * Rl[1] : Rl[0];
-	const uint32_t fast_cap = part_fast_cap(n, nleaves_total);
+	const uint32_t fast_cap = cap_override ? cap_override : part_fast_cap(n, nleaves_total);
 	const bool fast = (flags & PART_F_FAST) && !stable && nlevels == 2 && !final_hv_out &&
 			  (uint64_t)nleaves_total * fast_cap < 0xFFFFFFFFull;
 
@@ -531,7 +531,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keys = keys;
 		a.nullbits = nullbits;
 		a.n = n;
-		a.hv_in = l ? hv_buf[l - 1] : NULL;
+		a.hv_in = l ? hv_buf[l - 1] : raw_hv;	/* raw_hv: level 0 reads ready-made 64-bit sort keys */
 		a.rid_in = l ? rid_buf[l - 1] : NULL;
 		a.tiles = tiles;
 		a.hv_out = hv_buf[l];
@@ -565,6 +565,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
+				} else if (raw_hv) {
+					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
+						   PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
@@ -593,7 +596,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		if (!dry) {
 			a.hist = hist;
 			MDB_HIP(ctx, hipMemsetAsync(hist, 0, hlen * 4, ctx->stream));
-			if (l == 0) {
+			if (l == 0 && raw_hv) {
+				MDB_LAUNCH(ctx, "sort_hist_l0", k_part_hist<false>, grid8(ntiles), PART_THREADS, a);
+			} else if (l == 0) {
 				MDB_LAUNCH(ctx, "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
 			} else {
 				MDB_LAUNCH(ctx, "part_hist_l1", k_part_hist<false>, grid8(ntiles), PART_THREADS, a);
@@ -601,7 +606,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			int rc = mdb_scan_u32_inplace(ctx, hist, hlen, scan_tmp);
 			if (rc)
 				return rc;
-			if (stable && l == 0) {
+			if (l == 0 && raw_hv) {
+				MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, false>), grid8(ntiles), PART_THREADS, a);
+			} else if (stable && l == 0) {
 				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable) {
 				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true, false>), grid8(ntiles), PART_THREADS, a);
@@ -646,7 +653,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
 	return cv.bytes + 4096;
 }
 
@@ -662,7 +669,26 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	if ((uintptr_t)keys & 15)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u),
-			      MDB_DIGIT_RADIX, 0, false, NULL, out);
+			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out);
+}
+
+/* MSD radix partition of ready-made 64-bit sort keys (no hashing, no NULLs) by their top bits1 + bits2
+ * bits; with two levels the last one uses the fixed-capacity layout with `leaf_cap` rows per leaf (the
+ * caller guarantees no leaf can hold more).  Used to order GROUP BY results by first row id. */
+size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap)
+{
+	part_carver cv = { NULL, true, 0, false };
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, false, PART_F_FAST, MDB_DIGIT_RADIX, 0, false, NULL,
+			     (const uint64_t *)16, leaf_cap, NULL);
+	return cv.bytes + 4096;
+}
+
+int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap,
+		      mdb_part_result *out)
+{
+	part_carver cv = { ctx, false, 0, false };
+	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, PART_F_FAST, MDB_DIGIT_RADIX, 0, false, NULL, hv, leaf_cap,
+			      out);
 }
 
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
@@ -679,13 +705,13 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
 	 * original keys written back through the inverse hash) */
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, &res);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
