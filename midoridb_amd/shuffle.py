@@ -17,9 +17,9 @@ class KeyExchange:
         self.world = world
         self.device = device
 
-    def exchange(self, send_keys, send_counts, recv_buf=None):
+    def exchange(self, send_keys, send_counts, recv_buf=None, async_op=False):
         """send_keys: keys grouped by destination rank; send_counts: list[int] of len world.
-        Returns (recv_keys tensor, recv_counts list)."""
+        Returns (recv_keys tensor, recv_counts list, work handle or None)."""
         cin = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
         cout = torch.empty(self.world, dtype=torch.int64, device=self.device)
         dist.all_to_all_single(cout, cin)
@@ -28,8 +28,8 @@ class KeyExchange:
         if recv_buf is None or recv_buf.numel() < total:
             recv_buf = torch.empty(max(total, 1), dtype=send_keys.dtype, device=self.device)
         recv = recv_buf[:total]
-        dist.all_to_all_single(recv, send_keys[:sum(send_counts)], recv_counts, list(send_counts))
-        return recv, recv_counts
+        work = dist.all_to_all_single(recv, send_keys[:sum(send_counts)], recv_counts, list(send_counts), async_op=async_op)
+        return recv, recv_counts, work
 
 
 class DistributedJoinGroupCount:
@@ -50,28 +50,35 @@ class DistributedJoinGroupCount:
         self.join_fn = join_fn or (lambda ka, kb, out: dev.join_group_count(ka, None, kb, None, out=out))
 
     def run(self, a, b, out=None):
+        # table A's keys travel over xGMI while table B is being partitioned
         sa, ca = self.partition_fn(a, self.send_a)
+        ra, _, wa = self.ex.exchange(sa, ca, self.recv_a, async_op=True)
         sb, cb = self.partition_fn(b, self.send_b)
-        ra, _ = self.ex.exchange(sa, ca, self.recv_a)
-        rb, _ = self.ex.exchange(sb, cb, self.recv_b)
+        rb, _, wb = self.ex.exchange(sb, cb, self.recv_b, async_op=True)
+        for w in (wa, wb):
+            if w is not None:
+                w.wait()
         k, c, f, j = self.join_fn(ra, rb, out)
         self.last = (k, c, f)
         return k.numel() if hasattr(k, "numel") else len(k), j
 
 
-def algorithmic_bytes(kernel, n, world, kern):
-    """Algorithmic HBM bytes of ONE launch of `kernel` on tables of n rows per GPU:
-    what the launch must read once and write once, independent of how it is implemented.
-    A kernel name covers the launch for table A (carries 4-byte row ids) and for table B (keys
-    only); the figure is their average."""
-    a_key, rid = 8 * n, 4 * n
+def algorithmic_bytes(kernel, n, groups):
+    """Algorithmic HBM bytes of ONE launch of `kernel` on tables of n rows per GPU producing `groups`
+    result groups: what the launch must read once and write once, independent of how it is
+    implemented.  A partition kernel name covers the launch for table A (carries 4-byte row ids) and the
+    one for table B (keys only); the figure is their average."""
+    key, rid, g = 8 * n, 4 * n, groups
     table = {
-        "part_hist_l0": a_key,					# read the raw keys
-        "part_hist_l1": a_key,					# read the hashed keys
-        "part_scatter_l0": ((a_key + a_key + rid) + (a_key + a_key)) / 2,	# read key, write hash (+rid)
-        "part_scatter_l1": ((2 * (a_key + rid)) + (2 * a_key)) / 2,		# move hash (+rid)
-        "leaf_join_group_count": (a_key + rid) + a_key,				# read both partitioned tables once
-        "compact_nonzero_bits": a_key,
-        "gather64": a_key,
+        "part_hist_l0": key,                                            # read the raw keys
+        "part_scatter_l0": ((key + key + rid) + (key + key)) / 2,      # read key, write hash (+ row id)
+        "part_scatter_l1": ((2 * (key + rid)) + (2 * key)) / 2,        # move hash (+ row id) into its leaf
+        "leaf_join_group_count": (key + rid) + key + 8 * g,            # read both partitioned tables, write one record per group
+        "leaf_group_count": (key + rid) + 8 * g,
+        "sort_hist_l0": 8 * g,                                          # ordering sort over the group records
+        "sort_scatter_l0": 16 * g,
+        "sort_scatter_l1": 16 * g,
+        "order_leaf": 8 * g + 12 * g,                                   # read records, write (first row id, COUNT)
+        "gather64": 4 * g + 8 * g + 8 * g,                              # row id -> key of every group
     }
-    return float(table.get(kernel, a_key))
+    return float(table.get(kernel, key))
