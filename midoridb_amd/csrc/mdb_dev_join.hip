@@ -48,15 +48,19 @@ __device__ static inline uint32_t leaf_step(uint64_t hv, uint32_t slots)
 	return 1u + (uint32_t)(((uint64_t)y * (slots - 1)) >> 32);
 }
 
-/* insert-or-find hv (hv != 0); returns the slot or 0xFFFFFFFF when the table is full */
-__device__ static inline uint32_t leaf_insert(unsigned long long *keys, uint32_t slots, uint64_t hv)
+/* insert-or-find hv (hv != 0); returns the slot or 0xFFFFFFFF when the table is full; *created = this call
+ * claimed the slot (exactly one caller per distinct key sees true) */
+__device__ static inline uint32_t leaf_insert(unsigned long long *keys, uint32_t slots, uint64_t hv, bool *created = nullptr)
 {
 	uint32_t s = leaf_slot(hv, slots);
 	const uint32_t step = leaf_step(hv, slots);
 	for (uint32_t probe = 0; probe < slots; probe++) {
 		const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)hv);
-		if (old == 0ull || old == hv)
+		if (old == 0ull || old == hv) {
+			if (created)
+				*created = old == 0ull;
 			return s;
+		}
 		s += step;
 		if (s >= slots)
 			s -= slots;
@@ -189,6 +193,10 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
 		}
 		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
+		/* a leaf whose left side fits one register batch (the normal case) is emitted by the threads that
+		 * created its table slots; only oversized (skewed) leaves scan the whole table */
+		const bool by_owner = (l1 - l0) <= GC_THREADS * LEAF_BATCH;
+		uint32_t own[LEAF_BATCH];
 		if (live) {
 			/* build: left side (first batch already in registers) */
 			for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
@@ -207,16 +215,21 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 #pragma unroll
 				for (int u = 0; u < LEAF_BATCH; u++) {
 					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+					if (base == l0)
+						own[u] = 0xFFFFFFFFu;
 					if (i >= l1)
 						continue;
 					uint32_t s = GC_SLOTS;
+					bool created = false;
 					if (b.hv_l[u] != 0)
-						s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u]);
+						s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u], &created);
 					if (s == 0xFFFFFFFFu) {
 						atomicOr(a.status, 1u);
 					} else {
 						atomicAdd(&s_cnt[s], 1ull);
 						atomicMin(&s_first[s], b.rid_l[u]);
+						if (created && base == l0)
+							own[u] = s;	/* this thread emits (and clears) the group */
 					}
 				}
 			}
@@ -261,13 +274,26 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			uint32_t nrec = 0;
 #pragma unroll
 			for (int it = 0; it < GC_EMIT_ITERS; it++) {
-				const uint32_t s = threadIdx.x + (uint32_t)it * GC_THREADS;
 				recv[it] = 0;
-				if (s > GC_SLOTS)
-					continue;
+				uint32_t s;
+				if (by_owner) {
+					/* slots created by this thread, plus (thread 0) the side slot of the hash-0 key */
+					if (it < LEAF_BATCH)
+						s = own[it];
+					else if (it == LEAF_BATCH && threadIdx.x == 0)
+						s = GC_SLOTS;
+					else
+						continue;
+					if (s == 0xFFFFFFFFu)
+						continue;
+				} else {
+					s = threadIdx.x + (uint32_t)it * GC_THREADS;
+					if (s > GC_SLOTS)
+						continue;
+				}
 				const unsigned long long c2 = s_cnt[s];
 				if (s < GC_SLOTS) {
-					if (s_key[s] == 0ull)
+					if (!by_owner && s_key[s] == 0ull)
 						continue;
 					s_key[s] = 0ull;
 				} else if (c2 == 0ull) {
