@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""bench_operators.py - per-operator measurements of the OTHER rows of the hot path, beside the
+headline pipeline that bench.py times: scan+filter (config 1 scaled up), materialising join with payload
+(config 2), single-table GROUP BY, three-way join.  Not part of the driver's bench contract; writes one
+JSON document (default profiles/r01/operators.json) with milliseconds and the rate on each operator's
+algorithmic bytes, all measured with HIP events through the library's per-kernel profiler.
+
+    python bench_operators.py [--out profiles/r01/operators.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from midoridb_amd import dev as D  # noqa: E402
+from midoridb_amd.dev import DeviceCtx  # noqa: E402
+
+
+def timed(dev, fn, reps=5, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    dev.prof_enable(True)
+    dev.prof_reset()
+    fn()
+    prof = dev.prof_read()
+    dev.prof_enable(False)
+    return ms, {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01", "operators.json"))
+    args = ap.parse_args()
+    dev = DeviceCtx(0)
+    res = {}
+
+    # ---- scan + WHERE (config 1 shape at 10^8 rows): SELECT v FROM T WHERE v > N/2 ; v = permutation
+    n = 100_000_000
+    v = dev.gen_keys(n, 0, n, 7, 0)
+    prog = [(D.P_CMP_COL_CONST, D.CMP_GT, D.T_INT64, 0, 0, n // 2)]
+
+    def scan_filter():
+        sel = dev.filter(prog, [(v, None, None)], n)
+        out, _ = dev.gather64(v, None, sel, sel.numel())
+        return sel.numel()
+    ms, kern, m = timed(dev, scan_filter)
+    algo = 8 * n + 8 * m            # read every value once, write the survivors once
+    res["scan_filter_1e8"] = {"rows_in": n, "rows_out": m, "ms": ms, "algorithmic_bytes": algo,
+                              "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
+                              "note": "filter (ballot bitmap + scan + positions) then projection gather; 50% selectivity"}
+
+    # ---- materialising join with payload (config 2): 10^7 x 10^7, 1:1 keys, 4 output columns
+    n2 = 10_000_000
+    a_id, a_f = dev.gen_keys(n2, 0, n2, 42, 0), dev.gen_keys(n2, 0, n2, 43, 0)
+    b_id, b_f = dev.gen_keys(n2, 0, n2, 50, 0), dev.gen_keys(n2, 0, n2, 51, 0)
+
+    def join_payload():
+        l, r = dev.join_pairs(a_id, None, b_id, None)
+        j = l.numel()
+        c0, _ = dev.gather64(a_id, None, l, j)
+        c1, _ = dev.gather64(b_id, None, r, j)
+        c2, _ = dev.gather64(a_f, None, l, j)
+        c3, _ = dev.gather64(b_f, None, r, j)
+        return j
+    ms, kern, j = timed(dev, join_payload, reps=3, warmup=1)
+    algo = 8 * 2 * n2 + 8 * 2 * n2 + 8 * 4 * j      # keys + payload columns read once, 4 result columns written
+    res["join_payload_1e7"] = {"rows_per_table": n2, "joined_rows": j, "ms": ms, "joined_rows_per_s": j / (ms * 1e-3),
+                               "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
+                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + 4 projection gathers"}
+
+    # ---- single-table GROUP BY key COUNT(*) at 10^8 rows, 6.25M groups of 16
+    keys = dev.gen_keys(n, 0, n, 43, n // 16)
+
+    def group_by():
+        f, c = dev.group_count(keys, None)
+        return f.numel()
+    ms, kern, g = timed(dev, group_by)
+    algo = 8 * n + 12 * g
+    res["group_count_1e8"] = {"rows": n, "groups": g, "ms": ms, "algorithmic_bytes": algo,
+                              "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern}
+
+    # ---- three-way join on one key (config 5 shape), 10^7 rows per table, 1:1:1
+    c_id = dev.gen_keys(n2, 0, n2, 60, 0)
+
+    def three_way():
+        l, r = dev.join_pairs(a_id, None, b_id, None)
+        k_ab, _ = dev.gather64(a_id, None, l, l.numel())     # key column of the joined stream
+        p, q = dev.join_pairs(k_ab, None, c_id, None)
+        ra = dev.gather32(l, p)                               # compose row ids: A, B through the second join
+        rb = dev.gather32(r, p)
+        return p.numel()
+    ms, kern, j3 = timed(dev, three_way, reps=3, warmup=1)
+    res["three_way_join_1e7"] = {"rows_per_table": n2, "joined_rows": j3, "ms": ms, "joined_rows_per_s": j3 / (ms * 1e-3),
+                                 "kernels_ms": kern}
+
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in d.items() if kk != "kernels_ms"} for k, d in res.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -738,6 +738,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 {
 	__shared__ unsigned long long s_key[PJ_SLOTS];
 	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* [PJ_SLOTS] = the key with hash 0 */
+	__shared__ unsigned long long s_total;
 
 	const uint32_t leaf = blockIdx.x;
 	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
@@ -749,6 +750,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 			s_key[s] = 0ull;
 		s_cnt[s] = 0;
 	}
+	if (threadIdx.x == 0)
+		s_total = 0ull;
 	__syncthreads();
 	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
 		const uint64_t hv = a.hv_r[j];
@@ -777,8 +780,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 			}
 		}
 	}
+	/* one global atomic per workgroup (a per-thread atomic on this single address serialised 10^7 updates
+	 * and cost 1.5 ms at 10^7 rows - profiles/r01/operators.json history) */
 	if (mine)
-		atomicAdd(a.total64, mine);
+		atomicAdd(&s_total, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_total)
+		atomicAdd(a.total64, s_total);
 }
 
 /* ------------------------------------------------------------------ materialising join: emit phase
