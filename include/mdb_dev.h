@@ -202,6 +202,17 @@ int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
 			     int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 			     uint64_t *out_groups, uint64_t *out_joined);
 
+/* Split form for pipelines that receive the two tables at different times (the multi-GPU exchange):
+ * _begin() hashes and partitions the LEFT table and returns without a host sync, so the work overlaps
+ * whatever is still in flight (e.g. the right table's all-to-all); n_r_max bounds the right table's size
+ * for scratch sizing.  _finish() takes the right table and completes exactly like
+ * mdb_dev_join_group_count().  No other operator may run on the context in between. */
+int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+				   uint64_t n_r_max);
+int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+				    uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+				    uint64_t *out_groups, uint64_t *out_joined);
+
 /* ------------------------------------------------------------------ multi-GPU shuffle support
  *
  * Hash-partition a key column by destination GPU for the all-to-all exchange

@@ -28,6 +28,7 @@ struct mdb_dev_ctx {
 	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
 	hipEvent_t ev_fork, ev_join;
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
+	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	char err[512];
 	/* scratch arena (grow-only, bump allocated per operator) */
 	char *arena;

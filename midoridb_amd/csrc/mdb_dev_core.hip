@@ -5,6 +5,7 @@
  */
 #include "mdb_dev_internal.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include "mdb_gen.h"
 
 int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...)
@@ -65,6 +66,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	}
 	ctx->aux_stream = NULL;
 	ctx->ev_fork = ctx->ev_join = NULL;
+	ctx->pending_op = NULL;
 	ctx->overlap = false;	/* measured: no gain on one GPU (each kernel already fills the chip), kept for the multi-GPU exchange */
 	if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -100,6 +102,7 @@ extern "C" void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx)
 		(void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join)
 		(void)hipEventDestroy(ctx->ev_join);
+	free(ctx->pending_op);
 	if (ctx->arena)
 		(void)hipFree(ctx->arena);
 	if (ctx->d_status)

@@ -482,59 +482,69 @@ static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 
-static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
-			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
-			   uint64_t *out_joined)
-{
-	*out_groups = 0;
-	if (out_joined)
-		*out_joined = 0;
-	if (n_l == 0 || (has_r && n_r == 0))
-		return MIDORIDB_OK;
-
+/* The operator runs in two halves so that a multi-GPU pipeline can partition the left table while the
+ * right table is still arriving over xGMI (mdb_dev_join_group_count_begin / _finish). */
+struct gc_state {
+	bool active;
+	const int64_t *keys_l;
+	const uint64_t *null_l;
+	uint64_t n_l, n_r_cap;
+	bool has_r, null_group, fast, want_records;
 	int b1, b2;
-	mdb_choose_bits(n_l, GC_TARGET, &b1, &b2);
-	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast);
-	if (has_r)
-		need += mdb_partition_arena_bytes(n_r, b1, b2, false, fast);
+	mdb_part_result pl;
+};
+
+/* first half: size and claim the scratch arena, clear the status words, partition the left table */
+static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
+{
+	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
+	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
+	if (st->has_r)
+		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	{
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
-		need += mdb_align_up((n_l + 1) * 8) + mdb_align_up(n_l * 4) + 4096;
-		if (want_records && order_bits(n_l, &kb, &s1, &s2))
-			need += mdb_partition_raw_arena_bytes(n_l, s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) + (((size_t)1 << (s1 + s2)) + 4096) * 8;
+		need += mdb_align_up((st->n_l + 1) * 8) + mdb_align_up(st->n_l * 4) + 4096;
+		if (st->want_records && order_bits(st->n_l, &kb, &s1, &s2))
+			need += mdb_partition_raw_arena_bytes(st->n_l, s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) +
+				(((size_t)1 << (s1 + s2)) + 4096) * 8;
 		else
-			need += mdb_filter_arena_bytes(n_l);
+			need += mdb_filter_arena_bytes(st->n_l);
 	}
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
-
-	mdb_part_result pl, pr;
-	memset(&pr, 0, sizeof(pr));
-	/* d_status words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow),
-	 * [2..3] joined-row total (u64), [4..7] NULL-group stats (2 x u64) */
+	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
+	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
-	/* the two tables are independent until the leaf kernel: partition the right one on the auxiliary
-	 * stream so its kernels fill the tails and latency bubbles of the left one's */
-	hipStream_t main_stream = NULL;
-	if (has_r) {
-		rc = mdb_aux_begin(ctx, &main_stream);
-		if (rc)
-			return rc;
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, fast, &pr);
-		int rc2 = mdb_aux_end(ctx, main_stream);
-		if (rc)
-			return rc;
-		if (rc2)
-			return rc2;
-	}
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, fast, &pl);
+	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, true, false, st->fast, &st->pl);
 	if (rc)
 		return rc;
-	if (has_r && (rc = mdb_aux_join(ctx)))	/* the leaf kernel needs both tables */
-		return rc;
+	st->active = true;
+	return MIDORIDB_OK;
+}
+
+/* second half: partition the right table, join + count per leaf, order the groups, deliver */
+static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+		     int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+		     uint64_t *out_joined)
+{
+	const int64_t *keys_l = st->keys_l;
+	const uint64_t *null_l = st->null_l;
+	const uint64_t n_l = st->n_l;
+	const bool has_r = st->has_r, null_group = st->null_group, want_records = st->want_records;
+	mdb_part_result pl = st->pl, pr;
+	int rc;
+
+	st->active = false;
+	memset(&pr, 0, sizeof(pr));
+	if (has_r) {
+		if (n_r > st->n_r_cap)
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr);
+		if (rc)
+			return rc;
+	}
 	/* ---- result ordering: record mode (sort the groups by first row id) or dense mode (fallback) */
 	uint32_t kbits = 0;
 	int sb1 = 0, sb2 = 0;
@@ -678,6 +688,32 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	return MIDORIDB_OK;
 }
 
+static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
+			   bool want_records, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   uint64_t *out_joined)
+{
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	if (n_l == 0 || (has_r && n_r == 0))
+		return MIDORIDB_OK;
+	gc_state st;
+	memset(&st, 0, sizeof(st));
+	st.keys_l = keys_l;
+	st.null_l = null_l;
+	st.n_l = n_l;
+	st.n_r_cap = n_r;
+	st.has_r = has_r;
+	st.null_group = null_group;
+	st.fast = fast;
+	st.want_records = want_records;
+	int rc = gc_begin(ctx, &st);
+	if (rc)
+		return rc;
+	return gc_finish(ctx, &st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
+}
+
 static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			      const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group,
 			      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
@@ -708,6 +744,65 @@ extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l,
 	(void)flags;	/* groups always come out in first-occurrence order, which satisfies both modes */
 	return group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 				  cap, out_groups, out_joined);
+}
+
+/* ---- split form for pipelines whose right table arrives later (multi-GPU exchange) ---- */
+
+static gc_state *gc_pending(mdb_dev_ctx *ctx)
+{
+	if (!ctx->pending_op)
+		ctx->pending_op = calloc(1, sizeof(gc_state));
+	return (gc_state *)ctx->pending_op;
+}
+
+extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+					      uint64_t n_r_max)
+{
+	gc_state *st = gc_pending(ctx);
+	if (!st)
+		return -MIDORIDB_NOMEM;
+	memset(st, 0, sizeof(*st));
+	st->keys_l = keys_l;
+	st->null_l = null_l;
+	st->n_l = n_l;
+	st->n_r_cap = n_r_max;
+	st->has_r = true;
+	st->null_group = false;
+	st->fast = true;
+	st->want_records = true;
+	if (n_l == 0)
+		return MIDORIDB_OK;	/* nothing to prepare; finish() returns the empty result */
+	return gc_begin(ctx, st);
+}
+
+extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+					       uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first,
+					       uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	(void)flags;
+	gc_state *st = gc_pending(ctx);
+	if (!st || !st->keys_l)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join_group_count_finish without begin");
+	const int64_t *keys_l = st->keys_l;
+	const uint64_t *null_l = st->null_l;
+	const uint64_t n_l = st->n_l;
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	int rc = MIDORIDB_OK;
+	if (n_l == 0 || n_r == 0) {
+		if (st->active)
+			rc = mdb_dev_sync(ctx);		/* drain the prepared left partition */
+		st->active = false;
+		st->keys_l = NULL;
+		return rc;
+	}
+	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
+	st->keys_l = NULL;
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE)	/* skew / huge counts: redo the whole operator on the safe path */
+		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
+					cap, out_groups, out_joined);
+	return rc;
 }
 
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,

@@ -64,6 +64,8 @@ def _bind(lib):
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, c_uint32, P, P, P, c_uint64,
                                       POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dev_join_group_count_begin": ([P, P, P, c_uint64, c_uint64], c_int),
+        "mdb_dev_join_group_count_finish": ([P, P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, P, POINTER(c_uint64)], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
     }
@@ -79,7 +81,8 @@ DEV_SYMBOLS = [
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
-    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
+    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
+    "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
 ]
 
 
@@ -198,6 +201,29 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r,
                                                     flags, _ptr(ok), _ptr(oc), _ptr(of), cap, byref(g), byref(j)),
                   "join_group_count")
+        G = g.value
+        return ok[:G], oc[:G], of[:G], j.value
+
+    def join_group_count_begin(self, keys_l, null_l, n_r_max):
+        """Split form: partition the left table now (no host sync) ..."""
+        self._chk(self.lib.mdb_dev_join_group_count_begin(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), n_r_max),
+                  "join_group_count_begin")
+        self._pending_left = keys_l     # keep the tensor alive until finish()
+
+    def join_group_count_finish(self, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):
+        """... and complete with the right table; same results as join_group_count()."""
+        n_l = self._pending_left.numel()
+        cap = max(n_l, 1)
+        if out is None:
+            out = (torch.empty(cap, dtype=torch.int64, device=self.device),
+                   torch.empty(cap, dtype=torch.int64, device=self.device),
+                   torch.empty(cap, dtype=torch.int32, device=self.device))
+        ok, oc, of = out
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count_finish(self.h, _ptr(keys_r), _ptr(null_r), keys_r.numel(), flags, _ptr(ok),
+                                                           _ptr(oc), _ptr(of), min(cap, ok.numel()), byref(g), byref(j)),
+                  "join_group_count_finish")
+        self._pending_left = None
         G = g.value
         return ok[:G], oc[:G], of[:G], j.value
 

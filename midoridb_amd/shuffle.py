@@ -47,7 +47,8 @@ class DistributedJoinGroupCount:
         self.recv_a = torch.empty(cap, dtype=torch.int64, device=device)
         self.recv_b = torch.empty(cap, dtype=torch.int64, device=device)
         self.partition_fn = partition_fn or (lambda keys, out: dev.partition_by_dest(keys, None, world, out=out))
-        self.join_fn = join_fn or (lambda ka, kb, out: dev.join_group_count(ka, None, kb, None, out=out))
+        self.join_fn = join_fn      # None: split device operator (begin on A while B is still in flight)
+        self.n_r_max = cap
 
     def run(self, a, b, out=None):
         # table A's keys travel over xGMI while table B is being partitioned
@@ -55,10 +56,19 @@ class DistributedJoinGroupCount:
         ra, _, wa = self.ex.exchange(sa, ca, self.recv_a, async_op=True)
         sb, cb = self.partition_fn(b, self.send_b)
         rb, _, wb = self.ex.exchange(sb, cb, self.recv_b, async_op=True)
-        for w in (wa, wb):
-            if w is not None:
-                w.wait()
-        k, c, f, j = self.join_fn(ra, rb, out)
+        if self.join_fn is not None:
+            for w in (wa, wb):
+                if w is not None:
+                    w.wait()
+            k, c, f, j = self.join_fn(ra, rb, out)
+        else:
+            # A has arrived: hash + partition it locally while B's all-to-all is still running
+            if wa is not None:
+                wa.wait()
+            self.dev.join_group_count_begin(ra, None, self.n_r_max)
+            if wb is not None:
+                wb.wait()
+            k, c, f, j = self.dev.join_group_count_finish(rb, None, out=out)
         self.last = (k, c, f)
         return k.numel() if hasattr(k, "numel") else len(k), j
 

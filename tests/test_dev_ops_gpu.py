@@ -264,3 +264,22 @@ def test_large_properties_north_star(dev):
     assert bool((a[f.long()] == k).all())
     assert torch.unique(k).numel() == k.numel()
     assert int(k.max()) < N // 16
+
+
+def test_join_group_count_split_begin_finish(dev):
+    """begin() on the left table + finish() with the right table == the one-call operator (the multi-GPU
+    pipeline prepares the left table while the right one is still in flight)."""
+    rng = np.random.default_rng(77)
+    for n_l, n_r, dom in [(1000, 3000, 500), (1_200_000, 900_000, 800_000)]:
+        kl = rng.integers(0, dom, n_l, dtype=np.int64)
+        kr = rng.integers(0, dom, n_r, dtype=np.int64)
+        nl = rng.random(n_l) < 0.02
+        ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, None)
+        dl, dnl, dr = dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr)
+        dev.join_group_count_begin(dl, dnl, n_r + 10)
+        k, c, f, j = dev.join_group_count_finish(dr, None)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
+    # empty right side after a begin
+    dev.join_group_count_begin(dev.to_dev(np.arange(10, dtype=np.int64)), None, 5)
+    k, c, f, j = dev.join_group_count_finish(dev.to_dev(np.zeros(0, dtype=np.int64)), None)
+    assert k.numel() == 0 and j == 0
