@@ -392,13 +392,15 @@ __global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long lo
  *
  * The group records (first row id in the top kbits, COUNT(*) below) were radix-partitioned on the top
  * bits of the row id, so leaf i holds exactly the records whose row id lies in [i * range, (i+1) * range),
- * range <= ORD_RANGE.  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
+ * range <= ORD_RANGE (8192).  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
  * compacting the slots in order sorts the leaf; leaves are already in order.  This is what reproduces the
  * reference's "survivors keep table order" (executor_select.c:1542-1583) without 8-byte random writes
  * into a table-sized array.
  */
 #define ORD_THREADS 1024
-#define ORD_RANGE 2048u		/* row ids per ordering leaf = 2 LDS slots per thread */
+#define ORD_PER_THREAD 8
+#define ORD_RANGE (ORD_THREADS * ORD_PER_THREAD)	/* 8192 row ids per ordering leaf (64 KiB of LDS slots) */
+#define ORD_RANGE_BITS 13
 
 struct ord_args {
 	const unsigned long long *rec;
@@ -409,6 +411,8 @@ struct ord_args {
 	uint32_t kbits, leaf_bits;
 	uint32_t *out_first;
 	int64_t *out_count;
+	const int64_t *keys;		/* optional: key column to gather the group keys from ... */
+	int64_t *out_key;		/* ... into here (keys[first]) */
 };
 
 __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
@@ -432,26 +436,40 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 	const uint32_t range_bits = a.kbits - a.leaf_bits;
 	const uint32_t range = 1u << range_bits;
 	const unsigned long long cmask = (1ull << (64 - a.kbits)) - 1ull;
-	s_slot[2 * threadIdx.x] = 0ull;
-	s_slot[2 * threadIdx.x + 1] = 0ull;
+	/* thread t owns the ORD_PER_THREAD consecutive slots [t * ORD_PER_THREAD, ...) */
+#pragma unroll
+	for (int k = 0; k < ORD_PER_THREAD; k++)
+		s_slot[threadIdx.x + (uint32_t)k * ORD_THREADS] = 0ull;
 	__syncthreads();
 	for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
 		const unsigned long long r = a.rec[i];
 		s_slot[(uint32_t)(r >> (64 - a.kbits)) & (range - 1)] = r & cmask;	/* COUNT(*) >= 1 marks the slot */
 	}
 	__syncthreads();
-	const unsigned long long c0 = s_slot[2 * threadIdx.x], c1 = s_slot[2 * threadIdx.x + 1];
-	uint32_t total;
-	uint32_t pos = base + mdb_block_excl_scan((c0 != 0) + (c1 != 0), s_scan, &total);
-	const uint32_t first0 = (leaf << range_bits) + 2 * threadIdx.x;
-	if (c0) {
-		a.out_first[pos] = first0;
-		a.out_count[pos] = (int64_t)c0;
-		pos++;
+	unsigned long long c[ORD_PER_THREAD];
+	uint32_t mine = 0;
+#pragma unroll
+	for (int k = 0; k < ORD_PER_THREAD; k++) {
+		c[k] = s_slot[threadIdx.x * ORD_PER_THREAD + k];
+		mine += c[k] != 0;
 	}
-	if (c1) {
-		a.out_first[pos] = first0 + 1;
-		a.out_count[pos] = (int64_t)c1;
+	uint32_t total;
+	uint32_t pos = mdb_block_excl_scan(mine, s_scan, &total);	/* (syncs: every slot has been read) */
+	/* compact in LDS - (slot index, COUNT) packed in one word: COUNT < 2^(64-kbits) <= 2^51 - so that the
+	 * global writes below are coalesced (thread-contiguous slots would scatter them 64 B apart) */
+#pragma unroll
+	for (int k = 0; k < ORD_PER_THREAD; k++)
+		if (c[k])
+			s_slot[pos++] = ((unsigned long long)(threadIdx.x * ORD_PER_THREAD + k) << 51) | c[k];
+	__syncthreads();
+	const uint32_t first_base = leaf << range_bits;
+	for (uint32_t i = threadIdx.x; i < total; i += ORD_THREADS) {
+		const unsigned long long v = s_slot[i];
+		const uint32_t first = first_base + (uint32_t)(v >> 51);
+		a.out_first[base + i] = first;
+		a.out_count[base + i] = (int64_t)(v & ((1ull << 51) - 1ull));
+		if (a.out_key)
+			a.out_key[base + i] = a.keys[first];
 	}
 }
 
@@ -461,7 +479,7 @@ static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
 	uint32_t k = 1;
 	while (k < 32 && (1ull << k) < n_l)
 		k++;
-	int b = (int)k - 11;
+	int b = (int)k - ORD_RANGE_BITS;
 	if (b < 1)
 		b = 1;
 	if (b > 2 * MDB_MAX_RADIX_BITS)
@@ -649,6 +667,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		oa.leaf_bits = (uint32_t)(sb1 + sb2);
 		oa.out_first = first_out;
 		oa.out_count = out_count;
+		oa.keys = keys_l;
+		oa.out_key = out_key;
 		if (ps.leaf_cap) {
 			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
 			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
@@ -663,11 +683,6 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			oa.out_base = obase;
 		}
 		MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
-		if (out_key) {
-			rc = mdb_dev_gather64(ctx, keys_l, NULL, first_out, G, out_key, NULL);
-			if (rc)
-				return rc;
-		}
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
