@@ -64,6 +64,7 @@ struct mdb_level_args {
 	/* FAST (histogram-free) form: child (seg, digit) owns the fixed-capacity region [child*cap, child*cap+cap) */
 	uint32_t *cursor;		/* per child: elements placed so far (zeroed before the launch) */
 	uint32_t cap;
+	uint32_t nsub;			/* > 0: first level, child = digit * nsub + (block % nsub) sub-region; 0: child = seg * R + digit */
 	uint32_t *status;		/* bit 1 set when a child overflowed its region */
 };
 
@@ -312,18 +313,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	const uint32_t total_d = threadIdx.x < R ? s_cnt[threadIdx.x] : 0u;
 	uint32_t tile_total;
 	const uint32_t off_d = mdb_block_excl_scan(total_d, s_tmp, &tile_total);
+	uint32_t fast_base = 0, fast_child = 0;
 	if (threadIdx.x < R) {
 		s_cnt[threadIdx.x] = off_d;
 		if (FAST) {
 			/* no histogram pass: reserve the run's place in the child's fixed-capacity region with one
-			 * global atomic per (tile, digit) - ~96 tiles share a cursor, contention is negligible */
-			const uint32_t child = td.seg * R + threadIdx.x;
-			const uint32_t base = total_d ? atomicAdd(&a.cursor[child], total_d) : 0u;
-			const bool ok = base + total_d <= a.cap;
-			if (!ok)
-				atomicOr(a.status, 2u);
-			s_ok[threadIdx.x] = ok;
-			s_delta[threadIdx.x] = (int32_t)(child * a.cap + base - off_d);
+			 * global atomic per (tile, digit).  The returned base is only needed for the write-out, so
+			 * the atomic's round trip overlaps the LDS staging below. */
+			/* first level: 8 sub-regions per digit, picked by blockIdx % 8 (= the XCD under round-robin
+			 * dispatch, so an XCD's partial lines meet in its own L2) keep the contention per cursor low */
+			fast_child = a.nsub ? threadIdx.x * a.nsub + (blockIdx.x % a.nsub) : td.seg * R + threadIdx.x;
+			fast_base = total_d ? atomicAdd(&a.cursor[fast_child], total_d) : 0u;
 		} else {
 			s_delta[threadIdx.x] = (int32_t)(a.hist[(uint64_t)td.hbase + (uint64_t)threadIdx.x * td.nt] - off_d);
 		}
@@ -341,6 +341,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			if (HAS_RID)
 				s_rid[pos] = rid[r];
 		}
+	}
+	if (FAST && threadIdx.x < R) {
+		const bool ok = fast_base + total_d <= a.cap;
+		if (!ok)
+			atomicOr(a.status, 2u);
+		s_ok[threadIdx.x] = ok;
+		s_delta[threadIdx.x] = (int32_t)(fast_child * a.cap + fast_base - off_d);
 	}
 	__syncthreads();
 
@@ -422,6 +429,49 @@ __global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const
 	tiles[t] = d;
 }
 
+/* ---- histogram-free FIRST level: regions (digit, sub) of fixed capacity with atomic cursors -------------
+ * region r = digit * nsub + sub lives at [r * cap, r * cap + min(cursor[r], cap)) and belongs to parent
+ * partition r / nsub.  The next level's tiles are cut from the regions. */
+__global__ void k_part_region_ntiles(const uint32_t *__restrict__ cursor, uint32_t nreg, uint32_t cap, uint32_t *__restrict__ ntiles)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > nreg)
+		return;
+	uint32_t c = 0;
+	if (r < nreg) {
+		c = cursor[r];
+		c = c < cap ? c : cap;
+	}
+	ntiles[r] = (c + MDB_TILE - 1) / MDB_TILE;
+}
+
+__global__ void k_part_build_tiles_regions(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ tb, uint32_t nreg,
+					   uint32_t cap, uint32_t nsub, mdb_tile_desc *__restrict__ tiles, uint32_t max_tiles)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= max_tiles)
+		return;
+	mdb_tile_desc d;
+	d.start = d.len = d.hbase = d.nt = d.seg = 0;
+	if (t < tb[nreg]) {
+		uint32_t lo = 0, hi = nreg;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (tb[mid] <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		const uint32_t r = lo, tl = t - tb[r];
+		uint32_t c = cursor[r];
+		c = c < cap ? c : cap;
+		d.start = r * cap + tl * MDB_TILE;		/* cap is a multiple of 64: every tile starts 16-byte aligned */
+		d.len = (c - tl * MDB_TILE) < MDB_TILE ? (c - tl * MDB_TILE) : MDB_TILE;
+		d.seg = r / nsub;
+	}
+	tiles[t] = d;
+}
+
 __global__ void k_part_seg0(uint32_t *seg_start, uint32_t *tb, uint32_t n, uint32_t ntiles)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -472,7 +522,8 @@ void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2)
 static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; }
 
 #define PART_F_STABLE 1u	/* keep input order inside every leaf (ballot ranking) */
-#define PART_F_FAST 2u		/* last level without histogram: fixed-capacity leaf regions + atomic cursors */
+#define PART_F_FAST 2u		/* no histogram passes: fixed-capacity regions + atomic cursors (two-level partitions only) */
+#define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
 static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
@@ -496,11 +547,16 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const uint32_t fast_cap = cap_override ? cap_override : part_fast_cap(n, nleaves_total);
 	const bool fast = (flags & PART_F_FAST) && !stable && nlevels == 2 && !final_hv_out &&
 			  (uint64_t)nleaves_total * fast_cap < 0xFFFFFFFFull;
+	/* ... and, with it, to the first level: PART_NSUB fixed-capacity sub-regions per digit */
+	const uint32_t nreg0 = Rl[0] * PART_NSUB;
+	const uint32_t cap0 = (uint32_t)((((n + nreg0 - 1) / nreg0) * 5 / 4 + 1024 + 63) & ~63ull);
+	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0 * cap0 < 0xFFFFFFFFull;
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
 	for (int l = 0; l < nlevels; l++) {
-		const uint64_t elems = (fast && l == 1) ? (uint64_t)nleaves_total * fast_cap : (n ? n : 1);
+		const uint64_t elems = (fast && l == 1) ? (uint64_t)nleaves_total * fast_cap
+				       : ((fast0 && l == 0) ? (uint64_t)nreg0 * cap0 : (n ? n : 1));
 		if (l == nlevels - 1 && final_hv_out)
 			hv_buf[l] = final_hv_out;	/* last level writes straight into the caller's buffer */
 		else
@@ -552,6 +608,43 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			a.mbits = mb;
 		}
 
+		if (fast0 && l == 0) {
+			/* histogram-free first level */
+			uint32_t *cursor0 = (uint32_t *)cv.take((size_t)nreg0 * 4);
+			uint32_t *reg_nt = (uint32_t *)cv.take(((size_t)nreg0 + 1) * 4);
+			uint32_t *reg_scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words((uint64_t)nreg0 + 1) * 4);
+			const uint32_t next_tiles = (uint32_t)(n / MDB_TILE) + nreg0 + 1;
+			mdb_tile_desc *next_desc = (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
+			if (cv.failed)
+				return -MIDORIDB_INTERNAL;
+			if (!dry) {
+				a.cursor = cursor0;
+				a.cap = cap0;
+				a.nsub = PART_NSUB;
+				a.status = ctx->d_status;
+				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
+				if (raw_hv) {
+					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				} else if (want_rid) {
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
+				} else {
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				}
+				MDB_LAUNCH(ctx, "part_region_ntiles", k_part_region_ntiles, (nreg0 + 1 + 255) / 256, 256, cursor0, nreg0, cap0, reg_nt);
+				int rc = mdb_scan_u32_inplace(ctx, reg_nt, (uint64_t)nreg0 + 1, reg_scan_tmp);
+				if (rc)
+					return rc;
+				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
+					   cap0, PART_NSUB, next_desc, next_tiles);
+			}
+			used_bits += bits1;
+			seg_start = NULL;
+			tb = NULL;
+			S = R;
+			tiles = next_desc;
+			ntiles = next_tiles;
+			continue;
+		}
 		if (fast_level) {
 			/* histogram-free last level: one cursor per leaf, runs placed with global atomics */
 			leaf_cnt = (uint32_t *)cv.take((size_t)nchild * 4);
