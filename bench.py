@@ -257,6 +257,24 @@ def main():
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernels": kern,
         }
+        if world == 1 and not use_dist and args.variant == "D":
+            # the other synthetic variant of SURVEY 8d C3 (unique keys on both sides: G = n groups), same pipeline
+            try:
+                b_u = dev.gen_keys(n, 0, n, 43, 0)
+                for _ in range(2):
+                    dev.join_group_count(a, None, b_u, None, out=out)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reps = max(3, args.steps // 2)
+                for _ in range(reps):
+                    ku, cu, fu, ju = dev.join_group_count(a, None, b_u, None, out=out)
+                torch.cuda.synchronize()
+                dtu = (time.perf_counter() - t1) / reps
+                line["variant_U"] = {"workload": f"unique keys both sides, {n} rows/table", "joined_rows": ju, "groups": int(ku.numel()),
+                                     "ms_per_step": dtu * 1e3, "value": ju / dtu}
+                del b_u
+            except Exception as e:  # pragma: no cover
+                line["variant_U"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:
