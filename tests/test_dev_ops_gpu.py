@@ -283,3 +283,18 @@ def test_join_group_count_split_begin_finish(dev):
     dev.join_group_count_begin(dev.to_dev(np.arange(10, dtype=np.int64)), None, 5)
     k, c, f, j = dev.join_group_count_finish(dev.to_dev(np.zeros(0, dtype=np.int64)), None)
     assert k.numel() == 0 and j == 0
+
+
+@pytest.mark.parametrize("n_l,n_r", [(393_216, 393_216), (393_217, 1000), (400_000, 786_433), (786_433, 5), (100, 2_000_000),
+                                       (2_000_000, 100), (3_000_000, 3_000_000)])
+def test_join_group_count_level_boundaries_and_asymmetric_sizes(dev, n_l, n_r):
+    """Sizes around the one-level / two-level switch (393 216 build rows) and very unequal tables
+    (the leaf count follows the left table; the right side is streamed whatever its size)."""
+    rng = np.random.default_rng(n_l ^ n_r)
+    dom = max(10, min(n_l, n_r) * 2)
+    kl = rng.integers(0, dom, n_l, dtype=np.int64)
+    kr = rng.integers(0, dom, n_r, dtype=np.int64)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), None, dev.to_dev(kr), None)
+    assert j == ej
+    assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
