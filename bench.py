@@ -36,7 +36,7 @@ ROCPROF_NAMES = {
     "leaf_join_group_count": ["k_leaf_group_count<true>"],
     "leaf_group_count": ["k_leaf_group_count<false>"],
     "part_hist_l0": ["k_part_hist<true>"],
-    "part_scatter_l0": ["k_part_scatter<true, true, false, false>", "k_part_scatter<true, false, false, false>"],
+    "part_scatter_l0": ["k_part_scatter<true, true, false, true>", "k_part_scatter<true, false, false, true>"],
     "part_scatter_l1": ["k_part_scatter<false, true, false, true>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
@@ -66,6 +66,7 @@ def parse_args():
                     help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the result against the CPU oracle (rows <= 2e7)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary variant-U measurement (profiling runs)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -257,7 +258,7 @@ def main():
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernels": kern,
         }
-        if world == 1 and not use_dist and args.variant == "D":
+        if world == 1 and not use_dist and args.variant == "D" and not args.no_secondary:
             # the other synthetic variant of SURVEY 8d C3 (unique keys on both sides: G = n groups), same pipeline
             try:
                 b_u = dev.gen_keys(n, 0, n, 43, 0)

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" $ARGS > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" $ARGS > "$OUT/write.log" 2>&1
