@@ -11,6 +11,7 @@
 #include <string.h>
 #include <vector>
 #include <string>
+#include <unordered_map>
 #include "mdb_dev.h"
 
 #define MDB_WAVE 64
@@ -29,6 +30,11 @@ struct mdb_dev_ctx {
 	hipEvent_t ev_fork, ev_join;
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
+	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
+	 * allocates dozens of temporaries and hipMalloc/hipFree cost 0.1-0.3 ms each */
+	std::unordered_map<void *, size_t> live;		/* buffers handed out -> size */
+	std::vector<std::pair<void *, size_t>> cache;		/* released buffers kept for reuse */
+	size_t cache_bytes;
 	char err[512];
 	/* scratch arena (grow-only, bump allocated per operator) */
 	char *arena;
@@ -55,6 +61,10 @@ int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
 			return mdb_set_err((ctx), -MIDORIDB_INTERNAL, "%s failed: %s (%s:%d)", #call, \
 					   hipGetErrorString(e__), __FILE__, __LINE__);            \
 	} while (0)
+
+/* cached device allocations (mdb_dev_core.hip) */
+int mdb_cached_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr);
+int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr);
 
 /* scratch arena */
 int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes);

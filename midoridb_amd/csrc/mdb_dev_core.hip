@@ -67,6 +67,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->aux_stream = NULL;
 	ctx->ev_fork = ctx->ev_join = NULL;
 	ctx->pending_op = NULL;
+	ctx->cache_bytes = 0;
 	ctx->overlap = false;	/* measured: no gain on one GPU (each kernel already fills the chip), kept for the multi-GPU exchange */
 	if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -103,6 +104,10 @@ extern "C" void mdb_dev_ctx_destroy(mdb_dev_ctx *ctx)
 	if (ctx->ev_join)
 		(void)hipEventDestroy(ctx->ev_join);
 	free(ctx->pending_op);
+	for (auto &c : ctx->cache)
+		(void)hipFree(c.first);
+	for (auto &l : ctx->live)
+		(void)hipFree(l.first);
 	if (ctx->arena)
 		(void)hipFree(ctx->arena);
 	if (ctx->d_status)
@@ -227,22 +232,78 @@ extern "C" size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx)
 
 /* ------------------------------------------------------------------ memory */
 
-extern "C" int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
+#define MDB_CACHE_MAX_BUFFERS 24
+#define MDB_CACHE_MAX_BYTES ((size_t)16 << 30)
+
+int mdb_cached_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
 {
 	*dptr = NULL;
-	hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+	if (bytes == 0)
+		bytes = 8;
+	/* best fit among the released buffers: big enough, at most 2x too big */
+	int best = -1;
+	for (size_t i = 0; i < ctx->cache.size(); i++) {
+		const size_t sz = ctx->cache[i].second;
+		if (sz >= bytes && sz <= 2 * bytes + 4096 && (best < 0 || sz < ctx->cache[best].second))
+			best = (int)i;
+	}
+	if (best >= 0) {
+		*dptr = ctx->cache[best].first;
+		ctx->live[*dptr] = ctx->cache[best].second;
+		ctx->cache_bytes -= ctx->cache[best].second;
+		ctx->cache.erase(ctx->cache.begin() + best);
+		return MIDORIDB_OK;
+	}
+	hipError_t e = hipMalloc(dptr, bytes);
+	if (e != hipSuccess) {
+		/* memory pressure: drop the cache and retry once */
+		(void)hipStreamSynchronize(ctx->stream);
+		for (auto &c : ctx->cache)
+			(void)hipFree(c.first);
+		ctx->cache.clear();
+		ctx->cache_bytes = 0;
+		e = hipMalloc(dptr, bytes);
+	}
 	if (e != hipSuccess)
 		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	ctx->live[*dptr] = bytes;
 	return MIDORIDB_OK;
+}
+
+int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr)
+{
+	if (!dptr)
+		return MIDORIDB_OK;
+	auto it = ctx->live.find(dptr);
+	if (it == ctx->live.end()) {
+		/* not ours (or already released): plain free */
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MDB_HIP(ctx, hipFree(dptr));
+		return MIDORIDB_OK;
+	}
+	const size_t sz = it->second;
+	ctx->live.erase(it);
+	/* reuse is ordered by the context's stream: whoever gets the buffer next launches after every kernel
+	 * that still reads it */
+	ctx->cache.push_back(std::make_pair(dptr, sz));
+	ctx->cache_bytes += sz;
+	while (ctx->cache.size() > MDB_CACHE_MAX_BUFFERS || ctx->cache_bytes > MDB_CACHE_MAX_BYTES) {
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->cache_bytes -= ctx->cache.front().second;
+		MDB_HIP(ctx, hipFree(ctx->cache.front().first));
+		ctx->cache.erase(ctx->cache.begin());
+	}
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
+{
+	return mdb_cached_alloc(ctx, bytes, dptr);
 }
 
 extern "C" int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr)
 {
-	if (!dptr)
-		return MIDORIDB_OK;
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	MDB_HIP(ctx, hipFree(dptr));
-	return MIDORIDB_OK;
+	return mdb_cached_free(ctx, dptr);
 }
 
 extern "C" int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes)

@@ -1095,12 +1095,9 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	if (J == 0)
 		return MIDORIDB_OK;
 	uint32_t *ol = NULL, *orr = NULL;
-	hipError_t e1 = hipMalloc((void **)&ol, J * 4), e2 = hipMalloc((void **)&orr, J * 4);
-	if (e1 != hipSuccess || e2 != hipSuccess) {
+	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
 		if (ol)
-			(void)hipFree(ol);
-		if (orr)
-			(void)hipFree(orr);
+			(void)mdb_cached_free(ctx, ol);
 		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
 	}
 	a.out_l = ol;
