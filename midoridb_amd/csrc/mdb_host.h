@@ -62,6 +62,7 @@ struct mdb_table {
 	uint64_t generation;		/* bumped by every mutation */
 	uint64_t dev_generation;	/* generation the device mirror reflects (0 = none) */
 	uint64_t dev_rows;
+	uint64_t dev_cap;		/* rows the device buffers can hold (appends reuse the spare room) */
 	bool device_only;		/* rows were generated on the device; there is no host copy */
 };
 

@@ -54,6 +54,7 @@ static void table_drop_device(struct mdb_table *t, mdb_dev_ctx *dev)
 	}
 	t->dev_generation = 0;
 	t->dev_rows = 0;
+	t->dev_cap = 0;
 }
 
 void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev)
@@ -135,6 +136,9 @@ int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen)
 	return MIDORIDB_OK;
 }
 
+/* Bring the device mirror up to date.  Tables only ever grow (INSERT / bulk append), so when the device
+ * buffers still have room only the appended tail travels over PCIe (device-resident
+ * table cache with INSERT invalidation); otherwise the buffers are re-created at the host capacity. */
 int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen)
 {
 	int rc = mdb_catalog_device(cat, err, errlen);
@@ -142,20 +146,32 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 		return rc;
 	if (t->device_only || (t->dev_generation == t->generation && t->dev_rows == t->nrows))
 		return MIDORIDB_OK;
-	table_drop_device(t, cat->dev);
+	const bool append = t->dev_generation != 0 && t->nrows >= t->dev_rows && t->nrows <= t->dev_cap;
+	if (!append) {
+		table_drop_device(t, cat->dev);
+		t->dev_cap = t->cap > t->nrows ? t->cap : t->nrows;
+	}
+	const uint64_t from = append ? t->dev_rows : 0;
 	for (int c = 0; c < t->ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
 		if (col->type != MDB_CT_INTEGER && col->type != MDB_CT_DOUBLE)
 			continue;	/* never referenced by the device path (rejected at plan time) */
 		if (t->nrows == 0)
 			continue;
-		rc = mdb_dev_alloc(cat->dev, t->nrows * 8, &col->d_data);
-		if (!rc)
-			rc = mdb_dev_h2d(cat->dev, col->d_data, col->data, t->nrows * 8);
+		rc = MIDORIDB_OK;
+		if (!col->d_data)
+			rc = mdb_dev_alloc(cat->dev, t->dev_cap * 8, &col->d_data);
+		if (!rc && t->nrows > from)
+			rc = mdb_dev_h2d(cat->dev, (char *)col->d_data + from * 8, col->data + from, (t->nrows - from) * 8);
 		if (!rc && col->null_count) {
-			rc = mdb_dev_alloc(cat->dev, ((t->nrows + 63) / 64) * 8, (void **)&col->d_nullbits);
+			const uint64_t words = (t->dev_cap + 63) / 64;
+			uint64_t w0 = from / 64;
+			if (!col->d_nullbits) {		/* first NULL of this column: the whole bitmap goes up */
+				rc = mdb_dev_alloc(cat->dev, words * 8, (void **)&col->d_nullbits);
+				w0 = 0;
+			}
 			if (!rc)
-				rc = mdb_dev_h2d(cat->dev, col->d_nullbits, col->nullbits, ((t->nrows + 63) / 64) * 8);
+				rc = mdb_dev_h2d(cat->dev, col->d_nullbits + w0, col->nullbits + w0, ((t->nrows + 63) / 64 - w0) * 8);
 		}
 		if (rc) {
 			snprintf(err, errlen, "execution phase: cannot mirror table '%s' on the device: %s\n", t->name,
@@ -193,12 +209,10 @@ int mdb_reference_column_order(const char (*keys)[MDB_NAME_LEN], int nkeys, int 
 	size_t cap = 16;
 	int count = 0;
 	/* bucket chains as arrays, index 0 = head */
-	int *chain = calloc((size_t)nkeys * 4096 / 4096 + 1, sizeof(int));	/* placeholder to keep allocation pattern simple */
 	int **bucket;
 	int *blen;
 	int rc = MIDORIDB_OK;
 
-	free(chain);
 	bucket = calloc(cap, sizeof(int *));
 	blen = calloc(cap, sizeof(int));
 	if (!bucket || !blen)
