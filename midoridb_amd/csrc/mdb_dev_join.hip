@@ -26,6 +26,7 @@
 #define LEAF_THREADS 512		/* pairs-join leaf kernels */
 #define GC_THREADS 1024		/* group-count leaf kernel: 16 waves x 2 workgroups = 32 waves/CU hide the LDS probe latency */
 #define GC_EMIT_ITERS ((GC_SLOTS + 1 + GC_THREADS - 1) / GC_THREADS)	/* table slots visited per thread */
+#define GC_REC_CHUNK 16384u	/* record-list slots a workgroup reserves at a time (one global atomic per chunk) */
 #define LEAF_BATCH 2		/* keys loaded per thread before the first is consumed */
 #define GC_SLOTS 3833u		/* group-count table (prime, for double hashing): 20 B/slot -> 75 KiB, two workgroups per CU */
 #define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
@@ -100,7 +101,9 @@ struct gc_args {
 	uint32_t cap_r;
 	int64_t *dense_cnt;		/* dense mode: [n_l], zeroed: COUNT(*) written at the group's first L position */
 	unsigned long long *rec;	/* record mode: one 64-bit record per group, (first << (64 - kbits)) | COUNT(*) */
-	uint32_t *rec_count;		/* record mode: number of records written so far */
+	uint32_t *rec_count;		/* record mode: list slots handed out so far (the list has zero-filled gaps) */
+	uint32_t *rec_valid;		/* record mode: number of real records (= groups) */
+	uint32_t rec_cap;		/* record mode: capacity of the list */
 	uint32_t kbits;			/* record mode: bits of a left row id (0 = dense mode) */
 	unsigned long long *joined;	/* sum of all counts */
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 	__shared__ unsigned long long s_cnt[GC_SLOTS + 1];	/* [GC_SLOTS] = the key whose hash is 0 */
 	__shared__ uint32_t s_first[GC_SLOTS + 1];
 	__shared__ unsigned long long s_sum;
-	__shared__ uint32_t s_scan[32];
+	__shared__ uint32_t s_chunk[4];		/* record list chunk of this workgroup: [0] base [1] used [2] size [3] valid records */
 
 	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
 		if (s < GC_SLOTS)
@@ -172,7 +175,10 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 	}
 	if (threadIdx.x == 0)
 		s_sum = 0ull;
+	if (threadIdx.x < 4)
+		s_chunk[threadIdx.x] = 0;	/* size 0: the first live leaf reserves a chunk */
 	unsigned long long mine = 0;
+	uint32_t nvalid = 0;
 
 	uint32_t leaf = blockIdx.x;
 	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
@@ -197,6 +203,34 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		 * created its table slots; only oversized (skewed) leaves scan the whole table */
 		const bool by_owner = (l1 - l0) <= GC_THREADS * LEAF_BATCH;
 		uint32_t own[LEAF_BATCH];
+		if (live && a.kbits) {
+			/* Record list space: this leaf emits at most one record per left row (and per table slot).
+			 * When the workgroup's current chunk cannot hold that, the unused tail is zero-filled (the
+			 * ordering sort skips zero records) and a new chunk is reserved with ONE global atomic - i.e.
+			 * one atomic per ~10-170 leaves instead of one on the critical path of every leaf. */
+			const uint32_t rows = l1 - l0;
+			const uint32_t need = (rows < GC_SLOTS ? rows : GC_SLOTS) + 1;
+			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+			if (used + need > size) {		/* uniform: every thread read the same words */
+				for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+					a.rec[base + i] = 0ull;
+				__syncthreads();		/* everyone has read s_chunk */
+				if (threadIdx.x == 0) {
+					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
+					const uint32_t nb = atomicAdd(a.rec_count, want);
+					if (nb + want > a.rec_cap) {
+						atomicOr(a.status, 8u);	/* list capacity exhausted: sizing bug, reported as an error */
+						s_chunk[0] = 0;
+						s_chunk[2] = 0;
+					} else {
+						s_chunk[0] = nb;
+						s_chunk[2] = want;
+					}
+					s_chunk[1] = 0;
+				}
+				/* visible to everyone after the barrier that ends the build phase */
+			}
+		}
 		if (live) {
 			/* build: left side (first batch already in registers) */
 			for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
@@ -270,63 +304,62 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			 * appended to one global list (a single atomic per leaf reserves the space) and ordered
 			 * afterwards by a radix sort on the first row id; dense mode: COUNT(*) is scattered to the
 			 * group's first row position (8-byte random writes, only kept as a fallback). */
-			uint64_t recv[GC_EMIT_ITERS];
-			uint32_t nrec = 0;
+			const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
 #pragma unroll
 			for (int it = 0; it < GC_EMIT_ITERS; it++) {
-				recv[it] = 0;
-				uint32_t s;
+				unsigned long long recv = 0;
+				uint32_t s = 0xFFFFFFFFu;
 				if (by_owner) {
 					/* slots created by this thread, plus (thread 0) the side slot of the hash-0 key */
 					if (it < LEAF_BATCH)
 						s = own[it];
 					else if (it == LEAF_BATCH && threadIdx.x == 0)
 						s = GC_SLOTS;
-					else
-						continue;
-					if (s == 0xFFFFFFFFu)
-						continue;
 				} else {
 					s = threadIdx.x + (uint32_t)it * GC_THREADS;
 					if (s > GC_SLOTS)
-						continue;
+						s = 0xFFFFFFFFu;
 				}
-				const unsigned long long c2 = s_cnt[s];
-				if (s < GC_SLOTS) {
-					if (!by_owner && s_key[s] == 0ull)
-						continue;
-					s_key[s] = 0ull;
-				} else if (c2 == 0ull) {
-					continue;
-				}
-				const uint32_t cl = (uint32_t)c2, cr = (uint32_t)(c2 >> 32);
-				const uint32_t first = s_first[s];
-				s_cnt[s] = 0ull;
-				s_first[s] = 0xFFFFFFFFu;
-				if (cl && (!HAS_R || cr)) {
-					const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
-					mine += c;
-					if (a.kbits) {
-						if (c >> (64 - a.kbits))
-							atomicOr(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
-						recv[it] = ((unsigned long long)first << (64 - a.kbits)) | c;
-						nrec++;
-					} else {
-						a.dense_cnt[first] = (int64_t)c;
+				if (s != 0xFFFFFFFFu) {
+					const unsigned long long c2 = s_cnt[s];
+					const bool occupied = s < GC_SLOTS ? (by_owner || s_key[s] != 0ull) : c2 != 0ull;
+					if (occupied) {
+						const uint32_t cl = (uint32_t)c2, cr = (uint32_t)(c2 >> 32);
+						const uint32_t first = s_first[s];
+						if (s < GC_SLOTS)
+							s_key[s] = 0ull;
+						s_cnt[s] = 0ull;
+						s_first[s] = 0xFFFFFFFFu;
+						if (cl && (!HAS_R || cr)) {
+							const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
+							mine += c;
+							if (a.kbits) {
+								if (c >> (64 - a.kbits))
+									atomicOr(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+								recv = ((unsigned long long)first << (64 - a.kbits)) | c;
+							} else {
+								a.dense_cnt[first] = (int64_t)c;
+							}
+						}
 					}
 				}
-			}
-			if (a.kbits) {
-				uint32_t total;
-				uint32_t pos = mdb_block_excl_scan(nrec, s_scan, &total);
-				if (threadIdx.x == 0 && total)
-					s_scan[20] = atomicAdd(a.rec_count, total);
-				__syncthreads();
-				pos += s_scan[20];
-#pragma unroll
-				for (int it = 0; it < GC_EMIT_ITERS; it++)
-					if (recv[it])
-						a.rec[pos++] = recv[it];
+				if (a.kbits) {
+					/* wave-level append: one LDS atomic per wave and iteration, no workgroup barrier */
+					const uint64_t m = __ballot(recv != 0ull);
+					if (m) {
+						const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+						uint32_t wbase = 0;
+						if (mdb_lane() == leader)
+							wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
+						wbase = __shfl(wbase, (int)leader, MDB_WAVE);
+						if (recv) {
+							const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+							if (pos < csize)
+								a.rec[cbase + pos] = recv;
+							nvalid++;
+						}
+					}
+				}
 			}
 			__syncthreads();	/* the next leaf builds into the cleared tables */
 		}
@@ -336,11 +369,20 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		r0 = nr0;
 		r1 = nr1;
 	}
+	if (a.kbits) {
+		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+		for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+			a.rec[base + i] = 0ull;		/* unused tail of the last chunk */
+		if (nvalid)
+			atomicAdd(&s_chunk[3], nvalid);
+	}
 	if (mine)
 		atomicAdd(&s_sum, mine);
 	__syncthreads();
 	if (threadIdx.x == 0 && s_sum)
 		atomicAdd(a.joined, s_sum);
+	if (threadIdx.x == 0 && a.kbits && s_chunk[3])
+		atomicAdd(a.rec_valid, s_chunk[3]);
 }
 
 /* ------------------------------------------------------------------ compaction of the dense count array
@@ -378,13 +420,19 @@ __global__ void k_null_poke(const unsigned long long *cnt_first, int64_t *dense_
 		dense_cnt[cnt_first[1]] = (int64_t)cnt_first[0];
 }
 
-__global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long long *rec, uint32_t *rec_count, uint32_t kbits,
-			   uint32_t *status)
+__global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long long *rec, uint32_t *rec_count, uint32_t *rec_valid,
+			   uint32_t rec_cap, uint32_t kbits, uint32_t *status)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0 && cnt_first[0]) {
 		if (cnt_first[0] >> (64 - kbits))
 			atomicOr(status, 4u);
-		rec[atomicAdd(rec_count, 1u)] = (cnt_first[1] << (64 - kbits)) | cnt_first[0];
+		const uint32_t pos = atomicAdd(rec_count, 1u);
+		if (pos < rec_cap) {
+			rec[pos] = (cnt_first[1] << (64 - kbits)) | cnt_first[0];
+			atomicAdd(rec_valid, 1u);
+		} else {
+			atomicOr(status, 8u);
+		}
 	}
 }
 
@@ -500,6 +548,13 @@ static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 
+/* slots of the group-record list: every group once, plus the zero-filled gaps of the chunked reservation
+ * (at most one leaf's worth per chunk, one unfinished chunk per workgroup) */
+static uint64_t gc_rec_capacity(mdb_dev_ctx *ctx, uint64_t n_l)
+{
+	return n_l + n_l / 4 + (uint64_t)(2 * ctx->num_cus + 2) * GC_REC_CHUNK + 4096;
+}
+
 /* The operator runs in two halves so that a multi-GPU pipeline can partition the left table while the
  * right table is still arriving over xGMI (mdb_dev_join_group_count_begin / _finish). */
 struct gc_state {
@@ -522,9 +577,9 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	{
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
-		need += mdb_align_up((st->n_l + 1) * 8) + mdb_align_up(st->n_l * 4) + 4096;
+		need += mdb_align_up(gc_rec_capacity(ctx, st->n_l) * 8) + mdb_align_up(st->n_l * 4) + 4096;
 		if (st->want_records && order_bits(st->n_l, &kb, &s1, &s2))
-			need += mdb_partition_raw_arena_bytes(st->n_l, s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) +
+			need += mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) +
 				(((size_t)1 << (s1 + s2)) + 4096) * 8;
 		else
 			need += mdb_filter_arena_bytes(st->n_l);
@@ -534,7 +589,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		return rc;
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, true, false, st->fast, &st->pl);
 	if (rc)
 		return rc;
@@ -572,14 +627,16 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	unsigned long long *rec = NULL;
 	uint32_t *sel = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
 	if (records) {
-		rec = (unsigned long long *)mdb_arena_take(ctx, (n_l + 1) * 8);
+		rec = (unsigned long long *)mdb_arena_take(ctx, gc_rec_capacity(ctx, n_l) * 8);
 	} else {
 		dense = (int64_t *)mdb_arena_take(ctx, n_l * 8);
 	}
 	if (!sel || (!rec && !dense))
 		return -MIDORIDB_INTERNAL;
-	/* d_status u32 words: [0] flags, [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
+	/* d_status u32 words: [0] flags, [1] record-list length, [2..3] joined rows (u64), [4..7] NULL-group stats,
+	 * [8] number of records (groups) */
 	uint32_t *d_rec_count = ctx->d_status + 1;
+	uint32_t *d_rec_valid = ctx->d_status + 8;
 	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
 	unsigned long long *d_nullst = (unsigned long long *)(ctx->d_status + 4);
 	if (dense)
@@ -598,6 +655,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.dense_cnt = dense;
 	a.rec = rec;
 	a.rec_count = d_rec_count;
+	a.rec_valid = d_rec_valid;
+	a.rec_cap = records ? (uint32_t)gc_rec_capacity(ctx, n_l) : 0;
 	a.kbits = records ? kbits : 0;
 	a.joined = d_joined;
 	a.status = ctx->d_status;
@@ -616,20 +675,21 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		MDB_HIP(ctx, hipMemsetAsync(d_nullst + 1, 0xFF, 8, ctx->stream));
 		MDB_LAUNCH(ctx, "null_stats", k_null_stats, 256, 256, null_l, n_l, d_nullst);
 		if (records) {
-			MDB_LAUNCH(ctx, "null_rec", k_null_rec, 1, 64, d_nullst, rec, d_rec_count, kbits, ctx->d_status);
+			MDB_LAUNCH(ctx, "null_rec", k_null_rec, 1, 64, d_nullst, rec, d_rec_count, d_rec_valid, a.rec_cap, kbits, ctx->d_status);
 		} else {
 			MDB_LAUNCH(ctx, "null_poke", k_null_poke, 1, 64, d_nullst, dense);
 		}
 	}
 
 	uint64_t *h = ctx->h_pinned;
-	uint64_t G = 0;
+	uint64_t G = 0, list_len = 0;
 	uint32_t *first_out = out_first ? out_first : sel;
 	if (records) {
 		/* G, J and the status flags come back with one sync; the sort is sized by G */
-		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		G = h[1] >> 32;
+		list_len = h[1] >> 32;
+		G = (uint32_t)h[5];
 	} else {
 		uint32_t *d_total = NULL;
 		rc = mdb_filter_nonzero64(ctx, dense, n_l, sel, &d_total);
@@ -649,12 +709,14 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (status & 1u)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
 				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", GC_SLOTS);
+	if (status & 8u)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "group record list exhausted (sizing bug)");
 	if (G > cap)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
 		mdb_part_result ps;
-		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, G, sb1, sb2, ord_range, &ps);
+		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, &ps);
 		if (rc)
 			return rc;
 		ord_args oa;

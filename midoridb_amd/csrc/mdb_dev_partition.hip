@@ -64,6 +64,7 @@ struct mdb_level_args {
 	/* FAST (histogram-free) form: child (seg, digit) owns the fixed-capacity region [child*cap, child*cap+cap) */
 	uint32_t *cursor;		/* per child: elements placed so far (zeroed before the launch) */
 	uint32_t cap;
+	uint32_t skip_zero;		/* raw sort keys: a zero word is a gap in the input list, not a key */
 	uint32_t nsub;			/* > 0: first level, child = digit * nsub + (block % nsub) sub-region; 0: child = seg * R + digit */
 	uint32_t *status;		/* bit 1 set when a child overflowed its region */
 };
@@ -171,6 +172,10 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			valid[0] = false;
 		if (valid[1] && mdb_bit_is_set(a.nullbits, g0 + 1))
 			valid[1] = false;
+	}
+	if (!LEVEL0 && a.skip_zero) {
+		valid[0] = valid[0] && hv[0] != 0;
+		valid[1] = valid[1] && hv[1] != 0;
 	}
 }
 
@@ -588,6 +593,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.nullbits = nullbits;
 		a.n = n;
 		a.hv_in = l ? hv_buf[l - 1] : raw_hv;	/* raw_hv: level 0 reads ready-made 64-bit sort keys */
+		a.skip_zero = (l == 0 && raw_hv) ? 1u : 0u;
 		a.rid_in = l ? rid_buf[l - 1] : NULL;
 		a.tiles = tiles;
 		a.hv_out = hv_buf[l];
