@@ -440,7 +440,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *__
 }
 
 /* single block: exclusive scan of block_sums[0..nb) in place, carry across 1024-wide sweeps */
-__global__ __launch_bounds__(1024) void k_scan_spine(uint32_t *__restrict__ block_sums, uint32_t nb)
+__global__ __launch_bounds__(1024) void k_scan_spine(uint32_t *__restrict__ block_sums, uint32_t nb, bool write_total)
 {
 	__shared__ uint32_t tmp[32];
 	uint32_t carry = 0;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint32_t *__restrict__ bloc
 			block_sums[i] = carry + ex;
 		carry += total;
 	}
-	if (threadIdx.x == 0)
+	if (write_total && threadIdx.x == 0)
 		block_sums[nb] = carry;
 }
 
@@ -504,13 +504,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *__restric
 	}
 }
 
+/* single block: dst[0..n] = exclusive prefix sums of src[0..n) (dst[n] = the total) */
+__global__ __launch_bounds__(1024) void k_scan_excl_from(const uint32_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ dst)
+{
+	__shared__ uint32_t tmp[32];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base <= n; base += 1024) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < n ? src[i] : 0;
+		uint32_t total;
+		const uint32_t ex = mdb_block_excl_scan(v, tmp, &total);
+		if (i <= n)
+			dst[i] = carry + ex;
+		carry += total;
+	}
+}
+
+int mdb_scan_u32_small_from(mdb_dev_ctx *ctx, const uint32_t *src, uint32_t n, uint32_t *dst)
+{
+	MDB_LAUNCH(ctx, "scan_small", k_scan_excl_from, 1, 1024, src, n, dst);
+	return MIDORIDB_OK;
+}
+
 int mdb_scan_u32_inplace(mdb_dev_ctx *ctx, uint32_t *data, uint64_t len, uint32_t *block_sums)
 {
 	if (len == 0)
 		return MIDORIDB_OK;
+	if (len <= MDB_SCAN_SMALL) {
+		/* short arrays (leaf / region tables): one single-workgroup launch instead of three */
+		MDB_LAUNCH(ctx, "scan_small", k_scan_spine, 1, 1024, data, (uint32_t)len, false);
+		return MIDORIDB_OK;
+	}
 	uint32_t nb = (uint32_t)((len + MDB_SCAN_CHUNK - 1) / MDB_SCAN_CHUNK);
 	MDB_LAUNCH(ctx, "scan_reduce", k_scan_reduce, nb, SCAN_THREADS, data, len, block_sums);
-	MDB_LAUNCH(ctx, "scan_spine", k_scan_spine, 1, 1024, block_sums, nb);
+	MDB_LAUNCH(ctx, "scan_spine", k_scan_spine, 1, 1024, block_sums, nb, true);
 	MDB_LAUNCH(ctx, "scan_apply", k_scan_apply, nb, SCAN_THREADS, data, len, block_sums);
 	return MIDORIDB_OK;
 }

@@ -11,8 +11,11 @@
  * last value written; callers that need the grand total append one zero element.  `block_sums`
  * is scratch of mdb_scan_scratch_words(len) uint32 words. */
 #define MDB_SCAN_CHUNK 4096u
+#define MDB_SCAN_SMALL 16384u	/* up to here the scan is one single-workgroup launch */
 static inline size_t mdb_scan_scratch_words(uint64_t len) { return (size_t)((len + MDB_SCAN_CHUNK - 1) / MDB_SCAN_CHUNK) + 1; }
 int mdb_scan_u32_inplace(mdb_dev_ctx *ctx, uint32_t *data, uint64_t len, uint32_t *block_sums);
+/* dst[0..n] = exclusive prefix sums of src[0..n), dst[n] = total; one single-workgroup launch (n <= MDB_SCAN_SMALL) */
+int mdb_scan_u32_small_from(mdb_dev_ctx *ctx, const uint32_t *src, uint32_t n, uint32_t *dst);
 
 /* ---- radix partition (mdb_dev_partition.hip) ------------------------------------------------ */
 #define MDB_TILE 4096u		/* elements per partition tile */

@@ -437,17 +437,27 @@ __global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const
 /* ---- histogram-free FIRST level: regions (digit, sub) of fixed capacity with atomic cursors -------------
  * region r = digit * nsub + sub lives at [r * cap, r * cap + min(cursor[r], cap)) and belongs to parent
  * partition r / nsub.  The next level's tiles are cut from the regions. */
-__global__ void k_part_region_ntiles(const uint32_t *__restrict__ cursor, uint32_t nreg, uint32_t cap, uint32_t *__restrict__ ntiles)
+/* FAST first level: tiles per region (a region = the filled part of a fixed-capacity sub-region) and their
+ * exclusive scan, in one single-workgroup launch (there are only R * PART_NSUB + 1 entries). */
+__global__ __launch_bounds__(1024) void k_part_region_tiles_scan(const uint32_t *__restrict__ cursor, uint32_t nreg, uint32_t cap,
+								 uint32_t *__restrict__ tb)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r > nreg)
-		return;
-	uint32_t c = 0;
-	if (r < nreg) {
-		c = cursor[r];
-		c = c < cap ? c : cap;
+	__shared__ uint32_t s_tmp[32];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base <= nreg; base += 1024) {
+		const uint32_t r = base + threadIdx.x;
+		uint32_t c = 0;
+		if (r < nreg) {
+			c = cursor[r];
+			c = c < cap ? c : cap;
+		}
+		const uint32_t nt = (c + MDB_TILE - 1) / MDB_TILE;
+		uint32_t total;
+		const uint32_t ex = mdb_block_excl_scan(nt, s_tmp, &total);
+		if (r <= nreg)
+			tb[r] = carry + ex;
+		carry += total;
 	}
-	ntiles[r] = (c + MDB_TILE - 1) / MDB_TILE;
 }
 
 __global__ void k_part_build_tiles_regions(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ tb, uint32_t nreg,
@@ -576,7 +586,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	uint32_t *tb = (uint32_t *)cv.take(2 * 4);
 	if (cv.failed)
 		return -MIDORIDB_INTERNAL;
-	if (!dry)
+	if (!dry && !fast0)	/* the FAST first level has no parent segments to describe */
 		MDB_LAUNCH(ctx, "part_seg0", k_part_seg0, 1, 64, seg_start, tb, (uint32_t)n, nt0);
 
 	uint32_t ntiles = nt0;
@@ -618,7 +628,6 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			/* histogram-free first level */
 			uint32_t *cursor0 = (uint32_t *)cv.take((size_t)nreg0 * 4);
 			uint32_t *reg_nt = (uint32_t *)cv.take(((size_t)nreg0 + 1) * 4);
-			uint32_t *reg_scan_tmp = (uint32_t *)cv.take(mdb_scan_scratch_words((uint64_t)nreg0 + 1) * 4);
 			const uint32_t next_tiles = (uint32_t)(n / MDB_TILE) + nreg0 + 1;
 			mdb_tile_desc *next_desc = (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
 			if (cv.failed)
@@ -636,10 +645,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
-				MDB_LAUNCH(ctx, "part_region_ntiles", k_part_region_ntiles, (nreg0 + 1 + 255) / 256, 256, cursor0, nreg0, cap0, reg_nt);
-				int rc = mdb_scan_u32_inplace(ctx, reg_nt, (uint64_t)nreg0 + 1, reg_scan_tmp);
-				if (rc)
-					return rc;
+				MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, reg_nt);
 				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
 					   cap0, PART_NSUB, next_desc, next_tiles);
 			}
