@@ -143,6 +143,15 @@ int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_t *src_null
 int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
 int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n);
 
+/* ------------------------------------------------------------------ UPDATE ... SET col = literal
+ *
+ * Device half of set_field_to_value() (reference src/engine/executor_update.c:394-433): for every
+ * selected row (idx[k], or all rows 0..n-1 when idx == NULL) dst[row] = value_bits, and the row's bit
+ * in dst_nullbits is set (set_null != 0; the cell keeps its old bytes, as upstream) or cleared.
+ * dst_nullbits may be NULL when set_null == 0 (a column that has never held a NULL). */
+int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_nullbits, const uint32_t *idx, uint64_t n,
+			  int64_t value_bits, int set_null);
+
 /* ------------------------------------------------------------------ INNER JOIN (materialising)
  *
  * Replaces _join_nested_loop_tbl2tbl() for ON l = r (reference

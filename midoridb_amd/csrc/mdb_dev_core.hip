@@ -647,6 +647,42 @@ extern "C" int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n)
 	return MIDORIDB_OK;
 }
 
+/* UPDATE: one thread per selected row; NULL bits through word atomics (rows of one word may be spread
+ * over several threads) */
+__global__ __launch_bounds__(STREAM_THREADS) void k_scatter_set64(uint64_t *__restrict__ dst, unsigned long long *__restrict__ nullbits,
+								   const uint32_t *__restrict__ idx, uint64_t n, uint64_t value, int set_null)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k >= n)
+			continue;
+		const uint64_t row = idx ? (uint64_t)idx[k] : k;
+		if (!set_null)
+			dst[row] = value;
+		if (nullbits) {
+			const unsigned long long bit = 1ull << (row & 63);
+			if (set_null)
+				atomicOr(&nullbits[row >> 6], bit);
+			else
+				atomicAnd(&nullbits[row >> 6], ~bit);
+		}
+	}
+}
+
+extern "C" int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_nullbits, const uint32_t *idx, uint64_t n,
+				     int64_t value_bits, int set_null)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (set_null && !dst_nullbits)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "scatter_set64: SET NULL needs a NULL bitmap");
+	MDB_LAUNCH(ctx, "scatter_set64", k_scatter_set64, stream_grid(n), STREAM_THREADS, (uint64_t *)dst,
+		   (unsigned long long *)dst_nullbits, idx, n, (uint64_t)value_bits, set_null);
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dev_cross_pairs(mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint32_t *out_l, uint32_t *out_r)
 {
 	if (n_l == 0 || n_r == 0)

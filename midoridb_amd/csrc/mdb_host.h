@@ -153,13 +153,28 @@ struct mdb_insert {
 	struct mdb_expr ***vals;	/* [ntuples][nvals] literal expressions */
 };
 
-enum mdb_stmt_kind { MDB_ST_SELECT = 1, MDB_ST_CREATE, MDB_ST_INSERT };
+/* DELETE FROM t [WHERE ...] / UPDATE t SET col = literal [, ...] [WHERE ...]
+ * (reference AST: ast_delete.c / ast_update.c; executors executor_delete.c:412-459, executor_update.c:460-503) */
+struct mdb_assign {
+	char col[MDB_NAME_LEN];
+	struct mdb_expr *val;		/* literal: INT / FLOAT / NULL */
+};
+
+struct mdb_dml {
+	char name[MDB_NAME_LEN];
+	struct mdb_expr *where;		/* NULL = every row */
+	struct mdb_assign *assign;	/* UPDATE only */
+	int nassign;
+};
+
+enum mdb_stmt_kind { MDB_ST_SELECT = 1, MDB_ST_CREATE, MDB_ST_INSERT, MDB_ST_DELETE, MDB_ST_UPDATE };
 
 struct mdb_stmt {
 	int kind;
 	struct mdb_select sel;
 	struct mdb_create crt;
 	struct mdb_insert ins;
+	struct mdb_dml dml;
 };
 
 int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, size_t errlen);
@@ -183,6 +198,8 @@ void mdb_result_free(struct mdb_result *r);
 int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, size_t errlen);
 int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_rows_aff, char *err, size_t errlen);
 int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen);
+int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen);
+int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen);
 
 /* result column order of the reference (djb2 hashtable iteration) */
 int mdb_reference_column_order(const char (*keys)[MDB_NAME_LEN], int nkeys, int *order_out);

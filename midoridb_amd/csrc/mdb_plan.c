@@ -15,7 +15,7 @@
 /* wrapper node kinds that only live on the builder stack */
 enum {
 	BX_TABLE = 100, BX_JOIN, BX_ONEXPR, BX_WHERE, BX_GROUPBY, BX_HAVING, BX_ORDERBYITEM, BX_ORDERBYLIST,
-	BX_LIMIT, BX_SELECTALL,
+	BX_LIMIT, BX_SELECTALL, BX_ASSIGN,
 };
 
 static struct mdb_expr *ex_new(int kind)
@@ -452,6 +452,62 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 		} else if (!strcmp(t, "STMT")) {
 			done = true;
 			continue;
+		/* ---- DELETE / UPDATE ---- */
+		} else if (starts(t, "ASSIGN ")) {
+			e = ex_new(BX_ASSIGN);
+			if (e) {
+				copy_name(e->col, t + 7);
+				if (pop_n_into(&st, 1, e))
+					FAIL("error while running syntax analysis on query\n");
+			}
+		} else if (starts(t, "DELETEONE ")) {
+			struct mdb_dml *d = &out->dml;
+			copy_name(d->name, t + 10);
+			if (st.n > 1 || (st.n == 1 && st.v[0]->kind != BX_WHERE))
+				FAIL("error while running syntax analysis on query\n");
+			if (st.n == 1) {
+				struct mdb_expr *w = pop(&st);
+				d->where = w->kids[0];
+				w->kids[0] = NULL;
+				w->nkids = 0;
+				mdb_expr_free(w);
+			}
+			out->kind = MDB_ST_DELETE;
+			continue;
+		} else if (starts(t, "UPDATE ")) {
+			struct mdb_dml *d = &out->dml;
+			if (sscanf(t + 7, "%127[A-Za-z0-9_] %d %d", a, &x, &y) != 3 || x < 1 || y < 0 || y > 1 || st.n != x + y)
+				FAIL("error while running syntax analysis on query\n");
+			copy_name(d->name, a);
+			if (y) {
+				struct mdb_expr *w = pop(&st);
+				if (w->kind != BX_WHERE) {
+					mdb_expr_free(w);
+					FAIL("error while running syntax analysis on query\n");
+				}
+				d->where = w->kids[0];
+				w->kids[0] = NULL;
+				w->nkids = 0;
+				mdb_expr_free(w);
+			}
+			d->assign = calloc((size_t)x, sizeof(*d->assign));
+			if (!d->assign)
+				goto nomem;
+			d->nassign = x;
+			for (int k = x - 1; k >= 0; k--) {
+				struct mdb_expr *as = pop(&st);
+				if (as->kind != BX_ASSIGN) {
+					mdb_expr_free(as);
+					FAIL("error while running syntax analysis on query\n");
+				}
+				copy_name(d->assign[k].col, as->col);
+				d->assign[k].val = as->kids[0];
+				as->kids[0] = NULL;
+				as->nkids = 0;
+				mdb_expr_free(as);
+			}
+			out->kind = MDB_ST_UPDATE;
+			continue;
 		/* ---- CREATE TABLE ---- */
 		} else if (!strcmp(t, "STARTCOL") || starts(t, "ATTR ")) {
 			continue;
@@ -564,5 +620,9 @@ void mdb_stmt_free(struct mdb_stmt *s)
 		free(s->ins.vals[i]);
 	}
 	free(s->ins.vals);
+	mdb_expr_free(s->dml.where);
+	for (int i = 0; i < s->dml.nassign; i++)
+		mdb_expr_free(s->dml.assign[i].val);
+	free(s->dml.assign);
 	memset(s, 0, sizeof(*s));
 }

@@ -65,6 +65,14 @@ static struct query_output *run_rpn(struct database *db, struct mdb_rpn *rpn, st
 		rc = mdb_exec_insert(cat, &st.ins, &output->n_rows_aff, msg, msglen);
 		output->status = rc ? ST_ERROR : ST_OK_EXECUTED;
 		break;
+	case MDB_ST_DELETE:
+		rc = mdb_exec_delete(cat, &st.dml, &output->n_rows_aff, msg, msglen);
+		output->status = rc ? ST_ERROR : ST_OK_EXECUTED;
+		break;
+	case MDB_ST_UPDATE:
+		rc = mdb_exec_update(cat, &st.dml, &output->n_rows_aff, msg, msglen);
+		output->status = rc ? ST_ERROR : ST_OK_EXECUTED;
+		break;
 	case MDB_ST_SELECT: {
 		struct mdb_result *res = NULL;
 		rc = mdb_exec_select(cat, &st.sel, &res, msg, msglen);
@@ -297,6 +305,7 @@ int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint6
 	t->nrows = n;
 	t->device_only = true;
 	t->dev_rows = n;
+	t->dev_cap = n ? n : 1;
 	t->dev_generation = t->generation;
 	return MIDORIDB_OK;
 }

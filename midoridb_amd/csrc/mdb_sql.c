@@ -28,10 +28,10 @@ enum tk {
 };
 
 static const char *const KEYWORDS[] = {
-	"AND", "AS", "ASC", "AUTO_INCREMENT", "BY", "CREATE", "DATE", "DATETIME", "DESC", "DISTINCT",
+	"AND", "AS", "ASC", "AUTO_INCREMENT", "BY", "CREATE", "DATE", "DATETIME", "DELETE", "DESC", "DISTINCT",
 	"DOUBLE", "EXISTS", "FROM", "GROUP", "HAVING", "IF", "IN", "INDEX", "INNER", "INSERT", "INT",
 	"INT4", "INTEGER", "INTO", "IS", "JOIN", "KEY", "LEFT", "LIKE", "LIMIT", "MOD", "NOT", "NULL",
-	"ON", "OR", "ORDER", "OUTER", "PRIMARY", "RIGHT", "SELECT", "TABLE", "TINYINT", "UNIQUE",
+	"ON", "OR", "ORDER", "OUTER", "PRIMARY", "RIGHT", "SELECT", "SET", "TABLE", "TINYINT", "UNIQUE", "UPDATE",
 	"VALUE", "VALUES", "VARCHAR", "VARCHARACTER", "WHERE", "XOR", NULL
 };
 
@@ -51,6 +51,7 @@ struct parser {
 	char *err;
 	size_t errlen;
 	bool failed;
+	bool dml;		/* inside delete_expr / update_expr: names, literals, logic, comparisons, IS NULL, IN only */
 };
 
 static void fail(struct parser *p, const char *fmt, ...)
@@ -360,7 +361,7 @@ static void parse_primary(struct parser *p)
 		char first[256];
 		strcpy(first, l->text);
 		next(p);
-		if (is_punct(p, '.')) {
+		if (is_punct(p, '.') && !p->dml) {
 			next(p);
 			if (p->lx.type != T_NAME) {
 				fail(p, "syntax error, expecting column name after '.'");
@@ -390,6 +391,8 @@ static void parse_primary(struct parser *p)
 		next(p);
 		return;
 	case T_FCOUNT:
+		if (p->dml)
+			break;
 		next(p);
 		expect_punct(p, '(');
 		if (is_punct(p, '*')) {
@@ -416,7 +419,7 @@ static void parse_primary(struct parser *p)
 			expect_punct(p, ')');
 			return;
 		}
-		if (l->text[0] == '-') {
+		if (l->text[0] == '-' && !p->dml) {
 			next(p);
 			parse_expr(p, P_NEG);
 			emit(p, "NEG");
@@ -449,10 +452,10 @@ static void parse_expr(struct parser *p, int min_prec)
 		} else if (l->type == T_CMP) {
 			prec = P_CMP;
 			snprintf(op, sizeof(op), "CMP %d", l->sub);
-		} else if (is_punct(p, '+') || is_punct(p, '-')) {
+		} else if (!p->dml && (is_punct(p, '+') || is_punct(p, '-'))) {
 			prec = P_ADD;
 			strcpy(op, l->text[0] == '+' ? "ADD" : "SUB");
-		} else if (is_punct(p, '*') || is_punct(p, '/') || is_punct(p, '%') || is_kw(p, "MOD")) {
+		} else if (!p->dml && (is_punct(p, '*') || is_punct(p, '/') || is_punct(p, '%') || is_kw(p, "MOD"))) {
 			prec = P_MUL;
 			strcpy(op, l->text[0] == '*' ? "MUL" : (l->text[0] == '/' ? "DIV" : "MOD"));
 		} else if (is_kw(p, "IS")) {
@@ -477,7 +480,7 @@ static void parse_expr(struct parser *p, int min_prec)
 				n = parse_val_list(p);
 				expect_punct(p, ')');
 				emit(p, neg ? "ISNOTIN %d" : "ISIN %d", n);
-			} else if (accept_kw(p, "LIKE")) {
+			} else if (!p->dml && accept_kw(p, "LIKE")) {
 				parse_expr(p, P_ISIN + 1);
 				emit(p, neg ? "NOTLIKE" : "LIKE");
 			} else {
@@ -811,6 +814,78 @@ static void parse_insert(struct parser *p)
 	emit(p, "INSERTVALS %d %d %s", hascols, ntuples, tname);
 }
 
+/* DELETE FROM NAME [WHERE delete_expr]  (midorisql.y:309-343) */
+static void parse_delete(struct parser *p)
+{
+	char tname[256];
+
+	expect_kw(p, "FROM");
+	if (p->failed)
+		return;
+	if (p->lx.type != T_NAME) {
+		fail(p, "syntax error, expecting table name");
+		return;
+	}
+	strcpy(tname, p->lx.text);
+	next(p);
+	if (accept_kw(p, "WHERE")) {
+		p->dml = true;
+		parse_expr(p, P_OR);
+		p->dml = false;
+		emit(p, "WHERE");
+	}
+	emit(p, "DELETEONE %s", tname);
+}
+
+/* UPDATE NAME SET NAME = update_expr [, ...] [WHERE update_expr]  (midorisql.y:393-440) */
+static void parse_update(struct parser *p)
+{
+	char tname[256], cname[256];
+	int nassign = 0, haswhere = 0;
+
+	if (p->lx.type != T_NAME) {
+		fail(p, "syntax error, expecting table name");
+		return;
+	}
+	strcpy(tname, p->lx.text);
+	next(p);
+	expect_kw(p, "SET");
+	do {
+		if (p->failed)
+			return;
+		if (p->lx.type != T_NAME) {
+			fail(p, "syntax error, expecting column name");
+			return;
+		}
+		strcpy(cname, p->lx.text);
+		next(p);
+		if (p->lx.type != T_CMP) {
+			fail(p, "syntax error, expecting '='");
+			return;
+		}
+		if (p->lx.sub != 4) {
+			fail(p, "bad insert assignment to %s", cname);	/* the reference's own wording, midorisql.y:404 */
+			return;
+		}
+		next(p);
+		/* update_expr is left-recursive over COMPARISON too; the right-hand side of an assignment binds
+		 * tighter than a following comparison cannot occur before ',' or WHERE, so one full expression */
+		p->dml = true;
+		parse_expr(p, P_OR);
+		p->dml = false;
+		emit(p, "ASSIGN %s", cname);
+		nassign++;
+	} while (!p->failed && is_punct(p, ',') && (next(p), true));
+	if (accept_kw(p, "WHERE")) {
+		p->dml = true;
+		parse_expr(p, P_OR);
+		p->dml = false;
+		emit(p, "WHERE");
+		haswhere = 1;
+	}
+	emit(p, "UPDATE %s %d %d", tname, nassign, haswhere);
+}
+
 int mdb_sql_parse(const char *sql, struct mdb_rpn *out, char *err, size_t errlen)
 {
 	struct parser p = {0};
@@ -828,6 +903,10 @@ int mdb_sql_parse(const char *sql, struct mdb_rpn *out, char *err, size_t errlen
 		parse_create(&p);
 	else if (accept_kw(&p, "INSERT"))
 		parse_insert(&p);
+	else if (accept_kw(&p, "DELETE"))
+		parse_delete(&p);
+	else if (accept_kw(&p, "UPDATE"))
+		parse_update(&p);
 	else
 		fail(&p, "syntax error, unexpected '%s'", p.lx.type == T_EOF ? "end of input" : p.lx.text);
 	emit(&p, "STMT");

@@ -59,6 +59,7 @@ def _bind(lib):
         "mdb_dev_gather64": ([P, P, P, P, c_uint64, P, P], c_int),
         "mdb_dev_gather32": ([P, P, P, c_uint64, P], c_int),
         "mdb_dev_iota32": ([P, P, c_uint64], c_int),
+        "mdb_dev_scatter_set64": ([P, P, P, P, c_uint64, c_int64, c_int], c_int),
         "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
@@ -80,7 +81,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
 ]
@@ -294,6 +295,12 @@ class DeviceCtx:
         dst = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         self._chk(self.lib.mdb_dev_gather32(self.h, _ptr(src), _ptr(idx), n, _ptr(dst)), "gather32")
         return dst[:n]
+
+    def scatter_set64(self, dst, dst_nulls, idx, value_bits, set_null=False):
+        """UPDATE's device half: dst[idx[k]] = value (all rows when idx is None), NULL bits set or cleared."""
+        n = idx.numel() if idx is not None else dst.numel()
+        self._chk(self.lib.mdb_dev_scatter_set64(self.h, _ptr(dst), _ptr(dst_nulls), _ptr(idx), n, int(value_bits),
+                                                 1 if set_null else 0), "scatter_set64")
 
     def partition_by_dest(self, keys, nulls, n_dest, out=None):
         n = keys.numel()

@@ -96,6 +96,15 @@ def parse_rpn(rpn):
                     out["group"] = k[1]
                 else:
                     out["sel"].append(k)
+        elif head == "ASSIGN":
+            st.append(("assign", rest, st.pop()))
+        elif head == "DELETEONE":
+            out = {"kind": "delete", "table": rest, "where": st.pop()[1] if st else None}
+        elif head == "UPDATE":
+            tbl, na, hw = rest.split()
+            where = st.pop()[1] if int(hw) else None
+            out = {"kind": "update", "table": tbl, "assign": st[-int(na):], "where": where}
+            del st[-int(na):]
         elif head == "STMT":
             break
         else:
@@ -243,6 +252,37 @@ class Naive:
         if names == ["COUNT(*)"] and not q["group"]:		# handle_countonly_case :1590-1653
             rows = [{"COUNT(*)": len(rows)}] if rows else []
         return names, [tuple(self._raw(r[n]) for n in names) for r in rows]
+
+    # ---- DELETE / UPDATE (reference src/engine/executor_delete.c:412-440, executor_update.c:460-484) ------
+    def run_dml(self, rpn):
+        """Executes one DELETE or UPDATE statement on self.tables; returns the rows affected
+        (query_output.n_rows_aff).  Row predicate = eval_delete_row / should_update_row
+        (executor_delete.c:354-410, executor_update.c:318-392): same comparison rules as SELECT's WHERE
+        (NULL operand -> false), evaluated on the row's OLD values; UPDATE then applies every assignment
+        (set_field_to_value, executor_update.c:394-433).  DELETE keeps the survivors in scan order:
+        the reference only flags the row (table_delete_row) and every later scan skips flagged rows."""
+        q = parse_rpn(rpn)
+        cols, rows = self.tables[q["table"]]
+        tabs = [("table", q["table"], None)]
+        where = self._resolve(q["where"], tabs) if q["where"] is not None else None
+
+        def hit(r):
+            if where is None:
+                return True
+            return self._cond(where, {f"{q['table']}.{c}": v for c, v in zip(cols, r)})
+
+        if q["kind"] == "delete":
+            keep = [r for r in rows if not hit(r)]
+            n = len(rows) - len(keep)
+            rows[:] = keep
+            return n
+        n = 0
+        for r in rows:
+            if hit(r):
+                for _, col, val in q["assign"]:
+                    r[cols.index(col)] = None if val[0] == "null" else val[1]
+                n += 1
+        return n
 
     @staticmethod
     def _raw(v):

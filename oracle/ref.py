@@ -42,6 +42,12 @@ def _lib():
         L.ref_result_fetch.restype = ctypes.c_int64
         L.ref_table_rows.argtypes = [P, ctypes.c_char_p]
         L.ref_table_rows.restype = ctypes.c_int64
+        L.ref_rows_affected.argtypes = [P]
+        L.ref_rows_affected.restype = ctypes.c_int64
+        L.ref_table_fetch.argtypes = [P, ctypes.c_char_p, P, P, ctypes.c_int64]
+        L.ref_table_fetch.restype = ctypes.c_int64
+        L.ref_table_ncols.argtypes = [P, ctypes.c_char_p]
+        L.ref_table_ncols.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -127,6 +133,22 @@ class RefDB:
         # values only, as query_column_int64() would return them: the reference's NULL bitmap is not
         # reliable in results (see ref_harness.c), a NULL cell reads as 0
         return names, [tuple(int(vals[i, k]) for k in range(len(names))) for i in range(len(vals))]
+
+    def rows_affected(self):
+        return int(self.L.ref_rows_affected(self.h))
+
+    def table_dump(self, name):
+        """Live rows of a base table in scan order -> (values int64 [n, ncols], nulls bool [n, ncols])."""
+        nc = self.L.ref_table_ncols(self.h, name.encode())
+        n = self.L.ref_table_fetch(self.h, name.encode(), None, None, 0)
+        if nc < 0 or n < 0:
+            raise RefError(f"no table {name}")
+        vals = np.zeros((max(n, 1), nc), dtype=np.int64)
+        nulls = np.zeros((max(n, 1), nc), dtype=np.uint8)
+        if n:
+            self.L.ref_table_fetch(self.h, name.encode(), vals.ctypes.data_as(ctypes.c_void_p),
+                                   nulls.ctypes.data_as(ctypes.c_void_p), n)
+        return vals[:n], nulls[:n].astype(bool)
 
     def table_rows(self, name):
         return int(self.L.ref_table_rows(self.h, name.encode()))

@@ -40,6 +40,7 @@
 struct ref_ctx {
 	struct database db;
 	struct table *result;		/* result of the last successful SELECT */
+	int64_t rows_affected;		/* query_output.n_rows_aff of the last statement */
 	char err[1024];
 };
 
@@ -127,6 +128,7 @@ int ref_exec_rpn(void *h, const char *rpn)
 		ret = -4;
 		goto out_ast;
 	}
+	c->rows_affected = (int64_t)out->n_rows_aff;
 	if (node->node_type == AST_TYPE_SEL_SELECT) {
 		c->result = out->results.table;
 		ret = 1;
@@ -251,6 +253,60 @@ int64_t ref_result_fetch(void *h, int64_t *vals, uint8_t *nulls, int64_t cap_row
 		}
 	}
 	return n;
+}
+
+/* query_output.n_rows_aff of the last executed statement (INSERT / DELETE / UPDATE). */
+int64_t ref_rows_affected(void *h)
+{
+	return ((struct ref_ctx *)h)->rows_affected;
+}
+
+/*
+ * Live rows of a BASE table in scan order (what proc_from_clause_table() would see), 8-byte columns only:
+ * row-major raw cell bytes and the row header's NULL bits (reliable in base tables).  vals == NULL: count.
+ */
+int64_t ref_table_fetch(void *h, const char *table_name, int64_t *vals, uint8_t *nulls, int64_t cap_rows)
+{
+	struct ref_ctx *c = h;
+	struct table *t = database_table_get(&c->db, (char *)table_name);
+	struct list_head *pos;
+	size_t rs;
+	int64_t n = 0;
+
+	if (!t)
+		return -1;
+	rs = table_calc_row_size(t);
+	list_for_each(pos, t->datablock_head) {
+		struct datablock *b = list_entry(pos, struct datablock, head);
+		for (size_t i = 0; i < DATABLOCK_PAGE_SIZE / rs; i++) {
+			struct row *r = (struct row *)&b->data[rs * i];
+			size_t off = 0;
+			if (r->flags.empty)
+				break;
+			if (r->flags.deleted)
+				continue;
+			if (vals && n < cap_rows) {
+				for (int k = 0; k < t->column_count; k++) {
+					size_t sp = table_calc_column_space(&t->columns[k]);
+					int64_t v = 0;
+					if (sp == 8)
+						memcpy(&v, r->data + off, 8);
+					vals[n * t->column_count + k] = v;
+					nulls[n * t->column_count + k] = bit_test(r->null_bitmap, k, sizeof(r->null_bitmap));
+					off += sp;
+				}
+			}
+			n++;
+		}
+	}
+	return n;
+}
+
+int ref_table_ncols(void *h, const char *table_name)
+{
+	struct ref_ctx *c = h;
+	struct table *t = database_table_get(&c->db, (char *)table_name);
+	return t ? t->column_count : -1;
 }
 
 /* Number of live rows of a base table (sanity helper for the tests). */

@@ -49,3 +49,33 @@ def ddl_columns(case):
         body = s[s.index("(") + 1:s.rindex(")")]
         out[name] = [p.split()[0] for p in body.split(",")]
     return out
+
+
+# ---- DML scripts (tests/golden/dml.json) ---------------------------------------------------------------
+
+def script_schema(sql):
+    """CREATE TABLE T (a INT, x DOUBLE) -> ("T", ["a", "x"], ["INT", "DOUBLE"])."""
+    name = sql.split()[2]
+    body = sql[sql.index("(") + 1:sql.rindex(")")]
+    cols = [p.split()[0] for p in body.split(",")]
+    types = [p.split()[1].upper().replace("INTEGER", "INT") for p in body.split(",")]
+    return name, cols, types
+
+
+def insert_values(sql, types):
+    """INSERT INTO T VALUES (1, NULL, 0.5); -> [1, None, 0.5] (python ints / floats / None)."""
+    body = sql[sql.index("(", sql.upper().index("VALUES")) + 1:sql.rindex(")")]
+    out = []
+    for tok, ty in zip(body.split(","), types):
+        tok = tok.strip()
+        out.append(None if tok.upper() == "NULL" else (float(tok) if ty == "DOUBLE" else int(tok)))
+    return out
+
+
+def raw_cell(v):
+    """python value -> the 8 raw bytes as int64 (what the fixtures store), None stays None."""
+    if v is None:
+        return None
+    if isinstance(v, float):
+        return int(np.array([v], dtype=np.float64).view(np.int64)[0])
+    return int(v)

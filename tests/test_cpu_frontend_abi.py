@@ -65,6 +65,24 @@ def test_rpn_of_other_statement_kinds():
                                                                                                      "SELECT 0 3"] or True
 
 
+def test_rpn_of_delete_and_update():
+    # delete_stmt / update_stmt of the reference grammar (src/parser/midorisql.y:309-343, 393-440)
+    assert _rpn("DELETE FROM A;") == ["DELETEONE A", "STMT"]
+    assert _rpn("DELETE FROM A WHERE f1 > 5 AND (f2 IS NOT NULL OR f1 IN (1,2));") == [
+        "NAME f1", "NUMBER 5", "CMP 2", "NAME f2", "ISNOTNULL", "NAME f1", "NUMBER 1", "NUMBER 2", "ISIN 2", "OR", "AND", "WHERE",
+        "DELETEONE A", "STMT"]
+    assert _rpn("UPDATE A SET f1=42, f2=43WHERE 1 = 1;") == ["NUMBER 42", "ASSIGN f1", "NUMBER 43", "ASSIGN f2", "NUMBER 1", "NUMBER 1",
+                                                            "CMP 4", "WHERE", "UPDATE A 2 1", "STMT"]
+    assert _rpn("UPDATE A SET x = NULL;") == ["NULL", "ASSIGN x", "UPDATE A 1 0", "STMT"]
+    from oracle.ref import sql_to_rpn
+    for bad in ["UPDATE A SET f1 > 2;", "UPDATE A SET f1 = f1 + 1;", "DELETE FROM A WHERE A.f1 = 2;", "DELETE A;", "UPDATE A f1 = 2;"]:
+        with pytest.raises(ValueError):
+            sql_to_rpn(bad)
+    for case in G.load("dml.json"):
+        for st in case["steps"]:
+            assert _rpn(st["sql"])[-1] == "STMT"
+
+
 def test_operator_precedence_follows_the_grammar():
     # OR < XOR < AND < comparison (reference src/parser/midorisql.y:48-63)
     toks = _rpn("SELECT a FROM T WHERE a = 1 OR b = 2 AND c = 3 XOR d = 4;")
@@ -120,11 +138,26 @@ def test_ddl_dml_on_host_and_loud_failure_without_device():
         db.execute("CREATE TABLE IF NOT EXISTS A (z INT);")
         with pytest.raises(QueryError):
             db.execute("CREATE TABLE V (s VARCHAR(10));")		# unsupported on the device path
+        with pytest.raises(QueryError):
+            db.execute("UPDATE A SET nosuch = 1;")
+        with pytest.raises(QueryError):
+            db.execute("UPDATE A SET id_a = 1.5;")			# DOUBLE literal into an INT column
+        with pytest.raises(QueryError):
+            db.execute("DELETE FROM NOSUCH;")
+        with pytest.raises(QueryError):
+            db.execute("DELETE FROM A WHERE 3 < id_a;")		# the reference swaps the operands: rejected
+        with pytest.raises(QueryError):
+            db.execute("DELETE FROM A WHERE 1 = NULL;")		# value-to-value types differ
         if not torch.cuda.is_available():
             # the product has no CPU executor: a SELECT without a HIP device must fail, loudly
             with pytest.raises(QueryError) as ei:
                 db.query("SELECT id_a FROM A;")
             assert "no usable HIP device" in str(ei.value)
+            # ... and so must the WHERE evaluation of DELETE / UPDATE
+            for q in ("DELETE FROM A WHERE id_a = 1;", "UPDATE A SET id_a = 2 WHERE id_a = 1;"):
+                with pytest.raises(QueryError) as ei:
+                    db.execute(q)
+                assert "no usable HIP device" in str(ei.value)
 
 
 def test_front_end_drives_the_real_reference():

@@ -160,3 +160,37 @@ def test_naive_three_way_intended_semantics(case):
     got = {n: [r[i] for r in rows] for i, n in enumerate(names)}
     exp = {n: [r[i] for r in case["expect"]["rows"]] for i, n in enumerate(case["expect"]["names"])}
     assert got == exp
+
+
+# ---- DELETE / UPDATE scripts: the pure-Python restatement against vectors from the real reference ---------
+
+@pytest.mark.parametrize("case", G.load("dml.json"), ids=lambda c: c["name"])
+def test_naive_dml_matches_reference_vectors(case):
+    """oracle/naive.py run_dml() (scan_delete / scan_update restated) replays every script of
+    tests/golden/dml.json: rows affected, table contents after every DELETE / UPDATE, SELECT results."""
+    from oracle.naive import Naive
+    from oracle.ref import sql_to_rpn
+    nv = Naive({})
+    types = {}
+    for st in case["steps"]:
+        sql = st["sql"]
+        up = sql.upper()
+        if up.startswith("CREATE"):
+            name, cols, ty = G.script_schema(sql)
+            nv.tables[name] = (cols, [])
+            types[name] = ty
+        elif st["status"] == "error":
+            pass		# semantic errors: nothing may change (checked through the dump below)
+        elif up.startswith("INSERT"):
+            name = sql.split()[2]
+            nv.tables[name][1].append(G.insert_values(sql, types[name]))
+        elif up.startswith(("DELETE", "UPDATE")):
+            assert nv.run_dml(sql_to_rpn(sql)) == st["rows_affected"], sql
+        else:
+            names, rows = nv.run(sql_to_rpn(sql))
+            assert names == st["result"]["names"], sql
+            assert [list(r) for r in rows] == st["result"]["rows"], sql
+        for t, dump in st.get("tables", {}).items():
+            cols, rows = nv.tables[t]
+            got = [[G.raw_cell(r[c]) for r in rows] for c in range(len(cols))]
+            assert got == dump, f"{sql}: table {t}"
