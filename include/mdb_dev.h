@@ -152,6 +152,25 @@ int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n);
 int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_nullbits, const uint32_t *idx, uint64_t n,
 			  int64_t value_bits, int set_null);
 
+/* ------------------------------------------------------------------ ORDER BY
+ *
+ * The reference's grammar and semantic phase accept ORDER BY (src/parser/midorisql.y:183-191,
+ * src/parser/semantic_select.c:1895-1928) but executor_run_select_stmt() never looks at the node
+ * (SURVEY.md 8a D7); this is the device operator of the extension (8f row 4).
+ * perm_out[k] = position in the stream (0..n-1) of the row that comes k-th when the stream is sorted by
+ * keys[0], then keys[1], ...; ties keep the stream order (stable).  Row i of the stream reads
+ * values[rid ? rid[i] : i]; NULL sorts before every value (ASC: first, DESC: last); DOUBLE keys follow
+ * IEEE order with -0.0 before +0.0.  Synchronous. */
+#define MDB_SORT_MAX_KEYS 16
+struct mdb_sort_key {
+	const void *values;		/* int64_t[] or double[] */
+	const uint64_t *nullbits;	/* or NULL */
+	const uint32_t *rid;		/* or NULL = identity */
+	int32_t type;			/* enum mdb_valtype */
+	int32_t desc;			/* 0 ASC, 1 DESC */
+};
+int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out);
+
 /* ------------------------------------------------------------------ INNER JOIN (materialising)
  *
  * Replaces _join_nested_loop_tbl2tbl() for ON l = r (reference

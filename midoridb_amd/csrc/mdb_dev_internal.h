@@ -52,6 +52,12 @@ size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t 
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap,
 		      mdb_part_result *out);
 
+/* one stable least-significant-digit radix pass over (key, row id) pairs: digit = (key >> shift) & (2^bits - 1),
+ * bits <= 8.  hist = scratch of mdb_sort_pass_hist_words(n) uint32, scan_tmp = mdb_scan_scratch_words(of that). */
+size_t mdb_sort_pass_hist_words(uint64_t n);
+int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_in, uint64_t n, uint32_t shift, uint32_t bits,
+		  uint64_t *key_out, uint32_t *rid_out, uint32_t *hist, uint32_t *scan_tmp);
+
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
 

@@ -796,6 +796,46 @@ int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits
 			      out);
 }
 
+/* ---- one stable LSD radix pass (ORDER BY) --------------------------------------------------------
+ *
+ * (key_in, rid_in) -> (key_out, rid_out), stably ordered by the `bits`-wide digit at `shift`: the flat-tiled
+ * histogram / scan / ballot-ranked scatter of the exact partition path (STABLE keeps the input order inside
+ * every digit, which is what makes least-significant-digit-first sorting and multi-column ORDER BY work). */
+size_t mdb_sort_pass_hist_words(uint64_t n)
+{
+	const uint64_t nt = (n + MDB_TILE - 1) / MDB_TILE;
+	return (size_t)(nt ? nt : 1) * 256u + 1u;
+}
+
+int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_in, uint64_t n, uint32_t shift, uint32_t bits,
+		  uint64_t *key_out, uint32_t *rid_out, uint32_t *hist, uint32_t *scan_tmp)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (bits < 1 || bits > 8 || n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sort pass: bad digit width or too many rows");
+	mdb_level_args a;
+	memset(&a, 0, sizeof(a));
+	a.n = n;
+	a.hv_in = key_in;
+	a.rid_in = rid_in;
+	a.hv_out = key_out;
+	a.rid_out = rid_out;
+	a.ntiles = (uint32_t)((n + MDB_TILE - 1) / MDB_TILE);
+	a.R = 1u << bits;
+	a.mode = MDB_DIGIT_RADIX;
+	a.shift = shift;
+	a.mbits = bits;
+	a.hist = hist;
+	const uint64_t hlen = (uint64_t)a.ntiles * a.R;
+	MDB_LAUNCH(ctx, "orderby_hist", k_part_hist<false>, grid8(a.ntiles), PART_THREADS, a);
+	int rc = mdb_scan_u32_inplace(ctx, hist, hlen, scan_tmp);
+	if (rc)
+		return rc;
+	MDB_LAUNCH(ctx, "orderby_scatter", (k_part_scatter<false, true, true, false>), grid8(a.ntiles), PART_THREADS, a);
+	return MIDORIDB_OK;
+}
+
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
 
 extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,

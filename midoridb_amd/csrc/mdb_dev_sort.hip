@@ -1,0 +1,154 @@
+/*
+ * mdb_dev_sort.hip - ORDER BY on the device: a stable permutation that sorts a tuple stream by up to
+ * MDB_SORT_MAX_KEYS columns (ASC / DESC, INT64 or DOUBLE, NULL = smallest value).
+ *
+ * The reference parses ORDER BY but never executes it; this operator is the
+ * device half of the extension.  Method: least-significant-digit radix sort, last ORDER BY column first -
+ * every pass is stable (mdb_sort_pass: histogram, scan, ballot-ranked scatter), so ties of a later column
+ * keep the order the earlier passes produced and ties of all columns keep the stream order.  Per column:
+ *
+ *   k_sort_load     u[k] = order-preserving 64-bit image of the column value of stream row perm[k]
+ *                   (INT64: sign bit flipped; DOUBLE: IEEE total-order trick; DESC: complemented),
+ *                   block-reduced min / max / any-NULL
+ *   passes          only over the bits in which min and max differ (8-bit digits): small domains cost one
+ *                   or two passes instead of eight
+ *   NULL pass       one extra 1-bit pass when the column holds NULLs (first for ASC, last for DESC)
+ *
+ * HBM traffic per 8-bit pass and row: 8 B (histogram read) + 12 B read + 12 B written.
+ */
+#include "mdb_dev_internal.h"
+
+#define SORT_THREADS 256
+
+__device__ static inline uint64_t sort_image(uint64_t bits, int type, int desc)
+{
+	uint64_t u;
+	if (type == MDB_T_DOUBLE)
+		u = (bits >> 63) ? ~bits : (bits ^ 0x8000000000000000ull);
+	else
+		u = bits ^ 0x8000000000000000ull;
+	return desc ? ~u : u;
+}
+
+/* mm[0] = min image, mm[1] = max image, mm[2] = 1 when a NULL was seen (all over non-NULL rows) */
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_load(const uint64_t *__restrict__ values, const uint64_t *__restrict__ nullbits,
+							     const uint32_t *__restrict__ rid, const uint32_t *__restrict__ perm, uint64_t n,
+							     int type, int desc, uint64_t *__restrict__ u_out, unsigned long long *mm)
+{
+	__shared__ unsigned long long s_min, s_max;
+	__shared__ uint32_t s_null;
+	if (threadIdx.x == 0) {
+		s_min = ~0ull;
+		s_max = 0ull;
+		s_null = 0;
+	}
+	__syncthreads();
+	unsigned long long lo = ~0ull, hi = 0ull;
+	bool anynull = false;
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
+		const uint32_t p = perm[k];
+		const uint64_t row = rid ? (uint64_t)rid[p] : (uint64_t)p;
+		uint64_t u = 0;
+		if (nullbits && mdb_bit_is_set(nullbits, row)) {
+			anynull = true;
+		} else {
+			u = sort_image(values[row], type, desc);
+			lo = u < lo ? u : lo;
+			hi = u > hi ? u : hi;
+		}
+		u_out[k] = u;
+	}
+	if (lo <= hi) {
+		atomicMin(&s_min, lo);
+		atomicMax(&s_max, hi);
+	}
+	if (anynull)
+		atomicOr(&s_null, 1u);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_min <= s_max) {
+			atomicMin(&mm[0], s_min);
+			atomicMax(&mm[1], s_max);
+		}
+		if (s_null)
+			atomicOr(&mm[2], 1ull);
+	}
+}
+
+/* key of the NULL pass: ASC 0 = NULL, 1 = value; DESC 0 = value, 1 = NULL */
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_nullflag(const uint64_t *__restrict__ nullbits, const uint32_t *__restrict__ rid,
+								 const uint32_t *__restrict__ perm, uint64_t n, int desc,
+								 uint64_t *__restrict__ u_out)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
+		const uint32_t p = perm[k];
+		const uint64_t row = rid ? (uint64_t)rid[p] : (uint64_t)p;
+		const bool isnull = mdb_bit_is_set(nullbits, row);
+		u_out[k] = (uint64_t)(isnull == (desc != 0));
+	}
+}
+
+extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out)
+{
+	if (nkeys < 1 || nkeys > MDB_SORT_MAX_KEYS)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: between 1 and %d keys", MDB_SORT_MAX_KEYS);
+	if (n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: too many rows");
+	if (n == 0)
+		return MIDORIDB_OK;
+	const size_t hist_words = mdb_sort_pass_hist_words(n);
+	const size_t need = 2 * mdb_align_up(n * 8) + 2 * mdb_align_up(n * 4) + mdb_align_up(hist_words * 4) +
+			    mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	uint64_t *u[2] = { (uint64_t *)mdb_arena_take(ctx, n * 8), (uint64_t *)mdb_arena_take(ctx, n * 8) };
+	uint32_t *pm[2] = { (uint32_t *)mdb_arena_take(ctx, n * 4), (uint32_t *)mdb_arena_take(ctx, n * 4) };
+	uint32_t *hist = (uint32_t *)mdb_arena_take(ctx, hist_words * 4);
+	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(hist_words) * 4);
+	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 64);
+	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
+		return -MIDORIDB_INTERNAL;
+	rc = mdb_dev_iota32(ctx, pm[0], n);
+	if (rc)
+		return rc;
+	int cur = 0;	/* (u[cur], pm[cur]) hold the current order */
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	uint64_t *h = ctx->h_pinned;
+	for (int j = nkeys - 1; j >= 0; j--) {
+		const struct mdb_sort_key *key = &keys[j];
+		if (key->type != MDB_T_INT64 && key->type != MDB_T_DOUBLE)
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: key %d has an unknown type", j);
+		h[0] = ~0ull;
+		h[1] = 0ull;
+		h[2] = 0ull;
+		MDB_HIP(ctx, hipMemcpyAsync(mm, h, 24, hipMemcpyHostToDevice, ctx->stream));
+		MDB_LAUNCH(ctx, "orderby_load", k_sort_load, grid, SORT_THREADS, (const uint64_t *)key->values, key->nullbits, key->rid,
+			   (const uint32_t *)pm[cur], n, key->type, key->desc, u[cur], mm);
+		MDB_HIP(ctx, hipMemcpyAsync(h, mm, 24, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint64_t lo = h[0], hi = h[1];
+		const bool anynull = h[2] != 0;
+		uint32_t bits = 0;
+		if (lo <= hi && (lo ^ hi))
+			bits = 64u - (uint32_t)__builtin_clzll(lo ^ hi);
+		for (uint32_t shift = 0; shift < bits; shift += 8) {
+			const uint32_t w = bits - shift < 8 ? bits - shift : 8;
+			rc = mdb_sort_pass(ctx, u[cur], pm[cur], n, shift, w, u[cur ^ 1], pm[cur ^ 1], hist, scan_tmp);
+			if (rc)
+				return rc;
+			cur ^= 1;
+		}
+		if (anynull) {
+			MDB_LAUNCH(ctx, "orderby_nullflag", k_sort_nullflag, grid, SORT_THREADS, key->nullbits, key->rid, (const uint32_t *)pm[cur], n,
+				   key->desc, u[cur]);
+			rc = mdb_sort_pass(ctx, u[cur], pm[cur], n, 0, 1, u[cur ^ 1], pm[cur ^ 1], hist, scan_tmp);
+			if (rc)
+				return rc;
+			cur ^= 1;
+		}
+	}
+	MDB_HIP(ctx, hipMemcpyAsync(perm_out, pm[cur], n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}

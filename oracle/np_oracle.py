@@ -237,3 +237,29 @@ def gen_keys(n, first_index, domain, seed, modulus=0):
     if modulus:
         x = x % np.uint64(modulus)
     return x.astype(np.int64)
+
+
+def sort_perm(keys, n):
+    """Oracle of mdb_dev_sort_perm (ORDER BY; an extension, the reference never executes ORDER BY - SURVEY 8a D7):
+    keys = [(values, nulls bool or None, rid or None, is_double, desc)], row i of the stream reads values[rid[i]].
+    Stable; NULL is the smallest value (first for ASC, last for DESC); DOUBLE in IEEE order with -0.0 < +0.0.
+    Plain numpy: one stable argsort per key, last key first."""
+    perm = np.arange(n, dtype=np.int64)
+    for values, nulls, rid, is_double, desc in reversed(keys):
+        v = np.asarray(values)
+        rows = perm if rid is None else np.asarray(rid, dtype=np.int64)[perm]
+        bits = v.view(np.uint64)[rows] if v.dtype != np.uint64 else v[rows]
+        if is_double:
+            neg = (bits >> np.uint64(63)).astype(bool)
+            img = np.where(neg, ~bits, bits ^ np.uint64(1 << 63))
+        else:
+            img = bits ^ np.uint64(1 << 63)
+        if desc:
+            img = ~img
+        isnull = np.zeros(n, dtype=bool) if nulls is None else np.asarray(nulls, dtype=bool)[rows]
+        img = np.where(isnull, np.uint64(0), img)		# NULL rows tie with each other: they keep their order
+        order = np.argsort(img, kind="stable")
+        perm, isnull = perm[order], isnull[order]
+        flag = (isnull == bool(desc)).astype(np.uint8)	# ASC: NULL -> 0 (first); DESC: NULL -> 1 (last)
+        perm = perm[np.argsort(flag, kind="stable")]
+    return perm.astype(np.uint32)

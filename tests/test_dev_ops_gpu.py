@@ -298,3 +298,70 @@ def test_join_group_count_level_boundaries_and_asymmetric_sizes(dev, n_l, n_r):
     k, c, f, j = dev.join_group_count(dev.to_dev(kl), None, dev.to_dev(kr), None)
     assert j == ej
     assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).astype(np.int64), ef)
+
+
+# ---- ORDER BY: stable multi-key sort permutation (extension) -------------------------------------
+
+def _sort_case(dev, rng, n, specs, with_rid=False):
+    """specs: list of (kind, desc, null_frac); kind in small/full/neg/double/const."""
+    keys_np, keys_dev, keep = [], [], []
+    m = n if not with_rid else 2 * n + 3
+    rid = rng.integers(0, m, n).astype(np.uint32) if with_rid else None
+    rid_dev = dev.to_dev(rid) if with_rid else None
+    for kind, desc, nf in specs:
+        if kind == "small":
+            v = rng.integers(0, 7, m, dtype=np.int64)
+        elif kind == "full":
+            v = rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, m, dtype=np.int64)
+        elif kind == "neg":
+            v = rng.integers(-1000, 1000, m, dtype=np.int64)
+        elif kind == "const":
+            v = np.full(m, 42, dtype=np.int64)
+        else:
+            v = np.round(rng.normal(0, 100, m), 1)
+            v[rng.random(m) < 0.05] = -0.0
+            v[rng.random(m) < 0.05] = 0.0
+        nulls = (rng.random(m) < nf) if nf else None
+        vd = dev.to_dev(v)
+        nd = dev.nullbits_dev(nulls)
+        keep += [vd, nd]
+        keys_np.append((v, nulls, rid, kind == "double", desc))
+        keys_dev.append((vd, nd, rid_dev, D.T_DOUBLE if kind == "double" else D.T_INT64, desc))
+    got = _np(dev.sort_perm(keys_dev, n)).view(np.uint32)
+    want = orc.sort_perm(keys_np, n)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 100_000, 1_000_003])
+def test_sort_perm_single_key_sizes(dev, n):
+    rng = np.random.default_rng(n)
+    _sort_case(dev, rng, n, [("neg", False, 0.0)])
+    _sort_case(dev, rng, n, [("small", True, 0.1)])
+
+
+@pytest.mark.parametrize("specs", [
+    [("full", False, 0.0)], [("full", True, 0.2)], [("double", False, 0.0)], [("double", True, 0.1)], [("const", False, 0.0)],
+    [("const", True, 0.5)], [("small", False, 0.0), ("neg", True, 0.0)], [("small", True, 0.3), ("double", False, 0.3), ("small", False, 0.0)],
+    [("small", False, 1.0)], [("neg", False, 0.0), ("full", False, 0.0), ("double", True, 0.0), ("small", True, 0.2)],
+], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
+def test_sort_perm_key_kinds(dev, specs):
+    rng = np.random.default_rng(len(specs) * 7 + 1)
+    _sort_case(dev, rng, 50_000, specs)
+    _sort_case(dev, rng, 50_000, specs, with_rid=True)
+
+
+def test_sort_perm_large_property(dev):
+    """10^7 rows, 2 keys: result is a permutation, keys come out non-decreasing, ties keep stream order."""
+    n = 10_000_000
+    a = dev.gen_keys(n, 0, n, 5, 1000)			# 1000 distinct values
+    b = dev.gen_keys(n, 0, n, 6, 0)			# permutation
+    perm = dev.sort_perm([(a, None, None, D.T_INT64, False), (b, None, None, D.T_INT64, True)], n).to(torch.int64)
+    assert torch.equal(torch.sort(perm).values, torch.arange(n, device=perm.device))
+    sa, sb = a[perm], b[perm]
+    assert bool((sa[1:] >= sa[:-1]).all())
+    same = sa[1:] == sa[:-1]
+    assert bool((sb[1:][same] <= sb[:-1][same]).all())
+    one = dev.sort_perm([(a, None, None, D.T_INT64, False)], n).to(torch.int64)
+    s1 = a[one]
+    tie = s1[1:] == s1[:-1]
+    assert bool((one[1:][tie] > one[:-1][tie]).all())	# stability
