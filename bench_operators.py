@@ -106,6 +106,21 @@ def main():
     res["three_way_join_1e7"] = {"rows_per_table": n2, "joined_rows": j3, "ms": ms, "joined_rows_per_s": j3 / (ms * 1e-3),
                                  "kernels_ms": kern}
 
+    # ---- ORDER BY (extension): stable sort permutation of 10^8 rows on one INT64 key with 27
+    #      significant bits (4 radix passes), and a top-k over the north-star groups through query_execute()
+    k1 = dev.gen_keys(n, 0, n, 77, 0)
+
+    def order_by():
+        return dev.sort_perm([(k1, None, None, D.T_INT64, False)], n).numel()
+    ms, kern, _ = timed(dev, order_by, reps=3, warmup=1)
+    passes = 4
+    algo = n * (8 + 8) + passes * n * (8 + 12 + 12) + 4 * n     # image build + passes (hist read, pair read, pair write) + perm out
+    res["order_by_1e8"] = {"rows": n, "ms": ms, "rows_per_s": n / (ms * 1e-3), "passes": passes, "moved_bytes": algo,
+                           "moved_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
+                           "note": "mdb_dev_sort_perm, permutation keys < 2^27: 4 stable 8-bit LSD passes; moved_bytes is what "
+                                   "this method moves, not a lower bound"}
+    del k1
+
     # ---- the north-star query end to end through the drop-in C API (query_execute), tables generated on the
     #      device: includes planning, the device pipeline and the D2H copy of the result columns
     from midoridb_amd.query import DB
@@ -121,6 +136,14 @@ def main():
         t0 = time.perf_counter()
         r = db.query(q)
         wall = (time.perf_counter() - t0) * 1e3
+        qk = ("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a HAVING COUNT(*) > 1 "
+              "ORDER BY id_a DESC LIMIT 10;")
+        db.query(qk)
+        t1 = time.perf_counter()
+        rk = db.query(qk)
+        res["north_star_top10_via_query_execute_1e8"] = {"rows_per_table": n, "result_rows": rk.nrows, "executor_ms": rk.exec_ms,
+                                                         "wall_ms": (time.perf_counter() - t1) * 1e3,
+                                                         "note": "fused join+group count, HAVING filter, ORDER BY (radix sort of 6.25M groups), LIMIT"}
         res["north_star_via_query_execute_1e8"] = {
             "rows_per_table": n, "groups": r.nrows, "joined_rows": r.joined_rows, "wall_ms": wall, "executor_ms": r.exec_ms,
             "joined_rows_per_s_wall": r.joined_rows / (wall * 1e-3),

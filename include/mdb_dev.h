@@ -171,6 +171,12 @@ struct mdb_sort_key {
 };
 int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out);
 
+/* SELECT DISTINCT (midorisql.y:203, equally parsed-but-ignored upstream): out_sel[0..*out_count) = ascending
+ * stream positions of the FIRST occurrence of every distinct combination of the key columns (NULL equals NULL,
+ * DOUBLE compared by bits; `desc` is ignored).  out_sel has room for n entries.  Synchronous. */
+int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_sel,
+			 uint64_t *out_count);
+
 /* ------------------------------------------------------------------ INNER JOIN (materialising)
  *
  * Replaces _join_nested_loop_tbl2tbl() for ON l = r (reference

@@ -88,20 +88,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_nullflag(const uint64_t *
 	}
 }
 
-extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out)
+static size_t sort_arena_bytes(uint64_t n)
 {
-	if (nkeys < 1 || nkeys > MDB_SORT_MAX_KEYS)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: between 1 and %d keys", MDB_SORT_MAX_KEYS);
-	if (n >= 0xFFFFFFFFull)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: too many rows");
-	if (n == 0)
-		return MIDORIDB_OK;
 	const size_t hist_words = mdb_sort_pass_hist_words(n);
-	const size_t need = 2 * mdb_align_up(n * 8) + 2 * mdb_align_up(n * 4) + mdb_align_up(hist_words * 4) +
-			    mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096;
-	int rc = mdb_arena_begin(ctx, need);
-	if (rc)
-		return rc;
+	return 2 * mdb_align_up(n * 8) + 2 * mdb_align_up(n * 4) + mdb_align_up(hist_words * 4) +
+	       mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096;
+}
+
+/* sorts inside an arena the caller has begun (sort_arena_bytes(n) available); *perm = the arena buffer that holds
+ * the final permutation.  Synchronises per key (the digit range comes back from the device). */
+static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t **perm)
+{
+	const size_t hist_words = mdb_sort_pass_hist_words(n);
 	uint64_t *u[2] = { (uint64_t *)mdb_arena_take(ctx, n * 8), (uint64_t *)mdb_arena_take(ctx, n * 8) };
 	uint32_t *pm[2] = { (uint32_t *)mdb_arena_take(ctx, n * 4), (uint32_t *)mdb_arena_take(ctx, n * 4) };
 	uint32_t *hist = (uint32_t *)mdb_arena_take(ctx, hist_words * 4);
@@ -109,7 +107,7 @@ extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *ke
 	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 64);
 	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
 		return -MIDORIDB_INTERNAL;
-	rc = mdb_dev_iota32(ctx, pm[0], n);
+	int rc = mdb_dev_iota32(ctx, pm[0], n);
 	if (rc)
 		return rc;
 	int cur = 0;	/* (u[cur], pm[cur]) hold the current order */
@@ -118,7 +116,7 @@ extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *ke
 	for (int j = nkeys - 1; j >= 0; j--) {
 		const struct mdb_sort_key *key = &keys[j];
 		if (key->type != MDB_T_INT64 && key->type != MDB_T_DOUBLE)
-			return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort_perm: key %d has an unknown type", j);
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "sort: key %d has an unknown type", j);
 		h[0] = ~0ull;
 		h[1] = 0ull;
 		h[2] = 0ull;
@@ -148,7 +146,106 @@ extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *ke
 			cur ^= 1;
 		}
 	}
-	MDB_HIP(ctx, hipMemcpyAsync(perm_out, pm[cur], n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	*perm = pm[cur];
+	return MIDORIDB_OK;
+}
+
+static int sort_check(mdb_dev_ctx *ctx, const char *what, int nkeys, uint64_t n)
+{
+	if (nkeys < 1 || nkeys > MDB_SORT_MAX_KEYS)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "%s: between 1 and %d keys", what, MDB_SORT_MAX_KEYS);
+	if (n >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "%s: too many rows", what);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out)
+{
+	int rc = sort_check(ctx, "sort_perm", nkeys, n);
+	if (rc || n == 0)
+		return rc;
+	rc = mdb_arena_begin(ctx, sort_arena_bytes(n));
+	if (rc)
+		return rc;
+	uint32_t *perm = NULL;
+	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemcpyAsync(perm_out, perm, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ DISTINCT
+ *
+ * Rows equal in every key column (NULL = NULL, DOUBLE by bits) are adjacent after the stable sort and the first
+ * row of every run is the row's first occurrence in the stream: mark it in a dense flag array, compact the flags
+ * to ascending positions (the filter's bitmap -> positions kernels). */
+struct distinct_args {
+	struct mdb_sort_key key[MDB_SORT_MAX_KEYS];
+	int nkeys;
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void k_distinct_heads(distinct_args a, const uint32_t *__restrict__ perm, uint64_t n,
+								  int64_t *__restrict__ flags)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
+		const uint32_t p = perm[k];
+		bool head = k == 0;
+		if (!head) {
+			const uint32_t q = perm[k - 1];
+			for (int c = 0; c < a.nkeys && !head; c++) {
+				const struct mdb_sort_key &key = a.key[c];
+				const uint64_t rp = key.rid ? (uint64_t)key.rid[p] : (uint64_t)p;
+				const uint64_t rq = key.rid ? (uint64_t)key.rid[q] : (uint64_t)q;
+				const bool np = key.nullbits && mdb_bit_is_set(key.nullbits, rp);
+				const bool nq = key.nullbits && mdb_bit_is_set(key.nullbits, rq);
+				if (np != nq)
+					head = true;
+				else if (!np && ((const uint64_t *)key.values)[rp] != ((const uint64_t *)key.values)[rq])
+					head = true;
+			}
+		}
+		if (head)
+			flags[p] = 1;
+	}
+}
+
+size_t mdb_filter_arena_bytes(uint64_t n);
+int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint32_t *out_sel, uint32_t **d_total);
+
+extern "C" int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_sel,
+				    uint64_t *out_count)
+{
+	*out_count = 0;
+	int rc = sort_check(ctx, "distinct_sel", nkeys, n);
+	if (rc || n == 0)
+		return rc;
+	rc = mdb_arena_begin(ctx, sort_arena_bytes(n) + mdb_align_up(n * 8) + mdb_filter_arena_bytes(n) + 4096);
+	if (rc)
+		return rc;
+	uint32_t *perm = NULL;
+	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm);
+	if (rc)
+		return rc;
+	int64_t *flags = (int64_t *)mdb_arena_take(ctx, n * 8);
+	if (!flags)
+		return -MIDORIDB_INTERNAL;
+	MDB_HIP(ctx, hipMemsetAsync(flags, 0, n * 8, ctx->stream));
+	distinct_args a;
+	memset(&a, 0, sizeof(a));
+	for (int c = 0; c < nkeys; c++)
+		a.key[c] = keys[c];
+	a.nkeys = nkeys;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	MDB_LAUNCH(ctx, "distinct_heads", k_distinct_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	uint32_t *d_total = NULL;
+	rc = mdb_filter_nonzero64(ctx, flags, n, out_sel, &d_total);
+	if (rc)
+		return rc;
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_count = (uint32_t)h[0];
 	return MIDORIDB_OK;
 }

@@ -217,7 +217,13 @@ static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, siz
 	return MIDORIDB_OK;
 }
 
-/* predicate shape check (what the device predicate compiler accepts) */
+/* predicate shape check (what the device predicate compiler accepts); in the HAVING clause COUNT(*) is an
+ * INTEGER operand of comparisons (semantic_select.c:1983-1985 lets it through) */
+static bool is_having_clause(const char *clause)
+{
+	return strcmp(clause, "having") == 0;
+}
+
 static int check_predicate(const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
 {
 	int rc;
@@ -230,6 +236,8 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
 		for (int i = 0; i < 2; i++) {
 			const struct mdb_expr *o = e->kids[i];
+			if (o->kind == MDB_EX_COUNT && is_having_clause(clause))
+				continue;
 			if (o->kind != MDB_EX_FIELD && o->kind != MDB_EX_INT && o->kind != MDB_EX_FLOAT && o->kind != MDB_EX_NULL) {
 				ERR("expressions in %s clause must compare columns with INT/DOUBLE/NULL values\n", clause);
 				return -MIDORIDB_ERROR;
@@ -237,8 +245,8 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 		}
 		/* operand types must match exactly (reference check_value_types_cmp, semantic_select.c:2135-2186) */
 		{
-			int tl = l->kind == MDB_EX_FIELD ? l->type : (l->kind == MDB_EX_INT ? MDB_CT_INTEGER : (l->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
-			int tr = r->kind == MDB_EX_FIELD ? r->type : (r->kind == MDB_EX_INT ? MDB_CT_INTEGER : (r->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
+			int tl = l->kind == MDB_EX_FIELD ? l->type : ((l->kind == MDB_EX_INT || l->kind == MDB_EX_COUNT) ? MDB_CT_INTEGER : (l->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
+			int tr = r->kind == MDB_EX_FIELD ? r->type : ((r->kind == MDB_EX_INT || r->kind == MDB_EX_COUNT) ? MDB_CT_INTEGER : (r->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
 			if (tl >= 0 && tr >= 0 && tl != tr) {
 				ERR("comparison operands must have the same type\n");
 				return -MIDORIDB_ERROR;
@@ -283,6 +291,38 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 	}
 }
 
+static bool expr_has_count(const struct mdb_expr *e)
+{
+	if (e->kind == MDB_EX_COUNT)
+		return true;
+	for (int i = 0; i < e->nkids; i++)
+		if (expr_has_count(e->kids[i]))
+			return true;
+	return false;
+}
+
+/* every field under e appears in the select list ("SELECT list is not in <clause> clause", the reference's
+ * wording, semantic_select.c:1836-1852, 1965-1985) */
+static int fields_in_select_list(const struct mdb_select *s, const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
+{
+	int rc;
+	if (e->kind == MDB_EX_FIELD && !s->select_all) {
+		bool ok = false;
+		for (int i = 0; i < s->nsel; i++)
+			ok |= field_eq(s->sel[i], e);
+		if (!ok) {
+			ERR("SELECT list is not in %s clause: '%.128s'.'%.128s'\n", clause, e->tbl, e->col);
+			return -MIDORIDB_ERROR;
+		}
+	}
+	if (e->kind == MDB_EX_COUNT)
+		return MIDORIDB_OK;
+	for (int i = 0; i < e->nkids; i++)
+		if ((rc = fields_in_select_list(s, e->kids[i], clause, err, errlen)))
+			return rc;
+	return MIDORIDB_OK;
+}
+
 static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, size_t errlen)
 {
 	int rc;
@@ -316,11 +356,6 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 			ERR("only INNER JOIN is executed (the reference aborts on other join types, executor_select.c:1094)\n");
 			return -MIDORIDB_ERROR;
 		}
-	}
-	/* clauses that parse but are never executed by the reference: refuse loudly */
-	if (s->distinct || s->has_having || s->has_orderby || s->has_limit) {
-		ERR("DISTINCT / HAVING / ORDER BY / LIMIT are not executed by the reference executor and are rejected here\n");
-		return -MIDORIDB_ERROR;
 	}
 	for (int i = 0; i < s->nsel; i++) {
 		struct mdb_expr *e = s->sel[i];
@@ -383,6 +418,44 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 			ERR("mixing fields and COUNT in the select list requires a GROUP BY clause\n");
 			return -MIDORIDB_ERROR;
 		}
+		/* ---- DISTINCT / HAVING / ORDER BY / LIMIT: parsed and checked but never executed upstream (SURVEY 8a
+		 *      D7); executed here with SQL semantics (8f row 4), under the reference's own semantic rules */
+		if (s->distinct && (s->ngroup || ncount)) {
+			ERR("DISTINCT can't be combined with GROUP BY / COUNT on the MI355X path\n");
+			return -MIDORIDB_ERROR;
+		}
+		if (s->having) {
+			if ((rc = resolve_expr(s, s->having, err, errlen)) || (rc = check_predicate(s->having, "having", err, errlen)))
+				return rc;
+			/* fields must come from the SELECT list (check_having_clause_inselect, semantic_select.c:1953-2001) */
+			if ((rc = fields_in_select_list(s, s->having, "HAVING", err, errlen)))
+				return rc;
+			if (expr_has_count(s->having) && !s->ngroup) {
+				ERR("COUNT in the having-clause requires a GROUP BY clause on the MI355X path\n");
+				return -MIDORIDB_ERROR;
+			}
+			if (ncount && !s->ngroup) {
+				ERR("HAVING over an ungrouped COUNT is not supported on the MI355X path\n");
+				return -MIDORIDB_ERROR;
+			}
+		}
+		for (int i = 0; i < s->norder; i++) {
+			struct mdb_expr *o = s->order[i];
+			if (o->kind == MDB_EX_COUNT) {		/* check_orderby_clause_count, semantic_select.c:1755-1795 */
+				ERR("COUNT function can't be used in the orderby-clause\n");
+				return -MIDORIDB_ERROR;
+			}
+			if (o->kind != MDB_EX_NAME && o->kind != MDB_EX_FIELD) {	/* check_orderby_clause_expr :1718-1753 */
+				ERR("order-by clauses support only fields and aliases\n");
+				return -MIDORIDB_ERROR;
+			}
+			if ((rc = resolve_expr(s, o, err, errlen)) || (rc = fields_in_select_list(s, o, "ORDER BY", err, errlen)))
+				return rc;
+		}
+		if (s->norder > MDB_SORT_MAX_KEYS) {
+			ERR("too many ORDER BY items (max %d)\n", MDB_SORT_MAX_KEYS);
+			return -MIDORIDB_ERROR;
+		}
 	}
 	return MIDORIDB_OK;
 }
@@ -405,6 +478,8 @@ struct exec {
 	bool have_stream;		/* false until the first table is in the stream */
 	uint64_t n;			/* stream length */
 	int64_t *d_count;		/* COUNT(*) column of the stream (after GROUP BY), device */
+	bool fused;			/* north-star plan: the stream is (d_fused_key, d_count), no row ids */
+	int64_t *d_fused_key;
 	uint64_t joined_rows;
 };
 
@@ -468,6 +543,26 @@ static int stream_select(struct exec *x, int ntabs_in_stream, const uint32_t *se
 	return MIDORIDB_OK;
 }
 
+/* keep the rows sel[0..n_new) of the current stream: row-id vectors (or the fused key column) and COUNT(*) */
+static int stream_apply_sel(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
+{
+	if (x->d_count) {
+		int64_t *nc = dalloc(x, (n_new ? n_new : 1) * 8);
+		if (!nc || (n_new && mdb_dev_gather64(x->dev, x->d_count, NULL, sel, n_new, nc, NULL)))
+			return dev_fail(x, "re-mapping COUNT(*)");
+		x->d_count = nc;
+	}
+	if (x->fused) {
+		int64_t *nk = dalloc(x, (n_new ? n_new : 1) * 8);
+		if (!nk || (n_new && mdb_dev_gather64(x->dev, x->d_fused_key, NULL, sel, n_new, nk, NULL)))
+			return dev_fail(x, "re-mapping the group key");
+		x->d_fused_key = nk;
+		x->n = n_new;
+		return MIDORIDB_OK;
+	}
+	return stream_select(x, ntabs_in_stream, sel, n_new);
+}
+
 /* device pointer to a column's key/value vector for the current stream (gathered when needed) */
 static int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t **vals, const uint64_t **nulls)
 {
@@ -497,19 +592,38 @@ struct pred_prog {
 	int ncols;
 };
 
+/* device binding of a column-like operand for the current stream: a table column read through the table's
+ * row-id vector, the COUNT(*) column (HAVING), or - in the fused north-star plan, whose stream carries no row
+ * ids - the group key column (the only field S4 lets such a query name) */
+static void bind_operand(struct exec *x, const struct mdb_expr *f, const void **values, const uint64_t **nullbits, const uint32_t **rid)
+{
+	if (f->kind == MDB_EX_COUNT) {
+		*values = x->d_count;
+		*nullbits = NULL;
+		*rid = NULL;
+	} else if (x->fused) {
+		*values = x->d_fused_key;
+		*nullbits = NULL;
+		*rid = NULL;
+	} else {
+		struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
+		*values = col->d_data;
+		*nullbits = col->d_nullbits;
+		*rid = x->rid[f->tbl_idx];
+	}
+}
+
 static int pred_slot(struct exec *x, struct pred_prog *p, const struct mdb_expr *f)
 {
-	struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
+	const int st = f->kind == MDB_EX_COUNT ? -2 : f->tbl_idx, sc = f->kind == MDB_EX_COUNT ? -2 : f->col_idx;
 	for (int i = 0; i < p->ncols; i++)
-		if (p->slot_tbl[i] == f->tbl_idx && p->slot_col[i] == f->col_idx)
+		if (p->slot_tbl[i] == st && p->slot_col[i] == sc)
 			return i;
 	if (p->ncols == MDB_PRED_MAX_SLOTS)
 		return -1;
-	p->slot_tbl[p->ncols] = f->tbl_idx;
-	p->slot_col[p->ncols] = f->col_idx;
-	p->cols[p->ncols].values = col->d_data;
-	p->cols[p->ncols].nullbits = col->d_nullbits;
-	p->cols[p->ncols].rid = x->rid[f->tbl_idx];
+	p->slot_tbl[p->ncols] = st;
+	p->slot_col[p->ncols] = sc;
+	bind_operand(x, f, &p->cols[p->ncols].values, &p->cols[p->ncols].nullbits, &p->cols[p->ncols].rid);
 	return p->ncols++;
 }
 
@@ -563,22 +677,24 @@ static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_ex
 		return pred_emit(p, e->op == 0 ? MDB_P_AND : (e->op == 1 ? MDB_P_OR : MDB_P_XOR), 0, 0, 0, 0, 0);
 	case MDB_EX_CMP: {
 		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
-		if (l->kind == MDB_EX_FIELD && r->kind == MDB_EX_FIELD) {
+		const bool lcol = l->kind == MDB_EX_FIELD || l->kind == MDB_EX_COUNT, rcol = r->kind == MDB_EX_FIELD || r->kind == MDB_EX_COUNT;
+		if (lcol && rcol) {
 			a = pred_slot(x, p, l);
 			b = pred_slot(x, p, r);
 			if (a < 0 || b < 0)
 				return -1;
-			return pred_emit(p, MDB_P_CMP_COL_COL, e->op, l->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, b, 0);
+			return pred_emit(p, MDB_P_CMP_COL_COL, e->op, (l->kind == MDB_EX_FIELD && l->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64,
+					 a, b, 0);
 		}
-		if (l->kind == MDB_EX_FIELD || r->kind == MDB_EX_FIELD) {
-			const struct mdb_expr *f = l->kind == MDB_EX_FIELD ? l : r, *v = l->kind == MDB_EX_FIELD ? r : l;
+		if (lcol || rcol) {
+			const struct mdb_expr *f = lcol ? l : r, *v = lcol ? r : l;
 			if (v->kind == MDB_EX_NULL)	/* NULL operand: never true (executor_select.c:793-795) */
 				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
 			a = pred_slot(x, p, f);
 			if (a < 0)
 				return -1;
-			return pred_emit(p, l->kind == MDB_EX_FIELD ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
-					 f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
+			return pred_emit(p, lcol ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
+					 (f->kind == MDB_EX_FIELD && f->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
 		}
 		return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, const_cmp(e->op, l, r));
 	}
@@ -634,7 +750,7 @@ static int stream_filter(struct exec *x, int ntabs_in_stream, const struct mdb_e
 		return dev_fail(x, "allocating the selection vector");
 	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, x->n, sel, &m))
 		return dev_fail(x, "filter");
-	return stream_select(x, ntabs_in_stream, sel, m);
+	return stream_apply_sel(x, ntabs_in_stream, sel, m);
 }
 
 /* ------------------------------------------------------------------ FROM clause */
@@ -788,6 +904,81 @@ static int fused_shape(struct mdb_select *s, const struct mdb_expr **kl, const s
 	return -1;
 }
 
+/* HAVING, DISTINCT, ORDER BY, LIMIT over the finished stream (after FROM / WHERE / GROUP BY) */
+static int select_tail(struct exec *x, int has_count)
+{
+	struct mdb_select *s = x->s;
+	const bool count_only = has_count && !s->ngroup;
+	int rc;
+
+	if (count_only)
+		return MIDORIDB_OK;	/* one row: HAVING is rejected at plan time, ORDER BY has nothing to order, LIMIT is applied by the caller */
+	if (s->having && (rc = stream_filter(x, s->ntabs, s->having)))
+		return rc;
+	if (s->distinct && x->n > 1) {
+		struct mdb_sort_key keys[MDB_SORT_MAX_KEYS];
+		int nk = 0;
+		uint32_t *sel;
+		uint64_t m = 0;
+		for (int t = 0; t < s->ntabs; t++)
+			for (int c = 0; c < s->tabs[t].t->ncols; c++) {
+				struct mdb_expr f;
+				bool want = s->select_all;
+				for (int i = 0; i < s->nsel && !want; i++)
+					want = s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == t && s->sel[i]->col_idx == c;
+				if (!want)
+					continue;
+				if (nk == MDB_SORT_MAX_KEYS) {
+					snprintf(x->err, x->errlen, "DISTINCT over more than %d columns is not supported\n", MDB_SORT_MAX_KEYS);
+					return -MIDORIDB_ERROR;
+				}
+				memset(&f, 0, sizeof(f));
+				f.kind = MDB_EX_FIELD;
+				f.tbl_idx = t;
+				f.col_idx = c;
+				bind_operand(x, &f, &keys[nk].values, &keys[nk].nullbits, &keys[nk].rid);
+				keys[nk].type = s->tabs[t].t->cols[c].type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
+				keys[nk].desc = 0;
+				nk++;
+			}
+		sel = dalloc(x, x->n * 4);
+		if (!sel)
+			return dev_fail(x, "allocating the DISTINCT selection");
+		if (mdb_dev_distinct_sel(x->dev, keys, nk, x->n, sel, &m))
+			return dev_fail(x, "DISTINCT");
+		if ((rc = stream_apply_sel(x, s->ntabs, sel, m)))
+			return rc;
+	}
+	if (s->norder && x->n > 1) {
+		struct mdb_sort_key keys[MDB_SORT_MAX_KEYS];
+		uint32_t *perm;
+		for (int i = 0; i < s->norder; i++) {
+			bind_operand(x, s->order[i], &keys[i].values, &keys[i].nullbits, &keys[i].rid);
+			keys[i].type = s->order[i]->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
+			keys[i].desc = s->order_desc[i];
+		}
+		perm = dalloc(x, x->n * 4);
+		if (!perm)
+			return dev_fail(x, "allocating the ORDER BY permutation");
+		if (mdb_dev_sort_perm(x->dev, keys, s->norder, x->n, perm))
+			return dev_fail(x, "ORDER BY");
+		if ((rc = stream_apply_sel(x, s->ntabs, perm, x->n)))
+			return rc;
+	}
+	if (s->has_limit) {
+		const uint64_t off = (uint64_t)s->limit_off < x->n ? (uint64_t)s->limit_off : x->n;
+		const uint64_t cnt = (uint64_t)s->limit_cnt < x->n - off ? (uint64_t)s->limit_cnt : x->n - off;
+		if (off || cnt < x->n) {
+			uint32_t *idx = dalloc(x, (off + cnt ? off + cnt : 1) * 4);
+			if (!idx || mdb_dev_iota32(x->dev, idx, off + cnt))
+				return dev_fail(x, "LIMIT");
+			if ((rc = stream_apply_sel(x, s->ntabs, idx + off, cnt)))
+				return rc;
+		}
+	}
+	return MIDORIDB_OK;
+}
+
 int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen)
 {
 	struct exec x;
@@ -798,7 +989,6 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	double t0;
 	const struct mdb_expr *fkl = NULL, *fkr = NULL;
 	int fused;
-	int64_t *d_fused_key = NULL;
 
 	*out = NULL;
 	memset(&x, 0, sizeof(x));
@@ -854,17 +1044,18 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		struct mdb_table *lt = s->tabs[0].t, *rt = s->tabs[1].t;
 		struct mdb_column *lc = &lt->cols[fkl->col_idx], *rcq = &rt->cols[fkr->col_idx];
 		uint64_t cap = lt->nrows ? lt->nrows : 1, G = 0, J = 0;
-		d_fused_key = dalloc(&x, cap * 8);
+		x.d_fused_key = dalloc(&x, cap * 8);
 		x.d_count = dalloc(&x, cap * 8);
-		if (!d_fused_key || !x.d_count) {
+		if (!x.d_fused_key || !x.d_count) {
 			rc = dev_fail(&x, "allocating group outputs");
 			goto out;
 		}
 		if (mdb_dev_join_group_count(x.dev, lc->d_data, lc->d_nullbits, lt->nrows, rcq->d_data, rcq->d_nullbits, rt->nrows,
-					     MDB_ORDER_FIRST, d_fused_key, x.d_count, NULL, cap, &G, &J)) {
+					     MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G, &J)) {
 			rc = dev_fail(&x, "join + group count");
 			goto out;
 		}
+		x.fused = true;
 		x.n = G;
 		x.joined_rows = J;
 	} else {
@@ -897,6 +1088,10 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 	}
 
+	/* ---- HAVING -> DISTINCT -> ORDER BY -> LIMIT (SQL order of evaluation; extension) */
+	if ((rc = select_tail(&x, has_count)))
+		goto out;
+
 	/* ---- projection + COUNT-only handling */
 	res = calloc(1, sizeof(*res));
 	if (!res) {
@@ -906,6 +1101,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	{
 		bool count_only = has_count && !s->ngroup;	/* SELECT COUNT(*) FROM ... [WHERE ...] */
 		uint64_t out_rows = count_only ? (x.n ? 1 : 0) : x.n;	/* the reference returns no row for an empty input */
+		if (count_only && s->has_limit && (s->limit_off > 0 || s->limit_cnt == 0))
+			out_rows = 0;
 		int ncols = 0;
 		int *src = calloc((size_t)nkeys, sizeof(int));
 		if (!src) {
@@ -975,7 +1172,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					continue;
 				if (fused >= 0) {
 					/* only the group key can be selected (S4); both sides hold the same value */
-					if (mdb_dev_d2h(x.dev, res->data[c], d_fused_key, out_rows * 8)) {
+					if (mdb_dev_d2h(x.dev, res->data[c], x.d_fused_key, out_rows * 8)) {
 						free(src);
 						rc = dev_fail(&x, "reading the group key");
 						goto out;

@@ -134,7 +134,14 @@ struct mdb_select {
 	struct mdb_expr *where;
 	struct mdb_expr **group;
 	int ngroup;
-	bool has_having, has_orderby, has_limit;
+	/* clauses the reference parses and checks but never executes; executed here with SQL
+	 * semantics as the 8f row 4 extension */
+	struct mdb_expr *having;
+	struct mdb_expr **order;	/* ORDER BY items (fields) */
+	int *order_desc;		/* 0 ASC, 1 DESC (midorisql.y:175-177) */
+	int norder;
+	bool has_limit;
+	int64_t limit_off, limit_cnt;	/* LIMIT cnt | LIMIT off, cnt (midorisql.y:193-196) */
 };
 
 struct mdb_create {

@@ -173,13 +173,42 @@ static int finish_select(struct mdb_expr *root, struct mdb_stmt *out, char *err,
 			k->nkids = 0;
 			break;
 		case BX_HAVING:
-			s->has_having = true;
+			s->having = k->kids[0];
+			k->kids[0] = NULL;
+			k->nkids = 0;
 			break;
 		case BX_ORDERBYLIST:
-			s->has_orderby = true;
+			s->order = calloc((size_t)(k->nkids ? k->nkids : 1), sizeof(*s->order));
+			s->order_desc = calloc((size_t)(k->nkids ? k->nkids : 1), sizeof(int));
+			if (!s->order || !s->order_desc) {
+				rc = -MIDORIDB_NOMEM;
+				break;
+			}
+			for (int j = 0; j < k->nkids; j++) {
+				struct mdb_expr *it = k->kids[j];
+				if (it->kind != BX_ORDERBYITEM || it->nkids != 1) {
+					snprintf(err, errlen, "error while running syntax analysis on query\n");
+					rc = -MIDORIDB_ERROR;
+					break;
+				}
+				s->order[s->norder] = it->kids[0];
+				s->order_desc[s->norder] = it->op;
+				s->norder++;
+				it->kids[0] = NULL;
+				it->nkids = 0;
+			}
 			break;
 		case BX_LIMIT:
+			for (int j = 0; j < k->nkids; j++)
+				if (k->kids[j]->kind != MDB_EX_INT || k->kids[j]->ival < 0) {
+					snprintf(err, errlen, "LIMIT takes non-negative integer literals\n");
+					rc = -MIDORIDB_ERROR;
+				}
+			if (rc)
+				break;
 			s->has_limit = true;
+			s->limit_off = k->nkids == 2 ? k->kids[0]->ival : 0;
+			s->limit_cnt = k->kids[k->nkids - 1]->ival;
 			break;
 		default: {
 			struct mdb_expr **ns = realloc(s->sel, sizeof(*ns) * (size_t)(s->nsel + 1));
@@ -372,8 +401,11 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 				FAIL("error while running syntax analysis on query\n");
 		} else if (starts(t, "ORDERBYITEM ")) {
 			e = ex_new(BX_ORDERBYITEM);
-			if (e && pop_n_into(&st, 1, e))
-				FAIL("error while running syntax analysis on query\n");
+			if (e) {
+				e->op = atoi(t + 12) != 0;
+				if (pop_n_into(&st, 1, e))
+					FAIL("error while running syntax analysis on query\n");
+			}
 		} else if (starts(t, "CMP ")) {
 			e = ex_new(MDB_EX_CMP);
 			if (e) {
@@ -614,6 +646,11 @@ void mdb_stmt_free(struct mdb_stmt *s)
 	for (int i = 0; i < s->sel.ngroup; i++)
 		mdb_expr_free(s->sel.group[i]);
 	free(s->sel.group);
+	mdb_expr_free(s->sel.having);
+	for (int i = 0; i < s->sel.norder; i++)
+		mdb_expr_free(s->sel.order[i]);
+	free(s->sel.order);
+	free(s->sel.order_desc);
 	for (int i = 0; i < s->ins.ntuples; i++) {
 		for (int k = 0; k < s->ins.nvals; k++)
 			mdb_expr_free(s->ins.vals[i][k]);

@@ -82,11 +82,26 @@ def parse_rpn(rpn):
             g = st[-k:]
             del st[-k:]
             st.append(("groupby", g))
+        elif head == "HAVING":
+            st.append(("having", st.pop()))
+        elif head == "ORDERBYITEM":
+            st.append(("orderitem", int(rest), st.pop()))
+        elif head == "ORDERBYLIST":
+            k = int(rest)
+            items = st[-k:]
+            del st[-k:]
+            st.append(("orderby", items))
+        elif head == "LIMIT":
+            k = int(rest)
+            vals = st[-k:]
+            del st[-k:]
+            st.append(("limit", [v[1] for v in vals]))
         elif head == "SELECT":
-            _, n = rest.split()
+            d, n = rest.split()
             kids = st[-int(n):]
             del st[-int(n):]
-            out = {"sel": [], "from": [], "where": None, "group": []}
+            out = {"sel": [], "from": [], "where": None, "group": [], "distinct": bool(int(d) & 2), "having": None, "order": [],
+                   "limit": None}
             for k in kids:
                 if k[0] in ("table", "join"):
                     out["from"].append(k)
@@ -94,6 +109,12 @@ def parse_rpn(rpn):
                     out["where"] = k[1]
                 elif k[0] == "groupby":
                     out["group"] = k[1]
+                elif k[0] == "having":
+                    out["having"] = k[1]
+                elif k[0] == "orderby":
+                    out["order"] = k[1]
+                elif k[0] == "limit":
+                    out["limit"] = k[1]
                 else:
                     out["sel"].append(k)
         elif head == "ASSIGN":
@@ -173,6 +194,8 @@ class Naive:
             return ("isnull", e[1], self._resolve(e[2], tabs))
         if e[0] == "isin":
             return ("isin", e[1], self._resolve(e[2], tabs), e[3])
+        if e[0] == "orderitem":
+            return ("orderitem", e[1], self._resolve(e[2], tabs))
         return e
 
     def _value(self, e, row):
@@ -182,6 +205,8 @@ class Naive:
             return e[1]
         if e[0] == "null":
             return None
+        if e[0] == "count":			# HAVING COUNT(*) <op> n
+            return row["COUNT(*)"]
         raise AssertionError(e)
 
     def _cond(self, e, row):
@@ -251,7 +276,40 @@ class Naive:
         names = [k for k in order if k in wanted]		# proc_select_clause :1369-1433
         if names == ["COUNT(*)"] and not q["group"]:		# handle_countonly_case :1590-1653
             rows = [{"COUNT(*)": len(rows)}] if rows else []
+        # ---- HAVING / DISTINCT / ORDER BY / LIMIT: the reference parses and checks these clauses but its executor
+        #      never reads them, so there is no reference behaviour to pin: plain SQL semantics, the
+        #      specification of the 8f row 4 extension (NULL sorts lowest, sorting is stable, DISTINCT keeps first
+        #      occurrences, LIMIT off, cnt as in the grammar midorisql.y:193-196)
+        if q.get("having") is not None:
+            h = self._resolve(q["having"], tabs)
+            rows = [r for r in rows if self._cond(h, r)]
+        if q.get("distinct"):
+            seen, keep = set(), []
+            for r in rows:
+                k = tuple((r[n] is None, self._raw(r[n])) for n in names)
+                if k not in seen:
+                    seen.add(k)
+                    keep.append(r)
+            rows = keep
+        for it in reversed(q.get("order") or []):
+            _, desc, f = self._resolve(it, tabs)
+            col = f"{f[1]}.{f[2]}"
+            # sorted() is stable, also with reverse=True (ties keep their order)
+            rows = sorted(rows, key=lambda r: (r[col] is not None, self._order_image(r[col])), reverse=bool(desc))
+        if q.get("limit"):
+            off, cnt = (0, q["limit"][0]) if len(q["limit"]) == 1 else q["limit"]
+            rows = rows[off:off + cnt]
         return names, [tuple(self._raw(r[n]) for n in names) for r in rows]
+
+    @staticmethod
+    def _order_image(v):
+        """order-preserving integer image of a cell (IEEE total order for DOUBLE: -0.0 < +0.0), 0 for NULL"""
+        if v is None:
+            return 0
+        if isinstance(v, float):
+            b = struct.unpack("<Q", struct.pack("<d", v))[0]
+            return (~b & 0xFFFFFFFFFFFFFFFF) if b >> 63 else (b | (1 << 63))
+        return int(v) + (1 << 63)
 
     # ---- DELETE / UPDATE (reference src/engine/executor_delete.c:412-440, executor_update.c:460-484) ------
     def run_dml(self, rpn):

@@ -263,3 +263,22 @@ def sort_perm(keys, n):
         flag = (isnull == bool(desc)).astype(np.uint8)	# ASC: NULL -> 0 (first); DESC: NULL -> 1 (last)
         perm = perm[np.argsort(flag, kind="stable")]
     return perm.astype(np.uint32)
+
+
+def distinct_sel(keys, n):
+    """Oracle of mdb_dev_distinct_sel: ascending stream positions of the first occurrence of every distinct key
+    combination (NULL equals NULL, values compared by their 64 bits)."""
+    seen, out = set(), []
+    cols = []
+    for values, nulls, rid, _is_double, _desc in keys:
+        v = np.asarray(values)
+        rows = np.arange(n) if rid is None else np.asarray(rid, dtype=np.int64)
+        bits = v.view(np.uint64)[rows]
+        isnull = np.zeros(n, dtype=bool) if nulls is None else np.asarray(nulls, dtype=bool)[rows]
+        cols.append((np.where(isnull, np.uint64(0), bits), isnull))
+    for i in range(n):
+        k = tuple((int(b[i]), bool(z[i])) for b, z in cols)
+        if k not in seen:
+            seen.add(k)
+            out.append(i)
+    return np.array(out, dtype=np.uint32)

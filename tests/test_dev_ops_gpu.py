@@ -365,3 +365,19 @@ def test_sort_perm_large_property(dev):
     s1 = a[one]
     tie = s1[1:] == s1[:-1]
     assert bool((one[1:][tie] > one[:-1][tie]).all())	# stability
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 4097, 60_000])
+def test_distinct_sel(dev, n):
+    rng = np.random.default_rng(n + 11)
+    a = rng.integers(-3, 4, n, dtype=np.int64)
+    b = np.round(rng.normal(0, 1, n), 0)
+    na = rng.random(n) < 0.2
+    rid = rng.integers(0, n, n).astype(np.uint32)
+    ad, bd, nad, ridd = dev.to_dev(a), dev.to_dev(b), dev.nullbits_dev(na), dev.to_dev(rid)
+    for keys_np, keys_dev in [
+            ([(a, None, None, False, False)], [(ad, None, None, D.T_INT64, False)]),
+            ([(a, na, None, False, False), (b, None, None, True, False)], [(ad, nad, None, D.T_INT64, False), (bd, None, None, D.T_DOUBLE, False)]),
+            ([(b, None, rid, True, False), (a, na, rid, False, False)], [(bd, None, ridd, D.T_DOUBLE, False), (ad, nad, ridd, D.T_INT64, False)])]:
+        got = _np(dev.distinct_sel(keys_dev, n)).view(np.uint32)
+        assert np.array_equal(got, orc.distinct_sel(keys_np, n))

@@ -194,3 +194,30 @@ def test_naive_dml_matches_reference_vectors(case):
             cols, rows = nv.tables[t]
             got = [[G.raw_cell(r[c]) for r in rows] for c in range(len(cols))]
             assert got == dump, f"{sql}: table {t}"
+
+
+def test_naive_tail_clauses_agree_with_numpy_oracle():
+    """ORDER BY / DISTINCT have no reference behaviour to pin (upstream never executes them): the two
+    independent restatements used as checkers (oracle/naive.py: python sorted / set; oracle/np_oracle.py: stable
+    argsort per key on order-preserving 64-bit images) must agree with each other."""
+    from oracle.naive import Naive
+    from oracle.ref import sql_to_rpn
+    rng = np.random.default_rng(4)
+    n = 400
+    a = rng.integers(-5, 6, n)
+    x = np.round(rng.normal(0, 3, n), 0)
+    x[rng.random(n) < 0.1] = -0.0
+    na, nx = rng.random(n) < 0.15, rng.random(n) < 0.15
+    rows = [[None if na[i] else int(a[i]), None if nx[i] else float(x[i]), i] for i in range(n)]
+    nv = Naive({"T": (["a", "x", "i"], rows)})
+    for q, keys in [("SELECT a, x, i FROM T ORDER BY a, x DESC;", [(a, na, None, False, False), (x, nx, None, True, True)]),
+                    ("SELECT a, x, i FROM T ORDER BY x, a DESC;", [(x, nx, None, True, False), (a, na, None, False, True)]),
+                    ("SELECT a, x, i FROM T ORDER BY a DESC;", [(a, na, None, False, True)])]:
+        names, got = nv.run(sql_to_rpn(q))
+        perm = orc.sort_perm(keys, n)
+        k = names.index("T.i")			# result columns come in the reference's djb2 order
+        assert [r[k] for r in got] == perm.tolist(), q
+    names, got = nv.run(sql_to_rpn("SELECT DISTINCT a, x FROM T;"))
+    sel = orc.distinct_sel([(a, na, None, False, False), (x, nx, None, True, False)], n)
+    cell = {"T.a": lambda i: 0 if na[i] else int(a[i]), "T.x": lambda i: 0 if nx[i] else int(np.array([x[i]]).view(np.int64)[0])}
+    assert [tuple(r) for r in got] == [tuple(cell[c](i) for c in names) for i in sel]
