@@ -62,6 +62,11 @@ size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr);
 int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr);
 int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes);
+/* Page-locked host memory for result columns (D2H at PCIe rate instead of through the driver's staging copy).
+ * Process-wide pool, independent of any context: buffers are recycled by later results and may be freed after the
+ * context is gone (query_free() after database_close()).  Small requests fall back to malloc. */
+void *mdb_dev_host_alloc(size_t bytes);
+void mdb_dev_host_free(void *p);
 int mdb_dev_h2d(mdb_dev_ctx *ctx, void *dptr, const void *host, size_t bytes);	/* synchronous */
 int mdb_dev_d2h(mdb_dev_ctx *ctx, void *host, const void *dptr, size_t bytes);	/* synchronous */
 

@@ -331,6 +331,79 @@ extern "C" int mdb_dev_d2h(mdb_dev_ctx *ctx, void *host, const void *dptr, size_
 	return MIDORIDB_OK;
 }
 
+/* ------------------------------------------------------------------ pinned host pool (result columns) */
+
+#include <mutex>
+#include <vector>
+
+#define HOST_POOL_MIN (1u << 20)		/* below 1 MiB pinning costs more than it saves */
+#define HOST_POOL_KEEP ((size_t)8 << 30)	/* idle pinned bytes kept for reuse */
+
+struct host_buf {
+	void *p;
+	size_t bytes;
+	bool pinned, in_use;
+};
+static std::mutex g_host_mu;
+static std::vector<host_buf> g_host_pool;
+
+extern "C" void *mdb_dev_host_alloc(size_t bytes)
+{
+	if (bytes == 0)
+		bytes = 8;
+	std::lock_guard<std::mutex> lk(g_host_mu);
+	if (bytes >= HOST_POOL_MIN) {
+		/* best fit among the idle pinned buffers (at most 2x the request) */
+		int best = -1;
+		for (size_t i = 0; i < g_host_pool.size(); i++) {
+			const host_buf &b = g_host_pool[i];
+			if (b.pinned && !b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes && (best < 0 || b.bytes < g_host_pool[best].bytes))
+				best = (int)i;
+		}
+		if (best >= 0) {
+			g_host_pool[best].in_use = true;
+			return g_host_pool[best].p;
+		}
+		void *p = NULL;
+		if (hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p) {
+			g_host_pool.push_back({ p, bytes, true, true });
+			return p;
+		}
+		(void)hipGetLastError();
+	}
+	void *p = malloc(bytes);
+	if (p)
+		g_host_pool.push_back({ p, bytes, false, true });
+	return p;
+}
+
+extern "C" void mdb_dev_host_free(void *p)
+{
+	if (!p)
+		return;
+	std::lock_guard<std::mutex> lk(g_host_mu);
+	size_t idle = 0;
+	for (const host_buf &b : g_host_pool)
+		if (b.pinned && !b.in_use)
+			idle += b.bytes;
+	for (size_t i = 0; i < g_host_pool.size(); i++) {
+		host_buf &b = g_host_pool[i];
+		if (b.p != p)
+			continue;
+		if (b.pinned && idle + b.bytes <= HOST_POOL_KEEP) {
+			b.in_use = false;	/* stays pinned for the next result */
+			return;
+		}
+		if (b.pinned)
+			(void)hipHostFree(b.p);
+		else
+			free(b.p);
+		g_host_pool.erase(g_host_pool.begin() + (long)i);
+		return;
+	}
+	free(p);	/* not ours: plain malloc memory */
+}
+
 /* ------------------------------------------------------------------ profiling */
 
 void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name)

@@ -859,7 +859,7 @@ void mdb_result_free(struct mdb_result *r)
 		return;
 	for (int c = 0; c < r->ncols; c++) {
 		if (r->data)
-			free(r->data[c]);
+			mdb_dev_host_free(r->data[c]);
 		if (r->nullbits)
 			free(r->nullbits[c]);
 	}
@@ -1139,7 +1139,9 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		for (int c = 0; c < ncols; c++) {
 			int key = src[c];
 			memcpy(res->colname[c], keys[key], MDB_NAME_LEN);
-			res->data[c] = calloc((size_t)(out_rows ? out_rows : 1), 8);
+			res->data[c] = mdb_dev_host_alloc((size_t)(out_rows ? out_rows : 1) * 8);	/* pinned when large */
+			if (res->data[c] && out_rows <= 1)
+				res->data[c][0] = 0;
 			if (!res->data[c]) {
 				free(src);
 				rc = -MIDORIDB_NOMEM;
