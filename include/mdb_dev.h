@@ -257,11 +257,13 @@ int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, con
  * Hash-partition a key column by destination GPU for the all-to-all exchange
  * (SURVEY 8e): dest = hash(key) mod n_dest, NULL keys are dropped (they never
  * join).  out_keys (capacity n) receives the keys grouped by destination (order inside a
- * destination is unspecified); out_counts (HOST, n_dest entries) the group sizes.
- * Synchronises.
+ * destination is unspecified); out_rid (capacity n, or NULL) the source row of every out_keys
+ * entry, which is what carries payload columns and row identity through the exchange
+ * (send column = mdb_dev_gather64(column, out_rid)); out_counts (HOST, n_dest entries) the
+ * group sizes.  Synchronises.
  */
 int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			      uint32_t n_dest, int64_t *out_keys, uint64_t *out_counts);
+			      uint32_t n_dest, int64_t *out_keys, uint32_t *out_rid, uint64_t *out_counts);
 
 /* ------------------------------------------------------------------ synthetic data (bench / tests)
  * keys[i] = perm(i) mod modulus, perm = the bijection on [0, n) defined in

@@ -549,7 +549,7 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
-			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out)
+			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -577,7 +577,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		else
 			hv_buf[l] = (uint64_t *)cv.take(elems * 8);
 		if (want_rid)
-			rid_buf[l] = (uint32_t *)cv.take(elems * 4);
+			rid_buf[l] = (l == nlevels - 1 && final_rid_out) ? final_rid_out : (uint32_t *)cv.take(elems * 4);
 	}
 
 	/* segments of the current level */
@@ -839,7 +839,7 @@ int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
 
 extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-					 uint32_t n_dest, int64_t *out_keys, uint64_t *out_counts)
+					 uint32_t n_dest, int64_t *out_keys, uint32_t *out_rid, uint64_t *out_counts)
 {
 	if (n_dest == 0 || n_dest > PART_MAX_R)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: n_dest must be in [1, %u]", PART_MAX_R);
@@ -847,16 +847,21 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: too many rows");
 	if ((uintptr_t)keys & 15)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
+	for (uint32_t d = 0; d < n_dest; d++)
+		out_counts[d] = 0;
+	if (n == 0)
+		return MIDORIDB_OK;
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
-	 * original keys written back through the inverse hash) */
+	 * original keys written back through the inverse hash, source row ids beside them when asked for) */
+	const bool want_rid = out_rid != NULL;
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL, out_rid);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, false, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res, out_rid);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;

@@ -75,7 +75,7 @@ def _bind(lib):
                                       POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count_begin": ([P, P, P, c_uint64, c_uint64], c_int),
         "mdb_dev_join_group_count_finish": ([P, P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
-        "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, P, P, POINTER(c_uint64)], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
     }
     for name, (args, res) in sig.items():
@@ -341,12 +341,16 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_sort_perm(self.h, arr, len(keys), n, _ptr(perm)), "sort_perm")
         return perm[:n]
 
-    def partition_by_dest(self, keys, nulls, n_dest, out=None):
+    def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False):
+        """-> (keys grouped by destination, counts per destination[, source row of every entry])."""
         n = keys.numel()
         if out is None:
             out = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        rid = torch.empty(max(n, 1), dtype=torch.int32, device=self.device) if with_rid else None
         counts = (c_uint64 * n_dest)()
-        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, _ptr(out), counts),
+        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, _ptr(out), _ptr(rid), counts),
                   "partition_by_dest")
         counts = [int(c) for c in counts]
+        if with_rid:
+            return out[:sum(counts)], counts, rid[:sum(counts)]
         return out[:sum(counts)], counts

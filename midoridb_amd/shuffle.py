@@ -32,6 +32,42 @@ class KeyExchange:
         return recv, recv_counts, work
 
 
+class TableShuffle:
+    """Moves one table to its owners: rows travel to rank hash(key) mod world with their payload columns
+    (BASELINE configs 4 and 5: joins that materialise rows, DOUBLE payload included - payload bytes are moved as
+    opaque 8-byte cells, so they stay bit-exact).  partition_fn(keys) -> (keys grouped by destination, counts,
+    source row of every entry); gather_fn(column, rows) -> column in send order.  One counts exchange, then one
+    uneven all_to_all_single per column, all asynchronous and waited for together."""
+
+    def __init__(self, world, device, partition_fn, gather_fn):
+        self.world = world
+        self.device = device
+        self.ex = KeyExchange(world, device)
+        self.partition_fn = partition_fn
+        self.gather_fn = gather_fn
+
+    def run(self, keys, payload=(), with_origin=False, rank=0):
+        """-> (received keys, [received payload columns], received origin ids or None).  origin = (source rank << 32)
+        | source row: the global identity of a row after the exchange."""
+        send_keys, counts, rows = self.partition_fn(keys)
+        recv_keys, recv_counts, work = self.ex.exchange(send_keys, counts, async_op=True)
+        works = [work]
+        total, sent = sum(recv_counts), sum(counts)
+        cols = [self.gather_fn(c, rows) for c in payload]
+        if with_origin:
+            cols.append(rows.to(torch.int64) + (int(rank) << 32))
+        outs = []
+        for c in cols:
+            r = torch.empty(max(total, 1), dtype=c.dtype, device=self.device)[:total]
+            works.append(dist.all_to_all_single(r, c[:sent], recv_counts, list(counts), async_op=True))
+            outs.append(r)
+        for w in works:
+            if w is not None:
+                w.wait()
+        origin = outs.pop() if with_origin else None
+        return recv_keys, outs, origin
+
+
 class DistributedJoinGroupCount:
     """One rank's share of  A JOIN B ON id_a = id_b GROUP BY id_a COUNT(*)  over `world` GPUs."""
 

@@ -11,7 +11,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import np_oracle as orc  # noqa: E402
-from midoridb_amd.shuffle import DistributedJoinGroupCount  # noqa: E402
+from midoridb_amd.shuffle import DistributedJoinGroupCount, TableShuffle  # noqa: E402
 
 
 def main():
@@ -47,8 +47,63 @@ def main():
         assert np.array_equal(keys[o1], ek[o2]) and np.array_equal(cnts[o1], ec[o2])
         assert len(np.unique(keys)) == len(keys)		# groups are disjoint across ranks
         print("gloo distributed join ok", len(keys), "groups", ej, "joined rows")
+    payload_join(rank, world)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def payload_join(rank, world):
+    """BASELINE config 5 shape on 2 ranks: A(id_a, x DOUBLE) JOIN B(id_b, y DOUBLE) JOIN C(id_c, z INT) on one key,
+    every table shuffled with its payload and its origin id, joined locally (oracle operators), then checked on
+    rank 0 against one big join of the unsharded tables."""
+    n = 3_000
+    total = n * world
+    rng = np.random.default_rng(7)		# same stream on every rank: the global tables
+    ga = rng.integers(0, total // 2, total)
+    gb = rng.integers(0, total // 2, total)
+    gc = rng.integers(0, total // 2, total)
+    gx, gy, gz = rng.normal(0, 1, total), rng.normal(0, 1, total), rng.integers(0, 100, total)
+    sl = slice(rank * n, (rank + 1) * n)
+
+    def partition_fn(keys):
+        k = keys.numpy()
+        d = orc.dest_of(k, world)
+        o = np.argsort(d, kind="stable")
+        return torch.from_numpy(k[o]), [int(c) for c in np.bincount(d, minlength=world)], torch.from_numpy(o.astype(np.int32))
+
+    def gather_fn(col, rows):
+        return col[rows.to(torch.int64)]
+
+    sh = TableShuffle(world, torch.device("cpu"), partition_fn, gather_fn)
+    ka, (xa,), oa = sh.run(torch.from_numpy(ga[sl]), [torch.from_numpy(gx[sl])], with_origin=True, rank=rank)
+    kb, (yb,), ob = sh.run(torch.from_numpy(gb[sl]), [torch.from_numpy(gy[sl])], with_origin=True, rank=rank)
+    kc, (zc,), oc = sh.run(torch.from_numpy(gc[sl]), [torch.from_numpy(gz[sl])], with_origin=True, rank=rank)
+    assert np.all(orc.dest_of(ka.numpy(), world) == rank) and np.all(orc.dest_of(kc.numpy(), world) == rank)
+    # origin ids name the source rank and row: payload must be the source table's cell, bit for bit
+    src = (oa.numpy() >> 32) * n + (oa.numpy() & 0xFFFFFFFF)
+    assert np.array_equal(gx[src].view(np.int64), xa.numpy().view(np.int64)) and np.array_equal(ga[src], ka.numpy())
+    l, r = orc.join_pairs(ka.numpy(), None, kb.numpy(), None)
+    kab = ka.numpy()[l]
+    p, q = orc.join_pairs(kab, None, kc.numpy(), None)
+    rows = np.stack([kab[p], xa.numpy().view(np.int64)[l][p], yb.numpy().view(np.int64)[r][p], zc.numpy()[q]], axis=1)
+    gfirst, gcnt = orc.group_count(kab[p], None)
+    gk = kab[p][gfirst]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rows, gk, gcnt))
+    if rank == 0:
+        L, R = orc.join_pairs(ga, None, gb, None)
+        P, Q = orc.join_pairs(ga[L], None, gc, None)
+        want = np.stack([ga[L][P], gx.view(np.int64)[L][P], gy.view(np.int64)[R][P], gz[Q]], axis=1)
+        got = np.concatenate([g[0] for g in gathered])
+        assert got.shape == want.shape
+        assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])		# same multiset of joined rows
+        ef, ec = orc.group_count(ga[L][P], None)
+        ek = ga[L][P][ef]
+        k2 = np.concatenate([g[1] for g in gathered])
+        c2 = np.concatenate([g[2] for g in gathered])
+        o1, o2 = np.argsort(k2, kind="stable"), np.argsort(ek, kind="stable")
+        assert np.array_equal(k2[o1], ek[o2]) and np.array_equal(c2[o1], ec[o2])
+        print("gloo distributed payload join ok", len(got), "joined rows", len(ek), "groups")
 
 
 if __name__ == "__main__":

@@ -239,6 +239,12 @@ def test_partition_by_dest(dev, n_dest):
     off = np.concatenate([[0], np.cumsum(ec)])
     for d in range(n_dest):
         assert np.array_equal(np.sort(got[off[d]:off[d + 1]]), np.sort(ek[off[d]:off[d + 1]]))
+    # with row ids: every entry names its source row (that is how payload columns follow the keys)
+    out2, counts2, rid = dev.partition_by_dest(dev.to_dev(k), dev.nullbits_dev(nl), n_dest, with_rid=True)
+    assert counts2 == counts
+    r = _np(rid).view(np.uint32)
+    assert np.array_equal(k[r], _np(out2)) and len(np.unique(r)) == len(r) and not nl[r].any()
+    assert np.array_equal(orc.dest_of(_np(out2), n_dest), np.repeat(np.arange(n_dest), counts2))
 
 
 def test_gen_keys_matches_oracle(dev):
@@ -381,3 +387,17 @@ def test_distinct_sel(dev, n):
             ([(b, None, rid, True, False), (a, na, rid, False, False)], [(bd, None, ridd, D.T_DOUBLE, False), (ad, nad, ridd, D.T_INT64, False)])]:
         got = _np(dev.distinct_sel(keys_dev, n)).view(np.uint32)
         assert np.array_equal(got, orc.distinct_sel(keys_np, n))
+
+
+def test_table_shuffle_payload_join_rccl():
+    """BASELINE configs 4/5 exchange path with the device operators and RCCL (own process: it creates a process group)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_shuffle_gpu_worker.py")], cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rccl table shuffle payload join ok" in r.stdout

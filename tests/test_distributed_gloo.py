@@ -13,3 +13,4 @@ def test_hash_partition_all_to_all_join_world2():
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "gloo distributed join ok" in r.stdout
+    assert "gloo distributed payload join ok" in r.stdout		# 3-way join with DOUBLE/INT payload + GROUP BY (config 5 shape)
