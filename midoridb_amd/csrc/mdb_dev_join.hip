@@ -571,6 +571,12 @@ struct gc_state {
 static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 {
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
+	/* two 9-bit levels give at most 2^18 leaves; a leaf's LDS table holds GC_SLOTS distinct keys */
+	if ((st->n_l >> (st->b1 + st->b2)) > (uint64_t)GC_SLOTS * 7 / 10)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR,
+				   "%llu build rows exceed what one GPU shard groups in LDS (about %llu): partition the tables across GPUs "
+				   "(mdb_dev_partition_by_dest)",
+				   (unsigned long long)st->n_l, (unsigned long long)(((uint64_t)GC_SLOTS * 7 / 10) << (2 * MDB_MAX_RADIX_BITS)));
 	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->has_r)
 		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
