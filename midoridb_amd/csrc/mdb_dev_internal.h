@@ -48,9 +48,12 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out);
 
-size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap);
-int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap,
-		      mdb_part_result *out);
+/* fast = fixed-capacity regions + cursors (a region overflow sets bit 1 of ctx->d_status[0]: the caller must check it
+ * after the consumer kernel and redo with fast = false, the exact histogram layout) */
+/* digits0_used: how many of the 2^bits1 first-level digits can occur at all (0 = every one) - sizes the fast regions */
+size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used);
+int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
+		      uint32_t digits0_used, mdb_part_result *out);
 
 /* one stable least-significant-digit radix pass over (key, row id) pairs: digit = (key >> shift) & (2^bits - 1),
  * bits <= 8.  hist = scratch of mdb_sort_pass_hist_words(n) uint32, scan_tmp = mdb_scan_scratch_words(of that). */

@@ -543,6 +543,13 @@ static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
 	return true;
 }
 
+/* first-level digits of the ordering sort that can occur: row ids are < n_l, not < 2^kbits */
+static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
+{
+	const uint32_t shift = kbits - (uint32_t)sb1;
+	return (uint32_t)(((n_l ? n_l - 1 : 0) >> shift) + 1);
+}
+
 /* ------------------------------------------------------------------ group-count drivers */
 
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
@@ -585,8 +592,10 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		int s1 = 0, s2 = 0;
 		need += mdb_align_up(gc_rec_capacity(ctx, st->n_l) * 8) + mdb_align_up(st->n_l * 4) + 4096;
 		if (st->want_records && order_bits(st->n_l, &kb, &s1, &s2))
-			need += mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2))) +
-				(((size_t)1 << (s1 + s2)) + 4096) * 8;
+			need += mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2)), true,
+							      order_digits0(st->n_l, kb, s1)) +
+				mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2)), false, 0) +
+				2 * (((size_t)1 << (s1 + s2)) + 4096) * 8;
 		else
 			need += mdb_filter_arena_bytes(st->n_l);
 	}
@@ -721,41 +730,50 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		mdb_part_result ps;
-		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, &ps);
-		if (rc)
-			return rc;
-		ord_args oa;
-		oa.rec = (const unsigned long long *)ps.hv;
-		oa.off = ps.leaf_off;
-		oa.cnt = ps.leaf_cnt;
-		oa.cap = ps.leaf_cap;
-		oa.out_base = NULL;
-		oa.kbits = kbits;
-		oa.leaf_bits = (uint32_t)(sb1 + sb2);
-		oa.out_first = first_out;
-		oa.out_count = out_count;
-		oa.keys = keys_l;
-		oa.out_key = out_key;
-		if (ps.leaf_cap) {
-			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
-			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
-			uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
-			if (!obase || !otmp)
-				return -MIDORIDB_INTERNAL;
-			if (ps.nleaves <= MDB_SCAN_SMALL) {
-				rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
-			} else {
-				MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
-				MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
-				rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
-			}
+		/* order the group records by first row id: histogram-free regions first; if one overflows (the gaps of
+		 * the record list can bunch the records of one XCD's tile range) the exact layout redoes the sort */
+		for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
+			mdb_part_result ps;
+			rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0,
+					       order_digits0(n_l, kbits, sb1), &ps);
 			if (rc)
 				return rc;
-			oa.out_base = obase;
+			ord_args oa;
+			oa.rec = (const unsigned long long *)ps.hv;
+			oa.off = ps.leaf_off;
+			oa.cnt = ps.leaf_cnt;
+			oa.cap = ps.leaf_cap;
+			oa.out_base = NULL;
+			oa.kbits = kbits;
+			oa.leaf_bits = (uint32_t)(sb1 + sb2);
+			oa.out_first = first_out;
+			oa.out_count = out_count;
+			oa.keys = keys_l;
+			oa.out_key = out_key;
+			if (ps.leaf_cap) {
+				/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
+				uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
+				uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
+				if (!obase || !otmp)
+					return -MIDORIDB_INTERNAL;
+				if (ps.nleaves <= MDB_SCAN_SMALL) {
+					rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
+				} else {
+					MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
+					MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
+					rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
+				}
+				if (rc)
+					return rc;
+				oa.out_base = obase;
+			}
+			MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
+			MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			if (!sort_fast || !((uint32_t)h[8] & 2u))
+				break;
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* the other flag bits were checked above */
 		}
-		MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
-		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
 		if (rc)

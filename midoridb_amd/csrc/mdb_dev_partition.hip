@@ -549,7 +549,8 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
-			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL)
+			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL,
+			  uint32_t digits0_used = 0)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -564,7 +565,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			  (uint64_t)nleaves_total * fast_cap < 0xFFFFFFFFull;
 	/* ... and, with it, to the first level: PART_NSUB fixed-capacity sub-regions per digit */
 	const uint32_t nreg0 = Rl[0] * PART_NSUB;
-	const uint32_t cap0 = (uint32_t)((((n + nreg0 - 1) / nreg0) * 5 / 4 + 1024 + 63) & ~63ull);
+	/* raw sort keys need not cover the whole first digit range (row ids below n < 2^kbits): the regions are
+	 * sized for the digits that can occur */
+	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
+	const uint32_t cap0 = (uint32_t)((((n + nreg0_used - 1) / nreg0_used) * 5 / 4 + 1024 + 63) & ~63ull);
 	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0 * cap0 < 0xFFFFFFFFull;
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
@@ -780,20 +784,20 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 /* MSD radix partition of ready-made 64-bit sort keys (no hashing, no NULLs) by their top bits1 + bits2
  * bits; with two levels the last one uses the fixed-capacity layout with `leaf_cap` rows per leaf (the
  * caller guarantees no leaf can hold more).  Used to order GROUP BY results by first row id. */
-size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap)
+size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, false, PART_F_FAST, MDB_DIGIT_RADIX, 0, false, NULL,
-			     (const uint64_t *)16, leaf_cap, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, false, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL,
+			     (const uint64_t *)16, leaf_cap, NULL, NULL, digits0_used);
 	return cv.bytes + 4096;
 }
 
-int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap,
-		      mdb_part_result *out)
+int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
+		      uint32_t digits0_used, mdb_part_result *out)
 {
 	part_carver cv = { ctx, false, 0, false };
-	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, PART_F_FAST, MDB_DIGIT_RADIX, 0, false, NULL, hv, leaf_cap,
-			      out);
+	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, hv,
+			      leaf_cap, out, NULL, digits0_used);
 }
 
 /* ---- one stable LSD radix pass (ORDER BY) --------------------------------------------------------

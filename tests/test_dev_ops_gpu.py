@@ -401,3 +401,53 @@ def test_table_shuffle_payload_join_rccl():
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "rccl table shuffle payload join ok" in r.stdout
+
+
+@pytest.mark.parametrize("variant", ["D", "U"])
+def test_full_size_north_star_properties(dev, variant):
+    """BASELINE config 3 at its full size (10^8 rows per table) through size-independent properties:
+    D: B keys = permutation mod N/16 -> G = N/16 groups of exactly 16, J = N; U: both permutations -> G = N groups
+    of 1.  Keys distinct, groups in first-occurrence order of the left table, key = a[first], and the closed-form
+    checksums sum(keys) / sum(counts)."""
+    N = 100_000_000
+    a = dev.gen_keys(N, 0, N, 42, 0)
+    b = dev.gen_keys(N, 0, N, 43, N // 16 if variant == "D" else 0)
+    k, c, f, j = dev.join_group_count(a, None, b, None)
+    G = N // 16 if variant == "D" else N
+    assert j == N and k.numel() == G
+    assert bool((c == (16 if variant == "D" else 1)).all()) and int(c.sum()) == N
+    assert bool((f[1:] > f[:-1]).all())
+    assert bool((a[f.long()] == k).all())
+    assert int(k.sum()) == G * (G - 1) // 2 and int(k.min()) == 0 and int(k.max()) == G - 1	# a permutation of [0, G)
+    del k, c, f
+    torch.cuda.empty_cache()
+
+
+def test_full_size_three_way_join_properties(dev):
+    """BASELINE config 5 shape at 10^8 rows per table on one GPU (keys only): A, B, C independent permutations of
+    [0, N): (A join B) join C has exactly N rows, every A row once, and the composed row ids point at equal keys."""
+    N = 100_000_000
+    a, b, cc = (dev.gen_keys(N, 0, N, s, 0) for s in (42, 43, 44))
+    l, r = dev.join_pairs(a, None, b, None)
+    assert l.numel() == N
+    assert bool((l.long() == torch.arange(N, device=l.device)).all())		# left-major order, 1:1
+    assert bool((b[r.long()] == a).all())
+    del l
+    p, q = dev.join_pairs(a, None, cc, None)
+    assert p.numel() == N and bool((cc[q.long()] == a).all())
+    first, cnt = dev.group_count(a, None)
+    assert first.numel() == N and bool((cnt == 1).all())
+    del p, q, r, first, cnt
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [2_097_153, 3_000_000, 20_000_000, 67_108_865])
+def test_group_count_all_unique_partial_id_range(dev, n):
+    """GROUP BY over all-unique keys (G = n): every row id is a group's first row, and n just above a power of two
+    leaves half of the ordering sort's first-level digits empty - the fixed-capacity regions must be sized for the
+    digits that occur (regression: overflowing regions silently dropped records)."""
+    a = dev.gen_keys(n, 0, n, 42, 0)
+    first, cnt = dev.group_count(a, None)
+    assert first.numel() == n
+    assert bool((cnt == 1).all())
+    assert bool((first.long() == torch.arange(n, device=first.device)).all())
