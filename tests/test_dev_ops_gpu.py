@@ -451,3 +451,29 @@ def test_group_count_all_unique_partial_id_range(dev, n):
     assert first.numel() == n
     assert bool((cnt == 1).all())
     assert bool((first.long() == torch.arange(n, device=first.device)).all())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_join_group_count_randomised_large(dev, seed):
+    """Randomised sizes / key domains / duplicate factors / NULL rates up to 3*10^7 rows against the C hash-join
+    oracle (oracle/cpu_hash.c, pinned to the reference vectors): exact keys, counts, first rows, joined rows, order."""
+    from oracle import cpu
+    rng = np.random.default_rng(1000 + seed)
+    n_l = int(10 ** rng.uniform(5, 7.48))
+    n_r = int(10 ** rng.uniform(5, 7.48))
+    dom = int(max(2, n_l * 10 ** rng.uniform(-2.5, 0.5)))
+    lo = int(rng.integers(-dom, dom))
+    kl = rng.integers(lo, lo + dom, n_l, dtype=np.int64)
+    kr = rng.integers(lo, lo + dom, n_r, dtype=np.int64)
+    if seed % 3 == 0:
+        kl = rng.permutation(n_l).astype(np.int64) + lo		# unique build keys: G close to n_l
+    nl = (rng.random(n_l) < 0.02) if seed % 2 else None
+    nr = (rng.random(n_r) < 0.02) if seed % 4 == 1 else None
+    ek, ec, ef, ej = cpu.hash_join_group_count(kl, nl, kr, nr, 8)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert j == ej and k.numel() == len(ek)
+    assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec) and np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    # plain GROUP BY over the left keys: counts per key in first-occurrence order (numpy oracle)
+    first, cnt = dev.group_count(dev.to_dev(kl), dev.nullbits_dev(nl))
+    e_first, e_cnt = orc.group_count(kl, nl)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
