@@ -76,27 +76,32 @@ def cpu_baseline():
     """Time the CPU path on this box's host cores on a bounded sample of the same query.
 
     Preferred: the REAL reference executor (oracle/_ref, built in the authoring container from
-    /root/reference and shipped with the snapshot) on 2000 x 2000 rows through its own
+    /root/reference and shipped with the snapshot) on 5000 x 5000 rows (about 15 s) through its own
     ast -> semantic -> optimiser -> executor pipeline.  Fallback: oracle/cpu_naive.c ("port").
     """
-    n = 2000
+    n = 5000
     try:
         from oracle import ref as refmod
         if refmod.available():
-            db = refmod.RefDB()
-            a = np.arange(n, dtype=np.int64)
-            rng = np.random.default_rng(42)
-            db.create_int_table("A", ["id_a"])
-            db.create_int_table("B", ["id_b"])
-            db.bulk_insert("A", [rng.permutation(a)])
-            db.bulk_insert("B", [rng.permutation(a)])
-            t0 = time.perf_counter()
-            cols, rows = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;")
-            dt = time.perf_counter() - t0
-            db.close()
+            times = {}
+            for m in (n // 2, n):		# two sizes: the second shows the quadratic growth the extrapolation uses
+                db = refmod.RefDB()
+                a = np.arange(m, dtype=np.int64)
+                rng = np.random.default_rng(42)
+                db.create_int_table("A", ["id_a"])
+                db.create_int_table("B", ["id_b"])
+                db.bulk_insert("A", [rng.permutation(a)])
+                db.bulk_insert("B", [rng.permutation(a)])
+                t0 = time.perf_counter()
+                cols, rows = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;")
+                times[m] = time.perf_counter() - t0
+                db.close()
+            dt = times[n]
+            pairs_s = n * n / dt
             return {"value": n / dt, "unit": "joined rows/s", "cores": 1, "kind": "reference",
-                    "sample": f"north-star query, {n}x{n} unique keys, real reference executor via oracle/_ref "
-                              f"({dt:.2f} s; O(nA*nB) nested loop, {n * n / dt:.3g} row pairs/s)"}
+                    "sample": f"north-star query, {n}x{n} unique keys, real reference executor via oracle/_ref ({dt:.2f} s; "
+                              f"{n // 2}x{n // 2}: {times[n // 2]:.2f} s, i.e. O(nA*nB) nested loop at {pairs_s:.3g} row pairs/s; "
+                              f"10^8 x 10^8 rows would take {1e16 / pairs_s / 3.15e7:.0f} years)"}
     except Exception as e:  # pragma: no cover - diagnostic path
         sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
     from oracle import cpu
