@@ -246,17 +246,44 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 						}
 					}
 				}
+				/* first probe of every key of the batch issued back to back (the CAS round trips overlap);
+				 * only keys whose first slot is taken by another key walk on, one after the other */
+				uint32_t s_[LEAF_BATCH], step_[LEAF_BATCH];
+				unsigned long long old_[LEAF_BATCH];
+				bool act_[LEAF_BATCH];
 #pragma unroll
 				for (int u = 0; u < LEAF_BATCH; u++) {
 					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 					if (base == l0)
 						own[u] = 0xFFFFFFFFu;
+					act_[u] = i < l1 && b.hv_l[u] != 0;
+					s_[u] = leaf_slot(b.hv_l[u], GC_SLOTS);
+					step_[u] = leaf_step(b.hv_l[u], GC_SLOTS);
+					old_[u] = act_[u] ? atomicCAS(&s_key[s_[u]], 0ull, (unsigned long long)b.hv_l[u]) : 0ull;
+				}
+#pragma unroll
+				for (int u = 0; u < LEAF_BATCH; u++) {
+					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 					if (i >= l1)
 						continue;
 					uint32_t s = GC_SLOTS;
 					bool created = false;
-					if (b.hv_l[u] != 0)
-						s = leaf_insert(s_key, GC_SLOTS, b.hv_l[u], &created);
+					if (act_[u]) {
+						s = s_[u];
+						unsigned long long old = old_[u];
+						uint32_t probe = 1;
+						while (old != 0ull && old != b.hv_l[u]) {
+							if (probe++ >= GC_SLOTS) {
+								s = 0xFFFFFFFFu;
+								break;
+							}
+							s += step_[u];
+							if (s >= GC_SLOTS)
+								s -= GC_SLOTS;
+							old = atomicCAS(&s_key[s], 0ull, (unsigned long long)b.hv_l[u]);
+						}
+						created = old == 0ull;
+					}
 					if (s == 0xFFFFFFFFu) {
 						atomicOr(a.status, 1u);
 					} else {
@@ -279,14 +306,36 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 							b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
 						}
 					}
+					/* same shape as the build: the first slot of every key is read before any is examined */
+					uint32_t ps_[LEAF_BATCH], pstep_[LEAF_BATCH];
+					unsigned long long cur_[LEAF_BATCH];
+#pragma unroll
+					for (int u = 0; u < LEAF_BATCH; u++) {
+						ps_[u] = leaf_slot(b.hv_r[u], GC_SLOTS);
+						pstep_[u] = leaf_step(b.hv_r[u], GC_SLOTS);
+						cur_[u] = s_key[ps_[u]];
+					}
 #pragma unroll
 					for (int u = 0; u < LEAF_BATCH; u++) {
 						const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 						if (j >= r1)
 							continue;
 						uint32_t s = GC_SLOTS;
-						if (b.hv_r[u] != 0)
-							s = leaf_find(s_key, GC_SLOTS, b.hv_r[u]);
+						if (b.hv_r[u] != 0) {
+							unsigned long long cur = cur_[u];
+							uint32_t probe = 1;
+							s = ps_[u];
+							while (cur != b.hv_r[u]) {
+								if (cur == 0ull || probe++ >= GC_SLOTS) {
+									s = 0xFFFFFFFFu;
+									break;
+								}
+								s += pstep_[u];
+								if (s >= GC_SLOTS)
+									s -= GC_SLOTS;
+								cur = s_key[s];
+							}
+						}
 						if (s != 0xFFFFFFFFu)
 							atomicAdd(&s_cnt[s], 1ull << 32);
 					}
