@@ -328,7 +328,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			/* first level: 8 sub-regions per digit, picked by blockIdx % 8 (= the XCD under round-robin
 			 * dispatch, so an XCD's partial lines meet in its own L2) keep the contention per cursor low */
 			fast_child = a.nsub ? threadIdx.x * a.nsub + (blockIdx.x % a.nsub) : td.seg * R + threadIdx.x;
-			fast_base = total_d ? atomicAdd(&a.cursor[fast_child], total_d) : 0u;
+			/* first-level cursors are laid out sub-major (cursor[sub * R + digit]): the 256 atomics of one tile
+			 * fall into 8 consecutive 128-byte lines that only this XCD's tiles touch, instead of 64 lines
+			 * shared by every XCD (atomics on one line serialise) */
+			const uint32_t cidx = a.nsub ? (blockIdx.x % a.nsub) * R + threadIdx.x : fast_child;
+			fast_base = total_d ? atomicAdd(&a.cursor[cidx], total_d) : 0u;
 		} else {
 			s_delta[threadIdx.x] = (int32_t)(a.hist[(uint64_t)td.hbase + (uint64_t)threadIdx.x * td.nt] - off_d);
 		}
@@ -439,8 +443,14 @@ __global__ void k_part_build_tiles(const uint32_t *__restrict__ seg_start, const
  * partition r / nsub.  The next level's tiles are cut from the regions. */
 /* FAST first level: tiles per region (a region = the filled part of a fixed-capacity sub-region) and their
  * exclusive scan, in one single-workgroup launch (there are only R * PART_NSUB + 1 entries). */
+/* cursor of region r = digit * nsub + sub (sub-major cursor layout, see k_part_scatter) */
+__device__ static inline uint32_t part_region_cursor(const uint32_t *cursor, uint32_t r, uint32_t nreg, uint32_t nsub)
+{
+	return cursor[(r % nsub) * (nreg / nsub) + r / nsub];
+}
+
 __global__ __launch_bounds__(1024) void k_part_region_tiles_scan(const uint32_t *__restrict__ cursor, uint32_t nreg, uint32_t cap,
-								 uint32_t *__restrict__ tb)
+								 uint32_t nsub, uint32_t *__restrict__ tb)
 {
 	__shared__ uint32_t s_tmp[32];
 	uint32_t carry = 0;
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_part_region_tiles_scan(const uint32_t 
 		const uint32_t r = base + threadIdx.x;
 		uint32_t c = 0;
 		if (r < nreg) {
-			c = cursor[r];
+			c = part_region_cursor(cursor, r, nreg, nsub);
 			c = c < cap ? c : cap;
 		}
 		const uint32_t nt = (c + MDB_TILE - 1) / MDB_TILE;
@@ -478,7 +488,7 @@ __global__ void k_part_build_tiles_regions(const uint32_t *__restrict__ cursor, 
 				hi = mid;
 		}
 		const uint32_t r = lo, tl = t - tb[r];
-		uint32_t c = cursor[r];
+		uint32_t c = part_region_cursor(cursor, r, nreg, nsub);
 		c = c < cap ? c : cap;
 		d.start = r * cap + tl * MDB_TILE;		/* cap is a multiple of 64: every tile starts 16-byte aligned */
 		d.len = (c - tl * MDB_TILE) < MDB_TILE ? (c - tl * MDB_TILE) : MDB_TILE;
@@ -649,7 +659,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
-				MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, reg_nt);
+				MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, PART_NSUB, reg_nt);
 				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
 					   cap0, PART_NSUB, next_desc, next_tiles);
 			}
