@@ -220,8 +220,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	/* Row ids are staged through the SAME LDS as the hashes, after the hashes have been written out (unordered
+	 * form only): 35 KiB instead of 51 KiB per workgroup = 4 instead of 3 workgroups per CU, worth ~25 % of the
+	 * kernel's time (occupancy is what hides the HBM latency of the scattered runs) */
+	constexpr bool RID_SHARES_LDS = HAS_RID && !STABLE;
 	__shared__ uint64_t s_hv[MDB_TILE];
-	__shared__ uint32_t s_rid[HAS_RID ? MDB_TILE : 1];
+	__shared__ uint32_t s_rid_own[(HAS_RID && !RID_SHARES_LDS) ? MDB_TILE : 1];
+	uint32_t *const s_rid = RID_SHARES_LDS ? reinterpret_cast<uint32_t *>(s_hv) : s_rid_own;
 	__shared__ uint32_t s_cnt[PART_MAX_R];		/* per-digit counters, then tile-local digit starts */
 	__shared__ int32_t s_delta[PART_MAX_R];	/* global start of the digit's run minus its tile-local start */
 	__shared__ uint32_t s_wcnt[STABLE ? PART_WAVES * PART_MAX_R : 1];	/* STABLE: per-wave digit counts, then bases */
@@ -346,8 +351,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			uint32_t pos = s_cnt[dig[r]] + rank[r];
 			if (STABLE)
 				pos += s_wcnt[wave * PART_MAX_R + dig[r]];
+			rank[r] = pos;		/* staged position (reused for the row ids below) */
 			s_hv[pos] = hv[r];
-			if (HAS_RID)
+			if (HAS_RID && !RID_SHARES_LDS)
 				s_rid[pos] = rid[r];
 		}
 	}
@@ -361,15 +367,34 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	__syncthreads();
 
 	/* 5. write out: consecutive threads write consecutive addresses inside each digit's run */
-	for (uint32_t i = threadIdx.x; i < tile_total; i += PART_THREADS) {
+	uint32_t gpos[PART_ITEMS];
+#pragma unroll
+	for (int k = 0; k < PART_ITEMS; k++) {
+		const uint32_t i = threadIdx.x + (uint32_t)k * PART_THREADS;
+		gpos[k] = PART_INVALID;
+		if (i >= tile_total)
+			continue;
 		const uint64_t h = s_hv[i];
 		const uint32_t d = part_digit(a, h);
 		if (FAST && !s_ok[d])
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
 		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
+		gpos[k] = g;
 		a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
-		if (HAS_RID)
+		if (HAS_RID && !RID_SHARES_LDS)
 			a.rid_out[g] = s_rid[i];
+	}
+	if (RID_SHARES_LDS) {
+		__syncthreads();	/* every hash has been read: the buffer now takes the row ids */
+#pragma unroll
+		for (int r = 0; r < PART_ITEMS; r++)
+			if (dig[r] != PART_INVALID)
+				s_rid[rank[r]] = rid[r];
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < PART_ITEMS; k++)
+			if (gpos[k] != PART_INVALID)
+				a.rid_out[gpos[k]] = s_rid[threadIdx.x + (uint32_t)k * PART_THREADS];
 	}
 }
 
