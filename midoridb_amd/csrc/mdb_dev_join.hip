@@ -136,6 +136,29 @@ __device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t 
 	}
 }
 
+__device__ static inline void gc_load_l(const gc_args &a, uint32_t base, uint32_t end, gc_batch &b)
+{
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+		b.hv_l[u] = 0;
+		b.rid_l[u] = 0;
+		if (i < end) {
+			b.hv_l[u] = a.hv_l[i];
+			b.rid_l[u] = a.rid_l[i];
+		}
+	}
+}
+
+__device__ static inline void gc_load_r(const gc_args &a, uint32_t base, uint32_t end, gc_batch &b)
+{
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+		b.hv_r[u] = j < end ? a.hv_r[j] : 0;
+	}
+}
+
 template <bool HAS_R>
 __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, gc_batch &b)
 {
@@ -155,7 +178,131 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 	}
 }
 
-template <bool HAS_R>
+/* One side of a leaf goes INTO the table (insert-or-find, count, first left row id) ... */
+template <bool IS_L>
+__device__ static inline void gc_build_side(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
+					    gc_batch &b, uint32_t x0, uint32_t x1, uint32_t own[LEAF_BATCH])
+{
+	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
+		if (base != x0) {
+			if (IS_L)
+				gc_load_l(a, base, x1, b);
+			else
+				gc_load_r(a, base, x1, b);
+		}
+		/* first probe of every key of the batch issued back to back (the CAS round trips overlap);
+		 * only keys whose first slot is taken by another key walk on, one after the other */
+		uint32_t s_[LEAF_BATCH], step_[LEAF_BATCH];
+		unsigned long long old_[LEAF_BATCH];
+		bool act_[LEAF_BATCH];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			if (base == x0)
+				own[u] = 0xFFFFFFFFu;
+			act_[u] = i < x1 && hv != 0;
+			s_[u] = leaf_slot(hv, GC_SLOTS);
+			step_[u] = leaf_step(hv, GC_SLOTS);
+			old_[u] = act_[u] ? atomicCAS(&s_key[s_[u]], 0ull, (unsigned long long)hv) : 0ull;
+		}
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			if (i >= x1)
+				continue;
+			uint32_t s = GC_SLOTS;		/* the key whose hash is 0 has the side slot */
+			bool created = false;
+			if (act_[u]) {
+				s = s_[u];
+				unsigned long long old = old_[u];
+				uint32_t probe = 1;
+				while (old != 0ull && old != hv) {
+					if (probe++ >= GC_SLOTS) {
+						s = 0xFFFFFFFFu;
+						break;
+					}
+					s += step_[u];
+					if (s >= GC_SLOTS)
+						s -= GC_SLOTS;
+					old = atomicCAS(&s_key[s], 0ull, (unsigned long long)hv);
+				}
+				created = old == 0ull;
+			}
+			if (s == 0xFFFFFFFFu) {
+				atomicOr(a.status, 1u);
+			} else {
+				if (IS_L) {
+					atomicAdd(&s_cnt[s], 1ull);
+					atomicMin(&s_first[s], b.rid_l[u]);
+				} else {
+					atomicAdd(&s_cnt[s], 1ull << 32);
+				}
+				if (created && base == x0)
+					own[u] = s;	/* this thread emits (and clears) the group */
+			}
+		}
+	}
+}
+
+/* ... and the other side only LOOKS UP: a key that is not in the table costs one LDS read */
+template <bool IS_L>
+__device__ static inline void gc_probe_side(const gc_args &a, const unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
+					    gc_batch &b, uint32_t x0, uint32_t x1)
+{
+	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
+		if (base != x0) {
+			if (IS_L)
+				gc_load_l(a, base, x1, b);
+			else
+				gc_load_r(a, base, x1, b);
+		}
+		/* same shape as the build: the first slot of every key is read before any is examined */
+		uint32_t ps_[LEAF_BATCH], pstep_[LEAF_BATCH];
+		unsigned long long cur_[LEAF_BATCH];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			ps_[u] = leaf_slot(hv, GC_SLOTS);
+			pstep_[u] = leaf_step(hv, GC_SLOTS);
+			cur_[u] = s_key[ps_[u]];
+		}
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			if (j >= x1)
+				continue;
+			uint32_t s = GC_SLOTS;
+			if (hv != 0) {
+				unsigned long long cur = cur_[u];
+				uint32_t probe = 1;
+				s = ps_[u];
+				while (cur != hv) {
+					if (cur == 0ull || probe++ >= GC_SLOTS) {
+						s = 0xFFFFFFFFu;
+						break;
+					}
+					s += pstep_[u];
+					if (s >= GC_SLOTS)
+						s -= GC_SLOTS;
+					cur = s_key[s];
+				}
+			}
+			if (s != 0xFFFFFFFFu) {
+				if (IS_L) {
+					atomicAdd(&s_cnt[s], 1ull);
+					atomicMin(&s_first[s], b.rid_l[u]);
+				} else {
+					atomicAdd(&s_cnt[s], 1ull << 32);
+				}
+			}
+		}
+	}
+}
+
+template <bool HAS_R, bool BUILD_R>
 __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 {
 	/* slot = hashed key (0 = empty) + packed counters (low 32 bits: left rows, high 32 bits: right rows)
@@ -201,14 +348,15 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
 		/* a leaf whose left side fits one register batch (the normal case) is emitted by the threads that
 		 * created its table slots; only oversized (skewed) leaves scan the whole table */
-		const bool by_owner = (l1 - l0) <= GC_THREADS * LEAF_BATCH;
+		const uint32_t build_rows = (HAS_R && BUILD_R) ? r1 - r0 : l1 - l0;
+		const bool by_owner = build_rows <= GC_THREADS * LEAF_BATCH;
 		uint32_t own[LEAF_BATCH];
 		if (live && a.kbits) {
 			/* Record list space: this leaf emits at most one record per left row (and per table slot).
 			 * When the workgroup's current chunk cannot hold that, the unused tail is zero-filled (the
 			 * ordering sort skips zero records) and a new chunk is reserved with ONE global atomic - i.e.
 			 * one atomic per ~10-170 leaves instead of one on the critical path of every leaf. */
-			const uint32_t rows = l1 - l0;
+			const uint32_t rows = (HAS_R && (r1 - r0) < (l1 - l0)) ? r1 - r0 : l1 - l0;	/* a group needs a row on both sides */
 			const uint32_t need = (rows < GC_SLOTS ? rows : GC_SLOTS) + 1;
 			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
 			if (used + need > size) {		/* uniform: every thread read the same words */
@@ -232,115 +380,21 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			}
 		}
 		if (live) {
-			/* build: left side (first batch already in registers) */
-			for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
-				if (base != l0) {
-#pragma unroll
-					for (int u = 0; u < LEAF_BATCH; u++) {
-						const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-						b.hv_l[u] = 0;
-						b.rid_l[u] = 0;
-						if (i < l1) {
-							b.hv_l[u] = a.hv_l[i];
-							b.rid_l[u] = a.rid_l[i];
-						}
-					}
-				}
-				/* first probe of every key of the batch issued back to back (the CAS round trips overlap);
-				 * only keys whose first slot is taken by another key walk on, one after the other */
-				uint32_t s_[LEAF_BATCH], step_[LEAF_BATCH];
-				unsigned long long old_[LEAF_BATCH];
-				bool act_[LEAF_BATCH];
-#pragma unroll
-				for (int u = 0; u < LEAF_BATCH; u++) {
-					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-					if (base == l0)
-						own[u] = 0xFFFFFFFFu;
-					act_[u] = i < l1 && b.hv_l[u] != 0;
-					s_[u] = leaf_slot(b.hv_l[u], GC_SLOTS);
-					step_[u] = leaf_step(b.hv_l[u], GC_SLOTS);
-					old_[u] = act_[u] ? atomicCAS(&s_key[s_[u]], 0ull, (unsigned long long)b.hv_l[u]) : 0ull;
-				}
-#pragma unroll
-				for (int u = 0; u < LEAF_BATCH; u++) {
-					const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-					if (i >= l1)
-						continue;
-					uint32_t s = GC_SLOTS;
-					bool created = false;
-					if (act_[u]) {
-						s = s_[u];
-						unsigned long long old = old_[u];
-						uint32_t probe = 1;
-						while (old != 0ull && old != b.hv_l[u]) {
-							if (probe++ >= GC_SLOTS) {
-								s = 0xFFFFFFFFu;
-								break;
-							}
-							s += step_[u];
-							if (s >= GC_SLOTS)
-								s -= GC_SLOTS;
-							old = atomicCAS(&s_key[s], 0ull, (unsigned long long)b.hv_l[u]);
-						}
-						created = old == 0ull;
-					}
-					if (s == 0xFFFFFFFFu) {
-						atomicOr(a.status, 1u);
-					} else {
-						atomicAdd(&s_cnt[s], 1ull);
-						atomicMin(&s_first[s], b.rid_l[u]);
-						if (created && base == l0)
-							own[u] = s;	/* this thread emits (and clears) the group */
-					}
-				}
-			}
-			__syncthreads();
-
-			/* probe: right side */
-			if (HAS_R) {
-				for (uint32_t base = r0; base < r1; base += GC_THREADS * LEAF_BATCH) {
-					if (base != r0) {
-#pragma unroll
-						for (int u = 0; u < LEAF_BATCH; u++) {
-							const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-							b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
-						}
-					}
-					/* same shape as the build: the first slot of every key is read before any is examined */
-					uint32_t ps_[LEAF_BATCH], pstep_[LEAF_BATCH];
-					unsigned long long cur_[LEAF_BATCH];
-#pragma unroll
-					for (int u = 0; u < LEAF_BATCH; u++) {
-						ps_[u] = leaf_slot(b.hv_r[u], GC_SLOTS);
-						pstep_[u] = leaf_step(b.hv_r[u], GC_SLOTS);
-						cur_[u] = s_key[ps_[u]];
-					}
-#pragma unroll
-					for (int u = 0; u < LEAF_BATCH; u++) {
-						const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-						if (j >= r1)
-							continue;
-						uint32_t s = GC_SLOTS;
-						if (b.hv_r[u] != 0) {
-							unsigned long long cur = cur_[u];
-							uint32_t probe = 1;
-							s = ps_[u];
-							while (cur != b.hv_r[u]) {
-								if (cur == 0ull || probe++ >= GC_SLOTS) {
-									s = 0xFFFFFFFFu;
-									break;
-								}
-								s += pstep_[u];
-								if (s >= GC_SLOTS)
-									s -= GC_SLOTS;
-								cur = s_key[s];
-							}
-						}
-						if (s != 0xFFFFFFFFu)
-							atomicAdd(&s_cnt[s], 1ull << 32);
-					}
-				}
+			/* The table is built from the side with fewer rows per leaf (the right one when it is not the
+			 * larger table): with N:1 data (every left key unique, few of them matched) the left rows then
+			 * cost one LDS read each instead of an insert, a count, a minimum and a clear. */
+			if (HAS_R && BUILD_R) {
+				gc_build_side<false>(a, s_key, s_cnt, s_first, b, r0, r1, own);
 				__syncthreads();
+				gc_probe_side<true>(a, s_key, s_cnt, s_first, b, l0, l1);
+				__syncthreads();
+			} else {
+				gc_build_side<true>(a, s_key, s_cnt, s_first, b, l0, l1, own);
+				__syncthreads();
+				if (HAS_R) {
+					gc_probe_side<false>(a, s_key, s_cnt, s_first, b, r0, r1);
+					__syncthreads();
+				}
 			}
 		}
 
@@ -602,6 +656,7 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
 /* ------------------------------------------------------------------ group-count drivers */
 
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
+#define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 
 /* slots of the group-record list: every group once, plus the zero-filled gaps of the chunked reservation
@@ -618,7 +673,7 @@ struct gc_state {
 	const int64_t *keys_l;
 	const uint64_t *null_l;
 	uint64_t n_l, n_r_cap;
-	bool has_r, null_group, fast, want_records;
+	bool has_r, null_group, fast, want_records, no_build_r;
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -670,6 +725,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	const uint64_t *null_l = st->null_l;
 	const uint64_t n_l = st->n_l;
 	const bool has_r = st->has_r, null_group = st->null_group, want_records = st->want_records;
+	/* hash table on the side with fewer rows per leaf (the leaves are sized by the left table) */
+	const bool build_r = has_r && !st->no_build_r && n_r <= n_l;
 	mdb_part_result pl = st->pl, pr;
 	int rc;
 
@@ -729,10 +786,12 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		if (has_r) {
-			MDB_LAUNCH(ctx, "leaf_join_group_count", k_leaf_group_count<true>, grid, GC_THREADS, a);
+		if (has_r && build_r) {
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true>), grid, GC_THREADS, a);
+		} else if (has_r) {
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false>), grid, GC_THREADS, a);
 		} else {
-			MDB_LAUNCH(ctx, "leaf_group_count", k_leaf_group_count<false>, grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false>), grid, GC_THREADS, a);
 		}
 	}
 	if (null_group && null_l) {
@@ -770,6 +829,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if (status & 4u)
 		return GC_RETRY_DENSE;	/* a COUNT(*) too large to share a 64-bit record with its row id */
+	if ((status & 1u) && build_r)
+		return GC_RETRY_BUILD_L;
 	if (status & 1u)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
 				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", GC_SLOTS);
@@ -844,7 +905,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   bool want_records, bool no_build_r, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 			   uint64_t *out_joined)
 {
 	*out_groups = 0;
@@ -862,6 +923,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.null_group = null_group;
 	st.fast = fast;
 	st.want_records = want_records;
+	st.no_build_r = no_build_r;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
 		return rc;
@@ -875,15 +937,17 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 {
 	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
-	bool fast = true, records = true;
+	bool fast = true, records = true, no_build_r = false;
 	int rc;
-	for (int attempt = 0; attempt < 3; attempt++) {
-		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, out_key,
+	for (int attempt = 0; attempt < 4; attempt++) {
+		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, out_key,
 				     out_count, out_first, cap, out_groups, out_joined);
 		if (rc == GC_RETRY_EXACT)
 			fast = false;
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
+		else if (rc == GC_RETRY_BUILD_L)
+			no_build_r = true;
 		else
 			break;
 	}
@@ -953,7 +1017,7 @@ extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE)	/* skew / huge counts: redo the whole operator on the safe path */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L)	/* skew / huge counts: redo the whole operator on the safe path */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined);
 	return rc;
