@@ -124,7 +124,7 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
  * access when both belong to the tile (8-byte accesses reach only ~0.6x of the 16-byte rate,
  * MI355X_MICROARCH.md).  lead = 1 when the tile starts on an odd element.  valid[k] = element exists and is
  * not NULL. */
-template <bool LEVEL0, bool HAS_RID>
+template <bool LEVEL0, bool HAS_RID, bool RAW = false>
 __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint64_t hv[2],
 					 uint32_t rid[2], bool valid[2])
 {
@@ -173,13 +173,13 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		if (valid[1] && mdb_bit_is_set(a.nullbits, g0 + 1))
 			valid[1] = false;
 	}
-	if (!LEVEL0 && a.skip_zero) {
+	if (RAW && a.skip_zero) {
 		valid[0] = valid[0] && hv[0] != 0;
 		valid[1] = valid[1] && hv[1] != 0;
 	}
 }
 
-template <bool LEVEL0>
+template <bool LEVEL0, bool RAW = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 {
 	__shared__ uint32_t s_h[PART_MAX_R];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 		uint64_t hv[2];
 		uint32_t rid[2];
 		bool valid[2];
-		part_load2<LEVEL0, false>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid);
+		part_load2<LEVEL0, false, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid);
 		if (valid[0])
 			atomicAdd(&s_h[part_digit(a, hv[0])], 1u);
 		if (valid[1])
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
 	/* Row ids are staged through the SAME LDS as the hashes, after the hashes have been written out (unordered
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 #pragma unroll
 		for (int r = 0; r < PART_ITEMS / 2; r++) {
 			bool valid[2];
-			part_load2<LEVEL0, HAS_RID>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, &hv[2 * r], &rid[2 * r], valid);
+			part_load2<LEVEL0, HAS_RID, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, &hv[2 * r], &rid[2 * r], valid);
 			dig[2 * r] = valid[0] ? part_digit(a, hv[2 * r]) : PART_INVALID;
 			dig[2 * r + 1] = valid[1] ? part_digit(a, hv[2 * r + 1]) : PART_INVALID;
 		}
@@ -678,7 +678,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
 				if (raw_hv) {
-					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else {
@@ -710,7 +710,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv) {
-					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
@@ -741,7 +741,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			a.hist = hist;
 			MDB_HIP(ctx, hipMemsetAsync(hist, 0, hlen * 4, ctx->stream));
 			if (l == 0 && raw_hv) {
-				MDB_LAUNCH(ctx, "sort_hist_l0", k_part_hist<false>, grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "sort_hist_l0", (k_part_hist<false, true>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0) {
 				MDB_LAUNCH(ctx, "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
 			} else {
@@ -751,7 +751,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			if (rc)
 				return rc;
 			if (l == 0 && raw_hv) {
-				MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable && l == 0) {
 				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable) {
