@@ -232,7 +232,9 @@ int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
  * key, may be NULL): caller buffers of capacity `cap` (n_l is always enough).
  * With MDB_ORDER_FIRST the groups are in the reference's order (first occurrence in
  * L-major join order).  *out_groups = G, *out_joined = number of joined rows
- * (sum of counts).  Synchronises once at the end (to read G and J back).
+ * (sum of counts).  Synchronous: G, J and the overflow flags come back before the groups are ordered
+ * (the ordering sort is sized by G), completion after it.  Size limit per call: about 7*10^8 left rows
+ * (beyond that the tables must be sharded, see mdb_dev_partition_by_dest).
  */
 int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
 			     const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
