@@ -114,6 +114,169 @@ __device__ static inline bool pred_eval(const pred_args &p, uint64_t k)
 	return st & 1;
 }
 
+/* Two adjacent tuples (k0 even) of a stream that IS a base table (no row-id indirection): every operand is one
+ * 16-byte load (8-byte accesses reach only ~0.6x of that rate on gfx950, MI355X_MICROARCH.md). */
+__device__ static inline void pred_load_pair(const mdb_col_binding &c, uint64_t k0, bool both, uint64_t v[2], bool ok[2])
+{
+	const uint64_t *vals = reinterpret_cast<const uint64_t *>(c.values);
+	if (both) {
+		const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + k0);
+		v[0] = q.x;
+		v[1] = q.y;
+	} else {
+		v[0] = vals[k0];
+		v[1] = 0;
+	}
+	ok[0] = true;
+	ok[1] = both;
+	if (c.nullbits) {
+		const uint64_t w = c.nullbits[k0 >> 6] >> (k0 & 63);	/* k0 is even: both bits live in one word */
+		ok[0] = !(w & 1ull);
+		ok[1] = both && !(w & 2ull);
+	}
+}
+
+/* x0 / ok0 = the pair of column slot 0, loaded by the caller ahead of time (several tuples' loads in flight) */
+__device__ static inline void pred_eval_pair(const pred_args &p, uint64_t k0, bool both, const uint64_t x0[2], const bool ok0[2], bool out[2])
+{
+	uint64_t st0 = 0, st1 = 0;
+	auto load = [&](int slot, uint64_t v[2], bool ok[2]) {
+		if (slot == 0) {
+			v[0] = x0[0];
+			v[1] = x0[1];
+			ok[0] = ok0[0];
+			ok[1] = ok0[1];
+		} else {
+			pred_load_pair(p.cols[slot], k0, both, v, ok);
+		}
+	};
+	for (int i = 0; i < p.n_insns; i++) {
+		const mdb_pred_insn &in = p.insn[i];
+		uint64_t x[2], y[2];
+		bool okx[2], oky[2], b0 = false, b1 = false;
+		switch (in.op) {
+		case MDB_P_CMP_COL_CONST:
+			load(in.a, x, okx);
+			b0 = okx[0] && pred_cmp(in.cmp, in.type, x[0], (uint64_t)in.imm);
+			b1 = okx[1] && pred_cmp(in.cmp, in.type, x[1], (uint64_t)in.imm);
+			break;
+		case MDB_P_CMP_CONST_COL:
+			load(in.a, x, okx);
+			b0 = okx[0] && pred_cmp(in.cmp, in.type, (uint64_t)in.imm, x[0]);
+			b1 = okx[1] && pred_cmp(in.cmp, in.type, (uint64_t)in.imm, x[1]);
+			break;
+		case MDB_P_CMP_COL_COL:
+			load(in.a, x, okx);
+			load(in.b, y, oky);
+			b0 = okx[0] && oky[0] && pred_cmp(in.cmp, in.type, x[0], y[0]);
+			b1 = okx[1] && oky[1] && pred_cmp(in.cmp, in.type, x[1], y[1]);
+			break;
+		case MDB_P_ISNULL:
+			load(in.a, x, okx);
+			b0 = (!okx[0]) != (in.cmp != 0);
+			b1 = (!okx[1]) != (in.cmp != 0);
+			break;
+		case MDB_P_CONST:
+			b0 = b1 = in.imm != 0;
+			break;
+		default: {	/* AND / OR / XOR */
+			const uint64_t r0 = st0 & 1, l0 = (st0 >> 1) & 1, r1 = st1 & 1, l1 = (st1 >> 1) & 1;
+			st0 = ((st0 >> 2) << 1) | (in.op == MDB_P_AND ? (l0 & r0) : (in.op == MDB_P_OR ? (l0 | r0) : (l0 ^ r0)));
+			st1 = ((st1 >> 2) << 1) | (in.op == MDB_P_AND ? (l1 & r1) : (in.op == MDB_P_OR ? (l1 | r1) : (l1 ^ r1)));
+			continue;
+		}
+		}
+		st0 = (st0 << 1) | (uint64_t)b0;
+		st1 = (st1 << 1) | (uint64_t)b1;
+	}
+	out[0] = st0 & 1;
+	out[1] = both && (st1 & 1);
+}
+
+/* bit i of `even` -> bit 2i, bit i of `odd` -> bit 2i+1 (32 bits each) */
+__device__ static inline uint64_t filt_interleave32(uint32_t even, uint32_t odd)
+{
+	auto spread = [](uint64_t x) {
+		x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+		x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+		x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+		x = (x | (x << 2)) & 0x3333333333333333ull;
+		x = (x | (x << 1)) & 0x5555555555555555ull;
+		return x;
+	};
+	return spread(even) | (spread(odd) << 1);
+}
+
+/* Same result as k_pred_bits, for streams without row-id indirection: a lane evaluates the two adjacent tuples
+ * 2*lane, 2*lane+1 of a 128-tuple span with 16-byte loads; two ballots, bit-interleaved, give the span's two
+ * bitmap words.  MODE 0: predicate program, MODE 1: vals != 0. */
+template <int MODE>
+__global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_pair(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
+								 uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts)
+{
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0)
+		s_cnt = 0;
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+	uint32_t cnt = 0;
+	constexpr int AHEAD = 4;	/* spans whose first operand is requested before any is evaluated */
+	for (int r4 = 0; r4 < FILT_WORDS_PER_WAVE; r4 += 2 * AHEAD) {
+		uint64_t x0[AHEAD][2];
+		bool ok0[AHEAD][2];
+#pragma unroll
+		for (int u = 0; u < AHEAD; u++) {
+			const uint64_t k0 = ((word0 + r4 + 2 * u) << 6) + 2ull * mdb_lane();
+			x0[u][0] = x0[u][1] = 0;
+			ok0[u][0] = ok0[u][1] = false;
+			if (k0 < n) {
+				if (MODE == 1) {
+					if (k0 + 1 < n) {
+						const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + k0);
+						x0[u][0] = q.x;
+						x0[u][1] = q.y;
+					} else {
+						x0[u][0] = (uint64_t)vals[k0];
+					}
+				} else {
+					pred_load_pair(p.cols[0], k0, k0 + 1 < n, x0[u], ok0[u]);
+				}
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < AHEAD; u++) {
+			const uint64_t word = word0 + r4 + 2 * u;
+			const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
+			bool pass[2] = { false, false };
+			if (k0 < n) {
+				if (MODE == 1) {
+					pass[0] = x0[u][0] != 0;
+					pass[1] = x0[u][1] != 0;
+				} else {
+					pred_eval_pair(p, k0, k0 + 1 < n, x0[u], ok0[u], pass);
+				}
+			}
+			const uint64_t m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+			if ((word << 6) < n) {
+				const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
+				const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
+				if (mdb_lane() == 0) {
+					bits[word] = wa;
+					if (((word + 1) << 6) < n)
+						bits[word + 1] = wb;
+				}
+				cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+			}
+		}
+	}
+	if (mdb_lane() == 0 && cnt)
+		atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		block_counts[blockIdx.x] = s_cnt;
+}
+
 /* MODE 0: general predicate program; MODE 1: "vals[k] != 0" over an int64 array */
 template <int MODE>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
@@ -184,7 +347,7 @@ size_t mdb_filter_arena_bytes(uint64_t n)
 
 /* Shared tail: bitmap + block counts (arena) -> scan -> selection vector.  *d_total = device
  * address of the number of selected tuples.  No host sync. */
-static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, const int64_t *vals, uint64_t n, uint32_t *out_sel,
+static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols, const int64_t *vals, uint64_t n, uint32_t *out_sel,
 		      uint32_t **d_total)
 {
 	const uint32_t nb = filt_blocks(n);
@@ -197,9 +360,21 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, const int6
 	if (mode == 1) {
 		pred_args empty;
 		memset(&empty, 0, sizeof(empty));
-		MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+		if (((uintptr_t)vals & 15) == 0) {
+			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits_pair<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+		} else {
+			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+		}
 	} else {
-		MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+		/* base-table streams (no row-id vector, 16-byte aligned columns) take the paired 16-byte-load form */
+		bool direct = n_cols >= 1;	/* (a program of constants only has no column to stream) */
+		for (int c = 0; c < n_cols; c++)
+			direct = direct && !p->cols[c].rid && ((uintptr_t)p->cols[c].values & 15) == 0;
+		if (direct) {
+			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_pair<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+		} else {
+			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+		}
 	}
 	int rc = mdb_scan_u32_inplace(ctx, bc, (uint64_t)nb + 1, scan_tmp);
 	if (rc)
@@ -211,7 +386,7 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, const int6
 
 int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint32_t *out_sel, uint32_t **d_total)
 {
-	return filter_run(ctx, 1, NULL, vals, n, out_sel, d_total);
+	return filter_run(ctx, 1, NULL, 0, vals, n, out_sel, d_total);
 }
 
 extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols,
@@ -270,7 +445,7 @@ extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog
 	if (rc)
 		return rc;
 	uint32_t *d_total = NULL;
-	rc = filter_run(ctx, 0, &p, NULL, n, out_sel, &d_total);
+	rc = filter_run(ctx, 0, &p, n_cols, NULL, n, out_sel, &d_total);
 	if (rc)
 		return rc;
 	uint32_t *h = (uint32_t *)ctx->h_pinned;
