@@ -1036,15 +1036,20 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 struct pj_args {
 	const uint64_t *hv_l;
 	const uint32_t *rid_l;
-	const uint32_t *off_l;
+	const uint32_t *off_l;		/* exact leaf offsets, or (cnt, cap) of the fixed-capacity layout, as in gc_args */
+	const uint32_t *cnt_l;
+	uint32_t cap_l;
 	const uint64_t *hv_r;
 	const uint32_t *rid_r;
 	const uint32_t *off_r;
+	const uint32_t *cnt_r;
+	uint32_t cap_r;
 	uint32_t *match;	/* [n_l + 1]: count phase writes matches per left row; scanned into offsets */
 	uint32_t *out_l;
 	uint32_t *out_r;
 	uint32_t *status;
 	unsigned long long *total64;	/* 64-bit sum of all match counts (guards the 32-bit offsets) */
+	uint32_t nleaves;
 };
 
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
@@ -1054,10 +1059,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 	__shared__ unsigned long long s_total;
 
 	const uint32_t leaf = blockIdx.x;
-	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
-	const uint32_t r0 = a.off_r[leaf], r1 = a.off_r[leaf + 1];
+	uint32_t l0, l1, r0, r1;
+	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
 	if (l0 == l1 || r0 == r1)
 		return;
+	if (threadIdx.x == 0 && r1 - r0 > PJ_CHUNK)
+		atomicOr(a.status, 16u);	/* the emit kernel will sweep this leaf's right rows in several chunks: they must be in row-id order */
 	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
 		if (s < PJ_SLOTS)
 			s_key[s] = 0ull;
@@ -1122,8 +1130,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 	__shared__ uint32_t s_scan[32];
 
 	const uint32_t leaf = blockIdx.x;
-	const uint32_t l0 = a.off_l[leaf], l1 = a.off_l[leaf + 1];
-	const uint32_t r0 = a.off_r[leaf], r1 = a.off_r[leaf + 1];
+	uint32_t l0, l1, r0, r1;
+	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
 	if (l0 == l1 || r0 == r1)
 		return;
 	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
@@ -1234,64 +1243,76 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	int b1, b2;
 	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
 	const uint64_t mlen = n_l + 1;
-	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, false) + mdb_partition_arena_bytes(n_r, b1, b2, true, false) +
-		      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
-	int rc = mdb_arena_begin(ctx, need);
-	if (rc)
-		return rc;
-	mdb_part_result pl, pr;
-	/* right side stable: inside a leaf its rows stay in ascending row-id order, which the chunked emit
-	 * relies on (a key's row ids in a later chunk are all larger than those of an earlier chunk).
-	 * It is partitioned on the auxiliary stream, concurrently with the left table. */
-	hipStream_t main_stream = NULL;
-	rc = mdb_aux_begin(ctx, &main_stream);
-	if (rc)
-		return rc;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, true, false, &pr);
-	{
-		int rc2 = mdb_aux_end(ctx, main_stream);
+	pj_args a;
+	uint64_t J = 0;
+	uint64_t *h = ctx->h_pinned;
+	/* First with the histogram-free partition layout and the right side in arbitrary order (the emit kernel orders
+	 * every key's row ids itself inside one chunk); the exact, stable layout is the fallback when a region
+	 * overflows (skew) or a leaf holds more right rows than one chunk (their order across chunks matters). */
+	for (int fast = 1; fast >= 0; fast--) {
+		size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast != 0) + mdb_partition_arena_bytes(n_r, b1, b2, true, fast != 0) +
+			      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
+		int rc = mdb_arena_begin(ctx, need);
 		if (rc)
 			return rc;
-		if (rc2)
-			return rc2;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+		mdb_part_result pl, pr;
+		hipStream_t main_stream = NULL;
+		rc = mdb_aux_begin(ctx, &main_stream);	/* the right table is partitioned on the auxiliary stream (when enabled) */
+		if (rc)
+			return rc;
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, !fast, fast != 0, &pr);
+		{
+			int rc2 = mdb_aux_end(ctx, main_stream);
+			if (rc)
+				return rc;
+			if (rc2)
+				return rc2;
+		}
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, fast != 0, &pl);
+		if (rc)
+			return rc;
+		if ((rc = mdb_aux_join(ctx)))
+			return rc;
+		uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
+		uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
+		if (!match || !scan_tmp)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(match, 0, mlen * 4, ctx->stream));
+
+		a.hv_l = pl.hv;
+		a.rid_l = pl.rid;
+		a.off_l = pl.leaf_off;
+		a.cnt_l = pl.leaf_cnt;
+		a.cap_l = pl.leaf_cap;
+		a.hv_r = pr.hv;
+		a.rid_r = pr.rid;
+		a.off_r = pr.leaf_off;
+		a.cnt_r = pr.leaf_cnt;
+		a.cap_r = pr.leaf_cap;
+		a.match = match;
+		a.out_l = a.out_r = NULL;
+		a.status = ctx->d_status;
+		a.total64 = (unsigned long long *)(ctx->d_status + 2);
+		a.nleaves = pl.nleaves;
+		MDB_LAUNCH(ctx, "leaf_pairs_count", k_leaf_pairs_count, pl.nleaves, LEAF_THREADS, a);
+
+		/* offsets are 32-bit; the 64-bit total written by the count kernel guards against N:M blow-ups */
+		rc = mdb_scan_u32_inplace(ctx, match, mlen, scan_tmp);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemcpyAsync(&h[0], match + n_l, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		J = (uint32_t)h[0];
+		const uint32_t status = (uint32_t)h[1];
+		if (fast && (status & (2u | 16u)))
+			continue;	/* region overflow, or a multi-chunk leaf with unordered right rows */
+		if (status & 1u)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
+					   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", PJ_SLOTS);
+		break;
 	}
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, false, &pl);
-	if (rc)
-		return rc;
-	if ((rc = mdb_aux_join(ctx)))
-		return rc;
-	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
-	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
-	if (!match || !scan_tmp)
-		return -MIDORIDB_INTERNAL;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(match, 0, mlen * 4, ctx->stream));
-
-	pj_args a;
-	a.hv_l = pl.hv;
-	a.rid_l = pl.rid;
-	a.off_l = pl.leaf_off;
-	a.hv_r = pr.hv;
-	a.rid_r = pr.rid;
-	a.off_r = pr.leaf_off;
-	a.match = match;
-	a.out_l = a.out_r = NULL;
-	a.status = ctx->d_status;
-	a.total64 = (unsigned long long *)(ctx->d_status + 2);
-	MDB_LAUNCH(ctx, "leaf_pairs_count", k_leaf_pairs_count, pl.nleaves, LEAF_THREADS, a);
-
-	/* offsets are 32-bit; the 64-bit total written by the count kernel guards against N:M blow-ups */
-	rc = mdb_scan_u32_inplace(ctx, match, mlen, scan_tmp);
-	if (rc)
-		return rc;
-	uint64_t *h = ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(&h[0], match + n_l, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint64_t J = (uint32_t)h[0];
-	if ((uint32_t)h[1] & 1u)
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
-				   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", PJ_SLOTS);
 	if (h[2] != J)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join produces %llu rows: more than the 2^32-1 a single call can materialise",
 				   (unsigned long long)h[2]);
@@ -1305,7 +1326,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	}
 	a.out_l = ol;
 	a.out_r = orr;
-	MDB_LAUNCH(ctx, "leaf_pairs_emit", k_leaf_pairs_emit, pl.nleaves, LEAF_THREADS, a);
+	MDB_LAUNCH(ctx, "leaf_pairs_emit", k_leaf_pairs_emit, a.nleaves, LEAF_THREADS, a);
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*out_l = ol;
 	*out_r = orr;
