@@ -477,3 +477,32 @@ def test_join_group_count_randomised_large(dev, seed):
     first, cnt = dev.group_count(dev.to_dev(kl), dev.nullbits_dev(nl))
     e_first, e_cnt = orc.group_count(kl, nl)
     assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+
+
+def test_join_pairs_two_level_with_a_multi_chunk_leaf(dev):
+    """Two partition levels (histogram-free layout first) plus one key with 5000 right rows: that leaf spans several
+    emit chunks, so the operator has to notice and redo the join with the right side in row-id order."""
+    rng = np.random.default_rng(12)
+    n_l, n_r = 600_000, 1_000_000
+    kl = rng.integers(0, 800_000, n_l, dtype=np.int64)
+    kr = rng.integers(0, 800_000, n_r, dtype=np.int64)
+    kl[rng.choice(n_l, 300, replace=False)] = 77
+    kr[rng.choice(n_r, 5000, replace=False)] = 77
+    el, er = orc.join_pairs(kl, None, kr, None)
+    l, r = dev.join_pairs(dev.to_dev(kl), None, dev.to_dev(kr), None)
+    assert l.numel() == len(el)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_join_pairs_randomised_large(dev, seed):
+    rng = np.random.default_rng(300 + seed)
+    n_l = int(10 ** rng.uniform(5, 6.6))
+    n_r = int(10 ** rng.uniform(5, 6.6))
+    dom = int(max(2, max(n_l, n_r) * 10 ** rng.uniform(-0.5, 0.7)))	# about 0.2 .. 3 matches per row
+    kl, nl = _mk(rng, n_l, dom, 0.02 if seed % 2 else 0.0, -5)
+    kr, nr = _mk(rng, n_r, dom, 0.02 if seed % 3 == 0 else 0.0, -5)
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert l.numel() == len(el)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
