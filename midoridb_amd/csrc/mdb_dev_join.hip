@@ -561,7 +561,8 @@ struct ord_args {
 	uint32_t cap;
 	uint32_t kbits, leaf_bits;
 	uint32_t *out_first;
-	int64_t *out_count;
+	int64_t *out_count;		/* the record's payload as int64 (COUNT(*)), or ... */
+	uint32_t *out_val32;		/* ... payload - 1 as uint32 (right row id of a join pair) */
 	const int64_t *keys;		/* optional: key column to gather the group keys from ... */
 	int64_t *out_key;		/* ... into here (keys[first]) */
 };
@@ -618,7 +619,10 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 		const unsigned long long v = s_slot[i];
 		const uint32_t first = first_base + (uint32_t)(v >> 51);
 		a.out_first[base + i] = first;
-		a.out_count[base + i] = (int64_t)(v & ((1ull << 51) - 1ull));
+		if (a.out_val32)
+			a.out_val32[base + i] = (uint32_t)(v & ((1ull << 51) - 1ull)) - 1u;
+		else
+			a.out_count[base + i] = (int64_t)(v & ((1ull << 51) - 1ull));
 		if (a.out_key)
 			a.out_key[base + i] = a.keys[first];
 	}
@@ -651,6 +655,69 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
 {
 	const uint32_t shift = kbits - (uint32_t)sb1;
 	return (uint32_t)(((n_l ? n_l - 1 : 0) >> shift) + 1);
+}
+
+/* Order a record list ((row id << (64 - kbits)) | payload, zero words = gaps) by row id and deliver it:
+ * histogram-free regions first; if one overflows (the gaps of the list can bunch the records of one XCD's tile
+ * range) the exact layout redoes the sort.  Synchronises. */
+static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
+			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key)
+{
+	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
+	uint64_t *h = ctx->h_pinned;
+	int rc;
+	for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
+		mdb_part_result ps;
+		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0, order_digits0(n_l, kbits, sb1),
+				       &ps);
+		if (rc)
+			return rc;
+		ord_args oa;
+		oa.rec = (const unsigned long long *)ps.hv;
+		oa.off = ps.leaf_off;
+		oa.cnt = ps.leaf_cnt;
+		oa.cap = ps.leaf_cap;
+		oa.out_base = NULL;
+		oa.kbits = kbits;
+		oa.leaf_bits = (uint32_t)(sb1 + sb2);
+		oa.out_first = out_first;
+		oa.out_count = out_count;
+		oa.out_val32 = out_val32;
+		oa.keys = keys;
+		oa.out_key = out_key;
+		if (ps.leaf_cap) {
+			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
+			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
+			uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
+			if (!obase || !otmp)
+				return -MIDORIDB_INTERNAL;
+			if (ps.nleaves <= MDB_SCAN_SMALL) {
+				rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
+			} else {
+				MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
+				MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
+				rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
+			}
+			if (rc)
+				return rc;
+			oa.out_base = obase;
+		}
+		MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
+		MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (!sort_fast || !((uint32_t)h[8] & 2u))
+			break;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* the other flag bits were checked before */
+	}
+	return MIDORIDB_OK;
+}
+
+/* arena bytes of order_records() for a list of at most `cap` slots */
+static size_t order_records_arena_bytes(uint64_t cap, uint64_t n_l, uint32_t kbits, int sb1, int sb2)
+{
+	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
+	return mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, true, order_digits0(n_l, kbits, sb1)) +
+	       mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, false, 0) + 2 * (((size_t)1 << (sb1 + sb2)) + 4096) * 8;
 }
 
 /* ------------------------------------------------------------------ group-count drivers */
@@ -840,50 +907,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		/* order the group records by first row id: histogram-free regions first; if one overflows (the gaps of
-		 * the record list can bunch the records of one XCD's tile range) the exact layout redoes the sort */
-		for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
-			mdb_part_result ps;
-			rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0,
-					       order_digits0(n_l, kbits, sb1), &ps);
-			if (rc)
-				return rc;
-			ord_args oa;
-			oa.rec = (const unsigned long long *)ps.hv;
-			oa.off = ps.leaf_off;
-			oa.cnt = ps.leaf_cnt;
-			oa.cap = ps.leaf_cap;
-			oa.out_base = NULL;
-			oa.kbits = kbits;
-			oa.leaf_bits = (uint32_t)(sb1 + sb2);
-			oa.out_first = first_out;
-			oa.out_count = out_count;
-			oa.keys = keys_l;
-			oa.out_key = out_key;
-			if (ps.leaf_cap) {
-				/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
-				uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
-				uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
-				if (!obase || !otmp)
-					return -MIDORIDB_INTERNAL;
-				if (ps.nleaves <= MDB_SCAN_SMALL) {
-					rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
-				} else {
-					MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
-					MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
-					rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
-				}
-				if (rc)
-					return rc;
-				oa.out_base = obase;
-			}
-			MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
-			MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-			if (!sort_fast || !((uint32_t)h[8] & 2u))
-				break;
-			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* the other flag bits were checked above */
-		}
+		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key);
+		if (rc)
+			return rc;
 	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
 		if (rc)
@@ -1032,6 +1058,191 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 }
 
 /* ------------------------------------------------------------------ materialising join: count phase */
+
+/* ------------------------------------------------------------------ materialising join, unique right keys
+ *
+ * The common shape (primary key on the right: BASELINE configs 2 and 5): every left row matches at most one right
+ * row, so a pair is fully described by ONE 64-bit record (left row id, right row id + 1) - exactly the shape of the
+ * group records above.  One persistent kernel builds the per-leaf table (key -> right row id), probes it with the
+ * left rows and appends the records; the ordering sort + k_order_leaf then deliver (l, r) in left-row order.  No
+ * match-count array, no scan, no second table build.  A duplicate right key (or any overflow) is flagged and the
+ * caller falls back to the general count / scan / emit path.
+ */
+struct pu_args {
+	const uint64_t *hv_l;
+	const uint32_t *rid_l;
+	const uint32_t *off_l;
+	const uint32_t *cnt_l;
+	uint32_t cap_l;
+	const uint64_t *hv_r;
+	const uint32_t *rid_r;
+	const uint32_t *off_r;
+	const uint32_t *cnt_r;
+	uint32_t cap_r;
+	unsigned long long *rec;
+	uint32_t *rec_count;		/* list slots handed out (chunked, zero-filled gaps) */
+	uint32_t *rec_valid;		/* pairs */
+	uint32_t rec_cap;
+	uint32_t kbits;
+	uint32_t *status;		/* bit 0 table overflow, bit 3 list exhausted, bit 5 duplicate right key */
+	uint32_t nleaves;
+};
+
+__global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
+{
+	__shared__ unsigned long long s_key[GC_SLOTS];
+	__shared__ uint32_t s_val[GC_SLOTS + 1];	/* right row id + 1; [GC_SLOTS] = the key whose hash is 0 (0 = absent) */
+	__shared__ uint32_t s_chunk[4];			/* [0] base [1] used [2] size [3] pairs */
+
+	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+		if (s < GC_SLOTS)
+			s_key[s] = 0ull;
+		s_val[s] = 0;
+	}
+	if (threadIdx.x < 4)
+		s_chunk[threadIdx.x] = 0;
+	uint32_t npairs = 0;
+	__syncthreads();
+	for (uint32_t leaf = blockIdx.x; leaf < a.nleaves; leaf += gridDim.x) {
+		uint32_t l0, l1, r0, r1;
+		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+		if (l0 == l1 || r0 == r1)
+			continue;	/* uniform */
+		/* request the first batch of both sides before anything else */
+		uint64_t hr[LEAF_BATCH], hl[LEAF_BATCH];
+		uint32_t rr[LEAF_BATCH], rl[LEAF_BATCH];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint32_t i = l0 + (uint32_t)u * GC_THREADS + threadIdx.x;
+			hr[u] = j < r1 ? a.hv_r[j] : 0;
+			rr[u] = j < r1 ? a.rid_r[j] : 0;
+			hl[u] = i < l1 ? a.hv_l[i] : 0;
+			rl[u] = i < l1 ? a.rid_l[i] : 0;
+		}
+		{	/* list space for at most one record per left row (chunked reservation as in k_leaf_group_count) */
+			const uint32_t need = (l1 - l0) + 1;
+			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+			if (used + need > size) {
+				for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+					a.rec[base + i] = 0ull;
+				__syncthreads();
+				if (threadIdx.x == 0) {
+					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
+					const uint32_t nb = atomicAdd(a.rec_count, want);
+					if (nb + want > a.rec_cap) {
+						atomicOr(a.status, 8u);
+						s_chunk[0] = 0;
+						s_chunk[2] = 0;
+					} else {
+						s_chunk[0] = nb;
+						s_chunk[2] = want;
+					}
+					s_chunk[1] = 0;
+				}
+			}
+		}
+		/* build: right rows (unique keys expected) */
+		uint32_t own[LEAF_BATCH];
+		const bool by_owner = (r1 - r0) <= GC_THREADS * LEAF_BATCH;
+		for (uint32_t base = r0; base < r1; base += GC_THREADS * LEAF_BATCH) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+				if (base != r0) {
+					hr[u] = j < r1 ? a.hv_r[j] : 0;
+					rr[u] = j < r1 ? a.rid_r[j] : 0;
+				}
+				if (base == r0)
+					own[u] = 0xFFFFFFFFu;
+				if (j >= r1)
+					continue;
+				if (hr[u] == 0) {
+					if (atomicExch(&s_val[GC_SLOTS], rr[u] + 1u) != 0)
+						atomicOr(a.status, 32u);
+					continue;
+				}
+				bool created = false;
+				const uint32_t s = leaf_insert(s_key, GC_SLOTS, hr[u], &created);
+				if (s == 0xFFFFFFFFu) {
+					atomicOr(a.status, 1u);
+				} else if (!created) {
+					atomicOr(a.status, 32u);	/* the key is already there: not a unique-key join */
+				} else {
+					s_val[s] = rr[u] + 1u;
+					if (base == r0)
+						own[u] = s;
+				}
+			}
+		}
+		__syncthreads();
+		/* probe: left rows -> records */
+		const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
+		for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+				if (base != l0) {
+					hl[u] = i < l1 ? a.hv_l[i] : 0;
+					rl[u] = i < l1 ? a.rid_l[i] : 0;
+				}
+				unsigned long long recv = 0;
+				if (i < l1) {
+					uint32_t s = GC_SLOTS;
+					if (hl[u] != 0)
+						s = leaf_find(s_key, GC_SLOTS, hl[u]);
+					const uint32_t v = s != 0xFFFFFFFFu ? s_val[s] : 0u;
+					if (v)
+						recv = ((unsigned long long)rl[u] << (64 - a.kbits)) | v;
+				}
+				const uint64_t m = __ballot(recv != 0ull);
+				if (m) {
+					const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+					uint32_t wbase = 0;
+					if (mdb_lane() == leader)
+						wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
+					wbase = __shfl(wbase, (int)leader, MDB_WAVE);
+					if (recv) {
+						const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+						if (pos < csize)
+							a.rec[cbase + pos] = recv;
+						npairs++;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		/* clear what this leaf wrote */
+		if (by_owner) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++)
+				if (own[u] != 0xFFFFFFFFu) {
+					s_key[own[u]] = 0ull;
+					s_val[own[u]] = 0;
+				}
+			if (threadIdx.x == 0)
+				s_val[GC_SLOTS] = 0;
+		} else {
+			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+				if (s < GC_SLOTS)
+					s_key[s] = 0ull;
+				s_val[s] = 0;
+			}
+		}
+		__syncthreads();
+	}
+	{
+		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+		for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+			a.rec[base + i] = 0ull;
+		if (npairs)
+			atomicAdd(&s_chunk[3], npairs);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_chunk[3])
+		atomicAdd(a.rec_valid, s_chunk[3]);
+}
 
 struct pj_args {
 	const uint64_t *hv_l;
@@ -1232,6 +1443,82 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 	}
 }
 
+/* 0 = done, 1 = not applicable (duplicate right key / overflow: use the general path), < 0 = error */
+static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			     const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	int b1, b2, sb1 = 0, sb2 = 0;
+	uint32_t kbits = 0;
+	mdb_choose_bits(n_r, GC_TARGET, &b1, &b2);
+	if ((n_r >> (b1 + b2)) > (uint64_t)GC_SLOTS * 7 / 10 || !order_bits(n_l, &kbits, &sb1, &sb2))
+		return 1;
+	const uint64_t rec_cap = gc_rec_capacity(ctx, n_l);
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, true) + mdb_partition_arena_bytes(n_r, b1, b2, true, true) +
+		      mdb_align_up(rec_cap * 8) + order_records_arena_bytes(rec_cap, n_l, kbits, sb1, sb2) + 4096;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	mdb_part_result pl, pr;
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, false, true, &pr);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, true, &pl);
+	if (rc)
+		return rc;
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, rec_cap * 8);
+	if (!rec)
+		return -MIDORIDB_INTERNAL;
+	pu_args a;
+	a.hv_l = pl.hv;
+	a.rid_l = pl.rid;
+	a.off_l = pl.leaf_off;
+	a.cnt_l = pl.leaf_cnt;
+	a.cap_l = pl.leaf_cap;
+	a.hv_r = pr.hv;
+	a.rid_r = pr.rid;
+	a.off_r = pr.leaf_off;
+	a.cnt_r = pr.leaf_cnt;
+	a.cap_r = pr.leaf_cap;
+	a.rec = rec;
+	a.rec_count = ctx->d_status + 1;
+	a.rec_valid = ctx->d_status + 8;
+	a.rec_cap = (uint32_t)rec_cap;
+	a.kbits = kbits;
+	a.status = ctx->d_status;
+	a.nleaves = pl.nleaves;
+	{
+		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
+		MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique, grid, GC_THREADS, a);
+	}
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t status = (uint32_t)h[1];
+	const uint64_t list_len = h[1] >> 32, J = (uint32_t)h[5];
+	if (status & (1u | 2u | 8u | 32u))
+		return 1;
+	*out_count = J;
+	if (J == 0)
+		return 0;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+	}
+	rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, ol, NULL, orr, NULL, NULL);
+	if (rc) {
+		(void)mdb_cached_free(ctx, ol);
+		(void)mdb_cached_free(ctx, orr);
+		return rc;
+	}
+	*out_l = ol;
+	*out_r = orr;
+	return 0;
+}
+
 extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
 				  uint64_t *out_count)
@@ -1240,6 +1527,21 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	*out_count = 0;
 	if (n_l == 0 || n_r == 0)
 		return MIDORIDB_OK;
+	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records */
+	{
+		uint32_t *ul = NULL, *ur = NULL;
+		uint64_t uj = 0;
+		int urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+		if (urc < 0)
+			return urc;
+		if (urc == 0) {
+			*out_l = ul;
+			*out_r = ur;
+			*out_count = uj;
+			return MIDORIDB_OK;
+		}
+		/* urc > 0: a right key occurs twice, or a table / region overflowed: general path below */
+	}
 	int b1, b2;
 	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
 	const uint64_t mlen = n_l + 1;
