@@ -506,3 +506,20 @@ def test_join_pairs_randomised_large(dev, seed):
     l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
     assert l.numel() == len(el)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
+    """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
+    counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
+    n_l, dup = (1 << 27) + 5, 300_000
+    kl = torch.arange(n_l, dtype=torch.int64, device=dev.device) + 1_000_000
+    kl[:dup] = 7
+    kr = torch.cat([torch.full((dup,), 7, dtype=torch.int64, device=dev.device),
+                    torch.arange(1_000_000 + dup, 1_000_000 + dup + 1000, dtype=torch.int64, device=dev.device)])
+    k, c, f, j = dev.join_group_count(kl, None, kr, None)
+    assert k.numel() == 1001 and j == dup * dup + 1000
+    assert int(k[0]) == 7 and int(c[0]) == dup * dup and int(f[0]) == 0
+    assert bool((c[1:] == 1).all()) and bool((k[1:] == torch.arange(1_000_000 + dup, 1_000_000 + dup + 1000, device=dev.device)).all())
+    assert bool((f[1:].long() == torch.arange(dup, dup + 1000, device=dev.device)).all())
+    del kl, kr
+    torch.cuda.empty_cache()
