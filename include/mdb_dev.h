@@ -182,6 +182,13 @@ int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nke
 int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_sel,
 			 uint64_t *out_count);
 
+/* GROUP BY col_1, ..., col_k + COUNT(*) with composite-key semantics (rows are one group when they agree on every
+ * column, NULL = NULL): the reference instead applies its single-field loop once per field
+ * (executor_select.c:1537-1541), which is not a grouping by the combination - see DESIGN.md 2.  Output as
+ * mdb_dev_group_count(): out_first[g] = stream position of the group's first row (ascending), out_count[g]. */
+int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_first,
+			      int64_t *out_count, uint64_t cap, uint64_t *out_groups);
+
 /* ------------------------------------------------------------------ INNER JOIN (materialising)
  *
  * Replaces _join_nested_loop_tbl2tbl() for ON l = r (reference

@@ -61,6 +61,13 @@ size_t mdb_sort_pass_hist_words(uint64_t n);
 int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_in, uint64_t n, uint32_t shift, uint32_t bits,
 		  uint64_t *key_out, uint32_t *rid_out, uint32_t *hist, uint32_t *scan_tmp);
 
+/* ---- ordering of (row id, payload) records (mdb_dev_join.hip) ----------------------------------
+ * rec[i] = (row id << (64 - kbits)) | payload (payload >= 1; zero words are gaps), kbits = bits of a row id as
+ * returned by mdb_order_records_arena_bytes(); delivers out_first[] = row ids ascending, out_count[] = payloads. */
+size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kbits_out);
+int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_rows, uint32_t kbits,
+			       uint32_t *out_first, int64_t *out_count);
+
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
 

@@ -712,12 +712,33 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 	return MIDORIDB_OK;
 }
 
+/* exported for mdb_dev_sort.hip (multi-column GROUP BY): same list format, bits chosen here */
+int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_rows, uint32_t kbits,
+			       uint32_t *out_first, int64_t *out_count)
+{
+	uint32_t kb = 0;
+	int sb1 = 0, sb2 = 0;
+	if (!order_bits(n_rows, &kb, &sb1, &sb2) || kb != kbits)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "record ordering: unsupported row-id width");
+	return order_records(ctx, rec, list_len, n_rows, kbits, sb1, sb2, out_first, out_count, NULL, NULL, NULL);
+}
+
 /* arena bytes of order_records() for a list of at most `cap` slots */
 static size_t order_records_arena_bytes(uint64_t cap, uint64_t n_l, uint32_t kbits, int sb1, int sb2)
 {
 	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
 	return mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, true, order_digits0(n_l, kbits, sb1)) +
 	       mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, false, 0) + 2 * (((size_t)1 << (sb1 + sb2)) + 4096) * 8;
+}
+
+size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kbits_out)
+{
+	uint32_t kb = 0;
+	int sb1 = 0, sb2 = 0;
+	if (!order_bits(n_rows, &kb, &sb1, &sb2))
+		return 0;
+	*kbits_out = kb;
+	return order_records_arena_bytes(cap, n_rows, kb, sb1, sb2);
 }
 
 /* ------------------------------------------------------------------ group-count drivers */

@@ -249,3 +249,96 @@ extern "C" int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key 
 	*out_count = (uint32_t)h[0];
 	return MIDORIDB_OK;
 }
+
+/* ------------------------------------------------------------------ GROUP BY several columns + COUNT(*)
+ *
+ * The reference runs its single-field grouping loop once per GROUP BY field, one after the other
+ * (executor_select.c:1537-1541), which does not group by the combination of the fields; here rows form a group
+ * when they agree on every key column.  Stable sort by all columns -> equal rows are adjacent and the first row of
+ * a run is the group's first occurrence -> run lengths are the counts -> the (first row, count) records go through
+ * the same ordering path as the single-column operator, so groups come out in first-occurrence order.
+ */
+__global__ __launch_bounds__(SORT_THREADS) void k_group_heads(distinct_args a, const uint32_t *__restrict__ perm, uint64_t n,
+							       int64_t *__restrict__ flags)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
+		bool head = k == 0;
+		if (!head) {
+			const uint32_t p = perm[k], q = perm[k - 1];
+			for (int c = 0; c < a.nkeys && !head; c++) {
+				const struct mdb_sort_key &key = a.key[c];
+				const uint64_t rp = key.rid ? (uint64_t)key.rid[p] : (uint64_t)p;
+				const uint64_t rq = key.rid ? (uint64_t)key.rid[q] : (uint64_t)q;
+				const bool np = key.nullbits && mdb_bit_is_set(key.nullbits, rp);
+				const bool nq = key.nullbits && mdb_bit_is_set(key.nullbits, rq);
+				if (np != nq)
+					head = true;
+				else if (!np && ((const uint64_t *)key.values)[rp] != ((const uint64_t *)key.values)[rq])
+					head = true;
+			}
+		}
+		flags[k] = head ? 1 : 0;	/* indexed by SORTED position */
+	}
+}
+
+/* head_pos[g] = sorted position of group g's first row (ascending); record g = (perm[head] << (64 - kbits)) | run length */
+__global__ __launch_bounds__(SORT_THREADS) void k_group_records(const uint32_t *__restrict__ head_pos, uint64_t G, uint64_t n,
+								 const uint32_t *__restrict__ perm, uint32_t kbits, unsigned long long *__restrict__ rec)
+{
+	for (uint64_t g = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; g < G; g += (uint64_t)gridDim.x * SORT_THREADS) {
+		const uint64_t b = head_pos[g], e = g + 1 < G ? (uint64_t)head_pos[g + 1] : n;
+		rec[g] = ((unsigned long long)perm[b] << (64 - kbits)) | (unsigned long long)(e - b);
+	}
+}
+
+extern "C" int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_first,
+					 int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+{
+	*out_groups = 0;
+	int rc = sort_check(ctx, "group_count_multi", nkeys, n);
+	if (rc || n == 0)
+		return rc;
+	uint32_t kbits = 0;
+	const size_t order_bytes = mdb_order_records_arena_bytes(n, n, &kbits);
+	if (!order_bytes)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group_count_multi: too many rows");
+	rc = mdb_arena_begin(ctx, sort_arena_bytes(n) + 2 * mdb_align_up(n * 8) + mdb_align_up(n * 4) + mdb_filter_arena_bytes(n) + order_bytes + 8192);
+	if (rc)
+		return rc;
+	uint32_t *perm = NULL;
+	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm);
+	if (rc)
+		return rc;
+	int64_t *flags = (int64_t *)mdb_arena_take(ctx, n * 8);
+	uint32_t *head_pos = (uint32_t *)mdb_arena_take(ctx, n * 4);
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, n * 8);
+	if (!flags || !head_pos || !rec)
+		return -MIDORIDB_INTERNAL;
+	distinct_args a;
+	memset(&a, 0, sizeof(a));
+	for (int c = 0; c < nkeys; c++)
+		a.key[c] = keys[c];
+	a.nkeys = nkeys;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	MDB_LAUNCH(ctx, "groupby_heads", k_group_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	uint32_t *d_total = NULL;
+	rc = mdb_filter_nonzero64(ctx, flags, n, head_pos, &d_total);
+	if (rc)
+		return rc;
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t G = (uint32_t)h[0];
+	if (G > cap)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
+				   (unsigned long long)G);
+	const uint32_t ggrid = (uint32_t)(((G + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((G + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	MDB_LAUNCH(ctx, "groupby_records", k_group_records, ggrid ? ggrid : 1, SORT_THREADS, (const uint32_t *)head_pos, G, n, (const uint32_t *)perm,
+		   kbits, rec);
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
+	if (rc)
+		return rc;
+	*out_groups = G;
+	return MIDORIDB_OK;
+}

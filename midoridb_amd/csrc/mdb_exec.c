@@ -379,8 +379,8 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 		}
 	if (s->where && ((rc = resolve_expr(s, s->where, err, errlen)) || (rc = check_predicate(s->where, "where", err, errlen))))
 		return rc;
-	if (s->ngroup > 1) {
-		ERR("GROUP BY over more than one field is outside the reference's well-defined domain (SURVEY 8a R10) and not supported\n");
+	if (s->ngroup > MDB_SORT_MAX_KEYS) {
+		ERR("GROUP BY over more than %d fields is not supported\n", MDB_SORT_MAX_KEYS);
 		return -MIDORIDB_ERROR;
 	}
 	for (int i = 0; i < s->ngroup; i++) {
@@ -1085,6 +1085,35 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			}
 			if ((rc = stream_select(&x, s->ntabs, first, G)))
 				goto out;
+		} else if (s->ngroup > 1) {
+			/* several fields: groups = distinct combinations (the reference applies its single-field loop once
+			 * per field, executor_select.c:1537-1541, which is not a grouping by the combination: DESIGN.md 2) */
+			struct mdb_sort_key gk[MDB_SORT_MAX_KEYS];
+			uint32_t *first;
+			uint64_t G = 0;
+			for (int g = 0; g < s->ngroup; g++) {
+				bind_operand(&x, s->group[g], &gk[g].values, &gk[g].nullbits, &gk[g].rid);
+				gk[g].type = s->group[g]->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
+				gk[g].desc = 0;
+			}
+			first = dalloc(&x, (x.n ? x.n : 1) * 4);
+			x.d_count = dalloc(&x, (x.n ? x.n : 1) * 8);
+			if (!first || !x.d_count) {
+				rc = dev_fail(&x, "allocating group outputs");
+				goto out;
+			}
+			if (x.n && mdb_dev_group_count_multi(x.dev, gk, s->ngroup, x.n, first, x.d_count, x.n, &G)) {
+				rc = dev_fail(&x, "group count");
+				goto out;
+			}
+			{
+				int64_t *cnt = x.d_count;	/* stream_select must not re-map the fresh counts */
+				x.d_count = NULL;
+				rc = stream_select(&x, s->ntabs, first, G);
+				x.d_count = cnt;
+				if (rc)
+					goto out;
+			}
 		}
 	}
 

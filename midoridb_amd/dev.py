@@ -68,6 +68,7 @@ def _bind(lib):
         "mdb_dev_scatter_set64": ([P, P, P, P, c_uint64, c_int64, c_int], c_int),
         "mdb_dev_sort_perm": ([P, POINTER(SortKey), c_int, c_uint64, P], c_int),
         "mdb_dev_distinct_sel": ([P, POINTER(SortKey), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_group_count_multi": ([P, POINTER(SortKey), c_int, c_uint64, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
@@ -89,7 +90,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
 ]
@@ -326,6 +327,15 @@ class DeviceCtx:
         m = c_uint64(0)
         self._chk(self.lib.mdb_dev_distinct_sel(self.h, self._sort_keys(keys), len(keys), n, _ptr(sel), byref(m)), "distinct_sel")
         return sel[:m.value]
+
+    def group_count_multi(self, keys, n):
+        """GROUP BY several columns + COUNT(*): -> (first positions ascending, counts)."""
+        first = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        count = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        g = c_uint64(0)
+        self._chk(self.lib.mdb_dev_group_count_multi(self.h, self._sort_keys(keys), len(keys), n, _ptr(first), _ptr(count), n, byref(g)),
+                  "group_count_multi")
+        return first[:g.value], count[:g.value]
 
     def sort_perm(self, keys, n):
         """ORDER BY: keys = [(values, nullbits or None, rid or None, T_INT64 | T_DOUBLE, desc bool), ...] ->

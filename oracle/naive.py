@@ -256,14 +256,19 @@ class Naive:
         if q["where"] is not None:				# proc_where_clause :1435-1463
             w = self._resolve(q["where"], tabs)
             rows = [r for r in rows if self._cond(w, r)]
-        for g in q["group"]:					# proc_groupby_clause :1526-1588
-            gk = "{}.{}".format(*self._resolve(g, tabs)[1:])
+        if q["group"]:						# proc_groupby_clause :1526-1588
+            # One field: the reference's loop, restated (quadratic, first occurrence survives).  Several fields: the
+            # reference runs that loop once per field, one after the other (:1537-1541), which collapses
+            # `GROUP BY a, b` over {(1,1),(1,2),(2,1),...} into ONE row - not a grouping in any sense (verified
+            # against oracle/_ref).  Like D1/D2 the intended semantics are restated instead: rows are equal when
+            # they agree on EVERY group field (NULL equal to NULL, as in the single-field loop :1477-1478).
+            gks = ["{}.{}".format(*self._resolve(g, tabs)[1:]) for g in q["group"]]
             alive = [True] * len(rows)
             for i in range(len(rows)):
                 if not alive[i]:
                     continue
                 for j in range(i + 1, len(rows)):
-                    if alive[j] and rows[i][gk] == rows[j][gk]:	# NULL == NULL here (:1477-1478)
+                    if alive[j] and all(rows[i][gk] == rows[j][gk] for gk in gks):
                         alive[j] = False
                         rows[i]["COUNT(*)"] += 1
             rows = [r for r, a in zip(rows, alive) if a]

@@ -282,3 +282,24 @@ def distinct_sel(keys, n):
             seen.add(k)
             out.append(i)
     return np.array(out, dtype=np.uint32)
+
+
+def group_count_multi(keys, n):
+    """Oracle of mdb_dev_group_count_multi: rows are one group when they agree on every key column (NULL = NULL,
+    values by their 64 bits); -> (first positions ascending, counts)."""
+    cols = []
+    for values, nulls, rid, _is_double, _desc in keys:
+        v = np.asarray(values)
+        rows = np.arange(n) if rid is None else np.asarray(rid, dtype=np.int64)
+        bits = v.view(np.uint64)[rows]
+        isnull = np.zeros(n, dtype=bool) if nulls is None else np.asarray(nulls, dtype=bool)[rows]
+        cols.append((np.where(isnull, np.uint64(0), bits), isnull))
+    first, count = {}, {}
+    for i in range(n):
+        k = tuple((int(b[i]), bool(z[i])) for b, z in cols)
+        if k not in first:
+            first[k] = i
+            count[k] = 0
+        count[k] += 1
+    order = sorted(first, key=lambda k: first[k])
+    return np.array([first[k] for k in order], dtype=np.int64), np.array([count[k] for k in order], dtype=np.int64)

@@ -523,3 +523,33 @@ def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     assert bool((f[1:].long() == torch.arange(dup, dup + 1000, device=dev.device)).all())
     del kl, kr
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 4097, 80_000])
+def test_group_count_multi(dev, n):
+    rng = np.random.default_rng(n + 21)
+    a = rng.integers(-2, 3, n, dtype=np.int64)
+    b = rng.integers(0, 4, n, dtype=np.int64)
+    x = np.round(rng.normal(0, 1, n), 0)
+    na, nx = rng.random(n) < 0.2, rng.random(n) < 0.1
+    rid = rng.integers(0, n, n).astype(np.uint32)
+    ad, bd, xd, nad, nxd, ridd = dev.to_dev(a), dev.to_dev(b), dev.to_dev(x), dev.nullbits_dev(na), dev.nullbits_dev(nx), dev.to_dev(rid)
+    for keys_np, keys_dev in [
+            ([(a, na, None, False, False), (b, None, None, False, False)], [(ad, nad, None, D.T_INT64, False), (bd, None, None, D.T_INT64, False)]),
+            ([(x, nx, None, True, False), (a, na, None, False, False), (b, None, None, False, False)],
+             [(xd, nxd, None, D.T_DOUBLE, False), (ad, nad, None, D.T_INT64, False), (bd, None, None, D.T_INT64, False)]),
+            ([(b, None, rid, False, False), (x, nx, rid, True, False)], [(bd, None, ridd, D.T_INT64, False), (xd, nxd, ridd, D.T_DOUBLE, False)])]:
+        first, cnt = dev.group_count_multi(keys_dev, n)
+        ef, ec = orc.group_count_multi(keys_np, n)
+        assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
+
+
+def test_group_count_multi_large_property(dev):
+    """10^7 rows, key = (i mod 1000, i mod 7): 7000 groups (1000 and 7 are coprime), counts n/7000 +- 1, firsts = 0..6999."""
+    n = 10_000_000
+    i = torch.arange(n, dtype=torch.int64, device=dev.device)
+    a, b = i % 1000, i % 7
+    first, cnt = dev.group_count_multi([(a, None, None, D.T_INT64, False), (b, None, None, D.T_INT64, False)], n)
+    assert first.numel() == 7000 and int(cnt.sum()) == n
+    assert bool((first.long() == torch.arange(7000, device=dev.device)).all())
+    assert int(cnt.min()) >= n // 7000 and int(cnt.max()) <= n // 7000 + 1
