@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the result against the CPU oracle (rows <= 2e7)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary variant-U measurement (profiling runs)")
+    ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
+                    "column statistics allow it)")
+    ap.add_argument("--chunks", type=int, default=None, help="pieces per table in the multi-GPU exchange (default: 2 when N > 1)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -161,7 +164,19 @@ def main():
     cap = int(n * 1.3) + 4096 if use_dist else n
     out = (torch.empty(cap, dtype=torch.int64, device=dev.device), torch.empty(cap, dtype=torch.int64, device=dev.device),
            torch.empty(cap, dtype=torch.int32, device=dev.device))
-    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n) if use_dist else None
+    wire32 = False
+    if use_dist and not args.wire64:
+        # column statistics (computed once per table, outside the timed region, like a catalog would keep them):
+        # when every key of both columns fits 32 bits on every rank the exchange ships 4-byte keys
+        fits = 1.0
+        for col in (a, b):
+            lo, hi = dev.key_range(col)
+            if lo > hi or lo < -(1 << 31) or hi >= (1 << 31):
+                fits = 0.0
+        t = torch.tensor([fits], dtype=torch.float64, device=dev.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        wire32 = bool(t.item() > 0.5)
+    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n, chunks=args.chunks, wire32=wire32) if use_dist else None
 
     def step():
         if pipeline is None:
@@ -257,7 +272,8 @@ def main():
                                    f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
                        "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
-                       "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")},
+                       "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
+                                      + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else "")},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},

@@ -269,10 +269,16 @@ int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, con
  * destination is unspecified); out_rid (capacity n, or NULL) the source row of every out_keys
  * entry, which is what carries payload columns and row identity through the exchange
  * (send column = mdb_dev_gather64(column, out_rid)); out_counts (HOST, n_dest entries) the
- * group sizes.  Synchronises.
+ * group sizes.  keys32 != 0: out_keys is an int32_t[] - the 4-byte wire format for key columns whose
+ * statistics (mdb_dev_key_range) say that every key fits; it halves the bytes on xGMI, which is what bounds
+ * the exchange; the receiver widens with mdb_dev_widen32to64.  Synchronises.
  */
 int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			      uint32_t n_dest, int64_t *out_keys, uint32_t *out_rid, uint64_t *out_counts);
+			      uint32_t n_dest, int keys32, void *out_keys, uint32_t *out_rid, uint64_t *out_counts);
+/* column statistics: smallest / largest non-NULL key (min > max when there is none).  Synchronises. */
+int mdb_dev_key_range(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_min,
+		      int64_t *out_max);
+int mdb_dev_widen32to64(mdb_dev_ctx *ctx, const int32_t *src, uint64_t n, int64_t *dst);
 
 /* ------------------------------------------------------------------ synthetic data (bench / tests)
  * keys[i] = perm(i) mod modulus, perm = the bijection on [0, n) defined in

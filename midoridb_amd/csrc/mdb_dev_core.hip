@@ -756,6 +756,76 @@ extern "C" int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_
 	return MIDORIDB_OK;
 }
 
+/* ------------------------------------------------------------------ key statistics / 4-byte wire format */
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_key_range(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nullbits, uint64_t n,
+							       long long *mm)
+{
+	__shared__ long long s_lo, s_hi;
+	if (threadIdx.x == 0) {
+		s_lo = 0x7FFFFFFFFFFFFFFFll;
+		s_hi = -0x7FFFFFFFFFFFFFFFll - 1;
+	}
+	__syncthreads();
+	long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
+	for (uint64_t k = (uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * STREAM_THREADS) {
+		if (nullbits && mdb_bit_is_set(nullbits, k))
+			continue;
+		const long long v = keys[k];
+		lo = v < lo ? v : lo;
+		hi = v > hi ? v : hi;
+	}
+	if (lo <= hi) {
+		atomicMin(&s_lo, lo);
+		atomicMax(&s_hi, hi);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_lo <= s_hi) {
+		atomicMin(&mm[0], s_lo);
+		atomicMax(&mm[1], s_hi);
+	}
+}
+
+extern "C" int mdb_dev_key_range(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_min,
+				 int64_t *out_max)
+{
+	*out_min = 0x7FFFFFFFFFFFFFFFll;
+	*out_max = -0x7FFFFFFFFFFFFFFFll - 1;
+	if (n == 0)
+		return MIDORIDB_OK;
+	long long *mm = (long long *)(ctx->d_status + 12);	/* two 8-byte words of the status block */
+	long long *h = (long long *)ctx->h_pinned;
+	h[0] = *out_min;
+	h[1] = *out_max;
+	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
+	const uint64_t blocks = (n + STREAM_THREADS * STREAM_ROUNDS - 1) / (STREAM_THREADS * STREAM_ROUNDS);
+	MDB_LAUNCH(ctx, "key_range", k_key_range, (uint32_t)(blocks < 4096 ? blocks : 4096), STREAM_THREADS, keys, nullbits, n, mm);
+	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_min = h[0];
+	*out_max = h[1];
+	return MIDORIDB_OK;
+}
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_widen32(const int32_t *__restrict__ src, uint64_t n, int64_t *__restrict__ dst)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n)
+			dst[k] = (int64_t)src[k];
+	}
+}
+
+extern "C" int mdb_dev_widen32to64(mdb_dev_ctx *ctx, const int32_t *src, uint64_t n, int64_t *dst)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	MDB_LAUNCH(ctx, "widen32", k_widen32, stream_grid(n), STREAM_THREADS, src, n, dst);
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dev_cross_pairs(mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint32_t *out_l, uint32_t *out_r)
 {
 	if (n_l == 0 || n_r == 0)

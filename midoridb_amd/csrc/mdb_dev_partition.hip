@@ -60,7 +60,7 @@ struct mdb_level_args {
 	uint32_t shift;			/* RADIX mode: digit = (hv >> shift) & (R - 1) */
 	uint32_t mbits;			/* bits needed to tell digits apart (ballot rounds of the STABLE form) */
 	uint32_t mode;			/* enum mdb_digit_mode */
-	uint32_t inverse_out;		/* write fmix64^-1(hv) (= the original key) instead of hv */
+	uint32_t inverse_out;		/* write fmix64^-1(hv) (= the original key) instead of hv; 2 = as int32 (4-byte wire format) */
 	/* FAST (histogram-free) form: child (seg, digit) owns the fixed-capacity region [child*cap, child*cap+cap) */
 	uint32_t *cursor;		/* per child: elements placed so far (zeroed before the launch) */
 	uint32_t cap;
@@ -380,7 +380,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
 		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
 		gpos[k] = g;
-		a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
+		if (a.inverse_out == 2)
+			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)mdb_fmix64_inv(h);
+		else
+			a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
 		if (HAS_RID && !RID_SHARES_LDS)
 			a.rid_out[g] = s_rid[i];
 	}
@@ -585,7 +588,7 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
 			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL,
-			  uint32_t digits0_used = 0)
+			  uint32_t digits0_used = 0, bool keys32_out = false)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -650,7 +653,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.ntiles = ntiles;
 		a.R = R;
 		a.mode = l == 0 ? mode : MDB_DIGIT_RADIX;
-		a.inverse_out = (inverse_out && l == nlevels - 1) ? 1u : 0u;
+		a.inverse_out = (inverse_out && l == nlevels - 1) ? (keys32_out ? 2u : 1u) : 0u;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
 			a.shift = (uint32_t)(64 - used_bits - b);
@@ -878,7 +881,7 @@ int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_
 /* ---- multi-GPU destination partition ------------------------------------------------------------ */
 
 extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-					 uint32_t n_dest, int64_t *out_keys, uint32_t *out_rid, uint64_t *out_counts)
+					 uint32_t n_dest, int keys32, void *out_keys, uint32_t *out_rid, uint64_t *out_counts)
 {
 	if (n_dest == 0 || n_dest > PART_MAX_R)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: n_dest must be in [1, %u]", PART_MAX_R);
@@ -891,16 +894,19 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	if (n == 0)
 		return MIDORIDB_OK;
 	/* dry run for the arena size, then the real pass (one level, digit = low32(hash) mod n_dest,
-	 * original keys written back through the inverse hash, source row ids beside them when asked for) */
+	 * original keys written back through the inverse hash - as 4-byte integers when the caller knows from the
+	 * column's statistics that every key fits - source row ids beside them when asked for) */
 	const bool want_rid = out_rid != NULL;
 	part_carver dry = { NULL, true, 0, false };
-	(void)partition_impl(dry, NULL, NULL, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL, out_rid);
+	(void)partition_impl(dry, NULL, NULL, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL, out_rid, 0,
+			     keys32 != 0);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	rc = partition_impl(cv, keys, nullbits, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res, out_rid);
+	rc = partition_impl(cv, keys, nullbits, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res, out_rid, 0,
+			    keys32 != 0);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;

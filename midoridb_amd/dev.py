@@ -76,7 +76,9 @@ def _bind(lib):
                                       POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count_begin": ([P, P, P, c_uint64, c_uint64], c_int),
         "mdb_dev_join_group_count_finish": ([P, P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
-        "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, P, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, c_int, P, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_key_range": ([P, P, P, c_uint64, POINTER(c_int64), POINTER(c_int64)], c_int),
+        "mdb_dev_widen32to64": ([P, P, c_uint64, P], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
     }
     for name, (args, res) in sig.items():
@@ -92,7 +94,7 @@ DEV_SYMBOLS = [
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
-    "mdb_dev_partition_by_dest", "mdb_dev_gen_keys",
+    "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
 ]
 
 
@@ -351,16 +353,32 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_sort_perm(self.h, arr, len(keys), n, _ptr(perm)), "sort_perm")
         return perm[:n]
 
-    def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False):
-        """-> (keys grouped by destination, counts per destination[, source row of every entry])."""
+    def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False, keys32=False):
+        """-> (keys grouped by destination, counts per destination[, source row of every entry]).  keys32: the keys
+        come out as int32 (4-byte wire format; the caller knows from key_range() that they fit)."""
         n = keys.numel()
         if out is None:
-            out = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            out = torch.empty(max(n, 1), dtype=torch.int32 if keys32 else torch.int64, device=self.device)
+        elif keys32 and out.dtype != torch.int32:
+            out = out.view(torch.int32)
         rid = torch.empty(max(n, 1), dtype=torch.int32, device=self.device) if with_rid else None
         counts = (c_uint64 * n_dest)()
-        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, _ptr(out), _ptr(rid), counts),
-                  "partition_by_dest")
+        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, 1 if keys32 else 0, _ptr(out), _ptr(rid),
+                                                     counts), "partition_by_dest")
         counts = [int(c) for c in counts]
         if with_rid:
             return out[:sum(counts)], counts, rid[:sum(counts)]
         return out[:sum(counts)], counts
+
+    def key_range(self, keys, nulls=None):
+        """column statistics: (min, max) of the non-NULL keys"""
+        lo, hi = c_int64(0), c_int64(0)
+        self._chk(self.lib.mdb_dev_key_range(self.h, _ptr(keys), _ptr(nulls), keys.numel(), byref(lo), byref(hi)), "key_range")
+        return lo.value, hi.value
+
+    def widen32(self, src32, out=None):
+        n = src32.numel()
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        self._chk(self.lib.mdb_dev_widen32to64(self.h, _ptr(src32), n, _ptr(out)), "widen32to64")
+        return out[:n]

@@ -11,23 +11,29 @@ import torch.distributed as dist
 
 
 class KeyExchange:
-    """counts all-to-all (nGPU int64) followed by one uneven all_to_all_single of the keys."""
+    """counts all-to-all (nGPU int64) followed by one uneven all_to_all_single of the keys.  The tiny count
+    exchanges run on their own process group: on the data communicator they would queue behind a key transfer
+    that is still in flight and stall the host (they are read back with .tolist())."""
 
-    def __init__(self, world, device):
+    def __init__(self, world, device, count_group=None):
         self.world = world
         self.device = device
+        self.count_group = count_group
 
-    def exchange(self, send_keys, send_counts, recv_buf=None, async_op=False):
+    def exchange(self, send_keys, send_counts, recv_buf=None, async_op=False, recv_offset=0):
         """send_keys: keys grouped by destination rank; send_counts: list[int] of len world.
-        Returns (recv_keys tensor, recv_counts list, work handle or None)."""
+        Returns (recv_keys tensor, recv_counts list, work handle or None); the received keys land at
+        recv_buf[recv_offset:]."""
         cin = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
         cout = torch.empty(self.world, dtype=torch.int64, device=self.device)
-        dist.all_to_all_single(cout, cin)
+        dist.all_to_all_single(cout, cin, group=self.count_group)
         recv_counts = [int(x) for x in cout.tolist()]
         total = sum(recv_counts)
-        if recv_buf is None or recv_buf.numel() < total:
+        if recv_buf is None or recv_buf.numel() < recv_offset + total:
+            if recv_buf is not None and recv_offset:
+                raise RuntimeError("receive buffer too small for a chunked exchange")
             recv_buf = torch.empty(max(total, 1), dtype=send_keys.dtype, device=self.device)
-        recv = recv_buf[:total]
+        recv = recv_buf[recv_offset:recv_offset + total]
         work = dist.all_to_all_single(recv, send_keys[:sum(send_counts)], recv_counts, list(send_counts), async_op=async_op)
         return recv, recv_counts, work
 
@@ -69,41 +75,81 @@ class TableShuffle:
 
 
 class DistributedJoinGroupCount:
-    """One rank's share of  A JOIN B ON id_a = id_b GROUP BY id_a COUNT(*)  over `world` GPUs."""
+    """One rank's share of  A JOIN B ON id_a = id_b GROUP BY id_a COUNT(*)  over `world` GPUs.
 
-    def __init__(self, dev, world, rank, rows_per_rank, partition_fn=None, join_fn=None, device=None):
+    Every table goes out in `chunks` pieces (2 by default when there is more than one rank): the all-to-all of
+    piece i travels over xGMI while piece i+1 is still being partitioned by destination, and table B's pieces
+    travel while the received A is hashed and radix-partitioned locally - per-link xGMI bandwidth, not HBM, is
+    what bounds the exchange (0.7 of every table leaves each GPU at 8 ranks)."""
+
+    def __init__(self, dev, world, rank, rows_per_rank, partition_fn=None, join_fn=None, device=None, chunks=None, wire32=False,
+                 widen_fn=None):
+        """wire32: both key columns are known (column statistics, mdb_dev_key_range on every rank) to fit 32 bits: the
+        keys then cross xGMI as 4-byte integers - half the bytes of the step that bounds multi-GPU throughput - and
+        are widened on arrival (one streaming kernel per table, overlapped with the other table's transfer)."""
         self.dev = dev
         self.world = world
         self.rank = rank
         device = device if device is not None else dev.device
-        self.ex = KeyExchange(world, device)
+        self.chunks = max(1, int(chunks if chunks is not None else (2 if world > 1 else 1)))
+        count_group = dist.new_group() if self.chunks > 1 or world > 1 else None
+        self.ex = KeyExchange(world, device, count_group)
+        self.wire32 = bool(wire32)
         cap = int(rows_per_rank * 1.3) + 4096
-        self.send_a = torch.empty(max(rows_per_rank, 1), dtype=torch.int64, device=device)
-        self.send_b = torch.empty(max(rows_per_rank, 1), dtype=torch.int64, device=device)
+        self.send_a = torch.empty(max(rows_per_rank, 2) + 2, dtype=torch.int64, device=device)
+        self.send_b = torch.empty(max(rows_per_rank, 2) + 2, dtype=torch.int64, device=device)
         self.recv_a = torch.empty(cap, dtype=torch.int64, device=device)
         self.recv_b = torch.empty(cap, dtype=torch.int64, device=device)
-        self.partition_fn = partition_fn or (lambda keys, out: dev.partition_by_dest(keys, None, world, out=out))
+        if self.wire32:
+            self.recv_a32 = torch.empty(cap, dtype=torch.int32, device=device)
+            self.recv_b32 = torch.empty(cap, dtype=torch.int32, device=device)
+        self.partition_fn = partition_fn or (lambda keys, out: dev.partition_by_dest(keys, None, world, out=out, keys32=self.wire32))
+        self.widen_fn = widen_fn or (lambda src32, out: dev.widen32(src32, out=out))
         self.join_fn = join_fn      # None: split device operator (begin on A while B is still in flight)
         self.n_r_max = cap
 
+    def _send_table(self, keys, send_buf, recv_buf):
+        """partition by destination + exchange, piece by piece -> (received keys (view of recv_buf), work handles)"""
+        n = keys.numel()
+        per = -(-n // self.chunks)
+        per += per & 1                  # even piece starts keep the 16-byte alignment the partition kernel loads with
+        if self.wire32:
+            send_buf = send_buf.view(torch.int32)
+        works, off = [], 0
+        for c in range(self.chunks):
+            lo, hi = c * per, min(n, (c + 1) * per)
+            if lo >= hi and c > 0:
+                break
+            s, cnt = self.partition_fn(keys[lo:hi], send_buf[lo:hi] if hi > lo else send_buf[:1])
+            _, rc, w = self.ex.exchange(s, cnt, recv_buf, async_op=True, recv_offset=off)
+            off += sum(rc)
+            works.append(w)
+        return recv_buf[:off], works
+
+    @staticmethod
+    def _wait(works):
+        for w in works:
+            if w is not None:
+                w.wait()
+
     def run(self, a, b, out=None):
-        # table A's keys travel over xGMI while table B is being partitioned
-        sa, ca = self.partition_fn(a, self.send_a)
-        ra, _, wa = self.ex.exchange(sa, ca, self.recv_a, async_op=True)
-        sb, cb = self.partition_fn(b, self.send_b)
-        rb, _, wb = self.ex.exchange(sb, cb, self.recv_b, async_op=True)
+        # table A's pieces travel over xGMI while the next piece / table B is being partitioned
+        ra, wa = self._send_table(a, self.send_a, self.recv_a32 if self.wire32 else self.recv_a)
+        rb, wb = self._send_table(b, self.send_b, self.recv_b32 if self.wire32 else self.recv_b)
+        self._wait(wa)
+        if self.wire32:
+            ra = self.widen_fn(ra, self.recv_a)
         if self.join_fn is not None:
-            for w in (wa, wb):
-                if w is not None:
-                    w.wait()
+            self._wait(wb)
+            if self.wire32:
+                rb = self.widen_fn(rb, self.recv_b)
             k, c, f, j = self.join_fn(ra, rb, out)
         else:
             # A has arrived: hash + partition it locally while B's all-to-all is still running
-            if wa is not None:
-                wa.wait()
             self.dev.join_group_count_begin(ra, None, self.n_r_max)
-            if wb is not None:
-                wb.wait()
+            self._wait(wb)
+            if self.wire32:
+                rb = self.widen_fn(rb, self.recv_b)
             k, c, f, j = self.dev.join_group_count_finish(rb, None, out=out)
         self.last = (k, c, f)
         return k.numel() if hasattr(k, "numel") else len(k), j

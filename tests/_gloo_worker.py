@@ -31,8 +31,25 @@ def main():
         k, c, f, j = orc.join_group_count(ka.numpy(), None, kb.numpy(), None)
         return torch.from_numpy(k), torch.from_numpy(c), torch.from_numpy(f), j
 
-    pipe = DistributedJoinGroupCount(None, world, rank, n, partition_fn=partition_fn, join_fn=join_fn, device=torch.device("cpu"))
-    g, j = pipe.run(torch.from_numpy(a), torch.from_numpy(b), None)
+    def partition32_fn(keys, out):      # 4-byte wire format
+        k, counts = orc.partition_by_dest(keys.numpy(), None, world)
+        out[:len(k)] = torch.from_numpy(k.astype(np.int32))
+        return out[:len(k)], [int(c) for c in counts]
+
+    def widen_fn(src32, out):
+        out[:src32.numel()] = src32.to(torch.int64)
+        return out[:src32.numel()]
+
+    # chunked exchange (the default for world > 1 is 2 pieces; 3 also exercises an uneven last piece), 8- and 4-byte keys
+    for chunks, wire32 in ((1, False), (3, False), (None, False), (2, True)):
+        pipe = DistributedJoinGroupCount(None, world, rank, n, partition_fn=partition32_fn if wire32 else partition_fn, join_fn=join_fn,
+                                         device=torch.device("cpu"), chunks=chunks, wire32=wire32, widen_fn=widen_fn)
+        g, j = pipe.run(torch.from_numpy(a), torch.from_numpy(b), None)
+        if chunks == 1:
+            k1, c1 = pipe.last[0].numpy().copy(), pipe.last[1].numpy().copy()
+        else:       # same groups whatever the chunking (order inside a rank may differ)
+            o1, o2 = np.argsort(k1, kind="stable"), np.argsort(pipe.last[0].numpy(), kind="stable")
+            assert np.array_equal(k1[o1], pipe.last[0].numpy()[o2]) and np.array_equal(c1[o1], pipe.last[1].numpy()[o2])
     k, c, _ = pipe.last
     # every key this rank owns must hash to this rank; gather all results on rank 0 and compare with one big join
     assert np.all(orc.dest_of(k.numpy(), world) == rank)

@@ -553,3 +553,21 @@ def test_group_count_multi_large_property(dev):
     assert first.numel() == 7000 and int(cnt.sum()) == n
     assert bool((first.long() == torch.arange(7000, device=dev.device)).all())
     assert int(cnt.min()) >= n // 7000 and int(cnt.max()) <= n // 7000 + 1
+
+
+def test_partition_by_dest_4_byte_wire_format_and_key_range(dev):
+    rng = np.random.default_rng(5)
+    k = rng.integers(-2**31, 2**31, 300_001, dtype=np.int64)
+    nl = rng.random(len(k)) < 0.02
+    kd, nd = dev.to_dev(k), dev.nullbits_dev(nl)
+    assert dev.key_range(kd, nd) == (int(k[~nl].min()), int(k[~nl].max()))
+    assert dev.key_range(kd) == (int(k.min()), int(k.max()))
+    out8, c8 = dev.partition_by_dest(kd, nd, 4)
+    out4, c4, rid = dev.partition_by_dest(kd, nd, 4, with_rid=True, keys32=True)
+    assert c4 == c8 and out4.dtype == torch.int32
+    wide = dev.widen32(out4)
+    r = _np(rid).view(np.uint32)
+    assert np.array_equal(_np(wide), k[r])              # every 4-byte key widens back to its source row's key
+    off = np.concatenate([[0], np.cumsum(c8)])
+    for d in range(4):                                  # same multiset per destination as the 8-byte form
+        assert np.array_equal(np.sort(_np(wide)[off[d]:off[d + 1]]), np.sort(_np(out8)[off[d]:off[d + 1]]))
