@@ -117,9 +117,8 @@ class DistributedJoinGroupCount:
             send_buf = send_buf.view(torch.int32)
         works, off = [], 0
         for c in range(self.chunks):
-            lo, hi = c * per, min(n, (c + 1) * per)
-            if lo >= hi and c > 0:
-                break
+            lo, hi = min(n, c * per), min(n, (c + 1) * per)
+            # every rank runs every round, also with an empty piece: the collectives must pair up across ranks
             s, cnt = self.partition_fn(keys[lo:hi], send_buf[lo:hi] if hi > lo else send_buf[:1])
             _, rc, w = self.ex.exchange(s, cnt, recv_buf, async_op=True, recv_offset=off)
             off += sum(rc)
