@@ -178,3 +178,26 @@ def test_front_end_drives_the_real_reference():
         db.close()
         assert names == case["expect"]["names"], case["name"]
         assert [list(r) for r in rows] == case["expect"]["rows"], case["name"]
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = os.path.join(str(tmp_path), "readme_example")
+    cmd = ["gcc", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "readme_example.c"),
+           "-L" + os.path.join(ROOT, "midoridb_amd"), "-lmidoridb_amd", "-Wl,-rpath," + os.path.join(ROOT, "midoridb_amd"), "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_c_program_written_for_the_reference_api_compiles_and_fails_loudly_without_a_device(tmp_path):
+    """examples/readme_example.c uses only the reference's public API (database_open, query_execute, query_cur_step,
+    query_column_int64, query_free, database_close): it must compile against include/mdb_query.h and link against the
+    library; without a HIP device the SELECT reports an error (there is no CPU executor to fall back to)."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 3 and "no usable HIP device" in r.stderr
