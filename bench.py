@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary variant-U measurement (profiling runs)")
     ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
                     "column statistics allow it)")
-    ap.add_argument("--chunks", type=int, default=None, help="pieces per table in the multi-GPU exchange (default: 2 when N > 1)")
+    ap.add_argument("--chunks", type=int, default=None, help="pieces per table in the multi-GPU exchange (default 1)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()

@@ -77,10 +77,12 @@ class TableShuffle:
 class DistributedJoinGroupCount:
     """One rank's share of  A JOIN B ON id_a = id_b GROUP BY id_a COUNT(*)  over `world` GPUs.
 
-    Every table goes out in `chunks` pieces (2 by default when there is more than one rank): the all-to-all of
-    piece i travels over xGMI while piece i+1 is still being partitioned by destination, and table B's pieces
-    travel while the received A is hashed and radix-partitioned locally - per-link xGMI bandwidth, not HBM, is
-    what bounds the exchange (0.7 of every table leaves each GPU at 8 ranks)."""
+    Table A's all-to-all travels over xGMI while table B is partitioned by destination, and table B's while the
+    received A is hashed and radix-partitioned locally - per-link xGMI bandwidth, not HBM, is what bounds the
+    exchange (0.7 of every table leaves each GPU at 8 ranks).  `chunks` > 1 additionally splits every table into
+    pieces whose transfers overlap the partitioning of the next piece; measured on one GPU every extra round costs
+    ~0.7 ms of host synchronisation (counts must reach the host before a transfer can be posted), more than the
+    overlap can win at the transfer sizes of this workload, so the default is one piece."""
 
     def __init__(self, dev, world, rank, rows_per_rank, partition_fn=None, join_fn=None, device=None, chunks=None, wire32=False,
                  widen_fn=None):
@@ -91,7 +93,7 @@ class DistributedJoinGroupCount:
         self.world = world
         self.rank = rank
         device = device if device is not None else dev.device
-        self.chunks = max(1, int(chunks if chunks is not None else (2 if world > 1 else 1)))
+        self.chunks = max(1, int(chunks if chunks is not None else 1))
         count_group = dist.new_group() if self.chunks > 1 or world > 1 else None
         self.ex = KeyExchange(world, device, count_group)
         self.wire32 = bool(wire32)

@@ -40,7 +40,7 @@ def main():
         out[:src32.numel()] = src32.to(torch.int64)
         return out[:src32.numel()]
 
-    # chunked exchange (the default for world > 1 is 2 pieces; 3 also exercises an uneven last piece), 8- and 4-byte keys
+    # one piece (the default), several pieces (3 also exercises an uneven last piece), 8- and 4-byte keys
     for chunks, wire32 in ((1, False), (3, False), (None, False), (2, True)):
         pipe = DistributedJoinGroupCount(None, world, rank, n, partition_fn=partition32_fn if wire32 else partition_fn, join_fn=join_fn,
                                          device=torch.device("cpu"), chunks=chunks, wire32=wire32, widen_fn=widen_fn)
