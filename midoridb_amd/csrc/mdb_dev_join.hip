@@ -302,9 +302,80 @@ __device__ static inline void gc_probe_side(const gc_args &a, const unsigned lon
 	}
 }
 
-template <bool HAS_R, bool BUILD_R>
+/* Hot keys.  A leaf that received tens of thousands of rows holds few distinct keys with very many duplicates
+ * (more distinct keys than table slots is an error anyway), and one LDS atomic per row on the same slot serialises:
+ * 2*10^7 rows of one key took 77 ms.  For such leaves (GC_HEAVY rows or more on the side at hand) the lanes of a wave
+ * first merge their duplicates - leader's key, ballot of the lanes that hold the same key, one table operation for
+ * the whole group - so the table sees one update per distinct key per wave instead of one per row. */
+#define GC_HEAVY (8u * GC_THREADS * LEAF_BATCH)
+
+__device__ static inline uint32_t gc_wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_xor((int)v, d, MDB_WAVE);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+
+template <bool IS_L, bool INSERT>
+__device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
+					    gc_batch &b, uint32_t x0, uint32_t x1)
+{
+	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
+		if (base != x0) {
+			if (IS_L)
+				gc_load_l(a, base, x1, b);
+			else
+				gc_load_r(a, base, x1, b);
+		}
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			const uint32_t rid = IS_L ? b.rid_l[u] : 0u;
+			const bool active = i < x1;
+			uint64_t pending = __ballot(active);
+			while (pending) {	/* wave-uniform: one round per distinct key among the wave's rows */
+				const int leader = __ffsll((long long)pending) - 1;
+				const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)hv, leader, MDB_WAVE);
+				const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(hv >> 32), leader, MDB_WAVE);
+				const uint64_t lhv = ((uint64_t)hi << 32) | lo;
+				const bool mine = active && hv == lhv;
+				const uint64_t grp = __ballot(mine);
+				const uint32_t rmin = IS_L ? gc_wave_min_u32(mine ? rid : 0xFFFFFFFFu) : 0u;
+				if ((int)mdb_lane() == leader) {
+					uint32_t s = GC_SLOTS;
+					if (lhv != 0)
+						s = INSERT ? leaf_insert(s_key, GC_SLOTS, lhv) : leaf_find(s_key, GC_SLOTS, lhv);
+					if (s == 0xFFFFFFFFu) {
+						if (INSERT)
+							atomicOr(a.status, 1u);
+					} else if (IS_L) {
+						atomicAdd(&s_cnt[s], (unsigned long long)__popcll(grp));
+						atomicMin(&s_first[s], rmin);
+					} else {
+						atomicAdd(&s_cnt[s], (unsigned long long)__popcll(grp) << 32);
+					}
+				}
+				pending &= ~grp;
+			}
+		}
+	}
+}
+
+template <bool HAS_R, bool BUILD_R, bool HEAVY>
 __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 {
+	/* status bit 1: a partition region overflowed, the whole operator is redone on the exact layout - nothing to do here.
+	 * The HEAVY instance runs right after the plain one and only works when that one met (and skipped) a hot-key leaf. */
+	{
+		const uint32_t st = *(volatile const uint32_t *)a.status;
+		if ((st & 2u) || (HEAVY && !(st & 64u)))
+			return;
+	}
+
 	/* slot = hashed key (0 = empty) + packed counters (low 32 bits: left rows, high 32 bits: right rows)
 	 * + first left row id.  The tables are zeroed once; afterwards the emit pass clears exactly the slots
 	 * it reads as occupied, which halves the LDS traffic of a clear-everything-per-leaf loop. */
@@ -345,7 +416,15 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			if (HAS_R)
 				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
 		}
-		const bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
+		bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
+		const bool heavy_l = l1 - l0 >= GC_HEAVY, heavy_r = HAS_R && r1 - r0 >= GC_HEAVY;	/* hot keys: see gc_side_heavy */
+		if (HEAVY) {
+			live = live && (heavy_l || heavy_r);
+		} else if (live && (heavy_l || heavy_r)) {
+			if (threadIdx.x == 0)
+				atomicOr(a.status, 64u);	/* left to the HEAVY instance of this kernel */
+			live = false;
+		}
 		/* a leaf whose left side fits one register batch (the normal case) is emitted by the threads that
 		 * created its table slots; only oversized (skewed) leaves scan the whole table */
 		const uint32_t build_rows = (HAS_R && BUILD_R) ? r1 - r0 : l1 - l0;
@@ -384,15 +463,27 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			 * larger table): with N:1 data (every left key unique, few of them matched) the left rows then
 			 * cost one LDS read each instead of an insert, a count, a minimum and a clear. */
 			if (HAS_R && BUILD_R) {
-				gc_build_side<false>(a, s_key, s_cnt, s_first, b, r0, r1, own);
+				if (HEAVY && heavy_r)
+					gc_side_heavy<false, true>(a, s_key, s_cnt, s_first, b, r0, r1);
+				else
+					gc_build_side<false>(a, s_key, s_cnt, s_first, b, r0, r1, own);
 				__syncthreads();
-				gc_probe_side<true>(a, s_key, s_cnt, s_first, b, l0, l1);
+				if (HEAVY && heavy_l)
+					gc_side_heavy<true, false>(a, s_key, s_cnt, s_first, b, l0, l1);
+				else
+					gc_probe_side<true>(a, s_key, s_cnt, s_first, b, l0, l1);
 				__syncthreads();
 			} else {
-				gc_build_side<true>(a, s_key, s_cnt, s_first, b, l0, l1, own);
+				if (HEAVY && heavy_l)
+					gc_side_heavy<true, true>(a, s_key, s_cnt, s_first, b, l0, l1);
+				else
+					gc_build_side<true>(a, s_key, s_cnt, s_first, b, l0, l1, own);
 				__syncthreads();
 				if (HAS_R) {
-					gc_probe_side<false>(a, s_key, s_cnt, s_first, b, r0, r1);
+					if (HEAVY && heavy_r)
+						gc_side_heavy<false, false>(a, s_key, s_cnt, s_first, b, r0, r1);
+					else
+						gc_probe_side<false>(a, s_key, s_cnt, s_first, b, r0, r1);
 					__syncthreads();
 				}
 			}
@@ -751,7 +842,7 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
  * (at most one leaf's worth per chunk, one unfinished chunk per workgroup) */
 static uint64_t gc_rec_capacity(mdb_dev_ctx *ctx, uint64_t n_l)
 {
-	return n_l + n_l / 4 + (uint64_t)(2 * ctx->num_cus + 2) * GC_REC_CHUNK + 4096;
+	return n_l + n_l / 4 + (uint64_t)(4 * ctx->num_cus + 4) * GC_REC_CHUNK + 4096;	/* two kernel instances, one open chunk per workgroup */
 }
 
 /* The operator runs in two halves so that a multi-GPU pipeline can partition the left table while the
@@ -874,12 +965,16 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
+		/* the second launch of every pair returns at once unless the first met a hot-key leaf (status bit 6) */
 		if (has_r && build_r) {
-			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, true, true>), grid, GC_THREADS, a);
 		} else if (has_r) {
-			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false, false>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, false, true>), grid, GC_THREADS, a);
 		} else {
-			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false, false>), grid, GC_THREADS, a);
+			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<false, false, true>), grid, GC_THREADS, a);
 		}
 	}
 	if (null_group && null_l) {
