@@ -368,11 +368,10 @@ __device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long
 template <bool HAS_R, bool BUILD_R, bool HEAVY>
 __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 {
-	/* status bit 1: a partition region overflowed, the whole operator is redone on the exact layout - nothing to do here.
-	 * The HEAVY instance runs right after the plain one and only works when that one met (and skipped) a hot-key leaf. */
-	{
+	/* The HEAVY instance (single-workgroup fallback of the hot-key path) only works when the plain one met hot leaves. */
+	if (HEAVY) {
 		const uint32_t st = *(volatile const uint32_t *)a.status;
-		if ((st & 2u) || (HEAVY && !(st & 64u)))
+		if ((st & 2u) || !(st & 64u))
 			return;
 	}
 
@@ -416,15 +415,12 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			if (HAS_R)
 				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
 		}
-		bool live = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
+		const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
 		const bool heavy_l = l1 - l0 >= GC_HEAVY, heavy_r = HAS_R && r1 - r0 >= GC_HEAVY;	/* hot keys: see gc_side_heavy */
-		if (HEAVY) {
-			live = live && (heavy_l || heavy_r);
-		} else if (live && (heavy_l || heavy_r)) {
-			if (threadIdx.x == 0)
-				atomicOr(a.status, 64u);	/* left to the HEAVY instance of this kernel */
-			live = false;
-		}
+		const bool hot = nonempty && (heavy_l || heavy_r);
+		const bool live = HEAVY ? hot : (nonempty && !hot);
+		if (!HEAVY && hot && threadIdx.x == 0)
+			atomicOr(a.status, 64u);	/* left to the hot-key path */
 		/* a leaf whose left side fits one register batch (the normal case) is emitted by the threads that
 		 * created its table slots; only oversized (skewed) leaves scan the whole table */
 		const uint32_t build_rows = (HAS_R && BUILD_R) ? r1 - r0 : l1 - l0;
@@ -577,6 +573,193 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		atomicAdd(a.joined, s_sum);
 	if (threadIdx.x == 0 && a.kbits && s_chunk[3])
 		atomicAdd(a.rec_valid, s_chunk[3]);
+}
+
+/* ------------------------------------------------------------------ hot keys across the whole chip
+ *
+ * One workgroup streams a leaf at ~16 GB/s; a key with 10^7 duplicates would pin one workgroup for 10+ ms while the
+ * other 511 idle.  Hot leaves (GC_HEAVY rows or more on a side; the plain kernel skips them and raises status bit 6)
+ * are therefore cut into slices of HOT_SLICE rows that ALL resident workgroups share: every slice is merged into an
+ * LDS table with gc_side_heavy (a wave's duplicates first collapse into one update), the table is flushed into the
+ * leaf's table in global memory with one atomic triple per distinct key, and a last small kernel turns the global
+ * tables into group records exactly like the emit phase of the plain kernel.  At most HOT_MAX hot leaves take this
+ * path; beyond that the single-workgroup HEAVY instance of the leaf kernel does the work.
+ */
+#define HOT_MAX 64u
+#define HOT_SLOTS 8191u		/* global table per hot leaf (prime; a leaf holds at most GC_SLOTS distinct keys) */
+#define HOT_SLICE 65536u
+
+struct hot_args {
+	uint32_t *count;			/* number of hot leaves found */
+	uint32_t *leaf;				/* [HOT_MAX] */
+	unsigned long long *g_key;		/* [HOT_MAX][HOT_SLOTS] hashed key, 0 = empty */
+	unsigned long long *g_cnt;		/* [HOT_MAX][HOT_SLOTS + 1] packed counts; [HOT_SLOTS] = the key whose hash is 0 */
+	uint32_t *g_first;			/* [HOT_MAX][HOT_SLOTS + 1] */
+};
+
+template <bool HAS_R>
+__global__ void k_hot_list(gc_args a, hot_args h)
+{
+	const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+	if (leaf >= a.nleaves)
+		return;
+	uint32_t l0, l1, r0 = 0, r1 = 1;
+	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+	if (HAS_R)
+		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+	if (l0 == l1 || r0 == r1)
+		return;
+	if (l1 - l0 >= GC_HEAVY || (HAS_R && r1 - r0 >= GC_HEAVY)) {
+		const uint32_t i = atomicAdd(h.count, 1u);
+		if (i < HOT_MAX)
+			h.leaf[i] = leaf;
+	}
+}
+
+__global__ void k_hot_clear(hot_args h)
+{
+	const uint32_t nh = *h.count < HOT_MAX ? *h.count : HOT_MAX;
+	const uint64_t total = (uint64_t)nh * (HOT_SLOTS + 1);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t t = i / (HOT_SLOTS + 1), s = i % (HOT_SLOTS + 1);
+		if (s < HOT_SLOTS)
+			h.g_key[t * HOT_SLOTS + s] = 0ull;
+		h.g_cnt[i] = 0ull;
+		h.g_first[i] = 0xFFFFFFFFu;
+	}
+}
+
+__device__ static inline uint32_t hot_insert(unsigned long long *keys, uint64_t hv)
+{
+	uint32_t s = leaf_slot(hv, HOT_SLOTS);
+	const uint32_t step = leaf_step(hv, HOT_SLOTS);
+	for (uint32_t probe = 0; probe < HOT_SLOTS; probe++) {
+		const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)hv);
+		if (old == 0ull || old == hv)
+			return s;
+		s += step;
+		if (s >= HOT_SLOTS)
+			s -= HOT_SLOTS;
+	}
+	return 0xFFFFFFFFu;
+}
+
+template <bool HAS_R>
+__global__ __launch_bounds__(GC_THREADS, 8) void k_hot_slices(gc_args a, hot_args h)
+{
+	__shared__ unsigned long long s_key[GC_SLOTS];
+	__shared__ unsigned long long s_cnt[GC_SLOTS + 1];
+	__shared__ uint32_t s_first[GC_SLOTS + 1];
+	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+		if (s < GC_SLOTS)
+			s_key[s] = 0ull;
+		s_cnt[s] = 0ull;
+		s_first[s] = 0xFFFFFFFFu;
+	}
+	__syncthreads();
+	const uint32_t nh = *h.count;	/* <= HOT_MAX guaranteed by the host */
+	uint32_t task = 0;
+	gc_batch b;
+	for (uint32_t t = 0; t < nh; t++) {
+		const uint32_t leaf = h.leaf[t];
+		uint32_t l0, l1, r0 = 0, r1 = 0;
+		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+		if (HAS_R)
+			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+		const uint32_t nsl = (l1 - l0 + HOT_SLICE - 1) / HOT_SLICE, nsr = (r1 - r0 + HOT_SLICE - 1) / HOT_SLICE;
+		for (uint32_t k = 0; k < nsl + nsr; k++, task++) {
+			if (task % gridDim.x != blockIdx.x)
+				continue;	/* uniform */
+			const bool is_l = k < nsl;
+			const uint32_t x0 = is_l ? l0 + k * HOT_SLICE : r0 + (k - nsl) * HOT_SLICE;
+			const uint32_t xe = is_l ? l1 : r1;
+			const uint32_t x1 = x0 + HOT_SLICE < xe ? x0 + HOT_SLICE : xe;
+			if (is_l) {
+				gc_load_l(a, x0, x1, b);
+				gc_side_heavy<true, true>(a, s_key, s_cnt, s_first, b, x0, x1);
+			} else {
+				gc_load_r(a, x0, x1, b);
+				gc_side_heavy<false, true>(a, s_key, s_cnt, s_first, b, x0, x1);
+			}
+			__syncthreads();
+			/* flush the slice's table into the leaf's global table and clear it */
+			unsigned long long *gk = h.g_key + (uint64_t)t * HOT_SLOTS;
+			unsigned long long *gc = h.g_cnt + (uint64_t)t * (HOT_SLOTS + 1);
+			uint32_t *gf = h.g_first + (uint64_t)t * (HOT_SLOTS + 1);
+			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+				const unsigned long long c2 = s_cnt[s];
+				if (!c2)
+					continue;
+				uint32_t g = HOT_SLOTS;
+				if (s < GC_SLOTS) {
+					g = hot_insert(gk, s_key[s]);
+					s_key[s] = 0ull;
+				}
+				if (g == 0xFFFFFFFFu) {
+					atomicOr(a.status, 1u);
+				} else {
+					atomicAdd(&gc[g], c2);
+					if (is_l)
+						atomicMin(&gf[g], s_first[s]);
+				}
+				s_cnt[s] = 0ull;
+				s_first[s] = 0xFFFFFFFFu;
+			}
+			__syncthreads();
+		}
+	}
+}
+
+/* one workgroup per hot leaf: global table -> group records (or dense counts), like the emit phase of the leaf kernel */
+template <bool HAS_R>
+__global__ __launch_bounds__(1024) void k_hot_finish(gc_args a, hot_args h)
+{
+	__shared__ unsigned long long s_sum;
+	__shared__ uint32_t s_valid;
+	const uint32_t t = blockIdx.x;
+	if (t >= *h.count)
+		return;
+	if (threadIdx.x == 0) {
+		s_sum = 0ull;
+		s_valid = 0;
+	}
+	__syncthreads();
+	const unsigned long long *gc = h.g_cnt + (uint64_t)t * (HOT_SLOTS + 1);
+	const uint32_t *gf = h.g_first + (uint64_t)t * (HOT_SLOTS + 1);
+	unsigned long long mine = 0;
+	uint32_t nvalid = 0;
+	for (uint32_t s = threadIdx.x; s <= HOT_SLOTS; s += blockDim.x) {
+		const unsigned long long c2 = gc[s];
+		const uint32_t cl = (uint32_t)c2, cr = (uint32_t)(c2 >> 32);
+		if (!cl || (HAS_R && !cr))
+			continue;
+		const unsigned long long c = HAS_R ? (unsigned long long)cl * cr : (unsigned long long)cl;
+		const uint32_t first = gf[s];
+		mine += c;
+		if (a.kbits) {
+			if (c >> (64 - a.kbits))
+				atomicOr(a.status, 4u);
+			const uint32_t pos = atomicAdd(a.rec_count, 1u);
+			if (pos < a.rec_cap)
+				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
+			else
+				atomicOr(a.status, 8u);
+			nvalid++;
+		} else {
+			a.dense_cnt[first] = (int64_t)c;
+		}
+	}
+	if (mine)
+		atomicAdd(&s_sum, mine);
+	if (nvalid)
+		atomicAdd(&s_valid, nvalid);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_sum)
+			atomicAdd(a.joined, s_sum);
+		if (s_valid)
+			atomicAdd(a.rec_valid, s_valid);
+	}
 }
 
 /* ------------------------------------------------------------------ compaction of the dense count array
@@ -874,6 +1057,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
 		need += mdb_align_up(gc_rec_capacity(ctx, st->n_l) * 8) + mdb_align_up(st->n_l * 4) + 4096;
+		need += mdb_align_up((size_t)HOT_MAX * HOT_SLOTS * 8) + mdb_align_up((size_t)HOT_MAX * (HOT_SLOTS + 1) * 8) +
+			mdb_align_up((size_t)HOT_MAX * (HOT_SLOTS + 1) * 4) + 4096;	/* hot-key path (only touched when needed) */
 		if (st->want_records && order_bits(st->n_l, &kb, &s1, &s2))
 			need += mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2)), true,
 							      order_digits0(st->n_l, kb, s1)) +
@@ -965,16 +1150,12 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		/* the second launch of every pair returns at once unless the first met a hot-key leaf (status bit 6) */
 		if (has_r && build_r) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false>), grid, GC_THREADS, a);
-			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, true, true>), grid, GC_THREADS, a);
 		} else if (has_r) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false, false>), grid, GC_THREADS, a);
-			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, false, true>), grid, GC_THREADS, a);
 		} else {
 			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false, false>), grid, GC_THREADS, a);
-			MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<false, false, true>), grid, GC_THREADS, a);
 		}
 	}
 	if (null_group && null_l) {
@@ -987,13 +1168,58 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		}
 	}
 
+	/* G, J and the status flags come back with one sync; the sort is sized by G */
 	uint64_t *h = ctx->h_pinned;
 	uint64_t G = 0, list_len = 0;
 	uint32_t *first_out = out_first ? out_first : sel;
-	if (records) {
-		/* G, J and the status flags come back with one sync; the sort is sized by G */
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if ((uint32_t)h[1] & 2u)
+		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
+	if ((uint32_t)h[1] & 64u) {
+		/* hot keys: the plain kernel left the leaves with GC_HEAVY or more rows on a side to this path */
+		hot_args ha;
+		ha.count = (uint32_t *)mdb_arena_take(ctx, 64);
+		ha.leaf = (uint32_t *)mdb_arena_take(ctx, HOT_MAX * 4);
+		ha.g_key = (unsigned long long *)mdb_arena_take(ctx, (size_t)HOT_MAX * HOT_SLOTS * 8);
+		ha.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (size_t)HOT_MAX * (HOT_SLOTS + 1) * 8);
+		ha.g_first = (uint32_t *)mdb_arena_take(ctx, (size_t)HOT_MAX * (HOT_SLOTS + 1) * 4);
+		if (!ha.count || !ha.leaf || !ha.g_key || !ha.g_cnt || !ha.g_first)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(ha.count, 0, 4, ctx->stream));
+		if (has_r) {
+			MDB_LAUNCH(ctx, "hot_list", k_hot_list<true>, (pl.nleaves + 255) / 256, 256, a, ha);
+		} else {
+			MDB_LAUNCH(ctx, "hot_list", k_hot_list<false>, (pl.nleaves + 255) / 256, 256, a, ha);
+		}
+		MDB_HIP(ctx, hipMemcpyAsync(&h[9], ha.count, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t nhot = (uint32_t)h[9];
+		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+		if (nhot <= HOT_MAX) {
+			MDB_LAUNCH(ctx, "hot_clear", k_hot_clear, 256, 256, ha);
+			if (has_r) {
+				MDB_LAUNCH(ctx, "hot_slices", k_hot_slices<true>, resident, GC_THREADS, a, ha);
+				MDB_LAUNCH(ctx, "hot_finish", k_hot_finish<true>, nhot, 1024, a, ha);
+			} else {
+				MDB_LAUNCH(ctx, "hot_slices", k_hot_slices<false>, resident, GC_THREADS, a, ha);
+				MDB_LAUNCH(ctx, "hot_finish", k_hot_finish<false>, nhot, 1024, a, ha);
+			}
+		} else {
+			/* very many hot leaves: each is streamed by one workgroup (the HEAVY instance of the leaf kernel) */
+			const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
+			if (has_r && build_r) {
+				MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, true, true>), grid, GC_THREADS, a);
+			} else if (has_r) {
+				MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<true, false, true>), grid, GC_THREADS, a);
+			} else {
+				MDB_LAUNCH(ctx, "leaf_hot_keys", (k_leaf_group_count<false, false, true>), grid, GC_THREADS, a);
+			}
+		}
 		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	if (records) {
 		list_len = h[1] >> 32;
 		G = (uint32_t)h[5];
 	} else {
@@ -1002,7 +1228,6 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		if (rc)
 			return rc;
 		MDB_HIP(ctx, hipMemcpyAsync(&h[0], d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		G = (uint32_t)h[0];
 	}

@@ -571,3 +571,34 @@ def test_partition_by_dest_4_byte_wire_format_and_key_range(dev):
     off = np.concatenate([[0], np.cumsum(c8)])
     for d in range(4):                                  # same multiset per destination as the 8-byte form
         assert np.array_equal(np.sort(_np(wide)[off[d]:off[d + 1]]), np.sort(_np(out8)[off[d]:off[d + 1]]))
+
+
+@pytest.mark.parametrize("shape", ["one_key", "two_keys", "hot_plus_unique", "many_hot_keys", "hot_left_only"])
+def test_hot_keys(dev, shape):
+    """Keys with 10^5..10^6 duplicates: the plain leaf kernel hands such leaves to the hot-key path (slices shared by all
+    workgroups, merged through a table in global memory; more than 64 hot leaves: one workgroup per leaf).  Exact
+    result against the C hash oracle, for the join and for the plain GROUP BY."""
+    from oracle import cpu
+    rng = np.random.default_rng(len(shape))
+    n_l, n_r = 3_000_000, 1_000_000
+    if shape == "one_key":
+        kl, kr = np.full(n_l, 7, dtype=np.int64), np.full(n_r, 7, dtype=np.int64)
+    elif shape == "two_keys":
+        kl, kr = rng.integers(0, 2, n_l), rng.integers(0, 2, n_r)
+    elif shape == "hot_plus_unique":
+        kl = np.where(rng.random(n_l) < 0.5, 0, np.arange(n_l) + 10)
+        kr = np.where(rng.random(n_r) < 0.3, 0, rng.integers(10, n_l, n_r))
+    elif shape == "many_hot_keys":          # 150 keys x ~20000 rows each: more hot leaves than the shared path takes
+        kl, kr = rng.integers(0, 150, n_l), rng.integers(0, 150, n_r)
+    else:                                   # only the left side is hot; the right side has the key three times
+        kl = np.where(rng.random(n_l) < 0.4, 5, np.arange(n_l) + 10)
+        kr = np.concatenate([np.array([5, 5, 5]), rng.integers(10, n_l, n_r - 3)])
+    kl, kr = kl.astype(np.int64), kr.astype(np.int64)
+    nl = (rng.random(n_l) < 0.01) if shape == "hot_plus_unique" else None
+    ek, ec, ef, ej = cpu.hash_join_group_count(kl, nl, kr, None, 8)
+    k, c, f, j = dev.join_group_count(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), None)
+    assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    first, cnt = dev.group_count(dev.to_dev(kl), dev.nullbits_dev(nl))
+    e_first, e_cnt = orc.group_count(kl, nl)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
