@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6
 
 # names of the profiler's kernels in the rocprofv3 summary kept under profiles/ (PMC traffic per launch)
 ROCPROF_NAMES = {
-    "leaf_join_group_count": ["k_leaf_group_count<true, true>", "k_leaf_group_count<true, false>"],
-    "leaf_group_count": ["k_leaf_group_count<false, false>"],
+    "leaf_join_group_count": ["k_leaf_group_count<true, true, false>", "k_leaf_group_count<true, false, false>"],
+    "leaf_group_count": ["k_leaf_group_count<false, false, false>"],
     "part_hist_l0": ["k_part_hist<true>"],
     "part_scatter_l0": ["k_part_scatter<true, true, false, true, false>", "k_part_scatter<true, false, false, true, false>"],
     "part_scatter_l1": ["k_part_scatter<false, true, false, true, false>", "k_part_scatter<false, false, false, true, false>"],

@@ -3,7 +3,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from midoridb_amd.dev import DeviceCtx
 dev = DeviceCtx(0)
-n = 20_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 i = torch.arange(n, dtype=torch.int64, device=dev.device)
 cases = {
     "all rows one key": (torch.full((n,), 7, dtype=torch.int64, device=dev.device), torch.full((n // 10,), 7, dtype=torch.int64, device=dev.device)),
