@@ -817,15 +817,15 @@ __global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long lo
  *
  * The group records (first row id in the top kbits, COUNT(*) below) were radix-partitioned on the top
  * bits of the row id, so leaf i holds exactly the records whose row id lies in [i * range, (i+1) * range),
- * range <= ORD_RANGE (8192).  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
+ * range <= ORD_RANGE (4096).  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
  * compacting the slots in order sorts the leaf; leaves are already in order.  This is what reproduces the
  * reference's "survivors keep table order" (executor_select.c:1542-1583) without 8-byte random writes
  * into a table-sized array.
  */
-#define ORD_THREADS 1024
+#define ORD_THREADS 512
 #define ORD_PER_THREAD 8
-#define ORD_RANGE (ORD_THREADS * ORD_PER_THREAD)	/* 8192 row ids per ordering leaf (64 KiB of LDS slots) */
-#define ORD_RANGE_BITS 13
+#define ORD_RANGE (ORD_THREADS * ORD_PER_THREAD)	/* 4096 row ids per ordering leaf (32 KiB of LDS slots: 4 workgroups per CU; 8192 ids x 1024 threads measured 15 % slower, 2048 x 256 no faster) */
+#define ORD_RANGE_BITS 12
 
 struct ord_args {
 	const unsigned long long *rec;
