@@ -106,6 +106,26 @@ def main():
     res["three_way_join_1e7"] = {"rows_per_table": n2, "joined_rows": j3, "ms": ms, "joined_rows_per_s": j3 / (ms * 1e-3),
                                  "kernels_ms": kern}
 
+    # ---- BASELINE config 5 shape on one GPU at full size: (A join B) join C on one key, 10^8 rows per table, then
+    #      GROUP BY the key + COUNT(*); row ids composed through both joins (what a payload projection would gather with)
+    del a_id, a_f, b_id, b_f, c_id
+    torch.cuda.empty_cache()
+    big = [dev.gen_keys(n, 0, n, s, 0) for s in (42, 43, 44)]
+
+    def three_way_group():
+        l, r = dev.join_pairs(big[0], None, big[1], None)
+        k_ab, _ = dev.gather64(big[0], None, l, l.numel())
+        p, q = dev.join_pairs(k_ab, None, big[2], None)
+        ra, rb = dev.gather32(l, p), dev.gather32(r, p)
+        key, _ = dev.gather64(k_ab, None, p, p.numel())
+        first, cnt = dev.group_count(key, None)
+        return first.numel()
+    ms, kern, g3 = timed(dev, three_way_group, reps=2, warmup=1)
+    res["three_way_join_group_1e8"] = {"rows_per_table": n, "groups": g3, "ms": ms, "joined_rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
+                                       "note": "BASELINE configs[4] shape on ONE GPU: two materialising joins (unique keys) + GROUP BY + COUNT(*)"}
+    del big
+    torch.cuda.empty_cache()
+
     # ---- ORDER BY (extension): stable sort permutation of 10^8 rows on one INT64 key with 27
     #      significant bits (4 radix passes), and a top-k over the north-star groups through query_execute()
     k1 = dev.gen_keys(n, 0, n, 77, 0)
