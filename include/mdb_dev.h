@@ -250,6 +250,14 @@ int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
 			     int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 			     uint64_t *out_groups, uint64_t *out_joined);
 
+/* Chaining the fused operator over several tables joined on ONE key (A JOIN B ON a=b JOIN C ON a=c ... GROUP BY a,
+ * BASELINE configs[4]): run it on (A, B), then on (the group keys it returned, C) with out_first, and combine -
+ * a group of the second run at position k stems from group idx[k] of the first, so COUNT(*) = cnt1[idx[k]] * cnt2[k]
+ * and its first left row is first1[idx[k]] (first1 == NULL: idx[k] itself).  *out_sum = sum of the combined counts
+ * (= rows of the full join).  The joined rows of neither join are ever materialised.  Synchronises. */
+int mdb_dev_combine_counts(mdb_dev_ctx *ctx, const int64_t *cnt1, const uint32_t *first1, const uint32_t *idx, const int64_t *cnt2,
+			   uint64_t n, int64_t *out_cnt, uint32_t *out_first, uint64_t *out_sum);
+
 /* Split form for pipelines that receive the two tables at different times (the multi-GPU exchange):
  * _begin() hashes and partitions the LEFT table and returns without a host sync, so the work overlaps
  * whatever is still in flight (e.g. the right table's all-to-all); n_r_max bounds the right table's size

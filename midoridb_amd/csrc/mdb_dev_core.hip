@@ -756,6 +756,54 @@ extern "C" int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_
 	return MIDORIDB_OK;
 }
 
+/* ------------------------------------------------------------------ chained fused joins: combine two COUNT columns */
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_combine_counts(const int64_t *__restrict__ cnt1, const uint32_t *__restrict__ first1,
+								    const uint32_t *__restrict__ idx, const int64_t *__restrict__ cnt2, uint64_t n,
+								    int64_t *__restrict__ out_cnt, uint32_t *__restrict__ out_first,
+								    unsigned long long *sum)
+{
+	__shared__ unsigned long long s_sum;
+	if (threadIdx.x == 0)
+		s_sum = 0ull;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+	unsigned long long mine = 0;
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n) {
+			const uint32_t g = idx[k];
+			const int64_t c = cnt1[g] * cnt2[k];
+			out_cnt[k] = c;
+			if (out_first)
+				out_first[k] = first1 ? first1[g] : g;
+			mine += (unsigned long long)c;
+		}
+	}
+	if (mine)
+		atomicAdd(&s_sum, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_sum)
+		atomicAdd(sum, s_sum);
+}
+
+extern "C" int mdb_dev_combine_counts(mdb_dev_ctx *ctx, const int64_t *cnt1, const uint32_t *first1, const uint32_t *idx, const int64_t *cnt2,
+				      uint64_t n, int64_t *out_cnt, uint32_t *out_first, uint64_t *out_sum)
+{
+	*out_sum = 0;
+	if (n == 0)
+		return MIDORIDB_OK;
+	unsigned long long *d_sum = (unsigned long long *)(ctx->d_status + 12);
+	MDB_HIP(ctx, hipMemsetAsync(d_sum, 0, 8, ctx->stream));
+	MDB_LAUNCH(ctx, "combine_counts", k_combine_counts, stream_grid(n), STREAM_THREADS, cnt1, first1, idx, cnt2, n, out_cnt, out_first, d_sum);
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_sum = h[0];
+	return MIDORIDB_OK;
+}
+
 /* ------------------------------------------------------------------ key statistics / 4-byte wire format */
 
 __global__ __launch_bounds__(STREAM_THREADS) void k_key_range(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nullbits, uint64_t n,

@@ -108,6 +108,7 @@ struct gc_args {
 	unsigned long long *joined;	/* sum of all counts */
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
 	uint32_t nleaves;
+	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
 };
 
 /*
@@ -307,7 +308,7 @@ __device__ static inline void gc_probe_side(const gc_args &a, const unsigned lon
  * 2*10^7 rows of one key took 77 ms.  For such leaves (GC_HEAVY rows or more on the side at hand) the lanes of a wave
  * first merge their duplicates - leader's key, ballot of the lanes that hold the same key, one table operation for
  * the whole group - so the table sees one update per distinct key per wave instead of one per row. */
-#define GC_HEAVY (8u * GC_THREADS * LEAF_BATCH)
+#define GC_HEAVY (8u * GC_THREADS * LEAF_BATCH)	/* floor of the hot threshold (gc_args.heavy_l / heavy_r) */
 
 __device__ static inline uint32_t gc_wave_min_u32(uint32_t v)
 {
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
 		}
 		const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
-		const bool heavy_l = l1 - l0 >= GC_HEAVY, heavy_r = HAS_R && r1 - r0 >= GC_HEAVY;	/* hot keys: see gc_side_heavy */
+		const bool heavy_l = l1 - l0 >= a.heavy_l, heavy_r = HAS_R && r1 - r0 >= a.heavy_r;	/* hot keys: see gc_side_heavy */
 		const bool hot = nonempty && (heavy_l || heavy_r);
 		const bool live = HEAVY ? hot : (nonempty && !hot);
 		if (!HEAVY && hot && threadIdx.x == 0)
@@ -609,7 +610,7 @@ __global__ void k_hot_list(gc_args a, hot_args h)
 		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
 	if (l0 == l1 || r0 == r1)
 		return;
-	if (l1 - l0 >= GC_HEAVY || (HAS_R && r1 - r0 >= GC_HEAVY)) {
+	if (l1 - l0 >= a.heavy_l || (HAS_R && r1 - r0 >= a.heavy_r)) {
 		const uint32_t i = atomicAdd(h.count, 1u);
 		if (i < HOT_MAX)
 			h.leaf[i] = leaf;
@@ -1146,6 +1147,13 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.joined = d_joined;
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
+	{
+		/* hot = far above the side's average leaf: a much larger probe table spread evenly over the leaves is not skew */
+		const uint64_t avg_l = n_l / (pl.nleaves ? pl.nleaves : 1), avg_r = has_r ? n_r / (pl.nleaves ? pl.nleaves : 1) : 0;
+		const uint64_t hl = 8 * avg_l > GC_HEAVY ? 8 * avg_l : GC_HEAVY, hr = 8 * avg_r > GC_HEAVY ? 8 * avg_r : GC_HEAVY;
+		a.heavy_l = hl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hl;
+		a.heavy_r = hr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hr;
+	}
 	{
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;

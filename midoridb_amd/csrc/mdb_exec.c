@@ -878,29 +878,39 @@ static double now_ms(void)
 }
 
 /* is the plan the fused north-star shape?  returns the group field's side (0 = left key, 1 = right key) or -1 */
-static int fused_shape(struct mdb_select *s, const struct mdb_expr **kl, const struct mdb_expr **kr)
+/* The fused plan applies to  T0 JOIN T1 ON k0 = k1 [JOIN T2 ON (k0 | k1) = k2 ...] GROUP BY one of those keys, COUNT(*):
+ * every join is an equi-join on the SAME key (each ON clause ties the new table's column to a key column already
+ * in the chain), no WHERE.  keys[t] = the key field of table t.  Returns 0 when it applies, -1 otherwise. */
+static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys)
 {
-	struct mdb_expr *on;
-	if (s->ntabs != 2 || s->where || s->ngroup != 1 || !s->on[1])
+	if (s->ntabs < 2 || s->where || s->ngroup != 1)
 		return -1;
-	on = s->on[1];
-	if (on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
-		return -1;
-	if (on->kids[0]->tbl_idx == 0 && on->kids[1]->tbl_idx == 1) {
-		*kl = on->kids[0];
-		*kr = on->kids[1];
-	} else if (on->kids[0]->tbl_idx == 1 && on->kids[1]->tbl_idx == 0) {
-		*kl = on->kids[1];
-		*kr = on->kids[0];
-	} else {
-		return -1;
+	for (int t = 0; t < s->ntabs; t++)
+		keys[t] = NULL;
+	for (int t = 1; t < s->ntabs; t++) {
+		const struct mdb_expr *on = s->on[t], *mine, *other;
+		if (!on || on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
+			return -1;
+		if (on->kids[0]->tbl_idx == t && on->kids[1]->tbl_idx < t) {
+			mine = on->kids[0];
+			other = on->kids[1];
+		} else if (on->kids[1]->tbl_idx == t && on->kids[0]->tbl_idx < t) {
+			mine = on->kids[1];
+			other = on->kids[0];
+		} else {
+			return -1;
+		}
+		if (t == 1)
+			keys[0] = other;
+		else if (!keys[other->tbl_idx] || !field_eq(other, keys[other->tbl_idx]))
+			return -1;
+		if (mine->type != other->type)
+			return -1;
+		keys[t] = mine;
 	}
-	if ((*kl)->type != (*kr)->type)
-		return -1;
-	if (field_eq(s->group[0], *kl))
-		return 0;
-	if (field_eq(s->group[0], *kr))
-		return 1;
+	for (int t = 0; t < s->ntabs; t++)
+		if (field_eq(s->group[0], keys[t]))
+			return 0;
 	return -1;
 }
 
@@ -987,7 +997,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	int *order = NULL, *key_tbl = NULL, *key_col = NULL;
 	int nkeys = 0, rc, has_count = 0;
 	double t0;
-	const struct mdb_expr *fkl = NULL, *fkr = NULL;
+	const struct mdb_expr *fkeys[MDB_MAX_COLS];
 	int fused;
 
 	*out = NULL;
@@ -1038,11 +1048,13 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	}
 
 	t0 = now_ms();
-	fused = fused_shape(s, &fkl, &fkr);
+	fused = s->ntabs <= MDB_MAX_COLS ? fused_chain(s, fkeys) : -1;
 	if (fused >= 0) {
-		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join */
+		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join.  More than two tables
+		 *      on the same key chain the operator: the group keys of (T0, T1) are joined with T2, and so on; a group's
+		 *      COUNT(*) is the product of the per-table multiplicities (mdb_dev_combine_counts). */
 		struct mdb_table *lt = s->tabs[0].t, *rt = s->tabs[1].t;
-		struct mdb_column *lc = &lt->cols[fkl->col_idx], *rcq = &rt->cols[fkr->col_idx];
+		struct mdb_column *lc = &lt->cols[fkeys[0]->col_idx], *rcq = &rt->cols[fkeys[1]->col_idx];
 		uint64_t cap = lt->nrows ? lt->nrows : 1, G = 0, J = 0;
 		x.d_fused_key = dalloc(&x, cap * 8);
 		x.d_count = dalloc(&x, cap * 8);
@@ -1055,6 +1067,28 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			rc = dev_fail(&x, "join + group count");
 			goto out;
 		}
+		for (int t = 2; t < s->ntabs && G; t++) {
+			struct mdb_table *ct = s->tabs[t].t;
+			struct mdb_column *cc = &ct->cols[fkeys[t]->col_idx];
+			int64_t *key2 = dalloc(&x, G * 8), *cnt2 = dalloc(&x, G * 8), *cnt3 = dalloc(&x, G * 8);
+			uint32_t *first2 = dalloc(&x, G * 4);
+			uint64_t G2 = 0, J2 = 0;
+			if (!key2 || !cnt2 || !cnt3 || !first2) {
+				rc = dev_fail(&x, "allocating group outputs");
+				goto out;
+			}
+			if (mdb_dev_join_group_count(x.dev, x.d_fused_key, NULL, G, cc->d_data, cc->d_nullbits, ct->nrows, MDB_ORDER_FIRST, key2, cnt2,
+						     first2, G, &G2, &J2) ||
+			    mdb_dev_combine_counts(x.dev, x.d_count, NULL, first2, cnt2, G2, cnt3, NULL, &J)) {
+				rc = dev_fail(&x, "chained join + group count");
+				goto out;
+			}
+			x.d_fused_key = key2;
+			x.d_count = cnt3;
+			G = G2;
+		}
+		if (!G)
+			J = 0;
 		x.fused = true;
 		x.n = G;
 		x.joined_rows = J;

@@ -74,6 +74,7 @@ def _bind(lib):
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, c_uint32, P, P, P, c_uint64,
                                       POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dev_combine_counts": ([P, P, P, P, P, c_uint64, P, P, POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count_begin": ([P, P, P, c_uint64, c_uint64], c_int),
         "mdb_dev_join_group_count_finish": ([P, P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, c_int, P, P, POINTER(c_uint64)], c_int),
@@ -93,7 +94,7 @@ DEV_SYMBOLS = [
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
-    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
+    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
 ]
 
@@ -329,6 +330,16 @@ class DeviceCtx:
         m = c_uint64(0)
         self._chk(self.lib.mdb_dev_distinct_sel(self.h, self._sort_keys(keys), len(keys), n, _ptr(sel), byref(m)), "distinct_sel")
         return sel[:m.value]
+
+    def combine_counts(self, cnt1, first1, idx, cnt2):
+        """chained fused joins: (cnt1[idx] * cnt2, first1[idx] (or idx), sum)"""
+        n = idx.numel()
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        outf = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        tot = c_uint64(0)
+        self._chk(self.lib.mdb_dev_combine_counts(self.h, _ptr(cnt1), _ptr(first1), _ptr(idx), _ptr(cnt2), n, _ptr(out), _ptr(outf), byref(tot)),
+                  "combine_counts")
+        return out[:n], outf[:n], tot.value
 
     def group_count_multi(self, keys, n):
         """GROUP BY several columns + COUNT(*): -> (first positions ascending, counts)."""

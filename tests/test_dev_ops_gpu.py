@@ -602,3 +602,17 @@ def test_hot_keys(dev, shape):
     first, cnt = dev.group_count(dev.to_dev(kl), dev.nullbits_dev(nl))
     e_first, e_cnt = orc.group_count(kl, nl)
     assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+
+
+def test_combine_counts(dev):
+    rng = np.random.default_rng(9)
+    g1, n = 5000, 3000
+    cnt1 = rng.integers(1, 50, g1, dtype=np.int64)
+    first1 = rng.permutation(100_000)[:g1].astype(np.uint32)
+    idx = np.sort(rng.choice(g1, n, replace=False)).astype(np.uint32)
+    cnt2 = rng.integers(1, 9, n, dtype=np.int64)
+    out, outf, tot = dev.combine_counts(dev.to_dev(cnt1), dev.to_dev(first1), dev.to_dev(idx), dev.to_dev(cnt2))
+    assert np.array_equal(_np(out), cnt1[idx] * cnt2) and np.array_equal(_np(outf).view(np.uint32), first1[idx])
+    assert tot == int((cnt1[idx] * cnt2).sum())
+    out, outf, tot = dev.combine_counts(dev.to_dev(cnt1), None, dev.to_dev(idx), dev.to_dev(cnt2))
+    assert np.array_equal(_np(outf).view(np.uint32), idx)
