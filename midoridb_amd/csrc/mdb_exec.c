@@ -878,12 +878,99 @@ static double now_ms(void)
 }
 
 /* is the plan the fused north-star shape?  returns the group field's side (0 = left key, 1 = right key) or -1 */
+/* which FROM tables an expression reads: bit t set for table t */
+static uint64_t expr_tables(const struct mdb_expr *e)
+{
+	uint64_t m = 0;
+	if (!e)
+		return 0;
+	if (e->kind == MDB_EX_FIELD && e->tbl_idx >= 0 && e->tbl_idx < 64)
+		m |= 1ull << e->tbl_idx;
+	for (int i = 0; i < e->nkids; i++)
+		m |= expr_tables(e->kids[i]);
+	return m;
+}
+
+/* WHERE push-down for the fused plan: the reference filters AFTER the join (proc_where_clause :1435-1463), which for
+ * an inner join gives the same rows as filtering a table first whenever a conjunct reads only that table.  Returns
+ * true when every top-level AND-conjunct of the WHERE clause reads at most one table (constants go with table 0);
+ * conj[t][..] then lists table t's conjuncts. */
+#define PUSH_MAX 16
+static bool where_pushable(const struct mdb_select *s, const struct mdb_expr *conj[][PUSH_MAX], int *nconj)
+{
+	struct mdb_expr *all[64];
+	int n = 0;
+	for (int t = 0; t < s->ntabs; t++)
+		nconj[t] = 0;
+	if (!s->where)
+		return true;
+	if (s->ntabs > 64)
+		return false;
+	collect_conjuncts(s->where, all, &n, 64);
+	if (n > 64)
+		return false;
+	for (int i = 0; i < n; i++) {
+		const uint64_t m = expr_tables(all[i]);
+		int t = 0;
+		if (m & (m - 1))
+			return false;	/* reads two tables: stays above the join */
+		while (m && !((m >> t) & 1))
+			t++;
+		if (nconj[t] == PUSH_MAX)
+			return false;
+		conj[t][nconj[t]++] = all[i];
+	}
+	return true;
+}
+
+/* key column of table t for the fused plan: the base column, or - with pushed-down conjuncts - the keys of the rows
+ * that pass them (filter on the base table, then one gather of the key column) */
+static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struct mdb_expr *const *conj, int nconj,
+			 const void **vals, const uint64_t **nulls, uint64_t *n)
+{
+	struct mdb_table *tb = x->s->tabs[t].t;
+	struct mdb_column *col = &tb->cols[key->col_idx];
+	*vals = col->d_data;
+	*nulls = col->d_nullbits;
+	*n = tb->nrows;
+	if (!nconj || !tb->nrows)
+		return MIDORIDB_OK;
+	struct pred_prog p;
+	uint32_t *sel;
+	uint64_t m = 0;
+	memset(&p, 0, sizeof(p));
+	for (int i = 0; i < nconj; i++)
+		if (pred_compile(x, &p, conj[i]) || (i && pred_emit(&p, MDB_P_AND, 0, 0, 0, 0, 0))) {
+			snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
+				 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
+			return -MIDORIDB_ERROR;
+		}
+	sel = dalloc(x, tb->nrows * 4);
+	if (!sel)
+		return dev_fail(x, "allocating the selection vector");
+	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, tb->nrows, sel, &m))
+		return dev_fail(x, "filter");
+	{
+		int64_t *v = dalloc(x, (m ? m : 1) * 8);
+		uint64_t *nb = col->d_nullbits ? dalloc(x, ((m + 63) / 64 + 1) * 8) : NULL;
+		if (!v || (col->d_nullbits && !nb))
+			return dev_fail(x, "allocating a key column");
+		if (m && mdb_dev_gather64(x->dev, col->d_data, col->d_nullbits, sel, m, v, nb))
+			return dev_fail(x, "gathering a key column");
+		*vals = v;
+		*nulls = nb;
+		*n = m;
+	}
+	return MIDORIDB_OK;
+}
+
 /* The fused plan applies to  T0 JOIN T1 ON k0 = k1 [JOIN T2 ON (k0 | k1) = k2 ...] GROUP BY one of those keys, COUNT(*):
  * every join is an equi-join on the SAME key (each ON clause ties the new table's column to a key column already
- * in the chain), no WHERE.  keys[t] = the key field of table t.  Returns 0 when it applies, -1 otherwise. */
+ * in the chain); a WHERE clause must be pushable below the joins (where_pushable).  keys[t] = the key field of
+ * table t.  Returns 0 when it applies, -1 otherwise. */
 static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys)
 {
-	if (s->ntabs < 2 || s->where || s->ngroup != 1)
+	if (s->ntabs < 2 || s->ngroup != 1)
 		return -1;
 	for (int t = 0; t < s->ntabs; t++)
 		keys[t] = NULL;
@@ -997,7 +1084,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	int *order = NULL, *key_tbl = NULL, *key_col = NULL;
 	int nkeys = 0, rc, has_count = 0;
 	double t0;
-	const struct mdb_expr *fkeys[MDB_MAX_COLS];
+	const struct mdb_expr *fkeys[16];
 	int fused;
 
 	*out = NULL;
@@ -1048,28 +1135,40 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	}
 
 	t0 = now_ms();
-	fused = s->ntabs <= MDB_MAX_COLS ? fused_chain(s, fkeys) : -1;
+	const struct mdb_expr *push[16][PUSH_MAX];
+	int npush[16];
+	fused = s->ntabs <= 16 ? fused_chain(s, fkeys) : -1;
+	if (fused >= 0 && !where_pushable(s, push, npush))
+		fused = -1;
 	if (fused >= 0) {
 		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join.  More than two tables
 		 *      on the same key chain the operator: the group keys of (T0, T1) are joined with T2, and so on; a group's
-		 *      COUNT(*) is the product of the per-table multiplicities (mdb_dev_combine_counts). */
-		struct mdb_table *lt = s->tabs[0].t, *rt = s->tabs[1].t;
-		struct mdb_column *lc = &lt->cols[fkeys[0]->col_idx], *rcq = &rt->cols[fkeys[1]->col_idx];
-		uint64_t cap = lt->nrows ? lt->nrows : 1, G = 0, J = 0;
+		 *      COUNT(*) is the product of the per-table multiplicities (mdb_dev_combine_counts).  WHERE conjuncts that
+		 *      read one table filter that table before it enters the join. */
+		const void *lv, *rv;
+		const uint64_t *ln, *rn;
+		uint64_t nl_rows, nr_rows;
+		if ((rc = fused_operand(&x, 0, fkeys[0], push[0], npush[0], &lv, &ln, &nl_rows)) ||
+		    (rc = fused_operand(&x, 1, fkeys[1], push[1], npush[1], &rv, &rn, &nr_rows)))
+			goto out;
+		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
 		x.d_fused_key = dalloc(&x, cap * 8);
 		x.d_count = dalloc(&x, cap * 8);
 		if (!x.d_fused_key || !x.d_count) {
 			rc = dev_fail(&x, "allocating group outputs");
 			goto out;
 		}
-		if (mdb_dev_join_group_count(x.dev, lc->d_data, lc->d_nullbits, lt->nrows, rcq->d_data, rcq->d_nullbits, rt->nrows,
-					     MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G, &J)) {
+		if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
+					     &J)) {
 			rc = dev_fail(&x, "join + group count");
 			goto out;
 		}
 		for (int t = 2; t < s->ntabs && G; t++) {
-			struct mdb_table *ct = s->tabs[t].t;
-			struct mdb_column *cc = &ct->cols[fkeys[t]->col_idx];
+			const void *cv;
+			const uint64_t *cn;
+			uint64_t nc_rows;
+			if ((rc = fused_operand(&x, t, fkeys[t], push[t], npush[t], &cv, &cn, &nc_rows)))
+				goto out;
 			int64_t *key2 = dalloc(&x, G * 8), *cnt2 = dalloc(&x, G * 8), *cnt3 = dalloc(&x, G * 8);
 			uint32_t *first2 = dalloc(&x, G * 4);
 			uint64_t G2 = 0, J2 = 0;
@@ -1077,8 +1176,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				rc = dev_fail(&x, "allocating group outputs");
 				goto out;
 			}
-			if (mdb_dev_join_group_count(x.dev, x.d_fused_key, NULL, G, cc->d_data, cc->d_nullbits, ct->nrows, MDB_ORDER_FIRST, key2, cnt2,
-						     first2, G, &G2, &J2) ||
+			if (mdb_dev_join_group_count(x.dev, x.d_fused_key, NULL, G, cv, cn, nc_rows, MDB_ORDER_FIRST, key2, cnt2, first2, G, &G2,
+						     &J2) ||
 			    mdb_dev_combine_counts(x.dev, x.d_count, NULL, first2, cnt2, G2, cnt3, NULL, &J)) {
 				rc = dev_fail(&x, "chained join + group count");
 				goto out;
