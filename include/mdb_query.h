@@ -96,7 +96,8 @@ int query_column_type(struct result_set *res, int col_idx);		/* reference enum C
 uint64_t query_row_count(struct result_set *res);
 /* Whole result column at once (8-byte values, row order); NULL rows hold 0. */
 const int64_t *query_column_data(struct result_set *res, int col_idx);
-/* Device-pipeline milliseconds and joined-row count of the SELECT that produced `res`. */
+/* Device-pipeline milliseconds of the SELECT that produced `res`, and the rows its joins produced before
+ * aggregation (after the WHERE conjuncts that were pushed below the joins; 0 when the query has no join). */
 double query_exec_ms(struct result_set *res);
 uint64_t query_joined_rows(struct result_set *res);
 

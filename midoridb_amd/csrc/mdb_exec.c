@@ -768,7 +768,124 @@ static void collect_conjuncts(struct mdb_expr *e, struct mdb_expr **out, int *n,
 	}
 }
 
-static int join_next_table(struct exec *x, int t)
+/* which FROM tables an expression reads: bit t set for table t */
+static uint64_t expr_tables(const struct mdb_expr *e)
+{
+	uint64_t m = 0;
+	if (!e)
+		return 0;
+	if (e->kind == MDB_EX_FIELD && e->tbl_idx >= 0 && e->tbl_idx < 64)
+		m |= 1ull << e->tbl_idx;
+	for (int i = 0; i < e->nkids; i++)
+		m |= expr_tables(e->kids[i]);
+	return m;
+}
+
+/* WHERE push-down: the reference filters AFTER the joins (proc_where_clause :1435-1463), which for inner joins gives
+ * the same rows as filtering a table first whenever a conjunct reads only that table.  Splits the top-level
+ * AND-conjuncts of the WHERE clause: push[t][..] = table t's own conjuncts (constants go with table 0),
+ * residual[..] = conjuncts that read several tables and stay above the joins.  false = too many to split. */
+#define PUSH_MAX 16
+#define PUSH_TABS 16
+struct where_split {
+	const struct mdb_expr *push[PUSH_TABS][PUSH_MAX];
+	int npush[PUSH_TABS];
+	const struct mdb_expr *residual[64];
+	int nresidual;
+};
+
+static bool where_split(const struct mdb_select *s, struct where_split *w)
+{
+	struct mdb_expr *all[64];
+	int n = 0;
+	memset(w, 0, sizeof(*w));
+	if (!s->where)
+		return true;
+	if (s->ntabs > PUSH_TABS)
+		return false;
+	collect_conjuncts(s->where, all, &n, 64);
+	if (n > 64)
+		return false;
+	for (int i = 0; i < n; i++) {
+		const uint64_t m = expr_tables(all[i]);
+		int t = 0;
+		if (m & (m - 1)) {
+			w->residual[w->nresidual++] = all[i];
+			continue;
+		}
+		while (m && !((m >> t) & 1))
+			t++;
+		if (w->npush[t] == PUSH_MAX)
+			return false;
+		w->push[t][w->npush[t]++] = all[i];
+	}
+	return true;
+}
+
+/* rows of base table t that pass its pushed-down conjuncts: *sel = ascending row ids (NULL = every row), *m = how many */
+static int table_filter(struct exec *x, int t, const struct mdb_expr *const *conj, int nconj, const uint32_t **sel, uint64_t *m)
+{
+	struct mdb_table *tb = x->s->tabs[t].t;
+	struct pred_prog p;
+	uint32_t *v;
+	*sel = NULL;
+	*m = tb->nrows;
+	if (!nconj || !tb->nrows)
+		return MIDORIDB_OK;
+	memset(&p, 0, sizeof(p));
+	{
+		uint32_t *saved = x->rid[t];	/* the program reads the BASE table, whatever the stream holds for t */
+		x->rid[t] = NULL;
+		for (int i = 0; i < nconj; i++)
+			if (pred_compile(x, &p, conj[i]) || (i && pred_emit(&p, MDB_P_AND, 0, 0, 0, 0, 0))) {
+				x->rid[t] = saved;
+				snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
+					 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
+				return -MIDORIDB_ERROR;
+			}
+		x->rid[t] = saved;
+	}
+	v = dalloc(x, tb->nrows * 4);
+	if (!v)
+		return dev_fail(x, "allocating the selection vector");
+	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, tb->nrows, v, m))
+		return dev_fail(x, "filter");
+	*sel = v;
+	return MIDORIDB_OK;
+}
+
+/* column `key` of base table t restricted to the rows in sel (NULL = all): device pointers for an operator */
+static int table_column(struct exec *x, int t, const struct mdb_expr *key, const uint32_t *sel, uint64_t m, const void **vals,
+			const uint64_t **nulls)
+{
+	struct mdb_column *col = &x->s->tabs[t].t->cols[key->col_idx];
+	*vals = col->d_data;
+	*nulls = col->d_nullbits;
+	if (sel) {
+		int64_t *v = dalloc(x, (m ? m : 1) * 8);
+		uint64_t *nb = col->d_nullbits ? dalloc(x, ((m + 63) / 64 + 1) * 8) : NULL;
+		if (!v || (col->d_nullbits && !nb))
+			return dev_fail(x, "allocating a key column");
+		if (m && mdb_dev_gather64(x->dev, col->d_data, col->d_nullbits, sel, m, v, nb))
+			return dev_fail(x, "gathering a key column");
+		*vals = v;
+		*nulls = nb;
+	}
+	return MIDORIDB_OK;
+}
+
+/* key column of table t for the fused plan: the base column, or the keys of the rows that pass the pushed conjuncts */
+static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struct mdb_expr *const *conj, int nconj,
+			 const void **vals, const uint64_t **nulls, uint64_t *n)
+{
+	const uint32_t *sel;
+	int rc = table_filter(x, t, conj, nconj, &sel, n);
+	if (rc)
+		return rc;
+	return table_column(x, t, key, sel, *n, vals, nulls);
+}
+
+static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, int npconj)
 {
 	struct mdb_select *s = x->s;
 	struct mdb_table *rt = s->tabs[t].t;
@@ -799,14 +916,20 @@ static int join_next_table(struct exec *x, int t)
 			}
 		}
 	}
+	/* the new table's own WHERE conjuncts filter it before it is joined */
+	const uint32_t *rsel = NULL;
+	uint64_t r_rows = rt->nrows;
+	if ((rc = table_filter(x, t, pconj, npconj, &rsel, &r_rows)))
+		return rc;
 	if (key >= 0) {
 		const int64_t *vl;
 		const uint64_t *nl;
-		struct mdb_column *rc_col = &rt->cols[kr->col_idx];
-		if ((rc = stream_column(x, kl, &vl, &nl)))
+		const void *vr;
+		const uint64_t *nr;
+		if ((rc = stream_column(x, kl, &vl, &nl)) || (rc = table_column(x, t, kr, rsel, r_rows, &vr, &nr)))
 			return rc;
-		if (x->n && rt->nrows) {
-			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, rc_col->d_data, rc_col->d_nullbits, rt->nrows, &pl, &pr, &J))
+		if (x->n && r_rows) {
+			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J))
 				return dev_fail(x, "hash join");
 			if (pl && track(x, pl))
 				return -MIDORIDB_NOMEM;
@@ -815,10 +938,10 @@ static int join_next_table(struct exec *x, int t)
 		}
 	} else {
 		/* no equi-join key: FROM A, B (ON 1=1) or a general ON -> all pairs, then the ON predicate */
-		const uint64_t total = x->n * rt->nrows;
+		const uint64_t total = x->n * r_rows;
 		if (total > (1ull << 28)) {
 			snprintf(x->err, x->errlen, "execution phase: cross join of %llu x %llu rows is too large (no equi-join key in the ON clause)\n",
-				 (unsigned long long)x->n, (unsigned long long)rt->nrows);
+				 (unsigned long long)x->n, (unsigned long long)r_rows);
 			return -MIDORIDB_ERROR;
 		}
 		J = total;
@@ -827,9 +950,15 @@ static int join_next_table(struct exec *x, int t)
 			pr = dalloc(x, J * 4);
 			if (!pl || !pr)
 				return dev_fail(x, "allocating join pairs");
-			if (mdb_dev_cross_pairs(x->dev, x->n, rt->nrows, pl, pr))
+			if (mdb_dev_cross_pairs(x->dev, x->n, r_rows, pl, pr))
 				return dev_fail(x, "cross join");
 		}
+	}
+	if (rsel && J) {	/* pairs index the filtered right rows: back to row ids of the base table */
+		uint32_t *mapped = dalloc(x, J * 4);
+		if (!mapped || mdb_dev_gather32(x->dev, rsel, pr, J, mapped))
+			return dev_fail(x, "re-mapping row ids");
+		pr = mapped;
 	}
 	/* compose the stream: earlier tables through pl, the new table = pr */
 	if ((rc = stream_select(x, t, pl, J)))
@@ -878,92 +1007,6 @@ static double now_ms(void)
 }
 
 /* is the plan the fused north-star shape?  returns the group field's side (0 = left key, 1 = right key) or -1 */
-/* which FROM tables an expression reads: bit t set for table t */
-static uint64_t expr_tables(const struct mdb_expr *e)
-{
-	uint64_t m = 0;
-	if (!e)
-		return 0;
-	if (e->kind == MDB_EX_FIELD && e->tbl_idx >= 0 && e->tbl_idx < 64)
-		m |= 1ull << e->tbl_idx;
-	for (int i = 0; i < e->nkids; i++)
-		m |= expr_tables(e->kids[i]);
-	return m;
-}
-
-/* WHERE push-down for the fused plan: the reference filters AFTER the join (proc_where_clause :1435-1463), which for
- * an inner join gives the same rows as filtering a table first whenever a conjunct reads only that table.  Returns
- * true when every top-level AND-conjunct of the WHERE clause reads at most one table (constants go with table 0);
- * conj[t][..] then lists table t's conjuncts. */
-#define PUSH_MAX 16
-static bool where_pushable(const struct mdb_select *s, const struct mdb_expr *conj[][PUSH_MAX], int *nconj)
-{
-	struct mdb_expr *all[64];
-	int n = 0;
-	for (int t = 0; t < s->ntabs; t++)
-		nconj[t] = 0;
-	if (!s->where)
-		return true;
-	if (s->ntabs > 64)
-		return false;
-	collect_conjuncts(s->where, all, &n, 64);
-	if (n > 64)
-		return false;
-	for (int i = 0; i < n; i++) {
-		const uint64_t m = expr_tables(all[i]);
-		int t = 0;
-		if (m & (m - 1))
-			return false;	/* reads two tables: stays above the join */
-		while (m && !((m >> t) & 1))
-			t++;
-		if (nconj[t] == PUSH_MAX)
-			return false;
-		conj[t][nconj[t]++] = all[i];
-	}
-	return true;
-}
-
-/* key column of table t for the fused plan: the base column, or - with pushed-down conjuncts - the keys of the rows
- * that pass them (filter on the base table, then one gather of the key column) */
-static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struct mdb_expr *const *conj, int nconj,
-			 const void **vals, const uint64_t **nulls, uint64_t *n)
-{
-	struct mdb_table *tb = x->s->tabs[t].t;
-	struct mdb_column *col = &tb->cols[key->col_idx];
-	*vals = col->d_data;
-	*nulls = col->d_nullbits;
-	*n = tb->nrows;
-	if (!nconj || !tb->nrows)
-		return MIDORIDB_OK;
-	struct pred_prog p;
-	uint32_t *sel;
-	uint64_t m = 0;
-	memset(&p, 0, sizeof(p));
-	for (int i = 0; i < nconj; i++)
-		if (pred_compile(x, &p, conj[i]) || (i && pred_emit(&p, MDB_P_AND, 0, 0, 0, 0, 0))) {
-			snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
-				 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
-			return -MIDORIDB_ERROR;
-		}
-	sel = dalloc(x, tb->nrows * 4);
-	if (!sel)
-		return dev_fail(x, "allocating the selection vector");
-	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, tb->nrows, sel, &m))
-		return dev_fail(x, "filter");
-	{
-		int64_t *v = dalloc(x, (m ? m : 1) * 8);
-		uint64_t *nb = col->d_nullbits ? dalloc(x, ((m + 63) / 64 + 1) * 8) : NULL;
-		if (!v || (col->d_nullbits && !nb))
-			return dev_fail(x, "allocating a key column");
-		if (m && mdb_dev_gather64(x->dev, col->d_data, col->d_nullbits, sel, m, v, nb))
-			return dev_fail(x, "gathering a key column");
-		*vals = v;
-		*nulls = nb;
-		*n = m;
-	}
-	return MIDORIDB_OK;
-}
-
 /* The fused plan applies to  T0 JOIN T1 ON k0 = k1 [JOIN T2 ON (k0 | k1) = k2 ...] GROUP BY one of those keys, COUNT(*):
  * every join is an equi-join on the SAME key (each ON clause ties the new table's column to a key column already
  * in the chain); a WHERE clause must be pushable below the joins (where_pushable).  keys[t] = the key field of
@@ -1135,11 +1178,11 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	}
 
 	t0 = now_ms();
-	const struct mdb_expr *push[16][PUSH_MAX];
-	int npush[16];
-	fused = s->ntabs <= 16 ? fused_chain(s, fkeys) : -1;
-	if (fused >= 0 && !where_pushable(s, push, npush))
-		fused = -1;
+	struct where_split ws;
+	const bool split_ok = where_split(s, &ws);
+	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys) : -1;
+	if (fused >= 0 && (!split_ok || ws.nresidual))
+		fused = -1;	/* a conjunct reads several tables: it has to see the joined rows */
 	if (fused >= 0) {
 		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join.  More than two tables
 		 *      on the same key chain the operator: the group keys of (T0, T1) are joined with T2, and so on; a group's
@@ -1148,8 +1191,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		const void *lv, *rv;
 		const uint64_t *ln, *rn;
 		uint64_t nl_rows, nr_rows;
-		if ((rc = fused_operand(&x, 0, fkeys[0], push[0], npush[0], &lv, &ln, &nl_rows)) ||
-		    (rc = fused_operand(&x, 1, fkeys[1], push[1], npush[1], &rv, &rn, &nr_rows)))
+		if ((rc = fused_operand(&x, 0, fkeys[0], ws.push[0], ws.npush[0], &lv, &ln, &nl_rows)) ||
+		    (rc = fused_operand(&x, 1, fkeys[1], ws.push[1], ws.npush[1], &rv, &rn, &nr_rows)))
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
 		x.d_fused_key = dalloc(&x, cap * 8);
@@ -1167,7 +1210,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			const void *cv;
 			const uint64_t *cn;
 			uint64_t nc_rows;
-			if ((rc = fused_operand(&x, t, fkeys[t], push[t], npush[t], &cv, &cn, &nc_rows)))
+			if ((rc = fused_operand(&x, t, fkeys[t], ws.push[t], ws.npush[t], &cv, &cn, &nc_rows)))
 				goto out;
 			int64_t *key2 = dalloc(&x, G * 8), *cnt2 = dalloc(&x, G * 8), *cnt3 = dalloc(&x, G * 8);
 			uint32_t *first2 = dalloc(&x, G * 4);
@@ -1194,11 +1237,29 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	} else {
 		/* ---- general plan */
 		x.n = s->tabs[0].t->nrows;	/* scan: identity stream over the first table */
-		for (int t = 1; t < s->ntabs; t++)
-			if ((rc = join_next_table(&x, t)))
+		if (split_ok) {
+			/* WHERE conjuncts that read one table filter that table before it is joined; the others after the joins */
+			const uint32_t *sel0;
+			uint64_t m0;
+			if ((rc = table_filter(&x, 0, ws.push[0], ws.npush[0], &sel0, &m0)))
 				goto out;
-		if (s->where && (rc = stream_filter(&x, s->ntabs, s->where)))
-			goto out;
+			if (sel0) {
+				x.rid[0] = (uint32_t *)sel0;
+				x.n = m0;
+			}
+			for (int t = 1; t < s->ntabs; t++)
+				if ((rc = join_next_table(&x, t, ws.push[t], ws.npush[t])))
+					goto out;
+			for (int i = 0; i < ws.nresidual; i++)
+				if ((rc = stream_filter(&x, s->ntabs, ws.residual[i])))
+					goto out;
+		} else {
+			for (int t = 1; t < s->ntabs; t++)
+				if ((rc = join_next_table(&x, t, NULL, 0)))
+					goto out;
+			if (s->where && (rc = stream_filter(&x, s->ntabs, s->where)))
+				goto out;
+		}
 		if (s->ngroup == 1) {
 			const int64_t *kv;
 			const uint64_t *kn;
