@@ -1010,10 +1010,11 @@ static double now_ms(void)
 /* The fused plan applies to  T0 JOIN T1 ON k0 = k1 [JOIN T2 ON (k0 | k1) = k2 ...] GROUP BY one of those keys, COUNT(*):
  * every join is an equi-join on the SAME key (each ON clause ties the new table's column to a key column already
  * in the chain); a WHERE clause must be pushable below the joins (where_pushable).  keys[t] = the key field of
- * table t.  Returns 0 when it applies, -1 otherwise. */
-static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys)
+ * table t.  count_only: the query is SELECT COUNT(*) over the join without GROUP BY - the same operator, of which only
+ * the joined-row total is used.  Returns 0 when it applies, -1 otherwise. */
+static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool count_only)
 {
-	if (s->ntabs < 2 || s->ngroup != 1)
+	if (s->ntabs < 2 || (count_only ? s->ngroup != 0 : s->ngroup != 1))
 		return -1;
 	for (int t = 0; t < s->ntabs; t++)
 		keys[t] = NULL;
@@ -1038,6 +1039,8 @@ static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys)
 			return -1;
 		keys[t] = mine;
 	}
+	if (count_only)
+		return 0;	/* SELECT COUNT(*) FROM the join: only the number of joined rows is wanted */
 	for (int t = 0; t < s->ntabs; t++)
 		if (field_eq(s->group[0], keys[t]))
 			return 0;
@@ -1180,7 +1183,10 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	t0 = now_ms();
 	struct where_split ws;
 	const bool split_ok = where_split(s, &ws);
-	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys) : -1;
+	bool only_count = has_count && !s->ngroup && !s->select_all;
+	for (int i = 0; i < s->nsel; i++)
+		only_count = only_count && s->sel[i]->kind == MDB_EX_COUNT;
+	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys, only_count) : -1;
 	if (fused >= 0 && (!split_ok || ws.nresidual))
 		fused = -1;	/* a conjunct reads several tables: it has to see the joined rows */
 	if (fused >= 0) {
@@ -1232,7 +1238,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		if (!G)
 			J = 0;
 		x.fused = true;
-		x.n = G;
+		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */
 		x.joined_rows = J;
 	} else {
 		/* ---- general plan */
