@@ -1087,8 +1087,27 @@ static int select_tail(struct exec *x, int has_count)
 		sel = dalloc(x, x->n * 4);
 		if (!sel)
 			return dev_fail(x, "allocating the DISTINCT selection");
-		if (mdb_dev_distinct_sel(x->dev, keys, nk, x->n, sel, &m))
+		if (nk == 1) {
+			/* one column: the hash GROUP BY operator already returns first occurrences in order (2-3x faster
+			 * than sorting at 10^8 rows); its COUNT(*) output is not needed */
+			const void *kv = keys[0].values;
+			const uint64_t *kn = keys[0].nullbits;
+			int64_t *cnt = dalloc(x, x->n * 8);
+			if (!cnt)
+				return dev_fail(x, "allocating the DISTINCT selection");
+			if (keys[0].rid) {
+				int64_t *v = dalloc(x, x->n * 8);
+				uint64_t *nb = kn ? dalloc(x, ((x->n + 63) / 64 + 1) * 8) : NULL;
+				if (!v || (kn && !nb) || mdb_dev_gather64(x->dev, kv, kn, keys[0].rid, x->n, v, nb))
+					return dev_fail(x, "gathering the DISTINCT column");
+				kv = v;
+				kn = nb;
+			}
+			if (mdb_dev_group_count(x->dev, kv, kn, x->n, MDB_ORDER_FIRST, sel, cnt, x->n, &m))
+				return dev_fail(x, "DISTINCT");
+		} else if (mdb_dev_distinct_sel(x->dev, keys, nk, x->n, sel, &m)) {
 			return dev_fail(x, "DISTINCT");
+		}
 		if ((rc = stream_apply_sel(x, s->ntabs, sel, m)))
 			return rc;
 	}
