@@ -6,11 +6,14 @@
  *   mdb_dev_join_pairs        materialising INNER JOIN, pairs in the reference's emission order
  *
  * After mdb_partition_table() every leaf holds all rows (of both tables) whose hashed key shares
- * the same top bits, in original row order.  One workgroup owns one leaf: it builds an
- * open-addressing hash table in LDS keyed by the 64-bit hashed key (fmix64 is a bijection, so
- * equal hash <=> equal key; the value 0 = "empty slot", the single key that hashes to 0 is kept
- * in a dedicated side slot), then streams the other side through it.  All counters are LDS
- * atomics; global memory is read once, coalesced, and written once.
+ * the same top bits (in unspecified order; orders are restored from the row ids).  Persistent
+ * workgroups walk the leaves: each builds an open-addressing hash table in LDS keyed by the 64-bit
+ * hashed key (fmix64 is a bijection, so equal hash <=> equal key; the value 0 = "empty slot", the
+ * single key that hashes to 0 is kept in a dedicated side slot) from the side with fewer rows, then
+ * streams the other side through it.  All counters are LDS atomics; global memory is read once,
+ * coalesced, and written once.  Groups leave as 64-bit records (first row id, COUNT) that a radix
+ * sort + k_order_leaf put into the reference's order; hot keys take the k_hot_* path; joins whose
+ * right keys are unique emit one record per pair (k_leaf_pairs_unique) through the same ordering.
  *
  * Reference semantics reproduced (file:line = reference src/engine/executor_select.c):
  *   - a NULL join key matches nothing (:557-579)            -> NULL keys were dropped at level 0

@@ -8,7 +8,13 @@
  * build side fits one CU's LDS; equal keys always land in the same leaf, so each leaf is joined /
  * grouped independently by one workgroup (mdb_dev_join.hip).
  *
- * One level = histogram -> exclusive scan -> scatter, all tile based (MDB_TILE = 4096 keys):
+ * The default ("FAST") form has NO histogram pass: every child owns a fixed-capacity region and each (tile, digit)
+ * run reserves its place with one global atomic on the region's cursor (first level: 8 sub-regions per digit, one
+ * per XCD, cursors laid out so that a tile's 256 atomics fall into 8 lines private to its XCD); an overflowing
+ * region (skew) is flagged on the device and the caller redoes the operator with the exact form below, which is
+ * also what the stable variant (materialising N:M join) and the destination partition (multi-GPU) use.
+ *
+ * Exact form, one level = histogram -> exclusive scan -> scatter, all tile based (MDB_TILE = 4096 keys):
  *
  *   k_part_hist     per tile: LDS histogram of the level's digit, written digit-major
  *   (scan)          one exclusive scan over [segment][digit][tile] gives every tile its output
