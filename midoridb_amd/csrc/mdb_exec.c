@@ -12,14 +12,20 @@
  *   _join_nested_loop_tbl2mat :1151-1232 (3-way)       the same operator applied to the joined
  *                                                      stream (true (A x B) x C; the reference's
  *                                                      own tbl2mat is defective)
- *   proc_where_clause :1435-1463                       mdb_dev_filter over the stream
+ *   proc_where_clause :1435-1463                       mdb_dev_filter: conjuncts that read one table filter
+ *                                                      it BEFORE the join (same rows for inner joins),
+ *                                                      the rest run over the joined stream
  *   proc_groupby_clause :1526-1588                     mdb_dev_group_count over the gathered key
+ *                                                      (several fields: mdb_dev_group_count_multi)
  *   proc_select_clause :1369-1433 (projection)         mdb_dev_gather64 of the selected columns only
  *   handle_countonly_case :1590-1653                   COUNT(*) = stream length
  *   table_vacuum :1726                                 nothing to do (streams are always compact)
  *
  * plus one fused plan for the north-star shape (JOIN ... ON l = r GROUP BY that key, COUNT(*)),
- * which never materialises the joined rows (mdb_dev_join_group_count).
+ * which never materialises the joined rows (mdb_dev_join_group_count); it is chained over further
+ * tables joined on the same key and also answers SELECT COUNT(*) over such joins.  After the
+ * reference's phases come the clauses it parses but never executes - HAVING, DISTINCT, ORDER BY,
+ * LIMIT (select_tail) - and, at the end of the file, DELETE and UPDATE on the device mirror.
  *
  * Early materialisation is replaced by late materialisation: a tuple stream is a set of uint32
  * row-id vectors (one per FROM table; NULL = identity), so joins / filters / grouping move 4-byte

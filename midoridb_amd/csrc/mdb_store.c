@@ -4,9 +4,9 @@
  * Replaces, on this path, the reference's row store (reference src/primitive/: struct table with a
  * circular list of 4 KiB datablocks, 24-byte row header + 8-aligned payload, include/primitive/
  * row.h:15-28): every column is one contiguous int64_t[] / double[] plus a NULL bitmap, which is
- * exactly the layout the kernels read (include/mdb_dev.h).  INSERT appends on the host; the first
- * SELECT after a mutation re-uploads the table (generation counter) - incremental upload is a
- * "next" row.
+ * exactly the layout the kernels read (include/mdb_dev.h).  INSERT appends on the host and the next
+ * SELECT uploads only the appended tail into the device mirror (generation counter, spare capacity);
+ * DELETE and UPDATE are applied on the mirror itself (mdb_exec.c) - SURVEY.md 8f row 1.
  */
 #include "mdb_host.h"
 
