@@ -29,6 +29,7 @@ struct mdb_dev_ctx {
 	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
 	hipEvent_t ev_fork, ev_join;
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
+	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
 	 * allocates dozens of temporaries and hipMalloc/hipFree cost 0.1-0.3 ms each */
@@ -105,6 +106,18 @@ __host__ __device__ static inline uint64_t mdb_fmix64(uint64_t k)
 	k *= 0xc4ceb9fe1a85ec53ULL;
 	k ^= k >> 33;
 	return k;
+}
+
+/* murmur3 fmix32: a bijection on 32-bit words, fmix32(0) == 0.  The narrow form of the join (every key of both
+ * tables inside the int32 range) partitions and compares 32-bit hashes. */
+__host__ __device__ static inline uint32_t mdb_fmix32(uint32_t h)
+{
+	h ^= h >> 16;
+	h *= 0x85EBCA6Bu;
+	h ^= h >> 13;
+	h *= 0xC2B2AE35u;
+	h ^= h >> 16;
+	return h;
 }
 
 /* inverse of mdb_fmix64 (modular inverses of the two odd multipliers; x ^= x >> 33 is an involution

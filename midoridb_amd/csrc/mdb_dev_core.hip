@@ -68,6 +68,12 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->ev_fork = ctx->ev_join = NULL;
 	ctx->pending_op = NULL;
 	ctx->cache_bytes = 0;
+	ctx->narrow_mode = 1;
+	{
+		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
+		if (e && e[0] >= '0' && e[0] <= '2' && !e[1])
+			ctx->narrow_mode = e[0] - '0';
+	}
 	ctx->overlap = false;	/* measured: no gain on one GPU (each kernel already fills the chip), kept for the multi-GPU exchange */
 	if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -153,6 +159,14 @@ extern "C" int mdb_dev_sync(mdb_dev_ctx *ctx)
 extern "C" int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on)
 {
 	ctx->overlap = on != 0;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode)
+{
+	if (mode < 0 || mode > 2)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "narrow-key mode must be 0, 1 or 2");
+	ctx->narrow_mode = mode;
 	return MIDORIDB_OK;
 }
 

@@ -44,9 +44,11 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
  * otherwise the order inside a leaf is unspecified.  fast = skip the second level's histogram pass: every
  * leaf gets a fixed-capacity region and runs are placed with atomic cursors; if a leaf overflows, bit 1 of
  * ctx->d_status[0] is set and the caller must redo the operator with fast = false.  All temporaries and
- * outputs are carved from the arena (caller has called mdb_arena_begin with enough room).  No host sync. */
+ * outputs are carved from the arena (caller has called mdb_arena_begin with enough room).  No host sync.
+ * narrow (want_rid must be false): every key is expected inside the int32 range - a key outside raises bit 7 of
+ * ctx->d_status[0] and the caller redoes the operator wide.  1: hv[i] = fmix32(key) << 32 | row id, 2: fmix32(key) in both halves. */
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out);
+			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0);
 
 /* fast = fixed-capacity regions + cursors (a region overflow sets bit 1 of ctx->d_status[0]: the caller must check it
  * after the consumer kernel and redo with fast = false, the exact histogram layout) */

@@ -22,6 +22,7 @@
  *                                                            -> groups ordered by first L position
  *   - join output is left-major / right-minor (:1096-1141)   -> pairs ordered by (pos_l, pos_r)
  */
+#include <stdlib.h>
 #include "mdb_dev_internal.h"
 
 /* ------------------------------------------------------------------ shared leaf helpers */
@@ -112,7 +113,16 @@ struct gc_args {
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
 	uint32_t nleaves;
 	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
+	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r[j] = hash32 in both halves */
 };
+
+/* narrow word -> the 64-bit value the leaf tables work with (both halves = the 32-bit hash, so that the slot and the
+ * probe step still come from different multipliers; 0 only for the key whose hash is 0) */
+__device__ static inline uint64_t gc_narrow_hv(uint64_t w)
+{
+	const uint32_t h = (uint32_t)(w >> 32);
+	return ((uint64_t)h << 32) | h;
+}
 
 /*
  * Persistent form: gridDim.x workgroups (2 per CU) walk the leaves with stride gridDim.x.  The first
@@ -140,6 +150,30 @@ __device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t 
 	}
 }
 
+/* NW: 0 = 64-bit hashes, 1 = narrow words, 2 = whatever gc_args.narrow says (the rarely taken hot-key kernels) */
+template <int NW>
+__device__ static inline bool gc_is_narrow(const gc_args &a)
+{
+	return NW == 2 ? a.narrow != 0 : NW == 1;
+}
+
+/* The batch keeps the words as loaded (a conversion at load time would make the prefetch wait for its own loads);
+ * they are decoded where they are consumed. */
+template <bool IS_L, int NW>
+__device__ static inline uint64_t gc_batch_hv(const gc_args &a, const gc_batch &b, int u)
+{
+	/* right-side words already hold the hash in both halves (a word half nobody reads would be reused by the register
+	 * allocator while the load that writes it is still in flight, and the prefetch would wait for itself) */
+	return IS_L ? (gc_is_narrow<NW>(a) ? gc_narrow_hv(b.hv_l[u]) : b.hv_l[u]) : b.hv_r[u];
+}
+
+template <int NW>
+__device__ static inline uint32_t gc_batch_rid(const gc_args &a, const gc_batch &b, int u)
+{
+	return gc_is_narrow<NW>(a) ? (uint32_t)b.hv_l[u] : b.rid_l[u];
+}
+
+template <int NW>
 __device__ static inline void gc_load_l(const gc_args &a, uint32_t base, uint32_t end, gc_batch &b)
 {
 #pragma unroll
@@ -149,11 +183,13 @@ __device__ static inline void gc_load_l(const gc_args &a, uint32_t base, uint32_
 		b.rid_l[u] = 0;
 		if (i < end) {
 			b.hv_l[u] = a.hv_l[i];
-			b.rid_l[u] = a.rid_l[i];
+			if (!gc_is_narrow<NW>(a))
+				b.rid_l[u] = a.rid_l[i];
 		}
 	}
 }
 
+template <int NW>
 __device__ static inline void gc_load_r(const gc_args &a, uint32_t base, uint32_t end, gc_batch &b)
 {
 #pragma unroll
@@ -163,7 +199,7 @@ __device__ static inline void gc_load_r(const gc_args &a, uint32_t base, uint32_
 	}
 }
 
-template <bool HAS_R>
+template <bool HAS_R, int NW>
 __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, gc_batch &b)
 {
 #pragma unroll
@@ -173,7 +209,8 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 		b.rid_l[u] = 0;
 		if (i < l1) {
 			b.hv_l[u] = a.hv_l[i];
-			b.rid_l[u] = a.rid_l[i];
+			if (!gc_is_narrow<NW>(a))
+				b.rid_l[u] = a.rid_l[i];
 		}
 		if (HAS_R) {
 			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
@@ -183,16 +220,16 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 }
 
 /* One side of a leaf goes INTO the table (insert-or-find, count, first left row id) ... */
-template <bool IS_L>
+template <bool IS_L, int NW>
 __device__ static inline void gc_build_side(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
 					    gc_batch &b, uint32_t x0, uint32_t x1, uint32_t own[LEAF_BATCH])
 {
 	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
 		if (base != x0) {
 			if (IS_L)
-				gc_load_l(a, base, x1, b);
+				gc_load_l<NW>(a, base, x1, b);
 			else
-				gc_load_r(a, base, x1, b);
+				gc_load_r<NW>(a, base, x1, b);
 		}
 		/* first probe of every key of the batch issued back to back (the CAS round trips overlap);
 		 * only keys whose first slot is taken by another key walk on, one after the other */
@@ -202,7 +239,7 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
 			if (base == x0)
 				own[u] = 0xFFFFFFFFu;
 			act_[u] = i < x1 && hv != 0;
@@ -213,7 +250,7 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
 			if (i >= x1)
 				continue;
 			uint32_t s = GC_SLOTS;		/* the key whose hash is 0 has the side slot */
@@ -239,7 +276,7 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 			} else {
 				if (IS_L) {
 					atomicAdd(&s_cnt[s], 1ull);
-					atomicMin(&s_first[s], b.rid_l[u]);
+					atomicMin(&s_first[s], gc_batch_rid<NW>(a, b, u));
 				} else {
 					atomicAdd(&s_cnt[s], 1ull << 32);
 				}
@@ -251,23 +288,23 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 }
 
 /* ... and the other side only LOOKS UP: a key that is not in the table costs one LDS read */
-template <bool IS_L>
+template <bool IS_L, int NW>
 __device__ static inline void gc_probe_side(const gc_args &a, const unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
 					    gc_batch &b, uint32_t x0, uint32_t x1)
 {
 	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
 		if (base != x0) {
 			if (IS_L)
-				gc_load_l(a, base, x1, b);
+				gc_load_l<NW>(a, base, x1, b);
 			else
-				gc_load_r(a, base, x1, b);
+				gc_load_r<NW>(a, base, x1, b);
 		}
 		/* same shape as the build: the first slot of every key is read before any is examined */
 		uint32_t ps_[LEAF_BATCH], pstep_[LEAF_BATCH];
 		unsigned long long cur_[LEAF_BATCH];
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
-			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
 			ps_[u] = leaf_slot(hv, GC_SLOTS);
 			pstep_[u] = leaf_step(hv, GC_SLOTS);
 			cur_[u] = s_key[ps_[u]];
@@ -275,7 +312,7 @@ __device__ static inline void gc_probe_side(const gc_args &a, const unsigned lon
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
+			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
 			if (j >= x1)
 				continue;
 			uint32_t s = GC_SLOTS;
@@ -297,7 +334,7 @@ __device__ static inline void gc_probe_side(const gc_args &a, const unsigned lon
 			if (s != 0xFFFFFFFFu) {
 				if (IS_L) {
 					atomicAdd(&s_cnt[s], 1ull);
-					atomicMin(&s_first[s], b.rid_l[u]);
+					atomicMin(&s_first[s], gc_batch_rid<NW>(a, b, u));
 				} else {
 					atomicAdd(&s_cnt[s], 1ull << 32);
 				}
@@ -323,22 +360,22 @@ __device__ static inline uint32_t gc_wave_min_u32(uint32_t v)
 	return v;
 }
 
-template <bool IS_L, bool INSERT>
+template <bool IS_L, bool INSERT, int NW = 2>
 __device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
 					    gc_batch &b, uint32_t x0, uint32_t x1)
 {
 	for (uint32_t base = x0; base < x1; base += GC_THREADS * LEAF_BATCH) {
 		if (base != x0) {
 			if (IS_L)
-				gc_load_l(a, base, x1, b);
+				gc_load_l<NW>(a, base, x1, b);
 			else
-				gc_load_r(a, base, x1, b);
+				gc_load_r<NW>(a, base, x1, b);
 		}
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-			const uint64_t hv = IS_L ? b.hv_l[u] : b.hv_r[u];
-			const uint32_t rid = IS_L ? b.rid_l[u] : 0u;
+			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
+			const uint32_t rid = IS_L ? gc_batch_rid<NW>(a, b, u) : 0u;
 			const bool active = i < x1;
 			uint64_t pending = __ballot(active);
 			while (pending) {	/* wave-uniform: one round per distinct key among the wave's rows */
@@ -369,9 +406,10 @@ __device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long
 	}
 }
 
-template <bool HAS_R, bool BUILD_R, bool HEAVY>
+template <bool HAS_R, bool BUILD_R, bool HEAVY, bool NARROW = false>
 __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 {
+	constexpr int NW = HEAVY ? 2 : (NARROW ? 1 : 0);
 	/* The HEAVY instance (single-workgroup fallback of the hot-key path) only works when the plain one met hot leaves. */
 	if (HEAVY) {
 		const uint32_t st = *(volatile const uint32_t *)a.status;
@@ -408,7 +446,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
 		if (HAS_R)
 			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
-		gc_prefetch<HAS_R>(a, l0, l1, r0, r1, b);
+		gc_prefetch<HAS_R, NW>(a, l0, l1, r0, r1, b);
 	}
 	__syncthreads();
 	while (leaf < a.nleaves) {
@@ -466,24 +504,24 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 				if (HEAVY && heavy_r)
 					gc_side_heavy<false, true>(a, s_key, s_cnt, s_first, b, r0, r1);
 				else
-					gc_build_side<false>(a, s_key, s_cnt, s_first, b, r0, r1, own);
+					gc_build_side<false, NW>(a, s_key, s_cnt, s_first, b, r0, r1, own);
 				__syncthreads();
 				if (HEAVY && heavy_l)
 					gc_side_heavy<true, false>(a, s_key, s_cnt, s_first, b, l0, l1);
 				else
-					gc_probe_side<true>(a, s_key, s_cnt, s_first, b, l0, l1);
+					gc_probe_side<true, NW>(a, s_key, s_cnt, s_first, b, l0, l1);
 				__syncthreads();
 			} else {
 				if (HEAVY && heavy_l)
 					gc_side_heavy<true, true>(a, s_key, s_cnt, s_first, b, l0, l1);
 				else
-					gc_build_side<true>(a, s_key, s_cnt, s_first, b, l0, l1, own);
+					gc_build_side<true, NW>(a, s_key, s_cnt, s_first, b, l0, l1, own);
 				__syncthreads();
 				if (HAS_R) {
 					if (HEAVY && heavy_r)
 						gc_side_heavy<false, false>(a, s_key, s_cnt, s_first, b, r0, r1);
 					else
-						gc_probe_side<false>(a, s_key, s_cnt, s_first, b, r0, r1);
+						gc_probe_side<false, NW>(a, s_key, s_cnt, s_first, b, r0, r1);
 					__syncthreads();
 				}
 			}
@@ -491,7 +529,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 
 		/* request the next leaf's first batches now: they travel while this leaf is emitted */
 		if (next < a.nleaves)
-			gc_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, b);
+			gc_prefetch<HAS_R, NW>(a, nl0, nl1, nr0, nr1, b);
 
 		if (live) {
 			/* emit one COUNT(*) per group and clear the slot.  Record mode: the groups of this leaf are
@@ -679,10 +717,10 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_hot_slices(gc_args a, hot_arg
 			const uint32_t xe = is_l ? l1 : r1;
 			const uint32_t x1 = x0 + HOT_SLICE < xe ? x0 + HOT_SLICE : xe;
 			if (is_l) {
-				gc_load_l(a, x0, x1, b);
+				gc_load_l<2>(a, x0, x1, b);
 				gc_side_heavy<true, true>(a, s_key, s_cnt, s_first, b, x0, x1);
 			} else {
-				gc_load_r(a, x0, x1, b);
+				gc_load_r<2>(a, x0, x1, b);
 				gc_side_heavy<false, true>(a, s_key, s_cnt, s_first, b, x0, x1);
 			}
 			__syncthreads();
@@ -1024,6 +1062,7 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
 #define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
+#define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
 
 /* slots of the group-record list: every group once, plus the zero-filled gaps of the chunked reservation
  * (at most one leaf's worth per chunk, one unfinished chunk per workgroup) */
@@ -1040,6 +1079,7 @@ struct gc_state {
 	const uint64_t *null_l;
 	uint64_t n_l, n_r_cap;
 	bool has_r, null_group, fast, want_records, no_build_r;
+	bool narrow;		/* 32-bit hashes; the left words carry the row ids (see mdb_partition_table) */
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -1077,7 +1117,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, true, false, st->fast, &st->pl);
+	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
+				 st->narrow ? 1 : 0);
 	if (rc)
 		return rc;
 	st->active = true;
@@ -1103,7 +1144,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (has_r) {
 		if (n_r > st->n_r_cap)
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0);
 		if (rc)
 			return rc;
 	}
@@ -1150,6 +1191,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.joined = d_joined;
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
+	a.narrow = st->narrow ? 1u : 0u;
 	{
 		/* hot = far above the side's average leaf: a much larger probe table spread evenly over the leaves is not skew */
 		const uint64_t avg_l = n_l / (pl.nleaves ? pl.nleaves : 1), avg_r = has_r ? n_r / (pl.nleaves ? pl.nleaves : 1) : 0;
@@ -1161,10 +1203,16 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		if (has_r && build_r) {
+		if (has_r && build_r && st->narrow) {
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false, true>), grid, GC_THREADS, a);
+		} else if (has_r && build_r) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false>), grid, GC_THREADS, a);
+		} else if (has_r && st->narrow) {
+			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false, false, true>), grid, GC_THREADS, a);
 		} else if (has_r) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, false, false>), grid, GC_THREADS, a);
+		} else if (st->narrow) {
+			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false, false, true>), grid, GC_THREADS, a);
 		} else {
 			MDB_LAUNCH(ctx, "leaf_group_count", (k_leaf_group_count<false, false, false>), grid, GC_THREADS, a);
 		}
@@ -1185,6 +1233,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	uint32_t *first_out = out_first ? out_first : sel;
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if ((uint32_t)h[1] & 128u)
+		return GC_RETRY_WIDE;	/* a key outside the int32 range: the 32-bit hashes mean nothing */
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if ((uint32_t)h[1] & 64u) {
@@ -1281,9 +1331,64 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	return MIDORIDB_OK;
 }
 
+/* ---- narrow form: 32-bit hashes when every key of both tables lies inside the int32 range -------------------------
+ *
+ * The reference's integers are 32-bit in practice (literals go through atoi, compares through int: SURVEY D5), and a
+ * key column of such values does not need 8-byte hashes plus 4-byte row ids on its way through the two partition
+ * levels: the left side travels as ONE word (hash32 << 32 | row id), 8 instead of 12 bytes per row and pass.  Nothing
+ * is assumed: the first partition level checks every key it reads and raises status bit 7 on the first one outside the
+ * range, and the operator is then redone with 64-bit hashes (GC_RETRY_WIDE).  To keep that retry for adversarial
+ * inputs only, 2 x 4096 evenly spaced keys are looked at first (one tiny kernel + one sync, paid only by tables large
+ * enough for the bytes to matter).  mdb_dev_set_narrow_keys(): 0 never, 1 as described (default), 2 always try. */
+#define GC_NARROW_MIN_ROWS (1u << 20)
+#define GC_NARROW_SAMPLE 4096u
+
+__global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__restrict__ nl_bits, uint64_t nl,
+			     const int64_t *__restrict__ kr, const uint64_t *__restrict__ nr_bits, uint64_t nr, uint32_t *flag)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= GC_NARROW_SAMPLE)
+		return;
+	bool bad = false;
+	if (nl) {
+		const uint64_t i = (uint64_t)t * nl / GC_NARROW_SAMPLE;
+		if (!(nl_bits && mdb_bit_is_set(nl_bits, i)))
+			bad = bad || ((uint64_t)kl[i] + 0x80000000ull) >> 32;
+	}
+	if (kr && nr) {
+		const uint64_t j = (uint64_t)t * nr / GC_NARROW_SAMPLE;
+		if (!(nr_bits && mdb_bit_is_set(nr_bits, j)))
+			bad = bad || ((uint64_t)kr[j] + 0x80000000ull) >> 32;
+	}
+	if (bad)
+		atomicOr(flag, 1u);
+}
+
+static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, bool *narrow)
+{
+	*narrow = false;
+	if (ctx->narrow_mode == 0 || n_l == 0)
+		return MIDORIDB_OK;
+	if (ctx->narrow_mode == 2) {
+		*narrow = true;
+		return MIDORIDB_OK;
+	}
+	if (n_l + (keys_r ? n_r : 0) < GC_NARROW_MIN_ROWS)
+		return MIDORIDB_OK;
+	uint32_t *flag = ctx->d_status + 9;
+	MDB_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, flag);
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*narrow = h[0] == 0;
+	return MIDORIDB_OK;
+}
+
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, bool no_build_r, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   bool want_records, bool no_build_r, bool narrow, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 			   uint64_t *out_joined)
 {
 	*out_groups = 0;
@@ -1302,6 +1407,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.fast = fast;
 	st.want_records = want_records;
 	st.no_build_r = no_build_r;
+	st.narrow = narrow;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
 		return rc;
@@ -1315,12 +1421,16 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 {
 	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
-	bool fast = true, records = true, no_build_r = false;
-	int rc;
-	for (int attempt = 0; attempt < 4; attempt++) {
-		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, out_key,
-				     out_count, out_first, cap, out_groups, out_joined);
-		if (rc == GC_RETRY_EXACT)
+	bool fast = true, records = true, no_build_r = false, narrow = false;
+	int rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow);
+	if (rc)
+		return rc;
+	for (int attempt = 0; attempt < 5; attempt++) {
+		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
+				     out_key, out_count, out_first, cap, out_groups, out_joined);
+		if (rc == GC_RETRY_WIDE)
+			narrow = false;
+		else if (rc == GC_RETRY_EXACT)
 			fast = false;
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
@@ -1368,6 +1478,9 @@ extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *k
 	st->want_records = true;
 	if (n_l == 0)
 		return MIDORIDB_OK;	/* nothing to prepare; finish() returns the empty result */
+	int rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, NULL, NULL, 0, &st->narrow);	/* the right table is checked as it is partitioned */
+	if (rc)
+		return rc;
 	return gc_begin(ctx, st);
 }
 
@@ -1395,7 +1508,7 @@ extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L)	/* skew / huge counts: redo the whole operator on the safe path */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined);
 	return rc;

@@ -31,6 +31,7 @@
  * Blocks are mapped to tiles XCD-contiguously (blockIdx % 8 selects the XCD) so that adjacent
  * tiles - which extend each other's output runs - meet in the same 4 MiB L2.
  */
+#include <stdlib.h>
 #include "mdb_dev_internal.h"
 
 #define PART_THREADS 512
@@ -73,7 +74,22 @@ struct mdb_level_args {
 	uint32_t skip_zero;		/* raw sort keys: a zero word is a gap in the input list, not a key */
 	uint32_t nsub;			/* > 0: first level, child = digit * nsub + (block % nsub) sub-region; 0: child = seg * R + digit */
 	uint32_t *status;		/* bit 1 set when a child overflowed its region */
+	/* level 0, narrow form: every key must lie in the int32 range (otherwise bit 7 of *status is raised and the caller
+	 * redoes the operator in the wide form); the word written is fmix32(low 32 bits of the key) << 32, plus the row id in
+	 * the low half when narrow == 1 - hash and row id then travel as ONE 8-byte word and no row-id array exists - or
+	 * the hash once more when narrow == 2 */
+	uint32_t narrow;
 };
+
+/* level-0 word of one key */
+__device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_t key, uint32_t rid, bool *bad)
+{
+	if (!a.narrow)
+		return mdb_fmix64(key);
+	*bad = *bad || (key + 0x80000000ull) >> 32;
+	const uint32_t h = mdb_fmix32((uint32_t)key);
+	return ((uint64_t)h << 32) | (a.narrow == 1 ? rid : h);
+}
 
 __device__ static inline uint32_t part_digit(const mdb_level_args &a, uint64_t hv)
 {
@@ -117,7 +133,8 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
 	if (LEVEL0) {
 		if (a.nullbits && mdb_bit_is_set(a.nullbits, g))
 			return false;
-		*hv = mdb_fmix64((uint64_t)a.keys[g]);
+		bool bad = false;
+		*hv = part_hash_key(a, (uint64_t)a.keys[g], (uint32_t)g, &bad);
 		*rid = (uint32_t)g;
 	} else {
 		*hv = a.hv_in[g];
@@ -140,6 +157,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 	const bool in0 = e0 >= lead && e0 < lead + td.len;
 	const bool in1 = e1 < lead + td.len;	/* e1 >= 1 >= lead always */
 	const uint64_t g0 = base2 + e0;
+	bool bad[2] = { false, false };
 	hv[0] = hv[1] = 0;
 	rid[0] = rid[1] = 0;
 	valid[0] = in0;
@@ -147,8 +165,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 	if (in0 && in1) {
 		if (LEVEL0) {
 			const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
-			hv[0] = mdb_fmix64(k.x);
-			hv[1] = mdb_fmix64(k.y);
+			hv[0] = part_hash_key(a, k.x, (uint32_t)g0, &bad[0]);
+			hv[1] = part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1]);
 			rid[0] = (uint32_t)g0;
 			rid[1] = (uint32_t)g0 + 1;
 		} else {
@@ -165,7 +183,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const int k = in0 ? 0 : 1;
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
-			hv[k] = mdb_fmix64((uint64_t)a.keys[g]);
+			hv[k] = part_hash_key(a, (uint64_t)a.keys[g], (uint32_t)g, &bad[k]);
 			rid[k] = (uint32_t)g;
 		} else {
 			hv[k] = a.hv_in[g];
@@ -179,6 +197,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		if (valid[1] && mdb_bit_is_set(a.nullbits, g0 + 1))
 			valid[1] = false;
 	}
+	if (LEVEL0 && ((bad[0] && valid[0]) || (bad[1] && valid[1])))
+		atomicOr(a.status, 128u);	/* a key outside the int32 range: the narrow form does not apply */
 	if (RAW && a.skip_zero) {
 		valid[0] = valid[0] && hv[0] != 0;
 		valid[1] = valid[1] && hv[1] != 0;
@@ -582,6 +602,8 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 
 #define PART_F_STABLE 1u	/* keep input order inside every leaf (ballot ranking) */
 #define PART_F_FAST 2u		/* no histogram passes: fixed-capacity regions + atomic cursors (two-level partitions only) */
+#define PART_F_NARROW 4u	/* narrow form: words = fmix32(key) in both halves (mdb_level_args.narrow = 2) */
+#define PART_F_NARROW_RID 8u	/* narrow form with the row id in the low half of the word (narrow = 1; no row-id arrays) */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
@@ -660,6 +682,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.R = R;
 		a.mode = l == 0 ? mode : MDB_DIGIT_RADIX;
 		a.inverse_out = (inverse_out && l == nlevels - 1) ? (keys32_out ? 2u : 1u) : 0u;
+		a.narrow = l == 0 ? ((flags & PART_F_NARROW_RID) ? 1u : ((flags & PART_F_NARROW) ? 2u : 0u)) : 0u;
+		a.status = ctx ? ctx->d_status : NULL;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
 			a.shift = (uint32_t)(64 - used_bits - b);
@@ -811,8 +835,10 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			bool want_rid, bool stable, bool fast, mdb_part_result *out)
+			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow)
 {
+	if (narrow && (stable || want_rid))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "narrow partitioning carries row ids inside the word");
 	if (n >= 0xFFFFFFFFull)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "table of %llu rows exceeds the 32-bit row-id limit of one GPU shard",
 				   (unsigned long long)n);
@@ -821,7 +847,9 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "stable partitioning is only built with row ids");
 	if ((uintptr_t)keys & 15)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
-	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid, (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u),
+	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
+			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
+				      (narrow == 2 ? PART_F_NARROW : 0u),
 			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out);
 }
 
