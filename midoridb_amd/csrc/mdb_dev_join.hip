@@ -113,7 +113,7 @@ struct gc_args {
 	uint32_t *status;		/* bit 0: a leaf table overflowed */
 	uint32_t nleaves;
 	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
-	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r[j] = hash32 in both halves */
+	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r = array of 4-byte hash32 */
 };
 
 /* narrow word -> the 64-bit value the leaf tables work with (both halves = the 32-bit hash, so that the slot and the
@@ -135,6 +135,7 @@ struct gc_batch {
 	uint64_t hv_l[LEAF_BATCH];
 	uint32_t rid_l[LEAF_BATCH];
 	uint64_t hv_r[LEAF_BATCH];
+	uint32_t h32_r[LEAF_BATCH];	/* narrow form: the right side's 4-byte words */
 };
 
 __device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t *cnt, uint32_t cap, uint32_t leaf, uint32_t *b,
@@ -162,9 +163,11 @@ __device__ static inline bool gc_is_narrow(const gc_args &a)
 template <bool IS_L, int NW>
 __device__ static inline uint64_t gc_batch_hv(const gc_args &a, const gc_batch &b, int u)
 {
-	/* right-side words already hold the hash in both halves (a word half nobody reads would be reused by the register
-	 * allocator while the load that writes it is still in flight, and the prefetch would wait for itself) */
-	return IS_L ? (gc_is_narrow<NW>(a) ? gc_narrow_hv(b.hv_l[u]) : b.hv_l[u]) : b.hv_r[u];
+	if (!gc_is_narrow<NW>(a))
+		return IS_L ? b.hv_l[u] : b.hv_r[u];
+	if (IS_L)
+		return gc_narrow_hv(b.hv_l[u]);
+	return ((uint64_t)b.h32_r[u] << 32) | b.h32_r[u];	/* right side: 4-byte words */
 }
 
 template <int NW>
@@ -195,7 +198,13 @@ __device__ static inline void gc_load_r(const gc_args &a, uint32_t base, uint32_
 #pragma unroll
 	for (int u = 0; u < LEAF_BATCH; u++) {
 		const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-		b.hv_r[u] = j < end ? a.hv_r[j] : 0;
+		if (gc_is_narrow<NW>(a)) {
+			b.h32_r[u] = 0;
+			if (j < end)
+				b.h32_r[u] = reinterpret_cast<const uint32_t *>(a.hv_r)[j];
+		} else {
+			b.hv_r[u] = j < end ? a.hv_r[j] : 0;
+		}
 	}
 }
 
@@ -214,7 +223,13 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 		}
 		if (HAS_R) {
 			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
-			b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
+			if (gc_is_narrow<NW>(a)) {
+				b.h32_r[u] = 0;
+				if (j < r1)
+					b.h32_r[u] = reinterpret_cast<const uint32_t *>(a.hv_r)[j];
+			} else {
+				b.hv_r[u] = j < r1 ? a.hv_r[j] : 0;
+			}
 		}
 	}
 }
@@ -1094,6 +1109,9 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 				   "%llu build rows exceed what one GPU shard groups in LDS (about %llu): partition the tables across GPUs "
 				   "(mdb_dev_partition_by_dest)",
 				   (unsigned long long)st->n_l, (unsigned long long)(((uint64_t)GC_SLOTS * 7 / 10) << (2 * MDB_MAX_RADIX_BITS)));
+	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
+	if (st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
+		st->narrow = false;
 	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->has_r)
 		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
@@ -1144,6 +1162,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (has_r) {
 		if (n_r > st->n_r_cap)
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
+		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
+			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
 		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0);
 		if (rc)
 			return rc;
@@ -1431,7 +1451,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		if (rc == GC_RETRY_WIDE)
 			narrow = false;
 		else if (rc == GC_RETRY_EXACT)
-			fast = false;
+			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
 		else if (rc == GC_RETRY_BUILD_L)

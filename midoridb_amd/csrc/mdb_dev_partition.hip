@@ -32,6 +32,7 @@
  * tiles - which extend each other's output runs - meet in the same 4 MiB L2.
  */
 #include <stdlib.h>
+#include <type_traits>
 #include "mdb_dev_internal.h"
 
 #define PART_THREADS 512
@@ -91,10 +92,11 @@ __device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_
 	return ((uint64_t)h << 32) | (a.narrow == 1 ? rid : h);
 }
 
-__device__ static inline uint32_t part_digit(const mdb_level_args &a, uint64_t hv)
+template <typename W>
+__device__ static inline uint32_t part_digit(const mdb_level_args &a, W hv)
 {
 	if (a.mode == MDB_DIGIT_RADIX)
-		return (uint32_t)(hv >> a.shift) & (a.R - 1);
+		return (uint32_t)(hv >> a.shift) & (a.R - 1);	/* a.shift counts from the width of W */
 	return (uint32_t)hv % a.R;
 }
 
@@ -205,6 +207,29 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 	}
 }
 
+/* 4-byte words (the right side of the narrow form beyond level 0): the four adjacent elements 4p .. 4p+3 relative to
+ * the 4-aligned base of the tile, one 16-byte access when all belong to the tile */
+__device__ static inline void part_load4_w32(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint32_t hv[4], bool valid[4])
+{
+	const uint32_t lead = td.start & 3u;
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(a.hv_in) + (uint64_t)(td.start - lead) + 4 * (uint64_t)p;
+	const uint32_t e0 = 4 * p, end = lead + td.len;
+	if (e0 >= lead && e0 + 3 < end) {
+		const uint4 q = *reinterpret_cast<const uint4 *>(src);
+		hv[0] = q.x;
+		hv[1] = q.y;
+		hv[2] = q.z;
+		hv[3] = q.w;
+		valid[0] = valid[1] = valid[2] = valid[3] = true;
+		return;
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		valid[k] = e0 + k >= lead && e0 + k < end;
+		hv[k] = valid[k] ? src[k] : 0u;
+	}
+}
+
 template <bool LEVEL0, bool RAW = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 {
@@ -243,14 +268,18 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	/* W32: the words staged and written are 4-byte hashes (narrow form, right side: level 0 reads 8-byte keys and
+	 * writes 4-byte words, level 1 reads and writes 4-byte words); never with row ids */
+	static_assert(!W32 || (!HAS_RID && !STABLE && FAST && !RAW), "4-byte words: unordered FAST form without row ids only");
+	typedef typename std::conditional<W32, uint32_t, uint64_t>::type W;
 	/* Row ids are staged through the SAME LDS as the hashes, after the hashes have been written out (unordered
 	 * form only): 35 KiB instead of 51 KiB per workgroup = 4 instead of 3 workgroups per CU, worth ~25 % of the
 	 * kernel's time (occupancy is what hides the HBM latency of the scattered runs) */
 	constexpr bool RID_SHARES_LDS = HAS_RID && !STABLE;
-	__shared__ uint64_t s_hv[MDB_TILE];
+	__shared__ W s_hv[MDB_TILE];
 	__shared__ uint32_t s_rid_own[(HAS_RID && !RID_SHARES_LDS) ? MDB_TILE : 1];
 	uint32_t *const s_rid = RID_SHARES_LDS ? reinterpret_cast<uint32_t *>(s_hv) : s_rid_own;
 	__shared__ uint32_t s_cnt[PART_MAX_R];		/* per-digit counters, then tile-local digit starts */
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 
 	/* 1. load (coalesced).  STABLE: wave w owns the 512 consecutive keys [w*512, w*512+512), so that
 	 *    (wave, round, lane) order is input order; otherwise consecutive threads, consecutive keys. */
-	uint64_t hv[PART_ITEMS];
+	W hv[PART_ITEMS];
 	uint32_t rid[PART_ITEMS];
 	uint32_t dig[PART_ITEMS];
 	uint32_t rank[PART_ITEMS];
@@ -282,17 +311,34 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		for (int r = 0; r < PART_ITEMS; r++) {
 			const uint32_t i = wave * PART_WAVE_SPAN + (uint32_t)r * MDB_WAVE + lane;
 			bool valid = i < td.len;
-			hv[r] = 0;
+			uint64_t h = 0;
 			rid[r] = 0;
 			if (valid)
-				valid = part_load<LEVEL0>(a, td, i, &hv[r], &rid[r]);
+				valid = part_load<LEVEL0>(a, td, i, &h, &rid[r]);
+			hv[r] = (W)h;
 			dig[r] = valid ? part_digit(a, hv[r]) : PART_INVALID;
+		}
+	} else if (W32 && !LEVEL0) {
+#pragma unroll
+		for (int r = 0; r < PART_ITEMS / 4; r++) {
+			uint32_t h4[4];
+			bool valid[4];
+			part_load4_w32(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h4, valid);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				hv[4 * r + k] = (W)h4[k];
+				rid[4 * r + k] = 0;
+				dig[4 * r + k] = valid[k] ? part_digit(a, hv[4 * r + k]) : PART_INVALID;
+			}
 		}
 	} else {
 #pragma unroll
 		for (int r = 0; r < PART_ITEMS / 2; r++) {
 			bool valid[2];
-			part_load2<LEVEL0, HAS_RID, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, &hv[2 * r], &rid[2 * r], valid);
+			uint64_t h2[2];
+			part_load2<LEVEL0, HAS_RID, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
+			hv[2 * r] = (W)h2[0];		/* W32 at level 0: the narrow word holds the hash in both halves */
+			hv[2 * r + 1] = (W)h2[1];
 			dig[2 * r] = valid[0] ? part_digit(a, hv[2 * r]) : PART_INVALID;
 			dig[2 * r + 1] = valid[1] ? part_digit(a, hv[2 * r + 1]) : PART_INVALID;
 		}
@@ -400,13 +446,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		gpos[k] = PART_INVALID;
 		if (i >= tile_total)
 			continue;
-		const uint64_t h = s_hv[i];
+		const W h = s_hv[i];
 		const uint32_t d = part_digit(a, h);
 		if (FAST && !s_ok[d])
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
 		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
 		gpos[k] = g;
-		if (a.inverse_out == 2)
+		if (W32)
+			reinterpret_cast<uint32_t *>(a.hv_out)[g] = (uint32_t)h;
+		else if (a.inverse_out == 2)
 			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)mdb_fmix64_inv(h);
 		else
 			a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
@@ -636,6 +684,11 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
 	const uint32_t cap0 = (uint32_t)((((n + nreg0_used - 1) / nreg0_used) * 5 / 4 + 1024 + 63) & ~63ull);
 	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0 * cap0 < 0xFFFFFFFFull;
+	/* narrow form without row ids (right side of a join): 4-byte words from the first level's output on; only built for
+	 * the histogram-free layout of both levels (callers ask mdb_partition_w32_applies() first) */
+	const bool w32 = (flags & PART_F_NARROW) && fast0 && fast;
+	if ((flags & PART_F_NARROW) && !w32 && !dry)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "narrow partitioning without row ids needs the two-level fast layout");
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
@@ -645,7 +698,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		if (l == nlevels - 1 && final_hv_out)
 			hv_buf[l] = final_hv_out;	/* last level writes straight into the caller's buffer */
 		else
-			hv_buf[l] = (uint64_t *)cv.take(elems * 8);
+			hv_buf[l] = (uint64_t *)cv.take(elems * (w32 ? 4 : 8));
 		if (want_rid)
 			rid_buf[l] = (l == nlevels - 1 && final_rid_out) ? final_rid_out : (uint32_t *)cv.take(elems * 4);
 	}
@@ -686,7 +739,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.status = ctx ? ctx->d_status : NULL;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
-			a.shift = (uint32_t)(64 - used_bits - b);
+			a.shift = (uint32_t)((w32 ? 32 : 64) - used_bits - b);
 			a.mbits = (uint32_t)b;
 		} else {
 			uint32_t mb = 1;
@@ -712,6 +765,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
 				if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
+				} else if (w32) {
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else {
@@ -744,6 +799,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						   PART_THREADS, a);
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true, true>), grid8(ntiles),
+						   PART_THREADS, a);
+				} else if (w32) {
+					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
@@ -823,6 +881,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		out->leaf_cap = fast ? fast_cap : 0;
 		out->nleaves = S;
 		out->bits_total = (uint32_t)used_bits;
+		out->w32 = w32;
 	}
 	return MIDORIDB_OK;
 }
@@ -832,6 +891,16 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 	part_carver cv = { NULL, true, 0, false };
 	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
 	return cv.bytes + 4096;
+}
+
+bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast)
+{
+	part_carver cv = { NULL, true, 0, false };
+	mdb_part_result res;
+	memset(&res, 0, sizeof(res));
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, false, (fast ? PART_F_FAST : 0u) | PART_F_NARROW, MDB_DIGIT_RADIX, 0, false, NULL,
+			     NULL, 0, &res);
+	return res.w32;
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
