@@ -240,10 +240,11 @@ def main():
         pass
 
     if rank == 0:
+        narrow = dev.last_join_narrow()
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
         for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
             if d["ms_per_step"] > 0:
-                d["algorithmic_GBs"] = (shuffle.algorithmic_bytes(k, n, groups_total / max(world, 1)) * d["launches_per_step"]
+                d["algorithmic_GBs"] = (shuffle.algorithmic_bytes(k, n, groups_total / max(world, 1), narrow) * d["launches_per_step"]
                                         / (d["ms_per_step"] * 1e-3) / 1e9)
         # dominant kernel = the level-0/1 scatter; algorithmic bytes of one launch = every key it moves,
         # read once (8 B hashed key [+4 B row id]) and written once
@@ -253,7 +254,7 @@ def main():
             d = kern[dom_name]
             launches = max(d["launches_per_step"], 1e-9)
             avg_ms = d["ms_per_step"] / launches
-            bytes_per_launch = shuffle.algorithmic_bytes(dom_name, n, groups_total / max(world, 1))
+            bytes_per_launch = shuffle.algorithmic_bytes(dom_name, n, groups_total / max(world, 1), narrow)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
@@ -270,6 +271,7 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU, variant {args.variant} "
                                    f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
+                       "key_form": "narrow (int32-range keys verified on the device: 32-bit hashes)" if narrow else "wide (64-bit hashes)",
                        "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
                        "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")

@@ -62,6 +62,8 @@ int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on);
  * range makes the operator redo its work with 64-bit hashes; results are identical either way.
  * mode 0: never; 1 (default): when a sample of both key columns fits, tables of 2^20 rows or more; 2: always try. */
 int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode);
+/* 1 when the last completed join / GROUP BY operator of this context ran in the narrow form (for byte accounting) */
+int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory */

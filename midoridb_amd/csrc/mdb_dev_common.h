@@ -29,6 +29,7 @@ struct mdb_dev_ctx {
 	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
 	hipEvent_t ev_fork, ev_join;
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
+	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query

@@ -69,6 +69,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->pending_op = NULL;
 	ctx->cache_bytes = 0;
 	ctx->narrow_mode = 1;
+	ctx->last_narrow = 0;
 	{
 		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
 		if (e && e[0] >= '0' && e[0] <= '2' && !e[1])
@@ -160,6 +161,11 @@ extern "C" int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on)
 {
 	ctx->overlap = on != 0;
 	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx)
+{
+	return ctx->last_narrow;
 }
 
 extern "C" int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode)

@@ -1348,6 +1348,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	*out_groups = G;
 	if (out_joined)
 		*out_joined = joined;
+	ctx->last_narrow = st->narrow ? 1 : 0;
 	return MIDORIDB_OK;
 }
 

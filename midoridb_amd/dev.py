@@ -51,6 +51,7 @@ def _bind(lib):
         "mdb_dev_reserve": ([P, c_size_t], c_int),
         "mdb_dev_set_overlap": ([P, c_int], c_int),
         "mdb_dev_set_narrow_keys": ([P, c_int], c_int),
+        "mdb_dev_last_join_narrow": ([P], c_int),
         "mdb_dev_arena_bytes": ([P], c_size_t),
         "mdb_dev_alloc": ([P, c_size_t, POINTER(P)], c_int),
         "mdb_dev_free": ([P, P], c_int),
@@ -92,7 +93,7 @@ def _bind(lib):
 
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
-    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
@@ -179,6 +180,9 @@ class DeviceCtx:
 
     def set_overlap(self, on=True):
         self._chk(self.lib.mdb_dev_set_overlap(self.h, 1 if on else 0), "set_overlap")
+
+    def last_join_narrow(self):
+        return bool(self.lib.mdb_dev_last_join_narrow(self.h))
 
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""

@@ -156,12 +156,24 @@ class DistributedJoinGroupCount:
         return k.numel() if hasattr(k, "numel") else len(k), j
 
 
-def algorithmic_bytes(kernel, n, groups):
+def algorithmic_bytes(kernel, n, groups, narrow=False):
     """Algorithmic HBM bytes of ONE launch of `kernel` on tables of n rows per GPU producing `groups`
     result groups: what the launch must read once and write once, independent of how it is
     implemented.  A partition kernel name covers the launch for table A (carries 4-byte row ids) and the
-    one for table B (keys only); the figure is their average."""
+    one for table B (keys only); the figure is their average.  narrow: the form for int32-range keys (the left
+    side's hash and row id share one 8-byte word, the right side is a 4-byte hash after level 0) - fewer bytes
+    have to move, and the figure says so rather than crediting the kernels with the wide form's bytes."""
     key, rid, g = 8 * n, 4 * n, groups
+    if narrow:
+        h32 = 4 * n
+        table = {
+            "part_scatter_l0": ((key + key) + (key + h32)) / 2,            # read key; write hash|row id (A), 4-byte hash (B)
+            "part_scatter_l1": ((2 * key) + (2 * h32)) / 2,
+            "leaf_join_group_count": key + h32 + 8 * g,
+            "leaf_group_count": key + 8 * g,
+        }
+        if kernel in table:
+            return float(table[kernel])
     table = {
         "part_hist_l0": key,                                            # read the raw keys
         "part_scatter_l0": ((key + key + rid) + (key + key)) / 2,      # read key, write hash (+ row id)
