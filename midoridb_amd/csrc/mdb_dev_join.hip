@@ -552,8 +552,13 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 			 * afterwards by a radix sort on the first row id; dense mode: COUNT(*) is scattered to the
 			 * group's first row position (8-byte random writes, only kept as a fallback). */
 			const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
+			/* owner mode: one round per register-batch element, plus one for the side slot of the hash-0 key in the
+			 * single leaf that holds it (a wave that reads the flag after thread 0 cleared it has nothing to do there) */
+			const int iters = by_owner ? (s_cnt[GC_SLOTS] != 0ull ? LEAF_BATCH + 1 : LEAF_BATCH) : GC_EMIT_ITERS;
 #pragma unroll
 			for (int it = 0; it < GC_EMIT_ITERS; it++) {
+				if (it >= iters)
+					break;
 				unsigned long long recv = 0;
 				uint32_t s = 0xFFFFFFFFu;
 				if (by_owner) {

@@ -699,3 +699,42 @@ def test_narrow_form_large_property(dev, narrow_mode):
     for a, b in zip(out[0][:3], out[1][:3]):
         assert torch.equal(a, b)
     assert out[0][3] == out[1][3] == n
+
+
+@pytest.mark.parametrize("case", ["narrow_both", "right_wide", "left_wide", "right_all_null", "right_tiny", "right_empty_leaves"])
+def test_narrow_form_split_begin_finish_and_ragged_right_sides(dev, narrow_mode, case):
+    """The split operator decides the form from the left table alone at begin(); a right table with a key outside the
+    int32 range (seen only while it is partitioned at finish()) makes the whole operator run again wide.  Right sides
+    that leave most 4-byte leaf regions empty or hold NULLs only go through the same kernels."""
+    narrow_mode(2)
+    rng = np.random.default_rng(len(case))
+    n_l, n_r = 1_100_000, 700_000
+    kl = rng.integers(-400_000, 400_000, n_l, dtype=np.int64)
+    kr = rng.integers(-400_000, 400_000, n_r, dtype=np.int64)
+    nl = rng.random(n_l) < 0.01
+    nr = None
+    if case == "right_wide":
+        kr[n_r // 3] = 2**33 + 7
+    elif case == "left_wide":
+        kl[n_l // 5] = -2**35
+    elif case == "right_all_null":
+        nr = np.ones(n_r, dtype=bool)
+    elif case == "right_tiny":
+        kr, n_r = kr[:37].copy(), 37
+    elif case == "right_empty_leaves":
+        kr = rng.integers(100, 164, n_r, dtype=np.int64)          # 64 distinct keys: hot leaves, the rest empty
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dnl, dr, dnr = dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr)
+    for split in (False, True):
+        if split:
+            dev.join_group_count_begin(dl, dnl, n_r + 100)
+            k, c, f, j = dev.join_group_count_finish(dr, dnr)
+        else:
+            k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert j == ej
+        assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    if case == "narrow_both":
+        assert dev.last_join_narrow()
+    if case in ("right_wide", "left_wide"):
+        assert not dev.last_join_narrow()
