@@ -29,6 +29,11 @@ struct mdb_dev_ctx {
 	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
 	hipEvent_t ev_fork, ev_join;
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
+	/* outcome of the last narrow-form decision, keyed by the key columns it was made for: a repeated query over the same
+	 * columns skips the sampling kernel and its sync (every key is still verified while it is partitioned) */
+	const void *nh_kl, *nh_kr;
+	uint64_t nh_nl, nh_nr;
+	int nh_result;			/* -1 nothing remembered, 0 wide, 1 narrow */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */

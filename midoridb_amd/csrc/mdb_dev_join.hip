@@ -1390,6 +1390,15 @@ __global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__r
 		atomicOr(flag, 1u);
 }
 
+static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow)
+{
+	ctx->nh_kl = keys_l;
+	ctx->nh_nl = n_l;
+	ctx->nh_kr = keys_r;
+	ctx->nh_nr = keys_r ? n_r : 0;
+	ctx->nh_result = narrow ? 1 : 0;
+}
+
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			   const uint64_t *null_r, uint64_t n_r, bool *narrow)
 {
@@ -1402,6 +1411,10 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	}
 	if (n_l + (keys_r ? n_r : 0) < GC_NARROW_MIN_ROWS)
 		return MIDORIDB_OK;
+	if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
+		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
+		return MIDORIDB_OK;
+	}
 	uint32_t *flag = ctx->d_status + 9;
 	MDB_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
 	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, flag);
@@ -1409,6 +1422,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	MDB_HIP(ctx, hipMemcpyAsync(h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*narrow = h[0] == 0;
+	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow);
 	return MIDORIDB_OK;
 }
 
@@ -1454,9 +1468,11 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	for (int attempt = 0; attempt < 5; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
 				     out_key, out_count, out_first, cap, out_groups, out_joined);
-		if (rc == GC_RETRY_WIDE)
+		if (rc == GC_RETRY_WIDE) {
 			narrow = false;
-		else if (rc == GC_RETRY_EXACT)
+			if (ctx->narrow_mode == 1)
+				gc_narrow_note(ctx, keys_l, n_l, has_r ? keys_r : NULL, n_r, false);	/* the sample missed a wide key */
+		} else if (rc == GC_RETRY_EXACT)
 			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;

@@ -738,3 +738,24 @@ def test_narrow_form_split_begin_finish_and_ragged_right_sides(dev, narrow_mode,
         assert dev.last_join_narrow()
     if case in ("right_wide", "left_wide"):
         assert not dev.last_join_narrow()
+
+
+def test_narrow_form_decision_is_remembered_per_column_but_every_key_is_still_checked(dev, narrow_mode):
+    """Second query over the same key columns skips the sampling kernel; when the column's contents changed in place
+    (a key outside the int32 range now), the level-0 check still sends the operator to the wide form - and the
+    remembered decision flips, so the third query goes wide directly."""
+    narrow_mode(1)
+    rng = np.random.default_rng(5)
+    n = 1_200_000
+    kl = rng.integers(0, 300_000, n, dtype=np.int64)
+    kr = rng.integers(0, 300_000, n, dtype=np.int64)
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    for round_ in range(4):
+        if round_ == 2:
+            kl[n // 2] = 2**40
+            dl[n // 2] = 2**40
+        ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+        assert dev.last_join_narrow() == (round_ < 2)
