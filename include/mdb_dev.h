@@ -277,6 +277,18 @@ int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, con
 				    uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 				    uint64_t *out_groups, uint64_t *out_joined);
 
+/* The same operator over int32 key columns - what the other GPUs' keys look like on arrival when they crossed xGMI in
+ * the 4-byte wire format (mdb_dev_partition_by_dest with keys32): the first partition level reads the 4-byte keys
+ * directly, no widening pass.  No NULL bitmaps (NULL keys never leave their GPU); 8-byte aligned columns.
+ * out_key[] is int64 like everywhere else. */
+int mdb_dev_join_group_count_i32(mdb_dev_ctx *ctx, const int32_t *keys_l, uint64_t n_l, const int32_t *keys_r, uint64_t n_r,
+				 uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+				 uint64_t *out_groups, uint64_t *out_joined);
+int mdb_dev_join_group_count_begin_i32(mdb_dev_ctx *ctx, const int32_t *keys_l, uint64_t n_l, uint64_t n_r_max);
+int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32_t *keys_r, uint64_t n_r, uint32_t flags, int64_t *out_key,
+					int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+					uint64_t *out_joined);
+
 /* ------------------------------------------------------------------ multi-GPU shuffle support
  *
  * Hash-partition a key column by destination GPU for the all-to-all exchange

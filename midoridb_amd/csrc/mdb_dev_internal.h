@@ -50,7 +50,8 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
  * ctx->d_status[0] and the caller redoes the operator wide.  1: hv[i] = fmix32(key) << 32 | row id, 2: hv is an array of 4-byte words fmix32(key) - only in the
  * two-level fast layout, see mdb_partition_w32_applies(). */
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
-			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0);
+			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0,
+			bool keys32 = false);	/* keys32: `keys` points to int32 values */
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

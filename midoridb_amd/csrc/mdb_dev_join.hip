@@ -91,6 +91,13 @@ __device__ static inline uint32_t leaf_find(const unsigned long long *keys, uint
 	return 0xFFFFFFFFu;
 }
 
+__global__ void k_gather_i32(const int32_t *__restrict__ keys, const uint32_t *__restrict__ sel, uint64_t n, int64_t *__restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		out[i] = (int64_t)keys[sel[i]];
+}
+
 /* ------------------------------------------------------------------ fused join + group count */
 
 struct gc_args {
@@ -901,6 +908,7 @@ struct ord_args {
 	uint32_t *out_val32;		/* ... payload - 1 as uint32 (right row id of a join pair) */
 	const int64_t *keys;		/* optional: key column to gather the group keys from ... */
 	int64_t *out_key;		/* ... into here (keys[first]) */
+	uint32_t keys32;		/* `keys` is an int32 column */
 };
 
 __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 		else
 			a.out_count[base + i] = (int64_t)(v & ((1ull << 51) - 1ull));
 		if (a.out_key)
-			a.out_key[base + i] = a.keys[first];
+			a.out_key[base + i] = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[first] : a.keys[first];
 	}
 }
 
@@ -997,7 +1005,8 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
  * histogram-free regions first; if one overflows (the gaps of the list can bunch the records of one XCD's tile
  * range) the exact layout redoes the sort.  Synchronises. */
 static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
-			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key)
+			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,
+			 bool keys32 = false)
 {
 	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
 	uint64_t *h = ctx->h_pinned;
@@ -1021,6 +1030,7 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 		oa.out_val32 = out_val32;
 		oa.keys = keys;
 		oa.out_key = out_key;
+		oa.keys32 = keys32 ? 1u : 0u;
 		if (ps.leaf_cap) {
 			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
 			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
@@ -1100,6 +1110,7 @@ struct gc_state {
 	uint64_t n_l, n_r_cap;
 	bool has_r, null_group, fast, want_records, no_build_r;
 	bool narrow;		/* 32-bit hashes; the left words carry the row ids (see mdb_partition_table) */
+	bool keys32;		/* both key columns are int32 arrays (received over xGMI in the 4-byte wire format) */
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -1141,7 +1152,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
-				 st->narrow ? 1 : 0);
+				 st->narrow ? 1 : 0, st->keys32);
 	if (rc)
 		return rc;
 	st->active = true;
@@ -1169,7 +1180,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
 		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
 			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32);
 		if (rc)
 			return rc;
 	}
@@ -1334,14 +1345,17 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key);
+		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32);
 		if (rc)
 			return rc;
 	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
 		if (rc)
 			return rc;
-		if (out_key) {
+		if (out_key && st->keys32) {
+			MDB_LAUNCH(ctx, "gather_i32", k_gather_i32, (uint32_t)((G + 255) / 256), 256, reinterpret_cast<const int32_t *>(keys_l), sel, G,
+				   out_key);
+		} else if (out_key) {
 			rc = mdb_dev_gather64(ctx, keys_l, NULL, sel, G, out_key, NULL);
 			if (rc)
 				return rc;
@@ -1428,7 +1442,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, bool no_build_r, bool narrow, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   bool want_records, bool no_build_r, bool narrow, bool keys32, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 			   uint64_t *out_joined)
 {
 	*out_groups = 0;
@@ -1448,6 +1462,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.want_records = want_records;
 	st.no_build_r = no_build_r;
 	st.narrow = narrow;
+	st.keys32 = keys32;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
 		return rc;
@@ -1457,20 +1472,24 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			      const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group,
 			      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
-			      uint64_t *out_joined)
+			      uint64_t *out_joined, bool keys32 = false)
 {
 	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
-	int rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow);
+	int rc = MIDORIDB_OK;
+	if (keys32)
+		narrow = ctx->narrow_mode != 0;		/* int32 columns: nothing to sample */
+	else
+		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow);
 	if (rc)
 		return rc;
 	for (int attempt = 0; attempt < 5; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
-				     out_key, out_count, out_first, cap, out_groups, out_joined);
+				     keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
 		if (rc == GC_RETRY_WIDE) {
 			narrow = false;
-			if (ctx->narrow_mode == 1)
+			if (ctx->narrow_mode == 1 && !keys32)
 				gc_narrow_note(ctx, keys_l, n_l, has_r ? keys_r : NULL, n_r, false);	/* the sample missed a wide key */
 		} else if (rc == GC_RETRY_EXACT)
 			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
@@ -1503,8 +1522,7 @@ static gc_state *gc_pending(mdb_dev_ctx *ctx)
 	return (gc_state *)ctx->pending_op;
 }
 
-extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
-					      uint64_t n_r_max)
+static int gc_split_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, uint64_t n_r_max, bool keys32)
 {
 	gc_state *st = gc_pending(ctx);
 	if (!st)
@@ -1518,22 +1536,27 @@ extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *k
 	st->null_group = false;
 	st->fast = true;
 	st->want_records = true;
+	st->keys32 = keys32;
 	if (n_l == 0)
 		return MIDORIDB_OK;	/* nothing to prepare; finish() returns the empty result */
-	int rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, NULL, NULL, 0, &st->narrow);	/* the right table is checked as it is partitioned */
+	int rc = MIDORIDB_OK;
+	if (keys32)
+		st->narrow = ctx->narrow_mode != 0;
+	else
+		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, NULL, NULL, 0, &st->narrow);	/* the right table is checked as it is partitioned */
 	if (rc)
 		return rc;
 	return gc_begin(ctx, st);
 }
 
-extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
-					       uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first,
-					       uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, int64_t *out_key,
+			   int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined, bool keys32)
 {
-	(void)flags;
 	gc_state *st = gc_pending(ctx);
 	if (!st || !st->keys_l)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join_group_count_finish without begin");
+	if (st->keys32 != keys32)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join_group_count_finish: key width differs from begin()");
 	const int64_t *keys_l = st->keys_l;
 	const uint64_t *null_l = st->null_l;
 	const uint64_t n_l = st->n_l;
@@ -1552,8 +1575,47 @@ extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *
 	st->keys_l = NULL;
 	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
-					cap, out_groups, out_joined);
+					cap, out_groups, out_joined, keys32);
 	return rc;
+}
+
+extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+					      uint64_t n_r_max)
+{
+	return gc_split_begin(ctx, keys_l, null_l, n_l, n_r_max, false);
+}
+
+extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
+					       uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first,
+					       uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	(void)flags;
+	return gc_split_finish(ctx, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined, false);
+}
+
+/* ---- int32 key columns (what arrives over xGMI in the 4-byte wire format): same operator, no widening pass ---- */
+
+extern "C" int mdb_dev_join_group_count_i32(mdb_dev_ctx *ctx, const int32_t *keys_l, uint64_t n_l, const int32_t *keys_r, uint64_t n_r,
+					    uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+					    uint64_t *out_groups, uint64_t *out_joined)
+{
+	(void)flags;
+	return group_count_common(ctx, reinterpret_cast<const int64_t *>(keys_l), NULL, n_l, reinterpret_cast<const int64_t *>(keys_r), NULL,
+				  n_r, true, false, out_key, out_count, out_first, cap, out_groups, out_joined, true);
+}
+
+extern "C" int mdb_dev_join_group_count_begin_i32(mdb_dev_ctx *ctx, const int32_t *keys_l, uint64_t n_l, uint64_t n_r_max)
+{
+	return gc_split_begin(ctx, reinterpret_cast<const int64_t *>(keys_l), NULL, n_l, n_r_max, true);
+}
+
+extern "C" int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32_t *keys_r, uint64_t n_r, uint32_t flags,
+						   int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
+						   uint64_t *out_groups, uint64_t *out_joined)
+{
+	(void)flags;
+	return gc_split_finish(ctx, reinterpret_cast<const int64_t *>(keys_r), NULL, n_r, out_key, out_count, out_first, cap, out_groups,
+			       out_joined, true);
 }
 
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,

@@ -80,6 +80,7 @@ struct mdb_level_args {
 	 * the low half when narrow == 1 - hash and row id then travel as ONE 8-byte word and no row-id array exists - or
 	 * the hash once more when narrow == 2 */
 	uint32_t narrow;
+	uint32_t keys32;		/* level 0: `keys` is an array of int32 (keys that crossed xGMI in the 4-byte wire format) */
 };
 
 /* level-0 word of one key */
@@ -136,7 +137,8 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
 		if (a.nullbits && mdb_bit_is_set(a.nullbits, g))
 			return false;
 		bool bad = false;
-		*hv = part_hash_key(a, (uint64_t)a.keys[g], (uint32_t)g, &bad);
+		const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
+		*hv = part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad);
 		*rid = (uint32_t)g;
 	} else {
 		*hv = a.hv_in[g];
@@ -166,7 +168,14 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 	valid[1] = in1;
 	if (in0 && in1) {
 		if (LEVEL0) {
-			const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
+			ulonglong2 k;
+			if (a.keys32) {
+				const int2 q = *reinterpret_cast<const int2 *>(reinterpret_cast<const int32_t *>(a.keys) + g0);
+				k.x = (uint64_t)(int64_t)q.x;
+				k.y = (uint64_t)(int64_t)q.y;
+			} else {
+				k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
+			}
 			hv[0] = part_hash_key(a, k.x, (uint32_t)g0, &bad[0]);
 			hv[1] = part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1]);
 			rid[0] = (uint32_t)g0;
@@ -185,7 +194,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const int k = in0 ? 0 : 1;
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
-			hv[k] = part_hash_key(a, (uint64_t)a.keys[g], (uint32_t)g, &bad[k]);
+			const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
+			hv[k] = part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k]);
 			rid[k] = (uint32_t)g;
 		} else {
 			hv[k] = a.hv_in[g];
@@ -652,6 +662,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_FAST 2u		/* no histogram passes: fixed-capacity regions + atomic cursors (two-level partitions only) */
 #define PART_F_NARROW 4u	/* narrow form: words = fmix32(key) in both halves (mdb_level_args.narrow = 2) */
 #define PART_F_NARROW_RID 8u	/* narrow form with the row id in the low half of the word (narrow = 1; no row-id arrays) */
+#define PART_F_KEYS32 16u	/* the key column is int32 */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
@@ -737,6 +748,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.inverse_out = (inverse_out && l == nlevels - 1) ? (keys32_out ? 2u : 1u) : 0u;
 		a.narrow = l == 0 ? ((flags & PART_F_NARROW_RID) ? 1u : ((flags & PART_F_NARROW) ? 2u : 0u)) : 0u;
 		a.status = ctx ? ctx->d_status : NULL;
+		a.keys32 = (flags & PART_F_KEYS32) ? 1u : 0u;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
 			a.shift = (uint32_t)((w32 ? 32 : 64) - used_bits - b);
@@ -904,7 +916,7 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast)
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow)
+			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32)
 {
 	if (narrow && (stable || want_rid))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "narrow partitioning carries row ids inside the word");
@@ -914,11 +926,11 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	part_carver cv = { ctx, false, 0, false };
 	if (stable && !want_rid)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "stable partitioning is only built with row ids");
-	if ((uintptr_t)keys & 15)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device");
+	if ((uintptr_t)keys & (keys32 ? 7 : 15))
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device (8-byte for int32 keys)");
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
-				      (narrow == 2 ? PART_F_NARROW : 0u),
+				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u),
 			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out);
 }
 

@@ -79,6 +79,9 @@ def _bind(lib):
         "mdb_dev_combine_counts": ([P, P, P, P, P, c_uint64, P, P, POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count_begin": ([P, P, P, c_uint64, c_uint64], c_int),
         "mdb_dev_join_group_count_finish": ([P, P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dev_join_group_count_i32": ([P, P, c_uint64, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dev_join_group_count_begin_i32": ([P, P, c_uint64, c_uint64], c_int),
+        "mdb_dev_join_group_count_finish_i32": ([P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, c_int, P, P, POINTER(c_uint64)], c_int),
         "mdb_dev_key_range": ([P, P, P, c_uint64, POINTER(c_int64), POINTER(c_int64)], c_int),
         "mdb_dev_widen32to64": ([P, P, c_uint64, P], c_int),
@@ -97,6 +100,7 @@ DEV_SYMBOLS = [
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
+    "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
 ]
 
@@ -226,26 +230,52 @@ class DeviceCtx:
         G = g.value
         return ok[:G], oc[:G], of[:G], j.value
 
-    def join_group_count_begin(self, keys_l, null_l, n_r_max):
-        """Split form: partition the left table now (no host sync) ..."""
-        self._chk(self.lib.mdb_dev_join_group_count_begin(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), n_r_max),
-                  "join_group_count_begin")
-        self._pending_left = keys_l     # keep the tensor alive until finish()
-
-    def join_group_count_finish(self, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):
-        """... and complete with the right table; same results as join_group_count()."""
-        n_l = self._pending_left.numel()
+    def _gc_out(self, n_l, out):
         cap = max(n_l, 1)
         if out is None:
             out = (torch.empty(cap, dtype=torch.int64, device=self.device),
                    torch.empty(cap, dtype=torch.int64, device=self.device),
                    torch.empty(cap, dtype=torch.int32, device=self.device))
+        return cap, out
+
+    def join_group_count_begin(self, keys_l, null_l, n_r_max):
+        """Split form: partition the left table now (no host sync) ...  int32 key tensors (the 4-byte wire format of
+        the exchange) go to the _i32 entry points: no NULL bitmaps there."""
+        if keys_l.dtype == torch.int32:
+            if null_l is not None:
+                raise ValueError("int32 key columns carry no NULL bitmap")
+            self._chk(self.lib.mdb_dev_join_group_count_begin_i32(self.h, _ptr(keys_l), keys_l.numel(), n_r_max), "join_group_count_begin_i32")
+        else:
+            self._chk(self.lib.mdb_dev_join_group_count_begin(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), n_r_max),
+                      "join_group_count_begin")
+        self._pending_left = keys_l     # keep the tensor alive until finish()
+
+    def join_group_count_finish(self, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):
+        """... and complete with the right table; same results as join_group_count()."""
+        n_l = self._pending_left.numel()
+        cap, out = self._gc_out(n_l, out)
         ok, oc, of = out
         g, j = c_uint64(), c_uint64()
-        self._chk(self.lib.mdb_dev_join_group_count_finish(self.h, _ptr(keys_r), _ptr(null_r), keys_r.numel(), flags, _ptr(ok),
-                                                           _ptr(oc), _ptr(of), min(cap, ok.numel()), byref(g), byref(j)),
-                  "join_group_count_finish")
+        if keys_r.dtype == torch.int32:
+            if null_r is not None:
+                raise ValueError("int32 key columns carry no NULL bitmap")
+            self._chk(self.lib.mdb_dev_join_group_count_finish_i32(self.h, _ptr(keys_r), keys_r.numel(), flags, _ptr(ok), _ptr(oc), _ptr(of),
+                                                                   min(cap, ok.numel()), byref(g), byref(j)), "join_group_count_finish_i32")
+        else:
+            self._chk(self.lib.mdb_dev_join_group_count_finish(self.h, _ptr(keys_r), _ptr(null_r), keys_r.numel(), flags, _ptr(ok),
+                                                               _ptr(oc), _ptr(of), min(cap, ok.numel()), byref(g), byref(j)),
+                      "join_group_count_finish")
         self._pending_left = None
+        G = g.value
+        return ok[:G], oc[:G], of[:G], j.value
+
+    def join_group_count_i32(self, keys_l, keys_r, out=None, flags=MDB_ORDER_FIRST):
+        """join_group_count() over int32 key columns (no NULLs); keys come back as int64."""
+        cap, out = self._gc_out(keys_l.numel(), out)
+        ok, oc, of = out
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count_i32(self.h, _ptr(keys_l), keys_l.numel(), _ptr(keys_r), keys_r.numel(), flags, _ptr(ok),
+                                                        _ptr(oc), _ptr(of), min(cap, ok.numel()), byref(g), byref(j)), "join_group_count_i32")
         G = g.value
         return ok[:G], oc[:G], of[:G], j.value
 

@@ -759,3 +759,31 @@ def test_narrow_form_decision_is_remembered_per_column_but_every_key_is_still_ch
         assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
         assert dev.last_join_narrow() == (round_ < 2)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n_l,n_r,dom", [(1, 1, 1), (63, 130, 20), (5000, 4000, 900), (400_000, 500_000, 150_000),
+                                         (1_300_000, 1_100_001, 2_000_000), (3_000_000, 700_000, 40_000)])
+def test_join_group_count_over_int32_key_columns(dev, narrow_mode, mode, n_l, n_r, dom):
+    """The operator's int32 entry points (keys that crossed xGMI in the 4-byte wire format are consumed as they
+    arrive): same results as the int64 operator on the widened columns, one call and split, whole int32 range."""
+    narrow_mode(mode)
+    rng = np.random.default_rng(n_l + 3 * n_r + mode)
+    lo = int(rng.integers(-2**31, 2**31 - dom))
+    kl = rng.integers(lo, lo + dom, n_l, dtype=np.int64)
+    kr = rng.integers(lo, lo + dom, n_r, dtype=np.int64)
+    kl[0], kr[0] = -2**31, 2**31 - 1
+    if n_r > 1:
+        kr[1] = -2**31
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    dl = torch.from_numpy(kl.astype(np.int32)).to(dev.device)
+    dr = torch.from_numpy(kr.astype(np.int32)).to(dev.device)
+    for split in (False, True):
+        if split:
+            dev.join_group_count_begin(dl, None, n_r + 5)
+            k, c, f, j = dev.join_group_count_finish(dr, None)
+        else:
+            k, c, f, j = dev.join_group_count_i32(dl, dr)
+        assert j == ej and k.dtype == torch.int64
+        assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
