@@ -98,7 +98,7 @@ __device__ static inline uint32_t part_digit(const mdb_level_args &a, W hv)
 {
 	if (a.mode == MDB_DIGIT_RADIX)
 		return (uint32_t)(hv >> a.shift) & (a.R - 1);	/* a.shift counts from the width of W */
-	return (uint32_t)hv % a.R;
+	return (a.R & (a.R - 1)) == 0 ? (uint32_t)hv & (a.R - 1) : (uint32_t)hv % a.R;	/* 2, 4, 8 GPUs: no integer division */
 }
 
 /* XCD-contiguous block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so give
@@ -151,7 +151,7 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
  * access when both belong to the tile (8-byte accesses reach only ~0.6x of the 16-byte rate,
  * MI355X_MICROARCH.md).  lead = 1 when the tile starts on an odd element.  valid[k] = element exists and is
  * not NULL. */
-template <bool LEVEL0, bool HAS_RID, bool RAW = false>
+template <bool LEVEL0, bool HAS_RID, bool RAW = false, bool INV = false>
 __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint64_t hv[2],
 					 uint32_t rid[2], bool valid[2])
 {
@@ -176,8 +176,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			} else {
 				k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
 			}
-			hv[0] = part_hash_key(a, k.x, (uint32_t)g0, &bad[0]);
-			hv[1] = part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1]);
+			hv[0] = INV ? k.x : part_hash_key(a, k.x, (uint32_t)g0, &bad[0]);	/* INV: the caller keeps the key itself */
+			hv[1] = INV ? k.y : part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1]);
 			rid[0] = (uint32_t)g0;
 			rid[1] = (uint32_t)g0 + 1;
 		} else {
@@ -195,7 +195,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
 			const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
-			hv[k] = part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k]);
+			hv[k] = INV ? (uint64_t)key : part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k]);
 			rid[k] = (uint32_t)g;
 		} else {
 			hv[k] = a.hv_in[g];
@@ -278,9 +278,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	/* INV (destination partition for the exchange): what is staged and written is the KEY, not its hash - the digit is
+	 * taken from the hash once, at load time, and found again at write-out from the staged position (the tile-local
+	 * digit starts are in LDS anyway), instead of hashing back and forth */
+	static_assert(!INV || (LEVEL0 && !STABLE && !FAST && !RAW && !W32), "INV: unordered exact level-0 form only");
 	/* W32: the words staged and written are 4-byte hashes (narrow form, right side: level 0 reads 8-byte keys and
 	 * writes 4-byte words, level 1 reads and writes 4-byte words); never with row ids */
 	static_assert(!W32 || (!HAS_RID && !STABLE && FAST && !RAW), "4-byte words: unordered FAST form without row ids only");
@@ -346,11 +350,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		for (int r = 0; r < PART_ITEMS / 2; r++) {
 			bool valid[2];
 			uint64_t h2[2];
-			part_load2<LEVEL0, HAS_RID, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
+			part_load2<LEVEL0, HAS_RID, RAW, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
 			hv[2 * r] = (W)h2[0];		/* W32 at level 0: the narrow word holds the hash in both halves */
 			hv[2 * r + 1] = (W)h2[1];
-			dig[2 * r] = valid[0] ? part_digit(a, hv[2 * r]) : PART_INVALID;
-			dig[2 * r + 1] = valid[1] ? part_digit(a, hv[2 * r + 1]) : PART_INVALID;
+			dig[2 * r] = valid[0] ? part_digit(a, INV ? (W)mdb_fmix64(h2[0]) : hv[2 * r]) : PART_INVALID;
+			dig[2 * r + 1] = valid[1] ? part_digit(a, INV ? (W)mdb_fmix64(h2[1]) : hv[2 * r + 1]) : PART_INVALID;
 		}
 	}
 	__syncthreads();
@@ -457,13 +461,30 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		if (i >= tile_total)
 			continue;
 		const W h = s_hv[i];
-		const uint32_t d = part_digit(a, h);
+		uint32_t d;
+		if (INV) {	/* the last digit whose tile-local start is <= i (s_cnt[0] = 0) */
+			uint32_t lo = 0, hi = R;
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_cnt[mid] <= i)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			d = lo;
+		} else {
+			d = part_digit(a, h);
+		}
 		if (FAST && !s_ok[d])
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
 		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
 		gpos[k] = g;
 		if (W32)
 			reinterpret_cast<uint32_t *>(a.hv_out)[g] = (uint32_t)h;
+		else if (INV && a.inverse_out == 2)
+			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)h;	/* 4-byte wire format */
+		else if (INV)
+			a.hv_out[g] = h;
 		else if (a.inverse_out == 2)
 			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)mdb_fmix64_inv(h);
 		else
@@ -846,7 +867,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			if (l == 0 && raw_hv) {
 				MDB_LAUNCH(ctx, "sort_hist_l0", (k_part_hist<false, true>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0) {
-				MDB_LAUNCH(ctx, "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, mode == MDB_DIGIT_MOD ? "dest_hist" : "part_hist_l0", k_part_hist<true>, grid8(ntiles), PART_THREADS, a);
 			} else {
 				MDB_LAUNCH(ctx, "part_hist_l1", k_part_hist<false>, grid8(ntiles), PART_THREADS, a);
 			}
@@ -859,6 +880,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable) {
 				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true, false>), grid8(ntiles), PART_THREADS, a);
+			} else if (l == 0 && a.inverse_out && want_rid) {
+				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<true, true, false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+			} else if (l == 0 && a.inverse_out) {
+				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<true, false, false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0 && want_rid) {
 				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, false>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0) {
