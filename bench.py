@@ -33,11 +33,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6
 
 # names of the profiler's kernels in the rocprofv3 summary kept under profiles/ (PMC traffic per launch)
 ROCPROF_NAMES = {
-    "leaf_join_group_count": ["k_leaf_group_count<true, true, false>", "k_leaf_group_count<true, false, false>"],
-    "leaf_group_count": ["k_leaf_group_count<false, false, false>"],
-    "part_hist_l0": ["k_part_hist<true>"],
-    "part_scatter_l0": ["k_part_scatter<true, true, false, true, false>", "k_part_scatter<true, false, false, true, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, true, false, true, false>", "k_part_scatter<false, false, false, true, false>"],
+    "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
+                              "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
+    "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
+    "part_hist_l0": ["k_part_hist<true, false>"],
+    # level 0 / level 1 of the histogram-free partition: left table (8-byte words), right table (4-byte words in the narrow form)
+    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false>",
+                        "k_part_scatter<true, true, false, true, false, false, false>"],
+    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false>",
+                        "k_part_scatter<false, true, false, true, false, false, false>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
 }
