@@ -1425,7 +1425,9 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	}
 	if (n_l + (keys_r ? n_r : 0) < GC_NARROW_MIN_ROWS)
 		return MIDORIDB_OK;
-	if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
+	if (ctx->nh_distrust > 0)
+		ctx->nh_distrust--;
+	else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
 		return MIDORIDB_OK;
 	}
@@ -1489,6 +1491,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 				     keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
 		if (rc == GC_RETRY_WIDE) {
 			narrow = false;
+			if (ctx->narrow_mode == 1 && !keys32)
+				ctx->nh_distrust = 8;	/* whatever said "narrow" was wrong: look at the data itself the next few times */
 			if (ctx->narrow_mode == 1 && !keys32)
 				gc_narrow_note(ctx, keys_l, n_l, has_r ? keys_r : NULL, n_r, false);	/* the sample missed a wide key */
 		} else if (rc == GC_RETRY_EXACT)
