@@ -1661,6 +1661,8 @@ struct pu_args {
 	uint32_t nleaves;
 };
 
+/* NARROW: both sides travel as hash32 << 32 | row id words (no row-id arrays; see the narrow form of the group count) */
+template <bool NARROW>
 __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 {
 	__shared__ unsigned long long s_key[GC_SLOTS];
@@ -1690,9 +1692,12 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
 			const uint32_t i = l0 + (uint32_t)u * GC_THREADS + threadIdx.x;
 			hr[u] = j < r1 ? a.hv_r[j] : 0;
-			rr[u] = j < r1 ? a.rid_r[j] : 0;
 			hl[u] = i < l1 ? a.hv_l[i] : 0;
-			rl[u] = i < l1 ? a.rid_l[i] : 0;
+			rr[u] = rl[u] = 0;
+			if (!NARROW) {
+				rr[u] = j < r1 ? a.rid_r[j] : 0;
+				rl[u] = i < l1 ? a.rid_l[i] : 0;
+			}
 		}
 		{	/* list space for at most one record per left row (chunked reservation as in k_leaf_group_count) */
 			const uint32_t need = (l1 - l0) + 1;
@@ -1725,25 +1730,29 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 				const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 				if (base != r0) {
 					hr[u] = j < r1 ? a.hv_r[j] : 0;
-					rr[u] = j < r1 ? a.rid_r[j] : 0;
+					if (!NARROW)
+						rr[u] = j < r1 ? a.rid_r[j] : 0;
 				}
 				if (base == r0)
 					own[u] = 0xFFFFFFFFu;
 				if (j >= r1)
 					continue;
-				if (hr[u] == 0) {
-					if (atomicExch(&s_val[GC_SLOTS], rr[u] + 1u) != 0)
+				/* the words are decoded here, where they are used (not at load time: the first batch is in flight) */
+				const uint64_t key_r = NARROW ? gc_narrow_hv(hr[u]) : hr[u];
+				const uint32_t rid_r = NARROW ? (uint32_t)hr[u] : rr[u];
+				if (key_r == 0) {
+					if (atomicExch(&s_val[GC_SLOTS], rid_r + 1u) != 0)
 						atomicOr(a.status, 32u);
 					continue;
 				}
 				bool created = false;
-				const uint32_t s = leaf_insert(s_key, GC_SLOTS, hr[u], &created);
+				const uint32_t s = leaf_insert(s_key, GC_SLOTS, key_r, &created);
 				if (s == 0xFFFFFFFFu) {
 					atomicOr(a.status, 1u);
 				} else if (!created) {
 					atomicOr(a.status, 32u);	/* the key is already there: not a unique-key join */
 				} else {
-					s_val[s] = rr[u] + 1u;
+					s_val[s] = rid_r + 1u;
 					if (base == r0)
 						own[u] = s;
 				}
@@ -1758,16 +1767,19 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 				const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 				if (base != l0) {
 					hl[u] = i < l1 ? a.hv_l[i] : 0;
-					rl[u] = i < l1 ? a.rid_l[i] : 0;
+					if (!NARROW)
+						rl[u] = i < l1 ? a.rid_l[i] : 0;
 				}
 				unsigned long long recv = 0;
 				if (i < l1) {
+					const uint64_t key_l = NARROW ? gc_narrow_hv(hl[u]) : hl[u];
+					const uint32_t rid_l = NARROW ? (uint32_t)hl[u] : rl[u];
 					uint32_t s = GC_SLOTS;
-					if (hl[u] != 0)
-						s = leaf_find(s_key, GC_SLOTS, hl[u]);
+					if (key_l != 0)
+						s = leaf_find(s_key, GC_SLOTS, key_l);
 					const uint32_t v = s != 0xFFFFFFFFu ? s_val[s] : 0u;
 					if (v)
-						recv = ((unsigned long long)rl[u] << (64 - a.kbits)) | v;
+						recv = ((unsigned long long)rid_l << (64 - a.kbits)) | v;
 				}
 				const uint64_t m = __ballot(recv != 0ull);
 				if (m) {
@@ -2016,9 +2028,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 	}
 }
 
-/* 0 = done, 1 = not applicable (duplicate right key / overflow: use the general path), < 0 = error */
+/* 0 = done, 1 = not applicable (duplicate right key / overflow: use the general path), 2 = a key outside the int32 range met
+ * the narrow form (call again with narrow = false), < 0 = error */
 static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			     const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+			     const uint64_t *null_r, uint64_t n_r, bool narrow, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
 {
 	int b1, b2, sb1 = 0, sb2 = 0;
 	uint32_t kbits = 0;
@@ -2033,10 +2046,10 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 		return rc;
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	mdb_part_result pl, pr;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, false, true, &pr);
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, !narrow, false, true, &pr, narrow ? 1 : 0);
 	if (rc)
 		return rc;
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, true, &pl);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, !narrow, false, true, &pl, narrow ? 1 : 0);
 	if (rc)
 		return rc;
 	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, rec_cap * 8);
@@ -2063,13 +2076,19 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 	{
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique, grid, GC_THREADS, a);
+		if (narrow) {
+			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<true>, grid, GC_THREADS, a);
+		} else {
+			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<false>, grid, GC_THREADS, a);
+		}
 	}
 	uint64_t *h = ctx->h_pinned;
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const uint32_t status = (uint32_t)h[1];
 	const uint64_t list_len = h[1] >> 32, J = (uint32_t)h[5];
+	if (status & 128u)
+		return 2;
 	if (status & (1u | 2u | 8u | 32u))
 		return 1;
 	*out_count = J;
@@ -2104,7 +2123,18 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	{
 		uint32_t *ul = NULL, *ur = NULL;
 		uint64_t uj = 0;
-		int urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+		bool narrow = false;
+		int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow);
+		if (urc)
+			return urc;
+		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, &ul, &ur, &uj);
+		if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
+			if (ctx->narrow_mode == 1) {
+				ctx->nh_distrust = 8;
+				gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
+			}
+			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, &ul, &ur, &uj);
+		}
 		if (urc < 0)
 			return urc;
 		if (urc == 0) {

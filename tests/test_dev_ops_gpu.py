@@ -787,3 +787,35 @@ def test_join_group_count_over_int32_key_columns(dev, narrow_mode, mode, n_l, n_
         assert j == ej and k.dtype == torch.int64
         assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("n_l,n_r,shape", [(7, 5, "unique"), (5000, 3000, "unique"), (600_000, 500_000, "unique"), (1_300_000, 1_200_000, "unique"),
+                                           (40_000, 30_000, "dups"), (900_000, 450_000, "wide_right"), (900_000, 450_000, "wide_left_null"),
+                                           (300_000, 200_000, "edges")])
+def test_join_pairs_narrow_and_wide_forms(dev, narrow_mode, mode, n_l, n_r, shape):
+    """The materialising join with unique right keys in both forms (narrow: both sides travel as hash32 | row id words):
+    same (l, r) pairs in left-row order as the oracle; a key outside the int32 range sends the narrow attempt back to
+    64-bit hashes, a wide value under a NULL bit does not; duplicates on the right go on to the general path."""
+    narrow_mode(mode)
+    rng = np.random.default_rng(n_l + n_r + mode)
+    kr = rng.permutation(3 * n_r)[:n_r].astype(np.int64) - n_r                 # unique right keys, some negative
+    kl = rng.integers(-n_r, 2 * n_r, n_l, dtype=np.int64)
+    nl = rng.random(n_l) < 0.02
+    nr = None
+    if shape == "dups":
+        kr[: n_r // 3] = kr[n_r // 3: 2 * (n_r // 3)]
+    elif shape == "wide_right":
+        kr[n_r // 2] = 2**32 + int(kr[n_r // 2 + 1])                              # equal to another key in its low 32 bits
+        kl[17] = kr[n_r // 2]
+    elif shape == "wide_left_null":
+        kl[33] = 2**45
+        nl[33] = True
+    elif shape == "edges":
+        kr[:2] = [-2**31, 2**31 - 1]
+        kl[:4] = [2**31 - 1, -2**31, -2**31, 0]
+        nl[:4] = False
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert l.numel() == len(el)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
