@@ -158,6 +158,37 @@ __device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t 
 	}
 }
 
+/* the same in two steps, so that the words can be requested one whole leaf before they are needed */
+__device__ static inline uint2 gc_leaf_raw(const uint32_t *off, const uint32_t *cnt, uint32_t cap, uint32_t leaf)
+{
+	/* The index is hidden from the uniformity analysis: a load the compiler knows to be wave-uniform is moved into
+	 * scalar registers on arrival, i.e. waited for on the spot.  gc_leaf_decode() makes the words scalar again, one
+	 * leaf later. */
+	asm volatile("" : "+v"(leaf));
+	uint2 w;
+	if (cap) {
+		w.x = cnt[leaf];
+		w.y = 0;
+	} else {
+		w.x = off[leaf];
+		w.y = off[leaf + 1];
+	}
+	return w;
+}
+
+__device__ static inline void gc_leaf_decode(uint2 w, uint32_t cap, uint32_t leaf, uint32_t *b, uint32_t *e)
+{
+	w.x = __builtin_amdgcn_readfirstlane(w.x);
+	w.y = __builtin_amdgcn_readfirstlane(w.y);
+	if (cap) {
+		*b = leaf * cap;
+		*e = *b + (w.x < cap ? w.x : cap);
+	} else {
+		*b = w.x;
+		*e = w.y;
+	}
+}
+
 /* NW: 0 = 64-bit hashes, 1 = narrow words, 2 = whatever gc_args.narrow says (the rarely taken hot-key kernels) */
 template <int NW>
 __device__ static inline bool gc_is_narrow(const gc_args &a)
@@ -464,20 +495,34 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 	uint32_t leaf = blockIdx.x;
 	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
 	gc_batch b;
+	/* Leaf ranges are requested TWO leaves ahead and decoded one iteration later: read where they are needed (or one
+	 * leaf ahead but converted at once) each of the two loads was followed by s_waitcnt vmcnt(0) - two exposed L2 round
+	 * trips per leaf on the critical path of a kernel that has ~4 us per leaf. */
+	uint2 raw_l = make_uint2(0, 0), raw_r = make_uint2(0, 0);	/* of leaf + gridDim.x */
 	if (leaf < a.nleaves) {
 		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
 		if (HAS_R)
 			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
 		gc_prefetch<HAS_R, NW>(a, l0, l1, r0, r1, b);
+		if (leaf + gridDim.x < a.nleaves) {
+			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, leaf + gridDim.x);
+			if (HAS_R)
+				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, leaf + gridDim.x);
+		}
 	}
 	__syncthreads();
 	while (leaf < a.nleaves) {
-		const uint32_t next = leaf + gridDim.x;
+		const uint32_t next = leaf + gridDim.x, next2 = next + gridDim.x;
 		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
-		if (next < a.nleaves) {		/* range of the next leaf: in flight during this leaf */
-			gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, next, &nl0, &nl1);
+		if (next < a.nleaves) {		/* requested during the previous leaf */
+			gc_leaf_decode(raw_l, a.cap_l, next, &nl0, &nl1);
 			if (HAS_R)
-				gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, next, &nr0, &nr1);
+				gc_leaf_decode(raw_r, a.cap_r, next, &nr0, &nr1);
+		}
+		if (next2 < a.nleaves) {	/* in flight during this leaf, decoded at the top of the next */
+			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, next2);
+			if (HAS_R)
+				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, next2);
 		}
 		const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);	/* otherwise no group can come out of this leaf */
 		const bool heavy_l = l1 - l0 >= a.heavy_l, heavy_r = HAS_R && r1 - r0 >= a.heavy_r;	/* hot keys: see gc_side_heavy */
