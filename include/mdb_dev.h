@@ -268,9 +268,11 @@ int mdb_dev_combine_counts(mdb_dev_ctx *ctx, const int64_t *cnt1, const uint32_t
 
 /* Split form for pipelines that receive the two tables at different times (the multi-GPU exchange):
  * _begin() hashes and partitions the LEFT table and returns without a host sync, so the work overlaps
- * whatever is still in flight (e.g. the right table's all-to-all); n_r_max bounds the right table's size
- * for scratch sizing.  _finish() takes the right table and completes exactly like
- * mdb_dev_join_group_count().  No other operator may run on the context in between. */
+ * whatever is still in flight (e.g. the right table's all-to-all); n_r_max is the expected bound of the right
+ * table's size, for scratch sizing.  _finish() takes the right table and completes exactly like
+ * mdb_dev_join_group_count() - also when the table turns out larger than announced (skewed keys sent this GPU
+ * more than its share): the prepared work is then dropped and the operator runs once more on the real sizes.
+ * No other operator may run on the context in between. */
 int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 				   uint64_t n_r_max);
 int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,

@@ -1620,6 +1620,17 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 		st->keys_l = NULL;
 		return rc;
 	}
+	if (n_r > st->n_r_cap) {
+		/* more right rows than announced (a skewed exchange sent this GPU more than its share): the scratch arena was
+		 * sized for the announced table - drop the prepared left partition and run the whole operator on the real sizes */
+		rc = mdb_dev_sync(ctx);
+		st->active = false;
+		st->keys_l = NULL;
+		if (rc)
+			return rc;
+		return group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first, cap,
+					  out_groups, out_joined, keys32);
+	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
 	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE)	/* skew / huge counts / wide keys: redo the whole operator */

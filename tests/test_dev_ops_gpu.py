@@ -819,3 +819,21 @@ def test_join_pairs_narrow_and_wide_forms(dev, narrow_mode, mode, n_l, n_r, shap
     l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
     assert l.numel() == len(el)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+@pytest.mark.parametrize("i32", [False, True])
+def test_split_operator_with_a_right_table_larger_than_announced(dev, i32):
+    """A skewed exchange can hand a GPU more right rows than begin() was told: finish() still delivers the result."""
+    rng = np.random.default_rng(11)
+    n_l, n_r = 700_000, 2_500_000
+    kl = rng.integers(0, 50_000, n_l, dtype=np.int64)
+    kr = np.where(rng.random(n_r) < 0.5, 7, rng.integers(0, 50_000, n_r)).astype(np.int64)     # half the rows carry one key
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    if i32:
+        dl, dr = torch.from_numpy(kl.astype(np.int32)).to(dev.device), torch.from_numpy(kr.astype(np.int32)).to(dev.device)
+    else:
+        dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    dev.join_group_count_begin(dl, None, 900_000)
+    k, c, f, j = dev.join_group_count_finish(dr, None)
+    assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
