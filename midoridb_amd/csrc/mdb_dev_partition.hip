@@ -715,7 +715,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	 * sized for the digits that can occur */
 	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
 	const uint32_t cap0 = (uint32_t)((((n + nreg0_used - 1) / nreg0_used) * 5 / 4 + 1024 + 63) & ~63ull);
-	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0 * cap0 < 0xFFFFFFFFull;
+	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0_used * cap0 < 0xFFFFFFFFull;
 	/* narrow form without row ids (right side of a join): 4-byte words from the first level's output on; only built for
 	 * the histogram-free layout of both levels (callers ask mdb_partition_w32_applies() first) */
 	const bool w32 = (flags & PART_F_NARROW) && fast0 && fast;
@@ -726,7 +726,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	uint32_t *rid_buf[2] = { NULL, NULL };
 	for (int l = 0; l < nlevels; l++) {
 		const uint64_t elems = (fast && l == 1) ? (uint64_t)nleaves_total * fast_cap
-				       : ((fast0 && l == 0) ? (uint64_t)nreg0 * cap0 : (n ? n : 1));
+				       : ((fast0 && l == 0) ? (uint64_t)nreg0_used * cap0 : (n ? n : 1));	/* regions of digits that cannot occur are not allocated */
 		if (l == nlevels - 1 && final_hv_out)
 			hv_buf[l] = final_hv_out;	/* last level writes straight into the caller's buffer */
 		else

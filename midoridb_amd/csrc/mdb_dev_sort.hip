@@ -46,7 +46,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_load(const uint64_t *__re
 	unsigned long long lo = ~0ull, hi = 0ull;
 	bool anynull = false;
 	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
-		const uint32_t p = perm[k];
+		const uint32_t p = perm ? perm[k] : (uint32_t)k;
 		const uint64_t row = rid ? (uint64_t)rid[p] : (uint64_t)p;
 		uint64_t u = 0;
 		if (nullbits && mdb_bit_is_set(nullbits, row)) {
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_load(const uint64_t *__re
 			lo = u < lo ? u : lo;
 			hi = u > hi ? u : hi;
 		}
-		u_out[k] = u;
+		if (u_out)
+			u_out[k] = u;
 	}
 	if (lo <= hi) {
 		atomicMin(&s_min, lo);
@@ -88,11 +89,241 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_nullflag(const uint64_t *
 	}
 }
 
+/* ---- ORDER BY columns (up to 4) whose value ranges and the stream length together fit one word ---------------------
+ *
+ * word = [ per column: NULL flag | value image - min ] [ stream position ] (left-aligned, bit 0 set so that no word is zero): the
+ * words are unique, so ANY full sort of them is the stable sort of the column.  That lifts the restriction to stable
+ * least-significant-digit passes (ballot ranking: issue-bound, one 24-byte-per-row pass per 8 bits): the words are
+ * partitioned by their TOP bits with the histogram-free two-level scatter of the join (8 bytes per row and level),
+ * and every leaf - at most SORT_LEAF_CAP words - is finished in LDS (k_sort_leaf).  Value distributions that
+ * overflow a fixed-capacity region (the top bits are the values themselves, not a hash) are reported by the scatter
+ * kernels and sent to the general path. */
+#define SORT_LEAF_CAP 4096u
+#define SORT_LEAF_THREADS 512
+#define SORT_BUCKETS 1024u
+#define SORT_BUCKET_MAX 64u
+#define SORT_PACK_MIN_ROWS (1u << 18)
+
+#define SORT_PACK_MAX_KEYS 4
+struct sort_pack_args {
+	struct mdb_sort_key key[SORT_PACK_MAX_KEYS];	/* first = most significant */
+	uint64_t lo[SORT_PACK_MAX_KEYS];		/* smallest image of the column */
+	uint32_t kb[SORT_PACK_MAX_KEYS];		/* bits of (largest image - lo) */
+	int nkeys;
+	uint32_t rb, up;				/* bits of a stream position; left shift that aligns the word */
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, uint64_t n, uint64_t *__restrict__ w)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS) {
+		uint64_t v = 0;
+		for (int c = 0; c < a.nkeys; c++) {
+			const struct mdb_sort_key &key = a.key[c];
+			const uint64_t row = key.rid ? (uint64_t)key.rid[k] : k;
+			const uint64_t *values = (const uint64_t *)key.values;
+			if (key.nullbits) {
+				const bool isnull = mdb_bit_is_set(key.nullbits, row);
+				/* ASC: NULLs first (flag 0), DESC: NULLs last (flag 1) - as in the general path */
+				const uint64_t flag = (uint64_t)(isnull == (key.desc != 0));
+				v = (v << (a.kb[c] + 1)) | (flag << a.kb[c]) | (isnull ? 0ull : sort_image(values[row], key.type, key.desc) - a.lo[c]);
+			} else {
+				v = (v << a.kb[c]) | (sort_image(values[row], key.type, key.desc) - a.lo[c]);
+			}
+		}
+		w[k] = (((v << a.rb) | k) << a.up) | 1ull;
+	}
+}
+
+__global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t *__restrict__ w, const uint32_t *__restrict__ cnt,
+								  const uint32_t *__restrict__ out_base, uint32_t cap, uint32_t up, uint32_t rmask,
+								  uint32_t bshift, uint32_t *status, uint32_t *__restrict__ perm_out)
+{
+	/* The words of a leaf share their top bits.  They are dealt into SORT_BUCKETS buckets by the next bits (counting
+	 * with LDS atomics - the order of arrival does not matter, the words are unique), every bucket - one or two words
+	 * on average - is put in order by one thread, and the leaf is written out.  ~60 KiB of LDS traffic per leaf where a
+	 * bitonic network over the 4096 words moved 1.6 MiB (2.5 ms per 10^8 rows, LDS-bandwidth bound).  A bucket longer
+	 * than SORT_BUCKET_MAX (values bunched in their low bits) is reported and the caller takes the general path. */
+	__shared__ uint64_t s_w[SORT_LEAF_CAP];
+	__shared__ uint32_t s_cnt[SORT_BUCKETS + 1];	/* bucket sizes, then bucket starts (+ the total): 37 KiB of LDS, 4 workgroups per CU */
+	__shared__ uint32_t s_tmp[32];
+	const uint32_t leaf = blockIdx.x;
+	uint32_t c = cnt[leaf];
+	c = c < cap ? c : cap;		/* an overflowing region has been flagged by the scatter: the result is discarded */
+	if (c == 0)
+		return;
+	for (uint32_t b = threadIdx.x; b < SORT_BUCKETS; b += SORT_LEAF_THREADS)
+		s_cnt[b] = 0;
+	const uint64_t *src = w + (uint64_t)leaf * cap;
+	uint64_t v[SORT_LEAF_CAP / SORT_LEAF_THREADS];
+	uint32_t rank[SORT_LEAF_CAP / SORT_LEAF_THREADS];
+#pragma unroll
+	for (int e = 0; e < (int)(SORT_LEAF_CAP / SORT_LEAF_THREADS); e++) {
+		const uint32_t i = threadIdx.x + (uint32_t)e * SORT_LEAF_THREADS;
+		v[e] = i < c ? src[i] : 0ull;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < (int)(SORT_LEAF_CAP / SORT_LEAF_THREADS); e++) {
+		const uint32_t i = threadIdx.x + (uint32_t)e * SORT_LEAF_THREADS;
+		rank[e] = i < c ? atomicAdd(&s_cnt[(uint32_t)(v[e] >> bshift) & (SORT_BUCKETS - 1)], 1u) : 0u;
+	}
+	__syncthreads();
+	{
+		/* SORT_BUCKETS / SORT_LEAF_THREADS consecutive buckets per thread */
+		uint32_t mine[SORT_BUCKETS / SORT_LEAF_THREADS], sum = 0;
+#pragma unroll
+		for (int q = 0; q < (int)(SORT_BUCKETS / SORT_LEAF_THREADS); q++) {
+			mine[q] = s_cnt[threadIdx.x * (SORT_BUCKETS / SORT_LEAF_THREADS) + q];
+			sum += mine[q];
+		}
+		uint32_t total;
+		uint32_t run = mdb_block_excl_scan(sum, s_tmp, &total);	/* (its barriers: every size has been read) */
+#pragma unroll
+		for (int q = 0; q < (int)(SORT_BUCKETS / SORT_LEAF_THREADS); q++) {
+			s_cnt[threadIdx.x * (SORT_BUCKETS / SORT_LEAF_THREADS) + q] = run;
+			run += mine[q];
+		}
+		if (threadIdx.x == 0)
+			s_cnt[SORT_BUCKETS] = total;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < (int)(SORT_LEAF_CAP / SORT_LEAF_THREADS); e++) {
+		const uint32_t i = threadIdx.x + (uint32_t)e * SORT_LEAF_THREADS;
+		if (i < c)
+			s_w[s_cnt[(uint32_t)(v[e] >> bshift) & (SORT_BUCKETS - 1)] + rank[e]] = v[e];
+	}
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < SORT_BUCKETS; b += SORT_LEAF_THREADS) {
+		const uint32_t st = s_cnt[b], m = s_cnt[b + 1] - st;
+		if (m > SORT_BUCKET_MAX) {
+			atomicOr(status, 256u);
+			continue;
+		}
+		for (uint32_t x = 1; x < m; x++) {	/* insertion sort of a handful of words */
+			const uint64_t key = s_w[st + x];
+			uint32_t y = x;
+			while (y > 0 && s_w[st + y - 1] > key) {
+				s_w[st + y] = s_w[st + y - 1];
+				y--;
+			}
+			s_w[st + y] = key;
+		}
+	}
+	__syncthreads();
+	const uint32_t base = out_base[leaf];
+	for (uint32_t i = threadIdx.x; i < c; i += SORT_LEAF_THREADS)
+		perm_out[base + i] = (uint32_t)(s_w[i] >> up) & rmask;
+}
+
+static void sort_packed_bits(uint64_t n, int *b1, int *b2)
+{
+	int b = 2;
+	while (b < 2 * MDB_MAX_RADIX_BITS && ((uint64_t)2048 << b) < n)
+		b++;
+	*b1 = (b + 1) / 2;
+	*b2 = b - *b1;
+}
+
+static size_t sort_packed_arena_bytes(uint64_t n)
+{
+	if (n < SORT_PACK_MIN_ROWS)
+		return 0;
+	int b1, b2;
+	sort_packed_bits(n, &b1, &b2);
+	const size_t leaves = (size_t)1 << (b1 + b2);
+	return mdb_partition_raw_arena_bytes(n, b1, b2, SORT_LEAF_CAP, true, 0) + mdb_align_up((leaves + 1) * 4) +
+	       mdb_align_up(mdb_scan_scratch_words(leaves + 1) * 4) + mdb_align_up(n * 4) + 4096;
+}
+
+/* 0 = *perm holds the result, 1 = not applicable (range too wide, too few rows, skewed values): use the general path */
+static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint64_t *u, unsigned long long *mm,
+			    uint32_t **perm)
+{
+	if (n < SORT_PACK_MIN_ROWS || nkeys > SORT_PACK_MAX_KEYS)
+		return 1;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	uint64_t *h = ctx->h_pinned;
+	sort_pack_args pa;
+	memset(&pa, 0, sizeof(pa));
+	pa.nkeys = nkeys;
+	pa.rb = 1;
+	while (pa.rb < 32 && (1ull << pa.rb) < n)
+		pa.rb++;
+	uint32_t total = pa.rb;
+	uint64_t vmax = 0;	/* the largest composite value: every field at its maximum */
+	for (int c = 0; c < nkeys; c++) {
+		const struct mdb_sort_key *key = &keys[c];
+		if (key->type != MDB_T_INT64 && key->type != MDB_T_DOUBLE)
+			return 1;	/* the general path reports it */
+		/* one read-only pass per column for the range of its images */
+		h[0] = ~0ull;
+		h[1] = 0ull;
+		h[2] = 0ull;
+		MDB_HIP(ctx, hipMemcpyAsync(mm, h, 24, hipMemcpyHostToDevice, ctx->stream));
+		MDB_LAUNCH(ctx, "orderby_range", k_sort_load, grid, SORT_THREADS, (const uint64_t *)key->values, key->nullbits, key->rid,
+			   (const uint32_t *)NULL, n, key->type, key->desc, (uint64_t *)NULL, mm);
+		MDB_HIP(ctx, hipMemcpyAsync(h, mm, 24, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint64_t lo = h[0] <= h[1] ? h[0] : 0, hi = h[0] <= h[1] ? h[1] : 0;
+		uint32_t kb = 0;
+		if (hi != lo)
+			kb = 64u - (uint32_t)__builtin_clzll(hi - lo);
+		const uint32_t width = kb + (key->nullbits ? 1u : 0u);	/* the flag bit is spent whenever the column can hold NULLs */
+		total += width;
+		if (total > 63)
+			return 1;
+		pa.key[c] = *key;
+		pa.lo[c] = lo;
+		pa.kb[c] = kb;
+		vmax = (vmax << width) | ((key->nullbits ? (1ull << kb) : 0ull) | (hi - lo));
+	}
+	pa.up = 64 - total;
+	const uint32_t up = pa.up, rb = pa.rb;
+	int b1, b2;
+	sort_packed_bits(n, &b1, &b2);
+	/* first-level digits that can occur: the largest word's top bits */
+	const uint64_t wmax = (((vmax << rb) | (n - 1)) << up) | 1ull;
+	const uint32_t digits0 = (uint32_t)(wmax >> (64 - b1)) + 1u;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	MDB_LAUNCH(ctx, "orderby_pack", k_sort_pack, grid, SORT_THREADS, pa, n, u);
+	mdb_part_result ps;
+	int rc = mdb_partition_raw(ctx, u, n, b1, b2, SORT_LEAF_CAP, true, digits0, &ps);
+	if (rc)
+		return rc;
+	if (!ps.leaf_cap)
+		return 1;	/* the fixed-capacity layout does not apply at this size */
+	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
+	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
+	uint32_t *out = (uint32_t *)mdb_arena_take(ctx, n * 4);
+	if (!obase || !otmp || !out)
+		return -MIDORIDB_INTERNAL;
+	if (ps.nleaves <= MDB_SCAN_SMALL) {
+		rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
+	} else {
+		MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
+		rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
+	}
+	if (rc)
+		return rc;
+	/* buckets inside a leaf: the 10 bits below the partition bits (the word is left-aligned; `up` >= 1 unused low bits) */
+	const uint32_t bshift = 64u - (uint32_t)(b1 + b2) - 10u;
+	MDB_LAUNCH(ctx, "orderby_leaf", k_sort_leaf, ps.nleaves, SORT_LEAF_THREADS, (const uint64_t *)ps.hv, (const uint32_t *)ps.leaf_cnt,
+		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out);
+	MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if ((uint32_t)h[8] & (2u | 256u))
+		return 1;	/* a region or a bucket overflowed: the values are too unevenly spread for this path */
+	*perm = out;
+	return 0;
+}
+
 static size_t sort_arena_bytes(uint64_t n)
 {
 	const size_t hist_words = mdb_sort_pass_hist_words(n);
 	return 2 * mdb_align_up(n * 8) + 2 * mdb_align_up(n * 4) + mdb_align_up(hist_words * 4) +
-	       mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096;
+	       mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096 + sort_packed_arena_bytes(n);
 }
 
 /* sorts inside an arena the caller has begun (sort_arena_bytes(n) available); *perm = the arena buffer that holds
@@ -107,6 +338,11 @@ static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int
 	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 64);
 	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
 		return -MIDORIDB_INTERNAL;
+	{
+		const int prc = sort_perm_packed(ctx, keys, nkeys, n, u[0], mm, perm);
+		if (prc <= 0)
+			return prc;
+	}
 	int rc = mdb_dev_iota32(ctx, pm[0], n);
 	if (rc)
 		return rc;

@@ -837,3 +837,72 @@ def test_split_operator_with_a_right_table_larger_than_announced(dev, i32):
     k, c, f, j = dev.join_group_count_finish(dr, None)
     assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
     assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+
+
+@pytest.mark.parametrize("kind,desc,nf,with_rid", [
+    ("neg", False, 0.0, False), ("neg", True, 0.15, False), ("small", False, 0.0, True), ("small", True, 0.3, False),
+    ("double", False, 0.0, False), ("double", True, 0.2, True), ("const", False, 0.0, False), ("const", True, 0.5, False),
+    ("full", False, 0.0, False), ("small", False, 1.0, False),
+])
+@pytest.mark.parametrize("n", [262_144, 300_001, 1_500_000])
+def test_sort_perm_single_key_packed_path(dev, kind, desc, nf, with_rid, n):
+    """Single ORDER BY column from 2^18 rows on: value range and stream position share one word, partitioned by its top
+    bits and finished per leaf in LDS.  Against the numpy oracle: ascending / descending, NULLs first / last, DOUBLE
+    (incl. -0.0 / 0.0), all-equal and all-NULL columns, through a row-id vector; 'full' (64-bit range) does not fit
+    a word and takes the general path."""
+    _sort_case(dev, np.random.default_rng(n + len(kind)), n, [(kind, desc, nf)], with_rid=with_rid)
+
+
+@pytest.mark.parametrize("shape", ["bunched_high", "bunched_low", "two_values", "sorted", "reversed", "geometric"])
+def test_sort_perm_single_key_uneven_value_distributions(dev, shape):
+    """Value distributions the fixed-capacity leaves of the packed path cannot hold (the top bits are the values
+    themselves) are detected on the device and sorted by the general path: same permutation either way."""
+    n = 700_000
+    rng = np.random.default_rng(len(shape))
+    if shape == "bunched_high":
+        v = np.where(rng.random(n) < 0.9, 2**40 + rng.integers(0, 50, n), rng.integers(0, 2**41, n))
+    elif shape == "bunched_low":
+        v = rng.integers(0, 4, n) * 2**30                      # four values, far apart: low bits of the word all equal per value
+    elif shape == "two_values":
+        v = np.where(rng.random(n) < 0.5, -5, 10**12)
+    elif shape == "sorted":
+        v = np.arange(n) * 3 - 1000
+    elif shape == "reversed":
+        v = (n - np.arange(n)) * 7
+    else:
+        v = np.floor(np.exp(rng.uniform(0, 40, n))).astype(np.int64)
+    v = v.astype(np.int64)
+    nulls = rng.random(n) < 0.01
+    for desc in (False, True):
+        got = _np(dev.sort_perm([(dev.to_dev(v), dev.nullbits_dev(nulls), None, D.T_INT64, desc)], n)).view(np.uint32)
+        want = orc.sort_perm([(v, nulls, None, False, desc)], n)
+        assert np.array_equal(got, want)
+
+
+def test_sort_perm_packed_path_large_property(dev):
+    """10^8 rows, one key: a permutation, keys non-decreasing, ties in stream order."""
+    n = 100_000_000
+    for modulus in (0, 5000):
+        a = dev.gen_keys(n, 0, n, 9, modulus)
+        perm = dev.sort_perm([(a, None, None, D.T_INT64, False)], n).to(torch.int64)
+        s = a[perm]
+        assert bool((s[1:] >= s[:-1]).all())
+        tie = s[1:] == s[:-1]
+        assert bool((perm[1:][tie] > perm[:-1][tie]).all())
+        assert int(perm.sum()) == n * (n - 1) // 2 and int(perm.min()) == 0 and int(perm.max()) == n - 1
+        del perm, s, tie
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("specs", [
+    [("small", False, 0.0), ("neg", True, 0.0)], [("small", True, 0.3), ("neg", False, 0.2), ("small", False, 0.0)],
+    [("neg", False, 0.0), ("const", True, 0.4), ("neg", True, 0.0), ("small", False, 0.1)],
+    [("small", False, 0.0), ("neg", True, 0.0), ("small", True, 0.0), ("neg", False, 0.0), ("small", False, 0.0)],     # 5 keys: general path
+    [("small", False, 0.0), ("double", True, 0.1)],                                                                       # DOUBLE range: general path
+    [("neg", True, 1.0), ("small", False, 0.0)],
+], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
+def test_sort_perm_multi_key_packed_path(dev, specs):
+    """Several ORDER BY columns whose ranges fit one word together (composite word, most significant column first)."""
+    rng = np.random.default_rng(len(specs) * 13 + 5)
+    _sort_case(dev, rng, 400_003, specs)
+    _sort_case(dev, rng, 300_000, specs, with_rid=True)
