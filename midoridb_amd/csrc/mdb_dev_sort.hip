@@ -3,7 +3,9 @@
  * MDB_SORT_MAX_KEYS columns (ASC / DESC, INT64 or DOUBLE, NULL = smallest value).
  *
  * The reference parses ORDER BY but never executes it; this operator is the
- * device half of the extension.  Method: least-significant-digit radix sort, last ORDER BY column first -
+ * device half of the extension.  Two methods: when the value ranges of the columns and the stream length fit one
+ * 64-bit word together, the packed path further down (sort_perm_packed); otherwise, and whenever the packed path
+ * reports unevenly spread values, the general method: least-significant-digit radix sort, last ORDER BY column first -
  * every pass is stable (mdb_sort_pass: histogram, scan, ballot-ranked scatter), so ties of a later column
  * keep the order the earlier passes produced and ties of all columns keep the stream order.  Per column:
  *
