@@ -275,7 +275,7 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU, variant {args.variant} "
                                    f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
-                       "key_form": "narrow (int32-range keys verified on the device: 32-bit hashes)" if narrow else "wide (64-bit hashes)",
+                       "key_form": "narrow (keys within one 2^32-wide window, verified on the device: 32-bit hashes)" if narrow else "wide (64-bit hashes)",
                        "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
                        "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")

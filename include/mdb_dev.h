@@ -57,10 +57,13 @@ int mdb_dev_reserve(mdb_dev_ctx *ctx, size_t bytes);
  * measured on MI355X it does not shorten the single-GPU pipeline (every kernel already fills the chip). */
 int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on);
 /* Join / GROUP BY keys that all lie inside the int32 range (the reference's integers are 32-bit in practice: literals
- * through atoi `midorisql.l:85`, compares through `int` `executor_select.c:462`) are partitioned and compared as 32-bit
- * hashes, the row id sharing the 8-byte word.  Verified on the device for every key, never assumed: a key outside the
- * range makes the operator redo its work with 64-bit hashes; results are identical either way.
- * mode 0: never; 1 (default): when a sample of both key columns fits, tables of 2^20 rows or more; 2: always try. */
+ * through atoi `midorisql.l:85`, compares through `int` `executor_select.c:462`) - or, more generally, inside any
+ * 2^32-wide window of the int64 range (surrogate keys that start at 10^12, timestamps of one year ...; the window is
+ * centred on a sample of both columns) - are partitioned and compared as 32-bit hashes of their offset in the window,
+ * the row id sharing the 8-byte word.  Verified on the device for every key, never assumed: a key outside the
+ * window makes the operator redo its work with 64-bit hashes; results are identical either way.
+ * mode 0: never; 1 (default): when a sample of both key columns fits, tables of 2^20 rows or more; 2: always try
+ * (the plain int32 window, no sampling). */
 int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode);
 /* 1 when the last completed join / GROUP BY operator of this context ran in the narrow form (for byte accounting) */
 int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);

@@ -34,6 +34,7 @@ struct mdb_dev_ctx {
 	const void *nh_kl, *nh_kr;
 	uint64_t nh_nl, nh_nr;
 	int nh_result;			/* -1 nothing remembered, 0 wide, 1 narrow */
+	int64_t nh_base;		/* the window centre that went with "narrow" */
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */

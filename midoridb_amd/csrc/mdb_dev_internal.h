@@ -46,12 +46,13 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
  * leaf gets a fixed-capacity region and runs are placed with atomic cursors; if a leaf overflows, bit 1 of
  * ctx->d_status[0] is set and the caller must redo the operator with fast = false.  All temporaries and
  * outputs are carved from the arena (caller has called mdb_arena_begin with enough room).  No host sync.
- * narrow (want_rid must be false): every key is expected inside the int32 range - a key outside raises bit 7 of
+ * narrow (want_rid must be false): every key is expected within 2^31 of narrow_base - a key outside raises bit 7 of
  * ctx->d_status[0] and the caller redoes the operator wide.  1: hv[i] = fmix32(key) << 32 | row id, 2: hv is an array of 4-byte words fmix32(key) - only in the
  * two-level fast layout, see mdb_partition_w32_applies(). */
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0,
-			bool keys32 = false);	/* keys32: `keys` points to int32 values */
+			bool keys32 = false,	/* keys32: `keys` points to int32 values */
+			int64_t narrow_base = 0);	/* narrow: the keys are taken relative to this value (centre of their 2^32 window) */
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

@@ -1156,6 +1156,7 @@ struct gc_state {
 	bool has_r, null_group, fast, want_records, no_build_r;
 	bool narrow;		/* 32-bit hashes; the left words carry the row ids (see mdb_partition_table) */
 	bool keys32;		/* both key columns are int32 arrays (received over xGMI in the 4-byte wire format) */
+	int64_t base;		/* narrow form: centre of the key window (mdb_partition_table) */
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -1197,7 +1198,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
-				 st->narrow ? 1 : 0, st->keys32);
+				 st->narrow ? 1 : 0, st->keys32, st->base);
 	if (rc)
 		return rc;
 	st->active = true;
@@ -1225,7 +1226,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
 		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
 			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32, st->base);
 		if (rc)
 			return rc;
 	}
@@ -1428,40 +1429,75 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 #define GC_NARROW_MIN_ROWS (1u << 20)
 #define GC_NARROW_SAMPLE 4096u
 
-__global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__restrict__ nl_bits, uint64_t nl,
-			     const int64_t *__restrict__ kr, const uint64_t *__restrict__ nr_bits, uint64_t nr, uint32_t *flag)
+__device__ static inline long long gc_wave_min_i64(long long v)
 {
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= GC_NARROW_SAMPLE)
-		return;
-	bool bad = false;
-	if (nl) {
-		const uint64_t i = (uint64_t)t * nl / GC_NARROW_SAMPLE;
-		if (!(nl_bits && mdb_bit_is_set(nl_bits, i)))
-			bad = bad || ((uint64_t)kl[i] + 0x80000000ull) >> 32;
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1) {
+		const long long o = __shfl_xor(v, d, MDB_WAVE);
+		v = o < v ? o : v;
 	}
-	if (kr && nr) {
-		const uint64_t j = (uint64_t)t * nr / GC_NARROW_SAMPLE;
-		if (!(nr_bits && mdb_bit_is_set(nr_bits, j)))
-			bad = bad || ((uint64_t)kr[j] + 0x80000000ull) >> 32;
-	}
-	if (bad)
-		atomicOr(flag, 1u);
+	return v;
 }
 
-static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow)
+__device__ static inline long long gc_wave_max_i64(long long v)
+{
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1) {
+		const long long o = __shfl_xor(v, d, MDB_WAVE);
+		v = o > v ? o : v;
+	}
+	return v;
+}
+
+/* mm[0] = smallest, mm[1] = largest of 2 x GC_NARROW_SAMPLE evenly spaced non-NULL keys */
+__global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__restrict__ nl_bits, uint64_t nl,
+			     const int64_t *__restrict__ kr, const uint64_t *__restrict__ nr_bits, uint64_t nr, long long *mm)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
+	if (t < GC_NARROW_SAMPLE) {
+		if (nl) {
+			const uint64_t i = (uint64_t)t * nl / GC_NARROW_SAMPLE;
+			if (!(nl_bits && mdb_bit_is_set(nl_bits, i))) {
+				lo = kl[i];
+				hi = kl[i];
+			}
+		}
+		if (kr && nr) {
+			const uint64_t j = (uint64_t)t * nr / GC_NARROW_SAMPLE;
+			if (!(nr_bits && mdb_bit_is_set(nr_bits, j))) {
+				const long long v = kr[j];
+				lo = v < lo ? v : lo;
+				hi = v > hi ? v : hi;
+			}
+		}
+	}
+	lo = gc_wave_min_i64(lo);
+	hi = gc_wave_max_i64(hi);
+	if (mdb_lane() == 0 && lo <= hi) {
+		atomicMin(&mm[0], lo);
+		atomicMax(&mm[1], hi);
+	}
+}
+
+static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow,
+			   int64_t base = 0)
 {
 	ctx->nh_kl = keys_l;
 	ctx->nh_nl = n_l;
 	ctx->nh_kr = keys_r;
 	ctx->nh_nr = keys_r ? n_r : 0;
 	ctx->nh_result = narrow ? 1 : 0;
+	ctx->nh_base = base;
 }
 
+/* *narrow: try the narrow form; *base: centre of the 2^32-wide window of key values it will be tried with (0 = the plain
+ * int32 range, whenever the sampled keys lie inside it) */
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			   const uint64_t *null_r, uint64_t n_r, bool *narrow)
+			   const uint64_t *null_r, uint64_t n_r, bool *narrow, int64_t *base)
 {
 	*narrow = false;
+	*base = 0;
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
 	if (ctx->narrow_mode == 2) {
@@ -1474,22 +1510,35 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		ctx->nh_distrust--;
 	else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
+		*base = ctx->nh_base;
 		return MIDORIDB_OK;
 	}
-	uint32_t *flag = ctx->d_status + 9;
-	MDB_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, flag);
-	uint32_t *h = (uint32_t *)ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+	long long *mm = (long long *)(ctx->d_status + 10);
+	int64_t *h = (int64_t *)ctx->h_pinned;
+	h[0] = INT64_MAX;
+	h[1] = INT64_MIN;
+	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
+	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, mm);
+	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*narrow = h[0] == 0;
-	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow);
+	const int64_t lo = h[0], hi = h[1];
+	if (lo > hi) {
+		*narrow = true;		/* nothing but NULLs in the sample */
+	} else if (lo >= -(1ll << 31) && hi < (1ll << 31)) {
+		*narrow = true;
+	} else if ((uint64_t)hi - (uint64_t)lo < (1ull << 31)) {
+		/* a window anywhere in the int64 range (surrogate keys that start at 10^12, timestamps ...): centred on the
+		 * sample, so that keys up to 2^30 beyond either end of what was sampled still fit */
+		*narrow = true;
+		*base = (int64_t)((uint64_t)lo + (((uint64_t)hi - (uint64_t)lo) >> 1));
+	}
+	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base);
 	return MIDORIDB_OK;
 }
 
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, bool no_build_r, bool narrow, bool keys32, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+			   bool want_records, bool no_build_r, bool narrow, int64_t base, bool keys32, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 			   uint64_t *out_joined)
 {
 	*out_groups = 0;
@@ -1509,6 +1558,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.want_records = want_records;
 	st.no_build_r = no_build_r;
 	st.narrow = narrow;
+	st.base = base;
 	st.keys32 = keys32;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
@@ -1524,16 +1574,17 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	/* first the histogram-free layout for the second partition level; the exact layout is the fallback
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
+	int64_t base = 0;
 	int rc = MIDORIDB_OK;
 	if (keys32)
 		narrow = ctx->narrow_mode != 0;		/* int32 columns: nothing to sample */
 	else
-		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow);
+		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow, &base);
 	if (rc)
 		return rc;
 	for (int attempt = 0; attempt < 5; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
-				     keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
+				     base, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
 		if (rc == GC_RETRY_WIDE) {
 			narrow = false;
 			if (ctx->narrow_mode == 1 && !keys32)
@@ -1592,7 +1643,7 @@ static int gc_split_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_
 	if (keys32)
 		st->narrow = ctx->narrow_mode != 0;
 	else
-		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, NULL, NULL, 0, &st->narrow);	/* the right table is checked as it is partitioned */
+		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, NULL, NULL, 0, &st->narrow, &st->base);	/* the right table is checked as it is partitioned */
 	if (rc)
 		return rc;
 	return gc_begin(ctx, st);
@@ -2087,7 +2138,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 /* 0 = done, 1 = not applicable (duplicate right key / overflow: use the general path), 2 = a key outside the int32 range met
  * the narrow form (call again with narrow = false), < 0 = error */
 static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			     const uint64_t *null_r, uint64_t n_r, bool narrow, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+			     const uint64_t *null_r, uint64_t n_r, bool narrow, int64_t base, uint32_t **out_l, uint32_t **out_r,
+			     uint64_t *out_count)
 {
 	int b1, b2, sb1 = 0, sb2 = 0;
 	uint32_t kbits = 0;
@@ -2102,10 +2154,10 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 		return rc;
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	mdb_part_result pl, pr;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, !narrow, false, true, &pr, narrow ? 1 : 0);
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, !narrow, false, true, &pr, narrow ? 1 : 0, false, base);
 	if (rc)
 		return rc;
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, !narrow, false, true, &pl, narrow ? 1 : 0);
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, !narrow, false, true, &pl, narrow ? 1 : 0, false, base);
 	if (rc)
 		return rc;
 	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, rec_cap * 8);
@@ -2180,16 +2232,17 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 		uint32_t *ul = NULL, *ur = NULL;
 		uint64_t uj = 0;
 		bool narrow = false;
-		int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow);
+		int64_t base = 0;
+		int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base);
 		if (urc)
 			return urc;
-		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, &ul, &ur, &uj);
+		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, &ul, &ur, &uj);
 		if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
 			if (ctx->narrow_mode == 1) {
 				ctx->nh_distrust = 8;
 				gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
 			}
-			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, &ul, &ur, &uj);
+			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, 0, &ul, &ur, &uj);
 		}
 		if (urc < 0)
 			return urc;

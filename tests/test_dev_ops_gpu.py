@@ -906,3 +906,42 @@ def test_sort_perm_multi_key_packed_path(dev, specs):
     rng = np.random.default_rng(len(specs) * 13 + 5)
     _sort_case(dev, rng, 400_003, specs)
     _sort_case(dev, rng, 300_000, specs, with_rid=True)
+
+
+@pytest.mark.parametrize("shape", ["high_window", "negative_window", "outlier_above", "outlier_below", "too_wide", "int64_extremes"])
+def test_narrow_form_window_anywhere_in_the_int64_range(dev, narrow_mode, shape):
+    """Keys inside a 2^32-wide window far from zero (surrogate keys from 10^12 on, negative timestamps) take the narrow
+    form relative to the centre of the sampled window; a key outside the window - hidden from the sample - sends the
+    operator back to 64-bit hashes; sampled spans of 2^31 or more never try."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) + 100)
+    n_l, n_r = 1_400_000, 1_100_000
+    off = {"high_window": 10**12, "negative_window": -(2**61), "outlier_above": 7 * 10**15, "outlier_below": 10**10,
+           "too_wide": 5 * 10**9, "int64_extremes": 0}[shape]
+    span = 2**33 if shape == "too_wide" else 900_000
+    kl = off + rng.integers(0, span, n_l, dtype=np.int64)
+    kr = off + rng.integers(0, span, n_r, dtype=np.int64)
+    if shape == "outlier_above":
+        kl[n_l // 2 + 1] = off + 2**32 + 17          # same low 32 bits as off + 17
+        kr[5] = off + 17
+        kl[7] = off + 17
+    elif shape == "outlier_below":
+        kr[n_r // 2 + 1] = off - 2**31 - 10
+    elif shape == "int64_extremes":
+        kl[:2] = [np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+        kr[:2] = [np.iinfo(np.int64).max, np.iinfo(np.int64).min]
+    nl = rng.random(n_l) < 0.01
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, None)
+    dl, dnl, dr = dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr)
+    k, c, f, j = dev.join_group_count(dl, dnl, dr, None)
+    assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    assert dev.last_join_narrow() == (shape in ("high_window", "negative_window"))
+    first, cnt = dev.group_count(dl, dnl)
+    e_first, e_cnt = orc.group_count(kl, nl)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+    # materialising join on unique right keys of the same window
+    kr_u = off + rng.permutation(span if span < 2**31 else 3_000_000)[:n_r].astype(np.int64)
+    el, er = orc.join_pairs(kl, nl, kr_u, None)
+    l, r = dev.join_pairs(dl, dnl, dev.to_dev(kr_u), None)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
