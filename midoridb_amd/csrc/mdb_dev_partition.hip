@@ -483,8 +483,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		gpos[k] = g;
 		if (W32)
 			reinterpret_cast<uint32_t *>(a.hv_out)[g] = (uint32_t)h;
-		else if (INV && a.inverse_out == 2)
+		else if (INV && a.inverse_out == 2) {
+			if (((uint64_t)h + 0x80000000ull) >> 32)
+				atomicOr(a.status, 128u);	/* the caller's promise (column statistics) does not hold: reported, not truncated */
 			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)h;	/* 4-byte wire format */
+		}
 		else if (INV)
 			a.hv_out[g] = h;
 		else if (a.inverse_out == 2)
@@ -1048,13 +1051,20 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
+	if (keys32)
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
 	rc = partition_impl(cv, keys, nullbits, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res, out_rid, 0,
 			    keys32 != 0);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
 	MDB_HIP(ctx, hipMemcpyAsync(h_off, res.leaf_off, ((size_t)n_dest + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if (keys32)
+		MDB_HIP(ctx, hipMemcpyAsync(h_off + n_dest + 1, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (keys32 && (h_off[n_dest + 1] & 128u))
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: a key does not fit the 4-byte wire format (keys32 needs every key in "
+							 "the int32 range: check mdb_dev_key_range)");
 	for (uint32_t d = 0; d < n_dest; d++)
 		out_counts[d] = (uint64_t)h_off[d + 1] - h_off[d];
 	return MIDORIDB_OK;

@@ -571,6 +571,16 @@ def test_partition_by_dest_4_byte_wire_format_and_key_range(dev):
     off = np.concatenate([[0], np.cumsum(c8)])
     for d in range(4):                                  # same multiset per destination as the 8-byte form
         assert np.array_equal(np.sort(_np(wide)[off[d]:off[d + 1]]), np.sort(_np(out8)[off[d]:off[d + 1]]))
+    # a key outside the int32 range is reported, never truncated (a NULL row's stale value does not count)
+    k2 = k.copy()
+    k2[1234] = 2**31
+    nl2 = nl.copy()
+    nl2[1234] = False
+    with pytest.raises(D.DeviceError, match="4-byte wire format"):
+        dev.partition_by_dest(dev.to_dev(k2), dev.nullbits_dev(nl2), 4, keys32=True)
+    nl2[1234] = True
+    out_ok, c_ok = dev.partition_by_dest(dev.to_dev(k2), dev.nullbits_dev(nl2), 4, keys32=True)
+    assert sum(c_ok) == int((~nl2).sum())
 
 
 @pytest.mark.parametrize("shape", ["one_key", "two_keys", "hot_plus_unique", "many_hot_keys", "hot_left_only"])
