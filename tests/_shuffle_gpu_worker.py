@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import np_oracle as orc  # noqa: E402
 from midoridb_amd.dev import DeviceCtx  # noqa: E402
-from midoridb_amd.shuffle import TableShuffle  # noqa: E402
+from midoridb_amd.shuffle import DistributedJoinGroupCount, TableShuffle  # noqa: E402
 
 
 def main():
@@ -70,6 +70,34 @@ def main():
         o1, o2 = np.argsort(k2, kind="stable"), np.argsort(ek, kind="stable")
         assert np.array_equal(k2[o1], ek[o2]) and np.array_equal(c2[o1], ec[o2])
         print("rccl table shuffle payload join ok", len(got), "joined rows", len(ek), "groups", "world", world)
+    # ---- the north-star pipeline itself (bench.py --gpus N): partition by destination, key exchange, split join operator
+    #      with the DEVICE operators: 8-byte and 4-byte wire format (int32 keys are consumed as they arrive), one and two
+    #      pieces per table, narrow and 64-bit form of the join
+    m = 1_300_000
+    tot = m * world
+    rng = np.random.default_rng(23)
+    fa = rng.permutation(tot).astype(np.int64) - tot // 3
+    fb = rng.integers(-tot // 3, tot - tot // 3, tot, dtype=np.int64)
+    sl = slice(rank * m, (rank + 1) * m)
+    da, db = dev.to_dev(fa[sl]), dev.to_dev(fb[sl])
+    ek, ec, _, ej = orc.join_group_count(fa, None, fb, None)
+    for wire32, chunks, narrow in ((False, 1, 1), (True, 1, 1), (True, 2, 1), (True, 1, 0), (False, 2, 0)):
+        dev.set_narrow_keys(narrow)
+        pipe = DistributedJoinGroupCount(dev, world, rank, m, chunks=chunks, wire32=wire32)
+        g, j = pipe.run(da, db)
+        k, c, _ = pipe.last
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (k.cpu().numpy(), c.cpu().numpy(), int(j)))
+        if rank == 0:
+            k2, c2 = np.concatenate([x[0] for x in gathered]), np.concatenate([x[1] for x in gathered])
+            assert sum(x[2] for x in gathered) == ej
+            o1, o2 = np.argsort(k2, kind="stable"), np.argsort(ek, kind="stable")
+            assert np.array_equal(k2[o1], ek[o2]) and np.array_equal(c2[o1], ec[o2]), (wire32, chunks, narrow)
+        if world == 1:      # one rank: the result keeps the reference's first-occurrence order of what was received
+            assert k.numel() == len(ek)
+    dev.set_narrow_keys(1)
+    if rank == 0:
+        print("rccl distributed join group count ok", len(ek), "groups", ej, "joined rows")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -401,6 +401,7 @@ def test_table_shuffle_payload_join_rccl():
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "rccl table shuffle payload join ok" in r.stdout
+    assert "rccl distributed join group count ok" in r.stdout
 
 
 @pytest.mark.parametrize("variant", ["D", "U"])
