@@ -122,17 +122,28 @@ def cpu_baseline():
             "sample": f"north-star query, {n}x{n} unique keys, oracle/cpu_naive.c nested loop ({dt:.2f} s)"}
 
 
-def cpu_hash_yardstick(rows):
-    """Multi-threaded hash join on the host (oracle/cpu_hash.c) at a bounded size, for orientation."""
-    from oracle import cpu, np_oracle as orc
-    n = min(rows, 20_000_000)
-    a = orc.gen_keys(n, 0, n, 42, 0)
-    b = orc.gen_keys(n, 0, n, 43, n // 16)
+def cpu_hash_yardstick(a_dev, b_dev, gpu_result=None):
+    """the repo's multi-threaded CPU hash join + aggregate (oracle/cpu_hash.c, pinned to the reference's
+    vectors) on all host cores, on the SAME tables the GPU just processed - at the full configuration size when the host
+    has the cores for it (about 2 s on the GPU box), otherwise on the first 2*10^7 rows of each.  At full size its result
+    is also the parity check of the benchmark run itself: keys, counts and order of the GPU's result are compared."""
+    from oracle import cpu
     cores = os.cpu_count() or 1
+    rows = a_dev.numel()
+    full = cores >= 32 and rows <= 200_000_000
+    n = rows if full else min(rows, 20_000_000)
+    a = a_dev[:n].cpu().numpy()
+    b = b_dev[:n].cpu().numpy()
     t0 = time.perf_counter()
-    _, _, _, j = cpu.hash_join_group_count(a, None, b, None, cores)
+    ek, ec, _, j = cpu.hash_join_group_count(a, None, b, None, cores)
     dt = time.perf_counter() - t0
-    return {"value": j / dt, "unit": "joined rows/s", "cores": cores, "rows_per_table": n}
+    out = {"value": j / dt, "unit": "joined rows/s", "cores": cores, "rows_per_table": n, "seconds": dt,
+           "sample": "the benchmark's own tables, full size" if full else "first rows of the benchmark's tables"}
+    if full and gpu_result is not None:
+        k, c, jj = gpu_result
+        out["gpu_result_identical"] = bool(jj == j and k.numel() == len(ek) and np.array_equal(k.cpu().numpy(), ek)
+                                           and np.array_equal(c.cpu().numpy(), ec))
+    return out
 
 
 def main():
@@ -306,7 +317,11 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:
-                line["cpu_hash"] = cpu_hash_yardstick(n)
+                gpu_result = None
+                if pipeline is None:
+                    k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
+                    gpu_result = (k, c, jj)
+                line["cpu_hash"] = cpu_hash_yardstick(a, b, gpu_result)
             except Exception as e:  # pragma: no cover
                 line["cpu_hash"] = {"error": str(e)}
         if args.verify and n <= 20_000_000 and world == 1:
