@@ -146,6 +146,15 @@ def main():
     ms, kern, _ = timed(dev, order_by2, reps=3, warmup=1)
     res["order_by_two_keys_1e8"] = {"rows": n, "ms": ms, "rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
                                     "note": "ORDER BY k2 DESC, k1 ASC (9 + 27 value bits + 27 position bits = 63 bits: one word)"}
+    # GROUP BY two columns + COUNT(*) (composite-key semantics; sort, run heads, run lengths)
+    k3 = dev.gen_keys(n, 0, n, 79, 300)
+
+    def group_by2():
+        return dev.group_count_multi([(k2, None, None, D.T_INT64, False), (k3, None, None, D.T_INT64, False)], n)[0].numel()
+    ms, kern, groups2 = timed(dev, group_by2, reps=3, warmup=1)
+    res["group_by_two_columns_1e8"] = {"rows": n, "groups": groups2, "ms": ms, "rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
+                                       "note": "GROUP BY k2, k3 (512 x 300 value combinations) + COUNT(*), first-occurrence order"}
+    del k3
     del k2
     del k1
 

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, ui
 
 __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t *__restrict__ w, const uint32_t *__restrict__ cnt,
 								  const uint32_t *__restrict__ out_base, uint32_t cap, uint32_t up, uint32_t rmask,
-								  uint32_t bshift, uint32_t *status, uint32_t *__restrict__ perm_out)
+								  uint32_t bshift, uint32_t *status, uint32_t *__restrict__ perm_out,
+								  uint64_t *__restrict__ vkey_out, uint32_t rb)
 {
 	/* The words of a leaf share their top bits.  They are dealt into SORT_BUCKETS buckets by the next bits (counting
 	 * with LDS atomics - the order of arrival does not matter, the words are unique), every bucket - one or two words
@@ -214,8 +215,12 @@ __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t 
 	}
 	__syncthreads();
 	const uint32_t base = out_base[leaf];
-	for (uint32_t i = threadIdx.x; i < c; i += SORT_LEAF_THREADS)
-		perm_out[base + i] = (uint32_t)(s_w[i] >> up) & rmask;
+	for (uint32_t i = threadIdx.x; i < c; i += SORT_LEAF_THREADS) {
+		const uint64_t w = s_w[i] >> up;
+		perm_out[base + i] = (uint32_t)w & rmask;
+		if (vkey_out)
+			vkey_out[base + i] = w >> rb;	/* the composite value: equal for rows that agree on every column */
+	}
 }
 
 static void sort_packed_bits(uint64_t n, int *b1, int *b2)
@@ -235,12 +240,12 @@ static size_t sort_packed_arena_bytes(uint64_t n)
 	sort_packed_bits(n, &b1, &b2);
 	const size_t leaves = (size_t)1 << (b1 + b2);
 	return mdb_partition_raw_arena_bytes(n, b1, b2, SORT_LEAF_CAP, true, 0) + mdb_align_up((leaves + 1) * 4) +
-	       mdb_align_up(mdb_scan_scratch_words(leaves + 1) * 4) + mdb_align_up(n * 4) + 4096;
+	       mdb_align_up(mdb_scan_scratch_words(leaves + 1) * 4) + mdb_align_up(n * 4) + mdb_align_up(n * 8) + 4096;
 }
 
 /* 0 = *perm holds the result, 1 = not applicable (range too wide, too few rows, skewed values): use the general path */
 static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint64_t *u, unsigned long long *mm,
-			    uint32_t **perm)
+			    uint32_t **perm, uint64_t **vkey)
 {
 	if (n < SORT_PACK_MIN_ROWS || nkeys > SORT_PACK_MAX_KEYS)
 		return 1;
@@ -298,7 +303,8 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
 	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
 	uint32_t *out = (uint32_t *)mdb_arena_take(ctx, n * 4);
-	if (!obase || !otmp || !out)
+	uint64_t *vk = vkey ? (uint64_t *)mdb_arena_take(ctx, n * 8) : NULL;	/* sorted composite values, for callers that look for runs */
+	if (!obase || !otmp || !out || (vkey && !vk))
 		return -MIDORIDB_INTERNAL;
 	if (ps.nleaves <= MDB_SCAN_SMALL) {
 		rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
@@ -312,12 +318,14 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	/* buckets inside a leaf: the 10 bits below the partition bits (the word is left-aligned; `up` >= 1 unused low bits) */
 	const uint32_t bshift = 64u - (uint32_t)(b1 + b2) - 10u;
 	MDB_LAUNCH(ctx, "orderby_leaf", k_sort_leaf, ps.nleaves, SORT_LEAF_THREADS, (const uint64_t *)ps.hv, (const uint32_t *)ps.leaf_cnt,
-		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out);
+		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out, vk, rb);
 	MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if ((uint32_t)h[8] & (2u | 256u))
 		return 1;	/* a region or a bucket overflowed: the values are too unevenly spread for this path */
 	*perm = out;
+	if (vkey)
+		*vkey = vk;
 	return 0;
 }
 
@@ -330,8 +338,12 @@ static size_t sort_arena_bytes(uint64_t n)
 
 /* sorts inside an arena the caller has begun (sort_arena_bytes(n) available); *perm = the arena buffer that holds
  * the final permutation.  Synchronises per key (the digit range comes back from the device). */
-static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t **perm)
+/* vkey (optional): receives the sorted composite values when the packed path ran (rows equal in every column have equal
+ * values), NULL otherwise */
+static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t **perm, uint64_t **vkey = NULL)
 {
+	if (vkey)
+		*vkey = NULL;
 	const size_t hist_words = mdb_sort_pass_hist_words(n);
 	uint64_t *u[2] = { (uint64_t *)mdb_arena_take(ctx, n * 8), (uint64_t *)mdb_arena_take(ctx, n * 8) };
 	uint32_t *pm[2] = { (uint32_t *)mdb_arena_take(ctx, n * 4), (uint32_t *)mdb_arena_take(ctx, n * 4) };
@@ -341,9 +353,11 @@ static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int
 	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
 		return -MIDORIDB_INTERNAL;
 	{
-		const int prc = sort_perm_packed(ctx, keys, nkeys, n, u[0], mm, perm);
+		const int prc = sort_perm_packed(ctx, keys, nkeys, n, u[0], mm, perm, vkey);
 		if (prc <= 0)
 			return prc;
+		if (vkey)
+			*vkey = NULL;
 	}
 	int rc = mdb_dev_iota32(ctx, pm[0], n);
 	if (rc)
@@ -452,6 +466,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_distinct_heads(distinct_args a
 size_t mdb_filter_arena_bytes(uint64_t n);
 int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint32_t *out_sel, uint32_t **d_total);
 
+__global__ __launch_bounds__(SORT_THREADS) void k_distinct_heads_vkey(const uint64_t *__restrict__ vkey, const uint32_t *__restrict__ perm, uint64_t n,
+								       int64_t *__restrict__ flags)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS)
+		if (k == 0 || vkey[k] != vkey[k - 1])
+			flags[perm[k]] = 1;
+}
+
 extern "C" int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_sel,
 				    uint64_t *out_count)
 {
@@ -463,7 +485,8 @@ extern "C" int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key 
 	if (rc)
 		return rc;
 	uint32_t *perm = NULL;
-	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm);
+	uint64_t *vkey = NULL;
+	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm, &vkey);
 	if (rc)
 		return rc;
 	int64_t *flags = (int64_t *)mdb_arena_take(ctx, n * 8);
@@ -476,7 +499,11 @@ extern "C" int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key 
 		a.key[c] = keys[c];
 	a.nkeys = nkeys;
 	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
-	MDB_LAUNCH(ctx, "distinct_heads", k_distinct_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	if (vkey) {
+		MDB_LAUNCH(ctx, "distinct_heads", k_distinct_heads_vkey, grid, SORT_THREADS, (const uint64_t *)vkey, (const uint32_t *)perm, n, flags);
+	} else {
+		MDB_LAUNCH(ctx, "distinct_heads", k_distinct_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	}
 	uint32_t *d_total = NULL;
 	rc = mdb_filter_nonzero64(ctx, flags, n, out_sel, &d_total);
 	if (rc)
@@ -519,6 +546,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_group_heads(distinct_args a, c
 	}
 }
 
+/* the same from the sorted composite values of the packed sort: a streaming comparison of neighbours instead of four
+ * random column reads per row (4.5 ms -> 0.3 ms per 10^8 rows and two columns) */
+__global__ __launch_bounds__(SORT_THREADS) void k_group_heads_vkey(const uint64_t *__restrict__ vkey, uint64_t n, int64_t *__restrict__ flags)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS)
+		flags[k] = (k == 0 || vkey[k] != vkey[k - 1]) ? 1 : 0;
+}
+
 /* head_pos[g] = sorted position of group g's first row (ascending); record g = (perm[head] << (64 - kbits)) | run length */
 __global__ __launch_bounds__(SORT_THREADS) void k_group_records(const uint32_t *__restrict__ head_pos, uint64_t G, uint64_t n,
 								 const uint32_t *__restrict__ perm, uint32_t kbits, unsigned long long *__restrict__ rec)
@@ -544,7 +579,8 @@ extern "C" int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort
 	if (rc)
 		return rc;
 	uint32_t *perm = NULL;
-	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm);
+	uint64_t *vkey = NULL;
+	rc = sort_perm_impl(ctx, keys, nkeys, n, &perm, &vkey);
 	if (rc)
 		return rc;
 	int64_t *flags = (int64_t *)mdb_arena_take(ctx, n * 8);
@@ -558,7 +594,11 @@ extern "C" int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort
 		a.key[c] = keys[c];
 	a.nkeys = nkeys;
 	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
-	MDB_LAUNCH(ctx, "groupby_heads", k_group_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	if (vkey) {
+		MDB_LAUNCH(ctx, "groupby_heads", k_group_heads_vkey, grid, SORT_THREADS, (const uint64_t *)vkey, n, flags);
+	} else {
+		MDB_LAUNCH(ctx, "groupby_heads", k_group_heads, grid, SORT_THREADS, a, (const uint32_t *)perm, n, flags);
+	}
 	uint32_t *d_total = NULL;
 	rc = mdb_filter_nonzero64(ctx, flags, n, head_pos, &d_total);
 	if (rc)

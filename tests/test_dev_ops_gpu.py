@@ -956,3 +956,30 @@ def test_narrow_form_window_anywhere_in_the_int64_range(dev, narrow_mode, shape)
     el, er = orc.join_pairs(kl, nl, kr_u, None)
     l, r = dev.join_pairs(dl, dnl, dev.to_dev(kr_u), None)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+@pytest.mark.parametrize("n", [262_144, 600_001])
+def test_group_count_multi_and_distinct_on_the_packed_sort_path(dev, n):
+    """From 2^18 rows on, INT64 columns whose ranges fit one word are sorted by the packed path and the group / distinct
+    run heads come from its sorted composite values (no per-row column gathers): against the numpy oracle with NULLs,
+    negative values, a row-id vector, many and few groups; a DOUBLE column keeps the general path."""
+    rng = np.random.default_rng(n + 31)
+    a = rng.integers(-50, 50, n, dtype=np.int64)
+    b = rng.integers(10**12, 10**12 + 300, n, dtype=np.int64)
+    c = rng.integers(0, 2, n, dtype=np.int64)
+    x = np.round(rng.normal(0, 1, n), 0)
+    na, nb = rng.random(n) < 0.1, rng.random(n) < 0.3
+    rid = rng.integers(0, n, n).astype(np.uint32)
+    ad, bd, cd, xd = dev.to_dev(a), dev.to_dev(b), dev.to_dev(c), dev.to_dev(x)
+    nad, nbd, ridd = dev.nullbits_dev(na), dev.nullbits_dev(nb), dev.to_dev(rid)
+    for keys_np, keys_dev in [
+            ([(a, na, None, False, False), (b, nb, None, False, False)], [(ad, nad, None, D.T_INT64, False), (bd, nbd, None, D.T_INT64, False)]),
+            ([(c, None, None, False, False)], [(cd, None, None, D.T_INT64, False)]),
+            ([(b, None, rid, False, False), (a, na, rid, False, False), (c, None, rid, False, False)],
+             [(bd, None, ridd, D.T_INT64, False), (ad, nad, ridd, D.T_INT64, False), (cd, None, ridd, D.T_INT64, False)]),
+            ([(a, None, None, False, False), (x, None, None, True, False)], [(ad, None, None, D.T_INT64, False), (xd, None, None, D.T_DOUBLE, False)])]:
+        first, cnt = dev.group_count_multi(keys_dev, n)
+        ef, ec = orc.group_count_multi(keys_np, n)
+        assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
+        got = _np(dev.distinct_sel(keys_dev, n)).view(np.uint32)
+        assert np.array_equal(got, orc.distinct_sel(keys_np, n))
