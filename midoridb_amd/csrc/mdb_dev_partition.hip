@@ -689,6 +689,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NARROW 4u	/* narrow form: words = fmix32(key) in both halves (mdb_level_args.narrow = 2) */
 #define PART_F_NARROW_RID 8u	/* narrow form with the row id in the low half of the word (narrow = 1; no row-id arrays) */
 #define PART_F_KEYS32 16u	/* the key column is int32 */
+#define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
@@ -763,7 +764,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.nullbits = nullbits;
 		a.n = n;
 		a.hv_in = l ? hv_buf[l - 1] : raw_hv;	/* raw_hv: level 0 reads ready-made 64-bit sort keys */
-		a.skip_zero = (l == 0 && raw_hv) ? 1u : 0u;
+		a.skip_zero = (l == 0 && raw_hv && !(flags & PART_F_NO_GAPS)) ? 1u : 0u;
 		a.rid_in = l ? rid_buf[l - 1] : NULL;
 		a.tiles = tiles;
 		a.hv_out = hv_buf[l];
@@ -977,11 +978,11 @@ size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t 
 }
 
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
-		      uint32_t digits0_used, mdb_part_result *out)
+		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap)
 {
 	part_carver cv = { ctx, false, 0, false };
-	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, hv,
-			      leaf_cap, out, NULL, digits0_used);
+	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS),
+			      MDB_DIGIT_RADIX, 0, false, NULL, hv, leaf_cap, out, NULL, digits0_used);
 }
 
 /* ---- one stable LSD radix pass (ORDER BY) --------------------------------------------------------

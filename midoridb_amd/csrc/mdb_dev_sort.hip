@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_nullflag(const uint64_t *
 
 /* ---- ORDER BY columns (up to 4) whose value ranges and the stream length together fit one word ---------------------
  *
- * word = [ per column: NULL flag | value image - min ] [ stream position ] (left-aligned, bit 0 set so that no word is zero): the
+ * word = [ per column: NULL flag | value image - min ] [ stream position ] (left-aligned): the
  * words are unique, so ANY full sort of them is the stable sort of the column.  That lifts the restriction to stable
  * least-significant-digit passes (ballot ranking: issue-bound, one 24-byte-per-row pass per 8 bits): the words are
  * partitioned by their TOP bits with the histogram-free two-level scatter of the join (8 bytes per row and level),
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, ui
 				v = (v << a.kb[c]) | (sort_image(values[row], key.type, key.desc) - a.lo[c]);
 			}
 		}
-		w[k] = (((v << a.rb) | k) << a.up) | 1ull;
+		w[k] = ((v << a.rb) | k) << a.up;
 	}
 }
 
@@ -278,7 +278,7 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 			kb = 64u - (uint32_t)__builtin_clzll(hi - lo);
 		const uint32_t width = kb + (key->nullbits ? 1u : 0u);	/* the flag bit is spent whenever the column can hold NULLs */
 		total += width;
-		if (total > 63)
+		if (total > 64)
 			return 1;
 		pa.key[c] = *key;
 		pa.lo[c] = lo;
@@ -290,12 +290,12 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	int b1, b2;
 	sort_packed_bits(n, &b1, &b2);
 	/* first-level digits that can occur: the largest word's top bits */
-	const uint64_t wmax = (((vmax << rb) | (n - 1)) << up) | 1ull;
+	const uint64_t wmax = ((vmax << rb) | (n - 1)) << up;
 	const uint32_t digits0 = (uint32_t)(wmax >> (64 - b1)) + 1u;
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	MDB_LAUNCH(ctx, "orderby_pack", k_sort_pack, grid, SORT_THREADS, pa, n, u);
 	mdb_part_result ps;
-	int rc = mdb_partition_raw(ctx, u, n, b1, b2, SORT_LEAF_CAP, true, digits0, &ps);
+	int rc = mdb_partition_raw(ctx, u, n, b1, b2, SORT_LEAF_CAP, true, digits0, &ps, false);	/* no gaps: the zero word is row 0 of the smallest value */
 	if (rc)
 		return rc;
 	if (!ps.leaf_cap)
