@@ -983,3 +983,47 @@ def test_group_count_multi_and_distinct_on_the_packed_sort_path(dev, n):
         assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
         got = _np(dev.distinct_sel(keys_dev, n)).view(np.uint32)
         assert np.array_equal(got, orc.distinct_sel(keys_np, n))
+
+
+@pytest.mark.parametrize("shape", ["thousand", "two", "one", "negative", "span_4096", "span_4097", "outlier", "all_null", "half_null",
+                                   "huge_offset", "sorted_runs"])
+@pytest.mark.parametrize("n", [262_144, 1_300_001])
+def test_group_count_over_a_small_value_range(dev, shape, n):
+    """Plain GROUP BY + COUNT(*) whose key column spans few values (the direct LDS-table path from 2^18 rows on; a value
+    outside the sampled window or a span above 4096 falls back to the partitioned path): groups in first-occurrence
+    order, NULL group included, against the numpy oracle."""
+    rng = np.random.default_rng(n + len(shape))
+    nulls = None
+    if shape == "thousand":
+        k = rng.integers(0, 1000, n)
+    elif shape == "two":
+        k = rng.integers(0, 2, n)
+    elif shape == "one":
+        k = np.full(n, 7)
+    elif shape == "negative":
+        k = rng.integers(-300, -100, n)
+    elif shape == "span_4096":
+        k = rng.integers(5000, 5000 + 4096, n)
+        k[:2] = [5000, 5000 + 4095]
+    elif shape == "span_4097":
+        k = rng.integers(5000, 5000 + 4097, n)
+        k[:2] = [5000, 5000 + 4096]
+    elif shape == "outlier":
+        k = rng.integers(0, 50, n)
+        k[n // 2 + 1] = 10**9                       # not among the sampled rows
+        k[n // 3 + 1] = -70
+    elif shape == "all_null":
+        k = rng.integers(0, 10, n)
+        nulls = np.ones(n, dtype=bool)
+    elif shape == "half_null":
+        k = rng.integers(0, 10, n)
+        nulls = rng.random(n) < 0.5
+        nulls[:3] = [False, True, False]
+    elif shape == "huge_offset":
+        k = 2**62 + rng.integers(0, 600, n)
+    else:
+        k = np.repeat(np.arange(37)[::-1], n // 37 + 1)[:n]
+    k = np.asarray(k, dtype=np.int64)
+    first, cnt = dev.group_count(dev.to_dev(k), dev.nullbits_dev(nulls))
+    e_first, e_cnt = orc.group_count(k, nulls)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
