@@ -36,6 +36,9 @@ struct mdb_dev_ctx {
 	int nh_result;			/* -1 nothing remembered, 0 wide, 1 narrow */
 	int64_t nh_base;		/* the window centre that went with "narrow" */
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
+	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
+	uint64_t pu_dup_n;
+	int pu_dup_skips;
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */

@@ -70,6 +70,9 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->cache_bytes = 0;
 	ctx->narrow_mode = 1;
 	ctx->last_narrow = 0;
+	ctx->pu_dup_keys = NULL;
+	ctx->pu_dup_n = 0;
+	ctx->pu_dup_skips = 0;
 	ctx->nh_kl = ctx->nh_kr = NULL;
 	ctx->nh_nl = ctx->nh_nr = 0;
 	ctx->nh_result = -1;

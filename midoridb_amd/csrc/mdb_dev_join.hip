@@ -1971,6 +1971,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 	__shared__ unsigned long long s_key[GC_SLOTS];
 	__shared__ uint32_t s_val[GC_SLOTS + 1];	/* right row id + 1; [GC_SLOTS] = the key whose hash is 0 (0 = absent) */
 	__shared__ uint32_t s_chunk[4];			/* [0] base [1] used [2] size [3] pairs */
+	__shared__ uint32_t s_abort;			/* a duplicate right key (or a full table) was met: this is not a unique-key join */
 
 	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
 		if (s < GC_SLOTS)
@@ -1979,9 +1980,21 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 	}
 	if (threadIdx.x < 4)
 		s_chunk[threadIdx.x] = 0;
+	if (threadIdx.x == 0)
+		s_abort = 0;
 	uint32_t npairs = 0;
 	__syncthreads();
 	for (uint32_t leaf = blockIdx.x; leaf < a.nleaves; leaf += gridDim.x) {
+		/* The verdict "not unique" is raised ONCE per workgroup and ends its work (one global atomic per duplicate row -
+		 * 10^8 of them on one address for a right table with 16 rows per key - made this failed attempt cost 18 ms);
+		 * workgroups that have not met a duplicate themselves stop as soon as they see the flag. */
+		if (s_abort) {		/* uniform: read after the barriers that ended the previous leaf */
+			if (threadIdx.x == 0)
+				atomicOr(a.status, s_abort);
+			break;
+		}
+		if (*(volatile const uint32_t *)a.status & (32u | 1u))
+			break;
 		uint32_t l0, l1, r0, r1;
 		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
 		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
@@ -2045,15 +2058,15 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 				const uint32_t rid_r = NARROW ? (uint32_t)hr[u] : rr[u];
 				if (key_r == 0) {
 					if (atomicExch(&s_val[GC_SLOTS], rid_r + 1u) != 0)
-						atomicOr(a.status, 32u);
+						s_abort = 32u;
 					continue;
 				}
 				bool created = false;
 				const uint32_t s = leaf_insert(s_key, GC_SLOTS, key_r, &created);
 				if (s == 0xFFFFFFFFu) {
-					atomicOr(a.status, 1u);
+					s_abort = 1u;
 				} else if (!created) {
-					atomicOr(a.status, 32u);	/* the key is already there: not a unique-key join */
+					s_abort = 32u;		/* the key is already there: not a unique-key join */
 				} else {
 					s_val[s] = rid_r + 1u;
 					if (base == r0)
@@ -2128,6 +2141,8 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 			atomicAdd(&s_chunk[3], npairs);
 	}
 	__syncthreads();
+	if (threadIdx.x == 0 && s_abort)
+		atomicOr(a.status, s_abort);	/* (also when it was raised by the workgroup's last leaf) */
 	if (threadIdx.x == 0 && s_chunk[3])
 		atomicAdd(a.rec_valid, s_chunk[3]);
 }
@@ -2429,10 +2444,19 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 		uint64_t uj = 0;
 		bool narrow = false;
 		int64_t base = 0;
-		int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base);
-		if (urc)
-			return urc;
-		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, &ul, &ur, &uj);
+		int urc = 1;
+		/* a right column that proved not unique last time is not tried again (the attempt partitions both tables) */
+		bool known_dups = ctx->pu_dup_keys == keys_r && ctx->pu_dup_n == n_r;
+		if (known_dups && ++ctx->pu_dup_skips > 32) {	/* the buffer may hold other data by now: look again once in a while */
+			known_dups = false;
+			ctx->pu_dup_keys = NULL;
+		}
+		if (!known_dups) {
+			urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base);
+			if (urc)
+				return urc;
+			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, &ul, &ur, &uj);
+		}
 		if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
 			if (ctx->narrow_mode == 1) {
 				ctx->nh_distrust = 8;
@@ -2442,6 +2466,11 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 		}
 		if (urc < 0)
 			return urc;
+		if (urc == 1 && !known_dups) {
+			ctx->pu_dup_keys = keys_r;
+			ctx->pu_dup_n = n_r;
+			ctx->pu_dup_skips = 0;
+		}
 		if (urc == 0) {
 			*out_l = ul;
 			*out_r = ur;

@@ -113,7 +113,27 @@ struct query_output *query_execute(struct database *db, char *query)
 		output->status = ST_ERROR;
 		return output;
 	}
-	run_rpn(db, &rpn, output);
+	{
+		/* MDB_PROF_DUMP=1: per-kernel device time of every statement on stderr (diagnostics; serialises nothing by itself,
+		 * the events ride on the context's stream) */
+		struct mdb_catalog *cat = (struct mdb_catalog *)db->tables;
+		const int dump = getenv("MDB_PROF_DUMP") != NULL && cat && cat->dev;
+		if (dump) {
+			mdb_dev_prof_enable(cat->dev, 1);
+			mdb_dev_prof_reset(cat->dev);
+		}
+		run_rpn(db, &rpn, output);
+		if (dump) {
+			struct mdb_dev_prof_entry e[64];
+			int ne = 0;
+			if (mdb_dev_prof_read(cat->dev, e, 64, &ne) == 0) {
+				fprintf(stderr, "[mdb prof] %.60s\n", query);
+				for (int i = 0; i < ne; i++)
+					fprintf(stderr, "[mdb prof]   %-28s x%-4llu %9.3f ms\n", e[i].name, (unsigned long long)e[i].launches, e[i].total_ms);
+			}
+			mdb_dev_prof_enable(cat->dev, 0);
+		}
+	}
 	mdb_rpn_free(&rpn);
 	return output;
 }

@@ -21,6 +21,13 @@ stmts = [
     "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a ORDER BY id_a LIMIT 10;",
     "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE fa < 100 GROUP BY id_a LIMIT 10;",
     "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b;",
+    "SELECT fa, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY fa;",
+    "SELECT fb, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE fa < 500 AND fb > 100 GROUP BY fb;",
+    "SELECT id_a, fa, fb FROM A INNER JOIN B ON A.id_a = B.id_b WHERE fa = 3 AND fb = 5;",
+    "SELECT id_a, fa FROM A WHERE fa IN (1, 2, 3) LIMIT 10;",
+    "SELECT fa FROM A ORDER BY fa DESC LIMIT 10;",
+    "SELECT fb, id_b FROM B ORDER BY id_b, fb LIMIT 10;",
+    "SELECT COUNT(*) FROM A;",
     "UPDATE A SET fa = 5 WHERE fa = 6;",
     "DELETE FROM B WHERE fb = 299;",
 ]
