@@ -325,7 +325,7 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 				created = old == 0ull;
 			}
 			if (s == 0xFFFFFFFFu) {
-				atomicOr(a.status, 1u);
+				mdb_raise(a.status, 1u);
 			} else {
 				if (IS_L) {
 					atomicAdd(&s_cnt[s], 1ull);
@@ -445,7 +445,7 @@ __device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long
 						s = INSERT ? leaf_insert(s_key, GC_SLOTS, lhv) : leaf_find(s_key, GC_SLOTS, lhv);
 					if (s == 0xFFFFFFFFu) {
 						if (INSERT)
-							atomicOr(a.status, 1u);
+							mdb_raise(a.status, 1u);
 					} else if (IS_L) {
 						atomicAdd(&s_cnt[s], (unsigned long long)__popcll(grp));
 						atomicMin(&s_first[s], rmin);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		const bool hot = nonempty && (heavy_l || heavy_r);
 		const bool live = HEAVY ? hot : (nonempty && !hot);
 		if (!HEAVY && hot && threadIdx.x == 0)
-			atomicOr(a.status, 64u);	/* left to the hot-key path */
+			mdb_raise(a.status, 64u);	/* left to the hot-key path */
 		/* a leaf whose left side fits one register batch (the normal case) is emitted by the threads that
 		 * created its table slots; only oversized (skewed) leaves scan the whole table */
 		const uint32_t build_rows = (HAS_R && BUILD_R) ? r1 - r0 : l1 - l0;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
 					const uint32_t nb = atomicAdd(a.rec_count, want);
 					if (nb + want > a.rec_cap) {
-						atomicOr(a.status, 8u);	/* list capacity exhausted: sizing bug, reported as an error */
+						mdb_raise(a.status, 8u);	/* list capacity exhausted: sizing bug, reported as an error */
 						s_chunk[0] = 0;
 						s_chunk[2] = 0;
 					} else {
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 							mine += c;
 							if (a.kbits) {
 								if (c >> (64 - a.kbits))
-									atomicOr(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+									mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
 								recv = ((unsigned long long)first << (64 - a.kbits)) | c;
 							} else {
 								a.dense_cnt[first] = (int64_t)c;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_hot_slices(gc_args a, hot_arg
 					s_key[s] = 0ull;
 				}
 				if (g == 0xFFFFFFFFu) {
-					atomicOr(a.status, 1u);
+					mdb_raise(a.status, 1u);
 				} else {
 					atomicAdd(&gc[g], c2);
 					if (is_l)
@@ -852,12 +852,12 @@ __global__ __launch_bounds__(1024) void k_hot_finish(gc_args a, hot_args h)
 		mine += c;
 		if (a.kbits) {
 			if (c >> (64 - a.kbits))
-				atomicOr(a.status, 4u);
+				mdb_raise(a.status, 4u);
 			const uint32_t pos = atomicAdd(a.rec_count, 1u);
 			if (pos < a.rec_cap)
 				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
 			else
-				atomicOr(a.status, 8u);
+				mdb_raise(a.status, 8u);
 			nvalid++;
 		} else {
 			a.dense_cnt[first] = (int64_t)c;
@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 		}
 	}
 	if (__ballot(bad) && mdb_lane() == 0)
-		atomicOr(a.status, 1024u);
+		mdb_raise(a.status, 1024u);
 	__syncthreads();
 	const uint32_t copies = a.copy_mask + 1;
 	for (uint32_t off = threadIdx.x; off < a.range; off += GD_THREADS) {
@@ -1840,7 +1840,7 @@ __global__ void k_group_direct_emit(gd_args a, uint32_t kbits, unsigned long lon
 	if (!c)
 		return;
 	if (c >> (64 - kbits))
-		atomicOr(a.status, 4u);
+		mdb_raise(a.status, 4u);
 	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[slot] << (64 - kbits)) | c;
 }
 
@@ -2026,7 +2026,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
 					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
 					const uint32_t nb = atomicAdd(a.rec_count, want);
 					if (nb + want > a.rec_cap) {
-						atomicOr(a.status, 8u);
+						mdb_raise(a.status, 8u);
 						s_chunk[0] = 0;
 						s_chunk[2] = 0;
 					} else {
@@ -2179,7 +2179,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 	if (l0 == l1 || r0 == r1)
 		return;
 	if (threadIdx.x == 0 && r1 - r0 > PJ_CHUNK)
-		atomicOr(a.status, 16u);	/* the emit kernel will sweep this leaf's right rows in several chunks: they must be in row-id order */
+		mdb_raise(a.status, 16u);	/* the emit kernel will sweep this leaf's right rows in several chunks: they must be in row-id order */
 	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
 		if (s < PJ_SLOTS)
 			s_key[s] = 0ull;
@@ -2194,7 +2194,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 		if (hv != 0) {
 			s = leaf_insert(s_key, PJ_SLOTS, hv);
 			if (s == 0xFFFFFFFFu) {
-				atomicOr(a.status, 1u);
+				mdb_raise(a.status, 1u);
 				continue;
 			}
 		}
@@ -2258,7 +2258,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
 		const uint64_t hv = a.hv_r[j];
 		if (hv != 0 && leaf_insert(s_key, PJ_SLOTS, hv) == 0xFFFFFFFFu)
-			atomicOr(a.status, 1u);
+			mdb_raise(a.status, 1u);
 	}
 	__syncthreads();
 

@@ -212,7 +212,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			valid[1] = false;
 	}
 	if (LEVEL0 && ((bad[0] && valid[0]) || (bad[1] && valid[1])))
-		atomicOr(a.status, 128u);	/* a key outside the int32 range: the narrow form does not apply */
+		mdb_raise(a.status, 128u);	/* a key outside the int32 range: the narrow form does not apply */
 	if (RAW && a.skip_zero) {
 		valid[0] = valid[0] && hv[0] != 0;
 		valid[1] = valid[1] && hv[1] != 0;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	if (FAST && threadIdx.x < R) {
 		const bool ok = fast_base + total_d <= a.cap;
 		if (!ok)
-			atomicOr(a.status, 2u);
+			mdb_raise(a.status, 2u);
 		s_ok[threadIdx.x] = ok;
 		s_delta[threadIdx.x] = (int32_t)(fast_child * a.cap + fast_base - off_d);
 	}
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			reinterpret_cast<uint32_t *>(a.hv_out)[g] = (uint32_t)h;
 		else if (INV && a.inverse_out == 2) {
 			if (((uint64_t)h + 0x80000000ull) >> 32)
-				atomicOr(a.status, 128u);	/* the caller's promise (column statistics) does not hold: reported, not truncated */
+				mdb_raise(a.status, 128u);	/* the caller's promise (column statistics) does not hold: reported, not truncated */
 			reinterpret_cast<int32_t *>(a.hv_out)[g] = (int32_t)(int64_t)h;	/* 4-byte wire format */
 		}
 		else if (INV)
