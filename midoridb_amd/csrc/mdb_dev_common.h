@@ -38,6 +38,8 @@ struct mdb_dev_ctx {
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
 	uint64_t pu_dup_n;
+	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */
+	uint64_t pu_dupl_n;
 	int pu_dup_skips;
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */

@@ -72,6 +72,8 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->last_narrow = 0;
 	ctx->pu_dup_keys = NULL;
 	ctx->pu_dup_n = 0;
+	ctx->pu_dupl_keys = NULL;
+	ctx->pu_dupl_n = 0;
 	ctx->pu_dup_skips = 0;
 	ctx->nh_kl = ctx->nh_kr = NULL;
 	ctx->nh_nl = ctx->nh_nr = 0;

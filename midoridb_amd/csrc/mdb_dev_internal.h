@@ -77,6 +77,11 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
 int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_rows, uint32_t kbits,
 			       uint32_t *out_first, int64_t *out_count);
 
+/* (a, b) pairs of 32-bit ids (a < na, b < nb, unique as pairs; at least 2^18 of them) into ascending (a, b) order
+ * (mdb_dev_sort.hip).  0 = done, 1 = not applicable (few pairs, or a's too unevenly spread): the caller sorts another way. */
+int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint64_t na, uint64_t nb, uint32_t *out_a,
+		   uint32_t *out_b);
+
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
 

@@ -2345,8 +2345,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
 	}
 }
 
-/* 0 = done, 1 = not applicable (duplicate right key / overflow: use the general path), 2 = a key outside the int32 range met
- * the narrow form (call again with narrow = false), < 0 = error */
+/* 0 = done, 1 = not applicable (overflow: use the general path), 2 = a key outside the window met the narrow form (call
+ * again with narrow = false), 3 = a right key occurs more than once (not a unique-key join this way round), < 0 = error */
 static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			     const uint64_t *null_r, uint64_t n_r, bool narrow, int64_t base, uint32_t **out_l, uint32_t **out_r,
 			     uint64_t *out_count)
@@ -2407,7 +2407,9 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 	const uint64_t list_len = h[1] >> 32, J = (uint32_t)h[5];
 	if (status & 128u)
 		return 2;
-	if (status & (1u | 2u | 8u | 32u))
+	if (status & 32u)
+		return 3;	/* a right key occurs more than once */
+	if (status & (1u | 2u | 8u))
 		return 1;
 	*out_count = J;
 	if (J == 0)
@@ -2429,6 +2431,105 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 	return 0;
 }
 
+/* the unique-key join with its narrow-form decision and retry; result codes of join_pairs_unique() except 2 */
+static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	bool narrow = false;
+	int64_t base = 0;
+	int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base);
+	if (urc)
+		return urc;
+	urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, out_l, out_r, out_count);
+	if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
+		if (ctx->narrow_mode == 1) {
+			ctx->nh_distrust = 8;
+			gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
+		}
+		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, 0, out_l, out_r, out_count);
+	}
+	return urc;
+}
+
+/* Unique LEFT keys, duplicates on the right (FROM pk_table JOIN fk_table): the unique-key join runs with the sides
+ * swapped - it delivers the pairs in right-row order - and a stable sort by left row id puts them into the reference's
+ * left-major / right-minor order (for one left row the right rows are already ascending).  About half the time of the
+ * general count / scan / emit path.  Same result codes as join_pairs_unique(). */
+static int join_pairs_unique_left(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	if (n_l >= 0x7FFFFFFFull)
+		return 1;
+	uint32_t *sr = NULL, *sl = NULL;	/* swapped call: "left" ids are right rows, "right" ids are left rows */
+	uint64_t J = 0;
+	int rc = join_pairs_unique_auto(ctx, keys_r, null_r, n_r, keys_l, null_l, n_l, &sr, &sl, &J);
+	if (rc)
+		return rc;
+	*out_count = J;
+	if (J == 0)
+		return 0;
+	int64_t *wide = NULL;
+	uint32_t *perm = NULL, *ol = NULL, *orr = NULL;
+	rc = -MIDORIDB_NOMEM;
+	if (mdb_cached_alloc(ctx, J * 8, (void **)&wide) || mdb_cached_alloc(ctx, J * 4, (void **)&perm) ||
+	    mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		(void)mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+		goto fail;
+	}
+	/* the pairs as words, sorted: nothing to widen, no permutation to gather through */
+	rc = mdb_sort_pairs(ctx, sl, sr, J, n_l, n_r, ol, orr);
+	if (rc < 0)
+		goto fail;
+	if (rc == 0) {
+		(void)mdb_cached_free(ctx, wide);
+		(void)mdb_cached_free(ctx, perm);
+		(void)mdb_cached_free(ctx, sr);
+		(void)mdb_cached_free(ctx, sl);
+		*out_l = ol;
+		*out_r = orr;
+		return 0;
+	}
+	/* few pairs or unevenly spread left rows: stable sort of a permutation by left row id, two gathers */
+	rc = mdb_dev_widen32to64(ctx, (const int32_t *)sl, J, wide);
+	if (rc)
+		goto fail;
+	{
+		struct mdb_sort_key key;
+		memset(&key, 0, sizeof(key));
+		key.values = wide;
+		key.type = MDB_T_INT64;
+		rc = mdb_dev_sort_perm(ctx, &key, 1, J, perm);
+		if (rc)
+			goto fail;
+	}
+	rc = mdb_dev_gather32(ctx, sl, perm, J, ol);
+	if (!rc)
+		rc = mdb_dev_gather32(ctx, sr, perm, J, orr);
+	if (!rc)
+		rc = mdb_dev_sync(ctx);
+	if (rc)
+		goto fail;
+	(void)mdb_cached_free(ctx, wide);
+	(void)mdb_cached_free(ctx, perm);
+	(void)mdb_cached_free(ctx, sr);
+	(void)mdb_cached_free(ctx, sl);
+	*out_l = ol;
+	*out_r = orr;
+	return 0;
+fail:
+	if (wide)
+		(void)mdb_cached_free(ctx, wide);
+	if (perm)
+		(void)mdb_cached_free(ctx, perm);
+	if (ol)
+		(void)mdb_cached_free(ctx, ol);
+	if (orr)
+		(void)mdb_cached_free(ctx, orr);
+	(void)mdb_cached_free(ctx, sr);
+	(void)mdb_cached_free(ctx, sl);
+	return rc < 0 ? rc : -MIDORIDB_INTERNAL;
+}
+
 extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
 				  uint64_t *out_count)
@@ -2437,38 +2538,38 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	*out_count = 0;
 	if (n_l == 0 || n_r == 0)
 		return MIDORIDB_OK;
-	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records */
+	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records;
+	 *      unique left keys: the same with the sides swapped and a stable sort.  What a column turned out to be is
+	 *      remembered (by pointer and length), so that a repeated query does not pay for failed attempts. */
 	{
 		uint32_t *ul = NULL, *ur = NULL;
 		uint64_t uj = 0;
-		bool narrow = false;
-		int64_t base = 0;
-		int urc = 1;
-		/* a right column that proved not unique last time is not tried again (the attempt partitions both tables) */
-		bool known_dups = ctx->pu_dup_keys == keys_r && ctx->pu_dup_n == n_r;
-		if (known_dups && ++ctx->pu_dup_skips > 32) {	/* the buffer may hold other data by now: look again once in a while */
-			known_dups = false;
-			ctx->pu_dup_keys = NULL;
+		int urc = 3;
+		bool right_dups = ctx->pu_dup_keys == keys_r && ctx->pu_dup_n == n_r;
+		bool left_dups = ctx->pu_dupl_keys == keys_l && ctx->pu_dupl_n == n_l;
+		if ((right_dups || left_dups) && ++ctx->pu_dup_skips > 32) {	/* the buffers may hold other data by now: look again once in a while */
+			right_dups = left_dups = false;
+			ctx->pu_dup_keys = ctx->pu_dupl_keys = NULL;
 		}
-		if (!known_dups) {
-			urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base);
-			if (urc)
+		if (!right_dups) {
+			urc = join_pairs_unique_auto(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+			if (urc < 0)
 				return urc;
-			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, &ul, &ur, &uj);
-		}
-		if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
-			if (ctx->narrow_mode == 1) {
-				ctx->nh_distrust = 8;
-				gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
+			if (urc == 3) {
+				ctx->pu_dup_keys = keys_r;
+				ctx->pu_dup_n = n_r;
+				ctx->pu_dup_skips = 0;
 			}
-			urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, 0, &ul, &ur, &uj);
 		}
-		if (urc < 0)
-			return urc;
-		if (urc == 1 && !known_dups) {
-			ctx->pu_dup_keys = keys_r;
-			ctx->pu_dup_n = n_r;
-			ctx->pu_dup_skips = 0;
+		if (urc == 3 && !left_dups) {
+			urc = join_pairs_unique_left(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+			if (urc < 0)
+				return urc;
+			if (urc == 3) {
+				ctx->pu_dupl_keys = keys_l;
+				ctx->pu_dupl_n = n_l;
+				ctx->pu_dup_skips = 0;
+			}
 		}
 		if (urc == 0) {
 			*out_l = ul;
@@ -2476,7 +2577,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 			*out_count = uj;
 			return MIDORIDB_OK;
 		}
-		/* urc > 0: a right key occurs twice, or a table / region overflowed: general path below */
+		/* duplicates on both sides, or a table / region overflowed: general path below */
 	}
 	int b1, b2;
 	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_nullflag(const uint64_t *
 #define SORT_LEAF_CAP 4096u
 #define SORT_LEAF_THREADS 512
 #define SORT_BUCKETS 1024u
-#define SORT_BUCKET_MAX 64u
+#define SORT_BUCKET_MAX 1024u
 #define SORT_PACK_MIN_ROWS (1u << 18)
 
 #define SORT_PACK_MAX_KEYS 4
@@ -139,12 +139,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, ui
 __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t *__restrict__ w, const uint32_t *__restrict__ cnt,
 								  const uint32_t *__restrict__ out_base, uint32_t cap, uint32_t up, uint32_t rmask,
 								  uint32_t bshift, uint32_t *status, uint32_t *__restrict__ perm_out,
-								  uint64_t *__restrict__ vkey_out, uint32_t rb)
+								  uint64_t *__restrict__ vkey_out, uint32_t rb, uint32_t *__restrict__ hi32_out)
 {
 	/* The words of a leaf share their top bits.  They are dealt into SORT_BUCKETS buckets by the next bits (counting
 	 * with LDS atomics - the order of arrival does not matter, the words are unique), every bucket - one or two words
-	 * on average - is put in order by one thread, and the leaf is written out.  ~60 KiB of LDS traffic per leaf where a
-	 * bitonic network over the 4096 words moved 1.6 MiB (2.5 ms per 10^8 rows, LDS-bandwidth bound).  A bucket longer
+	 * on average - is put in order by counting ranks, and the leaf is written out.  ~60 KiB of LDS traffic per leaf where
+	 * a bitonic network over the 4096 words moved 1.6 MiB (2.5 ms per 10^8 rows, LDS-bandwidth bound).  A bucket longer
 	 * than SORT_BUCKET_MAX (values bunched in their low bits) is reported and the caller takes the general path. */
 	__shared__ uint64_t s_w[SORT_LEAF_CAP];
 	__shared__ uint32_t s_cnt[SORT_BUCKETS + 1];	/* bucket sizes, then bucket starts (+ the total): 37 KiB of LDS, 4 workgroups per CU */
@@ -197,21 +197,33 @@ __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t 
 			s_w[s_cnt[(uint32_t)(v[e] >> bshift) & (SORT_BUCKETS - 1)] + rank[e]] = v[e];
 	}
 	__syncthreads();
-	for (uint32_t b = threadIdx.x; b < SORT_BUCKETS; b += SORT_LEAF_THREADS) {
-		const uint32_t st = s_cnt[b], m = s_cnt[b + 1] - st;
-		if (m > SORT_BUCKET_MAX) {
-			atomicOr(status, 256u);
-			continue;
-		}
-		for (uint32_t x = 1; x < m; x++) {	/* insertion sort of a handful of words */
-			const uint64_t key = s_w[st + x];
-			uint32_t y = x;
-			while (y > 0 && s_w[st + y - 1] > key) {
-				s_w[st + y] = s_w[st + y - 1];
-				y--;
+	/* order inside the buckets: every word finds its rank among the words of its bucket by counting the smaller ones
+	 * (all threads busy, no dependent chain; one thread sorting a whole bucket by insertion took 5x as long when the
+	 * buckets hold 32 words each - keys with 16 duplicates), then moves to its final place */
+	uint32_t fin[SORT_LEAF_CAP / SORT_LEAF_THREADS];
+#pragma unroll
+	for (int e = 0; e < (int)(SORT_LEAF_CAP / SORT_LEAF_THREADS); e++) {
+		const uint32_t i = threadIdx.x + (uint32_t)e * SORT_LEAF_THREADS;
+		fin[e] = 0;
+		if (i < c) {
+			const uint32_t b = (uint32_t)(v[e] >> bshift) & (SORT_BUCKETS - 1);
+			const uint32_t st = s_cnt[b], m = s_cnt[b + 1] - st;
+			uint32_t r = 0;
+			if (m > SORT_BUCKET_MAX) {
+				mdb_raise(status, 256u);
+			} else {
+				for (uint32_t x = 0; x < m; x++)
+					r += s_w[st + x] < v[e];
 			}
-			s_w[st + y] = key;
+			fin[e] = st + r;
 		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < (int)(SORT_LEAF_CAP / SORT_LEAF_THREADS); e++) {
+		const uint32_t i = threadIdx.x + (uint32_t)e * SORT_LEAF_THREADS;
+		if (i < c)
+			s_w[fin[e]] = v[e];
 	}
 	__syncthreads();
 	const uint32_t base = out_base[leaf];
@@ -220,6 +232,8 @@ __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t 
 		perm_out[base + i] = (uint32_t)w & rmask;
 		if (vkey_out)
 			vkey_out[base + i] = w >> rb;	/* the composite value: equal for rows that agree on every column */
+		if (hi32_out)
+			hi32_out[base + i] = (uint32_t)(w >> rb);
 	}
 }
 
@@ -318,7 +332,7 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	/* buckets inside a leaf: the 10 bits below the partition bits (the word is left-aligned; `up` >= 1 unused low bits) */
 	const uint32_t bshift = 64u - (uint32_t)(b1 + b2) - 10u;
 	MDB_LAUNCH(ctx, "orderby_leaf", k_sort_leaf, ps.nleaves, SORT_LEAF_THREADS, (const uint64_t *)ps.hv, (const uint32_t *)ps.leaf_cnt,
-		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out, vk, rb);
+		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out, vk, rb, (uint32_t *)NULL);
 	MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if ((uint32_t)h[8] & (2u | 256u))
@@ -327,6 +341,71 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	if (vkey)
 		*vkey = vk;
 	return 0;
+}
+
+/* ---- (a, b) pairs of 32-bit ids, unique as pairs, into (a, b) order ------------------------------------------------
+ * word = a << bits(b) | b: the same top-bit partition + leaf sort; the sorted words ARE the pairs, nothing is gathered.
+ * Used by the join whose unique keys are on the left (mdb_dev_join.hip): its pairs arrive in right-row order. */
+__global__ __launch_bounds__(SORT_THREADS) void k_pairs_pack(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n, uint32_t rb,
+							      uint32_t up, uint64_t *__restrict__ w)
+{
+	for (uint64_t k = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k < n; k += (uint64_t)gridDim.x * SORT_THREADS)
+		w[k] = (((uint64_t)a[k] << rb) | b[k]) << up;
+}
+
+/* 0 = done, 1 = the fixed-capacity layout did not hold (skewed a): caller's fallback, < 0 = error.  na / nb: a < na, b < nb. */
+int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint64_t na, uint64_t nb, uint32_t *out_a,
+		   uint32_t *out_b)
+{
+	if (n < SORT_PACK_MIN_ROWS || n >= 0xFFFFFFFFull)
+		return 1;
+	uint32_t ab = 1, rb = 1;
+	while (ab < 32 && (1ull << ab) < na)
+		ab++;
+	while (rb < 32 && (1ull << rb) < nb)
+		rb++;
+	const uint32_t total = ab + rb, up = 64 - total;
+	int b1, b2;
+	sort_packed_bits(n, &b1, &b2);
+	const size_t leaves = (size_t)1 << (b1 + b2);
+	int rc = mdb_arena_begin(ctx, mdb_align_up(n * 8) + mdb_partition_raw_arena_bytes(n, b1, b2, SORT_LEAF_CAP, true, 0) +
+					      mdb_align_up((leaves + 1) * 4) + mdb_align_up(mdb_scan_scratch_words(leaves + 1) * 4) + 8192);
+	if (rc)
+		return rc;
+	uint64_t *w = (uint64_t *)mdb_arena_take(ctx, n * 8);
+	if (!w)
+		return -MIDORIDB_INTERNAL;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	const uint64_t wmax = (((na - 1) << rb) | (nb - 1)) << up;
+	const uint32_t digits0 = (uint32_t)(wmax >> (64 - b1)) + 1u;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	MDB_LAUNCH(ctx, "pairs_pack", k_pairs_pack, grid, SORT_THREADS, a, b, n, rb, up, w);
+	mdb_part_result ps;
+	rc = mdb_partition_raw(ctx, w, n, b1, b2, SORT_LEAF_CAP, true, digits0, &ps, false);
+	if (rc)
+		return rc;
+	if (!ps.leaf_cap)
+		return 1;
+	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
+	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
+	if (!obase || !otmp)
+		return -MIDORIDB_INTERNAL;
+	if (ps.nleaves <= MDB_SCAN_SMALL) {
+		rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
+	} else {
+		MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
+		rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
+	}
+	if (rc)
+		return rc;
+	const uint32_t bshift = 64u - (uint32_t)(b1 + b2) - 10u;
+	MDB_LAUNCH(ctx, "pairs_leaf", k_sort_leaf, ps.nleaves, SORT_LEAF_THREADS, (const uint64_t *)ps.hv, (const uint32_t *)ps.leaf_cnt,
+		   (const uint32_t *)obase, ps.leaf_cap, up, (uint32_t)((1ull << rb) - 1ull), bshift, ctx->d_status, out_b, (uint64_t *)NULL, rb, out_a);
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return ((uint32_t)h[8] & (2u | 256u)) ? 1 : 0;
 }
 
 static size_t sort_arena_bytes(uint64_t n)

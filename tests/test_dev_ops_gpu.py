@@ -1027,3 +1027,33 @@ def test_group_count_over_a_small_value_range(dev, shape, n):
     first, cnt = dev.group_count(dev.to_dev(k), dev.nullbits_dev(nulls))
     e_first, e_cnt = orc.group_count(k, nulls)
     assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n_l,n_r", [(5, 40), (3000, 50_000), (250_000, 900_000), (1_200_000, 2_500_000)])
+def test_join_pairs_unique_left_keys_duplicate_right_keys(dev, narrow_mode, mode, n_l, n_r):
+    """FROM pk_table JOIN fk_table: unique keys on the LEFT, many rows per key on the right - the unique-key join runs
+    with the sides swapped and a stable sort restores the reference's left-major / right-minor pair order.  Repeated on
+    the same columns (the remembered verdicts are used), with NULLs on both sides and unmatched keys."""
+    narrow_mode(mode)
+    rng = np.random.default_rng(n_l * 7 + n_r + mode)
+    kl = rng.permutation(2 * n_l)[:n_l].astype(np.int64) - n_l // 2                  # unique, half of them unmatched
+    kr = rng.integers(-n_l // 2, n_l, n_r, dtype=np.int64)                           # ~n_r / 1.5 n_l rows per key
+    nl = rng.random(n_l) < 0.02
+    nr = rng.random(n_r) < 0.02
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    dl, dnl, dr, dnr = dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr)
+    for _ in range(3):
+        l, r = dev.join_pairs(dl, dnl, dr, dnr)
+        assert l.numel() == len(el)
+        assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+    # the same buffers, now with a duplicate on the left as well: a true N:M join through the general path
+    kl2 = kl.copy()
+    kl2[n_l // 2] = kl2[0]
+    nl2 = nl.copy()
+    nl2[[0, n_l // 2]] = False
+    dl.copy_(torch.from_numpy(kl2))
+    dnl2 = dev.nullbits_dev(nl2)
+    el, er = orc.join_pairs(kl2, nl2, kr, nr)
+    l, r = dev.join_pairs(dl, dnl2, dr, dnr)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
