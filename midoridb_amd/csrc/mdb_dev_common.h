@@ -35,6 +35,11 @@ struct mdb_dev_ctx {
 	uint64_t nh_nl, nh_nr;
 	int nh_result;			/* -1 nothing remembered, 0 wide, 1 narrow */
 	int64_t nh_base;		/* the window centre that went with "narrow" */
+	/* range of the last key sample (smallest / largest of 2 x 4096 evenly spaced keys), by the columns it was taken from */
+	const void *sr_kl, *sr_kr;
+	uint64_t sr_nl, sr_nr;
+	int64_t sr_lo, sr_hi;
+	int sr_valid;
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
 	uint64_t pu_dup_n;

@@ -79,6 +79,8 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->nh_nl = ctx->nh_nr = 0;
 	ctx->nh_result = -1;
 	ctx->nh_distrust = 0;
+	ctx->sr_valid = 0;
+	ctx->sr_kl = ctx->sr_kr = NULL;
 	{
 		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
 		if (e && e[0] >= '0' && e[0] <= '2' && !e[1])

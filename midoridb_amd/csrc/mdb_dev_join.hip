@@ -1480,6 +1480,39 @@ __global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__r
 	}
 }
 
+/* smallest / largest of 2 x GC_NARROW_SAMPLE evenly spaced non-NULL keys (lo > hi: nothing but NULLs); remembered by the
+ * columns, so that the decisions that need it (narrow form, direct tables) share one kernel + sync, and a repeated query
+ * pays none.  fresh: take the sample again (a remembered verdict just proved wrong). */
+static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, bool fresh, int64_t *lo, int64_t *hi)
+{
+	if (!keys_r)
+		n_r = 0;
+	if (!fresh && ctx->sr_valid && ctx->sr_kl == keys_l && ctx->sr_nl == n_l && ctx->sr_kr == keys_r && ctx->sr_nr == n_r) {
+		*lo = ctx->sr_lo;
+		*hi = ctx->sr_hi;
+		return MIDORIDB_OK;
+	}
+	long long *mm = (long long *)(ctx->d_status + 10);
+	int64_t *h = (int64_t *)ctx->h_pinned;
+	h[0] = INT64_MAX;
+	h[1] = INT64_MIN;
+	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
+	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, mm);
+	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*lo = h[0];
+	*hi = h[1];
+	ctx->sr_kl = keys_l;
+	ctx->sr_nl = n_l;
+	ctx->sr_kr = keys_r;
+	ctx->sr_nr = n_r;
+	ctx->sr_lo = *lo;
+	ctx->sr_hi = *hi;
+	ctx->sr_valid = 1;
+	return MIDORIDB_OK;
+}
+
 static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow,
 			   int64_t base = 0)
 {
@@ -1506,22 +1539,19 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	}
 	if (n_l + (keys_r ? n_r : 0) < GC_NARROW_MIN_ROWS)
 		return MIDORIDB_OK;
-	if (ctx->nh_distrust > 0)
+	bool fresh = false;
+	if (ctx->nh_distrust > 0) {
 		ctx->nh_distrust--;
-	else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
+		fresh = true;
+	} else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
 		*base = ctx->nh_base;
 		return MIDORIDB_OK;
 	}
-	long long *mm = (long long *)(ctx->d_status + 10);
-	int64_t *h = (int64_t *)ctx->h_pinned;
-	h[0] = INT64_MAX;
-	h[1] = INT64_MIN;
-	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
-	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, mm);
-	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const int64_t lo = h[0], hi = h[1];
+	int64_t lo = 0, hi = 0;
+	const int src = gc_sample_range(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, fresh, &lo, &hi);
+	if (src)
+		return src;
 	if (lo > hi) {
 		*narrow = true;		/* nothing but NULLs in the sample */
 	} else if (lo >= -(1ll << 31) && hi < (1ll << 31)) {
@@ -1603,12 +1633,36 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	return rc;
 }
 
+static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
+			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
+			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined);
+
 extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 					const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags,
 					int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 					uint64_t *out_groups, uint64_t *out_joined)
 {
 	(void)flags;	/* groups always come out in first-occurrence order, which satisfies both modes */
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	if (n_l && n_r) {
+		/* both key columns inside one window of at most 4096 values (joins on a handful of hot values): counted directly */
+		uint32_t *tmp_first = NULL;
+		if (!out_first && mdb_cached_alloc(ctx, (cap ? cap : 1) * 4, (void **)&tmp_first))
+			tmp_first = NULL;
+		int drc = 1;
+		if (out_first || tmp_first)
+			drc = group_direct_try(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, out_key, out_first ? out_first : tmp_first, out_count,
+					       cap, out_groups, out_joined);
+		if (tmp_first)
+			(void)mdb_cached_free(ctx, tmp_first);
+		if (drc <= 0)
+			return drc;
+		*out_groups = 0;
+		if (out_joined)
+			*out_joined = 0;
+	}
 	return group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 				  cap, out_groups, out_joined);
 }
@@ -1830,7 +1884,11 @@ __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 	}
 }
 
-__global__ void k_group_direct_emit(gd_args a, uint32_t kbits, unsigned long long *rec, uint32_t *rec_n)
+/* g_cnt_r != NULL: join form - a group needs rows on both sides, COUNT(*) = left rows x right rows of the value.  The
+ * record carries the SLOT (+ 1) beside the first row, not the count: counts of hot values (10^7 x 10^7 rows of one key)
+ * do not fit beside a row id; k_group_direct_counts puts them in once the groups are in order. */
+__global__ void k_group_direct_emit(gd_args a, const unsigned long long *g_cnt_r, uint32_t kbits, unsigned long long *rec, uint32_t *rec_n,
+				    unsigned long long *joined)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t slot = t < a.range ? t : (t == a.range ? GD_RANGE : 0xFFFFFFFFu);
@@ -1839,28 +1897,39 @@ __global__ void k_group_direct_emit(gd_args a, uint32_t kbits, unsigned long lon
 	const unsigned long long c = a.g_cnt[slot];
 	if (!c)
 		return;
-	if (c >> (64 - kbits))
-		mdb_raise(a.status, 4u);
-	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[slot] << (64 - kbits)) | c;
+	if (g_cnt_r) {
+		const unsigned long long cr = g_cnt_r[slot];
+		if (!cr || slot == GD_RANGE)
+			return;
+		atomicAdd(joined, c * cr);	/* both below 2^32 (row counts of one GPU's tables) */
+	}
+	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[slot] << (64 - kbits)) | (unsigned long long)(slot + 1);
 }
 
-/* 0 = done, 1 = not applicable (use the partitioned path), < 0 = error */
-static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, bool null_group,
-			    uint32_t *out_first, int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+__global__ void k_group_direct_counts(int64_t *out_count, uint64_t G, const unsigned long long *g_cnt, const unsigned long long *g_cnt_r)
 {
-	if (n < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= G)
+		return;
+	const uint32_t slot = (uint32_t)out_count[g] - 1u;
+	out_count[g] = (int64_t)(g_cnt_r ? g_cnt[slot] * g_cnt_r[slot] : g_cnt[slot]);
+}
+
+/* 0 = done, 1 = not applicable (use the partitioned path), < 0 = error.  keys_r != NULL: the join form (both key columns
+ * inside one window; NULL keys never join) - also the cheap way through joins on a handful of hot values. */
+static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
+			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
+			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	if (n + (keys_r ? n_r : 0) < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
 		return 1;
-	/* range of a sample of the column (the same sample decides about the narrow form if the partitioned path runs after all) */
-	long long *mm = (long long *)(ctx->d_status + 10);
-	int64_t *h = (int64_t *)ctx->h_pinned;
-	h[0] = INT64_MAX;
-	h[1] = INT64_MIN;
-	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
-	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys, nullbits, n, (const int64_t *)NULL, (const uint64_t *)NULL,
-		   (uint64_t)0, mm);
-	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const int64_t lo = h[0], hi = h[1];
+	if (keys_r && (n_r >= 0xFFFFFFFFull || ((uintptr_t)keys_r & 15) || n_r == 0))
+		return 1;
+	/* range of a sample of the column(s) (shared with the narrow-form decision of the partitioned path) */
+	int64_t lo = 0, hi = 0;
+	int rc = gc_sample_range(ctx, keys, nullbits, n, keys_r, null_r, n_r, ctx->nh_distrust > 0, &lo, &hi);
+	if (rc)
+		return rc;
 	if (lo > hi)
 		return 1;
 	const uint64_t span = (uint64_t)hi - (uint64_t)lo + 1;
@@ -1877,7 +1946,7 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 	const size_t order_bytes = mdb_order_records_arena_bytes(GD_RANGE + 1, n, &kbits);
 	if (!order_bytes)
 		return 1;
-	int rc = mdb_arena_begin(ctx, order_bytes + 4 * mdb_align_up((GD_RANGE + 1) * 8) + 8192);
+	rc = mdb_arena_begin(ctx, order_bytes + 6 * mdb_align_up((GD_RANGE + 1) * 8) + 8192);
 	if (rc)
 		return rc;
 	gd_args a;
@@ -1889,36 +1958,71 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 	a.range = range;
 	a.copy_shift = shift;
 	a.copy_mask = copies - 1;
-	a.null_group = null_group ? 1u : 0u;
+	a.null_group = (null_group && !keys_r) ? 1u : 0u;
 	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8);
 	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GD_RANGE + 1) * 4);
 	a.status = ctx->d_status;
 	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8);
-	if (!a.g_cnt || !a.g_first || !rec)
+	unsigned long long *g_cnt_r = keys_r ? (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8) : NULL;
+	uint32_t *g_first_r = keys_r ? (uint32_t *)mdb_arena_take(ctx, (GD_RANGE + 1) * 4) : NULL;
+	if (!a.g_cnt || !a.g_first || !rec || (keys_r && (!g_cnt_r || !g_first_r)))
 		return -MIDORIDB_INTERNAL;
 	uint32_t *rec_n = ctx->d_status + 1;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8, ctx->stream));
+	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
 	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GD_RANGE + 1) * 8, ctx->stream));
 	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_RANGE + 1) * 4, ctx->stream));
-	const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
 	const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
-	MDB_LAUNCH(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, a);
-	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, kbits, rec, rec_n);
+	{
+		const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
+		MDB_LAUNCH(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, a);
+	}
+	if (keys_r) {
+		gd_args b = a;
+		b.keys = keys_r;
+		b.nullbits = null_r;
+		b.n = n_r;
+		b.g_cnt = g_cnt_r;
+		b.g_first = g_first_r;
+		MDB_HIP(ctx, hipMemsetAsync(g_cnt_r, 0, (GD_RANGE + 1) * 8, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(g_first_r, 0xFF, (GD_RANGE + 1) * 4, ctx->stream));
+		const uint64_t chunks = (n_r + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
+		MDB_LAUNCH(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, b);
+	}
+	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, (const unsigned long long *)g_cnt_r, kbits, rec, rec_n,
+		   d_joined);
 	uint32_t *h32 = (uint32_t *)ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (h32[0] & (1024u | 4u))
-		return 1;	/* a value outside the window, or a COUNT(*) too large for a record: the general path knows what to do */
+	if (h32[0] & 1024u)
+		ctx->sr_valid = 0;	/* the sample missed a value outside its range: not to be reused */
+	if (h32[0] & 1024u)
+		return 1;	/* a value outside the window: the partitioned path */
 	const uint64_t G = h32[1];
+	const uint64_t joined = (uint64_t)h32[2] | ((uint64_t)h32[3] << 32);
 	if (G > cap)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
 				   (unsigned long long)G);
 	*out_groups = G;
+	if (out_joined)
+		*out_joined = joined;
 	if (G == 0)
 		return 0;
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
 	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
-	return rc < 0 ? rc : (rc ? -MIDORIDB_INTERNAL : 0);
+	if (rc)
+		return rc < 0 ? rc : -MIDORIDB_INTERNAL;
+	MDB_LAUNCH(ctx, "group_direct_counts", k_group_direct_counts, (uint32_t)((G + 255) / 256), 256, out_count, G, (const unsigned long long *)a.g_cnt,
+		   (const unsigned long long *)g_cnt_r);
+	rc = mdb_dev_sync(ctx);
+	if (rc)
+		return rc;
+	if (out_key) {
+		rc = mdb_dev_gather64(ctx, keys, NULL, out_first, G, out_key, NULL);
+		if (!rc)
+			rc = mdb_dev_sync(ctx);
+	}
+	return rc;
 }
 
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,
@@ -1926,7 +2030,7 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 {
 	(void)flags;
 	*out_groups = 0;
-	const int drc = group_direct_try(ctx, keys, nullbits, n, true, out_first, out_count, cap, out_groups);
+	const int drc = group_direct_try(ctx, keys, nullbits, n, NULL, NULL, 0, true, NULL, out_first, out_count, cap, out_groups, NULL);
 	if (drc <= 0)
 		return drc;
 	return group_count_common(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups,

@@ -1057,3 +1057,41 @@ def test_join_pairs_unique_left_keys_duplicate_right_keys(dev, narrow_mode, mode
     el, er = orc.join_pairs(kl2, nl2, kr, nr)
     l, r = dev.join_pairs(dl, dnl2, dr, dnr)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+@pytest.mark.parametrize("shape", ["hundred", "one_key", "disjoint", "outlier_left", "outlier_right", "nulls", "offset", "span_too_wide"])
+def test_join_group_count_over_a_small_value_range(dev, shape):
+    """Join + GROUP BY join key + COUNT(*) whose key columns both lie in one window of at most 4096 values (joins on a few
+    hot values: N:M counts in the billions) take the direct LDS-table path; an unsampled value outside the window or a
+    wider span sends the operator through the partitioned path.  Keys, counts, first rows, joined-row total, order."""
+    rng = np.random.default_rng(len(shape) * 3)
+    n_l, n_r = 700_000, 1_100_000
+    nl = nr = None
+    if shape == "hundred":
+        kl, kr = rng.integers(0, 100, n_l), rng.integers(20, 140, n_r)
+    elif shape == "one_key":
+        kl, kr = np.full(n_l, 5), np.full(n_r, 5)
+    elif shape == "disjoint":
+        kl, kr = rng.integers(0, 50, n_l), rng.integers(60, 90, n_r)
+    elif shape == "outlier_left":
+        kl, kr = rng.integers(0, 100, n_l), rng.integers(0, 100, n_r)
+        kl[n_l // 2 + 1] = 10**7
+        kr[9] = 10**7
+    elif shape == "outlier_right":
+        kl, kr = rng.integers(0, 100, n_l), rng.integers(0, 100, n_r)
+        kr[n_r // 2 + 1] = -5000
+        kl[3] = -5000
+    elif shape == "nulls":
+        kl, kr = rng.integers(0, 30, n_l), rng.integers(0, 30, n_r)
+        nl, nr = rng.random(n_l) < 0.3, rng.random(n_r) < 0.6
+    elif shape == "offset":
+        kl, kr = -(2**50) + rng.integers(0, 3000, n_l), -(2**50) + rng.integers(0, 3000, n_r)
+    else:
+        kl, kr = rng.integers(0, 5000, n_l), rng.integers(0, 5000, n_r)
+    kl, kr = np.asarray(kl, dtype=np.int64), np.asarray(kr, dtype=np.int64)
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    for _ in range(2):
+        k, c, f, j = dev.join_group_count(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+        assert j == ej
+        assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
