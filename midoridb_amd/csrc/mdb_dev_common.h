@@ -40,6 +40,11 @@ struct mdb_dev_ctx {
 	uint64_t sr_nl, sr_nr;
 	int64_t sr_lo, sr_hi;
 	int sr_valid;
+	const void *gh_keys;		/* distinct values among the sampled keys of a column (group_hashed_try) */
+	uint64_t gh_n;
+	uint32_t gh_distinct;
+	int gh_uses;
+	int sr_uses, nh_uses;		/* remembered verdicts expire after a few uses: the same buffer may hold other data by then */
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
 	uint64_t pu_dup_n;

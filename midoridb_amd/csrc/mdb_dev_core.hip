@@ -80,6 +80,11 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->nh_result = -1;
 	ctx->nh_distrust = 0;
 	ctx->sr_valid = 0;
+	ctx->sr_uses = ctx->nh_uses = 0;
+	ctx->gh_keys = NULL;
+	ctx->gh_n = 0;
+	ctx->gh_distinct = 0;
+	ctx->gh_uses = 0;
 	ctx->sr_kl = ctx->sr_kr = NULL;
 	{
 		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */

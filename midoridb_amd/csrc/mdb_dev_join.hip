@@ -1428,6 +1428,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
  * enough for the bytes to matter).  mdb_dev_set_narrow_keys(): 0 never, 1 as described (default), 2 always try. */
 #define GC_NARROW_MIN_ROWS (1u << 20)
 #define GC_NARROW_SAMPLE 4096u
+#define GC_HINT_USES 8		/* a remembered sample / verdict serves this many calls, then the data is looked at again (one
+				 * tiny kernel + sync in eight calls; a buffer that was refilled is noticed within eight) */
 
 __device__ static inline long long gc_wave_min_i64(long long v)
 {
@@ -1488,7 +1490,8 @@ static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 {
 	if (!keys_r)
 		n_r = 0;
-	if (!fresh && ctx->sr_valid && ctx->sr_kl == keys_l && ctx->sr_nl == n_l && ctx->sr_kr == keys_r && ctx->sr_nr == n_r) {
+	if (!fresh && ctx->sr_valid && ctx->sr_kl == keys_l && ctx->sr_nl == n_l && ctx->sr_kr == keys_r && ctx->sr_nr == n_r &&
+	    ++ctx->sr_uses < GC_HINT_USES) {
 		*lo = ctx->sr_lo;
 		*hi = ctx->sr_hi;
 		return MIDORIDB_OK;
@@ -1510,6 +1513,7 @@ static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	ctx->sr_lo = *lo;
 	ctx->sr_hi = *hi;
 	ctx->sr_valid = 1;
+	ctx->sr_uses = 0;
 	return MIDORIDB_OK;
 }
 
@@ -1522,6 +1526,7 @@ static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l
 	ctx->nh_nr = keys_r ? n_r : 0;
 	ctx->nh_result = narrow ? 1 : 0;
 	ctx->nh_base = base;
+	ctx->nh_uses = 0;
 }
 
 /* *narrow: try the narrow form; *base: centre of the 2^32-wide window of key values it will be tried with (0 = the plain
@@ -1543,7 +1548,8 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	if (ctx->nh_distrust > 0) {
 		ctx->nh_distrust--;
 		fresh = true;
-	} else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0)) {
+	} else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0) &&
+		   ++ctx->nh_uses < GC_HINT_USES) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
 		*base = ctx->nh_base;
 		return MIDORIDB_OK;
@@ -2025,6 +2031,291 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 	return rc;
 }
 
+/* ------------------------------------------------------------------ GROUP BY with few distinct values, any value range
+ *
+ * The direct tables above need the values themselves to be close together.  A thousand customer ids scattered over the
+ * int64 range are the same shape - few groups, 10^5 equal rows each - and cost 3 ms per 10^8 rows through the partitioned
+ * path (a thousand hot leaves).  When a sample of the column holds few distinct values, every workgroup aggregates its
+ * share of the rows in an LDS hash table keyed by the hashed value (equal values of a wave are merged first, so a hot
+ * value costs one table update per wave, not one per row) and merges its table into a global one; a workgroup table that
+ * fills up (the sample was wrong about the column) raises a flag and the partitioned path takes over. */
+#define GH_SLOTS 4093u		/* per workgroup (prime): 12 B/slot + ... = 64 KiB, two workgroups per CU */
+#define GH_MAX_FILL 2800u	/* distinct values a workgroup table may take */
+#define GH_GSLOTS 16381u	/* global table (prime) */
+#define GH_SAMPLE_MAX 1200u	/* distinct values among the 4096 sampled keys up to which the path is tried */
+#define GH_MERGE_ROUNDS 16
+
+__global__ __launch_bounds__(1024) void k_key_sample_distinct(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nullbits, uint64_t n,
+							       uint32_t *out)
+{
+	/* number of distinct values among GC_NARROW_SAMPLE evenly spaced non-NULL keys (an LDS set) */
+	__shared__ unsigned long long s_set[8192];
+	__shared__ uint32_t s_n, s_zero;
+	for (uint32_t i = threadIdx.x; i < 8192; i += 1024)
+		s_set[i] = 0ull;
+	if (threadIdx.x == 0)
+		s_n = s_zero = 0;
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < GC_NARROW_SAMPLE; t += 1024) {
+		const uint64_t i = (uint64_t)t * n / GC_NARROW_SAMPLE;
+		if (nullbits && mdb_bit_is_set(nullbits, i))
+			continue;
+		const uint64_t hv = mdb_fmix64((uint64_t)keys[i]);
+		if (hv == 0) {
+			if (atomicExch(&s_zero, 1u) == 0)
+				atomicAdd(&s_n, 1u);
+			continue;
+		}
+		uint32_t s = (uint32_t)(((hv >> 32) * 8192ull) >> 32);
+		for (;;) {
+			const unsigned long long old = atomicCAS(&s_set[s], 0ull, (unsigned long long)hv);
+			if (old == 0ull) {
+				atomicAdd(&s_n, 1u);
+				break;
+			}
+			if (old == hv)
+				break;
+			s = (s + 1) & 8191u;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+		out[0] = s_n;
+}
+
+struct gh_args {
+	const int64_t *keys;
+	const uint64_t *nullbits;
+	uint64_t n;
+	uint32_t null_group;
+	unsigned long long *g_key;	/* [GH_GSLOTS] hashed value, 0 = empty */
+	unsigned long long *g_cnt;	/* [GH_GSLOTS + 2]: + the value whose hash is 0, + the NULL group */
+	uint32_t *g_first;		/* [GH_GSLOTS + 2] */
+	uint32_t *status;		/* bit 11: a table filled up */
+};
+
+__global__ __launch_bounds__(GD_THREADS) void k_group_hashed(gh_args a)
+{
+	__shared__ unsigned long long s_key[GH_SLOTS];
+	__shared__ uint32_t s_cnt[GH_SLOTS + 2];	/* [GH_SLOTS] hash-0 value, [GH_SLOTS + 1] NULL group */
+	__shared__ uint32_t s_first[GH_SLOTS + 2];
+	__shared__ uint32_t s_fill, s_bad;
+	for (uint32_t i = threadIdx.x; i < GH_SLOTS + 2; i += GD_THREADS) {
+		if (i < GH_SLOTS)
+			s_key[i] = 0ull;
+		s_cnt[i] = 0;
+		s_first[i] = 0xFFFFFFFFu;
+	}
+	if (threadIdx.x == 0)
+		s_fill = s_bad = 0;
+	__syncthreads();
+	for (uint64_t row0 = (uint64_t)blockIdx.x * (2 * GD_THREADS); row0 < a.n; row0 += (uint64_t)gridDim.x * (2 * GD_THREADS)) {
+		if (s_bad)
+			break;		/* (uniform enough: read by every thread at the top of a round; a late reader only does one more round) */
+		const uint64_t i0 = row0 + 2 * (uint64_t)threadIdx.x;
+		int64_t k[2] = { 0, 0 };
+		if (i0 + 1 < a.n) {
+			const longlong2 q = *reinterpret_cast<const longlong2 *>(a.keys + i0);
+			k[0] = q.x;
+			k[1] = q.y;
+		} else if (i0 < a.n) {
+			k[0] = a.keys[i0];
+		}
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			const uint64_t row = i0 + (uint64_t)u;
+			const bool valid = row < a.n;
+			const bool isnull = valid && a.nullbits && mdb_bit_is_set(a.nullbits, row);
+			if (a.nullbits) {
+				const uint64_t nm = __ballot(isnull);
+				if (nm && a.null_group && mdb_lane() == (uint32_t)__ffsll((long long)nm) - 1u) {
+					atomicAdd(&s_cnt[GH_SLOTS + 1], (uint32_t)__popcll(nm));
+					atomicMin(&s_first[GH_SLOTS + 1], (uint32_t)row);
+				}
+			}
+			const bool act = valid && !isnull;
+			const uint64_t hv = act ? mdb_fmix64((uint64_t)k[u]) : 0ull;
+			/* equal values of the wave are merged: up to GH_MERGE_ROUNDS leaders update the table for all lanes that
+			 * hold their value; whoever is left (many distinct values in the wave: little contention) goes alone */
+			uint64_t pending = __ballot(act);
+			uint32_t mult = 1, first_row = (uint32_t)row;
+			bool mine_todo = act;
+			for (int round = 0; round < GH_MERGE_ROUNDS && pending; round++) {
+				const int leader = __ffsll((long long)pending) - 1;
+				const uint32_t llo = (uint32_t)__shfl((int)(uint32_t)hv, leader, MDB_WAVE);
+				const uint32_t lhi = (uint32_t)__shfl((int)(uint32_t)(hv >> 32), leader, MDB_WAVE);
+				const bool same = mine_todo && (uint32_t)hv == llo && (uint32_t)(hv >> 32) == lhi;
+				const uint64_t grp = __ballot(same);
+				if (same) {
+					if ((int)mdb_lane() == leader) {
+						mult = (uint32_t)__popcll(grp);		/* the leader holds the smallest row of its group (rows grow with the lane) */
+					} else {
+						mine_todo = false;
+					}
+				}
+				pending &= ~grp;	/* (the leader stays in the loop: its value cannot come up again, and all leaders then
+							 * update the table together instead of one after the other) */
+				if (__popcll(grp) < 3)
+					break;		/* the wave's values are diverse: merging more leaders costs more than the atomics it saves */
+			}
+			if (mine_todo) {
+				uint32_t s;
+				if (hv == 0) {
+					s = GH_SLOTS;
+				} else {
+					s = leaf_slot(hv, GH_SLOTS);
+					const uint32_t step = leaf_step(hv, GH_SLOTS);
+					uint32_t probe = 0;
+					for (;;) {
+						const unsigned long long old = atomicCAS(&s_key[s], 0ull, (unsigned long long)hv);
+						if (old == hv)
+							break;
+						if (old == 0ull) {
+							if (atomicAdd(&s_fill, 1u) >= GH_MAX_FILL)
+								s_bad = 1;
+							break;
+						}
+						if (++probe >= GH_SLOTS) {
+							s_bad = 1;
+							s = 0xFFFFFFFFu;
+							break;
+						}
+						s += step;
+						if (s >= GH_SLOTS)
+							s -= GH_SLOTS;
+					}
+				}
+				if (s != 0xFFFFFFFFu) {
+					atomicAdd(&s_cnt[s], mult);
+					atomicMin(&s_first[s], first_row);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (s_bad) {
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 2048u);
+		return;
+	}
+	/* merge into the global table */
+	for (uint32_t s = threadIdx.x; s < GH_SLOTS + 2; s += GD_THREADS) {
+		const uint32_t c = s_cnt[s];
+		if (!c)
+			continue;
+		uint32_t g;
+		if (s >= GH_SLOTS) {
+			g = GH_GSLOTS + (s - GH_SLOTS);
+		} else {
+			const uint64_t hv = s_key[s];
+			g = leaf_slot(hv, GH_GSLOTS);
+			const uint32_t step = leaf_step(hv, GH_GSLOTS);
+			uint32_t probe = 0;
+			for (;;) {
+				const unsigned long long old = atomicCAS(&a.g_key[g], 0ull, (unsigned long long)hv);
+				if (old == 0ull || old == hv)
+					break;
+				if (++probe >= GH_GSLOTS) {
+					mdb_raise(a.status, 2048u);
+					g = 0xFFFFFFFFu;
+					break;
+				}
+				g += step;
+				if (g >= GH_GSLOTS)
+					g -= GH_GSLOTS;
+			}
+		}
+		if (g != 0xFFFFFFFFu) {
+			atomicAdd(&a.g_cnt[g], (unsigned long long)c);
+			atomicMin(&a.g_first[g], s_first[s]);
+		}
+	}
+}
+
+__global__ void k_group_hashed_emit(gh_args a, uint32_t kbits, unsigned long long *rec, uint32_t *rec_n)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= GH_GSLOTS + 2 || !a.g_cnt[g])
+		return;
+	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[g] << (64 - kbits)) | (unsigned long long)(g + 1);
+}
+
+/* 0 = done, 1 = not applicable, < 0 = error */
+static int group_hashed_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, bool null_group, uint32_t *out_first,
+			    int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+{
+	if (n < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
+		return 1;
+	/* distinct values in a sample of the column, remembered like the range sample */
+	uint32_t distinct;
+	if (ctx->gh_keys == keys && ctx->gh_n == n && ++ctx->gh_uses < GC_HINT_USES) {
+		distinct = ctx->gh_distinct;
+	} else {
+		uint32_t *d = ctx->d_status + 9;
+		MDB_LAUNCH(ctx, "key_sample_distinct", k_key_sample_distinct, 1, 1024, keys, nullbits, n, d);
+		uint32_t *h = (uint32_t *)ctx->h_pinned;
+		MDB_HIP(ctx, hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		distinct = h[0];
+		ctx->gh_keys = keys;
+		ctx->gh_n = n;
+		ctx->gh_distinct = distinct;
+		ctx->gh_uses = 0;
+	}
+	if (distinct > GH_SAMPLE_MAX)
+		return 1;
+	uint32_t kbits = 0;
+	const size_t order_bytes = mdb_order_records_arena_bytes(GH_GSLOTS + 2, n, &kbits);
+	if (!order_bytes)
+		return 1;
+	int rc = mdb_arena_begin(ctx, order_bytes + 4 * mdb_align_up((GH_GSLOTS + 2) * 8) + 8192);
+	if (rc)
+		return rc;
+	gh_args a;
+	memset(&a, 0, sizeof(a));
+	a.keys = keys;
+	a.nullbits = nullbits;
+	a.n = n;
+	a.null_group = null_group ? 1u : 0u;
+	a.g_key = (unsigned long long *)mdb_arena_take(ctx, GH_GSLOTS * 8);
+	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 8);
+	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 4);
+	a.status = ctx->d_status;
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 8);
+	if (!a.g_key || !a.g_cnt || !a.g_first || !rec)
+		return -MIDORIDB_INTERNAL;
+	uint32_t *rec_n = ctx->d_status + 1;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_key, 0, GH_GSLOTS * 8, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GH_GSLOTS + 2) * 8, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GH_GSLOTS + 2) * 4, ctx->stream));
+	const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
+	const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+	MDB_LAUNCH(ctx, "group_hashed", k_group_hashed, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, a);
+	MDB_LAUNCH(ctx, "group_hashed_emit", k_group_hashed_emit, (GH_GSLOTS + 2 + 255) / 256, 256, a, kbits, rec, rec_n);
+	uint32_t *h32 = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h32[0] & 2048u) {
+		ctx->gh_distinct = 0xFFFFFFFFu;	/* the sample was wrong about this column: not tried again while it is remembered */
+		return 1;
+	}
+	const uint64_t G = h32[1];
+	if (G > cap)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
+				   (unsigned long long)G);
+	*out_groups = G;
+	if (G == 0)
+		return 0;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
+	if (rc)
+		return rc < 0 ? rc : -MIDORIDB_INTERNAL;
+	MDB_LAUNCH(ctx, "group_direct_counts", k_group_direct_counts, (uint32_t)((G + 255) / 256), 256, out_count, G, (const unsigned long long *)a.g_cnt,
+		   (const unsigned long long *)NULL);
+	return mdb_dev_sync(ctx);
+}
+
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,
 				   uint32_t *out_first, int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
@@ -2033,6 +2324,11 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	const int drc = group_direct_try(ctx, keys, nullbits, n, NULL, NULL, 0, true, NULL, out_first, out_count, cap, out_groups, NULL);
 	if (drc <= 0)
 		return drc;
+	*out_groups = 0;
+	const int hrc = group_hashed_try(ctx, keys, nullbits, n, true, out_first, out_count, cap, out_groups);
+	if (hrc <= 0)
+		return hrc;
+	*out_groups = 0;
 	return group_count_common(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups,
 				  NULL);
 }

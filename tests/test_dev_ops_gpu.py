@@ -1095,3 +1095,24 @@ def test_join_group_count_over_a_small_value_range(dev, shape):
         assert j == ej
         assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+
+
+@pytest.mark.parametrize("d", [1, 7, 1000, 1150, 2600, 9000])
+@pytest.mark.parametrize("n", [262_144, 1_500_000])
+def test_group_count_few_distinct_values_anywhere_in_the_int64_range(dev, d, n):
+    """Plain GROUP BY + COUNT(*) over few distinct values that are NOT close together (the hashed per-workgroup tables; the
+    sample decides, a workgroup table that fills up sends the operator to the partitioned path): first-occurrence order,
+    NULL group, the value 0 (whose hash is 0), against the numpy oracle.  Twice, so that remembered verdicts are used."""
+    rng = np.random.default_rng(n + d)
+    vals = np.unique(np.concatenate([[0, -1, np.iinfo(np.int64).min, np.iinfo(np.int64).max],
+                                     rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, d, dtype=np.int64)]))[:max(d, 1)]
+    if d >= 2:
+        vals[0] = 0
+    k = vals[rng.integers(0, len(vals), n)]
+    k[:3] = vals[-1]
+    nulls = (rng.random(n) < 0.05) if d != 7 else None
+    e_first, e_cnt = orc.group_count(k, nulls)
+    kd, nd = dev.to_dev(k), dev.nullbits_dev(nulls)
+    for _ in range(2):
+        first, cnt = dev.group_count(kd, nd)
+        assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
