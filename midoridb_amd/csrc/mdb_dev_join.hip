@@ -273,7 +273,21 @@ __device__ static inline void gc_prefetch(const gc_args &a, uint32_t l0, uint32_
 }
 
 /* One side of a leaf goes INTO the table (insert-or-find, count, first left row id) ... */
-template <bool IS_L, int NW>
+__device__ static inline uint32_t gc_wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_xor((int)v, d, MDB_WAVE);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+
+/* MERGE (the plain GROUP BY instance): lanes of a wave that hold the same value are merged before the table is touched -
+ * one insert + one counter update for the group instead of one per row on the same LDS address (GROUP BY over 10^4 - 10^6
+ * distinct values: leaves with a few values and thousands of rows).  Given up after the first round that finds no
+ * duplicates of the leader, so columns of distinct values pay one ballot. */
+template <bool IS_L, int NW, bool MERGE = false>
 __device__ static inline void gc_build_side(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
 					    gc_batch &b, uint32_t x0, uint32_t x1, uint32_t own[LEAF_BATCH])
 {
@@ -289,13 +303,43 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 		uint32_t s_[LEAF_BATCH], step_[LEAF_BATCH];
 		unsigned long long old_[LEAF_BATCH];
 		bool act_[LEAF_BATCH];
+		uint32_t mult_[LEAF_BATCH], rid_[LEAF_BATCH];
+		bool drop_[LEAF_BATCH];
 #pragma unroll
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
+			mult_[u] = 1;
+			rid_[u] = IS_L ? gc_batch_rid<NW>(a, b, u) : 0u;
+			drop_[u] = false;
+			if (MERGE && x1 - x0 > GC_THREADS * LEAF_BATCH) {	/* (uniform) a leaf beyond one register batch: more rows than a
+										 * table of distinct values could hold - duplicates for sure */
+				const bool in = i < x1;
+				uint64_t pending = __ballot(in);
+				for (int round = 0; round < 8 && pending; round++) {
+					const int leader = __ffsll((long long)pending) - 1;
+					const uint32_t llo = (uint32_t)__shfl((int)(uint32_t)hv, leader, MDB_WAVE);
+					const uint32_t lhi = (uint32_t)__shfl((int)(uint32_t)(hv >> 32), leader, MDB_WAVE);
+					const bool same = in && !drop_[u] && (uint32_t)hv == llo && (uint32_t)(hv >> 32) == lhi;
+					const uint64_t grp = __ballot(same);
+					const uint32_t cnt = (uint32_t)__popcll(grp);
+					if (cnt < 8)
+						break;		/* few lanes per value: the LDS atomics cope, and a round costs more than it saves */
+					const uint32_t rmin = IS_L ? gc_wave_min_u32(same ? rid_[u] : 0xFFFFFFFFu) : 0u;
+					if (same) {
+						if ((int)mdb_lane() == leader) {
+							mult_[u] = cnt;
+							rid_[u] = rmin;
+						} else {
+							drop_[u] = true;
+						}
+					}
+					pending &= ~grp;
+				}
+			}
 			if (base == x0)
 				own[u] = 0xFFFFFFFFu;
-			act_[u] = i < x1 && hv != 0;
+			act_[u] = i < x1 && hv != 0 && !drop_[u];
 			s_[u] = leaf_slot(hv, GC_SLOTS);
 			step_[u] = leaf_step(hv, GC_SLOTS);
 			old_[u] = act_[u] ? atomicCAS(&s_key[s_[u]], 0ull, (unsigned long long)hv) : 0ull;
@@ -304,7 +348,7 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 		for (int u = 0; u < LEAF_BATCH; u++) {
 			const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
 			const uint64_t hv = gc_batch_hv<IS_L, NW>(a, b, u);
-			if (i >= x1)
+			if (i >= x1 || drop_[u])
 				continue;
 			uint32_t s = GC_SLOTS;		/* the key whose hash is 0 has the side slot */
 			bool created = false;
@@ -328,10 +372,10 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 				mdb_raise(a.status, 1u);
 			} else {
 				if (IS_L) {
-					atomicAdd(&s_cnt[s], 1ull);
-					atomicMin(&s_first[s], gc_batch_rid<NW>(a, b, u));
+					atomicAdd(&s_cnt[s], (unsigned long long)mult_[u]);
+					atomicMin(&s_first[s], rid_[u]);
 				} else {
-					atomicAdd(&s_cnt[s], 1ull << 32);
+					atomicAdd(&s_cnt[s], (unsigned long long)mult_[u] << 32);
 				}
 				if (created && base == x0)
 					own[u] = s;	/* this thread emits (and clears) the group */
@@ -402,16 +446,6 @@ __device__ static inline void gc_probe_side(const gc_args &a, const unsigned lon
  * first merge their duplicates - leader's key, ballot of the lanes that hold the same key, one table operation for
  * the whole group - so the table sees one update per distinct key per wave instead of one per row. */
 #define GC_HEAVY (8u * GC_THREADS * LEAF_BATCH)	/* floor of the hot threshold (gc_args.heavy_l / heavy_r) */
-
-__device__ static inline uint32_t gc_wave_min_u32(uint32_t v)
-{
-#pragma unroll
-	for (int d = 1; d < MDB_WAVE; d <<= 1) {
-		const uint32_t o = (uint32_t)__shfl_xor((int)v, d, MDB_WAVE);
-		v = o < v ? o : v;
-	}
-	return v;
-}
 
 template <bool IS_L, bool INSERT, int NW = 2>
 __device__ static inline void gc_side_heavy(const gc_args &a, unsigned long long *s_key, unsigned long long *s_cnt, uint32_t *s_first,
@@ -582,7 +616,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 				if (HEAVY && heavy_l)
 					gc_side_heavy<true, true>(a, s_key, s_cnt, s_first, b, l0, l1);
 				else
-					gc_build_side<true, NW>(a, s_key, s_cnt, s_first, b, l0, l1, own);
+					gc_build_side<true, NW, !HAS_R>(a, s_key, s_cnt, s_first, b, l0, l1, own);
 				__syncthreads();
 				if (HAS_R) {
 					if (HEAVY && heavy_r)
