@@ -2865,6 +2865,8 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 	return 0;
 }
 
+#define SORT_SWAP_MIN_ROWS (1u << 18)
+
 /* the unique-key join with its narrow-form decision and retry; result codes of join_pairs_unique() except 2 */
 static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
@@ -2995,7 +2997,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 				ctx->pu_dup_skips = 0;
 			}
 		}
-		if (urc == 3 && !left_dups) {
+		if (urc == 3 && !left_dups && n_l + n_r >= SORT_SWAP_MIN_ROWS) {	/* small tables: the general path has fewer launches */
 			urc = join_pairs_unique_left(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
 			if (urc < 0)
 				return urc;
