@@ -1673,6 +1673,167 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	return rc;
 }
 
+/* ------------------------------------------------------------------ tiny inputs: one kernel, one workgroup
+ *
+ * The reference's own tests and README work on a handful of rows; through the partitioned pipeline such a query is ~20
+ * launches and two synchronisations (~170 us).  Up to GC_THREADS * LEAF_BATCH rows per table one workgroup does the whole
+ * operator in LDS: table from the left rows (COUNT, first row), right rows counted into it, and - because a left row that
+ * is the first of its group knows so - the groups leave in first-occurrence order by a prefix sum over the rows, no sort. */
+#define TINY_ROWS (GC_THREADS * LEAF_BATCH)
+
+struct tiny_args {
+	const int64_t *keys_l;
+	const uint64_t *null_l;
+	uint32_t n_l;
+	const int64_t *keys_r;
+	const uint64_t *null_r;
+	uint32_t n_r;
+	uint32_t null_group;
+	int64_t *out_key;
+	int64_t *out_count;
+	uint32_t *out_first;
+	uint32_t cap;
+	uint32_t *status;	/* [1] groups, [2..3] joined rows, [0] bit 12: more groups than cap */
+};
+
+template <bool HAS_R>
+__global__ __launch_bounds__(GC_THREADS) void k_tiny_group_count(tiny_args a)
+{
+	__shared__ unsigned long long s_key[GC_SLOTS];
+	__shared__ unsigned long long s_cnt[GC_SLOTS + 2];	/* [GC_SLOTS] the value whose hash is 0, [GC_SLOTS + 1] the NULL group */
+	__shared__ uint32_t s_first[GC_SLOTS + 2];
+	__shared__ uint32_t s_tmp[32];
+	__shared__ unsigned long long s_sum;
+	for (uint32_t s = threadIdx.x; s < GC_SLOTS + 2; s += GC_THREADS) {
+		if (s < GC_SLOTS)
+			s_key[s] = 0ull;
+		s_cnt[s] = 0ull;
+		s_first[s] = 0xFFFFFFFFu;
+	}
+	if (threadIdx.x == 0)
+		s_sum = 0ull;
+	__syncthreads();
+	uint32_t slot[LEAF_BATCH];
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
+		slot[u] = 0xFFFFFFFFu;
+		if (i >= a.n_l)
+			continue;
+		if (a.null_l && mdb_bit_is_set(a.null_l, i)) {
+			if (!HAS_R && a.null_group)
+				slot[u] = GC_SLOTS + 1;
+		} else {
+			const uint64_t hv = mdb_fmix64((uint64_t)a.keys_l[i]);
+			slot[u] = hv ? leaf_insert(s_key, GC_SLOTS, hv) : GC_SLOTS;	/* 2048 values at most: the table cannot fill */
+		}
+		if (slot[u] != 0xFFFFFFFFu) {
+			atomicAdd(&s_cnt[slot[u]], 1ull);
+			atomicMin(&s_first[slot[u]], i);
+		}
+	}
+	__syncthreads();
+	if (HAS_R) {
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t j = threadIdx.x + (uint32_t)u * GC_THREADS;
+			if (j >= a.n_r || (a.null_r && mdb_bit_is_set(a.null_r, j)))
+				continue;
+			const uint64_t hv = mdb_fmix64((uint64_t)a.keys_r[j]);
+			const uint32_t s = hv ? leaf_find(s_key, GC_SLOTS, hv) : GC_SLOTS;
+			if (s != 0xFFFFFFFFu && (uint32_t)s_cnt[s])
+				atomicAdd(&s_cnt[s], 1ull << 32);
+		}
+		__syncthreads();
+	}
+	/* a left row that is the first of its group (and whose group survives the join) is a result row */
+	bool head[LEAF_BATCH];
+	unsigned long long cnt[LEAF_BATCH];
+	uint32_t mine = 0;
+	unsigned long long joined = 0;
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
+		head[u] = false;
+		cnt[u] = 0;
+		if (slot[u] != 0xFFFFFFFFu && s_first[slot[u]] == i) {
+			const unsigned long long c2 = s_cnt[slot[u]];
+			const unsigned long long cl = (uint32_t)c2, cr = c2 >> 32;
+			cnt[u] = HAS_R ? cl * cr : cl;
+			head[u] = cnt[u] != 0;
+			joined += cnt[u];
+		}
+	}
+	/* positions: rows are visited in index order across (u, thread): row = u * GC_THREADS + thread, so the prefix runs
+	 * over u = 0 first, then u = 1 */
+	uint32_t base = 0;
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		uint32_t total;
+		const uint32_t ex = mdb_block_excl_scan(head[u] ? 1u : 0u, s_tmp, &total);
+		if (head[u]) {
+			const uint32_t pos = base + ex;
+			if (pos < a.cap) {
+				const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
+				if (a.out_first)
+					a.out_first[pos] = i;
+				a.out_count[pos] = (int64_t)cnt[u];
+				if (a.out_key)
+					a.out_key[pos] = a.keys_l[i];
+			}
+		}
+		base += total;
+		(void)mine;
+	}
+	if (joined)
+		atomicAdd(&s_sum, joined);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		a.status[0] = base > a.cap ? 4096u : 0u;
+		a.status[1] = base;
+		*(unsigned long long *)(a.status + 2) = s_sum;
+	}
+}
+
+/* 0 = done, 1 = not applicable, < 0 = error */
+static int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			    const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, int64_t *out_key, int64_t *out_count,
+			    uint32_t *out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	if (n_l == 0 || n_l > TINY_ROWS || (has_r && (n_r == 0 || n_r > TINY_ROWS)) || !out_count)
+		return 1;
+	tiny_args a;
+	memset(&a, 0, sizeof(a));
+	a.keys_l = keys_l;
+	a.null_l = null_l;
+	a.n_l = (uint32_t)n_l;
+	a.keys_r = keys_r;
+	a.null_r = null_r;
+	a.n_r = has_r ? (uint32_t)n_r : 0u;
+	a.null_group = null_group ? 1u : 0u;
+	a.out_key = out_key;
+	a.out_count = out_count;
+	a.out_first = out_first;
+	a.cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+	a.status = ctx->d_status;
+	if (has_r) {
+		MDB_LAUNCH(ctx, "tiny_join_group_count", k_tiny_group_count<true>, 1, GC_THREADS, a);
+	} else {
+		MDB_LAUNCH(ctx, "tiny_group_count", k_tiny_group_count<false>, 1, GC_THREADS, a);
+	}
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h[0] & 4096u)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
+				   (unsigned long long)h[1]);
+	*out_groups = h[1];
+	if (out_joined)
+		*out_joined = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+	ctx->last_narrow = 0;
+	return 0;
+}
+
 static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
 			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
 			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined);
@@ -1686,6 +1847,12 @@ extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l,
 	*out_groups = 0;
 	if (out_joined)
 		*out_joined = 0;
+	{
+		const int trc = tiny_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first, cap,
+						 out_groups, out_joined);
+		if (trc <= 0)
+			return trc;
+	}
 	if (n_l && n_r) {
 		/* both key columns inside one window of at most 4096 values (joins on a handful of hot values): counted directly */
 		uint32_t *tmp_first = NULL;
@@ -2355,6 +2522,11 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 {
 	(void)flags;
 	*out_groups = 0;
+	{
+		const int trc = tiny_group_count(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups, NULL);
+		if (trc <= 0)
+			return trc;
+	}
 	const int drc = group_direct_try(ctx, keys, nullbits, n, NULL, NULL, 0, true, NULL, out_first, out_count, cap, out_groups, NULL);
 	if (drc <= 0)
 		return drc;

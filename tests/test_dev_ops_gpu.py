@@ -1116,3 +1116,17 @@ def test_group_count_few_distinct_values_anywhere_in_the_int64_range(dev, d, n):
     for _ in range(2):
         first, cnt = dev.group_count(kd, nd)
         assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+
+
+@pytest.mark.parametrize("n_l,n_r", [(1, 2048), (1023, 1), (1024, 1025), (2047, 2048), (2048, 2048), (2048, 2049), (2049, 7)])
+def test_single_workgroup_path_for_tiny_inputs_and_its_size_boundary(dev, n_l, n_r):
+    """Up to 2048 rows per table the whole operator is one kernel of one workgroup (groups leave in first-occurrence order by
+    a prefix sum over the left rows); one row more and the partitioned path runs.  Same results either side of the boundary:
+    NULLs on both sides, the value 0 (hash 0), negative values, heavy duplicates, plain GROUP BY with its NULL group."""
+    rng = np.random.default_rng(n_l * 5 + n_r)
+    kl = rng.integers(-3, 40, n_l, dtype=np.int64)
+    kr = rng.integers(-3, 60, n_r, dtype=np.int64)
+    nl = rng.random(n_l) < 0.1
+    nr = rng.random(n_r) < 0.1
+    _jgc_check(dev, kl, nl, kr, nr)
+    _jgc_check(dev, np.arange(n_l, dtype=np.int64)[::-1].copy(), None, rng.integers(0, max(n_l, 1), n_r, dtype=np.int64), None)
