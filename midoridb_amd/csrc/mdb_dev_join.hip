@@ -121,6 +121,8 @@ struct gc_args {
 	uint32_t nleaves;
 	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
 	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r = array of 4-byte hash32 */
+	uint32_t merge_all;		/* plain GROUP BY: the key sample held duplicates (some 10^4 - 10^5 distinct values): merge equal
+					 * values per wave in every leaf, not only in the oversize ones */
 };
 
 /* narrow word -> the 64-bit value the leaf tables work with (both halves = the 32-bit hash, so that the slot and the
@@ -312,8 +314,8 @@ __device__ static inline void gc_build_side(const gc_args &a, unsigned long long
 			mult_[u] = 1;
 			rid_[u] = IS_L ? gc_batch_rid<NW>(a, b, u) : 0u;
 			drop_[u] = false;
-			if (MERGE && x1 - x0 > GC_THREADS * LEAF_BATCH) {	/* (uniform) a leaf beyond one register batch: more rows than a
-										 * table of distinct values could hold - duplicates for sure */
+			if (MERGE && (a.merge_all || x1 - x0 > GC_THREADS * LEAF_BATCH)) {	/* (uniform) a leaf beyond one register batch holds
+												 * duplicates for sure; merge_all: the sample says most do */
 				const bool in = i < x1;
 				uint64_t pending = __ballot(in);
 				for (int round = 0; round < 8 && pending; round++) {
@@ -1308,6 +1310,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
 	a.narrow = st->narrow ? 1u : 0u;
+	/* 4096 sampled keys with fewer than 4050 distinct values among them: at most a few 10^5 distinct values in the column */
+	a.merge_all = (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) ? 1u : 0u;
 	{
 		/* hot = far above the side's average leaf: a much larger probe table spread evenly over the leaves is not skew */
 		const uint64_t avg_l = n_l / (pl.nleaves ? pl.nleaves : 1), avg_r = has_r ? n_r / (pl.nleaves ? pl.nleaves : 1) : 0;
@@ -1465,6 +1469,13 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 #define GC_HINT_USES 8		/* a remembered sample / verdict serves this many calls, then the data is looked at again (one
 				 * tiny kernel + sync in eight calls; a buffer that was refilled is noticed within eight) */
 
+/* position of sample t: pseudo-random, not evenly spaced - generated or periodic data (an affine sequence, a table sorted by
+ * a low-cardinality column) looks very different at a fixed stride than it is */
+__device__ static inline uint64_t gc_sample_pos(uint32_t t, uint64_t n)
+{
+	return mdb_fmix64(0x9E3779B97F4A7C15ull * (uint64_t)(t + 1)) % n;
+}
+
 __device__ static inline long long gc_wave_min_i64(long long v)
 {
 #pragma unroll
@@ -1493,14 +1504,14 @@ __global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__r
 	long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
 	if (t < GC_NARROW_SAMPLE) {
 		if (nl) {
-			const uint64_t i = (uint64_t)t * nl / GC_NARROW_SAMPLE;
+			const uint64_t i = gc_sample_pos(t, nl);
 			if (!(nl_bits && mdb_bit_is_set(nl_bits, i))) {
 				lo = kl[i];
 				hi = kl[i];
 			}
 		}
 		if (kr && nr) {
-			const uint64_t j = (uint64_t)t * nr / GC_NARROW_SAMPLE;
+			const uint64_t j = gc_sample_pos(t, nr);
 			if (!(nr_bits && mdb_bit_is_set(nr_bits, j))) {
 				const long long v = kr[j];
 				lo = v < lo ? v : lo;
@@ -2258,7 +2269,7 @@ __global__ __launch_bounds__(1024) void k_key_sample_distinct(const int64_t *__r
 		s_n = s_zero = 0;
 	__syncthreads();
 	for (uint32_t t = threadIdx.x; t < GC_NARROW_SAMPLE; t += 1024) {
-		const uint64_t i = (uint64_t)t * n / GC_NARROW_SAMPLE;
+		const uint64_t i = gc_sample_pos(t, n);
 		if (nullbits && mdb_bit_is_set(nullbits, i))
 			continue;
 		const uint64_t hv = mdb_fmix64((uint64_t)keys[i]);
