@@ -1760,7 +1760,6 @@ __global__ __launch_bounds__(GC_THREADS) void k_tiny_group_count(tiny_args a)
 	/* a left row that is the first of its group (and whose group survives the join) is a result row */
 	bool head[LEAF_BATCH];
 	unsigned long long cnt[LEAF_BATCH];
-	uint32_t mine = 0;
 	unsigned long long joined = 0;
 #pragma unroll
 	for (int u = 0; u < LEAF_BATCH; u++) {
@@ -1794,7 +1793,6 @@ __global__ __launch_bounds__(GC_THREADS) void k_tiny_group_count(tiny_args a)
 			}
 		}
 		base += total;
-		(void)mine;
 	}
 	if (joined)
 		atomicAdd(&s_sum, joined);
