@@ -3048,6 +3048,124 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
 
 #define SORT_SWAP_MIN_ROWS (1u << 18)
 
+/* ------------------------------------------------------------------ tiny materialising join: one kernel, one workgroup
+ *
+ * The reference's own test cases join a handful of rows (tests/engine/executor_select.c:102-260).  Up to TINY_ROWS rows per
+ * table the right keys sit in LDS and every left row simply walks over them - twice: once to count its matches, once,
+ * after a prefix sum over the left rows, to write its pairs - which is the reference's nested loop and delivers its
+ * left-major / right-minor order by construction.  All lanes read the same right row at the same time (an LDS broadcast). */
+#define TINY_PAIRS_CAP 65536u
+
+struct tinyp_args {
+	const int64_t *keys_l;
+	const uint64_t *null_l;
+	uint32_t n_l;
+	const int64_t *keys_r;
+	const uint64_t *null_r;
+	uint32_t n_r;
+	uint32_t *out_l, *out_r;
+	uint32_t cap;
+	uint32_t *status;	/* [0] bit 12: more pairs than cap, [1] pairs */
+};
+
+__global__ __launch_bounds__(GC_THREADS) void k_tiny_join_pairs(tinyp_args a)
+{
+	__shared__ int64_t s_kr[TINY_ROWS];
+	__shared__ uint8_t s_nr[TINY_ROWS];
+	__shared__ uint32_t s_tmp[32];
+	for (uint32_t j = threadIdx.x; j < a.n_r; j += GC_THREADS) {
+		s_kr[j] = a.keys_r[j];
+		s_nr[j] = a.null_r && mdb_bit_is_set(a.null_r, j);
+	}
+	__syncthreads();
+	int64_t kl[LEAF_BATCH];
+	bool ok[LEAF_BATCH];
+	uint32_t m[LEAF_BATCH];
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
+		ok[u] = i < a.n_l && !(a.null_l && mdb_bit_is_set(a.null_l, i));
+		kl[u] = ok[u] ? a.keys_l[i] : 0;
+		m[u] = 0;
+	}
+	for (uint32_t j = 0; j < a.n_r; j++) {
+		const int64_t k = s_kr[j];
+		const bool live = !s_nr[j];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++)
+			m[u] += ok[u] && live && kl[u] == k;
+	}
+	uint32_t base = 0, off[LEAF_BATCH];
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {	/* rows in index order: u = 0 covers rows 0 .. GC_THREADS - 1 */
+		uint32_t total;
+		off[u] = base + mdb_block_excl_scan(m[u], s_tmp, &total);
+		base += total;
+	}
+	if (base <= a.cap) {
+		for (uint32_t j = 0; j < a.n_r; j++) {
+			const int64_t k = s_kr[j];
+			const bool live = !s_nr[j];
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++)
+				if (ok[u] && live && kl[u] == k) {
+					a.out_l[off[u]] = threadIdx.x + (uint32_t)u * GC_THREADS;
+					a.out_r[off[u]] = j;
+					off[u]++;
+				}
+		}
+	}
+	if (threadIdx.x == 0) {
+		a.status[0] = base > a.cap ? 4096u : 0u;
+		a.status[1] = base;
+	}
+}
+
+/* 0 = done, 1 = not applicable (too many rows or pairs), < 0 = error */
+static int tiny_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	if (n_l > TINY_ROWS || n_r > TINY_ROWS)
+		return 1;
+	const uint64_t worst = n_l * n_r;
+	const uint32_t cap = worst < TINY_PAIRS_CAP ? (uint32_t)worst : TINY_PAIRS_CAP;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&ol) || mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %u join pairs", cap);
+	}
+	tinyp_args a;
+	a.keys_l = keys_l;
+	a.null_l = null_l;
+	a.n_l = (uint32_t)n_l;
+	a.keys_r = keys_r;
+	a.null_r = null_r;
+	a.n_r = (uint32_t)n_r;
+	a.out_l = ol;
+	a.out_r = orr;
+	a.cap = cap;
+	a.status = ctx->d_status;
+	mdb_prof_begin(ctx, "tiny_join_pairs");	/* (not MDB_LAUNCH: an error has two buffers to give back) */
+	hipLaunchKernelGGL(k_tiny_join_pairs, dim3(1), dim3(GC_THREADS), 0, ctx->stream, a);
+	mdb_prof_end(ctx);
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	hipError_t e = hipMemcpyAsync(h, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess || (h[0] & 4096u)) {
+		(void)mdb_cached_free(ctx, ol);
+		(void)mdb_cached_free(ctx, orr);
+		if (e != hipSuccess)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "tiny join failed: %s", hipGetErrorString(e));
+		return 1;	/* more pairs than the small buffers hold: the general path sizes its output exactly */
+	}
+	*out_l = ol;
+	*out_r = orr;
+	*out_count = h[1];
+	return 0;
+}
+
 /* the unique-key join with its narrow-form decision and retry; result codes of join_pairs_unique() except 2 */
 static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
@@ -3155,6 +3273,11 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	*out_count = 0;
 	if (n_l == 0 || n_r == 0)
 		return MIDORIDB_OK;
+	{
+		const int trc = tiny_join_pairs(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, out_l, out_r, out_count);
+		if (trc <= 0)
+			return trc;
+	}
 	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records;
 	 *      unique left keys: the same with the sides swapped and a stable sort.  What a column turned out to be is
 	 *      remembered (by pointer and length), so that a repeated query does not pay for failed attempts. */

@@ -1130,3 +1130,20 @@ def test_single_workgroup_path_for_tiny_inputs_and_its_size_boundary(dev, n_l, n
     nr = rng.random(n_r) < 0.1
     _jgc_check(dev, kl, nl, kr, nr)
     _jgc_check(dev, np.arange(n_l, dtype=np.int64)[::-1].copy(), None, rng.integers(0, max(n_l, 1), n_r, dtype=np.int64), None)
+
+
+@pytest.mark.parametrize("n_l,n_r,dom", [(1, 1, 1), (3, 2, 3), (6, 6, 3), (100, 300, 40), (2048, 31, 5000), (2048, 2048, 100_000),
+                                         (2048, 2048, 40), (2049, 10, 5), (300, 300, 1)])
+def test_single_workgroup_materialising_join_and_its_boundaries(dev, n_l, n_r, dom):
+    """Up to 2048 rows per table the materialising join is one single-workgroup kernel (the right keys in LDS, every left row
+    walks over them: the reference's nested loop, its pair order by construction); more than 65536 pairs, or one row more,
+    and the partitioned paths run.  NULLs, negative values, N:M duplicates."""
+    rng = np.random.default_rng(n_l * 3 + n_r + dom)
+    kl = rng.integers(-2, dom, n_l, dtype=np.int64)
+    kr = rng.integers(-2, dom, n_r, dtype=np.int64)
+    nl = rng.random(n_l) < 0.15
+    nr = rng.random(n_r) < 0.15
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert l.numel() == len(el)
+    assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
