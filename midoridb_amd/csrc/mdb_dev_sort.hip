@@ -408,6 +408,49 @@ int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint6
 	return ((uint32_t)h[8] & (2u | 256u)) ? 1 : 0;
 }
 
+/* ---- tiny inputs: one workgroup ranks every row by counting ---------------------------------------------------------
+ * Up to SORT_TINY_ROWS rows and SORT_PACK_MAX_KEYS columns: the (NULL flag, image) pairs of every column sit in LDS, row
+ * i's place is the number of rows that sort before it (ties: the smaller stream position) - n^2 comparisons, all lanes
+ * reading the same row j at the same time (LDS broadcast), one launch instead of the ~10 per column of the radix passes. */
+#define SORT_TINY_ROWS 2048u
+#define SORT_TINY_THREADS 1024
+
+struct sort_tiny_args {
+	struct mdb_sort_key key[SORT_PACK_MAX_KEYS];
+	int nkeys;
+	uint32_t n;
+};
+
+__global__ __launch_bounds__(SORT_TINY_THREADS) void k_sort_tiny(sort_tiny_args a, uint32_t *__restrict__ perm_out)
+{
+	__shared__ uint64_t s_img[SORT_PACK_MAX_KEYS][SORT_TINY_ROWS];
+	__shared__ uint8_t s_flag[SORT_PACK_MAX_KEYS][SORT_TINY_ROWS];
+	for (int c = 0; c < a.nkeys; c++) {
+		const struct mdb_sort_key &key = a.key[c];
+		for (uint32_t k = threadIdx.x; k < a.n; k += SORT_TINY_THREADS) {
+			const uint64_t row = key.rid ? (uint64_t)key.rid[k] : k;
+			const bool isnull = key.nullbits && mdb_bit_is_set(key.nullbits, row);
+			/* ASC: NULLs first (flag 0), DESC: NULLs last (flag 1) - as in the other paths */
+			s_flag[c][k] = (uint8_t)(isnull == (key.desc != 0));
+			s_img[c][k] = isnull ? 0ull : sort_image(((const uint64_t *)key.values)[row], key.type, key.desc);
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < a.n; i += SORT_TINY_THREADS) {
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < a.n; j++) {
+			int cmp = 0;	/* -1: j before i, +1: i before j */
+			for (int c = 0; c < a.nkeys && cmp == 0; c++) {
+				const uint8_t fj = s_flag[c][j], fi = s_flag[c][i];
+				const uint64_t vj = s_img[c][j], vi = s_img[c][i];
+				cmp = fj != fi ? (fj < fi ? -1 : 1) : (vj != vi ? (vj < vi ? -1 : 1) : 0);
+			}
+			rank += cmp < 0 || (cmp == 0 && j < i);
+		}
+		perm_out[rank] = i;
+	}
+}
+
 static size_t sort_arena_bytes(uint64_t n)
 {
 	const size_t hist_words = mdb_sort_pass_hist_words(n);
@@ -431,6 +474,22 @@ static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int
 	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 64);
 	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
 		return -MIDORIDB_INTERNAL;
+	if (n <= SORT_TINY_ROWS && nkeys <= SORT_PACK_MAX_KEYS) {
+		sort_tiny_args ta;
+		memset(&ta, 0, sizeof(ta));
+		bool types_ok = true;
+		for (int c = 0; c < nkeys; c++) {
+			ta.key[c] = keys[c];
+			types_ok = types_ok && (keys[c].type == MDB_T_INT64 || keys[c].type == MDB_T_DOUBLE);
+		}
+		if (types_ok) {		/* (an unknown type is reported by the general path below) */
+			ta.nkeys = nkeys;
+			ta.n = (uint32_t)n;
+			MDB_LAUNCH(ctx, "orderby_tiny", k_sort_tiny, 1, SORT_TINY_THREADS, ta, pm[0]);
+			*perm = pm[0];
+			return MIDORIDB_OK;
+		}
+	}
 	{
 		const int prc = sort_perm_packed(ctx, keys, nkeys, n, u[0], mm, perm, vkey);
 		if (prc <= 0)

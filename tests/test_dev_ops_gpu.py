@@ -1147,3 +1147,19 @@ def test_single_workgroup_materialising_join_and_its_boundaries(dev, n_l, n_r, d
     l, r = dev.join_pairs(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
     assert l.numel() == len(el)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
+
+
+@pytest.mark.parametrize("specs", [
+    [("full", False, 0.0)], [("full", True, 0.2)], [("double", False, 0.0)], [("double", True, 0.1)], [("const", True, 0.5)],
+    [("small", False, 0.0), ("neg", True, 0.0)], [("small", True, 0.3), ("double", False, 0.3), ("small", False, 0.0)],
+    [("small", False, 1.0)], [("neg", False, 0.0), ("full", False, 0.0), ("double", True, 0.0), ("small", True, 0.2)],
+    [("small", False, 0.0), ("neg", True, 0.0), ("small", True, 0.0), ("neg", False, 0.0), ("small", False, 0.0)],
+], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
+@pytest.mark.parametrize("n", [2, 777, 2048, 2049])
+def test_sort_perm_single_workgroup_path_for_tiny_inputs(dev, specs, n):
+    """Up to 2048 rows and four columns the permutation comes from one workgroup that ranks every row by counting; five
+    columns, or one row more, take the radix passes.  Same stable order (NULLs first ascending / last descending, DOUBLE
+    by total order) either way."""
+    rng = np.random.default_rng(n + len(specs))
+    _sort_case(dev, rng, n, specs)
+    _sort_case(dev, rng, n, specs, with_rid=True)
