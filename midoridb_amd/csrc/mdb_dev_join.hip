@@ -1657,6 +1657,11 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	bool fast = true, records = true, no_build_r = false, narrow = false;
 	int64_t base = 0;
 	int rc = MIDORIDB_OK;
+	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
+	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow
+	 * and be redone anyway - start with the exact layout */
+	if (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u)
+		fast = false;
 	if (keys32)
 		narrow = ctx->narrow_mode != 0;		/* int32 columns: nothing to sample */
 	else
