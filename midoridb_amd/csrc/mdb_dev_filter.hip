@@ -337,6 +337,132 @@ __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_cmp1(const int64_t *
 		block_counts[blockIdx.x] = s_cnt;
 }
 
+/* The next commonest predicates - several comparisons of ONE INT64 base-table column with constants, all joined by AND
+ * (ranges: fa >= 3 AND fa <= 900 AND fa <> 5) or all joined by OR (IN lists) - also without the interpreter: the column
+ * is loaded once, the terms are evaluated in registers (uniform switch per term). */
+#define FILT_MAX_TERMS 8
+struct filt_terms {
+	int32_t cmp[FILT_MAX_TERMS];
+	int64_t imm[FILT_MAX_TERMS];
+	int32_t n;
+	int32_t null_passes;	/* OR list with "col IS NULL" among its terms: a NULL row passes (otherwise it fails every term) */
+};
+
+template <bool IS_OR>
+__global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_terms(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
+								  filt_terms t, uint64_t n, uint64_t *__restrict__ bits,
+								  uint32_t *__restrict__ block_counts)
+{
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0)
+		s_cnt = 0;
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+	uint32_t cnt = 0;
+	auto eval = [&](int64_t a) -> bool {
+		bool r = !IS_OR;
+		for (int k = 0; k < t.n; k++) {
+			const int64_t imm = t.imm[k];
+			const int c = t.cmp[k];
+			const bool b = c == MDB_CMP_LT ? a < imm : c == MDB_CMP_GT ? a > imm : c == MDB_CMP_NE ? a != imm : c == MDB_CMP_EQ ? a == imm
+				       : c == MDB_CMP_LE ? a <= imm : a >= imm;
+			r = IS_OR ? (r || b) : (r && b);
+		}
+		return r;
+	};
+	constexpr int SPANS = FILT_WORDS_PER_WAVE / 2;
+	longlong2 q[SPANS];
+#pragma unroll
+	for (int u = 0; u < SPANS; u++) {
+		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * mdb_lane();
+		q[u] = make_longlong2(0, 0);
+		if (k0 + 1 < n)
+			q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
+		else if (k0 < n)
+			q[u].x = vals[k0];
+	}
+#pragma unroll
+	for (int u = 0; u < SPANS; u++) {
+		const uint64_t word = word0 + 2 * u;
+		const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
+		bool p0 = k0 < n && eval(q[u].x), p1 = k0 + 1 < n && eval(q[u].y);
+		if (nullbits && k0 < n) {
+			const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
+			if (t.null_passes) {
+				p0 = p0 || (w & 1ull);
+				p1 = (k0 + 1 < n) && (p1 || (w & 2ull));
+			} else {
+				p0 = p0 && !(w & 1ull);
+				p1 = p1 && !(w & 2ull);
+			}
+		}
+		const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+		if ((word << 6) < n) {
+			const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
+			const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
+			if (mdb_lane() == 0) {
+				bits[word] = wa;
+				if (((word + 1) << 6) < n)
+					bits[word + 1] = wb;
+			}
+			cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+		}
+	}
+	if (mdb_lane() == 0 && cnt)
+		atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		block_counts[blockIdx.x] = s_cnt;
+}
+
+/* is the program "terms on ONE INT64 column, all ANDed or all ORed"?  (a NULL makes every term false - and with it both the
+ * conjunction and the disjunction, which is what the interpreter computes: NULL <cmp> x is false) */
+static bool filter_one_column_terms(const pred_args *p, filt_terms *t, int *slot, bool *is_or)
+{
+	int n_and = 0, n_or = 0, col = -1, n_notnull = 0, n_isnull = 0;
+	t->n = 0;
+	t->null_passes = 0;
+	for (int i = 0; i < p->n_insns; i++) {
+		const mdb_pred_insn &in = p->insn[i];
+		if (in.op == MDB_P_AND) {
+			n_and++;
+		} else if (in.op == MDB_P_OR) {
+			n_or++;
+		} else if (in.op == MDB_P_ISNULL) {	/* IS NOT NULL in an AND list adds nothing (a NULL fails the comparisons), IS NULL in an OR list lets NULLs pass */
+			if (col >= 0 && in.a != col)
+				return false;
+			col = in.a;
+			if (in.cmp)
+				n_notnull++;
+			else
+				n_isnull++;
+		} else if ((in.op == MDB_P_CMP_COL_CONST || in.op == MDB_P_CMP_CONST_COL) && in.type == MDB_T_INT64) {
+			if (col >= 0 && in.a != col)
+				return false;
+			col = in.a;
+			if (t->n == FILT_MAX_TERMS)
+				return false;
+			int c = in.cmp;
+			if (in.op == MDB_P_CMP_CONST_COL)	/* imm <cmp> col  ==  col <flipped cmp> imm */
+				c = c == MDB_CMP_LT ? MDB_CMP_GT : c == MDB_CMP_GT ? MDB_CMP_LT : c == MDB_CMP_LE ? MDB_CMP_GE : c == MDB_CMP_GE ? MDB_CMP_LE : c;
+			t->cmp[t->n] = c;
+			t->imm[t->n] = in.imm;
+			t->n++;
+		} else {
+			return false;
+		}
+	}
+	if (t->n < 1 || (n_and && n_or) || n_and + n_or != t->n + n_notnull + n_isnull - 1 || n_and + n_or == 0)
+		return false;
+	if ((n_notnull && !n_and) || (n_isnull && !n_or) || n_isnull > 1)
+		return false;	/* IS NOT NULL only among ANDed terms, IS NULL (once) only among ORed ones */
+	t->null_passes = n_isnull ? 1 : 0;
+	*slot = col;
+	*is_or = n_or > 0;
+	return true;
+}
+
 /* MODE 0: general predicate program; MODE 1: "vals[k] != 0" over an int64 array */
 template <int MODE>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
@@ -431,6 +557,8 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols
 		for (int c = 0; c < n_cols; c++)
 			direct = direct && !p->cols[c].rid && ((uintptr_t)p->cols[c].values & 15) == 0;
 		const mdb_pred_insn &i0 = p->insn[0];
+		int tslot = 0;
+		bool tor = false;
 		if (direct && p->n_insns == 1 && i0.op == MDB_P_CMP_COL_CONST && i0.type == MDB_T_INT64) {
 			const int64_t *v = (const int64_t *)p->cols[i0.a].values;
 			const uint64_t *nbits = p->cols[i0.a].nullbits;
@@ -441,6 +569,14 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols
 			case MDB_CMP_EQ: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_EQ>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
 			case MDB_CMP_LE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
 			default: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
+			}
+		} else if (filt_terms ft; direct && filter_one_column_terms(p, &ft, &tslot, &tor)) {
+			const int64_t *v = (const int64_t *)p->cols[tslot].values;
+			const uint64_t *nbits = p->cols[tslot].nullbits;
+			if (tor) {
+				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<true>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc);
+			} else {
+				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<false>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc);
 			}
 		} else if (direct) {
 			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_pair<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);

@@ -1163,3 +1163,37 @@ def test_sort_perm_single_workgroup_path_for_tiny_inputs(dev, specs, n):
     rng = np.random.default_rng(n + len(specs))
     _sort_case(dev, rng, n, specs)
     _sort_case(dev, rng, n, specs, with_rid=True)
+
+
+@pytest.mark.parametrize("n", [1, 63, 129, 100_003, 1_000_001])
+def test_filter_one_column_term_lists(dev, n):
+    """Several comparisons of ONE INT64 column with constants, all ANDed (ranges) or all ORed (IN lists) - the specialised
+    kernels - against the numpy predicate oracle: every comparison operator, constant on either side, NULLs (a NULL fails
+    every term), up to 8 terms; 9 terms, a second column or mixed AND / OR go through the interpreter with the same result."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(-50, 50, n, dtype=np.int64)
+    b = rng.integers(-50, 50, n, dtype=np.int64)
+    na = rng.random(n) < 0.1
+    cols_np = [(a, na, None), (b, None, None)]
+    cols_dev = [(dev.to_dev(a), dev.nullbits_dev(na), None), (dev.to_dev(b), None, None)]
+    C, K = D.P_CMP_COL_CONST, D.P_CMP_CONST_COL
+    AND, OR = (D.P_AND, 0, 0, 0, 0, 0), (D.P_OR, 0, 0, 0, 0, 0)
+    progs = [
+        [(C, D.CMP_GE, D.T_INT64, 0, 0, -10), (C, D.CMP_LE, D.T_INT64, 0, 0, 30), AND],
+        [(K, D.CMP_LT, D.T_INT64, 0, 0, -10), (C, D.CMP_LT, D.T_INT64, 0, 0, 30), AND, (C, D.CMP_NE, D.T_INT64, 0, 0, 5), AND],
+        [(C, D.CMP_GT, D.T_INT64, 0, 0, 0), (C, D.CMP_NE, D.T_INT64, 0, 0, 7), (K, D.CMP_GE, D.T_INT64, 0, 0, 40), AND, AND],
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, v) for v in (1, 2, 3, -49, 49)] + [OR] * 4,
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, 1), (C, D.CMP_EQ, D.T_INT64, 0, 0, 2), OR, (C, D.CMP_GT, D.T_INT64, 0, 0, 45), OR],
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, v) for v in range(8)] + [OR] * 7,
+        [(D.P_ISNULL, 1, 0, 0, 0, 0), (C, D.CMP_NE, D.T_INT64, 0, 0, 5), AND, (C, D.CMP_GE, D.T_INT64, 0, 0, 3), AND],      # IS NOT NULL AND ...
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, 1), (C, D.CMP_EQ, D.T_INT64, 0, 0, 2), OR, (D.P_ISNULL, 0, 0, 0, 0, 0), OR],        # IN (...) OR IS NULL
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, 1), (D.P_ISNULL, 0, 0, 0, 0, 0), AND],                                              # IS NULL in an AND list: interpreter
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, 1), (D.P_ISNULL, 1, 0, 0, 0, 0), OR],                                              # IS NOT NULL in an OR list: interpreter
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, v) for v in range(9)] + [OR] * 8,                                  # 9 terms: interpreter
+        [(C, D.CMP_GE, D.T_INT64, 0, 0, -10), (C, D.CMP_LE, D.T_INT64, 1, 0, 30), AND],                   # two columns: interpreter
+        [(C, D.CMP_EQ, D.T_INT64, 0, 0, 1), (C, D.CMP_EQ, D.T_INT64, 0, 0, 2), OR, (C, D.CMP_LT, D.T_INT64, 0, 0, 2), AND],  # mixed
+    ]
+    for prog in progs:
+        exp = orc.filter_positions(prog, cols_np, n)
+        got = _np(dev.filter(prog, cols_dev, n)).astype(np.int64)
+        assert np.array_equal(got, exp), prog
