@@ -3,21 +3,31 @@
 
     SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;
 
-A "step" = one pass of the whole device pipeline (hash, partition both tables, per-leaf LDS hash
+A "step" = one pass of the whole device pipeline (hash, partition both tables, per-leaf LDS
 build/probe, ordered group emission) over synthetic INT64 tables that are already resident in
 HBM when the timed region starts.  N = 1: 10^8 rows per table on one GPU (BASELINE.json
-configs[2]).  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds 10^8
-rows of each table (weak scaling), keys are hash-partitioned by destination GPU, exchanged with
+configs[2]).  N > 1, one rank per GPU: keys are hash-partitioned by destination GPU, exchanged with
 one RCCL all-to-all per table over xGMI, then joined locally; no other collective is on the path.
+The primary line is WEAK scaling (every rank holds --rows rows of each table); the same run also
+measures the STRONG form the metric's wording suggests (2 x 10^8 rows in total, split over the
+ranks) and reports it under "strong_scaling".
 
-The JSON line carries `roofline` for the dominant kernel (live HIP-event timing through the
-library's per-kernel profiler) and `cpu_baseline` (the real reference executor if
-oracle/_ref/libmidori_ref.so travelled with the snapshot, else the repo's own C restatement).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks
+(`python -m torch.distributed.run` as a child process, before this process touches a GPU), relays
+rank 0's JSON line and exits with the children's code; under torch.distributed.run it is a rank.
+
+The JSON line carries `roofline` for the kernel that takes the most time per step (live HIP-event
+timing through the library's per-kernel profiler; kernel names = template instances, so the two
+tables' partition launches are not lumped together), `cpu_baseline` (the real reference executor
+if oracle/_ref/libmidori_ref.so travelled with the snapshot, else the repo's own C restatement),
+and, at N = 1: the wide (64-bit hash) form, the other synthetic variant, cold-start figures and the
+same query end to end through query_execute().
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,35 +39,66 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
+NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
-# names of the profiler's kernels in the rocprofv3 summary kept under profiles/ (PMC traffic per launch)
+# profiler kernel name -> kernel names in the rocprofv3 summary kept under profiles/ (PMC traffic per launch)
 ROCPROF_NAMES = {
     "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
                               "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
+    "leaf_join_direct": ["k_leaf_direct<true, true>", "k_leaf_direct<true, false>"],
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
-    "part_hist_l0": ["k_part_hist<true, false>"],
-    # level 0 / level 1 of the histogram-free partition: left table (8-byte words), right table (4-byte words in the narrow form)
-    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false>",
-                        "k_part_scatter<true, true, false, true, false, false, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false>",
-                        "k_part_scatter<false, true, false, true, false, false, false>"],
+    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false>"],
+    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false>"],
+    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false>"],
+    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false>"],
+    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false>"],
+    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
 }
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01/rocprof_summary.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), or None.  Counters cannot be collected from inside
-    this process; the summary comes from `bash profiles/collect.sh` on the same workload (10^8 rows, variant D)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "rocprof_summary.json")) as f:
-            ks = json.load(f)["kernels"]
-        vals = [ks[n]["hbm_read_bytes"] + ks[n]["hbm_write_bytes"] for n in ROCPROF_NAMES.get(kernel, []) if n in ks]
-        return sum(vals) / len(vals) if vals else None
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN/rocprof_summary.json:
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), newest round first, or None.  Counters cannot be collected
+    from inside this process; the summary comes from `bash profiles/collect.sh` on the same workload (10^8 rows, variant D)."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "rocprof_summary.json")) as f:
+                ks = json.load(f)["kernels"]
+            vals = [ks[n]["hbm_read_bytes"] + ks[n]["hbm_write_bytes"] for n in ROCPROF_NAMES.get(kernel, [])
+                    if n in ks and "hbm_read_bytes" in ks[n] and "hbm_write_bytes" in ks[n]]
+            if vals:
+                return {"bytes": sum(vals) / len(vals), "source": f"profiles/{rnd}/rocprof_summary.json"}
+        except Exception:
+            continue
+    return None
+
+
+def algorithmic_bytes(kernel, n, groups, narrow):
+    """Algorithmic HBM bytes of ONE launch of `kernel` on a table of n rows (G = `groups` result groups):
+    what the launch must read once and write once.  Kernel names are template instances, one table each."""
+    key, rid, h32, g = 8 * n, 4 * n, 4 * n, groups
+    table = {
+        "part_scatter_l0": key + key,               # read 8-byte keys, write 8-byte words (hash | row id in the narrow form)
+        "part_scatter_l0_w32": key + h32,           # narrow right side: read keys, write 4-byte hashes
+        "part_scatter_l0_rid": key + key + rid,     # wide left side: hash + row id out
+        "part_scatter_l1": key + key,
+        "part_scatter_l1_w32": h32 + h32,
+        "part_scatter_l1_rid": 2 * (key + rid),
+        "part_hist_l0": key,
+        "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
+        "leaf_join_direct": key + h32 + 8 * g,
+        "leaf_group_count": (key if narrow else key + rid) + 8 * g,
+        "sort_hist_l0": 8 * g,
+        "sort_scatter_l0": 16 * g,
+        "sort_scatter_l1": 16 * g,
+        "order_leaf": 8 * g + 8 * g + 16 * g,       # records + gathered keys in, (key, COUNT) out
+        "gather64": 4 * g + 8 * g + 8 * g,
+    }
+    return float(table.get(kernel, key))
 
 
 def parse_args():
@@ -65,18 +106,49 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per table per GPU")
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per table per GPU (weak scaling); 125000000 = BASELINE configs[3] on 8 GPUs")
     ap.add_argument("--variant", choices=["U", "D"], default="D",
                     help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="which form is the primary line at N > 1 (the other one is reported beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the result against the CPU oracle (rows <= 2e7)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary variant-U measurement (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip everything but the primary measurement and the per-kernel profile (profiling runs)")
     ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
                     "column statistics allow it)")
     ap.add_argument("--chunks", type=int, default=None, help="pieces per table in the multi-GPU exchange (default 1)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """N > 1 without a launcher: start the ranks as CHILD processes (never re-exec: a process that has touched the GPU
+    must not be replaced, and this one has not touched it - device_count() does not initialise HIP on this image),
+    relay rank 0's line, return the children's exit code."""
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        line = {"metric": METRIC, "value": None, "unit": "joined rows/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "skipped": f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {visible}"}
+        print(json.dumps(line), flush=True)
+        sys.stderr.write(f"[bench] {line['skipped']}\n")
+        return 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        sys.stderr.write("[bench] the ranks exited without a result line\n")
+        return 1
+    return p.returncode
 
 
 def cpu_baseline():
@@ -100,7 +172,7 @@ def cpu_baseline():
                 db.bulk_insert("A", [rng.permutation(a)])
                 db.bulk_insert("B", [rng.permutation(a)])
                 t0 = time.perf_counter()
-                cols, rows = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;")
+                cols, rows = db.query(NORTH)
                 times[m] = time.perf_counter() - t0
                 db.close()
             dt = times[n]
@@ -120,6 +192,26 @@ def cpu_baseline():
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "joined rows/s", "cores": 1, "kind": "port",
             "sample": f"north-star query, {n}x{n} unique keys, oracle/cpu_naive.c nested loop ({dt:.2f} s)"}
+
+
+def cpu_naive_sizes():
+    """the repo's restatement of the reference algorithm (oracle/cpu_naive.c: nested-loop join with early
+    materialisation, quadratic GROUP BY), one thread, at N = 1000 / 2000 / 4000 rows per table, with the quadratic
+    extrapolation to the configuration's size."""
+    from oracle import cpu
+    out = {"cores": 1, "kind": "port", "sizes": {}}
+    rng = np.random.default_rng(42)
+    pairs_s = 0.0
+    for n in (1000, 2000, 4000):
+        a = rng.permutation(np.arange(n, dtype=np.int64))
+        b = rng.permutation(np.arange(n, dtype=np.int64))
+        t0 = time.perf_counter()
+        cpu.naive_join_group_count(a, None, b, None)
+        dt = time.perf_counter() - t0
+        pairs_s = n * n / dt
+        out["sizes"][str(n)] = {"seconds": dt, "row_pairs_per_s": pairs_s, "joined_rows_per_s": n / dt}
+    out["extrapolated_seconds_at_1e8_x_1e8"] = 1e16 / pairs_s
+    return out
 
 
 def cpu_hash_yardstick(a_dev, b_dev, gpu_result=None):
@@ -146,8 +238,51 @@ def cpu_hash_yardstick(a_dev, b_dev, gpu_result=None):
     return out
 
 
+def end_to_end(n, mod_b, a_dev, b_dev):
+    """The same query through the drop-in C API (query_execute -> plan -> device pipeline -> D2H of the result into
+    page-locked host columns), reported beside `value`, never as it: (1) tables resident in the device
+    mirror, (2) tables that arrive as host columns, so the first SELECT also uploads 2 x 8n bytes over PCIe."""
+    from midoridb_amd.query import DB
+    out = {}
+    with DB() as db:
+        db.execute("CREATE TABLE A (id_a INT);")
+        db.execute("CREATE TABLE B (id_b INT);")
+        db.generate("A", n, 42, [0])
+        db.generate("B", n, 43, [mod_b])
+        walls, execs, rows = [], [], 0
+        for _ in range(4):
+            t0 = time.perf_counter()
+            r = db.query(NORTH)
+            walls.append((time.perf_counter() - t0) * 1e3)
+            execs.append(r.exec_ms)
+            rows, joined = r.nrows, r.joined_rows
+        out["device_resident_tables"] = {"wall_ms": min(walls[1:]), "executor_ms": min(execs[1:]), "first_call_wall_ms": walls[0],
+                                         "result_rows": rows, "joined_rows": joined, "value": joined / (min(walls[1:]) * 1e-3),
+                                         "includes": "SQL parse + plan + device pipeline + D2H of the result columns"}
+    ha, hb = a_dev.cpu().numpy(), b_dev.cpu().numpy()
+    with DB() as db:
+        db.execute("CREATE TABLE A (id_a INT);")
+        db.execute("CREATE TABLE B (id_b INT);")
+        t0 = time.perf_counter()
+        db.append_columns("A", [ha])
+        db.append_columns("B", [hb])
+        ingest_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        r = db.query(NORTH)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        r = db.query(NORTH)
+        again_ms = (time.perf_counter() - t0) * 1e3
+        out["host_resident_tables"] = {"bulk_ingest_ms": ingest_ms, "first_select_wall_ms": first_ms, "second_select_wall_ms": again_ms,
+                                       "h2d_bytes": 16 * n, "value_first_select": r.joined_rows / (first_ms * 1e-3),
+                                       "includes": "first SELECT: H2D upload of both key columns (pageable host memory) + everything above"}
+    return out
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     # stdout carries exactly ONE line (the JSON): everything else that native libraries print there
     # (e.g. RCCL's version banner) is routed to stderr at the file-descriptor level
     sys.stdout.flush()
@@ -156,11 +291,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and rank == 0:
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} ranks\n")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_shuffle
+    ranks_seen = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -169,20 +304,29 @@ def main():
     from midoridb_amd.dev import DeviceCtx
     from midoridb_amd import shuffle
 
+    t_ctx = time.perf_counter()
     dev = DeviceCtx(local_rank)
-    n = args.rows
-    total_rows = n * world
-    mod_b = total_rows // 16 if args.variant == "D" else 0
-    # rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)
-    a = dev.gen_keys(n, rank * n, total_rows, 42, 0)
-    b = dev.gen_keys(n, rank * n, total_rows, 43, mod_b)
-    cap = int(n * 1.3) + 4096 if use_dist else n
-    out = (torch.empty(cap, dtype=torch.int64, device=dev.device), torch.empty(cap, dtype=torch.int64, device=dev.device),
-           torch.empty(cap, dtype=torch.int32, device=dev.device))
-    wire32 = False
-    if use_dist and not args.wire64:
-        # column statistics (computed once per table, outside the timed region, like a catalog would keep them):
-        # when every key of both columns fits 32 bits on every rank the exchange ships 4-byte keys
+    if use_dist:
+        one = torch.ones(1, dtype=torch.float64, device=dev.device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())	# ranks that took part in a collective of the RCCL communicator
+
+    def make_tables(n_rank):
+        """rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)"""
+        total = n_rank * world
+        mod = total // 16 if args.variant == "D" else 0
+        return (dev.gen_keys(n_rank, rank * n_rank, total, 42, 0), dev.gen_keys(n_rank, rank * n_rank, total, 43, mod), total, mod)
+
+    def make_out(n_rank):
+        cap = int(n_rank * 1.3) + 4096 if use_dist else n_rank
+        return (torch.empty(cap, dtype=torch.int64, device=dev.device), torch.empty(cap, dtype=torch.int64, device=dev.device),
+                torch.empty(cap, dtype=torch.int32, device=dev.device))
+
+    def wire_format(a, b):
+        """column statistics (computed once per table, outside the timed region, like a catalog would keep them): when every
+        key of both columns fits 32 bits on every rank the exchange ships 4-byte keys"""
+        if not use_dist or args.wire64:
+            return False
         fits = 1.0
         for col in (a, b):
             lo, hi = dev.key_range(col)
@@ -190,17 +334,7 @@ def main():
                 fits = 0.0
         t = torch.tensor([fits], dtype=torch.float64, device=dev.device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        wire32 = bool(t.item() > 0.5)
-    pipeline = shuffle.DistributedJoinGroupCount(dev, world, rank, n, chunks=args.chunks, wire32=wire32) if use_dist else None
-
-    def step():
-        if pipeline is None:
-            k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
-            return k.numel(), j
-        return pipeline.run(a, b, out)
-
-    for _ in range(max(args.warmup, 1) if world == 1 else args.warmup):
-        g, j = step()
+        return bool(t.item() > 0.5)
 
     def barrier():
         torch.cuda.synchronize()
@@ -208,26 +342,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g, j = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev.device)
-    jsum = torch.tensor([float(j)], dtype=torch.float64, device=dev.device)
-    gsum = torch.tensor([float(g)], dtype=torch.float64, device=dev.device)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(jsum, op=dist.ReduceOp.SUM)
-        dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    joined_total = int(jsum.item())
-    groups_total = int(gsum.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = joined_total / (dt / args.steps)
+    def measure(n_rank, steps, warmup, cold=None):
+        """warmup + timed loop over fresh tables of n_rank rows per rank -> dict (max over ranks, totals over ranks)"""
+        a, b, total, mod = make_tables(n_rank)
+        out = make_out(n_rank)
+        w32 = wire_format(a, b)
+        pipe = shuffle.DistributedJoinGroupCount(dev, world, rank, n_rank, chunks=args.chunks, wire32=w32) if use_dist else None
 
-    # ---- per-kernel profile (outside the timed region): live HIP events around every launch
+        def step():
+            if pipe is None:
+                k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
+                return k.numel(), j
+            return pipe.run(a, b, out)
+
+        if cold is not None:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            cold["cold_first_query_ms"] = (time.perf_counter() - t0) * 1e3
+        g = j = 0
+        for _ in range(max(warmup, 1) if world == 1 else warmup):
+            g, j = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g, j = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        red = torch.tensor([dt, float(j), float(g)], dtype=torch.float64, device=dev.device)
+        if use_dist:
+            tmax = red[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            red[0] = tmax[0]
+        dt, joined, groups = float(red[0].item()), int(red[1].item()), int(red[2].item())
+        return {"a": a, "b": b, "out": out, "pipe": pipe, "step": step, "wire32": w32, "mod": mod, "n": n_rank, "total_rows": total,
+                "dt": dt, "ms_per_step": dt / steps * 1e3, "value": joined / (dt / steps), "joined": joined, "groups": groups}
+
+    cold = {}
+    n_weak = args.rows
+    n_strong = max(args.rows // world, 1)
+    n = n_strong if (args.scaling == "strong" and world > 1) else n_weak
+    m = measure(n, args.steps, args.warmup, cold)
+    cold["context_and_first_query_ms"] = (time.perf_counter() - t_ctx) * 1e3
+    a, b, out, step, pipeline = m["a"], m["b"], m["out"], m["step"], m["pipe"]
+    dt, joined_total, groups_total, total_rows, mod_b, wire32 = m["dt"], m["joined"], m["groups"], m["total_rows"], m["mod"], m["wire32"]
+    ms_per_step, value = m["ms_per_step"], m["value"]
+
+    # ---- per-kernel profile (outside the timed region): live HIP events around every launch, on the launch stream
     dev.prof_enable(True)
     dev.prof_reset()
     prof_steps = 3
@@ -254,68 +417,126 @@ def main():
     except Exception:
         pass
 
+    # the other scaling form, same process group, same kernels (N > 1 only)
+    other = None
+    if world > 1 and not args.no_secondary:
+        n_other = n_weak if n == n_strong else n_strong
+        if n_other != n:
+            mo = measure(n_other, max(3, args.steps // 2), 1)
+            other = {"scaling": "weak" if n_other == n_weak else "strong", "rows_per_table_per_gpu": n_other,
+                     "rows_per_table_total": mo["total_rows"], "ms_per_step": mo["ms_per_step"], "value": mo["value"],
+                     "joined_rows": mo["joined"], "groups": mo["groups"], "wire32": mo["wire32"]}
+            for key in ("a", "b", "out", "pipe", "step"):
+                mo.pop(key)
+
     if rank == 0:
         narrow = dev.last_join_narrow()
+        g_rank = groups_total / max(world, 1)
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
         for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
             if d["ms_per_step"] > 0:
-                d["algorithmic_GBs"] = (shuffle.algorithmic_bytes(k, n, groups_total / max(world, 1), narrow) * d["launches_per_step"]
-                                        / (d["ms_per_step"] * 1e-3) / 1e9)
-        # dominant kernel = the level-0/1 scatter; algorithmic bytes of one launch = every key it moves,
-        # read once (8 B hashed key [+4 B row id]) and written once
-        dom_name = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
-        roof = None
-        if dom_name:
-            d = kern[dom_name]
+                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
+
+        def roof_of(name):
+            d = kern[name]
             launches = max(d["launches_per_step"], 1e-9)
             avg_ms = d["ms_per_step"] / launches
-            bytes_per_launch = shuffle.algorithmic_bytes(dom_name, n, groups_total / max(world, 1), narrow)
+            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(dom_name) if (n == 100_000_000 and args.variant == "D" and world == 1) else None,
-                    "d2d_copy_GBs": copy_gbs,
-                    "frac_of_d2d_copy": (achieved / copy_gbs) if copy_gbs else None,
-                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch}
+            tr = pmc_traffic(name) if (n == 100_000_000 and args.variant == "D" and world == 1) else None
+            return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                    "d2d_copy_GBs": copy_gbs, "frac_of_d2d_copy": (achieved / copy_gbs) if copy_gbs else None,
+                    "avg_launch_ms": avg_ms, "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch}
+        # dominant kernel = the one instance that takes the most time per step (one table per partition launch)
+        dom_name = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+        roof = roof_of(dom_name) if dom_name else None
         # whole-pipeline view: the bytes any correct algorithm must move once
         algo_bytes = 8 * 2 * total_rows + 16 * groups_total
+        scaling_name = "strong" if (n == n_strong and world > 1) else "weak"
         line = {
-            "metric": "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": value, "unit": "joined rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling_name, "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU, variant {args.variant} "
+            "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU x {world} GPU = {total_rows} rows/table "
+                                   f"({scaling_name} scaling), variant {args.variant} "
                                    f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
                        "key_form": "narrow (keys within one 2^32-wide window, verified on the device: 32-bit hashes)" if narrow else "wide (64-bit hashes)",
-                       "rows_per_table_per_gpu": n, "joined_rows": joined_total, "groups": groups_total,
+                       "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
                        "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
-                                      + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else "")},
+                                      + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else ""),
+                       "rccl_ranks_seen": ranks_seen if use_dist else None},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernels": kern,
         }
-        if world == 1 and not use_dist and args.variant == "D" and not args.no_secondary:
-            # the other synthetic variant of SURVEY 8d C3 (unique keys on both sides: G = n groups), same pipeline
-            try:
-                b_u = dev.gen_keys(n, 0, n, 43, 0)
+        # the first-level scatter of the left table beside it: the bandwidth-bound kernel of the pipeline
+        for cand in ("part_scatter_l0", "part_scatter_l0_rid"):
+            if cand in kern and cand != dom_name:
+                line["roofline_scatter"] = roof_of(cand)
+                break
+        if other is not None:
+            line[other["scaling"] + "_scaling"] = other
+        elif world == 1:
+            line["strong_scaling"] = {"same_as_primary": True, "note": "at N = 1 the weak and the strong workload are the same 2 x 10^8 rows"}
+        line["cold_start"] = dict(cold, note="cold_first_query_ms: the first call in the process on fresh tables (scratch arena allocation, "
+                                  "key sampling + its host sync, first-launch code load); context_and_first_query_ms adds the context creation")
+        secondary = world == 1 and not use_dist and not args.no_secondary
+        if secondary:
+            reps = max(3, args.steps // 2)
+
+            def timed(fn):
                 for _ in range(2):
-                    dev.join_group_count(a, None, b_u, None, out=out)
+                    fn()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                reps = max(3, args.steps // 2)
                 for _ in range(reps):
-                    ku, cu, fu, ju = dev.join_group_count(a, None, b_u, None, out=out)
+                    r = fn()
                 torch.cuda.synchronize()
-                dtu = (time.perf_counter() - t1) / reps
-                line["variant_U"] = {"workload": f"unique keys both sides, {n} rows/table", "joined_rows": ju, "groups": int(ku.numel()),
-                                     "ms_per_step": dtu * 1e3, "value": ju / dtu}
-                del b_u
+                return (time.perf_counter() - t1) / reps, r
+            try:
+                # first query over columns the context has not seen (fresh pointers): pays the key sample and its sync, not the arena
+                a2, b2 = a.clone(), b.clone()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dev.join_group_count(a2, None, b2, None, out=out)
+                torch.cuda.synchronize()
+                line["cold_start"]["first_query_on_new_columns_ms"] = (time.perf_counter() - t1) * 1e3
+                del a2, b2
             except Exception as e:  # pragma: no cover
-                line["variant_U"] = {"error": str(e)}
+                line["cold_start"]["error"] = str(e)
+            try:
+                # the wide form (64-bit hashes + row-id arrays), forced: what keys outside any 2^32 window run as
+                dev.set_narrow_keys(0)
+                dtw, rw = timed(lambda: dev.join_group_count(a, None, b, None, out=out))
+                line["wide_form"] = {"ms_per_step": dtw * 1e3, "value": rw[3] / dtw, "narrow": dev.last_join_narrow()}
+            except Exception as e:  # pragma: no cover
+                line["wide_form"] = {"error": str(e)}
+            finally:
+                dev.set_narrow_keys(1)
+            if args.variant == "D":
+                # the other synthetic variant of SURVEY 8d C3 (unique keys on both sides: G = n groups), same pipeline
+                try:
+                    b_u = dev.gen_keys(n, 0, n, 43, 0)
+                    dtu, ru = timed(lambda: dev.join_group_count(a, None, b_u, None, out=out))
+                    line["variant_U"] = {"workload": f"unique keys both sides, {n} rows/table", "joined_rows": ru[3], "groups": int(ru[0].numel()),
+                                         "ms_per_step": dtu * 1e3, "value": ru[3] / dtu}
+                    del b_u
+                except Exception as e:  # pragma: no cover
+                    line["variant_U"] = {"error": str(e)}
+            try:
+                line["end_to_end"] = end_to_end(n, mod_b, a, b)
+            except Exception as e:  # pragma: no cover
+                line["end_to_end"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_naive"] = cpu_naive_sizes()
+            except Exception as e:  # pragma: no cover
+                line["cpu_naive"] = {"error": str(e)}
             try:
                 gpu_result = None
                 if pipeline is None:

@@ -155,6 +155,13 @@ int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_ins
  * src_nullbits is NULL. */
 int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_t *src_nullbits,
 		     const uint32_t *idx, uint64_t n, void *dst, uint64_t *dst_nullbits);
+/* DOUBLE equi-join keys (cmp_double_value_to_value, reference executor_select.c:440-460, compares with IEEE `==`):
+ * dst[k] = the key of row idx[k] (idx == NULL: row k) as a word that the join operators can compare bit for bit -
+ * -0.0 becomes +0.0 (they are equal upstream) and a NaN row gets its bit in dst_nullbits set (NaN equals nothing
+ * upstream, exactly like a NULL key, :557-579); the source's NULL bits are carried over.  dst_nullbits is required:
+ * (n + 63) / 64 words. */
+int mdb_dev_double_join_keys(mdb_dev_ctx *ctx, const double *src, const uint64_t *src_nullbits, const uint32_t *idx, uint64_t n,
+			     int64_t *dst, uint64_t *dst_nullbits);
 /* dst[k] = src[idx[k]] for uint32 row-id vectors (composition of tuple streams). */
 int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
 int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n);

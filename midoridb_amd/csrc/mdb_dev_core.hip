@@ -740,6 +740,49 @@ extern "C" int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_
 	return MIDORIDB_OK;
 }
 
+/* DOUBLE equi-join keys: the join operators compare 8-byte words, the reference compares IEEE doubles
+ * (cmp_double_value_to_value, reference src/engine/executor_select.c:440-460: `==`), which differ in two places -
+ * -0.0 == +0.0 (different words) and NaN != NaN (equal words).  This pass makes the word comparison exact: -0.0 is
+ * rewritten to +0.0 and a NaN row gets its NULL bit set (a NULL key never matches either, :557-579). */
+__global__ __launch_bounds__(STREAM_THREADS) void k_double_join_keys(const uint64_t *__restrict__ src, const uint64_t *__restrict__ src_null,
+								     const uint32_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ dst,
+								     uint64_t *__restrict__ dst_null)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		const bool in = k < n;
+		bool drop = false;
+		if (in) {
+			const uint64_t row = idx ? (uint64_t)idx[k] : k;
+			uint64_t v = src[row];
+			if (src_null)
+				drop = mdb_bit_is_set(src_null, row);
+			if ((v << 1) == 0)
+				v = 0;					/* -0.0 -> +0.0 */
+			if ((v << 1) > 0xFFE0000000000000ull)
+				drop = true;				/* NaN: exponent all ones, mantissa non-zero */
+			dst[k] = v;
+		}
+		const uint64_t m = __ballot(in && drop);
+		if (mdb_lane() == 0 && in)
+			dst_null[k >> 6] = m;
+	}
+}
+
+extern "C" int mdb_dev_double_join_keys(mdb_dev_ctx *ctx, const double *src, const uint64_t *src_nullbits, const uint32_t *idx, uint64_t n,
+					int64_t *dst, uint64_t *dst_nullbits)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (!dst || !dst_nullbits)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "double_join_keys: destination values and NULL bits are both required");
+	MDB_LAUNCH(ctx, "double_join_keys", k_double_join_keys, stream_grid(n), STREAM_THREADS, (const uint64_t *)src, src_nullbits, idx, n,
+		   (uint64_t *)dst, dst_nullbits);
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst)
 {
 	if (n == 0)

@@ -806,9 +806,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
-					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid) {
-					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
@@ -835,13 +835,13 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(leaf_cnt, 0, (size_t)nchild * 4, ctx->stream));
 				if (want_rid) {
-					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l1_rid", (k_part_scatter<false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (w32) {
-					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),

@@ -337,6 +337,10 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 		ERR("SELECT without FROM is not supported by the MI355X path\n");
 		return -MIDORIDB_ERROR;
 	}
+	if (s->ntabs > MDB_MAX_TABS) {
+		ERR("more than %d tables in the FROM clause are not supported\n", MDB_MAX_TABS);
+		return -MIDORIDB_ERROR;
+	}
 	for (int t = 0; t < s->ntabs; t++) {
 		s->tabs[t].t = mdb_catalog_find(cat, s->tabs[t].name);
 		if (!s->tabs[t].t) {
@@ -480,7 +484,7 @@ struct exec {
 	char *err;
 	size_t errlen;
 	struct dbuf_list bufs;
-	uint32_t *rid[MDB_MAX_COLS];	/* per FROM table: row-id vector of the current stream or NULL = identity */
+	uint32_t *rid[MDB_MAX_TABS];	/* per FROM table: row-id vector of the current stream or NULL = identity */
 	bool have_stream;		/* false until the first table is in the stream */
 	uint64_t n;			/* stream length */
 	int64_t *d_count;		/* COUNT(*) column of the stream (after GROUP BY), device */
@@ -585,6 +589,23 @@ static int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t
 		*vals = v;
 		*nulls = nb;
 	}
+	return MIDORIDB_OK;
+}
+
+/* Key vector of an equi-join over table column `col`, rows rid[0..n) (rid == NULL: rows 0..n-1).  INTEGER keys are the
+ * column itself; DOUBLE keys go through mdb_dev_double_join_keys so that the join's word comparison is the reference's
+ * IEEE `==` (cmp_double_value_to_value, executor_select.c:440-460): -0.0 joins +0.0, NaN joins nothing. */
+static int double_join_keys(struct exec *x, const struct mdb_column *col, const uint32_t *rid, uint64_t n, const void **vals,
+			    const uint64_t **nulls)
+{
+	int64_t *v = dalloc(x, (n ? n : 1) * 8);
+	uint64_t *nb = dalloc(x, ((n + 63) / 64 + 1) * 8);
+	if (!v || !nb)
+		return dev_fail(x, "allocating a key column");
+	if (mdb_dev_double_join_keys(x->dev, col->d_data, col->d_nullbits, rid, n, v, nb))
+		return dev_fail(x, "preparing DOUBLE join keys");
+	*vals = v;
+	*nulls = nb;
 	return MIDORIDB_OK;
 }
 
@@ -792,7 +813,7 @@ static uint64_t expr_tables(const struct mdb_expr *e)
  * AND-conjuncts of the WHERE clause: push[t][..] = table t's own conjuncts (constants go with table 0),
  * residual[..] = conjuncts that read several tables and stay above the joins.  false = too many to split. */
 #define PUSH_MAX 16
-#define PUSH_TABS 16
+#define PUSH_TABS MDB_MAX_TABS
 struct where_split {
 	const struct mdb_expr *push[PUSH_TABS][PUSH_MAX];
 	int npush[PUSH_TABS];
@@ -932,8 +953,15 @@ static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *
 		const uint64_t *nl;
 		const void *vr;
 		const uint64_t *nr;
-		if ((rc = stream_column(x, kl, &vl, &nl)) || (rc = table_column(x, t, kr, rsel, r_rows, &vr, &nr)))
+		if (kl->type == MDB_CT_DOUBLE) {
+			const void *dl;
+			if ((rc = double_join_keys(x, &s->tabs[kl->tbl_idx].t->cols[kl->col_idx], x->rid[kl->tbl_idx], x->n, &dl, &nl)) ||
+			    (rc = double_join_keys(x, &rt->cols[kr->col_idx], rsel, r_rows, &vr, &nr)))
+				return rc;
+			vl = dl;
+		} else if ((rc = stream_column(x, kl, &vl, &nl)) || (rc = table_column(x, t, kr, rsel, r_rows, &vr, &nr))) {
 			return rc;
+		}
 		if (x->n && r_rows) {
 			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J))
 				return dev_fail(x, "hash join");
@@ -1043,6 +1071,9 @@ static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool 
 			return -1;
 		if (mine->type != other->type)
 			return -1;
+		if (mine->type == MDB_CT_DOUBLE)
+			return -1;	/* DOUBLE keys join through their IEEE-canonical words (join_next_table), whose values are not
+					 * the column's: the general plan gathers the group keys from the table itself */
 		keys[t] = mine;
 	}
 	if (count_only)
@@ -1155,7 +1186,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	int *order = NULL, *key_tbl = NULL, *key_col = NULL;
 	int nkeys = 0, rc, has_count = 0;
 	double t0;
-	const struct mdb_expr *fkeys[16];
+	const struct mdb_expr *fkeys[MDB_MAX_TABS];
 	int fused;
 
 	*out = NULL;

@@ -32,6 +32,7 @@ int mdb_sql_parse(const char *sql, struct mdb_rpn *out, char *err, size_t errlen
 /* ------------------------------------------------------------------ catalog + columnar storage */
 #define MDB_MAX_COLS 128		/* reference TABLE_MAX_COLUMNS (include/primitive/table.h:16) */
 #define MDB_NAME_LEN 128
+#define MDB_MAX_TABS 16			/* FROM tables of one SELECT (per-table state of the executor is sized by it) */
 
 /* numeric values of the reference's enum COLUMN_TYPE (include/primitive/column.h:17-25) */
 enum mdb_coltype {

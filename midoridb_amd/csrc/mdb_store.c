@@ -163,11 +163,17 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 			rc = mdb_dev_alloc(cat->dev, t->dev_cap * 8, &col->d_data);
 		if (!rc && t->nrows > from)
 			rc = mdb_dev_h2d(cat->dev, (char *)col->d_data + from * 8, col->data + from, (t->nrows - from) * 8);
-		if (!rc && col->null_count) {
+		/* The device bitmap exists from the column's first NULL on and is then kept current for good: an UPDATE may
+		 * bring null_count back to 0 while the kernels still read the bitmap, so every later append uploads its
+		 * words too.  mdb_dev_alloc() recycles buffers without clearing them: the words beyond the rows uploaded so
+		 * far are zeroed here, once. */
+		if (!rc && (col->null_count || col->d_nullbits)) {
 			const uint64_t words = (t->dev_cap + 63) / 64;
 			uint64_t w0 = from / 64;
 			if (!col->d_nullbits) {		/* first NULL of this column: the whole bitmap goes up */
 				rc = mdb_dev_alloc(cat->dev, words * 8, (void **)&col->d_nullbits);
+				if (!rc)
+					rc = mdb_dev_memset(cat->dev, col->d_nullbits, 0, words * 8);
 				w0 = 0;
 			}
 			if (!rc)

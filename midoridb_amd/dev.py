@@ -65,6 +65,7 @@ def _bind(lib):
         "mdb_dev_prof_read": ([P, POINTER(ProfEntry), c_int, POINTER(c_int)], c_int),
         "mdb_dev_filter": ([P, POINTER(PredInsn), c_int, POINTER(ColBinding), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
         "mdb_dev_gather64": ([P, P, P, P, c_uint64, P, P], c_int),
+        "mdb_dev_double_join_keys": ([P, P, P, P, c_uint64, P, P], c_int),
         "mdb_dev_gather32": ([P, P, P, c_uint64, P], c_int),
         "mdb_dev_iota32": ([P, P, c_uint64], c_int),
         "mdb_dev_scatter_set64": ([P, P, P, P, c_uint64, c_int64, c_int], c_int),
@@ -98,7 +99,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_gather64", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
@@ -339,6 +340,15 @@ class DeviceCtx:
         if src_null is not None:
             dnull = torch.zeros((n + 63) // 64 or 1, dtype=torch.int64, device=self.device)
         self._chk(self.lib.mdb_dev_gather64(self.h, _ptr(src), _ptr(src_null), _ptr(idx), n, _ptr(dst), _ptr(dnull)), "gather64")
+        return dst[:n], dnull
+
+    def double_join_keys(self, src, src_null, idx=None):
+        """DOUBLE join keys as words that compare like IEEE `==`: (int64 words, NULL bits with the NaN rows added)."""
+        n = idx.numel() if idx is not None else src.numel()
+        dst = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        dnull = torch.zeros((n + 63) // 64 or 1, dtype=torch.int64, device=self.device)
+        self._chk(self.lib.mdb_dev_double_join_keys(self.h, _ptr(src), _ptr(src_null), _ptr(idx), n, _ptr(dst), _ptr(dnull)),
+                  "double_join_keys")
         return dst[:n], dnull
 
     def gather32(self, src, idx):

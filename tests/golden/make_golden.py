@@ -398,19 +398,54 @@ def dml_cases(seed, count):
     return cases
 
 
+def double_joins(seed, count):
+    """Equi-joins on DOUBLE keys: the reference compares them with IEEE `==` (cmp_double_value_to_value,
+    executor_select.c:440-460), so -0.0 joins +0.0 and NaN joins nothing - the two places where comparing the
+    8-byte words would differ.  NaN cannot be written as a literal: the rows enter through the bulk insert."""
+    S = "reference executor via oracle/_ref: DOUBLE join keys (+-0.0, NaN, duplicates, NULLs)"
+    ddl = ["CREATE TABLE A (x DOUBLE, fa INT);", "CREATE TABLE B (y DOUBLE, fb INT);"]
+    nan = float("nan")
+    fixed = {"A": ([[0.0, -0.0, nan, 1.5, 1.5, 2.0, 7.25], [1, 2, 3, 4, 5, 6, 7]], [[0, 0, 0, 0, 0, 0, 1], None]),
+             "B": ([[-0.0, 0.0, nan, 1.5, 3.0, 7.25], [10, 20, 30, 40, 50, 60]], [[0, 0, 0, 0, 0, 1], None])}
+    qs = ["SELECT * FROM A INNER JOIN B ON A.x = B.y;",
+          "SELECT fa, fb FROM A INNER JOIN B ON B.y = A.x WHERE fa > 1;",
+          "SELECT fa, COUNT(*) FROM A INNER JOIN B ON A.x = B.y GROUP BY fa;",
+          "SELECT COUNT(*) FROM A INNER JOIN B ON A.x = B.y;",
+          "SELECT fa, fb FROM A INNER JOIN B ON A.x = B.y AND fb > 10;"]
+    cases = [run_case(f"double_join_fixed_{i}", ddl, fixed, q, S) for i, q in enumerate(qs)]
+    rng = np.random.default_rng(seed)
+    pool = np.array([0.0, -0.0, nan, 0.5, 1.5, -1.5, 1e300, -1e-300])
+    for i in range(count):
+        na, nb = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        x, y = pool[rng.integers(0, len(pool), na)], pool[rng.integers(0, len(pool), nb)]
+        x[0] = 0.5
+        y[0] = 0.5			# at least one joined row (D8)
+        xn, yn = (rng.random(na) < 0.15).astype(int), (rng.random(nb) < 0.15).astype(int)
+        xn[0] = yn[0] = 0
+        tables = {"A": ([x.tolist(), rng.integers(0, 5, na).tolist()], [xn.tolist(), None]),
+                  "B": ([y.tolist(), rng.integers(0, 5, nb).tolist()], [yn.tolist(), None])}
+        cases.append(run_case(f"double_join_random_{seed}_{i}", ddl, tables, qs[i % 4], S))
+    return cases
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref/libmidori_ref.so missing: run `make -C oracle ref` where /root/reference exists")
     sets = {
-        "reference_tests.json": reference_tests(),
-        "probes.json": probes(),
-        "randomized.json": randomized(20261002, 72),
-        "three_way.json": three_way_cases(7, 8),
-        "column_order.json": column_orders(),
-        "config1.json": config1(),
-        "dml.json": dml_cases(99, 30),
+        "reference_tests.json": reference_tests,
+        "probes.json": probes,
+        "randomized.json": lambda: randomized(20261002, 72),
+        "three_way.json": lambda: three_way_cases(7, 8),
+        "column_order.json": column_orders,
+        "config1.json": config1,
+        "dml.json": lambda: dml_cases(99, 30),
+        "double_join.json": lambda: double_joins(5, 16),
     }
-    for fn, cases in sets.items():
+    only = set(sys.argv[1:])		# optional: file names to (re)generate; default all
+    for fn, make in sets.items():
+        if only and fn not in only:
+            continue
+        cases = make()
         with open(os.path.join(OUT, fn), "w") as f:
             json.dump(cases, f, indent=1)
         print(fn, len(cases), "cases")

@@ -226,6 +226,34 @@ def test_gather64_with_nulls(dev):
     assert np.array_equal(_np(out2), src)
 
 
+def test_double_join_keys_follow_ieee_equality(dev):
+    """DOUBLE equi-join keys (reference cmp_double_value_to_value, executor_select.c:440-460: IEEE `==`): after the
+    canonicalisation pass the join's word comparison gives exactly the pairs numpy's float `==` gives - -0.0 joins
+    +0.0, no NaN (of any payload or sign) joins anything, NULLs stay NULL."""
+    rng = np.random.default_rng(3)
+    pool = np.array([0.0, -0.0, np.nan, -np.nan, 0.5, -0.5, 1e308, -1e-308, np.inf, -np.inf])
+    specials = np.array([0x7FF8000000000001, 0xFFF0000000000001, 0x7FF0000000000000], dtype=np.uint64).view(np.float64)  # NaNs + inf
+    pool = np.concatenate([pool, specials])
+    x = pool[rng.integers(0, len(pool), 3001)]
+    y = pool[rng.integers(0, len(pool), 2777)]
+    xn, yn = rng.random(len(x)) < 0.1, rng.random(len(y)) < 0.1
+    kx, nx = dev.double_join_keys(dev.to_dev(x), dev.nullbits_dev(xn))
+    ky, ny = dev.double_join_keys(dev.to_dev(y), dev.nullbits_dev(yn))
+    pl, pr = dev.join_pairs(kx, nx, ky, ny)
+    with np.errstate(invalid="ignore"):
+        eq = (x[:, None] == y[None, :]) & ~xn[:, None] & ~yn[None, :]
+    el, er = np.nonzero(eq)			# row-major = (left, right) ascending: the reference's emission order
+    assert np.array_equal(_np(pl), el) and np.array_equal(_np(pr), er)
+    # through a row-id vector (joined streams), and the NULL bits of the result
+    idx = rng.integers(0, len(x), 999).astype(np.int32)
+    kg, ng = dev.double_join_keys(dev.to_dev(x), dev.nullbits_dev(xn), dev.to_dev(idx))
+    gx = x[idx]
+    assert np.array_equal(D.unpack_nullbits(_np(ng).view(np.uint64), len(idx)), xn[idx] | np.isnan(gx))
+    keep = ~(xn[idx] | np.isnan(gx))
+    assert np.array_equal(_np(kg).view(np.float64)[keep], gx[keep] + 0.0)		# x + 0.0 turns -0.0 into +0.0, nothing else
+    assert not np.signbit(_np(kg).view(np.float64)[keep & (gx == 0)]).any()
+
+
 @pytest.mark.parametrize("n_dest", [1, 2, 4, 8])
 def test_partition_by_dest(dev, n_dest):
     rng = np.random.default_rng(n_dest)

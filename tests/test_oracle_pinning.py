@@ -139,8 +139,8 @@ def _naive_for(case):
     return Naive(tables), sql_to_rpn(case["query"])
 
 
-@pytest.mark.parametrize("case", G.all_cases("reference_tests.json", "probes.json", "randomized.json", "column_order.json"),
-                         ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", G.all_cases("reference_tests.json", "probes.json", "randomized.json", "column_order.json",
+                                              "double_join.json"), ids=lambda c: c["name"])
 def test_naive_whole_query_vs_reference_vectors(case):
     if case["name"] in ("probe_count_first",):
         # SELECT COUNT(*), id_a ... GROUP BY id_a is in-domain; "SELECT COUNT(*) ... GROUP BY k" without k is not
