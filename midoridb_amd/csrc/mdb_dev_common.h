@@ -35,6 +35,8 @@ struct mdb_dev_ctx {
 	uint64_t nh_nl, nh_nr;
 	int nh_result;			/* -1 nothing remembered, 0 wide, 1 narrow */
 	int64_t nh_base;		/* the window centre that went with "narrow" */
+	uint32_t nh_kbits;		/* ... and the compact window the sample offered (0 = none): [nh_lo, nh_lo + 2^nh_kbits) */
+	int64_t nh_lo;
 	/* range of the last key sample (smallest / largest of 2 x 4096 evenly spaced keys), by the columns it was taken from */
 	const void *sr_kl, *sr_kr;
 	uint64_t sr_nl, sr_nr;
@@ -116,6 +118,18 @@ void mdb_prof_end(mdb_dev_ctx *ctx);
 					   hipGetErrorString(le__));                               \
 	} while (0)
 
+/* the same with dynamic LDS */
+#define MDB_LAUNCH_LDS(ctx, name, kernel, grid, block, lds_bytes, ...)                             \
+	do {                                                                                       \
+		mdb_prof_begin((ctx), (name));                                                     \
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (ctx)->stream, __VA_ARGS__); \
+		mdb_prof_end((ctx));                                                               \
+		hipError_t le__ = hipGetLastError();                                               \
+		if (le__ != hipSuccess)                                                            \
+			return mdb_set_err((ctx), -MIDORIDB_INTERNAL, "launch %s failed: %s", (name), \
+					   hipGetErrorString(le__));                               \
+	} while (0)
+
 /* ------------------------------------------------------------------ device helpers */
 #ifdef __HIPCC__
 
@@ -141,6 +155,22 @@ __host__ __device__ static inline uint32_t mdb_fmix32(uint32_t h)
 	h *= 0xC2B2AE35u;
 	h ^= h >> 16;
 	return h;
+}
+
+/* The same finaliser on k-bit words (8 <= k <= 32): x ^= x >> s and a multiplication by an odd constant modulo 2^k are
+ * both bijections of [0, 2^k), so mixk is one, and mixk(0) == 0.  The compact narrow form uses it on key - window base: a
+ * key column whose values span fewer than 2^k values hashes into k bits, the radix partition consumes the top bits and what
+ * is left below them is small enough to INDEX a per-leaf table in LDS directly (mdb_dev_join.hip, k_leaf_direct). */
+__host__ __device__ static inline uint32_t mdb_mixk(uint32_t x, uint32_t k)
+{
+	const uint32_t mask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+	const uint32_t s = (k + 1) >> 1;
+	x ^= x >> s;
+	x = (x * 0x85EBCA6Bu) & mask;
+	x ^= x >> s;
+	x = (x * 0xC2B2AE35u) & mask;
+	x ^= x >> s;
+	return x;
 }
 
 /* inverse of mdb_fmix64 (modular inverses of the two odd multipliers; x ^= x >> 33 is an involution

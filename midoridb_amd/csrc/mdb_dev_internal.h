@@ -52,7 +52,10 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0,
 			bool keys32 = false,	/* keys32: `keys` points to int32 values */
-			int64_t narrow_base = 0);	/* narrow: the keys are taken relative to this value (centre of their 2^32 window) */
+			int64_t narrow_base = 0,	/* narrow: the keys are taken relative to this value (centre of their 2^32 window) */
+			uint32_t narrow_kbits = 0);	/* compact narrow form: keys in [narrow_base, narrow_base + 2^narrow_kbits), hash32 =
+							 * mdb_mixk(key - narrow_base, narrow_kbits) << (32 - narrow_kbits): below the
+							 * bits1 + bits2 partition bits only narrow_kbits - bits1 - bits2 bits tell keys apart */
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

@@ -725,6 +725,270 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 		atomicAdd(a.rec_valid, s_chunk[3]);
 }
 
+/* ------------------------------------------------------------------ direct-address leaves (compact narrow form)
+ *
+ * When the keys of both tables span fewer than 2^k values (k found from the key sample, verified for every key by the
+ * first partition level), the 32-bit hash is mdb_mixk(key - base) in the top k bits of its field - a bijection of the
+ * window - and the radix partition has consumed the top b1 + b2 of them: inside a leaf only rem = k - b1 - b2 bits tell
+ * keys apart.  For rem <= LD_MAX_REM those bits INDEX the leaf's table: three plain arrays in LDS (right rows, left
+ * rows, first left row per key) - no stored keys, no compare-and-swap, no probe chains, no "table full".  A right row
+ * is ONE LDS add, a left row ONE LDS read (plus an add and a minimum when its key has right rows), and the emit pass
+ * walks the arrays linearly.  The hashed kernel above spends ~120 wave instructions per 64 rows and is issue bound
+ * (profiles/r01: 380 M vector + scalar instructions for 2 * 10^8 rows); this one is bound by the HBM stream of the
+ * partitioned rows.  Hashing (instead of partitioning by key range) keeps the leaves evenly filled whatever part of the
+ * window a table covers: the benchmark's right table holds the lowest sixteenth of the left table's key range.
+ *
+ * 512 threads, dynamic LDS of (12 << rem) + 32 bytes (24 KiB at rem = 11: four workgroups = 32 waves per CU).
+ * Persistent: the first register round of both sides of the NEXT leaf is requested before the current leaf is emitted.
+ */
+#define LD_THREADS 512
+#define LD_MAX_REM 12u
+#define LD_RB 1			/* 16-byte loads per thread in the right side's first round: 4 words each = 2048 rows */
+#define LD_RA 2			/* ... and the left side's: 2 words each = 2048 rows */
+
+struct ld_regs {
+	uint4 b[LD_RB];
+	ulonglong2 a[LD_RA];
+};
+
+/* first-round loads of one leaf, untouched until they are consumed (see gc_batch); positions are implied by the thread id.
+ * Rounds start at the 16-byte boundary at or below the leaf's first row: the words in front of it (the previous leaf's
+ * region, or the array's first words) are loaded and ignored. */
+template <bool HAS_R>
+__device__ static inline void ld_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, ld_regs &q)
+{
+	const uint32_t la = l0 & ~1u;
+#pragma unroll
+	for (int u = 0; u < LD_RA; u++) {
+		const uint32_t i = la + 2u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+		q.a[u] = make_ulonglong2(0ull, 0ull);
+		if (i < l1)
+			q.a[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
+	}
+	if (HAS_R) {
+		const uint32_t ra = r0 & ~3u;
+#pragma unroll
+		for (int u = 0; u < LD_RB; u++) {
+			const uint32_t j = ra + 4u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+			q.b[u] = make_uint4(0u, 0u, 0u, 0u);
+			if (j < r1)
+				q.b[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_r) + j);
+		}
+	}
+}
+
+/* one left row: narrow word = hash32 << 32 | row id */
+template <bool HAS_R>
+__device__ static inline void ld_left_row(unsigned long long w, uint32_t shift, uint32_t mask, const uint32_t *s_cr, uint32_t *s_cl,
+					  uint32_t *s_first)
+{
+	const uint32_t idx = ((uint32_t)(w >> 32) >> shift) & mask;
+	if (!HAS_R || s_cr[idx]) {
+		atomicAdd(&s_cl[idx], 1u);
+		atomicMin(&s_first[idx], (uint32_t)w);
+	}
+}
+
+template <bool HAS_R>
+__global__ __launch_bounds__(LD_THREADS) void k_leaf_direct(gc_args a, uint32_t rem, uint32_t shift)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
+	const uint32_t T = 1u << rem, mask = T - 1u;
+	uint32_t *const s_cr = ld_lds;			/* right rows per key */
+	uint32_t *const s_cl = ld_lds + T;		/* left rows per key (joins: only of keys that have right rows) */
+	uint32_t *const s_first = ld_lds + 2 * T;	/* first left row per key */
+	uint32_t *const s_chunk = ld_lds + 3 * T;	/* record list chunk: [0] base [1] used [2] size [3] valid records */
+	unsigned long long *const s_sum = reinterpret_cast<unsigned long long *>(ld_lds + 3 * T + 4);
+
+	for (uint32_t s = threadIdx.x; s < T; s += LD_THREADS) {
+		s_cr[s] = 0u;
+		s_cl[s] = 0u;
+		s_first[s] = 0xFFFFFFFFu;
+	}
+	if (threadIdx.x < 4)
+		s_chunk[threadIdx.x] = 0u;
+	if (threadIdx.x == 0)
+		*s_sum = 0ull;
+	unsigned long long mine = 0;
+	uint32_t nvalid = 0;
+
+	uint32_t leaf = blockIdx.x;
+	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+	ld_regs q;
+	uint2 raw_l = make_uint2(0, 0), raw_r = make_uint2(0, 0);	/* leaf ranges are requested two leaves ahead (see k_leaf_group_count) */
+	if (leaf < a.nleaves) {
+		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+		if (HAS_R)
+			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+		ld_prefetch<HAS_R>(a, l0, l1, r0, r1, q);
+		if (leaf + gridDim.x < a.nleaves) {
+			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, leaf + gridDim.x);
+			if (HAS_R)
+				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, leaf + gridDim.x);
+		}
+	}
+	__syncthreads();
+	const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
+	while (leaf < a.nleaves) {
+		const uint32_t next = leaf + gridDim.x, next2 = next + gridDim.x;
+		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
+		if (next < a.nleaves) {
+			gc_leaf_decode(raw_l, a.cap_l, next, &nl0, &nl1);
+			if (HAS_R)
+				gc_leaf_decode(raw_r, a.cap_r, next, &nr0, &nr1);
+		}
+		if (next2 < a.nleaves) {
+			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, next2);
+			if (HAS_R)
+				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, next2);
+		}
+		const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);
+		const bool hot = nonempty && (l1 - l0 >= a.heavy_l || (HAS_R && r1 - r0 >= a.heavy_r));
+		const bool live = nonempty && !hot;
+		if (hot && threadIdx.x == 0)
+			mdb_raise(a.status, 64u);	/* left to the hot-key path (hashed tables in global memory) */
+		if (live && a.kbits) {
+			/* record list space, reserved a chunk at a time: one global atomic per ~10-170 leaves (see k_leaf_group_count) */
+			const uint32_t rows = (HAS_R && (r1 - r0) < (l1 - l0)) ? r1 - r0 : l1 - l0;	/* a group needs a row on both sides */
+			const uint32_t need = (rows < T ? rows : T) + 1;
+			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+			if (used + need > size) {		/* uniform: every thread read the same words */
+				for (uint32_t i = used + threadIdx.x; i < size; i += LD_THREADS)
+					a.rec[base + i] = 0ull;
+				__syncthreads();		/* everyone has read s_chunk */
+				if (threadIdx.x == 0) {
+					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
+					const uint32_t nb = atomicAdd(a.rec_count, want);
+					if (nb + want > a.rec_cap) {
+						mdb_raise(a.status, 8u);
+						s_chunk[0] = 0;
+						s_chunk[2] = 0;
+					} else {
+						s_chunk[0] = nb;
+						s_chunk[2] = want;
+					}
+					s_chunk[1] = 0;
+				}
+				/* visible to everyone after the barrier that ends the count phase */
+			}
+		}
+		if (live) {
+			if (HAS_R) {
+				/* right rows: one LDS add each */
+				const uint32_t ra = r0 & ~3u;
+#pragma unroll
+				for (int u = 0; u < LD_RB; u++) {
+					const uint32_t j = ra + 4u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+					const uint32_t w[4] = { q.b[u].x, q.b[u].y, q.b[u].z, q.b[u].w };
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						if (j + k >= r0 && j + k < r1)
+							atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
+				}
+				for (uint32_t j = ra + 4u * (LD_RB * LD_THREADS + threadIdx.x); j < r1; j += 4u * LD_THREADS) {
+					const uint4 v = *reinterpret_cast<const uint4 *>(hv_r32 + j);
+					const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						if (j + k < r1)
+							atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
+				}
+				__syncthreads();
+			}
+			/* left rows: one LDS read each; rows whose key has right rows are counted and compete for "first" */
+			const uint32_t la = l0 & ~1u;
+#pragma unroll
+			for (int u = 0; u < LD_RA; u++) {
+				const uint32_t i = la + 2u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+				if (i >= l0 && i < l1)
+					ld_left_row<HAS_R>(q.a[u].x, shift, mask, s_cr, s_cl, s_first);
+				if (i + 1 < l1)		/* (i + 1 >= l0 always: la >= l0 - 1) */
+					ld_left_row<HAS_R>(q.a[u].y, shift, mask, s_cr, s_cl, s_first);
+			}
+			for (uint32_t i = la + 2u * (LD_RA * LD_THREADS + threadIdx.x); i < l1; i += 2u * LD_THREADS) {
+				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
+				ld_left_row<HAS_R>(v.x, shift, mask, s_cr, s_cl, s_first);
+				if (i + 1 < l1)
+					ld_left_row<HAS_R>(v.y, shift, mask, s_cr, s_cl, s_first);
+			}
+			__syncthreads();
+		}
+
+		/* the next leaf's first rounds travel while this leaf is emitted */
+		if (next < a.nleaves)
+			ld_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, q);
+
+		if (live) {
+			/* emit one record per key that has rows on both sides and clear what was touched */
+			const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
+			for (uint32_t s0 = 0; s0 < T; s0 += LD_THREADS) {	/* uniform trip count */
+				const uint32_t s = s0 + threadIdx.x;
+				unsigned long long recv = 0;
+				if (s < T) {
+					const uint32_t cl = s_cl[s];
+					uint32_t cr = 1u;
+					if (HAS_R) {
+						cr = s_cr[s];
+						if (cr)
+							s_cr[s] = 0u;
+					}
+					if (cl) {
+						const uint32_t first = s_first[s];
+						const unsigned long long c = (unsigned long long)cl * cr;
+						s_cl[s] = 0u;
+						s_first[s] = 0xFFFFFFFFu;
+						mine += c;
+						if (a.kbits) {
+							if (c >> (64 - a.kbits))
+								mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+							recv = ((unsigned long long)first << (64 - a.kbits)) | c;
+						} else {
+							a.dense_cnt[first] = (int64_t)c;
+						}
+					}
+				}
+				if (a.kbits) {
+					/* wave-level append: one LDS atomic per wave and iteration */
+					const uint64_t m = __ballot(recv != 0ull);
+					if (m) {
+						const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+						uint32_t wbase = 0;
+						if (mdb_lane() == leader)
+							wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
+						wbase = __shfl(wbase, (int)leader, MDB_WAVE);
+						if (recv) {
+							const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+							if (pos < csize)
+								a.rec[cbase + pos] = recv;
+							nvalid++;
+						}
+					}
+				}
+			}
+			__syncthreads();	/* the next leaf counts into the cleared arrays */
+		}
+		leaf = next;
+		l0 = nl0;
+		l1 = nl1;
+		r0 = nr0;
+		r1 = nr1;
+	}
+	if (a.kbits) {
+		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+		for (uint32_t i = used + threadIdx.x; i < size; i += LD_THREADS)
+			a.rec[base + i] = 0ull;		/* unused tail of the last chunk */
+		if (nvalid)
+			atomicAdd(&s_chunk[3], nvalid);
+	}
+	if (mine)
+		atomicAdd(s_sum, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && *s_sum)
+		atomicAdd(a.joined, *s_sum);
+	if (threadIdx.x == 0 && a.kbits && s_chunk[3])
+		atomicAdd(a.rec_valid, s_chunk[3]);
+}
+
 /* ------------------------------------------------------------------ hot keys across the whole chip
  *
  * One workgroup streams a leaf at ~16 GB/s; a key with 10^7 duplicates would pin one workgroup for 10+ ms while the
@@ -1174,6 +1438,18 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
 #define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 #define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
+#define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
+
+/* MDB_DIRECT_LEAF=0 keeps the compact narrow form off (A/B measurements, soaks of the hashed leaf kernel) */
+static bool ld_disabled(void)
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = getenv("MDB_DIRECT_LEAF");
+		v = (e && e[0] == '0') ? 1 : 0;
+	}
+	return v == 1;
+}
 
 /* slots of the group-record list: every group once, plus the zero-filled gaps of the chunked reservation
  * (at most one leaf's worth per chunk, one unfinished chunk per workgroup) */
@@ -1193,6 +1469,9 @@ struct gc_state {
 	bool narrow;		/* 32-bit hashes; the left words carry the row ids (see mdb_partition_table) */
 	bool keys32;		/* both key columns are int32 arrays (received over xGMI in the 4-byte wire format) */
 	int64_t base;		/* narrow form: centre of the key window (mdb_partition_table) */
+	uint32_t key_bits;	/* compact narrow form offered by the key sample: every key in [key_lo, key_lo + 2^key_bits) (0 = none) */
+	int64_t key_lo;
+	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -1210,6 +1489,11 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
 	if (st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
 		st->narrow = false;
+	/* compact narrow form + direct-address leaves: what the partition leaves of the key_bits-wide hash must index a table
+	 * of at most 2^LD_MAX_REM entries; fewer than 2^4 would mean leaves of a handful of keys with thousands of rows each
+	 * (same-address LDS atomics: the hashed kernel's wave-level merging handles those better) */
+	st->direct = st->narrow && st->key_bits && st->fast && st->b2 > 0 && st->want_records && !ld_disabled() &&
+		     st->key_bits >= (uint32_t)(st->b1 + st->b2) + 4u && st->key_bits <= (uint32_t)(st->b1 + st->b2) + LD_MAX_REM;
 	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->has_r)
 		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
@@ -1234,7 +1518,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
-				 st->narrow ? 1 : 0, st->keys32, st->base);
+				 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
 	if (rc)
 		return rc;
 	st->active = true;
@@ -1262,7 +1546,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
 		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
 			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32, st->base);
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32,
+					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
 		if (rc)
 			return rc;
 	}
@@ -1323,7 +1608,19 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		if (has_r && build_r && st->narrow) {
+		if (st->direct) {
+			/* compact narrow form: the leaf's table is indexed by the hash bits the partition left over */
+			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
+			const size_t lds = ((size_t)12 << rem) + 32;
+			uint32_t per_cu = (uint32_t)((size_t)(160 * 1024) / lds);
+			per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);	/* 4 x 512 threads = the CU's 32 waves */
+			const uint32_t dgrid = pl.nleaves < per_cu * (uint32_t)ctx->num_cus ? pl.nleaves : per_cu * (uint32_t)ctx->num_cus;
+			if (has_r) {
+				MDB_LAUNCH_LDS(ctx, "leaf_join_direct", k_leaf_direct<true>, dgrid, LD_THREADS, lds, a, rem, shift);
+			} else {
+				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", k_leaf_direct<false>, dgrid, LD_THREADS, lds, a, rem, shift);
+			}
+		} else if (has_r && build_r && st->narrow) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false, true>), grid, GC_THREADS, a);
 		} else if (has_r && build_r) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false>), grid, GC_THREADS, a);
@@ -1354,7 +1651,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if ((uint32_t)h[1] & 128u)
-		return GC_RETRY_WIDE;	/* a key outside the int32 range: the 32-bit hashes mean nothing */
+		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if ((uint32_t)h[1] & 64u) {
@@ -1451,7 +1748,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	*out_groups = G;
 	if (out_joined)
 		*out_joined = joined;
-	ctx->last_narrow = st->narrow ? 1 : 0;
+	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
 	return MIDORIDB_OK;
 }
 
@@ -1563,8 +1860,10 @@ static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 }
 
 static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow,
-			   int64_t base = 0)
+			   int64_t base = 0, uint32_t key_bits = 0, int64_t key_lo = 0)
 {
+	ctx->nh_kbits = narrow ? key_bits : 0u;
+	ctx->nh_lo = key_lo;
 	ctx->nh_kl = keys_l;
 	ctx->nh_nl = n_l;
 	ctx->nh_kr = keys_r;
@@ -1576,11 +1875,42 @@ static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l
 
 /* *narrow: try the narrow form; *base: centre of the 2^32-wide window of key values it will be tried with (0 = the plain
  * int32 range, whenever the sampled keys lie inside it) */
+/* The compact window offered by a key sample [lo, hi]: the sampled span, padded by a sixteenth of itself + 4096 on either
+ * side for the extremes the sample missed, rounded up to a power of two (the slack is split between the two ends).
+ * *kbits = 0: none (span of 2^31 or more, or nothing but NULLs sampled). */
+static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *wlo)
+{
+	*kbits = 0;
+	*wlo = 0;
+	if (lo > hi)
+		return;
+	const uint64_t span = (uint64_t)hi - (uint64_t)lo;
+	if (span >= (1ull << 31))
+		return;
+	const uint64_t pad = span / 16 + 4096, need = span + 2 * pad + 1;
+	uint32_t k = 8;
+	while ((1ull << k) < need)
+		k++;
+	if (k > 31)
+		return;
+	*kbits = k;
+	*wlo = (int64_t)((uint64_t)lo - pad - (((1ull << k) - need) >> 1));
+}
+
+struct gc_window {
+	uint32_t kbits;		/* 0 = no compact window */
+	int64_t lo;
+};
+
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			   const uint64_t *null_r, uint64_t n_r, bool *narrow, int64_t *base)
+			   const uint64_t *null_r, uint64_t n_r, bool *narrow, int64_t *base, gc_window *win = nullptr)
 {
 	*narrow = false;
 	*base = 0;
+	if (win) {
+		win->kbits = 0;
+		win->lo = 0;
+	}
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
 	if (ctx->narrow_mode == 2) {
@@ -1597,6 +1927,10 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		   ++ctx->nh_uses < GC_HINT_USES) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
 		*base = ctx->nh_base;
+		if (win && *narrow) {
+			win->kbits = ctx->nh_kbits;
+			win->lo = ctx->nh_lo;
+		}
 		return MIDORIDB_OK;
 	}
 	int64_t lo = 0, hi = 0;
@@ -1613,14 +1947,22 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		*narrow = true;
 		*base = (int64_t)((uint64_t)lo + (((uint64_t)hi - (uint64_t)lo) >> 1));
 	}
-	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base);
+	uint32_t kb = 0;
+	int64_t wlo = 0;
+	if (*narrow)
+		gc_compact_window(lo, hi, &kb, &wlo);
+	if (win) {
+		win->kbits = kb;
+		win->lo = wlo;
+	}
+	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base, kb, wlo);
 	return MIDORIDB_OK;
 }
 
 static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 			   const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, bool fast,
-			   bool want_records, bool no_build_r, bool narrow, int64_t base, bool keys32, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
-			   uint64_t *out_joined)
+			   bool want_records, bool no_build_r, bool narrow, int64_t base, gc_window win, bool keys32, int64_t *out_key, int64_t *out_count,
+			   uint32_t *out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
 {
 	*out_groups = 0;
 	if (out_joined)
@@ -1640,6 +1982,8 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.no_build_r = no_build_r;
 	st.narrow = narrow;
 	st.base = base;
+	st.key_bits = narrow ? win.kbits : 0u;
+	st.key_lo = win.lo;
 	st.keys32 = keys32;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
@@ -1656,6 +2000,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
 	int64_t base = 0;
+	gc_window win = { 0, 0 };
 	int rc = MIDORIDB_OK;
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow
@@ -1665,13 +2010,19 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	if (keys32)
 		narrow = ctx->narrow_mode != 0;		/* int32 columns: nothing to sample */
 	else
-		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow, &base);
+		rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow, &base, &win);
 	if (rc)
 		return rc;
-	for (int attempt = 0; attempt < 5; attempt++) {
+	for (int attempt = 0; attempt < 6; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
-				     base, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
-		if (rc == GC_RETRY_WIDE) {
+				     base, win, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
+		if (rc == GC_RETRY_PLAIN) {
+			/* the sample missed the column's extremes: the plain narrow form (any 2^32-wide window) is tried next,
+			 * and remembered for these columns */
+			win.kbits = 0;
+			if (ctx->narrow_mode == 1 && !keys32)
+				gc_narrow_note(ctx, keys_l, n_l, has_r ? keys_r : NULL, n_r, true, base);
+		} else if (rc == GC_RETRY_WIDE) {
 			narrow = false;
 			if (ctx->narrow_mode == 1 && !keys32)
 				ctx->nh_distrust = 8;	/* whatever said "narrow" was wrong: look at the data itself the next few times */

@@ -80,7 +80,10 @@ struct mdb_level_args {
 	 * the low half when narrow == 1 - hash and row id then travel as ONE 8-byte word and no row-id array exists - or
 	 * the hash once more when narrow == 2 */
 	uint32_t narrow;
-	int64_t narrow_base;		/* narrow form: centre of the 2^32-wide window of key values that the 32-bit words can tell apart */
+	int64_t narrow_base;		/* narrow form: centre of the 2^32-wide window of key values that the 32-bit words can tell apart
+					 * (compact form, narrow_kbits != 0: the window's LOW end) */
+	uint32_t narrow_kbits;		/* compact narrow form: every key must lie in [narrow_base, narrow_base + 2^narrow_kbits); the 32-bit
+					 * hash is mixk(key - narrow_base) in the TOP narrow_kbits bits of the field, zeros below */
 	uint32_t keys32;		/* level 0: `keys` is an array of int32 (keys that crossed xGMI in the 4-byte wire format) */
 };
 
@@ -89,9 +92,15 @@ __device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_
 {
 	if (!a.narrow)
 		return mdb_fmix64(key);
-	key -= (uint64_t)a.narrow_base;		/* (wraps: the test below is on the 64-bit difference) */
-	*bad = *bad || (key + 0x80000000ull) >> 32;
-	const uint32_t h = mdb_fmix32((uint32_t)key);
+	key -= (uint64_t)a.narrow_base;		/* (wraps: the tests below are on the 64-bit difference) */
+	uint32_t h;
+	if (a.narrow_kbits) {
+		*bad = *bad || (key >> a.narrow_kbits);
+		h = mdb_mixk((uint32_t)key, a.narrow_kbits) << (32u - a.narrow_kbits);
+	} else {
+		*bad = *bad || (key + 0x80000000ull) >> 32;
+		h = mdb_fmix32((uint32_t)key);
+	}
 	return ((uint64_t)h << 32) | (a.narrow == 1 ? rid : h);
 }
 
@@ -702,7 +711,7 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
 			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL,
-			  uint32_t digits0_used = 0, bool keys32_out = false, int64_t narrow_base = 0)
+			  uint32_t digits0_used = 0, bool keys32_out = false, int64_t narrow_base = 0, uint32_t narrow_kbits = 0)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -777,6 +786,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.status = ctx ? ctx->d_status : NULL;
 		a.keys32 = (flags & PART_F_KEYS32) ? 1u : 0u;
 		a.narrow_base = narrow_base;
+		a.narrow_kbits = a.narrow ? narrow_kbits : 0u;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
 			a.shift = (uint32_t)((w32 ? 32 : 64) - used_bits - b);
@@ -948,8 +958,11 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast)
 }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
-			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32, int64_t narrow_base)
+			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32, int64_t narrow_base,
+			uint32_t narrow_kbits)
 {
+	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "narrow partitioning carries row ids inside the word");
 	if (n >= 0xFFFFFFFFull)
@@ -963,7 +976,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
 				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u),
-			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0);
+			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u);
 }
 
 /* MSD radix partition of ready-made 64-bit sort keys (no hashing, no NULLs) by their top bits1 + bits2

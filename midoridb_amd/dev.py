@@ -189,6 +189,11 @@ class DeviceCtx:
     def last_join_narrow(self):
         return bool(self.lib.mdb_dev_last_join_narrow(self.h))
 
+    def last_join_form(self):
+        """0 wide (64-bit hashes), 1 narrow (32-bit hashes of a 2^32-wide window), 2 compact narrow (k-bit hashes of the
+        sampled window, direct-address leaves)"""
+        return int(self.lib.mdb_dev_last_join_narrow(self.h))
+
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""
         self._chk(self.lib.mdb_dev_set_narrow_keys(self.h, int(mode)), "set_narrow_keys")

@@ -5,6 +5,7 @@ tests/engine/executor_select.c:47-66): database_open -> query_execute -> while
 query_cur_step(...) == MIDORIDB_ROW: query_column_int64(...) -> query_free -> database_close.
 """
 import ctypes
+import time
 from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 import numpy as np
@@ -150,7 +151,10 @@ class DB:
         """SELECT -> Result.  step_cursor=True walks the result with query_cur_step()/query_column_int64()
         exactly like the reference's tests; otherwise whole columns are copied at once."""
         fn = self.lib.mdb_query_execute_rpn if rpn else self.lib.query_execute
-        out, status = self._run(fn(ctypes.byref(self.db), sql.encode()))
+        t0 = time.perf_counter()
+        raw = fn(ctypes.byref(self.db), sql.encode())
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3	# wall time of the C call alone (no Python-side copies)
+        out, status = self._run(raw)
         if status != ST_OK_WITH_RESULTS:
             self.lib.query_free(out)
             raise QueryError("not a SELECT")

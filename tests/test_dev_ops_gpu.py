@@ -986,6 +986,91 @@ def test_narrow_form_window_anywhere_in_the_int64_range(dev, narrow_mode, shape)
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
 
 
+@pytest.mark.parametrize("shape", ["dense_perm", "dup16", "offset_1e12", "negative", "nulls", "n_to_m", "rem4", "rem12", "sparse_not_direct",
+                                   "outlier_left", "outlier_right", "hot_key", "left_small", "right_small"])
+def test_compact_narrow_form_direct_address_leaves(dev, narrow_mode, shape):
+    """Keys that span fewer than 2^k values hash into k bits (mdb_mixk of key - window base, verified per key); what the
+    radix partition leaves of them indexes the leaf tables directly (k_leaf_direct).  Same groups, counts, first rows and
+    order as the oracle for dense and duplicated keys, windows anywhere in the int64 range, NULLs, N:M duplicates, the
+    smallest and largest table sizes, a hot key (left to the hot-key path), and a key outside the sampled window - hidden
+    from the sample - which sends the operator to the plain narrow form."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 7 + 1)
+    n_l, n_r = 1_500_000, 1_300_000
+    span, off, expect = 1_500_000, 0, 2
+    if shape == "offset_1e12":
+        off = 10**12
+    elif shape == "negative":
+        off = -(2**40)
+    elif shape == "rem4":
+        span = 12_000		# 14-bit window over 2^10 leaves
+    elif shape == "rem12":
+        span = 3_500_000	# 22-bit window
+    elif shape == "sparse_not_direct":
+        span, expect = 2**27, 1
+    elif shape == "left_small":
+        n_l = 500_000
+    elif shape == "right_small":
+        n_r = 5000
+    if shape == "dense_perm":
+        kl = off + rng.permutation(span)[:n_l].astype(np.int64)
+        kr = off + rng.permutation(span)[:n_r].astype(np.int64)
+    elif shape == "dup16":
+        kl = off + rng.permutation(span)[:n_l].astype(np.int64)
+        kr = off + (rng.permutation(span)[:n_r] % (span // 16)).astype(np.int64)
+    else:
+        kl = off + rng.integers(0, span, n_l, dtype=np.int64)
+        kr = off + rng.integers(0, span, n_r, dtype=np.int64)
+    nl = nr = None
+    if shape == "nulls":
+        nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.2
+        kl[nl] = rng.integers(-2**62, 2**62, int(nl.sum()))	# whatever lies under a NULL bit is no key
+    if shape == "outlier_left":
+        kl[n_l // 3 + 1] = off + span + span // 8 + 5000	# beyond the padding of the sampled window, inside the 2^32 one
+        kr[7] = kl[n_l // 3 + 1]
+        expect = 1
+    if shape == "outlier_right":
+        kr[n_r - 2] = off - span // 8 - 5000
+        kl[11] = kr[n_r - 2]
+        expect = 1
+    if shape == "hot_key":
+        kr[100_000:500_000] = off + 12345
+        kl[50_000:50_040] = off + 12345
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for round_ in range(2):		# the second call runs on the remembered verdict
+        k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+        assert dev.last_join_form() == expect, (shape, round_, dev.last_join_form())
+    first, cnt = dev.group_count(dl, dnl)
+    e_first, e_cnt = orc.group_count(kl, nl)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+    # right side grouped on its own (duplicates / the hot key on the build side of a plain GROUP BY)
+    first, cnt = dev.group_count(dr, dnr)
+    e_first, e_cnt = orc.group_count(kr, nr)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), e_first) and np.array_equal(_np(cnt), e_cnt)
+
+
+def test_compact_and_hashed_leaf_kernels_agree_at_scale(dev, narrow_mode):
+    """2 * 10^7 x 2 * 10^7 rows of the benchmark's generator: the compact form (direct-address leaves), the plain narrow form
+    and the wide form deliver identical columns."""
+    n = 20_000_000
+    kl = dev.gen_keys(n, 0, n, 42, 0)
+    out = {}
+    for variant, mod in (("D", n // 16), ("U", 0)):
+        kr = dev.gen_keys(n, 0, n, 43, mod)
+        for mode in (0, 2, 1):
+            narrow_mode(mode)
+            k, c, f, j = dev.join_group_count(kl, None, kr, None)
+            assert dev.last_join_form() == {0: 0, 2: 1, 1: 2}[mode]
+            out[mode] = (k.clone(), c.clone(), f.clone(), j)
+        for m in (2, 1):
+            for a, b in zip(out[0][:3], out[m][:3]):
+                assert torch.equal(a, b)
+            assert out[0][3] == out[m][3] == n
+
+
 @pytest.mark.parametrize("n", [262_144, 600_001])
 def test_group_count_multi_and_distinct_on_the_packed_sort_path(dev, n):
     """From 2^18 rows on, INT64 columns whose ranges fit one word are sorted by the packed path and the group / distinct
