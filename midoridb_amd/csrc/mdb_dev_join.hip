@@ -741,37 +741,58 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
  * 512 threads, dynamic LDS of (12 << rem) + 32 bytes (24 KiB at rem = 11: four workgroups = 32 waves per CU).
  * Persistent: the first register round of both sides of the NEXT leaf is requested before the current leaf is emitted.
  */
-#define LD_THREADS 512
 #define LD_MAX_REM 12u
-#define LD_RB 1			/* 16-byte loads per thread in the right side's first round: 4 words each = 2048 rows */
-#define LD_RA 2			/* ... and the left side's: 2 words each = 2048 rows */
+#define LD_ROUND 2048		/* rows of either side in the first (register) round of a leaf */
 
+template <int THREADS>
 struct ld_regs {
-	uint4 b[LD_RB];
-	ulonglong2 a[LD_RA];
+	static constexpr int RB = LD_ROUND / (4 * THREADS);	/* 16-byte loads per thread, right side: 4 words each */
+	static constexpr int RA = LD_ROUND / (2 * THREADS);	/* ... left side: 2 words each */
+	uint4 b[RB];
+	ulonglong2 a[RA];
+	uint32_t l1, r1;		/* ends of the requested leaf's two row ranges (they start at leaf * cap) */
+	uint2 next_l, next_r;		/* row counts of the leaf this register set will take NEXT, as loaded (gc_leaf_decode) */
 };
 
-/* first-round loads of one leaf, untouched until they are consumed (see gc_batch); positions are implied by the thread id.
- * Rounds start at the 16-byte boundary at or below the leaf's first row: the words in front of it (the previous leaf's
- * region, or the array's first words) are loaded and ignored. */
-template <bool HAS_R>
-__device__ static inline void ld_prefetch(const gc_args &a, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, ld_regs &q)
+/* Row counts of `leaf`, to be decoded one leaf's work later. */
+template <bool HAS_R, int THREADS>
+__device__ static inline void ld_request_counts(const gc_args &a, uint32_t leaf, ld_regs<THREADS> &q)
 {
-	const uint32_t la = l0 & ~1u;
+	q.next_l = make_uint2(0, 0);
+	q.next_r = make_uint2(0, 0);
+	if (leaf < a.nleaves) {
+		q.next_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, leaf);
+		if (HAS_R)
+			q.next_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, leaf);
+	}
+}
+
+/* First-round loads of `leaf` (whose counts were requested into q before), untouched until they are consumed: a
+ * conversion at load time would make the request wait for itself (see gc_batch).  A leaf is requested TWO leaves ahead of
+ * its turn, so its loads have a whole leaf's work to land in; its counts are requested two leaves before that, so that
+ * only the rows that exist are fetched (whole rounds regardless of the count were 30 % more bytes and 15 % slower). */
+template <bool HAS_R, int THREADS>
+__device__ static inline void ld_request(const gc_args &a, uint32_t leaf, ld_regs<THREADS> &q)
+{
+	uint32_t l0, r0 = 0;
+	gc_leaf_decode(q.next_l, a.cap_l, leaf, &l0, &q.l1);
+	q.r1 = 1;
+	if (HAS_R)
+		gc_leaf_decode(q.next_r, a.cap_r, leaf, &r0, &q.r1);
+	ld_request_counts<HAS_R, THREADS>(a, leaf + 2 * gridDim.x, q);
 #pragma unroll
-	for (int u = 0; u < LD_RA; u++) {
-		const uint32_t i = la + 2u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+	for (int u = 0; u < ld_regs<THREADS>::RA; u++) {
+		const uint32_t i = l0 + 2u * ((uint32_t)u * THREADS + threadIdx.x);
 		q.a[u] = make_ulonglong2(0ull, 0ull);
-		if (i < l1)
+		if (i < q.l1)
 			q.a[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
 	}
 	if (HAS_R) {
-		const uint32_t ra = r0 & ~3u;
 #pragma unroll
-		for (int u = 0; u < LD_RB; u++) {
-			const uint32_t j = ra + 4u * ((uint32_t)u * LD_THREADS + threadIdx.x);
+		for (int u = 0; u < ld_regs<THREADS>::RB; u++) {
+			const uint32_t j = r0 + 4u * ((uint32_t)u * THREADS + threadIdx.x);
 			q.b[u] = make_uint4(0u, 0u, 0u, 0u);
-			if (j < r1)
+			if (j < q.r1)
 				q.b[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_r) + j);
 		}
 	}
@@ -789,204 +810,206 @@ __device__ static inline void ld_left_row(unsigned long long w, uint32_t shift, 
 	}
 }
 
-template <bool HAS_R>
-__global__ __launch_bounds__(LD_THREADS) void k_leaf_direct(gc_args a, uint32_t rem, uint32_t shift)
+struct ld_state {
+	uint32_t *s_cr, *s_cl, *s_first, *s_chunk;
+	uint32_t T, mask, shift;
+	unsigned long long mine;
+	uint32_t nvalid;
+};
+
+/* one leaf: count the right rows, look the left rows up, request leaf + 2 * gridDim.x into the registers just consumed, emit */
+template <bool HAS_R, int THREADS>
+__device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t leaf, ld_regs<THREADS> &q)
 {
-	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
-	const uint32_t T = 1u << rem, mask = T - 1u;
-	uint32_t *const s_cr = ld_lds;			/* right rows per key */
-	uint32_t *const s_cl = ld_lds + T;		/* left rows per key (joins: only of keys that have right rows) */
-	uint32_t *const s_first = ld_lds + 2 * T;	/* first left row per key */
-	uint32_t *const s_chunk = ld_lds + 3 * T;	/* record list chunk: [0] base [1] used [2] size [3] valid records */
-	unsigned long long *const s_sum = reinterpret_cast<unsigned long long *>(ld_lds + 3 * T + 4);
-
-	for (uint32_t s = threadIdx.x; s < T; s += LD_THREADS) {
-		s_cr[s] = 0u;
-		s_cl[s] = 0u;
-		s_first[s] = 0xFFFFFFFFu;
+	uint32_t *const s_cr = st.s_cr, *const s_cl = st.s_cl, *const s_first = st.s_first, *const s_chunk = st.s_chunk;
+	const uint32_t T = st.T, mask = st.mask, shift = st.shift;
+	const uint32_t l0 = leaf * a.cap_l, l1 = q.l1, r0 = HAS_R ? leaf * a.cap_r : 0u, r1 = q.r1;
+	const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);
+	const bool hot = nonempty && (l1 - l0 >= a.heavy_l || (HAS_R && r1 - r0 >= a.heavy_r));
+	const bool live = nonempty && !hot;
+	if (hot && threadIdx.x == 0)
+		mdb_raise(a.status, 64u);	/* left to the hot-key path (hashed tables in global memory) */
+	if (live && a.kbits) {
+		/* record list space, reserved a chunk at a time: one global atomic per ~10-170 leaves (see k_leaf_group_count).
+		 * (Reserving for the DISTINCT right keys instead of the rows - counted with returning adds - left fewer zero-filled
+		 * gaps in the list but cost the kernel 25 %: profiles/micro/leaf_direct_exp.sh) */
+		const uint32_t rows = (HAS_R && (r1 - r0) < (l1 - l0)) ? r1 - r0 : l1 - l0;	/* a group needs a row on both sides */
+		const uint32_t need = (rows < T ? rows : T) + 1;
+		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+		if (used + need > size) {		/* uniform: every thread read the same words */
+			for (uint32_t i = used + threadIdx.x; i < size; i += THREADS)
+				a.rec[base + i] = 0ull;
+			__syncthreads();		/* everyone has read s_chunk */
+			if (threadIdx.x == 0) {
+				const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
+				const uint32_t nb = atomicAdd(a.rec_count, want);
+				if (nb + want > a.rec_cap) {
+					mdb_raise(a.status, 8u);
+					s_chunk[0] = 0;
+					s_chunk[2] = 0;
+				} else {
+					s_chunk[0] = nb;
+					s_chunk[2] = want;
+				}
+				s_chunk[1] = 0;
+			}
+			/* visible to everyone after the barrier that ends the count phase */
+		}
 	}
-	if (threadIdx.x < 4)
-		s_chunk[threadIdx.x] = 0u;
-	if (threadIdx.x == 0)
-		*s_sum = 0ull;
-	unsigned long long mine = 0;
-	uint32_t nvalid = 0;
-
-	uint32_t leaf = blockIdx.x;
-	uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
-	ld_regs q;
-	uint2 raw_l = make_uint2(0, 0), raw_r = make_uint2(0, 0);	/* leaf ranges are requested two leaves ahead (see k_leaf_group_count) */
-	if (leaf < a.nleaves) {
-		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
-		if (HAS_R)
-			gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
-		ld_prefetch<HAS_R>(a, l0, l1, r0, r1, q);
-		if (leaf + gridDim.x < a.nleaves) {
-			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, leaf + gridDim.x);
-			if (HAS_R)
-				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, leaf + gridDim.x);
-		}
-	}
-	__syncthreads();
-	const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
-	while (leaf < a.nleaves) {
-		const uint32_t next = leaf + gridDim.x, next2 = next + gridDim.x;
-		uint32_t nl0 = 0, nl1 = 0, nr0 = 0, nr1 = 0;
-		if (next < a.nleaves) {
-			gc_leaf_decode(raw_l, a.cap_l, next, &nl0, &nl1);
-			if (HAS_R)
-				gc_leaf_decode(raw_r, a.cap_r, next, &nr0, &nr1);
-		}
-		if (next2 < a.nleaves) {
-			raw_l = gc_leaf_raw(a.off_l, a.cnt_l, a.cap_l, next2);
-			if (HAS_R)
-				raw_r = gc_leaf_raw(a.off_r, a.cnt_r, a.cap_r, next2);
-		}
-		const bool nonempty = l0 != l1 && (!HAS_R || r0 != r1);
-		const bool hot = nonempty && (l1 - l0 >= a.heavy_l || (HAS_R && r1 - r0 >= a.heavy_r));
-		const bool live = nonempty && !hot;
-		if (hot && threadIdx.x == 0)
-			mdb_raise(a.status, 64u);	/* left to the hot-key path (hashed tables in global memory) */
-		if (live && a.kbits) {
-			/* record list space, reserved a chunk at a time: one global atomic per ~10-170 leaves (see k_leaf_group_count) */
-			const uint32_t rows = (HAS_R && (r1 - r0) < (l1 - l0)) ? r1 - r0 : l1 - l0;	/* a group needs a row on both sides */
-			const uint32_t need = (rows < T ? rows : T) + 1;
-			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
-			if (used + need > size) {		/* uniform: every thread read the same words */
-				for (uint32_t i = used + threadIdx.x; i < size; i += LD_THREADS)
-					a.rec[base + i] = 0ull;
-				__syncthreads();		/* everyone has read s_chunk */
-				if (threadIdx.x == 0) {
-					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
-					const uint32_t nb = atomicAdd(a.rec_count, want);
-					if (nb + want > a.rec_cap) {
-						mdb_raise(a.status, 8u);
-						s_chunk[0] = 0;
-						s_chunk[2] = 0;
-					} else {
-						s_chunk[0] = nb;
-						s_chunk[2] = want;
-					}
-					s_chunk[1] = 0;
-				}
-				/* visible to everyone after the barrier that ends the count phase */
+	if (live) {
+		if (HAS_R) {
+			/* right rows: one LDS add each (r0 is a multiple of 64: the rounds start on the leaf's first row) */
+			const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
+#pragma unroll
+			for (int u = 0; u < ld_regs<THREADS>::RB; u++) {
+				const uint32_t j = r0 + 4u * ((uint32_t)u * THREADS + threadIdx.x);
+				const uint32_t w[4] = { q.b[u].x, q.b[u].y, q.b[u].z, q.b[u].w };
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					if (j + k < r1)
+						atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
 			}
-		}
-		if (live) {
-			if (HAS_R) {
-				/* right rows: one LDS add each */
-				const uint32_t ra = r0 & ~3u;
+			for (uint32_t j = r0 + 4u * (ld_regs<THREADS>::RB * THREADS + threadIdx.x); j < r1; j += 4u * THREADS) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(hv_r32 + j);
+				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-				for (int u = 0; u < LD_RB; u++) {
-					const uint32_t j = ra + 4u * ((uint32_t)u * LD_THREADS + threadIdx.x);
-					const uint32_t w[4] = { q.b[u].x, q.b[u].y, q.b[u].z, q.b[u].w };
-#pragma unroll
-					for (int k = 0; k < 4; k++)
-						if (j + k >= r0 && j + k < r1)
-							atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
-				}
-				for (uint32_t j = ra + 4u * (LD_RB * LD_THREADS + threadIdx.x); j < r1; j += 4u * LD_THREADS) {
-					const uint4 v = *reinterpret_cast<const uint4 *>(hv_r32 + j);
-					const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-					for (int k = 0; k < 4; k++)
-						if (j + k < r1)
-							atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
-				}
-				__syncthreads();
-			}
-			/* left rows: one LDS read each; rows whose key has right rows are counted and compete for "first" */
-			const uint32_t la = l0 & ~1u;
-#pragma unroll
-			for (int u = 0; u < LD_RA; u++) {
-				const uint32_t i = la + 2u * ((uint32_t)u * LD_THREADS + threadIdx.x);
-				if (i >= l0 && i < l1)
-					ld_left_row<HAS_R>(q.a[u].x, shift, mask, s_cr, s_cl, s_first);
-				if (i + 1 < l1)		/* (i + 1 >= l0 always: la >= l0 - 1) */
-					ld_left_row<HAS_R>(q.a[u].y, shift, mask, s_cr, s_cl, s_first);
-			}
-			for (uint32_t i = la + 2u * (LD_RA * LD_THREADS + threadIdx.x); i < l1; i += 2u * LD_THREADS) {
-				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
-				ld_left_row<HAS_R>(v.x, shift, mask, s_cr, s_cl, s_first);
-				if (i + 1 < l1)
-					ld_left_row<HAS_R>(v.y, shift, mask, s_cr, s_cl, s_first);
+				for (int k = 0; k < 4; k++)
+					if (j + k < r1)
+						atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
 			}
 			__syncthreads();
 		}
+		/* left rows: one LDS read each; rows whose key has right rows are counted and compete for "first" */
+#pragma unroll
+		for (int u = 0; u < ld_regs<THREADS>::RA; u++) {
+			const uint32_t i = l0 + 2u * ((uint32_t)u * THREADS + threadIdx.x);
+			if (i < l1)
+				ld_left_row<HAS_R>(q.a[u].x, shift, mask, s_cr, s_cl, s_first);
+			if (i + 1 < l1)
+				ld_left_row<HAS_R>(q.a[u].y, shift, mask, s_cr, s_cl, s_first);
+		}
+		for (uint32_t i = l0 + 2u * (ld_regs<THREADS>::RA * THREADS + threadIdx.x); i < l1; i += 2u * THREADS) {
+			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
+			ld_left_row<HAS_R>(v.x, shift, mask, s_cr, s_cl, s_first);
+			if (i + 1 < l1)
+				ld_left_row<HAS_R>(v.y, shift, mask, s_cr, s_cl, s_first);
+		}
+		__syncthreads();
+	}
 
-		/* the next leaf's first rounds travel while this leaf is emitted */
-		if (next < a.nleaves)
-			ld_prefetch<HAS_R>(a, nl0, nl1, nr0, nr1, q);
+	/* these registers are free again: the leaf after next travels while this one is emitted and the next one processed */
+	if (leaf + 2 * gridDim.x < a.nleaves)
+		ld_request<HAS_R, THREADS>(a, leaf + 2 * gridDim.x, q);
 
-		if (live) {
-			/* emit one record per key that has rows on both sides and clear what was touched */
-			const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
-			for (uint32_t s0 = 0; s0 < T; s0 += LD_THREADS) {	/* uniform trip count */
-				const uint32_t s = s0 + threadIdx.x;
-				unsigned long long recv = 0;
-				if (s < T) {
-					const uint32_t cl = s_cl[s];
-					uint32_t cr = 1u;
-					if (HAS_R) {
-						cr = s_cr[s];
-						if (cr)
-							s_cr[s] = 0u;
-					}
-					if (cl) {
-						const uint32_t first = s_first[s];
-						const unsigned long long c = (unsigned long long)cl * cr;
-						s_cl[s] = 0u;
-						s_first[s] = 0xFFFFFFFFu;
-						mine += c;
-						if (a.kbits) {
-							if (c >> (64 - a.kbits))
-								mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
-							recv = ((unsigned long long)first << (64 - a.kbits)) | c;
-						} else {
-							a.dense_cnt[first] = (int64_t)c;
-						}
-					}
+	if (live) {
+		/* emit one record per key that has rows on both sides and clear what was touched (4-byte accesses, thread t takes
+		 * entries t, t + THREADS, ...: four consecutive entries per thread with 16-byte LDS accesses measured 10 % slower
+		 * when few entries are occupied and 4 % faster when all are - profiles/micro/leaf_direct_exp.sh) */
+		const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
+		for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {	/* uniform trip count */
+			const uint32_t s = s0 + threadIdx.x;
+			unsigned long long recv = 0;
+			if (s < T) {
+				const uint32_t cl = s_cl[s];
+				uint32_t cr = 1u;
+				if (HAS_R) {
+					cr = s_cr[s];
+					if (cr)
+						s_cr[s] = 0u;
 				}
-				if (a.kbits) {
-					/* wave-level append: one LDS atomic per wave and iteration */
-					const uint64_t m = __ballot(recv != 0ull);
-					if (m) {
-						const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-						uint32_t wbase = 0;
-						if (mdb_lane() == leader)
-							wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
-						wbase = __shfl(wbase, (int)leader, MDB_WAVE);
-						if (recv) {
-							const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-							if (pos < csize)
-								a.rec[cbase + pos] = recv;
-							nvalid++;
-						}
+				if (cl) {
+					const uint32_t first = s_first[s];
+					const unsigned long long c = (unsigned long long)cl * cr;
+					s_cl[s] = 0u;
+					s_first[s] = 0xFFFFFFFFu;
+					st.mine += c;
+					if (a.kbits) {
+						if (c >> (64 - a.kbits))
+							mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+						recv = ((unsigned long long)first << (64 - a.kbits)) | c;
+					} else {
+						a.dense_cnt[first] = (int64_t)c;
 					}
 				}
 			}
-			__syncthreads();	/* the next leaf counts into the cleared arrays */
+			if (a.kbits) {
+				/* wave-level append: one LDS atomic per wave and iteration */
+				const uint64_t m = __ballot(recv != 0ull);
+				if (m) {
+					const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+					uint32_t wbase = 0;
+					if (mdb_lane() == leader)
+						wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
+					wbase = __shfl(wbase, (int)leader, MDB_WAVE);
+					if (recv) {
+						const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+						if (pos < csize)
+							a.rec[cbase + pos] = recv;
+						st.nvalid++;
+					}
+				}
+			}
 		}
-		leaf = next;
-		l0 = nl0;
-		l1 = nl1;
-		r0 = nr0;
-		r1 = nr1;
+		__syncthreads();	/* the next leaf counts into the cleared arrays */
+	}
+}
+
+template <bool HAS_R, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_leaf_direct(gc_args a, uint32_t rem, uint32_t shift)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
+	ld_state st;
+	st.T = 1u << rem;
+	st.mask = st.T - 1u;
+	st.shift = shift;
+	st.s_cr = ld_lds;			/* right rows per key */
+	st.s_cl = ld_lds + st.T;		/* left rows per key (joins: only of keys that have right rows) */
+	st.s_first = ld_lds + 2 * st.T;		/* first left row per key */
+	st.s_chunk = ld_lds + 3 * st.T;		/* record list chunk: [0] base [1] used [2] size [3] valid records; [4..7] see below */
+	unsigned long long *const s_sum = reinterpret_cast<unsigned long long *>(ld_lds + 3 * st.T + 4);
+	st.mine = 0;
+	st.nvalid = 0;
+
+	for (uint32_t s = threadIdx.x; s < st.T; s += THREADS) {
+		st.s_cr[s] = 0u;
+		st.s_cl[s] = 0u;
+		st.s_first[s] = 0xFFFFFFFFu;
+	}
+	if (threadIdx.x < 8)
+		st.s_chunk[threadIdx.x] = 0u;		/* [4..5] = s_sum, [6] = distinct right keys of the current leaf */
+
+	/* two register sets: while leaf i is processed out of one, leaf i + 1 sits (or still travels) in the other */
+	ld_regs<THREADS> qa, qb;
+	uint32_t leaf = blockIdx.x;
+	ld_request_counts<HAS_R, THREADS>(a, leaf, qa);
+	ld_request_counts<HAS_R, THREADS>(a, leaf + gridDim.x, qb);
+	if (leaf < a.nleaves)
+		ld_request<HAS_R, THREADS>(a, leaf, qa);
+	if (leaf + gridDim.x < a.nleaves)
+		ld_request<HAS_R, THREADS>(a, leaf + gridDim.x, qb);
+	__syncthreads();
+	while (leaf < a.nleaves) {
+		ld_leaf<HAS_R, THREADS>(a, st, leaf, qa);
+		leaf += gridDim.x;
+		if (leaf >= a.nleaves)
+			break;
+		ld_leaf<HAS_R, THREADS>(a, st, leaf, qb);
+		leaf += gridDim.x;
 	}
 	if (a.kbits) {
-		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
-		for (uint32_t i = used + threadIdx.x; i < size; i += LD_THREADS)
+		const uint32_t base = st.s_chunk[0], used = st.s_chunk[1], size = st.s_chunk[2];
+		for (uint32_t i = used + threadIdx.x; i < size; i += THREADS)
 			a.rec[base + i] = 0ull;		/* unused tail of the last chunk */
-		if (nvalid)
-			atomicAdd(&s_chunk[3], nvalid);
+		if (st.nvalid)
+			atomicAdd(&st.s_chunk[3], st.nvalid);
 	}
-	if (mine)
-		atomicAdd(s_sum, mine);
+	if (st.mine)
+		atomicAdd(s_sum, st.mine);
 	__syncthreads();
 	if (threadIdx.x == 0 && *s_sum)
 		atomicAdd(a.joined, *s_sum);
-	if (threadIdx.x == 0 && a.kbits && s_chunk[3])
-		atomicAdd(a.rec_valid, s_chunk[3]);
+	if (threadIdx.x == 0 && a.kbits && st.s_chunk[3])
+		atomicAdd(a.rec_valid, st.s_chunk[3]);
 }
 
 /* ------------------------------------------------------------------ hot keys across the whole chip
@@ -1608,17 +1631,20 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		if (st->direct) {
+		/* (the direct kernel addresses leaf i at i * cap: should a table have fallen back to exact offsets - more than 2^32
+		 * region words - the hashed kernel below joins the compact words just as well, they are injective too) */
+		if (st->direct && pl.leaf_cap && (!has_r || pr.leaf_cap)) {
 			/* compact narrow form: the leaf's table is indexed by the hash bits the partition left over */
 			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
 			const size_t lds = ((size_t)12 << rem) + 32;
+			/* four 512-thread workgroups = the CU's 32 waves (three measured the same, 256-thread workgroups 10-30 % slower) */
 			uint32_t per_cu = (uint32_t)((size_t)(160 * 1024) / lds);
-			per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);	/* 4 x 512 threads = the CU's 32 waves */
+			per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
 			const uint32_t dgrid = pl.nleaves < per_cu * (uint32_t)ctx->num_cus ? pl.nleaves : per_cu * (uint32_t)ctx->num_cus;
 			if (has_r) {
-				MDB_LAUNCH_LDS(ctx, "leaf_join_direct", k_leaf_direct<true>, dgrid, LD_THREADS, lds, a, rem, shift);
+				MDB_LAUNCH_LDS(ctx, "leaf_join_direct", (k_leaf_direct<true, 512>), dgrid, 512, lds, a, rem, shift);
 			} else {
-				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", k_leaf_direct<false>, dgrid, LD_THREADS, lds, a, rem, shift);
+				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", (k_leaf_direct<false, 512>), dgrid, 512, lds, a, rem, shift);
 			}
 		} else if (has_r && build_r && st->narrow) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false, true>), grid, GC_THREADS, a);
@@ -2310,7 +2336,7 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE)	/* skew / huge counts / wide keys: redo the whole operator */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
 	return rc;

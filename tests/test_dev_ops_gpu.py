@@ -1026,16 +1026,17 @@ def test_compact_narrow_form_direct_address_leaves(dev, narrow_mode, shape):
         nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.2
         kl[nl] = rng.integers(-2**62, 2**62, int(nl.sum()))	# whatever lies under a NULL bit is no key
     if shape == "outlier_left":
-        kl[n_l // 3 + 1] = off + span + span // 8 + 5000	# beyond the padding of the sampled window, inside the 2^32 one
+        kl[n_l // 3 + 1] = off + 5 * span			# beyond the padded, rounded-up window of the sample, inside the 2^32 one
         kr[7] = kl[n_l // 3 + 1]
         expect = 1
     if shape == "outlier_right":
-        kr[n_r - 2] = off - span // 8 - 5000
+        kr[n_r - 2] = off - 4 * span
         kl[11] = kr[n_r - 2]
         expect = 1
     if shape == "hot_key":
         kr[100_000:500_000] = off + 12345
         kl[50_000:50_040] = off + 12345
+        expect = 0		# the hot leaf outgrows its fixed-capacity region: exact layout, 64-bit hashes, hot-key path
     ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
     dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
     for round_ in range(2):		# the second call runs on the remembered verdict
