@@ -65,7 +65,9 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);
 /* digits0_used: how many of the 2^bits1 first-level digits can occur at all (0 = every one) - sizes the fast regions */
 size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used);
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
-		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap = true);	/* zero words are gaps of a chunked list */
+		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap = true,	/* zero words are gaps of a chunked list */
+		      bool fold32 = false);	/* the first level folds every 8-byte word w into the 4-byte word (w >> 32) | (uint32_t)w - the caller knows
+					 * that the two parts share no bit - and everything after it moves 4-byte words (out->w32; two fast levels only) */
 
 /* one stable least-significant-digit radix pass over (key, row id) pairs: digit = (key >> shift) & (2^bits - 1),
  * bits <= 8.  hist = scratch of mdb_sort_pass_hist_words(n) uint32, scan_tmp = mdb_scan_scratch_words(of that). */

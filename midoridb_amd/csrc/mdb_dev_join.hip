@@ -676,6 +676,8 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 							if (a.kbits) {
 								if (c >> (64 - a.kbits))
 									mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+								if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
+									mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record */
 								recv = ((unsigned long long)first << (64 - a.kbits)) | c;
 							} else {
 								a.dense_cnt[first] = (int64_t)c;
@@ -926,6 +928,8 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 					if (a.kbits) {
 						if (c >> (64 - a.kbits))
 							mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+						if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
+							mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record (the ordering sort then moves 8-byte ones) */
 						recv = ((unsigned long long)first << (64 - a.kbits)) | c;
 					} else {
 						a.dense_cnt[first] = (int64_t)c;
@@ -955,7 +959,7 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 }
 
 template <bool HAS_R, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_leaf_direct(gc_args a, uint32_t rem, uint32_t shift)
+__global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* four workgroups per CU: at most 64 registers */(gc_args a, uint32_t rem, uint32_t shift)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
 	ld_state st;
@@ -1176,6 +1180,8 @@ __global__ __launch_bounds__(1024) void k_hot_finish(gc_args a, hot_args h)
 		if (a.kbits) {
 			if (c >> (64 - a.kbits))
 				mdb_raise(a.status, 4u);
+			if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
+				mdb_raise(a.status, 16u);
 			const uint32_t pos = atomicAdd(a.rec_count, 1u);
 			if (pos < a.rec_cap)
 				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
@@ -1240,6 +1246,8 @@ __global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long lo
 	if (threadIdx.x == 0 && blockIdx.x == 0 && cnt_first[0]) {
 		if (cnt_first[0] >> (64 - kbits))
 			atomicOr(status, 4u);
+		if (cnt_first[0] >> (32 - (kbits < 32 ? kbits : 31)))
+			atomicOr(status, 16u);
 		const uint32_t pos = atomicAdd(rec_count, 1u);
 		if (pos < rec_cap) {
 			rec[pos] = (cnt_first[1] << (64 - kbits)) | cnt_first[0];
@@ -1277,6 +1285,7 @@ struct ord_args {
 	const int64_t *keys;		/* optional: key column to gather the group keys from ... */
 	int64_t *out_key;		/* ... into here (keys[first]) */
 	uint32_t keys32;		/* `keys` is an int32 column */
+	uint32_t rec32;			/* the records are 4-byte words: (row id << (32 - kbits)) | payload */
 };
 
 __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
@@ -1305,9 +1314,18 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 	for (int k = 0; k < ORD_PER_THREAD; k++)
 		s_slot[threadIdx.x + (uint32_t)k * ORD_THREADS] = 0ull;
 	__syncthreads();
-	for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
-		const unsigned long long r = a.rec[i];
-		s_slot[(uint32_t)(r >> (64 - a.kbits)) & (range - 1)] = r & cmask;	/* COUNT(*) >= 1 marks the slot */
+	if (a.rec32) {
+		const uint32_t *const rec = reinterpret_cast<const uint32_t *>(a.rec);
+		const uint32_t cm32 = (1u << (32 - a.kbits)) - 1u;
+		for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
+			const uint32_t r = rec[i];
+			s_slot[(r >> (32 - a.kbits)) & (range - 1)] = r & cm32;
+		}
+	} else {
+		for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
+			const unsigned long long r = a.rec[i];
+			s_slot[(uint32_t)(r >> (64 - a.kbits)) & (range - 1)] = r & cmask;	/* COUNT(*) >= 1 marks the slot */
+		}
 	}
 	__syncthreads();
 	unsigned long long c[ORD_PER_THREAD];
@@ -1372,17 +1390,20 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
 /* Order a record list ((row id << (64 - kbits)) | payload, zero words = gaps) by row id and deliver it:
  * histogram-free regions first; if one overflows (the gaps of the list can bunch the records of one XCD's tile
  * range) the exact layout redoes the sort.  Synchronises. */
+/* rec32: every payload is below 2^(32 - kbits) - the sort's first level then folds the records into 4-byte words and
+ * everything after it moves half the bytes (10^8 groups of one row each: 1.3 -> 0.9 ms for the ordering) */
 static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
 			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,
-			 bool keys32 = false)
+			 bool keys32 = false, bool rec32 = false)
 {
+	rec32 = rec32 && sb2 > 0 && kbits < 32;
 	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
 	uint64_t *h = ctx->h_pinned;
 	int rc;
 	for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
 		mdb_part_result ps;
 		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0, order_digits0(n_l, kbits, sb1),
-				       &ps);
+				       &ps, true, rec32 && sort_fast != 0);
 		if (rc)
 			return rc;
 		ord_args oa;
@@ -1399,6 +1420,7 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 		oa.keys = keys;
 		oa.out_key = out_key;
 		oa.keys32 = keys32 ? 1u : 0u;
+		oa.rec32 = ps.w32 ? 1u : 0u;
 		if (ps.leaf_cap) {
 			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
 			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
@@ -1752,7 +1774,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32);
+		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32,
+				   !(status & 16u));
 		if (rc)
 			return rc;
 	} else if (G) {

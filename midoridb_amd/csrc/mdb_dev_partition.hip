@@ -85,6 +85,8 @@ struct mdb_level_args {
 	uint32_t narrow_kbits;		/* compact narrow form: every key must lie in [narrow_base, narrow_base + 2^narrow_kbits); the 32-bit
 					 * hash is mixk(key - narrow_base) in the TOP narrow_kbits bits of the field, zeros below */
 	uint32_t keys32;		/* level 0: `keys` is an array of int32 (keys that crossed xGMI in the 4-byte wire format) */
+	uint32_t fold64;		/* raw 4-byte words: the input is still the list of 8-byte records, folded on the fly (record >> 32 | low
+					 * half: the caller knows that the two parts do not overlap) */
 };
 
 /* level-0 word of one key */
@@ -242,12 +244,17 @@ __device__ static inline void part_load4_w32(const mdb_level_args &a, const mdb_
 		hv[2] = q.z;
 		hv[3] = q.w;
 		valid[0] = valid[1] = valid[2] = valid[3] = true;
-		return;
-	}
+	} else {
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		valid[k] = e0 + k >= lead && e0 + k < end;
-		hv[k] = valid[k] ? src[k] : 0u;
+		for (int k = 0; k < 4; k++) {
+			valid[k] = e0 + k >= lead && e0 + k < end;
+			hv[k] = valid[k] ? src[k] : 0u;
+		}
+	}
+	if (a.skip_zero) {
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			valid[k] = valid[k] && hv[k] != 0u;
 	}
 }
 
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	static_assert(!INV || (LEVEL0 && !STABLE && !FAST && !RAW && !W32), "INV: unordered exact level-0 form only");
 	/* W32: the words staged and written are 4-byte hashes (narrow form, right side: level 0 reads 8-byte keys and
 	 * writes 4-byte words, level 1 reads and writes 4-byte words); never with row ids */
-	static_assert(!W32 || (!HAS_RID && !STABLE && FAST && !RAW), "4-byte words: unordered FAST form without row ids only");
+	static_assert(!W32 || (!HAS_RID && !STABLE && FAST && !(LEVEL0 && RAW)), "4-byte words: unordered FAST form without row ids only");
 	typedef typename std::conditional<W32, uint32_t, uint64_t>::type W;
 	/* Row ids are staged through the SAME LDS as the hashes, after the hashes have been written out (unordered
 	 * form only): 35 KiB instead of 51 KiB per workgroup = 4 instead of 3 workgroups per CU, worth ~25 % of the
@@ -342,6 +349,19 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 				valid = part_load<LEVEL0>(a, td, i, &h, &rid[r]);
 			hv[r] = (W)h;
 			dig[r] = valid ? part_digit(a, hv[r]) : PART_INVALID;
+		}
+	} else if (W32 && RAW && a.fold64) {
+		/* group records on their way into the 4-byte ordering sort: 8-byte words in, folded */
+#pragma unroll
+		for (int r = 0; r < PART_ITEMS / 2; r++) {
+			bool valid[2];
+			uint64_t h2[2];
+			part_load2<false, false, true>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				hv[2 * r + k] = (W)((uint32_t)(h2[k] >> 32) | (uint32_t)h2[k]);
+				dig[2 * r + k] = valid[k] ? part_digit(a, hv[2 * r + k]) : PART_INVALID;
+			}
 		}
 	} else if (W32 && !LEVEL0) {
 #pragma unroll
@@ -699,6 +719,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NARROW_RID 8u	/* narrow form with the row id in the low half of the word (narrow = 1; no row-id arrays) */
 #define PART_F_KEYS32 16u	/* the key column is int32 */
 #define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
+#define PART_F_FOLD32 64u	/* raw 8-byte records are folded into 4-byte words by the first level (two-level fast layout only) */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
@@ -733,9 +754,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0_used * cap0 < 0xFFFFFFFFull;
 	/* narrow form without row ids (right side of a join): 4-byte words from the first level's output on; only built for
 	 * the histogram-free layout of both levels (callers ask mdb_partition_w32_applies() first) */
-	const bool w32 = (flags & PART_F_NARROW) && fast0 && fast;
-	if ((flags & PART_F_NARROW) && !w32 && !dry)
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "narrow partitioning without row ids needs the two-level fast layout");
+	const bool fold32 = (flags & PART_F_FOLD32) && raw_hv && fast0 && fast;
+	const bool w32 = ((flags & PART_F_NARROW) && fast0 && fast) || fold32;
+	if ((flags & (PART_F_NARROW | PART_F_FOLD32)) && !w32 && !dry)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4-byte partition words need the two-level fast layout");
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
@@ -774,6 +796,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.n = n;
 		a.hv_in = l ? hv_buf[l - 1] : raw_hv;	/* raw_hv: level 0 reads ready-made 64-bit sort keys */
 		a.skip_zero = (l == 0 && raw_hv && !(flags & PART_F_NO_GAPS)) ? 1u : 0u;
+		a.fold64 = (fold32 && l == 0) ? 1u : 0u;
 		a.rid_in = l ? rid_buf[l - 1] : NULL;
 		a.tiles = tiles;
 		a.hv_out = hv_buf[l];
@@ -813,7 +836,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.nsub = PART_NSUB;
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
-				if (raw_hv) {
+				if (raw_hv && fold32) {
+					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<false, false, false, true, true, true>), grid8(ntiles), PART_THREADS, a);
+				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
@@ -846,6 +871,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				MDB_HIP(ctx, hipMemsetAsync(leaf_cnt, 0, (size_t)nchild * 4, ctx->stream));
 				if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l1_rid", (k_part_scatter<false, true, false, true>), grid8(ntiles),
+						   PART_THREADS, a);
+				} else if (raw_hv && fold32) {
+					MDB_LAUNCH(ctx, "sort_scatter_l1_w32", (k_part_scatter<false, false, false, true, true, true>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true, true>), grid8(ntiles),
@@ -991,11 +1019,14 @@ size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t 
 }
 
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
-		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap)
+		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap, bool fold32)
 {
 	part_carver cv = { ctx, false, 0, false };
-	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false, (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS),
-			      MDB_DIGIT_RADIX, 0, false, NULL, hv, leaf_cap, out, NULL, digits0_used);
+	if (fold32 && (!fast || bits2 <= 0 || !zero_is_gap))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "folded raw words need the two-level fast layout");
+	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false,
+			      (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS) | (fold32 ? PART_F_FOLD32 : 0u), MDB_DIGIT_RADIX, 0,
+			      false, NULL, hv, leaf_cap, out, NULL, digits0_used);
 }
 
 /* ---- one stable LSD radix pass (ORDER BY) --------------------------------------------------------
