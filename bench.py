@@ -117,7 +117,6 @@ def parse_args():
                     help="skip everything but the primary measurement and the per-kernel profile (profiling runs)")
     ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
                     "column statistics allow it)")
-    ap.add_argument("--chunks", type=int, default=None, help="pieces per table in the multi-GPU exchange (default 1)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -299,14 +298,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from midoridb_amd.dev import DeviceCtx
-    from midoridb_amd import shuffle
+    from midoridb_amd.dist import DistCtx, WIRE_32, WIRE_64
 
     t_ctx = time.perf_counter()
     dev = DeviceCtx(local_rank)
+    dx = None
     if use_dist:
-        one = torch.ones(1, dtype=torch.float64, device=dev.device)
-        dist.all_reduce(one, op=dist.ReduceOp.SUM)
-        ranks_seen = int(one.item())	# ranks that took part in a collective of the RCCL communicator
+        # the exchange itself runs behind the C-ABI (include/mdb_dist.h: RCCL communicators created in C from an id that
+        # travels through the launcher's process group); torch.distributed only provides the barrier and the reductions
+        # of the timing contract
+        dx = DistCtx.from_torch(dev)
+        ranks_seen = dx.allreduce_sum([1])[0]	# ranks that took part in a collective of the library's RCCL communicator
 
     def make_tables(n_rank):
         """rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)"""
@@ -344,13 +346,16 @@ def main():
         a, b, total, mod = make_tables(n_rank)
         out = make_out(n_rank)
         w32 = wire_format(a, b)
-        pipe = shuffle.DistributedJoinGroupCount(dev, world, rank, n_rank, chunks=args.chunks, wire32=w32) if use_dist else None
+        pipe = dx
+        if dx is not None:
+            dx.set_wire(WIRE_32 if w32 else WIRE_64)
 
         def step():
             if pipe is None:
                 k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
                 return k.numel(), j
-            return pipe.run(a, b, out)
+            k, c, j = pipe.join_group_count(a, None, b, None, out=out)
+            return k.numel(), j
 
         if cold is not None:
             torch.cuda.synchronize()
@@ -464,7 +469,8 @@ def main():
                                     "direct-address leaf tables)"][dev.last_join_form()],
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
-                       "parallelism": f"hash-partition x{world}" + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
+                       "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
+                                      + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
                                       + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else ""),
                        "rccl_ranks_seen": ranks_seen if use_dist else None},
             "roofline": roof,
@@ -552,8 +558,7 @@ def main():
                 k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
                 ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))
             else:   # shuffled pipeline: same groups, order is not the reference's
-                _, jj = pipeline.run(a, b, out)
-                k, c, _ = pipeline.last
+                k, c, jj = pipeline.join_group_count(a, None, b, None, out=out)
                 o1, o2 = np.argsort(k.cpu().numpy(), kind="stable"), np.argsort(ek, kind="stable")
                 ok = (jj == ej and np.array_equal(k.cpu().numpy()[o1], ek[o2]) and np.array_equal(c.cpu().numpy()[o1], ec[o2]))
             line["verified_vs_oracle"] = bool(ok)
@@ -561,6 +566,7 @@ def main():
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
+        dx.close()
         dist.destroy_process_group()
     os.close(json_fd)
 

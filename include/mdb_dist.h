@@ -1,0 +1,113 @@
+/*
+ * mdb_dist.h - C-ABI of the multi-GPU form of the join / GROUP BY path: one process per GPU, the two key
+ * columns hash-partitioned by destination GPU, exchanged with one uneven all-to-all per table over xGMI
+ * (RCCL), joined locally.  Groups are disjoint across ranks - both tables are partitioned by
+ * the join key - so no reduction or gather is on the data path.
+ *
+ * What it replaces: nothing upstream is distributed; the reference's one entry point is query_execute()
+ * (reference src/engine/query.c:35-106) over the nested-loop join of src/engine/executor_select.c:1076-1149.
+ * This is how that same entry point shards: a host process per GPU opens its database, loads ITS rows of
+ * every table, and - with MIDORIDB_WORLD_SIZE / MIDORIDB_RANK / MIDORIDB_DIST_ID_FILE in the environment -
+ * query_execute() of the north-star shape (JOIN ... ON l = r [JOIN ...] GROUP BY that key, COUNT(*)) runs
+ * through mdb_dist_join_group_count(): every rank returns the groups whose keys hash to it, SELECT COUNT(*)
+ * over such a join returns the global count on every rank.  Hosts that manage their own buffers call the
+ * functions below directly (bench.py does, through ctypes).
+ *
+ * Plain pointers and sizes only.  Every function returns MIDORIDB_OK (0) or a negative code; the text of
+ * the last error is mdb_dist_last_error().  All "dptr" arguments are device pointers on the context's GPU.
+ */
+#ifndef MDB_DIST_H
+#define MDB_DIST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "mdb_dev.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdb_dist mdb_dist;
+
+#define MDB_DIST_ID_BYTES 128		/* = NCCL_UNIQUE_ID_BYTES */
+
+/* ------------------------------------------------------------------ rendezvous
+ * Rank 0 creates the communicator id, the host program ships the 128 bytes to the other ranks however it
+ * likes (MPI, a socket, a file, the launcher's store) and every rank calls mdb_dist_init() with it. */
+int mdb_dist_unique_id(void *id_out /* MDB_DIST_ID_BYTES */);
+/* The same through a file every rank can see: rank 0 writes the id (atomically: temp file + rename), the
+ * others wait up to timeout_s seconds for it.  The file is left in place; remove it between runs. */
+int mdb_dist_id_via_file(const char *path, int rank, double timeout_s, void *id_out);
+
+/* One communicator pair (key transfers; the tiny count exchanges have their own, so that they never queue
+ * behind a transfer in flight) over RCCL, for the GPU of `ctx`.  Collective: every rank calls it. */
+int mdb_dist_init(mdb_dev_ctx *ctx, int world, int rank, const void *id, mdb_dist **out);
+void mdb_dist_destroy(mdb_dist *d);
+int mdb_dist_world(const mdb_dist *d);
+int mdb_dist_rank(const mdb_dist *d);
+const char *mdb_dist_last_error(const mdb_dist *d);
+
+/* ------------------------------------------------------------------ transport plug-in
+ * The exchange needs three operations; RCCL provides them by default.  A host with its own fabric (MPI,
+ * a test harness that moves the bytes through host memory) passes them here instead of an id. */
+struct mdb_dist_transport {
+	void *self;
+	/* per peer `n` 64-bit counters: send[world * n] -> recv[world * n], HOST arrays, blocking */
+	int (*counts)(void *self, const uint64_t *send, uint64_t *recv, int n);
+	/* uneven all-to-all of DEVICE buffers, counts and displacements in elements of elem_bytes bytes, ordered on
+	 * `stream` (a hipStream_t): it may return before the bytes have moved, later work on `stream` sees them */
+	int (*alltoallv)(void *self, const void *d_send, const size_t *sendcounts, const size_t *sdispls, void *d_recv,
+			 const size_t *recvcounts, const size_t *rdispls, size_t elem_bytes, void *stream);
+	/* vals[n] (HOST) summed over the ranks, in place, blocking */
+	int (*allreduce_sum_u64)(void *self, uint64_t *vals, int n);
+	void (*destroy)(void *self);
+};
+int mdb_dist_init_transport(mdb_dev_ctx *ctx, int world, int rank, const struct mdb_dist_transport *t, mdb_dist **out);
+
+/* ------------------------------------------------------------------ options */
+enum mdb_dist_wire {
+	MDB_WIRE_AUTO = 0,	/* per call: 4-byte keys when the column statistics of BOTH tables on EVERY rank fit 32 bits
+				 * (mdb_dev_key_range + one tiny all-reduce; two extra read passes per call) */
+	MDB_WIRE_64 = 1,	/* always 8-byte keys */
+	MDB_WIRE_32 = 2,	/* the caller knows (catalog statistics) that every key fits 32 bits; a key that does not is
+				 * reported as an error by the partition kernel, never truncated */
+};
+int mdb_dist_set_wire(mdb_dist *d, int mode);
+/* 1 when the last exchange shipped 4-byte keys */
+int mdb_dist_last_wire32(const mdb_dist *d);
+
+/* ------------------------------------------------------------------ the sharded north-star operator
+ *
+ * SELECT l.key, COUNT(*) FROM L INNER JOIN R ON l.key = r.key GROUP BY l.key over tables whose rows are spread
+ * over the ranks in any way: keys_l / keys_r are THIS rank's rows.  Per table: partition by destination
+ * (mdb_dev_partition_by_dest: dest = hash(key) mod world, NULL keys dropped - a NULL key never joins,
+ * reference executor_select.c:557-579), counts exchange, uneven all-to-all; table L's transfer overlaps table
+ * R's partitioning, table R's the local hashing + radix partitioning of the received L
+ * (mdb_dev_join_group_count_begin / _finish).  out_key / out_count (capacity cap; the rows received for L are
+ * always enough): the groups whose key hashes to this rank, in order of first occurrence in the received
+ * stream.  *out_groups = their number, *out_joined = joined rows on this rank (sum of its counts).
+ * Collective and synchronous. */
+int mdb_dist_join_group_count(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			      const uint64_t *null_r, uint64_t n_r, int64_t *out_key, int64_t *out_count, uint64_t cap,
+			      uint64_t *out_groups, uint64_t *out_joined);
+/* The same with outputs allocated by the call, once the number of received left rows is known (*out_key, *out_count
+ * and, when out_first != NULL, *out_first: device buffers to release with mdb_dev_free; out_first[g] = position of the
+ * group's first row in the left stream the local join saw).  MDB_DIST_LEFT_IN_PLACE: the left rows are already on the
+ * rank their keys hash to - the groups a previous call returned - so only the right table is exchanged and out_first
+ * indexes keys_l itself: this is how query_execute() chains the operator over further tables joined on the same key
+ * (reference shape: A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a). */
+#define MDB_DIST_LEFT_IN_PLACE 1u
+int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				    const uint64_t *null_r, uint64_t n_r, uint32_t flags, int64_t **out_key, int64_t **out_count,
+				    uint32_t **out_first, uint64_t *out_groups, uint64_t *out_joined);
+/* rows of L this rank received in the last call (what `cap` has to cover), 0 before the first */
+uint64_t mdb_dist_last_received_left(const mdb_dist *d);
+
+/* helpers for hosts without a collective library of their own */
+int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n);
+int mdb_dist_barrier(mdb_dist *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDB_DIST_H */

@@ -1,0 +1,532 @@
+/*
+ * mdb_dist.hip - the multi-GPU exchange behind the C-ABI (include/mdb_dist.h): RCCL communicators, the
+ * per-table sequence  partition by destination -> counts -> uneven all-to-all,  and the sharded north-star
+ * operator built on the split form of the fused join + GROUP BY (mdb_dev_join.hip).  One process per GPU.
+ *
+ * xGMI is what bounds this step, not HBM: at 8 ranks 7/8 of every table leaves each GPU, one
+ * eighth per point-to-point link.  So the sequence keeps the links busy - table L's all-to-all runs while
+ * table R is partitioned by destination, table R's while the received L is hashed and radix-partitioned
+ * locally - and ships 4-byte keys whenever the column statistics allow it.  Transfers run on a stream of
+ * their own; the count exchanges on a communicator of their own.  The only host synchronisations are the ones
+ * the sizes force: the send counts come from the destination partition (exact layout: it ends with a
+ * read-back), the receive counts from the count exchange (128 bytes).
+ */
+#include <errno.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include <rccl/rccl.h>
+#include "mdb_dev_internal.h"
+#include "mdb_dist.h"
+
+struct mdb_dist {
+	mdb_dev_ctx *ctx;
+	int world, rank;
+	mdb_dist_transport t;
+	bool own_transport;		/* t.self is an rccl_transport created here */
+	hipStream_t comm_stream;	/* key transfers */
+	hipEvent_t ev_ready, ev_a, ev_b;
+	int wire_mode, last_wire32;
+	/* exchange buffers (grow-only): send = this rank's keys grouped by destination, recv = what arrived */
+	void *send[2], *recv[2];
+	uint64_t send_cap[2], recv_cap[2];	/* in 8-byte words */
+	uint64_t last_recv_left;
+	char err[512];
+};
+
+static int dist_err(mdb_dist *d, int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(d->err, sizeof(d->err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define DIST_HIP(d, call)                                                                              \
+	do {                                                                                           \
+		hipError_t e__ = (call);                                                               \
+		if (e__ != hipSuccess)                                                                 \
+			return dist_err((d), -MIDORIDB_INTERNAL, "%s failed: %s (%s:%d)", #call,          \
+					hipGetErrorString(e__), __FILE__, __LINE__);                   \
+	} while (0)
+
+/* ------------------------------------------------------------------ RCCL transport */
+
+struct rccl_transport {
+	ncclComm_t data, small;		/* key transfers / counts + reductions */
+	int world, rank, device;
+	hipStream_t small_stream;
+	uint64_t *d_buf, *h_buf;	/* 2 x world x 8 counters: device staging + pinned mirror */
+	char err[256];
+};
+
+#define RT_MAX_COUNTERS 8
+
+static int rt_fail(rccl_transport *rt, const char *what, ncclResult_t r)
+{
+	snprintf(rt->err, sizeof(rt->err), "%s: %s", what, ncclGetErrorString(r));
+	return -MIDORIDB_INTERNAL;
+}
+
+static int rt_counts(void *self, const uint64_t *send, uint64_t *recv, int n)
+{
+	rccl_transport *rt = (rccl_transport *)self;
+	if (n < 1 || n > RT_MAX_COUNTERS)
+		return -MIDORIDB_ERROR;
+	const size_t words = (size_t)rt->world * (size_t)n;
+	uint64_t *d_send = rt->d_buf, *d_recv = rt->d_buf + (size_t)rt->world * RT_MAX_COUNTERS;
+	uint64_t *h_send = rt->h_buf, *h_recv = rt->h_buf + (size_t)rt->world * RT_MAX_COUNTERS;
+	memcpy(h_send, send, words * 8);
+	if (hipMemcpyAsync(d_send, h_send, words * 8, hipMemcpyHostToDevice, rt->small_stream) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	ncclResult_t r = ncclAllToAll(d_send, d_recv, (size_t)n, ncclUint64, rt->small, rt->small_stream);
+	if (r != ncclSuccess)
+		return rt_fail(rt, "ncclAllToAll(counts)", r);
+	if (hipMemcpyAsync(h_recv, d_recv, words * 8, hipMemcpyDeviceToHost, rt->small_stream) != hipSuccess ||
+	    hipStreamSynchronize(rt->small_stream) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	memcpy(recv, h_recv, words * 8);
+	return MIDORIDB_OK;
+}
+
+static int rt_alltoallv(void *self, const void *d_send, const size_t *sendcounts, const size_t *sdispls, void *d_recv,
+			const size_t *recvcounts, const size_t *rdispls, size_t elem_bytes, void *stream)
+{
+	rccl_transport *rt = (rccl_transport *)self;
+	const ncclDataType_t ty = elem_bytes == 8 ? ncclUint64 : (elem_bytes == 4 ? ncclUint32 : ncclUint8);
+	if (elem_bytes != 8 && elem_bytes != 4 && elem_bytes != 1)
+		return -MIDORIDB_ERROR;
+	ncclResult_t r = ncclAllToAllv(d_send, sendcounts, sdispls, d_recv, recvcounts, rdispls, ty, rt->data, (hipStream_t)stream);
+	if (r != ncclSuccess)
+		return rt_fail(rt, "ncclAllToAllv", r);
+	return MIDORIDB_OK;
+}
+
+static int rt_allreduce(void *self, uint64_t *vals, int n)
+{
+	rccl_transport *rt = (rccl_transport *)self;
+	if (n < 1 || n > rt->world * RT_MAX_COUNTERS)
+		return -MIDORIDB_ERROR;
+	memcpy(rt->h_buf, vals, (size_t)n * 8);
+	if (hipMemcpyAsync(rt->d_buf, rt->h_buf, (size_t)n * 8, hipMemcpyHostToDevice, rt->small_stream) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	ncclResult_t r = ncclAllReduce(rt->d_buf, rt->d_buf, (size_t)n, ncclUint64, ncclSum, rt->small, rt->small_stream);
+	if (r != ncclSuccess)
+		return rt_fail(rt, "ncclAllReduce", r);
+	if (hipMemcpyAsync(rt->h_buf, rt->d_buf, (size_t)n * 8, hipMemcpyDeviceToHost, rt->small_stream) != hipSuccess ||
+	    hipStreamSynchronize(rt->small_stream) != hipSuccess)
+		return -MIDORIDB_INTERNAL;
+	memcpy(vals, rt->h_buf, (size_t)n * 8);
+	return MIDORIDB_OK;
+}
+
+static void rt_destroy(void *self)
+{
+	rccl_transport *rt = (rccl_transport *)self;
+	if (!rt)
+		return;
+	if (rt->data)
+		ncclCommDestroy(rt->data);
+	if (rt->small)
+		ncclCommDestroy(rt->small);
+	if (rt->small_stream)
+		(void)hipStreamDestroy(rt->small_stream);
+	if (rt->d_buf)
+		(void)hipFree(rt->d_buf);
+	if (rt->h_buf)
+		(void)hipHostFree(rt->h_buf);
+	free(rt);
+}
+
+extern "C" int mdb_dist_unique_id(void *id_out)
+{
+	ncclUniqueId id;
+	static_assert(sizeof(id) == MDB_DIST_ID_BYTES, "RCCL unique id size");
+	if (!id_out || ncclGetUniqueId(&id) != ncclSuccess)
+		return -MIDORIDB_INTERNAL;
+	memcpy(id_out, &id, sizeof(id));
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_id_via_file(const char *path, int rank, double timeout_s, void *id_out)
+{
+	if (!path || !id_out)
+		return -MIDORIDB_ERROR;
+	if (rank == 0) {
+		char tmp[4096];
+		int rc = mdb_dist_unique_id(id_out);
+		if (rc)
+			return rc;
+		if (snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid()) >= (int)sizeof(tmp))
+			return -MIDORIDB_ERROR;
+		FILE *f = fopen(tmp, "wb");
+		if (!f)
+			return -MIDORIDB_ERROR;
+		const bool ok = fwrite(id_out, 1, MDB_DIST_ID_BYTES, f) == MDB_DIST_ID_BYTES;
+		if (fclose(f) != 0 || !ok || rename(tmp, path) != 0) {
+			(void)remove(tmp);
+			return -MIDORIDB_ERROR;
+		}
+		return MIDORIDB_OK;
+	}
+	struct timespec t0, t;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (;;) {
+		FILE *f = fopen(path, "rb");
+		if (f) {
+			const size_t got = fread(id_out, 1, MDB_DIST_ID_BYTES, f);
+			fclose(f);
+			if (got == MDB_DIST_ID_BYTES)
+				return MIDORIDB_OK;
+		}
+		clock_gettime(CLOCK_MONOTONIC, &t);
+		if ((double)(t.tv_sec - t0.tv_sec) + (double)(t.tv_nsec - t0.tv_nsec) * 1e-9 > timeout_s)
+			return -MIDORIDB_ERROR;
+		usleep(2000);
+	}
+}
+
+/* ------------------------------------------------------------------ handle */
+
+static int dist_new(mdb_dev_ctx *ctx, int world, int rank, mdb_dist **out)
+{
+	if (!ctx || !out || world < 1 || rank < 0 || rank >= world || world > (1 << MDB_MAX_RADIX_BITS))
+		return -MIDORIDB_ERROR;
+	mdb_dist *d = (mdb_dist *)calloc(1, sizeof(*d));
+	if (!d)
+		return -MIDORIDB_NOMEM;
+	d->ctx = ctx;
+	d->world = world;
+	d->rank = rank;
+	d->wire_mode = MDB_WIRE_AUTO;
+	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_a, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_b, hipEventDisableTiming) != hipSuccess) {
+		mdb_dist_destroy(d);
+		return -MIDORIDB_INTERNAL;
+	}
+	*out = d;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_init(mdb_dev_ctx *ctx, int world, int rank, const void *id, mdb_dist **out)
+{
+	if (!id || !out)
+		return -MIDORIDB_ERROR;
+	*out = NULL;
+	mdb_dist *d = NULL;
+	int rc = dist_new(ctx, world, rank, &d);
+	if (rc)
+		return rc;
+	rccl_transport *rt = (rccl_transport *)calloc(1, sizeof(*rt));
+	if (!rt) {
+		mdb_dist_destroy(d);
+		return -MIDORIDB_NOMEM;
+	}
+	rt->world = world;
+	rt->rank = rank;
+	rt->device = ctx->device;
+	d->t.self = rt;
+	d->t.counts = rt_counts;
+	d->t.alltoallv = rt_alltoallv;
+	d->t.allreduce_sum_u64 = rt_allreduce;
+	d->t.destroy = rt_destroy;
+	d->own_transport = true;
+	ncclUniqueId uid;
+	memcpy(&uid, id, sizeof(uid));
+	/* the second communicator is split off the first with an id of its own, agreed on through the first:
+	 * rank 0 creates it and every rank learns it from an all-reduce (the other ranks contribute zeros) */
+	ncclResult_t r = ncclCommInitRank(&rt->data, world, uid, rank);
+	if (r != ncclSuccess) {
+		snprintf(ctx->err, sizeof(ctx->err), "ncclCommInitRank: %s", ncclGetErrorString(r));
+		mdb_dist_destroy(d);
+		return -MIDORIDB_INTERNAL;
+	}
+	const size_t words = (size_t)world * RT_MAX_COUNTERS * 2;
+	if (hipStreamCreateWithFlags(&rt->small_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipMalloc((void **)&rt->d_buf, (words > 64 ? words : 64) * 8) != hipSuccess ||
+	    hipHostMalloc((void **)&rt->h_buf, (words > 64 ? words : 64) * 8) != hipSuccess) {
+		mdb_dist_destroy(d);
+		return -MIDORIDB_INTERNAL;
+	}
+	{
+		ncclUniqueId uid2;
+		memset(&uid2, 0, sizeof(uid2));
+		if (rank == 0 && ncclGetUniqueId(&uid2) != ncclSuccess) {
+			mdb_dist_destroy(d);
+			return -MIDORIDB_INTERNAL;
+		}
+		uint64_t *h = rt->h_buf;
+		memcpy(h, &uid2, sizeof(uid2));
+		r = ncclSuccess;
+		if (hipMemcpyAsync(rt->d_buf, h, sizeof(uid2), hipMemcpyHostToDevice, rt->small_stream) != hipSuccess)
+			r = ncclSystemError;
+		if (r == ncclSuccess)
+			r = ncclAllReduce(rt->d_buf, rt->d_buf, sizeof(uid2) / 8, ncclUint64, ncclSum, rt->data, rt->small_stream);
+		if (r == ncclSuccess &&
+		    (hipMemcpyAsync(h, rt->d_buf, sizeof(uid2), hipMemcpyDeviceToHost, rt->small_stream) != hipSuccess ||
+		     hipStreamSynchronize(rt->small_stream) != hipSuccess))
+			r = ncclSystemError;
+		if (r == ncclSuccess) {
+			memcpy(&uid2, h, sizeof(uid2));
+			r = ncclCommInitRank(&rt->small, world, uid2, rank);
+		}
+		if (r != ncclSuccess) {
+			snprintf(ctx->err, sizeof(ctx->err), "second communicator: %s", ncclGetErrorString(r));
+			mdb_dist_destroy(d);
+			return -MIDORIDB_INTERNAL;
+		}
+	}
+	*out = d;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_init_transport(mdb_dev_ctx *ctx, int world, int rank, const struct mdb_dist_transport *t, mdb_dist **out)
+{
+	if (!t || !t->counts || !t->alltoallv || !t->allreduce_sum_u64 || !out)
+		return -MIDORIDB_ERROR;
+	*out = NULL;
+	mdb_dist *d = NULL;
+	int rc = dist_new(ctx, world, rank, &d);
+	if (rc)
+		return rc;
+	d->t = *t;
+	d->own_transport = false;
+	*out = d;
+	return MIDORIDB_OK;
+}
+
+extern "C" void mdb_dist_destroy(mdb_dist *d)
+{
+	if (!d)
+		return;
+	if (d->ctx)
+		(void)hipSetDevice(d->ctx->device);
+	if (d->comm_stream)
+		(void)hipStreamSynchronize(d->comm_stream);
+	if (d->t.destroy && d->t.self)
+		d->t.destroy(d->t.self);
+	for (int i = 0; i < 2; i++) {
+		if (d->send[i])
+			(void)hipFree(d->send[i]);
+		if (d->recv[i])
+			(void)hipFree(d->recv[i]);
+	}
+	if (d->ev_ready)
+		(void)hipEventDestroy(d->ev_ready);
+	if (d->ev_a)
+		(void)hipEventDestroy(d->ev_a);
+	if (d->ev_b)
+		(void)hipEventDestroy(d->ev_b);
+	if (d->comm_stream)
+		(void)hipStreamDestroy(d->comm_stream);
+	free(d);
+}
+
+extern "C" int mdb_dist_world(const mdb_dist *d) { return d ? d->world : 0; }
+extern "C" int mdb_dist_rank(const mdb_dist *d) { return d ? d->rank : -1; }
+extern "C" const char *mdb_dist_last_error(const mdb_dist *d) { return d ? d->err : "no distributed handle"; }
+extern "C" int mdb_dist_last_wire32(const mdb_dist *d) { return d ? d->last_wire32 : 0; }
+extern "C" uint64_t mdb_dist_last_received_left(const mdb_dist *d) { return d ? d->last_recv_left : 0; }
+
+extern "C" int mdb_dist_set_wire(mdb_dist *d, int mode)
+{
+	if (!d || mode < MDB_WIRE_AUTO || mode > MDB_WIRE_32)
+		return -MIDORIDB_ERROR;
+	d->wire_mode = mode;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n)
+{
+	if (!d || !vals)
+		return -MIDORIDB_ERROR;
+	const int rc = d->t.allreduce_sum_u64(d->t.self, vals, n);
+	return rc ? dist_err(d, rc, "all-reduce failed%s%s", d->own_transport ? ": " : "", d->own_transport ? ((rccl_transport *)d->t.self)->err : "") : rc;
+}
+
+extern "C" int mdb_dist_barrier(mdb_dist *d)
+{
+	uint64_t one = 1;
+	return mdb_dist_allreduce_sum_u64(d, &one, 1);
+}
+
+/* ------------------------------------------------------------------ the exchange */
+
+static int dist_reserve(mdb_dist *d, void **buf, uint64_t *cap, uint64_t words)
+{
+	if (words <= *cap)
+		return MIDORIDB_OK;
+	DIST_HIP(d, hipStreamSynchronize(d->comm_stream));	/* nothing may still read the old buffer */
+	DIST_HIP(d, hipStreamSynchronize(d->ctx->stream));
+	if (*buf)
+		DIST_HIP(d, hipFree(*buf));
+	*buf = NULL;
+	*cap = 0;
+	const uint64_t want = words + words / 8 + 4096;
+	DIST_HIP(d, hipMalloc(buf, want * 8));
+	*cap = want;
+	return MIDORIDB_OK;
+}
+
+/* one table: partition by destination into send[i], exchange counts, post the all-to-all into recv[i] on the transfer
+ * stream.  *n_recv = rows this rank receives (they are in recv[i] once `done` has happened) */
+static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64_t *nulls, uint64_t n, bool wire32, uint64_t *n_recv,
+			   hipEvent_t done)
+{
+	const int W = d->world;
+	uint64_t scnt[1 << MDB_MAX_RADIX_BITS], rcnt[1 << MDB_MAX_RADIX_BITS];
+	size_t sc[1 << MDB_MAX_RADIX_BITS], sd[1 << MDB_MAX_RADIX_BITS], rc_[1 << MDB_MAX_RADIX_BITS], rd[1 << MDB_MAX_RADIX_BITS];
+	int rc = dist_reserve(d, &d->send[i], &d->send_cap[i], n + 2);
+	if (rc)
+		return rc;
+	rc = mdb_dev_partition_by_dest(d->ctx, keys, nulls, n, (uint32_t)W, wire32 ? 1 : 0, d->send[i], NULL, scnt);	/* (synchronises) */
+	if (rc)
+		return dist_err(d, rc, "partition by destination: %s", mdb_dev_last_error(d->ctx));
+	rc = d->t.counts(d->t.self, scnt, rcnt, 1);
+	if (rc)
+		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", d->own_transport ? ((rccl_transport *)d->t.self)->err : "");
+	uint64_t total = 0, sent = 0;
+	for (int p = 0; p < W; p++) {
+		sc[p] = (size_t)scnt[p];
+		sd[p] = (size_t)sent;
+		rc_[p] = (size_t)rcnt[p];
+		rd[p] = (size_t)total;
+		sent += scnt[p];
+		total += rcnt[p];
+	}
+	if (total >= 0xFFFFFFFFull)
+		return dist_err(d, -MIDORIDB_ERROR, "%llu rows for one GPU shard exceed the 32-bit row-id limit", (unsigned long long)total);
+	rc = dist_reserve(d, &d->recv[i], &d->recv_cap[i], total + 2);
+	if (rc)
+		return rc;
+	rc = d->t.alltoallv(d->t.self, d->send[i], sc, sd, d->recv[i], rc_, rd, wire32 ? 4 : 8, d->comm_stream);
+	if (rc)
+		return dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", d->own_transport ? ((rccl_transport *)d->t.self)->err : "");
+	DIST_HIP(d, hipEventRecord(done, d->comm_stream));
+	*n_recv = total;
+	return MIDORIDB_OK;
+}
+
+/* common part: exchange (the left table only unless it is already in place), local join into buffers that are either the
+ * caller's (capacity cap) or allocated here once the number of received left rows is known */
+static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			  const uint64_t *null_r, uint64_t n_r, bool left_in_place, bool alloc_out, int64_t **out_key, int64_t **out_count,
+			  uint32_t **out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	mdb_dev_ctx *ctx = d->ctx;
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	DIST_HIP(d, hipSetDevice(ctx->device));
+	/* ---- wire format: every rank must take the same decision */
+	bool wire32 = d->wire_mode == MDB_WIRE_32 && !left_in_place;
+	if (d->wire_mode == MDB_WIRE_AUTO && !left_in_place) {
+		uint64_t wide = 0;
+		const int64_t *cols[2] = { keys_l, keys_r };
+		const uint64_t *nb[2] = { null_l, null_r };
+		const uint64_t ns[2] = { n_l, n_r };
+		for (int i = 0; i < 2; i++) {
+			int64_t lo = 0, hi = -1;
+			if (ns[i]) {
+				int rc = mdb_dev_key_range(ctx, cols[i], nb[i], ns[i], &lo, &hi);
+				if (rc)
+					return dist_err(d, rc, "key range: %s", mdb_dev_last_error(ctx));
+			}
+			if (lo <= hi && (lo < -(1ll << 31) || hi >= (1ll << 31)))
+				wide = 1;
+		}
+		int rc = mdb_dist_allreduce_sum_u64(d, &wide, 1);
+		if (rc)
+			return rc;
+		wire32 = wide == 0;
+	}
+	d->last_wire32 = wire32 ? 1 : 0;
+
+	/* the transfer stream starts behind whatever the caller queued on the context's stream (its key columns) */
+	DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
+	DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
+
+	/* ---- table L travels while table R is partitioned; table R travels while the received L is prepared */
+	uint64_t got_l = n_l, got_r = 0;
+	int rc;
+	if (!left_in_place) {
+		rc = dist_send_table(d, 0, keys_l, null_l, n_l, wire32, &got_l, d->ev_a);
+		if (rc)
+			return rc;
+	}
+	rc = dist_send_table(d, 1, keys_r, null_r, n_r, wire32, &got_r, d->ev_b);
+	if (rc)
+		return rc;
+	d->last_recv_left = got_l;
+	if (alloc_out) {
+		const uint64_t c = got_l ? got_l : 1;
+		*out_key = NULL;
+		*out_count = NULL;
+		if (out_first)
+			*out_first = NULL;
+		if (mdb_dev_alloc(ctx, c * 8, (void **)out_key) || mdb_dev_alloc(ctx, c * 8, (void **)out_count) ||
+		    (out_first && mdb_dev_alloc(ctx, c * 4, (void **)out_first))) {
+			if (*out_key)
+				mdb_dev_free(ctx, *out_key);
+			if (*out_count)
+				mdb_dev_free(ctx, *out_count);
+			*out_key = *out_count = NULL;
+			return dist_err(d, -MIDORIDB_NOMEM, "allocating group outputs: %s", mdb_dev_last_error(ctx));
+		}
+		cap = c;
+	} else if (got_l > cap) {
+		return dist_err(d, -MIDORIDB_ERROR, "group output capacity %llu is below the %llu left rows this rank received",
+				(unsigned long long)cap, (unsigned long long)got_l);
+	}
+	if (left_in_place) {
+		rc = mdb_dev_join_group_count_begin(ctx, keys_l, null_l, n_l, got_r);
+	} else {
+		DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_a, 0));
+		if (wire32)
+			rc = mdb_dev_join_group_count_begin_i32(ctx, (const int32_t *)d->recv[0], got_l, got_r);
+		else
+			rc = mdb_dev_join_group_count_begin(ctx, (const int64_t *)d->recv[0], NULL, got_l, got_r);
+	}
+	if (rc)
+		return dist_err(d, rc, "local join (begin): %s", mdb_dev_last_error(ctx));
+	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_b, 0));
+	uint64_t G = 0, J = 0;
+	uint32_t *first = out_first ? *out_first : NULL;
+	if (wire32 && !left_in_place)
+		rc = mdb_dev_join_group_count_finish_i32(ctx, (const int32_t *)d->recv[1], got_r, MDB_ORDER_FIRST, *out_key, *out_count, first, cap, &G,
+							 &J);
+	else	/* (a left table in place is int64: its right table always travels as 8-byte keys) */
+		rc = mdb_dev_join_group_count_finish(ctx, (const int64_t *)d->recv[1], NULL, got_r, MDB_ORDER_FIRST, *out_key, *out_count, first, cap,
+						     &G, &J);
+	if (rc)
+		return dist_err(d, rc, "local join (finish): %s", mdb_dev_last_error(ctx));
+	*out_groups = G;
+	if (out_joined)
+		*out_joined = J;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_join_group_count(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+					 const uint64_t *null_r, uint64_t n_r, int64_t *out_key, int64_t *out_count, uint64_t cap,
+					 uint64_t *out_groups, uint64_t *out_joined)
+{
+	if (!d || !out_groups || !out_key || !out_count)
+		return -MIDORIDB_ERROR;
+	return dist_join_impl(d, keys_l, null_l, n_l, keys_r, null_r, n_r, false, false, &out_key, &out_count, NULL, cap, out_groups, out_joined);
+}
+
+extern "C" int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+					       const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags, int64_t **out_key,
+					       int64_t **out_count, uint32_t **out_first, uint64_t *out_groups, uint64_t *out_joined)
+{
+	if (!d || !out_groups || !out_key || !out_count)
+		return -MIDORIDB_ERROR;
+	return dist_join_impl(d, keys_l, null_l, n_l, keys_r, null_r, n_r, (flags & MDB_DIST_LEFT_IN_PLACE) != 0, true, out_key, out_count, out_first,
+			      0, out_groups, out_joined);
+}

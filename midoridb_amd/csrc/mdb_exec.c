@@ -1257,32 +1257,64 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		    (rc = fused_operand(&x, 1, fkeys[1], ws.push[1], ws.npush[1], &rv, &rn, &nr_rows)))
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
-		x.d_fused_key = dalloc(&x, cap * 8);
-		x.d_count = dalloc(&x, cap * 8);
-		if (!x.d_fused_key || !x.d_count) {
-			rc = dev_fail(&x, "allocating group outputs");
-			goto out;
+		if (cat->dist) {
+			/* sharded mode: the tables hold this rank's rows; both key columns are exchanged (RCCL all-to-all per table,
+			 * include/mdb_dist.h) and this rank keeps the groups whose key hashes to it.  Collective: every rank runs the
+			 * same statement. */
+			if (mdb_dist_join_group_count_alloc(cat->dist, lv, ln, nl_rows, rv, rn, nr_rows, 0, &x.d_fused_key, &x.d_count, NULL, &G, &J)) {
+				snprintf(err, errlen, "execution phase: sharded join + group count: %s\n", mdb_dist_last_error(cat->dist));
+				rc = -MIDORIDB_INTERNAL;
+				goto out;
+			}
+			if (track(&x, x.d_fused_key) || track(&x, x.d_count)) {
+				rc = -MIDORIDB_NOMEM;
+				goto out;
+			}
+		} else {
+			x.d_fused_key = dalloc(&x, cap * 8);
+			x.d_count = dalloc(&x, cap * 8);
+			if (!x.d_fused_key || !x.d_count) {
+				rc = dev_fail(&x, "allocating group outputs");
+				goto out;
+			}
+			if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
+						     &J)) {
+				rc = dev_fail(&x, "join + group count");
+				goto out;
+			}
 		}
-		if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
-					     &J)) {
-			rc = dev_fail(&x, "join + group count");
-			goto out;
-		}
-		for (int t = 2; t < s->ntabs && G; t++) {
+		for (int t = 2; t < s->ntabs && (G || cat->dist); t++) {
 			const void *cv;
 			const uint64_t *cn;
 			uint64_t nc_rows;
 			if ((rc = fused_operand(&x, t, fkeys[t], ws.push[t], ws.npush[t], &cv, &cn, &nc_rows)))
 				goto out;
-			int64_t *key2 = dalloc(&x, G * 8), *cnt2 = dalloc(&x, G * 8), *cnt3 = dalloc(&x, G * 8);
-			uint32_t *first2 = dalloc(&x, G * 4);
+			int64_t *key2 = NULL, *cnt2 = NULL, *cnt3 = dalloc(&x, (G ? G : 1) * 8);
+			uint32_t *first2 = NULL;
 			uint64_t G2 = 0, J2 = 0;
+			if (cat->dist) {
+				/* the groups so far already live on the rank their key hashes to: only the new table travels */
+				if (mdb_dist_join_group_count_alloc(cat->dist, x.d_fused_key, NULL, G, cv, cn, nc_rows, MDB_DIST_LEFT_IN_PLACE, &key2, &cnt2,
+								    &first2, &G2, &J2)) {
+					snprintf(err, errlen, "execution phase: sharded join + group count: %s\n", mdb_dist_last_error(cat->dist));
+					rc = -MIDORIDB_INTERNAL;
+					goto out;
+				}
+				if (track(&x, key2) || track(&x, cnt2) || track(&x, first2)) {
+					rc = -MIDORIDB_NOMEM;
+					goto out;
+				}
+			} else {
+				key2 = dalloc(&x, G * 8);
+				cnt2 = dalloc(&x, G * 8);
+				first2 = dalloc(&x, G * 4);
+			}
 			if (!key2 || !cnt2 || !cnt3 || !first2) {
 				rc = dev_fail(&x, "allocating group outputs");
 				goto out;
 			}
-			if (mdb_dev_join_group_count(x.dev, x.d_fused_key, NULL, G, cv, cn, nc_rows, MDB_ORDER_FIRST, key2, cnt2, first2, G, &G2,
-						     &J2) ||
+			if ((!cat->dist && mdb_dev_join_group_count(x.dev, x.d_fused_key, NULL, G, cv, cn, nc_rows, MDB_ORDER_FIRST, key2, cnt2, first2, G,
+								    &G2, &J2)) ||
 			    mdb_dev_combine_counts(x.dev, x.d_count, NULL, first2, cnt2, G2, cnt3, NULL, &J)) {
 				rc = dev_fail(&x, "chained join + group count");
 				goto out;
@@ -1293,11 +1325,27 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 		if (!G)
 			J = 0;
+		if (cat->dist && only_count) {
+			/* SELECT COUNT(*) over the sharded join: every rank reports the global number of joined rows */
+			uint64_t tot = J;
+			if (mdb_dist_allreduce_sum_u64(cat->dist, &tot, 1)) {
+				snprintf(err, errlen, "execution phase: %s\n", mdb_dist_last_error(cat->dist));
+				rc = -MIDORIDB_INTERNAL;
+				goto out;
+			}
+			J = tot;
+		}
 		x.fused = true;
 		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */
 		x.joined_rows = J;
 	} else {
 		/* ---- general plan */
+		if (cat->dist && s->ntabs > 1) {
+			ERR("execution phase: in sharded mode (MIDORIDB_WORLD_SIZE) only joins of the fused shape - JOIN ... ON l = r [JOIN ...] "
+			    "GROUP BY that key, COUNT(*) - are exchanged between the ranks; this join would only see local rows\n");
+			rc = -MIDORIDB_ERROR;
+			goto out;
+		}
 		x.n = s->tabs[0].t->nrows;	/* scan: identity stream over the first table */
 		if (split_ok) {
 			/* WHERE conjuncts that read one table filter that table before it is joined; the others after the joins */

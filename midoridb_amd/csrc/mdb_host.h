@@ -15,6 +15,7 @@
 #include <stdarg.h>
 #include "mdb_error.h"
 #include "mdb_dev.h"
+#include "mdb_dist.h"
 #include "mdb_query.h"
 
 /* ------------------------------------------------------------------ RPN token queue
@@ -72,6 +73,9 @@ struct mdb_catalog {
 	int n, cap;
 	mdb_dev_ctx *dev;		/* created lazily by the first SELECT */
 	int dev_rc;			/* sticky result of the lazy creation */
+	/* sharded mode (MIDORIDB_WORLD_SIZE > 1 in the environment: one process per GPU, every process holds ITS rows of every
+	 * table): the RCCL exchange handle, created with the device context (include/mdb_dist.h) */
+	mdb_dist *dist;
 };
 
 struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name);

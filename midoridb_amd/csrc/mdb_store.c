@@ -74,6 +74,8 @@ void mdb_catalog_free(struct mdb_catalog *cat)
 	for (int i = 0; i < cat->n; i++)
 		mdb_table_free(cat->tables[i], cat->dev);
 	free(cat->tables);
+	if (cat->dist)
+		mdb_dist_destroy(cat->dist);
 	if (cat->dev)
 		mdb_dev_ctx_destroy(cat->dev);
 	memset(cat, 0, sizeof(*cat));
@@ -126,6 +128,25 @@ int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen)
 			cat->dev_rc = -MIDORIDB_INTERNAL;
 		} else {
 			cat->dev_rc = mdb_dev_ctx_create(device, MDB_STREAM_OWN, &cat->dev);
+		}
+		/* sharded mode: MIDORIDB_WORLD_SIZE ranks, this one MIDORIDB_RANK, the communicator id through the file
+		 * MIDORIDB_DIST_ID_FILE (rank 0 writes it).  Collective: every rank's first SELECT gets here. */
+		if (cat->dev && getenv("MIDORIDB_WORLD_SIZE") && atoi(getenv("MIDORIDB_WORLD_SIZE")) >= 1) {	/* (1: a one-rank exchange, for tests) */
+			const int world = atoi(getenv("MIDORIDB_WORLD_SIZE"));
+			const int rank = getenv("MIDORIDB_RANK") ? atoi(getenv("MIDORIDB_RANK")) : -1;
+			const char *idf = getenv("MIDORIDB_DIST_ID_FILE");
+			char id[MDB_DIST_ID_BYTES];
+			int rc = (rank < 0 || rank >= world || !idf) ? -MIDORIDB_ERROR : mdb_dist_id_via_file(idf, rank, 300.0, id);
+			if (!rc)
+				rc = mdb_dist_init(cat->dev, world, rank, id, &cat->dist);
+			if (rc) {
+				snprintf(err, errlen, "execution phase: cannot join the %d-rank exchange (MIDORIDB_RANK / MIDORIDB_DIST_ID_FILE): %s\n", world,
+					 mdb_dev_last_error(cat->dev));
+				mdb_dev_ctx_destroy(cat->dev);
+				cat->dev = NULL;
+				cat->dev_rc = rc;
+				return rc;
+			}
 		}
 	}
 	if (!cat->dev) {

@@ -1,0 +1,208 @@
+"""Python binding of the multi-GPU C-ABI (include/mdb_dist.h): the exchange itself - partition by destination,
+counts, uneven all-to-all over RCCL, local join - runs inside libmidoridb_amd.so; nothing here moves keys.
+
+The communicator id (128 bytes, created by rank 0 in C) has to reach the other ranks: `DistCtx.from_torch()` ships
+it through an already initialised torch.distributed process group, `DistCtx.from_file()` through a file, and
+`DistCtx(dev, world, rank, id_bytes)` takes it from wherever the host program got it.
+
+`DistCtx.with_transport()` plugs another fabric in through struct mdb_dist_transport (callbacks): the tests use it to
+run two ranks on ONE GPU with gloo carrying the bytes through host memory.
+"""
+import ctypes
+from ctypes import CFUNCTYPE, POINTER, Structure, byref, c_char_p, c_double, c_int, c_size_t, c_uint64, c_void_p
+
+import torch
+
+from .lib import load_library
+
+MDB_DIST_ID_BYTES = 128
+WIRE_AUTO, WIRE_64, WIRE_32 = 0, 1, 2
+
+_COUNTS = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int)
+_A2AV = CFUNCTYPE(c_int, c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_void_p, POINTER(c_size_t), POINTER(c_size_t),
+                  c_size_t, c_void_p)
+_ALLRED = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), c_int)
+_DESTROY = CFUNCTYPE(None, c_void_p)
+
+
+class Transport(Structure):
+    _fields_ = [("self", c_void_p), ("counts", _COUNTS), ("alltoallv", _A2AV), ("allreduce_sum_u64", _ALLRED), ("destroy", _DESTROY)]
+
+
+DIST_SYMBOLS = [
+    "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
+    "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
+    "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
+]
+
+
+def _bind(lib):
+    if getattr(lib, "_mdb_dist_bound", False):
+        return
+    P = c_void_p
+    sig = {
+        "mdb_dist_unique_id": ([P], c_int),
+        "mdb_dist_id_via_file": ([c_char_p, c_int, c_double, P], c_int),
+        "mdb_dist_init": ([P, c_int, c_int, P, POINTER(P)], c_int),
+        "mdb_dist_destroy": ([P], None),
+        "mdb_dist_world": ([P], c_int),
+        "mdb_dist_rank": ([P], c_int),
+        "mdb_dist_last_error": ([P], c_char_p),
+        "mdb_dist_init_transport": ([P, c_int, c_int, POINTER(Transport), POINTER(P)], c_int),
+        "mdb_dist_set_wire": ([P, c_int], c_int),
+        "mdb_dist_last_wire32": ([P], c_int),
+        "mdb_dist_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
+        "mdb_dist_join_group_count_alloc": ([P, P, P, c_uint64, P, P, c_uint64, ctypes.c_uint32, POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64),
+                                             POINTER(c_uint64)], c_int),
+        "mdb_dist_last_received_left": ([P], c_uint64),
+        "mdb_dist_allreduce_sum_u64": ([P, POINTER(c_uint64), c_int], c_int),
+        "mdb_dist_barrier": ([P], c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    lib._mdb_dist_bound = True
+
+
+class DistError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+class DistCtx:
+    """One rank's handle on the sharded operator (mdb_dist*) for the GPU of a DeviceCtx."""
+
+    def __init__(self, dev, world, rank, id_bytes=None, transport=None):
+        self.lib = load_library()
+        _bind(self.lib)
+        self.dev = dev
+        self.world = world
+        self.rank = rank
+        self._keep = transport          # the callbacks must outlive the handle
+        h = c_void_p()
+        if transport is not None:
+            rc = self.lib.mdb_dist_init_transport(dev.h, world, rank, byref(transport), byref(h))
+        else:
+            if id_bytes is None or len(id_bytes) != MDB_DIST_ID_BYTES:
+                raise DistError("a 128-byte communicator id is required")
+            buf = (ctypes.c_char * MDB_DIST_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+            rc = self.lib.mdb_dist_init(dev.h, world, rank, buf, byref(h))
+        if rc != 0:
+            msg = self.lib.mdb_dev_last_error(dev.h)
+            raise DistError(f"mdb_dist_init failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = h
+
+    # -- rendezvous --------------------------------------------------------------------------------------------
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        _bind(lib)
+        buf = ctypes.create_string_buffer(MDB_DIST_ID_BYTES)
+        if lib.mdb_dist_unique_id(buf) != 0:
+            raise DistError("mdb_dist_unique_id failed")
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, dev, group=None):
+        """The id travels through an initialised torch.distributed process group (any backend)."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(dev, world, rank, box[0])
+
+    @classmethod
+    def from_file(cls, dev, world, rank, path, timeout_s=120.0):
+        lib = load_library()
+        _bind(lib)
+        buf = ctypes.create_string_buffer(MDB_DIST_ID_BYTES)
+        if lib.mdb_dist_id_via_file(path.encode(), rank, timeout_s, buf) != 0:
+            raise DistError(f"no communicator id through {path}")
+        return cls(dev, world, rank, buf.raw)
+
+    @classmethod
+    def with_transport(cls, dev, world, rank, counts, alltoallv, allreduce):
+        """counts(send: list[int] of world*n, n) -> list[int]; alltoallv(d_send, sendcounts, sdispls, d_recv, recvcounts,
+        rdispls, elem_bytes, stream) with raw device pointers as ints; allreduce(vals: list[int]) -> list[int]."""
+        def c_counts(_self, send, recv, n):
+            try:
+                out = counts([int(send[i]) for i in range(world * n)], n)
+                for i, v in enumerate(out):
+                    recv[i] = int(v)
+                return 0
+            except Exception as e:  # pragma: no cover - reported through the return code
+                print("transport.counts failed:", e, flush=True)
+                return -2
+
+        def c_a2av(_self, d_send, sc, sd, d_recv, rc, rd, es, stream):
+            try:
+                alltoallv(d_send, [int(sc[i]) for i in range(world)], [int(sd[i]) for i in range(world)], d_recv,
+                          [int(rc[i]) for i in range(world)], [int(rd[i]) for i in range(world)], int(es), stream)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("transport.alltoallv failed:", e, flush=True)
+                return -2
+
+        def c_allred(_self, vals, n):
+            try:
+                out = allreduce([int(vals[i]) for i in range(n)])
+                for i, v in enumerate(out):
+                    vals[i] = int(v)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("transport.allreduce failed:", e, flush=True)
+                return -2
+
+        t = Transport(None, _COUNTS(c_counts), _A2AV(c_a2av), _ALLRED(c_allred), _DESTROY(lambda _s: None))
+        return cls(dev, world, rank, transport=t)
+
+    # -- operator ----------------------------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.mdb_dist_last_error(self.h)
+            raise DistError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_wire(self, mode):
+        self._chk(self.lib.mdb_dist_set_wire(self.h, int(mode)), "set_wire")
+
+    def last_wire32(self):
+        return bool(self.lib.mdb_dist_last_wire32(self.h))
+
+    def last_received_left(self):
+        return int(self.lib.mdb_dist_last_received_left(self.h))
+
+    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None):
+        """-> (keys[G], counts[G], joined rows on this rank): the groups whose key hashes to this rank."""
+        n_l, n_r = keys_l.numel(), keys_r.numel()
+        if out is None:
+            cap = int(n_l * 1.3) + 4096 if self.world > 1 else max(n_l, 1)
+            out = (torch.empty(cap, dtype=torch.int64, device=self.dev.device), torch.empty(cap, dtype=torch.int64, device=self.dev.device))
+        ok, oc = out[0], out[1]
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dist_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r, _ptr(ok),
+                                                     _ptr(oc), min(ok.numel(), oc.numel()), byref(g), byref(j)), "dist join_group_count")
+        return ok[:g.value], oc[:g.value], j.value
+
+    def allreduce_sum(self, vals):
+        arr = (c_uint64 * len(vals))(*[int(v) for v in vals])
+        self._chk(self.lib.mdb_dist_allreduce_sum_u64(self.h, arr, len(vals)), "allreduce")
+        return [int(v) for v in arr]
+
+    def barrier(self):
+        self._chk(self.lib.mdb_dist_barrier(self.h), "barrier")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mdb_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

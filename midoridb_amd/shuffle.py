@@ -1,10 +1,12 @@
-"""Multi-GPU form of the north-star pipeline: hash-partition by destination GPU -> one all-to-all
-per table over xGMI (RCCL through torch.distributed; backend "nccl" IS RCCL on ROCm) -> local
-LDS hash join + group count.  No other collective is on the data path: groups are disjoint
-across ranks because both tables are partitioned by the join key.
+"""Exchange helpers over torch.distributed for the rows of the path that carry PAYLOAD columns (BASELINE configs 4 / 5:
+joins that materialise rows): hash-partition by destination GPU with source row ids -> payload gathered into send order ->
+one uneven all-to-all per column (RCCL; backend "nccl" IS RCCL on ROCm) -> local joins (TableShuffle).
 
-The exchange logic is backend-neutral so the world_size-2 gloo tests on CPU run exactly this
-code with the oracle's partition/join functions plugged in instead of the device operators.
+The north-star operator itself (join + GROUP BY key + COUNT(*), keys only) is NOT here any more: its exchange lives
+behind the C-ABI (include/mdb_dist.h, csrc/mdb_dist.hip - RCCL communicators, counts, all-to-all and the split local join in
+C), bound by midoridb_amd/dist.py and used by bench.py and by query_execute()'s sharded mode.  DistributedJoinGroupCount below
+is the backend-neutral restatement of that sequence which the world_size-2 gloo test on CPU runs with the oracle's
+partition / join functions plugged in.
 """
 import torch
 import torch.distributed as dist

@@ -24,7 +24,7 @@ def _declared_functions(header):
     return sorted(set(n for n in names if n.startswith(("mdb_", "query_", "database_"))))
 
 
-@pytest.mark.parametrize("header", ["mdb_dev.h", "mdb_query.h"])
+@pytest.mark.parametrize("header", ["mdb_dev.h", "mdb_query.h", "mdb_dist.h"])
 def test_library_exports_every_declared_symbol(header):
     lib = _lib()
     names = _declared_functions(header)
@@ -36,6 +36,8 @@ def test_library_exports_every_declared_symbol(header):
 def test_python_binding_lists_match_headers():
     from midoridb_amd import dev, query
     assert set(dev.DEV_SYMBOLS) == set(_declared_functions("mdb_dev.h"))
+    from midoridb_amd import dist
+    assert set(dist.DIST_SYMBOLS) == set(_declared_functions("mdb_dist.h"))
     assert set(_declared_functions("mdb_query.h")) <= set(query.QUERY_SYMBOLS)
 
 

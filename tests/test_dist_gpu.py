@@ -1,0 +1,75 @@
+"""The multi-GPU exchange behind the C-ABI (include/mdb_dist.h, csrc/mdb_dist.hip) on the one-GPU test box:
+world size 1 over RCCL, and world size 2 on the same GPU with a test transport (gloo through host memory) plugged into
+struct mdb_dist_transport - the same C code path for counts, displacements, receive buffers, events and the local join."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(mode, nproc, port):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return r.stdout
+
+
+def test_sharded_join_group_count_over_rccl():
+    import torch
+    n = max(1, torch.cuda.device_count())
+    assert f"dist rccl world {n} ok" in _run("rccl", n, 29611)
+
+
+def test_sharded_join_group_count_two_ranks_one_gpu_test_transport():
+    assert "dist gloo world 2 ok" in _run("gloo", 2, 29612)
+
+
+def test_query_execute_in_sharded_mode_world1(tmp_path):
+    """query_execute() with MIDORIDB_WORLD_SIZE set runs the fused plan through mdb_dist_join_group_count_alloc (RCCL
+    communicators created inside database code from the id file; world size 1 on the test box): same groups and counts as
+    the single-GPU plan, chained over a third table, SELECT COUNT(*) all-reduced, other joins refused."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    script = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from midoridb_amd.query import DB, QueryError
+from oracle import np_oracle as orc
+rng = np.random.default_rng(4)
+n = 300_000
+a, b, c = rng.integers(0, 50_000, n), rng.integers(0, 60_000, n + 7), rng.integers(0, 50_000, 1000)
+with DB() as db:
+    for t, col, v in (("A", "id_a", a), ("B", "id_b", b), ("C", "id_c", c)):
+        db.execute(f"CREATE TABLE {t} ({col} INT);")
+        db.append_columns(t, [v.astype(np.int64)])
+    r = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;")
+    ek, ec, _, ej = orc.join_group_count(a, None, b, None)
+    got = dict(zip(r.columns[r.names.index("A.id_a")].tolist(), r.columns[r.names.index("COUNT(*)")].tolist()))
+    assert got == dict(zip(ek.tolist(), ec.tolist())) and r.joined_rows == ej
+    assert db.query("SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b;").rows() == [(ej,)]
+    r3 = db.query("SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c GROUP BY id_a;")
+    cc = dict(zip(*[x.tolist() for x in np.unique(c, return_counts=True)]))
+    exp3 = {k: v * cc[k] for k, v in zip(ek.tolist(), ec.tolist()) if k in cc}
+    assert dict(zip(r3.columns[r3.names.index("A.id_a")].tolist(), r3.columns[r3.names.index("COUNT(*)")].tolist())) == exp3
+    assert db.query("SELECT COUNT(*) FROM A WHERE id_a < 10;").rows() == [(int((a < 10).sum()),)]
+    try:
+        db.query("SELECT * FROM A INNER JOIN C ON A.id_a = C.id_c;")
+        raise SystemExit("a non-fused join must be refused in sharded mode")
+    except QueryError as e:
+        assert "sharded mode" in str(e)
+print("sharded query_execute ok")
+''' % ROOT
+    env = dict(os.environ, MIDORIDB_WORLD_SIZE="1", MIDORIDB_RANK="0", MIDORIDB_DIST_ID_FILE=str(tmp_path / "mdb_id"),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", script], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded query_execute ok" in r.stdout, r.stdout[-4000:]
