@@ -2,10 +2,10 @@
 """bench_operators.py - per-operator measurements of the OTHER rows of the hot path, beside the
 headline pipeline that bench.py times: scan+filter (config 1 scaled up), materialising join with payload
 (config 2), single-table GROUP BY, three-way join.  Not part of the driver's bench contract; writes one
-JSON document (default profiles/r01/operators.json) with milliseconds and the rate on each operator's
+JSON document (default profiles/r02/operators.json) with milliseconds and the rate on each operator's
 algorithmic bytes, all measured with HIP events through the library's per-kernel profiler.
 
-    python bench_operators.py [--out profiles/r01/operators.json]
+    python bench_operators.py [--out profiles/r02/operators.json]
 """
 import argparse
 import json
@@ -42,7 +42,7 @@ def timed(dev, fn, reps=5, warmup=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01", "operators.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "operators.json"))
     args = ap.parse_args()
     dev = DeviceCtx(0)
     res = {}
@@ -53,14 +53,25 @@ def main():
     prog = [(D.P_CMP_COL_CONST, D.CMP_GT, D.T_INT64, 0, 0, n // 2)]
 
     def scan_filter():
+        # scan + WHERE + projection in one operator: bitmap -> compacted values, no selection vector (mdb_dev_filter_project);
+        # (the copy of the library-allocated output into a torch tensor that dev.filter_project() makes is part of the time)
+        m, _ = dev.filter_project(prog, [(v, None, None)], n, [(v, None)])
+        return m
+    ms, kern, m = timed(dev, scan_filter)
+
+    def scan_filter_unfused():
         sel = dev.filter(prog, [(v, None, None)], n)
         out, _ = dev.gather64(v, None, sel, sel.numel())
         return sel.numel()
-    ms, kern, m = timed(dev, scan_filter)
+    ms_unfused, kern_unfused, _ = timed(dev, scan_filter_unfused)
     algo = 8 * n + 8 * m            # read every value once, write the survivors once
     res["scan_filter_1e8"] = {"rows_in": n, "rows_out": m, "ms": ms, "algorithmic_bytes": algo,
                               "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
-                              "note": "filter (ballot bitmap + scan + positions) then projection gather; 50% selectivity"}
+                              "device_ms": sum(kern.values()), "device_algorithmic_GBs": algo / (sum(kern.values()) * 1e-3) / 1e9,
+                              "unfused_ms": ms_unfused, "unfused_kernels_ms": kern_unfused,
+                              "note": "mdb_dev_filter_project (ballot bitmap + block scan + bitmap -> compacted values); 50% selectivity; "
+                                      "ms includes the binding's device-to-device copy of the result, device_ms is the operator's kernels; "
+                                      "unfused = filter (bitmap, scan, positions) + projection gather, the round-1 path"}
 
     # ---- materialising join with payload (config 2): 10^7 x 10^7, 1:1 keys, 4 output columns
     n2 = 10_000_000
@@ -70,16 +81,14 @@ def main():
     def join_payload():
         l, r = dev.join_pairs(a_id, None, b_id, None)
         j = l.numel()
-        c0, _ = dev.gather64(a_id, None, l, j)
-        c1, _ = dev.gather64(b_id, None, r, j)
-        c2, _ = dev.gather64(a_f, None, l, j)
-        c3, _ = dev.gather64(b_f, None, r, j)
+        dev.gather_cols([(a_id, None, l), (b_id, None, r), (a_f, None, l), (b_f, None, r)], j)   # the whole projection: one launch
         return j
     ms, kern, j = timed(dev, join_payload, reps=3, warmup=1)
     algo = 8 * 2 * n2 + 8 * 2 * n2 + 8 * 4 * j      # keys + payload columns read once, 4 result columns written
     res["join_payload_1e7"] = {"rows_per_table": n2, "joined_rows": j, "ms": ms, "joined_rows_per_s": j / (ms * 1e-3),
                                "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
-                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + 4 projection gathers"}
+                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + the projection of 4 columns in one launch "
+                                       "(mdb_dev_gather_cols)"}
 
     # ---- single-table GROUP BY key COUNT(*) at 10^8 rows, 6.25M groups of 16
     keys = dev.gen_keys(n, 0, n, 43, n // 16)
@@ -172,6 +181,17 @@ def main():
     from midoridb_amd.query import DB
     del v, keys
     torch.cuda.empty_cache()
+    with DB() as db:
+        # BASELINE configs[1] through the drop-in API: 10^7 x 10^7 rows, 4 result columns (320 MB of result over PCIe)
+        db.execute("CREATE TABLE A2 (id_a2 INT, f1 INT);")
+        db.execute("CREATE TABLE B2 (id_b2 INT, f2 INT);")
+        db.generate("A2", n2, 42)
+        db.generate("B2", n2, 50)
+        q2 = "SELECT * FROM A2 INNER JOIN B2 ON A2.id_a2 = B2.id_b2;"
+        db.query(q2)
+        r2 = db.query(q2)
+        res["join_payload_via_query_execute_1e7"] = {"rows_per_table": n2, "joined_rows": r2.nrows, "executor_ms": r2.exec_ms, "call_ms": db.last_call_ms,
+                                                     "note": "query_execute(): plan + join + projection + D2H of 4 x 10^7 x 8 B into pinned host columns"}
     with DB() as db:
         db.execute("CREATE TABLE A (id_a INT);")
         db.execute("CREATE TABLE B (id_b INT);")

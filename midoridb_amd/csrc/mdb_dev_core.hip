@@ -740,6 +740,90 @@ extern "C" int mdb_dev_gather64(mdb_dev_ctx *ctx, const void *src, const uint64_
 	return MIDORIDB_OK;
 }
 
+/* whole-result projection: see mdb_dev_gather_cols() in mdb_dev.h */
+struct gather_cols_args {
+	const uint64_t *src[MDB_GATHER_MAX_COLS];
+	const uint64_t *src_null[MDB_GATHER_MAX_COLS];
+	uint64_t *dst[MDB_GATHER_MAX_COLS];
+	uint64_t *dst_null[MDB_GATHER_MAX_COLS];
+	const uint32_t *rid[MDB_GATHER_MAX_RIDS];
+	uint8_t slot[MDB_GATHER_MAX_COLS];	/* which rid[] a column reads through; 0xFF = identity */
+	int ncols, nrids;
+	uint64_t n;
+};
+
+#define GC_ROUNDS 4	/* 256 x 4 = 1024 consecutive outputs per block: up to 4 x 16 gathers in flight per thread */
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_gather_cols(gather_cols_args a)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * GC_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < GC_ROUNDS; r++) {
+		/* one wave covers 64 consecutive outputs per round => one NULL word per wave, round and column */
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		const bool in = k < a.n;
+		uint32_t row[MDB_GATHER_MAX_RIDS];
+#pragma unroll
+		for (int t = 0; t < MDB_GATHER_MAX_RIDS; t++)
+			row[t] = (in && t < a.nrids) ? a.rid[t][k] : 0u;
+		for (int c = 0; c < a.ncols; c++) {
+			uint64_t src_row = k;
+			if (a.slot[c] != 0xFF) {
+#pragma unroll
+				for (int t = 0; t < MDB_GATHER_MAX_RIDS; t++)	/* (a compile-time index keeps row[] in registers) */
+					if (a.slot[c] == t)
+						src_row = row[t];
+			}
+			bool isnull = false;
+			if (in) {
+				a.dst[c][k] = a.src[c][src_row];
+				if (a.src_null[c])
+					isnull = mdb_bit_is_set(a.src_null[c], src_row);
+			}
+			if (a.dst_null[c]) {
+				const uint64_t m = __ballot(in && isnull);
+				if (mdb_lane() == 0 && in)
+					a.dst_null[c][k >> 6] = m;
+			}
+		}
+	}
+}
+
+extern "C" int mdb_dev_gather_cols(mdb_dev_ctx *ctx, const struct mdb_gather_col *cols, int ncols, uint64_t n)
+{
+	if (n == 0 || ncols == 0)
+		return MIDORIDB_OK;
+	if (!cols || ncols < 0 || ncols > MDB_GATHER_MAX_COLS)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "gather_cols: between 1 and %d columns per call", MDB_GATHER_MAX_COLS);
+	gather_cols_args a;
+	memset(&a, 0, sizeof(a));
+	a.ncols = ncols;
+	a.n = n;
+	for (int c = 0; c < ncols; c++) {
+		if (!cols[c].src || !cols[c].dst || (cols[c].src_nullbits && !cols[c].dst_nullbits))
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "gather_cols: column %d lacks a source, a destination or destination NULL bits", c);
+		a.src[c] = (const uint64_t *)cols[c].src;
+		a.src_null[c] = cols[c].src_nullbits;
+		a.dst[c] = (uint64_t *)cols[c].dst;
+		a.dst_null[c] = cols[c].dst_nullbits;
+		a.slot[c] = 0xFF;
+		if (cols[c].rid) {
+			int t = 0;
+			while (t < a.nrids && a.rid[t] != cols[c].rid)
+				t++;
+			if (t == a.nrids) {
+				if (a.nrids == MDB_GATHER_MAX_RIDS)
+					return mdb_set_err(ctx, -MIDORIDB_ERROR, "gather_cols: more than %d row-id vectors", MDB_GATHER_MAX_RIDS);
+				a.rid[a.nrids++] = cols[c].rid;
+			}
+			a.slot[c] = (uint8_t)t;
+		}
+	}
+	const uint32_t grid = (uint32_t)((n + (uint64_t)STREAM_THREADS * GC_ROUNDS - 1) / ((uint64_t)STREAM_THREADS * GC_ROUNDS));
+	MDB_LAUNCH(ctx, "gather_cols", k_gather_cols, grid, STREAM_THREADS, a);
+	return MIDORIDB_OK;
+}
+
 /* DOUBLE equi-join keys: the join operators compare 8-byte words, the reference compares IEEE doubles
  * (cmp_double_value_to_value, reference src/engine/executor_select.c:440-460: `==`), which differ in two places -
  * -0.0 == +0.0 (different words) and NaN != NaN (equal words).  This pass makes the word comparison exact: -0.0 is

@@ -193,6 +193,142 @@ __device__ static inline void pred_eval_pair(const pred_args &p, uint64_t k0, bo
 	out[1] = both && (st1 & 1);
 }
 
+/* bitmap -> compacted output columns, in row order: the surviving rows of up to FP_MAX_COLS base columns are written at
+ * their final positions (block offset + rank inside the block); NULL bits are rebuilt one output word at a time. */
+#define FP_MAX_COLS 16
+struct fp_args {
+	const uint64_t *src[FP_MAX_COLS];
+	const uint64_t *src_null[FP_MAX_COLS];
+	uint64_t *dst[FP_MAX_COLS];
+	unsigned long long *dst_null[FP_MAX_COLS];	/* zero-filled before the launch: rows of one word may come from two blocks */
+	int ncols;
+};
+
+
+/* ---- single-pass scan + WHERE + projection (mdb_dev_filter_project) --------------------------------------------
+ * The predicate kernels below can finish the job themselves: a workgroup that knows how many of its 4096 rows pass
+ * learns how many pass in all the row blocks before it (decoupled look-back over one 8-byte word per block: flag +
+ * count in ONE word, stored and polled with agent-scope atomics - the granule form of the inter-workgroup hand-off,
+ * cdna_hip_programming.md Guideline 16) and writes its surviving rows of every projected column straight to their final
+ * positions.  The column is read once and the output written once: no bitmap pass, no scan launches, no selection
+ * vector.  Row blocks are handed out by a ticket counter, so every block a workgroup waits for has started before it;
+ * the poll is bounded all the same (status bit 8 on time-out: reported as an error, never a hang). */
+struct fp_fused {
+	fp_args cols;
+	unsigned long long *state;	/* [row blocks]: 0 = nothing yet; FZ_AGG | rows of the block; FZ_PFX | rows up to and including it */
+	uint32_t *ticket;
+	uint32_t *status;
+};
+#define FZ_AGG (1ull << 62)
+#define FZ_PFX (2ull << 62)
+#define FZ_VAL ((1ull << 62) - 1ull)
+#define FZ_TIMEOUT 256u
+#define FZ_TILES 1u			/* row blocks (of 4096 rows) per workgroup in the single-pass form (8 per workgroup, i.e. fewer look-backs, measured 25 % slower: less parallelism) */
+
+__device__ static inline uint32_t filt_block_id(const fp_fused &fz)
+{
+	__shared__ uint32_t s_bid;
+	if (!fz.state)
+		return blockIdx.x;
+	if (threadIdx.x == 0)
+		s_bid = atomicAdd(fz.ticket, 1u);
+	__syncthreads();
+	return s_bid;
+}
+
+__device__ static inline uint32_t filt_wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 1; d < MDB_WAVE; d <<= 1)
+		v += (uint32_t)__shfl_xor((int)v, d, MDB_WAVE);
+	return v;
+}
+
+/* cnt = rows of the workgroup's FZ_TILES row blocks (bid * FZ_TILES ...) that pass (uniform); their bitmap words are in
+ * bits[] (written by this workgroup before the barrier the caller has just passed) */
+__device__ static inline void filt_fused_tail(const fp_fused &fz, uint32_t bid, uint32_t cnt, const uint64_t *bits, uint64_t n)
+{
+	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_woff[FZ_TILES * FILT_WORDS_PER_BLOCK];
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint64_t nwords = (n + 63) >> 6;
+	const uint64_t bword0 = (uint64_t)bid * FZ_TILES * FILT_WORDS_PER_BLOCK;
+	if (wave == 0) {
+		if (lane == 0)
+			__hip_atomic_store(&fz.state[bid], (bid == 0 ? FZ_PFX : FZ_AGG) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		/* the words' offsets inside the workgroup's rows, while the predecessors' counts travel */
+		uint32_t carry = 0;
+		for (uint32_t i = 0; i < FZ_TILES * FILT_WORDS_PER_BLOCK; i += MDB_WAVE) {
+			const uint64_t w = bword0 + i + lane;
+			const uint32_t c = w < nwords ? (uint32_t)__popcll(bits[w]) : 0;
+			const uint32_t incl = mdb_wave_incl_scan(c);
+			s_woff[i + lane] = carry + incl - c;
+			carry += (uint32_t)__shfl((int)incl, MDB_WAVE - 1, MDB_WAVE);
+		}
+		uint32_t excl = 0;
+		if (bid > 0) {
+			int64_t look = (int64_t)bid - 1;
+			uint32_t spins = 0;
+			for (;;) {
+				const int64_t idx = look - (int64_t)lane;	/* lane 0 = the nearest predecessor */
+				unsigned long long v = FZ_PFX;			/* in front of block 0: a prefix of zero rows */
+				for (;;) {
+					if (idx >= 0)
+						v = __hip_atomic_load(&fz.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (!__ballot((v >> 62) == 0))
+						break;
+					if (++spins > (1u << 22)) {
+						if (lane == 0)
+							atomicOr(fz.status, FZ_TIMEOUT);
+						v = FZ_PFX;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(2);
+				}
+				const uint64_t pm = __ballot((v >> 62) == 2);	/* predecessors that already know their inclusive prefix */
+				if (pm) {
+					const uint32_t first = (uint32_t)__ffsll((long long)pm) - 1u;
+					excl += filt_wave_sum_u32(lane <= first ? (uint32_t)(v & FZ_VAL) : 0u);
+					break;
+				}
+				excl += filt_wave_sum_u32((uint32_t)(v & FZ_VAL));
+				look -= MDB_WAVE;
+			}
+			if (lane == 0)
+				__hip_atomic_store(&fz.state[bid], FZ_PFX | (unsigned long long)(excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (lane == 0)
+			s_base = excl;
+	}
+	__syncthreads();
+	const uint32_t base_off = s_base;
+	const uint64_t lt = mdb_lanemask_lt();
+	const fp_args &a = fz.cols;
+	for (uint32_t sub = 0; sub < FZ_TILES; sub++) {
+#pragma unroll 2
+		for (int r = 0; r < FILT_WORDS_PER_WAVE; r++) {
+			const uint32_t wl = sub * FILT_WORDS_PER_BLOCK + wave * FILT_WORDS_PER_WAVE + r;
+			const uint64_t w = bword0 + wl;
+			if (w >= nwords)
+				break;
+			const uint64_t m = bits[w];
+			const bool keep = (m >> lane) & 1ull;
+			const uint64_t row = (w << 6) + lane;
+			const uint32_t pos = base_off + s_woff[wl] + (uint32_t)__popcll(m & lt);
+			for (int c = 0; c < a.ncols; c++) {
+				bool isnull = false;
+				if (keep) {
+					a.dst[c][pos] = a.src[c][row];
+					if (a.src_null[c])
+						isnull = mdb_bit_is_set(a.src_null[c], row);
+				}
+				if (a.dst_null[c] && isnull)
+					atomicOr(&a.dst_null[c][pos >> 6], 1ull << (pos & 63));
+			}
+		}
+	}
+}
+
 /* bit i of `even` -> bit 2i, bit i of `odd` -> bit 2i+1 (32 bits each) */
 __device__ static inline uint64_t filt_interleave32(uint32_t even, uint32_t odd)
 {
@@ -212,52 +348,124 @@ __device__ static inline uint64_t filt_interleave32(uint32_t even, uint32_t odd)
  * bitmap words.  MODE 0: predicate program, MODE 1: vals != 0. */
 template <int MODE>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_pair(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
-								 uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts)
+								 uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts, fp_fused fz)
 {
+	const uint32_t bid = filt_block_id(fz);
 	__shared__ uint32_t s_cnt;
 	if (threadIdx.x == 0)
 		s_cnt = 0;
 	__syncthreads();
 	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
 	uint32_t cnt = 0;
-	constexpr int AHEAD = 4;	/* spans whose first operand is requested before any is evaluated */
-	for (int r4 = 0; r4 < FILT_WORDS_PER_WAVE; r4 += 2 * AHEAD) {
-		uint64_t x0[AHEAD][2];
-		bool ok0[AHEAD][2];
+	const uint32_t tiles = fz.state ? FZ_TILES : 1u;	/* single pass: FZ_TILES consecutive row blocks per workgroup, one look-back */
+	for (uint32_t sub = 0; sub < tiles; sub++) {
+		const uint64_t word0 = ((uint64_t)bid * tiles + sub) * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+		constexpr int AHEAD = 4;	/* spans whose first operand is requested before any is evaluated */
+		for (int r4 = 0; r4 < FILT_WORDS_PER_WAVE; r4 += 2 * AHEAD) {
+			uint64_t x0[AHEAD][2];
+			bool ok0[AHEAD][2];
 #pragma unroll
-		for (int u = 0; u < AHEAD; u++) {
-			const uint64_t k0 = ((word0 + r4 + 2 * u) << 6) + 2ull * mdb_lane();
-			x0[u][0] = x0[u][1] = 0;
-			ok0[u][0] = ok0[u][1] = false;
-			if (k0 < n) {
-				if (MODE == 1) {
-					if (k0 + 1 < n) {
-						const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + k0);
-						x0[u][0] = q.x;
-						x0[u][1] = q.y;
+			for (int u = 0; u < AHEAD; u++) {
+				const uint64_t k0 = ((word0 + r4 + 2 * u) << 6) + 2ull * mdb_lane();
+				x0[u][0] = x0[u][1] = 0;
+				ok0[u][0] = ok0[u][1] = false;
+				if (k0 < n) {
+					if (MODE == 1) {
+						if (k0 + 1 < n) {
+							const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + k0);
+							x0[u][0] = q.x;
+							x0[u][1] = q.y;
+						} else {
+							x0[u][0] = (uint64_t)vals[k0];
+						}
 					} else {
-						x0[u][0] = (uint64_t)vals[k0];
+						pred_load_pair(p.cols[0], k0, k0 + 1 < n, x0[u], ok0[u]);
 					}
-				} else {
-					pred_load_pair(p.cols[0], k0, k0 + 1 < n, x0[u], ok0[u]);
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < AHEAD; u++) {
+				const uint64_t word = word0 + r4 + 2 * u;
+				const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
+				bool pass[2] = { false, false };
+				if (k0 < n) {
+					if (MODE == 1) {
+						pass[0] = x0[u][0] != 0;
+						pass[1] = x0[u][1] != 0;
+					} else {
+						pred_eval_pair(p, k0, k0 + 1 < n, x0[u], ok0[u], pass);
+					}
+				}
+				const uint64_t m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+				if ((word << 6) < n) {
+					const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
+					const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
+					if (mdb_lane() == 0) {
+						bits[word] = wa;
+						if (((word + 1) << 6) < n)
+							bits[word + 1] = wb;
+					}
+					cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
 				}
 			}
 		}
+	}
+	if (mdb_lane() == 0 && cnt)
+		atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (fz.state) {
+		filt_fused_tail(fz, bid, s_cnt, bits, n);
+		return;
+	}
+	if (threadIdx.x == 0)
+		block_counts[bid] = s_cnt;
+}
+
+/* The commonest predicate - ONE comparison of an INT64 base-table column with a constant (BASELINE config 1:
+ * WHERE v > 500000) - without the program interpreter: the interpreter costs ~200 vector instructions per 128
+ * tuples, which caps it near 3 TB/s, while a read-only stream reaches 6 TB/s on this chip
+ * (profiles/micro/read_bw.hip).  Same bitmap / block-count output as k_pred_bits_pair. */
+template <int CMP>
+__global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_cmp1(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
+								 int64_t imm, uint64_t n, uint64_t *__restrict__ bits,
+								 uint32_t *__restrict__ block_counts, fp_fused fz)
+{
+	const uint32_t bid = filt_block_id(fz);
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0)
+		s_cnt = 0;
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	uint32_t cnt = 0;
+	const uint32_t tiles = fz.state ? FZ_TILES : 1u;	/* single pass: FZ_TILES consecutive row blocks per workgroup, one look-back */
+	for (uint32_t sub = 0; sub < tiles; sub++) {
+		const uint64_t word0 = ((uint64_t)bid * tiles + sub) * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+		auto cmp = [&](int64_t a) -> bool {
+			return CMP == MDB_CMP_LT ? a < imm : CMP == MDB_CMP_GT ? a > imm : CMP == MDB_CMP_NE ? a != imm : CMP == MDB_CMP_EQ ? a == imm
+			       : CMP == MDB_CMP_LE ? a <= imm : a >= imm;
+		};
+		constexpr int SPANS = FILT_WORDS_PER_WAVE / 2;
+		longlong2 q[SPANS];
 #pragma unroll
-		for (int u = 0; u < AHEAD; u++) {
-			const uint64_t word = word0 + r4 + 2 * u;
+		for (int u = 0; u < SPANS; u++) {	/* every load of the wave's 8 spans is in flight before the first compare */
+			const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * mdb_lane();
+			q[u] = make_longlong2(0, 0);
+			if (k0 + 1 < n)
+				q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
+			else if (k0 < n)
+				q[u].x = vals[k0];
+		}
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t word = word0 + 2 * u;
 			const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
-			bool pass[2] = { false, false };
-			if (k0 < n) {
-				if (MODE == 1) {
-					pass[0] = x0[u][0] != 0;
-					pass[1] = x0[u][1] != 0;
-				} else {
-					pred_eval_pair(p, k0, k0 + 1 < n, x0[u], ok0[u], pass);
-				}
+			bool p0 = k0 < n && cmp(q[u].x), p1 = k0 + 1 < n && cmp(q[u].y);
+			if (nullbits && k0 < n) {
+				const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
+				p0 = p0 && !(w & 1ull);
+				p1 = p1 && !(w & 2ull);
 			}
-			const uint64_t m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+			const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
 			if ((word << 6) < n) {
 				const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
 				const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
@@ -273,68 +481,150 @@ __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_pair(pred_args p, co
 	if (mdb_lane() == 0 && cnt)
 		atomicAdd(&s_cnt, cnt);
 	__syncthreads();
+	if (fz.state) {
+		filt_fused_tail(fz, bid, s_cnt, bits, n);
+		return;
+	}
 	if (threadIdx.x == 0)
-		block_counts[blockIdx.x] = s_cnt;
+		block_counts[bid] = s_cnt;
 }
 
-/* The commonest predicate - ONE comparison of an INT64 base-table column with a constant (BASELINE config 1:
- * WHERE v > 500000) - without the program interpreter: the interpreter costs ~200 vector instructions per 128
- * tuples, which caps it near 3 TB/s, while a read-only stream reaches 6 TB/s on this chip
- * (profiles/micro/read_bw.hip).  Same bitmap / block-count output as k_pred_bits_pair. */
-template <int CMP>
-__global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_cmp1(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
-								 int64_t imm, uint64_t n, uint64_t *__restrict__ bits,
-								 uint32_t *__restrict__ block_counts)
+/* Single-pass scan + WHERE + projection for that commonest predicate: the workgroup's 4096 rows are loaded ONCE with
+ * 16-byte loads and stay in registers while it learns - by look-back over the row blocks in front of it - where its
+ * survivors go; every projected column is then written at its final position (the predicate's own column from the
+ * registers, the others from 16-byte loads of the same rows).  Traffic = the algorithmic bytes: the column read once,
+ * the survivors written once.  1024-thread workgroups (16384 rows each): the prefix travels along the row blocks at about
+ * 64 blocks per L2 round trip, so with 4096-row blocks it - not HBM - bounded the kernel (0.50 ms for 10^8 rows). */
+#define SP_THREADS 1024
+#define SP_WAVES (SP_THREADS / MDB_WAVE)
+
+template <int CMP, int SPANS>	/* SPANS = 128-row spans per wave: 8 = 16384 rows per workgroup */
+__global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
+								    int64_t imm, uint64_t n, fp_fused fz)
 {
-	__shared__ uint32_t s_cnt;
-	if (threadIdx.x == 0)
-		s_cnt = 0;
-	__syncthreads();
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
-	uint32_t cnt = 0;
+	const uint32_t bid = filt_block_id(fz);
+	__shared__ uint32_t s_wcnt[SP_WAVES];
+	__shared__ uint32_t s_base;
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint64_t word0 = ((uint64_t)bid * SP_WAVES + wave) * (2 * SPANS);
 	auto cmp = [&](int64_t a) -> bool {
 		return CMP == MDB_CMP_LT ? a < imm : CMP == MDB_CMP_GT ? a > imm : CMP == MDB_CMP_NE ? a != imm : CMP == MDB_CMP_EQ ? a == imm
 		       : CMP == MDB_CMP_LE ? a <= imm : a >= imm;
 	};
-	constexpr int SPANS = FILT_WORDS_PER_WAVE / 2;
 	longlong2 q[SPANS];
 #pragma unroll
-	for (int u = 0; u < SPANS; u++) {	/* every load of the wave's 8 spans is in flight before the first compare */
-		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * mdb_lane();
+	for (int u = 0; u < SPANS; u++) {
+		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
 		q[u] = make_longlong2(0, 0);
 		if (k0 + 1 < n)
 			q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
 		else if (k0 < n)
 			q[u].x = vals[k0];
 	}
-#pragma unroll
-	for (int u = 0; u < SPANS; u++) {
-		const uint64_t word = word0 + 2 * u;
-		const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
-		bool p0 = k0 < n && cmp(q[u].x), p1 = k0 + 1 < n && cmp(q[u].y);
+	/* survivors among the even / odd rows of a 128-row span (evaluated twice - to count and to place - rather than kept:
+	 * sixteen 64-bit masks beside the rows cost 150 registers, i.e. two thirds of the occupancy) */
+	auto survivors = [&](int u, bool *p0, bool *p1) {
+		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
+		*p0 = k0 < n && cmp(q[u].x);
+		*p1 = k0 + 1 < n && cmp(q[u].y);
 		if (nullbits && k0 < n) {
 			const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
-			p0 = p0 && !(w & 1ull);
-			p1 = p1 && !(w & 2ull);
+			*p0 = *p0 && !(w & 1ull);
+			*p1 = *p1 && !(w & 2ull);
 		}
-		const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-		if ((word << 6) < n) {
-			const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
-			const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
-			if (mdb_lane() == 0) {
-				bits[word] = wa;
-				if (((word + 1) << 6) < n)
-					bits[word + 1] = wb;
+	};
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int u = 0; u < SPANS; u++) {
+		bool p0, p1;
+		survivors(u, &p0, &p1);
+		cnt += (uint32_t)__popcll(__ballot(p0)) + (uint32_t)__popcll(__ballot(p1));
+	}
+	if (lane == 0)
+		s_wcnt[wave] = cnt;
+	__syncthreads();
+	if (wave == 0) {
+		uint32_t total = 0;
+#pragma unroll
+		for (int w = 0; w < SP_WAVES; w++)
+			total += s_wcnt[w];
+		if (lane == 0)
+			__hip_atomic_store(&fz.state[bid], (bid == 0 ? FZ_PFX : FZ_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		uint32_t excl = 0;
+		if (bid > 0) {
+			int64_t look = (int64_t)bid - 1;
+			uint32_t spins = 0;
+			for (;;) {
+				const int64_t idx = look - (int64_t)lane;
+				unsigned long long v = FZ_PFX;
+				for (;;) {
+					if (idx >= 0)
+						v = __hip_atomic_load(&fz.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (!__ballot((v >> 62) == 0))
+						break;
+					if (++spins > (1u << 22)) {
+						if (lane == 0)
+							atomicOr(fz.status, FZ_TIMEOUT);
+						v = FZ_PFX;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(2);
+				}
+				const uint64_t pm = __ballot((v >> 62) == 2);
+				if (pm) {
+					const uint32_t first = (uint32_t)__ffsll((long long)pm) - 1u;
+					excl += filt_wave_sum_u32(lane <= first ? (uint32_t)(v & FZ_VAL) : 0u);
+					break;
+				}
+				excl += filt_wave_sum_u32((uint32_t)(v & FZ_VAL));
+				look -= MDB_WAVE;
 			}
-			cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+			if (lane == 0)
+				__hip_atomic_store(&fz.state[bid], FZ_PFX | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (lane == 0)
+			s_base = excl;
+	}
+	__syncthreads();
+	uint32_t run = s_base;
+	for (uint32_t w = 0; w < wave; w++)
+		run += s_wcnt[w];
+	const uint64_t lt = mdb_lanemask_lt();
+	const fp_args &a = fz.cols;
+	for (int c = 0; c < a.ncols; c++) {
+		const bool same = a.src[c] == reinterpret_cast<const uint64_t *>(vals);	/* (uniform) the predicate's own column: still in registers */
+		uint32_t at = run;
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
+			bool p0, p1;
+			survivors(u, &p0, &p1);
+			const uint64_t m0u = __ballot(p0), m1u = __ballot(p1);
+			if (m0u | m1u) {
+				longlong2 x = q[u];
+				if (!same) {
+					x = make_longlong2(0, 0);
+					if (k0 + 1 < n)
+						x = *reinterpret_cast<const longlong2 *>(reinterpret_cast<const int64_t *>(a.src[c]) + k0);
+					else if (k0 < n)
+						x.x = (int64_t)a.src[c][k0];
+				}
+				const uint32_t pos0 = at + (uint32_t)__popcll(m0u & lt) + (uint32_t)__popcll(m1u & lt), pos1 = pos0 + (p0 ? 1u : 0u);
+				if (p0)
+					a.dst[c][pos0] = (uint64_t)x.x;
+				if (p1)
+					a.dst[c][pos1] = (uint64_t)x.y;
+				if (a.dst_null[c]) {	/* (a projected column other than the predicate's may hold NULLs in surviving rows) */
+					const uint64_t nw = a.src_null[c][k0 >> 6] >> (k0 & 63);
+					if (p0 && (nw & 1ull))
+						atomicOr(&a.dst_null[c][pos0 >> 6], 1ull << (pos0 & 63));
+					if (p1 && (nw & 2ull))
+						atomicOr(&a.dst_null[c][pos1 >> 6], 1ull << (pos1 & 63));
+				}
+			}
+			at += (uint32_t)__popcll(m0u) + (uint32_t)__popcll(m1u);
 		}
 	}
-	if (mdb_lane() == 0 && cnt)
-		atomicAdd(&s_cnt, cnt);
-	__syncthreads();
-	if (threadIdx.x == 0)
-		block_counts[blockIdx.x] = s_cnt;
 }
 
 /* The next commonest predicates - several comparisons of ONE INT64 base-table column with constants, all joined by AND
@@ -351,69 +641,77 @@ struct filt_terms {
 template <bool IS_OR>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_terms(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
 								  filt_terms t, uint64_t n, uint64_t *__restrict__ bits,
-								  uint32_t *__restrict__ block_counts)
+								  uint32_t *__restrict__ block_counts, fp_fused fz)
 {
+	const uint32_t bid = filt_block_id(fz);
 	__shared__ uint32_t s_cnt;
 	if (threadIdx.x == 0)
 		s_cnt = 0;
 	__syncthreads();
 	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
 	uint32_t cnt = 0;
-	auto eval = [&](int64_t a) -> bool {
-		bool r = !IS_OR;
-		for (int k = 0; k < t.n; k++) {
-			const int64_t imm = t.imm[k];
-			const int c = t.cmp[k];
-			const bool b = c == MDB_CMP_LT ? a < imm : c == MDB_CMP_GT ? a > imm : c == MDB_CMP_NE ? a != imm : c == MDB_CMP_EQ ? a == imm
-				       : c == MDB_CMP_LE ? a <= imm : a >= imm;
-			r = IS_OR ? (r || b) : (r && b);
-		}
-		return r;
-	};
-	constexpr int SPANS = FILT_WORDS_PER_WAVE / 2;
-	longlong2 q[SPANS];
-#pragma unroll
-	for (int u = 0; u < SPANS; u++) {
-		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * mdb_lane();
-		q[u] = make_longlong2(0, 0);
-		if (k0 + 1 < n)
-			q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
-		else if (k0 < n)
-			q[u].x = vals[k0];
-	}
-#pragma unroll
-	for (int u = 0; u < SPANS; u++) {
-		const uint64_t word = word0 + 2 * u;
-		const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
-		bool p0 = k0 < n && eval(q[u].x), p1 = k0 + 1 < n && eval(q[u].y);
-		if (nullbits && k0 < n) {
-			const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
-			if (t.null_passes) {
-				p0 = p0 || (w & 1ull);
-				p1 = (k0 + 1 < n) && (p1 || (w & 2ull));
-			} else {
-				p0 = p0 && !(w & 1ull);
-				p1 = p1 && !(w & 2ull);
+	const uint32_t tiles = fz.state ? FZ_TILES : 1u;	/* single pass: FZ_TILES consecutive row blocks per workgroup, one look-back */
+	for (uint32_t sub = 0; sub < tiles; sub++) {
+		const uint64_t word0 = ((uint64_t)bid * tiles + sub) * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
+		auto eval = [&](int64_t a) -> bool {
+			bool r = !IS_OR;
+			for (int k = 0; k < t.n; k++) {
+				const int64_t imm = t.imm[k];
+				const int c = t.cmp[k];
+				const bool b = c == MDB_CMP_LT ? a < imm : c == MDB_CMP_GT ? a > imm : c == MDB_CMP_NE ? a != imm : c == MDB_CMP_EQ ? a == imm
+					       : c == MDB_CMP_LE ? a <= imm : a >= imm;
+				r = IS_OR ? (r || b) : (r && b);
 			}
+			return r;
+		};
+		constexpr int SPANS = FILT_WORDS_PER_WAVE / 2;
+		longlong2 q[SPANS];
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * mdb_lane();
+			q[u] = make_longlong2(0, 0);
+			if (k0 + 1 < n)
+				q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
+			else if (k0 < n)
+				q[u].x = vals[k0];
 		}
-		const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-		if ((word << 6) < n) {
-			const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
-			const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
-			if (mdb_lane() == 0) {
-				bits[word] = wa;
-				if (((word + 1) << 6) < n)
-					bits[word + 1] = wb;
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t word = word0 + 2 * u;
+			const uint64_t k0 = (word << 6) + 2ull * mdb_lane();
+			bool p0 = k0 < n && eval(q[u].x), p1 = k0 + 1 < n && eval(q[u].y);
+			if (nullbits && k0 < n) {
+				const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
+				if (t.null_passes) {
+					p0 = p0 || (w & 1ull);
+					p1 = (k0 + 1 < n) && (p1 || (w & 2ull));
+				} else {
+					p0 = p0 && !(w & 1ull);
+					p1 = p1 && !(w & 2ull);
+				}
 			}
-			cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+			const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+			if ((word << 6) < n) {
+				const uint64_t wa = filt_interleave32((uint32_t)m0, (uint32_t)m1);
+				const uint64_t wb = filt_interleave32((uint32_t)(m0 >> 32), (uint32_t)(m1 >> 32));
+				if (mdb_lane() == 0) {
+					bits[word] = wa;
+					if (((word + 1) << 6) < n)
+						bits[word + 1] = wb;
+				}
+				cnt += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+			}
 		}
 	}
 	if (mdb_lane() == 0 && cnt)
 		atomicAdd(&s_cnt, cnt);
 	__syncthreads();
+	if (fz.state) {
+		filt_fused_tail(fz, bid, s_cnt, bits, n);
+		return;
+	}
 	if (threadIdx.x == 0)
-		block_counts[blockIdx.x] = s_cnt;
+		block_counts[bid] = s_cnt;
 }
 
 /* is the program "terms on ONE INT64 column, all ANDed or all ORed"?  (a NULL makes every term false - and with it both the
@@ -466,34 +764,42 @@ static bool filter_one_column_terms(const pred_args *p, filt_terms *t, int *slot
 /* MODE 0: general predicate program; MODE 1: "vals[k] != 0" over an int64 array */
 template <int MODE>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits(pred_args p, const int64_t *__restrict__ vals, uint64_t n,
-							    uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts)
+							    uint64_t *__restrict__ bits, uint32_t *__restrict__ block_counts, fp_fused fz)
 {
+	const uint32_t bid = filt_block_id(fz);
 	__shared__ uint32_t s_cnt;
 	if (threadIdx.x == 0)
 		s_cnt = 0;
 	__syncthreads();
 	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t word0 = (uint64_t)blockIdx.x * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
 	uint32_t cnt = 0;
+	const uint32_t tiles = fz.state ? FZ_TILES : 1u;	/* single pass: FZ_TILES consecutive row blocks per workgroup, one look-back */
+	for (uint32_t sub = 0; sub < tiles; sub++) {
+		const uint64_t word0 = ((uint64_t)bid * tiles + sub) * FILT_WORDS_PER_BLOCK + (uint64_t)wave * FILT_WORDS_PER_WAVE;
 #pragma unroll 4
-	for (int r = 0; r < FILT_WORDS_PER_WAVE; r++) {
-		const uint64_t word = word0 + r;
-		const uint64_t k = (word << 6) + mdb_lane();
-		bool pass = false;
-		if (k < n)
-			pass = MODE == 1 ? (vals[k] != 0) : pred_eval(p, k);
-		const uint64_t m = __ballot(pass);
-		if ((word << 6) < n) {
-			if (mdb_lane() == 0)
-				bits[word] = m;
-			cnt += (uint32_t)__popcll(m);
+		for (int r = 0; r < FILT_WORDS_PER_WAVE; r++) {
+			const uint64_t word = word0 + r;
+			const uint64_t k = (word << 6) + mdb_lane();
+			bool pass = false;
+			if (k < n)
+				pass = MODE == 1 ? (vals[k] != 0) : pred_eval(p, k);
+			const uint64_t m = __ballot(pass);
+			if ((word << 6) < n) {
+				if (mdb_lane() == 0)
+					bits[word] = m;
+				cnt += (uint32_t)__popcll(m);
+			}
 		}
 	}
 	if (mdb_lane() == 0 && cnt)
 		atomicAdd(&s_cnt, cnt);
 	__syncthreads();
+	if (fz.state) {
+		filt_fused_tail(fz, bid, s_cnt, bits, n);
+		return;
+	}
 	if (threadIdx.x == 0)
-		block_counts[blockIdx.x] = s_cnt;
+		block_counts[bid] = s_cnt;
 }
 
 __global__ __launch_bounds__(FILT_THREADS) void k_bits_to_sel(const uint64_t *__restrict__ bits, uint64_t n,
@@ -528,15 +834,19 @@ static inline uint32_t filt_blocks(uint64_t n) { return (uint32_t)((n + FILT_TUP
 size_t mdb_filter_arena_bytes(uint64_t n)
 {
 	const uint64_t nb = filt_blocks(n) + 1;
-	return mdb_align_up(((n + 63) / 64) * 8) + mdb_align_up(nb * 4) + mdb_align_up(mdb_scan_scratch_words(nb) * 4) + 1024;
+	return mdb_align_up(((n + 63) / 64) * 8) + mdb_align_up(nb * 4) + mdb_align_up(mdb_scan_scratch_words(nb) * 4) + mdb_align_up(nb * 8 + 64) + 1024;
 }
 
 /* Shared tail: bitmap + block counts (arena) -> scan -> selection vector.  *d_total = device
  * address of the number of selected tuples.  No host sync. */
 static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols, const int64_t *vals, uint64_t n, uint32_t *out_sel,
-		      uint32_t **d_total)
+		      uint32_t **d_total, const fp_fused *fuse = nullptr, uint32_t *last_block = nullptr)
 {
-	const uint32_t nb = filt_blocks(n);
+	fp_fused fz;
+	memset(&fz, 0, sizeof(fz));
+	if (fuse)
+		fz = *fuse;	/* single pass: the predicate kernel also compacts the projected columns (mdb_dev_filter_project) */
+	const uint32_t nb = fuse ? (filt_blocks(n) + FZ_TILES - 1) / FZ_TILES : filt_blocks(n);	/* workgroups */
 	uint64_t *bits = (uint64_t *)mdb_arena_take(ctx, ((n + 63) / 64) * 8);
 	uint32_t *bc = (uint32_t *)mdb_arena_take(ctx, ((size_t)nb + 1) * 4);
 	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nb + 1) * 4);
@@ -547,9 +857,9 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols
 		pred_args empty;
 		memset(&empty, 0, sizeof(empty));
 		if (((uintptr_t)vals & 15) == 0) {
-			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits_pair<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits_pair<1>, nb, FILT_THREADS, empty, vals, n, bits, bc, fz);
 		} else {
-			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits<1>, nb, FILT_THREADS, empty, vals, n, bits, bc);
+			MDB_LAUNCH(ctx, "compact_nonzero_bits", k_pred_bits<1>, nb, FILT_THREADS, empty, vals, n, bits, bc, fz);
 		}
 	} else {
 		/* base-table streams (no row-id vector, 16-byte aligned columns) take the paired 16-byte-load form */
@@ -559,31 +869,53 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols
 		const mdb_pred_insn &i0 = p->insn[0];
 		int tslot = 0;
 		bool tor = false;
-		if (direct && p->n_insns == 1 && i0.op == MDB_P_CMP_COL_CONST && i0.type == MDB_T_INT64) {
+		if (fuse && direct && p->n_insns == 1 && i0.op == MDB_P_CMP_COL_CONST && i0.type == MDB_T_INT64) {
+			/* single pass, rows kept in registers across the look-back */
+			const int64_t *v = (const int64_t *)p->cols[i0.a].values;
+			const uint64_t *nbits = p->cols[i0.a].nullbits;
+			/* 16384 rows per workgroup (8 spans per wave) measured 0.33 ms for 10^8 rows at 50 %, 8192 rows 0.36 ms
+			 * (profiles/micro/scan_project_exp.py) */
+			const uint64_t rows_per_block = (uint64_t)SP_WAVES * FILT_WORDS_PER_WAVE * 64;
+			const uint32_t nb = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
+			if (last_block)
+				*last_block = nb - 1;
+			switch (i0.cmp) {
+			case MDB_CMP_LT: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_LT, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			case MDB_CMP_GT: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_GT, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			case MDB_CMP_NE: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_NE, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			case MDB_CMP_EQ: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_EQ, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			case MDB_CMP_LE: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_LE, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			default: MDB_LAUNCH(ctx, "scan_project", (k_scan_project_cmp1<MDB_CMP_GE, 8>), nb, SP_THREADS, v, nbits, i0.imm, n, fz); break;
+			}
+		} else if (direct && p->n_insns == 1 && i0.op == MDB_P_CMP_COL_CONST && i0.type == MDB_T_INT64) {
 			const int64_t *v = (const int64_t *)p->cols[i0.a].values;
 			const uint64_t *nbits = p->cols[i0.a].nullbits;
 			switch (i0.cmp) {
-			case MDB_CMP_LT: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LT>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
-			case MDB_CMP_GT: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GT>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
-			case MDB_CMP_NE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_NE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
-			case MDB_CMP_EQ: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_EQ>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
-			case MDB_CMP_LE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
-			default: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc); break;
+			case MDB_CMP_LT: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LT>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
+			case MDB_CMP_GT: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GT>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
+			case MDB_CMP_NE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_NE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
+			case MDB_CMP_EQ: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_EQ>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
+			case MDB_CMP_LE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
+			default: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
 			}
 		} else if (filt_terms ft; direct && filter_one_column_terms(p, &ft, &tslot, &tor)) {
 			const int64_t *v = (const int64_t *)p->cols[tslot].values;
 			const uint64_t *nbits = p->cols[tslot].nullbits;
 			if (tor) {
-				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<true>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc);
+				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<true>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc, fz);
 			} else {
-				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<false>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc);
+				MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_terms<false>, nb, FILT_THREADS, v, nbits, ft, n, bits, bc, fz);
 			}
 		} else if (direct) {
-			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_pair<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_pair<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc, fz);
 		} else {
-			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc);
+			MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits<0>, nb, FILT_THREADS, *p, (const int64_t *)NULL, n, bits, bc, fz);
 		}
 	}
+	if (fuse && last_block && *last_block == 0xFFFFFFFFu)
+		*last_block = nb - 1;
+	if (fuse)
+		return MIDORIDB_OK;
 	int rc = mdb_scan_u32_inplace(ctx, bc, (uint64_t)nb + 1, scan_tmp);
 	if (rc)
 		return rc;
@@ -597,12 +929,116 @@ int mdb_filter_nonzero64(mdb_dev_ctx *ctx, const int64_t *vals, uint64_t n, uint
 	return filter_run(ctx, 1, NULL, 0, vals, n, out_sel, d_total);
 }
 
+static int filter_prepare(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols, int n_cols,
+			  uint64_t n, pred_args *p);
+
 extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols,
 			      int n_cols, uint64_t n, uint32_t *out_sel, uint64_t *out_count)
 {
 	*out_count = 0;
 	if (n == 0)
 		return MIDORIDB_OK;
+	pred_args p;
+	int rc = filter_prepare(ctx, prog, n_insns, cols, n_cols, n, &p);
+	if (rc)
+		return rc;
+	rc = mdb_arena_begin(ctx, mdb_filter_arena_bytes(n));
+	if (rc)
+		return rc;
+	uint32_t *d_total = NULL;
+	rc = filter_run(ctx, 0, &p, n_cols, NULL, n, out_sel, &d_total);
+	if (rc)
+		return rc;
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_count = h[0];
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_filter_project(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols,
+				      int n_cols, uint64_t n, const struct mdb_project_col *proj, int n_proj, uint64_t *out_count)
+{
+	if (!out_count || n_proj < 0 || n_proj > FP_MAX_COLS || (n_proj && !proj))
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter_project: between 0 and %d projected columns", FP_MAX_COLS);
+	*out_count = 0;
+	for (int c = 0; c < n_proj; c++) {
+		if (!proj[c].values || !proj[c].out_values || (proj[c].nullbits && !proj[c].out_nullbits))
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter_project: column %d lacks values or an output slot", c);
+		*proj[c].out_values = NULL;
+		if (proj[c].out_nullbits)
+			*proj[c].out_nullbits = NULL;
+	}
+	if (n == 0)
+		return MIDORIDB_OK;
+	pred_args p;
+	int rc = filter_prepare(ctx, prog, n_insns, cols, n_cols, n, &p);
+	if (rc)
+		return rc;
+	rc = mdb_arena_begin(ctx, mdb_filter_arena_bytes(n));
+	if (rc)
+		return rc;
+	/* The outputs are sized for every row (the number of survivors is known only when the single pass is over); the
+	 * buffers come from the context's recycling allocator, the caller reads *out_count rows of them. */
+	const uint32_t nb = (filt_blocks(n) + FZ_TILES - 1) / FZ_TILES;	/* workgroups = look-back words */
+	fp_fused fz;
+	memset(&fz, 0, sizeof(fz));
+	fz.cols.ncols = n_proj;
+	for (int c = 0; c < n_proj && !rc; c++) {
+		rc = mdb_dev_alloc(ctx, n * 8, proj[c].out_values);
+		if (!rc && proj[c].nullbits) {
+			const size_t bytes = (size_t)((n + 63) / 64) * 8;
+			rc = mdb_dev_alloc(ctx, bytes, (void **)proj[c].out_nullbits);
+			if (!rc)
+				rc = mdb_dev_memset(ctx, *proj[c].out_nullbits, 0, bytes);	/* rows of one word may come from two row blocks: the bits are OR-ed in */
+		}
+		fz.cols.src[c] = (const uint64_t *)proj[c].values;
+		fz.cols.src_null[c] = proj[c].nullbits;
+		fz.cols.dst[c] = rc ? NULL : (uint64_t *)*proj[c].out_values;
+		fz.cols.dst_null[c] = (rc || !proj[c].nullbits) ? NULL : (unsigned long long *)*proj[c].out_nullbits;
+	}
+	uint64_t *h = ctx->h_pinned;
+	if (!rc) {
+		fz.state = (unsigned long long *)mdb_arena_take(ctx, (size_t)nb * 8 + 64);
+		if (!fz.state)
+			rc = -MIDORIDB_INTERNAL;
+	}
+	if (!rc) {
+		fz.ticket = (uint32_t *)(fz.state + nb);
+		fz.status = ctx->d_status;
+		uint32_t *d_total = NULL;
+		if (hipMemsetAsync(fz.state, 0, (size_t)nb * 8 + 64, ctx->stream) != hipSuccess ||
+		    hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream) != hipSuccess)
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "filter_project: clearing the look-back words failed");
+		uint32_t last = 0xFFFFFFFFu;	/* the look-back word that holds the grand total: depends on the kernel's row-block size */
+		if (!rc)
+			rc = filter_run(ctx, 0, &p, n_cols, NULL, n, NULL, &d_total, &fz, &last);
+		if (!rc && (hipMemcpyAsync(&h[0], fz.state + last, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+			    hipMemcpyAsync(&h[1], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+			    hipStreamSynchronize(ctx->stream) != hipSuccess))
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "filter_project: %s", hipGetErrorString(hipGetLastError()));
+		if (!rc && (((uint32_t)h[1] & FZ_TIMEOUT) || (h[0] >> 62) != 2))
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "filter_project: the look-back over the row blocks did not complete");
+		if (!rc)
+			*out_count = h[0] & FZ_VAL;
+	}
+	if (rc) {
+		for (int c = 0; c < n_proj; c++) {
+			if (*proj[c].out_values)
+				mdb_dev_free(ctx, *proj[c].out_values);
+			*proj[c].out_values = NULL;
+			if (proj[c].out_nullbits && *proj[c].out_nullbits) {
+				mdb_dev_free(ctx, *proj[c].out_nullbits);
+				*proj[c].out_nullbits = NULL;
+			}
+		}
+	}
+	return rc;
+}
+
+static int filter_prepare(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, int n_insns, const struct mdb_col_binding *cols, int n_cols,
+			  uint64_t n, pred_args *pp)
+{
 	if (n >= 0xFFFFFFFFull)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: too many tuples");
 	if (n_insns <= 0 || n_insns > MDB_PRED_MAX_INSNS || n_cols < 0 || n_cols > MDB_PRED_MAX_SLOTS)
@@ -642,23 +1078,11 @@ extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog
 	if (depth != 1)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: malformed predicate program");
 
-	pred_args p;
+	pred_args &p = *pp;
 	memset(&p, 0, sizeof(p));
 	memcpy(p.insn, prog, sizeof(mdb_pred_insn) * (size_t)n_insns);
 	if (n_cols)
 		memcpy(p.cols, cols, sizeof(mdb_col_binding) * (size_t)n_cols);
 	p.n_insns = n_insns;
-
-	int rc = mdb_arena_begin(ctx, mdb_filter_arena_bytes(n));
-	if (rc)
-		return rc;
-	uint32_t *d_total = NULL;
-	rc = filter_run(ctx, 0, &p, n_cols, NULL, n, out_sel, &d_total);
-	if (rc)
-		return rc;
-	uint32_t *h = (uint32_t *)ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(h, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*out_count = h[0];
 	return MIDORIDB_OK;
 }

@@ -1183,8 +1183,10 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	struct exec x;
 	struct mdb_result *res = NULL;
 	char (*keys)[MDB_NAME_LEN] = NULL;
-	int *order = NULL, *key_tbl = NULL, *key_col = NULL;
-	int nkeys = 0, rc, has_count = 0;
+	int *order = NULL, *key_tbl = NULL, *key_col = NULL, *src = NULL;
+	int nkeys = 0, ncols = 0, rc, has_count = 0;
+	void **direct_vals = NULL;		/* scan + WHERE + projection plan: the result columns on the device, final */
+	uint64_t **direct_nulls = NULL;
 	double t0;
 	const struct mdb_expr *fkeys[MDB_MAX_TABS];
 	int fused;
@@ -1234,6 +1236,28 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			}
 		if ((rc = mdb_reference_column_order((const char (*)[MDB_NAME_LEN])keys, nkeys, order)))
 			goto out;
+	}
+
+	/* the result columns that are wanted, in the reference's order */
+	src = calloc((size_t)(nkeys ? nkeys : 1), sizeof(int));
+	if (!src) {
+		rc = -MIDORIDB_NOMEM;
+		goto out;
+	}
+	for (int k = 0; k < nkeys; k++) {
+		int key = order[k];
+		bool want = false;
+		if (key_tbl[key] < 0) {
+			want = true;
+		} else if (s->select_all) {
+			want = true;
+		} else {
+			for (int i = 0; i < s->nsel; i++)
+				if (s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == key_tbl[key] && s->sel[i]->col_idx == key_col[key])
+					want = true;
+		}
+		if (want)
+			src[ncols++] = key;
 	}
 
 	t0 = now_ms();
@@ -1338,6 +1362,45 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		x.fused = true;
 		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */
 		x.joined_rows = J;
+	} else if (s->ntabs == 1 && s->where && split_ok && !ws.nresidual && ws.npush[0] && !s->ngroup && !has_count && !s->distinct &&
+		   !s->norder && !s->having && !s->has_limit && s->tabs[0].t->nrows && ncols && ncols <= MDB_GATHER_MAX_COLS) {
+		/* ---- scan + WHERE + projection of one table (BASELINE configs[0] shape): the predicate bitmap is turned
+		 *      straight into the compacted result columns (mdb_dev_filter_project) - no selection vector, no gathers */
+		struct mdb_table *tb = s->tabs[0].t;
+		struct pred_prog p;
+		struct mdb_project_col pc[MDB_GATHER_MAX_COLS];
+		uint64_t m = 0;
+		memset(&p, 0, sizeof(p));
+		for (int i = 0; i < ws.npush[0]; i++)
+			if (pred_compile(&x, &p, ws.push[0][i]) || (i && pred_emit(&p, MDB_P_AND, 0, 0, 0, 0, 0))) {
+				ERR("execution phase: predicate too large for the device program (max %d steps, %d columns)\n", MDB_PRED_MAX_INSNS,
+				    MDB_PRED_MAX_SLOTS);
+				rc = -MIDORIDB_ERROR;
+				goto out;
+			}
+		direct_vals = calloc((size_t)ncols, sizeof(void *));
+		direct_nulls = calloc((size_t)ncols, sizeof(uint64_t *));
+		if (!direct_vals || !direct_nulls) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		for (int c = 0; c < ncols; c++) {
+			struct mdb_column *col = &tb->cols[key_col[src[c]]];
+			pc[c].values = col->d_data;
+			pc[c].nullbits = col->d_nullbits;
+			pc[c].out_values = &direct_vals[c];
+			pc[c].out_nullbits = &direct_nulls[c];
+		}
+		if (mdb_dev_filter_project(x.dev, p.insn, p.n, p.cols, p.ncols, tb->nrows, pc, ncols, &m)) {
+			rc = dev_fail(&x, "scan + filter + projection");
+			goto out;
+		}
+		for (int c = 0; c < ncols; c++)
+			if ((direct_vals[c] && track(&x, direct_vals[c])) || (direct_nulls[c] && track(&x, direct_nulls[c]))) {
+				rc = -MIDORIDB_NOMEM;
+				goto out;
+			}
+		x.n = m;
 	} else {
 		/* ---- general plan */
 		if (cat->dist && s->ntabs > 1) {
@@ -1436,50 +1499,35 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		uint64_t out_rows = count_only ? (x.n ? 1 : 0) : x.n;	/* the reference returns no row for an empty input */
 		if (count_only && s->has_limit && (s->limit_off > 0 || s->limit_cnt == 0))
 			out_rows = 0;
-		int ncols = 0;
-		int *src = calloc((size_t)nkeys, sizeof(int));
-		if (!src) {
-			rc = -MIDORIDB_NOMEM;
-			goto out;
-		}
-		for (int k = 0; k < nkeys; k++) {
-			int key = order[k];
-			bool want = false;
-			if (key_tbl[key] < 0) {
-				want = true;
-			} else if (s->select_all) {
-				want = true;
-			} else {
-				for (int i = 0; i < s->nsel; i++)
-					if (s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == key_tbl[key] &&
-					    s->sel[i]->col_idx == key_col[key])
-						want = true;
-			}
-			if (want)
-				src[ncols++] = key;
-		}
+		const void **d_vals = calloc((size_t)(ncols ? ncols : 1), sizeof(void *));
+		const uint64_t **d_nulls = calloc((size_t)(ncols ? ncols : 1), sizeof(uint64_t *));
 		res->ncols = ncols;
 		res->nrows = out_rows;
 		res->colname = calloc((size_t)(ncols ? ncols : 1), sizeof(*res->colname));
 		res->coltype = calloc((size_t)(ncols ? ncols : 1), sizeof(int));
 		res->data = calloc((size_t)(ncols ? ncols : 1), sizeof(int64_t *));
 		res->nullbits = calloc((size_t)(ncols ? ncols : 1), sizeof(uint64_t *));
-		if (!res->colname || !res->coltype || !res->data || !res->nullbits) {
-			free(src);
+		if (!d_vals || !d_nulls || !res->colname || !res->coltype || !res->data || !res->nullbits) {
+			free(d_vals);
+			free(d_nulls);
 			rc = -MIDORIDB_NOMEM;
 			goto out;
 		}
-		for (int c = 0; c < ncols; c++) {
+		/* pass 1: where every result column lives on the device.  Columns read through a row-id vector are gathered -
+		 * all of them in one launch per MDB_GATHER_MAX_COLS columns (mdb_dev_gather_cols), not one launch each */
+		struct mdb_gather_col gl[MDB_GATHER_MAX_COLS];
+		int ngl = 0, nrid = 0;
+		const uint32_t *seen_rid[MDB_GATHER_MAX_RIDS];
+		for (int c = 0; c < ncols && rc == MIDORIDB_OK; c++) {
 			int key = src[c];
 			memcpy(res->colname[c], keys[key], MDB_NAME_LEN);
 			res->data[c] = mdb_dev_host_alloc((size_t)(out_rows ? out_rows : 1) * 8);	/* pinned when large */
-			if (res->data[c] && out_rows <= 1)
-				res->data[c][0] = 0;
 			if (!res->data[c]) {
-				free(src);
 				rc = -MIDORIDB_NOMEM;
-				goto out;
+				break;
 			}
+			if (out_rows <= 1)
+				res->data[c][0] = 0;
 			if (key_tbl[key] < 0) {
 				res->coltype[c] = MDB_CT_INTEGER;
 				if (count_only) {
@@ -1487,72 +1535,91 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 						res->data[c][0] = (int64_t)x.n;
 				} else if (out_rows) {
 					if (!x.d_count) {	/* COUNT without aggregation cannot reach here (S4) */
-						free(src);
 						ERR("execution phase: internal error\n");
 						rc = -MIDORIDB_INTERNAL;
-						goto out;
+						break;
 					}
-					if (mdb_dev_d2h(x.dev, res->data[c], x.d_count, out_rows * 8)) {
-						free(src);
-						rc = dev_fail(&x, "reading COUNT(*)");
-						goto out;
-					}
+					d_vals[c] = x.d_count;
 				}
 				continue;
 			}
+			struct mdb_column *col = &s->tabs[key_tbl[key]].t->cols[key_col[key]];
+			res->coltype[c] = col->type;
+			if (!out_rows || count_only)
+				continue;
+			if (fused >= 0) {
+				d_vals[c] = x.d_fused_key;	/* only the group key can be selected (S4); both sides hold the same value */
+				continue;
+			}
+			if (direct_vals) {			/* scan + WHERE + projection plan: the columns are final already */
+				d_vals[c] = direct_vals[c];
+				d_nulls[c] = direct_nulls[c];
+				continue;
+			}
+			const uint32_t *rid = x.rid[key_tbl[key]];
+			if (!rid) {
+				d_vals[c] = col->d_data;
+				d_nulls[c] = col->d_nullbits;
+				continue;
+			}
 			{
-				struct mdb_column *col = &s->tabs[key_tbl[key]].t->cols[key_col[key]];
-				res->coltype[c] = col->type;
-				if (!out_rows || count_only)
-					continue;
-				if (fused >= 0) {
-					/* only the group key can be selected (S4); both sides hold the same value */
-					if (mdb_dev_d2h(x.dev, res->data[c], x.d_fused_key, out_rows * 8)) {
-						free(src);
-						rc = dev_fail(&x, "reading the group key");
-						goto out;
+				int t = 0;
+				while (t < nrid && seen_rid[t] != rid)
+					t++;
+				if (ngl == MDB_GATHER_MAX_COLS || (t == nrid && nrid == MDB_GATHER_MAX_RIDS)) {
+					if (mdb_dev_gather_cols(x.dev, gl, ngl, out_rows)) {
+						rc = dev_fail(&x, "projection gather");
+						break;
 					}
-					continue;
+					ngl = nrid = 0;
+					t = 0;
 				}
-				{
-					const uint32_t *rid = x.rid[key_tbl[key]];
-					const void *d_vals = col->d_data;
-					const uint64_t *d_nulls = col->d_nullbits;
-					if (rid) {
-						int64_t *v = dalloc(&x, out_rows * 8);
-						uint64_t *nb = col->d_nullbits ? dalloc(&x, ((out_rows + 63) / 64) * 8) : NULL;
-						if (!v || (col->d_nullbits && !nb) ||
-						    mdb_dev_gather64(x.dev, col->d_data, col->d_nullbits, rid, out_rows, v, nb)) {
-							free(src);
-							rc = dev_fail(&x, "projection gather");
-							goto out;
-						}
-						d_vals = v;
-						d_nulls = nb;
-					}
-					if (mdb_dev_d2h(x.dev, res->data[c], d_vals, out_rows * 8)) {
-						free(src);
-						rc = dev_fail(&x, "reading a result column");
-						goto out;
-					}
-					if (d_nulls) {
-						const uint64_t words = (out_rows + 63) / 64;
-						res->nullbits[c] = calloc((size_t)words, 8);
-						if (!res->nullbits[c] || mdb_dev_d2h(x.dev, res->nullbits[c], d_nulls, words * 8)) {
-							free(src);
-							rc = dev_fail(&x, "reading NULL bits");
-							goto out;
-						}
-						/* a NULL cell reads as 0 through query_column_int64(), like the reference
-						 * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
-						for (uint64_t i = 0; i < out_rows; i++)
-							if ((res->nullbits[c][i >> 6] >> (i & 63)) & 1)
-								res->data[c][i] = 0;
-					}
+				if (t == nrid)
+					seen_rid[nrid++] = rid;
+			}
+			int64_t *v = dalloc(&x, out_rows * 8);
+			uint64_t *nb = col->d_nullbits ? dalloc(&x, ((out_rows + 63) / 64) * 8) : NULL;
+			if (!v || (col->d_nullbits && !nb)) {
+				rc = dev_fail(&x, "projection gather");
+				break;
+			}
+			gl[ngl].src = col->d_data;
+			gl[ngl].src_nullbits = col->d_nullbits;
+			gl[ngl].rid = rid;
+			gl[ngl].dst = v;
+			gl[ngl].dst_nullbits = nb;
+			ngl++;
+			d_vals[c] = v;
+			d_nulls[c] = nb;
+		}
+		if (rc == MIDORIDB_OK && ngl && mdb_dev_gather_cols(x.dev, gl, ngl, out_rows))
+			rc = dev_fail(&x, "projection gather");
+		/* pass 2: device -> host */
+		for (int c = 0; c < ncols && rc == MIDORIDB_OK; c++) {
+			if (!d_vals[c] || !out_rows)
+				continue;
+			if (mdb_dev_d2h(x.dev, res->data[c], d_vals[c], out_rows * 8)) {
+				rc = dev_fail(&x, "reading a result column");
+				break;
+			}
+			if (d_nulls[c]) {
+				const uint64_t words = (out_rows + 63) / 64;
+				res->nullbits[c] = calloc((size_t)words, 8);
+				if (!res->nullbits[c] || mdb_dev_d2h(x.dev, res->nullbits[c], d_nulls[c], words * 8)) {
+					rc = dev_fail(&x, "reading NULL bits");
+					break;
 				}
+				/* a NULL cell reads as 0 through query_column_int64(), like the reference
+				 * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
+				for (uint64_t i = 0; i < out_rows; i++)
+					if ((res->nullbits[c][i >> 6] >> (i & 63)) & 1)
+						res->data[c][i] = 0;
 			}
 		}
-		free(src);
+		free(d_vals);
+		free(d_nulls);
+		if (rc)
+			goto out;
 	}
 	res->exec_ms = now_ms() - t0;
 	res->joined_rows = x.joined_rows;
@@ -1566,6 +1633,9 @@ out:
 	free(order);
 	free(key_tbl);
 	free(key_col);
+	free(src);
+	free(direct_vals);
+	free(direct_nulls);
 	return rc;
 }
 

@@ -33,6 +33,14 @@ class SortKey(ctypes.Structure):
     _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p), ("type", c_int32), ("desc", c_int32)]
 
 
+class GatherCol(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("src_nullbits", c_void_p), ("rid", c_void_p), ("dst", c_void_p), ("dst_nullbits", c_void_p)]
+
+
+class ProjectCol(ctypes.Structure):
+    _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("out_values", POINTER(c_void_p)), ("out_nullbits", POINTER(c_void_p))]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", c_uint32), ("total_ms", c_double)]
 
@@ -66,6 +74,9 @@ def _bind(lib):
         "mdb_dev_filter": ([P, POINTER(PredInsn), c_int, POINTER(ColBinding), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
         "mdb_dev_gather64": ([P, P, P, P, c_uint64, P, P], c_int),
         "mdb_dev_double_join_keys": ([P, P, P, P, c_uint64, P, P], c_int),
+        "mdb_dev_gather_cols": ([P, POINTER(GatherCol), c_int, c_uint64], c_int),
+        "mdb_dev_filter_project": ([P, POINTER(PredInsn), c_int, POINTER(ColBinding), c_int, c_uint64, POINTER(ProjectCol), c_int,
+                                    POINTER(c_uint64)], c_int),
         "mdb_dev_gather32": ([P, P, P, c_uint64, P], c_int),
         "mdb_dev_iota32": ([P, P, c_uint64], c_int),
         "mdb_dev_scatter_set64": ([P, P, P, P, c_uint64, c_int64, c_int], c_int),
@@ -99,7 +110,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
@@ -346,6 +357,56 @@ class DeviceCtx:
             dnull = torch.zeros((n + 63) // 64 or 1, dtype=torch.int64, device=self.device)
         self._chk(self.lib.mdb_dev_gather64(self.h, _ptr(src), _ptr(src_null), _ptr(idx), n, _ptr(dst), _ptr(dnull)), "gather64")
         return dst[:n], dnull
+
+    def gather_cols(self, cols, n):
+        """Whole-result projection in one launch: cols = [(src, src_nullbits or None, rid or None), ...] ->
+        [(values[n], nullbits words or None), ...]."""
+        arr = (GatherCol * len(cols))()
+        outs = []
+        for i, (src, nb, rid) in enumerate(cols):
+            dst = torch.empty(max(n, 1), dtype=src.dtype, device=self.device)
+            dnull = torch.zeros((n + 63) // 64 or 1, dtype=torch.int64, device=self.device) if nb is not None else None
+            arr[i] = GatherCol(src.data_ptr(), nb.data_ptr() if nb is not None else None, rid.data_ptr() if rid is not None else None,
+                               dst.data_ptr(), dnull.data_ptr() if dnull is not None else None)
+            outs.append((dst[:n], dnull))
+        self._chk(self.lib.mdb_dev_gather_cols(self.h, arr, len(cols), n), "gather_cols")
+        return outs
+
+    def filter_project(self, prog, cols, n, proj):
+        """Scan + WHERE + projection of one table: prog / cols as filter(); proj = [(values, nullbits or None), ...] ->
+        (count, [(values[count], nullbits words or None), ...]) - copies of the library-allocated outputs."""
+        insns = (PredInsn * max(len(prog), 1))()
+        for i, (op, cmp_, typ, a, b, imm) in enumerate(prog):
+            if typ == T_DOUBLE and isinstance(imm, float):
+                imm = int(np.float64(imm).view(np.int64))
+            insns[i] = PredInsn(op, cmp_, typ, a, b, 0, int(imm))
+        binds = (ColBinding * max(len(cols), 1))()
+        for i, (v, nb, rid) in enumerate(cols):
+            binds[i] = ColBinding(v.data_ptr(), nb.data_ptr() if nb is not None else None, rid.data_ptr() if rid is not None else None)
+        pcs = (ProjectCol * max(len(proj), 1))()
+        ov = [c_void_p() for _ in proj]
+        on = [c_void_p() for _ in proj]
+        for i, (v, nb) in enumerate(proj):
+            pcs[i] = ProjectCol(v.data_ptr(), nb.data_ptr() if nb is not None else None, ctypes.pointer(ov[i]), ctypes.pointer(on[i]))
+        cnt = c_uint64()
+        self._chk(self.lib.mdb_dev_filter_project(self.h, insns, len(prog), binds, len(cols), n, pcs, len(proj), byref(cnt)), "filter_project")
+        m = cnt.value
+        outs = []
+        for i, (v, nb) in enumerate(proj):
+            dst = torch.empty(max(m, 1), dtype=v.dtype, device=self.device)
+            dnull = None
+            if m:
+                self._chk(self.lib.mdb_dev_gather64(self.h, ov[i], None, None, m, _ptr(dst), None), "copy")
+                if nb is not None:
+                    words = (m + 63) // 64
+                    dnull = torch.empty(words, dtype=torch.int64, device=self.device)
+                    self._chk(self.lib.mdb_dev_gather64(self.h, on[i], None, None, words, _ptr(dnull), None), "copy")
+                self.sync()
+                self._chk(self.lib.mdb_dev_free(self.h, ov[i]), "free")
+                if nb is not None:
+                    self._chk(self.lib.mdb_dev_free(self.h, on[i]), "free")
+            outs.append((dst[:m], dnull))
+        return m, outs
 
     def double_join_keys(self, src, src_null, idx=None):
         """DOUBLE join keys as words that compare like IEEE `==`: (int64 words, NULL bits with the NaN rows added)."""

@@ -226,6 +226,62 @@ def test_gather64_with_nulls(dev):
     assert np.array_equal(_np(out2), src)
 
 
+def test_gather_cols_whole_projection_in_one_launch(dev):
+    """mdb_dev_gather_cols: 16 columns over 3 row-id vectors (and identity) in one launch = 16 separate gather64 calls."""
+    rng = np.random.default_rng(12)
+    n_src, n = 70_001, 123_457
+    rids = [rng.integers(0, n_src, n).astype(np.int32) for _ in range(3)] + [None]
+    d_rids = [dev.to_dev(r) if r is not None else None for r in rids]	# columns of one table share ONE row-id vector
+    cols, exp = [], []
+    for c in range(16):
+        src = rng.integers(-10**15, 10**15, n_src if rids[c % 4] is not None else n, dtype=np.int64)
+        nul = (rng.random(len(src)) < 0.2) if c % 3 else None
+        rid = rids[c % 4]
+        cols.append((dev.to_dev(src), dev.nullbits_dev(nul), d_rids[c % 4]))
+        idx = rid if rid is not None else np.arange(n)
+        exp.append((src[idx], None if nul is None else nul[idx]))
+    got = dev.gather_cols(cols, n)
+    for (v, nb), (ev, en) in zip(got, exp):
+        assert np.array_equal(_np(v), ev)
+        assert (nb is None) == (en is None)
+        if en is not None:
+            assert np.array_equal(D.unpack_nullbits(_np(nb).view(np.uint64), n), en)
+    # DOUBLE payload is moved as opaque 8-byte cells
+    x = rng.normal(0, 1, 1000)
+    (v, _), = dev.gather_cols([(dev.to_dev(x), None, dev.to_dev(np.arange(999, -1, -1, dtype=np.int32)))], 1000)
+    assert np.array_equal(_np(v).view(np.int64), x[::-1].view(np.int64))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 300_001])
+def test_filter_project_scan_where_projection(dev, n):
+    """mdb_dev_filter_project: the predicate bitmap goes straight into the compacted output columns (values and NULL bits in
+    row order) - equal to filter() + gather64 per column."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(-50, 50, n, dtype=np.int64)
+    b = rng.normal(0, 1, n)
+    na, nb_ = rng.random(n) < 0.1, rng.random(n) < 0.3
+    prog = [(D.P_CMP_COL_CONST, D.CMP_GT, D.T_INT64, 0, 0, -10), (D.P_CMP_COL_CONST, D.CMP_LT, D.T_DOUBLE, 1, 0, 0.5), (D.P_AND, 0, 0, 0, 0, 0)]
+    da, db, dna, dnb = dev.to_dev(a), dev.to_dev(b), dev.nullbits_dev(na), dev.nullbits_dev(nb_)
+    keep = (a > -10) & ~na & (b < 0.5) & ~nb_
+    m, outs = dev.filter_project(prog, [(da, dna, None), (db, dnb, None)], n, [(db, dnb), (da, None), (da, dna)])
+    assert m == int(keep.sum())
+    assert np.array_equal(_np(outs[0][0]).view(np.int64), b[keep].view(np.int64)) and np.array_equal(_np(outs[1][0]), a[keep])
+    assert outs[1][1] is None
+    if m:
+        assert not D.unpack_nullbits(_np(outs[0][1]).view(np.uint64), m).any()	# the predicate dropped every NULL of these columns
+    # a predicate on one column, projection of another with NULLs that survive
+    prog1 = [(D.P_CMP_COL_CONST, D.CMP_LE, D.T_INT64, 0, 0, 7)]
+    keep1 = (a <= 7) & ~na
+    m1, o1 = dev.filter_project(prog1, [(da, dna, None)], n, [(db, dnb)])
+    assert m1 == int(keep1.sum())
+    if m1:
+        assert np.array_equal(_np(o1[0][0]).view(np.int64), b[keep1].view(np.int64))
+        assert np.array_equal(D.unpack_nullbits(_np(o1[0][1]).view(np.uint64), m1), nb_[keep1])
+    # nothing survives / no projection
+    m0, o0 = dev.filter_project([(D.P_CONST, 0, 0, 0, 0, 0)], [], n, [(da, dna)])
+    assert m0 == 0 and o0[0][0].numel() == 0
+
+
 def test_double_join_keys_follow_ieee_equality(dev):
     """DOUBLE equi-join keys (reference cmp_double_value_to_value, executor_select.c:440-460: IEEE `==`): after the
     canonicalisation pass the join's word comparison gives exactly the pairs numpy's float `==` gives - -0.0 joins
