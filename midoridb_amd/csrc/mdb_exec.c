@@ -55,10 +55,9 @@ int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, si
 		return -MIDORIDB_ERROR;
 	}
 	for (int i = 0; i < c->ncols; i++) {
-		if (c->coltype[i] != MDB_CT_INTEGER && c->coltype[i] != MDB_CT_DOUBLE) {
-			ERR("column '%s': only INT/INTEGER and DOUBLE columns are supported by the MI355X path\n", c->colname[i]);
-			return -MIDORIDB_ERROR;
-		}
+		/* every reference column type can be declared (include/primitive/column.h:17-25).  INTEGER, DOUBLE, DATE,
+		 * DATETIME and TINYINT cells are 8-byte values that live on the device; VARCHAR cells stay on the host and a
+		 * statement is rejected only when it REFERENCES such a column */
 		for (int k = 0; k < i; k++)
 			if (strcmp(c->colname[i], c->colname[k]) == 0) {
 				ERR("duplicate column name: '%s'\n", c->colname[i]);
@@ -68,8 +67,11 @@ int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, si
 	t = mdb_table_new(c->name);
 	if (!t)
 		return -MIDORIDB_NOMEM;
-	for (int i = 0; i < c->ncols; i++)
+	for (int i = 0; i < c->ncols; i++) {
 		mdb_table_add_column(t, c->colname[i], c->coltype[i]);
+		t->cols[i].precision = c->colprec[i];
+		t->cols[i].not_null = c->notnull[i];
+	}
 	return mdb_catalog_add(cat, t);
 }
 
@@ -116,18 +118,55 @@ int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_r
 	rc = mdb_table_reserve(t, t->nrows + (uint64_t)ins->ntuples);
 	if (rc)
 		return rc;
-	/* validate everything before touching the table */
+	/* validate everything before touching the table: NOT NULL (semantic_insert.c:440-495), then the value / column type
+	 * rules of check_value_for_column (semantic_insert.c:283-330), with the reference's texts */
+	for (int c = 0; c < t->ncols; c++)
+		if (map[c] < 0 && t->cols[c].not_null) {
+			ERR("NOT NULL constraint failed: %s.%s\n", t->name, t->cols[c].name);
+			return -MIDORIDB_ERROR;
+		}
 	for (int r = 0; r < ins->ntuples; r++)
 		for (int c = 0; c < t->ncols; c++) {
 			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
-			if (!v || v->kind == MDB_EX_NULL)
+			const struct mdb_column *col = &t->cols[c];
+			int64_t tv;
+			if (!v)
 				continue;
-			if (t->cols[c].type == MDB_CT_INTEGER && v->kind != MDB_EX_INT) {
-				ERR("val requires an INTEGER column\n");
-				return -MIDORIDB_ERROR;
+			if (v->kind == MDB_EX_NULL) {
+				if (col->not_null) {
+					ERR("NOT NULL constraint failed: %s.%s\n", t->name, col->name);
+					return -MIDORIDB_ERROR;
+				}
+				continue;
 			}
-			if (t->cols[c].type == MDB_CT_DOUBLE && v->kind != MDB_EX_FLOAT) {
-				ERR("val requires a DOUBLE column\n");
+			if (v->kind == MDB_EX_STRING) {
+				if (col->type == MDB_CT_DATE || col->type == MDB_CT_DATETIME) {
+					if (!mdb_parse_time(v->sval, col->type, &tv)) {
+						ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", v->sval);
+						return -MIDORIDB_ERROR;
+					}
+				} else if (col->type == MDB_CT_VARCHAR) {
+					const size_t len = strlen(v->sval) - 2 + 1;	/* without the quotes, with the NUL */
+					if (len > (size_t)col->precision) {
+						ERR("column: '%s' supports up to %d ASCII chars, value contains %lu\n", col->name, col->precision,
+						    (unsigned long)len);
+						return -MIDORIDB_ERROR;
+					}
+				} else {
+					ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
+					return -MIDORIDB_ERROR;
+				}
+			} else if (v->kind == MDB_EX_INT && col->type != MDB_CT_INTEGER) {
+				ERR("val: '%ld' requires an INTEGER column\n", (long)v->ival);
+				return -MIDORIDB_ERROR;
+			} else if (v->kind == MDB_EX_FLOAT && col->type != MDB_CT_DOUBLE) {
+				ERR("val: '%f' requires a DOUBLE column\n", v->dval);
+				return -MIDORIDB_ERROR;
+			} else if (v->kind == MDB_EX_BOOL && col->type != MDB_CT_TINYINT) {
+				ERR("val: '%d' requires a TINYINT column\n", (int)v->ival);
+				return -MIDORIDB_ERROR;
+			} else if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_BOOL) {
+				ERR("only literal values can be inserted on the MI355X path\n");
 				return -MIDORIDB_ERROR;
 			}
 		}
@@ -136,16 +175,27 @@ int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_r
 		for (int c = 0; c < t->ncols; c++) {
 			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
 			struct mdb_column *col = &t->cols[c];
+			col->data[row] = 0;
 			if (!v || v->kind == MDB_EX_NULL) {
-				col->data[row] = 0;
 				col->nullbits[row >> 6] |= 1ull << (row & 63);
 				col->null_count++;
-			} else if (col->type == MDB_CT_INTEGER) {
-				col->data[row] = v->ival;
-				col->nullbits[row >> 6] &= ~(1ull << (row & 63));
-			} else {
+				continue;
+			}
+			col->nullbits[row >> 6] &= ~(1ull << (row & 63));
+			if (v->kind == MDB_EX_FLOAT) {
 				memcpy(&col->data[row], &v->dval, 8);
-				col->nullbits[row >> 6] &= ~(1ull << (row & 63));
+			} else if (v->kind == MDB_EX_STRING && col->type == MDB_CT_VARCHAR) {
+				const size_t len = strlen(v->sval) - 2;
+				char *str = malloc(len + 1);
+				if (!str)
+					return -MIDORIDB_NOMEM;	/* (rows already appended stay: the statement reports the failure) */
+				memcpy(str, v->sval + 1, len);
+				str[len] = 0;
+				col->data[row] = (int64_t)(intptr_t)str;
+			} else if (v->kind == MDB_EX_STRING) {
+				(void)mdb_parse_time(v->sval, col->type, &col->data[row]);	/* validated above */
+			} else {
+				col->data[row] = v->ival;	/* INT, BOOL (0 | 1) */
 			}
 		}
 		t->nrows++;
@@ -212,8 +262,8 @@ static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, siz
 	}
 	if (e->kind == MDB_EX_FIELD) {
 		e->type = s->tabs[e->tbl_idx].t->cols[e->col_idx].type;
-		if (e->type != MDB_CT_INTEGER && e->type != MDB_CT_DOUBLE) {
-			ERR("column '%s.%s': type not supported by the MI355X path\n", e->tbl, e->col);
+		if (!mdb_type_on_device(e->type)) {
+			ERR("column '%s.%s': VARCHAR columns are kept on the host and cannot be referenced on the MI355X path\n", e->tbl, e->col);
 			return -MIDORIDB_ERROR;
 		}
 	}
@@ -230,12 +280,30 @@ static bool is_having_clause(const char *clause)
 	return strcmp(clause, "having") == 0;
 }
 
-static int check_predicate(const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
+/* type of a comparison operand as the reference's semantic phase sees it (check_value_types_cmp, semantic_select.c:2135-2186):
+ * a raw string is a VARCHAR - SELECT does not box it into a DATE ("raw values are not auto-boxed", executor_select.c:193) -
+ * while DELETE / UPDATE parse it against a DATE / DATETIME column (semantic_delete.c:160-200): `dml` */
+static int operand_type(const struct mdb_expr *o, const struct mdb_expr *other, bool dml)
+{
+	switch (o->kind) {
+	case MDB_EX_FIELD: return o->type;
+	case MDB_EX_INT: case MDB_EX_COUNT: return MDB_CT_INTEGER;
+	case MDB_EX_FLOAT: return MDB_CT_DOUBLE;
+	case MDB_EX_BOOL: return MDB_CT_TINYINT;
+	case MDB_EX_STRING:
+		if (dml && other->kind == MDB_EX_FIELD && (other->type == MDB_CT_DATE || other->type == MDB_CT_DATETIME))
+			return other->type;
+		return MDB_CT_VARCHAR;
+	default: return -1;
+	}
+}
+
+static int check_predicate_x(const struct mdb_expr *e, const char *clause, bool dml, char *err, size_t errlen)
 {
 	int rc;
 	switch (e->kind) {
 	case MDB_EX_LOGOP:
-		if ((rc = check_predicate(e->kids[0], clause, err, errlen)) || (rc = check_predicate(e->kids[1], clause, err, errlen)))
+		if ((rc = check_predicate_x(e->kids[0], clause, dml, err, errlen)) || (rc = check_predicate_x(e->kids[1], clause, dml, err, errlen)))
 			return rc;
 		return MIDORIDB_OK;
 	case MDB_EX_CMP: {
@@ -244,19 +312,29 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 			const struct mdb_expr *o = e->kids[i];
 			if (o->kind == MDB_EX_COUNT && is_having_clause(clause))
 				continue;
-			if (o->kind != MDB_EX_FIELD && o->kind != MDB_EX_INT && o->kind != MDB_EX_FLOAT && o->kind != MDB_EX_NULL) {
-				ERR("expressions in %s clause must compare columns with INT/DOUBLE/NULL values\n", clause);
+			if (o->kind != MDB_EX_FIELD && o->kind != MDB_EX_INT && o->kind != MDB_EX_FLOAT && o->kind != MDB_EX_NULL &&
+			    o->kind != MDB_EX_BOOL && o->kind != MDB_EX_STRING) {
+				ERR("expressions in %s clause must compare columns with literal values\n", clause);
 				return -MIDORIDB_ERROR;
 			}
 		}
 		/* operand types must match exactly (reference check_value_types_cmp, semantic_select.c:2135-2186) */
 		{
-			int tl = l->kind == MDB_EX_FIELD ? l->type : ((l->kind == MDB_EX_INT || l->kind == MDB_EX_COUNT) ? MDB_CT_INTEGER : (l->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
-			int tr = r->kind == MDB_EX_FIELD ? r->type : ((r->kind == MDB_EX_INT || r->kind == MDB_EX_COUNT) ? MDB_CT_INTEGER : (r->kind == MDB_EX_FLOAT ? MDB_CT_DOUBLE : -1));
+			const int tl = operand_type(l, r, dml), tr = operand_type(r, l, dml);
+			int64_t tv;
 			if (tl >= 0 && tr >= 0 && tl != tr) {
 				ERR("comparison operands must have the same type\n");
 				return -MIDORIDB_ERROR;
 			}
+			if (tl == MDB_CT_VARCHAR || tr == MDB_CT_VARCHAR) {
+				ERR("VARCHAR values are kept on the host and cannot be compared on the MI355X path\n");
+				return -MIDORIDB_ERROR;
+			}
+			for (int i = 0; i < 2; i++)
+				if (e->kids[i]->kind == MDB_EX_STRING && !mdb_parse_time(e->kids[i]->sval, i ? tl : tr, &tv)) {
+					ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", e->kids[i]->sval);
+					return -MIDORIDB_ERROR;
+				}
 			if ((l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL) && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
 				ERR("NULL values can only use '=' or '<>' ops\n");
 				return -MIDORIDB_ERROR;
@@ -277,11 +355,12 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 		}
 		for (int i = 1; i < e->nkids; i++) {
 			const struct mdb_expr *v = e->kids[i];
-			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL) {
+			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL) {
 				ERR("IN-clause can only contain raw values\n");
 				return -MIDORIDB_ERROR;
 			}
 			if ((v->kind == MDB_EX_INT && e->kids[0]->type != MDB_CT_INTEGER) ||
+			    (v->kind == MDB_EX_BOOL && e->kids[0]->type != MDB_CT_TINYINT) ||
 			    (v->kind == MDB_EX_FLOAT && e->kids[0]->type != MDB_CT_DOUBLE)) {
 				ERR("comparison operands must have the same type\n");
 				return -MIDORIDB_ERROR;
@@ -295,6 +374,11 @@ static int check_predicate(const struct mdb_expr *e, const char *clause, char *e
 		ERR("expressions in %s clause must be a type of comparison\n", clause);
 		return -MIDORIDB_ERROR;
 	}
+}
+
+static int check_predicate(const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
+{
+	return check_predicate_x(e, clause, false, err, errlen);
 }
 
 static bool expr_has_count(const struct mdb_expr *e)
@@ -670,20 +754,33 @@ static int pred_emit(struct pred_prog *p, int op, int cmp, int type, int a, int 
 	return 0;
 }
 
-static int64_t lit_bits(const struct mdb_expr *v)
+/* the 8 bytes a literal stands for in a column of type coltype (a DATE / DATETIME string: its time_t, validated by
+ * check_predicate_x / the UPDATE checks) */
+static int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
 {
-	int64_t bits;
+	int64_t bits = 0;
 	if (v->kind == MDB_EX_FLOAT) {
 		memcpy(&bits, &v->dval, 8);
 		return bits;
 	}
+	if (v->kind == MDB_EX_STRING) {
+		(void)mdb_parse_time(v->sval, coltype, &bits);
+		return bits;
+	}
 	return v->ival;
+}
+
+static int64_t lit_bits(const struct mdb_expr *v)
+{
+	return lit_bits_for(v, MDB_CT_INTEGER);
 }
 
 static bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
 {
 	if (l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL)
 		return false;			/* executor_select.c:660-662 */
+	if (l->kind == MDB_EX_STRING || r->kind == MDB_EX_STRING)
+		return false;			/* (rejected by the type check; never evaluated) */
 	if (l->kind == MDB_EX_FLOAT) {
 		double a = l->dval, b = r->dval;
 		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
@@ -706,6 +803,8 @@ static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_ex
 		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
 		const bool lcol = l->kind == MDB_EX_FIELD || l->kind == MDB_EX_COUNT, rcol = r->kind == MDB_EX_FIELD || r->kind == MDB_EX_COUNT;
 		if (lcol && rcol) {
+			if (l->kind == MDB_EX_FIELD && l->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
 			a = pred_slot(x, p, l);
 			b = pred_slot(x, p, r);
 			if (a < 0 || b < 0)
@@ -717,11 +816,15 @@ static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_ex
 			const struct mdb_expr *f = lcol ? l : r, *v = lcol ? r : l;
 			if (v->kind == MDB_EX_NULL)	/* NULL operand: never true (executor_select.c:793-795) */
 				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			/* TINYINT (bool) operands only know = and <> upstream (cmp_bool_value_to_value, executor_select.c:484-494): false */
+			if (f->kind == MDB_EX_FIELD && f->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
 			a = pred_slot(x, p, f);
 			if (a < 0)
 				return -1;
 			return pred_emit(p, lcol ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
-					 (f->kind == MDB_EX_FIELD && f->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
+					 (f->kind == MDB_EX_FIELD && f->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64, a, 0,
+					 lit_bits_for(v, f->kind == MDB_EX_FIELD ? f->type : MDB_CT_INTEGER));
 		}
 		return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, const_cmp(e->op, l, r));
 	}
@@ -1716,7 +1819,7 @@ static int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct ex
 	s->tabs = tab;
 	s->ntabs = 1;
 	if (d->where) {
-		if ((rc = resolve_expr(s, d->where, err, errlen)) || (rc = check_predicate(d->where, "where", err, errlen)) ||
+		if ((rc = resolve_expr(s, d->where, err, errlen)) || (rc = check_predicate_x(d->where, "where", true, err, errlen)) ||
 		    (rc = dml_check_values(d->where, err, errlen)))
 			return rc;
 		if (dml_value_on_left(d->where)) {
@@ -1829,6 +1932,15 @@ int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		for (int c = 0; c < t->ncols; c++) {
 			struct mdb_column *col = &t->cols[c];
 			uint64_t nulls = 0;
+			if (col->type == MDB_CT_VARCHAR) {		/* the dropped rows' strings go with them */
+				uint64_t k = 0;
+				for (uint64_t r = 0; r < n_old; r++) {
+					if (k < n_keep && h_keep[k] == r)
+						k++;
+					else
+						free((void *)(intptr_t)col->data[r]);
+				}
+			}
 			for (uint64_t k = 0; k < n_keep; k++) {		/* ascending ids: in place */
 				const uint64_t r = h_keep[k];
 				const bool isnull = (col->nullbits[r >> 6] >> (r & 63)) & 1;
@@ -1896,8 +2008,8 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 			ERR("no such column: '%.128s'\n", d->assign[a].col);
 			return -MIDORIDB_ERROR;
 		}
-		if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL) {
-			ERR("only INT / DOUBLE / NULL literals can be assigned on the MI355X path\n");
+		if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL && v->kind != MDB_EX_STRING) {
+			ERR("only literal values can be assigned on the MI355X path\n");
 			return -MIDORIDB_ERROR;
 		}
 		if (v->kind == MDB_EX_INT && t->cols[acol[a]].type != MDB_CT_INTEGER) {
@@ -1906,6 +2018,33 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		}
 		if (v->kind == MDB_EX_FLOAT && t->cols[acol[a]].type != MDB_CT_DOUBLE) {
 			ERR("val: '%f' requires a DOUBLE column\n", v->dval);
+			return -MIDORIDB_ERROR;
+		}
+		if (v->kind == MDB_EX_BOOL && t->cols[acol[a]].type != MDB_CT_TINYINT) {
+			ERR("val: '%d' requires a TINYINT column\n", (int)v->ival);
+			return -MIDORIDB_ERROR;
+		}
+		if (v->kind == MDB_EX_STRING) {
+			const struct mdb_column *col = &t->cols[acol[a]];
+			int64_t tv;
+			if (col->type == MDB_CT_DATE || col->type == MDB_CT_DATETIME) {
+				if (!mdb_parse_time(v->sval, col->type, &tv)) {
+					ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", v->sval);
+					return -MIDORIDB_ERROR;
+				}
+			} else if (col->type == MDB_CT_VARCHAR) {
+				if (strlen(v->sval) - 2 + 1 > (size_t)col->precision) {
+					ERR("column: '%s' supports up to %d ASCII chars, value contains %lu\n", col->name, col->precision,
+					    (unsigned long)(strlen(v->sval) - 2 + 1));
+					return -MIDORIDB_ERROR;
+				}
+			} else {
+				ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
+				return -MIDORIDB_ERROR;
+			}
+		}
+		if (v->kind == MDB_EX_NULL && t->cols[acol[a]].not_null) {
+			ERR("NOT NULL constraint failed: %s.%s\n", t->name, t->cols[acol[a]].name);
 			return -MIDORIDB_ERROR;
 		}
 	}
@@ -1917,6 +2056,8 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		struct mdb_column *col = &t->cols[acol[a]];
 		const struct mdb_expr *v = d->assign[a].val;
 		const bool set_null = v->kind == MDB_EX_NULL;
+		if (!mdb_type_on_device(col->type))
+			continue;		/* VARCHAR: the host copy below is all there is */
 		if (set_null && !col->d_nullbits) {
 			const uint64_t words = (t->dev_cap + 63) / 64;
 			if (mdb_dev_alloc(x.dev, words * 8, (void **)&col->d_nullbits) || mdb_dev_memset(x.dev, col->d_nullbits, 0, words * 8)) {
@@ -1925,7 +2066,7 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 				goto out;
 			}
 		}
-		if (mdb_dev_scatter_set64(x.dev, col->d_data, col->d_nullbits, sel, m, set_null ? 0 : lit_bits(v), set_null)) {
+		if (mdb_dev_scatter_set64(x.dev, col->d_data, col->d_nullbits, sel, m, set_null ? 0 : lit_bits_for(v, col->type), set_null)) {
 			rc = dev_fail(&x, "updating a column");
 			t->dev_generation = 0;
 			goto out;
@@ -1954,10 +2095,33 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		for (int a = 0; a < d->nassign; a++) {
 			struct mdb_column *col = &t->cols[acol[a]];
 			const struct mdb_expr *v = d->assign[a].val;
-			const int64_t bits = v->kind == MDB_EX_NULL ? 0 : lit_bits(v);
+			const int64_t bits = v->kind == MDB_EX_NULL ? 0 : lit_bits_for(v, col->type);
 			for (uint64_t k = 0; k < m; k++) {
 				const uint64_t r = h_sel ? h_sel[k] : k;
 				const bool was_null = (col->nullbits[r >> 6] >> (r & 63)) & 1;
+				if (col->type == MDB_CT_VARCHAR) {	/* every row owns its string */
+					char *str = NULL;
+					if (v->kind == MDB_EX_STRING) {
+						const size_t len = strlen(v->sval) - 2;
+						str = malloc(len + 1);
+						if (!str) {
+							rc = -MIDORIDB_NOMEM;
+							goto out;
+						}
+						memcpy(str, v->sval + 1, len);
+						str[len] = 0;
+					}
+					free((void *)(intptr_t)col->data[r]);
+					col->data[r] = (int64_t)(intptr_t)str;
+					if (v->kind == MDB_EX_NULL) {
+						col->nullbits[r >> 6] |= 1ull << (r & 63);
+						col->null_count += !was_null;
+					} else {
+						col->nullbits[r >> 6] &= ~(1ull << (r & 63));
+						col->null_count -= was_null;
+					}
+					continue;
+				}
 				if (v->kind == MDB_EX_NULL) {
 					col->nullbits[r >> 6] |= 1ull << (r & 63);
 					col->null_count += !was_null;

@@ -47,7 +47,11 @@ enum mdb_coltype {
 
 struct mdb_column {
 	char name[MDB_NAME_LEN];
-	int type;			/* enum mdb_coltype; only the 8-byte INTEGER / DOUBLE types live on the device */
+	int type;			/* enum mdb_coltype.  INTEGER / DOUBLE / DATE / DATETIME (time_t) / TINYINT (0 | 1) cells are 8-byte values
+					 * mirrored on the device; a VARCHAR cell is a host pointer to a heap string (the reference's layout,
+					 * src/primitive/column.c:255-293) and never leaves the host: statements may not reference such a column */
+	int precision;			/* VARCHAR(n): n bytes including the NUL (reference column.precision) */
+	bool not_null;			/* NOT NULL / PRIMARY KEY (reference column.nullable == false, executor_create.c:37,53) */
 	int64_t *data;			/* host copy, 8 bytes per row */
 	uint64_t *nullbits;		/* host NULL bits (allocated with the column), bit set = NULL */
 	uint64_t null_count;
@@ -84,6 +88,10 @@ void mdb_catalog_free(struct mdb_catalog *cat);
 struct mdb_table *mdb_table_new(const char *name);
 void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev);
 int mdb_table_add_column(struct mdb_table *t, const char *name, int type);
+static inline bool mdb_type_on_device(int type) { return type != MDB_CT_VARCHAR; }
+/* time_t of a DATE ('%Y-%m-%d') / DATETIME ('%Y-%m-%d %H:%M:%S') literal, the reference's strptime + mktime
+ * (include/primitive/column.h:27-28, src/engine/executor_insert.c:15-40); false when it does not parse */
+bool mdb_parse_time(const char *quoted, int type, int64_t *out);
 int mdb_table_reserve(struct mdb_table *t, uint64_t rows);
 int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen);
 int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen);
@@ -114,6 +122,7 @@ struct mdb_expr {
 	char col[MDB_NAME_LEN];
 	int64_t ival;
 	double dval;
+	char *sval;			/* STRING literal, quotes included (heap) */
 	struct mdb_expr **kids;
 	int nkids;
 	/* resolution (FIELD): index into the plan's FROM tables and the column index there */
@@ -155,6 +164,9 @@ struct mdb_create {
 	int ncols;
 	char colname[MDB_MAX_COLS][MDB_NAME_LEN];
 	int coltype[MDB_MAX_COLS];
+	int colprec[MDB_MAX_COLS];	/* VARCHAR length */
+	bool notnull[MDB_MAX_COLS];	/* ATTR NOTNULL / ATTR PRIKEY in front of the COLUMNDEF (midorisql.y:468-472) */
+	bool pending_notnull;		/* (builder state: attributes seen for the column being defined) */
 };
 
 struct mdb_insert {

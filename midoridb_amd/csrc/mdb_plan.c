@@ -45,6 +45,7 @@ void mdb_expr_free(struct mdb_expr *e)
 	for (int i = 0; i < e->nkids; i++)
 		mdb_expr_free(e->kids[i]);
 	free(e->kids);
+	free(e->sval);
 	free(e);
 }
 
@@ -322,6 +323,10 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 				e->ival = atoi(t + 7);	/* 32-bit, as the reference (ast_select.c:75) */
 		} else if (starts(t, "STRING ")) {
 			e = ex_new(MDB_EX_STRING);
+			if (e && !(e->sval = strdup(t + 7))) {	/* the literal with its quotes, as the lexer hands it on */
+				mdb_expr_free(e);
+				e = NULL;
+			}
 		} else if (starts(t, "FLOAT ")) {
 			e = ex_new(MDB_EX_FLOAT);
 			if (e)
@@ -541,7 +546,14 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 			out->kind = MDB_ST_UPDATE;
 			continue;
 		/* ---- CREATE TABLE ---- */
-		} else if (!strcmp(t, "STARTCOL") || starts(t, "ATTR ")) {
+		} else if (!strcmp(t, "STARTCOL")) {
+			out->crt.pending_notnull = false;
+			continue;
+		} else if (starts(t, "ATTR ")) {
+			/* NOT NULL and PRIMARY KEY make the column non-nullable (reference executor_create.c:37,53); AUTO_INCREMENT
+			 * and UNIQUE are parsed and ignored upstream as well */
+			if (!strcmp(t + 5, "NOTNULL") || !strcmp(t + 5, "PRIKEY"))
+				out->crt.pending_notnull = true;
 			continue;
 		} else if (starts(t, "COLUMNDEF ")) {
 			struct mdb_create *c = &out->crt;
@@ -560,6 +572,9 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 			}
 			copy_name(c->colname[c->ncols], a);
 			c->coltype[c->ncols] = type;
+			c->colprec[c->ncols] = type == MDB_CT_VARCHAR ? x % 10000 : 8;
+			c->notnull[c->ncols] = c->pending_notnull;
+			c->pending_notnull = false;
 			c->ncols++;
 			continue;
 		} else if (starts(t, "CREATE ")) {

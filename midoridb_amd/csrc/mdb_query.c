@@ -278,8 +278,41 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 	rc = mdb_table_reserve(t, t->nrows + n);
 	if (rc)
 		return rc;
+	for (int c = 0; c < ncols; c++)		/* NOT NULL columns (reference semantic_insert.c:440-495) take no NULL flag */
+		if (t->cols[c].not_null && ((nulls && nulls[c]) || !cols[c]))
+			for (uint64_t i = 0; i < n; i++)
+				if (!cols[c] || nulls[c][i])
+					return -MIDORIDB_ERROR;
 	for (int c = 0; c < ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
+		if (col->type == MDB_CT_VARCHAR) {
+			/* cells are `const char *` (NULL pointer, NULL flag or cols[c] == NULL: SQL NULL); the strings are copied */
+			const char *const *strs = (const char *const *)cols[c];
+			for (uint64_t i = 0; i < n; i++) {
+				const uint64_t row = t->nrows + i;
+				const bool isnull = !strs || !strs[i] || (nulls && nulls[c] && nulls[c][i]);
+				col->data[row] = 0;
+				if (isnull) {
+					col->nullbits[row >> 6] |= 1ull << (row & 63);
+					col->null_count++;
+				} else {
+					size_t len = strlen(strs[i]);
+					char *str;
+					if (len + 1 > (size_t)col->precision)
+						len = (size_t)col->precision - 1;
+					str = malloc(len + 1);
+					if (!str)
+						return -MIDORIDB_NOMEM;
+					memcpy(str, strs[i], len);
+					str[len] = 0;
+					col->data[row] = (int64_t)(intptr_t)str;
+					col->nullbits[row >> 6] &= ~(1ull << (row & 63));
+				}
+			}
+			continue;
+		}
+		if (!cols[c])
+			return -MIDORIDB_ERROR;
 		memcpy(col->data + t->nrows, cols[c], n * 8);
 		for (uint64_t i = 0; i < n; i++) {
 			const uint64_t row = t->nrows + i;

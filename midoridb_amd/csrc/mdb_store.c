@@ -8,6 +8,9 @@
  * SELECT uploads only the appended tail into the device mirror (generation counter, spare capacity);
  * DELETE and UPDATE are applied on the mirror itself (mdb_exec.c) - SURVEY.md 8f row 1.
  */
+#define _XOPEN_SOURCE 700
+#define _DEFAULT_SOURCE
+#include <time.h>
 #include "mdb_host.h"
 
 struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name)
@@ -63,10 +66,39 @@ void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev)
 		return;
 	table_drop_device(t, dev);
 	for (int c = 0; c < t->ncols; c++) {
+		if (t->cols[c].type == MDB_CT_VARCHAR && t->cols[c].data)
+			for (uint64_t r = 0; r < t->nrows; r++)
+				free((void *)(intptr_t)t->cols[c].data[r]);	/* VARCHAR cells own their strings */
 		free(t->cols[c].data);
 		free(t->cols[c].nullbits);
 	}
 	free(t);
+}
+
+bool mdb_parse_time(const char *quoted, int type, int64_t *out)
+{
+	char buf[64];
+	struct tm tmv;
+	size_t len = strlen(quoted);
+	const char *fmt = type == MDB_CT_DATE ? "%Y-%m-%d" : "%Y-%m-%d %H:%M:%S";
+	time_t tv;
+	/* the token carries its quotes (midorisql.l STRING) */
+	if (len >= 2 && (quoted[0] == '\'' || quoted[0] == '"') && quoted[len - 1] == quoted[0]) {
+		quoted++;
+		len -= 2;
+	}
+	if (len >= sizeof(buf))
+		return false;
+	memcpy(buf, quoted, len);
+	buf[len] = 0;
+	memset(&tmv, 0, sizeof(tmv));
+	if (!strptime(buf, fmt, &tmv))
+		return false;
+	tv = mktime(&tmv);
+	if (tv == (time_t)-1)
+		return false;
+	*out = (int64_t)tv;
+	return true;
 }
 
 void mdb_catalog_free(struct mdb_catalog *cat)
@@ -175,8 +207,8 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 	const uint64_t from = append ? t->dev_rows : 0;
 	for (int c = 0; c < t->ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
-		if (col->type != MDB_CT_INTEGER && col->type != MDB_CT_DOUBLE)
-			continue;	/* never referenced by the device path (rejected at plan time) */
+		if (!mdb_type_on_device(col->type))
+			continue;	/* VARCHAR: host pointers, never referenced by the device path (rejected at plan time) */
 		if (t->nrows == 0)
 			continue;
 		rc = MIDORIDB_OK;

@@ -428,6 +428,85 @@ def double_joins(seed, count):
     return cases
 
 
+def typed_scripts():
+    """Tables that hold every reference column type (include/primitive/column.h:17-25): statements that reference the
+    INT / DOUBLE / DATE / DATETIME / TINYINT columns of tables which also contain VARCHAR columns, through the real
+    reference.  Recorded per statement: status, rows affected, SELECT results (a DATE / DATETIME cell reads as its time_t,
+    a TINYINT cell as 0 | 1); generated with TZ=UTC (mktime)."""
+    os.environ["TZ"] = "UTC"
+    import time
+    time.tzset()
+    S = "reference executor via oracle/_ref: mixed column types"
+    setup = [
+        "CREATE TABLE P (id INT, name VARCHAR(12), born DATE, seen DATETIME, ok TINYINT, w DOUBLE);",
+        "INSERT INTO P VALUES (1, 'ann', '1990-05-17', '2023-06-02 10:11:12', TRUE, 0.5);",
+        "INSERT INTO P VALUES (2, 'bob', '2001-02-03', '2023-06-03 00:00:00', FALSE, 1.5);",
+        "INSERT INTO P VALUES (3, NULL, NULL, NULL, NULL, NULL);",
+        "INSERT INTO P VALUES (4, 'dee', '2001-02-03', '2024-01-01 23:59:59', TRUE, 2.5);",
+        "INSERT INTO P (id, born) VALUES (5, '1970-01-02');",
+        "CREATE TABLE Q (qid INT, day DATE, note VARCHAR(5));",
+        "INSERT INTO Q VALUES (10, '2001-02-03', 'x'), (11, '1990-05-17', NULL), (12, '2030-12-31', 'zz'), (13, NULL, 'n');",
+    ]
+    scripts = {
+        "typed_select": setup + [
+            "SELECT id, born FROM P WHERE id > 1;",
+            "SELECT id, seen, ok FROM P WHERE born IS NOT NULL;",
+            "SELECT id FROM P WHERE ok = TRUE;",
+            "SELECT id FROM P WHERE ok <> TRUE;",
+            "SELECT id, w FROM P WHERE w >= 1.5 AND ok = FALSE;",
+            "SELECT id, qid FROM P INNER JOIN Q ON P.born = Q.day;",
+            "SELECT born, COUNT(*) FROM P INNER JOIN Q ON P.born = Q.day GROUP BY born;",
+            "SELECT COUNT(*) FROM P WHERE seen IS NULL;",
+            "SELECT id FROM P WHERE born = '2001-02-03';",
+            "SELECT id FROM P WHERE id = 'abc';",
+        ],
+        "typed_dml": setup + [
+            "DELETE FROM P WHERE born < '2000-01-01';",
+            "SELECT id, born FROM P;",
+            "UPDATE P SET seen = '2025-02-03 04:05:06', ok = FALSE WHERE id = 2;",
+            "UPDATE P SET name = 'zed' WHERE id = 4;",
+            "UPDATE P SET born = NULL WHERE ok = TRUE;",
+            "SELECT id, born, seen, ok FROM P;",
+            "DELETE FROM P WHERE seen >= '2025-01-01 00:00:00';",
+            "SELECT id FROM P;",
+            "INSERT INTO P VALUES (7, 'way too long a name', NULL, NULL, NULL, NULL);",
+            "INSERT INTO P VALUES (7, 'ok', '2020-13-45', NULL, NULL, NULL);",
+            "INSERT INTO P VALUES (7, 'ok', NULL, NULL, 5, NULL);",
+            "SELECT id FROM P;",
+        ],
+        "typed_not_null": [
+            "CREATE TABLE N (k INT PRIMARY KEY, v DOUBLE NOT NULL, note VARCHAR(8));",
+            "INSERT INTO N VALUES (1, 0.5, 'a');",
+            "INSERT INTO N VALUES (NULL, 0.5, 'a');",
+            "INSERT INTO N VALUES (2, NULL, 'a');",
+            "INSERT INTO N (k, note) VALUES (3, 'b');",
+            "INSERT INTO N (v, k) VALUES (1.5, 4);",
+            "SELECT k, v FROM N;",
+        ],
+    }
+    out = []
+    for name, stmts in scripts.items():
+        db = ref.RefDB()
+        steps = []
+        for sql in stmts:
+            st = {"sql": sql}
+            try:
+                rc = db.execute(sql)
+                st["status"] = "ok"
+                if rc == 1:
+                    names, rows = db.query(sql)
+                    st["result"] = {"names": names, "rows": [list(r) for r in rows]}
+                else:
+                    st["rows_affected"] = db.rows_affected()
+            except (ref.RefError, ValueError) as e:
+                st["status"] = "error"
+                st["error"] = str(e)
+            steps.append(st)
+        db.close()
+        out.append({"name": name, "source": S, "steps": steps})
+    return out
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref/libmidori_ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -440,6 +519,7 @@ def main():
         "config1.json": config1,
         "dml.json": lambda: dml_cases(99, 30),
         "double_join.json": lambda: double_joins(5, 16),
+        "typed_tables.json": typed_scripts,
     }
     only = set(sys.argv[1:])		# optional: file names to (re)generate; default all
     for fn, make in sets.items():

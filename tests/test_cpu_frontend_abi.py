@@ -138,8 +138,26 @@ def test_ddl_dml_on_host_and_loud_failure_without_device():
         with pytest.raises(QueryError):
             db.execute("CREATE TABLE A (z INT);")			# exists
         db.execute("CREATE TABLE IF NOT EXISTS A (z INT);")
-        with pytest.raises(QueryError):
-            db.execute("CREATE TABLE V (s VARCHAR(10));")		# unsupported on the device path
+        # every reference column type can be declared and filled (include/primitive/column.h:17-25); the value / column
+        # type rules and their texts are the reference's (semantic_insert.c:283-330, 440-495)
+        db.execute("CREATE TABLE V (id INT PRIMARY KEY, s VARCHAR(10), d DATE, ts DATETIME, ok TINYINT, w DOUBLE NOT NULL);")
+        assert db.execute("INSERT INTO V VALUES (1, 'abc', '2023-06-02', '2023-06-02 10:11:12', TRUE, 0.5), "
+                          "(2, NULL, NULL, NULL, FALSE, 1.5);") == 2
+        assert db.execute("INSERT INTO V (w, id) VALUES (2.5, 3);") == 1
+        for sql, frag in [("INSERT INTO V VALUES (NULL, 'x', NULL, NULL, NULL, 1.0);", "NOT NULL constraint failed: V.id"),
+                          ("INSERT INTO V (id) VALUES (9);", "NOT NULL constraint failed: V.w"),
+                          ("INSERT INTO V VALUES (4, 'much too long for ten', NULL, NULL, NULL, 1.0);", "supports up to 10 ASCII chars"),
+                          ("INSERT INTO V VALUES (4, 'x', 'not a date', NULL, NULL, 1.0);", "can't be parsed for DATE | DATETIME column"),
+                          ("INSERT INTO V VALUES (4, 5, NULL, NULL, NULL, 1.0);", "requires an INTEGER column"),
+                          ("INSERT INTO V VALUES (4, 'x', NULL, NULL, 1, 1.0);", "requires an INTEGER column"),
+                          ("INSERT INTO V VALUES (TRUE, 'x', NULL, NULL, NULL, 1.0);", "requires a TINYINT column"),
+                          ("INSERT INTO V VALUES (4, 'x', NULL, NULL, NULL, 'y');", "requires an VARCHAR() column"),
+                          ("UPDATE V SET w = NULL;", "NOT NULL constraint failed: V.w"),
+                          ("UPDATE V SET ok = 3;", "requires an INTEGER column"),
+                          ("UPDATE V SET d = 'yesterday';", "can't be parsed")]:
+            with pytest.raises(QueryError) as ei:
+                db.execute(sql)
+            assert frag in str(ei.value), (sql, str(ei.value))
         with pytest.raises(QueryError):
             db.execute("UPDATE A SET nosuch = 1;")
         with pytest.raises(QueryError):
