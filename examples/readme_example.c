@@ -10,7 +10,7 @@
  * tests/test_query_gpu.py::test_c_program_against_the_drop_in_library checks.
  */
 #include <stdio.h>
-#include <mdb_query.h>		/* upstream: #include <engine/query.h> */
+#include <engine/query.h>	/* the reference's include line: resolved by include/engine/query.h (forwarding header) */
 
 static int run(struct database *db, char *sql)
 {

@@ -7,7 +7,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(_HERE, "libmidoridb_amd.so")
+    """MDB_LIBRARY overrides the path (the sanitizer build `make -C midoridb_amd/csrc asan`, tests/test_sanitizers.py)."""
+    return os.environ.get("MDB_LIBRARY") or os.path.join(_HERE, "libmidoridb_amd.so")
 
 
 def load_library():

@@ -11,7 +11,7 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("MDB_ORACLE_LIBRARY") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `make -C oracle` (done by __graft_entry__.build())")
         L = ctypes.CDLL(path)
