@@ -43,6 +43,8 @@ def timed(dev, fn, reps=5, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "operators.json"))
+    ap.add_argument("--configs1", action="store_true", help="only the two BASELINE configs[0..1] shapes (scan_filter_1e8, join_payload_1e7): "
+                                                             "what profiles/collect.sh runs under rocprofv3")
     args = ap.parse_args()
     dev = DeviceCtx(0)
     res = {}
@@ -81,14 +83,32 @@ def main():
     def join_payload():
         l, r = dev.join_pairs(a_id, None, b_id, None)
         j = l.numel()
-        dev.gather_cols([(a_id, None, l), (b_id, None, r), (a_f, None, l), (b_f, None, r)], j)   # the whole projection: one launch
+        # the projection as the executor plans it (mdb_exec.c, projection pass 1): B's join key holds A's value in every joined
+        # tuple, so both key columns of SELECT * are ONE gather of A's column through the left row ids (ascending: near-sequential
+        # reads); the payload columns are gathered through their own row ids; one launch
+        dev.gather_cols([(a_id, None, l), (a_f, None, l), (b_f, None, r)], j)
         return j
     ms, kern, j = timed(dev, join_payload, reps=3, warmup=1)
     algo = 8 * 2 * n2 + 8 * 2 * n2 + 8 * 4 * j      # keys + payload columns read once, 4 result columns written
     res["join_payload_1e7"] = {"rows_per_table": n2, "joined_rows": j, "ms": ms, "joined_rows_per_s": j / (ms * 1e-3),
                                "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
-                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + the projection of 4 columns in one launch "
-                                       "(mdb_dev_gather_cols)"}
+                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + the projection in one launch "
+                                       "(mdb_dev_gather_cols): 3 gathers for the 4 result columns - the right key column is the left one"}
+
+    def join_payload4():
+        l, r = dev.join_pairs(a_id, None, b_id, None)
+        j = l.numel()
+        dev.gather_cols([(a_id, None, l), (b_id, None, r), (a_f, None, l), (b_f, None, r)], j)
+        return j
+    ms, kern, j = timed(dev, join_payload4, reps=3, warmup=1)
+    res["join_payload_1e7_four_gathers"] = {"rows_per_table": n2, "joined_rows": j, "ms": ms, "kernels_ms": kern,
+                                            "note": "the same with every result column gathered on its own (the round-1 plan)"}
+    if args.configs1:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+        print(json.dumps({k: {kk: vv for kk, vv in d.items() if kk != "kernels_ms"} for k, d in res.items()}, indent=1))
+        return
 
     # ---- single-table GROUP BY key COUNT(*) at 10^8 rows, 6.25M groups of 16
     keys = dev.gen_keys(n, 0, n, 43, n // 16)
@@ -149,6 +169,14 @@ def main():
                            "moved_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
                            "note": "mdb_dev_sort_perm, permutation keys < 2^27: packed-word path (the stable 8-bit LSD passes it "
                                    "replaces took 4.6 ms); moved_bytes is what this method moves, not a lower bound"}
+
+    def order_by_limit():
+        return dev.topk_perm([(k1, None, None, D.T_INT64, False)], n, 10)[1]
+    ms, kern, cand = timed(dev, order_by_limit, reps=3, warmup=1)
+    res["order_by_limit10_1e8"] = {"rows": n, "k": 10, "rows_sorted": cand, "ms": ms, "rows_per_s": n / (ms * 1e-3),
+                                   "algorithmic_GBs": n * 8 / (ms * 1e-3) / 1e9, "kernels_ms": kern,
+                                   "note": "mdb_dev_topk_perm: sample threshold + one filter pass + sort of the candidates, against order_by_1e8's "
+                                           "full sort; algorithmic bytes = one read of the key column"}
 
     def order_by2():
         return dev.sort_perm([(k2, None, None, D.T_INT64, True), (k1, None, None, D.T_INT64, False)], n).numel()

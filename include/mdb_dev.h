@@ -225,6 +225,13 @@ struct mdb_sort_key {
 	int32_t desc;			/* 0 ASC, 1 DESC */
 };
 int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *perm_out);
+/* ORDER BY ... LIMIT: perm_out[0..min(k, n)) = the first k entries of the permutation mdb_dev_sort_perm() would deliver,
+ * without sorting the table: a threshold from a sample of the first key, one filter pass that keeps the rows at or before
+ * it, the stable sort of those candidates only (*out_candidates, when not NULL: how many rows were sorted - n when the
+ * operator fell back to the full sort: small tables, k above an eighth of the rows, a first key with few distinct
+ * values).  Synchronous. */
+int mdb_dev_topk_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint64_t k, uint32_t *perm_out,
+		      uint64_t *out_candidates);
 
 /* SELECT DISTINCT (midorisql.y:203, equally parsed-but-ignored upstream): out_sel[0..*out_count) = ascending
  * stream positions of the FIRST occurrence of every distinct combination of the key columns (NULL equals NULL,

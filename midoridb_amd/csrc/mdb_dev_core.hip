@@ -184,6 +184,7 @@ extern "C" int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx)
 	return ctx->last_narrow;
 }
 
+
 extern "C" int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode)
 {
 	if (mode < 0 || mode > 2)

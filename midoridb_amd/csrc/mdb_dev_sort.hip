@@ -411,7 +411,8 @@ int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint6
 /* ---- tiny inputs: one workgroup ranks every row by counting ---------------------------------------------------------
  * Up to SORT_TINY_ROWS rows and SORT_PACK_MAX_KEYS columns: the (NULL flag, image) pairs of every column sit in LDS, row
  * i's place is the number of rows that sort before it (ties: the smaller stream position) - n^2 comparisons, all lanes
- * reading the same row j at the same time (LDS broadcast), one launch instead of the ~10 per column of the radix passes. */
+ * reading the same row j at the same time (LDS broadcast), one launch instead of the ~10 per column of the radix passes.
+ * One workgroup per 64 rows to rank (each loads all rows): 2048 rows took 1.16 ms on a single workgroup. */
 #define SORT_TINY_ROWS 2048u
 #define SORT_TINY_THREADS 1024
 
@@ -435,10 +436,16 @@ __global__ __launch_bounds__(SORT_TINY_THREADS) void k_sort_tiny(sort_tiny_args 
 			s_img[c][k] = isnull ? 0ull : sort_image(((const uint64_t *)key.values)[row], key.type, key.desc);
 		}
 	}
+	/* workgroup b ranks rows [64 b, 64 b + 64): lane = row i, wave w counts over the rows j = w, w + 16, ... (every lane of a
+	 * wave reads the same row j: LDS broadcast), the 16 partial counts meet in LDS */
+	__shared__ uint32_t s_rank[MDB_WAVE];
+	if (threadIdx.x < MDB_WAVE)
+		s_rank[threadIdx.x] = 0;
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < a.n; i += SORT_TINY_THREADS) {
+	const uint32_t i = blockIdx.x * MDB_WAVE + mdb_lane(), wave = threadIdx.x / MDB_WAVE;
+	if (i < a.n) {
 		uint32_t rank = 0;
-		for (uint32_t j = 0; j < a.n; j++) {
+		for (uint32_t j = wave; j < a.n; j += SORT_TINY_THREADS / MDB_WAVE) {
 			int cmp = 0;	/* -1: j before i, +1: i before j */
 			for (int c = 0; c < a.nkeys && cmp == 0; c++) {
 				const uint8_t fj = s_flag[c][j], fi = s_flag[c][i];
@@ -447,8 +454,11 @@ __global__ __launch_bounds__(SORT_TINY_THREADS) void k_sort_tiny(sort_tiny_args 
 			}
 			rank += cmp < 0 || (cmp == 0 && j < i);
 		}
-		perm_out[rank] = i;
+		atomicAdd(&s_rank[mdb_lane()], rank);
 	}
+	__syncthreads();
+	if (wave == 0 && i < a.n)
+		perm_out[s_rank[mdb_lane()]] = i;
 }
 
 static size_t sort_arena_bytes(uint64_t n)
@@ -485,7 +495,7 @@ static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int
 		if (types_ok) {		/* (an unknown type is reported by the general path below) */
 			ta.nkeys = nkeys;
 			ta.n = (uint32_t)n;
-			MDB_LAUNCH(ctx, "orderby_tiny", k_sort_tiny, 1, SORT_TINY_THREADS, ta, pm[0]);
+			MDB_LAUNCH(ctx, "orderby_tiny", k_sort_tiny, (ta.n + MDB_WAVE - 1) / MDB_WAVE, SORT_TINY_THREADS, ta, pm[0]);
 			*perm = pm[0];
 			return MIDORIDB_OK;
 		}
@@ -564,6 +574,182 @@ extern "C" int mdb_dev_sort_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *ke
 	MDB_HIP(ctx, hipMemcpyAsync(perm_out, perm, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ ORDER BY ... LIMIT k: the first k entries only
+ *
+ * Sorting 10^7 rows to keep 10 moves every row through the radix passes.  Instead: a strided sample of the first sort
+ * key is ordered (one workgroup), the sample element of a rank that leaves - with a wide margin - at least k rows at or
+ * before it becomes a threshold, ONE filter pass keeps the rows at or before the threshold in stream order (ties on the
+ * first key all included: whatever the further keys say, a row beyond the threshold has k rows before it), and only those
+ * candidates go through the stable sort with all keys.  A threshold that kept fewer than k rows (unrepresentative
+ * sample) or most of the table falls back to the full sort: the result is the same prefix of the same permutation. */
+#define TOPK_SAMPLE 2048u
+
+__global__ __launch_bounds__(256) void k_topk_sample(struct mdb_sort_key key, uint64_t stride, uint32_t s, uint64_t *__restrict__ vals,
+						     uint64_t *__restrict__ nullwords)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	bool isnull = false;
+	if (i < s) {
+		const uint64_t pos = (uint64_t)i * stride;
+		const uint64_t row = key.rid ? (uint64_t)key.rid[pos] : pos;
+		isnull = key.nullbits && mdb_bit_is_set(key.nullbits, row);
+		vals[i] = ((const uint64_t *)key.values)[row];
+	}
+	const uint64_t m = __ballot(isnull);
+	if (mdb_lane() == 0 && i < s)
+		nullwords[i >> 6] = m;
+}
+
+__global__ void k_topk_pick(const uint32_t *__restrict__ perm, uint32_t rank, const uint64_t *__restrict__ vals,
+			    const uint64_t *__restrict__ nullwords, uint64_t *__restrict__ out)
+{
+	const uint32_t p = perm[rank];
+	out[0] = vals[p];
+	out[1] = (nullwords[p >> 6] >> (p & 63)) & 1u;
+}
+
+/* *sorted: rows that went through a sort at the innermost level */
+static int topk_rec(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint64_t k, uint32_t *perm_out, uint64_t *sorted)
+{
+	int rc = MIDORIDB_OK;
+	*sorted = n;
+	uint32_t *full = NULL, *sel = NULL, *perm2 = NULL, *rids[MDB_SORT_MAX_KEYS] = { NULL };
+	uint64_t *vals = NULL;
+	uint64_t m = 0;
+	bool done = false;
+	/* rank of the threshold in the ordered sample: twice the expected rank of the k-th row plus a margin of 3 sample steps */
+	const uint64_t stride = n / TOPK_SAMPLE;
+	const uint64_t rank = stride ? 2 * ((k + stride - 1) / stride) + 3 : TOPK_SAMPLE;
+	if (n >= 8 * (uint64_t)TOPK_SAMPLE && rank < TOPK_SAMPLE / 4) {
+		const uint32_t s = TOPK_SAMPLE;
+		if ((rc = mdb_cached_alloc(ctx, (size_t)s * 8 + s / 8 + s * 4 + 16, (void **)&vals)))
+			return rc;
+		uint64_t *nullwords = vals + s;
+		uint32_t *sperm = (uint32_t *)(nullwords + s / 64);
+		uint64_t *picked = (uint64_t *)(sperm + s);
+		MDB_LAUNCH(ctx, "topk_sample", k_topk_sample, s / 256, 256, keys[0], stride, s, vals, nullwords);
+		struct mdb_sort_key sk = keys[0];
+		sk.values = vals;
+		sk.nullbits = nullwords;
+		sk.rid = NULL;
+		rc = mdb_dev_sort_perm(ctx, &sk, 1, s, sperm);
+		if (rc)
+			goto out;
+		MDB_LAUNCH(ctx, "topk_pick", k_topk_pick, 1, 1, sperm, (uint32_t)rank, vals, nullwords, picked);
+		uint64_t h[2];
+		if (hipMemcpyAsync(h, picked, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "topk_perm: reading the threshold failed");
+			goto out;
+		}
+		/* the rows at or before the threshold, in the order of the FIRST key (NULL first ascending, last descending) */
+		struct mdb_pred_insn prog[3];
+		int np = 0;
+		const bool thr_null = h[1] != 0, is_double = keys[0].type == MDB_T_DOUBLE;
+		double thr_d;
+		memcpy(&thr_d, &h[0], 8);
+		bool usable = !(is_double && thr_d != thr_d);
+		memset(prog, 0, sizeof(prog));
+		if (!keys[0].desc) {
+			if (keys[0].nullbits) {
+				prog[np].op = MDB_P_ISNULL;
+				np++;
+			}
+			if (!thr_null) {
+				prog[np].op = MDB_P_CMP_COL_CONST;
+				prog[np].cmp = MDB_CMP_LE;
+				prog[np].type = keys[0].type;
+				prog[np].imm = (int64_t)h[0];
+				np++;
+				if (np == 2)
+					prog[np++].op = MDB_P_OR;
+			}
+		} else if (thr_null) {
+			usable = false;		/* descending and the threshold is a NULL: every row is at or before it */
+		} else {
+			prog[np].op = MDB_P_CMP_COL_CONST;
+			prog[np].cmp = MDB_CMP_GE;
+			prog[np].type = keys[0].type;
+			prog[np].imm = (int64_t)h[0];
+			np++;
+		}
+		if (usable && np) {
+			struct mdb_col_binding cb = { keys[0].values, keys[0].nullbits, keys[0].rid };
+			if ((rc = mdb_cached_alloc(ctx, n * 4, (void **)&sel)))
+				goto out;
+			if ((rc = mdb_dev_filter(ctx, prog, np, &cb, 1, n, sel, &m)))
+				goto out;
+			if (m >= k && m <= n / 2) {
+				/* the candidates through the full stable sort: key columns read through row ids composed with `sel` */
+				struct mdb_sort_key k2[MDB_SORT_MAX_KEYS];
+				for (int i = 0; i < nkeys; i++) {
+					k2[i] = keys[i];
+					if (!keys[i].rid) {
+						k2[i].rid = sel;
+						continue;
+					}
+					int j = 0;
+					while (j < i && keys[j].rid != keys[i].rid)
+						j++;
+					if (j < i) {
+						k2[i].rid = k2[j].rid;
+						continue;
+					}
+					if ((rc = mdb_cached_alloc(ctx, m * 4, (void **)&rids[i])))
+						goto out;
+					if ((rc = mdb_dev_gather32(ctx, keys[i].rid, sel, m, rids[i])))
+						goto out;
+					k2[i].rid = rids[i];
+				}
+				/* (the candidates of 10^8 rows are still 2.5 * 10^5: the same again over them leaves a few hundred) */
+				if ((rc = mdb_cached_alloc(ctx, k * 4, (void **)&perm2)))
+					goto out;
+				if ((rc = topk_rec(ctx, k2, nkeys, m, k, perm2, sorted)))
+					goto out;
+				if ((rc = mdb_dev_gather32(ctx, sel, perm2, k, perm_out)))
+					goto out;
+				done = true;
+			}
+		}
+	}
+	if (!done) {
+		if ((rc = mdb_cached_alloc(ctx, n * 4, (void **)&full)))
+			goto out;
+		if ((rc = mdb_dev_sort_perm(ctx, keys, nkeys, n, full)))
+			goto out;
+		if (hipMemcpyAsync(perm_out, full, k * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+		    hipStreamSynchronize(ctx->stream) != hipSuccess)
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "topk_perm: copying the prefix failed");
+	}
+out:
+	for (int i = 0; i < nkeys; i++)
+		if (rids[i])
+			(void)mdb_cached_free(ctx, rids[i]);
+	if (perm2)
+		(void)mdb_cached_free(ctx, perm2);
+	if (sel)
+		(void)mdb_cached_free(ctx, sel);
+	if (full)
+		(void)mdb_cached_free(ctx, full);
+	if (vals)
+		(void)mdb_cached_free(ctx, vals);
+	return rc;
+}
+
+extern "C" int mdb_dev_topk_perm(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint64_t k, uint32_t *perm_out,
+				 uint64_t *out_candidates)
+{
+	int rc = sort_check(ctx, "topk_perm", nkeys, n);
+	if (out_candidates)
+		*out_candidates = n;
+	if (rc || n == 0 || k == 0)
+		return rc;
+	uint64_t sorted = n;
+	rc = topk_rec(ctx, keys, nkeys, n, k < n ? k : n, perm_out, &sorted);
+	if (out_candidates)
+		*out_candidates = sorted;
+	return rc;
 }
 
 /* ------------------------------------------------------------------ DISTINCT

@@ -508,6 +508,15 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 			ERR("SELECT * can't be combined with GROUP BY / COUNT\n");
 			return -MIDORIDB_ERROR;
 		}
+		if (s->select_all)
+			for (int t = 0; t < s->ntabs; t++)
+				for (int c = 0; c < s->tabs[t].t->ncols; c++)
+					if (!mdb_type_on_device(s->tabs[t].t->cols[c].type)) {
+						ERR("column '%s.%s': VARCHAR columns are kept on the host and cannot be referenced on the MI355X path "
+						    "(SELECT * over a table that has one: name the other columns)\n",
+						    s->tabs[t].t->name, s->tabs[t].t->cols[c].name);
+						return -MIDORIDB_ERROR;
+					}
 		if (ncount && nfield && !s->ngroup) {
 			ERR("mixing fields and COUNT in the select list requires a GROUP BY clause\n");
 			return -MIDORIDB_ERROR;
@@ -575,6 +584,10 @@ struct exec {
 	bool fused;			/* north-star plan: the stream is (d_fused_key, d_count), no row ids */
 	int64_t *d_fused_key;
 	uint64_t joined_rows;
+	/* per joined table: its equi-join key column holds, in every tuple of the stream, the value of an earlier table's column
+	 * (INT64-represented types: the join compared all 64 bits; never NULL - a NULL key joins nothing): the projection reads
+	 * that column, through the earlier table's row ids (ascending after a join: near-sequential reads instead of a random gather) */
+	int same_col[MDB_MAX_TABS], same_as_tbl[MDB_MAX_TABS], same_as_col[MDB_MAX_TABS];
 };
 
 static int dev_fail(struct exec *x, const char *what)
@@ -1065,6 +1078,11 @@ static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *
 		} else if ((rc = stream_column(x, kl, &vl, &nl)) || (rc = table_column(x, t, kr, rsel, r_rows, &vr, &nr))) {
 			return rc;
 		}
+		if (kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE) {
+			x->same_col[t] = kr->col_idx;
+			x->same_as_tbl[t] = kl->tbl_idx;
+			x->same_as_col[t] = kl->col_idx;
+		}
 		if (x->n && r_rows) {
 			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J))
 				return dev_fail(x, "hash join");
@@ -1259,12 +1277,20 @@ static int select_tail(struct exec *x, int has_count)
 			keys[i].type = s->order[i]->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
 			keys[i].desc = s->order_desc[i];
 		}
-		perm = dalloc(x, x->n * 4);
+		/* ORDER BY ... LIMIT: only the first offset + count rows of the order are ever looked at - top-k selection instead
+		 * of a sort of the whole stream (mdb_dev_topk_perm falls back to the sort by itself when that does not pay) */
+		uint64_t want = x->n;
+		if (s->has_limit && s->limit_off >= 0 && s->limit_cnt >= 0 && (uint64_t)s->limit_off + (uint64_t)s->limit_cnt < x->n)
+			want = (uint64_t)s->limit_off + (uint64_t)s->limit_cnt;
+		perm = dalloc(x, (want ? want : 1) * 4);
 		if (!perm)
 			return dev_fail(x, "allocating the ORDER BY permutation");
-		if (mdb_dev_sort_perm(x->dev, keys, s->norder, x->n, perm))
+		if (want < x->n) {
+			if (want && mdb_dev_topk_perm(x->dev, keys, s->norder, x->n, want, perm, NULL))
+				return dev_fail(x, "ORDER BY ... LIMIT");
+		} else if (mdb_dev_sort_perm(x->dev, keys, s->norder, x->n, perm))
 			return dev_fail(x, "ORDER BY");
-		if ((rc = stream_apply_sel(x, s->ntabs, perm, x->n)))
+		if ((rc = stream_apply_sel(x, s->ntabs, perm, want)))
 			return rc;
 	}
 	if (s->has_limit) {
@@ -1296,6 +1322,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 
 	*out = NULL;
 	memset(&x, 0, sizeof(x));
+	for (int t = 0; t < MDB_MAX_TABS; t++)
+		x.same_col[t] = -1;
 	if ((rc = resolve_select(cat, s, err, errlen)))
 		return rc;
 	if ((rc = mdb_catalog_device(cat, err, errlen)))
@@ -1659,11 +1687,31 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				d_nulls[c] = direct_nulls[c];
 				continue;
 			}
-			const uint32_t *rid = x.rid[key_tbl[key]];
+			int from_tbl = key_tbl[key];
+			const struct mdb_column *from = col;
+			while (x.same_col[from_tbl] == (int)(from - s->tabs[from_tbl].t->cols)) {	/* the join key of a joined table: read the earlier table's column */
+				const int t2 = x.same_as_tbl[from_tbl];
+				from = &s->tabs[t2].t->cols[x.same_as_col[from_tbl]];
+				from_tbl = t2;
+			}
+			const bool aliased = from != col;
+			const uint64_t *src_nb = aliased ? NULL : from->d_nullbits;
+			const uint32_t *rid = x.rid[from_tbl];
 			if (!rid) {
-				d_vals[c] = col->d_data;
-				d_nulls[c] = col->d_nullbits;
+				d_vals[c] = from->d_data;
+				d_nulls[c] = aliased ? NULL : from->d_nullbits;
 				continue;
+			}
+			{
+				/* the same column through the same row ids twice (SELECT * after an equi-join: both key columns): gathered once */
+				int g = 0;
+				while (g < ngl && !(gl[g].src == from->d_data && gl[g].rid == rid && gl[g].src_nullbits == src_nb))
+					g++;
+				if (g < ngl) {
+					d_vals[c] = gl[g].dst;
+					d_nulls[c] = gl[g].dst_nullbits;
+					continue;
+				}
 			}
 			{
 				int t = 0;
@@ -1681,13 +1729,13 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					seen_rid[nrid++] = rid;
 			}
 			int64_t *v = dalloc(&x, out_rows * 8);
-			uint64_t *nb = col->d_nullbits ? dalloc(&x, ((out_rows + 63) / 64) * 8) : NULL;
-			if (!v || (col->d_nullbits && !nb)) {
+			uint64_t *nb = src_nb ? dalloc(&x, ((out_rows + 63) / 64) * 8) : NULL;
+			if (!v || (src_nb && !nb)) {
 				rc = dev_fail(&x, "projection gather");
 				break;
 			}
-			gl[ngl].src = col->d_data;
-			gl[ngl].src_nullbits = col->d_nullbits;
+			gl[ngl].src = from->d_data;
+			gl[ngl].src_nullbits = src_nb;
 			gl[ngl].rid = rid;
 			gl[ngl].dst = v;
 			gl[ngl].dst_nullbits = nb;
@@ -1872,6 +1920,8 @@ int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 	int rc;
 
 	memset(&x, 0, sizeof(x));
+	for (int t = 0; t < MDB_MAX_TABS; t++)
+		x.same_col[t] = -1;
 	*n_rows_aff = 0;
 	rc = dml_select_rows(cat, d, &x, &s, &tab, true, &t, &keep, &n_keep, err, errlen);
 	if (rc)
@@ -1988,6 +2038,8 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 	int rc = MIDORIDB_OK;
 
 	memset(&x, 0, sizeof(x));
+	for (int t = 0; t < MDB_MAX_TABS; t++)
+		x.same_col[t] = -1;
 	*n_rows_aff = 0;
 	if (!t) {
 		ERR("table '%s' doesn't exist\n", d->name);

@@ -81,6 +81,7 @@ def _bind(lib):
         "mdb_dev_iota32": ([P, P, c_uint64], c_int),
         "mdb_dev_scatter_set64": ([P, P, P, P, c_uint64, c_int64, c_int], c_int),
         "mdb_dev_sort_perm": ([P, POINTER(SortKey), c_int, c_uint64, P], c_int),
+        "mdb_dev_topk_perm": ([P, POINTER(SortKey), c_int, c_uint64, c_uint64, P, POINTER(c_uint64)], c_int),
         "mdb_dev_distinct_sel": ([P, POINTER(SortKey), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
         "mdb_dev_group_count_multi": ([P, POINTER(SortKey), c_int, c_uint64, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
@@ -110,7 +111,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
+    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
@@ -478,6 +479,22 @@ class DeviceCtx:
         perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         self._chk(self.lib.mdb_dev_sort_perm(self.h, arr, len(keys), n, _ptr(perm)), "sort_perm")
         return perm[:n]
+
+    def topk_perm(self, keys, n, k):
+        """ORDER BY ... LIMIT k: the first k entries of sort_perm(keys, n) without sorting the table ->
+        (int32 tensor of min(k, n) stream positions, rows that went through the sort)."""
+        arr = (SortKey * len(keys))()
+        for i, (v, nb, rid, ty, desc) in enumerate(keys):
+            arr[i].values = v.data_ptr()
+            arr[i].nullbits = nb.data_ptr() if nb is not None else None
+            arr[i].rid = rid.data_ptr() if rid is not None else None
+            arr[i].type = ty
+            arr[i].desc = 1 if desc else 0
+        k = min(k, n)
+        perm = torch.empty(max(k, 1), dtype=torch.int32, device=self.device)
+        cand = c_uint64(0)
+        self._chk(self.lib.mdb_dev_topk_perm(self.h, arr, len(keys), n, k, _ptr(perm), ctypes.byref(cand)), "topk_perm")
+        return perm[:k], cand.value
 
     def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False, keys32=False):
         """-> (keys grouped by destination, counts per destination[, source row of every entry]).  keys32: the keys

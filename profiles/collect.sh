@@ -18,3 +18,12 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
 	--output-format csv -d "$OUT/lds" -- python3 "$R/bench.py" $ARGS > "$OUT/lds.log" 2>&1
 cd "$R" && python3 profiles/summarize.py "$OUT" "$R/gpurun_out/summary_$TAG.json"
+# BASELINE configs[0..1] shapes (scan + WHERE + projection at 10^8 rows, join with payload at 10^7): time + HBM bytes per kernel
+OPS=$OUT/configs1
+mkdir -p "$OPS"
+cd /tmp
+OARGS="--configs1 --out $OPS/operators.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OPS/kt" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OPS/fetch" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OPS/write" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/write.log" 2>&1
+cd "$R" && python3 profiles/summarize.py "$OPS" "$R/gpurun_out/summary_${TAG}_configs1.json"

@@ -392,8 +392,9 @@ def test_join_group_count_level_boundaries_and_asymmetric_sizes(dev, n_l, n_r):
 
 # ---- ORDER BY: stable multi-key sort permutation (extension) -------------------------------------
 
-def _sort_case(dev, rng, n, specs, with_rid=False):
-    """specs: list of (kind, desc, null_frac); kind in small/full/neg/double/const."""
+def _sort_case(dev, rng, n, specs, with_rid=False, topk=None):
+    """specs: list of (kind, desc, null_frac); kind in small/full/neg/double/const.  topk: list of k - the top-k operator
+    must deliver the first k entries of the same permutation; -> rows it sorted for every k."""
     keys_np, keys_dev, keep = [], [], []
     m = n if not with_rid else 2 * n + 3
     rid = rng.integers(0, m, n).astype(np.uint32) if with_rid else None
@@ -417,9 +418,44 @@ def _sort_case(dev, rng, n, specs, with_rid=False):
         keep += [vd, nd]
         keys_np.append((v, nulls, rid, kind == "double", desc))
         keys_dev.append((vd, nd, rid_dev, D.T_DOUBLE if kind == "double" else D.T_INT64, desc))
-    got = _np(dev.sort_perm(keys_dev, n)).view(np.uint32)
     want = orc.sort_perm(keys_np, n)
+    if topk is not None:
+        sorted_rows = []
+        for k in topk:
+            got, cand = dev.topk_perm(keys_dev, n, k)
+            assert np.array_equal(_np(got).view(np.uint32), want[:k]), (k, cand)
+            sorted_rows.append(cand)
+        return sorted_rows
+    got = _np(dev.sort_perm(keys_dev, n)).view(np.uint32)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("specs", [
+    [("full", False, 0.0)], [("full", True, 0.2)], [("full", False, 0.2)], [("double", False, 0.0)], [("double", True, 0.1)],
+    [("neg", False, 0.0), ("full", True, 0.0)], [("neg", True, 0.01), ("double", False, 0.3), ("small", False, 0.0)],
+    [("full", False, 0.999)], [("full", True, 0.999)],
+], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
+def test_topk_perm_is_the_prefix_of_the_stable_sort(dev, specs):
+    """ORDER BY ... LIMIT k (extension): threshold from a sample, one filter pass, sort of the candidates -
+    the same first k positions as the full stable sort for INT64 / DOUBLE first keys, ascending and descending, NULLs
+    first / last (also when almost every row is NULL and the threshold is one), ties on the first key broken by
+    further keys, through row-id vectors; and only a fraction of the rows goes through the sort."""
+    rng = np.random.default_rng(len(specs) * 11 + 3)
+    n = 400_000
+    ks = [1, 10, 1000, n // 40]
+    for with_rid in (False, True):
+        cand = _sort_case(dev, rng, n, specs, with_rid=with_rid, topk=ks)
+        if specs[0][0] != "neg" and specs[0][2] < 0.9:
+            assert all(c < n // 4 for c in cand), cand
+
+
+@pytest.mark.parametrize("specs,n", [([("small", False, 0.0)], 300_000), ([("const", True, 0.0), ("full", False, 0.0)], 300_000),
+                                     ([("full", False, 0.0)], 5000), ([("full", True, 0.0)], 0)])
+def test_topk_perm_falls_back_to_the_full_sort(dev, specs, n):
+    """few distinct first-key values (every candidate set is most of the table), small inputs, k above n/8, k > n"""
+    rng = np.random.default_rng(n + 1)
+    cand = _sort_case(dev, rng, n, specs, topk=[3, 50, n // 2, n, n + 5] if n else [0, 3])
+    assert n == 0 or cand[-1] == n
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 100_000, 1_000_003])
