@@ -67,6 +67,13 @@ int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on);
 int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode);
 /* 1 when the last completed join / GROUP BY operator of this context ran in the narrow form (for byte accounting) */
 int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
+/* Semi-join filter of the compact narrow form: when the key sample says that the right table covers less than a quarter of
+ * the left table's key range (or has less than a quarter of its rows), the right table is partitioned first, its hashed keys become
+ * a bitmap, and the second partition level of the left table drops the rows that can join nothing before writing them.
+ * Exact in effect (a row is only dropped when no right row can have its key): results are identical, only bytes moved
+ * change.  Environment MDB_SEMIJOIN=0 turns it off.
+ * -> 0 when the last completed join operator did not filter, else 1 + log2(adjacent hashed values per bitmap bit). */
+int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory */

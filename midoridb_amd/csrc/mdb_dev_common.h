@@ -37,6 +37,8 @@ struct mdb_dev_ctx {
 	int64_t nh_base;		/* the window centre that went with "narrow" */
 	uint32_t nh_kbits;		/* ... and the compact window the sample offered (0 = none): [nh_lo, nh_lo + 2^nh_kbits) */
 	int64_t nh_lo;
+	bool nh_selective;		/* ... and whether the right table looked like it covers a small part of the left table's keys */
+	uint64_t sr_span_l, sr_span_r;	/* spans of the two tables' sampled keys (last sample) */
 	/* range of the last key sample (smallest / largest of 2 x 4096 evenly spaced keys), by the columns it was taken from */
 	const void *sr_kl, *sr_kr;
 	uint64_t sr_nl, sr_nr;
@@ -53,6 +55,7 @@ struct mdb_dev_ctx {
 	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */
 	uint64_t pu_dupl_n;
 	int pu_dup_skips;
+	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */

@@ -70,6 +70,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->cache_bytes = 0;
 	ctx->narrow_mode = 1;
 	ctx->last_narrow = 0;
+	ctx->last_semijoin = 0;
 	ctx->pu_dup_keys = NULL;
 	ctx->pu_dup_n = 0;
 	ctx->pu_dupl_keys = NULL;
@@ -182,6 +183,11 @@ extern "C" int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on)
 extern "C" int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx)
 {
 	return ctx->last_narrow;
+}
+
+extern "C" int mdb_dev_last_join_filter(mdb_dev_ctx *ctx)
+{
+	return ctx->last_semijoin;
 }
 
 

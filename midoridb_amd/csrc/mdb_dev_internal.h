@@ -49,13 +49,25 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
  * narrow (want_rid must be false): every key is expected within 2^31 of narrow_base - a key outside raises bit 7 of
  * ctx->d_status[0] and the caller redoes the operator wide.  1: hv[i] = fmix32(key) << 32 | row id, 2: hv is an array of 4-byte words fmix32(key) - only in the
  * two-level fast layout, see mdb_partition_w32_applies(). */
+/* Semi-join filter of the second partition level: a bitmap of the hashed key values the OTHER table holds, one bit per
+ * 2^coarse adjacent values, laid out by first-level digit: digit d owns words [d * words, d * words + words).  The
+ * second level's workgroup loads its digit's slice into LDS (into the staging buffer, before it is needed) and drops the
+ * rows whose bit is clear before they are ranked and written. */
+struct mdb_part_filter {
+	const uint32_t *bits;
+	uint32_t words;		/* per first-level digit: a power of two, 4 ... 8192 (32 KiB) */
+	uint32_t shift;		/* bit index (before masking to the slice) = hash32 >> shift */
+};
+
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0,
 			bool keys32 = false,	/* keys32: `keys` points to int32 values */
 			int64_t narrow_base = 0,	/* narrow: the keys are taken relative to this value (centre of their 2^32 window) */
-			uint32_t narrow_kbits = 0);	/* compact narrow form: keys in [narrow_base, narrow_base + 2^narrow_kbits), hash32 =
+			uint32_t narrow_kbits = 0,	/* compact narrow form: keys in [narrow_base, narrow_base + 2^narrow_kbits), hash32 =
 							 * mdb_mixk(key - narrow_base, narrow_kbits) << (32 - narrow_kbits): below the
 							 * bits1 + bits2 partition bits only narrow_kbits - bits1 - bits2 bits tell keys apart */
+			const struct mdb_part_filter *flt = NULL);	/* semi-join filter at the second level (left side of a join in the
+									 * compact narrow form only), see struct mdb_part_filter */
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

@@ -744,12 +744,14 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
  * Persistent: the first register round of both sides of the NEXT leaf is requested before the current leaf is emitted.
  */
 #define LD_MAX_REM 12u
-#define LD_ROUND 2048		/* rows of either side in the first (register) round of a leaf */
+/* ROUND = rows of either side in the first (register) round of a leaf: 2048 (24 prefetch registers in the two sets, 64 in
+ * all).  4096 for the leaves of 2^12 entries (2 x 3052 rows on average at 10^8 rows) needs 80 registers + 11 spilled and
+ * measured 1-3 % slower than 2048 with the remaining rows loaded in the loop. */
 
-template <int THREADS>
+template <int THREADS, int ROUND>
 struct ld_regs {
-	static constexpr int RB = LD_ROUND / (4 * THREADS);	/* 16-byte loads per thread, right side: 4 words each */
-	static constexpr int RA = LD_ROUND / (2 * THREADS);	/* ... left side: 2 words each */
+	static constexpr int RB = ROUND / (4 * THREADS);	/* 16-byte loads per thread, right side: 4 words each */
+	static constexpr int RA = ROUND / (2 * THREADS);	/* ... left side: 2 words each */
 	uint4 b[RB];
 	ulonglong2 a[RA];
 	uint32_t l1, r1;		/* ends of the requested leaf's two row ranges (they start at leaf * cap) */
@@ -757,8 +759,8 @@ struct ld_regs {
 };
 
 /* Row counts of `leaf`, to be decoded one leaf's work later. */
-template <bool HAS_R, int THREADS>
-__device__ static inline void ld_request_counts(const gc_args &a, uint32_t leaf, ld_regs<THREADS> &q)
+template <bool HAS_R, int THREADS, int ROUND>
+__device__ static inline void ld_request_counts(const gc_args &a, uint32_t leaf, ld_regs<THREADS, ROUND> &q)
 {
 	q.next_l = make_uint2(0, 0);
 	q.next_r = make_uint2(0, 0);
@@ -773,17 +775,17 @@ __device__ static inline void ld_request_counts(const gc_args &a, uint32_t leaf,
  * conversion at load time would make the request wait for itself (see gc_batch).  A leaf is requested TWO leaves ahead of
  * its turn, so its loads have a whole leaf's work to land in; its counts are requested two leaves before that, so that
  * only the rows that exist are fetched (whole rounds regardless of the count were 30 % more bytes and 15 % slower). */
-template <bool HAS_R, int THREADS>
-__device__ static inline void ld_request(const gc_args &a, uint32_t leaf, ld_regs<THREADS> &q)
+template <bool HAS_R, int THREADS, int ROUND>
+__device__ static inline void ld_request(const gc_args &a, uint32_t leaf, ld_regs<THREADS, ROUND> &q)
 {
 	uint32_t l0, r0 = 0;
 	gc_leaf_decode(q.next_l, a.cap_l, leaf, &l0, &q.l1);
 	q.r1 = 1;
 	if (HAS_R)
 		gc_leaf_decode(q.next_r, a.cap_r, leaf, &r0, &q.r1);
-	ld_request_counts<HAS_R, THREADS>(a, leaf + 2 * gridDim.x, q);
+	ld_request_counts<HAS_R, THREADS, ROUND>(a, leaf + 2 * gridDim.x, q);
 #pragma unroll
-	for (int u = 0; u < ld_regs<THREADS>::RA; u++) {
+	for (int u = 0; u < ld_regs<THREADS, ROUND>::RA; u++) {
 		const uint32_t i = l0 + 2u * ((uint32_t)u * THREADS + threadIdx.x);
 		q.a[u] = make_ulonglong2(0ull, 0ull);
 		if (i < q.l1)
@@ -791,7 +793,7 @@ __device__ static inline void ld_request(const gc_args &a, uint32_t leaf, ld_reg
 	}
 	if (HAS_R) {
 #pragma unroll
-		for (int u = 0; u < ld_regs<THREADS>::RB; u++) {
+		for (int u = 0; u < ld_regs<THREADS, ROUND>::RB; u++) {
 			const uint32_t j = r0 + 4u * ((uint32_t)u * THREADS + threadIdx.x);
 			q.b[u] = make_uint4(0u, 0u, 0u, 0u);
 			if (j < q.r1)
@@ -820,8 +822,8 @@ struct ld_state {
 };
 
 /* one leaf: count the right rows, look the left rows up, request leaf + 2 * gridDim.x into the registers just consumed, emit */
-template <bool HAS_R, int THREADS>
-__device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t leaf, ld_regs<THREADS> &q)
+template <bool HAS_R, int THREADS, int ROUND>
+__device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t leaf, ld_regs<THREADS, ROUND> &q)
 {
 	uint32_t *const s_cr = st.s_cr, *const s_cl = st.s_cl, *const s_first = st.s_first, *const s_chunk = st.s_chunk;
 	const uint32_t T = st.T, mask = st.mask, shift = st.shift;
@@ -863,7 +865,7 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 			/* right rows: one LDS add each (r0 is a multiple of 64: the rounds start on the leaf's first row) */
 			const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
 #pragma unroll
-			for (int u = 0; u < ld_regs<THREADS>::RB; u++) {
+			for (int u = 0; u < ld_regs<THREADS, ROUND>::RB; u++) {
 				const uint32_t j = r0 + 4u * ((uint32_t)u * THREADS + threadIdx.x);
 				const uint32_t w[4] = { q.b[u].x, q.b[u].y, q.b[u].z, q.b[u].w };
 #pragma unroll
@@ -871,7 +873,7 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 					if (j + k < r1)
 						atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
 			}
-			for (uint32_t j = r0 + 4u * (ld_regs<THREADS>::RB * THREADS + threadIdx.x); j < r1; j += 4u * THREADS) {
+			for (uint32_t j = r0 + 4u * (ld_regs<THREADS, ROUND>::RB * THREADS + threadIdx.x); j < r1; j += 4u * THREADS) {
 				const uint4 v = *reinterpret_cast<const uint4 *>(hv_r32 + j);
 				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -883,14 +885,14 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 		}
 		/* left rows: one LDS read each; rows whose key has right rows are counted and compete for "first" */
 #pragma unroll
-		for (int u = 0; u < ld_regs<THREADS>::RA; u++) {
+		for (int u = 0; u < ld_regs<THREADS, ROUND>::RA; u++) {
 			const uint32_t i = l0 + 2u * ((uint32_t)u * THREADS + threadIdx.x);
 			if (i < l1)
 				ld_left_row<HAS_R>(q.a[u].x, shift, mask, s_cr, s_cl, s_first);
 			if (i + 1 < l1)
 				ld_left_row<HAS_R>(q.a[u].y, shift, mask, s_cr, s_cl, s_first);
 		}
-		for (uint32_t i = l0 + 2u * (ld_regs<THREADS>::RA * THREADS + threadIdx.x); i < l1; i += 2u * THREADS) {
+		for (uint32_t i = l0 + 2u * (ld_regs<THREADS, ROUND>::RA * THREADS + threadIdx.x); i < l1; i += 2u * THREADS) {
 			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_l + i);
 			ld_left_row<HAS_R>(v.x, shift, mask, s_cr, s_cl, s_first);
 			if (i + 1 < l1)
@@ -901,7 +903,7 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 
 	/* these registers are free again: the leaf after next travels while this one is emitted and the next one processed */
 	if (leaf + 2 * gridDim.x < a.nleaves)
-		ld_request<HAS_R, THREADS>(a, leaf + 2 * gridDim.x, q);
+		ld_request<HAS_R, THREADS, ROUND>(a, leaf + 2 * gridDim.x, q);
 
 	if (live) {
 		/* emit one record per key that has rows on both sides and clear what was touched (4-byte accesses, thread t takes
@@ -958,7 +960,7 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 	}
 }
 
-template <bool HAS_R, int THREADS>
+template <bool HAS_R, int THREADS, int ROUND>
 __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* four workgroups per CU: at most 64 registers */(gc_args a, uint32_t rem, uint32_t shift)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
@@ -983,21 +985,21 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 		st.s_chunk[threadIdx.x] = 0u;		/* [4..5] = s_sum, [6] = distinct right keys of the current leaf */
 
 	/* two register sets: while leaf i is processed out of one, leaf i + 1 sits (or still travels) in the other */
-	ld_regs<THREADS> qa, qb;
+	ld_regs<THREADS, ROUND> qa, qb;
 	uint32_t leaf = blockIdx.x;
-	ld_request_counts<HAS_R, THREADS>(a, leaf, qa);
-	ld_request_counts<HAS_R, THREADS>(a, leaf + gridDim.x, qb);
+	ld_request_counts<HAS_R, THREADS, ROUND>(a, leaf, qa);
+	ld_request_counts<HAS_R, THREADS, ROUND>(a, leaf + gridDim.x, qb);
 	if (leaf < a.nleaves)
-		ld_request<HAS_R, THREADS>(a, leaf, qa);
+		ld_request<HAS_R, THREADS, ROUND>(a, leaf, qa);
 	if (leaf + gridDim.x < a.nleaves)
-		ld_request<HAS_R, THREADS>(a, leaf + gridDim.x, qb);
+		ld_request<HAS_R, THREADS, ROUND>(a, leaf + gridDim.x, qb);
 	__syncthreads();
 	while (leaf < a.nleaves) {
-		ld_leaf<HAS_R, THREADS>(a, st, leaf, qa);
+		ld_leaf<HAS_R, THREADS, ROUND>(a, st, leaf, qa);
 		leaf += gridDim.x;
 		if (leaf >= a.nleaves)
 			break;
-		ld_leaf<HAS_R, THREADS>(a, st, leaf, qb);
+		ld_leaf<HAS_R, THREADS, ROUND>(a, st, leaf, qb);
 		leaf += gridDim.x;
 	}
 	if (a.kbits) {
@@ -1014,6 +1016,47 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 		atomicAdd(a.joined, *s_sum);
 	if (threadIdx.x == 0 && a.kbits && st.s_chunk[3])
 		atomicAdd(a.rec_valid, st.s_chunk[3]);
+}
+
+/* ------------------------------------------------------------------ semi-join filter (compact narrow form)
+ *
+ * Bitmap of the hashed key values the RIGHT table holds, one bit per 2^coarse adjacent values, built from its
+ * partitioned form: the 2^rem values a leaf can hold are a contiguous slice of the bitmap, so ONE WAVE per leaf sets the
+ * bits in LDS and writes the slice with coalesced stores (no global atomics); leaves are consecutive in the bitmap, so
+ * the slices of a first-level digit are too - which is what the left table's second partition level loads. */
+#define LB_WAVES 4u
+__global__ __launch_bounds__(LB_WAVES * MDB_WAVE) void k_leaf_bitmap(const uint32_t *__restrict__ hv_r, const uint32_t *__restrict__ cnt_r, uint32_t cap_r,
+								 uint32_t nleaves, uint32_t rem, uint32_t coarse, uint32_t shift,
+								 uint32_t *__restrict__ bits)
+{
+	__shared__ uint32_t s_bits[LB_WAVES][(1u << LD_MAX_REM) / 32];
+	const uint32_t wave = threadIdx.x / MDB_WAVE, lane = mdb_lane();
+	const uint32_t words = 1u << (rem - coarse - 5u), mask = (1u << rem) - 1u;	/* rem - coarse >= 5: at least one word */
+	const uint32_t rounds = (nleaves + gridDim.x * LB_WAVES - 1) / (gridDim.x * LB_WAVES);
+	for (uint32_t k = 0; k < rounds; k++) {
+		const uint32_t leaf = (k * gridDim.x + blockIdx.x) * LB_WAVES + wave;
+		for (uint32_t w = lane; w < words; w += MDB_WAVE)
+			s_bits[wave][w] = 0u;
+		__syncthreads();
+		if (leaf < nleaves) {
+			const uint32_t c = cnt_r[leaf], r0 = leaf * cap_r, r1 = r0 + (c < cap_r ? c : cap_r);
+			for (uint32_t j = r0 + 4u * lane; j < r1; j += 4u * MDB_WAVE) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(hv_r + j);	/* (regions start 16-byte aligned and are padded) */
+				const uint32_t h[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					if (j + q < r1) {
+						const uint32_t idx = ((h[q] >> shift) & mask) >> coarse;
+						atomicOr(&s_bits[wave][idx >> 5], 1u << (idx & 31u));
+					}
+			}
+		}
+		__syncthreads();
+		if (leaf < nleaves)
+			for (uint32_t w = lane; w < words; w += MDB_WAVE)
+				bits[(size_t)leaf * words + w] = s_bits[wave][w];
+		__syncthreads();
+	}
 }
 
 /* ------------------------------------------------------------------ hot keys across the whole chip
@@ -1511,12 +1554,17 @@ struct gc_state {
 	const uint64_t *null_l;
 	uint64_t n_l, n_r_cap;
 	bool has_r, null_group, fast, want_records, no_build_r;
+	bool defer_ok;		/* the caller runs gc_begin and gc_finish back to back: the left table may be partitioned in gc_finish */
 	bool narrow;		/* 32-bit hashes; the left words carry the row ids (see mdb_partition_table) */
 	bool keys32;		/* both key columns are int32 arrays (received over xGMI in the 4-byte wire format) */
 	int64_t base;		/* narrow form: centre of the key window (mdb_partition_table) */
 	uint32_t key_bits;	/* compact narrow form offered by the key sample: every key in [key_lo, key_lo + 2^key_bits) (0 = none) */
 	int64_t key_lo;
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
+	bool selective;		/* hint of the key sample: most left rows will find no partner */
+	uint32_t semijoin;	/* != 0: the LEFT table is partitioned after the right one (gc_finish), its second level dropping the rows
+				 * whose bit is clear in a bitmap of the right table's hashed keys; the value is log2 of the adjacent
+				 * hashed values that share a bit, plus 1 */
 	int b1, b2;
 	mdb_part_result pl;
 };
@@ -1539,7 +1587,38 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * (same-address LDS atomics: the hashed kernel's wave-level merging handles those better) */
 	st->direct = st->narrow && st->key_bits && st->fast && st->b2 > 0 && st->want_records && !ld_disabled() &&
 		     st->key_bits >= (uint32_t)(st->b1 + st->b2) + 4u && st->key_bits <= (uint32_t)(st->b1 + st->b2) + LD_MAX_REM;
+	if (st->direct) {
+		/* the direct-address kernel has no table to overflow and pays a fixed price per leaf (three barriers, the emit scan):
+		 * it prefers FEWER, larger leaves than the hashed kernel's 3833-slot table allows - tables of 2^LD_MAX_REM entries when
+		 * the second level has the bits to give (10^8 x 10^8 rows: 2^15 leaves of 2 x 3052 rows instead of 2^16; second-level
+		 * fan-out 128: -4 % on its scatter kernels as well).  MDB_LD_REM=<bits> overrides the target. */
+		const char *e = getenv("MDB_LD_REM");
+		const uint32_t want = e && atoi(e) >= 4 && atoi(e) <= (int)LD_MAX_REM ? (uint32_t)atoi(e) : LD_MAX_REM;
+		while (st->b2 > 1 && st->key_bits - (uint32_t)(st->b1 + st->b2) < want &&
+		       (1u << (st->b1 + st->b2 - 1)) >= 16u * (uint32_t)ctx->num_cus)	/* ... while every workgroup still has leaves to walk */
+			st->b2--;
+	}
+	/* Semi-join filter: when the key sample says that most left rows have no partner (a fact table joined with a
+	 * dimension that covers part of its key range - the benchmark's variant D: 1 row in 16), the right table is
+	 * partitioned FIRST, its hashed keys become a bitmap (k_leaf_bitmap: one contiguous slice per leaf), and the second
+	 * partition level of the left table drops every row whose bit is clear before it is ranked and written: that level's
+	 * writes and the leaf kernel's reads shrink to the rows that may have a partner.  The slice of a first-level digit
+	 * (<= 32 KiB: one bit per 2^c adjacent hashed values when the window is wide) is staged in LDS per tile; the first level
+	 * cannot filter - its rows are in table order, a lookup there costs a 128-byte line from L2 per row (measured: slower).
+	 * A wrong hint costs time, never results.  MDB_SEMIJOIN=0 switches it off, MDB_SEMIJOIN_SLICE=<log2 bits> sizes the slice. */
+	st->semijoin = 0;
+	if (st->direct && st->has_r && st->selective && st->defer_ok && !st->active) {
+		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
+		const uint32_t slice_max = e2 && atoi(e2) >= 7 && atoi(e2) <= 18 ? (uint32_t)atoi(e2) : 17u;	/* log2 bits: 2^17 = 16 KiB */
+		const uint32_t below0 = st->key_bits - (uint32_t)st->b1;		/* hash bits below the first-level digit */
+		const uint32_t coarse = below0 > slice_max ? below0 - slice_max : 0u;
+		const uint32_t rem = st->key_bits - (uint32_t)(st->b1 + st->b2);
+		if (!(e && e[0] == '0') && coarse <= 3u && rem >= coarse + 5u && below0 - coarse >= 7u)
+			st->semijoin = coarse + 1u;
+	}
 	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
+	if (st->semijoin)
+		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
 	if (st->has_r)
 		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	{
@@ -1562,10 +1641,12 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
-				 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
-	if (rc)
-		return rc;
+	if (!st->semijoin) {
+		rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
+					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
+		if (rc)
+			return rc;
+	}
 	st->active = true;
 	return MIDORIDB_OK;
 }
@@ -1595,6 +1676,28 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
 		if (rc)
 			return rc;
+	}
+	if (st->semijoin) {
+		/* the right table's hashed keys as a bitmap, then the left table through it */
+		const uint32_t coarse = st->semijoin - 1u, rem = st->key_bits - (uint32_t)(st->b1 + st->b2);
+		const size_t bytes = ((size_t)1 << (st->key_bits - coarse)) / 8;
+		uint32_t *bits = (uint32_t *)mdb_arena_take(ctx, bytes);
+		if (!bits)
+			return -MIDORIDB_INTERNAL;
+		if (!pr.leaf_cap || !pr.w32)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "semi-join filter: the right table is not in the 4-byte fixed-capacity layout");
+		const uint32_t groups = (pr.nleaves + LB_WAVES - 1) / LB_WAVES, resident = 16u * (uint32_t)ctx->num_cus;
+		MDB_LAUNCH(ctx, "leaf_bitmap", k_leaf_bitmap, groups < resident ? groups : resident, LB_WAVES * MDB_WAVE,
+			   reinterpret_cast<const uint32_t *>(pr.hv), pr.leaf_cnt, pr.leaf_cap, pr.nleaves, rem, coarse, 32u - st->key_bits, bits);
+		mdb_part_filter flt;
+		flt.bits = bits;
+		flt.words = 1u << (st->key_bits - (uint32_t)st->b1 - coarse - 5u);
+		flt.shift = 32u - st->key_bits + coarse;
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32, st->key_lo, st->key_bits,
+					 &flt);
+		if (rc)
+			return rc;
+		pl = st->pl;
 	}
 	/* ---- result ordering: record mode (sort the groups by first row id) or dense mode (fallback) */
 	uint32_t kbits = 0;
@@ -1664,9 +1767,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
 			const uint32_t dgrid = pl.nleaves < per_cu * (uint32_t)ctx->num_cus ? pl.nleaves : per_cu * (uint32_t)ctx->num_cus;
 			if (has_r) {
-				MDB_LAUNCH_LDS(ctx, "leaf_join_direct", (k_leaf_direct<true, 512>), dgrid, 512, lds, a, rem, shift);
+				MDB_LAUNCH_LDS(ctx, "leaf_join_direct", (k_leaf_direct<true, 512, 2048>), dgrid, 512, lds, a, rem, shift);
 			} else {
-				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", (k_leaf_direct<false, 512>), dgrid, 512, lds, a, rem, shift);
+				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", (k_leaf_direct<false, 512, 2048>), dgrid, 512, lds, a, rem, shift);
 			}
 		} else if (has_r && build_r && st->narrow) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false, true>), grid, GC_THREADS, a);
@@ -1798,6 +1901,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (out_joined)
 		*out_joined = joined;
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
+	ctx->last_semijoin = (int)st->semijoin;
 	return MIDORIDB_OK;
 }
 
@@ -1871,6 +1975,34 @@ __global__ void k_key_sample(const int64_t *__restrict__ kl, const uint64_t *__r
 		atomicMin(&mm[0], lo);
 		atomicMax(&mm[1], hi);
 	}
+	/* the two tables' own ranges (mm[2..3] left, mm[4..5] right): how much of the left table's key range the right one covers */
+	long long llo = 0x7FFFFFFFFFFFFFFFll, lhi = -0x7FFFFFFFFFFFFFFFll - 1, rlo = llo, rhi = lhi;
+	if (t < GC_NARROW_SAMPLE) {
+		if (nl) {
+			const uint64_t i = gc_sample_pos(t, nl);
+			if (!(nl_bits && mdb_bit_is_set(nl_bits, i)))
+				llo = lhi = kl[i];
+		}
+		if (kr && nr) {
+			const uint64_t j = gc_sample_pos(t, nr);
+			if (!(nr_bits && mdb_bit_is_set(nr_bits, j)))
+				rlo = rhi = kr[j];
+		}
+	}
+	llo = gc_wave_min_i64(llo);
+	lhi = gc_wave_max_i64(lhi);
+	rlo = gc_wave_min_i64(rlo);
+	rhi = gc_wave_max_i64(rhi);
+	if (mdb_lane() == 0) {
+		if (llo <= lhi) {
+			atomicMin(&mm[2], llo);
+			atomicMax(&mm[3], lhi);
+		}
+		if (rlo <= rhi) {
+			atomicMin(&mm[4], rlo);
+			atomicMax(&mm[5], rhi);
+		}
+	}
 }
 
 /* smallest / largest of 2 x GC_NARROW_SAMPLE evenly spaced non-NULL keys (lo > hi: nothing but NULLs); remembered by the
@@ -1889,14 +2021,19 @@ static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	}
 	long long *mm = (long long *)(ctx->d_status + 10);
 	int64_t *h = (int64_t *)ctx->h_pinned;
-	h[0] = INT64_MAX;
-	h[1] = INT64_MIN;
-	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 16, hipMemcpyHostToDevice, ctx->stream));
+	for (int i = 0; i < 6; i += 2) {
+		h[i] = INT64_MAX;
+		h[i + 1] = INT64_MIN;
+	}
+	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 48, hipMemcpyHostToDevice, ctx->stream));
 	MDB_LAUNCH(ctx, "key_sample", k_key_sample, GC_NARROW_SAMPLE / 256, 256, keys_l, null_l, n_l, keys_r, null_r, n_r, mm);
-	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 48, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*lo = h[0];
 	*hi = h[1];
+	/* spans of the two tables' sampled keys (0 = nothing sampled) */
+	ctx->sr_span_l = h[2] <= h[3] ? (uint64_t)h[3] - (uint64_t)h[2] + 1 : 0;
+	ctx->sr_span_r = h[4] <= h[5] ? (uint64_t)h[5] - (uint64_t)h[4] + 1 : 0;
 	ctx->sr_kl = keys_l;
 	ctx->sr_nl = n_l;
 	ctx->sr_kr = keys_r;
@@ -1949,6 +2086,8 @@ static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *
 struct gc_window {
 	uint32_t kbits;		/* 0 = no compact window */
 	int64_t lo;
+	bool selective;		/* the right table's sampled keys cover less than a quarter of the left table's sampled key range, or the right
+				 * table has less than a quarter of the left table's rows: most left rows will find no partner (semi-join filter) */
 };
 
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
@@ -1959,6 +2098,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	if (win) {
 		win->kbits = 0;
 		win->lo = 0;
+		win->selective = false;
 	}
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
@@ -1979,6 +2119,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		if (win && *narrow) {
 			win->kbits = ctx->nh_kbits;
 			win->lo = ctx->nh_lo;
+			win->selective = ctx->nh_selective;
 		}
 		return MIDORIDB_OK;
 	}
@@ -2000,11 +2141,14 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	int64_t wlo = 0;
 	if (*narrow)
 		gc_compact_window(lo, hi, &kb, &wlo);
+	const bool selective = keys_r && n_r && ((ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4) || n_r < n_l / 4);
 	if (win) {
 		win->kbits = kb;
 		win->lo = wlo;
+		win->selective = selective;
 	}
 	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base, kb, wlo);
+	ctx->nh_selective = selective;
 	return MIDORIDB_OK;
 }
 
@@ -2033,7 +2177,9 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.base = base;
 	st.key_bits = narrow ? win.kbits : 0u;
 	st.key_lo = win.lo;
+	st.selective = win.selective;
 	st.keys32 = keys32;
+	st.defer_ok = true;
 	int rc = gc_begin(ctx, &st);
 	if (rc)
 		return rc;
@@ -2049,7 +2195,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
 	int64_t base = 0;
-	gc_window win = { 0, 0 };
+	gc_window win = { 0, 0, false };
 	int rc = MIDORIDB_OK;
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow
@@ -2245,6 +2391,7 @@ static int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint6
 	if (out_joined)
 		*out_joined = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
 	ctx->last_narrow = 0;
+	ctx->last_semijoin = 0;
 	return 0;
 }
 

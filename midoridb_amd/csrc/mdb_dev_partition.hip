@@ -85,6 +85,11 @@ struct mdb_level_args {
 	uint32_t narrow_kbits;		/* compact narrow form: every key must lie in [narrow_base, narrow_base + 2^narrow_kbits); the 32-bit
 					 * hash is mixk(key - narrow_base) in the TOP narrow_kbits bits of the field, zeros below */
 	uint32_t keys32;		/* level 0: `keys` is an array of int32 (keys that crossed xGMI in the 4-byte wire format) */
+	/* semi-join filter (second level, left side of a join in the compact narrow form; struct mdb_part_filter): the slice of
+	 * first-level digit td.seg is words [seg * filter_words, ...); a row whose bit (hash32 >> filter_shift, masked to the
+	 * slice) is clear can join nothing and is dropped before it is ranked */
+	const uint32_t *filter;
+	uint32_t filter_words, filter_shift;
 	uint32_t fold64;		/* raw 4-byte words: the input is still the list of 8-byte records, folded on the fly (record >> 32 | low
 					 * half: the caller knows that the two parts do not overlap) */
 };
@@ -296,9 +301,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false, bool FILT = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
 	/* INV (destination partition for the exchange): what is staged and written is the KEY, not its hash - the digit is
 	 * taken from the hash once, at load time, and found again at write-out from the staged position (the tile-local
 	 * digit starts are in LDS anyway), instead of hashing back and forth */
@@ -331,6 +337,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	if (STABLE)
 		for (uint32_t i = threadIdx.x; i < PART_WAVES * PART_MAX_R; i += PART_THREADS)
 			s_wcnt[i] = 0;
+	/* the filter slice of this tile's first-level digit lives in the staging buffer until the rows are ranked (the
+	 * barrier after the load separates its last read from the first staged word) */
+	uint32_t *const s_flt = reinterpret_cast<uint32_t *>(s_hv);
+	if (FILT) {
+		const uint4 *src = reinterpret_cast<const uint4 *>(a.filter + (size_t)td.seg * a.filter_words);
+		for (uint32_t w = threadIdx.x; w < a.filter_words / 4; w += PART_THREADS)
+			reinterpret_cast<uint4 *>(s_flt)[w] = src[w];
+		__syncthreads();
+	}
 
 	/* 1. load (coalesced).  STABLE: wave w owns the 512 consecutive keys [w*512, w*512+512), so that
 	 *    (wave, round, lane) order is input order; otherwise consecutive threads, consecutive keys. */
@@ -382,6 +397,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			bool valid[2];
 			uint64_t h2[2];
 			part_load2<LEVEL0, HAS_RID, RAW, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
+			if (FILT) {		/* (narrow words: hash32 in the upper half) */
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const uint32_t bit = ((uint32_t)(h2[k] >> 32) >> a.filter_shift) & (a.filter_words * 32u - 1u);
+					valid[k] = valid[k] && ((s_flt[bit >> 5] >> (bit & 31u)) & 1u);
+				}
+			}
 			hv[2 * r] = (W)h2[0];		/* W32 at level 0: the narrow word holds the hash in both halves */
 			hv[2 * r + 1] = (W)h2[1];
 			dig[2 * r] = valid[0] ? part_digit(a, INV ? (W)mdb_fmix64(h2[0]) : hv[2 * r]) : PART_INVALID;
@@ -732,7 +754,8 @@ static inline uint32_t part_fast_cap(uint64_t n, uint32_t nleaves)
 static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
 			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL,
-			  uint32_t digits0_used = 0, bool keys32_out = false, int64_t narrow_base = 0, uint32_t narrow_kbits = 0)
+			  uint32_t digits0_used = 0, bool keys32_out = false, int64_t narrow_base = 0, uint32_t narrow_kbits = 0,
+			  const mdb_part_filter *flt = NULL)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -810,6 +833,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keys32 = (flags & PART_F_KEYS32) ? 1u : 0u;
 		a.narrow_base = narrow_base;
 		a.narrow_kbits = a.narrow ? narrow_kbits : 0u;
+		a.filter = (flt && l == 1) ? flt->bits : NULL;
+		a.filter_words = flt ? flt->words : 0u;
+		a.filter_shift = flt ? flt->shift : 0u;
 		if (a.mode == MDB_DIGIT_RADIX) {
 			const int b = l == 0 ? bits1 : bits2;
 			a.shift = (uint32_t)((w32 ? 32 : 64) - used_bits - b);
@@ -881,6 +907,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else if (w32) {
 					MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
+				} else if (a.filter) {
+					MDB_LAUNCH(ctx, "part_scatter_l1_semi", (k_part_scatter<false, false, false, true, false, false, false, true>),
+						   grid8(ntiles), PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
 						   PART_THREADS, a);
@@ -987,8 +1016,11 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast)
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int bits1, int bits2,
 			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32, int64_t narrow_base,
-			uint32_t narrow_kbits)
+			uint32_t narrow_kbits, const mdb_part_filter *flt)
 {
+	if (flt && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 || flt->words < 4 || flt->words > MDB_TILE * 2 ||
+		    (flt->words & (flt->words - 1))))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "semi-join filter: left side of the compact narrow form, two fast levels, slices of 4 ... 8192 words");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))
@@ -1004,7 +1036,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
 				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u),
-			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u);
+			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u, flt);
 }
 
 /* MSD radix partition of ready-made 64-bit sort keys (no hashing, no NULLs) by their top bits1 + bits2

@@ -60,6 +60,7 @@ def _bind(lib):
         "mdb_dev_set_overlap": ([P, c_int], c_int),
         "mdb_dev_set_narrow_keys": ([P, c_int], c_int),
         "mdb_dev_last_join_narrow": ([P], c_int),
+        "mdb_dev_last_join_filter": ([P], c_int),
         "mdb_dev_arena_bytes": ([P], c_size_t),
         "mdb_dev_alloc": ([P, c_size_t, POINTER(P)], c_int),
         "mdb_dev_free": ([P, P], c_int),
@@ -109,7 +110,7 @@ def _bind(lib):
 
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
-    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
@@ -205,6 +206,10 @@ class DeviceCtx:
         """0 wide (64-bit hashes), 1 narrow (32-bit hashes of a 2^32-wide window), 2 compact narrow (k-bit hashes of the
         sampled window, direct-address leaves)"""
         return int(self.lib.mdb_dev_last_join_narrow(self.h))
+
+    def last_join_filter(self):
+        """0: the last join did not filter the left table through the right table's key bitmap; else 1 + log2(values per bit)"""
+        return int(self.lib.mdb_dev_last_join_filter(self.h))
 
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""

@@ -1164,6 +1164,72 @@ def test_compact_and_hashed_leaf_kernels_agree_at_scale(dev, narrow_mode):
             assert out[0][3] == out[m][3] == n
 
 
+@pytest.mark.parametrize("shape", ["dup16", "subrange", "few_right_rows", "no_match", "nulls", "offset"])
+def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(dev, narrow_mode, monkeypatch, shape):
+    """Selective joins in the compact narrow form: the right table is partitioned first, its hashed keys become a bitmap
+    (k_leaf_bitmap) and the left table's second partition level drops the rows whose bit is clear (slice of the tile's
+    first-level digit staged in LDS).  Groups, counts, first rows, order and joined rows equal the oracle's with the filter
+    on (exact bitmap, and one bit per 2 / 4 / 8 adjacent hashed values) and off."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 13 + 5)
+    # (every shape its own table sizes: the operator remembers what it learned about a column by address and length, and
+    #  the allocator hands the next case the same addresses)
+    n_l, n_r, span, off = 3_000_000 + 4096 * len(shape), 2_500_000 + 4096 * len(shape), 3_000_000 + 4096 * len(shape), 0
+    kl = rng.permutation(span)[:n_l].astype(np.int64)
+    nl = nr = None
+    if shape == "dup16":
+        kr = (rng.permutation(span)[:n_r] % (span // 16)).astype(np.int64)
+    elif shape == "subrange":
+        kr = rng.integers(span // 3, span // 3 + span // 6, n_r, dtype=np.int64)
+    elif shape == "few_right_rows":
+        kr = rng.integers(0, span, 40_000, dtype=np.int64)
+    elif shape == "no_match":
+        kl = 2 * rng.integers(0, span // 2, n_l, dtype=np.int64)
+        kr = 2 * rng.integers(0, span // 12, n_r, dtype=np.int64) + 1
+    elif shape == "nulls":
+        kr = rng.integers(0, span // 10, n_r, dtype=np.int64)
+        nl, nr = rng.random(n_l) < 0.05, rng.random(kr.size) < 0.3
+    else:
+        off = -(2**45)
+        kr = rng.integers(0, span // 5, n_r, dtype=np.int64)
+    kl, kr = kl + off, kr + off
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for on, slice_bits, expect in ((None, None, 1), ("1", "13", 2), ("1", "12", 3), ("1", "11", 4), ("1", "9", 0), ("0", None, 0)):
+        for name, val in (("MDB_SEMIJOIN", on), ("MDB_SEMIJOIN_SLICE", slice_bits)):
+            if val is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, val)
+        k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert dev.last_join_form() == 2, (shape, on, slice_bits)
+        assert dev.last_join_filter() == expect, (shape, on, slice_bits, dev.last_join_filter())
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, on, slice_bits)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, on, slice_bits)
+
+
+def test_semijoin_filter_at_scale_matches_the_unfiltered_operator(dev, narrow_mode, monkeypatch):
+    """4 * 10^7 x 4 * 10^7 rows of the benchmark's variant D (1 left row in 16 has a partner): identical columns with the
+    filter on and off; variant U (every row has one) does not take the filter."""
+    narrow_mode(1)
+    n = 40_000_000
+    kl = dev.gen_keys(n, 0, n, 42, 0)
+    kr = dev.gen_keys(n, 0, n, 43, n // 16)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MDB_SEMIJOIN", mode)
+        k, c, f, j = dev.join_group_count(kl, None, kr, None)
+        assert (dev.last_join_filter() != 0) == (mode == "1")
+        out[mode] = (k.clone(), c.clone(), f.clone(), j)
+    for a, b in zip(out["0"][:3], out["1"][:3]):
+        assert torch.equal(a, b)
+    assert out["0"][3] == out["1"][3] == n
+    monkeypatch.delenv("MDB_SEMIJOIN")
+    kr = dev.gen_keys(n, 0, n, 43, 0)
+    dev.join_group_count(kl, None, kr, None)
+    assert dev.last_join_form() == 2 and dev.last_join_filter() == 0
+
+
 @pytest.mark.parametrize("n", [262_144, 600_001])
 def test_group_count_multi_and_distinct_on_the_packed_sort_path(dev, n):
     """From 2^18 rows on, INT64 columns whose ranges fit one word are sorted by the packed path and the group / distinct
