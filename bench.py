@@ -47,14 +47,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6
 ROCPROF_NAMES = {
     "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
                               "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
-    "leaf_join_direct": ["k_leaf_direct<true, true>", "k_leaf_direct<true, false>"],
+    "leaf_join_direct": ["k_leaf_direct<true, 512, 2048>", "k_leaf_direct<true, 512>"],
+    "leaf_bitmap": ["k_leaf_bitmap"],
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
-    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false>"],
-    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false>"],
-    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false>"],
-    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false>"],
-    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false>"],
+    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT> (the last parameter since round 2's semi-join filter)
+    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
+    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
+    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
+    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
+    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true>"],
+    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
+    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
 }
@@ -86,6 +89,9 @@ def algorithmic_bytes(kernel, n, groups, narrow):
         "part_scatter_l0_w32": key + h32,           # narrow right side: read keys, write 4-byte hashes
         "part_scatter_l0_rid": key + key + rid,     # wide left side: hash + row id out
         "part_scatter_l1": key + key,
+        "part_scatter_l1_semi": key + 8 * g,        # semi-join filter: every word in, the words that have a partner out (at least one
+                                                    # left row per group - exactly one in the benchmark's variants)
+        "leaf_bitmap": h32,                         # the right table's partitioned words in, a bitmap of 2^k / 2^c bits out
         "part_scatter_l1_w32": h32 + h32,
         "part_scatter_l1_rid": 2 * (key + rid),
         "part_hist_l0": key,

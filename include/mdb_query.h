@@ -90,6 +90,11 @@ struct query_output *mdb_query_execute_rpn(struct database *db, const char *rpn_
  * (src/engine/query.c:162-166).  These add typed access, NULL tests and metadata. */
 double query_column_double(struct result_set *res, int col_idx);
 bool query_column_is_null(struct result_set *res, int col_idx);
+/* VARCHAR column of the current row: the string (owned by the database, valid until database_close()); "" for a NULL
+ * cell (upstream such a cell points at an empty string; query_column_is_null() tells them apart), NULL for another column type.  query_column_int64() of such a column returns the string's id in the database's
+ * string dictionary (upstream: the bits of a heap pointer).  mdb_result_text_at(): the same for any row. */
+const char *query_column_text(struct result_set *res, int col_idx);
+const char *mdb_result_text_at(struct result_set *res, int col_idx, uint64_t row);
 int query_column_count(struct result_set *res);
 const char *query_column_name(struct result_set *res, int col_idx);	/* "T.col" / "COUNT(*)" */
 int query_column_type(struct result_set *res, int col_idx);		/* reference enum COLUMN_TYPE values */

@@ -185,13 +185,11 @@ int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_r
 			if (v->kind == MDB_EX_FLOAT) {
 				memcpy(&col->data[row], &v->dval, 8);
 			} else if (v->kind == MDB_EX_STRING && col->type == MDB_CT_VARCHAR) {
-				const size_t len = strlen(v->sval) - 2;
-				char *str = malloc(len + 1);
-				if (!str)
+				/* the cell is the string's id in the database's dictionary (struct mdb_strdict) */
+				const int64_t id = mdb_dict_intern(&cat->dict, v->sval + 1, strlen(v->sval) - 2);
+				if (!id)
 					return -MIDORIDB_NOMEM;	/* (rows already appended stay: the statement reports the failure) */
-				memcpy(str, v->sval + 1, len);
-				str[len] = 0;
-				col->data[row] = (int64_t)(intptr_t)str;
+				col->data[row] = id;
 			} else if (v->kind == MDB_EX_STRING) {
 				(void)mdb_parse_time(v->sval, col->type, &col->data[row]);	/* validated above */
 			} else {
@@ -262,10 +260,6 @@ static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, siz
 	}
 	if (e->kind == MDB_EX_FIELD) {
 		e->type = s->tabs[e->tbl_idx].t->cols[e->col_idx].type;
-		if (!mdb_type_on_device(e->type)) {
-			ERR("column '%s.%s': VARCHAR columns are kept on the host and cannot be referenced on the MI355X path\n", e->tbl, e->col);
-			return -MIDORIDB_ERROR;
-		}
 	}
 	for (int i = 0; i < e->nkids; i++)
 		if ((rc = resolve_expr(s, e->kids[i], err, errlen)))
@@ -326,12 +320,18 @@ static int check_predicate_x(const struct mdb_expr *e, const char *clause, bool 
 				ERR("comparison operands must have the same type\n");
 				return -MIDORIDB_ERROR;
 			}
-			if (tl == MDB_CT_VARCHAR || tr == MDB_CT_VARCHAR) {
-				ERR("VARCHAR values are kept on the host and cannot be compared on the MI355X path\n");
+			/* VARCHAR cells are dictionary ids: equal strings, equal ids - and nothing else (semantic_select.c:2171-2176,
+			 * semantic_delete.c:211-216) */
+			if ((tl == MDB_CT_VARCHAR || tr == MDB_CT_VARCHAR) && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
+				if (dml)
+					ERR("VARCHAR fields can only use '=' or '<>' ops\n");
+				else
+					ERR("VARCHAR values can only use '=' or '<>' ops\n");
 				return -MIDORIDB_ERROR;
 			}
 			for (int i = 0; i < 2; i++)
-				if (e->kids[i]->kind == MDB_EX_STRING && !mdb_parse_time(e->kids[i]->sval, i ? tl : tr, &tv)) {
+				if (e->kids[i]->kind == MDB_EX_STRING && (i ? tl : tr) != MDB_CT_VARCHAR &&
+				    !mdb_parse_time(e->kids[i]->sval, i ? tl : tr, &tv)) {
 					ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", e->kids[i]->sval);
 					return -MIDORIDB_ERROR;
 				}
@@ -355,8 +355,13 @@ static int check_predicate_x(const struct mdb_expr *e, const char *clause, bool 
 		}
 		for (int i = 1; i < e->nkids; i++) {
 			const struct mdb_expr *v = e->kids[i];
-			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL) {
+			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL &&
+			    v->kind != MDB_EX_STRING) {
 				ERR("IN-clause can only contain raw values\n");
+				return -MIDORIDB_ERROR;
+			}
+			if (v->kind == MDB_EX_STRING && e->kids[0]->type != MDB_CT_VARCHAR) {	/* (semantic_select.c:2308-2326) */
+				ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
 				return -MIDORIDB_ERROR;
 			}
 			if ((v->kind == MDB_EX_INT && e->kids[0]->type != MDB_CT_INTEGER) ||
@@ -508,15 +513,6 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 			ERR("SELECT * can't be combined with GROUP BY / COUNT\n");
 			return -MIDORIDB_ERROR;
 		}
-		if (s->select_all)
-			for (int t = 0; t < s->ntabs; t++)
-				for (int c = 0; c < s->tabs[t].t->ncols; c++)
-					if (!mdb_type_on_device(s->tabs[t].t->cols[c].type)) {
-						ERR("column '%s.%s': VARCHAR columns are kept on the host and cannot be referenced on the MI355X path "
-						    "(SELECT * over a table that has one: name the other columns)\n",
-						    s->tabs[t].t->name, s->tabs[t].t->cols[c].name);
-						return -MIDORIDB_ERROR;
-					}
 		if (ncount && nfield && !s->ngroup) {
 			ERR("mixing fields and COUNT in the select list requires a GROUP BY clause\n");
 			return -MIDORIDB_ERROR;
@@ -554,6 +550,10 @@ static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *e
 			}
 			if ((rc = resolve_expr(s, o, err, errlen)) || (rc = fields_in_select_list(s, o, "ORDER BY", err, errlen)))
 				return rc;
+			if (o->type == MDB_CT_VARCHAR) {	/* cells are dictionary ids: equality only, no collation order */
+				ERR("ORDER BY over the VARCHAR column '%s.%s' is not supported on the MI355X path\n", o->tbl, o->col);
+				return -MIDORIDB_ERROR;
+			}
 		}
 		if (s->norder > MDB_SORT_MAX_KEYS) {
 			ERR("too many ORDER BY items (max %d)\n", MDB_SORT_MAX_KEYS);
@@ -769,6 +769,9 @@ static int pred_emit(struct pred_prog *p, int op, int cmp, int type, int a, int 
 
 /* the 8 bytes a literal stands for in a column of type coltype (a DATE / DATETIME string: its time_t, validated by
  * check_predicate_x / the UPDATE checks) */
+/* the string dictionary of the database the running statement belongs to (set by the statement entry points) */
+static __thread const struct mdb_strdict *stmt_dict;
+
 static int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
 {
 	int64_t bits = 0;
@@ -776,6 +779,8 @@ static int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
 		memcpy(&bits, &v->dval, 8);
 		return bits;
 	}
+	if (v->kind == MDB_EX_STRING && coltype == MDB_CT_VARCHAR)	/* a string no cell holds has id -1: equal to nothing */
+		return stmt_dict ? mdb_dict_find(stmt_dict, v->sval + 1, strlen(v->sval) - 2) : -1;
 	if (v->kind == MDB_EX_STRING) {
 		(void)mdb_parse_time(v->sval, coltype, &bits);
 		return bits;
@@ -860,7 +865,7 @@ static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_ex
 				rc = pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
 			else
 				rc = pred_emit(p, MDB_P_CMP_COL_CONST, e->op ? MDB_CMP_NE : MDB_CMP_EQ,
-					       f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits(v));
+					       f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits_for(v, f->type));
 			if (rc)
 				return rc;
 			if (i > 1 && (rc = pred_emit(p, e->op ? MDB_P_AND : MDB_P_OR, 0, 0, 0, 0, 0)))
@@ -1309,6 +1314,7 @@ static int select_tail(struct exec *x, int has_count)
 
 int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen)
 {
+	stmt_dict = &cat->dict;
 	struct exec x;
 	struct mdb_result *res = NULL;
 	char (*keys)[MDB_NAME_LEN] = NULL;
@@ -1412,6 +1418,11 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		    (rc = fused_operand(&x, 1, fkeys[1], ws.push[1], ws.npush[1], &rv, &rn, &nr_rows)))
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
+		if (cat->dist && fkeys[0]->type == MDB_CT_VARCHAR) {
+			ERR("sharded mode: VARCHAR join keys are ids of this process's string dictionary and mean nothing to the other ranks\n");
+			rc = -MIDORIDB_ERROR;
+			goto out;
+		}
 		if (cat->dist) {
 			/* sharded mode: the tables hold this rank's rows; both key columns are exchanged (RCCL all-to-all per table,
 			 * include/mdb_dist.h) and this rank keeps the groups whose key hashes to it.  Collective: every rank runs the
@@ -1772,6 +1783,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		if (rc)
 			goto out;
 	}
+	res->dict = &cat->dict;
 	res->exec_ms = now_ms() - t0;
 	res->joined_rows = x.joined_rows;
 	*out = res;
@@ -1910,6 +1922,7 @@ static int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct ex
 
 int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen)
 {
+	stmt_dict = &cat->dict;
 	struct exec x;
 	struct mdb_select s;
 	struct mdb_from_tab tab;
@@ -1982,15 +1995,6 @@ int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		for (int c = 0; c < t->ncols; c++) {
 			struct mdb_column *col = &t->cols[c];
 			uint64_t nulls = 0;
-			if (col->type == MDB_CT_VARCHAR) {		/* the dropped rows' strings go with them */
-				uint64_t k = 0;
-				for (uint64_t r = 0; r < n_old; r++) {
-					if (k < n_keep && h_keep[k] == r)
-						k++;
-					else
-						free((void *)(intptr_t)col->data[r]);
-				}
-			}
 			for (uint64_t k = 0; k < n_keep; k++) {		/* ascending ids: in place */
 				const uint64_t r = h_keep[k];
 				const bool isnull = (col->nullbits[r >> 6] >> (r & 63)) & 1;
@@ -2027,6 +2031,7 @@ out:
 
 int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen)
 {
+	stmt_dict = &cat->dict;
 	struct exec x;
 	struct mdb_select s;
 	struct mdb_from_tab tab;
@@ -2085,11 +2090,15 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 					return -MIDORIDB_ERROR;
 				}
 			} else if (col->type == MDB_CT_VARCHAR) {
-				if (strlen(v->sval) - 2 + 1 > (size_t)col->precision) {
-					ERR("column: '%s' supports up to %d ASCII chars, value contains %lu\n", col->name, col->precision,
-					    (unsigned long)(strlen(v->sval) - 2 + 1));
-					return -MIDORIDB_ERROR;
+				/* UPDATE does not check the length (INSERT does): the reference copies the first precision - 1 characters
+				 * (strncpy, executor_update.c:425-426); the literal is cut here so that everything below sees that string */
+				const size_t len = strlen(v->sval) - 2, keep = col->precision > 0 ? (size_t)col->precision - 1 : 0;
+				if (len > keep) {
+					v->sval[1 + keep] = v->sval[0];
+					v->sval[2 + keep] = 0;
 				}
+				if (!mdb_dict_intern(&cat->dict, v->sval + 1, strlen(v->sval) - 2))	/* lit_bits_for() finds the id below */
+					return -MIDORIDB_NOMEM;
 			} else {
 				ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
 				return -MIDORIDB_ERROR;
@@ -2108,8 +2117,6 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 		struct mdb_column *col = &t->cols[acol[a]];
 		const struct mdb_expr *v = d->assign[a].val;
 		const bool set_null = v->kind == MDB_EX_NULL;
-		if (!mdb_type_on_device(col->type))
-			continue;		/* VARCHAR: the host copy below is all there is */
 		if (set_null && !col->d_nullbits) {
 			const uint64_t words = (t->dev_cap + 63) / 64;
 			if (mdb_dev_alloc(x.dev, words * 8, (void **)&col->d_nullbits) || mdb_dev_memset(x.dev, col->d_nullbits, 0, words * 8)) {
@@ -2151,29 +2158,6 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 			for (uint64_t k = 0; k < m; k++) {
 				const uint64_t r = h_sel ? h_sel[k] : k;
 				const bool was_null = (col->nullbits[r >> 6] >> (r & 63)) & 1;
-				if (col->type == MDB_CT_VARCHAR) {	/* every row owns its string */
-					char *str = NULL;
-					if (v->kind == MDB_EX_STRING) {
-						const size_t len = strlen(v->sval) - 2;
-						str = malloc(len + 1);
-						if (!str) {
-							rc = -MIDORIDB_NOMEM;
-							goto out;
-						}
-						memcpy(str, v->sval + 1, len);
-						str[len] = 0;
-					}
-					free((void *)(intptr_t)col->data[r]);
-					col->data[r] = (int64_t)(intptr_t)str;
-					if (v->kind == MDB_EX_NULL) {
-						col->nullbits[r >> 6] |= 1ull << (r & 63);
-						col->null_count += !was_null;
-					} else {
-						col->nullbits[r >> 6] &= ~(1ull << (r & 63));
-						col->null_count -= was_null;
-					}
-					continue;
-				}
 				if (v->kind == MDB_EX_NULL) {
 					col->nullbits[r >> 6] |= 1ull << (r & 63);
 					col->null_count += !was_null;

@@ -48,8 +48,10 @@ enum mdb_coltype {
 struct mdb_column {
 	char name[MDB_NAME_LEN];
 	int type;			/* enum mdb_coltype.  INTEGER / DOUBLE / DATE / DATETIME (time_t) / TINYINT (0 | 1) cells are 8-byte values
-					 * mirrored on the device; a VARCHAR cell is a host pointer to a heap string (the reference's layout,
-					 * src/primitive/column.c:255-293) and never leaves the host: statements may not reference such a column */
+					 * mirrored on the device; a VARCHAR cell is the 8-byte id of its string in the database's string
+					 * dictionary (struct mdb_strdict; the reference keeps a heap pointer per cell, src/primitive/column.c:
+					 * 255-293): equal strings have equal ids, so =, <>, IN, joins, GROUP BY and DISTINCT over VARCHAR
+					 * columns run on the device as INT64 work */
 	int precision;			/* VARCHAR(n): n bytes including the NUL (reference column.precision) */
 	bool not_null;			/* NOT NULL / PRIMARY KEY (reference column.nullable == false, executor_create.c:37,53) */
 	int64_t *data;			/* host copy, 8 bytes per row */
@@ -72,9 +74,25 @@ struct mdb_table {
 	bool device_only;		/* rows were generated on the device; there is no host copy */
 };
 
+/* The database's strings, each stored once: id = position + 1 (0 is what lies under a NULL cell, -1 the id of a literal
+ * no cell holds - it equals nothing).  Open addressing over FNV-1a; strings are never removed (a DELETE leaves its
+ * strings behind: ids must stay valid for the result sets and device mirrors that hold them). */
+struct mdb_strdict {
+	char **str;
+	uint32_t *len;
+	uint64_t n, cap;
+	uint64_t *slot;			/* id or 0 */
+	uint64_t nslots;
+};
+int64_t mdb_dict_intern(struct mdb_strdict *d, const char *s, size_t len);	/* id >= 1, or 0 when memory runs out */
+int64_t mdb_dict_find(const struct mdb_strdict *d, const char *s, size_t len);	/* id or -1 */
+const char *mdb_dict_str(const struct mdb_strdict *d, int64_t id);		/* NULL for an id the dictionary never gave out */
+void mdb_dict_free(struct mdb_strdict *d);
+
 struct mdb_catalog {
 	struct mdb_table **tables;
 	int n, cap;
+	struct mdb_strdict dict;
 	mdb_dev_ctx *dev;		/* created lazily by the first SELECT */
 	int dev_rc;			/* sticky result of the lazy creation */
 	/* sharded mode (MIDORIDB_WORLD_SIZE > 1 in the environment: one process per GPU, every process holds ITS rows of every
@@ -88,7 +106,7 @@ void mdb_catalog_free(struct mdb_catalog *cat);
 struct mdb_table *mdb_table_new(const char *name);
 void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev);
 int mdb_table_add_column(struct mdb_table *t, const char *name, int type);
-static inline bool mdb_type_on_device(int type) { return type != MDB_CT_VARCHAR; }
+static inline bool mdb_type_is_int64(int type) { return type != MDB_CT_DOUBLE; }	/* how the 8-byte cell compares on the device */
 /* time_t of a DATE ('%Y-%m-%d') / DATETIME ('%Y-%m-%d %H:%M:%S') literal, the reference's strptime + mktime
  * (include/primitive/column.h:27-28, src/engine/executor_insert.c:15-40); false when it does not parse */
 bool mdb_parse_time(const char *quoted, int type, int64_t *out);
@@ -215,6 +233,7 @@ struct mdb_result {
 	uint64_t nrows;
 	double exec_ms;			/* device pipeline wall time of the SELECT that produced it */
 	uint64_t joined_rows;		/* rows produced by the join before aggregation (0 when no join) */
+	const struct mdb_strdict *dict;	/* VARCHAR result cells are ids of this dictionary (the database's) */
 };
 void mdb_result_free(struct mdb_result *r);
 

@@ -208,6 +208,27 @@ double query_column_double(struct result_set *res, int col_idx)
 	return d;
 }
 
+const char *query_column_text(struct result_set *res, int col_idx)
+{
+	uint64_t row;
+	struct mdb_result *r = cur_row(res, col_idx, &row);
+	if (!r || r->coltype[col_idx] != MDB_CT_VARCHAR || !r->dict)
+		return NULL;
+	if (r->nullbits[col_idx] && ((r->nullbits[col_idx][row >> 6] >> (row & 63)) & 1))
+		return "";	/* upstream a NULL VARCHAR cell points at an empty string; query_column_is_null() tells them apart */
+	return mdb_dict_str(r->dict, r->data[col_idx][row]);
+}
+
+const char *mdb_result_text_at(struct result_set *res, int col_idx, uint64_t row)
+{
+	struct mdb_result *r = res ? res->table : NULL;
+	if (!r || col_idx < 0 || col_idx >= r->ncols || row >= r->nrows || r->coltype[col_idx] != MDB_CT_VARCHAR || !r->dict)
+		return NULL;
+	if (r->nullbits[col_idx] && ((r->nullbits[col_idx][row >> 6] >> (row & 63)) & 1))
+		return "";
+	return mdb_dict_str(r->dict, r->data[col_idx][row]);
+}
+
 bool query_column_is_null(struct result_set *res, int col_idx)
 {
 	uint64_t row;
@@ -286,7 +307,7 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 	for (int c = 0; c < ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
 		if (col->type == MDB_CT_VARCHAR) {
-			/* cells are `const char *` (NULL pointer, NULL flag or cols[c] == NULL: SQL NULL); the strings are copied */
+			/* cells are `const char *` (NULL pointer, NULL flag or cols[c] == NULL: SQL NULL); the strings are interned */
 			const char *const *strs = (const char *const *)cols[c];
 			for (uint64_t i = 0; i < n; i++) {
 				const uint64_t row = t->nrows + i;
@@ -297,15 +318,11 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 					col->null_count++;
 				} else {
 					size_t len = strlen(strs[i]);
-					char *str;
 					if (len + 1 > (size_t)col->precision)
 						len = (size_t)col->precision - 1;
-					str = malloc(len + 1);
-					if (!str)
+					col->data[row] = mdb_dict_intern(&cat->dict, strs[i], len);
+					if (!col->data[row])
 						return -MIDORIDB_NOMEM;
-					memcpy(str, strs[i], len);
-					str[len] = 0;
-					col->data[row] = (int64_t)(intptr_t)str;
 					col->nullbits[row >> 6] &= ~(1ull << (row & 63));
 				}
 			}

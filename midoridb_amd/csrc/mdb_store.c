@@ -66,9 +66,6 @@ void mdb_table_free(struct mdb_table *t, mdb_dev_ctx *dev)
 		return;
 	table_drop_device(t, dev);
 	for (int c = 0; c < t->ncols; c++) {
-		if (t->cols[c].type == MDB_CT_VARCHAR && t->cols[c].data)
-			for (uint64_t r = 0; r < t->nrows; r++)
-				free((void *)(intptr_t)t->cols[c].data[r]);	/* VARCHAR cells own their strings */
 		free(t->cols[c].data);
 		free(t->cols[c].nullbits);
 	}
@@ -101,8 +98,102 @@ bool mdb_parse_time(const char *quoted, int type, int64_t *out)
 	return true;
 }
 
+/* ------------------------------------------------------------------ string dictionary */
+static uint64_t dict_hash(const char *s, size_t len)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (size_t i = 0; i < len; i++)
+		h = (h ^ (unsigned char)s[i]) * 0x100000001b3ull;
+	return h ^ (h >> 29);
+}
+
+static uint64_t dict_probe(const struct mdb_strdict *d, const char *s, size_t len, bool *found)
+{
+	uint64_t i = dict_hash(s, len) & (d->nslots - 1);
+	*found = false;
+	while (d->slot[i]) {
+		const uint64_t id = d->slot[i];
+		if (d->len[id - 1] == len && memcmp(d->str[id - 1], s, len) == 0) {
+			*found = true;
+			return i;
+		}
+		i = (i + 1) & (d->nslots - 1);
+	}
+	return i;
+}
+
+int64_t mdb_dict_find(const struct mdb_strdict *d, const char *s, size_t len)
+{
+	bool found;
+	if (!d->nslots)
+		return -1;
+	const uint64_t i = dict_probe(d, s, len, &found);
+	return found ? (int64_t)d->slot[i] : -1;
+}
+
+int64_t mdb_dict_intern(struct mdb_strdict *d, const char *s, size_t len)
+{
+	bool found;
+	if ((d->n + 1) * 2 > d->nslots) {	/* keep the table at most half full */
+		const uint64_t ns = d->nslots ? d->nslots * 2 : 1024;
+		uint64_t *slot = calloc(ns, sizeof(*slot));
+		if (!slot)
+			return 0;
+		for (uint64_t id = 1; id <= d->n; id++) {
+			uint64_t i = dict_hash(d->str[id - 1], d->len[id - 1]) & (ns - 1);
+			while (slot[i])
+				i = (i + 1) & (ns - 1);
+			slot[i] = id;
+		}
+		free(d->slot);
+		d->slot = slot;
+		d->nslots = ns;
+	}
+	const uint64_t i = dict_probe(d, s, len, &found);
+	if (found)
+		return (int64_t)d->slot[i];
+	if (d->n == d->cap) {
+		const uint64_t nc = d->cap ? d->cap * 2 : 1024;
+		char **str = realloc(d->str, nc * sizeof(*str));
+		if (!str)
+			return 0;
+		d->str = str;
+		uint32_t *ln = realloc(d->len, nc * sizeof(*ln));
+		if (!ln)
+			return 0;
+		d->len = ln;
+		d->cap = nc;
+	}
+	char *copy = malloc(len + 1);
+	if (!copy)
+		return 0;
+	memcpy(copy, s, len);
+	copy[len] = 0;
+	d->str[d->n] = copy;
+	d->len[d->n] = (uint32_t)len;
+	d->n++;
+	d->slot[i] = d->n;
+	return (int64_t)d->n;
+}
+
+const char *mdb_dict_str(const struct mdb_strdict *d, int64_t id)
+{
+	return id >= 1 && (uint64_t)id <= d->n ? d->str[id - 1] : NULL;
+}
+
+void mdb_dict_free(struct mdb_strdict *d)
+{
+	for (uint64_t i = 0; i < d->n; i++)
+		free(d->str[i]);
+	free(d->str);
+	free(d->len);
+	free(d->slot);
+	memset(d, 0, sizeof(*d));
+}
+
 void mdb_catalog_free(struct mdb_catalog *cat)
 {
+	mdb_dict_free(&cat->dict);
 	for (int i = 0; i < cat->n; i++)
 		mdb_table_free(cat->tables[i], cat->dev);
 	free(cat->tables);
@@ -207,8 +298,6 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 	const uint64_t from = append ? t->dev_rows : 0;
 	for (int c = 0; c < t->ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
-		if (!mdb_type_on_device(col->type))
-			continue;	/* VARCHAR: host pointers, never referenced by the device path (rejected at plan time) */
 		if (t->nrows == 0)
 			continue;
 		rc = MIDORIDB_OK;

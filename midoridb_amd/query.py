@@ -29,6 +29,9 @@ class QueryOutputError(Structure):
     _fields_ = [("message", c_char * 1024)]
 
 
+CT_VARCHAR = 0        # reference enum COLUMN_TYPE (include/primitive/column.h:17-25)
+
+
 class QueryOutput(Structure):
     _fields_ = [("status", c_int), ("results", ResultSet), ("error", QueryOutputError), ("n_rows_aff", c_size_t)]
 
@@ -37,7 +40,7 @@ QUERY_SYMBOLS = [
     "database_open", "database_close", "query_execute", "query_cur_step", "query_column_int64", "query_free",
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
-    "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn",
+    "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
 ]
 
 
@@ -57,6 +60,10 @@ def _bind(lib):
     lib.query_cur_step.restype = c_int
     lib.query_column_int64.argtypes = [PRS, c_int]
     lib.query_column_int64.restype = c_int64
+    lib.query_column_text.argtypes = [PRS, c_int]
+    lib.query_column_text.restype = c_char_p
+    lib.mdb_result_text_at.argtypes = [PRS, c_int, c_uint64]
+    lib.mdb_result_text_at.restype = c_char_p
     lib.query_column_double.argtypes = [PRS, c_int]
     lib.query_column_double.restype = c_double
     lib.query_column_is_null.argtypes = [PRS, c_int]
@@ -105,7 +112,8 @@ class Result:
         return len(self.columns[0]) if self.columns else 0
 
     def rows(self):
-        return [tuple(int(c[i]) for c in self.columns) for i in range(self.nrows)]
+        """VARCHAR cells come as str (None for NULL), everything else as int (the 8-byte cell)"""
+        return [tuple(c[i] if (c[i] is None or isinstance(c[i], str)) else int(c[i]) for c in self.columns) for i in range(self.nrows)]
 
 
 class DB:
@@ -169,12 +177,20 @@ class DB:
             nulls = [[] for _ in range(nc)]
             while self.lib.query_cur_step(rs) == MIDORIDB_ROW:
                 for c in range(nc):
-                    cols[c].append(self.lib.query_column_int64(rs, c))
+                    if types[c] == CT_VARCHAR:
+                        t = self.lib.query_column_text(rs, c)
+                        cols[c].append(None if t is None else t.decode())
+                    else:
+                        cols[c].append(self.lib.query_column_int64(rs, c))
                     nulls[c].append(bool(self.lib.query_column_is_null(rs, c)))
-            cols = [np.array(c, dtype=np.int64) for c in cols]
+            cols = [np.array(c, dtype=object if types[i] == CT_VARCHAR else np.int64) for i, c in enumerate(cols)]
             nulls = [np.array(x, dtype=bool) for x in nulls]
         else:
             for c in range(nc):
+                if types[c] == CT_VARCHAR:       # dictionary ids -> strings
+                    texts = [self.lib.mdb_result_text_at(rs, c, i) for i in range(nrows)]
+                    cols.append(np.array([None if t is None else t.decode() for t in texts], dtype=object))
+                    continue
                 p = self.lib.query_column_data(rs, c)
                 cols.append(np.ctypeslib.as_array(p, shape=(nrows,)).copy() if nrows else np.zeros(0, dtype=np.int64))
             nulls = [None] * nc
@@ -184,9 +200,17 @@ class DB:
 
     # -- ingest -------------------------------------------------------------------------------
     def append_columns(self, table, cols, nulls=None):
+        """cols: one sequence per table column - numbers, or str / None for a VARCHAR column"""
         n = len(cols[0])
-        arrs = [np.ascontiguousarray(np.asarray(c).view(np.int64) if np.asarray(c).dtype == np.float64 else np.asarray(c, dtype=np.int64))
-                for c in cols]
+        arrs, keep = [], []
+        for c in cols:
+            if len(c) and any(isinstance(v, str) for v in c):     # VARCHAR: an array of char pointers (NULL = SQL NULL)
+                bufs = [None if v is None else ctypes.create_string_buffer(v.encode()) for v in c]
+                keep.append(bufs)
+                arrs.append(np.array([0 if b is None else ctypes.addressof(b) for b in bufs], dtype=np.int64))
+                continue
+            a = np.asarray(c)
+            arrs.append(np.ascontiguousarray(a.view(np.int64) if a.dtype == np.float64 else np.asarray(c, dtype=np.int64)))
         cp = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         narrs = None
         npp = None

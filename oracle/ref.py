@@ -131,8 +131,18 @@ class RefDB:
             raise RefError("not a SELECT")
         names, vals, _nulls = self.fetch()
         # values only, as query_column_int64() would return them: the reference's NULL bitmap is not
-        # reliable in results (see ref_harness.c), a NULL cell reads as 0
-        return names, [tuple(int(vals[i, k]) for k in range(len(names))) for i in range(len(vals))]
+        # reliable in results (see ref_harness.c), a NULL cell reads as 0.  A VARCHAR cell is a heap pointer in THIS
+        # process (src/primitive/column.c:255-293): it is followed here, a NULL cell (pointer 0) reads as None.
+        self.L.ref_result_coltype.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.L.ref_result_coltype.restype = ctypes.c_int
+        types = [self.L.ref_result_coltype(self.h, k) for k in range(len(names))]
+
+        def cell(i, k):
+            v = int(vals[i, k])
+            if types[k] != 0:
+                return v
+            return None if v == 0 else ctypes.string_at(v).decode()
+        return names, [tuple(cell(i, k) for k in range(len(names))) for i in range(len(vals))]
 
     def rows_affected(self):
         return int(self.L.ref_rows_affected(self.h))

@@ -102,6 +102,26 @@ FIXED = {
     "SELECT id, born FROM P;": ["NAME id", "NAME born", "TABLE P", "SELECT 0 3", "STMT"],
     "SELECT id, born, seen, ok FROM P;": ["NAME id", "NAME born", "NAME seen", "NAME ok", "TABLE P", "SELECT 0 5", "STMT"],
     "SELECT id FROM P;": ["NAME id", "TABLE P", "SELECT 0 2", "STMT"],
+    # ... VARCHAR columns
+    "SELECT id, name FROM P;": ["NAME id", "NAME name", "TABLE P", "SELECT 0 3", "STMT"],
+    "SELECT id FROM P WHERE name = 'bob';": ["NAME id", "TABLE P", "NAME name", "STRING 'bob'", "CMP 4", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT id FROM P WHERE name <> 'bob';": ["NAME id", "TABLE P", "NAME name", "STRING 'bob'", "CMP 3", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT id FROM P WHERE name = 'nobody';": ["NAME id", "TABLE P", "NAME name", "STRING 'nobody'", "CMP 4", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT id FROM P WHERE name <> 'nobody';": ["NAME id", "TABLE P", "NAME name", "STRING 'nobody'", "CMP 3", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT id, name FROM P WHERE name IS NULL;": ["NAME id", "NAME name", "TABLE P", "NAME name", "ISNULL", "WHERE", "SELECT 0 4", "STMT"],
+    "SELECT id FROM P WHERE name > 'ann';": ["NAME id", "TABLE P", "NAME name", "STRING 'ann'", "CMP 2", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT id FROM P WHERE name = 5;": ["NAME id", "TABLE P", "NAME name", "NUMBER 5", "CMP 4", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT qid, note FROM Q WHERE note = 'zz' OR note = 'x';":
+        ["NAME qid", "NAME note", "TABLE Q", "NAME note", "STRING 'zz'", "CMP 4", "NAME note", "STRING 'x'", "CMP 4", "OR", "WHERE", "SELECT 0 4", "STMT"],
+    "SELECT qid, note FROM Q;": ["NAME qid", "NAME note", "TABLE Q", "SELECT 0 3", "STMT"],
+    "SELECT cid, vid FROM C INNER JOIN V ON C.city = V.town;":
+        ["NAME cid", "NAME vid", "TABLE C", "TABLE V", "FIELDNAME C.city", "FIELDNAME V.town", "CMP 4", "ONEXPR", "JOIN 1", "SELECT 0 3", "STMT"],
+    "SELECT city, COUNT(*) FROM C GROUP BY city;": ["NAME city", "COUNTALL", "TABLE C", "NAME city", "GROUPBYLIST 1", "SELECT 0 4", "STMT"],
+    "SELECT city, COUNT(*) FROM C INNER JOIN V ON C.city = V.town GROUP BY city;":
+        ["NAME city", "COUNTALL", "TABLE C", "TABLE V", "FIELDNAME C.city", "FIELDNAME V.town", "CMP 4", "ONEXPR", "JOIN 1", "NAME city", "GROUPBYLIST 1",
+         "SELECT 0 4", "STMT"],
+    "SELECT cid FROM C WHERE city IN ('rome');": ["NAME cid", "TABLE C", "NAME city", "STRING 'rome'", "ISIN 1", "WHERE", "SELECT 0 3", "STMT"],
+    "SELECT cid FROM C WHERE city NOT IN ('rome');": ["NAME cid", "TABLE C", "NAME city", "STRING 'rome'", "ISNOTIN 1", "WHERE", "SELECT 0 3", "STMT"],
     "SELECT k, v FROM N;": ["NAME k", "NAME v", "TABLE N", "SELECT 0 3", "STMT"],
 }
 

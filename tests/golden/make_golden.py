@@ -459,12 +459,43 @@ def typed_scripts():
             "SELECT COUNT(*) FROM P WHERE seen IS NULL;",
             "SELECT id FROM P WHERE born = '2001-02-03';",
             "SELECT id FROM P WHERE id = 'abc';",
+            # VARCHAR: equality only; cells travel as ids of the database's string dictionary on the device
+            "SELECT id, name FROM P;",
+            "SELECT id FROM P WHERE name = 'bob';",
+            "SELECT id FROM P WHERE name <> 'bob';",
+            "SELECT id FROM P WHERE name = 'nobody';",
+            "SELECT id FROM P WHERE name <> 'nobody';",
+            "SELECT id, name FROM P WHERE name IS NULL;",
+            "SELECT id FROM P WHERE name > 'ann';",
+            "SELECT id FROM P WHERE name = 5;",
+            "SELECT qid, note FROM Q WHERE note = 'zz' OR note = 'x';",
+        ],
+        "typed_varchar_join_group": [
+            "CREATE TABLE C (cid INT, city VARCHAR(8));",
+            "CREATE TABLE V (vid INT, town VARCHAR(8));",
+            "INSERT INTO C VALUES (1, 'oslo'), (2, 'rome'), (3, 'oslo'), (4, NULL), (5, 'bern'), (6, 'rome'), (7, 'oslo');",
+            "INSERT INTO V VALUES (10, 'rome'), (11, 'oslo'), (12, 'paris'), (13, NULL), (14, 'oslo');",
+            "SELECT cid, vid FROM C INNER JOIN V ON C.city = V.town;",
+            "SELECT city, COUNT(*) FROM C GROUP BY city;",
+            "SELECT city, COUNT(*) FROM C INNER JOIN V ON C.city = V.town GROUP BY city;",
+            "SELECT cid FROM C WHERE city IN ('rome');",
+            "SELECT cid FROM C WHERE city NOT IN ('rome');",
         ],
         "typed_dml": setup + [
             "DELETE FROM P WHERE born < '2000-01-01';",
             "SELECT id, born FROM P;",
+            "DELETE FROM Q WHERE note = 'x';",
+            "SELECT qid, note FROM Q;",
+            "DELETE FROM Q WHERE note <> 'zz';",
+            "SELECT qid, note FROM Q;",
+            "DELETE FROM Q WHERE note >= 'a';",
+            "UPDATE Q SET note = 'new' WHERE note = 'zz';",
+            "UPDATE Q SET note = 'toolong' WHERE qid = 11;",
+            "SELECT qid, note FROM Q;",
             "UPDATE P SET seen = '2025-02-03 04:05:06', ok = FALSE WHERE id = 2;",
             "UPDATE P SET name = 'zed' WHERE id = 4;",
+            "UPDATE P SET name = 'bob2' WHERE name = 'bob';",
+            "SELECT id, name FROM P;",
             "UPDATE P SET born = NULL WHERE ok = TRUE;",
             "SELECT id, born, seen, ok FROM P;",
             "DELETE FROM P WHERE seen >= '2025-01-01 00:00:00';",
