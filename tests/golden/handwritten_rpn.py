@@ -128,6 +128,7 @@ FIXED = {
 N = r"(-?\d+)"
 # randomised fixtures: one hand-written queue per template, the literals of the case filled in
 TEMPLATES = [
+    (r"SELECT f1 FROM (TEST|[DU]\d);", lambda t: ["NAME f1", f"TABLE {t}", "SELECT 0 2", "STMT"]),
     (rf"SELECT f1, f2 FROM A INNER JOIN B ON A\.id_a = B\.id_b WHERE f1 > {N} AND f2 <= {N};",
      lambda k, m: ["NAME f1", "NAME f2"] + NORTH_AB + ["NAME f1", f"NUMBER {k}", "CMP 2", "NAME f2", f"NUMBER {m}", "CMP 5", "AND", "WHERE", "SELECT 0 4", "STMT"]),
     (r"SELECT id_a, COUNT\(\*\) FROM A GROUP BY id_a;", lambda: ["NAME id_a", "COUNTALL", "TABLE A", "NAME id_a", "GROUPBYLIST 1", "SELECT 0 4", "STMT"]),
@@ -153,5 +154,5 @@ def handwritten(sql):
     for pat, fn in TEMPLATES:
         m = re.fullmatch(pat, sql)
         if m:
-            return fn(*[int(g) for g in m.groups()])
+            return fn(*[int(g) if re.fullmatch(r"-?\d+", g) else g for g in m.groups()])
     return None

@@ -505,6 +505,36 @@ def typed_scripts():
             "INSERT INTO P VALUES (7, 'ok', NULL, NULL, 5, NULL);",
             "SELECT id FROM P;",
         ],
+        # the reference's own DELETE / UPDATE tests over DATE and VARCHAR columns (tests/engine/executor_delete.c:1107-1560,
+        # tests/engine/executor_update.c:1420-1975): the same tables and statements, the table re-read after each one (plus a
+        # NULL row, which no comparison matches: it keeps the table non-empty - the reference crashes on a SELECT over a table
+        # without live rows)
+        "ref_delete_date": sum([[f"CREATE TABLE D{i} (f1 DATE);",
+                                 f"INSERT INTO D{i} VALUES ('1990-01-01'), ('1991-01-01'), ('1992-01-01'), ('1993-01-01'), (NULL);",
+                                 f"DELETE FROM D{i} WHERE f1 {op} '{lit}';", f"SELECT f1 FROM D{i};"]
+                                for i, (op, lit) in enumerate([("=", "1990-01-01"), (">", "1990-01-01"), (">=", "1990-01-01"), ("<", "1991-01-01"),
+                                                               ("<=", "1992-01-01"), ("<>", "1992-01-01")])], []),
+        "ref_update_date": sum([[f"CREATE TABLE U{i} (f1 DATE);",
+                                 f"INSERT INTO U{i} VALUES ('1990-01-01'), ('1991-01-01'), ('1992-01-01'), ('1993-01-01'), (NULL);",
+                                 f"UPDATE U{i} SET f1 = '1993-01-01' WHERE f1 {op} '{lit}';", f"SELECT f1 FROM U{i};"]
+                                for i, (op, lit) in enumerate([("=", "1990-01-01"), (">", "1990-01-01"), (">=", "1990-01-01"), ("<", "1991-01-01"),
+                                                               ("<=", "1992-01-01"), ("<>", "1992-01-01")])], []),
+        "ref_dml_varchar": [
+            "CREATE TABLE TEST (f1 VARCHAR(4));",
+            "INSERT INTO TEST VALUES ('123');", "INSERT INTO TEST VALUES ('456');", "INSERT INTO TEST VALUES (NULL);", "INSERT INTO TEST VALUES ('789');",
+            "DELETE FROM TEST WHERE f1 > '123';", "DELETE FROM TEST WHERE f1 >= '456';", "DELETE FROM TEST WHERE f1 < NULL;", "DELETE FROM TEST WHERE f1 <= '789';",
+            "UPDATE TEST SET f1='852' WHERE f1 > '123';", "UPDATE TEST SET f1='852' WHERE f1 >= '456';", "UPDATE TEST SET f1='852' WHERE f1 < NULL;",
+            "UPDATE TEST SET f1='852' WHERE f1 <= '789';",
+            "SELECT f1 FROM TEST;",
+            "UPDATE TEST SET f1='852' WHERE f1 = '123';",
+            "SELECT f1 FROM TEST;",
+            "DELETE FROM TEST WHERE f1 = '852';",
+            "SELECT f1 FROM TEST;",
+            "DELETE FROM TEST WHERE f1 <> '456';",
+            "SELECT f1 FROM TEST;",
+            "UPDATE TEST SET f1 = NULL WHERE f1 = '456';",
+            "SELECT f1 FROM TEST;",
+        ],
         "typed_not_null": [
             "CREATE TABLE N (k INT PRIMARY KEY, v DOUBLE NOT NULL, note VARCHAR(8));",
             "INSERT INTO N VALUES (1, 0.5, 'a');",
