@@ -40,6 +40,7 @@
 #define PART_ITEMS (MDB_TILE / PART_THREADS)		/* 8 keys per thread */
 #define PART_WAVE_SPAN (MDB_TILE / PART_WAVES)		/* 512 consecutive keys per wave */
 #define PART_MAX_R (1u << MDB_MAX_RADIX_BITS)
+#define PART_FEW_DIGITS 4u	/* up to this many digits (destination GPUs) a wave ranks its keys with ballots, not one atomic per key */
 #define PART_INVALID 0xFFFFFFFFu
 
 struct mdb_tile_desc {
@@ -279,6 +280,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 		uint32_t rid[2];
 		bool valid[2];
 		part_load2<LEVEL0, false, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid);
+		if (LEVEL0 && a.R <= PART_FEW_DIGITS) {	/* few destinations: one add per wave and digit (see k_part_scatter) */
+			for (int k = 0; k < 2; k++) {
+				const uint32_t dg = valid[k] ? part_digit(a, hv[k]) : PART_INVALID;
+				for (uint32_t d = 0; d < a.R; d++) {
+					const uint64_t m = __ballot(dg == d);
+					if (m && mdb_lane() == (uint32_t)__ffsll((long long)m) - 1u)
+						atomicAdd(&s_h[d], (uint32_t)__popcll(m));
+				}
+			}
+			continue;
+		}
 		if (valid[0])
 			atomicAdd(&s_h[part_digit(a, hv[0])], 1u);
 		if (valid[1])
@@ -449,6 +461,27 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 				run += t;
 			}
 			s_cnt[threadIdx.x] = run;
+		}
+	} else if (INV && R <= PART_FEW_DIGITS) {
+		/* 1, 2, 4 destination GPUs: a wave's 64 keys would meet on one or two LDS words (32- to 64-way serialisation of the
+		 * returning atomics: the two by-destination kernels took 1.7 ms per 2 x 10^8 keys at one destination).  The lanes of
+		 * a digit find each other with one ballot per digit; the lowest of them takes the wave's share of the counter */
+		const uint64_t lt = mdb_lanemask_lt();
+#pragma unroll
+		for (int r = 0; r < PART_ITEMS; r++) {
+			rank[r] = 0u;
+			for (uint32_t d = 0; d < R; d++) {
+				const uint64_t m = __ballot(dig[r] == d);
+				if (!m)
+					continue;
+				const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+				uint32_t base = 0;
+				if (lane == leader)
+					base = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
+				base = __shfl(base, (int)leader, MDB_WAVE);
+				if (dig[r] == d)
+					rank[r] = base + (uint32_t)__popcll(m & lt);
+			}
 		}
 	} else {
 		/* one returning LDS atomic per key; order inside a digit = arrival order (unspecified) */
