@@ -1573,12 +1573,6 @@ struct gc_state {
 static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 {
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
-	/* two 9-bit levels give at most 2^18 leaves; a leaf's LDS table holds GC_SLOTS distinct keys */
-	if ((st->n_l >> (st->b1 + st->b2)) > (uint64_t)GC_SLOTS * 7 / 10)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR,
-				   "%llu build rows exceed what one GPU shard groups in LDS (about %llu): partition the tables across GPUs "
-				   "(mdb_dev_partition_by_dest)",
-				   (unsigned long long)st->n_l, (unsigned long long)(((uint64_t)GC_SLOTS * 7 / 10) << (2 * MDB_MAX_RADIX_BITS)));
 	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
 	if (st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
 		st->narrow = false;
@@ -1598,6 +1592,14 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		       (1u << (st->b1 + st->b2 - 1)) >= 16u * (uint32_t)ctx->num_cus)	/* ... while every workgroup still has leaves to walk */
 			st->b2--;
 	}
+	/* two 9-bit levels give at most 2^18 leaves; a leaf's LDS hash table holds GC_SLOTS distinct keys.  The direct-address
+	 * kernel has no such table (its leaves hold whatever rows share 2^rem key values): 10^9 x 10^9 rows of surrogate keys run
+	 * on one GPU */
+	if (!st->direct && (st->n_l >> (st->b1 + st->b2)) > (uint64_t)GC_SLOTS * 7 / 10)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR,
+				   "%llu build rows exceed what one GPU shard groups in LDS (about %llu): partition the tables across GPUs "
+				   "(mdb_dev_partition_by_dest)",
+				   (unsigned long long)st->n_l, (unsigned long long)(((uint64_t)GC_SLOTS * 7 / 10) << (2 * MDB_MAX_RADIX_BITS)));
 	/* Semi-join filter: when the key sample says that most left rows have no partner (a fact table joined with a
 	 * dimension that covers part of its key range - the benchmark's variant D: 1 row in 16), the right table is
 	 * partitioned FIRST, its hashed keys become a bitmap (k_leaf_bitmap: one contiguous slice per leaf), and the second

@@ -435,7 +435,7 @@ def _sort_case(dev, rng, n, specs, with_rid=False, topk=None):
     [("neg", False, 0.0), ("full", True, 0.0)], [("neg", True, 0.01), ("double", False, 0.3), ("small", False, 0.0)],
     [("full", False, 0.999)], [("full", True, 0.999)],
 ], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
-def test_topk_perm_is_the_prefix_of_the_stable_sort(dev, specs):
+def test_topk_perm_is_the_prefix_of_the_stable_sort_unpinned(dev, specs):
     """ORDER BY ... LIMIT k (extension): threshold from a sample, one filter pass, sort of the candidates -
     the same first k positions as the full stable sort for INT64 / DOUBLE first keys, ascending and descending, NULLs
     first / last (also when almost every row is NULL and the threshold is one), ties on the first key broken by
@@ -451,7 +451,7 @@ def test_topk_perm_is_the_prefix_of_the_stable_sort(dev, specs):
 
 @pytest.mark.parametrize("specs,n", [([("small", False, 0.0)], 300_000), ([("const", True, 0.0), ("full", False, 0.0)], 300_000),
                                      ([("full", False, 0.0)], 5000), ([("full", True, 0.0)], 0)])
-def test_topk_perm_falls_back_to_the_full_sort(dev, specs, n):
+def test_topk_perm_falls_back_to_the_full_sort_unpinned(dev, specs, n):
     """few distinct first-key values (every candidate set is most of the table), small inputs, k above n/8, k > n"""
     rng = np.random.default_rng(n + 1)
     cand = _sort_case(dev, rng, n, specs, topk=[3, 50, n // 2, n, n + 5] if n else [0, 3])
@@ -459,7 +459,7 @@ def test_topk_perm_falls_back_to_the_full_sort(dev, specs, n):
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 100_000, 1_000_003])
-def test_sort_perm_single_key_sizes(dev, n):
+def test_sort_perm_single_key_sizes_unpinned(dev, n):
     rng = np.random.default_rng(n)
     _sort_case(dev, rng, n, [("neg", False, 0.0)])
     _sort_case(dev, rng, n, [("small", True, 0.1)])
@@ -470,13 +470,13 @@ def test_sort_perm_single_key_sizes(dev, n):
     [("const", True, 0.5)], [("small", False, 0.0), ("neg", True, 0.0)], [("small", True, 0.3), ("double", False, 0.3), ("small", False, 0.0)],
     [("small", False, 1.0)], [("neg", False, 0.0), ("full", False, 0.0), ("double", True, 0.0), ("small", True, 0.2)],
 ], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
-def test_sort_perm_key_kinds(dev, specs):
+def test_sort_perm_key_kinds_unpinned(dev, specs):
     rng = np.random.default_rng(len(specs) * 7 + 1)
     _sort_case(dev, rng, 50_000, specs)
     _sort_case(dev, rng, 50_000, specs, with_rid=True)
 
 
-def test_sort_perm_large_property(dev):
+def test_sort_perm_large_property_unpinned(dev):
     """10^7 rows, 2 keys: result is a permutation, keys come out non-decreasing, ties keep stream order."""
     n = 10_000_000
     a = dev.gen_keys(n, 0, n, 5, 1000)			# 1000 distinct values
@@ -494,7 +494,7 @@ def test_sort_perm_large_property(dev):
 
 
 @pytest.mark.parametrize("n", [1, 2, 64, 4097, 60_000])
-def test_distinct_sel(dev, n):
+def test_distinct_sel_unpinned(dev, n):
     rng = np.random.default_rng(n + 11)
     a = rng.integers(-3, 4, n, dtype=np.int64)
     b = np.round(rng.normal(0, 1, n), 0)
@@ -647,7 +647,7 @@ def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
 
 
 @pytest.mark.parametrize("n", [1, 2, 65, 4097, 80_000])
-def test_group_count_multi(dev, n):
+def test_group_count_multi_unpinned(dev, n):
     rng = np.random.default_rng(n + 21)
     a = rng.integers(-2, 3, n, dtype=np.int64)
     b = rng.integers(0, 4, n, dtype=np.int64)
@@ -665,7 +665,7 @@ def test_group_count_multi(dev, n):
         assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
 
 
-def test_group_count_multi_large_property(dev):
+def test_group_count_multi_large_property_unpinned(dev):
     """10^7 rows, key = (i mod 1000, i mod 7): 7000 groups (1000 and 7 are coprime), counts n/7000 +- 1, firsts = 0..6999."""
     n = 10_000_000
     i = torch.arange(n, dtype=torch.int64, device=dev.device)
@@ -976,7 +976,7 @@ def test_split_operator_with_a_right_table_larger_than_announced(dev, i32):
     ("full", False, 0.0, False), ("small", False, 1.0, False),
 ])
 @pytest.mark.parametrize("n", [262_144, 300_001, 1_500_000])
-def test_sort_perm_single_key_packed_path(dev, kind, desc, nf, with_rid, n):
+def test_sort_perm_single_key_packed_path_unpinned(dev, kind, desc, nf, with_rid, n):
     """Single ORDER BY column from 2^18 rows on: value range and stream position share one word, partitioned by its top
     bits and finished per leaf in LDS.  Against the numpy oracle: ascending / descending, NULLs first / last, DOUBLE
     (incl. -0.0 / 0.0), all-equal and all-NULL columns, through a row-id vector; 'full' (64-bit range) does not fit
@@ -985,7 +985,7 @@ def test_sort_perm_single_key_packed_path(dev, kind, desc, nf, with_rid, n):
 
 
 @pytest.mark.parametrize("shape", ["bunched_high", "bunched_low", "two_values", "sorted", "reversed", "geometric"])
-def test_sort_perm_single_key_uneven_value_distributions(dev, shape):
+def test_sort_perm_single_key_uneven_value_distributions_unpinned(dev, shape):
     """Value distributions the fixed-capacity leaves of the packed path cannot hold (the top bits are the values
     themselves) are detected on the device and sorted by the general path: same permutation either way."""
     n = 700_000
@@ -1010,7 +1010,7 @@ def test_sort_perm_single_key_uneven_value_distributions(dev, shape):
         assert np.array_equal(got, want)
 
 
-def test_sort_perm_packed_path_large_property(dev):
+def test_sort_perm_packed_path_large_property_unpinned(dev):
     """10^8 rows, one key: a permutation, keys non-decreasing, ties in stream order."""
     n = 100_000_000
     for modulus in (0, 5000):
@@ -1032,7 +1032,7 @@ def test_sort_perm_packed_path_large_property(dev):
     [("small", False, 0.0), ("double", True, 0.1)],                                                                       # DOUBLE range: general path
     [("neg", True, 1.0), ("small", False, 0.0)],
 ], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
-def test_sort_perm_multi_key_packed_path(dev, specs):
+def test_sort_perm_multi_key_packed_path_unpinned(dev, specs):
     """Several ORDER BY columns whose ranges fit one word together (composite word, most significant column first)."""
     rng = np.random.default_rng(len(specs) * 13 + 5)
     _sort_case(dev, rng, 400_003, specs)
@@ -1164,6 +1164,25 @@ def test_compact_and_hashed_leaf_kernels_agree_at_scale(dev, narrow_mode):
             assert out[0][3] == out[m][3] == n
 
 
+def test_join_group_count_8e8_rows_per_table_on_one_gpu(dev, narrow_mode):
+    """Beyond the hashed leaf kernel's table capacity (7 * 10^8 build rows at 2^18 leaves): the direct-address leaves of the
+    compact narrow form have no table to overflow.  8 * 10^8 x 8 * 10^8 rows of the benchmark's generator (variant D),
+    checked through size-independent properties: groups, joined rows, every COUNT = 16, keys unique, first rows ascending."""
+    narrow_mode(1)
+    n = 800_000_000
+    kl = dev.gen_keys(n, 0, n, 42, 0)
+    kr = dev.gen_keys(n, 0, n, 43, n // 16)
+    k, c, f, j = dev.join_group_count(kl, None, kr, None)
+    assert dev.last_join_form() == 2
+    assert k.numel() == n // 16 and j == n and int(c.sum()) == n and int(c.min()) == 16 and int(c.max()) == 16
+    assert int(torch.unique(k).numel()) == k.numel()
+    fi = f.to(torch.int64) & 0xFFFFFFFF
+    assert bool((fi[1:] > fi[:-1]).all())
+    assert bool((kl[fi] == k).all())          # a group's key is the key of its first left row
+    del kl, kr, k, c, f, fi
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", ["dup16", "subrange", "few_right_rows", "no_match", "nulls", "offset"])
 def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(dev, narrow_mode, monkeypatch, shape):
     """Selective joins in the compact narrow form: the right table is partitioned first, its hashed keys become a bitmap
@@ -1231,7 +1250,7 @@ def test_semijoin_filter_at_scale_matches_the_unfiltered_operator(dev, narrow_mo
 
 
 @pytest.mark.parametrize("n", [262_144, 600_001])
-def test_group_count_multi_and_distinct_on_the_packed_sort_path(dev, n):
+def test_group_count_multi_and_distinct_on_the_packed_sort_path_unpinned(dev, n):
     """From 2^18 rows on, INT64 columns whose ranges fit one word are sorted by the packed path and the group / distinct
     run heads come from its sorted composite values (no per-row column gathers): against the numpy oracle with NULLs,
     negative values, a row-id vector, many and few groups; a DOUBLE column keeps the general path."""
@@ -1428,7 +1447,7 @@ def test_single_workgroup_materialising_join_and_its_boundaries(dev, n_l, n_r, d
     [("small", False, 0.0), ("neg", True, 0.0), ("small", True, 0.0), ("neg", False, 0.0), ("small", False, 0.0)],
 ], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
 @pytest.mark.parametrize("n", [2, 777, 2048, 2049])
-def test_sort_perm_single_workgroup_path_for_tiny_inputs(dev, specs, n):
+def test_sort_perm_single_workgroup_path_for_tiny_inputs_unpinned(dev, specs, n):
     """Up to 2048 rows and four columns the permutation comes from one workgroup that ranks every row by counting; five
     columns, or one row more, take the radix passes.  Same stable order (NULLs first ascending / last descending, DOUBLE
     by total order) either way."""
