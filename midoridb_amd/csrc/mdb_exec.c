@@ -1891,6 +1891,8 @@ static int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct ex
 	if ((rc = mdb_catalog_device(cat, err, errlen)) || (rc = mdb_table_sync_device(cat, t, err, errlen)))
 		return rc;
 	memset(x, 0, sizeof(*x));
+	for (int i = 0; i < MDB_MAX_TABS; i++)
+		x->same_col[i] = -1;
 	x->cat = cat;
 	x->dev = cat->dev;
 	x->s = s;

@@ -143,6 +143,25 @@ class DeviceError(RuntimeError):
     pass
 
 
+class _LibBuffer:
+    """__cuda_array_interface__ view of a device buffer owned by the library; torch keeps this object alive as long as a
+    tensor made from it exists, and the buffer is handed back to the library's allocator afterwards."""
+
+    def __init__(self, ctx, ptr, numel, dtype):
+        self._ctx, self._ptr = ctx, ptr
+        item = torch.empty(0, dtype=dtype).element_size()
+        kind = "f" if dtype.is_floating_point else "i"
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": f"<{kind}{item}", "data": (int(ptr), False), "version": 2}
+
+    def __del__(self):
+        try:
+            if self._ptr and self._ctx.h:
+                self._ctx.lib.mdb_dev_free(self._ctx.h, c_void_p(self._ptr))
+        except Exception:
+            pass
+        self._ptr = 0
+
+
 class DeviceCtx:
     """One mdb_dev_ctx bound to a torch device and (by default) torch's current stream."""
 
@@ -380,7 +399,8 @@ class DeviceCtx:
 
     def filter_project(self, prog, cols, n, proj):
         """Scan + WHERE + projection of one table: prog / cols as filter(); proj = [(values, nullbits or None), ...] ->
-        (count, [(values[count], nullbits words or None), ...]) - copies of the library-allocated outputs."""
+        (count, [(values[count], nullbits words or None), ...]): tensors over the library-allocated outputs themselves (no
+        copy; the buffer goes back to the library's allocator when the tensor is released)."""
         insns = (PredInsn * max(len(prog), 1))()
         for i, (op, cmp_, typ, a, b, imm) in enumerate(prog):
             if typ == T_DOUBLE and isinstance(imm, float):
@@ -399,20 +419,14 @@ class DeviceCtx:
         m = cnt.value
         outs = []
         for i, (v, nb) in enumerate(proj):
-            dst = torch.empty(max(m, 1), dtype=v.dtype, device=self.device)
-            dnull = None
-            if m:
-                self._chk(self.lib.mdb_dev_gather64(self.h, ov[i], None, None, m, _ptr(dst), None), "copy")
-                if nb is not None:
-                    words = (m + 63) // 64
-                    dnull = torch.empty(words, dtype=torch.int64, device=self.device)
-                    self._chk(self.lib.mdb_dev_gather64(self.h, on[i], None, None, words, _ptr(dnull), None), "copy")
-                self.sync()
-                self._chk(self.lib.mdb_dev_free(self.h, ov[i]), "free")
-                if nb is not None:
-                    self._chk(self.lib.mdb_dev_free(self.h, on[i]), "free")
-            outs.append((dst[:m], dnull))
+            dst = self._adopt(ov[i], max(n, 1), v.dtype)
+            dnull = self._adopt(on[i], (n + 63) // 64 or 1, torch.int64) if (nb is not None and on[i].value) else None
+            outs.append((dst[:m], dnull[:(m + 63) // 64] if dnull is not None else None))
         return m, outs
+
+    def _adopt(self, ptr, numel, dtype):
+        """a tensor over a buffer the library allocated (mdb_dev_alloc): no copy; mdb_dev_free when the tensor goes away"""
+        return torch.as_tensor(_LibBuffer(self, ptr.value, numel, dtype), device=self.device)
 
     def double_join_keys(self, src, src_null, idx=None):
         """DOUBLE join keys as words that compare like IEEE `==`: (int64 words, NULL bits with the NaN rows added)."""
