@@ -55,6 +55,7 @@ struct mdb_dev_ctx {
 	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */
 	uint64_t pu_dupl_n;
 	int pu_dup_skips;
+	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
@@ -172,6 +173,20 @@ __host__ __device__ static inline uint32_t mdb_mixk(uint32_t x, uint32_t k)
 	x = (x * 0x85EBCA6Bu) & mask;
 	x ^= x >> s;
 	x = (x * 0xC2B2AE35u) & mask;
+	x ^= x >> s;
+	return x;
+}
+
+/* inverse of mdb_mixk: x ^= x >> s is an involution on k-bit words (2 s >= k), the multipliers have inverses modulo 2^32
+ * and therefore modulo 2^k */
+__host__ __device__ static inline uint32_t mdb_unmixk(uint32_t x, uint32_t k)
+{
+	const uint32_t mask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+	const uint32_t s = (k + 1) >> 1;
+	x ^= x >> s;
+	x = (x * 0x7ED1B41Du) & mask;		/* 0xC2B2AE35^-1 */
+	x ^= x >> s;
+	x = (x * 0xA5CB9243u) & mask;		/* 0x85EBCA6B^-1 */
 	x ^= x >> s;
 	return x;
 }

@@ -121,6 +121,10 @@ struct gc_args {
 	uint32_t nleaves;
 	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
 	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r = array of 4-byte hash32 */
+	uint32_t keyed_cbits;		/* direct-address leaves, != 0: KEYED group records - (first row id, hashed key, COUNT(*)) with COUNT in
+					 * the low keyed_cbits bits and the key_bits-wide hashed key above it: the ordering kernel decodes the
+					 * group key from the record instead of gathering it from the key column (selective joins: the groups'
+					 * first rows are scattered over the left table, every gathered key costs a 128-byte line) */
 	uint32_t merge_all;		/* plain GROUP BY: the key sample held duplicates (some 10^4 - 10^5 distinct values): merge equal
 					 * values per wave in every leaf, not only in the oversize ones */
 };
@@ -816,7 +820,7 @@ __device__ static inline void ld_left_row(unsigned long long w, uint32_t shift, 
 
 struct ld_state {
 	uint32_t *s_cr, *s_cl, *s_first, *s_chunk;
-	uint32_t T, mask, shift;
+	uint32_t T, mask, shift, rem;
 	unsigned long long mine;
 	uint32_t nvalid;
 };
@@ -927,7 +931,12 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 					s_cl[s] = 0u;
 					s_first[s] = 0xFFFFFFFFu;
 					st.mine += c;
-					if (a.kbits) {
+					if (a.kbits && a.keyed_cbits) {
+						if (c >> a.keyed_cbits)
+							mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
+						recv = ((unsigned long long)first << (64 - a.kbits)) |
+						       ((unsigned long long)((leaf << st.rem) | s) << a.keyed_cbits) | c;
+					} else if (a.kbits) {
 						if (c >> (64 - a.kbits))
 							mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
 						if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
@@ -966,6 +975,7 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 	extern __shared__ __attribute__((aligned(16))) uint32_t ld_lds[];
 	ld_state st;
 	st.T = 1u << rem;
+	st.rem = rem;
 	st.mask = st.T - 1u;
 	st.shift = shift;
 	st.s_cr = ld_lds;			/* right rows per key */
@@ -1329,6 +1339,10 @@ struct ord_args {
 	int64_t *out_key;		/* ... into here (keys[first]) */
 	uint32_t keys32;		/* `keys` is an int32 column */
 	uint32_t rec32;			/* the records are 4-byte words: (row id << (32 - kbits)) | payload */
+	uint32_t keyed_cbits;		/* != 0: keyed records (gc_args.keyed_cbits): payload = hashed key << keyed_cbits | COUNT(*); the group key
+					 * is key_lo + mdb_unmixk(hashed key, key_bits), nothing is gathered */
+	uint32_t key_bits;
+	int64_t key_lo;
 };
 
 __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
@@ -1392,6 +1406,13 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 		const unsigned long long v = s_slot[i];
 		const uint32_t first = first_base + (uint32_t)(v >> 51);
 		a.out_first[base + i] = first;
+		if (a.keyed_cbits) {
+			const unsigned long long pay = v & ((1ull << 51) - 1ull);
+			a.out_count[base + i] = (int64_t)(pay & ((1ull << a.keyed_cbits) - 1ull));
+			if (a.out_key)
+				a.out_key[base + i] = a.key_lo + (int64_t)mdb_unmixk((uint32_t)(pay >> a.keyed_cbits), a.key_bits);
+			continue;
+		}
 		if (a.out_val32)
 			a.out_val32[base + i] = (uint32_t)(v & ((1ull << 51) - 1ull)) - 1u;
 		else
@@ -1437,9 +1458,9 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
  * everything after it moves half the bytes (10^8 groups of one row each: 1.3 -> 0.9 ms for the ordering) */
 static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
 			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,
-			 bool keys32 = false, bool rec32 = false)
+			 bool keys32 = false, bool rec32 = false, uint32_t keyed_cbits = 0, uint32_t key_bits = 0, int64_t key_lo = 0)
 {
-	rec32 = rec32 && sb2 > 0 && kbits < 32;
+	rec32 = rec32 && sb2 > 0 && kbits < 32 && !keyed_cbits;
 	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
 	uint64_t *h = ctx->h_pinned;
 	int rc;
@@ -1464,6 +1485,9 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 		oa.out_key = out_key;
 		oa.keys32 = keys32 ? 1u : 0u;
 		oa.rec32 = ps.w32 ? 1u : 0u;
+		oa.keyed_cbits = keyed_cbits;
+		oa.key_bits = key_bits;
+		oa.key_lo = key_lo;
 		if (ps.leaf_cap) {
 			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
 			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
@@ -1526,6 +1550,7 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
 #define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 #define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
+#define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
 #define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
 
 /* MDB_DIRECT_LEAF=0 keeps the compact narrow form off (A/B measurements, soaks of the hashed leaf kernel) */
@@ -1745,6 +1770,17 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
 	a.narrow = st->narrow ? 1u : 0u;
+	/* keyed records (see gc_args.keyed_cbits) when the join is selective - few groups, their first rows scattered over the left
+	 * table - and a COUNT(*) of at least 4 bits fits beside the row id and the hashed key (10 bits at 10^8 rows, 27 key bits);
+	 * a COUNT that does not fit is reported by the kernel and the operator redone with plain records (and remembered).
+	 * MDB_KEYED_RECORDS=0 switches them off */
+	uint32_t keyed_cbits = 0;
+	if (st->direct && has_r && st->selective && records && !ctx->keyed_distrust && pl.leaf_cap && pr.leaf_cap && kbits >= 13 &&
+	    kbits + st->key_bits + 4u <= 64u && !(getenv("MDB_KEYED_RECORDS") && getenv("MDB_KEYED_RECORDS")[0] == '0'))
+		keyed_cbits = 64u - kbits - st->key_bits;
+	if (ctx->keyed_distrust > 0)
+		ctx->keyed_distrust--;
+	a.keyed_cbits = keyed_cbits;
 	/* 4096 sampled keys with fewer than 4050 distinct values among them: at most a few 10^5 distinct values in the column */
 	a.merge_all = (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) ? 1u : 0u;
 	{
@@ -1807,6 +1843,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
+	if (((uint32_t)h[1] & 64u) && keyed_cbits) {
+		ctx->keyed_distrust = 64;	/* hot leaves go through kernels that write plain records: redo with those everywhere */
+		return GC_RETRY_UNKEYED;
+	}
 	if ((uint32_t)h[1] & 64u) {
 		/* hot keys: the plain kernel left the leaves with GC_HEAVY or more rows on a side to this path */
 		hot_args ha;
@@ -1866,6 +1906,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	const uint64_t joined = h[2];
 	if (status & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
+	if (status & 256u) {
+		ctx->keyed_distrust = 64;	/* a COUNT(*) too large for a keyed record: plain records, now and for a while */
+		return GC_RETRY_UNKEYED;
+	}
 	if (status & 4u)
 		return GC_RETRY_DENSE;	/* a COUNT(*) too large to share a 64-bit record with its row id */
 	if ((status & 1u) && build_r)
@@ -1880,7 +1924,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
 		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32,
-				   !(status & 16u));
+				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo);
 		if (rc)
 			return rc;
 	} else if (G) {
@@ -2229,6 +2273,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
+		else if (rc == GC_RETRY_UNKEYED)
+			;		/* (gc_finish has set ctx->keyed_distrust) */
 		else if (rc == GC_RETRY_BUILD_L)
 			no_build_r = true;
 		else
@@ -2508,7 +2554,7 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN)	/* skew / huge counts / wide keys: redo the whole operator */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
 	return rc;

@@ -1227,6 +1227,66 @@ def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(de
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, on, slice_bits)
 
 
+@pytest.mark.parametrize("shape", ["dup16", "subrange", "nulls", "offset"])
+def test_keyed_group_records_decode_the_key_instead_of_gathering_it(dev, narrow_mode, monkeypatch, shape):
+    """Selective joins in the compact narrow form write (first row, hashed key, COUNT) records and the ordering kernel
+    decodes the group key from them (mdb_unmixk) instead of gathering it from the key column: identical keys, counts,
+    first rows and order with the records keyed and plain, against the oracle."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 17 + 3)
+    n_l, n_r, span, off = 3_100_000 + 8192 * len(shape), 2_400_000 + 8192 * len(shape), 3_100_000 + 8192 * len(shape), 0
+    kl = rng.permutation(span)[:n_l].astype(np.int64)
+    nl = nr = None
+    if shape == "dup16":
+        kr = (rng.permutation(span)[:n_r] % (span // 16)).astype(np.int64)
+    elif shape == "subrange":
+        kr = rng.integers(span // 3, span // 3 + span // 6, n_r, dtype=np.int64)
+    elif shape == "nulls":
+        kr = rng.integers(0, span // 10, n_r, dtype=np.int64)
+        nl, nr = rng.random(n_l) < 0.05, rng.random(kr.size) < 0.3
+    elif shape == "offset":
+        off = 10**15
+        kr = rng.integers(0, span // 5, n_r, dtype=np.int64)
+    else:
+        off = 10**15
+        kr = rng.integers(0, span // 5, n_r, dtype=np.int64)
+    kl, kr = kl + off, kr + off
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for keyed in ("1", "0", "1"):
+        monkeypatch.setenv("MDB_KEYED_RECORDS", keyed)
+        k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert dev.last_join_form() == 2, (shape, keyed)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, keyed)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, keyed)
+
+
+def test_keyed_group_records_give_way_when_a_count_does_not_fit(dev, narrow_mode, monkeypatch):
+    """4 * 10^7 x 4 * 10^7 rows (26 row-id bits + 26 key bits leave 12 bits of a keyed record for COUNT(*)): one key that
+    8 left rows and 512 right rows hold has COUNT(*) = 4096 - the kernel reports it, the operator is redone with plain
+    records and remembers; results equal the plain-record run element for element."""
+    narrow_mode(1)
+    n = 40_000_000
+    kl = dev.gen_keys(n, 0, n, 42, 0)
+    kr = dev.gen_keys(n, 0, n, 43, n // 16)
+    key = int(kl[12345].item()) % (n // 16)		# a value both tables hold
+    pos_l = torch.arange(8, device=kl.device) * 4_000_001 + 77
+    pos_r = torch.arange(512, device=kl.device) * 70_001 + 5
+    kl[pos_l] = key
+    kr[pos_r] = key
+    out = {}
+    for keyed in ("0", "1", "1"):
+        monkeypatch.setenv("MDB_KEYED_RECORDS", keyed)
+        k, c, f, j = dev.join_group_count(kl, None, kr, None)
+        assert dev.last_join_form() == 2
+        out[keyed] = (k.clone(), c.clone(), f.clone(), j)
+    for a, b in zip(out["0"][:3], out["1"][:3]):
+        assert torch.equal(a, b)
+    assert out["0"][3] == out["1"][3]
+    k, c = out["1"][0], out["1"][1]
+    assert int(c[k == key].item()) >= 4096
+
+
 def test_semijoin_filter_at_scale_matches_the_unfiltered_operator(dev, narrow_mode, monkeypatch):
     """4 * 10^7 x 4 * 10^7 rows of the benchmark's variant D (1 left row in 16 has a partner): identical columns with the
     filter on and off; variant U (every row has one) does not take the filter."""
