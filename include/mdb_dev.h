@@ -67,12 +67,15 @@ int mdb_dev_set_overlap(mdb_dev_ctx *ctx, int on);
 int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode);
 /* 1 when the last completed join / GROUP BY operator of this context ran in the narrow form (for byte accounting) */
 int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
-/* Semi-join filter of the compact narrow form: when the key sample says that the right table covers less than a quarter of
- * the left table's key range (or has less than a quarter of its rows), the right table is partitioned first, its hashed keys become
- * a bitmap, and the second partition level of the left table drops the rows that can join nothing before writing them.
- * Exact in effect (a row is only dropped when no right row can have its key): results are identical, only bytes moved
- * change.  Environment MDB_SEMIJOIN=0 turns it off.
- * -> 0 when the last completed join operator did not filter, else 1 + log2(adjacent hashed values per bitmap bit). */
+/* Pruning of the left table in the compact narrow form (unsplit calls): the right table is partitioned first.
+ * Min-max pruning: its first partition level records the exact range of its keys and the left table's first level drops
+ * every row outside (MDB_MINMAX_PRUNE=0 turns it off).  Semi-join filter: when the key sample says that the right table
+ * has less than a quarter of the left table's rows without covering a small part of its range, its hashed keys also
+ * become a bitmap and the left table's second level drops the rows whose bit is clear (MDB_SEMIJOIN=0 turns it off).
+ * Both are exact in effect (a row is only dropped when no right row can have its key): results are identical, only the
+ * bytes moved change.
+ * -> of the last completed join operator: bit 8 = min-max pruning ran; low byte = 0 without the bitmap, else 1 +
+ * log2(adjacent hashed values per bitmap bit). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 

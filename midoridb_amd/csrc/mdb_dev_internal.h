@@ -54,10 +54,19 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
  * second level's workgroup loads its digit's slice into LDS (into the staging buffer, before it is needed) and drops the
  * rows whose bit is clear before they are ranked and written. */
 struct mdb_part_filter {
-	const uint32_t *bits;
+	const uint32_t *bits;	/* NULL: no bitmap */
 	uint32_t words;		/* per first-level digit: a power of two, 4 ... 8192 (32 KiB) */
 	uint32_t shift;		/* bit index (before masking to the slice) = hash32 >> shift */
+	/* min-max pruning at the FIRST level (compact narrow form): the right table's call passes minmax_out (two words the caller
+	 * initialised to 0xFFFFFFFF, 0: smallest / largest key - window base seen), the left table's call, later on the same
+	 * stream, passes the same words as range_in and drops the rows outside */
+	uint32_t *minmax_out;
+	uint32_t *minmax_tiles;	/* with minmax_out: scratch of mdb_part_minmax_words(n) words (a pair per first-level tile, reduced after the launch) */
+	const uint32_t *range_in;
+	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then
+				 * sized by the tiles that exist (a 4-byte read-back + synchronisation) instead of by the table */
 };
+static inline size_t mdb_part_minmax_words(uint64_t n) { return (size_t)((n + MDB_TILE - 1) / MDB_TILE + 8) * 2; }
 
 int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			int bits1, int bits2, bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow = 0,

@@ -1587,6 +1587,9 @@ struct gc_state {
 	int64_t key_lo;
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
+	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
+	bool defer_l;		/* the LEFT table is partitioned after the right one, in gc_finish (compact narrow form, unsplit call): the
+				 * right table's first level records its exact key range, the left table's drops the rows outside */
 	uint32_t semijoin;	/* != 0: the LEFT table is partitioned after the right one (gc_finish), its second level dropping the rows
 				 * whose bit is clear in a bitmap of the right table's hashed keys; the value is log2 of the adjacent
 				 * hashed values that share a bit, plus 1 */
@@ -1633,8 +1636,14 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * (<= 32 KiB: one bit per 2^c adjacent hashed values when the window is wide) is staged in LDS per tile; the first level
 	 * cannot filter - its rows are in table order, a lookup there costs a 128-byte line from L2 per row (measured: slower).
 	 * A wrong hint costs time, never results.  MDB_SEMIJOIN=0 switches it off, MDB_SEMIJOIN_SLICE=<log2 bits> sizes the slice. */
+	/* Min-max pruning, always when the call is not split: the right table goes first and its first partition level
+	 * records the exact range of its keys (two atomics per wave and tile); the left table's first level reads the two words
+	 * from device memory and drops every row outside - the classic dimension-range pruning of a fact table, exact, at the
+	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
+	 * below would filter nothing more and is not built. */
+	st->defer_l = st->direct && st->has_r && st->defer_ok && !st->active && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
 	st->semijoin = 0;
-	if (st->direct && st->has_r && st->selective && st->defer_ok && !st->active) {
+	if (st->defer_l && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
 		const uint32_t slice_max = e2 && atoi(e2) >= 7 && atoi(e2) <= 18 ? (uint32_t)atoi(e2) : 17u;	/* log2 bits: 2^17 = 16 KiB */
 		const uint32_t below0 = st->key_bits - (uint32_t)st->b1;		/* hash bits below the first-level digit */
@@ -1646,6 +1655,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->semijoin)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
+	if (st->defer_l)
+		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 4) + 256;
 	if (st->has_r)
 		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	{
@@ -1668,7 +1679,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	if (!st->semijoin) {
+	if (!st->defer_l) {
 		rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
 					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
 		if (rc)
@@ -1699,10 +1710,30 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
 		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
 			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
+		mdb_part_filter rflt;
+		memset(&rflt, 0, sizeof(rflt));
+		if (st->defer_l) {
+			/* [16] smallest, [17] largest key - window base of the right table (min-max pruning) */
+			rflt.minmax_out = ctx->d_status + 16;
+			rflt.minmax_tiles = (uint32_t *)mdb_arena_take(ctx, mdb_part_minmax_words(n_r) * 4);
+			if (!rflt.minmax_tiles)
+				return -MIDORIDB_INTERNAL;
+		}
 		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32,
-					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
+					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, st->defer_l ? &rflt : NULL);
 		if (rc)
 			return rc;
+	}
+	if (st->defer_l && !st->semijoin) {
+		mdb_part_filter flt;
+		memset(&flt, 0, sizeof(flt));
+		flt.range_in = ctx->d_status + 16;
+		flt.expect_pruned = st->by_span;
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32, st->key_lo, st->key_bits,
+					 &flt);
+		if (rc)
+			return rc;
+		pl = st->pl;
 	}
 	if (st->semijoin) {
 		/* the right table's hashed keys as a bitmap, then the left table through it */
@@ -1717,6 +1748,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		MDB_LAUNCH(ctx, "leaf_bitmap", k_leaf_bitmap, groups < resident ? groups : resident, LB_WAVES * MDB_WAVE,
 			   reinterpret_cast<const uint32_t *>(pr.hv), pr.leaf_cnt, pr.leaf_cap, pr.nleaves, rem, coarse, 32u - st->key_bits, bits);
 		mdb_part_filter flt;
+		memset(&flt, 0, sizeof(flt));
+		flt.range_in = ctx->d_status + 16;
+		flt.expect_pruned = st->by_span;
 		flt.bits = bits;
 		flt.words = 1u << (st->key_bits - (uint32_t)st->b1 - coarse - 5u);
 		flt.shift = 32u - st->key_bits + coarse;
@@ -1947,7 +1981,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (out_joined)
 		*out_joined = joined;
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
-	ctx->last_semijoin = (int)st->semijoin;
+	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0);
 	return MIDORIDB_OK;
 }
 
@@ -2134,6 +2168,7 @@ struct gc_window {
 	int64_t lo;
 	bool selective;		/* the right table's sampled keys cover less than a quarter of the left table's sampled key range, or the right
 				 * table has less than a quarter of the left table's rows: most left rows will find no partner (semi-join filter) */
+	bool by_span;		/* ... the former: min-max pruning at the first level will drop them, no bitmap needed */
 };
 
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
@@ -2145,6 +2180,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		win->kbits = 0;
 		win->lo = 0;
 		win->selective = false;
+		win->by_span = false;
 	}
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
@@ -2166,6 +2202,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 			win->kbits = ctx->nh_kbits;
 			win->lo = ctx->nh_lo;
 			win->selective = ctx->nh_selective;
+			win->by_span = ctx->nh_by_span;
 		}
 		return MIDORIDB_OK;
 	}
@@ -2187,12 +2224,15 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	int64_t wlo = 0;
 	if (*narrow)
 		gc_compact_window(lo, hi, &kb, &wlo);
-	const bool selective = keys_r && n_r && ((ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4) || n_r < n_l / 4);
+	const bool by_span = keys_r && n_r && ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4;
+	const bool selective = keys_r && n_r && (by_span || n_r < n_l / 4);
 	if (win) {
 		win->kbits = kb;
 		win->lo = wlo;
 		win->selective = selective;
+		win->by_span = by_span;
 	}
+	ctx->nh_by_span = by_span;
 	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base, kb, wlo);
 	ctx->nh_selective = selective;
 	return MIDORIDB_OK;
@@ -2224,6 +2264,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.key_bits = narrow ? win.kbits : 0u;
 	st.key_lo = win.lo;
 	st.selective = win.selective;
+	st.by_span = win.by_span;
 	st.keys32 = keys32;
 	st.defer_ok = true;
 	int rc = gc_begin(ctx, &st);
@@ -2241,7 +2282,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
 	int64_t base = 0;
-	gc_window win = { 0, 0, false };
+	gc_window win = { 0, 0, false, false };
 	int rc = MIDORIDB_OK;
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow

@@ -91,16 +91,24 @@ struct mdb_level_args {
 	 * slice) is clear can join nothing and is dropped before it is ranked */
 	const uint32_t *filter;
 	uint32_t filter_words, filter_shift;
+	/* min-max pruning (first level, compact narrow form): the RIGHT table's launch leaves the smallest and the largest
+	 * key - window base it saw in minmax_out[0..1] (atomics; the caller has stored 0xFFFFFFFF, 0 there), the LEFT table's
+	 * launch - later on the same stream - reads them through range_in and drops every row outside: such a row can join
+	 * nothing.  Exact, and free: one compare per row, no extra pass, no host round trip */
+	uint32_t *minmax_out;
+	const uint32_t *range_in;
 	uint32_t fold64;		/* raw 4-byte words: the input is still the list of 8-byte records, folded on the fly (record >> 32 | low
 					 * half: the caller knows that the two parts do not overlap) */
 };
 
 /* level-0 word of one key */
-__device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_t key, uint32_t rid, bool *bad)
+__device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_t key, uint32_t rid, bool *bad, uint64_t *rel = nullptr)
 {
 	if (!a.narrow)
 		return mdb_fmix64(key);
 	key -= (uint64_t)a.narrow_base;		/* (wraps: the tests below are on the 64-bit difference) */
+	if (rel)
+		*rel = key;
 	uint32_t h;
 	if (a.narrow_kbits) {
 		*bad = *bad || (key >> a.narrow_kbits);
@@ -172,7 +180,7 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
  * not NULL. */
 template <bool LEVEL0, bool HAS_RID, bool RAW = false, bool INV = false>
 __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint64_t hv[2],
-					 uint32_t rid[2], bool valid[2])
+					 uint32_t rid[2], bool valid[2], uint64_t *rel = nullptr /* [2]: key - narrow_base (narrow forms) */)
 {
 	const uint32_t lead = td.start & 1u;
 	const uint64_t base2 = (uint64_t)(td.start - lead);
@@ -195,8 +203,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			} else {
 				k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
 			}
-			hv[0] = INV ? k.x : part_hash_key(a, k.x, (uint32_t)g0, &bad[0]);	/* INV: the caller keeps the key itself */
-			hv[1] = INV ? k.y : part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1]);
+			hv[0] = INV ? k.x : part_hash_key(a, k.x, (uint32_t)g0, &bad[0], rel ? &rel[0] : nullptr);	/* INV: the caller keeps the key itself */
+			hv[1] = INV ? k.y : part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1], rel ? &rel[1] : nullptr);
 			rid[0] = (uint32_t)g0;
 			rid[1] = (uint32_t)g0 + 1;
 		} else {
@@ -214,7 +222,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
 			const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
-			hv[k] = INV ? (uint64_t)key : part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k]);
+			hv[k] = INV ? (uint64_t)key : part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k], rel ? &rel[k] : nullptr);
 			rid[k] = (uint32_t)g;
 		} else {
 			hv[k] = a.hv_in[g];
@@ -349,6 +357,14 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	if (STABLE)
 		for (uint32_t i = threadIdx.x; i < PART_WAVES * PART_MAX_R; i += PART_THREADS)
 			s_wcnt[i] = 0;
+	/* min-max pruning: the other table's key range (left side) / what this launch sees (right side) */
+	uint64_t range_lo = 0, range_hi = ~0ull;
+	uint32_t seen_min = 0xFFFFFFFFu, seen_max = 0u;
+	__shared__ uint32_t s_mm[2 * PART_WAVES];
+	if (LEVEL0 && a.range_in) {
+		range_lo = a.range_in[0];
+		range_hi = a.range_in[1];
+	}
 	/* the filter slice of this tile's first-level digit lives in the staging buffer until the rows are ranked (the
 	 * barrier after the load separates its last read from the first staged word) */
 	uint32_t *const s_flt = reinterpret_cast<uint32_t *>(s_hv);
@@ -408,7 +424,19 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		for (int r = 0; r < PART_ITEMS / 2; r++) {
 			bool valid[2];
 			uint64_t h2[2];
-			part_load2<LEVEL0, HAS_RID, RAW, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid);
+			constexpr bool RANGE = LEVEL0 && FAST && !RAW && !INV && !HAS_RID;	/* (the narrow forms' first level) */
+			uint64_t rel2[2] = { 0, 0 };
+			part_load2<LEVEL0, HAS_RID, RAW, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid, RANGE ? rel2 : nullptr);
+			if (RANGE && a.narrow_kbits) {
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					valid[k] = valid[k] && rel2[k] >= range_lo && rel2[k] <= range_hi;
+					if (a.minmax_out && valid[k]) {		/* (a valid row of the compact form: rel < 2^narrow_kbits <= 2^32) */
+						seen_min = rel2[k] < seen_min ? (uint32_t)rel2[k] : seen_min;
+						seen_max = rel2[k] > seen_max ? (uint32_t)rel2[k] : seen_max;
+					}
+				}
+			}
 			if (FILT) {		/* (narrow words: hash32 in the upper half) */
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
@@ -422,7 +450,32 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			dig[2 * r + 1] = valid[1] ? part_digit(a, INV ? (W)mdb_fmix64(h2[1]) : hv[2 * r + 1]) : PART_INVALID;
 		}
 	}
+	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_out) {
+#pragma unroll
+		for (int o = MDB_WAVE / 2; o > 0; o >>= 1) {
+			const uint32_t omin = (uint32_t)__shfl_xor((int)seen_min, o, MDB_WAVE), omax = (uint32_t)__shfl_xor((int)seen_max, o, MDB_WAVE);
+			seen_min = omin < seen_min ? omin : seen_min;
+			seen_max = omax > seen_max ? omax : seen_max;
+		}
+		if (lane == 0) {
+			s_mm[2 * wave] = seen_min;
+			s_mm[2 * wave + 1] = seen_max;
+		}
+	}
 	__syncthreads();
+	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_out && threadIdx.x == 0) {
+		/* one pair of plain stores per tile, reduced by k_part_minmax_reduce: atomics on two words from every wave of every
+		 * tile (2 x 10^5 of them on the same address) cost 4 ms, coherent loads of "the best so far" 0.2 ms */
+		uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+		for (int w = 0; w < PART_WAVES; w++) {
+			mn = s_mm[2 * w] < mn ? s_mm[2 * w] : mn;
+			mx = s_mm[2 * w + 1] > mx ? s_mm[2 * w + 1] : mx;
+		}
+		const uint32_t t = part_tile_of_block();
+		a.minmax_out[2 * t] = mn;
+		a.minmax_out[2 * t + 1] = ~mx;		/* (stored inverted: the array is initialised with one memset of 0xFF) */
+	}
 
 	/* 2. rank inside the digit */
 	if (STABLE) {
@@ -729,6 +782,37 @@ __global__ void k_part_seg0(uint32_t *seg_start, uint32_t *tb, uint32_t n, uint3
 	}
 }
 
+/* per-tile (min, max) pairs of the right table's first level -> the two words the left table's first level reads */
+__global__ __launch_bounds__(1024) void k_part_minmax_reduce(const uint32_t *__restrict__ tile_mm, uint32_t ntiles, uint32_t *__restrict__ out)
+{
+	__shared__ uint32_t s_mn[16], s_mx[16];
+	uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+		const uint32_t a = tile_mm[2 * t], b = ~tile_mm[2 * t + 1];
+		mn = a < mn ? a : mn;
+		mx = b > mx ? b : mx;
+	}
+#pragma unroll
+	for (int o = MDB_WAVE / 2; o > 0; o >>= 1) {
+		const uint32_t omin = (uint32_t)__shfl_xor((int)mn, o, MDB_WAVE), omax = (uint32_t)__shfl_xor((int)mx, o, MDB_WAVE);
+		mn = omin < mn ? omin : mn;
+		mx = omax > mx ? omax : mx;
+	}
+	if (mdb_lane() == 0) {
+		s_mn[threadIdx.x / MDB_WAVE] = mn;
+		s_mx[threadIdx.x / MDB_WAVE] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 0; w < 16; w++) {
+			mn = s_mn[w] < mn ? s_mn[w] : mn;
+			mx = s_mx[w] > mx ? s_mx[w] : mx;
+		}
+		out[0] = mn;
+		out[1] = mx;
+	}
+}
+
 /* ---- host orchestration ----------------------------------------------------------------------- */
 
 struct part_carver {
@@ -866,6 +950,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keys32 = (flags & PART_F_KEYS32) ? 1u : 0u;
 		a.narrow_base = narrow_base;
 		a.narrow_kbits = a.narrow ? narrow_kbits : 0u;
+		a.minmax_out = (flt && l == 0 && flt->minmax_out) ? flt->minmax_tiles : NULL;	/* per-tile pairs, reduced after the launch */
+		a.range_in = (flt && l == 0) ? flt->range_in : NULL;
 		a.filter = (flt && l == 1) ? flt->bits : NULL;
 		a.filter_words = flt ? flt->words : 0u;
 		a.filter_shift = flt ? flt->shift : 0u;
@@ -900,7 +986,11 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
+					if (a.minmax_out)
+						MDB_HIP(ctx, hipMemsetAsync(a.minmax_out, 0xFF, (size_t)grid8(ntiles) * 8, ctx->stream));
 					MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					if (a.minmax_out)
+						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else {
@@ -910,12 +1000,23 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
 					   cap0, PART_NSUB, next_desc, next_tiles);
 			}
+			uint32_t real_tiles = next_tiles;
+			if (!dry && flt && flt->range_in && flt->expect_pruned) {
+				/* min-max pruning may have dropped most rows: the second level is launched for the tiles that exist (one
+				 * 4-byte read-back and a synchronisation, ~15 us) - 26 000 workgroups that find an empty descriptor and leave
+				 * cost 0.09 ms at 10^8 rows */
+				uint64_t *h = ctx->h_pinned;
+				MDB_HIP(ctx, hipMemcpyAsync(&h[15], reg_nt + nreg0, 4, hipMemcpyDeviceToHost, ctx->stream));
+				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				const uint32_t got = (uint32_t)h[15];
+				real_tiles = got < next_tiles ? (got ? got : 1u) : next_tiles;
+			}
 			used_bits += bits1;
 			seg_start = NULL;
 			tb = NULL;
 			S = R;
 			tiles = next_desc;
-			ntiles = next_tiles;
+			ntiles = real_tiles;
 			continue;
 		}
 		if (fast_level) {
@@ -1051,9 +1152,12 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32, int64_t narrow_base,
 			uint32_t narrow_kbits, const mdb_part_filter *flt)
 {
-	if (flt && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 || flt->words < 4 || flt->words > MDB_TILE * 2 ||
-		    (flt->words & (flt->words - 1))))
+	if (flt && flt->bits && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 || flt->words < 4 || flt->words > MDB_TILE * 2 ||
+				 (flt->words & (flt->words - 1))))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "semi-join filter: left side of the compact narrow form, two fast levels, slices of 4 ... 8192 words");
+	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 ||
+							  (flt->minmax_out && (narrow != 2 || !flt->minmax_tiles))))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning: compact narrow form, two fast levels");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))

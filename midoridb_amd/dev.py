@@ -227,8 +227,10 @@ class DeviceCtx:
         return int(self.lib.mdb_dev_last_join_narrow(self.h))
 
     def last_join_filter(self):
-        """0: the last join did not filter the left table through the right table's key bitmap; else 1 + log2(values per bit)"""
-        return int(self.lib.mdb_dev_last_join_filter(self.h))
+        """(bitmap, minmax): bitmap = 0 when the last join did not filter the left table through the right table's key bitmap,
+        else 1 + log2(values per bit); minmax = whether the left table's first level pruned by the right table's key range"""
+        v = int(self.lib.mdb_dev_last_join_filter(self.h))
+        return v & 0xFF, bool(v & 0x100)
 
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""

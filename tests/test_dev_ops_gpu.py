@@ -1183,12 +1183,12 @@ def test_join_group_count_8e8_rows_per_table_on_one_gpu(dev, narrow_mode):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shape", ["dup16", "subrange", "few_right_rows", "no_match", "nulls", "offset"])
-def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(dev, narrow_mode, monkeypatch, shape):
-    """Selective joins in the compact narrow form: the right table is partitioned first, its hashed keys become a bitmap
-    (k_leaf_bitmap) and the left table's second partition level drops the rows whose bit is clear (slice of the tile's
-    first-level digit staged in LDS).  Groups, counts, first rows, order and joined rows equal the oracle's with the filter
-    on (exact bitmap, and one bit per 2 / 4 / 8 adjacent hashed values) and off."""
+@pytest.mark.parametrize("shape", ["dup16", "subrange", "few_right_rows", "fifth_of_the_rows_nulls", "no_match", "nulls", "offset"])
+def test_left_table_pruning_by_the_right_tables_keys_does_not_change_results(dev, narrow_mode, monkeypatch, shape):
+    """Compact narrow form, unsplit call: the right table is partitioned first.  Min-max pruning - its first level records
+    the exact key range, the left table's first level drops the rows outside - and, for right tables that are small but
+    spread over the whole range, the semi-join bitmap at the second level (exact, and one bit per 2 / 4 / 8 adjacent hashed
+    values).  Groups, counts, first rows, order and joined rows equal the oracle's with every combination on and off."""
     narrow_mode(1)
     rng = np.random.default_rng(len(shape) * 13 + 5)
     # (every shape its own table sizes: the operator remembers what it learned about a column by address and length, and
@@ -1196,12 +1196,16 @@ def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(de
     n_l, n_r, span, off = 3_000_000 + 4096 * len(shape), 2_500_000 + 4096 * len(shape), 3_000_000 + 4096 * len(shape), 0
     kl = rng.permutation(span)[:n_l].astype(np.int64)
     nl = nr = None
+    by_rows = shape in ("few_right_rows", "fifth_of_the_rows_nulls")
     if shape == "dup16":
         kr = (rng.permutation(span)[:n_r] % (span // 16)).astype(np.int64)
     elif shape == "subrange":
         kr = rng.integers(span // 3, span // 3 + span // 6, n_r, dtype=np.int64)
     elif shape == "few_right_rows":
         kr = rng.integers(0, span, 40_000, dtype=np.int64)
+    elif shape == "fifth_of_the_rows_nulls":
+        kr = rng.integers(0, span, n_l // 5, dtype=np.int64)
+        nl, nr = rng.random(n_l) < 0.05, rng.random(kr.size) < 0.3
     elif shape == "no_match":
         kl = 2 * rng.integers(0, span // 2, n_l, dtype=np.int64)
         kr = 2 * rng.integers(0, span // 12, n_r, dtype=np.int64) + 1
@@ -1214,17 +1218,18 @@ def test_semijoin_filter_drops_partnerless_left_rows_without_changing_results(de
     kl, kr = kl + off, kr + off
     ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
     dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
-    for on, slice_bits, expect in ((None, None, 1), ("1", "13", 2), ("1", "12", 3), ("1", "11", 4), ("1", "9", 0), ("0", None, 0)):
-        for name, val in (("MDB_SEMIJOIN", on), ("MDB_SEMIJOIN_SLICE", slice_bits)):
+    for prune, on, slice_bits, expect in ((None, None, None, 1), (None, "1", "13", 2), (None, "1", "12", 3), (None, "1", "11", 4), (None, "1", "9", 0),
+                                          (None, "0", None, 0), ("0", None, None, 0)):
+        for name, val in (("MDB_MINMAX_PRUNE", prune), ("MDB_SEMIJOIN", on), ("MDB_SEMIJOIN_SLICE", slice_bits)):
             if val is None:
                 monkeypatch.delenv(name, raising=False)
             else:
                 monkeypatch.setenv(name, val)
         k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
-        assert dev.last_join_form() == 2, (shape, on, slice_bits)
-        assert dev.last_join_filter() == expect, (shape, on, slice_bits, dev.last_join_filter())
-        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, on, slice_bits)
-        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, on, slice_bits)
+        assert dev.last_join_form() == 2, (shape, prune, on, slice_bits)
+        assert dev.last_join_filter() == ((expect if by_rows else 0) if prune is None else 0, prune is None), (shape, prune, on, slice_bits)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, prune, on, slice_bits)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, prune, on, slice_bits)
 
 
 @pytest.mark.parametrize("shape", ["dup16", "subrange", "nulls", "offset"])
@@ -1287,7 +1292,7 @@ def test_keyed_group_records_give_way_when_a_count_does_not_fit(dev, narrow_mode
     assert int(c[k == key].item()) >= 4096
 
 
-def test_semijoin_filter_at_scale_matches_the_unfiltered_operator(dev, narrow_mode, monkeypatch):
+def test_min_max_pruning_at_scale_matches_the_unpruned_operator(dev, narrow_mode, monkeypatch):
     """4 * 10^7 x 4 * 10^7 rows of the benchmark's variant D (1 left row in 16 has a partner): identical columns with the
     filter on and off; variant U (every row has one) does not take the filter."""
     narrow_mode(1)
@@ -1296,17 +1301,17 @@ def test_semijoin_filter_at_scale_matches_the_unfiltered_operator(dev, narrow_mo
     kr = dev.gen_keys(n, 0, n, 43, n // 16)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MDB_SEMIJOIN", mode)
+        monkeypatch.setenv("MDB_MINMAX_PRUNE", mode)
         k, c, f, j = dev.join_group_count(kl, None, kr, None)
-        assert (dev.last_join_filter() != 0) == (mode == "1")
+        assert dev.last_join_filter() == (0, mode == "1")		# the right table's SPAN is small: pruned by range, no bitmap
         out[mode] = (k.clone(), c.clone(), f.clone(), j)
     for a, b in zip(out["0"][:3], out["1"][:3]):
         assert torch.equal(a, b)
     assert out["0"][3] == out["1"][3] == n
-    monkeypatch.delenv("MDB_SEMIJOIN")
+    monkeypatch.delenv("MDB_MINMAX_PRUNE")
     kr = dev.gen_keys(n, 0, n, 43, 0)
-    dev.join_group_count(kl, None, kr, None)
-    assert dev.last_join_form() == 2 and dev.last_join_filter() == 0
+    k, c, f, j = dev.join_group_count(kl, None, kr, None)
+    assert dev.last_join_form() == 2 and dev.last_join_filter() == (0, True) and j == n and k.numel() == n	# nothing to prune
 
 
 @pytest.mark.parametrize("n", [262_144, 600_001])
