@@ -1588,6 +1588,7 @@ struct gc_state {
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
+	bool prunable;		/* the right table's keys cover less than 7/8 of the left table's range (sample) */
 	bool defer_l;		/* the LEFT table is partitioned after the right one, in gc_finish (compact narrow form, unsplit call): the
 				 * right table's first level records its exact key range, the left table's drops the rows outside */
 	uint32_t semijoin;	/* != 0: the LEFT table is partitioned after the right one (gc_finish), its second level dropping the rows
@@ -1636,12 +1637,14 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * (<= 32 KiB: one bit per 2^c adjacent hashed values when the window is wide) is staged in LDS per tile; the first level
 	 * cannot filter - its rows are in table order, a lookup there costs a 128-byte line from L2 per row (measured: slower).
 	 * A wrong hint costs time, never results.  MDB_SEMIJOIN=0 switches it off, MDB_SEMIJOIN_SLICE=<log2 bits> sizes the slice. */
-	/* Min-max pruning, always when the call is not split: the right table goes first and its first partition level
+	/* Min-max pruning, when the call is not split and the key sample says the right table's keys do not cover the left
+	 * table's whole range (or a bitmap is wanted, which also needs the right table first): the right table goes first and its first partition level
 	 * records the exact range of its keys (two atomics per wave and tile); the left table's first level reads the two words
 	 * from device memory and drops every row outside - the classic dimension-range pruning of a fact table, exact, at the
 	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
 	 * below would filter nothing more and is not built. */
-	st->defer_l = st->direct && st->has_r && st->defer_ok && !st->active && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+	st->defer_l = st->direct && st->has_r && st->defer_ok && !st->active && (st->prunable || st->selective) &&
+		      !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
 	st->semijoin = 0;
 	if (st->defer_l && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
@@ -2169,6 +2172,8 @@ struct gc_window {
 	bool selective;		/* the right table's sampled keys cover less than a quarter of the left table's sampled key range, or the right
 				 * table has less than a quarter of the left table's rows: most left rows will find no partner (semi-join filter) */
 	bool by_span;		/* ... the former: min-max pruning at the first level will drop them, no bitmap needed */
+	bool prunable;		/* the right table's sampled keys cover less than 7/8 of the left table's sampled range: worth recording the
+				 * right table's exact range for min-max pruning */
 };
 
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
@@ -2181,6 +2186,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		win->lo = 0;
 		win->selective = false;
 		win->by_span = false;
+		win->prunable = false;
 	}
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
@@ -2203,6 +2209,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 			win->lo = ctx->nh_lo;
 			win->selective = ctx->nh_selective;
 			win->by_span = ctx->nh_by_span;
+			win->prunable = ctx->nh_prunable;
 		}
 		return MIDORIDB_OK;
 	}
@@ -2226,13 +2233,16 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		gc_compact_window(lo, hi, &kb, &wlo);
 	const bool by_span = keys_r && n_r && ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4;
 	const bool selective = keys_r && n_r && (by_span || n_r < n_l / 4);
+	const bool prunable = keys_r && n_r && ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r / 7 < ctx->sr_span_l / 8;
 	if (win) {
 		win->kbits = kb;
 		win->lo = wlo;
 		win->selective = selective;
 		win->by_span = by_span;
+		win->prunable = prunable;
 	}
 	ctx->nh_by_span = by_span;
+	ctx->nh_prunable = prunable;
 	gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, *narrow, *base, kb, wlo);
 	ctx->nh_selective = selective;
 	return MIDORIDB_OK;
@@ -2265,6 +2275,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.key_lo = win.lo;
 	st.selective = win.selective;
 	st.by_span = win.by_span;
+	st.prunable = win.prunable;
 	st.keys32 = keys32;
 	st.defer_ok = true;
 	int rc = gc_begin(ctx, &st);
@@ -2282,7 +2293,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	 * when skewed keys overflow a leaf region (detected on the device, reported with the results) */
 	bool fast = true, records = true, no_build_r = false, narrow = false;
 	int64_t base = 0;
-	gc_window win = { 0, 0, false, false };
+	gc_window win = { 0, 0, false, false, false };
 	int rc = MIDORIDB_OK;
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow

@@ -1311,7 +1311,7 @@ def test_min_max_pruning_at_scale_matches_the_unpruned_operator(dev, narrow_mode
     monkeypatch.delenv("MDB_MINMAX_PRUNE")
     kr = dev.gen_keys(n, 0, n, 43, 0)
     k, c, f, j = dev.join_group_count(kl, None, kr, None)
-    assert dev.last_join_form() == 2 and dev.last_join_filter() == (0, True) and j == n and k.numel() == n	# nothing to prune
+    assert dev.last_join_form() == 2 and dev.last_join_filter() == (0, False) and j == n and k.numel() == n	# same key range: nothing to prune
 
 
 @pytest.mark.parametrize("n", [262_144, 600_001])
