@@ -52,6 +52,7 @@ ROCPROF_NAMES = {
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
     # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT> (the last parameter since round 2's semi-join filter)
     "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
+    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false>"],
     "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
     "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
     "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
@@ -80,10 +81,18 @@ def pmc_traffic(kernel):
     return None
 
 
-def algorithmic_bytes(kernel, n, groups, narrow):
+def algorithmic_bytes(kernel, n, groups, narrow, pruned=False):
     """Algorithmic HBM bytes of ONE launch of `kernel` on a table of n rows (G = `groups` result groups):
-    what the launch must read once and write once.  Kernel names are template instances, one table each."""
+    what the launch must read once and write once.  Kernel names are template instances, one table each.
+    pruned: min-max pruning ran - the left table's first level wrote only the rows inside the right table's key range, and the
+    kernels after it see those rows only (one left row per group in both benchmark variants: 8 G bytes)."""
     key, rid, h32, g = 8 * n, 4 * n, 4 * n, groups
+    if pruned:
+        t = {"part_scatter_l0_pruned": key + 8 * g,      # every key in, the words of the rows inside the range out
+             "part_scatter_l1": 8 * g + 8 * g, "part_scatter_l1_semi": 8 * g + 8 * g,
+             "leaf_join_direct": 8 * g + h32 + 8 * g}
+        if kernel in t:
+            return float(t[kernel])
     table = {
         "part_scatter_l0": key + key,               # read 8-byte keys, write 8-byte words (hash | row id in the narrow form)
         "part_scatter_l0_w32": key + h32,           # narrow right side: read keys, write 4-byte hashes
@@ -439,17 +448,18 @@ def main():
 
     if rank == 0:
         narrow = dev.last_join_narrow()
+        pruned = dev.last_join_filter()[1]
         g_rank = groups_total / max(world, 1)
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
         for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
             if d["ms_per_step"] > 0:
-                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
+                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow, pruned) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
 
         def roof_of(name):
             d = kern[name]
             launches = max(d["launches_per_step"], 1e-9)
             avg_ms = d["ms_per_step"] / launches
-            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow)
+            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow, pruned)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             tr = pmc_traffic(name) if (n == 100_000_000 and args.variant == "D" and world == 1) else None
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -473,6 +483,7 @@ def main():
                        "key_form": ["wide (64-bit hashes)", "narrow (keys within one 2^32-wide window, verified on the device: 32-bit hashes)",
                                     "compact narrow (keys within the sampled 2^k-wide window, verified on the device: k-bit hashes, "
                                     "direct-address leaf tables)"][dev.last_join_form()],
+                       "left_table_pruning": {"min_max": bool(dev.last_join_filter()[1]), "bitmap": int(dev.last_join_filter()[0])},
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
                        "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
@@ -485,7 +496,7 @@ def main():
             "kernels": kern,
         }
         # the first-level scatter of the left table beside it: the bandwidth-bound kernel of the pipeline
-        for cand in ("part_scatter_l0", "part_scatter_l0_rid"):
+        for cand in ("part_scatter_l0", "part_scatter_l0_pruned", "part_scatter_l0_rid", "part_scatter_l0_w32"):
             if cand in kern and cand != dom_name:
                 line["roofline_scatter"] = roof_of(cand)
                 break

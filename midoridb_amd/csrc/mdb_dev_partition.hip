@@ -993,6 +993,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
+				} else if (a.range_in) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
+					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
