@@ -1639,14 +1639,14 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * A wrong hint costs time, never results.  MDB_SEMIJOIN=0 switches it off, MDB_SEMIJOIN_SLICE=<log2 bits> sizes the slice. */
 	/* Min-max pruning, when the call is not split and the key sample says the right table's keys do not cover the left
 	 * table's whole range (or a bitmap is wanted, which also needs the right table first): the right table goes first and its first partition level
-	 * records the exact range of its keys (two atomics per wave and tile); the left table's first level reads the two words
+	 * records the exact range of its keys (a pair of stores per tile, reduced by one small kernel); the left table's first level reads the two words
 	 * from device memory and drops every row outside - the classic dimension-range pruning of a fact table, exact, at the
 	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
 	 * below would filter nothing more and is not built. */
-	st->defer_l = st->direct && st->has_r && st->defer_ok && !st->active && (st->prunable || st->selective) &&
-		      !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+	st->defer_l = st->narrow && st->fast && st->b2 > 0 && st->has_r && st->defer_ok && !st->active &&
+		      (st->prunable || (st->direct && st->selective)) && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
 	st->semijoin = 0;
-	if (st->defer_l && st->selective && !st->by_span) {
+	if (st->defer_l && st->direct && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
 		const uint32_t slice_max = e2 && atoi(e2) >= 7 && atoi(e2) <= 18 ? (uint32_t)atoi(e2) : 17u;	/* log2 bits: 2^17 = 16 KiB */
 		const uint32_t below0 = st->key_bits - (uint32_t)st->b1;		/* hash bits below the first-level digit */
@@ -1732,8 +1732,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		memset(&flt, 0, sizeof(flt));
 		flt.range_in = ctx->d_status + 16;
 		flt.expect_pruned = st->by_span;
-		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32, st->key_lo, st->key_bits,
-					 &flt);
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32,
+					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, &flt);
 		if (rc)
 			return rc;
 		pl = st->pl;

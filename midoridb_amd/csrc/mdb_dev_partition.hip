@@ -108,7 +108,7 @@ __device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_
 		return mdb_fmix64(key);
 	key -= (uint64_t)a.narrow_base;		/* (wraps: the tests below are on the 64-bit difference) */
 	if (rel)
-		*rel = key;
+		*rel = a.narrow_kbits ? key : key + 0x80000000ull;	/* a valid key's value is below 2^32 in both forms */
 	uint32_t h;
 	if (a.narrow_kbits) {
 		*bad = *bad || (key >> a.narrow_kbits);
@@ -427,11 +427,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			constexpr bool RANGE = LEVEL0 && FAST && !RAW && !INV && !HAS_RID;	/* (the narrow forms' first level) */
 			uint64_t rel2[2] = { 0, 0 };
 			part_load2<LEVEL0, HAS_RID, RAW, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid, RANGE ? rel2 : nullptr);
-			if (RANGE && a.narrow_kbits) {
+			if (RANGE && a.narrow) {
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					valid[k] = valid[k] && rel2[k] >= range_lo && rel2[k] <= range_hi;
-					if (a.minmax_out && valid[k]) {		/* (a valid row of the compact form: rel < 2^narrow_kbits <= 2^32) */
+					if (a.minmax_out && valid[k]) {		/* (a valid row of a narrow form: rel < 2^32) */
 						seen_min = rel2[k] < seen_min ? (uint32_t)rel2[k] : seen_min;
 						seen_max = rel2[k] > seen_max ? (uint32_t)rel2[k] : seen_max;
 					}
@@ -1157,9 +1157,9 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	if (flt && flt->bits && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 || flt->words < 4 || flt->words > MDB_TILE * 2 ||
 				 (flt->words & (flt->words - 1))))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "semi-join filter: left side of the compact narrow form, two fast levels, slices of 4 ... 8192 words");
-	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 ||
+	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || want_rid || stable || !fast || bits2 <= 0 ||
 							  (flt->minmax_out && (narrow != 2 || !flt->minmax_tiles))))
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning: compact narrow form, two fast levels");
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning: narrow forms, two fast levels");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))

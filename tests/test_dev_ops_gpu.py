@@ -1232,6 +1232,44 @@ def test_left_table_pruning_by_the_right_tables_keys_does_not_change_results(dev
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, prune, on, slice_bits)
 
 
+@pytest.mark.parametrize("shape", ["low_sixteenth", "middle", "negative_window", "nulls", "nothing_in_range"])
+def test_min_max_pruning_in_the_plain_narrow_form(dev, narrow_mode, monkeypatch, shape):
+    """Keys too sparse for the compact form (3 * 10^6 rows over a 2^31-wide range: hashed leaf tables, 32-bit hashes) are
+    pruned the same way: the right table's exact key range, recorded by its first partition level, drops the left rows
+    outside at theirs.  Same groups, counts, first rows and order as the oracle, with the pruning on and off."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 19 + 1)
+    n_l, n_r = 3_000_000 + 4096 * len(shape), 2_000_000 + 4096 * len(shape)
+    lo, hi = 0, 2**31 - 5
+    kl = rng.integers(lo, hi, n_l, dtype=np.int64)
+    nl = nr = None
+    if shape == "low_sixteenth":
+        pool = rng.choice(kl[kl < hi // 16], 300_000)
+    elif shape == "middle":
+        pool = rng.choice(kl[(kl > hi // 3) & (kl < hi // 3 + hi // 10)], 300_000)
+    elif shape == "negative_window":
+        kl = kl - 2**40 - 2**30
+        pool = rng.choice(kl[kl < -(2**40) - 2**30 + hi // 20], 300_000)
+    elif shape == "nulls":
+        pool = rng.choice(kl[kl < hi // 8], 300_000)
+        nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.2
+    else:
+        kl = kl >> 1
+        pool = 2**30 + 7 + rng.integers(0, 2**24, 300_000)	# right keys beyond every left key (still in the 2^31-wide window)
+    kr = pool[rng.integers(0, pool.size, n_r)]
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for prune in (None, "0", None):
+        if prune is None:
+            monkeypatch.delenv("MDB_MINMAX_PRUNE", raising=False)
+        else:
+            monkeypatch.setenv("MDB_MINMAX_PRUNE", prune)
+        k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert dev.last_join_form() == 1 and dev.last_join_filter() == (0, prune is None), (shape, prune, dev.last_join_form(), dev.last_join_filter())
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, prune)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, prune)
+
+
 @pytest.mark.parametrize("shape", ["dup16", "subrange", "nulls", "offset"])
 def test_keyed_group_records_decode_the_key_instead_of_gathering_it(dev, narrow_mode, monkeypatch, shape):
     """Selective joins in the compact narrow form write (first row, hashed key, COUNT) records and the ordering kernel
