@@ -1643,8 +1643,9 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * from device memory and drops every row outside - the classic dimension-range pruning of a fact table, exact, at the
 	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
 	 * below would filter nothing more and is not built. */
+	const char *prune_env = getenv("MDB_MINMAX_PRUNE");		/* 0: never, 2: whatever the key sample says (tests) */
 	st->defer_l = st->narrow && st->fast && st->b2 > 0 && st->has_r && st->defer_ok && !st->active &&
-		      (st->prunable || (st->direct && st->selective)) && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+		      (st->prunable || (st->direct && st->selective) || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
 	st->semijoin = 0;
 	if (st->defer_l && st->direct && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");

@@ -1183,6 +1183,29 @@ def test_join_group_count_8e8_rows_per_table_on_one_gpu(dev, narrow_mode):
     torch.cuda.empty_cache()
 
 
+def test_min_max_pruning_with_a_right_table_of_nothing_but_null_keys(dev, narrow_mode, monkeypatch):
+    """No right key at all: an empty join, as the reference's - a NULL key joins nothing (executor_select.c:557-579); with
+    the right table forced first (MDB_MINMAX_PRUNE=2: prune whatever the key sample says) the recorded range stays empty
+    (smallest > largest) and every left row is dropped.  One real right key at the far end of the left table's range brings
+    back exactly its group."""
+    narrow_mode(1)
+    monkeypatch.setenv("MDB_MINMAX_PRUNE", "2")
+    rng = np.random.default_rng(77)
+    n_l, n_r = 2_222_222, 700_000
+    kl = rng.permutation(n_l).astype(np.int64)
+    kr = rng.integers(0, n_l // 8, n_r, dtype=np.int64)
+    nr = np.ones(n_r, dtype=bool)
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    k, c, f, j = dev.join_group_count(dl, None, dr, dev.nullbits_dev(nr))
+    assert k.numel() == 0 and j == 0
+    nr[123] = False
+    kr[123] = n_l - 1
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, nr)
+    k, c, f, j = dev.join_group_count(dl, None, dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert ej == 1 and j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+
+
 @pytest.mark.parametrize("shape", ["dup16", "subrange", "few_right_rows", "fifth_of_the_rows_nulls", "no_match", "nulls", "offset"])
 def test_left_table_pruning_by_the_right_tables_keys_does_not_change_results(dev, narrow_mode, monkeypatch, shape):
     """Compact narrow form, unsplit call: the right table is partitioned first.  Min-max pruning - its first level records
