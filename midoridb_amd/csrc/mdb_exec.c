@@ -236,7 +236,7 @@ static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, siz
 		e->kind = MDB_EX_FIELD;
 		e->tbl_idx = ft;
 		e->col_idx = fc;
-		strncpy(e->tbl, s->tabs[ft].t->name, MDB_NAME_LEN - 1);
+		mdb_copy_name(e->tbl, s->tabs[ft].t->name);
 	} else if (e->kind == MDB_EX_FIELD) {
 		int ft = -1;
 		for (int t = 0; t < s->ntabs; t++)
@@ -256,7 +256,7 @@ static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, siz
 			ERR("no such column: '%.128s'.'%.128s'\n", e->tbl, e->col);
 			return -MIDORIDB_ERROR;
 		}
-		strncpy(e->tbl, s->tabs[ft].t->name, MDB_NAME_LEN - 1);	/* alias -> real table name */
+		mdb_copy_name(e->tbl, s->tabs[ft].t->name);	/* alias -> real table name */
 	}
 	if (e->kind == MDB_EX_FIELD) {
 		e->type = s->tabs[e->tbl_idx].t->cols[e->col_idx].type;
@@ -786,11 +786,6 @@ static int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
 		return bits;
 	}
 	return v->ival;
-}
-
-static int64_t lit_bits(const struct mdb_expr *v)
-{
-	return lit_bits_for(v, MDB_CT_INTEGER);
 }
 
 static bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
@@ -1874,7 +1869,7 @@ static int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct ex
 	*out_t = t;
 	memset(s, 0, sizeof(*s));
 	memset(tab, 0, sizeof(*tab));
-	strncpy(tab->name, t->name, MDB_NAME_LEN - 1);
+	mdb_copy_name(tab->name, t->name);
 	tab->t = t;
 	s->tabs = tab;
 	s->ntabs = 1;

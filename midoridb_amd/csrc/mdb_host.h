@@ -100,6 +100,14 @@ struct mdb_catalog {
 	mdb_dist *dist;
 };
 
+/* dst[MDB_NAME_LEN] = src, cut to MDB_NAME_LEN - 1 characters, always terminated */
+static inline void mdb_copy_name(char *dst, const char *src)
+{
+	const size_t n = strnlen(src, MDB_NAME_LEN - 1);
+	memcpy(dst, src, n);
+	dst[n] = 0;
+}
+
 struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name);
 int mdb_catalog_add(struct mdb_catalog *cat, struct mdb_table *t);
 void mdb_catalog_free(struct mdb_catalog *cat);

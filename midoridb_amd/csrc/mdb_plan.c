@@ -94,7 +94,7 @@ static int pop_n_into(struct bstack *st, int n, struct mdb_expr *parent)
 
 static void copy_name(char *dst, const char *src)
 {
-	strncpy(dst, src, MDB_NAME_LEN - 1);
+	mdb_copy_name(dst, src);
 	dst[MDB_NAME_LEN - 1] = 0;
 }
 

@@ -40,7 +40,7 @@ struct mdb_table *mdb_table_new(const char *name)
 	struct mdb_table *t = calloc(1, sizeof(*t));
 	if (!t)
 		return NULL;
-	strncpy(t->name, name, MDB_NAME_LEN - 1);
+	mdb_copy_name(t->name, name);
 	t->generation = 1;
 	return t;
 }
@@ -211,7 +211,7 @@ int mdb_table_add_column(struct mdb_table *t, const char *name, int type)
 		return -MIDORIDB_ERROR;
 	c = &t->cols[t->ncols++];
 	memset(c, 0, sizeof(*c));
-	strncpy(c->name, name, MDB_NAME_LEN - 1);
+	mdb_copy_name(c->name, name);
 	c->type = type;
 	return MIDORIDB_OK;
 }
