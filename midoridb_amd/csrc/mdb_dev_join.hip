@@ -1550,6 +1550,10 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
 #define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
 #define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
+/* words of ctx->d_status the fused operator uses beyond [0..9] (flags, record-list length, joined rows, NULL-group stats, records):
+ * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
+ * key - window base (min-max pruning, while it runs) */
+#define GC_ST_MINMAX 16
 #define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
 #define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
 
@@ -1718,7 +1722,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		memset(&rflt, 0, sizeof(rflt));
 		if (st->defer_l) {
 			/* [16] smallest, [17] largest key - window base of the right table (min-max pruning) */
-			rflt.minmax_out = ctx->d_status + 16;
+			rflt.minmax_out = ctx->d_status + GC_ST_MINMAX;
 			rflt.minmax_tiles = (uint32_t *)mdb_arena_take(ctx, mdb_part_minmax_words(n_r) * 4);
 			if (!rflt.minmax_tiles)
 				return -MIDORIDB_INTERNAL;
@@ -1731,7 +1735,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (st->defer_l && !st->semijoin) {
 		mdb_part_filter flt;
 		memset(&flt, 0, sizeof(flt));
-		flt.range_in = ctx->d_status + 16;
+		flt.range_in = ctx->d_status + GC_ST_MINMAX;
 		flt.expect_pruned = st->by_span;
 		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32,
 					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, &flt);
@@ -1753,7 +1757,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			   reinterpret_cast<const uint32_t *>(pr.hv), pr.leaf_cnt, pr.leaf_cap, pr.nleaves, rem, coarse, 32u - st->key_bits, bits);
 		mdb_part_filter flt;
 		memset(&flt, 0, sizeof(flt));
-		flt.range_in = ctx->d_status + 16;
+		flt.range_in = ctx->d_status + GC_ST_MINMAX;
 		flt.expect_pruned = st->by_span;
 		flt.bits = bits;
 		flt.words = 1u << (st->key_bits - (uint32_t)st->b1 - coarse - 5u);
