@@ -202,6 +202,7 @@ struct fp_args {
 	uint64_t *dst[FP_MAX_COLS];
 	unsigned long long *dst_null[FP_MAX_COLS];	/* zero-filled before the launch: rows of one word may come from two blocks */
 	int ncols;
+	uint32_t *sel_out;	/* != NULL: also (or only, ncols == 0) the surviving rows' positions - a selection vector (mdb_dev_filter) */
 };
 
 
@@ -625,6 +626,22 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64
 			at += (uint32_t)__popcll(m0u) + (uint32_t)__popcll(m1u);
 		}
 	}
+	if (a.sel_out) {
+		uint32_t at = run;
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
+			bool p0, p1;
+			survivors(u, &p0, &p1);
+			const uint64_t m0u = __ballot(p0), m1u = __ballot(p1);
+			const uint32_t pos0 = at + (uint32_t)__popcll(m0u & lt) + (uint32_t)__popcll(m1u & lt), pos1 = pos0 + (p0 ? 1u : 0u);
+			if (p0)
+				a.sel_out[pos0] = (uint32_t)k0;
+			if (p1)
+				a.sel_out[pos1] = (uint32_t)k0 + 1u;
+			at += (uint32_t)__popcll(m0u) + (uint32_t)__popcll(m1u);
+		}
+	}
 }
 
 /* The next commonest predicates - several comparisons of ONE INT64 base-table column with constants, all joined by AND
@@ -945,6 +962,36 @@ extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog
 	rc = mdb_arena_begin(ctx, mdb_filter_arena_bytes(n));
 	if (rc)
 		return rc;
+	/* one comparison of an INT64 base-table column with a constant (pushed-down WHERE conjuncts, DELETE / UPDATE, the
+	 * threshold filter of ORDER BY ... LIMIT): ONE pass - k_scan_project_cmp1 with the positions as its only output - instead
+	 * of bitmap, scan and bitmap -> positions (10^8 rows at 50 %: 0.29 -> 0.2 ms) */
+	if (n >= (1u << 18) && p.n_insns == 1 && p.insn[0].op == MDB_P_CMP_COL_CONST && p.insn[0].type == MDB_T_INT64 && n_cols >= 1 &&
+	    !p.cols[p.insn[0].a].rid && ((uintptr_t)p.cols[p.insn[0].a].values & 15) == 0) {
+		const uint64_t rows_per_block = (uint64_t)SP_WAVES * FILT_WORDS_PER_WAVE * 64;
+		const uint32_t nblk = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
+		fp_fused fz;
+		memset(&fz, 0, sizeof(fz));
+		fz.cols.sel_out = out_sel;
+		fz.state = (unsigned long long *)mdb_arena_take(ctx, (size_t)nblk * 8 + 64);
+		if (!fz.state)
+			return -MIDORIDB_INTERNAL;
+		fz.ticket = (uint32_t *)(fz.state + nblk);
+		fz.status = ctx->d_status;
+		MDB_HIP(ctx, hipMemsetAsync(fz.state, 0, (size_t)nblk * 8 + 64, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+		uint32_t *unused = NULL, last = 0xFFFFFFFFu;
+		rc = filter_run(ctx, 0, &p, n_cols, NULL, n, NULL, &unused, &fz, &last);
+		if (rc)
+			return rc;
+		uint64_t *h64 = ctx->h_pinned;
+		MDB_HIP(ctx, hipMemcpyAsync(&h64[0], fz.state + last, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipMemcpyAsync(&h64[1], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (((uint32_t)h64[1] & FZ_TIMEOUT) || (h64[0] >> 62) != 2)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "filter: the look-back over the row blocks did not complete");
+		*out_count = h64[0] & FZ_VAL;
+		return MIDORIDB_OK;
+	}
 	uint32_t *d_total = NULL;
 	rc = filter_run(ctx, 0, &p, n_cols, NULL, n, out_sel, &d_total);
 	if (rc)

@@ -203,6 +203,23 @@ def test_filter_programs(dev):
         assert np.array_equal(got, exp), prog
 
 
+@pytest.mark.parametrize("n", [262_144, 262_145, 1_000_003, 6_000_011])
+def test_filter_one_comparison_single_pass_selection_vector(dev, n):
+    """From 2^18 rows on, ONE comparison of an INT64 base-table column with a constant produces its selection vector in one
+    pass (k_scan_project_cmp1 with the positions as the only output, decoupled look-back over 16384-row blocks): all six
+    operators, with and without a NULL bitmap, every / no / one row passing, ragged tails."""
+    rng = np.random.default_rng(n % 977)
+    a = rng.integers(-1000, 1000, n, dtype=np.int64)
+    na = rng.random(n) < 0.07
+    for nulls in (None, na):
+        cols_np, cols_dev = [(a, nulls, None)], [(dev.to_dev(a), dev.nullbits_dev(nulls), None)]
+        for cmp_, imm in ((D.CMP_GT, 0), (D.CMP_LT, -300), (D.CMP_GE, 999), (D.CMP_LE, -1000), (D.CMP_EQ, 17), (D.CMP_NE, 17), (D.CMP_GT, 5000), (D.CMP_GE, -5000)):
+            prog = [(D.P_CMP_COL_CONST, cmp_, D.T_INT64, 0, 0, imm)]
+            exp = orc.filter_positions(prog, cols_np, n)
+            got = _np(dev.filter(prog, cols_dev, n)).astype(np.int64)
+            assert np.array_equal(got, exp), (n, cmp_, imm, nulls is not None)
+
+
 def test_filter_through_rid_vector(dev):
     rng = np.random.default_rng(5)
     a = rng.integers(0, 50, 1000, dtype=np.int64)
