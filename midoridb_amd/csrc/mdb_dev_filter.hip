@@ -499,19 +499,15 @@ __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_cmp1(const int64_t *
 #define SP_THREADS 1024
 #define SP_WAVES (SP_THREADS / MDB_WAVE)
 
-template <int CMP, int SPANS>	/* SPANS = 128-row spans per wave: 8 = 16384 rows per workgroup */
-__global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
-								    int64_t imm, uint64_t n, fp_fused fz)
+template <int SPANS, typename Pred>	/* SPANS = 128-row spans per wave: 8 = 16384 rows per workgroup; cmp(value) = the predicate on a non-NULL value */
+__device__ static inline void scan_project_body(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits, bool null_passes,
+						uint64_t n, const fp_fused &fz, Pred cmp)
 {
 	const uint32_t bid = filt_block_id(fz);
 	__shared__ uint32_t s_wcnt[SP_WAVES];
 	__shared__ uint32_t s_base;
 	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
 	const uint64_t word0 = ((uint64_t)bid * SP_WAVES + wave) * (2 * SPANS);
-	auto cmp = [&](int64_t a) -> bool {
-		return CMP == MDB_CMP_LT ? a < imm : CMP == MDB_CMP_GT ? a > imm : CMP == MDB_CMP_NE ? a != imm : CMP == MDB_CMP_EQ ? a == imm
-		       : CMP == MDB_CMP_LE ? a <= imm : a >= imm;
-	};
 	longlong2 q[SPANS];
 #pragma unroll
 	for (int u = 0; u < SPANS; u++) {
@@ -522,25 +518,31 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64
 		else if (k0 < n)
 			q[u].x = vals[k0];
 	}
-	/* survivors among the even / odd rows of a 128-row span (evaluated twice - to count and to place - rather than kept:
-	 * sixteen 64-bit masks beside the rows cost 150 registers, i.e. two thirds of the occupancy) */
-	auto survivors = [&](int u, bool *p0, bool *p1) {
-		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
-		*p0 = k0 < n && cmp(q[u].x);
-		*p1 = k0 + 1 < n && cmp(q[u].y);
-		if (nullbits && k0 < n) {
-			const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
-			*p0 = *p0 && !(w & 1ull);
-			*p1 = *p1 && !(w & 2ull);
-		}
-	};
-	uint32_t cnt = 0;
+	/* the predicate is evaluated ONCE per row; a lane keeps its 2 x SPANS verdicts as bits of one register (sixteen 64-bit
+	 * ballot masks kept beside the rows cost 150 registers - two thirds of the occupancy -, evaluating again for the count and
+	 * for every output column is cheap for one comparison but not for a term list: 0.56 ms instead of 0.33) */
+	uint32_t pbits = 0, cnt = 0;
 #pragma unroll
 	for (int u = 0; u < SPANS; u++) {
-		bool p0, p1;
-		survivors(u, &p0, &p1);
+		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
+		bool p0 = k0 < n && cmp(q[u].x), p1 = k0 + 1 < n && cmp(q[u].y);
+		if (nullbits && k0 < n) {
+			const uint64_t w = nullbits[k0 >> 6] >> (k0 & 63);
+			if (null_passes) {	/* an OR list with "IS NULL" among its terms */
+				p0 = p0 || (w & 1ull);
+				p1 = k0 + 1 < n && (p1 || (w & 2ull));
+			} else {
+				p0 = p0 && !(w & 1ull);
+				p1 = p1 && !(w & 2ull);
+			}
+		}
+		pbits |= (p0 ? 1u : 0u) << (2 * u) | (p1 ? 2u : 0u) << (2 * u);
 		cnt += (uint32_t)__popcll(__ballot(p0)) + (uint32_t)__popcll(__ballot(p1));
 	}
+	auto survivors = [&](int u, bool *p0, bool *p1) {
+		*p0 = (pbits >> (2 * u)) & 1u;
+		*p1 = (pbits >> (2 * u + 1)) & 1u;
+	};
 	if (lane == 0)
 		s_wcnt[wave] = cnt;
 	__syncthreads();
@@ -644,6 +646,16 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64
 	}
 }
 
+template <int CMP, int SPANS>
+__global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_cmp1(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
+								    int64_t imm, uint64_t n, fp_fused fz)
+{
+	scan_project_body<SPANS>(vals, nullbits, false, n, fz, [imm](int64_t a) -> bool {
+		return CMP == MDB_CMP_LT ? a < imm : CMP == MDB_CMP_GT ? a > imm : CMP == MDB_CMP_NE ? a != imm : CMP == MDB_CMP_EQ ? a == imm
+		       : CMP == MDB_CMP_LE ? a <= imm : a >= imm;
+	});
+}
+
 /* The next commonest predicates - several comparisons of ONE INT64 base-table column with constants, all joined by AND
  * (ranges: fa >= 3 AND fa <= 900 AND fa <> 5) or all joined by OR (IN lists) - also without the interpreter: the column
  * is loaded once, the terms are evaluated in registers (uniform switch per term). */
@@ -654,6 +666,24 @@ struct filt_terms {
 	int32_t n;
 	int32_t null_passes;	/* OR list with "col IS NULL" among its terms: a NULL row passes (otherwise it fails every term) */
 };
+
+/* ... in ONE pass when the output is the compacted rows / their positions (scan_project_body) */
+template <bool IS_OR, int SPANS>
+__global__ __launch_bounds__(SP_THREADS, 4) void k_scan_project_terms(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
+								     filt_terms t, uint64_t n, fp_fused fz)
+{
+	scan_project_body<SPANS>(vals, nullbits, t.null_passes != 0, n, fz, [&t](int64_t a) -> bool {
+		bool r = !IS_OR;
+		for (int k = 0; k < t.n; k++) {
+			const int64_t imm = t.imm[k];
+			const int c = t.cmp[k];
+			const bool b = c == MDB_CMP_LT ? a < imm : c == MDB_CMP_GT ? a > imm : c == MDB_CMP_NE ? a != imm : c == MDB_CMP_EQ ? a == imm
+				       : c == MDB_CMP_LE ? a <= imm : a >= imm;
+			r = IS_OR ? (r || b) : (r && b);
+		}
+		return r;
+	});
+}
 
 template <bool IS_OR>
 __global__ __launch_bounds__(FILT_THREADS) void k_pred_bits_terms(const int64_t *__restrict__ vals, const uint64_t *__restrict__ nullbits,
@@ -915,6 +945,19 @@ static int filter_run(mdb_dev_ctx *ctx, int mode, const pred_args *p, int n_cols
 			case MDB_CMP_LE: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_LE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
 			default: MDB_LAUNCH(ctx, "filter_pred_bits", k_pred_bits_cmp1<MDB_CMP_GE>, nb, FILT_THREADS, v, nbits, i0.imm, n, bits, bc, fz); break;
 			}
+		} else if (filt_terms ft; fuse && direct && filter_one_column_terms(p, &ft, &tslot, &tor)) {
+			/* ranges / IN lists over one column: the same single pass */
+			const int64_t *v = (const int64_t *)p->cols[tslot].values;
+			const uint64_t *nbits = p->cols[tslot].nullbits;
+			const uint64_t rows_per_block = (uint64_t)SP_WAVES * FILT_WORDS_PER_WAVE * 64;
+			const uint32_t nb = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
+			if (last_block)
+				*last_block = nb - 1;
+			if (tor) {
+				MDB_LAUNCH(ctx, "scan_project", (k_scan_project_terms<true, 8>), nb, SP_THREADS, v, nbits, ft, n, fz);
+			} else {
+				MDB_LAUNCH(ctx, "scan_project", (k_scan_project_terms<false, 8>), nb, SP_THREADS, v, nbits, ft, n, fz);
+			}
 		} else if (filt_terms ft; direct && filter_one_column_terms(p, &ft, &tslot, &tor)) {
 			const int64_t *v = (const int64_t *)p->cols[tslot].values;
 			const uint64_t *nbits = p->cols[tslot].nullbits;
@@ -963,10 +1006,13 @@ extern "C" int mdb_dev_filter(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog
 	if (rc)
 		return rc;
 	/* one comparison of an INT64 base-table column with a constant (pushed-down WHERE conjuncts, DELETE / UPDATE, the
-	 * threshold filter of ORDER BY ... LIMIT): ONE pass - k_scan_project_cmp1 with the positions as its only output - instead
-	 * of bitmap, scan and bitmap -> positions (10^8 rows at 50 %: 0.29 -> 0.2 ms) */
-	if (n >= (1u << 18) && p.n_insns == 1 && p.insn[0].op == MDB_P_CMP_COL_CONST && p.insn[0].type == MDB_T_INT64 && n_cols >= 1 &&
-	    !p.cols[p.insn[0].a].rid && ((uintptr_t)p.cols[p.insn[0].a].values & 15) == 0) {
+	 * threshold filter of ORDER BY ... LIMIT): ONE pass - scan_project_body with the positions as its only output - instead
+	 * of bitmap, scan and bitmap -> positions (10^8 rows at 50 %: 0.41 -> 0.30 ms) */
+	/* (term lists - ranges, IN lists - take the three passes here: their evaluation, not the passes, is what costs - 0.43 ms in
+	 * one pass against 0.41 in three at 10^8 rows; mdb_dev_filter_project does use the one-pass term kernel: it saves the gather) */
+	const bool one_pass = n >= (1u << 18) && n_cols >= 1 && p.n_insns == 1 && p.insn[0].op == MDB_P_CMP_COL_CONST && p.insn[0].type == MDB_T_INT64 &&
+			      !p.cols[p.insn[0].a].rid && ((uintptr_t)p.cols[p.insn[0].a].values & 15) == 0;
+	if (one_pass) {
 		const uint64_t rows_per_block = (uint64_t)SP_WAVES * FILT_WORDS_PER_WAVE * 64;
 		const uint32_t nblk = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
 		fp_fused fz;
