@@ -57,6 +57,9 @@ struct mdb_dev_ctx {
 	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */
 	uint64_t pu_dupl_n;
 	int pu_dup_skips;
+	bool r32_ok;			/* the last join over (r32_kl, r32_nl, r32_kr, r32_nr) fitted every COUNT(*) into a 4-byte group record */
+	const void *r32_kl, *r32_kr;
+	uint64_t r32_nl, r32_nr;
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */

@@ -87,7 +87,7 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);
 size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used);
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
 		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap = true,	/* zero words are gaps of a chunked list */
-		      bool fold32 = false);	/* the first level folds every 8-byte word w into the 4-byte word (w >> 32) | (uint32_t)w - the caller knows
+		      int fold32 = 0);	/* 1: the 8-byte records are folded into 4-byte words by the first level; 2: `hv` already holds 4-byte words */	/* the first level folds every 8-byte word w into the 4-byte word (w >> 32) | (uint32_t)w - the caller knows
 					 * that the two parts share no bit - and everything after it moves 4-byte words (out->w32; two fast levels only) */
 
 /* one stable least-significant-digit radix pass over (key, row id) pairs: digit = (key >> shift) & (2^bits - 1),

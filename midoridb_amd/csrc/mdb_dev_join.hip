@@ -121,6 +121,9 @@ struct gc_args {
 	uint32_t nleaves;
 	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
 	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r = array of 4-byte hash32 */
+	uint32_t rec32;			/* direct-address leaves: the records are written as 4-byte words (first row id << (32 - kbits)) | COUNT(*) - the
+					 * caller has seen, for these very columns, that every COUNT fits; one that does not raises status bit 9 and
+					 * the operator is redone with 8-byte records */
 	uint32_t keyed_cbits;		/* direct-address leaves, != 0: KEYED group records - (first row id, hashed key, COUNT(*)) with COUNT in
 					 * the low keyed_cbits bits and the key_bits-wide hashed key above it: the ordering kernel decodes the
 					 * group key from the record instead of gathering it from the key column (selective joins: the groups'
@@ -845,8 +848,12 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 		const uint32_t need = (rows < T ? rows : T) + 1;
 		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
 		if (used + need > size) {		/* uniform: every thread read the same words */
-			for (uint32_t i = used + threadIdx.x; i < size; i += THREADS)
-				a.rec[base + i] = 0ull;
+			for (uint32_t i = used + threadIdx.x; i < size; i += THREADS) {
+				if (a.rec32)
+					reinterpret_cast<uint32_t *>(a.rec)[base + i] = 0u;
+				else
+					a.rec[base + i] = 0ull;
+			}
 			__syncthreads();		/* everyone has read s_chunk */
 			if (threadIdx.x == 0) {
 				const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
@@ -941,7 +948,10 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 							mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
 						if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
 							mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record (the ordering sort then moves 8-byte ones) */
-						recv = ((unsigned long long)first << (64 - a.kbits)) | c;
+						recv = a.rec32 ? (unsigned long long)(((uint32_t)first << (32 - a.kbits)) | (uint32_t)c)
+							       : ((unsigned long long)first << (64 - a.kbits)) | c;
+						if (a.rec32 && (c >> (32 - a.kbits)))
+							mdb_raise(a.status, 512u);
 					} else {
 						a.dense_cnt[first] = (int64_t)c;
 					}
@@ -958,8 +968,12 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 					wbase = __shfl(wbase, (int)leader, MDB_WAVE);
 					if (recv) {
 						const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-						if (pos < csize)
-							a.rec[cbase + pos] = recv;
+						if (pos < csize) {
+							if (a.rec32)
+								reinterpret_cast<uint32_t *>(a.rec)[cbase + pos] = (uint32_t)recv;
+							else
+								a.rec[cbase + pos] = recv;
+						}
 						st.nvalid++;
 					}
 				}
@@ -1014,8 +1028,12 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 	}
 	if (a.kbits) {
 		const uint32_t base = st.s_chunk[0], used = st.s_chunk[1], size = st.s_chunk[2];
-		for (uint32_t i = used + threadIdx.x; i < size; i += THREADS)
-			a.rec[base + i] = 0ull;		/* unused tail of the last chunk */
+		for (uint32_t i = used + threadIdx.x; i < size; i += THREADS) {	/* unused tail of the last chunk */
+			if (a.rec32)
+				reinterpret_cast<uint32_t *>(a.rec)[base + i] = 0u;
+			else
+				a.rec[base + i] = 0ull;
+		}
 		if (st.nvalid)
 			atomicAdd(&st.s_chunk[3], st.nvalid);
 	}
@@ -1325,6 +1343,8 @@ __global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long lo
 #define ORD_RANGE (ORD_THREADS * ORD_PER_THREAD)	/* 4096 row ids per ordering leaf (32 KiB of LDS slots: 4 workgroups per CU; 8192 ids x 1024 threads measured 15 % slower, 2048 x 256 no faster) */
 #define ORD_RANGE_BITS 12
 
+#define GC_RETRY_REC64 1006	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
+
 struct ord_args {
 	const unsigned long long *rec;
 	const uint32_t *off;		/* exact layout: leaf offsets = output positions */
@@ -1458,16 +1478,19 @@ static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
  * everything after it moves half the bytes (10^8 groups of one row each: 1.3 -> 0.9 ms for the ordering) */
 static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
 			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,
-			 bool keys32 = false, bool rec32 = false, uint32_t keyed_cbits = 0, uint32_t key_bits = 0, int64_t key_lo = 0)
+			 bool keys32 = false, bool rec32 = false, uint32_t keyed_cbits = 0, uint32_t key_bits = 0, int64_t key_lo = 0,
+			 bool in32 = false /* the list already holds 4-byte records */)
 {
-	rec32 = rec32 && sb2 > 0 && kbits < 32 && !keyed_cbits;
+	rec32 = (rec32 || in32) && sb2 > 0 && kbits < 32 && !keyed_cbits;
+	if (in32 && !rec32)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4-byte group records need the two-level ordering sort");
 	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
 	uint64_t *h = ctx->h_pinned;
 	int rc;
 	for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
 		mdb_part_result ps;
 		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0, order_digits0(n_l, kbits, sb1),
-				       &ps, true, rec32 && sort_fast != 0);
+				       &ps, true, (rec32 && sort_fast != 0) ? (in32 ? 2 : 1) : 0);
 		if (rc)
 			return rc;
 		ord_args oa;
@@ -1510,6 +1533,8 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if (!sort_fast || !((uint32_t)h[8] & 2u))
 			break;
+		if (in32)
+			return GC_RETRY_REC64;	/* (a region of the ordering sort overflowed: its exact layout reads 8-byte records) */
 		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* the other flag bits were checked before */
 	}
 	return MIDORIDB_OK;
@@ -1823,6 +1848,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (ctx->keyed_distrust > 0)
 		ctx->keyed_distrust--;
 	a.keyed_cbits = keyed_cbits;
+	/* 4-byte records straight from the leaf kernel when the last run over these very columns saw every COUNT(*) fit beside the
+	 * row id (variant U: 10^8 records - 0.4 GB less to write and 0.4 GB less for the ordering sort to read) */
+	const bool r32_same = ctx->r32_ok && ctx->r32_kl == keys_l && ctx->r32_nl == n_l && ctx->r32_kr == keys_r && ctx->r32_nr == n_r;
+	a.rec32 = (r32_same && st->direct && has_r && records && !keyed_cbits && kbits < 32 && sb2 > 0 && pl.leaf_cap && pr.leaf_cap) ? 1u : 0u;
 	/* 4096 sampled keys with fewer than 4050 distinct values among them: at most a few 10^5 distinct values in the column */
 	a.merge_all = (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) ? 1u : 0u;
 	{
@@ -1888,6 +1917,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (((uint32_t)h[1] & 64u) && keyed_cbits) {
 		ctx->keyed_distrust = 64;	/* hot leaves go through kernels that write plain records: redo with those everywhere */
 		return GC_RETRY_UNKEYED;
+	}
+	if (a.rec32 && ((uint32_t)h[1] & (64u | 512u))) {
+		ctx->r32_ok = false;		/* a COUNT(*) that no longer fits, or hot leaves (their kernels write 8-byte records) */
+		return GC_RETRY_REC64;
 	}
 	if ((uint32_t)h[1] & 64u) {
 		/* hot keys: the plain kernel left the leaves with GC_HEAVY or more rows on a side to this path */
@@ -1966,9 +1999,17 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
 		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32,
-				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo);
+				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo, a.rec32 != 0);
+		if (rc == GC_RETRY_REC64)
+			ctx->r32_ok = false;
 		if (rc)
 			return rc;
+		/* remember whether 4-byte records would do for these columns */
+		ctx->r32_ok = st->direct && has_r && !keyed_cbits && !(status & 16u);
+		ctx->r32_kl = keys_l;
+		ctx->r32_nl = n_l;
+		ctx->r32_kr = keys_r;
+		ctx->r32_nr = n_r;
 	} else if (G) {
 		rc = mdb_dev_gather64(ctx, dense, NULL, sel, G, out_count, NULL);
 		if (rc)
@@ -2330,8 +2371,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
-		else if (rc == GC_RETRY_UNKEYED)
-			;		/* (gc_finish has set ctx->keyed_distrust) */
+		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64)
+			;		/* (gc_finish has set ctx->keyed_distrust / cleared ctx->r32_ok) */
 		else if (rc == GC_RETRY_BUILD_L)
 			no_build_r = true;
 		else
@@ -2611,7 +2652,7 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED)	/* skew / huge counts / wide keys: redo the whole operator */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
 	return rc;

@@ -858,6 +858,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NARROW_RID 8u	/* narrow form with the row id in the low half of the word (narrow = 1; no row-id arrays) */
 #define PART_F_KEYS32 16u	/* the key column is int32 */
 #define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
+#define PART_F_IN32 128u	/* with PART_F_FOLD32: the raw list already holds 4-byte words (nothing to fold) */
 #define PART_F_FOLD32 64u	/* raw 8-byte records are folded into 4-byte words by the first level (two-level fast layout only) */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
@@ -936,7 +937,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.n = n;
 		a.hv_in = l ? hv_buf[l - 1] : raw_hv;	/* raw_hv: level 0 reads ready-made 64-bit sort keys */
 		a.skip_zero = (l == 0 && raw_hv && !(flags & PART_F_NO_GAPS)) ? 1u : 0u;
-		a.fold64 = (fold32 && l == 0) ? 1u : 0u;
+		a.fold64 = (fold32 && l == 0 && !(flags & PART_F_IN32)) ? 1u : 0u;
 		a.rid_in = l ? rid_buf[l - 1] : NULL;
 		a.tiles = tiles;
 		a.hv_out = hv_buf[l];
@@ -1190,13 +1191,14 @@ size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t 
 }
 
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
-		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap, bool fold32)
+		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap, int fold32)
 {
 	part_carver cv = { ctx, false, 0, false };
 	if (fold32 && (!fast || bits2 <= 0 || !zero_is_gap))
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "folded raw words need the two-level fast layout");
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4-byte raw words need the two-level fast layout");
 	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false,
-			      (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS) | (fold32 ? PART_F_FOLD32 : 0u), MDB_DIGIT_RADIX, 0,
+			      (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS) | (fold32 ? PART_F_FOLD32 : 0u) | (fold32 == 2 ? PART_F_IN32 : 0u),
+			      MDB_DIGIT_RADIX, 0,
 			      false, NULL, hv, leaf_cap, out, NULL, digits0_used);
 }
 

@@ -1375,6 +1375,34 @@ def test_keyed_group_records_decode_the_key_instead_of_gathering_it(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, keyed)
 
 
+def test_four_byte_group_records_on_a_remembered_verdict_and_its_retraction(dev, narrow_mode):
+    """The second join over the same columns writes 4-byte group records straight from the leaf kernel (the first run saw every
+    COUNT(*) fit beside the row id).  When the buffers then change under the same addresses so that a COUNT no longer fits
+    (one key: 4 left x 300 right rows = 1200 >= 2^10 at 22 row-id bits), the kernel reports it and the operator is redone with
+    8-byte records: always the oracle's result."""
+    narrow_mode(1)
+    rng = np.random.default_rng(5150)
+    n = 3_000_000
+    kl = rng.permutation(n).astype(np.int64)
+    kr = rng.permutation(n).astype(np.int64)		# same range, unique keys: no pruning, no keyed records
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    for _ in range(3):
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        assert dev.last_join_form() == 2 and j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    kl[rng.choice(n, 4, replace=False)] = 777
+    kr[rng.choice(n, 300, replace=False)] = 777
+    dl.copy_(torch.from_numpy(kl).to(dl.device))
+    dr.copy_(torch.from_numpy(kr).to(dr.device))
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    for _ in range(2):
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    assert int(ec.max()) >= 1200
+
+
 def test_keyed_group_records_give_way_when_a_count_does_not_fit(dev, narrow_mode, monkeypatch):
     """4 * 10^7 x 4 * 10^7 rows (26 row-id bits + 26 key bits leave 12 bits of a keyed record for COUNT(*)): one key that
     8 left rows and 512 right rows hold has COUNT(*) = 4096 - the kernel reports it, the operator is redone with plain
