@@ -1425,7 +1425,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
 	for (uint32_t i = threadIdx.x; i < total; i += ORD_THREADS) {
 		const unsigned long long v = s_slot[i];
 		const uint32_t first = first_base + (uint32_t)(v >> 51);
-		a.out_first[base + i] = first;
+		if (a.out_first)		/* (a caller that only wants keys and counts: 4 bytes per group less to write) */
+			a.out_first[base + i] = first;
 		if (a.keyed_cbits) {
 			const unsigned long long pay = v & ((1ull << 51) - 1ull);
 			a.out_count[base + i] = (int64_t)(pay & ((1ull << a.keyed_cbits) - 1ull));
@@ -1998,7 +1999,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, first_out, out_count, NULL, keys_l, out_key, st->keys32,
+		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, out_first, out_count, NULL, keys_l, out_key, st->keys32,
 				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo, a.rec32 != 0);
 		if (rc == GC_RETRY_REC64)
 			ctx->r32_ok = false;
