@@ -364,6 +364,15 @@ def main():
         pipe = dx
         if dx is not None:
             dx.set_wire(WIRE_32 if w32 else WIRE_64)
+            # the same catalog statistics give every rank the two tables' GLOBAL key ranges: rows outside the other table's range
+            # stay home (min-max pruning before the shuffle; a key outside its own promised range would be reported as an error)
+            rng = []
+            for col in (a, b):
+                lo, hi = dev.key_range(col)
+                t = torch.tensor([-lo, hi], dtype=torch.float64, device=dev.device)     # (keys < 2^53 here: exact in float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rng.append((-int(t[0].item()), int(t[1].item())))
+            dx.set_key_ranges(rng[0], rng[1])
 
         def step():
             if pipe is None:
@@ -489,7 +498,8 @@ def main():
                        "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
                                       + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
                                       + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else ""),
-                       "rccl_ranks_seen": ranks_seen if use_dist else None},
+                       "rccl_ranks_seen": ranks_seen if use_dist else None,
+                       "pruned_before_shuffle": bool(dx.last_pruned()) if use_dist else None},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},

@@ -364,6 +364,14 @@ int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32_t *keys_r,
  */
 int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 			      uint32_t n_dest, int keys32, void *out_keys, uint32_t *out_rid, uint64_t *out_counts);
+/* ... _pruned: rows whose key lies outside [keep_lo, keep_hi] are dropped as well - the other table's GLOBAL key range, which
+ * the ranks know before the exchange (mdb_dev_key_range + one tiny exchange, or catalog statistics): a row outside it joins
+ * nothing on any GPU, so it need not cross xGMI (min-max pruning before the shuffle; mdb_dist_join_group_count does this).
+ * [own_lo, own_hi]: the range promised for THIS column (what the other table is pruned with): a key outside it is an error,
+ * never a silently wrong result.  INT64_MIN / INT64_MAX: no bound. */
+int mdb_dev_partition_by_dest_pruned(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t n_dest, int keys32,
+				     int64_t keep_lo, int64_t keep_hi, int64_t own_lo, int64_t own_hi, void *out_keys, uint32_t *out_rid,
+				     uint64_t *out_counts);
 /* column statistics: smallest / largest non-NULL key (min > max when there is none).  Synchronises. */
 int mdb_dev_key_range(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_min,
 		      int64_t *out_max);

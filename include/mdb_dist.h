@@ -67,7 +67,10 @@ int mdb_dist_init_transport(mdb_dev_ctx *ctx, int world, int rank, const struct 
 /* ------------------------------------------------------------------ options */
 enum mdb_dist_wire {
 	MDB_WIRE_AUTO = 0,	/* per call: 4-byte keys when the column statistics of BOTH tables on EVERY rank fit 32 bits
-				 * (mdb_dev_key_range + one tiny all-reduce; two extra read passes per call) */
+				 * (mdb_dev_key_range + one tiny exchange; two extra read passes per call).  The same statistics give
+				 * every rank the two tables' GLOBAL key ranges: rows outside the other table's range join nothing on any
+				 * GPU and are dropped before the shuffle (min-max pruning: a fact table whose dimension covers a
+				 * sixteenth of its key range sends a sixteenth of its rows) */
 	MDB_WIRE_64 = 1,	/* always 8-byte keys */
 	MDB_WIRE_32 = 2,	/* the caller knows (catalog statistics) that every key fits 32 bits; a key that does not is
 				 * reported as an error by the partition kernel, never truncated */
@@ -75,6 +78,13 @@ enum mdb_dist_wire {
 int mdb_dist_set_wire(mdb_dist *d, int mode);
 /* 1 when the last exchange shipped 4-byte keys */
 int mdb_dist_last_wire32(const mdb_dist *d);
+/* Catalog statistics for the next calls with MDB_WIRE_32 / MDB_WIRE_64 (MDB_WIRE_AUTO measures them itself): the GLOBAL
+ * [smallest, largest] key of the left and of the right table - the same on every rank.  Rows outside the OTHER table's range
+ * are dropped before the shuffle; a key outside the range promised for its OWN table is reported as an error by the
+ * partition kernel (supersets are fine, stale statistics are caught).  NULL, NULL: forget them. */
+int mdb_dist_set_key_ranges(mdb_dist *d, const int64_t left[2], const int64_t right[2]);
+/* 1 when the last call pruned the tables by each other's key range before the shuffle */
+int mdb_dist_last_pruned(const mdb_dist *d);
 
 /* ------------------------------------------------------------------ the sharded north-star operator
  *

@@ -63,6 +63,12 @@ struct mdb_part_filter {
 	uint32_t *minmax_out;
 	uint32_t *minmax_tiles;	/* with minmax_out: scratch of mdb_part_minmax_words(n) words (a pair per first-level tile, reduced after the launch) */
 	const uint32_t *range_in;
+	/* first level, any form: keep only the rows whose KEY lies in [keep_lo, keep_hi] (keep_on) - the other table's global key
+	 * range, known before an exchange (mdb_dev_partition_by_dest_pruned) */
+	bool keep_on;
+	int64_t keep_lo, keep_hi;
+	bool own_on;		/* ... and verify that every key of THIS table lies in [own_lo, own_hi] (a promised range: status bit 10 otherwise) */
+	int64_t own_lo, own_hi;
 	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then
 				 * sized by the tiles that exist (a 4-byte read-back + synchronisation) instead of by the table */
 };

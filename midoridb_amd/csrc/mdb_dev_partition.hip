@@ -97,6 +97,12 @@ struct mdb_level_args {
 	 * nothing.  Exact, and free: one compare per row, no extra pass, no host round trip */
 	uint32_t *minmax_out;
 	const uint32_t *range_in;
+	/* first level: rows whose key lies outside [keep_lo, keep_hi] are dropped (keep_on; partition by destination: the other
+	 * table's global key range is known before the exchange - nothing outside it can join on any GPU) */
+	uint32_t keep_on;
+	int64_t keep_lo, keep_hi;
+	uint32_t own_on;		/* every key of this table was promised to lie in [own_lo, own_hi]: one that does not raises status bit 10 */
+	int64_t own_lo, own_hi;
 	uint32_t fold64;		/* raw 4-byte words: the input is still the list of 8-byte records, folded on the fly (record >> 32 | low
 					 * half: the caller knows that the two parts do not overlap) */
 };
@@ -189,6 +195,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 	const bool in1 = e1 < lead + td.len;	/* e1 >= 1 >= lead always */
 	const uint64_t g0 = base2 + e0;
 	bool bad[2] = { false, false };
+	int64_t raw_key[2] = { 0, 0 };
 	hv[0] = hv[1] = 0;
 	rid[0] = rid[1] = 0;
 	valid[0] = in0;
@@ -203,6 +210,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			} else {
 				k = *reinterpret_cast<const ulonglong2 *>(a.keys + g0);
 			}
+			raw_key[0] = (int64_t)k.x;
+			raw_key[1] = (int64_t)k.y;
 			hv[0] = INV ? k.x : part_hash_key(a, k.x, (uint32_t)g0, &bad[0], rel ? &rel[0] : nullptr);	/* INV: the caller keeps the key itself */
 			hv[1] = INV ? k.y : part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1], rel ? &rel[1] : nullptr);
 			rid[0] = (uint32_t)g0;
@@ -222,6 +231,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
 			const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
+			raw_key[k] = key;
 			hv[k] = INV ? (uint64_t)key : part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k], rel ? &rel[k] : nullptr);
 			rid[k] = (uint32_t)g;
 		} else {
@@ -235,6 +245,13 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			valid[0] = false;
 		if (valid[1] && mdb_bit_is_set(a.nullbits, g0 + 1))
 			valid[1] = false;
+	}
+	if (LEVEL0 && a.own_on && ((valid[0] && (raw_key[0] < a.own_lo || raw_key[0] > a.own_hi)) ||
+				   (valid[1] && (raw_key[1] < a.own_lo || raw_key[1] > a.own_hi))))
+		mdb_raise(a.status, 1024u);
+	if (LEVEL0 && a.keep_on) {
+		valid[0] = valid[0] && raw_key[0] >= a.keep_lo && raw_key[0] <= a.keep_hi;
+		valid[1] = valid[1] && raw_key[1] >= a.keep_lo && raw_key[1] <= a.keep_hi;
 	}
 	if (LEVEL0 && ((bad[0] && valid[0]) || (bad[1] && valid[1])))
 		mdb_raise(a.status, 128u);	/* a key outside the int32 range: the narrow form does not apply */
@@ -951,6 +968,12 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keys32 = (flags & PART_F_KEYS32) ? 1u : 0u;
 		a.narrow_base = narrow_base;
 		a.narrow_kbits = a.narrow ? narrow_kbits : 0u;
+		a.own_on = (flt && l == 0 && flt->own_on) ? 1u : 0u;
+		a.own_lo = flt ? flt->own_lo : 0;
+		a.own_hi = flt ? flt->own_hi : 0;
+		a.keep_on = (flt && l == 0 && flt->keep_on) ? 1u : 0u;
+		a.keep_lo = flt ? flt->keep_lo : 0;
+		a.keep_hi = flt ? flt->keep_hi : 0;
 		a.minmax_out = (flt && l == 0 && flt->minmax_out) ? flt->minmax_tiles : NULL;	/* per-tile pairs, reduced after the launch */
 		a.range_in = (flt && l == 0) ? flt->range_in : NULL;
 		a.filter = (flt && l == 1) ? flt->bits : NULL;
@@ -1247,6 +1270,22 @@ int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_
 extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
 					 uint32_t n_dest, int keys32, void *out_keys, uint32_t *out_rid, uint64_t *out_counts)
 {
+	return mdb_dev_partition_by_dest_pruned(ctx, keys, nullbits, n, n_dest, keys32, INT64_MIN, INT64_MAX, INT64_MIN, INT64_MAX, out_keys, out_rid,
+						out_counts);
+}
+
+extern "C" int mdb_dev_partition_by_dest_pruned(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n,
+						uint32_t n_dest, int keys32, int64_t keep_lo, int64_t keep_hi, int64_t own_lo, int64_t own_hi,
+						void *out_keys, uint32_t *out_rid, uint64_t *out_counts)
+{
+	mdb_part_filter flt;
+	memset(&flt, 0, sizeof(flt));
+	flt.keep_on = keep_lo != INT64_MIN || keep_hi != INT64_MAX;
+	flt.keep_lo = keep_lo;
+	flt.keep_hi = keep_hi;
+	flt.own_on = own_lo != INT64_MIN || own_hi != INT64_MAX;
+	flt.own_lo = own_lo;
+	flt.own_hi = own_hi;
 	if (n_dest == 0 || n_dest > PART_MAX_R)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: n_dest must be in [1, %u]", PART_MAX_R);
 	if (n >= 0xFFFFFFFFull)
@@ -1263,23 +1302,24 @@ extern "C" int mdb_dev_partition_by_dest(mdb_dev_ctx *ctx, const int64_t *keys, 
 	const bool want_rid = out_rid != NULL;
 	part_carver dry = { NULL, true, 0, false };
 	(void)partition_impl(dry, NULL, NULL, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, NULL, out_rid, 0,
-			     keys32 != 0);
+			     keys32 != 0, 0, 0, &flt);
 	int rc = mdb_arena_begin(ctx, dry.bytes + 4096);
 	if (rc)
 		return rc;
 	part_carver cv = { ctx, false, 0, false };
 	mdb_part_result res;
-	if (keys32)
-		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
 	rc = partition_impl(cv, keys, nullbits, n, 1, 0, want_rid, 0u, MDB_DIGIT_MOD, n_dest, true, (uint64_t *)out_keys, NULL, 0, &res, out_rid, 0,
-			    keys32 != 0);
+			    keys32 != 0, 0, 0, &flt);
 	if (rc)
 		return rc;
 	uint32_t *h_off = (uint32_t *)ctx->h_pinned;
 	MDB_HIP(ctx, hipMemcpyAsync(h_off, res.leaf_off, ((size_t)n_dest + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-	if (keys32)
-		MDB_HIP(ctx, hipMemcpyAsync(h_off + n_dest + 1, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(h_off + n_dest + 1, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h_off[n_dest + 1] & 1024u)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: a key lies outside the range [%lld, %lld] promised for its column",
+				   (long long)own_lo, (long long)own_hi);
 	if (keys32 && (h_off[n_dest + 1] & 128u))
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "partition_by_dest: a key does not fit the 4-byte wire format (keys32 needs every key in "
 							 "the int32 range: check mdb_dev_key_range)");

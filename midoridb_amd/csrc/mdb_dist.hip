@@ -29,7 +29,9 @@ struct mdb_dist {
 	bool own_transport;		/* t.self is an rccl_transport created here */
 	hipStream_t comm_stream;	/* key transfers */
 	hipEvent_t ev_ready, ev_a, ev_b;
-	int wire_mode, last_wire32;
+	int wire_mode, last_wire32, last_pruned;
+	bool have_ranges;		/* mdb_dist_set_key_ranges(): promised global key ranges of the two tables of the next calls */
+	int64_t promised_lo[2], promised_hi[2];
 	/* exchange buffers (grow-only): send = this rank's keys grouped by destination, recv = what arrived */
 	void *send[2], *recv[2];
 	uint64_t send_cap[2], recv_cap[2];	/* in 8-byte words */
@@ -332,6 +334,21 @@ extern "C" int mdb_dist_world(const mdb_dist *d) { return d ? d->world : 0; }
 extern "C" int mdb_dist_rank(const mdb_dist *d) { return d ? d->rank : -1; }
 extern "C" const char *mdb_dist_last_error(const mdb_dist *d) { return d ? d->err : "no distributed handle"; }
 extern "C" int mdb_dist_last_wire32(const mdb_dist *d) { return d ? d->last_wire32 : 0; }
+extern "C" int mdb_dist_last_pruned(const mdb_dist *d) { return d ? d->last_pruned : 0; }
+
+extern "C" int mdb_dist_set_key_ranges(mdb_dist *d, const int64_t left[2], const int64_t right[2])
+{
+	if (!d)
+		return -MIDORIDB_ERROR;
+	d->have_ranges = left && right;
+	if (d->have_ranges) {
+		d->promised_lo[0] = left[0];
+		d->promised_hi[0] = left[1];
+		d->promised_lo[1] = right[0];
+		d->promised_hi[1] = right[1];
+	}
+	return MIDORIDB_OK;
+}
 extern "C" uint64_t mdb_dist_last_received_left(const mdb_dist *d) { return d ? d->last_recv_left : 0; }
 
 extern "C" int mdb_dist_set_wire(mdb_dist *d, int mode)
@@ -377,7 +394,8 @@ static int dist_reserve(mdb_dist *d, void **buf, uint64_t *cap, uint64_t words)
 /* one table: partition by destination into send[i], exchange counts, post the all-to-all into recv[i] on the transfer
  * stream.  *n_recv = rows this rank receives (they are in recv[i] once `done` has happened) */
 static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64_t *nulls, uint64_t n, bool wire32, uint64_t *n_recv,
-			   hipEvent_t done)
+			   hipEvent_t done, int64_t keep_lo = INT64_MIN, int64_t keep_hi = INT64_MAX, int64_t own_lo = INT64_MIN,
+			   int64_t own_hi = INT64_MAX)
 {
 	const int W = d->world;
 	uint64_t scnt[1 << MDB_MAX_RADIX_BITS], rcnt[1 << MDB_MAX_RADIX_BITS];
@@ -385,7 +403,8 @@ static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64
 	int rc = dist_reserve(d, &d->send[i], &d->send_cap[i], n + 2);
 	if (rc)
 		return rc;
-	rc = mdb_dev_partition_by_dest(d->ctx, keys, nulls, n, (uint32_t)W, wire32 ? 1 : 0, d->send[i], NULL, scnt);	/* (synchronises) */
+	rc = mdb_dev_partition_by_dest_pruned(d->ctx, keys, nulls, n, (uint32_t)W, wire32 ? 1 : 0, keep_lo, keep_hi, own_lo, own_hi, d->send[i],
+					      NULL, scnt);	/* (synchronises) */
 	if (rc)
 		return dist_err(d, rc, "partition by destination: %s", mdb_dev_last_error(d->ctx));
 	rc = d->t.counts(d->t.self, scnt, rcnt, 1);
@@ -426,11 +445,17 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	DIST_HIP(d, hipSetDevice(ctx->device));
 	/* ---- wire format: every rank must take the same decision */
 	bool wire32 = d->wire_mode == MDB_WIRE_32 && !left_in_place;
+	/* the two tables' GLOBAL key ranges (MDB_WIRE_AUTO: the column statistics are computed anyway): what lies outside the
+	 * other table's range joins nothing on any GPU and stays home - min-max pruning before the shuffle; a fact table whose
+	 * dimension covers a sixteenth of its key range sends a sixteenth of its rows */
+	int64_t glo[2] = { INT64_MIN, INT64_MIN }, ghi[2] = { INT64_MAX, INT64_MAX };
 	if (d->wire_mode == MDB_WIRE_AUTO && !left_in_place) {
-		uint64_t wide = 0;
+		const int W = d->world;
 		const int64_t *cols[2] = { keys_l, keys_r };
 		const uint64_t *nb[2] = { null_l, null_r };
 		const uint64_t ns[2] = { n_l, n_r };
+		/* (eight 32-bit halves per rank: the counters of a transport need not survive values beyond 2^63) */
+		uint64_t mine[4], all[8 << MDB_MAX_RADIX_BITS], sendv[8 << MDB_MAX_RADIX_BITS];
 		for (int i = 0; i < 2; i++) {
 			int64_t lo = 0, hi = -1;
 			if (ns[i]) {
@@ -438,15 +463,49 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 				if (rc)
 					return dist_err(d, rc, "key range: %s", mdb_dev_last_error(ctx));
 			}
-			if (lo <= hi && (lo < -(1ll << 31) || hi >= (1ll << 31)))
-				wide = 1;
+			if (lo > hi) {		/* no key at all on this rank */
+				lo = INT64_MAX;
+				hi = INT64_MIN;
+			}
+			mine[2 * i] = (uint64_t)lo;
+			mine[2 * i + 1] = (uint64_t)hi;
 		}
-		int rc = mdb_dist_allreduce_sum_u64(d, &wide, 1);
+		for (int p = 0; p < W; p++)
+			for (int q = 0; q < 4; q++) {
+				sendv[8 * p + 2 * q] = mine[q] >> 32;
+				sendv[8 * p + 2 * q + 1] = mine[q] & 0xFFFFFFFFull;
+			}
+		int rc = d->t.counts(d->t.self, sendv, all, 8);		/* every rank's four numbers to every rank */
 		if (rc)
-			return rc;
-		wire32 = wide == 0;
+			return dist_err(d, rc, "key range exchange failed");
+		for (int i = 0; i < 2; i++) {
+			int64_t lo = INT64_MAX, hi = INT64_MIN;
+			for (int p = 0; p < W; p++) {
+				const int64_t plo = (int64_t)((all[8 * p + 4 * i] << 32) | all[8 * p + 4 * i + 1]);
+				const int64_t phi = (int64_t)((all[8 * p + 4 * i + 2] << 32) | all[8 * p + 4 * i + 3]);
+				lo = plo < lo ? plo : lo;
+				hi = phi > hi ? phi : hi;
+			}
+			glo[i] = lo;
+			ghi[i] = hi;
+		}
+		bool wide = false;
+		for (int i = 0; i < 2; i++)
+			if (glo[i] <= ghi[i] && (glo[i] < -(1ll << 31) || ghi[i] >= (1ll << 31)))
+				wide = true;
+		wire32 = !wide;
 	}
 	d->last_wire32 = wire32 ? 1 : 0;
+	/* (a table without any key makes the other one's range empty: lo > hi drops every row, the join is empty) */
+	const bool measured = d->wire_mode == MDB_WIRE_AUTO && !left_in_place;
+	if (!measured && d->have_ranges && !left_in_place)
+		for (int i = 0; i < 2; i++) {
+			glo[i] = d->promised_lo[i];
+			ghi[i] = d->promised_hi[i];
+		}
+	const bool prune = (measured || (d->have_ranges && !left_in_place)) && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+	const bool verify = prune && !measured;		/* promised ranges are checked while each table is partitioned */
+	d->last_pruned = prune ? 1 : 0;
 
 	/* the transfer stream starts behind whatever the caller queued on the context's stream (its key columns) */
 	DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
@@ -456,11 +515,13 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	uint64_t got_l = n_l, got_r = 0;
 	int rc;
 	if (!left_in_place) {
-		rc = dist_send_table(d, 0, keys_l, null_l, n_l, wire32, &got_l, d->ev_a);
+		rc = dist_send_table(d, 0, keys_l, null_l, n_l, wire32, &got_l, d->ev_a, prune ? glo[1] : INT64_MIN, prune ? ghi[1] : INT64_MAX,
+				     verify ? glo[0] : INT64_MIN, verify ? ghi[0] : INT64_MAX);
 		if (rc)
 			return rc;
 	}
-	rc = dist_send_table(d, 1, keys_r, null_r, n_r, wire32, &got_r, d->ev_b);
+	rc = dist_send_table(d, 1, keys_r, null_r, n_r, wire32, &got_r, d->ev_b, prune ? glo[0] : INT64_MIN, prune ? ghi[0] : INT64_MAX,
+			     verify ? glo[1] : INT64_MIN, verify ? ghi[1] : INT64_MAX);
 	if (rc)
 		return rc;
 	d->last_recv_left = got_l;

@@ -97,6 +97,7 @@ def _bind(lib):
         "mdb_dev_join_group_count_begin_i32": ([P, P, c_uint64, c_uint64], c_int),
         "mdb_dev_join_group_count_finish_i32": ([P, P, c_uint64, c_uint32, P, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_partition_by_dest": ([P, P, P, c_uint64, c_uint32, c_int, P, P, POINTER(c_uint64)], c_int),
+        "mdb_dev_partition_by_dest_pruned": ([P, P, P, c_uint64, c_uint32, c_int, c_int64, c_int64, c_int64, c_int64, P, P, POINTER(c_uint64)], c_int),
         "mdb_dev_key_range": ([P, P, P, c_uint64, POINTER(c_int64), POINTER(c_int64)], c_int),
         "mdb_dev_widen32to64": ([P, P, c_uint64, P], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
@@ -115,7 +116,7 @@ DEV_SYMBOLS = [
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
-    "mdb_dev_partition_by_dest", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
+    "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
 ]
 
 
@@ -517,9 +518,11 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_topk_perm(self.h, arr, len(keys), n, k, _ptr(perm), ctypes.byref(cand)), "topk_perm")
         return perm[:k], cand.value
 
-    def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False, keys32=False):
+    def partition_by_dest(self, keys, nulls, n_dest, out=None, with_rid=False, keys32=False, keep=None, own=None):
         """-> (keys grouped by destination, counts per destination[, source row of every entry]).  keys32: the keys
-        come out as int32 (4-byte wire format; the caller knows from key_range() that they fit)."""
+        come out as int32 (4-byte wire format; the caller knows from key_range() that they fit).  keep = (lo, hi): rows
+        whose key lies outside are dropped (the other table's global key range); own = (lo, hi): the range promised for this
+        column - a key outside it is an error."""
         n = keys.numel()
         if out is None:
             out = torch.empty(max(n, 1), dtype=torch.int32 if keys32 else torch.int64, device=self.device)
@@ -527,8 +530,10 @@ class DeviceCtx:
             out = out.view(torch.int32)
         rid = torch.empty(max(n, 1), dtype=torch.int32, device=self.device) if with_rid else None
         counts = (c_uint64 * n_dest)()
-        self._chk(self.lib.mdb_dev_partition_by_dest(self.h, _ptr(keys), _ptr(nulls), n, n_dest, 1 if keys32 else 0, _ptr(out), _ptr(rid),
-                                                     counts), "partition_by_dest")
+        i64 = (-(1 << 63), (1 << 63) - 1)
+        keep, own = keep or i64, own or i64
+        self._chk(self.lib.mdb_dev_partition_by_dest_pruned(self.h, _ptr(keys), _ptr(nulls), n, n_dest, 1 if keys32 else 0, int(keep[0]), int(keep[1]),
+                                                            int(own[0]), int(own[1]), _ptr(out), _ptr(rid), counts), "partition_by_dest")
         counts = [int(c) for c in counts]
         if with_rid:
             return out[:sum(counts)], counts, rid[:sum(counts)]

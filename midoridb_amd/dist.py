@@ -33,6 +33,7 @@ DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned",
 ]
 
 
@@ -51,6 +52,8 @@ def _bind(lib):
         "mdb_dist_init_transport": ([P, c_int, c_int, POINTER(Transport), POINTER(P)], c_int),
         "mdb_dist_set_wire": ([P, c_int], c_int),
         "mdb_dist_last_wire32": ([P], c_int),
+        "mdb_dist_last_pruned": ([P], c_int),
+        "mdb_dist_set_key_ranges": ([P, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64)], c_int),
         "mdb_dist_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dist_join_group_count_alloc": ([P, P, P, c_uint64, P, P, c_uint64, ctypes.c_uint32, POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64),
                                              POINTER(c_uint64)], c_int),
@@ -171,6 +174,19 @@ class DistCtx:
 
     def last_wire32(self):
         return bool(self.lib.mdb_dist_last_wire32(self.h))
+
+    def last_pruned(self):
+        return bool(self.lib.mdb_dist_last_pruned(self.h))
+
+    def set_key_ranges(self, left=None, right=None):
+        """catalog statistics for WIRE_32 / WIRE_64 calls: the GLOBAL (smallest, largest) key of the left and right table (the same
+        on every rank); rows outside the other table's range stay home, a key outside its own promised range is an error.
+        None, None forgets them."""
+        if left is None or right is None:
+            self._chk(self.lib.mdb_dist_set_key_ranges(self.h, None, None), "set_key_ranges")
+            return
+        la, ra = (ctypes.c_int64 * 2)(int(left[0]), int(left[1])), (ctypes.c_int64 * 2)(int(right[0]), int(right[1]))
+        self._chk(self.lib.mdb_dist_set_key_ranges(self.h, la, ra), "set_key_ranges")
 
     def last_received_left(self):
         return int(self.lib.mdb_dist_last_received_left(self.h))

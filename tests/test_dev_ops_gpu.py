@@ -348,6 +348,33 @@ def test_partition_by_dest(dev, n_dest):
     assert np.array_equal(orc.dest_of(_np(out2), n_dest), np.repeat(np.arange(n_dest), counts2))
 
 
+@pytest.mark.parametrize("n_dest", [1, 2, 8])
+def test_partition_by_dest_pruned_by_the_other_tables_key_range(dev, n_dest):
+    """Min-max pruning before the shuffle: rows whose key lies outside [keep_lo, keep_hi] stay home (with and without the 4-byte
+    wire format, with row ids), a key outside the range promised for its own column is an error."""
+    rng = np.random.default_rng(50 + n_dest)
+    k = rng.integers(-10**6, 10**6, 300_001, dtype=np.int64)
+    nl = rng.random(len(k)) < 0.03
+    lo, hi = -250_000, 123_456
+    inside = (k >= lo) & (k <= hi)
+    ek, ec = orc.partition_by_dest(k[inside], nl[inside], n_dest)
+    off = np.concatenate([[0], np.cumsum(ec)])
+    for keys32 in (False, True):
+        out, counts, rid = dev.partition_by_dest(dev.to_dev(k), dev.nullbits_dev(nl), n_dest, with_rid=True, keys32=keys32, keep=(lo, hi),
+                                                 own=(-10**6, 10**6))
+        assert counts == ec.tolist()
+        got = _np(out).astype(np.int64)
+        for d in range(n_dest):
+            assert np.array_equal(np.sort(got[off[d]:off[d + 1]]), np.sort(ek[off[d]:off[d + 1]]))
+        r = _np(rid).view(np.uint32)
+        assert np.array_equal(k[r], got) and inside[r].all() and not nl[r].any()
+    with pytest.raises(D.DeviceError) as ei:
+        dev.partition_by_dest(dev.to_dev(k), dev.nullbits_dev(nl), n_dest, keep=(lo, hi), own=(-10**6, 500_000))
+    assert "promised" in str(ei.value)
+    out, counts = dev.partition_by_dest(dev.to_dev(k), dev.nullbits_dev(nl), n_dest, keep=(5, 4))	# an empty range keeps nothing
+    assert sum(counts) == 0
+
+
 def test_gen_keys_matches_oracle(dev):
     for (n, first, domain, seed, mod) in [(1000, 0, 1000, 42, 0), (5000, 2500, 10_000, 43, 0), (4096, 0, 4096, 44, 256)]:
         got = _np(dev.gen_keys(n, first, domain, seed, mod))
