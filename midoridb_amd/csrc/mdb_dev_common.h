@@ -37,6 +37,8 @@ struct mdb_dev_ctx {
 	int64_t nh_base;		/* the window centre that went with "narrow" */
 	uint32_t nh_kbits;		/* ... and the compact window the sample offered (0 = none): [nh_lo, nh_lo + 2^nh_kbits) */
 	int64_t nh_lo;
+	bool nh_r_based;		/* ... and the compact window was taken from the right table's keys alone */
+	int64_t sr_rlo, sr_rhi;		/* the right table's sampled extremes (last sample) */
 	bool nh_prunable;		/* ... or at least not all of it (min-max pruning worth recording the right table's range) */
 	bool nh_by_span;		/* ... because its sampled SPAN is small (min-max pruning does the work, no bitmap) */
 	bool nh_selective;		/* ... and whether the right table looked like it covers a small part of the left table's keys */

@@ -253,7 +253,9 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		valid[0] = valid[0] && raw_key[0] >= a.keep_lo && raw_key[0] <= a.keep_hi;
 		valid[1] = valid[1] && raw_key[1] >= a.keep_lo && raw_key[1] <= a.keep_hi;
 	}
-	if (LEVEL0 && ((bad[0] && valid[0]) || (bad[1] && valid[1])))
+	/* (with min-max pruning - range_in - a key outside the window is outside the right table's range, which lies inside the
+	 * window: the caller drops the row, nothing to report) */
+	if (LEVEL0 && !a.range_in && ((bad[0] && valid[0]) || (bad[1] && valid[1])))
 		mdb_raise(a.status, 128u);	/* a key outside the int32 range: the narrow form does not apply */
 	if (RAW && a.skip_zero) {
 		valid[0] = valid[0] && hv[0] != 0;
