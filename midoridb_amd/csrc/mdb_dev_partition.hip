@@ -448,15 +448,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			/* (the key-range tests of the by-destination partition are compiled into its own instance only: as run-time
 			 * branches they cost the join's first-level kernels 0.05 ms per 10^8 rows) */
 			part_load2<LEVEL0, HAS_RID, RAW, INV, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid, RANGE ? rel2 : nullptr);
-			if (RANGE && a.narrow) {
+			if (RANGE && a.range_in) {		/* (uniform) */
+				valid[0] = valid[0] && rel2[0] >= range_lo && rel2[0] <= range_hi;
+				valid[1] = valid[1] && rel2[1] >= range_lo && rel2[1] <= range_hi;
+			}
+			if (RANGE && a.minmax_out) {
 #pragma unroll
-				for (int k = 0; k < 2; k++) {
-					valid[k] = valid[k] && rel2[k] >= range_lo && rel2[k] <= range_hi;
-					if (a.minmax_out && valid[k]) {		/* (a valid row of a narrow form: rel < 2^32) */
+				for (int k = 0; k < 2; k++)
+					if (valid[k]) {		/* (a valid row of a narrow form: rel < 2^32) */
 						seen_min = rel2[k] < seen_min ? (uint32_t)rel2[k] : seen_min;
 						seen_max = rel2[k] > seen_max ? (uint32_t)rel2[k] : seen_max;
 					}
-				}
 			}
 			if (FILT) {		/* (narrow words: hash32 in the upper half) */
 #pragma unroll
