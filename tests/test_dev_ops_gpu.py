@@ -1258,6 +1258,35 @@ def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), info
 
 
+@pytest.mark.parametrize("shape", ["spread", "bunched"])
+def test_few_groups_are_ordered_through_row_id_bitmaps_or_the_general_sort_alike(dev, narrow_mode, monkeypatch, shape):
+    """Few group records among many left rows (a selective join) are ordered by k_order_leaf_sparse - leaves of 2^16 row
+    ids, ranks from a bitmap of the leaf's row ids - when a leaf's share fits a workgroup's registers.  'spread': the groups'
+    first rows lie all over the table (the attempt succeeds); 'bunched': every group's first row is among the first 250 000
+    rows, four leaves get 50 000 records each and the general ordering sort takes over.  Both equal the oracle and the
+    result with the attempt switched off."""
+    narrow_mode(1)
+    rng = np.random.default_rng(2024 if shape == "spread" else 2025)
+    n_l, groups = 16_000_000 + (4096 if shape == "spread" else 0), 200_000
+    if shape == "spread":
+        kl = rng.permutation(n_l).astype(np.int64)
+        kr = rng.choice(n_l, groups, replace=False).astype(np.int64)
+    else:
+        kl = rng.integers(0, groups, n_l, dtype=np.int64)
+        kl[:groups] = rng.permutation(groups)
+        kr = np.arange(groups, dtype=np.int64)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    assert ek.size == groups
+    if shape == "bunched":
+        assert int(ef.max()) < 250_000
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    for sparse in ("1", "0", "1"):
+        monkeypatch.setenv("MDB_ORDER_SPARSE", sparse)
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, sparse)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, sparse)
+
+
 def test_min_max_pruning_with_a_right_table_of_nothing_but_null_keys(dev, narrow_mode, monkeypatch):
     """No right key at all: an empty join, as the reference's - a NULL key joins nothing (executor_select.c:557-579); with
     the right table forced first (MDB_MINMAX_PRUNE=2: prune whatever the key sample says) the recorded range stays empty
