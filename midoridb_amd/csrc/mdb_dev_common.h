@@ -62,6 +62,8 @@ struct mdb_dev_ctx {
 	bool r32_ok;			/* the last join over (r32_kl, r32_nl, r32_kr, r32_nr) fitted every COUNT(*) into a 4-byte group record */
 	const void *r32_kl, *r32_kr;
 	uint64_t r32_nl, r32_nr;
+	const void *lw_bad_keys;	/* the left key column (and the two row counts) for which a 16-bit row count of the one-level direct leaves */
+	uint64_t lw_bad_nl, lw_bad_nr;	/* (k_leaf_wide) overflowed last: two levels for these columns */
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */

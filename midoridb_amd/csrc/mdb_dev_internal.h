@@ -35,6 +35,9 @@ struct mdb_part_result {
 	uint32_t nleaves;
 	uint32_t bits_total;
 	bool w32;		/* hv holds 4-byte words (narrow form without row ids) */
+	uint32_t nsub;		/* != 0: first level only (mdb_part_filter.level0_only) - nleaves = 2^bits1 digits, digit d's rows lie in nsub
+				 * regions: region r = d * nsub + s at [r * leaf_cap, r * leaf_cap + min(count, leaf_cap)), its count at
+				 * leaf_cnt[s * nleaves + d] */
 };
 
 /* bytes of arena needed by mdb_partition_table() */
@@ -69,6 +72,8 @@ struct mdb_part_filter {
 	int64_t keep_lo, keep_hi;
 	bool own_on;		/* ... and verify that every key of THIS table lies in [own_lo, own_hi] (a promised range: status bit 10 otherwise) */
 	int64_t own_lo, own_hi;
+	bool level0_only;	/* stop after the histogram-free first level (bits2 = 0): the consumer reads the digits' sub-regions itself
+				 * (mdb_part_result.nsub; k_leaf_wide in mdb_dev_join.hip) */
 	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then
 				 * sized by the tiles that exist (a 4-byte read-back + synchronisation) instead of by the table */
 };
@@ -83,6 +88,9 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 							 * bits1 + bits2 partition bits only narrow_kbits - bits1 - bits2 bits tell keys apart */
 			const struct mdb_part_filter *flt = NULL);	/* semi-join filter at the second level (left side of a join in the
 									 * compact narrow form only), see struct mdb_part_filter */
+
+/* arena bytes of a first-level-only partition (mdb_part_filter.level0_only) of n rows by bits1 bits */
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1);
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

@@ -1046,6 +1046,198 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 		atomicAdd(a.rec_valid, st.s_chunk[3]);
 }
 
+/* ------------------------------------------------------------------ wide direct-address leaves: ONE partition level
+ *
+ * Key windows of at most 2^23 values (a dimension table's keys; after R-based pruning the benchmark's variant D: 6.25 * 10^6
+ * right keys) need 11 bits of partitioning before k_leaf_direct's 2^12-entry tables fit - two scatter levels, the second one
+ * a full read + write of both tables for 3 or 4 bits.  Here the tables are partitioned ONCE, by 9 bits (histogram-free first
+ * level, mdb_part_filter.level0_only), and one 1024-thread workgroup joins a whole digit: 2^rem entries, rem <= 14, with the
+ * row counts as 16-BIT halves of 32-bit LDS words (8 bytes per entry instead of 12: 128 KiB at rem = 14).  A count that
+ * outgrows its half carries into (or out of) the neighbour - every such accident makes the sum of the halves SMALLER than the
+ * number of adds, which the emit pass checks: status bit 10, the operator is redone with two levels (and their hot-key path).
+ * The digit's rows lie in the PART_NSUB sub-regions the first level wrote; they are streamed with four 16-byte loads in
+ * flight per thread.  The records of a digit are counted first and appended with one global atomic: the list has no gaps.
+ * Variant D: second-level scatters 0.194 + 0.031 ms and leaf 0.133 ms -> see profiles/r02. */
+#define LW_THREADS 1024
+#define LW_MIN_REM 11u		/* one 32-bit word of halves per thread */
+#define LW_MAX_REM 14u
+#define LW_UNROLL 4
+
+__device__ static inline unsigned long long lw_block_sum(unsigned long long v, unsigned long long *s_red)
+{
+#pragma unroll
+	for (int o = 32; o; o >>= 1)
+		v += __shfl_down(v, o, MDB_WAVE);
+	__syncthreads();	/* protect s_red against a previous use */
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	unsigned long long t = 0;
+#pragma unroll
+	for (int w = 0; w < LW_THREADS / 64; w++)
+		t += s_red[w];
+	return t;
+}
+
+template <bool HAS_R>
+__global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t rem, uint32_t shift, uint32_t nsub)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
+	__shared__ unsigned long long s_red[LW_THREADS / 64];
+	__shared__ uint32_t s_scan[32];
+	__shared__ uint32_t s_base;
+	const uint32_t T = 1u << rem, mask = T - 1u, leaf = blockIdx.x;
+	uint32_t *const s_first = lw_lds;			/* first left row per key */
+	uint32_t *const s_cl = lw_lds + T;			/* left rows per key (joins: only of keys that have right rows), 16-bit halves */
+	uint32_t *const s_cr = lw_lds + T + T / 2;		/* right rows per key, 16-bit halves */
+	for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
+		s_first[s] = 0xFFFFFFFFu;
+	for (uint32_t s = threadIdx.x; s < (HAS_R ? T : T / 2); s += LW_THREADS)
+		s_cl[s] = 0u;
+	__syncthreads();
+
+	uint32_t rows_r = 0;
+	if (HAS_R) {
+		const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
+		for (uint32_t sub = 0; sub < nsub; sub++) {
+			const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
+			const uint32_t *const src = hv_r32 + (size_t)(leaf * nsub + sub) * a.cap_r;
+			rows_r += c;
+			for (uint32_t j0 = 0; j0 < c; j0 += 4u * LW_THREADS * LW_UNROLL) {	/* uniform trip count */
+				uint4 v[LW_UNROLL];
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 4u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					v[u] = make_uint4(0u, 0u, 0u, 0u);
+					if (j < c)
+						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+				}
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 4u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						if (j + k < c) {
+							const uint32_t idx = (w[k] >> shift) & mask;
+							atomicAdd(&s_cr[idx >> 1], 1u << ((idx & 1u) * 16u));
+						}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	uint32_t adds = 0;
+	for (uint32_t sub = 0; sub < nsub; sub++) {
+		const uint32_t c0 = a.cnt_l[sub * a.nleaves + leaf], c = c0 < a.cap_l ? c0 : a.cap_l;
+		const uint64_t *const src = a.hv_l + (size_t)(leaf * nsub + sub) * a.cap_l;
+		for (uint32_t i0 = 0; i0 < c; i0 += 2u * LW_THREADS * LW_UNROLL) {
+			ulonglong2 v[LW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < LW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+				v[u] = make_ulonglong2(0ull, 0ull);
+				if (i < c)
+					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
+			}
+#pragma unroll
+			for (int u = 0; u < LW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+				const unsigned long long w[2] = { v[u].x, v[u].y };
+#pragma unroll
+				for (int k = 0; k < 2; k++)
+					if (i + k < c) {
+						const uint32_t idx = ((uint32_t)(w[k] >> 32) >> shift) & mask;
+						if (!HAS_R || ((s_cr[idx >> 1] >> ((idx & 1u) * 16u)) & 0xFFFFu)) {
+							atomicAdd(&s_cl[idx >> 1], 1u << ((idx & 1u) * 16u));
+							atomicMin(&s_first[idx], (uint32_t)w[k]);
+							adds++;
+						}
+					}
+			}
+		}
+	}
+	__syncthreads();
+
+	/* emit: thread t owns the words [t * W, t * W + W) of halves = 2 W consecutive entries */
+	const uint32_t W = 1u << (rem - LW_MIN_REM);
+	uint32_t cl2[1u << (LW_MAX_REM - LW_MIN_REM)], cr2[1u << (LW_MAX_REM - LW_MIN_REM)];
+	uint32_t mine = 0;
+	unsigned long long sums = 0;	/* low half: right rows counted, high half: left rows counted */
+#pragma unroll
+	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_MIN_REM)); k++) {
+		cl2[k] = 0u;
+		cr2[k] = 0x00010001u;
+		if ((uint32_t)k < W) {
+			cl2[k] = s_cl[threadIdx.x * W + (uint32_t)k];
+			if (HAS_R)
+				cr2[k] = s_cr[threadIdx.x * W + (uint32_t)k];
+			mine += ((cl2[k] & 0xFFFFu) ? 1u : 0u) + ((cl2[k] >> 16) ? 1u : 0u);
+			sums += ((unsigned long long)((cl2[k] & 0xFFFFu) + (cl2[k] >> 16)) << 32) | (HAS_R ? (cr2[k] & 0xFFFFu) + (cr2[k] >> 16) : 0u);
+		}
+	}
+	const unsigned long long want = ((unsigned long long)adds << 32);
+	const unsigned long long got = lw_block_sum(sums, s_red), asked = lw_block_sum(want, s_red);
+	if (got != (asked | (HAS_R ? rows_r : 0u))) {	/* a 16-bit count overflowed: two levels and their hot-key path take over */
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 1024u);
+		return;
+	}
+	uint32_t total;
+	uint32_t pos = mdb_block_excl_scan(mine, s_scan, &total);
+	if (!total)
+		return;
+	if (a.kbits) {
+		if (threadIdx.x == 0) {
+			const uint32_t nb = atomicAdd(a.rec_count, total);
+			if (nb + total > a.rec_cap) {
+				mdb_raise(a.status, 8u);
+				s_base = 0xFFFFFFFFu;
+			} else {
+				s_base = nb;
+				atomicAdd(a.rec_valid, total);
+			}
+		}
+		__syncthreads();
+		if (s_base == 0xFFFFFFFFu)
+			return;
+		pos += s_base;
+	}
+	unsigned long long joined = 0;
+#pragma unroll
+	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_MIN_REM)); k++) {
+		if ((uint32_t)k >= W)
+			continue;
+#pragma unroll
+		for (int e = 0; e < 2; e++) {
+			const uint32_t cl = (cl2[k] >> (16 * e)) & 0xFFFFu;
+			if (!cl)
+				continue;
+			const uint32_t s = 2u * (threadIdx.x * W + (uint32_t)k) + (uint32_t)e;
+			const uint32_t first = s_first[s];
+			const unsigned long long c = (unsigned long long)cl * ((cr2[k] >> (16 * e)) & 0xFFFFu);
+			joined += c;
+			if (a.kbits && a.keyed_cbits) {
+				if (c >> a.keyed_cbits)
+					mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
+				a.rec[pos++] = ((unsigned long long)first << (64 - a.kbits)) | ((unsigned long long)((leaf << rem) | s) << a.keyed_cbits) | c;
+			} else if (a.kbits) {
+				if (c >> (64 - a.kbits))
+					mdb_raise(a.status, 4u);	/* COUNT(*) does not fit beside the row id */
+				if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
+					mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record */
+				a.rec[pos++] = ((unsigned long long)first << (64 - a.kbits)) | c;
+			} else {
+				a.dense_cnt[first] = (int64_t)c;
+			}
+		}
+	}
+	joined = lw_block_sum(joined, s_red);
+	if (threadIdx.x == 0 && joined)
+		atomicAdd(a.joined, joined);
+}
+
 /* ------------------------------------------------------------------ semi-join filter (compact narrow form)
  *
  * Bitmap of the hashed key values the RIGHT table holds, one bit per 2^coarse adjacent values, built from its
@@ -1749,6 +1941,7 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
  * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
  * key - window base (min-max pruning, while it runs) */
 #define GC_ST_MINMAX 16
+#define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
 #define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
 #define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
 
@@ -1785,6 +1978,7 @@ struct gc_state {
 	uint32_t key_bits;	/* compact narrow form offered by the key sample: every key in [key_lo, key_lo + 2^key_bits) (0 = none) */
 	int64_t key_lo;
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
+	bool one_level;		/* ... by k_leaf_wide: ONE partition level of 9 bits, tables of 2^(key_bits - 9) entries */
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
 	bool prunable;		/* the right table's keys cover less than 7/8 of the left table's range (sample) */
@@ -1804,15 +1998,28 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
 	if (st->r_based && !(st->has_r && st->defer_ok && !st->active && st->fast))
 		st->key_bits = 0;	/* (a window of the right table's keys only needs the left table pruned: not in this call - plain narrow form) */
+	/* key windows of 2^20 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
+	 * than 2^21 rows in all keep the two-level form, whose fixed costs are smaller) */
+	st->one_level = st->narrow && st->key_bits >= 9u + LW_MIN_REM && st->key_bits <= 9u + LW_MAX_REM && st->fast && st->want_records &&
+			!ld_disabled() && !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
+			st->n_l + (st->has_r ? st->n_r_cap : 0) >= (1ull << 21) &&
+			st->n_l < 3000000000ull && st->n_r_cap < 3000000000ull &&
+			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
+	if (st->one_level) {
+		st->b1 = 9;
+		st->b2 = 0;
+	}
 	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
-	if (st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
+	if (!st->one_level && st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
 		st->narrow = false;
 	/* compact narrow form + direct-address leaves: what the partition leaves of the key_bits-wide hash must index a table
 	 * of at most 2^LD_MAX_REM entries; fewer than 2^4 would mean leaves of a handful of keys with thousands of rows each
 	 * (same-address LDS atomics: the hashed kernel's wave-level merging handles those better) */
 	st->direct = st->narrow && st->key_bits && st->fast && st->b2 > 0 && st->want_records && !ld_disabled() &&
 		     st->key_bits >= (uint32_t)(st->b1 + st->b2) + 4u && st->key_bits <= (uint32_t)(st->b1 + st->b2) + LD_MAX_REM;
-	if (st->direct) {
+	if (st->one_level)
+		st->direct = true;
+	if (st->direct && !st->one_level) {
 		/* the direct-address kernel has no table to overflow and pays a fixed price per leaf (three barriers, the emit scan):
 		 * it prefers FEWER, larger leaves than the hashed kernel's 3833-slot table allows - tables of 2^LD_MAX_REM entries when
 		 * the second level has the bits to give (10^8 x 10^8 rows: 2^15 leaves of 2 x 3052 rows instead of 2^16; second-level
@@ -1846,10 +2053,10 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
 	 * below would filter nothing more and is not built. */
 	const char *prune_env = getenv("MDB_MINMAX_PRUNE");		/* 0: never, 2: whatever the key sample says (tests) */
-	st->defer_l = st->narrow && st->fast && st->b2 > 0 && st->has_r && st->defer_ok && !st->active &&
+	st->defer_l = st->narrow && st->fast && (st->b2 > 0 || st->one_level) && st->has_r && st->defer_ok && !st->active &&
 		      (st->prunable || (st->direct && st->selective) || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
 	st->semijoin = 0;
-	if (st->defer_l && st->direct && st->selective && !st->by_span) {
+	if (st->defer_l && st->direct && !st->one_level && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
 		const uint32_t slice_max = e2 && atoi(e2) >= 7 && atoi(e2) <= 18 ? (uint32_t)atoi(e2) : 17u;	/* log2 bits: 2^17 = 16 KiB */
 		const uint32_t below0 = st->key_bits - (uint32_t)st->b1;		/* hash bits below the first-level digit */
@@ -1858,13 +2065,14 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		if (!(e && e[0] == '0') && coarse <= 3u && rem >= coarse + 5u && below0 - coarse >= 7u)
 			st->semijoin = coarse + 1u;
 	}
-	size_t need = mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
+	size_t need = st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->semijoin)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
 	if (st->defer_l)
 		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 4) + 256;
 	if (st->has_r)
-		need += mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
+		need += st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
+				      : mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	{
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
@@ -1886,8 +2094,12 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
 	if (!st->defer_l) {
+		mdb_part_filter lflt;
+		memset(&lflt, 0, sizeof(lflt));
+		lflt.level0_only = st->one_level;
 		rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
-					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u);
+					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u,
+					 st->one_level ? &lflt : NULL);
 		if (rc)
 			return rc;
 	}
@@ -1914,10 +2126,11 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (has_r) {
 		if (n_r > st->n_r_cap)
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
-		if (st->narrow && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
+		if (st->narrow && !st->one_level && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
 			return GC_RETRY_WIDE;	/* split form: the left side was prepared narrow for a right table of another size */
 		mdb_part_filter rflt;
 		memset(&rflt, 0, sizeof(rflt));
+		rflt.level0_only = st->one_level;
 		if (st->defer_l) {
 			/* [16] smallest, [17] largest key - window base of the right table (min-max pruning) */
 			rflt.minmax_out = ctx->d_status + GC_ST_MINMAX;
@@ -1926,7 +2139,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				return -MIDORIDB_INTERNAL;
 		}
 		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32,
-					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, st->defer_l ? &rflt : NULL);
+					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, (st->defer_l || st->one_level) ? &rflt : NULL);
 		if (rc)
 			return rc;
 	}
@@ -1934,7 +2147,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		mdb_part_filter flt;
 		memset(&flt, 0, sizeof(flt));
 		flt.range_in = ctx->d_status + GC_ST_MINMAX;
-		flt.expect_pruned = st->by_span;
+		flt.expect_pruned = st->by_span && !st->one_level;
+		flt.level0_only = st->one_level;
 		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32,
 					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, &flt);
 		if (rc)
@@ -2024,7 +2238,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	/* 4-byte records straight from the leaf kernel when the last run over these very columns saw every COUNT(*) fit beside the
 	 * row id (variant U: 10^8 records - 0.4 GB less to write and 0.4 GB less for the ordering sort to read) */
 	const bool r32_same = ctx->r32_ok && ctx->r32_kl == keys_l && ctx->r32_nl == n_l && ctx->r32_kr == keys_r && ctx->r32_nr == n_r;
-	a.rec32 = (r32_same && st->direct && has_r && records && !keyed_cbits && kbits < 32 && sb2 > 0 && pl.leaf_cap && pr.leaf_cap) ? 1u : 0u;
+	a.rec32 = (r32_same && st->direct && !st->one_level && has_r && records && !keyed_cbits && kbits < 32 && sb2 > 0 && pl.leaf_cap && pr.leaf_cap) ? 1u : 0u;
 	/* 4096 sampled keys with fewer than 4050 distinct values among them: at most a few 10^5 distinct values in the column */
 	a.merge_all = (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) ? 1u : 0u;
 	{
@@ -2040,7 +2254,20 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
 		/* (the direct kernel addresses leaf i at i * cap: should a table have fallen back to exact offsets - more than 2^32
 		 * region words - the hashed kernel below joins the compact words just as well, they are injective too) */
-		if (st->direct && pl.leaf_cap && (!has_r || pr.leaf_cap)) {
+		if (st->one_level) {
+			/* ... by ALL the hash bits below the first level's 9 (k_leaf_wide) */
+			if (!pl.nsub || !pl.leaf_cap || (has_r && (!pr.nsub || !pr.w32 || pr.nsub != pl.nsub || pr.nleaves != pl.nleaves)))
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level direct leaves: the tables are not in the first-level layout");
+			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
+			const size_t lds = ((size_t)(has_r ? 8 : 6) << rem);
+			if (has_r) {
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				MDB_LAUNCH_LDS(ctx, "leaf_join_wide", (k_leaf_wide<true>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
+			} else {
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				MDB_LAUNCH_LDS(ctx, "leaf_group_wide", (k_leaf_wide<false>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
+			}
+		} else if (st->direct && pl.leaf_cap && (!has_r || pr.leaf_cap)) {
 			/* compact narrow form: the leaf's table is indexed by the hash bits the partition left over */
 			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
 			const size_t lds = ((size_t)12 << rem) + 32;
@@ -2087,6 +2314,12 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
+	if ((uint32_t)h[1] & 1024u) {
+		ctx->lw_bad_keys = keys_l;	/* a key with 2^16 or more rows on one side: two levels and their hot-key path, now and for these columns */
+		ctx->lw_bad_nl = n_l;
+		ctx->lw_bad_nr = st->n_r_cap;
+		return GC_RETRY_TWO_LEVEL;
+	}
 	if (((uint32_t)h[1] & 64u) && keyed_cbits) {
 		ctx->keyed_distrust = 64;	/* hot leaves go through kernels that write plain records: redo with those everywhere */
 		return GC_RETRY_UNKEYED;
@@ -2178,7 +2411,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		if (rc)
 			return rc;
 		/* remember whether 4-byte records would do for these columns */
-		ctx->r32_ok = st->direct && has_r && !keyed_cbits && !(status & 16u);
+		ctx->r32_ok = st->direct && !st->one_level && has_r && !keyed_cbits && !(status & 16u);
 		ctx->r32_kl = keys_l;
 		ctx->r32_nl = n_l;
 		ctx->r32_kr = keys_r;
@@ -2203,7 +2436,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (out_joined)
 		*out_joined = joined;
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
-	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0);
+	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0) | (st->one_level ? 0x200 : 0);
 	return MIDORIDB_OK;
 }
 
@@ -2579,8 +2812,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
-		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64)
-			;		/* (gc_finish has set ctx->keyed_distrust / cleared ctx->r32_ok) */
+		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 || rc == GC_RETRY_TWO_LEVEL)
+			;		/* (gc_finish has set ctx->keyed_distrust / cleared ctx->r32_ok / noted the columns in ctx->lw_bad_*) */
 		else if (rc == GC_RETRY_BUILD_L)
 			no_build_r = true;
 		else
@@ -2867,7 +3100,8 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	}
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
-	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64)	/* skew / huge counts / wide keys: redo the whole operator */
+	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 ||
+	    rc == GC_RETRY_TWO_LEVEL)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
 	return rc;

@@ -883,6 +883,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
 #define PART_F_IN32 128u	/* with PART_F_FOLD32: the raw list already holds 4-byte words (nothing to fold) */
 #define PART_F_FOLD32 64u	/* raw 8-byte records are folded into 4-byte words by the first level (two-level fast layout only) */
+#define PART_F_STOP0 256u	/* first level only (histogram-free layout), bits2 = 0: the consumer walks the digits' sub-regions */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
 /* capacity of one leaf region of the FAST form: 1.5 x the average leaf + 1024, rounded up to 64 */
@@ -902,12 +903,13 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const bool dry = cv.dry;
 	const bool stable = flags & PART_F_STABLE;
 	const int nlevels = bits2 > 0 ? 2 : 1;
+	const bool stop0 = (flags & PART_F_STOP0) && nlevels == 1;
 	const uint32_t Rl[2] = { mode == MDB_DIGIT_MOD ? n_dest : (1u << bits1), 1u << bits2 };
 	const uint32_t nt0 = n ? (uint32_t)((n + MDB_TILE - 1) / MDB_TILE) : 1u;
 	/* FAST applies to the second level only, and only while leaf * cap stays a 32-bit index */
 	const uint32_t nleaves_total = nlevels == 2 ? Rl[0] * Rl[1] : Rl[0];
 	const uint32_t fast_cap = cap_override ? cap_override : part_fast_cap(n, nleaves_total);
-	const bool fast = (flags & PART_F_FAST) && !stable && nlevels == 2 && !final_hv_out &&
+	const bool fast = (flags & PART_F_FAST) && !stable && (nlevels == 2 || stop0) && !final_hv_out &&
 			  (uint64_t)nleaves_total * fast_cap < 0xFFFFFFFFull;
 	/* ... and, with it, to the first level: PART_NSUB fixed-capacity sub-regions per digit */
 	const uint32_t nreg0 = Rl[0] * PART_NSUB;
@@ -922,6 +924,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const bool w32 = ((flags & PART_F_NARROW) && fast0 && fast) || fold32;
 	if ((flags & (PART_F_NARROW | PART_F_FOLD32)) && !w32 && !dry)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4-byte partition words need the two-level fast layout");
+	if ((flags & PART_F_STOP0) && !(stop0 && fast0) && !dry)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "first-level-only partition: histogram-free layout, one level");
 
 	uint64_t *hv_buf[2] = { NULL, NULL };
 	uint32_t *rid_buf[2] = { NULL, NULL };
@@ -1002,7 +1006,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			uint32_t *cursor0 = (uint32_t *)cv.take((size_t)nreg0 * 4);
 			uint32_t *reg_nt = (uint32_t *)cv.take(((size_t)nreg0 + 1) * 4);
 			const uint32_t next_tiles = (uint32_t)(n / MDB_TILE) + nreg0 + 1;
-			mdb_tile_desc *next_desc = (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
+			mdb_tile_desc *next_desc = stop0 ? NULL : (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
 			if (cv.failed)
 				return -MIDORIDB_INTERNAL;
 			if (!dry) {
@@ -1028,9 +1032,25 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
-				MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, PART_NSUB, reg_nt);
-				MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
-					   cap0, PART_NSUB, next_desc, next_tiles);
+				if (!stop0) {
+					MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, PART_NSUB, reg_nt);
+					MDB_LAUNCH(ctx, "part_build_tiles", k_part_build_tiles_regions, (next_tiles + 255) / 256, 256, cursor0, reg_nt, nreg0,
+						   cap0, PART_NSUB, next_desc, next_tiles);
+				}
+			}
+			if (stop0) {
+				if (out) {
+					out->hv = hv_buf[0];
+					out->rid = NULL;
+					out->leaf_off = NULL;
+					out->leaf_cnt = cursor0;
+					out->leaf_cap = cap0;
+					out->nleaves = R;
+					out->bits_total = (uint32_t)bits1;
+					out->w32 = w32;
+					out->nsub = PART_NSUB;
+				}
+				return MIDORIDB_OK;
 			}
 			uint32_t real_tiles = next_tiles;
 			if (!dry && flt && flt->range_in && flt->expect_pruned) {
@@ -1159,6 +1179,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		out->nleaves = S;
 		out->bits_total = (uint32_t)used_bits;
 		out->w32 = w32;
+		out->nsub = 0;
 	}
 	return MIDORIDB_OK;
 }
@@ -1167,6 +1188,13 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 {
 	part_carver cv = { NULL, true, 0, false };
 	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
+	return cv.bytes + 4096;
+}
+
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1)
+{
+	part_carver cv = { NULL, true, 0, false };
+	(void)partition_impl(cv, NULL, NULL, n, bits1, 0, false, PART_F_FAST | PART_F_STOP0, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
 	return cv.bytes + 4096;
 }
 
@@ -1184,10 +1212,13 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 			bool want_rid, bool stable, bool fast, mdb_part_result *out, int narrow, bool keys32, int64_t narrow_base,
 			uint32_t narrow_kbits, const mdb_part_filter *flt)
 {
+	const bool stop0 = flt && flt->level0_only;
+	if (stop0 && (!narrow || !narrow_kbits || want_rid || stable || !fast || bits2 != 0 || flt->bits))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "first-level-only partition: compact narrow form, bits2 = 0, no bitmap");
 	if (flt && flt->bits && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || bits2 <= 0 || flt->words < 4 || flt->words > MDB_TILE * 2 ||
 				 (flt->words & (flt->words - 1))))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "semi-join filter: left side of the compact narrow form, two fast levels, slices of 4 ... 8192 words");
-	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || want_rid || stable || !fast || bits2 <= 0 ||
+	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || want_rid || stable || !fast || (bits2 <= 0 && !stop0) ||
 							  (flt->minmax_out && (narrow != 2 || !flt->minmax_tiles))))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning: narrow forms, two fast levels");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
@@ -1204,7 +1235,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device (8-byte for int32 keys)");
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
-				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u),
+				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u) | (stop0 ? PART_F_STOP0 : 0u),
 			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u, flt);
 }
 

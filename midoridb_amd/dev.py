@@ -233,6 +233,10 @@ class DeviceCtx:
         v = int(self.lib.mdb_dev_last_join_filter(self.h))
         return v & 0xFF, bool(v & 0x100)
 
+    def last_join_levels(self):
+        """partition levels of the last join / GROUP BY operator's final attempt: 1 (wide direct-address leaves) or 2"""
+        return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x200 else 2
+
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""
         self._chk(self.lib.mdb_dev_set_narrow_keys(self.h, int(mode)), "set_narrow_keys")

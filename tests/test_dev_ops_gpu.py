@@ -1258,6 +1258,84 @@ def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), info
 
 
+@pytest.mark.parametrize("shape", ["dup16_pruned", "unique_2e22", "nulls_offset", "group_only"])
+def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_leaves(dev, narrow_mode, monkeypatch, shape):
+    """Compact narrow form with a window of 2^20 ... 2^23 key values: ONE 9-bit partition level and k_leaf_wide (tables of
+    2^(k - 9) entries, 16-bit row counts) instead of two levels and k_leaf_direct.  Same groups, counts, first rows and order
+    as the oracle and as the two-level form (MDB_ONE_LEVEL=0)."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 101 + 7)
+    nl = nr = None
+    has_r = True
+    if shape == "dup16_pruned":          # the benchmark's variant D in small: the right table holds the lowest sixteenth
+        n_l = n_r = 6_000_000 + 8192
+        kl = rng.permutation(16 * 5_000_000)[:n_l].astype(np.int64)
+        kr = rng.integers(0, 5_000_000, n_r, dtype=np.int64)
+    elif shape == "unique_2e22":
+        n_l, n_r = 4_000_000, 3_500_000
+        kl = rng.permutation(4_100_000)[:n_l].astype(np.int64)
+        kr = rng.permutation(4_100_000)[:n_r].astype(np.int64)
+    elif shape == "nulls_offset":
+        n_l, n_r = 2_500_000, 1_800_000
+        kl = rng.integers(0, 1_500_000, n_l, dtype=np.int64) - 2**40
+        kr = rng.integers(0, 1_500_000, n_r, dtype=np.int64) - 2**40
+        nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.1
+    else:
+        has_r = False
+        n_l, n_r = 7_000_000, 0
+        kl = rng.integers(0, 3_000_000, n_l, dtype=np.int64) * 2 + 10**12
+        kr = None
+    dl, dnl = dev.to_dev(kl), dev.nullbits_dev(nl)
+    if has_r:
+        ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+        dr, dnr = dev.to_dev(kr), dev.nullbits_dev(nr)
+    else:
+        ef, ec = orc.group_count(kl, nl)
+        ek = ej = None
+    for one_level in ("1", "0", "1"):
+        monkeypatch.setenv("MDB_ONE_LEVEL", one_level)
+        if has_r:
+            k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+            assert dev.last_join_form() == 2, shape
+            assert j == ej, (shape, one_level)
+            assert np.array_equal(_np(k), ek), (shape, one_level)
+        else:
+            f, c = dev.group_count(dl, dnl)
+        assert dev.last_join_levels() == (1 if one_level == "1" else 2), (shape, one_level)
+        assert np.array_equal(_np(c), ec), (shape, one_level)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, one_level)
+
+
+@pytest.mark.parametrize("rows_of_the_key", [65_535, 65_536, 70_000])
+def test_a_row_count_beyond_16_bits_sends_the_wide_direct_leaves_back_to_two_levels(dev, narrow_mode, rows_of_the_key):
+    """k_leaf_wide counts rows per key in 16-bit halves of LDS words.  A key with 2^16 or more rows carries into (or out
+    of) its neighbour; the kernel notices that the sum of the counts falls short of the rows it counted, and the operator is
+    redone with two partition levels.  1.6 * 10^8 rows (so that the one key's rows do not overflow a first-level region
+    before the leaf kernel sees them), plain GROUP BY, checked on the device against torch: COUNT per key, first row per key,
+    first-occurrence order.  65 535 rows still fit."""
+    narrow_mode(1)
+    n, span = 160_000_000, 4_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(rows_of_the_key)
+    kl = torch.randint(0, span, (n,), dtype=torch.int64, device="cuda", generator=g)
+    kl[kl == 777] = 778
+    kl[torch.randperm(n, device="cuda", generator=g)[:rows_of_the_key]] = 777
+    f, c = dev.group_count(kl, None)
+    assert dev.last_join_levels() == (1 if rows_of_the_key < 65_536 else 2)
+    fi = f.to(torch.int64) & 0xFFFFFFFF
+    assert bool((fi[1:] > fi[:-1]).all())
+    keys = kl[fi]
+    uk, uc = torch.unique(kl, return_counts=True)
+    o = torch.argsort(keys)
+    assert torch.equal(keys[o], uk) and torch.equal(c[o], uc)
+    assert int(c[keys == 777]) == rows_of_the_key
+    first = torch.full((span,), n, dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, kl, torch.arange(n, device="cuda"), "amin")
+    assert torch.equal(first[keys], fi)
+    del kl, first, uk, uc, keys, o
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", ["spread", "bunched"])
 def test_few_groups_are_ordered_through_row_id_bitmaps_or_the_general_sort_alike(dev, narrow_mode, monkeypatch, shape):
     """Few group records among many left rows (a selective join) are ordered by k_order_leaf_sparse - leaves of 2^16 row
@@ -1315,7 +1393,9 @@ def test_left_table_pruning_by_the_right_tables_keys_does_not_change_results(dev
     """Compact narrow form, unsplit call: the right table is partitioned first.  Min-max pruning - its first level records
     the exact key range, the left table's first level drops the rows outside - and, for right tables that are small but
     spread over the whole range, the semi-join bitmap at the second level (exact, and one bit per 2 / 4 / 8 adjacent hashed
-    values).  Groups, counts, first rows, order and joined rows equal the oracle's with every combination on and off."""
+    values).  Groups, counts, first rows, order and joined rows equal the oracle's with every combination on and off.  (The
+    bitmap belongs to the two-level form: these 2^22-value windows take ONE partition level unless MDB_ONE_LEVEL=0 - the
+    last combination - where the leaf kernel reads the left rows only once anyway.)"""
     narrow_mode(1)
     rng = np.random.default_rng(len(shape) * 13 + 5)
     # (every shape its own table sizes: the operator remembers what it learned about a column by address and length, and
@@ -1345,15 +1425,17 @@ def test_left_table_pruning_by_the_right_tables_keys_does_not_change_results(dev
     kl, kr = kl + off, kr + off
     ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
     dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
-    for prune, on, slice_bits, expect in ((None, None, None, 1), (None, "1", "13", 2), (None, "1", "12", 3), (None, "1", "11", 4), (None, "1", "9", 0),
-                                          (None, "0", None, 0), ("0", None, None, 0)):
-        for name, val in (("MDB_MINMAX_PRUNE", prune), ("MDB_SEMIJOIN", on), ("MDB_SEMIJOIN_SLICE", slice_bits)):
+    for prune, on, slice_bits, expect, one in ((None, None, None, 1, "0"), (None, "1", "13", 2, "0"), (None, "1", "12", 3, "0"), (None, "1", "11", 4, "0"),
+                                               (None, "1", "9", 0, "0"), (None, "0", None, 0, "0"), ("0", None, None, 0, "0"), (None, None, None, 0, None),
+                                               ("0", None, None, 0, None)):
+        for name, val in (("MDB_MINMAX_PRUNE", prune), ("MDB_SEMIJOIN", on), ("MDB_SEMIJOIN_SLICE", slice_bits), ("MDB_ONE_LEVEL", one)):
             if val is None:
                 monkeypatch.delenv(name, raising=False)
             else:
                 monkeypatch.setenv(name, val)
         k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
         assert dev.last_join_form() == 2, (shape, prune, on, slice_bits)
+        assert dev.last_join_levels() == (2 if one == "0" else 1), (shape, prune, on, slice_bits)
         assert dev.last_join_filter() == ((expect if by_rows else 0) if prune is None else 0, prune is None), (shape, prune, on, slice_bits)
         assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, prune, on, slice_bits)
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, prune, on, slice_bits)
