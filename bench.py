@@ -48,6 +48,9 @@ ROCPROF_NAMES = {
     "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
                               "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
     "leaf_join_direct": ["k_leaf_direct<true, 512, 2048>", "k_leaf_direct<true, 512>"],
+    "leaf_join_wide": ["k_leaf_wide<true>"],
+    "leaf_group_wide": ["k_leaf_wide<false>"],
+    "order_leaf_sparse": ["k_order_leaf_sparse"],
     "leaf_bitmap": ["k_leaf_bitmap"],
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
     # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT> (the last parameter since round 2's semi-join filter)
@@ -90,7 +93,8 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False):
     if pruned:
         t = {"part_scatter_l0_pruned": key + 8 * g,      # every key in, the words of the rows inside the range out
              "part_scatter_l1": 8 * g + 8 * g, "part_scatter_l1_semi": 8 * g + 8 * g,
-             "leaf_join_direct": 8 * g + h32 + 8 * g}
+             "leaf_join_direct": 8 * g + h32 + 8 * g,
+             "leaf_join_wide": 8 * g + h32 + 8 * g}
         if kernel in t:
             return float(t[kernel])
     table = {
@@ -106,6 +110,9 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False):
         "part_hist_l0": key,
         "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
         "leaf_join_direct": key + h32 + 8 * g,
+        "leaf_join_wide": key + h32 + 8 * g,         # one partition level: the first level's words in, one record per group out
+        "leaf_group_wide": key + 8 * g,
+        "order_leaf_sparse": 8 * g + 20 * g,        # keyed records in, (first row, key, COUNT) out
         "leaf_group_count": (key if narrow else key + rid) + 8 * g,
         "sort_hist_l0": 8 * g,
         "sort_scatter_l0": 16 * g,
@@ -493,6 +500,7 @@ def main():
                                     "compact narrow (keys within the sampled 2^k-wide window, verified on the device: k-bit hashes, "
                                     "direct-address leaf tables)"][dev.last_join_form()],
                        "left_table_pruning": {"min_max": bool(dev.last_join_filter()[1]), "bitmap": int(dev.last_join_filter()[0])},
+                       "partition_levels": dev.last_join_levels(),
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
                        "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
                        "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
