@@ -1057,7 +1057,10 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
  * number of adds, which the emit pass checks: status bit 10, the operator is redone with two levels (and their hot-key path).
  * The digit's rows lie in the PART_NSUB sub-regions the first level wrote; they are streamed with four 16-byte loads in
  * flight per thread.  The records of a digit are counted first and appended with one global atomic: the list has no gaps.
- * Variant D: second-level scatters 0.194 + 0.031 ms and leaf 0.133 ms -> see profiles/r02. */
+ * Variant D: second-level scatters 0.194 + 0.031 ms and leaf 0.133 ms -> 0.134 ms.  Ablations (same box): the streams alone,
+ * no LDS atomics, 0.116 ms; every atomic on one of 32 words 0.13; with the loads of the next step in flight while the current
+ * one is counted (unconditional loads, s_waitcnt vmcnt(4..7) instead of 0) 0.143 - not latency: with one workgroup per CU
+ * nothing streams while a workgroup clears its 128 KiB or emits. */
 #define LW_THREADS 1024
 #define LW_MIN_REM 11u		/* one 32-bit word of halves per thread */
 #define LW_MAX_REM 14u
