@@ -54,6 +54,8 @@ struct mdb_dev_ctx {
 	int gh_uses;
 	int sr_uses, nh_uses;		/* remembered verdicts expire after a few uses: the same buffer may hold other data by then */
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
+	const void *pw_bad_keys;	/* right key column (and row count) the one-level unique-key join (join_pairs_unique_wide) gave up on */
+	uint64_t pw_bad_n;
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
 	uint64_t pu_dup_n;
 	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */

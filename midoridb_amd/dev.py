@@ -343,22 +343,12 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_join_pairs(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), _ptr(keys_r), _ptr(null_r),
                                               keys_r.numel(), byref(pl), byref(pr), byref(cnt)), "join_pairs")
         J = cnt.value
-        ol = torch.empty(J, dtype=torch.int32, device=self.device)
-        orr = torch.empty(J, dtype=torch.int32, device=self.device)
-        if J:
-            # device-to-device copies out of the library-owned buffers, then release them
-            self._d2d(ol, pl, J * 4)
-            self._d2d(orr, pr, J * 4)
-            self.sync()
-        self._chk(self.lib.mdb_dev_free(self.h, pl), "free")
-        self._chk(self.lib.mdb_dev_free(self.h, pr), "free")
-        return ol, orr
-
-    def _d2d(self, dst_tensor, src_ptr, nbytes):
-        # identity gather through the library keeps everything on the context's stream
-        n32 = nbytes // 4
-        idx = torch.arange(n32, dtype=torch.int32, device=self.device)
-        self._chk(self.lib.mdb_dev_gather32(self.h, src_ptr, _ptr(idx), n32, _ptr(dst_tensor)), "gather32")
+        if not J:
+            self._chk(self.lib.mdb_dev_free(self.h, pl), "free")
+            self._chk(self.lib.mdb_dev_free(self.h, pr), "free")
+            return (torch.empty(0, dtype=torch.int32, device=self.device), torch.empty(0, dtype=torch.int32, device=self.device))
+        # tensors over the library's own buffers (no copy); they go back to its allocator when the tensors are collected
+        return self._adopt(pl, J, torch.int32), self._adopt(pr, J, torch.int32)
 
     def cross_pairs(self, n_l, n_r):
         ol = torch.empty(n_l * n_r, dtype=torch.int32, device=self.device)

@@ -1690,6 +1690,51 @@ def test_join_pairs_unique_left_keys_duplicate_right_keys(dev, narrow_mode, mode
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
 
 
+@pytest.mark.parametrize("shape", ["perm_both", "subset_nulls", "offset_2e24", "fk_to_pk", "one_duplicate_right_key", "unsampled_key_outside"])
+def test_join_pairs_unique_keys_in_a_window_up_to_2e24_take_one_partition_level(dev, narrow_mode, monkeypatch, shape):
+    """Unique right keys inside a compact window of at most 2^24 values (BASELINE configs[1]'s primary-key join): one 9-bit
+    partition level per table, a direct-address LDS table of right row ids per digit, the partner written to match[left row],
+    the pairs compacted out of match[] in left-row order.  Same pairs, same order as the oracle and as the two-level path
+    (MDB_ONE_LEVEL=0); a duplicated right key (noticed: fewer occupied entries than right rows) and a key outside the
+    sampled window (noticed by the first partition level) go through the other paths."""
+    narrow_mode(1)
+    rng = np.random.default_rng(len(shape) * 31 + 3)
+    nl = nr = None
+    if shape == "perm_both":
+        n_l, n_r = 3_000_000, 3_000_000
+        kl = rng.permutation(n_l).astype(np.int64)
+        kr = rng.permutation(n_r).astype(np.int64)
+    elif shape == "subset_nulls":
+        n_l, n_r = 2_200_000, 1_300_000
+        kl = rng.integers(0, 4_000_000, n_l, dtype=np.int64)
+        kr = rng.permutation(4_000_000)[:n_r].astype(np.int64)
+        nl, nr = rng.random(n_l) < 0.03, rng.random(n_r) < 0.05
+    elif shape == "offset_2e24":
+        n_l, n_r = 5_000_000, 9_000_000
+        kl = rng.integers(0, 16_000_000, n_l, dtype=np.int64) - 2**44
+        kr = rng.permutation(16_000_000)[:n_r].astype(np.int64) - 2**44
+    elif shape == "fk_to_pk":           # unique on the LEFT: the sides are swapped, then a stable sort
+        n_l, n_r = 1_500_000, 4_000_000
+        kl = rng.permutation(2_000_000)[:n_l].astype(np.int64)
+        kr = rng.integers(0, 2_000_000, n_r, dtype=np.int64)
+    elif shape == "one_duplicate_right_key":
+        n_l, n_r = 2_000_000, 2_000_001
+        kl = rng.integers(0, 2_000_000, n_l, dtype=np.int64)
+        kr = np.concatenate([rng.permutation(2_000_000), [777]]).astype(np.int64)
+    else:
+        n_l, n_r = 2_500_000, 2_500_000
+        kl = rng.permutation(n_l).astype(np.int64)
+        kr = rng.permutation(n_r).astype(np.int64)
+        kl[1_234_567] = 2**40          # (one row in 2.5 * 10^6: the 4096-key sample does not see it)
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    dl, dnl, dr, dnr = dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr)
+    for one_level in ("1", "0", "1"):
+        monkeypatch.setenv("MDB_ONE_LEVEL", one_level)
+        l, r = dev.join_pairs(dl, dnl, dr, dnr)
+        assert l.numel() == len(el), (shape, one_level)
+        assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er), (shape, one_level)
+
+
 @pytest.mark.parametrize("shape", ["hundred", "one_key", "disjoint", "outlier_left", "outlier_right", "nulls", "offset", "span_too_wide"])
 def test_join_group_count_over_a_small_value_range(dev, shape):
     """Join + GROUP BY join key + COUNT(*) whose key columns both lie in one window of at most 4096 values (joins on a few
