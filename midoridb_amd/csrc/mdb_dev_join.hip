@@ -4208,7 +4208,9 @@ static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint
  * left row reads its entry and writes the partner to match[left row id]: a random 4-byte write, but into an array of 4 n_L
  * bytes that the Infinity Cache holds (the path is taken up to 2^25 left rows).  The pairs in the reference's order - left
  * row ascending - are then the non-zero entries of match[] in index order: a count / scan / emit compaction instead of a
- * sort. */
+ * sort.  (The scatter is what the kernel's time is made of: 0.16 ms per 10^7 x 10^7 rows where the two streams need 0.06;
+ * non-temporal stores took 0.33 - the L2s merge the writes of neighbouring rows, which a digit's sub-regions deliver in
+ * roughly ascending order.) */
 #define PW_THREADS 1024
 #define PW_MIN_REM 10u
 #define PW_MAX_REM 15u
