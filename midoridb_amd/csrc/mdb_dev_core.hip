@@ -761,9 +761,48 @@ struct gather_cols_args {
 
 #define GC_ROUNDS 4	/* 256 x 4 = 1024 consecutive outputs per block: up to 4 x 16 gathers in flight per thread */
 
+/* NR = row-id vectors loaded per output row (the host rounds a.nrids up to 1, 2, 4 or 8 and lets the unused slots alias
+ * rid[0]).  A block whose outputs all exist loads its row ids, and then every column's GC_ROUNDS gathers, TOGETHER: behind
+ * "k < n" every load sits in a branch of its own, the compiler waits for it before the next one is issued, and a thread has
+ * one gather in flight. */
+template <int NR>
 __global__ __launch_bounds__(STREAM_THREADS) void k_gather_cols(gather_cols_args a)
 {
 	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * GC_ROUNDS);
+	if (NR > 0 && base + (uint64_t)STREAM_THREADS * GC_ROUNDS <= a.n) {	/* (uniform) */
+		uint32_t row[GC_ROUNDS][NR > 0 ? NR : 1];
+#pragma unroll
+		for (int r = 0; r < GC_ROUNDS; r++)
+#pragma unroll
+			for (int t = 0; t < NR; t++)
+				row[r][t] = a.rid[t][base + (uint64_t)r * STREAM_THREADS + threadIdx.x];
+		for (int c = 0; c < a.ncols; c++) {
+			const uint32_t slot = a.slot[c];
+			uint64_t v[GC_ROUNDS], src_row[GC_ROUNDS];
+#pragma unroll
+			for (int r = 0; r < GC_ROUNDS; r++) {
+				src_row[r] = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+#pragma unroll
+				for (int t = 0; t < NR; t++)
+					if (slot == (uint32_t)t)
+						src_row[r] = row[r][t];
+				v[r] = a.src[c][src_row[r]];
+			}
+#pragma unroll
+			for (int r = 0; r < GC_ROUNDS; r++)
+				a.dst[c][base + (uint64_t)r * STREAM_THREADS + threadIdx.x] = v[r];
+			if (a.dst_null[c]) {
+#pragma unroll
+				for (int r = 0; r < GC_ROUNDS; r++) {
+					const bool isnull = a.src_null[c] && mdb_bit_is_set(a.src_null[c], src_row[r]);
+					const uint64_t m = __ballot(isnull);
+					if (mdb_lane() == 0)
+						a.dst_null[c][(base + (uint64_t)r * STREAM_THREADS + threadIdx.x) >> 6] = m;
+				}
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int r = 0; r < GC_ROUNDS; r++) {
 		/* one wave covers 64 consecutive outputs per round => one NULL word per wave, round and column */
@@ -827,7 +866,19 @@ extern "C" int mdb_dev_gather_cols(mdb_dev_ctx *ctx, const struct mdb_gather_col
 		}
 	}
 	const uint32_t grid = (uint32_t)((n + (uint64_t)STREAM_THREADS * GC_ROUNDS - 1) / ((uint64_t)STREAM_THREADS * GC_ROUNDS));
-	MDB_LAUNCH(ctx, "gather_cols", k_gather_cols, grid, STREAM_THREADS, a);
+	for (int t = a.nrids; t < MDB_GATHER_MAX_RIDS; t++)
+		a.rid[t] = a.rid[0];	/* (the kernel instance may load more slots than are used) */
+	if (a.nrids == 0) {
+		MDB_LAUNCH(ctx, "gather_cols", k_gather_cols<0>, grid, STREAM_THREADS, a);
+	} else if (a.nrids == 1) {
+		MDB_LAUNCH(ctx, "gather_cols", k_gather_cols<1>, grid, STREAM_THREADS, a);
+	} else if (a.nrids == 2) {
+		MDB_LAUNCH(ctx, "gather_cols", k_gather_cols<2>, grid, STREAM_THREADS, a);
+	} else if (a.nrids <= 4) {
+		MDB_LAUNCH(ctx, "gather_cols", k_gather_cols<4>, grid, STREAM_THREADS, a);
+	} else {
+		MDB_LAUNCH(ctx, "gather_cols", k_gather_cols<8>, grid, STREAM_THREADS, a);
+	}
 	return MIDORIDB_OK;
 }
 

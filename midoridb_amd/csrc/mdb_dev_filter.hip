@@ -509,14 +509,22 @@ __device__ static inline void scan_project_body(const int64_t *__restrict__ vals
 	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
 	const uint64_t word0 = ((uint64_t)bid * SP_WAVES + wave) * (2 * SPANS);
 	longlong2 q[SPANS];
+	/* a workgroup whose rows all exist issues its loads together; behind the per-row range tests every load sits in a branch
+	 * of its own and the compiler waits for it (s_waitcnt vmcnt(0)) before it issues the next: one load in flight per thread */
+	if (((((uint64_t)bid + 1) * SP_WAVES * (2 * SPANS)) << 6) <= n) {	/* (uniform) */
 #pragma unroll
-	for (int u = 0; u < SPANS; u++) {
-		const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
-		q[u] = make_longlong2(0, 0);
-		if (k0 + 1 < n)
-			q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
-		else if (k0 < n)
-			q[u].x = vals[k0];
+		for (int u = 0; u < SPANS; u++)
+			q[u] = *reinterpret_cast<const longlong2 *>(vals + (((word0 + 2 * u) << 6) + 2ull * lane));
+	} else {
+#pragma unroll
+		for (int u = 0; u < SPANS; u++) {
+			const uint64_t k0 = ((word0 + 2 * u) << 6) + 2ull * lane;
+			q[u] = make_longlong2(0, 0);
+			if (k0 + 1 < n)
+				q[u] = *reinterpret_cast<const longlong2 *>(vals + k0);
+			else if (k0 < n)
+				q[u].x = vals[k0];
+		}
 	}
 	/* the predicate is evaluated ONCE per row; a lane keeps its 2 x SPANS verdicts as bits of one register (sixteen 64-bit
 	 * ballot masks kept beside the rows cost 150 registers - two thirds of the occupancy -, evaluating again for the count and

@@ -4311,15 +4311,25 @@ __global__ __launch_bounds__(MC_THREADS) void k_match_count(const uint32_t *__re
 {
 	__shared__ uint32_t s_tmp[32];
 	uint32_t c = 0;
+	if ((uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n) {	/* (uniform) a full block: its loads are issued together */
+		uint4 v[MC_PER_THREAD / 4];
 #pragma unroll
-	for (int q = 0; q < MC_PER_THREAD / 4; q++) {
-		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
-		if (i + 3 < n) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(match + i);
-			c += (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
-		} else {
-			for (uint32_t k = i; k < n && k < i + 4; k++)
-				c += match[k] != 0u;
+		for (int q = 0; q < MC_PER_THREAD / 4; q++)
+			v[q] = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++)
+			c += (v[q].x != 0u) + (v[q].y != 0u) + (v[q].z != 0u) + (v[q].w != 0u);
+	} else {
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+			const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
+			if (i + 3 < n) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(match + i);
+				c += (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
+			} else {
+				for (uint32_t k = i; k < n && k < i + 4; k++)
+					c += match[k] != 0u;
+			}
 		}
 	}
 	uint32_t total;
@@ -4339,8 +4349,19 @@ __global__ __launch_bounds__(MC_THREADS) void k_match_emit(const uint32_t *__res
 	__shared__ uint32_t s_l[MC_BLOCK], s_r[MC_BLOCK];
 	uint32_t m[MC_PER_THREAD];
 	uint32_t run = 0;
+	const bool full = (uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n;	/* (uniform) */
+	if (full) {
 #pragma unroll
-	for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
+			m[4 * q] = v.x;
+			m[4 * q + 1] = v.y;
+			m[4 * q + 2] = v.z;
+			m[4 * q + 3] = v.w;
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < MC_PER_THREAD / 4 && !full; q++) {
 		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
 		uint4 v = make_uint4(0u, 0u, 0u, 0u);
 		if (i + 3 < n) {
