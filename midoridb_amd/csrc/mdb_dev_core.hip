@@ -669,6 +669,28 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_gather64(const uint64_t *__r
 							     uint64_t *__restrict__ dst, uint64_t *__restrict__ dst_null)
 {
 	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+	if (idx && base + (uint64_t)STREAM_THREADS * STREAM_ROUNDS <= n) {	/* (uniform) a full block: row ids, then gathers, issued together */
+		uint32_t row[STREAM_ROUNDS];
+		uint64_t v[STREAM_ROUNDS];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			row[r] = idx[base + (uint64_t)r * STREAM_THREADS + threadIdx.x];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			v[r] = src[row[r]];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			dst[base + (uint64_t)r * STREAM_THREADS + threadIdx.x] = v[r];
+		if (dst_null) {
+#pragma unroll
+			for (int r = 0; r < STREAM_ROUNDS; r++) {
+				const uint64_t m = __ballot(src_null && mdb_bit_is_set(src_null, row[r]));
+				if (mdb_lane() == 0)
+					dst_null[(base + (uint64_t)r * STREAM_THREADS + threadIdx.x) >> 6] = m;
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int r = 0; r < STREAM_ROUNDS; r++) {
 		/* one wave covers 64 consecutive outputs per round => one NULL word per wave per round */
@@ -696,6 +718,19 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_gather32(const uint32_t *__r
 							     uint32_t *__restrict__ dst)
 {
 	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+	if (base + (uint64_t)STREAM_THREADS * STREAM_ROUNDS <= n) {	/* (uniform) a full block: row ids, then gathers, issued together */
+		uint32_t row[STREAM_ROUNDS], v[STREAM_ROUNDS];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			row[r] = idx[base + (uint64_t)r * STREAM_THREADS + threadIdx.x];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			v[r] = src[row[r]];
+#pragma unroll
+		for (int r = 0; r < STREAM_ROUNDS; r++)
+			dst[base + (uint64_t)r * STREAM_THREADS + threadIdx.x] = v[r];
+		return;
+	}
 #pragma unroll
 	for (int r = 0; r < STREAM_ROUNDS; r++) {
 		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;

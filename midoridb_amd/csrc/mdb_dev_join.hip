@@ -1676,7 +1676,12 @@ __global__ __launch_bounds__(OS_THREADS) void k_order_leaf_sparse(ord_args a)
 #pragma unroll
 	for (int k = 0; k < OS_PER_THREAD; k++) {
 		const uint32_t i = b + threadIdx.x + (uint32_t)k * OS_THREADS;
-		r[k] = i < e ? a.rec[i] : 0ull;
+		r[k] = a.rec[i < e ? i : b];	/* (unconditional loads - issued together; past the end: the first record, dropped) */
+	}
+#pragma unroll
+	for (int k = 0; k < OS_PER_THREAD; k++) {
+		const uint32_t i = b + threadIdx.x + (uint32_t)k * OS_THREADS;
+		r[k] = i < e ? r[k] : 0ull;
 		if (r[k]) {
 			const uint32_t idx = (uint32_t)(r[k] >> (64 - a.kbits)) & (range - 1);
 			atomicOr(&s_bits[idx >> 5], 1u << (idx & 31u));
