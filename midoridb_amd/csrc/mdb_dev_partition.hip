@@ -321,12 +321,19 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
 	for (uint32_t d = threadIdx.x; d < a.R; d += PART_THREADS)
 		s_h[d] = 0;
 	__syncthreads();
+	const bool full = td.len == MDB_TILE && !(td.start & 1u) && !(LEVEL0 && a.keys32);	/* (uniform) the tile's loads are issued together */
+	ulonglong2 pre[PART_ITEMS / 2];
+	if (full)
+		part_preload2<LEVEL0, PART_ITEMS / 2>(a, td, pre);
 #pragma unroll
 	for (int r = 0; r < PART_ITEMS / 2; r++) {
 		uint64_t hv[2];
 		uint32_t rid[2];
 		bool valid[2];
-		part_load2<LEVEL0, false, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid);
+		if (full)
+			part_load2<LEVEL0, false, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid, nullptr, &pre[r]);
+		else
+			part_load2<LEVEL0, false, RAW>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, hv, rid, valid);
 		if (LEVEL0 && a.R <= PART_FEW_DIGITS) {	/* few destinations: one add per wave and digit (see k_part_scatter) */
 			for (int k = 0; k < 2; k++) {
 				const uint32_t dg = valid[k] ? part_digit(a, hv[k]) : PART_INVALID;
