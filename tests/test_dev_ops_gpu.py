@@ -243,6 +243,32 @@ def test_gather64_with_nulls(dev):
     assert np.array_equal(_np(out2), src)
 
 
+@pytest.mark.parametrize("nrids", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("n", [1000, 1024, 4096, 70_001])
+def test_gather_cols_every_row_id_count_full_and_partial_blocks(dev, nrids, n):
+    """mdb_dev_gather_cols has kernel instances that load 1, 2, 4 or 8 row-id vectors per output row; blocks of 1024 outputs
+    that all exist issue their loads together, the last (partial) block keeps the per-row range tests.  Every column equals
+    the oracle's gather, NULL bits included, with each number of row-id vectors and with full / partial / no full blocks."""
+    rng = np.random.default_rng(nrids * 1000 + n)
+    m = 50_000
+    rids = [rng.integers(0, m, n, dtype=np.int64).astype(np.int32) for _ in range(nrids)]
+    d_rids = [dev.to_dev(r) for r in rids]
+    cols, want = [], []
+    for c in range(nrids + 1):              # one column per row-id vector + one identity column
+        src = rng.integers(-2**62, 2**62, max(m, n), dtype=np.int64)
+        nulls = rng.random(max(m, n)) < 0.2 if c % 2 == 0 else None
+        rid = rids[c] if c < nrids else None
+        cols.append((dev.to_dev(src), dev.nullbits_dev(nulls), d_rids[c] if c < nrids else None))
+        idx = rid.astype(np.int64) if rid is not None else np.arange(n)
+        want.append((src[idx], None if nulls is None else nulls[idx]))
+    got = dev.gather_cols(cols, n)
+    for c, ((v, nb), (ev, en)) in enumerate(zip(got, want)):
+        assert np.array_equal(_np(v), ev), (nrids, n, c)
+        assert (nb is None) == (en is None), (nrids, n, c)
+        if en is not None:
+            assert np.array_equal(D.unpack_nullbits(_np(nb).view(np.uint64), n), en), (nrids, n, c)
+
+
 def test_gather_cols_whole_projection_in_one_launch(dev):
     """mdb_dev_gather_cols: 16 columns over 3 row-id vectors (and identity) in one launch = 16 separate gather64 calls."""
     rng = np.random.default_rng(12)
