@@ -5,6 +5,7 @@ Every call goes through the C-ABI of libmidoridb_amd.so; results must be bit-exa
 two partition levels (> 393 216 build rows), ragged tails, NULLs, duplicates (N:M), keys
 that are negative / zero (the key whose hash is 0 has a dedicated slot), and skew.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -1253,7 +1254,7 @@ def test_join_group_count_8e8_rows_per_table_on_one_gpu(dev, narrow_mode):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDB_FUZZ_SEEDS", "24"))))	# (MDB_FUZZ_SEEDS=300: the soak run of tests/soak/README.md)
 def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_mode, seed):
     """Randomised shapes through whatever form and pruning path the operator picks for them (compact / plain narrow / wide,
     min-max pruning, bitmap, keyed records, their retries): table sizes from 3 * 10^5 to 3 * 10^6 rows, key ranges from dense
