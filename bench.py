@@ -48,20 +48,21 @@ ROCPROF_NAMES = {
     "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
                               "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
     "leaf_join_direct": ["k_leaf_direct<true, 512, 2048>", "k_leaf_direct<true, 512>"],
-    "leaf_join_wide": ["k_leaf_wide<true>"],
-    "leaf_group_wide": ["k_leaf_wide<false>"],
+    "leaf_join_wide": ["k_leaf_wide<true, true>", "k_leaf_wide<true, false>", "k_leaf_wide<true>"],
+    "leaf_group_wide": ["k_leaf_wide<false, false>", "k_leaf_wide<false>"],
     "order_leaf_sparse": ["k_order_leaf_sparse"],
     "leaf_bitmap": ["k_leaf_bitmap"],
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
-    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT> (the last parameter since round 2's semi-join filter)
-    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
-    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false>"],
-    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
-    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
-    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true>"],
-    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
-    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
+    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT, OUT16> (FILT since round 2's semi-join filter, OUT16 since the 2-byte
+    # first-level words of the one-level form; the profiles of earlier commits carry the shorter names)
+    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
+    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>"],
+    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
+    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
+    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
+    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true, false>", "k_part_scatter<false, false, false, true, false, false, false, true>"],
+    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
+    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
 }
@@ -84,12 +85,16 @@ def pmc_traffic(kernel):
     return None
 
 
-def algorithmic_bytes(kernel, n, groups, narrow, pruned=False):
+def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2):
     """Algorithmic HBM bytes of ONE launch of `kernel` on a table of n rows (G = `groups` result groups):
     what the launch must read once and write once.  Kernel names are template instances, one table each.
     pruned: min-max pruning ran - the left table's first level wrote only the rows inside the right table's key range, and the
     kernels after it see those rows only (one left row per group in both benchmark variants: 8 G bytes)."""
     key, rid, h32, g = 8 * n, 4 * n, 4 * n, groups
+    if levels == 1:         # one partition level: the right table travels as 2-byte words (the hash bits below the first level's digit)
+        t = {"part_scatter_l0_w32": key + 2 * n, "leaf_join_wide": (8 * g if pruned else key) + 2 * n + 8 * g}
+        if kernel in t:
+            return float(t[kernel])
     if pruned:
         t = {"part_scatter_l0_pruned": key + 8 * g,      # every key in, the words of the rows inside the range out
              "part_scatter_l1": 8 * g + 8 * g, "part_scatter_l1_semi": 8 * g + 8 * g,
@@ -465,17 +470,18 @@ def main():
     if rank == 0:
         narrow = dev.last_join_narrow()
         pruned = dev.last_join_filter()[1]
+        levels = 1 if (dev.last_join_levels() == 1 and os.environ.get("MDB_WORDS16", "1") != "0") else 2
         g_rank = groups_total / max(world, 1)
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
         for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
             if d["ms_per_step"] > 0:
-                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow, pruned) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
+                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow, pruned, levels) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
 
         def roof_of(name):
             d = kern[name]
             launches = max(d["launches_per_step"], 1e-9)
             avg_ms = d["ms_per_step"] / launches
-            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow, pruned)
+            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow, pruned, levels)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             tr = pmc_traffic(name) if (n == 100_000_000 and args.variant == "D" and world == 1) else None
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -35,6 +35,7 @@ struct mdb_part_result {
 	uint32_t nleaves;
 	uint32_t bits_total;
 	bool w32;		/* hv holds 4-byte words (narrow form without row ids) */
+	bool w16;		/* ... 2-byte words: the hash bits below the first level's digit (mdb_part_filter.out16) */
 	uint32_t nsub;		/* != 0: first level only (mdb_part_filter.level0_only) - nleaves = 2^bits1 digits, digit d's rows lie in nsub
 				 * regions: region r = d * nsub + s at [r * leaf_cap, r * leaf_cap + min(count, leaf_cap)), its count at
 				 * leaf_cnt[s * nleaves + d] */
@@ -72,6 +73,8 @@ struct mdb_part_filter {
 	int64_t keep_lo, keep_hi;
 	bool own_on;		/* ... and verify that every key of THIS table lies in [own_lo, own_hi] (a promised range: status bit 10 otherwise) */
 	int64_t own_lo, own_hi;
+	bool out16;		/* with level0_only, right side of the compact narrow form: 2-byte words (mdb_part_result.w16) when the hash bits
+				 * below the digit fit 16 bits */
 	bool level0_only;	/* stop after the histogram-free first level (bits2 = 0): the consumer reads the digits' sub-regions itself
 				 * (mdb_part_result.nsub; k_leaf_wide in mdb_dev_join.hip) */
 	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then

@@ -1082,7 +1082,7 @@ __device__ static inline unsigned long long lw_block_sum(unsigned long long v, u
 	return t;
 }
 
-template <bool HAS_R>
+template <bool HAS_R, bool R16 = false /* the right table's words are 2 bytes: the hash bits below the digit (mdb_part_result.w16) */>
 __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t rem, uint32_t shift, uint32_t nsub)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
@@ -1100,7 +1100,36 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 	__syncthreads();
 
 	uint32_t rows_r = 0;
-	if (HAS_R) {
+	if (HAS_R && R16) {
+		const uint16_t *const hv_r16 = reinterpret_cast<const uint16_t *>(a.hv_r);
+		for (uint32_t sub = 0; sub < nsub; sub++) {
+			const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
+			const uint16_t *const src = hv_r16 + (size_t)(leaf * nsub + sub) * a.cap_r;
+			rows_r += c;
+			for (uint32_t j0 = 0; j0 < c; j0 += 8u * LW_THREADS * LW_UNROLL) {	/* uniform trip count */
+				uint4 v[LW_UNROLL];
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					v[u] = make_uint4(0u, 0u, 0u, 0u);
+					if (j < c)
+						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+				}
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+					for (int k = 0; k < 8; k++)
+						if (j + k < c) {
+							const uint32_t idx = (w[k >> 1] >> (16 * (k & 1))) & mask;
+							atomicAdd(&s_cr[idx >> 1], 1u << ((idx & 1u) * 16u));
+						}
+				}
+			}
+		}
+		__syncthreads();
+	} else if (HAS_R) {
 		const uint32_t *const hv_r32 = reinterpret_cast<const uint32_t *>(a.hv_r);
 		for (uint32_t sub = 0; sub < nsub; sub++) {
 			const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
@@ -2139,6 +2168,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		mdb_part_filter rflt;
 		memset(&rflt, 0, sizeof(rflt));
 		rflt.level0_only = st->one_level;
+		rflt.out16 = st->one_level && !(getenv("MDB_WORDS16") && getenv("MDB_WORDS16")[0] == '0');
 		if (st->defer_l) {
 			/* [16] smallest, [17] largest key - window base of the right table (min-max pruning) */
 			rflt.minmax_out = ctx->d_status + GC_ST_MINMAX;
@@ -2268,7 +2298,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level direct leaves: the tables are not in the first-level layout");
 			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
 			const size_t lds = ((size_t)(has_r ? 8 : 6) << rem);
-			if (has_r) {
+			if (has_r && pr.w16) {
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				MDB_LAUNCH_LDS(ctx, "leaf_join_wide", (k_leaf_wide<true, true>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
+			} else if (has_r) {
 				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 				MDB_LAUNCH_LDS(ctx, "leaf_join_wide", (k_leaf_wide<true>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
 			} else {

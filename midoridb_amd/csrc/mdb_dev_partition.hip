@@ -103,6 +103,8 @@ struct mdb_level_args {
 	int64_t keep_lo, keep_hi;
 	uint32_t own_on;		/* every key of this table was promised to lie in [own_lo, own_hi]: one that does not raises status bit 10 */
 	int64_t own_lo, own_hi;
+	uint32_t out16_shift;		/* OUT16 instance (first level only, compact narrow form, 4-byte words): what is WRITTEN is the 16-bit word
+					 * (uint16_t)(hash32 >> out16_shift) - the hash bits below the digit, all the one-level leaf kernel needs */
 	uint32_t fold64;		/* raw 4-byte words: the input is still the list of 8-byte records, folded on the fly (record >> 32 | low
 					 * half: the caller knows that the two parts do not overlap) */
 };
@@ -367,9 +369,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false, bool FILT = false>
+template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false, bool FILT = false,
+	  bool OUT16 = false /* 2-byte words out (see mdb_level_args.out16_shift) */>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	static_assert(!OUT16 || (LEVEL0 && W32 && !RAW), "2-byte words: first level of the 4-byte form only");
 	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
 	/* INV (destination partition for the exchange): what is staged and written is the KEY, not its hash - the digit is
 	 * taken from the hash once, at load time, and found again at write-out from the staged position (the tile-local
@@ -695,7 +699,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
 		const uint32_t g = (uint32_t)((int32_t)i + s_delta[d]);
 		gpos[k] = g;
-		if (W32)
+		if (W32 && OUT16)
+			reinterpret_cast<uint16_t *>(a.hv_out)[g] = (uint16_t)((uint32_t)h >> a.out16_shift);
+		else if (W32)
 			reinterpret_cast<uint32_t *>(a.hv_out)[g] = (uint32_t)h;
 		else if (INV && a.inverse_out == 2) {
 			if (((uint64_t)h + 0x80000000ull) >> 32)
@@ -937,6 +943,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
 #define PART_F_IN32 128u	/* with PART_F_FOLD32: the raw list already holds 4-byte words (nothing to fold) */
 #define PART_F_FOLD32 64u	/* raw 8-byte records are folded into 4-byte words by the first level (two-level fast layout only) */
+#define PART_F_OUT16 512u	/* with PART_F_STOP0 and 4-byte words: the first level writes 2-byte words (hash bits below the digit) */
 #define PART_F_STOP0 256u	/* first level only (histogram-free layout), bits2 = 0: the consumer walks the digits' sub-regions */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
 
@@ -958,6 +965,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	const bool stable = flags & PART_F_STABLE;
 	const int nlevels = bits2 > 0 ? 2 : 1;
 	const bool stop0 = (flags & PART_F_STOP0) && nlevels == 1;
+	const bool out16 = stop0 && (flags & PART_F_OUT16) && (flags & PART_F_NARROW) && narrow_kbits && narrow_kbits - (uint32_t)bits1 <= 16u;
 	const uint32_t Rl[2] = { mode == MDB_DIGIT_MOD ? n_dest : (1u << bits1), 1u << bits2 };
 	const uint32_t nt0 = n ? (uint32_t)((n + MDB_TILE - 1) / MDB_TILE) : 1u;
 	/* FAST applies to the second level only, and only while leaf * cap stays a 32-bit index */
@@ -1076,7 +1084,13 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else if (w32) {
 					if (a.minmax_out)
 						MDB_HIP(ctx, hipMemsetAsync(a.minmax_out, 0xFF, (size_t)grid8(ntiles) * 8, ctx->stream));
-					MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					if (out16) {
+						a.out16_shift = 32u - narrow_kbits;
+						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true>), grid8(ntiles),
+							   PART_THREADS, a);
+					} else {
+						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					}
 					if (a.minmax_out)
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
 				} else if (want_rid) {
@@ -1102,6 +1116,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					out->nleaves = R;
 					out->bits_total = (uint32_t)bits1;
 					out->w32 = w32;
+					out->w16 = out16 && w32;
 					out->nsub = PART_NSUB;
 				}
 				return MIDORIDB_OK;
@@ -1233,6 +1248,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		out->nleaves = S;
 		out->bits_total = (uint32_t)used_bits;
 		out->w32 = w32;
+		out->w16 = false;
 		out->nsub = 0;
 	}
 	return MIDORIDB_OK;
@@ -1289,7 +1305,8 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "key columns must be 16-byte aligned on the device (8-byte for int32 keys)");
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
-				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u) | (stop0 ? PART_F_STOP0 : 0u),
+				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u) | (stop0 ? PART_F_STOP0 : 0u) |
+					      (stop0 && flt->out16 ? PART_F_OUT16 : 0u),
 			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u, flt);
 }
 
