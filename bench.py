@@ -53,16 +53,17 @@ ROCPROF_NAMES = {
     "order_leaf_sparse": ["k_order_leaf_sparse"],
     "leaf_bitmap": ["k_leaf_bitmap"],
     "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
-    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT, OUT16> (FILT since round 2's semi-join filter, OUT16 since the 2-byte
-    # first-level words of the one-level form; the profiles of earlier commits carry the shorter names)
-    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
-    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>"],
-    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
-    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
-    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true, false>", "k_part_scatter<false, false, false, true, false, false, false, true>"],
-    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
-    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
+    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT, OUT16, CF> (FILT since round 2's semi-join filter, OUT16 since the
+    # 2-byte first-level words of the one-level form, CF since the compile-time compact form; the profiles of earlier commits carry the
+    # shorter names)
+    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false, false, true>", "k_part_scatter<true, false, false, true, false, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
+    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false, false, true>", "k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>"],
+    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false, true, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, true, false>", "k_part_scatter<true, false, false, true, false, true, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
+    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
+    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
+    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true, false, false>", "k_part_scatter<false, false, false, true, false, false, false, true, false>", "k_part_scatter<false, false, false, true, false, false, false, true>"],
+    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
+    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
     "order_leaf": ["k_order_leaf"],
     "gather64": ["k_gather64"],
 }

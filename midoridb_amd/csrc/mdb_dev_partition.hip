@@ -110,8 +110,20 @@ struct mdb_level_args {
 };
 
 /* level-0 word of one key */
+/* CF: the compact narrow form of an int64 column, known at COMPILE time (RIDW: the word's low half is the row id, else the
+ * hash once more).  The generic body below picks the form per row from run-time fields - uniform branches and selects that
+ * made the first-level kernels issue-bound (75 vector + 40 scalar instructions per row, profiles/r02). */
+template <bool CF = false, bool RIDW = false>
 __device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_t key, uint32_t rid, bool *bad, uint64_t *rel = nullptr)
 {
+	if (CF) {
+		key -= (uint64_t)a.narrow_base;
+		if (rel)
+			*rel = key;
+		*bad = *bad || (key >> a.narrow_kbits);
+		const uint32_t h = mdb_mixk((uint32_t)key, a.narrow_kbits) << (32u - a.narrow_kbits);
+		return ((uint64_t)h << 32) | (RIDW ? rid : h);
+	}
 	if (!a.narrow)
 		return mdb_fmix64(key);
 	key -= (uint64_t)a.narrow_base;		/* (wraps: the tests below are on the 64-bit difference) */
@@ -128,10 +140,10 @@ __device__ static inline uint64_t part_hash_key(const mdb_level_args &a, uint64_
 	return ((uint64_t)h << 32) | (a.narrow == 1 ? rid : h);
 }
 
-template <typename W>
+template <bool CF = false, typename W>
 __device__ static inline uint32_t part_digit(const mdb_level_args &a, W hv)
 {
-	if (a.mode == MDB_DIGIT_RADIX)
+	if (CF || a.mode == MDB_DIGIT_RADIX)
 		return (uint32_t)(hv >> a.shift) & (a.R - 1);	/* a.shift counts from the width of W */
 	return (a.R & (a.R - 1)) == 0 ? (uint32_t)hv & (a.R - 1) : (uint32_t)hv % a.R;	/* 2, 4, 8 GPUs: no integer division */
 }
@@ -186,7 +198,8 @@ __device__ static inline bool part_load(const mdb_level_args &a, const mdb_tile_
  * access when both belong to the tile (8-byte accesses reach only ~0.6x of the 16-byte rate,
  * MI355X_MICROARCH.md).  lead = 1 when the tile starts on an odd element.  valid[k] = element exists and is
  * not NULL. */
-template <bool LEVEL0, bool HAS_RID, bool RAW = false, bool INV = false, bool KEEP = true /* compile the key-range tests (by-destination kernels) */>
+template <bool LEVEL0, bool HAS_RID, bool RAW = false, bool INV = false, bool KEEP = true /* compile the key-range tests (by-destination kernels) */,
+	  bool CF = false, bool RIDW = false /* see part_hash_key */>
 __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint64_t hv[2],
 					 uint32_t rid[2], bool valid[2], uint64_t *rel = nullptr /* [2]: key - narrow_base (narrow forms) */,
 					 const ulonglong2 *pre = nullptr /* the pair, already loaded (full, 16-byte aligned tiles: the caller
@@ -209,7 +222,7 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			ulonglong2 k;
 			if (pre) {
 				k = *pre;
-			} else if (a.keys32) {
+			} else if (!CF && a.keys32) {
 				const int2 q = *reinterpret_cast<const int2 *>(reinterpret_cast<const int32_t *>(a.keys) + g0);
 				k.x = (uint64_t)(int64_t)q.x;
 				k.y = (uint64_t)(int64_t)q.y;
@@ -220,8 +233,8 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			}
 			raw_key[0] = (int64_t)k.x;
 			raw_key[1] = (int64_t)k.y;
-			hv[0] = INV ? k.x : part_hash_key(a, k.x, (uint32_t)g0, &bad[0], rel ? &rel[0] : nullptr);	/* INV: the caller keeps the key itself */
-			hv[1] = INV ? k.y : part_hash_key(a, k.y, (uint32_t)g0 + 1, &bad[1], rel ? &rel[1] : nullptr);
+			hv[0] = INV ? k.x : part_hash_key<CF, RIDW>(a, k.x, (uint32_t)g0, &bad[0], rel ? &rel[0] : nullptr);	/* INV: the caller keeps the key itself */
+			hv[1] = INV ? k.y : part_hash_key<CF, RIDW>(a, k.y, (uint32_t)g0 + 1, &bad[1], rel ? &rel[1] : nullptr);
 			rid[0] = (uint32_t)g0;
 			rid[1] = (uint32_t)g0 + 1;
 		} else {
@@ -238,9 +251,9 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 		const int k = in0 ? 0 : 1;
 		const uint64_t g = g0 + (uint64_t)k;
 		if (LEVEL0) {
-			const int64_t key = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
+			const int64_t key = (!CF && a.keys32) ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[g] : a.keys[g];
 			raw_key[k] = key;
-			hv[k] = INV ? (uint64_t)key : part_hash_key(a, (uint64_t)key, (uint32_t)g, &bad[k], rel ? &rel[k] : nullptr);
+			hv[k] = INV ? (uint64_t)key : part_hash_key<CF, RIDW>(a, (uint64_t)key, (uint32_t)g, &bad[k], rel ? &rel[k] : nullptr);
 			rid[k] = (uint32_t)g;
 		} else {
 			hv[k] = a.hv_in[g];
@@ -369,10 +382,46 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * LDS: hv 32 KiB (+ rid 16 KiB when row ids travel) + 3 KiB of per-digit words => 4 (3) workgroups/CU
  * (+16 KiB for STABLE).
  */
+/* The rows of one thread in a FULL tile of the compact narrow form, no NULL bitmap: straight-line code, no per-row branch
+ * (the generic loop below spends ~25 scalar branches per pair of rows on conditions that are the same for the whole launch).
+ * MODE 1 (the one in use): min-max pruning, the left table - rows outside [range_lo, range_hi] are dropped (a key outside the
+ * window is outside the range: nothing to report); 0: plain; 2: the right table of a pruned join - the smallest / largest
+ * key - window base is recorded.  -> a key outside the window was seen (modes 0 and 2). */
+template <bool W32v, int MODE, typename W>
+__device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulonglong2 *pre, uint32_t row0, W *hv, uint32_t *dig, uint64_t range_lo,
+					   uint64_t range_hi, uint32_t &seen_min, uint32_t &seen_max)
+{
+	bool any_bad = false;
+	const uint32_t dshift = a.shift - (W32v ? 0u : 32u);	/* the digit's place inside the 32-bit hash */
+#pragma unroll
+	for (int r = 0; r < PART_ITEMS / 2; r++) {
+#pragma unroll
+		for (int e = 0; e < 2; e++) {
+			const uint64_t key = (e ? pre[r].y : pre[r].x) - (uint64_t)a.narrow_base;
+			bool ok = true;
+			if (MODE == 1)
+				ok = key >= range_lo && key <= range_hi;
+			else
+				any_bad = any_bad || (key >> a.narrow_kbits);
+			if (MODE == 2) {
+				seen_min = min(seen_min, (uint32_t)key);
+				seen_max = max(seen_max, (uint32_t)key);
+			}
+			const uint32_t h = mdb_mixk((uint32_t)key, a.narrow_kbits) << (32u - a.narrow_kbits);
+			const uint32_t rid = row0 + 2u * (uint32_t)r * PART_THREADS + (uint32_t)e;
+			hv[2 * r + e] = W32v ? (W)h : (W)(((uint64_t)h << 32) | rid);
+			dig[2 * r + e] = ok ? ((h >> dshift) & (a.R - 1u)) : PART_INVALID;
+		}
+	}
+	return any_bad;
+}
+
 template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false, bool FILT = false,
-	  bool OUT16 = false /* 2-byte words out (see mdb_level_args.out16_shift) */>
+	  bool OUT16 = false /* 2-byte words out (see mdb_level_args.out16_shift) */,
+	  bool CF = false /* first level of the compact narrow form over an int64 column (part_hash_key) */>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
 	static_assert(!OUT16 || (LEVEL0 && W32 && !RAW), "2-byte words: first level of the 4-byte form only");
 	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
 	/* INV (destination partition for the exchange): what is staged and written is the KEY, not its hash - the digit is
@@ -489,12 +538,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		}
 	} else {
 		constexpr bool PRE_OK = LEVEL0 || !HAS_RID;	/* (row-id arrays beyond the first level: the wide form keeps part_load2's own loads) */
-		const bool full = PRE_OK && td.len == MDB_TILE && !(td.start & 1u) && !(LEVEL0 && a.keys32);	/* (uniform) */
+		const bool full = PRE_OK && td.len == MDB_TILE && !(td.start & 1u) && !(LEVEL0 && !CF && a.keys32);	/* (uniform) */
 		ulonglong2 pre[PART_ITEMS / 2];
 		if (full)
 			part_preload2<LEVEL0, PART_ITEMS / 2>(a, td, pre);
+		/* (uniform) the pruned left table only: for the right table - with or without its key range recorded - the same
+		 * straight-line code measured equal (0.247 ms) or slower (0.235 -> 0.258 ms) than the loop below */
+		const bool straight = CF && !W32 && full && !a.nullbits && a.range_in;
+		if (straight)
+			(void)part_cf_rows<W32, 1, W>(a, pre, td.start + 2u * threadIdx.x, hv, dig, range_lo, range_hi, seen_min, seen_max);
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS / 2; r++) {
+		for (int r = 0; r < PART_ITEMS / 2 && !straight; r++) {
 			bool valid[2];
 			uint64_t h2[2];
 			constexpr bool RANGE = LEVEL0 && FAST && !RAW && !INV && !HAS_RID;	/* (the narrow forms' first level) */
@@ -502,10 +556,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			/* (the key-range tests of the by-destination partition are compiled into its own instance only: as run-time
 			 * branches they cost the join's first-level kernels 0.05 ms per 10^8 rows) */
 			if (full)
-				part_load2<LEVEL0, HAS_RID, RAW, INV, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid, RANGE ? rel2 : nullptr,
-									   &pre[r]);
+				part_load2<LEVEL0, HAS_RID, RAW, INV, INV, CF, !W32>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid,
+										     RANGE ? rel2 : nullptr, &pre[r]);
 			else
-				part_load2<LEVEL0, HAS_RID, RAW, INV, INV>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid, RANGE ? rel2 : nullptr);
+				part_load2<LEVEL0, HAS_RID, RAW, INV, INV, CF, !W32>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid,
+										     RANGE ? rel2 : nullptr);
 			if (RANGE && a.range_in) {		/* (uniform) */
 				valid[0] = valid[0] && rel2[0] >= range_lo && rel2[0] <= range_hi;
 				valid[1] = valid[1] && rel2[1] >= range_lo && rel2[1] <= range_hi;
@@ -527,8 +582,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			}
 			hv[2 * r] = (W)h2[0];		/* W32 at level 0: the narrow word holds the hash in both halves */
 			hv[2 * r + 1] = (W)h2[1];
-			dig[2 * r] = valid[0] ? part_digit(a, INV ? (W)mdb_fmix64(h2[0]) : hv[2 * r]) : PART_INVALID;
-			dig[2 * r + 1] = valid[1] ? part_digit(a, INV ? (W)mdb_fmix64(h2[1]) : hv[2 * r + 1]) : PART_INVALID;
+			dig[2 * r] = valid[0] ? part_digit<CF>(a, INV ? (W)mdb_fmix64(h2[0]) : hv[2 * r]) : PART_INVALID;
+			dig[2 * r + 1] = valid[1] ? part_digit<CF>(a, INV ? (W)mdb_fmix64(h2[1]) : hv[2 * r + 1]) : PART_INVALID;
 		}
 	}
 	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_out) {
@@ -693,7 +748,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			}
 			d = lo;
 		} else {
-			d = part_digit(a, h);
+			d = part_digit<CF>(a, h);
 		}
 		if (FAST && !s_ok[d])
 			continue;	/* overflowed child: the whole operator is re-run on the exact path */
@@ -1072,6 +1127,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			if (cv.failed)
 				return -MIDORIDB_INTERNAL;
 			if (!dry) {
+				/* compact narrow form over an int64 column: the instances that know so at compile time */
+				const bool cf = a.narrow && narrow_kbits && !(flags & PART_F_KEYS32) && mode == MDB_DIGIT_RADIX && !raw_hv && !want_rid;
 				a.cursor = cursor0;
 				a.cap = cap0;
 				a.nsub = PART_NSUB;
@@ -1086,8 +1143,16 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_HIP(ctx, hipMemsetAsync(a.minmax_out, 0xFF, (size_t)grid8(ntiles) * 8, ctx->stream));
 					if (out16) {
 						a.out16_shift = 32u - narrow_kbits;
-						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true>), grid8(ntiles),
-							   PART_THREADS, a);
+						if (cf) {
+							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true, true>),
+								   grid8(ntiles), PART_THREADS, a);
+						} else {
+							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true>),
+								   grid8(ntiles), PART_THREADS, a);
+						}
+					} else if (cf) {
+						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, false, true>),
+							   grid8(ntiles), PART_THREADS, a);
 					} else {
 						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
 					}
@@ -1095,8 +1160,14 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
-				} else if (a.range_in) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
+				} else if (a.range_in && cf) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
+					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<true, false, false, true, false, false, false, false, false, true>),
+						   grid8(ntiles), PART_THREADS, a);
+				} else if (a.range_in) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				} else if (cf) {
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true, false, false, false, false, false, true>), grid8(ntiles),
+						   PART_THREADS, a);
 				} else {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
 				}
