@@ -1062,7 +1062,8 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
  * one is counted (unconditional loads, s_waitcnt vmcnt(4..7) instead of 0) 0.143 - not latency: with one workgroup per CU
  * nothing streams while a workgroup clears its 128 KiB or emits. */
 #define LW_THREADS 1024
-#define LW_MIN_REM 11u		/* one 32-bit word of halves per thread */
+#define LW_MIN_REM 8u		/* tables of 256 entries at least (key windows from 2^17 values) */
+#define LW_EMIT_REM 11u		/* from here on every thread owns at least one 32-bit word of halves in the emit pass */
 #define LW_MAX_REM 14u
 #define LW_UNROLL 4
 
@@ -1193,15 +1194,15 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 	__syncthreads();
 
 	/* emit: thread t owns the words [t * W, t * W + W) of halves = 2 W consecutive entries */
-	const uint32_t W = 1u << (rem - LW_MIN_REM);
-	uint32_t cl2[1u << (LW_MAX_REM - LW_MIN_REM)], cr2[1u << (LW_MAX_REM - LW_MIN_REM)];
+	const uint32_t W = rem > LW_EMIT_REM ? 1u << (rem - LW_EMIT_REM) : 1u, nwords = T / 2;
+	uint32_t cl2[1u << (LW_MAX_REM - LW_EMIT_REM)], cr2[1u << (LW_MAX_REM - LW_EMIT_REM)];
 	uint32_t mine = 0;
 	unsigned long long sums = 0;	/* low half: right rows counted, high half: left rows counted */
 #pragma unroll
-	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_MIN_REM)); k++) {
+	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_EMIT_REM)); k++) {
 		cl2[k] = 0u;
 		cr2[k] = 0x00010001u;
-		if ((uint32_t)k < W) {
+		if ((uint32_t)k < W && threadIdx.x * W + (uint32_t)k < nwords) {
 			cl2[k] = s_cl[threadIdx.x * W + (uint32_t)k];
 			if (HAS_R)
 				cr2[k] = s_cr[threadIdx.x * W + (uint32_t)k];
@@ -1238,7 +1239,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 	}
 	unsigned long long joined = 0;
 #pragma unroll
-	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_MIN_REM)); k++) {
+	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_EMIT_REM)); k++) {
 		if ((uint32_t)k >= W)
 			continue;
 #pragma unroll
@@ -2015,6 +2016,7 @@ struct gc_state {
 	uint32_t key_bits;	/* compact narrow form offered by the key sample: every key in [key_lo, key_lo + 2^key_bits) (0 = none) */
 	int64_t key_lo;
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
+	bool fast1;		/* gc_window.fast1 */
 	bool one_level;		/* ... by k_leaf_wide: ONE partition level of 9 bits, tables of 2^(key_bits - 9) entries */
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
@@ -2035,7 +2037,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
 	if (st->r_based && !(st->has_r && st->defer_ok && !st->active && st->fast))
 		st->key_bits = 0;	/* (a window of the right table's keys only needs the left table pruned: not in this call - plain narrow form) */
-	/* key windows of 2^20 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
+	/* key windows of 2^17 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
 	 * than 2^21 rows in all keep the two-level form, whose fixed costs are smaller) */
 	st->one_level = st->narrow && st->key_bits >= 9u + LW_MIN_REM && st->key_bits <= 9u + LW_MAX_REM && st->fast && st->want_records &&
 			!ld_disabled() && !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
@@ -2045,6 +2047,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	if (st->one_level) {
 		st->b1 = 9;
 		st->b2 = 0;
+	} else if (st->fast1) {
+		st->fast = false;	/* (two fast levels: leaves of one or two values with thousands of rows each - regions would overflow) */
 	}
 	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
 	if (!st->one_level && st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
@@ -2677,6 +2681,7 @@ struct gc_window {
 				 * right table's exact range for min-max pruning */
 	bool r_based;		/* the compact window covers the RIGHT table's sampled keys only (by_span, unsplit call): the left rows outside
 				 * it are exactly the ones min-max pruning drops - fewer key bits, hence fewer and larger leaves */
+	bool fast1;		/* plain GROUP BY, duplicates in the key sample: the fixed-capacity layout only if the ONE-level form applies */
 };
 
 static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
@@ -2798,6 +2803,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.key_bits = narrow ? win.kbits : 0u;
 	st.key_lo = win.lo;
 	st.selective = win.selective;
+	st.fast1 = win.fast1;
 	st.by_span = win.by_span;
 	st.prunable = win.prunable;
 	st.r_based = win.r_based;
@@ -2823,8 +2829,15 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow
 	 * and be redone anyway - start with the exact layout */
-	if (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u)
-		fast = false;
+	/* ... unless there are still some 10^5 of them (3900 distinct among 4096 sampled: about 4 * 10^4 in the column) and the
+	 * one-level form applies: its 512 first-level regions hold 80 values or more each, their sizes vary by a few percent */
+	bool fast1 = false;
+	if (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) {
+		if (ctx->gh_distinct >= 3900u)
+			fast1 = true;
+		else
+			fast = false;
+	}
 	rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow, &base, &win, keys32, has_r);
 	if (rc)
 		return rc;
@@ -2834,6 +2847,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		narrow = ctx->narrow_mode != 0;
 		base = 0;
 	}
+	win.fast1 = fast1;
 	for (int attempt = 0; attempt < 6; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
 				     base, win, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
@@ -2849,8 +2863,10 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 				ctx->nh_distrust = 8;	/* whatever said "narrow" was wrong: look at the data itself the next few times */
 			if (ctx->narrow_mode == 1 && !keys32)
 				gc_narrow_note(ctx, keys_l, n_l, has_r ? keys_r : NULL, n_r, false);	/* the sample missed a wide key */
-		} else if (rc == GC_RETRY_EXACT)
-			fast = false;	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
+		} else if (rc == GC_RETRY_EXACT) {
+			fast = false;
+			win.fast1 = false;
+		}	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
 		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 || rc == GC_RETRY_TWO_LEVEL)

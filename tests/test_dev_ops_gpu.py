@@ -1285,9 +1285,9 @@ def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), info
 
 
-@pytest.mark.parametrize("shape", ["dup16_pruned", "unique_2e22", "nulls_offset", "group_only"])
+@pytest.mark.parametrize("shape", ["dup16_pruned", "unique_2e22", "nulls_offset", "group_only", "window_2e17_join", "window_2e18_group"])
 def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_leaves(dev, narrow_mode, monkeypatch, shape):
-    """Compact narrow form with a window of 2^20 ... 2^23 key values: ONE 9-bit partition level and k_leaf_wide (tables of
+    """Compact narrow form with a window of 2^17 ... 2^23 key values: ONE 9-bit partition level and k_leaf_wide (tables of
     2^(k - 9) entries, 16-bit row counts) instead of two levels and k_leaf_direct.  Same groups, counts, first rows and order
     as the oracle and as the two-level form (MDB_ONE_LEVEL=0)."""
     narrow_mode(1)
@@ -1307,6 +1307,16 @@ def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_l
         kl = rng.integers(0, 1_500_000, n_l, dtype=np.int64) - 2**40
         kr = rng.integers(0, 1_500_000, n_r, dtype=np.int64) - 2**40
         nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.1
+    elif shape == "window_2e17_join":      # tables of 2^8 entries per digit: a 10^5-key dimension, 30 fact rows per key
+        n_l, n_r = 3_000_000, 100_000
+        kl = rng.integers(0, 100_000, n_l, dtype=np.int64) + 7_000_000
+        kr = rng.permutation(100_000).astype(np.int64) + 7_000_000
+        nl = rng.random(n_l) < 0.02
+    elif shape == "window_2e18_group":     # 10^5 distinct values, 40 rows each: duplicates in the key sample, one level all the same
+        has_r = False
+        n_l, n_r = 4_000_000, 0
+        kl = rng.integers(0, 100_000, n_l, dtype=np.int64) * 2 - 100_000
+        kr = None
     else:
         has_r = False
         n_l, n_r = 7_000_000, 0
