@@ -3211,8 +3211,13 @@ extern "C" int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32
  * share of the rows directly in an LDS table indexed by (value - base) - COUNT and first row per value, the table
  * replicated per lane group when the range is small so that equal values in a wave do not meet on one LDS address -
  * and flushes it into a global table with one atomic pair per value it saw.  One streaming pass over the column.
- * A value outside the window (the sample missed it) is reported and the partitioned path takes over. */
-#define GD_RANGE 8192u
+ * A value outside the window (the sample missed it) is reported and the partitioned path takes over.
+ * Spans up to GD_SPAN_MAX (some 10^4 product / city / customer ids: 10^8 rows took 2.3 ms through two exact partition levels
+ * and the hashed leaves) get a window of 1.25 x the span in a table of up to GD_TABLE_MAX entries - 128 KiB of dynamic LDS,
+ * one workgroup per CU. */
+#define GD_RANGE 8192u		/* entries of the LDS table for spans up to GD_RANGE / 2 (two workgroups per CU), replicated per lane group */
+#define GD_TABLE_MAX 16384u	/* entries of a workgroup's LDS table (8 bytes each) */
+#define GD_SPAN_MAX 13000u
 #define GD_THREADS 1024
 #define GD_MIN_ROWS (1u << 18)
 
@@ -3223,19 +3228,20 @@ struct gd_args {
 	int64_t base;
 	uint32_t range;			/* values base .. base + range - 1 have a slot */
 	uint32_t copy_shift, copy_mask;	/* slot = (value - base) | ((lane & copy_mask) << copy_shift) */
-	uint32_t null_group;		/* NULL keys form a group (slot GD_RANGE of the global table) */
-	unsigned long long *g_cnt;	/* [GD_RANGE + 1] */
-	uint32_t *g_first;		/* [GD_RANGE + 1] */
+	uint32_t table;			/* entries of the LDS table: (copy_mask + 1) << copy_shift */
+	uint32_t null_group;		/* NULL keys form a group (slot GD_TABLE_MAX of the global table) */
+	unsigned long long *g_cnt;	/* [GD_TABLE_MAX + 1] */
+	uint32_t *g_first;		/* [GD_TABLE_MAX + 1] */
 	uint32_t *status;		/* bit 10: a value outside the window */
 };
 
 __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 {
-	__shared__ uint32_t s_cnt[GD_RANGE];
-	__shared__ uint32_t s_first[GD_RANGE];
+	extern __shared__ __attribute__((aligned(16))) uint32_t gd_lds[];
+	uint32_t *const s_cnt = gd_lds, *const s_first = gd_lds + a.table;
 	__shared__ unsigned long long s_null_cnt;
 	__shared__ uint32_t s_null_first;
-	for (uint32_t i = threadIdx.x; i < GD_RANGE; i += GD_THREADS) {
+	for (uint32_t i = threadIdx.x; i < a.table; i += GD_THREADS) {
 		s_cnt[i] = 0;
 		s_first[i] = 0xFFFFFFFFu;
 	}
@@ -3299,8 +3305,8 @@ __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 		}
 	}
 	if (threadIdx.x == 0 && s_null_cnt) {
-		atomicAdd(&a.g_cnt[GD_RANGE], s_null_cnt);
-		atomicMin(&a.g_first[GD_RANGE], s_null_first);
+		atomicAdd(&a.g_cnt[GD_TABLE_MAX], s_null_cnt);
+		atomicMin(&a.g_first[GD_TABLE_MAX], s_null_first);
 	}
 }
 
@@ -3311,7 +3317,7 @@ __global__ void k_group_direct_emit(gd_args a, const unsigned long long *g_cnt_r
 				    unsigned long long *joined)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t slot = t < a.range ? t : (t == a.range ? GD_RANGE : 0xFFFFFFFFu);
+	const uint32_t slot = t < a.range ? t : (t == a.range ? GD_TABLE_MAX : 0xFFFFFFFFu);
 	if (slot == 0xFFFFFFFFu)
 		return;
 	const unsigned long long c = a.g_cnt[slot];
@@ -3319,7 +3325,7 @@ __global__ void k_group_direct_emit(gd_args a, const unsigned long long *g_cnt_r
 		return;
 	if (g_cnt_r) {
 		const unsigned long long cr = g_cnt_r[slot];
-		if (!cr || slot == GD_RANGE)
+		if (!cr || slot == GD_TABLE_MAX)
 			return;
 		atomicAdd(joined, c * cr);	/* both below 2^32 (row counts of one GPU's tables) */
 	}
@@ -3353,20 +3359,21 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 	if (lo > hi)
 		return 1;
 	const uint64_t span = (uint64_t)hi - (uint64_t)lo + 1;
-	if (span > GD_RANGE / 2)
+	if (span > GD_SPAN_MAX)
 		return 1;
-	/* window: twice the sampled span (at least 64 values), centred on it; replicated while copies fit the table */
-	uint32_t range = (uint32_t)(2 * span < 64 ? 64 : 2 * span);
+	/* window: twice the sampled span (at least 64 values), centred on it - 1.25 x beyond GD_RANGE / 2 values, where the 4096
+	 * samples lie within a few values of the column's extremes; replicated while copies fit a GD_RANGE-entry table */
+	uint32_t range = (uint32_t)(span > GD_RANGE / 2 ? span + span / 4 : (2 * span < 64 ? 64 : 2 * span));
 	uint32_t shift = 0;
 	while ((1u << shift) < range)
 		shift++;
 	uint32_t copies = GD_RANGE >> shift;
 	copies = copies > 64 ? 64 : (copies < 1 ? 1 : copies);
 	uint32_t kbits = 0;
-	const size_t order_bytes = mdb_order_records_arena_bytes(GD_RANGE + 1, n, &kbits);
+	const size_t order_bytes = mdb_order_records_arena_bytes(GD_TABLE_MAX + 1, n, &kbits);
 	if (!order_bytes)
 		return 1;
-	rc = mdb_arena_begin(ctx, order_bytes + 6 * mdb_align_up((GD_RANGE + 1) * 8) + 8192);
+	rc = mdb_arena_begin(ctx, order_bytes + 6 * mdb_align_up((GD_TABLE_MAX + 1) * 8) + 8192);
 	if (rc)
 		return rc;
 	gd_args a;
@@ -3378,24 +3385,27 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 	a.range = range;
 	a.copy_shift = shift;
 	a.copy_mask = copies - 1;
+	a.table = copies << shift;
 	a.null_group = (null_group && !keys_r) ? 1u : 0u;
-	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8);
-	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GD_RANGE + 1) * 4);
+	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
+	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 4);
 	a.status = ctx->d_status;
-	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8);
-	unsigned long long *g_cnt_r = keys_r ? (unsigned long long *)mdb_arena_take(ctx, (GD_RANGE + 1) * 8) : NULL;
-	uint32_t *g_first_r = keys_r ? (uint32_t *)mdb_arena_take(ctx, (GD_RANGE + 1) * 4) : NULL;
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
+	unsigned long long *g_cnt_r = keys_r ? (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8) : NULL;
+	uint32_t *g_first_r = keys_r ? (uint32_t *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 4) : NULL;
 	if (!a.g_cnt || !a.g_first || !rec || (keys_r && (!g_cnt_r || !g_first_r)))
 		return -MIDORIDB_INTERNAL;
 	uint32_t *rec_n = ctx->d_status + 1;
 	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GD_RANGE + 1) * 8, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_RANGE + 1) * 4, ctx->stream));
-	const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
+	const size_t lds = (size_t)a.table * 8;
+	const uint32_t resident = (lds > 80 * 1024 ? 1u : 2u) * (uint32_t)ctx->num_cus;
+	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	{
 		const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, a);
+		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, a);
 	}
 	if (keys_r) {
 		gd_args b = a;
@@ -3404,10 +3414,10 @@ static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_
 		b.n = n_r;
 		b.g_cnt = g_cnt_r;
 		b.g_first = g_first_r;
-		MDB_HIP(ctx, hipMemsetAsync(g_cnt_r, 0, (GD_RANGE + 1) * 8, ctx->stream));
-		MDB_HIP(ctx, hipMemsetAsync(g_first_r, 0xFF, (GD_RANGE + 1) * 4, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(g_cnt_r, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(g_first_r, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
 		const uint64_t chunks = (n_r + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, b);
+		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, b);
 	}
 	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, (const unsigned long long *)g_cnt_r, kbits, rec, rec_n,
 		   d_joined);

@@ -1653,13 +1653,14 @@ def test_group_count_multi_and_distinct_on_the_packed_sort_path_unpinned(dev, n)
         assert np.array_equal(got, orc.distinct_sel(keys_np, n))
 
 
-@pytest.mark.parametrize("shape", ["thousand", "two", "one", "negative", "span_4096", "span_4097", "outlier", "all_null", "half_null",
-                                   "huge_offset", "sorted_runs"])
+@pytest.mark.parametrize("shape", ["thousand", "two", "one", "negative", "span_4096", "span_4097", "span_10000_nulls", "span_13000", "span_13500",
+                                   "span_12000_unsampled_extremes", "outlier", "all_null", "half_null", "huge_offset", "sorted_runs"])
 @pytest.mark.parametrize("n", [262_144, 1_300_001])
 def test_group_count_over_a_small_value_range(dev, shape, n):
-    """Plain GROUP BY + COUNT(*) whose key column spans few values (the direct LDS-table path from 2^18 rows on; a value
-    outside the sampled window or a span above 4096 falls back to the partitioned path): groups in first-occurrence
-    order, NULL group included, against the numpy oracle."""
+    """Plain GROUP BY + COUNT(*) whose key column spans few values (the direct LDS-table path from 2^18 rows on - up to 4096
+    values in a replicated 64 KiB table, up to 13 000 in a 128 KiB one with a window of 1.25 x the sampled span; a value
+    outside the window or a wider span falls back to the partitioned path): groups in first-occurrence order, NULL group
+    included, against the numpy oracle."""
     rng = np.random.default_rng(n + len(shape))
     nulls = None
     if shape == "thousand":
@@ -1676,6 +1677,17 @@ def test_group_count_over_a_small_value_range(dev, shape, n):
     elif shape == "span_4097":
         k = rng.integers(5000, 5000 + 4097, n)
         k[:2] = [5000, 5000 + 4096]
+    elif shape == "span_10000_nulls":
+        k = rng.integers(-4000, 6000, n)
+        nulls = rng.random(n) < 0.1
+    elif shape == "span_13000":
+        k = rng.integers(10**12, 10**12 + 13000, n)
+    elif shape == "span_13500":
+        k = rng.integers(0, 13500, n)
+    elif shape == "span_12000_unsampled_extremes":    # two values beyond the window of 1.25 x the sampled span
+        k = rng.integers(0, 12000, n)
+        k[n // 2 + 1] = -4000
+        k[n // 3 + 1] = 17000
     elif shape == "outlier":
         k = rng.integers(0, 50, n)
         k[n // 2 + 1] = 10**9                       # not among the sampled rows
@@ -1772,7 +1784,7 @@ def test_join_pairs_unique_keys_in_a_window_up_to_2e24_take_one_partition_level(
         assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er), (shape, one_level)
 
 
-@pytest.mark.parametrize("shape", ["hundred", "one_key", "disjoint", "outlier_left", "outlier_right", "nulls", "offset", "span_too_wide"])
+@pytest.mark.parametrize("shape", ["hundred", "one_key", "disjoint", "outlier_left", "outlier_right", "nulls", "offset", "span_too_wide", "span_11000"])
 def test_join_group_count_over_a_small_value_range(dev, shape):
     """Join + GROUP BY join key + COUNT(*) whose key columns both lie in one window of at most 4096 values (joins on a few
     hot values: N:M counts in the billions) take the direct LDS-table path; an unsampled value outside the window or a
@@ -1799,6 +1811,9 @@ def test_join_group_count_over_a_small_value_range(dev, shape):
         nl, nr = rng.random(n_l) < 0.3, rng.random(n_r) < 0.6
     elif shape == "offset":
         kl, kr = -(2**50) + rng.integers(0, 3000, n_l), -(2**50) + rng.integers(0, 3000, n_r)
+    elif shape == "span_11000":
+        kl, kr = rng.integers(0, 11000, n_l) - 3000, rng.integers(2000, 9000, n_r) - 3000
+        nl = rng.random(n_l) < 0.05
     else:
         kl, kr = rng.integers(0, 5000, n_l), rng.integers(0, 5000, n_r)
     kl, kr = np.asarray(kl, dtype=np.int64), np.asarray(kr, dtype=np.int64)
