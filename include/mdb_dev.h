@@ -75,7 +75,7 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * Both are exact in effect (a row is only dropped when no right row can have its key): results are identical, only the
  * bytes moved change.
  * -> of the last completed join / GROUP BY operator: bit 8 = min-max pruning ran; low byte = 0 without the bitmap, else 1 +
- * log2(adjacent hashed values per bitmap bit); bit 9 = the tables were partitioned ONCE (key windows of 2^17 ... 2^23
+ * log2(adjacent hashed values per bitmap bit); bit 9 = the tables were partitioned ONCE (key windows of 2^15 ... 2^23
  * values: one 9-bit level, direct-address leaf tables of 2^(k - 9) entries with 16-bit row counts; MDB_ONE_LEVEL=0 turns it
  * off; a key with 2^16 or more rows sends the operator back to two levels). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);

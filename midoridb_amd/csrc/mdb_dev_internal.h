@@ -73,6 +73,8 @@ struct mdb_part_filter {
 	int64_t keep_lo, keep_hi;
 	bool own_on;		/* ... and verify that every key of THIS table lies in [own_lo, own_hi] (a promised range: status bit 10 otherwise) */
 	int64_t own_lo, own_hi;
+	bool loose;		/* with level0_only: regions of 1.5 x (instead of 1.25 x) the average size - a column of some 10^4 - 10^5 distinct
+				 * values puts a few dozen of them, with thousands of rows each, into a region */
 	bool out16;		/* with level0_only, right side of the compact narrow form: 2-byte words (mdb_part_result.w16) when the hash bits
 				 * below the digit fit 16 bits */
 	bool level0_only;	/* stop after the histogram-free first level (bits2 = 0): the consumer reads the digits' sub-regions itself
@@ -93,7 +95,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 									 * compact narrow form only), see struct mdb_part_filter */
 
 /* arena bytes of a first-level-only partition (mdb_part_filter.level0_only) of n rows by bits1 bits */
-size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1);
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose = false /* mdb_part_filter.loose */);
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

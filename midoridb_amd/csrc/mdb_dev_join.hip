@@ -1062,7 +1062,8 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
  * one is counted (unconditional loads, s_waitcnt vmcnt(4..7) instead of 0) 0.143 - not latency: with one workgroup per CU
  * nothing streams while a workgroup clears its 128 KiB or emits. */
 #define LW_THREADS 1024
-#define LW_MIN_REM 8u		/* tables of 256 entries at least (key windows from 2^17 values) */
+#define LW_MIN_REM 6u		/* tables of 64 entries at least (key windows from 2^15 values: that few values per first-level region - their
+				 * number varies by 13 % - need the looser regions of mdb_part_filter.loose) */
 #define LW_EMIT_REM 11u		/* from here on every thread owns at least one 32-bit word of halves in the emit pass */
 #define LW_MAX_REM 14u
 #define LW_UNROLL 4
@@ -1238,6 +1239,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 		pos += s_base;
 	}
 	unsigned long long joined = 0;
+	uint32_t last_first = 0;	/* largest first row id of this digit's groups */
 #pragma unroll
 	for (int k = 0; k < (int)(1u << (LW_MAX_REM - LW_EMIT_REM)); k++) {
 		if ((uint32_t)k >= W)
@@ -1251,6 +1253,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 			const uint32_t first = s_first[s];
 			const unsigned long long c = (unsigned long long)cl * ((cr2[k] >> (16 * e)) & 0xFFFFu);
 			joined += c;
+			last_first = first > last_first ? first : last_first;
 			if (a.kbits && a.keyed_cbits) {
 				if (c >> a.keyed_cbits)
 					mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
@@ -1269,6 +1272,25 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 	joined = lw_block_sum(joined, s_red);
 	if (threadIdx.x == 0 && joined)
 		atomicAdd(a.joined, joined);
+	/* the largest first row id (status word 9): the groups of a plain GROUP BY over few values all begin in the first rows of the
+	 * table - the ordering sort then sizes its regions for the row-id range that occurs */
+#pragma unroll
+	for (int o = 32; o; o >>= 1) {
+		const uint32_t other = (uint32_t)__shfl_xor((int)last_first, o, MDB_WAVE);
+		last_first = other > last_first ? other : last_first;
+	}
+	__syncthreads();	/* (s_red is free again) */
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = last_first;
+	__syncthreads();
+	if (threadIdx.x == 0) {		/* ONE atomic per workgroup: 8192 of them on one address are 0.1 ms */
+		uint32_t m = 0;
+#pragma unroll
+		for (int w = 0; w < LW_THREADS / 64; w++)
+			m = (uint32_t)s_red[w] > m ? (uint32_t)s_red[w] : m;
+		if (m)
+			atomicMax(a.status + 9, m);
+	}
 }
 
 /* ------------------------------------------------------------------ semi-join filter (compact narrow form)
@@ -1834,7 +1856,10 @@ static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64
 		const uint32_t lb = kbits - OS_RANGE_BITS;
 		const int s1 = (int)((lb + 1) / 2), s2 = (int)lb - s1;
 		/* (the list has zero-filled gaps - chunk tails -, the scatter skips them: what counts is the number of records) */
-		if ((n_rec ? n_rec : list_len) <= order_sparse_most_records(kbits) && list_len <= order_sparse_most_slots(kbits)) {
+		/* leaves that can hold records: those below n_l (a caller that knows where the largest row id lies passes that) */
+		const uint64_t used_leaves = ((n_l ? n_l - 1 : 0) >> OS_RANGE_BITS) + 1;
+		if ((n_rec ? n_rec : list_len) <= (uint64_t)(OS_MAX_REC - 1024) * 2 / 3 * used_leaves &&
+		    (n_rec ? n_rec : list_len) <= order_sparse_most_records(kbits) && list_len <= order_sparse_most_slots(kbits)) {
 			mdb_part_result ps;
 			rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, s1, s2, 0, true, order_digits0(n_l, kbits, s1), &ps, true, 0);
 			if (rc)
@@ -2037,7 +2062,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
 	if (st->r_based && !(st->has_r && st->defer_ok && !st->active && st->fast))
 		st->key_bits = 0;	/* (a window of the right table's keys only needs the left table pruned: not in this call - plain narrow form) */
-	/* key windows of 2^17 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
+	/* key windows of 2^15 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
 	 * than 2^21 rows in all keep the two-level form, whose fixed costs are smaller) */
 	st->one_level = st->narrow && st->key_bits >= 9u + LW_MIN_REM && st->key_bits <= 9u + LW_MAX_REM && st->fast && st->want_records &&
 			!ld_disabled() && !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
@@ -2045,7 +2070,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			st->n_l < 3000000000ull && st->n_r_cap < 3000000000ull &&
 			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
 	if (st->one_level) {
-		st->b1 = 9;
+		st->b1 = st->key_bits <= 15u ? 8 : 9;	/* (a 2^15-value window: 256 regions of 128 values - see gc_window.fast1) */
 		st->b2 = 0;
 	} else if (st->fast1) {
 		st->fast = false;	/* (two fast levels: leaves of one or two values with thousands of rows each - regions would overflow) */
@@ -2106,7 +2131,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		if (!(e && e[0] == '0') && coarse <= 3u && rem >= coarse + 5u && below0 - coarse >= 7u)
 			st->semijoin = coarse + 1u;
 	}
-	size_t need = st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
+	size_t need = st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1, st->fast1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->semijoin)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
 	if (st->defer_l)
@@ -2138,6 +2163,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		mdb_part_filter lflt;
 		memset(&lflt, 0, sizeof(lflt));
 		lflt.level0_only = st->one_level;
+		lflt.loose = st->one_level && st->fast1;
 		rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
 					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u,
 					 st->one_level ? &lflt : NULL);
@@ -2449,7 +2475,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups",
 				   (unsigned long long)cap, (unsigned long long)G);
 	if (G && records) {
-		rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, out_first, out_count, NULL, keys_l, out_key, st->keys32,
+		/* (one-level leaves report the largest first row id: the sort's first-level regions are sized for the digits below it) */
+		const uint64_t last_first = (uint32_t)(h[5] >> 32);
+		const uint64_t n_ord = (st->one_level && last_first && last_first < n_l) ? last_first + 1 : n_l;
+		rc = order_records(ctx, rec, list_len, n_ord, kbits, sb1, sb2, out_first, out_count, NULL, keys_l, out_key, st->keys32,
 				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo, a.rec32 != 0, G);
 		if (rc == GC_RETRY_REC64)
 			ctx->r32_ok = false;
@@ -2829,11 +2858,12 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	/* plain GROUP BY whose key sample held duplicates (at most a few 10^5 distinct values): the leaves hold a few values with
 	 * hundreds or thousands of rows each, their sizes vary by whole multiples, and the fixed-capacity layout would overflow
 	 * and be redone anyway - start with the exact layout */
-	/* ... unless there are still some 10^5 of them (3900 distinct among 4096 sampled: about 4 * 10^4 in the column) and the
-	 * one-level form applies: its 512 first-level regions hold 80 values or more each, their sizes vary by a few percent */
+	/* ... unless there are still some 10^4 - 10^5 of them (3500 distinct among 4096 sampled: about 1.3 * 10^4 in the column) and
+	 * the one-level form applies: its 256 or 512 first-level regions hold 50 values or more each; sized at 1.5 x the average
+	 * (mdb_part_filter.loose) they take the variation of that number */
 	bool fast1 = false;
 	if (!has_r && ctx->gh_keys == keys_l && ctx->gh_n == n_l && ctx->gh_distinct < 4050u) {
-		if (ctx->gh_distinct >= 3900u)
+		if (ctx->gh_distinct >= 3500u)
 			fast1 = true;
 		else
 			fast = false;

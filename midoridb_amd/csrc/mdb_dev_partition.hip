@@ -998,6 +998,7 @@ static inline uint32_t grid8(uint32_t tiles) { return ((tiles + 7u) / 8u) * 8u; 
 #define PART_F_NO_GAPS 32u	/* raw words: a zero word is a word like any other, not a gap of the input list */
 #define PART_F_IN32 128u	/* with PART_F_FOLD32: the raw list already holds 4-byte words (nothing to fold) */
 #define PART_F_FOLD32 64u	/* raw 8-byte records are folded into 4-byte words by the first level (two-level fast layout only) */
+#define PART_F_LOOSE 1024u	/* first-level regions of 1.5 x (instead of 1.25 x) the average: few values per region, many rows per value */
 #define PART_F_OUT16 512u	/* with PART_F_STOP0 and 4-byte words: the first level writes 2-byte words (hash bits below the digit) */
 #define PART_F_STOP0 256u	/* first level only (histogram-free layout), bits2 = 0: the consumer walks the digits' sub-regions */
 #define PART_NSUB 8u		/* sub-regions per first-level digit in the FAST form */
@@ -1033,7 +1034,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	/* raw sort keys need not cover the whole first digit range (row ids below n < 2^kbits): the regions are
 	 * sized for the digits that can occur */
 	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
-	const uint32_t cap0 = (uint32_t)((((n + nreg0_used - 1) / nreg0_used) * 5 / 4 + 1024 + 63) & ~63ull);
+	const uint64_t avg0 = (n + nreg0_used - 1) / nreg0_used;
+	const uint32_t cap0 = (uint32_t)((((flags & PART_F_LOOSE) ? avg0 * 3 / 2 : avg0 * 5 / 4) + 1024 + 63) & ~63ull);
 	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0_used * cap0 < 0xFFFFFFFFull;
 	/* narrow form without row ids (right side of a join): 4-byte words from the first level's output on; only built for
 	 * the histogram-free layout of both levels (callers ask mdb_partition_w32_applies() first) */
@@ -1332,10 +1334,11 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 	return cv.bytes + 4096;
 }
 
-size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1)
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, 0, false, PART_F_FAST | PART_F_STOP0, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
+	(void)partition_impl(cv, NULL, NULL, n, bits1, 0, false, PART_F_FAST | PART_F_STOP0 | (loose ? PART_F_LOOSE : 0u), MDB_DIGIT_RADIX, 0, false, NULL,
+			     NULL, 0, NULL);
 	return cv.bytes + 4096;
 }
 
@@ -1377,7 +1380,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	return partition_impl(cv, keys, nullbits, n, bits1, bits2, want_rid,
 			      (stable ? PART_F_STABLE : 0u) | (fast ? PART_F_FAST : 0u) | (narrow == 1 ? PART_F_NARROW_RID : 0u) |
 				      (narrow == 2 ? PART_F_NARROW : 0u) | (keys32 ? PART_F_KEYS32 : 0u) | (stop0 ? PART_F_STOP0 : 0u) |
-					      (stop0 && flt->out16 ? PART_F_OUT16 : 0u),
+					      (stop0 && flt->out16 ? PART_F_OUT16 : 0u) | (stop0 && flt->loose ? PART_F_LOOSE : 0u),
 			      MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, out, NULL, 0, false, narrow ? narrow_base : 0, narrow ? narrow_kbits : 0u, flt);
 }
 

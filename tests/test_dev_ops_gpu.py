@@ -1285,9 +1285,9 @@ def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), info
 
 
-@pytest.mark.parametrize("shape", ["dup16_pruned", "unique_2e22", "nulls_offset", "group_only", "window_2e17_join", "window_2e18_group"])
+@pytest.mark.parametrize("shape", ["dup16_pruned", "unique_2e22", "nulls_offset", "group_only", "window_2e17_join", "window_2e18_group", "window_2e16_group"])
 def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_leaves(dev, narrow_mode, monkeypatch, shape):
-    """Compact narrow form with a window of 2^17 ... 2^23 key values: ONE 9-bit partition level and k_leaf_wide (tables of
+    """Compact narrow form with a window of 2^16 ... 2^23 key values: ONE 9-bit partition level and k_leaf_wide (tables of
     2^(k - 9) entries, 16-bit row counts) instead of two levels and k_leaf_direct.  Same groups, counts, first rows and order
     as the oracle and as the two-level form (MDB_ONE_LEVEL=0)."""
     narrow_mode(1)
@@ -1316,6 +1316,11 @@ def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_l
         has_r = False
         n_l, n_r = 4_000_000, 0
         kl = rng.integers(0, 100_000, n_l, dtype=np.int64) * 2 - 100_000
+        kr = None
+    elif shape == "window_2e16_group":     # 6 * 10^4 distinct values, 50 rows each: tables of 128 entries
+        has_r = False
+        n_l, n_r = 3_000_000, 0
+        kl = rng.integers(0, 60_000, n_l, dtype=np.int64) + 2**33
         kr = None
     else:
         has_r = False
