@@ -313,6 +313,33 @@ int mdb_cached_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
 	return MIDORIDB_OK;
 }
 
+/* What the operators remember about a key column - sampled ranges, narrow-form verdicts, duplicate flags ... - is keyed by
+ * the column's ADDRESS and length.  A buffer that is released (its address will be handed out again), or written to
+ * through the library (UPDATE: mdb_dev_scatter_set64; an upload into an existing buffer), takes what was learned about it
+ * along: the next operator over that address samples afresh instead of trusting a verdict about other data (results never
+ * depended on it - every verdict is verified on the device - but a wrong one costs a failed attempt, for up to 8 uses). */
+static void mdb_hints_drop(mdb_dev_ctx *ctx, const void *lo, size_t bytes)
+{
+	const uintptr_t a = (uintptr_t)lo, b = a + (bytes ? bytes : 1);
+	auto hit = [a, b](const void *p) { return p && (uintptr_t)p >= a && (uintptr_t)p < b; };
+	if (hit(ctx->nh_kl) || hit(ctx->nh_kr))
+		ctx->nh_result = -1;
+	if (hit(ctx->sr_kl) || hit(ctx->sr_kr))
+		ctx->sr_valid = 0;
+	if (hit(ctx->gh_keys))
+		ctx->gh_keys = NULL;
+	if (hit(ctx->pw_bad_keys))
+		ctx->pw_bad_keys = NULL;
+	if (hit(ctx->pu_dup_keys))
+		ctx->pu_dup_keys = NULL;
+	if (hit(ctx->pu_dupl_keys))
+		ctx->pu_dupl_keys = NULL;
+	if (hit(ctx->r32_kl) || hit(ctx->r32_kr))
+		ctx->r32_ok = false;
+	if (hit(ctx->lw_bad_keys))
+		ctx->lw_bad_keys = NULL;
+}
+
 int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr)
 {
 	if (!dptr)
@@ -325,6 +352,7 @@ int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr)
 		return MIDORIDB_OK;
 	}
 	const size_t sz = it->second;
+	mdb_hints_drop(ctx, dptr, sz);
 	ctx->live.erase(it);
 	/* reuse is ordered by the context's stream: whoever gets the buffer next launches after every kernel
 	 * that still reads it */
@@ -359,6 +387,7 @@ extern "C" int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t byt
 extern "C" int mdb_dev_h2d(mdb_dev_ctx *ctx, void *dptr, const void *host, size_t bytes)
 {
 	if (bytes) {
+		mdb_hints_drop(ctx, dptr, bytes);
 		MDB_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
@@ -1007,6 +1036,7 @@ extern "C" int mdb_dev_scatter_set64(mdb_dev_ctx *ctx, void *dst, uint64_t *dst_
 		return MIDORIDB_OK;
 	if (set_null && !dst_nullbits)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "scatter_set64: SET NULL needs a NULL bitmap");
+	mdb_hints_drop(ctx, dst, 8);	/* (hints are keyed by a column's first byte) */
 	MDB_LAUNCH(ctx, "scatter_set64", k_scatter_set64, stream_grid(n), STREAM_THREADS, (uint64_t *)dst,
 		   (unsigned long long *)dst_nullbits, idx, n, (uint64_t)value_bits, set_null);
 	return MIDORIDB_OK;
