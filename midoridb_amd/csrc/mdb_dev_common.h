@@ -54,6 +54,9 @@ struct mdb_dev_ctx {
 	int gh_uses;
 	int sr_uses, nh_uses;		/* remembered verdicts expire after a few uses: the same buffer may hold other data by then */
 	int nh_distrust;		/* > 0: a remembered "narrow" just proved wrong (buffer reused for other data): sample again for a while */
+	const void *ex_keys;		/* left key column (and the two row counts) whose histogram-free partition layout overflowed last time: */
+	uint64_t ex_nl, ex_nr;		/* the exact layout at once, for a few uses (a failed attempt costs a whole partition pass) */
+	int ex_uses;
 	const void *pw_bad_keys;	/* right key column (and row count) the one-level unique-key join (join_pairs_unique_wide) gave up on */
 	uint64_t pw_bad_n;
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */

@@ -328,6 +328,8 @@ static void mdb_hints_drop(mdb_dev_ctx *ctx, const void *lo, size_t bytes)
 		ctx->sr_valid = 0;
 	if (hit(ctx->gh_keys))
 		ctx->gh_keys = NULL;
+	if (hit(ctx->ex_keys))
+		ctx->ex_keys = NULL;
 	if (hit(ctx->pw_bad_keys))
 		ctx->pw_bad_keys = NULL;
 	if (hit(ctx->pu_dup_keys))

@@ -2878,6 +2878,11 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		base = 0;
 	}
 	win.fast1 = fast1;
+	/* the histogram-free layout overflowed on these very columns last time (skewed or heavily duplicated keys): exact at once */
+	if (fast && ctx->ex_keys == keys_l && ctx->ex_nl == n_l && ctx->ex_nr == (has_r ? n_r : 0) && ++ctx->ex_uses < GC_HINT_USES) {
+		fast = false;
+		win.fast1 = false;
+	}
 	for (int attempt = 0; attempt < 6; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
 				     base, win, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
@@ -2896,6 +2901,10 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		} else if (rc == GC_RETRY_EXACT) {
 			fast = false;
 			win.fast1 = false;
+			ctx->ex_keys = keys_l;
+			ctx->ex_nl = n_l;
+			ctx->ex_nr = has_r ? n_r : 0;
+			ctx->ex_uses = 0;
 		}	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
