@@ -81,7 +81,12 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
-/* ------------------------------------------------------------------ memory */
+/* ------------------------------------------------------------------ memory
+ * The join / GROUP BY operators remember what they learned about a key column (sampled range, key form, duplicate flags) by
+ * the column's device address and length, for a few uses.  Every remembered verdict is verified on the device - a stale one
+ * costs a failed attempt, never a result -, and the library drops what it knows about a buffer that is released
+ * (mdb_dev_free), uploaded into (mdb_dev_h2d) or updated (mdb_dev_scatter_set64).  A caller that rewrites a column in place
+ * by other means (its own kernels) pays at most a few slower calls. */
 int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr);
 int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr);
 int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes);
