@@ -113,6 +113,52 @@ int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const ui
 /* rows of L this rank received in the last call (what `cap` has to cover), 0 before the first */
 uint64_t mdb_dist_last_received_left(const mdb_dist *d);
 
+/* ------------------------------------------------------------------ sharded joins that materialise rows
+ *
+ * What the reference's one entry point does for ANY join (_join_nested_loop_tbl2tbl, reference
+ * src/engine/executor_select.c:1076-1149; recursive form :1151-1280) when the tables are spread over the ranks: the rows
+ * of a table (or of a joined tuple stream) are re-distributed so that every row lands on the rank its join key hashes to
+ * (dest = the same hash mdb_dev_partition_by_dest uses), payload columns travelling with the key; the join itself is then
+ * the single-GPU operator on what arrived.  BASELINE configs[3] (10^9-row INNER JOIN over 8 GPUs) and configs[4]
+ * (three-way join with DOUBLE payload) run through these two functions; query_execute() in sharded mode uses
+ * mdb_dist_shuffle_rows() for every join, GROUP BY and DISTINCT whose rows are not yet where their key hashes to.
+ *
+ * A column of the stream: 8-byte cells (INT64 values or the bits of a DOUBLE - moved as opaque words), optional NULL
+ * bits, read for stream position k at row rid[k] (rid == NULL: row k) - the tuple-stream convention of mdb_dev.h. */
+struct mdb_dist_col {
+	const void *values;
+	const uint64_t *nullbits;	/* or NULL */
+	const uint32_t *rid;		/* or NULL = identity */
+};
+#define MDB_DIST_SHUFFLE_MAX_COLS 64
+/* rows whose key is NULL are not dropped but all sent to one rank (GROUP BY / DISTINCT: NULL keys form one group,
+ * reference executor_select.c:1477-1482); without it they stay home and vanish, as a NULL key joins nothing (:557-579) */
+#define MDB_DIST_KEEP_NULL_KEYS 1u
+/* return as soon as the transfers are posted: the outputs may be passed to operators on the context's stream only after
+ * mdb_dist_wait_transfers() - lets the next table's partitioning overlap this table's transfers */
+#define MDB_DIST_NO_WAIT 2u
+
+/* keys[n] (with key_nulls) are the stream's partitioning key; cols[0..ncols) the columns to carry (the key column itself
+ * among them when the caller wants it back).  out_values[c] / out_nullbits[c]: device buffers allocated by the call
+ * (mdb_dev_free), *out_n rows each, in the order (source rank, position in that rank's send order); out_nullbits[c] is NULL
+ * when column c has no NULL bits on ANY rank.  At most MDB_DIST_SHUFFLE_MAX_COLS columns.  Collective; one host
+ * synchronisation (the counts).  A failure on one rank (allocation, a bad argument) is agreed on with the counts: every rank
+ * returns an error, none is left waiting in a collective. */
+int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uint64_t *key_nulls, uint64_t n, uint32_t flags,
+			  const struct mdb_dist_col *cols, int ncols, void **out_values, uint64_t **out_nullbits, uint64_t *out_n);
+int mdb_dist_wait_transfers(mdb_dist *d);
+
+/* SELECT ... FROM L INNER JOIN R ON l.key = r.key over sharded tables: both tables are shuffled by their key (L's transfers
+ * overlap R's partitioning), joined locally with mdb_dev_join_pairs and projected with mdb_dev_gather_cols.  Output (device
+ * buffers allocated by the call, *out_rows rows each - the joined rows whose key hashes to this rank, in (received left
+ * row, received right row) order): *out_key = the join key of every joined row (both sides hold the same value; pass
+ * NULL when not wanted), out_l[c] / out_l_nulls[c] = column c of cols_l, out_r[c] / out_r_nulls[c] = column c of cols_r.
+ * Collective and synchronous. */
+int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dist_col *cols_l,
+			int ncols_l, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, const struct mdb_dist_col *cols_r,
+			int ncols_r, int64_t **out_key, void **out_l, uint64_t **out_l_nulls, void **out_r, uint64_t **out_r_nulls,
+			uint64_t *out_rows);
+
 /* helpers for hosts without a collective library of their own */
 int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n);
 int mdb_dist_barrier(mdb_dist *d);

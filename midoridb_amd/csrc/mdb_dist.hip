@@ -22,6 +22,8 @@
 #include "mdb_dev_internal.h"
 #include "mdb_dist.h"
 
+#define SH_MAX_PENDING 1024
+
 struct mdb_dist {
 	mdb_dev_ctx *ctx;
 	int world, rank;
@@ -36,6 +38,11 @@ struct mdb_dist {
 	void *send[2], *recv[2];
 	uint64_t send_cap[2], recv_cap[2];	/* in 8-byte words */
 	uint64_t last_recv_left;
+	/* row shuffles (mdb_dist_shuffle_rows): buffers the posted transfers still read - released by mdb_dist_wait_transfers() */
+	hipEvent_t ev_sh;
+	bool sh_posted;
+	void *pend[SH_MAX_PENDING];
+	int npend;
 	char err[512];
 };
 
@@ -208,7 +215,8 @@ static int dist_new(mdb_dev_ctx *ctx, int world, int rank, mdb_dist **out)
 	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->ev_a, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->ev_b, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&d->ev_b, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_sh, hipEventDisableTiming) != hipSuccess) {
 		mdb_dist_destroy(d);
 		return -MIDORIDB_INTERNAL;
 	}
@@ -325,6 +333,10 @@ extern "C" void mdb_dist_destroy(mdb_dist *d)
 		(void)hipEventDestroy(d->ev_a);
 	if (d->ev_b)
 		(void)hipEventDestroy(d->ev_b);
+	if (d->ev_sh)
+		(void)hipEventDestroy(d->ev_sh);
+	for (int i = 0; i < d->npend; i++)
+		(void)mdb_dev_free(d->ctx, d->pend[i]);
 	if (d->comm_stream)
 		(void)hipStreamDestroy(d->comm_stream);
 	free(d);
@@ -590,4 +602,502 @@ extern "C" int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_
 		return -MIDORIDB_ERROR;
 	return dist_join_impl(d, keys_l, null_l, n_l, keys_r, null_r, n_r, (flags & MDB_DIST_LEFT_IN_PLACE) != 0, true, out_key, out_count, out_first,
 			      0, out_groups, out_joined);
+}
+
+/* ------------------------------------------------------------------ row shuffles: keys + payload columns
+ *
+ * The materialising joins of the path (reference executor_select.c:1076-1149, 1151-1280) over sharded tables: every row
+ * travels to the rank its key hashes to, with the columns the statement reads.  Per shuffle: ONE destination partition of
+ * the key column (mdb_dev_partition_by_dest, which also returns every outgoing key's source position), ONE count
+ * exchange (rows per peer + which columns carry NULL bits + this rank's status: a rank that failed says so there and all
+ * ranks leave together), the columns gathered into send order in one launch per 16 columns (mdb_dev_gather_cols through
+ * the source positions), one uneven all-to-all per column on the transfer stream.  NULL bits of all columns travel as ONE
+ * extra 8-byte word per row (bit c = column c is NULL), only when some rank has a NULL bitmap at all. */
+
+#define SH_THREADS 256
+
+struct sh_null_src {
+	const uint64_t *nb[MDB_DIST_SHUFFLE_MAX_COLS];
+	const uint32_t *rid[MDB_DIST_SHUFFLE_MAX_COLS];
+};
+struct sh_null_dst {
+	uint64_t *bits[MDB_DIST_SHUFFLE_MAX_COLS];
+};
+
+static inline uint32_t sh_grid(uint64_t n)
+{
+	const uint64_t g = (n + SH_THREADS - 1) / SH_THREADS;
+	return (uint32_t)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+/* mask[i] = bit c set when column c of the row at send position i is NULL */
+__global__ __launch_bounds__(SH_THREADS) void k_nullmask_pack(sh_null_src s, uint64_t colmask, const uint32_t *__restrict__ pos, uint64_t m,
+							       uint64_t *__restrict__ mask)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x; i < m; i += (uint64_t)gridDim.x * SH_THREADS) {
+		const uint32_t p = pos[i];
+		uint64_t w = 0;
+		for (uint64_t cm = colmask; cm; cm &= cm - 1) {
+			const int c = __builtin_ctzll(cm);
+			const uint32_t row = s.rid[c] ? s.rid[c][p] : p;
+			if (mdb_bit_is_set(s.nb[c], row))
+				w |= 1ull << c;
+		}
+		mask[i] = w;
+	}
+}
+
+/* the received mask words back into one NULL bitmap per column (a wave per 64 rows: ballot) */
+__global__ __launch_bounds__(SH_THREADS) void k_nullmask_unpack(const uint64_t *__restrict__ mask, uint64_t n, uint64_t colmask, sh_null_dst d)
+{
+	const uint64_t nwords = (n + 63) / 64;
+	for (uint64_t w = ((uint64_t)blockIdx.x * SH_THREADS + threadIdx.x) >> 6; w < nwords; w += ((uint64_t)gridDim.x * SH_THREADS) >> 6) {
+		const uint64_t i = w * 64 + mdb_lane();
+		const uint64_t mw = i < n ? mask[i] : 0;
+		for (uint64_t cm = colmask; cm; cm &= cm - 1) {
+			const int c = __builtin_ctzll(cm);
+			const uint64_t word = __ballot((mw >> c) & 1);
+			if (mdb_lane() == 0)
+				d.bits[c][w] = word;
+		}
+	}
+}
+
+/* partitioning key of a shuffle that keeps its NULL-key rows: one fixed value under every NULL cell, so that they all
+ * hash to the same rank (whatever bytes an UPDATE ... SET col = NULL left there) */
+__global__ __launch_bounds__(SH_THREADS) void k_zero_null_keys(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nulls, uint64_t n,
+							        int64_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SH_THREADS)
+		out[i] = mdb_bit_is_set(nulls, i) ? 0 : keys[i];
+}
+
+static void sh_pend(mdb_dist *d, void *p)
+{
+	if (!p)
+		return;
+	if (d->npend < SH_MAX_PENDING)
+		d->pend[d->npend++] = p;
+	/* (cannot happen: a shuffle keeps at most 2 * MDB_DIST_SHUFFLE_MAX_COLS + 16 buffers and waits when the list is half full) */
+}
+
+extern "C" int mdb_dist_wait_transfers(mdb_dist *d)
+{
+	if (!d)
+		return -MIDORIDB_ERROR;
+	DIST_HIP(d, hipSetDevice(d->ctx->device));
+	if (d->sh_posted)
+		DIST_HIP(d, hipStreamWaitEvent(d->ctx->stream, d->ev_sh, 0));
+	d->sh_posted = false;
+	/* the send buffers go back to the context's cache: its reuse is ordered on the context's stream, behind the wait */
+	for (int i = 0; i < d->npend; i++)
+		(void)mdb_dev_free(d->ctx, d->pend[i]);
+	d->npend = 0;
+	return MIDORIDB_OK;
+}
+
+#define SH_COUNTERS 3	/* per peer: rows, columns that carry NULL bits, status */
+
+static const char *transport_err(mdb_dist *d)
+{
+	return d->own_transport ? ((rccl_transport *)d->t.self)->err : "";
+}
+
+extern "C" int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uint64_t *key_nulls, uint64_t n, uint32_t flags,
+				     const struct mdb_dist_col *cols, int ncols, void **out_values, uint64_t **out_nullbits, uint64_t *out_n)
+{
+	if (!d || !out_n || ncols < 0 || ncols > MDB_DIST_SHUFFLE_MAX_COLS || (ncols && (!cols || !out_values || !out_nullbits)) || (n && !keys))
+		return d ? dist_err(d, -MIDORIDB_ERROR, "shuffle_rows: bad arguments") : -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = d->ctx;
+	const int W = d->world;
+	*out_n = 0;
+	for (int c = 0; c < ncols; c++) {
+		out_values[c] = NULL;
+		out_nullbits[c] = NULL;
+	}
+	DIST_HIP(d, hipSetDevice(ctx->device));
+	if (d->npend > SH_MAX_PENDING / 2) {
+		int rc = mdb_dist_wait_transfers(d);
+		if (rc)
+			return rc;
+	}
+	uint64_t scnt[1 << MDB_MAX_RADIX_BITS], sendv[SH_COUNTERS << MDB_MAX_RADIX_BITS], recvv[SH_COUNTERS << MDB_MAX_RADIX_BITS];
+	size_t sc[1 << MDB_MAX_RADIX_BITS], sd[1 << MDB_MAX_RADIX_BITS], rcn[1 << MDB_MAX_RADIX_BITS], rd[1 << MDB_MAX_RADIX_BITS];
+	char local_err[384];
+	local_err[0] = 0;
+	int status = MIDORIDB_OK;
+
+	/* ---- 1. destination partition of the key column: send order + the source position of every outgoing row */
+	void *kbuf = NULL, *canon = NULL;
+	uint32_t *pos = NULL;
+	for (int p = 0; p < W; p++)
+		scnt[p] = 0;
+	if (n >= 0xFFFFFFFFull) {
+		status = -MIDORIDB_ERROR;
+		snprintf(local_err, sizeof(local_err), "%llu rows exceed the 32-bit row-id limit of one shard", (unsigned long long)n);
+	}
+	if (!status && (mdb_dev_alloc(ctx, (n ? n : 1) * 8, &kbuf) || mdb_dev_alloc(ctx, (n ? n : 1) * 4, (void **)&pos))) {
+		status = -MIDORIDB_NOMEM;
+		snprintf(local_err, sizeof(local_err), "%s", mdb_dev_last_error(ctx));
+	}
+	const int64_t *pkeys = keys;
+	const uint64_t *pnulls = key_nulls;
+	if (!status && n && (flags & MDB_DIST_KEEP_NULL_KEYS) && key_nulls) {
+		if (mdb_dev_alloc(ctx, n * 8, &canon)) {
+			status = -MIDORIDB_NOMEM;
+			snprintf(local_err, sizeof(local_err), "%s", mdb_dev_last_error(ctx));
+		} else {
+			hipLaunchKernelGGL(k_zero_null_keys, dim3(sh_grid(n)), dim3(SH_THREADS), 0, ctx->stream, keys, key_nulls, n, (int64_t *)canon);
+			pkeys = (const int64_t *)canon;
+			pnulls = NULL;
+		}
+	}
+	if (!status && n) {
+		status = mdb_dev_partition_by_dest(ctx, pkeys, pnulls, n, (uint32_t)W, 0, kbuf, pos, scnt);	/* (synchronises) */
+		if (status) {
+			snprintf(local_err, sizeof(local_err), "partition by destination: %s", mdb_dev_last_error(ctx));
+			for (int p = 0; p < W; p++)
+				scnt[p] = 0;
+		}
+	}
+
+	/* ---- 2. counts + NULL-carrying columns + status: every rank gets here, whatever happened to it so far */
+	uint64_t colmask = 0;
+	for (int c = 0; c < ncols; c++)
+		if (cols[c].nullbits)
+			colmask |= 1ull << c;
+	for (int p = 0; p < W; p++) {
+		sendv[SH_COUNTERS * p] = scnt[p];
+		sendv[SH_COUNTERS * p + 1] = colmask;
+		sendv[SH_COUNTERS * p + 2] = status ? 1 : 0;
+	}
+	int rc = d->t.counts(d->t.self, sendv, recvv, SH_COUNTERS);
+	if (rc) {
+		(void)mdb_dev_free(ctx, kbuf);
+		(void)mdb_dev_free(ctx, pos);
+		(void)mdb_dev_free(ctx, canon);
+		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	}
+	uint64_t total = 0, m = 0, gmask = 0;
+	int failed_rank = -1;
+	for (int p = 0; p < W; p++) {
+		sc[p] = (size_t)scnt[p];
+		sd[p] = (size_t)m;
+		rcn[p] = (size_t)recvv[SH_COUNTERS * p];
+		rd[p] = (size_t)total;
+		m += scnt[p];
+		total += recvv[SH_COUNTERS * p];
+		gmask |= recvv[SH_COUNTERS * p + 1];
+		if (recvv[SH_COUNTERS * p + 2] && failed_rank < 0)
+			failed_rank = p;
+	}
+	if (failed_rank < 0 && total >= 0xFFFFFFFFull) {	/* (every rank sees its own total: agree on it the hard way - it is an error everywhere or nowhere) */
+		status = -MIDORIDB_ERROR;
+		snprintf(local_err, sizeof(local_err), "%llu rows for one GPU shard exceed the 32-bit row-id limit", (unsigned long long)total);
+	}
+	if (failed_rank >= 0 || status) {
+		(void)mdb_dev_free(ctx, kbuf);
+		(void)mdb_dev_free(ctx, pos);
+		(void)mdb_dev_free(ctx, canon);
+		if (status)
+			return dist_err(d, status, "shuffle: %s", local_err);
+		return dist_err(d, -MIDORIDB_ERROR, "shuffle: rank %d failed (its own message says why); nothing was exchanged", failed_rank);
+	}
+
+	/* ---- 3. the columns in send order, receive buffers */
+	void *send[MDB_DIST_SHUFFLE_MAX_COLS + 1], *comp[MDB_GATHER_MAX_RIDS];
+	const uint32_t *comp_of[MDB_GATHER_MAX_RIDS];
+	int ncomp = 0;
+	void *send_mask = NULL, *recv_mask = NULL;
+	bool key_buf_used = false;
+	rc = MIDORIDB_OK;
+	for (int c = 0; c <= MDB_DIST_SHUFFLE_MAX_COLS; c++)
+		send[c] = NULL;
+	struct mdb_gather_col gl[MDB_GATHER_MAX_COLS];
+	int ngl = 0, nrid_in_batch = 0;
+	const uint32_t *batch_rids[MDB_GATHER_MAX_RIDS];
+	for (int c = 0; c < ncols && !rc; c++) {
+		rc = mdb_dev_alloc(ctx, (total ? total : 1) * 8, &out_values[c]);
+		if (rc)
+			break;
+		if (gmask >> c & 1) {
+			rc = mdb_dev_alloc(ctx, ((total + 63) / 64 + 1) * 8, (void **)&out_nullbits[c]);
+			if (rc)
+				break;
+		}
+		if (!m)
+			continue;
+		if (cols[c].values == (const void *)keys && !cols[c].rid && !key_buf_used) {
+			send[c] = kbuf;		/* the key column itself: the partition wrote it in send order already */
+			key_buf_used = true;
+			continue;
+		}
+		const uint32_t *idx = pos;
+		if (cols[c].rid) {		/* stream position -> row of the base column: composed once per row-id vector */
+			int k = 0;
+			while (k < ncomp && comp_of[k] != cols[c].rid)
+				k++;
+			if (k == ncomp) {
+				if (ncomp == MDB_GATHER_MAX_RIDS) {
+					rc = -MIDORIDB_ERROR;
+					mdb_set_err(ctx, rc, "more than %d row-id vectors in one shuffle", MDB_GATHER_MAX_RIDS);
+					break;
+				}
+				rc = mdb_dev_alloc(ctx, m * 4, &comp[ncomp]);
+				if (!rc)
+					rc = mdb_dev_gather32(ctx, cols[c].rid, pos, m, (uint32_t *)comp[ncomp]);
+				if (rc)
+					break;
+				comp_of[ncomp++] = cols[c].rid;
+			}
+			idx = (const uint32_t *)comp[k];
+		}
+		rc = mdb_dev_alloc(ctx, m * 8, &send[c]);
+		if (rc)
+			break;
+		int t = 0;
+		while (t < nrid_in_batch && batch_rids[t] != idx)
+			t++;
+		if (ngl == MDB_GATHER_MAX_COLS || (t == nrid_in_batch && nrid_in_batch == MDB_GATHER_MAX_RIDS)) {
+			rc = mdb_dev_gather_cols(ctx, gl, ngl, m);
+			ngl = nrid_in_batch = 0;
+			t = 0;
+			if (rc)
+				break;
+		}
+		if (t == nrid_in_batch)
+			batch_rids[nrid_in_batch++] = idx;
+		gl[ngl].src = cols[c].values;
+		gl[ngl].src_nullbits = NULL;
+		gl[ngl].rid = idx;
+		gl[ngl].dst = send[c];
+		gl[ngl].dst_nullbits = NULL;
+		ngl++;
+	}
+	if (!rc && ngl)
+		rc = mdb_dev_gather_cols(ctx, gl, ngl, m);
+	if (!rc && gmask) {
+		rc = mdb_dev_alloc(ctx, (m ? m : 1) * 8, &send_mask);
+		if (!rc)
+			rc = mdb_dev_alloc(ctx, (total ? total : 1) * 8, &recv_mask);
+		if (!rc && m) {
+			if (colmask) {
+				sh_null_src s;
+				memset(&s, 0, sizeof(s));
+				for (int c = 0; c < ncols; c++) {
+					s.nb[c] = cols[c].nullbits;
+					s.rid[c] = cols[c].rid;
+				}
+				hipLaunchKernelGGL(k_nullmask_pack, dim3(sh_grid(m)), dim3(SH_THREADS), 0, ctx->stream, s, colmask, pos, m, (uint64_t *)send_mask);
+			} else {
+				rc = mdb_dev_memset(ctx, send_mask, 0, m * 8);
+			}
+		}
+	}
+	if (rc) {
+		/* a failure past the count exchange (allocation): the peers are about to post their transfers.  Nothing sane is
+		 * left but to post ours from whatever buffers exist - so the buffers are checked BEFORE anything is posted and the
+		 * failure is reported through the collective that follows */
+		snprintf(local_err, sizeof(local_err), "%s", mdb_dev_last_error(ctx));
+	}
+	{
+		/* second agreement (one word per peer): did every rank get its buffers?  Costs one tiny exchange; without it an
+		 * allocation failure on one rank would leave the others inside the all-to-all */
+		for (int p = 0; p < W; p++)
+			sendv[p] = rc ? 1 : 0;
+		int rc2 = d->t.counts(d->t.self, sendv, recvv, 1);
+		bool any = rc2 != 0;
+		for (int p = 0; p < W && !rc2; p++)
+			any = any || recvv[p] != 0;
+		if (any) {
+			for (int c = 0; c < ncols; c++) {
+				(void)mdb_dev_free(ctx, out_values[c]);
+				(void)mdb_dev_free(ctx, out_nullbits[c]);
+				out_values[c] = NULL;
+				out_nullbits[c] = NULL;
+				if (send[c] && send[c] != kbuf)
+					(void)mdb_dev_free(ctx, send[c]);
+			}
+			for (int k = 0; k < ncomp; k++)
+				(void)mdb_dev_free(ctx, comp[k]);
+			(void)mdb_dev_free(ctx, send_mask);
+			(void)mdb_dev_free(ctx, recv_mask);
+			(void)mdb_dev_free(ctx, kbuf);
+			(void)mdb_dev_free(ctx, pos);
+			(void)mdb_dev_free(ctx, canon);
+			if (rc2)
+				return dist_err(d, rc2, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+			if (rc)
+				return dist_err(d, rc, "shuffle: %s", local_err);
+			return dist_err(d, -MIDORIDB_ERROR, "shuffle: another rank could not allocate its buffers; nothing was exchanged");
+		}
+	}
+
+	/* ---- 4. transfers, on the transfer stream behind everything queued so far on the context's stream */
+	DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
+	DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
+	for (int c = 0; c < ncols; c++) {
+		rc = d->t.alltoallv(d->t.self, send[c] ? send[c] : kbuf, sc, sd, out_values[c], rcn, rd, 8, d->comm_stream);
+		if (rc)
+			return dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	}
+	if (gmask) {
+		rc = d->t.alltoallv(d->t.self, send_mask, sc, sd, recv_mask, rcn, rd, 8, d->comm_stream);
+		if (rc)
+			return dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+		sh_null_dst dst;
+		memset(&dst, 0, sizeof(dst));
+		for (int c = 0; c < ncols; c++)
+			dst.bits[c] = out_nullbits[c];
+		/* (on the transfer stream, right behind the mask's arrival) */
+		hipLaunchKernelGGL(k_nullmask_unpack, dim3(sh_grid(total ? total : 1)), dim3(SH_THREADS), 0, d->comm_stream, (const uint64_t *)recv_mask, total,
+				   gmask & (ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull)), dst);
+	}
+	DIST_HIP(d, hipEventRecord(d->ev_sh, d->comm_stream));
+	d->sh_posted = true;
+	for (int c = 0; c < ncols; c++)
+		if (send[c] && send[c] != kbuf)
+			sh_pend(d, send[c]);
+	for (int k = 0; k < ncomp; k++)
+		sh_pend(d, comp[k]);
+	sh_pend(d, send_mask);
+	sh_pend(d, recv_mask);
+	sh_pend(d, kbuf);
+	sh_pend(d, pos);
+	sh_pend(d, canon);
+	*out_n = total;
+	if (!(flags & MDB_DIST_NO_WAIT))
+		return mdb_dist_wait_transfers(d);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dist_col *cols_l,
+				   int ncols_l, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, const struct mdb_dist_col *cols_r,
+				   int ncols_r, int64_t **out_key, void **out_l, uint64_t **out_l_nulls, void **out_r, uint64_t **out_r_nulls,
+				   uint64_t *out_rows)
+{
+	if (!d || !out_rows || ncols_l < 0 || ncols_r < 0 || ncols_l >= MDB_DIST_SHUFFLE_MAX_COLS || ncols_r >= MDB_DIST_SHUFFLE_MAX_COLS ||
+	    (ncols_l && (!cols_l || !out_l || !out_l_nulls)) || (ncols_r && (!cols_r || !out_r || !out_r_nulls)))
+		return d ? dist_err(d, -MIDORIDB_ERROR, "join_pairs: bad arguments") : -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = d->ctx;
+	*out_rows = 0;
+	if (out_key)
+		*out_key = NULL;
+	/* column 0 of each shuffle = the key itself */
+	struct mdb_dist_col cl[MDB_DIST_SHUFFLE_MAX_COLS], cr[MDB_DIST_SHUFFLE_MAX_COLS];
+	void *vl[MDB_DIST_SHUFFLE_MAX_COLS], *vr[MDB_DIST_SHUFFLE_MAX_COLS];
+	uint64_t *bl[MDB_DIST_SHUFFLE_MAX_COLS], *br[MDB_DIST_SHUFFLE_MAX_COLS];
+	cl[0].values = keys_l;
+	cl[0].nullbits = NULL;	/* (rows with a NULL key stay home) */
+	cl[0].rid = NULL;
+	cr[0].values = keys_r;
+	cr[0].nullbits = NULL;
+	cr[0].rid = NULL;
+	for (int c = 0; c < ncols_l; c++)
+		cl[c + 1] = cols_l[c];
+	for (int c = 0; c < ncols_r; c++)
+		cr[c + 1] = cols_r[c];
+	uint64_t got_l = 0, got_r = 0, J = 0;
+	uint32_t *pl = NULL, *pr = NULL;
+	/* table L's transfers run while table R is partitioned and gathered */
+	int rc = mdb_dist_shuffle_rows(d, keys_l, null_l, n_l, MDB_DIST_NO_WAIT, cl, ncols_l + 1, vl, bl, &got_l);
+	int rc2 = mdb_dist_shuffle_rows(d, keys_r, null_r, n_r, MDB_DIST_NO_WAIT, cr, ncols_r + 1, vr, br, &got_r);	/* (collective: also after a failure) */
+	int rc3 = mdb_dist_wait_transfers(d);
+	if (!rc)
+		rc = rc2 ? rc2 : rc3;
+	if (rc) {	/* (a failed shuffle has released its own outputs and left NULLs behind) */
+		for (int c = 0; c <= ncols_l; c++) {
+			(void)mdb_dev_free(ctx, vl[c]);
+			(void)mdb_dev_free(ctx, bl[c]);
+		}
+		for (int c = 0; c <= ncols_r; c++) {
+			(void)mdb_dev_free(ctx, vr[c]);
+			(void)mdb_dev_free(ctx, br[c]);
+		}
+		return rc;
+	}
+	d->last_recv_left = got_l;
+	if (got_l && got_r) {
+		rc = mdb_dev_join_pairs(ctx, (const int64_t *)vl[0], NULL, got_l, (const int64_t *)vr[0], NULL, got_r, &pl, &pr, &J);
+		if (rc)
+			dist_err(d, rc, "local join: %s", mdb_dev_last_error(ctx));
+	}
+	/* projection: every output column of the joined rows in one launch per 16 */
+	struct mdb_gather_col gl[MDB_GATHER_MAX_COLS];
+	int ngl = 0;
+	const int nout = (out_key ? 1 : 0) + ncols_l + ncols_r;
+	for (int o = 0; o < nout && !rc; o++) {
+		const bool is_key = out_key && o == 0;
+		const int k = o - (out_key ? 1 : 0);
+		const bool left = is_key || k < ncols_l;
+		const int c = is_key ? 0 : (left ? k + 1 : k - ncols_l + 1);
+		void *dst = NULL;
+		uint64_t *dnb = NULL;
+		const uint64_t *snb = left ? bl[c] : br[c];
+		rc = mdb_dev_alloc(ctx, (J ? J : 1) * 8, &dst);
+		if (!rc && snb && !is_key)
+			rc = mdb_dev_alloc(ctx, ((J + 63) / 64 + 1) * 8, (void **)&dnb);
+		if (is_key)
+			*out_key = (int64_t *)dst;
+		else if (left) {
+			out_l[k] = dst;
+			out_l_nulls[k] = dnb;
+		} else {
+			out_r[k - ncols_l] = dst;
+			out_r_nulls[k - ncols_l] = dnb;
+		}
+		if (rc) {
+			dist_err(d, rc, "allocating the joined columns: %s", mdb_dev_last_error(ctx));
+			break;
+		}
+		if (!J)
+			continue;
+		if (ngl == MDB_GATHER_MAX_COLS) {
+			rc = mdb_dev_gather_cols(ctx, gl, ngl, J);
+			ngl = 0;
+			if (rc) {
+				dist_err(d, rc, "projection: %s", mdb_dev_last_error(ctx));
+				break;
+			}
+		}
+		gl[ngl].src = left ? vl[c] : vr[c];
+		gl[ngl].src_nullbits = is_key ? NULL : snb;
+		gl[ngl].rid = left ? pl : pr;
+		gl[ngl].dst = dst;
+		gl[ngl].dst_nullbits = dnb;
+		ngl++;
+	}
+	if (!rc && ngl && (rc = mdb_dev_gather_cols(ctx, gl, ngl, J)))
+		dist_err(d, rc, "projection: %s", mdb_dev_last_error(ctx));
+	for (int c = 0; c <= ncols_l; c++) {
+		(void)mdb_dev_free(ctx, vl[c]);
+		(void)mdb_dev_free(ctx, bl[c]);
+	}
+	for (int c = 0; c <= ncols_r; c++) {
+		(void)mdb_dev_free(ctx, vr[c]);
+		(void)mdb_dev_free(ctx, br[c]);
+	}
+	(void)mdb_dev_free(ctx, pl);
+	(void)mdb_dev_free(ctx, pr);
+	if (rc) {
+		if (out_key) {
+			(void)mdb_dev_free(ctx, *out_key);
+			*out_key = NULL;
+		}
+		for (int k = 0; k < ncols_l; k++) {
+			(void)mdb_dev_free(ctx, out_l[k]);
+			(void)mdb_dev_free(ctx, out_l_nulls[k]);
+			out_l[k] = NULL;
+			out_l_nulls[k] = NULL;
+		}
+		for (int k = 0; k < ncols_r; k++) {
+			(void)mdb_dev_free(ctx, out_r[k]);
+			(void)mdb_dev_free(ctx, out_r_nulls[k]);
+			out_r[k] = NULL;
+			out_r_nulls[k] = NULL;
+		}
+		return rc;
+	}
+	*out_rows = J;
+	return mdb_dev_sync(ctx) ? dist_err(d, -MIDORIDB_INTERNAL, "%s", mdb_dev_last_error(ctx)) : MIDORIDB_OK;
 }

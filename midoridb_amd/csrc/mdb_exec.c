@@ -588,6 +588,14 @@ struct exec {
 	 * (INT64-represented types: the join compared all 64 bits; never NULL - a NULL key joins nothing): the projection reads
 	 * that column, through the earlier table's row ids (ascending after a join: near-sequential reads instead of a random gather) */
 	int same_col[MDB_MAX_TABS], same_as_tbl[MDB_MAX_TABS], same_as_col[MDB_MAX_TABS];
+	/* sharded mode (cat->dist): a FROM table whose rows were exchanged is read through a SHADOW table - the same schema over the
+	 * columns this rank received - that stands in s->tabs[t].t for the rest of the statement (orig_tab[] puts the catalog's
+	 * tables back at the end).  part[]: the fields whose value the current stream is hash-partitioned by (all equal in every
+	 * tuple: the equi-join keys tied together so far); need[t][c]: the statement reads column c of table t */
+	struct mdb_table *shadow[MDB_MAX_TABS], *orig_tab[MDB_MAX_TABS];
+	const struct mdb_expr *part[2 * MDB_MAX_TABS];
+	int npart;
+	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
 };
 
 static int dev_fail(struct exec *x, const char *what)
@@ -704,6 +712,167 @@ static int double_join_keys(struct exec *x, const struct mdb_column *col, const 
 	*vals = v;
 	*nulls = nb;
 	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ sharded mode: row exchange
+ *
+ * One process per GPU, every process holds ITS rows of every table (include/mdb_dist.h).  The general plan stays what it
+ * is - the reference's phases, executor_select.c:1655-1744 - and gains ONE step: before an operator that must see all the
+ * rows of a key together (equi-join, GROUP BY, DISTINCT), the tuple stream is re-distributed so that every row lands on
+ * the rank its key hashes to (mdb_dist_shuffle_rows: key + the columns the statement still reads), unless it already is
+ * (x->part: the join keys tied together so far).  What arrives replaces the table for the rest of the statement. */
+
+static void mark_needed(struct exec *x, const struct mdb_expr *e)
+{
+	if (!e)
+		return;
+	if (e->kind == MDB_EX_FIELD && e->tbl_idx >= 0 && e->tbl_idx < MDB_MAX_TABS && e->col_idx >= 0 && e->col_idx < MDB_MAX_COLS)
+		x->need[e->tbl_idx][e->col_idx] = true;
+	for (int i = 0; i < e->nkids; i++)
+		mark_needed(x, e->kids[i]);
+}
+
+static void mark_needed_all(struct exec *x)
+{
+	const struct mdb_select *s = x->s;
+	for (int i = 0; i < s->nsel; i++)
+		mark_needed(x, s->sel[i]);
+	if (s->select_all)
+		for (int t = 0; t < s->ntabs; t++)
+			for (int c = 0; c < s->tabs[t].t->ncols; c++)
+				x->need[t][c] = true;
+	for (int t = 1; t < s->ntabs; t++)
+		mark_needed(x, s->on[t]);
+	mark_needed(x, s->where);
+	for (int g = 0; g < s->ngroup; g++)
+		mark_needed(x, s->group[g]);
+	mark_needed(x, s->having);
+	for (int o = 0; o < s->norder; o++)
+		mark_needed(x, s->order[o]);
+}
+
+static bool in_part(const struct exec *x, const struct mdb_expr *f)
+{
+	for (int i = 0; i < x->npart; i++)
+		if (x->part[i]->tbl_idx == f->tbl_idx && x->part[i]->col_idx == f->col_idx)
+			return true;
+	return false;
+}
+
+/* Tables tabs[0..nt) share one tuple stream of n tuples, table tabs[i] read through rid_of[i] (NULL = identity); kv / kn is
+ * the stream's partitioning key.  Afterwards each of those tables is a shadow over the rows this rank received, *n_out of
+ * them, all read by identity.  Collective: every rank calls it for the same statement at the same point. */
+static int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of, uint64_t n, const int64_t *kv, const uint64_t *kn,
+		      uint32_t flags, uint64_t *n_out)
+{
+	struct mdb_select *s = x->s;
+	struct mdb_dist_col cols[MDB_DIST_SHUFFLE_MAX_COLS];
+	int col_i[MDB_DIST_SHUFFLE_MAX_COLS], col_c[MDB_DIST_SHUFFLE_MAX_COLS], nc = 0;
+	void *ov[MDB_DIST_SHUFFLE_MAX_COLS];
+	uint64_t *on[MDB_DIST_SHUFFLE_MAX_COLS];
+	uint64_t got = 0;
+
+	for (int i = 0; i < nt; i++) {
+		const struct mdb_table *tb = s->tabs[tabs[i]].t;
+		for (int c = 0; c < tb->ncols; c++) {
+			if (!x->need[tabs[i]][c])
+				continue;
+			if (tb->cols[c].type == MDB_CT_VARCHAR) {
+				snprintf(x->err, x->errlen, "execution phase: sharded mode: VARCHAR column %s.%s cannot travel between the ranks (its cells are "
+							    "ids of this process's string dictionary)\n", tb->name, tb->cols[c].name);
+				return -MIDORIDB_ERROR;
+			}
+			if (nc == MDB_DIST_SHUFFLE_MAX_COLS) {
+				snprintf(x->err, x->errlen, "execution phase: sharded mode: more than %d columns in one exchange\n", MDB_DIST_SHUFFLE_MAX_COLS);
+				return -MIDORIDB_ERROR;
+			}
+			cols[nc].values = tb->cols[c].d_data;
+			cols[nc].nullbits = tb->cols[c].d_nullbits;
+			cols[nc].rid = rid_of[i];
+			col_i[nc] = i;
+			col_c[nc] = c;
+			nc++;
+		}
+	}
+	if (mdb_dist_shuffle_rows(x->cat->dist, kv, kn, n, flags, cols, nc, ov, on, &got)) {
+		snprintf(x->err, x->errlen, "execution phase: sharded exchange: %s\n", mdb_dist_last_error(x->cat->dist));
+		return -MIDORIDB_INTERNAL;
+	}
+	for (int k = 0; k < nc; k++)
+		if (track(x, ov[k]) || (on[k] && track(x, on[k])))
+			return -MIDORIDB_NOMEM;
+	for (int i = 0; i < nt; i++) {
+		const int t = tabs[i];
+		const struct mdb_table *tb = s->tabs[t].t;
+		struct mdb_table *sh = calloc(1, sizeof(*sh));
+		if (!sh)
+			return -MIDORIDB_NOMEM;
+		memcpy(sh->name, tb->name, sizeof(sh->name));
+		sh->ncols = tb->ncols;
+		for (int c = 0; c < tb->ncols; c++) {
+			memcpy(sh->cols[c].name, tb->cols[c].name, sizeof(sh->cols[c].name));
+			sh->cols[c].type = tb->cols[c].type;
+			sh->cols[c].precision = tb->cols[c].precision;
+			sh->cols[c].not_null = tb->cols[c].not_null;
+		}
+		for (int k = 0; k < nc; k++)
+			if (col_i[k] == i) {
+				sh->cols[col_c[k]].d_data = ov[k];
+				sh->cols[col_c[k]].d_nullbits = on[k];
+			}
+		sh->nrows = sh->dev_rows = got;
+		sh->dev_cap = got ? got : 1;
+		sh->device_only = true;
+		if (!x->orig_tab[t])
+			x->orig_tab[t] = s->tabs[t].t;
+		free(x->shadow[t]);
+		x->shadow[t] = sh;
+		s->tabs[t].t = sh;
+	}
+	*n_out = got;
+	return MIDORIDB_OK;
+}
+
+/* the current stream (tables 0..nt-1) partitioned by field f: afterwards every rank holds the tuples whose f hashes to it */
+static int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flags)
+{
+	int tabs[MDB_MAX_TABS];
+	uint32_t *rids[MDB_MAX_TABS];
+	const int64_t *kv;
+	const uint64_t *kn;
+	const void *dv;
+	uint64_t got = 0;
+	int rc;
+	if (f->type == MDB_CT_DOUBLE && !(flags & MDB_DIST_KEEP_NULL_KEYS)) {	/* a join key: -0.0 meets +0.0, NaN meets nothing */
+		if ((rc = double_join_keys(x, &x->s->tabs[f->tbl_idx].t->cols[f->col_idx], x->rid[f->tbl_idx], x->n, &dv, &kn)))
+			return rc;
+		kv = dv;
+	} else if ((rc = stream_column(x, f, &kv, &kn))) {
+		return rc;
+	}
+	for (int t = 0; t < nt; t++) {
+		tabs[t] = t;
+		rids[t] = x->rid[t];
+	}
+	if ((rc = shard_rows(x, tabs, nt, rids, x->n, kv, kn, flags, &got)))
+		return rc;
+	for (int t = 0; t < nt; t++)
+		x->rid[t] = NULL;
+	x->n = got;
+	x->npart = 0;
+	x->part[x->npart++] = f;
+	return MIDORIDB_OK;
+}
+
+static void shard_cleanup(struct exec *x)
+{
+	for (int t = 0; t < MDB_MAX_TABS; t++) {
+		if (x->orig_tab[t])
+			x->s->tabs[t].t = x->orig_tab[t];
+		free(x->shadow[t]);
+		x->shadow[t] = NULL;
+		x->orig_tab[t] = NULL;
+	}
 }
 
 /* ------------------------------------------------------------------ predicate compiler */
@@ -1064,6 +1233,33 @@ static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *
 	uint64_t r_rows = rt->nrows;
 	if ((rc = table_filter(x, t, pconj, npconj, &rsel, &r_rows)))
 		return rc;
+	if (x->cat->dist) {
+		/* sharded mode: both sides go where their join key hashes to - the left stream unless it already is there (joined on
+		 * this key before), the new table always (its rows that passed its own WHERE conjuncts at home) */
+		if (key < 0) {
+			snprintf(x->err, x->errlen, "execution phase: sharded mode (MIDORIDB_WORLD_SIZE): a join needs an equi-join key in its ON clause "
+						    "(l.col = r.col) to be exchanged between the ranks; this one would only see local rows\n");
+			return -MIDORIDB_ERROR;
+		}
+		if (!in_part(x, kl) && (rc = shard_stream(x, t, kl, 0)))
+			return rc;
+		{
+			const void *kv;
+			const uint64_t *kn;
+			const int tabs1[1] = { t };
+			uint32_t *rids1[1] = { (uint32_t *)rsel };
+			if (kr->type == MDB_CT_DOUBLE)
+				rc = double_join_keys(x, &rt->cols[kr->col_idx], rsel, r_rows, &kv, &kn);
+			else
+				rc = table_column(x, t, kr, rsel, r_rows, &kv, &kn);
+			if (rc || (rc = shard_rows(x, tabs1, 1, rids1, r_rows, kv, kn, 0, &r_rows)))
+				return rc;
+			rsel = NULL;
+			rt = s->tabs[t].t;
+		}
+		if (x->npart < 2 * MDB_MAX_TABS)
+			x->part[x->npart++] = kr;
+	}
 	if (key >= 0) {
 		const int64_t *vl;
 		const uint64_t *nl;
@@ -1337,6 +1533,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	x.s = s;
 	x.err = err;
 	x.errlen = errlen;
+	if (cat->dist)
+		mark_needed_all(&x);
 
 	/* ---- result column set in the reference's order (R3): COUNT(*) first if selected, then every column
 	 *      of every FROM table left to right; projected afterwards to the select list */
@@ -1540,9 +1738,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		x.n = m;
 	} else {
 		/* ---- general plan */
-		if (cat->dist && s->ntabs > 1) {
-			ERR("execution phase: in sharded mode (MIDORIDB_WORLD_SIZE) only joins of the fused shape - JOIN ... ON l = r [JOIN ...] "
-			    "GROUP BY that key, COUNT(*) - are exchanged between the ranks; this join would only see local rows\n");
+		if (cat->dist && s->has_limit && s->limit_off > 0) {
+			ERR("execution phase: sharded mode: LIMIT with an offset cannot be answered from one rank's rows\n");
 			rc = -MIDORIDB_ERROR;
 			goto out;
 		}
@@ -1568,6 +1765,42 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				if ((rc = join_next_table(&x, t, NULL, 0)))
 					goto out;
 			if (s->where && (rc = stream_filter(&x, s->ntabs, s->where)))
+				goto out;
+		}
+		if (cat->dist && s->ngroup) {
+			/* sharded mode: a group's rows must meet on one rank - they do when the stream is partitioned by one of the group
+			 * fields (a join key); otherwise it is exchanged by the first one, NULL keys included (one group, :1477-1482) */
+			bool placed = false;
+			for (int g = 0; g < s->ngroup; g++)
+				placed = placed || in_part(&x, s->group[g]);
+			if (!placed && (rc = shard_stream(&x, s->ntabs, s->group[0], MDB_DIST_KEEP_NULL_KEYS)))
+				goto out;
+		}
+		if (cat->dist && s->distinct) {
+			/* ... and so must equal rows under DISTINCT */
+			bool placed = false;
+			const struct mdb_expr *by = NULL;
+			static __thread struct mdb_expr first_col;
+			for (int i = 0; i < s->nsel; i++)
+				if (s->sel[i]->kind == MDB_EX_FIELD) {
+					placed = placed || in_part(&x, s->sel[i]);
+					by = by ? by : s->sel[i];
+				}
+			if (s->select_all) {
+				placed = placed || x.npart > 0;
+				if (!by && s->tabs[0].t->ncols) {
+					memset(&first_col, 0, sizeof(first_col));
+					first_col.kind = MDB_EX_FIELD;
+					first_col.type = s->tabs[0].t->cols[0].type;
+					by = &first_col;
+				}
+			}
+			if (!placed && (s->ngroup || !by)) {
+				ERR("execution phase: sharded mode: DISTINCT over an aggregate alone cannot be answered from one rank's groups\n");
+				rc = -MIDORIDB_ERROR;
+				goto out;
+			}
+			if (!placed && (rc = shard_stream(&x, s->ntabs, by, MDB_DIST_KEEP_NULL_KEYS)))
 				goto out;
 		}
 		if (s->ngroup == 1) {
@@ -1621,6 +1854,26 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 	}
 
+	if (cat->dist && fused < 0 && has_count && !s->ngroup) {
+		/* SELECT COUNT(*) [WHERE ...] in sharded mode: every rank reports the global count */
+		uint64_t tot = x.n;
+		if (mdb_dist_allreduce_sum_u64(cat->dist, &tot, 1)) {
+			snprintf(err, errlen, "execution phase: %s\n", mdb_dist_last_error(cat->dist));
+			rc = -MIDORIDB_INTERNAL;
+			goto out;
+		}
+		x.n = tot;
+	}
+	if (cat->dist && fused >= 0 && s->distinct) {
+		bool key_selected = false;
+		for (int i = 0; i < s->nsel; i++)
+			key_selected = key_selected || s->sel[i]->kind == MDB_EX_FIELD;
+		if (!key_selected) {
+			ERR("execution phase: sharded mode: DISTINCT over an aggregate alone cannot be answered from one rank's groups\n");
+			rc = -MIDORIDB_ERROR;
+			goto out;
+		}
+	}
 	/* ---- HAVING -> DISTINCT -> ORDER BY -> LIMIT (SQL order of evaluation; extension) */
 	if ((rc = select_tail(&x, has_count)))
 		goto out;
@@ -1785,6 +2038,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	res = NULL;
 	rc = MIDORIDB_OK;
 out:
+	shard_cleanup(&x);
 	free_all(&x);
 	mdb_result_free(res);
 	free(keys);

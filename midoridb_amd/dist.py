@@ -29,11 +29,18 @@ class Transport(Structure):
     _fields_ = [("self", c_void_p), ("counts", _COUNTS), ("alltoallv", _A2AV), ("allreduce_sum_u64", _ALLRED), ("destroy", _DESTROY)]
 
 
+class DistCol(Structure):
+    """struct mdb_dist_col: 8-byte cells, optional NULL bits, optional row-id vector (device pointers)."""
+    _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p)]
+
+
+KEEP_NULL_KEYS, NO_WAIT = 1, 2
+
 DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
-    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
 ]
 
 
@@ -60,6 +67,10 @@ def _bind(lib):
         "mdb_dist_last_received_left": ([P], c_uint64),
         "mdb_dist_allreduce_sum_u64": ([P, POINTER(c_uint64), c_int], c_int),
         "mdb_dist_barrier": ([P], c_int),
+        "mdb_dist_shuffle_rows": ([P, P, P, c_uint64, ctypes.c_uint32, POINTER(DistCol), c_int, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
+        "mdb_dist_wait_transfers": ([P], c_int),
+        "mdb_dist_join_pairs": ([P, P, P, c_uint64, POINTER(DistCol), c_int, P, P, c_uint64, POINTER(DistCol), c_int, POINTER(P), POINTER(P),
+                                 POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -202,6 +213,52 @@ class DistCtx:
         self._chk(self.lib.mdb_dist_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r, _ptr(ok),
                                                      _ptr(oc), min(ok.numel(), oc.numel()), byref(g), byref(j)), "dist join_group_count")
         return ok[:g.value], oc[:g.value], j.value
+
+    def _cols(self, cols):
+        arr = (DistCol * max(len(cols), 1))()
+        for i, c in enumerate(cols):
+            v, nb, rid = (c + (None, None))[:3] if isinstance(c, tuple) else (c, None, None)
+            arr[i] = DistCol(v.data_ptr(), nb.data_ptr() if nb is not None else None, rid.data_ptr() if rid is not None else None)
+        return arr
+
+    def _adopt(self, ptr, n, dtype):
+        """a device buffer the library allocated (mdb_dev_alloc) as a torch tensor that releases it with mdb_dev_free"""
+        return self.dev._adopt(c_void_p(int(ptr)), n, dtype)
+
+    def shuffle_rows(self, keys, key_nulls, cols, flags=0):
+        """cols: list of tensors or (values, nullbits, rid) tuples -> (list of (values, nullbits-or-None), received rows);
+        every row travels to the rank its key hashes to (mdb_dist_shuffle_rows)."""
+        nc = len(cols)
+        ov, on = (c_void_p * max(nc, 1))(), (c_void_p * max(nc, 1))()
+        got = c_uint64()
+        self._chk(self.lib.mdb_dist_shuffle_rows(self.h, _ptr(keys), _ptr(key_nulls), keys.numel(), flags, self._cols(cols), nc, ov, on,
+                                                 byref(got)), "dist shuffle_rows")
+        n = got.value
+        out = []
+        for c in range(nc):
+            src = cols[c][0] if isinstance(cols[c], tuple) else cols[c]
+            out.append((self._adopt(ov[c], n, src.dtype), self._adopt(on[c], (n + 63) // 64, torch.int64) if on[c] else None))
+        return out, n
+
+    def join_pairs(self, keys_l, null_l, cols_l, keys_r, null_r, cols_r):
+        """-> (key[J], [(values, nullbits) of cols_l], [... of cols_r], J): the joined rows whose key hashes to this rank."""
+        nl, nr = len(cols_l), len(cols_r)
+        ok = c_void_p()
+        ol, oln = (c_void_p * max(nl, 1))(), (c_void_p * max(nl, 1))()
+        orr, orn = (c_void_p * max(nr, 1))(), (c_void_p * max(nr, 1))()
+        rows = c_uint64()
+        self._chk(self.lib.mdb_dist_join_pairs(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), self._cols(cols_l), nl, _ptr(keys_r),
+                                               _ptr(null_r), keys_r.numel(), self._cols(cols_r), nr, byref(ok), ol, oln, orr, orn, byref(rows)),
+                  "dist join_pairs")
+        J = rows.value
+
+        def side(cols, ov, on):
+            out = []
+            for c in range(len(cols)):
+                src = cols[c][0] if isinstance(cols[c], tuple) else cols[c]
+                out.append((self._adopt(ov[c], J, src.dtype), self._adopt(on[c], (J + 63) // 64, torch.int64) if on[c] else None))
+            return out
+        return self._adopt(ok.value, J, torch.int64), side(cols_l, ol, oln), side(cols_r, orr, orn), J
 
     def allreduce_sum(self, vals):
         arr = (c_uint64 * len(vals))(*[int(v) for v in vals])

@@ -74,6 +74,83 @@ def check(dx, dev, world, rank, n, seed, lo, span, null_frac, expect_wire32):
         assert dx.last_wire32() == expect_wire32
 
 
+def _rows(cols):
+    """sorted list of row tuples from [(values ndarray, nulls bool ndarray or None)]: NULL cells compare as None, DOUBLE cells by bits"""
+    n = len(cols[0][0])
+    out = []
+    for v, nb in cols:
+        v = np.asarray(v)
+        bits = v.view(np.int64) if v.dtype == np.float64 else v.astype(np.int64)
+        out.append([None if (nb is not None and nb[i]) else int(bits[i]) for i in range(n)])
+    return sorted(zip(*out), key=lambda t: tuple((x is None, x or 0) for x in t))
+
+
+def _host(dev, pair, n):
+    from midoridb_amd.dev import unpack_nullbits
+    v, nb = pair
+    return v.cpu().numpy()[:n], (unpack_nullbits(nb.cpu().numpy(), n) if nb is not None else None)
+
+
+def check_shuffle_and_join(dx, dev, world, rank, n, seed):
+    """mdb_dist_shuffle_rows / mdb_dist_join_pairs against numpy: every rank must end up with exactly the rows (keys AND payload
+    cells, DOUBLE bits and NULL flags included) whose key hashes to it - the materialising joins of BASELINE configs[3] / [4]"""
+    from midoridb_amd.dist import KEEP_NULL_KEYS
+    rng = np.random.default_rng(seed)
+    total = n * world
+    ka = rng.integers(-50, total // 2, total, dtype=np.int64)
+    kb = rng.integers(-50, total // 2, total + 5 * world, dtype=np.int64)
+    kan, kbn = rng.random(len(ka)) < 0.02, rng.random(len(kb)) < 0.02
+    fa = rng.integers(-2**40, 2**40, len(ka), dtype=np.int64)
+    fan = rng.random(len(ka)) < 0.1
+    xa = rng.standard_normal(len(ka))
+    xa[::97] = -0.0
+    fb = rng.integers(0, 1000, len(kb), dtype=np.int64)
+    cut = [0] + [int(len(ka) * (r + 1) / world * (0.8 if r + 1 < world else 1.0)) for r in range(world)]
+    cutb = [0] + [int(len(kb) * (r + 1) / world) for r in range(world)]
+    la, lb = slice(cut[rank], cut[rank + 1]), slice(cutb[rank], cutb[rank + 1])
+    d_ka, d_kan = dev.to_dev(ka[la]), dev.nullbits_dev(kan[la])
+    d_fa, d_fan, d_xa = dev.to_dev(fa[la]), dev.nullbits_dev(fan[la]), dev.to_dev(xa[la])
+    d_kb, d_kbn, d_fb = dev.to_dev(kb[lb]), dev.nullbits_dev(kbn[lb]), dev.to_dev(fb[lb])
+    # --- shuffle of table A: key + INT64 payload with NULLs + DOUBLE payload
+    out, got = dx.shuffle_rows(d_ka, d_kan, [d_ka, (d_fa, d_fan), d_xa])
+    mine = (orc.dest_of(ka, world) == rank) & ~kan
+    exp = _rows([(ka[mine], None), (fa[mine], fan[mine]), (xa[mine], None)])
+    res = _rows([_host(dev, out[0], got), _host(dev, out[1], got), _host(dev, out[2], got)])
+    assert got == int(mine.sum()) and res == exp, (got, int(mine.sum()))
+    # --- the same stream read through a row-id vector (a filtered / joined tuple stream), NULL keys kept (GROUP BY shuffle)
+    nloc = cut[rank + 1] - cut[rank]
+    rid = rng.permutation(nloc)[: max(nloc * 2 // 3, 1)].astype(np.uint32)
+    d_rid = dev.to_dev(rid)
+    sk, skn = dev.gather64(d_ka, d_kan, d_rid, len(rid))
+    out, got = dx.shuffle_rows(sk, skn, [(d_ka, d_kan, d_rid), (d_fa, d_fan, d_rid), (d_xa, None, d_rid)], KEEP_NULL_KEYS)
+    # what every rank's stream holds, globally
+    allrid = [None] * world
+    dist.all_gather_object(allrid, (cut[rank], rid.astype(np.int64)))
+    gsel = np.concatenate([off + r for off, r in allrid])
+    gk, gkn = ka[gsel], kan[gsel]
+    dest = np.where(gkn, orc.dest_of(np.zeros(1, dtype=np.int64), world)[0], orc.dest_of(gk, world))
+    mine = dest == rank
+    exp = _rows([(gk[mine], gkn[mine]), (fa[gsel][mine], fan[gsel][mine]), (xa[gsel][mine], None)])
+    res = _rows([_host(dev, out[0], got), _host(dev, out[1], got), _host(dev, out[2], got)])
+    assert got == int(mine.sum()) and res == exp
+    # --- sharded materialising join with payload on both sides
+    key, lcols, rcols, J = dx.join_pairs(d_ka, d_kan, [(d_fa, d_fan), d_xa], d_kb, d_kbn, [d_fb])
+    pl, pr = orc.join_pairs(ka, kan, kb, kbn)
+    mine = orc.dest_of(ka[pl], world) == rank
+    pl, pr = pl[mine], pr[mine]
+    exp = _rows([(ka[pl], None), (fa[pl], fan[pl]), (xa[pl], None), (fb[pr], None)])
+    res = _rows([(key.cpu().numpy(), None), _host(dev, lcols[0], J), _host(dev, lcols[1], J), _host(dev, rcols[0], J)])
+    assert J == len(pl) and res == exp, (J, len(pl))
+    assert dx.allreduce_sum([J])[0] == len(mine)
+    # keys only (BASELINE configs[3]: SELECT * over two key columns), and an empty side
+    key, _, _, J = dx.join_pairs(d_ka, None, [], d_kb, None, [])
+    pl, pr = orc.join_pairs(ka, None, kb, None)
+    assert sorted(key.cpu().numpy().tolist()) == sorted(ka[pl][orc.dest_of(ka[pl], world) == rank].tolist())
+    e = torch.empty(0, dtype=torch.int64, device=dev.device)
+    key, lc, rc, J = dx.join_pairs(d_ka, d_kan, [d_xa], e, None, [e])
+    assert J == 0 and key.numel() == 0 and lc[0][0].numel() == 0
+
+
 def main():
     mode = sys.argv[1]
     rank = int(os.environ.get("RANK", "0"))
@@ -93,6 +170,8 @@ def main():
         check(dx, dev, world, rank, n, seed + 30, 0, n * world // 2, 0.01, False)
         dx.set_wire(WIRE_32)
         check(dx, dev, world, rank, n, seed + 40, -1000, n * world // 2, 0.0, True)
+    for n, seed in ((3_000, 5), (400_000, 6)):
+        check_shuffle_and_join(dx, dev, world, rank, n, seed)
     # min-max pruning before the shuffle (MDB_WIRE_AUTO): the right table's keys cover a twentieth of the left table's range -
     # left rows outside the right table's GLOBAL range stay home; the groups are the oracle's all the same
     dx.set_wire(WIRE_AUTO)
