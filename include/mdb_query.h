@@ -114,6 +114,16 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
  * column c gets perm_{seed+c}(i) mod modulus[c] (include/mdb_gen.h), i in [0, n). */
 int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint64_t seed, const uint64_t *modulus);
 
+/* Sharded mode set up by the host program instead of the environment (MIDORIDB_WORLD_SIZE / MIDORIDB_RANK /
+ * MIDORIDB_DIST_ID_FILE): mdb_database_device() returns the database's device context (created on first use; NULL
+ * without a usable HIP device), the host builds an exchange handle for it - mdb_dist_init() with a communicator id it
+ * shipped itself, or mdb_dist_init_transport() over its own fabric (include/mdb_dist.h) - and hands it over; the database
+ * owns it from then on (destroyed by database_close()).  Every later SELECT is collective. */
+struct mdb_dev_ctx;
+struct mdb_dist;
+struct mdb_dev_ctx *mdb_database_device(struct database *db);
+int mdb_database_set_dist(struct database *db, struct mdb_dist *dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -766,7 +766,7 @@ static int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *
 		      uint32_t flags, uint64_t *n_out)
 {
 	struct mdb_select *s = x->s;
-	struct mdb_dist_col cols[MDB_DIST_SHUFFLE_MAX_COLS];
+	struct mdb_dist_col cols[MDB_DIST_SHUFFLE_MAX_COLS] = { { NULL, NULL, NULL } };
 	int col_i[MDB_DIST_SHUFFLE_MAX_COLS], col_c[MDB_DIST_SHUFFLE_MAX_COLS], nc = 0;
 	void *ov[MDB_DIST_SHUFFLE_MAX_COLS];
 	uint64_t *on[MDB_DIST_SHUFFLE_MAX_COLS];
@@ -836,8 +836,8 @@ static int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *
 /* the current stream (tables 0..nt-1) partitioned by field f: afterwards every rank holds the tuples whose f hashes to it */
 static int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flags)
 {
-	int tabs[MDB_MAX_TABS];
-	uint32_t *rids[MDB_MAX_TABS];
+	int tabs[MDB_MAX_TABS] = { 0 };
+	uint32_t *rids[MDB_MAX_TABS] = { NULL };
 	const int64_t *kv;
 	const uint64_t *kn;
 	const void *dv;

@@ -285,6 +285,28 @@ void query_free(struct query_output *output)
 	free(output);
 }
 
+/* ------------------------------------------------------------------ sharded mode handed in by the host */
+
+struct mdb_dev_ctx *mdb_database_device(struct database *db)
+{
+	struct mdb_catalog *cat = db ? db->tables : NULL;
+	char err[256];
+	if (!cat || mdb_catalog_device(cat, err, sizeof(err)))
+		return NULL;
+	return cat->dev;
+}
+
+int mdb_database_set_dist(struct database *db, struct mdb_dist *dist)
+{
+	struct mdb_catalog *cat = db ? db->tables : NULL;
+	if (!cat || !cat->dev || !dist)
+		return -MIDORIDB_ERROR;
+	if (cat->dist)
+		mdb_dist_destroy(cat->dist);
+	cat->dist = dist;
+	return MIDORIDB_OK;
+}
+
 /* ------------------------------------------------------------------ bulk ingest */
 
 int mdb_table_append_columns(struct database *db, const char *table, int ncols, uint64_t n, const int64_t *const *cols,
@@ -299,11 +321,28 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 	rc = mdb_table_reserve(t, t->nrows + n);
 	if (rc)
 		return rc;
-	for (int c = 0; c < ncols; c++)		/* NOT NULL columns (reference semantic_insert.c:440-495) take no NULL flag */
-		if (t->cols[c].not_null && ((nulls && nulls[c]) || !cols[c]))
+	/* everything is validated before any column is touched: a missing column array, NULLs in NOT NULL columns (reference
+	 * semantic_insert.c:440-495) - for a VARCHAR column also a NULL string pointer -, a VARCHAR without room for a character */
+	uint64_t add_nulls[MDB_MAX_COLS] = { 0 };
+	for (int c = 0; c < ncols; c++) {
+		const struct mdb_column *col = &t->cols[c];
+		if (col->type == MDB_CT_VARCHAR) {
+			const char *const *strs = (const char *const *)cols[c];
+			if (col->precision < 1)
+				return -MIDORIDB_ERROR;
+			if (col->not_null)
+				for (uint64_t i = 0; i < n; i++)
+					if (!strs || !strs[i] || (nulls && nulls[c] && nulls[c][i]))
+						return -MIDORIDB_ERROR;
+			continue;
+		}
+		if (!cols[c])
+			return -MIDORIDB_ERROR;
+		if (col->not_null && nulls && nulls[c])
 			for (uint64_t i = 0; i < n; i++)
-				if (!cols[c] || nulls[c][i])
+				if (nulls[c][i])
 					return -MIDORIDB_ERROR;
+	}
 	for (int c = 0; c < ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
 		if (col->type == MDB_CT_VARCHAR) {
@@ -315,7 +354,7 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 				col->data[row] = 0;
 				if (isnull) {
 					col->nullbits[row >> 6] |= 1ull << (row & 63);
-					col->null_count++;
+					add_nulls[c]++;
 				} else {
 					size_t len = strlen(strs[i]);
 					if (len + 1 > (size_t)col->precision)
@@ -331,17 +370,34 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 		if (!cols[c])
 			return -MIDORIDB_ERROR;
 		memcpy(col->data + t->nrows, cols[c], n * 8);
+		if (!nulls || !nulls[c]) {
+			/* no NULL flags: the rows' bits are cleared a word at a time (the first and last word may be shared with other rows) */
+			const uint64_t r0 = t->nrows, r1 = t->nrows + n;
+			uint64_t i = r0;
+			for (; i < r1 && (i & 63); i++)
+				col->nullbits[i >> 6] &= ~(1ull << (i & 63));
+			if (i < r1) {
+				const uint64_t full = (r1 - i) / 64;
+				memset(col->nullbits + (i >> 6), 0, full * 8);
+				i += full * 64;
+			}
+			for (; i < r1; i++)
+				col->nullbits[i >> 6] &= ~(1ull << (i & 63));
+			continue;
+		}
 		for (uint64_t i = 0; i < n; i++) {
 			const uint64_t row = t->nrows + i;
-			if (nulls && nulls[c] && nulls[c][i]) {
+			if (nulls[c][i]) {
 				col->nullbits[row >> 6] |= 1ull << (row & 63);
 				col->data[row] = 0;
-				col->null_count++;
+				add_nulls[c]++;
 			} else {
 				col->nullbits[row >> 6] &= ~(1ull << (row & 63));
 			}
 		}
 	}
+	for (int c = 0; c < ncols; c++)
+		t->cols[c].null_count += add_nulls[c];
 	t->nrows += n;
 	t->generation++;
 	return MIDORIDB_OK;

@@ -41,6 +41,7 @@ QUERY_SYMBOLS = [
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
     "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
+    "mdb_database_device", "mdb_database_set_dist",
 ]
 
 
@@ -88,6 +89,10 @@ def _bind(lib):
     lib.mdb_table_append_columns.restype = c_int
     lib.mdb_table_generate.argtypes = [PDB, c_char_p, c_uint64, c_uint64, POINTER(c_uint64)]
     lib.mdb_table_generate.restype = c_int
+    lib.mdb_database_device.argtypes = [PDB]
+    lib.mdb_database_device.restype = c_void_p
+    lib.mdb_database_set_dist.argtypes = [PDB, c_void_p]
+    lib.mdb_database_set_dist.restype = c_int
     lib._mdb_query_bound = True
 
 
@@ -136,6 +141,19 @@ class DB:
 
     def __exit__(self, *a):
         self.close()
+
+    # -- sharded mode handed in by the host ------------------------------------------------------
+    def device_handle(self):
+        """mdb_dev_ctx* of the database (created on first use)"""
+        h = self.lib.mdb_database_device(ctypes.byref(self.db))
+        if not h:
+            raise QueryError("no usable HIP device")
+        return c_void_p(h)
+
+    def set_dist(self, dist_handle):
+        """the database takes ownership of an mdb_dist* built for device_handle()"""
+        if self.lib.mdb_database_set_dist(ctypes.byref(self.db), dist_handle) != 0:
+            raise QueryError("mdb_database_set_dist failed")
 
     # -- statements -------------------------------------------------------------------------
     def _run(self, out):
@@ -204,7 +222,9 @@ class DB:
         n = len(cols[0])
         arrs, keep = [], []
         for c in cols:
-            if len(c) and any(isinstance(v, str) for v in c):     # VARCHAR: an array of char pointers (NULL = SQL NULL)
+            is_text = (c.dtype.kind in "OUS" and any(isinstance(v, str) for v in c)) if isinstance(c, np.ndarray) else \
+                (len(c) and any(isinstance(v, str) for v in c))
+            if is_text:                                           # VARCHAR: an array of char pointers (NULL = SQL NULL)
                 bufs = [None if v is None else ctypes.create_string_buffer(v.encode()) for v in c]
                 keep.append(bufs)
                 arrs.append(np.array([0 if b is None else ctypes.addressof(b) for b in bufs], dtype=np.int64))

@@ -151,6 +151,101 @@ def check_shuffle_and_join(dx, dev, world, rank, n, seed):
     assert J == 0 and key.numel() == 0 and lc[0][0].numel() == 0
 
 
+class _DbDev:
+    """what DistCtx and the test transport need of a DeviceCtx, over the device context a database owns"""
+
+    def __init__(self, db, device):
+        from midoridb_amd.dev import _bind
+        _bind(db.lib)			# the mdb_dev_* prototypes the test transport calls
+        self.lib, self.h, self.device = db.lib, db.device_handle(), torch.device("cuda", device)
+
+    def sync(self):
+        assert self.lib.mdb_dev_sync(self.h) == 0
+
+
+def sharded_sql(world, rank):
+    """query_execute() in sharded mode at world size 2 on one GPU (mdb_database_set_dist with the test transport): every rank loads
+    ITS rows, runs the same statements, and the ranks' results together must be exactly the rows oracle/naive.py computes over
+    the whole tables - joins with payload (INT64 with NULLs, DOUBLE), three-way joins on one key and on two, WHERE conjuncts
+    pushed below the exchange, GROUP BY of a non-key column, DISTINCT, global COUNT(*)."""
+    from oracle.naive import Naive
+    from oracle.ref import sql_to_rpn
+    from midoridb_amd.query import DB, QueryError
+    rng = np.random.default_rng(77)
+    na, nb, nc = 600, 700, 200	# (oracle/naive.py joins with nested Python loops)
+    dom = 250
+
+    def col(n, lo, hi, nullp):
+        return rng.integers(lo, hi, n), rng.random(n) < nullp
+    xa = rng.integers(-4, 5, na) * 0.5
+    xa[rng.random(na) < 0.1] = -0.0
+    yb = rng.integers(-4, 5, nb) * 0.5
+    a = [col(na, 0, dom, 0.03), col(na, -50, 50, 0.1), (xa, rng.random(na) < 0.05)]
+    b = [col(nb, 0, dom, 0.03), col(nb, 0, 40, 0.0), (yb, np.zeros(nb, dtype=bool))]
+    c = [col(nc, 0, 60, 0.0), col(nc, 0, 9, 0.1)]
+    ddl = ["CREATE TABLE A (id_a INT, f1 INT, x DOUBLE);", "CREATE TABLE B (id_b INT, f2 INT, y DOUBLE);", "CREATE TABLE C (id_c INT, f3 INT);"]
+    queries = [
+        "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b;",
+        "SELECT f1, x, f2 FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f1 > -20 AND f2 < 30;",
+        "SELECT * FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c;",
+        "SELECT id_a, f2, f3 FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON B.f2 = C.id_c WHERE f3 <> 4;",
+        "SELECT id_a, id_b FROM A INNER JOIN B ON A.id_a = B.id_b AND f1 < f2;",
+        "SELECT f1, y FROM A INNER JOIN B ON A.x = B.y WHERE id_a < 40 AND id_b < 40;",
+        "SELECT f2, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f1 > -20 GROUP BY f2;",
+        "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;",
+        "SELECT id_c, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c GROUP BY id_c;",
+        "SELECT f1, COUNT(*) FROM A GROUP BY f1;",
+        "SELECT f1, f3 FROM A INNER JOIN C ON A.id_a = C.id_c GROUP BY f1, f3;",
+        "SELECT DISTINCT f1 FROM A;",
+        "SELECT DISTINCT f2, f3 FROM B INNER JOIN C ON B.f2 = C.id_c;",
+        "SELECT f2, COUNT(*) FROM B GROUP BY f2 HAVING COUNT(*) > 17;",
+    ]
+    counts = [
+        "SELECT COUNT(*) FROM A WHERE f1 > 0;",
+        "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f2 <= 10 OR f1 IS NULL;",
+        "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b;",
+    ]
+    tables = {}
+    with DB() as db:
+        dev = _DbDev(db, 0)
+        dx = gloo_transport(dev, world, rank)
+        db.set_dist(dx.h)
+        dx.h = None			# the database owns the handle now (the callbacks stay alive with dx)
+        for sdl, name, data in zip(ddl, "ABC", (a, b, c)):
+            db.execute(sdl)
+            n = len(data[0][0])
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            if name == "C" and rank == 0:
+                lo, hi = 0, 0		# one rank holds no row of C at all
+            elif name == "C":
+                lo = 0
+            db.append_columns(name, [d[0][lo:hi] for d in data], [d[1][lo:hi] for d in data])
+            cols = sdl[sdl.index("(") + 1:sdl.rindex(")")].split(",")
+            tables[name] = ([x.split()[0] for x in cols],
+                            [[None if d[1][i] else (float(d[0][i]) if d[0].dtype == np.float64 else int(d[0][i])) for d in data] for i in range(n)])
+        ex = Naive(tables)
+        for q in queries:
+            names, rows = ex.run(sql_to_rpn(q))
+            res = db.query(q)
+            assert res.names == names, q
+            parts = [None] * world
+            dist.all_gather_object(parts, res.rows())
+            got = sorted(r for p in parts for r in p)
+            assert got == sorted(rows), (q, len(got), len(rows))
+        for q in counts:
+            names, rows = ex.run(sql_to_rpn(q))
+            assert db.query(q).rows() == rows, q		# the global count on every rank
+        for q, what in (("SELECT * FROM A, C;", "equi-join key"), ("SELECT f1 FROM A INNER JOIN B ON A.id_a = B.id_b LIMIT 3, 4;", "LIMIT")):
+            try:
+                db.query(q)
+                raise SystemExit(f"{q} must be refused in sharded mode")
+            except QueryError as e:
+                assert what in str(e), str(e)
+    dist.barrier()
+    if rank == 0:
+        print(f"sharded sql world {world} ok", flush=True)
+
+
 def main():
     mode = sys.argv[1]
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +253,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) if mode == "rccl" else 0
     torch.cuda.set_device(local)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "sql":
+        sharded_sql(world, rank)
+        dist.destroy_process_group()
+        return
     dev = DeviceCtx(local)
     dx = DistCtx.from_torch(dev) if mode == "rccl" else gloo_transport(dev, world, rank)
     # keys of 2 x 10^5 rows per rank: single-level local partition; 1.2 x 10^6: two levels, sampled narrow / compact forms

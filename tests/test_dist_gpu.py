@@ -33,10 +33,16 @@ def test_sharded_join_group_count_two_ranks_one_gpu_test_transport():
     assert "dist gloo world 2 ok" in _run("gloo", 2, 29612)
 
 
+def test_query_execute_sharded_any_equi_join_two_ranks_one_gpu():
+    """every equi-join shape through query_execute() at world size 2 (rows exchanged by mdb_dist_shuffle_rows) vs oracle/naive.py"""
+    assert "sharded sql world 2 ok" in _run("sql", 2, 29613)
+
+
 def test_query_execute_in_sharded_mode_world1(tmp_path):
     """query_execute() with MIDORIDB_WORLD_SIZE set runs the fused plan through mdb_dist_join_group_count_alloc (RCCL
     communicators created inside database code from the id file; world size 1 on the test box): same groups and counts as
-    the single-GPU plan, chained over a third table, SELECT COUNT(*) all-reduced, other joins refused."""
+    the single-GPU plan, chained over a third table, SELECT COUNT(*) all-reduced, materialising joins exchanged, joins without an
+    equi-join key refused."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -62,9 +68,12 @@ with DB() as db:
     exp3 = {k: v * cc[k] for k, v in zip(ek.tolist(), ec.tolist()) if k in cc}
     assert dict(zip(r3.columns[r3.names.index("A.id_a")].tolist(), r3.columns[r3.names.index("COUNT(*)")].tolist())) == exp3
     assert db.query("SELECT COUNT(*) FROM A WHERE id_a < 10;").rows() == [(int((a < 10).sum()),)]
+    r = db.query("SELECT * FROM A INNER JOIN C ON A.id_a = C.id_c;")		# a materialising join: exchanged over RCCL like any other
+    pl, pr = orc.join_pairs(a, None, c, None)
+    assert sorted(r.columns[r.names.index("A.id_a")].tolist()) == sorted(a[pl].tolist()) and r.nrows == len(pl)
     try:
-        db.query("SELECT * FROM A INNER JOIN C ON A.id_a = C.id_c;")
-        raise SystemExit("a non-fused join must be refused in sharded mode")
+        db.query("SELECT * FROM A, C;")
+        raise SystemExit("a join without an equi-join key must be refused in sharded mode")
     except QueryError as e:
         assert "sharded mode" in str(e)
 print("sharded query_execute ok")
