@@ -145,6 +145,10 @@ def parse_args():
                     help="skip everything but the primary measurement and the per-kernel profile (profiling runs)")
     ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
                     "column statistics allow it)")
+    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=3,
+                    help="which BASELINE.json configuration (SURVEY 8d numbering): 3 = the north-star query (default, the metric's own "
+                         "configuration), 4 = configs[3]: SELECT * join over key columns (10^9 rows over 8 GPUs: --rows 125000000), "
+                         "5 = configs[4]: three-way join + GROUP BY with DOUBLE payload through query_execute() (bench_configs.py)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -324,6 +328,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.config != 3:
+        import bench_configs
+        bench_configs.run(args, world, rank, local_rank, json_fd)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        os.close(json_fd)
+        return
 
     from midoridb_amd.dev import DeviceCtx
     from midoridb_amd.dist import DistCtx, WIRE_32, WIRE_64

@@ -390,6 +390,10 @@ int mdb_dev_widen32to64(mdb_dev_ctx *ctx, const int32_t *src, uint64_t n, int64_
 int mdb_dev_gen_keys(mdb_dev_ctx *ctx, int64_t *keys, uint64_t n, uint64_t first_index, uint64_t domain,
 		     uint64_t seed, uint64_t modulus);
 
+/* payload columns of the synthetic tables: cell i = the (first_index + i)-th output of SplitMix64(seed),
+ * kind 0: INT64 = z >> 33; kind 1: DOUBLE = (double)(z >> 11) * 2^-53 */
+int mdb_dev_gen_payload(mdb_dev_ctx *ctx, void *out, uint64_t n, uint64_t first_index, uint64_t seed, int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,15 @@ static inline uint64_t mdb_splitmix64(uint64_t *state)
 	return z ^ (z >> 31);
 }
 
+/* the i-th output (i = 0, 1, ...) of the SplitMix64 stream seeded with `seed`, without stepping through the stream */
+MDB_HD static inline uint64_t mdb_splitmix64_at(uint64_t seed, uint64_t i)
+{
+	uint64_t z = seed + (i + 1) * 0x9e3779b97f4a7c15ULL;
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+	return z ^ (z >> 31);
+}
+
 static inline int mdb_is_prime_u64(uint64_t x)
 {
 	if (x < 2)

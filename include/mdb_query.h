@@ -114,6 +114,21 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
  * column c gets perm_{seed+c}(i) mod modulus[c] (include/mdb_gen.h), i in [0, n). */
 int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint64_t seed, const uint64_t *modulus);
 
+/* Results that stay on the device: after mdb_database_results_on_device(db, 1) a SELECT returns as soon as its result columns
+ * exist in HBM - no device-to-host copy inside query_execute() (for the north-star query at 10^8 rows that copy is 3/4 of
+ * the call).  query_column_data_device() hands out the device column (8-byte cells, query_row_count() of them, valid until
+ * query_free()); the first query_cur_step() / query_column_data() / ... on such a result copies the columns to the host,
+ * once, and from then on everything behaves as usual.  Such a result must be released (query_free) BEFORE database_close():
+ * its columns live in the database's device context. */
+int mdb_database_results_on_device(struct database *db, int on);
+const void *query_column_data_device(struct result_set *res, int col_idx);	/* NULL when the column is not on the device */
+
+/* mdb_table_generate() for one shard of a table spread over several processes: this process holds rows
+ * [first_index, first_index + n) of a table of `domain` rows.  INTEGER column c = perm_{seed+c}(i) mod modulus[c] as above;
+ * a DOUBLE column c = (double)(splitmix64(seed + c, i) >> 11) * 2^-53 (SURVEY.md 8d C5 payload). */
+int mdb_table_generate_shard(struct database *db, const char *table, uint64_t n, uint64_t first_index, uint64_t domain, uint64_t seed,
+			     const uint64_t *modulus);
+
 /* Sharded mode set up by the host program instead of the environment (MIDORIDB_WORLD_SIZE / MIDORIDB_RANK /
  * MIDORIDB_DIST_ID_FILE): mdb_database_device() returns the database's device context (created on first use; NULL
  * without a usable HIP device), the host builds an exchange handle for it - mdb_dist_init() with a communicator id it

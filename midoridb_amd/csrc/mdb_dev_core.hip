@@ -1202,3 +1202,31 @@ extern "C" int mdb_dev_gen_keys(mdb_dev_ctx *ctx, int64_t *keys, uint64_t n, uin
 	MDB_LAUNCH(ctx, "gen_keys", k_gen_keys, stream_grid(n), STREAM_THREADS, keys, n, first_index, perm, modulus);
 	return MIDORIDB_OK;
 }
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_gen_payload(uint64_t *__restrict__ out, uint64_t n, uint64_t first, uint64_t seed, int kind)
+{
+	const uint64_t base = (uint64_t)blockIdx.x * (STREAM_THREADS * STREAM_ROUNDS);
+#pragma unroll
+	for (int r = 0; r < STREAM_ROUNDS; r++) {
+		const uint64_t k = base + (uint64_t)r * STREAM_THREADS + threadIdx.x;
+		if (k < n) {
+			const uint64_t z = mdb_splitmix64_at(seed, first + k);
+			if (kind == 1) {
+				const double d = (double)(z >> 11) * 0x1.0p-53;
+				out[k] = (uint64_t)__double_as_longlong(d);
+			} else {
+				out[k] = z >> 33;
+			}
+		}
+	}
+}
+
+extern "C" int mdb_dev_gen_payload(mdb_dev_ctx *ctx, void *out, uint64_t n, uint64_t first_index, uint64_t seed, int kind)
+{
+	if (n == 0)
+		return MIDORIDB_OK;
+	if (kind != 0 && kind != 1)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "gen_payload: kind must be 0 (INT64) or 1 (DOUBLE)");
+	MDB_LAUNCH(ctx, "gen_payload", k_gen_payload, stream_grid(n), STREAM_THREADS, (uint64_t *)out, n, first_index, seed, kind);
+	return MIDORIDB_OK;
+}

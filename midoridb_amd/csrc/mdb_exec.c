@@ -1342,12 +1342,58 @@ void mdb_result_free(struct mdb_result *r)
 			mdb_dev_host_free(r->data[c]);
 		if (r->nullbits)
 			free(r->nullbits[c]);
+		if (r->d_data && r->d_data[c])
+			mdb_dev_free(r->dev, r->d_data[c]);
+		if (r->d_nullbits && r->d_nullbits[c])
+			mdb_dev_free(r->dev, r->d_nullbits[c]);
 	}
 	free(r->data);
 	free(r->nullbits);
+	free(r->d_data);
+	free(r->d_nullbits);
 	free(r->colname);
 	free(r->coltype);
 	free(r);
+}
+
+/* one result column device -> host; a NULL cell reads as 0 through query_column_int64(), like the reference
+ * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
+static int result_column_to_host(mdb_dev_ctx *dev, struct mdb_result *res, int c, const void *d_vals, const uint64_t *d_nulls)
+{
+	const uint64_t rows = res->nrows;
+	if (!d_vals || !rows)
+		return MIDORIDB_OK;
+	if (mdb_dev_d2h(dev, res->data[c], d_vals, rows * 8))
+		return -MIDORIDB_INTERNAL;
+	if (d_nulls) {
+		const uint64_t words = (rows + 63) / 64;
+		res->nullbits[c] = calloc((size_t)words, 8);
+		if (!res->nullbits[c] || mdb_dev_d2h(dev, res->nullbits[c], d_nulls, words * 8))
+			return -MIDORIDB_INTERNAL;
+		for (uint64_t i = 0; i < rows; i++)
+			if ((res->nullbits[c][i >> 6] >> (i & 63)) & 1)
+				res->data[c][i] = 0;
+	}
+	return MIDORIDB_OK;
+}
+
+int mdb_result_fetch(struct mdb_result *r)
+{
+	if (!r || r->fetched)
+		return MIDORIDB_OK;
+	for (int c = 0; c < r->ncols; c++) {
+		if (!r->d_data || !r->d_data[c])
+			continue;
+		if (!r->data[c]) {
+			r->data[c] = mdb_dev_host_alloc((size_t)(r->nrows ? r->nrows : 1) * 8);
+			if (!r->data[c])
+				return -MIDORIDB_NOMEM;
+		}
+		if (result_column_to_host(r->dev, r, c, r->d_data[c], r->d_nullbits ? r->d_nullbits[c] : NULL))
+			return -MIDORIDB_INTERNAL;
+	}
+	r->fetched = true;
+	return MIDORIDB_OK;
 }
 
 static double now_ms(void)
@@ -1903,6 +1949,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			rc = -MIDORIDB_NOMEM;
 			goto out;
 		}
+		const bool keep = cat->results_on_device && out_rows > 1;
 		/* pass 1: where every result column lives on the device.  Columns read through a row-id vector are gathered -
 		 * all of them in one launch per MDB_GATHER_MAX_COLS columns (mdb_dev_gather_cols), not one launch each */
 		struct mdb_gather_col gl[MDB_GATHER_MAX_COLS];
@@ -1911,13 +1958,15 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		for (int c = 0; c < ncols && rc == MIDORIDB_OK; c++) {
 			int key = src[c];
 			memcpy(res->colname[c], keys[key], MDB_NAME_LEN);
-			res->data[c] = mdb_dev_host_alloc((size_t)(out_rows ? out_rows : 1) * 8);	/* pinned when large */
-			if (!res->data[c]) {
-				rc = -MIDORIDB_NOMEM;
-				break;
+			if (!keep) {	/* (a result kept on the device gets its host columns on first use, mdb_result_fetch) */
+				res->data[c] = mdb_dev_host_alloc((size_t)(out_rows ? out_rows : 1) * 8);	/* pinned when large */
+				if (!res->data[c]) {
+					rc = -MIDORIDB_NOMEM;
+					break;
+				}
+				if (out_rows <= 1)
+					res->data[c][0] = 0;
 			}
-			if (out_rows <= 1)
-				res->data[c][0] = 0;
 			if (key_tbl[key] < 0) {
 				res->coltype[c] = MDB_CT_INTEGER;
 				if (count_only) {
@@ -2004,28 +2053,53 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 		if (rc == MIDORIDB_OK && ngl && mdb_dev_gather_cols(x.dev, gl, ngl, out_rows))
 			rc = dev_fail(&x, "projection gather");
-		/* pass 2: device -> host */
+		/* pass 2: device -> host - or, with results kept on the device (mdb_database_results_on_device), the device columns
+		 * become the result's own: a buffer of this statement changes hands, a base-table column is copied on the device */
+		res->fetched = !keep;
+		if (keep) {
+			res->dev = x.dev;
+			res->d_data = calloc((size_t)(ncols ? ncols : 1), sizeof(void *));
+			res->d_nullbits = calloc((size_t)(ncols ? ncols : 1), sizeof(uint64_t *));
+			if (!res->d_data || !res->d_nullbits)
+				rc = -MIDORIDB_NOMEM;
+		}
 		for (int c = 0; c < ncols && rc == MIDORIDB_OK; c++) {
 			if (!d_vals[c] || !out_rows)
 				continue;
-			if (mdb_dev_d2h(x.dev, res->data[c], d_vals[c], out_rows * 8)) {
-				rc = dev_fail(&x, "reading a result column");
-				break;
+			if (!keep) {
+				if (result_column_to_host(x.dev, res, c, d_vals[c], d_nulls[c]))
+					rc = dev_fail(&x, "reading a result column");
+				continue;
 			}
-			if (d_nulls[c]) {
-				const uint64_t words = (out_rows + 63) / 64;
-				res->nullbits[c] = calloc((size_t)words, 8);
-				if (!res->nullbits[c] || mdb_dev_d2h(x.dev, res->nullbits[c], d_nulls[c], words * 8)) {
-					rc = dev_fail(&x, "reading NULL bits");
-					break;
+			for (int pass = 0; pass < 2 && rc == MIDORIDB_OK; pass++) {
+				const void *src = pass ? (const void *)d_nulls[c] : d_vals[c];
+				const size_t bytes = pass ? (size_t)((out_rows + 63) / 64) * 8 : (size_t)out_rows * 8;
+				void *own = NULL;
+				bool shared = false;
+				if (!src)
+					continue;
+				for (int k = 0; k < c; k++)	/* the same device column under two result columns (both key columns of SELECT *) */
+					shared = shared || d_vals[k] == src || (const void *)d_nulls[k] == src;
+				for (int i = 0; i < x.bufs.n && !shared; i++)
+					if (x.bufs.p[i] == src) {
+						own = x.bufs.p[i];
+						x.bufs.p[i] = x.bufs.p[--x.bufs.n];
+						break;
+					}
+				if (!own) {
+					if (mdb_dev_alloc(x.dev, bytes, &own) || mdb_dev_gather64(x.dev, src, NULL, NULL, bytes / 8, own, NULL)) {
+						rc = dev_fail(&x, "keeping a result column on the device");
+						break;
+					}
 				}
-				/* a NULL cell reads as 0 through query_column_int64(), like the reference
-				 * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
-				for (uint64_t i = 0; i < out_rows; i++)
-					if ((res->nullbits[c][i >> 6] >> (i & 63)) & 1)
-						res->data[c][i] = 0;
+				if (pass)
+					res->d_nullbits[c] = own;
+				else
+					res->d_data[c] = own;
 			}
 		}
+		if (keep && rc == MIDORIDB_OK && mdb_dev_sync(x.dev))
+			rc = dev_fail(&x, "result columns");
 		free(d_vals);
 		free(d_nulls);
 		if (rc)

@@ -98,6 +98,7 @@ struct mdb_catalog {
 	/* sharded mode (MIDORIDB_WORLD_SIZE > 1 in the environment: one process per GPU, every process holds ITS rows of every
 	 * table): the RCCL exchange handle, created with the device context (include/mdb_dist.h) */
 	mdb_dist *dist;
+	bool results_on_device;		/* mdb_database_results_on_device(): SELECT results stay in HBM until a consumer reads them */
 };
 
 /* dst[MDB_NAME_LEN] = src, cut to MDB_NAME_LEN - 1 characters, always terminated */
@@ -242,7 +243,14 @@ struct mdb_result {
 	double exec_ms;			/* device pipeline wall time of the SELECT that produced it */
 	uint64_t joined_rows;		/* rows produced by the join before aggregation (0 when no join) */
 	const struct mdb_strdict *dict;	/* VARCHAR result cells are ids of this dictionary (the database's) */
+	/* results kept on the device (mdb_database_results_on_device): d_data[c] / d_nullbits[c] are buffers of `dev` owned by the
+	 * result; the host columns above are filled on first use (mdb_result_fetch) */
+	mdb_dev_ctx *dev;
+	void **d_data;
+	uint64_t **d_nullbits;
+	bool fetched;
 };
+int mdb_result_fetch(struct mdb_result *r);	/* host columns of a device-resident result (no-op otherwise) */
 void mdb_result_free(struct mdb_result *r);
 
 /* ------------------------------------------------------------------ executor */

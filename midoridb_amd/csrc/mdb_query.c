@@ -166,6 +166,8 @@ int query_cur_step(struct result_set *res)
 	if (!res || !res->table)
 		return MIDORIDB_OK;
 	r = res->table;
+	if (!r->fetched && mdb_result_fetch(r))
+		return MIDORIDB_OK;	/* (the device copy failed: no row is current) */
 	if (!res->cursor_blk) {
 		res->cursor_blk = r;
 		res->cursor_offset = 0;
@@ -224,6 +226,8 @@ const char *mdb_result_text_at(struct result_set *res, int col_idx, uint64_t row
 	struct mdb_result *r = res ? res->table : NULL;
 	if (!r || col_idx < 0 || col_idx >= r->ncols || row >= r->nrows || r->coltype[col_idx] != MDB_CT_VARCHAR || !r->dict)
 		return NULL;
+	if (!r->fetched && mdb_result_fetch(r))
+		return NULL;
 	if (r->nullbits[col_idx] && ((r->nullbits[col_idx][row >> 6] >> (row & 63)) & 1))
 		return "";
 	return mdb_dict_str(r->dict, r->data[col_idx][row]);
@@ -263,7 +267,24 @@ uint64_t query_row_count(struct result_set *res)
 const int64_t *query_column_data(struct result_set *res, int col_idx)
 {
 	struct mdb_result *r = res ? res->table : NULL;
+	if (r && !r->fetched && mdb_result_fetch(r))
+		return NULL;
 	return r && col_idx >= 0 && col_idx < r->ncols ? r->data[col_idx] : NULL;
+}
+
+const void *query_column_data_device(struct result_set *res, int col_idx)
+{
+	struct mdb_result *r = res ? res->table : NULL;
+	return r && r->d_data && col_idx >= 0 && col_idx < r->ncols ? r->d_data[col_idx] : NULL;
+}
+
+int mdb_database_results_on_device(struct database *db, int on)
+{
+	struct mdb_catalog *cat = db ? db->tables : NULL;
+	if (!cat)
+		return -MIDORIDB_ERROR;
+	cat->results_on_device = on != 0;
+	return MIDORIDB_OK;
 }
 
 double query_exec_ms(struct result_set *res)
@@ -403,7 +424,8 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 	return MIDORIDB_OK;
 }
 
-int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint64_t seed, const uint64_t *modulus)
+int mdb_table_generate_shard(struct database *db, const char *table, uint64_t n, uint64_t first_index, uint64_t domain, uint64_t seed,
+			     const uint64_t *modulus)
 {
 	struct mdb_catalog *cat = db ? db->tables : NULL;
 	struct mdb_table *t = cat ? mdb_catalog_find(cat, table) : NULL;
@@ -415,13 +437,16 @@ int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint6
 	rc = mdb_catalog_device(cat, err, sizeof(err));
 	if (rc)
 		return rc;
+	for (int c = 0; c < t->ncols; c++)
+		if (t->cols[c].type != MDB_CT_INTEGER && t->cols[c].type != MDB_CT_DOUBLE)
+			return -MIDORIDB_ERROR;
 	for (int c = 0; c < t->ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
-		if (col->type != MDB_CT_INTEGER)
-			return -MIDORIDB_ERROR;
 		rc = mdb_dev_alloc(cat->dev, (n ? n : 1) * 8, &col->d_data);
-		if (!rc)
-			rc = mdb_dev_gen_keys(cat->dev, col->d_data, n, 0, n, seed + (uint64_t)c, modulus ? modulus[c] : 0);
+		if (!rc && col->type == MDB_CT_DOUBLE)
+			rc = mdb_dev_gen_payload(cat->dev, col->d_data, n, first_index, seed + (uint64_t)c, 1);
+		else if (!rc)
+			rc = mdb_dev_gen_keys(cat->dev, col->d_data, n, first_index, domain, seed + (uint64_t)c, modulus ? modulus[c] : 0);
 		if (rc)
 			return rc;
 	}
@@ -434,4 +459,9 @@ int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint6
 	t->dev_cap = n ? n : 1;
 	t->dev_generation = t->generation;
 	return MIDORIDB_OK;
+}
+
+int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint64_t seed, const uint64_t *modulus)
+{
+	return mdb_table_generate_shard(db, table, n, 0, n, seed, modulus);
 }

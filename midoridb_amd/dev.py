@@ -101,6 +101,7 @@ def _bind(lib):
         "mdb_dev_key_range": ([P, P, P, c_uint64, POINTER(c_int64), POINTER(c_int64)], c_int),
         "mdb_dev_widen32to64": ([P, P, c_uint64, P], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
+        "mdb_dev_gen_payload": ([P, P, c_uint64, c_uint64, c_uint64, c_int], c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -116,7 +117,7 @@ DEV_SYMBOLS = [
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
-    "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys",
+    "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
 ]
 
 
@@ -261,6 +262,12 @@ class DeviceCtx:
     def gen_keys(self, n, first_index, domain, seed, modulus=0):
         out = torch.empty(n, dtype=torch.int64, device=self.device)
         self._chk(self.lib.mdb_dev_gen_keys(self.h, _ptr(out), n, first_index, domain, seed, modulus), "gen_keys")
+        return out
+
+    def gen_payload(self, n, first_index, seed, kind):
+        """payload column of the synthetic tables: kind 0 INT64 (SplitMix64 >> 33), kind 1 DOUBLE in [0, 1)"""
+        out = torch.empty(n, dtype=torch.float64 if kind == 1 else torch.int64, device=self.device)
+        self._chk(self.lib.mdb_dev_gen_payload(self.h, _ptr(out), n, first_index, seed, kind), "gen_payload")
         return out
 
     def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):

@@ -83,6 +83,21 @@ class DistError(RuntimeError):
     pass
 
 
+class DatabaseDevice:
+    """What DistCtx needs of a DeviceCtx, over the device context a database owns (mdb_database_device): lets a host build the
+    exchange handle for a database itself - over RCCL with an id it ships, or over its own fabric - and hand it over with
+    attach_to_database() (mdb_database_set_dist) instead of going through MIDORIDB_WORLD_SIZE / MIDORIDB_DIST_ID_FILE."""
+
+    def __init__(self, db, device_index=0):
+        from .dev import _bind as bind_dev
+        bind_dev(db.lib)
+        self.lib, self.h, self.device = db.lib, db.device_handle(), torch.device("cuda", device_index)
+
+    def sync(self):
+        if self.lib.mdb_dev_sync(self.h) != 0:
+            raise DistError("mdb_dev_sync failed")
+
+
 def _ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
@@ -259,6 +274,12 @@ class DistCtx:
                 out.append((self._adopt(ov[c], J, src.dtype), self._adopt(on[c], (J + 63) // 64, torch.int64) if on[c] else None))
             return out
         return self._adopt(ok.value, J, torch.int64), side(cols_l, ol, oln), side(cols_r, orr, orn), J
+
+    def attach_to_database(self, db):
+        """the database owns the handle from now on (destroyed by database_close); this object keeps the transport callbacks alive"""
+        db.set_dist(self.h)
+        db._dist_keepalive = self
+        self.h = None
 
     def allreduce_sum(self, vals):
         arr = (c_uint64 * len(vals))(*[int(v) for v in vals])

@@ -41,7 +41,7 @@ QUERY_SYMBOLS = [
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
     "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
-    "mdb_database_device", "mdb_database_set_dist",
+    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "query_column_data_device", "mdb_table_generate_shard",
 ]
 
 
@@ -93,6 +93,12 @@ def _bind(lib):
     lib.mdb_database_device.restype = c_void_p
     lib.mdb_database_set_dist.argtypes = [PDB, c_void_p]
     lib.mdb_database_set_dist.restype = c_int
+    lib.mdb_database_results_on_device.argtypes = [PDB, c_int]
+    lib.mdb_database_results_on_device.restype = c_int
+    lib.query_column_data_device.argtypes = [PRS, c_int]
+    lib.query_column_data_device.restype = c_void_p
+    lib.mdb_table_generate_shard.argtypes = [PDB, c_char_p, c_uint64, c_uint64, c_uint64, c_uint64, POINTER(c_uint64)]
+    lib.mdb_table_generate_shard.restype = c_int
     lib._mdb_query_bound = True
 
 
@@ -154,6 +160,38 @@ class DB:
         """the database takes ownership of an mdb_dist* built for device_handle()"""
         if self.lib.mdb_database_set_dist(ctypes.byref(self.db), dist_handle) != 0:
             raise QueryError("mdb_database_set_dist failed")
+
+    def results_on_device(self, on=True):
+        """SELECT results stay in HBM until a consumer reads them (mdb_database_results_on_device)"""
+        if self.lib.mdb_database_results_on_device(ctypes.byref(self.db), 1 if on else 0) != 0:
+            raise QueryError("mdb_database_results_on_device failed")
+
+    def query_device(self, sql, copy=True):
+        """SELECT with results kept on the device -> (names, types, [torch tensors or None per column], rows, joined rows, exec ms).
+        copy=False: no tensor is made (timing runs: the statement ends when its columns exist in HBM)."""
+        import torch
+        t0 = time.perf_counter()
+        raw = self.lib.query_execute(ctypes.byref(self.db), sql.encode())
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3
+        out, status = self._run(raw)
+        rs = ctypes.byref(out.contents.results)
+        nc, nrows = self.lib.query_column_count(rs), int(self.lib.query_row_count(rs))
+        names = [self.lib.query_column_name(rs, c).decode() for c in range(nc)]
+        types = [self.lib.query_column_type(rs, c) for c in range(nc)]
+        cols = []
+        for c in range(nc):
+            p = self.lib.query_column_data_device(rs, c)
+            if not copy or not p or not nrows:
+                cols.append(None)
+                continue
+            dt = torch.float64 if types[c] == 3 else torch.int64
+
+            class _View:
+                __cuda_array_interface__ = {"shape": (nrows,), "typestr": "<f8" if types[c] == 3 else "<i8", "data": (int(p), False), "version": 2}
+            cols.append(torch.as_tensor(_View(), device="cuda").clone().to(dt))
+        res = (names, types, cols, nrows, int(self.lib.query_joined_rows(rs)), float(self.lib.query_exec_ms(rs)))
+        self.lib.query_free(out)
+        return res
 
     # -- statements -------------------------------------------------------------------------
     def _run(self, out):
@@ -240,6 +278,14 @@ class DB:
         rc = self.lib.mdb_table_append_columns(ctypes.byref(self.db), table.encode(), len(arrs), n, cp, npp)
         if rc != 0:
             raise QueryError(f"mdb_table_append_columns({table}) failed: {rc}")
+
+    def generate_shard(self, table, n, first_index, domain, seed, modulus=None):
+        mod = None
+        if modulus is not None:
+            mod = (c_uint64 * len(modulus))(*modulus)
+        rc = self.lib.mdb_table_generate_shard(ctypes.byref(self.db), table.encode(), n, first_index, domain, seed, mod)
+        if rc != 0:
+            raise QueryError(f"mdb_table_generate_shard({table}) failed: {rc}")
 
     def generate(self, table, n, seed, modulus=None):
         mod = None

@@ -239,6 +239,20 @@ def gen_keys(n, first_index, domain, seed, modulus=0):
     return x.astype(np.int64)
 
 
+def gen_payload(n, first_index, seed, kind):
+    """include/mdb_gen.h mdb_splitmix64_at: cell i = output first_index + i of SplitMix64(seed); kind 0: INT64 = z >> 33,
+    kind 1: DOUBLE = (z >> 11) * 2^-53"""
+    with np.errstate(over="ignore"):
+        i = np.arange(first_index, first_index + n, dtype=np.uint64)
+        z = np.uint64(seed) + (i + np.uint64(1)) * np.uint64(0x9e3779b97f4a7c15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+        z = z ^ (z >> np.uint64(31))
+    if kind == 1:
+        return (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    return (z >> np.uint64(33)).astype(np.int64)
+
+
 def sort_perm(keys, n):
     """Oracle of mdb_dev_sort_perm (ORDER BY; an extension, the reference never executes ORDER BY - SURVEY 8a D7):
     keys = [(values, nulls bool or None, rid or None, is_double, desc)], row i of the stream reads values[rid[i]].

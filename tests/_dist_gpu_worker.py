@@ -151,18 +151,6 @@ def check_shuffle_and_join(dx, dev, world, rank, n, seed):
     assert J == 0 and key.numel() == 0 and lc[0][0].numel() == 0
 
 
-class _DbDev:
-    """what DistCtx and the test transport need of a DeviceCtx, over the device context a database owns"""
-
-    def __init__(self, db, device):
-        from midoridb_amd.dev import _bind
-        _bind(db.lib)			# the mdb_dev_* prototypes the test transport calls
-        self.lib, self.h, self.device = db.lib, db.device_handle(), torch.device("cuda", device)
-
-    def sync(self):
-        assert self.lib.mdb_dev_sync(self.h) == 0
-
-
 def sharded_sql(world, rank):
     """query_execute() in sharded mode at world size 2 on one GPU (mdb_database_set_dist with the test transport): every rank loads
     ITS rows, runs the same statements, and the ranks' results together must be exactly the rows oracle/naive.py computes over
@@ -207,10 +195,9 @@ def sharded_sql(world, rank):
     ]
     tables = {}
     with DB() as db:
-        dev = _DbDev(db, 0)
-        dx = gloo_transport(dev, world, rank)
-        db.set_dist(dx.h)
-        dx.h = None			# the database owns the handle now (the callbacks stay alive with dx)
+        from midoridb_amd.dist import DatabaseDevice
+        dx = gloo_transport(DatabaseDevice(db, 0), world, rank)
+        dx.attach_to_database(db)		# the database owns the handle now
         for sdl, name, data in zip(ddl, "ABC", (a, b, c)):
             db.execute(sdl)
             n = len(data[0][0])
