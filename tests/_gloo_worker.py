@@ -1,60 +1,27 @@
-"""Worker for tests/test_distributed_gloo.py: one rank of the hash-partition + all-to-all + local-join
-pipeline (midoridb_amd/shuffle.py) on CPU tensors over gloo, with the oracle's partition / join functions
-plugged in for the device operators.  Exits non-zero on any mismatch."""
+"""Worker for tests/test_distributed_gloo.py: one rank of the exchange protocol of mdb_dist.hip, modelled on CPU over gloo
+(tests/_exchange_model.py, oracle operators in place of the HIP kernels).  Exits non-zero on any mismatch."""
 import os
 import sys
 
 import numpy as np
-import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import np_oracle as orc  # noqa: E402
-from midoridb_amd.shuffle import DistributedJoinGroupCount, TableShuffle  # noqa: E402
+from tests import _exchange_model as xm  # noqa: E402
 
 
-def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+def north_star(rank, world):
+    """BASELINE configs[2] shape, sharded: every rank's groups hash to it, the ranks' groups together are one big join's"""
     n = 20_000
     total = n * world
     a = orc.gen_keys(n, rank * n, total, 42, 0)
     b = orc.gen_keys(n, rank * n, total, 43, total // 16)
-
-    def partition_fn(keys, out):
-        k, counts = orc.partition_by_dest(keys.numpy(), None, world)
-        out[:len(k)] = torch.from_numpy(k)
-        return out[:len(k)], [int(c) for c in counts]
-
-    def join_fn(ka, kb, out):
-        k, c, f, j = orc.join_group_count(ka.numpy(), None, kb.numpy(), None)
-        return torch.from_numpy(k), torch.from_numpy(c), torch.from_numpy(f), j
-
-    def partition32_fn(keys, out):      # 4-byte wire format
-        k, counts = orc.partition_by_dest(keys.numpy(), None, world)
-        out[:len(k)] = torch.from_numpy(k.astype(np.int32))
-        return out[:len(k)], [int(c) for c in counts]
-
-    def widen_fn(src32, out):
-        out[:src32.numel()] = src32.to(torch.int64)
-        return out[:src32.numel()]
-
-    # one piece (the default), several pieces (3 also exercises an uneven last piece), 8- and 4-byte keys
-    for chunks, wire32 in ((1, False), (3, False), (None, False), (2, True)):
-        pipe = DistributedJoinGroupCount(None, world, rank, n, partition_fn=partition32_fn if wire32 else partition_fn, join_fn=join_fn,
-                                         device=torch.device("cpu"), chunks=chunks, wire32=wire32, widen_fn=widen_fn)
-        g, j = pipe.run(torch.from_numpy(a), torch.from_numpy(b), None)
-        if chunks == 1:
-            k1, c1 = pipe.last[0].numpy().copy(), pipe.last[1].numpy().copy()
-        else:       # same groups whatever the chunking (order inside a rank may differ)
-            o1, o2 = np.argsort(k1, kind="stable"), np.argsort(pipe.last[0].numpy(), kind="stable")
-            assert np.array_equal(k1[o1], pipe.last[0].numpy()[o2]) and np.array_equal(c1[o1], pipe.last[1].numpy()[o2])
-    k, c, _ = pipe.last
-    # every key this rank owns must hash to this rank; gather all results on rank 0 and compare with one big join
-    assert np.all(orc.dest_of(k.numpy(), world) == rank)
+    k, c, j = xm.join_group_count(a, None, b, None)
+    assert np.all(orc.dest_of(k, world) == rank)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (k.numpy(), c.numpy(), j))
+    dist.all_gather_object(gathered, (k, c, j))
     if rank == 0:
         ek, ec, ef, ej = orc.join_group_count(orc.gen_keys(total, 0, total, 42, 0), None, orc.gen_keys(total, 0, total, 43, total // 16), None)
         keys = np.concatenate([x[0] for x in gathered])
@@ -64,45 +31,65 @@ def main():
         assert np.array_equal(keys[o1], ek[o2]) and np.array_equal(cnts[o1], ec[o2])
         assert len(np.unique(keys)) == len(keys)		# groups are disjoint across ranks
         print("gloo distributed join ok", len(keys), "groups", ej, "joined rows")
-    payload_join(rank, world)
-    dist.barrier()
-    dist.destroy_process_group()
+
+
+def shuffle_with_payload(rank, world):
+    """mdb_dist_shuffle_rows: keys with NULLs, an INT64 column with NULLs and a DOUBLE column, read through a row-id vector;
+    NULL keys dropped, or kept together on one rank; a failure on one rank reaches every rank through the counts"""
+    n = 5_000
+    rng = np.random.default_rng(11)		# same stream on every rank: the global table
+    total = n * world
+    gk = rng.integers(-20, total // 3, total)
+    gkn = rng.random(total) < 0.05
+    gf, gfn = rng.integers(-2**40, 2**40, total), rng.random(total) < 0.1
+    gx = rng.standard_normal(total)
+    sl = slice(rank * n, (rank + 1) * n)
+    rid = rng.permutation(n)[: n * 3 // 4] if rank == 0 else np.arange(n)		# rank 0's stream is a filtered, reordered one
+    sk, skn = gk[sl][rid], gkn[sl][rid]
+    cols = [(gk[sl], gkn[sl], rid), (gf[sl], gfn[sl], rid), (gx[sl], None, rid)]
+    streams = [None] * world
+    dist.all_gather_object(streams, rank * n + rid)
+    gsel = np.concatenate(streams)
+    for flags in (0, xm.KEEP_NULL_KEYS):
+        out, got = xm.shuffle_rows(sk, skn, cols, flags)
+        dest = orc.dest_of(gk[gsel], world)
+        if flags:
+            dest = np.where(gkn[gsel], orc.dest_of(np.zeros(1, dtype=np.int64), world)[0], dest)
+            mine = dest == rank
+        else:
+            mine = (dest == rank) & ~gkn[gsel]
+        want = gsel[mine]
+        assert got == len(want)
+        # received order = (source rank, send order): compare as multisets of (key, key-null, f, f-null, x bits)
+        def rows(k, kn, f, fn, x):
+            return sorted(zip((np.where(kn, 0, k)).tolist(), kn.tolist(), np.where(fn, 0, f).tolist(), fn.tolist(), x.view(np.int64).tolist()))
+        kn_got = out[0][1] if out[0][1] is not None else np.zeros(got, dtype=bool)
+        assert rows(out[0][0], kn_got, out[1][0], out[1][1], out[2][0]) == rows(gk[want], gkn[want] & bool(flags), gf[want], gfn[want], gx[want])
+        assert out[2][1] is None			# no rank has NULL bits for x: no bitmap comes back
+    try:
+        xm.shuffle_rows(sk, skn, cols, 0, fail=(rank == world - 1))
+        raise SystemExit("a failed rank must fail the exchange everywhere")
+    except xm.ExchangeFailed as e:
+        assert f"rank {world - 1} failed" in str(e)
+    if rank == 0:
+        print("gloo shuffle rows ok")
 
 
 def payload_join(rank, world):
-    """BASELINE config 5 shape on 2 ranks: A(id_a, x DOUBLE) JOIN B(id_b, y DOUBLE) JOIN C(id_c, z INT) on one key,
-    every table shuffled with its payload and its origin id, joined locally (oracle operators), then checked on
-    rank 0 against one big join of the unsharded tables."""
+    """BASELINE configs[4] shape on 2 ranks: A(id_a, x DOUBLE) JOIN B(id_b, y DOUBLE) JOIN C(id_c, z INT) on one key, every
+    table shuffled with its payload, joined locally, checked on rank 0 against one big join of the unsharded tables."""
     n = 3_000
     total = n * world
-    rng = np.random.default_rng(7)		# same stream on every rank: the global tables
-    ga = rng.integers(0, total // 2, total)
-    gb = rng.integers(0, total // 2, total)
-    gc = rng.integers(0, total // 2, total)
+    rng = np.random.default_rng(7)
+    ga, gb, gc = (rng.integers(0, total // 2, total) for _ in range(3))
     gx, gy, gz = rng.normal(0, 1, total), rng.normal(0, 1, total), rng.integers(0, 100, total)
     sl = slice(rank * n, (rank + 1) * n)
-
-    def partition_fn(keys):
-        k = keys.numpy()
-        d = orc.dest_of(k, world)
-        o = np.argsort(d, kind="stable")
-        return torch.from_numpy(k[o]), [int(c) for c in np.bincount(d, minlength=world)], torch.from_numpy(o.astype(np.int32))
-
-    def gather_fn(col, rows):
-        return col[rows.to(torch.int64)]
-
-    sh = TableShuffle(world, torch.device("cpu"), partition_fn, gather_fn)
-    ka, (xa,), oa = sh.run(torch.from_numpy(ga[sl]), [torch.from_numpy(gx[sl])], with_origin=True, rank=rank)
-    kb, (yb,), ob = sh.run(torch.from_numpy(gb[sl]), [torch.from_numpy(gy[sl])], with_origin=True, rank=rank)
-    kc, (zc,), oc = sh.run(torch.from_numpy(gc[sl]), [torch.from_numpy(gz[sl])], with_origin=True, rank=rank)
-    assert np.all(orc.dest_of(ka.numpy(), world) == rank) and np.all(orc.dest_of(kc.numpy(), world) == rank)
-    # origin ids name the source rank and row: payload must be the source table's cell, bit for bit
-    src = (oa.numpy() >> 32) * n + (oa.numpy() & 0xFFFFFFFF)
-    assert np.array_equal(gx[src].view(np.int64), xa.numpy().view(np.int64)) and np.array_equal(ga[src], ka.numpy())
-    l, r = orc.join_pairs(ka.numpy(), None, kb.numpy(), None)
-    kab = ka.numpy()[l]
-    p, q = orc.join_pairs(kab, None, kc.numpy(), None)
-    rows = np.stack([kab[p], xa.numpy().view(np.int64)[l][p], yb.numpy().view(np.int64)[r][p], zc.numpy()[q]], axis=1)
+    kab, (xa,), (yb,) = xm.join_pairs(ga[sl], None, [(gx[sl], None, None)], gb[sl], None, [(gy[sl], None, None)])
+    assert np.all(orc.dest_of(kab, world) == rank)
+    # the joined stream is already where its key hashes to: only C travels
+    co, _ = xm.shuffle_rows(gc[sl], None, [(gc[sl], None, None), (gz[sl], None, None)])
+    p, q = orc.join_pairs(kab, None, co[0][0], None)
+    rows = np.stack([kab[p], xa[0][p], yb[0][p], co[1][0][q]], axis=1)
     gfirst, gcnt = orc.group_count(kab[p], None)
     gk = kab[p][gfirst]
     gathered = [None] * world
@@ -121,6 +108,16 @@ def payload_join(rank, world):
         o1, o2 = np.argsort(k2, kind="stable"), np.argsort(ek, kind="stable")
         assert np.array_equal(k2[o1], ek[o2]) and np.array_equal(c2[o1], ec[o2])
         print("gloo distributed payload join ok", len(got), "joined rows", len(ek), "groups")
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    north_star(rank, world)
+    shuffle_with_payload(rank, world)
+    payload_join(rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -580,21 +580,6 @@ def test_distinct_sel_unpinned(dev, n):
         assert np.array_equal(got, orc.distinct_sel(keys_np, n))
 
 
-def test_table_shuffle_payload_join_rccl():
-    """BASELINE configs 4/5 exchange path with the device operators and RCCL (own process: it creates a process group)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_shuffle_gpu_worker.py")], cwd=root, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert "rccl table shuffle payload join ok" in r.stdout
-    assert "rccl distributed join group count ok" in r.stdout
-
-
 @pytest.mark.parametrize("variant", ["D", "U"])
 def test_full_size_north_star_properties(dev, variant):
     """BASELINE config 3 at its full size (10^8 rows per table) through size-independent properties:
