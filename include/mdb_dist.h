@@ -35,9 +35,12 @@ typedef struct mdb_dist mdb_dist;
  * Rank 0 creates the communicator id, the host program ships the 128 bytes to the other ranks however it
  * likes (MPI, a socket, a file, the launcher's store) and every rank calls mdb_dist_init() with it. */
 int mdb_dist_unique_id(void *id_out /* MDB_DIST_ID_BYTES */);
-/* The same through a file every rank can see: rank 0 writes the id (atomically: temp file + rename), the
- * others wait up to timeout_s seconds for it.  The file is left in place; remove it between runs. */
-int mdb_dist_id_via_file(const char *path, int rank, double timeout_s, void *id_out);
+/* The same through a file every rank can see (one node: a path in /tmp or /dev/shm).  Safe against leftovers of earlier
+ * runs: every rank r > 0 announces itself with a fresh nonce (path.hello.<r>), rank 0 removes any old id file, writes the id
+ * together with the nonces it has seen (atomically: temp file + rename), and a rank only accepts a file that carries its own
+ * nonce - a stale id can never be taken for this run's.  Rank 0 returns once every rank has taken the id; all wait at most
+ * timeout_s seconds. */
+int mdb_dist_id_via_file(const char *path, int world, int rank, double timeout_s, void *id_out);
 
 /* One communicator pair (key transfers; the tiny count exchanges have their own, so that they never queue
  * behind a transfer in flight) over RCCL, for the GPU of `ctx`.  Collective: every rank calls it. */

@@ -73,7 +73,7 @@ struct rccl_transport {
 	char err[256];
 };
 
-#define RT_MAX_COUNTERS 8
+#define RT_MAX_COUNTERS 12
 
 static int rt_fail(rccl_transport *rt, const char *what, ncclResult_t r)
 {
@@ -161,41 +161,137 @@ extern "C" int mdb_dist_unique_id(void *id_out)
 	return MIDORIDB_OK;
 }
 
-extern "C" int mdb_dist_id_via_file(const char *path, int rank, double timeout_s, void *id_out)
+/* The id through a file, safe against what an earlier run left behind.  A file that merely holds an id cannot be told from a
+ * stale one, and a rank that initialises RCCL with a stale id never comes back.  So every rank r > 0 announces itself with a
+ * fresh random nonce (path.hello.<r>), rank 0 - which removes any old id file first - writes the id together with the nonces
+ * it has seen, and rank r only accepts a file that carries ITS nonce, then withdraws its announcement; rank 0 returns when
+ * every announcement is gone (and rewrites the file when it finds one that changed: a leftover of a crashed run, overwritten
+ * by the live rank a moment later). */
+#define IDF_MAGIC 0x3230304449424D4Dull	/* "MMBIDI002"-ish: layout version of the id file */
+
+static double idf_now(void)
 {
-	if (!path || !id_out)
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return (double)t.tv_sec + (double)t.tv_nsec * 1e-9;
+}
+
+static uint64_t idf_nonce(void)
+{
+	uint64_t v = 0;
+	FILE *f = fopen("/dev/urandom", "rb");
+	if (f) {
+		if (fread(&v, 1, sizeof(v), f) != sizeof(v))
+			v = 0;
+		fclose(f);
+	}
+	struct timespec t;
+	clock_gettime(CLOCK_REALTIME, &t);
+	v ^= mdb_fmix64((uint64_t)t.tv_nsec ^ ((uint64_t)t.tv_sec << 30) ^ ((uint64_t)getpid() << 48));
+	return v ? v : 1;
+}
+
+static int idf_write_atomic(const char *path, const void *buf, size_t len)
+{
+	char tmp[4096];
+	if (snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid()) >= (int)sizeof(tmp))
 		return -MIDORIDB_ERROR;
+	FILE *f = fopen(tmp, "wb");
+	if (!f)
+		return -MIDORIDB_ERROR;
+	const bool ok = fwrite(buf, 1, len, f) == len;
+	if (fclose(f) != 0 || !ok || rename(tmp, path) != 0) {
+		(void)remove(tmp);
+		return -MIDORIDB_ERROR;
+	}
+	return MIDORIDB_OK;
+}
+
+static bool idf_read(const char *path, void *buf, size_t len)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f)
+		return false;
+	const size_t got = fread(buf, 1, len, f);
+	fclose(f);
+	return got == len;
+}
+
+extern "C" int mdb_dist_id_via_file(const char *path, int world, int rank, double timeout_s, void *id_out)
+{
+	if (!path || !id_out || world < 1 || rank < 0 || rank >= world || world > (1 << MDB_MAX_RADIX_BITS))
+		return -MIDORIDB_ERROR;
+	char hello[4096];
+	const size_t flen = 16 + 8 * (size_t)world + MDB_DIST_ID_BYTES;	/* magic, world, nonce of every rank (slot 0 unused), id */
+	uint64_t file[2 + (1 << MDB_MAX_RADIX_BITS) + MDB_DIST_ID_BYTES / 8];
+	const double t0 = idf_now();
 	if (rank == 0) {
-		char tmp[4096];
+		uint64_t known[1 << MDB_MAX_RADIX_BITS];
+		bool have[1 << MDB_MAX_RADIX_BITS], acked[1 << MDB_MAX_RADIX_BITS];
+		(void)remove(path);		/* whatever an earlier run left */
 		int rc = mdb_dist_unique_id(id_out);
 		if (rc)
 			return rc;
-		if (snprintf(tmp, sizeof(tmp), "%s.tmp.%ld", path, (long)getpid()) >= (int)sizeof(tmp))
-			return -MIDORIDB_ERROR;
-		FILE *f = fopen(tmp, "wb");
-		if (!f)
-			return -MIDORIDB_ERROR;
-		const bool ok = fwrite(id_out, 1, MDB_DIST_ID_BYTES, f) == MDB_DIST_ID_BYTES;
-		if (fclose(f) != 0 || !ok || rename(tmp, path) != 0) {
-			(void)remove(tmp);
-			return -MIDORIDB_ERROR;
+		for (int r = 0; r < world; r++) {
+			known[r] = 0;
+			have[r] = acked[r] = r == 0;
 		}
-		return MIDORIDB_OK;
-	}
-	struct timespec t0, t;
-	clock_gettime(CLOCK_MONOTONIC, &t0);
-	for (;;) {
-		FILE *f = fopen(path, "rb");
-		if (f) {
-			const size_t got = fread(id_out, 1, MDB_DIST_ID_BYTES, f);
-			fclose(f);
-			if (got == MDB_DIST_ID_BYTES)
+		bool written = false;
+		for (;;) {
+			bool changed = false, all_have = true, all_acked = true;
+			for (int r = 1; r < world; r++) {
+				if (acked[r])
+					continue;
+				uint64_t n = 0;
+				if (snprintf(hello, sizeof(hello), "%s.hello.%d", path, r) >= (int)sizeof(hello))
+					return -MIDORIDB_ERROR;
+				if (idf_read(hello, &n, sizeof(n)) && n) {
+					if (n != known[r]) {
+						known[r] = n;
+						changed = true;
+					}
+					have[r] = true;
+				} else if (have[r] && written && access(hello, F_OK) != 0) {
+					acked[r] = true;	/* the rank took the id and withdrew its announcement */
+				}
+				all_have = all_have && have[r];
+				all_acked = all_acked && acked[r];
+			}
+			if (all_have && (changed || !written)) {
+				file[0] = IDF_MAGIC;
+				file[1] = (uint64_t)world;
+				for (int r = 0; r < world; r++)
+					file[2 + r] = known[r];
+				memcpy(&file[2 + world], id_out, MDB_DIST_ID_BYTES);
+				rc = idf_write_atomic(path, file, flen);
+				if (rc)
+					return rc;
+				written = true;
+			}
+			if (all_acked && (written || world == 1))
 				return MIDORIDB_OK;
+			if (idf_now() - t0 > timeout_s)
+				return -MIDORIDB_ERROR;
+			usleep(1000);
 		}
-		clock_gettime(CLOCK_MONOTONIC, &t);
-		if ((double)(t.tv_sec - t0.tv_sec) + (double)(t.tv_nsec - t0.tv_nsec) * 1e-9 > timeout_s)
+	}
+	const uint64_t mine = idf_nonce();
+	if (snprintf(hello, sizeof(hello), "%s.hello.%d", path, rank) >= (int)sizeof(hello))
+		return -MIDORIDB_ERROR;
+	int rc = idf_write_atomic(hello, &mine, sizeof(mine));
+	if (rc)
+		return rc;
+	for (;;) {
+		if (idf_read(path, file, flen) && file[0] == IDF_MAGIC && file[1] == (uint64_t)world && file[2 + rank] == mine) {
+			memcpy(id_out, &file[2 + world], MDB_DIST_ID_BYTES);
+			(void)remove(hello);
+			return MIDORIDB_OK;
+		}
+		if (idf_now() - t0 > timeout_s) {
+			(void)remove(hello);
 			return -MIDORIDB_ERROR;
-		usleep(2000);
+		}
+		usleep(1000);
 	}
 }
 
@@ -413,17 +509,27 @@ static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64
 	uint64_t scnt[1 << MDB_MAX_RADIX_BITS], rcnt[1 << MDB_MAX_RADIX_BITS];
 	size_t sc[1 << MDB_MAX_RADIX_BITS], sd[1 << MDB_MAX_RADIX_BITS], rc_[1 << MDB_MAX_RADIX_BITS], rd[1 << MDB_MAX_RADIX_BITS];
 	int rc = dist_reserve(d, &d->send[i], &d->send_cap[i], n + 2);
-	if (rc)
-		return rc;
-	rc = mdb_dev_partition_by_dest_pruned(d->ctx, keys, nulls, n, (uint32_t)W, wire32 ? 1 : 0, keep_lo, keep_hi, own_lo, own_hi, d->send[i],
-					      NULL, scnt);	/* (synchronises) */
-	if (rc)
-		return dist_err(d, rc, "partition by destination: %s", mdb_dev_last_error(d->ctx));
-	rc = d->t.counts(d->t.self, scnt, rcnt, 1);
+	/* a failure on this rank (buffer, a key outside its promised range or the 4-byte wire format) travels WITH the counts: every
+	 * rank reaches the count exchange, sees it, and all of them leave together - none is left waiting in the all-to-all */
+	int prc = rc;
+	if (!prc)
+		prc = mdb_dev_partition_by_dest_pruned(d->ctx, keys, nulls, n, (uint32_t)W, wire32 ? 1 : 0, keep_lo, keep_hi, own_lo, own_hi, d->send[i],
+						       NULL, scnt);	/* (synchronises) */
+	uint64_t cs[2 << MDB_MAX_RADIX_BITS], cr[2 << MDB_MAX_RADIX_BITS];
+	for (int p = 0; p < W; p++) {
+		cs[2 * p] = prc ? 0 : scnt[p];
+		cs[2 * p + 1] = prc ? 1 : 0;
+	}
+	rc = d->t.counts(d->t.self, cs, cr, 2);
 	if (rc)
 		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", d->own_transport ? ((rccl_transport *)d->t.self)->err : "");
+	if (prc)
+		return dist_err(d, prc, "partition by destination: %s", mdb_dev_last_error(d->ctx));
 	uint64_t total = 0, sent = 0;
 	for (int p = 0; p < W; p++) {
+		if (cr[2 * p + 1])
+			return dist_err(d, -MIDORIDB_ERROR, "rank %d failed while it partitioned its rows (its own message says why); nothing was exchanged", p);
+		rcnt[p] = cr[2 * p];
 		sc[p] = (size_t)scnt[p];
 		sd[p] = (size_t)sent;
 		rc_[p] = (size_t)rcnt[p];
@@ -442,6 +548,21 @@ static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64
 	DIST_HIP(d, hipEventRecord(done, d->comm_stream));
 	*n_recv = total;
 	return MIDORIDB_OK;
+}
+
+/* the outputs a call allocated do not outlive its failure */
+static int dist_join_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t **out_key, int64_t **out_count, uint32_t **out_first, int rc)
+{
+	if (alloc_out) {
+		(void)mdb_dev_free(ctx, *out_key);
+		(void)mdb_dev_free(ctx, *out_count);
+		*out_key = *out_count = NULL;
+		if (out_first) {
+			(void)mdb_dev_free(ctx, *out_first);
+			*out_first = NULL;
+		}
+	}
+	return rc;
 }
 
 /* common part: exchange (the left table only unless it is already in place), local join into buffers that are either the
@@ -467,13 +588,14 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 		const uint64_t *nb[2] = { null_l, null_r };
 		const uint64_t ns[2] = { n_l, n_r };
 		/* (eight 32-bit halves per rank: the counters of a transport need not survive values beyond 2^63) */
-		uint64_t mine[4], all[8 << MDB_MAX_RADIX_BITS], sendv[8 << MDB_MAX_RADIX_BITS];
+		uint64_t mine[4], all[9 << MDB_MAX_RADIX_BITS], sendv[9 << MDB_MAX_RADIX_BITS];
+		int range_rc = MIDORIDB_OK;
 		for (int i = 0; i < 2; i++) {
 			int64_t lo = 0, hi = -1;
-			if (ns[i]) {
-				int rc = mdb_dev_key_range(ctx, cols[i], nb[i], ns[i], &lo, &hi);
-				if (rc)
-					return dist_err(d, rc, "key range: %s", mdb_dev_last_error(ctx));
+			if (ns[i] && !range_rc) {
+				range_rc = mdb_dev_key_range(ctx, cols[i], nb[i], ns[i], &lo, &hi);
+				if (range_rc)
+					dist_err(d, range_rc, "key range: %s", mdb_dev_last_error(ctx));
 			}
 			if (lo > hi) {		/* no key at all on this rank */
 				lo = INT64_MAX;
@@ -482,19 +604,26 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 			mine[2 * i] = (uint64_t)lo;
 			mine[2 * i + 1] = (uint64_t)hi;
 		}
-		for (int p = 0; p < W; p++)
+		for (int p = 0; p < W; p++) {
 			for (int q = 0; q < 4; q++) {
-				sendv[8 * p + 2 * q] = mine[q] >> 32;
-				sendv[8 * p + 2 * q + 1] = mine[q] & 0xFFFFFFFFull;
+				sendv[9 * p + 2 * q] = mine[q] >> 32;
+				sendv[9 * p + 2 * q + 1] = mine[q] & 0xFFFFFFFFull;
 			}
-		int rc = d->t.counts(d->t.self, sendv, all, 8);		/* every rank's four numbers to every rank */
+			sendv[9 * p + 8] = range_rc ? 1 : 0;	/* (status: a rank whose statistics pass failed takes every rank out with it) */
+		}
+		int rc = d->t.counts(d->t.self, sendv, all, 9);		/* every rank's four numbers (+ status) to every rank */
 		if (rc)
 			return dist_err(d, rc, "key range exchange failed");
+		if (range_rc)
+			return range_rc;
+		for (int p = 0; p < W; p++)
+			if (all[9 * p + 8])
+				return dist_err(d, -MIDORIDB_ERROR, "rank %d failed while it measured its key ranges; nothing was exchanged", p);
 		for (int i = 0; i < 2; i++) {
 			int64_t lo = INT64_MAX, hi = INT64_MIN;
 			for (int p = 0; p < W; p++) {
-				const int64_t plo = (int64_t)((all[8 * p + 4 * i] << 32) | all[8 * p + 4 * i + 1]);
-				const int64_t phi = (int64_t)((all[8 * p + 4 * i + 2] << 32) | all[8 * p + 4 * i + 3]);
+				const int64_t plo = (int64_t)((all[9 * p + 4 * i] << 32) | all[9 * p + 4 * i + 1]);
+				const int64_t phi = (int64_t)((all[9 * p + 4 * i + 2] << 32) | all[9 * p + 4 * i + 3]);
 				lo = plo < lo ? plo : lo;
 				hi = phi > hi ? phi : hi;
 			}
@@ -566,8 +695,10 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 		else
 			rc = mdb_dev_join_group_count_begin(ctx, (const int64_t *)d->recv[0], NULL, got_l, got_r);
 	}
-	if (rc)
-		return dist_err(d, rc, "local join (begin): %s", mdb_dev_last_error(ctx));
+	if (rc) {
+		dist_err(d, rc, "local join (begin): %s", mdb_dev_last_error(ctx));
+		return dist_join_fail(ctx, alloc_out, out_key, out_count, out_first, rc);
+	}
 	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_b, 0));
 	uint64_t G = 0, J = 0;
 	uint32_t *first = out_first ? *out_first : NULL;
@@ -577,8 +708,10 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	else	/* (a left table in place is int64: its right table always travels as 8-byte keys) */
 		rc = mdb_dev_join_group_count_finish(ctx, (const int64_t *)d->recv[1], NULL, got_r, MDB_ORDER_FIRST, *out_key, *out_count, first, cap,
 						     &G, &J);
-	if (rc)
-		return dist_err(d, rc, "local join (finish): %s", mdb_dev_last_error(ctx));
+	if (rc) {
+		dist_err(d, rc, "local join (finish): %s", mdb_dev_last_error(ctx));
+		return dist_join_fail(ctx, alloc_out, out_key, out_count, out_first, rc);
+	}
 	*out_groups = G;
 	if (out_joined)
 		*out_joined = J;

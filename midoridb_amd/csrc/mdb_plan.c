@@ -322,6 +322,11 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 			if (e)
 				e->ival = atoi(t + 7);	/* 32-bit, as the reference (ast_select.c:75) */
 		} else if (starts(t, "STRING ")) {
+			/* the lexer hands a string on WITH its quotes (midorisql.l: '...' or "..."); every later site strips them by
+			 * position, so a token without a matching pair - possible only through mdb_query_execute_rpn() - stops here */
+			const size_t sl = strlen(t + 7);
+			if (sl < 2 || (t[7] != '\'' && t[7] != '"') || t[7 + sl - 1] != t[7])
+				FAIL("error while running syntax analysis on query\n");
 			e = ex_new(MDB_EX_STRING);
 			if (e && !(e->sval = strdup(t + 7))) {	/* the literal with its quotes, as the lexer hands it on */
 				mdb_expr_free(e);

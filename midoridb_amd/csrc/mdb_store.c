@@ -259,7 +259,7 @@ int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen)
 			const int rank = getenv("MIDORIDB_RANK") ? atoi(getenv("MIDORIDB_RANK")) : -1;
 			const char *idf = getenv("MIDORIDB_DIST_ID_FILE");
 			char id[MDB_DIST_ID_BYTES];
-			int rc = (rank < 0 || rank >= world || !idf) ? -MIDORIDB_ERROR : mdb_dist_id_via_file(idf, rank, 300.0, id);
+			int rc = (rank < 0 || rank >= world || !idf) ? -MIDORIDB_ERROR : mdb_dist_id_via_file(idf, world, rank, 300.0, id);
 			if (!rc)
 				rc = mdb_dist_init(cat->dev, world, rank, id, &cat->dist);
 			if (rc) {

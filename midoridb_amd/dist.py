@@ -50,7 +50,7 @@ def _bind(lib):
     P = c_void_p
     sig = {
         "mdb_dist_unique_id": ([P], c_int),
-        "mdb_dist_id_via_file": ([c_char_p, c_int, c_double, P], c_int),
+        "mdb_dist_id_via_file": ([c_char_p, c_int, c_int, c_double, P], c_int),
         "mdb_dist_init": ([P, c_int, c_int, P, POINTER(P)], c_int),
         "mdb_dist_destroy": ([P], None),
         "mdb_dist_world": ([P], c_int),
@@ -149,7 +149,7 @@ class DistCtx:
         lib = load_library()
         _bind(lib)
         buf = ctypes.create_string_buffer(MDB_DIST_ID_BYTES)
-        if lib.mdb_dist_id_via_file(path.encode(), rank, timeout_s, buf) != 0:
+        if lib.mdb_dist_id_via_file(path.encode(), world, rank, timeout_s, buf) != 0:
             raise DistError(f"no communicator id through {path}")
         return cls(dev, world, rank, buf.raw)
 

@@ -271,3 +271,63 @@ def test_sql_front_end_emits_the_hand_written_rpn_of_every_fixture_select():
         assert _rpn(sql) == hw, sql
         checked += 1
     assert checked >= 150
+
+
+def test_rpn_string_tokens_need_their_quotes_and_bulk_append_validates_first():
+    """mdb_query_execute_rpn() takes the parser's queue from anyone: a STRING token that does not carry its pair of quotes (the
+    lexer always delivers them, reference midorisql.l:100-101) is a syntax error, never an out-of-bounds length.  And
+    mdb_table_append_columns() validates every column before it touches one (NULL strings in NOT NULL VARCHAR columns)."""
+    from midoridb_amd.query import DB, ST_ERROR
+    with DB() as db:
+        db.execute("CREATE TABLE T (a INT, s VARCHAR(8));")
+        for tok in ("STRING x", "STRING '", "STRING 'x", "STRING x'", "STRING "):
+            rpn = f"NUMBER 1\n{tok}\nVALUES 2\nINSERTVALS 0 1 T\nSTMT"
+            out = db.lib.mdb_query_execute_rpn(ctypes.byref(db.db), rpn.encode())
+            assert out.contents.status == ST_ERROR, tok
+            db.lib.query_free(out)
+        out = db.lib.mdb_query_execute_rpn(ctypes.byref(db.db), b"NUMBER 1\nSTRING 'ok'\nVALUES 2\nINSERTVALS 0 1 T\nSTMT")
+        assert out.contents.status != ST_ERROR, out.contents.error.message
+        db.lib.query_free(out)
+        db.execute("CREATE TABLE N (k INT, s VARCHAR(8) NOT NULL);")
+        with pytest.raises(Exception):
+            db.append_columns("N", [np.arange(3), ["a", None, "c"]])
+        db.append_columns("N", [np.arange(3), ["a", "b", "c"]])
+        # nothing of the refused batch stayed behind: 3 rows, and no NULL was counted for column k
+        out = db.lib.mdb_query_execute_rpn(ctypes.byref(db.db), b"NUMBER 7\nSTRING 'z'\nVALUES 2\nINSERTVALS 0 1 N\nSTMT")
+        assert out.contents.status != ST_ERROR
+        db.lib.query_free(out)
+
+
+def test_communicator_id_file_survives_leftovers_of_earlier_runs(tmp_path):
+    """mdb_dist_id_via_file: a stale id file and a stale announcement of a crashed run are lying around; three ranks (threads of a
+    fresh process here) that start at different times still end up with ONE fresh id - a rank only accepts a file that carries its
+    own nonce."""
+    import subprocess
+    import sys
+    script = r'''
+import ctypes, os, sys, threading, time
+sys.path.insert(0, %r)
+from midoridb_amd import dist as d
+from midoridb_amd.lib import load_library
+lib = load_library()
+d._bind(lib)
+p = os.path.join(%r, "id")
+open(p, "wb").write(b"x" * 200)
+open(p + ".hello.1", "wb").write(b"12345678")
+out = [None] * 3
+def run(r, delay):
+    time.sleep(delay)
+    b = ctypes.create_string_buffer(128)
+    out[r] = (lib.mdb_dist_id_via_file(p.encode(), 3, r, 30.0, b), b.raw)
+ths = [threading.Thread(target=run, args=a) for a in ((0, 0.0), (1, 0.3), (2, 0.1))]
+[t.start() for t in ths]
+[t.join() for t in ths]
+assert [o[0] for o in out] == [0, 0, 0], out
+assert out[0][1] == out[1][1] == out[2][1] and out[0][1] != b"x" * 128
+assert sorted(os.listdir(os.path.dirname(p))) == ["id"]		# announcements withdrawn
+b = ctypes.create_string_buffer(128)
+assert lib.mdb_dist_id_via_file(p.encode(), 2, 1, 0.2, b) != 0	# nobody plays rank 0: a timeout, not a stale id
+print("id file ok")
+''' % (ROOT, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "id file ok" in r.stdout, r.stdout[-3000:]
