@@ -43,44 +43,21 @@ METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
-# profiler kernel name -> kernel names in the rocprofv3 summary kept under profiles/ (PMC traffic per launch)
-ROCPROF_NAMES = {
-    "leaf_join_group_count": ["k_leaf_group_count<true, true, false, true>", "k_leaf_group_count<true, false, false, true>",
-                              "k_leaf_group_count<true, true, false, false>", "k_leaf_group_count<true, false, false, false>"],
-    "leaf_join_direct": ["k_leaf_direct<true, 512, 2048>", "k_leaf_direct<true, 512>"],
-    "leaf_join_wide": ["k_leaf_wide<true, true>", "k_leaf_wide<true, false>", "k_leaf_wide<true>"],
-    "leaf_group_wide": ["k_leaf_wide<false, false>", "k_leaf_wide<false>"],
-    "order_leaf_sparse": ["k_order_leaf_sparse"],
-    "leaf_bitmap": ["k_leaf_bitmap"],
-    "leaf_group_count": ["k_leaf_group_count<false, false, false, true>", "k_leaf_group_count<false, false, false, false>"],
-    # k_part_scatter<LEVEL0, HAS_RID, STABLE, FAST, RAW, W32, INV, FILT, OUT16, CF> (FILT since round 2's semi-join filter, OUT16 since the
-    # 2-byte first-level words of the one-level form, CF since the compile-time compact form; the profiles of earlier commits carry the
-    # shorter names)
-    "part_scatter_l0": ["k_part_scatter<true, false, false, true, false, false, false, false, false, true>", "k_part_scatter<true, false, false, true, false, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false>"],
-    "part_scatter_l0_pruned": ["k_part_scatter<true, false, false, true, false, false, false, false, false, true>", "k_part_scatter<true, false, false, true, false, false, false, false, false>", "k_part_scatter<true, false, false, true, false, false, false, false>"],
-    "part_scatter_l0_w32": ["k_part_scatter<true, false, false, true, false, true, false, false, true, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, true, false>", "k_part_scatter<true, false, false, true, false, true, false, false, true>", "k_part_scatter<true, false, false, true, false, true, false, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false, false>", "k_part_scatter<true, false, false, true, false, true, false, false>", "k_part_scatter<true, false, false, true, false, true, false>"],
-    "part_scatter_l0_rid": ["k_part_scatter<true, true, false, true, false, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false, false>", "k_part_scatter<true, true, false, true, false, false, false>"],
-    "part_scatter_l1": ["k_part_scatter<false, false, false, true, false, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, false, false>"],
-    "part_scatter_l1_semi": ["k_part_scatter<false, false, false, true, false, false, false, true, false, false>", "k_part_scatter<false, false, false, true, false, false, false, true, false>", "k_part_scatter<false, false, false, true, false, false, false, true>"],
-    "part_scatter_l1_w32": ["k_part_scatter<false, false, false, true, false, true, false, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false, false>", "k_part_scatter<false, false, false, true, false, true, false, false>", "k_part_scatter<false, false, false, true, false, true, false>"],
-    "part_scatter_l1_rid": ["k_part_scatter<false, true, false, true, false, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false, false>", "k_part_scatter<false, true, false, true, false, false, false>"],
-    "order_leaf": ["k_order_leaf"],
-    "gather64": ["k_gather64"],
-}
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN/rocprof_summary.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), newest round first, or None.  Counters cannot be collected
-    from inside this process; the summary comes from `bash profiles/collect.sh` on the same workload (10^8 rows, variant D)."""
-    for rnd in ("r02", "r01"):
+def pmc_traffic(rocprof_names, variant="D"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/rNN/rocprof_summary*.json: FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE), newest round first, or None.  `rocprof_names` = the names rocprofv3 lists the kernel's
+    template instances under; they come from the library itself (mdb_dev_prof_symbols: the symbols of what was launched under the
+    profiler name), so nothing here spells a mangled name.  Counters cannot be collected from inside this process; the summary comes
+    from `bash profiles/collect.sh` on the same workload (10^8 rows, the same variant)."""
+    suffix = "" if variant == "D" else f"_{variant}"
+    for rnd in ("r03", "r02", "r01"):
         try:
-            with open(os.path.join(ROOT, "profiles", rnd, "rocprof_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", rnd, f"rocprof_summary{suffix}.json")) as f:
                 ks = json.load(f)["kernels"]
-            vals = [ks[n]["hbm_read_bytes"] + ks[n]["hbm_write_bytes"] for n in ROCPROF_NAMES.get(kernel, [])
+            vals = [ks[n]["hbm_read_bytes"] + ks[n]["hbm_write_bytes"] for n in rocprof_names
                     if n in ks and "hbm_read_bytes" in ks[n] and "hbm_write_bytes" in ks[n]]
             if vals:
-                return {"bytes": sum(vals) / len(vals), "source": f"profiles/{rnd}/rocprof_summary.json"}
+                return {"bytes": sum(vals) / len(vals), "source": f"profiles/{rnd}/rocprof_summary{suffix}.json"}
         except Exception:
             continue
     return None
@@ -135,8 +112,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per table per GPU (weak scaling); 125000000 = BASELINE configs[3] on 8 GPUs")
-    ap.add_argument("--variant", choices=["U", "D"], default="D",
-                    help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates)")
+    ap.add_argument("--variant", choices=["U", "D", "S"], default="D",
+                    help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates, all in the lowest sixteenth "
+                         "of A's key range); S: the same duplication SPREAD over A's whole range, B keys = 16 * (perm mod N/16) - no range "
+                         "for min-max pruning to use, no small key window")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="which form is the primary line at N > 1 (the other one is reported beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -354,8 +333,11 @@ def main():
     def make_tables(n_rank):
         """rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)"""
         total = n_rank * world
-        mod = total // 16 if args.variant == "D" else 0
-        return (dev.gen_keys(n_rank, rank * n_rank, total, 42, 0), dev.gen_keys(n_rank, rank * n_rank, total, 43, mod), total, mod)
+        mod = total // 16 if args.variant in ("D", "S") else 0
+        b = dev.gen_keys(n_rank, rank * n_rank, total, 43, mod)
+        if args.variant == "S":
+            b.mul_(16)
+        return (dev.gen_keys(n_rank, rank * n_rank, total, 42, 0), b, total, mod)
 
     def make_out(n_rank):
         cap = int(n_rank * 1.3) + 4096 if use_dist else n_rank
@@ -449,6 +431,7 @@ def main():
     for _ in range(prof_steps):
         step()
     prof = dev.prof_read()
+    prof_syms = {k: dev.prof_symbols(k) for k in prof}     # rocprofv3's names of what ran under each profiler name
     dev.prof_enable(False)
     # practical HBM ceiling of this box: device-to-device copy of one key column (read + write)
     copy_gbs = None
@@ -486,7 +469,8 @@ def main():
         pruned = dev.last_join_filter()[1]
         levels = 1 if (dev.last_join_levels() == 1 and os.environ.get("MDB_WORDS16", "1") != "0") else 2
         g_rank = groups_total / max(world, 1)
-        kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps} for k, v in prof.items()}
+        kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps, "rocprof_names": prof_syms.get(k, [])}
+                for k, v in prof.items()}
         for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
             if d["ms_per_step"] > 0:
                 d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow, pruned, levels) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
@@ -497,7 +481,7 @@ def main():
             avg_ms = d["ms_per_step"] / launches
             bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow, pruned, levels)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            tr = pmc_traffic(name) if (n == 100_000_000 and args.variant == "D" and world == 1) else None
+            tr = pmc_traffic(prof_syms.get(name, []), args.variant) if (n == 100_000_000 and world == 1 and not use_dist) else None
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                     "d2d_copy_GBs": copy_gbs, "frac_of_d2d_copy": (achieved / copy_gbs) if copy_gbs else None,
@@ -515,7 +499,8 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU x {world} GPU = {total_rows} rows/table "
                                    f"({scaling_name} scaling), variant {args.variant} "
-                                   f"({'B keys 16x duplicated' if args.variant == 'D' else 'unique keys both sides'})",
+                                   + {"D": "(B keys 16x duplicated, in the lowest sixteenth of A's key range)", "U": "(unique keys both sides)",
+                                      "S": "(B keys 16x duplicated, spread over A's whole key range)"}[args.variant],
                        "key_form": ["wide (64-bit hashes)", "narrow (keys within one 2^32-wide window, verified on the device: 32-bit hashes)",
                                     "compact narrow (keys within the sampled 2^k-wide window, verified on the device: k-bit hashes, "
                                     "direct-address leaf tables)"][dev.last_join_form()],
@@ -577,16 +562,29 @@ def main():
                 line["wide_form"] = {"error": str(e)}
             finally:
                 dev.set_narrow_keys(1)
+            def pipe_frac(groups, seconds):
+                ab = 8 * 2 * n + 16 * groups
+                return {"algorithmic_bytes": ab, "achieved_GBs": ab / seconds / 1e9, "frac_of_peak": ab / seconds / 1e9 / HBM_PEAK_GBS}
+            if "wide_form" in line and "ms_per_step" in line["wide_form"]:
+                line["wide_form"]["pipeline"] = pipe_frac(groups_total, line["wide_form"]["ms_per_step"] * 1e-3)
             if args.variant == "D":
-                # the other synthetic variant of SURVEY 8d C3 (unique keys on both sides: G = n groups), same pipeline
-                try:
-                    b_u = dev.gen_keys(n, 0, n, 43, 0)
-                    dtu, ru = timed(lambda: dev.join_group_count(a, None, b_u, None, out=out))
-                    line["variant_U"] = {"workload": f"unique keys both sides, {n} rows/table", "joined_rows": ru[3], "groups": int(ru[0].numel()),
-                                         "ms_per_step": dtu * 1e3, "value": ru[3] / dtu}
-                    del b_u
-                except Exception as e:  # pragma: no cover
-                    line["variant_U"] = {"error": str(e)}
+                # the unfavourable variants beside the headline, same pipeline: U (unique keys on both sides, G = n groups,
+                # nothing to prune) and S (the headline's 16x duplication, but spread over A's whole key range: no range for min-max
+                # pruning, no small key window - what a fact table whose keys are not bunched at the bottom of the dimension's looks like)
+                for tag, workload, make_b in (
+                        ("variant_U", f"unique keys both sides, {n} rows/table", lambda: dev.gen_keys(n, 0, n, 43, 0)),
+                        ("variant_D_spread", f"B keys 16x duplicated and spread over A's whole range (id_b = 16 * (perm mod N/16)), {n} rows/table",
+                         lambda: dev.gen_keys(n, 0, n, 43, n // 16).mul_(16))):
+                    try:
+                        b_x = make_b()
+                        dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out))
+                        line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
+                                     "value": ru[3] / dtu, "pipeline": pipe_frac(int(ru[0].numel()), dtu),
+                                     "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
+                                     "min_max_pruning": bool(dev.last_join_filter()[1])}
+                        del b_x
+                    except Exception as e:  # pragma: no cover
+                        line[tag] = {"error": str(e)}
             try:
                 line["end_to_end"] = end_to_end(n, mod_b, a, b)
             except Exception as e:  # pragma: no cover
@@ -607,8 +605,8 @@ def main():
                 line["cpu_hash"] = {"error": str(e)}
         if args.verify and n <= 20_000_000 and world == 1:
             from oracle import cpu, np_oracle as orc
-            ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(n, 0, n, 42, 0), None, orc.gen_keys(n, 0, n, 43, mod_b),
-                                                       None, os.cpu_count() or 1)
+            eb = orc.gen_keys(n, 0, n, 43, mod_b) * (16 if args.variant == "S" else 1)
+            ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(n, 0, n, 42, 0), None, eb, None, os.cpu_count() or 1)
             if pipeline is None:
                 k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
                 ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))

@@ -111,6 +111,10 @@ struct mdb_dev_prof_entry {
 int mdb_dev_prof_enable(mdb_dev_ctx *ctx, int on);
 int mdb_dev_prof_reset(mdb_dev_ctx *ctx);
 int mdb_dev_prof_read(mdb_dev_ctx *ctx, struct mdb_dev_prof_entry *out, int cap, int *n_out);
+/* out (capacity cap) = the symbols of the kernels launched under profiler name `name` since profiling was enabled - the
+ * template instances an external profiler (rocprofv3) lists them under -, newline-separated: ties the live per-kernel
+ * timings to the rows of a rocprofv3 summary without anybody spelling a mangled name */
+int mdb_dev_prof_symbols(mdb_dev_ctx *ctx, const char *name, char *out, size_t cap);
 
 /* ------------------------------------------------------------------ scan + filter
  *

@@ -21,14 +21,12 @@ struct mdb_prof_rec {
 	hipEvent_t start, stop;
 };
 
-struct mdb_dev_ctx {
-	int device;
-	int num_cus;			/* compute units of the device (256 on MI355X) */
-	hipStream_t stream;		/* stream every operator launches on */
-	bool own_stream;
-	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
-	hipEvent_t ev_fork, ev_join;
-	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
+/* What the join / GROUP BY operators remember about key columns (sampled ranges, key forms, duplicate flags, layouts that
+ * overflowed): verdicts keyed by the columns' device addresses and lengths, each verified on the device when it is used - a
+ * stale one costs a failed attempt, never a result.  The live set belongs to ONE pair of key columns (memo_key); the context
+ * keeps the sets of the last MDB_MEMO_SLOTS pairs (mdb_memo_switch, mdb_dev_core.hip), so queries that alternate over several
+ * table pairs do not evict each other's verdicts and pay the key sample + its host sync on every call. */
+struct mdb_col_memo {
 	/* outcome of the last narrow-form decision, keyed by the key columns it was made for: a repeated query over the same
 	 * columns skips the sampling kernel and its sync (every key is still verified while it is partitioned) */
 	const void *nh_kl, *nh_kr;
@@ -70,10 +68,30 @@ struct mdb_dev_ctx {
 	const void *lw_bad_keys;	/* the left key column (and the two row counts) for which a 16-bit row count of the one-level direct leaves */
 	uint64_t lw_bad_nl, lw_bad_nr;	/* (k_leaf_wide) overflowed last: two levels for these columns */
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
+};
+
+#define MDB_MEMO_SLOTS 8
+struct mdb_memo_key {
+	const void *kl, *kr;
+	uint64_t nl, nr;
+	bool operator==(const mdb_memo_key &o) const { return kl == o.kl && kr == o.kr && nl == o.nl && nr == o.nr; }
+};
+
+struct mdb_dev_ctx : mdb_col_memo {
+	int device;
+	int num_cus;			/* compute units of the device (256 on MI355X) */
+	hipStream_t stream;		/* stream every operator launches on */
+	bool own_stream;
+	hipStream_t aux_stream;		/* second stream: the two tables of a join are partitioned concurrently */
+	hipEvent_t ev_fork, ev_join;
+	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
+	bool guess_remembered;		/* the last narrow-form decision came from the memo, not from a sample of the data */
+	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */
+	std::vector<std::pair<mdb_memo_key, mdb_col_memo>> memo_lru;	/* the other pairs' sets, most recently used last */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
 	 * allocates dozens of temporaries and hipMalloc/hipFree cost 0.1-0.3 ms each */
 	std::unordered_map<void *, size_t> live;		/* buffers handed out -> size */
@@ -91,12 +109,17 @@ struct mdb_dev_ctx {
 	/* profiling */
 	bool prof_on;
 	std::vector<std::string> prof_names;
+	std::vector<std::vector<const void *>> prof_kernels;	/* per name: the kernel functions (template instances) launched under it */
 	std::vector<mdb_prof_rec> prof_recs;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
 	size_t prof_pool_used;
 };
 
 int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
+
+/* make the live memo the one of the key-column pair (kl, nl, kr, nr) - kr = NULL for a one-column operator (GROUP BY): the set
+ * of the pair used before is put aside, the pair's own set (or an empty one) comes back (mdb_dev_core.hip) */
+void mdb_memo_switch(mdb_dev_ctx *ctx, const void *kl, uint64_t nl, const void *kr, uint64_t nr);
 
 #define MDB_HIP(ctx, call)                                                                         \
 	do {                                                                                       \
@@ -122,12 +145,12 @@ int mdb_aux_end(mdb_dev_ctx *ctx, hipStream_t saved_main);	/* back to the main s
 int mdb_aux_join(mdb_dev_ctx *ctx);				/* main stream waits for the marked aux work */
 
 /* profiling hooks around one launch */
-void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name);
+void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name, const void *kernel);
 void mdb_prof_end(mdb_dev_ctx *ctx);
 
 #define MDB_LAUNCH(ctx, name, kernel, grid, block, ...)                                            \
 	do {                                                                                       \
-		mdb_prof_begin((ctx), (name));                                                     \
+		mdb_prof_begin((ctx), (name), (const void *)(kernel));                             \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); \
 		mdb_prof_end((ctx));                                                               \
 		hipError_t le__ = hipGetLastError();                                               \
@@ -139,7 +162,7 @@ void mdb_prof_end(mdb_dev_ctx *ctx);
 /* the same with dynamic LDS */
 #define MDB_LAUNCH_LDS(ctx, name, kernel, grid, block, lds_bytes, ...)                             \
 	do {                                                                                       \
-		mdb_prof_begin((ctx), (name));                                                     \
+		mdb_prof_begin((ctx), (name), (const void *)(kernel));                             \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (ctx)->stream, __VA_ARGS__); \
 		mdb_prof_end((ctx));                                                               \
 		hipError_t le__ = hipGetLastError();                                               \

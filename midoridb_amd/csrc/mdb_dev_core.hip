@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include "mdb_gen.h"
+#include <cxxabi.h>
 
 int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -27,6 +28,12 @@ extern "C" int mdb_dev_device_count(void)
 	if (hipGetDeviceCount(&n) != hipSuccess)
 		return -MIDORIDB_INTERNAL;
 	return n;
+}
+
+static void memo_reset(mdb_col_memo &m)
+{
+	memset(&m, 0, sizeof(m));	/* (plain data: pointers, counters, flags) */
+	m.nh_result = -1;
 }
 
 extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
@@ -71,22 +78,8 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	ctx->narrow_mode = 1;
 	ctx->last_narrow = 0;
 	ctx->last_semijoin = 0;
-	ctx->pu_dup_keys = NULL;
-	ctx->pu_dup_n = 0;
-	ctx->pu_dupl_keys = NULL;
-	ctx->pu_dupl_n = 0;
-	ctx->pu_dup_skips = 0;
-	ctx->nh_kl = ctx->nh_kr = NULL;
-	ctx->nh_nl = ctx->nh_nr = 0;
-	ctx->nh_result = -1;
-	ctx->nh_distrust = 0;
-	ctx->sr_valid = 0;
-	ctx->sr_uses = ctx->nh_uses = 0;
-	ctx->gh_keys = NULL;
-	ctx->gh_n = 0;
-	ctx->gh_distinct = 0;
-	ctx->gh_uses = 0;
-	ctx->sr_kl = ctx->sr_kr = NULL;
+	memo_reset(*ctx);
+	ctx->memo_key = mdb_memo_key{ NULL, NULL, 0, 0 };
 	{
 		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
 		if (e && e[0] >= '0' && e[0] <= '2' && !e[1])
@@ -318,28 +311,72 @@ int mdb_cached_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
  * through the library (UPDATE: mdb_dev_scatter_set64; an upload into an existing buffer), takes what was learned about it
  * along: the next operator over that address samples afresh instead of trusting a verdict about other data (results never
  * depended on it - every verdict is verified on the device - but a wrong one costs a failed attempt, for up to 8 uses). */
+static void memo_drop(mdb_col_memo &m, uintptr_t a, uintptr_t b)
+{
+	auto hit = [a, b](const void *p) { return p && (uintptr_t)p >= a && (uintptr_t)p < b; };
+	if (hit(m.nh_kl) || hit(m.nh_kr))
+		m.nh_result = -1;
+	if (hit(m.sr_kl) || hit(m.sr_kr))
+		m.sr_valid = 0;
+	if (hit(m.gh_keys))
+		m.gh_keys = NULL;
+	if (hit(m.ex_keys))
+		m.ex_keys = NULL;
+	if (hit(m.pw_bad_keys))
+		m.pw_bad_keys = NULL;
+	if (hit(m.pu_dup_keys))
+		m.pu_dup_keys = NULL;
+	if (hit(m.pu_dupl_keys))
+		m.pu_dupl_keys = NULL;
+	if (hit(m.r32_kl) || hit(m.r32_kr))
+		m.r32_ok = false;
+	if (hit(m.lw_bad_keys))
+		m.lw_bad_keys = NULL;
+}
+
 static void mdb_hints_drop(mdb_dev_ctx *ctx, const void *lo, size_t bytes)
 {
 	const uintptr_t a = (uintptr_t)lo, b = a + (bytes ? bytes : 1);
-	auto hit = [a, b](const void *p) { return p && (uintptr_t)p >= a && (uintptr_t)p < b; };
-	if (hit(ctx->nh_kl) || hit(ctx->nh_kr))
-		ctx->nh_result = -1;
-	if (hit(ctx->sr_kl) || hit(ctx->sr_kr))
-		ctx->sr_valid = 0;
-	if (hit(ctx->gh_keys))
-		ctx->gh_keys = NULL;
-	if (hit(ctx->ex_keys))
-		ctx->ex_keys = NULL;
-	if (hit(ctx->pw_bad_keys))
-		ctx->pw_bad_keys = NULL;
-	if (hit(ctx->pu_dup_keys))
-		ctx->pu_dup_keys = NULL;
-	if (hit(ctx->pu_dupl_keys))
-		ctx->pu_dupl_keys = NULL;
-	if (hit(ctx->r32_kl) || hit(ctx->r32_kr))
-		ctx->r32_ok = false;
-	if (hit(ctx->lw_bad_keys))
-		ctx->lw_bad_keys = NULL;
+	memo_drop(*ctx, a, b);
+	/* the sets put aside for other column pairs: a set whose own columns are touched goes altogether */
+	for (size_t i = 0; i < ctx->memo_lru.size();) {
+		const mdb_memo_key &k = ctx->memo_lru[i].first;
+		const bool own = (k.kl && (uintptr_t)k.kl >= a && (uintptr_t)k.kl < b) || (k.kr && (uintptr_t)k.kr >= a && (uintptr_t)k.kr < b);
+		if (own) {
+			ctx->memo_lru.erase(ctx->memo_lru.begin() + (long)i);
+			continue;
+		}
+		memo_drop(ctx->memo_lru[i].second, a, b);
+		i++;
+	}
+}
+
+void mdb_memo_switch(mdb_dev_ctx *ctx, const void *kl, uint64_t nl, const void *kr, uint64_t nr)
+{
+	const mdb_memo_key key{ kl, kr, nl, kr ? nr : 0 };
+	if (ctx->memo_key == key)
+		return;
+	/* put the live set aside under the pair it belongs to */
+	if (ctx->memo_key.kl) {
+		size_t i = 0;
+		while (i < ctx->memo_lru.size() && !(ctx->memo_lru[i].first == ctx->memo_key))
+			i++;
+		if (i < ctx->memo_lru.size())
+			ctx->memo_lru.erase(ctx->memo_lru.begin() + (long)i);
+		ctx->memo_lru.push_back(std::make_pair(ctx->memo_key, static_cast<const mdb_col_memo &>(*ctx)));
+		if (ctx->memo_lru.size() > MDB_MEMO_SLOTS)
+			ctx->memo_lru.erase(ctx->memo_lru.begin());
+	}
+	size_t i = 0;
+	while (i < ctx->memo_lru.size() && !(ctx->memo_lru[i].first == key))
+		i++;
+	if (i < ctx->memo_lru.size()) {
+		static_cast<mdb_col_memo &>(*ctx) = ctx->memo_lru[i].second;
+		ctx->memo_lru.erase(ctx->memo_lru.begin() + (long)i);
+	} else {
+		memo_reset(*ctx);
+	}
+	ctx->memo_key = key;
 }
 
 int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr)
@@ -480,7 +517,7 @@ extern "C" void mdb_dev_host_free(void *p)
 
 /* ------------------------------------------------------------------ profiling */
 
-void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name)
+void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name, const void *kernel)
 {
 	if (!ctx->prof_on)
 		return;
@@ -492,7 +529,16 @@ void mdb_prof_begin(mdb_dev_ctx *ctx, const char *name)
 		}
 	if (id < 0) {
 		ctx->prof_names.push_back(name);
+		ctx->prof_kernels.push_back(std::vector<const void *>());
 		id = (int)ctx->prof_names.size() - 1;
+	}
+	{
+		auto &ks = ctx->prof_kernels[(size_t)id];
+		bool seen = false;
+		for (const void *k : ks)
+			seen = seen || k == kernel;
+		if (!seen && kernel)
+			ks.push_back(kernel);
 	}
 	if (ctx->prof_pool_used == ctx->prof_pool.size()) {
 		hipEvent_t a, b;
@@ -550,6 +596,55 @@ extern "C" int mdb_dev_prof_read(mdb_dev_ctx *ctx, struct mdb_dev_prof_entry *ou
 		}
 	}
 	*n_out = n;
+	return MIDORIDB_OK;
+}
+
+/* The symbols of the kernels launched under a profiler name since profiling was enabled (the template instances a profiler
+ * such as rocprofv3 lists them under), separated by newlines: the one table that ties this library's per-kernel timings to
+ * the rows of an external profile - nothing outside has to spell a mangled name. */
+extern "C" int mdb_dev_prof_symbols(mdb_dev_ctx *ctx, const char *name, char *out, size_t cap)
+{
+	if (!out || !cap || !name)
+		return -MIDORIDB_ERROR;
+	out[0] = 0;
+	size_t used = 0;
+	for (size_t i = 0; i < ctx->prof_names.size(); i++) {
+		if (ctx->prof_names[i] != name)
+			continue;
+		for (const void *k : ctx->prof_kernels[i]) {
+			const char *mangled = hipKernelNameRefByPtr(k, ctx->stream);
+			if (!mangled)
+				continue;
+			/* demangled, without "void " and the argument list: the form rocprofv3's kernel trace shows */
+			int st = 0;
+			char *dm = abi::__cxa_demangle(mangled, NULL, NULL, &st);
+			std::string nm = (st == 0 && dm) ? dm : mangled;
+			free(dm);
+			if (nm.compare(0, 5, "void ") == 0)
+				nm.erase(0, 5);
+			{
+				int depth = 0;
+				for (size_t c = 0; c < nm.size(); c++) {
+					if (nm[c] == '<')
+						depth++;
+					else if (nm[c] == '>')
+						depth--;
+					else if (nm[c] == '(' && depth == 0) {
+						nm.erase(c);
+						break;
+					}
+				}
+			}
+			const char *sym = nm.c_str();
+			const size_t len = nm.size();
+			if (used + len + 2 > cap)
+				return -MIDORIDB_ERROR;
+			if (used)
+				out[used++] = '\n';
+			memcpy(out + used, sym, len + 1);
+			used += len;
+		}
+	}
 	return MIDORIDB_OK;
 }
 

@@ -2737,6 +2737,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	if (n_l + (keys_r ? n_r : 0) < GC_NARROW_MIN_ROWS)
 		return MIDORIDB_OK;
 	bool fresh = false;
+	ctx->guess_remembered = false;
 	if (ctx->nh_distrust > 0) {
 		ctx->nh_distrust--;
 		fresh = true;
@@ -2744,6 +2745,7 @@ static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		   !(ctx->nh_r_based && !prune_ok) &&	/* (a window of the right table's keys alone is no use to a call that cannot prune) */
 		   ++ctx->nh_uses < GC_HINT_USES) {
 		*narrow = ctx->nh_result == 1;	/* same columns as last time: what held then (gc_narrow_note) */
+		ctx->guess_remembered = true;
 		*base = ctx->nh_base;
 		if (win && *narrow) {
 			win->kbits = ctx->nh_kbits;
@@ -2886,7 +2888,19 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 	for (int attempt = 0; attempt < 6; attempt++) {
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
 				     base, win, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
-		if (rc == GC_RETRY_PLAIN) {
+		if ((rc == GC_RETRY_PLAIN || rc == GC_RETRY_WIDE) && ctx->guess_remembered && ctx->narrow_mode == 1 && !keys32) {
+			/* a REMEMBERED verdict proved wrong: the buffers hold other data than when it was made (a caller's allocator handed
+			 * the same addresses out again).  Not a reason to give the narrow forms up: forget, look at the data itself, go on */
+			ctx->nh_result = -1;
+			ctx->sr_valid = 0;
+			ctx->nh_distrust = 1;
+			narrow = false;
+			base = 0;
+			rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, has_r ? keys_r : NULL, null_r, n_r, &narrow, &base, &win, keys32, has_r);
+			if (rc)
+				return rc;
+			win.fast1 = fast1 && fast;
+		} else if (rc == GC_RETRY_PLAIN) {
 			/* the sample missed the column's extremes: the plain narrow form (any 2^32-wide window) is tried next,
 			 * and remembered for these columns */
 			win.kbits = 0;
@@ -3091,6 +3105,7 @@ extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l,
 	*out_groups = 0;
 	if (out_joined)
 		*out_joined = 0;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);	/* what was learned about THIS pair of columns */
 	{
 		const int trc = tiny_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first, cap,
 						 out_groups, out_joined);
@@ -3224,6 +3239,7 @@ extern "C" int mdb_dev_join_group_count_i32(mdb_dev_ctx *ctx, const int32_t *key
 					    uint64_t *out_groups, uint64_t *out_joined)
 {
 	(void)flags;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
 	return group_count_common(ctx, reinterpret_cast<const int64_t *>(keys_l), NULL, n_l, reinterpret_cast<const int64_t *>(keys_r), NULL,
 				  n_r, true, false, out_key, out_count, out_first, cap, out_groups, out_joined, true);
 }
@@ -3784,6 +3800,7 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 {
 	(void)flags;
 	*out_groups = 0;
+	mdb_memo_switch(ctx, keys, n, NULL, 0);
 	{
 		const int trc = tiny_group_count(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups, NULL);
 		if (trc <= 0)
@@ -4686,7 +4703,7 @@ static int tiny_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	a.out_r = orr;
 	a.cap = cap;
 	a.status = ctx->d_status;
-	mdb_prof_begin(ctx, "tiny_join_pairs");	/* (not MDB_LAUNCH: an error has two buffers to give back) */
+	mdb_prof_begin(ctx, "tiny_join_pairs", (const void *)k_tiny_join_pairs);	/* (not MDB_LAUNCH: an error has two buffers to give back) */
 	hipLaunchKernelGGL(k_tiny_join_pairs, dim3(1), dim3(GC_THREADS), 0, ctx->stream, a);
 	mdb_prof_end(ctx);
 	uint32_t *h = (uint32_t *)ctx->h_pinned;
@@ -4825,6 +4842,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	*out_count = 0;
 	if (n_l == 0 || n_r == 0)
 		return MIDORIDB_OK;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
 	{
 		const int trc = tiny_join_pairs(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, out_l, out_r, out_count);
 		if (trc <= 0)

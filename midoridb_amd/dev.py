@@ -72,6 +72,7 @@ def _bind(lib):
         "mdb_dev_prof_enable": ([P, c_int], c_int),
         "mdb_dev_prof_reset": ([P], c_int),
         "mdb_dev_prof_read": ([P, POINTER(ProfEntry), c_int, POINTER(c_int)], c_int),
+        "mdb_dev_prof_symbols": ([P, c_char_p, c_char_p, c_size_t], c_int),
         "mdb_dev_filter": ([P, POINTER(PredInsn), c_int, POINTER(ColBinding), c_int, c_uint64, P, POINTER(c_uint64)], c_int),
         "mdb_dev_gather64": ([P, P, P, P, c_uint64, P, P], c_int),
         "mdb_dev_double_join_keys": ([P, P, P, P, c_uint64, P, P], c_int),
@@ -113,7 +114,7 @@ def _bind(lib):
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
-    "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_filter",
+    "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
     "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
@@ -257,6 +258,13 @@ class DeviceCtx:
         n = c_int()
         self._chk(self.lib.mdb_dev_prof_read(self.h, buf, 64, byref(n)), "prof_read")
         return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(n.value)}
+
+    def prof_symbols(self, name):
+        """kernel names as rocprofv3's kernel trace lists them (demangled by the library, without the argument list) launched under
+        profiler name `name`"""
+        buf = ctypes.create_string_buffer(16384)
+        self._chk(self.lib.mdb_dev_prof_symbols(self.h, name.encode(), buf, len(buf)), "prof_symbols")
+        return [x for x in buf.value.decode().split("\n") if x]
 
     # ---- operators ------------------------------------------------------------------------
     def gen_keys(self, n, first_index, domain, seed, modulus=0):

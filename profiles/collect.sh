@@ -1,29 +1,45 @@
 #!/bin/bash
 # Commands that produce the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
 # Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains
 # besides --kernel-trace are combined with --pmc).  The program after "--" is python3 itself.
+# One set of passes per workload of the north-star query: variant D (the headline), U (unique keys), S (the headline's duplication
+# spread over the whole key range) and D in the wide form (64-bit hashes: MDB_NARROW_KEYS=0 is read by the library at context
+# creation) -> summary_<tag>[_U|_S|_wide].json; kernel names need no table: bench.py's line carries, per profiler name, the names
+# rocprofv3 lists its kernels under (mdb_dev_prof_symbols).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+passes() {	# $1 = output directory, $2... = program and arguments
+	local OUT=$1; shift
+	mkdir -p "$OUT"
+	rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- "$@" > "$OUT/kt.log" 2>&1
+	rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- "$@" > "$OUT/fetch.log" 2>&1
+	rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- "$@" > "$OUT/write.log" 2>&1
+	rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES \
+		--output-format csv -d "$OUT/sq" -- "$@" > "$OUT/sq.log" 2>&1
+	rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
+		--output-format csv -d "$OUT/lds" -- "$@" > "$OUT/lds.log" 2>&1
+}
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" $ARGS > "$OUT/kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" $ARGS > "$OUT/write.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES \
-	--output-format csv -d "$OUT/sq" -- python3 "$R/bench.py" $ARGS > "$OUT/sq.log" 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
-	--output-format csv -d "$OUT/lds" -- python3 "$R/bench.py" $ARGS > "$OUT/lds.log" 2>&1
-cd "$R" && python3 profiles/summarize.py "$OUT" "$R/gpurun_out/summary_$TAG.json"
+for V in D U S; do
+	SUF=""; [ "$V" != "D" ] && SUF="_$V"
+	passes "$R/gpurun_out/prof_$TAG$SUF" python3 "$R/bench.py" $ARGS --variant $V
+	(cd "$R" && python3 profiles/summarize.py "$R/gpurun_out/prof_$TAG$SUF" "$R/gpurun_out/summary_$TAG$SUF.json")
+done
+export MDB_NARROW_KEYS=0
+passes "$R/gpurun_out/prof_${TAG}_wide" python3 "$R/bench.py" $ARGS --variant D
+unset MDB_NARROW_KEYS
+(cd "$R" && python3 profiles/summarize.py "$R/gpurun_out/prof_${TAG}_wide" "$R/gpurun_out/summary_${TAG}_wide.json")
+# the sharded operator on one GPU (forced shuffle: partition by destination, RCCL all-to-all with itself, split local join)
+passes "$R/gpurun_out/prof_${TAG}_shuffle" python3 "$R/bench.py" $ARGS --variant D --force-shuffle
+(cd "$R" && python3 profiles/summarize.py "$R/gpurun_out/prof_${TAG}_shuffle" "$R/gpurun_out/summary_${TAG}_shuffle.json")
 # BASELINE configs[0..1] shapes (scan + WHERE + projection at 10^8 rows, join with payload at 10^7): time + HBM bytes per kernel
-OPS=$OUT/configs1
+OPS=$R/gpurun_out/prof_$TAG/configs1
 mkdir -p "$OPS"
-cd /tmp
 OARGS="--configs1 --out $OPS/operators.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OPS/kt" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OPS/fetch" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OPS/write" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/write.log" 2>&1
-cd "$R" && python3 profiles/summarize.py "$OPS" "$R/gpurun_out/summary_${TAG}_configs1.json"
+(cd "$R" && python3 profiles/summarize.py "$OPS" "$R/gpurun_out/summary_${TAG}_configs1.json")

@@ -1915,3 +1915,38 @@ def test_filter_one_column_term_lists(dev, n):
         exp = orc.filter_positions(prog, cols_np, n)
         got = _np(dev.filter(prog, cols_dev, n)).astype(np.int64)
         assert np.array_equal(got, exp), prog
+
+
+def test_column_memo_keeps_several_table_pairs(dev):
+    """What the operators learn about key columns is kept per PAIR of columns (an LRU of mdb_col_memo sets): queries that alternate over
+    several table pairs find their verdicts again - no key sample (and no host sync for it) after each pair's first call; results
+    are the oracle's throughout."""
+    n = 1_500_000
+    pairs = []
+    for s in range(3):
+        a = dev.gen_keys(n, 0, n, 100 + s, 0)
+        b = dev.gen_keys(n, 0, n, 200 + s, n // (4 << s))
+        exp = orc.join_group_count(orc.gen_keys(n, 0, n, 100 + s, 0), None, orc.gen_keys(n, 0, n, 200 + s, n // (4 << s)), None)
+        pairs.append((a, b, exp))
+
+    def run_all():
+        for a, b, (ek, ec, ef, ej) in pairs:
+            k, c, f, j = dev.join_group_count(a, None, b, None)
+            assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    run_all()                   # every pair's first call: samples
+    dev.prof_enable(True)
+    dev.prof_reset()
+    for _ in range(3):
+        run_all()
+    prof = dev.prof_read()
+    dev.prof_enable(False)
+    assert prof.get("key_sample", (0, 0.0))[0] == 0, prof.get("key_sample")
+    # a column written through the library (upload) loses what was known about it - and only it
+    host = _np(pairs[0][0])
+    dev._chk(dev.lib.mdb_dev_h2d(dev.h, pairs[0][0].data_ptr(), host.ctypes.data, 8 * n), "h2d")
+    dev.prof_enable(True)
+    dev.prof_reset()
+    run_all()
+    prof = dev.prof_read()
+    dev.prof_enable(False)
+    assert prof.get("key_sample", (0, 0.0))[0] == 1, prof.get("key_sample")
