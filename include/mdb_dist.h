@@ -88,6 +88,12 @@ int mdb_dist_last_wire32(const mdb_dist *d);
 int mdb_dist_set_key_ranges(mdb_dist *d, const int64_t left[2], const int64_t right[2]);
 /* 1 when the last call pruned the tables by each other's key range before the shuffle */
 int mdb_dist_last_pruned(const mdb_dist *d);
+/* 1 when the last mdb_dist_join_group_count() shipped first-level partition regions instead of keys (both global key ranges
+ * known, the right table's spanning at most 2^30 values, world a power of two up to 8, caller-provided output buffers): each
+ * table is partitioned once - by the join's own first level, whose digit's top bits are the destination - the all-to-alls
+ * are posted without a count reaching a host, and the receiver joins what arrived without hashing it again; groups come out
+ * in leaf order.  MDB_DIST_FUSED=0 keeps the key-by-destination path. */
+int mdb_dist_last_fused(const mdb_dist *d);
 
 /* ------------------------------------------------------------------ the sharded north-star operator
  *

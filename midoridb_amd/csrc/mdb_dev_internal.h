@@ -21,6 +21,15 @@ int mdb_scan_u32_small_from(mdb_dev_ctx *ctx, const uint32_t *src, uint32_t n, u
 #define MDB_TILE 4096u		/* elements per partition tile */
 #define MDB_MAX_RADIX_BITS 9	/* up to 512-way per level */
 
+/* one tile of a partition level's input (mdb_dev_partition.hip) */
+struct mdb_tile_desc {
+	uint32_t start;		/* first input element of the tile */
+	uint32_t len;		/* elements in the tile (0 = unused tile) */
+	uint32_t hbase;		/* histogram index of (segment, digit 0, this tile) */
+	uint32_t nt;		/* tiles in this tile's segment = histogram stride between digits */
+	uint32_t seg;		/* index of the segment (parent partition) the tile belongs to */
+};
+
 enum mdb_digit_mode {
 	MDB_DIGIT_RADIX = 0,	/* digit = bit field of the hashed key (MSD levels) */
 	MDB_DIGIT_MOD = 1,	/* digit = low32(hash) mod n_dest (multi-GPU destination) */
@@ -79,6 +88,7 @@ struct mdb_part_filter {
 				 * below the digit fit 16 bits */
 	bool level0_only;	/* stop after the histogram-free first level (bits2 = 0): the consumer reads the digits' sub-regions itself
 				 * (mdb_part_result.nsub; k_leaf_wide in mdb_dev_join.hip) */
+	uint32_t region_cap;	/* with level0_only, != 0: words per first-level region (a multiple of 64) instead of 1.25 x the average + 1024 */
 	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then
 				 * sized by the tiles that exist (a 4-byte read-back + synchronisation) instead of by the table */
 };
@@ -114,6 +124,50 @@ int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits
 size_t mdb_sort_pass_hist_words(uint64_t n);
 int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_in, uint64_t n, uint32_t shift, uint32_t bits,
 		  uint64_t *key_out, uint32_t *rid_out, uint32_t *hist, uint32_t *scan_tmp);
+
+/* One histogram-free radix level over 4-byte words that lie in caller-described tiles: word w of tile t belongs to segment
+ * tiles[t].seg and goes to child seg * 2^bits + ((w >> shift) & (2^bits - 1)); child c owns words_out[c * cap, c * cap + cap),
+ * cursor[c] (zeroed by the call) counts its words; bit 1 of ctx->d_status[0] is raised when a child overflows.  Tile starts
+ * must be multiples of 4 words.  No host sync. */
+int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const mdb_tile_desc *tiles, uint32_t ntiles, int bits, uint32_t shift,
+			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap);
+
+/* ---- the sharded join + GROUP BY with first-level regions on the wire (mdb_dev_shard.hip) ------------------------------
+ *
+ * Every rank partitions ITS rows of a table ONCE with the histogram-free first level of the compact narrow form (512 digits,
+ * 8 per-XCD sub-regions each, fixed capacity, 4- or 2-byte words = the k-bit hash of key - window base); the digit's top
+ * bits are the destination rank, so the regions of one destination are one contiguous block of a size every rank knows
+ * beforehand: the blocks ARE the all-to-all, no counts have to reach a host before it is posted.  The receiver joins the
+ * regions it got from all ranks - straight from them when the hash bits below the digit index an LDS table (one level), or
+ * after one more partition level of its own - and emits (key, COUNT) pairs; no row ids travel and no result ordering runs
+ * (across ranks SQL leaves the order open anyway). */
+struct mdb_shard_plan {
+	uint32_t world, rank;
+	uint32_t D, Dp, nsub;		/* first-level digits, digits per destination, sub-regions per digit */
+	uint32_t kbits;			/* key window [key_lo, key_lo + 2^kbits) */
+	int64_t key_lo;
+	uint32_t cap[2];		/* words per first-level region: left, right table */
+	uint32_t wbytes;		/* bytes per word on the wire: 4, or 2 when the hash bits below the digit fit */
+	int b2;				/* receiver: bits of its own partition level (0: the regions are joined as they are) */
+	uint32_t rem;			/* key bits that index the leaf tables */
+	uint64_t block_words[2];	/* words per destination block = Dp * nsub * cap */
+	uint32_t leaf_cap[2];		/* b2 > 0: words per leaf region of the receiver's level */
+	uint64_t l_rel_hi;		/* the left table keeps the rows with key - key_lo in [0, l_rel_hi] (= the right table's range) */
+};
+/* 0 = plan made; 1 = this shape is not served (window too wide, world not a power of two ...): the caller takes another path */
+int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_t n_r_max, int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi,
+			mdb_shard_plan *plan);
+size_t mdb_shard_arena_bytes(const mdb_shard_plan *plan, uint64_t n_l, uint64_t n_r);
+/* sender: side 0 = left (rows outside the right table's range are dropped), 1 = right; *regions = the region buffer
+ * (world * block_words[side] words of wbytes bytes, destination-major), *cursors = D * nsub region counters (sub-major).
+ * The caller has begun the arena and cleared ctx->d_status[0..15].  No host sync. */
+int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
+			const void **regions, const uint32_t **cursors);
+/* receiver: recv_x = world blocks of block_words[x] words (source-major), cnt_x = world cursor arrays of D * nsub counters;
+ * out_key / out_count (capacity cap): the groups; d_status[1] = their number, d_status[2..3] = joined rows (u64), flags in
+ * d_status[0] (bit 1 a region overflowed, bit 3 cap too small, bit 7 a right key outside the window).  No host sync. */
+int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, const void *recv_l, const uint32_t *cnt_l, const void *recv_r,
+		   const uint32_t *cnt_r, int64_t *out_key, int64_t *out_count, uint64_t cap);
 
 /* ---- ordering of (row id, payload) records (mdb_dev_join.hip) ----------------------------------
  * rec[i] = (row id << (64 - kbits)) | payload (payload >= 1; zero words are gaps), kbits = bits of a row id as

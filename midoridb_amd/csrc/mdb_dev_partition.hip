@@ -43,14 +43,6 @@
 #define PART_FEW_DIGITS 4u	/* up to this many digits (destination GPUs) a wave ranks its keys with ballots, not one atomic per key */
 #define PART_INVALID 0xFFFFFFFFu
 
-struct mdb_tile_desc {
-	uint32_t start;		/* first input element of the tile */
-	uint32_t len;		/* elements in the tile (0 = unused tile) */
-	uint32_t hbase;		/* histogram index of (segment, digit 0, this tile) */
-	uint32_t nt;		/* tiles in this tile's segment = histogram stride between digits */
-	uint32_t seg;		/* index of the segment (parent partition) the tile belongs to */
-};
-
 struct mdb_level_args {
 	/* level 0 input */
 	const int64_t *keys;
@@ -1035,7 +1027,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	 * sized for the digits that can occur */
 	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
 	const uint64_t avg0 = (n + nreg0_used - 1) / nreg0_used;
-	const uint32_t cap0 = (uint32_t)((((flags & PART_F_LOOSE) ? avg0 * 3 / 2 : avg0 * 5 / 4) + 1024 + 63) & ~63ull);
+	/* (flt->region_cap: the caller fixes the capacity of a first-level region itself - the sharded operator, whose ranks must
+	 * agree on it: the regions ARE the transfer blocks, mdb_dev_shard.hip) */
+	const uint32_t cap0 = (flt && flt->region_cap) ? flt->region_cap
+						       : (uint32_t)((((flags & PART_F_LOOSE) ? avg0 * 3 / 2 : avg0 * 5 / 4) + 1024 + 63) & ~63ull);
 	const bool fast0 = fast && mode == MDB_DIGIT_RADIX && (uint64_t)nreg0_used * cap0 < 0xFFFFFFFFull;
 	/* narrow form without row ids (right side of a join): 4-byte words from the first level's output on; only built for
 	 * the histogram-free layout of both levels (callers ask mdb_partition_w32_applies() first) */
@@ -1405,6 +1400,32 @@ int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits
 			      (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS) | (fold32 ? PART_F_FOLD32 : 0u) | (fold32 == 2 ? PART_F_IN32 : 0u),
 			      MDB_DIGIT_RADIX, 0,
 			      false, NULL, hv, leaf_cap, out, NULL, digits0_used);
+}
+
+/* ---- one histogram-free radix level over 4-byte words in caller-described tiles (the receiver's second level of the
+ * sharded operator, mdb_dev_shard.hip: its input regions came from several ranks) ------------------------------------- */
+int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const mdb_tile_desc *tiles, uint32_t ntiles, int bits, uint32_t shift,
+			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap)
+{
+	if (bits < 1 || bits > MDB_MAX_RADIX_BITS || !ntiles)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "words level: bad digit width");
+	mdb_level_args a;
+	memset(&a, 0, sizeof(a));
+	a.hv_in = reinterpret_cast<const uint64_t *>(words_in);
+	a.tiles = tiles;
+	a.hv_out = reinterpret_cast<uint64_t *>(words_out);
+	a.ntiles = ntiles;
+	a.R = 1u << bits;
+	a.mode = MDB_DIGIT_RADIX;
+	a.shift = shift;
+	a.mbits = (uint32_t)bits;
+	a.cursor = cursor;
+	a.cap = cap;
+	a.nsub = 0;
+	a.status = ctx->d_status;
+	MDB_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)nchild * 4, ctx->stream));
+	MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+	return MIDORIDB_OK;
 }
 
 /* ---- one stable LSD radix pass (ORDER BY) --------------------------------------------------------

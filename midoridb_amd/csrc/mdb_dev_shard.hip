@@ -1,0 +1,425 @@
+/*
+ * mdb_dev_shard.hip - device side of the sharded join + GROUP BY key + COUNT(*) with FIRST-LEVEL REGIONS ON THE WIRE
+ * (include/mdb_dist.h: mdb_dist_join_group_count; the reference's phases it stands for are the join and
+ * GROUP BY loops of src/engine/executor_select.c:1076-1149, 1526-1588).
+ *
+ * Before: partition by destination (histogram + scatter, a pass of its own), counts to the host, all-to-all of keys, and
+ * then the local operator read what arrived and partitioned it again - 3.1 x the local operator before a byte crossed xGMI.
+ * Now the sender's ONE pass is the join's first partition level itself: the compact narrow form's 512-digit histogram-free
+ * scatter (mdb_dev_partition.hip), whose digit's top log2(world) bits are the destination rank.  A destination's regions
+ * are one contiguous block of a size every rank can compute (fixed-capacity regions), so the all-to-all is posted without
+ * any count reaching a host; the region counters travel as 16 KiB beside it and are only ever read by kernels.  The
+ * receiver builds region descriptors (source rank x digit x sub-region), and either joins a digit straight from its
+ * regions (the hash bits below the digit index an LDS table: k_shard_leaf, one level) or runs one partition level of its
+ * own over them first.  What travels is the k-bit hash of key - window base (4 bytes, or 2 when k - 9 <= 16): no row ids,
+ * and the groups come out as (key, COUNT) pairs in leaf order - across ranks SQL leaves the order open, so the ordering
+ * sort of the single-GPU operator (40 % of it for unique keys) does not run.
+ *
+ * HBM-bound byte work like the rest of the path: no MFMA.  Rooflines: sender pass = 8 n read + wbytes * n written per
+ * table; receiver = the received words read once (+ one read-write level when b2 > 0) + 16 G written.
+ */
+#include "mdb_dev_internal.h"
+
+#define SH_NSUB 8u		/* = PART_NSUB of mdb_dev_partition.hip: sub-regions per first-level digit */
+#define SH_D_BITS 9
+#define SH_ONE_LEVEL_MAX_REM 14u	/* 2^14 entries x 8 bytes = 128 KiB of LDS */
+#define SH_LEAF_REM 12u		/* two levels: leaves of at most 2^12 key values */
+#define SH_RANGE_WORD 24	/* words of ctx->d_status that hold the left table's pruning range */
+
+static uint32_t sh_ceil_log2(uint64_t v)
+{
+	uint32_t b = 0;
+	while (b < 63 && (1ull << b) < v)
+		b++;
+	return b;
+}
+
+static uint32_t sh_round64(uint64_t v) { return (uint32_t)((v + 63) & ~63ull); }
+
+int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_t n_r_max, int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi,
+			mdb_shard_plan *p)
+{
+	memset(p, 0, sizeof(*p));
+	if (world < 1 || world > 8 || (world & (world - 1)) || rank >= world)
+		return 1;
+	if (r_lo > r_hi || l_lo > l_hi)
+		return 1;		/* (a table without any key: the caller's ordinary path answers "no groups") */
+	const uint64_t rspan = (uint64_t)r_hi - (uint64_t)r_lo + 1;
+	if (rspan == 0 || rspan > (1ull << 30))
+		return 1;
+	uint32_t k = sh_ceil_log2(rspan);
+	if (k < SH_D_BITS + 4u)
+		k = SH_D_BITS + 4u;	/* (tiny windows: still 16 values per digit) */
+	if (n_l_max >= 0xF0000000ull || n_r_max >= 0xF0000000ull)
+		return 1;
+	p->world = world;
+	p->rank = rank;
+	p->D = 1u << SH_D_BITS;
+	p->Dp = p->D / world;
+	p->nsub = SH_NSUB;
+	p->kbits = k;
+	p->key_lo = r_lo;
+	p->l_rel_hi = rspan - 1;
+	const uint32_t below = k - SH_D_BITS;
+	if (below <= SH_ONE_LEVEL_MAX_REM && p->Dp >= 128u) {
+		p->b2 = 0;
+		p->rem = below;
+	} else {
+		int b2 = below > SH_LEAF_REM ? (int)(below - SH_LEAF_REM) : 2;
+		if (b2 > MDB_MAX_RADIX_BITS)
+			return 1;	/* (windows beyond 2^30 values) */
+		if ((uint32_t)b2 > below - 2u)
+			b2 = (int)below - 2;
+		if (b2 < 1)
+			return 1;
+		p->b2 = b2;
+		p->rem = below - (uint32_t)b2;
+	}
+	p->wbytes = (p->b2 == 0 && below <= 16u) ? 2u : 4u;
+	/* regions: 1.25 x the average + 1024 words, like the single-GPU first level; the left table's by the rows expected to
+	 * survive the pruning (its keys taken as evenly spread over its range; an underestimate overflows a region, which is
+	 * reported and answered by the exact path) */
+	const uint64_t lspan = (uint64_t)l_hi - (uint64_t)l_lo + 1;
+	long double frac = lspan ? (long double)rspan / (long double)lspan : 1.0L;
+	if (frac > 1.0L || lspan == 0)
+		frac = 1.0L;
+	const uint64_t nl_est = (uint64_t)((long double)n_l_max * frac * 1.1L) + 1;
+	const uint64_t regions = (uint64_t)p->D * p->nsub;
+	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 5 / 4 / regions + 1024);
+	p->cap[1] = sh_round64(n_r_max * 5 / 4 / regions + 1024);
+	for (int x = 0; x < 2; x++) {
+		p->block_words[x] = (uint64_t)p->Dp * p->nsub * p->cap[x];
+		if (p->block_words[x] * world >= 0xFFFFFFFFull)
+			return 1;
+	}
+	if (p->b2) {
+		/* the receiver's leaves: 1.5 x the average + 1024 (its rows are known only as a bound: what the regions can hold) */
+		const uint64_t nleaves = (uint64_t)p->Dp << p->b2;
+		for (int x = 0; x < 2; x++) {
+			const uint64_t bound = p->block_words[x] * world * 4 / 5;	/* (the regions are sized 1.25 x) */
+			p->leaf_cap[x] = sh_round64(bound * 3 / 2 / nleaves + 1024);
+			if (nleaves * p->leaf_cap[x] >= 0xFFFFFFFFull)
+				return 1;
+		}
+	}
+	return 0;
+}
+
+static size_t sh_recv_side_bytes(const mdb_shard_plan *p, int x)
+{
+	const uint64_t nreg = (uint64_t)p->D * p->nsub, max_tiles = p->block_words[x] * p->world / MDB_TILE + nreg + 1;
+	size_t b = 2 * mdb_align_up(nreg * 4) + mdb_align_up((nreg + 1) * 4) + 4096;		/* region start / count, tile bases */
+	if (p->b2)
+		b += mdb_align_up(max_tiles * sizeof(mdb_tile_desc)) + mdb_align_up(((size_t)p->Dp << p->b2) * p->leaf_cap[x] * 4) +
+		     mdb_align_up(((size_t)p->Dp << p->b2) * 4);
+	return b;
+}
+
+size_t mdb_shard_arena_bytes(const mdb_shard_plan *p, uint64_t n_l, uint64_t n_r)
+{
+	/* sender: the two region buffers + their cursors (the first-level partition's own carving) */
+	size_t b = 0;
+	for (int x = 0; x < 2; x++)
+		b += mdb_align_up((size_t)p->D * p->nsub * p->cap[x] * 4) + 4 * mdb_align_up((size_t)p->D * p->nsub * 4 + 8) + 4096;
+	(void)n_l;
+	(void)n_r;
+	return b + sh_recv_side_bytes(p, 0) + sh_recv_side_bytes(p, 1) + 65536;
+}
+
+int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
+			const void **regions, const uint32_t **cursors)
+{
+	mdb_part_filter flt;
+	mdb_part_result res;
+	memset(&flt, 0, sizeof(flt));
+	memset(&res, 0, sizeof(res));
+	flt.level0_only = true;
+	flt.out16 = p->wbytes == 2;
+	flt.region_cap = p->cap[side];
+	if (side == 0) {
+		/* the left table keeps the rows inside the right table's (global) key range = the window: what lies outside joins
+		 * nothing on any rank */
+		uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 512;
+		h[0] = 0u;
+		h[1] = (uint32_t)p->l_rel_hi;
+		MDB_HIP(ctx, hipMemcpyAsync(ctx->d_status + SH_RANGE_WORD, h, 8, hipMemcpyHostToDevice, ctx->stream));
+		flt.range_in = ctx->d_status + SH_RANGE_WORD;
+	}
+	if (n == 0) {
+		/* nothing to partition: an all-zero cursor array and a region buffer nobody reads */
+		uint32_t *cur = (uint32_t *)mdb_arena_take(ctx, (size_t)p->D * p->nsub * 4);
+		void *buf = mdb_arena_take(ctx, (size_t)p->D * p->nsub * p->cap[side] * p->wbytes);
+		if (!cur || !buf)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(cur, 0, (size_t)p->D * p->nsub * 4, ctx->stream));
+		*regions = buf;
+		*cursors = cur;
+		return MIDORIDB_OK;
+	}
+	int rc = mdb_partition_table(ctx, keys, nulls, n, SH_D_BITS, 0, false, false, true, &res, 2, false, p->key_lo, p->kbits, &flt);
+	if (rc)
+		return rc;
+	if (!res.nsub || res.nsub != p->nsub || res.leaf_cap != p->cap[side] || !res.w32 || (p->wbytes == 2) != res.w16)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded operator: the first level did not deliver the agreed region layout");
+	*regions = res.hv;
+	*cursors = res.leaf_cnt;
+	return MIDORIDB_OK;
+}
+
+/* ------------------------------------------------------------------ receiver */
+
+/* region r = dl * (world * nsub) + q * nsub + s: the rows rank q sent for this rank's digit dl from its sub-region s */
+__global__ void k_shard_regions(const uint32_t *__restrict__ cnt, uint32_t world, uint32_t D, uint32_t Dp, uint32_t nsub, uint32_t d0, uint32_t cap,
+				uint32_t block_words, uint32_t *__restrict__ reg_start, uint32_t *__restrict__ reg_cnt, uint32_t *status)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, nreg = Dp * world * nsub;
+	if (r >= nreg)
+		return;
+	const uint32_t dl = r / (world * nsub), q = (r / nsub) % world, s = r % nsub;
+	uint32_t c = cnt[(size_t)q * D * nsub + (size_t)s * D + d0 + dl];	/* (the sender's cursors are laid out sub-major) */
+	if (c > cap) {
+		mdb_raise(status, 2u);		/* the sender's region overflowed (it said so on its own rank as well) */
+		c = cap;
+	}
+	reg_start[r] = q * block_words + (dl * nsub + s) * cap;
+	reg_cnt[r] = c;
+}
+
+/* tiles of MDB_TILE words per region: tb[r] = first tile of region r, tb[nreg] = their number (one workgroup) */
+__global__ __launch_bounds__(1024) void k_shard_tiles_scan(const uint32_t *__restrict__ reg_cnt, uint32_t nreg, uint32_t *__restrict__ tb)
+{
+	__shared__ uint32_t s_tmp[32];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base <= nreg; base += 1024) {
+		const uint32_t r = base + threadIdx.x;
+		const uint32_t nt = r < nreg ? (reg_cnt[r] + MDB_TILE - 1) / MDB_TILE : 0u;
+		uint32_t total;
+		const uint32_t ex = mdb_block_excl_scan(nt, s_tmp, &total);
+		if (r <= nreg)
+			tb[r] = carry + ex;
+		carry += total;
+	}
+}
+
+__global__ void k_shard_tiles_build(const uint32_t *__restrict__ reg_start, const uint32_t *__restrict__ reg_cnt, const uint32_t *__restrict__ tb,
+				    uint32_t nreg, uint32_t regs_per_seg, mdb_tile_desc *__restrict__ tiles, uint32_t max_tiles)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= max_tiles)
+		return;
+	mdb_tile_desc d;
+	d.start = d.len = d.hbase = d.nt = d.seg = 0;
+	if (t < tb[nreg]) {
+		uint32_t lo = 0, hi = nreg;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (tb[mid] <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		const uint32_t r = lo, tl = t - tb[r], c = reg_cnt[r];
+		d.start = reg_start[r] + tl * MDB_TILE;		/* (regions start at multiples of 64 words) */
+		d.len = (c - tl * MDB_TILE) < MDB_TILE ? (c - tl * MDB_TILE) : MDB_TILE;
+		d.seg = r / regs_per_seg;
+	}
+	tiles[t] = d;
+}
+
+struct sh_leaf_args {
+	const void *words[2];		/* [0] left, [1] right: 4- or 2-byte words */
+	const uint32_t *seg_start[2];	/* nseg per leaf; NULL: ONE segment per leaf at leaf * cap (the receiver's own level) */
+	const uint32_t *seg_cnt[2];	/* ... its counters (clamped to cap when seg_start is NULL) */
+	uint32_t nseg, cap[2];
+	uint32_t rem, shift;		/* table index = (word >> shift) & (2^rem - 1) */
+	uint32_t kbits, hash_base;	/* k-bit hash of slot s of leaf i = hash_base + (i << rem) + s */
+	long long key_lo;
+	long long *out_key, *out_count;
+	uint32_t out_cap;
+	uint32_t *status;		/* [0] flags, [1] groups so far, [2..3] joined rows (u64) */
+};
+
+/* One workgroup per leaf: the right rows count into cr[], the left rows into cl[] (only where a right row exists), every
+ * slot with both is a group: key = key_lo + unmixk(hash), COUNT(*) = cl * cr.  Plain 32-bit LDS counters: no count can
+ * overflow, nothing is probed or compared - the k-bit hash is a bijection of the window. */
+template <int THREADS, typename WT>
+__global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t sh_lds[];
+	__shared__ uint32_t s_scan[32];
+	__shared__ unsigned long long s_red[THREADS / 64];
+	__shared__ uint32_t s_base;
+	const uint32_t T = 1u << a.rem, mask = T - 1u, leaf = blockIdx.x;
+	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + T;
+	for (uint32_t s = threadIdx.x; s < 2 * T; s += THREADS)
+		sh_lds[s] = 0u;
+	__syncthreads();
+	constexpr uint32_t PER = 16u / sizeof(WT);	/* words per 16-byte load */
+#pragma unroll
+	for (int side = 1; side >= 0; side--) {
+		const WT *const base = reinterpret_cast<const WT *>(a.words[side]);
+		for (uint32_t j = 0; j < a.nseg; j++) {
+			uint32_t c, start;
+			if (a.seg_start[side]) {
+				start = a.seg_start[side][leaf * a.nseg + j];
+				c = a.seg_cnt[side][leaf * a.nseg + j];
+			} else {
+				start = leaf * a.cap[side];
+				c = a.seg_cnt[side][leaf];
+				c = c < a.cap[side] ? c : a.cap[side];
+			}
+			const WT *const src = base + start;
+			for (uint32_t i0 = 0; i0 < c; i0 += PER * THREADS * 4u) {	/* uniform trip count; four 16-byte loads in flight */
+				uint4 v[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const uint32_t i = i0 + PER * ((uint32_t)u * THREADS + threadIdx.x);
+					v[u] = make_uint4(0u, 0u, 0u, 0u);
+					if (i < c)
+						v[u] = *reinterpret_cast<const uint4 *>(src + i);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const uint32_t i = i0 + PER * ((uint32_t)u * THREADS + threadIdx.x);
+					const uint32_t w4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+					for (uint32_t e = 0; e < PER; e++) {
+						if (i + e >= c)
+							continue;
+						const uint32_t w = sizeof(WT) == 4 ? w4[e] : (w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu;
+						const uint32_t idx = (sizeof(WT) == 4 ? (w >> a.shift) : w) & mask;
+						if (side == 1)
+							atomicAdd(&s_cr[idx], 1u);
+						else if (s_cr[idx])
+							atomicAdd(&s_cl[idx], 1u);
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+	/* emit: thread t owns the slots [t * W, t * W + W) */
+	const uint32_t W = T > (uint32_t)THREADS ? T / THREADS : 1u;
+	uint32_t mine = 0;
+	for (uint32_t k = 0; k < W; k++) {
+		const uint32_t s = threadIdx.x * W + k;
+		if (s < T && s_cl[s])
+			mine++;
+	}
+	uint32_t total;
+	uint32_t pos = mdb_block_excl_scan(mine, s_scan, &total);
+	if (!total)
+		return;
+	if (threadIdx.x == 0) {
+		const uint32_t nb = atomicAdd(a.status + 1, total);
+		if ((uint64_t)nb + total > a.out_cap) {
+			mdb_raise(a.status, 8u);
+			s_base = 0xFFFFFFFFu;
+		} else {
+			s_base = nb;
+		}
+	}
+	__syncthreads();
+	if (s_base == 0xFFFFFFFFu)
+		return;
+	pos += s_base;
+	unsigned long long joined = 0;
+	for (uint32_t k = 0; k < W; k++) {
+		const uint32_t s = threadIdx.x * W + k;
+		if (s >= T)
+			break;
+		const uint32_t cl = s_cl[s];
+		if (!cl)
+			continue;
+		const unsigned long long c = (unsigned long long)cl * s_cr[s];
+		const uint32_t h = a.hash_base + (leaf << a.rem) + s;
+		a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
+		a.out_count[pos] = (long long)c;
+		joined += c;
+		pos++;
+	}
+#pragma unroll
+	for (int o = 32; o; o >>= 1)
+		joined += __shfl_down(joined, o, MDB_WAVE);
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = joined;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+#pragma unroll
+		for (int w = 0; w < THREADS / 64; w++)
+			t += s_red[w];
+		if (t)
+			atomicAdd(reinterpret_cast<unsigned long long *>(a.status + 2), t);
+	}
+}
+
+int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *recv_l, const uint32_t *cnt_l, const void *recv_r,
+		   const uint32_t *cnt_r, int64_t *out_key, int64_t *out_count, uint64_t cap)
+{
+	const uint32_t nreg = p->D * p->nsub, regs_per_digit = p->world * p->nsub, d0 = p->rank * p->Dp;
+	const void *recv[2] = { recv_l, recv_r };
+	const uint32_t *cnt[2] = { cnt_l, cnt_r };
+	uint32_t *reg_start[2], *reg_cnt[2];
+	sh_leaf_args a;
+	memset(&a, 0, sizeof(a));
+	for (int x = 0; x < 2; x++) {
+		reg_start[x] = (uint32_t *)mdb_arena_take(ctx, (size_t)nreg * 4);
+		reg_cnt[x] = (uint32_t *)mdb_arena_take(ctx, (size_t)nreg * 4);
+		if (!reg_start[x] || !reg_cnt[x])
+			return -MIDORIDB_INTERNAL;
+		MDB_LAUNCH(ctx, "shard_regions", k_shard_regions, (nreg + 255) / 256, 256, cnt[x], p->world, p->D, p->Dp, p->nsub, d0, p->cap[x],
+			   (uint32_t)p->block_words[x], reg_start[x], reg_cnt[x], ctx->d_status);
+	}
+	a.rem = p->rem;
+	a.shift = 32u - p->kbits;
+	a.kbits = p->kbits;
+	a.hash_base = d0 << (p->kbits - SH_D_BITS);
+	a.key_lo = p->key_lo;
+	a.out_key = reinterpret_cast<long long *>(out_key);
+	a.out_count = reinterpret_cast<long long *>(out_count);
+	a.out_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+	a.status = ctx->d_status;
+	const size_t lds = (size_t)8 << p->rem;
+	if (p->b2 == 0) {
+		/* one level: a digit is joined straight from the regions every rank sent for it */
+		a.nseg = regs_per_digit;
+		for (int x = 0; x < 2; x++) {
+			a.words[x] = recv[x];
+			a.seg_start[x] = reg_start[x];
+			a.seg_cnt[x] = reg_cnt[x];
+			a.cap[x] = p->cap[x];
+		}
+		/* (one level means k - 9 <= 14 key bits below the digit: they always fit the 2-byte words) */
+		if (p->wbytes != 2)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: one-level plan without 2-byte words");
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<1024, uint16_t>), p->Dp, 1024, lds, a);
+		return MIDORIDB_OK;
+	}
+	/* two levels: the receiver's own level over the regions of all ranks, then its leaves */
+	const uint32_t nleaves = p->Dp << p->b2;
+	for (int x = 0; x < 2; x++) {
+		const uint32_t max_tiles = (uint32_t)(p->block_words[x] * p->world / MDB_TILE) + nreg + 1;
+		uint32_t *tb = (uint32_t *)mdb_arena_take(ctx, ((size_t)nreg + 1) * 4);
+		mdb_tile_desc *tiles = (mdb_tile_desc *)mdb_arena_take(ctx, (size_t)max_tiles * sizeof(mdb_tile_desc));
+		uint32_t *leaves = (uint32_t *)mdb_arena_take(ctx, (size_t)nleaves * p->leaf_cap[x] * 4);
+		uint32_t *cursor = (uint32_t *)mdb_arena_take(ctx, (size_t)nleaves * 4);
+		if (!tb || !tiles || !leaves || !cursor)
+			return -MIDORIDB_INTERNAL;
+		MDB_LAUNCH(ctx, "shard_tiles_scan", k_shard_tiles_scan, 1, 1024, reg_cnt[x], nreg, tb);
+		MDB_LAUNCH(ctx, "shard_tiles_build", k_shard_tiles_build, (max_tiles + 255) / 256, 256, reg_start[x], reg_cnt[x], tb, nreg, regs_per_digit,
+			   tiles, max_tiles);
+		int rc = mdb_partition_words_level(ctx, reinterpret_cast<const uint32_t *>(recv[x]), tiles, max_tiles, p->b2,
+						   32u - SH_D_BITS - (uint32_t)p->b2, leaves, cursor, nleaves, p->leaf_cap[x]);
+		if (rc)
+			return rc;
+		a.words[x] = leaves;
+		a.seg_start[x] = NULL;
+		a.seg_cnt[x] = cursor;
+		a.cap[x] = p->leaf_cap[x];
+	}
+	a.nseg = 1;
+	MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<512, uint32_t>), nleaves, 512, lds, a);
+	return MIDORIDB_OK;
+}

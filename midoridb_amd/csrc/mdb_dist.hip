@@ -31,7 +31,7 @@ struct mdb_dist {
 	bool own_transport;		/* t.self is an rccl_transport created here */
 	hipStream_t comm_stream;	/* key transfers */
 	hipEvent_t ev_ready, ev_a, ev_b;
-	int wire_mode, last_wire32, last_pruned;
+	int wire_mode, last_wire32, last_pruned, last_fused;
 	bool have_ranges;		/* mdb_dist_set_key_ranges(): promised global key ranges of the two tables of the next calls */
 	int64_t promised_lo[2], promised_hi[2];
 	/* exchange buffers (grow-only): send = this rank's keys grouped by destination, recv = what arrived */
@@ -443,6 +443,7 @@ extern "C" int mdb_dist_rank(const mdb_dist *d) { return d ? d->rank : -1; }
 extern "C" const char *mdb_dist_last_error(const mdb_dist *d) { return d ? d->err : "no distributed handle"; }
 extern "C" int mdb_dist_last_wire32(const mdb_dist *d) { return d ? d->last_wire32 : 0; }
 extern "C" int mdb_dist_last_pruned(const mdb_dist *d) { return d ? d->last_pruned : 0; }
+extern "C" int mdb_dist_last_fused(const mdb_dist *d) { return d ? d->last_fused : 0; }
 
 extern "C" int mdb_dist_set_key_ranges(mdb_dist *d, const int64_t left[2], const int64_t right[2])
 {
@@ -479,6 +480,11 @@ extern "C" int mdb_dist_barrier(mdb_dist *d)
 {
 	uint64_t one = 1;
 	return mdb_dist_allreduce_sum_u64(d, &one, 1);
+}
+
+static const char *transport_err(mdb_dist *d)
+{
+	return d->own_transport ? ((rccl_transport *)d->t.self)->err : "";
 }
 
 /* ------------------------------------------------------------------ the exchange */
@@ -548,6 +554,162 @@ static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64
 	DIST_HIP(d, hipEventRecord(done, d->comm_stream));
 	*n_recv = total;
 	return MIDORIDB_OK;
+}
+
+static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_t *out_count, int rc)
+{
+	if (alloc_out) {
+		(void)mdb_dev_free(ctx, out_key);
+		(void)mdb_dev_free(ctx, out_count);
+	}
+	return rc;
+}
+
+/* ------------------------------------------------------------------ the sharded operator with first-level regions on the wire
+ *
+ * mdb_dev_shard.hip: each table is partitioned ONCE, by the join's own first level, whose digit's top bits are the
+ * destination; the regions of a destination are one block of a size every rank knows, so both all-to-alls are posted without
+ * a count reaching a host, and the receiver joins what arrived without hashing or partitioning it again.  Host round trips
+ * per call: one tiny exchange up front (the ranks' row counts: region capacities must be agreed on) and one at the end (the
+ * ranks' status words: a region that overflowed anywhere sends EVERY rank to the exact path below) - two, where the
+ * key-by-destination path needs four plus two read-backs.  Needs the two tables' global key ranges (promised, or measured
+ * by MDB_WIRE_AUTO) and a right-table range of at most 2^30 values; MDB_DIST_FUSED=0 switches it off.
+ * Returns 0 = done, 1 = not served / fell back (agreed by all ranks), < 0 = error. */
+static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r, const uint64_t *null_r,
+			   uint64_t n_r, const int64_t glo[2], const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p,
+			   int64_t **out_count_p, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+{
+	mdb_dev_ctx *ctx = d->ctx;
+	const int W = d->world;
+	if (getenv("MDB_DIST_FUSED") && getenv("MDB_DIST_FUSED")[0] == '0')
+		return 1;
+	/* ---- every rank's row counts (region capacities are sized by the largest), and whether its output buffers can take the
+	 *      groups: a decision every rank takes from the same numbers */
+	uint64_t sendv[3 << MDB_MAX_RADIX_BITS], recvv[3 << MDB_MAX_RADIX_BITS];
+	for (int p = 0; p < W; p++) {
+		sendv[3 * p] = n_l;
+		sendv[3 * p + 1] = n_r;
+		sendv[3 * p + 2] = alloc_out ? ~0ull : cap;
+	}
+	int rc = d->t.counts(d->t.self, sendv, recvv, 3);
+	if (rc)
+		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	uint64_t nl_max = 0, nr_max = 0, cap_min = ~0ull, nl_sum = 0;
+	for (int p = 0; p < W; p++) {
+		nl_sum += recvv[3 * p];
+		nl_max = recvv[3 * p] > nl_max ? recvv[3 * p] : nl_max;
+		nr_max = recvv[3 * p + 1] > nr_max ? recvv[3 * p + 1] : nr_max;
+		cap_min = recvv[3 * p + 2] < cap_min ? recvv[3 * p + 2] : cap_min;
+	}
+	mdb_shard_plan plan;
+	if (mdb_shard_plan_make((uint32_t)W, (uint32_t)d->rank, nl_max, nr_max, glo[0], ghi[0], glo[1], ghi[1], &plan))
+		return 1;
+	/* the groups of a rank: at most the left rows it can receive, at most the key values that hash to it */
+	const uint64_t recv_bound_l = plan.block_words[0] * (uint64_t)W;
+	const uint64_t values = ((uint64_t)1 << plan.kbits) / (uint64_t)W;
+	uint64_t group_bound = recv_bound_l < values ? recv_bound_l : values;
+	group_bound = nl_sum < group_bound ? nl_sum : group_bound;	/* ... and never more than there are left rows at all */
+	if (cap_min < group_bound)
+		return 1;	/* (a caller's buffer that may not hold this path's groups: the exact path knows its sizes) */
+	int64_t *out_key = alloc_out ? NULL : *out_key_p, *out_count = alloc_out ? NULL : *out_count_p;
+	if (alloc_out) {
+		/* (an allocation that fails on one rank only would leave the others in the all-to-all: sized by the agreed bound, it
+		 * fails everywhere or nowhere on equal GPUs; the status exchange at the end still catches the rest) */
+		if (mdb_dev_alloc(ctx, (group_bound ? group_bound : 1) * 8, (void **)&out_key) ||
+		    mdb_dev_alloc(ctx, (group_bound ? group_bound : 1) * 8, (void **)&out_count)) {
+			(void)mdb_dev_free(ctx, out_key);
+			return dist_err(d, -MIDORIDB_NOMEM, "allocating group outputs: %s", mdb_dev_last_error(ctx));
+		}
+		cap = group_bound ? group_bound : 1;
+	}
+
+	const size_t wb = plan.wbytes, ncur = (size_t)plan.D * plan.nsub;
+	size_t need = mdb_shard_arena_bytes(&plan, n_l, n_r);
+	for (int x = 0; x < 2; x++)
+		need += mdb_align_up(plan.block_words[x] * (size_t)W * wb) + mdb_align_up(ncur * (size_t)W * 4) + 512;
+	rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "%s", mdb_dev_last_error(ctx)));
+	DIST_HIP(d, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	void *recv[2];
+	uint32_t *rcnt[2];
+	for (int x = 0; x < 2; x++) {
+		recv[x] = mdb_arena_take(ctx, plan.block_words[x] * (size_t)W * wb);
+		rcnt[x] = (uint32_t *)mdb_arena_take(ctx, ncur * (size_t)W * 4);
+		if (!recv[x] || !rcnt[x])
+			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "%s", mdb_dev_last_error(ctx)));
+	}
+	/* ---- each table: ONE partition pass, then its blocks and its region counters travel (fixed sizes: nothing to wait for) */
+	size_t bc[1 << MDB_MAX_RADIX_BITS], bd[1 << MDB_MAX_RADIX_BITS], cc[1 << MDB_MAX_RADIX_BITS], cd0[1 << MDB_MAX_RADIX_BITS],
+		cdr[1 << MDB_MAX_RADIX_BITS];
+	const int64_t *keys[2] = { keys_l, keys_r };
+	const uint64_t *nulls[2] = { null_l, null_r };
+	const uint64_t ns[2] = { n_l, n_r };
+	hipEvent_t evs[2] = { d->ev_a, d->ev_b };
+	int prc = MIDORIDB_OK;
+	for (int x = 0; x < 2; x++) {
+		const void *regions = NULL;
+		const uint32_t *cursors = NULL;
+		if (!prc)
+			prc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], ns[x], &regions, &cursors);
+		if (prc)
+			break;
+		for (int p = 0; p < W; p++) {
+			bc[p] = (size_t)plan.block_words[x] * wb;
+			bd[p] = (size_t)p * plan.block_words[x] * wb;
+			cc[p] = ncur;
+			cd0[p] = 0;		/* every rank gets the whole counter array */
+			cdr[p] = (size_t)p * ncur;
+		}
+		DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
+		DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
+		rc = d->t.alltoallv(d->t.self, regions, bc, bd, recv[x], bc, bd, 1, d->comm_stream);
+		if (!rc)
+			rc = d->t.alltoallv(d->t.self, cursors, cc, cd0, rcnt[x], cc, cdr, 4, d->comm_stream);
+		if (rc)
+			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
+		DIST_HIP(d, hipEventRecord(evs[x], d->comm_stream));
+	}
+	/* (a rank whose partition call failed outright - not a flag on the device, a launch or sizing error - cannot post its
+	 * transfers: it reports through the status exchange below, which every rank reaches; its peers' receives for this call
+	 * would then hang, so such a failure is fatal for the communicator and reported as such) */
+	if (prc)
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded first level: %s", mdb_dev_last_error(ctx)));
+	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_a, 0));
+	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_b, 0));
+	rc = mdb_shard_join(ctx, &plan, recv[0], rcnt[0], recv[1], rcnt[1], out_key, out_count, cap);
+	if (rc)
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "sharded join: %s", mdb_dev_last_error(ctx)));
+	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+	DIST_HIP(d, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	DIST_HIP(d, hipStreamSynchronize(ctx->stream));
+	const uint32_t flags = h[0];
+	const uint64_t G = h[1], J = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+	/* ---- one word per rank: what went wrong anywhere sends everybody the same way */
+	uint64_t st[3] = { (flags & 2u) ? 1u : 0u, (flags & 128u) ? 1u : 0u, (flags & ~(2u | 128u)) ? 1u : 0u };
+	rc = d->t.allreduce_sum_u64(d->t.self, st, 3);
+	if (rc)
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "status exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
+	if (st[2])
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "sharded join: group output overflow (status %u on this rank)", flags));
+	if (st[1]) {
+		if (promised)
+			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_ERROR, "partition_by_dest: a key lies outside the range [%lld, %lld] promised for its column",
+					(long long)glo[1], (long long)ghi[1]));
+		return fused_fail(ctx, alloc_out, out_key, out_count, 1);
+	}
+	if (st[0])
+		return fused_fail(ctx, alloc_out, out_key, out_count, 1);	/* skewed keys outgrew a fixed-capacity region somewhere: the exact path */
+	d->last_recv_left = G;	/* (rows are not counted on this path: the groups are a lower bound) */
+	if (alloc_out) {
+		*out_key_p = out_key;
+		*out_count_p = out_count;
+	}
+	*out_groups = G;
+	if (out_joined)
+		*out_joined = J;
+	d->last_fused = 1;
+	return 0;
 }
 
 /* the outputs a call allocated do not outlive its failure */
@@ -648,6 +810,14 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	const bool verify = prune && !measured;		/* promised ranges are checked while each table is partitioned */
 	d->last_pruned = prune ? 1 : 0;
 
+	d->last_fused = 0;
+	if (prune && !left_in_place && !out_first) {
+		/* both global key ranges are known: the first partition level IS the exchange (mdb_dev_shard.hip) */
+		const int frc = dist_join_fused(d, keys_l, null_l, n_l, keys_r, null_r, n_r, glo, ghi, verify, alloc_out, out_key, out_count, cap, out_groups,
+						out_joined);
+		if (frc <= 0)
+			return frc;
+	}
 	/* the transfer stream starts behind whatever the caller queued on the context's stream (its key columns) */
 	DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
 	DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
@@ -831,10 +1001,6 @@ extern "C" int mdb_dist_wait_transfers(mdb_dist *d)
 
 #define SH_COUNTERS 3	/* per peer: rows, columns that carry NULL bits, status */
 
-static const char *transport_err(mdb_dist *d)
-{
-	return d->own_transport ? ((rccl_transport *)d->t.self)->err : "";
-}
 
 extern "C" int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uint64_t *key_nulls, uint64_t n, uint32_t flags,
 				     const struct mdb_dist_col *cols, int ncols, void **out_values, uint64_t **out_nullbits, uint64_t *out_n)

@@ -40,7 +40,7 @@ DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
-    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
 ]
 
 
@@ -60,6 +60,7 @@ def _bind(lib):
         "mdb_dist_set_wire": ([P, c_int], c_int),
         "mdb_dist_last_wire32": ([P], c_int),
         "mdb_dist_last_pruned": ([P], c_int),
+        "mdb_dist_last_fused": ([P], c_int),
         "mdb_dist_set_key_ranges": ([P, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64)], c_int),
         "mdb_dist_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dist_join_group_count_alloc": ([P, P, P, c_uint64, P, P, c_uint64, ctypes.c_uint32, POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64),
@@ -203,6 +204,10 @@ class DistCtx:
 
     def last_pruned(self):
         return bool(self.lib.mdb_dist_last_pruned(self.h))
+
+    def last_fused(self):
+        """the last join_group_count shipped first-level partition regions (mdb_dev_shard.hip) instead of keys"""
+        return bool(self.lib.mdb_dist_last_fused(self.h))
 
     def set_key_ranges(self, left=None, right=None):
         """catalog statistics for WIRE_32 / WIRE_64 calls: the GLOBAL (smallest, largest) key of the left and right table (the same

@@ -181,6 +181,31 @@ def dest_of(keys, n_dest):
     return ((hv & np.uint64(0xFFFFFFFF)) % np.uint64(n_dest)).astype(np.int64)
 
 
+def mixk(x, k):
+    """include csrc/mdb_dev_common.h mdb_mixk: the murmur3 finaliser on k-bit words (a bijection of [0, 2^k))"""
+    x = np.asarray(x, dtype=np.uint64)
+    mask = np.uint64((1 << k) - 1)
+    s = np.uint64((k + 1) >> 1)
+    x = x ^ (x >> s)
+    x = (x * np.uint64(0x85EBCA6B)) & mask
+    x = x ^ (x >> s)
+    x = (x * np.uint64(0xC2B2AE35)) & mask
+    x = x ^ (x >> s)
+    return x
+
+
+def dest_of_fused(keys, n_dest, r_lo, r_span):
+    """destination rank of a key when the sharded operator ships first-level regions (mdb_dev_shard.hip): the top log2(n_dest)
+    bits of the k-bit hash of key - r_lo, k = the bits of the right table's global key range (at least 13)"""
+    k = max(int(np.ceil(np.log2(max(int(r_span), 1)))), 13)
+    while (1 << k) < r_span:
+        k += 1
+    with np.errstate(over="ignore"):
+        rel = (np.asarray(keys, dtype=np.int64) - np.int64(r_lo)).astype(np.uint64)
+    h = mixk(rel, k)
+    return (h >> np.uint64(k - 9)).astype(np.int64) // (512 // n_dest)
+
+
 def partition_by_dest(keys, nulls, n_dest):
     """-> (keys grouped by destination, stable inside a destination; counts per destination)."""
     keys = np.asarray(keys, dtype=np.int64)

@@ -29,17 +29,23 @@ def gloo_transport(dev, world, rank):
         return cout.tolist()
 
     def alltoallv(d_send, sc, sd, d_recv, rc, rd, es, _stream):
+        """any counts / displacements (the region exchange sends every peer the SAME counter array: displacement 0 for all)"""
         torch.cuda.synchronize()
         dev.sync()
-        nsend, nrecv = sum(sc), sum(rc)
-        assert sd == [sum(sc[:i]) for i in range(world)] and rd == [sum(rc[:i]) for i in range(world)]
-        hs = np.zeros(max(nsend, 1) * es, dtype=np.uint8)
-        if nsend:
-            assert dev.lib.mdb_dev_d2h(dev.h, hs.ctypes.data, d_send, nsend * es) == 0
+        hi = max([sd[i] + sc[i] for i in range(world)] + [0])
+        hs = np.zeros(max(hi, 1) * es, dtype=np.uint8)
+        if hi:
+            assert dev.lib.mdb_dev_d2h(dev.h, hs.ctypes.data, d_send, hi * es) == 0
+        send = np.concatenate([hs[sd[i] * es:(sd[i] + sc[i]) * es] for i in range(world)]) if hi else np.zeros(0, dtype=np.uint8)
+        nrecv = sum(rc)
         hr = torch.empty(max(nrecv, 1) * es, dtype=torch.uint8)
-        dist.all_to_all_single(hr[:nrecv * es], torch.from_numpy(hs)[:nsend * es], [c * es for c in rc], [c * es for c in sc])
-        if nrecv:
-            assert dev.lib.mdb_dev_h2d(dev.h, d_recv, hr.numpy().ctypes.data, nrecv * es) == 0
+        dist.all_to_all_single(hr[:nrecv * es], torch.from_numpy(np.ascontiguousarray(send)), [c * es for c in rc], [c * es for c in sc])
+        off = 0
+        for i in range(world):
+            if rc[i]:
+                piece = hr[off:off + rc[i] * es].numpy()
+                assert dev.lib.mdb_dev_h2d(dev.h, d_recv + rd[i] * es, piece.ctypes.data, rc[i] * es) == 0
+            off += rc[i] * es
 
     def allreduce(vals):
         t = torch.tensor(vals, dtype=torch.int64)
@@ -47,6 +53,17 @@ def gloo_transport(dev, world, rank):
         return t.tolist()
 
     return DistCtx.with_transport(dev, world, rank, counts, alltoallv, allreduce)
+
+
+def owned(dx, keys, world, rank, gb, nb=None, promised=None):
+    """which of `keys` this rank owns after the last join_group_count: by the hash of the key-by-destination path, or - when first-level
+    regions travelled (mdb_dist_last_fused) - by the top bits of the window hash of the right table's global range"""
+    if not dx.last_fused():
+        return orc.dest_of(keys, world) == rank
+    if promised is None:
+        v = gb if nb is None else gb[~nb]
+        promised = (int(v.min()), int(v.max()))
+    return orc.dest_of_fused(keys, world, promised[0], promised[1] - promised[0] + 1) == rank
 
 
 def check(dx, dev, world, rank, n, seed, lo, span, null_frac, expect_wire32):
@@ -63,14 +80,14 @@ def check(dx, dev, world, rank, n, seed, lo, span, null_frac, expect_wire32):
     k, c, j = dx.join_group_count(dev.to_dev(ga[la]), dev.nullbits_dev(na[la]) if null_frac else None, dev.to_dev(gb[lb]),
                                   dev.nullbits_dev(nb[lb]) if null_frac else None)
     ek, ec, _, ej = orc.join_group_count(ga, na, gb, nb)
-    mine = orc.dest_of(ek, world) == rank
+    mine = owned(dx, ek, world, rank, gb, nb if null_frac else None)
     got = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
     exp = dict(zip(ek[mine].tolist(), ec[mine].tolist()))
     assert len(got) == k.numel(), "duplicate group keys"
     assert got == exp, (len(got), len(exp))
     assert j == int(ec[mine].sum())
     assert dx.allreduce_sum([j])[0] == ej
-    if expect_wire32 is not None:
+    if expect_wire32 is not None and not dx.last_fused():
         assert dx.last_wire32() == expect_wire32
 
 
@@ -233,6 +250,45 @@ def sharded_sql(world, rank):
         print(f"sharded sql world {world} ok", flush=True)
 
 
+def fused_shapes(dx, dev, world, rank):
+    """the regions-on-the-wire operator through its forms: one level (2-byte and 4-byte words), the receiver's own second level,
+    duplicates on both sides, NULL keys, an empty right table on one rank, a rank with far fewer rows; and skewed keys that
+    overflow a region (every rank takes the exact path together)"""
+    rng = np.random.default_rng(99)
+    dx.set_wire(WIRE_32)
+    for n, span, dup in ((300_000, 40_000, 3), (500_000, 3_000_000, 1), (400_000, 60_000_000, 2), (1_500_000, 1_200_000, 1)):
+        total = n * world
+        base = 5_000_000
+        ga = base + rng.integers(0, span, total, dtype=np.int64)
+        gb = base + rng.integers(0, span, total // dup + 7, dtype=np.int64)
+        na, nb = rng.random(len(ga)) < 0.01, rng.random(len(gb)) < 0.01
+        cut = [0] + [int(len(ga) * (r + 1) / world * (0.5 if r + 1 < world else 1.0)) for r in range(world)]
+        cutb = [0] + [int(len(gb) * (r + 1) / world) for r in range(world)]
+        la, lb = slice(cut[rank], cut[rank + 1]), slice(cutb[rank], cutb[rank + 1])
+        dx.set_key_ranges((base - 3, base + span + 3), (base, base + span - 1))
+        out = (torch.empty(total + 8, dtype=torch.int64, device=dev.device), torch.empty(total + 8, dtype=torch.int64, device=dev.device))
+        k, c, j = dx.join_group_count(dev.to_dev(ga[la]), dev.nullbits_dev(na[la]), dev.to_dev(gb[lb]), dev.nullbits_dev(nb[lb]), out=out)
+        assert dx.last_fused(), (n, span)
+        ek, ec, _, ej = orc.join_group_count(ga, na, gb, nb)
+        mine = owned(dx, ek, world, rank, gb, promised=(base, base + span - 1))
+        got = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
+        assert len(got) == k.numel() and got == dict(zip(ek[mine].tolist(), ec[mine].tolist())), (n, span, len(got), int(mine.sum()))
+        assert dx.allreduce_sum([j])[0] == ej
+    # 90 % of the left rows share one key: its region overflows on the sender -> all ranks fall back, same groups
+    n = 400_000
+    ga = 1000 + rng.integers(0, 50_000, n * world, dtype=np.int64)
+    ga[rng.random(len(ga)) < 0.9] = 1234
+    gb = 1000 + rng.integers(0, 50_000, n * world, dtype=np.int64)
+    la = slice(rank * n, (rank + 1) * n)
+    dx.set_key_ranges((1000, 51_000), (1000, 51_000))
+    out = (torch.empty(n * world + 8, dtype=torch.int64, device=dev.device), torch.empty(n * world + 8, dtype=torch.int64, device=dev.device))
+    k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None, out=out)
+    ek, ec, _, ej = orc.join_group_count(ga, None, gb, None)
+    assert not dx.last_fused()
+    assert dx.allreduce_sum([j])[0] == ej and dx.allreduce_sum([k.numel()])[0] == len(ek)
+    dx.set_key_ranges(None, None)
+
+
 def main():
     mode = sys.argv[1]
     rank = int(os.environ.get("RANK", "0"))
@@ -268,9 +324,10 @@ def main():
     la, lb = slice(rank * n, (rank + 1) * n), slice(rank * n, (rank + 1) * n)
     k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[lb]), None)
     ek, ec, _, ej = orc.join_group_count(ga, None, gb, None)
-    mine = orc.dest_of(ek, world) == rank
+    mine = owned(dx, ek, world, rank, gb)
     assert dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())) == dict(zip(ek[mine].tolist(), ec[mine].tolist()))
     assert dx.allreduce_sum([j])[0] == ej
+    mine = orc.dest_of(ek, world) == rank
     received = dx.allreduce_sum([dx.last_received_left()])[0]
     assert received <= n * world // 20 + 1, received		# (of the n * world left rows)
     # the same with catalog statistics instead of measured ranges (WIRE_32 + promised ranges: supersets are fine), and a promise
@@ -279,8 +336,16 @@ def main():
     dx.set_key_ranges((10**6, 10**6 + n * world), (10**6 + n * world // 3 - 5, 10**6 + n * world // 3 + n * world // 20 + 5))
     k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[lb]), None)
     assert dx.last_pruned()
-    assert dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())) == dict(zip(ek[mine].tolist(), ec[mine].tolist()))
+    assert dx.last_fused()		# known ranges: the first partition level IS the exchange (mdb_dev_shard.hip, regions on the wire)
+    mine_f = owned(dx, ek, world, rank, gb, promised=(10**6 + n * world // 3 - 5, 10**6 + n * world // 3 + n * world // 20 + 5))
+    assert dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())) == dict(zip(ek[mine_f].tolist(), ec[mine_f].tolist()))
     assert dx.allreduce_sum([dx.last_received_left()])[0] <= n * world // 20 + 11
+    os.environ["MDB_DIST_FUSED"] = "0"	# ... and the key-by-destination path on the same input
+    k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[lb]), None)
+    assert not dx.last_fused()
+    assert dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())) == dict(zip(ek[mine].tolist(), ec[mine].tolist()))
+    del os.environ["MDB_DIST_FUSED"]
+    fused_shapes(dx, dev, world, rank)
     dx.set_key_ranges((10**6, 10**6 + n * world), (10**6 + n * world // 3, 10**6 + n * world // 3 + 10))	# too tight for the right table
     try:
         dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[lb]), None)
