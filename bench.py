@@ -507,10 +507,13 @@ def main():
                        "left_table_pruning": {"min_max": bool(dev.last_join_filter()[1]), "bitmap": int(dev.last_join_filter()[0])},
                        "partition_levels": dev.last_join_levels(),
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
-                       "order": "reference first-occurrence order" if not use_dist else "per rank, first occurrence in the received stream",
+                       "order": "reference first-occurrence order" if not use_dist else "per rank, unspecified (leaf order; first occurrence in the "
+                                "received stream on the key-by-destination path)",
                        "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
                                       + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")
-                                      + ((", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire") if use_dist else ""),
+                                      + ((", first-level partition regions on the wire (each table partitioned once; the receiver joins the "
+                                          "regions of all ranks: mdb_dev_shard.hip)" if dx.last_fused() else
+                                          (", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire")) if use_dist else ""),
                        "rccl_ranks_seen": ranks_seen if use_dist else None,
                        "pruned_before_shuffle": bool(dx.last_pruned()) if use_dist else None},
             "roofline": roof,

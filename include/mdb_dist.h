@@ -116,6 +116,10 @@ int mdb_dist_join_group_count(mdb_dist *d, const int64_t *keys_l, const uint64_t
  * indexes keys_l itself: this is how query_execute() chains the operator over further tables joined on the same key
  * (reference shape: A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a). */
 #define MDB_DIST_LEFT_IN_PLACE 1u
+/* the groups must land where their KEY hashes to (mdb_dev_partition_by_dest's hash) because a later MDB_DIST_LEFT_IN_PLACE call
+ * will send another table after them: the regions-on-the-wire path (mdb_dist_last_fused), whose placement follows the hash of
+ * the key's offset in this call's window, is not taken */
+#define MDB_DIST_PLACE_BY_KEY_HASH 2u
 int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				    const uint64_t *null_r, uint64_t n_r, uint32_t flags, int64_t **out_key, int64_t **out_count,
 				    uint32_t **out_first, uint64_t *out_groups, uint64_t *out_joined);

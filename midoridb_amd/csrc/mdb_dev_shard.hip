@@ -23,7 +23,8 @@
 #define SH_NSUB 8u		/* = PART_NSUB of mdb_dev_partition.hip: sub-regions per first-level digit */
 #define SH_D_BITS 9
 #define SH_ONE_LEVEL_MAX_REM 14u	/* 2^14 entries x 8 bytes = 128 KiB of LDS */
-#define SH_LEAF_REM 12u		/* two levels: leaves of at most 2^12 key values */
+#define SH_LEAF_REM 13u		/* two levels: leaves of 2^13 key values (64 KiB of counters, 1024 threads: 0.46 ms for 2 x 10^8 rows where
+				 * 2^12-value leaves - twice as many workgroups, each with its fixed costs - take 0.82 and 2^14 0.55) */
 #define SH_RANGE_WORD 24	/* words of ctx->d_status that hold the left table's pruning range */
 
 static uint32_t sh_ceil_log2(uint64_t v)
@@ -65,7 +66,13 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_
 		p->b2 = 0;
 		p->rem = below;
 	} else {
-		int b2 = below > SH_LEAF_REM ? (int)(below - SH_LEAF_REM) : 2;
+		uint32_t leaf_rem = SH_LEAF_REM;
+		{
+			const char *e = getenv("MDB_SHARD_REM");	/* (measurements) */
+			if (e && atoi(e) >= 8 && atoi(e) <= (int)SH_ONE_LEVEL_MAX_REM)
+				leaf_rem = (uint32_t)atoi(e);
+		}
+		int b2 = below > leaf_rem ? (int)(below - leaf_rem) : 2;
 		if (b2 > MDB_MAX_RADIX_BITS)
 			return 1;	/* (windows beyond 2^30 values) */
 		if ((uint32_t)b2 > below - 2u)
@@ -246,13 +253,15 @@ template <int THREADS, typename WT>
 __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t sh_lds[];
-	__shared__ uint32_t s_scan[32];
 	__shared__ unsigned long long s_red[THREADS / 64];
-	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_base, s_total, s_off;
 	const uint32_t T = 1u << a.rem, mask = T - 1u, leaf = blockIdx.x;
 	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + T;
 	for (uint32_t s = threadIdx.x; s < 2 * T; s += THREADS)
 		sh_lds[s] = 0u;
+	if (threadIdx.x == 0)
+		s_total = 0;
+	uint32_t groups = 0;		/* slots whose first left row this thread saw */
 	__syncthreads();
 	constexpr uint32_t PER = 16u / sizeof(WT);	/* words per 16-byte load */
 #pragma unroll
@@ -290,24 +299,28 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 						const uint32_t idx = (sizeof(WT) == 4 ? (w >> a.shift) : w) & mask;
 						if (side == 1)
 							atomicAdd(&s_cr[idx], 1u);
-						else if (s_cr[idx])
-							atomicAdd(&s_cl[idx], 1u);
+						else if (s_cr[idx] && atomicAdd(&s_cl[idx], 1u) == 0u)
+							groups++;
 					}
 				}
 			}
 		}
 		__syncthreads();
 	}
-	/* emit: thread t owns the slots [t * W, t * W + W) */
-	const uint32_t W = T > (uint32_t)THREADS ? T / THREADS : 1u;
-	uint32_t mine = 0;
-	for (uint32_t k = 0; k < W; k++) {
-		const uint32_t s = threadIdx.x * W + k;
-		if (s < T && s_cl[s])
-			mine++;
+	/* emit.  The groups of the leaf were counted while the left rows came in (a slot's first left row); one global atomic
+	 * reserves their places.  Slots are walked THREADS at a time - consecutive threads, consecutive slots: conflict-free LDS
+	 * reads - and the groups of a wave's 64 slots are written side by side (ballot + popcount, the wave's share of the
+	 * workgroup's range from one LDS atomic): coalesced stores.  Any order will do: across ranks SQL leaves it open. */
+	{
+		uint32_t g = groups;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			g += __shfl_down(g, o, MDB_WAVE);
+		if (mdb_lane() == 0 && g)
+			atomicAdd(&s_total, g);
 	}
-	uint32_t total;
-	uint32_t pos = mdb_block_excl_scan(mine, s_scan, &total);
+	__syncthreads();
+	const uint32_t total = s_total;
 	if (!total)
 		return;
 	if (threadIdx.x == 0) {
@@ -318,25 +331,30 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 		} else {
 			s_base = nb;
 		}
+		s_off = 0;
 	}
 	__syncthreads();
 	if (s_base == 0xFFFFFFFFu)
 		return;
-	pos += s_base;
 	unsigned long long joined = 0;
-	for (uint32_t k = 0; k < W; k++) {
-		const uint32_t s = threadIdx.x * W + k;
-		if (s >= T)
-			break;
-		const uint32_t cl = s_cl[s];
-		if (!cl)
+	for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {
+		const uint32_t s = s0 + threadIdx.x;
+		const uint32_t cl = s < T ? s_cl[s] : 0u;
+		const uint64_t m = __ballot(cl != 0u);
+		if (!m)
 			continue;
-		const unsigned long long c = (unsigned long long)cl * s_cr[s];
-		const uint32_t h = a.hash_base + (leaf << a.rem) + s;
-		a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
-		a.out_count[pos] = (long long)c;
-		joined += c;
-		pos++;
+		uint32_t wbase = 0;
+		if (mdb_lane() == 0)
+			wbase = atomicAdd(&s_off, (uint32_t)__popcll(m));
+		wbase = __shfl(wbase, 0, MDB_WAVE);
+		if (cl) {
+			const uint32_t pos = s_base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+			const unsigned long long c = (unsigned long long)cl * s_cr[s];
+			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
+			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
+			a.out_count[pos] = (long long)c;
+			joined += c;
+		}
 	}
 #pragma unroll
 	for (int o = 32; o; o >>= 1)
@@ -420,6 +438,11 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *recv_l
 		a.cap[x] = p->leaf_cap[x];
 	}
 	a.nseg = 1;
-	MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<512, uint32_t>), nleaves, 512, lds, a);
+	if (p->rem > 10u) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<1024, uint32_t>), nleaves, 1024, lds, a);
+	} else {
+		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<512, uint32_t>), nleaves, 512, lds, a);
+	}
 	return MIDORIDB_OK;
 }

@@ -556,6 +556,18 @@ static int dist_send_table(mdb_dist *d, int i, const int64_t *keys, const uint64
 	return MIDORIDB_OK;
 }
 
+/* the operator's flag word as three counters the ranks can sum: a region overflowed (the exact path answers), a right key outside
+ * the window, anything else */
+__global__ void k_status_words(const uint32_t *status, uint64_t *out)
+{
+	if (threadIdx.x == 0) {
+		const uint32_t f = status[0];
+		out[0] = (f & 2u) ? 1u : 0u;
+		out[1] = (f & 128u) ? 1u : 0u;
+		out[2] = (f & ~(2u | 128u)) ? 1u : 0u;
+	}
+}
+
 static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_t *out_count, int rc)
 {
 	if (alloc_out) {
@@ -589,7 +601,7 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 	for (int p = 0; p < W; p++) {
 		sendv[3 * p] = n_l;
 		sendv[3 * p + 1] = n_r;
-		sendv[3 * p + 2] = alloc_out ? ~0ull : cap;
+		sendv[3 * p + 2] = alloc_out ? (1ull << 62) : cap;	/* (a transport's counters need not survive values beyond 2^63) */
 	}
 	int rc = d->t.counts(d->t.self, sendv, recvv, 3);
 	if (rc)
@@ -680,14 +692,33 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 	rc = mdb_shard_join(ctx, &plan, recv[0], rcnt[0], recv[1], rcnt[1], out_key, out_count, cap);
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "sharded join: %s", mdb_dev_last_error(ctx)));
+	/* ---- G, J and the flags come back with ONE host synchronisation; what went wrong anywhere sends every rank the same way:
+	 *      over RCCL the ranks' flags are summed on the device, on the operator's own stream, before that read-back (a host
+	 *      all-reduce is a second round trip); a host's own transport is asked the usual way */
 	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
-	DIST_HIP(d, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	uint64_t st[3] = { 0, 0, 0 };
+	bool reduced_on_device = false;
+	if (d->own_transport) {
+		rccl_transport *rt = (rccl_transport *)d->t.self;
+		uint64_t *dflags = reinterpret_cast<uint64_t *>(ctx->d_status + 32);	/* (three 8-byte words beyond what the operators use) */
+		hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status, dflags);
+		ncclResult_t nr = ncclAllReduce(dflags, dflags, 3, ncclUint64, ncclSum, rt->small, ctx->stream);
+		if (nr != ncclSuccess)
+			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "status all-reduce: %s", ncclGetErrorString(nr)));
+		reduced_on_device = true;
+	}
+	DIST_HIP(d, hipMemcpyAsync(h, ctx->d_status, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	DIST_HIP(d, hipStreamSynchronize(ctx->stream));
 	const uint32_t flags = h[0];
 	const uint64_t G = h[1], J = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
-	/* ---- one word per rank: what went wrong anywhere sends everybody the same way */
-	uint64_t st[3] = { (flags & 2u) ? 1u : 0u, (flags & 128u) ? 1u : 0u, (flags & ~(2u | 128u)) ? 1u : 0u };
-	rc = d->t.allreduce_sum_u64(d->t.self, st, 3);
+	if (reduced_on_device) {
+		memcpy(st, h + 32, sizeof(st));
+	} else {
+		st[0] = (flags & 2u) ? 1u : 0u;
+		st[1] = (flags & 128u) ? 1u : 0u;
+		st[2] = (flags & ~(2u | 128u)) ? 1u : 0u;
+		rc = d->t.allreduce_sum_u64(d->t.self, st, 3);
+	}
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "status exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
 	if (st[2])
@@ -731,7 +762,7 @@ static int dist_join_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t **out_key, i
  * caller's (capacity cap) or allocated here once the number of received left rows is known */
 static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			  const uint64_t *null_r, uint64_t n_r, bool left_in_place, bool alloc_out, int64_t **out_key, int64_t **out_count,
-			  uint32_t **out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+			  uint32_t **out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined, bool by_key_hash = false)
 {
 	mdb_dev_ctx *ctx = d->ctx;
 	*out_groups = 0;
@@ -811,7 +842,7 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	d->last_pruned = prune ? 1 : 0;
 
 	d->last_fused = 0;
-	if (prune && !left_in_place && !out_first) {
+	if (prune && !left_in_place && !out_first && !by_key_hash) {
 		/* both global key ranges are known: the first partition level IS the exchange (mdb_dev_shard.hip) */
 		const int frc = dist_join_fused(d, keys_l, null_l, n_l, keys_r, null_r, n_r, glo, ghi, verify, alloc_out, out_key, out_count, cap, out_groups,
 						out_joined);
@@ -904,7 +935,7 @@ extern "C" int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_
 	if (!d || !out_groups || !out_key || !out_count)
 		return -MIDORIDB_ERROR;
 	return dist_join_impl(d, keys_l, null_l, n_l, keys_r, null_r, n_r, (flags & MDB_DIST_LEFT_IN_PLACE) != 0, true, out_key, out_count, out_first,
-			      0, out_groups, out_joined);
+			      0, out_groups, out_joined, (flags & MDB_DIST_PLACE_BY_KEY_HASH) != 0);
 }
 
 /* ------------------------------------------------------------------ row shuffles: keys + payload columns

@@ -1666,7 +1666,9 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			/* sharded mode: the tables hold this rank's rows; both key columns are exchanged (RCCL all-to-all per table,
 			 * include/mdb_dist.h) and this rank keeps the groups whose key hashes to it.  Collective: every rank runs the
 			 * same statement. */
-			if (mdb_dist_join_group_count_alloc(cat->dist, lv, ln, nl_rows, rv, rn, nr_rows, 0, &x.d_fused_key, &x.d_count, NULL, &G, &J)) {
+			/* (more tables follow on the same key: the groups must lie where their key hashes to, for the tables sent after them) */
+			if (mdb_dist_join_group_count_alloc(cat->dist, lv, ln, nl_rows, rv, rn, nr_rows, s->ntabs > 2 ? MDB_DIST_PLACE_BY_KEY_HASH : 0u,
+							    &x.d_fused_key, &x.d_count, NULL, &G, &J)) {
 				snprintf(err, errlen, "execution phase: sharded join + group count: %s\n", mdb_dist_last_error(cat->dist));
 				rc = -MIDORIDB_INTERNAL;
 				goto out;
