@@ -644,7 +644,7 @@ static int topk_rec(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys
 			goto out;
 		}
 		/* the rows at or before the threshold, in the order of the FIRST key (NULL first ascending, last descending) */
-		struct mdb_pred_insn prog[3];
+		struct mdb_pred_insn prog[5];
 		int np = 0;
 		const bool thr_null = h[1] != 0, is_double = keys[0].type == MDB_T_DOUBLE;
 		double thr_d;
@@ -673,6 +673,18 @@ static int topk_rec(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys
 			prog[np].type = keys[0].type;
 			prog[np].imm = (int64_t)h[0];
 			np++;
+		}
+		if (usable && np && is_double) {
+			/* NaN rows are candidates whatever the threshold: mdb_dev_sort_perm orders DOUBLE keys by their bits (NaNs with
+			 * the sign bit first, the others last), the IEEE comparisons above are false for them - without this a NaN that
+			 * sorts first would be missing from the prefix.  col <> col is true exactly for NaN */
+			prog[np].op = MDB_P_CMP_COL_COL;
+			prog[np].cmp = MDB_CMP_NE;
+			prog[np].type = MDB_T_DOUBLE;
+			prog[np].a = 0;
+			prog[np].b = 0;
+			np++;
+			prog[np++].op = MDB_P_OR;
 		}
 		if (usable && np) {
 			struct mdb_col_binding cb = { keys[0].values, keys[0].nullbits, keys[0].rid };

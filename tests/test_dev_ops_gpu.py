@@ -483,12 +483,16 @@ def _sort_case(dev, rng, n, specs, with_rid=False, topk=None):
             v = np.round(rng.normal(0, 100, m), 1)
             v[rng.random(m) < 0.05] = -0.0
             v[rng.random(m) < 0.05] = 0.0
+            if kind == "nan":          # NaNs of both signs (they can enter through the bulk append API): ordered by their bits, like everything
+                v[rng.random(m) < 0.001] = np.nan
+                neg = rng.random(m) < 0.0005
+                v.view(np.uint64)[neg] = np.uint64(0xFFF8000000000001)
         nulls = (rng.random(m) < nf) if nf else None
         vd = dev.to_dev(v)
         nd = dev.nullbits_dev(nulls)
         keep += [vd, nd]
-        keys_np.append((v, nulls, rid, kind == "double", desc))
-        keys_dev.append((vd, nd, rid_dev, D.T_DOUBLE if kind == "double" else D.T_INT64, desc))
+        keys_np.append((v, nulls, rid, kind in ("double", "nan"), desc))
+        keys_dev.append((vd, nd, rid_dev, D.T_DOUBLE if kind in ("double", "nan") else D.T_INT64, desc))
     want = orc.sort_perm(keys_np, n)
     if topk is not None:
         sorted_rows = []
@@ -504,7 +508,7 @@ def _sort_case(dev, rng, n, specs, with_rid=False, topk=None):
 @pytest.mark.parametrize("specs", [
     [("full", False, 0.0)], [("full", True, 0.2)], [("full", False, 0.2)], [("double", False, 0.0)], [("double", True, 0.1)],
     [("neg", False, 0.0), ("full", True, 0.0)], [("neg", True, 0.01), ("double", False, 0.3), ("small", False, 0.0)],
-    [("full", False, 0.999)], [("full", True, 0.999)],
+    [("full", False, 0.999)], [("full", True, 0.999)], [("nan", False, 0.0)], [("nan", True, 0.05), ("small", False, 0.0)],
 ], ids=lambda s: "+".join(f"{k}{'D' if d else 'A'}{int(nf * 10)}" for k, d, nf in s))
 def test_topk_perm_is_the_prefix_of_the_stable_sort_unpinned(dev, specs):
     """ORDER BY ... LIMIT k (extension): threshold from a sample, one filter pass, sort of the candidates -
