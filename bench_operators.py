@@ -154,6 +154,15 @@ def main():
     ms, kern, g3 = timed(dev, three_way_group, reps=2, warmup=1)
     res["three_way_join_group_1e8"] = {"rows_per_table": n, "groups": g3, "ms": ms, "joined_rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
                                        "note": "BASELINE configs[4] shape on ONE GPU: two materialising joins (unique keys) + GROUP BY + COUNT(*)"}
+
+    def three_way_fused():
+        k, c, f, j = dev.join_group_count_multi(big[0], None, [(big[1], None), (big[2], None)])
+        return k.numel()
+    ms, kern, g3f = timed(dev, three_way_fused, reps=3, warmup=1)
+    res["three_way_join_group_fused_1e8"] = {"rows_per_table": n, "groups": g3f, "ms": ms, "joined_rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
+                                             "one_pass": dev.last_join_multi(),
+                                             "note": "the same query through mdb_dev_join_group_count_multi: every table partitioned once, the right "
+                                                     "tables' counts multiplied in the leaf kernel, the groups ordered once; no joined row exists"}
     del big
     torch.cuda.empty_cache()
 

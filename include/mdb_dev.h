@@ -77,7 +77,8 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * -> of the last completed join / GROUP BY operator: bit 8 = min-max pruning ran; low byte = 0 without the bitmap, else 1 +
  * log2(adjacent hashed values per bitmap bit); bit 9 = the tables were partitioned ONCE (key windows of 2^15 ... 2^23
  * values: one 9-bit level, direct-address leaf tables of 2^(k - 9) entries with 16-bit row counts; MDB_ONE_LEVEL=0 turns it
- * off; a key with 2^16 or more rows sends the operator back to two levels). */
+ * off; a key with 2^16 or more rows sends the operator back to two levels); bit 10 = several right tables were counted in one
+ * pass (mdb_dev_join_group_count_multi did not chain two-table operators). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
@@ -335,6 +336,18 @@ int mdb_dev_join_group_count(mdb_dev_ctx *ctx,
  * (= rows of the full join).  The joined rows of neither join are ever materialised.  Synchronises. */
 int mdb_dev_combine_counts(mdb_dev_ctx *ctx, const int64_t *cnt1, const uint32_t *first1, const uint32_t *idx, const int64_t *cnt2,
 			   uint64_t n, int64_t *out_cnt, uint32_t *out_first, uint64_t *out_sum);
+
+/* The same shape in ONE operator: left table L and n_right (1 ... 3) right tables, all joined on one key -
+ * SELECT l.key, COUNT(*) FROM L JOIN R0 ON l.key = r0.key JOIN R1 ON l.key = r1.key ... GROUP BY l.key (reference:
+ * recursive join executor_select.c:1151-1280 + GROUP BY :1526-1588; BASELINE configs[4]).  COUNT(*) of a key = its rows in L
+ * x its rows in R0 x its rows in R1 ...; outputs exactly as mdb_dev_join_group_count() (first-occurrence order, out_first =
+ * first L position, *out_joined = rows of the full join).  Every table is partitioned once and the groups ordered once when the
+ * keys take the compact narrow form; otherwise the call chains the two-table operator itself.  keys_r / null_r / n_r:
+ * HOST arrays of n_right entries (null_r may be NULL, or hold NULLs).  Synchronous. */
+int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
+				   const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r, uint32_t flags,
+				   int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+				   uint64_t *out_joined);
 
 /* Split form for pipelines that receive the two tables at different times (the multi-GPU exchange):
  * _begin() hashes and partitions the LEFT table and returns without a host sync, so the work overlaps

@@ -100,6 +100,8 @@ __global__ void k_gather_i32(const int32_t *__restrict__ keys, const uint32_t *_
 
 /* ------------------------------------------------------------------ fused join + group count */
 
+#define GC_MAX_EXTRA 2		/* right tables beyond the first one (mdb_dev_join_group_count_multi: up to 3 right tables) */
+
 struct gc_args {
 	const uint64_t *hv_l;
 	const uint32_t *rid_l;
@@ -130,6 +132,13 @@ struct gc_args {
 					 * first rows are scattered over the left table, every gathered key costs a 128-byte line) */
 	uint32_t merge_all;		/* plain GROUP BY: the key sample held duplicates (some 10^4 - 10^5 distinct values): merge equal
 					 * values per wave in every leaf, not only in the oversize ones */
+	/* further right tables joined on the SAME key (A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a: BASELINE configs[4]) -
+	 * direct-address leaves only: partitioned exactly like the right table (4-byte words, fixed-capacity leaves), counted into
+	 * LDS arrays of their own; a key's right count becomes the PRODUCT of its counts in all right tables */
+	uint32_t nextra;
+	const uint32_t *hv_x[GC_MAX_EXTRA];
+	const uint32_t *cnt_x[GC_MAX_EXTRA];
+	uint32_t cap_x[GC_MAX_EXTRA];
 };
 
 /* narrow word -> the 64-bit value the leaf tables work with (both halves = the 32-bit hash, so that the slot and the
@@ -823,6 +832,7 @@ __device__ static inline void ld_left_row(unsigned long long w, uint32_t shift, 
 
 struct ld_state {
 	uint32_t *s_cr, *s_cl, *s_first, *s_chunk;
+	uint32_t *s_cx;		/* nextra arrays of T counters: the further right tables */
 	uint32_t T, mask, shift, rem;
 	unsigned long long mine;
 	uint32_t nvalid;
@@ -891,6 +901,33 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 				for (int k = 0; k < 4; k++)
 					if (j + k < r1)
 						atomicAdd(&s_cr[(w[k] >> shift) & mask], 1u);
+			}
+			if (a.nextra) {		/* (uniform) further right tables on the same key: their rows, then the product of the counts */
+				for (uint32_t x = 0; x < a.nextra; x++) {
+					uint32_t *const s_c = st.s_cx + x * T;
+					const uint32_t x0 = leaf * a.cap_x[x], xc = a.cnt_x[x][leaf], x1 = x0 + (xc < a.cap_x[x] ? xc : a.cap_x[x]);
+					for (uint32_t j = x0 + 4u * threadIdx.x; j < x1; j += 4u * THREADS) {
+						const uint4 v = *reinterpret_cast<const uint4 *>(a.hv_x[x] + j);
+						const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							if (j + k < x1)
+								atomicAdd(&s_c[(w[k] >> shift) & mask], 1u);
+					}
+				}
+				__syncthreads();
+				for (uint32_t sl = threadIdx.x; sl < T; sl += THREADS) {
+					unsigned long long c = s_cr[sl];
+					for (uint32_t x = 0; x < a.nextra; x++) {
+						c *= st.s_cx[x * T + sl];
+						st.s_cx[x * T + sl] = 0u;
+						if (c >> 32) {		/* the product of the right counts no longer fits: reported, the caller chains 2-table operators */
+							mdb_raise(a.status, 2048u);
+							c = 0;
+						}
+					}
+					s_cr[sl] = (uint32_t)c;
+				}
 			}
 			__syncthreads();
 		}
@@ -996,6 +1033,9 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
 	st.s_cl = ld_lds + st.T;		/* left rows per key (joins: only of keys that have right rows) */
 	st.s_first = ld_lds + 2 * st.T;		/* first left row per key */
 	st.s_chunk = ld_lds + 3 * st.T;		/* record list chunk: [0] base [1] used [2] size [3] valid records; [4..7] see below */
+	st.s_cx = ld_lds + 3 * st.T + 8;	/* (further right tables) */
+	for (uint32_t s = threadIdx.x; s < a.nextra * st.T; s += THREADS)
+		st.s_cx[s] = 0u;
 	unsigned long long *const s_sum = reinterpret_cast<unsigned long long *>(ld_lds + 3 * st.T + 4);
 	st.mine = 0;
 	st.nvalid = 0;
@@ -2004,6 +2044,7 @@ size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kb
  * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
  * key - window base (min-max pruning, while it runs) */
 #define GC_ST_MINMAX 16
+#define GC_ST_WINDOW 20	/* [20..21] 0 and 2^key_bits - 1: the whole window as a pruning range (further right tables drop what lies outside) */
 #define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
 #define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
 #define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
@@ -2054,7 +2095,22 @@ struct gc_state {
 				 * hashed values that share a bit, plus 1 */
 	int b1, b2;
 	mdb_part_result pl;
+	/* further right tables on the same key (mdb_dev_join_group_count_multi) */
+	int nextra;
+	const int64_t *xkeys[GC_MAX_EXTRA];
+	const uint64_t *xnull[GC_MAX_EXTRA];
+	uint64_t xn[GC_MAX_EXTRA];
 };
+
+#define GC_NOT_SERVED 1008	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of
+				 * counts overflowed, or a hot leaf): the caller chains two-table operators instead */
+struct gc_extras {
+	int n;
+	const int64_t *keys[GC_MAX_EXTRA];
+	const uint64_t *nulls[GC_MAX_EXTRA];
+	uint64_t rows[GC_MAX_EXTRA];
+};
+static thread_local const gc_extras *gc_pending_extras = NULL;	/* set by mdb_dev_join_group_count_multi around its call of the operator */
 
 /* first half: size and claim the scratch arena, clear the status words, partition the left table */
 static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
@@ -2069,6 +2125,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			st->n_l + (st->has_r ? st->n_r_cap : 0) >= (1ull << 21) &&
 			st->n_l < 3000000000ull && st->n_r_cap < 3000000000ull &&
 			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
+	if (st->nextra)
+		st->one_level = false;	/* (further right tables: the two-level direct-address kernel counts them) */
 	if (st->one_level) {
 		st->b1 = st->key_bits <= 15u ? 8 : 9;	/* (a 2^15-value window: 256 regions of 128 values - see gc_window.fast1) */
 		st->b2 = 0;
@@ -2085,6 +2143,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		     st->key_bits >= (uint32_t)(st->b1 + st->b2) + 4u && st->key_bits <= (uint32_t)(st->b1 + st->b2) + LD_MAX_REM;
 	if (st->one_level)
 		st->direct = true;
+	if (st->nextra && !(st->direct && st->has_r && st->fast))
+		return GC_NOT_SERVED;
 	if (st->direct && !st->one_level) {
 		/* the direct-address kernel has no table to overflow and pays a fixed price per leaf (three barriers, the emit scan):
 		 * it prefers FEWER, larger leaves than the hashed kernel's 3833-slot table allows - tables of 2^LD_MAX_REM entries when
@@ -2139,6 +2199,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	if (st->has_r)
 		need += st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
 				      : mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
+	for (int x = 0; x < st->nextra; x++)
+		need += mdb_partition_arena_bytes(st->xn[x], st->b1, st->b2, false, st->fast) + 512;
 	{
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
@@ -2210,6 +2272,30 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, (st->defer_l || st->one_level) ? &rflt : NULL);
 		if (rc)
 			return rc;
+	}
+	mdb_part_result px[GC_MAX_EXTRA];
+	memset(px, 0, sizeof(px));
+	if (st->nextra) {
+		/* the further right tables, partitioned exactly like the first: same window, same bits, 4-byte words.  Their keys
+		 * outside the window are dropped, not reported: the window holds every key of the left table (or of the first right
+		 * table, with the left one pruned to it), so such a key joins nothing */
+		uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 520;
+		h[0] = 0u;
+		h[1] = st->key_bits >= 32u ? 0xFFFFFFFFu : ((1u << st->key_bits) - 1u);
+		MDB_HIP(ctx, hipMemcpyAsync(ctx->d_status + GC_ST_WINDOW, h, 8, hipMemcpyHostToDevice, ctx->stream));
+		for (int x = 0; x < st->nextra; x++) {
+			mdb_part_filter xf;
+			memset(&xf, 0, sizeof(xf));
+			xf.range_in = ctx->d_status + GC_ST_WINDOW;
+			if (!mdb_partition_w32_applies(st->xn[x], st->b1, st->b2, st->fast))
+				return GC_NOT_SERVED;
+			rc = mdb_partition_table(ctx, st->xkeys[x], st->xnull[x], st->xn[x], st->b1, st->b2, false, false, st->fast, &px[x], 2, st->keys32,
+						 st->key_lo, st->key_bits, &xf);
+			if (rc)
+				return rc;
+			if (!px[x].w32 || !px[x].leaf_cap || !px[x].leaf_cnt || px[x].nleaves != (1u << (st->b1 + st->b2)))
+				return GC_NOT_SERVED;
+		}
 	}
 	if (st->defer_l && !st->semijoin) {
 		mdb_part_filter flt;
@@ -2291,13 +2377,19 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.joined = d_joined;
 	a.status = ctx->d_status;
 	a.nleaves = pl.nleaves;
+	a.nextra = (uint32_t)st->nextra;
+	for (int x = 0; x < GC_MAX_EXTRA; x++) {
+		a.hv_x[x] = x < st->nextra ? reinterpret_cast<const uint32_t *>(px[x].hv) : NULL;
+		a.cnt_x[x] = x < st->nextra ? px[x].leaf_cnt : NULL;
+		a.cap_x[x] = x < st->nextra ? px[x].leaf_cap : 0u;
+	}
 	a.narrow = st->narrow ? 1u : 0u;
 	/* keyed records (see gc_args.keyed_cbits) when the join is selective - few groups, their first rows scattered over the left
 	 * table - and a COUNT(*) of at least 4 bits fits beside the row id and the hashed key (10 bits at 10^8 rows, 27 key bits);
 	 * a COUNT that does not fit is reported by the kernel and the operator redone with plain records (and remembered).
 	 * MDB_KEYED_RECORDS=0 switches them off */
 	uint32_t keyed_cbits = 0;
-	if (st->direct && has_r && st->selective && records && !ctx->keyed_distrust && pl.leaf_cap && pr.leaf_cap && kbits >= 13 &&
+	if (st->direct && has_r && !st->nextra && st->selective && records && !ctx->keyed_distrust && pl.leaf_cap && pr.leaf_cap && kbits >= 13 &&
 	    kbits + st->key_bits + 4u <= 64u && !(getenv("MDB_KEYED_RECORDS") && getenv("MDB_KEYED_RECORDS")[0] == '0'))
 		keyed_cbits = 64u - kbits - st->key_bits;
 	if (ctx->keyed_distrust > 0)
@@ -2341,7 +2433,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		} else if (st->direct && pl.leaf_cap && (!has_r || pr.leaf_cap)) {
 			/* compact narrow form: the leaf's table is indexed by the hash bits the partition left over */
 			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
-			const size_t lds = ((size_t)12 << rem) + 32;
+			if (st->nextra && !(pl.leaf_cap && pr.leaf_cap))
+				return GC_NOT_SERVED;
+			const size_t lds = ((size_t)(12 + 4 * st->nextra) << rem) + 32;
 			/* four 512-thread workgroups = the CU's 32 waves (three measured the same, 256-thread workgroups 10-30 % slower) */
 			uint32_t per_cu = (uint32_t)((size_t)(160 * 1024) / lds);
 			per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
@@ -2351,6 +2445,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			} else {
 				MDB_LAUNCH_LDS(ctx, "leaf_group_direct", (k_leaf_direct<false, 512, 2048>), dgrid, 512, lds, a, rem, shift);
 			}
+		} else if (st->nextra) {
+			return GC_NOT_SERVED;
 		} else if (has_r && build_r && st->narrow) {
 			MDB_LAUNCH(ctx, "leaf_join_group_count", (k_leaf_group_count<true, true, false, true>), grid, GC_THREADS, a);
 		} else if (has_r && build_r) {
@@ -2383,6 +2479,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if ((uint32_t)h[1] & 128u)
 		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
+	if (st->nextra && ((uint32_t)h[1] & (2u | 64u | 2048u)))
+		return GC_NOT_SERVED;	/* skewed keys, hot leaves, a product of counts beyond 32 bits: the chain of two-table operators */
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if ((uint32_t)h[1] & 1024u) {
@@ -2510,7 +2608,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if (out_joined)
 		*out_joined = joined;
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
-	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0) | (st->one_level ? 0x200 : 0);
+	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0);
 	return MIDORIDB_OK;
 }
 
@@ -2840,6 +2938,14 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.r_based = win.r_based;
 	st.keys32 = keys32;
 	st.defer_ok = true;
+	if (gc_pending_extras && has_r) {
+		st.nextra = gc_pending_extras->n;
+		for (int x = 0; x < st.nextra; x++) {
+			st.xkeys[x] = gc_pending_extras->keys[x];
+			st.xnull[x] = gc_pending_extras->nulls[x];
+			st.xn[x] = gc_pending_extras->rows[x];
+		}
+	}
 	int rc = gc_begin(ctx, &st);
 	if (rc)
 		return rc;
@@ -3215,6 +3321,112 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	    rc == GC_RETRY_TWO_LEVEL)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
+	return rc;
+}
+
+/* ---- one left table, up to three right tables, ONE key: A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a, COUNT(*)
+ *
+ * The reference runs this shape as a recursive join (executor_select.c:1151-1280) followed by the GROUP BY loop (:1526-1588).
+ * Here every table is partitioned once with the same hash; the direct-address leaf kernel counts the rows of every right
+ * table into an LDS array of its own, multiplies the counts per key, and the left rows then meet ONE right count as in the
+ * two-table operator (COUNT(*) = left rows x the product).  No joined row of any join exists, and the groups are ordered
+ * once - where chaining two-table operators (what query_execute() did before, and what this function still does when the
+ * keys do not take the compact narrow form, are skewed, or a product of counts outgrows 32 bits) partitions the group keys
+ * again and orders twice. */
+extern "C" int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
+					      const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r, uint32_t flags,
+					      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
+					      uint64_t *out_joined)
+{
+	if (!out_groups || n_right < 1 || n_right > 1 + GC_MAX_EXTRA || !keys_r || !n_r)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join_group_count_multi: one to %d right tables", 1 + GC_MAX_EXTRA);
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	if (n_right == 1)
+		return mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], flags, out_key, out_count, out_first,
+						cap, out_groups, out_joined);
+	if (!n_l)
+		return MIDORIDB_OK;
+	uint64_t smallest = n_l;
+	for (int t = 0; t < n_right; t++) {
+		if (!n_r[t])
+			return MIDORIDB_OK;
+		smallest = n_r[t] < smallest ? n_r[t] : smallest;
+	}
+	int rc = GC_NOT_SERVED;
+	if (smallest >= (1u << 16) && n_l >= (1u << 20)) {	/* (small tables: the chain's single-workgroup and one-level forms are quicker) */
+		gc_extras ex;
+		memset(&ex, 0, sizeof(ex));
+		ex.n = n_right - 1;
+		for (int t = 1; t < n_right; t++) {
+			ex.keys[t - 1] = keys_r[t];
+			ex.nulls[t - 1] = null_r ? null_r[t] : NULL;
+			ex.rows[t - 1] = n_r[t];
+		}
+		mdb_memo_switch(ctx, keys_l, n_l, keys_r[0], n_r[0]);
+		gc_pending_extras = &ex;
+		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], true, false, out_key, out_count, out_first, cap,
+					out_groups, out_joined);
+		gc_pending_extras = NULL;
+	}
+	if (rc != GC_NOT_SERVED)
+		return rc;
+	/* ---- the chain: groups of (L, R0), then (those group keys, R1) ..., counts multiplied */
+	*out_groups = 0;
+	int64_t *key[2] = { NULL, NULL }, *cnt[3] = { NULL, NULL, NULL };
+	uint32_t *first[2] = { NULL, NULL }, *idx = NULL;
+	uint64_t G = 0, J = 0;
+	const uint64_t room = n_l ? n_l : 1;
+	rc = MIDORIDB_OK;
+	for (int i = 0; i < 2 && !rc; i++) {
+		rc = mdb_dev_alloc(ctx, room * 8, (void **)&key[i]);
+		if (!rc)
+			rc = mdb_dev_alloc(ctx, room * 4, (void **)&first[i]);
+	}
+	for (int i = 0; i < 3 && !rc; i++)
+		rc = mdb_dev_alloc(ctx, room * 8, (void **)&cnt[i]);
+	if (!rc)
+		rc = mdb_dev_alloc(ctx, room * 4, (void **)&idx);
+	int cur = 0;		/* key[cur], cnt[cur], first[cur]: the groups so far */
+	if (!rc)
+		rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], flags, key[0], cnt[0], first[0], room, &G,
+					      &J);
+	for (int t = 1; t < n_right && !rc && G; t++) {
+		uint64_t G2 = 0, J2 = 0;
+		const int nxt = cur ^ 1;
+		rc = mdb_dev_join_group_count(ctx, key[cur], NULL, G, keys_r[t], null_r ? null_r[t] : NULL, n_r[t], flags, key[nxt], cnt[2], idx, room, &G2,
+					      &J2);
+		if (!rc)
+			rc = mdb_dev_combine_counts(ctx, cnt[cur], first[cur], idx, cnt[2], G2, cnt[nxt], first[nxt], &J);
+		cur = nxt;
+		G = G2;
+	}
+	if (!rc && G > cap)
+		rc = mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap, (unsigned long long)G);
+	if (!rc && G) {
+		hipError_t e = hipMemcpyAsync(out_count, cnt[cur], G * 8, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && out_key)
+			e = hipMemcpyAsync(out_key, key[cur], G * 8, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && out_first)
+			e = hipMemcpyAsync(out_first, first[cur], G * 4, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess)
+			rc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join_group_count_multi: %s", hipGetErrorString(e));
+	}
+	for (int i = 0; i < 2; i++) {
+		(void)mdb_dev_free(ctx, key[i]);
+		(void)mdb_dev_free(ctx, first[i]);
+	}
+	for (int i = 0; i < 3; i++)
+		(void)mdb_dev_free(ctx, cnt[i]);
+	(void)mdb_dev_free(ctx, idx);
+	if (!rc) {
+		*out_groups = G;
+		if (out_joined)
+			*out_joined = G ? J : 0;
+	}
 	return rc;
 }
 

@@ -1657,6 +1657,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		    (rc = fused_operand(&x, 1, fkeys[1], ws.push[1], ws.npush[1], &rv, &rn, &nr_rows)))
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
+		bool multi_done = false;
 		if (cat->dist && fkeys[0]->type == MDB_CT_VARCHAR) {
 			ERR("sharded mode: VARCHAR join keys are ids of this process's string dictionary and mean nothing to the other ranks\n");
 			rc = -MIDORIDB_ERROR;
@@ -1684,13 +1685,35 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				rc = dev_fail(&x, "allocating group outputs");
 				goto out;
 			}
-			if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
-						     &J)) {
+			if (s->ntabs > 2 && s->ntabs <= 4) {
+				/* A JOIN B ON a = b JOIN C ON a = c [JOIN D ...]: every table partitioned once, the right tables' counts multiplied
+				 * in the leaf kernel, the groups ordered once (mdb_dev_join_group_count_multi; it chains by itself when the keys
+				 * do not take the compact form) */
+				const int64_t *rk[3];
+				const uint64_t *rnb[3];
+				uint64_t rrows[3];
+				rk[0] = rv;
+				rnb[0] = rn;
+				rrows[0] = nr_rows;
+				for (int t = 2; t < s->ntabs; t++) {
+					const void *cv;
+					if ((rc = fused_operand(&x, t, fkeys[t], ws.push[t], ws.npush[t], &cv, &rnb[t - 1], &rrows[t - 1])))
+						goto out;
+					rk[t - 1] = cv;
+				}
+				if (mdb_dev_join_group_count_multi(x.dev, lv, ln, nl_rows, s->ntabs - 1, rk, rnb, rrows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL,
+								   cap, &G, &J)) {
+					rc = dev_fail(&x, "join + group count over several tables");
+					goto out;
+				}
+				multi_done = true;
+			} else if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
+							    &J)) {
 				rc = dev_fail(&x, "join + group count");
 				goto out;
 			}
 		}
-		for (int t = 2; t < s->ntabs && (G || cat->dist); t++) {
+		for (int t = 2; t < s->ntabs && (G || cat->dist) && !multi_done; t++) {
 			const void *cv;
 			const uint64_t *cn;
 			uint64_t nc_rows;

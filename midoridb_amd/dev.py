@@ -102,6 +102,8 @@ def _bind(lib):
         "mdb_dev_key_range": ([P, P, P, c_uint64, POINTER(c_int64), POINTER(c_int64)], c_int),
         "mdb_dev_widen32to64": ([P, P, c_uint64, P], c_int),
         "mdb_dev_gen_keys": ([P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_uint64], c_int),
+        "mdb_dev_join_group_count_multi": ([P, P, P, c_uint64, c_int, POINTER(P), POINTER(P), POINTER(c_uint64), c_uint32, P, P, P, c_uint64,
+                                            POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_gen_payload": ([P, P, c_uint64, c_uint64, c_uint64, c_int], c_int),
     }
     for name, (args, res) in sig.items():
@@ -116,7 +118,7 @@ DEV_SYMBOLS = [
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
-    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
+    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
 ]
@@ -235,6 +237,10 @@ class DeviceCtx:
         v = int(self.lib.mdb_dev_last_join_filter(self.h))
         return v & 0xFF, bool(v & 0x100)
 
+    def last_join_multi(self):
+        """the last join_group_count_multi counted all its right tables in one pass (no chain of two-table operators)"""
+        return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x400)
+
     def last_join_levels(self):
         """partition levels of the last join / GROUP BY operator's final attempt: 1 (wide direct-address leaves) or 2"""
         return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x200 else 2
@@ -293,6 +299,18 @@ class DeviceCtx:
                   "join_group_count")
         G = g.value
         return ok[:G], oc[:G], of[:G], j.value
+
+    def join_group_count_multi(self, keys_l, null_l, rights, out=None, flags=MDB_ORDER_FIRST):
+        """rights: [(keys, nullbits or None), ...] (1 ... 3 tables joined to keys_l on the one key) -> (keys[G], counts[G], first[G], joined rows)"""
+        n_l, nr = keys_l.numel(), len(rights)
+        cap, (ok, oc, of) = self._gc_out(n_l, out)
+        kr = (c_void_p * nr)(*[r[0].data_ptr() for r in rights])
+        nb = (c_void_p * nr)(*[(r[1].data_ptr() if r[1] is not None else None) for r in rights])
+        ns = (c_uint64 * nr)(*[r[0].numel() for r in rights])
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count_multi(self.h, _ptr(keys_l), _ptr(null_l), n_l, nr, kr, nb, ns, flags, _ptr(ok), _ptr(oc), _ptr(of),
+                                                          cap, byref(g), byref(j)), "join_group_count_multi")
+        return ok[:g.value], oc[:g.value], of[:g.value], j.value
 
     def _gc_out(self, n_l, out):
         cap = max(n_l, 1)

@@ -1954,3 +1954,35 @@ def test_column_memo_keeps_several_table_pairs(dev):
     prof = dev.prof_read()
     dev.prof_enable(False)
     assert prof.get("key_sample", (0, 0.0))[0] == 1, prof.get("key_sample")
+
+
+@pytest.mark.parametrize("shape", ["unique_3", "dups_3", "four_tables", "selective", "wide_keys", "small", "skew", "nulls"])
+def test_join_group_count_multi_same_key(dev, shape):
+    """mdb_dev_join_group_count_multi: L JOIN R0 JOIN R1 [JOIN R2] on ONE key + GROUP BY + COUNT(*) (BASELINE configs[4] shape) - every table
+    partitioned once, the right tables' counts multiplied in the leaf kernel; keys that do not take the compact form, skew, tiny tables go
+    through the chain of two-table operators inside the same call.  Oracle: per-key products of the tables' counts, in first-occurrence order."""
+    rng = np.random.default_rng(len(shape) * 7)
+    n = {"small": 3000}.get(shape, 1_300_000)
+    span = {"unique_3": n, "dups_3": n // 8, "four_tables": n // 3, "selective": n, "wide_keys": n, "small": 500, "skew": n // 4, "nulls": n // 2}[shape]
+    off = 10**14 if shape == "wide_keys" else 1000
+    mk = lambda m, s=span: off + rng.integers(0, s, m, dtype=np.int64) * (2**33 if shape == "wide_keys" else 1)  # noqa: E731
+    kl = off + rng.permutation(n).astype(np.int64) if shape == "unique_3" else mk(n)
+    rights = [mk(n), mk(n - 1000)] + ([mk(n // 2)] if shape == "four_tables" else [])
+    if shape == "selective":
+        rights[0] = off + rng.integers(0, n // 20, n // 4, dtype=np.int64)
+    if shape == "skew":
+        rights[1][rng.random(len(rights[1])) < 0.6] = off + 77
+        kl[rng.random(n) < 0.3] = off + 77
+    nl = (rng.random(n) < 0.02) if shape == "nulls" else None
+    nrs = [(rng.random(len(r)) < 0.02) if shape == "nulls" else None for r in rights]
+    # oracle: the two-table oracle chained (counts multiplied through first-occurrence order)
+    ek, ec, ef, _ = orc.join_group_count(kl, nl, rights[0], nrs[0])
+    for r, nr_ in zip(rights[1:], nrs[1:]):
+        k2, c2, f2, _ = orc.join_group_count(ek, None, r, nr_)
+        ec, ef, ek = ec[f2] * c2, ef[f2], k2
+    k, c, f, j = dev.join_group_count_multi(dev.to_dev(kl), dev.nullbits_dev(nl), [(dev.to_dev(r), dev.nullbits_dev(m)) for r, m in zip(rights, nrs)])
+    assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+    assert j == int(ec.sum())
+    if shape != "nulls":
+        assert dev.last_join_multi() == (shape in ("unique_3", "dups_3", "four_tables", "selective")), shape
