@@ -123,6 +123,17 @@ int mdb_dist_join_group_count(mdb_dist *d, const int64_t *keys_l, const uint64_t
 int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				    const uint64_t *null_r, uint64_t n_r, uint32_t flags, int64_t **out_key, int64_t **out_count,
 				    uint32_t **out_first, uint64_t *out_groups, uint64_t *out_joined);
+/* One left table and 2 ... 3 right tables, all joined on ONE key - SELECT l.key, COUNT(*) FROM L JOIN R0 ON l.key = r0.key JOIN R1 ON
+ * l.key = r1.key ... GROUP BY l.key (reference: recursive join executor_select.c:1151-1280 + GROUP BY :1526-1588; BASELINE
+ * configs[4]) - as ONE exchange: every table is partitioned once with the same window hash (mdb_dist_last_fused), every rank
+ * joins the regions of all tables it received and multiplies the right tables' counts per key.  keys_r / null_r / n_r: HOST
+ * arrays of n_right entries.  Returns MIDORIDB_OK (*out_key / *out_count allocated by the call: mdb_dev_free), 1 when this
+ * shape is not served - the global key ranges are not known (neither MDB_WIRE_AUTO nor mdb_dist_set_key_ranges) or too wide,
+ * skewed keys overflowed a region ... - on EVERY rank alike, and the caller chains mdb_dist_join_group_count_alloc calls
+ * (MDB_DIST_PLACE_BY_KEY_HASH, then MDB_DIST_LEFT_IN_PLACE), or a negative error code.  Collective and synchronous. */
+int mdb_dist_join_group_count_multi_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
+					  const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r, int64_t **out_key,
+					  int64_t **out_count, uint64_t *out_groups, uint64_t *out_joined);
 /* rows of L this rank received in the last call (what `cap` has to cover), 0 before the first */
 uint64_t mdb_dist_last_received_left(const mdb_dist *d);
 

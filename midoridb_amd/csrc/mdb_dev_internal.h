@@ -141,33 +141,36 @@ int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const 
  * regions it got from all ranks - straight from them when the hash bits below the digit index an LDS table (one level), or
  * after one more partition level of its own - and emits (key, COUNT) pairs; no row ids travel and no result ordering runs
  * (across ranks SQL leaves the order open anyway). */
+#define MDB_SHARD_MAX_TABS 4
 struct mdb_shard_plan {
 	uint32_t world, rank;
 	uint32_t D, Dp, nsub;		/* first-level digits, digits per destination, sub-regions per digit */
 	uint32_t kbits;			/* key window [key_lo, key_lo + 2^kbits) */
 	int64_t key_lo;
-	uint32_t cap[2];		/* words per first-level region: left, right table */
+	uint32_t ntab;			/* tables: [0] the left one, [1] the right one, [2..] further right tables joined on the same key */
+	uint32_t cap[MDB_SHARD_MAX_TABS];	/* words per first-level region of each table */
 	uint32_t wbytes;		/* bytes per word on the wire: 4, or 2 when the hash bits below the digit fit */
 	int b2;				/* receiver: bits of its own partition level (0: the regions are joined as they are) */
 	uint32_t rem;			/* key bits that index the leaf tables */
-	uint64_t block_words[2];	/* words per destination block = Dp * nsub * cap */
-	uint32_t leaf_cap[2];		/* b2 > 0: words per leaf region of the receiver's level */
+	uint64_t block_words[MDB_SHARD_MAX_TABS];	/* words per destination block = Dp * nsub * cap */
+	uint32_t leaf_cap[MDB_SHARD_MAX_TABS];		/* b2 > 0: words per leaf region of the receiver's level */
 	uint64_t l_rel_hi;		/* the left table keeps the rows with key - key_lo in [0, l_rel_hi] (= the right table's range) */
 };
 /* 0 = plan made; 1 = this shape is not served (window too wide, world not a power of two ...): the caller takes another path */
-int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_t n_r_max, int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi,
-			mdb_shard_plan *plan);
-size_t mdb_shard_arena_bytes(const mdb_shard_plan *plan, uint64_t n_l, uint64_t n_r);
-/* sender: side 0 = left (rows outside the right table's range are dropped), 1 = right; *regions = the region buffer
+int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint64_t *n_max /* [ntab]: the largest shard of each table */,
+			int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi, mdb_shard_plan *plan);
+size_t mdb_shard_arena_bytes(const mdb_shard_plan *plan);
+/* sender: table 0 = left (rows outside the right table's range are dropped), 1 = right (a key outside the window is reported),
+ * 2.. = further right tables (rows outside the window are dropped: they join nothing); *regions = the region buffer
  * (world * block_words[side] words of wbytes bytes, destination-major), *cursors = D * nsub region counters (sub-major).
  * The caller has begun the arena and cleared ctx->d_status[0..15].  No host sync. */
 int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
 			const void **regions, const uint32_t **cursors);
-/* receiver: recv_x = world blocks of block_words[x] words (source-major), cnt_x = world cursor arrays of D * nsub counters;
+/* receiver: recv[x] = world blocks of block_words[x] words (source-major), cnt[x] = world cursor arrays of D * nsub counters;
  * out_key / out_count (capacity cap): the groups; d_status[1] = their number, d_status[2..3] = joined rows (u64), flags in
  * d_status[0] (bit 1 a region overflowed, bit 3 cap too small, bit 7 a right key outside the window).  No host sync. */
-int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, const void *recv_l, const uint32_t *cnt_l, const void *recv_r,
-		   const uint32_t *cnt_r, int64_t *out_key, int64_t *out_count, uint64_t cap);
+int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, const void *const *recv, const uint32_t *const *cnt, int64_t *out_key,
+		   int64_t *out_count, uint64_t cap);
 
 /* ---- ordering of (row id, payload) records (mdb_dev_join.hip) ----------------------------------
  * rec[i] = (row id << (64 - kbits)) | payload (payload >= 1; zero words are gaps), kbits = bits of a row id as

@@ -37,12 +37,13 @@ static uint32_t sh_ceil_log2(uint64_t v)
 
 static uint32_t sh_round64(uint64_t v) { return (uint32_t)((v + 63) & ~63ull); }
 
-int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_t n_r_max, int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi,
+int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint64_t *n_max, int64_t l_lo, int64_t l_hi, int64_t r_lo, int64_t r_hi,
 			mdb_shard_plan *p)
 {
 	memset(p, 0, sizeof(*p));
-	if (world < 1 || world > 8 || (world & (world - 1)) || rank >= world)
+	if (world < 1 || world > 8 || (world & (world - 1)) || rank >= world || ntab < 2 || ntab > MDB_SHARD_MAX_TABS)
 		return 1;
+	const uint64_t n_l_max = n_max[0];
 	if (r_lo > r_hi || l_lo > l_hi)
 		return 1;		/* (a table without any key: the caller's ordinary path answers "no groups") */
 	const uint64_t rspan = (uint64_t)r_hi - (uint64_t)r_lo + 1;
@@ -51,9 +52,11 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_
 	uint32_t k = sh_ceil_log2(rspan);
 	if (k < SH_D_BITS + 4u)
 		k = SH_D_BITS + 4u;	/* (tiny windows: still 16 values per digit) */
-	if (n_l_max >= 0xF0000000ull || n_r_max >= 0xF0000000ull)
-		return 1;
+	for (uint32_t x = 0; x < ntab; x++)
+		if (n_max[x] >= 0xF0000000ull)
+			return 1;
 	p->world = world;
+	p->ntab = ntab;
 	p->rank = rank;
 	p->D = 1u << SH_D_BITS;
 	p->Dp = p->D / world;
@@ -62,11 +65,13 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_
 	p->key_lo = r_lo;
 	p->l_rel_hi = rspan - 1;
 	const uint32_t below = k - SH_D_BITS;
-	if (below <= SH_ONE_LEVEL_MAX_REM && p->Dp >= 128u) {
+	/* (4 bytes of LDS per table and key value of a leaf: three or four tables take leaves of half the values) */
+	const uint32_t one_level_rem = ntab > 2 ? SH_ONE_LEVEL_MAX_REM - 1u : SH_ONE_LEVEL_MAX_REM;
+	if (below <= one_level_rem && p->Dp >= 128u) {
 		p->b2 = 0;
 		p->rem = below;
 	} else {
-		uint32_t leaf_rem = SH_LEAF_REM;
+		uint32_t leaf_rem = ntab > 2 ? SH_LEAF_REM - 1u : SH_LEAF_REM;
 		{
 			const char *e = getenv("MDB_SHARD_REM");	/* (measurements) */
 			if (e && atoi(e) >= 8 && atoi(e) <= (int)SH_ONE_LEVEL_MAX_REM)
@@ -93,8 +98,9 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_
 	const uint64_t nl_est = (uint64_t)((long double)n_l_max * frac * 1.1L) + 1;
 	const uint64_t regions = (uint64_t)p->D * p->nsub;
 	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 5 / 4 / regions + 1024);
-	p->cap[1] = sh_round64(n_r_max * 5 / 4 / regions + 1024);
-	for (int x = 0; x < 2; x++) {
+	for (uint32_t x = 1; x < ntab; x++)
+		p->cap[x] = sh_round64(n_max[x] * 5 / 4 / regions + 1024);	/* (further right tables: sized for all their rows, though only those in the window travel) */
+	for (uint32_t x = 0; x < ntab; x++) {
 		p->block_words[x] = (uint64_t)p->Dp * p->nsub * p->cap[x];
 		if (p->block_words[x] * world >= 0xFFFFFFFFull)
 			return 1;
@@ -102,7 +108,7 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint64_t n_l_max, uint64_
 	if (p->b2) {
 		/* the receiver's leaves: 1.5 x the average + 1024 (its rows are known only as a bound: what the regions can hold) */
 		const uint64_t nleaves = (uint64_t)p->Dp << p->b2;
-		for (int x = 0; x < 2; x++) {
+		for (uint32_t x = 0; x < ntab; x++) {
 			const uint64_t bound = p->block_words[x] * world * 4 / 5;	/* (the regions are sized 1.25 x) */
 			p->leaf_cap[x] = sh_round64(bound * 3 / 2 / nleaves + 1024);
 			if (nleaves * p->leaf_cap[x] >= 0xFFFFFFFFull)
@@ -122,15 +128,13 @@ static size_t sh_recv_side_bytes(const mdb_shard_plan *p, int x)
 	return b;
 }
 
-size_t mdb_shard_arena_bytes(const mdb_shard_plan *p, uint64_t n_l, uint64_t n_r)
+size_t mdb_shard_arena_bytes(const mdb_shard_plan *p)
 {
-	/* sender: the two region buffers + their cursors (the first-level partition's own carving) */
-	size_t b = 0;
-	for (int x = 0; x < 2; x++)
-		b += mdb_align_up((size_t)p->D * p->nsub * p->cap[x] * 4) + 4 * mdb_align_up((size_t)p->D * p->nsub * 4 + 8) + 4096;
-	(void)n_l;
-	(void)n_r;
-	return b + sh_recv_side_bytes(p, 0) + sh_recv_side_bytes(p, 1) + 65536;
+	/* sender: the region buffers + their cursors (the first-level partition's own carving); receiver: per table */
+	size_t b = 65536;
+	for (uint32_t x = 0; x < p->ntab; x++)
+		b += mdb_align_up((size_t)p->D * p->nsub * p->cap[x] * 4) + 4 * mdb_align_up((size_t)p->D * p->nsub * 4 + 8) + 4096 + sh_recv_side_bytes(p, (int)x);
+	return b;
 }
 
 int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
@@ -143,9 +147,9 @@ int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, con
 	flt.level0_only = true;
 	flt.out16 = p->wbytes == 2;
 	flt.region_cap = p->cap[side];
-	if (side == 0) {
-		/* the left table keeps the rows inside the right table's (global) key range = the window: what lies outside joins
-		 * nothing on any rank */
+	if (side != 1) {
+		/* the left table (and any further right table) keeps the rows inside the right table's (global) key range = the
+		 * window: what lies outside joins nothing on any rank */
 		uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 512;
 		h[0] = 0u;
 		h[1] = (uint32_t)p->l_rel_hi;
@@ -234,10 +238,11 @@ __global__ void k_shard_tiles_build(const uint32_t *__restrict__ reg_start, cons
 }
 
 struct sh_leaf_args {
-	const void *words[2];		/* [0] left, [1] right: 4- or 2-byte words */
-	const uint32_t *seg_start[2];	/* nseg per leaf; NULL: ONE segment per leaf at leaf * cap (the receiver's own level) */
-	const uint32_t *seg_cnt[2];	/* ... its counters (clamped to cap when seg_start is NULL) */
-	uint32_t nseg, cap[2];
+	uint32_t ntab;			/* [0] left, [1 .. ntab) right tables */
+	const void *words[MDB_SHARD_MAX_TABS];		/* 4- or 2-byte words */
+	const uint32_t *seg_start[MDB_SHARD_MAX_TABS];	/* nseg per leaf; NULL: ONE segment per leaf at leaf * cap (the receiver's own level) */
+	const uint32_t *seg_cnt[MDB_SHARD_MAX_TABS];	/* ... its counters (clamped to cap when seg_start is NULL) */
+	uint32_t nseg, cap[MDB_SHARD_MAX_TABS];
 	uint32_t rem, shift;		/* table index = (word >> shift) & (2^rem - 1) */
 	uint32_t kbits, hash_base;	/* k-bit hash of slot s of leaf i = hash_base + (i << rem) + s */
 	long long key_lo;
@@ -246,9 +251,10 @@ struct sh_leaf_args {
 	uint32_t *status;		/* [0] flags, [1] groups so far, [2..3] joined rows (u64) */
 };
 
-/* One workgroup per leaf: the right rows count into cr[], the left rows into cl[] (only where a right row exists), every
- * slot with both is a group: key = key_lo + unmixk(hash), COUNT(*) = cl * cr.  Plain 32-bit LDS counters: no count can
- * overflow, nothing is probed or compared - the k-bit hash is a bijection of the window. */
+/* One workgroup per leaf: the right rows count into cr[] (several right tables on the same key: each into an array of its
+ * own, multiplied per slot afterwards), the left rows into cl[] (only where the right side has rows), every slot with both
+ * is a group: key = key_lo + unmixk(hash), COUNT(*) = cl * cr.  Plain 32-bit LDS counters; nothing is probed or compared -
+ * the k-bit hash is a bijection of the window. */
 template <int THREADS, typename WT>
 __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 {
@@ -256,16 +262,18 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 	__shared__ unsigned long long s_red[THREADS / 64];
 	__shared__ uint32_t s_base, s_total, s_off;
 	const uint32_t T = 1u << a.rem, mask = T - 1u, leaf = blockIdx.x;
-	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + T;
-	for (uint32_t s = threadIdx.x; s < 2 * T; s += THREADS)
+	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + T;	/* (right tables beyond the first: sh_lds + x * T, x = 2 ...) */
+	for (uint32_t s = threadIdx.x; s < a.ntab * T; s += THREADS)
 		sh_lds[s] = 0u;
 	if (threadIdx.x == 0)
 		s_total = 0;
 	uint32_t groups = 0;		/* slots whose first left row this thread saw */
 	__syncthreads();
 	constexpr uint32_t PER = 16u / sizeof(WT);	/* words per 16-byte load */
-#pragma unroll
-	for (int side = 1; side >= 0; side--) {
+	for (int pass = 0; pass < (int)a.ntab; pass++) {
+		/* the right tables first (1, 2, ...), the left table last */
+		const int side = pass + 1 < (int)a.ntab ? pass + 1 : 0;
+		uint32_t *const s_cx = sh_lds + (side >= 2 ? (uint32_t)side * T : 0u);
 		const WT *const base = reinterpret_cast<const WT *>(a.words[side]);
 		for (uint32_t j = 0; j < a.nseg; j++) {
 			uint32_t c, start;
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 							continue;
 						const uint32_t w = sizeof(WT) == 4 ? w4[e] : (w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu;
 						const uint32_t idx = (sizeof(WT) == 4 ? (w >> a.shift) : w) & mask;
-						if (side == 1)
-							atomicAdd(&s_cr[idx], 1u);
+						if (side >= 1)
+							atomicAdd(&s_cx[idx], 1u);
 						else if (s_cr[idx] && atomicAdd(&s_cl[idx], 1u) == 0u)
 							groups++;
 					}
@@ -306,6 +314,20 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 			}
 		}
 		__syncthreads();
+		if (a.ntab > 2 && pass + 2 == (int)a.ntab) {
+			/* every right table is counted: one right count per slot = the product (a product beyond 32 bits is reported) */
+			for (uint32_t sl = threadIdx.x; sl < T; sl += THREADS) {
+				unsigned long long c = s_cr[sl];
+				for (uint32_t x = 2; x < a.ntab; x++)
+					c *= sh_lds[x * T + sl];
+				if (c >> 32) {
+					mdb_raise(a.status, 2048u);
+					c = 0;
+				}
+				s_cr[sl] = (uint32_t)c;
+			}
+			__syncthreads();
+		}
 	}
 	/* emit.  The groups of the leaf were counted while the left rows came in (a slot's first left row); one global atomic
 	 * reserves their places.  Slots are walked THREADS at a time - consecutive threads, consecutive slots: conflict-free LDS
@@ -372,16 +394,15 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 	}
 }
 
-int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *recv_l, const uint32_t *cnt_l, const void *recv_r,
-		   const uint32_t *cnt_r, int64_t *out_key, int64_t *out_count, uint64_t cap)
+int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const *recv, const uint32_t *const *cnt, int64_t *out_key,
+		   int64_t *out_count, uint64_t cap)
 {
 	const uint32_t nreg = p->D * p->nsub, regs_per_digit = p->world * p->nsub, d0 = p->rank * p->Dp;
-	const void *recv[2] = { recv_l, recv_r };
-	const uint32_t *cnt[2] = { cnt_l, cnt_r };
-	uint32_t *reg_start[2], *reg_cnt[2];
+	uint32_t *reg_start[MDB_SHARD_MAX_TABS], *reg_cnt[MDB_SHARD_MAX_TABS];
 	sh_leaf_args a;
 	memset(&a, 0, sizeof(a));
-	for (int x = 0; x < 2; x++) {
+	a.ntab = p->ntab;
+	for (uint32_t x = 0; x < p->ntab; x++) {
 		reg_start[x] = (uint32_t *)mdb_arena_take(ctx, (size_t)nreg * 4);
 		reg_cnt[x] = (uint32_t *)mdb_arena_take(ctx, (size_t)nreg * 4);
 		if (!reg_start[x] || !reg_cnt[x])
@@ -398,11 +419,13 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *recv_l
 	a.out_count = reinterpret_cast<long long *>(out_count);
 	a.out_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 	a.status = ctx->d_status;
-	const size_t lds = (size_t)8 << p->rem;
+	const size_t lds = (size_t)(4 * p->ntab) << p->rem;
+	if (lds > 150 * 1024)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: leaf tables of %zu bytes", lds);
 	if (p->b2 == 0) {
 		/* one level: a digit is joined straight from the regions every rank sent for it */
 		a.nseg = regs_per_digit;
-		for (int x = 0; x < 2; x++) {
+		for (uint32_t x = 0; x < p->ntab; x++) {
 			a.words[x] = recv[x];
 			a.seg_start[x] = reg_start[x];
 			a.seg_cnt[x] = reg_cnt[x];
@@ -417,7 +440,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *recv_l
 	}
 	/* two levels: the receiver's own level over the regions of all ranks, then its leaves */
 	const uint32_t nleaves = p->Dp << p->b2;
-	for (int x = 0; x < 2; x++) {
+	for (uint32_t x = 0; x < p->ntab; x++) {
 		const uint32_t max_tiles = (uint32_t)(p->block_words[x] * p->world / MDB_TILE) + nreg + 1;
 		uint32_t *tb = (uint32_t *)mdb_arena_take(ctx, ((size_t)nreg + 1) * 4);
 		mdb_tile_desc *tiles = (mdb_tile_desc *)mdb_arena_take(ctx, (size_t)max_tiles * sizeof(mdb_tile_desc));

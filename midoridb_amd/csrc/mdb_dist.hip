@@ -562,9 +562,9 @@ __global__ void k_status_words(const uint32_t *status, uint64_t *out)
 {
 	if (threadIdx.x == 0) {
 		const uint32_t f = status[0];
-		out[0] = (f & 2u) ? 1u : 0u;
+		out[0] = (f & (2u | 2048u)) ? 1u : 0u;
 		out[1] = (f & 128u) ? 1u : 0u;
-		out[2] = (f & ~(2u | 128u)) ? 1u : 0u;
+		out[2] = (f & ~(2u | 128u | 2048u)) ? 1u : 0u;
 	}
 }
 
@@ -587,34 +587,38 @@ static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_
  * key-by-destination path needs four plus two read-backs.  Needs the two tables' global key ranges (promised, or measured
  * by MDB_WIRE_AUTO) and a right-table range of at most 2^30 values; MDB_DIST_FUSED=0 switches it off.
  * Returns 0 = done, 1 = not served / fell back (agreed by all ranks), < 0 = error. */
-static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r, const uint64_t *null_r,
-			   uint64_t n_r, const int64_t glo[2], const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p,
-			   int64_t **out_count_p, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
+static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, const uint64_t *const *nulls, const uint64_t *ns, const int64_t glo[2],
+			   const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p, int64_t **out_count_p, uint64_t cap,
+			   uint64_t *out_groups, uint64_t *out_joined)
 {
+	/* tables: [0] the left one, [1] the right one, [2 ...] further right tables joined on the same key */
 	mdb_dev_ctx *ctx = d->ctx;
 	const int W = d->world;
 	if (getenv("MDB_DIST_FUSED") && getenv("MDB_DIST_FUSED")[0] == '0')
 		return 1;
+	if (ntab < 2 || ntab > MDB_SHARD_MAX_TABS)
+		return 1;
 	/* ---- every rank's row counts (region capacities are sized by the largest), and whether its output buffers can take the
 	 *      groups: a decision every rank takes from the same numbers */
-	uint64_t sendv[3 << MDB_MAX_RADIX_BITS], recvv[3 << MDB_MAX_RADIX_BITS];
+	const int NC = MDB_SHARD_MAX_TABS + 1;
+	uint64_t sendv[(MDB_SHARD_MAX_TABS + 1) << MDB_MAX_RADIX_BITS], recvv[(MDB_SHARD_MAX_TABS + 1) << MDB_MAX_RADIX_BITS];
 	for (int p = 0; p < W; p++) {
-		sendv[3 * p] = n_l;
-		sendv[3 * p + 1] = n_r;
-		sendv[3 * p + 2] = alloc_out ? (1ull << 62) : cap;	/* (a transport's counters need not survive values beyond 2^63) */
+		for (int x = 0; x < MDB_SHARD_MAX_TABS; x++)
+			sendv[NC * p + x] = x < ntab ? ns[x] : 0;
+		sendv[NC * p + MDB_SHARD_MAX_TABS] = alloc_out ? (1ull << 62) : cap;	/* (a transport's counters need not survive values beyond 2^63) */
 	}
-	int rc = d->t.counts(d->t.self, sendv, recvv, 3);
+	int rc = d->t.counts(d->t.self, sendv, recvv, NC);
 	if (rc)
 		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
-	uint64_t nl_max = 0, nr_max = 0, cap_min = ~0ull, nl_sum = 0;
+	uint64_t n_max[MDB_SHARD_MAX_TABS] = { 0, 0, 0, 0 }, cap_min = ~0ull, nl_sum = 0;
 	for (int p = 0; p < W; p++) {
-		nl_sum += recvv[3 * p];
-		nl_max = recvv[3 * p] > nl_max ? recvv[3 * p] : nl_max;
-		nr_max = recvv[3 * p + 1] > nr_max ? recvv[3 * p + 1] : nr_max;
-		cap_min = recvv[3 * p + 2] < cap_min ? recvv[3 * p + 2] : cap_min;
+		nl_sum += recvv[NC * p];
+		for (int x = 0; x < ntab; x++)
+			n_max[x] = recvv[NC * p + x] > n_max[x] ? recvv[NC * p + x] : n_max[x];
+		cap_min = recvv[NC * p + MDB_SHARD_MAX_TABS] < cap_min ? recvv[NC * p + MDB_SHARD_MAX_TABS] : cap_min;
 	}
 	mdb_shard_plan plan;
-	if (mdb_shard_plan_make((uint32_t)W, (uint32_t)d->rank, nl_max, nr_max, glo[0], ghi[0], glo[1], ghi[1], &plan))
+	if (mdb_shard_plan_make((uint32_t)W, (uint32_t)d->rank, (uint32_t)ntab, n_max, glo[0], ghi[0], glo[1], ghi[1], &plan))
 		return 1;
 	/* the groups of a rank: at most the left rows it can receive, at most the key values that hash to it */
 	const uint64_t recv_bound_l = plan.block_words[0] * (uint64_t)W;
@@ -634,18 +638,17 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 		}
 		cap = group_bound ? group_bound : 1;
 	}
-
 	const size_t wb = plan.wbytes, ncur = (size_t)plan.D * plan.nsub;
-	size_t need = mdb_shard_arena_bytes(&plan, n_l, n_r);
-	for (int x = 0; x < 2; x++)
+	size_t need = mdb_shard_arena_bytes(&plan);
+	for (int x = 0; x < ntab; x++)
 		need += mdb_align_up(plan.block_words[x] * (size_t)W * wb) + mdb_align_up(ncur * (size_t)W * 4) + 512;
 	rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "%s", mdb_dev_last_error(ctx)));
 	DIST_HIP(d, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	void *recv[2];
-	uint32_t *rcnt[2];
-	for (int x = 0; x < 2; x++) {
+	void *recv[MDB_SHARD_MAX_TABS];
+	uint32_t *rcnt[MDB_SHARD_MAX_TABS];
+	for (int x = 0; x < ntab; x++) {
 		recv[x] = mdb_arena_take(ctx, plan.block_words[x] * (size_t)W * wb);
 		rcnt[x] = (uint32_t *)mdb_arena_take(ctx, ncur * (size_t)W * 4);
 		if (!recv[x] || !rcnt[x])
@@ -654,12 +657,8 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 	/* ---- each table: ONE partition pass, then its blocks and its region counters travel (fixed sizes: nothing to wait for) */
 	size_t bc[1 << MDB_MAX_RADIX_BITS], bd[1 << MDB_MAX_RADIX_BITS], cc[1 << MDB_MAX_RADIX_BITS], cd0[1 << MDB_MAX_RADIX_BITS],
 		cdr[1 << MDB_MAX_RADIX_BITS];
-	const int64_t *keys[2] = { keys_l, keys_r };
-	const uint64_t *nulls[2] = { null_l, null_r };
-	const uint64_t ns[2] = { n_l, n_r };
-	hipEvent_t evs[2] = { d->ev_a, d->ev_b };
 	int prc = MIDORIDB_OK;
-	for (int x = 0; x < 2; x++) {
+	for (int x = 0; x < ntab; x++) {
 		const void *regions = NULL;
 		const uint32_t *cursors = NULL;
 		if (!prc)
@@ -680,16 +679,15 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 			rc = d->t.alltoallv(d->t.self, cursors, cc, cd0, rcnt[x], cc, cdr, 4, d->comm_stream);
 		if (rc)
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
-		DIST_HIP(d, hipEventRecord(evs[x], d->comm_stream));
 	}
 	/* (a rank whose partition call failed outright - not a flag on the device, a launch or sizing error - cannot post its
-	 * transfers: it reports through the status exchange below, which every rank reaches; its peers' receives for this call
-	 * would then hang, so such a failure is fatal for the communicator and reported as such) */
+	 * transfers; its peers' receives for this call would then hang, so such a failure is fatal for the communicator and
+	 * reported as such) */
 	if (prc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded first level: %s", mdb_dev_last_error(ctx)));
-	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_a, 0));
+	DIST_HIP(d, hipEventRecord(d->ev_b, d->comm_stream));
 	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_b, 0));
-	rc = mdb_shard_join(ctx, &plan, recv[0], rcnt[0], recv[1], rcnt[1], out_key, out_count, cap);
+	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, out_count, cap);
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "sharded join: %s", mdb_dev_last_error(ctx)));
 	/* ---- G, J and the flags come back with ONE host synchronisation; what went wrong anywhere sends every rank the same way:
@@ -714,9 +712,9 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 	if (reduced_on_device) {
 		memcpy(st, h + 32, sizeof(st));
 	} else {
-		st[0] = (flags & 2u) ? 1u : 0u;
+		st[0] = (flags & (2u | 2048u)) ? 1u : 0u;
 		st[1] = (flags & 128u) ? 1u : 0u;
-		st[2] = (flags & ~(2u | 128u)) ? 1u : 0u;
+		st[2] = (flags & ~(2u | 128u | 2048u)) ? 1u : 0u;
 		rc = d->t.allreduce_sum_u64(d->t.self, st, 3);
 	}
 	if (rc)
@@ -730,7 +728,7 @@ static int dist_join_fused(mdb_dist *d, const int64_t *keys_l, const uint64_t *n
 		return fused_fail(ctx, alloc_out, out_key, out_count, 1);
 	}
 	if (st[0])
-		return fused_fail(ctx, alloc_out, out_key, out_count, 1);	/* skewed keys outgrew a fixed-capacity region somewhere: the exact path */
+		return fused_fail(ctx, alloc_out, out_key, out_count, 1);	/* skewed keys outgrew a fixed-capacity region somewhere (or a product of counts 32 bits): the exact path */
 	d->last_recv_left = G;	/* (rows are not counted on this path: the groups are a lower bound) */
 	if (alloc_out) {
 		*out_key_p = out_key;
@@ -758,24 +756,13 @@ static int dist_join_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t **out_key, i
 	return rc;
 }
 
-/* common part: exchange (the left table only unless it is already in place), local join into buffers that are either the
- * caller's (capacity cap) or allocated here once the number of received left rows is known */
-static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			  const uint64_t *null_r, uint64_t n_r, bool left_in_place, bool alloc_out, int64_t **out_key, int64_t **out_count,
-			  uint32_t **out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined, bool by_key_hash = false)
+/* MDB_WIRE_AUTO: the GLOBAL [smallest, largest] key of the left and of the right table - one statistics pass per table on
+ * every rank, one tiny exchange - and whether all of them fit 32 bits (the 4-byte wire format) */
+static int dist_measure_ranges(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			       const uint64_t *null_r, uint64_t n_r, int64_t glo[2], int64_t ghi[2], bool *fits32)
 {
 	mdb_dev_ctx *ctx = d->ctx;
-	*out_groups = 0;
-	if (out_joined)
-		*out_joined = 0;
-	DIST_HIP(d, hipSetDevice(ctx->device));
-	/* ---- wire format: every rank must take the same decision */
-	bool wire32 = d->wire_mode == MDB_WIRE_32 && !left_in_place;
-	/* the two tables' GLOBAL key ranges (MDB_WIRE_AUTO: the column statistics are computed anyway): what lies outside the
-	 * other table's range joins nothing on any GPU and stays home - min-max pruning before the shuffle; a fact table whose
-	 * dimension covers a sixteenth of its key range sends a sixteenth of its rows */
-	int64_t glo[2] = { INT64_MIN, INT64_MIN }, ghi[2] = { INT64_MAX, INT64_MAX };
-	if (d->wire_mode == MDB_WIRE_AUTO && !left_in_place) {
+	{
 		const int W = d->world;
 		const int64_t *cols[2] = { keys_l, keys_r };
 		const uint64_t *nb[2] = { null_l, null_r };
@@ -827,7 +814,32 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 		for (int i = 0; i < 2; i++)
 			if (glo[i] <= ghi[i] && (glo[i] < -(1ll << 31) || ghi[i] >= (1ll << 31)))
 				wide = true;
-		wire32 = !wide;
+		*fits32 = !wide;
+	}
+	return MIDORIDB_OK;
+}
+
+/* common part: exchange (the left table only unless it is already in place), local join into buffers that are either the
+ * caller's (capacity cap) or allocated here once the number of received left rows is known */
+static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			  const uint64_t *null_r, uint64_t n_r, bool left_in_place, bool alloc_out, int64_t **out_key, int64_t **out_count,
+			  uint32_t **out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined, bool by_key_hash = false)
+{
+	mdb_dev_ctx *ctx = d->ctx;
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	DIST_HIP(d, hipSetDevice(ctx->device));
+	/* ---- wire format: every rank must take the same decision */
+	bool wire32 = d->wire_mode == MDB_WIRE_32 && !left_in_place;
+	/* the two tables' GLOBAL key ranges (MDB_WIRE_AUTO: the column statistics are computed anyway): what lies outside the
+	 * other table's range joins nothing on any GPU and stays home - min-max pruning before the shuffle; a fact table whose
+	 * dimension covers a sixteenth of its key range sends a sixteenth of its rows */
+	int64_t glo[2] = { INT64_MIN, INT64_MIN }, ghi[2] = { INT64_MAX, INT64_MAX };
+	if (d->wire_mode == MDB_WIRE_AUTO && !left_in_place) {
+		const int mrc = dist_measure_ranges(d, keys_l, null_l, n_l, keys_r, null_r, n_r, glo, ghi, &wire32);
+		if (mrc)
+			return mrc;
 	}
 	d->last_wire32 = wire32 ? 1 : 0;
 	/* (a table without any key makes the other one's range empty: lo > hi drops every row, the join is empty) */
@@ -844,8 +856,10 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 	d->last_fused = 0;
 	if (prune && !left_in_place && !out_first && !by_key_hash) {
 		/* both global key ranges are known: the first partition level IS the exchange (mdb_dev_shard.hip) */
-		const int frc = dist_join_fused(d, keys_l, null_l, n_l, keys_r, null_r, n_r, glo, ghi, verify, alloc_out, out_key, out_count, cap, out_groups,
-						out_joined);
+		const int64_t *fk[2] = { keys_l, keys_r };
+		const uint64_t *fn[2] = { null_l, null_r };
+		const uint64_t fs[2] = { n_l, n_r };
+		const int frc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, verify, alloc_out, out_key, out_count, cap, out_groups, out_joined);
 		if (frc <= 0)
 			return frc;
 	}
@@ -1430,4 +1444,51 @@ extern "C" int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uin
 	}
 	*out_rows = J;
 	return mdb_dev_sync(ctx) ? dist_err(d, -MIDORIDB_INTERNAL, "%s", mdb_dev_last_error(ctx)) : MIDORIDB_OK;
+}
+
+/* One left table and 2 ... 3 right tables, all joined on ONE key (A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a, COUNT(*):
+ * BASELINE configs[4]) over sharded tables, as ONE exchange: every table partitioned once with the same window hash, every
+ * rank joins the regions of ALL tables it received and multiplies the right tables' counts per key (mdb_dev_shard.hip).
+ * Returns 0 = done (outputs allocated by the call, as mdb_dist_join_group_count_alloc), 1 = not served (the key ranges are not
+ * known or do not fit, skewed keys ...: every rank gets the same answer and the caller chains two-table calls), < 0 = error. */
+extern "C" int mdb_dist_join_group_count_multi_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
+							     const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r,
+							     int64_t **out_key, int64_t **out_count, uint64_t *out_groups, uint64_t *out_joined)
+{
+	if (!d || !out_key || !out_count || !out_groups || n_right < 1 || n_right + 1 > MDB_SHARD_MAX_TABS || !keys_r || !n_r)
+		return d ? dist_err(d, -MIDORIDB_ERROR, "join_group_count_multi: bad arguments") : -MIDORIDB_ERROR;
+	*out_groups = 0;
+	if (out_joined)
+		*out_joined = 0;
+	*out_key = NULL;
+	*out_count = NULL;
+	DIST_HIP(d, hipSetDevice(d->ctx->device));
+	int64_t glo[2] = { INT64_MIN, INT64_MIN }, ghi[2] = { INT64_MAX, INT64_MAX };
+	bool promised = false, fits32 = false;
+	if (d->wire_mode == MDB_WIRE_AUTO) {
+		const int mrc = dist_measure_ranges(d, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], glo, ghi, &fits32);
+		if (mrc)
+			return mrc;
+	} else if (d->have_ranges) {
+		for (int i = 0; i < 2; i++) {
+			glo[i] = d->promised_lo[i];
+			ghi[i] = d->promised_hi[i];
+		}
+		promised = true;
+	} else {
+		return 1;
+	}
+	const int64_t *keys[MDB_SHARD_MAX_TABS];
+	const uint64_t *nulls[MDB_SHARD_MAX_TABS];
+	uint64_t ns[MDB_SHARD_MAX_TABS];
+	keys[0] = keys_l;
+	nulls[0] = null_l;
+	ns[0] = n_l;
+	for (int t = 0; t < n_right; t++) {
+		keys[t + 1] = keys_r[t];
+		nulls[t + 1] = null_r ? null_r[t] : NULL;
+		ns[t + 1] = n_r[t];
+	}
+	d->last_fused = 0;
+	return dist_join_fused(d, n_right + 1, keys, nulls, ns, glo, ghi, promised, true, out_key, out_count, 0, out_groups, out_joined);
 }

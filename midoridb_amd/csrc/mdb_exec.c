@@ -1663,7 +1663,38 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			rc = -MIDORIDB_ERROR;
 			goto out;
 		}
-		if (cat->dist) {
+		if (cat->dist && s->ntabs > 2 && s->ntabs <= 4) {
+			/* sharded mode, three or four tables on one key: ONE exchange - every table partitioned once with the same hash, the
+			 * right tables' counts multiplied where the regions meet (mdb_dist_join_group_count_multi_alloc); when that form is
+			 * not served (every rank learns so together) the chain of two-table calls below runs */
+			const int64_t *rk[3];
+			const uint64_t *rnb[3];
+			uint64_t rrows[3];
+			rk[0] = rv;
+			rnb[0] = rn;
+			rrows[0] = nr_rows;
+			for (int t = 2; t < s->ntabs; t++) {
+				const void *cv;
+				if ((rc = fused_operand(&x, t, fkeys[t], ws.push[t], ws.npush[t], &cv, &rnb[t - 1], &rrows[t - 1])))
+					goto out;
+				rk[t - 1] = cv;
+			}
+			const int mrc = mdb_dist_join_group_count_multi_alloc(cat->dist, lv, ln, nl_rows, s->ntabs - 1, rk, rnb, rrows, &x.d_fused_key, &x.d_count,
+									      &G, &J);
+			if (mrc < 0) {
+				snprintf(err, errlen, "execution phase: sharded join + group count: %s\n", mdb_dist_last_error(cat->dist));
+				rc = -MIDORIDB_INTERNAL;
+				goto out;
+			}
+			if (mrc == 0) {
+				if (track(&x, x.d_fused_key) || track(&x, x.d_count)) {
+					rc = -MIDORIDB_NOMEM;
+					goto out;
+				}
+				multi_done = true;
+			}
+		}
+		if (cat->dist && !multi_done) {
 			/* sharded mode: the tables hold this rank's rows; both key columns are exchanged (RCCL all-to-all per table,
 			 * include/mdb_dist.h) and this rank keeps the groups whose key hashes to it.  Collective: every rank runs the
 			 * same statement. */
@@ -1678,7 +1709,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				rc = -MIDORIDB_NOMEM;
 				goto out;
 			}
-		} else {
+		} else if (!cat->dist) {
 			x.d_fused_key = dalloc(&x, cap * 8);
 			x.d_count = dalloc(&x, cap * 8);
 			if (!x.d_fused_key || !x.d_count) {

@@ -40,7 +40,7 @@ DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
-    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
 ]
 
 
@@ -61,6 +61,8 @@ def _bind(lib):
         "mdb_dist_last_wire32": ([P], c_int),
         "mdb_dist_last_pruned": ([P], c_int),
         "mdb_dist_last_fused": ([P], c_int),
+        "mdb_dist_join_group_count_multi_alloc": ([P, P, P, c_uint64, c_int, POINTER(P), POINTER(P), POINTER(c_uint64), POINTER(P), POINTER(P),
+                                                   POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dist_set_key_ranges": ([P, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64)], c_int),
         "mdb_dist_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dist_join_group_count_alloc": ([P, P, P, c_uint64, P, P, c_uint64, ctypes.c_uint32, POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64),
@@ -285,6 +287,21 @@ class DistCtx:
         db.set_dist(self.h)
         db._dist_keepalive = self
         self.h = None
+
+    def join_group_count_multi(self, keys_l, null_l, rights):
+        """rights = [(keys, nullbits or None), ...] (2 or 3 tables, all joined to keys_l on one key) -> (keys[G], counts[G], joined rows on this
+        rank), or None when the shape is not served and the caller has to chain two-table calls"""
+        nr = len(rights)
+        kr = (c_void_p * nr)(*[r[0].data_ptr() for r in rights])
+        nb = (c_void_p * nr)(*[(r[1].data_ptr() if r[1] is not None else None) for r in rights])
+        ns = (c_uint64 * nr)(*[r[0].numel() for r in rights])
+        ok, oc, g, j = c_void_p(), c_void_p(), c_uint64(), c_uint64()
+        rc = self.lib.mdb_dist_join_group_count_multi_alloc(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), nr, kr, nb, ns, byref(ok), byref(oc),
+                                                            byref(g), byref(j))
+        if rc == 1:
+            return None
+        self._chk(rc, "dist join_group_count_multi")
+        return self._adopt(ok.value, g.value, torch.int64), self._adopt(oc.value, g.value, torch.int64), j.value
 
     def allreduce_sum(self, vals):
         arr = (c_uint64 * len(vals))(*[int(v) for v in vals])

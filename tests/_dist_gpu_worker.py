@@ -274,6 +274,29 @@ def fused_shapes(dx, dev, world, rank):
         got = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
         assert len(got) == k.numel() and got == dict(zip(ek[mine].tolist(), ec[mine].tolist())), (n, span, len(got), int(mine.sum()))
         assert dx.allreduce_sum([j])[0] == ej
+    # three and four tables on one key in ONE exchange (BASELINE configs[4] shape): counts multiplied where the regions meet
+    for n, span, nright in ((300_000, 50_000, 2), (600_000, 40_000_000, 2), (250_000, 20_000, 3)):
+        total = n * world
+        base = -7_000
+        ga = base + rng.integers(0, span, total, dtype=np.int64)
+        rights = [base + rng.integers(0, span, total // (t + 1) + 11, dtype=np.int64) for t in range(nright)]
+        rights[-1][:100] = base - 5 - np.arange(100)		# keys of a further table outside the window: they join nothing, silently
+        la = slice(rank * n, (rank + 1) * n)
+        cuts = [slice(len(r) * rank // world, len(r) * (rank + 1) // world) for r in rights]
+        dx.set_key_ranges((base, base + span - 1), (base, base + span - 1))
+        got = dx.join_group_count_multi(dev.to_dev(ga[la]), None, [(dev.to_dev(r[c]), None) for r, c in zip(rights, cuts)])
+        assert got is not None and dx.last_fused(), (n, span, nright)
+        k, c, j = got
+        ek, ec, ef, _ = orc.join_group_count(ga, None, rights[0], None)
+        for r in rights[1:]:
+            k2, c2, f2, _ = orc.join_group_count(ek, None, r, None)
+            ek, ec = k2, ec[f2] * c2
+        mine = owned(dx, ek, world, rank, rights[0], promised=(base, base + span - 1))
+        res = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
+        assert len(res) == k.numel() and res == dict(zip(ek[mine].tolist(), ec[mine].tolist())), (n, span, nright)
+        assert dx.allreduce_sum([j])[0] == int(ec.sum())
+    dx.set_key_ranges(None, None)
+    assert dx.join_group_count_multi(dev.to_dev(ga[la]), None, [(dev.to_dev(r[c]), None) for r, c in zip(rights, cuts)]) is None	# ranges unknown: not served
     # 90 % of the left rows share one key: its region overflows on the sender -> all ranks fall back, same groups
     n = 400_000
     ga = 1000 + rng.integers(0, 50_000, n * world, dtype=np.int64)

@@ -618,7 +618,25 @@ def test_full_size_three_way_join_properties(dev):
     assert p.numel() == N and bool((cc[q.long()] == a).all())
     first, cnt = dev.group_count(a, None)
     assert first.numel() == N and bool((cnt == 1).all())
-    del p, q, r, first, cnt
+    del first, cnt
+    # DOUBLE / INT payload carried through both joins (x of A, y of B, z of C: SURVEY 8d C5), bit-exact: the projection of the
+    # three-way join gathers y through r and z through q; every gathered cell must be the cell of the row with the equal key
+    y = dev.gen_payload(N, 0, 143, 1)
+    z = dev.gen_payload(N, 0, 144, 0)
+    (yo, _), (zo, _) = dev.gather_cols([(y, None, r), (z, None, q)], N)
+    # inverse check without a host copy: scatter the gathered cells back by the partner row - the source column must re-appear
+    back = torch.empty_like(y)
+    back[r.long()] = yo
+    assert bool((back.view(torch.int64) == y.view(torch.int64)).all())
+    backz = torch.empty_like(z)
+    backz[q.long()] = zo
+    assert bool((backz == z).all())
+    del p, q, r, y, z, yo, zo, back, backz
+    # ... and the same query as ONE operator: every key once, COUNT(*) = 1, first rows = A's rows, 10^8 joined rows
+    k3, c3, f3, j3 = dev.join_group_count_multi(a, None, [(b, None), (cc, None)])
+    assert j3 == N and k3.numel() == N and bool((c3 == 1).all()) and bool((k3 == a).all())
+    assert bool((f3.long() == torch.arange(N, device=f3.device)).all())
+    assert dev.last_join_multi()
     torch.cuda.empty_cache()
 
 
