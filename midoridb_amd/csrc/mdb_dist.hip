@@ -1315,6 +1315,93 @@ extern "C" int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uin
 	return MIDORIDB_OK;
 }
 
+/* ---- a join whose only output is the key column (BASELINE configs[3]: SELECT * over two key columns): no row has to be
+ * identified, so the regions-on-the-wire operator answers it - (key, COUNT) per key that occurs on both sides, every key then
+ * written COUNT times (unique keys: the groups ARE the joined rows) */
+__global__ __launch_bounds__(SH_THREADS) void k_counts_u32(const int64_t *__restrict__ cnt, uint64_t n, uint32_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * SH_THREADS)
+		out[i] = i < n ? (uint32_t)cnt[i] : 0u;		/* (one more word: the scan's grand total lands there) */
+}
+
+__global__ __launch_bounds__(SH_THREADS) void k_expand_keys(const int64_t *__restrict__ key, const uint32_t *__restrict__ pos, uint64_t n,
+							     int64_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SH_THREADS) {
+		const int64_t k = key[i];
+		for (uint32_t p = pos[i], e = pos[i + 1]; p < e; p++)
+			out[p] = k;
+	}
+}
+
+/* 0 = done, 1 = not served (every rank alike), < 0 = error */
+static int dist_join_keys_only(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r, const uint64_t *null_r,
+			       uint64_t n_r, int64_t **out_key, uint64_t *out_rows)
+{
+	mdb_dev_ctx *ctx = d->ctx;
+	int64_t glo[2] = { INT64_MIN, INT64_MIN }, ghi[2] = { INT64_MAX, INT64_MAX };
+	bool promised = false, fits32 = false;
+	if (d->wire_mode == MDB_WIRE_AUTO) {
+		const int mrc = dist_measure_ranges(d, keys_l, null_l, n_l, keys_r, null_r, n_r, glo, ghi, &fits32);
+		if (mrc)
+			return mrc;
+	} else if (d->have_ranges) {
+		for (int i = 0; i < 2; i++) {
+			glo[i] = d->promised_lo[i];
+			ghi[i] = d->promised_hi[i];
+		}
+		promised = true;
+	} else {
+		return 1;
+	}
+	const int64_t *fk[2] = { keys_l, keys_r };
+	const uint64_t *fn[2] = { null_l, null_r };
+	const uint64_t fs[2] = { n_l, n_r };
+	int64_t *gk = NULL, *gc = NULL;
+	uint64_t G = 0, J = 0;
+	d->last_fused = 0;
+	int rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J);
+	if (rc)
+		return rc;
+	if (J == G) {		/* every COUNT is 1: the group keys are the joined rows */
+		(void)mdb_dev_free(ctx, gc);
+		*out_key = gk;
+		*out_rows = G;
+		return 0;
+	}
+	if (J >= 0xFFFFFFFFull) {
+		(void)mdb_dev_free(ctx, gk);
+		(void)mdb_dev_free(ctx, gc);
+		return dist_err(d, -MIDORIDB_ERROR, "%llu joined rows exceed the 32-bit row limit of one GPU shard", (unsigned long long)J);
+	}
+	uint32_t *pos = NULL, *tmp = NULL;
+	int64_t *rows = NULL;
+	rc = mdb_dev_alloc(ctx, (G + 1) * 4, (void **)&pos);
+	if (!rc)
+		rc = mdb_dev_alloc(ctx, mdb_scan_scratch_words(G + 1) * 4, (void **)&tmp);
+	if (!rc)
+		rc = mdb_dev_alloc(ctx, (J ? J : 1) * 8, (void **)&rows);
+	if (!rc) {
+		hipLaunchKernelGGL(k_counts_u32, dim3(sh_grid(G + 1)), dim3(SH_THREADS), 0, ctx->stream, gc, G, pos);
+		rc = mdb_scan_u32_inplace(ctx, pos, G + 1, tmp);
+	}
+	if (!rc)
+		hipLaunchKernelGGL(k_expand_keys, dim3(sh_grid(G)), dim3(SH_THREADS), 0, ctx->stream, gk, pos, G, rows);
+	if (!rc)
+		rc = mdb_dev_sync(ctx);
+	(void)mdb_dev_free(ctx, pos);
+	(void)mdb_dev_free(ctx, tmp);
+	(void)mdb_dev_free(ctx, gk);
+	(void)mdb_dev_free(ctx, gc);
+	if (rc) {
+		(void)mdb_dev_free(ctx, rows);
+		return dist_err(d, rc, "expanding the joined keys: %s", mdb_dev_last_error(ctx));
+	}
+	*out_key = rows;
+	*out_rows = J;
+	return 0;
+}
+
 extern "C" int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dist_col *cols_l,
 				   int ncols_l, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, const struct mdb_dist_col *cols_r,
 				   int ncols_r, int64_t **out_key, void **out_l, uint64_t **out_l_nulls, void **out_r, uint64_t **out_r_nulls,
@@ -1327,6 +1414,13 @@ extern "C" int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uin
 	*out_rows = 0;
 	if (out_key)
 		*out_key = NULL;
+	if (out_key && !ncols_l && !ncols_r) {
+		/* only the key column is wanted: nothing has to say WHICH rows met - the regions-on-the-wire operator counts the
+		 * keys' partners and every key is written COUNT times (rows then come out in leaf order, not in received-row order) */
+		const int krc = dist_join_keys_only(d, keys_l, null_l, n_l, keys_r, null_r, n_r, out_key, out_rows);
+		if (krc <= 0)
+			return krc;
+	}
 	/* column 0 of each shuffle = the key itself */
 	struct mdb_dist_col cl[MDB_DIST_SHUFFLE_MAX_COLS], cr[MDB_DIST_SHUFFLE_MAX_COLS];
 	void *vl[MDB_DIST_SHUFFLE_MAX_COLS], *vr[MDB_DIST_SHUFFLE_MAX_COLS];

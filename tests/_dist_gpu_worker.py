@@ -274,6 +274,18 @@ def fused_shapes(dx, dev, world, rank):
         got = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
         assert len(got) == k.numel() and got == dict(zip(ek[mine].tolist(), ec[mine].tolist())), (n, span, len(got), int(mine.sum()))
         assert dx.allreduce_sum([j])[0] == ej
+    # the join of two key columns alone (BASELINE configs[3]): regions on the wire, every key written COUNT times
+    for n, span in ((200_000, 30_000), (700_000, 700_000)):
+        total = n * world
+        ga = 100 + (rng.permutation(total).astype(np.int64) if span == n else rng.integers(0, span, total, dtype=np.int64))
+        gb = 100 + (rng.permutation(total).astype(np.int64)[: total - 5] if span == n else rng.integers(0, span, total, dtype=np.int64))
+        la, lb = slice(rank * n, (rank + 1) * n), slice(len(gb) * rank // world, len(gb) * (rank + 1) // world)
+        dx.set_key_ranges((100, 100 + total), (100, 100 + total))
+        key, _, _, J = dx.join_pairs(dev.to_dev(ga[la]), None, [], dev.to_dev(gb[lb]), None, [])
+        assert dx.last_fused()
+        pl, pr = orc.join_pairs(ga, None, gb, None)
+        mine = owned(dx, ga[pl], world, rank, gb, promised=(100, 100 + total))
+        assert J == int(mine.sum()) and np.array_equal(np.sort(key.cpu().numpy()), np.sort(ga[pl][mine]))
     # three and four tables on one key in ONE exchange (BASELINE configs[4] shape): counts multiplied where the regions meet
     for n, span, nright in ((300_000, 50_000, 2), (600_000, 40_000_000, 2), (250_000, 20_000, 3)):
         total = n * world
