@@ -1,9 +1,13 @@
 /*
- * mdb_dev_join.hip - per-leaf LDS hash build/probe kernels and the operators built on them:
+ * mdb_dev_join.hip - the fused INNER JOIN + GROUP BY join key + COUNT(*) operator (north-star query): per-leaf LDS kernels
+ * (hashed tables, direct-address tables of the compact narrow form, one-level wide tables, hot keys), its planning (key
+ * sample, key forms, pruning), retries, the split form for the multi-GPU exchange and the N-way form, and the drivers of
  *
- *   mdb_dev_join_group_count  INNER JOIN + GROUP BY join key + COUNT(*), fused (north-star query)
- *   mdb_dev_group_count       GROUP BY key + COUNT(*) over one key column
- *   mdb_dev_join_pairs        materialising INNER JOIN, pairs in the reference's emission order
+ *   mdb_dev_join_group_count[_multi | _begin / _finish | _i32]
+ *   mdb_dev_group_count       GROUP BY key + COUNT(*) over one key column (fast paths: mdb_dev_groupby.hip)
+ *
+ * The ordering of the group records lives in mdb_dev_order.hip, the materialising join (mdb_dev_join_pairs) in
+ * mdb_dev_pairs.hip; what the files share is mdb_dev_join_internal.h.
  *
  * After mdb_partition_table() every leaf holds all rows (of both tables) whose hashed key shares
  * the same top bits (in unspecified order; orders are restored from the row ids).  Persistent
@@ -22,74 +26,7 @@
  *                                                            -> groups ordered by first L position
  *   - join output is left-major / right-minor (:1096-1141)   -> pairs ordered by (pos_l, pos_r)
  */
-#include <stdlib.h>
-#include "mdb_dev_internal.h"
-
-/* ------------------------------------------------------------------ shared leaf helpers */
-
-#define LEAF_THREADS 512		/* pairs-join leaf kernels */
-#define GC_THREADS 1024		/* group-count leaf kernel: 16 waves x 2 workgroups = 32 waves/CU hide the LDS probe latency */
-#define GC_EMIT_ITERS ((GC_SLOTS + 1 + GC_THREADS - 1) / GC_THREADS)	/* table slots visited per thread */
-#define GC_REC_CHUNK 16384u	/* record-list slots a workgroup reserves at a time (one global atomic per chunk) */
-#define LEAF_BATCH 2		/* keys loaded per thread before the first is consumed */
-#define GC_SLOTS 3833u		/* group-count table (prime, for double hashing): 20 B/slot -> 75 KiB, two workgroups per CU */
-#define GC_TARGET 1536u		/* average build keys per leaf (load factor ~0.4) */
-#define PJ_SLOTS 2039u		/* pairs table (prime) */
-#define PJ_TARGET 640u
-#define PJ_CHUNK 2048u		/* right-side rows staged per sweep in the emit kernel */
-
-__device__ static inline uint32_t leaf_slot(uint64_t hv, uint32_t slots)
-{
-	const uint32_t x = (uint32_t)hv * 0x9E3779B1u;
-	return (uint32_t)(((uint64_t)x * slots) >> 32);
-}
-
-/* Double hashing: the probe step comes from the other half of the hashed key, in [1, slots - 1]; the table
- * sizes are prime, so every step visits all slots.  Linear probing clusters: at load 0.4 the longest of the
- * 64 probe chains a wave waits for was ~2x longer, and the wave pays the longest. */
-__device__ static inline uint32_t leaf_step(uint64_t hv, uint32_t slots)
-{
-	const uint32_t y = (uint32_t)(hv >> 32) * 0x85EBCA6Bu;
-	return 1u + (uint32_t)(((uint64_t)y * (slots - 1)) >> 32);
-}
-
-/* insert-or-find hv (hv != 0); returns the slot or 0xFFFFFFFF when the table is full; *created = this call
- * claimed the slot (exactly one caller per distinct key sees true) */
-__device__ static inline uint32_t leaf_insert(unsigned long long *keys, uint32_t slots, uint64_t hv, bool *created = nullptr)
-{
-	uint32_t s = leaf_slot(hv, slots);
-	const uint32_t step = leaf_step(hv, slots);
-	for (uint32_t probe = 0; probe < slots; probe++) {
-		const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)hv);
-		if (old == 0ull || old == hv) {
-			if (created)
-				*created = old == 0ull;
-			return s;
-		}
-		s += step;
-		if (s >= slots)
-			s -= slots;
-	}
-	return 0xFFFFFFFFu;
-}
-
-/* find hv (hv != 0) after the build phase; 0xFFFFFFFF = absent */
-__device__ static inline uint32_t leaf_find(const unsigned long long *keys, uint32_t slots, uint64_t hv)
-{
-	uint32_t s = leaf_slot(hv, slots);
-	const uint32_t step = leaf_step(hv, slots);
-	for (uint32_t probe = 0; probe < slots; probe++) {
-		const unsigned long long cur = keys[s];
-		if (cur == hv)
-			return s;
-		if (cur == 0ull)
-			return 0xFFFFFFFFu;
-		s += step;
-		if (s >= slots)
-			s -= slots;
-	}
-	return 0xFFFFFFFFu;
-}
+#include "mdb_dev_join_internal.h"
 
 __global__ void k_gather_i32(const int32_t *__restrict__ keys, const uint32_t *__restrict__ sel, uint64_t n, int64_t *__restrict__ out)
 {
@@ -100,54 +37,6 @@ __global__ void k_gather_i32(const int32_t *__restrict__ keys, const uint32_t *_
 
 /* ------------------------------------------------------------------ fused join + group count */
 
-#define GC_MAX_EXTRA 2		/* right tables beyond the first one (mdb_dev_join_group_count_multi: up to 3 right tables) */
-
-struct gc_args {
-	const uint64_t *hv_l;
-	const uint32_t *rid_l;
-	const uint32_t *off_l;		/* exact leaf offsets, or ... */
-	const uint32_t *cnt_l;		/* ... rows per leaf of the fixed-capacity (fast) layout */
-	uint32_t cap_l;			/* 0 = exact offsets */
-	const uint64_t *hv_r;		/* NULL: plain GROUP BY over the left stream */
-	const uint32_t *off_r;
-	const uint32_t *cnt_r;
-	uint32_t cap_r;
-	int64_t *dense_cnt;		/* dense mode: [n_l], zeroed: COUNT(*) written at the group's first L position */
-	unsigned long long *rec;	/* record mode: one 64-bit record per group, (first << (64 - kbits)) | COUNT(*) */
-	uint32_t *rec_count;		/* record mode: list slots handed out so far (the list has zero-filled gaps) */
-	uint32_t *rec_valid;		/* record mode: number of real records (= groups) */
-	uint32_t rec_cap;		/* record mode: capacity of the list */
-	uint32_t kbits;			/* record mode: bits of a left row id (0 = dense mode) */
-	unsigned long long *joined;	/* sum of all counts */
-	uint32_t *status;		/* bit 0: a leaf table overflowed */
-	uint32_t nleaves;
-	uint32_t heavy_l, heavy_r;	/* rows of a side from which a leaf counts as hot (>= GC_HEAVY and >= 8x the side's average leaf) */
-	uint32_t narrow;		/* narrow form: hv_l[i] = hash32 << 32 | row id (rid_l unused), hv_r = array of 4-byte hash32 */
-	uint32_t rec32;			/* direct-address leaves: the records are written as 4-byte words (first row id << (32 - kbits)) | COUNT(*) - the
-					 * caller has seen, for these very columns, that every COUNT fits; one that does not raises status bit 9 and
-					 * the operator is redone with 8-byte records */
-	uint32_t keyed_cbits;		/* direct-address leaves, != 0: KEYED group records - (first row id, hashed key, COUNT(*)) with COUNT in
-					 * the low keyed_cbits bits and the key_bits-wide hashed key above it: the ordering kernel decodes the
-					 * group key from the record instead of gathering it from the key column (selective joins: the groups'
-					 * first rows are scattered over the left table, every gathered key costs a 128-byte line) */
-	uint32_t merge_all;		/* plain GROUP BY: the key sample held duplicates (some 10^4 - 10^5 distinct values): merge equal
-					 * values per wave in every leaf, not only in the oversize ones */
-	/* further right tables joined on the SAME key (A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a: BASELINE configs[4]) -
-	 * direct-address leaves only: partitioned exactly like the right table (4-byte words, fixed-capacity leaves), counted into
-	 * LDS arrays of their own; a key's right count becomes the PRODUCT of its counts in all right tables */
-	uint32_t nextra;
-	const uint32_t *hv_x[GC_MAX_EXTRA];
-	const uint32_t *cnt_x[GC_MAX_EXTRA];
-	uint32_t cap_x[GC_MAX_EXTRA];
-};
-
-/* narrow word -> the 64-bit value the leaf tables work with (both halves = the 32-bit hash, so that the slot and the
- * probe step still come from different multipliers; 0 only for the key whose hash is 0) */
-__device__ static inline uint64_t gc_narrow_hv(uint64_t w)
-{
-	const uint32_t h = (uint32_t)(w >> 32);
-	return ((uint64_t)h << 32) | h;
-}
 
 /*
  * Persistent form: gridDim.x workgroups (2 per CU) walk the leaves with stride gridDim.x.  The first
@@ -163,18 +52,6 @@ struct gc_batch {
 	uint32_t h32_r[LEAF_BATCH];	/* narrow form: the right side's 4-byte words */
 };
 
-__device__ static inline void gc_leaf_range(const uint32_t *off, const uint32_t *cnt, uint32_t cap, uint32_t leaf, uint32_t *b,
-					    uint32_t *e)
-{
-	if (cap) {
-		const uint32_t c = cnt[leaf];
-		*b = leaf * cap;
-		*e = *b + (c < cap ? c : cap);
-	} else {
-		*b = off[leaf];
-		*e = off[leaf + 1];
-	}
-}
 
 /* the same in two steps, so that the words can be requested one whole leaf before they are needed */
 __device__ static inline uint2 gc_leaf_raw(const uint32_t *off, const uint32_t *cnt, uint32_t cap, uint32_t leaf)
@@ -1101,28 +978,6 @@ __global__ __launch_bounds__(THREADS, 4 * THREADS / 256) void k_leaf_direct	/* f
  * no LDS atomics, 0.116 ms; every atomic on one of 32 words 0.13; with the loads of the next step in flight while the current
  * one is counted (unconditional loads, s_waitcnt vmcnt(4..7) instead of 0) 0.143 - not latency: with one workgroup per CU
  * nothing streams while a workgroup clears its 128 KiB or emits. */
-#define LW_THREADS 1024
-#define LW_MIN_REM 6u		/* tables of 64 entries at least (key windows from 2^15 values: that few values per first-level region - their
-				 * number varies by 13 % - need the looser regions of mdb_part_filter.loose) */
-#define LW_EMIT_REM 11u		/* from here on every thread owns at least one 32-bit word of halves in the emit pass */
-#define LW_MAX_REM 14u
-#define LW_UNROLL 4
-
-__device__ static inline unsigned long long lw_block_sum(unsigned long long v, unsigned long long *s_red)
-{
-#pragma unroll
-	for (int o = 32; o; o >>= 1)
-		v += __shfl_down(v, o, MDB_WAVE);
-	__syncthreads();	/* protect s_red against a previous use */
-	if (mdb_lane() == 0)
-		s_red[threadIdx.x >> 6] = v;
-	__syncthreads();
-	unsigned long long t = 0;
-#pragma unroll
-	for (int w = 0; w < LW_THREADS / 64; w++)
-		t += s_red[w];
-	return t;
-}
 
 template <bool HAS_R, bool R16 = false /* the right table's words are 2 bytes: the hash bits below the digit (mdb_part_result.w16) */>
 __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t rem, uint32_t shift, uint32_t nsub)
@@ -1616,441 +1471,11 @@ __global__ void k_null_rec(const unsigned long long *cnt_first, unsigned long lo
 	}
 }
 
-/* ------------------------------------------------------------------ ordering the groups by first row id
- *
- * The group records (first row id in the top kbits, COUNT(*) below) were radix-partitioned on the top
- * bits of the row id, so leaf i holds exactly the records whose row id lies in [i * range, (i+1) * range),
- * range <= ORD_RANGE (4096).  Row ids are distinct, so dropping each record at LDS slot (row id - i * range) and
- * compacting the slots in order sorts the leaf; leaves are already in order.  This is what reproduces the
- * reference's "survivors keep table order" (executor_select.c:1542-1583) without 8-byte random writes
- * into a table-sized array.
- */
-#define ORD_THREADS 512
-#define ORD_PER_THREAD 8
-#define ORD_RANGE (ORD_THREADS * ORD_PER_THREAD)	/* 4096 row ids per ordering leaf (32 KiB of LDS slots: 4 workgroups per CU; 8192 ids x 1024 threads measured 15 % slower, 2048 x 256 no faster) */
-#define ORD_RANGE_BITS 12
-
-#define GC_RETRY_REC64 1006	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
-
-struct ord_args {
-	const unsigned long long *rec;
-	const uint32_t *off;		/* exact layout: leaf offsets = output positions */
-	const uint32_t *cnt;		/* fast layout: records per leaf ... */
-	const uint32_t *out_base;	/* ... and their exclusive prefix = output positions */
-	uint32_t cap;
-	uint32_t kbits, leaf_bits;
-	uint32_t *out_first;
-	int64_t *out_count;		/* the record's payload as int64 (COUNT(*)), or ... */
-	uint32_t *out_val32;		/* ... payload - 1 as uint32 (right row id of a join pair) */
-	const int64_t *keys;		/* optional: key column to gather the group keys from ... */
-	int64_t *out_key;		/* ... into here (keys[first]) */
-	uint32_t keys32;		/* `keys` is an int32 column */
-	uint32_t rec32;			/* the records are 4-byte words: (row id << (32 - kbits)) | payload */
-	uint32_t keyed_cbits;		/* != 0: keyed records (gc_args.keyed_cbits): payload = hashed key << keyed_cbits | COUNT(*); the group key
-					 * is key_lo + mdb_unmixk(hashed key, key_bits), nothing is gathered */
-	uint32_t key_bits;
-	int64_t key_lo;
-	uint32_t *status;		/* k_order_leaf_sparse: bit 1 when a leaf holds more records than it can rank */
-};
-
-__global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
-{
-	__shared__ unsigned long long s_slot[ORD_RANGE];
-	__shared__ uint32_t s_scan[32];
-	const uint32_t leaf = blockIdx.x;
-	uint32_t b, e, base;
-	if (a.cap) {
-		const uint32_t c = a.cnt[leaf];
-		b = leaf * a.cap;
-		e = b + (c < a.cap ? c : a.cap);
-		base = a.out_base[leaf];
-	} else {
-		b = a.off[leaf];
-		e = a.off[leaf + 1];
-		base = b;
-	}
-	if (b == e)
-		return;
-	const uint32_t range_bits = a.kbits - a.leaf_bits;
-	const uint32_t range = 1u << range_bits;
-	const unsigned long long cmask = (1ull << (64 - a.kbits)) - 1ull;
-	/* thread t owns the ORD_PER_THREAD consecutive slots [t * ORD_PER_THREAD, ...) */
-#pragma unroll
-	for (int k = 0; k < ORD_PER_THREAD; k++)
-		s_slot[threadIdx.x + (uint32_t)k * ORD_THREADS] = 0ull;
-	__syncthreads();
-	if (a.rec32) {
-		const uint32_t *const rec = reinterpret_cast<const uint32_t *>(a.rec);
-		const uint32_t cm32 = (1u << (32 - a.kbits)) - 1u;
-		for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
-			const uint32_t r = rec[i];
-			s_slot[(r >> (32 - a.kbits)) & (range - 1)] = r & cm32;
-		}
-	} else {
-		for (uint32_t i = b + threadIdx.x; i < e; i += ORD_THREADS) {
-			const unsigned long long r = a.rec[i];
-			s_slot[(uint32_t)(r >> (64 - a.kbits)) & (range - 1)] = r & cmask;	/* COUNT(*) >= 1 marks the slot */
-		}
-	}
-	__syncthreads();
-	unsigned long long c[ORD_PER_THREAD];
-	uint32_t mine = 0;
-#pragma unroll
-	for (int k = 0; k < ORD_PER_THREAD; k++) {
-		c[k] = s_slot[threadIdx.x * ORD_PER_THREAD + k];
-		mine += c[k] != 0;
-	}
-	uint32_t total;
-	uint32_t pos = mdb_block_excl_scan(mine, s_scan, &total);	/* (syncs: every slot has been read) */
-	/* compact in LDS - (slot index, COUNT) packed in one word: COUNT < 2^(64-kbits) <= 2^51 - so that the
-	 * global writes below are coalesced (thread-contiguous slots would scatter them 64 B apart) */
-#pragma unroll
-	for (int k = 0; k < ORD_PER_THREAD; k++)
-		if (c[k])
-			s_slot[pos++] = ((unsigned long long)(threadIdx.x * ORD_PER_THREAD + k) << 51) | c[k];
-	__syncthreads();
-	const uint32_t first_base = leaf << range_bits;
-	for (uint32_t i = threadIdx.x; i < total; i += ORD_THREADS) {
-		const unsigned long long v = s_slot[i];
-		const uint32_t first = first_base + (uint32_t)(v >> 51);
-		if (a.out_first)		/* (a caller that only wants keys and counts: 4 bytes per group less to write) */
-			a.out_first[base + i] = first;
-		if (a.keyed_cbits) {
-			const unsigned long long pay = v & ((1ull << 51) - 1ull);
-			a.out_count[base + i] = (int64_t)(pay & ((1ull << a.keyed_cbits) - 1ull));
-			if (a.out_key)
-				a.out_key[base + i] = a.key_lo + (int64_t)mdb_unmixk((uint32_t)(pay >> a.keyed_cbits), a.key_bits);
-			continue;
-		}
-		if (a.out_val32)
-			a.out_val32[base + i] = (uint32_t)(v & ((1ull << 51) - 1ull)) - 1u;
-		else
-			a.out_count[base + i] = (int64_t)(v & ((1ull << 51) - 1ull));
-		if (a.out_key)
-			a.out_key[base + i] = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[first] : a.keys[first];
-	}
-}
-
-/* The same for FEW records (selective joins: 6.25 * 10^6 groups among 10^8 left rows are 256 records per 4096-id leaf - 24 414
- * workgroups that mostly clear and scan empty LDS slots).  Leaves of 2^16 row ids instead: a record's place among its leaf's
- * records is the number of records with a smaller row id, i.e. the number of set bits below its own in a BITMAP of the leaf's
- * row ids (8 KiB of LDS) - records in registers, one LDS atomic each to set the bit, a block scan over the word popcounts,
- * one popcount each to rank; the records are then staged in LDS at their ranks, so that the three output columns are written
- * with consecutive threads on consecutive rows (written straight from the registers - 64 scattered rows per store
- * instruction - the kernel took 0.20 ms for 6.25 * 10^6 records, staged 0.054; k_order_leaf takes 0.10). */
-#define OS_THREADS 1024
-#define OS_RANGE_BITS 16u
-#define OS_PER_THREAD 8
-#define OS_MAX_REC (OS_THREADS * OS_PER_THREAD)
-
-__global__ __launch_bounds__(OS_THREADS) void k_order_leaf_sparse(ord_args a)
-{
-	__shared__ uint32_t s_bits[1u << (OS_RANGE_BITS - 5)];
-	__shared__ uint32_t s_pfx[1u << (OS_RANGE_BITS - 5)];
-	__shared__ unsigned long long s_stage[OS_MAX_REC];	/* the records at their ranks */
-	__shared__ uint32_t s_scan[32];
-	const uint32_t leaf = blockIdx.x;
-	const uint32_t c = a.cnt[leaf], b = leaf * a.cap, e = b + c, base = a.out_base[leaf];
-	if (!c)
-		return;
-	if (c > a.cap || c > OS_MAX_REC) {	/* the scatter's region overflowed, or more records than the registers of a workgroup hold
-						 * (row ids bunched): the general path takes over */
-		if (threadIdx.x == 0)
-			mdb_raise(a.status, 2u);
-		return;
-	}
-	const uint32_t range_bits = a.kbits - a.leaf_bits, range = 1u << range_bits;
-	const uint32_t words = range_bits > 5 ? 1u << (range_bits - 5) : 1u;
-	for (uint32_t w = threadIdx.x; w < words; w += OS_THREADS)
-		s_bits[w] = 0u;
-	__syncthreads();
-	unsigned long long r[OS_PER_THREAD];
-#pragma unroll
-	for (int k = 0; k < OS_PER_THREAD; k++) {
-		const uint32_t i = b + threadIdx.x + (uint32_t)k * OS_THREADS;
-		r[k] = a.rec[i < e ? i : b];	/* (unconditional loads - issued together; past the end: the first record, dropped) */
-	}
-#pragma unroll
-	for (int k = 0; k < OS_PER_THREAD; k++) {
-		const uint32_t i = b + threadIdx.x + (uint32_t)k * OS_THREADS;
-		r[k] = i < e ? r[k] : 0ull;
-		if (r[k]) {
-			const uint32_t idx = (uint32_t)(r[k] >> (64 - a.kbits)) & (range - 1);
-			atomicOr(&s_bits[idx >> 5], 1u << (idx & 31u));
-		}
-	}
-	__syncthreads();
-	/* exclusive prefix of the words' popcounts: thread t owns words [t * per, t * per + per) */
-	const uint32_t per = (words + OS_THREADS - 1) / OS_THREADS;
-	uint32_t mine = 0;
-	for (uint32_t q = 0; q < per; q++) {
-		const uint32_t w = threadIdx.x * per + q;
-		if (w < words)
-			mine += (uint32_t)__popc(s_bits[w]);
-	}
-	uint32_t total;
-	uint32_t run = mdb_block_excl_scan(mine, s_scan, &total);
-	for (uint32_t q = 0; q < per; q++) {
-		const uint32_t w = threadIdx.x * per + q;
-		if (w < words) {
-			s_pfx[w] = run;
-			run += (uint32_t)__popc(s_bits[w]);
-		}
-	}
-	__syncthreads();
-	const unsigned long long cmask = (1ull << (64 - a.kbits)) - 1ull;
-#pragma unroll
-	for (int k = 0; k < OS_PER_THREAD; k++) {
-		if (!r[k])
-			continue;
-		const uint32_t idx = (uint32_t)(r[k] >> (64 - a.kbits)) & (range - 1);
-		s_stage[s_pfx[idx >> 5] + (uint32_t)__popc(s_bits[idx >> 5] & ((1u << (idx & 31u)) - 1u))] = r[k];
-	}
-	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < total; i += OS_THREADS) {
-		const unsigned long long rec = s_stage[i];
-		const uint32_t idx = (uint32_t)(rec >> (64 - a.kbits)) & (range - 1);
-		const uint32_t pos = base + i;
-		const uint32_t first = (leaf << range_bits) + idx;
-		const unsigned long long pay = rec & cmask;
-		if (a.out_first)
-			a.out_first[pos] = first;
-		if (a.keyed_cbits) {
-			a.out_count[pos] = (int64_t)(pay & ((1ull << a.keyed_cbits) - 1ull));
-			if (a.out_key)
-				a.out_key[pos] = a.key_lo + (int64_t)mdb_unmixk((uint32_t)(pay >> a.keyed_cbits), a.key_bits);
-		} else {
-			a.out_count[pos] = (int64_t)pay;
-			if (a.out_key)
-				a.out_key[pos] = a.keys32 ? (int64_t)reinterpret_cast<const int32_t *>(a.keys)[first] : a.keys[first];
-		}
-	}
-}
-
-/* bits of the ordering sort: leaves of at most ORD_RANGE row ids, at most 9 bits per level */
-static bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2)
-{
-	uint32_t k = 1;
-	while (k < 32 && (1ull << k) < n_l)
-		k++;
-	int b = (int)k - ORD_RANGE_BITS;
-	if (b < 1)
-		b = 1;
-	if (b > 2 * MDB_MAX_RADIX_BITS)
-		return false;
-	*kbits = k;
-	if (b <= MDB_MAX_RADIX_BITS) {
-		*sb1 = b;
-		*sb2 = 0;
-	} else {
-		*sb1 = (b + 1) / 2;
-		*sb2 = b - *sb1;
-	}
-	return true;
-}
-
-/* first-level digits of the ordering sort that can occur: row ids are < n_l, not < 2^kbits */
-static uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1)
-{
-	const uint32_t shift = kbits - (uint32_t)sb1;
-	return (uint32_t)(((n_l ? n_l - 1 : 0) >> shift) + 1);
-}
-
-/* k_order_leaf_sparse is tried for row ids of kbits bits when its leaves (2^OS_RANGE_BITS ids) take one or two scatter levels */
-static bool order_sparse_bits(uint32_t kbits)
-{
-	return kbits >= OS_RANGE_BITS + 2 && kbits - OS_RANGE_BITS <= 2 * MDB_MAX_RADIX_BITS;
-}
-
-/* most records the attempt is made for (a leaf holds OS_MAX_REC: the average leaves half of the slack of the scatter's regions),
- * and most list slots - zero-filled gaps included - its arena is reserved for */
-static uint64_t order_sparse_most_records(uint32_t kbits)
-{
-	return (uint64_t)(OS_MAX_REC - 1024) * 2 / 3 << (kbits - OS_RANGE_BITS);
-}
-
-static uint64_t order_sparse_most_slots(uint32_t kbits)
-{
-	return 4 * order_sparse_most_records(kbits);
-}
-
-/* Order a record list ((row id << (64 - kbits)) | payload, zero words = gaps) by row id and deliver it:
- * histogram-free regions first; if one overflows (the gaps of the list can bunch the records of one XCD's tile
- * range) the exact layout redoes the sort.  Synchronises. */
-/* rec32: every payload is below 2^(32 - kbits) - the sort's first level then folds the records into 4-byte words and
- * everything after it moves half the bytes (10^8 groups of one row each: 1.3 -> 0.9 ms for the ordering) */
-static int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
-			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,
-			 bool keys32 = false, bool rec32 = false, uint32_t keyed_cbits = 0, uint32_t key_bits = 0, int64_t key_lo = 0,
-			 bool in32 = false /* the list already holds 4-byte records */, uint64_t n_rec = 0 /* records in the list (0: unknown) */)
-{
-	rec32 = (rec32 || in32) && sb2 > 0 && kbits < 32 && !keyed_cbits;
-	if (in32 && !rec32)
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4-byte group records need the two-level ordering sort");
-	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
-	uint64_t *h = ctx->h_pinned;
-	int rc;
-	/* few 8-byte records of a join (out_count wanted): leaves of 2^16 row ids ranked through a bitmap (k_order_leaf_sparse) */
-	if (!rec32 && !out_val32 && out_count && order_sparse_bits(kbits) &&
-	    !(getenv("MDB_ORDER_SPARSE") && getenv("MDB_ORDER_SPARSE")[0] == '0')) {
-		const uint32_t lb = kbits - OS_RANGE_BITS;
-		const int s1 = (int)((lb + 1) / 2), s2 = (int)lb - s1;
-		/* (the list has zero-filled gaps - chunk tails -, the scatter skips them: what counts is the number of records) */
-		/* leaves that can hold records: those below n_l (a caller that knows where the largest row id lies passes that) */
-		const uint64_t used_leaves = ((n_l ? n_l - 1 : 0) >> OS_RANGE_BITS) + 1;
-		if ((n_rec ? n_rec : list_len) <= (uint64_t)(OS_MAX_REC - 1024) * 2 / 3 * used_leaves &&
-		    (n_rec ? n_rec : list_len) <= order_sparse_most_records(kbits) && list_len <= order_sparse_most_slots(kbits)) {
-			mdb_part_result ps;
-			rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, s1, s2, 0, true, order_digits0(n_l, kbits, s1), &ps, true, 0);
-			if (rc)
-				return rc;
-			if (ps.leaf_cap && !ps.w32) {
-				uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
-				uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
-				if (!obase || !otmp)
-					return -MIDORIDB_INTERNAL;
-				if (ps.nleaves <= MDB_SCAN_SMALL) {
-					rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
-				} else {
-					MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
-					MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
-					rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
-				}
-				if (rc)
-					return rc;
-				ord_args oa;
-				memset(&oa, 0, sizeof(oa));
-				oa.rec = (const unsigned long long *)ps.hv;
-				oa.cnt = ps.leaf_cnt;
-				oa.cap = ps.leaf_cap;
-				oa.out_base = obase;
-				oa.kbits = kbits;
-				oa.leaf_bits = lb;
-				oa.out_first = out_first;
-				oa.out_count = out_count;
-				oa.keys = keys;
-				oa.out_key = out_key;
-				oa.keys32 = keys32 ? 1u : 0u;
-				oa.keyed_cbits = keyed_cbits;
-				oa.key_bits = key_bits;
-				oa.key_lo = key_lo;
-				oa.status = ctx->d_status;
-				MDB_LAUNCH(ctx, "order_leaf_sparse", k_order_leaf_sparse, ps.nleaves, OS_THREADS, oa);
-				MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-				if (!((uint32_t)h[8] & 2u))
-					return MIDORIDB_OK;
-				MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* a region overflowed (row ids bunched): the general path */
-			}
-		}
-	}
-	for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
-		mdb_part_result ps;
-		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0, order_digits0(n_l, kbits, sb1),
-				       &ps, true, (rec32 && sort_fast != 0) ? (in32 ? 2 : 1) : 0);
-		if (rc)
-			return rc;
-		ord_args oa;
-		oa.rec = (const unsigned long long *)ps.hv;
-		oa.off = ps.leaf_off;
-		oa.cnt = ps.leaf_cnt;
-		oa.cap = ps.leaf_cap;
-		oa.out_base = NULL;
-		oa.kbits = kbits;
-		oa.leaf_bits = (uint32_t)(sb1 + sb2);
-		oa.out_first = out_first;
-		oa.out_count = out_count;
-		oa.out_val32 = out_val32;
-		oa.keys = keys;
-		oa.out_key = out_key;
-		oa.keys32 = keys32 ? 1u : 0u;
-		oa.rec32 = ps.w32 ? 1u : 0u;
-		oa.keyed_cbits = keyed_cbits;
-		oa.key_bits = key_bits;
-		oa.key_lo = key_lo;
-		if (ps.leaf_cap) {
-			/* fast layout: output position of a leaf = exclusive prefix of the leaf sizes */
-			uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)ps.nleaves + 1) * 4);
-			uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
-			if (!obase || !otmp)
-				return -MIDORIDB_INTERNAL;
-			if (ps.nleaves <= MDB_SCAN_SMALL) {
-				rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
-			} else {
-				MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
-				MDB_HIP(ctx, hipMemsetAsync(obase + ps.nleaves, 0, 4, ctx->stream));
-				rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)ps.nleaves + 1, otmp);
-			}
-			if (rc)
-				return rc;
-			oa.out_base = obase;
-		}
-		MDB_LAUNCH(ctx, "order_leaf", k_order_leaf, ps.nleaves, ORD_THREADS, oa);
-		MDB_HIP(ctx, hipMemcpyAsync(&h[8], ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		if (!sort_fast || !((uint32_t)h[8] & 2u))
-			break;
-		if (in32)
-			return GC_RETRY_REC64;	/* (a region of the ordering sort overflowed: its exact layout reads 8-byte records) */
-		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* the other flag bits were checked before */
-	}
-	return MIDORIDB_OK;
-}
-
-/* exported for mdb_dev_sort.hip (multi-column GROUP BY): same list format, bits chosen here */
-int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_rows, uint32_t kbits,
-			       uint32_t *out_first, int64_t *out_count)
-{
-	uint32_t kb = 0;
-	int sb1 = 0, sb2 = 0;
-	if (!order_bits(n_rows, &kb, &sb1, &sb2) || kb != kbits)
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "record ordering: unsupported row-id width");
-	return order_records(ctx, rec, list_len, n_rows, kbits, sb1, sb2, out_first, out_count, NULL, NULL, NULL);
-}
-
-/* arena bytes of order_records() for a list of at most `cap` slots */
-static size_t order_records_arena_bytes(uint64_t cap, uint64_t n_l, uint32_t kbits, int sb1, int sb2)
-{
-	const uint32_t ord_range = 1u << (kbits - (uint32_t)(sb1 + sb2));
-	size_t sparse = 0;	/* the attempt with 2^16-id leaves (k_order_leaf_sparse) comes first and may be followed by the general path */
-	if (order_sparse_bits(kbits)) {
-		const uint32_t lb = kbits - OS_RANGE_BITS;
-		const int s1 = (int)((lb + 1) / 2), s2 = (int)lb - s1;
-		const uint64_t most = order_sparse_most_slots(kbits);
-		sparse = mdb_partition_raw_arena_bytes(cap < most ? cap : most, s1, s2, 0, true, order_digits0(n_l, kbits, s1)) +
-			 2 * (((size_t)1 << lb) + 4096) * 8;
-	}
-	return sparse + mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, true, order_digits0(n_l, kbits, sb1)) +
-	       mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, false, 0) + 2 * (((size_t)1 << (sb1 + sb2)) + 4096) * 8;
-}
-
-size_t mdb_order_records_arena_bytes(uint64_t cap, uint64_t n_rows, uint32_t *kbits_out)
-{
-	uint32_t kb = 0;
-	int sb1 = 0, sb2 = 0;
-	if (!order_bits(n_rows, &kb, &sb1, &sb2))
-		return 0;
-	*kbits_out = kb;
-	return order_records_arena_bytes(cap, n_rows, kb, sb1, sb2);
-}
-
 /* ------------------------------------------------------------------ group-count drivers */
 
-#define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
-#define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
-#define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
-#define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
-/* words of ctx->d_status the fused operator uses beyond [0..9] (flags, record-list length, joined rows, NULL-group stats, records):
- * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
- * key - window base (min-max pruning, while it runs) */
-#define GC_ST_MINMAX 16
-#define GC_ST_WINDOW 20	/* [20..21] 0 and 2^key_bits - 1: the whole window as a pruning range (further right tables drop what lies outside) */
-#define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
-#define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
-#define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
 
 /* MDB_DIRECT_LEAF=0 keeps the compact narrow form off (A/B measurements, soaks of the hashed leaf kernel) */
-static bool ld_disabled(void)
+bool ld_disabled(void)
 {
 	static int v = -1;
 	if (v < 0) {
@@ -2062,7 +1487,7 @@ static bool ld_disabled(void)
 
 /* slots of the group-record list: every group once, plus the zero-filled gaps of the chunked reservation
  * (at most one leaf's worth per chunk, one unfinished chunk per workgroup) */
-static uint64_t gc_rec_capacity(mdb_dev_ctx *ctx, uint64_t n_l)
+uint64_t gc_rec_capacity(mdb_dev_ctx *ctx, uint64_t n_l)
 {
 	return n_l + n_l / 4 + (uint64_t)(4 * ctx->num_cus + 4) * GC_REC_CHUNK + 4096;	/* two kernel instances, one open chunk per workgroup */
 }
@@ -2102,8 +1527,6 @@ struct gc_state {
 	uint64_t xn[GC_MAX_EXTRA];
 };
 
-#define GC_NOT_SERVED 1008	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of
-				 * counts overflowed, or a hot leaf): the caller chains two-table operators instead */
 struct gc_extras {
 	int n;
 	const int64_t *keys[GC_MAX_EXTRA];
@@ -2621,17 +2044,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
  * range, and the operator is then redone with 64-bit hashes (GC_RETRY_WIDE).  To keep that retry for adversarial
  * inputs only, 2 x 4096 evenly spaced keys are looked at first (one tiny kernel + one sync, paid only by tables large
  * enough for the bytes to matter).  mdb_dev_set_narrow_keys(): 0 never, 1 as described (default), 2 always try. */
-#define GC_NARROW_MIN_ROWS (1u << 20)
-#define GC_NARROW_SAMPLE 4096u
-#define GC_HINT_USES 8		/* a remembered sample / verdict serves this many calls, then the data is looked at again (one
-				 * tiny kernel + sync in eight calls; a buffer that was refilled is noticed within eight) */
 
-/* position of sample t: pseudo-random, not evenly spaced - generated or periodic data (an affine sequence, a table sorted by
- * a low-cardinality column) looks very different at a fixed stride than it is */
-__device__ static inline uint64_t gc_sample_pos(uint32_t t, uint64_t n)
-{
-	return mdb_fmix64(0x9E3779B97F4A7C15ull * (uint64_t)(t + 1)) % n;
-}
 
 __device__ static inline long long gc_wave_min_i64(long long v)
 {
@@ -2716,8 +2129,8 @@ __global__ void k_key_sample(const K *__restrict__ kl, const uint64_t *__restric
 /* smallest / largest of 2 x GC_NARROW_SAMPLE evenly spaced non-NULL keys (lo > hi: nothing but NULLs); remembered by the
  * columns, so that the decisions that need it (narrow form, direct tables) share one kernel + sync, and a repeated query
  * pays none.  fresh: take the sample again (a remembered verdict just proved wrong). */
-static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			   const uint64_t *null_r, uint64_t n_r, bool fresh, int64_t *lo, int64_t *hi, bool keys32 = false)
+int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, bool fresh, int64_t *lo, int64_t *hi, bool keys32)
 {
 	if (!keys_r)
 		n_r = 0;
@@ -2760,8 +2173,8 @@ static int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	return MIDORIDB_OK;
 }
 
-static void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow,
-			   int64_t base = 0, uint32_t key_bits = 0, int64_t key_lo = 0)
+void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, bool narrow,
+			   int64_t base, uint32_t key_bits, int64_t key_lo)
 {
 	ctx->nh_kbits = narrow ? key_bits : 0u;
 	ctx->nh_lo = key_lo;
@@ -2798,22 +2211,10 @@ static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *
 	*wlo = (int64_t)((uint64_t)lo - pad - (((1ull << k) - need) >> 1));
 }
 
-struct gc_window {
-	uint32_t kbits;		/* 0 = no compact window */
-	int64_t lo;
-	bool selective;		/* the right table's sampled keys cover less than a quarter of the left table's sampled key range, or the right
-				 * table has less than a quarter of the left table's rows: most left rows will find no partner (semi-join filter) */
-	bool by_span;		/* ... the former: min-max pruning at the first level will drop them, no bitmap needed */
-	bool prunable;		/* the right table's sampled keys cover less than 7/8 of the left table's sampled range: worth recording the
-				 * right table's exact range for min-max pruning */
-	bool r_based;		/* the compact window covers the RIGHT table's sampled keys only (by_span, unsplit call): the left rows outside
-				 * it are exactly the ones min-max pruning drops - fewer key bits, hence fewer and larger leaves */
-	bool fast1;		/* plain GROUP BY, duplicates in the key sample: the fixed-capacity layout only if the ONE-level form applies */
-};
 
-static int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			   const uint64_t *null_r, uint64_t n_r, bool *narrow, int64_t *base, gc_window *win = nullptr, bool keys32 = false,
-			   bool prune_ok = false /* unsplit call: min-max pruning can run */)
+int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, bool *narrow, int64_t *base, gc_window *win, bool keys32,
+			   bool prune_ok /* unsplit call: min-max pruning can run */)
 {
 	*narrow = false;
 	*base = 0;
@@ -3044,7 +2445,6 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
  * launches and two synchronisations (~170 us).  Up to GC_THREADS * LEAF_BATCH rows per table one workgroup does the whole
  * operator in LDS: table from the left rows (COUNT, first row), right rows counted into it, and - because a left row that
  * is the first of its group knows so - the groups leave in first-occurrence order by a prefix sum over the rows, no sort. */
-#define TINY_ROWS (GC_THREADS * LEAF_BATCH)
 
 struct tiny_args {
 	const int64_t *keys_l;
@@ -3159,7 +2559,7 @@ __global__ __launch_bounds__(GC_THREADS) void k_tiny_group_count(tiny_args a)
 }
 
 /* 0 = done, 1 = not applicable, < 0 = error */
-static int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			    const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, int64_t *out_key, int64_t *out_count,
 			    uint32_t *out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
 {
@@ -3198,9 +2598,6 @@ static int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint6
 	return 0;
 }
 
-static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
-			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
-			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined);
 
 extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 					const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags,
@@ -3470,543 +2867,6 @@ extern "C" int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32
 			       out_joined, true);
 }
 
-/* ------------------------------------------------------------------ GROUP BY over a small value range
- *
- * SELECT fa, COUNT(*) FROM A GROUP BY fa with a thousand distinct values is the other common shape of the operator, and
- * the worst one for the partitioned path: a thousand leaves of 10^5 equal rows each (3.8 ms per 10^8 rows through the
- * hot-key kernels).  When a sample of the column spans at most GD_RANGE / 2 values, every workgroup instead counts its
- * share of the rows directly in an LDS table indexed by (value - base) - COUNT and first row per value, the table
- * replicated per lane group when the range is small so that equal values in a wave do not meet on one LDS address -
- * and flushes it into a global table with one atomic pair per value it saw.  One streaming pass over the column.
- * A value outside the window (the sample missed it) is reported and the partitioned path takes over.
- * Spans up to GD_SPAN_MAX (some 10^4 product / city / customer ids: 10^8 rows took 2.3 ms through two exact partition levels
- * and the hashed leaves) get a window of 1.25 x the span in a table of up to GD_TABLE_MAX entries - 128 KiB of dynamic LDS,
- * one workgroup per CU. */
-#define GD_RANGE 8192u		/* entries of the LDS table for spans up to GD_RANGE / 2 (two workgroups per CU), replicated per lane group */
-#define GD_TABLE_MAX 16384u	/* entries of a workgroup's LDS table (8 bytes each) */
-#define GD_SPAN_MAX 13000u
-#define GD_THREADS 1024
-#define GD_MIN_ROWS (1u << 18)
-
-struct gd_args {
-	const int64_t *keys;
-	const uint64_t *nullbits;
-	uint64_t n;
-	int64_t base;
-	uint32_t range;			/* values base .. base + range - 1 have a slot */
-	uint32_t copy_shift, copy_mask;	/* slot = (value - base) | ((lane & copy_mask) << copy_shift) */
-	uint32_t table;			/* entries of the LDS table: (copy_mask + 1) << copy_shift */
-	uint32_t null_group;		/* NULL keys form a group (slot GD_TABLE_MAX of the global table) */
-	unsigned long long *g_cnt;	/* [GD_TABLE_MAX + 1] */
-	uint32_t *g_first;		/* [GD_TABLE_MAX + 1] */
-	uint32_t *status;		/* bit 10: a value outside the window */
-};
-
-__global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t gd_lds[];
-	uint32_t *const s_cnt = gd_lds, *const s_first = gd_lds + a.table;
-	__shared__ unsigned long long s_null_cnt;
-	__shared__ uint32_t s_null_first;
-	for (uint32_t i = threadIdx.x; i < a.table; i += GD_THREADS) {
-		s_cnt[i] = 0;
-		s_first[i] = 0xFFFFFFFFu;
-	}
-	if (threadIdx.x == 0) {
-		s_null_cnt = 0;
-		s_null_first = 0xFFFFFFFFu;
-	}
-	__syncthreads();
-	const uint32_t copy = (mdb_lane() & a.copy_mask) << a.copy_shift;
-	bool bad = false;
-	for (uint64_t row0 = (uint64_t)blockIdx.x * (2 * GD_THREADS); row0 < a.n; row0 += (uint64_t)gridDim.x * (2 * GD_THREADS)) {
-		const uint64_t i0 = row0 + 2 * (uint64_t)threadIdx.x;
-		int64_t k[2] = { 0, 0 };
-		if (i0 + 1 < a.n) {
-			const longlong2 q = *reinterpret_cast<const longlong2 *>(a.keys + i0);
-			k[0] = q.x;
-			k[1] = q.y;
-		} else if (i0 < a.n) {
-			k[0] = a.keys[i0];
-		}
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			const uint64_t row = i0 + (uint64_t)u;
-			const bool valid = row < a.n;
-			const bool isnull = valid && a.nullbits && mdb_bit_is_set(a.nullbits, row);
-			if (a.nullbits) {
-				const uint64_t nm = __ballot(isnull);
-				if (nm && a.null_group && mdb_lane() == (uint32_t)__ffsll((long long)nm) - 1u) {
-					atomicAdd(&s_null_cnt, (unsigned long long)__popcll(nm));
-					atomicMin(&s_null_first, (uint32_t)row);	/* rows grow with the lane: the first NULL lane holds the smallest */
-				}
-			}
-			if (valid && !isnull) {
-				const uint64_t off = (uint64_t)k[u] - (uint64_t)a.base;
-				if (off >= a.range) {
-					bad = true;
-				} else {
-					const uint32_t idx = (uint32_t)off | copy;
-					atomicAdd(&s_cnt[idx], 1u);
-					atomicMin(&s_first[idx], (uint32_t)row);
-				}
-			}
-		}
-	}
-	if (__ballot(bad) && mdb_lane() == 0)
-		mdb_raise(a.status, 1024u);
-	__syncthreads();
-	const uint32_t copies = a.copy_mask + 1;
-	for (uint32_t off = threadIdx.x; off < a.range; off += GD_THREADS) {
-		unsigned long long total = 0;
-		uint32_t first = 0xFFFFFFFFu;
-		for (uint32_t c = 0; c < copies; c++) {
-			const uint32_t idx = off | (c << a.copy_shift);
-			total += s_cnt[idx];
-			const uint32_t f = s_first[idx];
-			first = f < first ? f : first;
-		}
-		if (total) {
-			atomicAdd(&a.g_cnt[off], total);
-			atomicMin(&a.g_first[off], first);
-		}
-	}
-	if (threadIdx.x == 0 && s_null_cnt) {
-		atomicAdd(&a.g_cnt[GD_TABLE_MAX], s_null_cnt);
-		atomicMin(&a.g_first[GD_TABLE_MAX], s_null_first);
-	}
-}
-
-/* g_cnt_r != NULL: join form - a group needs rows on both sides, COUNT(*) = left rows x right rows of the value.  The
- * record carries the SLOT (+ 1) beside the first row, not the count: counts of hot values (10^7 x 10^7 rows of one key)
- * do not fit beside a row id; k_group_direct_counts puts them in once the groups are in order. */
-__global__ void k_group_direct_emit(gd_args a, const unsigned long long *g_cnt_r, uint32_t kbits, unsigned long long *rec, uint32_t *rec_n,
-				    unsigned long long *joined)
-{
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t slot = t < a.range ? t : (t == a.range ? GD_TABLE_MAX : 0xFFFFFFFFu);
-	if (slot == 0xFFFFFFFFu)
-		return;
-	const unsigned long long c = a.g_cnt[slot];
-	if (!c)
-		return;
-	if (g_cnt_r) {
-		const unsigned long long cr = g_cnt_r[slot];
-		if (!cr || slot == GD_TABLE_MAX)
-			return;
-		atomicAdd(joined, c * cr);	/* both below 2^32 (row counts of one GPU's tables) */
-	}
-	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[slot] << (64 - kbits)) | (unsigned long long)(slot + 1);
-}
-
-__global__ void k_group_direct_counts(int64_t *out_count, uint64_t G, const unsigned long long *g_cnt, const unsigned long long *g_cnt_r)
-{
-	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= G)
-		return;
-	const uint32_t slot = (uint32_t)out_count[g] - 1u;
-	out_count[g] = (int64_t)(g_cnt_r ? g_cnt[slot] * g_cnt_r[slot] : g_cnt[slot]);
-}
-
-/* 0 = done, 1 = not applicable (use the partitioned path), < 0 = error.  keys_r != NULL: the join form (both key columns
- * inside one window; NULL keys never join) - also the cheap way through joins on a handful of hot values. */
-static int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
-			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
-			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
-{
-	if (n + (keys_r ? n_r : 0) < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
-		return 1;
-	if (keys_r && (n_r >= 0xFFFFFFFFull || ((uintptr_t)keys_r & 15) || n_r == 0))
-		return 1;
-	/* range of a sample of the column(s) (shared with the narrow-form decision of the partitioned path) */
-	int64_t lo = 0, hi = 0;
-	int rc = gc_sample_range(ctx, keys, nullbits, n, keys_r, null_r, n_r, ctx->nh_distrust > 0, &lo, &hi);
-	if (rc)
-		return rc;
-	if (lo > hi)
-		return 1;
-	const uint64_t span = (uint64_t)hi - (uint64_t)lo + 1;
-	if (span > GD_SPAN_MAX)
-		return 1;
-	/* window: twice the sampled span (at least 64 values), centred on it - 1.25 x beyond GD_RANGE / 2 values, where the 4096
-	 * samples lie within a few values of the column's extremes; replicated while copies fit a GD_RANGE-entry table */
-	uint32_t range = (uint32_t)(span > GD_RANGE / 2 ? span + span / 4 : (2 * span < 64 ? 64 : 2 * span));
-	uint32_t shift = 0;
-	while ((1u << shift) < range)
-		shift++;
-	uint32_t copies = GD_RANGE >> shift;
-	copies = copies > 64 ? 64 : (copies < 1 ? 1 : copies);
-	uint32_t kbits = 0;
-	const size_t order_bytes = mdb_order_records_arena_bytes(GD_TABLE_MAX + 1, n, &kbits);
-	if (!order_bytes)
-		return 1;
-	rc = mdb_arena_begin(ctx, order_bytes + 6 * mdb_align_up((GD_TABLE_MAX + 1) * 8) + 8192);
-	if (rc)
-		return rc;
-	gd_args a;
-	memset(&a, 0, sizeof(a));
-	a.keys = keys;
-	a.nullbits = nullbits;
-	a.n = n;
-	a.base = (int64_t)((uint64_t)lo - (uint64_t)((range - span) / 2));
-	a.range = range;
-	a.copy_shift = shift;
-	a.copy_mask = copies - 1;
-	a.table = copies << shift;
-	a.null_group = (null_group && !keys_r) ? 1u : 0u;
-	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
-	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 4);
-	a.status = ctx->d_status;
-	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
-	unsigned long long *g_cnt_r = keys_r ? (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8) : NULL;
-	uint32_t *g_first_r = keys_r ? (uint32_t *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 4) : NULL;
-	if (!a.g_cnt || !a.g_first || !rec || (keys_r && (!g_cnt_r || !g_first_r)))
-		return -MIDORIDB_INTERNAL;
-	uint32_t *rec_n = ctx->d_status + 1;
-	unsigned long long *d_joined = (unsigned long long *)(ctx->d_status + 2);
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
-	const size_t lds = (size_t)a.table * 8;
-	const uint32_t resident = (lds > 80 * 1024 ? 1u : 2u) * (uint32_t)ctx->num_cus;
-	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	{
-		const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, a);
-	}
-	if (keys_r) {
-		gd_args b = a;
-		b.keys = keys_r;
-		b.nullbits = null_r;
-		b.n = n_r;
-		b.g_cnt = g_cnt_r;
-		b.g_first = g_first_r;
-		MDB_HIP(ctx, hipMemsetAsync(g_cnt_r, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
-		MDB_HIP(ctx, hipMemsetAsync(g_first_r, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
-		const uint64_t chunks = (n_r + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, b);
-	}
-	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, (const unsigned long long *)g_cnt_r, kbits, rec, rec_n,
-		   d_joined);
-	uint32_t *h32 = (uint32_t *)ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (h32[0] & 1024u)
-		ctx->sr_valid = 0;	/* the sample missed a value outside its range: not to be reused */
-	if (h32[0] & 1024u)
-		return 1;	/* a value outside the window: the partitioned path */
-	const uint64_t G = h32[1];
-	const uint64_t joined = (uint64_t)h32[2] | ((uint64_t)h32[3] << 32);
-	if (G > cap)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
-				   (unsigned long long)G);
-	*out_groups = G;
-	if (out_joined)
-		*out_joined = joined;
-	if (G == 0)
-		return 0;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
-	if (rc)
-		return rc < 0 ? rc : -MIDORIDB_INTERNAL;
-	MDB_LAUNCH(ctx, "group_direct_counts", k_group_direct_counts, (uint32_t)((G + 255) / 256), 256, out_count, G, (const unsigned long long *)a.g_cnt,
-		   (const unsigned long long *)g_cnt_r);
-	rc = mdb_dev_sync(ctx);
-	if (rc)
-		return rc;
-	if (out_key) {
-		rc = mdb_dev_gather64(ctx, keys, NULL, out_first, G, out_key, NULL);
-		if (!rc)
-			rc = mdb_dev_sync(ctx);
-	}
-	return rc;
-}
-
-/* ------------------------------------------------------------------ GROUP BY with few distinct values, any value range
- *
- * The direct tables above need the values themselves to be close together.  A thousand customer ids scattered over the
- * int64 range are the same shape - few groups, 10^5 equal rows each - and cost 3 ms per 10^8 rows through the partitioned
- * path (a thousand hot leaves).  When a sample of the column holds few distinct values, every workgroup aggregates its
- * share of the rows in an LDS hash table keyed by the hashed value (equal values of a wave are merged first, so a hot
- * value costs one table update per wave, not one per row) and merges its table into a global one; a workgroup table that
- * fills up (the sample was wrong about the column) raises a flag and the partitioned path takes over. */
-#define GH_SLOTS 4093u		/* per workgroup (prime): 12 B/slot + ... = 64 KiB, two workgroups per CU */
-#define GH_MAX_FILL 2800u	/* distinct values a workgroup table may take */
-#define GH_GSLOTS 16381u	/* global table (prime) */
-#define GH_SAMPLE_MAX 1200u	/* distinct values among the 4096 sampled keys up to which the path is tried */
-#define GH_MERGE_ROUNDS 16
-
-__global__ __launch_bounds__(1024) void k_key_sample_distinct(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nullbits, uint64_t n,
-							       uint32_t *out)
-{
-	/* number of distinct values among GC_NARROW_SAMPLE evenly spaced non-NULL keys (an LDS set) */
-	__shared__ unsigned long long s_set[8192];
-	__shared__ uint32_t s_n, s_zero;
-	for (uint32_t i = threadIdx.x; i < 8192; i += 1024)
-		s_set[i] = 0ull;
-	if (threadIdx.x == 0)
-		s_n = s_zero = 0;
-	__syncthreads();
-	for (uint32_t t = threadIdx.x; t < GC_NARROW_SAMPLE; t += 1024) {
-		const uint64_t i = gc_sample_pos(t, n);
-		if (nullbits && mdb_bit_is_set(nullbits, i))
-			continue;
-		const uint64_t hv = mdb_fmix64((uint64_t)keys[i]);
-		if (hv == 0) {
-			if (atomicExch(&s_zero, 1u) == 0)
-				atomicAdd(&s_n, 1u);
-			continue;
-		}
-		uint32_t s = (uint32_t)(((hv >> 32) * 8192ull) >> 32);
-		for (;;) {
-			const unsigned long long old = atomicCAS(&s_set[s], 0ull, (unsigned long long)hv);
-			if (old == 0ull) {
-				atomicAdd(&s_n, 1u);
-				break;
-			}
-			if (old == hv)
-				break;
-			s = (s + 1) & 8191u;
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0)
-		out[0] = s_n;
-}
-
-struct gh_args {
-	const int64_t *keys;
-	const uint64_t *nullbits;
-	uint64_t n;
-	uint32_t null_group;
-	unsigned long long *g_key;	/* [GH_GSLOTS] hashed value, 0 = empty */
-	unsigned long long *g_cnt;	/* [GH_GSLOTS + 2]: + the value whose hash is 0, + the NULL group */
-	uint32_t *g_first;		/* [GH_GSLOTS + 2] */
-	uint32_t *status;		/* bit 11: a table filled up */
-};
-
-__global__ __launch_bounds__(GD_THREADS) void k_group_hashed(gh_args a)
-{
-	__shared__ unsigned long long s_key[GH_SLOTS];
-	__shared__ uint32_t s_cnt[GH_SLOTS + 2];	/* [GH_SLOTS] hash-0 value, [GH_SLOTS + 1] NULL group */
-	__shared__ uint32_t s_first[GH_SLOTS + 2];
-	__shared__ uint32_t s_fill, s_bad;
-	for (uint32_t i = threadIdx.x; i < GH_SLOTS + 2; i += GD_THREADS) {
-		if (i < GH_SLOTS)
-			s_key[i] = 0ull;
-		s_cnt[i] = 0;
-		s_first[i] = 0xFFFFFFFFu;
-	}
-	if (threadIdx.x == 0)
-		s_fill = s_bad = 0;
-	__syncthreads();
-	for (uint64_t row0 = (uint64_t)blockIdx.x * (2 * GD_THREADS); row0 < a.n; row0 += (uint64_t)gridDim.x * (2 * GD_THREADS)) {
-		if (s_bad)
-			break;		/* (uniform enough: read by every thread at the top of a round; a late reader only does one more round) */
-		const uint64_t i0 = row0 + 2 * (uint64_t)threadIdx.x;
-		int64_t k[2] = { 0, 0 };
-		if (i0 + 1 < a.n) {
-			const longlong2 q = *reinterpret_cast<const longlong2 *>(a.keys + i0);
-			k[0] = q.x;
-			k[1] = q.y;
-		} else if (i0 < a.n) {
-			k[0] = a.keys[i0];
-		}
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			const uint64_t row = i0 + (uint64_t)u;
-			const bool valid = row < a.n;
-			const bool isnull = valid && a.nullbits && mdb_bit_is_set(a.nullbits, row);
-			if (a.nullbits) {
-				const uint64_t nm = __ballot(isnull);
-				if (nm && a.null_group && mdb_lane() == (uint32_t)__ffsll((long long)nm) - 1u) {
-					atomicAdd(&s_cnt[GH_SLOTS + 1], (uint32_t)__popcll(nm));
-					atomicMin(&s_first[GH_SLOTS + 1], (uint32_t)row);
-				}
-			}
-			const bool act = valid && !isnull;
-			const uint64_t hv = act ? mdb_fmix64((uint64_t)k[u]) : 0ull;
-			/* equal values of the wave are merged: up to GH_MERGE_ROUNDS leaders update the table for all lanes that
-			 * hold their value; whoever is left (many distinct values in the wave: little contention) goes alone */
-			uint64_t pending = __ballot(act);
-			uint32_t mult = 1, first_row = (uint32_t)row;
-			bool mine_todo = act;
-			for (int round = 0; round < GH_MERGE_ROUNDS && pending; round++) {
-				const int leader = __ffsll((long long)pending) - 1;
-				const uint32_t llo = (uint32_t)__shfl((int)(uint32_t)hv, leader, MDB_WAVE);
-				const uint32_t lhi = (uint32_t)__shfl((int)(uint32_t)(hv >> 32), leader, MDB_WAVE);
-				const bool same = mine_todo && (uint32_t)hv == llo && (uint32_t)(hv >> 32) == lhi;
-				const uint64_t grp = __ballot(same);
-				if (same) {
-					if ((int)mdb_lane() == leader) {
-						mult = (uint32_t)__popcll(grp);		/* the leader holds the smallest row of its group (rows grow with the lane) */
-					} else {
-						mine_todo = false;
-					}
-				}
-				pending &= ~grp;	/* (the leader stays in the loop: its value cannot come up again, and all leaders then
-							 * update the table together instead of one after the other) */
-				if (__popcll(grp) < 3)
-					break;		/* the wave's values are diverse: merging more leaders costs more than the atomics it saves */
-			}
-			if (mine_todo) {
-				uint32_t s;
-				if (hv == 0) {
-					s = GH_SLOTS;
-				} else {
-					s = leaf_slot(hv, GH_SLOTS);
-					const uint32_t step = leaf_step(hv, GH_SLOTS);
-					uint32_t probe = 0;
-					for (;;) {
-						const unsigned long long old = atomicCAS(&s_key[s], 0ull, (unsigned long long)hv);
-						if (old == hv)
-							break;
-						if (old == 0ull) {
-							if (atomicAdd(&s_fill, 1u) >= GH_MAX_FILL)
-								s_bad = 1;
-							break;
-						}
-						if (++probe >= GH_SLOTS) {
-							s_bad = 1;
-							s = 0xFFFFFFFFu;
-							break;
-						}
-						s += step;
-						if (s >= GH_SLOTS)
-							s -= GH_SLOTS;
-					}
-				}
-				if (s != 0xFFFFFFFFu) {
-					atomicAdd(&s_cnt[s], mult);
-					atomicMin(&s_first[s], first_row);
-				}
-			}
-		}
-	}
-	__syncthreads();
-	if (s_bad) {
-		if (threadIdx.x == 0)
-			mdb_raise(a.status, 2048u);
-		return;
-	}
-	/* merge into the global table */
-	for (uint32_t s = threadIdx.x; s < GH_SLOTS + 2; s += GD_THREADS) {
-		const uint32_t c = s_cnt[s];
-		if (!c)
-			continue;
-		uint32_t g;
-		if (s >= GH_SLOTS) {
-			g = GH_GSLOTS + (s - GH_SLOTS);
-		} else {
-			const uint64_t hv = s_key[s];
-			g = leaf_slot(hv, GH_GSLOTS);
-			const uint32_t step = leaf_step(hv, GH_GSLOTS);
-			uint32_t probe = 0;
-			for (;;) {
-				const unsigned long long old = atomicCAS(&a.g_key[g], 0ull, (unsigned long long)hv);
-				if (old == 0ull || old == hv)
-					break;
-				if (++probe >= GH_GSLOTS) {
-					mdb_raise(a.status, 2048u);
-					g = 0xFFFFFFFFu;
-					break;
-				}
-				g += step;
-				if (g >= GH_GSLOTS)
-					g -= GH_GSLOTS;
-			}
-		}
-		if (g != 0xFFFFFFFFu) {
-			atomicAdd(&a.g_cnt[g], (unsigned long long)c);
-			atomicMin(&a.g_first[g], s_first[s]);
-		}
-	}
-}
-
-__global__ void k_group_hashed_emit(gh_args a, uint32_t kbits, unsigned long long *rec, uint32_t *rec_n)
-{
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= GH_GSLOTS + 2 || !a.g_cnt[g])
-		return;
-	rec[atomicAdd(rec_n, 1u)] = ((unsigned long long)a.g_first[g] << (64 - kbits)) | (unsigned long long)(g + 1);
-}
-
-/* 0 = done, 1 = not applicable, < 0 = error */
-static int group_hashed_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, bool null_group, uint32_t *out_first,
-			    int64_t *out_count, uint64_t cap, uint64_t *out_groups)
-{
-	if (n < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
-		return 1;
-	/* distinct values in a sample of the column, remembered like the range sample */
-	uint32_t distinct;
-	if (ctx->gh_keys == keys && ctx->gh_n == n && ++ctx->gh_uses < GC_HINT_USES) {
-		distinct = ctx->gh_distinct;
-	} else {
-		uint32_t *d = ctx->d_status + 9;
-		MDB_LAUNCH(ctx, "key_sample_distinct", k_key_sample_distinct, 1, 1024, keys, nullbits, n, d);
-		uint32_t *h = (uint32_t *)ctx->h_pinned;
-		MDB_HIP(ctx, hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		distinct = h[0];
-		ctx->gh_keys = keys;
-		ctx->gh_n = n;
-		ctx->gh_distinct = distinct;
-		ctx->gh_uses = 0;
-	}
-	if (distinct > GH_SAMPLE_MAX)
-		return 1;
-	uint32_t kbits = 0;
-	const size_t order_bytes = mdb_order_records_arena_bytes(GH_GSLOTS + 2, n, &kbits);
-	if (!order_bytes)
-		return 1;
-	int rc = mdb_arena_begin(ctx, order_bytes + 4 * mdb_align_up((GH_GSLOTS + 2) * 8) + 8192);
-	if (rc)
-		return rc;
-	gh_args a;
-	memset(&a, 0, sizeof(a));
-	a.keys = keys;
-	a.nullbits = nullbits;
-	a.n = n;
-	a.null_group = null_group ? 1u : 0u;
-	a.g_key = (unsigned long long *)mdb_arena_take(ctx, GH_GSLOTS * 8);
-	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 8);
-	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 4);
-	a.status = ctx->d_status;
-	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GH_GSLOTS + 2) * 8);
-	if (!a.g_key || !a.g_cnt || !a.g_first || !rec)
-		return -MIDORIDB_INTERNAL;
-	uint32_t *rec_n = ctx->d_status + 1;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_key, 0, GH_GSLOTS * 8, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GH_GSLOTS + 2) * 8, ctx->stream));
-	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GH_GSLOTS + 2) * 4, ctx->stream));
-	const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-	const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
-	MDB_LAUNCH(ctx, "group_hashed", k_group_hashed, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, a);
-	MDB_LAUNCH(ctx, "group_hashed_emit", k_group_hashed_emit, (GH_GSLOTS + 2 + 255) / 256, 256, a, kbits, rec, rec_n);
-	uint32_t *h32 = (uint32_t *)ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (h32[0] & 2048u) {
-		ctx->gh_distinct = 0xFFFFFFFFu;	/* the sample was wrong about this column: not tried again while it is remembered */
-		return 1;
-	}
-	const uint64_t G = h32[1];
-	if (G > cap)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
-				   (unsigned long long)G);
-	*out_groups = G;
-	if (G == 0)
-		return 0;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
-	if (rc)
-		return rc < 0 ? rc : -MIDORIDB_INTERNAL;
-	MDB_LAUNCH(ctx, "group_direct_counts", k_group_direct_counts, (uint32_t)((G + 255) / 256), 256, out_count, G, (const unsigned long long *)a.g_cnt,
-		   (const unsigned long long *)NULL);
-	return mdb_dev_sync(ctx);
-}
-
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,
 				   uint32_t *out_first, int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
@@ -4028,1169 +2888,4 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	*out_groups = 0;
 	return group_count_common(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups,
 				  NULL);
-}
-
-/* ------------------------------------------------------------------ materialising join: count phase */
-
-/* ------------------------------------------------------------------ materialising join, unique right keys
- *
- * The common shape (primary key on the right: BASELINE configs 2 and 5): every left row matches at most one right
- * row, so a pair is fully described by ONE 64-bit record (left row id, right row id + 1) - exactly the shape of the
- * group records above.  One persistent kernel builds the per-leaf table (key -> right row id), probes it with the
- * left rows and appends the records; the ordering sort + k_order_leaf then deliver (l, r) in left-row order.  No
- * match-count array, no scan, no second table build.  A duplicate right key (or any overflow) is flagged and the
- * caller falls back to the general count / scan / emit path.
- */
-struct pu_args {
-	const uint64_t *hv_l;
-	const uint32_t *rid_l;
-	const uint32_t *off_l;
-	const uint32_t *cnt_l;
-	uint32_t cap_l;
-	const uint64_t *hv_r;
-	const uint32_t *rid_r;
-	const uint32_t *off_r;
-	const uint32_t *cnt_r;
-	uint32_t cap_r;
-	unsigned long long *rec;
-	uint32_t *rec_count;		/* list slots handed out (chunked, zero-filled gaps) */
-	uint32_t *rec_valid;		/* pairs */
-	uint32_t rec_cap;
-	uint32_t kbits;
-	uint32_t *status;		/* bit 0 table overflow, bit 3 list exhausted, bit 5 duplicate right key */
-	uint32_t nleaves;
-};
-
-/* NARROW: both sides travel as hash32 << 32 | row id words (no row-id arrays; see the narrow form of the group count) */
-template <bool NARROW>
-__global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
-{
-	__shared__ unsigned long long s_key[GC_SLOTS];
-	__shared__ uint32_t s_val[GC_SLOTS + 1];	/* right row id + 1; [GC_SLOTS] = the key whose hash is 0 (0 = absent) */
-	__shared__ uint32_t s_chunk[4];			/* [0] base [1] used [2] size [3] pairs */
-	__shared__ uint32_t s_abort;			/* a duplicate right key (or a full table) was met: this is not a unique-key join */
-
-	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
-		if (s < GC_SLOTS)
-			s_key[s] = 0ull;
-		s_val[s] = 0;
-	}
-	if (threadIdx.x < 4)
-		s_chunk[threadIdx.x] = 0;
-	if (threadIdx.x == 0)
-		s_abort = 0;
-	uint32_t npairs = 0;
-	__syncthreads();
-	for (uint32_t leaf = blockIdx.x; leaf < a.nleaves; leaf += gridDim.x) {
-		/* The verdict "not unique" is raised ONCE per workgroup and ends its work (one global atomic per duplicate row -
-		 * 10^8 of them on one address for a right table with 16 rows per key - made this failed attempt cost 18 ms).
-		 * Workgroups that meet no duplicate themselves run to the end: looking at the global flag once per leaf put an
-		 * uncached round trip on every leaf's critical path (0.24 -> 0.45 ms per 10^7 x 10^7 join). */
-		if (s_abort) {		/* uniform: read after the barriers that ended the previous leaf */
-			if (threadIdx.x == 0)
-				atomicOr(a.status, s_abort);
-			break;
-		}
-		uint32_t l0, l1, r0, r1;
-		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
-		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
-		if (l0 == l1 || r0 == r1)
-			continue;	/* uniform */
-		/* request the first batch of both sides before anything else */
-		uint64_t hr[LEAF_BATCH], hl[LEAF_BATCH];
-		uint32_t rr[LEAF_BATCH], rl[LEAF_BATCH];
-#pragma unroll
-		for (int u = 0; u < LEAF_BATCH; u++) {
-			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
-			const uint32_t i = l0 + (uint32_t)u * GC_THREADS + threadIdx.x;
-			hr[u] = j < r1 ? a.hv_r[j] : 0;
-			hl[u] = i < l1 ? a.hv_l[i] : 0;
-			rr[u] = rl[u] = 0;
-			if (!NARROW) {
-				rr[u] = j < r1 ? a.rid_r[j] : 0;
-				rl[u] = i < l1 ? a.rid_l[i] : 0;
-			}
-		}
-		{	/* list space for at most one record per left row (chunked reservation as in k_leaf_group_count) */
-			const uint32_t need = (l1 - l0) + 1;
-			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
-			if (used + need > size) {
-				for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
-					a.rec[base + i] = 0ull;
-				__syncthreads();
-				if (threadIdx.x == 0) {
-					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
-					const uint32_t nb = atomicAdd(a.rec_count, want);
-					if (nb + want > a.rec_cap) {
-						mdb_raise(a.status, 8u);
-						s_chunk[0] = 0;
-						s_chunk[2] = 0;
-					} else {
-						s_chunk[0] = nb;
-						s_chunk[2] = want;
-					}
-					s_chunk[1] = 0;
-				}
-			}
-		}
-		/* build: right rows (unique keys expected) */
-		uint32_t own[LEAF_BATCH];
-		const bool by_owner = (r1 - r0) <= GC_THREADS * LEAF_BATCH;
-		for (uint32_t base = r0; base < r1; base += GC_THREADS * LEAF_BATCH) {
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++) {
-				const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-				if (base != r0) {
-					hr[u] = j < r1 ? a.hv_r[j] : 0;
-					if (!NARROW)
-						rr[u] = j < r1 ? a.rid_r[j] : 0;
-				}
-				if (base == r0)
-					own[u] = 0xFFFFFFFFu;
-				if (j >= r1)
-					continue;
-				/* the words are decoded here, where they are used (not at load time: the first batch is in flight) */
-				const uint64_t key_r = NARROW ? gc_narrow_hv(hr[u]) : hr[u];
-				const uint32_t rid_r = NARROW ? (uint32_t)hr[u] : rr[u];
-				if (key_r == 0) {
-					if (atomicExch(&s_val[GC_SLOTS], rid_r + 1u) != 0)
-						s_abort = 32u;
-					continue;
-				}
-				bool created = false;
-				const uint32_t s = leaf_insert(s_key, GC_SLOTS, key_r, &created);
-				if (s == 0xFFFFFFFFu) {
-					s_abort = 1u;
-				} else if (!created) {
-					s_abort = 32u;		/* the key is already there: not a unique-key join */
-				} else {
-					s_val[s] = rid_r + 1u;
-					if (base == r0)
-						own[u] = s;
-				}
-			}
-		}
-		__syncthreads();
-		/* probe: left rows -> records */
-		const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
-		for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++) {
-				const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
-				if (base != l0) {
-					hl[u] = i < l1 ? a.hv_l[i] : 0;
-					if (!NARROW)
-						rl[u] = i < l1 ? a.rid_l[i] : 0;
-				}
-				unsigned long long recv = 0;
-				if (i < l1) {
-					const uint64_t key_l = NARROW ? gc_narrow_hv(hl[u]) : hl[u];
-					const uint32_t rid_l = NARROW ? (uint32_t)hl[u] : rl[u];
-					uint32_t s = GC_SLOTS;
-					if (key_l != 0)
-						s = leaf_find(s_key, GC_SLOTS, key_l);
-					const uint32_t v = s != 0xFFFFFFFFu ? s_val[s] : 0u;
-					if (v)
-						recv = ((unsigned long long)rid_l << (64 - a.kbits)) | v;
-				}
-				const uint64_t m = __ballot(recv != 0ull);
-				if (m) {
-					const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-					uint32_t wbase = 0;
-					if (mdb_lane() == leader)
-						wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
-					wbase = __shfl(wbase, (int)leader, MDB_WAVE);
-					if (recv) {
-						const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-						if (pos < csize)
-							a.rec[cbase + pos] = recv;
-						npairs++;
-					}
-				}
-			}
-		}
-		__syncthreads();
-		/* clear what this leaf wrote */
-		if (by_owner) {
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++)
-				if (own[u] != 0xFFFFFFFFu) {
-					s_key[own[u]] = 0ull;
-					s_val[own[u]] = 0;
-				}
-			if (threadIdx.x == 0)
-				s_val[GC_SLOTS] = 0;
-		} else {
-			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
-				if (s < GC_SLOTS)
-					s_key[s] = 0ull;
-				s_val[s] = 0;
-			}
-		}
-		__syncthreads();
-	}
-	{
-		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
-		for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
-			a.rec[base + i] = 0ull;
-		if (npairs)
-			atomicAdd(&s_chunk[3], npairs);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0 && s_abort)
-		atomicOr(a.status, s_abort);	/* (also when it was raised by the workgroup's last leaf) */
-	if (threadIdx.x == 0 && s_chunk[3])
-		atomicAdd(a.rec_valid, s_chunk[3]);
-}
-
-struct pj_args {
-	const uint64_t *hv_l;
-	const uint32_t *rid_l;
-	const uint32_t *off_l;		/* exact leaf offsets, or (cnt, cap) of the fixed-capacity layout, as in gc_args */
-	const uint32_t *cnt_l;
-	uint32_t cap_l;
-	const uint64_t *hv_r;
-	const uint32_t *rid_r;
-	const uint32_t *off_r;
-	const uint32_t *cnt_r;
-	uint32_t cap_r;
-	uint32_t *match;	/* [n_l + 1]: count phase writes matches per left row; scanned into offsets */
-	uint32_t *out_l;
-	uint32_t *out_r;
-	uint32_t *status;
-	unsigned long long *total64;	/* 64-bit sum of all match counts (guards the 32-bit offsets) */
-	uint32_t nleaves;
-};
-
-__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
-{
-	__shared__ unsigned long long s_key[PJ_SLOTS];
-	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* [PJ_SLOTS] = the key with hash 0 */
-	__shared__ unsigned long long s_total;
-
-	const uint32_t leaf = blockIdx.x;
-	uint32_t l0, l1, r0, r1;
-	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
-	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
-	if (l0 == l1 || r0 == r1)
-		return;
-	if (threadIdx.x == 0 && r1 - r0 > PJ_CHUNK)
-		mdb_raise(a.status, 16u);	/* the emit kernel will sweep this leaf's right rows in several chunks: they must be in row-id order */
-	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
-		if (s < PJ_SLOTS)
-			s_key[s] = 0ull;
-		s_cnt[s] = 0;
-	}
-	if (threadIdx.x == 0)
-		s_total = 0ull;
-	__syncthreads();
-	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
-		const uint64_t hv = a.hv_r[j];
-		uint32_t s = PJ_SLOTS;
-		if (hv != 0) {
-			s = leaf_insert(s_key, PJ_SLOTS, hv);
-			if (s == 0xFFFFFFFFu) {
-				mdb_raise(a.status, 1u);
-				continue;
-			}
-		}
-		atomicAdd(&s_cnt[s], 1u);
-	}
-	__syncthreads();
-	unsigned long long mine = 0;
-	for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
-		const uint64_t hv = a.hv_l[i];
-		uint32_t s = PJ_SLOTS;
-		if (hv != 0)
-			s = leaf_find(s_key, PJ_SLOTS, hv);
-		if (s != 0xFFFFFFFFu) {
-			const uint32_t m = s_cnt[s];
-			if (m) {
-				a.match[a.rid_l[i]] = m;
-				mine += m;
-			}
-		}
-	}
-	/* one global atomic per workgroup (a per-thread atomic on this single address serialised 10^7 updates
-	 * and cost 1.5 ms at 10^7 rows - profiles/r01/operators.json history) */
-	if (mine)
-		atomicAdd(&s_total, mine);
-	__syncthreads();
-	if (threadIdx.x == 0 && s_total)
-		atomicAdd(a.total64, s_total);
-}
-
-/* ------------------------------------------------------------------ materialising join: emit phase
- *
- * Per leaf: table of the right side's distinct keys; the right rows are swept in chunks of
- * PJ_CHUNK.  Inside a chunk the row ids of each key are placed contiguously (LDS counting sort by
- * slot; ranks by comparing row ids, so every key's list is ascending = right-minor order), then
- * every left row of the leaf copies its key's list to out[offset(left row) + matches so far].
- */
-__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
-{
-	__shared__ unsigned long long s_key[PJ_SLOTS];
-	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* matches of the slot inside the current chunk */
-	__shared__ uint32_t s_start[PJ_SLOTS + 1];	/* first list position of the slot inside the chunk */
-	__shared__ uint32_t s_cur[PJ_SLOTS + 1];
-	__shared__ uint32_t s_prior[PJ_SLOTS + 1];	/* matches of the slot in earlier chunks */
-	__shared__ uint32_t s_tmp[PJ_CHUNK];
-	__shared__ uint32_t s_sorted[PJ_CHUNK];
-	__shared__ uint16_t s_eslot[PJ_CHUNK];
-	__shared__ uint32_t s_scan[32];
-
-	const uint32_t leaf = blockIdx.x;
-	uint32_t l0, l1, r0, r1;
-	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
-	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
-	if (l0 == l1 || r0 == r1)
-		return;
-	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
-		if (s < PJ_SLOTS)
-			s_key[s] = 0ull;
-		s_prior[s] = 0;
-	}
-	__syncthreads();
-	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
-		const uint64_t hv = a.hv_r[j];
-		if (hv != 0 && leaf_insert(s_key, PJ_SLOTS, hv) == 0xFFFFFFFFu)
-			mdb_raise(a.status, 1u);
-	}
-	__syncthreads();
-
-	constexpr uint32_t PER_T = (PJ_SLOTS + 1 + LEAF_THREADS - 1) / LEAF_THREADS;	/* slots scanned per thread */
-	for (uint32_t c0 = r0; c0 < r1; c0 += PJ_CHUNK) {
-		const uint32_t clen = (r1 - c0) < PJ_CHUNK ? (r1 - c0) : PJ_CHUNK;
-		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
-			s_cnt[s] = 0;
-			s_cur[s] = 0;
-		}
-		__syncthreads();
-		/* count the chunk's rows per slot */
-		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
-			const uint64_t hv = a.hv_r[c0 + e];
-			uint32_t s = PJ_SLOTS;
-			if (hv != 0)
-				s = leaf_find(s_key, PJ_SLOTS, hv);
-			if (s == 0xFFFFFFFFu)
-				s = PJ_SLOTS;	/* only after an overflow, which fails the whole call anyway */
-			s_eslot[e] = (uint16_t)s;
-			atomicAdd(&s_cnt[s], 1u);
-		}
-		__syncthreads();
-		/* exclusive scan of the slot counts -> list starts */
-		{
-			uint32_t v[PER_T], sum = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < PER_T; k++) {
-				const uint32_t s = threadIdx.x * PER_T + k;
-				v[k] = s <= PJ_SLOTS ? s_cnt[s] : 0;
-				sum += v[k];
-			}
-			uint32_t total;
-			uint32_t run = mdb_block_excl_scan(sum, s_scan, &total);
-#pragma unroll
-			for (uint32_t k = 0; k < PER_T; k++) {
-				const uint32_t s = threadIdx.x * PER_T + k;
-				if (s <= PJ_SLOTS)
-					s_start[s] = run;
-				run += v[k];
-			}
-		}
-		__syncthreads();
-		/* place row ids by slot (arbitrary order inside a list) */
-		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
-			const uint32_t s = s_eslot[e];
-			const uint32_t pos = s_start[s] + atomicAdd(&s_cur[s], 1u);
-			s_tmp[pos] = a.rid_r[c0 + e];
-		}
-		__syncthreads();
-		/* rank every row id inside its list (row ids are distinct) -> ascending lists */
-		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
-			const uint32_t s = s_eslot[e];
-			const uint32_t rid = a.rid_r[c0 + e];
-			const uint32_t b = s_start[s], m = s_cnt[s];
-			uint32_t rank = 0;
-			for (uint32_t k = 0; k < m; k++)
-				rank += s_tmp[b + k] < rid;
-			s_sorted[b + rank] = rid;
-		}
-		__syncthreads();
-		/* every left row copies its key's list */
-		for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
-			const uint64_t hv = a.hv_l[i];
-			uint32_t s = PJ_SLOTS;
-			if (hv != 0)
-				s = leaf_find(s_key, PJ_SLOTS, hv);
-			if (s == 0xFFFFFFFFu)
-				continue;
-			const uint32_t m = s_cnt[s];
-			if (!m)
-				continue;
-			const uint32_t rid = a.rid_l[i];
-			const uint32_t base = a.match[rid] + s_prior[s];
-			const uint32_t b = s_start[s];
-			for (uint32_t k = 0; k < m; k++) {
-				a.out_l[base + k] = rid;
-				a.out_r[base + k] = s_sorted[b + k];
-			}
-		}
-		__syncthreads();
-		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS)
-			s_prior[s] += s_cnt[s];
-		__syncthreads();
-	}
-}
-
-/* 0 = done, 1 = not applicable (overflow: use the general path), 2 = a key outside the window met the narrow form (call
- * again with narrow = false), 3 = a right key occurs more than once (not a unique-key join this way round), < 0 = error */
-static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			     const uint64_t *null_r, uint64_t n_r, bool narrow, int64_t base, uint32_t **out_l, uint32_t **out_r,
-			     uint64_t *out_count)
-{
-	int b1, b2, sb1 = 0, sb2 = 0;
-	uint32_t kbits = 0;
-	mdb_choose_bits(n_r, GC_TARGET, &b1, &b2);
-	if ((n_r >> (b1 + b2)) > (uint64_t)GC_SLOTS * 7 / 10 || !order_bits(n_l, &kbits, &sb1, &sb2))
-		return 1;
-	const uint64_t rec_cap = gc_rec_capacity(ctx, n_l);
-	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, true) + mdb_partition_arena_bytes(n_r, b1, b2, true, true) +
-		      mdb_align_up(rec_cap * 8) + order_records_arena_bytes(rec_cap, n_l, kbits, sb1, sb2) + 4096;
-	int rc = mdb_arena_begin(ctx, need);
-	if (rc)
-		return rc;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	mdb_part_result pl, pr;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, !narrow, false, true, &pr, narrow ? 1 : 0, false, base);
-	if (rc)
-		return rc;
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, !narrow, false, true, &pl, narrow ? 1 : 0, false, base);
-	if (rc)
-		return rc;
-	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, rec_cap * 8);
-	if (!rec)
-		return -MIDORIDB_INTERNAL;
-	pu_args a;
-	a.hv_l = pl.hv;
-	a.rid_l = pl.rid;
-	a.off_l = pl.leaf_off;
-	a.cnt_l = pl.leaf_cnt;
-	a.cap_l = pl.leaf_cap;
-	a.hv_r = pr.hv;
-	a.rid_r = pr.rid;
-	a.off_r = pr.leaf_off;
-	a.cnt_r = pr.leaf_cnt;
-	a.cap_r = pr.leaf_cap;
-	a.rec = rec;
-	a.rec_count = ctx->d_status + 1;
-	a.rec_valid = ctx->d_status + 8;
-	a.rec_cap = (uint32_t)rec_cap;
-	a.kbits = kbits;
-	a.status = ctx->d_status;
-	a.nleaves = pl.nleaves;
-	{
-		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
-		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
-		if (narrow) {
-			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<true>, grid, GC_THREADS, a);
-		} else {
-			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<false>, grid, GC_THREADS, a);
-		}
-	}
-	uint64_t *h = ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint32_t status = (uint32_t)h[1];
-	const uint64_t list_len = h[1] >> 32, J = (uint32_t)h[5];
-	if (status & 128u)
-		return 2;
-	if (status & 32u)
-		return 3;	/* a right key occurs more than once */
-	if (status & (1u | 2u | 8u))
-		return 1;
-	*out_count = J;
-	if (J == 0)
-		return 0;
-	uint32_t *ol = NULL, *orr = NULL;
-	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
-		if (ol)
-			(void)mdb_cached_free(ctx, ol);
-		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
-	}
-	rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, ol, NULL, orr, NULL, NULL);
-	if (rc) {
-		(void)mdb_cached_free(ctx, ol);
-		(void)mdb_cached_free(ctx, orr);
-		return rc;
-	}
-	*out_l = ol;
-	*out_r = orr;
-	return 0;
-}
-
-/* ------------------------------------------------------------------ unique right keys in a window of at most 2^24 values: ONE level
- *
- * The primary-key join of BASELINE configs[1] (10^7 x 10^7 rows, 4 result columns).  Through the path above it is two
- * partition levels per table, a hashed leaf table, one 8-byte record per pair and an ordering sort of the records by left row
- * id: 0.46 ms of kernels before the projection.  When the key sample offers a compact window of at most 2^24 values (the
- * k-bit bijection of the compact narrow form) both tables are partitioned ONCE by 9 bits (mdb_part_filter.level0_only) and
- * one 1024-thread workgroup joins a whole digit: a table of 2^(k-9) <= 2^15 LDS words indexed by the remaining hash bits
- * holds right row id + 1 - plain stores, no atomics: that the right keys are unique is checked afterwards (the number of
- * occupied entries must equal the number of right rows; otherwise status bit 5 and the caller takes the other paths).  A
- * left row reads its entry and writes the partner to match[left row id]: a random 4-byte write, but into an array of 4 n_L
- * bytes that the Infinity Cache holds (the path is taken up to 2^25 left rows).  The pairs in the reference's order - left
- * row ascending - are then the non-zero entries of match[] in index order: a count / scan / emit compaction instead of a
- * sort.  (The scatter is what the kernel's time is made of: 0.16 ms per 10^7 x 10^7 rows where the two streams need 0.06;
- * non-temporal stores took 0.33 - the L2s merge the writes of neighbouring rows, which a digit's sub-regions deliver in
- * roughly ascending order.) */
-#define PW_THREADS 1024
-#define PW_MIN_REM 10u
-#define PW_MAX_REM 15u
-#define PW_UNROLL 4
-#define PW_MAX_LEFT (1ull << 25)
-#define MC_THREADS 256
-#define MC_PER_THREAD 16
-#define MC_BLOCK (MC_THREADS * MC_PER_THREAD)
-
-struct pw_args {
-	const uint64_t *hv_l, *hv_r;		/* first-level output: hash32 << 32 | row id */
-	const uint32_t *cnt_l, *cnt_r;		/* rows per sub-region: [sub * nleaves + digit] */
-	uint32_t cap_l, cap_r, nleaves, nsub;
-	uint32_t *match;			/* [n_l], zeroed: right row id + 1 of the left row's partner */
-	unsigned long long *joined;
-	uint32_t *status;
-};
-
-__global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_wide(pw_args a, uint32_t rem, uint32_t shift)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t pw_tab[];
-	__shared__ unsigned long long s_red[PW_THREADS / 64];
-	const uint32_t T = 1u << rem, mask = T - 1u, leaf = blockIdx.x;
-	for (uint32_t s = threadIdx.x; s < T; s += PW_THREADS)
-		pw_tab[s] = 0u;
-	__syncthreads();
-	uint32_t rows_r = 0;
-	for (uint32_t sub = 0; sub < a.nsub; sub++) {
-		const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
-		const uint64_t *const src = a.hv_r + (size_t)(leaf * a.nsub + sub) * a.cap_r;
-		rows_r += c;
-		for (uint32_t i0 = 0; i0 < c; i0 += 2u * PW_THREADS * PW_UNROLL) {	/* uniform trip count */
-			ulonglong2 v[PW_UNROLL];
-#pragma unroll
-			for (int u = 0; u < PW_UNROLL; u++) {
-				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
-				v[u] = make_ulonglong2(0ull, 0ull);
-				if (i < c)
-					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
-			}
-#pragma unroll
-			for (int u = 0; u < PW_UNROLL; u++) {
-				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
-				if (i < c)
-					pw_tab[((uint32_t)(v[u].x >> 32) >> shift) & mask] = (uint32_t)v[u].x + 1u;
-				if (i + 1 < c)
-					pw_tab[((uint32_t)(v[u].y >> 32) >> shift) & mask] = (uint32_t)v[u].y + 1u;
-			}
-		}
-	}
-	__syncthreads();
-	/* unique right keys: every right row has its own entry */
-	unsigned long long occupied = 0;
-	for (uint32_t s = threadIdx.x; s < T; s += PW_THREADS)
-		occupied += pw_tab[s] != 0u;
-	occupied = lw_block_sum(occupied, s_red);
-	if (occupied != rows_r) {
-		if (threadIdx.x == 0)
-			mdb_raise(a.status, 32u);
-		return;
-	}
-	unsigned long long pairs = 0;
-	for (uint32_t sub = 0; sub < a.nsub; sub++) {
-		const uint32_t c0 = a.cnt_l[sub * a.nleaves + leaf], c = c0 < a.cap_l ? c0 : a.cap_l;
-		const uint64_t *const src = a.hv_l + (size_t)(leaf * a.nsub + sub) * a.cap_l;
-		for (uint32_t i0 = 0; i0 < c; i0 += 2u * PW_THREADS * PW_UNROLL) {
-			ulonglong2 v[PW_UNROLL];
-#pragma unroll
-			for (int u = 0; u < PW_UNROLL; u++) {
-				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
-				v[u] = make_ulonglong2(0ull, 0ull);
-				if (i < c)
-					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
-			}
-#pragma unroll
-			for (int u = 0; u < PW_UNROLL; u++) {
-				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
-				const unsigned long long w[2] = { v[u].x, v[u].y };
-#pragma unroll
-				for (int k = 0; k < 2; k++)
-					if (i + k < c) {
-						const uint32_t r = pw_tab[((uint32_t)(w[k] >> 32) >> shift) & mask];
-						if (r) {
-							a.match[(uint32_t)w[k]] = r;
-							pairs++;
-						}
-					}
-			}
-		}
-	}
-	pairs = lw_block_sum(pairs, s_red);
-	if (threadIdx.x == 0 && pairs)
-		atomicAdd(a.joined, pairs);
-}
-
-/* non-zero entries per block of MC_BLOCK entries (lane-interleaved 16-byte loads: a wave reads 1 KiB per instruction) */
-__global__ __launch_bounds__(MC_THREADS) void k_match_count(const uint32_t *__restrict__ match, uint32_t n, uint32_t *__restrict__ blk)
-{
-	__shared__ uint32_t s_tmp[32];
-	uint32_t c = 0;
-	if ((uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n) {	/* (uniform) a full block: its loads are issued together */
-		uint4 v[MC_PER_THREAD / 4];
-#pragma unroll
-		for (int q = 0; q < MC_PER_THREAD / 4; q++)
-			v[q] = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
-#pragma unroll
-		for (int q = 0; q < MC_PER_THREAD / 4; q++)
-			c += (v[q].x != 0u) + (v[q].y != 0u) + (v[q].z != 0u) + (v[q].w != 0u);
-	} else {
-#pragma unroll
-		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
-			const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
-			if (i + 3 < n) {
-				const uint4 v = *reinterpret_cast<const uint4 *>(match + i);
-				c += (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
-			} else {
-				for (uint32_t k = i; k < n && k < i + 4; k++)
-					c += match[k] != 0u;
-			}
-		}
-	}
-	uint32_t total;
-	(void)mdb_block_excl_scan(c, s_tmp, &total);
-	if (threadIdx.x == 0)
-		blk[blockIdx.x] = total;
-}
-
-/* the pairs in left-row order: (i, match[i] - 1) for every non-zero entry.  The block's entries are loaded lane-interleaved
- * (chunk q = entries [q * 1024, q * 1024 + 1024) of the block, 4 consecutive ones per thread), ranked chunk by chunk, staged
- * in LDS at their ranks and written with consecutive threads on consecutive pairs (thread-contiguous loads and stores - 64
- * scattered 4-byte accesses per instruction - took 0.10 ms per 10^7 entries instead of 0.03). */
-__global__ __launch_bounds__(MC_THREADS) void k_match_emit(const uint32_t *__restrict__ match, uint32_t n, const uint32_t *__restrict__ blk_start,
-							   uint32_t *__restrict__ out_l, uint32_t *__restrict__ out_r)
-{
-	__shared__ uint32_t s_tmp[32];
-	__shared__ uint32_t s_l[MC_BLOCK], s_r[MC_BLOCK];
-	uint32_t m[MC_PER_THREAD];
-	uint32_t run = 0;
-	const bool full = (uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n;	/* (uniform) */
-	if (full) {
-#pragma unroll
-		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
-			m[4 * q] = v.x;
-			m[4 * q + 1] = v.y;
-			m[4 * q + 2] = v.z;
-			m[4 * q + 3] = v.w;
-		}
-	}
-#pragma unroll
-	for (int q = 0; q < MC_PER_THREAD / 4 && !full; q++) {
-		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
-		uint4 v = make_uint4(0u, 0u, 0u, 0u);
-		if (i + 3 < n) {
-			v = *reinterpret_cast<const uint4 *>(match + i);
-		} else {
-			if (i < n)
-				v.x = match[i];
-			if (i + 1 < n)
-				v.y = match[i + 1];
-			if (i + 2 < n)
-				v.z = match[i + 2];
-		}
-		m[4 * q] = v.x;
-		m[4 * q + 1] = v.y;
-		m[4 * q + 2] = v.z;
-		m[4 * q + 3] = v.w;
-	}
-#pragma unroll
-	for (int q = 0; q < MC_PER_THREAD / 4; q++) {
-		const uint32_t c = (m[4 * q] != 0u) + (m[4 * q + 1] != 0u) + (m[4 * q + 2] != 0u) + (m[4 * q + 3] != 0u);
-		uint32_t total;
-		uint32_t pos = run + mdb_block_excl_scan(c, s_tmp, &total);
-		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-			if (m[4 * q + k]) {
-				s_l[pos] = i + (uint32_t)k;
-				s_r[pos] = m[4 * q + k] - 1u;
-				pos++;
-			}
-		run += total;
-	}
-	__syncthreads();
-	const uint32_t start = blk_start[blockIdx.x];
-	for (uint32_t p = threadIdx.x; p < run; p += MC_THREADS) {
-		out_l[start + p] = s_l[p];
-		out_r[start + p] = s_r[p];
-	}
-}
-
-/* 0 = done, 1 = not applicable (a first-level region overflowed), 2 = a key outside the window, 3 = a right key occurs more
- * than once, < 0 = error */
-static int join_pairs_unique_wide(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-				  const uint64_t *null_r, uint64_t n_r, uint32_t kbits, int64_t lo, uint32_t **out_l, uint32_t **out_r,
-				  uint64_t *out_count)
-{
-	const int b1 = 9;
-	const uint32_t rem = kbits - (uint32_t)b1, shift = 32u - kbits;
-	const uint32_t nb = (uint32_t)((n_l + MC_BLOCK - 1) / MC_BLOCK);
-	const size_t need = mdb_partition_level0_arena_bytes(n_l, b1) + mdb_partition_level0_arena_bytes(n_r, b1) + mdb_align_up(n_l * 4) +
-			    mdb_align_up(((size_t)nb + 2) * 4) + mdb_align_up(mdb_scan_scratch_words((uint64_t)nb + 1) * 4) + 8192;
-	int rc = mdb_arena_begin(ctx, need);
-	if (rc)
-		return rc;
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	mdb_part_filter flt;
-	memset(&flt, 0, sizeof(flt));
-	flt.level0_only = true;
-	mdb_part_result pl, pr;
-	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, 0, false, false, true, &pr, 1, false, lo, kbits, &flt);
-	if (rc)
-		return rc;
-	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, 0, false, false, true, &pl, 1, false, lo, kbits, &flt);
-	if (rc)
-		return rc;
-	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
-	uint32_t *blk = (uint32_t *)mdb_arena_take(ctx, ((size_t)nb + 2) * 4);
-	uint32_t *blk_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nb + 1) * 4);
-	if (!match || !blk || !blk_tmp)
-		return -MIDORIDB_INTERNAL;
-	if (!pl.nsub || !pr.nsub || pl.nsub != pr.nsub || pl.nleaves != pr.nleaves || pl.w32 || pr.w32)
-		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level unique-key join: the tables are not in the first-level layout");
-	MDB_HIP(ctx, hipMemsetAsync(match, 0, n_l * 4, ctx->stream));
-	pw_args a;
-	a.hv_l = pl.hv;
-	a.hv_r = pr.hv;
-	a.cnt_l = pl.leaf_cnt;
-	a.cnt_r = pr.leaf_cnt;
-	a.cap_l = pl.leaf_cap;
-	a.cap_r = pr.leaf_cap;
-	a.nleaves = pl.nleaves;
-	a.nsub = pl.nsub;
-	a.match = match;
-	a.joined = (unsigned long long *)(ctx->d_status + 2);
-	a.status = ctx->d_status;
-	const size_t lds = (size_t)4 << rem;
-	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	MDB_LAUNCH_LDS(ctx, "leaf_pairs_wide", k_leaf_pairs_wide, pl.nleaves, PW_THREADS, lds, a, rem, shift);
-	/* the compaction's first half needs nothing from the host */
-	MDB_LAUNCH(ctx, "match_count", k_match_count, nb, MC_THREADS, match, (uint32_t)n_l, blk);
-	MDB_HIP(ctx, hipMemsetAsync(blk + nb, 0, 4, ctx->stream));
-	rc = mdb_scan_u32_inplace(ctx, blk, (uint64_t)nb + 1, blk_tmp);
-	if (rc)
-		return rc;
-	uint64_t *h = ctx->h_pinned;
-	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint32_t status = (uint32_t)h[1];
-	const uint64_t J = h[2];
-	if (status & 128u)
-		return 2;
-	if (status & 32u)
-		return 3;
-	if (status & 2u)
-		return 1;
-	*out_count = J;
-	if (J == 0)
-		return 0;
-	uint32_t *ol = NULL, *orr = NULL;
-	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
-		if (ol)
-			(void)mdb_cached_free(ctx, ol);
-		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
-	}
-	MDB_LAUNCH(ctx, "match_emit", k_match_emit, nb, MC_THREADS, match, (uint32_t)n_l, blk, ol, orr);
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*out_l = ol;
-	*out_r = orr;
-	return 0;
-}
-
-#define SORT_SWAP_MIN_ROWS (1u << 18)
-
-/* ------------------------------------------------------------------ tiny materialising join: one kernel, one workgroup
- *
- * The reference's own test cases join a handful of rows (tests/engine/executor_select.c:102-260).  Up to TINY_ROWS rows per
- * table the right keys sit in LDS and every left row simply walks over them - twice: once to count its matches, once,
- * after a prefix sum over the left rows, to write its pairs - which is the reference's nested loop and delivers its
- * left-major / right-minor order by construction.  All lanes read the same right row at the same time (an LDS broadcast). */
-#define TINY_PAIRS_CAP 65536u
-
-struct tinyp_args {
-	const int64_t *keys_l;
-	const uint64_t *null_l;
-	uint32_t n_l;
-	const int64_t *keys_r;
-	const uint64_t *null_r;
-	uint32_t n_r;
-	uint32_t *out_l, *out_r;
-	uint32_t cap;
-	uint32_t *status;	/* [0] bit 12: more pairs than cap, [1] pairs */
-};
-
-__global__ __launch_bounds__(GC_THREADS) void k_tiny_join_pairs(tinyp_args a)
-{
-	__shared__ int64_t s_kr[TINY_ROWS];
-	__shared__ uint8_t s_nr[TINY_ROWS];
-	__shared__ uint32_t s_tmp[32];
-	for (uint32_t j = threadIdx.x; j < a.n_r; j += GC_THREADS) {
-		s_kr[j] = a.keys_r[j];
-		s_nr[j] = a.null_r && mdb_bit_is_set(a.null_r, j);
-	}
-	__syncthreads();
-	int64_t kl[LEAF_BATCH];
-	bool ok[LEAF_BATCH];
-	uint32_t m[LEAF_BATCH];
-#pragma unroll
-	for (int u = 0; u < LEAF_BATCH; u++) {
-		const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
-		ok[u] = i < a.n_l && !(a.null_l && mdb_bit_is_set(a.null_l, i));
-		kl[u] = ok[u] ? a.keys_l[i] : 0;
-		m[u] = 0;
-	}
-	for (uint32_t j = 0; j < a.n_r; j++) {
-		const int64_t k = s_kr[j];
-		const bool live = !s_nr[j];
-#pragma unroll
-		for (int u = 0; u < LEAF_BATCH; u++)
-			m[u] += ok[u] && live && kl[u] == k;
-	}
-	uint32_t base = 0, off[LEAF_BATCH];
-#pragma unroll
-	for (int u = 0; u < LEAF_BATCH; u++) {	/* rows in index order: u = 0 covers rows 0 .. GC_THREADS - 1 */
-		uint32_t total;
-		off[u] = base + mdb_block_excl_scan(m[u], s_tmp, &total);
-		base += total;
-	}
-	if (base <= a.cap) {
-		for (uint32_t j = 0; j < a.n_r; j++) {
-			const int64_t k = s_kr[j];
-			const bool live = !s_nr[j];
-#pragma unroll
-			for (int u = 0; u < LEAF_BATCH; u++)
-				if (ok[u] && live && kl[u] == k) {
-					a.out_l[off[u]] = threadIdx.x + (uint32_t)u * GC_THREADS;
-					a.out_r[off[u]] = j;
-					off[u]++;
-				}
-		}
-	}
-	if (threadIdx.x == 0) {
-		a.status[0] = base > a.cap ? 4096u : 0u;
-		a.status[1] = base;
-	}
-}
-
-/* 0 = done, 1 = not applicable (too many rows or pairs), < 0 = error */
-static int tiny_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-			   const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
-{
-	if (n_l > TINY_ROWS || n_r > TINY_ROWS)
-		return 1;
-	const uint64_t worst = n_l * n_r;
-	const uint32_t cap = worst < TINY_PAIRS_CAP ? (uint32_t)worst : TINY_PAIRS_CAP;
-	uint32_t *ol = NULL, *orr = NULL;
-	if (mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&ol) || mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&orr)) {
-		if (ol)
-			(void)mdb_cached_free(ctx, ol);
-		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %u join pairs", cap);
-	}
-	tinyp_args a;
-	a.keys_l = keys_l;
-	a.null_l = null_l;
-	a.n_l = (uint32_t)n_l;
-	a.keys_r = keys_r;
-	a.null_r = null_r;
-	a.n_r = (uint32_t)n_r;
-	a.out_l = ol;
-	a.out_r = orr;
-	a.cap = cap;
-	a.status = ctx->d_status;
-	mdb_prof_begin(ctx, "tiny_join_pairs", (const void *)k_tiny_join_pairs);	/* (not MDB_LAUNCH: an error has two buffers to give back) */
-	hipLaunchKernelGGL(k_tiny_join_pairs, dim3(1), dim3(GC_THREADS), 0, ctx->stream, a);
-	mdb_prof_end(ctx);
-	uint32_t *h = (uint32_t *)ctx->h_pinned;
-	hipError_t e = hipMemcpyAsync(h, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(ctx->stream);
-	if (e != hipSuccess || (h[0] & 4096u)) {
-		(void)mdb_cached_free(ctx, ol);
-		(void)mdb_cached_free(ctx, orr);
-		if (e != hipSuccess)
-			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "tiny join failed: %s", hipGetErrorString(e));
-		return 1;	/* more pairs than the small buffers hold: the general path sizes its output exactly */
-	}
-	*out_l = ol;
-	*out_r = orr;
-	*out_count = h[1];
-	return 0;
-}
-
-/* the unique-key join with its narrow-form decision and retry; result codes of join_pairs_unique() except 2 */
-static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
-{
-	bool narrow = false;
-	int64_t base = 0;
-	gc_window win = { 0, 0, false, false, false, false };
-	int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base, &win);
-	if (urc)
-		return urc;
-	/* a compact window of at most 2^24 key values: one partition level, see join_pairs_unique_wide (MDB_ONE_LEVEL=0 switches
-	 * it off).  What it cannot do - a key outside the window after all, a first-level region overflow - goes the usual way */
-	if (narrow && win.kbits >= 9u + PW_MIN_REM && win.kbits <= 9u + PW_MAX_REM && n_l <= PW_MAX_LEFT && n_l + n_r >= (1ull << 20) &&
-	    !(ctx->pw_bad_keys == keys_r && ctx->pw_bad_n == n_r) && !ld_disabled() &&
-	    !(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0')) {
-		urc = join_pairs_unique_wide(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, win.kbits, win.lo, out_l, out_r, out_count);
-		if (urc <= 0 || urc == 3)
-			return urc;
-		ctx->pw_bad_keys = keys_r;
-		ctx->pw_bad_n = n_r;
-	}
-	urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, out_l, out_r, out_count);
-	if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
-		if (ctx->narrow_mode == 1) {
-			ctx->nh_distrust = 8;
-			gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
-		}
-		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, 0, out_l, out_r, out_count);
-	}
-	return urc;
-}
-
-/* Unique LEFT keys, duplicates on the right (FROM pk_table JOIN fk_table): the unique-key join runs with the sides
- * swapped - it delivers the pairs in right-row order - and a stable sort by left row id puts them into the reference's
- * left-major / right-minor order (for one left row the right rows are already ascending).  About half the time of the
- * general count / scan / emit path.  Same result codes as join_pairs_unique(). */
-static int join_pairs_unique_left(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
-				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
-{
-	if (n_l >= 0x7FFFFFFFull)
-		return 1;
-	uint32_t *sr = NULL, *sl = NULL;	/* swapped call: "left" ids are right rows, "right" ids are left rows */
-	uint64_t J = 0;
-	int rc = join_pairs_unique_auto(ctx, keys_r, null_r, n_r, keys_l, null_l, n_l, &sr, &sl, &J);
-	if (rc)
-		return rc;
-	*out_count = J;
-	if (J == 0)
-		return 0;
-	int64_t *wide = NULL;
-	uint32_t *perm = NULL, *ol = NULL, *orr = NULL;
-	rc = -MIDORIDB_NOMEM;
-	if (mdb_cached_alloc(ctx, J * 8, (void **)&wide) || mdb_cached_alloc(ctx, J * 4, (void **)&perm) ||
-	    mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
-		(void)mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
-		goto fail;
-	}
-	/* the pairs as words, sorted: nothing to widen, no permutation to gather through */
-	rc = mdb_sort_pairs(ctx, sl, sr, J, n_l, n_r, ol, orr);
-	if (rc < 0)
-		goto fail;
-	if (rc == 0) {
-		(void)mdb_cached_free(ctx, wide);
-		(void)mdb_cached_free(ctx, perm);
-		(void)mdb_cached_free(ctx, sr);
-		(void)mdb_cached_free(ctx, sl);
-		*out_l = ol;
-		*out_r = orr;
-		return 0;
-	}
-	/* few pairs or unevenly spread left rows: stable sort of a permutation by left row id, two gathers */
-	rc = mdb_dev_widen32to64(ctx, (const int32_t *)sl, J, wide);
-	if (rc)
-		goto fail;
-	{
-		struct mdb_sort_key key;
-		memset(&key, 0, sizeof(key));
-		key.values = wide;
-		key.type = MDB_T_INT64;
-		rc = mdb_dev_sort_perm(ctx, &key, 1, J, perm);
-		if (rc)
-			goto fail;
-	}
-	rc = mdb_dev_gather32(ctx, sl, perm, J, ol);
-	if (!rc)
-		rc = mdb_dev_gather32(ctx, sr, perm, J, orr);
-	if (!rc)
-		rc = mdb_dev_sync(ctx);
-	if (rc)
-		goto fail;
-	(void)mdb_cached_free(ctx, wide);
-	(void)mdb_cached_free(ctx, perm);
-	(void)mdb_cached_free(ctx, sr);
-	(void)mdb_cached_free(ctx, sl);
-	*out_l = ol;
-	*out_r = orr;
-	return 0;
-fail:
-	if (wide)
-		(void)mdb_cached_free(ctx, wide);
-	if (perm)
-		(void)mdb_cached_free(ctx, perm);
-	if (ol)
-		(void)mdb_cached_free(ctx, ol);
-	if (orr)
-		(void)mdb_cached_free(ctx, orr);
-	(void)mdb_cached_free(ctx, sr);
-	(void)mdb_cached_free(ctx, sl);
-	return rc < 0 ? rc : -MIDORIDB_INTERNAL;
-}
-
-extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
-				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
-				  uint64_t *out_count)
-{
-	*out_l = *out_r = NULL;
-	*out_count = 0;
-	if (n_l == 0 || n_r == 0)
-		return MIDORIDB_OK;
-	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
-	{
-		const int trc = tiny_join_pairs(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, out_l, out_r, out_count);
-		if (trc <= 0)
-			return trc;
-	}
-	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records;
-	 *      unique left keys: the same with the sides swapped and a stable sort.  What a column turned out to be is
-	 *      remembered (by pointer and length), so that a repeated query does not pay for failed attempts. */
-	{
-		uint32_t *ul = NULL, *ur = NULL;
-		uint64_t uj = 0;
-		int urc = 3;
-		bool right_dups = ctx->pu_dup_keys == keys_r && ctx->pu_dup_n == n_r;
-		bool left_dups = ctx->pu_dupl_keys == keys_l && ctx->pu_dupl_n == n_l;
-		if ((right_dups || left_dups) && ++ctx->pu_dup_skips > 32) {	/* the buffers may hold other data by now: look again once in a while */
-			right_dups = left_dups = false;
-			ctx->pu_dup_keys = ctx->pu_dupl_keys = NULL;
-		}
-		if (!right_dups) {
-			urc = join_pairs_unique_auto(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
-			if (urc < 0)
-				return urc;
-			if (urc == 3) {
-				ctx->pu_dup_keys = keys_r;
-				ctx->pu_dup_n = n_r;
-				ctx->pu_dup_skips = 0;
-			}
-		}
-		if (urc == 3 && !left_dups && n_l + n_r >= SORT_SWAP_MIN_ROWS) {	/* small tables: the general path has fewer launches */
-			urc = join_pairs_unique_left(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
-			if (urc < 0)
-				return urc;
-			if (urc == 3) {
-				ctx->pu_dupl_keys = keys_l;
-				ctx->pu_dupl_n = n_l;
-				ctx->pu_dup_skips = 0;
-			}
-		}
-		if (urc == 0) {
-			*out_l = ul;
-			*out_r = ur;
-			*out_count = uj;
-			return MIDORIDB_OK;
-		}
-		/* duplicates on both sides, or a table / region overflowed: general path below */
-	}
-	int b1, b2;
-	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
-	const uint64_t mlen = n_l + 1;
-	pj_args a;
-	uint64_t J = 0;
-	uint64_t *h = ctx->h_pinned;
-	/* First with the histogram-free partition layout and the right side in arbitrary order (the emit kernel orders
-	 * every key's row ids itself inside one chunk); the exact, stable layout is the fallback when a region
-	 * overflows (skew) or a leaf holds more right rows than one chunk (their order across chunks matters). */
-	for (int fast = 1; fast >= 0; fast--) {
-		size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast != 0) + mdb_partition_arena_bytes(n_r, b1, b2, true, fast != 0) +
-			      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
-		int rc = mdb_arena_begin(ctx, need);
-		if (rc)
-			return rc;
-		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
-		mdb_part_result pl, pr;
-		hipStream_t main_stream = NULL;
-		rc = mdb_aux_begin(ctx, &main_stream);	/* the right table is partitioned on the auxiliary stream (when enabled) */
-		if (rc)
-			return rc;
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, !fast, fast != 0, &pr);
-		{
-			int rc2 = mdb_aux_end(ctx, main_stream);
-			if (rc)
-				return rc;
-			if (rc2)
-				return rc2;
-		}
-		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, fast != 0, &pl);
-		if (rc)
-			return rc;
-		if ((rc = mdb_aux_join(ctx)))
-			return rc;
-		uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
-		uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
-		if (!match || !scan_tmp)
-			return -MIDORIDB_INTERNAL;
-		MDB_HIP(ctx, hipMemsetAsync(match, 0, mlen * 4, ctx->stream));
-
-		a.hv_l = pl.hv;
-		a.rid_l = pl.rid;
-		a.off_l = pl.leaf_off;
-		a.cnt_l = pl.leaf_cnt;
-		a.cap_l = pl.leaf_cap;
-		a.hv_r = pr.hv;
-		a.rid_r = pr.rid;
-		a.off_r = pr.leaf_off;
-		a.cnt_r = pr.leaf_cnt;
-		a.cap_r = pr.leaf_cap;
-		a.match = match;
-		a.out_l = a.out_r = NULL;
-		a.status = ctx->d_status;
-		a.total64 = (unsigned long long *)(ctx->d_status + 2);
-		a.nleaves = pl.nleaves;
-		MDB_LAUNCH(ctx, "leaf_pairs_count", k_leaf_pairs_count, pl.nleaves, LEAF_THREADS, a);
-
-		/* offsets are 32-bit; the 64-bit total written by the count kernel guards against N:M blow-ups */
-		rc = mdb_scan_u32_inplace(ctx, match, mlen, scan_tmp);
-		if (rc)
-			return rc;
-		MDB_HIP(ctx, hipMemcpyAsync(&h[0], match + n_l, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		J = (uint32_t)h[0];
-		const uint32_t status = (uint32_t)h[1];
-		if (fast && (status & (2u | 16u)))
-			continue;	/* region overflow, or a multi-chunk leaf with unordered right rows */
-		if (status & 1u)
-			return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
-					   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", PJ_SLOTS);
-		break;
-	}
-	if (h[2] != J)
-		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join produces %llu rows: more than the 2^32-1 a single call can materialise",
-				   (unsigned long long)h[2]);
-	if (J == 0)
-		return MIDORIDB_OK;
-	uint32_t *ol = NULL, *orr = NULL;
-	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
-		if (ol)
-			(void)mdb_cached_free(ctx, ol);
-		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
-	}
-	a.out_l = ol;
-	a.out_r = orr;
-	MDB_LAUNCH(ctx, "leaf_pairs_emit", k_leaf_pairs_emit, a.nleaves, LEAF_THREADS, a);
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*out_l = ol;
-	*out_r = orr;
-	*out_count = J;
-	return MIDORIDB_OK;
 }

@@ -1,0 +1,1171 @@
+/*
+ * mdb_dev_pairs.hip - materialising INNER JOIN (_join_nested_loop_tbl2tbl, executor_select.c:1076-1149): pairs in the reference's left-major / right-minor order
+ * (split off mdb_dev_join.hip; what the files share: mdb_dev_join_internal.h).  Hand-written HIP for gfx950, HBM-bound
+ * integer work: no MFMA.
+ */
+#include "mdb_dev_join_internal.h"
+
+/* ------------------------------------------------------------------ materialising join: count phase */
+
+/* ------------------------------------------------------------------ materialising join, unique right keys
+ *
+ * The common shape (primary key on the right: BASELINE configs 2 and 5): every left row matches at most one right
+ * row, so a pair is fully described by ONE 64-bit record (left row id, right row id + 1) - exactly the shape of the
+ * group records above.  One persistent kernel builds the per-leaf table (key -> right row id), probes it with the
+ * left rows and appends the records; the ordering sort + k_order_leaf then deliver (l, r) in left-row order.  No
+ * match-count array, no scan, no second table build.  A duplicate right key (or any overflow) is flagged and the
+ * caller falls back to the general count / scan / emit path.
+ */
+struct pu_args {
+	const uint64_t *hv_l;
+	const uint32_t *rid_l;
+	const uint32_t *off_l;
+	const uint32_t *cnt_l;
+	uint32_t cap_l;
+	const uint64_t *hv_r;
+	const uint32_t *rid_r;
+	const uint32_t *off_r;
+	const uint32_t *cnt_r;
+	uint32_t cap_r;
+	unsigned long long *rec;
+	uint32_t *rec_count;		/* list slots handed out (chunked, zero-filled gaps) */
+	uint32_t *rec_valid;		/* pairs */
+	uint32_t rec_cap;
+	uint32_t kbits;
+	uint32_t *status;		/* bit 0 table overflow, bit 3 list exhausted, bit 5 duplicate right key */
+	uint32_t nleaves;
+};
+
+/* NARROW: both sides travel as hash32 << 32 | row id words (no row-id arrays; see the narrow form of the group count) */
+template <bool NARROW>
+__global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_pairs_unique(pu_args a)
+{
+	__shared__ unsigned long long s_key[GC_SLOTS];
+	__shared__ uint32_t s_val[GC_SLOTS + 1];	/* right row id + 1; [GC_SLOTS] = the key whose hash is 0 (0 = absent) */
+	__shared__ uint32_t s_chunk[4];			/* [0] base [1] used [2] size [3] pairs */
+	__shared__ uint32_t s_abort;			/* a duplicate right key (or a full table) was met: this is not a unique-key join */
+
+	for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+		if (s < GC_SLOTS)
+			s_key[s] = 0ull;
+		s_val[s] = 0;
+	}
+	if (threadIdx.x < 4)
+		s_chunk[threadIdx.x] = 0;
+	if (threadIdx.x == 0)
+		s_abort = 0;
+	uint32_t npairs = 0;
+	__syncthreads();
+	for (uint32_t leaf = blockIdx.x; leaf < a.nleaves; leaf += gridDim.x) {
+		/* The verdict "not unique" is raised ONCE per workgroup and ends its work (one global atomic per duplicate row -
+		 * 10^8 of them on one address for a right table with 16 rows per key - made this failed attempt cost 18 ms).
+		 * Workgroups that meet no duplicate themselves run to the end: looking at the global flag once per leaf put an
+		 * uncached round trip on every leaf's critical path (0.24 -> 0.45 ms per 10^7 x 10^7 join). */
+		if (s_abort) {		/* uniform: read after the barriers that ended the previous leaf */
+			if (threadIdx.x == 0)
+				atomicOr(a.status, s_abort);
+			break;
+		}
+		uint32_t l0, l1, r0, r1;
+		gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+		gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+		if (l0 == l1 || r0 == r1)
+			continue;	/* uniform */
+		/* request the first batch of both sides before anything else */
+		uint64_t hr[LEAF_BATCH], hl[LEAF_BATCH];
+		uint32_t rr[LEAF_BATCH], rl[LEAF_BATCH];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++) {
+			const uint32_t j = r0 + (uint32_t)u * GC_THREADS + threadIdx.x;
+			const uint32_t i = l0 + (uint32_t)u * GC_THREADS + threadIdx.x;
+			hr[u] = j < r1 ? a.hv_r[j] : 0;
+			hl[u] = i < l1 ? a.hv_l[i] : 0;
+			rr[u] = rl[u] = 0;
+			if (!NARROW) {
+				rr[u] = j < r1 ? a.rid_r[j] : 0;
+				rl[u] = i < l1 ? a.rid_l[i] : 0;
+			}
+		}
+		{	/* list space for at most one record per left row (chunked reservation as in k_leaf_group_count) */
+			const uint32_t need = (l1 - l0) + 1;
+			const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+			if (used + need > size) {
+				for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+					a.rec[base + i] = 0ull;
+				__syncthreads();
+				if (threadIdx.x == 0) {
+					const uint32_t want = need > GC_REC_CHUNK ? need : GC_REC_CHUNK;
+					const uint32_t nb = atomicAdd(a.rec_count, want);
+					if (nb + want > a.rec_cap) {
+						mdb_raise(a.status, 8u);
+						s_chunk[0] = 0;
+						s_chunk[2] = 0;
+					} else {
+						s_chunk[0] = nb;
+						s_chunk[2] = want;
+					}
+					s_chunk[1] = 0;
+				}
+			}
+		}
+		/* build: right rows (unique keys expected) */
+		uint32_t own[LEAF_BATCH];
+		const bool by_owner = (r1 - r0) <= GC_THREADS * LEAF_BATCH;
+		for (uint32_t base = r0; base < r1; base += GC_THREADS * LEAF_BATCH) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t j = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+				if (base != r0) {
+					hr[u] = j < r1 ? a.hv_r[j] : 0;
+					if (!NARROW)
+						rr[u] = j < r1 ? a.rid_r[j] : 0;
+				}
+				if (base == r0)
+					own[u] = 0xFFFFFFFFu;
+				if (j >= r1)
+					continue;
+				/* the words are decoded here, where they are used (not at load time: the first batch is in flight) */
+				const uint64_t key_r = NARROW ? gc_narrow_hv(hr[u]) : hr[u];
+				const uint32_t rid_r = NARROW ? (uint32_t)hr[u] : rr[u];
+				if (key_r == 0) {
+					if (atomicExch(&s_val[GC_SLOTS], rid_r + 1u) != 0)
+						s_abort = 32u;
+					continue;
+				}
+				bool created = false;
+				const uint32_t s = leaf_insert(s_key, GC_SLOTS, key_r, &created);
+				if (s == 0xFFFFFFFFu) {
+					s_abort = 1u;
+				} else if (!created) {
+					s_abort = 32u;		/* the key is already there: not a unique-key join */
+				} else {
+					s_val[s] = rid_r + 1u;
+					if (base == r0)
+						own[u] = s;
+				}
+			}
+		}
+		__syncthreads();
+		/* probe: left rows -> records */
+		const uint32_t cbase = s_chunk[0], csize = s_chunk[2];
+		for (uint32_t base = l0; base < l1; base += GC_THREADS * LEAF_BATCH) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++) {
+				const uint32_t i = base + (uint32_t)u * GC_THREADS + threadIdx.x;
+				if (base != l0) {
+					hl[u] = i < l1 ? a.hv_l[i] : 0;
+					if (!NARROW)
+						rl[u] = i < l1 ? a.rid_l[i] : 0;
+				}
+				unsigned long long recv = 0;
+				if (i < l1) {
+					const uint64_t key_l = NARROW ? gc_narrow_hv(hl[u]) : hl[u];
+					const uint32_t rid_l = NARROW ? (uint32_t)hl[u] : rl[u];
+					uint32_t s = GC_SLOTS;
+					if (key_l != 0)
+						s = leaf_find(s_key, GC_SLOTS, key_l);
+					const uint32_t v = s != 0xFFFFFFFFu ? s_val[s] : 0u;
+					if (v)
+						recv = ((unsigned long long)rid_l << (64 - a.kbits)) | v;
+				}
+				const uint64_t m = __ballot(recv != 0ull);
+				if (m) {
+					const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+					uint32_t wbase = 0;
+					if (mdb_lane() == leader)
+						wbase = atomicAdd(&s_chunk[1], (uint32_t)__popcll(m));
+					wbase = __shfl(wbase, (int)leader, MDB_WAVE);
+					if (recv) {
+						const uint32_t pos = wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+						if (pos < csize)
+							a.rec[cbase + pos] = recv;
+						npairs++;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		/* clear what this leaf wrote */
+		if (by_owner) {
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++)
+				if (own[u] != 0xFFFFFFFFu) {
+					s_key[own[u]] = 0ull;
+					s_val[own[u]] = 0;
+				}
+			if (threadIdx.x == 0)
+				s_val[GC_SLOTS] = 0;
+		} else {
+			for (uint32_t s = threadIdx.x; s <= GC_SLOTS; s += GC_THREADS) {
+				if (s < GC_SLOTS)
+					s_key[s] = 0ull;
+				s_val[s] = 0;
+			}
+		}
+		__syncthreads();
+	}
+	{
+		const uint32_t base = s_chunk[0], used = s_chunk[1], size = s_chunk[2];
+		for (uint32_t i = used + threadIdx.x; i < size; i += GC_THREADS)
+			a.rec[base + i] = 0ull;
+		if (npairs)
+			atomicAdd(&s_chunk[3], npairs);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_abort)
+		atomicOr(a.status, s_abort);	/* (also when it was raised by the workgroup's last leaf) */
+	if (threadIdx.x == 0 && s_chunk[3])
+		atomicAdd(a.rec_valid, s_chunk[3]);
+}
+
+struct pj_args {
+	const uint64_t *hv_l;
+	const uint32_t *rid_l;
+	const uint32_t *off_l;		/* exact leaf offsets, or (cnt, cap) of the fixed-capacity layout, as in gc_args */
+	const uint32_t *cnt_l;
+	uint32_t cap_l;
+	const uint64_t *hv_r;
+	const uint32_t *rid_r;
+	const uint32_t *off_r;
+	const uint32_t *cnt_r;
+	uint32_t cap_r;
+	uint32_t *match;	/* [n_l + 1]: count phase writes matches per left row; scanned into offsets */
+	uint32_t *out_l;
+	uint32_t *out_r;
+	uint32_t *status;
+	unsigned long long *total64;	/* 64-bit sum of all match counts (guards the 32-bit offsets) */
+	uint32_t nleaves;
+};
+
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
+{
+	__shared__ unsigned long long s_key[PJ_SLOTS];
+	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* [PJ_SLOTS] = the key with hash 0 */
+	__shared__ unsigned long long s_total;
+
+	const uint32_t leaf = blockIdx.x;
+	uint32_t l0, l1, r0, r1;
+	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+	if (l0 == l1 || r0 == r1)
+		return;
+	if (threadIdx.x == 0 && r1 - r0 > PJ_CHUNK)
+		mdb_raise(a.status, 16u);	/* the emit kernel will sweep this leaf's right rows in several chunks: they must be in row-id order */
+	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+		if (s < PJ_SLOTS)
+			s_key[s] = 0ull;
+		s_cnt[s] = 0;
+	}
+	if (threadIdx.x == 0)
+		s_total = 0ull;
+	__syncthreads();
+	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
+		const uint64_t hv = a.hv_r[j];
+		uint32_t s = PJ_SLOTS;
+		if (hv != 0) {
+			s = leaf_insert(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu) {
+				mdb_raise(a.status, 1u);
+				continue;
+			}
+		}
+		atomicAdd(&s_cnt[s], 1u);
+	}
+	__syncthreads();
+	unsigned long long mine = 0;
+	for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
+		const uint64_t hv = a.hv_l[i];
+		uint32_t s = PJ_SLOTS;
+		if (hv != 0)
+			s = leaf_find(s_key, PJ_SLOTS, hv);
+		if (s != 0xFFFFFFFFu) {
+			const uint32_t m = s_cnt[s];
+			if (m) {
+				a.match[a.rid_l[i]] = m;
+				mine += m;
+			}
+		}
+	}
+	/* one global atomic per workgroup (a per-thread atomic on this single address serialised 10^7 updates
+	 * and cost 1.5 ms at 10^7 rows - profiles/r01/operators.json history) */
+	if (mine)
+		atomicAdd(&s_total, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_total)
+		atomicAdd(a.total64, s_total);
+}
+
+/* ------------------------------------------------------------------ materialising join: emit phase
+ *
+ * Per leaf: table of the right side's distinct keys; the right rows are swept in chunks of
+ * PJ_CHUNK.  Inside a chunk the row ids of each key are placed contiguously (LDS counting sort by
+ * slot; ranks by comparing row ids, so every key's list is ascending = right-minor order), then
+ * every left row of the leaf copies its key's list to out[offset(left row) + matches so far].
+ */
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_emit(pj_args a)
+{
+	__shared__ unsigned long long s_key[PJ_SLOTS];
+	__shared__ uint32_t s_cnt[PJ_SLOTS + 1];	/* matches of the slot inside the current chunk */
+	__shared__ uint32_t s_start[PJ_SLOTS + 1];	/* first list position of the slot inside the chunk */
+	__shared__ uint32_t s_cur[PJ_SLOTS + 1];
+	__shared__ uint32_t s_prior[PJ_SLOTS + 1];	/* matches of the slot in earlier chunks */
+	__shared__ uint32_t s_tmp[PJ_CHUNK];
+	__shared__ uint32_t s_sorted[PJ_CHUNK];
+	__shared__ uint16_t s_eslot[PJ_CHUNK];
+	__shared__ uint32_t s_scan[32];
+
+	const uint32_t leaf = blockIdx.x;
+	uint32_t l0, l1, r0, r1;
+	gc_leaf_range(a.off_l, a.cnt_l, a.cap_l, leaf, &l0, &l1);
+	gc_leaf_range(a.off_r, a.cnt_r, a.cap_r, leaf, &r0, &r1);
+	if (l0 == l1 || r0 == r1)
+		return;
+	for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+		if (s < PJ_SLOTS)
+			s_key[s] = 0ull;
+		s_prior[s] = 0;
+	}
+	__syncthreads();
+	for (uint32_t j = r0 + threadIdx.x; j < r1; j += LEAF_THREADS) {
+		const uint64_t hv = a.hv_r[j];
+		if (hv != 0 && leaf_insert(s_key, PJ_SLOTS, hv) == 0xFFFFFFFFu)
+			mdb_raise(a.status, 1u);
+	}
+	__syncthreads();
+
+	constexpr uint32_t PER_T = (PJ_SLOTS + 1 + LEAF_THREADS - 1) / LEAF_THREADS;	/* slots scanned per thread */
+	for (uint32_t c0 = r0; c0 < r1; c0 += PJ_CHUNK) {
+		const uint32_t clen = (r1 - c0) < PJ_CHUNK ? (r1 - c0) : PJ_CHUNK;
+		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS) {
+			s_cnt[s] = 0;
+			s_cur[s] = 0;
+		}
+		__syncthreads();
+		/* count the chunk's rows per slot */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint64_t hv = a.hv_r[c0 + e];
+			uint32_t s = PJ_SLOTS;
+			if (hv != 0)
+				s = leaf_find(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu)
+				s = PJ_SLOTS;	/* only after an overflow, which fails the whole call anyway */
+			s_eslot[e] = (uint16_t)s;
+			atomicAdd(&s_cnt[s], 1u);
+		}
+		__syncthreads();
+		/* exclusive scan of the slot counts -> list starts */
+		{
+			uint32_t v[PER_T], sum = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < PER_T; k++) {
+				const uint32_t s = threadIdx.x * PER_T + k;
+				v[k] = s <= PJ_SLOTS ? s_cnt[s] : 0;
+				sum += v[k];
+			}
+			uint32_t total;
+			uint32_t run = mdb_block_excl_scan(sum, s_scan, &total);
+#pragma unroll
+			for (uint32_t k = 0; k < PER_T; k++) {
+				const uint32_t s = threadIdx.x * PER_T + k;
+				if (s <= PJ_SLOTS)
+					s_start[s] = run;
+				run += v[k];
+			}
+		}
+		__syncthreads();
+		/* place row ids by slot (arbitrary order inside a list) */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint32_t s = s_eslot[e];
+			const uint32_t pos = s_start[s] + atomicAdd(&s_cur[s], 1u);
+			s_tmp[pos] = a.rid_r[c0 + e];
+		}
+		__syncthreads();
+		/* rank every row id inside its list (row ids are distinct) -> ascending lists */
+		for (uint32_t e = threadIdx.x; e < clen; e += LEAF_THREADS) {
+			const uint32_t s = s_eslot[e];
+			const uint32_t rid = a.rid_r[c0 + e];
+			const uint32_t b = s_start[s], m = s_cnt[s];
+			uint32_t rank = 0;
+			for (uint32_t k = 0; k < m; k++)
+				rank += s_tmp[b + k] < rid;
+			s_sorted[b + rank] = rid;
+		}
+		__syncthreads();
+		/* every left row copies its key's list */
+		for (uint32_t i = l0 + threadIdx.x; i < l1; i += LEAF_THREADS) {
+			const uint64_t hv = a.hv_l[i];
+			uint32_t s = PJ_SLOTS;
+			if (hv != 0)
+				s = leaf_find(s_key, PJ_SLOTS, hv);
+			if (s == 0xFFFFFFFFu)
+				continue;
+			const uint32_t m = s_cnt[s];
+			if (!m)
+				continue;
+			const uint32_t rid = a.rid_l[i];
+			const uint32_t base = a.match[rid] + s_prior[s];
+			const uint32_t b = s_start[s];
+			for (uint32_t k = 0; k < m; k++) {
+				a.out_l[base + k] = rid;
+				a.out_r[base + k] = s_sorted[b + k];
+			}
+		}
+		__syncthreads();
+		for (uint32_t s = threadIdx.x; s <= PJ_SLOTS; s += LEAF_THREADS)
+			s_prior[s] += s_cnt[s];
+		__syncthreads();
+	}
+}
+
+/* 0 = done, 1 = not applicable (overflow: use the general path), 2 = a key outside the window met the narrow form (call
+ * again with narrow = false), 3 = a right key occurs more than once (not a unique-key join this way round), < 0 = error */
+static int join_pairs_unique(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			     const uint64_t *null_r, uint64_t n_r, bool narrow, int64_t base, uint32_t **out_l, uint32_t **out_r,
+			     uint64_t *out_count)
+{
+	int b1, b2, sb1 = 0, sb2 = 0;
+	uint32_t kbits = 0;
+	mdb_choose_bits(n_r, GC_TARGET, &b1, &b2);
+	if ((n_r >> (b1 + b2)) > (uint64_t)GC_SLOTS * 7 / 10 || !order_bits(n_l, &kbits, &sb1, &sb2))
+		return 1;
+	const uint64_t rec_cap = gc_rec_capacity(ctx, n_l);
+	size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, true) + mdb_partition_arena_bytes(n_r, b1, b2, true, true) +
+		      mdb_align_up(rec_cap * 8) + order_records_arena_bytes(rec_cap, n_l, kbits, sb1, sb2) + 4096;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	mdb_part_result pl, pr;
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, !narrow, false, true, &pr, narrow ? 1 : 0, false, base);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, !narrow, false, true, &pl, narrow ? 1 : 0, false, base);
+	if (rc)
+		return rc;
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, rec_cap * 8);
+	if (!rec)
+		return -MIDORIDB_INTERNAL;
+	pu_args a;
+	a.hv_l = pl.hv;
+	a.rid_l = pl.rid;
+	a.off_l = pl.leaf_off;
+	a.cnt_l = pl.leaf_cnt;
+	a.cap_l = pl.leaf_cap;
+	a.hv_r = pr.hv;
+	a.rid_r = pr.rid;
+	a.off_r = pr.leaf_off;
+	a.cnt_r = pr.leaf_cnt;
+	a.cap_r = pr.leaf_cap;
+	a.rec = rec;
+	a.rec_count = ctx->d_status + 1;
+	a.rec_valid = ctx->d_status + 8;
+	a.rec_cap = (uint32_t)rec_cap;
+	a.kbits = kbits;
+	a.status = ctx->d_status;
+	a.nleaves = pl.nleaves;
+	{
+		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
+		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
+		if (narrow) {
+			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<true>, grid, GC_THREADS, a);
+		} else {
+			MDB_LAUNCH(ctx, "leaf_pairs_unique", k_leaf_pairs_unique<false>, grid, GC_THREADS, a);
+		}
+	}
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t status = (uint32_t)h[1];
+	const uint64_t list_len = h[1] >> 32, J = (uint32_t)h[5];
+	if (status & 128u)
+		return 2;
+	if (status & 32u)
+		return 3;	/* a right key occurs more than once */
+	if (status & (1u | 2u | 8u))
+		return 1;
+	*out_count = J;
+	if (J == 0)
+		return 0;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+	}
+	rc = order_records(ctx, rec, list_len, n_l, kbits, sb1, sb2, ol, NULL, orr, NULL, NULL);
+	if (rc) {
+		(void)mdb_cached_free(ctx, ol);
+		(void)mdb_cached_free(ctx, orr);
+		return rc;
+	}
+	*out_l = ol;
+	*out_r = orr;
+	return 0;
+}
+
+/* ------------------------------------------------------------------ unique right keys in a window of at most 2^24 values: ONE level
+ *
+ * The primary-key join of BASELINE configs[1] (10^7 x 10^7 rows, 4 result columns).  Through the path above it is two
+ * partition levels per table, a hashed leaf table, one 8-byte record per pair and an ordering sort of the records by left row
+ * id: 0.46 ms of kernels before the projection.  When the key sample offers a compact window of at most 2^24 values (the
+ * k-bit bijection of the compact narrow form) both tables are partitioned ONCE by 9 bits (mdb_part_filter.level0_only) and
+ * one 1024-thread workgroup joins a whole digit: a table of 2^(k-9) <= 2^15 LDS words indexed by the remaining hash bits
+ * holds right row id + 1 - plain stores, no atomics: that the right keys are unique is checked afterwards (the number of
+ * occupied entries must equal the number of right rows; otherwise status bit 5 and the caller takes the other paths).  A
+ * left row reads its entry and writes the partner to match[left row id]: a random 4-byte write, but into an array of 4 n_L
+ * bytes that the Infinity Cache holds (the path is taken up to 2^25 left rows).  The pairs in the reference's order - left
+ * row ascending - are then the non-zero entries of match[] in index order: a count / scan / emit compaction instead of a
+ * sort.  (The scatter is what the kernel's time is made of: 0.16 ms per 10^7 x 10^7 rows where the two streams need 0.06;
+ * non-temporal stores took 0.33 - the L2s merge the writes of neighbouring rows, which a digit's sub-regions deliver in
+ * roughly ascending order.) */
+#define PW_THREADS 1024
+#define PW_MIN_REM 10u
+#define PW_MAX_REM 15u
+#define PW_UNROLL 4
+#define PW_MAX_LEFT (1ull << 25)
+#define MC_THREADS 256
+#define MC_PER_THREAD 16
+#define MC_BLOCK (MC_THREADS * MC_PER_THREAD)
+
+struct pw_args {
+	const uint64_t *hv_l, *hv_r;		/* first-level output: hash32 << 32 | row id */
+	const uint32_t *cnt_l, *cnt_r;		/* rows per sub-region: [sub * nleaves + digit] */
+	uint32_t cap_l, cap_r, nleaves, nsub;
+	uint32_t *match;			/* [n_l], zeroed: right row id + 1 of the left row's partner */
+	unsigned long long *joined;
+	uint32_t *status;
+};
+
+__global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_wide(pw_args a, uint32_t rem, uint32_t shift)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t pw_tab[];
+	__shared__ unsigned long long s_red[PW_THREADS / 64];
+	const uint32_t T = 1u << rem, mask = T - 1u, leaf = blockIdx.x;
+	for (uint32_t s = threadIdx.x; s < T; s += PW_THREADS)
+		pw_tab[s] = 0u;
+	__syncthreads();
+	uint32_t rows_r = 0;
+	for (uint32_t sub = 0; sub < a.nsub; sub++) {
+		const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
+		const uint64_t *const src = a.hv_r + (size_t)(leaf * a.nsub + sub) * a.cap_r;
+		rows_r += c;
+		for (uint32_t i0 = 0; i0 < c; i0 += 2u * PW_THREADS * PW_UNROLL) {	/* uniform trip count */
+			ulonglong2 v[PW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
+				v[u] = make_ulonglong2(0ull, 0ull);
+				if (i < c)
+					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
+			}
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
+				if (i < c)
+					pw_tab[((uint32_t)(v[u].x >> 32) >> shift) & mask] = (uint32_t)v[u].x + 1u;
+				if (i + 1 < c)
+					pw_tab[((uint32_t)(v[u].y >> 32) >> shift) & mask] = (uint32_t)v[u].y + 1u;
+			}
+		}
+	}
+	__syncthreads();
+	/* unique right keys: every right row has its own entry */
+	unsigned long long occupied = 0;
+	for (uint32_t s = threadIdx.x; s < T; s += PW_THREADS)
+		occupied += pw_tab[s] != 0u;
+	occupied = lw_block_sum(occupied, s_red);
+	if (occupied != rows_r) {
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 32u);
+		return;
+	}
+	unsigned long long pairs = 0;
+	for (uint32_t sub = 0; sub < a.nsub; sub++) {
+		const uint32_t c0 = a.cnt_l[sub * a.nleaves + leaf], c = c0 < a.cap_l ? c0 : a.cap_l;
+		const uint64_t *const src = a.hv_l + (size_t)(leaf * a.nsub + sub) * a.cap_l;
+		for (uint32_t i0 = 0; i0 < c; i0 += 2u * PW_THREADS * PW_UNROLL) {
+			ulonglong2 v[PW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
+				v[u] = make_ulonglong2(0ull, 0ull);
+				if (i < c)
+					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
+			}
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * PW_THREADS + threadIdx.x);
+				const unsigned long long w[2] = { v[u].x, v[u].y };
+#pragma unroll
+				for (int k = 0; k < 2; k++)
+					if (i + k < c) {
+						const uint32_t r = pw_tab[((uint32_t)(w[k] >> 32) >> shift) & mask];
+						if (r) {
+							a.match[(uint32_t)w[k]] = r;
+							pairs++;
+						}
+					}
+			}
+		}
+	}
+	pairs = lw_block_sum(pairs, s_red);
+	if (threadIdx.x == 0 && pairs)
+		atomicAdd(a.joined, pairs);
+}
+
+/* non-zero entries per block of MC_BLOCK entries (lane-interleaved 16-byte loads: a wave reads 1 KiB per instruction) */
+__global__ __launch_bounds__(MC_THREADS) void k_match_count(const uint32_t *__restrict__ match, uint32_t n, uint32_t *__restrict__ blk)
+{
+	__shared__ uint32_t s_tmp[32];
+	uint32_t c = 0;
+	if ((uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n) {	/* (uniform) a full block: its loads are issued together */
+		uint4 v[MC_PER_THREAD / 4];
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++)
+			v[q] = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++)
+			c += (v[q].x != 0u) + (v[q].y != 0u) + (v[q].z != 0u) + (v[q].w != 0u);
+	} else {
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+			const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
+			if (i + 3 < n) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(match + i);
+				c += (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
+			} else {
+				for (uint32_t k = i; k < n && k < i + 4; k++)
+					c += match[k] != 0u;
+			}
+		}
+	}
+	uint32_t total;
+	(void)mdb_block_excl_scan(c, s_tmp, &total);
+	if (threadIdx.x == 0)
+		blk[blockIdx.x] = total;
+}
+
+/* the pairs in left-row order: (i, match[i] - 1) for every non-zero entry.  The block's entries are loaded lane-interleaved
+ * (chunk q = entries [q * 1024, q * 1024 + 1024) of the block, 4 consecutive ones per thread), ranked chunk by chunk, staged
+ * in LDS at their ranks and written with consecutive threads on consecutive pairs (thread-contiguous loads and stores - 64
+ * scattered 4-byte accesses per instruction - took 0.10 ms per 10^7 entries instead of 0.03). */
+__global__ __launch_bounds__(MC_THREADS) void k_match_emit(const uint32_t *__restrict__ match, uint32_t n, const uint32_t *__restrict__ blk_start,
+							   uint32_t *__restrict__ out_l, uint32_t *__restrict__ out_r)
+{
+	__shared__ uint32_t s_tmp[32];
+	__shared__ uint32_t s_l[MC_BLOCK], s_r[MC_BLOCK];
+	uint32_t m[MC_PER_THREAD];
+	uint32_t run = 0;
+	const bool full = (uint64_t)(blockIdx.x + 1) * MC_BLOCK <= n;	/* (uniform) */
+	if (full) {
+#pragma unroll
+		for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(match + blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u);
+			m[4 * q] = v.x;
+			m[4 * q + 1] = v.y;
+			m[4 * q + 2] = v.z;
+			m[4 * q + 3] = v.w;
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < MC_PER_THREAD / 4 && !full; q++) {
+		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
+		uint4 v = make_uint4(0u, 0u, 0u, 0u);
+		if (i + 3 < n) {
+			v = *reinterpret_cast<const uint4 *>(match + i);
+		} else {
+			if (i < n)
+				v.x = match[i];
+			if (i + 1 < n)
+				v.y = match[i + 1];
+			if (i + 2 < n)
+				v.z = match[i + 2];
+		}
+		m[4 * q] = v.x;
+		m[4 * q + 1] = v.y;
+		m[4 * q + 2] = v.z;
+		m[4 * q + 3] = v.w;
+	}
+#pragma unroll
+	for (int q = 0; q < MC_PER_THREAD / 4; q++) {
+		const uint32_t c = (m[4 * q] != 0u) + (m[4 * q + 1] != 0u) + (m[4 * q + 2] != 0u) + (m[4 * q + 3] != 0u);
+		uint32_t total;
+		uint32_t pos = run + mdb_block_excl_scan(c, s_tmp, &total);
+		const uint32_t i = blockIdx.x * MC_BLOCK + ((uint32_t)q * MC_THREADS + threadIdx.x) * 4u;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			if (m[4 * q + k]) {
+				s_l[pos] = i + (uint32_t)k;
+				s_r[pos] = m[4 * q + k] - 1u;
+				pos++;
+			}
+		run += total;
+	}
+	__syncthreads();
+	const uint32_t start = blk_start[blockIdx.x];
+	for (uint32_t p = threadIdx.x; p < run; p += MC_THREADS) {
+		out_l[start + p] = s_l[p];
+		out_r[start + p] = s_r[p];
+	}
+}
+
+/* 0 = done, 1 = not applicable (a first-level region overflowed), 2 = a key outside the window, 3 = a right key occurs more
+ * than once, < 0 = error */
+static int join_pairs_unique_wide(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				  const uint64_t *null_r, uint64_t n_r, uint32_t kbits, int64_t lo, uint32_t **out_l, uint32_t **out_r,
+				  uint64_t *out_count)
+{
+	const int b1 = 9;
+	const uint32_t rem = kbits - (uint32_t)b1, shift = 32u - kbits;
+	const uint32_t nb = (uint32_t)((n_l + MC_BLOCK - 1) / MC_BLOCK);
+	const size_t need = mdb_partition_level0_arena_bytes(n_l, b1) + mdb_partition_level0_arena_bytes(n_r, b1) + mdb_align_up(n_l * 4) +
+			    mdb_align_up(((size_t)nb + 2) * 4) + mdb_align_up(mdb_scan_scratch_words((uint64_t)nb + 1) * 4) + 8192;
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	mdb_part_filter flt;
+	memset(&flt, 0, sizeof(flt));
+	flt.level0_only = true;
+	mdb_part_result pl, pr;
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, 0, false, false, true, &pr, 1, false, lo, kbits, &flt);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, 0, false, false, true, &pl, 1, false, lo, kbits, &flt);
+	if (rc)
+		return rc;
+	uint32_t *match = (uint32_t *)mdb_arena_take(ctx, n_l * 4);
+	uint32_t *blk = (uint32_t *)mdb_arena_take(ctx, ((size_t)nb + 2) * 4);
+	uint32_t *blk_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nb + 1) * 4);
+	if (!match || !blk || !blk_tmp)
+		return -MIDORIDB_INTERNAL;
+	if (!pl.nsub || !pr.nsub || pl.nsub != pr.nsub || pl.nleaves != pr.nleaves || pl.w32 || pr.w32)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level unique-key join: the tables are not in the first-level layout");
+	MDB_HIP(ctx, hipMemsetAsync(match, 0, n_l * 4, ctx->stream));
+	pw_args a;
+	a.hv_l = pl.hv;
+	a.hv_r = pr.hv;
+	a.cnt_l = pl.leaf_cnt;
+	a.cnt_r = pr.leaf_cnt;
+	a.cap_l = pl.leaf_cap;
+	a.cap_r = pr.leaf_cap;
+	a.nleaves = pl.nleaves;
+	a.nsub = pl.nsub;
+	a.match = match;
+	a.joined = (unsigned long long *)(ctx->d_status + 2);
+	a.status = ctx->d_status;
+	const size_t lds = (size_t)4 << rem;
+	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	MDB_LAUNCH_LDS(ctx, "leaf_pairs_wide", k_leaf_pairs_wide, pl.nleaves, PW_THREADS, lds, a, rem, shift);
+	/* the compaction's first half needs nothing from the host */
+	MDB_LAUNCH(ctx, "match_count", k_match_count, nb, MC_THREADS, match, (uint32_t)n_l, blk);
+	MDB_HIP(ctx, hipMemsetAsync(blk + nb, 0, 4, ctx->stream));
+	rc = mdb_scan_u32_inplace(ctx, blk, (uint64_t)nb + 1, blk_tmp);
+	if (rc)
+		return rc;
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t status = (uint32_t)h[1];
+	const uint64_t J = h[2];
+	if (status & 128u)
+		return 2;
+	if (status & 32u)
+		return 3;
+	if (status & 2u)
+		return 1;
+	*out_count = J;
+	if (J == 0)
+		return 0;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+	}
+	MDB_LAUNCH(ctx, "match_emit", k_match_emit, nb, MC_THREADS, match, (uint32_t)n_l, blk, ol, orr);
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_l = ol;
+	*out_r = orr;
+	return 0;
+}
+
+#define SORT_SWAP_MIN_ROWS (1u << 18)
+
+/* ------------------------------------------------------------------ tiny materialising join: one kernel, one workgroup
+ *
+ * The reference's own test cases join a handful of rows (tests/engine/executor_select.c:102-260).  Up to TINY_ROWS rows per
+ * table the right keys sit in LDS and every left row simply walks over them - twice: once to count its matches, once,
+ * after a prefix sum over the left rows, to write its pairs - which is the reference's nested loop and delivers its
+ * left-major / right-minor order by construction.  All lanes read the same right row at the same time (an LDS broadcast). */
+#define TINY_PAIRS_CAP 65536u
+
+struct tinyp_args {
+	const int64_t *keys_l;
+	const uint64_t *null_l;
+	uint32_t n_l;
+	const int64_t *keys_r;
+	const uint64_t *null_r;
+	uint32_t n_r;
+	uint32_t *out_l, *out_r;
+	uint32_t cap;
+	uint32_t *status;	/* [0] bit 12: more pairs than cap, [1] pairs */
+};
+
+__global__ __launch_bounds__(GC_THREADS) void k_tiny_join_pairs(tinyp_args a)
+{
+	__shared__ int64_t s_kr[TINY_ROWS];
+	__shared__ uint8_t s_nr[TINY_ROWS];
+	__shared__ uint32_t s_tmp[32];
+	for (uint32_t j = threadIdx.x; j < a.n_r; j += GC_THREADS) {
+		s_kr[j] = a.keys_r[j];
+		s_nr[j] = a.null_r && mdb_bit_is_set(a.null_r, j);
+	}
+	__syncthreads();
+	int64_t kl[LEAF_BATCH];
+	bool ok[LEAF_BATCH];
+	uint32_t m[LEAF_BATCH];
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {
+		const uint32_t i = threadIdx.x + (uint32_t)u * GC_THREADS;
+		ok[u] = i < a.n_l && !(a.null_l && mdb_bit_is_set(a.null_l, i));
+		kl[u] = ok[u] ? a.keys_l[i] : 0;
+		m[u] = 0;
+	}
+	for (uint32_t j = 0; j < a.n_r; j++) {
+		const int64_t k = s_kr[j];
+		const bool live = !s_nr[j];
+#pragma unroll
+		for (int u = 0; u < LEAF_BATCH; u++)
+			m[u] += ok[u] && live && kl[u] == k;
+	}
+	uint32_t base = 0, off[LEAF_BATCH];
+#pragma unroll
+	for (int u = 0; u < LEAF_BATCH; u++) {	/* rows in index order: u = 0 covers rows 0 .. GC_THREADS - 1 */
+		uint32_t total;
+		off[u] = base + mdb_block_excl_scan(m[u], s_tmp, &total);
+		base += total;
+	}
+	if (base <= a.cap) {
+		for (uint32_t j = 0; j < a.n_r; j++) {
+			const int64_t k = s_kr[j];
+			const bool live = !s_nr[j];
+#pragma unroll
+			for (int u = 0; u < LEAF_BATCH; u++)
+				if (ok[u] && live && kl[u] == k) {
+					a.out_l[off[u]] = threadIdx.x + (uint32_t)u * GC_THREADS;
+					a.out_r[off[u]] = j;
+					off[u]++;
+				}
+		}
+	}
+	if (threadIdx.x == 0) {
+		a.status[0] = base > a.cap ? 4096u : 0u;
+		a.status[1] = base;
+	}
+}
+
+/* 0 = done, 1 = not applicable (too many rows or pairs), < 0 = error */
+static int tiny_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			   const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	if (n_l > TINY_ROWS || n_r > TINY_ROWS)
+		return 1;
+	const uint64_t worst = n_l * n_r;
+	const uint32_t cap = worst < TINY_PAIRS_CAP ? (uint32_t)worst : TINY_PAIRS_CAP;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&ol) || mdb_cached_alloc(ctx, (size_t)cap * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %u join pairs", cap);
+	}
+	tinyp_args a;
+	a.keys_l = keys_l;
+	a.null_l = null_l;
+	a.n_l = (uint32_t)n_l;
+	a.keys_r = keys_r;
+	a.null_r = null_r;
+	a.n_r = (uint32_t)n_r;
+	a.out_l = ol;
+	a.out_r = orr;
+	a.cap = cap;
+	a.status = ctx->d_status;
+	mdb_prof_begin(ctx, "tiny_join_pairs", (const void *)k_tiny_join_pairs);	/* (not MDB_LAUNCH: an error has two buffers to give back) */
+	hipLaunchKernelGGL(k_tiny_join_pairs, dim3(1), dim3(GC_THREADS), 0, ctx->stream, a);
+	mdb_prof_end(ctx);
+	uint32_t *h = (uint32_t *)ctx->h_pinned;
+	hipError_t e = hipMemcpyAsync(h, ctx->d_status, 8, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess || (h[0] & 4096u)) {
+		(void)mdb_cached_free(ctx, ol);
+		(void)mdb_cached_free(ctx, orr);
+		if (e != hipSuccess)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "tiny join failed: %s", hipGetErrorString(e));
+		return 1;	/* more pairs than the small buffers hold: the general path sizes its output exactly */
+	}
+	*out_l = ol;
+	*out_r = orr;
+	*out_count = h[1];
+	return 0;
+}
+
+/* the unique-key join with its narrow-form decision and retry; result codes of join_pairs_unique() except 2 */
+static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	bool narrow = false;
+	int64_t base = 0;
+	gc_window win = { 0, 0, false, false, false, false };
+	int urc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base, &win);
+	if (urc)
+		return urc;
+	/* a compact window of at most 2^24 key values: one partition level, see join_pairs_unique_wide (MDB_ONE_LEVEL=0 switches
+	 * it off).  What it cannot do - a key outside the window after all, a first-level region overflow - goes the usual way */
+	if (narrow && win.kbits >= 9u + PW_MIN_REM && win.kbits <= 9u + PW_MAX_REM && n_l <= PW_MAX_LEFT && n_l + n_r >= (1ull << 20) &&
+	    !(ctx->pw_bad_keys == keys_r && ctx->pw_bad_n == n_r) && !ld_disabled() &&
+	    !(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0')) {
+		urc = join_pairs_unique_wide(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, win.kbits, win.lo, out_l, out_r, out_count);
+		if (urc <= 0 || urc == 3)
+			return urc;
+		ctx->pw_bad_keys = keys_r;
+		ctx->pw_bad_n = n_r;
+	}
+	urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, narrow, base, out_l, out_r, out_count);
+	if (urc == 2) {	/* the sample (or what was remembered about these columns) missed a wide key */
+		if (ctx->narrow_mode == 1) {
+			ctx->nh_distrust = 8;
+			gc_narrow_note(ctx, keys_l, n_l, keys_r, n_r, false);
+		}
+		urc = join_pairs_unique(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, 0, out_l, out_r, out_count);
+	}
+	return urc;
+}
+
+/* Unique LEFT keys, duplicates on the right (FROM pk_table JOIN fk_table): the unique-key join runs with the sides
+ * swapped - it delivers the pairs in right-row order - and a stable sort by left row id puts them into the reference's
+ * left-major / right-minor order (for one left row the right rows are already ascending).  About half the time of the
+ * general count / scan / emit path.  Same result codes as join_pairs_unique(). */
+static int join_pairs_unique_left(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				  const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r, uint64_t *out_count)
+{
+	if (n_l >= 0x7FFFFFFFull)
+		return 1;
+	uint32_t *sr = NULL, *sl = NULL;	/* swapped call: "left" ids are right rows, "right" ids are left rows */
+	uint64_t J = 0;
+	int rc = join_pairs_unique_auto(ctx, keys_r, null_r, n_r, keys_l, null_l, n_l, &sr, &sl, &J);
+	if (rc)
+		return rc;
+	*out_count = J;
+	if (J == 0)
+		return 0;
+	int64_t *wide = NULL;
+	uint32_t *perm = NULL, *ol = NULL, *orr = NULL;
+	rc = -MIDORIDB_NOMEM;
+	if (mdb_cached_alloc(ctx, J * 8, (void **)&wide) || mdb_cached_alloc(ctx, J * 4, (void **)&perm) ||
+	    mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		(void)mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+		goto fail;
+	}
+	/* the pairs as words, sorted: nothing to widen, no permutation to gather through */
+	rc = mdb_sort_pairs(ctx, sl, sr, J, n_l, n_r, ol, orr);
+	if (rc < 0)
+		goto fail;
+	if (rc == 0) {
+		(void)mdb_cached_free(ctx, wide);
+		(void)mdb_cached_free(ctx, perm);
+		(void)mdb_cached_free(ctx, sr);
+		(void)mdb_cached_free(ctx, sl);
+		*out_l = ol;
+		*out_r = orr;
+		return 0;
+	}
+	/* few pairs or unevenly spread left rows: stable sort of a permutation by left row id, two gathers */
+	rc = mdb_dev_widen32to64(ctx, (const int32_t *)sl, J, wide);
+	if (rc)
+		goto fail;
+	{
+		struct mdb_sort_key key;
+		memset(&key, 0, sizeof(key));
+		key.values = wide;
+		key.type = MDB_T_INT64;
+		rc = mdb_dev_sort_perm(ctx, &key, 1, J, perm);
+		if (rc)
+			goto fail;
+	}
+	rc = mdb_dev_gather32(ctx, sl, perm, J, ol);
+	if (!rc)
+		rc = mdb_dev_gather32(ctx, sr, perm, J, orr);
+	if (!rc)
+		rc = mdb_dev_sync(ctx);
+	if (rc)
+		goto fail;
+	(void)mdb_cached_free(ctx, wide);
+	(void)mdb_cached_free(ctx, perm);
+	(void)mdb_cached_free(ctx, sr);
+	(void)mdb_cached_free(ctx, sl);
+	*out_l = ol;
+	*out_r = orr;
+	return 0;
+fail:
+	if (wide)
+		(void)mdb_cached_free(ctx, wide);
+	if (perm)
+		(void)mdb_cached_free(ctx, perm);
+	if (ol)
+		(void)mdb_cached_free(ctx, ol);
+	if (orr)
+		(void)mdb_cached_free(ctx, orr);
+	(void)mdb_cached_free(ctx, sr);
+	(void)mdb_cached_free(ctx, sl);
+	return rc < 0 ? rc : -MIDORIDB_INTERNAL;
+}
+
+extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
+				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
+				  uint64_t *out_count)
+{
+	*out_l = *out_r = NULL;
+	*out_count = 0;
+	if (n_l == 0 || n_r == 0)
+		return MIDORIDB_OK;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
+	{
+		const int trc = tiny_join_pairs(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, out_l, out_r, out_count);
+		if (trc <= 0)
+			return trc;
+	}
+	/* ---- unique right keys (the usual primary-key join): one record per pair, ordered like group records;
+	 *      unique left keys: the same with the sides swapped and a stable sort.  What a column turned out to be is
+	 *      remembered (by pointer and length), so that a repeated query does not pay for failed attempts. */
+	{
+		uint32_t *ul = NULL, *ur = NULL;
+		uint64_t uj = 0;
+		int urc = 3;
+		bool right_dups = ctx->pu_dup_keys == keys_r && ctx->pu_dup_n == n_r;
+		bool left_dups = ctx->pu_dupl_keys == keys_l && ctx->pu_dupl_n == n_l;
+		if ((right_dups || left_dups) && ++ctx->pu_dup_skips > 32) {	/* the buffers may hold other data by now: look again once in a while */
+			right_dups = left_dups = false;
+			ctx->pu_dup_keys = ctx->pu_dupl_keys = NULL;
+		}
+		if (!right_dups) {
+			urc = join_pairs_unique_auto(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+			if (urc < 0)
+				return urc;
+			if (urc == 3) {
+				ctx->pu_dup_keys = keys_r;
+				ctx->pu_dup_n = n_r;
+				ctx->pu_dup_skips = 0;
+			}
+		}
+		if (urc == 3 && !left_dups && n_l + n_r >= SORT_SWAP_MIN_ROWS) {	/* small tables: the general path has fewer launches */
+			urc = join_pairs_unique_left(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
+			if (urc < 0)
+				return urc;
+			if (urc == 3) {
+				ctx->pu_dupl_keys = keys_l;
+				ctx->pu_dupl_n = n_l;
+				ctx->pu_dup_skips = 0;
+			}
+		}
+		if (urc == 0) {
+			*out_l = ul;
+			*out_r = ur;
+			*out_count = uj;
+			return MIDORIDB_OK;
+		}
+		/* duplicates on both sides, or a table / region overflowed: general path below */
+	}
+	int b1, b2;
+	mdb_choose_bits(n_r, PJ_TARGET, &b1, &b2);
+	const uint64_t mlen = n_l + 1;
+	pj_args a;
+	uint64_t J = 0;
+	uint64_t *h = ctx->h_pinned;
+	/* First with the histogram-free partition layout and the right side in arbitrary order (the emit kernel orders
+	 * every key's row ids itself inside one chunk); the exact, stable layout is the fallback when a region
+	 * overflows (skew) or a leaf holds more right rows than one chunk (their order across chunks matters). */
+	for (int fast = 1; fast >= 0; fast--) {
+		size_t need = mdb_partition_arena_bytes(n_l, b1, b2, true, fast != 0) + mdb_partition_arena_bytes(n_r, b1, b2, true, fast != 0) +
+			      mdb_align_up(mlen * 4) + mdb_align_up(mdb_scan_scratch_words(mlen) * 4) + 4096;
+		int rc = mdb_arena_begin(ctx, need);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+		mdb_part_result pl, pr;
+		hipStream_t main_stream = NULL;
+		rc = mdb_aux_begin(ctx, &main_stream);	/* the right table is partitioned on the auxiliary stream (when enabled) */
+		if (rc)
+			return rc;
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, true, !fast, fast != 0, &pr);
+		{
+			int rc2 = mdb_aux_end(ctx, main_stream);
+			if (rc)
+				return rc;
+			if (rc2)
+				return rc2;
+		}
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, true, false, fast != 0, &pl);
+		if (rc)
+			return rc;
+		if ((rc = mdb_aux_join(ctx)))
+			return rc;
+		uint32_t *match = (uint32_t *)mdb_arena_take(ctx, mlen * 4);
+		uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(mlen) * 4);
+		if (!match || !scan_tmp)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(match, 0, mlen * 4, ctx->stream));
+
+		a.hv_l = pl.hv;
+		a.rid_l = pl.rid;
+		a.off_l = pl.leaf_off;
+		a.cnt_l = pl.leaf_cnt;
+		a.cap_l = pl.leaf_cap;
+		a.hv_r = pr.hv;
+		a.rid_r = pr.rid;
+		a.off_r = pr.leaf_off;
+		a.cnt_r = pr.leaf_cnt;
+		a.cap_r = pr.leaf_cap;
+		a.match = match;
+		a.out_l = a.out_r = NULL;
+		a.status = ctx->d_status;
+		a.total64 = (unsigned long long *)(ctx->d_status + 2);
+		a.nleaves = pl.nleaves;
+		MDB_LAUNCH(ctx, "leaf_pairs_count", k_leaf_pairs_count, pl.nleaves, LEAF_THREADS, a);
+
+		/* offsets are 32-bit; the 64-bit total written by the count kernel guards against N:M blow-ups */
+		rc = mdb_scan_u32_inplace(ctx, match, mlen, scan_tmp);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemcpyAsync(&h[0], match + n_l, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		J = (uint32_t)h[0];
+		const uint32_t status = (uint32_t)h[1];
+		if (fast && (status & (2u | 16u)))
+			continue;	/* region overflow, or a multi-chunk leaf with unordered right rows */
+		if (status & 1u)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL,
+					   "leaf hash table overflow (more than %u distinct keys in one leaf): unsupported key skew", PJ_SLOTS);
+		break;
+	}
+	if (h[2] != J)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join produces %llu rows: more than the 2^32-1 a single call can materialise",
+				   (unsigned long long)h[2]);
+	if (J == 0)
+		return MIDORIDB_OK;
+	uint32_t *ol = NULL, *orr = NULL;
+	if (mdb_cached_alloc(ctx, J * 4, (void **)&ol) || mdb_cached_alloc(ctx, J * 4, (void **)&orr)) {
+		if (ol)
+			(void)mdb_cached_free(ctx, ol);
+		return mdb_set_err(ctx, -MIDORIDB_NOMEM, "cannot allocate %llu join pairs", (unsigned long long)J);
+	}
+	a.out_l = ol;
+	a.out_r = orr;
+	MDB_LAUNCH(ctx, "leaf_pairs_emit", k_leaf_pairs_emit, a.nleaves, LEAF_THREADS, a);
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_l = ol;
+	*out_r = orr;
+	*out_count = J;
+	return MIDORIDB_OK;
+}
