@@ -408,11 +408,46 @@ __device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulongl
 	return any_bad;
 }
 
-template <bool LEVEL0, bool HAS_RID, bool STABLE, bool FAST, bool RAW = false, bool W32 = false, bool INV = false, bool FILT = false,
-	  bool OUT16 = false /* 2-byte words out (see mdb_level_args.out16_shift) */,
-	  bool CF = false /* first level of the compact narrow form over an int64 column (part_hash_key) */>
+/* One instance of the scatter kernel = one of these structs: what the instance knows at compile time.
+ *   LEVEL0  reads the key column (hashes, drops NULLs); otherwise the previous level's words through tile descriptors
+ *   HAS_RID row ids travel in an array of their own (the 64-bit form's left side); STABLE keeps the input order inside a digit
+ *   FAST    histogram-free: fixed-capacity regions + cursors (otherwise exact offsets from a histogram pass)
+ *   RAW     the input words are ready-made sort keys (ordering of group records); W32: 4-byte words; OUT16: 2-byte words out
+ *   INV     partition by destination GPU: what is written is the KEY (and the key-range tests are compiled in)
+ *   FILT    second level with the semi-join bitmap; CF: first level of the compact narrow form over an int64 column
+ * The struct's name is what a profiler shows as the kernel's template argument. */
+struct pf_base {
+	static constexpr bool LEVEL0 = false, HAS_RID = false, STABLE = false, FAST = false, RAW = false, W32 = false, INV = false, FILT = false,
+			      OUT16 = false, CF = false;
+};
+struct pf_word_hist : pf_base {  };
+struct pf_word_hist_raw : pf_base { static constexpr bool RAW = true; };
+struct pf_word : pf_base { static constexpr bool FAST = true; };
+struct pf_word_semi : pf_base { static constexpr bool FAST = true; static constexpr bool FILT = true; };
+struct pf_word_w32 : pf_base { static constexpr bool FAST = true; static constexpr bool W32 = true; };
+struct pf_word_raw : pf_base { static constexpr bool FAST = true; static constexpr bool RAW = true; };
+struct pf_word_raw_w32 : pf_base { static constexpr bool FAST = true; static constexpr bool RAW = true; static constexpr bool W32 = true; };
+struct pf_word_rid_hist : pf_base { static constexpr bool HAS_RID = true; };
+struct pf_word_rid : pf_base { static constexpr bool HAS_RID = true; static constexpr bool FAST = true; };
+struct pf_word_rid_stable_hist : pf_base { static constexpr bool HAS_RID = true; static constexpr bool STABLE = true; };
+struct pf_key_hist : pf_base { static constexpr bool LEVEL0 = true; };
+struct pf_key_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool INV = true; };
+struct pf_key : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; };
+struct pf_key_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool CF = true; };
+struct pf_key_w32 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; };
+struct pf_key_w32_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool CF = true; };
+struct pf_key_w32_out16 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; };
+struct pf_key_w32_out16_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; static constexpr bool CF = true; };
+struct pf_key_rid_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; };
+struct pf_key_rid_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool INV = true; };
+struct pf_key_rid : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; };
+struct pf_key_rid_stable_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool STABLE = true; };
+
+template <typename F /* one of the pf_* structs above */>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
+	constexpr bool LEVEL0 = F::LEVEL0, HAS_RID = F::HAS_RID, STABLE = F::STABLE, FAST = F::FAST, RAW = F::RAW, W32 = F::W32, INV = F::INV, FILT = F::FILT,
+		       OUT16 = F::OUT16, CF = F::CF;
 	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
 	static_assert(!OUT16 || (LEVEL0 && W32 && !RAW), "2-byte words: first level of the 4-byte form only");
 	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
@@ -1132,41 +1167,41 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
 				if (raw_hv && fold32) {
-					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<false, false, false, true, true, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<pf_word_raw_w32>), grid8(ntiles), PART_THREADS, a);
 				} else if (raw_hv) {
-					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, true, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<pf_word_raw>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
 					if (a.minmax_out)
 						MDB_HIP(ctx, hipMemsetAsync(a.minmax_out, 0xFF, (size_t)grid8(ntiles) * 8, ctx->stream));
 					if (out16) {
 						a.out16_shift = 32u - narrow_kbits;
 						if (cf) {
-							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true, true>),
+							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32_out16_cf>),
 								   grid8(ntiles), PART_THREADS, a);
 						} else {
-							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, true>),
+							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32_out16>),
 								   grid8(ntiles), PART_THREADS, a);
 						}
 					} else if (cf) {
-						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true, false, false, false, true>),
+						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32_cf>),
 							   grid8(ntiles), PART_THREADS, a);
 					} else {
-						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<true, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32>), grid8(ntiles), PART_THREADS, a);
 					}
 					if (a.minmax_out)
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
 				} else if (want_rid) {
-					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<true, true, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<pf_key_rid>), grid8(ntiles), PART_THREADS, a);
 				} else if (a.range_in && cf) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
-					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<true, false, false, true, false, false, false, false, false, true>),
+					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key_cf>),
 						   grid8(ntiles), PART_THREADS, a);
 				} else if (a.range_in) {
-					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key>), grid8(ntiles), PART_THREADS, a);
 				} else if (cf) {
-					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true, false, false, false, false, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_cf>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else {
-					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, true>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key>), grid8(ntiles), PART_THREADS, a);
 				}
 				if (!stop0) {
 					MDB_LAUNCH(ctx, "part_region_tiles", k_part_region_tiles_scan, 1, 1024, cursor0, nreg0, cap0, PART_NSUB, reg_nt);
@@ -1219,22 +1254,22 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(leaf_cnt, 0, (size_t)nchild * 4, ctx->stream));
 				if (want_rid) {
-					MDB_LAUNCH(ctx, "part_scatter_l1_rid", (k_part_scatter<false, true, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l1_rid", (k_part_scatter<pf_word_rid>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv && fold32) {
-					MDB_LAUNCH(ctx, "sort_scatter_l1_w32", (k_part_scatter<false, false, false, true, true, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "sort_scatter_l1_w32", (k_part_scatter<pf_word_raw_w32>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv) {
-					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<false, false, false, true, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "sort_scatter_l1", (k_part_scatter<pf_word_raw>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (w32) {
-					MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<pf_word_w32>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (a.filter) {
-					MDB_LAUNCH(ctx, "part_scatter_l1_semi", (k_part_scatter<false, false, false, true, false, false, false, true>),
+					MDB_LAUNCH(ctx, "part_scatter_l1_semi", (k_part_scatter<pf_word_semi>),
 						   grid8(ntiles), PART_THREADS, a);
 				} else {
-					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, true>), grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<pf_word>), grid8(ntiles),
 						   PART_THREADS, a);
 				}
 			}
@@ -1272,23 +1307,23 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			if (rc)
 				return rc;
 			if (l == 0 && raw_hv) {
-				MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<pf_word_hist_raw>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable && l == 0) {
-				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<true, true, true, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0_stable", (k_part_scatter<pf_key_rid_stable_hist>), grid8(ntiles), PART_THREADS, a);
 			} else if (stable) {
-				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<false, true, true, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1_stable", (k_part_scatter<pf_word_rid_stable_hist>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0 && a.inverse_out && want_rid) {
-				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<true, true, false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<pf_key_rid_hist_dest>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0 && a.inverse_out) {
-				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<true, false, false, false, false, false, true>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "dest_scatter", (k_part_scatter<pf_key_hist_dest>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0 && want_rid) {
-				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, true, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_rid_hist>), grid8(ntiles), PART_THREADS, a);
 			} else if (l == 0) {
-				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<true, false, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_hist>), grid8(ntiles), PART_THREADS, a);
 			} else if (want_rid) {
-				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, true, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<pf_word_rid_hist>), grid8(ntiles), PART_THREADS, a);
 			} else {
-				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<false, false, false, false>), grid8(ntiles), PART_THREADS, a);
+				MDB_LAUNCH(ctx, "part_scatter_l1", (k_part_scatter<pf_word_hist>), grid8(ntiles), PART_THREADS, a);
 			}
 			MDB_LAUNCH(ctx, "part_children", k_part_children, (nchild + 1 + 255) / 256, 256, hist, tb, S, R, child_start,
 				   child_nt);
@@ -1424,7 +1459,7 @@ int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const 
 	a.nsub = 0;
 	a.status = ctx->d_status;
 	MDB_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)nchild * 4, ctx->stream));
-	MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<false, false, false, true, false, true>), grid8(ntiles), PART_THREADS, a);
+	MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<pf_word_w32>), grid8(ntiles), PART_THREADS, a);
 	return MIDORIDB_OK;
 }
 
@@ -1464,7 +1499,7 @@ int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_
 	int rc = mdb_scan_u32_inplace(ctx, hist, hlen, scan_tmp);
 	if (rc)
 		return rc;
-	MDB_LAUNCH(ctx, "orderby_scatter", (k_part_scatter<false, true, true, false>), grid8(a.ntiles), PART_THREADS, a);
+	MDB_LAUNCH(ctx, "orderby_scatter", (k_part_scatter<pf_word_rid_stable_hist>), grid8(a.ntiles), PART_THREADS, a);
 	return MIDORIDB_OK;
 }
 
