@@ -68,6 +68,9 @@ struct mdb_col_memo {
 	const void *lw_bad_keys;	/* the left key column (and the two row counts) for which a 16-bit row count of the one-level direct leaves */
 	uint64_t lw_bad_nl, lw_bad_nr;	/* (k_leaf_wide) overflowed last: two levels for these columns */
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
+	const void *lg_kl, *lg_kr;	/* the last join over (lg_kl, lg_nl, lg_kr, lg_nr) delivered lg_groups groups: when that is under a quarter of the */
+	uint64_t lg_nl, lg_nr, lg_groups;	/* left rows, most left rows find no partner whatever the tables' sizes and ranges say (a right table */
+	bool lg_valid;			/* of few distinct keys spread over the left table's range): the next join filters them early */
 };
 
 #define MDB_MEMO_SLOTS 8

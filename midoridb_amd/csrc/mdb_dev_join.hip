@@ -2032,6 +2032,14 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	*out_groups = G;
 	if (out_joined)
 		*out_joined = joined;
+	if (has_r && !st->nextra) {
+		ctx->lg_kl = keys_l;
+		ctx->lg_nl = n_l;
+		ctx->lg_kr = keys_r;
+		ctx->lg_nr = n_r;
+		ctx->lg_groups = G;
+		ctx->lg_valid = true;
+	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
 	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0);
 	return MIDORIDB_OK;
@@ -2194,6 +2202,14 @@ void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 /* The compact window offered by a key sample [lo, hi]: the sampled span, padded by a sixteenth of itself + 4096 on either
  * side for the extremes the sample missed, rounded up to a power of two (the slack is split between the two ends).
  * *kbits = 0: none (span of 2^31 or more, or nothing but NULLs sampled). */
+/* what the previous join over the same columns learned: few groups for many left rows (every use is exact whatever it says:
+ * the bitmap filter only drops rows that can have no partner) */
+static bool gc_learned_selective(const mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r)
+{
+	return ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r && keys_r &&
+	       ctx->lg_groups < n_l / 4;
+}
+
 static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *wlo)
 {
 	*kbits = 0;
@@ -2251,7 +2267,7 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 		if (win && *narrow) {
 			win->kbits = ctx->nh_kbits;
 			win->lo = ctx->nh_lo;
-			win->selective = ctx->nh_selective;
+			win->selective = ctx->nh_selective || gc_learned_selective(ctx, keys_l, n_l, keys_r, n_r);
 			win->by_span = ctx->nh_by_span;
 			win->prunable = ctx->nh_prunable;
 			win->r_based = ctx->nh_r_based;
@@ -2277,7 +2293,9 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 	if (*narrow)
 		gc_compact_window(lo, hi, &kb, &wlo);
 	const bool by_span = keys_r && n_r && ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4;
-	const bool selective = keys_r && n_r && (by_span || n_r < n_l / 4);
+	/* ... or the last join over these very columns found a partner for under a quarter of the left rows: a right table of few
+	 * distinct keys spread over the left table's whole range (no sample of 4096 keys shows that) */
+	const bool selective = keys_r && n_r && (by_span || n_r < n_l / 4 || gc_learned_selective(ctx, keys_l, n_l, keys_r, n_r));
 	const bool prunable = keys_r && n_r && ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r / 7 < ctx->sr_span_l / 8;
 	/* the right table covers a small part of the left table's range and min-max pruning will drop the left rows outside it:
 	 * the compact window need only cover the RIGHT table's keys (variant D: 23 key bits instead of 27 - 4096 leaves of
