@@ -170,7 +170,9 @@ int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, int side, 
  * out_key / out_count (capacity cap): the groups; d_status[1] = their number, d_status[2..3] = joined rows (u64), flags in
  * d_status[0] (bit 1 a region overflowed, bit 3 cap too small, bit 7 a right key outside the window).  No host sync. */
 int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, const void *const *recv, const uint32_t *const *cnt, int64_t *out_key,
-		   int64_t *out_count, uint64_t cap);
+		   int64_t *out_count, uint64_t cap, void *const *arrived = NULL /* [ntab] hipEvent_t or NULL: table x's blocks and counters
+		   have arrived when arrived[x] has happened - the context's stream waits for it right before the first kernel that reads
+		   table x, so the receiver's level over one table runs while the next table is still on the wire */);
 
 /* ---- ordering of (row id, payload) records (mdb_dev_join.hip) ----------------------------------
  * rec[i] = (row id << (64 - kbits)) | payload (payload >= 1; zero words are gaps), kbits = bits of a row id as

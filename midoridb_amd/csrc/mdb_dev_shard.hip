@@ -7,7 +7,7 @@
  * then the local operator read what arrived and partitioned it again - 3.1 x the local operator before a byte crossed xGMI.
  * Now the sender's ONE pass is the join's first partition level itself: the compact narrow form's 512-digit histogram-free
  * scatter (mdb_dev_partition.hip), whose digit's top log2(world) bits are the destination rank.  A destination's regions
- * are one contiguous block of a size every rank can compute (fixed-capacity regions), so the all-to-all is posted without
+ * are one contiguous block of a size every rank can compute (fixed-capacity regions: the average + 1/16 + 1024 words), so the all-to-all is posted without
  * any count reaching a host; the region counters travel as 16 KiB beside it and are only ever read by kernels.  The
  * receiver builds region descriptors (source rank x digit x sub-region), and either joins a digit straight from its
  * regions (the hash bits below the digit index an LDS table: k_shard_leaf, one level) or runs one partition level of its
@@ -97,9 +97,12 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 		frac = 1.0L;
 	const uint64_t nl_est = (uint64_t)((long double)n_l_max * frac * 1.1L) + 1;
 	const uint64_t regions = (uint64_t)p->D * p->nsub;
-	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 5 / 4 / regions + 1024);
+	/* (a region's fill is the sum of its tiles' shares of a bijective hash: for 10^8 rows 24 414 +- 160 rows - the 1024 words
+	 * cover that; the factor covers the XCDs' uneven tile counts.  Every word of slack crosses xGMI: 1/16, not the single-GPU
+	 * first level's 1/4) */
+	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 17 / 16 / regions + 1024);
 	for (uint32_t x = 1; x < ntab; x++)
-		p->cap[x] = sh_round64(n_max[x] * 5 / 4 / regions + 1024);	/* (further right tables: sized for all their rows, though only those in the window travel) */
+		p->cap[x] = sh_round64(n_max[x] * 17 / 16 / regions + 1024);	/* (further right tables: sized for all their rows, though only those in the window travel) */
 	for (uint32_t x = 0; x < ntab; x++) {
 		p->block_words[x] = (uint64_t)p->Dp * p->nsub * p->cap[x];
 		if (p->block_words[x] * world >= 0xFFFFFFFFull)
@@ -109,7 +112,7 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 		/* the receiver's leaves: 1.5 x the average + 1024 (its rows are known only as a bound: what the regions can hold) */
 		const uint64_t nleaves = (uint64_t)p->Dp << p->b2;
 		for (uint32_t x = 0; x < ntab; x++) {
-			const uint64_t bound = p->block_words[x] * world * 4 / 5;	/* (the regions are sized 1.25 x) */
+			const uint64_t bound = p->block_words[x] * world;	/* (what the regions can hold at most) */
 			p->leaf_cap[x] = sh_round64(bound * 3 / 2 / nleaves + 1024);
 			if (nleaves * p->leaf_cap[x] >= 0xFFFFFFFFull)
 				return 1;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 }
 
 int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const *recv, const uint32_t *const *cnt, int64_t *out_key,
-		   int64_t *out_count, uint64_t cap)
+		   int64_t *out_count, uint64_t cap, void *const *arrived)
 {
 	const uint32_t nreg = p->D * p->nsub, regs_per_digit = p->world * p->nsub, d0 = p->rank * p->Dp;
 	uint32_t *reg_start[MDB_SHARD_MAX_TABS], *reg_cnt[MDB_SHARD_MAX_TABS];
@@ -407,6 +410,12 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		reg_cnt[x] = (uint32_t *)mdb_arena_take(ctx, (size_t)nreg * 4);
 		if (!reg_start[x] || !reg_cnt[x])
 			return -MIDORIDB_INTERNAL;
+	}
+	/* one level: the leaf kernel needs every table; two levels: table x's own level only needs table x */
+	for (uint32_t x = 0; x < p->ntab && p->b2 == 0; x++)
+		if (arrived && arrived[x])
+			MDB_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)arrived[x], 0));
+	for (uint32_t x = 0; x < p->ntab && p->b2 == 0; x++) {
 		MDB_LAUNCH(ctx, "shard_regions", k_shard_regions, (nreg + 255) / 256, 256, cnt[x], p->world, p->D, p->Dp, p->nsub, d0, p->cap[x],
 			   (uint32_t)p->block_words[x], reg_start[x], reg_cnt[x], ctx->d_status);
 	}
@@ -441,6 +450,10 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 	/* two levels: the receiver's own level over the regions of all ranks, then its leaves */
 	const uint32_t nleaves = p->Dp << p->b2;
 	for (uint32_t x = 0; x < p->ntab; x++) {
+		if (arrived && arrived[x])
+			MDB_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)arrived[x], 0));
+		MDB_LAUNCH(ctx, "shard_regions", k_shard_regions, (nreg + 255) / 256, 256, cnt[x], p->world, p->D, p->Dp, p->nsub, d0, p->cap[x],
+			   (uint32_t)p->block_words[x], reg_start[x], reg_cnt[x], ctx->d_status);
 		const uint32_t max_tiles = (uint32_t)(p->block_words[x] * p->world / MDB_TILE) + nreg + 1;
 		uint32_t *tb = (uint32_t *)mdb_arena_take(ctx, ((size_t)nreg + 1) * 4);
 		mdb_tile_desc *tiles = (mdb_tile_desc *)mdb_arena_take(ctx, (size_t)max_tiles * sizeof(mdb_tile_desc));

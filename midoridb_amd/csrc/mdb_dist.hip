@@ -40,6 +40,7 @@ struct mdb_dist {
 	uint64_t last_recv_left;
 	/* row shuffles (mdb_dist_shuffle_rows): buffers the posted transfers still read - released by mdb_dist_wait_transfers() */
 	hipEvent_t ev_sh;
+	hipEvent_t ev_tab[MDB_SHARD_MAX_TABS];	/* the sharded operator: table x has arrived */
 	bool sh_posted;
 	void *pend[SH_MAX_PENDING];
 	int npend;
@@ -312,7 +313,11 @@ static int dist_new(mdb_dev_ctx *ctx, int world, int rank, mdb_dist **out)
 	    hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->ev_a, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->ev_b, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->ev_sh, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&d->ev_sh, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_tab[0], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_tab[1], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_tab[2], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->ev_tab[3], hipEventDisableTiming) != hipSuccess) {
 		mdb_dist_destroy(d);
 		return -MIDORIDB_INTERNAL;
 	}
@@ -431,6 +436,9 @@ extern "C" void mdb_dist_destroy(mdb_dist *d)
 		(void)hipEventDestroy(d->ev_b);
 	if (d->ev_sh)
 		(void)hipEventDestroy(d->ev_sh);
+	for (int x = 0; x < MDB_SHARD_MAX_TABS; x++)
+		if (d->ev_tab[x])
+			(void)hipEventDestroy(d->ev_tab[x]);
 	for (int i = 0; i < d->npend; i++)
 		(void)mdb_dev_free(d->ctx, d->pend[i]);
 	if (d->comm_stream)
@@ -679,15 +687,17 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 			rc = d->t.alltoallv(d->t.self, cursors, cc, cd0, rcnt[x], cc, cdr, 4, d->comm_stream);
 		if (rc)
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
+		DIST_HIP(d, hipEventRecord(d->ev_tab[x], d->comm_stream));
 	}
 	/* (a rank whose partition call failed outright - not a flag on the device, a launch or sizing error - cannot post its
 	 * transfers; its peers' receives for this call would then hang, so such a failure is fatal for the communicator and
 	 * reported as such) */
 	if (prc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded first level: %s", mdb_dev_last_error(ctx)));
-	DIST_HIP(d, hipEventRecord(d->ev_b, d->comm_stream));
-	DIST_HIP(d, hipStreamWaitEvent(ctx->stream, d->ev_b, 0));
-	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, out_count, cap);
+	/* (the receiver waits for a table right before the first kernel that reads it: its own level over the left table runs while
+	 * the right table is still on the wire) */
+	void *arrived[MDB_SHARD_MAX_TABS] = { d->ev_tab[0], d->ev_tab[1], d->ev_tab[2], d->ev_tab[3] };
+	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, out_count, cap, arrived);
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "sharded join: %s", mdb_dev_last_error(ctx)));
 	/* ---- G, J and the flags come back with ONE host synchronisation; what went wrong anywhere sends every rank the same way:
