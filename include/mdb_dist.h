@@ -187,6 +187,8 @@ int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null
 			uint64_t *out_rows);
 
 /* helpers for hosts without a collective library of their own */
+/* every rank's n (<= 8) 64-bit values to every rank: all[p * n + i] = value i of rank p (HOST arrays, blocking, collective) */
+int mdb_dist_allgather_u64(mdb_dist *d, const uint64_t *mine, int n, uint64_t *all);
 int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n);
 int mdb_dist_barrier(mdb_dist *d);
 

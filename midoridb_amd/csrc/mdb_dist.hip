@@ -47,6 +47,8 @@ struct mdb_dist {
 	char err[512];
 };
 
+static const char *transport_err(mdb_dist *d);
+
 static int dist_err(mdb_dist *d, int code, const char *fmt, ...)
 {
 	va_list ap;
@@ -482,6 +484,37 @@ extern "C" int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n)
 		return -MIDORIDB_ERROR;
 	const int rc = d->t.allreduce_sum_u64(d->t.self, vals, n);
 	return rc ? dist_err(d, rc, "all-reduce failed%s%s", d->own_transport ? ": " : "", d->own_transport ? ((rccl_transport *)d->t.self)->err : "") : rc;
+}
+
+extern "C" int mdb_dist_allgather_u64(mdb_dist *d, const uint64_t *mine, int n, uint64_t *all)
+{
+	if (!d || !mine || !all || n < 1 || n > 8)
+		return -MIDORIDB_ERROR;
+	/* (values travel as 32-bit halves: a transport's counters need not survive values beyond 2^63) */
+	uint64_t sendv[16 << MDB_MAX_RADIX_BITS], recvv[16 << MDB_MAX_RADIX_BITS];
+	for (int p = 0; p < d->world; p++)
+		for (int i = 0; i < n; i++) {
+			sendv[2 * n * p + 2 * i] = mine[i] >> 32;
+			sendv[2 * n * p + 2 * i + 1] = mine[i] & 0xFFFFFFFFull;
+		}
+	int rc = 0;
+	for (int half = 0; half < 2 * n && !rc; half += RT_MAX_COUNTERS) {	/* at most RT_MAX_COUNTERS counters per exchange */
+		const int cnt = 2 * n - half < RT_MAX_COUNTERS ? 2 * n - half : RT_MAX_COUNTERS;
+		uint64_t s2[RT_MAX_COUNTERS << MDB_MAX_RADIX_BITS], r2[RT_MAX_COUNTERS << MDB_MAX_RADIX_BITS];
+		for (int p = 0; p < d->world; p++)
+			for (int i = 0; i < cnt; i++)
+				s2[cnt * p + i] = sendv[2 * n * p + half + i];
+		rc = d->t.counts(d->t.self, s2, r2, cnt);
+		for (int p = 0; p < d->world && !rc; p++)
+			for (int i = 0; i < cnt; i++)
+				recvv[2 * n * p + half + i] = r2[cnt * p + i];
+	}
+	if (rc)
+		return dist_err(d, rc, "all-gather failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	for (int p = 0; p < d->world; p++)
+		for (int i = 0; i < n; i++)
+			all[n * p + i] = (recvv[2 * n * p + 2 * i] << 32) | recvv[2 * n * p + 2 * i + 1];
+	return MIDORIDB_OK;
 }
 
 extern "C" int mdb_dist_barrier(mdb_dist *d)

@@ -595,6 +595,7 @@ struct exec {
 	struct mdb_table *shadow[MDB_MAX_TABS], *orig_tab[MDB_MAX_TABS];
 	const struct mdb_expr *part[2 * MDB_MAX_TABS];
 	int npart;
+	bool promised;		/* the exchange handle holds this statement's key ranges (shard_promise_ranges) */
 	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
 };
 
@@ -864,8 +865,69 @@ static int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32
 	return MIDORIDB_OK;
 }
 
+/* Sharded joins on key columns of BASE tables: the exchange is told the two tables' GLOBAL key ranges from catalog statistics -
+ * the smallest / largest key of each rank's mirror, computed once per table generation (one pass) and agreed on with one tiny
+ * all-gather per statement - instead of measuring both columns on every call (MDB_WIRE_AUTO: two passes over the columns per
+ * query).  With the ranges known the operator ships first-level partition regions (mdb_dev_shard.hip).  A filtered table's keys
+ * lie inside its column's range: a superset is fine. */
+static int shard_promise_ranges(struct exec *x, const struct mdb_expr *fl, const struct mdb_expr *fr)
+{
+	struct mdb_column *cols[2] = { &x->s->tabs[fl->tbl_idx].t->cols[fl->col_idx], &x->s->tabs[fr->tbl_idx].t->cols[fr->col_idx] };
+	struct mdb_table *tabs[2] = { x->s->tabs[fl->tbl_idx].t, x->s->tabs[fr->tbl_idx].t };
+	uint64_t mine[4], all[4 * 512];
+	const int W = mdb_dist_world(x->cat->dist);
+	if (W > 512)
+		return MIDORIDB_OK;
+	for (int i = 0; i < 2; i++) {
+		if (cols[i]->st_generation != tabs[i]->generation + 1) {
+			int64_t lo = 0, hi = -1;
+			if (tabs[i]->nrows && mdb_dev_key_range(x->dev, cols[i]->d_data, cols[i]->d_nullbits, tabs[i]->nrows, &lo, &hi))
+				return dev_fail(x, "column statistics");
+			cols[i]->st_lo = lo;
+			cols[i]->st_hi = hi;
+			cols[i]->st_generation = tabs[i]->generation + 1;
+		}
+		const bool none = cols[i]->st_lo > cols[i]->st_hi;
+		/* (as offsets from the smallest int64: every rank's minimum of the unsigned images is the global minimum) */
+		mine[2 * i] = none ? ~0ull : (uint64_t)cols[i]->st_lo ^ 0x8000000000000000ull;
+		mine[2 * i + 1] = none ? 0ull : (uint64_t)cols[i]->st_hi ^ 0x8000000000000000ull;
+	}
+	if (mdb_dist_allgather_u64(x->cat->dist, mine, 4, all)) {
+		snprintf(x->err, x->errlen, "execution phase: %s\n", mdb_dist_last_error(x->cat->dist));
+		return -MIDORIDB_INTERNAL;
+	}
+	int64_t g[2][2];
+	bool fits32 = true;
+	for (int i = 0; i < 2; i++) {
+		uint64_t lo = ~0ull, hi = 0;
+		for (int p = 0; p < W; p++) {
+			lo = all[4 * p + 2 * i] < lo ? all[4 * p + 2 * i] : lo;
+			hi = all[4 * p + 2 * i + 1] > hi ? all[4 * p + 2 * i + 1] : hi;
+		}
+		g[i][0] = (int64_t)(lo ^ 0x8000000000000000ull);
+		g[i][1] = (int64_t)(hi ^ 0x8000000000000000ull);
+		if (lo > hi) {		/* no key on any rank: an empty range (lo > hi) */
+			g[i][0] = 0;
+			g[i][1] = -1;
+		} else if (g[i][0] < -(1ll << 31) || g[i][1] >= (1ll << 31)) {
+			fits32 = false;
+		}
+	}
+	if (g[0][0] > g[0][1] || g[1][0] > g[1][1])
+		return MIDORIDB_OK;	/* (a table without keys: the measuring path answers "no groups") */
+	if (mdb_dist_set_key_ranges(x->cat->dist, g[0], g[1]) || mdb_dist_set_wire(x->cat->dist, fits32 ? MDB_WIRE_32 : MDB_WIRE_64))
+		return -MIDORIDB_INTERNAL;
+	x->promised = true;
+	return MIDORIDB_OK;
+}
+
 static void shard_cleanup(struct exec *x)
 {
+	if (x->promised) {	/* back to per-call measurement for whoever uses the handle next */
+		(void)mdb_dist_set_key_ranges(x->cat->dist, NULL, NULL);
+		(void)mdb_dist_set_wire(x->cat->dist, MDB_WIRE_AUTO);
+		x->promised = false;
+	}
 	for (int t = 0; t < MDB_MAX_TABS; t++) {
 		if (x->orig_tab[t])
 			x->s->tabs[t].t = x->orig_tab[t];
@@ -1663,6 +1725,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			rc = -MIDORIDB_ERROR;
 			goto out;
 		}
+		if (cat->dist && fkeys[0]->type != MDB_CT_DOUBLE && (rc = shard_promise_ranges(&x, fkeys[0], fkeys[1])))
+			goto out;
 		if (cat->dist && s->ntabs > 2 && s->ntabs <= 4) {
 			/* sharded mode, three or four tables on one key: ONE exchange - every table partitioned once with the same hash, the
 			 * right tables' counts multiplied where the regions meet (mdb_dist_join_group_count_multi_alloc); when that form is

@@ -60,6 +60,10 @@ struct mdb_column {
 	/* device mirror */
 	void *d_data;
 	uint64_t *d_nullbits;		/* NULL when null_count == 0 */
+	/* catalog statistics of the device mirror: smallest / largest non-NULL value (st_lo > st_hi: none) as of table generation
+	 * st_generation + 1 (0 = never computed) - what sharded joins promise the exchange instead of measuring per query */
+	uint64_t st_generation;
+	int64_t st_lo, st_hi;
 };
 
 struct mdb_table {

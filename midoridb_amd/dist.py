@@ -40,7 +40,7 @@ DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
-    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
 ]
 
 
@@ -70,6 +70,7 @@ def _bind(lib):
         "mdb_dist_last_received_left": ([P], c_uint64),
         "mdb_dist_allreduce_sum_u64": ([P, POINTER(c_uint64), c_int], c_int),
         "mdb_dist_barrier": ([P], c_int),
+        "mdb_dist_allgather_u64": ([P, POINTER(c_uint64), c_int, POINTER(c_uint64)], c_int),
         "mdb_dist_shuffle_rows": ([P, P, P, c_uint64, ctypes.c_uint32, POINTER(DistCol), c_int, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dist_wait_transfers": ([P], c_int),
         "mdb_dist_join_pairs": ([P, P, P, c_uint64, POINTER(DistCol), c_int, P, P, c_uint64, POINTER(DistCol), c_int, POINTER(P), POINTER(P),
