@@ -204,11 +204,15 @@ def sharded_sql(world, rank):
         "SELECT DISTINCT f1 FROM A;",
         "SELECT DISTINCT f2, f3 FROM B INNER JOIN C ON B.f2 = C.id_c;",
         "SELECT f2, COUNT(*) FROM B GROUP BY f2 HAVING COUNT(*) > 17;",
+        "SELECT id_a, f1 FROM A WHERE f1 IS NULL;",
+        "SELECT id_a, x FROM A INNER JOIN B ON A.id_a = B.id_b WHERE x > 0.4 ORDER BY id_a;",
+        "SELECT id_b, COUNT(*) FROM B INNER JOIN C ON B.f2 = C.id_c GROUP BY id_b;",
     ]
     counts = [
         "SELECT COUNT(*) FROM A WHERE f1 > 0;",
         "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f2 <= 10 OR f1 IS NULL;",
         "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b;",
+        "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON B.f2 = C.id_c;",
     ]
     tables = {}
     with DB() as db:
