@@ -130,7 +130,8 @@ int mdb_sort_pass(mdb_dev_ctx *ctx, const uint64_t *key_in, const uint32_t *rid_
  * cursor[c] (zeroed by the call) counts its words; bit 1 of ctx->d_status[0] is raised when a child overflows.  Tile starts
  * must be multiples of 4 words.  No host sync. */
 int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const mdb_tile_desc *tiles, uint32_t ntiles, int bits, uint32_t shift,
-			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap);
+			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap,
+			      uint32_t out16_shift = 0 /* != 0: the children receive 2-byte words (uint16_t)(word >> out16_shift); cap counts them */);
 
 /* ---- the sharded join + GROUP BY with first-level regions on the wire (mdb_dev_shard.hip) ------------------------------
  *

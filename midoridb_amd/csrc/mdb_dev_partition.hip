@@ -425,6 +425,7 @@ struct pf_word_hist_raw : pf_base { static constexpr bool RAW = true; };
 struct pf_word : pf_base { static constexpr bool FAST = true; };
 struct pf_word_semi : pf_base { static constexpr bool FAST = true; static constexpr bool FILT = true; };
 struct pf_word_w32 : pf_base { static constexpr bool FAST = true; static constexpr bool W32 = true; };
+struct pf_word_w32_out16 : pf_base { static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; };
 struct pf_word_raw : pf_base { static constexpr bool FAST = true; static constexpr bool RAW = true; };
 struct pf_word_raw_w32 : pf_base { static constexpr bool FAST = true; static constexpr bool RAW = true; static constexpr bool W32 = true; };
 struct pf_word_rid_hist : pf_base { static constexpr bool HAS_RID = true; };
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	constexpr bool LEVEL0 = F::LEVEL0, HAS_RID = F::HAS_RID, STABLE = F::STABLE, FAST = F::FAST, RAW = F::RAW, W32 = F::W32, INV = F::INV, FILT = F::FILT,
 		       OUT16 = F::OUT16, CF = F::CF;
 	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
-	static_assert(!OUT16 || (LEVEL0 && W32 && !RAW), "2-byte words: first level of the 4-byte form only");
+	static_assert(!OUT16 || (W32 && !RAW), "2-byte words out: the 4-byte form only");
 	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
 	/* INV (destination partition for the exchange): what is staged and written is the KEY, not its hash - the digit is
 	 * taken from the hash once, at load time, and found again at write-out from the staged position (the tile-local
@@ -1440,7 +1441,7 @@ int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits
 /* ---- one histogram-free radix level over 4-byte words in caller-described tiles (the receiver's second level of the
  * sharded operator, mdb_dev_shard.hip: its input regions came from several ranks) ------------------------------------- */
 int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const mdb_tile_desc *tiles, uint32_t ntiles, int bits, uint32_t shift,
-			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap)
+			      uint32_t *words_out, uint32_t *cursor, uint32_t nchild, uint32_t cap, uint32_t out16_shift)
 {
 	if (bits < 1 || bits > MDB_MAX_RADIX_BITS || !ntiles)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "words level: bad digit width");
@@ -1459,7 +1460,12 @@ int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const 
 	a.nsub = 0;
 	a.status = ctx->d_status;
 	MDB_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)nchild * 4, ctx->stream));
-	MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<pf_word_w32>), grid8(ntiles), PART_THREADS, a);
+	if (out16_shift) {	/* the children are leaves whose key bits fit 16: 2-byte words out, (uint16_t)(word >> out16_shift) */
+		a.out16_shift = out16_shift;
+		MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<pf_word_w32_out16>), grid8(ntiles), PART_THREADS, a);
+	} else {
+		MDB_LAUNCH(ctx, "part_scatter_l1_w32", (k_part_scatter<pf_word_w32>), grid8(ntiles), PART_THREADS, a);
+	}
 	return MIDORIDB_OK;
 }
 

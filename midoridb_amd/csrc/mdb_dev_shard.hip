@@ -449,6 +449,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 	}
 	/* two levels: the receiver's own level over the regions of all ranks, then its leaves */
 	const uint32_t nleaves = p->Dp << p->b2;
+	const bool leaf16 = p->rem <= 16u && !(getenv("MDB_SHARD_LEAF16") && getenv("MDB_SHARD_LEAF16")[0] == '0');
 	for (uint32_t x = 0; x < p->ntab; x++) {
 		if (arrived && arrived[x])
 			MDB_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)arrived[x], 0));
@@ -464,8 +465,9 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		MDB_LAUNCH(ctx, "shard_tiles_scan", k_shard_tiles_scan, 1, 1024, reg_cnt[x], nreg, tb);
 		MDB_LAUNCH(ctx, "shard_tiles_build", k_shard_tiles_build, (max_tiles + 255) / 256, 256, reg_start[x], reg_cnt[x], tb, nreg, regs_per_digit,
 			   tiles, max_tiles);
+		/* (a leaf's key bits fit 16: its words are written - and read by the leaf kernel - as 2 bytes) */
 		int rc = mdb_partition_words_level(ctx, reinterpret_cast<const uint32_t *>(recv[x]), tiles, max_tiles, p->b2,
-						   32u - SH_D_BITS - (uint32_t)p->b2, leaves, cursor, nleaves, p->leaf_cap[x]);
+						   32u - SH_D_BITS - (uint32_t)p->b2, leaves, cursor, nleaves, p->leaf_cap[x], leaf16 ? 32u - p->kbits : 0u);
 		if (rc)
 			return rc;
 		a.words[x] = leaves;
@@ -474,7 +476,12 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		a.cap[x] = p->leaf_cap[x];
 	}
 	a.nseg = 1;
-	if (p->rem > 10u) {
+	if (leaf16 && p->rem > 10u) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<1024, uint16_t>), nleaves, 1024, lds, a);
+	} else if (leaf16) {
+		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<512, uint16_t>), nleaves, 512, lds, a);
+	} else if (p->rem > 10u) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<1024, uint32_t>), nleaves, 1024, lds, a);
 	} else {
