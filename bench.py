@@ -579,6 +579,17 @@ def main():
                 return {"algorithmic_bytes": ab, "achieved_GBs": ab / seconds / 1e9, "frac_of_peak": ab / seconds / 1e9 / HBM_PEAK_GBS}
             if "wide_form" in line and "ms_per_step" in line["wide_form"]:
                 line["wide_form"]["pipeline"] = pipe_frac(groups_total, line["wide_form"]["ms_per_step"] * 1e-3)
+            def unordered_of(b_tab, expect):
+                # the same operator called without MDB_ORDER_FIRST and without first rows: the groups in unspecified order, no row ids
+                # carried and no ordering sort (reported BESIDE the ordered figures, never as `value`)
+                try:
+                    dtx, rx = timed(lambda: dev.join_group_count_unordered(a, None, b_tab, None, out=out))
+                    return {"ms_per_step": dtx * 1e3, "value": rx[2] / dtx, "served_by_unordered_form": bool(dev.last_join_unordered()),
+                            "same_groups_and_joined_rows": bool(int(rx[0].numel()) == expect[0] and rx[2] == expect[1]),
+                            "pipeline": pipe_frac(int(rx[0].numel()), dtx)}
+                except Exception as e:  # pragma: no cover
+                    return {"error": str(e)}
+            line["unordered"] = unordered_of(b, (groups_total, joined_total))
             if args.variant == "D":
                 # the unfavourable variants beside the headline, same pipeline: U (unique keys on both sides, G = n groups,
                 # nothing to prune) and S (the headline's 16x duplication, but spread over A's whole key range: no range for min-max
@@ -594,6 +605,7 @@ def main():
                                      "value": ru[3] / dtu, "pipeline": pipe_frac(int(ru[0].numel()), dtu),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
                                      "min_max_pruning": bool(dev.last_join_filter()[1])}
+                        line[tag]["unordered"] = unordered_of(b_x, (int(ru[0].numel()), ru[3]))
                         del b_x
                     except Exception as e:  # pragma: no cover
                         line[tag] = {"error": str(e)}

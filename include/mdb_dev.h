@@ -317,7 +317,9 @@ int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
  * out_key[g], out_count[g] (and optionally out_first[g] = first L position of the
  * key, may be NULL): caller buffers of capacity `cap` (n_l is always enough).
  * With MDB_ORDER_FIRST the groups are in the reference's order (first occurrence in
- * L-major join order).  *out_groups = G, *out_joined = number of joined rows
+ * L-major join order).  Without it - and without out_first - the order is unspecified and the operator may
+ * skip everything that order costs: no row id travels through the partition levels and no ordering sort runs
+ * (10^8 x 10^8 unique keys: 1.6 ms instead of 2.6; bit 11 of mdb_dev_last_join_filter() says this form ran).  *out_groups = G, *out_joined = number of joined rows
  * (sum of counts).  Synchronous: G, J and the overflow flags come back before the groups are ordered
  * (the ordering sort is sized by G), completion after it.  Size limit per call: about 7*10^8 left rows
  * (beyond that the tables must be sharded, see mdb_dev_partition_by_dest).

@@ -2619,16 +2619,95 @@ int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nu
 }
 
 
+/* Groups in UNSPECIFIED order (the caller did not pass MDB_ORDER_FIRST and wants no first rows): nothing has to remember which
+ * left row a group began with, so no row id travels through the partition levels and no ordering sort runs - the pipeline of the
+ * sharded operator's receiver (mdb_dev_shard.hip) on this GPU's own first-level regions: 4-byte (or 2-byte) words of the k-bit
+ * window hash for BOTH tables, counts per leaf, (key decoded from the table slot, COUNT) written where the leaf kernel finds it.
+ * Window = the right table's sampled key range, padded like the compact form's; every right key is checked against it on the
+ * device, left rows outside it join nothing.  10^8 x 10^8 unique keys: 1.5 ms of kernels where the ordered operator takes 2.56.
+ * 0 = done, 1 = not served (window too wide, a key outside it, skew, a region overflow ...): the ordered operator answers. */
+static int gc_unordered_try(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			    const uint64_t *null_r, uint64_t n_r, int64_t *out_key, int64_t *out_count, uint64_t cap, uint64_t *out_groups,
+			    uint64_t *out_joined)
+{
+	if (n_l + n_r < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (getenv("MDB_UNORDERED") && getenv("MDB_UNORDERED")[0] == '0'))
+		return 1;
+	bool fresh = false;
+	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+	mdb_shard_plan plan;
+again: {
+	int64_t lo = 0, hi = 0;
+	int rc = gc_sample_range(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, fresh || ctx->nh_distrust > 0, &lo, &hi);
+	const bool remembered = ctx->sr_uses > 0;
+	if (rc)
+		return rc;
+	if (!ctx->sr_span_r || !ctx->sr_span_l)
+		return 1;
+	uint32_t kb = 0;
+	int64_t wlo = 0;
+	gc_compact_window(ctx->sr_rlo, ctx->sr_rhi, &kb, &wlo);
+	if (!kb || kb > 30u)
+		return 1;
+	const uint64_t n_max[2] = { n_l, n_r };
+	if (mdb_shard_plan_make(1, 0, 2, n_max, 0, (int64_t)(ctx->sr_span_l + ctx->sr_span_l / 8), wlo, wlo + (int64_t)((1ull << kb) - 1), &plan))
+		return 1;
+	rc = mdb_arena_begin(ctx, mdb_shard_arena_bytes(&plan));
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	const int64_t *keys[2] = { keys_l, keys_r };
+	const uint64_t *nulls[2] = { null_l, null_r };
+	const void *regions[2] = { NULL, NULL };
+	const uint32_t *cursors[2] = { NULL, NULL };
+	for (int x = 1; x >= 0; x--) {		/* (the right table first, as in the ordered operator) */
+		rc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], n_max[x], &regions[x], &cursors[x]);
+		if (rc)
+			return rc;
+	}
+	rc = mdb_shard_join(ctx, &plan, regions, cursors, out_key, out_count, cap);	/* (world 1: what was sent is what arrived) */
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h[0]) {
+		if (getenv("MDB_DEBUG_UNORDERED"))
+			fprintf(stderr, "unordered form not served: flags %u (k %u, b2 %u, rem %u)\n", h[0], plan.kbits, plan.b2, plan.rem);
+		if ((h[0] & 128u) && remembered && !fresh) {
+			fresh = true;	/* the window came from a remembered sample and the column's contents have changed since */
+			goto again;
+		}
+		if (h[0] & 128u)
+			ctx->nh_distrust = 8;	/* a right key outside the sampled window: look at the data itself the next few times */
+		return 1;
+	}
+	}
+	*out_groups = h[1];
+	if (out_joined)
+		*out_joined = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+	ctx->last_narrow = 2;
+	ctx->last_semijoin = 0x100 | 0x800 | (plan.b2 ? 0 : 0x200);
+	return 0;
+}
+
 extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 					const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags,
 					int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 					uint64_t *out_groups, uint64_t *out_joined)
 {
-	(void)flags;	/* groups always come out in first-occurrence order, which satisfies both modes */
 	*out_groups = 0;
 	if (out_joined)
 		*out_joined = 0;
 	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);	/* what was learned about THIS pair of columns */
+	if (!(flags & MDB_ORDER_FIRST) && !out_first && out_key && n_l && n_r) {
+		/* no order asked for: no row ids, no ordering sort (otherwise - and whenever this form is not served - the groups come
+		 * out in first-occurrence order, which satisfies both modes) */
+		const int urc = gc_unordered_try(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, out_key, out_count, cap, out_groups, out_joined);
+		if (urc <= 0)
+			return urc;
+		*out_groups = 0;
+		if (out_joined)
+			*out_joined = 0;
+	}
 	{
 		const int trc = tiny_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first, cap,
 						 out_groups, out_joined);

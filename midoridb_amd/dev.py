@@ -241,6 +241,10 @@ class DeviceCtx:
         """the last join_group_count_multi counted all its right tables in one pass (no chain of two-table operators)"""
         return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x400)
 
+    def last_join_unordered(self):
+        """the last join_group_count ran without row ids and ordering (flags without MDB_ORDER_FIRST, no first rows wanted)"""
+        return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x800)
+
     def last_join_levels(self):
         """partition levels of the last join / GROUP BY operator's final attempt: 1 (wide direct-address leaves) or 2"""
         return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x200 else 2
@@ -299,6 +303,18 @@ class DeviceCtx:
                   "join_group_count")
         G = g.value
         return ok[:G], oc[:G], of[:G], j.value
+
+    def join_group_count_unordered(self, keys_l, null_l, keys_r, null_r, out=None):
+        """the same operator without MDB_ORDER_FIRST and without first rows: groups in unspecified order -> (keys[G], counts[G], joined_rows)"""
+        n_l, n_r = keys_l.numel(), keys_r.numel()
+        cap = max(n_l, 1)
+        if out is None:
+            out = (torch.empty(cap, dtype=torch.int64, device=self.device), torch.empty(cap, dtype=torch.int64, device=self.device))
+        ok, oc = out[0], out[1]
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r, 0, _ptr(ok), _ptr(oc),
+                                                    None, cap, byref(g), byref(j)), "join_group_count (unordered)")
+        return ok[:g.value], oc[:g.value], j.value
 
     def join_group_count_multi(self, keys_l, null_l, rights, out=None, flags=MDB_ORDER_FIRST):
         """rights: [(keys, nullbits or None), ...] (1 ... 3 tables joined to keys_l on the one key) -> (keys[G], counts[G], first[G], joined rows)"""

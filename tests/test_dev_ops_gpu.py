@@ -2006,3 +2006,35 @@ def test_join_group_count_multi_same_key(dev, shape):
     assert j == int(ec.sum())
     if shape != "nulls":
         assert dev.last_join_multi() == (shape in ("unique_3", "dups_3", "four_tables", "selective")), shape
+
+
+@pytest.mark.parametrize("shape", ["dense_unique", "dim_in_low_range", "dups_spread", "nulls_both", "window_far_from_zero", "keys_beyond_any_window",
+                                   "skew", "small"])
+def test_join_group_count_without_order(dev, shape):
+    """mdb_dev_join_group_count without MDB_ORDER_FIRST and without first rows: the groups may come in any order, and the operator then
+    moves no row ids and sorts nothing (the sharded operator's receiver pipeline on this GPU's own regions).  Same groups and counts as
+    the oracle, as a set; shapes the form does not serve (keys beyond any 2^30-value window, skew, small tables) are answered by the
+    ordered operator through the same call."""
+    rng = np.random.default_rng(len(shape))
+    n = 3000 if shape == "small" else 2_400_000
+    off = {"window_far_from_zero": -(2**50), "keys_beyond_any_window": 0}.get(shape, 77)
+    kl = off + rng.permutation(n).astype(np.int64)
+    kr = off + rng.permutation(n).astype(np.int64)[: n - 999]
+    if shape == "dim_in_low_range":
+        kr = off + rng.integers(0, n // 16, n, dtype=np.int64)
+    elif shape == "dups_spread":
+        kr = off + 16 * rng.integers(0, n // 16, n, dtype=np.int64)
+        kl = off + rng.integers(0, n, n, dtype=np.int64)
+    elif shape == "keys_beyond_any_window":
+        kl = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        kr = np.concatenate([kl[: n // 2], rng.integers(-2**62, 2**62, n // 2, dtype=np.int64)])
+    elif shape == "skew":
+        kl[rng.random(n) < 0.7] = off + 5
+        kr[rng.random(len(kr)) < 0.5] = off + 5
+    nl = (rng.random(n) < 0.02) if shape == "nulls_both" else None
+    nr = (rng.random(len(kr)) < 0.02) if shape == "nulls_both" else None
+    ek, ec, _, ej = orc.join_group_count(kl, nl, kr, nr)
+    k, c, j = dev.join_group_count_unordered(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    got = dict(zip(_np(k).tolist(), _np(c).tolist()))
+    assert len(got) == k.numel() and got == dict(zip(ek.tolist(), ec.tolist())) and j == ej
+    assert dev.last_join_unordered() == (shape not in ("keys_beyond_any_window", "skew", "small")), shape
