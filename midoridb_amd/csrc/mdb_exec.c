@@ -1802,8 +1802,10 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					goto out;
 				}
 				multi_done = true;
-			} else if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL, cap, &G,
-							    &J)) {
+			} else if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows,
+							    /* (a bare COUNT(*) has no group order to keep; nor has a GROUP BY when the database says so) */
+							    (only_count || (cat->groups_any_order && s->ntabs == 2)) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
+							    x.d_count, NULL, cap, &G, &J)) {
 				rc = dev_fail(&x, "join + group count");
 				goto out;
 			}

@@ -102,6 +102,7 @@ struct mdb_catalog {
 	/* sharded mode (MIDORIDB_WORLD_SIZE > 1 in the environment: one process per GPU, every process holds ITS rows of every
 	 * table): the RCCL exchange handle, created with the device context (include/mdb_dist.h) */
 	mdb_dist *dist;
+	bool groups_any_order;		/* mdb_database_groups_any_order(): GROUP BY over a join need not keep first-occurrence order */
 	bool results_on_device;		/* mdb_database_results_on_device(): SELECT results stay in HBM until a consumer reads them */
 };
 

@@ -287,6 +287,15 @@ int mdb_database_results_on_device(struct database *db, int on)
 	return MIDORIDB_OK;
 }
 
+int mdb_database_groups_any_order(struct database *db, int on)
+{
+	struct mdb_catalog *cat = db ? db->tables : NULL;
+	if (!cat)
+		return -MIDORIDB_ERROR;
+	cat->groups_any_order = on != 0;
+	return MIDORIDB_OK;
+}
+
 double query_exec_ms(struct result_set *res)
 {
 	return res && res->table ? ((struct mdb_result *)res->table)->exec_ms : 0.0;

@@ -41,7 +41,7 @@ QUERY_SYMBOLS = [
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
     "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
-    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "query_column_data_device", "mdb_table_generate_shard",
+    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "mdb_database_groups_any_order", "query_column_data_device", "mdb_table_generate_shard",
 ]
 
 
@@ -95,6 +95,8 @@ def _bind(lib):
     lib.mdb_database_set_dist.restype = c_int
     lib.mdb_database_results_on_device.argtypes = [PDB, c_int]
     lib.mdb_database_results_on_device.restype = c_int
+    lib.mdb_database_groups_any_order.argtypes = [PDB, c_int]
+    lib.mdb_database_groups_any_order.restype = c_int
     lib.query_column_data_device.argtypes = [PRS, c_int]
     lib.query_column_data_device.restype = c_void_p
     lib.mdb_table_generate_shard.argtypes = [PDB, c_char_p, c_uint64, c_uint64, c_uint64, c_uint64, POINTER(c_uint64)]
@@ -165,6 +167,11 @@ class DB:
         """SELECT results stay in HBM until a consumer reads them (mdb_database_results_on_device)"""
         if self.lib.mdb_database_results_on_device(ctypes.byref(self.db), 1 if on else 0) != 0:
             raise QueryError("mdb_database_results_on_device failed")
+
+    def groups_any_order(self, on=True):
+        """GROUP BY over a join may return its groups in any order (mdb_database_groups_any_order)"""
+        if self.lib.mdb_database_groups_any_order(ctypes.byref(self.db), 1 if on else 0) != 0:
+            raise QueryError("mdb_database_groups_any_order failed")
 
     def query_device(self, sql, copy=True):
         """SELECT with results kept on the device -> (names, types, [torch tensors or None per column], rows, joined rows, exec ms).
