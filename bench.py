@@ -128,6 +128,8 @@ def parse_args():
                     help="which BASELINE.json configuration (SURVEY 8d numbering): 3 = the north-star query (default, the metric's own "
                          "configuration), 4 = configs[3]: SELECT * join over key columns (10^9 rows over 8 GPUs: --rows 125000000), "
                          "5 = configs[4]: three-way join + GROUP BY with DOUBLE payload through query_execute() (bench_configs.py)")
+    ap.add_argument("--unordered", action="store_true", help="N = 1: time the operator without MDB_ORDER_FIRST (groups in unspecified order) - "
+                    "evidence runs only; the default line keeps the reference's first-occurrence order")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -270,7 +272,15 @@ def end_to_end(n, mod_b, a_dev, b_dev):
         for _ in range(4):
             db.query_device(NORTH, copy=False)
             dwalls.append(db.last_call_ms)
+        db.groups_any_order(True)        # ... and without the reference's first-occurrence group order (mdb_database_groups_any_order)
+        awalls = []
+        for _ in range(4):
+            db.query_device(NORTH, copy=False)
+            awalls.append(db.last_call_ms)
+        db.groups_any_order(False)
         db.results_on_device(False)
+        out["device_resident_any_group_order"] = {"wall_ms": min(awalls[1:]), "value": joined / (min(awalls[1:]) * 1e-3),
+                                                  "includes": "as device_resident_tables_and_result, groups in unspecified order"}
         out["device_resident_tables_and_result"] = {"wall_ms": min(dwalls[1:]), "value": joined / (min(dwalls[1:]) * 1e-3),
                                                     "includes": "wall time of query_execute(): SQL parse + plan + device pipeline; the result "
                                                                 "columns stay in HBM (query_column_data_device), fetched on first cursor use"}
@@ -392,6 +402,9 @@ def main():
             dx.set_key_ranges(rng[0], rng[1])
 
         def step():
+            if pipe is None and args.unordered:
+                k, c, j = dev.join_group_count_unordered(a, None, b, None, out=out)
+                return k.numel(), j
             if pipe is None:
                 k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
                 return k.numel(), j
@@ -516,7 +529,8 @@ def main():
                        "left_table_pruning": {"min_max": bool(dev.last_join_filter()[1]), "bitmap": int(dev.last_join_filter()[0])},
                        "partition_levels": dev.last_join_levels(),
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
-                       "order": "reference first-occurrence order" if not use_dist else "per rank, unspecified (leaf order; first occurrence in the "
+                       "order": "unspecified (--unordered: mdb_dev_join_group_count without MDB_ORDER_FIRST)" if (args.unordered and not use_dist) else
+                                "reference first-occurrence order" if not use_dist else "per rank, unspecified (leaf order; first occurrence in the "
                                 "received stream on the key-by-destination path)",
                        "parallelism": f"hash-partition x{world}, exchange behind the C-ABI (mdb_dist_join_group_count: RCCL all-to-all per table)"
                                       + (" (forced shuffle)" if args.force_shuffle and world == 1 else "")

@@ -43,3 +43,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OPS/kt" -- python3 "$R
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OPS/fetch" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OPS/write" -- python3 "$R/bench_operators.py" $OARGS > "$OPS/write.log" 2>&1
 (cd "$R" && python3 profiles/summarize.py "$OPS" "$R/gpurun_out/summary_${TAG}_configs1.json")
+# the operator without MDB_ORDER_FIRST (groups in unspecified order: no row ids, no ordering sort), variants D and U
+for V in D U; do
+	passes "$R/gpurun_out/prof_${TAG}_unordered_$V" python3 "$R/bench.py" $ARGS --variant $V --unordered
+	(cd "$R" && python3 profiles/summarize.py "$R/gpurun_out/prof_${TAG}_unordered_$V" "$R/gpurun_out/summary_${TAG}_unordered_$V.json")
+done
+# what goes under profiles/$TAG/: the summaries and rocprofv3's own per-kernel statistics of each kernel-trace pass
+PUB=$R/gpurun_out/publish_$TAG
+mkdir -p "$PUB"
+for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U; do
+	[ -f "$R/gpurun_out/summary_$TAG$S.json" ] && cp "$R/gpurun_out/summary_$TAG$S.json" "$PUB/rocprof_summary$S.json"
+	D="$R/gpurun_out/prof_$TAG$S/kt"
+	[ "$S" = _configs1 ] && D="$OPS/kt"
+	F=$(find "$D" -name '*kernel_stats.csv' 2>/dev/null | head -1)
+	[ -n "$F" ] && cp "$F" "$PUB/kernel_stats$S.csv"
+done
