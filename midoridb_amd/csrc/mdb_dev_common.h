@@ -246,41 +246,37 @@ __host__ __device__ static inline uint64_t mdb_fmix64_inv(uint64_t k)
 __device__ static inline uint32_t mdb_lane(void) { return threadIdx.x & (MDB_WAVE - 1); }
 __device__ static inline uint64_t mdb_lanemask_lt(void) { return (1ull << mdb_lane()) - 1ull; }
 
-/* inclusive scan across the 64 lanes of a wave */
+/* inclusive scan across the 64 lanes of a wave: data-parallel-primitive moves inside the vector ALU (shifts by 1, 2, 4, 8 inside
+ * every row of 16 lanes, then the last lane of a row broadcast to the next row, then lane 31 to the upper half) - six adds, no
+ * trip through the LDS crossbar (six ds_bpermute round trips of ~60 cycles each before) */
 __device__ static inline uint32_t mdb_wave_incl_scan(uint32_t v)
 {
-#pragma unroll
-	for (int d = 1; d < MDB_WAVE; d <<= 1) {
-		uint32_t t = __shfl_up(v, d, MDB_WAVE);
-		if ((int)mdb_lane() >= d)
-			v += t;
-	}
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
 	return v;
 }
 
 /* Block-wide exclusive scan of one value per thread.  blockDim.x must be a multiple of 64 and
  * <= 1024; `tmp` is LDS scratch of at least 17 words.  Returns the exclusive prefix, *total the
- * block sum.  Contains __syncthreads(): call from uniform control flow. */
+ * block sum.  Contains __syncthreads(): call from uniform control flow.
+ * Every wave scans the (at most 16) wave totals itself: two barriers and no serial walk by one thread (which cost 2 000 -
+ * 4 000 cycles per call with 16 waves - a quarter of a partition tile's fixed costs). */
 __device__ static inline uint32_t mdb_block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total)
 {
-	const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-	uint32_t incl = mdb_wave_incl_scan(v);
+	const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = mdb_lane();
+	const uint32_t incl = mdb_wave_incl_scan(v);
 	__syncthreads();	/* protect tmp against a previous use */
-	if (mdb_lane() == MDB_WAVE - 1)
+	if (lane == MDB_WAVE - 1)
 		tmp[wave] = incl;
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t run = 0;
-		for (uint32_t w = 0; w < nwaves; w++) {
-			uint32_t t = tmp[w];
-			tmp[w] = run;
-			run += t;
-		}
-		tmp[16] = run;
-	}
-	__syncthreads();
-	*total = tmp[16];
-	return incl - v + tmp[wave];
+	const uint32_t pi = mdb_wave_incl_scan(lane < nwaves ? tmp[lane] : 0u);
+	*total = (uint32_t)__shfl((int)pi, (int)nwaves - 1, MDB_WAVE);
+	const uint32_t before = (uint32_t)__shfl((int)pi, wave ? (int)wave - 1 : 0, MDB_WAVE);
+	return incl - v + (wave ? before : 0u);
 }
 
 /* Raise flag bits in a device status word.  The word is looked at first: a condition that holds for every row of a

@@ -145,6 +145,7 @@ int mdb_partition_words_level(mdb_dev_ctx *ctx, const uint32_t *words_in, const 
 #define MDB_SHARD_MAX_TABS 4
 struct mdb_shard_plan {
 	uint32_t world, rank;
+	uint32_t dbits;			/* first-level digit bits: 9 (the join's own first level), or 12 (the wide fan-out form) */
 	uint32_t D, Dp, nsub;		/* first-level digits, digits per destination, sub-regions per digit */
 	uint32_t kbits;			/* key window [key_lo, key_lo + 2^kbits) */
 	int64_t key_lo;

@@ -25,6 +25,8 @@
 #define SH_ONE_LEVEL_MAX_REM 14u	/* 2^14 entries x 8 bytes = 128 KiB of LDS */
 #define SH_LEAF_REM 13u		/* two levels: leaves of 2^13 key values (64 KiB of counters, 1024 threads: 0.46 ms for 2 x 10^8 rows where
 				 * 2^12-value leaves - twice as many workgroups, each with its fixed costs - take 0.82 and 2^14 0.55) */
+#define SHW_D_BITS 12		/* the wide fan-out form: 4096 first-level digits */
+#define SHW_MAX_REM 15u		/* ... and at most 15 key bits below them: 2-byte words with a spare bit, 2 x 2^15 16-bit counters = 128 KiB of LDS */
 #define SH_RANGE_WORD 24	/* words of ctx->d_status that hold the left table's pruning range */
 
 static uint32_t sh_ceil_log2(uint64_t v)
@@ -55,19 +57,24 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 	for (uint32_t x = 0; x < ntab; x++)
 		if (n_max[x] >= 0xF0000000ull)
 			return 1;
+	/* windows of 2^24 .. 2^27 values, two tables: 4096 first-level digits (k_shard_scatter_wide) leave at most 15 key bits below the
+	 * digit - one level, no second pass over either table (variant U: 2^27 values, 1.42 -> 1.0 ms) */
+	const bool wide = ntab == 2 && k > SH_D_BITS + SH_ONE_LEVEL_MAX_REM && k <= SHW_D_BITS + SHW_MAX_REM &&
+			  !(getenv("MDB_SHARD_WIDE") && getenv("MDB_SHARD_WIDE")[0] == '0');
+	p->dbits = wide ? SHW_D_BITS : SH_D_BITS;
 	p->world = world;
 	p->ntab = ntab;
 	p->rank = rank;
-	p->D = 1u << SH_D_BITS;
+	p->D = 1u << p->dbits;
 	p->Dp = p->D / world;
 	p->nsub = SH_NSUB;
 	p->kbits = k;
 	p->key_lo = r_lo;
 	p->l_rel_hi = rspan - 1;
-	const uint32_t below = k - SH_D_BITS;
+	const uint32_t below = k - p->dbits;
 	/* (4 bytes of LDS per table and key value of a leaf: three or four tables take leaves of half the values) */
 	const uint32_t one_level_rem = ntab > 2 ? SH_ONE_LEVEL_MAX_REM - 1u : SH_ONE_LEVEL_MAX_REM;
-	if (below <= one_level_rem && p->Dp >= 128u) {
+	if (wide || (below <= one_level_rem && p->Dp >= 128u)) {
 		p->b2 = 0;
 		p->rem = below;
 	} else {
@@ -100,9 +107,11 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 	/* (a region's fill is the sum of its tiles' shares of a bijective hash: for 10^8 rows 24 414 +- 160 rows - the 1024 words
 	 * cover that; the factor covers the XCDs' uneven tile counts.  Every word of slack crosses xGMI: 1/16, not the single-GPU
 	 * first level's 1/4) */
-	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 17 / 16 / regions + 1024);
+	/* (4096 digits: a region holds an eighth of that - 3052 +- 55 rows -, and 1024 words of slack each would be a third of the buffer) */
+	const uint64_t slack = wide ? 320 : 1024;
+	p->cap[0] = sh_round64((nl_est < n_l_max ? nl_est : n_l_max) * 17 / 16 / regions + slack);
 	for (uint32_t x = 1; x < ntab; x++)
-		p->cap[x] = sh_round64(n_max[x] * 17 / 16 / regions + 1024);	/* (further right tables: sized for all their rows, though only those in the window travel) */
+		p->cap[x] = sh_round64(n_max[x] * 17 / 16 / regions + slack);	/* (further right tables: sized for all their rows, though only those in the window travel) */
 	for (uint32_t x = 0; x < ntab; x++) {
 		p->block_words[x] = (uint64_t)p->Dp * p->nsub * p->cap[x];
 		if (p->block_words[x] * world >= 0xFFFFFFFFull)
@@ -140,6 +149,280 @@ size_t mdb_shard_arena_bytes(const mdb_shard_plan *p)
 	return b;
 }
 
+
+/* ------------------------------------------------------------------ the wide fan-out form: 4096 first-level digits
+ *
+ * One pass per table that leaves at most 15 key bits below the digit for windows of up to 2^27 values, where the 512-digit
+ * level needs a second pass over both tables.  What makes 4096 digits affordable is the tile: 32 768 (or 16 384) rows staged in
+ * LDS as 2-byte words, so that a digit's run in a tile is still ~8 (4) words, written by consecutive lanes, and a tile still
+ * costs one global atomic per digit - 12.5 M per 10^8 rows, as many as 512 digits x 4096-row tiles.  The staged word is all
+ * that is kept per position: its spare 16th bit marks the first word of a digit's run, and the position's run - hence its
+ * place in the region buffer - is the number of marks up to it (one ballot per 64 positions on top of per-chunk counts).
+ * Region and cursor layout are the 512-digit level's (digit-major regions of `cap` words with nsub sub-regions per digit,
+ * sub-major cursors): the receiver's descriptors do not care which kernel filled them. */
+struct shw_scatter_args {
+	const long long *keys;
+	const unsigned long long *nullbits;
+	uint32_t n;
+	long long key_lo;
+	uint32_t kbits, rem;	/* rem = kbits - 12 <= 15 */
+	uint32_t report;	/* 1 (the right table): a key outside the window raises flag 128; 0: rows with key - key_lo > rel_hi are dropped */
+	uint32_t rel_hi;
+	uint16_t *out;
+	uint32_t *cursor;	/* [nsub][4096] */
+	uint32_t cap, nsub;
+	uint32_t *status;
+	uint32_t rows_per_wg;	/* (even) */
+	uint32_t dbg;
+};
+
+/* a barrier that waits for the wave's LDS operations only: global loads (the next tile's keys) and the cursor atomics stay in
+ * flight across it (__syncthreads() waits for every outstanding memory operation) */
+__device__ static inline void shw_barrier(void)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+/* exclusive scan over the workgroup, one barrier: every wave scans the waves' totals itself */
+__device__ static inline uint32_t shw_block_excl_scan(uint32_t v, uint32_t *tmp /* [waves] */, uint32_t nwaves, uint32_t *total)
+{
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint32_t incl = mdb_wave_incl_scan(v);
+	if (lane == MDB_WAVE - 1)
+		tmp[wave] = incl;
+	shw_barrier();
+	const uint32_t pi = mdb_wave_incl_scan(lane < nwaves ? tmp[lane] : 0u);
+	*total = (uint32_t)__shfl((int)pi, (int)nwaves - 1, MDB_WAVE);
+	const uint32_t before = (uint32_t)__shfl((int)pi, wave ? (int)wave - 1 : 0, MDB_WAVE);
+	return incl - v + (wave ? before : 0u);
+}
+
+template <int THREADS, int RPT /* rows per thread */, bool PREFETCH>
+__global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024 or two of 512 per CU */) void k_shard_scatter_wide(shw_scatter_args a)
+{
+	constexpr uint32_t TILE = THREADS * RPT, D = 1u << SHW_D_BITS, DPT = D / THREADS, NCHUNK = TILE / 64u, HALF = RPT / 2;
+	static_assert(TILE <= 32768u && DPT >= 2 && (DPT & 1) == 0 && (RPT % 4) == 0, "tile shape");
+	extern __shared__ __attribute__((aligned(16))) uint32_t shw_lds[];
+	uint32_t *const s_cnt = shw_lds;			/* [D / 2] two 16-bit counters per word, then the digits' tile-local starts */
+	uint32_t *const s_delta = s_cnt + D / 2;		/* [D] per NON-EMPTY digit, in digit order: where its run goes minus its tile-local start */
+	uint32_t *const s_chunk = s_delta + D;			/* [NCHUNK] runs that begin before staged position 64 c */
+	uint32_t *const s_bad = s_chunk + NCHUNK;		/* [D / 32] non-empty digits (by ordinal) whose run did not fit its region */
+	uint32_t *const s_tmp = s_bad + D / 32;			/* [32] */
+	uint16_t *const s_stage = reinterpret_cast<uint16_t *>(s_tmp + 32);	/* [TILE] */
+	__shared__ uint32_t s_any_bad;
+
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane(), sub = blockIdx.x % a.nsub;
+	const uint32_t wmask = (1u << a.rem) - 1u;
+	const uint64_t limit = a.report ? ((1ull << a.kbits) - 1ull) : (uint64_t)a.rel_hi;
+	const uint64_t le = mdb_lanemask_lt() | (1ull << lane);
+	for (uint32_t i = threadIdx.x; i < D / 32; i += THREADS)
+		s_bad[i] = 0u;
+	if (threadIdx.x == 0)
+		s_any_bad = 0u;
+	ulonglong2 nxt[HALF / 2];	/* the first half of the next tile's keys, requested while this tile is written out */
+	bool have_nxt = false;		/* (uniform) */
+
+	/* A workgroup takes one contiguous range of rows, tile after tile.  All CUs start together, and a tile's phases use different
+	 * parts of the chip (the key loads HBM, the ranking and staging LDS, the cursor atomics L2): left alone, every CU loads while
+	 * HBM is saturated and then computes while it idles.  The FIRST tile of a workgroup is therefore 1/4, 2/4, 3/4 or 4/4 of a
+	 * tile, by workgroup number: the CUs run their phases a quarter period apart. */
+	const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_wg;
+	const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+	bool first = true;
+	for (uint64_t row0 = r_begin; row0 < r_end;) {
+		uint32_t want = TILE;
+		if (first && !(a.dbg & 32u))
+			want = (TILE / 4u) * (((blockIdx.x / a.nsub) & 3u) + 1u);
+		first = false;
+		const uint32_t len = (uint32_t)((r_end - row0) < want ? (r_end - row0) : want);
+		const bool full = len == TILE;	/* (uniform) */
+		/* (the thread's number, made opaque per tile: otherwise the addresses of all its loads and LDS accesses are computed once,
+		 * before the loop, and kept in ~70 registers across it - spills) */
+		uint32_t tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		for (uint32_t i = tid; i < D / 2; i += THREADS)
+			s_cnt[i] = 0u;
+		if (tid == 0)
+			s_chunk[0] = 0u;
+		shw_barrier();
+		long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
+		if (a.dbg & 16u)
+			tc0 = clock64();
+
+		/* 1. load (16 bytes = two keys per access, a half of the thread's rows in flight at a time), hash, rank inside the digit */
+		uint32_t packed[RPT];	/* digit << 16 | rank, or ~0 for a row that is not taken */
+		uint32_t word2[HALF];	/* the rows' 2-byte words, two per register */
+#pragma unroll
+		for (int hblock = 0; hblock < 2; hblock++) {
+			ulonglong2 pre[HALF / 2];
+#pragma unroll
+			for (int r = 0; r < HALF / 2; r++) {
+				const uint32_t e0 = 2u * ((uint32_t)(hblock * (HALF / 2) + r) * THREADS + tid);
+				if (PREFETCH && hblock == 0 && have_nxt)
+					pre[r] = nxt[r];
+				else if (full || e0 + 1u < len)		/* (row0 is even and the column 16-byte aligned) */
+					pre[r] = *reinterpret_cast<const ulonglong2 *>(a.keys + row0 + e0);
+				else if (e0 < len)
+					pre[r] = make_ulonglong2((unsigned long long)a.keys[row0 + e0], 0ull);
+				else
+					pre[r] = make_ulonglong2(0ull, 0ull);
+			}
+#pragma unroll
+			for (int r = 0; r < HALF / 2; r++) {
+				const int pr = hblock * (HALF / 2) + r;		/* pair number of this thread */
+				const uint32_t e0 = 2u * ((uint32_t)pr * THREADS + tid);	/* tile-relative row of the pair's first key */
+				const unsigned long long kk[2] = { pre[r].x, pre[r].y };
+				bool ok[2] = { e0 < len, e0 + 1u < len };
+				if (a.nullbits && ok[0]) {	/* (row0 + e0 is even: both bits live in one word) */
+					const unsigned long long nb = a.nullbits[(row0 + e0) >> 6] >> ((row0 + e0) & 63u);
+					ok[0] = !(nb & 1ull);
+					ok[1] = ok[1] && !(nb & 2ull);
+				}
+				uint32_t w2 = 0u;
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const unsigned long long rel = kk[e] - (unsigned long long)a.key_lo;
+					const bool take = ok[e] && rel <= limit;
+					if (a.report && ok[e] && !take)
+						mdb_raise(a.status, 128u);	/* a right key outside the window: the caller's form does not apply */
+					uint32_t pk = 0xFFFFFFFFu;
+					if (take) {
+						const uint32_t h = mdb_mixk((uint32_t)rel, a.kbits);
+						const uint32_t dig = h >> a.rem, sh = (dig & 1u) << 4;
+						const uint32_t rank = (atomicAdd(&s_cnt[dig >> 1], 1u << sh) >> sh) & 0xFFFFu;
+						pk = (dig << 16) | rank;
+						w2 |= ((h & wmask) | (rank == 0u ? 0x8000u : 0u)) << (16 * e);
+					}
+					packed[2 * pr + e] = pk;
+				}
+				word2[pr] = w2;
+			}
+		}
+		shw_barrier();
+		if (a.dbg & 16u)
+			tc1 = clock64();
+
+		/* 2. digit counts -> tile-local starts (written back over the counters), the ordinal of every non-empty digit, the runs
+		 *    that begin before every 64th staged position, and the run's place in its region: one global atomic per (tile,
+		 *    non-empty digit), whose round trip the staging below covers */
+		uint32_t cnt[DPT], v = 0u;
+#pragma unroll
+		for (int j = 0; j < (int)DPT / 2; j++) {
+			const uint32_t c2 = s_cnt[tid * (DPT / 2) + j];
+			cnt[2 * j] = c2 & 0xFFFFu;
+			cnt[2 * j + 1] = c2 >> 16;
+			v += cnt[2 * j] + cnt[2 * j + 1] + ((cnt[2 * j] ? 1u : 0u) + (cnt[2 * j + 1] ? 1u : 0u)) * 65536u;
+		}
+		uint32_t tot;
+		const uint32_t ex = shw_block_excl_scan(v, s_tmp, THREADS / 64, &tot);	/* rows below bit 16 (<= 32 768), non-empty digits above */
+		const uint32_t tile_total = tot & 0xFFFFu;
+		uint32_t base[DPT], st0[DPT];
+		const uint32_t ord0 = ex >> 16;
+		{
+			uint32_t start = ex & 0xFFFFu, ord = ord0;
+#pragma unroll
+			for (int j = 0; j < (int)DPT; j++) {
+				const uint32_t d = tid * DPT + (uint32_t)j;
+				st0[j] = start;
+				base[j] = 0u;
+				if (cnt[j]) {
+					base[j] = (a.dbg & 2u) ? 0u : atomicAdd(&a.cursor[sub * D + d], cnt[j]);
+					/* this run is the last one to begin before position 64 c for every c with start < 64 c <= start + count */
+					for (uint32_t c = (start >> 6) + 1u; (c << 6) <= start + cnt[j] && c < NCHUNK; c++)
+						s_chunk[c] = ord + 1u;
+					ord++;
+					start += cnt[j];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < (int)DPT / 2; j++)
+				s_cnt[tid * (DPT / 2) + j] = st0[2 * j] | (st0[2 * j + 1] << 16);
+		}
+		shw_barrier();
+		if (a.dbg & 16u)
+			tc2 = clock64();
+
+		/* 3. stage by digit */
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+			if (packed[r] != 0xFFFFFFFFu) {
+				const uint32_t dig = packed[r] >> 16;
+				const uint32_t st = (s_cnt[dig >> 1] >> ((dig & 1u) << 4)) & 0xFFFFu;
+				s_stage[st + (packed[r] & 0xFFFFu)] = (uint16_t)(word2[r >> 1] >> (16 * (r & 1)));
+			}
+		}
+		/* the next tile's first keys: on their way while this tile is written out */
+		have_nxt = false;
+		if (PREFETCH && row0 + len + TILE <= r_end) {
+			const uint64_t nrow0 = row0 + len;
+#pragma unroll
+			for (int r = 0; r < HALF / 2; r++)
+				nxt[r] = *reinterpret_cast<const ulonglong2 *>(a.keys + nrow0 + 2u * ((uint32_t)r * THREADS + tid));
+			have_nxt = true;
+		}
+		{
+			uint32_t ord = ord0;
+#pragma unroll
+			for (int j = 0; j < (int)DPT; j++) {
+				if (cnt[j]) {
+					const uint32_t d = tid * DPT + (uint32_t)j;
+					if (base[j] + cnt[j] > a.cap) {
+						mdb_raise(a.status, 2u);	/* the region is full: reported, the operator takes its exact path */
+						atomicOr(&s_bad[ord >> 5], 1u << (ord & 31u));
+						s_any_bad = 1u;
+					}
+					s_delta[ord] = (d * a.nsub + sub) * a.cap + base[j] - st0[j];
+					ord++;
+				}
+			}
+		}
+		shw_barrier();
+		if (a.dbg & 16u)
+			tc3 = clock64();
+
+		/* 4. write out: consecutive lanes, consecutive positions of a run; a position's run = the runs that begin before its
+		 *    chunk of 64 + the marks up to it inside the chunk */
+		const bool any_bad = s_any_bad != 0u;
+#pragma unroll
+		for (int k = 0; k < RPT; k++) {
+			const uint32_t i = (uint32_t)k * THREADS + tid;
+			const uint32_t sv = i < tile_total ? s_stage[i] : 0u;
+			const uint64_t m = __ballot(sv & 0x8000u);
+			if (i >= tile_total)
+				continue;
+			const uint32_t ord = s_chunk[(uint32_t)k * (THREADS / 64) + wave] + (uint32_t)__popcll(m & le) - 1u;
+			if (any_bad && ((s_bad[ord >> 5] >> (ord & 31u)) & 1u))
+				continue;
+			if (!(a.dbg & 1u))
+				a.out[i + s_delta[ord]] = (uint16_t)(sv & 0x7FFFu);
+		}
+		shw_barrier();
+		if ((a.dbg & 16u) && tid == 0) {
+			tc4 = clock64();
+			unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.status + 64);
+			atomicAdd(&acc[0], (unsigned long long)(tc1 - tc0));
+			atomicAdd(&acc[1], (unsigned long long)(tc2 - tc1));
+			atomicAdd(&acc[2], (unsigned long long)(tc3 - tc2));
+			atomicAdd(&acc[3], (unsigned long long)(tc4 - tc3));
+			atomicAdd(&acc[4], 1ull);
+		}
+		if (any_bad) {		/* (rare: clear the marks of this tile's full regions) */
+			for (uint32_t i = tid; i < D / 32; i += THREADS)
+				s_bad[i] = 0u;
+			if (tid == 0)
+				s_any_bad = 0u;
+			shw_barrier();
+		}
+		row0 += len;
+	}
+}
+
+static size_t shw_scatter_lds(uint32_t tile)
+{
+	const uint32_t D = 1u << SHW_D_BITS;
+	return (size_t)4 * (D / 2 + D + tile / 64 + D / 32 + 32) + (size_t)2 * tile;
+}
+
 int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
 			const void **regions, const uint32_t **cursors)
 {
@@ -166,6 +449,58 @@ int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, con
 		if (!cur || !buf)
 			return -MIDORIDB_INTERNAL;
 		MDB_HIP(ctx, hipMemsetAsync(cur, 0, (size_t)p->D * p->nsub * 4, ctx->stream));
+		*regions = buf;
+		*cursors = cur;
+		return MIDORIDB_OK;
+	}
+	if (p->dbits == SHW_D_BITS) {
+		const size_t nreg = (size_t)p->D * p->nsub;
+		uint32_t *cur = (uint32_t *)mdb_arena_take(ctx, nreg * 4);
+		uint16_t *buf = (uint16_t *)mdb_arena_take(ctx, nreg * p->cap[side] * 2);
+		if (!cur || !buf)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(cur, 0, nreg * 4, ctx->stream));
+		shw_scatter_args a;
+		memset(&a, 0, sizeof(a));
+		a.keys = reinterpret_cast<const long long *>(keys);
+		a.nullbits = reinterpret_cast<const unsigned long long *>(nulls);
+		a.n = (uint32_t)n;
+		a.key_lo = p->key_lo;
+		a.kbits = p->kbits;
+		a.rem = p->rem;
+		a.report = side == 1;
+		a.rel_hi = (uint32_t)p->l_rel_hi;
+		a.out = buf;
+		a.cursor = cur;
+		a.cap = p->cap[side];
+		a.nsub = p->nsub;
+		a.status = ctx->d_status;
+		a.dbg = getenv("MDB_SHW_DBG") ? (uint32_t)atoi(getenv("MDB_SHW_DBG")) : 0u;
+		static int shape = -1;	/* (measurements: MDB_SHARD_WIDE_TILE = 0: 1024 threads x 32 rows with prefetch, 1: without, 2: 1024 x 16) */
+		if (shape < 0)
+			shape = getenv("MDB_SHARD_WIDE_TILE") ? atoi(getenv("MDB_SHARD_WIDE_TILE")) : 0;
+		const char *const pname = side ? "shard_scatter_wide_r" : "shard_scatter_wide_l";
+		const uint32_t tile = (shape == 2 || shape == 3) ? 16384u : 32768u;
+		const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile), wgs = (uint32_t)ctx->num_cus * ((shape == 2 || shape == 3) ? 2u : 1u);
+		uint32_t grid = ntiles < wgs ? ntiles : wgs;	/* persistent workgroups: tile t, t + grid, ... */
+		a.rows_per_wg = (uint32_t)(((n + grid - 1) / grid + 1) & ~1ull);
+		if (shape == 3) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<512, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+							 (int)shw_scatter_lds(tile)));
+			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<512, 32, false>), grid, 512, shw_scatter_lds(tile), a);
+		} else if (shape == 2) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+							 (int)shw_scatter_lds(tile)));
+			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 16, false>), grid, 1024, shw_scatter_lds(tile), a);
+		} else if (shape == 1) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+							 (int)shw_scatter_lds(tile)));
+			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 32, false>), grid, 1024, shw_scatter_lds(tile), a);
+		} else {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+							 (int)shw_scatter_lds(tile)));
+			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 32, true>), grid, 1024, shw_scatter_lds(tile), a);
+		}
 		*regions = buf;
 		*cursors = cur;
 		return MIDORIDB_OK;
@@ -397,6 +732,151 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 	}
 }
 
+/* The leaf kernel of the wide fan-out form: up to 2^15 key values per leaf, two tables, 16-bit counters (two per LDS word; a
+ * count beyond 65 535 is reported - flag 2048 - and the operator takes another path), 2-byte words.  A leaf's rows arrive as
+ * world x nsub short segments (a few thousand words each): they are read as ONE list of 16-byte chunks, so that every lane has
+ * a load in flight whatever the segments' lengths. */
+#define SHW_MAX_SEG 64u
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t sh_lds[];
+	__shared__ unsigned long long s_red[THREADS / 64];
+	__shared__ uint32_t s_base, s_total, s_off;
+	__shared__ uint32_t s_seg_chunk0[SHW_MAX_SEG + 1], s_seg_start[SHW_MAX_SEG], s_seg_cnt[SHW_MAX_SEG];
+	const uint32_t T = 1u << a.rem, HW = T >> 1, mask = T - 1u, leaf = blockIdx.x;
+	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + HW;
+	for (uint32_t s = threadIdx.x; s < 2u * HW; s += THREADS)
+		sh_lds[s] = 0u;
+	if (threadIdx.x == 0)
+		s_total = 0;
+	uint32_t groups = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		const int side = 1 - pass;	/* the right table first */
+		const uint16_t *const base = reinterpret_cast<const uint16_t *>(a.words[side]);
+		__syncthreads();
+		if (threadIdx.x < a.nseg) {
+			uint32_t c = a.seg_cnt[side][leaf * a.nseg + threadIdx.x];
+			s_seg_start[threadIdx.x] = a.seg_start[side][leaf * a.nseg + threadIdx.x];
+			s_seg_cnt[threadIdx.x] = c;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t run = 0;
+			for (uint32_t j = 0; j < a.nseg; j++) {
+				s_seg_chunk0[j] = run;
+				run += (s_seg_cnt[j] + 7u) >> 3;
+			}
+			s_seg_chunk0[a.nseg] = run;
+		}
+		__syncthreads();
+		const uint32_t nchunks = s_seg_chunk0[a.nseg];
+		for (uint32_t q0 = 0; q0 < nchunks; q0 += THREADS * 4u) {	/* uniform trip count; four 16-byte loads in flight */
+			uint4 v[4];
+			uint32_t nv[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t q = q0 + (uint32_t)u * THREADS + threadIdx.x;
+				v[u] = make_uint4(0u, 0u, 0u, 0u);
+				nv[u] = 0u;
+				if (q < nchunks) {
+					uint32_t lo = 0, hi = a.nseg;	/* the last segment whose first chunk is <= q */
+					while (hi - lo > 1u) {
+						const uint32_t mid = (lo + hi) >> 1;
+						if (s_seg_chunk0[mid] <= q)
+							lo = mid;
+						else
+							hi = mid;
+					}
+					const uint32_t off = (q - s_seg_chunk0[lo]) << 3, c = s_seg_cnt[lo];
+					nv[u] = c - off < 8u ? c - off : 8u;
+					v[u] = *reinterpret_cast<const uint4 *>(base + s_seg_start[lo] + off);	/* (regions start at multiples of 64 words) */
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t w4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+				for (uint32_t e = 0; e < 8u; e++) {
+					if (e >= nv[u])
+						continue;
+					const uint32_t idx = ((w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu) & mask, sh = (idx & 1u) << 4;
+					if (side == 1) {
+						if (((atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu) == 0xFFFFu)
+							mdb_raise(a.status, 2048u);
+					} else if ((s_cr[idx >> 1] >> sh) & 0xFFFFu) {
+						const uint32_t old = (atomicAdd(&s_cl[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+						if (old == 0u)
+							groups++;
+						else if (old == 0xFFFFu)
+							mdb_raise(a.status, 2048u);
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	{
+		uint32_t g = groups;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			g += __shfl_down(g, o, MDB_WAVE);
+		if (mdb_lane() == 0 && g)
+			atomicAdd(&s_total, g);
+	}
+	__syncthreads();
+	const uint32_t total = s_total;
+	if (!total)
+		return;
+	if (threadIdx.x == 0) {
+		const uint32_t nb = atomicAdd(a.status + 1, total);
+		if ((uint64_t)nb + total > a.out_cap) {
+			mdb_raise(a.status, 8u);
+			s_base = 0xFFFFFFFFu;
+		} else {
+			s_base = nb;
+		}
+		s_off = 0;
+	}
+	__syncthreads();
+	if (s_base == 0xFFFFFFFFu)
+		return;
+	unsigned long long joined = 0;
+	for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {
+		const uint32_t s = s0 + threadIdx.x, sh = (s & 1u) << 4;
+		const uint32_t cl = s < T ? (s_cl[s >> 1] >> sh) & 0xFFFFu : 0u;
+		const uint64_t m = __ballot(cl != 0u);
+		if (!m)
+			continue;
+		uint32_t wbase = 0;
+		if (mdb_lane() == 0)
+			wbase = atomicAdd(&s_off, (uint32_t)__popcll(m));
+		wbase = __shfl(wbase, 0, MDB_WAVE);
+		if (cl) {
+			const uint32_t pos = s_base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+			const unsigned long long c = (unsigned long long)cl * ((s_cr[s >> 1] >> sh) & 0xFFFFu);
+			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
+			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
+			a.out_count[pos] = (long long)c;
+			joined += c;
+		}
+	}
+#pragma unroll
+	for (int o = 32; o; o >>= 1)
+		joined += __shfl_down(joined, o, MDB_WAVE);
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = joined;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+#pragma unroll
+		for (int w = 0; w < THREADS / 64; w++)
+			t += s_red[w];
+		if (t)
+			atomicAdd(reinterpret_cast<unsigned long long *>(a.status + 2), t);
+	}
+}
+
 int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const *recv, const uint32_t *const *cnt, int64_t *out_key,
 		   int64_t *out_count, uint64_t cap, void *const *arrived)
 {
@@ -422,13 +902,13 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 	a.rem = p->rem;
 	a.shift = 32u - p->kbits;
 	a.kbits = p->kbits;
-	a.hash_base = d0 << (p->kbits - SH_D_BITS);
+	a.hash_base = d0 << (p->kbits - p->dbits);
 	a.key_lo = p->key_lo;
 	a.out_key = reinterpret_cast<long long *>(out_key);
 	a.out_count = reinterpret_cast<long long *>(out_count);
 	a.out_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 	a.status = ctx->d_status;
-	const size_t lds = (size_t)(4 * p->ntab) << p->rem;
+	const size_t lds = p->dbits == SHW_D_BITS ? (size_t)4 << p->rem : (size_t)(4 * p->ntab) << p->rem;
 	if (lds > 150 * 1024)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: leaf tables of %zu bytes", lds);
 	if (p->b2 == 0) {
@@ -443,6 +923,13 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		/* (one level means k - 9 <= 14 key bits below the digit: they always fit the 2-byte words) */
 		if (p->wbytes != 2)
 			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: one-level plan without 2-byte words");
+		if (p->dbits == SHW_D_BITS) {
+			if (regs_per_digit > SHW_MAX_SEG || p->ntab != 2)
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: wide fan-out plan with %u segments per leaf, %u tables", regs_per_digit, p->ntab);
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf_wide<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			MDB_LAUNCH_LDS(ctx, "shard_leaf_wide", (k_shard_leaf_wide<1024>), p->Dp, 1024, lds, a);
+			return MIDORIDB_OK;
+		}
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "shard_leaf", (k_shard_leaf<1024, uint16_t>), p->Dp, 1024, lds, a);
 		return MIDORIDB_OK;
@@ -467,7 +954,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 			   tiles, max_tiles);
 		/* (a leaf's key bits fit 16: its words are written - and read by the leaf kernel - as 2 bytes) */
 		int rc = mdb_partition_words_level(ctx, reinterpret_cast<const uint32_t *>(recv[x]), tiles, max_tiles, p->b2,
-						   32u - SH_D_BITS - (uint32_t)p->b2, leaves, cursor, nleaves, p->leaf_cap[x], leaf16 ? 32u - p->kbits : 0u);
+						   32u - p->dbits - (uint32_t)p->b2, leaves, cursor, nleaves, p->leaf_cap[x], leaf16 ? 32u - p->kbits : 0u);
 		if (rc)
 			return rc;
 		a.words[x] = leaves;

@@ -2009,7 +2009,7 @@ def test_join_group_count_multi_same_key(dev, shape):
 
 
 @pytest.mark.parametrize("shape", ["dense_unique", "dim_in_low_range", "dups_spread", "nulls_both", "window_far_from_zero", "keys_beyond_any_window",
-                                   "skew", "small"])
+                                   "skew", "small", "sparse_keys_window_2^25", "sparse_keys_window_2^27_nulls_dups", "window_2^24"])
 def test_join_group_count_without_order(dev, shape):
     """mdb_dev_join_group_count without MDB_ORDER_FIRST and without first rows: the groups may come in any order, and the operator then
     moves no row ids and sorts nothing (the sharded operator's receiver pipeline on this GPU's own regions).  Same groups and counts as
@@ -2028,11 +2028,18 @@ def test_join_group_count_without_order(dev, shape):
     elif shape == "keys_beyond_any_window":
         kl = rng.integers(-2**62, 2**62, n, dtype=np.int64)
         kr = np.concatenate([kl[: n // 2], rng.integers(-2**62, 2**62, n // 2, dtype=np.int64)])
+    elif shape == "sparse_keys_window_2^25":     # (windows of 2^24 .. 2^27 values: the 4096-digit first level, one pass per table)
+        kl, kr = off + 8 * (kl - off), off + 8 * (kr - off)
+    elif shape == "sparse_keys_window_2^27_nulls_dups":
+        kl = off + 40 * rng.integers(0, n, n, dtype=np.int64)
+        kr = off + 40 * rng.integers(0, n, n + 12345, dtype=np.int64)
+    elif shape == "window_2^24":
+        kl, kr = off - 2**40 + 5 * (kl - off), off - 2**40 + 5 * (kr - off)
     elif shape == "skew":
         kl[rng.random(n) < 0.7] = off + 5
         kr[rng.random(len(kr)) < 0.5] = off + 5
-    nl = (rng.random(n) < 0.02) if shape == "nulls_both" else None
-    nr = (rng.random(len(kr)) < 0.02) if shape == "nulls_both" else None
+    nl = (rng.random(n) < 0.02) if "nulls" in shape else None
+    nr = (rng.random(len(kr)) < 0.02) if "nulls" in shape else None
     ek, ec, _, ej = orc.join_group_count(kl, nl, kr, nr)
     k, c, j = dev.join_group_count_unordered(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
     got = dict(zip(_np(k).tolist(), _np(c).tolist()))
