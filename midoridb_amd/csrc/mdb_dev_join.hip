@@ -2669,14 +2669,6 @@ again: {
 		return rc;
 	MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (getenv("MDB_SHW_DBG") && (atoi(getenv("MDB_SHW_DBG")) & 16)) {
-		unsigned long long acc[5];
-		(void)hipMemcpy(acc, ctx->d_status + 64, sizeof(acc), hipMemcpyDeviceToHost);
-		(void)hipMemset(ctx->d_status + 64, 0, sizeof(acc));
-		if (acc[4])
-			fprintf(stderr, "wide scatter phases (cycles per tile): load+rank %llu, digits %llu, stage+delta %llu, write %llu (%llu tiles)\n",
-				acc[0] / acc[4], acc[1] / acc[4], acc[2] / acc[4], acc[3] / acc[4], acc[4]);
-	}
 	if (h[0]) {
 		if (getenv("MDB_DEBUG_UNORDERED"))
 			fprintf(stderr, "unordered form not served: flags %u (k %u, b2 %u, rem %u)\n", h[0], plan.kbits, plan.b2, plan.rem);

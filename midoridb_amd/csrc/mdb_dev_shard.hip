@@ -173,7 +173,6 @@ struct shw_scatter_args {
 	uint32_t cap, nsub;
 	uint32_t *status;
 	uint32_t rows_per_wg;	/* (even) */
-	uint32_t dbg;
 };
 
 /* a barrier that waits for the wave's LDS operations only: global loads (the next tile's keys) and the cursor atomics stay in
@@ -197,7 +196,7 @@ __device__ static inline uint32_t shw_block_excl_scan(uint32_t v, uint32_t *tmp 
 	return incl - v + (wave ? before : 0u);
 }
 
-template <int THREADS, int RPT /* rows per thread */, bool PREFETCH>
+template <int THREADS, int RPT /* rows per thread */>
 __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024 or two of 512 per CU */) void k_shard_scatter_wide(shw_scatter_args a)
 {
 	constexpr uint32_t TILE = THREADS * RPT, D = 1u << SHW_D_BITS, DPT = D / THREADS, NCHUNK = TILE / 64u, HALF = RPT / 2;
@@ -219,22 +218,15 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 		s_bad[i] = 0u;
 	if (threadIdx.x == 0)
 		s_any_bad = 0u;
-	ulonglong2 nxt[HALF / 2];	/* the first half of the next tile's keys, requested while this tile is written out */
-	bool have_nxt = false;		/* (uniform) */
 
-	/* A workgroup takes one contiguous range of rows, tile after tile.  All CUs start together, and a tile's phases use different
-	 * parts of the chip (the key loads HBM, the ranking and staging LDS, the cursor atomics L2): left alone, every CU loads while
-	 * HBM is saturated and then computes while it idles.  The FIRST tile of a workgroup is therefore 1/4, 2/4, 3/4 or 4/4 of a
-	 * tile, by workgroup number: the CUs run their phases a quarter period apart. */
+	/* A workgroup takes one contiguous range of rows, tile after tile (one workgroup per CU: 90 KiB of LDS).  Measured per tile
+	 * of 32 768 rows (clock64 around the phases, 10^8 rows): load + rank 32 000 cycles, digits 5 000, stage 8 000, write-out
+	 * 16 600 - the sum is the kernel; keys requested one tile ahead, and first tiles of unequal length per workgroup (the CUs'
+	 * phases spread over the period) both left the total where it was. */
 	const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_wg;
 	const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
-	bool first = true;
 	for (uint64_t row0 = r_begin; row0 < r_end;) {
-		uint32_t want = TILE;
-		if (first && !(a.dbg & 32u))
-			want = (TILE / 4u) * (((blockIdx.x / a.nsub) & 3u) + 1u);
-		first = false;
-		const uint32_t len = (uint32_t)((r_end - row0) < want ? (r_end - row0) : want);
+		const uint32_t len = (uint32_t)((r_end - row0) < TILE ? (r_end - row0) : TILE);
 		const bool full = len == TILE;	/* (uniform) */
 		/* (the thread's number, made opaque per tile: otherwise the addresses of all its loads and LDS accesses are computed once,
 		 * before the loop, and kept in ~70 registers across it - spills) */
@@ -245,9 +237,6 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 		if (tid == 0)
 			s_chunk[0] = 0u;
 		shw_barrier();
-		long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
-		if (a.dbg & 16u)
-			tc0 = clock64();
 
 		/* 1. load (16 bytes = two keys per access, a half of the thread's rows in flight at a time), hash, rank inside the digit */
 		uint32_t packed[RPT];	/* digit << 16 | rank, or ~0 for a row that is not taken */
@@ -258,9 +247,7 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 #pragma unroll
 			for (int r = 0; r < HALF / 2; r++) {
 				const uint32_t e0 = 2u * ((uint32_t)(hblock * (HALF / 2) + r) * THREADS + tid);
-				if (PREFETCH && hblock == 0 && have_nxt)
-					pre[r] = nxt[r];
-				else if (full || e0 + 1u < len)		/* (row0 is even and the column 16-byte aligned) */
+				if (full || e0 + 1u < len)		/* (row0 is even and the column 16-byte aligned) */
 					pre[r] = *reinterpret_cast<const ulonglong2 *>(a.keys + row0 + e0);
 				else if (e0 < len)
 					pre[r] = make_ulonglong2((unsigned long long)a.keys[row0 + e0], 0ull);
@@ -299,8 +286,6 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 			}
 		}
 		shw_barrier();
-		if (a.dbg & 16u)
-			tc1 = clock64();
 
 		/* 2. digit counts -> tile-local starts (written back over the counters), the ordinal of every non-empty digit, the runs
 		 *    that begin before every 64th staged position, and the run's place in its region: one global atomic per (tile,
@@ -326,7 +311,7 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 				st0[j] = start;
 				base[j] = 0u;
 				if (cnt[j]) {
-					base[j] = (a.dbg & 2u) ? 0u : atomicAdd(&a.cursor[sub * D + d], cnt[j]);
+					base[j] = atomicAdd(&a.cursor[sub * D + d], cnt[j]);
 					/* this run is the last one to begin before position 64 c for every c with start < 64 c <= start + count */
 					for (uint32_t c = (start >> 6) + 1u; (c << 6) <= start + cnt[j] && c < NCHUNK; c++)
 						s_chunk[c] = ord + 1u;
@@ -339,8 +324,6 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 				s_cnt[tid * (DPT / 2) + j] = st0[2 * j] | (st0[2 * j + 1] << 16);
 		}
 		shw_barrier();
-		if (a.dbg & 16u)
-			tc2 = clock64();
 
 		/* 3. stage by digit */
 #pragma unroll
@@ -350,15 +333,6 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 				const uint32_t st = (s_cnt[dig >> 1] >> ((dig & 1u) << 4)) & 0xFFFFu;
 				s_stage[st + (packed[r] & 0xFFFFu)] = (uint16_t)(word2[r >> 1] >> (16 * (r & 1)));
 			}
-		}
-		/* the next tile's first keys: on their way while this tile is written out */
-		have_nxt = false;
-		if (PREFETCH && row0 + len + TILE <= r_end) {
-			const uint64_t nrow0 = row0 + len;
-#pragma unroll
-			for (int r = 0; r < HALF / 2; r++)
-				nxt[r] = *reinterpret_cast<const ulonglong2 *>(a.keys + nrow0 + 2u * ((uint32_t)r * THREADS + tid));
-			have_nxt = true;
 		}
 		{
 			uint32_t ord = ord0;
@@ -377,8 +351,6 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 			}
 		}
 		shw_barrier();
-		if (a.dbg & 16u)
-			tc3 = clock64();
 
 		/* 4. write out: consecutive lanes, consecutive positions of a run; a position's run = the runs that begin before its
 		 *    chunk of 64 + the marks up to it inside the chunk */
@@ -393,19 +365,9 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 			const uint32_t ord = s_chunk[(uint32_t)k * (THREADS / 64) + wave] + (uint32_t)__popcll(m & le) - 1u;
 			if (any_bad && ((s_bad[ord >> 5] >> (ord & 31u)) & 1u))
 				continue;
-			if (!(a.dbg & 1u))
-				a.out[i + s_delta[ord]] = (uint16_t)(sv & 0x7FFFu);
+			a.out[i + s_delta[ord]] = (uint16_t)(sv & 0x7FFFu);
 		}
 		shw_barrier();
-		if ((a.dbg & 16u) && tid == 0) {
-			tc4 = clock64();
-			unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.status + 64);
-			atomicAdd(&acc[0], (unsigned long long)(tc1 - tc0));
-			atomicAdd(&acc[1], (unsigned long long)(tc2 - tc1));
-			atomicAdd(&acc[2], (unsigned long long)(tc3 - tc2));
-			atomicAdd(&acc[3], (unsigned long long)(tc4 - tc3));
-			atomicAdd(&acc[4], 1ull);
-		}
 		if (any_bad) {		/* (rare: clear the marks of this tile's full regions) */
 			for (uint32_t i = tid; i < D / 32; i += THREADS)
 				s_bad[i] = 0u;
@@ -475,32 +437,12 @@ int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, con
 		a.cap = p->cap[side];
 		a.nsub = p->nsub;
 		a.status = ctx->d_status;
-		a.dbg = getenv("MDB_SHW_DBG") ? (uint32_t)atoi(getenv("MDB_SHW_DBG")) : 0u;
-		static int shape = -1;	/* (measurements: MDB_SHARD_WIDE_TILE = 0: 1024 threads x 32 rows with prefetch, 1: without, 2: 1024 x 16) */
-		if (shape < 0)
-			shape = getenv("MDB_SHARD_WIDE_TILE") ? atoi(getenv("MDB_SHARD_WIDE_TILE")) : 0;
-		const char *const pname = side ? "shard_scatter_wide_r" : "shard_scatter_wide_l";
-		const uint32_t tile = (shape == 2 || shape == 3) ? 16384u : 32768u;
-		const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile), wgs = (uint32_t)ctx->num_cus * ((shape == 2 || shape == 3) ? 2u : 1u);
-		uint32_t grid = ntiles < wgs ? ntiles : wgs;	/* persistent workgroups: tile t, t + grid, ... */
+		const uint32_t tile = 32768u, ntiles = (uint32_t)((n + tile - 1) / tile);
+		const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;	/* one workgroup per CU, a contiguous range of rows each */
 		a.rows_per_wg = (uint32_t)(((n + grid - 1) / grid + 1) & ~1ull);
-		if (shape == 3) {
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<512, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-							 (int)shw_scatter_lds(tile)));
-			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<512, 32, false>), grid, 512, shw_scatter_lds(tile), a);
-		} else if (shape == 2) {
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-							 (int)shw_scatter_lds(tile)));
-			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 16, false>), grid, 1024, shw_scatter_lds(tile), a);
-		} else if (shape == 1) {
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-							 (int)shw_scatter_lds(tile)));
-			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 32, false>), grid, 1024, shw_scatter_lds(tile), a);
-		} else {
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-							 (int)shw_scatter_lds(tile)));
-			MDB_LAUNCH_LDS(ctx, pname, (k_shard_scatter_wide<1024, 32, true>), grid, 1024, shw_scatter_lds(tile), a);
-		}
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+						 (int)shw_scatter_lds(tile)));
+		MDB_LAUNCH_LDS(ctx, side ? "shard_scatter_wide_r" : "shard_scatter_wide_l", (k_shard_scatter_wide<1024, 32>), grid, 1024, shw_scatter_lds(tile), a);
 		*regions = buf;
 		*cursors = cur;
 		return MIDORIDB_OK;
@@ -923,11 +865,15 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		/* (one level means k - 9 <= 14 key bits below the digit: they always fit the 2-byte words) */
 		if (p->wbytes != 2)
 			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: one-level plan without 2-byte words");
-		if (p->dbits == SHW_D_BITS) {
-			if (regs_per_digit > SHW_MAX_SEG || p->ntab != 2)
-				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: wide fan-out plan with %u segments per leaf, %u tables", regs_per_digit, p->ntab);
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf_wide<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			MDB_LAUNCH_LDS(ctx, "shard_leaf_wide", (k_shard_leaf_wide<1024>), p->Dp, 1024, lds, a);
+		if (p->dbits == SHW_D_BITS && (regs_per_digit > SHW_MAX_SEG || p->ntab != 2))
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: wide fan-out plan with %u segments per leaf, %u tables", regs_per_digit, p->ntab);
+		/* two tables: 16-bit counters (half the LDS: two workgroups per CU at 2^14 values per digit; a count beyond 65 535 is
+		 * reported and answered by another path) */
+		if (p->dbits == SHW_D_BITS || (p->ntab == 2 && regs_per_digit <= SHW_MAX_SEG && p->rem >= 1u &&
+					       !(getenv("MDB_SHARD_LEAF_U16") && getenv("MDB_SHARD_LEAF_U16")[0] == '0'))) {
+			const size_t lds16 = (size_t)4 << p->rem;
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf_wide<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+			MDB_LAUNCH_LDS(ctx, "shard_leaf_wide", (k_shard_leaf_wide<1024>), p->Dp, 1024, lds16, a);
 			return MIDORIDB_OK;
 		}
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf<1024, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

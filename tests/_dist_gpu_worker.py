@@ -260,7 +260,8 @@ def fused_shapes(dx, dev, world, rank):
     overflow a region (every rank takes the exact path together)"""
     rng = np.random.default_rng(99)
     dx.set_wire(WIRE_32)
-    for n, span, dup in ((300_000, 40_000, 3), (500_000, 3_000_000, 1), (400_000, 60_000_000, 2), (1_500_000, 1_200_000, 1)):
+    for n, span, dup in ((300_000, 40_000, 3), (500_000, 3_000_000, 1), (400_000, 60_000_000, 2), (1_500_000, 1_200_000, 1),
+                         (600_000, 130_000_000, 1), (500_000, 17_000_000, 4)):   # (windows of 2^24 .. 2^27 values: 4096 first-level digits)
         total = n * world
         base = 5_000_000
         ga = base + rng.integers(0, span, total, dtype=np.int64)
