@@ -42,7 +42,7 @@ def timed(dev, fn, reps=5, warmup=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "operators.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "operators.json"))
     ap.add_argument("--configs1", action="store_true", help="only the two BASELINE configs[0..1] shapes (scan_filter_1e8, join_payload_1e7): "
                                                              "what profiles/collect.sh runs under rocprofv3")
     args = ap.parse_args()
@@ -163,6 +163,14 @@ def main():
                                              "one_pass": dev.last_join_multi(),
                                              "note": "the same query through mdb_dev_join_group_count_multi: every table partitioned once, the right "
                                                      "tables' counts multiplied in the leaf kernel, the groups ordered once; no joined row exists"}
+
+    def three_way_unordered():
+        k, c, j = dev.join_group_count_multi_unordered(big[0], None, [(big[1], None), (big[2], None)])
+        return k.numel()
+    ms, kern, g3u = timed(dev, three_way_unordered, reps=3, warmup=1)
+    res["three_way_join_group_unordered_1e8"] = {"rows_per_table": n, "groups": g3u, "ms": ms, "joined_rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
+                                                 "unordered_form": dev.last_join_unordered(),
+                                                 "note": "the same call without MDB_ORDER_FIRST (mdb_database_groups_any_order): no row ids, no ordering sort"}
     del big
     torch.cuda.empty_cache()
 

@@ -2628,7 +2628,8 @@ int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nu
  * 0 = done, 1 = not served (window too wide, a key outside it, skew, a region overflow ...): the ordered operator answers. */
 static int gc_unordered_try(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			    const uint64_t *null_r, uint64_t n_r, int64_t *out_key, int64_t *out_count, uint64_t cap, uint64_t *out_groups,
-			    uint64_t *out_joined)
+			    uint64_t *out_joined, int n_extra = 0, const int64_t *const *keys_x = NULL, const uint64_t *const *null_x = NULL,
+			    const uint64_t *n_x = NULL /* further right tables on the same key: their rows outside the window join nothing */)
 {
 	if (n_l + n_r < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (getenv("MDB_UNORDERED") && getenv("MDB_UNORDERED")[0] == '0'))
 		return 1;
@@ -2648,18 +2649,26 @@ again: {
 	gc_compact_window(ctx->sr_rlo, ctx->sr_rhi, &kb, &wlo);
 	if (!kb || kb > 30u)
 		return 1;
-	const uint64_t n_max[2] = { n_l, n_r };
-	if (mdb_shard_plan_make(1, 0, 2, n_max, 0, (int64_t)(ctx->sr_span_l + ctx->sr_span_l / 8), wlo, wlo + (int64_t)((1ull << kb) - 1), &plan))
+	uint64_t n_max[MDB_SHARD_MAX_TABS] = { n_l, n_r, 0, 0 };
+	if (n_extra < 0 || 2 + n_extra > MDB_SHARD_MAX_TABS)
+		return 1;
+	for (int t = 0; t < n_extra; t++)
+		n_max[2 + t] = n_x[t];
+	if (mdb_shard_plan_make(1, 0, 2u + (uint32_t)n_extra, n_max, 0, (int64_t)(ctx->sr_span_l + ctx->sr_span_l / 8), wlo, wlo + (int64_t)((1ull << kb) - 1), &plan))
 		return 1;
 	rc = mdb_arena_begin(ctx, mdb_shard_arena_bytes(&plan));
 	if (rc)
 		return rc;
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	const int64_t *keys[2] = { keys_l, keys_r };
-	const uint64_t *nulls[2] = { null_l, null_r };
-	const void *regions[2] = { NULL, NULL };
-	const uint32_t *cursors[2] = { NULL, NULL };
-	for (int x = 1; x >= 0; x--) {		/* (the right table first, as in the ordered operator) */
+	const int64_t *keys[MDB_SHARD_MAX_TABS] = { keys_l, keys_r, NULL, NULL };
+	const uint64_t *nulls[MDB_SHARD_MAX_TABS] = { null_l, null_r, NULL, NULL };
+	const void *regions[MDB_SHARD_MAX_TABS] = { NULL, NULL, NULL, NULL };
+	const uint32_t *cursors[MDB_SHARD_MAX_TABS] = { NULL, NULL, NULL, NULL };
+	for (int t = 0; t < n_extra; t++) {
+		keys[2 + t] = keys_x[t];
+		nulls[2 + t] = null_x ? null_x[t] : NULL;
+	}
+	for (int x = 1 + n_extra; x >= 0; x--) {		/* (the right table first, as in the ordered operator) */
 		rc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], n_max[x], &regions[x], &cursors[x]);
 		if (rc)
 			return rc;
@@ -2851,6 +2860,21 @@ extern "C" int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *k
 		smallest = n_r[t] < smallest ? n_r[t] : smallest;
 	}
 	int rc = GC_NOT_SERVED;
+	if (!(flags & MDB_ORDER_FIRST) && !out_first && out_key && smallest >= (1u << 16)) {
+		/* no order asked for: every table partitioned once or twice without row ids, the right tables' counts multiplied in
+		 * the leaf tables, no ordering sort */
+		mdb_memo_switch(ctx, keys_l, n_l, keys_r[0], n_r[0]);
+		const int urc = gc_unordered_try(ctx, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], out_key, out_count, cap, out_groups,
+						 out_joined, n_right - 1, keys_r + 1, null_r ? null_r + 1 : NULL, n_r + 1);
+		if (urc <= 0) {
+			if (urc == 0)
+				ctx->last_semijoin |= 0x400;
+			return urc;
+		}
+		*out_groups = 0;
+		if (out_joined)
+			*out_joined = 0;
+	}
 	if (smallest >= (1u << 16) && n_l >= (1u << 20)) {	/* (small tables: the chain's single-workgroup and one-level forms are quicker) */
 		gc_extras ex;
 		memset(&ex, 0, sizeof(ex));

@@ -1796,7 +1796,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 						goto out;
 					rk[t - 1] = cv;
 				}
-				if (mdb_dev_join_group_count_multi(x.dev, lv, ln, nl_rows, s->ntabs - 1, rk, rnb, rrows, MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL,
+				if (mdb_dev_join_group_count_multi(x.dev, lv, ln, nl_rows, s->ntabs - 1, rk, rnb, rrows,
+								   (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL,
 								   cap, &G, &J)) {
 					rc = dev_fail(&x, "join + group count over several tables");
 					goto out;
@@ -1804,7 +1805,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				multi_done = true;
 			} else if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows,
 							    /* (a bare COUNT(*) has no group order to keep; nor has a GROUP BY when the database says so) */
-							    (only_count || (cat->groups_any_order && s->ntabs == 2)) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
+							    (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
 							    x.d_count, NULL, cap, &G, &J)) {
 				rc = dev_fail(&x, "join + group count");
 				goto out;

@@ -328,6 +328,20 @@ class DeviceCtx:
                                                           cap, byref(g), byref(j)), "join_group_count_multi")
         return ok[:g.value], oc[:g.value], of[:g.value], j.value
 
+    def join_group_count_multi_unordered(self, keys_l, null_l, rights, out=None):
+        """the same without MDB_ORDER_FIRST and without first rows: groups in unspecified order -> (keys[G], counts[G], joined rows)"""
+        n_l, nr = keys_l.numel(), len(rights)
+        cap = max(n_l, 1)
+        if out is None:
+            out = (torch.empty(cap, dtype=torch.int64, device=self.device), torch.empty(cap, dtype=torch.int64, device=self.device))
+        kr = (c_void_p * nr)(*[r[0].data_ptr() for r in rights])
+        nb = (c_void_p * nr)(*[(r[1].data_ptr() if r[1] is not None else None) for r in rights])
+        ns = (c_uint64 * nr)(*[r[0].numel() for r in rights])
+        g, j = c_uint64(), c_uint64()
+        self._chk(self.lib.mdb_dev_join_group_count_multi(self.h, _ptr(keys_l), _ptr(null_l), n_l, nr, kr, nb, ns, 0, _ptr(out[0]), _ptr(out[1]), None,
+                                                          cap, byref(g), byref(j)), "join_group_count_multi (unordered)")
+        return out[0][:g.value], out[1][:g.value], j.value
+
     def _gc_out(self, n_l, out):
         cap = max(n_l, 1)
         if out is None:

@@ -2006,6 +2006,11 @@ def test_join_group_count_multi_same_key(dev, shape):
     assert j == int(ec.sum())
     if shape != "nulls":
         assert dev.last_join_multi() == (shape in ("unique_3", "dups_3", "four_tables", "selective")), shape
+    # the same call without MDB_ORDER_FIRST and without first rows: the same groups in any order
+    k, c, j = dev.join_group_count_multi_unordered(dev.to_dev(kl), dev.nullbits_dev(nl), [(dev.to_dev(r), dev.nullbits_dev(m)) for r, m in zip(rights, nrs)])
+    assert j == int(ec.sum()) and dict(zip(_np(k).tolist(), _np(c).tolist())) == dict(zip(ek.tolist(), ec.tolist())) and k.numel() == len(ek)
+    if shape in ("unique_3", "dups_3", "four_tables"):      # ("selective": under 2^21 rows in the first two tables - the ordered operator answers)
+        assert dev.last_join_unordered(), shape
 
 
 @pytest.mark.parametrize("shape", ["dense_unique", "dim_in_low_range", "dups_spread", "nulls_both", "window_far_from_zero", "keys_beyond_any_window",
