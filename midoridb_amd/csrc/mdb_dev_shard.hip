@@ -685,77 +685,103 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 	extern __shared__ __attribute__((aligned(16))) uint32_t sh_lds[];
 	__shared__ unsigned long long s_red[THREADS / 64];
 	__shared__ uint32_t s_base, s_total, s_off;
-	__shared__ uint32_t s_seg_chunk0[SHW_MAX_SEG + 1], s_seg_start[SHW_MAX_SEG], s_seg_cnt[SHW_MAX_SEG];
+	/* [side][segment]: first 16-byte chunk (prefix), start and length of the segment */
+	__shared__ uint32_t s_seg_chunk0[2][SHW_MAX_SEG + 1], s_seg_start[2][SHW_MAX_SEG], s_seg_cnt[2][SHW_MAX_SEG];
 	const uint32_t T = 1u << a.rem, HW = T >> 1, mask = T - 1u, leaf = blockIdx.x;
 	uint32_t *const s_cr = sh_lds, *const s_cl = sh_lds + HW;
+	/* both tables' segment tables at once (one round trip), while the counters are cleared */
+	if (threadIdx.x < 2u * SHW_MAX_SEG) {
+		const uint32_t side = threadIdx.x / SHW_MAX_SEG, j = threadIdx.x % SHW_MAX_SEG;
+		if (j < a.nseg) {
+			s_seg_start[side][j] = a.seg_start[side][leaf * a.nseg + j];
+			s_seg_cnt[side][j] = a.seg_cnt[side][leaf * a.nseg + j];
+		}
+	}
 	for (uint32_t s = threadIdx.x; s < 2u * HW; s += THREADS)
 		sh_lds[s] = 0u;
 	if (threadIdx.x == 0)
 		s_total = 0;
+	__syncthreads();
+	if (threadIdx.x < 2u) {
+		uint32_t run = 0;
+		for (uint32_t j = 0; j < a.nseg; j++) {
+			s_seg_chunk0[threadIdx.x][j] = run;
+			run += (s_seg_cnt[threadIdx.x][j] + 7u) >> 3;
+		}
+		s_seg_chunk0[threadIdx.x][a.nseg] = run;
+	}
+	__syncthreads();
 	uint32_t groups = 0;
-	for (int pass = 0; pass < 2; pass++) {
-		const int side = 1 - pass;	/* the right table first */
-		const uint16_t *const base = reinterpret_cast<const uint16_t *>(a.words[side]);
-		__syncthreads();
-		if (threadIdx.x < a.nseg) {
-			uint32_t c = a.seg_cnt[side][leaf * a.nseg + threadIdx.x];
-			s_seg_start[threadIdx.x] = a.seg_start[side][leaf * a.nseg + threadIdx.x];
-			s_seg_cnt[threadIdx.x] = c;
+	/* chunk q of a table = eight 2-byte words of one of its segments (regions start at multiples of 64 words) */
+	auto fetch = [&](int side, uint32_t q, uint32_t nchunks, uint4 &v, uint32_t &nv) {
+		v = make_uint4(0u, 0u, 0u, 0u);
+		nv = 0u;
+		if (q >= nchunks)
+			return;
+		uint32_t lo = 0, hi = a.nseg;	/* the last segment whose first chunk is <= q */
+		while (hi - lo > 1u) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (s_seg_chunk0[side][mid] <= q)
+				lo = mid;
+			else
+				hi = mid;
 		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint32_t run = 0;
-			for (uint32_t j = 0; j < a.nseg; j++) {
-				s_seg_chunk0[j] = run;
-				run += (s_seg_cnt[j] + 7u) >> 3;
-			}
-			s_seg_chunk0[a.nseg] = run;
-		}
-		__syncthreads();
-		const uint32_t nchunks = s_seg_chunk0[a.nseg];
-		for (uint32_t q0 = 0; q0 < nchunks; q0 += THREADS * 4u) {	/* uniform trip count; four 16-byte loads in flight */
-			uint4 v[4];
-			uint32_t nv[4];
+		const uint32_t off = (q - s_seg_chunk0[side][lo]) << 3, c = s_seg_cnt[side][lo];
+		nv = c - off < 8u ? c - off : 8u;
+		v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.words[side]) + s_seg_start[side][lo] + off);
+	};
+	auto count = [&](int side, const uint4 &v, uint32_t nv) {
+		const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const uint32_t q = q0 + (uint32_t)u * THREADS + threadIdx.x;
-				v[u] = make_uint4(0u, 0u, 0u, 0u);
-				nv[u] = 0u;
-				if (q < nchunks) {
-					uint32_t lo = 0, hi = a.nseg;	/* the last segment whose first chunk is <= q */
-					while (hi - lo > 1u) {
-						const uint32_t mid = (lo + hi) >> 1;
-						if (s_seg_chunk0[mid] <= q)
-							lo = mid;
-						else
-							hi = mid;
-					}
-					const uint32_t off = (q - s_seg_chunk0[lo]) << 3, c = s_seg_cnt[lo];
-					nv[u] = c - off < 8u ? c - off : 8u;
-					v[u] = *reinterpret_cast<const uint4 *>(base + s_seg_start[lo] + off);	/* (regions start at multiples of 64 words) */
-				}
-			}
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const uint32_t w4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
-#pragma unroll
-				for (uint32_t e = 0; e < 8u; e++) {
-					if (e >= nv[u])
-						continue;
-					const uint32_t idx = ((w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu) & mask, sh = (idx & 1u) << 4;
-					if (side == 1) {
-						if (((atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu) == 0xFFFFu)
-							mdb_raise(a.status, 2048u);
-					} else if ((s_cr[idx >> 1] >> sh) & 0xFFFFu) {
-						const uint32_t old = (atomicAdd(&s_cl[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
-						if (old == 0u)
-							groups++;
-						else if (old == 0xFFFFu)
-							mdb_raise(a.status, 2048u);
-					}
-				}
+		for (uint32_t e = 0; e < 8u; e++) {
+			if (e >= nv)
+				continue;
+			const uint32_t idx = ((w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu) & mask, sh = (idx & 1u) << 4;
+			if (side == 1) {
+				if (((atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu) == 0xFFFFu)
+					mdb_raise(a.status, 2048u);
+			} else if ((s_cr[idx >> 1] >> sh) & 0xFFFFu) {
+				const uint32_t old = (atomicAdd(&s_cl[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+				if (old == 0u)
+					groups++;
+				else if (old == 0xFFFFu)
+					mdb_raise(a.status, 2048u);
 			}
 		}
+	};
+	const uint32_t nch_r = s_seg_chunk0[1][a.nseg], nch_l = s_seg_chunk0[0][a.nseg];
+	/* the right table's first four chunks per thread AND the left table's are requested before anything is counted: the left
+	 * rows are on their way while the right ones go through the LDS atomics */
+	uint4 vr[4], vl[4];
+	uint32_t nr[4], nl[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		fetch(1, (uint32_t)u * THREADS + threadIdx.x, nch_r, vr[u], nr[u]);
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		fetch(0, (uint32_t)u * THREADS + threadIdx.x, nch_l, vl[u], nl[u]);
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		count(1, vr[u], nr[u]);
+	for (uint32_t q0 = THREADS * 4u; q0 < nch_r; q0 += THREADS * 4u) {	/* (uniform trip count) */
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			fetch(1, q0 + (uint32_t)u * THREADS + threadIdx.x, nch_r, vr[u], nr[u]);
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			count(1, vr[u], nr[u]);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		count(0, vl[u], nl[u]);
+	for (uint32_t q0 = THREADS * 4u; q0 < nch_l; q0 += THREADS * 4u) {
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			fetch(0, q0 + (uint32_t)u * THREADS + threadIdx.x, nch_l, vl[u], nl[u]);
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			count(0, vl[u], nl[u]);
 	}
 	__syncthreads();
 	{
