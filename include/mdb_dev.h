@@ -319,7 +319,7 @@ int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
  * With MDB_ORDER_FIRST the groups are in the reference's order (first occurrence in
  * L-major join order).  Without it - and without out_first - the order is unspecified and the operator may
  * skip everything that order costs: no row id travels through the partition levels and no ordering sort runs
- * (10^8 x 10^8 unique keys: 1.6 ms instead of 2.6; bit 11 of mdb_dev_last_join_filter() says this form ran).  *out_groups = G, *out_joined = number of joined rows
+ * (10^8 x 10^8 unique keys: 1.2 ms instead of 2.6; bit 11 of mdb_dev_last_join_filter() says this form ran).  *out_groups = G, *out_joined = number of joined rows
  * (sum of counts).  Synchronous: G, J and the overflow flags come back before the groups are ordered
  * (the ordering sort is sized by G), completion after it.  Size limit per call: about 7*10^8 left rows
  * (beyond that the tables must be sharded, see mdb_dev_partition_by_dest).
@@ -342,7 +342,7 @@ int mdb_dev_combine_counts(mdb_dev_ctx *ctx, const int64_t *cnt1, const uint32_t
 /* The same shape in ONE operator: left table L and n_right (1 ... 3) right tables, all joined on one key -
  * SELECT l.key, COUNT(*) FROM L JOIN R0 ON l.key = r0.key JOIN R1 ON l.key = r1.key ... GROUP BY l.key (reference:
  * recursive join executor_select.c:1151-1280 + GROUP BY :1526-1588; BASELINE configs[4]).  COUNT(*) of a key = its rows in L
- * x its rows in R0 x its rows in R1 ...; outputs exactly as mdb_dev_join_group_count() (first-occurrence order, out_first =
+ * x its rows in R0 x its rows in R1 ...; outputs exactly as mdb_dev_join_group_count() (first-occurrence order with MDB_ORDER_FIRST - any order, cheaper, without it and without out_first; out_first =
  * first L position, *out_joined = rows of the full join).  Every table is partitioned once and the groups ordered once when the
  * keys take the compact narrow form; otherwise the call chains the two-table operator itself.  keys_r / null_r / n_r:
  * HOST arrays of n_right entries (null_r may be NULL, or hold NULLs).  Synchronous. */
