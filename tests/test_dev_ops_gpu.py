@@ -604,6 +604,35 @@ def test_full_size_north_star_properties(dev, variant):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("variant", ["D", "U", "S"])
+def test_full_size_north_star_in_any_order(dev, variant):
+    """The same full-size workloads through the operator WITHOUT MDB_ORDER_FIRST (no row ids, no ordering sort; U and S through the
+    4096-digit first level): the groups as a set - distinct keys, the closed-form key and count sums, every count what the generator
+    makes it - and, key for key, the ordered operator's result (both sorted by key on the device)."""
+    N = 100_000_000
+    a = dev.gen_keys(N, 0, N, 42, 0)
+    b = dev.gen_keys(N, 0, N, 43, 0 if variant == "U" else N // 16)
+    if variant == "S":
+        b.mul_(16)
+    k, c, j = dev.join_group_count_unordered(a, None, b, None)
+    assert dev.last_join_unordered()
+    G = N if variant == "U" else N // 16
+    assert j == N and k.numel() == G and int(c.sum()) == N
+    assert bool((c == (1 if variant == "U" else 16)).all())
+    ks, order = torch.sort(k)
+    assert bool((ks[1:] > ks[:-1]).all())                                              # every key once
+    step = 16 if variant == "S" else 1
+    assert int(ks[0]) == 0 and int(ks[-1]) == step * (G - 1) and int(ks.sum()) == step * G * (G - 1) // 2
+    cs = c[order]
+    del k, c, order
+    ko, co, fo, jo = dev.join_group_count(a, None, b, None)
+    assert jo == j and ko.numel() == G
+    kos, oo = torch.sort(ko)
+    assert bool((kos == ks).all()) and bool((co[oo] == cs).all())
+    del ko, co, fo, kos, oo, ks, cs
+    torch.cuda.empty_cache()
+
+
 def test_full_size_three_way_join_properties(dev):
     """BASELINE config 5 shape at 10^8 rows per table on one GPU (keys only): A, B, C independent permutations of
     [0, N): (A join B) join C has exactly N rows, every A row once, and the composed row ids point at equal keys."""
@@ -637,6 +666,11 @@ def test_full_size_three_way_join_properties(dev):
     assert j3 == N and k3.numel() == N and bool((c3 == 1).all()) and bool((k3 == a).all())
     assert bool((f3.long() == torch.arange(N, device=f3.device)).all())
     assert dev.last_join_multi()
+    del k3, c3, f3
+    # ... and in any order: the same set of groups
+    ku, cu, ju = dev.join_group_count_multi_unordered(a, None, [(b, None), (cc, None)])
+    assert dev.last_join_unordered() and ju == N and ku.numel() == N and bool((cu == 1).all())
+    assert bool((torch.sort(ku)[0] == torch.arange(N, device=ku.device)).all())
     torch.cuda.empty_cache()
 
 
