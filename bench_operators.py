@@ -122,6 +122,17 @@ def main():
     algo = 8 * n + 12 * g
     res["group_count_1e8"] = {"rows": n, "groups": g, "ms": ms, "algorithmic_bytes": algo,
                               "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern}
+    gk_out = (torch.empty(n, dtype=torch.int64, device=dev.device), torch.empty(n, dtype=torch.int64, device=dev.device))
+
+    def group_by_keys():
+        r = dev.group_count_keys(keys, None, out=gk_out)
+        return -1 if r is None else r[0].numel()
+    ms, kern, gk = timed(dev, group_by_keys)
+    algo = 8 * n + 16 * max(gk, 0)
+    res["group_count_keys_any_order_1e8"] = {"rows": n, "groups": gk, "ms": ms, "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9,
+                                            "kernels_ms": kern, "note": "mdb_dev_group_count_keys: (key, COUNT) pairs in unspecified order - no row "
+                                                                          "ids, no ordering sort (mdb_database_groups_any_order)"}
+    del gk_out
 
     # ---- three-way join on one key (config 5 shape), 10^7 rows per table, 1:1:1
     c_id = dev.gen_keys(n2, 0, n2, 60, 0)

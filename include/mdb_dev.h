@@ -307,6 +307,14 @@ int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 			uint32_t flags, uint32_t *out_first, int64_t *out_count, uint64_t cap,
 			uint64_t *out_groups);
 
+/* The same grouping as (key, COUNT(*)) PAIRS in unspecified order, for statements that select nothing but the group key and
+ * COUNT(*) and ask for no order (mdb_database_groups_any_order): no row ids, no ordering sort - one partition pass of 2-byte
+ * words and a counting pass (10^8 rows, 6.25 * 10^6 groups: 0.35 ms instead of 0.84).  out_key / out_count: caller buffers of
+ * capacity cap.  Returns 1 - and writes nothing - when it does not serve the column (NULL keys present: pass nullbits only when
+ * there are any; keys beyond every 2^30-value window; skew; fewer than 2^21 rows): mdb_dev_group_count() then answers. */
+int mdb_dev_group_count_keys(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_key,
+			     int64_t *out_count, uint64_t cap, uint64_t *out_groups);
+
 /* ------------------------------------------------------------------ fused north-star pipeline
  *
  * SELECT l.key, COUNT(*) FROM L INNER JOIN R ON l.key = r.key GROUP BY l.key

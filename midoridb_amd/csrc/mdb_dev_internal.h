@@ -156,6 +156,7 @@ struct mdb_shard_plan {
 	uint32_t rem;			/* key bits that index the leaf tables */
 	uint64_t block_words[MDB_SHARD_MAX_TABS];	/* words per destination block = Dp * nsub * cap */
 	uint32_t leaf_cap[MDB_SHARD_MAX_TABS];		/* b2 > 0: words per leaf region of the receiver's level */
+	bool right_only;		/* GROUP BY of ONE table (it plays the right table; the left one has no rows): a slot's group is its first row, COUNT = its rows */
 	uint64_t l_rel_hi;		/* the left table keeps the rows with key - key_lo in [0, l_rel_hi] (= the right table's range) */
 };
 /* 0 = plan made; 1 = this shape is not served (window too wide, world not a power of two ...): the caller takes another path */

@@ -2698,6 +2698,67 @@ again: {
 	return 0;
 }
 
+/* GROUP BY key + COUNT(*) of ONE column as (key, COUNT) pairs in unspecified order (include/mdb_dev.h): the any-order operator's
+ * pipeline with the table in the right table's place and no left table - one first level of 2-byte words (two levels beyond
+ * 2^27 values), every leaf slot with rows is a group.  1 = not served (NULL keys, keys beyond a 2^30-value window, skew that
+ * overflows a region, small tables): the caller's ordered operator answers. */
+extern "C" int mdb_dev_group_count_keys(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_key,
+					int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+{
+	if (!ctx || !out_groups || !out_key || !out_count)
+		return -MIDORIDB_ERROR;
+	*out_groups = 0;
+	if (nullbits || n < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (getenv("MDB_UNORDERED") && getenv("MDB_UNORDERED")[0] == '0'))
+		return 1;
+	mdb_memo_switch(ctx, keys, n, NULL, 0);
+	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+	for (int attempt = 0; attempt < 2; attempt++) {
+		int64_t lo = 0, hi = 0;
+		int rc = gc_sample_range(ctx, keys, NULL, n, NULL, NULL, 0, attempt > 0 || ctx->nh_distrust > 0, &lo, &hi);
+		if (rc)
+			return rc;
+		const bool remembered = ctx->sr_uses > 0;
+		uint32_t kb = 0;
+		int64_t wlo = 0;
+		if (lo <= hi)
+			gc_compact_window(lo, hi, &kb, &wlo);
+		if (!kb || kb > 30u)
+			return 1;
+		mdb_shard_plan plan;
+		const uint64_t n_max[2] = { 0, n };
+		if (mdb_shard_plan_make(1, 0, 2, n_max, 0, 0, wlo, wlo + (int64_t)((1ull << kb) - 1), &plan))
+			return 1;
+		plan.right_only = true;
+		rc = mdb_arena_begin(ctx, mdb_shard_arena_bytes(&plan));
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+		const void *regions[2] = { NULL, NULL };
+		const uint32_t *cursors[2] = { NULL, NULL };
+		rc = mdb_shard_partition(ctx, &plan, 1, keys, NULL, n, &regions[1], &cursors[1]);
+		if (!rc)
+			rc = mdb_shard_partition(ctx, &plan, 0, NULL, NULL, 0, &regions[0], &cursors[0]);	/* (no rows: all-zero counters) */
+		if (!rc)
+			rc = mdb_shard_join(ctx, &plan, regions, cursors, out_key, out_count, cap);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (!h[0]) {
+			*out_groups = h[1];
+			return MIDORIDB_OK;
+		}
+		if (getenv("MDB_DEBUG_UNORDERED"))
+			fprintf(stderr, "group_count_keys not served: flags %u (k %u, b2 %u, rem %u)\n", h[0], plan.kbits, plan.b2, plan.rem);
+		if (!((h[0] & 128u) && remembered && attempt == 0)) {	/* (a remembered sample of a column whose contents changed: taken again, once) */
+			if (h[0] & 128u)
+				ctx->nh_distrust = 8;
+			return 1;
+		}
+	}
+	return 1;
+}
+
 extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 					const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t flags,
 					int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,

@@ -529,6 +529,7 @@ struct sh_leaf_args {
 	long long *out_key, *out_count;
 	uint32_t out_cap;
 	uint32_t *status;		/* [0] flags, [1] groups so far, [2..3] joined rows (u64) */
+	uint32_t right_only;		/* no left table: every slot the (one) right table has rows in is a group, COUNT(*) = those rows */
 };
 
 /* One workgroup per leaf: the right rows count into cr[] (several right tables on the same key: each into an array of its
@@ -585,9 +586,10 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 							continue;
 						const uint32_t w = sizeof(WT) == 4 ? w4[e] : (w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu;
 						const uint32_t idx = (sizeof(WT) == 4 ? (w >> a.shift) : w) & mask;
-						if (side >= 1)
-							atomicAdd(&s_cx[idx], 1u);
-						else if (s_cr[idx] && atomicAdd(&s_cl[idx], 1u) == 0u)
+						if (side >= 1) {
+							if (atomicAdd(&s_cx[idx], 1u) == 0u && a.right_only)
+								groups++;
+						} else if (s_cr[idx] && atomicAdd(&s_cl[idx], 1u) == 0u)
 							groups++;
 					}
 				}
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 	unsigned long long joined = 0;
 	for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {
 		const uint32_t s = s0 + threadIdx.x;
-		const uint32_t cl = s < T ? s_cl[s] : 0u;
+		const uint32_t cl = s < T ? (a.right_only ? s_cr[s] : s_cl[s]) : 0u;
 		const uint64_t m = __ballot(cl != 0u);
 		if (!m)
 			continue;
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 		wbase = __shfl(wbase, 0, MDB_WAVE);
 		if (cl) {
 			const uint32_t pos = s_base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-			const unsigned long long c = (unsigned long long)cl * s_cr[s];
+			const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * s_cr[s];
 			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
 			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
 			a.out_count[pos] = (long long)c;
@@ -738,8 +740,11 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 				continue;
 			const uint32_t idx = ((w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu) & mask, sh = (idx & 1u) << 4;
 			if (side == 1) {
-				if (((atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu) == 0xFFFFu)
+				const uint32_t old = (atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+				if (old == 0xFFFFu)
 					mdb_raise(a.status, 2048u);
+				else if (old == 0u && a.right_only)
+					groups++;
 			} else if ((s_cr[idx >> 1] >> sh) & 0xFFFFu) {
 				const uint32_t old = (atomicAdd(&s_cl[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
 				if (old == 0u)
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 	unsigned long long joined = 0;
 	for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {
 		const uint32_t s = s0 + threadIdx.x, sh = (s & 1u) << 4;
-		const uint32_t cl = s < T ? (s_cl[s >> 1] >> sh) & 0xFFFFu : 0u;
+		const uint32_t cl = s < T ? ((a.right_only ? s_cr : s_cl)[s >> 1] >> sh) & 0xFFFFu : 0u;
 		const uint64_t m = __ballot(cl != 0u);
 		if (!m)
 			continue;
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 		wbase = __shfl(wbase, 0, MDB_WAVE);
 		if (cl) {
 			const uint32_t pos = s_base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-			const unsigned long long c = (unsigned long long)cl * ((s_cr[s >> 1] >> sh) & 0xFFFFu);
+			const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * ((s_cr[s >> 1] >> sh) & 0xFFFFu);
 			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
 			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
 			a.out_count[pos] = (long long)c;
@@ -876,6 +881,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 	a.out_count = reinterpret_cast<long long *>(out_count);
 	a.out_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 	a.status = ctx->d_status;
+	a.right_only = p->right_only ? 1u : 0u;
 	const size_t lds = p->dbits == SHW_D_BITS ? (size_t)4 << p->rem : (size_t)(4 * p->ntab) << p->rem;
 	if (lds > 150 * 1024)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "sharded join: leaf tables of %zu bytes", lds);

@@ -1979,6 +1979,31 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			uint64_t G = 0;
 			if ((rc = stream_column(&x, s->group[0], &kv, &kn)))
 				goto out;
+			/* any order allowed (mdb_database_groups_any_order), an INTEGER-like key without NULLs: (key, COUNT) pairs without row
+			 * ids or an ordering sort - the stream becomes what the fused plan's is (S4: only the group key and COUNT(*) can be
+			 * named from here on) */
+			if (cat->groups_any_order && !cat->dist && !x.fused && x.n && s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE &&
+			    !s->select_all && !s->distinct &&
+			    s->tabs[s->group[0]->tbl_idx].t->cols[s->group[0]->col_idx].null_count == 0) {
+				int64_t *gk = dalloc(&x, x.n * 8), *gc = dalloc(&x, x.n * 8);
+				uint64_t Gk = 0;
+				if (!gk || !gc) {
+					rc = dev_fail(&x, "allocating group outputs");
+					goto out;
+				}
+				const int krc = mdb_dev_group_count_keys(x.dev, kv, NULL, x.n, gk, gc, x.n, &Gk);
+				if (krc < 0) {
+					rc = dev_fail(&x, "group count (any order)");
+					goto out;
+				}
+				if (krc == 0) {
+					x.d_fused_key = gk;
+					x.d_count = gc;
+					x.fused = true;
+					x.n = Gk;
+					goto grouped;
+				}
+			}
 			first = dalloc(&x, (x.n ? x.n : 1) * 4);
 			x.d_count = dalloc(&x, (x.n ? x.n : 1) * 8);
 			if (!first || !x.d_count) {
@@ -2023,6 +2048,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 	}
 
+grouped:
 	if (cat->dist && fused < 0 && has_count && !s->ngroup) {
 		/* SELECT COUNT(*) [WHERE ...] in sharded mode: every rank reports the global count */
 		uint64_t tot = x.n;
@@ -2109,7 +2135,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			res->coltype[c] = col->type;
 			if (!out_rows || count_only)
 				continue;
-			if (fused >= 0) {
+			if (fused >= 0 || x.fused) {
 				d_vals[c] = x.d_fused_key;	/* only the group key can be selected (S4); both sides hold the same value */
 				continue;
 			}

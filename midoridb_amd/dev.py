@@ -89,6 +89,7 @@ def _bind(lib):
         "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
+        "mdb_dev_group_count_keys": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_group_count": ([P, P, P, c_uint64, P, P, c_uint64, c_uint32, P, P, P, c_uint64,
                                       POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dev_combine_counts": ([P, P, P, P, P, c_uint64, P, P, POINTER(c_uint64)], c_int),
@@ -118,7 +119,7 @@ DEV_SYMBOLS = [
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_cross_pairs",
-    "mdb_dev_group_count", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
+    "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
 ]
@@ -400,6 +401,20 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_group_count(self.h, _ptr(keys), _ptr(nulls), n, flags, _ptr(of), _ptr(oc), cap, byref(g)),
                   "group_count")
         return of[:g.value], oc[:g.value]
+
+    def group_count_keys(self, keys, nulls, out=None):
+        """GROUP BY + COUNT(*) as (keys[G], counts[G]) in unspecified order, or None when the form does not serve the column
+        (mdb_dev_group_count_keys returns 1: the ordered operator answers)"""
+        n = keys.numel()
+        cap = max(n, 1)
+        if out is None:
+            out = (torch.empty(cap, dtype=torch.int64, device=self.device), torch.empty(cap, dtype=torch.int64, device=self.device))
+        g = c_uint64()
+        rc = self.lib.mdb_dev_group_count_keys(self.h, _ptr(keys), _ptr(nulls), n, _ptr(out[0]), _ptr(out[1]), cap, byref(g))
+        if rc == 1:
+            return None
+        self._chk(rc, "group_count_keys")
+        return out[0][:g.value], out[1][:g.value]
 
     def join_pairs(self, keys_l, null_l, keys_r, null_r):
         pl, pr, cnt = c_void_p(), c_void_p(), c_uint64()

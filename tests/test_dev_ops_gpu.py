@@ -2084,3 +2084,35 @@ def test_join_group_count_without_order(dev, shape):
     got = dict(zip(_np(k).tolist(), _np(c).tolist()))
     assert len(got) == k.numel() and got == dict(zip(ek.tolist(), ec.tolist())) and j == ej
     assert dev.last_join_unordered() == (shape not in ("keys_beyond_any_window", "skew", "small")), shape
+
+
+@pytest.mark.parametrize("shape", ["dups16", "unique_window_2^22", "sparse_window_2^26", "far_from_zero", "few_values", "beyond_any_window", "nulls", "small", "skew"])
+def test_group_count_keys_in_any_order(dev, shape):
+    """mdb_dev_group_count_keys: GROUP BY + COUNT(*) of one column as (key, COUNT) pairs in unspecified order - the same groups as the
+    oracle's, as a set; what the form does not serve (NULL keys, keys beyond any 2^30-value window, skew, small tables) returns 1 and
+    the ordered operator answers."""
+    rng = np.random.default_rng(len(shape) + 3)
+    n = 3000 if shape == "small" else 2_500_000
+    k = {"dups16": lambda: 9 + rng.integers(0, n // 16, n, dtype=np.int64),
+         "unique_window_2^22": lambda: -5 + rng.permutation(n).astype(np.int64),
+         "sparse_window_2^26": lambda: 7 + 20 * rng.integers(0, n, n, dtype=np.int64),
+         "far_from_zero": lambda: 2**55 + rng.integers(0, n // 3, n, dtype=np.int64),
+         "few_values": lambda: rng.integers(0, 100, n, dtype=np.int64),
+         "beyond_any_window": lambda: rng.integers(-2**62, 2**62, n, dtype=np.int64),
+         "nulls": lambda: rng.integers(0, n // 4, n, dtype=np.int64),
+         "small": lambda: rng.integers(0, 50, n, dtype=np.int64),
+         "skew": lambda: np.where(rng.random(n) < 0.8, 12345, rng.integers(0, n, n, dtype=np.int64))}[shape]()
+    nulls = (rng.random(n) < 0.01) if shape == "nulls" else None
+    got = dev.group_count_keys(dev.to_dev(k), dev.nullbits_dev(nulls))
+    if shape in ("beyond_any_window", "nulls", "small", "skew", "few_values"):
+        if shape != "few_values":
+            assert got is None, shape
+        if got is None:
+            return
+    assert got is not None, shape
+    keys, counts = got
+    vals, cnt = np.unique(k, return_counts=True)
+    res = dict(zip(_np(keys).tolist(), _np(counts).tolist()))
+    assert len(res) == keys.numel() and res == dict(zip(vals.tolist(), cnt.tolist()))
+    ef, ec = orc.group_count(k, None)
+    assert sorted(res.items()) == sorted(zip(k[ef].tolist(), ec.tolist()))
