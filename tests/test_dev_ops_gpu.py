@@ -2116,3 +2116,28 @@ def test_group_count_keys_in_any_order(dev, shape):
     assert len(res) == keys.numel() and res == dict(zip(vals.tolist(), cnt.tolist()))
     ef, ec = orc.group_count(k, None)
     assert sorted(res.items()) == sorted(zip(k[ef].tolist(), ec.tolist()))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_any_order_operators_random_shapes(dev, seed):
+    """Random table sizes (odd, not multiples of any tile), key windows of 2^13 ... 2^29 values anywhere in the int64 range, duplication on
+    either side, NULLs: the any-order join + GROUP BY (one partition level of 512 or 4096 digits, or two levels) and the any-order GROUP BY
+    against the oracle, as sets."""
+    rng = np.random.default_rng(1000 + seed)
+    n_l = int(rng.integers(1_100_000, 3_500_000)) | 1
+    n_r = int(rng.integers(1_100_000, 3_500_000))
+    kbits = int(rng.integers(13, 30))
+    span = int(2 ** kbits * rng.uniform(0.55, 0.85))
+    base = int(rng.integers(-2**60, 2**60))
+    kl = base + rng.integers(0, span, n_l, dtype=np.int64)
+    kr = base + rng.integers(0, max(span // int(rng.integers(1, 20)), 1), n_r, dtype=np.int64)
+    nl = (rng.random(n_l) < 0.03) if seed % 3 == 0 else None
+    nr = (rng.random(n_r) < 0.03) if seed % 3 == 1 else None
+    ek, ec, _, ej = orc.join_group_count(kl, nl, kr, nr)
+    k, c, j = dev.join_group_count_unordered(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    assert j == ej and k.numel() == len(ek)
+    assert dict(zip(_np(k).tolist(), _np(c).tolist())) == dict(zip(ek.tolist(), ec.tolist())), (seed, kbits, n_l, n_r)
+    got = dev.group_count_keys(dev.to_dev(kr), None)
+    if got is not None:
+        vals, cnt = np.unique(kr, return_counts=True)
+        assert dict(zip(_np(got[0]).tolist(), _np(got[1]).tolist())) == dict(zip(vals.tolist(), cnt.tolist())), (seed, kbits)
