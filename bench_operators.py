@@ -88,7 +88,10 @@ def main():
         # the projection as the executor plans it (mdb_exec.c, projection pass 1): B's join key holds A's value in every joined
         # tuple, so both key columns of SELECT * are ONE gather of A's column through the left row ids (ascending: near-sequential
         # reads); the payload columns are gathered through their own row ids; one launch
-        dev.gather_cols([(a_id, None, l), (a_f, None, l), (b_f, None, r)], j)
+        # ... and when every left row found exactly one partner (mdb_dev_last_pairs_identity: the primary-key join) the left row ids
+        # are 0, 1, 2 ...: A's columns are read as they stand
+        lid = None if dev.last_pairs_identity() else l
+        dev.gather_cols([(a_id, None, lid), (a_f, None, lid), (b_f, None, r)], j)
         return j
     ms, kern, j = timed(dev, join_payload, reps=3, warmup=1)
     algo = 8 * 2 * n2 + 8 * 2 * n2 + 8 * 4 * j      # keys + payload columns read once, 4 result columns written

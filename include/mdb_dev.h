@@ -80,6 +80,10 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * off; a key with 2^16 or more rows sends the operator back to two levels); bit 10 = several right tables were counted in one
  * pass (mdb_dev_join_group_count_multi did not chain two-table operators). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
+/* 1 when the last mdb_dev_join_pairs() matched EVERY left row with exactly one right row (unique right keys, no left row
+ * without a partner - the primary-key join of BASELINE configs[1]): out_l is then 0, 1, 2 ... and the left table's columns
+ * of the joined stream are its columns as they stand - a caller need not gather them through out_l. */
+int mdb_dev_last_pairs_identity(mdb_dev_ctx *ctx);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory

@@ -90,6 +90,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
+	int last_pairs_identity;	/* the last mdb_dev_join_pairs: every left row joined exactly one right row - its left vector is 0, 1, 2 ... */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	bool guess_remembered;		/* the last narrow-form decision came from the memo, not from a sample of the data */

@@ -178,6 +178,11 @@ extern "C" int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx)
 	return ctx->last_narrow;
 }
 
+extern "C" int mdb_dev_last_pairs_identity(mdb_dev_ctx *ctx)
+{
+	return ctx ? ctx->last_pairs_identity : 0;
+}
+
 extern "C" int mdb_dev_last_join_filter(mdb_dev_ctx *ctx)
 {
 	return ctx->last_semijoin;

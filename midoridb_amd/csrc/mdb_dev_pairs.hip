@@ -1027,6 +1027,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 {
 	*out_l = *out_r = NULL;
 	*out_count = 0;
+	ctx->last_pairs_identity = 0;
 	if (n_l == 0 || n_r == 0)
 		return MIDORIDB_OK;
 	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
@@ -1048,10 +1049,12 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 			right_dups = left_dups = false;
 			ctx->pu_dup_keys = ctx->pu_dupl_keys = NULL;
 		}
+		bool right_unique = false;
 		if (!right_dups) {
 			urc = join_pairs_unique_auto(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &ul, &ur, &uj);
 			if (urc < 0)
 				return urc;
+			right_unique = urc == 0;
 			if (urc == 3) {
 				ctx->pu_dup_keys = keys_r;
 				ctx->pu_dup_n = n_r;
@@ -1072,6 +1075,8 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 			*out_l = ul;
 			*out_r = ur;
 			*out_count = uj;
+			/* (unique right keys: a left row has at most one partner; as many pairs as left rows, in left-row order: 0, 1, 2 ...) */
+			ctx->last_pairs_identity = right_unique && uj == n_l;
 			return MIDORIDB_OK;
 		}
 		/* duplicates on both sides, or a table / region overflowed: general path below */

@@ -1373,8 +1373,11 @@ static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *
 			return dev_fail(x, "re-mapping row ids");
 		pr = mapped;
 	}
-	/* compose the stream: earlier tables through pl, the new table = pr */
-	if ((rc = stream_select(x, t, pl, J)))
+	/* compose the stream: earlier tables through pl, the new table = pr - unless pl is 0, 1, 2 ... (every row of the stream joined
+	 * exactly one right row: a primary-key join): the earlier tables' row ids then stand as they are, nothing is gathered */
+	if (key >= 0 && J == x->n && pl && mdb_dev_last_pairs_identity(x->dev))
+		x->n = J;
+	else if ((rc = stream_select(x, t, pl, J)))
 		return rc;
 	x->rid[t] = pr;
 	x->joined_rows = J;

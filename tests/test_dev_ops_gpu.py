@@ -2141,3 +2141,21 @@ def test_any_order_operators_random_shapes(dev, seed):
     if got is not None:
         vals, cnt = np.unique(kr, return_counts=True)
         assert dict(zip(_np(got[0]).tolist(), _np(got[1]).tolist())) == dict(zip(vals.tolist(), cnt.tolist())), (seed, kbits)
+
+
+def test_join_pairs_reports_an_identity_left_vector(dev):
+    """mdb_dev_last_pairs_identity: unique right keys and a partner for every left row (the primary-key join of BASELINE configs[1])
+    -> the left vector is 0, 1, 2 ... and says so; one left row without a partner, or a right key twice, and it does not."""
+    rng = np.random.default_rng(5)
+    n = 700_000
+    a = rng.permutation(n).astype(np.int64) + 10
+    b = rng.permutation(n).astype(np.int64) + 10
+    l, r = dev.join_pairs(dev.to_dev(a), None, dev.to_dev(b), None)
+    assert dev.last_pairs_identity() and np.array_equal(_np(l).view(np.uint32), np.arange(n, dtype=np.uint32))
+    a2 = a.copy()
+    a2[123] = -5                                        # a left row without a partner
+    l, r = dev.join_pairs(dev.to_dev(a2), None, dev.to_dev(b), None)
+    assert not dev.last_pairs_identity() and l.numel() == n - 1
+    b2 = np.concatenate([b, b[:1]])                     # a right key twice: n + 1 pairs
+    l, r = dev.join_pairs(dev.to_dev(a), None, dev.to_dev(b2), None)
+    assert not dev.last_pairs_identity() and l.numel() == n + 1
