@@ -134,6 +134,16 @@ int mdb_dist_join_group_count_alloc(mdb_dist *d, const int64_t *keys_l, const ui
 int mdb_dist_join_group_count_multi_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
 					  const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r, int64_t **out_key,
 					  int64_t **out_count, uint64_t *out_groups, uint64_t *out_joined);
+
+/* GROUP BY key + COUNT(*) of ONE sharded key column (reference src/engine/executor_select.c:1526-1588 over rows spread across the
+ * ranks) as (key, COUNT) pairs in unspecified order, every key on exactly one rank: each rank's single partition pass writes 2- or
+ * 4-byte words into first-level regions, the regions travel (no rows, no row ids), the receiver counts per leaf slot.  For
+ * statements that select nothing but the group key and COUNT(*) and ask for no order.  Collective.  Outputs allocated by the call
+ * (mdb_dev_free).  Returns 1 - the same on every rank - when it does not serve the column (global key range unknown - see
+ * mdb_dist_set_key_ranges, whose RIGHT range is the column's here - or wider than 2^30 values, a NULL bitmap passed, skew): the
+ * caller then exchanges the rows (mdb_dist_shuffle_rows) and groups locally. */
+int mdb_dist_group_count_keys_alloc(mdb_dist *d, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t **out_key,
+				    int64_t **out_count, uint64_t *out_groups);
 /* rows of L this rank received in the last call (what `cap` has to cover), 0 before the first */
 uint64_t mdb_dist_last_received_left(const mdb_dist *d);
 

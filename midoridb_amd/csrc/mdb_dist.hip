@@ -630,7 +630,7 @@ static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_
  * Returns 0 = done, 1 = not served / fell back (agreed by all ranks), < 0 = error. */
 static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, const uint64_t *const *nulls, const uint64_t *ns, const int64_t glo[2],
 			   const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p, int64_t **out_count_p, uint64_t cap,
-			   uint64_t *out_groups, uint64_t *out_joined)
+			   uint64_t *out_groups, uint64_t *out_joined, bool right_only = false /* GROUP BY of table [1] alone: table [0] has no rows and does not travel */)
 {
 	/* tables: [0] the left one, [1] the right one, [2 ...] further right tables joined on the same key */
 	mdb_dev_ctx *ctx = d->ctx;
@@ -653,7 +653,7 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
 	uint64_t n_max[MDB_SHARD_MAX_TABS] = { 0, 0, 0, 0 }, cap_min = ~0ull, nl_sum = 0;
 	for (int p = 0; p < W; p++) {
-		nl_sum += recvv[NC * p];
+		nl_sum += recvv[NC * p + (right_only ? 1 : 0)];
 		for (int x = 0; x < ntab; x++)
 			n_max[x] = recvv[NC * p + x] > n_max[x] ? recvv[NC * p + x] : n_max[x];
 		cap_min = recvv[NC * p + MDB_SHARD_MAX_TABS] < cap_min ? recvv[NC * p + MDB_SHARD_MAX_TABS] : cap_min;
@@ -661,8 +661,9 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	mdb_shard_plan plan;
 	if (mdb_shard_plan_make((uint32_t)W, (uint32_t)d->rank, (uint32_t)ntab, n_max, glo[0], ghi[0], glo[1], ghi[1], &plan))
 		return 1;
+	plan.right_only = right_only;
 	/* the groups of a rank: at most the left rows it can receive, at most the key values that hash to it */
-	const uint64_t recv_bound_l = plan.block_words[0] * (uint64_t)W;
+	const uint64_t recv_bound_l = plan.block_words[right_only ? 1 : 0] * (uint64_t)W;
 	const uint64_t values = ((uint64_t)1 << plan.kbits) / (uint64_t)W;
 	uint64_t group_bound = recv_bound_l < values ? recv_bound_l : values;
 	group_bound = nl_sum < group_bound ? nl_sum : group_bound;	/* ... and never more than there are left rows at all */
@@ -702,6 +703,11 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	for (int x = 0; x < ntab; x++) {
 		const void *regions = NULL;
 		const uint32_t *cursors = NULL;
+		if (right_only && x == 0) {	/* no left table: nothing travels, every region counter reads zero */
+			DIST_HIP(d, hipMemsetAsync(rcnt[0], 0, ncur * (size_t)W * 4, ctx->stream));
+			DIST_HIP(d, hipEventRecord(d->ev_tab[0], ctx->stream));
+			continue;
+		}
 		if (!prc)
 			prc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], ns[x], &regions, &cursors);
 		if (prc)
@@ -784,6 +790,13 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	return 0;
 }
 
+/* GROUP BY key + COUNT(*) of ONE sharded column as (key, COUNT) pairs, every key on the rank its hash belongs to, in unspecified
+ * order (include/mdb_dist.h): each rank's ONE partition pass writes the 2- or 4-byte words of its keys into first-level regions,
+ * the regions travel, the receiver counts per leaf slot - no rows are exchanged, no row ids exist, nothing is ordered.
+ * 0 = done (outputs allocated by the call), 1 = not served (the global key range is unknown or spans more than 2^30 values, NULL
+ * keys, skew: every rank gets the same answer - the caller exchanges rows and groups locally), < 0 = error. */
+static int dist_group_keys_impl(mdb_dist *d, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t **out_key, int64_t **out_count,
+				uint64_t *out_groups);
 /* the outputs a call allocated do not outlive its failure */
 static int dist_join_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t **out_key, int64_t **out_count, uint32_t **out_first, int rc)
 {
@@ -1588,6 +1601,46 @@ extern "C" int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uin
  * rank joins the regions of ALL tables it received and multiplies the right tables' counts per key (mdb_dev_shard.hip).
  * Returns 0 = done (outputs allocated by the call, as mdb_dist_join_group_count_alloc), 1 = not served (the key ranges are not
  * known or do not fit, skewed keys ...: every rank gets the same answer and the caller chains two-table calls), < 0 = error. */
+static int dist_group_keys_impl(mdb_dist *d, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t **out_key, int64_t **out_count,
+				uint64_t *out_groups)
+{
+	int64_t glo[2] = { 0, 0 }, ghi[2] = { 0, 0 };
+	bool promised = false, fits32 = false;
+	if (nullbits)
+		return 1;	/* (every rank passes NULL or none does: the caller agrees on that first) */
+	if (d->wire_mode == MDB_WIRE_AUTO) {
+		const int mrc = dist_measure_ranges(d, keys, NULL, n, keys, NULL, n, glo, ghi, &fits32);
+		if (mrc)
+			return mrc;
+	} else if (d->have_ranges) {
+		glo[1] = d->promised_lo[1];
+		ghi[1] = d->promised_hi[1];
+		promised = true;
+	} else {
+		return 1;
+	}
+	glo[0] = glo[1];	/* (the absent left table's range: the right table's, nothing is pruned) */
+	ghi[0] = ghi[1];
+	const int64_t *kk[2] = { NULL, keys };
+	const uint64_t *nn[2] = { NULL, NULL };
+	const uint64_t ns[2] = { 0, n };
+	uint64_t joined = 0;
+	d->last_fused = 0;
+	return dist_join_fused(d, 2, kk, nn, ns, glo, ghi, promised, true, out_key, out_count, 0, out_groups, &joined, true);
+}
+
+extern "C" int mdb_dist_group_count_keys_alloc(mdb_dist *d, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t **out_key,
+					       int64_t **out_count, uint64_t *out_groups)
+{
+	if (!d || !out_key || !out_count || !out_groups)
+		return d ? dist_err(d, -MIDORIDB_ERROR, "group_count_keys: bad arguments") : -MIDORIDB_ERROR;
+	*out_groups = 0;
+	*out_key = NULL;
+	*out_count = NULL;
+	DIST_HIP(d, hipSetDevice(d->ctx->device));
+	return dist_group_keys_impl(d, keys, nullbits, n, out_key, out_count, out_groups);
+}
+
 extern "C" int mdb_dist_join_group_count_multi_alloc(mdb_dist *d, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int n_right,
 							     const int64_t *const *keys_r, const uint64_t *const *null_r, const uint64_t *n_r,
 							     int64_t **out_key, int64_t **out_count, uint64_t *out_groups, uint64_t *out_joined)

@@ -1945,6 +1945,43 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			bool placed = false;
 			for (int g = 0; g < s->ngroup; g++)
 				placed = placed || in_part(&x, s->group[g]);
+			if (!placed && cat->groups_any_order && s->ngroup == 1 && !x.fused && !s->select_all && !s->distinct &&
+			    s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE && s->group[0]->type != MDB_CT_VARCHAR) {
+				/* any order allowed and only the group key and COUNT(*) can be named (S4): no rows need to travel - every rank's ONE
+				 * partition pass over its key column, the first-level regions exchanged, counted where they land
+				 * (mdb_dist_group_count_keys_alloc).  Every rank must take the same way: they agree on "no NULL keys anywhere" first. */
+				uint64_t ok = s->tabs[s->group[0]->tbl_idx].t->cols[s->group[0]->col_idx].null_count == 0 ? 1u : 0u;
+				if (mdb_dist_allreduce_sum_u64(cat->dist, &ok, 1)) {
+					snprintf(err, errlen, "execution phase: %s\n", mdb_dist_last_error(cat->dist));
+					rc = -MIDORIDB_INTERNAL;
+					goto out;
+				}
+				if (ok == (uint64_t)mdb_dist_world(cat->dist)) {
+					const int64_t *kv;
+					const uint64_t *kn;
+					int64_t *gk = NULL, *gc = NULL;
+					uint64_t Gk = 0;
+					if ((rc = stream_column(&x, s->group[0], &kv, &kn)) || (rc = shard_promise_ranges(&x, s->group[0], s->group[0])))
+						goto out;
+					const int krc = mdb_dist_group_count_keys_alloc(cat->dist, kv, NULL, x.n, &gk, &gc, &Gk);
+					if (krc < 0) {
+						snprintf(err, errlen, "execution phase: sharded group count: %s\n", mdb_dist_last_error(cat->dist));
+						rc = -MIDORIDB_INTERNAL;
+						goto out;
+					}
+					if (krc == 0) {
+						if (track(&x, gk) || track(&x, gc)) {
+							rc = -MIDORIDB_NOMEM;
+							goto out;
+						}
+						x.d_fused_key = gk;
+						x.d_count = gc;
+						x.fused = true;
+						x.n = Gk;
+						goto grouped;
+					}
+				}
+			}
 			if (!placed && (rc = shard_stream(&x, s->ntabs, s->group[0], MDB_DIST_KEEP_NULL_KEYS)))
 				goto out;
 		}

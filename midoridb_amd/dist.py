@@ -40,7 +40,7 @@ DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
-    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
+    "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_group_count_keys_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
 ]
 
 
@@ -61,6 +61,7 @@ def _bind(lib):
         "mdb_dist_last_wire32": ([P], c_int),
         "mdb_dist_last_pruned": ([P], c_int),
         "mdb_dist_last_fused": ([P], c_int),
+        "mdb_dist_group_count_keys_alloc": ([P, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dist_join_group_count_multi_alloc": ([P, P, P, c_uint64, c_int, POINTER(P), POINTER(P), POINTER(c_uint64), POINTER(P), POINTER(P),
                                                    POINTER(c_uint64), POINTER(c_uint64)], c_int),
         "mdb_dist_set_key_ranges": ([P, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64)], c_int),
@@ -303,6 +304,16 @@ class DistCtx:
             return None
         self._chk(rc, "dist join_group_count_multi")
         return self._adopt(ok.value, g.value, torch.int64), self._adopt(oc.value, g.value, torch.int64), j.value
+
+    def group_count_keys(self, keys, nulls=None):
+        """GROUP BY + COUNT(*) of one sharded key column -> (keys[G], counts[G]) of the keys that live on this rank, in unspecified
+        order; None when the form does not serve the column (every rank gets None: exchange the rows and group locally)"""
+        ok, oc, g = c_void_p(), c_void_p(), c_uint64()
+        rc = self.lib.mdb_dist_group_count_keys_alloc(self.h, _ptr(keys), _ptr(nulls), keys.numel(), byref(ok), byref(oc), byref(g))
+        if rc == 1:
+            return None
+        self._chk(rc, "dist group_count_keys")
+        return self._adopt(ok.value, g.value, torch.int64), self._adopt(oc.value, g.value, torch.int64)
 
     def allreduce_sum(self, vals):
         arr = (c_uint64 * len(vals))(*[int(v) for v in vals])

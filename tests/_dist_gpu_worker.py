@@ -243,6 +243,18 @@ def sharded_sql(world, rank):
         for q in counts:
             names, rows = ex.run(sql_to_rpn(q))
             assert db.query(q).rows() == rows, q		# the global count on every rank
+        # any order allowed: GROUP BY of one table ships first-level regions of the key column instead of rows (no NULL key on any
+        # rank: f2; f1 has NULLs and keeps the row exchange) - the ranks' groups together are the oracle's, as a set
+        db.groups_any_order(True)
+        for q in ("SELECT f2, COUNT(*) FROM B GROUP BY f2;", "SELECT f1, COUNT(*) FROM A GROUP BY f1;",
+                  "SELECT f2, COUNT(*) FROM B GROUP BY f2 HAVING COUNT(*) > 17;", "SELECT COUNT(*) FROM B GROUP BY f2;"):
+            names, rows = ex.run(sql_to_rpn(q))
+            res = db.query(q)
+            assert res.names == names, q
+            parts = [None] * world
+            dist.all_gather_object(parts, res.rows())
+            assert sorted(r for p in parts for r in p) == sorted(rows), q
+        db.groups_any_order(False)
         for q, what in (("SELECT * FROM A, C;", "equi-join key"), ("SELECT f1 FROM A INNER JOIN B ON A.id_a = B.id_b LIMIT 3, 4;", "LIMIT")):
             try:
                 db.query(q)
@@ -312,7 +324,22 @@ def fused_shapes(dx, dev, world, rank):
         res = dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist()))
         assert len(res) == k.numel() and res == dict(zip(ek[mine].tolist(), ec[mine].tolist())), (n, span, nright)
         assert dx.allreduce_sum([j])[0] == int(ec.sum())
+    # GROUP BY of ONE sharded column as (key, COUNT) pairs: regions of the key column on the wire, nothing else
+    for n, span, dup in ((400_000, 50_000, 1), (700_000, 3_000_000, 2), (500_000, 90_000_000, 1)):
+        total = n * world
+        base = -123_456
+        gk = base + rng.integers(0, span, total // dup, dtype=np.int64).repeat(dup)
+        rng.shuffle(gk)
+        mine_rows = slice(rank * len(gk) // world, (rank + 1) * len(gk) // world)
+        dx.set_key_ranges((base, base + span - 1), (base, base + span - 1))
+        got = dx.group_count_keys(dev.to_dev(gk[mine_rows]))
+        assert got is not None and dx.last_fused(), (n, span)
+        vals, cnt = np.unique(gk, return_counts=True)
+        own = orc.dest_of_fused(vals, world, base, span) == rank
+        res = dict(zip(got[0].cpu().numpy().tolist(), got[1].cpu().numpy().tolist()))
+        assert len(res) == got[0].numel() and res == dict(zip(vals[own].tolist(), cnt[own].tolist())), (n, span, len(res), int(own.sum()))
     dx.set_key_ranges(None, None)
+    assert dx.group_count_keys(dev.to_dev(gk[mine_rows])) is None        # ranges unknown: not served, on every rank
     assert dx.join_group_count_multi(dev.to_dev(ga[la]), None, [(dev.to_dev(r[c]), None) for r, c in zip(rights, cuts)]) is None	# ranges unknown: not served
     # 90 % of the left rows share one key: its region overflows on the sender -> all ranks fall back, same groups
     n = 400_000
