@@ -95,6 +95,31 @@ int mdb_dist_last_pruned(const mdb_dist *d);
  * in leaf order.  MDB_DIST_FUSED=0 keeps the key-by-destination path. */
 int mdb_dist_last_fused(const mdb_dist *d);
 
+/* What the last regions-on-the-wire call planned - the shape every rank derived from the same agreed numbers (world size, the
+ * largest shard of each table, the global key ranges): which branch of the layout a workload lands on at world 2, 4 or 8 can be
+ * asserted by tests and printed by bench.py before an 8-GPU node is at hand.  Returns 1 when no such call has planned yet. */
+struct mdb_dist_plan_info {
+	uint32_t world, tables;
+	uint32_t digit_bits;		/* first-level digits on the sender: 9 (512) or 12 (4096, the wide fan-out form) */
+	uint32_t digits_per_rank;	/* 2^digit_bits / world */
+	uint32_t key_bits;		/* the key window holds 2^key_bits values */
+	uint32_t receiver_bits;		/* bits of the receiver's own partition level; 0 = digits are joined straight from the regions */
+	uint32_t leaf_bits;		/* key bits that index a leaf's LDS tables */
+	uint32_t word_bytes;		/* bytes per row on the wire: 2 or 4 */
+	uint32_t completed;		/* 1: the call was answered by this path (mdb_dist_last_fused) */
+	uint32_t region_words[4];	/* capacity of one first-level region, per table */
+	uint64_t block_bytes[4];	/* bytes one rank sends to ONE peer for table x (fixed-size blocks: slack included) */
+	uint64_t bytes_per_peer;	/* all tables' blocks + region counters: what crosses ONE xGMI link per direction and call */
+};
+int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *out);
+/* Where a regions-on-the-wire call spends its time on this rank (measurement aid: HIP events on the operator's and the transfer
+ * stream; off by default).  ms[0] = first level of every table (sender), ms[1] = time the receiver's first kernel waited for
+ * the last block to arrive after the sender's passes were done (the wire, as far as it is not hidden), ms[2] = receiver (region
+ * descriptors, own level if any, leaves), ms[3] = the whole device pipeline. */
+#define MDB_DIST_PHASES 4
+int mdb_dist_set_phase_timing(mdb_dist *d, int on);
+int mdb_dist_last_phases(const mdb_dist *d, double *ms /* [MDB_DIST_PHASES] */);
+
 /* ------------------------------------------------------------------ the sharded north-star operator
  *
  * SELECT l.key, COUNT(*) FROM L INNER JOIN R ON l.key = r.key GROUP BY l.key over tables whose rows are spread

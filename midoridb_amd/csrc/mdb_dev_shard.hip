@@ -468,7 +468,10 @@ __global__ void k_shard_regions(const uint32_t *__restrict__ cnt, uint32_t world
 		return;
 	const uint32_t dl = r / (world * nsub), q = (r / nsub) % world, s = r % nsub;
 	uint32_t c = cnt[(size_t)q * D * nsub + (size_t)s * D + d0 + dl];	/* (the sender's cursors are laid out sub-major) */
-	if (c > cap) {
+	if (c == 0xFFFFFFFFu) {
+		mdb_raise(status, 16384u);	/* rank q's first level failed: it sent counters that say so instead of counts (mdb_dist.hip) */
+		c = 0;
+	} else if (c > cap) {
 		mdb_raise(status, 2u);		/* the sender's region overflowed (it said so on its own rank as well) */
 		c = cap;
 	}

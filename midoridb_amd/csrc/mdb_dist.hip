@@ -41,6 +41,13 @@ struct mdb_dist {
 	/* row shuffles (mdb_dist_shuffle_rows): buffers the posted transfers still read - released by mdb_dist_wait_transfers() */
 	hipEvent_t ev_sh;
 	hipEvent_t ev_tab[MDB_SHARD_MAX_TABS];	/* the sharded operator: table x has arrived */
+	/* what the last regions-on-the-wire call planned (mdb_dist_last_plan) and, on request, where its time went (mdb_dist_last_phases) */
+	mdb_shard_plan last_plan;
+	bool have_plan;
+	bool time_phases;
+	hipEvent_t ev_t0, ev_t1, ev_part[MDB_SHARD_MAX_TABS], ev_arr[MDB_SHARD_MAX_TABS];	/* (created on first use, with timing) */
+	double phase_ms[MDB_DIST_PHASES];
+	uint64_t seq;			/* collective calls made through this handle: every rank's must agree (checked with the counts) */
 	bool sh_posted;
 	void *pend[SH_MAX_PENDING];
 	int npend;
@@ -69,7 +76,10 @@ static int dist_err(mdb_dist *d, int code, const char *fmt, ...)
 /* ------------------------------------------------------------------ RCCL transport */
 
 struct rccl_transport {
-	ncclComm_t data, small;		/* key transfers / counts + reductions */
+	ncclComm_t data, small;		/* key transfers / counts + reductions (always on small_stream, host-synchronous) */
+	ncclComm_t status;		/* the sharded operator's status all-reduce, always on the context's stream: a communicator of its own,
+					 * so that no communicator is ever used on two streams (operations of one communicator must be issued in
+					 * the same order on every rank; with one stream per communicator program order is that order) */
 	int world, rank, device;
 	hipStream_t small_stream;
 	uint64_t *d_buf, *h_buf;	/* 2 x world x 8 counters: device staging + pinned mirror */
@@ -145,6 +155,8 @@ static void rt_destroy(void *self)
 		ncclCommDestroy(rt->data);
 	if (rt->small)
 		ncclCommDestroy(rt->small);
+	if (rt->status)
+		ncclCommDestroy(rt->status);
 	if (rt->small_stream)
 		(void)hipStreamDestroy(rt->small_stream);
 	if (rt->d_buf)
@@ -352,8 +364,6 @@ extern "C" int mdb_dist_init(mdb_dev_ctx *ctx, int world, int rank, const void *
 	d->own_transport = true;
 	ncclUniqueId uid;
 	memcpy(&uid, id, sizeof(uid));
-	/* the second communicator is split off the first with an id of its own, agreed on through the first:
-	 * rank 0 creates it and every rank learns it from an all-reduce (the other ranks contribute zeros) */
 	ncclResult_t r = ncclCommInitRank(&rt->data, world, uid, rank);
 	if (r != ncclSuccess) {
 		snprintf(ctx->err, sizeof(ctx->err), "ncclCommInitRank: %s", ncclGetErrorString(r));
@@ -367,7 +377,10 @@ extern "C" int mdb_dist_init(mdb_dev_ctx *ctx, int world, int rank, const void *
 		mdb_dist_destroy(d);
 		return -MIDORIDB_INTERNAL;
 	}
-	{
+	/* the further communicators each get an id of their own, agreed on through the first: rank 0 creates it and every rank
+	 * learns it from an all-reduce (the other ranks contribute zeros) */
+	ncclComm_t *further[2] = { &rt->small, &rt->status };
+	for (int c = 0; c < 2; c++) {
 		ncclUniqueId uid2;
 		memset(&uid2, 0, sizeof(uid2));
 		if (rank == 0 && ncclGetUniqueId(&uid2) != ncclSuccess) {
@@ -387,10 +400,10 @@ extern "C" int mdb_dist_init(mdb_dev_ctx *ctx, int world, int rank, const void *
 			r = ncclSystemError;
 		if (r == ncclSuccess) {
 			memcpy(&uid2, h, sizeof(uid2));
-			r = ncclCommInitRank(&rt->small, world, uid2, rank);
+			r = ncclCommInitRank(further[c], world, uid2, rank);
 		}
 		if (r != ncclSuccess) {
-			snprintf(ctx->err, sizeof(ctx->err), "second communicator: %s", ncclGetErrorString(r));
+			snprintf(ctx->err, sizeof(ctx->err), "communicator %d: %s", c + 2, ncclGetErrorString(r));
 			mdb_dist_destroy(d);
 			return -MIDORIDB_INTERNAL;
 		}
@@ -438,9 +451,18 @@ extern "C" void mdb_dist_destroy(mdb_dist *d)
 		(void)hipEventDestroy(d->ev_b);
 	if (d->ev_sh)
 		(void)hipEventDestroy(d->ev_sh);
-	for (int x = 0; x < MDB_SHARD_MAX_TABS; x++)
+	for (int x = 0; x < MDB_SHARD_MAX_TABS; x++) {
 		if (d->ev_tab[x])
 			(void)hipEventDestroy(d->ev_tab[x]);
+		if (d->ev_part[x])
+			(void)hipEventDestroy(d->ev_part[x]);
+		if (d->ev_arr[x])
+			(void)hipEventDestroy(d->ev_arr[x]);
+	}
+	if (d->ev_t0)
+		(void)hipEventDestroy(d->ev_t0);
+	if (d->ev_t1)
+		(void)hipEventDestroy(d->ev_t1);
 	for (int i = 0; i < d->npend; i++)
 		(void)mdb_dev_free(d->ctx, d->pend[i]);
 	if (d->comm_stream)
@@ -454,6 +476,57 @@ extern "C" const char *mdb_dist_last_error(const mdb_dist *d) { return d ? d->er
 extern "C" int mdb_dist_last_wire32(const mdb_dist *d) { return d ? d->last_wire32 : 0; }
 extern "C" int mdb_dist_last_pruned(const mdb_dist *d) { return d ? d->last_pruned : 0; }
 extern "C" int mdb_dist_last_fused(const mdb_dist *d) { return d ? d->last_fused : 0; }
+
+extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *out)
+{
+	if (!d || !out)
+		return -MIDORIDB_ERROR;
+	memset(out, 0, sizeof(*out));
+	if (!d->have_plan)
+		return 1;
+	const mdb_shard_plan *p = &d->last_plan;
+	out->world = p->world;
+	out->tables = p->ntab;
+	out->digit_bits = p->dbits;
+	out->digits_per_rank = p->Dp;
+	out->key_bits = p->kbits;
+	out->receiver_bits = (uint32_t)p->b2;
+	out->leaf_bits = p->rem;
+	out->word_bytes = p->wbytes;
+	out->completed = d->last_fused ? 1u : 0u;
+	for (uint32_t x = 0; x < p->ntab; x++) {
+		out->region_words[x] = p->cap[x];
+		out->block_bytes[x] = p->block_words[x] * p->wbytes;
+		if (!(p->right_only && x == 0))
+			out->bytes_per_peer += p->block_words[x] * p->wbytes + (uint64_t)p->D * p->nsub * 4;
+	}
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_set_phase_timing(mdb_dist *d, int on)
+{
+	if (!d)
+		return -MIDORIDB_ERROR;
+	if (on && !d->ev_t0) {
+		DIST_HIP(d, hipSetDevice(d->ctx->device));
+		DIST_HIP(d, hipEventCreate(&d->ev_t0));
+		DIST_HIP(d, hipEventCreate(&d->ev_t1));
+		for (int x = 0; x < MDB_SHARD_MAX_TABS; x++) {
+			DIST_HIP(d, hipEventCreate(&d->ev_part[x]));
+			DIST_HIP(d, hipEventCreate(&d->ev_arr[x]));
+		}
+	}
+	d->time_phases = on != 0;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_last_phases(const mdb_dist *d, double *ms)
+{
+	if (!d || !ms)
+		return -MIDORIDB_ERROR;
+	memcpy(ms, d->phase_ms, sizeof(d->phase_ms));
+	return MIDORIDB_OK;
+}
 
 extern "C" int mdb_dist_set_key_ranges(mdb_dist *d, const int64_t left[2], const int64_t right[2])
 {
@@ -628,6 +701,16 @@ static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_
  * key-by-destination path needs four plus two read-backs.  Needs the two tables' global key ranges (promised, or measured
  * by MDB_WIRE_AUTO) and a right-table range of at most 2^30 values; MDB_DIST_FUSED=0 switches it off.
  * Returns 0 = done, 1 = not served / fell back (agreed by all ranks), < 0 = error. */
+/* MDB_DIST_FAULT="<step>:<rank>" (the fault-injection mode of the test suite): this rank behaves as if `step` had failed */
+static bool dist_fault_injected(const mdb_dist *d, const char *step)
+{
+	const char *e = getenv("MDB_DIST_FAULT");
+	const size_t l = strlen(step);
+	return e && strncmp(e, step, l) == 0 && e[l] == ':' && atoi(e + l + 1) == d->rank;
+}
+
+#define DIST_PEER_FAILED 16384u	/* status bit: a peer's region counters say that its first level failed (k_shard_regions) */
+
 static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, const uint64_t *const *nulls, const uint64_t *ns, const int64_t glo[2],
 			   const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p, int64_t **out_count_p, uint64_t cap,
 			   uint64_t *out_groups, uint64_t *out_joined, bool right_only = false /* GROUP BY of table [1] alone: table [0] has no rows and does not travel */)
@@ -639,20 +722,29 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		return 1;
 	if (ntab < 2 || ntab > MDB_SHARD_MAX_TABS)
 		return 1;
-	/* ---- every rank's row counts (region capacities are sized by the largest), and whether its output buffers can take the
-	 *      groups: a decision every rank takes from the same numbers */
-	const int NC = MDB_SHARD_MAX_TABS + 1;
-	uint64_t sendv[(MDB_SHARD_MAX_TABS + 1) << MDB_MAX_RADIX_BITS], recvv[(MDB_SHARD_MAX_TABS + 1) << MDB_MAX_RADIX_BITS];
+	/* ---- every rank's row counts (region capacities are sized by the largest), whether its output buffers can take the
+	 *      groups - a decision every rank takes from the same numbers - and WHICH call this is: the exchange rests on every rank
+	 *      issuing the same collectives in the same order, so the ranks compare (kind of call, tables, calls made so far) before
+	 *      anything is posted; ranks that disagree all return an error instead of pairing transfers of different calls */
+	const int NC = MDB_SHARD_MAX_TABS + 2;
+	const uint64_t guard = (1ull << 56) | ((uint64_t)ntab << 48) | ((uint64_t)(right_only ? 1 : 0) << 47) | (++d->seq & 0xFFFFFFFFFFull);
+	uint64_t sendv[(MDB_SHARD_MAX_TABS + 2) << MDB_MAX_RADIX_BITS], recvv[(MDB_SHARD_MAX_TABS + 2) << MDB_MAX_RADIX_BITS];
 	for (int p = 0; p < W; p++) {
 		for (int x = 0; x < MDB_SHARD_MAX_TABS; x++)
 			sendv[NC * p + x] = x < ntab ? ns[x] : 0;
 		sendv[NC * p + MDB_SHARD_MAX_TABS] = alloc_out ? (1ull << 62) : cap;	/* (a transport's counters need not survive values beyond 2^63) */
+		sendv[NC * p + MDB_SHARD_MAX_TABS + 1] = guard;
 	}
 	int rc = d->t.counts(d->t.self, sendv, recvv, NC);
 	if (rc)
 		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
 	uint64_t n_max[MDB_SHARD_MAX_TABS] = { 0, 0, 0, 0 }, cap_min = ~0ull, nl_sum = 0;
 	for (int p = 0; p < W; p++) {
+		if (recvv[NC * p + MDB_SHARD_MAX_TABS + 1] != guard)
+			return dist_err(d, -MIDORIDB_ERROR, "the ranks are not in the same collective call: rank %d is in call %llu (kind %llu), rank %d in call %llu "
+					"(kind %llu); nothing was exchanged", p, (unsigned long long)(recvv[NC * p + MDB_SHARD_MAX_TABS + 1] & 0xFFFFFFFFFFull),
+					(unsigned long long)(recvv[NC * p + MDB_SHARD_MAX_TABS + 1] >> 47), d->rank,
+					(unsigned long long)(guard & 0xFFFFFFFFFFull), (unsigned long long)(guard >> 47));
 		nl_sum += recvv[NC * p + (right_only ? 1 : 0)];
 		for (int x = 0; x < ntab; x++)
 			n_max[x] = recvv[NC * p + x] > n_max[x] ? recvv[NC * p + x] : n_max[x];
@@ -662,6 +754,9 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	if (mdb_shard_plan_make((uint32_t)W, (uint32_t)d->rank, (uint32_t)ntab, n_max, glo[0], ghi[0], glo[1], ghi[1], &plan))
 		return 1;
 	plan.right_only = right_only;
+	d->last_plan = plan;
+	d->have_plan = true;
+	memset(d->phase_ms, 0, sizeof(d->phase_ms));
 	/* the groups of a rank: at most the left rows it can receive, at most the key values that hash to it */
 	const uint64_t recv_bound_l = plan.block_words[right_only ? 1 : 0] * (uint64_t)W;
 	const uint64_t values = ((uint64_t)1 << plan.kbits) / (uint64_t)W;
@@ -672,7 +767,7 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	int64_t *out_key = alloc_out ? NULL : *out_key_p, *out_count = alloc_out ? NULL : *out_count_p;
 	if (alloc_out) {
 		/* (an allocation that fails on one rank only would leave the others in the all-to-all: sized by the agreed bound, it
-		 * fails everywhere or nowhere on equal GPUs; the status exchange at the end still catches the rest) */
+		 * fails everywhere or nowhere on equal GPUs; what fails later - a rank's first level - is told to the peers, below) */
 		if (mdb_dev_alloc(ctx, (group_bound ? group_bound : 1) * 8, (void **)&out_key) ||
 		    mdb_dev_alloc(ctx, (group_bound ? group_bound : 1) * 8, (void **)&out_count)) {
 			(void)mdb_dev_free(ctx, out_key);
@@ -688,6 +783,9 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "%s", mdb_dev_last_error(ctx)));
 	DIST_HIP(d, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	const bool timed = d->time_phases && d->ev_t0;
+	if (timed)
+		DIST_HIP(d, hipEventRecord(d->ev_t0, ctx->stream));
 	void *recv[MDB_SHARD_MAX_TABS];
 	uint32_t *rcnt[MDB_SHARD_MAX_TABS];
 	for (int x = 0; x < ntab; x++) {
@@ -696,10 +794,17 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		if (!recv[x] || !rcnt[x])
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "%s", mdb_dev_last_error(ctx)));
 	}
-	/* ---- each table: ONE partition pass, then its blocks and its region counters travel (fixed sizes: nothing to wait for) */
+	/* ---- each table: ONE partition pass, then its blocks and its region counters travel (fixed sizes: nothing to wait for).
+	 *      A rank whose first level fails (a launch or sizing error, not a flag on the device) still posts what its peers are
+	 *      waiting for - blocks nobody will read and region counters of 0xFFFFFFFF, which every receiver's descriptor kernel reads
+	 *      as "this peer failed" - so that every rank reaches the status exchange and returns an error; none is left in the
+	 *      all-to-all */
 	size_t bc[1 << MDB_MAX_RADIX_BITS], bd[1 << MDB_MAX_RADIX_BITS], cc[1 << MDB_MAX_RADIX_BITS], cd0[1 << MDB_MAX_RADIX_BITS],
 		cdr[1 << MDB_MAX_RADIX_BITS];
 	int prc = MIDORIDB_OK;
+	char perr[256] = "";
+	void *fail_blocks = NULL;
+	uint32_t *fail_counters = NULL;
 	for (int x = 0; x < ntab; x++) {
 		const void *regions = NULL;
 		const uint32_t *cursors = NULL;
@@ -708,10 +813,30 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 			DIST_HIP(d, hipEventRecord(d->ev_tab[0], ctx->stream));
 			continue;
 		}
-		if (!prc)
-			prc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], ns[x], &regions, &cursors);
-		if (prc)
-			break;
+		if (!prc) {
+			if (dist_fault_injected(d, "first_level"))
+				prc = mdb_set_err(ctx, -MIDORIDB_INTERNAL, "fault injected into the first level of table %d (MDB_DIST_FAULT)", x);
+			else
+				prc = mdb_shard_partition(ctx, &plan, x, keys[x], nulls[x], ns[x], &regions, &cursors);
+			if (prc)
+				snprintf(perr, sizeof(perr), "%s", mdb_dev_last_error(ctx));
+		}
+		if (prc) {
+			if (!fail_blocks) {
+				size_t words = 0;
+				for (int y = 0; y < ntab; y++)
+					words = plan.block_words[y] > words ? plan.block_words[y] : words;
+				if (mdb_dev_alloc(ctx, words * (size_t)W * wb + 64, &fail_blocks) || mdb_dev_alloc(ctx, ncur * 4, (void **)&fail_counters) ||
+				    hipMemsetAsync(fail_counters, 0xFF, ncur * 4, ctx->stream) != hipSuccess) {
+					(void)mdb_dev_free(ctx, fail_blocks);
+					(void)mdb_dev_free(ctx, fail_counters);
+					/* (nothing left to tell the peers with: fatal for the communicator) */
+					return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded first level: %s (and the peers could not be told)", perr));
+				}
+			}
+			regions = fail_blocks;
+			cursors = fail_counters;
+		}
 		for (int p = 0; p < W; p++) {
 			bc[p] = (size_t)plan.block_words[x] * wb;
 			bd[p] = (size_t)p * plan.block_words[x] * wb;
@@ -720,6 +845,8 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 			cdr[p] = (size_t)p * ncur;
 		}
 		DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
+		if (timed)
+			DIST_HIP(d, hipEventRecord(d->ev_part[x], ctx->stream));
 		DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
 		rc = d->t.alltoallv(d->t.self, regions, bc, bd, recv[x], bc, bd, 1, d->comm_stream);
 		if (!rc)
@@ -727,18 +854,21 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		if (rc)
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
 		DIST_HIP(d, hipEventRecord(d->ev_tab[x], d->comm_stream));
+		if (timed)
+			DIST_HIP(d, hipEventRecord(d->ev_arr[x], d->comm_stream));
 	}
-	/* (a rank whose partition call failed outright - not a flag on the device, a launch or sizing error - cannot post its
-	 * transfers; its peers' receives for this call would then hang, so such a failure is fatal for the communicator and
-	 * reported as such) */
-	if (prc)
-		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded first level: %s", mdb_dev_last_error(ctx)));
 	/* (the receiver waits for a table right before the first kernel that reads it: its own level over the left table runs while
 	 * the right table is still on the wire) */
 	void *arrived[MDB_SHARD_MAX_TABS] = { d->ev_tab[0], d->ev_tab[1], d->ev_tab[2], d->ev_tab[3] };
 	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, out_count, cap, arrived);
-	if (rc)
-		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "sharded join: %s", mdb_dev_last_error(ctx)));
+	if (rc && !prc) {
+		/* (the same holds for the receiver's launches: the peers are told through the status exchange) */
+		prc = rc;
+		snprintf(perr, sizeof(perr), "%s", mdb_dev_last_error(ctx));
+		uint32_t *h1 = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 520;
+		h1[0] = DIST_PEER_FAILED;
+		DIST_HIP(d, hipMemcpyAsync(ctx->d_status, h1, 4, hipMemcpyHostToDevice, ctx->stream));
+	}
 	/* ---- G, J and the flags come back with ONE host synchronisation; what went wrong anywhere sends every rank the same way:
 	 *      over RCCL the ranks' flags are summed on the device, on the operator's own stream, before that read-back (a host
 	 *      all-reduce is a second round trip); a host's own transport is asked the usual way */
@@ -749,13 +879,20 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		rccl_transport *rt = (rccl_transport *)d->t.self;
 		uint64_t *dflags = reinterpret_cast<uint64_t *>(ctx->d_status + 32);	/* (three 8-byte words beyond what the operators use) */
 		hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status, dflags);
-		ncclResult_t nr = ncclAllReduce(dflags, dflags, 3, ncclUint64, ncclSum, rt->small, ctx->stream);
+		ncclResult_t nr = ncclAllReduce(dflags, dflags, 3, ncclUint64, ncclSum, rt->status, ctx->stream);
 		if (nr != ncclSuccess)
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "status all-reduce: %s", ncclGetErrorString(nr)));
 		reduced_on_device = true;
 	}
+	if (timed)
+		DIST_HIP(d, hipEventRecord(d->ev_t1, ctx->stream));
 	DIST_HIP(d, hipMemcpyAsync(h, ctx->d_status, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	DIST_HIP(d, hipStreamSynchronize(ctx->stream));
+	if (fail_blocks) {
+		DIST_HIP(d, hipStreamSynchronize(d->comm_stream));
+		(void)mdb_dev_free(ctx, fail_blocks);
+		(void)mdb_dev_free(ctx, fail_counters);
+	}
 	const uint32_t flags = h[0];
 	const uint64_t G = h[1], J = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
 	if (reduced_on_device) {
@@ -763,13 +900,34 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	} else {
 		st[0] = (flags & (2u | 2048u)) ? 1u : 0u;
 		st[1] = (flags & 128u) ? 1u : 0u;
-		st[2] = (flags & ~(2u | 128u | 2048u)) ? 1u : 0u;
+		st[2] = ((flags & ~(2u | 128u | 2048u)) || prc) ? 1u : 0u;
 		rc = d->t.allreduce_sum_u64(d->t.self, st, 3);
 	}
+	if (timed) {
+		/* (events of two streams share one clock) */
+		float first = 0.f, arr_last = 0.f, total = 0.f, v = 0.f;
+		const int x_first = right_only ? 1 : 0;
+		for (int x = x_first; x < ntab; x++) {
+			if (hipEventElapsedTime(&v, d->ev_t0, d->ev_part[x]) == hipSuccess && v > first)
+				first = v;
+			if (hipStreamSynchronize(d->comm_stream) == hipSuccess && hipEventElapsedTime(&v, d->ev_t0, d->ev_arr[x]) == hipSuccess && v > arr_last)
+				arr_last = v;
+		}
+		(void)hipEventElapsedTime(&total, d->ev_t0, d->ev_t1);
+		d->phase_ms[0] = first;
+		d->phase_ms[1] = arr_last > first ? arr_last - first : 0.0;
+		d->phase_ms[2] = total - (arr_last > first ? arr_last : first);
+		d->phase_ms[3] = total;
+	}
+	if (prc)
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, prc, "sharded operator failed on this rank (the peers have been told): %s", perr));
 	if (rc)
 		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, rc, "status exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d)));
-	if (st[2])
-		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "sharded join: group output overflow (status %u on this rank)", flags));
+	if (st[2]) {
+		if (flags & DIST_PEER_FAILED)
+			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_ERROR, "sharded join: a peer failed in its first partition level (its own message says why); no result"));
+		return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_INTERNAL, "sharded join: failed on %llu rank(s) (status %u on this rank)", (unsigned long long)st[2], flags));
+	}
 	if (st[1]) {
 		if (promised)
 			return fused_fail(ctx, alloc_out, out_key, out_count, dist_err(d, -MIDORIDB_ERROR, "partition_by_dest: a key lies outside the range [%lld, %lld] promised for its column",

@@ -876,6 +876,13 @@ static int shard_promise_ranges(struct exec *x, const struct mdb_expr *fl, const
 	struct mdb_table *tabs[2] = { x->s->tabs[fl->tbl_idx].t, x->s->tabs[fr->tbl_idx].t };
 	uint64_t mine[4], all[4 * 512];
 	const int W = mdb_dist_world(x->cat->dist);
+	/* a promise an earlier step of this statement made is about OTHER columns: forgotten before anything else, so that a return
+	 * without a new promise (below) leaves the handle measuring by itself instead of holding ranges that are not these columns' */
+	if (x->promised) {
+		(void)mdb_dist_set_key_ranges(x->cat->dist, NULL, NULL);
+		(void)mdb_dist_set_wire(x->cat->dist, MDB_WIRE_AUTO);
+		x->promised = false;
+	}
 	if (W > 512)
 		return MIDORIDB_OK;
 	for (int i = 0; i < 2; i++) {
@@ -1949,20 +1956,26 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			    s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE && s->group[0]->type != MDB_CT_VARCHAR) {
 				/* any order allowed and only the group key and COUNT(*) can be named (S4): no rows need to travel - every rank's ONE
 				 * partition pass over its key column, the first-level regions exchanged, counted where they land
-				 * (mdb_dist_group_count_keys_alloc).  Every rank must take the same way: they agree on "no NULL keys anywhere" first. */
-				uint64_t ok = s->tabs[s->group[0]->tbl_idx].t->cols[s->group[0]->col_idx].null_count == 0 ? 1u : 0u;
+				 * (mdb_dist_group_count_keys_alloc).  Every rank must take the same way: they agree on "no NULL keys anywhere" first.
+				 * The decision is taken from the STREAM's key column (its NULL bitmap as it is after joins and exchanges: a shadow table
+				 * that arrived over the wire carries bitmaps but no NULL counts), never from catalog counters. */
+				const int64_t *kv;
+				const uint64_t *kn;
+				if ((rc = stream_column(&x, s->group[0], &kv, &kn)))
+					goto out;
+				uint64_t ok = kn == NULL ? 1u : 0u;
 				if (mdb_dist_allreduce_sum_u64(cat->dist, &ok, 1)) {
 					snprintf(err, errlen, "execution phase: %s\n", mdb_dist_last_error(cat->dist));
 					rc = -MIDORIDB_INTERNAL;
 					goto out;
 				}
 				if (ok == (uint64_t)mdb_dist_world(cat->dist)) {
-					const int64_t *kv;
-					const uint64_t *kn;
 					int64_t *gk = NULL, *gc = NULL;
 					uint64_t Gk = 0;
-					if ((rc = stream_column(&x, s->group[0], &kv, &kn)) || (rc = shard_promise_ranges(&x, s->group[0], s->group[0])))
+					if ((rc = shard_promise_ranges(&x, s->group[0], s->group[0])))
 						goto out;
+					if (!x.promised)
+						goto exchange_rows;	/* (no range to promise - an empty column somewhere: the row exchange answers) */
 					const int krc = mdb_dist_group_count_keys_alloc(cat->dist, kv, NULL, x.n, &gk, &gc, &Gk);
 					if (krc < 0) {
 						snprintf(err, errlen, "execution phase: sharded group count: %s\n", mdb_dist_last_error(cat->dist));
@@ -1982,6 +1995,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					}
 				}
 			}
+exchange_rows:
 			if (!placed && (rc = shard_stream(&x, s->ntabs, s->group[0], MDB_DIST_KEEP_NULL_KEYS)))
 				goto out;
 		}

@@ -34,13 +34,22 @@ class DistCol(Structure):
     _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p)]
 
 
+class PlanInfo(Structure):
+    """struct mdb_dist_plan_info: what the last regions-on-the-wire call planned"""
+    _fields_ = [("world", ctypes.c_uint32), ("tables", ctypes.c_uint32), ("digit_bits", ctypes.c_uint32), ("digits_per_rank", ctypes.c_uint32),
+                ("key_bits", ctypes.c_uint32), ("receiver_bits", ctypes.c_uint32), ("leaf_bits", ctypes.c_uint32), ("word_bytes", ctypes.c_uint32),
+                ("completed", ctypes.c_uint32), ("region_words", ctypes.c_uint32 * 4), ("block_bytes", c_uint64 * 4), ("bytes_per_peer", c_uint64)]
+
+
 KEEP_NULL_KEYS, NO_WAIT = 1, 2
+DIST_PHASES = 4
 
 DIST_SYMBOLS = [
     "mdb_dist_unique_id", "mdb_dist_id_via_file", "mdb_dist_init", "mdb_dist_destroy", "mdb_dist_world", "mdb_dist_rank",
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
     "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_group_count_keys_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
+    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases",
 ]
 
 
@@ -61,6 +70,9 @@ def _bind(lib):
         "mdb_dist_last_wire32": ([P], c_int),
         "mdb_dist_last_pruned": ([P], c_int),
         "mdb_dist_last_fused": ([P], c_int),
+        "mdb_dist_last_plan": ([P, POINTER(PlanInfo)], c_int),
+        "mdb_dist_set_phase_timing": ([P, c_int], c_int),
+        "mdb_dist_last_phases": ([P, POINTER(c_double)], c_int),
         "mdb_dist_group_count_keys_alloc": ([P, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dist_join_group_count_multi_alloc": ([P, P, P, c_uint64, c_int, POINTER(P), POINTER(P), POINTER(c_uint64), POINTER(P), POINTER(P),
                                                    POINTER(c_uint64), POINTER(c_uint64)], c_int),
@@ -212,6 +224,27 @@ class DistCtx:
     def last_fused(self):
         """the last join_group_count shipped first-level partition regions (mdb_dev_shard.hip) instead of keys"""
         return bool(self.lib.mdb_dist_last_fused(self.h))
+
+    def last_plan(self):
+        """-> dict of what the last regions-on-the-wire call planned (mdb_dist_last_plan), or None before the first such call"""
+        info = PlanInfo()
+        rc = self.lib.mdb_dist_last_plan(self.h, byref(info))
+        if rc == 1:
+            return None
+        self._chk(rc, "last_plan")
+        d = {k: getattr(info, k) for k, _ in PlanInfo._fields_ if k not in ("region_words", "block_bytes")}
+        d["region_words"] = list(info.region_words)[:info.tables]
+        d["block_bytes"] = list(info.block_bytes)[:info.tables]
+        return d
+
+    def set_phase_timing(self, on=True):
+        self._chk(self.lib.mdb_dist_set_phase_timing(self.h, 1 if on else 0), "set_phase_timing")
+
+    def last_phases(self):
+        """-> {first_level_ms, wire_wait_ms, receiver_ms, device_ms} of the last regions-on-the-wire call (set_phase_timing)"""
+        ms = (c_double * DIST_PHASES)()
+        self._chk(self.lib.mdb_dist_last_phases(self.h, ms), "last_phases")
+        return {"first_level_ms": ms[0], "wire_wait_ms": ms[1], "receiver_ms": ms[2], "device_ms": ms[3]}
 
     def set_key_ranges(self, left=None, right=None):
         """catalog statistics for WIRE_32 / WIRE_64 calls: the GLOBAL (smallest, largest) key of the left and right table (the same

@@ -246,8 +246,13 @@ def sharded_sql(world, rank):
         # any order allowed: GROUP BY of one table ships first-level regions of the key column instead of rows (no NULL key on any
         # rank: f2; f1 has NULLs and keeps the row exchange) - the ranks' groups together are the oracle's, as a set
         db.groups_any_order(True)
+        # ... and after a join the decision "no NULL key" comes from the exchanged stream's bitmap, not from catalog counters (the
+        # shadow tables that arrive over the wire have none): f1 carries NULLs through the join, f2 does not
         for q in ("SELECT f2, COUNT(*) FROM B GROUP BY f2;", "SELECT f1, COUNT(*) FROM A GROUP BY f1;",
-                  "SELECT f2, COUNT(*) FROM B GROUP BY f2 HAVING COUNT(*) > 17;", "SELECT COUNT(*) FROM B GROUP BY f2;"):
+                  "SELECT f2, COUNT(*) FROM B GROUP BY f2 HAVING COUNT(*) > 17;", "SELECT COUNT(*) FROM B GROUP BY f2;",
+                  "SELECT f1, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY f1;",
+                  "SELECT f2, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY f2;",
+                  "SELECT f3, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON B.f2 = C.id_c GROUP BY f3;"):
             names, rows = ex.run(sql_to_rpn(q))
             res = db.query(q)
             assert res.names == names, q

@@ -11,16 +11,39 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(mode, nproc, port):
+def _run(mode, nproc, port, worker="_dist_gpu_worker.py", timeout=1200):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), mode]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+           "--master-port", str(port), os.path.join(ROOT, "tests", worker), mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-4000:]
     return r.stdout
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_every_sharded_operator_at_world_4_and_8_on_one_gpu(world):
+    """N contexts on one device, bytes moved by the test transport: join + GROUP BY (one level with 2-byte words, the receiver's own
+    level, 4096-digit senders, a 2^30-value window = BASELINE configs[3]'s plan), three and four tables in one exchange (configs[4]),
+    GROUP BY of one column, the keys-only and the materialising join, row shuffles, skew -> fallback on every rank; each case
+    asserts which branch of mdb_shard_plan_make ran (mdb_dist_last_plan)"""
+    assert f"plans shapes world {world} ok" in _run("shapes", world, 29620 + world, "_dist_plans_worker.py", 900)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_query_execute_sharded_at_world_4_and_8_on_one_gpu(world):
+    """the statement shapes of the world-2 test and BASELINE configs[4]'s own statement (three tables, DOUBLE payload, one key,
+    GROUP BY; and its join-only form) through query_execute() in sharded mode"""
+    assert f"plans sql world {world} ok" in _run("sql", world, 29640 + world, "_dist_plans_worker.py", 900)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_a_rank_whose_first_level_fails_takes_every_rank_out_with_an_error(world):
+    """fault injection (MDB_DIST_FAULT): the failing rank posts what its peers wait for and says so in its region counters; an error
+    on every rank, nobody hangs, the next call works; ranks in different collective calls find out before anything is posted"""
+    assert f"plans fault world {world} ok" in _run("fault", world, 29660 + world, "_dist_plans_worker.py", 600)
 
 
 def test_sharded_join_group_count_over_rccl():
