@@ -43,40 +43,125 @@ METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
+
+
+def _pmc_summary(suffix):
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, f"rocprof_summary{suffix}.json")
+        try:
+            with open(path) as f:
+                return json.load(f)["kernels"], f"profiles/{rnd}/rocprof_summary{suffix}.json"
+        except Exception:
+            continue
+    return None, None
+
+
 def pmc_traffic(rocprof_names, variant="D"):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/rNN/rocprof_summary*.json: FETCH_SIZE x2 per
     the gfx950 correction + WRITE_SIZE), newest round first, or None.  `rocprof_names` = the names rocprofv3 lists the kernel's
     template instances under; they come from the library itself (mdb_dev_prof_symbols: the symbols of what was launched under the
-    profiler name), so nothing here spells a mangled name.  Counters cannot be collected from inside this process; the summary comes
-    from `bash profiles/collect.sh` on the same workload (10^8 rows, the same variant)."""
+    profiler name), so nothing here spells a mangled name; several instances are weighted by their launch counts in the profiled
+    run.  Counters cannot be collected from inside this process; the summary comes from `bash profiles/collect.sh` on the same
+    workload (10^8 rows, the same variant: suffix "" = D, "_U", "_S", "_wide", "_shuffle")."""
     suffix = "" if variant == "D" else f"_{variant}"
-    for rnd in ("r03", "r02", "r01"):
-        try:
-            with open(os.path.join(ROOT, "profiles", rnd, f"rocprof_summary{suffix}.json")) as f:
-                ks = json.load(f)["kernels"]
-            vals = [ks[n]["hbm_read_bytes"] + ks[n]["hbm_write_bytes"] for n in rocprof_names
-                    if n in ks and "hbm_read_bytes" in ks[n] and "hbm_write_bytes" in ks[n]]
-            if vals:
-                return {"bytes": sum(vals) / len(vals), "source": f"profiles/{rnd}/rocprof_summary{suffix}.json"}
-        except Exception:
+    ks, src = _pmc_summary(suffix)
+    if ks is None:
+        return None
+    num = den = 0.0
+    for n in rocprof_names:
+        d = ks.get(n)
+        if d and "hbm_read_bytes" in d and "hbm_write_bytes" in d:
+            w = float(d.get("calls", 1) or 1)
+            num += w * (d["hbm_read_bytes"] + d["hbm_write_bytes"])
+            den += w
+    return {"bytes": num / den, "source": src} if den else None
+
+
+def pmc_step_traffic(kern, variant, algo_bytes):
+    """HBM bytes ONE step moves by the PMC counters: per profiler name, bytes per launch (committed summary of the same workload) x
+    the launches per step measured live in this run; over the whole-query algorithmic bytes of SURVEY 8(d).  None when a summary for
+    this variant is not committed or does not cover a kernel that ran."""
+    total, src, missing = 0.0, None, []
+    for name, d in kern.items():
+        tr = pmc_traffic(d.get("rocprof_names", []), variant)
+        if tr is None:
+            missing.append(name)
             continue
+        total += tr["bytes"] * d["launches_per_step"]
+        src = tr["source"]
+    if src is None:
+        return None
+    return {"pmc_bytes_per_step": total, "algorithmic_bytes": algo_bytes, "traffic_over_algorithmic": total / algo_bytes if algo_bytes else None,
+            "source": src, "kernels_without_counters": missing}
+
+
+def scatter_word_bytes(instances):
+    """(bytes read, bytes written) per row by the k_part_scatter instance(s) that ran, from the traits in their names - pf_key*: 8-byte
+    keys in, pf_word*: words in; _w32: 4-byte words; _out16: 2-byte words out; _rid: a 4-byte row id beside the word.  The instance
+    that RAN decides, not the profiler name it ran under (forced shuffle runs both tables under part_scatter_l0_w32)."""
+    ins, outs = [], []
+    for name in instances:
+        i = name.find("k_part_scatter<")
+        if i < 0:
+            continue
+        t = name[i + len("k_part_scatter<"):].split(">")[0]
+        rid = 4 if "_rid" in t else 0
+        w32, out16 = "_w32" in t, "_out16" in t
+        if t.startswith("pf_key"):
+            ins.append(8)
+        else:
+            ins.append((4 if w32 else 8) + rid)
+        outs.append((2 if out16 else 4 if w32 else 8) + rid)
+    if not ins:
+        return None
+    return sum(ins) / len(ins), sum(outs) / len(outs)
+
+
+FIRST_LEVEL = ("part_scatter_l0", "part_scatter_l0_w32", "part_scatter_l0_rid", "part_scatter_l0_pruned", "part_hist_l0",
+               "shard_scatter_wide_l", "shard_scatter_wide_r")
+WRITES_RESULT = ("order_leaf", "order_leaf_sparse", "shard_leaf", "shard_leaf_wide")
+
+
+def survey_bytes(kernel, n, groups):
+    """SURVEY 8(d)'s algorithmic bytes that ONE launch of `kernel` consumes: the whole query owes 8 (nA + nB) bytes of keys read and
+    16 G bytes of result written, once, whatever the passes in between.  A first-level pass is where a table's 8 n key bytes are
+    read; the kernel that writes the groups owns the 16 G; every pass in between (second levels, leaves that write records, the
+    ordering sort) moves bytes SURVEY 8(d) does not count - None: such a kernel has only its own I/O to be priced against."""
+    if kernel in FIRST_LEVEL:
+        return 8.0 * n
+    if kernel in WRITES_RESULT:
+        return 16.0 * groups
     return None
 
 
-def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2):
-    """Algorithmic HBM bytes of ONE launch of `kernel` on a table of n rows (G = `groups` result groups):
-    what the launch must read once and write once.  Kernel names are template instances, one table each.
+def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instances=(), launches=1.0, left_kept=None):
+    """The kernel's OWN I/O per launch: what the launch must read once and write once given the words this design
+    moves - `roofline.frac_kernel_io`, next to the SURVEY 8(d) figure of survey_bytes().  Kernel names are template instances, one
+    table each; the scatter kernels' word sizes come from the instance that ran (scatter_word_bytes).
     pruned: min-max pruning ran - the left table's first level wrote only the rows inside the right table's key range, and the
-    kernels after it see those rows only (one left row per group in both benchmark variants: 8 G bytes)."""
+    kernels after it see those rows only (one left row per group in both benchmark variants: left_kept = G)."""
     key, rid, h32, g = 8 * n, 4 * n, 4 * n, groups
+    kept = left_kept if left_kept is not None else (g if pruned else n)
+    wb = scatter_word_bytes(instances)
+    if wb is not None and kernel.startswith("part_scatter_l"):
+        bin_, bout = wb
+        if kernel == "part_scatter_l0_pruned":
+            return float(bin_ * n + bout * kept)
+        if kernel.startswith("part_scatter_l0"):
+            if launches >= 1.5:     # both tables under one name (the sharded operator's sender): the right table whole, the left one pruned
+                return float((bin_ * n + bout * n + bin_ * n + bout * kept) / 2)
+            return float(bin_ * n + bout * n)
+        rows = kept if (pruned and kernel in ("part_scatter_l1", "part_scatter_l1_semi")) else n
+        if kernel == "part_scatter_l1_semi":
+            return float(bin_ * rows + bout * g)
+        return float((bin_ + bout) * rows)
     if levels == 1:         # one partition level: the right table travels as 2-byte words (the hash bits below the first level's digit)
-        t = {"part_scatter_l0_w32": key + 2 * n, "leaf_join_wide": (8 * g if pruned else key) + 2 * n + 8 * g}
+        t = {"leaf_join_wide": (8 * g if pruned else key) + 2 * n + 8 * g}
         if kernel in t:
             return float(t[kernel])
     if pruned:
-        t = {"part_scatter_l0_pruned": key + 8 * g,      # every key in, the words of the rows inside the range out
-             "part_scatter_l1": 8 * g + 8 * g, "part_scatter_l1_semi": 8 * g + 8 * g,
-             "leaf_join_direct": 8 * g + h32 + 8 * g,
+        t = {"leaf_join_direct": 8 * g + h32 + 8 * g,
              "leaf_join_wide": 8 * g + h32 + 8 * g}
         if kernel in t:
             return float(t[kernel])
@@ -85,12 +170,12 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2):
         "part_scatter_l0_w32": key + h32,           # narrow right side: read keys, write 4-byte hashes
         "part_scatter_l0_rid": key + key + rid,     # wide left side: hash + row id out
         "part_scatter_l1": key + key,
-        "part_scatter_l1_semi": key + 8 * g,        # semi-join filter: every word in, the words that have a partner out (at least one
-                                                    # left row per group - exactly one in the benchmark's variants)
         "leaf_bitmap": h32,                         # the right table's partitioned words in, a bitmap of 2^k / 2^c bits out
         "part_scatter_l1_w32": h32 + h32,
         "part_scatter_l1_rid": 2 * (key + rid),
         "part_hist_l0": key,
+        "shard_scatter_wide_l": key + 2 * kept, "shard_scatter_wide_r": key + 2 * n,
+        "shard_leaf_wide": 2 * (kept + n) + 16 * g, "shard_leaf": 4 * (kept + n) + 16 * g,
         "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
         "leaf_join_direct": key + h32 + 8 * g,
         "leaf_join_wide": key + h32 + 8 * g,         # one partition level: the first level's words in, one record per group out
@@ -493,21 +578,38 @@ def main():
         g_rank = groups_total / max(world, 1)
         kern = {k: {"launches_per_step": v[0] / prof_steps, "ms_per_step": v[1] / prof_steps, "rocprof_names": prof_syms.get(k, [])}
                 for k, v in prof.items()}
-        for k, d in kern.items():   # per-kernel achieved rate on its algorithmic bytes
+        left_kept = g_rank if (pruned or (use_dist and args.variant == "D")) else n     # left rows that survive the range test (one per group in D)
+
+        def own_io(name):
+            d = kern[name]
+            return algorithmic_bytes(name, n, g_rank, narrow, pruned, levels, d["rocprof_names"], d["launches_per_step"], left_kept)
+        for k, d in kern.items():   # per-kernel achieved rate on the bytes the kernel itself must move
             if d["ms_per_step"] > 0:
-                d["algorithmic_GBs"] = (algorithmic_bytes(k, n, g_rank, narrow, pruned, levels) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9)
+                d["kernel_io_GBs"] = own_io(k) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9
+        pmc_variant = "shuffle" if use_dist else args.variant
 
         def roof_of(name):
+            """`achieved` / `frac`: SURVEY 8(d)'s algorithmic bytes the launch consumes (8 B per row for a first-level pass, 16 B per
+            group for the kernel that writes the result) / its average duration; kernels SURVEY 8(d) counts no bytes for are priced on
+            their own I/O and say so (`basis`).  `frac_kernel_io`: the same launch on everything this design makes it read and write."""
             d = kern[name]
             launches = max(d["launches_per_step"], 1e-9)
             avg_ms = d["ms_per_step"] / launches
-            bytes_per_launch = algorithmic_bytes(name, n, g_rank, narrow, pruned, levels)
+            io_bytes = own_io(name)
+            sv = survey_bytes(name, n, g_rank)
+            bytes_per_launch = sv if sv is not None else io_bytes
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            tr = pmc_traffic(prof_syms.get(name, []), args.variant) if (n == 100_000_000 and world == 1 and not use_dist) else None
+            achieved_io = io_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            tr = pmc_traffic(d["rocprof_names"], pmc_variant) if (n == 100_000_000 and world == 1) else None
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "basis": "SURVEY 8(d) bytes this launch consumes" if sv is not None else "kernel's own I/O (SURVEY 8(d) counts no bytes for this pass)",
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "kernel_io_bytes_per_launch": io_bytes, "achieved_kernel_io": achieved_io, "frac_kernel_io": achieved_io / HBM_PEAK_GBS,
                     "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                    "d2d_copy_GBs": copy_gbs, "frac_of_d2d_copy": (achieved / copy_gbs) if copy_gbs else None,
-                    "avg_launch_ms": avg_ms, "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch}
+                    "traffic_over_kernel_io": (tr["bytes"] / io_bytes) if (tr and io_bytes) else None,
+                    "d2d_copy_GBs": copy_gbs, "frac_of_d2d_copy": (achieved_io / copy_gbs) if copy_gbs else None,
+                    "frac_of_d2d_copy_note": "kernel's own I/O over the box's copy rate (read + write): cannot exceed ~1",
+                    "avg_launch_ms": avg_ms, "launches_per_step": d["launches_per_step"]}
         # dominant kernel = the one instance that takes the most time per step (one table per partition launch)
         dom_name = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
         roof = roof_of(dom_name) if dom_name else None

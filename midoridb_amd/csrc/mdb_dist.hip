@@ -495,10 +495,11 @@ extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *
 	out->word_bytes = p->wbytes;
 	out->completed = d->last_fused ? 1u : 0u;
 	for (uint32_t x = 0; x < p->ntab; x++) {
+		if (p->right_only && x == 0)
+			continue;	/* (GROUP BY of one table: there is no left table, nothing of it travels) */
 		out->region_words[x] = p->cap[x];
 		out->block_bytes[x] = p->block_words[x] * p->wbytes;
-		if (!(p->right_only && x == 0))
-			out->bytes_per_peer += p->block_words[x] * p->wbytes + (uint64_t)p->D * p->nsub * 4;
+		out->bytes_per_peer += p->block_words[x] * p->wbytes + (uint64_t)p->D * p->nsub * 4;
 	}
 	return MIDORIDB_OK;
 }

@@ -225,8 +225,8 @@ def sharded_sql(world, rank):
             lo, hi = n * rank // world, n * (rank + 1) // world
             if name == "C" and rank == 0:
                 lo, hi = 0, 0		# one rank holds no row of C at all
-            elif name == "C":
-                lo = 0
+            elif name == "C" and rank == 1:
+                lo = 0			# (... rank 1 holds them as well)
             db.append_columns(name, [d[0][lo:hi] for d in data], [d[1][lo:hi] for d in data])
             cols = sdl[sdl.index("(") + 1:sdl.rindex(")")].split(",")
             tables[name] = ([x.split()[0] for x in cols],

@@ -226,17 +226,18 @@ def fault(world, rank):
     la = slice(rank * n, (rank + 1) * n)
     dx.set_key_ranges((0, 199_999), (0, 199_999))
     ek, ec, _, ej = orc.join_group_count(ga, None, gb, None)
+    out = (torch.empty(n * world + 8, dtype=torch.int64, device=dev.device), torch.empty(n * world + 8, dtype=torch.int64, device=dev.device))
     bad = world - 1
     for attempt in range(2):
         os.environ["MDB_DIST_FAULT"] = f"first_level:{bad}"
         try:
-            dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None)
+            dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None, out=out)
             raise SystemExit(f"rank {rank}: the call must fail on every rank")
         except DistError as e:
             msg = str(e)
             assert ("fault injected" in msg) if rank == bad else ("a peer failed" in msg), msg
         del os.environ["MDB_DIST_FAULT"]
-        k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None)
+        k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None, out=out)
         assert dx.last_fused()
         mine = owned(dx, ek, world, rank, gb, promised=(0, 199_999))
         assert dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())) == dict(zip(ek[mine].tolist(), ec[mine].tolist()))
@@ -246,11 +247,11 @@ def fault(world, rank):
         if rank == 0:
             dx.group_count_keys(dev.to_dev(ga[la]))		# (a different kind of call than the peers make)
         else:
-            dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None)
+            dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None, out=out)
         raise SystemExit("a call paired with another kind of call must fail")
     except DistError as e:
         assert "not in the same collective call" in str(e), str(e)
-    k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None)	# ... and nothing was left half-posted
+    k, c, j = dx.join_group_count(dev.to_dev(ga[la]), None, dev.to_dev(gb[la]), None, out=out)	# ... and nothing was left half-posted
     assert dx.last_fused() and dx.allreduce_sum([j])[0] == ej
     dx.close()
     dev.close()
@@ -292,12 +293,14 @@ def config5_sql(world, rank):
         il, ir = pl[p2], pr[p2]
         exp_rows = sorted(zip(ka[il].tolist(), x[il].view(np.int64).tolist(), y[ir].view(np.int64).tolist(), z[pc].tolist()))
         cols = {nm: r.columns[i] for i, nm in enumerate(r.names)}
-        mine = list(zip(cols["A.id_a"].tolist(), np.asarray(cols["A.x"], dtype=np.float64).view(np.int64).tolist(),
-                        np.asarray(cols["B.y"], dtype=np.float64).view(np.int64).tolist(), cols["C.z"].tolist()))
+        mine = list(zip(cols["A.id_a"].tolist(), cols["A.x"].tolist(), cols["B.y"].tolist(), cols["C.z"].tolist()))	# (8-byte cells: a DOUBLE's bits)
         assert cols["B.id_b"].tolist() == cols["A.id_a"].tolist() == cols["C.id_c"].tolist()
         parts = [None] * world
         dist.all_gather_object(parts, mine)
-        assert sorted(t for p in parts for t in p) == exp_rows
+        got_rows = sorted(t for p in parts for t in p)
+        assert len(got_rows) == len(exp_rows), (len(got_rows), len(exp_rows))
+        bad = [(g, e) for g, e in zip(got_rows, exp_rows) if g != e]
+        assert not bad, (len(bad), bad[:3])
         assert db.query("SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON A.id_a = C.id_c;").rows() == [(len(exp_rows),)]
     dist.barrier()
 
