@@ -215,6 +215,8 @@ def parse_args():
                          "5 = configs[4]: three-way join + GROUP BY with DOUBLE payload through query_execute() (bench_configs.py)")
     ap.add_argument("--unordered", action="store_true", help="N = 1: time the operator without MDB_ORDER_FIRST (groups in unspecified order) - "
                     "evidence runs only; the default line keeps the reference's first-occurrence order")
+    ap.add_argument("--reference-order", action="store_true", help="--config 4 at N = 1: time mdb_dev_join_pairs + the key gather (joined rows in "
+                    "the reference's left-major order) instead of mdb_dev_join_keys (unspecified order, like the sharded form)")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -540,6 +542,37 @@ def main():
     prof = dev.prof_read()
     prof_syms = {k: dev.prof_symbols(k) for k in prof}     # rocprofv3's names of what ran under each profiler name
     dev.prof_enable(False)
+    # the sharded operator, per rank: where a call's time goes (first level / the wire as far as it is not hidden / receiver) and
+    # what the plan puts on ONE xGMI link per call, next to what that link can carry (MI355X: 7 links x ~153 GB/s per GPU, point to
+    # point - an all-to-all's block for a peer crosses the one link to that peer)
+    exchange = None
+    if use_dist:
+        dx.set_phase_timing(True)
+        ph = []
+        for _ in range(3):
+            step()
+            ph.append(dx.last_phases())
+        dx.set_phase_timing(False)
+        mine = {k: sorted(p[k] for p in ph)[1] for k in ph[0]}      # median of three
+        plan = dx.last_plan() if dx.last_fused() else None
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, {"rank": rank, "phases_ms": mine})
+        else:
+            per_rank = [{"rank": 0, "phases_ms": mine}]
+        XGMI_LINK_GBS = 153.0
+        exchange = {"path": "first-level regions on the wire" if plan else "keys by destination",
+                    "plan": plan, "per_rank": per_rank,
+                    "phases_note": "HIP events on the operator's and the transfer stream: first_level_ms = this rank's partition passes; "
+                                   "wire_wait_ms = how long after them the last block arrived (what of the transfer is NOT hidden behind the passes); "
+                                   "receiver_ms = region descriptors, the receiver's own level if any, leaves; device_ms = all of it"}
+        if plan:
+            bpp = plan["bytes_per_peer"]
+            exchange["per_link"] = {"bytes_per_peer_per_call": bpp, "peers": world - 1, "xgmi_link_GBs": XGMI_LINK_GBS,
+                                    "predicted_link_ms": bpp / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0,
+                                    "note": "bytes one rank sends to ONE peer per call (fixed-size blocks, slack included, + region counters) / one "
+                                            "link's rate: the floor of wire time when every peer is one hop away and the links run in parallel; "
+                                            "compare with first_level_ms (the transfer of table x overlaps the pass over table x + 1) and wire_wait_ms"}
     # practical HBM ceiling of this box: device-to-device copy of one key column (read + write)
     copy_gbs = None
     try:
@@ -643,9 +676,13 @@ def main():
                        "pruned_before_shuffle": bool(dx.last_pruned()) if use_dist else None},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
-                         "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "frac_of_peak": algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / max(world, 1)},
             "kernels": kern,
         }
+        if n == 100_000_000 and world == 1:
+            line["pipeline"]["traffic"] = pmc_step_traffic(kern, pmc_variant, algo_bytes)
+        if exchange is not None:
+            line["exchange"] = exchange
         # the first-level scatter of the left table beside it: the bandwidth-bound kernel of the pipeline
         for cand in ("part_scatter_l0", "part_scatter_l0_pruned", "part_scatter_l0_rid", "part_scatter_l0_w32"):
             if cand in kern and cand != dom_name:
@@ -690,11 +727,26 @@ def main():
                 line["wide_form"] = {"error": str(e)}
             finally:
                 dev.set_narrow_keys(1)
-            def pipe_frac(groups, seconds):
+            def pipe_frac(groups, seconds, variant=None, fn=None):
                 ab = 8 * 2 * n + 16 * groups
-                return {"algorithmic_bytes": ab, "achieved_GBs": ab / seconds / 1e9, "frac_of_peak": ab / seconds / 1e9 / HBM_PEAK_GBS}
+                d = {"algorithmic_bytes": ab, "achieved_GBs": ab / seconds / 1e9, "frac_of_peak": ab / seconds / 1e9 / HBM_PEAK_GBS}
+                if variant is not None and fn is not None and n == 100_000_000:
+                    # which kernels one step of THIS workload launches (live), priced with the committed PMC summary of the same workload
+                    dev.prof_enable(True)
+                    dev.prof_reset()
+                    fn()
+                    pr = dev.prof_read()
+                    dev.prof_enable(False)
+                    kk = {k: {"launches_per_step": float(v[0]), "rocprof_names": dev.prof_symbols(k)} for k, v in pr.items()}
+                    d["traffic"] = pmc_step_traffic(kk, variant, ab)
+                return d
             if "wide_form" in line and "ms_per_step" in line["wide_form"]:
-                line["wide_form"]["pipeline"] = pipe_frac(groups_total, line["wide_form"]["ms_per_step"] * 1e-3)
+                try:
+                    dev.set_narrow_keys(0)
+                    line["wide_form"]["pipeline"] = pipe_frac(groups_total, line["wide_form"]["ms_per_step"] * 1e-3, "wide",
+                                                              lambda: dev.join_group_count(a, None, b, None, out=out))
+                finally:
+                    dev.set_narrow_keys(1)
             def unordered_of(b_tab, expect):
                 # the same operator called without MDB_ORDER_FIRST and without first rows: the groups in unspecified order, no row ids
                 # carried and no ordering sort (reported BESIDE the ordered figures, never as `value`)
@@ -718,7 +770,9 @@ def main():
                         b_x = make_b()
                         dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out))
                         line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
-                                     "value": ru[3] / dtu, "pipeline": pipe_frac(int(ru[0].numel()), dtu),
+                                     "value": ru[3] / dtu,
+                                     "pipeline": pipe_frac(int(ru[0].numel()), dtu, "U" if tag == "variant_U" else "S",
+                                                           lambda: dev.join_group_count(a, None, b_x, None, out=out)),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
                                      "min_max_pruning": bool(dev.last_join_filter()[1])}
                         line[tag]["unordered"] = unordered_of(b_x, (int(ru[0].numel()), ru[3]))

@@ -77,7 +77,9 @@ def run(args, world, rank, local_rank, json_fd):
             if dx is not None:
                 key, _, _, J = dx.join_pairs(a, None, [], b, None, [])
                 return J
-            pl, pr = dev.join_pairs(a, None, b, None)
+            if not args.reference_order:
+                return dev.join_keys(a, None, b, None).numel()      # the key column of every joined row, any order (mdb_dev_join_keys)
+            pl, pr = dev.join_pairs(a, None, b, None)       # (left row, right row) pairs in the reference's order + the key gather
             J = pl.numel()
             dev.gather64(a, None, pl, J)
             return J
@@ -101,7 +103,10 @@ def run(args, world, rank, local_rank, json_fd):
                        "parallelism": (f"hash-partition x{world}, mdb_dist_join_pairs"
                                        + (" (key columns only: first-level partition regions on the wire, every key written COUNT times)"
                                           if fused else " (RCCL all-to-all of keys by destination, local join)")
-                                       + (" (forced shuffle)" if world == 1 else "")) if use_dist else "single GPU, mdb_dev_join_pairs + gather"},
+                                       + (" (forced shuffle)" if world == 1 else "")) if use_dist else
+                                      ("single GPU, mdb_dev_join_pairs + key gather (the reference's left-major row order)" if args.reference_order else
+                                       "single GPU, mdb_dev_join_keys (key column of the joined rows in unspecified order, as the sharded "
+                                       "form delivers it: regions of 2-byte words, no row ids)")},
             "pipeline": {"algorithmic_bytes": algo, "achieved_GBs": algo / (dt / args.steps) / 1e9,
                          "frac_of_peak": algo / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": algo / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

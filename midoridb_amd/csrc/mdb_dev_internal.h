@@ -189,6 +189,10 @@ int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, 
 int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint64_t na, uint64_t nb, uint32_t *out_a,
 		   uint32_t *out_b);
 
+/* (key, COUNT) groups -> every key written COUNT times (mdb_dev_pairs.hip): *out = a device array of `joined` keys allocated with
+ * mdb_dev_alloc.  joined = the sum of the counts (< 2^32).  Synchronises. */
+int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t *count, uint64_t groups, uint64_t joined, int64_t **out);
+
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
 

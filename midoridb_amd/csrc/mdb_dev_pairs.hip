@@ -1174,3 +1174,115 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	*out_count = J;
 	return MIDORIDB_OK;
 }
+
+
+/* ------------------------------------------------------------------ a join whose only output is the key column
+ *
+ * (include/mdb_dev.h: mdb_dev_join_keys; reference shape: _join_nested_loop_tbl2tbl, executor_select.c:1076-1149, followed by a
+ * projection of the two key columns).  Nothing has to say WHICH rows met: (key, COUNT) per key that occurs on both sides - the
+ * any-order join + GROUP BY operator - and every key written COUNT times. */
+#define XK_THREADS 256
+
+__global__ __launch_bounds__(XK_THREADS) void k_counts_u32(const int64_t *__restrict__ cnt, uint64_t n, uint32_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * XK_THREADS + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * XK_THREADS)
+		out[i] = i < n ? (uint32_t)cnt[i] : 0u;		/* (one more word: the scan's grand total lands there) */
+}
+
+/* one wave per group run: lane j writes copies j, j + 64, ... (a group's copies are adjacent: coalesced stores whatever COUNT is) */
+__global__ __launch_bounds__(XK_THREADS) void k_expand_keys(const int64_t *__restrict__ key, const uint32_t *__restrict__ pos, uint64_t n,
+							     int64_t *__restrict__ out)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t wave = ((uint64_t)blockIdx.x * XK_THREADS + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * XK_THREADS) >> 6;
+	for (uint64_t base = wave * 64; base < n; base += nwaves * 64) {
+		const uint64_t i = base + lane;
+		const int64_t k = i < n ? key[i] : 0;
+		const uint32_t p = i < n ? pos[i] : 0u, e = i < n ? pos[i + 1] : 0u;
+		if (__all(e - p <= 1u)) {		/* (unique partners: one store per lane) */
+			if (e > p)
+				out[p] = k;
+			continue;
+		}
+		for (uint32_t g = 0; g < 64u; g++) {
+			const int64_t kg = __shfl(k, (int)g, 64);
+			const uint32_t pg = (uint32_t)__shfl((int)p, (int)g, 64), eg = (uint32_t)__shfl((int)e, (int)g, 64);
+			for (uint32_t q = pg + lane; q < eg; q += 64u)
+				out[q] = kg;
+		}
+	}
+}
+
+static inline uint32_t xk_grid(uint64_t n)
+{
+	const uint64_t b = (n + XK_THREADS - 1) / XK_THREADS;
+	return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t *count, uint64_t groups, uint64_t joined, int64_t **out)
+{
+	*out = NULL;
+	if (joined >= 0xFFFFFFFFull)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "%llu joined rows exceed the 32-bit row limit of one GPU", (unsigned long long)joined);
+	uint32_t *pos = NULL, *tmp = NULL;
+	int64_t *rows = NULL;
+	int rc = mdb_dev_alloc(ctx, (groups + 1) * 4, (void **)&pos);
+	if (!rc)
+		rc = mdb_dev_alloc(ctx, mdb_scan_scratch_words(groups + 1) * 4, (void **)&tmp);
+	if (!rc)
+		rc = mdb_dev_alloc(ctx, (joined ? joined : 1) * 8, (void **)&rows);
+	if (!rc) {
+		hipLaunchKernelGGL(k_counts_u32, dim3(xk_grid(groups + 1)), dim3(XK_THREADS), 0, ctx->stream, count, groups, pos);
+		rc = mdb_scan_u32_inplace(ctx, pos, groups + 1, tmp);
+	}
+	if (!rc && groups)
+		hipLaunchKernelGGL(k_expand_keys, dim3(xk_grid(groups)), dim3(XK_THREADS), 0, ctx->stream, key, pos, groups, rows);
+	if (!rc)
+		rc = mdb_dev_sync(ctx);
+	(void)mdb_dev_free(ctx, pos);
+	(void)mdb_dev_free(ctx, tmp);
+	if (rc) {
+		(void)mdb_dev_free(ctx, rows);
+		return rc;
+	}
+	*out = rows;
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_join_keys(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows)
+{
+	if (!ctx || !out_key || !out_rows)
+		return -MIDORIDB_ERROR;
+	*out_key = NULL;
+	*out_rows = 0;
+	const uint64_t cap = n_l ? n_l : 1;	/* (a group per distinct left key at most) */
+	int64_t *gk = NULL, *gc = NULL;
+	if (mdb_dev_alloc(ctx, cap * 8, (void **)&gk) || mdb_dev_alloc(ctx, cap * 8, (void **)&gc)) {
+		(void)mdb_dev_free(ctx, gk);
+		return -MIDORIDB_NOMEM;
+	}
+	uint64_t G = 0, J = 0;
+	/* (no MDB_ORDER_FIRST, no first rows: the any-order form where it is served, else the ordered operator - its groups serve as well) */
+	int rc = (n_l && n_r) ? mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, 0u, gk, gc, NULL, cap, &G, &J) : MIDORIDB_OK;
+	if (rc) {
+		(void)mdb_dev_free(ctx, gk);
+		(void)mdb_dev_free(ctx, gc);
+		return rc;
+	}
+	if (J == G) {		/* every COUNT is 1: the group keys ARE the joined rows */
+		(void)mdb_dev_free(ctx, gc);
+		*out_key = gk;
+		*out_rows = G;
+		return MIDORIDB_OK;
+	}
+	int64_t *rows = NULL;
+	rc = mdb_expand_keys_by_count(ctx, gk, gc, G, J, &rows);
+	(void)mdb_dev_free(ctx, gk);
+	(void)mdb_dev_free(ctx, gc);
+	if (rc)
+		return rc;
+	*out_key = rows;
+	*out_rows = J;
+	return MIDORIDB_OK;
+}

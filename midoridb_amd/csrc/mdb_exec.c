@@ -1519,6 +1519,32 @@ static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool 
 	return -1;
 }
 
+/* a two-table INNER JOIN ON l = r whose result columns are all one of the two key columns, nothing else asked of it, order left
+ * open by the host (mdb_database_groups_any_order): kj[0..1] = the key fields (left table's first) */
+static bool keys_only_join(const struct mdb_select *s, const struct mdb_catalog *cat, int has_count, const int *key_tbl, const int *key_col,
+			   const int *src, int ncols, const struct mdb_expr **kj)
+{
+	if (cat->dist || !cat->groups_any_order || s->ntabs != 2 || s->where || s->ngroup || has_count || s->distinct || s->norder || s->having ||
+	    s->has_limit || !ncols)
+		return false;
+	const struct mdb_expr *on = s->on[1];
+	if (!on || on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
+		return false;
+	const struct mdb_expr *a = on->kids[0], *b = on->kids[1];
+	if (a->tbl_idx == b->tbl_idx || a->type != b->type || a->type == MDB_CT_DOUBLE)
+		return false;	/* (DOUBLE keys join through their IEEE-canonical words, whose values are not the column's) */
+	kj[0] = a->tbl_idx == 0 ? a : b;
+	kj[1] = a->tbl_idx == 0 ? b : a;
+	if (!s->tabs[0].t->nrows || !s->tabs[1].t->nrows)
+		return false;	/* (an empty side: the general plan answers "no rows") */
+	for (int c = 0; c < ncols; c++) {
+		const int t = key_tbl[src[c]], col = key_col[src[c]];
+		if (t < 0 || !((t == kj[0]->tbl_idx && col == kj[0]->col_idx) || (t == kj[1]->tbl_idx && col == kj[1]->col_idx)))
+			return false;
+	}
+	return true;
+}
+
 /* HAVING, DISTINCT, ORDER BY, LIMIT over the finished stream (after FROM / WHERE / GROUP BY) */
 static int select_tail(struct exec *x, int has_count)
 {
@@ -1633,6 +1659,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	uint64_t **direct_nulls = NULL;
 	double t0;
 	const struct mdb_expr *fkeys[MDB_MAX_TABS];
+	const struct mdb_expr *kj[2] = { NULL, NULL };
 	int fused;
 
 	*out = NULL;
@@ -1875,6 +1902,27 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		}
 		x.fused = true;
 		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */
+		x.joined_rows = J;
+	} else if (keys_only_join(s, cat, has_count, key_tbl, key_col, src, ncols, kj)) {
+		/* ---- a two-table equi-join whose select list names nothing but the two key columns (BASELINE configs[3]: SELECT * over
+		 *      two key columns), any order allowed (mdb_database_groups_any_order): both sides hold the same value in every
+		 *      joined row, so no row has to be identified - the any-order join + GROUP BY pipeline counts every key's partners and
+		 *      the key is written COUNT times (mdb_dev_join_keys); the stream is the fused plan's: one key column, no row ids */
+		const struct mdb_column *cl = &s->tabs[kj[0]->tbl_idx].t->cols[kj[0]->col_idx], *cr = &s->tabs[kj[1]->tbl_idx].t->cols[kj[1]->col_idx];
+		int64_t *jk = NULL;
+		uint64_t J = 0;
+		if (mdb_dev_join_keys(x.dev, cl->d_data, cl->d_nullbits, s->tabs[kj[0]->tbl_idx].t->nrows, cr->d_data, cr->d_nullbits,
+				      s->tabs[kj[1]->tbl_idx].t->nrows, &jk, &J)) {
+			rc = dev_fail(&x, "join of two key columns");
+			goto out;
+		}
+		if (jk && track(&x, jk)) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+		x.d_fused_key = jk;
+		x.fused = true;
+		x.n = J;
 		x.joined_rows = J;
 	} else if (s->ntabs == 1 && s->where && split_ok && !ws.nresidual && ws.npush[0] && !s->ngroup && !has_count && !s->distinct &&
 		   !s->norder && !s->having && !s->has_limit && s->tabs[0].t->nrows && ncols && ncols <= MDB_GATHER_MAX_COLS) {

@@ -741,6 +741,39 @@ def test_join_pairs_randomised_large(dev, seed):
     assert np.array_equal(_np(l).astype(np.int64), el) and np.array_equal(_np(r).astype(np.int64), er)
 
 
+@pytest.mark.parametrize("case", ["tiny", "unique_2e22", "dups_both", "nulls", "sparse_2e29", "beyond_any_window", "empty_right", "no_match"])
+def test_join_keys_is_the_key_column_of_join_pairs_as_a_multiset(dev, case):
+    """mdb_dev_join_keys (BASELINE configs[3]: a join whose only output is its key columns): every joined row's key, in unspecified
+    order - equal to keys_l[pos_l] over the oracle's pairs as a multiset; every size class (single-workgroup kernel, one level, the
+    4096-digit level, two levels, the ordered operator as the fallback)"""
+    rng = np.random.default_rng(hash(case) % 1000)
+    nl = nr = None
+    if case == "tiny":
+        kl, kr = rng.integers(0, 20, 300), rng.integers(0, 20, 200)
+    elif case == "unique_2e22":
+        kl, kr = rng.permutation(3_000_000) + 50, rng.permutation(3_000_000)[:2_500_000] + 50
+    elif case == "dups_both":
+        kl, kr = rng.integers(-1000, 400_000, 1_500_000), rng.integers(-1000, 400_000, 1_200_000)
+    elif case == "nulls":
+        kl, kr = rng.integers(0, 2_000_000, 1_300_000), rng.integers(0, 2_000_000, 1_300_000)
+        nl, nr = rng.random(len(kl)) < 0.05, rng.random(len(kr)) < 0.05
+    elif case == "sparse_2e29":
+        pool = rng.integers(0, 1 << 29, 1_000_000)
+        kl, kr = pool[rng.integers(0, len(pool), 1_400_000)] + 10**12, pool[rng.integers(0, len(pool), 1_100_000)] + 10**12
+    elif case == "beyond_any_window":
+        pool = rng.integers(-2**62, 2**62, 800_000)
+        kl, kr = pool[rng.integers(0, len(pool), 1_200_000)], pool[rng.integers(0, len(pool), 1_200_000)]
+    elif case == "empty_right":
+        kl, kr = rng.integers(0, 1000, 5000), np.zeros(0, dtype=np.int64)
+    else:
+        kl, kr = rng.integers(0, 10**6, 1_200_000), rng.integers(2 * 10**6, 3 * 10**6, 1_200_000)
+    kl, kr = kl.astype(np.int64), kr.astype(np.int64)
+    got = dev.join_keys(dev.to_dev(kl), dev.nullbits_dev(nl) if nl is not None else None, dev.to_dev(kr), dev.nullbits_dev(nr) if nr is not None else None)
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    assert got.numel() == len(el)
+    assert np.array_equal(np.sort(_np(got)), np.sort(kl[el]))
+
+
 def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
     counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
