@@ -94,6 +94,9 @@ size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
  * by other means (its own kernels) pays at most a few slower calls. */
 int mdb_dev_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr);
 int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr);
+/* bytes the allocator holds behind a buffer of mdb_dev_alloc (it hands out released buffers of up to twice the size asked for),
+ * 0 for a pointer it does not know */
+size_t mdb_dev_alloc_size(mdb_dev_ctx *ctx, const void *dptr);
 int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes);
 /* Page-locked host memory for result columns (D2H at PCIe rate instead of through the driver's staging copy).
  * Process-wide pool, independent of any context: buffers are recycled by later results and may be freed after the

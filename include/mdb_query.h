@@ -74,7 +74,9 @@ void database_close(struct database *db);
 struct query_output *query_execute(struct database *db, char *query);
 
 /* MIDORIDB_ROW (4) while a row is current, MIDORIDB_OK (0) at the end - for results of ANY
- * size (the reference's own cursor breaks past one 4 KiB datablock). */
+ * size (the reference's own cursor breaks past one 4 KiB datablock).  A result kept on the
+ * device (mdb_database_results_on_device) is copied to the host by the first step: -MIDORIDB_INTERNAL when
+ * that copy fails (no row is current; a `== MIDORIDB_ROW` loop ends as it does at the end of the result). */
 int query_cur_step(struct result_set *res);
 int64_t query_column_int64(struct result_set *res, int col_idx);
 void query_free(struct query_output *output);
@@ -122,6 +124,10 @@ int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint6
  * its columns live in the database's device context. */
 int mdb_database_results_on_device(struct database *db, int on);
 const void *query_column_data_device(struct result_set *res, int col_idx);	/* NULL when the column is not on the device */
+/* ... and its NULL flags: a device bitmap of query_row_count() bits (bit set = the cell is NULL - the reference's polarity,
+ * include/primitive/row.h - whose 8-byte cell then holds whatever the table stored), or NULL when no cell of the column is NULL
+ * (or the column is not on the device).  The host path reports the same flags through query_column_is_null(). */
+const uint64_t *query_column_nulls_device(struct result_set *res, int col_idx);
 
 /* Group order: the reference emits the groups of a GROUP BY in the order their first row occurs, and so does this library by
  * default.  SQL promises no order without ORDER BY: after mdb_database_groups_any_order(db, 1) a join + GROUP BY + COUNT(*)

@@ -423,6 +423,14 @@ extern "C" int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr)
 	return mdb_cached_free(ctx, dptr);
 }
 
+extern "C" size_t mdb_dev_alloc_size(mdb_dev_ctx *ctx, const void *dptr)
+{
+	if (!ctx || !dptr)
+		return 0;
+	auto it = ctx->live.find(const_cast<void *>(dptr));
+	return it == ctx->live.end() ? 0 : it->second;
+}
+
 extern "C" int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes)
 {
 	if (bytes)

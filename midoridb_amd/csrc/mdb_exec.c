@@ -1439,7 +1439,8 @@ static int result_column_to_host(mdb_dev_ctx *dev, struct mdb_result *res, int c
 		return -MIDORIDB_INTERNAL;
 	if (d_nulls) {
 		const uint64_t words = (rows + 63) / 64;
-		res->nullbits[c] = calloc((size_t)words, 8);
+		if (!res->nullbits[c])		/* (a fetch that is tried again after a failure finds the bitmap of its first attempt) */
+			res->nullbits[c] = calloc((size_t)words, 8);
 		if (!res->nullbits[c] || mdb_dev_d2h(dev, res->nullbits[c], d_nulls, words * 8))
 			return -MIDORIDB_INTERNAL;
 		for (uint64_t i = 0; i < rows; i++)
@@ -2331,8 +2332,12 @@ grouped:
 					continue;
 				for (int k = 0; k < c; k++)	/* the same device column under two result columns (both key columns of SELECT *) */
 					shared = shared || d_vals[k] == src || (const void *)d_nulls[k] == src;
+				/* (a statement buffer sized for the worst case - every left row a group - must not pin hundreds of megabytes
+				 * behind a small result until query_free: such a column is copied into a buffer of its own size instead) */
 				for (int i = 0; i < x.bufs.n && !shared; i++)
 					if (x.bufs.p[i] == src) {
+						if (mdb_dev_alloc_size(x.dev, src) > 4 * bytes + ((size_t)1 << 20))
+							break;
 						own = x.bufs.p[i];
 						x.bufs.p[i] = x.bufs.p[--x.bufs.n];
 						break;

@@ -167,7 +167,9 @@ int query_cur_step(struct result_set *res)
 		return MIDORIDB_OK;
 	r = res->table;
 	if (!r->fetched && mdb_result_fetch(r))
-		return MIDORIDB_OK;	/* (the device copy failed: no row is current) */
+		return -MIDORIDB_INTERNAL;	/* the device-to-host copy of a result kept on the device failed: no row is current, and the
+						 * caller can tell this from the end of an empty result (MIDORIDB_OK); a loop over
+						 * `== MIDORIDB_ROW` ends either way */
 	if (!res->cursor_blk) {
 		res->cursor_blk = r;
 		res->cursor_offset = 0;
@@ -276,6 +278,12 @@ const void *query_column_data_device(struct result_set *res, int col_idx)
 {
 	struct mdb_result *r = res ? res->table : NULL;
 	return r && r->d_data && col_idx >= 0 && col_idx < r->ncols ? r->d_data[col_idx] : NULL;
+}
+
+const uint64_t *query_column_nulls_device(struct result_set *res, int col_idx)
+{
+	struct mdb_result *r = res ? res->table : NULL;
+	return r && r->d_data && r->d_nullbits && col_idx >= 0 && col_idx < r->ncols ? r->d_nullbits[col_idx] : NULL;
 }
 
 int mdb_database_results_on_device(struct database *db, int on)

@@ -41,7 +41,7 @@ QUERY_SYMBOLS = [
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
     "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
-    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "mdb_database_groups_any_order", "query_column_data_device", "mdb_table_generate_shard",
+    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "mdb_database_groups_any_order", "query_column_data_device", "query_column_nulls_device", "mdb_table_generate_shard",
 ]
 
 
@@ -99,6 +99,8 @@ def _bind(lib):
     lib.mdb_database_groups_any_order.restype = c_int
     lib.query_column_data_device.argtypes = [PRS, c_int]
     lib.query_column_data_device.restype = c_void_p
+    lib.query_column_nulls_device.argtypes = [PRS, c_int]
+    lib.query_column_nulls_device.restype = c_void_p
     lib.mdb_table_generate_shard.argtypes = [PDB, c_char_p, c_uint64, c_uint64, c_uint64, c_uint64, POINTER(c_uint64)]
     lib.mdb_table_generate_shard.restype = c_int
     lib._mdb_query_bound = True
@@ -196,6 +198,19 @@ class DB:
             class _View:
                 __cuda_array_interface__ = {"shape": (nrows,), "typestr": "<f8" if types[c] == 3 else "<i8", "data": (int(p), False), "version": 2}
             cols.append(torch.as_tensor(_View(), device="cuda").clone().to(dt))
+        self.last_device_nulls = []      # per column: the NULL flags as a bool tensor, or None when no cell is NULL (query_column_nulls_device)
+        for c in range(nc):
+            pn = self.lib.query_column_nulls_device(rs, c) if copy and nrows else None
+            if not pn:
+                self.last_device_nulls.append(None)
+                continue
+            words = (nrows + 63) // 64
+
+            class _Bits:
+                __cuda_array_interface__ = {"shape": (words,), "typestr": "<i8", "data": (int(pn), False), "version": 2}
+            w = torch.as_tensor(_Bits(), device="cuda").clone()
+            bits = (w.unsqueeze(1) >> torch.arange(64, device=w.device, dtype=torch.int64)) & 1
+            self.last_device_nulls.append(bits.reshape(-1)[:nrows].bool())
         res = (names, types, cols, nrows, int(self.lib.query_joined_rows(rs)), float(self.lib.query_exec_ms(rs)))
         self.lib.query_free(out)
         return res
