@@ -76,6 +76,12 @@ struct mdb_part_filter {
 	uint32_t *minmax_out;
 	uint32_t *minmax_tiles;	/* with minmax_out: scratch of mdb_part_minmax_words(n) words (a pair per first-level tile, reduced after the launch) */
 	const uint32_t *range_in;
+	/* the same in the 64-bit form (mdb_partition_table with narrow = 0): the right table (no row ids) leaves [lo, hi] of its keys as
+	 * two signed 64-bit words in minmax64_out (scratch: minmax64_tiles, mdb_part_minmax_words(n) * 2 uint32 words), the left table
+	 * (with row ids) reads them through range64_in */
+	long long *minmax64_out;
+	unsigned long long *minmax64_tiles;
+	const long long *range64_in;
 	/* first level, any form: keep only the rows whose KEY lies in [keep_lo, keep_hi] (keep_on) - the other table's global key
 	 * range, known before an exchange (mdb_dev_partition_by_dest_pruned) */
 	bool keep_on;

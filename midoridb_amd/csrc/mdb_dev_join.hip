@@ -1513,6 +1513,7 @@ struct gc_state {
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
 	bool prunable;		/* the right table's keys cover less than 7/8 of the left table's range (sample) */
 	bool r_based;		/* the compact window covers the right table's keys only: min-max pruning must run (gc_window.r_based) */
+	bool defer_l64;		/* the same in the 64-bit form (keys that fit no 2^32 window): min-max pruning on the raw keys */
 	bool defer_l;		/* the LEFT table is partitioned after the right one, in gc_finish (compact narrow form, unsplit call): the
 				 * right table's first level records its exact key range, the left table's drops the rows outside */
 	uint32_t semijoin;	/* != 0: the LEFT table is partitioned after the right one (gc_finish), its second level dropping the rows
@@ -1606,6 +1607,11 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	const char *prune_env = getenv("MDB_MINMAX_PRUNE");		/* 0: never, 2: whatever the key sample says (tests) */
 	st->defer_l = st->narrow && st->fast && (st->b2 > 0 || st->one_level) && st->has_r && st->defer_ok && !st->active &&
 		      (st->prunable || (st->direct && st->selective) || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
+	/* ... and in the 64-bit form (hashes, snowflake ids: keys beyond every 2^32 window) just the same - the range test does not
+	 * care how wide the keys are: the right table's first level records the smallest and the largest KEY, the left table's drops
+	 * the rows outside before they are hashed, ranked or written (12 bytes per row and level in this form) */
+	st->defer_l64 = !st->narrow && st->fast && st->b2 > 0 && st->has_r && st->defer_ok && !st->active && !st->nextra && !st->keys32 &&
+			(st->prunable || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
 	st->semijoin = 0;
 	if (st->defer_l && st->direct && !st->one_level && st->selective && !st->by_span) {
 		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
@@ -1621,6 +1627,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
 	if (st->defer_l)
 		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 4) + 256;
+	if (st->defer_l64)
+		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 8) + 256;
 	if (st->has_r)
 		need += st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
 				      : mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
@@ -1646,7 +1654,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	if (!st->defer_l) {
+	if (!st->defer_l && !st->defer_l64) {
 		mdb_part_filter lflt;
 		memset(&lflt, 0, sizeof(lflt));
 		lflt.level0_only = st->one_level;
@@ -1693,10 +1701,28 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			if (!rflt.minmax_tiles)
 				return -MIDORIDB_INTERNAL;
 		}
+		if (st->defer_l64) {
+			/* [GC_ST_MINMAX64 ..]: smallest, largest key of the right table as two signed 64-bit words */
+			rflt.minmax64_out = reinterpret_cast<long long *>(ctx->d_status + GC_ST_MINMAX64);
+			rflt.minmax64_tiles = (unsigned long long *)mdb_arena_take(ctx, mdb_part_minmax_words(n_r) * 8);
+			if (!rflt.minmax64_tiles)
+				return -MIDORIDB_INTERNAL;
+		}
 		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, st->b1, st->b2, false, false, st->fast, &pr, st->narrow ? 2 : 0, st->keys32,
-					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, (st->defer_l || st->one_level) ? &rflt : NULL);
+					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u,
+					 (st->defer_l || st->one_level || st->defer_l64) ? &rflt : NULL);
 		if (rc)
 			return rc;
+	}
+	if (st->defer_l64) {
+		mdb_part_filter flt;
+		memset(&flt, 0, sizeof(flt));
+		flt.range64_in = reinterpret_cast<const long long *>(ctx->d_status + GC_ST_MINMAX64);
+		flt.expect_pruned = st->by_span;
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, true, false, st->fast, &st->pl, 0, st->keys32, st->base, 0u, &flt);
+		if (rc)
+			return rc;
+		pl = st->pl;
 	}
 	mdb_part_result px[GC_MAX_EXTRA];
 	memset(px, 0, sizeof(px));
@@ -2041,7 +2067,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		ctx->lg_valid = true;
 	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
-	ctx->last_semijoin = (int)st->semijoin | (st->defer_l ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0);
+	ctx->last_semijoin = (int)st->semijoin | ((st->defer_l || st->defer_l64) ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0);
 	return MIDORIDB_OK;
 }
 
@@ -2245,6 +2271,15 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 		win->prunable = false;
 		win->r_based = false;
 	}
+	if (ctx->narrow_mode == 0 && n_l && keys_r && n_r && prune_ok && win && n_l + n_r >= GC_NARROW_MIN_ROWS) {
+		/* the narrow forms are switched off, min-max pruning is not: what the key sample says about the two tables' ranges */
+		int64_t lo = 0, hi = 0;
+		const int src = gc_sample_range(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, false, &lo, &hi, keys32);
+		if (src)
+			return src;
+		win->by_span = ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r < ctx->sr_span_l / 4;
+		win->prunable = ctx->sr_span_l && ctx->sr_span_r && ctx->sr_span_r / 7 < ctx->sr_span_l / 8;
+	}
 	if (ctx->narrow_mode == 0 || n_l == 0)
 		return MIDORIDB_OK;
 	if (ctx->narrow_mode == 2) {
@@ -2271,6 +2306,9 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 			win->by_span = ctx->nh_by_span;
 			win->prunable = ctx->nh_prunable;
 			win->r_based = ctx->nh_r_based;
+		} else if (win) {	/* (the 64-bit form prunes by the key range as well) */
+			win->by_span = ctx->nh_by_span;
+			win->prunable = ctx->nh_prunable;
 		}
 		return MIDORIDB_OK;
 	}

@@ -172,6 +172,7 @@ __device__ static inline unsigned long long lw_block_sum(unsigned long long v, u
  * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
  * key - window base (min-max pruning, while it runs) */
 #define GC_ST_MINMAX 16
+#define GC_ST_MINMAX64 40	/* [40..43] the right table's smallest / largest key as two signed 64-bit words (min-max pruning, 64-bit form) */
 #define GC_ST_WINDOW 20	/* [20..21] 0 and 2^key_bits - 1: the whole window as a pruning range (further right tables drop what lies outside) */
 #define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
 #define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */

@@ -89,6 +89,11 @@ struct mdb_level_args {
 	 * nothing.  Exact, and free: one compare per row, no extra pass, no host round trip */
 	uint32_t *minmax_out;
 	const uint32_t *range_in;
+	/* the same for the 64-bit form (keys that fit no 2^32 window: hashes, snowflake ids - R64 instances): per-tile pairs of the
+	 * smallest / largest key as order-preserving unsigned images (key ^ 2^63; the largest stored inverted) / the other table's
+	 * range [lo, hi] as two signed keys in device memory */
+	unsigned long long *minmax64_out;
+	const long long *range64_in;
 	/* first level: rows whose key lies outside [keep_lo, keep_hi] are dropped (keep_on; partition by destination: the other
 	 * table's global key range is known before the exchange - nothing outside it can join on any GPU) */
 	uint32_t keep_on;
@@ -195,7 +200,8 @@ template <bool LEVEL0, bool HAS_RID, bool RAW = false, bool INV = false, bool KE
 __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile_desc &td, uint32_t p, uint64_t hv[2],
 					 uint32_t rid[2], bool valid[2], uint64_t *rel = nullptr /* [2]: key - narrow_base (narrow forms) */,
 					 const ulonglong2 *pre = nullptr /* the pair, already loaded (full, 16-byte aligned tiles: the caller
-									  * issues a tile's loads together - see part_preload2) */)
+									  * issues a tile's loads together - see part_preload2) */,
+					 int64_t *raw_out = nullptr /* [2]: the keys themselves (level 0; the 64-bit form's key-range tests) */)
 {
 	const uint32_t lead = td.start & 1u;
 	const uint64_t base2 = (uint64_t)(td.start - lead);
@@ -252,6 +258,10 @@ __device__ static inline void part_load2(const mdb_level_args &a, const mdb_tile
 			if (HAS_RID)
 				rid[k] = a.rid_in[g];
 		}
+	}
+	if (LEVEL0 && raw_out) {
+		raw_out[0] = raw_key[0];
+		raw_out[1] = raw_key[1];
 	}
 	if (LEVEL0 && a.nullbits) {
 		if (valid[0] && mdb_bit_is_set(a.nullbits, g0))
@@ -418,7 +428,7 @@ __device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulongl
  * The struct's name is what a profiler shows as the kernel's template argument. */
 struct pf_base {
 	static constexpr bool LEVEL0 = false, HAS_RID = false, STABLE = false, FAST = false, RAW = false, W32 = false, INV = false, FILT = false,
-			      OUT16 = false, CF = false;
+			      OUT16 = false, CF = false, R64 = false, MM64 = false;
 };
 struct pf_word_hist : pf_base {  };
 struct pf_word_hist_raw : pf_base { static constexpr bool RAW = true; };
@@ -443,12 +453,16 @@ struct pf_key_rid_hist : pf_base { static constexpr bool LEVEL0 = true; static c
 struct pf_key_rid_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool INV = true; };
 struct pf_key_rid : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; };
 struct pf_key_rid_stable_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool STABLE = true; };
+/* min-max pruning in the 64-bit form: the right table's first level records its key range (mm64), the left table's drops the rows outside (r64) */
+struct pf_key_mm64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool MM64 = true; };
+struct pf_key_rid_r64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; static constexpr bool R64 = true; };
 
 template <typename F /* one of the pf_* structs above */>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
 	constexpr bool LEVEL0 = F::LEVEL0, HAS_RID = F::HAS_RID, STABLE = F::STABLE, FAST = F::FAST, RAW = F::RAW, W32 = F::W32, INV = F::INV, FILT = F::FILT,
-		       OUT16 = F::OUT16, CF = F::CF;
+		       OUT16 = F::OUT16, CF = F::CF, R64 = F::R64, MM64 = F::MM64;
+	static_assert(!(R64 || MM64) || (LEVEL0 && FAST && !RAW && !INV && !W32 && !CF && !STABLE), "64-bit key range: first level of the 64-bit form only");
 	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
 	static_assert(!OUT16 || (W32 && !RAW), "2-byte words out: the 4-byte form only");
 	static_assert(!FILT || (!LEVEL0 && !HAS_RID && !STABLE && FAST && !RAW && !W32 && !INV), "semi-join filter: second level of the narrow left side only");
@@ -491,6 +505,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	if (LEVEL0 && a.range_in) {
 		range_lo = a.range_in[0];
 		range_hi = a.range_in[1];
+	}
+	/* 64-bit form: the keys' order-preserving unsigned images (key ^ 2^63) */
+	uint64_t seen_min64 = ~0ull, seen_max64 = 0ull, r64_lo = 0ull, r64_hi = ~0ull;
+	uint64_t *const s_mm64 = reinterpret_cast<uint64_t *>(s_delta);	/* (2 x PART_WAVES words of a buffer that step 3 fills later) */
+	if (R64 && a.range64_in) {	/* the other table's key range, left there by its own first level earlier on this stream */
+		r64_lo = (uint64_t)a.range64_in[0] ^ 0x8000000000000000ull;
+		r64_hi = (uint64_t)a.range64_in[1] ^ 0x8000000000000000ull;
 	}
 	/* the filter slice of this tile's first-level digit lives in the staging buffer until the rows are ranked (the
 	 * barrier after the load separates its last read from the first staged word) */
@@ -583,12 +604,29 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			uint64_t rel2[2] = { 0, 0 };
 			/* (the key-range tests of the by-destination partition are compiled into its own instance only: as run-time
 			 * branches they cost the join's first-level kernels 0.05 ms per 10^8 rows) */
+			int64_t raw2[2] = { 0, 0 };
 			if (full)
 				part_load2<LEVEL0, HAS_RID, RAW, INV, INV, CF, !W32>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid,
-										     RANGE ? rel2 : nullptr, &pre[r]);
+										     RANGE ? rel2 : nullptr, &pre[r], (R64 || MM64) ? raw2 : nullptr);
 			else
 				part_load2<LEVEL0, HAS_RID, RAW, INV, INV, CF, !W32>(a, td, (uint32_t)r * PART_THREADS + threadIdx.x, h2, &rid[2 * r], valid,
-										     RANGE ? rel2 : nullptr);
+										     RANGE ? rel2 : nullptr, nullptr, (R64 || MM64) ? raw2 : nullptr);
+			if (R64 || MM64) {	/* (order-preserving unsigned images) */
+				rel2[0] = (uint64_t)raw2[0] ^ 0x8000000000000000ull;
+				rel2[1] = (uint64_t)raw2[1] ^ 0x8000000000000000ull;
+			}
+			if (R64) {
+				valid[0] = valid[0] && rel2[0] >= r64_lo && rel2[0] <= r64_hi;
+				valid[1] = valid[1] && rel2[1] >= r64_lo && rel2[1] <= r64_hi;
+			}
+			if (MM64) {
+#pragma unroll
+				for (int k = 0; k < 2; k++)
+					if (valid[k]) {
+						seen_min64 = rel2[k] < seen_min64 ? rel2[k] : seen_min64;
+						seen_max64 = rel2[k] > seen_max64 ? rel2[k] : seen_max64;
+					}
+			}
 			if (RANGE && a.range_in) {		/* (uniform) */
 				valid[0] = valid[0] && rel2[0] >= range_lo && rel2[0] <= range_hi;
 				valid[1] = valid[1] && rel2[1] >= range_lo && rel2[1] <= range_hi;
@@ -626,7 +664,31 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			s_mm[2 * wave + 1] = seen_max;
 		}
 	}
+	if (MM64) {
+#pragma unroll
+		for (int o = MDB_WAVE / 2; o > 0; o >>= 1) {
+			const uint64_t omin = ((uint64_t)(uint32_t)__shfl_xor((int)(seen_min64 >> 32), o, MDB_WAVE) << 32) | (uint32_t)__shfl_xor((int)seen_min64, o, MDB_WAVE);
+			const uint64_t omax = ((uint64_t)(uint32_t)__shfl_xor((int)(seen_max64 >> 32), o, MDB_WAVE) << 32) | (uint32_t)__shfl_xor((int)seen_max64, o, MDB_WAVE);
+			seen_min64 = omin < seen_min64 ? omin : seen_min64;
+			seen_max64 = omax > seen_max64 ? omax : seen_max64;
+		}
+		if (lane == 0) {
+			s_mm64[2 * wave] = seen_min64;
+			s_mm64[2 * wave + 1] = seen_max64;
+		}
+	}
 	__syncthreads();
+	if (MM64 && threadIdx.x == 0) {
+		uint64_t mn = ~0ull, mx = 0ull;
+#pragma unroll
+		for (int w = 0; w < PART_WAVES; w++) {
+			mn = s_mm64[2 * w] < mn ? s_mm64[2 * w] : mn;
+			mx = s_mm64[2 * w + 1] > mx ? s_mm64[2 * w + 1] : mx;
+		}
+		const uint32_t t = part_tile_of_block();
+		a.minmax64_out[2 * t] = mn;
+		a.minmax64_out[2 * t + 1] = ~mx;	/* (stored inverted: the array is initialised with one memset of 0xFF) */
+	}
 	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_out && threadIdx.x == 0) {
 		/* one pair of plain stores per tile, reduced by k_part_minmax_reduce: atomics on two words from every wave of every
 		 * tile (2 x 10^5 of them on the same address) cost 4 ms, coherent loads of "the best so far" 0.2 ms */
@@ -948,6 +1010,37 @@ __global__ void k_part_seg0(uint32_t *seg_start, uint32_t *tb, uint32_t n, uint3
 	}
 }
 
+/* the same for the 64-bit form: per-tile pairs of order-preserving images -> [lo, hi] as signed keys (an empty table: lo > hi) */
+__global__ __launch_bounds__(1024) void k_part_minmax64_reduce(const unsigned long long *__restrict__ tile_mm, uint32_t ntiles, long long *__restrict__ out)
+{
+	__shared__ unsigned long long s_mn[16], s_mx[16];
+	unsigned long long mn = ~0ull, mx = 0ull;
+	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+		const unsigned long long a = tile_mm[2 * t], b = ~tile_mm[2 * t + 1];
+		mn = a < mn ? a : mn;
+		mx = b > mx ? b : mx;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const unsigned long long omn = ((unsigned long long)(uint32_t)__shfl_xor((int)(mn >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)mn, o, 64);
+		const unsigned long long omx = ((unsigned long long)(uint32_t)__shfl_xor((int)(mx >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)mx, o, 64);
+		mn = omn < mn ? omn : mn;
+		mx = omx > mx ? omx : mx;
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		s_mn[threadIdx.x >> 6] = mn;
+		s_mx[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 16; w++) {
+			mn = s_mn[w] < mn ? s_mn[w] : mn;
+			mx = s_mx[w] > mx ? s_mx[w] : mx;
+		}
+		out[0] = (long long)(mn ^ 0x8000000000000000ull);	/* (no key at all: lo = INT64_MAX > hi = INT64_MIN - every left row is dropped) */
+		out[1] = (long long)(mx ^ 0x8000000000000000ull);
+	}
+}
+
 /* per-tile (min, max) pairs of the right table's first level -> the two words the left table's first level reads */
 __global__ __launch_bounds__(1024) void k_part_minmax_reduce(const uint32_t *__restrict__ tile_mm, uint32_t ntiles, uint32_t *__restrict__ out)
 {
@@ -1136,6 +1229,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keep_hi = flt ? flt->keep_hi : 0;
 		a.minmax_out = (flt && l == 0 && flt->minmax_out) ? flt->minmax_tiles : NULL;	/* per-tile pairs, reduced after the launch */
 		a.range_in = (flt && l == 0) ? flt->range_in : NULL;
+		a.minmax64_out = (flt && l == 0 && flt->minmax64_out) ? flt->minmax64_tiles : NULL;
+		a.range64_in = (flt && l == 0) ? flt->range64_in : NULL;
 		a.filter = (flt && l == 1) ? flt->bits : NULL;
 		a.filter_words = flt ? flt->words : 0u;
 		a.filter_shift = flt ? flt->shift : 0u;
@@ -1191,8 +1286,15 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					}
 					if (a.minmax_out)
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
+				} else if (want_rid && a.range64_in) {	/* 64-bit form, left table, min-max pruning */
+					MDB_LAUNCH(ctx, "part_scatter_l0_rid_pruned", (k_part_scatter<pf_key_rid_r64>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<pf_key_rid>), grid8(ntiles), PART_THREADS, a);
+				} else if (a.minmax64_out) {		/* 64-bit form, right table: its key range recorded */
+					MDB_HIP(ctx, hipMemsetAsync(a.minmax64_out, 0xFF, (size_t)grid8(ntiles) * 16, ctx->stream));
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_mm64>), grid8(ntiles), PART_THREADS, a);
+					MDB_LAUNCH(ctx, "part_minmax", k_part_minmax64_reduce, 1, 1024, (const unsigned long long *)a.minmax64_out, grid8(ntiles),
+						   flt->minmax64_out);
 				} else if (a.range_in && cf) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
 					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key_cf>),
 						   grid8(ntiles), PART_THREADS, a);
@@ -1226,7 +1328,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				return MIDORIDB_OK;
 			}
 			uint32_t real_tiles = next_tiles;
-			if (!dry && flt && flt->range_in && flt->expect_pruned) {
+			if (!dry && flt && (flt->range_in || flt->range64_in) && flt->expect_pruned) {
 				/* min-max pruning may have dropped most rows: the second level is launched for the tiles that exist (one
 				 * 4-byte read-back and a synchronisation, ~15 us) - 26 000 workgroups that find an empty descriptor and leave
 				 * cost 0.09 ms at 10^8 rows */
@@ -1396,6 +1498,9 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	if (flt && (flt->minmax_out || flt->range_in) && (!narrow || want_rid || stable || !fast || (bits2 <= 0 && !stop0) ||
 							  (flt->minmax_out && (narrow != 2 || !flt->minmax_tiles))))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning: narrow forms, two fast levels");
+	if (flt && (flt->minmax64_out || flt->range64_in) && (narrow || stable || !fast || bits2 <= 0 || (flt->minmax64_out && (want_rid || !flt->minmax64_tiles)) ||
+							      (flt->range64_in && !want_rid)))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning, 64-bit form: two fast levels, the right table without and the left with row ids");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))
