@@ -42,7 +42,7 @@ def timed(dev, fn, reps=5, warmup=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "operators.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "operators.json"))
     ap.add_argument("--configs1", action="store_true", help="only the two BASELINE configs[0..1] shapes (scan_filter_1e8, join_payload_1e7): "
                                                              "what profiles/collect.sh runs under rocprofv3")
     args = ap.parse_args()
@@ -93,12 +93,28 @@ def main():
         lid = None if dev.last_pairs_identity() else l
         dev.gather_cols([(a_id, None, lid), (a_f, None, lid), (b_f, None, r)], j)
         return j
-    ms, kern, j = timed(dev, join_payload, reps=3, warmup=1)
+    ms_pairs, kern_pairs, j = timed(dev, join_payload, reps=3, warmup=1)
     algo = 8 * 2 * n2 + 8 * 2 * n2 + 8 * 4 * j      # keys + payload columns read once, 4 result columns written
+
+    def join_payload_carried():
+        # the executor's plan since round 4 (mdb_exec.c: join_with_payload): every left row has its one partner, so B's payload cell
+        # travels through B's one partition level and lands at the left row's place - no partner row ids, no compaction, no random
+        # gather; A's columns are read as they stand (copied: the result owns its columns), B's key column is A's
+        out = dev.join_payload(a_id, None, b_id, None, [b_f])
+        if out is None:
+            return join_payload()
+        dev.gather_cols([(a_id, None, None), (a_f, None, None)], n2)
+        return n2
+    ms, kern, j = timed(dev, join_payload_carried, reps=3, warmup=1)
     res["join_payload_1e7"] = {"rows_per_table": n2, "joined_rows": j, "ms": ms, "joined_rows_per_s": j / (ms * 1e-3),
-                               "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "kernels_ms": kern,
-                               "note": "mdb_dev_join_pairs (pairs in the reference's (l, r) order) + the projection in one launch "
-                                       "(mdb_dev_gather_cols): 3 gathers for the 4 result columns - the right key column is the left one"}
+                               "algorithmic_bytes": algo, "algorithmic_GBs": algo / (ms * 1e-3) / 1e9, "frac_of_peak": algo / (ms * 1e-3) / 1e9 / 8000.0,
+                               "kernels_ms": kern,
+                               "note": "mdb_dev_join_payload: the right table's payload cell carried through its one partition level and written at "
+                                       "the left row's place (every left row has its one partner: verified on the device) + the copies of A's "
+                                       "two columns into the result; B's key column is A's",
+                               "pairs_path": {"ms": ms_pairs, "kernels_ms": kern_pairs,
+                                              "note": "round 3's plan: mdb_dev_join_pairs (pairs in the reference's (l, r) order) + the projection in "
+                                                      "one launch (mdb_dev_gather_cols): 3 gathers for the 4 result columns"}}
 
     def join_payload4():
         l, r = dev.join_pairs(a_id, None, b_id, None)

@@ -302,6 +302,18 @@ int mdb_dev_join_pairs(mdb_dev_ctx *ctx,
 int mdb_dev_join_keys(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 		      const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows);
 
+/* The join of a foreign key to a primary key with the right table's payload: when EVERY left row has exactly one partner (unique
+ * right keys, referential integrity - verified on the device, not assumed) the joined rows are the left rows in their own order,
+ * and all a projection needs of the right table are its payload cells in that order.  Up to two 8-byte payload columns of the
+ * right table (pay_in[c]: n_r cells each, no NULL bitmap) travel through its one partition level beside the key and are written to
+ * out[c][i] = cell of left row i's partner (caller buffers of n_l cells) - instead of a scatter of partner row ids, a compaction and a
+ * random 8-byte gather per cell (BASELINE configs[1], 10^7 x 10^7 rows, SELECT *: 0.58 -> 0.4 ms).  Returns MIDORIDB_OK when served;
+ * 1 when it is not such a join - a left row without partner (NULL keys included), duplicate right keys, keys outside every 2^24-value
+ * window, fewer than 2^20 rows in all: nothing usable was written, mdb_dev_join_pairs answers - or a negative error code.  Synchronises.
+ * (reference: _join_nested_loop_tbl2tbl + cpy_cols / _merge_rows, src/engine/executor_select.c:1076-1149, 340-438) */
+int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+			 const uint64_t *null_r, uint64_t n_r, const void *const *pay_in, int npay, void *const *out);
+
 /* Cross join (FROM A, B  ==  JOIN ... ON 1=1, reference optimiser_select.c:395-464):
  * all n_l * n_r pairs in (l, r) order, into caller buffers of that capacity. */
 int mdb_dev_cross_pairs(mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint32_t *out_l, uint32_t *out_r);

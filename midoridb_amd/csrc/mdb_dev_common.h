@@ -57,6 +57,9 @@ struct mdb_col_memo {
 	int ex_uses;
 	const void *pw_bad_keys;	/* right key column (and row count) the one-level unique-key join (join_pairs_unique_wide) gave up on */
 	uint64_t pw_bad_n;
+	const void *jp_bad_l, *jp_bad_r;	/* key columns mdb_dev_join_payload found not to be an every-left-row-has-its-partner join */
+	uint64_t jp_bad_nl, jp_bad_nr;
+	int jp_bad_skips;
 	const void *pu_dup_keys;	/* right key column that the unique-key join found duplicates in (not tried again) */
 	uint64_t pu_dup_n;
 	const void *pu_dupl_keys;	/* ... and the left key column that did (both: a true N:M join, the general path) */

@@ -45,6 +45,7 @@ struct mdb_part_result {
 	uint32_t bits_total;
 	bool w32;		/* hv holds 4-byte words (narrow form without row ids) */
 	bool w16;		/* ... 2-byte words: the hash bits below the first level's digit (mdb_part_filter.out16) */
+	uint64_t *pay[2];	/* first level only, mdb_part_filter.npay: the payload cells, laid out like hv (the cell of hv[i] is pay[c][i]) */
 	uint32_t nsub;		/* != 0: first level only (mdb_part_filter.level0_only) - nleaves = 2^bits1 digits, digit d's rows lie in nsub
 				 * regions: region r = d * nsub + s at [r * leaf_cap, r * leaf_cap + min(count, leaf_cap)), its count at
 				 * leaf_cnt[s * nleaves + d] */
@@ -82,6 +83,10 @@ struct mdb_part_filter {
 	long long *minmax64_out;
 	unsigned long long *minmax64_tiles;
 	const long long *range64_in;
+	/* level0_only, narrow = 1 (hash | row id words): up to two 8-byte payload columns of the table travel with the rows
+	 * (mdb_part_result.pay) - a join that carries the right table's payload to the leaf instead of gathering it afterwards */
+	const void *pay_in[2];
+	int npay;
 	/* first level, any form: keep only the rows whose KEY lies in [keep_lo, keep_hi] (keep_on) - the other table's global key
 	 * range, known before an exchange (mdb_dev_partition_by_dest_pruned) */
 	bool keep_on;
@@ -111,7 +116,7 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 									 * compact narrow form only), see struct mdb_part_filter */
 
 /* arena bytes of a first-level-only partition (mdb_part_filter.level0_only) of n rows by bits1 bits */
-size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose = false /* mdb_part_filter.loose */);
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose = false /* mdb_part_filter.loose */, int npay = 0 /* mdb_part_filter.npay */);
 
 /* whether narrow = 2 is available for a table of n rows */
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);

@@ -790,6 +790,270 @@ static int join_pairs_unique_wide(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	return 0;
 }
 
+/* ------------------------------------------------------------------ the same join when EVERY left row has its one partner, with the
+ * right table's payload carried to the leaf (BASELINE configs[1]: A(id_a, f1) JOIN B(id_b, f2) on primary keys, SELECT *)
+ *
+ * Through mdb_dev_join_pairs + the projection, B's payload column is a random gather through the right row ids: 10^7 8-byte
+ * reads that each move a 128-byte line (PMC: 1.87 GB read for 0.32 GB algorithmic, 0.22 of the 0.58 ms), after a 4-byte scatter
+ * of the partners (0.34 GB written for 0.04).  Here up to two payload cells of the right table travel through its ONE partition
+ * level beside the word (k_part_scatter<pf_key_cf_pay>: read in row order, written in region order - both sequential), the
+ * leaf's LDS table holds the right row's PLACE in the digit's regions instead of its row id, and a left row that finds its
+ * partner copies the cells from there (the digit's regions: lines the workgroup has just streamed) to out[left row id] - the one
+ * scattered access left, an 8-byte store per cell.  When every left row found a partner (referential integrity: counted, not
+ * assumed) the outputs ARE the joined rows' payload columns in left-row order, no row ids exist and nothing is compacted;
+ * otherwise the call says "not served" and the pairs path answers.  (reference: _join_nested_loop_tbl2tbl + cpy_cols/merge_rows,
+ * executor_select.c:1076-1149, 340-438) */
+struct pp_args {
+	const uint64_t *hv_l, *hv_r;
+	const uint64_t *pay_r[2];
+	uint64_t *out[2];
+	uint32_t npay;
+	const uint32_t *cnt_l, *cnt_r;
+	uint32_t cap_l, cap_r, nleaves, nsub;
+	unsigned long long *joined;
+	uint32_t *status;
+};
+
+/* a digit's rows lie in nsub sub-regions: walked one after the other, every region is a round of its own - load, look up, load, store,
+ * each waiting for the one before (8 rounds of mostly idle threads per digit: the kernel took 0.31 ms where its streams need 0.06).
+ * Here the sub-regions' 16-byte chunks (pairs of words) form ONE list: pstart[s] = chunks before sub-region s, pstart[nsub] = all */
+#define PP_MAX_SUB 8
+__device__ static inline void pp_locate(const uint32_t *pstart, uint32_t nsub, uint32_t p, uint32_t *sub, uint32_t *i)
+{
+	uint32_t s = 0;
+#pragma unroll
+	for (uint32_t k = 1; k < PP_MAX_SUB; k++)
+		s += (k < nsub && p >= pstart[k]) ? 1u : 0u;
+	*sub = s;
+	*i = 2u * (p - pstart[s]);
+}
+
+template <typename E /* table entry: the partner's place among the digit's regions + 1 (uint16_t when nsub * cap_r < 2^16: 64 KiB of LDS at
+		       * 2^15 entries, two workgroups per CU - the phases of one overlap the other's) */>
+__global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_payload(pp_args a, uint32_t rem, uint32_t shift)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t pp_lds[];
+	E *const tab = reinterpret_cast<E *>(pp_lds);
+	__shared__ unsigned long long s_red[PW_THREADS / 64];
+	__shared__ uint32_t s_cnt[2][PP_MAX_SUB], s_pstart[2][PP_MAX_SUB + 1];
+	const uint32_t T = 1u << rem, mask = T - 1u, leaf = blockIdx.x;
+	for (uint32_t s = threadIdx.x; s < T * sizeof(E) / 4u; s += PW_THREADS)
+		pp_lds[s] = 0u;
+	if (threadIdx.x < 2u * PP_MAX_SUB) {
+		const uint32_t side = threadIdx.x / PP_MAX_SUB, sub = threadIdx.x % PP_MAX_SUB;
+		uint32_t c = 0;
+		if (sub < a.nsub) {
+			c = side ? a.cnt_r[sub * a.nleaves + leaf] : a.cnt_l[sub * a.nleaves + leaf];
+			const uint32_t cap = side ? a.cap_r : a.cap_l;
+			c = c < cap ? c : cap;
+		}
+		s_cnt[side][sub] = c;
+	}
+	__syncthreads();
+	if (threadIdx.x < 2u) {
+		uint32_t run = 0;
+		for (uint32_t k = 0; k < PP_MAX_SUB; k++) {
+			s_pstart[threadIdx.x][k] = run;
+			run += (s_cnt[threadIdx.x][k] + 1u) >> 1;
+		}
+		s_pstart[threadIdx.x][PP_MAX_SUB] = run;
+	}
+	__syncthreads();
+	/* ---- the right table: every row's place into the table */
+	uint32_t rows_r = 0;
+	for (uint32_t k = 0; k < a.nsub; k++)
+		rows_r += s_cnt[1][k];
+	{
+		const uint32_t P = s_pstart[1][PP_MAX_SUB];
+		for (uint32_t p0 = 0; p0 < P; p0 += PW_THREADS * PW_UNROLL) {	/* uniform trip count */
+			ulonglong2 v[PW_UNROLL];
+			uint32_t place[PW_UNROLL], left_in_sub[PW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t p = p0 + (uint32_t)u * PW_THREADS + threadIdx.x, pc = p < P ? p : P - 1u;
+				uint32_t sub, i;
+				pp_locate(s_pstart[1], a.nsub, pc, &sub, &i);
+				v[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_r + (size_t)(leaf * a.nsub + sub) * a.cap_r + i);
+				place[u] = sub * a.cap_r + i + 1u;
+				left_in_sub[u] = p < P ? s_cnt[1][sub] - i : 0u;	/* rows of the chunk that exist: 0, 1 or 2+ */
+			}
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				if (left_in_sub[u] >= 1u)
+					tab[((uint32_t)(v[u].x >> 32) >> shift) & mask] = (E)place[u];
+				if (left_in_sub[u] >= 2u)
+					tab[((uint32_t)(v[u].y >> 32) >> shift) & mask] = (E)(place[u] + 1u);
+			}
+		}
+	}
+	__syncthreads();
+	unsigned long long occupied = 0;
+	for (uint32_t s = threadIdx.x; s < T; s += PW_THREADS)
+		occupied += tab[s] != 0;
+	occupied = lw_block_sum(occupied, s_red);
+	if (occupied != rows_r) {	/* a right key occurs twice */
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 32u);
+		return;
+	}
+	/* ---- the left table: partner's place -> its cells -> out[left row id] */
+	const size_t base_r = (size_t)leaf * a.nsub * a.cap_r;
+	unsigned long long pairs = 0;
+	{
+		const uint32_t P = s_pstart[0][PP_MAX_SUB];
+		for (uint32_t p0 = 0; p0 < P; p0 += PW_THREADS * PW_UNROLL) {
+			ulonglong2 v[PW_UNROLL];
+			uint32_t have[PW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				const uint32_t p = p0 + (uint32_t)u * PW_THREADS + threadIdx.x, pc = p < P ? p : P - 1u;
+				uint32_t sub, i;
+				pp_locate(s_pstart[0], a.nsub, pc, &sub, &i);
+				v[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_l + (size_t)(leaf * a.nsub + sub) * a.cap_l + i);
+				have[u] = p < P ? s_cnt[0][sub] - i : 0u;
+			}
+			/* the partners' places first, then their cells (loads in flight together; a row without partner reads the digit's first
+			 * cell: a load behind a per-row test is waited for before the next one is issued), then the stores */
+			uint32_t e[2 * PW_UNROLL];
+			uint64_t cell[2][2 * PW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < PW_UNROLL; u++) {
+				e[2 * u] = have[u] >= 1u ? (uint32_t)tab[((uint32_t)(v[u].x >> 32) >> shift) & mask] : 0u;
+				e[2 * u + 1] = have[u] >= 2u ? (uint32_t)tab[((uint32_t)(v[u].y >> 32) >> shift) & mask] : 0u;
+			}
+#pragma unroll
+			for (int q = 0; q < 2 * PW_UNROLL; q++)
+				cell[0][q] = a.pay_r[0][base_r + (e[q] ? e[q] - 1u : 0u)];
+			if (a.npay > 1u) {	/* (uniform) */
+#pragma unroll
+				for (int q = 0; q < 2 * PW_UNROLL; q++)
+					cell[1][q] = a.pay_r[1][base_r + (e[q] ? e[q] - 1u : 0u)];
+			}
+#pragma unroll
+			for (int q = 0; q < 2 * PW_UNROLL; q++)
+				if (e[q]) {
+					const uint32_t lrid = (uint32_t)((q & 1) ? v[q >> 1].y : v[q >> 1].x);
+					a.out[0][lrid] = cell[0][q];
+					if (a.npay > 1u)
+						a.out[1][lrid] = cell[1][q];
+					pairs++;
+				}
+		}
+	}
+	pairs = lw_block_sum(pairs, s_red);
+	if (threadIdx.x == 0 && pairs)
+		atomicAdd(a.joined, pairs);
+}
+
+/* 0 = done: every one of the n_l left rows has its partner and out[c][i] = payload cell c of left row i's partner;
+ * 1 = not served (some left row without a partner - NULL keys included -, duplicate right keys, no compact window of at most 2^24
+ * values, a region overflow ...: mdb_dev_join_pairs answers); < 0 = error.  Synchronises. */
+extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+				    const uint64_t *null_r, uint64_t n_r, const void *const *pay_in, int npay, void *const *out)
+{
+	if (!ctx || !keys_l || !keys_r || !pay_in || !out || npay < 1 || npay > 2)
+		return -MIDORIDB_ERROR;
+	for (int c = 0; c < npay; c++)
+		if (!pay_in[c] || !out[c])
+			return -MIDORIDB_ERROR;
+	if (n_l == 0 || n_r == 0 || n_l >= 0xFFFFFFFFull || n_r >= 0xFFFFFFFFull || n_l + n_r < (1ull << 20) || ld_disabled() ||
+	    (getenv("MDB_JOIN_PAYLOAD") && getenv("MDB_JOIN_PAYLOAD")[0] == '0'))
+		return 1;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
+	if (ctx->jp_bad_l == keys_l && ctx->jp_bad_nl == n_l && ctx->jp_bad_r == keys_r && ctx->jp_bad_nr == n_r && ++ctx->jp_bad_skips < 32)
+		return 1;	/* (these columns were not such a join last time: not tried again for a while) */
+	for (int attempt = 0; attempt < 2; attempt++) {
+	bool narrow = false;
+	int64_t base = 0;
+	gc_window win = { 0, 0, false, false, false, false };
+	int rc = gc_narrow_guess(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, &narrow, &base, &win);
+	if (rc)
+		return rc;
+	const bool remembered = ctx->guess_remembered;
+	if (!narrow || !win.kbits || win.kbits > 9u + PW_MAX_REM)
+		return 1;
+	const int b1 = 9;
+	/* (a dimension table of a few thousand keys: the window may be wider than its keys need) */
+	const uint32_t kbits = win.kbits < 9u + PW_MIN_REM ? 9u + PW_MIN_REM : win.kbits, rem = kbits - (uint32_t)b1, shift = 32u - kbits;
+	rc = mdb_arena_begin(ctx, mdb_partition_level0_arena_bytes(n_l, b1) + mdb_partition_level0_arena_bytes(n_r, b1, false, npay) + 8192);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	mdb_part_filter flt, rflt;
+	memset(&flt, 0, sizeof(flt));
+	flt.level0_only = true;
+	rflt = flt;
+	rflt.npay = npay;
+	for (int c = 0; c < npay; c++)
+		rflt.pay_in[c] = pay_in[c];
+	mdb_part_result pl, pr;
+	memset(&pl, 0, sizeof(pl));
+	memset(&pr, 0, sizeof(pr));
+	rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, 0, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
+	if (rc)
+		return rc;
+	rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, 0, false, false, true, &pl, 1, false, win.lo, kbits, &flt);
+	if (rc)
+		return rc;
+	if (!pl.nsub || pl.nsub != pr.nsub || pl.nleaves != pr.nleaves || pl.w32 || pr.w32 || !pr.pay[0] || (npay > 1 && !pr.pay[1]))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: the tables are not in the first-level layout");
+	pp_args a;
+	memset(&a, 0, sizeof(a));
+	a.hv_l = pl.hv;
+	a.hv_r = pr.hv;
+	a.npay = (uint32_t)npay;
+	for (int c = 0; c < npay; c++) {
+		a.pay_r[c] = pr.pay[c];
+		a.out[c] = reinterpret_cast<uint64_t *>(out[c]);
+	}
+	a.cnt_l = pl.leaf_cnt;
+	a.cnt_r = pr.leaf_cnt;
+	a.cap_l = pl.leaf_cap;
+	a.cap_r = pr.leaf_cap;
+	a.nleaves = pl.nleaves;
+	a.nsub = pl.nsub;
+	a.joined = (unsigned long long *)(ctx->d_status + 2);
+	a.status = ctx->d_status;
+	if (pl.nsub > PP_MAX_SUB)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: %u sub-regions per digit", pl.nsub);
+	if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(getenv("MDB_PP_E16") && getenv("MDB_PP_E16")[0] == '0')) {
+		const size_t lds = (size_t)2 << rem;
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_payload<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_payload<uint16_t>, pl.nleaves, PW_THREADS, lds, a, rem, shift);
+	} else {
+		const size_t lds = (size_t)4 << rem;
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_payload<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_payload<uint32_t>, pl.nleaves, PW_THREADS, lds, a, rem, shift);
+	}
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t status = (uint32_t)h[1];
+	const uint64_t J = h[2];
+	if (status == 0 && J == n_l)
+		return MIDORIDB_OK;
+	if ((status & 128u) && remembered && attempt == 0) {
+		/* a REMEMBERED window proved wrong: the buffers hold other data than when it was learned (a caller's allocator handed the
+		 * same addresses out again) - forget, look at the data itself, once more */
+		ctx->nh_result = -1;
+		ctx->sr_valid = 0;
+		ctx->nh_distrust = 1;
+		continue;
+	}
+	if (status & 128u) {	/* a key outside the window after all: the sample is not trusted for a while */
+		ctx->nh_distrust = 8;
+	} else {
+		ctx->jp_bad_l = keys_l;
+		ctx->jp_bad_nl = n_l;
+		ctx->jp_bad_r = keys_r;
+		ctx->jp_bad_nr = n_r;
+		ctx->jp_bad_skips = 0;
+	}
+	return 1;
+	}
+	return 1;
+}
+
 #define SORT_SWAP_MIN_ROWS (1u << 18)
 
 /* ------------------------------------------------------------------ tiny materialising join: one kernel, one workgroup

@@ -94,6 +94,11 @@ struct mdb_level_args {
 	 * range [lo, hi] as two signed keys in device memory */
 	unsigned long long *minmax64_out;
 	const long long *range64_in;
+	/* PAY instance (first level of a join that carries payload cells through its one partition level): up to two 8-byte columns of
+	 * the table, read at the row's own index and written at the row's place in the regions, beside its word */
+	const uint64_t *pay_in[2];
+	uint64_t *pay_out[2];
+	uint32_t npay;
 	/* first level: rows whose key lies outside [keep_lo, keep_hi] are dropped (keep_on; partition by destination: the other
 	 * table's global key range is known before the exchange - nothing outside it can join on any GPU) */
 	uint32_t keep_on;
@@ -428,7 +433,7 @@ __device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulongl
  * The struct's name is what a profiler shows as the kernel's template argument. */
 struct pf_base {
 	static constexpr bool LEVEL0 = false, HAS_RID = false, STABLE = false, FAST = false, RAW = false, W32 = false, INV = false, FILT = false,
-			      OUT16 = false, CF = false, R64 = false, MM64 = false;
+			      OUT16 = false, CF = false, R64 = false, MM64 = false, PAY = false;
 };
 struct pf_word_hist : pf_base {  };
 struct pf_word_hist_raw : pf_base { static constexpr bool RAW = true; };
@@ -449,6 +454,7 @@ struct pf_key_w32 : pf_base { static constexpr bool LEVEL0 = true; static conste
 struct pf_key_w32_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool CF = true; };
 struct pf_key_w32_out16 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; };
 struct pf_key_w32_out16_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; static constexpr bool CF = true; };
+struct pf_key_cf_pay : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool CF = true; static constexpr bool PAY = true; };
 struct pf_key_rid_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; };
 struct pf_key_rid_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool INV = true; };
 struct pf_key_rid : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; };
@@ -461,7 +467,8 @@ template <typename F /* one of the pf_* structs above */>
 __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
 	constexpr bool LEVEL0 = F::LEVEL0, HAS_RID = F::HAS_RID, STABLE = F::STABLE, FAST = F::FAST, RAW = F::RAW, W32 = F::W32, INV = F::INV, FILT = F::FILT,
-		       OUT16 = F::OUT16, CF = F::CF, R64 = F::R64, MM64 = F::MM64;
+		       OUT16 = F::OUT16, CF = F::CF, R64 = F::R64, MM64 = F::MM64, PAY = F::PAY;
+	static_assert(!PAY || (LEVEL0 && FAST && CF && !W32), "payload cells travel with the first level of the compact narrow form (8-byte words)");
 	static_assert(!(R64 || MM64) || (LEVEL0 && FAST && !RAW && !INV && !W32 && !CF && !STABLE), "64-bit key range: first level of the 64-bit form only");
 	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
 	static_assert(!OUT16 || (W32 && !RAW), "2-byte words out: the 4-byte form only");
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			part_preload2<LEVEL0, PART_ITEMS / 2>(a, td, pre);
 		/* (uniform) the pruned left table only: for the right table - with or without its key range recorded - the same
 		 * straight-line code measured equal (0.247 ms) or slower (0.235 -> 0.258 ms) than the loop below */
-		const bool straight = CF && !W32 && full && !a.nullbits && a.range_in;
+		const bool straight = CF && !W32 && !PAY && full && !a.nullbits && a.range_in;
 		if (straight)
 			(void)part_cf_rows<W32, 1, W>(a, pre, td.start + 2u * threadIdx.x, hv, dig, range_lo, range_hi, seen_min, seen_max);
 #pragma unroll
@@ -861,6 +868,27 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			a.hv_out[g] = a.inverse_out ? mdb_fmix64_inv(h) : h;
 		if (HAS_RID && !RID_SHARES_LDS)
 			a.rid_out[g] = s_rid[i];
+	}
+	if (PAY) {
+		/* the payload cells take the hashes' way through the same LDS buffer, one column after the other: read at the row's own
+		 * index (consecutive threads, consecutive pairs of rows), staged at the row's rank, written beside its word */
+		uint64_t *const s_pay = reinterpret_cast<uint64_t *>(s_hv);
+		for (uint32_t c = 0; c < a.npay; c++) {	/* (uniform) */
+			uint64_t pv[PART_ITEMS];
+#pragma unroll
+			for (int r = 0; r < PART_ITEMS; r++)
+				pv[r] = dig[r] != PART_INVALID ? a.pay_in[c][rid[r]] : 0ull;
+			__syncthreads();	/* every word of the previous round has been read */
+#pragma unroll
+			for (int r = 0; r < PART_ITEMS; r++)
+				if (dig[r] != PART_INVALID)
+					s_pay[rank[r]] = pv[r];
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < PART_ITEMS; k++)
+				if (gpos[k] != PART_INVALID)
+					a.pay_out[c][gpos[k]] = s_pay[threadIdx.x + (uint32_t)k * PART_THREADS];
+		}
 	}
 	if (RID_SHARES_LDS) {
 		__syncthreads();	/* every hash has been read: the buffer now takes the row ids */
@@ -1182,6 +1210,10 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		if (want_rid)
 			rid_buf[l] = (l == nlevels - 1 && final_rid_out) ? final_rid_out : (uint32_t *)cv.take(elems * 4);
 	}
+	uint64_t *pay_buf[2] = { NULL, NULL };
+	const int npay = (flt && stop0 && fast0 && !w32) ? flt->npay : 0;
+	for (int c = 0; c < npay && c < 2; c++)
+		pay_buf[c] = (uint64_t *)cv.take((uint64_t)nreg0_used * cap0 * 8);
 
 	/* segments of the current level */
 	uint32_t S = 1;
@@ -1286,6 +1318,15 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					}
 					if (a.minmax_out)
 						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
+				} else if (npay) {
+					if (!cf || a.narrow != 1u)
+						return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "payload cells travel with the compact narrow form's hash | row id words only");
+					a.npay = (uint32_t)npay;
+					for (int c = 0; c < npay; c++) {
+						a.pay_in[c] = reinterpret_cast<const uint64_t *>(flt->pay_in[c]);
+						a.pay_out[c] = pay_buf[c];
+					}
+					MDB_LAUNCH(ctx, "part_scatter_l0_pay", (k_part_scatter<pf_key_cf_pay>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid && a.range64_in) {	/* 64-bit form, left table, min-max pruning */
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid_pruned", (k_part_scatter<pf_key_rid_r64>), grid8(ntiles), PART_THREADS, a);
 				} else if (want_rid) {
@@ -1324,6 +1365,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					out->w32 = w32;
 					out->w16 = out16 && w32;
 					out->nsub = PART_NSUB;
+					out->pay[0] = pay_buf[0];
+					out->pay[1] = pay_buf[1];
 				}
 				return MIDORIDB_OK;
 			}
@@ -1467,12 +1510,16 @@ size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid
 	return cv.bytes + 4096;
 }
 
-size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose)
+size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose, int npay)
 {
 	part_carver cv = { NULL, true, 0, false };
+	mdb_part_filter flt;
+	memset(&flt, 0, sizeof(flt));
+	flt.level0_only = true;
+	flt.npay = npay;
 	(void)partition_impl(cv, NULL, NULL, n, bits1, 0, false, PART_F_FAST | PART_F_STOP0 | (loose ? PART_F_LOOSE : 0u), MDB_DIGIT_RADIX, 0, false, NULL,
-			     NULL, 0, NULL);
-	return cv.bytes + 4096;
+			     NULL, 0, NULL, NULL, 0, false, 0, 0u, npay ? &flt : NULL);
+	return cv.bytes + 4096 + (size_t)npay * 512;
 }
 
 bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast)

@@ -1266,6 +1266,65 @@ static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, cons
 	return table_column(x, t, key, sel, *n, vals, nulls);
 }
 
+/* The join of table t when EVERY row of the stream finds exactly one partner in it (a foreign key to a primary key) and the statement
+ * reads at most two other columns of t, neither with NULLs: mdb_dev_join_payload carries those cells through t's one partition level
+ * and delivers them in stream order - no partner row ids, no compaction, no random gather in the projection (BASELINE configs[1]).
+ * Table t is then read through a SHADOW (like a table that arrived over the wire in sharded mode): its key column is the stream's own
+ * key column, its payload columns are the carried cells, its row-id vector the identity.  0 = done, 1 = not such a join (nothing
+ * changed: the pairs path answers), < 0 = error. */
+static int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl, const void *vr,
+			     const uint64_t *nr, uint64_t r_rows)
+{
+	struct mdb_select *s = x->s;
+	const struct mdb_table *rt = s->tabs[t].t;
+	int pc[2], np = 0;
+	for (int c = 0; c < rt->ncols; c++) {
+		if (!x->need[t][c] || c == kr->col_idx)
+			continue;
+		if (np == 2 || rt->cols[c].d_nullbits || !rt->cols[c].d_data)
+			return 1;
+		pc[np++] = c;
+	}
+	if (!np || !x->n || x->orig_tab[t])
+		return 1;
+	const void *pin[2] = { NULL, NULL };
+	void *out[2] = { NULL, NULL };
+	for (int i = 0; i < np; i++) {
+		pin[i] = rt->cols[pc[i]].d_data;
+		out[i] = dalloc(x, x->n * 8);
+		if (!out[i])
+			return dev_fail(x, "allocating carried columns");
+	}
+	const int rc = mdb_dev_join_payload(x->dev, vl, nl, x->n, (const int64_t *)vr, nr, r_rows, pin, np, out);
+	if (rc == 1)
+		return 1;
+	if (rc)
+		return dev_fail(x, "join with payload");
+	struct mdb_table *sh = calloc(1, sizeof(*sh));
+	if (!sh)
+		return -MIDORIDB_NOMEM;
+	memcpy(sh->name, rt->name, sizeof(sh->name));
+	sh->ncols = rt->ncols;
+	for (int c = 0; c < rt->ncols; c++) {
+		memcpy(sh->cols[c].name, rt->cols[c].name, sizeof(sh->cols[c].name));
+		sh->cols[c].type = rt->cols[c].type;
+		sh->cols[c].precision = rt->cols[c].precision;
+		sh->cols[c].not_null = rt->cols[c].not_null;
+	}
+	sh->cols[kr->col_idx].d_data = (void *)vl;	/* (in every joined tuple the key of t IS the stream's key; a NULL key joined nothing) */
+	for (int i = 0; i < np; i++)
+		sh->cols[pc[i]].d_data = out[i];
+	sh->nrows = sh->dev_rows = x->n;
+	sh->dev_cap = x->n;
+	sh->device_only = true;
+	x->orig_tab[t] = s->tabs[t].t;
+	x->shadow[t] = sh;
+	s->tabs[t].t = sh;
+	x->rid[t] = NULL;
+	x->joined_rows = x->n;
+	return 0;
+}
+
 static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, int npconj)
 {
 	struct mdb_select *s = x->s;
@@ -1347,6 +1406,19 @@ static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *
 			x->same_col[t] = kr->col_idx;
 			x->same_as_tbl[t] = kl->tbl_idx;
 			x->same_as_col[t] = kl->col_idx;
+		}
+		if (x->n && r_rows && !x->cat->dist && !rsel && kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE) {
+			const int prc = join_with_payload(x, t, kr, vl, nl, vr, nr, r_rows);
+			if (prc < 0)
+				return prc;
+			if (prc == 0) {
+				for (int i = 0; i < nconj; i++)		/* residual ON conjuncts, on the merged tuples */
+					if (i != key && (rc = stream_filter(x, t + 1, conj[i])))
+						return rc;
+				if (nconj > 1)
+					x->joined_rows = x->n;
+				return MIDORIDB_OK;
+			}
 		}
 		if (x->n && r_rows) {
 			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J))
@@ -1679,8 +1751,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	x.s = s;
 	x.err = err;
 	x.errlen = errlen;
-	if (cat->dist)
-		mark_needed_all(&x);
+	mark_needed_all(&x);	/* (which columns the statement reads: the sharded exchange and the join that carries payload cells ask) */
 
 	/* ---- result column set in the reference's order (R3): COUNT(*) first if selected, then every column
 	 *      of every FROM table left to right; projected afterwards to the select list */

@@ -774,6 +774,57 @@ def test_join_keys_is_the_key_column_of_join_pairs_as_a_multiset(dev, case):
     assert np.array_equal(np.sort(_np(got)), np.sort(kl[el]))
 
 
+@pytest.mark.parametrize("case", ["pk_pk_two_cells", "fk_to_pk_one_cell", "window_far_from_zero", "left_row_without_partner", "null_left_key",
+                                  "duplicate_right_key", "keys_beyond_a_window", "small"])
+def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case):
+    """mdb_dev_join_payload (BASELINE configs[1]: a primary-key join with payload): when every left row has exactly one partner the
+    outputs are the partners' payload cells in left-row order (INT64 and DOUBLE bits alike) - equal to payload[pos_r] over the oracle's
+    pairs; any other join is refused with "not served" (the pairs path answers), never answered wrongly"""
+    rng = np.random.default_rng(len(case) * 13 + 5)
+    n = 1_500_000
+    nl = None
+    served = True
+    if case in ("pk_pk_two_cells", "window_far_from_zero", "left_row_without_partner", "null_left_key", "duplicate_right_key"):
+        off = 10**12 if case == "window_far_from_zero" else 0
+        kl, kr = rng.permutation(n).astype(np.int64) + off, rng.permutation(n).astype(np.int64) + off
+        if case == "left_row_without_partner":
+            kl[12345] = n + 77 + off
+            served = False
+        if case == "null_left_key":
+            nl = np.zeros(n, dtype=bool)
+            nl[777] = True
+            served = False
+        if case == "duplicate_right_key":
+            kr[5] = kr[6]
+            served = False
+        pay = [rng.integers(-2**60, 2**60, n, dtype=np.int64), rng.standard_normal(n)]
+    elif case == "fk_to_pk_one_cell":		# a fact table's foreign key: 3 * 10^6 left rows over 2 * 10^5 right keys
+        kr = rng.permutation(200_000).astype(np.int64) + 1000
+        kl = kr[rng.integers(0, len(kr), 3_000_000)]
+        pay = [rng.integers(0, 10**9, len(kr), dtype=np.int64)]
+    elif case == "keys_beyond_a_window":
+        kr = np.unique(rng.integers(-2**62, 2**62, n, dtype=np.int64))
+        kl = rng.permutation(kr)
+        pay = [np.arange(len(kr), dtype=np.int64)]
+        served = False
+    else:
+        kl, kr = rng.permutation(3000).astype(np.int64), rng.permutation(3000).astype(np.int64)
+        pay = [np.arange(3000, dtype=np.int64)]
+        served = False			# (small tables: the pairs path has fewer launches)
+    got = dev.join_payload(dev.to_dev(kl), dev.nullbits_dev(nl) if nl is not None else None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+    if not served:
+        assert got is None, case
+        return
+    assert got is not None, case
+    el, er = orc.join_pairs(kl, None, kr, None)
+    assert len(el) == len(kl) and np.array_equal(el, np.arange(len(kl)))
+    for g, p in zip(got, pay):
+        assert np.array_equal(_np(g).view(np.int64), p[er].view(np.int64)), case
+    # and the same call again (remembered verdicts)
+    again = dev.join_payload(dev.to_dev(kl), None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+    assert again is not None and np.array_equal(_np(again[0]).view(np.int64), pay[0][er].view(np.int64))
+
+
 def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
     counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
