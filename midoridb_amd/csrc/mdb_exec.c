@@ -37,575 +37,19 @@
  * column names across FROM tables S1, operand types S2, GROUP BY rule S4) happen in
  * resolve_select() below.
  */
-#include "mdb_host.h"
-#include <time.h>
-
-#define ERR(...) snprintf(err, errlen, __VA_ARGS__)
-
-/* ------------------------------------------------------------------ CREATE / INSERT (host storage) */
-
-int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, size_t errlen)
-{
-	struct mdb_table *t;
-
-	if (mdb_catalog_find(cat, c->name)) {
-		if (c->if_not_exists)
-			return MIDORIDB_OK;
-		ERR("table '%s' already exists\n", c->name);
-		return -MIDORIDB_ERROR;
-	}
-	for (int i = 0; i < c->ncols; i++) {
-		/* every reference column type can be declared (include/primitive/column.h:17-25).  INTEGER, DOUBLE, DATE,
-		 * DATETIME and TINYINT cells are 8-byte values that live on the device; VARCHAR cells stay on the host and a
-		 * statement is rejected only when it REFERENCES such a column */
-		for (int k = 0; k < i; k++)
-			if (strcmp(c->colname[i], c->colname[k]) == 0) {
-				ERR("duplicate column name: '%s'\n", c->colname[i]);
-				return -MIDORIDB_ERROR;
-			}
-	}
-	t = mdb_table_new(c->name);
-	if (!t)
-		return -MIDORIDB_NOMEM;
-	for (int i = 0; i < c->ncols; i++) {
-		mdb_table_add_column(t, c->colname[i], c->coltype[i]);
-		t->cols[i].precision = c->colprec[i];
-		t->cols[i].not_null = c->notnull[i];
-	}
-	return mdb_catalog_add(cat, t);
-}
-
-int mdb_exec_insert(struct mdb_catalog *cat, struct mdb_insert *ins, size_t *n_rows_aff, char *err, size_t errlen)
-{
-	struct mdb_table *t = mdb_catalog_find(cat, ins->name);
-	int map[MDB_MAX_COLS];
-	int rc;
-
-	if (!t) {
-		ERR("table '%s' doesn't exist\n", ins->name);
-		return -MIDORIDB_ERROR;
-	}
-	if (t->device_only) {
-		ERR("table '%s' was generated on the device and is read-only\n", ins->name);
-		return -MIDORIDB_ERROR;
-	}
-	for (int c = 0; c < t->ncols; c++)
-		map[c] = -1;
-	if (ins->ncolnames) {
-		if (ins->ncolnames != ins->nvals) {
-			ERR("column count doesn't match value count\n");
-			return -MIDORIDB_ERROR;
-		}
-		for (int k = 0; k < ins->ncolnames; k++) {
-			int found = -1;
-			for (int c = 0; c < t->ncols; c++)
-				if (strcmp(t->cols[c].name, ins->colname[k]) == 0)
-					found = c;
-			if (found < 0) {
-				ERR("no such column: '%.128s'\n", ins->colname[k]);
-				return -MIDORIDB_ERROR;
-			}
-			map[found] = k;
-		}
-	} else {
-		if (ins->nvals != t->ncols) {
-			ERR("column count doesn't match value count\n");
-			return -MIDORIDB_ERROR;
-		}
-		for (int c = 0; c < t->ncols; c++)
-			map[c] = c;
-	}
-	rc = mdb_table_reserve(t, t->nrows + (uint64_t)ins->ntuples);
-	if (rc)
-		return rc;
-	/* validate everything before touching the table: NOT NULL (semantic_insert.c:440-495), then the value / column type
-	 * rules of check_value_for_column (semantic_insert.c:283-330), with the reference's texts */
-	for (int c = 0; c < t->ncols; c++)
-		if (map[c] < 0 && t->cols[c].not_null) {
-			ERR("NOT NULL constraint failed: %s.%s\n", t->name, t->cols[c].name);
-			return -MIDORIDB_ERROR;
-		}
-	for (int r = 0; r < ins->ntuples; r++)
-		for (int c = 0; c < t->ncols; c++) {
-			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
-			const struct mdb_column *col = &t->cols[c];
-			int64_t tv;
-			if (!v)
-				continue;
-			if (v->kind == MDB_EX_NULL) {
-				if (col->not_null) {
-					ERR("NOT NULL constraint failed: %s.%s\n", t->name, col->name);
-					return -MIDORIDB_ERROR;
-				}
-				continue;
-			}
-			if (v->kind == MDB_EX_STRING) {
-				if (col->type == MDB_CT_DATE || col->type == MDB_CT_DATETIME) {
-					if (!mdb_parse_time(v->sval, col->type, &tv)) {
-						ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", v->sval);
-						return -MIDORIDB_ERROR;
-					}
-				} else if (col->type == MDB_CT_VARCHAR) {
-					const size_t len = strlen(v->sval) - 2 + 1;	/* without the quotes, with the NUL */
-					if (len > (size_t)col->precision) {
-						ERR("column: '%s' supports up to %d ASCII chars, value contains %lu\n", col->name, col->precision,
-						    (unsigned long)len);
-						return -MIDORIDB_ERROR;
-					}
-				} else {
-					ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
-					return -MIDORIDB_ERROR;
-				}
-			} else if (v->kind == MDB_EX_INT && col->type != MDB_CT_INTEGER) {
-				ERR("val: '%ld' requires an INTEGER column\n", (long)v->ival);
-				return -MIDORIDB_ERROR;
-			} else if (v->kind == MDB_EX_FLOAT && col->type != MDB_CT_DOUBLE) {
-				ERR("val: '%f' requires a DOUBLE column\n", v->dval);
-				return -MIDORIDB_ERROR;
-			} else if (v->kind == MDB_EX_BOOL && col->type != MDB_CT_TINYINT) {
-				ERR("val: '%d' requires a TINYINT column\n", (int)v->ival);
-				return -MIDORIDB_ERROR;
-			} else if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_BOOL) {
-				ERR("only literal values can be inserted on the MI355X path\n");
-				return -MIDORIDB_ERROR;
-			}
-		}
-	for (int r = 0; r < ins->ntuples; r++) {
-		const uint64_t row = t->nrows;
-		for (int c = 0; c < t->ncols; c++) {
-			struct mdb_expr *v = map[c] >= 0 ? ins->vals[r][map[c]] : NULL;
-			struct mdb_column *col = &t->cols[c];
-			col->data[row] = 0;
-			if (!v || v->kind == MDB_EX_NULL) {
-				col->nullbits[row >> 6] |= 1ull << (row & 63);
-				col->null_count++;
-				continue;
-			}
-			col->nullbits[row >> 6] &= ~(1ull << (row & 63));
-			if (v->kind == MDB_EX_FLOAT) {
-				memcpy(&col->data[row], &v->dval, 8);
-			} else if (v->kind == MDB_EX_STRING && col->type == MDB_CT_VARCHAR) {
-				/* the cell is the string's id in the database's dictionary (struct mdb_strdict) */
-				const int64_t id = mdb_dict_intern(&cat->dict, v->sval + 1, strlen(v->sval) - 2);
-				if (!id)
-					return -MIDORIDB_NOMEM;	/* (rows already appended stay: the statement reports the failure) */
-				col->data[row] = id;
-			} else if (v->kind == MDB_EX_STRING) {
-				(void)mdb_parse_time(v->sval, col->type, &col->data[row]);	/* validated above */
-			} else {
-				col->data[row] = v->ival;	/* INT, BOOL (0 | 1) */
-			}
-		}
-		t->nrows++;
-	}
-	t->generation++;
-	*n_rows_aff = (size_t)ins->ntuples;
-	return MIDORIDB_OK;
-}
-
-/* ------------------------------------------------------------------ plan resolution */
-
-static bool field_eq(const struct mdb_expr *a, const struct mdb_expr *b)
-{
-	return a->kind == MDB_EX_FIELD && b->kind == MDB_EX_FIELD && a->tbl_idx == b->tbl_idx && a->col_idx == b->col_idx;
-}
-
-static int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, size_t errlen)
-{
-	int rc;
-
-	if (!e)
-		return MIDORIDB_OK;
-	if (e->kind == MDB_EX_NAME) {
-		int ft = -1, fc = -1, hits = 0;
-		for (int t = 0; t < s->ntabs; t++)
-			for (int c = 0; c < s->tabs[t].t->ncols; c++)
-				if (strcmp(s->tabs[t].t->cols[c].name, e->col) == 0) {
-					ft = t;
-					fc = c;
-					hits++;
-				}
-		if (hits == 0) {
-			ERR("no such column: '%.128s'\n", e->col);
-			return -MIDORIDB_ERROR;
-		}
-		if (hits > 1) {
-			ERR("ambiguous column name: '%.128s'\n", e->col);
-			return -MIDORIDB_ERROR;
-		}
-		e->kind = MDB_EX_FIELD;
-		e->tbl_idx = ft;
-		e->col_idx = fc;
-		mdb_copy_name(e->tbl, s->tabs[ft].t->name);
-	} else if (e->kind == MDB_EX_FIELD) {
-		int ft = -1;
-		for (int t = 0; t < s->ntabs; t++)
-			if (strcmp(s->tabs[t].alias, e->tbl) == 0 || (!s->tabs[t].alias[0] && strcmp(s->tabs[t].name, e->tbl) == 0) ||
-			    strcmp(s->tabs[t].name, e->tbl) == 0)
-				ft = t;
-		if (ft < 0) {
-			ERR("table is not part of from clause: '%.128s'\n", e->tbl);
-			return -MIDORIDB_ERROR;
-		}
-		e->tbl_idx = ft;
-		e->col_idx = -1;
-		for (int c = 0; c < s->tabs[ft].t->ncols; c++)
-			if (strcmp(s->tabs[ft].t->cols[c].name, e->col) == 0)
-				e->col_idx = c;
-		if (e->col_idx < 0) {
-			ERR("no such column: '%.128s'.'%.128s'\n", e->tbl, e->col);
-			return -MIDORIDB_ERROR;
-		}
-		mdb_copy_name(e->tbl, s->tabs[ft].t->name);	/* alias -> real table name */
-	}
-	if (e->kind == MDB_EX_FIELD) {
-		e->type = s->tabs[e->tbl_idx].t->cols[e->col_idx].type;
-	}
-	for (int i = 0; i < e->nkids; i++)
-		if ((rc = resolve_expr(s, e->kids[i], err, errlen)))
-			return rc;
-	return MIDORIDB_OK;
-}
-
-/* predicate shape check (what the device predicate compiler accepts); in the HAVING clause COUNT(*) is an
- * INTEGER operand of comparisons (semantic_select.c:1983-1985 lets it through) */
-static bool is_having_clause(const char *clause)
-{
-	return strcmp(clause, "having") == 0;
-}
-
-/* type of a comparison operand as the reference's semantic phase sees it (check_value_types_cmp, semantic_select.c:2135-2186):
- * a raw string is a VARCHAR - SELECT does not box it into a DATE ("raw values are not auto-boxed", executor_select.c:193) -
- * while DELETE / UPDATE parse it against a DATE / DATETIME column (semantic_delete.c:160-200): `dml` */
-static int operand_type(const struct mdb_expr *o, const struct mdb_expr *other, bool dml)
-{
-	switch (o->kind) {
-	case MDB_EX_FIELD: return o->type;
-	case MDB_EX_INT: case MDB_EX_COUNT: return MDB_CT_INTEGER;
-	case MDB_EX_FLOAT: return MDB_CT_DOUBLE;
-	case MDB_EX_BOOL: return MDB_CT_TINYINT;
-	case MDB_EX_STRING:
-		if (dml && other->kind == MDB_EX_FIELD && (other->type == MDB_CT_DATE || other->type == MDB_CT_DATETIME))
-			return other->type;
-		return MDB_CT_VARCHAR;
-	default: return -1;
-	}
-}
-
-static int check_predicate_x(const struct mdb_expr *e, const char *clause, bool dml, char *err, size_t errlen)
-{
-	int rc;
-	switch (e->kind) {
-	case MDB_EX_LOGOP:
-		if ((rc = check_predicate_x(e->kids[0], clause, dml, err, errlen)) || (rc = check_predicate_x(e->kids[1], clause, dml, err, errlen)))
-			return rc;
-		return MIDORIDB_OK;
-	case MDB_EX_CMP: {
-		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
-		for (int i = 0; i < 2; i++) {
-			const struct mdb_expr *o = e->kids[i];
-			if (o->kind == MDB_EX_COUNT && is_having_clause(clause))
-				continue;
-			if (o->kind != MDB_EX_FIELD && o->kind != MDB_EX_INT && o->kind != MDB_EX_FLOAT && o->kind != MDB_EX_NULL &&
-			    o->kind != MDB_EX_BOOL && o->kind != MDB_EX_STRING) {
-				ERR("expressions in %s clause must compare columns with literal values\n", clause);
-				return -MIDORIDB_ERROR;
-			}
-		}
-		/* operand types must match exactly (reference check_value_types_cmp, semantic_select.c:2135-2186) */
-		{
-			const int tl = operand_type(l, r, dml), tr = operand_type(r, l, dml);
-			int64_t tv;
-			if (tl >= 0 && tr >= 0 && tl != tr) {
-				ERR("comparison operands must have the same type\n");
-				return -MIDORIDB_ERROR;
-			}
-			/* VARCHAR cells are dictionary ids: equal strings, equal ids - and nothing else (semantic_select.c:2171-2176,
-			 * semantic_delete.c:211-216) */
-			if ((tl == MDB_CT_VARCHAR || tr == MDB_CT_VARCHAR) && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
-				if (dml)
-					ERR("VARCHAR fields can only use '=' or '<>' ops\n");
-				else
-					ERR("VARCHAR values can only use '=' or '<>' ops\n");
-				return -MIDORIDB_ERROR;
-			}
-			for (int i = 0; i < 2; i++)
-				if (e->kids[i]->kind == MDB_EX_STRING && (i ? tl : tr) != MDB_CT_VARCHAR &&
-				    !mdb_parse_time(e->kids[i]->sval, i ? tl : tr, &tv)) {
-					ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", e->kids[i]->sval);
-					return -MIDORIDB_ERROR;
-				}
-			if ((l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL) && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
-				ERR("NULL values can only use '=' or '<>' ops\n");
-				return -MIDORIDB_ERROR;
-			}
-		}
-		return MIDORIDB_OK;
-	}
-	case MDB_EX_ISNULL:
-		if (e->kids[0]->kind != MDB_EX_FIELD) {
-			ERR("only fields are allowed in IS NULL|IS NOT NULL\n");
-			return -MIDORIDB_ERROR;
-		}
-		return MIDORIDB_OK;
-	case MDB_EX_ISIN:
-		if (e->kids[0]->kind != MDB_EX_FIELD) {
-			ERR("Fields aren't allowed on IN-clauses\n");
-			return -MIDORIDB_ERROR;
-		}
-		for (int i = 1; i < e->nkids; i++) {
-			const struct mdb_expr *v = e->kids[i];
-			if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL &&
-			    v->kind != MDB_EX_STRING) {
-				ERR("IN-clause can only contain raw values\n");
-				return -MIDORIDB_ERROR;
-			}
-			if (v->kind == MDB_EX_STRING && e->kids[0]->type != MDB_CT_VARCHAR) {	/* (semantic_select.c:2308-2326) */
-				ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
-				return -MIDORIDB_ERROR;
-			}
-			if ((v->kind == MDB_EX_INT && e->kids[0]->type != MDB_CT_INTEGER) ||
-			    (v->kind == MDB_EX_BOOL && e->kids[0]->type != MDB_CT_TINYINT) ||
-			    (v->kind == MDB_EX_FLOAT && e->kids[0]->type != MDB_CT_DOUBLE)) {
-				ERR("comparison operands must have the same type\n");
-				return -MIDORIDB_ERROR;
-			}
-		}
-		return MIDORIDB_OK;
-	case MDB_EX_COUNT:
-		ERR("COUNT function can't be used in the %s-clause\n", clause);
-		return -MIDORIDB_ERROR;
-	default:
-		ERR("expressions in %s clause must be a type of comparison\n", clause);
-		return -MIDORIDB_ERROR;
-	}
-}
-
-static int check_predicate(const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
-{
-	return check_predicate_x(e, clause, false, err, errlen);
-}
-
-static bool expr_has_count(const struct mdb_expr *e)
-{
-	if (e->kind == MDB_EX_COUNT)
-		return true;
-	for (int i = 0; i < e->nkids; i++)
-		if (expr_has_count(e->kids[i]))
-			return true;
-	return false;
-}
-
-/* every field under e appears in the select list ("SELECT list is not in <clause> clause", the reference's
- * wording, semantic_select.c:1836-1852, 1965-1985) */
-static int fields_in_select_list(const struct mdb_select *s, const struct mdb_expr *e, const char *clause, char *err, size_t errlen)
-{
-	int rc;
-	if (e->kind == MDB_EX_FIELD && !s->select_all) {
-		bool ok = false;
-		for (int i = 0; i < s->nsel; i++)
-			ok |= field_eq(s->sel[i], e);
-		if (!ok) {
-			ERR("SELECT list is not in %s clause: '%.128s'.'%.128s'\n", clause, e->tbl, e->col);
-			return -MIDORIDB_ERROR;
-		}
-	}
-	if (e->kind == MDB_EX_COUNT)
-		return MIDORIDB_OK;
-	for (int i = 0; i < e->nkids; i++)
-		if ((rc = fields_in_select_list(s, e->kids[i], clause, err, errlen)))
-			return rc;
-	return MIDORIDB_OK;
-}
-
-static int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, size_t errlen)
-{
-	int rc;
-
-	if (s->ntabs == 0) {
-		ERR("SELECT without FROM is not supported by the MI355X path\n");
-		return -MIDORIDB_ERROR;
-	}
-	if (s->ntabs > MDB_MAX_TABS) {
-		ERR("more than %d tables in the FROM clause are not supported\n", MDB_MAX_TABS);
-		return -MIDORIDB_ERROR;
-	}
-	for (int t = 0; t < s->ntabs; t++) {
-		s->tabs[t].t = mdb_catalog_find(cat, s->tabs[t].name);
-		if (!s->tabs[t].t) {
-			ERR("table doesn't exist: '%.128s'\n", s->tabs[t].name);
-			return -MIDORIDB_ERROR;
-		}
-		for (int u = 0; u < t; u++) {
-			const char *a = s->tabs[t].alias[0] ? s->tabs[t].alias : s->tabs[t].name;
-			const char *b = s->tabs[u].alias[0] ? s->tabs[u].alias : s->tabs[u].name;
-			if (strcmp(a, b) == 0) {
-				ERR("Not unique table/alias: '%.128s'\n", a);
-				return -MIDORIDB_ERROR;
-			}
-			/* S1: bare column names must be unique across all FROM tables (semantic_select.c:2470-2478) */
-			for (int c = 0; c < s->tabs[t].t->ncols; c++)
-				for (int d = 0; d < s->tabs[u].t->ncols; d++)
-					if (strcmp(s->tabs[t].t->cols[c].name, s->tabs[u].t->cols[d].name) == 0) {
-						ERR("duplicate column name: '%s'\n", s->tabs[t].t->cols[c].name);
-						return -MIDORIDB_ERROR;
-					}
-		}
-		if (s->join_type[t] != 1) {
-			ERR("only INNER JOIN is executed (the reference aborts on other join types, executor_select.c:1094)\n");
-			return -MIDORIDB_ERROR;
-		}
-	}
-	for (int i = 0; i < s->nsel; i++) {
-		struct mdb_expr *e = s->sel[i];
-		if (e->kind == MDB_EX_COUNT) {
-			for (int k = 0; k < e->nkids; k++)
-				if ((rc = resolve_expr(s, e->kids[k], err, errlen)))
-					return rc;
-			continue;
-		}
-		if (e->kind != MDB_EX_NAME && e->kind != MDB_EX_FIELD) {
-			ERR("only columns and COUNT(*) are supported in the select list (aliases and expressions are not executed by the reference)\n");
-			return -MIDORIDB_ERROR;
-		}
-		if ((rc = resolve_expr(s, e, err, errlen)))
-			return rc;
-	}
-	for (int t = 1; t < s->ntabs; t++)
-		if (s->on[t]) {
-			if ((rc = resolve_expr(s, s->on[t], err, errlen)) || (rc = check_predicate(s->on[t], "JOIN ON", err, errlen)))
-				return rc;
-		}
-	if (s->where && ((rc = resolve_expr(s, s->where, err, errlen)) || (rc = check_predicate(s->where, "where", err, errlen))))
-		return rc;
-	if (s->ngroup > MDB_SORT_MAX_KEYS) {
-		ERR("GROUP BY over more than %d fields is not supported\n", MDB_SORT_MAX_KEYS);
-		return -MIDORIDB_ERROR;
-	}
-	for (int i = 0; i < s->ngroup; i++) {
-		if (s->group[i]->kind != MDB_EX_NAME && s->group[i]->kind != MDB_EX_FIELD) {
-			ERR("group-by clauses support only fields and aliases\n");
-			return -MIDORIDB_ERROR;
-		}
-		if ((rc = resolve_expr(s, s->group[i], err, errlen)))
-			return rc;
-	}
-	/* S4: with GROUP BY or COUNT, every plain select field must be a GROUP BY field */
-	{
-		int ncount = 0, nfield = 0;
-		for (int i = 0; i < s->nsel; i++) {
-			if (s->sel[i]->kind == MDB_EX_COUNT) {
-				ncount++;
-				continue;
-			}
-			nfield++;
-			if (s->ngroup) {
-				bool ok = false;
-				for (int g = 0; g < s->ngroup; g++)
-					ok |= field_eq(s->sel[i], s->group[g]);
-				if (!ok) {
-					ERR("SELECT list is not in GROUP BY clause: '%.128s'.'%.128s'\n", s->sel[i]->tbl, s->sel[i]->col);
-					return -MIDORIDB_ERROR;
-				}
-			}
-		}
-		if (s->select_all && (s->ngroup || ncount)) {
-			ERR("SELECT * can't be combined with GROUP BY / COUNT\n");
-			return -MIDORIDB_ERROR;
-		}
-		if (ncount && nfield && !s->ngroup) {
-			ERR("mixing fields and COUNT in the select list requires a GROUP BY clause\n");
-			return -MIDORIDB_ERROR;
-		}
-		/* ---- DISTINCT / HAVING / ORDER BY / LIMIT: parsed and checked but never executed upstream (SURVEY 8a
-		 *      D7); executed here with SQL semantics (8f row 4), under the reference's own semantic rules */
-		if (s->distinct && (s->ngroup || ncount)) {
-			ERR("DISTINCT can't be combined with GROUP BY / COUNT on the MI355X path\n");
-			return -MIDORIDB_ERROR;
-		}
-		if (s->having) {
-			if ((rc = resolve_expr(s, s->having, err, errlen)) || (rc = check_predicate(s->having, "having", err, errlen)))
-				return rc;
-			/* fields must come from the SELECT list (check_having_clause_inselect, semantic_select.c:1953-2001) */
-			if ((rc = fields_in_select_list(s, s->having, "HAVING", err, errlen)))
-				return rc;
-			if (expr_has_count(s->having) && !s->ngroup) {
-				ERR("COUNT in the having-clause requires a GROUP BY clause on the MI355X path\n");
-				return -MIDORIDB_ERROR;
-			}
-			if (ncount && !s->ngroup) {
-				ERR("HAVING over an ungrouped COUNT is not supported on the MI355X path\n");
-				return -MIDORIDB_ERROR;
-			}
-		}
-		for (int i = 0; i < s->norder; i++) {
-			struct mdb_expr *o = s->order[i];
-			if (o->kind == MDB_EX_COUNT) {		/* check_orderby_clause_count, semantic_select.c:1755-1795 */
-				ERR("COUNT function can't be used in the orderby-clause\n");
-				return -MIDORIDB_ERROR;
-			}
-			if (o->kind != MDB_EX_NAME && o->kind != MDB_EX_FIELD) {	/* check_orderby_clause_expr :1718-1753 */
-				ERR("order-by clauses support only fields and aliases\n");
-				return -MIDORIDB_ERROR;
-			}
-			if ((rc = resolve_expr(s, o, err, errlen)) || (rc = fields_in_select_list(s, o, "ORDER BY", err, errlen)))
-				return rc;
-			if (o->type == MDB_CT_VARCHAR) {	/* cells are dictionary ids: equality only, no collation order */
-				ERR("ORDER BY over the VARCHAR column '%s.%s' is not supported on the MI355X path\n", o->tbl, o->col);
-				return -MIDORIDB_ERROR;
-			}
-		}
-		if (s->norder > MDB_SORT_MAX_KEYS) {
-			ERR("too many ORDER BY items (max %d)\n", MDB_SORT_MAX_KEYS);
-			return -MIDORIDB_ERROR;
-		}
-	}
-	return MIDORIDB_OK;
-}
+#include "mdb_exec_internal.h"
 
 /* ------------------------------------------------------------------ device-side execution state */
 
-struct dbuf_list {
-	void **p;
-	int n, cap;
-};
 
-struct exec {
-	struct mdb_catalog *cat;
-	mdb_dev_ctx *dev;
-	struct mdb_select *s;
-	char *err;
-	size_t errlen;
-	struct dbuf_list bufs;
-	uint32_t *rid[MDB_MAX_TABS];	/* per FROM table: row-id vector of the current stream or NULL = identity */
-	bool have_stream;		/* false until the first table is in the stream */
-	uint64_t n;			/* stream length */
-	int64_t *d_count;		/* COUNT(*) column of the stream (after GROUP BY), device */
-	bool fused;			/* north-star plan: the stream is (d_fused_key, d_count), no row ids */
-	int64_t *d_fused_key;
-	uint64_t joined_rows;
-	/* per joined table: its equi-join key column holds, in every tuple of the stream, the value of an earlier table's column
-	 * (INT64-represented types: the join compared all 64 bits; never NULL - a NULL key joins nothing): the projection reads
-	 * that column, through the earlier table's row ids (ascending after a join: near-sequential reads instead of a random gather) */
-	int same_col[MDB_MAX_TABS], same_as_tbl[MDB_MAX_TABS], same_as_col[MDB_MAX_TABS];
-	/* sharded mode (cat->dist): a FROM table whose rows were exchanged is read through a SHADOW table - the same schema over the
-	 * columns this rank received - that stands in s->tabs[t].t for the rest of the statement (orig_tab[] puts the catalog's
-	 * tables back at the end).  part[]: the fields whose value the current stream is hash-partitioned by (all equal in every
-	 * tuple: the equi-join keys tied together so far); need[t][c]: the statement reads column c of table t */
-	struct mdb_table *shadow[MDB_MAX_TABS], *orig_tab[MDB_MAX_TABS];
-	const struct mdb_expr *part[2 * MDB_MAX_TABS];
-	int npart;
-	bool promised;		/* the exchange handle holds this statement's key ranges (shard_promise_ranges) */
-	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
-};
 
-static int dev_fail(struct exec *x, const char *what)
+int dev_fail(struct exec *x, const char *what)
 {
 	snprintf(x->err, x->errlen, "execution phase: %s: %s\n", what, mdb_dev_last_error(x->dev));
 	return -MIDORIDB_INTERNAL;
 }
 
-static int track(struct exec *x, void *p)
+int track(struct exec *x, void *p)
 {
 	if (x->bufs.n == x->bufs.cap) {
 		int nc = x->bufs.cap ? x->bufs.cap * 2 : 32;
@@ -619,7 +63,7 @@ static int track(struct exec *x, void *p)
 	return 0;
 }
 
-static void *dalloc(struct exec *x, size_t bytes)
+void *dalloc(struct exec *x, size_t bytes)
 {
 	void *p = NULL;
 	if (mdb_dev_alloc(x->dev, bytes ? bytes : 8, &p))
@@ -631,7 +75,7 @@ static void *dalloc(struct exec *x, size_t bytes)
 	return p;
 }
 
-static void free_all(struct exec *x)
+void free_all(struct exec *x)
 {
 	for (int i = 0; i < x->bufs.n; i++)
 		mdb_dev_free(x->dev, x->bufs.p[i]);
@@ -641,7 +85,7 @@ static void free_all(struct exec *x)
 }
 
 /* Re-map every row-id vector of the stream through `sel` (n_new positions into the old stream). */
-static int stream_select(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
+int stream_select(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
 {
 	for (int t = 0; t < ntabs_in_stream; t++) {
 		if (x->rid[t]) {
@@ -660,7 +104,7 @@ static int stream_select(struct exec *x, int ntabs_in_stream, const uint32_t *se
 }
 
 /* keep the rows sel[0..n_new) of the current stream: row-id vectors (or the fused key column) and COUNT(*) */
-static int stream_apply_sel(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
+int stream_apply_sel(struct exec *x, int ntabs_in_stream, const uint32_t *sel, uint64_t n_new)
 {
 	if (x->d_count) {
 		int64_t *nc = dalloc(x, (n_new ? n_new : 1) * 8);
@@ -680,7 +124,7 @@ static int stream_apply_sel(struct exec *x, int ntabs_in_stream, const uint32_t 
 }
 
 /* device pointer to a column's key/value vector for the current stream (gathered when needed) */
-static int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t **vals, const uint64_t **nulls)
+int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t **vals, const uint64_t **nulls)
 {
 	struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
 	*vals = col->d_data;
@@ -701,7 +145,7 @@ static int stream_column(struct exec *x, const struct mdb_expr *f, const int64_t
 /* Key vector of an equi-join over table column `col`, rows rid[0..n) (rid == NULL: rows 0..n-1).  INTEGER keys are the
  * column itself; DOUBLE keys go through mdb_dev_double_join_keys so that the join's word comparison is the reference's
  * IEEE `==` (cmp_double_value_to_value, executor_select.c:440-460): -0.0 joins +0.0, NaN joins nothing. */
-static int double_join_keys(struct exec *x, const struct mdb_column *col, const uint32_t *rid, uint64_t n, const void **vals,
+int double_join_keys(struct exec *x, const struct mdb_column *col, const uint32_t *rid, uint64_t n, const void **vals,
 			    const uint64_t **nulls)
 {
 	int64_t *v = dalloc(x, (n ? n : 1) * 8);
@@ -715,429 +159,10 @@ static int double_join_keys(struct exec *x, const struct mdb_column *col, const 
 	return MIDORIDB_OK;
 }
 
-/* ------------------------------------------------------------------ sharded mode: row exchange
- *
- * One process per GPU, every process holds ITS rows of every table (include/mdb_dist.h).  The general plan stays what it
- * is - the reference's phases, executor_select.c:1655-1744 - and gains ONE step: before an operator that must see all the
- * rows of a key together (equi-join, GROUP BY, DISTINCT), the tuple stream is re-distributed so that every row lands on
- * the rank its key hashes to (mdb_dist_shuffle_rows: key + the columns the statement still reads), unless it already is
- * (x->part: the join keys tied together so far).  What arrives replaces the table for the rest of the statement. */
-
-static void mark_needed(struct exec *x, const struct mdb_expr *e)
-{
-	if (!e)
-		return;
-	if (e->kind == MDB_EX_FIELD && e->tbl_idx >= 0 && e->tbl_idx < MDB_MAX_TABS && e->col_idx >= 0 && e->col_idx < MDB_MAX_COLS)
-		x->need[e->tbl_idx][e->col_idx] = true;
-	for (int i = 0; i < e->nkids; i++)
-		mark_needed(x, e->kids[i]);
-}
-
-static void mark_needed_all(struct exec *x)
-{
-	const struct mdb_select *s = x->s;
-	for (int i = 0; i < s->nsel; i++)
-		mark_needed(x, s->sel[i]);
-	if (s->select_all)
-		for (int t = 0; t < s->ntabs; t++)
-			for (int c = 0; c < s->tabs[t].t->ncols; c++)
-				x->need[t][c] = true;
-	for (int t = 1; t < s->ntabs; t++)
-		mark_needed(x, s->on[t]);
-	mark_needed(x, s->where);
-	for (int g = 0; g < s->ngroup; g++)
-		mark_needed(x, s->group[g]);
-	mark_needed(x, s->having);
-	for (int o = 0; o < s->norder; o++)
-		mark_needed(x, s->order[o]);
-}
-
-static bool in_part(const struct exec *x, const struct mdb_expr *f)
-{
-	for (int i = 0; i < x->npart; i++)
-		if (x->part[i]->tbl_idx == f->tbl_idx && x->part[i]->col_idx == f->col_idx)
-			return true;
-	return false;
-}
-
-/* Tables tabs[0..nt) share one tuple stream of n tuples, table tabs[i] read through rid_of[i] (NULL = identity); kv / kn is
- * the stream's partitioning key.  Afterwards each of those tables is a shadow over the rows this rank received, *n_out of
- * them, all read by identity.  Collective: every rank calls it for the same statement at the same point. */
-static int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of, uint64_t n, const int64_t *kv, const uint64_t *kn,
-		      uint32_t flags, uint64_t *n_out)
-{
-	struct mdb_select *s = x->s;
-	struct mdb_dist_col cols[MDB_DIST_SHUFFLE_MAX_COLS] = { { NULL, NULL, NULL } };
-	int col_i[MDB_DIST_SHUFFLE_MAX_COLS], col_c[MDB_DIST_SHUFFLE_MAX_COLS], nc = 0;
-	void *ov[MDB_DIST_SHUFFLE_MAX_COLS];
-	uint64_t *on[MDB_DIST_SHUFFLE_MAX_COLS];
-	uint64_t got = 0;
-
-	for (int i = 0; i < nt; i++) {
-		const struct mdb_table *tb = s->tabs[tabs[i]].t;
-		for (int c = 0; c < tb->ncols; c++) {
-			if (!x->need[tabs[i]][c])
-				continue;
-			if (tb->cols[c].type == MDB_CT_VARCHAR) {
-				snprintf(x->err, x->errlen, "execution phase: sharded mode: VARCHAR column %s.%s cannot travel between the ranks (its cells are "
-							    "ids of this process's string dictionary)\n", tb->name, tb->cols[c].name);
-				return -MIDORIDB_ERROR;
-			}
-			if (nc == MDB_DIST_SHUFFLE_MAX_COLS) {
-				snprintf(x->err, x->errlen, "execution phase: sharded mode: more than %d columns in one exchange\n", MDB_DIST_SHUFFLE_MAX_COLS);
-				return -MIDORIDB_ERROR;
-			}
-			cols[nc].values = tb->cols[c].d_data;
-			cols[nc].nullbits = tb->cols[c].d_nullbits;
-			cols[nc].rid = rid_of[i];
-			col_i[nc] = i;
-			col_c[nc] = c;
-			nc++;
-		}
-	}
-	if (mdb_dist_shuffle_rows(x->cat->dist, kv, kn, n, flags, cols, nc, ov, on, &got)) {
-		snprintf(x->err, x->errlen, "execution phase: sharded exchange: %s\n", mdb_dist_last_error(x->cat->dist));
-		return -MIDORIDB_INTERNAL;
-	}
-	for (int k = 0; k < nc; k++)
-		if (track(x, ov[k]) || (on[k] && track(x, on[k])))
-			return -MIDORIDB_NOMEM;
-	for (int i = 0; i < nt; i++) {
-		const int t = tabs[i];
-		const struct mdb_table *tb = s->tabs[t].t;
-		struct mdb_table *sh = calloc(1, sizeof(*sh));
-		if (!sh)
-			return -MIDORIDB_NOMEM;
-		memcpy(sh->name, tb->name, sizeof(sh->name));
-		sh->ncols = tb->ncols;
-		for (int c = 0; c < tb->ncols; c++) {
-			memcpy(sh->cols[c].name, tb->cols[c].name, sizeof(sh->cols[c].name));
-			sh->cols[c].type = tb->cols[c].type;
-			sh->cols[c].precision = tb->cols[c].precision;
-			sh->cols[c].not_null = tb->cols[c].not_null;
-		}
-		for (int k = 0; k < nc; k++)
-			if (col_i[k] == i) {
-				sh->cols[col_c[k]].d_data = ov[k];
-				sh->cols[col_c[k]].d_nullbits = on[k];
-			}
-		sh->nrows = sh->dev_rows = got;
-		sh->dev_cap = got ? got : 1;
-		sh->device_only = true;
-		if (!x->orig_tab[t])
-			x->orig_tab[t] = s->tabs[t].t;
-		free(x->shadow[t]);
-		x->shadow[t] = sh;
-		s->tabs[t].t = sh;
-	}
-	*n_out = got;
-	return MIDORIDB_OK;
-}
-
-/* the current stream (tables 0..nt-1) partitioned by field f: afterwards every rank holds the tuples whose f hashes to it */
-static int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flags)
-{
-	int tabs[MDB_MAX_TABS] = { 0 };
-	uint32_t *rids[MDB_MAX_TABS] = { NULL };
-	const int64_t *kv;
-	const uint64_t *kn;
-	const void *dv;
-	uint64_t got = 0;
-	int rc;
-	if (f->type == MDB_CT_DOUBLE && !(flags & MDB_DIST_KEEP_NULL_KEYS)) {	/* a join key: -0.0 meets +0.0, NaN meets nothing */
-		if ((rc = double_join_keys(x, &x->s->tabs[f->tbl_idx].t->cols[f->col_idx], x->rid[f->tbl_idx], x->n, &dv, &kn)))
-			return rc;
-		kv = dv;
-	} else if ((rc = stream_column(x, f, &kv, &kn))) {
-		return rc;
-	}
-	for (int t = 0; t < nt; t++) {
-		tabs[t] = t;
-		rids[t] = x->rid[t];
-	}
-	if ((rc = shard_rows(x, tabs, nt, rids, x->n, kv, kn, flags, &got)))
-		return rc;
-	for (int t = 0; t < nt; t++)
-		x->rid[t] = NULL;
-	x->n = got;
-	x->npart = 0;
-	x->part[x->npart++] = f;
-	return MIDORIDB_OK;
-}
-
-/* Sharded joins on key columns of BASE tables: the exchange is told the two tables' GLOBAL key ranges from catalog statistics -
- * the smallest / largest key of each rank's mirror, computed once per table generation (one pass) and agreed on with one tiny
- * all-gather per statement - instead of measuring both columns on every call (MDB_WIRE_AUTO: two passes over the columns per
- * query).  With the ranges known the operator ships first-level partition regions (mdb_dev_shard.hip).  A filtered table's keys
- * lie inside its column's range: a superset is fine. */
-static int shard_promise_ranges(struct exec *x, const struct mdb_expr *fl, const struct mdb_expr *fr)
-{
-	struct mdb_column *cols[2] = { &x->s->tabs[fl->tbl_idx].t->cols[fl->col_idx], &x->s->tabs[fr->tbl_idx].t->cols[fr->col_idx] };
-	struct mdb_table *tabs[2] = { x->s->tabs[fl->tbl_idx].t, x->s->tabs[fr->tbl_idx].t };
-	uint64_t mine[4], all[4 * 512];
-	const int W = mdb_dist_world(x->cat->dist);
-	/* a promise an earlier step of this statement made is about OTHER columns: forgotten before anything else, so that a return
-	 * without a new promise (below) leaves the handle measuring by itself instead of holding ranges that are not these columns' */
-	if (x->promised) {
-		(void)mdb_dist_set_key_ranges(x->cat->dist, NULL, NULL);
-		(void)mdb_dist_set_wire(x->cat->dist, MDB_WIRE_AUTO);
-		x->promised = false;
-	}
-	if (W > 512)
-		return MIDORIDB_OK;
-	for (int i = 0; i < 2; i++) {
-		if (cols[i]->st_generation != tabs[i]->generation + 1) {
-			int64_t lo = 0, hi = -1;
-			if (tabs[i]->nrows && mdb_dev_key_range(x->dev, cols[i]->d_data, cols[i]->d_nullbits, tabs[i]->nrows, &lo, &hi))
-				return dev_fail(x, "column statistics");
-			cols[i]->st_lo = lo;
-			cols[i]->st_hi = hi;
-			cols[i]->st_generation = tabs[i]->generation + 1;
-		}
-		const bool none = cols[i]->st_lo > cols[i]->st_hi;
-		/* (as offsets from the smallest int64: every rank's minimum of the unsigned images is the global minimum) */
-		mine[2 * i] = none ? ~0ull : (uint64_t)cols[i]->st_lo ^ 0x8000000000000000ull;
-		mine[2 * i + 1] = none ? 0ull : (uint64_t)cols[i]->st_hi ^ 0x8000000000000000ull;
-	}
-	if (mdb_dist_allgather_u64(x->cat->dist, mine, 4, all)) {
-		snprintf(x->err, x->errlen, "execution phase: %s\n", mdb_dist_last_error(x->cat->dist));
-		return -MIDORIDB_INTERNAL;
-	}
-	int64_t g[2][2];
-	bool fits32 = true;
-	for (int i = 0; i < 2; i++) {
-		uint64_t lo = ~0ull, hi = 0;
-		for (int p = 0; p < W; p++) {
-			lo = all[4 * p + 2 * i] < lo ? all[4 * p + 2 * i] : lo;
-			hi = all[4 * p + 2 * i + 1] > hi ? all[4 * p + 2 * i + 1] : hi;
-		}
-		g[i][0] = (int64_t)(lo ^ 0x8000000000000000ull);
-		g[i][1] = (int64_t)(hi ^ 0x8000000000000000ull);
-		if (lo > hi) {		/* no key on any rank: an empty range (lo > hi) */
-			g[i][0] = 0;
-			g[i][1] = -1;
-		} else if (g[i][0] < -(1ll << 31) || g[i][1] >= (1ll << 31)) {
-			fits32 = false;
-		}
-	}
-	if (g[0][0] > g[0][1] || g[1][0] > g[1][1])
-		return MIDORIDB_OK;	/* (a table without keys: the measuring path answers "no groups") */
-	if (mdb_dist_set_key_ranges(x->cat->dist, g[0], g[1]) || mdb_dist_set_wire(x->cat->dist, fits32 ? MDB_WIRE_32 : MDB_WIRE_64))
-		return -MIDORIDB_INTERNAL;
-	x->promised = true;
-	return MIDORIDB_OK;
-}
-
-static void shard_cleanup(struct exec *x)
-{
-	if (x->promised) {	/* back to per-call measurement for whoever uses the handle next */
-		(void)mdb_dist_set_key_ranges(x->cat->dist, NULL, NULL);
-		(void)mdb_dist_set_wire(x->cat->dist, MDB_WIRE_AUTO);
-		x->promised = false;
-	}
-	for (int t = 0; t < MDB_MAX_TABS; t++) {
-		if (x->orig_tab[t])
-			x->s->tabs[t].t = x->orig_tab[t];
-		free(x->shadow[t]);
-		x->shadow[t] = NULL;
-		x->orig_tab[t] = NULL;
-	}
-}
-
-/* ------------------------------------------------------------------ predicate compiler */
-
-struct pred_prog {
-	struct mdb_pred_insn insn[MDB_PRED_MAX_INSNS];
-	int n;
-	struct mdb_col_binding cols[MDB_PRED_MAX_SLOTS];
-	int slot_tbl[MDB_PRED_MAX_SLOTS], slot_col[MDB_PRED_MAX_SLOTS];
-	int ncols;
-};
-
-/* device binding of a column-like operand for the current stream: a table column read through the table's
- * row-id vector, the COUNT(*) column (HAVING), or - in the fused north-star plan, whose stream carries no row
- * ids - the group key column (the only field S4 lets such a query name) */
-static void bind_operand(struct exec *x, const struct mdb_expr *f, const void **values, const uint64_t **nullbits, const uint32_t **rid)
-{
-	if (f->kind == MDB_EX_COUNT) {
-		*values = x->d_count;
-		*nullbits = NULL;
-		*rid = NULL;
-	} else if (x->fused) {
-		*values = x->d_fused_key;
-		*nullbits = NULL;
-		*rid = NULL;
-	} else {
-		struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
-		*values = col->d_data;
-		*nullbits = col->d_nullbits;
-		*rid = x->rid[f->tbl_idx];
-	}
-}
-
-static int pred_slot(struct exec *x, struct pred_prog *p, const struct mdb_expr *f)
-{
-	const int st = f->kind == MDB_EX_COUNT ? -2 : f->tbl_idx, sc = f->kind == MDB_EX_COUNT ? -2 : f->col_idx;
-	for (int i = 0; i < p->ncols; i++)
-		if (p->slot_tbl[i] == st && p->slot_col[i] == sc)
-			return i;
-	if (p->ncols == MDB_PRED_MAX_SLOTS)
-		return -1;
-	p->slot_tbl[p->ncols] = st;
-	p->slot_col[p->ncols] = sc;
-	bind_operand(x, f, &p->cols[p->ncols].values, &p->cols[p->ncols].nullbits, &p->cols[p->ncols].rid);
-	return p->ncols++;
-}
-
-static int pred_emit(struct pred_prog *p, int op, int cmp, int type, int a, int b, int64_t imm)
-{
-	struct mdb_pred_insn *in;
-	if (p->n == MDB_PRED_MAX_INSNS)
-		return -1;
-	in = &p->insn[p->n++];
-	memset(in, 0, sizeof(*in));
-	in->op = op;
-	in->cmp = cmp;
-	in->type = type;
-	in->a = a;
-	in->b = b;
-	in->imm = imm;
-	return 0;
-}
-
-/* the 8 bytes a literal stands for in a column of type coltype (a DATE / DATETIME string: its time_t, validated by
- * check_predicate_x / the UPDATE checks) */
-/* the string dictionary of the database the running statement belongs to (set by the statement entry points) */
-static __thread const struct mdb_strdict *stmt_dict;
-
-static int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
-{
-	int64_t bits = 0;
-	if (v->kind == MDB_EX_FLOAT) {
-		memcpy(&bits, &v->dval, 8);
-		return bits;
-	}
-	if (v->kind == MDB_EX_STRING && coltype == MDB_CT_VARCHAR)	/* a string no cell holds has id -1: equal to nothing */
-		return stmt_dict ? mdb_dict_find(stmt_dict, v->sval + 1, strlen(v->sval) - 2) : -1;
-	if (v->kind == MDB_EX_STRING) {
-		(void)mdb_parse_time(v->sval, coltype, &bits);
-		return bits;
-	}
-	return v->ival;
-}
-
-static bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
-{
-	if (l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL)
-		return false;			/* executor_select.c:660-662 */
-	if (l->kind == MDB_EX_STRING || r->kind == MDB_EX_STRING)
-		return false;			/* (rejected by the type check; never evaluated) */
-	if (l->kind == MDB_EX_FLOAT) {
-		double a = l->dval, b = r->dval;
-		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
-	} else {
-		int64_t a = l->ival, b = r->ival;
-		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
-	}
-}
-
-static int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_expr *e)
-{
-	int rc = 0, a, b;
-
-	switch (e->kind) {
-	case MDB_EX_LOGOP:
-		if ((rc = pred_compile(x, p, e->kids[0])) || (rc = pred_compile(x, p, e->kids[1])))
-			return rc;
-		return pred_emit(p, e->op == 0 ? MDB_P_AND : (e->op == 1 ? MDB_P_OR : MDB_P_XOR), 0, 0, 0, 0, 0);
-	case MDB_EX_CMP: {
-		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
-		const bool lcol = l->kind == MDB_EX_FIELD || l->kind == MDB_EX_COUNT, rcol = r->kind == MDB_EX_FIELD || r->kind == MDB_EX_COUNT;
-		if (lcol && rcol) {
-			if (l->kind == MDB_EX_FIELD && l->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
-				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
-			a = pred_slot(x, p, l);
-			b = pred_slot(x, p, r);
-			if (a < 0 || b < 0)
-				return -1;
-			return pred_emit(p, MDB_P_CMP_COL_COL, e->op, (l->kind == MDB_EX_FIELD && l->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64,
-					 a, b, 0);
-		}
-		if (lcol || rcol) {
-			const struct mdb_expr *f = lcol ? l : r, *v = lcol ? r : l;
-			if (v->kind == MDB_EX_NULL)	/* NULL operand: never true (executor_select.c:793-795) */
-				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
-			/* TINYINT (bool) operands only know = and <> upstream (cmp_bool_value_to_value, executor_select.c:484-494): false */
-			if (f->kind == MDB_EX_FIELD && f->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
-				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
-			a = pred_slot(x, p, f);
-			if (a < 0)
-				return -1;
-			return pred_emit(p, lcol ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
-					 (f->kind == MDB_EX_FIELD && f->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64, a, 0,
-					 lit_bits_for(v, f->kind == MDB_EX_FIELD ? f->type : MDB_CT_INTEGER));
-		}
-		return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, const_cmp(e->op, l, r));
-	}
-	case MDB_EX_ISNULL:
-		a = pred_slot(x, p, e->kids[0]);
-		if (a < 0)
-			return -1;
-		return pred_emit(p, MDB_P_ISNULL, e->op ? 1 : 0, 0, a, 0, 0);
-	case MDB_EX_ISIN: {
-		/* x IN (v1..vk)  = (x = v1) OR ... OR (x = vk)   - SQL semantics; the reference's
-		 *                  conjunction (eval_isxin :1013-1021) is defect D3, identical for k = 1
-		 * x NOT IN (...) = (x <> v1) AND ... AND (x <> vk) - same as the reference */
-		const struct mdb_expr *f = e->kids[0];
-		a = pred_slot(x, p, f);
-		if (a < 0)
-			return -1;
-		for (int i = 1; i < e->nkids; i++) {
-			const struct mdb_expr *v = e->kids[i];
-			if (v->kind == MDB_EX_NULL)
-				rc = pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
-			else
-				rc = pred_emit(p, MDB_P_CMP_COL_CONST, e->op ? MDB_CMP_NE : MDB_CMP_EQ,
-					       f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits_for(v, f->type));
-			if (rc)
-				return rc;
-			if (i > 1 && (rc = pred_emit(p, e->op ? MDB_P_AND : MDB_P_OR, 0, 0, 0, 0, 0)))
-				return rc;
-		}
-		return 0;
-	}
-	default:
-		return -1;
-	}
-}
-
-/* filter the current stream (tables 0..ntabs-1) by predicate e */
-static int stream_filter(struct exec *x, int ntabs_in_stream, const struct mdb_expr *e)
-{
-	struct pred_prog p;
-	uint32_t *sel;
-	uint64_t m = 0;
-
-	if (x->n == 0)
-		return MIDORIDB_OK;
-	memset(&p, 0, sizeof(p));
-	if (pred_compile(x, &p, e)) {
-		snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
-			 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
-		return -MIDORIDB_ERROR;
-	}
-	sel = dalloc(x, x->n * 4);
-	if (!sel)
-		return dev_fail(x, "allocating the selection vector");
-	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, x->n, sel, &m))
-		return dev_fail(x, "filter");
-	return stream_apply_sel(x, ntabs_in_stream, sel, m);
-}
-
 /* ------------------------------------------------------------------ FROM clause */
 
 /* split an ON expression into conjuncts; pick the first "left-stream field = field of table t" as the hash key */
-static void collect_conjuncts(struct mdb_expr *e, struct mdb_expr **out, int *n, int cap)
+void collect_conjuncts(struct mdb_expr *e, struct mdb_expr **out, int *n, int cap)
 {
 	if (e->kind == MDB_EX_LOGOP && e->op == 0) {
 		collect_conjuncts(e->kids[0], out, n, cap);
@@ -1150,7 +175,7 @@ static void collect_conjuncts(struct mdb_expr *e, struct mdb_expr **out, int *n,
 }
 
 /* which FROM tables an expression reads: bit t set for table t */
-static uint64_t expr_tables(const struct mdb_expr *e)
+uint64_t expr_tables(const struct mdb_expr *e)
 {
 	uint64_t m = 0;
 	if (!e)
@@ -1166,16 +191,8 @@ static uint64_t expr_tables(const struct mdb_expr *e)
  * the same rows as filtering a table first whenever a conjunct reads only that table.  Splits the top-level
  * AND-conjuncts of the WHERE clause: push[t][..] = table t's own conjuncts (constants go with table 0),
  * residual[..] = conjuncts that read several tables and stay above the joins.  false = too many to split. */
-#define PUSH_MAX 16
-#define PUSH_TABS MDB_MAX_TABS
-struct where_split {
-	const struct mdb_expr *push[PUSH_TABS][PUSH_MAX];
-	int npush[PUSH_TABS];
-	const struct mdb_expr *residual[64];
-	int nresidual;
-};
 
-static bool where_split(const struct mdb_select *s, struct where_split *w)
+bool where_split(const struct mdb_select *s, struct where_split *w)
 {
 	struct mdb_expr *all[64];
 	int n = 0;
@@ -1204,7 +221,7 @@ static bool where_split(const struct mdb_select *s, struct where_split *w)
 }
 
 /* rows of base table t that pass its pushed-down conjuncts: *sel = ascending row ids (NULL = every row), *m = how many */
-static int table_filter(struct exec *x, int t, const struct mdb_expr *const *conj, int nconj, const uint32_t **sel, uint64_t *m)
+int table_filter(struct exec *x, int t, const struct mdb_expr *const *conj, int nconj, const uint32_t **sel, uint64_t *m)
 {
 	struct mdb_table *tb = x->s->tabs[t].t;
 	struct pred_prog p;
@@ -1236,7 +253,7 @@ static int table_filter(struct exec *x, int t, const struct mdb_expr *const *con
 }
 
 /* column `key` of base table t restricted to the rows in sel (NULL = all): device pointers for an operator */
-static int table_column(struct exec *x, int t, const struct mdb_expr *key, const uint32_t *sel, uint64_t m, const void **vals,
+int table_column(struct exec *x, int t, const struct mdb_expr *key, const uint32_t *sel, uint64_t m, const void **vals,
 			const uint64_t **nulls)
 {
 	struct mdb_column *col = &x->s->tabs[t].t->cols[key->col_idx];
@@ -1256,7 +273,7 @@ static int table_column(struct exec *x, int t, const struct mdb_expr *key, const
 }
 
 /* key column of table t for the fused plan: the base column, or the keys of the rows that pass the pushed conjuncts */
-static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struct mdb_expr *const *conj, int nconj,
+int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struct mdb_expr *const *conj, int nconj,
 			 const void **vals, const uint64_t **nulls, uint64_t *n)
 {
 	const uint32_t *sel;
@@ -1272,7 +289,7 @@ static int fused_operand(struct exec *x, int t, const struct mdb_expr *key, cons
  * Table t is then read through a SHADOW (like a table that arrived over the wire in sharded mode): its key column is the stream's own
  * key column, its payload columns are the carried cells, its row-id vector the identity.  0 = done, 1 = not such a join (nothing
  * changed: the pairs path answers), < 0 = error. */
-static int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl, const void *vr,
+int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl, const void *vr,
 			     const uint64_t *nr, uint64_t r_rows)
 {
 	struct mdb_select *s = x->s;
@@ -1325,7 +342,7 @@ static int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, c
 	return 0;
 }
 
-static int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, int npconj)
+int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, int npconj)
 {
 	struct mdb_select *s = x->s;
 	struct mdb_table *rt = s->tabs[t].t;
@@ -1502,7 +519,7 @@ void mdb_result_free(struct mdb_result *r)
 
 /* one result column device -> host; a NULL cell reads as 0 through query_column_int64(), like the reference
  * (cpy_cols skips the copy into the zeroed row, executor_select.c:384-387) */
-static int result_column_to_host(mdb_dev_ctx *dev, struct mdb_result *res, int c, const void *d_vals, const uint64_t *d_nulls)
+int result_column_to_host(mdb_dev_ctx *dev, struct mdb_result *res, int c, const void *d_vals, const uint64_t *d_nulls)
 {
 	const uint64_t rows = res->nrows;
 	if (!d_vals || !rows)
@@ -1541,7 +558,7 @@ int mdb_result_fetch(struct mdb_result *r)
 	return MIDORIDB_OK;
 }
 
-static double now_ms(void)
+double now_ms(void)
 {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1554,7 +571,7 @@ static double now_ms(void)
  * in the chain); a WHERE clause must be pushable below the joins (where_pushable).  keys[t] = the key field of
  * table t.  count_only: the query is SELECT COUNT(*) over the join without GROUP BY - the same operator, of which only
  * the joined-row total is used.  Returns 0 when it applies, -1 otherwise. */
-static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool count_only)
+int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool count_only)
 {
 	if (s->ntabs < 2 || (count_only ? s->ngroup != 0 : s->ngroup != 1))
 		return -1;
@@ -1594,7 +611,7 @@ static int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool 
 
 /* a two-table INNER JOIN ON l = r whose result columns are all one of the two key columns, nothing else asked of it, order left
  * open by the host (mdb_database_groups_any_order): kj[0..1] = the key fields (left table's first) */
-static bool keys_only_join(const struct mdb_select *s, const struct mdb_catalog *cat, int has_count, const int *key_tbl, const int *key_col,
+bool keys_only_join(const struct mdb_select *s, const struct mdb_catalog *cat, int has_count, const int *key_tbl, const int *key_col,
 			   const int *src, int ncols, const struct mdb_expr **kj)
 {
 	if (cat->dist || !cat->groups_any_order || s->ntabs != 2 || s->where || s->ngroup || has_count || s->distinct || s->norder || s->having ||
@@ -1616,108 +633,6 @@ static bool keys_only_join(const struct mdb_select *s, const struct mdb_catalog 
 			return false;
 	}
 	return true;
-}
-
-/* HAVING, DISTINCT, ORDER BY, LIMIT over the finished stream (after FROM / WHERE / GROUP BY) */
-static int select_tail(struct exec *x, int has_count)
-{
-	struct mdb_select *s = x->s;
-	const bool count_only = has_count && !s->ngroup;
-	int rc;
-
-	if (count_only)
-		return MIDORIDB_OK;	/* one row: HAVING is rejected at plan time, ORDER BY has nothing to order, LIMIT is applied by the caller */
-	if (s->having && (rc = stream_filter(x, s->ntabs, s->having)))
-		return rc;
-	if (s->distinct && x->n > 1) {
-		struct mdb_sort_key keys[MDB_SORT_MAX_KEYS];
-		int nk = 0;
-		uint32_t *sel;
-		uint64_t m = 0;
-		for (int t = 0; t < s->ntabs; t++)
-			for (int c = 0; c < s->tabs[t].t->ncols; c++) {
-				struct mdb_expr f;
-				bool want = s->select_all;
-				for (int i = 0; i < s->nsel && !want; i++)
-					want = s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == t && s->sel[i]->col_idx == c;
-				if (!want)
-					continue;
-				if (nk == MDB_SORT_MAX_KEYS) {
-					snprintf(x->err, x->errlen, "DISTINCT over more than %d columns is not supported\n", MDB_SORT_MAX_KEYS);
-					return -MIDORIDB_ERROR;
-				}
-				memset(&f, 0, sizeof(f));
-				f.kind = MDB_EX_FIELD;
-				f.tbl_idx = t;
-				f.col_idx = c;
-				bind_operand(x, &f, &keys[nk].values, &keys[nk].nullbits, &keys[nk].rid);
-				keys[nk].type = s->tabs[t].t->cols[c].type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
-				keys[nk].desc = 0;
-				nk++;
-			}
-		sel = dalloc(x, x->n * 4);
-		if (!sel)
-			return dev_fail(x, "allocating the DISTINCT selection");
-		if (nk == 1) {
-			/* one column: the hash GROUP BY operator already returns first occurrences in order (2-3x faster
-			 * than sorting at 10^8 rows); its COUNT(*) output is not needed */
-			const void *kv = keys[0].values;
-			const uint64_t *kn = keys[0].nullbits;
-			int64_t *cnt = dalloc(x, x->n * 8);
-			if (!cnt)
-				return dev_fail(x, "allocating the DISTINCT selection");
-			if (keys[0].rid) {
-				int64_t *v = dalloc(x, x->n * 8);
-				uint64_t *nb = kn ? dalloc(x, ((x->n + 63) / 64 + 1) * 8) : NULL;
-				if (!v || (kn && !nb) || mdb_dev_gather64(x->dev, kv, kn, keys[0].rid, x->n, v, nb))
-					return dev_fail(x, "gathering the DISTINCT column");
-				kv = v;
-				kn = nb;
-			}
-			if (mdb_dev_group_count(x->dev, kv, kn, x->n, MDB_ORDER_FIRST, sel, cnt, x->n, &m))
-				return dev_fail(x, "DISTINCT");
-		} else if (mdb_dev_distinct_sel(x->dev, keys, nk, x->n, sel, &m)) {
-			return dev_fail(x, "DISTINCT");
-		}
-		if ((rc = stream_apply_sel(x, s->ntabs, sel, m)))
-			return rc;
-	}
-	if (s->norder && x->n > 1) {
-		struct mdb_sort_key keys[MDB_SORT_MAX_KEYS];
-		uint32_t *perm;
-		for (int i = 0; i < s->norder; i++) {
-			bind_operand(x, s->order[i], &keys[i].values, &keys[i].nullbits, &keys[i].rid);
-			keys[i].type = s->order[i]->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64;
-			keys[i].desc = s->order_desc[i];
-		}
-		/* ORDER BY ... LIMIT: only the first offset + count rows of the order are ever looked at - top-k selection instead
-		 * of a sort of the whole stream (mdb_dev_topk_perm falls back to the sort by itself when that does not pay) */
-		uint64_t want = x->n;
-		if (s->has_limit && s->limit_off >= 0 && s->limit_cnt >= 0 && (uint64_t)s->limit_off + (uint64_t)s->limit_cnt < x->n)
-			want = (uint64_t)s->limit_off + (uint64_t)s->limit_cnt;
-		perm = dalloc(x, (want ? want : 1) * 4);
-		if (!perm)
-			return dev_fail(x, "allocating the ORDER BY permutation");
-		if (want < x->n) {
-			if (want && mdb_dev_topk_perm(x->dev, keys, s->norder, x->n, want, perm, NULL))
-				return dev_fail(x, "ORDER BY ... LIMIT");
-		} else if (mdb_dev_sort_perm(x->dev, keys, s->norder, x->n, perm))
-			return dev_fail(x, "ORDER BY");
-		if ((rc = stream_apply_sel(x, s->ntabs, perm, want)))
-			return rc;
-	}
-	if (s->has_limit) {
-		const uint64_t off = (uint64_t)s->limit_off < x->n ? (uint64_t)s->limit_off : x->n;
-		const uint64_t cnt = (uint64_t)s->limit_cnt < x->n - off ? (uint64_t)s->limit_cnt : x->n - off;
-		if (off || cnt < x->n) {
-			uint32_t *idx = dalloc(x, (off + cnt ? off + cnt : 1) * 4);
-			if (!idx || mdb_dev_iota32(x->dev, idx, off + cnt))
-				return dev_fail(x, "LIMIT");
-			if ((rc = stream_apply_sel(x, s->ntabs, idx + off, cnt)))
-				return rc;
-		}
-	}
-	return MIDORIDB_OK;
 }
 
 int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_result **out, char *err, size_t errlen)
@@ -2449,384 +1364,5 @@ out:
 	free(src);
 	free(direct_vals);
 	free(direct_nulls);
-	return rc;
-}
-
-/* ------------------------------------------------------------------ DELETE / UPDATE
- *
- * MI355X replacements of scan_delete() (reference src/engine/executor_delete.c:412-440) and scan_update()
- * (src/engine/executor_update.c:460-484), the two callers SURVEY.md 8f row 1 names beside INSERT: the
- * WHERE clause runs through the same device predicate program as SELECT's (mdb_dev_filter), the rows are
- * removed (order-preserving compaction = what a later scan of the reference's flagged rows sees) or
- * rewritten ON the device mirror, and the host copy - when the table has one - follows, so the mirror is
- * never re-uploaded because of a DELETE or an UPDATE.
- *
- * Semantics kept (and where the reference's defects bound the domain):
- *   - a comparison with a NULL operand is false; IS [NOT] NULL reads the bitmap (executor_delete.c:170-195, 300-316)
- *   - literal types must equal the column type (semantic_delete.c:226-262, semantic_update.c:229-265)
- *   - UPDATE evaluates WHERE on the row's old values, then applies every assignment (executor_update.c:474-476)
- *   - SET col = NULL sets the NULL bit and leaves the cell's bytes; a value clears it (:411-415)
- *   - `value <op> column` is rejected: the reference evaluates it as `column <op> value` (executor_delete.c:281-283)
- *   - INT comparisons upstream go through `int` parameters (executor_delete.c:52): identical for values in
- *     [-2^31, 2^31), which is SURVEY's agreement domain D5
- *   - x NOT IN (a, b, ...) with more than one value is true upstream when x differs from ANY value
- *     (executor_delete.c:318-352); here it has SQL semantics, as in SELECT (defect D3)
- */
-static int dml_value_on_left(const struct mdb_expr *e)
-{
-	if (!e)
-		return 0;
-	if (e->kind == MDB_EX_CMP && e->kids[0]->kind != MDB_EX_FIELD && e->kids[1]->kind == MDB_EX_FIELD)
-		return 1;
-	for (int i = 0; i < e->nkids; i++)
-		if (dml_value_on_left(e->kids[i]))
-			return 1;
-	return 0;
-}
-
-/* value-to-value comparisons: both literals of one kind (semantic_delete.c:273-325, semantic_update.c:276-328) */
-static int dml_check_values(const struct mdb_expr *e, char *err, size_t errlen)
-{
-	int rc;
-	if (!e)
-		return MIDORIDB_OK;
-	if (e->kind == MDB_EX_CMP && e->kids[0]->kind != MDB_EX_FIELD && e->kids[1]->kind != MDB_EX_FIELD) {
-		if (e->kids[0]->kind != e->kids[1]->kind) {
-			ERR("value-to-value comparison don't have the same type\n");
-			return -MIDORIDB_ERROR;
-		}
-		if (e->kids[0]->kind == MDB_EX_NULL && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE) {
-			ERR("value-to-value NULL comparisons can only use '=' or '<>'\n");
-			return -MIDORIDB_ERROR;
-		}
-	}
-	for (int i = 0; i < e->nkids; i++)
-		if ((rc = dml_check_values(e->kids[i], err, errlen)))
-			return rc;
-	return MIDORIDB_OK;
-}
-
-/* common front half: table lookup, WHERE resolution and checks, device mirror, selection.
- * *sel = device vector of the selected row positions (ascending), NULL when every row is selected
- * (no WHERE); with `complement` the rows NOT matching the predicate are selected instead. */
-static int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct exec *x, struct mdb_select *s, struct mdb_from_tab *tab,
-			   bool complement, struct mdb_table **out_t, const uint32_t **sel, uint64_t *m, char *err, size_t errlen)
-{
-	struct mdb_table *t = mdb_catalog_find(cat, d->name);
-	int rc;
-
-	*sel = NULL;
-	*m = 0;
-	if (!t) {
-		ERR("table '%s' doesn't exist\n", d->name);
-		return -MIDORIDB_ERROR;
-	}
-	*out_t = t;
-	memset(s, 0, sizeof(*s));
-	memset(tab, 0, sizeof(*tab));
-	mdb_copy_name(tab->name, t->name);
-	tab->t = t;
-	s->tabs = tab;
-	s->ntabs = 1;
-	if (d->where) {
-		if ((rc = resolve_expr(s, d->where, err, errlen)) || (rc = check_predicate_x(d->where, "where", true, err, errlen)) ||
-		    (rc = dml_check_values(d->where, err, errlen)))
-			return rc;
-		if (dml_value_on_left(d->where)) {
-			ERR("comparisons in DELETE/UPDATE must have the column on the left (the reference evaluates 'value <op> column' "
-			    "as 'column <op> value', executor_delete.c:281-283)\n");
-			return -MIDORIDB_ERROR;
-		}
-	}
-	if ((rc = mdb_catalog_device(cat, err, errlen)) || (rc = mdb_table_sync_device(cat, t, err, errlen)))
-		return rc;
-	memset(x, 0, sizeof(*x));
-	for (int i = 0; i < MDB_MAX_TABS; i++)
-		x->same_col[i] = -1;
-	x->cat = cat;
-	x->dev = cat->dev;
-	x->s = s;
-	x->err = err;
-	x->errlen = errlen;
-	x->n = t->nrows;
-	*m = t->nrows;
-	if (d->where && t->nrows) {
-		struct pred_prog p;
-		uint32_t *v;
-		memset(&p, 0, sizeof(p));
-		if (pred_compile(x, &p, d->where) ||
-		    (complement && (pred_emit(&p, MDB_P_CONST, 0, 0, 0, 0, 1) || pred_emit(&p, MDB_P_XOR, 0, 0, 0, 0, 0)))) {
-			ERR("execution phase: predicate too large for the device program (max %d steps, %d columns)\n", MDB_PRED_MAX_INSNS,
-			    MDB_PRED_MAX_SLOTS);
-			return -MIDORIDB_ERROR;
-		}
-		v = dalloc(x, t->nrows * 4);
-		if (!v)
-			return dev_fail(x, "allocating the selection vector");
-		if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, t->nrows, v, m))
-			return dev_fail(x, "filter");
-		*sel = v;
-	} else if (complement) {
-		*m = 0;		/* no WHERE: nothing is kept */
-	}
-	return MIDORIDB_OK;
-}
-
-int mdb_exec_delete(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen)
-{
-	stmt_dict = &cat->dict;
-	struct exec x;
-	struct mdb_select s;
-	struct mdb_from_tab tab;
-	struct mdb_table *t = NULL;
-	const uint32_t *keep = NULL;
-	uint32_t *h_keep = NULL;
-	uint64_t n_keep = 0, n_old;
-	int rc;
-
-	memset(&x, 0, sizeof(x));
-	for (int t = 0; t < MDB_MAX_TABS; t++)
-		x.same_col[t] = -1;
-	*n_rows_aff = 0;
-	rc = dml_select_rows(cat, d, &x, &s, &tab, true, &t, &keep, &n_keep, err, errlen);
-	if (rc)
-		goto out;
-	n_old = t->nrows;
-	if (n_keep == n_old)
-		goto out;	/* nothing matched */
-	if (t->dev_cap < n_old)
-		t->dev_cap = n_old;
-	/* ---- device mirror: order-preserving compaction of every column */
-	for (int c = 0; c < t->ncols; c++) {
-		struct mdb_column *col = &t->cols[c];
-		void *nd = NULL;
-		uint64_t *nb = NULL;
-		if (!col->d_data)
-			continue;
-		if (n_keep) {
-			const uint64_t words = (t->dev_cap + 63) / 64;
-			if (mdb_dev_alloc(x.dev, t->dev_cap * 8, &nd) ||
-			    (col->d_nullbits && (mdb_dev_alloc(x.dev, words * 8, (void **)&nb) || mdb_dev_memset(x.dev, nb, 0, words * 8))) ||
-			    mdb_dev_gather64(x.dev, col->d_data, col->d_nullbits, keep, n_keep, nd, nb)) {
-				if (nd)
-					mdb_dev_free(x.dev, nd);
-				if (nb)
-					mdb_dev_free(x.dev, nb);
-				rc = dev_fail(&x, "compacting a column");
-				/* columns already swapped are shorter than the rest: drop the mirror, the host copy is intact */
-				t->dev_generation = 0;
-				goto out;
-			}
-		}
-		if (mdb_dev_sync(x.dev)) {
-			rc = dev_fail(&x, "compacting a column");
-			t->dev_generation = 0;
-			goto out;
-		}
-		mdb_dev_free(x.dev, col->d_data);
-		if (col->d_nullbits)
-			mdb_dev_free(x.dev, col->d_nullbits);
-		col->d_data = nd;
-		col->d_nullbits = nb;
-	}
-	/* ---- host copy */
-	if (!t->device_only) {
-		if (n_keep) {
-			h_keep = malloc(n_keep * 4);
-			if (!h_keep) {
-				rc = -MIDORIDB_NOMEM;
-				t->dev_generation = 0;
-				goto out;
-			}
-			if (mdb_dev_d2h(x.dev, h_keep, keep, n_keep * 4)) {
-				rc = dev_fail(&x, "reading the surviving row ids");
-				t->dev_generation = 0;
-				goto out;
-			}
-		}
-		for (int c = 0; c < t->ncols; c++) {
-			struct mdb_column *col = &t->cols[c];
-			uint64_t nulls = 0;
-			for (uint64_t k = 0; k < n_keep; k++) {		/* ascending ids: in place */
-				const uint64_t r = h_keep[k];
-				const bool isnull = (col->nullbits[r >> 6] >> (r & 63)) & 1;
-				col->data[k] = col->data[r];
-				if (isnull)
-					col->nullbits[k >> 6] |= 1ull << (k & 63);
-				else
-					col->nullbits[k >> 6] &= ~(1ull << (k & 63));
-				nulls += isnull;
-			}
-			for (uint64_t k = n_keep; k < n_old; k++)		/* vacated tail: clean bits for later appends */
-				col->nullbits[k >> 6] &= ~(1ull << (k & 63));
-			col->null_count = nulls;
-		}
-	}
-	t->nrows = n_keep;
-	t->generation++;
-	if (t->dev_generation) {
-		if (n_keep == 0) {
-			t->dev_generation = 0;	/* empty mirror: rebuilt by the next upload */
-			t->dev_rows = 0;
-			t->dev_cap = 0;
-		} else {
-			t->dev_generation = t->generation;
-			t->dev_rows = n_keep;
-		}
-	}
-	*n_rows_aff = (size_t)(n_old - n_keep);
-out:
-	free(h_keep);
-	free_all(&x);
-	return rc;
-}
-
-int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_aff, char *err, size_t errlen)
-{
-	stmt_dict = &cat->dict;
-	struct exec x;
-	struct mdb_select s;
-	struct mdb_from_tab tab;
-	struct mdb_table *t = mdb_catalog_find(cat, d->name);
-	const uint32_t *sel = NULL;
-	uint32_t *h_sel = NULL;
-	uint64_t m = 0;
-	int acol[MDB_MAX_COLS];
-	int rc = MIDORIDB_OK;
-
-	memset(&x, 0, sizeof(x));
-	for (int t = 0; t < MDB_MAX_TABS; t++)
-		x.same_col[t] = -1;
-	*n_rows_aff = 0;
-	if (!t) {
-		ERR("table '%s' doesn't exist\n", d->name);
-		return -MIDORIDB_ERROR;
-	}
-	if (d->nassign > MDB_MAX_COLS) {
-		ERR("too many assignments\n");
-		return -MIDORIDB_ERROR;
-	}
-	/* assignment checks (semantic_update.c:418-460: the value must have the column's type, NULL always fits) */
-	for (int a = 0; a < d->nassign; a++) {
-		const struct mdb_expr *v = d->assign[a].val;
-		acol[a] = -1;
-		for (int c = 0; c < t->ncols; c++)
-			if (strcmp(t->cols[c].name, d->assign[a].col) == 0)
-				acol[a] = c;
-		if (acol[a] < 0) {
-			ERR("no such column: '%.128s'\n", d->assign[a].col);
-			return -MIDORIDB_ERROR;
-		}
-		if (v->kind != MDB_EX_INT && v->kind != MDB_EX_FLOAT && v->kind != MDB_EX_NULL && v->kind != MDB_EX_BOOL && v->kind != MDB_EX_STRING) {
-			ERR("only literal values can be assigned on the MI355X path\n");
-			return -MIDORIDB_ERROR;
-		}
-		if (v->kind == MDB_EX_INT && t->cols[acol[a]].type != MDB_CT_INTEGER) {
-			ERR("val: '%ld' requires an INTEGER column\n", (long)v->ival);
-			return -MIDORIDB_ERROR;
-		}
-		if (v->kind == MDB_EX_FLOAT && t->cols[acol[a]].type != MDB_CT_DOUBLE) {
-			ERR("val: '%f' requires a DOUBLE column\n", v->dval);
-			return -MIDORIDB_ERROR;
-		}
-		if (v->kind == MDB_EX_BOOL && t->cols[acol[a]].type != MDB_CT_TINYINT) {
-			ERR("val: '%d' requires a TINYINT column\n", (int)v->ival);
-			return -MIDORIDB_ERROR;
-		}
-		if (v->kind == MDB_EX_STRING) {
-			const struct mdb_column *col = &t->cols[acol[a]];
-			int64_t tv;
-			if (col->type == MDB_CT_DATE || col->type == MDB_CT_DATETIME) {
-				if (!mdb_parse_time(v->sval, col->type, &tv)) {
-					ERR("val: '%.256s' can't be parsed for DATE | DATETIME column\n", v->sval);
-					return -MIDORIDB_ERROR;
-				}
-			} else if (col->type == MDB_CT_VARCHAR) {
-				/* UPDATE does not check the length (INSERT does): the reference copies the first precision - 1 characters
-				 * (strncpy, executor_update.c:425-426); the literal is cut here so that everything below sees that string */
-				const size_t len = strlen(v->sval) - 2, keep = col->precision > 0 ? (size_t)col->precision - 1 : 0;
-				if (len > keep) {
-					v->sval[1 + keep] = v->sval[0];
-					v->sval[2 + keep] = 0;
-				}
-				if (!mdb_dict_intern(&cat->dict, v->sval + 1, strlen(v->sval) - 2))	/* lit_bits_for() finds the id below */
-					return -MIDORIDB_NOMEM;
-			} else {
-				ERR("val: '%.256s' requires an VARCHAR() column\n", v->sval);
-				return -MIDORIDB_ERROR;
-			}
-		}
-		if (v->kind == MDB_EX_NULL && t->cols[acol[a]].not_null) {
-			ERR("NOT NULL constraint failed: %s.%s\n", t->name, t->cols[acol[a]].name);
-			return -MIDORIDB_ERROR;
-		}
-	}
-	rc = dml_select_rows(cat, d, &x, &s, &tab, false, &t, &sel, &m, err, errlen);
-	if (rc || m == 0)
-		goto out;
-	/* ---- device mirror */
-	for (int a = 0; a < d->nassign; a++) {
-		struct mdb_column *col = &t->cols[acol[a]];
-		const struct mdb_expr *v = d->assign[a].val;
-		const bool set_null = v->kind == MDB_EX_NULL;
-		if (set_null && !col->d_nullbits) {
-			const uint64_t words = (t->dev_cap + 63) / 64;
-			if (mdb_dev_alloc(x.dev, words * 8, (void **)&col->d_nullbits) || mdb_dev_memset(x.dev, col->d_nullbits, 0, words * 8)) {
-				rc = dev_fail(&x, "allocating a NULL bitmap");
-				t->dev_generation = 0;
-				goto out;
-			}
-		}
-		if (mdb_dev_scatter_set64(x.dev, col->d_data, col->d_nullbits, sel, m, set_null ? 0 : lit_bits_for(v, col->type), set_null)) {
-			rc = dev_fail(&x, "updating a column");
-			t->dev_generation = 0;
-			goto out;
-		}
-	}
-	if (mdb_dev_sync(x.dev)) {
-		rc = dev_fail(&x, "updating a column");
-		t->dev_generation = 0;
-		goto out;
-	}
-	/* ---- host copy */
-	if (!t->device_only) {
-		if (sel) {
-			h_sel = malloc(m * 4);
-			if (!h_sel) {
-				rc = -MIDORIDB_NOMEM;
-				t->dev_generation = 0;
-				goto out;
-			}
-			if (mdb_dev_d2h(x.dev, h_sel, sel, m * 4)) {
-				rc = dev_fail(&x, "reading the selected row ids");
-				t->dev_generation = 0;
-				goto out;
-			}
-		}
-		for (int a = 0; a < d->nassign; a++) {
-			struct mdb_column *col = &t->cols[acol[a]];
-			const struct mdb_expr *v = d->assign[a].val;
-			const int64_t bits = v->kind == MDB_EX_NULL ? 0 : lit_bits_for(v, col->type);
-			for (uint64_t k = 0; k < m; k++) {
-				const uint64_t r = h_sel ? h_sel[k] : k;
-				const bool was_null = (col->nullbits[r >> 6] >> (r & 63)) & 1;
-				if (v->kind == MDB_EX_NULL) {
-					col->nullbits[r >> 6] |= 1ull << (r & 63);
-					col->null_count += !was_null;
-				} else {
-					col->data[r] = bits;
-					col->nullbits[r >> 6] &= ~(1ull << (r & 63));
-					col->null_count -= was_null;
-				}
-			}
-		}
-	}
-	t->generation++;
-	if (t->dev_generation)
-		t->dev_generation = t->generation;
-	*n_rows_aff = (size_t)m;
-out:
-	free(h_sel);
-	free_all(&x);
 	return rc;
 }

@@ -1,0 +1,189 @@
+/*
+ * mdb_exec_pred.c - WHERE / ON / HAVING expressions compiled into the device's postfix predicate programs (mdb_dev_filter)
+ * and run over the tuple stream (reference: eval_row_cond / eval_cmp / eval_isxnull / eval_isxin,
+ * src/engine/executor_select.c:865-1074).  Split off mdb_exec.c in round 4.
+ */
+#include "mdb_exec_internal.h"
+
+/* ------------------------------------------------------------------ predicate compiler */
+
+
+/* device binding of a column-like operand for the current stream: a table column read through the table's
+ * row-id vector, the COUNT(*) column (HAVING), or - in the fused north-star plan, whose stream carries no row
+ * ids - the group key column (the only field S4 lets such a query name) */
+void bind_operand(struct exec *x, const struct mdb_expr *f, const void **values, const uint64_t **nullbits, const uint32_t **rid)
+{
+	if (f->kind == MDB_EX_COUNT) {
+		*values = x->d_count;
+		*nullbits = NULL;
+		*rid = NULL;
+	} else if (x->fused) {
+		*values = x->d_fused_key;
+		*nullbits = NULL;
+		*rid = NULL;
+	} else {
+		struct mdb_column *col = &x->s->tabs[f->tbl_idx].t->cols[f->col_idx];
+		*values = col->d_data;
+		*nullbits = col->d_nullbits;
+		*rid = x->rid[f->tbl_idx];
+	}
+}
+
+int pred_slot(struct exec *x, struct pred_prog *p, const struct mdb_expr *f)
+{
+	const int st = f->kind == MDB_EX_COUNT ? -2 : f->tbl_idx, sc = f->kind == MDB_EX_COUNT ? -2 : f->col_idx;
+	for (int i = 0; i < p->ncols; i++)
+		if (p->slot_tbl[i] == st && p->slot_col[i] == sc)
+			return i;
+	if (p->ncols == MDB_PRED_MAX_SLOTS)
+		return -1;
+	p->slot_tbl[p->ncols] = st;
+	p->slot_col[p->ncols] = sc;
+	bind_operand(x, f, &p->cols[p->ncols].values, &p->cols[p->ncols].nullbits, &p->cols[p->ncols].rid);
+	return p->ncols++;
+}
+
+int pred_emit(struct pred_prog *p, int op, int cmp, int type, int a, int b, int64_t imm)
+{
+	struct mdb_pred_insn *in;
+	if (p->n == MDB_PRED_MAX_INSNS)
+		return -1;
+	in = &p->insn[p->n++];
+	memset(in, 0, sizeof(*in));
+	in->op = op;
+	in->cmp = cmp;
+	in->type = type;
+	in->a = a;
+	in->b = b;
+	in->imm = imm;
+	return 0;
+}
+
+/* the 8 bytes a literal stands for in a column of type coltype (a DATE / DATETIME string: its time_t, validated by
+ * check_predicate_x / the UPDATE checks) */
+/* the string dictionary of the database the running statement belongs to (set by the statement entry points) */
+__thread const struct mdb_strdict *stmt_dict __attribute__((visibility("hidden")));
+
+int64_t lit_bits_for(const struct mdb_expr *v, int coltype)
+{
+	int64_t bits = 0;
+	if (v->kind == MDB_EX_FLOAT) {
+		memcpy(&bits, &v->dval, 8);
+		return bits;
+	}
+	if (v->kind == MDB_EX_STRING && coltype == MDB_CT_VARCHAR)	/* a string no cell holds has id -1: equal to nothing */
+		return stmt_dict ? mdb_dict_find(stmt_dict, v->sval + 1, strlen(v->sval) - 2) : -1;
+	if (v->kind == MDB_EX_STRING) {
+		(void)mdb_parse_time(v->sval, coltype, &bits);
+		return bits;
+	}
+	return v->ival;
+}
+
+bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
+{
+	if (l->kind == MDB_EX_NULL || r->kind == MDB_EX_NULL)
+		return false;			/* executor_select.c:660-662 */
+	if (l->kind == MDB_EX_STRING || r->kind == MDB_EX_STRING)
+		return false;			/* (rejected by the type check; never evaluated) */
+	if (l->kind == MDB_EX_FLOAT) {
+		double a = l->dval, b = r->dval;
+		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
+	} else {
+		int64_t a = l->ival, b = r->ival;
+		return op == 1 ? a < b : op == 2 ? a > b : op == 3 ? a != b : op == 4 ? a == b : op == 5 ? a <= b : a >= b;
+	}
+}
+
+int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_expr *e)
+{
+	int rc = 0, a, b;
+
+	switch (e->kind) {
+	case MDB_EX_LOGOP:
+		if ((rc = pred_compile(x, p, e->kids[0])) || (rc = pred_compile(x, p, e->kids[1])))
+			return rc;
+		return pred_emit(p, e->op == 0 ? MDB_P_AND : (e->op == 1 ? MDB_P_OR : MDB_P_XOR), 0, 0, 0, 0, 0);
+	case MDB_EX_CMP: {
+		const struct mdb_expr *l = e->kids[0], *r = e->kids[1];
+		const bool lcol = l->kind == MDB_EX_FIELD || l->kind == MDB_EX_COUNT, rcol = r->kind == MDB_EX_FIELD || r->kind == MDB_EX_COUNT;
+		if (lcol && rcol) {
+			if (l->kind == MDB_EX_FIELD && l->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			a = pred_slot(x, p, l);
+			b = pred_slot(x, p, r);
+			if (a < 0 || b < 0)
+				return -1;
+			return pred_emit(p, MDB_P_CMP_COL_COL, e->op, (l->kind == MDB_EX_FIELD && l->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64,
+					 a, b, 0);
+		}
+		if (lcol || rcol) {
+			const struct mdb_expr *f = lcol ? l : r, *v = lcol ? r : l;
+			if (v->kind == MDB_EX_NULL)	/* NULL operand: never true (executor_select.c:793-795) */
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			/* TINYINT (bool) operands only know = and <> upstream (cmp_bool_value_to_value, executor_select.c:484-494): false */
+			if (f->kind == MDB_EX_FIELD && f->type == MDB_CT_TINYINT && e->op != MDB_CMP_EQ && e->op != MDB_CMP_NE)
+				return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			a = pred_slot(x, p, f);
+			if (a < 0)
+				return -1;
+			return pred_emit(p, lcol ? MDB_P_CMP_COL_CONST : MDB_P_CMP_CONST_COL, e->op,
+					 (f->kind == MDB_EX_FIELD && f->type == MDB_CT_DOUBLE) ? MDB_T_DOUBLE : MDB_T_INT64, a, 0,
+					 lit_bits_for(v, f->kind == MDB_EX_FIELD ? f->type : MDB_CT_INTEGER));
+		}
+		return pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, const_cmp(e->op, l, r));
+	}
+	case MDB_EX_ISNULL:
+		a = pred_slot(x, p, e->kids[0]);
+		if (a < 0)
+			return -1;
+		return pred_emit(p, MDB_P_ISNULL, e->op ? 1 : 0, 0, a, 0, 0);
+	case MDB_EX_ISIN: {
+		/* x IN (v1..vk)  = (x = v1) OR ... OR (x = vk)   - SQL semantics; the reference's
+		 *                  conjunction (eval_isxin :1013-1021) is defect D3, identical for k = 1
+		 * x NOT IN (...) = (x <> v1) AND ... AND (x <> vk) - same as the reference */
+		const struct mdb_expr *f = e->kids[0];
+		a = pred_slot(x, p, f);
+		if (a < 0)
+			return -1;
+		for (int i = 1; i < e->nkids; i++) {
+			const struct mdb_expr *v = e->kids[i];
+			if (v->kind == MDB_EX_NULL)
+				rc = pred_emit(p, MDB_P_CONST, 0, 0, 0, 0, 0);
+			else
+				rc = pred_emit(p, MDB_P_CMP_COL_CONST, e->op ? MDB_CMP_NE : MDB_CMP_EQ,
+					       f->type == MDB_CT_DOUBLE ? MDB_T_DOUBLE : MDB_T_INT64, a, 0, lit_bits_for(v, f->type));
+			if (rc)
+				return rc;
+			if (i > 1 && (rc = pred_emit(p, e->op ? MDB_P_AND : MDB_P_OR, 0, 0, 0, 0, 0)))
+				return rc;
+		}
+		return 0;
+	}
+	default:
+		return -1;
+	}
+}
+
+/* filter the current stream (tables 0..ntabs-1) by predicate e */
+int stream_filter(struct exec *x, int ntabs_in_stream, const struct mdb_expr *e)
+{
+	struct pred_prog p;
+	uint32_t *sel;
+	uint64_t m = 0;
+
+	if (x->n == 0)
+		return MIDORIDB_OK;
+	memset(&p, 0, sizeof(p));
+	if (pred_compile(x, &p, e)) {
+		snprintf(x->err, x->errlen, "execution phase: predicate too large for the device program (max %d steps, %d columns)\n",
+			 MDB_PRED_MAX_INSNS, MDB_PRED_MAX_SLOTS);
+		return -MIDORIDB_ERROR;
+	}
+	sel = dalloc(x, x->n * 4);
+	if (!sel)
+		return dev_fail(x, "allocating the selection vector");
+	if (mdb_dev_filter(x->dev, p.insn, p.n, p.cols, p.ncols, x->n, sel, &m))
+		return dev_fail(x, "filter");
+	return stream_apply_sel(x, ntabs_in_stream, sel, m);
+}
