@@ -683,6 +683,29 @@ def main():
             line["pipeline"]["traffic"] = pmc_step_traffic(kern, pmc_variant, algo_bytes)
         if exchange is not None:
             line["exchange"] = exchange
+        if world == 1:
+            # what the sharded operator WOULD plan for this workload at 2, 4 and 8 GPUs (weak scaling: the same rows per GPU, the key
+            # ranges of the N-fold tables) - mdb_dist_plan_preview, a host computation: which layout branch runs and what crosses one
+            # xGMI link per call, so that the first multi-GPU run can be read against a prediction
+            try:
+                from midoridb_amd.dist import plan_preview
+                prev = {}
+                for w in (2, 4, 8):
+                    tot = n * w
+                    r_hi = {"D": tot // 16 - 1, "U": tot - 1, "S": 16 * (tot // 16 - 1)}[args.variant]
+                    pp = plan_preview(w, [n, n], (0, tot - 1), (0, r_hi))
+                    if pp is None:
+                        prev[str(w)] = {"path": "keys by destination (the regions-on-the-wire plan does not serve this shape)"}
+                        continue
+                    prev[str(w)] = {"plan": {k: pp[k] for k in ("digit_bits", "digits_per_rank", "key_bits", "receiver_bits", "leaf_bits", "word_bytes")},
+                                    "bytes_per_peer_per_call": pp["bytes_per_peer"],
+                                    "predicted_link_ms": pp["bytes_per_peer"] / (153.0 * 1e9) * 1e3}
+                line["exchange_preview"] = {"scaling": "weak", "xgmi_link_GBs": 153.0, "by_world": prev,
+                                            "note": "predicted_link_ms = bytes one rank sends to ONE peer per call / one xGMI link's rate; the pass "
+                                                    "over table x + 1 overlaps the transfer of table x, so the wire shows where it exceeds ~half the "
+                                                    "first-level time (2 GPUs: every other row crosses the one link between the pair)"}
+            except Exception as e:  # pragma: no cover
+                line["exchange_preview"] = {"error": str(e)}
         # the first-level scatter of the left table beside it: the bandwidth-bound kernel of the pipeline
         for cand in ("part_scatter_l0", "part_scatter_l0_pruned", "part_scatter_l0_rid", "part_scatter_l0_w32"):
             if cand in kern and cand != dom_name:

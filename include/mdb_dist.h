@@ -112,6 +112,12 @@ struct mdb_dist_plan_info {
 	uint64_t bytes_per_peer;	/* all tables' blocks + region counters: what crosses ONE xGMI link per direction and call */
 };
 int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *out);
+/* The plan a call WOULD make at `world` ranks (1, 2, 4, 8) for `tables` tables whose largest shards hold rows_per_rank[t] rows and whose
+ * global key ranges are left[] / right[]: a pure host computation (no handle, no GPU) - capacity planning, and what bench.py prints
+ * beside a one-GPU measurement: bytes per xGMI link and call at 2, 4 and 8 GPUs.  Returns 1 when the shape is not served by the
+ * regions-on-the-wire path at that world size (the key-by-destination path would run). */
+int mdb_dist_plan_preview(int world, int tables, const uint64_t *rows_per_rank, const int64_t left[2], const int64_t right[2],
+			  struct mdb_dist_plan_info *out);
 /* Where a regions-on-the-wire call spends its time on this rank (measurement aid: HIP events on the operator's and the transfer
  * stream; off by default).  ms[0] = first level of every table (sender), ms[1] = time the receiver's first kernel waited for
  * the last block to arrive after the sender's passes were done (the wire, as far as it is not hidden), ms[2] = receiver (region

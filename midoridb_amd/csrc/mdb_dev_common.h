@@ -57,6 +57,9 @@ struct mdb_col_memo {
 	int ex_uses;
 	const void *pw_bad_keys;	/* right key column (and row count) the one-level unique-key join (join_pairs_unique_wide) gave up on */
 	uint64_t pw_bad_n;
+	const void *jk_dup_l, *jk_dup_r;	/* key columns whose join had COUNTs above 1 (mdb_dev_join_keys asks for the COUNT column at once) */
+	uint64_t jk_dup_nl, jk_dup_nr;
+	int jk_dup_uses;
 	const void *jp_bad_l, *jp_bad_r;	/* key columns mdb_dev_join_payload found not to be an every-left-row-has-its-partner join */
 	uint64_t jp_bad_nl, jp_bad_nr;
 	int jp_bad_skips;
@@ -95,6 +98,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
 	int last_pairs_identity;	/* the last mdb_dev_join_pairs: every left row joined exactly one right row - its left vector is 0, 1, 2 ... */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
+	int unordered_no_counts;	/* set by mdb_dev_join_keys around its call of the any-order operator: group keys only, no COUNT column */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	bool guess_remembered;		/* the last narrow-form decision came from the memo, not from a sample of the data */
 	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */

@@ -2711,7 +2711,7 @@ again: {
 		if (rc)
 			return rc;
 	}
-	rc = mdb_shard_join(ctx, &plan, regions, cursors, out_key, out_count, cap);	/* (world 1: what was sent is what arrived) */
+	rc = mdb_shard_join(ctx, &plan, regions, cursors, out_key, ctx->unordered_no_counts ? NULL : out_count, cap);	/* (world 1: what was sent is what arrived) */
 	if (rc)
 		return rc;
 	MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));

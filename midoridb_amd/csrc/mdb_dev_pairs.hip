@@ -945,6 +945,121 @@ __global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_payload(pp_args a, ui
 		atomicAdd(a.joined, pairs);
 }
 
+/* ONE payload column: the cells themselves sit in the LDS table (8 bytes per key value, 2^14 of them: 128 KiB) - a right row drops
+ * its cell at its key's slot, a left row picks it up: no global lookup at all, the only scattered access left is the store to
+ * out[left row id].  A digit of 2^15 key values (windows of 2^24) is joined in two passes over its words, one per half of the
+ * slots - the second pass reads what the first has just pulled through the L2.  (The variant above looks the cells up in the digit's
+ * regions: 10^7 scattered 8-byte loads fetch 32-byte sectors that leave the 4 MiB L2 before their other cells are asked for -
+ * PMC: 0.98 GB fetched for 0.24 GB - and cost 0.08 ms of its 0.30.)  Duplicate right keys are seen by the occupancy bitmap. */
+#define PC_SLOT_BITS 14u
+__global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_cell(pp_args a, uint32_t rem, uint32_t shift)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t pp_lds[];
+	__shared__ unsigned long long s_red[PW_THREADS / 64];
+	__shared__ uint32_t s_cnt[2][PP_MAX_SUB], s_pstart[2][PP_MAX_SUB + 1];
+	__shared__ uint32_t s_dup;
+	const uint32_t lowbits = rem < PC_SLOT_BITS ? rem : PC_SLOT_BITS, npass = 1u << (rem - lowbits), S = 1u << lowbits, leaf = blockIdx.x;
+	const uint32_t mask = (1u << rem) - 1u;
+	uint64_t *const cellt = reinterpret_cast<uint64_t *>(pp_lds);		/* [S] */
+	uint32_t *const occ = pp_lds + 2u * S;					/* [S / 32] */
+	if (threadIdx.x == 0)
+		s_dup = 0u;
+	if (threadIdx.x < 2u * PP_MAX_SUB) {
+		const uint32_t side = threadIdx.x / PP_MAX_SUB, sub = threadIdx.x % PP_MAX_SUB;
+		uint32_t c = 0;
+		if (sub < a.nsub) {
+			c = side ? a.cnt_r[sub * a.nleaves + leaf] : a.cnt_l[sub * a.nleaves + leaf];
+			const uint32_t cap = side ? a.cap_r : a.cap_l;
+			c = c < cap ? c : cap;
+		}
+		s_cnt[side][sub] = c;
+	}
+	__syncthreads();
+	if (threadIdx.x < 2u) {
+		uint32_t run = 0;
+		for (uint32_t k = 0; k < PP_MAX_SUB; k++) {
+			s_pstart[threadIdx.x][k] = run;
+			run += (s_cnt[threadIdx.x][k] + 1u) >> 1;
+		}
+		s_pstart[threadIdx.x][PP_MAX_SUB] = run;
+	}
+	__syncthreads();
+	unsigned long long pairs = 0;
+	for (uint32_t pass = 0; pass < npass; pass++) {		/* (uniform) */
+		for (uint32_t w = threadIdx.x; w < (S >> 5 ? S >> 5 : 1u); w += PW_THREADS)
+			occ[w] = 0u;
+		__syncthreads();
+		{	/* ---- right rows of this pass's slots: cell into the table, occupancy bit set */
+			const uint32_t P = s_pstart[1][PP_MAX_SUB];
+			for (uint32_t p0 = 0; p0 < P; p0 += PW_THREADS * PW_UNROLL) {
+				ulonglong2 v[PW_UNROLL], cv[PW_UNROLL];
+				uint32_t have[PW_UNROLL];
+#pragma unroll
+				for (int u = 0; u < PW_UNROLL; u++) {
+					const uint32_t p = p0 + (uint32_t)u * PW_THREADS + threadIdx.x, pc = p < P ? p : P - 1u;
+					uint32_t sub, i;
+					pp_locate(s_pstart[1], a.nsub, pc, &sub, &i);
+					const size_t at = (size_t)(leaf * a.nsub + sub) * a.cap_r + i;
+					v[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_r + at);
+					cv[u] = *reinterpret_cast<const ulonglong2 *>(a.pay_r[0] + at);
+					have[u] = p < P ? s_cnt[1][sub] - i : 0u;
+				}
+#pragma unroll
+				for (int u = 0; u < PW_UNROLL; u++) {
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						const uint32_t slot = ((uint32_t)((k ? v[u].y : v[u].x) >> 32) >> shift) & mask;
+						if (have[u] > (uint32_t)k && (slot >> lowbits) == pass) {
+							const uint32_t lo = slot & (S - 1u);
+							const uint32_t old = atomicOr(&occ[lo >> 5], 1u << (lo & 31u));
+							if (old & (1u << (lo & 31u)))
+								s_dup = 1u;	/* a right key occurs twice */
+							cellt[lo] = k ? cv[u].y : cv[u].x;
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (s_dup) {
+			if (threadIdx.x == 0)
+				mdb_raise(a.status, 32u);
+			return;
+		}
+		{	/* ---- left rows of this pass's slots: the partner's cell, if there is a partner, to out[left row id] */
+			const uint32_t P = s_pstart[0][PP_MAX_SUB];
+			for (uint32_t p0 = 0; p0 < P; p0 += PW_THREADS * PW_UNROLL) {
+				ulonglong2 v[PW_UNROLL];
+				uint32_t have[PW_UNROLL];
+#pragma unroll
+				for (int u = 0; u < PW_UNROLL; u++) {
+					const uint32_t p = p0 + (uint32_t)u * PW_THREADS + threadIdx.x, pc = p < P ? p : P - 1u;
+					uint32_t sub, i;
+					pp_locate(s_pstart[0], a.nsub, pc, &sub, &i);
+					v[u] = *reinterpret_cast<const ulonglong2 *>(a.hv_l + (size_t)(leaf * a.nsub + sub) * a.cap_l + i);
+					have[u] = p < P ? s_cnt[0][sub] - i : 0u;
+				}
+#pragma unroll
+				for (int u = 0; u < PW_UNROLL; u++) {
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						const unsigned long long w = k ? v[u].y : v[u].x;
+						const uint32_t slot = ((uint32_t)(w >> 32) >> shift) & mask, lo = slot & (S - 1u);
+						if (have[u] > (uint32_t)k && (slot >> lowbits) == pass && ((occ[lo >> 5] >> (lo & 31u)) & 1u)) {
+							a.out[0][(uint32_t)w] = cellt[lo];
+							pairs++;
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+	pairs = lw_block_sum(pairs, s_red);
+	if (threadIdx.x == 0 && pairs)
+		atomicAdd(a.joined, pairs);
+}
+
 /* 0 = done: every one of the n_l left rows has its partner and out[c][i] = payload cell c of left row i's partner;
  * 1 = not served (some left row without a partner - NULL keys included -, duplicate right keys, no compact window of at most 2^24
  * values, a region overflow ...: mdb_dev_join_pairs answers); < 0 = error.  Synchronises. */
@@ -1016,7 +1131,12 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	a.status = ctx->d_status;
 	if (pl.nsub > PP_MAX_SUB)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: %u sub-regions per digit", pl.nsub);
-	if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(getenv("MDB_PP_E16") && getenv("MDB_PP_E16")[0] == '0')) {
+	if (npay == 1 && !(getenv("MDB_PP_CELL") && getenv("MDB_PP_CELL")[0] == '0')) {
+		const uint32_t lowbits = rem < PC_SLOT_BITS ? rem : PC_SLOT_BITS;
+		const size_t lds = ((size_t)8 << lowbits) + ((size_t)1 << lowbits) / 8 + 64;
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_cell, pl.nleaves, PW_THREADS, lds, a, rem, shift);
+	} else if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(getenv("MDB_PP_E16") && getenv("MDB_PP_E16")[0] == '0')) {
 		const size_t lds = (size_t)2 << rem;
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_payload<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_payload<uint16_t>, pl.nleaves, PW_THREADS, lds, a, rem, shift);
@@ -1528,7 +1648,25 @@ extern "C" int mdb_dev_join_keys(mdb_dev_ctx *ctx, const int64_t *keys_l, const 
 	}
 	uint64_t G = 0, J = 0;
 	/* (no MDB_ORDER_FIRST, no first rows: the any-order form where it is served, else the ordered operator - its groups serve as well) */
-	int rc = (n_l && n_r) ? mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, 0u, gk, gc, NULL, cap, &G, &J) : MIDORIDB_OK;
+	/* first WITHOUT the COUNT column (primary-key joins: every COUNT is 1, and writing 10^8 of them is 0.8 GB of the leaf kernel's
+	 * 2.0): J == G says that this was right; otherwise - or when these columns had duplicates last time - once more with counts */
+	int rc = MIDORIDB_OK;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
+	const bool had_dups = ctx->jk_dup_l == keys_l && ctx->jk_dup_nl == n_l && ctx->jk_dup_r == keys_r && ctx->jk_dup_nr == n_r && ++ctx->jk_dup_uses < 32;
+	if (n_l && n_r && !had_dups) {
+		ctx->unordered_no_counts = 1;
+		rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, 0u, gk, gc, NULL, cap, &G, &J);
+		ctx->unordered_no_counts = 0;
+		if (!rc && J != G) {
+			ctx->jk_dup_l = keys_l;
+			ctx->jk_dup_nl = n_l;
+			ctx->jk_dup_r = keys_r;
+			ctx->jk_dup_nr = n_r;
+			ctx->jk_dup_uses = 0;
+		}
+	}
+	if (!rc && n_l && n_r && (had_dups || J != G))
+		rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, 0u, gk, gc, NULL, cap, &G, &J);
 	if (rc) {
 		(void)mdb_dev_free(ctx, gk);
 		(void)mdb_dev_free(ctx, gc);

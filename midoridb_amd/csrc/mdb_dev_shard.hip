@@ -659,7 +659,8 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf(sh_leaf_args a)
 			const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * s_cr[s];
 			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
 			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
-			a.out_count[pos] = (long long)c;
+			if (a.out_count)	/* (NULL: the caller wants the keys alone and learns from J == G that every COUNT is 1) */
+				a.out_count[pos] = (long long)c;
 			joined += c;
 		}
 	}
@@ -833,7 +834,8 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 			const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * ((s_cr[s >> 1] >> sh) & 0xFFFFu);
 			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
 			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
-			a.out_count[pos] = (long long)c;
+			if (a.out_count)	/* (NULL: the caller wants the keys alone and learns from J == G that every COUNT is 1) */
+				a.out_count[pos] = (long long)c;
 			joined += c;
 		}
 	}

@@ -496,6 +496,8 @@ extern "C" int mdb_dist_last_wire32(const mdb_dist *d) { return d ? d->last_wire
 extern "C" int mdb_dist_last_pruned(const mdb_dist *d) { return d ? d->last_pruned : 0; }
 extern "C" int mdb_dist_last_fused(const mdb_dist *d) { return d ? d->last_fused : 0; }
 
+static void plan_info_fill(const mdb_shard_plan *p, bool completed, struct mdb_dist_plan_info *out);
+
 extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *out)
 {
 	if (!d || !out)
@@ -503,7 +505,25 @@ extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *
 	memset(out, 0, sizeof(*out));
 	if (!d->have_plan)
 		return 1;
-	const mdb_shard_plan *p = &d->last_plan;
+	plan_info_fill(&d->last_plan, d->last_fused != 0, out);
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dist_plan_preview(int world, int tables, const uint64_t *rows_per_rank, const int64_t left[2], const int64_t right[2],
+				     struct mdb_dist_plan_info *out)
+{
+	if (!out || !rows_per_rank || !left || !right || tables < 2 || tables > MDB_SHARD_MAX_TABS)
+		return -MIDORIDB_ERROR;
+	memset(out, 0, sizeof(*out));
+	mdb_shard_plan plan;
+	if (mdb_shard_plan_make((uint32_t)world, 0u, (uint32_t)tables, rows_per_rank, left[0], left[1], right[0], right[1], &plan))
+		return 1;
+	plan_info_fill(&plan, false, out);
+	return MIDORIDB_OK;
+}
+
+static void plan_info_fill(const mdb_shard_plan *p, bool completed, struct mdb_dist_plan_info *out)
+{
 	out->world = p->world;
 	out->tables = p->ntab;
 	out->digit_bits = p->dbits;
@@ -512,7 +532,7 @@ extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *
 	out->receiver_bits = (uint32_t)p->b2;
 	out->leaf_bits = p->rem;
 	out->word_bytes = p->wbytes;
-	out->completed = d->last_fused ? 1u : 0u;
+	out->completed = completed ? 1u : 0u;
 	for (uint32_t x = 0; x < p->ntab; x++) {
 		if (p->right_only && x == 0)
 			continue;	/* (GROUP BY of one table: there is no left table, nothing of it travels) */
@@ -520,7 +540,6 @@ extern "C" int mdb_dist_last_plan(const mdb_dist *d, struct mdb_dist_plan_info *
 		out->block_bytes[x] = p->block_words[x] * p->wbytes;
 		out->bytes_per_peer += p->block_words[x] * p->wbytes + (uint64_t)p->D * p->nsub * 4;
 	}
-	return MIDORIDB_OK;
 }
 
 extern "C" int mdb_dist_set_phase_timing(mdb_dist *d, int on)
@@ -733,7 +752,8 @@ static bool dist_fault_injected(const mdb_dist *d, const char *step)
 
 static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, const uint64_t *const *nulls, const uint64_t *ns, const int64_t glo[2],
 			   const int64_t ghi[2], bool promised, bool alloc_out, int64_t **out_key_p, int64_t **out_count_p, uint64_t cap,
-			   uint64_t *out_groups, uint64_t *out_joined, bool right_only = false /* GROUP BY of table [1] alone: table [0] has no rows and does not travel */)
+			   uint64_t *out_groups, uint64_t *out_joined, bool right_only = false /* GROUP BY of table [1] alone: table [0] has no rows and does not travel */,
+			   bool no_counts = false /* the caller wants the group keys alone (and J, G): the COUNT column is not written */)
 {
 	/* tables: [0] the left one, [1] the right one, [2 ...] further right tables joined on the same key */
 	mdb_dev_ctx *ctx = d->ctx;
@@ -880,7 +900,7 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	/* (the receiver waits for a table right before the first kernel that reads it: its own level over the left table runs while
 	 * the right table is still on the wire) */
 	void *arrived[MDB_SHARD_MAX_TABS] = { d->ev_tab[0], d->ev_tab[1], d->ev_tab[2], d->ev_tab[3] };
-	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, out_count, cap, arrived);
+	rc = mdb_shard_join(ctx, &plan, recv, rcnt, out_key, no_counts ? NULL : out_count, cap, arrived);
 	if (rc && !prc) {
 		/* (the same holds for the receiver's launches: the peers are told through the status exchange) */
 		prc = rc;
@@ -1578,9 +1598,29 @@ static int dist_join_keys_only(mdb_dist *d, const int64_t *keys_l, const uint64_
 	int64_t *gk = NULL, *gc = NULL;
 	uint64_t G = 0, J = 0;
 	d->last_fused = 0;
-	int rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J);
+	/* first WITHOUT the COUNT column (primary-key joins: every COUNT is 1 - 8 of the 16 bytes a group costs the leaf kernel); the ranks
+	 * then agree on whether that was right everywhere (one tiny exchange) and, if not, all of them run the call again with counts */
+	int rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J, false, true);
 	if (rc)
 		return rc;
+	{
+		uint64_t dups = J != G ? 1u : 0u;
+		rc = d->t.allreduce_sum_u64(d->t.self, &dups, 1);
+		if (rc) {
+			(void)mdb_dev_free(ctx, gk);
+			(void)mdb_dev_free(ctx, gc);
+			return dist_err(d, rc, "status exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+		}
+		if (dups) {
+			(void)mdb_dev_free(ctx, gk);
+			(void)mdb_dev_free(ctx, gc);
+			gk = gc = NULL;
+			d->last_fused = 0;
+			rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J);
+			if (rc)
+				return rc;
+		}
+	}
 	if (J == G) {		/* every COUNT is 1: the group keys are the joined rows */
 		(void)mdb_dev_free(ctx, gc);
 		*out_key = gk;

@@ -49,7 +49,7 @@ DIST_SYMBOLS = [
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
     "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_group_count_keys_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
-    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases",
+    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases", "mdb_dist_plan_preview",
 ]
 
 
@@ -71,6 +71,7 @@ def _bind(lib):
         "mdb_dist_last_pruned": ([P], c_int),
         "mdb_dist_last_fused": ([P], c_int),
         "mdb_dist_last_plan": ([P, POINTER(PlanInfo)], c_int),
+        "mdb_dist_plan_preview": ([c_int, c_int, POINTER(c_uint64), POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(PlanInfo)], c_int),
         "mdb_dist_set_phase_timing": ([P, c_int], c_int),
         "mdb_dist_last_phases": ([P, POINTER(c_double)], c_int),
         "mdb_dist_group_count_keys_alloc": ([P, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
@@ -98,6 +99,30 @@ def _bind(lib):
 
 class DistError(RuntimeError):
     pass
+
+
+def _plan_dict(info):
+    d = {k: getattr(info, k) for k, _ in PlanInfo._fields_ if k not in ("region_words", "block_bytes")}
+    d["region_words"] = list(info.region_words)[:info.tables]
+    d["block_bytes"] = list(info.block_bytes)[:info.tables]
+    return d
+
+
+def plan_preview(world, rows_per_rank, left_range, right_range):
+    """The regions-on-the-wire plan `world` ranks would make for tables of rows_per_rank[t] rows per rank and these global key
+    ranges (mdb_dist_plan_preview: pure host computation, no GPU) -> dict as DistCtx.last_plan(), or None when that path would
+    not serve the shape"""
+    lib = load_library()
+    _bind(lib)
+    info = PlanInfo()
+    rows = (c_uint64 * len(rows_per_rank))(*[int(r) for r in rows_per_rank])
+    la, ra = (ctypes.c_int64 * 2)(int(left_range[0]), int(left_range[1])), (ctypes.c_int64 * 2)(int(right_range[0]), int(right_range[1]))
+    rc = lib.mdb_dist_plan_preview(int(world), len(rows_per_rank), rows, la, ra, byref(info))
+    if rc == 1:
+        return None
+    if rc:
+        raise DistError(f"mdb_dist_plan_preview failed ({rc})")
+    return _plan_dict(info)
 
 
 class DatabaseDevice:
@@ -232,10 +257,7 @@ class DistCtx:
         if rc == 1:
             return None
         self._chk(rc, "last_plan")
-        d = {k: getattr(info, k) for k, _ in PlanInfo._fields_ if k not in ("region_words", "block_bytes")}
-        d["region_words"] = list(info.region_words)[:info.tables]
-        d["block_bytes"] = list(info.block_bytes)[:info.tables]
-        return d
+        return _plan_dict(info)
 
     def set_phase_timing(self, on=True):
         self._chk(self.lib.mdb_dist_set_phase_timing(self.h, 1 if on else 0), "set_phase_timing")

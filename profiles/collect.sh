@@ -1,6 +1,6 @@
 #!/bin/bash
 # Commands that produce the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r04'
 # Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains
 # besides --kernel-trace are combined with --pmc).  The program after "--" is python3 itself.
 # One set of passes per workload of the north-star query: variant D (the headline), U (unique keys), S (the headline's duplication
@@ -8,7 +8,7 @@
 # creation) -> summary_<tag>[_U|_S|_wide].json; kernel names need no table: bench.py's line carries, per profiler name, the names
 # rocprofv3 lists its kernels under (mdb_dev_prof_symbols).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 passes() {	# $1 = output directory, $2... = program and arguments
@@ -48,13 +48,23 @@ for V in D U; do
 	passes "$R/gpurun_out/prof_${TAG}_unordered_$V" python3 "$R/bench.py" $ARGS --variant $V --unordered
 	(cd "$R" && python3 profiles/summarize.py "$R/gpurun_out/prof_${TAG}_unordered_$V" "$R/gpurun_out/summary_${TAG}_unordered_$V.json")
 done
+# BASELINE configs[3] on one GPU (round 4): the join of two key columns, unique keys, 10^8 rows per table - mdb_dev_join_keys
+# (any order, the sharded form's pipeline on local regions): time + HBM bytes per kernel
+C4=$R/gpurun_out/prof_${TAG}_config4
+mkdir -p "$C4"
+C4ARGS="--config 4 --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$C4/kt" -- python3 "$R/bench.py" $C4ARGS > "$C4/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$C4/fetch" -- python3 "$R/bench.py" $C4ARGS > "$C4/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$C4/write" -- python3 "$R/bench.py" $C4ARGS > "$C4/write.log" 2>&1
+(cd "$R" && python3 profiles/summarize.py "$C4" "$R/gpurun_out/summary_${TAG}_config4.json")
 # what goes under profiles/$TAG/: the summaries and rocprofv3's own per-kernel statistics of each kernel-trace pass
 PUB=$R/gpurun_out/publish_$TAG
 mkdir -p "$PUB"
-for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U; do
+for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U _config4; do
 	[ -f "$R/gpurun_out/summary_$TAG$S.json" ] && cp "$R/gpurun_out/summary_$TAG$S.json" "$PUB/rocprof_summary$S.json"
 	D="$R/gpurun_out/prof_$TAG$S/kt"
 	[ "$S" = _configs1 ] && D="$OPS/kt"
+	[ "$S" = _config4 ] && D="$C4/kt"
 	F=$(find "$D" -name '*kernel_stats.csv' 2>/dev/null | head -1)
 	[ -n "$F" ] && cp "$F" "$PUB/kernel_stats$S.csv"
 done
