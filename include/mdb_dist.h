@@ -212,6 +212,13 @@ struct mdb_dist_col {
 int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uint64_t *key_nulls, uint64_t n, uint32_t flags,
 			  const struct mdb_dist_col *cols, int ncols, void **out_values, uint64_t **out_nullbits, uint64_t *out_n);
 int mdb_dist_wait_transfers(mdb_dist *d);
+/* Every rank's rows to EVERY rank (the small side of a join without an equi-join key - FROM A, B or a general ON expression,
+ * reference executor_select.c:1096-1141, optimiser_select.c:395-464: nothing says which rank a row's partners live on, so the table is
+ * replicated and every rank pairs its own rows of the other side with all of it).  cols as above; out_values[c] / out_nullbits[c]:
+ * the rows of all ranks in rank order (*out_n of them, the same on every rank), allocated by the call.  Collective and synchronous;
+ * a failure on one rank is agreed on before anything is posted. */
+int mdb_dist_broadcast_rows(mdb_dist *d, uint64_t n, const struct mdb_dist_col *cols, int ncols, void **out_values, uint64_t **out_nullbits,
+			    uint64_t *out_n);
 
 /* SELECT ... FROM L INNER JOIN R ON l.key = r.key over sharded tables: both tables are shuffled by their key (L's transfers
  * overlap R's partitioning), joined locally with mdb_dev_join_pairs and projected with mdb_dev_gather_cols.  Output (device

@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_nullmask_pack(sh_null_src s, uin
 							       uint64_t *__restrict__ mask)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x; i < m; i += (uint64_t)gridDim.x * SH_THREADS) {
-		const uint32_t p = pos[i];
+		const uint32_t p = pos ? pos[i] : (uint32_t)i;	/* (pos == NULL: the rows as they stand - a broadcast) */
 		uint64_t w = 0;
 		for (uint64_t cm = colmask; cm; cm &= cm - 1) {
 			const int c = __builtin_ctzll(cm);
@@ -1567,6 +1567,162 @@ extern "C" int mdb_dist_shuffle_rows(mdb_dist *d, const int64_t *keys, const uin
 	if (!(flags & MDB_DIST_NO_WAIT))
 		return mdb_dist_wait_transfers(d);
 	return MIDORIDB_OK;
+}
+
+/* ---- every rank's rows to EVERY rank: the small side of a join that has no equi-join key (FROM A, B; a general ON expression -
+ * reference _join_nested_loop_tbl2tbl with any predicate, executor_select.c:1096-1141, optimiser_select.c:395-464): nothing says which
+ * rank a row's partners live on, so the table is replicated and every rank pairs ITS rows of the other side with all of it - each
+ * (l, r) pair is produced exactly once, on the rank that holds l.  One count exchange (rows per rank + which columns carry NULL bits +
+ * status), one all-to-all per column in which every peer is sent the SAME buffer, NULL bits as one word per row. */
+extern "C" int mdb_dist_broadcast_rows(mdb_dist *d, uint64_t n, const struct mdb_dist_col *cols, int ncols, void **out_values,
+				       uint64_t **out_nullbits, uint64_t *out_n)
+{
+	if (!d || !out_n || ncols < 1 || ncols > MDB_DIST_SHUFFLE_MAX_COLS || !cols || !out_values || !out_nullbits)
+		return d ? dist_err(d, -MIDORIDB_ERROR, "broadcast_rows: bad arguments") : -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = d->ctx;
+	const int W = d->world;
+	*out_n = 0;
+	for (int c = 0; c < ncols; c++) {
+		out_values[c] = NULL;
+		out_nullbits[c] = NULL;
+	}
+	DIST_HIP(d, hipSetDevice(ctx->device));
+	if (d->npend > SH_MAX_PENDING / 2) {
+		int wrc = mdb_dist_wait_transfers(d);
+		if (wrc)
+			return wrc;
+	}
+	uint64_t sendv[SH_COUNTERS << MDB_MAX_RADIX_BITS], recvv[SH_COUNTERS << MDB_MAX_RADIX_BITS];
+	size_t sc[1 << MDB_MAX_RADIX_BITS], sd[1 << MDB_MAX_RADIX_BITS], rcn[1 << MDB_MAX_RADIX_BITS], rd[1 << MDB_MAX_RADIX_BITS];
+	/* ---- the rows in one contiguous buffer per column (a stream read through row ids is gathered first), and the mask words */
+	uint64_t colmask = 0;
+	for (int c = 0; c < ncols; c++)
+		if (cols[c].nullbits)
+			colmask |= 1ull << c;
+	void *send[MDB_DIST_SHUFFLE_MAX_COLS], *own[MDB_DIST_SHUFFLE_MAX_COLS + 2];
+	int nown = 0;
+	int status = n >= 0xFFFFFFFFull ? -MIDORIDB_ERROR : MIDORIDB_OK;
+	for (int c = 0; c < ncols && !status; c++) {
+		send[c] = const_cast<void *>(cols[c].values);
+		if (cols[c].rid && n) {
+			void *buf = NULL;
+			status = mdb_dev_alloc(ctx, n * 8, &buf);
+			if (!status) {
+				own[nown++] = buf;
+				status = mdb_dev_gather64(ctx, (const int64_t *)cols[c].values, NULL, cols[c].rid, n, (int64_t *)buf, NULL);
+				send[c] = buf;
+			}
+		}
+	}
+	void *send_mask = NULL;
+	if (!status && colmask && n) {
+		status = mdb_dev_alloc(ctx, n * 8, &send_mask);
+		if (!status) {
+			own[nown++] = send_mask;
+			sh_null_src src;
+			memset(&src, 0, sizeof(src));
+			for (int c = 0; c < ncols; c++) {
+				src.nb[c] = cols[c].nullbits;
+				src.rid[c] = cols[c].rid;
+			}
+			hipLaunchKernelGGL(k_nullmask_pack, dim3(sh_grid(n)), dim3(SH_THREADS), 0, ctx->stream, src, colmask, (const uint32_t *)NULL, n, (uint64_t *)send_mask);
+		}
+	}
+	char local_err[256];
+	snprintf(local_err, sizeof(local_err), "%s", status ? mdb_dev_last_error(ctx) : "");
+	for (int p = 0; p < W; p++) {
+		sendv[SH_COUNTERS * p] = status ? 0 : n;
+		sendv[SH_COUNTERS * p + 1] = colmask;
+		sendv[SH_COUNTERS * p + 2] = status ? 1 : 0;
+	}
+	int rc = d->t.counts(d->t.self, sendv, recvv, SH_COUNTERS);
+	uint64_t total = 0, gmask = 0;
+	int failed_rank = -1;
+	for (int p = 0; p < W && !rc; p++) {
+		sc[p] = (size_t)n;
+		sd[p] = 0;		/* every peer is sent the same rows */
+		rcn[p] = (size_t)recvv[SH_COUNTERS * p];
+		rd[p] = (size_t)total;
+		total += recvv[SH_COUNTERS * p];
+		gmask |= recvv[SH_COUNTERS * p + 1];
+		if (recvv[SH_COUNTERS * p + 2] && failed_rank < 0)
+			failed_rank = p;
+	}
+	if (!rc && failed_rank < 0 && total >= 0xFFFFFFFFull) {
+		status = -MIDORIDB_ERROR;
+		snprintf(local_err, sizeof(local_err), "%llu broadcast rows exceed the 32-bit row-id limit of one shard", (unsigned long long)total);
+	}
+	/* receive buffers; whether every rank got them is agreed on before anything is posted (as in mdb_dist_shuffle_rows) */
+	void *recv_mask = NULL;
+	int arc = MIDORIDB_OK;
+	if (!rc && failed_rank < 0 && !status) {
+		for (int c = 0; c < ncols && !arc; c++) {
+			arc = mdb_dev_alloc(ctx, (total ? total : 1) * 8, &out_values[c]);
+			if (!arc && (gmask >> c & 1))
+				arc = mdb_dev_alloc(ctx, ((total + 63) / 64 + 1) * 8, (void **)&out_nullbits[c]);
+		}
+		if (!arc && gmask)
+			arc = mdb_dev_alloc(ctx, (total ? total : 1) * 8, &recv_mask);
+		if (!arc && gmask && !send_mask && n) {	/* (another rank has NULLs, this one has none: all-zero words) */
+			arc = mdb_dev_alloc(ctx, n * 8, &send_mask);
+			if (!arc) {
+				own[nown++] = send_mask;
+				arc = mdb_dev_memset(ctx, send_mask, 0, n * 8);
+			}
+		}
+		for (int p = 0; p < W; p++)
+			sendv[p] = arc ? 1 : 0;
+		int rc2 = d->t.counts(d->t.self, sendv, recvv, 1);
+		for (int p = 0; p < W && !rc2; p++)
+			if (recvv[p] && !arc)
+				arc = -MIDORIDB_NOMEM;
+		if (rc2)
+			rc = rc2;
+	}
+	if (rc || failed_rank >= 0 || status || arc) {
+		for (int c = 0; c < ncols; c++) {
+			(void)mdb_dev_free(ctx, out_values[c]);
+			(void)mdb_dev_free(ctx, out_nullbits[c]);
+			out_values[c] = NULL;
+			out_nullbits[c] = NULL;
+		}
+		(void)mdb_dev_free(ctx, recv_mask);
+		for (int k = 0; k < nown; k++)
+			(void)mdb_dev_free(ctx, own[k]);
+		if (rc)
+			return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+		if (status)
+			return dist_err(d, status, "broadcast: %s", local_err);
+		if (failed_rank >= 0)
+			return dist_err(d, -MIDORIDB_ERROR, "broadcast: rank %d failed (its own message says why); nothing was exchanged", failed_rank);
+		return dist_err(d, arc, "broadcast: a rank could not allocate its buffers; nothing was exchanged");
+	}
+	DIST_HIP(d, hipEventRecord(d->ev_ready, ctx->stream));
+	DIST_HIP(d, hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
+	/* (a rank without rows still takes part: its sends are empty, and a valid pointer stands in for its buffers) */
+	for (int c = 0; c < ncols; c++) {
+		rc = d->t.alltoallv(d->t.self, n ? send[c] : out_values[c], sc, sd, out_values[c], rcn, rd, 8, d->comm_stream);
+		if (rc)
+			return dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	}
+	if (gmask) {
+		rc = d->t.alltoallv(d->t.self, n ? send_mask : recv_mask, sc, sd, recv_mask, rcn, rd, 8, d->comm_stream);
+		if (rc)
+			return dist_err(d, rc, "all-to-all failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+		sh_null_dst dst;
+		memset(&dst, 0, sizeof(dst));
+		for (int c = 0; c < ncols; c++)
+			dst.bits[c] = out_nullbits[c];
+		hipLaunchKernelGGL(k_nullmask_unpack, dim3(sh_grid(total ? total : 1)), dim3(SH_THREADS), 0, d->comm_stream, (const uint64_t *)recv_mask, total,
+				   gmask & (ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull)), dst);
+	}
+	DIST_HIP(d, hipEventRecord(d->ev_sh, d->comm_stream));
+	d->sh_posted = true;
+	for (int k = 0; k < nown; k++)
+		sh_pend(d, own[k]);
+	sh_pend(d, recv_mask);
+	*out_n = total;
+	return mdb_dist_wait_transfers(d);
 }
 
 /* ---- a join whose only output is the key column (BASELINE configs[3]: SELECT * over two key columns): no row has to be

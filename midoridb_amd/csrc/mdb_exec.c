@@ -382,10 +382,16 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 		/* sharded mode: both sides go where their join key hashes to - the left stream unless it already is there (joined on
 		 * this key before), the new table always (its rows that passed its own WHERE conjuncts at home) */
 		if (key < 0) {
-			snprintf(x->err, x->errlen, "execution phase: sharded mode (MIDORIDB_WORLD_SIZE): a join needs an equi-join key in its ON clause "
-						    "(l.col = r.col) to be exchanged between the ranks; this one would only see local rows\n");
-			return -MIDORIDB_ERROR;
-		}
+			/* no equi-join key (FROM A, B; a general ON expression: reference executor_select.c:1096-1141): nothing says which rank a
+			 * row's partners live on - the new table (its rows that passed its own WHERE conjuncts) is replicated on every rank
+			 * and each rank pairs ITS stream with all of it: every (l, r) pair is produced exactly once, where l lives */
+			const int tabs1[1] = { t };
+			uint32_t *rids1[1] = { (uint32_t *)rsel };
+			if ((rc = shard_rows(x, tabs1, 1, rids1, r_rows, NULL, NULL, SHARD_BROADCAST, &r_rows)))
+				return rc;
+			rsel = NULL;
+			rt = s->tabs[t].t;
+		} else {
 		if (!in_part(x, kl) && (rc = shard_stream(x, t, kl, 0)))
 			return rc;
 		{
@@ -404,6 +410,7 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 		}
 		if (x->npart < 2 * MDB_MAX_TABS)
 			x->part[x->npart++] = kr;
+		}
 	}
 	if (key >= 0) {
 		const int64_t *vl;
@@ -448,7 +455,12 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 	} else {
 		/* no equi-join key: FROM A, B (ON 1=1) or a general ON -> all pairs, then the ON predicate */
 		const uint64_t total = x->n * r_rows;
-		if (total > (1ull << 28)) {
+		uint64_t too_large = total > (1ull << 28) ? 1u : 0u;
+		if (x->cat->dist && mdb_dist_allreduce_sum_u64(x->cat->dist, &too_large, 1)) {	/* (every rank must leave the statement together) */
+			snprintf(x->err, x->errlen, "execution phase: %s\n", mdb_dist_last_error(x->cat->dist));
+			return -MIDORIDB_INTERNAL;
+		}
+		if (too_large) {
 			snprintf(x->err, x->errlen, "execution phase: cross join of %llu x %llu rows is too large (no equi-join key in the ON clause)\n",
 				 (unsigned long long)x->n, (unsigned long long)r_rows);
 			return -MIDORIDB_ERROR;

@@ -88,6 +88,7 @@ int double_join_keys(struct exec *x, const struct mdb_column *col, const uint32_
 void mark_needed(struct exec *x, const struct mdb_expr *e);
 void mark_needed_all(struct exec *x);
 bool in_part(const struct exec *x, const struct mdb_expr *f);
+#define SHARD_BROADCAST (1u << 30)	/* shard_rows flag: every rank's rows to every rank (mdb_dist_broadcast_rows) instead of rows by key */
 int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of, uint64_t n, const int64_t *kv, const uint64_t *kn, uint32_t flags, uint64_t *n_out);
 int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flags);
 int shard_promise_ranges(struct exec *x, const struct mdb_expr *fl, const struct mdb_expr *fr);

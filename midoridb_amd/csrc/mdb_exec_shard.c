@@ -86,7 +86,20 @@ int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of,
 			nc++;
 		}
 	}
-	if (mdb_dist_shuffle_rows(x->cat->dist, kv, kn, n, flags, cols, nc, ov, on, &got)) {
+	if (flags & SHARD_BROADCAST) {
+		/* the small side of a join without an equi-join key: every rank's rows to every rank (a statement that reads no column of
+		 * the table - SELECT COUNT(*) FROM A, B - only needs their number) */
+		if (nc == 0) {
+			got = n;
+			if (mdb_dist_allreduce_sum_u64(x->cat->dist, &got, 1)) {
+				snprintf(x->err, x->errlen, "execution phase: %s\n", mdb_dist_last_error(x->cat->dist));
+				return -MIDORIDB_INTERNAL;
+			}
+		} else if (mdb_dist_broadcast_rows(x->cat->dist, n, cols, nc, ov, on, &got)) {
+			snprintf(x->err, x->errlen, "execution phase: sharded broadcast: %s\n", mdb_dist_last_error(x->cat->dist));
+			return -MIDORIDB_INTERNAL;
+		}
+	} else if (mdb_dist_shuffle_rows(x->cat->dist, kv, kn, n, flags, cols, nc, ov, on, &got)) {
 		snprintf(x->err, x->errlen, "execution phase: sharded exchange: %s\n", mdb_dist_last_error(x->cat->dist));
 		return -MIDORIDB_INTERNAL;
 	}

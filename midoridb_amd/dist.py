@@ -49,7 +49,7 @@ DIST_SYMBOLS = [
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
     "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_group_count_keys_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
-    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases", "mdb_dist_plan_preview",
+    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases", "mdb_dist_plan_preview", "mdb_dist_broadcast_rows",
 ]
 
 
@@ -87,6 +87,7 @@ def _bind(lib):
         "mdb_dist_allgather_u64": ([P, POINTER(c_uint64), c_int, POINTER(c_uint64)], c_int),
         "mdb_dist_shuffle_rows": ([P, P, P, c_uint64, ctypes.c_uint32, POINTER(DistCol), c_int, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dist_wait_transfers": ([P], c_int),
+        "mdb_dist_broadcast_rows": ([P, c_uint64, POINTER(DistCol), c_int, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dist_join_pairs": ([P, P, P, c_uint64, POINTER(DistCol), c_int, P, P, c_uint64, POINTER(DistCol), c_int, POINTER(P), POINTER(P),
                                  POINTER(P), POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
     }
@@ -318,6 +319,19 @@ class DistCtx:
             src = cols[c][0] if isinstance(cols[c], tuple) else cols[c]
             out.append((self._adopt(ov[c], n, src.dtype), self._adopt(on[c], (n + 63) // 64, torch.int64) if on[c] else None))
         return out, n
+
+    def broadcast_rows(self, n, cols):
+        """every rank's n rows of `cols` to every rank -> (list of (values, nullbits-or-None), total rows) (mdb_dist_broadcast_rows)"""
+        nc = len(cols)
+        ov, on = (c_void_p * nc)(), (c_void_p * nc)()
+        got = c_uint64()
+        self._chk(self.lib.mdb_dist_broadcast_rows(self.h, n, self._cols(cols), nc, ov, on, byref(got)), "dist broadcast_rows")
+        m = got.value
+        out = []
+        for c in range(nc):
+            src = cols[c][0] if isinstance(cols[c], tuple) else cols[c]
+            out.append((self._adopt(ov[c], m, src.dtype), self._adopt(on[c], (m + 63) // 64, torch.int64) if on[c] else None))
+        return out, m
 
     def join_pairs(self, keys_l, null_l, cols_l, keys_r, null_r, cols_r):
         """-> (key[J], [(values, nullbits) of cols_l], [... of cols_r], J): the joined rows whose key hashes to this rank."""

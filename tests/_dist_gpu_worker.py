@@ -172,7 +172,8 @@ def sharded_sql(world, rank):
     """query_execute() in sharded mode at world size 2 on one GPU (mdb_database_set_dist with the test transport): every rank loads
     ITS rows, runs the same statements, and the ranks' results together must be exactly the rows oracle/naive.py computes over
     the whole tables - joins with payload (INT64 with NULLs, DOUBLE), three-way joins on one key and on two, WHERE conjuncts
-    pushed below the exchange, GROUP BY of a non-key column, DISTINCT, global COUNT(*)."""
+    pushed below the exchange, GROUP BY of a non-key column, DISTINCT, global COUNT(*), cross and non-equi joins (the new table
+    replicated on every rank)."""
     from oracle.naive import Naive
     from oracle.ref import sql_to_rpn
     from midoridb_amd.query import DB, QueryError
@@ -207,12 +208,17 @@ def sharded_sql(world, rank):
         "SELECT id_a, f1 FROM A WHERE f1 IS NULL;",
         "SELECT id_a, x FROM A INNER JOIN B ON A.id_a = B.id_b WHERE x > 0.4 ORDER BY id_a;",
         "SELECT id_b, COUNT(*) FROM B INNER JOIN C ON B.f2 = C.id_c GROUP BY id_b;",
+        # joins without an equi-join key: the new table is replicated on every rank (mdb_dist_broadcast_rows), each rank pairs its own rows with it
+        "SELECT id_a, id_c FROM A, C WHERE f1 > 40;",
+        "SELECT id_a, f3 FROM A INNER JOIN C ON A.id_a < C.id_c AND f3 = 2;",
+        "SELECT f3, COUNT(*) FROM A, C WHERE f1 > 45 GROUP BY f3;",
     ]
     counts = [
         "SELECT COUNT(*) FROM A WHERE f1 > 0;",
         "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b WHERE f2 <= 10 OR f1 IS NULL;",
         "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b;",
         "SELECT COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b INNER JOIN C ON B.f2 = C.id_c;",
+        "SELECT COUNT(*) FROM A, C;",
     ]
     tables = {}
     with DB() as db:
@@ -260,7 +266,7 @@ def sharded_sql(world, rank):
             dist.all_gather_object(parts, res.rows())
             assert sorted(r for p in parts for r in p) == sorted(rows), q
         db.groups_any_order(False)
-        for q, what in (("SELECT * FROM A, C;", "equi-join key"), ("SELECT f1 FROM A INNER JOIN B ON A.id_a = B.id_b LIMIT 3, 4;", "LIMIT")):
+        for q, what in (("SELECT f1 FROM A INNER JOIN B ON A.id_a = B.id_b LIMIT 3, 4;", "LIMIT"),):
             try:
                 db.query(q)
                 raise SystemExit(f"{q} must be refused in sharded mode")

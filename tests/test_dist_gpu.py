@@ -65,7 +65,7 @@ def test_query_execute_in_sharded_mode_world1(tmp_path):
     """query_execute() with MIDORIDB_WORLD_SIZE set runs the fused plan through mdb_dist_join_group_count_alloc (RCCL
     communicators created inside database code from the id file; world size 1 on the test box): same groups and counts as
     the single-GPU plan, chained over a third table, SELECT COUNT(*) all-reduced, materialising joins exchanged, joins without an
-    equi-join key refused."""
+    equi-join key answered by replicating the new table."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -94,11 +94,13 @@ with DB() as db:
     r = db.query("SELECT * FROM A INNER JOIN C ON A.id_a = C.id_c;")		# a materialising join: exchanged over RCCL like any other
     pl, pr = orc.join_pairs(a, None, c, None)
     assert sorted(r.columns[r.names.index("A.id_a")].tolist()) == sorted(a[pl].tolist()) and r.nrows == len(pl)
+    few = db.query("SELECT id_a, id_c FROM A, C WHERE id_a < 3 AND id_c < 5;")		# no equi-join key: C is replicated (mdb_dist_broadcast_rows)
+    assert few.nrows == int((a < 3).sum()) * int((c < 5).sum())
     try:
         db.query("SELECT * FROM A, C;")
-        raise SystemExit("a join without an equi-join key must be refused in sharded mode")
+        raise SystemExit("3 x 10^8 pairs of a cross join must be refused")
     except QueryError as e:
-        assert "sharded mode" in str(e)
+        assert "too large" in str(e)
 print("sharded query_execute ok")
 ''' % ROOT
     env = dict(os.environ, MIDORIDB_WORLD_SIZE="1", MIDORIDB_RANK="0", MIDORIDB_DIST_ID_FILE=str(tmp_path / "mdb_id"),
