@@ -493,7 +493,7 @@ def main():
                 k, c, j = dev.join_group_count_unordered(a, None, b, None, out=out)
                 return k.numel(), j
             if pipe is None:
-                k, c, f, j = dev.join_group_count(a, None, b, None, out=out)
+                k, c, f, j = dev.join_group_count(a, None, b, None, out=out, want_first=False)
                 return k.numel(), j
             k, c, j = pipe.join_group_count(a, None, b, None, out=out)
             return k.numel(), j
@@ -664,6 +664,7 @@ def main():
                        "left_table_pruning": {"min_max": bool(dev.last_join_filter()[1]), "bitmap": int(dev.last_join_filter()[0])},
                        "partition_levels": dev.last_join_levels(),
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
+                       "result": "(group key, COUNT(*)) per group - the statement's two result columns, what query_execute() asks the operator for",
                        "order": "unspecified (--unordered: mdb_dev_join_group_count without MDB_ORDER_FIRST)" if (args.unordered and not use_dist) else
                                 "reference first-occurrence order" if not use_dist else "per rank, unspecified (leaf order; first occurrence in the "
                                 "received stream on the key-by-destination path)",
@@ -735,7 +736,7 @@ def main():
                 a2, b2 = a.clone(), b.clone()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                dev.join_group_count(a2, None, b2, None, out=out)
+                dev.join_group_count(a2, None, b2, None, out=out, want_first=False)
                 torch.cuda.synchronize()
                 line["cold_start"]["first_query_on_new_columns_ms"] = (time.perf_counter() - t1) * 1e3
                 del a2, b2
@@ -744,7 +745,7 @@ def main():
             try:
                 # the wide form (64-bit hashes + row-id arrays), forced: what keys outside any 2^32 window run as
                 dev.set_narrow_keys(0)
-                dtw, rw = timed(lambda: dev.join_group_count(a, None, b, None, out=out))
+                dtw, rw = timed(lambda: dev.join_group_count(a, None, b, None, out=out, want_first=False))
                 line["wide_form"] = {"ms_per_step": dtw * 1e3, "value": rw[3] / dtw, "narrow": dev.last_join_narrow()}
             except Exception as e:  # pragma: no cover
                 line["wide_form"] = {"error": str(e)}
@@ -767,7 +768,7 @@ def main():
                 try:
                     dev.set_narrow_keys(0)
                     line["wide_form"]["pipeline"] = pipe_frac(groups_total, line["wide_form"]["ms_per_step"] * 1e-3, "wide",
-                                                              lambda: dev.join_group_count(a, None, b, None, out=out))
+                                                              lambda: dev.join_group_count(a, None, b, None, out=out, want_first=False))
                 finally:
                     dev.set_narrow_keys(1)
             def unordered_of(b_tab, expect):
@@ -791,11 +792,11 @@ def main():
                          lambda: dev.gen_keys(n, 0, n, 43, n // 16).mul_(16))):
                     try:
                         b_x = make_b()
-                        dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out))
+                        dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False))
                         line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
                                      "value": ru[3] / dtu,
                                      "pipeline": pipe_frac(int(ru[0].numel()), dtu, "U" if tag == "variant_U" else "S",
-                                                           lambda: dev.join_group_count(a, None, b_x, None, out=out)),
+                                                           lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False)),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
                                      "min_max_pruning": bool(dev.last_join_filter()[1])}
                         line[tag]["unordered"] = unordered_of(b_x, (int(ru[0].numel()), ru[3]))
@@ -815,7 +816,7 @@ def main():
             try:
                 gpu_result = None
                 if pipeline is None:
-                    k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
+                    k, c, f, jj = dev.join_group_count(a, None, b, None, out=out, want_first=False)
                     gpu_result = (k, c, jj)
                 line["cpu_hash"] = cpu_hash_yardstick(a, b, gpu_result)
             except Exception as e:  # pragma: no cover
@@ -825,7 +826,7 @@ def main():
             eb = orc.gen_keys(n, 0, n, 43, mod_b) * (16 if args.variant == "S" else 1)
             ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(n, 0, n, 42, 0), None, eb, None, os.cpu_count() or 1)
             if pipeline is None:
-                k, c, f, jj = dev.join_group_count(a, None, b, None, out=out)
+                k, c, f, jj = dev.join_group_count(a, None, b, None, out=out, want_first=False)
                 ok = (jj == ej and np.array_equal(k.cpu().numpy(), ek) and np.array_equal(c.cpu().numpy(), ec))
             else:   # shuffled pipeline: same groups, order is not the reference's
                 k, c, jj = pipeline.join_group_count(a, None, b, None, out=out)

@@ -225,6 +225,10 @@ int mdb_dev_double_join_keys(mdb_dev_ctx *ctx, const double *src, const uint64_t
 			     int64_t *dst, uint64_t *dst_nullbits);
 /* dst[k] = src[idx[k]] for uint32 row-id vectors (composition of tuple streams). */
 int mdb_dev_gather32(mdb_dev_ctx *ctx, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
+/* out[i] = table[cells[i]] (0 for a cell outside [0, table_n)): 8-byte ids translated through a device table - how VARCHAR cells
+ * (ids of one process's string dictionary, reference src/primitive/column.c:255-293 keeps heap pointers) become ids every rank agrees
+ * on before they cross xGMI, and local ids again after.  In place when out == cells.  Asynchronous on the context's stream. */
+int mdb_dev_map_ids(mdb_dev_ctx *ctx, const int64_t *cells, uint64_t n, const int64_t *table, uint64_t table_n, int64_t *out);
 int mdb_dev_iota32(mdb_dev_ctx *ctx, uint32_t *dst, uint64_t n);
 
 /* ------------------------------------------------------------------ UPDATE ... SET col = literal

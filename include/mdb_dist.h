@@ -238,6 +238,10 @@ int mdb_dist_join_pairs(mdb_dist *d, const int64_t *keys_l, const uint64_t *null
 /* every rank's n (<= 8) 64-bit values to every rank: all[p * n + i] = value i of rank p (HOST arrays, blocking, collective) */
 int mdb_dist_allgather_u64(mdb_dist *d, const uint64_t *mine, int n, uint64_t *all);
 int mdb_dist_allreduce_sum_u64(mdb_dist *d, uint64_t *vals, int n);
+/* every rank's n bytes (HOST) to every rank: *all = malloc'd concatenation in rank order (free()), counts[p] = rank p's bytes
+ * (counts: world entries).  For small variable-length payloads - query_execute() in sharded mode announces the new entries of the
+ * ranks' string dictionaries with it, so that VARCHAR cells can travel as ids every rank agrees on. */
+int mdb_dist_allgather_bytes(mdb_dist *d, const void *mine, uint64_t n, void **all, uint64_t *counts);
 int mdb_dist_barrier(mdb_dist *d);
 
 #ifdef __cplusplus

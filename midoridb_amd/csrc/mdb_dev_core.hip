@@ -423,6 +423,28 @@ extern "C" int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr)
 	return mdb_cached_free(ctx, dptr);
 }
 
+/* out[i] = table[cells[i]] for 0 <= cells[i] < table_n, else 0 (dictionary ids of one rank <-> the ranks' common ids: mdb_exec_shard.c) */
+__global__ __launch_bounds__(256) void k_map_ids(const long long *__restrict__ cells, unsigned long long n, const long long *__restrict__ table,
+						   unsigned long long table_n, long long *__restrict__ out)
+{
+	for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+		const long long c = cells[i];
+		out[i] = (c >= 0 && (unsigned long long)c < table_n) ? table[c] : 0;
+	}
+}
+
+extern "C" int mdb_dev_map_ids(mdb_dev_ctx *ctx, const int64_t *cells, uint64_t n, const int64_t *table, uint64_t table_n, int64_t *out)
+{
+	if (!ctx || (n && (!cells || !out || !table)))
+		return -MIDORIDB_ERROR;
+	if (!n)
+		return MIDORIDB_OK;
+	const uint64_t b = (n + 255) / 256;
+	MDB_LAUNCH(ctx, "map_ids", k_map_ids, (uint32_t)(b > 16384 ? 16384 : b), 256, reinterpret_cast<const long long *>(cells), (unsigned long long)n,
+		   reinterpret_cast<const long long *>(table), (unsigned long long)table_n, reinterpret_cast<long long *>(out));
+	return MIDORIDB_OK;
+}
+
 extern "C" size_t mdb_dev_alloc_size(mdb_dev_ctx *ctx, const void *dptr)
 {
 	if (!ctx || !dptr)

@@ -629,6 +629,68 @@ extern "C" int mdb_dist_allgather_u64(mdb_dist *d, const uint64_t *mine, int n, 
 	return MIDORIDB_OK;
 }
 
+/* every rank's `n` bytes to every rank (HOST buffers; *all = malloc'd concatenation in rank order, counts[p] = rank p's bytes):
+ * small variable-length payloads - the new entries of the ranks' string dictionaries.  Collective, blocking. */
+extern "C" int mdb_dist_allgather_bytes(mdb_dist *d, const void *mine, uint64_t n, void **all, uint64_t *counts)
+{
+	if (!d || !all || !counts || (n && !mine))
+		return d ? dist_err(d, -MIDORIDB_ERROR, "allgather_bytes: bad arguments") : -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = d->ctx;
+	const int W = d->world;
+	*all = NULL;
+	DIST_HIP(d, hipSetDevice(ctx->device));
+	uint64_t sendv[1 << MDB_MAX_RADIX_BITS], recvv[1 << MDB_MAX_RADIX_BITS];
+	size_t sc[1 << MDB_MAX_RADIX_BITS], sd[1 << MDB_MAX_RADIX_BITS], rcn[1 << MDB_MAX_RADIX_BITS], rd[1 << MDB_MAX_RADIX_BITS];
+	for (int p = 0; p < W; p++)
+		sendv[p] = n;
+	int rc = d->t.counts(d->t.self, sendv, recvv, 1);
+	if (rc)
+		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
+	uint64_t total = 0;
+	for (int p = 0; p < W; p++) {
+		counts[p] = recvv[p];
+		sc[p] = (size_t)n;
+		sd[p] = 0;
+		rcn[p] = (size_t)recvv[p];
+		rd[p] = (size_t)total;
+		total += recvv[p];
+	}
+	char *host = (char *)malloc(total ? total : 1);
+	void *dsend = NULL, *drecv = NULL;
+	int arc = host ? MIDORIDB_OK : -MIDORIDB_NOMEM;
+	if (!arc)
+		arc = mdb_dev_alloc(ctx, n ? n : 1, &dsend);
+	if (!arc)
+		arc = mdb_dev_alloc(ctx, total ? total : 1, &drecv);
+	/* (the ranks agree on their buffers before anything is posted) */
+	for (int p = 0; p < W; p++)
+		sendv[p] = arc ? 1 : 0;
+	rc = d->t.counts(d->t.self, sendv, recvv, 1);
+	for (int p = 0; p < W && !rc; p++)
+		if (recvv[p] && !arc)
+			arc = -MIDORIDB_NOMEM;
+	if (!rc && !arc && total) {
+		if (n && hipMemcpyAsync(dsend, mine, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+			arc = -MIDORIDB_INTERNAL;
+		if (!arc && (hipEventRecord(d->ev_ready, ctx->stream) != hipSuccess || hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0) != hipSuccess))
+			arc = -MIDORIDB_INTERNAL;
+		if (!arc)
+			rc = d->t.alltoallv(d->t.self, dsend, sc, sd, drecv, rcn, rd, 1, d->comm_stream);
+		if (!rc && !arc && (hipStreamSynchronize(d->comm_stream) != hipSuccess ||
+				    hipMemcpy(host, drecv, total, hipMemcpyDeviceToHost) != hipSuccess))
+			arc = -MIDORIDB_INTERNAL;
+	}
+	(void)mdb_dev_free(ctx, dsend);
+	(void)mdb_dev_free(ctx, drecv);
+	if (rc || arc) {
+		free(host);
+		return rc ? dist_err(d, rc, "all-gather failed%s%s", d->own_transport ? ": " : "", transport_err(d))
+			  : dist_err(d, arc, "all-gather of %llu bytes: buffers or copies failed on some rank", (unsigned long long)total);
+	}
+	*all = host;
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dist_barrier(mdb_dist *d)
 {
 	uint64_t one = 1;

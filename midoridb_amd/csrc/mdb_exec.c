@@ -403,6 +403,11 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 				rc = double_join_keys(x, &rt->cols[kr->col_idx], rsel, r_rows, &kv, &kn);
 			else
 				rc = table_column(x, t, kr, rsel, r_rows, &kv, &kn);
+			if (!rc && kr->type == MDB_CT_VARCHAR) {	/* (rows go where their STRING hashes to: the ranks' common id of it) */
+				const int64_t *common = NULL;
+				rc = shard_ids(x, kv, r_rows, true, false, &common);
+				kv = common;
+			}
 			if (rc || (rc = shard_rows(x, tabs1, 1, rids1, r_rows, kv, kn, 0, &r_rows)))
 				return rc;
 			rsel = NULL;
@@ -743,6 +748,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys, only_count) : -1;
 	if (fused >= 0 && (!split_ok || ws.nresidual))
 		fused = -1;	/* a conjunct reads several tables: it has to see the joined rows */
+	if (fused >= 0 && cat->dist && s->ntabs > 2 && fkeys[0]->type == MDB_CT_VARCHAR)
+		fused = -1;	/* (sharded chains over VARCHAR keys: the general plan exchanges the rows by their strings' common ids) */
 	if (fused >= 0) {
 		/* ---- north-star plan: join + GROUP BY key + COUNT(*) without materialising the join.  More than two tables
 		 *      on the same key chain the operator: the group keys of (T0, T1) are joined with T2, and so on; a group's
@@ -756,12 +763,17 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
 		bool multi_done = false;
-		if (cat->dist && fkeys[0]->type == MDB_CT_VARCHAR) {
-			ERR("sharded mode: VARCHAR join keys are ids of this process's string dictionary and mean nothing to the other ranks\n");
-			rc = -MIDORIDB_ERROR;
-			goto out;
+		const bool text_keys = cat->dist && fkeys[0]->type == MDB_CT_VARCHAR;
+		if (text_keys) {
+			/* sharded mode, VARCHAR join keys: the ids of this process's dictionary mean nothing to the other ranks - the operator
+			 * runs on the ranks' common ids (shard_ids) and its group keys are translated back where they arrive */
+			const int64_t *cl = NULL, *cr = NULL;
+			if ((rc = shard_ids(&x, (const int64_t *)lv, nl_rows, true, false, &cl)) || (rc = shard_ids(&x, (const int64_t *)rv, nr_rows, true, false, &cr)))
+				goto out;
+			lv = cl;
+			rv = cr;
 		}
-		if (cat->dist && fkeys[0]->type != MDB_CT_DOUBLE && (rc = shard_promise_ranges(&x, fkeys[0], fkeys[1])))
+		if (cat->dist && fkeys[0]->type != MDB_CT_DOUBLE && !text_keys && (rc = shard_promise_ranges(&x, fkeys[0], fkeys[1])))
 			goto out;
 		if (cat->dist && s->ntabs > 2 && s->ntabs <= 4) {
 			/* sharded mode, three or four tables on one key: ONE exchange - every table partitioned once with the same hash, the
@@ -898,6 +910,11 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				goto out;
 			}
 			J = tot;
+		}
+		if (text_keys && G && !only_count) {	/* the group keys that arrived: common ids -> ids of this rank's dictionary */
+			const int64_t *same = NULL;
+			if ((rc = shard_ids(&x, x.d_fused_key, G, false, true, &same)))
+				goto out;
 		}
 		x.fused = true;
 		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */

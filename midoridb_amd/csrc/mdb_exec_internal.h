@@ -46,6 +46,7 @@ struct exec {
 	const struct mdb_expr *part[2 * MDB_MAX_TABS];
 	int npart;
 	bool promised;		/* the exchange handle holds this statement's key ranges (shard_promise_ranges) */
+	bool dict_synced;	/* the ranks' string dictionaries were made known to each other for this statement (shard_dict_sync) */
 	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
 };
 
@@ -88,6 +89,8 @@ int double_join_keys(struct exec *x, const struct mdb_column *col, const uint32_
 void mark_needed(struct exec *x, const struct mdb_expr *e);
 void mark_needed_all(struct exec *x);
 bool in_part(const struct exec *x, const struct mdb_expr *f);
+int shard_dict_sync(struct exec *x);
+int shard_ids(struct exec *x, const int64_t *cells, uint64_t n, bool to_common, bool in_place, const int64_t **out);
 #define SHARD_BROADCAST (1u << 30)	/* shard_rows flag: every rank's rows to every rank (mdb_dist_broadcast_rows) instead of rows by key */
 int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of, uint64_t n, const int64_t *kv, const uint64_t *kn, uint32_t flags, uint64_t *n_out);
 int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flags);

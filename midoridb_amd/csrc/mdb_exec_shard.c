@@ -54,6 +54,139 @@ bool in_part(const struct exec *x, const struct mdb_expr *f)
 /* Tables tabs[0..nt) share one tuple stream of n tuples, table tabs[i] read through rid_of[i] (NULL = identity); kv / kn is
  * the stream's partitioning key.  Afterwards each of those tables is a shadow over the rows this rank received, *n_out of
  * them, all read by identity.  Collective: every rank calls it for the same statement at the same point. */
+/* ---- strings in sharded mode.  A VARCHAR cell is the id of its string in THIS process's dictionary (mdb_store.c; upstream keeps a heap
+ * pointer per cell, src/primitive/column.c:255-293): meaningless on another rank.  Before the first VARCHAR cell of a statement crosses
+ * xGMI the ranks make their dictionaries known to each other: every rank announces the strings it has not announced yet (one
+ * all-gather of bytes), and every rank interns ALL announcements, in rank order, into its own dictionary and into a second one, the
+ * COMMON dictionary - built from the same strings in the same order everywhere, so its ids mean the same on every rank.  Cells travel
+ * as common ids (one table lookup per cell on the device before the exchange, one after it): equal strings stay equal ids, joins,
+ * GROUP BY and DISTINCT over VARCHAR columns stay INT64 work, and what a rank returns are ids of its own dictionary again. */
+static int dict_tables_grow(struct mdb_catalog *cat, uint64_t nl, uint64_t ng)
+{
+	if (nl + 1 > cat->l2g_cap) {
+		uint64_t c = cat->l2g_cap ? cat->l2g_cap : 1024;
+		while (c < nl + 1)
+			c *= 2;
+		int64_t *p = realloc(cat->l2g, c * sizeof(*p));
+		if (!p)
+			return -MIDORIDB_NOMEM;
+		memset(p + cat->l2g_cap, 0, (c - cat->l2g_cap) * sizeof(*p));
+		cat->l2g = p;
+		cat->l2g_cap = c;
+	}
+	if (ng + 1 > cat->g2l_cap) {
+		uint64_t c = cat->g2l_cap ? cat->g2l_cap : 1024;
+		while (c < ng + 1)
+			c *= 2;
+		int64_t *p = realloc(cat->g2l, c * sizeof(*p));
+		if (!p)
+			return -MIDORIDB_NOMEM;
+		memset(p + cat->g2l_cap, 0, (c - cat->g2l_cap) * sizeof(*p));
+		cat->g2l = p;
+		cat->g2l_cap = c;
+	}
+	return MIDORIDB_OK;
+}
+
+/* collective: every rank of the statement gets here at the same point (whether a statement moves VARCHAR cells follows from its text and
+ * the schema alone); once per statement */
+int shard_dict_sync(struct exec *x)
+{
+	struct mdb_catalog *cat = x->cat;
+	if (x->dict_synced)
+		return MIDORIDB_OK;
+	const int W = mdb_dist_world(cat->dist);
+	int lrc = dict_tables_grow(cat, cat->dict.n, cat->gdict.n);
+	/* this rank's announcements: [u32 length][bytes] per string it has not announced */
+	size_t bytes = 0;
+	for (uint64_t id = 1; id <= cat->dict.n && !lrc; id++)
+		if (!cat->l2g[id])
+			bytes += 4 + cat->dict.len[id - 1];
+	char *mine = malloc(bytes ? bytes : 1);
+	if (!mine)
+		lrc = -MIDORIDB_NOMEM;
+	size_t at = 0;
+	for (uint64_t id = 1; id <= cat->dict.n && !lrc; id++)
+		if (!cat->l2g[id]) {
+			const uint32_t len = cat->dict.len[id - 1];
+			memcpy(mine + at, &len, 4);
+			memcpy(mine + at + 4, cat->dict.str[id - 1], len);
+			at += 4 + len;
+		}
+	void *all = NULL;
+	uint64_t counts[512];
+	if (W > 512)
+		lrc = -MIDORIDB_ERROR;
+	/* (a rank in trouble still takes part, with nothing to say: its failure is its own, the collective completes) */
+	const int rc = mdb_dist_allgather_bytes(cat->dist, mine, lrc ? 0 : at, &all, counts);
+	free(mine);
+	if (rc) {
+		snprintf(x->err, x->errlen, "execution phase: dictionary exchange: %s\n", mdb_dist_last_error(cat->dist));
+		return -MIDORIDB_INTERNAL;
+	}
+	if (!lrc) {
+		const char *p = all;
+		for (int r = 0; r < W && !lrc; r++) {
+			const char *end = p + counts[r];
+			while (p < end && !lrc) {
+				uint32_t len;
+				memcpy(&len, p, 4);
+				const int64_t l = mdb_dict_intern(&cat->dict, p + 4, len), g = mdb_dict_intern(&cat->gdict, p + 4, len);
+				if (!l || !g || dict_tables_grow(cat, (uint64_t)l, (uint64_t)g)) {
+					lrc = -MIDORIDB_NOMEM;
+					break;
+				}
+				cat->l2g[l] = g;
+				cat->g2l[g] = l;
+				p += 4 + len;
+			}
+		}
+	}
+	free(all);
+	/* device copies of the two tables, when they grew */
+	if (!lrc && (cat->d_l2g_n != cat->dict.n + 1 || cat->d_g2l_n != cat->gdict.n + 1)) {
+		(void)mdb_dev_sync(x->dev);
+		(void)mdb_dev_free(x->dev, cat->d_l2g);
+		(void)mdb_dev_free(x->dev, cat->d_g2l);
+		cat->d_l2g = cat->d_g2l = NULL;
+		cat->d_l2g_n = cat->d_g2l_n = 0;
+		void *a = NULL, *b = NULL;
+		if (mdb_dev_alloc(x->dev, (cat->dict.n + 1) * 8, &a) || mdb_dev_alloc(x->dev, (cat->gdict.n + 1) * 8, &b) ||
+		    mdb_dev_h2d(x->dev, a, cat->l2g, (cat->dict.n + 1) * 8) || mdb_dev_h2d(x->dev, b, cat->g2l, (cat->gdict.n + 1) * 8)) {
+			(void)mdb_dev_free(x->dev, a);
+			(void)mdb_dev_free(x->dev, b);
+			lrc = -MIDORIDB_NOMEM;
+		} else {
+			cat->d_l2g = a;
+			cat->d_g2l = b;
+			cat->d_l2g_n = cat->dict.n + 1;
+			cat->d_g2l_n = cat->gdict.n + 1;
+		}
+	}
+	if (lrc) {
+		snprintf(x->err, x->errlen, "execution phase: dictionary exchange: out of memory\n");
+		return lrc;
+	}
+	x->dict_synced = true;
+	return MIDORIDB_OK;
+}
+
+/* n VARCHAR cells as ids of the common dictionary (to_common) or of this rank's own again: *out = a statement buffer, or `cells` itself
+ * when in_place */
+int shard_ids(struct exec *x, const int64_t *cells, uint64_t n, bool to_common, bool in_place, const int64_t **out)
+{
+	int rc = shard_dict_sync(x);
+	if (rc)
+		return rc;
+	int64_t *dst = in_place ? (int64_t *)cells : dalloc(x, (n ? n : 1) * 8);
+	if (!dst)
+		return dev_fail(x, "allocating translated string ids");
+	if (mdb_dev_map_ids(x->dev, cells, n, to_common ? x->cat->d_l2g : x->cat->d_g2l, to_common ? x->cat->d_l2g_n : x->cat->d_g2l_n, dst))
+		return dev_fail(x, "translating string ids");
+	*out = dst;
+	return MIDORIDB_OK;
+}
+
 int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of, uint64_t n, const int64_t *kv, const uint64_t *kn,
 		      uint32_t flags, uint64_t *n_out)
 {
@@ -62,6 +195,7 @@ int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of,
 	int col_i[MDB_DIST_SHUFFLE_MAX_COLS], col_c[MDB_DIST_SHUFFLE_MAX_COLS], nc = 0;
 	void *ov[MDB_DIST_SHUFFLE_MAX_COLS];
 	uint64_t *on[MDB_DIST_SHUFFLE_MAX_COLS];
+	bool is_text[MDB_DIST_SHUFFLE_MAX_COLS] = { false };
 	uint64_t got = 0;
 
 	for (int i = 0; i < nt; i++) {
@@ -69,16 +203,21 @@ int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of,
 		for (int c = 0; c < tb->ncols; c++) {
 			if (!x->need[tabs[i]][c])
 				continue;
-			if (tb->cols[c].type == MDB_CT_VARCHAR) {
-				snprintf(x->err, x->errlen, "execution phase: sharded mode: VARCHAR column %s.%s cannot travel between the ranks (its cells are "
-							    "ids of this process's string dictionary)\n", tb->name, tb->cols[c].name);
-				return -MIDORIDB_ERROR;
-			}
 			if (nc == MDB_DIST_SHUFFLE_MAX_COLS) {
 				snprintf(x->err, x->errlen, "execution phase: sharded mode: more than %d columns in one exchange\n", MDB_DIST_SHUFFLE_MAX_COLS);
 				return -MIDORIDB_ERROR;
 			}
 			cols[nc].values = tb->cols[c].d_data;
+			if (tb->cols[c].type == MDB_CT_VARCHAR && tb->cols[c].d_data) {
+				/* the column's cells as ids of the ranks' common dictionary (the whole column: the rows that travel are read
+				 * from it through their row ids) */
+				const int64_t *common = NULL;
+				const int trc = shard_ids(x, tb->cols[c].d_data, tb->device_only ? tb->dev_rows : tb->nrows, true, false, &common);
+				if (trc)
+					return trc;
+				cols[nc].values = common;
+				is_text[nc] = true;
+			}
 			cols[nc].nullbits = tb->cols[c].d_nullbits;
 			cols[nc].rid = rid_of[i];
 			col_i[nc] = i;
@@ -106,6 +245,13 @@ int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of,
 	for (int k = 0; k < nc; k++)
 		if (track(x, ov[k]) || (on[k] && track(x, on[k])))
 			return -MIDORIDB_NOMEM;
+	for (int k = 0; k < nc; k++)
+		if (is_text[k] && got) {	/* what arrived: common ids -> ids of this rank's dictionary, where it stands */
+			const int64_t *same = NULL;
+			const int trc = shard_ids(x, ov[k], got, false, true, &same);
+			if (trc)
+				return trc;
+		}
 	for (int i = 0; i < nt; i++) {
 		const int t = tabs[i];
 		const struct mdb_table *tb = s->tabs[t].t;
@@ -155,6 +301,8 @@ int shard_stream(struct exec *x, int nt, const struct mdb_expr *f, uint32_t flag
 	} else if ((rc = stream_column(x, f, &kv, &kn))) {
 		return rc;
 	}
+	if (f->type == MDB_CT_VARCHAR && (rc = shard_ids(x, kv, x->n, true, false, &kv)))	/* (placement by the string, not by one rank's id of it) */
+		return rc;
 	for (int t = 0; t < nt; t++) {
 		tabs[t] = t;
 		rids[t] = x->rid[t];

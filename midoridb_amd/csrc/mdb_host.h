@@ -102,6 +102,14 @@ struct mdb_catalog {
 	/* sharded mode (MIDORIDB_WORLD_SIZE > 1 in the environment: one process per GPU, every process holds ITS rows of every
 	 * table): the RCCL exchange handle, created with the device context (include/mdb_dist.h) */
 	mdb_dist *dist;
+	/* ... and the strings: a VARCHAR cell is the id of its string in THIS process's dictionary; cells that cross xGMI travel as ids of
+	 * the ranks' COMMON dictionary `gdict`, which every rank builds from the same announcements in the same order (shard_dict_sync,
+	 * mdb_exec_shard.c).  l2g[local id] = common id (0: not announced yet), g2l[common id] = local id; d_*: device copies */
+	struct mdb_strdict gdict;
+	int64_t *l2g, *g2l;
+	uint64_t l2g_cap, g2l_cap;
+	int64_t *d_l2g, *d_g2l;
+	uint64_t d_l2g_n, d_g2l_n;	/* entries the device copies hold */
 	bool groups_any_order;		/* mdb_database_groups_any_order(): GROUP BY over a join need not keep first-occurrence order */
 	bool results_on_device;		/* mdb_database_results_on_device(): SELECT results stay in HBM until a consumer reads them */
 };

@@ -194,6 +194,13 @@ void mdb_dict_free(struct mdb_strdict *d)
 void mdb_catalog_free(struct mdb_catalog *cat)
 {
 	mdb_dict_free(&cat->dict);
+	mdb_dict_free(&cat->gdict);
+	free(cat->l2g);
+	free(cat->g2l);
+	if (cat->dev) {
+		(void)mdb_dev_free(cat->dev, cat->d_l2g);
+		(void)mdb_dev_free(cat->dev, cat->d_g2l);
+	}
 	for (int i = 0; i < cat->n; i++)
 		mdb_table_free(cat->tables[i], cat->dev);
 	free(cat->tables);

@@ -122,7 +122,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size",
+    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
@@ -297,21 +297,22 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_gen_payload(self.h, _ptr(out), n, first_index, seed, kind), "gen_payload")
         return out
 
-    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST):
-        """-> (keys[G], counts[G], first[G], joined_rows); tensors are views into `out` buffers."""
+    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST, want_first=True):
+        """-> (keys[G], counts[G], first[G], joined_rows); tensors are views into `out` buffers.  want_first=False: the result
+        query_execute() asks for - (key, COUNT) in first-occurrence order, no first-row column (first[G] is returned as None)."""
         n_l, n_r = keys_l.numel(), keys_r.numel()
         cap = max(n_l, 1)
         if out is None:
             out = (torch.empty(cap, dtype=torch.int64, device=self.device),
                    torch.empty(cap, dtype=torch.int64, device=self.device),
-                   torch.empty(cap, dtype=torch.int32, device=self.device))
-        ok, oc, of = out
+                   torch.empty(cap, dtype=torch.int32, device=self.device) if want_first else None)
+        ok, oc, of = out[0], out[1], (out[2] if want_first else None)
         g, j = c_uint64(), c_uint64()
         self._chk(self.lib.mdb_dev_join_group_count(self.h, _ptr(keys_l), _ptr(null_l), n_l, _ptr(keys_r), _ptr(null_r), n_r,
                                                     flags, _ptr(ok), _ptr(oc), _ptr(of), cap, byref(g), byref(j)),
                   "join_group_count")
         G = g.value
-        return ok[:G], oc[:G], of[:G], j.value
+        return ok[:G], oc[:G], (of[:G] if of is not None else None), j.value
 
     def join_group_count_unordered(self, keys_l, null_l, keys_r, null_r, out=None):
         """the same operator without MDB_ORDER_FIRST and without first rows: groups in unspecified order -> (keys[G], counts[G], joined_rows)"""

@@ -49,7 +49,7 @@ DIST_SYMBOLS = [
     "mdb_dist_last_error", "mdb_dist_init_transport", "mdb_dist_set_wire", "mdb_dist_last_wire32", "mdb_dist_join_group_count",
     "mdb_dist_join_group_count_alloc", "mdb_dist_last_received_left", "mdb_dist_allreduce_sum_u64", "mdb_dist_barrier",
     "mdb_dist_set_key_ranges", "mdb_dist_last_pruned", "mdb_dist_last_fused", "mdb_dist_join_group_count_multi_alloc", "mdb_dist_group_count_keys_alloc", "mdb_dist_allgather_u64", "mdb_dist_shuffle_rows", "mdb_dist_wait_transfers", "mdb_dist_join_pairs",
-    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases", "mdb_dist_plan_preview", "mdb_dist_broadcast_rows",
+    "mdb_dist_last_plan", "mdb_dist_set_phase_timing", "mdb_dist_last_phases", "mdb_dist_plan_preview", "mdb_dist_broadcast_rows", "mdb_dist_allgather_bytes",
 ]
 
 

@@ -11,7 +11,8 @@ and checks every rank's groups against the numpy oracle restricted to the keys t
   shapes : the operators called directly (join_group_count, _multi, group_count_keys, join_pairs keys-only and with payload,
            shuffle_rows), skew -> fallback on every rank, a key window of 2^30 values (configs[3]: 10^9 unique keys)
   sql    : query_execute() in sharded mode: the 17 statement shapes of the world-2 test, then configs[4]'s own statement - three
-           tables with DOUBLE payload joined on one key + GROUP BY, and its join-only form - against numpy
+           tables with DOUBLE payload joined on one key + GROUP BY, and its join-only form - against numpy; VARCHAR columns whose
+           cells cross the ranks as ids of a common dictionary
   fault  : one rank's first level fails (MDB_DIST_FAULT): every rank must return an error, none may hang; the call after works
 """
 import os
@@ -305,6 +306,68 @@ def config5_sql(world, rank):
     dist.barrier()
 
 
+def varchar_sql(world, rank):
+    """VARCHAR columns in sharded mode: a cell is the id of its string in ONE process's dictionary, so before cells cross the ranks the
+    dictionaries are made known to each other and the cells travel as ids of a common dictionary every rank builds alike (shard_dict_sync).
+    Ranks load different rows - and so hold different dictionaries with different ids for the same strings: joins on a VARCHAR key, GROUP BY
+    and DISTINCT over one, VARCHAR payload behind an INT join, a string literal in WHERE - against plain Python over the whole tables"""
+    import collections
+    from midoridb_amd.query import DB
+    from midoridb_amd.dist import DatabaseDevice
+    rng = np.random.default_rng(23)
+    names = [f"name-{i:04d}" for i in range(400)] + ["", "x", "a rather long string, 31 chars.."]
+    npq, nq = 3000 * world, 1100 * world
+    pn = [names[i] for i in rng.integers(0, len(names), npq)]
+    pv = rng.integers(0, 300, npq)
+    qn = [names[i] for i in rng.integers(50, len(names), nq)]		# (Q never holds the first 50 names, P never ... some of the last)
+    qw = rng.integers(0, 300, nq)
+    with DB() as db:
+        dx = gloo_transport(DatabaseDevice(db, 0), world, rank)
+        dx.attach_to_database(db)
+        db.execute("CREATE TABLE P (name VARCHAR(40), v INT);")
+        db.execute("CREATE TABLE Q (name2 VARCHAR(40), w INT);")
+        # uneven, ORDER-SHUFFLED shards: every rank interns the strings in another order, so the same string has different ids everywhere
+        lo, hi = npq * rank // world, npq * (rank + 1) // world
+        order = rng.permutation(hi - lo) if rank % 2 else np.arange(hi - lo)[::-1]
+        db.append_columns("P", [[pn[lo + i] for i in order], pv[lo:hi][order]])
+        lo2, hi2 = nq * rank // world, nq * (rank + 1) // world
+        db.append_columns("Q", [qn[lo2:hi2], qw[lo2:hi2]])
+
+        def gathered(sql):
+            r = db.query(sql)
+            parts = [None] * world
+            dist.all_gather_object(parts, [tuple(x.item() if hasattr(x, "item") else x for x in row) for row in zip(*[c.tolist() for c in r.columns])])
+            return r.names, sorted(t for p in parts for t in p)
+        nm, got = gathered("SELECT name, COUNT(*) FROM P GROUP BY name;")
+        cnt = collections.Counter(pn)
+        assert got == sorted((cnt[k], k) if nm[0] == "COUNT(*)" else (k, cnt[k]) for k in cnt), (len(got), len(cnt))
+        nm, got = gathered("SELECT DISTINCT name FROM P;")
+        assert got == sorted((k,) for k in cnt)
+        nm, got = gathered("SELECT name, COUNT(*) FROM P INNER JOIN Q ON P.name = Q.name2 GROUP BY name;")
+        cq = collections.Counter(qn)
+        exp = {k: cnt[k] * cq[k] for k in cnt if k in cq}
+        assert got == sorted((exp[k], k) if nm[0] == "COUNT(*)" else (k, exp[k]) for k in exp), (len(got), len(exp))
+        nm, got = gathered("SELECT name, v, w FROM P INNER JOIN Q ON P.name = Q.name2 WHERE v < 20;")
+        byname = collections.defaultdict(list)
+        for n2, w in zip(qn, qw.tolist()):
+            byname[n2].append(w)
+        cols = {c: i for i, c in enumerate(nm)}
+        exp_rows = sorted(tuple({"P.name": n1, "P.v": v, "Q.w": w}[c] for c in nm) for n1, v in zip(pn, pv.tolist()) if v < 20 for w in byname.get(n1, ()))
+        assert got == exp_rows, (len(got), len(exp_rows), cols)
+        nm, got = gathered("SELECT name, name2 FROM P INNER JOIN Q ON P.v = Q.w WHERE name = 'name-0007';")	# VARCHAR payload on both sides, INT key
+        byw = collections.defaultdict(list)
+        for n2, w in zip(qn, qw.tolist()):
+            byw[w].append(n2)
+        exp_rows = sorted(tuple({"P.name": n1, "Q.name2": n2}[c] for c in nm) for n1, v in zip(pn, pv.tolist()) if n1 == "name-0007" for n2 in byw.get(v, ()))
+        assert got == exp_rows, (len(got), len(exp_rows))
+        # rows inserted later bring new strings: announced by the next statement that moves VARCHAR cells
+        db.execute(f"INSERT INTO P VALUES ('late-{rank}', 1), ('late-all', 2);")
+        nm, got = gathered("SELECT name, COUNT(*) FROM P GROUP BY name;")
+        late = dict((t[nm.index("P.name")], t[nm.index("COUNT(*)")]) for t in got if str(t[nm.index("P.name")]).startswith("late-"))
+        assert late == dict([(f"late-{r}", 1) for r in range(world)] + [("late-all", world)]), late
+    dist.barrier()
+
+
 def main():
     mode = sys.argv[1]
     rank = int(os.environ.get("RANK", "0"))
@@ -318,6 +381,7 @@ def main():
     elif mode == "sql":
         sharded_sql(world, rank)
         config5_sql(world, rank)
+        varchar_sql(world, rank)
     else:
         raise SystemExit(f"unknown mode {mode}")
     dist.barrier()
