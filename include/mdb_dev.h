@@ -146,6 +146,9 @@ enum mdb_pred_op {
 	MDB_P_AND           = 6,
 	MDB_P_OR            = 7,
 	MDB_P_XOR           = 8,
+	MDB_P_IN_BITS       = 9,	/* push (bit <col a's value> of the device bit table at imm is set) ^ cmp, false for a NULL cell and for
+					 * a value beyond the table's b 64-bit words: set membership of small non-negative ids - LIKE over a
+					 * VARCHAR column, whose cells are dictionary ids (the pattern is matched once per distinct string) */
 };
 /* comparison codes = the reference's enum ast_comparison_type (include/parser/ast.h:71-84) */
 enum mdb_cmp { MDB_CMP_LT = 1, MDB_CMP_GT = 2, MDB_CMP_NE = 3, MDB_CMP_EQ = 4, MDB_CMP_LE = 5, MDB_CMP_GE = 6 };

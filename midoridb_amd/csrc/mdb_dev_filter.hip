@@ -96,6 +96,14 @@ __device__ static inline bool pred_eval(const pred_args &p, uint64_t k)
 			b = b != (in.cmp != 0);
 			st = (st << 1) | (uint64_t)b;
 			break;
+		case MDB_P_IN_BITS: {
+			const bool okx = pred_load(p.cols[in.a], k, &x);
+			const bool in_table = okx && (x >> 6) < (uint64_t)(uint32_t)in.b;
+			const bool hit = in_table && ((reinterpret_cast<const uint64_t *>((uintptr_t)in.imm)[x >> 6] >> (x & 63u)) & 1u);
+			b = okx && (hit != (in.cmp != 0));
+			st = (st << 1) | (uint64_t)b;
+			break;
+		}
 		case MDB_P_CONST:
 			st = (st << 1) | (uint64_t)(in.imm != 0);
 			break;
@@ -176,6 +184,15 @@ __device__ static inline void pred_eval_pair(const pred_args &p, uint64_t k0, bo
 			b0 = (!okx[0]) != (in.cmp != 0);
 			b1 = (!okx[1]) != (in.cmp != 0);
 			break;
+		case MDB_P_IN_BITS: {
+			load(in.a, x, okx);
+			const uint64_t *const tab = reinterpret_cast<const uint64_t *>((uintptr_t)in.imm);
+			const bool h0 = okx[0] && (x[0] >> 6) < (uint64_t)(uint32_t)in.b && ((tab[x[0] >> 6] >> (x[0] & 63u)) & 1u);
+			const bool h1 = okx[1] && (x[1] >> 6) < (uint64_t)(uint32_t)in.b && ((tab[x[1] >> 6] >> (x[1] & 63u)) & 1u);
+			b0 = okx[0] && (h0 != (in.cmp != 0));
+			b1 = okx[1] && (h1 != (in.cmp != 0));
+			break;
+		}
 		case MDB_P_CONST:
 			b0 = b1 = in.imm != 0;
 			break;
@@ -1156,6 +1173,9 @@ static int filter_prepare(mdb_dev_ctx *ctx, const struct mdb_pred_insn *prog, in
 		case MDB_P_CMP_COL_CONST:
 		case MDB_P_CMP_CONST_COL:
 		case MDB_P_ISNULL:
+		case MDB_P_IN_BITS:
+			if (in.op == MDB_P_IN_BITS && (!in.imm || in.b < 0))
+				return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: a bit-table test without a table");
 			if (in.a < 0 || in.a >= n_cols)
 				return mdb_set_err(ctx, -MIDORIDB_ERROR, "filter: bad column slot");
 			depth++;

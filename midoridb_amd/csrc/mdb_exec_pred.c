@@ -95,6 +95,29 @@ bool const_cmp(int op, const struct mdb_expr *l, const struct mdb_expr *r)
 	}
 }
 
+/* SQL LIKE: '%' any run of characters (none included), '_' exactly one; everything else itself, case-sensitive */
+static bool like_match(const char *s, size_t n, const char *pat, size_t m)
+{
+	size_t i = 0, j = 0, star = (size_t)-1, mark = 0;
+	while (i < n) {
+		if (j < m && pat[j] == '%') {
+			star = j++;
+			mark = i;
+		} else if (j < m && (pat[j] == '_' || pat[j] == s[i])) {
+			i++;
+			j++;
+		} else if (star != (size_t)-1) {
+			j = star + 1;
+			i = ++mark;
+		} else {
+			return false;
+		}
+	}
+	while (j < m && pat[j] == '%')
+		j++;
+	return j == m;
+}
+
 int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_expr *e)
 {
 	int rc = 0, a, b;
@@ -159,6 +182,30 @@ int pred_compile(struct exec *x, struct pred_prog *p, const struct mdb_expr *e)
 				return rc;
 		}
 		return 0;
+	}
+	case MDB_EX_LIKE: {
+		/* the pattern is matched ONCE per distinct string, on the host, against the database's dictionary; the device sees a bit per
+		 * dictionary id and tests the cell's (MDB_P_IN_BITS): 10^8 cells over 10^4 distinct strings are 10^4 matches */
+		const struct mdb_expr *f = e->kids[0], *v = e->kids[1];
+		const struct mdb_strdict *d = stmt_dict;
+		const size_t plen = strlen(v->sval) >= 2 ? strlen(v->sval) - 2 : 0;
+		const uint64_t words = ((d ? d->n : 0) + 1 + 63) / 64;
+		uint64_t *bits = calloc((size_t)words, 8);
+		if (!bits)
+			return -1;
+		for (uint64_t id = 1; d && id <= d->n; id++)
+			if (like_match(d->str[id - 1], d->len[id - 1], v->sval + 1, plen))
+				bits[id >> 6] |= 1ull << (id & 63);
+		void *dbits = dalloc(x, (size_t)words * 8);
+		if (!dbits || mdb_dev_h2d(x->dev, dbits, bits, (size_t)words * 8)) {
+			free(bits);
+			return -1;
+		}
+		free(bits);
+		a = pred_slot(x, p, f);
+		if (a < 0)
+			return -1;
+		return pred_emit(p, MDB_P_IN_BITS, e->op ? 1 : 0, MDB_T_INT64, a, (int)(words > 0x7FFFFFFF ? 0x7FFFFFFF : words), (int64_t)(uintptr_t)dbits);
 	}
 	default:
 		return -1;

@@ -178,6 +178,16 @@ int check_predicate_x(const struct mdb_expr *e, const char *clause, bool dml, ch
 	case MDB_EX_COUNT:
 		ERR("COUNT function can't be used in the %s-clause\n", clause);
 		return -MIDORIDB_ERROR;
+	case MDB_EX_LIKE:
+		/* upstream parses LIKE, checks its operands (semantic_select.c) and then evaluates it - and NOT LIKE - to TRUE for every
+		 * row, NULL cells included (executor_select.c:1027-1074: no case for it): a defect, not a semantics to keep.  Here it
+		 * has SQL's meaning over a VARCHAR column and a string pattern ('%' any run of characters, '_' any one character; a
+		 * NULL cell matches nothing, neither does it under NOT LIKE), SELECT only */
+		if (dml || e->nkids != 2 || e->kids[0]->kind != MDB_EX_FIELD || e->kids[0]->type != MDB_CT_VARCHAR || e->kids[1]->kind != MDB_EX_STRING) {
+			ERR("expressions in %s clause must be a type of comparison (LIKE takes a VARCHAR column and a string pattern)\n", clause);
+			return -MIDORIDB_ERROR;
+		}
+		return MIDORIDB_OK;
 	default:
 		ERR("expressions in %s clause must be a type of comparison\n", clause);
 		return -MIDORIDB_ERROR;

@@ -453,6 +453,8 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 				FAIL("error while running syntax analysis on query\n");
 		} else if (!strcmp(t, "LIKE") || !strcmp(t, "NOTLIKE")) {
 			e = ex_new(MDB_EX_LIKE);
+			if (e)
+				e->op = !strcmp(t, "NOTLIKE");
 			if (e && pop_n_into(&st, 2, e))
 				FAIL("error while running syntax analysis on query\n");
 		} else if (!strcmp(t, "ONEXPR")) {
