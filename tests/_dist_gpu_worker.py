@@ -212,6 +212,7 @@ def sharded_sql(world, rank):
         "SELECT id_a, id_c FROM A, C WHERE f1 > 40;",
         "SELECT id_a, f3 FROM A INNER JOIN C ON A.id_a < C.id_c AND f3 = 2;",
         "SELECT f3, COUNT(*) FROM A, C WHERE f1 > 45 GROUP BY f3;",
+        "SELECT f1, f3 FROM A, C WHERE id_a < 6;",			# NULL cells on both sides of a replicated join
     ]
     counts = [
         "SELECT COUNT(*) FROM A WHERE f1 > 0;",
