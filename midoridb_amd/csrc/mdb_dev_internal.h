@@ -45,14 +45,14 @@ struct mdb_part_result {
 	uint32_t bits_total;
 	bool w32;		/* hv holds 4-byte words (narrow form without row ids) */
 	bool w16;		/* ... 2-byte words: the hash bits below the first level's digit (mdb_part_filter.out16) */
-	uint64_t *pay[2];	/* first level only, mdb_part_filter.npay: the payload cells, laid out like hv (the cell of hv[i] is pay[c][i]) */
+	uint64_t *pay[2];	/* mdb_part_filter.npay: the payload cells, laid out like hv (the cell of hv[i] is pay[c][i]) */
 	uint32_t nsub;		/* != 0: first level only (mdb_part_filter.level0_only) - nleaves = 2^bits1 digits, digit d's rows lie in nsub
 				 * regions: region r = d * nsub + s at [r * leaf_cap, r * leaf_cap + min(count, leaf_cap)), its count at
 				 * leaf_cnt[s * nleaves + d] */
 };
 
 /* bytes of arena needed by mdb_partition_table() */
-size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast);
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast, int npay = 0 /* mdb_part_filter.npay */);
 
 /* Partition one key column into 2^(bits1+bits2) leaves by the top bits of fmix64(key), dropping
  * NULL keys.  stable = keep input order inside every leaf (slower ballot ranking; requires want_rid),
@@ -83,8 +83,9 @@ struct mdb_part_filter {
 	long long *minmax64_out;
 	unsigned long long *minmax64_tiles;
 	const long long *range64_in;
-	/* level0_only, narrow = 1 (hash | row id words): up to two 8-byte payload columns of the table travel with the rows
-	 * (mdb_part_result.pay) - a join that carries the right table's payload to the leaf instead of gathering it afterwards */
+	/* narrow = 1 (hash | row id words), histogram-free layout, one level (level0_only) or two: up to two 8-byte payload columns of the
+	 * table travel with the rows (mdb_part_result.pay) - a join that carries the right table's payload to the leaf instead of
+	 * gathering it afterwards */
 	const void *pay_in[2];
 	int npay;
 	/* first level, any form: keep only the rows whose KEY lies in [keep_lo, keep_hi] (keep_on) - the other table's global key

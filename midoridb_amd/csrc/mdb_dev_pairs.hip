@@ -1060,6 +1060,98 @@ __global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_cell(pp_args a, uint3
 		atomicAdd(a.joined, pairs);
 }
 
+/* Key windows beyond 2^24 values (10^8-row primary-key joins: 27 key bits): two partition levels - the right table's cells travel
+ * through both (k_part_scatter<pf_key_cf_pay>, <pf_word_pay>) - down to leaves of 2^rem <= 2^12 key values, whose cells (8 or 16 bytes
+ * per value) and occupancy bits sit in LDS; one 256-thread workgroup per leaf, several per CU.  Same contract as above. */
+struct pl_args {
+	const uint64_t *hv_l, *hv_r;
+	const uint64_t *pay_r[2];
+	uint64_t *out[2];
+	uint32_t npay;
+	const uint32_t *cnt_l, *cnt_r;
+	uint32_t cap_l, cap_r, nleaves;
+	unsigned long long *joined;
+	uint32_t *status;
+};
+#define PL_THREADS 256
+#define PL_MAX_REM 12u
+
+template <int NP /* payload columns: 32 KiB of LDS each - four (two) workgroups per CU */>
+__global__ __launch_bounds__(PL_THREADS) void k_leaf_pairs_cell2(pl_args a, uint32_t rem, uint32_t shift)
+{
+	__shared__ uint64_t s_cell[NP][1u << PL_MAX_REM];
+	__shared__ uint32_t s_occ[(1u << PL_MAX_REM) / 32];
+	__shared__ unsigned long long s_red[PL_THREADS / 64];
+	__shared__ uint32_t s_dup;
+	const uint32_t T = 1u << rem, mask = T - 1u;
+	unsigned long long pairs = 0;
+	for (uint32_t leaf = blockIdx.x; leaf < a.nleaves; leaf += gridDim.x) {		/* (uniform) */
+		for (uint32_t w = threadIdx.x; w < (T >> 5 ? T >> 5 : 1u); w += PL_THREADS)
+			s_occ[w] = 0u;
+		if (threadIdx.x == 0)
+			s_dup = 0u;
+		__syncthreads();
+		const uint32_t cr0 = a.cnt_r[leaf], cr = cr0 < a.cap_r ? cr0 : a.cap_r, cl0 = a.cnt_l[leaf], cl = cl0 < a.cap_l ? cl0 : a.cap_l;
+		const size_t br = (size_t)leaf * a.cap_r, bl = (size_t)leaf * a.cap_l;
+		for (uint32_t i0 = 0; i0 < cr; i0 += 2u * PL_THREADS) {
+			const uint32_t i = i0 + 2u * threadIdx.x, ic = i < cr ? i : 0u;
+			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_r + br + ic);
+			const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(a.pay_r[0] + br + ic);
+			ulonglong2 c1 = make_ulonglong2(0ull, 0ull);
+			if (NP > 1)
+				c1 = *reinterpret_cast<const ulonglong2 *>(a.pay_r[1] + br + ic);
+#pragma unroll
+			for (int k = 0; k < 2; k++)
+				if (i + (uint32_t)k < cr) {
+					const uint32_t slot = ((uint32_t)((k ? v.y : v.x) >> 32) >> shift) & mask;
+					const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+					if (old & (1u << (slot & 31u)))
+						s_dup = 1u;
+					s_cell[0][slot] = k ? c0.y : c0.x;
+					if (NP > 1)
+						s_cell[1][slot] = k ? c1.y : c1.x;
+				}
+		}
+		__syncthreads();
+		if (s_dup) {	/* a right key occurs twice */
+			if (threadIdx.x == 0)
+				mdb_raise(a.status, 32u);
+			return;
+		}
+		for (uint32_t i0 = 0; i0 < cl; i0 += 2u * PL_THREADS) {
+			const uint32_t i = i0 + 2u * threadIdx.x, ic = i < cl ? i : 0u;
+			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_l + bl + ic);
+#pragma unroll
+			for (int k = 0; k < 2; k++)
+				if (i + (uint32_t)k < cl) {
+					const unsigned long long w = k ? v.y : v.x;
+					const uint32_t slot = ((uint32_t)(w >> 32) >> shift) & mask;
+					if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
+						a.out[0][(uint32_t)w] = s_cell[0][slot];
+						if (NP > 1)
+							a.out[1][(uint32_t)w] = s_cell[1][slot];
+						pairs++;
+					}
+				}
+		}
+		__syncthreads();
+	}
+	/* (lw_block_sum is written for 1024-thread workgroups) */
+#pragma unroll
+	for (int o = 32; o; o >>= 1)
+		pairs += __shfl_down(pairs, o, MDB_WAVE);
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = pairs;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+		for (int w = 0; w < PL_THREADS / 64; w++)
+			t += s_red[w];
+		if (t)
+			atomicAdd(a.joined, t);
+	}
+}
+
 /* 0 = done: every one of the n_l left rows has its partner and out[c][i] = payload cell c of left row i's partner;
  * 1 = not served (some left row without a partner - NULL keys included -, duplicate right keys, no compact window of at most 2^24
  * values, a region overflow ...: mdb_dev_join_pairs answers); < 0 = error.  Synchronises. */
@@ -1085,8 +1177,89 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	if (rc)
 		return rc;
 	const bool remembered = ctx->guess_remembered;
-	if (!narrow || !win.kbits || win.kbits > 9u + PW_MAX_REM)
+	if (getenv("MDB_DEBUG_PAYLOAD"))
+		fprintf(stderr, "join_payload: narrow %d window 2^%u at %lld (attempt %d, remembered %d)\n", (int)narrow, win.kbits, (long long)win.lo, attempt, (int)remembered);
+	if (!narrow || !win.kbits)
 		return 1;
+	if (win.kbits > 9u + PW_MAX_REM) {
+		/* ---- windows of 2^25 ... 2^30 values: two levels, leaves of 2^12 values */
+		if (win.kbits > 30u)
+			return 1;
+		const uint32_t kbits = win.kbits, shift = 32u - kbits;
+		const int b1 = 9, b2 = (int)kbits - 9 - (int)PL_MAX_REM;
+		const uint32_t rem = kbits - (uint32_t)(b1 + b2);
+		if (b2 < 1 || b2 > MDB_MAX_RADIX_BITS || n_l >= 0xF0000000ull || n_r >= 0xF0000000ull)
+			return 1;
+		rc = mdb_arena_begin(ctx, mdb_partition_arena_bytes(n_l, b1, b2, false, true) + mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay) + 8192);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+		mdb_part_filter rflt;
+		memset(&rflt, 0, sizeof(rflt));
+		rflt.npay = npay;
+		for (int c = 0; c < npay; c++)
+			rflt.pay_in[c] = pay_in[c];
+		mdb_part_result pl, pr;
+		memset(&pl, 0, sizeof(pl));
+		memset(&pr, 0, sizeof(pr));
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
+		if (rc)
+			return rc;
+		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, false, false, true, &pl, 1, false, win.lo, kbits, NULL);
+		if (rc)
+			return rc;
+		if (!pl.leaf_cap || !pr.leaf_cap || !pl.leaf_cnt || !pr.leaf_cnt || pl.nleaves != pr.nleaves || pl.w32 || pr.w32 || !pr.pay[0] ||
+		    (npay > 1 && !pr.pay[1]))
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: the tables are not in the two-level fixed-capacity layout");
+		pl_args a;
+		memset(&a, 0, sizeof(a));
+		a.hv_l = pl.hv;
+		a.hv_r = pr.hv;
+		a.npay = (uint32_t)npay;
+		for (int c = 0; c < npay; c++) {
+			a.pay_r[c] = pr.pay[c];
+			a.out[c] = reinterpret_cast<uint64_t *>(out[c]);
+		}
+		a.cnt_l = pl.leaf_cnt;
+		a.cnt_r = pr.leaf_cnt;
+		a.cap_l = pl.leaf_cap;
+		a.cap_r = pr.leaf_cap;
+		a.nleaves = pl.nleaves;
+		a.joined = (unsigned long long *)(ctx->d_status + 2);
+		a.status = ctx->d_status;
+		const uint32_t grid = pl.nleaves < 8u * (uint32_t)ctx->num_cus ? pl.nleaves : 8u * (uint32_t)ctx->num_cus;
+		if (npay > 1) {
+			MDB_LAUNCH(ctx, "leaf_pairs_payload", k_leaf_pairs_cell2<2>, grid, PL_THREADS, a, rem, shift);
+		} else {
+			MDB_LAUNCH(ctx, "leaf_pairs_payload", k_leaf_pairs_cell2<1>, grid, PL_THREADS, a, rem, shift);
+		}
+		uint64_t *h = ctx->h_pinned;
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t status = (uint32_t)h[1];
+		const uint64_t J = h[2];
+		if (getenv("MDB_DEBUG_PAYLOAD"))
+			fprintf(stderr, "join_payload (two levels): k %u b2 %d rem %u status %u J %llu of %llu left rows\n", kbits, b2, rem, status, (unsigned long long)J,
+				(unsigned long long)n_l);
+		if (status == 0 && J == n_l)
+			return MIDORIDB_OK;
+		if ((status & 128u) && remembered && attempt == 0) {
+			ctx->nh_result = -1;
+			ctx->sr_valid = 0;
+			ctx->nh_distrust = 1;
+			continue;
+		}
+		if (status & 128u) {
+			ctx->nh_distrust = 8;
+		} else if (!(status & 2u)) {	/* (a region overflow says nothing about the join) */
+			ctx->jp_bad_l = keys_l;
+			ctx->jp_bad_nl = n_l;
+			ctx->jp_bad_r = keys_r;
+			ctx->jp_bad_nr = n_r;
+			ctx->jp_bad_skips = 0;
+		}
+		return 1;
+	}
 	const int b1 = 9;
 	/* (a dimension table of a few thousand keys: the window may be wider than its keys need) */
 	const uint32_t kbits = win.kbits < 9u + PW_MIN_REM ? 9u + PW_MIN_REM : win.kbits, rem = kbits - (uint32_t)b1, shift = 32u - kbits;

@@ -454,6 +454,7 @@ struct pf_key_w32 : pf_base { static constexpr bool LEVEL0 = true; static conste
 struct pf_key_w32_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool CF = true; };
 struct pf_key_w32_out16 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; };
 struct pf_key_w32_out16_cf : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool W32 = true; static constexpr bool OUT16 = true; static constexpr bool CF = true; };
+struct pf_word_pay : pf_base { static constexpr bool FAST = true; static constexpr bool PAY = true; };	/* second level of a join that carries payload cells */
 struct pf_key_cf_pay : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool CF = true; static constexpr bool PAY = true; };
 struct pf_key_rid_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; };
 struct pf_key_rid_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool INV = true; };
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 {
 	constexpr bool LEVEL0 = F::LEVEL0, HAS_RID = F::HAS_RID, STABLE = F::STABLE, FAST = F::FAST, RAW = F::RAW, W32 = F::W32, INV = F::INV, FILT = F::FILT,
 		       OUT16 = F::OUT16, CF = F::CF, R64 = F::R64, MM64 = F::MM64, PAY = F::PAY;
-	static_assert(!PAY || (LEVEL0 && FAST && CF && !W32), "payload cells travel with the first level of the compact narrow form (8-byte words)");
+	static_assert(!PAY || (FAST && !W32 && !HAS_RID && !RAW && !INV && !FILT && (CF || !LEVEL0)),
+		      "payload cells travel with the compact narrow form's 8-byte hash | row id words: its first level, or a second level over them");
 	static_assert(!(R64 || MM64) || (LEVEL0 && FAST && !RAW && !INV && !W32 && !CF && !STABLE), "64-bit key range: first level of the 64-bit form only");
 	static_assert(!CF || (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && !STABLE), "compact-form instance: first level of the narrow join forms only");
 	static_assert(!OUT16 || (W32 && !RAW), "2-byte words out: the 4-byte form only");
@@ -874,10 +876,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		 * index (consecutive threads, consecutive pairs of rows), staged at the row's rank, written beside its word */
 		uint64_t *const s_pay = reinterpret_cast<uint64_t *>(s_hv);
 		for (uint32_t c = 0; c < a.npay; c++) {	/* (uniform) */
+			/* (element r of this thread = pair r / 2 of the tile, relative to its even-aligned base - part_load2's addressing) */
+			const uint64_t base2 = (uint64_t)td.start - (td.start & 1u);
 			uint64_t pv[PART_ITEMS];
 #pragma unroll
 			for (int r = 0; r < PART_ITEMS; r++)
-				pv[r] = dig[r] != PART_INVALID ? a.pay_in[c][rid[r]] : 0ull;
+				pv[r] = dig[r] != PART_INVALID ? a.pay_in[c][base2 + 2u * ((uint32_t)(r >> 1) * PART_THREADS + threadIdx.x) + (uint32_t)(r & 1)] : 0ull;
 			__syncthreads();	/* every word of the previous round has been read */
 #pragma unroll
 			for (int r = 0; r < PART_ITEMS; r++)
@@ -1210,10 +1214,14 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		if (want_rid)
 			rid_buf[l] = (l == nlevels - 1 && final_rid_out) ? final_rid_out : (uint32_t *)cv.take(elems * 4);
 	}
-	uint64_t *pay_buf[2] = { NULL, NULL };
-	const int npay = (flt && stop0 && fast0 && !w32) ? flt->npay : 0;
-	for (int c = 0; c < npay && c < 2; c++)
+	/* payload cells beside the words (mdb_part_filter.npay): one buffer per level, laid out like that level's words */
+	uint64_t *pay_buf[2] = { NULL, NULL }, *pay_buf1[2] = { NULL, NULL };
+	const int npay = (flt && fast0 && !w32 && (stop0 || (fast && nlevels == 2))) ? flt->npay : 0;
+	for (int c = 0; c < npay && c < 2; c++) {
 		pay_buf[c] = (uint64_t *)cv.take((uint64_t)nreg0_used * cap0 * 8);
+		if (!stop0)
+			pay_buf1[c] = (uint64_t *)cv.take((uint64_t)nleaves_total * fast_cap * 8);
+	}
 
 	/* segments of the current level */
 	uint32_t S = 1;
@@ -1399,7 +1407,14 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.cap = fast_cap;
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(leaf_cnt, 0, (size_t)nchild * 4, ctx->stream));
-				if (want_rid) {
+				if (npay) {
+					a.npay = (uint32_t)npay;
+					for (int c = 0; c < npay; c++) {
+						a.pay_in[c] = pay_buf[c];
+						a.pay_out[c] = pay_buf1[c];
+					}
+					MDB_LAUNCH(ctx, "part_scatter_l1_pay", (k_part_scatter<pf_word_pay>), grid8(ntiles), PART_THREADS, a);
+				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l1_rid", (k_part_scatter<pf_word_rid>), grid8(ntiles),
 						   PART_THREADS, a);
 				} else if (raw_hv && fold32) {
@@ -1499,15 +1514,21 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		out->w32 = w32;
 		out->w16 = false;
 		out->nsub = 0;
+		out->pay[0] = nlevels == 2 ? pay_buf1[0] : NULL;
+		out->pay[1] = nlevels == 2 ? pay_buf1[1] : NULL;
 	}
 	return MIDORIDB_OK;
 }
 
-size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast)
+size_t mdb_partition_arena_bytes(uint64_t n, int bits1, int bits2, bool want_rid, bool fast, int npay)
 {
 	part_carver cv = { NULL, true, 0, false };
-	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL);
-	return cv.bytes + 4096;
+	mdb_part_filter flt;
+	memset(&flt, 0, sizeof(flt));
+	flt.npay = npay;
+	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, want_rid, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL, NULL, 0, NULL, NULL, 0, false,
+			     0, 0u, npay ? &flt : NULL);
+	return cv.bytes + 4096 + (size_t)npay * 1024;
 }
 
 size_t mdb_partition_level0_arena_bytes(uint64_t n, int bits1, bool loose, int npay)
@@ -1548,6 +1569,8 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 	if (flt && (flt->minmax64_out || flt->range64_in) && (narrow || stable || !fast || bits2 <= 0 || (flt->minmax64_out && (want_rid || !flt->minmax64_tiles)) ||
 							      (flt->range64_in && !want_rid)))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "min-max pruning, 64-bit form: two fast levels, the right table without and the left with row ids");
+	if (flt && flt->npay && (narrow != 1 || !narrow_kbits || want_rid || stable || !fast || flt->npay < 0 || flt->npay > 2 || (bits2 <= 0 && !stop0)))
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "payload cells: compact narrow form with hash | row id words, histogram-free layout, at most two columns");
 	if (narrow_kbits && (!narrow || narrow_kbits < 8 || narrow_kbits > 32 || (uint32_t)(bits1 + bits2) > narrow_kbits))
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "compact narrow form: bad window width");
 	if (narrow && (stable || want_rid))

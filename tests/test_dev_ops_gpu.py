@@ -775,7 +775,8 @@ def test_join_keys_is_the_key_column_of_join_pairs_as_a_multiset(dev, case):
 
 
 @pytest.mark.parametrize("case", ["pk_pk_two_cells", "fk_to_pk_one_cell", "window_far_from_zero", "left_row_without_partner", "null_left_key",
-                                  "duplicate_right_key", "keys_beyond_a_window", "small"])
+                                  "duplicate_right_key", "keys_beyond_a_window", "small", "window_2e27_two_levels", "window_2e29_two_cells",
+                                  "window_2e27_duplicate_right_key"])
 def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case):
     """mdb_dev_join_payload (BASELINE configs[1]: a primary-key join with payload): when every left row has exactly one partner the
     outputs are the partners' payload cells in left-row order (INT64 and DOUBLE bits alike) - equal to payload[pos_r] over the oracle's
@@ -802,6 +803,16 @@ def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case
         kr = rng.permutation(200_000).astype(np.int64) + 1000
         kl = kr[rng.integers(0, len(kr), 3_000_000)]
         pay = [rng.integers(0, 10**9, len(kr), dtype=np.int64)]
+    elif case in ("window_2e27_two_levels", "window_2e29_two_cells", "window_2e27_duplicate_right_key"):
+        # sparse unique keys over 2^27 / 2^29 values: two partition levels, the cells travel through both
+        span = 1 << (29 if "2e29" in case else 27)
+        kr = np.unique(rng.integers(0, span, 2_200_000, dtype=np.int64)) - 12345
+        kl = kr[rng.integers(0, len(kr), 2_500_000)]		# a foreign key: duplicates on the left
+        pay = [rng.integers(-2**62, 2**62, len(kr), dtype=np.int64)] + ([rng.standard_normal(len(kr))] if "two_cells" in case else [])
+        if "duplicate" in case:
+            kr = kr.copy()
+            kr[100] = kr[101]
+            served = False
     elif case == "keys_beyond_a_window":
         kr = np.unique(rng.integers(-2**62, 2**62, n, dtype=np.int64))
         kl = rng.permutation(kr)
