@@ -188,6 +188,11 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *plan, const void *con
 		   int64_t *out_count, uint64_t cap, void *const *arrived = NULL /* [ntab] hipEvent_t or NULL: table x's blocks and counters
 		   have arrived when arrived[x] has happened - the context's stream waits for it right before the first kernel that reads
 		   table x, so the receiver's level over one table runs while the next table is still on the wire */);
+/* one 4096-digit pass over a key column of the compact narrow form (mdb_dev_shard.hip): 2-byte words, or 4-byte row words with run headers */
+uint32_t mdb_scatter4096_cap(const mdb_dev_ctx *ctx, uint64_t n, bool row_words);
+size_t mdb_scatter4096_arena_bytes(const mdb_dev_ctx *ctx, uint64_t n, bool row_words);
+int mdb_scatter4096(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nulls, uint64_t n, int64_t key_lo, uint32_t kbits, bool report, uint32_t rel_hi,
+		    uint32_t cap, bool row_words, const char *name, void **regions, uint32_t **cursors);
 
 /* ---- ordering of (row id, payload) records (mdb_dev_join.hip) ----------------------------------
  * rec[i] = (row id << (64 - kbits)) | payload (payload >= 1; zero words are gaps), kbits = bits of a row id as

@@ -1188,6 +1188,322 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 	}
 }
 
+/* ------------------------------------------------------------------ the same over the digits of ONE 4096-digit pass (round 4)
+ *
+ * Key windows of 2^24 ... 2^27 values (10^8 unique keys per table: the benchmark's variants U and S) took two 9-bit levels and
+ * k_leaf_direct: the left table's 8-byte words written and read twice.  Here both tables go through ONE 4096-digit pass
+ * (mdb_dev_shard.hip: k_shard_scatter_wide - 2-byte words for the right table, 4-byte ROW words for the left one: the row's place
+ * in its tile | hash bits, one header per run naming the tile) and one workgroup joins a digit of up to 2^15 values from ONE table
+ * of 4 bytes per value - right rows (5 bits) above the first left row (27 bits: min over the left rows, the count bits are final by
+ * then) - plus 4 bits of left rows per value: 144 KiB of LDS.  More than 31 right or 15 left rows of one key are noticed (the sums of
+ * the fields fall short of the rows counted) and reported - flag 1024: two levels and their hot-key path take over.
+ *   A digit's words (at most 4 chunks of eight right words and 8 chunks of four left words per thread: the regions' capacity is
+ * checked by the caller) are loaded once, all loads in flight together - and, the kernel being one 1024-thread workgroup per CU that
+ * nothing else overlaps with, the NEXT digit's words are requested as soon as the current ones are counted, while its groups are
+ * emitted (persistent grid; ablations at 10^8 x 10^8 unique keys: loads + clears alone 0.235 ms of a 0.85 ms two-pass version).
+ *   A left word's row id needs the last header before it, which may lie in another lane's or another wave's words: a ballot inside
+ * the wave, one LDS word per wave and one barrier per 4096 words across them (a region begins with a header: nothing is carried from
+ * one region into the next by mistake).  Records and flags are k_leaf_wide's; the groups leave by wave-level append (coalesced). */
+/* a barrier that waits for the wave's LDS operations only: the next digit's global loads stay in flight across it (__syncthreads() waits
+ * for every outstanding memory operation) */
+__device__ static inline void lw12_barrier(void)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#define LW12_RB 4	/* 16-byte chunks per thread: right (8 words each) ... */
+#define LW12_LB 8	/* ... and left (4 words each) */
+#define LW12_NSUB 8	/* sub-regions per digit (SH_NSUB of mdb_dev_shard.hip) */
+#define LW12_MAX_CR 31u
+#define LW12_MAX_CL 15u
+
+__global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t rem /* hash bits below the digit */, uint32_t nsub)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
+	__shared__ unsigned long long s_red[LW_THREADS / 64];
+	__shared__ uint32_t s_red32[LW_THREADS / 64];
+	__shared__ uint32_t s_base;
+	/* [buffer][side][sub-region]: first 16-byte chunk (prefix) and words of a digit's sub-regions, side 0 left (4 words per chunk), 1 right (8) */
+	__shared__ uint32_t s_chunk0[2][2][17], s_cnt[2][2][16];		/* (nsub <= 16) */
+	__shared__ uint32_t s_wlast[2][LW_THREADS / 64], s_carry[2];
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint32_t T = 1u << rem, mask = T - 1u;
+	uint32_t *const s_fc = lw_lds;			/* right rows << 27 | first left row */
+	uint32_t *const s_cl = lw_lds + T;		/* left rows per key (only of keys that have right rows), 4 bits each */
+	uint32_t leaf = blockIdx.x, buf = 0;
+	if (leaf >= a.nleaves || nsub != LW12_NSUB)
+		return;
+	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 31: (side, sub-region) */
+		const uint32_t side = threadIdx.x >> 4, j = threadIdx.x & 15u;
+		if (threadIdx.x >= 32u || j >= nsub)
+			return 0u;
+		const uint32_t c0 = (side ? a.cnt_r : a.cnt_l)[j * a.nleaves + d], cap = side ? a.cap_r : a.cap_l;
+		return c0 < cap ? c0 : cap;
+	};
+	auto seg_prefix = [&](uint32_t b) {		/* threads 0, 1 */
+		uint32_t run = 0;
+		for (uint32_t j = 0; j < nsub; j++) {
+			s_chunk0[b][threadIdx.x][j] = run;
+			run += threadIdx.x ? (s_cnt[b][1][j] + 7u) >> 3 : (s_cnt[b][0][j] + 3u) >> 2;
+		}
+		s_chunk0[b][threadIdx.x][nsub] = run;
+	};
+	uint4 vr[LW12_RB], vl[LW12_LB];
+	uint32_t nvr = 0, nvl = 0;	/* words of each chunk, 4 bits each */
+	/* chunk q of a side: the sub-regions' first chunks are the same for every thread - read once, kept in scalar registers (as a loop
+	 * over LDS per chunk, 12 chunks per thread and digit, this search was a third of the kernel) */
+	auto fetch_all = [&](uint32_t d, uint32_t b) {
+		nvr = nvl = 0u;
+#pragma unroll
+		for (int side = 1; side >= 0; side--) {
+			uint32_t c0[LW12_NSUB + 1];
+#pragma unroll
+			for (int j = 0; j <= LW12_NSUB; j++)
+				c0[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk0[b][side][j]);
+			const uint32_t per = side ? 8u : 4u;
+#pragma unroll
+			for (int u = 0; u < (side ? LW12_RB : LW12_LB); u++) {
+				const uint32_t q = (uint32_t)u * LW_THREADS + threadIdx.x;
+				uint4 v = make_uint4(0u, 0u, 0u, 0u);
+				uint32_t nv = 0u;
+				if (q < c0[LW12_NSUB]) {
+					uint32_t sg = 0, first = 0;	/* the last sub-region whose first chunk is <= q */
+#pragma unroll
+					for (int j = 1; j < LW12_NSUB; j++) {
+						sg += c0[j] <= q ? 1u : 0u;
+						first = c0[j] <= q ? c0[j] : first;
+					}
+					const uint32_t off = (q - first) * per, c = s_cnt[b][side][sg];
+					nv = c - off < per ? c - off : per;
+					if (side)
+						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_r) + (size_t)(d * LW12_NSUB + sg) * a.cap_r + off);
+					else
+						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_l) + (size_t)(d * LW12_NSUB + sg) * a.cap_l + off);
+				}
+				if (side) {
+					vr[u < LW12_RB ? u : 0] = v;
+					nvr |= nv << (4 * u);
+				} else {
+					vl[u] = v;
+					nvl |= nv << (4 * u);
+				}
+			}
+		}
+	};
+	{
+		const uint32_t c = seg_count(leaf);
+		if (threadIdx.x < 32u)
+			s_cnt[0][threadIdx.x >> 4][threadIdx.x & 15u] = c;
+		if (threadIdx.x == 0)
+			s_carry[0] = 0u;
+		__syncthreads();
+		if (threadIdx.x < 2u)
+			seg_prefix(0);
+		__syncthreads();
+		fetch_all(leaf, 0);
+	}
+	unsigned long long joined = 0;
+	uint32_t last_first = 0;	/* largest first row id of this workgroup's groups */
+	uint32_t it = 0;
+	bool bad = false;		/* (uniform) a digit whose words do not fit the registers, or whose counts overflowed */
+	for (; leaf < a.nleaves; leaf += gridDim.x, buf ^= 1u) {
+		const uint32_t next = leaf + gridDim.x;
+		const uint32_t nch_l = s_chunk0[buf][0][nsub], nch_r = s_chunk0[buf][1][nsub];
+		if (nch_l > LW12_LB * LW_THREADS || nch_r > LW12_RB * LW_THREADS) {	/* (the caller sized the regions so that this cannot happen) */
+			bad = true;
+			break;
+		}
+		const uint32_t next_c = next < a.nleaves ? seg_count(next) : 0u;	/* (on its way while this digit is counted) */
+		for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
+			s_fc[s] = 0x07FFFFFFu;
+		for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
+			s_cl[s] = 0u;
+		__syncthreads();
+		uint32_t adds = 0, radds = 0;
+#pragma unroll
+		for (int u = 0; u < LW12_RB; u++) {
+			const uint32_t w[4] = { vr[u].x, vr[u].y, vr[u].z, vr[u].w }, nv = (nvr >> (4 * u)) & 15u;
+#pragma unroll
+			for (uint32_t k = 0; k < 8u; k++) {
+				if (k >= nv)
+					continue;
+				atomicAdd(&s_fc[(w[k >> 1] >> (16u * (k & 1u))) & mask], 1u << 27);
+				radds++;
+			}
+		}
+		if (threadIdx.x < 32u)
+			s_cnt[buf ^ 1u][threadIdx.x >> 4][threadIdx.x & 15u] = next_c;
+		__syncthreads();
+		if (threadIdx.x < 2u)
+			seg_prefix(buf ^ 1u);
+#pragma unroll
+		for (int u = 0; u < LW12_LB; u++) {
+			if ((uint32_t)u * LW_THREADS >= nch_l)	/* (uniform) */
+				continue;
+			const uint32_t w[4] = { vl[u].x, vl[u].y, vl[u].z, vl[u].w }, nv = (nvl >> (4 * u)) & 15u;
+			/* the last header among this thread's words, the nearest earlier lane's, the nearest earlier wave's of this round, else what the
+			 * previous round left */
+			uint32_t my_last = 0u;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; k++)
+				if (k < nv && (w[k] >> 31))
+					my_last = w[k];
+			const uint64_t bal = __ballot(my_last != 0u), before = bal & mdb_lanemask_lt();
+			uint32_t cur = (uint32_t)__shfl((int)my_last, before ? 63 - __clzll((long long)before) : 0, MDB_WAVE);
+			const uint32_t p = it & 1u;
+			const uint32_t wave_last = (uint32_t)__shfl((int)my_last, bal ? 63 - __clzll((long long)bal) : 0, MDB_WAVE);
+			if (lane == 0)
+				s_wlast[p][wave] = bal ? wave_last : 0u;
+			__syncthreads();
+			{
+				const uint32_t x = lane < LW_THREADS / 64 ? s_wlast[p][lane] : 0u;
+				const uint64_t ball = __ballot(x != 0u), earlier = ball & ((1ull << wave) - 1ull);
+				const uint32_t carried = s_carry[p];
+				const uint32_t from_waves = (uint32_t)__shfl((int)x, earlier ? 63 - __clzll((long long)earlier) : 0, MDB_WAVE);
+				const uint32_t round_last = (uint32_t)__shfl((int)x, ball ? 63 - __clzll((long long)ball) : 0, MDB_WAVE);
+				if (!before)
+					cur = earlier ? from_waves : carried;
+				if (threadIdx.x == 0)
+					s_carry[p ^ 1u] = ball ? round_last : carried;
+			}
+			it++;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; k++) {
+				if (k >= nv)
+					continue;
+				if (w[k] >> 31) {
+					cur = w[k];
+					continue;
+				}
+				const uint32_t idx = w[k] & mask, fc = s_fc[idx];
+				if (fc >> 27) {		/* (the right rows are all counted: the top bits are final, the minimum is over the row id) */
+					atomicMin(&s_fc[idx], (fc & 0xF8000000u) | (((cur & 0x7FFFFFFFu) << 1) + ((w[k] >> 15) & 0x7FFFu)));
+					atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
+					adds++;
+				}
+			}
+		}
+		__syncthreads();
+
+		/* groups of the digit: the non-zero left counts.  Wave w owns the values [w * T / 16, (w + 1) * T / 16): their groups leave side by side */
+		const uint32_t per_wave = T / (LW_THREADS / 64);
+		uint32_t mine = 0;
+		for (uint32_t s = lane; s < per_wave / 8; s += MDB_WAVE) {
+			const uint32_t c8 = s_cl[wave * (per_wave / 8) + s];
+			mine += (uint32_t)__popc((c8 | (c8 >> 1) | (c8 >> 2) | (c8 >> 3)) & 0x11111111u);
+		}
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			mine += (uint32_t)__shfl_down((int)mine, o, MDB_WAVE);
+		if (lane == 0)
+			s_red32[wave] = mine;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t total = 0;
+#pragma unroll
+			for (int w = 0; w < LW_THREADS / 64; w++)
+				total += s_red32[w];
+			uint32_t nb = 0xFFFFFFFFu;
+			if (total) {
+				nb = atomicAdd(a.rec_count, total);
+				if (nb + total > a.rec_cap) {
+					mdb_raise(a.status, 8u);
+					nb = 0xFFFFFFFFu;
+				} else {
+					atomicAdd(a.rec_valid, total);
+				}
+			}
+			s_base = nb;
+		}
+		/* the registers are free: the next digit's words, in flight while this one's groups are written */
+		if (next < a.nleaves)
+			fetch_all(next, buf ^ 1u);
+		lw12_barrier();
+		const uint32_t base = s_base;
+		uint32_t run = 0;	/* groups of the waves before this one, then of this wave so far (uniform) */
+		{
+			const uint32_t x = lane < wave ? s_red32[lane] : 0u;	/* (at most 16 waves) */
+			uint32_t t = x;
+#pragma unroll
+			for (int o = 32; o; o >>= 1)
+				t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
+			run = t;
+		}
+		unsigned long long sums = 0;	/* low half: right rows counted, high half: left rows counted */
+		for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {
+			const uint32_t s = wave * per_wave + s0 + lane;
+			const uint32_t fc = s_fc[s], cl = (s_cl[s >> 3] >> ((s & 7u) * 4u)) & 15u, cr = fc >> 27;
+			sums += ((unsigned long long)cl << 32) | cr;
+			const uint64_t m = __ballot(cl != 0u);
+			if (!m || base == 0xFFFFFFFFu)
+				continue;
+			const uint32_t wbase = run;
+			run += (uint32_t)__popcll(m);
+			if (cl) {
+				const uint32_t pos = base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
+				const uint32_t first = fc & 0x07FFFFFFu;
+				const unsigned long long c = (unsigned long long)cl * cr;
+				joined += c;
+				last_first = first > last_first ? first : last_first;
+				if (a.keyed_cbits) {
+					if (c >> a.keyed_cbits)
+						mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
+					a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | ((unsigned long long)((leaf << rem) | s) << a.keyed_cbits) | c;
+				} else {
+					if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
+						mdb_raise(a.status, 16u);	/* COUNT(*) does not fit a 4-byte record */
+					if (a.rec32) {		/* (4-byte records on a remembered verdict, like k_leaf_direct) */
+						if (c >> (32 - a.kbits))
+							mdb_raise(a.status, 512u);
+						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | (uint32_t)c;
+					} else
+						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
+				}
+			}
+		}
+		/* a count field that overflowed carried into its neighbour (or out of the word): the fields then sum to less than was added */
+		const unsigned long long want = ((unsigned long long)adds << 32) | radds;
+		unsigned long long diff = sums - want;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			diff += __shfl_down(diff, o, MDB_WAVE);
+		lw12_barrier();	/* (s_red is free; every wave has read its part of the tables: they may be cleared) */
+		if (lane == 0)
+			s_red[wave] = diff;
+		lw12_barrier();
+		diff = 0ull;
+#pragma unroll
+		for (int w = 0; w < LW_THREADS / 64; w++)
+			diff += s_red[w];
+		if (diff != 0ull) {
+			bad = true;
+			break;
+		}
+	}
+	if (bad && threadIdx.x == 0)
+		mdb_raise(a.status, 1024u);
+	joined = lw_block_sum(joined, s_red);
+	if (threadIdx.x == 0 && joined)
+		atomicAdd(a.joined, joined);
+#pragma unroll
+	for (int o = 32; o; o >>= 1) {
+		const uint32_t other = (uint32_t)__shfl_xor((int)last_first, o, MDB_WAVE);
+		last_first = other > last_first ? other : last_first;
+	}
+	__syncthreads();	/* (s_red is free again) */
+	if (lane == 0)
+		s_red[wave] = last_first;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t m = 0;
+#pragma unroll
+		for (int w = 0; w < LW_THREADS / 64; w++)
+			m = (uint32_t)s_red[w] > m ? (uint32_t)s_red[w] : m;
+		if (m)
+			atomicMax(a.status + 9, m);
+	}
+}
+
 /* ------------------------------------------------------------------ semi-join filter (compact narrow form)
  *
  * Bitmap of the hashed key values the RIGHT table holds, one bit per 2^coarse adjacent values, built from its
@@ -1509,6 +1825,7 @@ struct gc_state {
 	bool direct;		/* ... taken: the leaves are joined by k_leaf_direct (decided in gc_begin, where the leaf count is known) */
 	bool fast1;		/* gc_window.fast1 */
 	bool one_level;		/* ... by k_leaf_wide: ONE partition level of 9 bits, tables of 2^(key_bits - 9) entries */
+	bool wide12;		/* ... by k_leaf_wide over the digits of ONE 4096-digit pass per table (mdb_scatter4096): key windows of 2^24 ... 2^27 values */
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
 	bool prunable;		/* the right table's keys cover less than 7/8 of the left table's range (sample) */
@@ -1551,6 +1868,23 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
 	if (st->nextra)
 		st->one_level = false;	/* (further right tables: the two-level direct-address kernel counts them) */
+	/* key windows of 2^24 ... 2^27 values (10^8 unique keys: variants U and S): what two 9-bit levels and k_leaf_direct did - the left
+	 * table's 8-byte words written and read twice - is ONE 4096-digit pass per table (2-byte words for the right table, 4-byte row words
+	 * for the left one) and k_leaf_wide over digits of up to 2^15 values, two workgroups per digit.  Unsplit calls of a two-table join
+	 * over int64 columns; tables large enough for 8192 workgroups that clear 128 KiB of LDS each to pay (MDB_WIDE12_MIN=<rows>,
+	 * MDB_WIDE12=0 switches it off) */
+	{
+		const char *e = getenv("MDB_WIDE12"), *e2 = getenv("MDB_WIDE12_MIN");
+		const uint64_t min_rows = e2 && atoll(e2) > 0 ? (uint64_t)atoll(e2) : (1ull << 26);
+		st->wide12 = !st->one_level && st->narrow && st->has_r && st->key_bits > 9u + LW_MAX_REM && st->key_bits <= 12u + LW_MAX_REM + 1u && st->fast &&
+			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && !st->nextra && !st->keys32 &&
+			     !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
+			     st->n_l + st->n_r_cap >= min_rows && st->n_l < 0xF0000000ull && st->n_r_cap < 0xF0000000ull && !(e && e[0] == '0');
+	}
+	if (st->wide12) {
+		st->b1 = 12;
+		st->b2 = 0;
+	}
 	if (st->one_level) {
 		st->b1 = st->key_bits <= 15u ? 8 : 9;	/* (a 2^15-value window: 256 regions of 128 values - see gc_window.fast1) */
 		st->b2 = 0;
@@ -1558,18 +1892,18 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		st->fast = false;	/* (two fast levels: leaves of one or two values with thousands of rows each - regions would overflow) */
 	}
 	/* the narrow form of a join needs the right side's 4-byte layout (two fast levels); plain GROUP BY has no such limit */
-	if (!st->one_level && st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
+	if (!st->one_level && !st->wide12 && st->narrow && st->has_r && !mdb_partition_w32_applies(st->n_r_cap, st->b1, st->b2, st->fast))
 		st->narrow = false;
 	/* compact narrow form + direct-address leaves: what the partition leaves of the key_bits-wide hash must index a table
 	 * of at most 2^LD_MAX_REM entries; fewer than 2^4 would mean leaves of a handful of keys with thousands of rows each
 	 * (same-address LDS atomics: the hashed kernel's wave-level merging handles those better) */
 	st->direct = st->narrow && st->key_bits && st->fast && st->b2 > 0 && st->want_records && !ld_disabled() &&
 		     st->key_bits >= (uint32_t)(st->b1 + st->b2) + 4u && st->key_bits <= (uint32_t)(st->b1 + st->b2) + LD_MAX_REM;
-	if (st->one_level)
+	if (st->one_level || st->wide12)
 		st->direct = true;
 	if (st->nextra && !(st->direct && st->has_r && st->fast))
 		return GC_NOT_SERVED;
-	if (st->direct && !st->one_level) {
+	if (st->direct && !st->one_level && !st->wide12) {
 		/* the direct-address kernel has no table to overflow and pays a fixed price per leaf (three barriers, the emit scan):
 		 * it prefers FEWER, larger leaves than the hashed kernel's 3833-slot table allows - tables of 2^LD_MAX_REM entries when
 		 * the second level has the bits to give (10^8 x 10^8 rows: 2^15 leaves of 2 x 3052 rows instead of 2^16; second-level
@@ -1622,7 +1956,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		if (!(e && e[0] == '0') && coarse <= 3u && rem >= coarse + 5u && below0 - coarse >= 7u)
 			st->semijoin = coarse + 1u;
 	}
-	size_t need = st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1, st->fast1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
+	size_t need = st->wide12 ? mdb_scatter4096_arena_bytes(ctx, st->n_l, true)
+		      : st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1, st->fast1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->semijoin)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
 	if (st->defer_l)
@@ -1630,7 +1965,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	if (st->defer_l64)
 		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 8) + 256;
 	if (st->has_r)
-		need += st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
+		need += st->wide12 ? mdb_scatter4096_arena_bytes(ctx, st->n_r_cap, false)
+		      : st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
 				      : mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	for (int x = 0; x < st->nextra; x++)
 		need += mdb_partition_arena_bytes(st->xn[x], st->b1, st->b2, false, st->fast) + 512;
@@ -1654,7 +1990,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
 	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
-	if (!st->defer_l && !st->defer_l64) {
+	if (!st->defer_l && !st->defer_l64 && !st->wide12) {
 		mdb_part_filter lflt;
 		memset(&lflt, 0, sizeof(lflt));
 		lflt.level0_only = st->one_level;
@@ -1685,7 +2021,35 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 
 	st->active = false;
 	memset(&pr, 0, sizeof(pr));
-	if (has_r) {
+	if (st->wide12) {
+		/* both tables through one 4096-digit pass each; a key outside the window is reported (the left table's, when the window was
+		 * taken from the right table's keys alone, is dropped: it has no partner) */
+		if (n_r > st->n_r_cap)
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
+		void *rb = NULL, *lb = NULL;
+		uint32_t *rcur = NULL, *lcur = NULL;
+		const uint32_t cap_r = mdb_scatter4096_cap(ctx, n_r, false), cap_l = mdb_scatter4096_cap(ctx, n_l, true);
+		rc = mdb_scatter4096(ctx, keys_r, null_r, n_r, st->key_lo, st->key_bits, true, 0u, cap_r, false, "part_scatter_wide12_r", &rb, &rcur);
+		if (rc)
+			return rc;
+		rc = mdb_scatter4096(ctx, keys_l, null_l, n_l, st->key_lo, st->key_bits, !st->r_based, (uint32_t)((1ull << st->key_bits) - 1ull), cap_l, true,
+				     "part_scatter_wide12_l", &lb, &lcur);
+		if (rc)
+			return rc;
+		memset(&pl, 0, sizeof(pl));
+		pl.hv = (uint64_t *)lb;
+		pl.leaf_cnt = lcur;
+		pl.leaf_cap = cap_l;
+		pr.hv = (uint64_t *)rb;
+		pr.leaf_cnt = rcur;
+		pr.leaf_cap = cap_r;
+		pl.nleaves = pr.nleaves = 4096u;
+		pl.bits_total = pr.bits_total = 12u;
+		pl.nsub = pr.nsub = 8u;
+		pl.w32 = pr.w32 = true;
+		pr.w16 = true;
+	}
+	if (has_r && !st->wide12) {
 		if (n_r > st->n_r_cap)
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
 		if (st->narrow && !st->one_level && !mdb_partition_w32_applies(n_r, st->b1, st->b2, st->fast))
@@ -1865,7 +2229,14 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		const uint32_t grid = pl.nleaves < resident ? pl.nleaves : resident;
 		/* (the direct kernel addresses leaf i at i * cap: should a table have fallen back to exact offsets - more than 2^32
 		 * region words - the hashed kernel below joins the compact words just as well, they are injective too) */
-		if (st->one_level) {
+		if (st->wide12) {
+			/* one 1024-thread workgroup per CU walks the digits (the next digit's words are loaded while the current one's groups leave) */
+			const uint32_t rem = st->key_bits - 12u;
+			const size_t lds = ((size_t)4 << rem) + ((size_t)1 << rem) / 2;
+			const uint32_t wgrid = pl.nleaves < (uint32_t)ctx->num_cus ? pl.nleaves : (uint32_t)ctx->num_cus;
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12, wgrid, LW_THREADS, lds, a, rem, pl.nsub);
+		} else if (st->one_level) {
 			/* ... by ALL the hash bits below the first level's 9 (k_leaf_wide) */
 			if (!pl.nsub || !pl.leaf_cap || (has_r && (!pr.nsub || !pr.w32 || pr.nsub != pl.nsub || pr.nleaves != pl.nleaves)))
 				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level direct leaves: the tables are not in the first-level layout");
@@ -2067,7 +2438,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		ctx->lg_valid = true;
 	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
-	ctx->last_semijoin = (int)st->semijoin | ((st->defer_l || st->defer_l64) ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0);
+	ctx->last_semijoin = (int)st->semijoin | ((st->defer_l || st->defer_l64) ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0) |
+			     (st->wide12 ? 0x1000 : 0);
 	return MIDORIDB_OK;
 }
 

@@ -168,7 +168,7 @@ struct shw_scatter_args {
 	uint32_t kbits, rem;	/* rem = kbits - 12 <= 15 */
 	uint32_t report;	/* 1 (the right table): a key outside the window raises flag 128; 0: rows with key - key_lo > rel_hi are dropped */
 	uint32_t rel_hi;
-	uint16_t *out;
+	void *out;		/* 2-byte words, or 4-byte row words (ROWS) */
 	uint32_t *cursor;	/* [nsub][4096] */
 	uint32_t cap, nsub;
 	uint32_t *status;
@@ -196,10 +196,18 @@ __device__ static inline uint32_t shw_block_excl_scan(uint32_t v, uint32_t *tmp 
 	return incl - v + (wave ? before : 0u);
 }
 
-template <int THREADS, int RPT /* rows per thread */>
+/* ROWS: the words carry the ROW as well (the left table of the ordered operator, mdb_dev_join.hip: k_leaf_wide<.., L32>) - not as a
+ * 27-bit row id beside the 15 hash bits (8-byte words: 16 384-row tiles, measured 0.65 ms per 10^8 rows - what the two 512-digit levels
+ * they were to replace take), but as the row's place INSIDE ITS TILE (15 bits) in a 4-byte word, and one HEADER word in front of every run
+ * (tile x digit: ~8 words) that names the tile: bit 31 set, the tile's first row / 2 below.  The reader resolves a word's row as
+ * 2 * header + place; a region always begins with a header.  Staged like the 2-byte words (the spare top bit marks a run's first word),
+ * 128 KiB for the same 32 768-row tiles. */
+template <int THREADS, int RPT /* rows per thread */, bool ROWS = false>
 __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024 or two of 512 per CU */) void k_shard_scatter_wide(shw_scatter_args a)
 {
+	typedef typename std::conditional<ROWS, uint32_t, uint16_t>::type W;
 	constexpr uint32_t TILE = THREADS * RPT, D = 1u << SHW_D_BITS, DPT = D / THREADS, NCHUNK = TILE / 64u, HALF = RPT / 2;
+	constexpr uint32_t MARK = ROWS ? 0x80000000u : 0x8000u, HDR = ROWS ? 1u : 0u;	/* words a run takes beyond its rows */
 	static_assert(TILE <= 32768u && DPT >= 2 && (DPT & 1) == 0 && (RPT % 4) == 0, "tile shape");
 	extern __shared__ __attribute__((aligned(16))) uint32_t shw_lds[];
 	uint32_t *const s_cnt = shw_lds;			/* [D / 2] two 16-bit counters per word, then the digits' tile-local starts */
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 	uint32_t *const s_chunk = s_delta + D;			/* [NCHUNK] runs that begin before staged position 64 c */
 	uint32_t *const s_bad = s_chunk + NCHUNK;		/* [D / 32] non-empty digits (by ordinal) whose run did not fit its region */
 	uint32_t *const s_tmp = s_bad + D / 32;			/* [32] */
-	uint16_t *const s_stage = reinterpret_cast<uint16_t *>(s_tmp + 32);	/* [TILE] */
+	W *const s_stage = reinterpret_cast<W *>(s_tmp + 32);	/* [TILE] */
 	__shared__ uint32_t s_any_bad;
 
 	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane(), sub = blockIdx.x % a.nsub;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 				st0[j] = start;
 				base[j] = 0u;
 				if (cnt[j]) {
-					base[j] = atomicAdd(&a.cursor[sub * D + d], cnt[j]);
+					base[j] = atomicAdd(&a.cursor[sub * D + d], cnt[j] + HDR);
 					/* this run is the last one to begin before position 64 c for every c with start < 64 c <= start + count */
 					for (uint32_t c = (start >> 6) + 1u; (c << 6) <= start + cnt[j] && c < NCHUNK; c++)
 						s_chunk[c] = ord + 1u;
@@ -331,7 +339,12 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 			if (packed[r] != 0xFFFFFFFFu) {
 				const uint32_t dig = packed[r] >> 16;
 				const uint32_t st = (s_cnt[dig >> 1] >> ((dig & 1u) << 4)) & 0xFFFFu;
-				s_stage[st + (packed[r] & 0xFFFFu)] = (uint16_t)(word2[r >> 1] >> (16 * (r & 1)));
+				const uint32_t w16 = (word2[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+				if (ROWS)	/* (the row's place in the tile: pair r / 2 of this thread, element r & 1) */
+					s_stage[st + (packed[r] & 0xFFFFu)] = (W)(((w16 & 0x8000u) << 16) | ((2u * ((uint32_t)(r >> 1) * THREADS + tid) + (uint32_t)(r & 1)) << 15) |
+										  (w16 & 0x7FFFu));
+				else
+					s_stage[st + (packed[r] & 0xFFFFu)] = (W)w16;
 			}
 		}
 		{
@@ -340,12 +353,12 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 			for (int j = 0; j < (int)DPT; j++) {
 				if (cnt[j]) {
 					const uint32_t d = tid * DPT + (uint32_t)j;
-					if (base[j] + cnt[j] > a.cap) {
+					if (base[j] + cnt[j] + HDR > a.cap) {
 						mdb_raise(a.status, 2u);	/* the region is full: reported, the operator takes its exact path */
 						atomicOr(&s_bad[ord >> 5], 1u << (ord & 31u));
 						s_any_bad = 1u;
 					}
-					s_delta[ord] = (d * a.nsub + sub) * a.cap + base[j] - st0[j];
+					s_delta[ord] = (d * a.nsub + sub) * a.cap + base[j] + HDR - st0[j];
 					ord++;
 				}
 			}
@@ -359,13 +372,16 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 		for (int k = 0; k < RPT; k++) {
 			const uint32_t i = (uint32_t)k * THREADS + tid;
 			const uint32_t sv = i < tile_total ? s_stage[i] : 0u;
-			const uint64_t m = __ballot(sv & 0x8000u);
+			const uint64_t m = __ballot(sv & MARK);
 			if (i >= tile_total)
 				continue;
 			const uint32_t ord = s_chunk[(uint32_t)k * (THREADS / 64) + wave] + (uint32_t)__popcll(m & le) - 1u;
 			if (any_bad && ((s_bad[ord >> 5] >> (ord & 31u)) & 1u))
 				continue;
-			a.out[i + s_delta[ord]] = (uint16_t)(sv & 0x7FFFu);
+			const uint32_t g = i + s_delta[ord];
+			reinterpret_cast<W *>(a.out)[g] = (W)(sv & (MARK - 1u));
+			if (ROWS && (sv & MARK))	/* the run's header: the tile (row0 is even) */
+				reinterpret_cast<W *>(a.out)[g - 1u] = (W)(0x80000000u | (uint32_t)(row0 >> 1));
 		}
 		shw_barrier();
 		if (any_bad) {		/* (rare: clear the marks of this tile's full regions) */
@@ -379,10 +395,78 @@ __global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024
 	}
 }
 
-static size_t shw_scatter_lds(uint32_t tile)
+static size_t shw_scatter_lds(uint32_t tile, size_t word_bytes = 2)
 {
 	const uint32_t D = 1u << SHW_D_BITS;
-	return (size_t)4 * (D / 2 + D + tile / 64 + D / 32 + 32) + (size_t)2 * tile;
+	return (size_t)4 * (D / 2 + D + tile / 64 + D / 32 + 32) + word_bytes * tile;
+}
+
+/* region capacity (words) of a table of at most n rows partitioned by mdb_scatter4096: the average + 1/16 + 320 words (a region's fill:
+ * 3052 +- 55 rows at 10^8), plus - row words - one header per tile whose workgroup writes to the region's sub-region */
+uint32_t mdb_scatter4096_cap(const mdb_dev_ctx *ctx, uint64_t n, bool row_words)
+{
+	const uint64_t regions = (uint64_t)(1u << SHW_D_BITS) * SH_NSUB, tile = 32768;
+	uint64_t cap = n * 17 / 16 / regions + 320;
+	if (row_words) {
+		const uint64_t ntiles = (n + tile - 1) / tile, grid = ntiles < (uint64_t)ctx->num_cus ? (ntiles ? ntiles : 1) : (uint64_t)ctx->num_cus;
+		const uint64_t rows_per_wg = (n + grid - 1) / grid + 1;
+		cap += ((grid + SH_NSUB - 1) / SH_NSUB) * ((rows_per_wg + tile - 1) / tile) + 8;
+	}
+	return sh_round64(cap);
+}
+
+size_t mdb_scatter4096_arena_bytes(const mdb_dev_ctx *ctx, uint64_t n, bool row_words)
+{
+	const size_t nreg = (size_t)(1u << SHW_D_BITS) * SH_NSUB;
+	return mdb_align_up(nreg * 4) + mdb_align_up(nreg * mdb_scatter4096_cap(ctx, n, row_words) * (row_words ? 4 : 2)) + 4096;
+}
+
+/* One 4096-digit pass over a key column (compact narrow form: every key in [key_lo, key_lo + 2^kbits), 12 < kbits <= 27): regions of `cap`
+ * words - 2-byte hash bits below the digit, or 4-byte row words (see k_shard_scatter_wide) - and their cursors [nsub = 8][4096], both from the
+ * arena.  report: a key outside the window raises status bit 7; otherwise rows with key - key_lo > rel_hi are dropped. */
+int mdb_scatter4096(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nulls, uint64_t n, int64_t key_lo, uint32_t kbits, bool report, uint32_t rel_hi,
+		    uint32_t cap, bool row_words, const char *name, void **regions, uint32_t **cursors)
+{
+	const size_t nreg = (size_t)(1u << SHW_D_BITS) * SH_NSUB;
+	if (kbits <= SHW_D_BITS || kbits > SHW_D_BITS + SHW_MAX_REM || n >= 0xF0000000ull)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "4096-digit pass: %u key bits, %llu rows", kbits, (unsigned long long)n);
+	uint32_t *cur = (uint32_t *)mdb_arena_take(ctx, nreg * 4);
+	void *buf = mdb_arena_take(ctx, nreg * cap * (row_words ? 4 : 2));
+	if (!cur || !buf)
+		return -MIDORIDB_INTERNAL;
+	MDB_HIP(ctx, hipMemsetAsync(cur, 0, nreg * 4, ctx->stream));
+	*regions = buf;
+	*cursors = cur;
+	if (n == 0)
+		return MIDORIDB_OK;
+	shw_scatter_args a;
+	memset(&a, 0, sizeof(a));
+	a.keys = reinterpret_cast<const long long *>(keys);
+	a.nullbits = reinterpret_cast<const unsigned long long *>(nulls);
+	a.n = (uint32_t)n;
+	a.key_lo = key_lo;
+	a.kbits = kbits;
+	a.rem = kbits - SHW_D_BITS;
+	a.report = report ? 1u : 0u;
+	a.rel_hi = rel_hi;
+	a.out = buf;
+	a.cursor = cur;
+	a.cap = cap;
+	a.nsub = SH_NSUB;
+	a.status = ctx->d_status;
+	const uint32_t tile = 32768u, ntiles = (uint32_t)((n + tile - 1) / tile);
+	const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;	/* one workgroup per CU, a contiguous range of rows each */
+	a.rows_per_wg = (uint32_t)(((n + grid - 1) / grid + 1) & ~1ull);
+	if (row_words) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+						 (int)shw_scatter_lds(tile, 4)));
+		MDB_LAUNCH_LDS(ctx, name, (k_shard_scatter_wide<1024, 32, true>), grid, 1024, shw_scatter_lds(tile, 4), a);
+	} else {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+						 (int)shw_scatter_lds(tile)));
+		MDB_LAUNCH_LDS(ctx, name, (k_shard_scatter_wide<1024, 32>), grid, 1024, shw_scatter_lds(tile), a);
+	}
+	return MIDORIDB_OK;
 }
 
 int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, const int64_t *keys, const uint64_t *nulls, uint64_t n,
@@ -416,33 +500,12 @@ int mdb_shard_partition(mdb_dev_ctx *ctx, const mdb_shard_plan *p, int side, con
 		return MIDORIDB_OK;
 	}
 	if (p->dbits == SHW_D_BITS) {
-		const size_t nreg = (size_t)p->D * p->nsub;
-		uint32_t *cur = (uint32_t *)mdb_arena_take(ctx, nreg * 4);
-		uint16_t *buf = (uint16_t *)mdb_arena_take(ctx, nreg * p->cap[side] * 2);
-		if (!cur || !buf)
-			return -MIDORIDB_INTERNAL;
-		MDB_HIP(ctx, hipMemsetAsync(cur, 0, nreg * 4, ctx->stream));
-		shw_scatter_args a;
-		memset(&a, 0, sizeof(a));
-		a.keys = reinterpret_cast<const long long *>(keys);
-		a.nullbits = reinterpret_cast<const unsigned long long *>(nulls);
-		a.n = (uint32_t)n;
-		a.key_lo = p->key_lo;
-		a.kbits = p->kbits;
-		a.rem = p->rem;
-		a.report = side == 1;
-		a.rel_hi = (uint32_t)p->l_rel_hi;
-		a.out = buf;
-		a.cursor = cur;
-		a.cap = p->cap[side];
-		a.nsub = p->nsub;
-		a.status = ctx->d_status;
-		const uint32_t tile = 32768u, ntiles = (uint32_t)((n + tile - 1) / tile);
-		const uint32_t grid = ntiles < (uint32_t)ctx->num_cus ? ntiles : (uint32_t)ctx->num_cus;	/* one workgroup per CU, a contiguous range of rows each */
-		a.rows_per_wg = (uint32_t)(((n + grid - 1) / grid + 1) & ~1ull);
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-						 (int)shw_scatter_lds(tile)));
-		MDB_LAUNCH_LDS(ctx, side ? "shard_scatter_wide_r" : "shard_scatter_wide_l", (k_shard_scatter_wide<1024, 32>), grid, 1024, shw_scatter_lds(tile), a);
+		void *buf = NULL;
+		uint32_t *cur = NULL;
+		int rc4 = mdb_scatter4096(ctx, keys, nulls, n, p->key_lo, p->kbits, side == 1, (uint32_t)p->l_rel_hi, p->cap[side], false,
+					  side ? "shard_scatter_wide_r" : "shard_scatter_wide_l", &buf, &cur);
+		if (rc4)
+			return rc4;
 		*regions = buf;
 		*cursors = cur;
 		return MIDORIDB_OK;

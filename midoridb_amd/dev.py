@@ -254,9 +254,14 @@ class DeviceCtx:
         """the last join_group_count ran without row ids and ordering (flags without MDB_ORDER_FIRST, no first rows wanted)"""
         return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x800)
 
+    def last_join_one_pass_4096(self):
+        """the last ordered join_group_count took ONE 4096-digit pass per table (key windows of 2^24 ... 2^27 values: 4-byte row words
+        for the left table, leaves of up to 2^15 values shared by two workgroups)"""
+        return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x1000)
+
     def last_join_levels(self):
         """partition levels of the last join / GROUP BY operator's final attempt: 1 (wide direct-address leaves) or 2"""
-        return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x200 else 2
+        return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x1200 else 2
 
     def set_narrow_keys(self, mode):
         """32-bit hashes for int32-range join keys: 0 never, 1 sampled and verified (default), 2 always try."""

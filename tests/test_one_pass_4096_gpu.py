@@ -1,0 +1,130 @@
+"""The ordered join + GROUP BY + COUNT(*) over key windows of 2^24 ... 2^27 values (10^8 unique keys per table: BASELINE
+configs[2]'s unfavourable variants): ONE 4096-digit pass per table - 2-byte words for the right table, 4-byte ROW words with
+run headers for the left one (mdb_dev_shard.hip: k_shard_scatter_wide<.., ROWS>) - and k_leaf_wide over digits of up to 2^15
+values, two workgroups per digit.  Groups, counts, first rows and order are the oracle's
+(/root/reference/src/engine/executor_select.c:1076-1149 join, 1526-1588 first-occurrence order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from midoridb_amd.dev import DeviceCtx
+    d = DeviceCtx(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture()
+def forced():
+    """the form is meant for tables of 2^26 rows and more: let it run on the test's small ones"""
+    os.environ["MDB_WIDE12_MIN"] = "1"
+    yield
+    del os.environ["MDB_WIDE12_MIN"]
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _check(dev, kl, nl, kr, nr, expect_form=True, rounds=2):
+    ek, ec, ef, ej = orc.join_group_count(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for round_ in range(rounds):     # the second call runs on remembered verdicts (4-byte records among them)
+        k, c, f, j = dev.join_group_count(dl, dnl, dr, dnr)
+        assert j == ej, (round_, j, ej)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), round_
+        assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), round_
+        if expect_form is not None:
+            assert dev.last_join_one_pass_4096() == expect_form, (round_, dev.last_join_form())
+
+
+@pytest.mark.parametrize("bits", [24, 25, 26, 27])
+@pytest.mark.parametrize("shape", ["unique", "dup16_right", "n_to_m", "nulls", "negative_offset", "offset_1e12"])
+def test_one_pass_4096_matches_the_oracle(dev, forced, bits, shape):
+    rng = np.random.default_rng(bits * 31 + len(shape))
+    span = (1 << bits) - int(rng.integers(1, 1 << (bits - 2)))      # the window rounds up to 2^bits
+    n_l, n_r = 1_200_000 + int(rng.integers(0, 5000)), 1_000_000 + int(rng.integers(0, 5000))
+    off = {"negative_offset": -(2**41) - 12345, "offset_1e12": 10**12 + 7}.get(shape, 0)
+    if shape == "n_to_m":
+        kl = off + rng.integers(0, span, n_l, dtype=np.int64)
+        kr = off + rng.integers(0, span, n_r, dtype=np.int64)
+        kl[: n_l // 2] = kl[n_l // 2: 2 * (n_l // 2)]               # every key of the first half twice on the left
+        kr[: n_r // 3] = kl[: n_r // 3]                             # ... and a third of the right rows among them
+    else:
+        pl = rng.permutation(span)[: max(n_l, n_r)].astype(np.int64)
+        kl = off + pl[:n_l]
+        pr = rng.permutation(span)[:n_r].astype(np.int64)
+        kr = off + (pr if shape != "dup16_right" else 16 * (pr % (span // 16)))
+    # the sample must see the window's ends (2 x 4096 pseudo-random positions of 10^6 rows do not): pin them
+    kl[0], kl[-1] = off, off + span - 1
+    nl = nr = None
+    if shape == "nulls":
+        nl, nr = rng.random(n_l) < 0.07, rng.random(n_r) < 0.15
+        nl[0] = nl[-1] = False
+        kl[nl] = rng.integers(-2**62, 2**62, int(nl.sum()))
+        kr[nr] = rng.integers(-2**62, 2**62, int(nr.sum()))
+    _check(dev, kl, nl, kr, nr, expect_form=None)
+    assert dev.last_join_form() in (1, 2)
+    # whether the compact window was offered is the sample's business; when it was, the 4096-digit pass must have run
+    if dev.last_join_form() == 2:
+        assert dev.last_join_one_pass_4096()
+
+
+def test_one_pass_4096_a_key_with_70000_rows_falls_back(dev, forced):
+    """16-bit row counts per key value: a key with more rows is reported by the leaf kernel and the operator redone with two
+    levels (and their hot-key path) - same result."""
+    rng = np.random.default_rng(5)
+    span, n_l, n_r = (1 << 26) - 77, 1_500_000, 1_500_000
+    kl = rng.permutation(span)[:n_l].astype(np.int64)
+    kr = rng.permutation(span)[:n_r].astype(np.int64)
+    kl[0], kl[-1] = 0, span - 1
+    kr[200_000:270_000] = 4242
+    kl[1000:1003] = 4242
+    _check(dev, kl, None, kr, None, expect_form=None, rounds=2)
+    assert not dev.last_join_one_pass_4096()
+
+
+def test_one_pass_4096_left_rows_outside_the_right_tables_window(dev, forced):
+    """the right table's keys fill a 2^26 window, the left table's spread over 2^31: the window is the right table's (by_span), left rows
+    outside it have no partner and are dropped by the pass"""
+    rng = np.random.default_rng(6)
+    n_l, n_r = 3_000_000, 1_500_000
+    base = 5 * 2**26 + 1234
+    kr = base + rng.permutation((1 << 26) - 999)[:n_r].astype(np.int64)
+    kl = rng.integers(0, 1 << 31, n_l, dtype=np.int64)
+    kl[::7] = kr[rng.integers(0, n_r, len(kl[::7]))]
+    _check(dev, kl, None, kr, None, expect_form=None)
+
+
+def test_one_pass_4096_at_scale_equals_the_two_level_form(dev):
+    """4 * 10^7 x 4 * 10^7 rows of the benchmark's generator, variants U and S: the one-pass form (default from 2^26 rows in all) and
+    the two-level form (MDB_WIDE12=0) deliver identical columns."""
+    n = 40_000_000
+    kl = dev.gen_keys(n, 0, n, 42, 0)
+    for variant in ("U", "S"):
+        kr = dev.gen_keys(n, 0, n, 43, 0 if variant == "U" else n // 16)
+        if variant == "S":
+            kr = kr * 16
+        out = {}
+        for mode in ("1", "0"):
+            os.environ["MDB_WIDE12"] = mode
+            try:
+                for _ in range(2):
+                    k, c, f, j = dev.join_group_count(kl, None, kr, None)
+                assert dev.last_join_one_pass_4096() == (mode == "1"), (variant, mode)
+                out[mode] = (k.clone(), c.clone(), f.clone(), j)
+            finally:
+                del os.environ["MDB_WIDE12"]
+        for a, b in zip(out["1"][:3], out["0"][:3]):
+            assert torch.equal(a, b), variant
+        assert out["1"][3] == out["0"][3]
+        del out
+        torch.cuda.empty_cache()
