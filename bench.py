@@ -119,7 +119,7 @@ def scatter_word_bytes(instances):
 
 
 FIRST_LEVEL = ("part_scatter_l0", "part_scatter_l0_w32", "part_scatter_l0_rid", "part_scatter_l0_pruned", "part_hist_l0",
-               "shard_scatter_wide_l", "shard_scatter_wide_r")
+               "shard_scatter_wide_l", "shard_scatter_wide_r", "part_scatter_wide12_l", "part_scatter_wide12_r")
 WRITES_RESULT = ("order_leaf", "order_leaf_sparse", "shard_leaf", "shard_leaf_wide")
 
 
@@ -175,6 +175,9 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
         "part_scatter_l1_rid": 2 * (key + rid),
         "part_hist_l0": key,
         "shard_scatter_wide_l": key + 2 * kept, "shard_scatter_wide_r": key + 2 * n,
+        # the ordered form's one 4096-digit pass per table: 2-byte words (right), 4-byte row words + one header per ~8-word run (left)
+        "part_scatter_wide12_r": key + 2 * n, "part_scatter_wide12_l": key + 4.5 * kept,
+        "leaf_join_wide12": 2 * n + 4.5 * kept + 8 * g,     # both tables' words in, one record per group out (4 bytes when every COUNT fits)
         "shard_leaf_wide": 2 * (kept + n) + 16 * g, "shard_leaf": 4 * (kept + n) + 16 * g,
         "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
         "leaf_join_direct": key + h32 + 8 * g,

@@ -1250,44 +1250,57 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	};
 	uint4 vr[LW12_RB], vl[LW12_LB];
 	uint32_t nvr = 0, nvl = 0;	/* words of each chunk, 4 bits each */
-	/* chunk q of a side: the sub-regions' first chunks are the same for every thread - read once, kept in scalar registers (as a loop
-	 * over LDS per chunk, 12 chunks per thread and digit, this search was a third of the kernel) */
-	auto fetch_all = [&](uint32_t d, uint32_t b) {
-		nvr = nvl = 0u;
+	/* chunk q of a side lies in the last sub-region j whose first chunk c0[j] is <= q, at word (d * 8 + j) * cap + (q - c0[j]) * per of the
+	 * table's buffer, and holds min(per, cnt[j] - (q - c0[j]) * per) words.  The three per-region terms of that - where the region's
+	 * chunk 0 would sit minus c0[j] * per, and cnt[j] + c0[j] * per - are the same for every thread: read once per digit and side, kept in
+	 * scalar registers, selected by seven compares (as a search loop over LDS per chunk, 12 chunks per thread and digit, and then as
+	 * 135 instructions of 64-bit address arithmetic per chunk, this was the largest single part of the kernel) */
+	auto fetch_all = [&](uint32_t d, uint32_t b, const int sides /* 1 left, 2 right, 3 both */) {
 #pragma unroll
 		for (int side = 1; side >= 0; side--) {
-			uint32_t c0[LW12_NSUB + 1];
+			if (!(sides & (1 << side)))
+				continue;
+			const uint32_t per = side ? 8u : 4u, cap = side ? a.cap_r : a.cap_l;
+			uint32_t c0[LW12_NSUB + 1], delta[LW12_NSUB], endq[LW12_NSUB];
 #pragma unroll
 			for (int j = 0; j <= LW12_NSUB; j++)
 				c0[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk0[b][side][j]);
-			const uint32_t per = side ? 8u : 4u;
+#pragma unroll
+			for (int j = 0; j < LW12_NSUB; j++) {
+				const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[b][side][j]);
+				delta[j] = (d * LW12_NSUB + (uint32_t)j) * cap - c0[j] * per;	/* (word index: below 2^32, checked by the caller) */
+				endq[j] = cnt + c0[j] * per;
+			}
+			uint32_t nvs = 0u;
 #pragma unroll
 			for (int u = 0; u < (side ? LW12_RB : LW12_LB); u++) {
-				const uint32_t q = (uint32_t)u * LW_THREADS + threadIdx.x;
+				const uint32_t q = (uint32_t)u * LW_THREADS + threadIdx.x, qp = q * per;
 				uint4 v = make_uint4(0u, 0u, 0u, 0u);
 				uint32_t nv = 0u;
 				if (q < c0[LW12_NSUB]) {
-					uint32_t sg = 0, first = 0;	/* the last sub-region whose first chunk is <= q */
+					uint32_t dl = delta[0], en = endq[0];
 #pragma unroll
 					for (int j = 1; j < LW12_NSUB; j++) {
-						sg += c0[j] <= q ? 1u : 0u;
-						first = c0[j] <= q ? c0[j] : first;
+						const bool in = c0[j] <= q;
+						dl = in ? delta[j] : dl;
+						en = in ? endq[j] : en;
 					}
-					const uint32_t off = (q - first) * per, c = s_cnt[b][side][sg];
-					nv = c - off < per ? c - off : per;
+					nv = en - qp < per ? en - qp : per;
 					if (side)
-						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_r) + (size_t)(d * LW12_NSUB + sg) * a.cap_r + off);
+						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_r) + (dl + qp));
 					else
-						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_l) + (size_t)(d * LW12_NSUB + sg) * a.cap_l + off);
+						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_l) + (dl + qp));
 				}
-				if (side) {
+				if (side)
 					vr[u < LW12_RB ? u : 0] = v;
-					nvr |= nv << (4 * u);
-				} else {
+				else
 					vl[u] = v;
-					nvl |= nv << (4 * u);
-				}
+				nvs |= nv << (4 * u);
 			}
+			if (side)
+				nvr = nvs;
+			else
+				nvl = nvs;
 		}
 	};
 	{
@@ -1300,7 +1313,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		if (threadIdx.x < 2u)
 			seg_prefix(0);
 		__syncthreads();
-		fetch_all(leaf, 0);
+		fetch_all(leaf, 0, 2);
 	}
 	unsigned long long joined = 0;
 	uint32_t last_first = 0;	/* largest first row id of this workgroup's groups */
@@ -1313,27 +1326,37 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			bad = true;
 			break;
 		}
+		/* the left words: on their way while the tables are cleared and the right words counted (the right words were requested while the
+		 * previous digit's groups left: held across that phase they are 16 registers, with the left ones 48 - spills, whose reloads wait
+		 * for everything in flight) */
+		fetch_all(leaf, buf, 1);
 		const uint32_t next_c = next < a.nleaves ? seg_count(next) : 0u;	/* (on its way while this digit is counted) */
 		for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
 			s_fc[s] = 0x07FFFFFFu;
 		for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
 			s_cl[s] = 0u;
-		__syncthreads();
+		lw12_barrier();
 		uint32_t adds = 0, radds = 0;
 #pragma unroll
 		for (int u = 0; u < LW12_RB; u++) {
 			const uint32_t w[4] = { vr[u].x, vr[u].y, vr[u].z, vr[u].w }, nv = (nvr >> (4 * u)) & 15u;
+			if (nv == 8u) {		/* (all but a sub-region's last chunk; the words are below 2^rem as they were written) */
 #pragma unroll
-			for (uint32_t k = 0; k < 8u; k++) {
-				if (k >= nv)
-					continue;
-				atomicAdd(&s_fc[(w[k >> 1] >> (16u * (k & 1u))) & mask], 1u << 27);
-				radds++;
+				for (uint32_t k = 0; k < 4u; k++) {
+					atomicAdd(&s_fc[w[k] & 0xFFFFu], 1u << 27);
+					atomicAdd(&s_fc[w[k] >> 16], 1u << 27);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t k = 0; k < 8u; k++)
+					if (k < nv)
+						atomicAdd(&s_fc[(w[k >> 1] >> (16u * (k & 1u))) & mask], 1u << 27);
 			}
+			radds += nv;
 		}
 		if (threadIdx.x < 32u)
 			s_cnt[buf ^ 1u][threadIdx.x >> 4][threadIdx.x & 15u] = next_c;
-		__syncthreads();
+		lw12_barrier();
 		if (threadIdx.x < 2u)
 			seg_prefix(buf ^ 1u);
 #pragma unroll
@@ -1354,7 +1377,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			const uint32_t wave_last = (uint32_t)__shfl((int)my_last, bal ? 63 - __clzll((long long)bal) : 0, MDB_WAVE);
 			if (lane == 0)
 				s_wlast[p][wave] = bal ? wave_last : 0u;
-			__syncthreads();
+			lw12_barrier();
 			{
 				const uint32_t x = lane < LW_THREADS / 64 ? s_wlast[p][lane] : 0u;
 				const uint64_t ball = __ballot(x != 0u), earlier = ball & ((1ull << wave) - 1ull);
@@ -1367,37 +1390,45 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					s_carry[p ^ 1u] = ball ? round_last : carried;
 			}
 			it++;
+			uint32_t fcv[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; k++)
+				fcv[k] = s_fc[w[k] & mask];	/* (a header's or an absent word's slot is read and ignored) */
+			uint32_t row2 = cur << 1;	/* the tile's first row (the header's top bit leaves) */
 #pragma unroll
 			for (uint32_t k = 0; k < 4u; k++) {
-				if (k >= nv)
-					continue;
-				if (w[k] >> 31) {
-					cur = w[k];
-					continue;
-				}
-				const uint32_t idx = w[k] & mask, fc = s_fc[idx];
-				if (fc >> 27) {		/* (the right rows are all counted: the top bits are final, the minimum is over the row id) */
-					atomicMin(&s_fc[idx], (fc & 0xF8000000u) | (((cur & 0x7FFFFFFFu) << 1) + ((w[k] >> 15) & 0x7FFFu)));
+				const bool hdr = (w[k] >> 31) != 0u;
+				row2 = hdr ? w[k] << 1 : row2;
+				const uint32_t idx = w[k] & mask, fc = fcv[k];
+				if (k < nv && !hdr && (fc >> 27)) {	/* (the right rows are all counted: the top bits are final, the minimum is over the row id) */
+					atomicMin(&s_fc[idx], (fc & 0xF8000000u) | (row2 + ((w[k] >> 15) & 0x7FFFu)));
 					atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
 					adds++;
 				}
 			}
 		}
-		__syncthreads();
+		lw12_barrier();
 
-		/* groups of the digit: the non-zero left counts.  Wave w owns the values [w * T / 16, (w + 1) * T / 16): their groups leave side by side */
-		const uint32_t per_wave = T / (LW_THREADS / 64);
-		uint32_t mine = 0;
-		for (uint32_t s = lane; s < per_wave / 8; s += MDB_WAVE) {
-			const uint32_t c8 = s_cl[wave * (per_wave / 8) + s];
-			mine += (uint32_t)__popc((c8 | (c8 >> 1) | (c8 >> 2) | (c8 >> 3)) & 0x11111111u);
+		/* groups of the digit: the non-zero left counts.  Wave w owns the values [w * T / 16, (w + 1) * T / 16): their groups leave side by side,
+		 * 64 values a step, written by consecutive lanes.  With one workgroup per CU the kernel is bound by the instructions it issues
+		 * (ablations: this pass 0.16 of 0.41 ms at 50 instructions per value): one loop per record format, the rare conditions - a COUNT(*) that
+		 * does not fit its field - tested once per digit on the largest COUNT seen, not per value. */
+		const uint32_t per_wave = T / (LW_THREADS / 64), words_per_wave = per_wave / 8;
+		uint32_t mine = 0, sum_cl = 0, sum_cr = 0;
+		for (uint32_t wi = lane; wi < words_per_wave; wi += MDB_WAVE) {
+			const uint32_t cw = s_cl[wave * words_per_wave + wi];
+			mine += (uint32_t)__popc((cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x11111111u);
+			sum_cl += (((cw & 0x0F0F0F0Fu) + ((cw >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24;	/* (eight nibbles of at most 15: their sum fits a byte) */
 		}
+		{
+			uint32_t t = mine;
 #pragma unroll
-		for (int o = 32; o; o >>= 1)
-			mine += (uint32_t)__shfl_down((int)mine, o, MDB_WAVE);
-		if (lane == 0)
-			s_red32[wave] = mine;
-		__syncthreads();
+			for (int o = 32; o; o >>= 1)
+				t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
+			if (lane == 0)
+				s_red32[wave] = t;
+		}
+		lw12_barrier();
 		if (threadIdx.x == 0) {
 			uint32_t total = 0;
 #pragma unroll
@@ -1415,52 +1446,69 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			}
 			s_base = nb;
 		}
-		/* the registers are free: the next digit's words, in flight while this one's groups are written */
+		/* registers are free: the next digit's right words, in flight while this one's groups are written */
 		if (next < a.nleaves)
-			fetch_all(next, buf ^ 1u);
+			fetch_all(next, buf ^ 1u, 2);
 		lw12_barrier();
 		const uint32_t base = s_base;
 		uint32_t run = 0;	/* groups of the waves before this one, then of this wave so far (uniform) */
 		{
-			const uint32_t x = lane < wave ? s_red32[lane] : 0u;	/* (at most 16 waves) */
-			uint32_t t = x;
+			uint32_t t = lane < wave ? s_red32[lane] : 0u;	/* (at most 16 waves) */
 #pragma unroll
 			for (int o = 32; o; o >>= 1)
 				t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
-			run = t;
+			run = base + t;		/* (base = ~0: nothing is written) */
 		}
-		unsigned long long sums = 0;	/* low half: right rows counted, high half: left rows counted */
-		for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {
-			const uint32_t s = wave * per_wave + s0 + lane;
-			const uint32_t fc = s_fc[s], cl = (s_cl[s >> 3] >> ((s & 7u) * 4u)) & 15u, cr = fc >> 27;
-			sums += ((unsigned long long)cl << 32) | cr;
-			const uint64_t m = __ballot(cl != 0u);
-			if (!m || base == 0xFFFFFFFFu)
-				continue;
-			const uint32_t wbase = run;
-			run += (uint32_t)__popcll(m);
-			if (cl) {
-				const uint32_t pos = base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-				const uint32_t first = fc & 0x07FFFFFFu;
-				const unsigned long long c = (unsigned long long)cl * cr;
-				joined += c;
-				last_first = first > last_first ? first : last_first;
-				if (a.keyed_cbits) {
-					if (c >> a.keyed_cbits)
-						mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
-					a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | ((unsigned long long)((leaf << rem) | s) << a.keyed_cbits) | c;
-				} else {
-					if (c >> (32 - (a.kbits < 32 ? a.kbits : 31)))
-						mdb_raise(a.status, 16u);	/* COUNT(*) does not fit a 4-byte record */
-					if (a.rec32) {		/* (4-byte records on a remembered verdict, like k_leaf_direct) */
-						if (c >> (32 - a.kbits))
-							mdb_raise(a.status, 512u);
-						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | (uint32_t)c;
-					} else
-						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
-				}
-			}
+		const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
+		uint32_t cmax = 0, jsum = 0;
+		/* FMT 0: 8-byte records, 1: 4-byte records, 2: keyed 8-byte records */
+#define LW12_EMIT(FMT)                                                                                                                  \
+		for (uint32_t s0 = 0; s0 < per_wave; s0 += 4u * MDB_WAVE) {	/* (per_wave >= 256: a digit has 2^12 values at least) */   \
+			uint32_t fc4[4], cw4[4];                                                                                       \
+			_Pragma("unroll") for (int e = 0; e < 4; e++) {                                                                \
+				const uint32_t sl = s_begin + s0 + (uint32_t)e * MDB_WAVE;                                             \
+				fc4[e] = s_fc[sl];                                                                                     \
+				cw4[e] = s_cl[sl >> 3];                                                                                \
+			}                                                                                                              \
+			_Pragma("unroll") for (int e = 0; e < 4; e++) {                                                                \
+				const uint32_t fc = fc4[e], cl = (cw4[e] >> nib) & 15u, cr = fc >> 27;                                 \
+				sum_cr += cr;                                                                                          \
+				const uint64_t m = __ballot(cl != 0u);                                                                 \
+				if (!m)                                                                                                \
+					continue;                                                                                      \
+				const uint32_t pos = run + (uint32_t)__popcll(m & mdb_lanemask_lt());                                  \
+				run += (uint32_t)__popcll(m);                                                                          \
+				if (cl && base != 0xFFFFFFFFu) {                                                                       \
+					const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr;                                          \
+					jsum += c;                                                                                     \
+					cmax = c > cmax ? c : cmax;                                                                    \
+					last_first = first > last_first ? first : last_first;                                          \
+					if (FMT == 1)                                                                                  \
+						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | c;              \
+					else if (FMT == 0)                                                                             \
+						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;                        \
+					else                                                                                           \
+						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) |                           \
+							     ((unsigned long long)((leaf << rem) | (s_begin + s0 + (uint32_t)e * MDB_WAVE)) << a.keyed_cbits) | c; \
+				}                                                                                                      \
+			}                                                                                                              \
 		}
+		if (a.keyed_cbits) {
+			LW12_EMIT(2)
+		} else if (a.rec32) {
+			LW12_EMIT(1)
+		} else {
+			LW12_EMIT(0)
+		}
+#undef LW12_EMIT
+		joined += jsum;
+		if (cmax) {	/* (a COUNT(*) of at most 15 * 31) */
+			if (a.keyed_cbits && (cmax >> a.keyed_cbits))
+				mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
+			if (!a.keyed_cbits && (cmax >> (32 - (a.kbits < 32 ? a.kbits : 31))))
+				mdb_raise(a.status, 16u | (a.rec32 ? 512u : 0u));	/* ... a 4-byte record (written on a remembered verdict: redone with 8-byte ones) */
+		}
+		const unsigned long long sums = ((unsigned long long)sum_cl << 32) | sum_cr;	/* low half: right rows counted, high half: left rows counted */
 		/* a count field that overflowed carried into its neighbour (or out of the word): the fields then sum to less than was added */
 		const unsigned long long want = ((unsigned long long)adds << 32) | radds;
 		unsigned long long diff = sums - want;
@@ -1870,16 +1918,23 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		st->one_level = false;	/* (further right tables: the two-level direct-address kernel counts them) */
 	/* key windows of 2^24 ... 2^27 values (10^8 unique keys: variants U and S): what two 9-bit levels and k_leaf_direct did - the left
 	 * table's 8-byte words written and read twice - is ONE 4096-digit pass per table (2-byte words for the right table, 4-byte row words
-	 * for the left one) and k_leaf_wide over digits of up to 2^15 values, two workgroups per digit.  Unsplit calls of a two-table join
-	 * over int64 columns; tables large enough for 8192 workgroups that clear 128 KiB of LDS each to pay (MDB_WIDE12_MIN=<rows>,
-	 * MDB_WIDE12=0 switches it off) */
+	 * for the left one) and k_leaf_wide12 over digits of up to 2^15 values.  Unsplit calls of a two-table join over int64 columns, at
+	 * most 2^27 left rows (the leaf keeps a first row in 27 bits) and region capacities the leaf's registers hold; from 2^24 rows in all
+	 * (measured equal to the two-level form at 8 * 10^6 rows per table, 15 % faster at 10^8: profiles/micro/one_pass_4096_sweep.py;
+	 * MDB_WIDE12_MIN=<rows> moves the threshold, MDB_WIDE12=0 switches the form off) */
 	{
 		const char *e = getenv("MDB_WIDE12"), *e2 = getenv("MDB_WIDE12_MIN");
-		const uint64_t min_rows = e2 && atoll(e2) > 0 ? (uint64_t)atoll(e2) : (1ull << 26);
+		const uint64_t min_rows = e2 && atoll(e2) > 0 ? (uint64_t)atoll(e2) : (1ull << 24);
 		st->wide12 = !st->one_level && st->narrow && st->has_r && st->key_bits > 9u + LW_MAX_REM && st->key_bits <= 12u + LW_MAX_REM + 1u && st->fast &&
 			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && !st->nextra && !st->keys32 &&
+			     !st->prunable /* (a right table that covers part of the left table's key range: min-max pruning drops most left rows first) */ &&
 			     !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
-			     st->n_l + st->n_r_cap >= min_rows && st->n_l < 0xF0000000ull && st->n_r_cap < 0xF0000000ull && !(e && e[0] == '0');
+			     st->n_l + st->n_r_cap >= min_rows && st->n_l <= (1ull << 27) /* (k_leaf_wide12 keeps a first row in 27 bits) */ &&
+			     st->n_r_cap < 0xF0000000ull && !(e && e[0] == '0');
+		/* ... and a digit's words must fit the leaf kernel's registers: 8 sub-regions of at most LW12_LB (LW12_RB) chunks per thread */
+		if (st->wide12 && ((uint64_t)mdb_scatter4096_cap(ctx, st->n_l, true) * LW12_NSUB > (uint64_t)LW12_LB * LW_THREADS * 4u ||
+				   (uint64_t)mdb_scatter4096_cap(ctx, st->n_r_cap, false) * LW12_NSUB > (uint64_t)LW12_RB * LW_THREADS * 8u))
+			st->wide12 = false;
 	}
 	if (st->wide12) {
 		st->b1 = 12;

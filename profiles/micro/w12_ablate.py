@@ -3,7 +3,7 @@ kernel times of variant U through bench.py."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for m in (sys.argv[1:] or ["0", "8", "4", "5", "6", "7"]):
-    env = dict(os.environ, MDB_DEBUG_W12=m)
+    env = dict(os.environ, MDB_DEBUG_W12=m, MDB_LIBRARY=os.path.join(ROOT, "midoridb_amd", "csrc", "build", "libabl.so"))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--variant", "U", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"],
                        env=env, capture_output=True, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
