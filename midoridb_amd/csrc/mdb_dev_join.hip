@@ -1016,12 +1016,20 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 				for (int u = 0; u < LW_UNROLL; u++) {
 					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
 					const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+					if (j + 8u <= c) {	/* (all but a sub-region's last chunk: no test per word - one workgroup per CU is bound by the instructions it issues) */
 #pragma unroll
-					for (int k = 0; k < 8; k++)
-						if (j + k < c) {
+						for (int k = 0; k < 8; k++) {
 							const uint32_t idx = (w[k >> 1] >> (16 * (k & 1))) & mask;
 							atomicAdd(&s_cr[idx >> 1], 1u << ((idx & 1u) * 16u));
 						}
+					} else {
+#pragma unroll
+						for (int k = 0; k < 8; k++)
+							if (j + k < c) {
+								const uint32_t idx = (w[k >> 1] >> (16 * (k & 1))) & mask;
+								atomicAdd(&s_cr[idx >> 1], 1u << ((idx & 1u) * 16u));
+							}
+					}
 				}
 			}
 		}
