@@ -78,7 +78,11 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * log2(adjacent hashed values per bitmap bit); bit 9 = the tables were partitioned ONCE (key windows of 2^15 ... 2^23
  * values: one 9-bit level, direct-address leaf tables of 2^(k - 9) entries with 16-bit row counts; MDB_ONE_LEVEL=0 turns it
  * off; a key with 2^16 or more rows sends the operator back to two levels); bit 10 = several right tables were counted in one
- * pass (mdb_dev_join_group_count_multi did not chain two-table operators). */
+ * pass (mdb_dev_join_group_count_multi did not chain two-table operators); bit 11 = the operator ran without MDB_ORDER_FIRST
+ * (any group order); bit 12 = the ordered operator took ONE 4096-digit pass per table (key windows of 2^24 ... 2^27 values, from
+ * 2^24 rows in all, at most 2^27 left rows, no min-max pruning to be had: the left table's rows travel as 4-byte words that name
+ * their place in a 32 768-row tile, one workgroup joins a digit of up to 2^15 key values; MDB_WIDE12=0 turns it off,
+ * MDB_WIDE12_MIN=<rows> moves the threshold; more than 31 right or 15 left rows of one key send the operator back to two levels). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 /* 1 when the last mdb_dev_join_pairs() matched EVERY left row with exactly one right row (unique right keys, no left row
  * without a partner - the primary-key join of BASELINE configs[1]): out_l is then 0, 1, 2 ... and the left table's columns
