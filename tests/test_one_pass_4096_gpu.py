@@ -92,6 +92,31 @@ def test_one_pass_4096_a_key_with_70000_rows_falls_back(dev, forced):
     assert not dev.last_join_one_pass_4096()
 
 
+@pytest.mark.parametrize("side,rows", [("right", 31), ("right", 32), ("right", 40), ("left", 15), ("left", 16), ("left", 20), ("both", 15)])
+def test_one_pass_4096_count_fields_at_and_beyond_their_limits(dev, forced, side, rows):
+    """5 bits of right rows and 4 bits of left rows per key value in the leaf kernel's table: 31 / 15 rows fit, one more is noticed (the sums of
+    the fields fall short of the rows counted) and answered by the two-level form - the oracle's result either way."""
+    rng = np.random.default_rng(rows * 3 + len(side))
+    # (sizes of their own per case: what the operator remembers about a column pair goes by address and length, and the allocator hands the same
+    # addresses out again)
+    span, n_l, n_r = (1 << 25) - 4321, 1_100_000 + 1000 * rows + 37 * len(side), 1_050_000 + 512 * rows
+    kl = rng.permutation(span)[:n_l].astype(np.int64)
+    kr = rng.permutation(span)[:n_r].astype(np.int64)
+    kl[0], kl[-1] = 0, span - 1
+    key = int(kl[5])
+    kr[kr == key] = key + 1 if key + 1 < span else key - 1
+    if side in ("right", "both"):
+        kr[rng.choice(n_r, rows if side == "right" else 31, replace=False)] = key
+    else:
+        kr[77] = key
+    if side in ("left", "both"):
+        idx = rng.choice(np.arange(10, n_l - 10), rows - 1, replace=False)
+        kl[idx] = key
+    _check(dev, kl, None, kr, None, expect_form=None)
+    fits = (side == "right" and rows <= 31) or (side == "left" and rows <= 15) or side == "both"
+    assert dev.last_join_one_pass_4096() == fits, (side, rows)
+
+
 def test_one_pass_4096_left_rows_outside_the_right_tables_window(dev, forced):
     """the right table's keys fill a 2^26 window, the left table's spread over 2^31: the window is the right table's (by_span), left rows
     outside it have no partner and are dropped by the pass"""
