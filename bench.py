@@ -157,12 +157,12 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
             return float(bin_ * rows + bout * g)
         return float((bin_ + bout) * rows)
     if levels == 1:         # one partition level: the right table travels as 2-byte words (the hash bits below the first level's digit)
-        t = {"leaf_join_wide": (8 * g if pruned else key) + 2 * n + 8 * g}
+        t = {"leaf_join_wide": (8 * g if pruned else key) + 2 * n + 8 * g, "leaf_join_wide4": (8 * g if pruned else key) + 2 * n + 8 * g}
         if kernel in t:
             return float(t[kernel])
     if pruned:
         t = {"leaf_join_direct": 8 * g + h32 + 8 * g,
-             "leaf_join_wide": 8 * g + h32 + 8 * g}
+             "leaf_join_wide": 8 * g + h32 + 8 * g, "leaf_join_wide4": 8 * g + h32 + 8 * g}
         if kernel in t:
             return float(t[kernel])
     table = {
@@ -182,6 +182,7 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
         "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
         "leaf_join_direct": key + h32 + 8 * g,
         "leaf_join_wide": key + h32 + 8 * g,         # one partition level: the first level's words in, one record per group out
+        "leaf_join_wide4": key + h32 + 8 * g,        # ... with 4-byte table entries (two workgroups per CU)
         "leaf_group_wide": key + 8 * g,
         "order_leaf_sparse": 8 * g + 20 * g,        # keyed records in, (first row, key, COUNT) out
         "leaf_group_count": (key if narrow else key + rid) + 8 * g,

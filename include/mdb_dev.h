@@ -77,7 +77,8 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * -> of the last completed join / GROUP BY operator: bit 8 = min-max pruning ran; low byte = 0 without the bitmap, else 1 +
  * log2(adjacent hashed values per bitmap bit); bit 9 = the tables were partitioned ONCE (key windows of 2^15 ... 2^23
  * values: one 9-bit level, direct-address leaf tables of 2^(k - 9) entries with 16-bit row counts; MDB_ONE_LEVEL=0 turns it
- * off; a key with 2^16 or more rows sends the operator back to two levels); bit 10 = several right tables were counted in one
+ * off; a key with 2^16 or more rows sends the operator back to two levels; joins with up to 31 right and 15 left rows per key keep 4 bytes
+ * per key value in the leaf - two workgroups per CU -, others take the 16-bit counts on the same partitioned tables: MDB_LEAF4=0); bit 10 = several right tables were counted in one
  * pass (mdb_dev_join_group_count_multi did not chain two-table operators); bit 11 = the operator ran without MDB_ORDER_FIRST
  * (any group order); bit 12 = the ordered operator took ONE 4096-digit pass per table (key windows of 2^24 ... 2^27 values, from
  * 2^24 rows in all, at most 2^27 left rows, no min-max pruning to be had: the left table's rows travel as 4-byte words that name

@@ -73,6 +73,8 @@ struct mdb_col_memo {
 	uint64_t r32_nl, r32_nr;
 	const void *lw_bad_keys;	/* the left key column (and the two row counts) for which a 16-bit row count of the one-level direct leaves */
 	uint64_t lw_bad_nl, lw_bad_nr;	/* (k_leaf_wide) overflowed last: two levels for these columns */
+	const void *l4_bad_keys;	/* ... and the one for which k_leaf_wide4's 5-bit / 4-bit counts did (more than 31 right or 15 left rows of a key): */
+	uint64_t l4_bad_nl, l4_bad_nr;	/* k_leaf_wide's 16-bit counts at once */
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
 	const void *lg_kl, *lg_kr;	/* the last join over (lg_kl, lg_nl, lg_kr, lg_nr) delivered lg_groups groups: when that is under a quarter of the */
 	uint64_t lg_nl, lg_nr, lg_groups;	/* left rows, most left rows find no partner whatever the tables' sizes and ranges say (a right table */

@@ -337,6 +337,8 @@ static void memo_drop(mdb_col_memo &m, uintptr_t a, uintptr_t b)
 		m.r32_ok = false;
 	if (hit(m.lw_bad_keys))
 		m.lw_bad_keys = NULL;
+	if (hit(m.l4_bad_keys))
+		m.l4_bad_keys = NULL;
 	if (hit(m.lg_kl) || hit(m.lg_kr))
 		m.lg_valid = false;
 }

@@ -1560,6 +1560,196 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	}
 }
 
+/* ------------------------------------------------------------------ k_leaf_wide with k_leaf_wide12's table (round 4)
+ *
+ * ONE partition level (512 digits of up to 2^14 values), joins whose right table travels as 2-byte words: the table of k_leaf_wide12 -
+ * 4 bytes per key value (right rows in 5 bits above the first left row in 27) + 4 bits of left rows - is 72 KiB where k_leaf_wide's
+ * 8 bytes per value are 128: TWO workgroups per CU, one streaming while the other clears or emits, and all 512 digits of the benchmark's
+ * variant D resident at once instead of in two rounds.  More than 31 right or 15 left rows of one key are noticed (checksums) and
+ * reported - flag 4096: the caller launches k_leaf_wide on the same partitioned tables and remembers the columns. */
+__global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per CU */) void k_leaf_wide4(gc_args a, uint32_t rem, uint32_t shift, uint32_t nsub)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
+	__shared__ unsigned long long s_red[LW_THREADS / 64];
+	__shared__ uint32_t s_red32[LW_THREADS / 64];
+	__shared__ uint32_t s_base;
+	const uint32_t T = 1u << rem, mask = T - 1u, leaf = blockIdx.x, wave = threadIdx.x >> 6, lane = mdb_lane();
+	uint32_t *const s_fc = lw_lds;			/* right rows << 27 | first left row */
+	uint32_t *const s_cl = lw_lds + T;		/* left rows per key (only of keys that have right rows), 4 bits each */
+	for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
+		s_fc[s] = 0x07FFFFFFu;
+	for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
+		s_cl[s] = 0u;
+	__syncthreads();
+	uint32_t rows_r = 0;
+	{
+		const uint16_t *const hv_r16 = reinterpret_cast<const uint16_t *>(a.hv_r);
+		for (uint32_t sub = 0; sub < nsub; sub++) {
+			const uint32_t c0 = a.cnt_r[sub * a.nleaves + leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
+			const uint16_t *const src = hv_r16 + (size_t)(leaf * nsub + sub) * a.cap_r;
+			rows_r += c;
+			for (uint32_t j0 = 0; j0 < c; j0 += 8u * LW_THREADS * LW_UNROLL) {	/* uniform trip count */
+				uint4 v[LW_UNROLL];
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					v[u] = make_uint4(0u, 0u, 0u, 0u);
+					if (j < c)
+						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+				}
+#pragma unroll
+				for (int u = 0; u < LW_UNROLL; u++) {
+					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+					const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+					if (j + 8u <= c) {
+#pragma unroll
+						for (int k = 0; k < 8; k++)
+							atomicAdd(&s_fc[(w[k >> 1] >> (16 * (k & 1))) & mask], 1u << 27);
+					} else {
+#pragma unroll
+						for (int k = 0; k < 8; k++)
+							if (j + k < c)
+								atomicAdd(&s_fc[(w[k >> 1] >> (16 * (k & 1))) & mask], 1u << 27);
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t adds = 0;
+	for (uint32_t sub = 0; sub < nsub; sub++) {
+		const uint32_t c0 = a.cnt_l[sub * a.nleaves + leaf], c = c0 < a.cap_l ? c0 : a.cap_l;
+		const uint64_t *const src = a.hv_l + (size_t)(leaf * nsub + sub) * a.cap_l;
+		for (uint32_t i0 = 0; i0 < c; i0 += 2u * LW_THREADS * LW_UNROLL) {
+			ulonglong2 v[LW_UNROLL];
+#pragma unroll
+			for (int u = 0; u < LW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+				v[u] = make_ulonglong2(0ull, 0ull);
+				if (i < c)
+					v[u] = *reinterpret_cast<const ulonglong2 *>(src + i);
+			}
+#pragma unroll
+			for (int u = 0; u < LW_UNROLL; u++) {
+				const uint32_t i = i0 + 2u * ((uint32_t)u * LW_THREADS + threadIdx.x);
+				const unsigned long long w[2] = { v[u].x, v[u].y };
+#pragma unroll
+				for (int k = 0; k < 2; k++)
+					if (i + k < c) {
+						const uint32_t idx = ((uint32_t)(w[k] >> 32) >> shift) & mask, fc = s_fc[idx];
+						if (fc >> 27) {		/* (the right rows are all counted: the top bits are final, the minimum is over the row id) */
+							atomicMin(&s_fc[idx], (fc & 0xF8000000u) | (uint32_t)w[k]);
+							atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
+							adds++;
+						}
+					}
+			}
+		}
+	}
+	__syncthreads();
+	/* groups: wave w owns the values [w * T / 16, (w + 1) * T / 16) - see k_leaf_wide12 */
+	const uint32_t per_wave = T / (LW_THREADS / 64), words_per_wave = per_wave / 8;
+	uint32_t mine = 0, sum_cl = 0, sum_cr = 0;
+	for (uint32_t wi = lane; wi < words_per_wave; wi += MDB_WAVE) {
+		const uint32_t cw = s_cl[wave * words_per_wave + wi];
+		mine += (uint32_t)__popc((cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x11111111u);
+		sum_cl += (((cw & 0x0F0F0F0Fu) + ((cw >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24;
+	}
+	{
+		uint32_t t = mine;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
+		if (lane == 0)
+			s_red32[wave] = t;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+#pragma unroll
+		for (int w = 0; w < LW_THREADS / 64; w++)
+			total += s_red32[w];
+		uint32_t nb = 0xFFFFFFFFu;
+		if (total) {
+			nb = atomicAdd(a.rec_count, total);
+			if (nb + total > a.rec_cap) {
+				mdb_raise(a.status, 8u);
+				nb = 0xFFFFFFFFu;
+			} else {
+				atomicAdd(a.rec_valid, total);
+			}
+		}
+		s_base = nb;
+	}
+	__syncthreads();
+	const uint32_t base = s_base;
+	uint32_t run = 0;
+	{
+		uint32_t t = lane < wave ? s_red32[lane] : 0u;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
+		run = base + t;
+	}
+	const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
+	uint32_t cmax = 0, jsum = 0, last_first = 0;
+	for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {	/* (per_wave >= 4: tables of 64 values at least; lanes beyond per_wave idle) */
+		const uint32_t sl = s_begin + s0;
+		const bool live = s0 + lane < per_wave;
+		const uint32_t fc = live ? s_fc[sl] : 0u, cl = live ? (s_cl[sl >> 3] >> nib) & 15u : 0u, cr = fc >> 27;
+		sum_cr += cr;
+		const uint64_t m = __ballot(cl != 0u);
+		if (!m)
+			continue;
+		const uint32_t pos = run + (uint32_t)__popcll(m & mdb_lanemask_lt());
+		run += (uint32_t)__popcll(m);
+		if (cl && base != 0xFFFFFFFFu) {
+			const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr;
+			jsum += c;
+			cmax = c > cmax ? c : cmax;
+			last_first = first > last_first ? first : last_first;
+			if (a.keyed_cbits)
+				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | ((unsigned long long)((leaf << rem) | sl) << a.keyed_cbits) | c;
+			else
+				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
+		}
+	}
+	if (cmax) {
+		if (a.keyed_cbits && (cmax >> a.keyed_cbits))
+			mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
+		if (!a.keyed_cbits && (cmax >> (32 - (a.kbits < 32 ? a.kbits : 31))))
+			mdb_raise(a.status, 16u);	/* ... a 4-byte record */
+	}
+	/* a count field that overflowed carried into its neighbour (or out of the word): the fields then sum to less than was added */
+	const unsigned long long sums = ((unsigned long long)sum_cl << 32) | sum_cr, want = (unsigned long long)adds << 32;
+	const unsigned long long diff = lw_block_sum(sums - want, s_red);
+	if (diff != (unsigned long long)rows_r) {
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 4096u);
+		return;
+	}
+	const unsigned long long joined = lw_block_sum((unsigned long long)jsum, s_red);
+	if (threadIdx.x == 0 && joined)
+		atomicAdd(a.joined, joined);
+#pragma unroll
+	for (int o = 32; o; o >>= 1) {
+		const uint32_t other = (uint32_t)__shfl_xor((int)last_first, o, MDB_WAVE);
+		last_first = other > last_first ? other : last_first;
+	}
+	__syncthreads();	/* (s_red is free again) */
+	if (lane == 0)
+		s_red[wave] = last_first;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t m = 0;
+#pragma unroll
+		for (int w = 0; w < LW_THREADS / 64; w++)
+			m = (uint32_t)s_red[w] > m ? (uint32_t)s_red[w] : m;
+		if (m)
+			atomicMax(a.status + 9, m);
+	}
+}
+
 /* ------------------------------------------------------------------ semi-join filter (compact narrow form)
  *
  * Bitmap of the hashed key values the RIGHT table holds, one bit per 2^coarse adjacent values, built from its
@@ -2286,6 +2476,11 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		a.heavy_l = hl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hl;
 		a.heavy_r = hr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hr;
 	}
+	/* one-level joins with 2-byte right words: k_leaf_wide4's 4 bytes per key value (two workgroups per CU) unless these columns are known to
+	 * hold more than 31 right or 15 left rows of a key (MDB_LEAF4=0 switches it off) */
+	const bool leaf4 = st->one_level && has_r && pr.w16 && records && !null_group && n_l <= (1ull << 27) && st->key_bits >= (uint32_t)pl.bits_total + 10u &&
+			   !(ctx->l4_bad_keys == keys_l && ctx->l4_bad_nl == n_l && ctx->l4_bad_nr == n_r) &&
+			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
 	{
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
@@ -2305,7 +2500,11 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "one-level direct leaves: the tables are not in the first-level layout");
 			const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
 			const size_t lds = ((size_t)(has_r ? 8 : 6) << rem);
-			if (has_r && pr.w16) {
+			if (has_r && pr.w16 && leaf4) {
+				const size_t lds4 = ((size_t)4 << rem) + (((size_t)1 << rem) / 2 < 64 ? 64 : ((size_t)1 << rem) / 2);
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+				MDB_LAUNCH_LDS(ctx, "leaf_join_wide4", k_leaf_wide4, pl.nleaves, LW_THREADS, lds4, a, rem, shift, pl.nsub);
+			} else if (has_r && pr.w16) {
 				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 				MDB_LAUNCH_LDS(ctx, "leaf_join_wide", (k_leaf_wide<true, true>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
 			} else if (has_r) {
@@ -2362,6 +2561,24 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	uint32_t *first_out = out_first ? out_first : sel;
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (leaf4 && ((uint32_t)h[1] & 4096u) && !((uint32_t)h[1] & (2u | 128u))) {
+		/* a key with more rows than k_leaf_wide4's count fields hold: the same partitioned tables through k_leaf_wide (16-bit counts), now
+		 * and for these columns */
+		ctx->l4_bad_keys = keys_l;
+		ctx->l4_bad_nl = n_l;
+		ctx->l4_bad_nr = n_r;
+		uint32_t *hw = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 528;
+		hw[0] = (uint32_t)h[1] & ~(4096u | 256u | 16u | 8u);
+		MDB_HIP(ctx, hipMemcpyAsync(ctx->d_status, hw, 4, hipMemcpyHostToDevice, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 12, ctx->stream));	/* record-list length, joined rows */
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 8, 0, 8, ctx->stream));	/* records, largest first row */
+		const uint32_t rem = st->key_bits - pl.bits_total, shift = 32u - st->key_bits;
+		const size_t lds = (size_t)8 << rem;
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_join_wide", (k_leaf_wide<true, true>), pl.nleaves, LW_THREADS, lds, a, rem, shift, pl.nsub);
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
 	if ((uint32_t)h[1] & 128u)
 		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
 	if (st->nextra && ((uint32_t)h[1] & (2u | 64u | 2048u)))

@@ -153,3 +153,25 @@ def test_one_pass_4096_at_scale_equals_the_two_level_form(dev):
         assert out["1"][3] == out["0"][3]
         del out
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("side,rows", [("right", 16), ("right", 31), ("right", 32), ("right", 300), ("left", 15), ("left", 16), ("left", 200)])
+def test_one_level_leaf_with_4_byte_table_entries_and_its_fallback(dev, side, rows):
+    """Key windows of up to 2^23 values (one 9-bit level): k_leaf_wide4 keeps 5 bits of right rows and 4 bits of left rows per key value
+    (two workgroups per CU); a key with more is noticed and the SAME partitioned tables go through k_leaf_wide's 16-bit counts - the
+    oracle's result, one partition level, on the first call and on the remembered verdict."""
+    rng = np.random.default_rng(rows * 5 + len(side))
+    span, n_l, n_r = (1 << 21) - 999, 1_300_000 + 1000 * rows + 41 * len(side), 1_200_000 + 640 * rows
+    kl = rng.permutation(span)[:n_l].astype(np.int64)
+    kr = rng.integers(0, span, n_r, dtype=np.int64)
+    kl[0], kl[-1] = 0, span - 1
+    key = int(kl[9])
+    kr[kr == key] = key + 1 if key + 1 < span else key - 1
+    # (random right keys: a few values per key at most - far below the fields' limits - besides the planted one)
+    if side == "right":
+        kr[rng.choice(n_r, rows, replace=False)] = key
+    else:
+        kr[123] = key
+        kl[rng.choice(np.arange(20, n_l - 20), rows - 1, replace=False)] = key
+    _check(dev, kl, None, kr, None, expect_form=None, rounds=3)
+    assert dev.last_join_form() == 2 and dev.last_join_levels() == 1
