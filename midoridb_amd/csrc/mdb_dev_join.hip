@@ -1225,6 +1225,10 @@ __device__ static inline void lw12_barrier(void)
 #define LW12_MAX_CR 31u
 #define LW12_MAX_CL 15u
 
+/* NX = 1: a further right table on the same key (A JOIN B ON a = b JOIN C ON a = c GROUP BY a: BASELINE configs[4]) - partitioned like the
+ * first one; its rows are counted into the (still unused) 4-bit fields, the two counts multiplied into the 5-bit field before the left rows
+ * come (a product beyond 31, or 16 rows of a key in the further table: flag 1024 like every count that does not fit). */
+template <int NX>
 __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t rem /* hash bits below the digit */, uint32_t nsub)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	__shared__ uint32_t s_red32[LW_THREADS / 64];
 	__shared__ uint32_t s_base;
 	/* [buffer][side][sub-region]: first 16-byte chunk (prefix) and words of a digit's sub-regions, side 0 left (4 words per chunk), 1 right (8) */
-	__shared__ uint32_t s_chunk0[2][2][17], s_cnt[2][2][16];		/* (nsub <= 16) */
+	__shared__ uint32_t s_chunk0[2][2 + NX][17], s_cnt[2][2 + NX][16];		/* (nsub <= 16; side 2: the further right table) */
 	__shared__ uint32_t s_wlast[2][LW_THREADS / 64], s_carry[2];
 	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
 	const uint32_t T = 1u << rem, mask = T - 1u;
@@ -1241,34 +1245,37 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	uint32_t leaf = blockIdx.x, buf = 0;
 	if (leaf >= a.nleaves || nsub != LW12_NSUB)
 		return;
-	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 31: (side, sub-region) */
+	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 16 * (2 + NX) - 1: (side, sub-region) */
 		const uint32_t side = threadIdx.x >> 4, j = threadIdx.x & 15u;
-		if (threadIdx.x >= 32u || j >= nsub)
+		if (threadIdx.x >= 16u * (2u + NX) || j >= nsub)
 			return 0u;
-		const uint32_t c0 = (side ? a.cnt_r : a.cnt_l)[j * a.nleaves + d], cap = side ? a.cap_r : a.cap_l;
+		const uint32_t c0 = (side == 0 ? a.cnt_l : side == 1 ? a.cnt_r : a.cnt_x[0])[j * a.nleaves + d];
+		const uint32_t cap = side == 0 ? a.cap_l : side == 1 ? a.cap_r : a.cap_x[0];
 		return c0 < cap ? c0 : cap;
 	};
-	auto seg_prefix = [&](uint32_t b) {		/* threads 0, 1 */
+	auto seg_prefix = [&](uint32_t b) {		/* threads 0 .. 1 + NX */
 		uint32_t run = 0;
 		for (uint32_t j = 0; j < nsub; j++) {
 			s_chunk0[b][threadIdx.x][j] = run;
-			run += threadIdx.x ? (s_cnt[b][1][j] + 7u) >> 3 : (s_cnt[b][0][j] + 3u) >> 2;
+			run += threadIdx.x ? (s_cnt[b][threadIdx.x][j] + 7u) >> 3 : (s_cnt[b][0][j] + 3u) >> 2;
 		}
 		s_chunk0[b][threadIdx.x][nsub] = run;
 	};
-	uint4 vr[LW12_RB], vl[LW12_LB];
+	uint4 vr[LW12_RB], vl[LW12_LB / 2];	/* (the left table's chunks 4 .. 7 take the right table's registers once its words are counted) */
 	uint32_t nvr = 0, nvl = 0;	/* words of each chunk, 4 bits each */
 	/* chunk q of a side lies in the last sub-region j whose first chunk c0[j] is <= q, at word (d * 8 + j) * cap + (q - c0[j]) * per of the
 	 * table's buffer, and holds min(per, cnt[j] - (q - c0[j]) * per) words.  The three per-region terms of that - where the region's
 	 * chunk 0 would sit minus c0[j] * per, and cnt[j] + c0[j] * per - are the same for every thread: read once per digit and side, kept in
 	 * scalar registers, selected by seven compares (as a search loop over LDS per chunk, 12 chunks per thread and digit, and then as
 	 * 135 instructions of 64-bit address arithmetic per chunk, this was the largest single part of the kernel) */
-	auto fetch_all = [&](uint32_t d, uint32_t b, const int sides /* 1 left, 2 right, 3 both */) {
+	auto fetch_all = [&](uint32_t d, uint32_t b, const int sides /* 1 left (chunks 0 .. 3), 8 left (chunks 4 .. 7, into the right table's registers), 2 right,
+							       * 4 the further right table (into the right table's registers) */) {
 #pragma unroll
-		for (int side = 1; side >= 0; side--) {
-			if (!(sides & (1 << side)))
+		for (int side = 1 + NX; side >= 0; side--) {
+			if (!(sides & (1 << side)) && !(side == 0 && (sides & 8)))
 				continue;
-			const uint32_t per = side ? 8u : 4u, cap = side ? a.cap_r : a.cap_l;
+			const int u_lo = (side == 0 && !(sides & 1)) ? LW12_LB / 2 : 0, u_hi = side ? LW12_RB : ((sides & 8) ? LW12_LB : LW12_LB / 2);
+			const uint32_t per = side ? 8u : 4u, cap = side == 0 ? a.cap_l : side == 1 ? a.cap_r : a.cap_x[0];
 			uint32_t c0[LW12_NSUB + 1], delta[LW12_NSUB], endq[LW12_NSUB];
 #pragma unroll
 			for (int j = 0; j <= LW12_NSUB; j++)
@@ -1279,9 +1286,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				delta[j] = (d * LW12_NSUB + (uint32_t)j) * cap - c0[j] * per;	/* (word index: below 2^32, checked by the caller) */
 				endq[j] = cnt + c0[j] * per;
 			}
-			uint32_t nvs = 0u;
+			uint32_t nvs = side ? 0u : nvl;
 #pragma unroll
-			for (int u = 0; u < (side ? LW12_RB : LW12_LB); u++) {
+			for (int u = u_lo; u < u_hi; u++) {
 				const uint32_t q = (uint32_t)u * LW_THREADS + threadIdx.x, qp = q * per;
 				uint4 v = make_uint4(0u, 0u, 0u, 0u);
 				uint32_t nv = 0u;
@@ -1294,16 +1301,20 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 						en = in ? endq[j] : en;
 					}
 					nv = en - qp < per ? en - qp : per;
-					if (side)
+					if (side == 1)
 						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_r) + (dl + qp));
+					else if (side == 2)
+						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_x[0]) + (dl + qp));
 					else
 						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_l) + (dl + qp));
 				}
 				if (side)
 					vr[u < LW12_RB ? u : 0] = v;
+				else if (u < LW12_LB / 2)
+					vl[u < LW12_LB / 2 ? u : 0] = v;
 				else
-					vl[u] = v;
-				nvs |= nv << (4 * u);
+					vr[u >= LW12_LB / 2 ? u - LW12_LB / 2 : 0] = v;
+				nvs = (nvs & ~(15u << (4 * u))) | (nv << (4 * u));
 			}
 			if (side)
 				nvr = nvs;
@@ -1313,12 +1324,12 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	};
 	{
 		const uint32_t c = seg_count(leaf);
-		if (threadIdx.x < 32u)
+		if (threadIdx.x < 16u * (2u + NX))
 			s_cnt[0][threadIdx.x >> 4][threadIdx.x & 15u] = c;
 		if (threadIdx.x == 0)
 			s_carry[0] = 0u;
 		__syncthreads();
-		if (threadIdx.x < 2u)
+		if (threadIdx.x < 2u + NX)
 			seg_prefix(0);
 		__syncthreads();
 		fetch_all(leaf, 0, 2);
@@ -1330,7 +1341,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	for (; leaf < a.nleaves; leaf += gridDim.x, buf ^= 1u) {
 		const uint32_t next = leaf + gridDim.x;
 		const uint32_t nch_l = s_chunk0[buf][0][nsub], nch_r = s_chunk0[buf][1][nsub];
-		if (nch_l > LW12_LB * LW_THREADS || nch_r > LW12_RB * LW_THREADS) {	/* (the caller sized the regions so that this cannot happen) */
+		if (nch_l > LW12_LB * LW_THREADS || nch_r > LW12_RB * LW_THREADS || (NX && s_chunk0[buf][NX ? 2 : 1][nsub] > LW12_RB * LW_THREADS)) {	/* (the caller sized the regions so that this cannot happen) */
 			bad = true;
 			break;
 		}
@@ -1362,16 +1373,78 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			}
 			radds += nv;
 		}
-		if (threadIdx.x < 32u)
+		if (threadIdx.x < 16u * (2u + NX))
 			s_cnt[buf ^ 1u][threadIdx.x >> 4][threadIdx.x & 15u] = next_c;
+		bool prod_bad = false;
+		if (NX) {
+			/* the further right table: its words into the registers the first one's have left, its rows into the 4-bit fields; then
+			 * the 5-bit field becomes the product of the two counts and the 4-bit fields are the left table's again */
+			fetch_all(leaf, buf, 4);
+			uint32_t xadds = 0;
+#pragma unroll
+			for (int u = 0; u < LW12_RB; u++) {
+				const uint32_t w[4] = { vr[u].x, vr[u].y, vr[u].z, vr[u].w }, nv = (nvr >> (4 * u)) & 15u;
+#pragma unroll
+				for (uint32_t k = 0; k < 8u; k++)
+					if (k < nv) {
+						const uint32_t idx = (w[k >> 1] >> (16u * (k & 1u))) & mask;
+						atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
+					}
+				xadds += nv;
+			}
+			lw12_barrier();
+			uint32_t sum_b = 0, sum_x = 0;
+			for (uint32_t s0 = 0; s0 < T; s0 += LW_THREADS * 8u) {		/* (a thread: eight consecutive values = one word of 4-bit fields) */
+				const uint32_t wi = (s0 >> 3) + threadIdx.x;
+				if (wi >= T / 8u)
+					continue;
+				const uint32_t cw = s_cl[wi];
+				const uint4 f0 = *reinterpret_cast<const uint4 *>(s_fc + wi * 8u), f1 = *reinterpret_cast<const uint4 *>(s_fc + wi * 8u + 4u);
+				uint32_t f[8] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w };
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const uint32_t cb = f[e] >> 27, cx = (cw >> (4 * e)) & 15u, pr = cb * cx;
+					sum_b += cb;
+					sum_x += cx;
+					prod_bad = prod_bad || pr > LW12_MAX_CR;
+					f[e] = (pr << 27) | 0x07FFFFFFu;
+				}
+				*reinterpret_cast<uint4 *>(s_fc + wi * 8u) = make_uint4(f[0], f[1], f[2], f[3]);
+				*reinterpret_cast<uint4 *>(s_fc + wi * 8u + 4u) = make_uint4(f[4], f[5], f[6], f[7]);
+				s_cl[wi] = 0u;
+			}
+			/* (counts that overflowed their fields: the fields sum to less than the rows counted) */
+			unsigned long long d2 = (((unsigned long long)sum_x << 32) | sum_b) - (((unsigned long long)xadds << 32) | radds);
+#pragma unroll
+			for (int o = 32; o; o >>= 1)
+				d2 += __shfl_down(d2, o, MDB_WAVE);
+			const uint64_t pb = __ballot(prod_bad);
+			lw12_barrier();
+			if (lane == 0) {
+				s_red[wave] = d2;
+				s_red32[wave] = pb ? 1u : 0u;
+			}
+			lw12_barrier();
+			unsigned long long t = 0ull;
+			uint32_t anyp = 0u;
+#pragma unroll
+			for (int w = 0; w < LW_THREADS / 64; w++) {
+				t += s_red[w];
+				anyp |= s_red32[w];
+			}
+			prod_bad = anyp != 0u || t != 0ull;
+			radds = 0;	/* (the 5-bit fields now hold products: their sum is not the rows counted - checked above) */
+		}
+		fetch_all(leaf, buf, 8);	/* (the right words are counted: their registers take the left table's chunks 4 .. 7) */
 		lw12_barrier();
-		if (threadIdx.x < 2u)
+		if (threadIdx.x < 2u + NX)
 			seg_prefix(buf ^ 1u);
 #pragma unroll
 		for (int u = 0; u < LW12_LB; u++) {
 			if ((uint32_t)u * LW_THREADS >= nch_l)	/* (uniform) */
 				continue;
-			const uint32_t w[4] = { vl[u].x, vl[u].y, vl[u].z, vl[u].w }, nv = (nvl >> (4 * u)) & 15u;
+			const uint4 vw = u < LW12_LB / 2 ? vl[u < LW12_LB / 2 ? u : 0] : vr[u >= LW12_LB / 2 ? u - LW12_LB / 2 : 0];
+			const uint32_t w[4] = { vw.x, vw.y, vw.z, vw.w }, nv = (nvl >> (4 * u)) & 15u;
 			/* the last header among this thread's words, the nearest earlier lane's, the nearest earlier wave's of this round, else what the
 			 * previous round left */
 			uint32_t my_last = 0u;
@@ -1516,7 +1589,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			if (!a.keyed_cbits && (cmax >> (32 - (a.kbits < 32 ? a.kbits : 31))))
 				mdb_raise(a.status, 16u | (a.rec32 ? 512u : 0u));	/* ... a 4-byte record (written on a remembered verdict: redone with 8-byte ones) */
 		}
-		const unsigned long long sums = ((unsigned long long)sum_cl << 32) | sum_cr;	/* low half: right rows counted, high half: left rows counted */
+		const unsigned long long sums = ((unsigned long long)sum_cl << 32) | (NX ? 0u : sum_cr);	/* low half: right rows counted, high half: left rows counted */
 		/* a count field that overflowed carried into its neighbour (or out of the word): the fields then sum to less than was added */
 		const unsigned long long want = ((unsigned long long)adds << 32) | radds;
 		unsigned long long diff = sums - want;
@@ -1531,7 +1604,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 #pragma unroll
 		for (int w = 0; w < LW_THREADS / 64; w++)
 			diff += s_red[w];
-		if (diff != 0ull) {
+		if (diff != 0ull || prod_bad) {
 			bad = true;
 			break;
 		}
@@ -2124,14 +2197,15 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		const char *e = getenv("MDB_WIDE12"), *e2 = getenv("MDB_WIDE12_MIN");
 		const uint64_t min_rows = e2 && atoll(e2) > 0 ? (uint64_t)atoll(e2) : (1ull << 24);
 		st->wide12 = !st->one_level && st->narrow && st->has_r && st->key_bits > 9u + LW_MAX_REM && st->key_bits <= 12u + LW_MAX_REM + 1u && st->fast &&
-			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && !st->nextra && !st->keys32 &&
+			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && st->nextra <= 1 && !st->keys32 &&
 			     !st->prunable /* (a right table that covers part of the left table's key range: min-max pruning drops most left rows first) */ &&
 			     !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
 			     st->n_l + st->n_r_cap >= min_rows && st->n_l <= (1ull << 27) /* (k_leaf_wide12 keeps a first row in 27 bits) */ &&
 			     st->n_r_cap < 0xF0000000ull && !(e && e[0] == '0');
 		/* ... and a digit's words must fit the leaf kernel's registers: 8 sub-regions of at most LW12_LB (LW12_RB) chunks per thread */
 		if (st->wide12 && ((uint64_t)mdb_scatter4096_cap(ctx, st->n_l, true) * LW12_NSUB > (uint64_t)LW12_LB * LW_THREADS * 4u ||
-				   (uint64_t)mdb_scatter4096_cap(ctx, st->n_r_cap, false) * LW12_NSUB > (uint64_t)LW12_RB * LW_THREADS * 8u))
+				   (uint64_t)mdb_scatter4096_cap(ctx, st->n_r_cap, false) * LW12_NSUB > (uint64_t)LW12_RB * LW_THREADS * 8u ||
+				   (st->nextra && (uint64_t)mdb_scatter4096_cap(ctx, st->xn[0], false) * LW12_NSUB > (uint64_t)LW12_RB * LW_THREADS * 8u)))
 			st->wide12 = false;
 	}
 	if (st->wide12) {
@@ -2222,7 +2296,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		      : st->one_level ? mdb_partition_level0_arena_bytes(st->n_r_cap, st->b1)
 				      : mdb_partition_arena_bytes(st->n_r_cap, st->b1, st->b2, false, st->fast);
 	for (int x = 0; x < st->nextra; x++)
-		need += mdb_partition_arena_bytes(st->xn[x], st->b1, st->b2, false, st->fast) + 512;
+		need += st->wide12 ? mdb_scatter4096_arena_bytes(ctx, st->xn[x], false) : mdb_partition_arena_bytes(st->xn[x], st->b1, st->b2, false, st->fast) + 512;
 	{
 		uint32_t kb = 0;
 		int s1 = 0, s2 = 0;
@@ -2302,6 +2376,22 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		pl.w32 = pr.w32 = true;
 		pr.w16 = true;
 	}
+	mdb_part_result px[GC_MAX_EXTRA];
+	memset(px, 0, sizeof(px));
+	if (st->wide12 && st->nextra) {
+		/* the further right table like the first one; its keys outside the window are dropped, not reported: the window holds every key of
+		 * the left table, so such a key joins nothing */
+		void *xb = NULL;
+		uint32_t *xcur = NULL;
+		const uint32_t cap_x = mdb_scatter4096_cap(ctx, st->xn[0], false);
+		rc = mdb_scatter4096(ctx, st->xkeys[0], st->xnull[0], st->xn[0], st->key_lo, st->key_bits, false, (uint32_t)((1ull << st->key_bits) - 1ull), cap_x, false,
+				     "part_scatter_wide12_r", &xb, &xcur);
+		if (rc)
+			return rc;
+		px[0].hv = (uint64_t *)xb;
+		px[0].leaf_cnt = xcur;
+		px[0].leaf_cap = cap_x;
+	}
 	if (has_r && !st->wide12) {
 		if (n_r > st->n_r_cap)
 			return mdb_set_err(ctx, -MIDORIDB_ERROR, "right table larger than announced at begin()");
@@ -2341,9 +2431,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return rc;
 		pl = st->pl;
 	}
-	mdb_part_result px[GC_MAX_EXTRA];
-	memset(px, 0, sizeof(px));
-	if (st->nextra) {
+	if (st->nextra && !st->wide12) {
 		/* the further right tables, partitioned exactly like the first: same window, same bits, 4-byte words.  Their keys
 		 * outside the window are dropped, not reported: the window holds every key of the left table (or of the first right
 		 * table, with the left one pruned to it), so such a key joins nothing */
@@ -2492,8 +2580,13 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			const uint32_t rem = st->key_bits - 12u;
 			const size_t lds = ((size_t)4 << rem) + ((size_t)1 << rem) / 2;
 			const uint32_t wgrid = pl.nleaves < (uint32_t)ctx->num_cus ? pl.nleaves : (uint32_t)ctx->num_cus;
-			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12, wgrid, LW_THREADS, lds, a, rem, pl.nsub);
+			if (st->nextra) {
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<1>, wgrid, LW_THREADS, lds, a, rem, pl.nsub);
+			} else {
+				MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<0>, wgrid, LW_THREADS, lds, a, rem, pl.nsub);
+			}
 		} else if (st->one_level) {
 			/* ... by ALL the hash bits below the first level's 9 (k_leaf_wide) */
 			if (!pl.nsub || !pl.leaf_cap || (has_r && (!pr.nsub || !pr.w32 || pr.nsub != pl.nsub || pr.nleaves != pl.nleaves)))

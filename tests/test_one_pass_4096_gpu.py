@@ -175,3 +175,45 @@ def test_one_level_leaf_with_4_byte_table_entries_and_its_fallback(dev, side, ro
         kl[rng.choice(np.arange(20, n_l - 20), rows - 1, replace=False)] = key
     _check(dev, kl, None, kr, None, expect_form=None, rounds=3)
     assert dev.last_join_form() == 2 and dev.last_join_levels() == 1
+
+
+@pytest.mark.parametrize("shape", ["unique", "dups", "nulls", "product_beyond_31", "further_table_16_rows_of_a_key", "keys_outside_the_window"])
+def test_one_pass_4096_three_tables_on_one_key(dev, forced, shape):
+    """A JOIN B ON a = b JOIN C ON a = c GROUP BY a (BASELINE configs[4]'s shape) through the one-pass form: the further right table goes
+    through the same 4096-digit pass, its rows are counted into the leaf's 4-bit fields and the two right counts multiplied before the left
+    rows come.  Oracle: the two-table oracle chained; counts that do not fit the fields are answered by the two-level form."""
+    rng = np.random.default_rng(len(shape) * 11)
+    span = (1 << 25) - 777
+    n = 1_150_000 + 97 * len(shape)
+    kl = rng.permutation(span)[:n].astype(np.int64)
+    kl[0], kl[-1] = 0, span - 1
+    # (right tables of at most 2 and 3 rows per key: products of counts that fit the leaf's 5-bit field)
+    pb, pc = rng.permutation(n), rng.permutation(n)
+    rb = np.concatenate([kl[pb[: n // 2]], kl[pb[: n // 2 - 500]]])
+    rc = np.concatenate([kl[pc[: n // 3]], kl[pc[: n // 3]], kl[pc[: n // 3 - 900]]])
+    if shape == "unique":
+        rb, rc = rng.permutation(kl)[: n - 500], rng.permutation(kl)[: n - 900]
+    elif shape == "product_beyond_31":
+        rb[:8], rc[:8] = kl[11], kl[11]                                             # 8 x 8 = 64 > 31
+    elif shape == "further_table_16_rows_of_a_key":
+        rc[:16] = kl[13]
+        rb[5] = kl[13]
+    elif shape == "keys_outside_the_window":
+        rc = rc.copy()
+        rc[::50] = span + 10**9 + rng.integers(0, 10**6, len(rc[::50]))             # dropped: they join nothing
+    nl = nb = nc = None
+    if shape == "nulls":
+        nl, nb, nc = rng.random(n) < 0.03, rng.random(len(rb)) < 0.05, rng.random(len(rc)) < 0.08
+        nl[0] = nl[-1] = False
+    ek, ec, ef, _ = orc.join_group_count(kl, nl, rb, nb)
+    k2, c2, f2, _ = orc.join_group_count(ek, None, rc, nc)
+    ec, ef, ek = ec[f2] * c2, ef[f2], k2
+    dl, db, dc = dev.to_dev(kl), dev.to_dev(rb), dev.to_dev(rc)
+    for round_ in range(2):
+        k, c, f, j = dev.join_group_count_multi(dl, dev.nullbits_dev(nl), [(db, dev.nullbits_dev(nb)), (dc, dev.nullbits_dev(nc))])
+        assert np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, round_)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef)
+        assert j == int(ec.sum())
+    # (counts that do not fit: the two-level form, or the chain of two-table operators - whose own calls may take the one-pass form)
+    if shape not in ("product_beyond_31", "further_table_16_rows_of_a_key"):
+        assert dev.last_join_multi() and dev.last_join_one_pass_4096(), shape
