@@ -1225,6 +1225,12 @@ grouped:
 		for (int c = 0; c < ncols && rc == MIDORIDB_OK; c++) {
 			int key = src[c];
 			memcpy(res->colname[c], keys[key], MDB_NAME_LEN);
+			for (int i = 0; s->sel_alias && !s->select_all && i < s->nsel; i++)	/* `item AS name` names the column (the first alias of an item wins) */
+				if (s->sel_alias[i][0] && (key_tbl[key] < 0 ? s->sel[i]->kind == MDB_EX_COUNT
+									      : s->sel[i]->kind == MDB_EX_FIELD && s->sel[i]->tbl_idx == key_tbl[key] && s->sel[i]->col_idx == key_col[key])) {
+					mdb_copy_name(res->colname[c], s->sel_alias[i]);
+					break;
+				}
 			if (!keep) {	/* (a result kept on the device gets its host columns on first use, mdb_result_fetch) */
 				res->data[c] = mdb_dev_host_alloc((size_t)(out_rows ? out_rows : 1) * 8);	/* pinned when large */
 				if (!res->data[c]) {

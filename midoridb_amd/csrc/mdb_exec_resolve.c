@@ -13,6 +13,39 @@ bool field_eq(const struct mdb_expr *a, const struct mdb_expr *b)
 	return a->kind == MDB_EX_FIELD && b->kind == MDB_EX_FIELD && a->tbl_idx == b->tbl_idx && a->col_idx == b->col_idx;
 }
 
+/* a bare name that is a select-list alias stands for the aliased item: a column (any clause) or COUNT(*) (HAVING); names of real columns win */
+static void subst_alias(const struct mdb_select *s, struct mdb_expr *e, bool count_ok)
+{
+	if (!e)
+		return;
+	if (e->kind == MDB_EX_NAME && s->sel_alias) {
+		for (int t = 0; t < s->ntabs; t++)
+			for (int c = 0; c < s->tabs[t].t->ncols; c++)
+				if (strcmp(s->tabs[t].t->cols[c].name, e->col) == 0)
+					return;
+		for (int i = 0; i < s->nsel; i++) {
+			if (!s->sel_alias[i][0] || strcmp(s->sel_alias[i], e->col) != 0)
+				continue;
+			const struct mdb_expr *to = s->sel[i];
+			if (to->kind == MDB_EX_FIELD) {		/* (resolved: the select list is resolved first) */
+				e->kind = MDB_EX_FIELD;
+				mdb_copy_name(e->tbl, to->tbl);
+				mdb_copy_name(e->col, to->col);
+				e->tbl_idx = to->tbl_idx;
+				e->col_idx = to->col_idx;
+				e->type = to->type;
+			} else if (to->kind == MDB_EX_COUNT && count_ok && to->nkids == 0) {
+				e->kind = MDB_EX_COUNT;
+				e->op = to->op;
+				e->ival = to->ival;
+			}
+			return;
+		}
+	}
+	for (int i = 0; i < e->nkids; i++)
+		subst_alias(s, e->kids[i], count_ok);
+}
+
 int resolve_expr(struct mdb_select *s, struct mdb_expr *e, char *err, size_t errlen)
 {
 	int rc;
@@ -269,6 +302,29 @@ int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, siz
 			return -MIDORIDB_ERROR;
 		}
 	}
+	/* `column AS name` / `COUNT(*) AS name` (upstream parses and checks aliases, then fails at execution: "cannot build columns hashtable" -
+	 * SURVEY.md 8a D7; here the alias names the result column and may stand for its item in GROUP BY, HAVING and ORDER BY) */
+	for (int i = 0; i < s->nsel; i++) {
+		struct mdb_expr *e = s->sel[i];
+		if (e->kind != MDB_EX_ALIAS || e->nkids != 1)
+			continue;
+		struct mdb_expr *kid = e->kids[0];
+		if (kid->kind != MDB_EX_NAME && kid->kind != MDB_EX_FIELD && kid->kind != MDB_EX_COUNT)
+			continue;	/* (an aliased expression: rejected below like the expression itself) */
+		if (!s->sel_alias && !(s->sel_alias = calloc((size_t)s->nsel, sizeof(*s->sel_alias)))) {
+			ERR("out of memory\n");
+			return -MIDORIDB_NOMEM;
+		}
+		for (int k = 0; k < i; k++)
+			if (s->sel_alias[k][0] && strcmp(s->sel_alias[k], e->col) == 0) {
+				ERR("duplicate alias: '%.128s'\n", e->col);
+				return -MIDORIDB_ERROR;
+			}
+		mdb_copy_name(s->sel_alias[i], e->col);
+		e->nkids = 0;
+		mdb_expr_free(e);
+		s->sel[i] = kid;
+	}
 	for (int i = 0; i < s->nsel; i++) {
 		struct mdb_expr *e = s->sel[i];
 		if (e->kind == MDB_EX_COUNT) {
@@ -278,7 +334,7 @@ int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, siz
 			continue;
 		}
 		if (e->kind != MDB_EX_NAME && e->kind != MDB_EX_FIELD) {
-			ERR("only columns and COUNT(*) are supported in the select list (aliases and expressions are not executed by the reference)\n");
+			ERR("only columns and COUNT(*) - with or without an alias - are supported in the select list (expressions are not executed by the reference)\n");
 			return -MIDORIDB_ERROR;
 		}
 		if ((rc = resolve_expr(s, e, err, errlen)))
@@ -296,6 +352,7 @@ int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, siz
 		return -MIDORIDB_ERROR;
 	}
 	for (int i = 0; i < s->ngroup; i++) {
+		subst_alias(s, s->group[i], false);
 		if (s->group[i]->kind != MDB_EX_NAME && s->group[i]->kind != MDB_EX_FIELD) {
 			ERR("group-by clauses support only fields and aliases\n");
 			return -MIDORIDB_ERROR;
@@ -337,6 +394,7 @@ int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, siz
 			return -MIDORIDB_ERROR;
 		}
 		if (s->having) {
+			subst_alias(s, s->having, true);
 			if ((rc = resolve_expr(s, s->having, err, errlen)) || (rc = check_predicate(s->having, "having", err, errlen)))
 				return rc;
 			/* fields must come from the SELECT list (check_having_clause_inselect, semantic_select.c:1953-2001) */
@@ -353,6 +411,7 @@ int resolve_select(struct mdb_catalog *cat, struct mdb_select *s, char *err, siz
 		}
 		for (int i = 0; i < s->norder; i++) {
 			struct mdb_expr *o = s->order[i];
+			subst_alias(s, o, false);
 			if (o->kind == MDB_EX_COUNT) {		/* check_orderby_clause_count, semantic_select.c:1755-1795 */
 				ERR("COUNT function can't be used in the orderby-clause\n");
 				return -MIDORIDB_ERROR;

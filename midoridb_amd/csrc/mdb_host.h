@@ -181,6 +181,7 @@ struct mdb_select {
 	bool distinct, select_all;
 	struct mdb_expr **sel;
 	int nsel;
+	char (*sel_alias)[MDB_NAME_LEN];	/* [nsel] or NULL: `expr AS name` of a select item ("" without one), filled by the resolver */
 	struct mdb_from_tab *tabs;
 	struct mdb_expr **on;
 	int *join_type;

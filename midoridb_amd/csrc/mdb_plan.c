@@ -659,6 +659,7 @@ void mdb_stmt_free(struct mdb_stmt *s)
 	for (int i = 0; i < s->sel.nsel; i++)
 		mdb_expr_free(s->sel.sel[i]);
 	free(s->sel.sel);
+	free(s->sel.sel_alias);
 	for (int i = 0; i < s->sel.ntabs; i++)
 		mdb_expr_free(s->sel.on[i]);
 	free(s->sel.on);
