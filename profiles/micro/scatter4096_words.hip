@@ -10,6 +10,7 @@
 #include <type_traits>
 
 #define SHW_D_BITS 12
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct args {
 	const unsigned long long *in;	// keys (SRC 0, 1) or records (SRC 2)
@@ -230,6 +231,244 @@ __global__ __launch_bounds__(THREADS, 4) void k_scatter4096(args a)
 	}
 }
 
+// ---- two resident workgroups per CU: nothing per row is kept in registers across the phases - the keys are read TWICE (the second time
+// from L2 / the Infinity Cache), counted in the first pass (non-returning LDS atomics), ranked and staged in the second (returning atomics on
+// the digits' running positions); a run's first word is marked in a bitmap by the digit's owner.  24 576-row tiles: 78 KiB of LDS.
+template <int THREADS, int RPT>
+__global__ __launch_bounds__(THREADS, 8) void k_scatter4096_2p(args a)
+{
+	constexpr uint32_t TILE = THREADS * RPT, D = 1u << SHW_D_BITS, DPT = D / THREADS, NCHUNK = TILE / 64u, BATCH = (RPT % 16) ? 4 : 8;
+	static_assert((RPT % (2 * BATCH)) == 0 && DPT == 4, "tile shape");
+	extern __shared__ __attribute__((aligned(16))) uint32_t shw_lds[];
+	uint32_t *const s_cnt = shw_lds;			// [D / 2] counts, then running positions (16-bit halves)
+	uint32_t *const s_delta = s_cnt + D / 2;		// [D] per non-empty digit, in digit order
+	uint32_t *const s_chunk = s_delta + D;			// [NCHUNK]
+	uint32_t *const s_mark = s_chunk + NCHUNK;		// [TILE / 32] first words of runs
+	uint32_t *const s_bad = s_mark + TILE / 32;		// [D / 32]
+	uint32_t *const s_tmp = s_bad + D / 32;			// [32]
+	uint16_t *const s_stage = reinterpret_cast<uint16_t *>(s_tmp + 32);	// [TILE]
+	__shared__ uint32_t s_any_bad;
+	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane(), sub = blockIdx.x % a.nsub;
+	const uint32_t wmask = (1u << a.rem) - 1u;
+	const uint64_t limit = (1ull << a.kbits) - 1ull;
+	const uint64_t le = mdb_lanemask_lt() | (1ull << lane);
+	for (uint32_t i = threadIdx.x; i < D / 32; i += THREADS)
+		s_bad[i] = 0u;
+	if (threadIdx.x == 0)
+		s_any_bad = 0u;
+	const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_wg;
+	const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+	for (uint64_t row0 = r_begin; row0 < r_end;) {
+		const uint32_t len = (uint32_t)((r_end - row0) < TILE ? (r_end - row0) : TILE);
+		const bool full = len == TILE;
+		uint32_t tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		for (uint32_t i = tid; i < D / 2; i += THREADS)
+			s_cnt[i] = 0u;
+		for (uint32_t i = tid; i < TILE / 32; i += THREADS)
+			s_mark[i] = 0u;
+		if (tid == 0)
+			s_chunk[0] = 0u;
+		shw_barrier();
+		// pass 1: count
+#pragma unroll 1
+		for (int b0 = 0; b0 < RPT / 2; b0 += BATCH) {
+			ulonglong2 pre[BATCH];
+#pragma unroll
+			for (int r = 0; r < (int)BATCH; r++) {
+				const uint32_t e0 = 2u * ((uint32_t)(b0 + r) * THREADS + tid);
+				if (full || e0 + 1u < len)
+					pre[r] = *reinterpret_cast<const ulonglong2 *>(a.in + row0 + e0);
+				else if (e0 < len)
+					pre[r] = make_ulonglong2(a.in[row0 + e0], ~0ull);
+				else
+					pre[r] = make_ulonglong2(~0ull, ~0ull);
+			}
+#pragma unroll
+			for (int r = 0; r < (int)BATCH; r++) {
+				const unsigned long long kk[2] = { pre[r].x, pre[r].y };
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const unsigned long long rel = kk[e] - (unsigned long long)a.key_lo;
+					if (rel <= limit) {
+						const uint32_t dig = mdb_mixk((uint32_t)rel, a.kbits) >> a.rem;
+						atomicAdd(&s_cnt[dig >> 1], 1u << ((dig & 1u) << 4));
+					}
+				}
+			}
+		}
+		shw_barrier();
+		// digits: counts -> tile-local starts (the counters become running positions), cursor atomics, chunk table, run marks
+		uint32_t cnt[DPT], v = 0u;
+#pragma unroll
+		for (int j = 0; j < (int)DPT / 2; j++) {
+			const uint32_t c2 = s_cnt[tid * (DPT / 2) + j];
+			cnt[2 * j] = c2 & 0xFFFFu;
+			cnt[2 * j + 1] = c2 >> 16;
+			v += cnt[2 * j] + cnt[2 * j + 1] + ((cnt[2 * j] ? 1u : 0u) + (cnt[2 * j + 1] ? 1u : 0u)) * 65536u;
+		}
+		uint32_t tot;
+		const uint32_t ex = shw_block_excl_scan(v, s_tmp, THREADS / 64, &tot);
+		const uint32_t tile_total = tot & 0xFFFFu;
+		{
+			uint32_t start = ex & 0xFFFFu, ord = ex >> 16, st0[DPT];
+#pragma unroll
+			for (int j = 0; j < (int)DPT; j++) {
+				const uint32_t d = tid * DPT + (uint32_t)j;
+				st0[j] = start;
+				if (cnt[j]) {
+					const uint32_t base = atomicAdd(&a.cursor[sub * D + d], cnt[j]);
+					for (uint32_t c = (start >> 6) + 1u; (c << 6) <= start + cnt[j] && c < NCHUNK; c++)
+						s_chunk[c] = ord + 1u;
+					atomicOr(&s_mark[start >> 5], 1u << (start & 31u));
+					if (base + cnt[j] > a.cap) {
+						mdb_raise(a.status, 2u);
+						atomicOr(&s_bad[ord >> 5], 1u << (ord & 31u));
+						s_any_bad = 1u;
+					}
+					s_delta[ord] = (d * a.nsub + sub) * a.cap + base - start;
+					ord++;
+					start += cnt[j];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < (int)DPT / 2; j++)
+				s_cnt[tid * (DPT / 2) + j] = st0[2 * j] | (st0[2 * j + 1] << 16);
+		}
+		shw_barrier();
+		// pass 2: the same keys again, ranked at the digits' running positions and staged
+#pragma unroll 1
+		for (int b0 = 0; b0 < RPT / 2; b0 += BATCH) {
+			ulonglong2 pre[BATCH];
+#pragma unroll
+			for (int r = 0; r < (int)BATCH; r++) {
+				const uint32_t e0 = 2u * ((uint32_t)(b0 + r) * THREADS + tid);
+				if (full || e0 + 1u < len)
+					pre[r] = *reinterpret_cast<const ulonglong2 *>(a.in + row0 + e0);
+				else if (e0 < len)
+					pre[r] = make_ulonglong2(a.in[row0 + e0], ~0ull);
+				else
+					pre[r] = make_ulonglong2(~0ull, ~0ull);
+			}
+#pragma unroll
+			for (int r = 0; r < (int)BATCH; r++) {
+				const unsigned long long kk[2] = { pre[r].x, pre[r].y };
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const unsigned long long rel = kk[e] - (unsigned long long)a.key_lo;
+					if (rel <= limit) {
+						const uint32_t h = mdb_mixk((uint32_t)rel, a.kbits), dig = h >> a.rem, sh = (dig & 1u) << 4;
+						const uint32_t pos = (atomicAdd(&s_cnt[dig >> 1], 1u << sh) >> sh) & 0xFFFFu;
+						s_stage[pos] = (uint16_t)(h & wmask);
+					}
+				}
+			}
+		}
+		shw_barrier();
+		const bool any_bad = s_any_bad != 0u;
+#pragma unroll 4
+		for (int k = 0; k < RPT; k++) {
+			const uint32_t i = (uint32_t)k * THREADS + tid;
+			const uint32_t mk = i < tile_total ? (s_mark[i >> 5] >> (i & 31u)) & 1u : 0u;
+			const uint64_t m = __ballot(mk != 0u);
+			if (i >= tile_total)
+				continue;
+			const uint32_t ord = s_chunk[(uint32_t)k * (THREADS / 64) + wave] + (uint32_t)__popcll(m & le) - 1u;
+			if (any_bad && ((s_bad[ord >> 5] >> (ord & 31u)) & 1u))
+				continue;
+			reinterpret_cast<uint16_t *>(a.out)[i + s_delta[ord]] = s_stage[i];
+		}
+		shw_barrier();
+		if (any_bad) {
+			for (uint32_t i = tid; i < D / 32; i += THREADS)
+				s_bad[i] = 0u;
+			if (tid == 0)
+				s_any_bad = 0u;
+			shw_barrier();
+		}
+		row0 += len;
+	}
+}
+
+template <int THREADS, int RPT>
+static void run2p(const char *what, const unsigned long long *in, uint32_t n, uint32_t kbits, uint32_t cus, uint32_t per_cu)
+{
+	const uint32_t D = 1u << SHW_D_BITS, nsub = 8, tile = THREADS * RPT;
+	const uint32_t cap = (uint32_t)(((uint64_t)n * 17 / 16 / (D * nsub) + 320 + 63) & ~63ull);
+	uint32_t *cur, *status;
+	uint16_t *out;
+	CK(hipMalloc(&cur, (size_t)D * nsub * 4));
+	CK(hipMalloc(&status, 64));
+	CK(hipMalloc(&out, (size_t)D * nsub * cap * 2));
+	CK(hipMemset(status, 0, 64));
+	args a;
+	memset(&a, 0, sizeof(a));
+	a.in = in;
+	a.n = n;
+	a.kbits = kbits;
+	a.rem = kbits - 12;
+	a.out = out;
+	a.cursor = cur;
+	a.cap = cap;
+	a.nsub = nsub;
+	a.status = status;
+	const uint32_t ntiles = (n + tile - 1) / tile, grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+	a.rows_per_wg = (uint32_t)((((uint64_t)n + grid - 1) / grid + 1) & ~1ull);
+	const size_t lds = (size_t)4 * (D / 2 + D + tile / 64 + tile / 32 + D / 32 + 32) + (size_t)2 * tile;
+	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter4096_2p<THREADS, RPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	float best = 1e9f, sum = 0;
+	const int iters = 6;
+	for (int it = 0; it < iters; it++) {
+		CK(hipMemsetAsync(cur, 0, (size_t)D * nsub * 4));
+		hipEventRecord(e0);
+		hipLaunchKernelGGL((k_scatter4096_2p<THREADS, RPT>), dim3(grid), dim3(THREADS), lds, 0, a);
+		hipEventRecord(e1);
+		CK(hipEventSynchronize(e1));
+		float ms;
+		hipEventElapsedTime(&ms, e0, e1);
+		if (it) {
+			sum += ms;
+			best = ms < best ? ms : best;
+		}
+	}
+	uint32_t st = 0;
+	CK(hipMemcpy(&st, status, 4, hipMemcpyDeviceToHost));
+	std::vector<uint32_t> hc((size_t)D * nsub);
+	CK(hipMemcpy(hc.data(), cur, hc.size() * 4, hipMemcpyDeviceToHost));
+	uint64_t total = 0;
+	for (uint32_t c : hc)
+		total += c;
+	// spot check: the multiset of words of a few digits equals what the keys hash to
+	std::vector<unsigned long long> hk(n);
+	CK(hipMemcpy(hk.data(), in, (size_t)n * 8, hipMemcpyDeviceToHost));
+	uint64_t bad = 0;
+	for (uint32_t d : { 0u, 777u, 4095u }) {
+		std::vector<uint32_t> want(1u << (kbits - 12), 0), got(1u << (kbits - 12), 0);
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t h = mdb_mixk((uint32_t)hk[i], kbits);
+			if ((h >> (kbits - 12)) == d)
+				want[h & ((1u << (kbits - 12)) - 1u)]++;
+		}
+		for (uint32_t sb = 0; sb < nsub; sb++) {
+			const uint32_t c = hc[(size_t)sb * D + d];
+			std::vector<uint16_t> w(c);
+			CK(hipMemcpy(w.data(), out + ((size_t)d * nsub + sb) * cap, (size_t)c * 2, hipMemcpyDeviceToHost));
+			for (uint16_t x : w)
+				got[x]++;
+		}
+		for (size_t i = 0; i < want.size(); i++)
+			bad += want[i] != got[i];
+	}
+	printf("%-58s tile %5u lds %6zu B x %u / CU: avg %.3f ms best %.3f ms  rows placed %llu of %u, status %u, digits checked: %llu wrong values\n", what, tile, lds, per_cu,
+	       sum / (iters - 1), best, (unsigned long long)total, n, st, (unsigned long long)bad);
+	hipFree(cur);
+	hipFree(status);
+	hipFree(out);
+}
+
 static size_t lds_bytes(uint32_t tile, size_t wb)
 {
 	const uint32_t D = 1u << SHW_D_BITS;
@@ -252,7 +491,6 @@ __global__ void k_gen_rec(unsigned long long *rec, uint32_t n, uint32_t kbits)
 	}
 }
 
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int THREADS, int RPT, int SRC>
 static void run(const char *what, const unsigned long long *in, uint32_t n, uint32_t kbits, uint32_t rem, uint32_t cbits, uint32_t cus)
@@ -367,6 +605,10 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("%u rows, %u CUs, kbits %u (digits 4096, %u bits below)\n", n, cus, kbits, kbits - 12);
 	run<1024, 32, 0>("key -> 2-byte words (the product's kernel)", keys, n, kbits, kbits - 12, 0, cus);
+	run2p<1024, 32>("two passes over the keys, 32 768-row tiles, 1 / CU", keys, n, kbits, cus, 1);
+	run2p<1024, 16>("two passes over the keys, 16 384-row tiles, 2 / CU", keys, n, kbits, cus, 2);
+	run2p<1024, 16>("two passes over the keys, 16 384-row tiles, 1 / CU", keys, n, kbits, cus, 1);
+	run2p<1024, 24>("two passes over the keys, 24 576-row tiles, 2 / CU", keys, n, kbits, cus, 2);
 	run<1024, 16, 0>("key -> 2-byte words, 16 384-row tiles", keys, n, kbits, kbits - 12, 0, cus);
 	run<1024, 16, 0>("key -> 2-byte words, 16 384-row tiles, 2 workgroups / CU", keys, n, kbits, kbits - 12, 0, 2 * cus);
 	run<512, 32, 0>("key -> 2-byte words, 16 384-row tiles, 512 thr, 2 / CU", keys, n, kbits, kbits - 12, 0, 2 * cus);
