@@ -1243,7 +1243,12 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	uint32_t *const s_fc = lw_lds;			/* right rows << 27 | first left row */
 	uint32_t *const s_cl = lw_lds + T;		/* left rows per key (only of keys that have right rows), 4 bits each */
 	uint32_t leaf = blockIdx.x, buf = 0;
-	if (leaf >= a.nleaves || nsub != LW12_NSUB)
+	if (nsub != LW12_NSUB) {	/* (the caller's layout is not the one this kernel walks: say so, never an empty result) */
+		if (threadIdx.x == 0)
+			mdb_raise(a.status, 1024u);
+		return;
+	}
+	if (leaf >= a.nleaves)
 		return;
 	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 16 * (2 + NX) - 1: (side, sub-region) */
 		const uint32_t side = threadIdx.x >> 4, j = threadIdx.x & 15u;
