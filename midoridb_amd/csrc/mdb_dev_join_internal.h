@@ -232,5 +232,10 @@ int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
 			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined);
 bool ld_disabled(void);
+/* mdb_dev_leaf_wide.hip: one workgroup per first-level digit */
+int leaf_wide_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint32_t rem, uint32_t shift, uint32_t nsub, bool has_r, bool r16);
+int leaf_wide4_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint32_t rem, uint32_t shift, uint32_t nsub);
+bool leaf_wide12_fits(const mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint64_t n_x);
+int leaf_wide12_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint32_t rem, uint32_t nsub, int nextra);
 
 #endif /* MDB_DEV_JOIN_INTERNAL_H */
