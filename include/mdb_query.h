@@ -45,7 +45,8 @@ enum query_output_status {
 	ST_ERROR
 };
 
-/* reference include/engine/query.h:24-28.  `table` points at the columnar result;
+/* reference include/engine/query.h:24-28.  `table` points at the columnar result, which BEGINS with the reference's
+ * `struct table` layout (include/mdb_legacy.h: columns always, datablocks of rows for results of up to 4096 rows);
  * `cursor_blk` is non-NULL once stepping has started; `cursor_offset` is the current row. */
 struct result_set {
 	void *table;

@@ -525,6 +525,8 @@ void mdb_result_free(struct mdb_result *r)
 		if (r->d_nullbits && r->d_nullbits[c])
 			mdb_dev_free(r->dev, r->d_nullbits[c]);
 	}
+	mdb_result_legacy_free(r);
+	pthread_mutex_destroy(&r->legacy.mutex);
 	free(r->data);
 	free(r->nullbits);
 	free(r->d_data);
@@ -572,6 +574,7 @@ int mdb_result_fetch(struct mdb_result *r)
 			return -MIDORIDB_INTERNAL;
 	}
 	r->fetched = true;
+	mdb_result_legacy_rows(r);
 	return MIDORIDB_OK;
 }
 
@@ -1383,6 +1386,8 @@ grouped:
 			goto out;
 	}
 	res->dict = &cat->dict;
+	mdb_result_legacy_header(res);		/* the reference's struct table in front of the columnar result (include/mdb_legacy.h) ... */
+	mdb_result_legacy_rows(res);		/* ... and, for a small result whose columns are on the host, its rows as datablocks */
 	res->exec_ms = now_ms() - t0;
 	res->joined_rows = x.joined_rows;
 	*out = res;

@@ -16,6 +16,7 @@
 #include "mdb_error.h"
 #include "mdb_dev.h"
 #include "mdb_dist.h"
+#include "mdb_legacy.h"
 #include "mdb_query.h"
 
 /* ------------------------------------------------------------------ RPN token queue
@@ -248,6 +249,9 @@ void mdb_expr_free(struct mdb_expr *e);
 
 /* ------------------------------------------------------------------ result set */
 struct mdb_result {
+	struct mdb_legacy_table legacy;	/* FIRST: what `results.table` points at begins with the reference's struct table (include/mdb_legacy.h) */
+	struct mdb_legacy_list_head legacy_head;
+	bool legacy_built;
 	int ncols;
 	char (*colname)[MDB_NAME_LEN];
 	int *coltype;
@@ -264,6 +268,9 @@ struct mdb_result {
 	uint64_t **d_nullbits;
 	bool fetched;
 };
+void mdb_result_legacy_header(struct mdb_result *r);	/* mdb_legacy.c */
+void mdb_result_legacy_rows(struct mdb_result *r);
+void mdb_result_legacy_free(struct mdb_result *r);
 int mdb_result_fetch(struct mdb_result *r);	/* host columns of a device-resident result (no-op otherwise) */
 void mdb_result_free(struct mdb_result *r);
 

@@ -233,9 +233,11 @@ class DB:
         self.lib.query_free(out)
         return n
 
-    def query(self, sql, rpn=False, step_cursor=False):
+    def query(self, sql, rpn=False, step_cursor=False, with_table=None):
         """SELECT -> Result.  step_cursor=True walks the result with query_cur_step()/query_column_int64()
-        exactly like the reference's tests; otherwise whole columns are copied at once."""
+        exactly like the reference's tests; otherwise whole columns are copied at once.  with_table: a callable that is handed
+        `results.table` (an address) while the result is alive - what a consumer that reads the reference's `struct table` itself sees
+        (include/mdb_legacy.h); its return value is kept in Result.table_view."""
         fn = self.lib.mdb_query_execute_rpn if rpn else self.lib.query_execute
         t0 = time.perf_counter()
         raw = fn(ctypes.byref(self.db), sql.encode())
@@ -273,6 +275,8 @@ class DB:
                 cols.append(np.ctypeslib.as_array(p, shape=(nrows,)).copy() if nrows else np.zeros(0, dtype=np.int64))
             nulls = [None] * nc
         res = Result(names, types, cols, nulls, float(self.lib.query_exec_ms(rs)), int(self.lib.query_joined_rows(rs)))
+        if with_table is not None:
+            res.table_view = with_table(out.contents.results.table)
         self.lib.query_free(out)
         return res
 

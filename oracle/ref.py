@@ -48,8 +48,56 @@ def _lib():
         L.ref_table_fetch.restype = ctypes.c_int64
         L.ref_table_ncols.argtypes = [P, ctypes.c_char_p]
         L.ref_table_ncols.restype = ctypes.c_int
+        if hasattr(L, "ref_foreign_fetch"):
+            L.ref_foreign_ncols.argtypes = [P]
+            L.ref_foreign_ncols.restype = ctypes.c_int
+            L.ref_foreign_colname.argtypes = [P, ctypes.c_int]
+            L.ref_foreign_colname.restype = ctypes.c_char_p
+            L.ref_foreign_coltype.argtypes = [P, ctypes.c_int]
+            L.ref_foreign_coltype.restype = ctypes.c_int
+            L.ref_foreign_is_count.argtypes = [P, ctypes.c_int]
+            L.ref_foreign_is_count.restype = ctypes.c_int
+            L.ref_foreign_name.argtypes = [P]
+            L.ref_foreign_name.restype = ctypes.c_char_p
+            L.ref_foreign_fetch.argtypes = [P, P, P, ctypes.c_int64]
+            L.ref_foreign_fetch.restype = ctypes.c_int64
+            L.ref_foreign_text.argtypes = [ctypes.c_int64]
+            L.ref_foreign_text.restype = ctypes.c_char_p
+            L.ref_foreign_cursor_walk.argtypes = [P, ctypes.c_int, P, ctypes.c_int64]
+            L.ref_foreign_cursor_walk.restype = ctypes.c_int64
         _LIB = L
     return _LIB
+
+
+def foreign_table(table_ptr, max_rows=1 << 16):
+    """A `struct table *` that came from the PRODUCT (the legacy view in front of a result, include/mdb_legacy.h) read with the reference's
+    compiled layouts -> (table name, [(column name, type, is_count)], rows as a list of tuples of (value, is_null); VARCHAR values as str)."""
+    L = _lib()
+    nc = L.ref_foreign_ncols(table_ptr)
+    cols = [(L.ref_foreign_colname(table_ptr, i).decode(), L.ref_foreign_coltype(table_ptr, i), bool(L.ref_foreign_is_count(table_ptr, i))) for i in range(nc)]
+    n = L.ref_foreign_fetch(table_ptr, None, None, 0)
+    vals = np.zeros((max(n, 1), max(nc, 1)), dtype=np.int64)
+    nulls = np.zeros((max(n, 1), max(nc, 1)), dtype=np.uint8)
+    got = L.ref_foreign_fetch(table_ptr, vals.ctypes.data_as(ctypes.c_void_p), nulls.ctypes.data_as(ctypes.c_void_p), max(n, 1))
+    assert got == n
+    rows = []
+    for r in range(n):
+        row = []
+        for c in range(nc):
+            v = int(vals[r, c])
+            if cols[c][1] == 0:     # CT_VARCHAR: the cell is a pointer
+                v = L.ref_foreign_text(v).decode()
+            row.append((v, bool(nulls[r, c])))
+        rows.append(tuple(row))
+    return L.ref_foreign_name(table_ptr).decode(), cols, rows
+
+
+def foreign_cursor_walk(table_ptr, col, cap=1 << 16):
+    """column `col` of a foreign table through the reference's cursor arithmetic (query_cur_step + query_column_int64)"""
+    L = _lib()
+    out = np.zeros(cap, dtype=np.int64)
+    n = L.ref_foreign_cursor_walk(table_ptr, col, out.ctypes.data_as(ctypes.c_void_p), cap)
+    return out[: min(n, cap)].tolist(), n
 
 
 def sql_to_rpn(sql):

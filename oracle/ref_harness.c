@@ -255,6 +255,120 @@ int64_t ref_result_fetch(void *h, int64_t *vals, uint8_t *nulls, int64_t cap_row
 	return n;
 }
 
+/*
+ * A `struct table *` that did NOT come from this library - the product's legacy view of a result (include/mdb_legacy.h) - read
+ * with the reference's own compiled struct layouts, list macros and helpers: the same walk as ref_result_fetch.  What the tests
+ * use to prove that a consumer built against the reference's headers finds its rows behind `output->results.table`.
+ */
+int ref_foreign_ncols(void *table)
+{
+	return ((struct table *)table)->column_count;
+}
+
+const char *ref_foreign_colname(void *table, int i)
+{
+	return ((struct table *)table)->columns[i].name;
+}
+
+int ref_foreign_coltype(void *table, int i)
+{
+	return (int)((struct table *)table)->columns[i].type;
+}
+
+int ref_foreign_is_count(void *table, int i)
+{
+	return ((struct table *)table)->columns[i].is_count;
+}
+
+const char *ref_foreign_name(void *table)
+{
+	return ((struct table *)table)->name;
+}
+
+/* rows as ref_result_fetch reads them; a VARCHAR cell (a pointer) is returned as the pointer's value: ref_foreign_text() reads it */
+int64_t ref_foreign_fetch(void *table, int64_t *vals, uint8_t *nulls, int64_t cap_rows)
+{
+	struct table *t = table;
+	struct list_head *pos;
+	size_t rs;
+	int64_t n = 0;
+
+	if (!t || !t->datablock_head)
+		return -1;
+	rs = table_calc_row_size(t);
+	list_for_each(pos, t->datablock_head) {
+		struct datablock *b = list_entry(pos, struct datablock, head);
+		for (size_t i = 0; i < DATABLOCK_PAGE_SIZE / rs; i++) {
+			struct row *r = (struct row *)&b->data[rs * i];
+			size_t off = 0;
+			if (r->flags.empty)
+				break;
+			if (r->flags.deleted)
+				continue;
+			if (vals && n < cap_rows) {
+				for (int k = 0; k < t->column_count; k++) {
+					int64_t v = 0;
+					size_t sp = table_calc_column_space(&t->columns[k]);
+					if (sp == 8)
+						memcpy(&v, r->data + off, 8);
+					else if (sp == 1)
+						v = *(bool *)(r->data + off);
+					vals[n * t->column_count + k] = v;
+					nulls[n * t->column_count + k] = bit_test(r->null_bitmap, k, sizeof(r->null_bitmap));
+					off += sp;
+				}
+			}
+			n++;
+		}
+	}
+	return n;
+}
+
+const char *ref_foreign_text(int64_t cell)
+{
+	return (const char *)(uintptr_t)cell;
+}
+
+/* the reference's own cursor arithmetic (query_cur_step + query_column_int64, src/engine/query.c:108-168, restated: query.c itself is
+ * left out of this build because it calls the parser) over a foreign result_set: rows until the cursor says "end" */
+int64_t ref_foreign_cursor_walk(void *table, int col, int64_t *out, int64_t cap)
+{
+	struct table *t = table;
+	struct datablock *blk = NULL;
+	size_t off = 0, rs = table_calc_row_size(t);
+	int64_t n = 0;
+
+	if (list_is_empty(t->datablock_head))
+		return 0;
+	for (;;) {
+		struct row *row;
+		if (!blk) {
+			blk = container_of(t->datablock_head->next, typeof(struct datablock), head);
+			off = 0;
+		} else if (off + rs > DATABLOCK_PAGE_SIZE) {
+			blk = container_of(blk->head.next, typeof(struct datablock), head);
+			off = 0;
+			if (&blk->head == t->datablock_head)
+				break;
+		} else {
+			off += rs;
+		}
+		if (off + rs > DATABLOCK_PAGE_SIZE)
+			continue;	/* (the reference reads past the page here - SURVEY 8a D4; the walk skips to the next block instead) */
+		row = (struct row *)&blk->data[off];
+		if (row->flags.empty)
+			break;
+		if (n < cap) {
+			size_t o = 0;
+			for (int i = 0; i < col; i++)
+				o += table_calc_column_space(&t->columns[i]);
+			out[n] = *(int64_t *)(row->data + o);
+		}
+		n++;
+	}
+	return n;
+}
+
 /* query_output.n_rows_aff of the last executed statement (INSERT / DELETE / UPDATE). */
 int64_t ref_rows_affected(void *h)
 {

@@ -254,6 +254,38 @@ def test_reference_readme_program_compiles_against_the_forwarding_headers(tmp_pa
     assert r.returncode in (0, 255), (r.returncode, r.stdout)
 
 
+def test_legacy_view_structs_have_the_references_layout(tmp_path):
+    """include/mdb_legacy.h restates the layouts behind `struct result_set.table` (table.h:23-42, column.h:30-49, datablock.h:9-13,
+    row.h:15-28, linkedlist.h:11-14): a C file that includes BOTH the reference's headers (when the reference is present: authoring
+    container) and ours compiles only if every size and member offset agrees."""
+    import os
+    import shutil
+    import subprocess
+    if not os.path.isdir("/root/reference/include") or not shutil.which("gcc"):
+        pytest.skip("needs the reference's headers and gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("struct table", "struct mdb_legacy_table", ["name", "columns", "column_count", "datablock_head", "free_dtbkl_offset", "mutex"]),
+             ("struct column", "struct mdb_legacy_column", ["name", "type", "precision", "indexed", "nullable", "unique", "auto_inc", "primary_key", "is_count"]),
+             ("struct datablock", "struct mdb_legacy_datablock", ["block_id", "data", "head"]),
+             ("struct list_head", "struct mdb_legacy_list_head", ["next", "prev"])]
+    lines = ["#include <primitive/table.h>", "#include <primitive/row.h>", "#include <primitive/datablock.h>", "#include <stddef.h>", '#include "mdb_legacy.h"']
+    for ref_t, my_t, members in pairs:
+        lines.append(f'_Static_assert(sizeof({ref_t}) == sizeof({my_t}), "size of {my_t}");')
+        for m in members:
+            lines.append(f'_Static_assert(offsetof({ref_t}, {m}) == offsetof({my_t}, {m}), "{my_t}.{m}");')
+    lines += ['_Static_assert(sizeof(struct row) == sizeof(struct mdb_legacy_row), "row header");',
+              '_Static_assert(offsetof(struct row, flags) == offsetof(struct mdb_legacy_row, empty), "row.flags");',
+              '_Static_assert(offsetof(struct row, null_bitmap) == offsetof(struct mdb_legacy_row, null_bitmap), "row.null_bitmap");',
+              '_Static_assert(offsetof(struct row, data) == offsetof(struct mdb_legacy_row, data), "row.data");',
+              '_Static_assert(DATABLOCK_PAGE_SIZE == MDB_LEGACY_PAGE_SIZE && TABLE_MAX_COLUMNS == MDB_LEGACY_MAX_COLUMNS, "constants");',
+              "int main(void) { return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    r = subprocess.run(["gcc", "-std=gnu11", "-w", "-I/root/reference/include", "-I" + os.path.join(root, "include"), "-c", str(src), "-o", str(tmp_path / "layout.o")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+
+
 def test_sql_front_end_emits_the_hand_written_rpn_of_every_fixture_select():
     """The fixtures were recorded by feeding the real reference the RPN that mdb_sql.c emitted; this pins that RPN to
     token queues written BY HAND from the reference grammar (tests/golden/handwritten_rpn.py), for every SELECT of every
