@@ -217,3 +217,28 @@ def test_one_pass_4096_three_tables_on_one_key(dev, forced, shape):
     # (counts that do not fit: the two-level form, or the chain of two-table operators - whose own calls may take the one-pass form)
     if shape not in ("product_beyond_31", "further_table_16_rows_of_a_key"):
         assert dev.last_join_multi() and dev.last_join_one_pass_4096(), shape
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MDB_FUZZ_SEEDS_4096", "16"))))
+def test_one_pass_4096_random_shapes(dev, forced, seed):
+    """Random table sizes, windows of 2^23 ... 2^27 values anywhere in the int64 range, duplicate factors up to and beyond the leaf's count
+    fields, NULL fractions, left rows outside the right table's range: always the oracle's groups, counts, first rows and order - through the
+    one-pass form where it applies and through whatever answers when it does not."""
+    rng = np.random.default_rng(1000 + seed)
+    bits = int(rng.integers(23, 28))
+    span = (1 << bits) - int(rng.integers(1, 1 << (bits - 3)))
+    n_l, n_r = int(rng.integers(1_000_000, 2_600_000)), int(rng.integers(400_000, 2_600_000))
+    off = int(rng.choice([0, 12345, -(2**45), 10**13]))
+    dup_l, dup_r = int(rng.choice([1, 1, 2, 3, 9, 17])), int(rng.choice([1, 1, 2, 5, 16, 33]))
+    base_l = rng.permutation(span)[: max(n_l // dup_l, 1)]
+    kl = off + base_l[rng.integers(0, len(base_l), n_l)].astype(np.int64) if dup_l > 1 else off + rng.permutation(span)[:n_l].astype(np.int64)
+    pool = base_l if rng.random() < 0.5 else rng.permutation(span)[: max(n_r // dup_r, 1)]
+    kr = off + pool[rng.integers(0, len(pool), n_r)].astype(np.int64)
+    kl[0], kl[-1] = off, off + span - 1
+    if rng.random() < 0.25:          # some left rows far outside the right table's window
+        kl[rng.integers(1, len(kl) - 1, len(kl) // 50)] += 2**33
+    nl = nr = None
+    if rng.random() < 0.4:
+        nl, nr = rng.random(len(kl)) < 0.04, rng.random(n_r) < 0.06
+        nl[0] = nl[-1] = False
+    _check(dev, kl, nl, kr, nr, expect_form=None, rounds=2)
