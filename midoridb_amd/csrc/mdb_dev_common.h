@@ -75,6 +75,8 @@ struct mdb_col_memo {
 	uint64_t lw_bad_nl, lw_bad_nr;	/* (k_leaf_wide) overflowed last: two levels for these columns */
 	const void *l4_bad_keys;	/* ... and the one for which k_leaf_wide4's 5-bit / 4-bit counts did (more than 31 right or 15 left rows of a key): */
 	uint64_t l4_bad_nl, l4_bad_nr;	/* k_leaf_wide's 16-bit counts at once */
+	int lw_bad_uses, l4_bad_uses;	/* both verdicts serve MDB_BAD_LEAF_USES calls, then the fast form is tried again: the columns go by address and length,
+					 * and a caller's allocator hands the same addresses out for other data */
 	int keyed_distrust;		/* > 0: a COUNT(*) did not fit a keyed group record lately - plain records for the next operators */
 	const void *lg_kl, *lg_kr;	/* the last join over (lg_kl, lg_nl, lg_kr, lg_nr) delivered lg_groups groups: when that is under a quarter of the */
 	uint64_t lg_nl, lg_nr, lg_groups;	/* left rows, most left rows find no partner whatever the tables' sizes and ranges say (a right table */
@@ -82,6 +84,7 @@ struct mdb_col_memo {
 };
 
 #define MDB_MEMO_SLOTS 8
+#define MDB_BAD_LEAF_USES 32
 struct mdb_memo_key {
 	const void *kl, *kr;
 	uint64_t nl, nr;

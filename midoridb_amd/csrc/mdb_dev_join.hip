@@ -1313,16 +1313,29 @@ struct gc_extras {
 };
 static thread_local const gc_extras *gc_pending_extras = NULL;	/* set by mdb_dev_join_group_count_multi around its call of the operator */
 
+/* a remembered "these columns overflow the digit-per-workgroup leaves' counts" (ctx->lw_bad_*) serves MDB_BAD_LEAF_USES calls */
+static bool gc_lw_bad(mdb_dev_ctx *ctx, const gc_state *st)
+{
+	if (!(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap))
+		return false;
+	if (++ctx->lw_bad_uses > MDB_BAD_LEAF_USES) {
+		ctx->lw_bad_keys = NULL;
+		return false;
+	}
+	return true;
+}
+
 /* first half: size and claim the scratch arena, clear the status words, partition the left table */
 static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 {
 	mdb_choose_bits(st->n_l, GC_TARGET, &st->b1, &st->b2);
+	const bool lw_bad = gc_lw_bad(ctx, st);
 	if (st->r_based && !(st->has_r && st->defer_ok && !st->active && st->fast))
 		st->key_bits = 0;	/* (a window of the right table's keys only needs the left table pruned: not in this call - plain narrow form) */
 	/* key windows of 2^15 ... 2^23 values: one 9-bit level and k_leaf_wide (MDB_ONE_LEVEL=0 switches it off; tables of fewer
 	 * than 2^21 rows in all keep the two-level form, whose fixed costs are smaller) */
 	st->one_level = st->narrow && st->key_bits >= 9u + LW_MIN_REM && st->key_bits <= 9u + LW_MAX_REM && st->fast && st->want_records &&
-			!ld_disabled() && !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
+			!ld_disabled() && !lw_bad &&
 			st->n_l + (st->has_r ? st->n_r_cap : 0) >= (1ull << 21) &&
 			st->n_l < 3000000000ull && st->n_r_cap < 3000000000ull &&
 			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
@@ -1340,7 +1353,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		st->wide12 = !st->one_level && st->narrow && st->has_r && st->key_bits > 9u + LW_MAX_REM && st->key_bits <= 12u + LW_MAX_REM + 1u && st->fast &&
 			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && st->nextra <= 1 && !st->keys32 &&
 			     !st->prunable /* (a right table that covers part of the left table's key range: min-max pruning drops most left rows first) */ &&
-			     !(ctx->lw_bad_keys == st->keys_l && ctx->lw_bad_nl == st->n_l && ctx->lw_bad_nr == st->n_r_cap) &&
+			     !lw_bad &&
 			     st->n_l + st->n_r_cap >= min_rows && st->n_l <= (1ull << 27) /* (k_leaf_wide12 keeps a first row in 27 bits) */ &&
 			     st->n_r_cap < 0xF0000000ull && !(e && e[0] == '0');
 		/* ... and a digit's words must fit the leaf kernel's registers: 8 sub-regions of at most LW12_LB (LW12_RB) chunks per thread */
@@ -1706,7 +1719,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	/* one-level joins with 2-byte right words: k_leaf_wide4's 4 bytes per key value (two workgroups per CU) unless these columns are known to
 	 * hold more than 31 right or 15 left rows of a key (MDB_LEAF4=0 switches it off) */
 	const bool leaf4 = st->one_level && has_r && pr.w16 && records && !null_group && n_l <= (1ull << 27) && st->key_bits >= (uint32_t)pl.bits_total + 10u &&
-			   !(ctx->l4_bad_keys == keys_l && ctx->l4_bad_nl == n_l && ctx->l4_bad_nr == n_r) &&
+			   !(ctx->l4_bad_keys == keys_l && ctx->l4_bad_nl == n_l && ctx->l4_bad_nr == n_r && ++ctx->l4_bad_uses <= MDB_BAD_LEAF_USES) &&
 			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
 	{
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
@@ -1779,6 +1792,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* a key with more rows than k_leaf_wide4's count fields hold: the same partitioned tables through k_leaf_wide (16-bit counts), now
 		 * and for these columns */
 		ctx->l4_bad_keys = keys_l;
+		ctx->l4_bad_uses = 0;
 		ctx->l4_bad_nl = n_l;
 		ctx->l4_bad_nr = n_r;
 		uint32_t *hw = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 528;
@@ -1798,6 +1812,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	if ((uint32_t)h[1] & 2u)
 		return GC_RETRY_EXACT;	/* a leaf outgrew its fixed-capacity region (skewed keys) */
 	if ((uint32_t)h[1] & 1024u) {
+		ctx->lw_bad_uses = 0;
 		ctx->lw_bad_keys = keys_l;	/* a key with 2^16 or more rows on one side: two levels and their hot-key path, now and for these columns */
 		ctx->lw_bad_nl = n_l;
 		ctx->lw_bad_nr = st->n_r_cap;
