@@ -450,18 +450,22 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				if (wi >= T / 8u)
 					continue;
 				const uint32_t cw = s_cl[wi];
-				const uint4 f0 = *reinterpret_cast<const uint4 *>(s_fc + wi * 8u), f1 = *reinterpret_cast<const uint4 *>(s_fc + wi * 8u + 4u);
-				uint32_t f[8] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w };
+				uint32_t worst = 0;
 #pragma unroll
-				for (int e = 0; e < 8; e++) {
-					const uint32_t cb = f[e] >> 27, cx = (cw >> (4 * e)) & 15u, pr = cb * cx;
-					sum_b += cb;
-					sum_x += cx;
-					prod_bad = prod_bad || pr > LW12_MAX_CR;
-					f[e] = (pr << 27) | 0x07FFFFFFu;
+				for (int hf = 0; hf < 2; hf++) {	/* (four values at a time: the kernel has no registers to spare) */
+					const uint4 fq = *reinterpret_cast<const uint4 *>(s_fc + wi * 8u + 4u * hf);
+					uint32_t f[4] = { fq.x, fq.y, fq.z, fq.w };
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						const uint32_t cb = f[e] >> 27, cx = (cw >> (4 * (4 * hf + e))) & 15u, pr = cb * cx;
+						sum_b += cb;
+						sum_x += cx;
+						worst = pr > worst ? pr : worst;
+						f[e] = (pr << 27) | 0x07FFFFFFu;
+					}
+					*reinterpret_cast<uint4 *>(s_fc + wi * 8u + 4u * hf) = make_uint4(f[0], f[1], f[2], f[3]);
 				}
-				*reinterpret_cast<uint4 *>(s_fc + wi * 8u) = make_uint4(f[0], f[1], f[2], f[3]);
-				*reinterpret_cast<uint4 *>(s_fc + wi * 8u + 4u) = make_uint4(f[4], f[5], f[6], f[7]);
+				prod_bad = prod_bad || worst > LW12_MAX_CR;
 				s_cl[wi] = 0u;
 			}
 			/* (counts that overflowed their fields: the fields sum to less than the rows counted) */
