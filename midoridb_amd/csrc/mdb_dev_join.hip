@@ -1439,6 +1439,10 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		      : st->one_level ? mdb_partition_level0_arena_bytes(st->n_l, st->b1, st->fast1) : mdb_partition_arena_bytes(st->n_l, st->b1, st->b2, true, st->fast);
 	if (st->semijoin)
 		need += mdb_align_up(((size_t)1 << (st->key_bits - (st->semijoin - 1u))) / 8) + 4096;
+	if (st->one_level && st->has_r) {	/* (k_leaf_wide4's ranged emit: the ordering kernel's ranges, filled by the leaf kernel - tables of up to 1536 ranges) */
+		const size_t ranges = (st->n_l >> ORDER_RANGE_BITS) + 2 < 1538 ? (size_t)(st->n_l >> ORDER_RANGE_BITS) + 2 : 1538;
+		need += mdb_align_up(ranges * ORDER_RANGE_CAP * 8) + mdb_align_up(ranges * 4) + 512;
+	}
 	if (st->defer_l)
 		need += mdb_align_up(mdb_part_minmax_words(st->n_r_cap) * 4) + 256;
 	if (st->defer_l64)
@@ -1721,6 +1725,26 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	const bool leaf4 = st->one_level && has_r && pr.w16 && records && !null_group && n_l <= (1ull << 27) && st->key_bits >= (uint32_t)pl.bits_total + 10u &&
 			   !(ctx->l4_bad_keys == keys_l && ctx->l4_bad_nl == n_l && ctx->l4_bad_nr == n_r && ++ctx->l4_bad_uses <= MDB_BAD_LEAF_USES) &&
 			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
+	/* ... and when the last join over these very columns told how many groups to expect, and they are few enough for the ordering kernel's
+	 * ranges of 2^16 row ids, k_leaf_wide4 writes its records straight into those ranges: no record list, none of the two scatter levels that
+	 * would partition it by row id (MDB_ORDER_RANGES=0 switches it off) */
+	uint32_t rg_n = 0;
+	bool ranged = leaf4 && ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r &&
+		      order_ranges_apply(n_l, kbits, ctx->lg_groups + ctx->lg_groups / 8, &rg_n) &&
+		      !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
+	a.rg_rec = NULL;
+	a.rg_cnt = NULL;
+	a.rg_cap = a.rg_shift = a.rg_n = 0;
+	if (ranged) {
+		a.rg_rec = (unsigned long long *)mdb_arena_take(ctx, (size_t)rg_n * ORDER_RANGE_CAP * 8);
+		a.rg_cnt = (uint32_t *)mdb_arena_take(ctx, (size_t)rg_n * 4);
+		if (!a.rg_rec || !a.rg_cnt)
+			return -MIDORIDB_INTERNAL;
+		MDB_HIP(ctx, hipMemsetAsync(a.rg_cnt, 0, (size_t)rg_n * 4, ctx->stream));
+		a.rg_cap = ORDER_RANGE_CAP;
+		a.rg_shift = ORDER_RANGE_BITS;
+		a.rg_n = rg_n;
+	}
 	{
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
@@ -1788,22 +1812,44 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	uint32_t *first_out = out_first ? out_first : sel;
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (leaf4 && ((uint32_t)h[1] & 4096u) && !((uint32_t)h[1] & (2u | 128u))) {
+	if (leaf4 && ((uint32_t)h[1] & (4096u | 8192u)) && !((uint32_t)h[1] & (2u | 128u))) {
 		/* a key with more rows than k_leaf_wide4's count fields hold: the same partitioned tables through k_leaf_wide (16-bit counts), now
-		 * and for these columns */
-		ctx->l4_bad_keys = keys_l;
-		ctx->l4_bad_uses = 0;
-		ctx->l4_bad_nl = n_l;
-		ctx->l4_bad_nr = n_r;
+		 * and for these columns; a range of row ids with more groups than its region holds (more groups than last time, or bunched):
+		 * k_leaf_wide4 again, into the record list */
+		const bool counts_bad = ((uint32_t)h[1] & 4096u) != 0;
+		if (counts_bad) {
+			ctx->l4_bad_keys = keys_l;
+			ctx->l4_bad_uses = 0;
+			ctx->l4_bad_nl = n_l;
+			ctx->l4_bad_nr = n_r;
+		}
+		ranged = false;
+		a.rg_rec = NULL;
+		ctx->lg_valid = false;
 		uint32_t *hw = reinterpret_cast<uint32_t *>(ctx->h_pinned) + 528;
-		hw[0] = (uint32_t)h[1] & ~(4096u | 256u | 16u | 8u);
+		hw[0] = (uint32_t)h[1] & ~(4096u | 8192u | 256u | 16u | 8u);
 		MDB_HIP(ctx, hipMemcpyAsync(ctx->d_status, hw, 4, hipMemcpyHostToDevice, ctx->stream));
 		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 12, ctx->stream));	/* record-list length, joined rows */
 		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 8, 0, 8, ctx->stream));	/* records, largest first row */
-		if ((rc = leaf_wide_launch(ctx, a, pl.nleaves, st->key_bits - pl.bits_total, 32u - st->key_bits, pl.nsub, true, true)))
+		if ((rc = counts_bad ? leaf_wide_launch(ctx, a, pl.nleaves, st->key_bits - pl.bits_total, 32u - st->key_bits, pl.nsub, true, true)
+				     : leaf_wide4_launch(ctx, a, pl.nleaves, st->key_bits - pl.bits_total, 32u - st->key_bits, pl.nsub)))
 			return rc;
 		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (!counts_bad && ((uint32_t)h[1] & 4096u) && !((uint32_t)h[1] & (2u | 128u))) {	/* (the counts overflow as well: seen only now) */
+			ctx->l4_bad_keys = keys_l;
+			ctx->l4_bad_uses = 0;
+			ctx->l4_bad_nl = n_l;
+			ctx->l4_bad_nr = n_r;
+			hw[0] = (uint32_t)h[1] & ~(4096u | 8192u | 256u | 16u | 8u);
+			MDB_HIP(ctx, hipMemcpyAsync(ctx->d_status, hw, 4, hipMemcpyHostToDevice, ctx->stream));
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 12, ctx->stream));
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 8, 0, 8, ctx->stream));
+			if ((rc = leaf_wide_launch(ctx, a, pl.nleaves, st->key_bits - pl.bits_total, 32u - st->key_bits, pl.nsub, true, true)))
+				return rc;
+			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		}
 	}
 	if ((uint32_t)h[1] & 128u)
 		return st->direct ? GC_RETRY_PLAIN : GC_RETRY_WIDE;	/* a key outside the window: the 32-bit hashes mean nothing */
@@ -1905,8 +1951,12 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* (one-level leaves report the largest first row id: the sort's first-level regions are sized for the digits below it) */
 		const uint64_t last_first = (uint32_t)(h[5] >> 32);
 		const uint64_t n_ord = (st->one_level && last_first && last_first < n_l) ? last_first + 1 : n_l;
-		rc = order_records(ctx, rec, list_len, n_ord, kbits, sb1, sb2, out_first, out_count, NULL, keys_l, out_key, st->keys32,
-				   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo, a.rec32 != 0, G);
+		if (ranged)
+			rc = order_presorted(ctx, a.rg_rec, a.rg_cnt, rg_n, kbits, out_first, out_count, keys_l, out_key, st->keys32, keyed_cbits, st->key_bits,
+					     st->key_lo);
+		else
+			rc = order_records(ctx, rec, list_len, n_ord, kbits, sb1, sb2, out_first, out_count, NULL, keys_l, out_key, st->keys32,
+					   !(status & 16u), keyed_cbits, st->key_bits, st->key_lo, a.rec32 != 0, G);
 		if (rc == GC_RETRY_REC64)
 			ctx->r32_ok = false;
 		if (rc)
@@ -1946,7 +1996,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
 	ctx->last_semijoin = (int)st->semijoin | ((st->defer_l || st->defer_l64) ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0) |
-			     (st->wide12 ? 0x1000 : 0);
+			     (st->wide12 ? 0x1000 : 0) | (ranged ? 0x2000 : 0);
 	return MIDORIDB_OK;
 }
 

@@ -114,6 +114,12 @@ struct gc_args {
 	/* further right tables joined on the SAME key (A JOIN B ON a = b JOIN C ON a = c ... GROUP BY a: BASELINE configs[4]) -
 	 * direct-address leaves only: partitioned exactly like the right table (4-byte words, fixed-capacity leaves), counted into
 	 * LDS arrays of their own; a key's right count becomes the PRODUCT of its counts in all right tables */
+	/* k_leaf_wide4, rg_rec != NULL: the group records are written straight into the ordering kernel's ranges of 2^rg_shift first row ids -
+	 * region r of rg_cap records at rg_rec + r * rg_cap, its fill in rg_cnt[r] (zeroed by the caller) - instead of one list that two scatter
+	 * levels then partition by row id; a range that outgrows its region raises flag 8192 */
+	unsigned long long *rg_rec;
+	uint32_t *rg_cnt;
+	uint32_t rg_cap, rg_shift, rg_n;
 	uint32_t nextra;
 	const uint32_t *hv_x[GC_MAX_EXTRA];
 	const uint32_t *cnt_x[GC_MAX_EXTRA];
@@ -210,6 +216,13 @@ __device__ static inline uint64_t gc_sample_pos(uint32_t t, uint64_t n)
 /* ---- host functions that cross the files (definitions: see the list at the top) */
 uint64_t gc_rec_capacity(mdb_dev_ctx *ctx, uint64_t n_l);
 bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2);
+/* ranges of 2^ORDER_RANGE_BITS first row ids, ORDER_RANGE_CAP records each, as k_order_leaf_sparse ranks them: whether records of a table of
+ * n_l rows expected to number `groups` may be written into them by the leaf kernel itself, and the ordering of such ranges */
+#define ORDER_RANGE_BITS 16u
+#define ORDER_RANGE_CAP 8192u
+bool order_ranges_apply(uint64_t n_l, uint32_t kbits, uint64_t groups, uint32_t *nranges);
+int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const uint32_t *counts, uint32_t nranges, uint32_t kbits, uint32_t *out_first,
+		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo);
 uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1);
 int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
 			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,

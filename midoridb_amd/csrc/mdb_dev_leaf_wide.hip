@@ -708,6 +708,10 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 		s_fc[s] = 0x07FFFFFFu;
 	for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
 		s_cl[s] = 0u;
+	uint32_t *const s_rg = s_cl + (T / 8 < 16u ? 16u : T / 8);	/* ranged emit (a.rg_rec): groups per range of first row ids, then their places */
+	if (a.rg_rec)
+		for (uint32_t r = threadIdx.x; r < a.rg_n; r += LW_THREADS)
+			s_rg[r] = 0u;
 	__syncthreads();
 	uint32_t rows_r = 0;
 	{
@@ -798,7 +802,10 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 		for (int w = 0; w < LW_THREADS / 64; w++)
 			total += s_red32[w];
 		uint32_t nb = 0xFFFFFFFFu;
-		if (total) {
+		if (total && a.rg_rec) {	/* (no list: the records go to their ranges) */
+			atomicAdd(a.rec_valid, total);
+			nb = 0u;
+		} else if (total) {
 			nb = atomicAdd(a.rec_count, total);
 			if (nb + total > a.rec_cap) {
 				mdb_raise(a.status, 8u);
@@ -821,7 +828,45 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 	}
 	const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
 	uint32_t cmax = 0, jsum = 0, last_first = 0;
-	for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {	/* (per_wave >= 4: tables of 64 values at least; lanes beyond per_wave idle) */
+	if (a.rg_rec && base != 0xFFFFFFFFu) {
+		/* the ordering kernel's ranges of 2^rg_shift first row ids are filled here: a digit's groups per range are counted, a place for
+		 * them reserved with one global atomic per (digit, range), and every record written there - ~8 records side by side per run */
+		for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {
+			const uint32_t sl = s_begin + s0;
+			if (s0 + lane < per_wave && ((s_cl[sl >> 3] >> nib) & 15u))
+				atomicAdd(&s_rg[(s_fc[sl] & 0x07FFFFFFu) >> a.rg_shift], 1u);
+		}
+		__syncthreads();
+		for (uint32_t r = threadIdx.x; r < a.rg_n; r += LW_THREADS) {
+			const uint32_t c = s_rg[r];
+			if (!c)
+				continue;
+			uint32_t at = atomicAdd(&a.rg_cnt[r], c);
+			if (at + c > a.rg_cap) {
+				mdb_raise(a.status, 8192u);	/* a range outgrew its region: the caller takes the record list and its sort */
+				at = a.rg_cap;
+			}
+			s_rg[r] = at;
+		}
+		__syncthreads();
+		for (uint32_t s0 = 0; s0 < per_wave; s0 += MDB_WAVE) {
+			const uint32_t sl = s_begin + s0;
+			const bool live = s0 + lane < per_wave;
+			const uint32_t fc = live ? s_fc[sl] : 0u, cl = live ? (s_cl[sl >> 3] >> nib) & 15u : 0u, cr = fc >> 27;
+			sum_cr += cr;
+			if (!cl)
+				continue;
+			const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr, r = first >> a.rg_shift;
+			jsum += c;
+			cmax = c > cmax ? c : cmax;
+			last_first = first > last_first ? first : last_first;
+			const uint32_t at = atomicAdd(&s_rg[r], 1u);
+			if (at < a.rg_cap)
+				a.rg_rec[(size_t)r * a.rg_cap + at] = ((unsigned long long)first << (64 - a.kbits)) |
+								       (a.keyed_cbits ? ((unsigned long long)((leaf << rem) | sl) << a.keyed_cbits) : 0ull) | c;
+		}
+	}
+	for (uint32_t s0 = 0; s0 < ((a.rg_rec && base != 0xFFFFFFFFu) ? 0u : per_wave); s0 += MDB_WAVE) {	/* (per_wave >= 4: tables of 64 values at least; lanes beyond per_wave idle) */
 		const uint32_t sl = s_begin + s0;
 		const bool live = s0 + lane < per_wave;
 		const uint32_t fc = live ? s_fc[sl] : 0u, cl = live ? (s_cl[sl >> 3] >> nib) & 15u : 0u, cr = fc >> 27;
@@ -898,7 +943,7 @@ int leaf_wide_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint3
 
 int leaf_wide4_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint32_t rem, uint32_t shift, uint32_t nsub)
 {
-	const size_t lds4 = ((size_t)4 << rem) + (((size_t)1 << rem) / 2 < 64 ? 64 : ((size_t)1 << rem) / 2);
+	const size_t lds4 = ((size_t)4 << rem) + (((size_t)1 << rem) / 2 < 64 ? 64 : ((size_t)1 << rem) / 2) + (a.rg_rec ? (size_t)a.rg_n * 4 : 0);
 	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
 	MDB_LAUNCH_LDS(ctx, "leaf_join_wide4", k_leaf_wide4, nleaves, LW_THREADS, lds4, a, rem, shift, nsub);
 	return MIDORIDB_OK;

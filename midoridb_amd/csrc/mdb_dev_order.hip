@@ -385,6 +385,58 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 	return MIDORIDB_OK;
 }
 
+/* Group records that their leaf kernel wrote straight into the ranges k_order_leaf_sparse ranks (k_leaf_wide4's ranged emit): the two
+ * scatter levels, their tile kernels and the record list are not there at all - variant D: 0.067 of the ordering's 0.115 ms. */
+bool order_ranges_apply(uint64_t n_l, uint32_t kbits, uint64_t groups, uint32_t *nranges)
+{
+	static_assert(ORDER_RANGE_BITS == OS_RANGE_BITS && ORDER_RANGE_CAP == OS_MAX_REC, "the ranged emit fills k_order_leaf_sparse's leaves");
+	if (!n_l || !order_sparse_bits(kbits))
+		return false;
+	const uint64_t used = ((n_l - 1) >> OS_RANGE_BITS) + 1;
+	*nranges = (uint32_t)used;
+	/* (the same head-room as order_records leaves its sparse attempt: an average range two thirds full at most) */
+	return used <= 1536 && groups && groups <= (uint64_t)(OS_MAX_REC - 1024) * 2 / 3 * used;
+}
+
+int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const uint32_t *counts, uint32_t nranges, uint32_t kbits, uint32_t *out_first,
+		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo)
+{
+	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)nranges + 1) * 4);
+	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nranges + 1) * 4);
+	if (!obase || !otmp)
+		return -MIDORIDB_INTERNAL;
+	int rc;
+	if (nranges <= MDB_SCAN_SMALL) {
+		rc = mdb_scan_u32_small_from(ctx, counts, nranges, obase);
+	} else {
+		MDB_HIP(ctx, hipMemcpyAsync(obase, counts, (size_t)nranges * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MDB_HIP(ctx, hipMemsetAsync(obase + nranges, 0, 4, ctx->stream));
+		rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)nranges + 1, otmp);
+	}
+	if (rc)
+		return rc;
+	ord_args oa;
+	memset(&oa, 0, sizeof(oa));
+	oa.rec = regions;
+	oa.cnt = counts;
+	oa.cap = ORDER_RANGE_CAP;
+	oa.out_base = obase;
+	oa.kbits = kbits;
+	oa.leaf_bits = kbits - OS_RANGE_BITS;
+	oa.out_first = out_first;
+	oa.out_count = out_count;
+	oa.keys = keys;
+	oa.out_key = out_key;
+	oa.keys32 = keys32 ? 1u : 0u;
+	oa.keyed_cbits = keyed_cbits;
+	oa.key_bits = key_bits;
+	oa.key_lo = key_lo;
+	oa.status = ctx->d_status;
+	MDB_LAUNCH(ctx, "order_leaf_sparse", k_order_leaf_sparse, nranges, OS_THREADS, oa);
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MIDORIDB_OK;
+}
+
 /* exported for mdb_dev_sort.hip (multi-column GROUP BY): same list format, bits chosen here */
 int mdb_order_records_by_rowid(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_rows, uint32_t kbits,
 			       uint32_t *out_first, int64_t *out_count)

@@ -259,6 +259,10 @@ class DeviceCtx:
         for the left table, leaves of up to 2^15 values shared by two workgroups)"""
         return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x1000)
 
+    def last_join_ranged_order(self):
+        """the last one-level join wrote its group records straight into the ordering kernel's row-id ranges (no record list, no sort levels)"""
+        return bool(self.lib.mdb_dev_last_join_filter(self.h) & 0x2000)
+
     def last_join_levels(self):
         """partition levels of the last join / GROUP BY operator's final attempt: 1 (wide direct-address leaves) or 2"""
         return 1 if int(self.lib.mdb_dev_last_join_filter(self.h)) & 0x1200 else 2

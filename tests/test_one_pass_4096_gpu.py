@@ -242,3 +242,39 @@ def test_one_pass_4096_random_shapes(dev, forced, seed):
         nl, nr = rng.random(len(kl)) < 0.04, rng.random(n_r) < 0.06
         nl[0] = nl[-1] = False
     _check(dev, kl, nl, kr, nr, expect_form=None, rounds=2)
+
+
+@pytest.mark.parametrize("shape", ["dim_in_low_range", "groups_bunched_in_the_first_rows", "more_groups_than_last_time"])
+def test_one_level_leaf_writes_its_records_into_the_ordering_ranges(dev, shape):
+    """From the second call over the same columns on, a one-level join whose group count is known and small enough writes its group records
+    straight into the ordering kernel's ranges of 2^16 row ids (no record list, no sort levels): the oracle's result; a range with more
+    groups than its region holds (groups bunched in the table's first rows; other data at the same addresses) sends the records through the
+    list and its sort."""
+    rng = np.random.default_rng(len(shape) * 13)
+    n_l, n_r = 2_600_000 + 31 * len(shape), 2_300_000
+    span = 1 << 20
+    if shape == "groups_bunched_in_the_first_rows":
+        # every left key that has a partner sits in the first 60 000 rows: one range of 2^16 ids gets all the groups
+        kl = (span + rng.permutation(4 * n_l)[:n_l]).astype(np.int64)
+        kl[:60_000] = rng.permutation(span)[:60_000]
+        kr = rng.permutation(span)[:60_000][rng.integers(0, 60_000, n_r)].astype(np.int64)
+        kr[:60_000] = kl[:60_000]
+    else:
+        kl = rng.permutation(16 * span)[:n_l].astype(np.int64)
+        kr = rng.integers(0, span, n_r, dtype=np.int64)
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    ranged = []
+    for round_ in range(3):
+        if shape == "more_groups_than_last_time" and round_ == 2:
+            # other data in the same buffers: many more groups than the remembered count
+            kl2 = rng.permutation(span + span // 2)[:n_l].astype(np.int64) if n_l <= span + span // 2 else None
+            kl = rng.integers(0, span, n_l, dtype=np.int64)
+            dl.copy_(torch.from_numpy(kl).to(dl.device))
+            ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, round_)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, round_)
+        ranged.append(dev.last_join_ranged_order())
+    if shape == "dim_in_low_range":
+        assert ranged == [False, True, True], ranged
