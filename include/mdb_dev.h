@@ -83,7 +83,9 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * (any group order); bit 12 = the ordered operator took ONE 4096-digit pass per table (key windows of 2^24 ... 2^27 values, from
  * 2^24 rows in all, at most 2^27 left rows, no min-max pruning to be had: the left table's rows travel as 4-byte words that name
  * their place in a 32 768-row tile, one workgroup joins a digit of up to 2^15 key values; MDB_WIDE12=0 turns it off,
- * MDB_WIDE12_MIN=<rows> moves the threshold; more than 31 right or 15 left rows of one key send the operator back to two levels). */
+ * MDB_WIDE12_MIN=<rows> moves the threshold; more than 31 right or 15 left rows of one key send the operator back to two levels); bit 13 = the
+ * one-level join wrote its group records straight into the ordering kernel's ranges of 2^16 row ids (from the second call over the same columns
+ * on, when the remembered group count is small enough; MDB_ORDER_RANGES=0 turns it off). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 /* 1 when the last mdb_dev_join_pairs() matched EVERY left row with exactly one right row (unique right keys, no left row
  * without a partner - the primary-key join of BASELINE configs[1]): out_l is then 0, 1, 2 ... and the left table's columns
