@@ -79,7 +79,12 @@ def run(args, world, rank, local_rank, json_fd):
                 return J
             if not args.reference_order:
                 return dev.join_keys(a, None, b, None).numel()      # the key column of every joined row, any order (mdb_dev_join_keys)
-            pl, pr = dev.join_pairs(a, None, b, None)       # (left row, right row) pairs in the reference's order + the key gather
+            # the reference's left-major row order: a primary-key join through the ordered join + GROUP BY + COUNT(*) operator
+            # (mdb_dev_join_keys_ordered, round 4); with duplicates on a side the pairs + the key gather
+            k = dev.join_keys_ordered(a, None, b, None)
+            if k is not None:
+                return k.numel()
+            pl, pr = dev.join_pairs(a, None, b, None)
             J = pl.numel()
             dev.gather64(a, None, pl, J)
             return J
@@ -104,7 +109,7 @@ def run(args, world, rank, local_rank, json_fd):
                                        + (" (key columns only: first-level partition regions on the wire, every key written COUNT times)"
                                           if fused else " (RCCL all-to-all of keys by destination, local join)")
                                        + (" (forced shuffle)" if world == 1 else "")) if use_dist else
-                                      ("single GPU, mdb_dev_join_pairs + key gather (the reference's left-major row order)" if args.reference_order else
+                                      ("single GPU, mdb_dev_join_keys_ordered (the reference's left-major row order; a primary-key join: the ordered join + GROUP BY + COUNT(*) operator, J == G)" if args.reference_order else
                                        "single GPU, mdb_dev_join_keys (key column of the joined rows in unspecified order, as the sharded "
                                        "form delivers it: regions of 2-byte words, no row ids)")},
             "pipeline": {"algorithmic_bytes": algo, "achieved_GBs": algo / (dt / args.steps) / 1e9,

@@ -1806,6 +1806,48 @@ int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t
 	return MIDORIDB_OK;
 }
 
+/* The same in the REFERENCE's row order (left-major, executor_select.c:1096-1141) for the join whose every key has one row on either
+ * side - a primary-key join: the ordered join + GROUP BY + COUNT(*) operator delivers the keys that have partners in the left table's row
+ * order, and J == G says that every COUNT is 1, i.e. that these keys ARE the joined rows.  *served = 0 (nothing allocated) when J != G -
+ * duplicates on a side: the caller's materialising join answers -, remembered for these columns. */
+extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
+					 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows, int *served)
+{
+	if (!ctx || !out_key || !out_rows || !served)
+		return -MIDORIDB_ERROR;
+	*out_key = NULL;
+	*out_rows = 0;
+	*served = 0;
+	if (!n_l || !n_r)
+		return MIDORIDB_OK;
+	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
+	if (ctx->jk_dup_l == keys_l && ctx->jk_dup_nl == n_l && ctx->jk_dup_r == keys_r && ctx->jk_dup_nr == n_r && ++ctx->jk_dup_uses < 32)
+		return MIDORIDB_OK;	/* (these columns had duplicates last time) */
+	int64_t *gk = NULL, *gc = NULL;
+	if (mdb_dev_alloc(ctx, n_l * 8, (void **)&gk) || mdb_dev_alloc(ctx, n_l * 8, (void **)&gc)) {
+		(void)mdb_dev_free(ctx, gk);
+		return -MIDORIDB_NOMEM;
+	}
+	uint64_t G = 0, J = 0;
+	const int rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, MDB_ORDER_FIRST, gk, gc, NULL, n_l, &G, &J);
+	(void)mdb_dev_free(ctx, gc);
+	if (rc || J != G) {
+		(void)mdb_dev_free(ctx, gk);
+		if (!rc) {
+			ctx->jk_dup_l = keys_l;
+			ctx->jk_dup_nl = n_l;
+			ctx->jk_dup_r = keys_r;
+			ctx->jk_dup_nr = n_r;
+			ctx->jk_dup_uses = 0;
+		}
+		return rc;
+	}
+	*out_key = gk;
+	*out_rows = G;
+	*served = 1;
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dev_join_keys(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows)
 {

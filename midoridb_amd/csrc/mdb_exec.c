@@ -629,13 +629,13 @@ int fused_chain(struct mdb_select *s, const struct mdb_expr **keys, bool count_o
 	return -1;
 }
 
-/* a two-table INNER JOIN ON l = r whose result columns are all one of the two key columns, nothing else asked of it, order left
- * open by the host (mdb_database_groups_any_order): kj[0..1] = the key fields (left table's first) */
+/* a two-table INNER JOIN ON l = r whose result columns are all one of the two key columns, nothing else asked of it: kj[0..1] = the key
+ * fields (left table's first).  With the order left open by the host (mdb_database_groups_any_order) mdb_dev_join_keys answers; in the
+ * reference's order mdb_dev_join_keys_ordered, when the join turns out to be a primary-key join */
 bool keys_only_join(const struct mdb_select *s, const struct mdb_catalog *cat, int has_count, const int *key_tbl, const int *key_col,
 			   const int *src, int ncols, const struct mdb_expr **kj)
 {
-	if (cat->dist || !cat->groups_any_order || s->ntabs != 2 || s->where || s->ngroup || has_count || s->distinct || s->norder || s->having ||
-	    s->has_limit || !ncols)
+	if (cat->dist || s->ntabs != 2 || s->where || s->ngroup || has_count || s->distinct || s->norder || s->having || s->has_limit || !ncols)
 		return false;
 	const struct mdb_expr *on = s->on[1];
 	if (!on || on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
@@ -749,6 +749,27 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	for (int i = 0; i < s->nsel; i++)
 		only_count = only_count && s->sel[i]->kind == MDB_EX_COUNT;
 	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys, only_count) : -1;
+	/* the join of two key columns, nothing else selected: in the reference's order it is tried as a primary-key join first (the keys with
+	 * partners in the left table's row order; large tables only: the attempt runs the ordered join + GROUP BY operator), and left to the
+	 * materialising join below when a key has several rows on a side */
+	bool keys_only = keys_only_join(s, cat, has_count, key_tbl, key_col, src, ncols, kj);
+	int64_t *keys_ordered = NULL;
+	uint64_t keys_ordered_rows = 0;
+	if (keys_only && !cat->groups_any_order) {
+		const struct mdb_table *tl = s->tabs[kj[0]->tbl_idx].t, *tr = s->tabs[kj[1]->tbl_idx].t;
+		int served = 0;
+		if (tl->nrows + tr->nrows >= (1u << 21) &&
+		    mdb_dev_join_keys_ordered(x.dev, tl->cols[kj[0]->col_idx].d_data, tl->cols[kj[0]->col_idx].d_nullbits, tl->nrows, tr->cols[kj[1]->col_idx].d_data,
+					      tr->cols[kj[1]->col_idx].d_nullbits, tr->nrows, &keys_ordered, &keys_ordered_rows, &served)) {
+			rc = dev_fail(&x, "join of two key columns");
+			goto out;
+		}
+		keys_only = served != 0;
+		if (keys_ordered && track(&x, keys_ordered)) {
+			rc = -MIDORIDB_NOMEM;
+			goto out;
+		}
+	}
 	if (fused >= 0 && (!split_ok || ws.nresidual))
 		fused = -1;	/* a conjunct reads several tables: it has to see the joined rows */
 	if (fused >= 0 && cat->dist && s->ntabs > 2 && fkeys[0]->type == MDB_CT_VARCHAR)
@@ -922,20 +943,20 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		x.fused = true;
 		x.n = only_count ? J : G;	/* COUNT(*) without GROUP BY = the stream length = the joined rows */
 		x.joined_rows = J;
-	} else if (keys_only_join(s, cat, has_count, key_tbl, key_col, src, ncols, kj)) {
+	} else if (keys_only) {
 		/* ---- a two-table equi-join whose select list names nothing but the two key columns (BASELINE configs[3]: SELECT * over
 		 *      two key columns), any order allowed (mdb_database_groups_any_order): both sides hold the same value in every
 		 *      joined row, so no row has to be identified - the any-order join + GROUP BY pipeline counts every key's partners and
 		 *      the key is written COUNT times (mdb_dev_join_keys); the stream is the fused plan's: one key column, no row ids */
 		const struct mdb_column *cl = &s->tabs[kj[0]->tbl_idx].t->cols[kj[0]->col_idx], *cr = &s->tabs[kj[1]->tbl_idx].t->cols[kj[1]->col_idx];
-		int64_t *jk = NULL;
-		uint64_t J = 0;
-		if (mdb_dev_join_keys(x.dev, cl->d_data, cl->d_nullbits, s->tabs[kj[0]->tbl_idx].t->nrows, cr->d_data, cr->d_nullbits,
-				      s->tabs[kj[1]->tbl_idx].t->nrows, &jk, &J)) {
+		int64_t *jk = keys_ordered;	/* (the reference's order: answered above) */
+		uint64_t J = keys_ordered_rows;
+		if (cat->groups_any_order && mdb_dev_join_keys(x.dev, cl->d_data, cl->d_nullbits, s->tabs[kj[0]->tbl_idx].t->nrows, cr->d_data, cr->d_nullbits,
+							      s->tabs[kj[1]->tbl_idx].t->nrows, &jk, &J)) {
 			rc = dev_fail(&x, "join of two key columns");
 			goto out;
 		}
-		if (jk && track(&x, jk)) {
+		if (jk && jk != keys_ordered && track(&x, jk)) {
 			rc = -MIDORIDB_NOMEM;
 			goto out;
 		}

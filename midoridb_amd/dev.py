@@ -90,6 +90,7 @@ def _bind(lib):
         "mdb_dev_group_count_multi": ([P, POINTER(SortKey), c_int, c_uint64, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_join_pairs": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dev_join_keys": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(c_uint64)], c_int),
+        "mdb_dev_join_keys_ordered": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(c_uint64), POINTER(c_int)], c_int),
         "mdb_dev_join_payload": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), c_int, POINTER(P)], c_int),
         "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
@@ -122,7 +123,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_map_ids",
+    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
@@ -451,6 +452,20 @@ class DeviceCtx:
         pk, cnt = c_void_p(), c_uint64()
         self._chk(self.lib.mdb_dev_join_keys(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), _ptr(keys_r), _ptr(null_r), keys_r.numel(),
                                              byref(pk), byref(cnt)), "join_keys")
+        if not cnt.value:
+            if pk:
+                self._chk(self.lib.mdb_dev_free(self.h, pk), "free")
+            return torch.empty(0, dtype=torch.int64, device=self.device)
+        return self._adopt(pk, cnt.value, torch.int64)
+
+    def join_keys_ordered(self, keys_l, null_l, keys_r, null_r):
+        """the join's key column in the reference's row order when it is a primary-key join (one row per key on either side), else None
+        (mdb_dev_join_keys_ordered)"""
+        pk, cnt, served = c_void_p(), c_uint64(), c_int()
+        self._chk(self.lib.mdb_dev_join_keys_ordered(self.h, _ptr(keys_l), _ptr(null_l), keys_l.numel(), _ptr(keys_r), _ptr(null_r), keys_r.numel(),
+                                                     byref(pk), byref(cnt), byref(served)), "join_keys_ordered")
+        if not served.value:
+            return None
         if not cnt.value:
             if pk:
                 self._chk(self.lib.mdb_dev_free(self.h, pk), "free")

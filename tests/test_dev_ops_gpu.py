@@ -2299,3 +2299,33 @@ def test_join_pairs_reports_an_identity_left_vector(dev):
     b2 = np.concatenate([b, b[:1]])                     # a right key twice: n + 1 pairs
     l, r = dev.join_pairs(dev.to_dev(a), None, dev.to_dev(b2), None)
     assert not dev.last_pairs_identity() and l.numel() == n + 1
+
+
+@pytest.mark.parametrize("shape", ["unique_both", "unique_both_nulls", "right_duplicates", "left_duplicates", "window_2^26"])
+def test_join_keys_in_the_references_order_for_primary_key_joins(dev, shape):
+    """mdb_dev_join_keys_ordered: a join whose only output is its key column, in the reference's left-major order
+    (executor_select.c:1096-1141), answered by the ordered join + GROUP BY + COUNT(*) operator when every key has one row on either side
+    (J == G) - the keys of the oracle's pairs; duplicates on a side are left to mdb_dev_join_pairs (None), remembered."""
+    rng = np.random.default_rng(len(shape) * 3)
+    n_l, n_r = 2_300_000 + 1000 * len(shape), 2_100_000 + 777 * len(shape)      # (what the operator remembers about a column pair goes by address and length)
+    span = (1 << 26) - 5 if shape == "window_2^26" else 3_000_000
+    kl = rng.permutation(span)[:n_l].astype(np.int64) - 1000
+    kr = rng.permutation(span)[:n_r].astype(np.int64) - 1000
+    nl = nr = None
+    if shape == "unique_both_nulls":
+        nl, nr = rng.random(n_l) < 0.05, rng.random(n_r) < 0.05
+    if shape == "right_duplicates":
+        kr[:1000] = kr[1000:2000]
+        kr[5] = kl[7]
+        kr[6] = kl[7]
+    if shape == "left_duplicates":
+        kl[10:20] = kl[30]
+        kr[3] = kl[30]
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
+    for round_ in range(2):
+        got = dev.join_keys_ordered(dl, dnl, dr, dnr)
+        if shape in ("right_duplicates", "left_duplicates"):
+            assert got is None, (shape, round_)
+        else:
+            assert got is not None and np.array_equal(_np(got), kl[el]), (shape, round_)
