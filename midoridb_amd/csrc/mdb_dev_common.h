@@ -101,6 +101,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	bool overlap;			/* false: everything on the main stream (isolated per-kernel timing) */
 	int last_semijoin;		/* ... and dropped left rows through the right table's key bitmap (0 no; else 1 + log2 values per bit) */
 	int last_narrow;		/* the last join / GROUP BY operator ran in the narrow form */
+	bool last_left_dups_known, last_left_dups;	/* ... through leaf kernels that tell whether a key with partners has several LEFT rows, and whether one has */
 	int last_pairs_identity;	/* the last mdb_dev_join_pairs: every left row joined exactly one right row - its left vector is 0, 1, 2 ... */
 	int narrow_mode;		/* 32-bit hashes for int32-range join keys: 0 never, 1 sampled + verified (default), 2 always try */
 	int unordered_no_counts;	/* set by mdb_dev_join_keys around its call of the any-order operator: group keys only, no COUNT column */

@@ -853,6 +853,8 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 					s_cl[s] = 0u;
 					s_first[s] = 0xFFFFFFFFu;
 					st.mine += c;
+					if (HAS_R && cl > 1u && cr)
+						mdb_raise(a.status, GC_ST_LEFT_DUPS);	/* (a matched key with several left rows: mdb_dev_join_keys_ordered asks) */
 					if (a.kbits && a.keyed_cbits) {
 						if (c >> a.keyed_cbits)
 							mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
@@ -1995,6 +1997,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		ctx->lg_valid = true;
 	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
+	ctx->last_left_dups_known = st->direct && has_r && !(status & 64u);	/* (the hot-key kernels and the hashed leaves do not say) */
+	ctx->last_left_dups = (status & GC_ST_LEFT_DUPS) != 0;
 	ctx->last_semijoin = (int)st->semijoin | ((st->defer_l || st->defer_l64) ? 0x100 : 0) | (st->one_level ? 0x200 : 0) | (st->nextra ? 0x400 : 0) |
 			     (st->wide12 ? 0x1000 : 0) | (ranged ? 0x2000 : 0);
 	return MIDORIDB_OK;

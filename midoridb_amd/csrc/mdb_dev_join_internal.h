@@ -170,6 +170,7 @@ __device__ static inline unsigned long long lw_block_sum(unsigned long long v, u
 	return t;
 }
 
+#define GC_ST_LEFT_DUPS 32768u	/* status bit 15: a key that has partners has several rows in the LEFT table (raised by the direct-address leaf kernels) */
 #define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
 #define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
 #define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */

@@ -198,6 +198,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 			const uint32_t cl = (cl2[k] >> (16 * e)) & 0xFFFFu;
 			if (!cl)
 				continue;
+			if (HAS_R && cl > 1u)
+				mdb_raise(a.status, GC_ST_LEFT_DUPS);
 			const uint32_t s = 2u * (threadIdx.x * W + (uint32_t)k) + (uint32_t)e;
 			const uint32_t first = s_first[s];
 			const unsigned long long c = (unsigned long long)cl * ((cr2[k] >> (16 * e)) & 0xFFFFu);
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			run = base + t;		/* (base = ~0: nothing is written) */
 		}
 		const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
-		uint32_t cmax = 0, jsum = 0;
+		uint32_t cmax = 0, jsum = 0, clmax = 0;
 		/* FMT 0: 8-byte records, 1: 4-byte records, 2: keyed 8-byte records */
 #define LW12_EMIT(FMT)                                                                                                                  \
 		for (uint32_t s0 = 0; s0 < per_wave; s0 += 4u * MDB_WAVE) {	/* (per_wave >= 256: a digit has 2^12 values at least) */   \
@@ -618,6 +620,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr;                                          \
 					jsum += c;                                                                                     \
 					cmax = c > cmax ? c : cmax;                                                                    \
+					clmax = cl > clmax ? cl : clmax;                                                               \
 					last_first = first > last_first ? first : last_first;                                          \
 					if (FMT == 1)                                                                                  \
 						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | c;              \
@@ -638,6 +641,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		}
 #undef LW12_EMIT
 		joined += jsum;
+		if (clmax > 1u)
+			mdb_raise(a.status, GC_ST_LEFT_DUPS);
 		if (cmax) {	/* (a COUNT(*) of at most 15 * 31) */
 			if (a.keyed_cbits && (cmax >> a.keyed_cbits))
 				mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 		run = base + t;
 	}
 	const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
-	uint32_t cmax = 0, jsum = 0, last_first = 0;
+	uint32_t cmax = 0, jsum = 0, last_first = 0, clmax = 0;
 	if (a.rg_rec && base != 0xFFFFFFFFu) {
 		/* the ordering kernel's ranges of 2^rg_shift first row ids are filled here: a digit's groups per range are counted, a place for
 		 * them reserved with one global atomic per (digit, range), and every record written there - ~8 records side by side per run */
@@ -859,6 +864,7 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 			const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr, r = first >> a.rg_shift;
 			jsum += c;
 			cmax = c > cmax ? c : cmax;
+			clmax = cl > clmax ? cl : clmax;
 			last_first = first > last_first ? first : last_first;
 			const uint32_t at = atomicAdd(&s_rg[r], 1u);
 			if (at < a.rg_cap)
@@ -880,6 +886,7 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 			const uint32_t first = fc & 0x07FFFFFFu, c = cl * cr;
 			jsum += c;
 			cmax = c > cmax ? c : cmax;
+			clmax = cl > clmax ? cl : clmax;
 			last_first = first > last_first ? first : last_first;
 			if (a.keyed_cbits)
 				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | ((unsigned long long)((leaf << rem) | sl) << a.keyed_cbits) | c;
@@ -887,6 +894,8 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 				a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;
 		}
 	}
+	if (clmax > 1u)
+		mdb_raise(a.status, GC_ST_LEFT_DUPS);
 	if (cmax) {
 		if (a.keyed_cbits && (cmax >> a.keyed_cbits))
 			mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */

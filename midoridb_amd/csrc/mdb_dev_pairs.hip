@@ -1806,10 +1806,11 @@ int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t
 	return MIDORIDB_OK;
 }
 
-/* The same in the REFERENCE's row order (left-major, executor_select.c:1096-1141) for the join whose every key has one row on either
- * side - a primary-key join: the ordered join + GROUP BY + COUNT(*) operator delivers the keys that have partners in the left table's row
- * order, and J == G says that every COUNT is 1, i.e. that these keys ARE the joined rows.  *served = 0 (nothing allocated) when J != G -
- * duplicates on a side: the caller's materialising join answers -, remembered for these columns. */
+/* The same in the REFERENCE's row order (left-major, executor_select.c:1096-1141) for the join whose matched keys are unique in the LEFT
+ * table: the ordered join + GROUP BY + COUNT(*) operator delivers the keys that have partners in the left table's row order with their
+ * COUNTs; J == G says that every COUNT is 1 - these keys ARE the joined rows -, and when its direct-address leaf kernels saw no key with
+ * several left rows (status bit GC_ST_LEFT_DUPS) a COUNT is the number of the left row's partners: the key, COUNT times.  *served = 0
+ * (nothing allocated) otherwise - the caller's materialising join answers -, remembered for these columns. */
 extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 					 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows, int *served)
 {
@@ -1829,7 +1830,22 @@ extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l
 		return -MIDORIDB_NOMEM;
 	}
 	uint64_t G = 0, J = 0;
-	const int rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, MDB_ORDER_FIRST, gk, gc, NULL, n_l, &G, &J);
+	ctx->last_left_dups_known = false;
+	int rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, MDB_ORDER_FIRST, gk, gc, NULL, n_l, &G, &J);
+	if (!rc && J != G && ctx->last_left_dups_known && !ctx->last_left_dups) {
+		/* duplicates on the RIGHT side only (a dimension joined with its facts): a left row's joined rows all carry its key - the key,
+		 * COUNT times, in the left table's row order */
+		int64_t *rows = NULL;
+		rc = mdb_expand_keys_by_count(ctx, gk, gc, G, J, &rows);
+		(void)mdb_dev_free(ctx, gk);
+		(void)mdb_dev_free(ctx, gc);
+		if (rc)
+			return rc;
+		*out_key = rows;
+		*out_rows = J;
+		*served = 1;
+		return MIDORIDB_OK;
+	}
 	(void)mdb_dev_free(ctx, gc);
 	if (rc || J != G) {
 		(void)mdb_dev_free(ctx, gk);

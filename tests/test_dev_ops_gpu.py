@@ -2305,7 +2305,8 @@ def test_join_pairs_reports_an_identity_left_vector(dev):
 def test_join_keys_in_the_references_order_for_primary_key_joins(dev, shape):
     """mdb_dev_join_keys_ordered: a join whose only output is its key column, in the reference's left-major order
     (executor_select.c:1096-1141), answered by the ordered join + GROUP BY + COUNT(*) operator when every key has one row on either side
-    (J == G) - the keys of the oracle's pairs; duplicates on a side are left to mdb_dev_join_pairs (None), remembered."""
+    (J == G), or one row in the LEFT table (the direct-address leaf kernels say so): every key COUNT times at its left row's place - the keys
+    of the oracle's pairs; duplicate LEFT keys are left to mdb_dev_join_pairs (None), remembered."""
     rng = np.random.default_rng(len(shape) * 3)
     n_l, n_r = 2_300_000 + 1000 * len(shape), 2_100_000 + 777 * len(shape)      # (what the operator remembers about a column pair goes by address and length)
     span = (1 << 26) - 5 if shape == "window_2^26" else 3_000_000
@@ -2325,7 +2326,43 @@ def test_join_keys_in_the_references_order_for_primary_key_joins(dev, shape):
     dl, dr, dnl, dnr = dev.to_dev(kl), dev.to_dev(kr), dev.nullbits_dev(nl), dev.nullbits_dev(nr)
     for round_ in range(2):
         got = dev.join_keys_ordered(dl, dnl, dr, dnr)
-        if shape in ("right_duplicates", "left_duplicates"):
+        if shape == "left_duplicates":       # (the materialising join answers: rows of one key are not adjacent in the left-major order)
             assert got is None, (shape, round_)
-        else:
+        else:                               # (duplicates on the right side only: every key COUNT times at its left row's place)
             assert got is not None and np.array_equal(_np(got), kl[el]), (shape, round_)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_join_keys_in_the_references_order_random_shapes(dev, seed):
+    """Random sizes, key windows (one 9-bit level, two levels, the 4096-digit pass, keys outside every window), right-side multiplicities
+    from 1 to 70, NULLs: whenever mdb_dev_join_keys_ordered answers, it is the key column of the oracle's pairs in their order; duplicate
+    left keys among the matched ones always make it decline."""
+    rng = np.random.default_rng(4000 + seed)
+    n_l = int(rng.integers(1_100_000, 2_400_000)) + seed
+    n_r = int(rng.integers(1_100_000, 2_400_000)) + 3 * seed
+    bits = int(rng.choice([21, 22, 23, 25, 26, 40]))
+    span = (1 << bits) - int(rng.integers(1, 1 << (bits - 3))) if bits < 40 else None
+    kl = (rng.permutation(span)[:n_l] if span else rng.integers(0, 1 << 40, n_l)).astype(np.int64)
+    n_l = len(kl)
+    if span is None:
+        kl = np.unique(kl)
+        rng.shuffle(kl)
+        n_l = len(kl)
+    mult = int(rng.choice([1, 1, 2, 7, 30, 70]))
+    pool = kl[rng.integers(0, n_l, max(n_r // mult, 1))]
+    kr = pool[rng.integers(0, len(pool), n_r)].astype(np.int64)
+    left_dups = rng.random() < 0.3
+    if left_dups:
+        kl[100:103] = kr[17]
+    nl = nr = None
+    if rng.random() < 0.4:
+        nl, nr = rng.random(n_l) < 0.03, rng.random(n_r) < 0.03
+        if left_dups:
+            nl[100:103] = False
+            nr[17] = False
+    el, er = orc.join_pairs(kl, nl, kr, nr)
+    got = dev.join_keys_ordered(dev.to_dev(kl), dev.nullbits_dev(nl), dev.to_dev(kr), dev.nullbits_dev(nr))
+    if left_dups:
+        assert got is None
+    elif got is not None:
+        assert np.array_equal(_np(got), kl[el]), (seed, bits, mult)
