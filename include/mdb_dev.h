@@ -85,7 +85,8 @@ int mdb_dev_last_join_narrow(mdb_dev_ctx *ctx);
  * their place in a 32 768-row tile, one workgroup joins a digit of up to 2^15 key values; MDB_WIDE12=0 turns it off,
  * MDB_WIDE12_MIN=<rows> moves the threshold; more than 31 right or 15 left rows of one key send the operator back to two levels); bit 13 = the
  * one-level join wrote its group records straight into the ordering kernel's ranges of 2^16 row ids (from the second call over the same columns
- * on, when the remembered group count is small enough; MDB_ORDER_RANGES=0 turns it off). */
+ * on, when the remembered group count is small enough; MDB_ORDER_RANGES=0 turns it off) - the ordering kernel is then launched right behind the
+ * leaf kernel, before the host has seen the group count, its writes bounded by `cap`: one sync per call (MDB_ORDER_EARLY=0: two). */
 int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
 /* 1 when the last mdb_dev_join_pairs() matched EVERY left row with exactly one right row (unique right keys, no left row
  * without a partner - the primary-key join of BASELINE configs[1]): out_l is then 0, 1, 2 ... and the left table's columns

@@ -1812,6 +1812,17 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	uint64_t *h = ctx->h_pinned;
 	uint64_t G = 0, list_len = 0;
 	uint32_t *first_out = out_first ? out_first : sel;
+	/* ... except where the leaf kernel has filled the ordering kernel's ranges itself: that kernel needs no size, and is launched right behind it
+	 * (its writes bounded by the caller's capacity; should the status words ask for another path, that path writes the columns again) - the
+	 * step's only sync then comes after its last kernel (MDB_ORDER_EARLY=0: after the leaf kernel, as elsewhere) */
+	bool ordered_early = false;
+	if (ranged && cap && !(getenv("MDB_ORDER_EARLY") && getenv("MDB_ORDER_EARLY")[0] == '0')) {
+		rc = order_presorted(ctx, a.rg_rec, a.rg_cnt, rg_n, kbits, out_first, out_count, keys_l, out_key, st->keys32, keyed_cbits, st->key_bits,
+				     st->key_lo, cap);
+		if (rc)
+			return rc;
+		ordered_early = true;
+	}
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (leaf4 && ((uint32_t)h[1] & (4096u | 8192u)) && !((uint32_t)h[1] & (2u | 128u))) {
@@ -1953,7 +1964,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* (one-level leaves report the largest first row id: the sort's first-level regions are sized for the digits below it) */
 		const uint64_t last_first = (uint32_t)(h[5] >> 32);
 		const uint64_t n_ord = (st->one_level && last_first && last_first < n_l) ? last_first + 1 : n_l;
-		if (ranged)
+		if (ranged && ordered_early)
+			rc = MIDORIDB_OK;	/* (done, and waited for with the status words) */
+		else if (ranged)
 			rc = order_presorted(ctx, a.rg_rec, a.rg_cnt, rg_n, kbits, out_first, out_count, keys_l, out_key, st->keys32, keyed_cbits, st->key_bits,
 					     st->key_lo);
 		else

@@ -223,7 +223,8 @@ bool order_bits(uint64_t n_l, uint32_t *kbits, int *sb1, int *sb2);
 #define ORDER_RANGE_CAP 8192u
 bool order_ranges_apply(uint64_t n_l, uint32_t kbits, uint64_t groups, uint32_t *nranges);
 int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const uint32_t *counts, uint32_t nranges, uint32_t kbits, uint32_t *out_first,
-		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo);
+		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo,
+		    uint64_t early_cap = 0);
 uint32_t order_digits0(uint64_t n_l, uint32_t kbits, int sb1);
 int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list_len, uint64_t n_l, uint32_t kbits, int sb1,
 			 int sb2, uint32_t *out_first, int64_t *out_count, uint32_t *out_val32, const int64_t *keys, int64_t *out_key,

@@ -38,7 +38,10 @@ struct ord_args {
 					 * is key_lo + mdb_unmixk(hashed key, key_bits), nothing is gathered */
 	uint32_t key_bits;
 	int64_t key_lo;
-	uint32_t *status;		/* k_order_leaf_sparse: bit 1 when a leaf holds more records than it can rank */
+	uint32_t *status;		/* k_order_leaf_sparse: bit 1 when a leaf holds more records than it can rank (NULL: such a leaf is skipped in silence -
+					 * the caller learns of it from the kernel that filled the leaves) */
+	uint32_t out_cap;		/* k_order_leaf_sparse, != 0: rows of the output columns; groups beyond are not written (launched before the group
+					 * count is known to the host) */
 };
 
 __global__ __launch_bounds__(ORD_THREADS) void k_order_leaf(ord_args a)
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_order_leaf_sparse(ord_args a)
 		return;
 	if (c > a.cap || c > OS_MAX_REC) {	/* the scatter's region overflowed, or more records than the registers of a workgroup hold
 						 * (row ids bunched): the general path takes over */
-		if (threadIdx.x == 0)
+		if (threadIdx.x == 0 && a.status)
 			mdb_raise(a.status, 2u);
 		return;
 	}
@@ -199,6 +202,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_order_leaf_sparse(ord_args a)
 		const unsigned long long rec = s_stage[i];
 		const uint32_t idx = (uint32_t)(rec >> (64 - a.kbits)) & (range - 1);
 		const uint32_t pos = base + i;
+		if (a.out_cap && pos >= a.out_cap)
+			break;
 		const uint32_t first = (leaf << range_bits) + idx;
 		const unsigned long long pay = rec & cmask;
 		if (a.out_first)
@@ -339,6 +344,7 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 		if (rc)
 			return rc;
 		ord_args oa;
+		memset(&oa, 0, sizeof(oa));
 		oa.rec = (const unsigned long long *)ps.hv;
 		oa.off = ps.leaf_off;
 		oa.cnt = ps.leaf_cnt;
@@ -399,7 +405,8 @@ bool order_ranges_apply(uint64_t n_l, uint32_t kbits, uint64_t groups, uint32_t 
 }
 
 int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const uint32_t *counts, uint32_t nranges, uint32_t kbits, uint32_t *out_first,
-		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo)
+		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo,
+		    uint64_t early_cap)
 {
 	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)nranges + 1) * 4);
 	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nranges + 1) * 4);
@@ -431,9 +438,13 @@ int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const u
 	oa.keyed_cbits = keyed_cbits;
 	oa.key_bits = key_bits;
 	oa.key_lo = key_lo;
-	oa.status = ctx->d_status;
+	/* early_cap != 0: launched behind the kernel that fills the ranges, before its status words have been looked at - no status of its own, no
+	 * write beyond the caller's columns, no sync: the caller's one sync covers both kernels */
+	oa.status = early_cap ? NULL : ctx->d_status;
+	oa.out_cap = early_cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)early_cap;
 	MDB_LAUNCH(ctx, "order_leaf_sparse", k_order_leaf_sparse, nranges, OS_THREADS, oa);
-	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (!early_cap)
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MIDORIDB_OK;
 }
 

@@ -278,3 +278,36 @@ def test_one_level_leaf_writes_its_records_into_the_ordering_ranges(dev, shape):
         ranged.append(dev.last_join_ranged_order())
     if shape == "dim_in_low_range":
         assert ranged == [False, True, True], ranged
+
+
+def test_ordering_launched_before_the_group_count_is_known_stays_inside_the_callers_columns(dev):
+    """With the ranges filled by the leaf kernel, the ordering kernel is launched right behind it, before the host has seen the group
+    count: result columns SMALLER than the groups are reported (the operator's capacity error), and nothing is written behind them."""
+    from ctypes import byref, c_uint64, c_void_p
+    from midoridb_amd import dev as D
+    rng = np.random.default_rng(77)
+    n_l, n_r, span = 2_600_077, 2_300_000, 1 << 20
+    kl = rng.permutation(16 * span)[:n_l].astype(np.int64)
+    kr = rng.integers(0, span, n_r, dtype=np.int64)
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    G = len(ek)
+    for _ in range(2):
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+    assert dev.last_join_ranged_order() and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    cap, guard = G - 1000, 4096
+    SENT = -0x0123456789ABCDEF
+    ok = torch.full((cap + guard,), SENT, dtype=torch.int64, device=dl.device)
+    oc = torch.full((cap + guard,), SENT, dtype=torch.int64, device=dl.device)
+    of = torch.full((cap + guard,), -7, dtype=torch.int32, device=dl.device)
+    g, j = c_uint64(), c_uint64()
+    rc = dev.lib.mdb_dev_join_group_count(dev.h, c_void_p(dl.data_ptr()), None, n_l, c_void_p(dr.data_ptr()), None, n_r, D.MDB_ORDER_FIRST,
+                                          c_void_p(ok.data_ptr()), c_void_p(oc.data_ptr()), c_void_p(of.data_ptr()), cap, byref(g), byref(j))
+    assert rc != 0 and b"capacity" in (dev.lib.mdb_dev_last_error(dev.h) or b"")
+    torch.cuda.synchronize()
+    assert bool((ok[cap:] == SENT).all()) and bool((oc[cap:] == SENT).all()) and bool((of[cap:] == -7).all())
+    # exactly enough room: served, and the sentinel behind the last group is still there
+    rc = dev.lib.mdb_dev_join_group_count(dev.h, c_void_p(dl.data_ptr()), None, n_l, c_void_p(dr.data_ptr()), None, n_r, D.MDB_ORDER_FIRST,
+                                          c_void_p(ok.data_ptr()), c_void_p(oc.data_ptr()), c_void_p(of.data_ptr()), G, byref(g), byref(j))
+    assert rc == 0 and g.value == G and j.value == ej
+    assert np.array_equal(_np(ok[:G]), ek) and np.array_equal(_np(oc[:G]), ec) and int(ok[G]) == SENT and int(of[G]) == -7
