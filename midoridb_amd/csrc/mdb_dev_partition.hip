@@ -696,7 +696,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		}
 		const uint32_t t = part_tile_of_block();
 		a.minmax64_out[2 * t] = mn;
-		a.minmax64_out[2 * t + 1] = ~mx;	/* (stored inverted: the array is initialised with one memset of 0xFF) */
+		a.minmax64_out[2 * t + 1] = ~mx;	/* (stored inverted) */
 	}
 	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_out && threadIdx.x == 0) {
 		/* one pair of plain stores per tile, reduced by k_part_minmax_reduce: atomics on two words from every wave of every
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		}
 		const uint32_t t = part_tile_of_block();
 		a.minmax_out[2 * t] = mn;
-		a.minmax_out[2 * t + 1] = ~mx;		/* (stored inverted: the array is initialised with one memset of 0xFF) */
+		a.minmax_out[2 * t + 1] = ~mx;		/* (stored inverted) */
 	}
 
 	/* 2. rank inside the digit */
@@ -1307,8 +1307,6 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<pf_word_raw>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
-					if (a.minmax_out)
-						MDB_HIP(ctx, hipMemsetAsync(a.minmax_out, 0xFF, (size_t)grid8(ntiles) * 8, ctx->stream));
 					if (out16) {
 						a.out16_shift = 32u - narrow_kbits;
 						if (cf) {
@@ -1325,7 +1323,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32>), grid8(ntiles), PART_THREADS, a);
 					}
 					if (a.minmax_out)
-						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, grid8(ntiles), flt->minmax_out);
+						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, ntiles, flt->minmax_out);	/* (every tile below ntiles has left its pair) */
 				} else if (npay) {
 					if (!cf || a.narrow != 1u)
 						return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "payload cells travel with the compact narrow form's hash | row id words only");
@@ -1340,9 +1338,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				} else if (want_rid) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_rid", (k_part_scatter<pf_key_rid>), grid8(ntiles), PART_THREADS, a);
 				} else if (a.minmax64_out) {		/* 64-bit form, right table: its key range recorded */
-					MDB_HIP(ctx, hipMemsetAsync(a.minmax64_out, 0xFF, (size_t)grid8(ntiles) * 16, ctx->stream));
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_mm64>), grid8(ntiles), PART_THREADS, a);
-					MDB_LAUNCH(ctx, "part_minmax", k_part_minmax64_reduce, 1, 1024, (const unsigned long long *)a.minmax64_out, grid8(ntiles),
+					MDB_LAUNCH(ctx, "part_minmax", k_part_minmax64_reduce, 1, 1024, (const unsigned long long *)a.minmax64_out, ntiles,
 						   flt->minmax64_out);
 				} else if (a.range_in && cf) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
 					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key_cf>),
