@@ -141,9 +141,19 @@ __global__ __launch_bounds__(OS_THREADS) void k_order_leaf_sparse(ord_args a)
 	__shared__ unsigned long long s_stage[OS_MAX_REC];	/* the records at their ranks */
 	__shared__ uint32_t s_scan[32];
 	const uint32_t leaf = blockIdx.x;
-	const uint32_t c = a.cnt[leaf], b = leaf * a.cap, e = b + c, base = a.out_base[leaf];
+	const uint32_t c = a.cnt[leaf], b = leaf * a.cap, e = b + c;
 	if (!c)
 		return;
+	uint32_t base;
+	if (a.out_base) {
+		base = a.out_base[leaf];
+	} else {		/* (uniform) no scanned counts: the leaves before this one are few enough (<= 1536) to be added up here */
+		uint32_t mine = 0;
+		for (uint32_t i = threadIdx.x; i < leaf; i += OS_THREADS)
+			mine += a.cnt[i];
+		(void)mdb_block_excl_scan(mine, s_scan, &base);
+		__syncthreads();	/* (s_scan is used again below) */
+	}
 	if (c > a.cap || c > OS_MAX_REC) {	/* the scatter's region overflowed, or more records than the registers of a workgroup hold
 						 * (row ids bunched): the general path takes over */
 		if (threadIdx.x == 0 && a.status)
@@ -408,26 +418,13 @@ int order_presorted(mdb_dev_ctx *ctx, const unsigned long long *regions, const u
 		    int64_t *out_count, const int64_t *keys, int64_t *out_key, bool keys32, uint32_t keyed_cbits, uint32_t key_bits, int64_t key_lo,
 		    uint64_t early_cap)
 {
-	uint32_t *obase = (uint32_t *)mdb_arena_take(ctx, ((size_t)nranges + 1) * 4);
-	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)nranges + 1) * 4);
-	if (!obase || !otmp)
-		return -MIDORIDB_INTERNAL;
-	int rc;
-	if (nranges <= MDB_SCAN_SMALL) {
-		rc = mdb_scan_u32_small_from(ctx, counts, nranges, obase);
-	} else {
-		MDB_HIP(ctx, hipMemcpyAsync(obase, counts, (size_t)nranges * 4, hipMemcpyDeviceToDevice, ctx->stream));
-		MDB_HIP(ctx, hipMemsetAsync(obase + nranges, 0, 4, ctx->stream));
-		rc = mdb_scan_u32_inplace(ctx, obase, (uint64_t)nranges + 1, otmp);
-	}
-	if (rc)
-		return rc;
+	/* (no scan of the counts: at most 1536 ranges - every workgroup adds up the counts before its own) */
 	ord_args oa;
 	memset(&oa, 0, sizeof(oa));
 	oa.rec = regions;
 	oa.cnt = counts;
 	oa.cap = ORDER_RANGE_CAP;
-	oa.out_base = obase;
+	oa.out_base = NULL;
 	oa.kbits = kbits;
 	oa.leaf_bits = kbits - OS_RANGE_BITS;
 	oa.out_first = out_first;
