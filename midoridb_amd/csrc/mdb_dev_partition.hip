@@ -88,6 +88,7 @@ struct mdb_level_args {
 	 * launch - later on the same stream - reads them through range_in and drops every row outside: such a row can join
 	 * nothing.  Exact, and free: one compare per row, no extra pass, no host round trip */
 	uint32_t *minmax_out;
+	uint32_t *minmax_final;	/* with minmax_out: the two words the reduce kernel's workgroups meet in - preset here (no key: lo > hi) */
 	const uint32_t *range_in;
 	/* the same for the 64-bit form (keys that fit no 2^32 window: hashes, snowflake ids - R64 instances): per-tile pairs of the
 	 * smallest / largest key as order-preserving unsigned images (key ^ 2^63; the largest stored inverted) / the other table's
@@ -496,6 +497,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	__shared__ uint8_t s_ok[FAST ? PART_MAX_R : 1];			/* FAST: the digit's run fits its region */
 	__shared__ uint32_t s_tmp[32];
 
+	if (LEVEL0 && FAST && !RAW && !INV && !HAS_RID && a.minmax_final && blockIdx.x == 0 && threadIdx.x == 0) {
+		a.minmax_final[0] = 0xFFFFFFFFu;
+		a.minmax_final[1] = 0u;
+	}
 	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
 	if (td.len == 0)
 		return;
@@ -1073,15 +1078,33 @@ __global__ __launch_bounds__(1024) void k_part_minmax64_reduce(const unsigned lo
 	}
 }
 
-/* per-tile (min, max) pairs of the right table's first level -> the two words the left table's first level reads */
-__global__ __launch_bounds__(1024) void k_part_minmax_reduce(const uint32_t *__restrict__ tile_mm, uint32_t ntiles, uint32_t *__restrict__ out)
+/* per-tile (min, max) pairs of the right table's first level -> the two words the left table's first level reads.  One workgroup takes ~10 us
+ * for the 195 KB of a 10^8-row table (what one CU can pull), so MM_GROUPS of them share the pairs and meet in the two words with one atomic pair per
+ * wave; the words are preset by the scatter kernel's first workgroup (mdb_level_args.minmax_final) */
+#define MM_GROUPS 64u
+#define MM_THREADS 256u
+__global__ __launch_bounds__(MM_THREADS) void k_part_minmax_reduce(const uint32_t *__restrict__ tile_mm, uint32_t ntiles, uint32_t *__restrict__ out)
 {
-	__shared__ uint32_t s_mn[16], s_mx[16];
 	uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-		const uint32_t a = tile_mm[2 * t], b = ~tile_mm[2 * t + 1];
-		mn = a < mn ? a : mn;
-		mx = b > mx ? b : mx;
+	/* two pairs per 16-byte load, a workgroup's loads issued together where they are few */
+	const uint4 *const mm2 = reinterpret_cast<const uint4 *>(tile_mm);
+	const uint32_t n2 = ntiles / 2u;
+	for (uint32_t t0 = blockIdx.x * MM_THREADS; t0 < n2; t0 += 4u * MM_GROUPS * MM_THREADS) {
+		uint4 q[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4u; u++) {
+			const uint32_t t = t0 + u * MM_GROUPS * MM_THREADS + threadIdx.x;
+			q[u] = t < n2 ? mm2[t] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < 4u; u++) {
+			mn = min(mn, min(q[u].x, q[u].z));
+			mx = max(mx, max(~q[u].y, ~q[u].w));
+		}
+	}
+	if ((ntiles & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+		mn = min(mn, tile_mm[2u * (ntiles - 1u)]);
+		mx = max(mx, ~tile_mm[2u * (ntiles - 1u) + 1u]);
 	}
 #pragma unroll
 	for (int o = MDB_WAVE / 2; o > 0; o >>= 1) {
@@ -1089,18 +1112,9 @@ __global__ __launch_bounds__(1024) void k_part_minmax_reduce(const uint32_t *__r
 		mn = omin < mn ? omin : mn;
 		mx = omax > mx ? omax : mx;
 	}
-	if (mdb_lane() == 0) {
-		s_mn[threadIdx.x / MDB_WAVE] = mn;
-		s_mx[threadIdx.x / MDB_WAVE] = mx;
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		for (int w = 0; w < 16; w++) {
-			mn = s_mn[w] < mn ? s_mn[w] : mn;
-			mx = s_mx[w] > mx ? s_mx[w] : mx;
-		}
-		out[0] = mn;
-		out[1] = mx;
+	if (mdb_lane() == 0 && mn <= mx) {	/* (a wave that saw no key has nothing to add) */
+		atomicMin(&out[0], mn);
+		atomicMax(&out[1], mx);
 	}
 }
 
@@ -1268,6 +1282,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 		a.keep_lo = flt ? flt->keep_lo : 0;
 		a.keep_hi = flt ? flt->keep_hi : 0;
 		a.minmax_out = (flt && l == 0 && flt->minmax_out) ? flt->minmax_tiles : NULL;	/* per-tile pairs, reduced after the launch */
+		a.minmax_final = a.minmax_out ? flt->minmax_out : NULL;
 		a.range_in = (flt && l == 0) ? flt->range_in : NULL;
 		a.minmax64_out = (flt && l == 0 && flt->minmax64_out) ? flt->minmax64_tiles : NULL;
 		a.range64_in = (flt && l == 0) ? flt->range64_in : NULL;
@@ -1323,7 +1338,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32>), grid8(ntiles), PART_THREADS, a);
 					}
 					if (a.minmax_out)
-						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, 1, 1024, (const uint32_t *)a.minmax_out, ntiles, flt->minmax_out);	/* (every tile below ntiles has left its pair) */
+						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, MM_GROUPS, MM_THREADS, (const uint32_t *)a.minmax_out, ntiles, flt->minmax_out);	/* (every tile below ntiles has left its pair) */
 				} else if (npay) {
 					if (!cf || a.narrow != 1u)
 						return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "payload cells travel with the compact narrow form's hash | row id words only");
