@@ -159,6 +159,7 @@ __device__ static inline uint32_t part_tile_of_block(void)
 	return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 }
 
+template <uint32_t TILE = MDB_TILE>
 __device__ static inline mdb_tile_desc part_get_tile(const mdb_level_args &a, uint32_t t)
 {
 	mdb_tile_desc d;
@@ -168,9 +169,9 @@ __device__ static inline mdb_tile_desc part_get_tile(const mdb_level_args &a, ui
 	}
 	if (a.tiles)
 		return a.tiles[t];
-	const uint64_t start = (uint64_t)t * MDB_TILE;
+	const uint64_t start = (uint64_t)t * TILE;
 	d.start = (uint32_t)start;
-	d.len = start < a.n ? (uint32_t)((a.n - start) < MDB_TILE ? (a.n - start) : MDB_TILE) : 0;
+	d.len = start < a.n ? (uint32_t)((a.n - start) < TILE ? (a.n - start) : TILE) : 0;
 	d.hbase = t;
 	d.nt = a.ntiles;
 	d.seg = 0;
@@ -395,14 +396,14 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(mdb_level_args a)
  * MODE 1 (the one in use): min-max pruning, the left table - rows outside [range_lo, range_hi] are dropped (a key outside the
  * window is outside the range: nothing to report); 0: plain; 2: the right table of a pruned join - the smallest / largest
  * key - window base is recorded.  -> a key outside the window was seen (modes 0 and 2). */
-template <bool W32v, int MODE, typename W>
+template <bool W32v, int MODE, typename W, int ITEMS = PART_ITEMS>
 __device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulonglong2 *pre, uint32_t row0, W *hv, uint32_t *dig, uint64_t range_lo,
 					   uint64_t range_hi, uint32_t &seen_min, uint32_t &seen_max)
 {
 	bool any_bad = false;
 	const uint32_t dshift = a.shift - (W32v ? 0u : 32u);	/* the digit's place inside the 32-bit hash */
 #pragma unroll
-	for (int r = 0; r < PART_ITEMS / 2; r++) {
+	for (int r = 0; r < ITEMS / 2; r++) {
 #pragma unroll
 		for (int e = 0; e < 2; e++) {
 			const uint64_t key = (e ? pre[r].y : pre[r].x) - (uint64_t)a.narrow_base;
@@ -435,6 +436,7 @@ __device__ static inline bool part_cf_rows(const mdb_level_args &a, const ulongl
 struct pf_base {
 	static constexpr bool LEVEL0 = false, HAS_RID = false, STABLE = false, FAST = false, RAW = false, W32 = false, INV = false, FILT = false,
 			      OUT16 = false, CF = false, R64 = false, MM64 = false, PAY = false;
+	static constexpr uint32_t TMUL = 1;	/* tile = TMUL x MDB_TILE rows (a histogram-free pass that cuts its own tiles: large tables) */
 };
 struct pf_word_hist : pf_base {  };
 struct pf_word_hist_raw : pf_base { static constexpr bool RAW = true; };
@@ -461,6 +463,12 @@ struct pf_key_rid_hist : pf_base { static constexpr bool LEVEL0 = true; static c
 struct pf_key_rid_hist_dest : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool INV = true; };
 struct pf_key_rid : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; };
 struct pf_key_rid_stable_hist : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool STABLE = true; };
+/* the same with tiles of 2 x MDB_TILE rows (tables of 2^25 rows and more: half the cursor atomics, runs twice as long - whole 32-byte sectors of
+ * 2-byte words; 10^8 rows: the right table's pass 0.241 -> 0.222 ms, the ordering sort's first level 0.174 -> 0.155, same-box A/B.  Smaller tables
+ * keep MDB_TILE: fewer tiles than workgroup slots leave CUs idle) */
+struct pf_key_cf_t2 : pf_key_cf { static constexpr uint32_t TMUL = 2; };
+struct pf_key_w32_out16_cf_t2 : pf_key_w32_out16_cf { static constexpr uint32_t TMUL = 2; };
+struct pf_word_raw_w32_t2 : pf_word_raw_w32 { static constexpr uint32_t TMUL = 2; };
 /* min-max pruning in the 64-bit form: the right table's first level records its key range (mm64), the left table's drops the rows outside (r64) */
 struct pf_key_mm64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool MM64 = true; };
 struct pf_key_rid_r64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; static constexpr bool R64 = true; };
@@ -483,13 +491,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	/* W32: the words staged and written are 4-byte hashes (narrow form, right side: level 0 reads 8-byte keys and
 	 * writes 4-byte words, level 1 reads and writes 4-byte words); never with row ids */
 	static_assert(!W32 || (!HAS_RID && !STABLE && FAST && !(LEVEL0 && RAW)), "4-byte words: unordered FAST form without row ids only");
+	constexpr uint32_t TILE = MDB_TILE * F::TMUL;
+	constexpr int ITEMS = (int)(PART_ITEMS * F::TMUL);
+	static_assert(F::TMUL == 1 || (FAST && !STABLE && !HAS_RID && !INV && !FILT && !PAY && !R64 && !MM64), "larger tiles: histogram-free passes that cut their own tiles only");
 	typedef typename std::conditional<W32, uint32_t, uint64_t>::type W;
 	/* Row ids are staged through the SAME LDS as the hashes, after the hashes have been written out (unordered
 	 * form only): 35 KiB instead of 51 KiB per workgroup = 4 instead of 3 workgroups per CU, worth ~25 % of the
 	 * kernel's time (occupancy is what hides the HBM latency of the scattered runs) */
 	constexpr bool RID_SHARES_LDS = HAS_RID && !STABLE;
-	__shared__ W s_hv[MDB_TILE];
-	__shared__ uint32_t s_rid_own[(HAS_RID && !RID_SHARES_LDS) ? MDB_TILE : 1];
+	__shared__ W s_hv[TILE];
+	__shared__ uint32_t s_rid_own[(HAS_RID && !RID_SHARES_LDS) ? TILE : 1];
 	uint32_t *const s_rid = RID_SHARES_LDS ? reinterpret_cast<uint32_t *>(s_hv) : s_rid_own;
 	__shared__ uint32_t s_cnt[PART_MAX_R];		/* per-digit counters, then tile-local digit starts */
 	__shared__ int32_t s_delta[PART_MAX_R];	/* global start of the digit's run minus its tile-local start */
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		a.minmax_final[0] = 0xFFFFFFFFu;
 		a.minmax_final[1] = 0u;
 	}
-	const mdb_tile_desc td = part_get_tile(a, part_tile_of_block());
+	const mdb_tile_desc td = part_get_tile<TILE>(a, part_tile_of_block());
 	if (td.len == 0)
 		return;
 	const uint32_t R = a.R;
@@ -539,13 +550,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 
 	/* 1. load (coalesced).  STABLE: wave w owns the 512 consecutive keys [w*512, w*512+512), so that
 	 *    (wave, round, lane) order is input order; otherwise consecutive threads, consecutive keys. */
-	W hv[PART_ITEMS];
-	uint32_t rid[PART_ITEMS];
-	uint32_t dig[PART_ITEMS];
-	uint32_t rank[PART_ITEMS];
+	W hv[ITEMS];
+	uint32_t rid[ITEMS];
+	uint32_t dig[ITEMS];
+	uint32_t rank[ITEMS];
 	if (STABLE) {
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS; r++) {
+		for (int r = 0; r < ITEMS; r++) {
 			const uint32_t i = wave * PART_WAVE_SPAN + (uint32_t)r * MDB_WAVE + lane;
 			bool valid = i < td.len;
 			uint64_t h = 0;
@@ -557,12 +568,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		}
 	} else if (W32 && RAW && a.fold64) {
 		/* group records on their way into the 4-byte ordering sort: 8-byte words in, folded */
-		const bool full = td.len == MDB_TILE && !(td.start & 1u);	/* (uniform) */
-		ulonglong2 pre[PART_ITEMS / 2];
+		const bool full = td.len == TILE && !(td.start & 1u);	/* (uniform) */
+		ulonglong2 pre[ITEMS / 2];
 		if (full)
-			part_preload2<false, PART_ITEMS / 2>(a, td, pre);
+			part_preload2<false, ITEMS / 2>(a, td, pre);
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS / 2; r++) {
+		for (int r = 0; r < ITEMS / 2; r++) {
 			bool valid[2];
 			uint64_t h2[2];
 			if (full)
@@ -576,16 +587,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 			}
 		}
 	} else if (W32 && !LEVEL0) {
-		const bool full = td.len == MDB_TILE && !(td.start & 3u);	/* (uniform) */
-		uint4 pre[PART_ITEMS / 4];
+		const bool full = td.len == TILE && !(td.start & 3u);	/* (uniform) */
+		uint4 pre[ITEMS / 4];
 		if (full) {
 			const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.hv_in) + td.start;
 #pragma unroll
-			for (int r = 0; r < PART_ITEMS / 4; r++)
+			for (int r = 0; r < ITEMS / 4; r++)
 				pre[r] = *reinterpret_cast<const uint4 *>(src + 4u * ((uint32_t)r * PART_THREADS + threadIdx.x));
 		}
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS / 4; r++) {
+		for (int r = 0; r < ITEMS / 4; r++) {
 			uint32_t h4[4];
 			bool valid[4];
 			if (full)
@@ -601,17 +612,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		}
 	} else {
 		constexpr bool PRE_OK = LEVEL0 || !HAS_RID;	/* (row-id arrays beyond the first level: the wide form keeps part_load2's own loads) */
-		const bool full = PRE_OK && td.len == MDB_TILE && !(td.start & 1u) && !(LEVEL0 && !CF && a.keys32);	/* (uniform) */
-		ulonglong2 pre[PART_ITEMS / 2];
+		const bool full = PRE_OK && td.len == TILE && !(td.start & 1u) && !(LEVEL0 && !CF && a.keys32);	/* (uniform) */
+		ulonglong2 pre[ITEMS / 2];
 		if (full)
-			part_preload2<LEVEL0, PART_ITEMS / 2>(a, td, pre);
+			part_preload2<LEVEL0, ITEMS / 2>(a, td, pre);
 		/* (uniform) the pruned left table only: for the right table - with or without its key range recorded - the same
 		 * straight-line code measured equal (0.247 ms) or slower (0.235 -> 0.258 ms) than the loop below */
 		const bool straight = CF && !W32 && !PAY && full && !a.nullbits && a.range_in;
 		if (straight)
-			(void)part_cf_rows<W32, 1, W>(a, pre, td.start + 2u * threadIdx.x, hv, dig, range_lo, range_hi, seen_min, seen_max);
+			(void)part_cf_rows<W32, 1, W, ITEMS>(a, pre, td.start + 2u * threadIdx.x, hv, dig, range_lo, range_hi, seen_min, seen_max);
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS / 2 && !straight; r++) {
+		for (int r = 0; r < ITEMS / 2 && !straight; r++) {
 			bool valid[2];
 			uint64_t h2[2];
 			constexpr bool RANGE = LEVEL0 && FAST && !RAW && !INV && !HAS_RID;	/* (the narrow forms' first level) */
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		volatile uint32_t *wc = &s_wcnt[wave * PART_MAX_R];
 		const uint64_t lt = mdb_lanemask_lt();
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS; r++) {
+		for (int r = 0; r < ITEMS; r++) {
 			const bool valid = dig[r] != PART_INVALID;
 			const uint32_t d = dig[r];
 			uint64_t peers = __ballot(valid);
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		 * a digit find each other with one ballot per digit; the lowest of them takes the wave's share of the counter */
 		const uint64_t lt = mdb_lanemask_lt();
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS; r++) {
+		for (int r = 0; r < ITEMS; r++) {
 			rank[r] = 0u;
 			for (uint32_t d = 0; d < R; d++) {
 				const uint64_t m = __ballot(dig[r] == d);
@@ -779,7 +790,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	} else {
 		/* one returning LDS atomic per key; order inside a digit = arrival order (unspecified) */
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS; r++)
+		for (int r = 0; r < ITEMS; r++)
 			rank[r] = dig[r] != PART_INVALID ? atomicAdd(&s_cnt[dig[r]], 1u) : 0u;
 	}
 	__syncthreads();
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 
 	/* 4. stage sorted by digit */
 #pragma unroll
-	for (int r = 0; r < PART_ITEMS; r++) {
+	for (int r = 0; r < ITEMS; r++) {
 		if (dig[r] != PART_INVALID) {
 			uint32_t pos = s_cnt[dig[r]] + rank[r];
 			if (STABLE)
@@ -832,9 +843,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	__syncthreads();
 
 	/* 5. write out: consecutive threads write consecutive addresses inside each digit's run */
-	uint32_t gpos[PART_ITEMS];
+	uint32_t gpos[ITEMS];
 #pragma unroll
-	for (int k = 0; k < PART_ITEMS; k++) {
+	for (int k = 0; k < ITEMS; k++) {
 		const uint32_t i = threadIdx.x + (uint32_t)k * PART_THREADS;
 		gpos[k] = PART_INVALID;
 		if (i >= tile_total)
@@ -883,18 +894,18 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 		for (uint32_t c = 0; c < a.npay; c++) {	/* (uniform) */
 			/* (element r of this thread = pair r / 2 of the tile, relative to its even-aligned base - part_load2's addressing) */
 			const uint64_t base2 = (uint64_t)td.start - (td.start & 1u);
-			uint64_t pv[PART_ITEMS];
+			uint64_t pv[ITEMS];
 #pragma unroll
-			for (int r = 0; r < PART_ITEMS; r++)
+			for (int r = 0; r < ITEMS; r++)
 				pv[r] = dig[r] != PART_INVALID ? a.pay_in[c][base2 + 2u * ((uint32_t)(r >> 1) * PART_THREADS + threadIdx.x) + (uint32_t)(r & 1)] : 0ull;
 			__syncthreads();	/* every word of the previous round has been read */
 #pragma unroll
-			for (int r = 0; r < PART_ITEMS; r++)
+			for (int r = 0; r < ITEMS; r++)
 				if (dig[r] != PART_INVALID)
 					s_pay[rank[r]] = pv[r];
 			__syncthreads();
 #pragma unroll
-			for (int k = 0; k < PART_ITEMS; k++)
+			for (int k = 0; k < ITEMS; k++)
 				if (gpos[k] != PART_INVALID)
 					a.pay_out[c][gpos[k]] = s_pay[threadIdx.x + (uint32_t)k * PART_THREADS];
 		}
@@ -902,12 +913,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(mdb_level_args a)
 	if (RID_SHARES_LDS) {
 		__syncthreads();	/* every hash has been read: the buffer now takes the row ids */
 #pragma unroll
-		for (int r = 0; r < PART_ITEMS; r++)
+		for (int r = 0; r < ITEMS; r++)
 			if (dig[r] != PART_INVALID)
 				s_rid[rank[r]] = rid[r];
 		__syncthreads();
 #pragma unroll
-		for (int k = 0; k < PART_ITEMS; k++)
+		for (int k = 0; k < ITEMS; k++)
 			if (gpos[k] != PART_INVALID)
 				a.rid_out[gpos[k]] = s_rid[threadIdx.x + (uint32_t)k * PART_THREADS];
 	}
@@ -1317,14 +1328,26 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.nsub = PART_NSUB;
 				a.status = ctx->d_status;
 				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
-				if (raw_hv && fold32) {
+				/* tables of 2^25 rows and more: tiles of 2 x MDB_TILE rows in the instances that have them (MDB_TILE2=0: never) */
+				const char *t2min = getenv("MDB_TILE2_MIN");	/* (tests: the form on small tables) */
+				const bool t2 = n >= (t2min && atoll(t2min) > 0 ? (uint64_t)atoll(t2min) : (1ull << 25)) &&
+						!(getenv("MDB_TILE2") && getenv("MDB_TILE2")[0] == '0');
+				const uint32_t ntiles2 = (uint32_t)((n + 2ull * MDB_TILE - 1) / (2ull * MDB_TILE));
+				if (raw_hv && fold32 && t2) {
+					a.ntiles = ntiles2;
+					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<pf_word_raw_w32_t2>), grid8(ntiles2), PART_THREADS, a);
+				} else if (raw_hv && fold32) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<pf_word_raw_w32>), grid8(ntiles), PART_THREADS, a);
 				} else if (raw_hv) {
 					MDB_LAUNCH(ctx, "sort_scatter_l0", (k_part_scatter<pf_word_raw>), grid8(ntiles), PART_THREADS, a);
 				} else if (w32) {
 					if (out16) {
 						a.out16_shift = 32u - narrow_kbits;
-						if (cf) {
+						if (cf && t2) {
+							a.ntiles = ntiles2;
+							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32_out16_cf_t2>),
+								   grid8(ntiles2), PART_THREADS, a);
+						} else if (cf) {
 							MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32_out16_cf>),
 								   grid8(ntiles), PART_THREADS, a);
 						} else {
@@ -1338,7 +1361,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 						MDB_LAUNCH(ctx, "part_scatter_l0_w32", (k_part_scatter<pf_key_w32>), grid8(ntiles), PART_THREADS, a);
 					}
 					if (a.minmax_out)
-						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, MM_GROUPS, MM_THREADS, (const uint32_t *)a.minmax_out, ntiles, flt->minmax_out);	/* (every tile below ntiles has left its pair) */
+						MDB_LAUNCH(ctx, "part_minmax", k_part_minmax_reduce, MM_GROUPS, MM_THREADS, (const uint32_t *)a.minmax_out, a.ntiles, flt->minmax_out);	/* (every tile of the launch has left its pair) */
 				} else if (npay) {
 					if (!cf || a.narrow != 1u)
 						return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "payload cells travel with the compact narrow form's hash | row id words only");
@@ -1356,11 +1379,17 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_mm64>), grid8(ntiles), PART_THREADS, a);
 					MDB_LAUNCH(ctx, "part_minmax", k_part_minmax64_reduce, 1, 1024, (const unsigned long long *)a.minmax64_out, ntiles,
 						   flt->minmax64_out);
+				} else if (a.range_in && cf && t2) {
+					a.ntiles = ntiles2;
+					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key_cf_t2>), grid8(ntiles2), PART_THREADS, a);
 				} else if (a.range_in && cf) {	/* (the same instance under another name: its bytes differ - most rows are read, not written) */
 					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key_cf>),
 						   grid8(ntiles), PART_THREADS, a);
 				} else if (a.range_in) {
 					MDB_LAUNCH(ctx, "part_scatter_l0_pruned", (k_part_scatter<pf_key>), grid8(ntiles), PART_THREADS, a);
+				} else if (cf && t2) {
+					a.ntiles = ntiles2;
+					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_cf_t2>), grid8(ntiles2), PART_THREADS, a);
 				} else if (cf) {
 					MDB_LAUNCH(ctx, "part_scatter_l0", (k_part_scatter<pf_key_cf>), grid8(ntiles),
 						   PART_THREADS, a);

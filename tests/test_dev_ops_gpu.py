@@ -1423,6 +1423,18 @@ def test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_
         assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), info
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_join_group_count_random_shapes_with_tiles_of_twice_the_rows(dev, narrow_mode, seed):
+    """Tables of 2^25 rows and more go through the histogram-free first levels in tiles of 2 x 4096 rows (k_part_scatter<..._t2>): the same
+    shape fuzz with that form switched on for the test's small tables (MDB_TILE2_MIN) - partial last tiles, NULLs, pruned left tables,
+    the ordering sort's first level."""
+    os.environ["MDB_TILE2_MIN"] = "1"
+    try:
+        test_join_group_count_random_shapes_every_form_and_pruning_path(dev, narrow_mode, 100 + seed)
+    finally:
+        del os.environ["MDB_TILE2_MIN"]
+
+
 @pytest.mark.parametrize("case", ["variant_d_forced_wide", "hashes_2e62", "right_sticks_out", "disjoint", "nulls_dups", "not_prunable"])
 def test_min_max_pruning_in_the_64_bit_form(dev, narrow_mode, case):
     """Keys that fit no 2^32 window (hashes, snowflake ids) - or the narrow forms switched off - still prune the left table by the right
