@@ -466,9 +466,12 @@ struct pf_key_rid_stable_hist : pf_base { static constexpr bool LEVEL0 = true; s
 /* the same with tiles of 2 x MDB_TILE rows (tables of 2^25 rows and more: half the cursor atomics, runs twice as long - whole 32-byte sectors of
  * 2-byte words; 10^8 rows: the right table's pass 0.241 -> 0.222 ms, the ordering sort's first level 0.174 -> 0.155, same-box A/B.  Smaller tables
  * keep MDB_TILE: fewer tiles than workgroup slots leave CUs idle) */
-struct pf_key_cf_t2 : pf_key_cf { static constexpr uint32_t TMUL = 2; };
-struct pf_key_w32_out16_cf_t2 : pf_key_w32_out16_cf { static constexpr uint32_t TMUL = 2; };
-struct pf_word_raw_w32_t2 : pf_word_raw_w32 { static constexpr uint32_t TMUL = 2; };
+#ifndef PART_TMUL
+#define PART_TMUL 2u
+#endif
+struct pf_key_cf_t2 : pf_key_cf { static constexpr uint32_t TMUL = PART_TMUL; };
+struct pf_key_w32_out16_cf_t2 : pf_key_w32_out16_cf { static constexpr uint32_t TMUL = PART_TMUL; };
+struct pf_word_raw_w32_t2 : pf_word_raw_w32 { static constexpr uint32_t TMUL = PART_TMUL; };
 /* min-max pruning in the 64-bit form: the right table's first level records its key range (mm64), the left table's drops the rows outside (r64) */
 struct pf_key_mm64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool FAST = true; static constexpr bool MM64 = true; };
 struct pf_key_rid_r64 : pf_base { static constexpr bool LEVEL0 = true; static constexpr bool HAS_RID = true; static constexpr bool FAST = true; static constexpr bool R64 = true; };
@@ -1332,7 +1335,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				const char *t2min = getenv("MDB_TILE2_MIN");	/* (tests: the form on small tables) */
 				const bool t2 = n >= (t2min && atoll(t2min) > 0 ? (uint64_t)atoll(t2min) : (1ull << 25)) &&
 						!(getenv("MDB_TILE2") && getenv("MDB_TILE2")[0] == '0');
-				const uint32_t ntiles2 = (uint32_t)((n + 2ull * MDB_TILE - 1) / (2ull * MDB_TILE));
+				const uint32_t ntiles2 = (uint32_t)((n + (uint64_t)PART_TMUL * MDB_TILE - 1) / ((uint64_t)PART_TMUL * MDB_TILE));
 				if (raw_hv && fold32 && t2) {
 					a.ntiles = ntiles2;
 					MDB_LAUNCH(ctx, "sort_scatter_l0_w32", (k_part_scatter<pf_word_raw_w32_t2>), grid8(ntiles2), PART_THREADS, a);
