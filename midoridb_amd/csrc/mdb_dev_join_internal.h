@@ -204,8 +204,10 @@ struct gc_window {
 #define TINY_ROWS (GC_THREADS * LEAF_BATCH)	/* rows per table up to which ONE workgroup does the whole operator in LDS */
 #define GC_NARROW_MIN_ROWS (1u << 20)
 #define GC_NARROW_SAMPLE 4096u
-#define GC_HINT_USES 8		/* a remembered sample / verdict serves this many calls, then the data is looked at again (one
-				 * tiny kernel + sync in eight calls; a buffer that was refilled is noticed within eight) */
+#define GC_HINT_USES 32		/* a remembered sample / verdict serves this many calls, then the data is looked at again (one tiny
+				 * kernel + sync - ~50 us, a tenth of a 10^7-row query - in 32 calls; a buffer refilled with another
+				 * distribution runs that long on a plan that is exact but may not be the best; a hint the data
+				 * contradicts is noticed by the kernels at once) */
 
 /* position of sample t: pseudo-random, not evenly spaced - generated or periodic data (an affine sequence, a table sorted by
  * a low-cardinality column) looks very different at a fixed stride than it is */
