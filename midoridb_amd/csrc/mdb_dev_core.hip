@@ -341,6 +341,10 @@ static void memo_drop(mdb_col_memo &m, uintptr_t a, uintptr_t b)
 		m.l4_bad_keys = NULL;
 	if (hit(m.lg_kl) || hit(m.lg_kr))
 		m.lg_valid = false;
+	if (hit(m.jk_dup_l) || hit(m.jk_dup_r))
+		m.jk_dup_l = m.jk_dup_r = NULL;
+	if (hit(m.jp_bad_l) || hit(m.jp_bad_r))
+		m.jp_bad_l = m.jp_bad_r = NULL;
 }
 
 static void mdb_hints_drop(mdb_dev_ctx *ctx, const void *lo, size_t bytes)

@@ -48,6 +48,7 @@ struct mdb_dist {
 	hipEvent_t ev_t0, ev_t1, ev_part[MDB_SHARD_MAX_TABS], ev_arr[MDB_SHARD_MAX_TABS];	/* (created on first use, with timing) */
 	double phase_ms[MDB_DIST_PHASES];
 	uint64_t seq;			/* collective calls made through this handle: every rank's must agree (checked with the counts) */
+	bool ko_had_dups;		/* the last keys-only join through this handle met a key twice on some rank (the same on every rank) */
 	bool sh_posted;
 	void *pend[SH_MAX_PENDING];
 	int npend;
@@ -842,11 +843,20 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 		return dist_err(d, rc, "count exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
 	uint64_t n_max[MDB_SHARD_MAX_TABS] = { 0, 0, 0, 0 }, cap_min = ~0ull, nl_sum = 0;
 	for (int p = 0; p < W; p++) {
-		if (recvv[NC * p + MDB_SHARD_MAX_TABS + 1] != guard)
+		if (recvv[NC * p + MDB_SHARD_MAX_TABS + 1] != guard) {
+			/* every rank has the same numbers in front of it: all continue from the largest call number seen, so the handle
+			 * keeps working once the callers are in step again (a mismatch used to fail every later call) */
+			uint64_t seq_max = 0;
+			for (int q = 0; q < W; q++) {
+				const uint64_t sq = recvv[NC * q + MDB_SHARD_MAX_TABS + 1] & 0xFFFFFFFFFFull;
+				seq_max = sq > seq_max ? sq : seq_max;
+			}
+			d->seq = seq_max;
 			return dist_err(d, -MIDORIDB_ERROR, "the ranks are not in the same collective call: rank %d is in call %llu (kind %llu), rank %d in call %llu "
 					"(kind %llu); nothing was exchanged", p, (unsigned long long)(recvv[NC * p + MDB_SHARD_MAX_TABS + 1] & 0xFFFFFFFFFFull),
 					(unsigned long long)(recvv[NC * p + MDB_SHARD_MAX_TABS + 1] >> 47), d->rank,
 					(unsigned long long)(guard & 0xFFFFFFFFFFull), (unsigned long long)(guard >> 47));
+		}
 		nl_sum += recvv[NC * p + (right_only ? 1 : 0)];
 		for (int x = 0; x < ntab; x++)
 			n_max[x] = recvv[NC * p + x] > n_max[x] ? recvv[NC * p + x] : n_max[x];
@@ -1818,7 +1828,10 @@ static int dist_join_keys_only(mdb_dist *d, const int64_t *keys_l, const uint64_
 	d->last_fused = 0;
 	/* first WITHOUT the COUNT column (primary-key joins: every COUNT is 1 - 8 of the 16 bytes a group costs the leaf kernel); the ranks
 	 * then agree on whether that was right everywhere (one tiny exchange) and, if not, all of them run the call again with counts */
-	int rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J, false, true);
+	/* (what the previous keys-only call over this handle found is remembered - every rank saw the same sum, so every rank remembers the
+	 * same thing: a foreign-key or N:M join asks for the COUNT column at once instead of paying two whole exchanges per call) */
+	const bool with_counts = d->ko_had_dups;
+	int rc = dist_join_fused(d, 2, fk, fn, fs, glo, ghi, promised, true, &gk, &gc, 0, &G, &J, false, !with_counts);
 	if (rc)
 		return rc;
 	{
@@ -1829,7 +1842,8 @@ static int dist_join_keys_only(mdb_dist *d, const int64_t *keys_l, const uint64_
 			(void)mdb_dev_free(ctx, gc);
 			return dist_err(d, rc, "status exchange failed%s%s", d->own_transport ? ": " : "", transport_err(d));
 		}
-		if (dups) {
+		d->ko_had_dups = dups != 0;
+		if (dups && !with_counts) {
 			(void)mdb_dev_free(ctx, gk);
 			(void)mdb_dev_free(ctx, gc);
 			gk = gc = NULL;

@@ -533,6 +533,7 @@ void mdb_result_free(struct mdb_result *r)
 	free(r->d_nullbits);
 	free(r->colname);
 	free(r->coltype);
+	free(r->colprec);
 	free(r);
 }
 
@@ -1232,9 +1233,10 @@ grouped:
 		res->nrows = out_rows;
 		res->colname = calloc((size_t)(ncols ? ncols : 1), sizeof(*res->colname));
 		res->coltype = calloc((size_t)(ncols ? ncols : 1), sizeof(int));
+		res->colprec = calloc((size_t)(ncols ? ncols : 1), sizeof(int));
 		res->data = calloc((size_t)(ncols ? ncols : 1), sizeof(int64_t *));
 		res->nullbits = calloc((size_t)(ncols ? ncols : 1), sizeof(uint64_t *));
-		if (!d_vals || !d_nulls || !res->colname || !res->coltype || !res->data || !res->nullbits) {
+		if (!d_vals || !d_nulls || !res->colname || !res->coltype || !res->colprec || !res->data || !res->nullbits) {
 			free(d_vals);
 			free(d_nulls);
 			rc = -MIDORIDB_NOMEM;
@@ -1281,6 +1283,7 @@ grouped:
 			}
 			struct mdb_column *col = &s->tabs[key_tbl[key]].t->cols[key_col[key]];
 			res->coltype[c] = col->type;
+			res->colprec[c] = col->type == MDB_CT_VARCHAR ? col->precision : 0;
 			if (!out_rows || count_only)
 				continue;
 			if (fused >= 0 || x.fused) {

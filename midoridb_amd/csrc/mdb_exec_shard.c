@@ -163,9 +163,16 @@ int shard_dict_sync(struct exec *x)
 			cat->d_g2l_n = cat->gdict.n + 1;
 		}
 	}
-	if (lrc) {
-		snprintf(x->err, x->errlen, "execution phase: dictionary exchange: out of memory\n");
-		return lrc;
+	/* a rank-local failure (memory, interning, the upload) is every rank's: the peers would go on to the statement's next collective
+	 * and wait there for a rank that has returned */
+	uint64_t failed = lrc ? 1 : 0;
+	if (mdb_dist_allreduce_sum_u64(cat->dist, &failed, 1)) {
+		snprintf(x->err, x->errlen, "execution phase: dictionary exchange: %s\n", mdb_dist_last_error(cat->dist));
+		return -MIDORIDB_INTERNAL;
+	}
+	if (failed) {
+		snprintf(x->err, x->errlen, "execution phase: dictionary exchange: out of memory%s\n", lrc ? "" : " on another rank");
+		return lrc ? lrc : -MIDORIDB_NOMEM;
 	}
 	x->dict_synced = true;
 	return MIDORIDB_OK;
@@ -208,11 +215,14 @@ int shard_rows(struct exec *x, const int *tabs, int nt, uint32_t *const *rid_of,
 				return -MIDORIDB_ERROR;
 			}
 			cols[nc].values = tb->cols[c].d_data;
-			if (tb->cols[c].type == MDB_CT_VARCHAR && tb->cols[c].d_data) {
+			if (tb->cols[c].type == MDB_CT_VARCHAR) {
 				/* the column's cells as ids of the ranks' common dictionary (the whole column: the rows that travel are read
-				 * from it through their row ids) */
+				 * from it through their row ids).  Decided from the SCHEMA alone: a rank that holds no row of the table has no
+				 * device column (mdb_table_sync_device skips empty tables) and must still take part in the dictionary exchange,
+				 * a collective, and translate what arrives. */
 				const int64_t *common = NULL;
-				const int trc = shard_ids(x, tb->cols[c].d_data, tb->device_only ? tb->dev_rows : tb->nrows, true, false, &common);
+				const uint64_t have = tb->cols[c].d_data ? (tb->device_only ? tb->dev_rows : tb->nrows) : 0;
+				const int trc = shard_ids(x, tb->cols[c].d_data, have, true, false, &common);
 				if (trc)
 					return trc;
 				cols[nc].values = common;

@@ -255,6 +255,8 @@ struct mdb_result {
 	int ncols;
 	char (*colname)[MDB_NAME_LEN];
 	int *coltype;
+	int *colprec;			/* the declared VARCHAR(n) of a VARCHAR result column (the legacy view's column.precision), else 0 */
+	char *legacy_text;		/* the legacy view's VARCHAR cells: `precision` zero-filled bytes each, as upstream allocates them */
 	int64_t **data;			/* host columns, 8-byte values (0 for NULL) */
 	uint64_t **nullbits;		/* host NULL bits per column or NULL */
 	uint64_t nrows;

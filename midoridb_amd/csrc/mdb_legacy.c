@@ -20,7 +20,9 @@ void mdb_result_legacy_header(struct mdb_result *r)
 		memset(col, 0, sizeof(*col));
 		snprintf(col->name, sizeof(col->name), "%s", r->colname[c]);
 		col->type = r->coltype[c];
-		col->precision = r->coltype[c] == MDB_CT_VARCHAR ? 256 : (int)legacy_col_space(r->coltype[c]);
+		/* VARCHAR: the DECLARED length - upstream allocates that many bytes per cell and its own code copies that many from the cell's
+		 * pointer (row.c table_insert_row), so the cells below are buffers of exactly that size */
+		col->precision = r->coltype[c] == MDB_CT_VARCHAR ? (r->colprec && r->colprec[c] > 0 ? r->colprec[c] : 256) : (int)legacy_col_space(r->coltype[c]);
 		col->nullable = true;
 		col->is_count = strcmp(r->colname[c], "COUNT(*)") == 0;
 	}
@@ -40,6 +42,8 @@ void mdb_result_legacy_free(struct mdb_result *r)
 	}
 	r->legacy_head.next = r->legacy_head.prev = &r->legacy_head;
 	r->legacy_built = false;
+	free(r->legacy_text);
+	r->legacy_text = NULL;
 }
 
 /* the rows of a small result whose columns are on the host, as datablocks; a result that is too large, not fetched yet, or wider than the
@@ -58,6 +62,20 @@ void mdb_result_legacy_rows(struct mdb_result *r)
 	const size_t per_block = MDB_LEGACY_PAGE_SIZE / row_size;
 	if (!per_block)
 		return;
+	/* VARCHAR cells: one zero-filled buffer of `precision` bytes per cell (what upstream's zalloc'd cell is), so a consumer that copies
+	 * column->precision bytes from the pointer - as upstream's table_insert_row does - stays inside it.  More than 64 MiB of them: the
+	 * empty list (the cursor serves such a result) */
+	size_t text_bytes = 0;
+	for (int c = 0; c < r->ncols; c++)
+		if (r->coltype[c] == MDB_CT_VARCHAR)
+			text_bytes += (size_t)t->columns[c].precision * r->nrows;
+	if (text_bytes > ((size_t)64 << 20))
+		return;
+	char *text = NULL;
+	if (text_bytes && !(text = calloc(1, text_bytes)))
+		return;
+	free(r->legacy_text);
+	r->legacy_text = text;
 	struct mdb_legacy_datablock *blk = NULL;
 	size_t free_off = 0;
 	uint64_t id = 0;
@@ -90,8 +108,12 @@ void mdb_result_legacy_rows(struct mdb_result *r)
 			if (r->coltype[c] == MDB_CT_TINYINT) {
 				row->data[off] = isnull ? 0 : (char)(r->data[c][i] != 0);
 			} else if (r->coltype[c] == MDB_CT_VARCHAR) {
-				const char *sv = isnull ? "" : (r->dict ? mdb_dict_str(r->dict, r->data[c][i]) : NULL);
-				const uintptr_t pv = (uintptr_t)(sv ? sv : "");
+				const char *sv = isnull ? NULL : (r->dict ? mdb_dict_str(r->dict, r->data[c][i]) : NULL);
+				const size_t prec = (size_t)t->columns[c].precision;
+				if (sv && prec)
+					snprintf(text, prec, "%s", sv);
+				const uintptr_t pv = (uintptr_t)text;
+				text += prec;
 				memcpy(row->data + off, &pv, sizeof(pv));
 			} else {
 				const int64_t v = isnull ? 0 : r->data[c][i];

@@ -63,6 +63,11 @@ def _lib():
             L.ref_foreign_fetch.restype = ctypes.c_int64
             L.ref_foreign_text.argtypes = [ctypes.c_int64]
             L.ref_foreign_text.restype = ctypes.c_char_p
+            if hasattr(L, "ref_foreign_precision"):
+                L.ref_foreign_precision.argtypes = [P, ctypes.c_int]
+                L.ref_foreign_precision.restype = ctypes.c_int
+                L.ref_foreign_text_cell_ok.argtypes = [ctypes.c_int64, ctypes.c_int]
+                L.ref_foreign_text_cell_ok.restype = ctypes.c_int
             L.ref_foreign_cursor_walk.argtypes = [P, ctypes.c_int, P, ctypes.c_int64]
             L.ref_foreign_cursor_walk.restype = ctypes.c_int64
         _LIB = L
@@ -85,7 +90,9 @@ def foreign_table(table_ptr, max_rows=1 << 16):
         row = []
         for c in range(nc):
             v = int(vals[r, c])
-            if cols[c][1] == 0:     # CT_VARCHAR: the cell is a pointer
+            if cols[c][1] == 0:     # CT_VARCHAR: the cell is a pointer to `precision` bytes (read whole, as upstream's row copy does)
+                if hasattr(L, "ref_foreign_precision"):
+                    assert L.ref_foreign_text_cell_ok(v, L.ref_foreign_precision(table_ptr, c)) == 1, (r, c)
                 v = L.ref_foreign_text(v).decode()
             row.append((v, bool(nulls[r, c])))
         rows.append(tuple(row))

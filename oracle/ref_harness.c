@@ -280,6 +280,30 @@ int ref_foreign_is_count(void *table, int i)
 	return ((struct table *)table)->columns[i].is_count;
 }
 
+int ref_foreign_precision(void *table, int i)
+{
+	return ((struct table *)table)->columns[i].precision;
+}
+
+/* a VARCHAR cell read the way upstream's own code reads one (table_insert_row, src/primitive/row.c: memcpy of column->precision bytes from
+ * the cell's pointer): copies `precision` bytes out and says whether everything behind the string's NUL is zero, as in a zalloc'd cell */
+int ref_foreign_text_cell_ok(int64_t cell, int precision)
+{
+	char *copy = malloc(precision > 0 ? (size_t)precision : 1);
+	int ok = 1, seen_nul = 0;
+	if (!copy)
+		return -1;
+	memcpy(copy, (const char *)(uintptr_t)cell, (size_t)precision);
+	for (int i = 0; i < precision; i++) {
+		if (seen_nul && copy[i])
+			ok = 0;
+		if (!copy[i])
+			seen_nul = 1;
+	}
+	free(copy);
+	return ok && seen_nul;
+}
+
 const char *ref_foreign_name(void *table)
 {
 	return ((struct table *)table)->name;

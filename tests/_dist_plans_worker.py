@@ -366,6 +366,59 @@ def varchar_sql(world, rank):
         late = dict((t[nm.index("P.name")], t[nm.index("COUNT(*)")]) for t in got if str(t[nm.index("P.name")]).startswith("late-"))
         assert late == dict([(f"late-{r}", 1) for r in range(world)] + [("late-all", world)]), late
     dist.barrier()
+    varchar_empty_rank(world, rank)
+
+
+def varchar_empty_rank(world, rank):
+    """A rank that holds NO row of a table with a VARCHAR column (no device column at all: mdb_table_sync_device skips empty tables) takes
+    part in the dictionary exchange all the same - whether a statement moves VARCHAR cells follows from its text and the schema alone - and
+    translates the ids that arrive (round 5; the advisor's finding on mdb_exec_shard.c): VARCHAR as the join key and as payload behind an INT
+    key, the empty rank on either side"""
+    import collections
+    from midoridb_amd.query import DB
+    from midoridb_amd.dist import DatabaseDevice
+    names = [f"s{i:03d}" for i in range(90)]
+    for empty_tab in ("P", "Q"):
+        for empty_rank in sorted({0, world - 1}):
+            rng = np.random.default_rng(100 + empty_rank)
+            rows = {"P": [(names[i], int(v)) for i, v in zip(rng.integers(0, 90, 700 * world), rng.integers(0, 60, 700 * world))],
+                    "Q": [(names[i], int(v)) for i, v in zip(rng.integers(20, 90, 300 * world), rng.integers(0, 60, 300 * world))]}
+            with DB() as db:
+                dx = gloo_transport(DatabaseDevice(db, 0), world, rank)
+                dx.attach_to_database(db)
+                db.execute("CREATE TABLE P (name VARCHAR(40), v INT);")
+                db.execute("CREATE TABLE Q (name2 VARCHAR(40), w INT);")
+                for tab in ("P", "Q"):
+                    # the rows of `empty_tab` are dealt to every rank but `empty_rank`; the other table to all ranks
+                    holders = [r for r in range(world) if not (tab == empty_tab and r == empty_rank)]
+                    if rank in holders:
+                        mine = rows[tab][holders.index(rank)::len(holders)]
+                        db.append_columns(tab, [[t[0] for t in mine], np.array([t[1] for t in mine], dtype=np.int64)])
+
+                def gathered(sql):
+                    r = db.query(sql)
+                    parts = [None] * world
+                    dist.all_gather_object(parts, [tuple(x.item() if hasattr(x, "item") else x for x in row) for row in zip(*[c.tolist() for c in r.columns])])
+                    return r.names, sorted(t for p in parts for t in p)
+                cp, cq = collections.Counter(t[0] for t in rows["P"]), collections.Counter(t[0] for t in rows["Q"])
+                nm, got = gathered("SELECT name, COUNT(*) FROM P INNER JOIN Q ON P.name = Q.name2 GROUP BY name;")	# VARCHAR key, fused plan
+                exp = {k: cp[k] * cq[k] for k in cp if k in cq}
+                assert got == sorted((exp[k], k) if nm[0] == "COUNT(*)" else (k, exp[k]) for k in exp), (empty_tab, empty_rank, len(got), len(exp))
+                nm, got = gathered("SELECT name, v, w FROM P INNER JOIN Q ON P.name = Q.name2 WHERE v < 9;")		# VARCHAR key, rows materialised
+                byname = collections.defaultdict(list)
+                for n2, w in rows["Q"]:
+                    byname[n2].append(w)
+                exp_rows = sorted(tuple({"P.name": n1, "P.v": v, "Q.w": w}[c] for c in nm) for n1, v in rows["P"] if v < 9 for w in byname.get(n1, ()))
+                assert got == exp_rows, (empty_tab, empty_rank, len(got), len(exp_rows))
+                nm, got = gathered("SELECT name, name2 FROM P INNER JOIN Q ON P.v = Q.w WHERE v < 5;")			# VARCHAR payload, INT key
+                byw = collections.defaultdict(list)
+                for n2, w in rows["Q"]:
+                    byw[w].append(n2)
+                exp_rows = sorted(tuple({"P.name": n1, "Q.name2": n2}[c] for c in nm) for n1, v in rows["P"] if v < 5 for n2 in byw.get(v, ()))
+                assert got == exp_rows, (empty_tab, empty_rank, len(got), len(exp_rows))
+                nm, got = gathered("SELECT DISTINCT name2 FROM Q;")
+                assert got == sorted((k,) for k in cq), (empty_tab, empty_rank)
+            dist.barrier()
 
 
 def main():
