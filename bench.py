@@ -221,6 +221,13 @@ def parse_args():
                     "evidence runs only; the default line keeps the reference's first-occurrence order")
     ap.add_argument("--reference-order", action="store_true", help="--config 4 at N = 1: time mdb_dev_join_pairs + the key gather (joined rows in "
                     "the reference's left-major order) instead of mdb_dev_join_keys (unspecified order, like the sharded form)")
+    ap.add_argument("--transport", choices=["rccl", "test"], default="rccl",
+                    help="N > 1: `rccl` = one rank per GPU, RCCL over xGMI (the measurement); `test` = N ranks on GPU 0, the blocks carried "
+                         "through host memory by a gloo process group (DistCtx.over_host_group) - runs the N > 1 code of this file on a "
+                         "one-GPU box; its timings say nothing about xGMI")
+    ap.add_argument("--peer-timeout", type=float, default=600.0,
+                    help="N > 1: seconds a rank waits in one phase (a collective, a step) before it gives up and EXITS non-zero - a rank "
+                         "that lost a peer must not hang the job")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
     return ap.parse_args()
@@ -231,7 +238,7 @@ def launch_ranks(args):
     must not be replaced, and this one has not touched it - device_count() does not initialise HIP on this image),
     relay rank 0's line, return the children's exit code."""
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < (1 if args.transport == "test" else args.gpus):
         line = {"metric": METRIC, "value": None, "unit": "joined rows/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                 "skipped": f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {visible}"}
         print(json.dumps(line), flush=True)
@@ -396,6 +403,33 @@ def end_to_end(n, mod_b, a_dev, b_dev):
     return out
 
 
+class Watchdog:
+    """N > 1: a rank that lost a peer sits in a collective for ever (RCCL kernels do not time out).  A thread watches the main thread's
+    heartbeat - one per phase - and, when a phase outlasts the timeout, says where and EXITS the process non-zero (os._exit: no re-exec,
+    no clean-up that could block on the device), so the launcher sees a failed rank and ends the others."""
+
+    def __init__(self, timeout_s, rank):
+        import threading
+        self.timeout, self.rank, self.t, self.what, self.on = float(timeout_s), rank, time.monotonic(), "start-up", True
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def beat(self, what):
+        self.t, self.what = time.monotonic(), what
+
+    def stop(self):
+        self.on = False
+
+    def _run(self):
+        while self.on:
+            time.sleep(min(1.0, self.timeout / 4))
+            if self.on and time.monotonic() - self.t > self.timeout:
+                sys.stderr.write(f"[bench] rank {self.rank}: no progress for {self.timeout:.0f} s in phase '{self.what}' - a peer is gone "
+                                 "or a collective hangs; exiting non-zero\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -410,20 +444,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} ranks\n")
+    host_wire = args.transport == "test"
+    if host_wire:
+        local_rank = 0          # every rank on GPU 0: the wire is host memory
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_shuffle
     ranks_seen = 1
+    watchdog = Watchdog(args.peer_timeout, rank) if world > 1 else None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        if host_wire:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.peer_timeout))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=args.peer_timeout))
 
     if args.config != 3:
         import bench_configs
-        bench_configs.run(args, world, rank, local_rank, json_fd)
+        bench_configs.run(args, world, rank, local_rank, json_fd, watchdog)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
+        if watchdog:
+            watchdog.stop()
         os.close(json_fd)
         return
 
@@ -437,8 +482,23 @@ def main():
         # the exchange itself runs behind the C-ABI (include/mdb_dist.h: RCCL communicators created in C from an id that
         # travels through the launcher's process group); torch.distributed only provides the barrier and the reductions
         # of the timing contract
-        dx = DistCtx.from_torch(dev)
-        ranks_seen = dx.allreduce_sum([1])[0]	# ranks that took part in a collective of the library's RCCL communicator
+        dx = DistCtx.over_host_group(dev) if host_wire else DistCtx.from_torch(dev)
+        ranks_seen = dx.allreduce_sum([1])[0]	# ranks that took part in a collective of the library's own communicator
+        if ranks_seen != world:
+            raise SystemExit(f"[bench] rank {rank}: the library's communicator saw {ranks_seen} ranks, the launcher {world}")
+
+    def all_reduce_(t, op):
+        """the timing contract's reductions: on the device over RCCL; through the host when the process group is gloo"""
+        if host_wire:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def beat(what):
+        if watchdog:
+            watchdog.beat(what)
 
     def make_tables(n_rank):
         """rank r holds rows [r*n, (r+1)*n) of the global tables (pre-sharded round-robin is equivalent for a permutation)"""
@@ -465,7 +525,7 @@ def main():
             if lo > hi or lo < -(1 << 31) or hi >= (1 << 31):
                 fits = 0.0
         t = torch.tensor([fits], dtype=torch.float64, device=dev.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        all_reduce_(t, dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
 
     def barrier():
@@ -474,23 +534,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def promise_ranges(a, b, w32):
+        """the exchange handle is told the wire format and the two tables' GLOBAL key ranges (what a catalog keeps per column)"""
+        if dx is None:
+            return
+        dx.set_wire(WIRE_32 if w32 else WIRE_64)
+        # the same catalog statistics give every rank the two tables' GLOBAL key ranges: rows outside the other table's range
+        # stay home (min-max pruning before the shuffle; a key outside its own promised range would be reported as an error)
+        rng = []
+        for col in (a, b):
+            lo, hi = dev.key_range(col)
+            t = torch.tensor([-lo, hi], dtype=torch.float64, device=dev.device)     # (keys < 2^53 here: exact in float64)
+            all_reduce_(t, dist.ReduceOp.MAX)
+            rng.append((-int(t[0].item()), int(t[1].item())))
+        dx.set_key_ranges(rng[0], rng[1])
+
     def measure(n_rank, steps, warmup, cold=None):
         """warmup + timed loop over fresh tables of n_rank rows per rank -> dict (max over ranks, totals over ranks)"""
         a, b, total, mod = make_tables(n_rank)
         out = make_out(n_rank)
         w32 = wire_format(a, b)
         pipe = dx
-        if dx is not None:
-            dx.set_wire(WIRE_32 if w32 else WIRE_64)
-            # the same catalog statistics give every rank the two tables' GLOBAL key ranges: rows outside the other table's range
-            # stay home (min-max pruning before the shuffle; a key outside its own promised range would be reported as an error)
-            rng = []
-            for col in (a, b):
-                lo, hi = dev.key_range(col)
-                t = torch.tensor([-lo, hi], dtype=torch.float64, device=dev.device)     # (keys < 2^53 here: exact in float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                rng.append((-int(t[0].item()), int(t[1].item())))
-            dx.set_key_ranges(rng[0], rng[1])
+        promise_ranges(a, b, w32)
 
         def step():
             if pipe is None and args.unordered:
@@ -510,18 +575,29 @@ def main():
             cold["cold_first_query_ms"] = (time.perf_counter() - t0) * 1e3
         g = j = 0
         for _ in range(max(warmup, 1) if world == 1 else warmup):
+            beat("warm-up step")
             g, j = step()
+        fault = os.environ.get("MDB_BENCH_FAULT", "")       # tests: `exit:<rank>` / `hang:<rank>` after the warm-up
+        if fault and world > 1 and fault.split(":")[1] == str(rank):
+            if fault.startswith("exit"):
+                sys.stderr.write(f"[bench] rank {rank}: MDB_BENCH_FAULT=exit\n")
+                os._exit(7)
+            sys.stderr.write(f"[bench] rank {rank}: MDB_BENCH_FAULT=hang\n")
+            while True:
+                time.sleep(1)
+        beat("barrier before the timed steps")
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             g, j = step()
         barrier()
         dt = time.perf_counter() - t0
+        beat("timed steps done")
         red = torch.tensor([dt, float(j), float(g)], dtype=torch.float64, device=dev.device)
         if use_dist:
             tmax = red[:1].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            all_reduce_(tmax, dist.ReduceOp.MAX)
+            all_reduce_(red, dist.ReduceOp.SUM)
             red[0] = tmax[0]
         dt, joined, groups = float(red[0].item()), int(red[1].item()), int(red[2].item())
         return {"a": a, "b": b, "out": out, "pipe": pipe, "step": step, "wire32": w32, "mod": mod, "n": n_rank, "total_rows": total,
@@ -550,6 +626,7 @@ def main():
     # what the plan puts on ONE xGMI link per call, next to what that link can carry (MI355X: 7 links x ~153 GB/s per GPU, point to
     # point - an all-to-all's block for a peer crosses the one link to that peer)
     exchange = None
+    beat("per-kernel profile done")
     if use_dist:
         dx.set_phase_timing(True)
         ph = []
@@ -607,6 +684,23 @@ def main():
                      "joined_rows": mo["joined"], "groups": mo["groups"], "wire32": mo["wire32"]}
             for key in ("a", "b", "out", "pipe", "step"):
                 mo.pop(key)
+
+    # --verify at N > 1 (small tables): every rank's groups gathered on rank 0 and compared with the CPU oracle over the GLOBAL tables -
+    # the groups are disjoint across ranks, their union in any order must be the oracle's
+    verified_dist = None
+    if args.verify and world > 1 and total_rows <= 20_000_000:
+        beat("verify: one more step + gather of every rank's groups")
+        promise_ranges(a, b, wire32)    # (the other scaling leg left ITS tables' ranges with the handle)
+        k, c, jj = pipeline.join_group_count(a, None, b, None, out=out)
+        parts = [None] * world
+        dist.all_gather_object(parts, (k.cpu().numpy(), c.cpu().numpy(), int(jj)))
+        if rank == 0:
+            from oracle import cpu, np_oracle as orc
+            eb = orc.gen_keys(total_rows, 0, total_rows, 43, mod_b) * (16 if args.variant == "S" else 1)
+            ek, ec, ef, ej = cpu.hash_join_group_count(orc.gen_keys(total_rows, 0, total_rows, 42, 0), None, eb, None, os.cpu_count() or 1)
+            gk, gc = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+            o1, o2 = np.argsort(gk, kind="stable"), np.argsort(ek, kind="stable")
+            verified_dist = bool(sum(p[2] for p in parts) == ej and np.array_equal(gk[o1], ek[o2]) and np.array_equal(gc[o1], ec[o2]))
 
     if rank == 0:
         narrow = dev.last_join_narrow()
@@ -677,7 +771,9 @@ def main():
                                       + ((", first-level partition regions on the wire (each table partitioned once; the receiver joins the "
                                           "regions of all ranks: mdb_dev_shard.hip)" if dx.last_fused() else
                                           (", 4-byte keys on the wire" if wire32 else ", 8-byte keys on the wire")) if use_dist else ""),
-                       "rccl_ranks_seen": ranks_seen if use_dist else None,
+                       "rccl_ranks_seen": ("test transport" if host_wire else ranks_seen) if use_dist else None,
+                       "transport": ("host memory through a gloo process group, all ranks on GPU 0 (--transport test: exercises this file's "
+                                     "N > 1 code; the wire's timings mean nothing)" if host_wire else "RCCL") if use_dist else None,
                        "pruned_before_shuffle": bool(dx.last_pruned()) if use_dist else None},
             "roofline": roof,
             "pipeline": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / (dt / args.steps) / 1e9,
@@ -716,6 +812,12 @@ def main():
             if cand in kern and cand != dom_name:
                 line["roofline_scatter"] = roof_of(cand)
                 break
+        if "roofline_scatter" not in line and use_dist and roof is not None:
+            # the sharded operator's sender runs BOTH tables' first-level passes under one profiler name: that entry, averaged over the two
+            first = [k for k in kern if k.startswith(("part_scatter_l0", "shard_scatter", "part_by_dest"))]
+            if first:
+                line["roofline_scatter"] = dict(roof_of(max(first, key=lambda k: kern[k]["ms_per_step"])),
+                                                note="sharded operator: both tables' first-level passes run under this one profiler name")
         if other is not None:
             line[other["scaling"] + "_scaling"] = other
         elif world == 1:
@@ -811,8 +913,13 @@ def main():
                 line["end_to_end"] = end_to_end(n, mod_b, a, b)
             except Exception as e:  # pragma: no cover
                 line["end_to_end"] = {"error": str(e)}
-        if not args.no_cpu_baseline:
+        if args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+            line["cpu_baseline_note"] = "--no-cpu-baseline"
+        else:
+            beat("CPU baseline (rank 0)")
             line["cpu_baseline"] = cpu_baseline()
+            beat("CPU yardsticks (rank 0)")
             try:
                 line["cpu_naive"] = cpu_naive_sizes()
             except Exception as e:  # pragma: no cover
@@ -837,12 +944,17 @@ def main():
                 o1, o2 = np.argsort(k.cpu().numpy(), kind="stable"), np.argsort(ek, kind="stable")
                 ok = (jj == ej and np.array_equal(k.cpu().numpy()[o1], ek[o2]) and np.array_equal(c.cpu().numpy()[o1], ec[o2]))
             line["verified_vs_oracle"] = bool(ok)
+        if verified_dist is not None:
+            line["verified_vs_oracle"] = verified_dist
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
+        beat("final barrier (rank 0 may be timing the CPU baseline)")
         dist.barrier()
         dx.close()
         dist.destroy_process_group()
+    if watchdog:
+        watchdog.stop()
     os.close(json_fd)
 
 

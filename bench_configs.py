@@ -23,12 +23,32 @@ HBM_PEAK_GBS = 8000.0
 METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 
 
-def run(args, world, rank, local_rank, json_fd):
+def run(args, world, rank, local_rank, json_fd, watchdog=None):
     from midoridb_amd.dev import DeviceCtx
     from midoridb_amd.dist import DatabaseDevice, DistCtx
     use_dist = world > 1 or args.force_shuffle
+    host_wire = getattr(args, "transport", "rccl") == "test"     # N ranks on GPU 0, blocks through host memory (bench.py --transport test)
     n = args.rows
     total = n * world
+
+    def beat(what):
+        if watchdog:
+            watchdog.beat(what)
+
+    def all_reduce_(t, op):
+        if host_wire:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def make_dist(dev):
+        dx = DistCtx.over_host_group(dev) if host_wire else DistCtx.from_torch(dev)
+        seen = dx.allreduce_sum([1])[0]
+        if seen != world:
+            raise SystemExit(f"[bench] rank {rank}: the library's communicator saw {seen} ranks, the launcher {world}")
+        return dx
 
     def barrier():
         torch.cuda.synchronize()
@@ -39,7 +59,9 @@ def run(args, world, rank, local_rank, json_fd):
     def timed(step, steps, warmup):
         r = None
         for _ in range(max(warmup, 1)):
+            beat("warm-up step")
             r = step()
+        beat("timed steps")
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -49,16 +71,17 @@ def run(args, world, rank, local_rank, json_fd):
         red = torch.tensor([dt, float(r)], dtype=torch.float64, device=f"cuda:{local_rank}")
         if use_dist:
             tmax = red[:1].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            all_reduce_(tmax, dist.ReduceOp.MAX)
+            all_reduce_(red, dist.ReduceOp.SUM)
             red[0] = tmax[0]
+        beat("timed steps done")
         return float(red[0].item()), int(red[1].item())
 
     line = {"metric": METRIC, "unit": "joined rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic"}
     if args.config == 4:
         dev = DeviceCtx(local_rank)
-        dx = DistCtx.from_torch(dev) if use_dist else None
+        dx = make_dist(dev) if use_dist else None
         a = dev.gen_keys(n, rank * n, total, 42, 0)
         b = dev.gen_keys(n, rank * n, total, 43, 0)
         if dx is not None:
@@ -68,7 +91,7 @@ def run(args, world, rank, local_rank, json_fd):
             for col in (a, b):
                 lo, hi = dev.key_range(col)
                 t = torch.tensor([-lo, hi], dtype=torch.float64, device=dev.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                all_reduce_(t, dist.ReduceOp.MAX)
                 rng.append((-int(t[0].item()), int(t[1].item())))
             dx.set_wire(WIRE_32)
             dx.set_key_ranges(rng[0], rng[1])
@@ -131,7 +154,7 @@ def run(args, world, rank, local_rank, json_fd):
         os.environ["MIDORIDB_DEVICE"] = str(local_rank)
         with DB() as db:
             if use_dist:
-                DistCtx.from_torch(DatabaseDevice(db, local_rank)).attach_to_database(db)
+                make_dist(DatabaseDevice(db, local_rank)).attach_to_database(db)
             db.execute("CREATE TABLE A (id_a INT, x DOUBLE);")
             db.execute("CREATE TABLE B (id_b INT, y DOUBLE);")
             db.execute("CREATE TABLE C (id_c INT, z INT);")
@@ -166,6 +189,10 @@ def run(args, world, rank, local_rank, json_fd):
                 "join_only_form": dict(res["joined"], query=JOINED, note="x, y DOUBLE and z INT carried as payload: 6 result columns"),
                 "cpu_baseline": None,
             })
+    if use_dist:    # (make_dist() has checked that the library's own communicator saw every rank)
+        line["config"]["rccl_ranks_seen"] = "test transport" if host_wire else world
+        if host_wire:
+            line["config"]["transport"] = "host memory through a gloo process group, all ranks on GPU 0 (--transport test)"
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -232,6 +232,51 @@ class DistCtx:
         t = Transport(None, _COUNTS(c_counts), _A2AV(c_a2av), _ALLRED(c_allred), _DESTROY(lambda _s: None))
         return cls(dev, world, rank, transport=t)
 
+    @classmethod
+    def over_host_group(cls, dev, group=None):
+        """A bring-up / test transport: the blocks cross the ranks through HOST memory, carried by a torch.distributed process group of a
+        CPU backend (gloo) - so N ranks can share ONE GPU (the GPU suite's world 2 / 4 / 8 runs, `bench.py --transport test`).  Every
+        kernel, plan and count exchange is the product's; only the wire differs (timings of the wire mean nothing)."""
+        import numpy as np
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def counts(send, n):
+            cin = torch.tensor(send, dtype=torch.int64)
+            cout = torch.empty(world * n, dtype=torch.int64)
+            dist.all_to_all_single(cout, cin, group=group)
+            return cout.tolist()
+
+        def alltoallv(d_send, sc, sd, d_recv, rc, rd, es, _stream):
+            # any counts / displacements (the region exchange sends every peer the SAME counter array: displacement 0 for all)
+            torch.cuda.synchronize()
+            dev.sync()
+            hi = max([sd[i] + sc[i] for i in range(world)] + [0])
+            hs = np.zeros(max(hi, 1) * es, dtype=np.uint8)
+            if hi and dev.lib.mdb_dev_d2h(dev.h, hs.ctypes.data, d_send, hi * es) != 0:
+                raise DistError("host transport: device -> host copy failed")
+            send = np.concatenate([hs[sd[i] * es:(sd[i] + sc[i]) * es] for i in range(world)]) if hi else np.zeros(0, dtype=np.uint8)
+            nrecv = sum(rc)
+            hr = torch.empty(max(nrecv, 1) * es, dtype=torch.uint8)
+            dist.all_to_all_single(hr[:nrecv * es], torch.from_numpy(np.ascontiguousarray(send)), [c * es for c in rc], [c * es for c in sc],
+                                   group=group)
+            off = 0
+            for i in range(world):
+                if rc[i]:
+                    piece = hr[off:off + rc[i] * es].numpy()
+                    if dev.lib.mdb_dev_h2d(dev.h, d_recv + rd[i] * es, piece.ctypes.data, rc[i] * es) != 0:
+                        raise DistError("host transport: host -> device copy failed")
+                off += rc[i] * es
+
+        def allreduce(vals):
+            t = torch.tensor(vals, dtype=torch.int64)
+            dist.all_reduce(t, group=group)
+            return t.tolist()
+
+        from .dev import _bind as bind_dev
+        bind_dev(dev.lib)
+        return cls.with_transport(dev, world, rank, counts, alltoallv, allreduce)
+
     # -- operator ----------------------------------------------------------------------------------------------
     def _chk(self, rc, what):
         if rc != 0:

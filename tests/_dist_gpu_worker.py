@@ -22,37 +22,9 @@ from midoridb_amd.dist import DistCtx, WIRE_32, WIRE_64, WIRE_AUTO  # noqa: E402
 
 
 def gloo_transport(dev, world, rank):
-    def counts(send, n):
-        cin = torch.tensor(send, dtype=torch.int64)
-        cout = torch.empty(world * n, dtype=torch.int64)
-        dist.all_to_all_single(cout, cin)
-        return cout.tolist()
-
-    def alltoallv(d_send, sc, sd, d_recv, rc, rd, es, _stream):
-        """any counts / displacements (the region exchange sends every peer the SAME counter array: displacement 0 for all)"""
-        torch.cuda.synchronize()
-        dev.sync()
-        hi = max([sd[i] + sc[i] for i in range(world)] + [0])
-        hs = np.zeros(max(hi, 1) * es, dtype=np.uint8)
-        if hi:
-            assert dev.lib.mdb_dev_d2h(dev.h, hs.ctypes.data, d_send, hi * es) == 0
-        send = np.concatenate([hs[sd[i] * es:(sd[i] + sc[i]) * es] for i in range(world)]) if hi else np.zeros(0, dtype=np.uint8)
-        nrecv = sum(rc)
-        hr = torch.empty(max(nrecv, 1) * es, dtype=torch.uint8)
-        dist.all_to_all_single(hr[:nrecv * es], torch.from_numpy(np.ascontiguousarray(send)), [c * es for c in rc], [c * es for c in sc])
-        off = 0
-        for i in range(world):
-            if rc[i]:
-                piece = hr[off:off + rc[i] * es].numpy()
-                assert dev.lib.mdb_dev_h2d(dev.h, d_recv + rd[i] * es, piece.ctypes.data, rc[i] * es) == 0
-            off += rc[i] * es
-
-    def allreduce(vals):
-        t = torch.tensor(vals, dtype=torch.int64)
-        dist.all_reduce(t)
-        return t.tolist()
-
-    return DistCtx.with_transport(dev, world, rank, counts, alltoallv, allreduce)
+    """world ranks on ONE GPU: the product's host-memory transport over this process group (midoridb_amd.dist.DistCtx.over_host_group)"""
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    return DistCtx.over_host_group(dev)
 
 
 def owned(dx, keys, world, rank, gb, nb=None, promised=None):
