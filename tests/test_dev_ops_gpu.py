@@ -776,7 +776,8 @@ def test_join_keys_is_the_key_column_of_join_pairs_as_a_multiset(dev, case):
 
 @pytest.mark.parametrize("case", ["pk_pk_two_cells", "fk_to_pk_one_cell", "window_far_from_zero", "left_row_without_partner", "null_left_key",
                                   "duplicate_right_key", "keys_beyond_a_window", "small", "window_2e27_two_levels", "window_2e29_two_cells",
-                                  "window_2e27_duplicate_right_key"])
+                                  "window_2e27_duplicate_right_key", "row_order_2e25", "row_order_2e26_two_cells", "row_order_whole_tiles",
+                                  "row_order_left_row_without_partner", "row_order_hot_key"])
 def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case):
     """mdb_dev_join_payload (BASELINE configs[1]: a primary-key join with payload): when every left row has exactly one partner the
     outputs are the partners' payload cells in left-row order (INT64 and DOUBLE bits alike) - equal to payload[pos_r] over the oracle's
@@ -813,6 +814,21 @@ def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case
             kr = kr.copy()
             kr[100] = kr[101]
             served = False
+    elif case.startswith("row_order"):
+        # round 5 (mdb_dev_rowjoin.hip): windows of 2^25 ... 2^27 values - the left table sorted tile by tile, the result placed in row order
+        # (the operator pads the sampled range and rounds it up to a power of two: these spans give windows of 2^25, 2^26, 2^27)
+        span = 1 << (24 if "2e25" in case else 25 if "2e26" in case else 26)
+        kr = np.unique(rng.integers(0, span, 1_800_000, dtype=np.int64)) + 10**10
+        nleft = 32768 * 70 if "whole_tiles" in case else 2_345_679
+        kl = kr[rng.integers(0, len(kr), nleft)]
+        if "hot_key" in case:		# one key on 200 000 consecutive left rows: pieces of a whole tile in one digit
+            kl[500_000:700_000] = kr[4242]
+        if "without_partner" in case:
+            kl[nleft - 3] = kr[7] + 1 if kr[7] + 1 != kr[8] else kr[7] - 1
+            if kl[nleft - 3] in (kr[6], kr[8]):
+                kl[nleft - 3] = 10**10 + span - 1 if kr[-1] != 10**10 + span - 1 else 10**10
+            served = False
+        pay = [rng.integers(-2**62, 2**62, len(kr), dtype=np.int64)] + ([rng.standard_normal(len(kr))] if "two_cells" in case else [])
     elif case == "keys_beyond_a_window":
         kr = np.unique(rng.integers(-2**62, 2**62, n, dtype=np.int64))
         kl = rng.permutation(kr)
@@ -822,7 +838,13 @@ def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case
         kl, kr = rng.permutation(3000).astype(np.int64), rng.permutation(3000).astype(np.int64)
         pay = [np.arange(3000, dtype=np.int64)]
         served = False			# (small tables: the pairs path has fewer launches)
+    dev.prof_enable(True)
+    dev.prof_reset()
     got = dev.join_payload(dev.to_dev(kl), dev.nullbits_dev(nl) if nl is not None else None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+    ran = set(dev.prof_read())
+    dev.prof_enable(False)
+    if case.startswith("row_order"):
+        assert {"rowjoin_tile_sort", "rowjoin_leaf"} <= ran and (not served or "rowjoin_place" in ran), (case, ran)
     if not served:
         assert got is None, case
         return
