@@ -119,8 +119,9 @@ int mdb_table_generate(struct database *db, const char *table, uint64_t n, uint6
 
 /* Results that stay on the device: after mdb_database_results_on_device(db, 1) a SELECT returns as soon as its result columns
  * exist in HBM - no device-to-host copy inside query_execute() (for the north-star query at 10^8 rows that copy is 3/4 of
- * the call).  query_column_data_device() hands out the device column (8-byte cells, query_row_count() of them, valid until
- * query_free()); the first query_cur_step() / query_column_data() / ... on such a result copies the columns to the host,
+ * the call).  query_column_data_device() hands out the device column (8-byte cells, query_row_count() of them, READ-ONLY, valid until
+ * query_free(); two result columns that hold the same values by construction - both key columns of `SELECT *` over an equi-join - may
+ * be one buffer); the first query_cur_step() / query_column_data() / ... on such a result copies the columns to the host,
  * once, and from then on everything behaves as usual.  Such a result must be released (query_free) BEFORE database_close():
  * its columns live in the database's device context. */
 int mdb_database_results_on_device(struct database *db, int on);

@@ -1194,8 +1194,9 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		/* round 5: the left table sorted tile by tile, the result written in row order without a scattered store per row
 		 * (mdb_dev_rowjoin.hip) - windows of 2^25 ... 2^27 values */
 		const bool by_rows = mdb_rowjoin_serves(n_l, n_r, kbits, keys_l, null_l, out, npay);
-		rc = mdb_arena_begin(ctx, (by_rows ? mdb_rowjoin_arena_bytes(n_l, kbits) : mdb_partition_arena_bytes(n_l, b1, b2, false, true)) +
-					  mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay) + 8192);
+		const bool tiled_r = by_rows && mdb_rowjoin_tiles_right(keys_r, null_r, pay_in, npay);
+		rc = mdb_arena_begin(ctx, (by_rows ? mdb_rowjoin_arena_bytes(n_l, tiled_r ? n_r : 0, kbits, npay) : mdb_partition_arena_bytes(n_l, b1, b2, false, true)) +
+					  (tiled_r ? 0 : mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay)) + 8192);
 		if (rc)
 			return rc;
 		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
@@ -1207,13 +1208,15 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		mdb_part_result pl, pr;
 		memset(&pl, 0, sizeof(pl));
 		memset(&pr, 0, sizeof(pr));
-		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
-		if (rc)
-			return rc;
+		if (!tiled_r) {
+			rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
+			if (rc)
+				return rc;
+		}
 		if (by_rows) {
-			if (!pr.leaf_cap || !pr.leaf_cnt || pr.w32 || !pr.pay[0] || (npay > 1 && !pr.pay[1]) || pr.nleaves != (1u << (b1 + b2)))
+			if (!tiled_r && (!pr.leaf_cap || !pr.leaf_cnt || pr.w32 || !pr.pay[0] || (npay > 1 && !pr.pay[1]) || pr.nleaves != (1u << (b1 + b2))))
 				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: the right table is not in the two-level fixed-capacity layout");
-			rc = mdb_rowjoin_run(ctx, keys_l, null_l, n_l, win.lo, kbits, &pr, rem, npay, out);
+			rc = mdb_rowjoin_run(ctx, keys_l, n_l, keys_r, n_r, pay_in, win.lo, kbits, tiled_r ? NULL : &pr, rem, npay, out);
 			if (rc)
 				return rc;
 			uint64_t *h = ctx->h_pinned;

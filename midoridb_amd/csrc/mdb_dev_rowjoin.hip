@@ -43,14 +43,18 @@ struct rj_sort_args {
 	uint64_t n;
 	int64_t base;		/* window [base, base + 2^kbits) */
 	uint32_t kbits, dbits;
-	uint32_t *words;	/* [ntiles * RJ_TILE] */
+	uint32_t *words;	/* [ntiles * RJ_TILE]: slot inside the digit << 15 | row inside the tile */
 	uint16_t *offs;		/* [ntiles * (D + 8)]: digit starts inside the tile, entry D = rows of the tile */
+	/* CELLS (the right table): up to two payload columns travel with the words - cells[c][tile * RJ_TILE + p] belongs to word p of the tile */
+	const uint64_t *pay_in[2];
+	uint64_t *cells[2];
+	uint32_t npay;
 	uint32_t *status;
 };
 
 /* ---- 1. tile sort.  FULL: a tile of exactly RJ_TILE rows - straight-line code, no per-row branch (the generic form spends a dozen scalar
  * branches per row and spills); the table's last, partial tile takes the other instance */
-template <bool FULL>
+template <bool FULL, bool CELLS>
 __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uint32_t tile0)
 {
 	extern __shared__ uint32_t rj_lds[];
@@ -147,75 +151,232 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 				const uint32_t h = hr[2 * j + e], d = h >> rem;
 				const uint32_t pos = (atomicAdd(&s_cnt[d >> 1], 1u << (16u * (d & 1u))) >> (16u * (d & 1u))) & 0xFFFFu;
 				s_stage[pos] = ((h & smask) << RJ_TILE_BITS) | r;
+				if (CELLS)
+					hr[2 * j + e] = pos;	/* (the row's cells follow it there) */
 			}
 		}
 	}
 	__syncthreads();
-	uint4 *const dst = reinterpret_cast<uint4 *>(a.words + row0);
-	const uint4 *const st = reinterpret_cast<const uint4 *>(s_stage);
-	for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS)
-		dst[i] = st[i];		/* (the words behind a partial last tile's rows are never read) */
+	{
+		uint4 *const dst = reinterpret_cast<uint4 *>(a.words + row0);
+		const uint4 *const st = reinterpret_cast<const uint4 *>(s_stage);
+		for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS)
+			dst[i] = st[i];		/* (the words behind a partial last tile's rows are never read) */
+	}
+	if (!CELLS)
+		return;
+	/* the cells: loaded in row order like the keys, dropped at their words' places in LDS - 16 384 at a time: two rounds per
+	 * column -, written out in order */
+	uint64_t *const s_cells = reinterpret_cast<uint64_t *>(s_stage);
+	for (uint32_t c = 0; c < a.npay; c++) {		/* (uniform) */
+		const ulonglong2 *csrc = reinterpret_cast<const ulonglong2 *>(a.pay_in[c] + row0);
+		ulonglong2 cv[RJ_ITEMS / 2];
+#pragma unroll
+		for (int j = 0; j < (int)RJ_ITEMS / 2; j++) {
+			const uint32_t p = (uint32_t)j * RJ_THREADS + threadIdx.x;
+			if (FULL) {
+				cv[j] = csrc[p];
+			} else {
+				cv[j] = make_ulonglong2(0ull, 0ull);
+				if (2u * p < cnt)
+					cv[j].x = a.pay_in[c][row0 + 2u * p];
+				if (2u * p + 1u < cnt)
+					cv[j].y = a.pay_in[c][row0 + 2u * p + 1u];
+			}
+		}
+		for (uint32_t round = 0; round < 2u; round++) {
+			__syncthreads();	/* (the staging area is free: its last readers are done) */
+#pragma unroll
+			for (int j = 0; j < (int)RJ_ITEMS / 2; j++) {
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const uint32_t r = 2u * ((uint32_t)j * RJ_THREADS + threadIdx.x) + (uint32_t)e;
+					const uint32_t pos = hr[2 * j + e];
+					if ((FULL || r < cnt) && (pos >> (RJ_TILE_BITS - 1u)) == round)
+						s_cells[pos & (RJ_TILE / 2 - 1u)] = e ? cv[j].y : cv[j].x;
+				}
+			}
+			__syncthreads();
+			const uint32_t p0 = round * (RJ_TILE / 2);
+			if (p0 < cnt) {
+				const uint32_t m = cnt - p0 < RJ_TILE / 2 ? cnt - p0 : RJ_TILE / 2;
+				ulonglong2 *const cd = reinterpret_cast<ulonglong2 *>(a.cells[c] + row0 + p0);
+				const ulonglong2 *const cs = reinterpret_cast<const ulonglong2 *>(s_cells);
+				for (uint32_t i = threadIdx.x; 2u * i < m; i += RJ_THREADS)
+					cd[i] = cs[i];	/* (an odd last cell takes its undefined neighbour along: inside the tile's block) */
+			}
+		}
+	}
+}
+
+/* ---- 1b. the tiles' digit offsets transposed: offT[d * tstride + t] = offs[t * (D + 8) + d], d = 0 .. D - so that a leaf workgroup
+ * reads its digit's starts (and the next digit's: the ends) of ALL tiles as two contiguous runs instead of one request per tile */
+__global__ __launch_bounds__(256) void k_rj_transpose_offs(const uint16_t *offs, uint32_t ntiles, uint32_t D, uint32_t tstride, uint16_t *offT)
+{
+	__shared__ uint16_t s_t[64][66];
+	const uint32_t t0 = blockIdx.x * 64u, d0 = blockIdx.y * 64u;
+	for (uint32_t i = threadIdx.x; i < 64u * 64u; i += 256u) {
+		const uint32_t tt = i >> 6, dd = i & 63u;
+		s_t[tt][dd] = (t0 + tt < ntiles && d0 + dd <= D) ? offs[(size_t)(t0 + tt) * (D + 8u) + d0 + dd] : (uint16_t)0;
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < 64u * 64u; i += 256u) {
+		const uint32_t dd = i >> 6, tt = i & 63u;
+		if (d0 + dd <= D && t0 + tt < tstride)
+			offT[(size_t)(d0 + dd) * tstride + t0 + tt] = s_t[tt][dd];
+	}
 }
 
 /* ---- 2. leaf */
 struct rj_leaf_args {
-	/* the right table in the two-level fixed-capacity layout of mdb_partition_table (leaves of 2^12 key values; the cell of hv_r[i]
-	 * is pay_r[i]): a digit of 2^14 values = 4 consecutive leaves */
+	/* the right table, TILED_R: sorted tile by tile like the left one, the cells at the words' positions */
+	const uint32_t *words_r;
+	const uint16_t *offT_r;
+	uint32_t ntiles_r, tstride_r;
+	/* ... or in the two-level fixed-capacity layout of mdb_partition_table (leaves of 2^12 key values; the cell of hv_r[i] is
+	 * cells_r[i]): a digit of 2^14 values = 4 consecutive leaves */
 	const uint64_t *hv_r;
-	const uint64_t *pay_r;
 	const uint32_t *cnt_r;
 	uint32_t cap_r, shift_r /* 32 - kbits */, rem_r /* 12 */;
+	const uint64_t *cells_r;
 	const uint32_t *words_l;
-	const uint16_t *offs_l;
-	uint32_t ntiles, dbits;
+	const uint16_t *offT_l;
+	uint32_t ntiles, tstride, dbits;
 	uint64_t *cells_al;	/* [ntiles * RJ_TILE]: cells_al[i] = the cell of the left row that words_l[i] names */
 	uint32_t count_pairs;	/* the first cell's pass counts the joined rows */
+	uint32_t ablate;	/* measurement only (MDB_RJ_ABLATE): 1 no build, 2 no probe, 4 no cell stores, 8 no right cells read */
 	unsigned long long *joined;
 	uint32_t *status;
 };
 
 #define RJ_LEAF_THREADS 1024
-#define RJ_BATCH 256u		/* word indices a wave lists per round */
 
 /* blockIdx -> digit: workgroups are dealt to the 8 XCDs round-robin; XCD x walks the digits [x * D / 8, (x + 1) * D / 8) in
- * order, so the digits that share a line of a tile's words / cells / offsets are neighbours in time on ONE L2 */
+ * order, so the digits that share a line of a tile's words / cells are neighbours in time on ONE L2 */
 __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
 {
 	return (b & 7u) * (D >> 3) + (b >> 3);
 }
 
+/* Digit d's pieces over all tiles of a tile-sorted table.  A wave takes RJ_G x 64 tiles per sweep: lane = one tile's piece in each of
+ * the RJ_G groups (start and end: coalesced loads from the transposed offsets); then LPP consecutive lanes take one piece together -
+ * consecutive lanes, consecutive words: a piece is one request each way, 64 / LPP pieces per instruction; the piece's place comes from
+ * its lane through the wave's crossbar (no LDS memory).  LPP = twice the average piece, so most pieces are done in one step.
+ * The kernel is a chain of dependent memory round trips (offsets -> words -> LDS -> store), so what matters is how many loads a lane
+ * has in flight: `load(unit, i)` is called for UNITS pieces' words first (it only ISSUES loads into the caller's registers), then
+ * `use(unit, i)` for each of them; words beyond a piece's first LPP go through `slow(i)` (load and use in one), rarely.
+ * All lanes of the wave call it together. */
+#define RJ_G 4
+template <int LPP, int UNITS, typename FL, typename FU, typename FS>
+__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow)
+{
+	static_assert((RJ_G * LPP) % UNITS == 0 && LPP <= 64, "units per sweep");
+	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
+	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
+		uint32_t sg[RJ_G], lg[RJ_G];
+#pragma unroll
+		for (int g = 0; g < RJ_G; g++) {
+			const uint32_t t = t0 + (uint32_t)g * nwaves * 64u + lane;	/* (the rows are padded to a multiple of 64 tiles: zeros) */
+			sg[g] = 0;
+			lg[g] = 0;
+			if (t < tstride) {
+				sg[g] = o0[t];
+				lg[g] = (uint32_t)o1[t] - sg[g];
+			}
+		}
+		uint32_t longest = 0;
+#pragma unroll
+		for (int u0 = 0; u0 < RJ_G * LPP; u0 += UNITS) {
+			uint32_t idx[UNITS];
+			bool on[UNITS];
+#pragma unroll
+			for (int u = 0; u < UNITS; u++) {
+				const int g = (u0 + u) / LPP, sb = (u0 + u) % LPP;
+				const int src = sb * (64 / LPP) + (int)(lane / LPP);
+				const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
+				idx[u] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_TILE + ps + lane % LPP;
+				on[u] = lane % LPP < pl;
+				longest = pl > longest ? pl : longest;
+				if (on[u])
+					load(u, idx[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < UNITS; u++)
+				if (on[u])
+					use(u, idx[u]);
+		}
+		if (__any(longest > (uint32_t)LPP)) {		/* pieces longer than LPP words: their rest, one step at a time */
+#pragma unroll 1
+			for (int g = 0; g < RJ_G; g++)
+#pragma unroll 1
+				for (int sb = 0; sb < LPP; sb++) {
+					const int src = sb * (64 / LPP) + (int)(lane / LPP);
+					const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
+					const uint32_t base = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_TILE + ps;
+					for (uint32_t k = LPP + lane % LPP; __any(k < pl); k += LPP)
+						if (k < pl)
+							slow(base + k);
+				}
+		}
+	}
+}
+
+template <bool TILED_R, int LPP>
 __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 {
 	extern __shared__ uint64_t rj_cell[];					/* 2^14 cells */
 	uint32_t *const s_occ = reinterpret_cast<uint32_t *>(rj_cell + (1u << RJ_SLOT_BITS));	/* 2^14 bits */
-	uint32_t *const s_list = s_occ + (1u << RJ_SLOT_BITS) / 32;		/* per wave: RJ_BATCH word indices */
 	__shared__ unsigned long long s_red[RJ_LEAF_THREADS / 64];
 	__shared__ uint32_t s_dup;
 	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D);
-	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = RJ_LEAF_THREADS / 64;
 	for (uint32_t w = threadIdx.x; w < (1u << RJ_SLOT_BITS) / 32; w += RJ_LEAF_THREADS)
-		s_occ[w] = 0u;
+		s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
 	if (threadIdx.x == 0)
 		s_dup = 0u;
 	__syncthreads();
-	/* build: the digit's right rows, 2^(14 - rem_r) leaves one after the other */
-	const uint32_t lpd = 1u << (RJ_SLOT_BITS - a.rem_r), rmask = (1u << a.rem_r) - 1u;
-	for (uint32_t q = 0; q < lpd; q++) {
-		const uint32_t leaf = d * lpd + q, c0 = a.cnt_r[leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
-		const size_t b = (size_t)leaf * a.cap_r;
-		for (uint32_t i0 = 0; i0 < c; i0 += 2u * RJ_LEAF_THREADS) {
-			const uint32_t i = i0 + 2u * threadIdx.x, ic = i < c ? i : 0u;
-			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_r + b + ic);
-			const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(a.pay_r + b + ic);
+	/* build: the digit's right rows - their cells dropped at their slots */
+	if (TILED_R) {
+		bool dup = false;
+		if (!(a.ablate & 1u)) {
+			constexpr int UB = 8;
+			uint32_t w[UB];
+			uint64_t c[UB];
+			auto put = [&](uint32_t word, uint64_t cell) {
+				const uint32_t slot = word >> RJ_TILE_BITS;
+				const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+				dup = dup || (old & (1u << (slot & 31u)));
+				rj_cell[slot] = cell;
+			};
+			rj_for_pieces<LPP, UB>(a.offT_r, a.tstride_r, a.ntiles_r, d,
+				[&](int u, uint32_t idx) {
+					w[u] = a.words_r[idx];
+					c[u] = (a.ablate & 8u) ? 0ull : a.cells_r[idx];
+				},
+				[&](int u, uint32_t) { put(w[u], c[u]); },
+				[&](uint32_t idx) { put(a.words_r[idx], a.cells_r[idx]); });
+		}
+		if (dup)
+			s_dup = 1u;
+	} else {
+		const uint32_t lpd = 1u << (RJ_SLOT_BITS - a.rem_r), rmask = (1u << a.rem_r) - 1u;
+		for (uint32_t q = 0; q < lpd; q++) {
+			const uint32_t leaf = d * lpd + q, c0 = a.cnt_r[leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
+			const size_t b = (size_t)leaf * a.cap_r;
+			for (uint32_t i0 = 0; i0 < c; i0 += 2u * RJ_LEAF_THREADS) {
+				const uint32_t i = i0 + 2u * threadIdx.x, ic = i < c ? i : 0u;
+				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_r + b + ic);
+				const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(a.cells_r + b + ic);
 #pragma unroll
-			for (int k = 0; k < 2; k++)
-				if (i + (uint32_t)k < c) {
-					const uint32_t slot = (q << a.rem_r) | (((uint32_t)((k ? v.y : v.x) >> 32) >> a.shift_r) & rmask);
-					const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
-					if (old & (1u << (slot & 31u)))
-						s_dup = 1u;
-					rj_cell[slot] = k ? p.y : p.x;
-				}
+				for (int k = 0; k < 2; k++)
+					if (i + (uint32_t)k < c) {
+						const uint32_t slot = (q << a.rem_r) | (((uint32_t)((k ? v.y : v.x) >> 32) >> a.shift_r) & rmask);
+						const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+						if (old & (1u << (slot & 31u)))
+							s_dup = 1u;
+						rj_cell[slot] = k ? p.y : p.x;
+					}
+			}
 		}
 	}
 	__syncthreads();
@@ -224,47 +385,31 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			mdb_raise(a.status, 32u);
 		return;
 	}
-	/* probe: lane = one left tile's piece of this digit; the pieces' words are listed per wave (RJ_BATCH at a time) so that
-	 * consecutive lanes then take consecutive words */
-	uint32_t *const list = s_list + wave * RJ_BATCH;
+	/* probe: every left row of the digit picks its partner's cell up and leaves it at its word's place */
 	unsigned long long pairs = 0;
 	uint32_t miss = 0;
-	const size_t ostride = (size_t)D + 8u;
-	for (uint32_t t0 = wave * 64u; t0 < a.ntiles; t0 += nwaves * 64u) {
-		const uint32_t t = t0 + lane;
-		uint32_t s = 0, len = 0;
-		if (t < a.ntiles) {
-			const uint16_t *o = a.offs_l + (size_t)t * ostride + d;
-			s = o[0];
-			len = (uint32_t)o[1] - s;	/* (entry D = the tile's rows) */
-		}
-		uint32_t done = 0;
-		while (__ballot(done < len)) {		/* (uniform over the wave) */
-			const uint32_t left = len - done;
-			const uint32_t incl = mdb_wave_incl_scan(left), before = incl - left;
-			const uint32_t total = (uint32_t)__shfl((int)incl, 63, MDB_WAVE);
-			uint32_t take = before < RJ_BATCH ? RJ_BATCH - before : 0u;
-			take = take < left ? take : left;
-			const uint32_t base = t * RJ_TILE + s + done;
-			for (uint32_t j = 0; j < take; j++)
-				list[before + j] = base + j;
-			done += take;
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_s_waitcnt(0xc07f);	/* lgkmcnt(0): the wave's LDS writes have landed */
-			const uint32_t m = total < RJ_BATCH ? total : RJ_BATCH;
-			for (uint32_t k = lane; k < m; k += 64u) {
-				const uint32_t idx = list[k];
-				const uint32_t slot = a.words_l[idx] >> RJ_TILE_BITS;
-				if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
+	{
+		constexpr int UP = 16;
+		uint32_t w[UP];
+		auto take = [&](uint32_t word, uint32_t idx) {
+			const uint32_t slot = word >> RJ_TILE_BITS;
+			if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
+				if (!(a.ablate & 4u))
 					a.cells_al[idx] = rj_cell[slot];
-					pairs++;
-				} else {
-					miss = 1u;
-				}
+				pairs++;
+			} else {
+				miss = 1u;
 			}
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_s_waitcnt(0xc07f);	/* ... and its reads are done before the list is rewritten */
-		}
+		};
+		rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d,
+			[&](int u, uint32_t idx) { w[u] = (a.ablate & 2u) ? 0u : a.words_l[idx]; },
+			[&](int u, uint32_t idx) {
+				if (a.ablate & 2u)
+					pairs++;
+				else
+					take(w[u], idx);
+			},
+			[&](uint32_t idx) { take(a.words_l[idx], idx); });
 	}
 	if (miss)
 		mdb_raise(a.status, 4u);	/* a left row without partner */
@@ -333,69 +478,167 @@ bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *
 	return true;
 }
 
-size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint32_t kbits)
+/* whether the right table takes the tile sort as well (otherwise the caller partitions it with mdb_partition_table) */
+bool mdb_rowjoin_tiles_right(const void *keys_r, const void *null_r, const void *const *pay_in, int npay)
 {
-	const uint32_t dbits = kbits - RJ_SLOT_BITS;
-	const uint64_t ntiles = (n_l + RJ_TILE - 1) / RJ_TILE;
-	return mdb_align_up(ntiles * RJ_TILE * 4) + mdb_align_up(ntiles * (((size_t)1 << dbits) + 8u) * 2) + mdb_align_up(ntiles * RJ_TILE * 8) + 4096;
+	if (null_r || ((uintptr_t)keys_r & 15u) || (getenv("MDB_ROWJOIN_TILED_R") && getenv("MDB_ROWJOIN_TILED_R")[0] == '0'))
+		return false;
+	for (int c = 0; c < npay; c++)
+		if ((uintptr_t)pay_in[c] & 15u)
+			return false;
+	return true;
 }
 
-/* the right table has been partitioned (pr: two levels, leaves of 2^12 values, cells beside the words); the arena holds
- * mdb_rowjoin_arena_bytes() more; ctx->d_status has been cleared by the caller.  Queues everything; no host sync.  Flags in
- * d_status[0]: 4 a left row without partner, 32 duplicate right key, 64 NULL left key, 128 key outside the window; joined rows
- * (u64) at d_status[2]. */
-int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, int64_t win_lo, uint32_t kbits,
-		    const mdb_part_result *pr, uint32_t rem_r, int npay, void *const *out)
+static size_t rj_tiles(uint64_t n) { return (size_t)((n + RJ_TILE - 1) / RJ_TILE); }
+
+size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r_tiled /* 0: the caller partitions the right table */, uint32_t kbits, int npay)
+{
+	const uint32_t dbits = kbits - RJ_SLOT_BITS;
+	const size_t ostride = ((size_t)1 << dbits) + 8u;
+	/* (+ 64: a 16-byte load may start at a block's last word or cell) */
+	size_t b = mdb_align_up(rj_tiles(n_l) * RJ_TILE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_TILE * 8 + 64) + 4096;
+	if (n_r_tiled)
+		b += mdb_align_up(rj_tiles(n_r_tiled) * RJ_TILE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r_tiled) + 64) * ostride * 2) +
+		     (size_t)npay * mdb_align_up(rj_tiles(n_r_tiled) * RJ_TILE * 8 + 64) + 4096;
+	return b;
+}
+
+/* the tile sort of one table + its offsets transposed: *offT_out = [D + 1][*tstride_out] */
+template <bool CELLS>
+static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *name, uint16_t **offT_out, uint32_t *tstride_out)
+{
+	const uint32_t D = 1u << sa.dbits;
+	const size_t lds = (size_t)(D >> 1) * 4 + (size_t)RJ_TILE * 4;
+	const uint32_t nfull = (uint32_t)(sa.n / RJ_TILE), ntiles = (uint32_t)rj_tiles(sa.n), tstride = (ntiles + 63u) & ~63u;
+	uint16_t *offT = (uint16_t *)mdb_arena_take(ctx, (size_t)(D + 1u) * tstride * 2);
+	if (!offT)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+	if (nfull) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_tile_sort<true, CELLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, name, (k_rj_tile_sort<true, CELLS>), nfull, RJ_THREADS, lds, sa, 0u);
+	}
+	if (nfull < ntiles) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_tile_sort<false, CELLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, name, (k_rj_tile_sort<false, CELLS>), 1u, RJ_THREADS, lds, sa, nfull);
+	}
+	MDB_LAUNCH(ctx, "rowjoin_offsets", k_rj_transpose_offs, dim3(tstride / 64u, (D + 64u) / 64u), 256, sa.offs, ntiles, D, tstride, offT);
+	*offT_out = offT;
+	*tstride_out = tstride;
+	return MIDORIDB_OK;
+}
+
+/* pr != NULL: the right table has been partitioned by the caller (two levels, leaves of 2^rem_r values, cells beside the words);
+ * pr == NULL: it is tile-sorted here (mdb_rowjoin_tiles_right() said yes).  The arena holds mdb_rowjoin_arena_bytes() more;
+ * ctx->d_status has been cleared by the caller.  Queues everything; no host sync.  Flags in d_status[0]: 4 a left row without
+ * partner, 32 duplicate right key, 128 key outside the window; joined rows (u64) at d_status[2]. */
+int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
+		    int64_t win_lo, uint32_t kbits, const mdb_part_result *pr, uint32_t rem_r, int npay, void *const *out)
 {
 	const uint32_t dbits = kbits - RJ_SLOT_BITS, D = 1u << dbits;
-	const uint32_t ntiles = (uint32_t)((n_l + RJ_TILE - 1) / RJ_TILE);
-	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 4);
-	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * (D + 8u) * 2);
-	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 8);
+	const uint32_t ntiles = (uint32_t)rj_tiles(n_l), ntiles_r = (uint32_t)rj_tiles(n_r);
+	const size_t ostride = (size_t)D + 8u;
+	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 4 + 64);
+	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * ostride * 2);
+	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 8 + 64);
 	if (!words || !offs || !cells_al)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
 	rj_sort_args sa;
-	memset(&sa, 0, sizeof(sa));
-	sa.keys = keys_l;
-	sa.n = n_l;
-	sa.base = win_lo;
-	sa.kbits = kbits;
-	sa.dbits = dbits;
-	sa.words = words;
-	sa.offs = offs;
-	sa.status = ctx->d_status;
-	const size_t lds_sort = (size_t)(D >> 1) * 4 + (size_t)RJ_TILE * 4;
-	const uint32_t nfull = (uint32_t)(n_l / RJ_TILE);
-	if (nfull) {
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_tile_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-		MDB_LAUNCH_LDS(ctx, "rowjoin_tile_sort", k_rj_tile_sort<true>, nfull, RJ_THREADS, lds_sort, sa, 0u);
+	uint32_t *words_r = NULL;
+	uint16_t *offs_r = NULL, *offT_r = NULL, *offT_l = NULL;
+	uint32_t tstride_r = 0, tstride_l = 0;
+	if (!pr) {
+		memset(&sa, 0, sizeof(sa));
+		words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_TILE * 4 + 64);
+		offs_r = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
+		for (int c = 0; c < npay; c++) {
+			sa.pay_in[c] = reinterpret_cast<const uint64_t *>(pay_in[c]);
+			sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_TILE * 8 + 64);
+			if (!sa.cells[c])
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+		}
+		if (!words_r || !offs_r)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+		sa.keys = keys_r;
+		sa.n = n_r;
+		sa.base = win_lo;
+		sa.kbits = kbits;
+		sa.dbits = dbits;
+		sa.words = words_r;
+		sa.offs = offs_r;
+		sa.npay = (uint32_t)npay;
+		sa.status = ctx->d_status;
+		const int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
+		if (rc)
+			return rc;
 	}
-	if (nfull < ntiles) {
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_tile_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-		MDB_LAUNCH_LDS(ctx, "rowjoin_tile_sort", k_rj_tile_sort<false>, 1u, RJ_THREADS, lds_sort, sa, nfull);
+	rj_sort_args sl;
+	memset(&sl, 0, sizeof(sl));
+	sl.keys = keys_l;
+	sl.n = n_l;
+	sl.base = win_lo;
+	sl.kbits = kbits;
+	sl.dbits = dbits;
+	sl.words = words;
+	sl.offs = offs;
+	sl.status = ctx->d_status;
+	{
+		const int rc = rj_sort_table<false>(ctx, sl, "rowjoin_tile_sort", &offT_l, &tstride_l);
+		if (rc)
+			return rc;
 	}
-	const size_t lds_leaf = ((size_t)8 << RJ_SLOT_BITS) + ((size_t)1 << RJ_SLOT_BITS) / 8 + (size_t)(RJ_LEAF_THREADS / 64) * RJ_BATCH * 4;
+	const size_t lds_leaf = ((size_t)8 << RJ_SLOT_BITS) + ((size_t)1 << RJ_SLOT_BITS) / 8;
 	const size_t lds_place = (size_t)(RJ_TILE / 2) * 8;
-	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf));
 	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
+	/* lanes per piece = twice the average piece (32 768 rows of a tile over D digits) */
+	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : 32;
 	for (int c = 0; c < npay; c++) {
 		rj_leaf_args la;
 		memset(&la, 0, sizeof(la));
-		la.hv_r = pr->hv;
-		la.pay_r = pr->pay[c];
-		la.cnt_r = pr->leaf_cnt;
-		la.cap_r = pr->leaf_cap;
-		la.shift_r = 32u - kbits;
-		la.rem_r = rem_r;
+		if (pr) {
+			la.hv_r = pr->hv;
+			la.cells_r = pr->pay[c];
+			la.cnt_r = pr->leaf_cnt;
+			la.cap_r = pr->leaf_cap;
+			la.shift_r = 32u - kbits;
+			la.rem_r = rem_r;
+		} else {
+			la.words_r = words_r;
+			la.offT_r = offT_r;
+			la.ntiles_r = ntiles_r;
+			la.tstride_r = tstride_r;
+			la.cells_r = sa.cells[c];
+		}
 		la.words_l = words;
-		la.offs_l = offs;
+		la.offT_l = offT_l;
 		la.ntiles = ntiles;
+		la.tstride = tstride_l;
 		la.dbits = dbits;
 		la.cells_al = cells_al;
 		la.count_pairs = c == 0;
+		la.ablate = getenv("MDB_RJ_ABLATE") ? (uint32_t)atoi(getenv("MDB_RJ_ABLATE")) : 0u;
 		la.joined = (unsigned long long *)(ctx->d_status + 2);
 		la.status = ctx->d_status;
-		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", k_rj_leaf, D, RJ_LEAF_THREADS, lds_leaf, la);
+#define RJ_LAUNCH_LEAF(TR, L)                                                                                                                          \
+	do {                                                                                                                                          \
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf<TR, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
+		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<TR, L>), D, RJ_LEAF_THREADS, lds_leaf, la);                                              \
+	} while (0)
+		if (pr) {
+			if (lpp == 8)
+				RJ_LAUNCH_LEAF(false, 8);
+			else if (lpp == 16)
+				RJ_LAUNCH_LEAF(false, 16);
+			else
+				RJ_LAUNCH_LEAF(false, 32);
+		} else {
+			if (lpp == 8)
+				RJ_LAUNCH_LEAF(true, 8);
+			else if (lpp == 16)
+				RJ_LAUNCH_LEAF(true, 16);
+			else
+				RJ_LAUNCH_LEAF(true, 32);
+		}
+#undef RJ_LAUNCH_LEAF
 		rj_place_args pa;
 		memset(&pa, 0, sizeof(pa));
 		pa.words_l = words;

@@ -520,9 +520,15 @@ void mdb_result_free(struct mdb_result *r)
 			mdb_dev_host_free(r->data[c]);
 		if (r->nullbits)
 			free(r->nullbits[c]);
-		if (r->d_data && r->d_data[c])
+		/* (two result columns may be ONE device buffer - both key columns of SELECT * over an equi-join: freed with the first) */
+		bool dup_d = false, dup_n = false;
+		for (int k = 0; k < c; k++) {
+			dup_d = dup_d || (r->d_data && r->d_data[c] && r->d_data[k] == r->d_data[c]);
+			dup_n = dup_n || (r->d_nullbits && r->d_nullbits[c] && r->d_nullbits[k] == r->d_nullbits[c]);
+		}
+		if (r->d_data && r->d_data[c] && !dup_d)
 			mdb_dev_free(r->dev, r->d_data[c]);
-		if (r->d_nullbits && r->d_nullbits[c])
+		if (r->d_nullbits && r->d_nullbits[c] && !dup_n)
 			mdb_dev_free(r->dev, r->d_nullbits[c]);
 	}
 	mdb_result_legacy_free(r);
@@ -1378,8 +1384,22 @@ grouped:
 				bool shared = false;
 				if (!src)
 					continue;
-				for (int k = 0; k < c; k++)	/* the same device column under two result columns (both key columns of SELECT *) */
-					shared = shared || d_vals[k] == src || (const void *)d_nulls[k] == src;
+				/* the same device column under two result columns (both key columns of SELECT * over an equi-join): ONE buffer of the
+				 * result serves both - query_column_data_device() hands out read-only columns - instead of a copy each (0.3 ms per
+				 * 10^8-row column) */
+				for (int k = 0; k < c && !own; k++) {
+					if (d_vals[k] == src && res->d_data[k])
+						own = res->d_data[k];
+					else if ((const void *)d_nulls[k] == src && res->d_nullbits[k])
+						own = res->d_nullbits[k];
+				}
+				if (own) {
+					if (pass)
+						res->d_nullbits[c] = own;
+					else
+						res->d_data[c] = own;
+					continue;
+				}
 				/* (a statement buffer sized for the worst case - every left row a group - must not pin hundreds of megabytes
 				 * behind a small result until query_free: such a column is copied into a buffer of its own size instead) */
 				for (int i = 0; i < x.bufs.n && !shared; i++)
