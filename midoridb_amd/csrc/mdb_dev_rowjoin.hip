@@ -32,6 +32,13 @@
 
 #define RJ_TILE 32768u		/* left rows per tile: 15 bits of a word name the row inside its tile */
 #define RJ_TILE_BITS 15u
+#ifndef RJ_SKEW
+#define RJ_SKEW 80u		/* words (cells) between the end of one tile's block and the start of the next: see RJ_STRIDE */
+#endif
+/* A tile's block of the word / cell arrays starts at tile * RJ_STRIDE: blocks exactly 2^17 bytes apart would put digit d's piece of
+ * EVERY tile - the same place in each block, give or take a few words - on the same L2 / memory channel, and a leaf workgroup asks for
+ * exactly those, 3052 of them in a row */
+#define RJ_STRIDE (RJ_TILE + RJ_SKEW)
 #define RJ_THREADS 1024
 #define RJ_ITEMS (RJ_TILE / RJ_THREADS)		/* 32 rows per thread */
 #define RJ_SLOT_BITS 14u	/* key values per digit: 2^14 eight-byte cells = 128 KiB of LDS */
@@ -43,9 +50,9 @@ struct rj_sort_args {
 	uint64_t n;
 	int64_t base;		/* window [base, base + 2^kbits) */
 	uint32_t kbits, dbits;
-	uint32_t *words;	/* [ntiles * RJ_TILE]: slot inside the digit << 15 | row inside the tile */
+	uint32_t *words;	/* [ntiles * RJ_STRIDE]: slot inside the digit << 15 | row inside the tile */
 	uint16_t *offs;		/* [ntiles * (D + 8)]: digit starts inside the tile, entry D = rows of the tile */
-	/* CELLS (the right table): up to two payload columns travel with the words - cells[c][tile * RJ_TILE + p] belongs to word p of the tile */
+	/* CELLS (the right table): up to two payload columns travel with the words - cells[c][tile * RJ_STRIDE + p] belongs to word p of the tile */
 	const uint64_t *pay_in[2];
 	uint64_t *cells[2];
 	uint32_t npay;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 	uint32_t *const s_stage = rj_lds + (D >> 1);		/* RJ_TILE words */
 	__shared__ uint32_t s_tmp[32];
 	const uint32_t tile = tile0 + blockIdx.x;
-	const uint64_t row0 = (uint64_t)tile * RJ_TILE;
+	const uint64_t row0 = (uint64_t)tile * RJ_TILE, blk0 = (uint64_t)tile * RJ_STRIDE;
 	const uint32_t cnt = FULL ? RJ_TILE : (uint32_t)(a.n - row0);
 	for (uint32_t i = threadIdx.x; i < (D >> 1); i += RJ_THREADS)
 		s_cnt[i] = 0u;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 	}
 	__syncthreads();
 	{
-		uint4 *const dst = reinterpret_cast<uint4 *>(a.words + row0);
+		uint4 *const dst = reinterpret_cast<uint4 *>(a.words + blk0);
 		const uint4 *const st = reinterpret_cast<const uint4 *>(s_stage);
 		for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS)
 			dst[i] = st[i];		/* (the words behind a partial last tile's rows are never read) */
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 			const uint32_t p0 = round * (RJ_TILE / 2);
 			if (p0 < cnt) {
 				const uint32_t m = cnt - p0 < RJ_TILE / 2 ? cnt - p0 : RJ_TILE / 2;
-				ulonglong2 *const cd = reinterpret_cast<ulonglong2 *>(a.cells[c] + row0 + p0);
+				ulonglong2 *const cd = reinterpret_cast<ulonglong2 *>(a.cells[c] + blk0 + p0);
 				const ulonglong2 *const cs = reinterpret_cast<const ulonglong2 *>(s_cells);
 				for (uint32_t i = threadIdx.x; 2u * i < m; i += RJ_THREADS)
 					cd[i] = cs[i];	/* (an odd last cell takes its undefined neighbour along: inside the tile's block) */
@@ -242,7 +249,7 @@ struct rj_leaf_args {
 	const uint32_t *words_l;
 	const uint16_t *offT_l;
 	uint32_t ntiles, tstride, dbits;
-	uint64_t *cells_al;	/* [ntiles * RJ_TILE]: cells_al[i] = the cell of the left row that words_l[i] names */
+	uint64_t *cells_al;	/* [ntiles * RJ_STRIDE]: cells_al[i] = the cell of the left row that words_l[i] names */
 	uint32_t count_pairs;	/* the first cell's pass counts the joined rows */
 	uint32_t ablate;	/* measurement only (MDB_RJ_ABLATE): 1 no build, 2 no probe, 4 no cell stores, 8 no right cells read */
 	unsigned long long *joined;
@@ -295,7 +302,7 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 				const int g = (u0 + u) / LPP, sb = (u0 + u) % LPP;
 				const int src = sb * (64 / LPP) + (int)(lane / LPP);
 				const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
-				idx[u] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_TILE + ps + lane % LPP;
+				idx[u] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps + lane % LPP;
 				on[u] = lane % LPP < pl;
 				longest = pl > longest ? pl : longest;
 				if (on[u])
@@ -313,7 +320,7 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 				for (int sb = 0; sb < LPP; sb++) {
 					const int src = sb * (64 / LPP) + (int)(lane / LPP);
 					const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
-					const uint32_t base = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_TILE + ps;
+					const uint32_t base = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps;
 					for (uint32_t k = LPP + lane % LPP; __any(k < pl); k += LPP)
 						if (k < pl)
 							slow(base + k);
@@ -436,11 +443,11 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_place(rj_place_args a)
 	const uint32_t b = blockIdx.x, tile = (b >> 4) * 8u + (b & 7u), half = (b >> 3) & 1u;
 	if (tile >= a.ntiles)
 		return;
-	const uint64_t row0 = (uint64_t)tile * RJ_TILE;
+	const uint64_t row0 = (uint64_t)tile * RJ_TILE, blk0 = (uint64_t)tile * RJ_STRIDE;
 	const uint32_t cnt = a.n - row0 < RJ_TILE ? (uint32_t)(a.n - row0) : RJ_TILE;
 	if (half * (RJ_TILE / 2) >= cnt)
 		return;
-	const uint4 *const wsrc = reinterpret_cast<const uint4 *>(a.words_l + row0);
+	const uint4 *const wsrc = reinterpret_cast<const uint4 *>(a.words_l + blk0);
 	for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS) {
 		const uint4 w = wsrc[i];
 		const uint32_t ws[4] = { w.x, w.y, w.z, w.w };
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_place(rj_place_args a)
 		for (int e = 0; e < 4; e++) {
 			const uint32_t r = ws[e] & (RJ_TILE - 1u);
 			if (4u * i + (uint32_t)e < cnt && (r >> (RJ_TILE_BITS - 1u)) == half)
-				rj_rows[r & (RJ_TILE / 2 - 1u)] = a.cells_al[row0 + 4u * i + (uint32_t)e];
+				rj_rows[r & (RJ_TILE / 2 - 1u)] = a.cells_al[blk0 + 4u * i + (uint32_t)e];
 		}
 	}
 	__syncthreads();
@@ -496,10 +503,10 @@ size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r_tiled /* 0: the caller
 	const uint32_t dbits = kbits - RJ_SLOT_BITS;
 	const size_t ostride = ((size_t)1 << dbits) + 8u;
 	/* (+ 64: a 16-byte load may start at a block's last word or cell) */
-	size_t b = mdb_align_up(rj_tiles(n_l) * RJ_TILE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_TILE * 8 + 64) + 4096;
+	size_t b = mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64) + 4096;
 	if (n_r_tiled)
-		b += mdb_align_up(rj_tiles(n_r_tiled) * RJ_TILE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r_tiled) + 64) * ostride * 2) +
-		     (size_t)npay * mdb_align_up(rj_tiles(n_r_tiled) * RJ_TILE * 8 + 64) + 4096;
+		b += mdb_align_up(rj_tiles(n_r_tiled) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r_tiled) + 64) * ostride * 2) +
+		     (size_t)npay * mdb_align_up(rj_tiles(n_r_tiled) * RJ_STRIDE * 8 + 64) + 4096;
 	return b;
 }
 
@@ -537,9 +544,9 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	const uint32_t dbits = kbits - RJ_SLOT_BITS, D = 1u << dbits;
 	const uint32_t ntiles = (uint32_t)rj_tiles(n_l), ntiles_r = (uint32_t)rj_tiles(n_r);
 	const size_t ostride = (size_t)D + 8u;
-	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 4 + 64);
+	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 4 + 64);
 	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * ostride * 2);
-	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_TILE * 8 + 64);
+	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 8 + 64);
 	if (!words || !offs || !cells_al)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
 	rj_sort_args sa;
@@ -548,11 +555,11 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	uint32_t tstride_r = 0, tstride_l = 0;
 	if (!pr) {
 		memset(&sa, 0, sizeof(sa));
-		words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_TILE * 4 + 64);
+		words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 4 + 64);
 		offs_r = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
 		for (int c = 0; c < npay; c++) {
 			sa.pay_in[c] = reinterpret_cast<const uint64_t *>(pay_in[c]);
-			sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_TILE * 8 + 64);
+			sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 8 + 64);
 			if (!sa.cells[c])
 				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
 		}
