@@ -1182,6 +1182,44 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		fprintf(stderr, "join_payload: narrow %d window 2^%u at %lld (attempt %d, remembered %d)\n", (int)narrow, win.kbits, (long long)win.lo, attempt, (int)remembered);
 	if (!narrow || !win.kbits)
 		return 1;
+	/* ---- round 5: both tables sorted tile by tile, the cells placed in the left table's row order without one scattered store per joined
+	 * row (mdb_dev_rowjoin.hip): windows of up to 2^27 values, NULL-free 16-byte-aligned columns */
+	if (mdb_rowjoin_serves(n_l, n_r, win.kbits, keys_l, null_l, keys_r, null_r, pay_in, out, npay)) {
+		const uint32_t kbits = win.kbits;
+		rc = mdb_arena_begin(ctx, mdb_rowjoin_arena_bytes(n_l, n_r, kbits, npay) + 8192);
+		if (rc)
+			return rc;
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+		rc = mdb_rowjoin_run(ctx, keys_l, n_l, keys_r, n_r, pay_in, win.lo, kbits, npay, out);
+		if (rc)
+			return rc;
+		uint64_t *h = ctx->h_pinned;
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t status = (uint32_t)h[1];
+		const uint64_t J = h[2];
+		if (getenv("MDB_DEBUG_PAYLOAD"))
+			fprintf(stderr, "join_payload (row order): k %u status %u J %llu of %llu left rows\n", kbits, status, (unsigned long long)J,
+				(unsigned long long)n_l);
+		if (status == 0 && J == n_l)
+			return MIDORIDB_OK;
+		if ((status & 128u) && remembered && attempt == 0) {
+			ctx->nh_result = -1;
+			ctx->sr_valid = 0;
+			ctx->nh_distrust = 1;
+			continue;
+		}
+		if (status & 128u) {
+			ctx->nh_distrust = 8;
+		} else {
+			ctx->jp_bad_l = keys_l;
+			ctx->jp_bad_nl = n_l;
+			ctx->jp_bad_r = keys_r;
+			ctx->jp_bad_nr = n_r;
+			ctx->jp_bad_skips = 0;
+		}
+		return 1;
+	}
 	if (win.kbits > 9u + PW_MAX_REM) {
 		/* ---- windows of 2^25 ... 2^30 values: two levels, leaves of 2^12 values */
 		if (win.kbits > 30u)
@@ -1191,12 +1229,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		const uint32_t rem = kbits - (uint32_t)(b1 + b2);
 		if (b2 < 1 || b2 > MDB_MAX_RADIX_BITS || n_l >= 0xF0000000ull || n_r >= 0xF0000000ull)
 			return 1;
-		/* round 5: the left table sorted tile by tile, the result written in row order without a scattered store per row
-		 * (mdb_dev_rowjoin.hip) - windows of 2^25 ... 2^27 values */
-		const bool by_rows = mdb_rowjoin_serves(n_l, n_r, kbits, keys_l, null_l, out, npay);
-		const bool tiled_r = by_rows && mdb_rowjoin_tiles_right(keys_r, null_r, pay_in, npay);
-		rc = mdb_arena_begin(ctx, (by_rows ? mdb_rowjoin_arena_bytes(n_l, tiled_r ? n_r : 0, kbits, npay) : mdb_partition_arena_bytes(n_l, b1, b2, false, true)) +
-					  (tiled_r ? 0 : mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay)) + 8192);
+		rc = mdb_arena_begin(ctx, mdb_partition_arena_bytes(n_l, b1, b2, false, true) + mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay) + 8192);
 		if (rc)
 			return rc;
 		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
@@ -1208,44 +1241,9 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		mdb_part_result pl, pr;
 		memset(&pl, 0, sizeof(pl));
 		memset(&pr, 0, sizeof(pr));
-		if (!tiled_r) {
-			rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
-			if (rc)
-				return rc;
-		}
-		if (by_rows) {
-			if (!tiled_r && (!pr.leaf_cap || !pr.leaf_cnt || pr.w32 || !pr.pay[0] || (npay > 1 && !pr.pay[1]) || pr.nleaves != (1u << (b1 + b2))))
-				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: the right table is not in the two-level fixed-capacity layout");
-			rc = mdb_rowjoin_run(ctx, keys_l, n_l, keys_r, n_r, pay_in, win.lo, kbits, tiled_r ? NULL : &pr, rem, npay, out);
-			if (rc)
-				return rc;
-			uint64_t *h = ctx->h_pinned;
-			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
-			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-			const uint32_t status = (uint32_t)h[1];
-			const uint64_t J = h[2];
-			if (getenv("MDB_DEBUG_PAYLOAD"))
-				fprintf(stderr, "join_payload (row order): k %u status %u J %llu of %llu left rows\n", kbits, status, (unsigned long long)J,
-					(unsigned long long)n_l);
-			if (status == 0 && J == n_l)
-				return MIDORIDB_OK;
-			if ((status & 128u) && remembered && attempt == 0) {
-				ctx->nh_result = -1;
-				ctx->sr_valid = 0;
-				ctx->nh_distrust = 1;
-				continue;
-			}
-			if (status & 128u) {
-				ctx->nh_distrust = 8;
-			} else if (!(status & 2u)) {
-				ctx->jp_bad_l = keys_l;
-				ctx->jp_bad_nl = n_l;
-				ctx->jp_bad_r = keys_r;
-				ctx->jp_bad_nr = n_r;
-				ctx->jp_bad_skips = 0;
-			}
-			return 1;
-		}
+		rc = mdb_partition_table(ctx, keys_r, null_r, n_r, b1, b2, false, false, true, &pr, 1, false, win.lo, kbits, &rflt);
+		if (rc)
+			return rc;
 		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, b1, b2, false, false, true, &pl, 1, false, win.lo, kbits, NULL);
 		if (rc)
 			return rc;

@@ -116,13 +116,15 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 	if (bad)
 		mdb_raise(a.status, 128u);
 	__syncthreads();
-	/* exclusive scan of the D counters: thread t owns D / 1024 consecutive digits (D >= 2048: 2, 4 or 8) */
+	/* exclusive scan of the D counters: thread t owns 1, 2 or 4 consecutive words of two counters each (D = 8 ... 8192; with fewer than
+	 * 2048 digits the first D / 2 threads own one word each) */
 	{
-		const uint32_t per = D / RJ_THREADS, w0 = threadIdx.x * (per >> 1);
+		const uint32_t nw = D >> 1, wpt = nw >= RJ_THREADS ? nw / RJ_THREADS : 1u, w0 = threadIdx.x * wpt;
+		const bool mine = w0 < nw;
 		uint32_t c[8], sum = 0;
 #pragma unroll
 		for (uint32_t i = 0; i < 4; i++)
-			if (i < (per >> 1)) {
+			if (i < wpt && mine) {
 				const uint32_t w = s_cnt[w0 + i];
 				c[2 * i] = w & 0xFFFFu;
 				c[2 * i + 1] = w >> 16;
@@ -130,10 +132,10 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 			}
 		uint32_t total;
 		uint32_t run = mdb_block_excl_scan(sum, s_tmp, &total);
-		uint16_t *const og = a.offs + (size_t)tile * (D + 8u) + (size_t)threadIdx.x * per;
+		uint16_t *const og = a.offs + (size_t)tile * (D + 8u) + (size_t)w0 * 2u;
 #pragma unroll
 		for (uint32_t i = 0; i < 4; i++)
-			if (i < (per >> 1)) {
+			if (i < wpt && mine) {
 				const uint32_t s0 = run, s1 = run + c[2 * i];
 				run = s1 + c[2 * i + 1];
 				s_cnt[w0 + i] = s0 | (s1 << 16);	/* (a start is <= 32 768: 16 bits) */
@@ -236,19 +238,14 @@ __global__ __launch_bounds__(256) void k_rj_transpose_offs(const uint16_t *offs,
 
 /* ---- 2. leaf */
 struct rj_leaf_args {
-	/* the right table, TILED_R: sorted tile by tile like the left one, the cells at the words' positions */
+	/* the right table: sorted tile by tile like the left one, the cells at the words' positions */
 	const uint32_t *words_r;
 	const uint16_t *offT_r;
 	uint32_t ntiles_r, tstride_r;
-	/* ... or in the two-level fixed-capacity layout of mdb_partition_table (leaves of 2^12 key values; the cell of hv_r[i] is
-	 * cells_r[i]): a digit of 2^14 values = 4 consecutive leaves */
-	const uint64_t *hv_r;
-	const uint32_t *cnt_r;
-	uint32_t cap_r, shift_r /* 32 - kbits */, rem_r /* 12 */;
 	const uint64_t *cells_r;
 	const uint32_t *words_l;
 	const uint16_t *offT_l;
-	uint32_t ntiles, tstride, dbits;
+	uint32_t ntiles, tstride, dbits, sbits /* key values per digit: 2^sbits <= 2^14 */;
 	uint64_t *cells_al;	/* [ntiles * RJ_STRIDE]: cells_al[i] = the cell of the left row that words_l[i] names */
 	uint32_t count_pairs;	/* the first cell's pass counts the joined rows */
 	uint32_t ablate;	/* measurement only (MDB_RJ_ABLATE): 1 no build, 2 no probe, 4 no cell stores, 8 no right cells read */
@@ -265,19 +262,19 @@ __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
 	return (b & 7u) * (D >> 3) + (b >> 3);
 }
 
-/* Digit d's pieces over all tiles of a tile-sorted table.  A wave takes RJ_G x 64 tiles per sweep: lane = one tile's piece in each of
- * the RJ_G groups (start and end: coalesced loads from the transposed offsets); then LPP consecutive lanes take one piece together -
+/* Digit d's pieces over all tiles of a tile-sorted table.  A wave takes 32 / LPP x 64 tiles per sweep: lane = one tile's piece in each of
+ * the 32 / LPP groups (start and end: coalesced loads from the transposed offsets); then LPP consecutive lanes take one piece together -
  * consecutive lanes, consecutive words: a piece is one request each way, 64 / LPP pieces per instruction; the piece's place comes from
  * its lane through the wave's crossbar (no LDS memory).  LPP = twice the average piece, so most pieces are done in one step.
  * The kernel is a chain of dependent memory round trips (offsets -> words -> LDS -> store), so what matters is how many loads a lane
  * has in flight: `load(unit, i)` is called for UNITS pieces' words first (it only ISSUES loads into the caller's registers), then
  * `use(unit, i)` for each of them; words beyond a piece's first LPP go through `slow(i)` (load and use in one), rarely.
  * All lanes of the wave call it together. */
-#define RJ_G 4
 template <int LPP, int UNITS, typename FL, typename FU, typename FS>
 __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow)
 {
-	static_assert((RJ_G * LPP) % UNITS == 0 && LPP <= 64, "units per sweep");
+	constexpr int RJ_G = LPP >= 32 ? 1 : 32 / LPP;	/* tile groups per sweep: 32 (64) pieces' steps per lane and sweep */
+	static_assert(LPP >= 8 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
 	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
@@ -329,62 +326,72 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 	}
 }
 
-template <bool TILED_R, int LPP>
+/* The same for pieces of 32 words and more (windows of up to 2^24 values: 1024 digits and fewer): the whole wave walks one piece after
+ * the other, 64 x UNITS words of it in flight (LPP = 64 selects it) */
+template <int UNITS, typename FL, typename FU>
+__device__ static inline void rj_for_long_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use)
+{
+	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
+	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u) {
+		const uint32_t t = t0 + lane;		/* (the rows are padded to a multiple of 64 tiles: zeros) */
+		const uint32_t s = o0[t], len = (uint32_t)o1[t] - s;
+		for (int j = 0; j < 64; j++) {
+			const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)s, j), pl = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
+			const uint32_t base = (t0 + (uint32_t)j) * RJ_STRIDE + ps;
+			for (uint32_t k0 = 0; k0 < pl; k0 += 64u * UNITS) {		/* (uniform) */
+#pragma unroll
+				for (int u = 0; u < UNITS; u++)
+					if (k0 + (uint32_t)u * 64u + lane < pl)
+						load(u, base + k0 + (uint32_t)u * 64u + lane);
+#pragma unroll
+				for (int u = 0; u < UNITS; u++)
+					if (k0 + (uint32_t)u * 64u + lane < pl)
+						use(u, base + k0 + (uint32_t)u * 64u + lane);
+			}
+		}
+	}
+}
+
+template <int LPP, bool LONG>
 __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 {
-	extern __shared__ uint64_t rj_cell[];					/* 2^14 cells */
-	uint32_t *const s_occ = reinterpret_cast<uint32_t *>(rj_cell + (1u << RJ_SLOT_BITS));	/* 2^14 bits */
+	extern __shared__ uint64_t rj_cell[];					/* 2^sbits cells */
+	uint32_t *const s_occ = reinterpret_cast<uint32_t *>(rj_cell + (1u << a.sbits));	/* 2^sbits bits (at least one word) */
 	__shared__ unsigned long long s_red[RJ_LEAF_THREADS / 64];
 	__shared__ uint32_t s_dup;
 	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D);
-	for (uint32_t w = threadIdx.x; w < (1u << RJ_SLOT_BITS) / 32; w += RJ_LEAF_THREADS)
+	for (uint32_t w = threadIdx.x; w < ((1u << a.sbits) + 31u) / 32u; w += blockDim.x)
 		s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
 	if (threadIdx.x == 0)
 		s_dup = 0u;
 	__syncthreads();
 	/* build: the digit's right rows - their cells dropped at their slots */
-	if (TILED_R) {
-		bool dup = false;
-		if (!(a.ablate & 1u)) {
-			constexpr int UB = 8;
-			uint32_t w[UB];
-			uint64_t c[UB];
-			auto put = [&](uint32_t word, uint64_t cell) {
-				const uint32_t slot = word >> RJ_TILE_BITS;
-				const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
-				dup = dup || (old & (1u << (slot & 31u)));
-				rj_cell[slot] = cell;
-			};
-			rj_for_pieces<LPP, UB>(a.offT_r, a.tstride_r, a.ntiles_r, d,
-				[&](int u, uint32_t idx) {
-					w[u] = a.words_r[idx];
-					c[u] = (a.ablate & 8u) ? 0ull : a.cells_r[idx];
-				},
-				[&](int u, uint32_t) { put(w[u], c[u]); },
-				[&](uint32_t idx) { put(a.words_r[idx], a.cells_r[idx]); });
-		}
-		if (dup)
-			s_dup = 1u;
-	} else {
-		const uint32_t lpd = 1u << (RJ_SLOT_BITS - a.rem_r), rmask = (1u << a.rem_r) - 1u;
-		for (uint32_t q = 0; q < lpd; q++) {
-			const uint32_t leaf = d * lpd + q, c0 = a.cnt_r[leaf], c = c0 < a.cap_r ? c0 : a.cap_r;
-			const size_t b = (size_t)leaf * a.cap_r;
-			for (uint32_t i0 = 0; i0 < c; i0 += 2u * RJ_LEAF_THREADS) {
-				const uint32_t i = i0 + 2u * threadIdx.x, ic = i < c ? i : 0u;
-				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.hv_r + b + ic);
-				const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(a.cells_r + b + ic);
-#pragma unroll
-				for (int k = 0; k < 2; k++)
-					if (i + (uint32_t)k < c) {
-						const uint32_t slot = (q << a.rem_r) | (((uint32_t)((k ? v.y : v.x) >> 32) >> a.shift_r) & rmask);
-						const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
-						if (old & (1u << (slot & 31u)))
-							s_dup = 1u;
-						rj_cell[slot] = k ? p.y : p.x;
-					}
-			}
-		}
+	{
+	bool dup = false;
+	if (!(a.ablate & 1u)) {
+		constexpr int UB = 8;
+		uint32_t w[UB];
+		uint64_t c[UB];
+		auto put = [&](uint32_t word, uint64_t cell) {
+			const uint32_t slot = word >> RJ_TILE_BITS;
+			const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+			dup = dup || (old & (1u << (slot & 31u)));
+			rj_cell[slot] = cell;
+		};
+		auto ld = [&](int u, uint32_t idx) {
+			w[u] = a.words_r[idx];
+			c[u] = (a.ablate & 8u) ? 0ull : a.cells_r[idx];
+		};
+		auto us = [&](int u, uint32_t) { put(w[u], c[u]); };
+		if (LPP == 64)
+			rj_for_long_pieces<UB>(a.offT_r, a.tstride_r, a.ntiles_r, d, ld, us);
+		else
+			rj_for_pieces<(LPP == 64 ? 32 : LPP), UB>(a.offT_r, a.tstride_r, a.ntiles_r, d, ld, us,
+								  [&](uint32_t idx) { put(a.words_r[idx], a.cells_r[idx]); });
+	}
+	if (dup)
+		s_dup = 1u;
 	}
 	__syncthreads();
 	if (s_dup) {	/* a right key occurs twice */
@@ -408,22 +415,34 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 				miss = 1u;
 			}
 		};
-		rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d,
-			[&](int u, uint32_t idx) { w[u] = (a.ablate & 2u) ? 0u : a.words_l[idx]; },
-			[&](int u, uint32_t idx) {
-				if (a.ablate & 2u)
-					pairs++;
-				else
-					take(w[u], idx);
-			},
-			[&](uint32_t idx) { take(a.words_l[idx], idx); });
+		auto ld = [&](int u, uint32_t idx) { w[u] = (a.ablate & 2u) ? 0u : a.words_l[idx]; };
+		auto us = [&](int u, uint32_t idx) {
+			if (a.ablate & 2u)
+				pairs++;
+			else
+				take(w[u], idx);
+		};
+		if (LONG)
+			rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
+		else
+			rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); });
 	}
 	if (miss)
 		mdb_raise(a.status, 4u);	/* a left row without partner */
 	if (a.count_pairs) {
-		pairs = lw_block_sum(pairs, s_red);
-		if (threadIdx.x == 0 && pairs)
-			atomicAdd(a.joined, pairs);
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			pairs += __shfl_down(pairs, o, MDB_WAVE);
+		if (mdb_lane() == 0)
+			s_red[threadIdx.x >> 6] = pairs;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long t = 0;
+			for (uint32_t w = 0; w < (blockDim.x >> 6); w++)
+				t += s_red[w];
+			if (t)
+				atomicAdd(a.joined, t);
+		}
 	}
 }
 
@@ -469,45 +488,47 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_place(rj_place_args a)
 }
 
 /* ---- host */
-bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *keys_l, const void *null_l, void *const *out, int npay)
-{
-	if (null_l)	/* (a NULL left key has no partner: not this operator's join) */
-		return false;
-	if (getenv("MDB_ROWJOIN") && getenv("MDB_ROWJOIN")[0] == '0')
-		return false;
-	if (kbits < RJ_SLOT_BITS + 11u || kbits > RJ_SLOT_BITS + RJ_MAX_DBITS)	/* 2048 ... 8192 digits (windows of 2^25 ... 2^27 values) */
-		return false;
-	if (n_l >= 0xF0000000ull || n_r >= 0xF0000000ull || ((uintptr_t)keys_l & 15u))
-		return false;
-	for (int c = 0; c < npay; c++)
-		if ((uintptr_t)out[c] & 15u)
-			return false;
-	return true;
-}
-
-/* whether the right table takes the tile sort as well (otherwise the caller partitions it with mdb_partition_table) */
-bool mdb_rowjoin_tiles_right(const void *keys_r, const void *null_r, const void *const *pay_in, int npay)
-{
-	if (null_r || ((uintptr_t)keys_r & 15u) || (getenv("MDB_ROWJOIN_TILED_R") && getenv("MDB_ROWJOIN_TILED_R")[0] == '0'))
-		return false;
-	for (int c = 0; c < npay; c++)
-		if ((uintptr_t)pay_in[c] & 15u)
-			return false;
-	return true;
-}
-
 static size_t rj_tiles(uint64_t n) { return (size_t)((n + RJ_TILE - 1) / RJ_TILE); }
 
-size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r_tiled /* 0: the caller partitions the right table */, uint32_t kbits, int npay)
+/* digits of the tile sort: as many as a tile's counters allow (8192: pieces of 4 words, a leaf table of 2^(kbits - 13) <= 2^14 cells -
+ * small tables keep several leaf workgroups on a CU), at least 2^8 key values per digit, never fewer than 8 digits (one per XCD) */
+uint32_t mdb_rowjoin_dbits(uint32_t kbits)
 {
-	const uint32_t dbits = kbits - RJ_SLOT_BITS;
+	const uint32_t d = kbits > 8u + 3u ? kbits - 8u : 3u;
+	return d > RJ_MAX_DBITS ? RJ_MAX_DBITS : d;
+}
+
+bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *keys_l, const void *null_l, const void *keys_r, const void *null_r,
+			const void *const *pay_in, void *const *out, int npay)
+{
+	if (null_l || null_r)	/* (a NULL left key has no partner: not this operator's join; a nullable right key column: the older forms) */
+		return false;
+	/* MDB_ROWJOIN: 0 never, 2 whenever the form applies; default: left tables of 2^24 rows and more - up to there a result column
+	 * (128 MB) stays in the Infinity Cache and the older forms' scattered 8-byte stores land in it (10^7 x 10^7 rows: 0.44 ms against
+	 * 0.56 here; 10^8 x 10^8: 6.0 ms against 2.9) */
+	const char *knob = getenv("MDB_ROWJOIN");
+	if (knob && knob[0] == '0')
+		return false;
+	if (n_l < ((uint64_t)1 << 24) && !(knob && knob[0] == '2'))
+		return false;
+	if (kbits < 15u || kbits > RJ_SLOT_BITS + RJ_MAX_DBITS)	/* 8 ... 8192 digits (windows of up to 2^27 values) */
+		return false;
+	if (n_l >= 0xF0000000ull || n_r >= 0xF0000000ull || ((uintptr_t)keys_l & 15u) || ((uintptr_t)keys_r & 15u))
+		return false;
+	for (int c = 0; c < npay; c++)
+		if (((uintptr_t)out[c] & 15u) || ((uintptr_t)pay_in[c] & 15u))
+			return false;
+	return true;
+}
+
+size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r, uint32_t kbits, int npay)
+{
+	const uint32_t dbits = mdb_rowjoin_dbits(kbits);
 	const size_t ostride = ((size_t)1 << dbits) + 8u;
 	/* (+ 64: a 16-byte load may start at a block's last word or cell) */
-	size_t b = mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64) + 4096;
-	if (n_r_tiled)
-		b += mdb_align_up(rj_tiles(n_r_tiled) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r_tiled) + 64) * ostride * 2) +
-		     (size_t)npay * mdb_align_up(rj_tiles(n_r_tiled) * RJ_STRIDE * 8 + 64) + 4096;
-	return b;
+	return mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64) +
+	       mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r) + 64) * ostride * 2) +
+	       (size_t)npay * mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 8 + 64) + 8192;
 }
 
 /* the tile sort of one table + its offsets transposed: *offT_out = [D + 1][*tstride_out] */
@@ -534,50 +555,41 @@ static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *n
 	return MIDORIDB_OK;
 }
 
-/* pr != NULL: the right table has been partitioned by the caller (two levels, leaves of 2^rem_r values, cells beside the words);
- * pr == NULL: it is tile-sorted here (mdb_rowjoin_tiles_right() said yes).  The arena holds mdb_rowjoin_arena_bytes() more;
- * ctx->d_status has been cleared by the caller.  Queues everything; no host sync.  Flags in d_status[0]: 4 a left row without
- * partner, 32 duplicate right key, 128 key outside the window; joined rows (u64) at d_status[2]. */
 int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
-		    int64_t win_lo, uint32_t kbits, const mdb_part_result *pr, uint32_t rem_r, int npay, void *const *out)
+		    int64_t win_lo, uint32_t kbits, int npay, void *const *out)
 {
-	const uint32_t dbits = kbits - RJ_SLOT_BITS, D = 1u << dbits;
+	const uint32_t dbits = mdb_rowjoin_dbits(kbits), D = 1u << dbits;
 	const uint32_t ntiles = (uint32_t)rj_tiles(n_l), ntiles_r = (uint32_t)rj_tiles(n_r);
 	const size_t ostride = (size_t)D + 8u;
 	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 4 + 64);
 	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * ostride * 2);
 	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 8 + 64);
-	if (!words || !offs || !cells_al)
+	uint32_t *words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 4 + 64);
+	uint16_t *offs_r = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
+	if (!words || !offs || !cells_al || !words_r || !offs_r)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
-	rj_sort_args sa;
-	uint32_t *words_r = NULL;
-	uint16_t *offs_r = NULL, *offT_r = NULL, *offT_l = NULL;
+	uint16_t *offT_r = NULL, *offT_l = NULL;
 	uint32_t tstride_r = 0, tstride_l = 0;
-	if (!pr) {
-		memset(&sa, 0, sizeof(sa));
-		words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 4 + 64);
-		offs_r = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
-		for (int c = 0; c < npay; c++) {
-			sa.pay_in[c] = reinterpret_cast<const uint64_t *>(pay_in[c]);
-			sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 8 + 64);
-			if (!sa.cells[c])
-				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
-		}
-		if (!words_r || !offs_r)
+	rj_sort_args sa;
+	memset(&sa, 0, sizeof(sa));
+	for (int c = 0; c < npay; c++) {
+		sa.pay_in[c] = reinterpret_cast<const uint64_t *>(pay_in[c]);
+		sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 8 + 64);
+		if (!sa.cells[c])
 			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
-		sa.keys = keys_r;
-		sa.n = n_r;
-		sa.base = win_lo;
-		sa.kbits = kbits;
-		sa.dbits = dbits;
-		sa.words = words_r;
-		sa.offs = offs_r;
-		sa.npay = (uint32_t)npay;
-		sa.status = ctx->d_status;
-		const int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
-		if (rc)
-			return rc;
 	}
+	sa.keys = keys_r;
+	sa.n = n_r;
+	sa.base = win_lo;
+	sa.kbits = kbits;
+	sa.dbits = dbits;
+	sa.words = words_r;
+	sa.offs = offs_r;
+	sa.npay = (uint32_t)npay;
+	sa.status = ctx->d_status;
+	int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
+	if (rc)
+		return rc;
 	rj_sort_args sl;
 	memset(&sl, 0, sizeof(sl));
 	sl.keys = keys_l;
@@ -588,63 +600,53 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	sl.words = words;
 	sl.offs = offs;
 	sl.status = ctx->d_status;
-	{
-		const int rc = rj_sort_table<false>(ctx, sl, "rowjoin_tile_sort", &offT_l, &tstride_l);
-		if (rc)
-			return rc;
-	}
-	const size_t lds_leaf = ((size_t)8 << RJ_SLOT_BITS) + ((size_t)1 << RJ_SLOT_BITS) / 8;
+	rc = rj_sort_table<false>(ctx, sl, "rowjoin_tile_sort", &offT_l, &tstride_l);
+	if (rc)
+		return rc;
+	const uint32_t sbits = kbits - dbits;
+	const size_t lds_leaf = ((size_t)8 << sbits) + ((((size_t)1 << sbits) + 31) / 32) * 4;
 	const size_t lds_place = (size_t)(RJ_TILE / 2) * 8;
 	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
-	/* lanes per piece = twice the average piece (32 768 rows of a tile over D digits) */
-	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : 32;
+	/* lanes per piece = twice the average piece (32 768 rows of a tile over D digits); fewer than 1024 digits (windows below 2^18 values):
+	 * the whole wave walks one piece after the other */
+	/* workgroups of the leaf: as many threads as the table's LDS leaves room for several of on a CU (a digit is a chain of dependent
+	 * round trips - offsets, words, cells -: what hides them is another digit on the same CU) */
+	const uint32_t leaf_threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
+	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : dbits == 11 ? 32 : dbits == 10 ? 64 : 0;
 	for (int c = 0; c < npay; c++) {
 		rj_leaf_args la;
 		memset(&la, 0, sizeof(la));
-		if (pr) {
-			la.hv_r = pr->hv;
-			la.cells_r = pr->pay[c];
-			la.cnt_r = pr->leaf_cnt;
-			la.cap_r = pr->leaf_cap;
-			la.shift_r = 32u - kbits;
-			la.rem_r = rem_r;
-		} else {
-			la.words_r = words_r;
-			la.offT_r = offT_r;
-			la.ntiles_r = ntiles_r;
-			la.tstride_r = tstride_r;
-			la.cells_r = sa.cells[c];
-		}
+		la.words_r = words_r;
+		la.offT_r = offT_r;
+		la.ntiles_r = ntiles_r;
+		la.tstride_r = tstride_r;
+		la.cells_r = sa.cells[c];
 		la.words_l = words;
 		la.offT_l = offT_l;
 		la.ntiles = ntiles;
 		la.tstride = tstride_l;
 		la.dbits = dbits;
+		la.sbits = sbits;
 		la.cells_al = cells_al;
 		la.count_pairs = c == 0;
 		la.ablate = getenv("MDB_RJ_ABLATE") ? (uint32_t)atoi(getenv("MDB_RJ_ABLATE")) : 0u;
 		la.joined = (unsigned long long *)(ctx->d_status + 2);
 		la.status = ctx->d_status;
-#define RJ_LAUNCH_LEAF(TR, L)                                                                                                                          \
-	do {                                                                                                                                          \
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf<TR, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
-		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<TR, L>), D, RJ_LEAF_THREADS, lds_leaf, la);                                              \
+#define RJ_LAUNCH_LEAF(L, LONG)                                                                                                                   \
+	do {                                                                                                                                      \
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf<L, LONG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
+		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<L, LONG>), D, leaf_threads, lds_leaf, la);                                            \
 	} while (0)
-		if (pr) {
-			if (lpp == 8)
-				RJ_LAUNCH_LEAF(false, 8);
-			else if (lpp == 16)
-				RJ_LAUNCH_LEAF(false, 16);
-			else
-				RJ_LAUNCH_LEAF(false, 32);
-		} else {
-			if (lpp == 8)
-				RJ_LAUNCH_LEAF(true, 8);
-			else if (lpp == 16)
-				RJ_LAUNCH_LEAF(true, 16);
-			else
-				RJ_LAUNCH_LEAF(true, 32);
-		}
+		if (lpp == 8)
+			RJ_LAUNCH_LEAF(8, false);
+		else if (lpp == 16)
+			RJ_LAUNCH_LEAF(16, false);
+		else if (lpp == 32)
+			RJ_LAUNCH_LEAF(32, false);
+		else if (lpp == 64)
+			RJ_LAUNCH_LEAF(64, false);
+		else
+			RJ_LAUNCH_LEAF(64, true);
 #undef RJ_LAUNCH_LEAF
 		rj_place_args pa;
 		memset(&pa, 0, sizeof(pa));
