@@ -17,4 +17,10 @@ size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r, uint32_t kbits, int n
 int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
 		    int64_t win_lo, uint32_t kbits, int npay, void *const *out);
 
+
+/* GROUP BY key + COUNT(*) of one NULL-free key column through the tile sort: 0 = done (groups in first-row order), 1 = not served
+ * (*outside: a key lay outside the window), < 0 = error.  Synchronises. */
+int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
+			  uint64_t cap, uint64_t *out_groups, bool *outside);
+
 #endif

@@ -660,3 +660,269 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	}
 	return MIDORIDB_OK;
 }
+
+/* ------------------------------------------------------------------ GROUP BY key + COUNT(*) over a tile-sorted column (round 5)
+ *
+ * The reference's proc_groupby_clause (/root/reference/src/engine/executor_select.c:1526-1588, cmp_rows_col_mattbl :1465-1499, inc_count_cols
+ * :1501-1524) keeps the FIRST row of every key and counts the others into it: (first row id, COUNT) per key, in first-row order.  The key
+ * column goes through the tile sort above (one sequential pass, 4-byte words that name the row inside its tile), then one workgroup per key
+ * digit walks the digit's piece of every tile and keeps, per key value, the smallest row id and the number of rows in two LDS arrays
+ * (direct-addressed by the slot bits).  The groups leave either straight into the ordering kernel's ranges of 2^16 first row ids
+ * (k_order_leaf_sparse: few groups) or as one record list for the ordering sort.  Before: two 8-byte partition levels + a leaf that
+ * reads 12 bytes per row. */
+struct rg_group_args {
+	const uint32_t *words;
+	const uint16_t *offT;
+	uint32_t ntiles, tstride, dbits, sbits;
+	uint32_t row_bits;		/* a record = first row id << (64 - row_bits) | COUNT */
+	unsigned long long *rg_rec;	/* ranged emit (NULL: the list): region r of rg_cap records at rg_rec + r * rg_cap, its fill in rg_cnt[r] */
+	uint32_t *rg_cnt;
+	uint32_t rg_cap, rg_shift, rg_n;
+	unsigned long long *rec;	/* the list */
+	uint32_t *rec_count;
+	uint32_t rec_cap;
+	uint32_t *groups;
+	uint32_t *status;
+};
+
+template <int LPP>
+__global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf(rg_group_args a)
+{
+	extern __shared__ uint32_t rg_lds[];
+	const uint32_t S = 1u << a.sbits;
+	uint32_t *const s_first = rg_lds, *const s_count = rg_lds + S, *const s_rg = s_count + S;
+	__shared__ uint32_t s_tmp[32];
+	__shared__ uint32_t s_base;
+	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D);
+	for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+		s_first[i] = 0xFFFFFFFFu;
+		s_count[i] = 0u;
+	}
+	for (uint32_t r = threadIdx.x; r < (a.rg_rec ? a.rg_n : 0u); r += blockDim.x)
+		s_rg[r] = 0u;
+	__syncthreads();
+	{
+		constexpr int UG = 16;
+		uint32_t w[UG];
+		auto take = [&](uint32_t word, uint32_t idx) {
+			const uint32_t slot = word >> RJ_TILE_BITS, row = (idx / RJ_STRIDE) * RJ_TILE + (word & (RJ_TILE - 1u));
+			atomicMin(&s_first[slot], row);
+			atomicAdd(&s_count[slot], 1u);
+		};
+		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
+				       [&](int u, uint32_t idx) { take(w[u], idx); }, [&](uint32_t idx) { take(a.words[idx], idx); });
+	}
+	__syncthreads();
+	if (a.rg_rec) {
+		/* the ordering kernel's ranges of 2^rg_shift first row ids are filled here: the digit's groups per range are counted, a place for
+		 * them reserved with one global atomic per (digit, range), and every record written there */
+		uint32_t mine = 0;
+		for (uint32_t i = threadIdx.x; i < S; i += blockDim.x)
+			if (s_count[i]) {
+				atomicAdd(&s_rg[s_first[i] >> a.rg_shift], 1u);
+				mine++;
+			}
+		uint32_t total;
+		(void)mdb_block_excl_scan(mine, s_tmp, &total);		/* (two barriers: s_rg is complete behind it) */
+		if (threadIdx.x == 0 && total)
+			atomicAdd(a.groups, total);
+		for (uint32_t r = threadIdx.x; r < a.rg_n; r += blockDim.x) {
+			const uint32_t c = s_rg[r];
+			if (!c)
+				continue;
+			uint32_t at = atomicAdd(&a.rg_cnt[r], c);
+			if (at + c > a.rg_cap) {
+				mdb_raise(a.status, 8192u);	/* a range outgrew its region: the caller takes the record list and its sort */
+				at = a.rg_cap;
+			}
+			s_rg[r] = at;
+		}
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+			const uint32_t c = s_count[i];
+			if (!c)
+				continue;
+			const uint32_t first = s_first[i], r = first >> a.rg_shift;
+			const uint32_t at = atomicAdd(&s_rg[r], 1u);
+			if (at < a.rg_cap)
+				a.rg_rec[(size_t)r * a.rg_cap + at] = ((unsigned long long)first << (64 - a.row_bits)) | c;
+		}
+		return;
+	}
+	/* one list: the workgroup's groups side by side, wherever the list's cursor stands */
+	uint32_t mine = 0, cmax = 0;
+	for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+		mine += s_count[i] ? 1u : 0u;
+		cmax = s_count[i] > cmax ? s_count[i] : cmax;
+	}
+	if (cmax >> (32u - a.row_bits))		/* (a COUNT that does not fit beside its row id in 32 bits: the ordering sort keeps 8-byte records) */
+		mdb_raise(a.status, 512u);
+	uint32_t total;
+	uint32_t at = mdb_block_excl_scan(mine, s_tmp, &total);
+	if (threadIdx.x == 0) {
+		uint32_t nb = 0xFFFFFFFFu;
+		if (total) {
+			nb = atomicAdd(a.rec_count, total);
+			if (nb + total > a.rec_cap) {
+				mdb_raise(a.status, 8u);	/* (sized for every key value of the window and every row: cannot happen) */
+				nb = 0xFFFFFFFFu;
+			} else {
+				atomicAdd(a.groups, total);
+			}
+		}
+		s_base = nb;
+	}
+	__syncthreads();
+	if (s_base == 0xFFFFFFFFu)
+		return;
+	at += s_base;
+	for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+		const uint32_t c = s_count[i];
+		if (c)
+			a.rec[at++] = ((unsigned long long)s_first[i] << (64 - a.row_bits)) | c;
+	}
+}
+
+static uint32_t rg_group_dbits(uint32_t kbits)
+{
+	/* a digit's two LDS arrays hold 2^(kbits - dbits) <= 2^14 key values; at least 1024 digits: pieces of at most 32 words on average,
+	 * several of them in flight per wave */
+	const uint32_t d = kbits > 13u + 10u ? kbits - 13u : 10u;
+	return d > RJ_MAX_DBITS ? RJ_MAX_DBITS : d;
+}
+
+/* 0 = done: out_first[g] / out_count[g] = the first row and the rows of group g, groups in first-row order; 1 = not served (the caller's
+ * other forms answer); < 0 = error.  NULL-free key column, keys inside [win_lo, win_lo + 2^kbits) - verified: a key outside -> 1 with
+ * *outside = true.  Synchronises. */
+int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
+			  uint64_t cap, uint64_t *out_groups, bool *outside)
+{
+	*outside = false;
+	/* MDB_GROUP_TILED=1 switches the form on: measured at 10^8 rows (profiles/r05/group_tiled.json) it is no faster than the partitioned
+	 * path - 6.25 x 10^6 groups of 16: tile sort 0.25 + leaf 0.37 ms against first level 0.36 + leaf 0.21; unique keys 2.18 against 2.06 ms;
+	 * 2.5 x 10^7 groups spread over 2^27 values 1.54 against 1.77 - the leaf's walk over 3052 tiles' pieces is a chain of dependent round
+	 * trips; the parity tests run both */
+	if (kbits < 13u || kbits > 14u + RJ_MAX_DBITS || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
+	    !(getenv("MDB_GROUP_TILED") && getenv("MDB_GROUP_TILED")[0] == '1'))
+		return 1;
+	const uint32_t dbits = rg_group_dbits(kbits), sbits = kbits - dbits, D = 1u << dbits;
+	if (sbits > 14u)
+		return 1;
+	uint32_t row_bits = 0;
+	int sb1 = 0, sb2 = 0;
+	if (!order_bits(n, &row_bits, &sb1, &sb2))
+		return 1;
+	const uint32_t ntiles = (uint32_t)rj_tiles(n);
+	const size_t ostride = (size_t)D + 8u;
+	const uint64_t values = (uint64_t)1 << kbits, most = (n < values ? n : values) + 1024;	/* groups: at most the rows, at most the window's key values */
+	uint32_t rg_n = 0;
+	const bool ranged = order_ranges_apply(n, row_bits, most < ((uint64_t)1 << 23) ? most : ((uint64_t)1 << 22), &rg_n) && values <= ((uint64_t)1 << 23) &&
+			    !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
+	size_t need = mdb_align_up((size_t)ntiles * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up(((size_t)ntiles + 64) * ostride * 2) + mdb_align_up(most * 8) +
+		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
+	if (ranged)
+		need += mdb_align_up((size_t)rg_n * ORDER_RANGE_CAP * 8) + mdb_align_up((size_t)rg_n * 4);
+	int rc = mdb_arena_begin(ctx, need);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 4 + 64);
+	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * ostride * 2);
+	if (!words || !offs)
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a tile-sorted column: %s", ctx->err);
+	rj_sort_args sa;
+	memset(&sa, 0, sizeof(sa));
+	sa.keys = keys;
+	sa.n = n;
+	sa.base = win_lo;
+	sa.kbits = kbits;
+	sa.dbits = dbits;
+	sa.words = words;
+	sa.offs = offs;
+	sa.status = ctx->d_status;
+	uint16_t *offT = NULL;
+	uint32_t tstride = 0;
+	rc = rj_sort_table<false>(ctx, sa, "group_tile_sort", &offT, &tstride);
+	if (rc)
+		return rc;
+	rg_group_args ga;
+	memset(&ga, 0, sizeof(ga));
+	ga.words = words;
+	ga.offT = offT;
+	ga.ntiles = ntiles;
+	ga.tstride = tstride;
+	ga.dbits = dbits;
+	ga.sbits = sbits;
+	ga.row_bits = row_bits;
+	ga.groups = ctx->d_status + 1;
+	ga.rec_count = ctx->d_status + 2;
+	ga.status = ctx->d_status;
+	const uint32_t threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
+	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : dbits == 11 ? 32 : 64;
+	uint64_t *h = ctx->h_pinned;
+	for (int attempt = ranged ? 0 : 1; attempt < 2; attempt++) {
+		if (attempt == 0) {
+			ga.rg_rec = (unsigned long long *)mdb_arena_take(ctx, (size_t)rg_n * ORDER_RANGE_CAP * 8);
+			ga.rg_cnt = (uint32_t *)mdb_arena_take(ctx, (size_t)rg_n * 4);
+			if (!ga.rg_rec || !ga.rg_cnt)
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a tile-sorted column: %s", ctx->err);
+			MDB_HIP(ctx, hipMemsetAsync(ga.rg_cnt, 0, (size_t)rg_n * 4, ctx->stream));
+			ga.rg_cap = ORDER_RANGE_CAP;
+			ga.rg_shift = ORDER_RANGE_BITS;
+			ga.rg_n = rg_n;
+		} else {
+			ga.rg_rec = NULL;
+			ga.rg_n = 0;
+			ga.rec = (unsigned long long *)mdb_arena_take(ctx, most * 8);
+			if (!ga.rec)
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a tile-sorted column: %s", ctx->err);
+			ga.rec_cap = (uint32_t)(most > 0xFFFFFFFFull ? 0xFFFFFFFFull : most);
+			if (ranged)	/* (behind a ranged attempt that overflowed - its flags and counters go; NOT before the first attempt: the tile
+					 * sort's "key outside the window" flag is in there) */
+				MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+		}
+		const size_t lds = ((size_t)8 << sbits) + (ga.rg_rec ? (size_t)rg_n * 4 : 0);
+#define RJ_LAUNCH_GROUP(L)                                                                                                                        \
+	do {                                                                                                                                      \
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_group_leaf<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+		MDB_LAUNCH_LDS(ctx, "group_tile_leaf", (k_rj_group_leaf<L>), D, threads, lds, ga);                                                   \
+	} while (0)
+		if (lpp == 8)
+			RJ_LAUNCH_GROUP(8);
+		else if (lpp == 16)
+			RJ_LAUNCH_GROUP(16);
+		else if (lpp == 32)
+			RJ_LAUNCH_GROUP(32);
+		else
+			RJ_LAUNCH_GROUP(64);
+#undef RJ_LAUNCH_GROUP
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t *hs = reinterpret_cast<const uint32_t *>(&h[1]);
+		const uint32_t status = hs[0], groups = hs[1], list_len = hs[2];
+		if (status & 128u) {
+			*outside = true;
+			return 1;
+		}
+		if (status & 8u)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a tile-sorted column: the record list overflowed");
+		if (status & 512u)
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));	/* (the ordering kernels raise flags of their own there) */
+		if (attempt == 0 && (status & 8192u))
+			continue;	/* more groups in a range of first rows than its region holds: the list and its sort */
+		const bool rec32 = attempt == 1 && !(status & 512u) && row_bits < 32u;
+		if (groups > cap)
+			return mdb_set_err(ctx, -MIDORIDB_ERROR, "GROUP BY: %u groups, room for %llu", groups, (unsigned long long)cap);
+		if (attempt == 0) {
+			rc = order_presorted(ctx, ga.rg_rec, ga.rg_cnt, rg_n, row_bits, out_first, out_count, NULL, NULL, false, 0, 0, 0);
+		} else {
+			rc = groups ? order_records(ctx, ga.rec, list_len, n, row_bits, sb1, sb2, out_first, out_count, NULL, NULL, NULL, false, rec32, 0, 0, 0, false, groups) : MIDORIDB_OK;
+		}
+		if (rc)
+			return rc;
+		*out_groups = groups;
+		return MIDORIDB_OK;
+	}
+	return 1;
+}
+

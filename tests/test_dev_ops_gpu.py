@@ -119,6 +119,39 @@ def test_group_count(dev, n, domain, null_frac):
     assert np.array_equal(_np(c), ec)
 
 
+@pytest.mark.parametrize("case", ["uniform_first_rows_2e22", "bunched_first_rows_2e20", "unique_2e23", "sparse_2e26", "hot_value", "far_from_zero"])
+def test_group_count_through_the_tile_sort(dev, case, monkeypatch):
+    """GROUP BY key + COUNT(*) of a NULL-free column through the tile sort (mdb_group_count_tiled, MDB_GROUP_TILED=1; off by default -
+    measured no faster than the partitioned path): first row and COUNT per key in first-row order, bit-exact against the oracle, for both
+    ways the groups leave the leaf kernel - the ordering kernel's row-id ranges (first rows spread evenly) and the record list + sort"""
+    rng = np.random.default_rng(len(case))
+    n = 2_300_000
+    if case == "uniform_first_rows_2e22":      # most keys once or twice: first rows everywhere -> ranged emit
+        k = rng.integers(0, 1 << 22, n)
+    elif case == "bunched_first_rows_2e20":    # ~2 rows per key on average over 2^20 values, every key's first row early
+        k = np.concatenate([rng.permutation(1 << 20), rng.integers(0, 1 << 20, n - (1 << 20))])
+    elif case == "unique_2e23":
+        k = rng.permutation(1 << 23)[:n]
+    elif case == "sparse_2e26":
+        k = rng.integers(0, 1 << 26, n)
+    elif case == "hot_value":                  # 300 000 consecutive rows of one value: pieces of whole tiles in one digit
+        k = rng.integers(0, 1 << 21, n)
+        k[900_000:1_200_000] = 777
+    else:
+        k = rng.integers(0, 1 << 21, n) + 10**13
+    k = k.astype(np.int64)
+    ef, ec = orc.group_count(k, None)
+    monkeypatch.setenv("MDB_GROUP_TILED", "1")
+    dev.prof_enable(True)
+    dev.prof_reset()
+    f, c = dev.group_count(dev.to_dev(k), None)
+    ran = set(dev.prof_read())
+    dev.prof_enable(False)
+    assert {"group_tile_sort", "group_tile_leaf"} <= ran, ran
+    assert ("order_leaf_sparse" in ran) == (case in ("uniform_first_rows_2e22", "hot_value", "far_from_zero")) or "order_leaf" in ran, ran
+    assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case
+
+
 def test_group_count_golden_case10(dev):
     # reference tests/engine/executor_select.c:318-346 : id = 1,1,3,3,4 -> (1,2)(3,2)(4,1)
     k = np.array([1, 1, 3, 3, 4], dtype=np.int64)
