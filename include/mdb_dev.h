@@ -92,6 +92,40 @@ int mdb_dev_last_join_filter(mdb_dev_ctx *ctx);
  * without a partner - the primary-key join of BASELINE configs[1]): out_l is then 0, 1, 2 ... and the left table's columns
  * of the joined stream are its columns as they stand - a caller need not gather them through out_l. */
 int mdb_dev_last_pairs_identity(mdb_dev_ctx *ctx);
+
+/* ---- catalog statistics instead of key samples (round 5).  A caller that KNOWS its key columns - query_execute() keeps the smallest /
+ * largest value of every column as rows are ingested (csrc/mdb_store.c) - hands that to the operators: between
+ *	mdb_dev_call_stats(ctx, keys_l, &stats_l, keys_r, &stats_r);	(keys_r / stats_r NULL for a one-column operator)
+ * and
+ *	mdb_dev_call_stats(ctx, NULL, NULL, NULL, NULL);
+ * every join / GROUP BY operator called with exactly these key-column pointers takes its key windows, its pruning and narrow-form
+ * decisions from the statistics: no sampling kernel, no host synchronisation for it, nothing remembered by address, and the first query
+ * over a column costs what the twentieth does.  The range may be a superset of the column's (rows deleted since, a filtered copy of the
+ * column): every key is still verified on the device.  min > max: the column holds no non-NULL value.  Raw callers that pass nothing
+ * keep the sampled decisions. */
+struct mdb_dev_col_stats {
+	int64_t min, max;	/* smallest / largest non-NULL value (a superset range is fine) */
+	uint64_t rows, nulls;	/* informational */
+};
+int mdb_dev_call_stats(mdb_dev_ctx *ctx, const void *keys_l, const struct mdb_dev_col_stats *l, const void *keys_r, const struct mdb_dev_col_stats *r);
+
+/* What the last join / GROUP BY operator of this context did (for tests, EXPLAIN-like output and byte accounting) */
+struct mdb_dev_plan_info {
+	uint32_t key_form;	/* 0: 64-bit hashes; 1: 32-bit hashes of a 2^32-wide window; 2: k-bit hashes of a compact window, direct-address leaves */
+	uint32_t key_bits;	/* key_form 2: the window holds 2^key_bits values */
+	uint32_t levels;	/* partition levels of the final attempt (1 or 2) */
+	uint32_t digits;	/* first-level digits: 512, or 4096 (one 4096-digit pass per table) */
+	uint32_t minmax_pruned;	/* the left table's first level dropped the rows outside the right table's key range */
+	uint32_t semijoin;	/* 0, or 1 + log2(values per bit of the right table's key bitmap) */
+	uint32_t any_order;	/* ran without row ids and ordering */
+	uint32_t ranged_order;	/* group records written straight into the ordering kernel's ranges */
+	uint32_t multi_one_pass;	/* several right tables counted in one pass */
+	uint32_t retries;	/* times the operator was redone (0: the first plan held) */
+	uint32_t samples;	/* key-sample kernels (each with a host synchronisation) the call launched */
+	uint32_t from_stats;	/* 1: windows and ranges came from mdb_dev_call_stats() */
+	uint32_t payload_form;	/* last mdb_dev_join_payload: 0 not served, 1 one level (cells in the leaf's LDS), 2 two levels, 3 row order (tile sort) */
+};
+int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory

@@ -107,6 +107,13 @@ struct mdb_dev_ctx : mdb_col_memo {
 	int unordered_no_counts;	/* set by mdb_dev_join_keys around its call of the any-order operator: group keys only, no COUNT column */
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	bool guess_remembered;		/* the last narrow-form decision came from the memo, not from a sample of the data */
+	/* mdb_dev_call_stats(): the caller's statistics of the key columns of the calls that follow */
+	bool cs_on, cs_has_r;
+	const void *cs_kl, *cs_kr;
+	struct mdb_dev_col_stats cs_l, cs_r;
+	/* mdb_dev_last_plan(): what the current / last operator did beyond the last_* words */
+	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form;
+	int pl_depth;			/* operators that call operators: the outermost one's entry clears the counters (mdb_plan_scope) */
 	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */
 	std::vector<std::pair<mdb_memo_key, mdb_col_memo>> memo_lru;	/* the other pairs' sets, most recently used last */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
@@ -133,6 +140,21 @@ struct mdb_dev_ctx : mdb_col_memo {
 };
 
 int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
+
+/* first statement of every public join / GROUP BY operator: what mdb_dev_last_plan() counts starts at the OUTERMOST operator's entry */
+struct mdb_plan_scope {
+	mdb_dev_ctx *c;
+	explicit mdb_plan_scope(mdb_dev_ctx *ctx) : c(ctx)
+	{
+		if (c && c->pl_depth++ == 0)
+			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = 0;
+	}
+	~mdb_plan_scope()
+	{
+		if (c)
+			c->pl_depth--;
+	}
+};
 
 /* make the live memo the one of the key-column pair (kl, nl, kr, nr) - kr = NULL for a one-column operator (GROUP BY): the set
  * of the pair used before is put aside, the pair's own set (or an empty one) comes back (mdb_dev_core.hip) */

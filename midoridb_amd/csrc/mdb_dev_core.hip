@@ -188,6 +188,50 @@ extern "C" int mdb_dev_last_join_filter(mdb_dev_ctx *ctx)
 	return ctx->last_semijoin;
 }
 
+extern "C" int mdb_dev_call_stats(mdb_dev_ctx *ctx, const void *keys_l, const struct mdb_dev_col_stats *l, const void *keys_r, const struct mdb_dev_col_stats *r)
+{
+	if (!ctx)
+		return -MIDORIDB_ERROR;
+	ctx->cs_on = false;
+	ctx->cs_has_r = false;
+	ctx->cs_kl = ctx->cs_kr = NULL;
+	if (!keys_l || !l || (getenv("MDB_CALL_STATS") && getenv("MDB_CALL_STATS")[0] == '0'))	/* (the knob: A/B runs against the sampled decisions) */
+		return MIDORIDB_OK;
+	if ((keys_r != NULL) != (r != NULL))
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "mdb_dev_call_stats: a right key column and its statistics go together");
+	ctx->cs_on = true;
+	ctx->cs_kl = keys_l;
+	ctx->cs_l = *l;
+	if (keys_r) {
+		ctx->cs_has_r = true;
+		ctx->cs_kr = keys_r;
+		ctx->cs_r = *r;
+	}
+	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out)
+{
+	if (!ctx || !out)
+		return -MIDORIDB_ERROR;
+	memset(out, 0, sizeof(*out));
+	const int f = ctx->last_semijoin;
+	out->key_form = (uint32_t)ctx->last_narrow;
+	out->key_bits = ctx->last_narrow == 2 ? ctx->pl_key_bits : 0u;
+	out->levels = (f & 0x1200) ? 1u : 2u;
+	out->digits = (f & 0x1000) ? 4096u : 512u;
+	out->minmax_pruned = (f & 0x100) ? 1u : 0u;
+	out->semijoin = (uint32_t)(f & 0xFF);
+	out->any_order = (f & 0x800) ? 1u : 0u;
+	out->ranged_order = (f & 0x2000) ? 1u : 0u;
+	out->multi_one_pass = (f & 0x400) ? 1u : 0u;
+	out->retries = ctx->pl_retries;
+	out->samples = ctx->pl_samples;
+	out->from_stats = ctx->pl_from_stats;
+	out->payload_form = ctx->pl_payload_form;
+	return MIDORIDB_OK;
+}
+
 
 extern "C" int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode)
 {

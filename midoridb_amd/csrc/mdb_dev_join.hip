@@ -2117,6 +2117,40 @@ int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 {
 	if (!keys_r)
 		n_r = 0;
+	if (ctx->cs_on && ctx->cs_kl == keys_l && (!keys_r || (ctx->cs_has_r && ctx->cs_kr == keys_r)) && !keys32) {
+		/* the caller's statistics of exactly these columns (mdb_dev_call_stats): what a sample would estimate, known - no kernel, no
+		 * synchronisation, nothing remembered by address */
+		const struct mdb_dev_col_stats &l = ctx->cs_l, &r = ctx->cs_r;
+		const bool has_l = n_l && l.min <= l.max, has_r = keys_r && n_r && r.min <= r.max;
+		*lo = INT64_MAX;
+		*hi = INT64_MIN;
+		if (has_l) {
+			*lo = l.min;
+			*hi = l.max;
+		}
+		if (has_r) {
+			*lo = r.min < *lo ? r.min : *lo;
+			*hi = r.max > *hi ? r.max : *hi;
+		}
+		ctx->sr_span_l = has_l ? (uint64_t)l.max - (uint64_t)l.min + 1 : 0;
+		ctx->sr_span_r = has_r ? (uint64_t)r.max - (uint64_t)r.min + 1 : 0;
+		if (has_l && !ctx->sr_span_l)
+			ctx->sr_span_l = ~0ull;		/* (the whole int64 range) */
+		if (has_r && !ctx->sr_span_r)
+			ctx->sr_span_r = ~0ull;
+		ctx->sr_rlo = has_r ? r.min : INT64_MAX;
+		ctx->sr_rhi = has_r ? r.max : INT64_MIN;
+		ctx->sr_kl = keys_l;
+		ctx->sr_nl = n_l;
+		ctx->sr_kr = keys_r;
+		ctx->sr_nr = n_r;
+		ctx->sr_lo = *lo;
+		ctx->sr_hi = *hi;
+		ctx->sr_valid = 1;
+		ctx->sr_uses = 0;
+		ctx->pl_from_stats = 1;
+		return MIDORIDB_OK;
+	}
 	if (!fresh && ctx->sr_valid && ctx->sr_kl == keys_l && ctx->sr_nl == n_l && ctx->sr_kr == keys_r && ctx->sr_nr == n_r &&
 	    ++ctx->sr_uses < GC_HINT_USES) {
 		*lo = ctx->sr_lo;
@@ -2130,6 +2164,7 @@ int gc_sample_range(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 		h[i + 1] = INT64_MIN;
 	}
 	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 48, hipMemcpyHostToDevice, ctx->stream));
+	ctx->pl_samples++;
 	if (keys32) {
 		MDB_LAUNCH(ctx, "key_sample", k_key_sample<int32_t>, GC_NARROW_SAMPLE / 256, 256, reinterpret_cast<const int32_t *>(keys_l), null_l, n_l,
 			   reinterpret_cast<const int32_t *>(keys_r), null_r, n_r, mm);
@@ -2237,7 +2272,10 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 		return MIDORIDB_OK;
 	bool fresh = false;
 	ctx->guess_remembered = false;
-	if (ctx->nh_distrust > 0) {
+	const bool by_stats = ctx->cs_on && ctx->cs_kl == keys_l && (!keys_r || (ctx->cs_has_r && ctx->cs_kr == keys_r)) && !keys32;
+	if (by_stats) {
+		/* (decided afresh from the caller's statistics every time: it costs nothing and depends on nothing remembered) */
+	} else if (ctx->nh_distrust > 0) {
 		ctx->nh_distrust--;
 		fresh = true;
 	} else if (ctx->nh_result >= 0 && ctx->nh_kl == keys_l && ctx->nh_nl == n_l && ctx->nh_kr == keys_r && ctx->nh_nr == (keys_r ? n_r : 0) &&
@@ -2398,6 +2436,8 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		win.fast1 = false;
 	}
 	for (int attempt = 0; attempt < 6; attempt++) {
+		ctx->pl_retries = (uint32_t)attempt;
+		ctx->pl_key_bits = narrow ? win.kbits : 0u;
 		rc = group_count_run(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, has_r, null_group, fast, records, no_build_r, narrow,
 				     base, win, keys32, out_key, out_count, out_first, cap, out_groups, out_joined);
 		if ((rc == GC_RETRY_PLAIN || rc == GC_RETRY_WIDE) && ctx->guess_remembered && ctx->narrow_mode == 1 && !keys32) {
@@ -2690,6 +2730,7 @@ again: {
 extern "C" int mdb_dev_group_count_keys(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_key,
 					int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
+	mdb_plan_scope plan_scope(ctx);
 	if (!ctx || !out_groups || !out_key || !out_count)
 		return -MIDORIDB_ERROR;
 	*out_groups = 0;
@@ -2749,6 +2790,7 @@ extern "C" int mdb_dev_join_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l,
 					int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 					uint64_t *out_groups, uint64_t *out_joined)
 {
+	mdb_plan_scope plan_scope(ctx);
 	*out_groups = 0;
 	if (out_joined)
 		*out_joined = 0;
@@ -2889,6 +2931,7 @@ extern "C" int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *k
 					      int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 					      uint64_t *out_joined)
 {
+	mdb_plan_scope plan_scope(ctx);
 	if (!out_groups || n_right < 1 || n_right > 1 + GC_MAX_EXTRA || !keys_r || !n_r)
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "join_group_count_multi: one to %d right tables", 1 + GC_MAX_EXTRA);
 	*out_groups = 0;
@@ -2999,6 +3042,7 @@ extern "C" int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *k
 extern "C" int mdb_dev_join_group_count_begin(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l,
 					      uint64_t n_r_max)
 {
+	mdb_plan_scope plan_scope(ctx);
 	return gc_split_begin(ctx, keys_l, null_l, n_l, n_r_max, false);
 }
 
@@ -3006,6 +3050,7 @@ extern "C" int mdb_dev_join_group_count_finish(mdb_dev_ctx *ctx, const int64_t *
 					       uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first,
 					       uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
 {
+	mdb_plan_scope plan_scope(ctx);
 	(void)flags;
 	return gc_split_finish(ctx, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined, false);
 }
@@ -3016,6 +3061,7 @@ extern "C" int mdb_dev_join_group_count_i32(mdb_dev_ctx *ctx, const int32_t *key
 					    uint32_t flags, int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 					    uint64_t *out_groups, uint64_t *out_joined)
 {
+	mdb_plan_scope plan_scope(ctx);
 	(void)flags;
 	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
 	return group_count_common(ctx, reinterpret_cast<const int64_t *>(keys_l), NULL, n_l, reinterpret_cast<const int64_t *>(keys_r), NULL,
@@ -3024,6 +3070,7 @@ extern "C" int mdb_dev_join_group_count_i32(mdb_dev_ctx *ctx, const int32_t *key
 
 extern "C" int mdb_dev_join_group_count_begin_i32(mdb_dev_ctx *ctx, const int32_t *keys_l, uint64_t n_l, uint64_t n_r_max)
 {
+	mdb_plan_scope plan_scope(ctx);
 	return gc_split_begin(ctx, reinterpret_cast<const int64_t *>(keys_l), NULL, n_l, n_r_max, true);
 }
 
@@ -3031,6 +3078,7 @@ extern "C" int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32
 						   int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap,
 						   uint64_t *out_groups, uint64_t *out_joined)
 {
+	mdb_plan_scope plan_scope(ctx);
 	(void)flags;
 	return gc_split_finish(ctx, reinterpret_cast<const int64_t *>(keys_r), NULL, n_r, out_key, out_count, out_first, cap, out_groups,
 			       out_joined, true);
@@ -3039,6 +3087,7 @@ extern "C" int mdb_dev_join_group_count_finish_i32(mdb_dev_ctx *ctx, const int32
 extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, uint32_t flags,
 				   uint32_t *out_first, int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
+	mdb_plan_scope plan_scope(ctx);
 	(void)flags;
 	*out_groups = 0;
 	mdb_memo_switch(ctx, keys, n, NULL, 0);

@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_leaf_pairs_cell2(pl_args a, uint
 extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				    const uint64_t *null_r, uint64_t n_r, const void *const *pay_in, int npay, void *const *out)
 {
+	mdb_plan_scope plan_scope(ctx);
 	if (!ctx || !keys_l || !keys_r || !pay_in || !out || npay < 1 || npay > 2)
 		return -MIDORIDB_ERROR;
 	for (int c = 0; c < npay; c++)
@@ -1201,8 +1202,10 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		if (getenv("MDB_DEBUG_PAYLOAD"))
 			fprintf(stderr, "join_payload (row order): k %u status %u J %llu of %llu left rows\n", kbits, status, (unsigned long long)J,
 				(unsigned long long)n_l);
-		if (status == 0 && J == n_l)
+		if (status == 0 && J == n_l) {
+			ctx->pl_payload_form = 3;
 			return MIDORIDB_OK;
+		}
 		if ((status & 128u) && remembered && attempt == 0) {
 			ctx->nh_result = -1;
 			ctx->sr_valid = 0;
@@ -1280,8 +1283,10 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		if (getenv("MDB_DEBUG_PAYLOAD"))
 			fprintf(stderr, "join_payload (two levels): k %u b2 %d rem %u status %u J %llu of %llu left rows\n", kbits, b2, rem, status, (unsigned long long)J,
 				(unsigned long long)n_l);
-		if (status == 0 && J == n_l)
+		if (status == 0 && J == n_l) {
+			ctx->pl_payload_form = 2;
 			return MIDORIDB_OK;
+		}
 		if ((status & 128u) && remembered && attempt == 0) {
 			ctx->nh_result = -1;
 			ctx->sr_valid = 0;
@@ -1362,8 +1367,10 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const uint32_t status = (uint32_t)h[1];
 	const uint64_t J = h[2];
-	if (status == 0 && J == n_l)
+	if (status == 0 && J == n_l) {
+		ctx->pl_payload_form = 1;
 		return MIDORIDB_OK;
+	}
 	if ((status & 128u) && remembered && attempt == 0) {
 		/* a REMEMBERED window proved wrong: the buffers hold other data than when it was learned (a caller's allocator handed the
 		 * same addresses out again) - forget, look at the data itself, once more */
@@ -1621,6 +1628,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 				  const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r, uint32_t **out_l, uint32_t **out_r,
 				  uint64_t *out_count)
 {
+	mdb_plan_scope plan_scope(ctx);
 	*out_l = *out_r = NULL;
 	*out_count = 0;
 	ctx->last_pairs_identity = 0;
@@ -1853,6 +1861,7 @@ int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t
 extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 					 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows, int *served)
 {
+	mdb_plan_scope plan_scope(ctx);
 	if (!ctx || !out_key || !out_rows || !served)
 		return -MIDORIDB_ERROR;
 	*out_key = NULL;
@@ -1906,6 +1915,7 @@ extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l
 extern "C" int mdb_dev_join_keys(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 				 const uint64_t *null_r, uint64_t n_r, int64_t **out_key, uint64_t *out_rows)
 {
+	mdb_plan_scope plan_scope(ctx);
 	if (!ctx || !out_key || !out_rows)
 		return -MIDORIDB_ERROR;
 	*out_key = NULL;

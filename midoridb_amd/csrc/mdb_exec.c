@@ -289,6 +289,35 @@ int fused_operand(struct exec *x, int t, const struct mdb_expr *key, const struc
  * Table t is then read through a SHADOW (like a table that arrived over the wire in sharded mode): its key column is the stream's own
  * key column, its payload columns are the carried cells, its row-id vector the identity.  0 = done, 1 = not such a join (nothing
  * changed: the pairs path answers), < 0 = error. */
+/* The catalog's statistics of the key columns of the operator call that follows (mdb_dev_call_stats, include/mdb_dev.h): fl / fr = the
+ * fields the key columns pl / pr come from - the columns themselves or filtered streams of them (a superset range is fine).  Nothing is
+ * handed over for column types without a range (DOUBLE, VARCHAR), for shadow tables of the sharded mode, or when a range cannot be had:
+ * the operator then looks at the data itself.  op_stats_end() after the call. */
+void op_stats_begin(struct exec *x, const struct mdb_expr *fl, const void *pl, const struct mdb_expr *fr, const void *pr)
+{
+	struct mdb_dev_col_stats st[2];
+	const struct mdb_expr *f[2] = { fl, fr };
+	memset(st, 0, sizeof(st));
+	if (x->cat->dist || !fl || !pl || (fr && !pr))
+		return;
+	for (int i = 0; i < (fr ? 2 : 1); i++) {
+		if (f[i]->kind != MDB_EX_FIELD || f[i]->tbl_idx < 0 || x->orig_tab[f[i]->tbl_idx])
+			return;
+		struct mdb_table *tb = x->s->tabs[f[i]->tbl_idx].t;
+		struct mdb_column *col = &tb->cols[f[i]->col_idx];
+		if (mdb_col_range(x->cat, tb, col, &st[i].min, &st[i].max) != MIDORIDB_OK)
+			return;
+		st[i].rows = tb->device_only ? tb->dev_rows : tb->nrows;
+		st[i].nulls = col->null_count;
+	}
+	(void)mdb_dev_call_stats(x->dev, pl, &st[0], fr ? pr : NULL, fr ? &st[1] : NULL);
+}
+
+void op_stats_end(struct exec *x)
+{
+	(void)mdb_dev_call_stats(x->dev, NULL, NULL, NULL, NULL);
+}
+
 int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl, const void *vr,
 			     const uint64_t *nr, uint64_t r_rows)
 {
@@ -436,8 +465,12 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 			x->same_as_tbl[t] = kl->tbl_idx;
 			x->same_as_col[t] = kl->col_idx;
 		}
+		if (kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE)
+			op_stats_begin(x, kl, vl, kr, vr);	/* (until the join is done: op_stats_end below / at the early returns) */
 		if (x->n && r_rows && !x->cat->dist && !rsel && kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE) {
 			const int prc = join_with_payload(x, t, kr, vl, nl, vr, nr, r_rows);
+			if (prc <= 0)
+				op_stats_end(x);
 			if (prc < 0)
 				return prc;
 			if (prc == 0) {
@@ -450,13 +483,16 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 			}
 		}
 		if (x->n && r_rows) {
-			if (mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J))
+			const int jrc = mdb_dev_join_pairs(x->dev, vl, nl, x->n, vr, nr, r_rows, &pl, &pr, &J);
+			op_stats_end(x);
+			if (jrc)
 				return dev_fail(x, "hash join");
 			if (pl && track(x, pl))
 				return -MIDORIDB_NOMEM;
 			if (pr && track(x, pr))
 				return -MIDORIDB_NOMEM;
 		}
+		op_stats_end(x);
 	} else {
 		/* no equi-join key: FROM A, B (ON 1=1) or a general ON -> all pairs, then the ON predicate */
 		const uint64_t total = x->n * r_rows;
@@ -765,9 +801,15 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	if (keys_only && !cat->groups_any_order) {
 		const struct mdb_table *tl = s->tabs[kj[0]->tbl_idx].t, *tr = s->tabs[kj[1]->tbl_idx].t;
 		int served = 0;
-		if (tl->nrows + tr->nrows >= (1u << 21) &&
-		    mdb_dev_join_keys_ordered(x.dev, tl->cols[kj[0]->col_idx].d_data, tl->cols[kj[0]->col_idx].d_nullbits, tl->nrows, tr->cols[kj[1]->col_idx].d_data,
-					      tr->cols[kj[1]->col_idx].d_nullbits, tr->nrows, &keys_ordered, &keys_ordered_rows, &served)) {
+		int krc = 0;
+		if (tl->nrows + tr->nrows >= (1u << 21)) {
+			op_stats_begin(&x, kj[0], tl->cols[kj[0]->col_idx].d_data, kj[1], tr->cols[kj[1]->col_idx].d_data);
+			krc = mdb_dev_join_keys_ordered(x.dev, tl->cols[kj[0]->col_idx].d_data, tl->cols[kj[0]->col_idx].d_nullbits, tl->nrows,
+							 tr->cols[kj[1]->col_idx].d_data, tr->cols[kj[1]->col_idx].d_nullbits, tr->nrows, &keys_ordered,
+							 &keys_ordered_rows, &served);
+			op_stats_end(&x);
+		}
+		if (krc) {
 			rc = dev_fail(&x, "join of two key columns");
 			goto out;
 		}
@@ -882,12 +924,18 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					goto out;
 				}
 				multi_done = true;
-			} else if (mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows,
-							    /* (a bare COUNT(*) has no group order to keep; nor has a GROUP BY when the database says so) */
-							    (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
-							    x.d_count, NULL, cap, &G, &J)) {
-				rc = dev_fail(&x, "join + group count");
-				goto out;
+			} else {
+				if (fkeys[0]->type != MDB_CT_DOUBLE && !text_keys)
+					op_stats_begin(&x, fkeys[0], lv, fkeys[1], rv);
+				const int frc = mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows,
+									  /* (a bare COUNT(*) has no group order to keep; nor has a GROUP BY when the database says so) */
+									  (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
+									  x.d_count, NULL, cap, &G, &J);
+				op_stats_end(&x);
+				if (frc) {
+					rc = dev_fail(&x, "join + group count");
+					goto out;
+				}
 			}
 		}
 		for (int t = 2; t < s->ntabs && (G || cat->dist) && !multi_done; t++) {
@@ -958,10 +1006,15 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		const struct mdb_column *cl = &s->tabs[kj[0]->tbl_idx].t->cols[kj[0]->col_idx], *cr = &s->tabs[kj[1]->tbl_idx].t->cols[kj[1]->col_idx];
 		int64_t *jk = keys_ordered;	/* (the reference's order: answered above) */
 		uint64_t J = keys_ordered_rows;
-		if (cat->groups_any_order && mdb_dev_join_keys(x.dev, cl->d_data, cl->d_nullbits, s->tabs[kj[0]->tbl_idx].t->nrows, cr->d_data, cr->d_nullbits,
-							      s->tabs[kj[1]->tbl_idx].t->nrows, &jk, &J)) {
-			rc = dev_fail(&x, "join of two key columns");
-			goto out;
+		if (cat->groups_any_order) {
+			op_stats_begin(&x, kj[0], cl->d_data, kj[1], cr->d_data);
+			const int krc2 = mdb_dev_join_keys(x.dev, cl->d_data, cl->d_nullbits, s->tabs[kj[0]->tbl_idx].t->nrows, cr->d_data, cr->d_nullbits,
+							   s->tabs[kj[1]->tbl_idx].t->nrows, &jk, &J);
+			op_stats_end(&x);
+			if (krc2) {
+				rc = dev_fail(&x, "join of two key columns");
+				goto out;
+			}
 		}
 		if (jk && jk != keys_ordered && track(&x, jk)) {
 			rc = -MIDORIDB_NOMEM;
@@ -1140,7 +1193,9 @@ exchange_rows:
 					rc = dev_fail(&x, "allocating group outputs");
 					goto out;
 				}
+				op_stats_begin(&x, s->group[0], kv, NULL, NULL);
 				const int krc = mdb_dev_group_count_keys(x.dev, kv, NULL, x.n, gk, gc, x.n, &Gk);
+				op_stats_end(&x);
 				if (krc < 0) {
 					rc = dev_fail(&x, "group count (any order)");
 					goto out;
@@ -1159,7 +1214,11 @@ exchange_rows:
 				rc = dev_fail(&x, "allocating group outputs");
 				goto out;
 			}
-			if (x.n && mdb_dev_group_count(x.dev, kv, kn, x.n, MDB_ORDER_FIRST, first, x.d_count, x.n, &G)) {
+			if (s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE)
+				op_stats_begin(&x, s->group[0], kv, NULL, NULL);
+			const int grc = x.n ? mdb_dev_group_count(x.dev, kv, kn, x.n, MDB_ORDER_FIRST, first, x.d_count, x.n, &G) : 0;
+			op_stats_end(&x);
+			if (grc) {
 				rc = dev_fail(&x, "group count");
 				goto out;
 			}

@@ -121,4 +121,8 @@ int dml_check_values(const struct mdb_expr *e, char *err, size_t errlen);
 int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct exec *x, struct mdb_select *s, struct mdb_from_tab *tab, bool complement, struct mdb_table **out_t, const uint32_t **sel, uint64_t *m, char *err, size_t errlen);
 
 #pragma GCC visibility pop
+/* the catalog's statistics of an operator call's key columns (mdb_exec.c) */
+void op_stats_begin(struct exec *x, const struct mdb_expr *fl, const void *pl, const struct mdb_expr *fr, const void *pr);
+void op_stats_end(struct exec *x);
+
 #endif

@@ -355,7 +355,7 @@ int shard_promise_ranges(struct exec *x, const struct mdb_expr *fl, const struct
 			cols[i]->st_lo = lo;
 			cols[i]->st_hi = hi;
 			cols[i]->st_generation = tabs[i]->generation + 1;
-		}
+		}	/* (any column type: what travels are the 8-byte cells) */
 		const bool none = cols[i]->st_lo > cols[i]->st_hi;
 		/* (as offsets from the smallest int64: every rank's minimum of the unsigned images is the global minimum) */
 		mine[2 * i] = none ? ~0ull : (uint64_t)cols[i]->st_lo ^ 0x8000000000000000ull;

@@ -62,7 +62,8 @@ struct mdb_column {
 	void *d_data;
 	uint64_t *d_nullbits;		/* NULL when null_count == 0 */
 	/* catalog statistics of the device mirror: smallest / largest non-NULL value (st_lo > st_hi: none) as of table generation
-	 * st_generation + 1 (0 = never computed) - what sharded joins promise the exchange instead of measuring per query */
+	 * st_generation - 1 (0 = never computed; mdb_col_range) - what sharded joins promise the exchange instead of measuring per query and
+	 * what every join / GROUP BY operator is handed instead of sampling its key columns (mdb_dev_call_stats) */
 	uint64_t st_generation;
 	int64_t st_lo, st_hi;
 };
@@ -135,6 +136,8 @@ static inline bool mdb_type_is_int64(int type) { return type != MDB_CT_DOUBLE; }
 bool mdb_parse_time(const char *quoted, int type, int64_t *out);
 int mdb_table_reserve(struct mdb_table *t, uint64_t rows);
 int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen);
+bool mdb_col_has_range(const struct mdb_column *col);
+int mdb_col_range(struct mdb_catalog *cat, struct mdb_table *t, struct mdb_column *col, int64_t *lo, int64_t *hi);	/* 0 ok, 1 no range for this type */
 int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen);
 
 /* ------------------------------------------------------------------ statement plans */

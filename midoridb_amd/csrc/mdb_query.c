@@ -475,6 +475,10 @@ int mdb_table_generate_shard(struct database *db, const char *table, uint64_t n,
 	t->dev_rows = n;
 	t->dev_cap = n ? n : 1;
 	t->dev_generation = t->generation;
+	for (int c = 0; c < t->ncols; c++) {	/* catalog statistics, as an ingest would leave them (mdb_table_sync_device) */
+		int64_t lo, hi;
+		(void)mdb_col_range(cat, t, &t->cols[c], &lo, &hi);
+	}
 	return MIDORIDB_OK;
 }
 

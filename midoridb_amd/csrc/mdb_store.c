@@ -335,8 +335,62 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 			return rc;
 		}
 	}
+	/* catalog statistics (smallest / largest non-NULL value of every integer-like column), kept with the mirror: rows that were
+	 * appended widen what was known (one pass over the uploaded tail), anything else is looked at whole.  The operators take their key
+	 * windows from these instead of sampling the columns on every first query (mdb_dev_call_stats, include/mdb_dev.h) */
+	for (int c = 0; c < t->ncols && t->nrows; c++) {
+		struct mdb_column *col = &t->cols[c];
+		if (!mdb_col_has_range(col) || !col->d_data)
+			continue;
+		const bool widen = append && col->st_generation == t->dev_generation + 1 && t->nrows > from;
+		const uint64_t r0 = widen ? from : 0;
+		int64_t lo = 0, hi = -1;
+		/* (a NULL bitmap is read by row index: the tail's range is taken over whole words from the word that holds its first row) */
+		const uint64_t a0 = col->d_nullbits ? (r0 & ~(uint64_t)63) : r0;
+		if (mdb_dev_key_range(cat->dev, (const int64_t *)col->d_data + a0, col->d_nullbits ? col->d_nullbits + a0 / 64 : NULL, t->nrows - a0, &lo, &hi)) {
+			col->st_generation = 0;		/* (not fatal: looked at again when somebody asks) */
+			continue;
+		}
+		if (widen && col->st_lo <= col->st_hi) {
+			lo = lo <= hi && lo < col->st_lo ? lo : col->st_lo;
+			hi = hi > col->st_hi ? hi : col->st_hi;
+			if (lo > hi) {
+				lo = col->st_lo;
+				hi = col->st_hi;
+			}
+		}
+		col->st_lo = lo;
+		col->st_hi = hi;
+		col->st_generation = t->generation + 1;
+	}
 	t->dev_generation = t->generation;
 	t->dev_rows = t->nrows;
+	return MIDORIDB_OK;
+}
+
+bool mdb_col_has_range(const struct mdb_column *col)
+{
+	return col->type == MDB_CT_INTEGER || col->type == MDB_CT_DATE || col->type == MDB_CT_DATETIME || col->type == MDB_CT_TINYINT;
+}
+
+/* The column's smallest / largest non-NULL value over the device mirror as it stands (lo > hi: none) - kept current by
+ * mdb_table_sync_device() for tables that only grow, computed here (one pass on the device) after a DELETE / UPDATE or for a table that
+ * was generated on the device.  A SUPERSET of the live values is what the callers need and what a filtered stream of the column gets. */
+int mdb_col_range(struct mdb_catalog *cat, struct mdb_table *t, struct mdb_column *col, int64_t *lo, int64_t *hi)
+{
+	if (!mdb_col_has_range(col))
+		return 1;
+	const uint64_t rows = t->device_only ? t->dev_rows : t->nrows;
+	if (col->st_generation != t->generation + 1) {
+		int64_t l = 0, h = -1;
+		if (rows && (!col->d_data || mdb_dev_key_range(cat->dev, col->d_data, col->d_nullbits, rows, &l, &h)))
+			return -MIDORIDB_INTERNAL;
+		col->st_lo = l;
+		col->st_hi = h;
+		col->st_generation = t->generation + 1;
+	}
+	*lo = col->st_lo;
+	*hi = col->st_hi;
 	return MIDORIDB_OK;
 }
 

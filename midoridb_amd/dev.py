@@ -45,6 +45,26 @@ class ProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", c_uint32), ("total_ms", c_double)]
 
 
+class ColStats(ctypes.Structure):
+    """struct mdb_dev_col_stats: what a catalog knows about a key column (include/mdb_dev.h)"""
+    _fields_ = [("min", c_int64), ("max", c_int64), ("rows", c_uint64), ("nulls", c_uint64)]
+
+
+class PlanInfo(ctypes.Structure):
+    """struct mdb_dev_plan_info: what the last join / GROUP BY operator did"""
+    _fields_ = [(k, ctypes.c_uint32) for k in ("key_form", "key_bits", "levels", "digits", "minmax_pruned", "semijoin", "any_order", "ranged_order",
+                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form")]
+
+
+def last_plan_of(lib, handle):
+    """mdb_dev_last_plan of a raw context handle (a DeviceCtx's, or a database's: DB.device_handle()) -> dict"""
+    _bind(lib)
+    info = PlanInfo()
+    if lib.mdb_dev_last_plan(handle, byref(info)) != 0:
+        raise RuntimeError("mdb_dev_last_plan failed")
+    return {k: int(getattr(info, k)) for k, _ in PlanInfo._fields_}
+
+
 def _bind(lib):
     if getattr(lib, "_mdb_dev_bound", False):
         return
@@ -61,6 +81,8 @@ def _bind(lib):
         "mdb_dev_set_narrow_keys": ([P, c_int], c_int),
         "mdb_dev_last_join_narrow": ([P], c_int),
         "mdb_dev_last_join_filter": ([P], c_int),
+        "mdb_dev_call_stats": ([P, P, POINTER(ColStats), P, POINTER(ColStats)], c_int),
+        "mdb_dev_last_plan": ([P, POINTER(PlanInfo)], c_int),
         "mdb_dev_last_pairs_identity": ([P], c_int),
         "mdb_dev_arena_bytes": ([P], c_size_t),
         "mdb_dev_alloc": ([P, c_size_t, POINTER(P)], c_int),
@@ -121,7 +143,7 @@ def _bind(lib):
 
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
-    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
@@ -228,6 +250,18 @@ class DeviceCtx:
 
     def set_overlap(self, on=True):
         self._chk(self.lib.mdb_dev_set_overlap(self.h, 1 if on else 0), "set_overlap")
+
+    def last_plan(self):
+        """what the last join / GROUP BY operator did (mdb_dev_last_plan) -> dict"""
+        return last_plan_of(self.lib, self.h)
+
+    def call_stats(self, keys_l=None, stats_l=None, keys_r=None, stats_r=None):
+        """catalog statistics (min, max) of the key columns of the operator calls that follow - call_stats() with nothing ends it"""
+        def st(col, v):
+            return None if v is None else ColStats(int(v[0]), int(v[1]), col.numel(), 0)
+        sl, sr = st(keys_l, stats_l), st(keys_r, stats_r)
+        self._chk(self.lib.mdb_dev_call_stats(self.h, _ptr(keys_l) if sl is not None else None, byref(sl) if sl is not None else None,
+                                              _ptr(keys_r) if sr is not None else None, byref(sr) if sr is not None else None), "call_stats")
 
     def last_join_narrow(self):
         return bool(self.lib.mdb_dev_last_join_narrow(self.h))

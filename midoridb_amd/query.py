@@ -160,6 +160,11 @@ class DB:
             raise QueryError("no usable HIP device")
         return c_void_p(h)
 
+    def last_plan(self):
+        """what the last join / GROUP BY operator of this database's device context did (mdb_dev_last_plan) -> dict"""
+        from .dev import last_plan_of
+        return last_plan_of(self.lib, self.device_handle())
+
     def set_dist(self, dist_handle):
         """the database takes ownership of an mdb_dist* built for device_handle()"""
         if self.lib.mdb_database_set_dist(ctypes.byref(self.db), dist_handle) != 0:

@@ -2439,3 +2439,62 @@ def test_join_keys_in_the_references_order_random_shapes(dev, seed):
         assert got is None
     elif got is not None:
         assert np.array_equal(_np(got), kl[el]), (seed, bits, mult)
+
+
+# ---- round 5: catalog statistics instead of key samples (mdb_dev_call_stats), and what an operator did (mdb_dev_last_plan)
+@pytest.mark.parametrize("variant", ["D", "U", "S"])
+def test_call_stats_replace_the_key_sample_and_the_plan_says_so(dev, variant):
+    """the same join + GROUP BY with and without the caller's statistics: identical results; with them no sampling kernel runs, nothing
+    is retried, and the plan is the one the sampled call arrives at"""
+    n = 3_000_000
+    a = dev.gen_keys(n, 0, n, 42, 0)
+    b = dev.gen_keys(n, 0, n, 43, 0 if variant == "U" else n // 16)
+    if variant == "S":
+        b.mul_(16)
+    k0, c0, f0, j0 = dev.join_group_count(a, None, b, None)
+    sampled = dev.last_plan()
+    assert sampled["from_stats"] == 0      # (it may have been retried: a verdict remembered by address for a buffer that now holds other data)
+    a2, b2 = a.clone(), b.clone()       # columns the context has never seen: nothing remembered by address
+    dev.call_stats(a2, dev.key_range(a2), b2, dev.key_range(b2))
+    try:
+        k1, c1, f1, j1 = dev.join_group_count(a2, None, b2, None)
+        plan = dev.last_plan()
+    finally:
+        dev.call_stats()
+    assert plan["from_stats"] == 1 and plan["samples"] == 0 and plan["retries"] == 0, plan
+    if sampled["retries"] == 0:
+        assert {k: plan[k] for k in ("key_form", "levels", "digits", "minmax_pruned")} == {k: sampled[k] for k in ("key_form", "levels", "digits", "minmax_pruned")}, (plan, sampled)
+    assert j1 == j0 and torch.equal(k1, k0) and torch.equal(c1, c0) and torch.equal(f1, f0)
+    # the statistics gone: a fresh pair of columns is sampled again
+    a3, b3 = a.clone(), b.clone()
+    dev.join_group_count(a3, None, b3, None)
+    assert dev.last_plan()["from_stats"] == 0      # (sampled - or remembered by address, when the allocator handed out a buffer seen before)
+
+
+def test_call_stats_that_do_not_hold_cost_a_retry_never_a_result(dev):
+    """statistics are a promise the device checks: a range narrower than the column's sends the operator to the forms that need none -
+    the result is the oracle's"""
+    rng = np.random.default_rng(9)
+    n = 1_500_000
+    kl, kr = rng.integers(0, 4_000_000, n).astype(np.int64), rng.integers(0, 4_000_000, n).astype(np.int64)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    a, b = dev.to_dev(kl), dev.to_dev(kr)
+    dev.call_stats(a, (1000, 2_000_000), b, (0, 1_000_000))      # both too narrow
+    try:
+        k, c, f, j = dev.join_group_count(a, None, b, None)
+        plan = dev.last_plan()
+    finally:
+        dev.call_stats()
+    assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec)
+    assert plan["from_stats"] == 1 and plan["retries"] >= 1, plan
+
+
+def test_join_payload_plan_names_the_form(dev, monkeypatch):
+    rng = np.random.default_rng(10)
+    kr = np.unique(rng.integers(0, 1 << 26, 2_000_000, dtype=np.int64))
+    kl = kr[rng.integers(0, len(kr), 2_400_000)]
+    pay = [rng.integers(0, 1 << 40, len(kr), dtype=np.int64)]
+    for knob, form in (("2", 3), ("0", 2)):
+        monkeypatch.setenv("MDB_ROWJOIN", knob)
+        got = dev.join_payload(dev.to_dev(kl), None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+        assert got is not None and dev.last_plan()["payload_form"] == form, (knob, dev.last_plan())
