@@ -1735,6 +1735,15 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	bool ranged = leaf4 && ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r &&
 		      order_ranges_apply(n_l, kbits, ctx->lg_groups + ctx->lg_groups / 8, &rg_n) &&
 		      !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
+	/* ... or the caller's statistics say so before any join has run (mdb_dev_call_stats): a group needs a right key, and there are at
+	 * most as many of those as values in the right column's range */
+	if (!ranged && leaf4 && ctx->cs_on && ctx->cs_kl == keys_l && ctx->cs_has_r && ctx->cs_kr == keys_r && ctx->cs_r.min <= ctx->cs_r.max &&
+	    !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0')) {
+		const uint64_t span_r = (uint64_t)ctx->cs_r.max - (uint64_t)ctx->cs_r.min + 1;
+		uint64_t bound = span_r && span_r < n_r ? span_r : n_r;
+		bound = bound < n_l ? bound : n_l;
+		ranged = order_ranges_apply(n_l, kbits, bound, &rg_n);
+	}
 	a.rg_rec = NULL;
 	a.rg_cnt = NULL;
 	a.rg_cap = a.rg_shift = a.rg_n = 0;
