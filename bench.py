@@ -43,7 +43,7 @@ METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
 
 
 def _pmc_summary(suffix):
@@ -191,6 +191,8 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
         "sort_scatter_l1": 16 * g,
         "order_leaf": 8 * g + 8 * g + 16 * g,       # records + gathered keys in, (key, COUNT) out
         "gather64": 4 * g + 8 * g + 8 * g,
+        # the reduce over the right pass's per-tile (min, max) pairs: 8 bytes per tile of 4096 / 8192 keys, not the table
+        "part_minmax": 8 * (n / 4096 + 8), "key_sample": 2 * 4096 * 8, "shard_regions": 4 * 512 * 8 * 2,
     }
     return float(table.get(kernel, key))
 
@@ -200,7 +202,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per table per GPU (weak scaling); 125000000 = BASELINE configs[3] on 8 GPUs")
+    ap.add_argument("--rows", type=int, default=None, help="rows per table per GPU (weak scaling; default 10^8, 10^7 for --config 2); 125000000 = BASELINE "
+                    "configs[3] on 8 GPUs")
     ap.add_argument("--variant", choices=["U", "D", "S"], default="D",
                     help="U: both key columns are permutations (1:1); D: B keys = perm mod N/16 (1:16 duplicates, all in the lowest sixteenth "
                          "of A's key range); S: the same duplication SPREAD over A's whole range, B keys = 16 * (perm mod N/16) - no range "
@@ -213,9 +216,9 @@ def parse_args():
                     help="skip everything but the primary measurement and the per-kernel profile (profiling runs)")
     ap.add_argument("--wire64", action="store_true", help="multi-GPU exchange: always ship 8-byte keys (default: 4-byte keys when the "
                     "column statistics allow it)")
-    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=3,
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=3,
                     help="which BASELINE.json configuration (SURVEY 8d numbering): 3 = the north-star query (default, the metric's own "
-                         "configuration), 4 = configs[3]: SELECT * join over key columns (10^9 rows over 8 GPUs: --rows 125000000), "
+                         "configuration), 2 = configs[1]: two-table join with payload at 10^7 rows through query_execute(), 4 = configs[3]: SELECT * join over key columns (10^9 rows over 8 GPUs: --rows 125000000), "
                          "5 = configs[4]: three-way join + GROUP BY with DOUBLE payload through query_execute() (bench_configs.py)")
     ap.add_argument("--unordered", action="store_true", help="N = 1: time the operator without MDB_ORDER_FIRST (groups in unspecified order) - "
                     "evidence runs only; the default line keeps the reference's first-occurrence order")
@@ -230,7 +233,10 @@ def parse_args():
                          "that lost a peer must not hang the job")
     ap.add_argument("--force-shuffle", action="store_true",
                     help="run the multi-GPU pipeline (partition by destination + RCCL all-to-all + local join) even with one rank")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == 3 and not args.rows:
+        args.rows = 100_000_000
+    return args
 
 
 def launch_ranks(args):

@@ -8,7 +8,7 @@
 # creation) -> summary_<tag>[_U|_S|_wide].json; kernel names need no table: bench.py's line carries, per profiler name, the names
 # rocprofv3 lists its kernels under (mdb_dev_prof_symbols).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 passes() {	# $1 = output directory, $2... = program and arguments
@@ -57,14 +57,31 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$C4/kt" -- python3 "$R/
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$C4/fetch" -- python3 "$R/bench.py" $C4ARGS > "$C4/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$C4/write" -- python3 "$R/bench.py" $C4ARGS > "$C4/write.log" 2>&1
 (cd "$R" && python3 profiles/summarize.py "$C4" "$R/gpurun_out/summary_${TAG}_config4.json")
+# round 5: the other BASELINE configurations through bench.py --config N (bench_configs.py reads these summaries for roofline.traffic):
+# configs[1] (--config 2: join with payload at 10^7 rows through query_execute), configs[3] in the reference's row order, configs[4]
+# (--config 5: the grouped statement and its join-only form in one run - the row-order payload join's kernels, mdb_dev_rowjoin.hip)
+cfg_passes() {	# $1 = suffix, $2... = bench.py arguments
+	local SUF=$1; shift
+	local D=$R/gpurun_out/prof_${TAG}_$SUF
+	mkdir -p "$D"
+	rocprofv3 --kernel-trace --stats --output-format csv -d "$D/kt" -- python3 "$R/bench.py" "$@" --no-cpu-baseline > "$D/kt.log" 2>&1
+	rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -- python3 "$R/bench.py" "$@" --no-cpu-baseline > "$D/fetch.log" 2>&1
+	rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -- python3 "$R/bench.py" "$@" --no-cpu-baseline > "$D/write.log" 2>&1
+	(cd "$R" && python3 profiles/summarize.py "$D" "$R/gpurun_out/summary_${TAG}_$SUF.json")
+}
+cfg_passes config2 --config 2 --steps 5 --warmup 2
+cfg_passes config4_reference_order --config 4 --reference-order --steps 3 --warmup 1
+cfg_passes config5 --config 5 --steps 4 --warmup 1
+cp "$R/gpurun_out/summary_${TAG}_config5.json" "$R/gpurun_out/summary_${TAG}_config5_join.json"
 # what goes under profiles/$TAG/: the summaries and rocprofv3's own per-kernel statistics of each kernel-trace pass
 PUB=$R/gpurun_out/publish_$TAG
 mkdir -p "$PUB"
-for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U _config4; do
+for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U _config4 _config2 _config4_reference_order _config5 _config5_join; do
 	[ -f "$R/gpurun_out/summary_$TAG$S.json" ] && cp "$R/gpurun_out/summary_$TAG$S.json" "$PUB/rocprof_summary$S.json"
 	D="$R/gpurun_out/prof_$TAG$S/kt"
 	[ "$S" = _configs1 ] && D="$OPS/kt"
 	[ "$S" = _config4 ] && D="$C4/kt"
+	[ "$S" = _config5_join ] && D="$R/gpurun_out/prof_${TAG}_config5/kt"
 	F=$(find "$D" -name '*kernel_stats.csv' 2>/dev/null | head -1)
 	[ -n "$F" ] && cp "$F" "$PUB/kernel_stats$S.csv"
 done
