@@ -136,6 +136,8 @@ static inline bool mdb_type_is_int64(int type) { return type != MDB_CT_DOUBLE; }
 bool mdb_parse_time(const char *quoted, int type, int64_t *out);
 int mdb_table_reserve(struct mdb_table *t, uint64_t rows);
 int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen);
+int mdb_table_bulk_copy(struct mdb_catalog *cat, struct mdb_table *t, int ncols, uint64_t n, const int64_t *const *cols, bool *mirrored);
+void mdb_table_bulk_mirrored(struct mdb_catalog *cat, struct mdb_table *t, uint64_t old_rows, uint64_t old_generation);
 bool mdb_col_has_range(const struct mdb_column *col);
 int mdb_col_range(struct mdb_catalog *cat, struct mdb_table *t, struct mdb_column *col, int64_t *lo, int64_t *hi);	/* 0 ok, 1 no range for this type */
 int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen);

@@ -381,6 +381,36 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 				if (nulls[c][i])
 					return -MIDORIDB_ERROR;
 	}
+	/* large appends of plain 8-byte columns without NULL flags: copied by several threads, chunk by chunk, the device mirror following
+	 * behind (mdb_table_bulk_copy, mdb_store.c) - the first SELECT then uploads nothing */
+	bool plain = n >= ((uint64_t)1 << 20) && !(getenv("MDB_INGEST_BULK") && getenv("MDB_INGEST_BULK")[0] == '0');
+	for (int c = 0; c < ncols && plain; c++)
+		plain = t->cols[c].type != MDB_CT_VARCHAR && !(nulls && nulls[c]);
+	if (plain) {
+		const uint64_t r0 = t->nrows, r1 = t->nrows + n, old_gen = t->generation;
+		for (int c = 0; c < ncols; c++) {	/* the rows' NULL bits, cleared a word at a time (the first and last word may be shared) */
+			struct mdb_column *col = &t->cols[c];
+			uint64_t i = r0;
+			for (; i < r1 && (i & 63); i++)
+				col->nullbits[i >> 6] &= ~(1ull << (i & 63));
+			if (i < r1) {
+				const uint64_t full = (r1 - i) / 64;
+				memset(col->nullbits + (i >> 6), 0, full * 8);
+				i += full * 64;
+			}
+			for (; i < r1; i++)
+				col->nullbits[i >> 6] &= ~(1ull << (i & 63));
+		}
+		bool mirrored = false;
+		rc = mdb_table_bulk_copy(cat, t, ncols, n, cols, &mirrored);
+		if (rc)
+			return rc;
+		t->nrows += n;
+		t->generation++;
+		if (mirrored)
+			mdb_table_bulk_mirrored(cat, t, r0, old_gen);
+		return MIDORIDB_OK;
+	}
 	for (int c = 0; c < ncols; c++) {
 		struct mdb_column *col = &t->cols[c];
 		if (col->type == MDB_CT_VARCHAR) {

@@ -363,3 +363,21 @@ print("id file ok")
 ''' % (ROOT, str(tmp_path))
     r = subprocess.run([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "id file ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_bulk_ingest_in_chunks_by_several_threads_without_a_device(monkeypatch):
+    """mdb_table_append_columns over 2^20 rows and more of plain 8-byte columns: the chunked, multi-threaded copy into the host store
+    (mdb_table_bulk_copy, round 5).  No GPU here: the device mirror does not follow, nothing else changes - the call succeeds, a second
+    append lands behind the first, appends with NULL flags or strings keep the column-at-a-time path.  (What arrives is checked against
+    numpy by the GPU suite; this one runs under AddressSanitizer as well.)"""
+    from midoridb_amd.query import DB
+    rng = np.random.default_rng(3)
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("MDB_INGEST_THREADS", threads)
+        with DB() as db:
+            db.execute("CREATE TABLE T (a INT, b DOUBLE);")
+            n = (1 << 20) + 12345
+            db.append_columns("T", [rng.integers(-10**15, 10**15, n), rng.standard_normal(n)])
+            db.append_columns("T", [rng.integers(0, 9, 3 * n + 7), rng.standard_normal(3 * n + 7)])      # several chunks, ragged tail
+            db.append_columns("T", [np.arange(5), np.zeros(5)], nulls=[np.array([0, 1, 0, 0, 1], dtype=np.uint8), None])
+            db.append_columns("T", [rng.integers(0, 9, n), rng.standard_normal(n)])                      # behind rows with NULL flags
