@@ -466,15 +466,21 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_place(rj_place_args a)
 	const uint32_t cnt = a.n - row0 < RJ_TILE ? (uint32_t)(a.n - row0) : RJ_TILE;
 	if (half * (RJ_TILE / 2) >= cnt)
 		return;
+	/* four words and their four cells per lane and step: 16-byte loads, every cell of the tile read by both halves' workgroups (the second
+	 * finds the lines in its XCD's L2) - a vector memory instruction costs its ~70 cycles whatever it carries (profiles/r05/piece_loads.txt):
+	 * 8-byte loads of the one half's cells alone were twice the instructions (0.45 -> 0.30 ms per 10^8 rows) */
 	const uint4 *const wsrc = reinterpret_cast<const uint4 *>(a.words_l + blk0);
+	const ulonglong2 *const csrc = reinterpret_cast<const ulonglong2 *>(a.cells_al + blk0);
 	for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS) {
 		const uint4 w = wsrc[i];
+		const ulonglong2 c01 = csrc[2u * i], c23 = csrc[2u * i + 1u];	/* (inside the tile's block: RJ_STRIDE leaves room behind a partial tile) */
 		const uint32_t ws[4] = { w.x, w.y, w.z, w.w };
+		const uint64_t cs[4] = { c01.x, c01.y, c23.x, c23.y };
 #pragma unroll
 		for (int e = 0; e < 4; e++) {
 			const uint32_t r = ws[e] & (RJ_TILE - 1u);
 			if (4u * i + (uint32_t)e < cnt && (r >> (RJ_TILE_BITS - 1u)) == half)
-				rj_rows[r & (RJ_TILE / 2 - 1u)] = a.cells_al[blk0 + 4u * i + (uint32_t)e];
+				rj_rows[r & (RJ_TILE / 2 - 1u)] = cs[e];
 		}
 	}
 	__syncthreads();

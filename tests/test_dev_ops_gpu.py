@@ -2498,3 +2498,20 @@ def test_join_payload_plan_names_the_form(dev, monkeypatch):
         monkeypatch.setenv("MDB_ROWJOIN", knob)
         got = dev.join_payload(dev.to_dev(kl), None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
         assert got is not None and dev.last_plan()["payload_form"] == form, (knob, dev.last_plan())
+
+
+@pytest.mark.parametrize("cells", [1, 2])
+def test_join_payload_1e8_rows_every_left_row_gets_its_partners_cells(dev, cells):
+    """BASELINE configs[4]'s join-only shape at its full size (10^8 x 10^8 unique keys in two different orders), through the row-order
+    form: a size-independent property instead of an oracle run - the right table's payload cells are FUNCTIONS of its key (an INT64
+    one and a DOUBLE one), so out[c][i] must equal f_c(key_l[i]) for every left row, bit for bit; and the plan says which form ran"""
+    n = 100_000_000
+    a = dev.gen_keys(n, 0, n, 42, 0)
+    b = dev.gen_keys(n, 0, n, 43, 0)
+    pay = [b * 3 + 1, (b.to(torch.float64) * 0.5 - 7.25)][:cells]
+    got = dev.join_payload(a, None, b, None, pay)
+    assert got is not None and dev.last_plan()["payload_form"] == 3, dev.last_plan()
+    assert torch.equal(got[0], a * 3 + 1)
+    if cells == 2:
+        assert torch.equal(got[1].view(torch.int64), (a.to(torch.float64) * 0.5 - 7.25).view(torch.int64))
+    del got, pay
