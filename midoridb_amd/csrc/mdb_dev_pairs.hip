@@ -1348,11 +1348,22 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	a.status = ctx->d_status;
 	if (pl.nsub > PP_MAX_SUB)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: %u sub-regions per digit", pl.nsub);
-	if (npay == 1 && !(getenv("MDB_PP_CELL") && getenv("MDB_PP_CELL")[0] == '0')) {
+	if (!(getenv("MDB_PP_CELL") && getenv("MDB_PP_CELL")[0] == '0')) {
+		/* the cells IN the leaf's LDS table: one scattered access per joined row.  Two carried columns: the kernel once per column
+		 * (round 5: 0.51 -> 2 x 0.22 ms at 10^7 rows - the region-lookup leaf pays two scattered accesses per row and cell pair); the second
+		 * launch counts its pairs into a word nobody reads */
 		const uint32_t lowbits = rem < PC_SLOT_BITS ? rem : PC_SLOT_BITS;
 		const size_t lds = ((size_t)8 << lowbits) + ((size_t)1 << lowbits) / 8 + 64;
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_cell), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_cell, pl.nleaves, PW_THREADS, lds, a, rem, shift);
+		for (int c = 0; c < npay; c++) {
+			pp_args ac = a;
+			ac.pay_r[0] = a.pay_r[c];
+			ac.out[0] = a.out[c];
+			ac.npay = 1;
+			if (c)
+				ac.joined = (unsigned long long *)(ctx->d_status + 6);
+			MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_cell, pl.nleaves, PW_THREADS, lds, ac, rem, shift);
+		}
 	} else if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(getenv("MDB_PP_E16") && getenv("MDB_PP_E16")[0] == '0')) {
 		const size_t lds = (size_t)2 << rem;
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_payload<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

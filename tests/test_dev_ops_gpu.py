@@ -810,7 +810,7 @@ def test_join_keys_is_the_key_column_of_join_pairs_as_a_multiset(dev, case):
 @pytest.mark.parametrize("case", ["pk_pk_two_cells", "fk_to_pk_one_cell", "window_far_from_zero", "left_row_without_partner", "null_left_key",
                                   "duplicate_right_key", "keys_beyond_a_window", "small", "window_2e27_two_levels", "window_2e29_two_cells",
                                   "window_2e27_duplicate_right_key", "row_order_2e25", "row_order_2e26_two_cells", "row_order_whole_tiles",
-                                  "row_order_left_row_without_partner", "row_order_hot_key"])
+                                  "row_order_left_row_without_partner", "row_order_hot_key", "row_order_window_2e16", "row_order_window_2e19_two_cells"])
 def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case, monkeypatch):
     """mdb_dev_join_payload (BASELINE configs[1]: a primary-key join with payload): when every left row has exactly one partner the
     outputs are the partners' payload cells in left-row order (INT64 and DOUBLE bits alike) - equal to payload[pos_r] over the oracle's
@@ -850,8 +850,10 @@ def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case
     elif case.startswith("row_order"):
         # round 5 (mdb_dev_rowjoin.hip): windows of 2^25 ... 2^27 values - the left table sorted tile by tile, the result placed in row order
         # (the operator pads the sampled range and rounds it up to a power of two: these spans give windows of 2^25, 2^26, 2^27)
-        span = 1 << (24 if "2e25" in case else 25 if "2e26" in case else 26)
-        kr = np.unique(rng.integers(0, span, 1_800_000, dtype=np.int64)) + 10**10
+        # (2e16 / 2e19: a fact table against a small dimension - few digits, pieces of hundreds of words: the leaf's whole-wave walk and
+        # its one-piece-per-instruction form)
+        span = 1 << (24 if "2e25" in case else 25 if "2e26" in case else 15 if "2e16" in case else 18 if "2e19" in case else 26)
+        kr = np.unique(rng.integers(0, span, min(1_800_000, span), dtype=np.int64)) + 10**10
         nleft = 32768 * 70 if "whole_tiles" in case else 2_345_679
         kl = kr[rng.integers(0, len(kr), nleft)]
         if "hot_key" in case:		# one key on 200 000 consecutive left rows: pieces of a whole tile in one digit
