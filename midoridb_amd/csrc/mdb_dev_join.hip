@@ -575,6 +575,7 @@ __global__ __launch_bounds__(GC_THREADS, 8) void k_leaf_group_count(gc_args a)
 									mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record */
 								recv = ((unsigned long long)first << (64 - a.kbits)) | c;
 							} else {
+								if (first < a.dense_n)
 								a.dense_cnt[first] = (int64_t)c;
 							}
 						}
@@ -871,7 +872,8 @@ __device__ static inline void ld_leaf(const gc_args &a, ld_state &st, uint32_t l
 						if (a.rec32 && (c >> (32 - a.kbits)))
 							mdb_raise(a.status, 512u);
 					} else {
-						a.dense_cnt[first] = (int64_t)c;
+						if (first < a.dense_n)
+								a.dense_cnt[first] = (int64_t)c;
 					}
 				}
 			}
@@ -1181,7 +1183,8 @@ __global__ __launch_bounds__(1024) void k_hot_finish(gc_args a, hot_args h)
 				mdb_raise(a.status, 8u);
 			nvalid++;
 		} else {
-			a.dense_cnt[first] = (int64_t)c;
+			if (first < a.dense_n)
+								a.dense_cnt[first] = (int64_t)c;
 		}
 	}
 	if (mine)
@@ -1684,6 +1687,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.cnt_r = pr.leaf_cnt;
 	a.cap_r = pr.leaf_cap;
 	a.dense_cnt = dense;
+	a.dense_n = (uint32_t)n_l;
 	a.rec = rec;
 	a.rec_count = d_rec_count;
 	a.rec_valid = d_rec_valid;

@@ -92,6 +92,8 @@ struct gc_args {
 	const uint32_t *cnt_r;
 	uint32_t cap_r;
 	int64_t *dense_cnt;		/* dense mode: [n_l], zeroed: COUNT(*) written at the group's first L position */
+	uint32_t dense_n;		/* ... = n_l: a first row id is checked against it before it indexes dense_cnt[] - a fixed-capacity region that
+					 * overflowed (status bit 1: the operator is redone) holds slots nobody wrote, with whatever an earlier call left */
 	unsigned long long *rec;	/* record mode: one 64-bit record per group, (first << (64 - kbits)) | COUNT(*) */
 	uint32_t *rec_count;		/* record mode: list slots handed out so far (the list has zero-filled gaps) */
 	uint32_t *rec_valid;		/* record mode: number of real records (= groups) */

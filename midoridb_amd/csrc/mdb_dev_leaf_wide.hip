@@ -216,7 +216,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 					mdb_raise(a.status, 16u);	/* ... nor in a 4-byte record */
 				a.rec[pos++] = ((unsigned long long)first << (64 - a.kbits)) | c;
 			} else {
-				a.dense_cnt[first] = (int64_t)c;
+				if (first < a.dense_n)
+								a.dense_cnt[first] = (int64_t)c;
 			}
 		}
 	}

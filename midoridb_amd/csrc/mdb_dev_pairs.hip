@@ -231,6 +231,8 @@ struct pj_args {
 	const uint32_t *cnt_r;
 	uint32_t cap_r;
 	uint32_t *match;	/* [n_l + 1]: count phase writes matches per left row; scanned into offsets */
+	uint32_t n_l;		/* a row id read from a region is checked against it before it indexes match[]: a fixed-capacity region that overflowed
+				 * (status bit 1: the join is redone with exact regions) holds slots nobody wrote */
 	uint32_t *out_l;
 	uint32_t *out_r;
 	uint32_t *status;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_pairs_count(pj_args a)
 			s = leaf_find(s_key, PJ_SLOTS, hv);
 		if (s != 0xFFFFFFFFu) {
 			const uint32_t m = s_cnt[s];
-			if (m) {
+			if (m && a.rid_l[i] < a.n_l) {
 				a.match[a.rid_l[i]] = m;
 				mine += m;
 			}
@@ -533,6 +535,8 @@ struct pw_args {
 	const uint32_t *cnt_l, *cnt_r;		/* rows per sub-region: [sub * nleaves + digit] */
 	uint32_t cap_l, cap_r, nleaves, nsub;
 	uint32_t *match;			/* [n_l], zeroed: right row id + 1 of the left row's partner */
+	uint32_t n_l;				/* a word's row id is checked against it before it indexes match[]: a region that overflowed (status
+						 * bit 1: the operator is redone) holds slots nobody wrote - whatever an earlier call left there */
 	unsigned long long *joined;
 	uint32_t *status;
 };
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_wide(pw_args a, uint3
 				for (int k = 0; k < 2; k++)
 					if (i + k < c) {
 						const uint32_t r = pw_tab[((uint32_t)(w[k] >> 32) >> shift) & mask];
-						if (r) {
+						if (r && (uint32_t)w[k] < a.n_l) {
 							a.match[(uint32_t)w[k]] = r;
 							pairs++;
 						}
@@ -753,6 +757,7 @@ static int join_pairs_unique_wide(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	a.nleaves = pl.nleaves;
 	a.nsub = pl.nsub;
 	a.match = match;
+	a.n_l = (uint32_t)n_l;
 	a.joined = (unsigned long long *)(ctx->d_status + 2);
 	a.status = ctx->d_status;
 	const size_t lds = (size_t)4 << rem;
@@ -811,6 +816,8 @@ struct pp_args {
 	uint32_t npay;
 	const uint32_t *cnt_l, *cnt_r;
 	uint32_t cap_l, cap_r, nleaves, nsub;
+	uint32_t n_l;		/* rows of the left table: a word's row id is checked against it before it indexes out[] (an overflowed region -
+				 * status bit 1, the join is then "not served" - holds slots nobody wrote: whatever an earlier call left there) */
 	unsigned long long *joined;
 	uint32_t *status;
 };
@@ -934,6 +941,8 @@ __global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_payload(pp_args a, ui
 			for (int q = 0; q < 2 * PW_UNROLL; q++)
 				if (e[q]) {
 					const uint32_t lrid = (uint32_t)((q & 1) ? v[q >> 1].y : v[q >> 1].x);
+					if (lrid >= a.n_l)
+						continue;
 					a.out[0][lrid] = cell[0][q];
 					if (a.npay > 1u)
 						a.out[1][lrid] = cell[1][q];
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_leaf_pairs_cell(pp_args a, uint3
 					for (int k = 0; k < 2; k++) {
 						const unsigned long long w = k ? v[u].y : v[u].x;
 						const uint32_t slot = ((uint32_t)(w >> 32) >> shift) & mask, lo = slot & (S - 1u);
-						if (have[u] > (uint32_t)k && (slot >> lowbits) == pass && ((occ[lo >> 5] >> (lo & 31u)) & 1u)) {
+						if (have[u] > (uint32_t)k && (slot >> lowbits) == pass && ((occ[lo >> 5] >> (lo & 31u)) & 1u) && (uint32_t)w < a.n_l) {
 							a.out[0][(uint32_t)w] = cellt[lo];
 							pairs++;
 						}
@@ -1071,6 +1080,7 @@ struct pl_args {
 	uint32_t npay;
 	const uint32_t *cnt_l, *cnt_r;
 	uint32_t cap_l, cap_r, nleaves;
+	uint32_t n_l;		/* (as in pp_args) */
 	unsigned long long *joined;
 	uint32_t *status;
 };
@@ -1127,7 +1137,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_leaf_pairs_cell2(pl_args a, uint
 				if (i + (uint32_t)k < cl) {
 					const unsigned long long w = k ? v.y : v.x;
 					const uint32_t slot = ((uint32_t)(w >> 32) >> shift) & mask;
-					if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
+					if (((s_occ[slot >> 5] >> (slot & 31u)) & 1u) && (uint32_t)w < a.n_l) {
 						a.out[0][(uint32_t)w] = s_cell[0][slot];
 						if (NP > 1)
 							a.out[1][(uint32_t)w] = s_cell[1][slot];
@@ -1267,6 +1277,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		a.cap_l = pl.leaf_cap;
 		a.cap_r = pr.leaf_cap;
 		a.nleaves = pl.nleaves;
+		a.n_l = (uint32_t)n_l;
 		a.joined = (unsigned long long *)(ctx->d_status + 2);
 		a.status = ctx->d_status;
 		const uint32_t grid = pl.nleaves < 8u * (uint32_t)ctx->num_cus ? pl.nleaves : 8u * (uint32_t)ctx->num_cus;
@@ -1344,6 +1355,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	a.cap_r = pr.leaf_cap;
 	a.nleaves = pl.nleaves;
 	a.nsub = pl.nsub;
+	a.n_l = (uint32_t)n_l;
 	a.joined = (unsigned long long *)(ctx->d_status + 2);
 	a.status = ctx->d_status;
 	if (pl.nsub > PP_MAX_SUB)
@@ -1747,6 +1759,7 @@ extern "C" int mdb_dev_join_pairs(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 		a.cnt_r = pr.leaf_cnt;
 		a.cap_r = pr.leaf_cap;
 		a.match = match;
+		a.n_l = (uint32_t)n_l;
 		a.out_l = a.out_r = NULL;
 		a.status = ctx->d_status;
 		a.total64 = (unsigned long long *)(ctx->d_status + 2);

@@ -2502,6 +2502,32 @@ def test_join_payload_plan_names_the_form(dev, monkeypatch):
         assert got is not None and dev.last_plan()["payload_form"] == form, (knob, dev.last_plan())
 
 
+def test_join_payload_older_forms_after_a_region_overflow_write_inside_their_arrays(dev, monkeypatch):
+    """The sequence the payload soak faulted on (round 5): a served two-level join, then - older forms, same sizes - a join whose hot key
+    (150 000 left rows of one key) overflows a fixed-capacity region.  The region's slots nobody wrote still hold row ids of the EARLIER
+    call's larger table: a leaf that indexed a result column with them wrote outside it (a GPU memory access fault ends the process,
+    so surviving the sequence is the assertion).  Now: not served, or served right."""
+    monkeypatch.setenv("MDB_ROWJOIN", "0")
+    rng = np.random.default_rng(70_014)
+    span = 1 << 25
+    kr = np.unique(rng.integers(0, span, 1_500_000)).astype(np.int64) + 10**15
+    big_l = kr[rng.integers(0, len(kr), 3_100_001)]
+    pay = [rng.integers(-2**62, 2**62, len(kr), dtype=np.int64), rng.standard_normal(len(kr))]
+    got = dev.join_payload(dev.to_dev(big_l), None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+    assert got is not None
+    order = np.argsort(kr, kind="stable")
+    assert np.array_equal(_np(got[0]), pay[0][order][np.searchsorted(kr[order], big_l)])
+    del got
+    kl = kr[rng.integers(0, len(kr), 2_345_679)]
+    kl[1_000_000:1_150_000] = kr[12345]
+    for _ in range(3):
+        got = dev.join_payload(dev.to_dev(kl), None, dev.to_dev(kr), None, [dev.to_dev(p) for p in pay])
+        if got is not None:
+            pos = np.searchsorted(kr[order], kl)
+            assert all(np.array_equal(_np(g).view(np.int64), p[order][pos].view(np.int64)) for g, p in zip(got, pay))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("cells", [1, 2])
 def test_join_payload_1e8_rows_every_left_row_gets_its_partners_cells(dev, cells):
     """BASELINE configs[4]'s join-only shape at its full size (10^8 x 10^8 unique keys in two different orders), through the row-order
