@@ -14,7 +14,8 @@
 #define MDB_SCAN_SMALL 16384u	/* up to here the scan is one single-workgroup launch */
 static inline size_t mdb_scan_scratch_words(uint64_t len) { return (size_t)((len + MDB_SCAN_CHUNK - 1) / MDB_SCAN_CHUNK) + 1; }
 int mdb_scan_u32_inplace(mdb_dev_ctx *ctx, uint32_t *data, uint64_t len, uint32_t *block_sums);
-/* dst[0..n] = exclusive prefix sums of src[0..n), dst[n] = total; one single-workgroup launch (n <= MDB_SCAN_SMALL) */
+/* dst[0..n] = exclusive prefix sums of src[0..n), dst[n] = total; one single-workgroup launch (n <= MDB_SCAN_FROM_MAX) */
+#define MDB_SCAN_FROM_MAX 65536u
 int mdb_scan_u32_small_from(mdb_dev_ctx *ctx, const uint32_t *src, uint32_t n, uint32_t *dst);
 
 /* ---- radix partition (mdb_dev_partition.hip) ------------------------------------------------ */
@@ -125,11 +126,14 @@ bool mdb_partition_w32_applies(uint64_t n, int bits1, int bits2, bool fast);
 /* fast = fixed-capacity regions + cursors (a region overflow sets bit 1 of ctx->d_status[0]: the caller must check it
  * after the consumer kernel and redo with fast = false, the exact histogram layout) */
 /* digits0_used: how many of the 2^bits1 first-level digits can occur at all (0 = every one) - sizes the fast regions */
-size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used);
+/* digit0_rows: the words are row ids and a first-level digit spans that many of them (0: not so) - sizes the fast first-level regions for
+ * the most a digit can hold instead of the average */
+size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used, uint64_t digit0_rows = 0);
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
 		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap = true,	/* zero words are gaps of a chunked list */
-		      int fold32 = 0);	/* 1: the 8-byte records are folded into 4-byte words by the first level; 2: `hv` already holds 4-byte words */	/* the first level folds every 8-byte word w into the 4-byte word (w >> 32) | (uint32_t)w - the caller knows
+		      int fold32 = 0,	/* 1: the 8-byte records are folded into 4-byte words by the first level; 2: `hv` already holds 4-byte words */	/* the first level folds every 8-byte word w into the 4-byte word (w >> 32) | (uint32_t)w - the caller knows
 					 * that the two parts share no bit - and everything after it moves 4-byte words (out->w32; two fast levels only) */
+		      uint64_t digit0_rows = 0);
 
 /* one stable least-significant-digit radix pass over (key, row id) pairs: digit = (key >> shift) & (2^bits - 1),
  * bits <= 8.  hist = scratch of mdb_sort_pass_hist_words(n) uint32, scan_tmp = mdb_scan_scratch_words(of that). */

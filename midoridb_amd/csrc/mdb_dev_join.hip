@@ -1467,7 +1467,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			mdb_align_up((size_t)HOT_MAX * (HOT_SLOTS + 1) * 4) + 4096;	/* hot-key path (only touched when needed) */
 		if (st->want_records && order_bits(st->n_l, &kb, &s1, &s2))
 			need += mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2)), true,
-							      order_digits0(st->n_l, kb, s1)) +
+							      order_digits0(st->n_l, kb, s1), (uint64_t)1 << (kb - (uint32_t)s1)) +
 				mdb_partition_raw_arena_bytes(gc_rec_capacity(ctx, st->n_l), s1, s2, 1u << (kb - (uint32_t)(s1 + s2)), false, 0) +
 				2 * (((size_t)1 << (s1 + s2)) + 4096) * 8;
 		else

@@ -312,7 +312,7 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 				uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
 				if (!obase || !otmp)
 					return -MIDORIDB_INTERNAL;
-				if (ps.nleaves <= MDB_SCAN_SMALL) {
+				if (ps.nleaves <= MDB_SCAN_FROM_MAX) {
 					rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
 				} else {
 					MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -350,7 +350,7 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 	for (int sort_fast = 1; sort_fast >= 0; sort_fast--) {
 		mdb_part_result ps;
 		rc = mdb_partition_raw(ctx, (const uint64_t *)rec, list_len, sb1, sb2, ord_range, sort_fast != 0, order_digits0(n_l, kbits, sb1),
-				       &ps, true, (rec32 && sort_fast != 0) ? (in32 ? 2 : 1) : 0);
+				       &ps, true, (rec32 && sort_fast != 0) ? (in32 ? 2 : 1) : 0, (uint64_t)1 << (kbits - (uint32_t)sb1));
 		if (rc)
 			return rc;
 		ord_args oa;
@@ -378,7 +378,7 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 			uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
 			if (!obase || !otmp)
 				return -MIDORIDB_INTERNAL;
-			if (ps.nleaves <= MDB_SCAN_SMALL) {
+			if (ps.nleaves <= MDB_SCAN_FROM_MAX) {
 				rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
 			} else {
 				MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -468,7 +468,7 @@ size_t order_records_arena_bytes(uint64_t cap, uint64_t n_l, uint32_t kbits, int
 		sparse = mdb_partition_raw_arena_bytes(cap < most ? cap : most, s1, s2, 0, true, order_digits0(n_l, kbits, s1)) +
 			 2 * (((size_t)1 << lb) + 4096) * 8;
 	}
-	return sparse + mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, true, order_digits0(n_l, kbits, sb1)) +
+	return sparse + mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, true, order_digits0(n_l, kbits, sb1), (uint64_t)1 << (kbits - (uint32_t)sb1)) +
 	       mdb_partition_raw_arena_bytes(cap, sb1, sb2, ord_range, false, 0) + 2 * (((size_t)1 << (sb1 + sb2)) + 4096) * 8;
 }
 

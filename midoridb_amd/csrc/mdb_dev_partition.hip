@@ -1195,7 +1195,7 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 			  bool want_rid, uint32_t flags, uint32_t mode, uint32_t n_dest, bool inverse_out, uint64_t *final_hv_out,
 			  const uint64_t *raw_hv, uint32_t cap_override, mdb_part_result *out, uint32_t *final_rid_out = NULL,
 			  uint32_t digits0_used = 0, bool keys32_out = false, int64_t narrow_base = 0, uint32_t narrow_kbits = 0,
-			  const mdb_part_filter *flt = NULL)
+			  const mdb_part_filter *flt = NULL, uint64_t raw_digit_rows = 0)
 {
 	mdb_dev_ctx *ctx = cv.ctx;
 	const bool dry = cv.dry;
@@ -1215,7 +1215,17 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 	/* raw sort keys need not cover the whole first digit range (row ids below n < 2^kbits): the regions are
 	 * sized for the digits that can occur */
 	const uint32_t nreg0_used = (digits0_used && digits0_used < Rl[0] ? digits0_used : Rl[0]) * PART_NSUB;
-	const uint64_t avg0 = (n + nreg0_used - 1) / nreg0_used;
+	uint64_t avg0 = (n + nreg0_used - 1) / nreg0_used;
+	/* raw sort keys that are ROW IDS (the ordering of group records by first row): a first-level digit spans raw_digit_rows ids and every id
+	 * occurs once at most, so min(n, raw_digit_rows) words is the most a digit can receive - and receives, where the first rows bunch
+	 * (single-table GROUP BY over random duplicates: most groups' first rows lie in the first tenth of the table).  Regions sized for
+	 * that never send the sort to its exact layout; the list's order has nothing to do with the row ids, so a digit's words spread
+	 * evenly over its sub-regions */
+	if (raw_digit_rows) {
+		const uint64_t most = n < raw_digit_rows ? n : raw_digit_rows, per_sub = (most + PART_NSUB - 1) / PART_NSUB;
+		if (per_sub > avg0)
+			avg0 = per_sub;
+	}
 	/* (flt->region_cap: the caller fixes the capacity of a first-level region itself - the sharded operator, whose ranks must
 	 * agree on it: the regions ARE the transfer blocks, mdb_dev_shard.hip) */
 	const uint32_t cap0 = (flt && flt->region_cap) ? flt->region_cap
@@ -1637,16 +1647,16 @@ int mdb_partition_table(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *n
 /* MSD radix partition of ready-made 64-bit sort keys (no hashing, no NULLs) by their top bits1 + bits2
  * bits; with two levels the last one uses the fixed-capacity layout with `leaf_cap` rows per leaf (the
  * caller guarantees no leaf can hold more).  Used to order GROUP BY results by first row id. */
-size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used)
+size_t mdb_partition_raw_arena_bytes(uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast, uint32_t digits0_used, uint64_t digit0_rows)
 {
 	part_carver cv = { NULL, true, 0, false };
 	(void)partition_impl(cv, NULL, NULL, n, bits1, bits2, false, fast ? PART_F_FAST : 0u, MDB_DIGIT_RADIX, 0, false, NULL,
-			     (const uint64_t *)16, leaf_cap, NULL, NULL, digits0_used);
+			     (const uint64_t *)16, leaf_cap, NULL, NULL, digits0_used, false, 0, 0, NULL, fast ? digit0_rows : 0);
 	return cv.bytes + 4096;
 }
 
 int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits1, int bits2, uint32_t leaf_cap, bool fast,
-		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap, int fold32)
+		      uint32_t digits0_used, mdb_part_result *out, bool zero_is_gap, int fold32, uint64_t digit0_rows)
 {
 	part_carver cv = { ctx, false, 0, false };
 	if (fold32 && (!fast || bits2 <= 0 || !zero_is_gap))
@@ -1654,7 +1664,7 @@ int mdb_partition_raw(mdb_dev_ctx *ctx, const uint64_t *hv, uint64_t n, int bits
 	return partition_impl(cv, NULL, NULL, n, bits1, bits2, false,
 			      (fast ? PART_F_FAST : 0u) | (zero_is_gap ? 0u : PART_F_NO_GAPS) | (fold32 ? PART_F_FOLD32 : 0u) | (fold32 == 2 ? PART_F_IN32 : 0u),
 			      MDB_DIGIT_RADIX, 0,
-			      false, NULL, hv, leaf_cap, out, NULL, digits0_used);
+			      false, NULL, hv, leaf_cap, out, NULL, digits0_used, false, 0, 0, NULL, fast ? digit0_rows : 0);
 }
 
 /* ---- one histogram-free radix level over 4-byte words in caller-described tiles (the receiver's second level of the

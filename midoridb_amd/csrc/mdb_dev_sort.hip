@@ -320,7 +320,7 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 	uint64_t *vk = vkey ? (uint64_t *)mdb_arena_take(ctx, n * 8) : NULL;	/* sorted composite values, for callers that look for runs */
 	if (!obase || !otmp || !out || (vkey && !vk))
 		return -MIDORIDB_INTERNAL;
-	if (ps.nleaves <= MDB_SCAN_SMALL) {
+	if (ps.nleaves <= MDB_SCAN_FROM_MAX) {
 		rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
 	} else {
 		MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -390,7 +390,7 @@ int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint6
 	uint32_t *otmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words((uint64_t)ps.nleaves + 1) * 4);
 	if (!obase || !otmp)
 		return -MIDORIDB_INTERNAL;
-	if (ps.nleaves <= MDB_SCAN_SMALL) {
+	if (ps.nleaves <= MDB_SCAN_FROM_MAX) {
 		rc = mdb_scan_u32_small_from(ctx, ps.leaf_cnt, ps.nleaves, obase);
 	} else {
 		MDB_HIP(ctx, hipMemcpyAsync(obase, ps.leaf_cnt, (size_t)ps.nleaves * 4, hipMemcpyDeviceToDevice, ctx->stream));
