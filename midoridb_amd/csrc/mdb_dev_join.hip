@@ -3117,8 +3117,8 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	if (hrc <= 0)
 		return hrc;
 	*out_groups = 0;
-	/* round 5: a NULL-free key column inside a compact window of 2^13 ... 2^27 values goes through the tile sort (mdb_dev_rowjoin.hip):
-	 * one sequential pass of 4-byte row words instead of two 8-byte partition levels */
+	/* round 5: a NULL-free key column inside a compact window of 2^18 ... 2^25 values goes through the band sort (mdb_dev_bandgroup.hip):
+	 * one pass of 4-byte row words instead of 8-byte ones (and, MDB_GROUP_TILED=1, the tile sort of mdb_dev_rowjoin.hip: windows of 2^13 ... 2^27) */
 	if (!nullbits && n >= ((uint64_t)1 << 21) && ctx->narrow_mode != 0 && !ld_disabled()) {
 		for (int attempt = 0; attempt < 2; attempt++) {
 			int64_t lo = 0, hi = 0;
@@ -3133,10 +3133,16 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 			if (!kb)
 				break;
 			bool outside = false;
-			rc = mdb_group_count_tiled(ctx, keys, n, wlo, kb, out_first, out_count, cap, out_groups, &outside);
+			rc = mdb_group_count_banded(ctx, keys, n, wlo, kb, out_first, out_count, cap, out_groups, &outside);
 			if (rc <= 0)
 				return rc;
 			*out_groups = 0;
+			if (!outside) {
+				rc = mdb_group_count_tiled(ctx, keys, n, wlo, kb, out_first, out_count, cap, out_groups, &outside);
+				if (rc <= 0)
+					return rc;
+				*out_groups = 0;
+			}
 			if (!(outside && remembered && attempt == 0)) {	/* (a remembered sample of a column whose contents changed: taken again, once) */
 				if (outside)
 					ctx->nh_distrust = 8;

@@ -12,8 +12,9 @@ for name, keys in (("groups_of_16", dev.gen_keys(n, 0, n, 43, n // 16)), ("uniqu
                    ("groups_of_4_spread", dev.gen_keys(n, 0, n, 45, n // 4).mul_(4))):
     row = {"rows": n, "keys": name}
     ref = None
-    for form in ("0", "1"):
-        os.environ["MDB_GROUP_TILED"] = form
+    for form in ("0", "1", "banded"):
+        os.environ["MDB_GROUP_TILED"] = "1" if form == "1" else "0"
+        os.environ["MDB_GROUP_BANDED"] = "1" if form == "banded" else "0"
         for _ in range(3):
             f, c = dev.group_count(keys, None)
         torch.cuda.synchronize()
@@ -27,11 +28,11 @@ for name, keys in (("groups_of_16", dev.gen_keys(n, 0, n, 43, n // 16)), ("uniqu
         dev.group_count(keys, None)
         kern = {k: round(v[1], 4) for k, v in dev.prof_read().items() if v[1] > 0}
         dev.prof_enable(False)
-        tag = "tiled" if form == "1" else "partitioned"
+        tag = {"0": "partitioned", "1": "tiled", "banded": "banded"}[form]
         row[tag + "_ms"], row[tag + "_kernels"], row["groups"] = round(ms, 4), kern, f.numel()
         if ref is None:
             ref = (f.clone(), c.clone())
         else:
-            row["identical"] = bool(torch.equal(ref[0], f) and torch.equal(ref[1], c))
+            row["identical"] = bool(row.get("identical", True) and torch.equal(ref[0], f) and torch.equal(ref[1], c))
     print(json.dumps(row), flush=True)
     del keys, ref

@@ -4,7 +4,7 @@ with durations and the gaps between kernels.
     python3 profiles/micro/group_trace.py show gpurun_out/gtrace"""
 import glob, os, sys, csv
 if sys.argv[1] == "run":
-    sys.path.insert(0, ".")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import torch
     from midoridb_amd.dev import DeviceCtx
     dev = DeviceCtx(0)

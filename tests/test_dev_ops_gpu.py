@@ -152,6 +152,52 @@ def test_group_count_through_the_tile_sort(dev, case, monkeypatch):
     assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case
 
 
+@pytest.mark.parametrize("case", ["groups_of_17_2e18", "uniform_2e21", "bunched_first_rows_2e22", "sparse_2e24", "whole_bands", "hot_value", "negative_keys"])
+def test_group_count_through_the_band_sort(dev, case, monkeypatch):
+    """GROUP BY key + COUNT(*) of a NULL-free column through the band sort (mdb_dev_bandgroup.hip: 4-byte row words, the default for windows of
+    2^18 ... 2^25 key values from 2^22 rows on): first row and COUNT per key in first-row order, bit-exact against the oracle - a ragged last tile
+    and band, windows at both ends of the range, first rows bunched at the table's start, keys far from zero; a hot value overflows its region:
+    the other forms answer (same result), and the column is remembered"""
+    rng = np.random.default_rng(len(case) + 5)
+    n = 4_500_000 + 777
+    if case == "groups_of_17_2e18":
+        k = rng.integers(0, 1 << 18, n)
+    elif case == "uniform_2e21":
+        k = rng.integers(0, 1 << 21, n)
+    elif case == "bunched_first_rows_2e22":
+        k = np.concatenate([rng.permutation(1 << 22), rng.integers(0, 1 << 22, n - (1 << 22))])
+    elif case == "sparse_2e24":                # (a sampled window is padded: 2^25 values, the form's widest)
+        k = rng.integers(0, 1 << 24, n)
+    elif case == "whole_bands":
+        n = 18 << 18
+        k = rng.integers(0, 3_000_000, n)
+    elif case == "hot_value":                  # 400 000 rows of one value within two bands: its digit's regions there overflow
+        n += 4096                              # (what is remembered about a column goes by address and length: not the next case's column)
+        k = rng.integers(0, 1 << 21, n)
+        k[900_000:1_300_000] = 777
+    else:
+        k = rng.integers(0, 1 << 20, n) - 10**13
+    k = k.astype(np.int64)
+    ef, ec = orc.group_count(k, None)
+    dk = dev.to_dev(k)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    f, c = dev.group_count(dk, None)
+    ran = {k for k, v in dev.prof_read().items() if v[0] > 0}
+    dev.prof_reset()
+    f2, c2 = dev.group_count(dk, None)
+    ran2 = {k for k, v in dev.prof_read().items() if v[0] > 0}
+    dev.prof_enable(False)
+    assert {"group_band_sort", "group_band_leaf"} <= ran, ran
+    assert any(k.startswith(("leaf_", "hot_")) for k in ran) == (case == "hot_value"), ran       # (the partitioned path's kernels)
+    assert ("group_band_sort" in ran2) == (case != "hot_value"), ran2
+    assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case
+    assert np.array_equal(_np(f2).astype(np.int64), ef) and np.array_equal(_np(c2), ec), case
+    monkeypatch.setenv("MDB_GROUP_BANDED", "0")
+    f3, c3 = dev.group_count(dk, None)
+    assert torch.equal(f3, f) and torch.equal(c3, c)
+
+
 def test_group_count_golden_case10(dev):
     # reference tests/engine/executor_select.c:318-346 : id = 1,1,3,3,4 -> (1,2)(3,2)(4,1)
     k = np.array([1, 1, 3, 3, 4], dtype=np.int64)
@@ -1549,6 +1595,7 @@ def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_l
     2^(k - 9) entries, 16-bit row counts) instead of two levels and k_leaf_direct.  Same groups, counts, first rows and order
     as the oracle and as the two-level form (MDB_ONE_LEVEL=0)."""
     narrow_mode(1)
+    monkeypatch.setenv("MDB_GROUP_BANDED", "0")     # (single-table GROUP BY from 2^22 rows on goes through the band sort by default: its own test)
     rng = np.random.default_rng(len(shape) * 101 + 7)
     nl = nr = None
     has_r = True
@@ -1607,13 +1654,14 @@ def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_l
 
 
 @pytest.mark.parametrize("rows_of_the_key", [65_535, 65_536, 70_000])
-def test_a_row_count_beyond_16_bits_sends_the_wide_direct_leaves_back_to_two_levels(dev, narrow_mode, rows_of_the_key):
+def test_a_row_count_beyond_16_bits_sends_the_wide_direct_leaves_back_to_two_levels(dev, narrow_mode, rows_of_the_key, monkeypatch):
     """k_leaf_wide counts rows per key in 16-bit halves of LDS words.  A key with 2^16 or more rows carries into (or out
     of) its neighbour; the kernel notices that the sum of the counts falls short of the rows it counted, and the operator is
     redone with two partition levels.  1.6 * 10^8 rows (so that the one key's rows do not overflow a first-level region
     before the leaf kernel sees them), plain GROUP BY, checked on the device against torch: COUNT per key, first row per key,
     first-occurrence order.  65 535 rows still fit."""
     narrow_mode(1)
+    monkeypatch.setenv("MDB_GROUP_BANDED", "0")     # (the partitioned path is what is tested here)
     n, span = 160_000_000, 4_000_000
     g = torch.Generator(device="cuda")
     g.manual_seed(rows_of_the_key)
