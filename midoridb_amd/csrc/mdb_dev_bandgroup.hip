@@ -409,7 +409,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	la.rec_count = ctx->d_status + 2;
 	la.status = ctx->d_status;
 	const size_t lds_leaf = (size_t)8 << sbits;
-	const uint32_t threads = getenv("MDB_BG_LEAF_THREADS") ? (uint32_t)atoi(getenv("MDB_BG_LEAF_THREADS")) : 1024u;
+	const uint32_t threads = 1024u;
 #define BG_LAUNCH_LEAF(N)                                                                                                                         \
 	do {                                                                                                                                      \
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_group_leaf<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \

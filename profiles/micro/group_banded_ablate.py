@@ -8,9 +8,7 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 dev = DeviceCtx(0)
 keys = dev.gen_keys(n, 0, n, 43, n // 16)
 for ab in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "1", "2", "3", "4", "5")):
-    os.environ["MDB_BG_ABLATE"] = ab.split(":")[0]
-    if ":" in ab:
-        os.environ["MDB_BG_LEAF_THREADS"] = ab.split(":")[1]
+    os.environ["MDB_BG_ABLATE"] = ab
     for _ in range(2):
         dev.group_count(keys, None)
     dev.prof_enable(True)

@@ -11,13 +11,13 @@ dev = D.DeviceCtx(0)
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 t0 = time.time()
-sizes = [300_000, 1_500_000, 3_000_000]
+sizes = [300_000, 1_500_000, 3_000_000, 4_700_001, 6_291_456]       # (the last two: the band sort's tables, 2^22 rows and more)
 bufs = {n: torch.empty(n, dtype=torch.int64, device=dev.device) for n in sizes}
 for seed in range(seeds):
     rng = np.random.default_rng(50_000 + seed)
     n = int(rng.choice(sizes))
     d = int(min(n, max(1, 10 ** rng.uniform(0, 6.5))))
-    shape = rng.choice(["dense", "scattered", "offset", "outlier"])
+    shape = rng.choice(["dense", "scattered", "offset", "outlier", "hot"])
     if shape == "dense":
         vals = np.arange(d, dtype=np.int64) - d // 3
     elif shape == "scattered":
@@ -25,8 +25,11 @@ for seed in range(seeds):
     elif shape == "offset":
         vals = 10**15 + np.arange(d, dtype=np.int64) * int(rng.choice([1, 3, 1000]))
     else:
-        vals = np.arange(d, dtype=np.int64)
+        vals = np.arange(d, dtype=np.int64) * int(rng.choice([1, 1, 7]))
     k = vals[rng.integers(0, len(vals), n)]
+    if shape == "hot":      # a run of one value: a digit's region of a band overflows (band sort), a leaf region overflows (partitioned path)
+        a = int(rng.integers(0, n - n // 8))
+        k[a:a + n // 8] = vals[0]
     if shape == "outlier":
         k[int(rng.integers(0, n))] = -2**40
         k[int(rng.integers(0, n))] = 2**50
