@@ -804,12 +804,13 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 			  uint64_t cap, uint64_t *out_groups, bool *outside)
 {
 	*outside = false;
-	/* MDB_GROUP_TILED=1 switches the form on: measured at 10^8 rows (profiles/r05/group_tiled.json) it is no faster than the partitioned
-	 * path - 6.25 x 10^6 groups of 16: tile sort 0.25 + leaf 0.37 ms against first level 0.36 + leaf 0.21; unique keys 2.18 against 2.06 ms;
-	 * 2.5 x 10^7 groups spread over 2^27 values 1.54 against 1.77 - the leaf's walk over 3052 tiles' pieces is a chain of dependent round
-	 * trips; the parity tests run both */
-	if (kbits < 13u || kbits > 14u + RJ_MAX_DBITS || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
-	    !(getenv("MDB_GROUP_TILED") && getenv("MDB_GROUP_TILED")[0] == '1'))
+	/* Taken for windows of 2^26 and 2^27 values (below, the band sort of mdb_dev_bandgroup.hip serves; MDB_GROUP_TILED=1: every window from
+	 * 2^13 values on - the parity tests; =0: never).  At 10^8 rows (profiles/r05/group_forms.json): 2.5 x 10^7 groups spread over 2^27
+	 * values 1.20 ms against the partitioned path's 1.83; 10^8 unique keys 2.20 against 2.06 - the leaf's walk over 3052 tiles' pieces of
+	 * four words is bound by requests, and every row leaves it as a group record */
+	const char *const knob = getenv("MDB_GROUP_TILED");
+	const bool on = knob ? knob[0] == '1' : (kbits >= 26u && n >= ((uint64_t)1 << 24));	/* (measured at 10^8 rows only: large tables) */
+	if (!on || kbits < 13u || kbits > 14u + RJ_MAX_DBITS || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) || n < ((uint64_t)1 << 21))
 		return 1;
 	const uint32_t dbits = rg_group_dbits(kbits), sbits = kbits - dbits, D = 1u << dbits;
 	if (sbits > 14u)

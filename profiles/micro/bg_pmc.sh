@@ -16,11 +16,15 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0][:60]
-        if "k_bg_" not in k:
+        if "gen_keys" in k or "rocclr" in k:
             continue
         a = agg[k][row["Counter_Name"]]
         a[0] += 1
         a[1] += float(row["Counter_Value"])
+calls = 4.0   # group_trace.py runs the operator four times
+tot = 0.0
 for k, cs in sorted(agg.items()):
-    print(k, {c: (v[0], round(v[1] / v[0] / 1e6, 3)) for c, v in cs.items()}, "(launches, per launch in 1e6 units; FETCH_SIZE / WRITE_SIZE in KB -> GB: x 1e-6 ... x 2 for FETCH on gfx950)")
+    print(k, {c: (v[0], round(v[1] / v[0] / 1e6, 3)) for c, v in cs.items()}, "(launches, per launch in 1e6 units; FETCH_SIZE / WRITE_SIZE in KB)")
+    tot += (2.0 * cs["FETCH_SIZE"][1] + cs["WRITE_SIZE"][1]) * 1024.0 / calls if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs else 0.0
+print("HBM bytes per call (FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KB -> bytes): %.3f GB; algorithmic 8 B x 10^8 rows + 12 B x 6.25 x 10^6 groups = 0.875 GB" % (tot / 1e9))
 PY

@@ -198,6 +198,32 @@ def test_group_count_through_the_band_sort(dev, case, monkeypatch):
     assert torch.equal(f3, f) and torch.equal(c3, c)
 
 
+@pytest.mark.parametrize("span_bits", [26, 27])
+def test_group_count_windows_of_2e26_and_2e27_values_go_through_the_tile_sort(dev, span_bits):
+    """Where the band sort does not reach (windows of 2^26 and 2^27 key values) large tables take the tile sort by default
+    (mdb_group_count_tiled): 2 x 10^7 rows, ~1.3 rows per key, checked on the device against torch - COUNT per key, first row per key,
+    first-occurrence order"""
+    n, span = 20_000_000 + 4097, 1 << span_bits
+    g = torch.Generator(device="cuda")
+    g.manual_seed(span_bits)
+    kl = torch.randint(0, span, (n,), dtype=torch.int64, device="cuda", generator=g) - 5_000_000_000
+    dev.prof_enable(True)
+    dev.prof_reset()
+    f, c = dev.group_count(kl, None)
+    ran = {k for k, v in dev.prof_read().items() if v[0] > 0}
+    dev.prof_enable(False)
+    assert {"group_tile_sort", "group_tile_leaf"} <= ran and "group_band_sort" not in ran, ran
+    fi = f.to(torch.int64) & 0xFFFFFFFF
+    assert bool((fi[1:] > fi[:-1]).all())
+    keys = kl[fi]
+    uk, uc = torch.unique(kl, return_counts=True)
+    o = torch.argsort(keys)
+    assert torch.equal(keys[o], uk) and torch.equal(c[o], uc)
+    first = torch.full((uk.numel(),), n, dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, torch.searchsorted(uk, kl), torch.arange(n, device="cuda"), "amin")
+    assert torch.equal(first, fi[o])
+
+
 def test_group_count_golden_case10(dev):
     # reference tests/engine/executor_select.c:318-346 : id = 1,1,3,3,4 -> (1,2)(3,2)(4,1)
     k = np.array([1, 1, 3, 3, 4], dtype=np.int64)
