@@ -1,4 +1,4 @@
-"""One mdb_dev_group_count call at 10^8 rows under `rocprofv3 --kernel-trace`: the launch sequence of the LAST call (after warm-up), in order,
+"""One mdb_dev_group_count call (g16 | unique | g4) or one headline join + GROUP BY (joinD) at 10^8 rows under `rocprofv3 --kernel-trace`: the launch sequence of the LAST call (after warm-up), in order,
 with durations and the gaps between kernels.
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gtrace -- python3 profiles/micro/group_trace.py run
     python3 profiles/micro/group_trace.py show gpurun_out/gtrace"""
@@ -10,6 +10,13 @@ if sys.argv[1] == "run":
     dev = DeviceCtx(0)
     n = 100_000_000
     shape = sys.argv[2] if len(sys.argv) > 2 else "g16"
+    if shape == "joinD":      # the headline: A(10^8 unique keys) JOIN B(10^8 rows, 16 per key) GROUP BY key, COUNT(*)
+        a, b = dev.gen_keys(n, 0, n, 42, 0), dev.gen_keys(n, 0, n, 43, n // 16)
+        for _ in range(5):
+            k, c, f, j = dev.join_group_count(a, None, b, None)
+            torch.cuda.synchronize()
+        print("groups", k.numel(), dev.last_plan())
+        sys.exit(0)
     keys = dev.gen_keys(n, 0, n, 43, {"g16": n // 16, "unique": 0, "g4": n // 4}[shape])
     for _ in range(4):
         f, c = dev.group_count(keys, None)
@@ -26,7 +33,7 @@ else:
     ends = [int(r["End_Timestamp"]) for r in rows]
     cut = 0
     for i in range(1, len(rows)):
-        if starts[i] - ends[i - 1] > 150_000:
+        if "gen_keys" in rows[i - 1]["Kernel_Name"] or starts[i] - ends[i - 1] > 150_000:
             cut = i
     t0 = starts[cut]
     tot = 0

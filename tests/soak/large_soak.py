@@ -1,5 +1,6 @@
 """Randomised LARGE shapes (3 * 10^7 ... 1.2 * 10^8 rows per table: first-level tiles of 8192 keys, the one-pass 4096-digit form, the one-level
-pruned form with ranged ordering) against the multi-threaded C hash-join oracle - every call twice (the second runs on what the first learned):
+pruned form with ranged ordering) against the multi-threaded C hash-join oracle - every call twice (the second runs on what the first learned);
+then GROUP BY + COUNT(*) of the right table's column alone (band sort / tile sort / partitioned path by window), checked against torch on the device:
     python tests/soak/large_soak.py [cases]"""
 import sys, time
 import numpy as np
@@ -44,6 +45,21 @@ for seed in range(cases):
         if not ok:
             bad += 1
             print("MISMATCH", seed, shape, n_l, n_r, off, round_, dev.last_join_form(), hex(int(dev.lib.mdb_dev_last_join_filter(dev.h))), flush=True)
+    # single-table GROUP BY of the right table's column (duplicates: the band sort up to 2^25 key values, the tile sort at 2^26 / 2^27, the
+    # partitioned path beyond), checked on the device: first rows ascending, COUNT and first row of every key
+    for round_ in range(2):
+        gf, gc = dev.group_count(dr, None)
+        fi = gf.to(torch.int64) & 0xFFFFFFFF
+        keys = dr[fi]
+        uk, uc = torch.unique(dr, return_counts=True)
+        o = torch.argsort(keys)
+        first = torch.full((uk.numel(),), n_r, dtype=torch.int64, device=dr.device)
+        first.scatter_reduce_(0, torch.searchsorted(uk, dr), torch.arange(n_r, device=dr.device), "amin")
+        ok = bool((fi[1:] > fi[:-1]).all()) and keys.numel() == uk.numel() and torch.equal(keys[o], uk) and torch.equal(gc[o], uc) and torch.equal(first, fi[o])
+        if not ok:
+            bad += 1
+            print("GROUP BY MISMATCH", seed, shape, n_r, off, round_, dev.last_plan(), flush=True)
+        del gf, gc, fi, keys, uk, uc, o, first
     print(f"case {seed}: shape {shape}, {n_l} x {n_r} rows, {len(ek)} groups, form {dev.last_join_form()}, flags {hex(int(dev.lib.mdb_dev_last_join_filter(dev.h)))}", flush=True)
     del dl, dr, k, c, f
     torch.cuda.empty_cache()
