@@ -338,7 +338,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 			   uint64_t cap, uint64_t *out_groups, bool *outside)
 {
 	*outside = false;
-	if (kbits < 18u || kbits > 14u + BG_MAX_DBITS || n < ((uint64_t)1 << 22) || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
+	if (kbits < 18u || kbits > 14u + BG_MAX_DBITS || n < ((uint64_t)1 << 21) || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
 	    (getenv("MDB_GROUP_BANDED") && getenv("MDB_GROUP_BANDED")[0] == '0'))
 		return 1;
 	/* the regions overflowed on this very column last time (a hot key): not tried again for a while */

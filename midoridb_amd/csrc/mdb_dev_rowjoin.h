@@ -23,7 +23,7 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
 			  uint64_t cap, uint64_t *out_groups, bool *outside);
 
-/* ... through the band sort (mdb_dev_bandgroup.hip): windows of 2^18 ... 2^25 values, tables of 2^22 rows and more; same contract */
+/* ... through the band sort (mdb_dev_bandgroup.hip): windows of 2^18 ... 2^25 values, tables of 2^21 rows and more; same contract */
 int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
 			   uint64_t cap, uint64_t *out_groups, bool *outside);
 

@@ -11,7 +11,7 @@ dev = D.DeviceCtx(0)
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 t0 = time.time()
-sizes = [300_000, 1_500_000, 3_000_000, 4_700_001, 6_291_456]       # (the last two: the band sort's tables, 2^22 rows and more)
+sizes = [300_000, 1_500_000, 3_000_000, 4_700_001, 6_291_456]       # (from 2^21 rows on: the band sort, windows of 2^18 key values and more)
 bufs = {n: torch.empty(n, dtype=torch.int64, device=dev.device) for n in sizes}
 for seed in range(seeds):
     rng = np.random.default_rng(50_000 + seed)

@@ -142,6 +142,7 @@ def test_group_count_through_the_tile_sort(dev, case, monkeypatch):
     k = k.astype(np.int64)
     ef, ec = orc.group_count(k, None)
     monkeypatch.setenv("MDB_GROUP_TILED", "1")
+    monkeypatch.setenv("MDB_GROUP_BANDED", "0")     # (the band sort would serve most of these windows first)
     dev.prof_enable(True)
     dev.prof_reset()
     f, c = dev.group_count(dev.to_dev(k), None)
@@ -155,7 +156,7 @@ def test_group_count_through_the_tile_sort(dev, case, monkeypatch):
 @pytest.mark.parametrize("case", ["groups_of_17_2e18", "uniform_2e21", "bunched_first_rows_2e22", "sparse_2e24", "whole_bands", "hot_value", "negative_keys"])
 def test_group_count_through_the_band_sort(dev, case, monkeypatch):
     """GROUP BY key + COUNT(*) of a NULL-free column through the band sort (mdb_dev_bandgroup.hip: 4-byte row words, the default for windows of
-    2^18 ... 2^25 key values from 2^22 rows on): first row and COUNT per key in first-row order, bit-exact against the oracle - a ragged last tile
+    2^18 ... 2^25 key values from 2^21 rows on): first row and COUNT per key in first-row order, bit-exact against the oracle - a ragged last tile
     and band, windows at both ends of the range, first rows bunched at the table's start, keys far from zero; a hot value overflows its region:
     the other forms answer (same result), and the column is remembered"""
     rng = np.random.default_rng(len(case) + 5)
@@ -1621,7 +1622,7 @@ def test_key_windows_up_to_2e23_are_partitioned_once_and_joined_by_wide_direct_l
     2^(k - 9) entries, 16-bit row counts) instead of two levels and k_leaf_direct.  Same groups, counts, first rows and order
     as the oracle and as the two-level form (MDB_ONE_LEVEL=0)."""
     narrow_mode(1)
-    monkeypatch.setenv("MDB_GROUP_BANDED", "0")     # (single-table GROUP BY from 2^22 rows on goes through the band sort by default: its own test)
+    monkeypatch.setenv("MDB_GROUP_BANDED", "0")     # (single-table GROUP BY from 2^21 rows on goes through the band sort by default: its own test)
     rng = np.random.default_rng(len(shape) * 101 + 7)
     nl = nr = None
     has_r = True
