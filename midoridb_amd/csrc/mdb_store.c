@@ -11,6 +11,7 @@
 #define _XOPEN_SOURCE 700
 #define _DEFAULT_SOURCE
 #include <time.h>
+#include <sys/mman.h>
 #include "mdb_host.h"
 
 struct mdb_table *mdb_catalog_find(struct mdb_catalog *cat, const char *name)
@@ -223,6 +224,18 @@ int mdb_table_add_column(struct mdb_table *t, const char *name, int type)
 	return MIDORIDB_OK;
 }
 
+/* A column of millions of rows is first touched by the bulk loader's threads: with 4 KiB pages that is 2.4 x 10^5 page faults per GB - most of
+ * what an ingest of host arrays costs.  Where the kernel hands out transparent huge pages on request (THP "madvise"), ask for them (2 MiB
+ * pages: 512 x fewer faults); MDB_INGEST_THP=0: do not ask. */
+static void mdb_ask_huge_pages(void *p, size_t bytes)
+{
+	const uintptr_t a = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+	const char *knob = getenv("MDB_INGEST_THP");
+	if (bytes < ((size_t)8 << 20) || e <= a || (knob && knob[0] == '0'))
+		return;
+	(void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);	/* (advice: a kernel without THP says EINVAL, nothing depends on it) */
+}
+
 int mdb_table_reserve(struct mdb_table *t, uint64_t rows)
 {
 	uint64_t ncap;
@@ -238,6 +251,7 @@ int mdb_table_reserve(struct mdb_table *t, uint64_t rows)
 		if (!nd)
 			return -MIDORIDB_NOMEM;
 		t->cols[c].data = nd;
+		mdb_ask_huge_pages(nd, sizeof(int64_t) * ncap);
 		nb = realloc(t->cols[c].nullbits, sizeof(uint64_t) * new_words);
 		if (!nb)
 			return -MIDORIDB_NOMEM;
