@@ -313,6 +313,20 @@ void op_stats_begin(struct exec *x, const struct mdb_expr *fl, const void *pl, c
 	(void)mdb_dev_call_stats(x->dev, pl, &st[0], fr ? pr : NULL, fr ? &st[1] : NULL);
 }
 
+/* Most groups a GROUP BY over the key field f can have, by the catalog: a group needs a key value, and the column holds at most
+ * max - min + 1 of them (a filtered stream of the column: fewer).  `rows` when nothing is known. */
+uint64_t op_groups_bound(struct exec *x, const struct mdb_expr *f, uint64_t rows)
+{
+	int64_t lo, hi;
+	if (x->cat->dist || !f || f->kind != MDB_EX_FIELD || f->tbl_idx < 0 || x->orig_tab[f->tbl_idx])
+		return rows;
+	struct mdb_table *tb = x->s->tabs[f->tbl_idx].t;
+	if (mdb_col_range(x->cat, tb, &tb->cols[f->col_idx], &lo, &hi) != MIDORIDB_OK || lo > hi)
+		return rows;
+	const uint64_t span = (uint64_t)hi - (uint64_t)lo;	/* (max - min: + 1 below, unless that is 2^64) */
+	return span + 1 && span + 1 < rows ? span + 1 : rows;
+}
+
 void op_stats_end(struct exec *x)
 {
 	(void)mdb_dev_call_stats(x->dev, NULL, NULL, NULL, NULL);
@@ -835,6 +849,12 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		    (rc = fused_operand(&x, 1, fkeys[1], ws.push[1], ws.npush[1], &rv, &rn, &nr_rows)))
 			goto out;
 		uint64_t cap = nl_rows ? nl_rows : 1, G = 0, J = 0;
+		/* a group of the join needs a key that both sides hold: no more groups than rows or key values of either column (catalog
+		 * statistics) - the output columns are sized for that, and become the result's own without a copy when the bound is close */
+		if (!cat->dist && fkeys[0]->type != MDB_CT_DOUBLE) {
+			cap = op_groups_bound(&x, fkeys[0], cap);
+			cap = op_groups_bound(&x, fkeys[1], cap < nr_rows ? cap : (nr_rows ? nr_rows : 1));
+		}
 		bool multi_done = false;
 		const bool text_keys = cat->dist && fkeys[0]->type == MDB_CT_VARCHAR;
 		if (text_keys) {
@@ -1208,15 +1228,21 @@ exchange_rows:
 					goto grouped;
 				}
 			}
-			first = dalloc(&x, (x.n ? x.n : 1) * 4);
-			x.d_count = dalloc(&x, (x.n ? x.n : 1) * 8);
+			/* (no more groups than key values in the column's range - catalog statistics -, plus the NULL group) */
+			uint64_t gcap = x.n ? x.n : 1;
+			if (s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE) {
+				const uint64_t b = op_groups_bound(&x, s->group[0], gcap);
+				gcap = b + 1 < gcap ? b + 1 : gcap;
+			}
+			first = dalloc(&x, gcap * 4);
+			x.d_count = dalloc(&x, gcap * 8);
 			if (!first || !x.d_count) {
 				rc = dev_fail(&x, "allocating group outputs");
 				goto out;
 			}
 			if (s->group[0]->kind == MDB_EX_FIELD && s->group[0]->type != MDB_CT_DOUBLE)
 				op_stats_begin(&x, s->group[0], kv, NULL, NULL);
-			const int grc = x.n ? mdb_dev_group_count(x.dev, kv, kn, x.n, MDB_ORDER_FIRST, first, x.d_count, x.n, &G) : 0;
+			const int grc = x.n ? mdb_dev_group_count(x.dev, kv, kn, x.n, MDB_ORDER_FIRST, first, x.d_count, gcap, &G) : 0;
 			op_stats_end(&x);
 			if (grc) {
 				rc = dev_fail(&x, "group count");

@@ -124,5 +124,6 @@ int dml_select_rows(struct mdb_catalog *cat, struct mdb_dml *d, struct exec *x, 
 /* the catalog's statistics of an operator call's key columns (mdb_exec.c) */
 void op_stats_begin(struct exec *x, const struct mdb_expr *fl, const void *pl, const struct mdb_expr *fr, const void *pr);
 void op_stats_end(struct exec *x);
+uint64_t op_groups_bound(struct exec *x, const struct mdb_expr *f, uint64_t rows);
 
 #endif
