@@ -2231,7 +2231,8 @@ static bool gc_learned_selective(const mdb_dev_ctx *ctx, const int64_t *keys_l, 
 	       ctx->lg_groups < n_l / 4;
 }
 
-static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *wlo)
+/* exact: [lo, hi] is the catalog's range of the column (every key lies inside), not a sample's: no margin around it */
+static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *wlo, bool exact = false)
 {
 	*kbits = 0;
 	*wlo = 0;
@@ -2240,7 +2241,7 @@ static void gc_compact_window(int64_t lo, int64_t hi, uint32_t *kbits, int64_t *
 	const uint64_t span = (uint64_t)hi - (uint64_t)lo;
 	if (span >= (1ull << 31))
 		return;
-	const uint64_t pad = span / 16 + 4096, need = span + 2 * pad + 1;
+	const uint64_t pad = exact ? 0 : span / 16 + 4096, need = span + 2 * pad + 1;
 	uint32_t k = 8;
 	while ((1ull << k) < need)
 		k++;
@@ -3129,7 +3130,7 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 			uint32_t kb = 0;
 			int64_t wlo = 0;
 			if (lo <= hi)
-				gc_compact_window(lo, hi, &kb, &wlo);
+				gc_compact_window(lo, hi, &kb, &wlo, ctx->pl_from_stats != 0);
 			if (!kb)
 				break;
 			bool outside = false;

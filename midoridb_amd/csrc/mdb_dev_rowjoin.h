@@ -27,4 +27,10 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
 			   uint64_t cap, uint64_t *out_groups, bool *outside);
 
+/* ---- groups of nearly unique keys as one bit per row + exceptions (mdb_dev_dense.hip) */
+size_t mdb_dense_arena_bytes(uint64_t n);
+int mdb_dense_bits_begin(mdb_dev_ctx *ctx, uint64_t n, unsigned long long **bits);
+int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n, const unsigned long long *exc, uint32_t n_exc, uint32_t *out_first,
+		   int64_t *out_count);
+
 #endif

@@ -270,8 +270,8 @@ __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
  * has in flight: `load(unit, i)` is called for UNITS pieces' words first (it only ISSUES loads into the caller's registers), then
  * `use(unit, i)` for each of them; words beyond a piece's first LPP go through `slow(i)` (load and use in one), rarely.
  * All lanes of the wave call it together. */
-template <int LPP, int UNITS, typename FL, typename FU, typename FS>
-__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow)
+template <int LPP, int UNITS, typename FL, typename FU, typename FS, typename FD>
+__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, FD done /* after the `use`s of a batch */)
 {
 	constexpr int RJ_G = LPP >= 32 ? 1 : 32 / LPP;	/* tile groups per sweep: 32 (64) pieces' steps per lane and sweep */
 	static_assert(LPP >= 8 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
@@ -309,6 +309,7 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 			for (int u = 0; u < UNITS; u++)
 				if (on[u])
 					use(u, idx[u]);
+			done();
 		}
 		if (__any(longest > (uint32_t)LPP)) {		/* pieces longer than LPP words: their rest, one step at a time */
 #pragma unroll 1
@@ -324,6 +325,12 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 				}
 		}
 	}
+}
+
+template <int LPP, int UNITS, typename FL, typename FU, typename FS>
+__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow)
+{
+	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, slow, [] {});
 }
 
 /* The same for pieces of 32 words and more (windows of up to 2^24 values: 1024 digits and fewer): the whole wave walks one piece after
@@ -689,7 +696,131 @@ struct rg_group_args {
 	uint32_t rec_cap;
 	uint32_t *groups;
 	uint32_t *status;
+	/* k_rj_group_leaf_dense (nearly unique keys, mdb_dev_dense.hip): one bit per row - cleared here for every row that is not the first of
+	 * its key - and the keys with more than one row as exceptions (first row << 32 | COUNT) */
+	unsigned int *dense_bits;	/* NULL: the pilot - duplicates are only counted */
+	unsigned long long *exc;
+	uint32_t exc_cap;
+	uint32_t *dense_cnt;		/* [0] rows that are not the first of their key, [1] exceptions, [2] rows seen */
 };
+
+/* ---- the same walk for a column whose keys are nearly unique: no record per group.  A row that meets an earlier row of its key in the
+ * table of smallest row ids is, or makes that one, a row that is not the key's first: min(old, new) stays, max(old, new) is settled - its
+ * bit is cleared (every row but the final smallest is settled exactly once).  Launched over the first `gridDim.x` digits only with
+ * dense_bits = NULL it is the pilot that says how many rows of a sample of the KEYS are duplicates. */
+template <int LPP>
+__global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf_dense(rg_group_args a)
+{
+	extern __shared__ uint32_t rg_lds[];
+	const uint32_t S = 1u << a.sbits;
+	uint32_t *const s_first = rg_lds, *const s_count = rg_lds + S;
+	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D), lane = mdb_lane(), wave = threadIdx.x >> 6;
+	for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+		s_first[i] = 0xFFFFFFFFu;
+		s_count[i] = 0u;
+	}
+	__syncthreads();
+	uint32_t dups = 0;
+	{
+		/* (the table's answer - the smallest row so far - is needed here: a batch's 16 requests go out together, then the answers are
+		 * looked at; one at a time every row would wait for its own round trip to the LDS) */
+		constexpr int UG = LPP >= 32 ? 8 : 16;		/* (three registers per request in flight) */
+		uint32_t w[UG], rw[UG], pv[UG];
+		uint32_t live = 0;
+		auto settle = [&](uint32_t prev, uint32_t row) {
+			if (prev != 0xFFFFFFFFu) {
+				const uint32_t loser = prev > row ? prev : row;
+				if (a.dense_bits)
+					atomicAnd(&a.dense_bits[loser >> 5], ~(1u << (loser & 31u)));
+				dups++;
+			}
+		};
+		auto ask = [&](int u, uint32_t word, uint32_t idx) {
+			const uint32_t slot = word >> RJ_TILE_BITS;
+			rw[u] = (idx / RJ_STRIDE) * RJ_TILE + (word & (RJ_TILE - 1u));
+			pv[u] = atomicMin(&s_first[slot], rw[u]);
+			atomicAdd(&s_count[slot], 1u);
+			live |= 1u << u;
+		};
+		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
+				       [&](int u, uint32_t idx) { ask(u, w[u], idx); },
+				       [&](uint32_t idx) {
+					       const uint32_t word = a.words[idx], slot = word >> RJ_TILE_BITS,
+							      row = (idx / RJ_STRIDE) * RJ_TILE + (word & (RJ_TILE - 1u));
+					       const uint32_t prev = atomicMin(&s_first[slot], row);
+					       atomicAdd(&s_count[slot], 1u);
+					       settle(prev, row);
+				       },
+				       [&] {
+#pragma unroll
+					       for (int u = 0; u < UG; u++)
+						       if (live & (1u << u))
+							       settle(pv[u], rw[u]);
+					       live = 0;
+				       });
+	}
+	__syncthreads();
+	uint32_t groups = 0, nexc = 0, rows = 0;
+	for (uint32_t i0 = wave * 64u; i0 < S; i0 += blockDim.x) {
+		const uint32_t c = i0 + lane < S ? s_count[i0 + lane] : 0u;
+		groups += c ? 1u : 0u;
+		nexc += c > 1u ? 1u : 0u;
+		rows += c;
+	}
+#pragma unroll
+	for (int o = 32; o; o >>= 1) {
+		dups += (uint32_t)__shfl_xor((int)dups, o, MDB_WAVE);
+		groups += (uint32_t)__shfl_xor((int)groups, o, MDB_WAVE);
+		nexc += (uint32_t)__shfl_xor((int)nexc, o, MDB_WAVE);
+		rows += (uint32_t)__shfl_xor((int)rows, o, MDB_WAVE);
+	}
+	/* one atomic per counter and WORKGROUP (every wave on its own: 5 x 10^5 atomics on three addresses - 2 ms of a 3 ms kernel) */
+	__shared__ uint32_t s_sum[4][RJ_LEAF_THREADS / 64];
+	__shared__ uint32_t s_ebase;
+	const uint32_t nwaves = blockDim.x >> 6;
+	if (lane == 0) {
+		s_sum[0][wave] = dups;
+		s_sum[1][wave] = groups;
+		s_sum[2][wave] = rows;
+		s_sum[3][wave] = nexc;
+	}
+	__syncthreads();
+	if (threadIdx.x < 4u) {
+		uint32_t t = 0;
+		for (uint32_t w = 0; w < nwaves; w++)
+			t += s_sum[threadIdx.x][w];
+		if (t) {
+			if (threadIdx.x == 0)
+				atomicAdd(&a.dense_cnt[0], t);
+			else if (threadIdx.x == 1)
+				atomicAdd(a.groups, t);
+			else if (threadIdx.x == 2)
+				atomicAdd(&a.dense_cnt[2], t);
+			else
+				s_ebase = atomicAdd(&a.dense_cnt[1], t);
+		} else if (threadIdx.x == 3) {
+			s_ebase = 0u;
+		}
+	}
+	__syncthreads();
+	uint32_t ebase = s_ebase;
+	for (uint32_t w = 0; w < wave; w++)
+		ebase += s_sum[3][w];
+	if (!a.exc || !nexc)
+		return;
+	if (ebase + nexc > a.exc_cap) {		/* (more keys with several rows than the list holds: the caller takes the record form) */
+		if (lane == 0)
+			mdb_raise(a.status, 16384u);
+		return;
+	}
+	for (uint32_t i0 = wave * 64u; i0 < S; i0 += blockDim.x) {
+		const uint32_t c = i0 + lane < S ? s_count[i0 + lane] : 0u;
+		const uint64_t m = __ballot(c > 1u);
+		if (c > 1u)
+			a.exc[ebase + (uint32_t)__popcll(m & mdb_lanemask_lt())] = ((unsigned long long)s_first[i0 + lane] << 32) | c;
+		ebase += (uint32_t)__popcll(m);
+	}
+}
 
 template <int LPP>
 __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf(rg_group_args a)
@@ -829,6 +960,9 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	if (ranged)
 		need += mdb_align_up((size_t)rg_n * ORDER_RANGE_CAP * 8) + mdb_align_up((size_t)rg_n * 4);
+	const bool dense_ok = n >= ((uint64_t)1 << 22) && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
+	if (dense_ok)
+		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
@@ -867,6 +1001,71 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	const uint32_t threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
 	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : dbits == 11 ? 32 : 64;
 	uint64_t *h = ctx->h_pinned;
+#define RJ_LAUNCH_DENSE(L, GRID)                                                                                                                  \
+	do {                                                                                                                                      \
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_group_leaf_dense<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)8 << sbits))); \
+		MDB_LAUNCH_LDS(ctx, "group_tile_leaf_dense", (k_rj_group_leaf_dense<L>), (GRID), threads, (size_t)8 << sbits, ga);                     \
+	} while (0)
+#define RJ_LAUNCH_DENSE_ANY(GRID)                                                                                                                 \
+	do {                                                                                                                                      \
+		if (lpp == 8)                                                                                                                     \
+			RJ_LAUNCH_DENSE(8, GRID);                                                                                                 \
+		else if (lpp == 16)                                                                                                               \
+			RJ_LAUNCH_DENSE(16, GRID);                                                                                                \
+		else if (lpp == 32)                                                                                                               \
+			RJ_LAUNCH_DENSE(32, GRID);                                                                                                \
+		else                                                                                                                              \
+			RJ_LAUNCH_DENSE(64, GRID);                                                                                                \
+	} while (0)
+	/* Nearly unique keys?  A pilot over 64 of the digits - a fair sample of the KEYS: all rows of a key are in one digit - counts the rows
+	 * that are not the first of their key.  One in 16 at most: the groups leave as one bit per row + exceptions (mdb_dev_dense.hip)
+	 * instead of a record each and a sort of the records.  MDB_GROUP_DENSE=0: never. */
+	if (dense_ok) {
+		ga.dense_cnt = ctx->d_status + 4;
+		ga.dense_bits = NULL;
+		ga.exc = NULL;
+		RJ_LAUNCH_DENSE_ANY(D < 64u ? D : 64u);
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t *ps = reinterpret_cast<const uint32_t *>(&h[1]);
+		if (ps[0] & 128u) {
+			*outside = true;
+			return 1;
+		}
+		const uint64_t pilot_dups = ps[4], pilot_rows = ps[6];
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 7 * sizeof(uint32_t), ctx->stream));
+		if (pilot_rows && pilot_dups * 16u <= pilot_rows) {
+			unsigned long long *bits = NULL;
+			const uint64_t exc_cap = n / 8 + 4096;
+			if ((rc = mdb_dense_bits_begin(ctx, n, &bits)))
+				return rc;
+			ga.dense_bits = reinterpret_cast<unsigned int *>(bits);
+			ga.exc = (unsigned long long *)mdb_arena_take(ctx, exc_cap * 8);
+			if (!ga.exc)
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a tile-sorted column: %s", ctx->err);
+			ga.exc_cap = (uint32_t)exc_cap;
+			RJ_LAUNCH_DENSE_ANY(D);
+			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
+			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			const uint32_t dstatus = ps[0], groups = ps[1], n_exc = ps[5];
+			if (getenv("MDB_DEBUG_GROUP"))
+				fprintf(stderr, "group_count (tile sort, dense): pilot %llu of %llu rows not first; %u groups, %u rows not first, %u exceptions, status %u\n",
+					(unsigned long long)pilot_dups, (unsigned long long)pilot_rows, groups, ps[4], n_exc, dstatus);
+			if (!(dstatus & 16384u) && (uint64_t)groups + ps[4] == n) {
+				if (groups > cap)
+					return mdb_set_err(ctx, -MIDORIDB_ERROR, "GROUP BY: %u groups, room for %llu", groups, (unsigned long long)cap);
+				if ((rc = mdb_dense_emit(ctx, bits, n, ga.exc, n_exc, out_first, out_count)))
+					return rc;
+				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				*out_groups = groups;
+				return MIDORIDB_OK;
+			}
+			/* (the exception list overflowed - the pilot's digits were not typical: the record form below) */
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 8 * sizeof(uint32_t), ctx->stream));
+		}
+	}
+#undef RJ_LAUNCH_DENSE_ANY
+#undef RJ_LAUNCH_DENSE
 	for (int attempt = ranged ? 0 : 1; attempt < 2; attempt++) {
 		if (attempt == 0) {
 			ga.rg_rec = (unsigned long long *)mdb_arena_take(ctx, (size_t)rg_n * ORDER_RANGE_CAP * 8);
