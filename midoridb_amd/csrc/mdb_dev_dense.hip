@@ -38,7 +38,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_count(const unsigned long 
 
 /* base[b] = groups before block b.  wordbase[w] = groups before the 64 rows of word w (the exceptions find their ranks with it). */
 __global__ __launch_bounds__(DN_THREADS) void k_dense_expand(const unsigned long long *__restrict__ bits, uint64_t n, const uint32_t *__restrict__ base,
-							      uint32_t *__restrict__ wordbase, uint32_t *__restrict__ out_first, int64_t *__restrict__ out_count)
+							      uint32_t *__restrict__ wordbase, uint32_t *__restrict__ out_first, int64_t *__restrict__ out_count,
+							      const int64_t *__restrict__ keys, uint32_t keys32, int64_t *__restrict__ out_key)
 {
 	__shared__ uint32_t s_tmp[32];
 	__shared__ unsigned long long s_w[DN_THREADS];
@@ -58,8 +59,12 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_expand(const unsigned long
 		const unsigned long long ww = s_w[wave * 64u + k];	/* (the same word for the whole wave: one broadcast read) */
 		if ((ww >> lane) & 1ull) {
 			const uint32_t pos = s_b[wave * 64u + k] + (uint32_t)__popcll(ww & below);
-			out_first[pos] = (uint32_t)(((uint64_t)blockIdx.x * DN_THREADS + wave * 64u + k) * 64u + lane);
+			const uint32_t row = (uint32_t)(((uint64_t)blockIdx.x * DN_THREADS + wave * 64u + k) * 64u + lane);
+			if (out_first)
+				out_first[pos] = row;
 			out_count[pos] = 1;
+			if (out_key)		/* (the join's group key: the left table's key of the group's first row - consecutive lanes, consecutive rows) */
+				out_key[pos] = keys32 ? (int64_t)reinterpret_cast<const int32_t *>(keys)[row] : keys[row];
 		}
 	}
 }
@@ -96,7 +101,7 @@ int mdb_dense_bits_begin(mdb_dev_ctx *ctx, uint64_t n, unsigned long long **bits
 /* out_first[g] / out_count[g] of the `groups` set bits among the first n, COUNT 1 but for the n_exc exceptions.  No host sync; the set
  * bits are the caller's count of groups (the leaf kernel counted them): checked by the caller against its output capacity before. */
 int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n, const unsigned long long *exc, uint32_t n_exc, uint32_t *out_first,
-		   int64_t *out_count)
+		   int64_t *out_count, const int64_t *keys, bool keys32, int64_t *out_key)
 {
 	const uint64_t nwords = (n + 63) / 64, nblocks = (nwords + DN_THREADS - 1) / DN_THREADS;
 	if (nblocks >= 0x7FFFFFFFull)
@@ -118,7 +123,8 @@ int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n,
 	}
 	if (rc)
 		return rc;
-	MDB_LAUNCH(ctx, "dense_expand", k_dense_expand, (uint32_t)nblocks, DN_THREADS, bits, n, base, wordbase, out_first, out_count);
+	MDB_LAUNCH(ctx, "dense_expand", k_dense_expand, (uint32_t)nblocks, DN_THREADS, bits, n, base, wordbase, out_first, out_count, keys, keys32 ? 1u : 0u,
+		   out_key);
 	if (n_exc) {
 		const uint32_t grid = (n_exc + 255u) / 256u;
 		MDB_LAUNCH(ctx, "dense_patch", k_dense_patch, grid < 4096u ? grid : 4096u, 256, exc, n_exc, bits, wordbase, out_count);

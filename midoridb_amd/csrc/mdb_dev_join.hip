@@ -1473,6 +1473,8 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		else
 			need += mdb_filter_arena_bytes(st->n_l);
 	}
+	if (st->wide12 && !st->nextra)	/* (the groups as one bit per left row + exceptions, mdb_dev_dense.hip) */
+		need += mdb_dense_arena_bytes(st->n_l) + mdb_align_up((st->n_l / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
@@ -1761,6 +1763,29 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		a.rg_shift = ORDER_RANGE_BITS;
 		a.rg_n = rg_n;
 	}
+	/* The last join over these columns made nearly every left row a group of COUNT 1 (a primary key joined with another, or with its
+	 * foreign keys - BASELINE configs[2]'s variant U): k_leaf_wide12 then clears one bit per left row that is NO group's first row and
+	 * lists the groups whose COUNT is not 1, instead of a record per group and the ordering sort of 10^8 records (MDB_JOIN_BITS=0: never) */
+	unsigned long long *dn_bits = NULL;
+	a.dn_bits = NULL;
+	a.dn_exc = NULL;
+	a.dn_exc_cap = 0;
+	a.dn_cnt = ctx->d_status + 12;
+	if (st->wide12 && !st->nextra && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l &&
+	    ctx->lg_kr == keys_r && ctx->lg_nr == n_r && ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16 &&
+	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
+		if (ctx->dn_distrust > 0) {
+			ctx->dn_distrust--;
+		} else {
+			if ((rc = mdb_dense_bits_begin(ctx, n_l, &dn_bits)))
+				return rc;
+			a.dn_bits = reinterpret_cast<unsigned int *>(dn_bits);
+			a.dn_exc_cap = (uint32_t)(n_l / 8 + 4096);
+			a.dn_exc = (unsigned long long *)mdb_arena_take(ctx, (size_t)a.dn_exc_cap * 8);
+			if (!a.dn_exc)
+				return -MIDORIDB_INTERNAL;
+		}
+	}
 	{
 		/* persistent grid: two 75 KiB workgroups fit one CU's 160 KiB of LDS */
 		const uint32_t resident = 2u * (uint32_t)ctx->num_cus;
@@ -1837,8 +1862,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			return rc;
 		ordered_early = true;
 	}
-	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 56, hipMemcpyDeviceToHost, ctx->stream));	/* (words 12, 13: the bit-per-row form's counters) */
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t dn_cleared = reinterpret_cast<const uint32_t *>(&h[1])[12], dn_exceptions = reinterpret_cast<const uint32_t *>(&h[1])[13];
 	if (leaf4 && ((uint32_t)h[1] & (4096u | 8192u)) && !((uint32_t)h[1] & (2u | 128u))) {
 		/* a key with more rows than k_leaf_wide4's count fields hold: the same partitioned tables through k_leaf_wide (16-bit counts), now
 		 * and for these columns; a range of row ids with more groups than its region holds (more groups than last time, or bunched):
@@ -1978,7 +2004,18 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		/* (one-level leaves report the largest first row id: the sort's first-level regions are sized for the digits below it) */
 		const uint64_t last_first = (uint32_t)(h[5] >> 32);
 		const uint64_t n_ord = (st->one_level && last_first && last_first < n_l) ? last_first + 1 : n_l;
-		if (ranged && ordered_early)
+		if (dn_bits) {
+			if (getenv("MDB_DEBUG_GROUP"))
+				fprintf(stderr, "join + GROUP BY (bit per left row): %llu groups, %u rows cleared of %llu, %u exceptions, status %u\n",
+					(unsigned long long)G, dn_cleared, (unsigned long long)n_l, dn_exceptions, status);
+			if ((status & 131072u) || (uint64_t)G + dn_cleared != n_l) {	/* (more groups of COUNT != 1 than last time: the record form) */
+				ctx->dn_distrust = 32;
+				return GC_RETRY_NODENSE;
+			}
+			rc = mdb_dense_emit(ctx, dn_bits, n_l, a.dn_exc, dn_exceptions, out_first, out_count, keys_l, st->keys32, out_key);
+			if (!rc)
+				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		} else if (ranged && ordered_early)
 			rc = MIDORIDB_OK;	/* (done, and waited for with the status words) */
 		else if (ranged)
 			rc = order_presorted(ctx, a.rg_rec, a.rg_cnt, rg_n, kbits, out_first, out_count, keys_l, out_key, st->keys32, keyed_cbits, st->key_bits,
@@ -2021,6 +2058,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		ctx->lg_kr = keys_r;
 		ctx->lg_nr = n_r;
 		ctx->lg_groups = G;
+		ctx->lg_joined = joined;
 		ctx->lg_valid = true;
 	}
 	ctx->last_narrow = st->direct ? 2 : (st->narrow ? 1 : 0);
@@ -2488,7 +2526,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		}	/* (gc_begin then also leaves the narrow form of a join: it is only built on the fast layout) */
 		else if (rc == GC_RETRY_DENSE)
 			records = false;
-		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 || rc == GC_RETRY_TWO_LEVEL)
+		else if (rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 || rc == GC_RETRY_TWO_LEVEL || rc == GC_RETRY_NODENSE)
 			;		/* (gc_finish has set ctx->keyed_distrust / cleared ctx->r32_ok / noted the columns in ctx->lw_bad_*) */
 		else if (rc == GC_RETRY_BUILD_L)
 			no_build_r = true;
@@ -2925,7 +2963,7 @@ static int gc_split_finish(mdb_dev_ctx *ctx, const int64_t *keys_r, const uint64
 	rc = gc_finish(ctx, st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
 	st->keys_l = NULL;
 	if (rc == GC_RETRY_EXACT || rc == GC_RETRY_DENSE || rc == GC_RETRY_BUILD_L || rc == GC_RETRY_WIDE || rc == GC_RETRY_PLAIN || rc == GC_RETRY_UNKEYED || rc == GC_RETRY_REC64 ||
-	    rc == GC_RETRY_TWO_LEVEL)	/* skew / huge counts / wide keys: redo the whole operator */
+	    rc == GC_RETRY_TWO_LEVEL || rc == GC_RETRY_NODENSE)	/* skew / huge counts / wide keys: redo the whole operator */
 		rc = group_count_common(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, true, false, out_key, out_count, out_first,
 					cap, out_groups, out_joined, keys32);
 	return rc;

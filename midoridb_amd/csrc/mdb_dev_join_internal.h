@@ -122,6 +122,13 @@ struct gc_args {
 	unsigned long long *rg_rec;
 	uint32_t *rg_cnt;
 	uint32_t rg_cap, rg_shift, rg_n;
+	/* k_leaf_wide12, dn_bits != NULL (nearly every left row a group of COUNT 1 - remembered from the last call over these columns): no
+	 * record per group.  One bit per LEFT row, set by the caller, cleared here for every row that is no group's first row (no partner, or
+	 * not the first of its key); groups whose COUNT is not 1 are appended to dn_exc as first row << 32 | COUNT (mdb_dev_dense.hip expands) */
+	unsigned int *dn_bits;
+	unsigned long long *dn_exc;
+	uint32_t dn_exc_cap;
+	uint32_t *dn_cnt;		/* [0] bits cleared, [1] exceptions */
 	uint32_t nextra;
 	const uint32_t *hv_x[GC_MAX_EXTRA];
 	const uint32_t *cnt_x[GC_MAX_EXTRA];
@@ -186,6 +193,7 @@ __device__ static inline unsigned long long lw_block_sum(unsigned long long v, u
 #define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
 #define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
 #define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
+#define GC_RETRY_NODENSE 1008	/* internal: the bit-per-row form of the groups met more groups of COUNT != 1 than its list holds (ctx->dn_distrust is set) */
 #define GC_RETRY_REC64 1006	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
 #define GC_NOT_SERVED 1008	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of
 				 * counts overflowed, or a hot leaf): the caller chains two-table operators instead */

@@ -277,7 +277,7 @@ __device__ static inline void lw12_barrier(void)
 /* NX = 1: a further right table on the same key (A JOIN B ON a = b JOIN C ON a = c GROUP BY a: BASELINE configs[4]) - partitioned like the
  * first one; its rows are counted into the (still unused) 4-bit fields, the two counts multiplied into the 5-bit field before the left rows
  * come (a product beyond 31, or 16 rows of a key in the further table: flag 1024 like every count that does not fit). */
-template <int NX>
+template <int NX, bool DN = false /* the bit-per-row form of the groups (gc_args.dn_bits; two tables only) */>
 __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t rem /* hash bits below the digit */, uint32_t nsub)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		fetch_all(leaf, 0, 2);
 	}
 	unsigned long long joined = 0;
+	uint32_t cleared = 0;		/* (bit-per-row form) rows found not to be a group's first row */
 	uint32_t last_first = 0;	/* largest first row id of this workgroup's groups */
 	uint32_t it = 0;
 	bool bad = false;		/* (uniform) a digit whose words do not fit the registers, or whose counts overflowed */
@@ -534,6 +535,35 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			for (uint32_t k = 0; k < 4u; k++)
 				fcv[k] = s_fc[w[k] & mask];	/* (a header's or an absent word's slot is read and ignored) */
 			uint32_t row2 = cur << 1;	/* the tile's first row (the header's top bit leaves) */
+			if (DN) {
+				/* the bit-per-row form: the table's answer - the smallest row so far - says which of two rows of a key is NOT its first
+				 * (four requests go out, then the answers are looked at); a row without partner is no group at all */
+				uint32_t prev[4], rowk[4];
+#pragma unroll
+				for (uint32_t k = 0; k < 4u; k++) {
+					const bool hdr = (w[k] >> 31) != 0u;
+					row2 = hdr ? w[k] << 1 : row2;
+					const uint32_t idx = w[k] & mask, fc = fcv[k];
+					rowk[k] = row2 + ((w[k] >> 15) & 0x7FFFu);
+					prev[k] = 0xFFFFFFFEu;	/* (header / absent word) */
+					if (k < nv && !hdr) {
+						prev[k] = 0xFFFFFFFFu;	/* (no partner) */
+						if (fc >> 27) {
+							prev[k] = atomicMin(&s_fc[idx], (fc & 0xF8000000u) | rowk[k]) & 0x07FFFFFFu;
+							atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
+							adds++;
+						}
+					}
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < 4u; k++) {
+					if (prev[k] == 0xFFFFFFFEu || prev[k] == 0x07FFFFFFu)
+						continue;	/* (nothing there, or the key's first row so far) */
+					const uint32_t loser = prev[k] == 0xFFFFFFFFu ? rowk[k] : (prev[k] > rowk[k] ? prev[k] : rowk[k]);
+					atomicAnd(&a.dn_bits[loser >> 5], ~(1u << (loser & 31u)));
+					cleared++;
+				}
+			} else {
 #pragma unroll
 			for (uint32_t k = 0; k < 4u; k++) {
 				const bool hdr = (w[k] >> 31) != 0u;
@@ -544,6 +574,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					atomicAdd(&s_cl[idx >> 3], 1u << ((idx & 7u) * 4u));
 					adds++;
 				}
+			}
 			}
 		}
 		lw12_barrier();
@@ -574,7 +605,10 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			for (int w = 0; w < LW_THREADS / 64; w++)
 				total += s_red32[w];
 			uint32_t nb = 0xFFFFFFFFu;
-			if (total) {
+			if (total && DN) {	/* (no list: the groups are the bits that stay set) */
+				atomicAdd(a.rec_valid, total);
+				nb = 0u;
+			} else if (total) {
 				nb = atomicAdd(a.rec_count, total);
 				if (nb + total > a.rec_cap) {
 					mdb_raise(a.status, 8u);
@@ -623,7 +657,22 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					cmax = c > cmax ? c : cmax;                                                                    \
 					clmax = cl > clmax ? cl : clmax;                                                               \
 					last_first = first > last_first ? first : last_first;                                          \
-					if (FMT == 1)                                                                                  \
+					if (FMT == 3) {                                                                                \
+						const uint64_t me = __ballot(c != 1u);                                                 \
+						if (me) {	/* (groups whose COUNT is not 1: the exceptions - rare in this form) */ \
+							uint32_t eb = 0;                                                               \
+							if (lane == (uint32_t)__ffsll((long long)me) - 1u)                             \
+								eb = atomicAdd(&a.dn_cnt[1], (uint32_t)__popcll(me));                  \
+							eb = (uint32_t)__shfl((int)eb, __ffsll((long long)me) - 1, MDB_WAVE);          \
+							if (c != 1u) {                                                                 \
+								const uint32_t ep = eb + (uint32_t)__popcll(me & mdb_lanemask_lt());   \
+								if (ep < a.dn_exc_cap)                                                 \
+									a.dn_exc[ep] = ((unsigned long long)first << 32) | c;          \
+								else                                                                   \
+									mdb_raise(a.status, 131072u);                                  \
+							}                                                                              \
+						}                                                                                      \
+					} else if (FMT == 1)                                                                           \
 						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | c;              \
 					else if (FMT == 0)                                                                             \
 						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;                        \
@@ -633,7 +682,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				}                                                                                                      \
 			}                                                                                                              \
 		}
-		if (a.keyed_cbits) {
+		if (DN) {
+			LW12_EMIT(3)
+		} else if (a.keyed_cbits) {
 			LW12_EMIT(2)
 		} else if (a.rec32) {
 			LW12_EMIT(1)
@@ -644,7 +695,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		joined += jsum;
 		if (clmax > 1u)
 			mdb_raise(a.status, GC_ST_LEFT_DUPS);
-		if (cmax) {	/* (a COUNT(*) of at most 15 * 31) */
+		if (cmax && !DN) {	/* (a COUNT(*) of at most 15 * 31) */
 			if (a.keyed_cbits && (cmax >> a.keyed_cbits))
 				mdb_raise(a.status, 256u);	/* COUNT(*) does not fit a keyed record: redone with plain records */
 			if (!a.keyed_cbits && (cmax >> (32 - (a.kbits < 32 ? a.kbits : 31))))
@@ -675,6 +726,11 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	joined = lw_block_sum(joined, s_red);
 	if (threadIdx.x == 0 && joined)
 		atomicAdd(a.joined, joined);
+	if (DN) {
+		const unsigned long long cl_all = lw_block_sum((unsigned long long)cleared, s_red);
+		if (threadIdx.x == 0 && cl_all)
+			atomicAdd(&a.dn_cnt[0], (uint32_t)cl_all);
+	}
 #pragma unroll
 	for (int o = 32; o; o >>= 1) {
 		const uint32_t other = (uint32_t)__shfl_xor((int)last_first, o, MDB_WAVE);
@@ -975,6 +1031,9 @@ int leaf_wide12_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uin
 	if (nextra) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<1>, wgrid, LW_THREADS, lds, a, rem, nsub);
+	} else if (a.dn_bits) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12_bits", (k_leaf_wide12<0, true>), wgrid, LW_THREADS, lds, a, rem, nsub);
 	} else {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<0>, wgrid, LW_THREADS, lds, a, rem, nsub);

@@ -31,6 +31,6 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 size_t mdb_dense_arena_bytes(uint64_t n);
 int mdb_dense_bits_begin(mdb_dev_ctx *ctx, uint64_t n, unsigned long long **bits);
 int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n, const unsigned long long *exc, uint32_t n_exc, uint32_t *out_first,
-		   int64_t *out_count);
+		   int64_t *out_count, const int64_t *keys = NULL, bool keys32 = false, int64_t *out_key = NULL);
 
 #endif

@@ -311,3 +311,41 @@ def test_ordering_launched_before_the_group_count_is_known_stays_inside_the_call
                                           c_void_p(ok.data_ptr()), c_void_p(oc.data_ptr()), c_void_p(of.data_ptr()), G, byref(g), byref(j))
     assert rc == 0 and g.value == G and j.value == ej
     assert np.array_equal(_np(ok[:G]), ek) and np.array_equal(_np(oc[:G]), ec) and int(ok[G]) == SENT and int(of[G]) == -7
+
+
+@pytest.mark.parametrize("shape", ["unique_both", "a_few_exceptions", "many_exceptions_next_time"])
+def test_one_pass_4096_nearly_every_left_row_a_group_of_count_1_leaves_as_bits(dev, forced, shape, monkeypatch):
+    """Once a join over these columns has made nearly every left row a group of COUNT 1 (variant U: two primary keys), the next one clears
+    one bit per left row that is NO group's first row and lists the groups whose COUNT is not 1 (k_leaf_wide12<0, true>), and
+    mdb_dev_dense.hip writes key, COUNT and first row from the bits - no record per group, no ordering sort.  Same groups, counts, first
+    rows and order as the oracle: left rows without partner, a left key twice, right keys twice and 20 times; and when the data behind
+    the same addresses has changed to many exceptions the list overflows and the record form answers (same result)."""
+    rng = np.random.default_rng(len(shape))
+    n = 4_300_000 + 77 + 4096 * len(shape)      # (what the operator remembers goes by address AND length: not the previous case's columns)
+    kl = rng.permutation(1 << 26)[:n].astype(np.int64) - 3_000_000_000
+    kr = rng.permutation(kl)
+    if shape != "unique_both":
+        kr[:30_000] = kr[30_000:60_000]                 # 30 000 right keys twice (COUNT 2), 30 000 left rows lose their partner
+        kr[100_000:100_020] = kr[7]                     # one right key 21 times
+        kl[200_000:205_000] = kl[300_000:305_000]       # 5000 left keys twice: the later row is no first row, COUNT 2 (x right rows)
+    dl, dr = dev.to_dev(kl), dev.to_dev(kr)
+    ek, ec, ef, ej = orc.join_group_count(kl, None, kr, None)
+    for round_ in range(3):
+        if round_ == 2 and shape == "many_exceptions_next_time":
+            kr2 = kr.copy()
+            kr2[: n // 2] = kr2[n // 2: 2 * (n // 2)]   # half of the right keys twice: 2 x 10^6 exceptions, more than the list holds
+            dr.copy_(torch.from_numpy(kr2))
+            ek, ec, ef, ej = orc.join_group_count(kl, None, kr2, None)
+        dev.prof_enable(True)
+        dev.prof_reset()
+        k, c, f, j = dev.join_group_count(dl, None, dr, None)
+        ran = {kk for kk, v in dev.prof_read().items() if v[0] > 0}
+        dev.prof_enable(False)
+        assert j == ej and np.array_equal(_np(k), ek) and np.array_equal(_np(c), ec), (shape, round_)
+        assert np.array_equal(_np(f).view(np.uint32).astype(np.int64), ef), (shape, round_)
+        assert dev.last_join_one_pass_4096(), (shape, round_)
+        assert ("leaf_join_wide12_bits" in ran) == (round_ >= 1), (shape, round_, ran)
+        assert ("dense_expand" in ran) == (round_ >= 1 and not (round_ == 2 and shape == "many_exceptions_next_time")), (shape, round_, ran)
+    monkeypatch.setenv("MDB_JOIN_BITS", "0")
+    k2, c2, f2, j2 = dev.join_group_count(dl, None, dr, None)
+    assert j2 == ej and torch.equal(k2, k) and torch.equal(c2, c) and torch.equal(f2, f)
