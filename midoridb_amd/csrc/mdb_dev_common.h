@@ -81,6 +81,7 @@ struct mdb_col_memo {
 	const void *lg_kl, *lg_kr;	/* the last join over (lg_kl, lg_nl, lg_kr, lg_nr) delivered lg_groups groups: when that is under a quarter of the */
 	uint64_t lg_nl, lg_nr, lg_groups;	/* left rows, most left rows find no partner whatever the tables' sizes and ranges say (a right table */
 	bool lg_valid;			/* of few distinct keys spread over the left table's range): the next join filters them early */
+	uint32_t lg_nextra;		/* (further right tables of that join: the three-table operator remembers too) */
 	uint64_t lg_joined;		/* ... and lg_joined joined rows: nearly every left row a group of COUNT 1 -> the groups as one bit per row (k_leaf_wide12) */
 	int dn_distrust;		/* calls for which that form is not tried (its exception list overflowed) */
 };

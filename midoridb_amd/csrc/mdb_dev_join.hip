@@ -1473,7 +1473,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		else
 			need += mdb_filter_arena_bytes(st->n_l);
 	}
-	if (st->wide12 && !st->nextra)	/* (the groups as one bit per left row + exceptions, mdb_dev_dense.hip) */
+	if (st->wide12 && st->nextra <= 1)	/* (the groups as one bit per left row + exceptions, mdb_dev_dense.hip) */
 		need += mdb_dense_arena_bytes(st->n_l) + mdb_align_up((st->n_l / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
@@ -1738,7 +1738,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	 * ranges of 2^16 row ids, k_leaf_wide4 writes its records straight into those ranges: no record list, none of the two scatter levels that
 	 * would partition it by row id (MDB_ORDER_RANGES=0 switches it off) */
 	uint32_t rg_n = 0;
-	bool ranged = leaf4 && ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r &&
+	bool ranged = leaf4 && ctx->lg_valid && !ctx->lg_nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r &&
 		      order_ranges_apply(n_l, kbits, ctx->lg_groups + ctx->lg_groups / 8, &rg_n) &&
 		      !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
 	/* ... or the caller's statistics say so before any join has run (mdb_dev_call_stats): a group needs a right key, and there are at
@@ -1771,8 +1771,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.dn_exc = NULL;
 	a.dn_exc_cap = 0;
 	a.dn_cnt = ctx->d_status + 12;
-	if (st->wide12 && !st->nextra && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l &&
-	    ctx->lg_kr == keys_r && ctx->lg_nr == n_r && ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16 &&
+	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra &&
+	    ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r && ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16 &&
 	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
 		if (ctx->dn_distrust > 0) {
 			ctx->dn_distrust--;
@@ -2052,7 +2052,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	*out_groups = G;
 	if (out_joined)
 		*out_joined = joined;
-	if (has_r && !st->nextra) {
+	if (has_r) {
+		ctx->lg_nextra = (uint32_t)st->nextra;
 		ctx->lg_kl = keys_l;
 		ctx->lg_nl = n_l;
 		ctx->lg_kr = keys_r;
@@ -2265,7 +2266,7 @@ void gc_narrow_note(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
  * the bitmap filter only drops rows that can have no partner) */
 static bool gc_learned_selective(const mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r)
 {
-	return ctx->lg_valid && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r && keys_r &&
+	return ctx->lg_valid && !ctx->lg_nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r && keys_r &&
 	       ctx->lg_groups < n_l / 4;
 }
 

@@ -277,7 +277,7 @@ __device__ static inline void lw12_barrier(void)
 /* NX = 1: a further right table on the same key (A JOIN B ON a = b JOIN C ON a = c GROUP BY a: BASELINE configs[4]) - partitioned like the
  * first one; its rows are counted into the (still unused) 4-bit fields, the two counts multiplied into the 5-bit field before the left rows
  * come (a product beyond 31, or 16 rows of a key in the further table: flag 1024 like every count that does not fit). */
-template <int NX, bool DN = false /* the bit-per-row form of the groups (gc_args.dn_bits; two tables only) */>
+template <int NX, bool DN = false /* the bit-per-row form of the groups (gc_args.dn_bits) */>
 __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t rem /* hash bits below the digit */, uint32_t nsub)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lw_lds[];
@@ -1028,7 +1028,10 @@ int leaf_wide12_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uin
 {
 	const size_t lds = ((size_t)4 << rem) + ((size_t)1 << rem) / 2;
 	const uint32_t wgrid = nleaves < (uint32_t)ctx->num_cus ? nleaves : (uint32_t)ctx->num_cus;
-	if (nextra) {
+	if (nextra && a.dn_bits) {
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12_bits", (k_leaf_wide12<1, true>), wgrid, LW_THREADS, lds, a, rem, nsub);
+	} else if (nextra) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<1>, wgrid, LW_THREADS, lds, a, rem, nsub);
 	} else if (a.dn_bits) {
