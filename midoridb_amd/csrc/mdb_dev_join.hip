@@ -1770,13 +1770,39 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.dn_bits = NULL;
 	a.dn_exc = NULL;
 	a.dn_exc_cap = 0;
+	a.dn_pilot = 0;
 	a.dn_cnt = ctx->d_status + 12;
-	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra &&
-	    ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r && ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16 &&
+	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) &&
 	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
-		if (ctx->dn_distrust > 0) {
-			ctx->dn_distrust--;
-		} else {
+		bool want_bits = false;
+		if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
+			/* (what the last join over these very columns delivered) */
+			if (ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16) {
+				if (ctx->dn_distrust > 0)
+					ctx->dn_distrust--;
+				else
+					want_bits = true;
+			}
+		} else if (!(getenv("MDB_JOIN_PILOT") && getenv("MDB_JOIN_PILOT")[0] == '0')) {
+			/* nothing remembered (a first statement): the pilot - the same kernel over the first 64 of the 4096 digits (all rows of a key are
+			 * in one digit: a fair sample of the keys), nothing written but the counters: left rows that are no group's first row, groups
+			 * whose COUNT is not 1.  One in 16 of the rows at most each: the bit-per-row form */
+			a.dn_pilot = 64;
+			if ((rc = leaf_wide12_launch(ctx, a, pl.nleaves, st->key_bits - 12u, pl.nsub, st->nextra)))
+				return rc;
+			a.dn_pilot = 0;
+			uint64_t *hp = ctx->h_pinned;
+			MDB_HIP(ctx, hipMemcpyAsync(&hp[1], ctx->d_status, 56, hipMemcpyDeviceToHost, ctx->stream));
+			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			const uint32_t *pw = reinterpret_cast<const uint32_t *>(&hp[1]);
+			const uint64_t p_groups = pw[8], p_cleared = pw[12], p_exc = pw[13], p_rows = p_groups + p_cleared;
+			want_bits = p_rows && p_cleared * 16 <= p_rows && p_exc * 16 <= p_rows;
+			if (getenv("MDB_DEBUG_GROUP"))
+				fprintf(stderr, "join + GROUP BY (pilot over 64 digits): %llu left rows, %llu no group's first row, %llu groups of COUNT != 1 -> %s\n",
+					(unsigned long long)p_rows, (unsigned long long)p_cleared, (unsigned long long)p_exc, want_bits ? "a bit per left row" : "records");
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 13 * sizeof(uint32_t), ctx->stream));	/* (the flags of word 0 stay: they are facts about the data) */
+		}
+		if (want_bits) {
 			if ((rc = mdb_dense_bits_begin(ctx, n_l, &dn_bits)))
 				return rc;
 			a.dn_bits = reinterpret_cast<unsigned int *>(dn_bits);

@@ -129,6 +129,7 @@ struct gc_args {
 	unsigned long long *dn_exc;
 	uint32_t dn_exc_cap;
 	uint32_t *dn_cnt;		/* [0] bits cleared, [1] exceptions */
+	uint32_t dn_pilot;		/* != 0 (dn_bits = dn_exc = NULL): the pilot - the first dn_pilot digits only, nothing but the counters is written */
 	uint32_t nextra;
 	const uint32_t *hv_x[GC_MAX_EXTRA];
 	const uint32_t *cnt_x[GC_MAX_EXTRA];

@@ -297,7 +297,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			mdb_raise(a.status, 1024u);
 		return;
 	}
-	if (leaf >= a.nleaves)
+	/* (the bit-per-row form's pilot: the first dn_pilot digits only, nothing written but the counters - gc_args.dn_pilot) */
+	const uint32_t run_leaves = (DN && a.dn_pilot && a.dn_pilot < a.nleaves) ? a.dn_pilot : a.nleaves;
+	if (leaf >= run_leaves)
 		return;
 	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 16 * (2 + NX) - 1: (side, sub-region) */
 		const uint32_t side = threadIdx.x >> 4, j = threadIdx.x & 15u;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	uint32_t last_first = 0;	/* largest first row id of this workgroup's groups */
 	uint32_t it = 0;
 	bool bad = false;		/* (uniform) a digit whose words do not fit the registers, or whose counts overflowed */
-	for (; leaf < a.nleaves; leaf += gridDim.x, buf ^= 1u) {
+	for (; leaf < run_leaves; leaf += gridDim.x, buf ^= 1u) {
 		const uint32_t next = leaf + gridDim.x;
 		const uint32_t nch_l = s_chunk0[buf][0][nsub], nch_r = s_chunk0[buf][1][nsub];
 		if (nch_l > LW12_LB * LW_THREADS || nch_r > LW12_RB * LW_THREADS || (NX && s_chunk0[buf][NX ? 2 : 1][nsub] > LW12_RB * LW_THREADS)) {	/* (the caller sized the regions so that this cannot happen) */
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		 * previous digit's groups left: held across that phase they are 16 registers, with the left ones 48 - spills, whose reloads wait
 		 * for everything in flight) */
 		fetch_all(leaf, buf, 1);
-		const uint32_t next_c = next < a.nleaves ? seg_count(next) : 0u;	/* (on its way while this digit is counted) */
+		const uint32_t next_c = next < run_leaves ? seg_count(next) : 0u;	/* (on its way while this digit is counted) */
 		for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
 			s_fc[s] = 0x07FFFFFFu;
 		for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					if (prev[k] == 0xFFFFFFFEu || prev[k] == 0x07FFFFFFu)
 						continue;	/* (nothing there, or the key's first row so far) */
 					const uint32_t loser = prev[k] == 0xFFFFFFFFu ? rowk[k] : (prev[k] > rowk[k] ? prev[k] : rowk[k]);
-					atomicAnd(&a.dn_bits[loser >> 5], ~(1u << (loser & 31u)));
+					if (a.dn_bits)
+						atomicAnd(&a.dn_bits[loser >> 5], ~(1u << (loser & 31u)));
 					cleared++;
 				}
 			} else {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			s_base = nb;
 		}
 		/* registers are free: the next digit's right words, in flight while this one's groups are written */
-		if (next < a.nleaves)
+		if (next < run_leaves)
 			fetch_all(next, buf ^ 1u, 2);
 		lw12_barrier();
 		const uint32_t base = s_base;
@@ -666,7 +669,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 							eb = (uint32_t)__shfl((int)eb, __ffsll((long long)me) - 1, MDB_WAVE);          \
 							if (c != 1u) {                                                                 \
 								const uint32_t ep = eb + (uint32_t)__popcll(me & mdb_lanemask_lt());   \
-								if (ep < a.dn_exc_cap)                                                 \
+								if (!a.dn_exc)                                                         \
+									;	/* (the pilot: counted only) */                        \
+								else if (ep < a.dn_exc_cap)                                            \
 									a.dn_exc[ep] = ((unsigned long long)first << 32) | c;          \
 								else                                                                   \
 									mdb_raise(a.status, 131072u);                                  \
@@ -1027,14 +1032,16 @@ bool leaf_wide12_fits(const mdb_dev_ctx *ctx, uint64_t n_l, uint64_t n_r, uint64
 int leaf_wide12_launch(mdb_dev_ctx *ctx, const gc_args &a, uint32_t nleaves, uint32_t rem, uint32_t nsub, int nextra)
 {
 	const size_t lds = ((size_t)4 << rem) + ((size_t)1 << rem) / 2;
-	const uint32_t wgrid = nleaves < (uint32_t)ctx->num_cus ? nleaves : (uint32_t)ctx->num_cus;
-	if (nextra && a.dn_bits) {
+	uint32_t wgrid = nleaves < (uint32_t)ctx->num_cus ? nleaves : (uint32_t)ctx->num_cus;
+	if (a.dn_pilot && a.dn_pilot < wgrid)
+		wgrid = a.dn_pilot;
+	if (nextra && (a.dn_bits || a.dn_pilot)) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12_bits", (k_leaf_wide12<1, true>), wgrid, LW_THREADS, lds, a, rem, nsub);
 	} else if (nextra) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12", k_leaf_wide12<1>, wgrid, LW_THREADS, lds, a, rem, nsub);
-	} else if (a.dn_bits) {
+	} else if (a.dn_bits || a.dn_pilot) {
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_wide12<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_join_wide12_bits", (k_leaf_wide12<0, true>), wgrid, LW_THREADS, lds, a, rem, nsub);
 	} else {
