@@ -1772,7 +1772,9 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.dn_exc_cap = 0;
 	a.dn_pilot = 0;
 	a.dn_cnt = ctx->d_status + 12;
-	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) &&
+	/* (every left row must reach the leaf kernel for its bit to be looked at: no NULL keys - rows dropped for another reason, pruned by the
+	 * right table's key range, show as G + cleared != n_l below and send the call to the record form) */
+	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l &&
 	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
 		bool want_bits = false;
 		if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
