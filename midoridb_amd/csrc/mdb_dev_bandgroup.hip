@@ -213,6 +213,12 @@ struct bg_leaf_args {
 	uint32_t *rec_count;
 	uint32_t *groups;
 	uint32_t *status;
+	/* k_bg_group_leaf<NL, true> (nearly unique keys, mdb_dev_dense.hip): one bit per row - cleared here for every row that is not the first
+	 * of its key - and the keys with several rows as exceptions (first row << 32 | COUNT); dense_bits = NULL: the pilot, counters only */
+	unsigned int *dense_bits;
+	unsigned long long *exc;
+	uint32_t exc_cap;
+	uint32_t *dense_cnt;		/* [0] rows that are not the first of their key, [1] exceptions, [2] rows seen */
 };
 
 #ifndef BG_UNITS
@@ -220,7 +226,7 @@ struct bg_leaf_args {
 #endif
 
 /* NL: 16-byte loads per lane and piece: a region holds cap <= NL * 256 words */
-template <uint32_t NL>
+template <uint32_t NL, bool DN = false /* the bit-per-row form of nearly unique keys */>
 __global__ __launch_bounds__(1024, 8 /* waves per SIMD: two workgroups per CU */) void k_bg_group_leaf(bg_leaf_args a)
 {
 	extern __shared__ uint32_t bgl_lds[];
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(1024, 8 /* waves per SIMD: two workgroups per CU */
 		s_count[i] = 0u;
 	}
 	__syncthreads();
+	uint32_t dups = 0;
 	{
 		/* wave w takes the bands [w * per, (w + 1) * per): their word counts first (one read per band, all in flight), then BG_UNITS loads of
 		 * 16 bytes per lane at a time - NL per piece (a region of `cap` words is NL x 256 words at most), BG_UNITS / NL pieces side by side:
@@ -267,6 +274,30 @@ __global__ __launch_bounds__(1024, 8 /* waves per SIMD: two workgroups per CU */
 					const uint32_t q = u / NL, k = (u % NL) * 256u + 4u * lane;
 					const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
 					const uint32_t hi = (bb + p0 + q) << BG_ROW_BITS;
+					if (DN) {
+						/* (of two rows of a key that meet in the table of smallest rows the larger is settled: not a first row - four
+						 * requests go out, then the answers are looked at) */
+						uint32_t prev[4], rowe[4];
+#pragma unroll
+						for (int e = 0; e < 4; e++) {
+							prev[e] = 0xFFFFFFFFu;
+							rowe[e] = hi | (w[e] & ((1u << BG_ROW_BITS) - 1u));
+							if (k + (uint32_t)e < pc[q]) {
+								const uint32_t slot = w[e] >> BG_ROW_BITS;
+								prev[e] = atomicMin(&s_first[slot], rowe[e]);
+								atomicAdd(&s_count[slot], 1u);
+							}
+						}
+#pragma unroll
+						for (int e = 0; e < 4; e++)
+							if (prev[e] != 0xFFFFFFFFu) {
+								const uint32_t loser = prev[e] > rowe[e] ? prev[e] : rowe[e];
+								if (a.dense_bits)
+									atomicAnd(&a.dense_bits[loser >> 5], ~(1u << (loser & 31u)));
+								dups++;
+							}
+						continue;
+					}
 #pragma unroll
 					for (int e = 0; e < 4; e++)
 						if (k + (uint32_t)e < pc[q]) {
@@ -279,6 +310,60 @@ __global__ __launch_bounds__(1024, 8 /* waves per SIMD: two workgroups per CU */
 		}
 	}
 	__syncthreads();
+	if (DN) {
+		/* no record per group: the counters, and the keys with several rows as exceptions */
+		__shared__ uint32_t s_sum[4][16];
+		__shared__ uint32_t s_ebase;
+		uint32_t groups = 0, nexc = 0, rows = 0;
+		for (uint32_t i0 = wave * 64u; i0 < S; i0 += blockDim.x) {
+			const uint32_t c = s_count[i0 + lane];
+			groups += c ? 1u : 0u;
+			nexc += c > 1u ? 1u : 0u;
+			rows += c;
+		}
+#pragma unroll
+		for (int o = 32; o; o >>= 1) {
+			dups += (uint32_t)__shfl_xor((int)dups, o, MDB_WAVE);
+			groups += (uint32_t)__shfl_xor((int)groups, o, MDB_WAVE);
+			nexc += (uint32_t)__shfl_xor((int)nexc, o, MDB_WAVE);
+			rows += (uint32_t)__shfl_xor((int)rows, o, MDB_WAVE);
+		}
+		if (lane == 0) {
+			s_sum[0][wave] = dups;
+			s_sum[1][wave] = groups;
+			s_sum[2][wave] = rows;
+			s_sum[3][wave] = nexc;
+		}
+		__syncthreads();
+		if (threadIdx.x < 4u) {		/* (one atomic per counter and workgroup) */
+			uint32_t t = 0;
+			for (uint32_t w = 0; w < nwaves; w++)
+				t += s_sum[threadIdx.x][w];
+			if (threadIdx.x == 3)
+				s_ebase = t ? atomicAdd(&a.dense_cnt[1], t) : 0u;
+			else if (t)
+				atomicAdd(threadIdx.x == 0 ? &a.dense_cnt[0] : threadIdx.x == 1 ? a.groups : &a.dense_cnt[2], t);
+		}
+		__syncthreads();
+		if (!a.exc || !nexc)
+			return;
+		uint32_t ebase = s_ebase;
+		for (uint32_t w = 0; w < wave; w++)
+			ebase += s_sum[3][w];
+		if (ebase + nexc > a.exc_cap) {
+			if (lane == 0)
+				mdb_raise(a.status, 16384u);	/* (more keys with several rows than the list holds: the record form) */
+			return;
+		}
+		for (uint32_t i0 = wave * 64u; i0 < S; i0 += blockDim.x) {
+			const uint32_t c = s_count[i0 + lane];
+			const uint64_t m = __ballot(c > 1u);
+			if (c > 1u)
+				a.exc[ebase + (uint32_t)__popcll(m & mdb_lanemask_lt())] = ((unsigned long long)s_first[i0 + lane] << 32) | c;
+			ebase += (uint32_t)__popcll(m);
+		}
+		return;
+	}
 	/* the groups leave side by side: wave by wave, lane by lane */
 	uint32_t mine = 0, cmax = 0;
 	for (uint32_t i0 = wave * 64u; i0 < S; i0 += blockDim.x) {
@@ -358,6 +443,10 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	const uint64_t values = (uint64_t)1 << kbits, most = (n < values ? n : values) + 1024;	/* groups: at most the rows, at most the window's key values */
 	size_t need = mdb_align_up((size_t)nbands * bstride * 4 + 64) + mdb_align_up((size_t)D * nbands * 4) + mdb_align_up(most * 8) +
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
+	/* (nearly unique keys need nearly as many key values as rows: a window with fewer cannot hold them - no pilot) */
+	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
+	if (dense_ok)
+		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
@@ -410,21 +499,70 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	la.status = ctx->d_status;
 	const size_t lds_leaf = (size_t)8 << sbits;
 	const uint32_t threads = 1024u;
-#define BG_LAUNCH_LEAF(N)                                                                                                                         \
-	do {                                                                                                                                      \
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_group_leaf<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
-		MDB_LAUNCH_LDS(ctx, "group_band_leaf", k_bg_group_leaf<N>, D, threads, lds_leaf, la);                                               \
-	} while (0)
-	if (rcap <= 256u)
-		BG_LAUNCH_LEAF(1);
-	else if (rcap <= 512u)
-		BG_LAUNCH_LEAF(2);
-	else if (rcap <= 1024u)
-		BG_LAUNCH_LEAF(4);
-	else
+	if (rcap > 1024u)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a band-sorted column: %u words per region", rcap);
-#undef BG_LAUNCH_LEAF
 	uint64_t *h = ctx->h_pinned;
+#define BG_LAUNCH_LEAF(N, DNF, GRID, NAME)                                                                                                        \
+	do {                                                                                                                                      \
+		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_group_leaf<N, DNF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
+		MDB_LAUNCH_LDS(ctx, NAME, (k_bg_group_leaf<N, DNF>), (GRID), threads, lds_leaf, la);                                                 \
+	} while (0)
+#define BG_LAUNCH_ANY(DNF, GRID, NAME)                                                                                                            \
+	do {                                                                                                                                      \
+		if (rcap <= 256u)                                                                                                                 \
+			BG_LAUNCH_LEAF(1, DNF, GRID, NAME);                                                                                       \
+		else if (rcap <= 512u)                                                                                                            \
+			BG_LAUNCH_LEAF(2, DNF, GRID, NAME);                                                                                       \
+		else                                                                                                                              \
+			BG_LAUNCH_LEAF(4, DNF, GRID, NAME);                                                                                       \
+	} while (0)
+	/* Nearly unique keys?  The pilot - the same leaf over 64 digits, counters only - counts the rows that are not the first of their key:
+	 * one in 16 at most, and the groups leave as one bit per row + exceptions (mdb_dev_dense.hip), no record per group, no sort */
+	if (dense_ok) {
+		la.dense_cnt = ctx->d_status + 4;
+		la.dense_bits = NULL;
+		la.exc = NULL;
+		BG_LAUNCH_ANY(true, D < 64u ? D : 64u, "group_band_leaf_dense");
+		MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const uint32_t *ps = reinterpret_cast<const uint32_t *>(&h[1]);
+		const uint64_t pilot_dups = ps[4], pilot_rows = ps[6];
+		const bool bad_table = (ps[0] & (128u | 2u)) != 0;	/* (a key outside the window, a region that overflowed: dealt with below, on the full run's flags) */
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 7 * sizeof(uint32_t), ctx->stream));
+		if (!bad_table && pilot_rows && pilot_dups * 16u <= pilot_rows) {
+			unsigned long long *bits = NULL;
+			const uint64_t exc_cap = n / 8 + 4096;
+			if ((rc = mdb_dense_bits_begin(ctx, n, &bits)))
+				return rc;
+			la.dense_bits = reinterpret_cast<unsigned int *>(bits);
+			la.exc = (unsigned long long *)mdb_arena_take(ctx, exc_cap * 8);
+			if (!la.exc)
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "GROUP BY over a band-sorted column: %s", ctx->err);
+			la.exc_cap = (uint32_t)exc_cap;
+			BG_LAUNCH_ANY(true, D, "group_band_leaf_dense");
+			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
+			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			const uint32_t dstatus = ps[0], dgroups = ps[1], n_exc = ps[5];
+			if (getenv("MDB_DEBUG_GROUP"))
+				fprintf(stderr, "group_count (band sort, dense): pilot %llu of %llu rows not first; %u groups, %u rows not first, %u exceptions, status %u\n",
+					(unsigned long long)pilot_dups, (unsigned long long)pilot_rows, dgroups, ps[4], n_exc, dstatus);
+			if (!(dstatus & (16384u | 128u | 2u)) && (uint64_t)dgroups + ps[4] == n) {
+				if (dgroups > cap)
+					return mdb_set_err(ctx, -MIDORIDB_ERROR, "GROUP BY: %u groups, room for %llu", dgroups, (unsigned long long)cap);
+				if ((rc = mdb_dense_emit(ctx, bits, n, la.exc, n_exc, out_first, out_count)))
+					return rc;
+				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				*out_groups = dgroups;
+				ctx->pl_key_bits = kbits;
+				return MIDORIDB_OK;
+			}
+			/* (the exception list overflowed, or the table's flags ask for another path: the record form says which) */
+			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 7 * sizeof(uint32_t), ctx->stream));
+		}
+	}
+	BG_LAUNCH_ANY(false, D, "group_band_leaf");
+#undef BG_LAUNCH_ANY
+#undef BG_LAUNCH_LEAF
 	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const uint32_t *hs = reinterpret_cast<const uint32_t *>(&h[1]);

@@ -960,7 +960,8 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	if (ranged)
 		need += mdb_align_up((size_t)rg_n * ORDER_RANGE_CAP * 8) + mdb_align_up((size_t)rg_n * 4);
-	const bool dense_ok = n >= ((uint64_t)1 << 22) && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
+	/* (nearly unique keys need nearly as many key values as rows: a window with fewer cannot hold them - no pilot) */
+	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
 	if (dense_ok)
 		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);

@@ -229,15 +229,16 @@ def test_group_count_windows_of_2e26_and_2e27_values_go_through_the_tile_sort(de
     assert torch.equal(first, fi[o])
 
 
+@pytest.mark.parametrize("form", ["tile_sort", "band_sort"])
 @pytest.mark.parametrize("case", ["unique", "one_percent_pairs", "some_triples_and_a_run", "eight_percent_duplicates"])
-def test_group_count_nearly_unique_keys_leave_as_bits_and_exceptions(dev, case, monkeypatch):
+def test_group_count_nearly_unique_keys_leave_as_bits_and_exceptions(dev, case, form, monkeypatch):
     """The tile-sorted GROUP BY over a column whose keys are nearly unique (a pilot over 64 key digits counts the rows that are not the
     first of their key: one in 16 at most): no record per group and no sort of records - one bit per row, cleared for every row that is
     not its key's first, plus (first row, COUNT) exceptions for the keys with several rows, expanded by mdb_dev_dense.hip.  Bit-exact
     against the oracle; more duplicates than that: the record form, same result."""
     rng = np.random.default_rng(len(case) + 31)
-    n = 4_400_000 + 123
-    k = rng.permutation(1 << 26)[:n].astype(np.int64) + 7_000_000_000
+    n = 4_400_000 + 123 + (4096 if form == "band_sort" else 0)
+    k = rng.permutation(1 << (26 if form == "tile_sort" else 23))[:n].astype(np.int64) + 7_000_000_000
     if case == "one_percent_pairs":
         src = rng.integers(0, n, n // 100)
         k[rng.integers(0, n, n // 100)] = k[src]
@@ -245,22 +246,25 @@ def test_group_count_nearly_unique_keys_leave_as_bits_and_exceptions(dev, case, 
         for _ in range(2):
             src = rng.integers(0, n, 20_000)
             k[rng.integers(0, n, 20_000)] = k[src]
-        k[1_000_000:1_003_000] = k[17]                 # 3000 rows of one key: one exception with a large COUNT
+        run = 3000 if form == "tile_sort" else 100     # (hundreds of rows of one key inside one band overflow its region: the band sort's other test)
+        k[1_000_000:1_000_000 + run] = k[17]           # a run of rows of one key: one exception with a large COUNT
     elif case == "eight_percent_duplicates":
         src = rng.integers(0, n, n // 12)
         k[rng.integers(0, n, n // 12)] = k[src]
     ef, ec = orc.group_count(k, None)
-    monkeypatch.setenv("MDB_GROUP_TILED", "1")
-    monkeypatch.setenv("MDB_GROUP_BANDED", "0")
+    if form == "tile_sort":
+        monkeypatch.setenv("MDB_GROUP_TILED", "1")
+        monkeypatch.setenv("MDB_GROUP_BANDED", "0")
+    leaf = "group_tile_leaf" if form == "tile_sort" else "group_band_leaf"
     dk = dev.to_dev(k)
     dev.prof_enable(True)
     dev.prof_reset()
     f, c = dev.group_count(dk, None)
     ran = {kk for kk, v in dev.prof_read().items() if v[0] > 0}
     dev.prof_enable(False)
-    assert "group_tile_leaf_dense" in ran, ran                       # (the pilot at least)
+    assert leaf + "_dense" in ran, ran                                # (the pilot at least)
     assert ("dense_expand" in ran) == (case != "eight_percent_duplicates"), ran
-    assert ("group_tile_leaf" in ran) == (case == "eight_percent_duplicates"), ran
+    assert (leaf in ran) == (case == "eight_percent_duplicates"), ran
     assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case
     monkeypatch.setenv("MDB_GROUP_DENSE", "0")
     f2, c2 = dev.group_count(dk, None)
