@@ -1772,9 +1772,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.dn_exc_cap = 0;
 	a.dn_pilot = 0;
 	a.dn_cnt = ctx->d_status + 12;
-	/* (every left row must reach the leaf kernel for its bit to be looked at: no NULL keys - rows dropped for another reason, pruned by the
-	 * right table's key range, show as G + cleared != n_l below and send the call to the record form) */
-	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l &&
+	/* (every left row must reach the leaf kernel for its bit to be looked at: no NULL keys, no window that covers the right table's keys
+	 * only - left rows outside it are dropped by the first level; rows dropped for another reason show as G + cleared != n_l below and
+	 * send the call to the record form) */
+	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l && !st->r_based &&
 	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
 		bool want_bits = false;
 		if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
@@ -1785,7 +1786,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 				else
 					want_bits = true;
 			}
-		} else if (!(getenv("MDB_JOIN_PILOT") && getenv("MDB_JOIN_PILOT")[0] == '0')) {
+		} else {
 			/* nothing remembered (a first statement): the pilot - the same kernel over the first 64 of the 4096 digits (all rows of a key are
 			 * in one digit: a fair sample of the keys), nothing written but the counters: left rows that are no group's first row, groups
 			 * whose COUNT is not 1.  One in 16 of the rows at most each: the bit-per-row form */
