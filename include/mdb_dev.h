@@ -139,6 +139,12 @@ int mdb_dev_free(mdb_dev_ctx *ctx, void *dptr);
 /* bytes the allocator holds behind a buffer of mdb_dev_alloc (it hands out released buffers of up to twice the size asked for),
  * 0 for a pointer it does not know */
 size_t mdb_dev_alloc_size(mdb_dev_ctx *ctx, const void *dptr);
+/* A buffer of mdb_dev_alloc with several READERS: mdb_dev_retain() adds a holder, every holder ends with mdb_dev_free(), the last one
+ * releases the buffer; mdb_dev_holders() = holders beyond the first.  query_execute() uses it to hand a table's device column to a
+ * device-resident result without a copy (SELECT * over a join in the left table's row order: the left table's columns ARE result
+ * columns): a holder must not write; the store copies a column that has other holders before an UPDATE writes into it. */
+int mdb_dev_retain(mdb_dev_ctx *ctx, const void *dptr);
+unsigned mdb_dev_holders(mdb_dev_ctx *ctx, const void *dptr);
 int mdb_dev_memset(mdb_dev_ctx *ctx, void *dptr, int byte, size_t bytes);
 /* Page-locked host memory for result columns (D2H at PCIe rate instead of through the driver's staging copy).
  * Process-wide pool, independent of any context: buffers are recycled by later results and may be freed after the

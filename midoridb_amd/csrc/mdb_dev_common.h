@@ -122,6 +122,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
 	 * allocates dozens of temporaries and hipMalloc/hipFree cost 0.1-0.3 ms each */
 	std::unordered_map<void *, size_t> live;		/* buffers handed out -> size */
+	std::unordered_map<void *, uint32_t> holders;		/* ... -> holders beyond the first (mdb_dev_retain) */
 	std::vector<std::pair<void *, size_t>> cache;		/* released buffers kept for reuse */
 	size_t cache_bytes;
 	char err[512];

@@ -447,6 +447,14 @@ int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr)
 		MDB_HIP(ctx, hipFree(dptr));
 		return MIDORIDB_OK;
 	}
+	{
+		auto hs = ctx->holders.find(dptr);
+		if (hs != ctx->holders.end()) {		/* (other holders read it: this one is gone, the buffer stays) */
+			if (--hs->second == 0)
+				ctx->holders.erase(hs);
+			return MIDORIDB_OK;
+		}
+	}
 	const size_t sz = it->second;
 	mdb_hints_drop(ctx, dptr, sz);
 	ctx->live.erase(it);
@@ -493,6 +501,22 @@ extern "C" int mdb_dev_map_ids(mdb_dev_ctx *ctx, const int64_t *cells, uint64_t 
 	MDB_LAUNCH(ctx, "map_ids", k_map_ids, (uint32_t)(b > 16384 ? 16384 : b), 256, reinterpret_cast<const long long *>(cells), (unsigned long long)n,
 		   reinterpret_cast<const long long *>(table), (unsigned long long)table_n, reinterpret_cast<long long *>(out));
 	return MIDORIDB_OK;
+}
+
+extern "C" int mdb_dev_retain(mdb_dev_ctx *ctx, const void *dptr)
+{
+	if (!ctx || !dptr || ctx->live.find(const_cast<void *>(dptr)) == ctx->live.end())
+		return -MIDORIDB_ERROR;
+	ctx->holders[const_cast<void *>(dptr)]++;
+	return MIDORIDB_OK;
+}
+
+extern "C" unsigned mdb_dev_holders(mdb_dev_ctx *ctx, const void *dptr)
+{
+	if (!ctx || !dptr)
+		return 0;
+	auto it = ctx->holders.find(const_cast<void *>(dptr));
+	return it == ctx->holders.end() ? 0u : it->second;
 }
 
 extern "C" size_t mdb_dev_alloc_size(mdb_dev_ctx *ctx, const void *dptr)

@@ -1495,6 +1495,17 @@ grouped:
 						x.bufs.p[i] = x.bufs.p[--x.bufs.n];
 						break;
 					}
+				/* a base table's own device column, all of its rows in order (no row ids between): the result becomes one more holder
+				 * of the buffer instead of copying it (0.04 ms per 10^7-row column, 0.3 per 10^8) - result columns are read-only, rows
+				 * appended later lie behind the result's, and an UPDATE copies a column that has other holders before it writes */
+				if (!own && !shared && mdb_dev_alloc_size(x.dev, src) >= bytes &&
+				    !(getenv("MDB_RESULT_ALIAS") && getenv("MDB_RESULT_ALIAS")[0] == '0')) {
+					bool stmt_buf = false;
+					for (int i = 0; i < x.bufs.n; i++)
+						stmt_buf = stmt_buf || x.bufs.p[i] == src;
+					if (!stmt_buf && mdb_dev_retain(x.dev, src) == 0)
+						own = (void *)src;
+				}
 				if (!own) {
 					if (mdb_dev_alloc(x.dev, bytes, &own) || mdb_dev_gather64(x.dev, src, NULL, NULL, bytes / 8, own, NULL)) {
 						rc = dev_fail(&x, "keeping a result column on the device");

@@ -490,6 +490,21 @@ int mdb_exec_update(struct mdb_catalog *cat, struct mdb_dml *d, size_t *n_rows_a
 				goto out;
 			}
 		}
+		/* a device-resident result may hold the column as well (mdb_dev_retain, mdb_exec.c): it keeps the old cells, the table moves on */
+		for (int pass = 0; pass < 2; pass++) {
+			void **slot = pass ? (void **)&col->d_nullbits : &col->d_data;
+			if (!*slot || !mdb_dev_holders(x.dev, *slot))
+				continue;
+			const size_t bytes = pass ? (size_t)((t->dev_cap + 63) / 64) * 8 : (size_t)t->dev_cap * 8;
+			void *mine = NULL;
+			if (mdb_dev_alloc(x.dev, bytes, &mine) || mdb_dev_gather64(x.dev, *slot, NULL, NULL, bytes / 8, mine, NULL)) {
+				rc = dev_fail(&x, "copying a column that a result still reads");
+				t->dev_generation = 0;
+				goto out;
+			}
+			mdb_dev_free(x.dev, *slot);	/* (one holder less: the results keep it) */
+			*slot = mine;
+		}
 		if (mdb_dev_scatter_set64(x.dev, col->d_data, col->d_nullbits, sel, m, set_null ? 0 : lit_bits_for(v, col->type), set_null)) {
 			rc = dev_fail(&x, "updating a column");
 			t->dev_generation = 0;
