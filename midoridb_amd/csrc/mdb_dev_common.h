@@ -179,6 +179,12 @@ int mdb_cached_free(mdb_dev_ctx *ctx, void *dptr);
 /* scratch arena */
 int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes);
 void *mdb_arena_take(mdb_dev_ctx *ctx, size_t bytes);
+/* behind the 128 status words of ctx->d_status: a block of counters that one memset clears together with them at the start of an
+ * operator call - the first-level cursors of both tables (2 x 4096 words) and the ordering ranges' fills (2048 words) - instead of a
+ * fill command each (5 us apiece between two kernels) */
+#define MDB_ZERO_BLK_OFF 128u
+#define MDB_ZERO_BLK_SLOT 4096u
+#define MDB_ZERO_BLK_WORDS (2u * MDB_ZERO_BLK_SLOT + 2048u)
 static inline size_t mdb_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 /* run the following launches on the auxiliary stream (after everything queued so far on the main

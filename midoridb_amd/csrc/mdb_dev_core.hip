@@ -92,7 +92,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 		mdb_dev_ctx_destroy(ctx);
 		return -MIDORIDB_INTERNAL;
 	}
-	if (hipMalloc((void **)&ctx->d_status, 64 * sizeof(uint64_t)) != hipSuccess ||
+	if (hipMalloc((void **)&ctx->d_status, 64 * sizeof(uint64_t) + (size_t)MDB_ZERO_BLK_WORDS * 4) != hipSuccess ||
 	    hipHostMalloc((void **)&ctx->h_pinned, 1024 * sizeof(uint64_t)) != hipSuccess ||
 	    hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint64_t), ctx->stream) != hipSuccess) {
 		mdb_dev_ctx_destroy(ctx);

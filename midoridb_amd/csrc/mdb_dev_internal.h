@@ -102,6 +102,9 @@ struct mdb_part_filter {
 	bool level0_only;	/* stop after the histogram-free first level (bits2 = 0): the consumer reads the digits' sub-regions itself
 				 * (mdb_part_result.nsub; k_leaf_wide in mdb_dev_join.hip) */
 	uint32_t region_cap;	/* with level0_only, != 0: words per first-level region (a multiple of 64) instead of 1.25 x the average + 1024 */
+	uint32_t *cursor0_ext;	/* != NULL: the first level's region cursors live here (cursor0_ext_words of them at least), ALREADY ZERO - the caller's
+				 * one memset covers them (ctx->d_status + MDB_ZERO_BLK_OFF) - instead of an arena block and a memset of its own */
+	uint32_t cursor0_ext_words;
 	bool expect_pruned;	/* with range_in: the caller expects most rows to be dropped (key sample): the second level's grid is then
 				 * sized by the tiles that exist (a 4-byte read-back + synchronisation) instead of by the table */
 };

@@ -1295,6 +1295,8 @@ struct gc_state {
 	bool selective;		/* hint of the key sample: most left rows will find no partner */
 	bool by_span;		/* ... because the right table's keys cover a small part of the left table's range */
 	bool prunable;		/* the right table's keys cover less than 7/8 of the left table's range (sample) */
+	bool own_call;		/* begin and finish are the two halves of ONE operator call (not the split API): the first-level cursors and the ordering
+				 * ranges' fills may live in the status block's counter area, cleared with it (MDB_ZERO_BLK_*) */
 	bool r_based;		/* the compact window covers the right table's keys only: min-max pruning must run (gc_window.r_based) */
 	bool defer_l64;		/* the same in the 64-bit form (keys that fit no 2^32 window): min-max pruning on the raw keys */
 	bool defer_l;		/* the LEFT table is partitioned after the right one, in gc_finish (compact narrow form, unsplit call): the
@@ -1480,12 +1482,21 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		return rc;
 	/* d_status u32 words: [0] flags (bit 0 leaf table overflow, bit 1 fast-layout region overflow, bit 2
 	 * COUNT too large for a record), [1] record count, [2..3] joined rows (u64), [4..7] NULL-group stats */
-	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	if (st->own_call && !st->wide12) {
+		/* the status words and, behind them, the counters this call's kernels start from zero: one fill for all of them */
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, ((size_t)MDB_ZERO_BLK_OFF + MDB_ZERO_BLK_WORDS) * 4, ctx->stream));
+	} else {
+		MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	}
 	if (!st->defer_l && !st->defer_l64 && !st->wide12) {
 		mdb_part_filter lflt;
 		memset(&lflt, 0, sizeof(lflt));
 		lflt.level0_only = st->one_level;
 		lflt.loose = st->one_level && st->fast1;
+		if (st->own_call) {
+			lflt.cursor0_ext = ctx->d_status + MDB_ZERO_BLK_OFF + MDB_ZERO_BLK_SLOT;
+			lflt.cursor0_ext_words = MDB_ZERO_BLK_SLOT;
+		}
 		rc = mdb_partition_table(ctx, st->keys_l, st->null_l, st->n_l, st->b1, st->b2, !st->narrow, false, st->fast, &st->pl,
 					 st->narrow ? 1 : 0, st->keys32, st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u,
 					 st->one_level ? &lflt : NULL);
@@ -1565,6 +1576,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		memset(&rflt, 0, sizeof(rflt));
 		rflt.level0_only = st->one_level;
 		rflt.out16 = st->one_level && !(getenv("MDB_WORDS16") && getenv("MDB_WORDS16")[0] == '0');
+		if (st->own_call) {
+			rflt.cursor0_ext = ctx->d_status + MDB_ZERO_BLK_OFF;
+			rflt.cursor0_ext_words = MDB_ZERO_BLK_SLOT;
+		}
 		if (st->defer_l) {
 			/* [16] smallest, [17] largest key - window base of the right table (min-max pruning) */
 			rflt.minmax_out = ctx->d_status + GC_ST_MINMAX;
@@ -1623,6 +1638,10 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		flt.range_in = ctx->d_status + GC_ST_MINMAX;
 		flt.expect_pruned = st->by_span && !st->one_level;
 		flt.level0_only = st->one_level;
+		if (st->own_call) {
+			flt.cursor0_ext = ctx->d_status + MDB_ZERO_BLK_OFF + MDB_ZERO_BLK_SLOT;
+			flt.cursor0_ext_words = MDB_ZERO_BLK_SLOT;
+		}
 		rc = mdb_partition_table(ctx, keys_l, null_l, n_l, st->b1, st->b2, false, false, st->fast, &st->pl, 1, st->keys32,
 					 st->direct ? st->key_lo : st->base, st->direct ? st->key_bits : 0u, &flt);
 		if (rc)
@@ -1755,10 +1774,14 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	a.rg_cap = a.rg_shift = a.rg_n = 0;
 	if (ranged) {
 		a.rg_rec = (unsigned long long *)mdb_arena_take(ctx, (size_t)rg_n * ORDER_RANGE_CAP * 8);
-		a.rg_cnt = (uint32_t *)mdb_arena_take(ctx, (size_t)rg_n * 4);
+		const bool rg_in_block = st->own_call && rg_n <= MDB_ZERO_BLK_WORDS - 2u * MDB_ZERO_BLK_SLOT;
+		a.rg_cnt = rg_in_block ? ctx->d_status + MDB_ZERO_BLK_OFF + 2u * MDB_ZERO_BLK_SLOT : (uint32_t *)mdb_arena_take(ctx, (size_t)rg_n * 4);
 		if (!a.rg_rec || !a.rg_cnt)
 			return -MIDORIDB_INTERNAL;
-		MDB_HIP(ctx, hipMemsetAsync(a.rg_cnt, 0, (size_t)rg_n * 4, ctx->stream));
+		/* (the arena hands out whole 256-byte units: cleared as such - a length that is no multiple of 16 bytes costs the runtime a second fill
+		 * kernel, 5 us of the step) */
+		if (!rg_in_block)
+			MDB_HIP(ctx, hipMemsetAsync(a.rg_cnt, 0, mdb_align_up((size_t)rg_n * 4), ctx->stream));
 		a.rg_cap = ORDER_RANGE_CAP;
 		a.rg_shift = ORDER_RANGE_BITS;
 		a.rg_n = rg_n;
@@ -2464,6 +2487,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.r_based = win.r_based;
 	st.keys32 = keys32;
 	st.defer_ok = true;
+	st.own_call = !(getenv("MDB_ZERO_BLOCK") && getenv("MDB_ZERO_BLOCK")[0] == '0');
 	if (gc_pending_extras && has_r) {
 		st.nextra = gc_pending_extras->n;
 		for (int x = 0; x < st.nextra; x++) {

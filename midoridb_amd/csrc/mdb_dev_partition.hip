@@ -1327,7 +1327,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 
 		if (fast0 && l == 0) {
 			/* histogram-free first level */
-			uint32_t *cursor0 = (uint32_t *)cv.take((size_t)nreg0 * 4);
+			const bool cursor_ext = !dry && flt && flt->cursor0_ext && nreg0 <= flt->cursor0_ext_words;
+			uint32_t *cursor0 = cursor_ext ? flt->cursor0_ext : (uint32_t *)cv.take((size_t)nreg0 * 4);
 			uint32_t *reg_nt = (uint32_t *)cv.take(((size_t)nreg0 + 1) * 4);
 			const uint32_t next_tiles = (uint32_t)(n / MDB_TILE) + nreg0 + 1;
 			mdb_tile_desc *next_desc = stop0 ? NULL : (mdb_tile_desc *)cv.take((size_t)next_tiles * sizeof(mdb_tile_desc));
@@ -1340,7 +1341,8 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				a.cap = cap0;
 				a.nsub = PART_NSUB;
 				a.status = ctx->d_status;
-				MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
+				if (!cursor_ext)
+					MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
 				/* tables of 2^25 rows and more: tiles of 2 x MDB_TILE rows in the instances that have them (MDB_TILE2=0: never) */
 				const char *t2min = getenv("MDB_TILE2_MIN");	/* (tests: the form on small tables) */
 				const bool t2 = n >= (t2min && atoll(t2min) > 0 ? (uint64_t)atoll(t2min) : (1ull << 25)) &&
