@@ -10,6 +10,9 @@ if sys.argv[1] == "run":
     dev = DeviceCtx(0)
     n = 100_000_000
     shape = sys.argv[2] if len(sys.argv) > 2 else "g16"
+    if shape == "joinD64":    # the headline's tables through the 64-bit form (keys that fit no 2^32 window get it)
+        dev.lib.mdb_dev_set_narrow_keys(dev.h, 0)
+        shape = "joinD"
     if shape == "joinD":      # the headline: A(10^8 unique keys) JOIN B(10^8 rows, 16 per key) GROUP BY key, COUNT(*)
         a, b = dev.gen_keys(n, 0, n, 42, 0), dev.gen_keys(n, 0, n, 43, n // 16)
         for _ in range(5):
