@@ -124,6 +124,9 @@ struct mdb_dev_plan_info {
 	uint32_t samples;	/* key-sample kernels (each with a host synchronisation) the call launched */
 	uint32_t from_stats;	/* 1: windows and ranges came from mdb_dev_call_stats() */
 	uint32_t payload_form;	/* last mdb_dev_join_payload: 0 not served, 1 one level (cells in the leaf's LDS), 2 two levels, 3 row order (tile sort) */
+	uint32_t group_form;	/* last mdb_dev_group_count: 0 the partitioned path (or one of its small-input forms), 1 band sort (4-byte row words), 2 tile sort */
+	uint32_t groups_as_bits;	/* the groups left the leaf kernel as one bit per row + exceptions (nearly unique keys / nearly every left row a group of
+				 * COUNT 1), not as a record each: 1 decided by a pilot launch, 2 by what the last call over the columns delivered */
 };
 int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);

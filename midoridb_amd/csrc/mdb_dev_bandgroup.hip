@@ -554,6 +554,8 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 				*out_groups = dgroups;
 				ctx->pl_key_bits = kbits;
+				ctx->pl_group_form = 1;
+				ctx->pl_bits = 1;
 				return MIDORIDB_OK;
 			}
 			/* (the exception list overflowed, or the table's flags ask for another path: the record form says which) */
@@ -593,5 +595,6 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 		return rc;
 	*out_groups = groups;
 	ctx->pl_key_bits = kbits;
+	ctx->pl_group_form = 1;
 	return MIDORIDB_OK;
 }

@@ -115,7 +115,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	const void *cs_kl, *cs_kr;
 	struct mdb_dev_col_stats cs_l, cs_r;
 	/* mdb_dev_last_plan(): what the current / last operator did beyond the last_* words */
-	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form;
+	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form, pl_group_form, pl_bits;
 	int pl_depth;			/* operators that call operators: the outermost one's entry clears the counters (mdb_plan_scope) */
 	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */
 	std::vector<std::pair<mdb_memo_key, mdb_col_memo>> memo_lru;	/* the other pairs' sets, most recently used last */
@@ -151,7 +151,7 @@ struct mdb_plan_scope {
 	explicit mdb_plan_scope(mdb_dev_ctx *ctx) : c(ctx)
 	{
 		if (c && c->pl_depth++ == 0)
-			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = 0;
+			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = c->pl_group_form = c->pl_bits = 0;
 	}
 	~mdb_plan_scope()
 	{

@@ -229,6 +229,8 @@ extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out
 	out->samples = ctx->pl_samples;
 	out->from_stats = ctx->pl_from_stats;
 	out->payload_form = ctx->pl_payload_form;
+	out->group_form = ctx->pl_group_form;
+	out->groups_as_bits = ctx->pl_bits;
 	return MIDORIDB_OK;
 }
 

@@ -1800,7 +1800,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	 * send the call to the record form) */
 	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l && !st->r_based &&
 	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
-		bool want_bits = false;
+		bool want_bits = false, by_pilot = false;
 		if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
 			/* (what the last join over these very columns delivered) */
 			if (ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16) {
@@ -1823,6 +1823,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			const uint32_t *pw = reinterpret_cast<const uint32_t *>(&hp[1]);
 			const uint64_t p_groups = pw[8], p_cleared = pw[12], p_exc = pw[13], p_rows = p_groups + p_cleared;
 			want_bits = p_rows && p_cleared * 16 <= p_rows && p_exc * 16 <= p_rows;
+			by_pilot = true;
 			if (getenv("MDB_DEBUG_GROUP"))
 				fprintf(stderr, "join + GROUP BY (pilot over 64 digits): %llu left rows, %llu no group's first row, %llu groups of COUNT != 1 -> %s\n",
 					(unsigned long long)p_rows, (unsigned long long)p_cleared, (unsigned long long)p_exc, want_bits ? "a bit per left row" : "records");
@@ -1836,6 +1837,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			a.dn_exc = (unsigned long long *)mdb_arena_take(ctx, (size_t)a.dn_exc_cap * 8);
 			if (!a.dn_exc)
 				return -MIDORIDB_INTERNAL;
+			ctx->pl_bits = by_pilot ? 1u : 2u;
 		}
 	}
 	{
@@ -2062,6 +2064,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 					(unsigned long long)G, dn_cleared, (unsigned long long)n_l, dn_exceptions, status);
 			if ((status & 131072u) || (uint64_t)G + dn_cleared != n_l) {	/* (more groups of COUNT != 1 than last time: the record form) */
 				ctx->dn_distrust = 32;
+				ctx->pl_bits = 0;
 				return GC_RETRY_NODENSE;
 			}
 			rc = mdb_dense_emit(ctx, dn_bits, n_l, a.dn_exc, dn_exceptions, out_first, out_count, keys_l, st->keys32, out_key);

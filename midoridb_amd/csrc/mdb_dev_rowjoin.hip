@@ -1059,6 +1059,9 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 					return rc;
 				MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 				*out_groups = groups;
+				ctx->pl_key_bits = kbits;
+				ctx->pl_group_form = 2;
+				ctx->pl_bits = 1;
 				return MIDORIDB_OK;
 			}
 			/* (the exception list overflowed - the pilot's digits were not typical: the record form below) */
@@ -1128,6 +1131,8 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 		if (rc)
 			return rc;
 		*out_groups = groups;
+		ctx->pl_key_bits = kbits;
+		ctx->pl_group_form = 2;
 		return MIDORIDB_OK;
 	}
 	return 1;

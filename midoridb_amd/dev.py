@@ -53,7 +53,7 @@ class ColStats(ctypes.Structure):
 class PlanInfo(ctypes.Structure):
     """struct mdb_dev_plan_info: what the last join / GROUP BY operator did"""
     _fields_ = [(k, ctypes.c_uint32) for k in ("key_form", "key_bits", "levels", "digits", "minmax_pruned", "semijoin", "any_order", "ranged_order",
-                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form")]
+                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "groups_as_bits")]
 
 
 def last_plan_of(lib, handle):

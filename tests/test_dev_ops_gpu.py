@@ -191,6 +191,7 @@ def test_group_count_through_the_band_sort(dev, case, monkeypatch):
     dev.prof_enable(False)
     assert {"group_band_sort", "group_band_leaf"} <= ran, ran
     assert any(k.startswith(("leaf_", "hot_")) for k in ran) == (case == "hot_value"), ran       # (the partitioned path's kernels)
+    assert dev.last_plan()["group_form"] == (0 if case == "hot_value" else 1), dev.last_plan()    # (of the second call)
     assert ("group_band_sort" in ran2) == (case != "hot_value"), ran2
     assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case
     assert np.array_equal(_np(f2).astype(np.int64), ef) and np.array_equal(_np(c2), ec), case
@@ -263,6 +264,8 @@ def test_group_count_nearly_unique_keys_leave_as_bits_and_exceptions(dev, case, 
     ran = {kk for kk, v in dev.prof_read().items() if v[0] > 0}
     dev.prof_enable(False)
     assert leaf + "_dense" in ran, ran                                # (the pilot at least)
+    plan = dev.last_plan()
+    assert plan["group_form"] == (2 if form == "tile_sort" else 1) and plan["groups_as_bits"] == (0 if case == "eight_percent_duplicates" else 1), plan
     assert ("dense_expand" in ran) == (case != "eight_percent_duplicates"), ran
     assert (leaf in ran) == (case == "eight_percent_duplicates"), ran
     assert np.array_equal(_np(f).astype(np.int64), ef) and np.array_equal(_np(c), ec), case

@@ -347,6 +347,8 @@ def test_one_pass_4096_nearly_every_left_row_a_group_of_count_1_leaves_as_bits(d
         assert dev.last_join_one_pass_4096(), (shape, round_)
         # round 0: nothing is remembered about the columns - a pilot over 64 digits decides; later: what the last call delivered
         assert "leaf_join_wide12_bits" in ran, (shape, round_, ran)
+        bits = dev.last_plan()["groups_as_bits"]      # 1: a pilot decided, 2: the last call's outcome, 0: the record form answered after all
+        assert bits == (0 if (round_ == 2 and shape == "many_exceptions_next_time") else (1 if round_ == 0 else 2)), (shape, round_, bits)
         assert ("dense_expand" in ran) == (not (round_ == 2 and shape == "many_exceptions_next_time")), (shape, round_, ran)
     monkeypatch.setenv("MDB_JOIN_BITS", "0")
     k2, c2, f2, j2 = dev.join_group_count(dl, None, dr, None)
