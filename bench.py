@@ -940,8 +940,9 @@ def main():
                     try:
                         b_x = make_b()
                         dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False))
+                        plan_x = dev.last_plan()
                         line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
-                                     "value": ru[3] / dtu,
+                                     "value": ru[3] / dtu, "plan": plan_x,
                                      "pipeline": pipe_frac(int(ru[0].numel()), dtu, "U" if tag == "variant_U" else "S",
                                                            lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False)),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
