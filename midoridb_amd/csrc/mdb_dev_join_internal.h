@@ -180,24 +180,27 @@ __device__ static inline unsigned long long lw_block_sum(unsigned long long v, u
 	return t;
 }
 
+/* internal return codes of the operator's attempts (never leave the library): ONE enum, so that no two can share a value
+ * (round 5 gave GC_RETRY_NODENSE the value of GC_NOT_SERVED and an unserved three-table operator was retried six times) */
+enum gc_internal_rc {
+	GC_RETRY_EXACT = 1000,	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
+	GC_RETRY_DENSE,	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
+	GC_RETRY_BUILD_L,	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
+	GC_RETRY_WIDE,	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
+	GC_RETRY_PLAIN,	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
+	GC_RETRY_UNKEYED,	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
+	GC_RETRY_REC64,	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
+	GC_RETRY_TWO_LEVEL,	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
+	GC_RETRY_NODENSE,	/* internal: the bit-per-row form of the groups met more groups of COUNT != 1 than its list holds (ctx->dn_distrust is set) */
+	GC_NOT_SERVED,	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of counts overflowed, or a hot leaf): the caller chains two-table operators instead */
+};
 #define GC_ST_LEFT_DUPS 32768u	/* status bit 15: a key that has partners has several rows in the LEFT table (raised by the direct-address leaf kernels) */
-#define GC_RETRY_EXACT 1000	/* internal: a fast-layout leaf overflowed, redo with exact histograms */
-#define GC_RETRY_BUILD_L 1002	/* internal: the right side's distinct keys overflowed a leaf table, redo building on the left side */
-#define GC_RETRY_DENSE 1001	/* internal: a COUNT(*) does not fit a group record, redo with the dense ordering */
-#define GC_RETRY_WIDE 1003	/* internal: a key outside the int32 range met the narrow form, redo with 64-bit hashes */
 /* words of ctx->d_status the fused operator uses beyond [0..9] (flags, record-list length, joined rows, NULL-group stats, records):
  * [10..21] the key sample's six 8-byte extremes (before the operator starts), [16..17] the right table's smallest / largest
  * key - window base (min-max pruning, while it runs) */
 #define GC_ST_MINMAX 16
 #define GC_ST_MINMAX64 40	/* [40..43] the right table's smallest / largest key as two signed 64-bit words (min-max pruning, 64-bit form) */
 #define GC_ST_WINDOW 20	/* [20..21] 0 and 2^key_bits - 1: the whole window as a pruning range (further right tables drop what lies outside) */
-#define GC_RETRY_TWO_LEVEL 1007	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
-#define GC_RETRY_UNKEYED 1005	/* internal: a COUNT(*) does not fit a keyed group record (ctx->keyed_distrust is set): redo with plain records */
-#define GC_RETRY_PLAIN 1004	/* internal: a key outside the compact window (the sample missed the column's extremes): redo in the plain narrow form */
-#define GC_RETRY_NODENSE 1008	/* internal: the bit-per-row form of the groups met more groups of COUNT != 1 than its list holds (ctx->dn_distrust is set) */
-#define GC_RETRY_REC64 1006	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
-#define GC_NOT_SERVED 1008	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of
-				 * counts overflowed, or a hot leaf): the caller chains two-table operators instead */
 
 struct gc_window {
 	uint32_t kbits;		/* 0 = no compact window */

@@ -19,13 +19,13 @@
  * table; receiver = the received words read once (+ one read-write level when b2 > 0) + 16 G written.
  */
 #include "mdb_dev_internal.h"
+#include "mdb_dev_scatter4096.h"
 
 #define SH_NSUB 8u		/* = PART_NSUB of mdb_dev_partition.hip: sub-regions per first-level digit */
 #define SH_D_BITS 9
 #define SH_ONE_LEVEL_MAX_REM 14u	/* 2^14 entries x 8 bytes = 128 KiB of LDS */
 #define SH_LEAF_REM 13u		/* two levels: leaves of 2^13 key values (64 KiB of counters, 1024 threads: 0.46 ms for 2 x 10^8 rows where
 				 * 2^12-value leaves - twice as many workgroups, each with its fixed costs - take 0.82 and 2^14 0.55) */
-#define SHW_D_BITS 12		/* the wide fan-out form: 4096 first-level digits */
 #define SHW_MAX_REM 15u		/* ... and at most 15 key bits below them: 2-byte words with a spare bit, 2 x 2^15 16-bit counters = 128 KiB of LDS */
 #define SH_RANGE_WORD 24	/* words of ctx->d_status that hold the left table's pruning range */
 
@@ -160,247 +160,6 @@ size_t mdb_shard_arena_bytes(const mdb_shard_plan *p)
  * place in the region buffer - is the number of marks up to it (one ballot per 64 positions on top of per-chunk counts).
  * Region and cursor layout are the 512-digit level's (digit-major regions of `cap` words with nsub sub-regions per digit,
  * sub-major cursors): the receiver's descriptors do not care which kernel filled them. */
-struct shw_scatter_args {
-	const long long *keys;
-	const unsigned long long *nullbits;
-	uint32_t n;
-	long long key_lo;
-	uint32_t kbits, rem;	/* rem = kbits - 12 <= 15 */
-	uint32_t report;	/* 1 (the right table): a key outside the window raises flag 128; 0: rows with key - key_lo > rel_hi are dropped */
-	uint32_t rel_hi;
-	void *out;		/* 2-byte words, or 4-byte row words (ROWS) */
-	uint32_t *cursor;	/* [nsub][4096] */
-	uint32_t cap, nsub;
-	uint32_t *status;
-	uint32_t rows_per_wg;	/* (even) */
-};
-
-/* a barrier that waits for the wave's LDS operations only: global loads (the next tile's keys) and the cursor atomics stay in
- * flight across it (__syncthreads() waits for every outstanding memory operation) */
-__device__ static inline void shw_barrier(void)
-{
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-/* exclusive scan over the workgroup, one barrier: every wave scans the waves' totals itself */
-__device__ static inline uint32_t shw_block_excl_scan(uint32_t v, uint32_t *tmp /* [waves] */, uint32_t nwaves, uint32_t *total)
-{
-	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
-	const uint32_t incl = mdb_wave_incl_scan(v);
-	if (lane == MDB_WAVE - 1)
-		tmp[wave] = incl;
-	shw_barrier();
-	const uint32_t pi = mdb_wave_incl_scan(lane < nwaves ? tmp[lane] : 0u);
-	*total = (uint32_t)__shfl((int)pi, (int)nwaves - 1, MDB_WAVE);
-	const uint32_t before = (uint32_t)__shfl((int)pi, wave ? (int)wave - 1 : 0, MDB_WAVE);
-	return incl - v + (wave ? before : 0u);
-}
-
-/* ROWS: the words carry the ROW as well (the left table of the ordered operator, mdb_dev_join.hip: k_leaf_wide<.., L32>) - not as a
- * 27-bit row id beside the 15 hash bits (8-byte words: 16 384-row tiles, measured 0.65 ms per 10^8 rows - what the two 512-digit levels
- * they were to replace take), but as the row's place INSIDE ITS TILE (15 bits) in a 4-byte word, and one HEADER word in front of every run
- * (tile x digit: ~8 words) that names the tile: bit 31 set, the tile's first row / 2 below.  The reader resolves a word's row as
- * 2 * header + place; a region always begins with a header.  Staged like the 2-byte words (the spare top bit marks a run's first word),
- * 128 KiB for the same 32 768-row tiles. */
-template <int THREADS, int RPT /* rows per thread */, bool ROWS = false>
-__global__ __launch_bounds__(THREADS, 4 /* waves per SIMD: one workgroup of 1024 or two of 512 per CU */) void k_shard_scatter_wide(shw_scatter_args a)
-{
-	typedef typename std::conditional<ROWS, uint32_t, uint16_t>::type W;
-	constexpr uint32_t TILE = THREADS * RPT, D = 1u << SHW_D_BITS, DPT = D / THREADS, NCHUNK = TILE / 64u, HALF = RPT / 2;
-	constexpr uint32_t MARK = ROWS ? 0x80000000u : 0x8000u, HDR = ROWS ? 1u : 0u;	/* words a run takes beyond its rows */
-	static_assert(TILE <= 32768u && DPT >= 2 && (DPT & 1) == 0 && (RPT % 4) == 0, "tile shape");
-	extern __shared__ __attribute__((aligned(16))) uint32_t shw_lds[];
-	uint32_t *const s_cnt = shw_lds;			/* [D / 2] two 16-bit counters per word, then the digits' tile-local starts */
-	uint32_t *const s_delta = s_cnt + D / 2;		/* [D] per NON-EMPTY digit, in digit order: where its run goes minus its tile-local start */
-	uint32_t *const s_chunk = s_delta + D;			/* [NCHUNK] runs that begin before staged position 64 c */
-	uint32_t *const s_bad = s_chunk + NCHUNK;		/* [D / 32] non-empty digits (by ordinal) whose run did not fit its region */
-	uint32_t *const s_tmp = s_bad + D / 32;			/* [32] */
-	W *const s_stage = reinterpret_cast<W *>(s_tmp + 32);	/* [TILE] */
-	__shared__ uint32_t s_any_bad;
-
-	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane(), sub = blockIdx.x % a.nsub;
-	const uint32_t wmask = (1u << a.rem) - 1u;
-	const uint64_t limit = a.report ? ((1ull << a.kbits) - 1ull) : (uint64_t)a.rel_hi;
-	const uint64_t le = mdb_lanemask_lt() | (1ull << lane);
-	for (uint32_t i = threadIdx.x; i < D / 32; i += THREADS)
-		s_bad[i] = 0u;
-	if (threadIdx.x == 0)
-		s_any_bad = 0u;
-
-	/* A workgroup takes one contiguous range of rows, tile after tile (one workgroup per CU: 90 KiB of LDS).  Measured per tile
-	 * of 32 768 rows (clock64 around the phases, 10^8 rows): load + rank 32 000 cycles, digits 5 000, stage 8 000, write-out
-	 * 16 600 - the sum is the kernel; keys requested one tile ahead, and first tiles of unequal length per workgroup (the CUs'
-	 * phases spread over the period) both left the total where it was. */
-	const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_wg;
-	const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
-	for (uint64_t row0 = r_begin; row0 < r_end;) {
-		const uint32_t len = (uint32_t)((r_end - row0) < TILE ? (r_end - row0) : TILE);
-		const bool full = len == TILE;	/* (uniform) */
-		/* (the thread's number, made opaque per tile: otherwise the addresses of all its loads and LDS accesses are computed once,
-		 * before the loop, and kept in ~70 registers across it - spills) */
-		uint32_t tid = threadIdx.x;
-		asm volatile("" : "+v"(tid));
-		for (uint32_t i = tid; i < D / 2; i += THREADS)
-			s_cnt[i] = 0u;
-		if (tid == 0)
-			s_chunk[0] = 0u;
-		shw_barrier();
-
-		/* 1. load (16 bytes = two keys per access, a half of the thread's rows in flight at a time), hash, rank inside the digit */
-		uint32_t packed[RPT];	/* digit << 16 | rank, or ~0 for a row that is not taken */
-		uint32_t word2[HALF];	/* the rows' 2-byte words, two per register */
-#pragma unroll
-		for (int hblock = 0; hblock < 2; hblock++) {
-			ulonglong2 pre[HALF / 2];
-#pragma unroll
-			for (int r = 0; r < HALF / 2; r++) {
-				const uint32_t e0 = 2u * ((uint32_t)(hblock * (HALF / 2) + r) * THREADS + tid);
-				if (full || e0 + 1u < len)		/* (row0 is even and the column 16-byte aligned) */
-					pre[r] = *reinterpret_cast<const ulonglong2 *>(a.keys + row0 + e0);
-				else if (e0 < len)
-					pre[r] = make_ulonglong2((unsigned long long)a.keys[row0 + e0], 0ull);
-				else
-					pre[r] = make_ulonglong2(0ull, 0ull);
-			}
-#pragma unroll
-			for (int r = 0; r < HALF / 2; r++) {
-				const int pr = hblock * (HALF / 2) + r;		/* pair number of this thread */
-				const uint32_t e0 = 2u * ((uint32_t)pr * THREADS + tid);	/* tile-relative row of the pair's first key */
-				const unsigned long long kk[2] = { pre[r].x, pre[r].y };
-				bool ok[2] = { e0 < len, e0 + 1u < len };
-				if (a.nullbits && ok[0]) {	/* (row0 + e0 is even: both bits live in one word) */
-					const unsigned long long nb = a.nullbits[(row0 + e0) >> 6] >> ((row0 + e0) & 63u);
-					ok[0] = !(nb & 1ull);
-					ok[1] = ok[1] && !(nb & 2ull);
-				}
-				uint32_t w2 = 0u;
-#pragma unroll
-				for (int e = 0; e < 2; e++) {
-					const unsigned long long rel = kk[e] - (unsigned long long)a.key_lo;
-					const bool take = ok[e] && rel <= limit;
-					if (a.report && ok[e] && !take)
-						mdb_raise(a.status, 128u);	/* a right key outside the window: the caller's form does not apply */
-					uint32_t pk = 0xFFFFFFFFu;
-					if (take) {
-						const uint32_t h = mdb_mixk((uint32_t)rel, a.kbits);
-						const uint32_t dig = h >> a.rem, sh = (dig & 1u) << 4;
-						const uint32_t rank = (atomicAdd(&s_cnt[dig >> 1], 1u << sh) >> sh) & 0xFFFFu;
-						pk = (dig << 16) | rank;
-						w2 |= ((h & wmask) | (rank == 0u ? 0x8000u : 0u)) << (16 * e);
-					}
-					packed[2 * pr + e] = pk;
-				}
-				word2[pr] = w2;
-			}
-		}
-		shw_barrier();
-
-		/* 2. digit counts -> tile-local starts (written back over the counters), the ordinal of every non-empty digit, the runs
-		 *    that begin before every 64th staged position, and the run's place in its region: one global atomic per (tile,
-		 *    non-empty digit), whose round trip the staging below covers */
-		uint32_t cnt[DPT], v = 0u;
-#pragma unroll
-		for (int j = 0; j < (int)DPT / 2; j++) {
-			const uint32_t c2 = s_cnt[tid * (DPT / 2) + j];
-			cnt[2 * j] = c2 & 0xFFFFu;
-			cnt[2 * j + 1] = c2 >> 16;
-			v += cnt[2 * j] + cnt[2 * j + 1] + ((cnt[2 * j] ? 1u : 0u) + (cnt[2 * j + 1] ? 1u : 0u)) * 65536u;
-		}
-		uint32_t tot;
-		const uint32_t ex = shw_block_excl_scan(v, s_tmp, THREADS / 64, &tot);	/* rows below bit 16 (<= 32 768), non-empty digits above */
-		const uint32_t tile_total = tot & 0xFFFFu;
-		uint32_t base[DPT], st0[DPT];
-		const uint32_t ord0 = ex >> 16;
-		{
-			uint32_t start = ex & 0xFFFFu, ord = ord0;
-#pragma unroll
-			for (int j = 0; j < (int)DPT; j++) {
-				const uint32_t d = tid * DPT + (uint32_t)j;
-				st0[j] = start;
-				base[j] = 0u;
-				if (cnt[j]) {
-					base[j] = atomicAdd(&a.cursor[sub * D + d], cnt[j] + HDR);
-					/* this run is the last one to begin before position 64 c for every c with start < 64 c <= start + count */
-					for (uint32_t c = (start >> 6) + 1u; (c << 6) <= start + cnt[j] && c < NCHUNK; c++)
-						s_chunk[c] = ord + 1u;
-					ord++;
-					start += cnt[j];
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < (int)DPT / 2; j++)
-				s_cnt[tid * (DPT / 2) + j] = st0[2 * j] | (st0[2 * j + 1] << 16);
-		}
-		shw_barrier();
-
-		/* 3. stage by digit */
-#pragma unroll
-		for (int r = 0; r < RPT; r++) {
-			if (packed[r] != 0xFFFFFFFFu) {
-				const uint32_t dig = packed[r] >> 16;
-				const uint32_t st = (s_cnt[dig >> 1] >> ((dig & 1u) << 4)) & 0xFFFFu;
-				const uint32_t w16 = (word2[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
-				if (ROWS)	/* (the row's place in the tile: pair r / 2 of this thread, element r & 1) */
-					s_stage[st + (packed[r] & 0xFFFFu)] = (W)(((w16 & 0x8000u) << 16) | ((2u * ((uint32_t)(r >> 1) * THREADS + tid) + (uint32_t)(r & 1)) << 15) |
-										  (w16 & 0x7FFFu));
-				else
-					s_stage[st + (packed[r] & 0xFFFFu)] = (W)w16;
-			}
-		}
-		{
-			uint32_t ord = ord0;
-#pragma unroll
-			for (int j = 0; j < (int)DPT; j++) {
-				if (cnt[j]) {
-					const uint32_t d = tid * DPT + (uint32_t)j;
-					if (base[j] + cnt[j] + HDR > a.cap) {
-						mdb_raise(a.status, 2u);	/* the region is full: reported, the operator takes its exact path */
-						atomicOr(&s_bad[ord >> 5], 1u << (ord & 31u));
-						s_any_bad = 1u;
-					}
-					s_delta[ord] = (d * a.nsub + sub) * a.cap + base[j] + HDR - st0[j];
-					ord++;
-				}
-			}
-		}
-		shw_barrier();
-
-		/* 4. write out: consecutive lanes, consecutive positions of a run; a position's run = the runs that begin before its
-		 *    chunk of 64 + the marks up to it inside the chunk */
-		const bool any_bad = s_any_bad != 0u;
-#pragma unroll
-		for (int k = 0; k < RPT; k++) {
-			const uint32_t i = (uint32_t)k * THREADS + tid;
-			const uint32_t sv = i < tile_total ? s_stage[i] : 0u;
-			const uint64_t m = __ballot(sv & MARK);
-			if (i >= tile_total)
-				continue;
-			const uint32_t ord = s_chunk[(uint32_t)k * (THREADS / 64) + wave] + (uint32_t)__popcll(m & le) - 1u;
-			if (any_bad && ((s_bad[ord >> 5] >> (ord & 31u)) & 1u))
-				continue;
-			const uint32_t g = i + s_delta[ord];
-			reinterpret_cast<W *>(a.out)[g] = (W)(sv & (MARK - 1u));
-			if (ROWS && (sv & MARK))	/* the run's header: the tile (row0 is even) */
-				reinterpret_cast<W *>(a.out)[g - 1u] = (W)(0x80000000u | (uint32_t)(row0 >> 1));
-		}
-		shw_barrier();
-		if (any_bad) {		/* (rare: clear the marks of this tile's full regions) */
-			for (uint32_t i = tid; i < D / 32; i += THREADS)
-				s_bad[i] = 0u;
-			if (tid == 0)
-				s_any_bad = 0u;
-			shw_barrier();
-		}
-		row0 += len;
-	}
-}
-
-static size_t shw_scatter_lds(uint32_t tile, size_t word_bytes = 2)
-{
-	const uint32_t D = 1u << SHW_D_BITS;
-	return (size_t)4 * (D / 2 + D + tile / 64 + D / 32 + 32) + word_bytes * tile;
-}
-
 /* region capacity (words) of a table of at most n rows partitioned by mdb_scatter4096: the average + 1/16 + 320 words (a region's fill:
  * 3052 +- 55 rows at 10^8), plus - row words - one header per tile whose workgroup writes to the region's sub-region */
 uint32_t mdb_scatter4096_cap(const mdb_dev_ctx *ctx, uint64_t n, bool row_words)
@@ -462,9 +221,19 @@ int mdb_scatter4096(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nulls
 						 (int)shw_scatter_lds(tile, 4)));
 		MDB_LAUNCH_LDS(ctx, name, (k_shard_scatter_wide<1024, 32, true>), grid, 1024, shw_scatter_lds(tile, 4), a);
 	} else {
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_scatter_wide<1024, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-						 (int)shw_scatter_lds(tile)));
-		MDB_LAUNCH_LDS(ctx, name, (k_shard_scatter_wide<1024, 32>), grid, 1024, shw_scatter_lds(tile), a);
+		/* hash words: the streaming form (mdb_dev_scatter4096.h) - 8 x 16 bytes of keys in flight per thread across all phases, as non-temporal
+		 * loads (read once: they should not push the regions' half-written lines out of the L2s); same words, regions and cursors.  Same
+		 * box, 10^8 unique keys in 2^27 values: 0.316 ms against 0.352 (profiles/r06/scatter4096_ab.txt) */
+		const size_t lds = shs_stream_lds(tile, 2);
+		if (nulls) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter4096_stream<1024, 32, false, true, 8, 0, 2>),
+							 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			MDB_LAUNCH_LDS(ctx, name, (k_scatter4096_stream<1024, 32, false, true, 8, 0, 2>), grid, 1024, lds, a);
+		} else {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter4096_stream<1024, 32, false, false, 8, 0, 2>),
+							 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			MDB_LAUNCH_LDS(ctx, name, (k_scatter4096_stream<1024, 32, false, false, 8, 0, 2>), grid, 1024, lds, a);
+		}
 	}
 	return MIDORIDB_OK;
 }
