@@ -302,8 +302,15 @@ __device__ static inline void part_preload2(const mdb_level_args &a, const mdb_t
 {
 	const uint64_t *const src = (LEVEL0 ? reinterpret_cast<const uint64_t *>(a.keys) : a.hv_in) + td.start;
 #pragma unroll
-	for (int r = 0; r < PAIRS; r++)
-		pre[r] = *reinterpret_cast<const ulonglong2 *>(src + 2u * ((uint32_t)r * PART_THREADS + threadIdx.x));
+	for (int r = 0; r < PAIRS; r++) {
+		if (LEVEL0) {	/* a key column is read once: non-temporal, so that it does not push the regions' half-written lines out of the L2s */
+			typedef unsigned long long ull2_nt __attribute__((ext_vector_type(2)));
+			const ull2_nt v = __builtin_nontemporal_load(reinterpret_cast<const ull2_nt *>(src + 2u * ((uint32_t)r * PART_THREADS + threadIdx.x)));
+			pre[r] = make_ulonglong2(v.x, v.y);
+		} else {
+			pre[r] = *reinterpret_cast<const ulonglong2 *>(src + 2u * ((uint32_t)r * PART_THREADS + threadIdx.x));
+		}
+	}
 }
 
 /* 4-byte words (the right side of the narrow form beyond level 0): the four adjacent elements 4p .. 4p+3 relative to
