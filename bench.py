@@ -178,6 +178,12 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
         # the ordered form's one 4096-digit pass per table: 2-byte words (right), 4-byte row words + one header per ~8-word run (left)
         "part_scatter_wide12_r": key + 2 * n, "part_scatter_wide12_l": key + 4.5 * kept,
         "leaf_join_wide12": 2 * n + 4.5 * kept + 8 * g,     # both tables' words in, one record per group out (4 bytes when every COUNT fits)
+        # ... the bit-per-row form: the same words in, one bit per left row touched (cleared where the row is no group's first), no record out
+        "leaf_join_wide12_bits": 2 * n + 4.5 * kept + n / 8,
+        "dense_count": n / 8,                       # the bits, counted per block of rows
+        "dense_expand": n / 8 + key + 20 * g,       # the bits and the left key column in, (first row, key, COUNT) per group out
+        "dense_patch": 16,                          # the exceptions' COUNTs (a handful)
+        "expand_keys": 16 * g + key,                # (key, COUNT) per group in, every key COUNT times out
         "shard_leaf_wide": 2 * (kept + n) + 16 * g, "shard_leaf": 4 * (kept + n) + 16 * g,
         "leaf_join_group_count": (key + h32 if narrow else key + rid + key) + 8 * g,    # both partitioned tables in, one record per group out
         "leaf_join_direct": key + h32 + 8 * g,
@@ -197,7 +203,9 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
     small = ("scan_", "part_build_tiles", "part_region_tiles", "part_seg0", "part_children", "shard_tiles", "order_ranges", "key_range")
     if kernel not in table and kernel.startswith(small):
         return 0.0      # descriptor / scan kernels over a few thousand words: no table bytes to price them on
-    return float(table.get(kernel, key))
+    # (a kernel this table does not know is NOT priced - it used to be priced as "one key column", which gave dense_count, 12.5 MB of
+    # bits, a fraction of 8.55 in round 5's tables; profiles/make_tables.py refuses an unpriced kernel above 0.02 ms and a fraction > 1)
+    return float(table.get(kernel, 0.0))
 
 
 def parse_args():
@@ -449,6 +457,13 @@ class Watchdog:
                 os._exit(3)
 
 
+def dist_of(ms):
+    """min / median / p90 / max of per-step times (ms)"""
+    v = sorted(ms)
+    n = len(v)
+    return {"steps": n, "min": v[0], "median": v[n // 2], "p90": v[min(n - 1, (9 * n) // 10)], "max": v[-1], "mean": sum(v) / n}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -606,12 +621,29 @@ def main():
                 time.sleep(1)
         beat("barrier before the timed steps")
         barrier()
+        c0 = dev.counters()
         t0 = time.perf_counter()
         for _ in range(steps):
             g, j = step()
         barrier()
         dt = time.perf_counter() - t0
+        c1 = dev.counters()
         beat("timed steps done")
+        # how the steps are distributed: the same number of steps again, each between two synchronisations of its own (`value` stays the mean
+        # of the contract's loop above: one clock around all K steps)
+        each = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            each.append((time.perf_counter() - t1) * 1e3)
+        c2 = dev.counters()
+        step_dist = dict(dist_of(each), retries_in_timed_steps=c1["retries"] - c0["retries"], samples_in_timed_steps=c1["samples"] - c0["samples"],
+                         arena_grows_in_timed_steps=c1["arena_grows"] - c0["arena_grows"], alloc_misses_in_timed_steps=c1["alloc_misses"] - c0["alloc_misses"],
+                         retries_in_distribution_steps=c2["retries"] - c1["retries"],
+                         note="min / median / p90 / max over the same number of steps run right after the timed loop, each between its own "
+                              "synchronisations (wall clock, this rank); *_in_timed_steps: mdb_dev_counters() read before and after the timed loop")
         red = torch.tensor([dt, float(j), float(g)], dtype=torch.float64, device=dev.device)
         if use_dist:
             tmax = red[:1].clone()
@@ -620,7 +652,7 @@ def main():
             red[0] = tmax[0]
         dt, joined, groups = float(red[0].item()), int(red[1].item()), int(red[2].item())
         return {"a": a, "b": b, "out": out, "pipe": pipe, "step": step, "wire32": w32, "mod": mod, "n": n_rank, "total_rows": total,
-                "dt": dt, "ms_per_step": dt / steps * 1e3, "value": joined / (dt / steps), "joined": joined, "groups": groups}
+                "dt": dt, "ms_per_step": dt / steps * 1e3, "value": joined / (dt / steps), "joined": joined, "groups": groups, "step_ms": step_dist}
 
     cold = {}
     n_weak = args.rows
@@ -771,6 +803,7 @@ def main():
             "value": value, "unit": "joined rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling_name, "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
+            "step_ms": m["step_ms"], "retries_in_timed_steps": m["step_ms"]["retries_in_timed_steps"], "last_plan": dev.last_plan(),
             "config": {"workload": f"A JOIN B ON id_a=id_b GROUP BY id_a COUNT(*), {n} rows/table/GPU x {world} GPU = {total_rows} rows/table "
                                    f"({scaling_name} scaling), variant {args.variant} "
                                    + {"D": "(B keys 16x duplicated, in the lowest sixteenth of A's key range)", "U": "(unique keys both sides)",
@@ -850,15 +883,27 @@ def main():
         if secondary:
             reps = max(3, args.steps // 2)
 
+            last_dist = {}
+
             def timed(fn):
+                """mean seconds per call over `reps` calls, each between its own synchronisations (every operator call ends with a host read
+                anyway); the distribution, the retries / arena growths / allocator misses the calls paid and the last call's plan are left
+                in last_dist for the caller's line"""
                 for _ in range(2):
                     fn()
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
+                c0 = dev.counters()
+                each = []
                 for _ in range(reps):
+                    t1 = time.perf_counter()
                     r = fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t1) / reps, r
+                    torch.cuda.synchronize()
+                    each.append((time.perf_counter() - t1) * 1e3)
+                c1 = dev.counters()
+                last_dist.clear()
+                last_dist.update(dist_of(each), retries_in_timed_steps=c1["retries"] - c0["retries"], arena_grows_in_timed_steps=c1["arena_grows"] - c0["arena_grows"],
+                                 alloc_misses_in_timed_steps=c1["alloc_misses"] - c0["alloc_misses"], plan=dev.last_plan())
+                return sum(each) / reps * 1e-3, r
             try:
                 # first query over columns the context has not seen (fresh pointers): pays the key sample and its sync, not the arena
                 a2, b2 = a.clone(), b.clone()
@@ -893,7 +938,7 @@ def main():
                 # the wide form (64-bit hashes + row-id arrays), forced: what keys outside any 2^32 window run as
                 dev.set_narrow_keys(0)
                 dtw, rw = timed(lambda: dev.join_group_count(a, None, b, None, out=out, want_first=False))
-                line["wide_form"] = {"ms_per_step": dtw * 1e3, "value": rw[3] / dtw, "narrow": dev.last_join_narrow()}
+                line["wide_form"] = {"ms_per_step": dtw * 1e3, "value": rw[3] / dtw, "narrow": dev.last_join_narrow(), "step_ms": dict(last_dist)}
             except Exception as e:  # pragma: no cover
                 line["wide_form"] = {"error": str(e)}
             finally:
@@ -923,7 +968,7 @@ def main():
                 # carried and no ordering sort (reported BESIDE the ordered figures, never as `value`)
                 try:
                     dtx, rx = timed(lambda: dev.join_group_count_unordered(a, None, b_tab, None, out=out))
-                    return {"ms_per_step": dtx * 1e3, "value": rx[2] / dtx, "served_by_unordered_form": bool(dev.last_join_unordered()),
+                    return {"ms_per_step": dtx * 1e3, "value": rx[2] / dtx, "step_ms": dict(last_dist), "served_by_unordered_form": bool(dev.last_join_unordered()),
                             "same_groups_and_joined_rows": bool(int(rx[0].numel()) == expect[0] and rx[2] == expect[1]),
                             "pipeline": pipe_frac(int(rx[0].numel()), dtx)}
                 except Exception as e:  # pragma: no cover
@@ -942,7 +987,7 @@ def main():
                         dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False))
                         plan_x = dev.last_plan()
                         line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
-                                     "value": ru[3] / dtu, "plan": plan_x,
+                                     "value": ru[3] / dtu, "plan": plan_x, "step_ms": dict(last_dist),
                                      "pipeline": pipe_frac(int(ru[0].numel()), dtu, "U" if tag == "variant_U" else "S",
                                                            lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False)),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),

@@ -163,7 +163,9 @@ def run(args, world, rank, local_rank, json_fd, watchdog=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, steps, warmup):
+    last_dist = {}
+
+    def timed(step, steps, warmup, dev=None):
         r = None
         for _ in range(max(warmup, 1)):
             beat("warm-up step")
@@ -182,6 +184,22 @@ def run(args, world, rank, local_rank, json_fd, watchdog=None):
             all_reduce_(red, dist.ReduceOp.SUM)
             red[0] = tmax[0]
         beat("timed steps done")
+        # how the steps are distributed: the same number again, each between its own synchronisations; `value` stays the mean of the loop above
+        c0 = dev.counters() if dev is not None else None
+        each = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            each.append((time.perf_counter() - t1) * 1e3)
+        v = sorted(each)
+        last_dist.clear()
+        last_dist.update({"steps": steps, "min": v[0], "median": v[steps // 2], "p90": v[min(steps - 1, (9 * steps) // 10)], "max": v[-1], "mean": sum(v) / steps})
+        if dev is not None:
+            c1 = dev.counters()
+            last_dist.update(retries=c1["retries"] - c0["retries"], arena_grows=c1["arena_grows"] - c0["arena_grows"],
+                             alloc_misses=c1["alloc_misses"] - c0["alloc_misses"], plan=dev.last_plan())
         return float(red[0].item()), int(red[1].item())
 
     def roof(algo, ms, kern, tag, note):
@@ -234,14 +252,14 @@ def run(args, world, rank, local_rank, json_fd, watchdog=None):
                 return J
             finally:
                 dev.call_stats()
-        dt, joined = timed(step, args.steps, args.warmup)
+        dt, joined = timed(step, args.steps, args.warmup, dev)
         ms = dt / args.steps * 1e3
         fused = dx is not None and dx.last_fused()
         kern = Prof(dev.lib, dev.h).run(step)
         algo = 8 * 2 * total + 8 * joined * 2
         written = 8 * joined        # ONE key column is written: id_a and id_b hold the same value in every joined row
         line.update({
-            "value": joined / (dt / args.steps), "ms_per_step": ms,
+            "value": joined / (dt / args.steps), "ms_per_step": ms, "step_ms": dict(last_dist),
             "config": {"workload": f"BASELINE configs[3] (SURVEY C4): SELECT * FROM A INNER JOIN B ON id_a = id_b, key columns only, unique keys, "
                                    f"{n} rows/table/GPU x {world} GPU = {total} rows/table; the joined rows' key column is materialised once "
                                    "(id_a and id_b hold the same value in every joined row)",
@@ -299,13 +317,13 @@ def run(args, world, rank, local_rank, json_fd, watchdog=None):
                 r = db.query_device(SQL, copy=False)
                 last["rows"] = r[3]
                 return r[4] if r[4] else r[3]
-            dt, joined = timed(step, args.steps, args.warmup)
+            dt, joined = timed(step, args.steps, args.warmup, db)
             ms = dt / args.steps * 1e3
             kern = Prof(db.lib, db.device_handle()).run(step)
             plan = db.last_plan()
             algo = 8 * 4 * n + 8 * 4 * joined        # four 8-byte columns read once, four written per joined row
             line.update({
-                "value": joined / (dt / args.steps), "ms_per_step": ms,
+                "value": joined / (dt / args.steps), "ms_per_step": ms, "step_ms": dict(last_dist),
                 "config": {"workload": f"BASELINE configs[1] (SURVEY C2): SELECT * FROM A(id_a, fa) INNER JOIN B(id_b, fb) ON id_a = id_b, unique keys, "
                                        f"{n} rows per table, one GPU, through query_execute() with results kept on the device",
                            "query": SQL, "rows_per_table_per_gpu": n, "rows_per_table_total": n, "joined_rows": joined,
@@ -361,8 +379,8 @@ def run(args, world, rank, local_rank, json_fd, watchdog=None):
                     r = db.query_device(sql, copy=False)
                     step.rows = r[3]
                     return r[4]
-                dt, joined = timed(step, steps, args.warmup)
-                res[name] = {"ms_per_step": dt / steps * 1e3, "value": joined / (dt / steps), "joined_rows": joined, "result_rows_rank0": step.rows,
+                dt, joined = timed(step, steps, args.warmup, db)
+                res[name] = {"ms_per_step": dt / steps * 1e3, "step_ms": dict(last_dist), "value": joined / (dt / steps), "joined_rows": joined, "result_rows_rank0": step.rows,
                              "steps": steps, "kernels": prof.run(step), "plan": db.last_plan()}
             g = res["grouped"]
             algo = 8 * 3 * total + 16 * g["joined_rows"]	# three key columns read once, (key, COUNT) per group written (G = joined rows here)

@@ -129,6 +129,16 @@ struct mdb_dev_plan_info {
 				 * COUNT 1), not as a record each: 1 decided by a pilot launch, 2 by what the last call over the columns delivered */
 };
 int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
+/* Running totals since the context was created: what a call that took longer than its neighbours paid for.  Read before and after a timed
+ * loop (bench.py: `retries_in_timed_steps`), they cost the loop nothing. */
+struct mdb_dev_counters {
+	uint64_t operator_calls;	/* outermost join / GROUP BY operator calls */
+	uint64_t retries;		/* times an operator was redone inside them (a plan that did not hold) */
+	uint64_t samples;		/* key-sample kernels, each with a host synchronisation */
+	uint64_t arena_grows;		/* the scratch arena was released and allocated larger (a device synchronisation + hipFree + hipMalloc) */
+	uint64_t alloc_misses;		/* mdb_dev_alloc() calls no released buffer could serve (hipMalloc) */
+};
+int mdb_dev_counters(mdb_dev_ctx *ctx, struct mdb_dev_counters *out);
 size_t mdb_dev_arena_bytes(mdb_dev_ctx *ctx);
 
 /* ------------------------------------------------------------------ memory

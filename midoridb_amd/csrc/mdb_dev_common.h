@@ -117,6 +117,8 @@ struct mdb_dev_ctx : mdb_col_memo {
 	/* mdb_dev_last_plan(): what the current / last operator did beyond the last_* words */
 	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form, pl_group_form, pl_bits;
 	int pl_depth;			/* operators that call operators: the outermost one's entry clears the counters (mdb_plan_scope) */
+	/* mdb_dev_counters(): running totals since the context was created (what a slow call paid for) */
+	uint64_t ct_calls, ct_retries, ct_samples, ct_arena_grows, ct_alloc_misses;
 	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */
 	std::vector<std::pair<mdb_memo_key, mdb_col_memo>> memo_lru;	/* the other pairs' sets, most recently used last */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
@@ -155,8 +157,11 @@ struct mdb_plan_scope {
 	}
 	~mdb_plan_scope()
 	{
-		if (c)
-			c->pl_depth--;
+		if (c && --c->pl_depth == 0) {
+			c->ct_calls++;
+			c->ct_retries += c->pl_retries;
+			c->ct_samples += c->pl_samples;
+		}
 	}
 };
 

@@ -235,6 +235,18 @@ extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out
 }
 
 
+extern "C" int mdb_dev_counters(mdb_dev_ctx *ctx, struct mdb_dev_counters *out)
+{
+	if (!ctx || !out)
+		return -MIDORIDB_ERROR;
+	out->operator_calls = ctx->ct_calls;
+	out->retries = ctx->ct_retries;
+	out->samples = ctx->ct_samples;
+	out->arena_grows = ctx->ct_arena_grows;
+	out->alloc_misses = ctx->ct_alloc_misses;
+	return MIDORIDB_OK;
+}
+
 extern "C" int mdb_dev_set_narrow_keys(mdb_dev_ctx *ctx, int mode)
 {
 	if (mode < 0 || mode > 2)
@@ -285,6 +297,7 @@ int mdb_arena_begin(mdb_dev_ctx *ctx, size_t total_bytes)
 			ctx->arena_cap = 0;
 		}
 		size_t want = total_bytes + total_bytes / 16;
+		ctx->ct_arena_grows++;
 		hipError_t e = hipMalloc((void **)&ctx->arena, want);
 		if (e != hipSuccess)
 			return mdb_set_err(ctx, -MIDORIDB_NOMEM, "scratch arena of %zu bytes: %s", want, hipGetErrorString(e));
@@ -341,6 +354,7 @@ int mdb_cached_alloc(mdb_dev_ctx *ctx, size_t bytes, void **dptr)
 		ctx->cache.erase(ctx->cache.begin() + best);
 		return MIDORIDB_OK;
 	}
+	ctx->ct_alloc_misses++;
 	hipError_t e = hipMalloc(dptr, bytes);
 	if (e != hipSuccess) {
 		/* memory pressure: drop the cache and retry once */

@@ -56,6 +56,20 @@ class PlanInfo(ctypes.Structure):
                                                 "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "groups_as_bits")]
 
 
+class Counters(ctypes.Structure):
+    """struct mdb_dev_counters: running totals of a context"""
+    _fields_ = [(k, ctypes.c_uint64) for k in ("operator_calls", "retries", "samples", "arena_grows", "alloc_misses")]
+
+
+def counters_of(lib, handle):
+    """mdb_dev_counters of a raw context handle -> dict"""
+    _bind(lib)
+    c = Counters()
+    if lib.mdb_dev_counters(handle, byref(c)) != 0:
+        raise RuntimeError("mdb_dev_counters failed")
+    return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
+
+
 def last_plan_of(lib, handle):
     """mdb_dev_last_plan of a raw context handle (a DeviceCtx's, or a database's: DB.device_handle()) -> dict"""
     _bind(lib)
@@ -81,6 +95,7 @@ def _bind(lib):
         "mdb_dev_set_narrow_keys": ([P, c_int], c_int),
         "mdb_dev_last_join_narrow": ([P], c_int),
         "mdb_dev_last_join_filter": ([P], c_int),
+        "mdb_dev_counters": ([P, POINTER(Counters)], c_int),
         "mdb_dev_call_stats": ([P, P, POINTER(ColStats), P, POINTER(ColStats)], c_int),
         "mdb_dev_last_plan": ([P, POINTER(PlanInfo)], c_int),
         "mdb_dev_last_pairs_identity": ([P], c_int),
@@ -145,7 +160,7 @@ def _bind(lib):
 
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
-    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_counters", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_retain", "mdb_dev_holders", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
@@ -256,6 +271,10 @@ class DeviceCtx:
     def last_plan(self):
         """what the last join / GROUP BY operator did (mdb_dev_last_plan) -> dict"""
         return last_plan_of(self.lib, self.h)
+
+    def counters(self):
+        """running totals since the context was created (mdb_dev_counters) -> dict"""
+        return counters_of(self.lib, self.h)
 
     def call_stats(self, keys_l=None, stats_l=None, keys_r=None, stats_r=None):
         """catalog statistics (min, max) of the key columns of the operator calls that follow - call_stats() with nothing ends it"""

@@ -165,6 +165,11 @@ class DB:
         from .dev import last_plan_of
         return last_plan_of(self.lib, self.device_handle())
 
+    def counters(self):
+        """running totals of this database's device context (mdb_dev_counters) -> dict"""
+        from .dev import counters_of
+        return counters_of(self.lib, self.device_handle())
+
     def set_dist(self, dist_handle):
         """the database takes ownership of an mdb_dist* built for device_handle()"""
         if self.lib.mdb_database_set_dist(ctypes.byref(self.db), dist_handle) != 0:

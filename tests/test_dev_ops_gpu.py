@@ -2615,6 +2615,31 @@ def test_call_stats_that_do_not_hold_cost_a_retry_never_a_result(dev):
     assert plan["from_stats"] == 1 and plan["retries"] >= 1, plan
 
 
+def test_counters_say_what_a_call_paid_for(dev):
+    """mdb_dev_counters(): running totals a caller reads around a timed loop (bench.py: retries_in_timed_steps) - a first call over new
+    columns pays a key sample, statistics that do not hold pay a retry, repeated calls pay nothing"""
+    n = 1_200_000
+    a = dev.gen_keys(n, 0, n, 42, 0)
+    b = dev.gen_keys(n, 0, n, 43, n // 16)
+    c0 = dev.counters()
+    dev.join_group_count(a, None, b, None)
+    c1 = dev.counters()
+    assert c1["operator_calls"] == c0["operator_calls"] + 1 and c1["samples"] >= c0["samples"] + 1, (c0, c1)
+    for _ in range(5):
+        dev.join_group_count(a, None, b, None)
+    c2 = dev.counters()
+    assert c2["operator_calls"] == c1["operator_calls"] + 5
+    assert {k: c2[k] - c1[k] for k in ("retries", "samples", "arena_grows", "alloc_misses")} == {"retries": 0, "samples": 0, "arena_grows": 0, "alloc_misses": 0} or \
+        c2["alloc_misses"] > c1["alloc_misses"], (c1, c2)      # (result columns are allocated per call: the allocator's cache may miss; nothing else moves)
+    dev.call_stats(a, (1000, 2000), b, (0, 10))     # a promise the device finds broken: the operator is redone
+    try:
+        dev.join_group_count(a, None, b, None)
+    finally:
+        dev.call_stats()
+    c3 = dev.counters()
+    assert c3["retries"] >= c2["retries"] + 1, (c2, c3)
+
+
 def test_join_payload_plan_names_the_form(dev, monkeypatch):
     rng = np.random.default_rng(10)
     kr = np.unique(rng.integers(0, 1 << 26, 2_000_000, dtype=np.int64))
