@@ -105,8 +105,18 @@ int mdb_dev_last_pairs_identity(mdb_dev_ctx *ctx);
  * keep the sampled decisions. */
 struct mdb_dev_col_stats {
 	int64_t min, max;	/* smallest / largest non-NULL value (a superset range is fine) */
-	uint64_t rows, nulls;	/* informational */
+	uint64_t rows, nulls;	/* rows of the column, NULLs among them (exact when MDB_COL_DISTINCT is set: "the column holds every value of
+				 * [min, max]" is rows - nulls == max - min + 1) */
+	uint64_t flags;		/* MDB_COL_* */
 };
+/* No non-NULL value occurs twice in the column - MEASURED over all its rows (mdb_dev_distinct_scan; the store measures at ingest, follows
+ * appended rows, and drops the verdict with an UPDATE: the reference carries UNIQUE / PRIMARY KEY per column, include/primitive/column.h:41-46,
+ * set by src/engine/executor_create.c:29-58, and never enforces them - so this flag is never taken from DDL).  With it the operators run
+ * the forms that need unique keys without a pilot launch and without remembering a column by its address: a join + GROUP BY of two such
+ * columns leaves its groups as one bit per left row from the first statement on (verified like every promise: counts that do not add up
+ * send the call to the record form), a GROUP BY over one is the identity - the one form that TRUSTS a statistic (verifying it would be the
+ * scan that measured it): set the flag only from a measurement. */
+#define MDB_COL_DISTINCT 1ull
 int mdb_dev_call_stats(mdb_dev_ctx *ctx, const void *keys_l, const struct mdb_dev_col_stats *l, const void *keys_r, const struct mdb_dev_col_stats *r);
 
 /* What the last join / GROUP BY operator of this context did (for tests, EXPLAIN-like output and byte accounting) */
@@ -124,11 +134,33 @@ struct mdb_dev_plan_info {
 	uint32_t samples;	/* key-sample kernels (each with a host synchronisation) the call launched */
 	uint32_t from_stats;	/* 1: windows and ranges came from mdb_dev_call_stats() */
 	uint32_t payload_form;	/* last mdb_dev_join_payload: 0 not served, 1 one level (cells in the leaf's LDS), 2 two levels, 3 row order (tile sort) */
-	uint32_t group_form;	/* last mdb_dev_group_count: 0 the partitioned path (or one of its small-input forms), 1 band sort (4-byte row words), 2 tile sort */
+	uint32_t group_form;	/* last mdb_dev_group_count: 0 the partitioned path (or one of its small-input forms), 1 band sort (4-byte row words), 2 tile sort,
+				 * 3 the identity (MDB_COL_DISTINCT: group i = row i) */
+	uint32_t arena_mib;	/* mdb_dev_explain_* only: MiB of scratch arena the plan asks for (mdb_dev_reserve) */
+	uint32_t small_form;	/* 0, or the operator answered before any partition level: 1 one workgroup in LDS (at most 2048 rows per table), 2 per-workgroup
+				 * LDS tables (both key columns inside one window of at most 4096 values) */
 	uint32_t groups_as_bits;	/* the groups left the leaf kernel as one bit per row + exceptions (nearly unique keys / nearly every left row a group of
-				 * COUNT 1), not as a record each: 1 decided by a pilot launch, 2 by what the last call over the columns delivered */
+				 * COUNT 1), not as a record each: 1 decided by a pilot launch, 2 by what the last call over the columns delivered, 3 by the
+				 * caller's statistics (MDB_COL_DISTINCT on both key columns, the right one holding every value of its range) */
 };
 int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
+/* Plans as data: what mdb_dev_join_group_count (further_tables > 0: mdb_dev_join_group_count_multi) / mdb_dev_group_count WOULD do for key
+ * columns with these statistics - the operators' own decision code, run up to its first launch on a context without a device: a pure host
+ * computation (no GPU needed), so that a change of a heuristic shows as a diff of tests/golden/plans.json.  as_sample != 0: the numbers are
+ * treated as what a key sample found on a first call of a raw caller (from_stats 0, samples 1; the forms that only a catalog's promise
+ * opens are not taken: groups_as_bits 1 = "a pilot launch decides").  The sharded operator's plan: mdb_dist_plan_preview (mdb_dist.h). */
+struct mdb_dev_explain_request {
+	struct mdb_dev_col_stats left, right;	/* rows = the tables' rows; right is ignored by mdb_dev_explain_group_count */
+	uint32_t further_tables;		/* further right tables joined on the same key (0 ... 2) */
+	uint64_t further_rows[2];
+	uint32_t left_nulls_bitmap;		/* != 0: the left key column comes with a NULL bitmap */
+	uint32_t as_sample;
+	uint32_t num_cus;			/* 0: 256 (MI355X) */
+};
+int mdb_dev_explain_join_group_count(const struct mdb_dev_explain_request *rq, struct mdb_dev_plan_info *out);
+int mdb_dev_explain_group_count(const struct mdb_dev_explain_request *rq, struct mdb_dev_plan_info *out);
+int mdb_dev_explain_join_payload(const struct mdb_dev_explain_request *rq, int cells /* 1 or 2 payload columns */, struct mdb_dev_plan_info *out);
+
 /* Running totals since the context was created: what a call that took longer than its neighbours paid for.  Read before and after a timed
  * loop (bench.py: `retries_in_timed_steps`), they cost the loop nothing. */
 struct mdb_dev_counters {
@@ -513,6 +545,12 @@ int mdb_dev_partition_by_dest_pruned(mdb_dev_ctx *ctx, const int64_t *keys, cons
 int mdb_dev_key_range(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t *out_min,
 		      int64_t *out_max);
 int mdb_dev_widen32to64(mdb_dev_ctx *ctx, const int32_t *src, uint64_t n, int64_t *dst);
+/* "no key twice": every non-NULL key of rows [0, n) sets its bit (key - window_lo) in `seen` (a device bitmap of window_bits bits the caller
+ * owns - cleared by the caller before the column's first rows, kept for the rows appended later); *out_twice = 1 when a bit was already set
+ * (a value twice, among these rows or against the rows scanned into `seen` before) or a key lies outside the window (nothing is known then),
+ * else 0.  One scattered atomic per row: ~1.3 ms per 10^8 rows, off the query path.  Synchronises. */
+int mdb_dev_distinct_scan(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t window_lo, uint64_t window_bits,
+			  uint32_t *seen, int *out_twice);
 
 /* ------------------------------------------------------------------ synthetic data (bench / tests)
  * keys[i] = perm(i) mod modulus, perm = the bijection on [0, n) defined in

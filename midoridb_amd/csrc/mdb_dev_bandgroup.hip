@@ -447,6 +447,15 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
 	if (dense_ok)
 		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
+	if (ctx->explain) {	/* (mdb_dev_explain_group_count: the band sort serves - nothing is launched; nearly unique keys: a pilot decides) */
+		ctx->explain->group_form = 1;
+		ctx->explain->key_form = 2;
+		ctx->explain->key_bits = kbits;
+		ctx->explain->from_stats = ctx->explain_as_sample ? 0u : ctx->pl_from_stats;
+		ctx->explain->samples = ctx->explain_as_sample ? 1u : 0u;
+		ctx->explain->groups_as_bits = dense_ok ? 1u : 0u;
+		return MIDORIDB_OK;
+	}
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;

@@ -115,10 +115,13 @@ struct mdb_dev_ctx : mdb_col_memo {
 	const void *cs_kl, *cs_kr;
 	struct mdb_dev_col_stats cs_l, cs_r;
 	/* mdb_dev_last_plan(): what the current / last operator did beyond the last_* words */
-	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form, pl_group_form, pl_bits;
+	uint32_t pl_retries, pl_samples, pl_from_stats, pl_key_bits, pl_payload_form, pl_group_form, pl_bits, pl_small_form;
 	int pl_depth;			/* operators that call operators: the outermost one's entry clears the counters (mdb_plan_scope) */
 	/* mdb_dev_counters(): running totals since the context was created (what a slow call paid for) */
 	uint64_t ct_calls, ct_retries, ct_samples, ct_arena_grows, ct_alloc_misses;
+	/* mdb_dev_explain_*(): the operator's own decision code runs and stops in front of its first launch (a context without a device) */
+	struct mdb_dev_plan_info *explain;
+	bool explain_as_sample;		/* ... as if the statistics were what a key sample found: the forms only a catalog's promise opens are not taken */
 	mdb_memo_key memo_key;		/* the key-column pair the live mdb_col_memo belongs to */
 	std::vector<std::pair<mdb_memo_key, mdb_col_memo>> memo_lru;	/* the other pairs' sets, most recently used last */
 	/* mdb_dev_alloc / mdb_dev_free recycle buffers (stream-ordered reuse on the context's stream): a query
@@ -153,7 +156,7 @@ struct mdb_plan_scope {
 	explicit mdb_plan_scope(mdb_dev_ctx *ctx) : c(ctx)
 	{
 		if (c && c->pl_depth++ == 0)
-			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = c->pl_group_form = c->pl_bits = 0;
+			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = c->pl_group_form = c->pl_bits = c->pl_small_form = 0;
 	}
 	~mdb_plan_scope()
 	{

@@ -231,6 +231,7 @@ extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out
 	out->payload_form = ctx->pl_payload_form;
 	out->group_form = ctx->pl_group_form;
 	out->groups_as_bits = ctx->pl_bits;
+	out->small_form = ctx->pl_small_form;
 	return MIDORIDB_OK;
 }
 
@@ -1394,6 +1395,44 @@ extern "C" int mdb_dev_key_range(mdb_dev_ctx *ctx, const int64_t *keys, const ui
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*out_min = h[0];
 	*out_max = h[1];
+	return MIDORIDB_OK;
+}
+
+/* "no key twice" as a measured statistic (include/mdb_dev.h: MDB_COL_DISTINCT): one bit per key value of the column's window */
+__global__ __launch_bounds__(STREAM_THREADS) void k_distinct_scan(const int64_t *__restrict__ keys, const uint64_t *__restrict__ nullbits, uint64_t n,
+								  int64_t lo, uint64_t bits, uint32_t *seen, uint32_t *flag)
+{
+	bool twice = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * STREAM_THREADS) {
+		if (nullbits && mdb_bit_is_set(nullbits, i))
+			continue;
+		const uint64_t b = (uint64_t)keys[i] - (uint64_t)lo;
+		if (b >= bits) {
+			twice = true;	/* (outside the window: nothing can be said) */
+			continue;
+		}
+		const uint32_t m = 1u << (b & 31u);
+		twice |= (atomicOr(&seen[b >> 5], m) & m) != 0u;
+	}
+	if (__ballot(twice) && mdb_lane() == 0)
+		mdb_raise(flag, 1u);
+}
+
+extern "C" int mdb_dev_distinct_scan(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, int64_t window_lo, uint64_t window_bits,
+				     uint32_t *seen, int *out_twice)
+{
+	*out_twice = 0;
+	if (n == 0)
+		return MIDORIDB_OK;
+	uint32_t *flag = ctx->d_status + 12;
+	MDB_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+	const uint64_t blocks = (n + STREAM_THREADS * STREAM_ROUNDS - 1) / (STREAM_THREADS * STREAM_ROUNDS);
+	MDB_LAUNCH(ctx, "distinct_scan", k_distinct_scan, (uint32_t)(blocks < 8192 ? blocks : 8192), STREAM_THREADS, keys, nullbits, n, window_lo, window_bits,
+		   seen, flag);
+	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+	MDB_HIP(ctx, hipMemcpyAsync(h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_twice = h[0] ? 1 : 0;
 	return MIDORIDB_OK;
 }
 

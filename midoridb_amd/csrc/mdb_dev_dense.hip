@@ -131,3 +131,30 @@ int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n,
 	}
 	return MIDORIDB_OK;
 }
+
+/* ------------------------------------------------------------------ GROUP BY over a column the catalog knows to hold no value twice
+ * (mdb_dev_group_count): group i = row i, COUNT 1 */
+__global__ __launch_bounds__(256) void k_group_identity(uint64_t n, uint32_t *__restrict__ out_first, long long *__restrict__ out_count)
+{
+	const uint64_t i4 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+	if (i4 + 3u < n && !((uintptr_t)out_first & 15u) && !((uintptr_t)out_count & 15u)) {
+		*reinterpret_cast<uint4 *>(out_first + i4) = make_uint4((uint32_t)i4, (uint32_t)i4 + 1u, (uint32_t)i4 + 2u, (uint32_t)i4 + 3u);
+		*reinterpret_cast<longlong2 *>(out_count + i4) = make_longlong2(1ll, 1ll);
+		*reinterpret_cast<longlong2 *>(out_count + i4 + 2u) = make_longlong2(1ll, 1ll);
+	} else {
+		for (uint64_t i = i4; i < n && i < i4 + 4u; i++) {
+			out_first[i] = (uint32_t)i;
+			out_count[i] = 1ll;
+		}
+	}
+}
+
+int mdb_group_identity(mdb_dev_ctx *ctx, uint64_t n, uint32_t *out_first, int64_t *out_count)
+{
+	if (!n)
+		return MIDORIDB_OK;
+	const uint64_t blocks = (n + 1023u) / 1024u;
+	MDB_LAUNCH(ctx, "group_identity", k_group_identity, (uint32_t)blocks, 256, n, out_first, reinterpret_cast<long long *>(out_count));
+	return MIDORIDB_OK;
+}
+

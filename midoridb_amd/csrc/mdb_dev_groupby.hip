@@ -149,7 +149,7 @@ int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 			    const uint64_t *null_r, uint64_t n_r, bool null_group, int64_t *out_key, uint32_t *out_first, int64_t *out_count,
 			    uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
 {
-	if (n + (keys_r ? n_r : 0) < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
+	if (n + (keys_r ? n_r : 0) < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || ((!out_first || !out_count) && !ctx->explain))
 		return 1;
 	if (keys_r && (n_r >= 0xFFFFFFFFull || ((uintptr_t)keys_r & 15) || n_r == 0))
 		return 1;
@@ -175,6 +175,11 @@ int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 	const size_t order_bytes = mdb_order_records_arena_bytes(GD_TABLE_MAX + 1, n, &kbits);
 	if (!order_bytes)
 		return 1;
+	if (ctx->explain) {	/* (mdb_dev_explain_*: per-workgroup LDS tables over a window of at most 4096 values - nothing is launched) */
+		ctx->explain->small_form = 2;
+		ctx->explain->from_stats = ctx->pl_from_stats;
+		return MIDORIDB_OK;
+	}
 	rc = mdb_arena_begin(ctx, order_bytes + 6 * mdb_align_up((GD_TABLE_MAX + 1) * 8) + 8192);
 	if (rc)
 		return rc;
@@ -471,7 +476,7 @@ int group_hashed_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 			    int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
 	if (n < GD_MIN_ROWS || n >= 0xFFFFFFFFull || ((uintptr_t)keys & 15) || !out_first || !out_count)
-		return 1;
+		return 1;	/* (mdb_dev_explain_group_count passes no outputs: whether a column has few distinct values is no statistic a catalog hands over) */
 	/* distinct values in a sample of the column, remembered like the range sample */
 	uint32_t distinct;
 	if (ctx->gh_keys == keys && ctx->gh_n == n && ++ctx->gh_uses < GC_HINT_USES) {

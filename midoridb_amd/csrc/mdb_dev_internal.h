@@ -217,6 +217,9 @@ int mdb_sort_pairs(mdb_dev_ctx *ctx, const uint32_t *a, const uint32_t *b, uint6
  * mdb_dev_alloc.  joined = the sum of the counts (< 2^32).  Synchronises. */
 int mdb_expand_keys_by_count(mdb_dev_ctx *ctx, const int64_t *key, const int64_t *count, uint64_t groups, uint64_t joined, int64_t **out);
 
+/* group i = row i, COUNT 1 (mdb_dev_dense.hip): a GROUP BY over a column whose statistics say MDB_COL_DISTINCT */
+int mdb_group_identity(mdb_dev_ctx *ctx, uint64_t n, uint32_t *out_first, int64_t *out_count);
+
 /* choose level bits so that the average leaf holds about `target` keys */
 void mdb_choose_bits(uint64_t n, uint32_t target, int *bits1, int *bits2);
 

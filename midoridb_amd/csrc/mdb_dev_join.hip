@@ -1477,6 +1477,10 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	}
 	if (st->wide12 && st->nextra <= 1)	/* (the groups as one bit per left row + exceptions, mdb_dev_dense.hip) */
 		need += mdb_dense_arena_bytes(st->n_l) + mdb_align_up((st->n_l / 8 + 4096) * 8);
+	if (ctx->explain) {	/* (mdb_dev_explain_*: the plan is made - no arena, no launch) */
+		ctx->explain->arena_mib = (uint32_t)((need + (1u << 20) - 1) >> 20);
+		return GC_EXPLAINED;
+	}
 	int rc = mdb_arena_begin(ctx, need);
 	if (rc)
 		return rc;
@@ -1508,6 +1512,62 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 }
 
 /* second half: partition the right table, join + count per leaf, order the groups, deliver */
+
+/* ---- decisions that only a caller's statistics open (mdb_dev_call_stats), shared by the operator and by mdb_dev_explain_join_group_count */
+/* one-level joins: the groups are few enough (a group needs a right key: at most as many as values in the right column's range) for the
+ * ordering kernel's ranges - k_leaf_wide4 writes its records straight into them on the FIRST call */
+static bool gc_ranged_by_stats(const mdb_dev_ctx *ctx, const int64_t *keys_l, const int64_t *keys_r, uint64_t n_l, uint64_t n_r, uint32_t kbits, uint32_t *rg_n)
+{
+	if (!(ctx->cs_on && !ctx->explain_as_sample && ctx->cs_kl == keys_l && ctx->cs_has_r && ctx->cs_kr == keys_r && ctx->cs_r.min <= ctx->cs_r.max) ||
+	    (getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0'))
+		return false;
+	const uint64_t span_r = (uint64_t)ctx->cs_r.max - (uint64_t)ctx->cs_r.min + 1;
+	uint64_t bound = span_r && span_r < n_r ? span_r : n_r;
+	bound = bound < n_l ? bound : n_l;
+	return order_ranges_apply(n_l, kbits, bound, rg_n);
+}
+
+/* the one-pass 4096-digit join of two tables: no key twice in the left column, none twice in the right one (MDB_COL_DISTINCT, measured at
+ * ingest), and the right column holds EVERY value of its range, which covers the left column's - every left row is a group of COUNT 1,
+ * whatever the statement before this one was: the groups leave as one bit per left row without a pilot launch and its host round trip */
+static bool gc_bits_by_stats(const mdb_dev_ctx *ctx, int nextra, const int64_t *keys_l, const int64_t *keys_r, uint64_t n_r)
+{
+	return !nextra && ctx->dn_distrust == 0 && ctx->cs_on && !ctx->explain_as_sample && ctx->cs_kl == keys_l && ctx->cs_has_r && ctx->cs_kr == keys_r &&
+	       (ctx->cs_l.flags & MDB_COL_DISTINCT) && (ctx->cs_r.flags & MDB_COL_DISTINCT) && !ctx->cs_r.nulls && ctx->cs_r.min <= ctx->cs_r.max &&
+	       (uint64_t)ctx->cs_r.max - (uint64_t)ctx->cs_r.min + 1 == n_r && ctx->cs_l.min >= ctx->cs_r.min && ctx->cs_l.max <= ctx->cs_r.max;
+}
+
+/* whether the bit-per-row form of the groups may be asked at all (every left row must reach the leaf kernel for its bit to be looked at) */
+static bool gc_bits_possible(const gc_state *st, bool records, bool has_r, uint64_t cap, uint64_t n_l)
+{
+	return st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l && !st->r_based &&
+	       !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0');
+}
+
+/* mdb_dev_explain_join_group_count: the plan gc_begin has just made, as mdb_dev_last_plan would report it after the run */
+static void gc_explain_fill(mdb_dev_ctx *ctx, const gc_state *st, const int64_t *keys_r, uint64_t n_r, uint64_t cap)
+{
+	struct mdb_dev_plan_info *o = ctx->explain;
+	uint32_t kbits = 0, rg_n = 0;
+	int sb1 = 0, sb2 = 0;
+	const bool records = st->want_records && order_bits(st->n_l, &kbits, &sb1, &sb2);
+	o->key_form = st->narrow ? (st->key_bits ? 2u : 1u) : 0u;
+	o->key_bits = st->narrow ? st->key_bits : 0u;
+	o->levels = (st->one_level || st->wide12) ? 1u : 2u;
+	o->digits = st->wide12 ? 4096u : 512u;
+	o->minmax_pruned = (st->defer_l || st->defer_l64) ? 1u : 0u;
+	o->semijoin = st->semijoin;
+	o->multi_one_pass = st->nextra ? 1u : 0u;
+	o->from_stats = ctx->explain_as_sample ? 0u : ctx->pl_from_stats;
+	o->samples = ctx->explain_as_sample ? 1u : 0u;
+	const bool w16 = st->one_level && st->has_r && !(getenv("MDB_WORDS16") && getenv("MDB_WORDS16")[0] == '0');
+	const bool leaf4 = st->one_level && st->has_r && w16 && records && !st->null_group && st->n_l <= (1ull << 27) && st->key_bits >= (uint32_t)st->b1 + 10u &&
+			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
+	o->ranged_order = leaf4 && gc_ranged_by_stats(ctx, st->keys_l, keys_r, st->n_l, n_r, kbits, &rg_n) ? 1u : 0u;
+	if (gc_bits_possible(st, records, st->has_r, cap, st->n_l))
+		o->groups_as_bits = gc_bits_by_stats(ctx, st->nextra, st->keys_l, keys_r, n_r) ? 3u : 1u /* (a pilot launch decides) */;
+}
+
 static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, const uint64_t *null_r, uint64_t n_r,
 		     int64_t *out_key, int64_t *out_count, uint32_t *out_first, uint64_t cap, uint64_t *out_groups,
 		     uint64_t *out_joined)
@@ -1762,13 +1822,8 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		      !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
 	/* ... or the caller's statistics say so before any join has run (mdb_dev_call_stats): a group needs a right key, and there are at
 	 * most as many of those as values in the right column's range */
-	if (!ranged && leaf4 && ctx->cs_on && ctx->cs_kl == keys_l && ctx->cs_has_r && ctx->cs_kr == keys_r && ctx->cs_r.min <= ctx->cs_r.max &&
-	    !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0')) {
-		const uint64_t span_r = (uint64_t)ctx->cs_r.max - (uint64_t)ctx->cs_r.min + 1;
-		uint64_t bound = span_r && span_r < n_r ? span_r : n_r;
-		bound = bound < n_l ? bound : n_l;
-		ranged = order_ranges_apply(n_l, kbits, bound, &rg_n);
-	}
+	if (!ranged && leaf4)
+		ranged = gc_ranged_by_stats(ctx, keys_l, keys_r, n_l, n_r, kbits, &rg_n);
 	a.rg_rec = NULL;
 	a.rg_cnt = NULL;
 	a.rg_cap = a.rg_shift = a.rg_n = 0;
@@ -1798,10 +1853,17 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	/* (every left row must reach the leaf kernel for its bit to be looked at: no NULL keys, no window that covers the right table's keys
 	 * only - left rows outside it are dropped by the first level; rows dropped for another reason show as G + cleared != n_l below and
 	 * send the call to the record form) */
-	if (st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l && !st->r_based &&
-	    !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0')) {
-		bool want_bits = false, by_pilot = false;
-		if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
+	if (gc_bits_possible(st, records, has_r, cap, n_l)) {
+		bool want_bits = false, by_pilot = false, by_stats = false;
+		/* The catalog says (MDB_COL_DISTINCT, measured at ingest): no key twice in the left column, none twice in the right one, and the
+		 * right column holds EVERY value of its range, which covers the left column's - every left row is a group of COUNT 1, whatever
+		 * the statement before this one was: no pilot launch and its host round trip, nothing remembered by the columns' addresses.
+		 * (Two tables only; a promise that does not hold shows below as it does for the other two ways to get here: G + cleared != n_l,
+		 * or more exceptions than the list holds - the call is redone with records.) */
+		if (gc_bits_by_stats(ctx, st->nextra, keys_l, keys_r, n_r)) {
+			want_bits = true;
+			by_stats = true;
+		} else if (ctx->lg_valid && ctx->lg_nextra == (uint32_t)st->nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r) {
 			/* (what the last join over these very columns delivered) */
 			if (ctx->lg_groups >= n_l - n_l / 16 && ctx->lg_joined <= ctx->lg_groups + ctx->lg_groups / 16) {
 				if (ctx->dn_distrust > 0)
@@ -1837,7 +1899,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			a.dn_exc = (unsigned long long *)mdb_arena_take(ctx, (size_t)a.dn_exc_cap * 8);
 			if (!a.dn_exc)
 				return -MIDORIDB_INTERNAL;
-			ctx->pl_bits = by_pilot ? 1u : 2u;
+			ctx->pl_bits = by_stats ? 3u : by_pilot ? 1u : 2u;
 		}
 	}
 	{
@@ -2500,6 +2562,8 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 		}
 	}
 	int rc = gc_begin(ctx, &st);
+	if (rc == GC_EXPLAINED)		/* (mdb_dev_explain_*: gc_begin stopped in front of its arena) */
+		gc_explain_fill(ctx, &st, keys_r, n_r, cap);
 	if (rc)
 		return rc;
 	return gc_finish(ctx, &st, keys_r, null_r, n_r, out_key, out_count, out_first, cap, out_groups, out_joined);
@@ -2590,7 +2654,7 @@ static int group_count_common(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
 		else
 			break;
 	}
-	return rc;
+	return rc == GC_EXPLAINED ? MIDORIDB_OK : rc;
 }
 
 /* ------------------------------------------------------------------ tiny inputs: one kernel, one workgroup
@@ -2717,8 +2781,13 @@ int tiny_group_count(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nu
 			    const uint64_t *null_r, uint64_t n_r, bool has_r, bool null_group, int64_t *out_key, int64_t *out_count,
 			    uint32_t *out_first, uint64_t cap, uint64_t *out_groups, uint64_t *out_joined)
 {
-	if (n_l == 0 || n_l > TINY_ROWS || (has_r && (n_r == 0 || n_r > TINY_ROWS)) || !out_count)
+	if (n_l == 0 || n_l > TINY_ROWS || (has_r && (n_r == 0 || n_r > TINY_ROWS)) || (!out_count && !ctx->explain))
 		return 1;
+	if (ctx->explain) {
+		ctx->explain->small_form = 1;
+		return MIDORIDB_OK;
+	}
+	ctx->pl_small_form = 1;
 	tiny_args a;
 	memset(&a, 0, sizeof(a));
 	a.keys_l = keys_l;
@@ -3090,6 +3159,12 @@ extern "C" int mdb_dev_join_group_count_multi(mdb_dev_ctx *ctx, const int64_t *k
 	}
 	if (rc != GC_NOT_SERVED)
 		return rc;
+	if (ctx->explain) {	/* (mdb_dev_explain_*: the chain of two-table operators - its first step's plan, multi_one_pass 0) */
+		uint64_t g0 = 0, j0 = 0;
+		rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r[0], null_r ? null_r[0] : NULL, n_r[0], flags, NULL, NULL, NULL, n_l ? n_l : 1, &g0, &j0);
+		ctx->explain->multi_one_pass = 0;
+		return rc;
+	}
 	/* ---- the chain: groups of (L, R0), then (those group keys, R1) ..., counts multiplied */
 	*out_groups = 0;
 	int64_t *key[2] = { NULL, NULL }, *cnt[3] = { NULL, NULL, NULL };
@@ -3199,6 +3274,25 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	mdb_plan_scope plan_scope(ctx);
 	(void)flags;
 	*out_groups = 0;
+	/* The catalog says no value occurs twice in this NULL-free column (MDB_COL_DISTINCT: measured at ingest over all rows, followed through
+	 * every append, dropped with an UPDATE): every row is the first and only row of its group - the reference's loop
+	 * (/root/reference/src/engine/executor_select.c:1526-1588) would find no second row for any key.  Written without looking at a key:
+	 * 12 bytes per row.  (The one form that TRUSTS a statistic: verifying it is the scan that measured it.) */
+	if (ctx->cs_on && !ctx->explain_as_sample && ctx->cs_kl == keys && !ctx->cs_has_r && (ctx->cs_l.flags & MDB_COL_DISTINCT) && !nullbits && n && n <= cap &&
+	    n < 0xFFFFFFFFull && !(getenv("MDB_GROUP_IDENTITY") && getenv("MDB_GROUP_IDENTITY")[0] == '0')) {
+		if (ctx->explain) {
+			ctx->explain->group_form = 3;
+			ctx->explain->from_stats = 1;
+			return MIDORIDB_OK;
+		}
+		int rc = mdb_group_identity(ctx, n, out_first, out_count);
+		if (rc)
+			return rc;
+		ctx->pl_from_stats = 1;
+		ctx->pl_group_form = 3;
+		*out_groups = n;
+		return MIDORIDB_OK;
+	}
 	mdb_memo_switch(ctx, keys, n, NULL, 0);
 	{
 		const int trc = tiny_group_count(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups, NULL);
@@ -3248,4 +3342,95 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	}
 	return group_count_common(ctx, keys, nullbits, n, NULL, NULL, 0, false, true, NULL, out_count, out_first, cap, out_groups,
 				  NULL);
+}
+
+/* ------------------------------------------------------------------ plans as data (include/mdb_dev.h: mdb_dev_explain_*)
+ *
+ * A context without a device - only what the decision code reads (CU count, key-form mode, an empty memo) - gets the caller's statistics
+ * under two made-up column addresses, ctx->explain points at the answer, and the operator's ENTRY POINT is called: every path it takes
+ * stops where it would launch (tiny_group_count, group_direct_try, group_count_run behind gc_begin). */
+#define EXPLAIN_KL ((const int64_t *)0x1000)
+#define EXPLAIN_KR ((const int64_t *)0x2000)
+#define EXPLAIN_KX ((const int64_t *)0x3000)
+
+static mdb_dev_ctx *explain_ctx(const struct mdb_dev_explain_request *rq, struct mdb_dev_plan_info *out, bool has_r)
+{
+	mdb_dev_ctx *ctx = new (std::nothrow) mdb_dev_ctx();
+	if (!ctx)
+		return NULL;
+	memset(static_cast<mdb_col_memo *>(ctx), 0, sizeof(mdb_col_memo));
+	ctx->nh_result = -1;
+	ctx->device = -1;
+	ctx->num_cus = rq->num_cus ? (int)rq->num_cus : 256;
+	ctx->narrow_mode = 1;
+	ctx->err[0] = 0;
+	memset(out, 0, sizeof(*out));
+	ctx->explain = out;
+	ctx->explain_as_sample = rq->as_sample != 0;
+	ctx->cs_on = true;
+	ctx->cs_kl = EXPLAIN_KL;
+	ctx->cs_l = rq->left;
+	ctx->cs_has_r = has_r;
+	if (has_r) {
+		ctx->cs_kr = EXPLAIN_KR;
+		ctx->cs_r = rq->right;
+	}
+	return ctx;
+}
+
+extern "C" int mdb_dev_explain_join_group_count(const struct mdb_dev_explain_request *rq, struct mdb_dev_plan_info *out)
+{
+	if (!rq || !out || rq->further_tables > 2)
+		return -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = explain_ctx(rq, out, true);
+	if (!ctx)
+		return -MIDORIDB_NOMEM;
+	const uint64_t n_l = rq->left.rows, n_r = rq->right.rows;
+	const uint64_t *null_l = rq->left_nulls_bitmap ? (const uint64_t *)0x4000 : NULL;
+	uint64_t groups = 0, joined = 0;
+	int rc;
+	if (rq->further_tables) {
+		const int64_t *rk[3] = { EXPLAIN_KR, EXPLAIN_KX, EXPLAIN_KX + 0x1000 };
+		const uint64_t *rn[3] = { NULL, NULL, NULL };
+		const uint64_t rows[3] = { n_r, rq->further_rows[0], rq->further_rows[1] };
+		rc = mdb_dev_join_group_count_multi(ctx, EXPLAIN_KL, null_l, n_l, 1 + (int)rq->further_tables, rk, rn, rows, MDB_ORDER_FIRST, NULL, NULL, NULL,
+						    n_l, &groups, &joined);
+	} else {
+		rc = mdb_dev_join_group_count(ctx, EXPLAIN_KL, null_l, n_l, EXPLAIN_KR, NULL, n_r, MDB_ORDER_FIRST, NULL, NULL, NULL, n_l, &groups, &joined);
+	}
+	if (rc && getenv("MDB_DEBUG_EXPLAIN"))
+		fprintf(stderr, "mdb_dev_explain_join_group_count: %d (%s)\n", rc, ctx->err);
+	delete ctx;
+	return rc;
+}
+
+extern "C" int mdb_dev_explain_join_payload(const struct mdb_dev_explain_request *rq, int cells, struct mdb_dev_plan_info *out)
+{
+	if (!rq || !out || cells < 1 || cells > 2)
+		return -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = explain_ctx(rq, out, true);
+	if (!ctx)
+		return -MIDORIDB_NOMEM;
+	const void *pay[2] = { (const void *)0x5000, (const void *)0x6000 };
+	void *dst[2] = { (void *)0x7000, (void *)0x8000 };
+	int rc = mdb_dev_join_payload(ctx, EXPLAIN_KL, rq->left_nulls_bitmap ? (const uint64_t *)0x4000 : NULL, rq->left.rows, EXPLAIN_KR, NULL, rq->right.rows, pay,
+				      cells, dst);
+	if (rc == 1)
+		rc = MIDORIDB_OK;	/* (not served: payload_form 0 - mdb_dev_join_pairs and a gather answer) */
+	delete ctx;
+	return rc;
+}
+
+extern "C" int mdb_dev_explain_group_count(const struct mdb_dev_explain_request *rq, struct mdb_dev_plan_info *out)
+{
+	if (!rq || !out)
+		return -MIDORIDB_ERROR;
+	mdb_dev_ctx *ctx = explain_ctx(rq, out, false);
+	if (!ctx)
+		return -MIDORIDB_NOMEM;
+	uint64_t groups = 0;
+	const int rc = mdb_dev_group_count(ctx, EXPLAIN_KL, rq->left_nulls_bitmap ? (const uint64_t *)0x4000 : NULL, rq->left.rows, MDB_ORDER_FIRST, NULL, NULL,
+					   rq->left.rows, &groups);
+	delete ctx;
+	return rc;
 }

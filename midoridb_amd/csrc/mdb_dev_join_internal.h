@@ -192,6 +192,7 @@ enum gc_internal_rc {
 	GC_RETRY_REC64,	/* internal: 4-byte group records were written on a remembered verdict that no longer holds: redo with 8-byte ones */
 	GC_RETRY_TWO_LEVEL,	/* internal: a 16-bit row count of k_leaf_wide overflowed (ctx->lw_bad_* remember the columns): redo with two levels */
 	GC_RETRY_NODENSE,	/* internal: the bit-per-row form of the groups met more groups of COUNT != 1 than its list holds (ctx->dn_distrust is set) */
+	GC_EXPLAINED,	/* internal: mdb_dev_explain_*() - the plan is written, nothing was launched */
 	GC_NOT_SERVED,	/* internal: further right tables, but the operator did not take the two-level direct-address form (or a product of counts overflowed, or a hot leaf): the caller chains two-table operators instead */
 };
 #define GC_ST_LEFT_DUPS 32768u	/* status bit 15: a key that has partners has several rows in the LEFT table (raised by the direct-address leaf kernels) */

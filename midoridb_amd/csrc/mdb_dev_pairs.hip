@@ -1175,6 +1175,17 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	for (int c = 0; c < npay; c++)
 		if (!pay_in[c] || !out[c])
 			return -MIDORIDB_ERROR;
+	auto explained = [&](uint32_t form, uint32_t kbits, uint32_t levels, size_t arena) {	/* (mdb_dev_explain_join_payload: nothing is launched) */
+		ctx->explain->payload_form = form;
+		ctx->explain->key_form = 2;
+		ctx->explain->key_bits = kbits;
+		ctx->explain->levels = levels;
+		ctx->explain->digits = 512;
+		ctx->explain->from_stats = ctx->explain_as_sample ? 0u : ctx->pl_from_stats;
+		ctx->explain->samples = ctx->explain_as_sample ? 1u : 0u;
+		ctx->explain->arena_mib = (uint32_t)((arena + (1u << 20) - 1) >> 20);
+		return MIDORIDB_OK;
+	};
 	if (n_l == 0 || n_r == 0 || n_l >= 0xFFFFFFFFull || n_r >= 0xFFFFFFFFull || n_l + n_r < (1ull << 20) || ld_disabled() ||
 	    (getenv("MDB_JOIN_PAYLOAD") && getenv("MDB_JOIN_PAYLOAD")[0] == '0'))
 		return 1;
@@ -1197,6 +1208,8 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	 * row (mdb_dev_rowjoin.hip): windows of up to 2^27 values, NULL-free 16-byte-aligned columns */
 	if (mdb_rowjoin_serves(n_l, n_r, win.kbits, keys_l, null_l, keys_r, null_r, pay_in, out, npay)) {
 		const uint32_t kbits = win.kbits;
+		if (ctx->explain)
+			return explained(3, kbits, 1, mdb_rowjoin_arena_bytes(n_l, n_r, kbits, npay) + 8192);
 		rc = mdb_arena_begin(ctx, mdb_rowjoin_arena_bytes(n_l, n_r, kbits, npay) + 8192);
 		if (rc)
 			return rc;
@@ -1242,6 +1255,8 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		const uint32_t rem = kbits - (uint32_t)(b1 + b2);
 		if (b2 < 1 || b2 > MDB_MAX_RADIX_BITS || n_l >= 0xF0000000ull || n_r >= 0xF0000000ull)
 			return 1;
+		if (ctx->explain)
+			return explained(2, kbits, 2, mdb_partition_arena_bytes(n_l, b1, b2, false, true) + mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay) + 8192);
 		rc = mdb_arena_begin(ctx, mdb_partition_arena_bytes(n_l, b1, b2, false, true) + mdb_partition_arena_bytes(n_r, b1, b2, false, true, npay) + 8192);
 		if (rc)
 			return rc;
@@ -1318,6 +1333,8 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	const int b1 = 9;
 	/* (a dimension table of a few thousand keys: the window may be wider than its keys need) */
 	const uint32_t kbits = win.kbits < 9u + PW_MIN_REM ? 9u + PW_MIN_REM : win.kbits, rem = kbits - (uint32_t)b1, shift = 32u - kbits;
+	if (ctx->explain)
+		return explained(1, kbits, 1, mdb_partition_level0_arena_bytes(n_l, b1) + mdb_partition_level0_arena_bytes(n_r, b1, false, npay) + 8192);
 	rc = mdb_arena_begin(ctx, mdb_partition_level0_arena_bytes(n_l, b1) + mdb_partition_level0_arena_bytes(n_r, b1, false, npay) + 8192);
 	if (rc)
 		return rc;

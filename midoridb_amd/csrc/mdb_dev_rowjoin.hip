@@ -950,6 +950,14 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	int sb1 = 0, sb2 = 0;
 	if (!order_bits(n, &row_bits, &sb1, &sb2))
 		return 1;
+	if (ctx->explain) {	/* (mdb_dev_explain_group_count: the tile sort serves - nothing is launched) */
+		ctx->explain->group_form = 2;
+		ctx->explain->key_form = 2;
+		ctx->explain->key_bits = kbits;
+		ctx->explain->from_stats = ctx->explain_as_sample ? 0u : ctx->pl_from_stats;
+		ctx->explain->samples = ctx->explain_as_sample ? 1u : 0u;
+		return MIDORIDB_OK;
+	}
 	const uint32_t ntiles = (uint32_t)rj_tiles(n);
 	const size_t ostride = (size_t)D + 8u;
 	const uint64_t values = (uint64_t)1 << kbits, most = (n < values ? n : values) + 1024;	/* groups: at most the rows, at most the window's key values */

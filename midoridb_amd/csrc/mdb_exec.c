@@ -309,6 +309,9 @@ void op_stats_begin(struct exec *x, const struct mdb_expr *fl, const void *pl, c
 			return;
 		st[i].rows = tb->device_only ? tb->dev_rows : tb->nrows;
 		st[i].nulls = col->null_count;
+		/* (measured at ingest, followed through appended rows; a filtered stream of a column without a value twice has none either) */
+		if (mdb_col_distinct(x->cat, tb, col))
+			st[i].flags |= MDB_COL_DISTINCT;
 	}
 	(void)mdb_dev_call_stats(x->dev, pl, &st[0], fr ? pr : NULL, fr ? &st[1] : NULL);
 }

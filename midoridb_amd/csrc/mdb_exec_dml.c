@@ -33,6 +33,7 @@ int mdb_exec_create(struct mdb_catalog *cat, struct mdb_create *c, char *err, si
 		mdb_table_add_column(t, c->colname[i], c->coltype[i]);
 		t->cols[i].precision = c->colprec[i];
 		t->cols[i].not_null = c->notnull[i];
+		t->cols[i].declared_unique = c->unique[i];
 	}
 	return mdb_catalog_add(cat, t);
 }

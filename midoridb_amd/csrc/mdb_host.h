@@ -66,6 +66,17 @@ struct mdb_column {
 	 * what every join / GROUP BY operator is handed instead of sampling its key columns (mdb_dev_call_stats) */
 	uint64_t st_generation;
 	int64_t st_lo, st_hi;
+	/* "no non-NULL value twice" - MEASURED on the device over all rows (mdb_dev_distinct_scan), as of table generation dv_generation - 1
+	 * (0 = not measured): at ingest, followed through appended rows (the bitmap of the values seen stays on the device while it is small),
+	 * looked at again after an UPDATE / DELETE when somebody asks (mdb_col_distinct).  The reference keeps UNIQUE / PRIMARY KEY per
+	 * column (include/primitive/column.h:41-46, set by src/engine/executor_create.c:29-58) and never enforces them: declared_unique only
+	 * says the column is worth measuring whatever it looks like. */
+	uint64_t dv_generation;
+	bool dv_distinct;
+	bool declared_unique;
+	uint32_t *d_seen;		/* device bitmap: bit (value - seen_lo) of every non-NULL value of the rows measured (NULL: not kept) */
+	int64_t seen_lo;
+	uint64_t seen_bits;
 };
 
 struct mdb_table {
@@ -139,6 +150,9 @@ int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *er
 int mdb_table_bulk_copy(struct mdb_catalog *cat, struct mdb_table *t, int ncols, uint64_t n, const int64_t *const *cols, bool *mirrored);
 void mdb_table_bulk_mirrored(struct mdb_catalog *cat, struct mdb_table *t, uint64_t old_rows, uint64_t old_generation);
 bool mdb_col_has_range(const struct mdb_column *col);
+/* is the column known to hold no non-NULL value twice, as of now?  Measures (one pass on the device) when nothing is known for this generation and
+ * the column is large enough to matter or declared UNIQUE / PRIMARY KEY; false when unknown or not measurable (key window too wide for a bitmap) */
+bool mdb_col_distinct(struct mdb_catalog *cat, struct mdb_table *t, struct mdb_column *col);
 int mdb_col_range(struct mdb_catalog *cat, struct mdb_table *t, struct mdb_column *col, int64_t *lo, int64_t *hi);	/* 0 ok, 1 no range for this type */
 int mdb_catalog_device(struct mdb_catalog *cat, char *err, size_t errlen);
 
@@ -213,7 +227,8 @@ struct mdb_create {
 	int coltype[MDB_MAX_COLS];
 	int colprec[MDB_MAX_COLS];	/* VARCHAR length */
 	bool notnull[MDB_MAX_COLS];	/* ATTR NOTNULL / ATTR PRIKEY in front of the COLUMNDEF (midorisql.y:468-472) */
-	bool pending_notnull;		/* (builder state: attributes seen for the column being defined) */
+	bool unique[MDB_MAX_COLS];	/* ATTR UNIQUEKEY / ATTR PRIKEY: never enforced (upstream neither) - the column's distinct-ness gets MEASURED */
+	bool pending_notnull, pending_unique;	/* (builder state: attributes seen for the column being defined) */
 };
 
 struct mdb_insert {

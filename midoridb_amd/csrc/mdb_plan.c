@@ -555,12 +555,16 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 		/* ---- CREATE TABLE ---- */
 		} else if (!strcmp(t, "STARTCOL")) {
 			out->crt.pending_notnull = false;
+			out->crt.pending_unique = false;
 			continue;
 		} else if (starts(t, "ATTR ")) {
 			/* NOT NULL and PRIMARY KEY make the column non-nullable (reference executor_create.c:37,53); AUTO_INCREMENT
 			 * and UNIQUE are parsed and ignored upstream as well */
 			if (!strcmp(t + 5, "NOTNULL") || !strcmp(t + 5, "PRIKEY"))
 				out->crt.pending_notnull = true;
+			/* (UNIQUE / PRIMARY KEY: not enforced here either - remembered as "worth measuring", mdb_col_distinct) */
+			if (!strcmp(t + 5, "UNIQUEKEY") || !strcmp(t + 5, "PRIKEY"))
+				out->crt.pending_unique = true;
 			continue;
 		} else if (starts(t, "COLUMNDEF ")) {
 			struct mdb_create *c = &out->crt;
@@ -581,7 +585,9 @@ int mdb_plan_build(const struct mdb_rpn *rpn, struct mdb_stmt *out, char *err, s
 			c->coltype[c->ncols] = type;
 			c->colprec[c->ncols] = type == MDB_CT_VARCHAR ? x % 10000 : 8;
 			c->notnull[c->ncols] = c->pending_notnull;
+			c->unique[c->ncols] = c->pending_unique;
 			c->pending_notnull = false;
+			c->pending_unique = false;
 			c->ncols++;
 			continue;
 		} else if (starts(t, "CREATE ")) {

@@ -47,13 +47,52 @@ class ProfEntry(ctypes.Structure):
 
 class ColStats(ctypes.Structure):
     """struct mdb_dev_col_stats: what a catalog knows about a key column (include/mdb_dev.h)"""
-    _fields_ = [("min", c_int64), ("max", c_int64), ("rows", c_uint64), ("nulls", c_uint64)]
+    _fields_ = [("min", c_int64), ("max", c_int64), ("rows", c_uint64), ("nulls", c_uint64), ("flags", c_uint64)]
+
+
+COL_DISTINCT = 1     # MDB_COL_DISTINCT
 
 
 class PlanInfo(ctypes.Structure):
     """struct mdb_dev_plan_info: what the last join / GROUP BY operator did"""
     _fields_ = [(k, ctypes.c_uint32) for k in ("key_form", "key_bits", "levels", "digits", "minmax_pruned", "semijoin", "any_order", "ranged_order",
-                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "groups_as_bits")]
+                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "arena_mib", "small_form", "groups_as_bits")]
+
+
+class ExplainRequest(ctypes.Structure):
+    """struct mdb_dev_explain_request"""
+    _fields_ = [("left", ColStats), ("right", ColStats), ("further_tables", c_uint32), ("further_rows", c_uint64 * 2), ("left_nulls_bitmap", c_uint32),
+                ("as_sample", c_uint32), ("num_cus", c_uint32)]
+
+
+def explain(op, left, right=None, further_rows=(), as_sample=False, left_nulls_bitmap=False, num_cus=256, lib=None, cells=1):
+    """plans as data - what the operator WOULD run for key columns with these statistics, without a GPU (mdb_dev_explain_*).
+    op: "join_group_count" | "group_count" | "join_payload" (cells payload columns); left / right: dicts with min, max, rows and
+    optionally nulls, distinct -> plan dict"""
+    lib = lib or load_library()
+    _bind(lib)
+
+    def st(d):
+        return ColStats(int(d["min"]), int(d["max"]), int(d["rows"]), int(d.get("nulls", 0)), COL_DISTINCT if d.get("distinct") else 0)
+    rq = ExplainRequest()
+    rq.left = st(left)
+    if right is not None:
+        rq.right = st(right)
+    rq.further_tables = len(further_rows)
+    for i, r in enumerate(further_rows):
+        rq.further_rows[i] = int(r)
+    rq.left_nulls_bitmap = 1 if left_nulls_bitmap else 0
+    rq.as_sample = 1 if as_sample else 0
+    rq.num_cus = num_cus
+    info = PlanInfo()
+    if op == "join_payload":
+        rc = lib.mdb_dev_explain_join_payload(byref(rq), int(cells), byref(info))
+    else:
+        fn = lib.mdb_dev_explain_join_group_count if op == "join_group_count" else lib.mdb_dev_explain_group_count
+        rc = fn(byref(rq), byref(info))
+    if rc != 0:
+        raise RuntimeError(f"mdb_dev_explain_{op} failed ({rc})")
+    return {k: int(getattr(info, k)) for k, _ in PlanInfo._fields_}
 
 
 class Counters(ctypes.Structure):
@@ -96,6 +135,10 @@ def _bind(lib):
         "mdb_dev_last_join_narrow": ([P], c_int),
         "mdb_dev_last_join_filter": ([P], c_int),
         "mdb_dev_counters": ([P, POINTER(Counters)], c_int),
+        "mdb_dev_explain_join_group_count": ([POINTER(ExplainRequest), POINTER(PlanInfo)], c_int),
+        "mdb_dev_explain_group_count": ([POINTER(ExplainRequest), POINTER(PlanInfo)], c_int),
+        "mdb_dev_explain_join_payload": ([POINTER(ExplainRequest), c_int, POINTER(PlanInfo)], c_int),
+        "mdb_dev_distinct_scan": ([P, P, P, c_uint64, c_int64, c_uint64, P, POINTER(c_int)], c_int),
         "mdb_dev_call_stats": ([P, P, POINTER(ColStats), P, POINTER(ColStats)], c_int),
         "mdb_dev_last_plan": ([P, POINTER(PlanInfo)], c_int),
         "mdb_dev_last_pairs_identity": ([P], c_int),
@@ -160,7 +203,7 @@ def _bind(lib):
 
 DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
-    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_counters", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
+    "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_counters", "mdb_dev_distinct_scan", "mdb_dev_explain_join_group_count", "mdb_dev_explain_group_count", "mdb_dev_explain_join_payload", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
     "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_retain", "mdb_dev_holders", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
@@ -272,14 +315,26 @@ class DeviceCtx:
         """what the last join / GROUP BY operator did (mdb_dev_last_plan) -> dict"""
         return last_plan_of(self.lib, self.h)
 
+    def distinct(self, keys, nulls=None, key_range=None):
+        """no non-NULL key twice? - measured with mdb_dev_distinct_scan over a fresh bitmap of the column's window (what the store does at ingest)"""
+        lo, hi = key_range if key_range is not None else self.key_range(keys, nulls)
+        if lo > hi:
+            return True
+        bits = hi - lo + 1
+        seen = torch.zeros((bits + 31) // 32, dtype=torch.int32, device=self.device)
+        tw = c_int(0)
+        self._chk(self.lib.mdb_dev_distinct_scan(self.h, _ptr(keys), _ptr(nulls) if nulls is not None else None, keys.numel(), lo, bits, _ptr(seen), byref(tw)),
+                  "distinct_scan")
+        return tw.value == 0
+
     def counters(self):
         """running totals since the context was created (mdb_dev_counters) -> dict"""
         return counters_of(self.lib, self.h)
 
     def call_stats(self, keys_l=None, stats_l=None, keys_r=None, stats_r=None):
         """catalog statistics (min, max) of the key columns of the operator calls that follow - call_stats() with nothing ends it"""
-        def st(col, v):
-            return None if v is None else ColStats(int(v[0]), int(v[1]), col.numel(), 0)
+        def st(col, v):      # v = (min, max) or (min, max, flags)
+            return None if v is None else ColStats(int(v[0]), int(v[1]), col.numel(), 0, int(v[2]) if len(v) > 2 else 0)
         sl, sr = st(keys_l, stats_l), st(keys_r, stats_r)
         self._chk(self.lib.mdb_dev_call_stats(self.h, _ptr(keys_l) if sl is not None else None, byref(sl) if sl is not None else None,
                                               _ptr(keys_r) if sr is not None else None, byref(sr) if sr is not None else None), "call_stats")

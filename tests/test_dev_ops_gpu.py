@@ -2640,6 +2640,48 @@ def test_counters_say_what_a_call_paid_for(dev):
     assert c3["retries"] >= c2["retries"] + 1, (c2, c3)
 
 
+def test_distinct_statistic_runs_the_bit_form_without_a_pilot_and_a_wrong_flag_never_costs_a_result(dev):
+    """round 6: MDB_COL_DISTINCT in mdb_dev_call_stats (what the store measures at ingest with mdb_dev_distinct_scan): two key columns without a
+    value twice, the right one holding every value of its range - the join + GROUP BY leaves its groups as one bit per left row on the first
+    call (groups_as_bits == 3: by statistics; no pilot, no sample); a flag that does not hold is caught by the leaf's own counting"""
+    rng = np.random.default_rng(61)
+    n = 17_000_000
+    ka, kb = rng.permutation(n).astype(np.int64) + 40, rng.permutation(n).astype(np.int64) + 40
+    a, b = dev.to_dev(ka), dev.to_dev(kb)
+    assert dev.distinct(a) and dev.distinct(b)
+    dev.call_stats(a, (40, n + 39, 1), b, (40, n + 39, 1))
+    try:
+        k, c, f, j = dev.join_group_count(a, None, b, None)
+        plan = dev.last_plan()
+    finally:
+        dev.call_stats()
+    assert plan["groups_as_bits"] == 3 and plan["samples"] == 0 and plan["retries"] == 0 and plan["digits"] == 4096, plan
+    assert j == n and np.array_equal(_np(k), ka) and bool((_np(c) == 1).all()) and np.array_equal(_np(f), np.arange(n))
+    # the same promise over a column that DOES hold a value twice (a raw caller's mistake): one left row finds no partner, one finds two
+    kb2 = kb.copy()
+    kb2[5] = kb2[6]
+    b2 = dev.to_dev(kb2)
+    assert not dev.distinct(b2)
+    a2 = a.clone()      # (fresh addresses: nothing remembered)
+    dev.call_stats(a2, (40, n + 39, 1), b2, (40, n + 39, 1))
+    try:
+        k, c, f, j = dev.join_group_count(a2, None, b2, None)
+    finally:
+        dev.call_stats()
+    cnt = np.bincount(kb2 - 40, minlength=n)
+    sel = cnt[ka - 40] > 0
+    assert j == n and np.array_equal(_np(k), ka[sel]) and np.array_equal(_np(c), cnt[ka - 40][sel]) and np.array_equal(_np(f), np.nonzero(sel)[0])
+    # GROUP BY over a distinct column: the identity (group_form 3)
+    dev.call_stats(a, (40, n + 39, 1))
+    try:
+        gf, gc_ = dev.group_count(a, None)[:2]
+        plan = dev.last_plan()
+    finally:
+        dev.call_stats()
+    assert plan["group_form"] == 3, plan
+    assert np.array_equal(_np(gf), np.arange(n)) and bool((_np(gc_) == 1).all())
+
+
 def test_join_payload_plan_names_the_form(dev, monkeypatch):
     rng = np.random.default_rng(10)
     kr = np.unique(rng.integers(0, 1 << 26, 2_000_000, dtype=np.int64))
