@@ -144,6 +144,8 @@ struct mdb_dev_plan_info {
 				 * caller's statistics (MDB_COL_DISTINCT on both key columns, the right one holding every value of its range) */
 };
 int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
+/* The MDB_* environment knobs are read once per process and kept: a process that changes one while it runs calls this. */
+void mdb_dev_reload_knobs(void);
 /* Plans as data: what mdb_dev_join_group_count (further_tables > 0: mdb_dev_join_group_count_multi) / mdb_dev_group_count WOULD do for key
  * columns with these statistics - the operators' own decision code, run up to its first launch on a context without a device: a pure host
  * computation (no GPU needed), so that a change of a heuristic shows as a diff of tests/golden/plans.json.  as_sample != 0: the numbers are

@@ -424,7 +424,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 {
 	*outside = false;
 	if (kbits < 18u || kbits > 14u + BG_MAX_DBITS || n < ((uint64_t)1 << 21) || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
-	    (getenv("MDB_GROUP_BANDED") && getenv("MDB_GROUP_BANDED")[0] == '0'))
+	    (mdb_knob("MDB_GROUP_BANDED") && mdb_knob("MDB_GROUP_BANDED")[0] == '0'))
 		return 1;
 	/* the regions overflowed on this very column last time (a hot key): not tried again for a while */
 	if (ctx->ex_keys == keys && ctx->ex_nl == n && ctx->ex_nr == 0 && ctx->ex_uses < GC_HINT_USES)
@@ -444,7 +444,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	size_t need = mdb_align_up((size_t)nbands * bstride * 4 + 64) + mdb_align_up((size_t)D * nbands * 4) + mdb_align_up(most * 8) +
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	/* (nearly unique keys need nearly as many key values as rows: a window with fewer cannot hold them - no pilot) */
-	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
+	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(mdb_knob("MDB_GROUP_DENSE") && mdb_knob("MDB_GROUP_DENSE")[0] == '0');
 	if (dense_ok)
 		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	if (ctx->explain) {	/* (mdb_dev_explain_group_count: the band sort serves - nothing is launched; nearly unique keys: a pilot decides) */
@@ -480,7 +480,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	sa.nfull = nfull;
 	sa.ntiles = ntiles;
 	sa.status = ctx->d_status;
-	sa.ablate = getenv("MDB_BG_ABLATE") ? (uint32_t)atoi(getenv("MDB_BG_ABLATE")) : 0u;
+	sa.ablate = mdb_knob("MDB_BG_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_BG_ABLATE")) : 0u;
 	const size_t lds_sort = ((size_t)(D >> 1) + D + BG_TILE / 32u + BG_TILE) * 4;
 	if (nfull) {
 		const uint32_t full_bands = (nfull + BG_BAND_TILES - 1u) / BG_BAND_TILES, grid = ((full_bands + 7u) & ~7u) * BG_BAND_TILES;	/* (8 XCDs x bands per XCD x tiles per band) */
@@ -552,7 +552,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
 			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 			const uint32_t dstatus = ps[0], dgroups = ps[1], n_exc = ps[5];
-			if (getenv("MDB_DEBUG_GROUP"))
+			if (mdb_knob("MDB_DEBUG_GROUP"))
 				fprintf(stderr, "group_count (band sort, dense): pilot %llu of %llu rows not first; %u groups, %u rows not first, %u exceptions, status %u\n",
 					(unsigned long long)pilot_dups, (unsigned long long)pilot_rows, dgroups, ps[4], n_exc, dstatus);
 			if (!(dstatus & (16384u | 128u | 2u)) && (uint64_t)dgroups + ps[4] == n) {
@@ -578,7 +578,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const uint32_t *hs = reinterpret_cast<const uint32_t *>(&h[1]);
 	const uint32_t status = hs[0], groups = hs[1], list_len = hs[2];
-	if (getenv("MDB_DEBUG_GROUP"))
+	if (mdb_knob("MDB_DEBUG_GROUP"))
 		fprintf(stderr, "group_count (band sort): window 2^%u at %lld, %u digits, %u bands, %u words per region: status %u, %u groups\n", kbits,
 			(long long)win_lo, D, nbands, rcap, status, groups);
 	if (status & 128u) {

@@ -149,6 +149,8 @@ struct mdb_dev_ctx : mdb_col_memo {
 };
 
 int mdb_set_err(mdb_dev_ctx *ctx, int code, const char *fmt, ...);
+/* the value of an MDB_* environment knob (NULL: not set) - the library's ONE reader of the environment, kept per process (mdb_dev_core.hip) */
+extern "C" const char *mdb_knob(const char *name);
 
 /* first statement of every public join / GROUP BY operator: what mdb_dev_last_plan() counts starts at the OUTERMOST operator's entry */
 struct mdb_plan_scope {

@@ -30,6 +30,39 @@ extern "C" int mdb_dev_device_count(void)
 	return n;
 }
 
+
+/* ------------------------------------------------------------------ environment knobs: ONE reader
+ *
+ * Every MDB_* knob of the library (INTEGRATION.md lists them) is read through mdb_knob(): looked up in the environment ONCE per process and
+ * kept - the operators ask for a handful per call, on the call path.  A process that changes a knob while it runs (tests, same-process A/B
+ * scripts) says so: mdb_dev_reload_knobs() (the Python binding does it whenever os.environ changes an MDB_* variable). */
+#include <mutex>
+static std::mutex g_knob_mu;
+static struct { const char *name; char *value; } g_knobs[192];
+static int g_nknobs = 0;
+
+extern "C" const char *mdb_knob(const char *name)
+{
+	std::lock_guard<std::mutex> g(g_knob_mu);
+	for (int i = 0; i < g_nknobs; i++)
+		if (g_knobs[i].name == name || !strcmp(g_knobs[i].name, name))
+			return g_knobs[i].value;
+	const char *v = getenv(name);
+	if (g_nknobs == (int)(sizeof(g_knobs) / sizeof(g_knobs[0])))
+		return v;	/* (more knobs than slots: read through) */
+	g_knobs[g_nknobs].name = name;		/* (string literals of the library) */
+	g_knobs[g_nknobs].value = v ? strdup(v) : NULL;
+	return g_knobs[g_nknobs++].value;
+}
+
+extern "C" void mdb_dev_reload_knobs(void)
+{
+	std::lock_guard<std::mutex> g(g_knob_mu);
+	for (int i = 0; i < g_nknobs; i++)
+		free(g_knobs[i].value);
+	g_nknobs = 0;
+}
+
 static void memo_reset(mdb_col_memo &m)
 {
 	memset(&m, 0, sizeof(m));	/* (plain data: pointers, counters, flags) */
@@ -81,7 +114,7 @@ extern "C" int mdb_dev_ctx_create(int device, void *stream, mdb_dev_ctx **out)
 	memo_reset(*ctx);
 	ctx->memo_key = mdb_memo_key{ NULL, NULL, 0, 0 };
 	{
-		const char *e = getenv("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
+		const char *e = mdb_knob("MDB_NARROW_KEYS");	/* whole-suite soaks: force one form (see mdb_dev_set_narrow_keys) */
 		if (e && e[0] >= '0' && e[0] <= '2' && !e[1])
 			ctx->narrow_mode = e[0] - '0';
 	}
@@ -195,7 +228,7 @@ extern "C" int mdb_dev_call_stats(mdb_dev_ctx *ctx, const void *keys_l, const st
 	ctx->cs_on = false;
 	ctx->cs_has_r = false;
 	ctx->cs_kl = ctx->cs_kr = NULL;
-	if (!keys_l || !l || (getenv("MDB_CALL_STATS") && getenv("MDB_CALL_STATS")[0] == '0'))	/* (the knob: A/B runs against the sampled decisions) */
+	if (!keys_l || !l || (mdb_knob("MDB_CALL_STATS") && mdb_knob("MDB_CALL_STATS")[0] == '0'))	/* (the knob: A/B runs against the sampled decisions) */
 		return MIDORIDB_OK;
 	if ((keys_r != NULL) != (r != NULL))
 		return mdb_set_err(ctx, -MIDORIDB_ERROR, "mdb_dev_call_stats: a right key column and its statistics go together");

@@ -1261,7 +1261,7 @@ bool ld_disabled(void)
 {
 	static int v = -1;
 	if (v < 0) {
-		const char *e = getenv("MDB_DIRECT_LEAF");
+		const char *e = mdb_knob("MDB_DIRECT_LEAF");
 		v = (e && e[0] == '0') ? 1 : 0;
 	}
 	return v == 1;
@@ -1346,7 +1346,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			!ld_disabled() && !lw_bad &&
 			st->n_l + (st->has_r ? st->n_r_cap : 0) >= (1ull << 21) &&
 			st->n_l < 3000000000ull && st->n_r_cap < 3000000000ull &&
-			!(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0');
+			!(mdb_knob("MDB_ONE_LEVEL") && mdb_knob("MDB_ONE_LEVEL")[0] == '0');
 	if (st->nextra)
 		st->one_level = false;	/* (further right tables: the two-level direct-address kernel counts them) */
 	/* key windows of 2^24 ... 2^27 values (10^8 unique keys: variants U and S): what two 9-bit levels and k_leaf_direct did - the left
@@ -1356,7 +1356,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * (measured equal to the two-level form at 8 * 10^6 rows per table, 15 % faster at 10^8: profiles/micro/one_pass_4096_sweep.py;
 	 * MDB_WIDE12_MIN=<rows> moves the threshold, MDB_WIDE12=0 switches the form off) */
 	{
-		const char *e = getenv("MDB_WIDE12"), *e2 = getenv("MDB_WIDE12_MIN");
+		const char *e = mdb_knob("MDB_WIDE12"), *e2 = mdb_knob("MDB_WIDE12_MIN");
 		const uint64_t min_rows = e2 && atoll(e2) > 0 ? (uint64_t)atoll(e2) : (1ull << 24);
 		st->wide12 = !st->one_level && st->narrow && st->has_r && st->key_bits > 9u + LW_MAX_REM && st->key_bits <= 12u + LW_MAX_REM + 1u && st->fast &&
 			     st->want_records && !ld_disabled() && st->defer_ok && !st->active && st->nextra <= 1 && !st->keys32 &&
@@ -1395,7 +1395,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 		 * it prefers FEWER, larger leaves than the hashed kernel's 3833-slot table allows - tables of 2^LD_MAX_REM entries when
 		 * the second level has the bits to give (10^8 x 10^8 rows: 2^15 leaves of 2 x 3052 rows instead of 2^16; second-level
 		 * fan-out 128: -4 % on its scatter kernels as well).  MDB_LD_REM=<bits> overrides the target. */
-		const char *e = getenv("MDB_LD_REM");
+		const char *e = mdb_knob("MDB_LD_REM");
 		/* (further right tables take 4 more bytes of LDS per entry each: tables of 2^11 entries keep three workgroups on a CU -
 		 * three tables of 10^8 rows: leaf kernel 0.72 -> 0.52 ms) */
 		const uint32_t want = e && atoi(e) >= 4 && atoi(e) <= (int)LD_MAX_REM ? (uint32_t)atoi(e) : (st->nextra ? LD_MAX_REM - 1u : LD_MAX_REM);
@@ -1425,7 +1425,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 	 * from device memory and drops every row outside - the classic dimension-range pruning of a fact table, exact, at the
 	 * price of one compare per row.  Where it removes most left rows (the right table's SPAN is small: by_span) the bitmap
 	 * below would filter nothing more and is not built. */
-	const char *prune_env = getenv("MDB_MINMAX_PRUNE");		/* 0: never, 2: whatever the key sample says (tests) */
+	const char *prune_env = mdb_knob("MDB_MINMAX_PRUNE");		/* 0: never, 2: whatever the key sample says (tests) */
 	st->defer_l = st->narrow && st->fast && (st->b2 > 0 || st->one_level) && st->has_r && st->defer_ok && !st->active &&
 		      (st->prunable || (st->direct && st->selective) || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
 	/* ... and in the 64-bit form (hashes, snowflake ids: keys beyond every 2^32 window) just the same - the range test does not
@@ -1435,7 +1435,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 			(st->prunable || (prune_env && prune_env[0] == '2')) && !(prune_env && prune_env[0] == '0');
 	st->semijoin = 0;
 	if (st->defer_l && st->direct && !st->one_level && st->selective && !st->by_span) {
-		const char *e = getenv("MDB_SEMIJOIN"), *e2 = getenv("MDB_SEMIJOIN_SLICE");
+		const char *e = mdb_knob("MDB_SEMIJOIN"), *e2 = mdb_knob("MDB_SEMIJOIN_SLICE");
 		const uint32_t slice_max = e2 && atoi(e2) >= 7 && atoi(e2) <= 18 ? (uint32_t)atoi(e2) : 17u;	/* log2 bits: 2^17 = 16 KiB */
 		const uint32_t below0 = st->key_bits - (uint32_t)st->b1;		/* hash bits below the first-level digit */
 		const uint32_t coarse = below0 > slice_max ? below0 - slice_max : 0u;
@@ -1519,7 +1519,7 @@ static int gc_begin(mdb_dev_ctx *ctx, gc_state *st)
 static bool gc_ranged_by_stats(const mdb_dev_ctx *ctx, const int64_t *keys_l, const int64_t *keys_r, uint64_t n_l, uint64_t n_r, uint32_t kbits, uint32_t *rg_n)
 {
 	if (!(ctx->cs_on && !ctx->explain_as_sample && ctx->cs_kl == keys_l && ctx->cs_has_r && ctx->cs_kr == keys_r && ctx->cs_r.min <= ctx->cs_r.max) ||
-	    (getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0'))
+	    (mdb_knob("MDB_ORDER_RANGES") && mdb_knob("MDB_ORDER_RANGES")[0] == '0'))
 		return false;
 	const uint64_t span_r = (uint64_t)ctx->cs_r.max - (uint64_t)ctx->cs_r.min + 1;
 	uint64_t bound = span_r && span_r < n_r ? span_r : n_r;
@@ -1541,7 +1541,7 @@ static bool gc_bits_by_stats(const mdb_dev_ctx *ctx, int nextra, const int64_t *
 static bool gc_bits_possible(const gc_state *st, bool records, bool has_r, uint64_t cap, uint64_t n_l)
 {
 	return st->wide12 && st->nextra <= 1 && records && has_r && cap && n_l >= ((uint64_t)1 << 22) && !st->null_l && !st->r_based &&
-	       !(getenv("MDB_JOIN_BITS") && getenv("MDB_JOIN_BITS")[0] == '0');
+	       !(mdb_knob("MDB_JOIN_BITS") && mdb_knob("MDB_JOIN_BITS")[0] == '0');
 }
 
 /* mdb_dev_explain_join_group_count: the plan gc_begin has just made, as mdb_dev_last_plan would report it after the run */
@@ -1560,9 +1560,9 @@ static void gc_explain_fill(mdb_dev_ctx *ctx, const gc_state *st, const int64_t 
 	o->multi_one_pass = st->nextra ? 1u : 0u;
 	o->from_stats = ctx->explain_as_sample ? 0u : ctx->pl_from_stats;
 	o->samples = ctx->explain_as_sample ? 1u : 0u;
-	const bool w16 = st->one_level && st->has_r && !(getenv("MDB_WORDS16") && getenv("MDB_WORDS16")[0] == '0');
+	const bool w16 = st->one_level && st->has_r && !(mdb_knob("MDB_WORDS16") && mdb_knob("MDB_WORDS16")[0] == '0');
 	const bool leaf4 = st->one_level && st->has_r && w16 && records && !st->null_group && st->n_l <= (1ull << 27) && st->key_bits >= (uint32_t)st->b1 + 10u &&
-			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
+			   !(mdb_knob("MDB_LEAF4") && mdb_knob("MDB_LEAF4")[0] == '0');
 	o->ranged_order = leaf4 && gc_ranged_by_stats(ctx, st->keys_l, keys_r, st->n_l, n_r, kbits, &rg_n) ? 1u : 0u;
 	if (gc_bits_possible(st, records, st->has_r, cap, st->n_l))
 		o->groups_as_bits = gc_bits_by_stats(ctx, st->nextra, st->keys_l, keys_r, n_r) ? 3u : 1u /* (a pilot launch decides) */;
@@ -1635,7 +1635,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		mdb_part_filter rflt;
 		memset(&rflt, 0, sizeof(rflt));
 		rflt.level0_only = st->one_level;
-		rflt.out16 = st->one_level && !(getenv("MDB_WORDS16") && getenv("MDB_WORDS16")[0] == '0');
+		rflt.out16 = st->one_level && !(mdb_knob("MDB_WORDS16") && mdb_knob("MDB_WORDS16")[0] == '0');
 		if (st->own_call) {
 			rflt.cursor0_ext = ctx->d_status + MDB_ZERO_BLK_OFF;
 			rflt.cursor0_ext_words = MDB_ZERO_BLK_SLOT;
@@ -1790,7 +1790,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	 * MDB_KEYED_RECORDS=0 switches them off */
 	uint32_t keyed_cbits = 0;
 	if (st->direct && has_r && !st->nextra && st->selective && records && !ctx->keyed_distrust && pl.leaf_cap && pr.leaf_cap && kbits >= 13 &&
-	    kbits + st->key_bits + 4u <= 64u && !(getenv("MDB_KEYED_RECORDS") && getenv("MDB_KEYED_RECORDS")[0] == '0'))
+	    kbits + st->key_bits + 4u <= 64u && !(mdb_knob("MDB_KEYED_RECORDS") && mdb_knob("MDB_KEYED_RECORDS")[0] == '0'))
 		keyed_cbits = 64u - kbits - st->key_bits;
 	if (ctx->keyed_distrust > 0)
 		ctx->keyed_distrust--;
@@ -1812,14 +1812,14 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	 * hold more than 31 right or 15 left rows of a key (MDB_LEAF4=0 switches it off) */
 	const bool leaf4 = st->one_level && has_r && pr.w16 && records && !null_group && n_l <= (1ull << 27) && st->key_bits >= (uint32_t)pl.bits_total + 10u &&
 			   !(ctx->l4_bad_keys == keys_l && ctx->l4_bad_nl == n_l && ctx->l4_bad_nr == n_r && ++ctx->l4_bad_uses <= MDB_BAD_LEAF_USES) &&
-			   !(getenv("MDB_LEAF4") && getenv("MDB_LEAF4")[0] == '0');
+			   !(mdb_knob("MDB_LEAF4") && mdb_knob("MDB_LEAF4")[0] == '0');
 	/* ... and when the last join over these very columns told how many groups to expect, and they are few enough for the ordering kernel's
 	 * ranges of 2^16 row ids, k_leaf_wide4 writes its records straight into those ranges: no record list, none of the two scatter levels that
 	 * would partition it by row id (MDB_ORDER_RANGES=0 switches it off) */
 	uint32_t rg_n = 0;
 	bool ranged = leaf4 && ctx->lg_valid && !ctx->lg_nextra && ctx->lg_kl == keys_l && ctx->lg_nl == n_l && ctx->lg_kr == keys_r && ctx->lg_nr == n_r &&
 		      order_ranges_apply(n_l, kbits, ctx->lg_groups + ctx->lg_groups / 8, &rg_n) &&
-		      !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
+		      !(mdb_knob("MDB_ORDER_RANGES") && mdb_knob("MDB_ORDER_RANGES")[0] == '0');
 	/* ... or the caller's statistics say so before any join has run (mdb_dev_call_stats): a group needs a right key, and there are at
 	 * most as many of those as values in the right column's range */
 	if (!ranged && leaf4)
@@ -1886,7 +1886,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 			const uint64_t p_groups = pw[8], p_cleared = pw[12], p_exc = pw[13], p_rows = p_groups + p_cleared;
 			want_bits = p_rows && p_cleared * 16 <= p_rows && p_exc * 16 <= p_rows;
 			by_pilot = true;
-			if (getenv("MDB_DEBUG_GROUP"))
+			if (mdb_knob("MDB_DEBUG_GROUP"))
 				fprintf(stderr, "join + GROUP BY (pilot over 64 digits): %llu left rows, %llu no group's first row, %llu groups of COUNT != 1 -> %s\n",
 					(unsigned long long)p_rows, (unsigned long long)p_cleared, (unsigned long long)p_exc, want_bits ? "a bit per left row" : "records");
 			MDB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, 13 * sizeof(uint32_t), ctx->stream));	/* (the flags of word 0 stay: they are facts about the data) */
@@ -1971,7 +1971,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 	 * (its writes bounded by the caller's capacity; should the status words ask for another path, that path writes the columns again) - the
 	 * step's only sync then comes after its last kernel (MDB_ORDER_EARLY=0: after the leaf kernel, as elsewhere) */
 	bool ordered_early = false;
-	if (ranged && cap && !(getenv("MDB_ORDER_EARLY") && getenv("MDB_ORDER_EARLY")[0] == '0')) {
+	if (ranged && cap && !(mdb_knob("MDB_ORDER_EARLY") && mdb_knob("MDB_ORDER_EARLY")[0] == '0')) {
 		rc = order_presorted(ctx, a.rg_rec, a.rg_cnt, rg_n, kbits, out_first, out_count, keys_l, out_key, st->keys32, keyed_cbits, st->key_bits,
 				     st->key_lo, cap);
 		if (rc)
@@ -2121,7 +2121,7 @@ static int gc_finish(mdb_dev_ctx *ctx, gc_state *st, const int64_t *keys_r, cons
 		const uint64_t last_first = (uint32_t)(h[5] >> 32);
 		const uint64_t n_ord = (st->one_level && last_first && last_first < n_l) ? last_first + 1 : n_l;
 		if (dn_bits) {
-			if (getenv("MDB_DEBUG_GROUP"))
+			if (mdb_knob("MDB_DEBUG_GROUP"))
 				fprintf(stderr, "join + GROUP BY (bit per left row): %llu groups, %u rows cleared of %llu, %u exceptions, status %u\n",
 					(unsigned long long)G, dn_cleared, (unsigned long long)n_l, dn_exceptions, status);
 			if ((status & 131072u) || (uint64_t)G + dn_cleared != n_l) {	/* (more groups of COUNT != 1 than last time: the record form) */
@@ -2414,7 +2414,7 @@ int gc_narrow_guess(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *nul
 {
 	*narrow = false;
 	*base = 0;
-	prune_ok = prune_ok && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+	prune_ok = prune_ok && !(mdb_knob("MDB_MINMAX_PRUNE") && mdb_knob("MDB_MINMAX_PRUNE")[0] == '0');
 	if (win) {
 		win->kbits = 0;
 		win->lo = 0;
@@ -2552,7 +2552,7 @@ static int group_count_run(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64
 	st.r_based = win.r_based;
 	st.keys32 = keys32;
 	st.defer_ok = true;
-	st.own_call = !(getenv("MDB_ZERO_BLOCK") && getenv("MDB_ZERO_BLOCK")[0] == '0');
+	st.own_call = !(mdb_knob("MDB_ZERO_BLOCK") && mdb_knob("MDB_ZERO_BLOCK")[0] == '0');
 	if (gc_pending_extras && has_r) {
 		st.nextra = gc_pending_extras->n;
 		for (int x = 0; x < st.nextra; x++) {
@@ -2834,7 +2834,7 @@ static int gc_unordered_try(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint6
 			    uint64_t *out_joined, int n_extra = 0, const int64_t *const *keys_x = NULL, const uint64_t *const *null_x = NULL,
 			    const uint64_t *n_x = NULL /* further right tables on the same key: their rows outside the window join nothing */)
 {
-	if (n_l + n_r < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (getenv("MDB_UNORDERED") && getenv("MDB_UNORDERED")[0] == '0'))
+	if (n_l + n_r < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (mdb_knob("MDB_UNORDERED") && mdb_knob("MDB_UNORDERED")[0] == '0'))
 		return 1;
 	bool fresh = false;
 	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
@@ -2882,7 +2882,7 @@ again: {
 	MDB_HIP(ctx, hipMemcpyAsync(h, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (h[0]) {
-		if (getenv("MDB_DEBUG_UNORDERED"))
+		if (mdb_knob("MDB_DEBUG_UNORDERED"))
 			fprintf(stderr, "unordered form not served: flags %u (k %u, b2 %u, rem %u)\n", h[0], plan.kbits, plan.b2, plan.rem);
 		if ((h[0] & 128u) && remembered && !fresh) {
 			fresh = true;	/* the window came from a remembered sample and the column's contents have changed since */
@@ -2912,7 +2912,7 @@ extern "C" int mdb_dev_group_count_keys(mdb_dev_ctx *ctx, const int64_t *keys, c
 	if (!ctx || !out_groups || !out_key || !out_count)
 		return -MIDORIDB_ERROR;
 	*out_groups = 0;
-	if (nullbits || n < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (getenv("MDB_UNORDERED") && getenv("MDB_UNORDERED")[0] == '0'))
+	if (nullbits || n < (1ull << 21) || ctx->narrow_mode == 0 || ld_disabled() || (mdb_knob("MDB_UNORDERED") && mdb_knob("MDB_UNORDERED")[0] == '0'))
 		return 1;
 	mdb_memo_switch(ctx, keys, n, NULL, 0);
 	uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
@@ -2952,7 +2952,7 @@ extern "C" int mdb_dev_group_count_keys(mdb_dev_ctx *ctx, const int64_t *keys, c
 			*out_groups = h[1];
 			return MIDORIDB_OK;
 		}
-		if (getenv("MDB_DEBUG_UNORDERED"))
+		if (mdb_knob("MDB_DEBUG_UNORDERED"))
 			fprintf(stderr, "group_count_keys not served: flags %u (k %u, b2 %u, rem %u)\n", h[0], plan.kbits, plan.b2, plan.rem);
 		if (!((h[0] & 128u) && remembered && attempt == 0)) {	/* (a remembered sample of a column whose contents changed: taken again, once) */
 			if (h[0] & 128u)
@@ -3279,7 +3279,7 @@ extern "C" int mdb_dev_group_count(mdb_dev_ctx *ctx, const int64_t *keys, const 
 	 * (/root/reference/src/engine/executor_select.c:1526-1588) would find no second row for any key.  Written without looking at a key:
 	 * 12 bytes per row.  (The one form that TRUSTS a statistic: verifying it is the scan that measured it.) */
 	if (ctx->cs_on && !ctx->explain_as_sample && ctx->cs_kl == keys && !ctx->cs_has_r && (ctx->cs_l.flags & MDB_COL_DISTINCT) && !nullbits && n && n <= cap &&
-	    n < 0xFFFFFFFFull && !(getenv("MDB_GROUP_IDENTITY") && getenv("MDB_GROUP_IDENTITY")[0] == '0')) {
+	    n < 0xFFFFFFFFull && !(mdb_knob("MDB_GROUP_IDENTITY") && mdb_knob("MDB_GROUP_IDENTITY")[0] == '0')) {
 		if (ctx->explain) {
 			ctx->explain->group_form = 3;
 			ctx->explain->from_stats = 1;
@@ -3398,7 +3398,7 @@ extern "C" int mdb_dev_explain_join_group_count(const struct mdb_dev_explain_req
 	} else {
 		rc = mdb_dev_join_group_count(ctx, EXPLAIN_KL, null_l, n_l, EXPLAIN_KR, NULL, n_r, MDB_ORDER_FIRST, NULL, NULL, NULL, n_l, &groups, &joined);
 	}
-	if (rc && getenv("MDB_DEBUG_EXPLAIN"))
+	if (rc && mdb_knob("MDB_DEBUG_EXPLAIN"))
 		fprintf(stderr, "mdb_dev_explain_join_group_count: %d (%s)\n", rc, ctx->err);
 	delete ctx;
 	return rc;

@@ -295,7 +295,7 @@ int order_records(mdb_dev_ctx *ctx, const unsigned long long *rec, uint64_t list
 	int rc;
 	/* few 8-byte records of a join (out_count wanted): leaves of 2^16 row ids ranked through a bitmap (k_order_leaf_sparse) */
 	if (!rec32 && !out_val32 && out_count && order_sparse_bits(kbits) &&
-	    !(getenv("MDB_ORDER_SPARSE") && getenv("MDB_ORDER_SPARSE")[0] == '0')) {
+	    !(mdb_knob("MDB_ORDER_SPARSE") && mdb_knob("MDB_ORDER_SPARSE")[0] == '0')) {
 		const uint32_t lb = kbits - OS_RANGE_BITS;
 		const int s1 = (int)((lb + 1) / 2), s2 = (int)lb - s1;
 		/* (the list has zero-filled gaps - chunk tails -, the scatter skips them: what counts is the number of records) */

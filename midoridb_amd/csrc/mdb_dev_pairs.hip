@@ -1187,7 +1187,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		return MIDORIDB_OK;
 	};
 	if (n_l == 0 || n_r == 0 || n_l >= 0xFFFFFFFFull || n_r >= 0xFFFFFFFFull || n_l + n_r < (1ull << 20) || ld_disabled() ||
-	    (getenv("MDB_JOIN_PAYLOAD") && getenv("MDB_JOIN_PAYLOAD")[0] == '0'))
+	    (mdb_knob("MDB_JOIN_PAYLOAD") && mdb_knob("MDB_JOIN_PAYLOAD")[0] == '0'))
 		return 1;
 	mdb_memo_switch(ctx, keys_l, n_l, keys_r, n_r);
 	if (ctx->jp_bad_l == keys_l && ctx->jp_bad_nl == n_l && ctx->jp_bad_r == keys_r && ctx->jp_bad_nr == n_r && ++ctx->jp_bad_skips < 32)
@@ -1200,7 +1200,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	if (rc)
 		return rc;
 	const bool remembered = ctx->guess_remembered;
-	if (getenv("MDB_DEBUG_PAYLOAD"))
+	if (mdb_knob("MDB_DEBUG_PAYLOAD"))
 		fprintf(stderr, "join_payload: narrow %d window 2^%u at %lld (attempt %d, remembered %d)\n", (int)narrow, win.kbits, (long long)win.lo, attempt, (int)remembered);
 	if (!narrow || !win.kbits)
 		return 1;
@@ -1222,7 +1222,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		const uint32_t status = (uint32_t)h[1];
 		const uint64_t J = h[2];
-		if (getenv("MDB_DEBUG_PAYLOAD"))
+		if (mdb_knob("MDB_DEBUG_PAYLOAD"))
 			fprintf(stderr, "join_payload (row order): k %u status %u J %llu of %llu left rows\n", kbits, status, (unsigned long long)J,
 				(unsigned long long)n_l);
 		if (status == 0 && J == n_l) {
@@ -1306,7 +1306,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		const uint32_t status = (uint32_t)h[1];
 		const uint64_t J = h[2];
-		if (getenv("MDB_DEBUG_PAYLOAD"))
+		if (mdb_knob("MDB_DEBUG_PAYLOAD"))
 			fprintf(stderr, "join_payload (two levels): k %u b2 %d rem %u status %u J %llu of %llu left rows\n", kbits, b2, rem, status, (unsigned long long)J,
 				(unsigned long long)n_l);
 		if (status == 0 && J == n_l) {
@@ -1377,7 +1377,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	a.status = ctx->d_status;
 	if (pl.nsub > PP_MAX_SUB)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join with payload: %u sub-regions per digit", pl.nsub);
-	if (!(getenv("MDB_PP_CELL") && getenv("MDB_PP_CELL")[0] == '0')) {
+	if (!(mdb_knob("MDB_PP_CELL") && mdb_knob("MDB_PP_CELL")[0] == '0')) {
 		/* the cells IN the leaf's LDS table: one scattered access per joined row.  Two carried columns: the kernel once per column
 		 * (round 5: 0.51 -> 2 x 0.22 ms at 10^7 rows - the region-lookup leaf pays two scattered accesses per row and cell pair); the second
 		 * launch counts its pairs into a word nobody reads */
@@ -1393,7 +1393,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 				ac.joined = (unsigned long long *)(ctx->d_status + 6);
 			MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_cell, pl.nleaves, PW_THREADS, lds, ac, rem, shift);
 		}
-	} else if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(getenv("MDB_PP_E16") && getenv("MDB_PP_E16")[0] == '0')) {
+	} else if ((uint64_t)pr.nsub * pr.leaf_cap < 0xFFFFull && !(mdb_knob("MDB_PP_E16") && mdb_knob("MDB_PP_E16")[0] == '0')) {
 		const size_t lds = (size_t)2 << rem;
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_pairs_payload<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, "leaf_pairs_payload", k_leaf_pairs_payload<uint16_t>, pl.nleaves, PW_THREADS, lds, a, rem, shift);
@@ -1567,7 +1567,7 @@ static int join_pairs_unique_auto(mdb_dev_ctx *ctx, const int64_t *keys_l, const
 	 * it off).  What it cannot do - a key outside the window after all, a first-level region overflow - goes the usual way */
 	if (narrow && win.kbits >= 9u + PW_MIN_REM && win.kbits <= 9u + PW_MAX_REM && n_l <= PW_MAX_LEFT && n_l + n_r >= (1ull << 20) &&
 	    !(ctx->pw_bad_keys == keys_r && ctx->pw_bad_n == n_r) && !ld_disabled() &&
-	    !(getenv("MDB_ONE_LEVEL") && getenv("MDB_ONE_LEVEL")[0] == '0')) {
+	    !(mdb_knob("MDB_ONE_LEVEL") && mdb_knob("MDB_ONE_LEVEL")[0] == '0')) {
 		urc = join_pairs_unique_wide(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, win.kbits, win.lo, out_l, out_r, out_count);
 		if (urc <= 0 || urc == 3)
 			return urc;

@@ -1351,9 +1351,9 @@ static int partition_impl(part_carver &cv, const int64_t *keys, const uint64_t *
 				if (!cursor_ext)
 					MDB_HIP(ctx, hipMemsetAsync(cursor0, 0, (size_t)nreg0 * 4, ctx->stream));
 				/* tables of 2^25 rows and more: tiles of 2 x MDB_TILE rows in the instances that have them (MDB_TILE2=0: never) */
-				const char *t2min = getenv("MDB_TILE2_MIN");	/* (tests: the form on small tables) */
+				const char *t2min = mdb_knob("MDB_TILE2_MIN");	/* (tests: the form on small tables) */
 				const bool t2 = n >= (t2min && atoll(t2min) > 0 ? (uint64_t)atoll(t2min) : (1ull << 25)) &&
-						!(getenv("MDB_TILE2") && getenv("MDB_TILE2")[0] == '0');
+						!(mdb_knob("MDB_TILE2") && mdb_knob("MDB_TILE2")[0] == '0');
 				const uint32_t ntiles2 = (uint32_t)((n + (uint64_t)PART_TMUL * MDB_TILE - 1) / ((uint64_t)PART_TMUL * MDB_TILE));
 				if (raw_hv && fold32 && t2) {
 					a.ntiles = ntiles2;

@@ -519,7 +519,7 @@ bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *
 	/* MDB_ROWJOIN: 0 never, 2 whenever the form applies; default: left tables of 2^24 rows and more - up to there a result column
 	 * (128 MB) stays in the Infinity Cache and the older forms' scattered 8-byte stores land in it (10^7 x 10^7 rows: 0.44 ms against
 	 * 0.56 here; 10^8 x 10^8: 6.0 ms against 2.9) */
-	const char *knob = getenv("MDB_ROWJOIN");
+	const char *knob = mdb_knob("MDB_ROWJOIN");
 	if (knob && knob[0] == '0')
 		return false;
 	if (n_l < ((uint64_t)1 << 24) && !(knob && knob[0] == '2'))
@@ -642,7 +642,7 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 		la.sbits = sbits;
 		la.cells_al = cells_al;
 		la.count_pairs = c == 0;
-		la.ablate = getenv("MDB_RJ_ABLATE") ? (uint32_t)atoi(getenv("MDB_RJ_ABLATE")) : 0u;
+		la.ablate = mdb_knob("MDB_RJ_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_RJ_ABLATE")) : 0u;
 		la.joined = (unsigned long long *)(ctx->d_status + 2);
 		la.status = ctx->d_status;
 #define RJ_LAUNCH_LEAF(L, LONG)                                                                                                                   \
@@ -939,7 +939,7 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	 * 2^13 values on - the parity tests; =0: never).  At 10^8 rows (profiles/r05/group_forms.json): 2.5 x 10^7 groups spread over 2^27
 	 * values 1.20 ms against the partitioned path's 1.83; 10^8 unique keys 2.20 against 2.06 - the leaf's walk over 3052 tiles' pieces of
 	 * four words is bound by requests, and every row leaves it as a group record */
-	const char *const knob = getenv("MDB_GROUP_TILED");
+	const char *const knob = mdb_knob("MDB_GROUP_TILED");
 	const bool on = knob ? knob[0] == '1' : (kbits >= 26u && n >= ((uint64_t)1 << 24));	/* (measured at 10^8 rows only: large tables) */
 	if (!on || kbits < 13u || kbits > 14u + RJ_MAX_DBITS || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) || n < ((uint64_t)1 << 21))
 		return 1;
@@ -963,13 +963,13 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	const uint64_t values = (uint64_t)1 << kbits, most = (n < values ? n : values) + 1024;	/* groups: at most the rows, at most the window's key values */
 	uint32_t rg_n = 0;
 	const bool ranged = order_ranges_apply(n, row_bits, most < ((uint64_t)1 << 23) ? most : ((uint64_t)1 << 22), &rg_n) && values <= ((uint64_t)1 << 23) &&
-			    !(getenv("MDB_ORDER_RANGES") && getenv("MDB_ORDER_RANGES")[0] == '0');
+			    !(mdb_knob("MDB_ORDER_RANGES") && mdb_knob("MDB_ORDER_RANGES")[0] == '0');
 	size_t need = mdb_align_up((size_t)ntiles * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up(((size_t)ntiles + 64) * ostride * 2) + mdb_align_up(most * 8) +
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	if (ranged)
 		need += mdb_align_up((size_t)rg_n * ORDER_RANGE_CAP * 8) + mdb_align_up((size_t)rg_n * 4);
 	/* (nearly unique keys need nearly as many key values as rows: a window with fewer cannot hold them - no pilot) */
-	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(getenv("MDB_GROUP_DENSE") && getenv("MDB_GROUP_DENSE")[0] == '0');
+	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(mdb_knob("MDB_GROUP_DENSE") && mdb_knob("MDB_GROUP_DENSE")[0] == '0');
 	if (dense_ok)
 		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	int rc = mdb_arena_begin(ctx, need);
@@ -1057,7 +1057,7 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 			MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream));
 			MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 			const uint32_t dstatus = ps[0], groups = ps[1], n_exc = ps[5];
-			if (getenv("MDB_DEBUG_GROUP"))
+			if (mdb_knob("MDB_DEBUG_GROUP"))
 				fprintf(stderr, "group_count (tile sort, dense): pilot %llu of %llu rows not first; %u groups, %u rows not first, %u exceptions, status %u\n",
 					(unsigned long long)pilot_dups, (unsigned long long)pilot_rows, groups, ps[4], n_exc, dstatus);
 			if (!(dstatus & 16384u) && (uint64_t)groups + ps[4] == n) {

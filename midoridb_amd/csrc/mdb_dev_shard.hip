@@ -60,7 +60,7 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 	/* windows of 2^24 .. 2^27 values, two tables: 4096 first-level digits (k_shard_scatter_wide) leave at most 15 key bits below the
 	 * digit - one level, no second pass over either table (variant U: 2^27 values, 1.42 -> 1.0 ms) */
 	const bool wide = ntab == 2 && k > SH_D_BITS + SH_ONE_LEVEL_MAX_REM && k <= SHW_D_BITS + SHW_MAX_REM &&
-			  !(getenv("MDB_SHARD_WIDE") && getenv("MDB_SHARD_WIDE")[0] == '0');
+			  !(mdb_knob("MDB_SHARD_WIDE") && mdb_knob("MDB_SHARD_WIDE")[0] == '0');
 	p->dbits = wide ? SHW_D_BITS : SH_D_BITS;
 	p->world = world;
 	p->ntab = ntab;
@@ -80,7 +80,7 @@ int mdb_shard_plan_make(uint32_t world, uint32_t rank, uint32_t ntab, const uint
 	} else {
 		uint32_t leaf_rem = ntab > 2 ? SH_LEAF_REM - 1u : SH_LEAF_REM;
 		{
-			const char *e = getenv("MDB_SHARD_REM");	/* (measurements) */
+			const char *e = mdb_knob("MDB_SHARD_REM");	/* (measurements) */
 			if (e && atoi(e) >= 8 && atoi(e) <= (int)SH_ONE_LEVEL_MAX_REM)
 				leaf_rem = (uint32_t)atoi(e);
 		}
@@ -739,7 +739,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 		/* two tables: 16-bit counters (half the LDS: two workgroups per CU at 2^14 values per digit; a count beyond 65 535 is
 		 * reported and answered by another path) */
 		if (p->dbits == SHW_D_BITS || (p->ntab == 2 && regs_per_digit <= SHW_MAX_SEG && p->rem >= 1u &&
-					       !(getenv("MDB_SHARD_LEAF_U16") && getenv("MDB_SHARD_LEAF_U16")[0] == '0'))) {
+					       !(mdb_knob("MDB_SHARD_LEAF_U16") && mdb_knob("MDB_SHARD_LEAF_U16")[0] == '0'))) {
 			const size_t lds16 = (size_t)4 << p->rem;
 			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shard_leaf_wide<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
 			MDB_LAUNCH_LDS(ctx, "shard_leaf_wide", (k_shard_leaf_wide<1024>), p->Dp, 1024, lds16, a);
@@ -751,7 +751,7 @@ int mdb_shard_join(mdb_dev_ctx *ctx, const mdb_shard_plan *p, const void *const 
 	}
 	/* two levels: the receiver's own level over the regions of all ranks, then its leaves */
 	const uint32_t nleaves = p->Dp << p->b2;
-	const bool leaf16 = p->rem <= 16u && !(getenv("MDB_SHARD_LEAF16") && getenv("MDB_SHARD_LEAF16")[0] == '0');
+	const bool leaf16 = p->rem <= 16u && !(mdb_knob("MDB_SHARD_LEAF16") && mdb_knob("MDB_SHARD_LEAF16")[0] == '0');
 	for (uint32_t x = 0; x < p->ntab; x++) {
 		if (arrived && arrived[x])
 			MDB_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)arrived[x], 0));

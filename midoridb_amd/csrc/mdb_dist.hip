@@ -806,7 +806,7 @@ static int fused_fail(mdb_dev_ctx *ctx, bool alloc_out, int64_t *out_key, int64_
 /* MDB_DIST_FAULT="<step>:<rank>" (the fault-injection mode of the test suite): this rank behaves as if `step` had failed */
 static bool dist_fault_injected(const mdb_dist *d, const char *step)
 {
-	const char *e = getenv("MDB_DIST_FAULT");
+	const char *e = mdb_knob("MDB_DIST_FAULT");
 	const size_t l = strlen(step);
 	return e && strncmp(e, step, l) == 0 && e[l] == ':' && atoi(e + l + 1) == d->rank;
 }
@@ -821,7 +821,7 @@ static int dist_join_fused(mdb_dist *d, int ntab, const int64_t *const *keys, co
 	/* tables: [0] the left one, [1] the right one, [2 ...] further right tables joined on the same key */
 	mdb_dev_ctx *ctx = d->ctx;
 	const int W = d->world;
-	if (getenv("MDB_DIST_FUSED") && getenv("MDB_DIST_FUSED")[0] == '0')
+	if (mdb_knob("MDB_DIST_FUSED") && mdb_knob("MDB_DIST_FUSED")[0] == '0')
 		return 1;
 	if (ntab < 2 || ntab > MDB_SHARD_MAX_TABS)
 		return 1;
@@ -1175,7 +1175,7 @@ static int dist_join_impl(mdb_dist *d, const int64_t *keys_l, const uint64_t *nu
 			glo[i] = d->promised_lo[i];
 			ghi[i] = d->promised_hi[i];
 		}
-	const bool prune = (measured || (d->have_ranges && !left_in_place)) && !(getenv("MDB_MINMAX_PRUNE") && getenv("MDB_MINMAX_PRUNE")[0] == '0');
+	const bool prune = (measured || (d->have_ranges && !left_in_place)) && !(mdb_knob("MDB_MINMAX_PRUNE") && mdb_knob("MDB_MINMAX_PRUNE")[0] == '0');
 	const bool verify = prune && !measured;		/* promised ranges are checked while each table is partitioned */
 	d->last_pruned = prune ? 1 : 0;
 

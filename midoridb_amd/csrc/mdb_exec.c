@@ -1502,7 +1502,7 @@ grouped:
 				 * of the buffer instead of copying it (0.04 ms per 10^7-row column, 0.3 per 10^8) - result columns are read-only, rows
 				 * appended later lie behind the result's, and an UPDATE copies a column that has other holders before it writes */
 				if (!own && !shared && mdb_dev_alloc_size(x.dev, src) >= bytes &&
-				    !(getenv("MDB_RESULT_ALIAS") && getenv("MDB_RESULT_ALIAS")[0] == '0')) {
+				    !(mdb_knob("MDB_RESULT_ALIAS") && mdb_knob("MDB_RESULT_ALIAS")[0] == '0')) {
 					bool stmt_buf = false;
 					for (int i = 0; i < x.bufs.n; i++)
 						stmt_buf = stmt_buf || x.bufs.p[i] == src;

@@ -149,6 +149,8 @@ int mdb_table_reserve(struct mdb_table *t, uint64_t rows);
 int mdb_table_sync_device(struct mdb_catalog *cat, struct mdb_table *t, char *err, size_t errlen);
 int mdb_table_bulk_copy(struct mdb_catalog *cat, struct mdb_table *t, int ncols, uint64_t n, const int64_t *const *cols, bool *mirrored);
 void mdb_table_bulk_mirrored(struct mdb_catalog *cat, struct mdb_table *t, uint64_t old_rows, uint64_t old_generation);
+/* the value of an MDB_* environment knob, through the library's one reader of the environment (mdb_dev_core.hip: kept per process, mdb_dev_reload_knobs()) */
+const char *mdb_knob(const char *name);
 bool mdb_col_has_range(const struct mdb_column *col);
 /* is the column known to hold no non-NULL value twice, as of now?  Measures (one pass on the device) when nothing is known for this generation and
  * the column is large enough to matter or declared UNIQUE / PRIMARY KEY; false when unknown or not measurable (key window too wide for a bitmap) */

@@ -117,7 +117,7 @@ struct query_output *query_execute(struct database *db, char *query)
 		/* MDB_PROF_DUMP=1: per-kernel device time of every statement on stderr (diagnostics; serialises nothing by itself,
 		 * the events ride on the context's stream) */
 		struct mdb_catalog *cat = (struct mdb_catalog *)db->tables;
-		const int dump = getenv("MDB_PROF_DUMP") != NULL && cat && cat->dev;
+		const int dump = mdb_knob("MDB_PROF_DUMP") != NULL && cat && cat->dev;
 		if (dump) {
 			mdb_dev_prof_enable(cat->dev, 1);
 			mdb_dev_prof_reset(cat->dev);
@@ -383,7 +383,7 @@ int mdb_table_append_columns(struct database *db, const char *table, int ncols, 
 	}
 	/* large appends of plain 8-byte columns without NULL flags: copied by several threads, chunk by chunk, the device mirror following
 	 * behind (mdb_table_bulk_copy, mdb_store.c) - the first SELECT then uploads nothing */
-	bool plain = n >= ((uint64_t)1 << 20) && !(getenv("MDB_INGEST_BULK") && getenv("MDB_INGEST_BULK")[0] == '0');
+	bool plain = n >= ((uint64_t)1 << 20) && !(mdb_knob("MDB_INGEST_BULK") && mdb_knob("MDB_INGEST_BULK")[0] == '0');
 	for (int c = 0; c < ncols && plain; c++)
 		plain = t->cols[c].type != MDB_CT_VARCHAR && !(nulls && nulls[c]);
 	if (plain) {

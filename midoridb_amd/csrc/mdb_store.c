@@ -236,7 +236,7 @@ int mdb_table_add_column(struct mdb_table *t, const char *name, int type)
 static void mdb_ask_huge_pages(void *p, size_t bytes)
 {
 	const uintptr_t a = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
-	const char *knob = getenv("MDB_INGEST_THP");
+	const char *knob = mdb_knob("MDB_INGEST_THP");
 	if (bytes < ((size_t)8 << 20) || e <= a || (knob && knob[0] == '0'))
 		return;
 	(void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);	/* (advice: a kernel without THP says EINVAL, nothing depends on it) */
@@ -447,7 +447,7 @@ int mdb_table_bulk_copy(struct mdb_catalog *cat, struct mdb_table *t, int ncols,
 {
 	*mirrored = false;
 	int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
-	const char *env = getenv("MDB_INGEST_THREADS");
+	const char *env = mdb_knob("MDB_INGEST_THREADS");
 	if (env && atoi(env) > 0)
 		nthreads = atoi(env);
 	nthreads = nthreads < 1 ? 1 : nthreads > INGEST_MAX_THREADS ? INGEST_MAX_THREADS : nthreads;
