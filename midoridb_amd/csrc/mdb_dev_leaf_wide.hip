@@ -9,6 +9,15 @@
  */
 #include "mdb_dev_join_internal.h"
 
+/* a region's words are read once: non-temporal, so that they do not push out what the leaf keeps coming back to (the bits of the left rows,
+ * the ordering ranges it fills) */
+__device__ static inline uint4 lw_load_nt(const void *p)
+{
+	typedef unsigned int u4_nt __attribute__((ext_vector_type(4)));
+	const u4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u4_nt *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 /* ------------------------------------------------------------------ wide direct-address leaves: ONE partition level
  *
  * Key windows of at most 2^23 values (a dimension table's keys; after R-based pruning the benchmark's variant D: 6.25 * 10^6
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
 					v[u] = make_uint4(0u, 0u, 0u, 0u);
 					if (j < c)
-						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+						v[u] = lw_load_nt(src + j);
 				}
 #pragma unroll
 				for (int u = 0; u < LW_UNROLL; u++) {
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide(gc_args a, uint32_t re
 					const uint32_t j = j0 + 4u * ((uint32_t)u * LW_THREADS + threadIdx.x);
 					v[u] = make_uint4(0u, 0u, 0u, 0u);
 					if (j < c)
-						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+						v[u] = lw_load_nt(src + j);
 				}
 #pragma unroll
 				for (int u = 0; u < LW_UNROLL; u++) {
@@ -358,11 +367,11 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					}
 					nv = en - qp < per ? en - qp : per;
 					if (side == 1)
-						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_r) + (dl + qp));
+						v = lw_load_nt(reinterpret_cast<const uint16_t *>(a.hv_r) + (dl + qp));
 					else if (side == 2)
-						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.hv_x[0]) + (dl + qp));
+						v = lw_load_nt(reinterpret_cast<const uint16_t *>(a.hv_x[0]) + (dl + qp));
 					else
-						v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(a.hv_l) + (dl + qp));
+						v = lw_load_nt(reinterpret_cast<const uint32_t *>(a.hv_l) + (dl + qp));
 				}
 				if (side)
 					vr[u < LW12_RB ? u : 0] = v;
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(LW_THREADS, 8 /* waves per SIMD: two workgroups per
 					const uint32_t j = j0 + 8u * ((uint32_t)u * LW_THREADS + threadIdx.x);
 					v[u] = make_uint4(0u, 0u, 0u, 0u);
 					if (j < c)
-						v[u] = *reinterpret_cast<const uint4 *>(src + j);
+						v[u] = lw_load_nt(src + j);
 				}
 #pragma unroll
 				for (int u = 0; u < LW_UNROLL; u++) {

@@ -8,7 +8,7 @@
 # creation) -> summary_<tag>[_U|_S|_wide].json; kernel names need no table: bench.py's line carries, per profiler name, the names
 # rocprofv3 lists its kernels under (mdb_dev_prof_symbols).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 passes() {	# $1 = output directory, $2... = program and arguments
@@ -72,7 +72,14 @@ cfg_passes() {	# $1 = suffix, $2... = bench.py arguments
 cfg_passes config2 --config 2 --steps 5 --warmup 2
 cfg_passes config4_reference_order --config 4 --reference-order --steps 3 --warmup 1
 cfg_passes config5 --config 5 --steps 4 --warmup 1
-cp "$R/gpurun_out/summary_${TAG}_config5.json" "$R/gpurun_out/summary_${TAG}_config5_join.json"
+# the join-only statement of configs[4] ALONE (profiles/micro/config5_join_only_kernels.py): in the run above the grouped statement launches
+# kernels of the same names, and traffic per launch averaged over both would price neither (advisor, round 5)
+J5=$R/gpurun_out/prof_${TAG}_config5_join
+mkdir -p "$J5"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$J5/kt" -- python3 "$R/profiles/micro/config5_join_only_kernels.py" > "$J5/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$J5/fetch" -- python3 "$R/profiles/micro/config5_join_only_kernels.py" > "$J5/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$J5/write" -- python3 "$R/profiles/micro/config5_join_only_kernels.py" > "$J5/write.log" 2>&1
+(cd "$R" && python3 profiles/summarize.py "$J5" "$R/gpurun_out/summary_${TAG}_config5_join.json")
 # what goes under profiles/$TAG/: the summaries and rocprofv3's own per-kernel statistics of each kernel-trace pass
 PUB=$R/gpurun_out/publish_$TAG
 mkdir -p "$PUB"
@@ -81,7 +88,7 @@ for S in "" _U _S _wide _shuffle _configs1 _unordered_D _unordered_U _config4 _c
 	D="$R/gpurun_out/prof_$TAG$S/kt"
 	[ "$S" = _configs1 ] && D="$OPS/kt"
 	[ "$S" = _config4 ] && D="$C4/kt"
-	[ "$S" = _config5_join ] && D="$R/gpurun_out/prof_${TAG}_config5/kt"
+	[ "$S" = _config5_join ] && D="$J5/kt"
 	F=$(find "$D" -name '*kernel_stats.csv' 2>/dev/null | head -1)
 	[ -n "$F" ] && cp "$F" "$PUB/kernel_stats$S.csv"
 done
