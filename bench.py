@@ -43,7 +43,7 @@ METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 NORTH = "SELECT id_a, COUNT(*) FROM A INNER JOIN B ON A.id_a = B.id_b GROUP BY id_a;"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")
 
 
 def _pmc_summary(suffix):

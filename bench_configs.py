@@ -32,7 +32,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0
 METRIC = "joined rows/sec, 2x10^8-row INT64 INNER JOIN+GROUP BY, 1/2/4/8 MI355X"
 ROOT = os.path.dirname(os.path.abspath(__file__))
-PROFILE_ROUNDS = ("r05", "r04")
+PROFILE_ROUNDS = ("r06", "r05", "r04")
 
 
 def _pmc_kernels(tag):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# The bench lines kept under profiles/<tag>/ (run on the GPU box): bash profiles/bench_artifacts.sh r05
-TAG=${1:-r05}; O=gpurun_out/bench_$TAG; mkdir -p $O
+# The bench lines kept under profiles/<tag>/ (run on the GPU box): bash profiles/bench_artifacts.sh r06
+TAG=${1:-r06}; O=gpurun_out/bench_$TAG; mkdir -p $O
 last() { tail -n 1; }
 python bench.py 2>/dev/null | last > $O/bench_driver_command.json		# what the driver runs: N = 1, variant D, defaults
 for V in U S; do
