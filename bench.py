@@ -596,7 +596,9 @@ def main():
                 k, c, j = dev.join_group_count_unordered(a, None, b, None, out=out)
                 return k.numel(), j
             if pipe is None:
-                k, c, f, j = dev.join_group_count(a, None, b, None, out=out, want_first=False)
+                # (MDB_KEYS_MAY_ALIAS, as query_execute() calls the operator: when every left row is a group - variant U - the group keys ARE the
+                # left key column and are not copied; the headline's variant D is not such a join: everything is written)
+                k, c, f, j = dev.join_group_count(a, None, b, None, out=out, want_first=False, alias=True)
                 return k.numel(), j
             k, c, j = pipe.join_group_count(a, None, b, None, out=out)
             return k.numel(), j
@@ -815,6 +817,9 @@ def main():
                        "partition_levels": dev.last_join_levels(),
                        "rows_per_table_per_gpu": n, "rows_per_table_total": total_rows, "joined_rows": joined_total, "groups": groups_total,
                        "result": "(group key, COUNT(*)) per group - the statement's two result columns, what query_execute() asks the operator for",
+                       "operator_flags": "MDB_ORDER_FIRST | MDB_KEYS_MAY_ALIAS, as query_execute() calls the operator (group keys that would be an exact copy "
+                                         "of the left key column - every left row a group: variant U - are not written; variant D and S: everything is written)",
+                       "group_keys_are_left_column": bool(dev.last_plan().get("keys_are_left_column")) if not use_dist else False,
                        "order": "unspecified (--unordered: mdb_dev_join_group_count without MDB_ORDER_FIRST)" if (args.unordered and not use_dist) else
                                 "reference first-occurrence order" if not use_dist else "per rank, unspecified (leaf order; first occurrence in the "
                                 "received stream on the key-by-destination path)",
@@ -984,14 +989,19 @@ def main():
                          lambda: dev.gen_keys(n, 0, n, 43, n // 16).mul_(16))):
                     try:
                         b_x = make_b()
-                        dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False))
+                        dtu, ru = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False, alias=True))
                         plan_x = dev.last_plan()
                         line[tag] = {"workload": workload, "joined_rows": ru[3], "groups": int(ru[0].numel()), "ms_per_step": dtu * 1e3,
                                      "value": ru[3] / dtu, "plan": plan_x, "step_ms": dict(last_dist),
+                                     "group_keys": ("the left key column itself (every left row is a group: MDB_KEYS_MAY_ALIAS, as query_execute() calls the "
+                                                    "operator - not copied)") if plan_x.get("keys_are_left_column") else "written by the operator",
                                      "pipeline": pipe_frac(int(ru[0].numel()), dtu, "U" if tag == "variant_U" else "S",
                                                            lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False)),
                                      "key_form": dev.last_join_form(), "partition_levels": dev.last_join_levels(),
                                      "min_max_pruning": bool(dev.last_join_filter()[1])}
+                        if plan_x.get("keys_are_left_column"):
+                            dtc, _ = timed(lambda: dev.join_group_count(a, None, b_x, None, out=out, want_first=False))
+                            line[tag]["ms_per_step_keys_copied"] = dtc * 1e3      # the same call without the flag: out_key written (round 5's figure)
                         line[tag]["unordered"] = unordered_of(b_x, (int(ru[0].numel()), ru[3]))
                         del b_x
                     except Exception as e:  # pragma: no cover

@@ -265,6 +265,8 @@ extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out
 	out->group_form = ctx->pl_group_form;
 	out->groups_as_bits = ctx->pl_bits;
 	out->small_form = ctx->pl_small_form;
+	out->keys_are_left_column = ctx->pl_keys_left;
+	out->counts_all_one = ctx->pl_counts_one;
 	return MIDORIDB_OK;
 }
 

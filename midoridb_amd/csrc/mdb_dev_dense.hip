@@ -62,7 +62,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_expand(const unsigned long
 			const uint32_t row = (uint32_t)(((uint64_t)blockIdx.x * DN_THREADS + wave * 64u + k) * 64u + lane);
 			if (out_first)
 				out_first[pos] = row;
-			out_count[pos] = 1;
+			if (out_count)
+				out_count[pos] = 1;
 			if (out_key)		/* (the join's group key: the left table's key of the group's first row - consecutive lanes, consecutive rows) */
 				out_key[pos] = keys32 ? (int64_t)reinterpret_cast<const int32_t *>(keys)[row] : keys[row];
 		}
@@ -106,6 +107,8 @@ int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n,
 	const uint64_t nwords = (n + 63) / 64, nblocks = (nwords + DN_THREADS - 1) / DN_THREADS;
 	if (nblocks >= 0x7FFFFFFFull)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "dense group emit: too many rows");
+	if (!out_first && !out_count && !out_key)
+		return MIDORIDB_OK;	/* (nothing to write: the caller takes the left key column for the group keys and every COUNT is 1) */
 	uint32_t *wordbase = (uint32_t *)mdb_arena_take(ctx, nwords * 4 + 64);
 	uint32_t *cnt = (uint32_t *)mdb_arena_take(ctx, (nblocks + 2) * 4);
 	uint32_t *base = (uint32_t *)mdb_arena_take(ctx, (nblocks + 2) * 4);
@@ -125,7 +128,7 @@ int mdb_dense_emit(mdb_dev_ctx *ctx, const unsigned long long *bits, uint64_t n,
 		return rc;
 	MDB_LAUNCH(ctx, "dense_expand", k_dense_expand, (uint32_t)nblocks, DN_THREADS, bits, n, base, wordbase, out_first, out_count, keys, keys32 ? 1u : 0u,
 		   out_key);
-	if (n_exc) {
+	if (n_exc && out_count) {
 		const uint32_t grid = (n_exc + 255u) / 256u;
 		MDB_LAUNCH(ctx, "dense_patch", k_dense_patch, grid < 4096u ? grid : 4096u, 256, exc, n_exc, bits, wordbase, out_count);
 	}

@@ -1920,7 +1920,30 @@ extern "C" int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l
 	}
 	uint64_t G = 0, J = 0;
 	ctx->last_left_dups_known = false;
-	int rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, MDB_ORDER_FIRST, gk, gc, NULL, n_l, &G, &J);
+	/* (no copies where the operator knows for free that none is needed: every left row a group of COUNT 1 - two primary keys - makes the joined
+	 * rows' key column the LEFT KEY COLUMN ITSELF, in its order: *served = 2, nothing allocated, nothing written) */
+	const bool was_a = ctx->key_alias_ok, was_o = ctx->counts_optional;
+	ctx->key_alias_ok = ctx->counts_optional = true;	/* (this call is the outermost operator: its wishes hold for the one it calls) */
+	int rc = mdb_dev_join_group_count(ctx, keys_l, null_l, n_l, keys_r, null_r, n_r, MDB_ORDER_FIRST | MDB_KEYS_MAY_ALIAS | MDB_COUNTS_OPTIONAL, gk, gc, NULL,
+					  n_l, &G, &J);
+	ctx->key_alias_ok = was_a;
+	ctx->counts_optional = was_o;
+	const bool keys_left = !rc && ctx->pl_keys_left != 0, counts_one = !rc && ctx->pl_counts_one != 0;
+	if (keys_left && J == G) {
+		(void)mdb_dev_free(ctx, gk);
+		(void)mdb_dev_free(ctx, gc);
+		*out_key = const_cast<int64_t *>(keys_l);
+		*out_rows = G;
+		*served = 2;
+		return MIDORIDB_OK;
+	}
+	if (!rc && (keys_left || counts_one) && J != G) {
+		/* (cannot be: COUNTs that are all 1 join as many rows as there are groups, and a COUNT above 1 keeps the COUNT column) */
+		(void)mdb_dev_free(ctx, gk);
+		(void)mdb_dev_free(ctx, gc);
+		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "join of two key columns: %llu joined rows in %llu groups without a COUNT column", (unsigned long long)J,
+				   (unsigned long long)G);
+	}
 	if (!rc && J != G && ctx->last_left_dups_known && !ctx->last_left_dups) {
 		/* duplicates on the RIGHT side only (a dimension joined with its facts): a left row's joined rows all carry its key - the key,
 		 * COUNT times, in the left table's row order */

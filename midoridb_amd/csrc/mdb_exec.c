@@ -831,7 +831,8 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			goto out;
 		}
 		keys_only = served != 0;
-		if (keys_ordered && track(&x, keys_ordered)) {
+		/* (served == 2: the joined rows' key column IS the left table's key column - held by the result, never freed here) */
+		if (keys_ordered && served != 2 && track(&x, keys_ordered)) {
 			rc = -MIDORIDB_NOMEM;
 			goto out;
 		}
@@ -858,7 +859,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 			cap = op_groups_bound(&x, fkeys[0], cap);
 			cap = op_groups_bound(&x, fkeys[1], cap < nr_rows ? cap : (nr_rows ? nr_rows : 1));
 		}
-		bool multi_done = false;
+		bool multi_done = false, alias_checked = false;
 		const bool text_keys = cat->dist && fkeys[0]->type == MDB_CT_VARCHAR;
 		if (text_keys) {
 			/* sharded mode, VARCHAR join keys: the ids of this process's dictionary mean nothing to the other ranks - the operator
@@ -941,25 +942,35 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 					rk[t - 1] = cv;
 				}
 				if (mdb_dev_join_group_count_multi(x.dev, lv, ln, nl_rows, s->ntabs - 1, rk, rnb, rrows,
-								   (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key, x.d_count, NULL,
-								   cap, &G, &J)) {
+								   ((only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST) | MDB_KEYS_MAY_ALIAS, x.d_fused_key,
+								   x.d_count, NULL, cap, &G, &J)) {
 					rc = dev_fail(&x, "join + group count over several tables");
 					goto out;
 				}
 				multi_done = true;
+				alias_checked = true;
 			} else {
 				if (fkeys[0]->type != MDB_CT_DOUBLE && !text_keys)
 					op_stats_begin(&x, fkeys[0], lv, fkeys[1], rv);
 				const int frc = mdb_dev_join_group_count(x.dev, lv, ln, nl_rows, rv, rn, nr_rows,
 									  /* (a bare COUNT(*) has no group order to keep; nor has a GROUP BY when the database says so) */
-									  (only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST, x.d_fused_key,
-									  x.d_count, NULL, cap, &G, &J);
+									  ((only_count || cat->groups_any_order) ? 0u : MDB_ORDER_FIRST) | MDB_KEYS_MAY_ALIAS,
+									  x.d_fused_key, x.d_count, NULL, cap, &G, &J);
 				op_stats_end(&x);
 				if (frc) {
 					rc = dev_fail(&x, "join + group count");
 					goto out;
 				}
+				alias_checked = true;
 			}
+		}
+		if (alias_checked) {
+			/* every left row turned out to be a group: the group keys ARE the left key column, in its order - the operator wrote none
+			 * (MDB_KEYS_MAY_ALIAS) and the stream reads the column itself; a result kept on the device becomes one more holder of the
+			 * table's buffer (0.8 GB less read and written at 10^8 rows) */
+			struct mdb_dev_plan_info pi;
+			if (mdb_dev_last_plan(x.dev, &pi) == 0 && pi.keys_are_left_column && G == nl_rows)
+				x.d_fused_key = (int64_t *)(uintptr_t)lv;
 		}
 		for (int t = 2; t < s->ntabs && (G || cat->dist) && !multi_done; t++) {
 			const void *cv;

@@ -13,6 +13,8 @@ import torch
 from .lib import load_library
 
 MDB_ORDER_FIRST = 1
+MDB_KEYS_MAY_ALIAS = 2
+MDB_COUNTS_OPTIONAL = 4
 
 # predicate opcodes / comparison codes / value types (include/mdb_dev.h)
 P_CMP_COL_CONST, P_CMP_CONST_COL, P_CMP_COL_COL, P_ISNULL, P_CONST, P_AND, P_OR, P_XOR = 1, 2, 3, 4, 5, 6, 7, 8
@@ -56,7 +58,7 @@ COL_DISTINCT = 1     # MDB_COL_DISTINCT
 class PlanInfo(ctypes.Structure):
     """struct mdb_dev_plan_info: what the last join / GROUP BY operator did"""
     _fields_ = [(k, ctypes.c_uint32) for k in ("key_form", "key_bits", "levels", "digits", "minmax_pruned", "semijoin", "any_order", "ranged_order",
-                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "arena_mib", "small_form", "groups_as_bits")]
+                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "arena_mib", "small_form", "keys_are_left_column", "counts_all_one", "groups_as_bits")]
 
 
 class ExplainRequest(ctypes.Structure):
@@ -417,9 +419,16 @@ class DeviceCtx:
         self._chk(self.lib.mdb_dev_gen_payload(self.h, _ptr(out), n, first_index, seed, kind), "gen_payload")
         return out
 
-    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST, want_first=True):
+    def join_group_count(self, keys_l, null_l, keys_r, null_r, out=None, flags=MDB_ORDER_FIRST, want_first=True, no_copies=False, alias=False):
         """-> (keys[G], counts[G], first[G], joined_rows); tensors are views into `out` buffers.  want_first=False: the result
-        query_execute() asks for - (key, COUNT) in first-occurrence order, no first-row column (first[G] is returned as None)."""
+        query_execute() asks for - (key, COUNT) in first-occurrence order, no first-row column (first[G] is returned as None).
+        alias: MDB_KEYS_MAY_ALIAS, as query_execute() calls the operator - when every left row is a group the keys returned ARE keys_l (not a
+        copy); no_copies: MDB_COUNTS_OPTIONAL as well (mdb_dev_join_keys_ordered's call) - when every COUNT is 1 the counts come back as None
+        (last_plan() says which)."""
+        if no_copies:
+            flags |= MDB_KEYS_MAY_ALIAS | MDB_COUNTS_OPTIONAL
+        elif alias:
+            flags |= MDB_KEYS_MAY_ALIAS
         n_l, n_r = keys_l.numel(), keys_r.numel()
         cap = max(n_l, 1)
         if out is None:
@@ -432,6 +441,9 @@ class DeviceCtx:
                                                     flags, _ptr(ok), _ptr(oc), _ptr(of), cap, byref(g), byref(j)),
                   "join_group_count")
         G = g.value
+        if no_copies or alias:
+            p = self.last_plan()
+            return (keys_l[:G] if p["keys_are_left_column"] else ok[:G]), (None if p["counts_all_one"] else oc[:G]), (of[:G] if of is not None else None), j.value
         return ok[:G], oc[:G], (of[:G] if of is not None else None), j.value
 
     def join_group_count_unordered(self, keys_l, null_l, keys_r, null_r, out=None):
@@ -576,6 +588,8 @@ class DeviceCtx:
                                                      byref(pk), byref(cnt), byref(served)), "join_keys_ordered")
         if not served.value:
             return None
+        if served.value == 2:       # every left row joined exactly one right row: the joined rows' key column IS keys_l (nothing was copied)
+            return keys_l[:cnt.value]
         if not cnt.value:
             if pk:
                 self._chk(self.lib.mdb_dev_free(self.h, pk), "free")

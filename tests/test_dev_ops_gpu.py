@@ -2682,6 +2682,39 @@ def test_distinct_statistic_runs_the_bit_form_without_a_pilot_and_a_wrong_flag_n
     assert np.array_equal(_np(gf), np.arange(n)) and bool((_np(gc_) == 1).all())
 
 
+def test_join_group_count_writes_no_copy_of_what_the_left_column_already_says(dev):
+    """round 6: MDB_KEYS_MAY_ALIAS | MDB_COUNTS_OPTIONAL (how query_execute() calls the operator) - when every left row turns out to be a group, in
+    row order, the group keys ARE the left key column: the operator writes none and says so; when every COUNT is 1 it writes no COUNT column;
+    a key with two right rows keeps the COUNT column, a left row without partner keeps the key column.  Same results as the copying call."""
+    rng = np.random.default_rng(62)
+    n = 17_000_000
+    ka, kb = rng.permutation(n).astype(np.int64) + 40, rng.permutation(n).astype(np.int64) + 40
+    a, b = dev.to_dev(ka), dev.to_dev(kb)
+    k0, c0, f0, j0 = dev.join_group_count(a, None, b, None, want_first=False)
+    assert dev.last_plan()["digits"] == 4096
+    for _ in range(2):      # (the second call runs the bit-per-row form on what the first one delivered)
+        k, c, f, j = dev.join_group_count(a, None, b, None, want_first=False, no_copies=True)
+    p = dev.last_plan()
+    assert p["groups_as_bits"] in (1, 2) and p["keys_are_left_column"] == 1 and p["counts_all_one"] == 1, p
+    assert j == n and k.data_ptr() == a.data_ptr() and k.numel() == n and c is None and torch.equal(k, k0) and bool((c0 == 1).all())
+    # ... and mdb_dev_join_keys_ordered hands the left column back as the joined rows' key column
+    jk = dev.join_keys_ordered(a, None, b, None)
+    assert jk is not None and jk.data_ptr() == a.data_ptr() and jk.numel() == n
+    # one right key twice: the COUNT column is written (its 2 at the key's place), the keys of the left rows - one of them lost its partner - too
+    kb2 = kb.copy()
+    kb2[5] = kb2[6]
+    b2, a2 = dev.to_dev(kb2), a.clone()
+    for _ in range(2):
+        k, c, f, j = dev.join_group_count(a2, None, b2, None, want_first=False, no_copies=True)
+    p = dev.last_plan()
+    assert p["keys_are_left_column"] == 0 and p["counts_all_one"] == 0, p
+    cnt = np.bincount(kb2 - 40, minlength=n)
+    sel = cnt[ka - 40] > 0
+    assert j == n and np.array_equal(_np(k), ka[sel]) and np.array_equal(_np(c), cnt[ka - 40][sel])
+    jk = dev.join_keys_ordered(a2, None, b2, None)
+    assert jk is not None and jk.data_ptr() != a2.data_ptr() and np.array_equal(_np(jk), np.repeat(ka[sel], cnt[ka - 40][sel]))
+
+
 def test_join_payload_plan_names_the_form(dev, monkeypatch):
     rng = np.random.default_rng(10)
     kr = np.unique(rng.integers(0, 1 << 26, 2_000_000, dtype=np.int64))
