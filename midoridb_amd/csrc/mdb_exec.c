@@ -1262,8 +1262,15 @@ exchange_rows:
 				rc = dev_fail(&x, "group count");
 				goto out;
 			}
-			if ((rc = stream_select(&x, s->ntabs, first, G)))
-				goto out;
+			{
+				/* the catalog knew that the column holds no value twice and the operator answered with the identity (group i = row i of the
+				 * stream, COUNT 1): the stream stays what it is - no row-id vector to compose, no gather through one in the projection; a
+				 * result kept on the device holds the table's columns */
+				struct mdb_dev_plan_info pi;
+				const bool identity = x.n && G == x.n && mdb_dev_last_plan(x.dev, &pi) == 0 && pi.group_form == 3;
+				if (!identity && (rc = stream_select(&x, s->ntabs, first, G)))
+					goto out;
+			}
 		} else if (s->ngroup > 1) {
 			/* several fields: groups = distinct combinations (the reference applies its single-field loop once
 			 * per field, executor_select.c:1537-1541, which is not a grouping by the combination: DESIGN.md 2) */
