@@ -144,6 +144,8 @@ struct mdb_dev_plan_info {
 	uint32_t groups_as_bits;	/* the groups left the leaf kernel as one bit per row + exceptions (nearly unique keys / nearly every left row a group of
 				 * COUNT 1), not as a record each: 1 decided by a pilot launch, 2 by what the last call over the columns delivered, 3 by the
 				 * caller's statistics (MDB_COL_DISTINCT on both key columns, the right one holding every value of its range) */
+	uint32_t payload_tables;	/* right tables the last payload join served in ONE call: 1 mdb_dev_join_payload, 2 ... mdb_dev_join_payload_multi (the left
+				 * table sorted once, one leaf launch, one placement pass); 0 not served */
 };
 int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out);
 /* The MDB_* environment knobs are read once per process and kept: a process that changes one while it runs calls this. */
@@ -425,6 +427,25 @@ int mdb_dev_join_keys_ordered(mdb_dev_ctx *ctx, const int64_t *keys_l, const uin
  * (reference: _join_nested_loop_tbl2tbl + cpy_cols / _merge_rows, src/engine/executor_select.c:1076-1149, 340-438) */
 int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const int64_t *keys_r,
 			 const uint64_t *null_r, uint64_t n_r, const void *const *pay_in, int npay, void *const *out);
+
+/* ... of ONE left key column with several right tables on that key (SELECT * FROM A JOIN B ON A.k = B.k JOIN C ON A.k = C.k: BASELINE
+ * configs[4]'s join-only form; reference: _join_nested_loop_tbl2tbl then _join_nested_loop_tbl2mat, src/engine/executor_select.c:1076-1232):
+ * right[t].out[c][i] = payload cell c of left row i's partner in table t.  Left tables of 2^24 rows and more, at most four payload columns
+ * over all tables, no NULL keys; [key_min, key_max] is the caller's bound on every key of every table (the catalog's ranges; at most 2^27
+ * values) - verified on the device like every property of the join: MIDORIDB_OK when served, 1 when not (a key outside the bound, a left
+ * row without partner in some table, a right key twice, a smaller table ...: nothing usable was written - the caller joins table by table
+ * with mdb_dev_join_payload / mdb_dev_join_pairs), or a negative error code.  The left table is sorted once, one leaf launch and one
+ * placement pass serve all the tables (round 6).  Nothing is sampled or remembered.  Synchronises. */
+struct mdb_dev_payload_right {
+	const int64_t *keys;
+	const uint64_t *nulls;	/* NULL bitmap of the key column or NULL (a nullable right key column is not served) */
+	uint64_t rows;
+	int npay;		/* 1 or 2 */
+	const void *pay_in[2];	/* rows cells of 8 bytes each, no NULL bitmap */
+	void *out[2];		/* caller buffers of n_l cells */
+};
+int mdb_dev_join_payload_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dev_payload_right *right,
+			       int nright, int64_t key_min, int64_t key_max);
 
 /* Cross join (FROM A, B  ==  JOIN ... ON 1=1, reference optimiser_select.c:395-464):
  * all n_l * n_r pairs in (l, r) order, into caller buffers of that capacity. */

@@ -110,7 +110,7 @@ struct mdb_dev_ctx : mdb_col_memo {
 	int unordered_no_counts;	/* set by mdb_dev_join_keys around its call of the any-order operator: group keys only, no COUNT column */
 	/* the caller's MDB_KEYS_MAY_ALIAS / MDB_COUNTS_OPTIONAL of the current join + GROUP BY call, and what became of them (mdb_dev_last_plan) */
 	bool key_alias_ok, counts_optional;
-	uint32_t pl_keys_left, pl_counts_one;
+	uint32_t pl_keys_left, pl_counts_one, pl_payload_tables;
 	void *pending_op;		/* state of a begun-but-unfinished split operator (mdb_dev_join.hip) */
 	bool guess_remembered;		/* the last narrow-form decision came from the memo, not from a sample of the data */
 	/* mdb_dev_call_stats(): the caller's statistics of the key columns of the calls that follow */
@@ -161,7 +161,7 @@ struct mdb_plan_scope {
 	explicit mdb_plan_scope(mdb_dev_ctx *ctx) : c(ctx)
 	{
 		if (c && c->pl_depth++ == 0)
-			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = c->pl_group_form = c->pl_bits = c->pl_small_form = c->pl_keys_left = c->pl_counts_one = 0;
+			c->pl_retries = c->pl_samples = c->pl_from_stats = c->pl_key_bits = c->pl_payload_form = c->pl_group_form = c->pl_bits = c->pl_small_form = c->pl_keys_left = c->pl_counts_one = c->pl_payload_tables = 0;
 	}
 	~mdb_plan_scope()
 	{

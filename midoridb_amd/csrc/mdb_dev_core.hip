@@ -267,6 +267,7 @@ extern "C" int mdb_dev_last_plan(mdb_dev_ctx *ctx, struct mdb_dev_plan_info *out
 	out->small_form = ctx->pl_small_form;
 	out->keys_are_left_column = ctx->pl_keys_left;
 	out->counts_all_one = ctx->pl_counts_one;
+	out->payload_tables = ctx->pl_payload_tables;
 	return MIDORIDB_OK;
 }
 

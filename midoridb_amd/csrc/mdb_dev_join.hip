@@ -3440,6 +3440,26 @@ extern "C" int mdb_dev_explain_join_payload(const struct mdb_dev_explain_request
 		return -MIDORIDB_NOMEM;
 	const void *pay[2] = { (const void *)0x5000, (const void *)0x6000 };
 	void *dst[2] = { (void *)0x7000, (void *)0x8000 };
+	if (rq->further_tables) {	/* several right tables on the one key: mdb_dev_join_payload_multi, the window = the statistics' ranges */
+		struct mdb_dev_payload_right rt[3];
+		memset(rt, 0, sizeof(rt));
+		int64_t lo = rq->left.min < rq->right.min ? rq->left.min : rq->right.min, hi = rq->left.max > rq->right.max ? rq->left.max : rq->right.max;
+		const uint32_t nrt = 1u + (rq->further_tables > 2u ? 2u : rq->further_tables);
+		for (uint32_t t = 0; t < nrt; t++) {
+			rt[t].keys = EXPLAIN_KR;
+			rt[t].rows = t ? rq->further_rows[t - 1] : rq->right.rows;
+			rt[t].npay = cells;
+			for (int c = 0; c < cells; c++) {
+				rt[t].pay_in[c] = pay[c];
+				rt[t].out[c] = dst[c];
+			}
+		}
+		int mrc = rq->left_nulls_bitmap ? 1 : mdb_dev_join_payload_multi(ctx, EXPLAIN_KL, NULL, rq->left.rows, rt, (int)nrt, lo, hi);
+		if (mrc == 1)
+			mrc = MIDORIDB_OK;	/* (not served: payload_form 0 - the caller joins table by table) */
+		delete ctx;
+		return mrc;
+	}
 	int rc = mdb_dev_join_payload(ctx, EXPLAIN_KL, rq->left_nulls_bitmap ? (const uint64_t *)0x4000 : NULL, rq->left.rows, EXPLAIN_KR, NULL, rq->right.rows, pay,
 				      cells, dst);
 	if (rc == 1)

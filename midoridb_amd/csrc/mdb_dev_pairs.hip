@@ -1177,6 +1177,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 			return -MIDORIDB_ERROR;
 	auto explained = [&](uint32_t form, uint32_t kbits, uint32_t levels, size_t arena) {	/* (mdb_dev_explain_join_payload: nothing is launched) */
 		ctx->explain->payload_form = form;
+		ctx->explain->payload_tables = form ? 1u : 0u;
 		ctx->explain->key_form = 2;
 		ctx->explain->key_bits = kbits;
 		ctx->explain->levels = levels;
@@ -1225,8 +1226,9 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		if (mdb_knob("MDB_DEBUG_PAYLOAD"))
 			fprintf(stderr, "join_payload (row order): k %u status %u J %llu of %llu left rows\n", kbits, status, (unsigned long long)J,
 				(unsigned long long)n_l);
-		if (status == 0 && J == n_l) {
+		if (status == 0 && J == (uint64_t)npay * n_l) {
 			ctx->pl_payload_form = 3;
+			ctx->pl_payload_tables = 1;
 			return MIDORIDB_OK;
 		}
 		if ((status & 128u) && remembered && attempt == 0) {
@@ -1311,6 +1313,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 				(unsigned long long)n_l);
 		if (status == 0 && J == n_l) {
 			ctx->pl_payload_form = 2;
+			ctx->pl_payload_tables = 1;
 			return MIDORIDB_OK;
 		}
 		if ((status & 128u) && remembered && attempt == 0) {
@@ -1409,6 +1412,7 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 	const uint64_t J = h[2];
 	if (status == 0 && J == n_l) {
 		ctx->pl_payload_form = 1;
+		ctx->pl_payload_tables = 1;
 		return MIDORIDB_OK;
 	}
 	if ((status & 128u) && remembered && attempt == 0) {
@@ -1429,6 +1433,87 @@ extern "C" int mdb_dev_join_payload(mdb_dev_ctx *ctx, const int64_t *keys_l, con
 		ctx->jp_bad_skips = 0;
 	}
 	return 1;
+	}
+	return 1;
+}
+
+/* One left key column joined with SEVERAL right tables on that key, each carrying up to two payload columns - SELECT * FROM A JOIN B ON
+ * A.k = B.k JOIN C ON A.k = C.k with B.k and C.k primary keys that cover A.k (BASELINE configs[4]'s join-only form; the reference's
+ * _join_nested_loop_tbl2tbl followed by _join_nested_loop_tbl2mat, /root/reference/src/engine/executor_select.c:1076-1232): the row-order
+ * form sorts the left table's tiles ONCE and serves every right table from one leaf launch and one placement pass (mdb_dev_rowjoin.hip).
+ * The key window is the CALLER's statement about the columns ([key_min, key_max] covers every key of every table: the catalog's ranges)
+ * and is verified like every promise: a key outside, a left row without partner in some table, a right key twice -> 1, nothing usable
+ * written, the caller joins table by table.  Nothing is sampled, nothing remembered.  Synchronises. */
+extern "C" int mdb_dev_join_payload_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, const uint64_t *null_l, uint64_t n_l, const struct mdb_dev_payload_right *right,
+					  int nright, int64_t key_min, int64_t key_max)
+{
+	mdb_plan_scope plan_scope(ctx);
+	if (!ctx || !keys_l || !right || nright < 1 || nright > 4)
+		return -MIDORIDB_ERROR;
+	struct mdb_rowjoin_right rt[4];
+	int streams = 0;
+	memset(rt, 0, sizeof(rt));
+	for (int t = 0; t < nright; t++) {
+		if (!right[t].keys || right[t].npay < 1 || right[t].npay > 2)
+			return -MIDORIDB_ERROR;
+		for (int c = 0; c < right[t].npay; c++)
+			if (!right[t].pay_in[c] || !right[t].out[c])
+				return -MIDORIDB_ERROR;
+		streams += right[t].npay;
+	}
+	if (streams > 4 || key_min > key_max || n_l == 0 || ld_disabled() || (mdb_knob("MDB_JOIN_PAYLOAD") && mdb_knob("MDB_JOIN_PAYLOAD")[0] == '0') ||
+	    (mdb_knob("MDB_JOIN_PAYLOAD_MULTI") && mdb_knob("MDB_JOIN_PAYLOAD_MULTI")[0] == '0'))
+		return 1;
+	const uint64_t span = (uint64_t)key_max - (uint64_t)key_min;
+	if (span >= ((uint64_t)1 << 27))
+		return 1;
+	uint32_t kbits = 15;
+	while (((uint64_t)1 << kbits) <= span)
+		kbits++;
+	for (int t = 0; t < nright; t++) {
+		if (!mdb_rowjoin_serves(n_l, right[t].rows, kbits, keys_l, null_l, right[t].keys, right[t].nulls, right[t].pay_in, right[t].out, right[t].npay))
+			return 1;
+		rt[t].keys = right[t].keys;
+		rt[t].n = right[t].rows;
+		rt[t].npay = right[t].npay;
+		for (int c = 0; c < right[t].npay; c++) {
+			rt[t].pay_in[c] = right[t].pay_in[c];
+			rt[t].out[c] = right[t].out[c];
+		}
+	}
+	const size_t arena = mdb_rowjoin_arena_bytes_multi(n_l, rt, nright, kbits) + 8192;
+	if (ctx->explain) {
+		ctx->explain->payload_form = 3;
+		ctx->explain->payload_tables = (uint32_t)nright;
+		ctx->explain->key_form = 2;
+		ctx->explain->key_bits = kbits;
+		ctx->explain->levels = 1;
+		ctx->explain->digits = 1u << mdb_rowjoin_dbits(kbits);
+		ctx->explain->from_stats = 1;
+		ctx->explain->arena_mib = (uint32_t)((arena + (1u << 20) - 1) >> 20);
+		return MIDORIDB_OK;
+	}
+	int rc = mdb_arena_begin(ctx, arena);
+	if (rc)
+		return rc;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16 * sizeof(uint32_t), ctx->stream));
+	rc = mdb_rowjoin_run_multi(ctx, keys_l, n_l, rt, nright, key_min, kbits);
+	if (rc)
+		return rc;
+	uint64_t *h = ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(&h[1], ctx->d_status, 40, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t status = (uint32_t)h[1];
+	const uint64_t J = h[2];
+	if (mdb_knob("MDB_DEBUG_PAYLOAD"))
+		fprintf(stderr, "join_payload_multi (row order): %d tables, %d columns, k %u status %u J %llu of %llu x %d\n", nright, streams, kbits, status,
+			(unsigned long long)J, (unsigned long long)n_l, streams);
+	if (status == 0 && J == (uint64_t)streams * n_l) {
+		ctx->pl_payload_form = 3;
+		ctx->pl_payload_tables = (uint32_t)nright;
+		ctx->pl_key_bits = kbits;
+		ctx->pl_from_stats = 1;
+		return MIDORIDB_OK;
 	}
 	return 1;
 }

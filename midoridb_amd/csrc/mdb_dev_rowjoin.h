@@ -17,6 +17,19 @@ size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r, uint32_t kbits, int n
 int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
 		    int64_t win_lo, uint32_t kbits, int npay, void *const *out);
 
+/* ... of ONE left key column with several right tables on that key (mdb_dev_join_payload_multi): the left table is sorted once, one leaf
+ * launch and one placement pass serve every (right table, payload column) pair - at most four.  d_status[2..3] then holds the (left row,
+ * payload column) pairs served: the columns x the left rows when every left row found its partner in every table */
+struct mdb_rowjoin_right {
+	const int64_t *keys;
+	uint64_t n;
+	int npay;		/* 1 or 2 */
+	const void *pay_in[2];
+	void *out[2];
+};
+size_t mdb_rowjoin_arena_bytes_multi(uint64_t n_l, const struct mdb_rowjoin_right *rt, int nrt, uint32_t kbits);
+int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const struct mdb_rowjoin_right *rt, int nrt, int64_t win_lo, uint32_t kbits);
+
 
 /* GROUP BY key + COUNT(*) of one NULL-free key column through the tile sort: 0 = done (groups in first-row order), 1 = not served
  * (*outside: a key lay outside the window), < 0 = error.  Synchronises. */

@@ -45,6 +45,10 @@
 #define RJ_MAX_DBITS 13u	/* up to 8192 digits per tile (16 KiB of packed 16-bit counters) */
 #define RJ_LOADS 8		/* 16-byte key loads a thread of the tile sort issues before it consumes the first */
 
+struct rj_rec {
+	uint32_t word, lo, hi;	/* slot inside the digit << 15 | row inside the tile; the cell's halves */
+};
+
 struct rj_sort_args {
 	const int64_t *keys;
 	uint64_t n;
@@ -52,9 +56,11 @@ struct rj_sort_args {
 	uint32_t kbits, dbits;
 	uint32_t *words;	/* [ntiles * RJ_STRIDE]: slot inside the digit << 15 | row inside the tile */
 	uint16_t *offs;		/* [ntiles * (D + 8)]: digit starts inside the tile, entry D = rows of the tile */
-	/* CELLS (the right table): up to two payload columns travel with the words - cells[c][tile * RJ_STRIDE + p] belongs to word p of the tile */
+	/* CELLS (a right table): up to two payload columns travel with the words - recs[c][tile * RJ_STRIDE + p] = { word p of the tile, the
+	 * row's cell of column c }: ONE 12-byte record per row and column, so that the leaf asks for a (tile, digit) piece of a right table
+	 * once instead of once for the words and once for the cells (it is bound by requests, not bytes: round 6); `words` is not written */
 	const uint64_t *pay_in[2];
-	uint64_t *cells[2];
+	rj_rec *recs[2];
 	uint32_t npay;
 	uint32_t *status;
 };
@@ -159,24 +165,27 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 				/* the digit's start has become its cursor: two 16-bit cursors per word, a cursor ends at most at 32 768 */
 				const uint32_t h = hr[2 * j + e], d = h >> rem;
 				const uint32_t pos = (atomicAdd(&s_cnt[d >> 1], 1u << (16u * (d & 1u))) >> (16u * (d & 1u))) & 0xFFFFu;
-				s_stage[pos] = ((h & smask) << RJ_TILE_BITS) | r;
 				if (CELLS)
-					hr[2 * j + e] = pos;	/* (the row's cells follow it there) */
+					hr[2 * j + e] = ((h & smask) << RJ_TILE_BITS) | pos;	/* (slot | place: the row's records are built from it below) */
+				else
+					s_stage[pos] = ((h & smask) << RJ_TILE_BITS) | r;
 			}
 		}
 	}
 	__syncthreads();
-	{
+	if (!CELLS) {
 		uint4 *const dst = reinterpret_cast<uint4 *>(a.words + blk0);
 		const uint4 *const st = reinterpret_cast<const uint4 *>(s_stage);
 		for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS)
 			dst[i] = st[i];		/* (the words behind a partial last tile's rows are never read) */
-	}
-	if (!CELLS)
 		return;
-	/* the cells: loaded in row order like the keys, dropped at their words' places in LDS - 16 384 at a time: two rounds per
-	 * column -, written out in order */
-	uint64_t *const s_cells = reinterpret_cast<uint64_t *>(s_stage);
+	}
+	/* the records: a column's cells loaded in row order like the keys, every row's { word, cell } dropped at its place in LDS - a quarter of
+	 * the tile's places at a time (8192 x 12 bytes of the staging area): four rounds per column -, written out in order, 16 bytes per lane
+	 * (a quarter's 98 304 bytes and a tile's block start are multiples of 16) */
+	rj_rec *const s_rec = reinterpret_cast<rj_rec *>(s_stage);
+	constexpr uint32_t RJ_Q = RJ_TILE / 4, RJ_QBITS = RJ_TILE_BITS - 2u;
+#pragma unroll 1
 	for (uint32_t c = 0; c < a.npay; c++) {		/* (uniform) */
 		const ulonglong2 *csrc = reinterpret_cast<const ulonglong2 *>(a.pay_in[c] + row0);
 		ulonglong2 cv[RJ_ITEMS / 2];
@@ -193,26 +202,38 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 					cv[j].y = a.pay_in[c][row0 + 2u * p + 1u];
 			}
 		}
-		for (uint32_t round = 0; round < 2u; round++) {
+#pragma unroll 1
+		for (uint32_t round = 0; round < 4u; round++) {
 			__syncthreads();	/* (the staging area is free: its last readers are done) */
+			/* (what a round derives from a row's slot | place - address, word, predicate - is computed in the round: kept across
+			 * the rounds it is three more values per row, and the kernel spills) */
+#pragma unroll
+			for (int i = 0; i < (int)RJ_ITEMS; i++)
+				asm volatile("" : "+v"(hr[i]));
 #pragma unroll
 			for (int j = 0; j < (int)RJ_ITEMS / 2; j++) {
 #pragma unroll
 				for (int e = 0; e < 2; e++) {
 					const uint32_t r = 2u * ((uint32_t)j * RJ_THREADS + threadIdx.x) + (uint32_t)e;
-					const uint32_t pos = hr[2 * j + e];
-					if ((FULL || r < cnt) && (pos >> (RJ_TILE_BITS - 1u)) == round)
-						s_cells[pos & (RJ_TILE / 2 - 1u)] = e ? cv[j].y : cv[j].x;
+					const uint32_t sp = hr[2 * j + e], pos = sp & (RJ_TILE - 1u);
+					if ((FULL || r < cnt) && (pos >> RJ_QBITS) == round) {
+						const uint64_t cell = e ? cv[j].y : cv[j].x;
+						rj_rec rec;
+						rec.word = (sp & ~(RJ_TILE - 1u)) | r;
+						rec.lo = (uint32_t)cell;
+						rec.hi = (uint32_t)(cell >> 32);
+						s_rec[pos & (RJ_Q - 1u)] = rec;
+					}
 				}
 			}
 			__syncthreads();
-			const uint32_t p0 = round * (RJ_TILE / 2);
+			const uint32_t p0 = round * RJ_Q;
 			if (p0 < cnt) {
-				const uint32_t m = cnt - p0 < RJ_TILE / 2 ? cnt - p0 : RJ_TILE / 2;
-				ulonglong2 *const cd = reinterpret_cast<ulonglong2 *>(a.cells[c] + blk0 + p0);
-				const ulonglong2 *const cs = reinterpret_cast<const ulonglong2 *>(s_cells);
-				for (uint32_t i = threadIdx.x; 2u * i < m; i += RJ_THREADS)
-					cd[i] = cs[i];	/* (an odd last cell takes its undefined neighbour along: inside the tile's block) */
+				const uint32_t m = cnt - p0 < RJ_Q ? cnt - p0 : RJ_Q;	/* records of this round: 3 m words, 16 bytes per lane and step */
+				uint4 *const rd = reinterpret_cast<uint4 *>(a.recs[c] + blk0 + p0);
+				const uint4 *const st = reinterpret_cast<const uint4 *>(s_rec);
+				for (uint32_t i = threadIdx.x; 4u * i < 3u * m; i += RJ_THREADS)
+					rd[i] = st[i];	/* (a last odd piece takes undefined words along: inside the tile's block - RJ_SKEW) */
 			}
 		}
 	}
@@ -237,19 +258,19 @@ __global__ __launch_bounds__(256) void k_rj_transpose_offs(const uint16_t *offs,
 }
 
 /* ---- 2. leaf */
+#define RJ_MAX_STREAMS 4	/* (right table, payload column) pairs one leaf launch serves: two tables of two cells each */
 struct rj_leaf_args {
-	/* the right table: sorted tile by tile like the left one, the cells at the words' positions */
-	const uint32_t *words_r;
-	const uint16_t *offT_r;
-	uint32_t ntiles_r, tstride_r;
-	const uint64_t *cells_r;
+	/* the right tables' payload columns, one STREAM each: sorted tile by tile like the left table, { word, cell } per row */
+	uint32_t nstreams;
+	const rj_rec *recs[RJ_MAX_STREAMS];
+	const uint16_t *offT_r[RJ_MAX_STREAMS];
+	uint32_t ntiles_r[RJ_MAX_STREAMS], tstride_r[RJ_MAX_STREAMS];
+	uint64_t *cells_al[RJ_MAX_STREAMS];	/* [ntiles * RJ_STRIDE] each: cells_al[s][i] = stream s's cell of the left row that words_l[i] names */
 	const uint32_t *words_l;
 	const uint16_t *offT_l;
 	uint32_t ntiles, tstride, dbits, sbits /* key values per digit: 2^sbits <= 2^14 */;
-	uint64_t *cells_al;	/* [ntiles * RJ_STRIDE]: cells_al[i] = the cell of the left row that words_l[i] names */
-	uint32_t count_pairs;	/* the first cell's pass counts the joined rows */
 	uint32_t ablate;	/* measurement only (MDB_RJ_ABLATE): 1 no build, 2 no probe, 4 no cell stores, 8 no right cells read */
-	unsigned long long *joined;
+	unsigned long long *joined;	/* += (left row, stream) pairs served: nstreams x the left rows when every row found its partner in every table */
 	uint32_t *status;
 };
 
@@ -275,7 +296,11 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 {
 	constexpr int RJ_G = LPP >= 32 ? 1 : 32 / LPP;	/* tile groups per sweep: 32 (64) pieces' steps per lane and sweep */
 	static_assert(LPP >= 8 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
-	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	uint32_t lane = mdb_lane();
+	/* (called once per stream and phase from a loop: what is derived from the lane - the crossbar's source lanes of every step - is derived
+	 * HERE, per call; hoisted out of the caller's loop for all its calls at once it costs two dozen registers and the loads' answers spill) */
+	asm volatile("" : "+v"(lane));
+	const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
 		uint32_t sg[RJ_G], lg[RJ_G];
@@ -368,96 +393,100 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 	__shared__ unsigned long long s_red[RJ_LEAF_THREADS / 64];
 	__shared__ uint32_t s_dup;
 	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D);
-	for (uint32_t w = threadIdx.x; w < ((1u << a.sbits) + 31u) / 32u; w += blockDim.x)
-		s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
-	if (threadIdx.x == 0)
-		s_dup = 0u;
-	__syncthreads();
-	/* build: the digit's right rows - their cells dropped at their slots */
-	{
-	bool dup = false;
-	if (!(a.ablate & 1u)) {
-		constexpr int UB = 8;
-		uint32_t w[UB];
-		uint64_t c[UB];
-		auto put = [&](uint32_t word, uint64_t cell) {
-			const uint32_t slot = word >> RJ_TILE_BITS;
-			const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
-			dup = dup || (old & (1u << (slot & 31u)));
-			rj_cell[slot] = cell;
-		};
-		auto ld = [&](int u, uint32_t idx) {
-			w[u] = a.words_r[idx];
-			c[u] = (a.ablate & 8u) ? 0ull : a.cells_r[idx];
-		};
-		auto us = [&](int u, uint32_t) { put(w[u], c[u]); };
-		if (LPP == 64)
-			rj_for_long_pieces<UB>(a.offT_r, a.tstride_r, a.ntiles_r, d, ld, us);
-		else
-			rj_for_pieces<(LPP == 64 ? 32 : LPP), UB>(a.offT_r, a.tstride_r, a.ntiles_r, d, ld, us,
-								  [&](uint32_t idx) { put(a.words_r[idx], a.cells_r[idx]); });
-	}
-	if (dup)
-		s_dup = 1u;
-	}
-	__syncthreads();
-	if (s_dup) {	/* a right key occurs twice */
-		if (threadIdx.x == 0)
-			mdb_raise(a.status, 32u);
-		return;
-	}
-	/* probe: every left row of the digit picks its partner's cell up and leaves it at its word's place */
 	unsigned long long pairs = 0;
 	uint32_t miss = 0;
-	{
-		constexpr int UP = 16;
-		uint32_t w[UP];
-		auto take = [&](uint32_t word, uint32_t idx) {
-			const uint32_t slot = word >> RJ_TILE_BITS;
-			if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
-				if (!(a.ablate & 4u))
-					a.cells_al[idx] = rj_cell[slot];
-				pairs++;
-			} else {
-				miss = 1u;
+	if (threadIdx.x == 0)
+		s_dup = 0u;
+	/* one round per stream: the digit's cells of that right column into the table, then the digit's left rows looked up (a second
+	 * stream's round finds the left words and offsets of the first one in its XCD's L2) */
+#pragma unroll 1
+	for (uint32_t s = 0; s < a.nstreams; s++) {		/* (uniform) */
+		if (s)
+			__syncthreads();	/* (the last round's lookups are done) */
+		for (uint32_t w = threadIdx.x; w < ((1u << a.sbits) + 31u) / 32u; w += blockDim.x)
+			s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
+		__syncthreads();
+		/* build: the digit's right rows - their cells dropped at their slots */
+		{
+			bool dup = false;
+			if (!(a.ablate & 1u)) {
+				constexpr int UB = 8;
+				rj_rec rv[UB];
+				const rj_rec *const recs = a.recs[s];
+				auto put = [&](const rj_rec &r) {
+					const uint32_t slot = r.word >> RJ_TILE_BITS;
+					const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+					dup = dup || (old & (1u << (slot & 31u)));
+					rj_cell[slot] = (a.ablate & 8u) ? 0ull : ((uint64_t)r.hi << 32 | r.lo);
+				};
+				auto ld = [&](int u, uint32_t idx) { rv[u] = recs[idx]; };
+				auto us = [&](int u, uint32_t) { put(rv[u]); };
+				if (LPP == 64)
+					rj_for_long_pieces<UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us);
+				else
+					rj_for_pieces<(LPP == 64 ? 32 : LPP), UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us,
+										  [&](uint32_t idx) { put(recs[idx]); });
 			}
-		};
-		auto ld = [&](int u, uint32_t idx) { w[u] = (a.ablate & 2u) ? 0u : a.words_l[idx]; };
-		auto us = [&](int u, uint32_t idx) {
-			if (a.ablate & 2u)
-				pairs++;
+			if (dup)
+				s_dup = 1u;
+		}
+		__syncthreads();
+		if (s_dup) {	/* a right key occurs twice */
+			if (threadIdx.x == 0)
+				mdb_raise(a.status, 32u);
+			return;
+		}
+		/* probe: every left row of the digit picks its partner's cell up and leaves it at its word's place */
+		{
+			constexpr int UP = 16;
+			uint32_t w[UP];
+			uint64_t *const cells_al = a.cells_al[s];
+			auto take = [&](uint32_t word, uint32_t idx) {
+				const uint32_t slot = word >> RJ_TILE_BITS;
+				if ((s_occ[slot >> 5] >> (slot & 31u)) & 1u) {
+					if (!(a.ablate & 4u))
+						cells_al[idx] = rj_cell[slot];
+					pairs++;
+				} else {
+					miss = 1u;
+				}
+			};
+			auto ld = [&](int u, uint32_t idx) { w[u] = (a.ablate & 2u) ? 0u : a.words_l[idx]; };
+			auto us = [&](int u, uint32_t idx) {
+				if (a.ablate & 2u)
+					pairs++;
+				else
+					take(w[u], idx);
+			};
+			if (LONG)
+				rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
 			else
-				take(w[u], idx);
-		};
-		if (LONG)
-			rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
-		else
-			rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); });
+				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); });
+		}
 	}
 	if (miss)
 		mdb_raise(a.status, 4u);	/* a left row without partner */
-	if (a.count_pairs) {
 #pragma unroll
-		for (int o = 32; o; o >>= 1)
-			pairs += __shfl_down(pairs, o, MDB_WAVE);
-		if (mdb_lane() == 0)
-			s_red[threadIdx.x >> 6] = pairs;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			unsigned long long t = 0;
-			for (uint32_t w = 0; w < (blockDim.x >> 6); w++)
-				t += s_red[w];
-			if (t)
-				atomicAdd(a.joined, t);
-		}
+	for (int o = 32; o; o >>= 1)
+		pairs += __shfl_down(pairs, o, MDB_WAVE);
+	if (mdb_lane() == 0)
+		s_red[threadIdx.x >> 6] = pairs;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+		for (uint32_t w = 0; w < (blockDim.x >> 6); w++)
+			t += s_red[w];
+		if (t)
+			atomicAdd(a.joined, t);
 	}
 }
 
 /* ---- 3. placement */
 struct rj_place_args {
 	const uint32_t *words_l;
-	const uint64_t *cells_al;
-	uint64_t *out;
+	uint32_t ncols;
+	const uint64_t *cells_al[RJ_MAX_STREAMS];
+	uint64_t *out[RJ_MAX_STREAMS];
 	uint64_t n;
 	uint32_t ntiles;
 };
@@ -475,29 +504,43 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_place(rj_place_args a)
 		return;
 	/* four words and their four cells per lane and step: 16-byte loads, every cell of the tile read by both halves' workgroups (the second
 	 * finds the lines in its XCD's L2) - a vector memory instruction costs its ~70 cycles whatever it carries (profiles/r05/piece_loads.txt):
-	 * 8-byte loads of the one half's cells alone were twice the instructions (0.45 -> 0.30 ms per 10^8 rows) */
+	 * 8-byte loads of the one half's cells alone were twice the instructions (0.45 -> 0.30 ms per 10^8 rows).  The tile's words are read
+	 * ONCE for all the columns the join carries (round 6) */
 	const uint4 *const wsrc = reinterpret_cast<const uint4 *>(a.words_l + blk0);
-	const ulonglong2 *const csrc = reinterpret_cast<const ulonglong2 *>(a.cells_al + blk0);
-	for (uint32_t i = threadIdx.x; 4u * i < cnt; i += RJ_THREADS) {
-		const uint4 w = wsrc[i];
-		const ulonglong2 c01 = csrc[2u * i], c23 = csrc[2u * i + 1u];	/* (inside the tile's block: RJ_STRIDE leaves room behind a partial tile) */
-		const uint32_t ws[4] = { w.x, w.y, w.z, w.w };
-		const uint64_t cs[4] = { c01.x, c01.y, c23.x, c23.y };
+	uint4 wv[RJ_ITEMS / 4];
 #pragma unroll
-		for (int e = 0; e < 4; e++) {
-			const uint32_t r = ws[e] & (RJ_TILE - 1u);
-			if (4u * i + (uint32_t)e < cnt && (r >> (RJ_TILE_BITS - 1u)) == half)
-				rj_rows[r & (RJ_TILE / 2 - 1u)] = cs[e];
-		}
+	for (int k = 0; k < (int)RJ_ITEMS / 4; k++) {
+		const uint32_t i = (uint32_t)k * RJ_THREADS + threadIdx.x;
+		wv[k] = 4u * i < cnt ? wsrc[i] : make_uint4(0u, 0u, 0u, 0u);
 	}
-	__syncthreads();
 	const uint32_t r0 = half * (RJ_TILE / 2), m = cnt - r0 < RJ_TILE / 2 ? cnt - r0 : RJ_TILE / 2;
-	ulonglong2 *const dst = reinterpret_cast<ulonglong2 *>(a.out + row0 + r0);
-	const ulonglong2 *const st = reinterpret_cast<const ulonglong2 *>(rj_rows);
-	for (uint32_t i = threadIdx.x; 2u * i + 1u < m; i += RJ_THREADS)
-		dst[i] = st[i];
-	if ((m & 1u) && threadIdx.x == 0)
-		a.out[row0 + r0 + m - 1u] = rj_rows[m - 1u];
+	for (uint32_t c = 0; c < a.ncols; c++) {	/* (uniform) */
+		const ulonglong2 *const csrc = reinterpret_cast<const ulonglong2 *>(a.cells_al[c] + blk0);
+		if (c)
+			__syncthreads();	/* (the last column has left the staging area) */
+#pragma unroll
+		for (int k = 0; k < (int)RJ_ITEMS / 4; k++) {
+			const uint32_t i = (uint32_t)k * RJ_THREADS + threadIdx.x;
+			if (4u * i < cnt) {
+				const ulonglong2 c01 = csrc[2u * i], c23 = csrc[2u * i + 1u];	/* (inside the tile's block: RJ_STRIDE leaves room behind a partial tile) */
+				const uint32_t ws[4] = { wv[k].x, wv[k].y, wv[k].z, wv[k].w };
+				const uint64_t cs[4] = { c01.x, c01.y, c23.x, c23.y };
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					const uint32_t r = ws[e] & (RJ_TILE - 1u);
+					if (4u * i + (uint32_t)e < cnt && (r >> (RJ_TILE_BITS - 1u)) == half)
+						rj_rows[r & (RJ_TILE / 2 - 1u)] = cs[e];
+				}
+			}
+		}
+		__syncthreads();
+		ulonglong2 *const dst = reinterpret_cast<ulonglong2 *>(a.out[c] + row0 + r0);
+		const ulonglong2 *const st = reinterpret_cast<const ulonglong2 *>(rj_rows);
+		for (uint32_t i = threadIdx.x; 2u * i + 1u < m; i += RJ_THREADS)
+			dst[i] = st[i];
+		if ((m & 1u) && threadIdx.x == 0)
+			a.out[c][row0 + r0 + m - 1u] = rj_rows[m - 1u];
+	}
 }
 
 /* ---- host */
@@ -534,14 +577,34 @@ bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *
 	return true;
 }
 
+/* (+ 64: a 16-byte load may start at a block's last word or cell) */
+static size_t rj_left_arena_bytes(uint64_t n_l, size_t ostride, int streams)
+{
+	return mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) +
+	       (size_t)streams * mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64);
+}
+
+static size_t rj_right_arena_bytes(uint64_t n_r, size_t ostride, int npay)
+{
+	return 2 * mdb_align_up((rj_tiles(n_r) + 64) * ostride * 2) + (size_t)npay * mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 12 + 64);
+}
+
 size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r, uint32_t kbits, int npay)
 {
-	const uint32_t dbits = mdb_rowjoin_dbits(kbits);
-	const size_t ostride = ((size_t)1 << dbits) + 8u;
-	/* (+ 64: a 16-byte load may start at a block's last word or cell) */
-	return mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) + mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64) +
-	       mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_r) + 64) * ostride * 2) +
-	       (size_t)npay * mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 8 + 64) + 8192;
+	const size_t ostride = ((size_t)1 << mdb_rowjoin_dbits(kbits)) + 8u;
+	return rj_left_arena_bytes(n_l, ostride, npay) + rj_right_arena_bytes(n_r, ostride, npay) + 8192;
+}
+
+size_t mdb_rowjoin_arena_bytes_multi(uint64_t n_l, const struct mdb_rowjoin_right *rt, int nrt, uint32_t kbits)
+{
+	const size_t ostride = ((size_t)1 << mdb_rowjoin_dbits(kbits)) + 8u;
+	size_t need = 8192;
+	int streams = 0;
+	for (int t = 0; t < nrt; t++) {
+		need += rj_right_arena_bytes(rt[t].n, ostride, rt[t].npay);
+		streams += rt[t].npay;
+	}
+	return need + rj_left_arena_bytes(n_l, ostride, streams);
 }
 
 /* the tile sort of one table + its offsets transposed: *offT_out = [D + 1][*tstride_out] */
@@ -568,41 +631,68 @@ static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *n
 	return MIDORIDB_OK;
 }
 
-int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
-		    int64_t win_lo, uint32_t kbits, int npay, void *const *out)
+/* One left table against up to RJ_MAX_STREAMS (right table, payload column) pairs on ONE key (round 6): the left table is sorted once, every
+ * right table once, ONE leaf launch walks a digit's left rows once per stream and ONE placement pass reads a tile's words once for all the
+ * columns.  Before, SELECT * over three tables on one key (BASELINE configs[4]'s join-only form; the reference's _join_nested_loop_tbl2mat,
+ * /root/reference/src/engine/executor_select.c:1151-1232) sorted the left table's tiles twice and ran two leaves with two streams each
+ * for the right table's words and cells. */
+int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const struct mdb_rowjoin_right *rt, int nrt, int64_t win_lo, uint32_t kbits)
 {
 	const uint32_t dbits = mdb_rowjoin_dbits(kbits), D = 1u << dbits;
-	const uint32_t ntiles = (uint32_t)rj_tiles(n_l), ntiles_r = (uint32_t)rj_tiles(n_r);
+	const uint32_t ntiles = (uint32_t)rj_tiles(n_l);
 	const size_t ostride = (size_t)D + 8u;
+	rj_leaf_args la;
+	rj_place_args pa;
+	memset(&la, 0, sizeof(la));
+	memset(&pa, 0, sizeof(pa));
+	for (int t = 0; t < nrt; t++) {
+		if (rt[t].npay < 1 || rt[t].npay > 2 || la.nstreams + (uint32_t)rt[t].npay > RJ_MAX_STREAMS)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %d payload columns of table %d", rt[t].npay, t);
+		const uint32_t ntiles_r = (uint32_t)rj_tiles(rt[t].n);
+		rj_sort_args sa;
+		memset(&sa, 0, sizeof(sa));
+		sa.offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
+		if (!sa.offs)
+			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+		for (int c = 0; c < rt[t].npay; c++) {
+			sa.pay_in[c] = reinterpret_cast<const uint64_t *>(rt[t].pay_in[c]);
+			sa.recs[c] = (rj_rec *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 12 + 64);
+			if (!sa.recs[c])
+				return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+		}
+		sa.keys = rt[t].keys;
+		sa.n = rt[t].n;
+		sa.base = win_lo;
+		sa.kbits = kbits;
+		sa.dbits = dbits;
+		sa.npay = (uint32_t)rt[t].npay;
+		sa.status = ctx->d_status;
+		uint16_t *offT_r = NULL;
+		uint32_t tstride_r = 0;
+		const int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
+		if (rc)
+			return rc;
+		for (int c = 0; c < rt[t].npay; c++) {
+			const uint32_t s = la.nstreams++;
+			la.recs[s] = sa.recs[c];
+			la.offT_r[s] = offT_r;
+			la.ntiles_r[s] = ntiles_r;
+			la.tstride_r[s] = tstride_r;
+			pa.out[s] = reinterpret_cast<uint64_t *>(rt[t].out[c]);
+		}
+	}
 	uint32_t *words = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 4 + 64);
 	uint16_t *offs = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles * ostride * 2);
-	uint64_t *cells_al = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 8 + 64);
-	uint32_t *words_r = (uint32_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 4 + 64);
-	uint16_t *offs_r = (uint16_t *)mdb_arena_take(ctx, (size_t)ntiles_r * ostride * 2);
-	if (!words || !offs || !cells_al || !words_r || !offs_r)
+	if (!words || !offs)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
-	uint16_t *offT_r = NULL, *offT_l = NULL;
-	uint32_t tstride_r = 0, tstride_l = 0;
-	rj_sort_args sa;
-	memset(&sa, 0, sizeof(sa));
-	for (int c = 0; c < npay; c++) {
-		sa.pay_in[c] = reinterpret_cast<const uint64_t *>(pay_in[c]);
-		sa.cells[c] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles_r * RJ_STRIDE * 8 + 64);
-		if (!sa.cells[c])
+	for (uint32_t s = 0; s < la.nstreams; s++) {
+		la.cells_al[s] = (uint64_t *)mdb_arena_take(ctx, (size_t)ntiles * RJ_STRIDE * 8 + 64);
+		if (!la.cells_al[s])
 			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
+		pa.cells_al[s] = la.cells_al[s];
 	}
-	sa.keys = keys_r;
-	sa.n = n_r;
-	sa.base = win_lo;
-	sa.kbits = kbits;
-	sa.dbits = dbits;
-	sa.words = words_r;
-	sa.offs = offs_r;
-	sa.npay = (uint32_t)npay;
-	sa.status = ctx->d_status;
-	int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
-	if (rc)
-		return rc;
+	uint16_t *offT_l = NULL;
+	uint32_t tstride_l = 0;
 	rj_sort_args sl;
 	memset(&sl, 0, sizeof(sl));
 	sl.keys = keys_l;
@@ -613,7 +703,7 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	sl.words = words;
 	sl.offs = offs;
 	sl.status = ctx->d_status;
-	rc = rj_sort_table<false>(ctx, sl, "rowjoin_tile_sort", &offT_l, &tstride_l);
+	const int rc = rj_sort_table<false>(ctx, sl, "rowjoin_tile_sort", &offT_l, &tstride_l);
 	if (rc)
 		return rc;
 	const uint32_t sbits = kbits - dbits;
@@ -626,52 +716,53 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
 	 * round trips - offsets, words, cells -: what hides them is another digit on the same CU) */
 	const uint32_t leaf_threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
 	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : dbits == 11 ? 32 : dbits == 10 ? 64 : 0;
-	for (int c = 0; c < npay; c++) {
-		rj_leaf_args la;
-		memset(&la, 0, sizeof(la));
-		la.words_r = words_r;
-		la.offT_r = offT_r;
-		la.ntiles_r = ntiles_r;
-		la.tstride_r = tstride_r;
-		la.cells_r = sa.cells[c];
-		la.words_l = words;
-		la.offT_l = offT_l;
-		la.ntiles = ntiles;
-		la.tstride = tstride_l;
-		la.dbits = dbits;
-		la.sbits = sbits;
-		la.cells_al = cells_al;
-		la.count_pairs = c == 0;
-		la.ablate = mdb_knob("MDB_RJ_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_RJ_ABLATE")) : 0u;
-		la.joined = (unsigned long long *)(ctx->d_status + 2);
-		la.status = ctx->d_status;
+	la.words_l = words;
+	la.offT_l = offT_l;
+	la.ntiles = ntiles;
+	la.tstride = tstride_l;
+	la.dbits = dbits;
+	la.sbits = sbits;
+	la.ablate = mdb_knob("MDB_RJ_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_RJ_ABLATE")) : 0u;
+	la.joined = (unsigned long long *)(ctx->d_status + 2);
+	la.status = ctx->d_status;
 #define RJ_LAUNCH_LEAF(L, LONG)                                                                                                                   \
 	do {                                                                                                                                      \
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf<L, LONG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
 		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<L, LONG>), D, leaf_threads, lds_leaf, la);                                            \
 	} while (0)
-		if (lpp == 8)
-			RJ_LAUNCH_LEAF(8, false);
-		else if (lpp == 16)
-			RJ_LAUNCH_LEAF(16, false);
-		else if (lpp == 32)
-			RJ_LAUNCH_LEAF(32, false);
-		else if (lpp == 64)
-			RJ_LAUNCH_LEAF(64, false);
-		else
-			RJ_LAUNCH_LEAF(64, true);
+	if (lpp == 8)
+		RJ_LAUNCH_LEAF(8, false);
+	else if (lpp == 16)
+		RJ_LAUNCH_LEAF(16, false);
+	else if (lpp == 32)
+		RJ_LAUNCH_LEAF(32, false);
+	else if (lpp == 64)
+		RJ_LAUNCH_LEAF(64, false);
+	else
+		RJ_LAUNCH_LEAF(64, true);
 #undef RJ_LAUNCH_LEAF
-		rj_place_args pa;
-		memset(&pa, 0, sizeof(pa));
-		pa.words_l = words;
-		pa.cells_al = cells_al;
-		pa.out = reinterpret_cast<uint64_t *>(out[c]);
-		pa.n = n_l;
-		pa.ntiles = ntiles;
-		const uint32_t grid = ((ntiles + 7u) / 8u) * 16u;
-		MDB_LAUNCH_LDS(ctx, "rowjoin_place", k_rj_place, grid, RJ_THREADS, lds_place, pa);
-	}
+	pa.words_l = words;
+	pa.ncols = la.nstreams;
+	pa.n = n_l;
+	pa.ntiles = ntiles;
+	const uint32_t grid = ((ntiles + 7u) / 8u) * 16u;
+	MDB_LAUNCH_LDS(ctx, "rowjoin_place", k_rj_place, grid, RJ_THREADS, lds_place, pa);
 	return MIDORIDB_OK;
+}
+
+int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const int64_t *keys_r, uint64_t n_r, const void *const *pay_in,
+		    int64_t win_lo, uint32_t kbits, int npay, void *const *out)
+{
+	struct mdb_rowjoin_right rt;
+	memset(&rt, 0, sizeof(rt));
+	rt.keys = keys_r;
+	rt.n = n_r;
+	rt.npay = npay;
+	for (int c = 0; c < npay && c < 2; c++) {
+		rt.pay_in[c] = pay_in[c];
+		rt.out[c] = out[c];
+	}
+	return mdb_rowjoin_run_multi(ctx, keys_l, n_l, &rt, 1, win_lo, kbits);
 }
 
 /* ------------------------------------------------------------------ GROUP BY key + COUNT(*) over a tile-sorted column (round 5)

@@ -335,6 +335,147 @@ void op_stats_end(struct exec *x)
 	(void)mdb_dev_call_stats(x->dev, NULL, NULL, NULL, NULL);
 }
 
+/* Table t after a join that carried its payload cells to the stream's rows: read through a SHADOW whose key column is the stream's own key
+ * column, whose payload columns pc[0 .. np) are the carried cells out[], whose row-id vector is the identity */
+static int payload_shadow(struct exec *x, int t, int key_col, const int64_t *vl, const int *pc, int np, void *const *out)
+{
+	struct mdb_select *s = x->s;
+	const struct mdb_table *rt = s->tabs[t].t;
+	struct mdb_table *sh = calloc(1, sizeof(*sh));
+	if (!sh)
+		return -MIDORIDB_NOMEM;
+	memcpy(sh->name, rt->name, sizeof(sh->name));
+	sh->ncols = rt->ncols;
+	for (int c = 0; c < rt->ncols; c++) {
+		memcpy(sh->cols[c].name, rt->cols[c].name, sizeof(sh->cols[c].name));
+		sh->cols[c].type = rt->cols[c].type;
+		sh->cols[c].precision = rt->cols[c].precision;
+		sh->cols[c].not_null = rt->cols[c].not_null;
+	}
+	sh->cols[key_col].d_data = (void *)vl;	/* (in every joined tuple the key of t IS the stream's key; a NULL key joined nothing) */
+	for (int i = 0; i < np; i++)
+		sh->cols[pc[i]].d_data = out[i];
+	sh->nrows = sh->dev_rows = x->n;
+	sh->dev_cap = x->n;
+	sh->device_only = true;
+	x->orig_tab[t] = s->tabs[t].t;
+	x->shadow[t] = sh;
+	s->tabs[t].t = sh;
+	x->rid[t] = NULL;
+	x->joined_rows = x->n;
+	return 0;
+}
+
+/* the payload columns of table t a join would have to carry: the columns the statement reads, the key column apart - at most two, none
+ * with NULLs, all on the device; -1 when the table does not qualify */
+static int payload_columns(struct exec *x, int t, int key_col, int *pc)
+{
+	const struct mdb_table *rt = x->s->tabs[t].t;
+	int np = 0;
+	for (int c = 0; c < rt->ncols; c++) {
+		if (!x->need[t][c] || c == key_col)
+			continue;
+		if (np == 2 || rt->cols[c].d_nullbits || !rt->cols[c].d_data)
+			return -1;
+		pc[np++] = c;
+	}
+	return np;
+}
+
+/* SEVERAL tables joined to the stream on ONE key, each a primary-key table that every row of the stream finds exactly one partner in
+ * (SELECT * FROM A JOIN B ON A.k = B.k JOIN C ON A.k = C.k - BASELINE configs[4]'s join-only form; the reference joins B, then C against the
+ * materialised A x B: executor_select.c:1076-1232): table t and the tables behind it whose whole ON clause is `earlier key = own column`,
+ * that have no WHERE conjunct of their own and qualify like table t does, are handed to mdb_dev_join_payload_multi in one call - the
+ * stream's key column is sorted once for all of them - with the catalog's key ranges as the window.  0 = done for table t and
+ * x->joined_ahead[] tables (join_next_table returns at once for those), 1 = not such a statement or not such a join (nothing changed:
+ * table t is joined on its own), < 0 = error. */
+static int join_with_payload_multi(struct exec *x, int t, const struct mdb_expr *kl, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl,
+				   const void *vr, const uint64_t *nr, uint64_t r_rows)
+{
+	struct mdb_select *s = x->s;
+	struct mdb_dev_payload_right right[4];
+	const struct mdb_expr *keys[4];
+	int tabs[4], pcs[4][2], nt = 0, streams = 0;
+	int64_t lo, hi;
+	const char *rowjoin = mdb_knob("MDB_ROWJOIN");	/* ("2": the row-order form for tables of any size - tests) */
+	if ((x->n < ((uint64_t)1 << 24) && !(rowjoin && rowjoin[0] == '2')) || nl || nr || x->orig_tab[t] || kl->kind != MDB_EX_FIELD || kl->tbl_idx < 0 || x->orig_tab[kl->tbl_idx])
+		return 1;
+	{
+		struct mdb_table *lt = s->tabs[kl->tbl_idx].t;
+		if (mdb_col_range(x->cat, lt, &lt->cols[kl->col_idx], &lo, &hi) != MIDORIDB_OK || lo > hi)
+			return 1;
+	}
+	memset(right, 0, sizeof(right));
+	for (int t2 = t; t2 < s->ntabs && nt < 4; t2++) {
+		const struct mdb_expr *k2 = kr;
+		if (t2 > t) {
+			const struct mdb_expr *on = s->on[t2], *mine = NULL, *other = NULL;
+			if (!on || on->kind != MDB_EX_CMP || on->op != MDB_CMP_EQ || on->kids[0]->kind != MDB_EX_FIELD || on->kids[1]->kind != MDB_EX_FIELD)
+				break;
+			if (on->kids[0]->tbl_idx == t2 && on->kids[1]->tbl_idx < t2) {
+				mine = on->kids[0];
+				other = on->kids[1];
+			} else if (on->kids[1]->tbl_idx == t2 && on->kids[0]->tbl_idx < t2) {
+				mine = on->kids[1];
+				other = on->kids[0];
+			} else {
+				break;
+			}
+			bool same_key = field_eq(other, kl);	/* (the stream's key, or the key column of a table this call joins on it) */
+			for (int i = 0; i < nt && !same_key; i++)
+				same_key = field_eq(other, keys[i]);
+			if (!same_key || mine->type == MDB_CT_DOUBLE || x->orig_tab[t2] || (x->ws ? x->ws->npush[t2] != 0 : 0))
+				break;
+			k2 = mine;
+		}
+		struct mdb_table *rt = s->tabs[t2].t;
+		const int np = payload_columns(x, t2, k2->col_idx, pcs[nt]);
+		int64_t rlo, rhi;
+		if (np < 1 || streams + np > 4 || !rt->nrows || mdb_col_range(x->cat, rt, &rt->cols[k2->col_idx], &rlo, &rhi) != MIDORIDB_OK || rlo > rhi)
+			break;
+		const void *kv = vr;
+		const uint64_t *kn = nr;
+		if (t2 > t && table_column(x, t2, k2, NULL, rt->nrows, &kv, &kn))
+			break;
+		if (kn)
+			break;
+		lo = rlo < lo ? rlo : lo;
+		hi = rhi > hi ? rhi : hi;
+		right[nt].keys = (const int64_t *)kv;
+		right[nt].rows = t2 > t ? rt->nrows : r_rows;
+		right[nt].npay = np;
+		for (int i = 0; i < np; i++)
+			right[nt].pay_in[i] = rt->cols[pcs[nt][i]].d_data;
+		keys[nt] = k2;
+		tabs[nt] = t2;
+		streams += np;
+		nt++;
+	}
+	if (nt < 2 || (uint64_t)hi - (uint64_t)lo >= ((uint64_t)1 << 27))
+		return 1;
+	for (int i = 0; i < nt; i++)
+		for (int c = 0; c < right[i].npay; c++)
+			if (!(right[i].out[c] = dalloc(x, x->n * 8)))
+				return dev_fail(x, "allocating carried columns");
+	const int rc = mdb_dev_join_payload_multi(x->dev, vl, NULL, x->n, right, nt, lo, hi);
+	if (rc == 1)
+		return 1;
+	if (rc)
+		return dev_fail(x, "join with payload (several tables on one key)");
+	for (int i = 0; i < nt; i++) {
+		const int prc = payload_shadow(x, tabs[i], keys[i]->col_idx, vl, pcs[i], right[i].npay, right[i].out);
+		if (prc)
+			return prc;
+		if (i) {
+			x->joined_ahead[tabs[i]] = true;
+			x->same_col[tabs[i]] = keys[i]->col_idx;
+			x->same_as_tbl[tabs[i]] = kl->tbl_idx;
+			x->same_as_col[tabs[i]] = kl->col_idx;
+		}
+	}
+	return 0;
+}
+
 int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const int64_t *vl, const uint64_t *nl, const void *vr,
 			     const uint64_t *nr, uint64_t r_rows)
 {
@@ -363,29 +504,7 @@ int join_with_payload(struct exec *x, int t, const struct mdb_expr *kr, const in
 		return 1;
 	if (rc)
 		return dev_fail(x, "join with payload");
-	struct mdb_table *sh = calloc(1, sizeof(*sh));
-	if (!sh)
-		return -MIDORIDB_NOMEM;
-	memcpy(sh->name, rt->name, sizeof(sh->name));
-	sh->ncols = rt->ncols;
-	for (int c = 0; c < rt->ncols; c++) {
-		memcpy(sh->cols[c].name, rt->cols[c].name, sizeof(sh->cols[c].name));
-		sh->cols[c].type = rt->cols[c].type;
-		sh->cols[c].precision = rt->cols[c].precision;
-		sh->cols[c].not_null = rt->cols[c].not_null;
-	}
-	sh->cols[kr->col_idx].d_data = (void *)vl;	/* (in every joined tuple the key of t IS the stream's key; a NULL key joined nothing) */
-	for (int i = 0; i < np; i++)
-		sh->cols[pc[i]].d_data = out[i];
-	sh->nrows = sh->dev_rows = x->n;
-	sh->dev_cap = x->n;
-	sh->device_only = true;
-	x->orig_tab[t] = s->tabs[t].t;
-	x->shadow[t] = sh;
-	s->tabs[t].t = sh;
-	x->rid[t] = NULL;
-	x->joined_rows = x->n;
-	return 0;
+	return payload_shadow(x, t, kr->col_idx, vl, pc, np, out);
 }
 
 int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, int npconj)
@@ -399,6 +518,8 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 	uint64_t J = 0;
 	int rc;
 
+	if (x->joined_ahead[t])		/* (joined together with an earlier table on the same key: join_with_payload_multi) */
+		return MIDORIDB_OK;
 	if (s->on[t]) {
 		collect_conjuncts(s->on[t], conj, &nconj, 32);
 		if (nconj > 32)
@@ -485,7 +606,9 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 		if (kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE)
 			op_stats_begin(x, kl, vl, kr, vr);	/* (until the join is done: op_stats_end below / at the early returns) */
 		if (x->n && r_rows && !x->cat->dist && !rsel && kl->type != MDB_CT_DOUBLE && kr->type != MDB_CT_DOUBLE) {
-			const int prc = join_with_payload(x, t, kr, vl, nl, vr, nr, r_rows);
+			int prc = nconj == 1 ? join_with_payload_multi(x, t, kl, kr, vl, nl, vr, nr, r_rows) : 1;
+			if (prc == 1)
+				prc = join_with_payload(x, t, kr, vl, nl, vr, nr, r_rows);
 			if (prc <= 0)
 				op_stats_end(x);
 			if (prc < 0)
@@ -1115,6 +1238,7 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 				x.rid[0] = (uint32_t *)sel0;
 				x.n = m0;
 			}
+			x.ws = &ws;
 			for (int t = 1; t < s->ntabs; t++)
 				if ((rc = join_next_table(&x, t, ws.push[t], ws.npush[t])))
 					goto out;

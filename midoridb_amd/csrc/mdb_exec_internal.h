@@ -20,6 +20,8 @@ struct dbuf_list {
 	int n, cap;
 };
 
+struct where_split;
+
 struct exec {
 	struct mdb_catalog *cat;
 	mdb_dev_ctx *dev;
@@ -48,6 +50,8 @@ struct exec {
 	bool promised;		/* the exchange handle holds this statement's key ranges (shard_promise_ranges) */
 	bool dict_synced;	/* the ranks' string dictionaries were made known to each other for this statement (shard_dict_sync) */
 	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
+	const struct where_split *ws;		/* the WHERE conjuncts pushed down to single tables (general plan; NULL: none are) */
+	bool joined_ahead[MDB_MAX_TABS];	/* table t was joined together with an earlier table on the same key (join_with_payload_multi) */
 };
 
 struct pred_prog {

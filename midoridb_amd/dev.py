@@ -31,6 +31,10 @@ class ColBinding(ctypes.Structure):
     _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p)]
 
 
+class PayloadRight(ctypes.Structure):     # struct mdb_dev_payload_right (include/mdb_dev.h)
+    _fields_ = [("keys", c_void_p), ("nulls", c_void_p), ("rows", c_uint64), ("npay", c_int), ("pay_in", c_void_p * 2), ("out", c_void_p * 2)]
+
+
 class SortKey(ctypes.Structure):
     _fields_ = [("values", c_void_p), ("nullbits", c_void_p), ("rid", c_void_p), ("type", c_int32), ("desc", c_int32)]
 
@@ -58,7 +62,7 @@ COL_DISTINCT = 1     # MDB_COL_DISTINCT
 class PlanInfo(ctypes.Structure):
     """struct mdb_dev_plan_info: what the last join / GROUP BY operator did"""
     _fields_ = [(k, ctypes.c_uint32) for k in ("key_form", "key_bits", "levels", "digits", "minmax_pruned", "semijoin", "any_order", "ranged_order",
-                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "arena_mib", "small_form", "keys_are_left_column", "counts_all_one", "groups_as_bits")]
+                                                "multi_one_pass", "retries", "samples", "from_stats", "payload_form", "group_form", "arena_mib", "small_form", "keys_are_left_column", "counts_all_one", "groups_as_bits", "payload_tables")]
 
 
 class ExplainRequest(ctypes.Structure):
@@ -176,6 +180,7 @@ def _bind(lib):
         "mdb_dev_join_keys": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(c_uint64)], c_int),
         "mdb_dev_join_keys_ordered": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), POINTER(c_uint64), POINTER(c_int)], c_int),
         "mdb_dev_join_payload": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(P), c_int, POINTER(P)], c_int),
+        "mdb_dev_join_payload_multi": ([P, P, P, c_uint64, POINTER(PayloadRight), c_int, c_int64, c_int64], c_int),
         "mdb_dev_cross_pairs": ([P, c_uint64, c_uint64, P, P], c_int),
         "mdb_dev_group_count": ([P, P, P, c_uint64, c_uint32, P, P, c_uint64, POINTER(c_uint64)], c_int),
         "mdb_dev_group_count_keys": ([P, P, P, c_uint64, P, P, c_uint64, POINTER(c_uint64)], c_int),
@@ -207,7 +212,7 @@ DEV_SYMBOLS = [
     "mdb_dev_ctx_create", "mdb_dev_ctx_destroy", "mdb_dev_ctx_set_stream", "mdb_dev_last_error", "mdb_dev_sync",
     "mdb_dev_device_count", "mdb_dev_reserve", "mdb_dev_set_overlap", "mdb_dev_set_narrow_keys", "mdb_dev_last_join_narrow", "mdb_dev_last_join_filter", "mdb_dev_call_stats", "mdb_dev_last_plan", "mdb_dev_reload_knobs", "mdb_dev_counters", "mdb_dev_distinct_scan", "mdb_dev_explain_join_group_count", "mdb_dev_explain_group_count", "mdb_dev_explain_join_payload", "mdb_dev_last_pairs_identity", "mdb_dev_arena_bytes", "mdb_dev_alloc", "mdb_dev_free", "mdb_dev_memset",
     "mdb_dev_host_alloc", "mdb_dev_host_free", "mdb_dev_h2d", "mdb_dev_d2h", "mdb_dev_prof_enable", "mdb_dev_prof_reset", "mdb_dev_prof_read", "mdb_dev_prof_symbols", "mdb_dev_filter",
-    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_retain", "mdb_dev_holders", "mdb_dev_map_ids",
+    "mdb_dev_gather64", "mdb_dev_gather_cols", "mdb_dev_filter_project", "mdb_dev_double_join_keys", "mdb_dev_gather32", "mdb_dev_iota32", "mdb_dev_scatter_set64", "mdb_dev_sort_perm", "mdb_dev_topk_perm", "mdb_dev_distinct_sel", "mdb_dev_group_count_multi", "mdb_dev_join_pairs", "mdb_dev_join_keys", "mdb_dev_join_keys_ordered", "mdb_dev_join_payload", "mdb_dev_join_payload_multi", "mdb_dev_cross_pairs", "mdb_dev_alloc_size", "mdb_dev_retain", "mdb_dev_holders", "mdb_dev_map_ids",
     "mdb_dev_group_count", "mdb_dev_group_count_keys", "mdb_dev_join_group_count", "mdb_dev_join_group_count_multi", "mdb_dev_combine_counts", "mdb_dev_join_group_count_begin", "mdb_dev_join_group_count_finish",
     "mdb_dev_join_group_count_i32", "mdb_dev_join_group_count_begin_i32", "mdb_dev_join_group_count_finish_i32",
     "mdb_dev_partition_by_dest", "mdb_dev_partition_by_dest_pruned", "mdb_dev_key_range", "mdb_dev_widen32to64", "mdb_dev_gen_keys", "mdb_dev_gen_payload",
@@ -607,6 +612,28 @@ class DeviceCtx:
         if rc == 1:
             return None
         self._chk(rc, "join_payload")
+        return outs
+
+    def join_payload_multi(self, keys_l, rights, key_min, key_max):
+        """rights: list of (keys_r, [one or two payload tensors]) - several right tables joined with ONE left key column; [key_min, key_max]
+        bounds every key of every table -> per table the list of carried columns (len(keys_l) cells each), or None when not served
+        (mdb_dev_join_payload_multi)"""
+        arr = (PayloadRight * len(rights))()
+        outs = []
+        for i, (kr, payload) in enumerate(rights):
+            o = [torch.empty(keys_l.numel(), dtype=p.dtype, device=self.device) for p in payload]
+            outs.append(o)
+            arr[i].keys = kr.data_ptr()
+            arr[i].nulls = None
+            arr[i].rows = kr.numel()
+            arr[i].npay = len(payload)
+            for c, (pi, po) in enumerate(zip(payload, o)):
+                arr[i].pay_in[c] = pi.data_ptr()
+                arr[i].out[c] = po.data_ptr()
+        rc = self.lib.mdb_dev_join_payload_multi(self.h, _ptr(keys_l), None, keys_l.numel(), arr, len(rights), int(key_min), int(key_max))
+        if rc == 1:
+            return None
+        self._chk(rc, "join_payload_multi")
         return outs
 
     def cross_pairs(self, n_l, n_r):

@@ -34,6 +34,8 @@ def test_the_plans_of_the_baseline_configurations():
         if "with_catalog_statistics" in e:
             assert e["with_catalog_statistics"]["samples"] == 0 and e["with_catalog_statistics"]["retries"] == 0, name
     assert p["GROUP BY over a primary key, 10^8 rows"]["with_catalog_statistics"]["group_form"] == 3
-    assert p["configs[4] join-only form: payload join, 10^8 rows"]["with_catalog_statistics"]["payload_form"] == 3
+    assert p["configs[4] join-only form, table by table: payload join, 10^8 rows"]["with_catalog_statistics"]["payload_form"] == 3
+    m = p["configs[4] join-only form: B and C in one payload join, 10^8 rows"]["with_catalog_statistics"]
+    assert m["payload_form"] == 3 and m["payload_tables"] == 2 and m["digits"] == 8192
     assert p["configs[1] join + payload, 10^7 rows, two cells"]["with_catalog_statistics"]["payload_form"] == 1
     assert p["README query, 6 rows per table"]["with_catalog_statistics"]["small_form"] == 1

@@ -1021,6 +1021,69 @@ def test_join_payload_carries_the_right_tables_cells_to_every_left_row(dev, case
     assert again is not None and np.array_equal(_np(again[0]).view(np.int64), pay[0][er].view(np.int64))
 
 
+@pytest.mark.parametrize("case", ["two_tables_one_cell_each", "two_tables_two_cells_each", "three_tables", "one_table_two_cells", "window_2e19",
+                                  "left_row_without_partner_in_the_second_table", "duplicate_key_in_the_second_table", "key_outside_the_bound",
+                                  "foreign_keys_on_the_left", "partial_last_tile_only"])
+def test_join_payload_multi_one_left_sort_serves_every_right_table(dev, case, monkeypatch):
+    """mdb_dev_join_payload_multi (BASELINE configs[4]'s join-only form: SELECT * over A, B, C on one key; the reference joins B, then C
+    against the materialised A x B - executor_select.c:1076-1232): right[t].out[c][i] = payload cell c of left row i's partner in table
+    t, bit for bit what payload[np_oracle.join_pairs] says; the left table's tiles are sorted ONCE, one leaf launch and one placement
+    pass serve all tables; any statement about the tables that does not hold is refused ("not served"), never answered wrongly"""
+    rng = np.random.default_rng(len(case) * 7 + 1)
+    monkeypatch.setenv("MDB_ROWJOIN", "2")     # (by default the form takes left tables of 2^24 rows and more)
+    span = 1 << (18 if case == "window_2e19" else 21)
+    base = -5_000_000
+    ntab = 3 if case == "three_tables" else 1 if case == "one_table_two_cells" else 2
+    cells = 2 if "two_cells" in case else 1
+    served = True
+    nleft = 20_000 if case == "partial_last_tile_only" else 1_234_567
+    rights = []
+    for t in range(ntab):
+        kr = rng.permutation(span).astype(np.int64)[: span - 1000 * t] + base     # (tables of different sizes: different tile counts)
+        if case == "partial_last_tile_only":
+            kr = kr[:30_000]
+        pay = [rng.integers(-2**62, 2**62, len(kr), dtype=np.int64), rng.standard_normal(len(kr))][:cells]
+        rights.append((kr, pay))
+    common = rights[0][0]
+    for kr, _ in rights[1:]:
+        common = np.intersect1d(common, kr)
+    kl = common[rng.integers(0, len(common), nleft)] if case in ("foreign_keys_on_the_left", "partial_last_tile_only") else rng.permutation(common)[:nleft]
+    lo, hi = base, base + span - 1
+    if case == "left_row_without_partner_in_the_second_table":
+        missing = np.setdiff1d(rights[0][0], rights[1][0])
+        kl = kl.copy()
+        kl[nleft // 2] = missing[0]
+        served = False
+    if case == "duplicate_key_in_the_second_table":
+        kr = rights[1][0].copy()
+        kr[10] = kr[11]
+        rights[1] = (kr, rights[1][1])
+        kl = kl[(kl != rights[1][0][10])]
+        served = False
+    if case == "key_outside_the_bound":
+        kl = kl.copy()
+        kl[5] = hi + 3
+        served = False
+    dev.prof_enable(True)
+    dev.prof_reset()
+    got = dev.join_payload_multi(dev.to_dev(kl), [(dev.to_dev(kr), [dev.to_dev(p) for p in pay]) for kr, pay in rights], lo, hi)
+    ran = dev.prof_read()
+    dev.prof_enable(False)
+    plan = dev.last_plan()
+    nfull, npart = len(kl) // 32768, 1 if len(kl) % 32768 else 0
+    assert ran["rowjoin_tile_sort"][0] == (1 if nfull else 0) + npart, ran      # the left table: once, whatever the number of right tables
+    assert ran["rowjoin_leaf"][0] == 1 and (not served or ran["rowjoin_place"][0] == 1), ran
+    if not served:
+        assert got is None and plan["payload_form"] == 0, (case, plan)
+        return
+    assert got is not None and plan["payload_form"] == 3 and plan["payload_tables"] == ntab and plan["samples"] == 0, (case, plan)
+    for (kr, pay), outs in zip(rights, got):
+        el, er = orc.join_pairs(kl, None, kr, None)
+        assert np.array_equal(el, np.arange(len(kl)))
+        for g, p in zip(outs, pay):
+            assert np.array_equal(_np(g).view(np.int64), p[er].view(np.int64)), case
+
+
 def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
     counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
