@@ -239,21 +239,22 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_tile_sort(rj_sort_args a, uin
 	}
 }
 
-/* ---- 1b. the tiles' digit offsets transposed: offT[d * tstride + t] = offs[t * (D + 8) + d], d = 0 .. D - so that a leaf workgroup
- * reads its digit's starts (and the next digit's: the ends) of ALL tiles as two contiguous runs instead of one request per tile */
-__global__ __launch_bounds__(256) void k_rj_transpose_offs(const uint16_t *offs, uint32_t ntiles, uint32_t D, uint32_t tstride, uint16_t *offT)
+/* ---- 1b. the tiles' digit offsets transposed and paired: offT[d * tstride + t] = start of digit d in tile t | its end << 16 (= the start of
+ * digit d + 1; entry D = the tile's rows), d = 0 .. D - 1 - so that a leaf workgroup reads its digit's pieces of ALL tiles as one contiguous
+ * run of 4-byte words instead of one request per tile, and a lane holds a piece's place in ONE register */
+__global__ __launch_bounds__(256) void k_rj_transpose_offs(const uint16_t *offs, uint32_t ntiles, uint32_t D, uint32_t tstride, uint32_t *offT)
 {
 	__shared__ uint16_t s_t[64][66];
 	const uint32_t t0 = blockIdx.x * 64u, d0 = blockIdx.y * 64u;
-	for (uint32_t i = threadIdx.x; i < 64u * 64u; i += 256u) {
-		const uint32_t tt = i >> 6, dd = i & 63u;
+	for (uint32_t i = threadIdx.x; i < 64u * 65u; i += 256u) {
+		const uint32_t tt = i / 65u, dd = i % 65u;
 		s_t[tt][dd] = (t0 + tt < ntiles && d0 + dd <= D) ? offs[(size_t)(t0 + tt) * (D + 8u) + d0 + dd] : (uint16_t)0;
 	}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < 64u * 64u; i += 256u) {
 		const uint32_t dd = i >> 6, tt = i & 63u;
-		if (d0 + dd <= D && t0 + tt < tstride)
-			offT[(size_t)(d0 + dd) * tstride + t0 + tt] = s_t[tt][dd];
+		if (d0 + dd < D && t0 + tt < tstride)
+			offT[(size_t)(d0 + dd) * tstride + t0 + tt] = (uint32_t)s_t[tt][dd] | ((uint32_t)s_t[tt][dd + 1u] << 16);
 	}
 }
 
@@ -263,13 +264,14 @@ struct rj_leaf_args {
 	/* the right tables' payload columns, one STREAM each: sorted tile by tile like the left table, { word, cell } per row */
 	uint32_t nstreams;
 	const rj_rec *recs[RJ_MAX_STREAMS];
-	const uint16_t *offT_r[RJ_MAX_STREAMS];
+	const uint32_t *offT_r[RJ_MAX_STREAMS];
 	uint32_t ntiles_r[RJ_MAX_STREAMS], tstride_r[RJ_MAX_STREAMS];
 	uint64_t *cells_al[RJ_MAX_STREAMS];	/* [ntiles * RJ_STRIDE] each: cells_al[s][i] = stream s's cell of the left row that words_l[i] names */
 	const uint32_t *words_l;
-	const uint16_t *offT_l;
+	const uint32_t *offT_l;
 	uint32_t ntiles, tstride, dbits, sbits /* key values per digit: 2^sbits <= 2^14 */;
 	uint32_t ablate;	/* measurement only (MDB_RJ_ABLATE): 1 no build, 2 no probe, 4 no cell stores, 8 no right cells read */
+	unsigned long long *trace;	/* measurement only (MDB_RJ_TRACE): workgroup 8's wave 0 leaves wall_clock64() stamps at its phase boundaries */
 	unsigned long long *joined;	/* += (left row, stream) pairs served: nstreams x the left rows when every row found its partner in every table */
 	uint32_t *status;
 };
@@ -292,7 +294,8 @@ __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
  * `use(unit, i)` for each of them; words beyond a piece's first LPP go through `slow(i)` (load and use in one), rarely.
  * All lanes of the wave call it together. */
 template <int LPP, int UNITS, typename FL, typename FU, typename FS, typename FD>
-__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, FD done /* after the `use`s of a batch */)
+__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, FD done /* after the `use`s of a batch */,
+					    bool skip_slow = false /* measurement only */)
 {
 	constexpr int RJ_G = LPP >= 32 ? 1 : 32 / LPP;	/* tile groups per sweep: 32 (64) pieces' steps per lane and sweep */
 	static_assert(LPP >= 8 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
@@ -301,18 +304,16 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 	 * HERE, per call; hoisted out of the caller's loop for all its calls at once it costs two dozen registers and the loads' answers spill) */
 	asm volatile("" : "+v"(lane));
 	const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
+	const uint32_t *const o0 = offT + (size_t)d * tstride;
+#pragma unroll 1
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
 		uint32_t sg[RJ_G], lg[RJ_G];
 #pragma unroll
 		for (int g = 0; g < RJ_G; g++) {
 			const uint32_t t = t0 + (uint32_t)g * nwaves * 64u + lane;	/* (the rows are padded to a multiple of 64 tiles: zeros) */
-			sg[g] = 0;
-			lg[g] = 0;
-			if (t < tstride) {
-				sg[g] = o0[t];
-				lg[g] = (uint32_t)o1[t] - sg[g];
-			}
+			const uint32_t se = t < tstride ? o0[t] : 0u;
+			sg[g] = se & 0xFFFFu;
+			lg[g] = (se >> 16) - sg[g];
 		}
 		uint32_t longest = 0;
 #pragma unroll
@@ -336,7 +337,7 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 					use(u, idx[u]);
 			done();
 		}
-		if (__any(longest > (uint32_t)LPP)) {		/* pieces longer than LPP words: their rest, one step at a time */
+		if (!skip_slow && __any(longest > (uint32_t)LPP)) {		/* pieces longer than LPP words: their rest, one step at a time */
 #pragma unroll 1
 			for (int g = 0; g < RJ_G; g++)
 #pragma unroll 1
@@ -353,21 +354,21 @@ __device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstri
 }
 
 template <int LPP, int UNITS, typename FL, typename FU, typename FS>
-__device__ static inline void rj_for_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow)
+__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, bool skip_slow = false)
 {
-	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, slow, [] {});
+	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, slow, [] {}, skip_slow);
 }
 
 /* The same for pieces of 32 words and more (windows of up to 2^24 values: 1024 digits and fewer): the whole wave walks one piece after
  * the other, 64 x UNITS words of it in flight (LPP = 64 selects it) */
 template <int UNITS, typename FL, typename FU>
-__device__ static inline void rj_for_long_pieces(const uint16_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use)
+__device__ static inline void rj_for_long_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use)
 {
 	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-	const uint16_t *const o0 = offT + (size_t)d * tstride, *const o1 = o0 + tstride;
+	const uint32_t *const o0 = offT + (size_t)d * tstride;
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u) {
 		const uint32_t t = t0 + lane;		/* (the rows are padded to a multiple of 64 tiles: zeros) */
-		const uint32_t s = o0[t], len = (uint32_t)o1[t] - s;
+		const uint32_t se = o0[t], s = se & 0xFFFFu, len = (se >> 16) - s;
 		for (int j = 0; j < 64; j++) {
 			const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)s, j), pl = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
 			const uint32_t base = (t0 + (uint32_t)j) * RJ_STRIDE + ps;
@@ -385,6 +386,13 @@ __device__ static inline void rj_for_long_pieces(const uint16_t *offT, uint32_t 
 	}
 }
 
+/* a barrier that waits for the wave's LDS operations only: the leaf's phases hand each other LDS contents, never global memory - the
+ * cell stores stay in flight across it (__syncthreads() waits for every outstanding memory operation) */
+__device__ static inline void rj_barrier(void)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int LPP, bool LONG>
 __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 {
@@ -392,26 +400,45 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 	uint32_t *const s_occ = reinterpret_cast<uint32_t *>(rj_cell + (1u << a.sbits));	/* 2^sbits bits (at least one word) */
 	__shared__ unsigned long long s_red[RJ_LEAF_THREADS / 64];
 	__shared__ uint32_t s_dup;
-	const uint32_t D = 1u << a.dbits, d = rj_digit_of_block(blockIdx.x, D);
-	unsigned long long pairs = 0;
+	/* blockIdx -> digits: workgroups are dealt to the 8 XCDs round-robin; XCD x walks the digits [x * D / 8, (x + 1) * D / 8) in order, its
+	 * `per` workgroups taking consecutive ones - the digits that share a line of a tile's words / cells are neighbours in time on ONE L2.
+	 * A workgroup stays and takes its XCD's next digit (round 6: a workgroup's launch - 16 waves, 130 KiB of LDS that the one before must
+	 * have given back - is not paid 32 times per CU) */
+	const uint32_t D = 1u << a.dbits, xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
+	uint32_t pairs = 0;	/* (a thread serves fewer than 2^32 rows) */
 	uint32_t miss = 0;
+	bool first = true;
 	if (threadIdx.x == 0)
 		s_dup = 0u;
+	constexpr int LP = LPP == 64 ? 32 : LPP;	/* (lanes per piece of the piece walker; LPP 64: the build walks whole-wave pieces) */
+	uint32_t tr_n = 0;
+	const bool tracing = a.trace && blockIdx.x == 8u && threadIdx.x == 0;
+#define RJ_STAMP()                                              \
+	do {                                                    \
+		if (tracing && tr_n < 60u)                      \
+			a.trace[tr_n++] = wall_clock64();       \
+	} while (0)
+#pragma unroll 1
+	for (uint32_t dl = blockIdx.x >> 3; dl < (D >> 3); dl += per) {
+	const uint32_t d = xcd * (D >> 3) + dl;
 	/* one round per stream: the digit's cells of that right column into the table, then the digit's left rows looked up (a second
 	 * stream's round finds the left words and offsets of the first one in its XCD's L2) */
 #pragma unroll 1
 	for (uint32_t s = 0; s < a.nstreams; s++) {		/* (uniform) */
-		if (s)
-			__syncthreads();	/* (the last round's lookups are done) */
+		if (!first)
+			rj_barrier();	/* (the last round's lookups are done) */
+		first = false;
+		RJ_STAMP();	/* 0: round begins */
 		for (uint32_t w = threadIdx.x; w < ((1u << a.sbits) + 31u) / 32u; w += blockDim.x)
 			s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
-		__syncthreads();
+		rj_barrier();
+		RJ_STAMP();	/* 1: table cleared */
 		/* build: the digit's right rows - their cells dropped at their slots */
 		{
 			bool dup = false;
 			if (!(a.ablate & 1u)) {
 				constexpr int UB = 8;
-				rj_rec rv[UB];
+				rj_rec rv[UB] = {};	/* (defined here on every path: not carried around the loops as "whatever they held") */
 				const rj_rec *const recs = a.recs[s];
 				auto put = [&](const rj_rec &r) {
 					const uint32_t slot = r.word >> RJ_TILE_BITS;
@@ -424,22 +451,23 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 				if (LPP == 64)
 					rj_for_long_pieces<UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us);
 				else
-					rj_for_pieces<(LPP == 64 ? 32 : LPP), UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us,
-										  [&](uint32_t idx) { put(recs[idx]); });
+					rj_for_pieces<LP, UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, [&](uint32_t idx) { put(recs[idx]); }, (a.ablate & 16u) != 0);
 			}
 			if (dup)
 				s_dup = 1u;
 		}
-		__syncthreads();
+		RJ_STAMP();	/* 2: this wave's share of the build done */
+		rj_barrier();
+		RJ_STAMP();	/* 3: every wave's */
 		if (s_dup) {	/* a right key occurs twice */
 			if (threadIdx.x == 0)
 				mdb_raise(a.status, 32u);
-			return;
+			return;		/* (every thread reads the same flag: the workgroup leaves together) */
 		}
 		/* probe: every left row of the digit picks its partner's cell up and leaves it at its word's place */
 		{
 			constexpr int UP = 16;
-			uint32_t w[UP];
+			uint32_t w[UP] = {};
 			uint64_t *const cells_al = a.cells_al[s];
 			auto take = [&](uint32_t word, uint32_t idx) {
 				const uint32_t slot = word >> RJ_TILE_BITS;
@@ -461,17 +489,21 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			if (LONG)
 				rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
 			else
-				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); });
+				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); }, (a.ablate & 16u) != 0);
 		}
+		RJ_STAMP();	/* 4: this wave's share of the probe done */
 	}
+	}
+#undef RJ_STAMP
 	if (miss)
 		mdb_raise(a.status, 4u);	/* a left row without partner */
+	unsigned long long wpairs = pairs;
 #pragma unroll
 	for (int o = 32; o; o >>= 1)
-		pairs += __shfl_down(pairs, o, MDB_WAVE);
+		wpairs += __shfl_down(wpairs, o, MDB_WAVE);
 	if (mdb_lane() == 0)
-		s_red[threadIdx.x >> 6] = pairs;
-	__syncthreads();
+		s_red[threadIdx.x >> 6] = wpairs;
+	rj_barrier();
 	if (threadIdx.x == 0) {
 		unsigned long long t = 0;
 		for (uint32_t w = 0; w < (blockDim.x >> 6); w++)
@@ -580,13 +612,13 @@ bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *
 /* (+ 64: a 16-byte load may start at a block's last word or cell) */
 static size_t rj_left_arena_bytes(uint64_t n_l, size_t ostride, int streams)
 {
-	return mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) +
+	return mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 4 + 64) + 3 * mdb_align_up((rj_tiles(n_l) + 64) * ostride * 2) +
 	       (size_t)streams * mdb_align_up(rj_tiles(n_l) * RJ_STRIDE * 8 + 64);
 }
 
 static size_t rj_right_arena_bytes(uint64_t n_r, size_t ostride, int npay)
 {
-	return 2 * mdb_align_up((rj_tiles(n_r) + 64) * ostride * 2) + (size_t)npay * mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 12 + 64);
+	return 3 * mdb_align_up((rj_tiles(n_r) + 64) * ostride * 2) + (size_t)npay * mdb_align_up(rj_tiles(n_r) * RJ_STRIDE * 12 + 64);
 }
 
 size_t mdb_rowjoin_arena_bytes(uint64_t n_l, uint64_t n_r, uint32_t kbits, int npay)
@@ -607,14 +639,14 @@ size_t mdb_rowjoin_arena_bytes_multi(uint64_t n_l, const struct mdb_rowjoin_righ
 	return need + rj_left_arena_bytes(n_l, ostride, streams);
 }
 
-/* the tile sort of one table + its offsets transposed: *offT_out = [D + 1][*tstride_out] */
+/* the tile sort of one table + its offsets transposed: *offT_out = [D][*tstride_out] (start | end << 16) */
 template <bool CELLS>
-static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *name, uint16_t **offT_out, uint32_t *tstride_out)
+static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *name, uint32_t **offT_out, uint32_t *tstride_out)
 {
 	const uint32_t D = 1u << sa.dbits;
 	const size_t lds = (size_t)(D >> 1) * 4 + (size_t)RJ_TILE * 4;
 	const uint32_t nfull = (uint32_t)(sa.n / RJ_TILE), ntiles = (uint32_t)rj_tiles(sa.n), tstride = (ntiles + 63u) & ~63u;
-	uint16_t *offT = (uint16_t *)mdb_arena_take(ctx, (size_t)(D + 1u) * tstride * 2);
+	uint32_t *offT = (uint32_t *)mdb_arena_take(ctx, (size_t)D * tstride * 4);
 	if (!offT)
 		return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
 	if (nfull) {
@@ -625,7 +657,7 @@ static int rj_sort_table(mdb_dev_ctx *ctx, const rj_sort_args &sa, const char *n
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_tile_sort<false, CELLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		MDB_LAUNCH_LDS(ctx, name, (k_rj_tile_sort<false, CELLS>), 1u, RJ_THREADS, lds, sa, nfull);
 	}
-	MDB_LAUNCH(ctx, "rowjoin_offsets", k_rj_transpose_offs, dim3(tstride / 64u, (D + 64u) / 64u), 256, sa.offs, ntiles, D, tstride, offT);
+	MDB_LAUNCH(ctx, "rowjoin_offsets", k_rj_transpose_offs, dim3(tstride / 64u, (D + 63u) / 64u), 256, sa.offs, ntiles, D, tstride, offT);
 	*offT_out = offT;
 	*tstride_out = tstride;
 	return MIDORIDB_OK;
@@ -667,7 +699,7 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 		sa.dbits = dbits;
 		sa.npay = (uint32_t)rt[t].npay;
 		sa.status = ctx->d_status;
-		uint16_t *offT_r = NULL;
+		uint32_t *offT_r = NULL;
 		uint32_t tstride_r = 0;
 		const int rc = rj_sort_table<true>(ctx, sa, "rowjoin_tile_sort_r", &offT_r, &tstride_r);
 		if (rc)
@@ -691,7 +723,7 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 			return mdb_set_err(ctx, -MIDORIDB_INTERNAL, "row-order join: %s", ctx->err);
 		pa.cells_al[s] = la.cells_al[s];
 	}
-	uint16_t *offT_l = NULL;
+	uint32_t *offT_l = NULL;
 	uint32_t tstride_l = 0;
 	rj_sort_args sl;
 	memset(&sl, 0, sizeof(sl));
@@ -707,15 +739,23 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 	if (rc)
 		return rc;
 	const uint32_t sbits = kbits - dbits;
-	const size_t lds_leaf = ((size_t)8 << sbits) + ((((size_t)1 << sbits) + 31) / 32) * 4;
+	const uint32_t leaf_threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
+	const size_t lds_leaf = ((size_t)8 << sbits) + ((((size_t)1 << sbits) + 31) / 32) * 4;	/* cells, occupancy bits */
 	const size_t lds_place = (size_t)(RJ_TILE / 2) * 8;
 	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
 	/* lanes per piece = twice the average piece (32 768 rows of a tile over D digits); fewer than 1024 digits (windows below 2^18 values):
 	 * the whole wave walks one piece after the other */
 	/* workgroups of the leaf: as many threads as the table's LDS leaves room for several of on a CU (a digit is a chain of dependent
 	 * round trips - offsets, words, cells -: what hides them is another digit on the same CU) */
-	const uint32_t leaf_threads = sbits >= 14u ? 1024u : sbits == 13u ? 512u : 256u;
 	const int lpp = dbits >= 13 ? 8 : dbits == 12 ? 16 : dbits == 11 ? 32 : dbits == 10 ? 64 : 0;
+	/* as many workgroups as the device holds at a time (a multiple of 8: the XCDs), each walking its share of its XCD's digits */
+	uint32_t leaf_grid = D;
+	if (!(mdb_knob("MDB_RJ_PERSIST") && mdb_knob("MDB_RJ_PERSIST")[0] == '0')) {
+		const uint32_t per_cu = (uint32_t)(((size_t)160 << 10) / (lds_leaf + 1024)), by_threads = 2048u / leaf_threads;
+		const uint32_t held = ((uint32_t)ctx->num_cus * (per_cu < by_threads ? (per_cu ? per_cu : 1u) : by_threads)) & ~7u;
+		if (held >= 8u && held < D)
+			leaf_grid = held;
+	}
 	la.words_l = words;
 	la.offT_l = offT_l;
 	la.ntiles = ntiles;
@@ -725,10 +765,15 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 	la.ablate = mdb_knob("MDB_RJ_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_RJ_ABLATE")) : 0u;
 	la.joined = (unsigned long long *)(ctx->d_status + 2);
 	la.status = ctx->d_status;
+	if (mdb_knob("MDB_RJ_TRACE")) {
+		la.trace = (unsigned long long *)mdb_arena_take(ctx, 64 * 8);
+		if (la.trace)
+			MDB_HIP(ctx, hipMemsetAsync(la.trace, 0, 64 * 8, ctx->stream));
+	}
 #define RJ_LAUNCH_LEAF(L, LONG)                                                                                                                   \
 	do {                                                                                                                                      \
 		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rj_leaf<L, LONG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf)); \
-		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<L, LONG>), D, leaf_threads, lds_leaf, la);                                            \
+		MDB_LAUNCH_LDS(ctx, "rowjoin_leaf", (k_rj_leaf<L, LONG>), leaf_grid, leaf_threads, lds_leaf, la);                                    \
 	} while (0)
 	if (lpp == 8)
 		RJ_LAUNCH_LEAF(8, false);
@@ -741,6 +786,15 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 	else
 		RJ_LAUNCH_LEAF(64, true);
 #undef RJ_LAUNCH_LEAF
+	if (la.trace) {		/* measurement only */
+		unsigned long long h[64];
+		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MDB_HIP(ctx, hipMemcpy(h, la.trace, sizeof(h), hipMemcpyDeviceToHost));
+		fprintf(stderr, "rowjoin_leaf trace (workgroup 8, wave 0; 10 ns ticks since the first stamp; 0 round begins, 1 table cleared, 2 own build done, 3 all built, 4 own probe done):\n");
+		for (int i = 0; i < 60 && h[i]; i++)
+			fprintf(stderr, "%s%llu", i % 5 ? " " : i ? "\n  " : "  ", h[i] - h[0]);
+		fprintf(stderr, "\n");
+	}
 	pa.words_l = words;
 	pa.ncols = la.nstreams;
 	pa.n = n_l;
@@ -776,7 +830,7 @@ int mdb_rowjoin_run(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l, const
  * reads 12 bytes per row. */
 struct rg_group_args {
 	const uint32_t *words;
-	const uint16_t *offT;
+	const uint32_t *offT;
 	uint32_t ntiles, tstride, dbits, sbits;
 	uint32_t row_bits;		/* a record = first row id << (64 - row_bits) | COUNT */
 	unsigned long long *rg_rec;	/* ranged emit (NULL: the list): region r of rg_cap records at rg_rec + r * rg_cap, its fill in rg_cnt[r] */
@@ -1055,7 +1109,7 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	uint32_t rg_n = 0;
 	const bool ranged = order_ranges_apply(n, row_bits, most < ((uint64_t)1 << 23) ? most : ((uint64_t)1 << 22), &rg_n) && values <= ((uint64_t)1 << 23) &&
 			    !(mdb_knob("MDB_ORDER_RANGES") && mdb_knob("MDB_ORDER_RANGES")[0] == '0');
-	size_t need = mdb_align_up((size_t)ntiles * RJ_STRIDE * 4 + 64) + 2 * mdb_align_up(((size_t)ntiles + 64) * ostride * 2) + mdb_align_up(most * 8) +
+	size_t need = mdb_align_up((size_t)ntiles * RJ_STRIDE * 4 + 64) + 3 * mdb_align_up(((size_t)ntiles + 64) * ostride * 2) + mdb_align_up(most * 8) +
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	if (ranged)
 		need += mdb_align_up((size_t)rg_n * ORDER_RANGE_CAP * 8) + mdb_align_up((size_t)rg_n * 4);
@@ -1081,7 +1135,7 @@ int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int
 	sa.words = words;
 	sa.offs = offs;
 	sa.status = ctx->d_status;
-	uint16_t *offT = NULL;
+	uint32_t *offT = NULL;
 	uint32_t tstride = 0;
 	rc = rj_sort_table<false>(ctx, sa, "group_tile_sort", &offT, &tstride);
 	if (rc)
