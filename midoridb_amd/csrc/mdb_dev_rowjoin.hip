@@ -307,13 +307,14 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 	const uint32_t *const o0 = offT + (size_t)d * tstride;
 #pragma unroll 1
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
-		uint32_t sg[RJ_G], lg[RJ_G];
+		/* a piece's start | end << 16 stays ONE word until the lanes that walk the piece have it: one crossbar read per step, not two - the
+		 * leaf is bound by what it asks of the LDS pipeline (~20 cycles per wave-instruction and CU, profiles/r06/lds_atomics.txt: crossbar
+		 * reads, table atomics, cell reads), round 6 */
+		uint32_t se[RJ_G];
 #pragma unroll
 		for (int g = 0; g < RJ_G; g++) {
 			const uint32_t t = t0 + (uint32_t)g * nwaves * 64u + lane;	/* (the rows are padded to a multiple of 64 tiles: zeros) */
-			const uint32_t se = t < tstride ? o0[t] : 0u;
-			sg[g] = se & 0xFFFFu;
-			lg[g] = (se >> 16) - sg[g];
+			se[g] = t < tstride ? o0[t] : 0u;
 		}
 		uint32_t longest = 0;
 #pragma unroll
@@ -324,7 +325,7 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 			for (int u = 0; u < UNITS; u++) {
 				const int g = (u0 + u) / LPP, sb = (u0 + u) % LPP;
 				const int src = sb * (64 / LPP) + (int)(lane / LPP);
-				const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
+				const uint32_t pse = (uint32_t)__shfl((int)se[g], src, MDB_WAVE), ps = pse & 0xFFFFu, pl = (pse >> 16) - ps;
 				idx[u] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps + lane % LPP;
 				on[u] = lane % LPP < pl;
 				longest = pl > longest ? pl : longest;
@@ -343,7 +344,7 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 #pragma unroll 1
 				for (int sb = 0; sb < LPP; sb++) {
 					const int src = sb * (64 / LPP) + (int)(lane / LPP);
-					const uint32_t ps = (uint32_t)__shfl((int)sg[g], src, MDB_WAVE), pl = (uint32_t)__shfl((int)lg[g], src, MDB_WAVE);
+					const uint32_t pse = (uint32_t)__shfl((int)se[g], src, MDB_WAVE), ps = pse & 0xFFFFu, pl = (pse >> 16) - ps;
 					const uint32_t base = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps;
 					for (uint32_t k = LPP + lane % LPP; __any(k < pl); k += LPP)
 						if (k < pl)
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 	const uint32_t D = 1u << a.dbits, xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
 	uint32_t pairs = 0;	/* (a thread serves fewer than 2^32 rows) */
 	uint32_t miss = 0;
+	uint32_t unset = 0;	/* right rows put - occupancy bits seen set (summed over the workgroup's threads: the right rows whose key had been put before) */
 	bool first = true;
 	if (threadIdx.x == 0)
 		s_dup = 0u;
@@ -433,17 +435,18 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			s_occ[w] = (a.ablate & 1u) ? 0xFFFFFFFFu : 0u;
 		rj_barrier();
 		RJ_STAMP();	/* 1: table cleared */
-		/* build: the digit's right rows - their cells dropped at their slots */
+		/* build: the digit's right rows - their cells dropped at their slots.  A right key twice: two rows, one bit - the bits set are
+		 * counted against the rows put once the table stands (no atomic that has to come back with the old word), the difference kept
+		 * until the workgroup leaves: what a call with such a table wrote is not used */
 		{
-			bool dup = false;
 			if (!(a.ablate & 1u)) {
 				constexpr int UB = 8;
 				rj_rec rv[UB] = {};	/* (defined here on every path: not carried around the loops as "whatever they held") */
 				const rj_rec *const recs = a.recs[s];
 				auto put = [&](const rj_rec &r) {
 					const uint32_t slot = r.word >> RJ_TILE_BITS;
-					const uint32_t old = atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
-					dup = dup || (old & (1u << (slot & 31u)));
+					atomicOr(&s_occ[slot >> 5], 1u << (slot & 31u));
+					unset++;
 					rj_cell[slot] = (a.ablate & 8u) ? 0ull : ((uint64_t)r.hi << 32 | r.lo);
 				};
 				auto ld = [&](int u, uint32_t idx) { rv[u] = recs[idx]; };
@@ -453,17 +456,12 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 				else
 					rj_for_pieces<LP, UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, [&](uint32_t idx) { put(recs[idx]); }, (a.ablate & 16u) != 0);
 			}
-			if (dup)
-				s_dup = 1u;
 		}
 		RJ_STAMP();	/* 2: this wave's share of the build done */
 		rj_barrier();
 		RJ_STAMP();	/* 3: every wave's */
-		if (s_dup) {	/* a right key occurs twice */
-			if (threadIdx.x == 0)
-				mdb_raise(a.status, 32u);
-			return;		/* (every thread reads the same flag: the workgroup leaves together) */
-		}
+		for (uint32_t w = threadIdx.x; w < ((1u << a.sbits) + 31u) / 32u && !(a.ablate & 1u); w += blockDim.x)
+			unset -= (uint32_t)__popc(s_occ[w]);
 		/* probe: every left row of the digit picks its partner's cell up and leaves it at its word's place */
 		{
 			constexpr int UP = 16;
@@ -497,6 +495,13 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 #undef RJ_STAMP
 	if (miss)
 		mdb_raise(a.status, 4u);	/* a left row without partner */
+	{
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			unset += (uint32_t)__shfl_down((int)unset, o, MDB_WAVE);
+		if (mdb_lane() == 0 && unset)
+			atomicAdd(&s_dup, unset);
+	}
 	unsigned long long wpairs = pairs;
 #pragma unroll
 	for (int o = 32; o; o >>= 1)
@@ -510,6 +515,8 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			t += s_red[w];
 		if (t)
 			atomicAdd(a.joined, t);
+		if (s_dup)	/* a right key occurs twice */
+			mdb_raise(a.status, 32u);
 	}
 }
 
