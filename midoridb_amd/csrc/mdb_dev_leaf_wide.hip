@@ -525,7 +525,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			const uint64_t bal = __ballot(my_last != 0u), before = bal & mdb_lanemask_lt();
 			uint32_t cur = (uint32_t)__shfl((int)my_last, before ? 63 - __clzll((long long)before) : 0, MDB_WAVE);
 			const uint32_t p = it & 1u;
-			const uint32_t wave_last = (uint32_t)__shfl((int)my_last, bal ? 63 - __clzll((long long)bal) : 0, MDB_WAVE);
+			/* (a lane every lane of the wave names alike: read through a scalar register, not through the LDS crossbar - the kernel is bound by
+			 * what it asks of the LDS pipeline, round 6) */
+			const uint32_t wave_last = (uint32_t)__builtin_amdgcn_readlane((int)my_last, bal ? 63 - __clzll((long long)bal) : 0);
 			if (lane == 0)
 				s_wlast[p][wave] = bal ? wave_last : 0u;
 			lw12_barrier();
@@ -533,8 +535,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				const uint32_t x = lane < LW_THREADS / 64 ? s_wlast[p][lane] : 0u;
 				const uint64_t ball = __ballot(x != 0u), earlier = ball & ((1ull << wave) - 1ull);
 				const uint32_t carried = s_carry[p];
-				const uint32_t from_waves = (uint32_t)__shfl((int)x, earlier ? 63 - __clzll((long long)earlier) : 0, MDB_WAVE);
-				const uint32_t round_last = (uint32_t)__shfl((int)x, ball ? 63 - __clzll((long long)ball) : 0, MDB_WAVE);
+				const uint32_t from_waves = (uint32_t)__builtin_amdgcn_readlane((int)x, earlier ? 63 - __clzll((long long)earlier) : 0);
+				const uint32_t round_last = (uint32_t)__builtin_amdgcn_readlane((int)x, ball ? 63 - __clzll((long long)ball) : 0);
 				if (!before)
 					cur = earlier ? from_waves : carried;
 				if (threadIdx.x == 0)

@@ -325,6 +325,8 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 			for (int u = 0; u < UNITS; u++) {
 				const int g = (u0 + u) / LPP, sb = (u0 + u) % LPP;
 				const int src = sb * (64 / LPP) + (int)(lane / LPP);
+				/* (measured, not kept: every lane reading its piece's offsets word itself - 8 lanes one address, L1 hits - instead of this
+				 * crossbar read: 1.40 -> 1.82 ms per stream; the kernel is short of vector memory instructions before it is short of LDS ones) */
 				const uint32_t pse = (uint32_t)__shfl((int)se[g], src, MDB_WAVE), ps = pse & 0xFFFFu, pl = (pse >> 16) - ps;
 				idx[u] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps + lane % LPP;
 				on[u] = lane % LPP < pl;
@@ -589,8 +591,12 @@ static size_t rj_tiles(uint64_t n) { return (size_t)((n + RJ_TILE - 1) / RJ_TILE
  * small tables keep several leaf workgroups on a CU), at least 2^8 key values per digit, never fewer than 8 digits (one per XCD) */
 uint32_t mdb_rowjoin_dbits(uint32_t kbits)
 {
-	const uint32_t d = kbits > 8u + 3u ? kbits - 8u : 3u;
-	return d > RJ_MAX_DBITS ? RJ_MAX_DBITS : d;
+	uint32_t d = kbits > 8u + 3u ? kbits - 8u : 3u;
+	d = d > RJ_MAX_DBITS ? RJ_MAX_DBITS : d;
+	const char *knob = mdb_knob("MDB_RJ_DBITS");	/* (measurement: fewer digits, longer pieces - never fewer than the leaf's table allows) */
+	if (knob && atoi(knob) >= 3 && (uint32_t)atoi(knob) < d && kbits - (uint32_t)atoi(knob) <= RJ_SLOT_BITS)
+		d = (uint32_t)atoi(knob);
+	return d;
 }
 
 bool mdb_rowjoin_serves(uint64_t n_l, uint64_t n_r, uint32_t kbits, const void *keys_l, const void *null_l, const void *keys_r, const void *null_r,
