@@ -137,6 +137,10 @@ const uint64_t *query_column_nulls_device(struct result_set *res, int col_idx);
  * MDB_ORDER_FIRST: 0.56 instead of 0.72 ms for the README query at 10^8 rows, 1.4 instead of 2.6 ms with unique keys).
  * SELECT COUNT(*) over a join, whose result has no order to keep, always runs that way. */
 int mdb_database_groups_any_order(struct database *db, int on);
+/* Join elimination (round 6): tables of this database's SELECT statements so far that were NOT joined at all, because the catalog's measured
+ * statistics said that every row of the other side finds exactly one partner in them (their key column holds no value twice, no NULL, and every
+ * value of its range, which covers the other side's) and the statement read nothing of them but that key.  MDB_JOIN_ELIMINATION=0: never. */
+unsigned long long mdb_database_joins_eliminated(struct database *db);
 
 /* mdb_table_generate() for one shard of a table spread over several processes: this process holds rows
  * [first_index, first_index + n) of a table of `domain` rows.  INTEGER column c = perm_{seed+c}(i) mod modulus[c] as above;

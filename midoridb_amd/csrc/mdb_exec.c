@@ -382,6 +382,53 @@ static int payload_columns(struct exec *x, int t, int key_col, int *pc)
 	return np;
 }
 
+/* Join elimination (round 6): table t joined on `stream key = its own column kr`, when the CATALOG says that every row of the
+ * stream finds exactly one partner in it - kr holds no value twice (MDB_COL_DISTINCT: measured at ingest, followed through appends, looked
+ * at again after UPDATE / DELETE), no NULL, and as many rows as its range has values: EVERY value of [min, max]; the stream's key column
+ * has no NULL and its range lies inside - and the statement reads nothing of t but that key: the joined rows ARE the stream's rows, t's key
+ * column in them IS the stream's key column.  The reference runs its nested loop over B for every row of A
+ * (/root/reference/src/engine/executor_select.c:1076-1149) to find the same; here the table is not touched at all.  The statistics are the
+ * store's own invariants (ranges are never narrower than the data, the distinct flag is never set on a column that holds a value twice):
+ * a range that went stale wider only makes the rule not apply.  MDB_JOIN_ELIMINATION=0: never. */
+static bool join_is_total_by_catalog(struct exec *x, const struct mdb_expr *kl, const struct mdb_expr *kr)
+{
+	const char *knob = mdb_knob("MDB_JOIN_ELIMINATION");
+	if (x->cat->dist || (knob && knob[0] == '0') || !kl || !kr || kl->kind != MDB_EX_FIELD || kr->kind != MDB_EX_FIELD || kl->tbl_idx < 0 || kr->tbl_idx < 0 ||
+	    kl->type == MDB_CT_DOUBLE || kr->type == MDB_CT_DOUBLE || kl->type != kr->type || x->orig_tab[kr->tbl_idx])
+		return false;
+	/* (the stream's key may be named through a table that was itself joined this way: its key column is an earlier table's) */
+	int lt = kl->tbl_idx, lc = kl->col_idx;
+	for (int hops = 0; x->orig_tab[lt] && hops < MDB_MAX_TABS; hops++) {
+		if (x->same_col[lt] != lc)
+			return false;
+		const int nt = x->same_as_tbl[lt];
+		lc = x->same_as_col[lt];
+		lt = nt;
+	}
+	if (x->orig_tab[lt])
+		return false;
+	struct mdb_table *tl = x->s->tabs[lt].t, *tr = x->s->tabs[kr->tbl_idx].t;
+	struct mdb_column *cl = &tl->cols[lc], *cr = &tr->cols[kr->col_idx];
+	const uint64_t r_rows = tr->device_only ? tr->dev_rows : tr->nrows;
+	int64_t llo, lhi, rlo, rhi;
+	if (!r_rows || cl->null_count || cr->null_count || mdb_col_range(x->cat, tl, cl, &llo, &lhi) != MIDORIDB_OK ||
+	    mdb_col_range(x->cat, tr, cr, &rlo, &rhi) != MIDORIDB_OK || rlo > rhi)
+		return false;
+	if ((uint64_t)rhi - (uint64_t)rlo + 1 != r_rows || (llo <= lhi && (llo < rlo || lhi > rhi)))
+		return false;
+	return mdb_col_distinct(x->cat, tr, cr);	/* (last: it may scan the column) */
+}
+
+/* ... and nothing but the key column of table t is read by the statement */
+static bool only_key_needed(const struct exec *x, int t, int key_col)
+{
+	const struct mdb_table *rt = x->s->tabs[t].t;
+	for (int c = 0; c < rt->ncols; c++)
+		if (x->need[t][c] && c != key_col)
+			return false;
+	return true;
+}
+
 /* SEVERAL tables joined to the stream on ONE key, each a primary-key table that every row of the stream finds exactly one partner in
  * (SELECT * FROM A JOIN B ON A.k = B.k JOIN C ON A.k = C.k - BASELINE configs[4]'s join-only form; the reference joins B, then C against the
  * materialised A x B: executor_select.c:1076-1232): table t and the tables behind it whose whole ON clause is `earlier key = own column`,
@@ -538,6 +585,20 @@ int join_next_table(struct exec *x, int t, const struct mdb_expr *const *pconj, 
 					key = i;
 				}
 			}
+		}
+	}
+	if (key >= 0 && nconj == 1 && !npconj && !x->cat->dist && x->n && only_key_needed(x, t, kr->col_idx) && join_is_total_by_catalog(x, kl, kr)) {
+		/* join elimination: the catalog says every row of the stream has exactly one partner, and only t's key is read */
+		const int64_t *vl;
+		const uint64_t *nl;
+		if ((rc = stream_column(x, kl, &vl, &nl)))
+			return rc;
+		if (!nl) {
+			x->same_col[t] = kr->col_idx;
+			x->same_as_tbl[t] = kl->tbl_idx;
+			x->same_as_col[t] = kl->col_idx;
+			x->joins_eliminated++;
+			return payload_shadow(x, t, kr->col_idx, vl, NULL, 0, NULL);
 		}
 	}
 	/* the new table's own WHERE conjuncts filter it before it is joined */
@@ -932,6 +993,16 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 	for (int i = 0; i < s->nsel; i++)
 		only_count = only_count && s->sel[i]->kind == MDB_EX_COUNT;
 	fused = s->ntabs <= PUSH_TABS ? fused_chain(s, fkeys, only_count) : -1;
+	if (fused >= 0 && !cat->dist && split_ok) {
+		/* join elimination: when the catalog says every right table of the chain is a complete primary key over the first table's key range,
+		 * the fused join + GROUP BY operator has nothing to find out - the general plan drops those joins (join_next_table) and groups the
+		 * first table's key column alone (the identity when that column holds no value twice) */
+		bool all = s->ntabs > 1;
+		for (int t = 1; t < s->ntabs && all; t++)
+			all = !ws.npush[t] && only_key_needed(&x, t, fkeys[t]->col_idx) && join_is_total_by_catalog(&x, fkeys[0], fkeys[t]);
+		if (all)
+			fused = -1;
+	}
 	/* the join of two key columns, nothing else selected: in the reference's order it is tried as a primary-key join first (the keys with
 	 * partners in the left table's row order; large tables only: the attempt runs the ordered join + GROUP BY operator), and left to the
 	 * materialising join below when a key has several rows on a side */
@@ -1679,6 +1750,7 @@ grouped:
 	res = NULL;
 	rc = MIDORIDB_OK;
 out:
+	cat->joins_eliminated += (uint64_t)x.joins_eliminated;
 	shard_cleanup(&x);
 	free_all(&x);
 	mdb_result_free(res);

@@ -51,6 +51,7 @@ struct exec {
 	bool dict_synced;	/* the ranks' string dictionaries were made known to each other for this statement (shard_dict_sync) */
 	bool need[MDB_MAX_TABS][MDB_MAX_COLS];
 	const struct where_split *ws;		/* the WHERE conjuncts pushed down to single tables (general plan; NULL: none are) */
+	int joins_eliminated;			/* tables that were not joined at all: the catalog said every row of the stream has exactly one partner (join_next_table) */
 	bool joined_ahead[MDB_MAX_TABS];	/* table t was joined together with an earlier table on the same key (join_with_payload_multi) */
 };
 

@@ -123,6 +123,7 @@ struct mdb_catalog {
 	uint64_t l2g_cap, g2l_cap;
 	int64_t *d_l2g, *d_g2l;
 	uint64_t d_l2g_n, d_g2l_n;	/* entries the device copies hold */
+	uint64_t joins_eliminated;	/* tables of SELECT statements that were not joined at all: the catalog said every row has exactly one partner (mdb_exec.c) */
 	bool groups_any_order;		/* mdb_database_groups_any_order(): GROUP BY over a join need not keep first-occurrence order */
 	bool results_on_device;		/* mdb_database_results_on_device(): SELECT results stay in HBM until a consumer reads them */
 };

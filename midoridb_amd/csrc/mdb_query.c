@@ -304,6 +304,12 @@ int mdb_database_groups_any_order(struct database *db, int on)
 	return MIDORIDB_OK;
 }
 
+unsigned long long mdb_database_joins_eliminated(struct database *db)
+{
+	struct mdb_catalog *cat = db ? db->tables : NULL;
+	return cat ? cat->joins_eliminated : 0ull;
+}
+
 double query_exec_ms(struct result_set *res)
 {
 	return res && res->table ? ((struct mdb_result *)res->table)->exec_ms : 0.0;

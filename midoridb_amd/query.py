@@ -41,7 +41,7 @@ QUERY_SYMBOLS = [
     "mdb_query_execute_rpn", "query_column_double", "query_column_is_null", "query_column_count", "query_column_name",
     "query_column_type", "query_row_count", "query_column_data", "query_exec_ms", "query_joined_rows",
     "mdb_table_append_columns", "mdb_table_generate", "mdb_sql_to_rpn", "query_column_text", "mdb_result_text_at",
-    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "mdb_database_groups_any_order", "query_column_data_device", "query_column_nulls_device", "mdb_table_generate_shard",
+    "mdb_database_device", "mdb_database_set_dist", "mdb_database_results_on_device", "mdb_database_groups_any_order", "mdb_database_joins_eliminated", "query_column_data_device", "query_column_nulls_device", "mdb_table_generate_shard",
 ]
 
 
@@ -97,6 +97,8 @@ def _bind(lib):
     lib.mdb_database_results_on_device.restype = c_int
     lib.mdb_database_groups_any_order.argtypes = [PDB, c_int]
     lib.mdb_database_groups_any_order.restype = c_int
+    lib.mdb_database_joins_eliminated.argtypes = [PDB]
+    lib.mdb_database_joins_eliminated.restype = ctypes.c_ulonglong
     lib.query_column_data_device.argtypes = [PRS, c_int]
     lib.query_column_data_device.restype = c_void_p
     lib.query_column_nulls_device.argtypes = [PRS, c_int]
@@ -174,6 +176,10 @@ class DB:
         """the database takes ownership of an mdb_dist* built for device_handle()"""
         if self.lib.mdb_database_set_dist(ctypes.byref(self.db), dist_handle) != 0:
             raise QueryError("mdb_database_set_dist failed")
+
+    def joins_eliminated(self):
+        """tables of this database's SELECT statements so far that the catalog's statistics made unnecessary to join (mdb_database_joins_eliminated)"""
+        return int(self.lib.mdb_database_joins_eliminated(ctypes.byref(self.db)))
 
     def results_on_device(self, on=True):
         """SELECT results stay in HBM until a consumer reads them (mdb_database_results_on_device)"""

@@ -1084,6 +1084,38 @@ def test_join_payload_multi_one_left_sort_serves_every_right_table(dev, case, mo
             assert np.array_equal(_np(g).view(np.int64), p[er].view(np.int64)), case
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_join_payload_multi_random_shapes(dev, seed, monkeypatch):
+    """mdb_dev_join_payload_multi over seeded random shapes - 1 to 4 right tables, 1 or 2 cells each (4 columns at most), windows of 2^15 ...
+    2^22 values anywhere in int64, left tables from a fraction of a tile to dozens of tiles, foreign keys or a permutation on the left:
+    every carried column equals payload[np_oracle.join_pairs], bit for bit"""
+    rng = np.random.default_rng(9000 + seed)
+    monkeypatch.setenv("MDB_ROWJOIN", "2")
+    bits = int(rng.integers(15, 23))
+    span = 1 << bits
+    base = int(rng.integers(-2**40, 2**40))
+    ntab = int(rng.integers(1, 5))
+    cells = [int(rng.integers(1, 3)) for _ in range(ntab)]
+    while sum(cells) > 4:
+        cells[int(np.argmax(cells))] -= 1
+    universe = rng.permutation(span).astype(np.int64)[: int(span * rng.uniform(0.5, 1.0))] + base
+    rights = []
+    for t in range(ntab):
+        kr = rng.permutation(universe)
+        pay = [rng.integers(-2**63, 2**63 - 1, len(kr), dtype=np.int64), rng.standard_normal(len(kr))][: cells[t]]
+        rights.append((kr, pay))
+    nleft = int(rng.integers(1000, 40 * 32768))
+    kl = universe[rng.integers(0, len(universe), nleft)] if seed % 2 else rng.permutation(universe)[: min(nleft, len(universe))]
+    got = dev.join_payload_multi(dev.to_dev(kl), [(dev.to_dev(kr), [dev.to_dev(p) for p in pay]) for kr, pay in rights], base, base + span - 1)
+    plan = dev.last_plan()
+    assert got is not None and plan["payload_form"] == 3 and plan["payload_tables"] == ntab, (seed, plan)
+    for (kr, pay), outs in zip(rights, got):
+        order = np.argsort(kr)
+        pos = order[np.searchsorted(kr[order], kl)]
+        for g, p in zip(outs, pay):
+            assert np.array_equal(_np(g).view(np.int64), p[pos].view(np.int64)), seed
+
+
 def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
     counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
