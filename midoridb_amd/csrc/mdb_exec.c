@@ -1013,7 +1013,14 @@ int mdb_exec_select(struct mdb_catalog *cat, struct mdb_select *s, struct mdb_re
 		const struct mdb_table *tl = s->tabs[kj[0]->tbl_idx].t, *tr = s->tabs[kj[1]->tbl_idx].t;
 		int served = 0;
 		int krc = 0;
-		if (tl->nrows + tr->nrows >= (1u << 21)) {
+		if (tl->nrows && !tl->cols[kj[0]->col_idx].d_nullbits && tl->cols[kj[0]->col_idx].d_data && join_is_total_by_catalog(&x, kj[0], kj[1])) {
+			/* join elimination: every row of the left table has exactly one partner (the catalog's statistics) - the joined rows' key column
+			 * IS the left table's key column, in its order, without a kernel */
+			keys_ordered = (int64_t *)tl->cols[kj[0]->col_idx].d_data;
+			keys_ordered_rows = tl->nrows;
+			served = 2;
+			x.joins_eliminated++;
+		} else if (tl->nrows + tr->nrows >= (1u << 21)) {
 			op_stats_begin(&x, kj[0], tl->cols[kj[0]->col_idx].d_data, kj[1], tr->cols[kj[1]->col_idx].d_data);
 			krc = mdb_dev_join_keys_ordered(x.dev, tl->cols[kj[0]->col_idx].d_data, tl->cols[kj[0]->col_idx].d_nullbits, tl->nrows,
 							 tr->cols[kj[1]->col_idx].d_data, tr->cols[kj[1]->col_idx].d_nullbits, tr->nrows, &keys_ordered,
