@@ -291,14 +291,14 @@ __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
  * its lane through the wave's crossbar (no LDS memory).  LPP = twice the average piece, so most pieces are done in one step.
  * The kernel is a chain of dependent memory round trips (offsets -> words -> LDS -> store), so what matters is how many loads a lane
  * has in flight: `load(unit, i)` is called for UNITS pieces' words first (it only ISSUES loads into the caller's registers), then
- * `use(unit, i)` for each of them; words beyond a piece's first LPP go through `slow(i)` (load and use in one), rarely.
+ * `use(unit, i)` for each of them; words beyond a piece's first LPP take the same two calls, tier by tier (below).
  * All lanes of the wave call it together. */
-template <int LPP, int UNITS, typename FL, typename FU, typename FS, typename FD>
-__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, FD done /* after the `use`s of a batch */,
-					    bool skip_slow = false /* measurement only */)
+template <int LPP, int UNITS, typename FL, typename FU, typename FD>
+__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FD done /* after the `use`s of a batch */,
+					    bool skip_slow = false /* measurement only: pieces are cut off after LPP words */)
 {
-	constexpr int RJ_G = LPP >= 32 ? 1 : 32 / LPP;	/* tile groups per sweep: 32 (64) pieces' steps per lane and sweep */
-	static_assert(LPP >= 8 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
+	constexpr int RJ_G = LPP >= 32 ? 1 : LPP == 16 ? 2 : 4;	/* tile groups per sweep: 16 (LPP 4), 32 or 64 pieces' steps per lane and sweep */
+	static_assert(LPP >= 4 && LPP <= 64 && (RJ_G * LPP) % UNITS == 0, "units per sweep");
 	uint32_t lane = mdb_lane();
 	/* (called once per stream and phase from a loop: what is derived from the lane - the crossbar's source lanes of every step - is derived
 	 * HERE, per call; hoisted out of the caller's loop for all its calls at once it costs two dozen registers and the loads' answers spill) */
@@ -340,26 +340,65 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 					use(u, idx[u]);
 			done();
 		}
-		if (!skip_slow && __any(longest > (uint32_t)LPP)) {		/* pieces longer than LPP words: their rest, one step at a time */
+		if (!skip_slow && __any(longest > (uint32_t)LPP)) {
+			/* pieces longer than LPP words (one in 50 at an average of LPP / 2, more than a third at an average of LPP: nearly every sweep
+			 * has some).  Tier by tier - words [tier x LPP, (tier + 1) x LPP) of the pieces that have them -, ALL tile groups together
+			 * (round 6): per group the owners of such pieces are a ballot; lane group q takes the q-th of them - found by clearing q bits of
+			 * the mask, no LDS -, one crossbar read for its offsets word, and the groups' loads go out before the first is used: a round trip
+			 * per 64 / LPP pieces and group where walking the 32 steps again, one dependent load at a time, cost a fifth of the leaf
+			 * (profiles/r06/rj_ablate.txt: 1.39 ms with, 1.08 without the long pieces; 1.24 with this) */
+			constexpr int NQ = 64 / LPP;
+			static_assert(RJ_G <= UNITS, "a load slot per tile group");
 #pragma unroll 1
-			for (int g = 0; g < RJ_G; g++)
-#pragma unroll 1
-				for (int sb = 0; sb < LPP; sb++) {
-					const int src = sb * (64 / LPP) + (int)(lane / LPP);
-					const uint32_t pse = (uint32_t)__shfl((int)se[g], src, MDB_WAVE), ps = pse & 0xFFFFu, pl = (pse >> 16) - ps;
-					const uint32_t base = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)src) * RJ_STRIDE + ps;
-					for (uint32_t k = LPP + lane % LPP; __any(k < pl); k += LPP)
-						if (k < pl)
-							slow(base + k);
+			for (uint32_t tier = 1; __any(tier * (uint32_t)LPP < longest); tier++) {
+				unsigned long long lm[RJ_G];
+				bool more = false;
+#pragma unroll
+				for (int g = 0; g < RJ_G; g++) {
+					lm[g] = __ballot((se[g] >> 16) - (se[g] & 0xFFFFu) > tier * (uint32_t)LPP);
+					more = more || lm[g] != 0ull;
 				}
+				if (!more)
+					break;
+#pragma unroll 1
+				while (more) {
+					uint32_t lidx[RJ_G];
+					bool lon[RJ_G];
+					more = false;
+#pragma unroll
+					for (int g = 0; g < RJ_G; g++) {
+						unsigned long long m = lm[g];
+#pragma unroll
+						for (int i = 0; i < NQ - 1; i++)
+							if ((int)(lane / LPP) > i)
+								m &= m - 1ull;
+						const int j = m ? __ffsll((long long)m) - 1 : 0;
+						const uint32_t pse = (uint32_t)__shfl((int)se[g], j, MDB_WAVE), ps = pse & 0xFFFFu, pl = (pse >> 16) - ps;
+						lidx[g] = (t0 + (uint32_t)g * nwaves * 64u + (uint32_t)j) * RJ_STRIDE + ps + tier * (uint32_t)LPP + lane % LPP;
+						lon[g] = m && tier * (uint32_t)LPP + lane % LPP < pl;
+						if (lon[g])
+							load(g, lidx[g]);
+						/* (the NQ pieces this pass took leave the mask) */
+#pragma unroll
+						for (int i = 0; i < NQ; i++)
+							lm[g] &= lm[g] - 1ull;
+						more = more || lm[g] != 0ull;
+					}
+#pragma unroll
+					for (int g = 0; g < RJ_G; g++)
+						if (lon[g])
+							use(g, lidx[g]);
+					done();
+				}
+			}
 		}
 	}
 }
 
-template <int LPP, int UNITS, typename FL, typename FU, typename FS>
-__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FS slow, bool skip_slow = false)
+template <int LPP, int UNITS, typename FL, typename FU>
+__device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, bool skip_slow = false)
 {
-	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, slow, [] {}, skip_slow);
+	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, [] {}, skip_slow);
 }
 
 /* The same for pieces of 32 words and more (windows of up to 2^24 values: 1024 digits and fewer): the whole wave walks one piece after
@@ -456,7 +495,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 				if (LPP == 64)
 					rj_for_long_pieces<UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us);
 				else
-					rj_for_pieces<LP, UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, [&](uint32_t idx) { put(recs[idx]); }, (a.ablate & 16u) != 0);
+					rj_for_pieces<LP, UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, (a.ablate & 16u) != 0);
 			}
 		}
 		RJ_STAMP();	/* 2: this wave's share of the build done */
@@ -489,7 +528,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			if (LONG)
 				rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
 			else
-				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, [&](uint32_t idx) { take(a.words_l[idx], idx); }, (a.ablate & 16u) != 0);
+				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, (a.ablate & 16u) != 0);
 		}
 		RJ_STAMP();	/* 4: this wave's share of the probe done */
 	}
@@ -902,13 +941,6 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf_dense(rg_grou
 		};
 		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
 				       [&](int u, uint32_t idx) { ask(u, w[u], idx); },
-				       [&](uint32_t idx) {
-					       const uint32_t word = a.words[idx], slot = word >> RJ_TILE_BITS,
-							      row = (idx / RJ_STRIDE) * RJ_TILE + (word & (RJ_TILE - 1u));
-					       const uint32_t prev = atomicMin(&s_first[slot], row);
-					       atomicAdd(&s_count[slot], 1u);
-					       settle(prev, row);
-				       },
 				       [&] {
 #pragma unroll
 					       for (int u = 0; u < UG; u++)
@@ -1005,7 +1037,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf(rg_group_args
 			atomicAdd(&s_count[slot], 1u);
 		};
 		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
-				       [&](int u, uint32_t idx) { take(w[u], idx); }, [&](uint32_t idx) { take(a.words[idx], idx); });
+				       [&](int u, uint32_t idx) { take(w[u], idx); });
 	}
 	__syncthreads();
 	if (a.rg_rec) {
