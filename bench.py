@@ -135,7 +135,7 @@ def survey_bytes(kernel, n, groups):
     return None
 
 
-def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instances=(), launches=1.0, left_kept=None):
+def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instances=(), launches=1.0, left_kept=None, keys_alias=False):
     """The kernel's OWN I/O per launch: what the launch must read once and write once given the words this design
     moves - `roofline.frac_kernel_io`, next to the SURVEY 8(d) figure of survey_bytes().  Kernel names are template instances, one
     table each; the scatter kernels' word sizes come from the instance that ran (scatter_word_bytes).
@@ -181,7 +181,10 @@ def algorithmic_bytes(kernel, n, groups, narrow, pruned=False, levels=2, instanc
         # ... the bit-per-row form: the same words in, one bit per left row touched (cleared where the row is no group's first), no record out
         "leaf_join_wide12_bits": 2 * n + 4.5 * kept + n / 8,
         "dense_count": n / 8,                       # the bits, counted per block of rows
-        "dense_expand": n / 8 + key + 20 * g,       # the bits and the left key column in, (first row, key, COUNT) per group out
+        # the bits and the left key column in, (first row, key, COUNT) per group out; MDB_KEYS_MAY_ALIAS and every left row a group: the key
+        # column is neither read nor written (the caller reads the left column itself), and this benchmark asks for no first-row column -
+        # COUNT per group out
+        "dense_expand": n / 8 + 8 * g if keys_alias else n / 8 + key + 20 * g,
         "dense_patch": 16,                          # the exceptions' COUNTs (a handful)
         "expand_keys": 16 * g + key,                # (key, COUNT) per group in, every key COUNT times out
         "shard_leaf_wide": 2 * (kept + n) + 16 * g, "shard_leaf": 4 * (kept + n) + 16 * g,
@@ -764,9 +767,11 @@ def main():
                 for k, v in prof.items()}
         left_kept = g_rank if (pruned or (use_dist and args.variant == "D")) else n     # left rows that survive the range test (one per group in D)
 
+        keys_alias = bool(dev.last_plan().get("keys_are_left_column")) if not use_dist else False
+
         def own_io(name):
             d = kern[name]
-            return algorithmic_bytes(name, n, g_rank, narrow, pruned, levels, d["rocprof_names"], d["launches_per_step"], left_kept)
+            return algorithmic_bytes(name, n, g_rank, narrow, pruned, levels, d["rocprof_names"], d["launches_per_step"], left_kept, keys_alias)
         for k, d in kern.items():   # per-kernel achieved rate on the bytes the kernel itself must move
             if d["ms_per_step"] > 0 and own_io(k) > 0:
                 d["kernel_io_GBs"] = own_io(k) * d["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9
