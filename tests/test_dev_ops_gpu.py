@@ -1116,6 +1116,49 @@ def test_join_payload_multi_random_shapes(dev, seed, monkeypatch):
             assert np.array_equal(_np(g).view(np.int64), p[pos].view(np.int64)), seed
 
 
+@pytest.mark.parametrize("persist", ["0", "1"])
+@pytest.mark.parametrize("shape", ["hot_key_on_the_left", "window_2e27", "right_table_smaller_than_a_tile", "nullable_right_key_column"])
+def test_join_payload_multi_leaf_grids_and_long_pieces(dev, shape, persist, monkeypatch):
+    """the row-order leaf both ways (workgroups that stay and walk their XCD's digits / one workgroup per digit: MDB_RJ_PERSIST) over what its piece
+    walker finds hardest: a key on 150 000 consecutive left rows (pieces of a whole tile: thousands of tiers), a window of 2^27 values (8192 digits,
+    pieces of a few words, most sweeps with a long piece), a right table of a fraction of a tile; and a right key column that comes with a NULL
+    bitmap is refused, not read"""
+    rng = np.random.default_rng(31 + len(shape))
+    monkeypatch.setenv("MDB_ROWJOIN", "2")
+    monkeypatch.setenv("MDB_RJ_PERSIST", persist)
+    if shape == "window_2e27":
+        span, nr, nl = 1 << 27, 3_000_000, 2_500_000
+    elif shape == "right_table_smaller_than_a_tile":
+        span, nr, nl = 1 << 16, 9_000, 400_000
+    else:
+        span, nr, nl = 1 << 20, 700_000, 1_000_000
+    base = 123_456_789
+    kr = rng.choice(span, nr, replace=False).astype(np.int64) + base
+    kr2 = rng.permutation(kr)
+    kl = kr[rng.integers(0, nr, nl)]
+    if shape == "hot_key_on_the_left":
+        kl[200_000:350_000] = kr[99]
+    pay1, pay2 = rng.integers(-2**62, 2**62, nr, dtype=np.int64), rng.standard_normal(nr)
+    rights = [(kr, [pay1]), (kr2, [pay2])]
+    if shape == "nullable_right_key_column":
+        arr = (D.PayloadRight * 1)()
+        d_kr, d_p = dev.to_dev(kr), dev.to_dev(pay1)
+        nb = dev.nullbits_dev(np.zeros(nr, dtype=bool))
+        out = torch.empty(nl, dtype=torch.int64, device=dev.device)
+        arr[0].keys, arr[0].nulls, arr[0].rows, arr[0].npay = d_kr.data_ptr(), nb.data_ptr(), nr, 1
+        arr[0].pay_in[0], arr[0].out[0] = d_p.data_ptr(), out.data_ptr()
+        d_kl = dev.to_dev(kl)
+        rc = dev.lib.mdb_dev_join_payload_multi(dev.h, d_kl.data_ptr(), None, nl, arr, 1, base, base + span - 1)
+        assert rc == 1
+        return
+    got = dev.join_payload_multi(dev.to_dev(kl), [(dev.to_dev(k), [dev.to_dev(p) for p in pay]) for k, pay in rights], base, base + span - 1)
+    assert got is not None and dev.last_plan()["payload_tables"] == 2
+    for (k, pay), outs in zip(rights, got):
+        order = np.argsort(k)
+        pos = order[np.searchsorted(k[order], kl)]
+        assert np.array_equal(_np(outs[0]).view(np.int64), pay[0][pos].view(np.int64)), (shape, persist)
+
+
 def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     """A COUNT(*) that does not fit beside its row id in a 64-bit group record (2^28 > n_l > 2^27 -> 28 id bits, so
     counts >= 2^36): flagged by the leaf kernel, the operator redoes the query with the dense ordering."""
