@@ -14,18 +14,22 @@
  *
  *   1. tile sort (k_rj_tile_sort): every tile of 32 768 consecutive left rows is sorted by key digit INSIDE ITS OWN BLOCK of the
  *      word array - words_l[tile * 32768 + p] = (slot inside the digit << 15 | row inside the tile) - plus the tile's digit
- *      offsets (u16).  Sequential reads, sequential writes, no global atomics, nothing that can overflow.
- *   2. leaf (k_rj_leaf): one workgroup per key digit of 2^14 key values: the right table's cells of the digit in an LDS table
- *      (direct-addressed by the slot bits: no stored keys, no probing; an occupancy bitmap sees duplicate right keys and left
- *      rows without partner), then the digit's piece of EVERY left tile - a few words each, found through the tile offsets - is
- *      looked up and the cell written at the SAME position of a cell array laid out like the word array (cells_al[tile * 32768 +
- *      p]): consecutive lanes take consecutive words of a piece, so a piece is one request each way, and adjacent digits -
- *      neighbours on the same XCD (blockIdx -> digit mapping below) - complete each other's lines in that XCD's L2.
- *   3. placement (k_rj_place): one workgroup per half tile reads the tile's words and cells (sequential), drops every cell at
- *      LDS[row inside the half tile] and writes the result column coalesced.
+ *      offsets (u16).  Sequential reads, sequential writes, no global atomics, nothing that can overflow.  A right table is sorted the
+ *      same way into 12-byte records { word, payload cell } - one record array per payload column (round 6): a (tile, digit) piece of a
+ *      right table is ONE request for the leaf.  The offsets are transposed and paired (start | end << 16 per digit and tile).
+ *   2. leaf (k_rj_leaf): workgroups that stay on their CU and walk their XCD's key digits of 2^14 key values; per digit one round per
+ *      (right table, payload column) stream - up to four: several primary-key tables joined on one key in ONE call,
+ *      mdb_dev_join_payload_multi -: the stream's cells of the digit in an LDS table (direct-addressed by the slot bits: no stored keys,
+ *      no probing; an occupancy bitmap sees duplicate right keys and left rows without partner), then the digit's piece of EVERY left
+ *      tile - a few words each, found through the offsets - is looked up and the cell written at the SAME position of a cell array laid
+ *      out like the word array (cells_al[s][tile * 32768 + p]): consecutive lanes take consecutive words of a piece, so a piece is one
+ *      request each way, and adjacent digits - neighbours on the same XCD - complete each other's lines in that XCD's L2.
+ *   3. placement (k_rj_place): one workgroup per half tile reads the tile's words once and, per carried column, its cells (sequential),
+ *      drops every cell at LDS[row inside the half tile] and writes the result column coalesced.
  *
- * Per joined row and cell: 8 B key + 4 B word + (2 + 4) B offsets/word re-read + 8 B cell written, read, and written again in
- * row order - all of it in whole lines.
+ * Per joined row and cell: 8 B key + 4 B word + 12 B record written and read + 4 B word re-read + 8 B cell written, read, and written
+ * again in row order - all of it in whole lines.  What bounds the leaf was measured in round 6 (profiles/r06/README.md section 7): the
+ * instructions it issues (vector memory and LDS), not requests, latency or the TLB.
  */
 #include "mdb_dev_join_internal.h"
 #include "mdb_dev_rowjoin.h"
