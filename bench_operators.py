@@ -131,6 +131,24 @@ def main():
         print(json.dumps({k: {kk: vv for kk, vv in d.items() if kk != "kernels_ms"} for k, d in res.items()}, indent=1))
         return
 
+    # ---- the row-order payload join at 10^8 x 10^8 rows (mdb_dev_rowjoin.hip; BASELINE configs[4]'s join-only shape at operator level): one right
+    #      table with one and two cells, and B and C in ONE call (mdb_dev_join_payload_multi: the left table's tiles sorted once)
+    ka, kb, kc = dev.gen_keys(n, 0, n, 42, 0), dev.gen_keys(n, 0, n, 43, 0), dev.gen_keys(n, 0, n, 44, 0)
+    pb, pc = kb * 3 + 1, kc * 5 - 2
+    for name, fn, cols in (("join_payload_1e8_one_cell", lambda: dev.join_payload(ka, None, kb, None, [pb])[0].numel(), 1),
+                           ("join_payload_1e8_two_cells", lambda: dev.join_payload(ka, None, kb, None, [pb, kb])[0].numel(), 2),
+                           ("join_payload_multi_1e8_two_tables", lambda: dev.join_payload_multi(ka, [(kb, [pb]), (kc, [pc])], 0, n - 1)[0][0].numel(), 2)):
+        ms, kern, j = timed(dev, fn, reps=3, warmup=1)
+        tables = 2 if "multi" in name else 1
+        algo = 8 * n + tables * 8 * n + cols * 8 * n + cols * 8 * j         # key columns and payload columns read once, the carried columns written
+        res[name] = {"rows_per_table": n, "joined_rows": j, "carried_columns": cols, "ms": ms, "joined_rows_per_s": j / (ms * 1e-3), "algorithmic_bytes": algo,
+                     "frac_of_peak": algo / (ms * 1e-3) / 1e9 / 8000.0, "kernels_ms": kern, "payload_tables": dev.last_plan()["payload_tables"],
+                     "note": "every left row has its one partner in every right table (verified on the device); the carried columns in the left table's row order"}
+    got = dev.join_payload_multi(ka, [(kb, [pb]), (kc, [pc])], 0, n - 1)
+    res["join_payload_multi_1e8_two_tables"]["identical_to_f_of_key"] = bool(torch.equal(got[0][0], ka * 3 + 1) and torch.equal(got[1][0], ka * 5 - 2))
+    del ka, kb, kc, pb, pc, got
+    torch.cuda.empty_cache()
+
     # ---- single-table GROUP BY key COUNT(*) at 10^8 rows, 6.25M groups of 16
     keys = dev.gen_keys(n, 0, n, 43, n // 16)
 
