@@ -549,7 +549,6 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 		s_seg_chunk0[threadIdx.x][a.nseg] = run;
 	}
 	__syncthreads();
-	uint32_t groups = 0;
 	/* chunk q of a table = eight 2-byte words of one of its segments (regions start at multiples of 64 words) */
 	auto fetch = [&](int side, uint32_t q, uint32_t nchunks, uint4 &v, uint32_t &nv) {
 		v = make_uint4(0u, 0u, 0u, 0u);
@@ -568,6 +567,10 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 		nv = c - off < 8u ? c - off : 8u;
 		v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.words[side]) + s_seg_start[side][lo] + off);
 	};
+	/* (round 6) the counters' atomics do not come back: the groups are counted from the finished tables where they leave, and a 16-bit
+	 * counter that overflowed shows as fields that sum to less than the rows added (a carry out of the low field takes 65 535 off the sum,
+	 * out of the high one 65 536) - flag 2048 as before */
+	uint32_t added[2] = { 0u, 0u };		/* rows this thread counted: [0] left (those whose key the right table holds), [1] right */
 	auto count = [&](int side, const uint4 &v, uint32_t nv) {
 		const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -576,17 +579,11 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 				continue;
 			const uint32_t idx = ((w4[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu) & mask, sh = (idx & 1u) << 4;
 			if (side == 1) {
-				const uint32_t old = (atomicAdd(&s_cr[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
-				if (old == 0xFFFFu)
-					mdb_raise(a.status, 2048u);
-				else if (old == 0u && a.right_only)
-					groups++;
+				atomicAdd(&s_cr[idx >> 1], 1u << sh);
+				added[1]++;
 			} else if ((s_cr[idx >> 1] >> sh) & 0xFFFFu) {
-				const uint32_t old = (atomicAdd(&s_cl[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
-				if (old == 0u)
-					groups++;
-				else if (old == 0xFFFFu)
-					mdb_raise(a.status, 2048u);
+				atomicAdd(&s_cl[idx >> 1], 1u << sh);
+				added[0]++;
 			}
 		}
 	};
@@ -625,51 +622,106 @@ __global__ __launch_bounds__(THREADS) void k_shard_leaf_wide(sh_leaf_args a)
 			count(0, vl[u], nl[u]);
 	}
 	__syncthreads();
-	{
-		uint32_t g = groups;
+	/* the groups leave (round 6): wave w owns the packed counter words [w * HW / waves, (w + 1) * HW / waves) - two key values each.  It reads
+	 * its words ONCE into registers, counts its groups and takes its place among the workgroup's with ONE LDS atomic; the workgroup then takes
+	 * its place in the output, and every wave writes the even values' groups and the odd values' of every 64 words side by side: ballots and
+	 * popcounts only.  (Before: every wave iteration read two counters per lane, bumped a shared cursor and broadcast it through the crossbar -
+	 * 32 times per wave: 0.15 ms of the kernel's 0.46 at 10^8 x 10^8 unique keys, profiles/r06/README.md section 10.) */
+	unsigned long long joined = 0;
+	/* (a lane takes PAIRS of packed words - four key values - with one 8-byte LDS read per table) */
+	constexpr uint32_t NW = THREADS / 64, MAXIT = (1u << 15) / 4u / NW / 64u > 0u ? (1u << 15) / 4u / NW / 64u : 1u;	/* word pairs per lane at 2^15 values */
+	const uint32_t lane = mdb_lane(), wave = threadIdx.x >> 6;
+	const uint32_t HP = HW >> 1;		/* word pairs of a table (tables of 4 values and more; below: pair 0 holds the one word and a zero) */
+	const uint32_t ppw = HP / NW;		/* pairs per wave (HP >= NW: tables of 2^7 values and more; else wave 0 takes all) */
+	const uint32_t p_begin = ppw ? wave * ppw : 0u, p_cnt = ppw ? ppw : (wave == 0 ? (HP ? HP : 1u) : 0u);
+	const uint32_t *const s_g = a.right_only ? s_cr : s_cl;
+	auto pair_of = [&](const uint32_t *tab, uint32_t pi) -> uint2 {
+		if (HW < 2u)	/* (a table of two key values: one word) */
+			return make_uint2(tab[0], 0u);
+		return *reinterpret_cast<const uint2 *>(tab + 2u * pi);
+	};
+	uint2 gw[MAXIT];
+	uint32_t mine = 0, fsum_g = 0;
 #pragma unroll
-		for (int o = 32; o; o >>= 1)
-			g += __shfl_down(g, o, MDB_WAVE);
-		if (mdb_lane() == 0 && g)
-			atomicAdd(&s_total, g);
+	for (uint32_t it = 0; it < MAXIT; it++) {
+		const uint32_t pi = it * 64u + lane;
+		gw[it] = pi < p_cnt ? pair_of(s_g, p_begin + pi) : make_uint2(0u, 0u);
+		mine += ((gw[it].x & 0xFFFFu) ? 1u : 0u) + ((gw[it].x >> 16) ? 1u : 0u) + ((gw[it].y & 0xFFFFu) ? 1u : 0u) + ((gw[it].y >> 16) ? 1u : 0u);
+		fsum_g += (gw[it].x & 0xFFFFu) + (gw[it].x >> 16) + (gw[it].y & 0xFFFFu) + (gw[it].y >> 16);
 	}
+#pragma unroll
+	for (int o = 32; o; o >>= 1)
+		mine += (uint32_t)__shfl_xor((int)mine, o, MDB_WAVE);
+	uint32_t run = 0;
+	if (lane == 0 && mine)
+		run = atomicAdd(&s_total, mine);	/* (this wave's place among the workgroup's groups) */
+	run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
 	__syncthreads();
 	const uint32_t total = s_total;
-	if (!total)
-		return;
 	if (threadIdx.x == 0) {
-		const uint32_t nb = atomicAdd(a.status + 1, total);
-		if ((uint64_t)nb + total > a.out_cap) {
-			mdb_raise(a.status, 8u);
-			s_base = 0xFFFFFFFFu;
-		} else {
-			s_base = nb;
+		uint32_t nb = 0;
+		if (total) {
+			nb = atomicAdd(a.status + 1, total);
+			if ((uint64_t)nb + total > a.out_cap) {
+				mdb_raise(a.status, 8u);
+				nb = 0xFFFFFFFFu;
+			}
 		}
-		s_off = 0;
+		s_base = nb;
 	}
 	__syncthreads();
-	if (s_base == 0xFFFFFFFFu)
-		return;
-	unsigned long long joined = 0;
-	for (uint32_t s0 = 0; s0 < T; s0 += THREADS) {
-		const uint32_t s = s0 + threadIdx.x, sh = (s & 1u) << 4;
-		const uint32_t cl = s < T ? ((a.right_only ? s_cr : s_cl)[s >> 1] >> sh) & 0xFFFFu : 0u;
-		const uint64_t m = __ballot(cl != 0u);
-		if (!m)
+	const bool writing = total && s_base != 0xFFFFFFFFu;
+	run += s_base;
+	const uint64_t below = mdb_lanemask_lt();
+	uint32_t fsum_r = 0;
+#pragma unroll
+	for (uint32_t it = 0; it < MAXIT; it++) {
+		const uint32_t pi = it * 64u + lane;
+		if (it * 64u >= p_cnt)	/* (uniform) */
 			continue;
-		uint32_t wbase = 0;
-		if (mdb_lane() == 0)
-			wbase = atomicAdd(&s_off, (uint32_t)__popcll(m));
-		wbase = __shfl(wbase, 0, MDB_WAVE);
-		if (cl) {
-			const uint32_t pos = s_base + wbase + (uint32_t)__popcll(m & mdb_lanemask_lt());
-			const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * ((s_cr[s >> 1] >> sh) & 0xFFFFu);
-			const uint32_t h = a.hash_base + (leaf << a.rem) + s;
-			a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
-			if (a.out_count)	/* (NULL: the caller wants the keys alone and learns from J == G that every COUNT is 1) */
-				a.out_count[pos] = (long long)c;
-			joined += c;
+		/* (the right table's counters: the COUNTs' other factor, and - summed - the check that none of them overflowed) */
+		const uint2 r2 = pi < p_cnt ? pair_of(s_cr, p_begin + pi) : make_uint2(0u, 0u);
+		fsum_r += (r2.x & 0xFFFFu) + (r2.x >> 16) + (r2.y & 0xFFFFu) + (r2.y >> 16);
+		if (!writing || !__ballot((gw[it].x | gw[it].y) != 0u))	/* (uniform) */
+			continue;
+#pragma unroll
+		for (uint32_t e = 0; e < 4u; e++) {
+			const uint32_t gword = e < 2u ? gw[it].x : gw[it].y, rword = e < 2u ? r2.x : r2.y;
+			const uint32_t cl = (gword >> (16u * (e & 1u))) & 0xFFFFu;
+			const uint64_t m = __ballot(cl != 0u);
+			if (cl) {
+				const uint32_t pos = run + (uint32_t)__popcll(m & below), sl = 4u * (p_begin + pi) + e;
+				const unsigned long long c = a.right_only ? (unsigned long long)cl : (unsigned long long)cl * ((rword >> (16u * (e & 1u))) & 0xFFFFu);
+				const uint32_t h = a.hash_base + (leaf << a.rem) + sl;
+				a.out_key[pos] = a.key_lo + (long long)mdb_unmixk(h, a.kbits);
+				if (a.out_count)	/* (NULL: the caller wants the keys alone and learns from J == G that every COUNT is 1) */
+					a.out_count[pos] = (long long)c;
+				joined += c;
+			}
+			run += (uint32_t)__popcll(m);
 		}
+	}
+	{
+		/* counters that overflowed: the fields' sums against the rows added (left fields / rows in the high half, right in the low one) */
+		const unsigned long long have = ((unsigned long long)(a.right_only ? 0u : fsum_g) << 32) | fsum_r;
+		const unsigned long long want = ((unsigned long long)added[0] << 32) | added[1];
+		unsigned long long diff = have - want;
+#pragma unroll
+		for (int o = 32; o; o >>= 1)
+			diff += __shfl_down(diff, o, MDB_WAVE);
+		__syncthreads();	/* (s_red: free) */
+		if (lane == 0)
+			s_red[wave] = diff;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long t = 0;
+#pragma unroll
+			for (int w = 0; w < THREADS / 64; w++)
+				t += s_red[w];
+			if (t)
+				mdb_raise(a.status, 2048u);
+		}
+		__syncthreads();
 	}
 #pragma unroll
 	for (int o = 32; o; o >>= 1)

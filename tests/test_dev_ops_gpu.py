@@ -1898,6 +1898,45 @@ def test_a_row_count_beyond_16_bits_sends_the_wide_direct_leaves_back_to_two_lev
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("rows_of_the_key", [65_535, 65_536, 70_000])
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_a_row_count_beyond_16_bits_in_the_any_order_leaf_is_noticed_not_wrapped(dev, rows_of_the_key, side):
+    """the any-order join + GROUP BY (no MDB_ORDER_FIRST; the sharded operator's receiver runs the same leaf) counts rows per key in 16-bit
+    halves of LDS words with atomics that do not come back (round 6): a key with 2^16 rows or more carries into its neighbour or out of the
+    word - noticed as fields that sum to less than the rows added (flag 2048), the operator then answers by another path.  Either way:
+    every key's COUNT = its left rows x its right rows, checked on the device against torch; 65 535 rows still fit."""
+    n, span = 40_000_000, 1 << 26
+    g = torch.Generator(device="cuda")
+    g.manual_seed(rows_of_the_key * (1 if side == "right" else 3))
+    kr = torch.randint(0, span, (n,), dtype=torch.int64, device="cuda", generator=g) + 1_000_000_000
+    kl = kr[torch.randint(0, n, (n,), device="cuda", generator=g)]
+    hot, other = kr[12345].clone(), kr[12346].clone()
+    tgt = kr if side == "right" else kl
+    kr[kr == hot] = other
+    kl[kl == hot] = other
+    tgt[torch.randperm(n, device="cuda", generator=g)[:rows_of_the_key]] = hot
+    if side == "right":
+        kl[:5] = hot
+    else:
+        kr[:3] = hot
+    dev.prof_enable(True)
+    dev.prof_reset()
+    k, c, j = dev.join_group_count_unordered(kl, None, kr, None)
+    ran = set(dev.prof_read())
+    dev.prof_enable(False)
+    assert "shard_leaf_wide" in ran, ran        # (the leaf this test is about did run - and, beyond 65 535 rows, was not the one that answered)
+    ul, cl = torch.unique(kl, return_counts=True)
+    ur, cr = torch.unique(kr, return_counts=True)
+    pos = torch.searchsorted(ur, ul).clamp(max=ur.numel() - 1)
+    hit = ur[pos] == ul
+    ek, ec = ul[hit], cl[hit] * cr[pos[hit]]
+    o = torch.argsort(k)
+    assert torch.equal(k[o], ek) and torch.equal(c[o], ec) and j == int(ec.sum())
+    assert int(c[k == hot]) == rows_of_the_key * (5 if side == "right" else 3)
+    del kl, kr, ul, ur, cl, cr, k, c
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", ["spread", "bunched"])
 def test_few_groups_are_ordered_through_row_id_bitmaps_or_the_general_sort_alike(dev, narrow_mode, monkeypatch, shape):
     """Few group records among many left rows (a selective join) are ordered by k_order_leaf_sparse - leaves of 2^16 row
