@@ -671,24 +671,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					cmax = c > cmax ? c : cmax;                                                                    \
 					clmax = cl > clmax ? cl : clmax;                                                               \
 					last_first = first > last_first ? first : last_first;                                          \
-					if (FMT == 3) {                                                                                \
-						const uint64_t me = __ballot(c != 1u);                                                 \
-						if (me) {	/* (groups whose COUNT is not 1: the exceptions - rare in this form) */ \
-							uint32_t eb = 0;                                                               \
-							if (lane == (uint32_t)__ffsll((long long)me) - 1u)                             \
-								eb = atomicAdd(&a.dn_cnt[1], (uint32_t)__popcll(me));                  \
-							eb = (uint32_t)__shfl((int)eb, __ffsll((long long)me) - 1, MDB_WAVE);          \
-							if (c != 1u) {                                                                 \
-								const uint32_t ep = eb + (uint32_t)__popcll(me & mdb_lanemask_lt());   \
-								if (!a.dn_exc)                                                         \
-									;	/* (the pilot: counted only) */                        \
-								else if (ep < a.dn_exc_cap)                                            \
-									a.dn_exc[ep] = ((unsigned long long)first << 32) | c;          \
-								else                                                                   \
-									mdb_raise(a.status, 131072u);                                  \
-							}                                                                              \
-						}                                                                                      \
-					} else if (FMT == 1)                                                                           \
+					if (FMT == 1)                                                                           \
 						reinterpret_cast<uint32_t *>(a.rec)[pos] = (first << (32 - a.kbits)) | c;              \
 					else if (FMT == 0)                                                                             \
 						a.rec[pos] = ((unsigned long long)first << (64 - a.kbits)) | c;                        \
@@ -699,7 +682,52 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			}                                                                                                              \
 		}
 		if (DN) {
-			LW12_EMIT(3)
+			/* no list to write, so no position to work out: a lane takes FOUR consecutive values - one 16-byte read of the table, one word of
+			 * 4-bit fields - instead of one value in 64 (two LDS reads and a ballot a value, round 6: the pass 0.1 ms of the kernel's 0.35) */
+			if (base != 0xFFFFFFFFu)
+				for (uint32_t q = lane; q < per_wave / 4u; q += MDB_WAVE) {
+					const uint32_t sl0 = wave * per_wave + 4u * q;
+					const uint4 fq = *reinterpret_cast<const uint4 *>(s_fc + sl0);
+					const uint32_t cw = s_cl[sl0 >> 3] >> (16u * (q & 1u)), f[4] = { fq.x, fq.y, fq.z, fq.w };
+					bool odd = false;
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						const uint32_t cl = (cw >> (4 * e)) & 15u, cr = f[e] >> 27, c = cl * cr, first = cl ? f[e] & 0x07FFFFFFu : 0u;
+						sum_cr += cr;
+						jsum += c;
+						cmax = c > cmax ? c : cmax;
+						clmax = cl > clmax ? cl : clmax;
+						last_first = first > last_first ? first : last_first;
+						odd = odd || c > 1u;
+					}
+					if (!__ballot(odd))
+						continue;
+#pragma unroll
+					for (int e = 0; e < 4; e++) {	/* (groups whose COUNT is not 1: the exceptions - rare in this form) */
+						const uint32_t c = ((cw >> (4 * e)) & 15u) * (f[e] >> 27);
+						const uint64_t me = __ballot(c > 1u);
+						if (!me)
+							continue;
+						uint32_t eb = 0;
+						if (lane == (uint32_t)__ffsll((long long)me) - 1u)
+							eb = atomicAdd(&a.dn_cnt[1], (uint32_t)__popcll(me));
+						eb = (uint32_t)__shfl((int)eb, __ffsll((long long)me) - 1, MDB_WAVE);
+						if (c > 1u) {
+							const uint32_t ep = eb + (uint32_t)__popcll(me & mdb_lanemask_lt());
+							if (!a.dn_exc)
+								;	/* (the pilot: counted only) */
+							else if (ep < a.dn_exc_cap)
+								a.dn_exc[ep] = ((unsigned long long)(f[e] & 0x07FFFFFFu) << 32) | c;
+							else
+								mdb_raise(a.status, 131072u);
+						}
+					}
+				}
+			else
+				for (uint32_t q = lane; q < per_wave / 4u; q += MDB_WAVE) {	/* (no group in the digit: the right rows are still checked) */
+					const uint4 fq = *reinterpret_cast<const uint4 *>(s_fc + wave * per_wave + 4u * q);
+					sum_cr += (fq.x >> 27) + (fq.y >> 27) + (fq.z >> 27) + (fq.w >> 27);
+				}
 		} else if (a.keyed_cbits) {
 			LW12_EMIT(2)
 		} else if (a.rec32) {
