@@ -296,7 +296,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	/* [buffer][side][sub-region]: first 16-byte chunk (prefix) and words of a digit's sub-regions, side 0 left (4 words per chunk), 1 right (8) */
 	__shared__ uint32_t s_chunk0[2][2 + NX][17], s_cnt[2][2 + NX][16];		/* (nsub <= 16; side 2: the further right table) */
 	__shared__ uint32_t s_wlast[2][LW_THREADS / 64], s_carry[2];
-	const uint32_t wave = threadIdx.x >> 6, lane = mdb_lane();
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = mdb_lane();	/* (the wave: a scalar - what is derived from it is not kept in vector registers across the digit loop) */
 	const uint32_t T = 1u << rem, mask = T - 1u;
 	uint32_t *const s_fc = lw_lds;			/* right rows << 27 | first left row */
 	uint32_t *const s_cl = lw_lds + T;		/* left rows per key (only of keys that have right rows), 4 bits each */
@@ -311,20 +311,23 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 	if (leaf >= run_leaves)
 		return;
 	auto seg_count = [&](uint32_t d) -> uint32_t {		/* threads 0 .. 16 * (2 + NX) - 1: (side, sub-region) */
-		const uint32_t side = threadIdx.x >> 4, j = threadIdx.x & 15u;
-		if (threadIdx.x >= 16u * (2u + NX) || j >= nsub)
+		uint32_t tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));	/* (as in fetch_all below: no address kept across the digit loop) */
+		const uint32_t side = tid >> 4, j = tid & 15u;
+		if (tid >= 16u * (2u + NX) || j >= nsub)
 			return 0u;
 		const uint32_t c0 = (side == 0 ? a.cnt_l : side == 1 ? a.cnt_r : a.cnt_x[0])[j * a.nleaves + d];
 		const uint32_t cap = side == 0 ? a.cap_l : side == 1 ? a.cap_r : a.cap_x[0];
 		return c0 < cap ? c0 : cap;
 	};
 	auto seg_prefix = [&](uint32_t b) {		/* threads 0 .. 1 + NX */
-		uint32_t run = 0;
+		uint32_t run = 0, tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
 		for (uint32_t j = 0; j < nsub; j++) {
-			s_chunk0[b][threadIdx.x][j] = run;
-			run += threadIdx.x ? (s_cnt[b][threadIdx.x][j] + 7u) >> 3 : (s_cnt[b][0][j] + 3u) >> 2;
+			s_chunk0[b][tid][j] = run;
+			run += tid ? (s_cnt[b][tid][j] + 7u) >> 3 : (s_cnt[b][0][j] + 3u) >> 2;
 		}
-		s_chunk0[b][threadIdx.x][nsub] = run;
+		s_chunk0[b][tid][nsub] = run;
 	};
 	uint4 vr[LW12_RB], vl[LW12_LB / 2];	/* (the left table's chunks 4 .. 7 take the right table's registers once its words are counted) */
 	uint32_t nvr = 0, nvl = 0;	/* words of each chunk, 4 bits each */
@@ -352,9 +355,16 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				endq[j] = cnt + c0[j] * per;
 			}
 			uint32_t nvs = side ? 0u : nvl;
+			/* (what a thread's chunks and the table's address come to is the same for every digit: left to itself the compiler keeps them in
+			 * vector registers across the digit loop, spills them with a further right table, and reloads each one in front of its load
+			 * behind s_waitcnt vmcnt(0) - the four loads of a side then go out one after the other's answer.  Recomputed per call instead.) */
+			uint32_t tid = threadIdx.x;
+			asm volatile("" : "+v"(tid));
+			const void *tbl = side == 1 ? (const void *)a.hv_r : side == 2 ? (const void *)a.hv_x[0] : (const void *)a.hv_l;
+			asm volatile("" : "+s"(tbl));
 #pragma unroll
 			for (int u = u_lo; u < u_hi; u++) {
-				const uint32_t q = (uint32_t)u * LW_THREADS + threadIdx.x, qp = q * per;
+				const uint32_t q = (uint32_t)u * LW_THREADS + tid, qp = q * per;
 				uint4 v = make_uint4(0u, 0u, 0u, 0u);
 				uint32_t nv = 0u;
 				if (q < c0[LW12_NSUB]) {
@@ -366,12 +376,10 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 						en = in ? endq[j] : en;
 					}
 					nv = en - qp < per ? en - qp : per;
-					if (side == 1)
-						v = lw_load_nt(reinterpret_cast<const uint16_t *>(a.hv_r) + (dl + qp));
-					else if (side == 2)
-						v = lw_load_nt(reinterpret_cast<const uint16_t *>(a.hv_x[0]) + (dl + qp));
+					if (side)
+						v = lw_load_nt(reinterpret_cast<const uint16_t *>(tbl) + (dl + qp));
 					else
-						v = lw_load_nt(reinterpret_cast<const uint32_t *>(a.hv_l) + (dl + qp));
+						v = lw_load_nt(reinterpret_cast<const uint32_t *>(tbl) + (dl + qp));
 				}
 				if (side)
 					vr[u < LW12_RB ? u : 0] = v;
@@ -416,10 +424,15 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 		 * for everything in flight) */
 		fetch_all(leaf, buf, 1);
 		const uint32_t next_c = next < run_leaves ? seg_count(next) : 0u;	/* (on its way while this digit is counted) */
-		for (uint32_t s = threadIdx.x; s < T; s += LW_THREADS)
-			s_fc[s] = 0x07FFFFFFu;
-		for (uint32_t s = threadIdx.x; s < T / 8; s += LW_THREADS)
-			s_cl[s] = 0u;
+		{	/* (16 bytes a store: a quarter of the LDS instructions - the kernel is bound by their number; T >= 2^12) */
+			uint32_t tid = threadIdx.x;
+			asm volatile("" : "+v"(tid));	/* (no address kept - and spilled - across the digit loop) */
+			const uint4 none = make_uint4(0x07FFFFFFu, 0x07FFFFFFu, 0x07FFFFFFu, 0x07FFFFFFu), zero = make_uint4(0u, 0u, 0u, 0u);
+			for (uint32_t s = tid; s < T / 4u; s += LW_THREADS)
+				reinterpret_cast<uint4 *>(s_fc)[s] = none;
+			for (uint32_t s = tid; s < T / 32u; s += LW_THREADS)
+				reinterpret_cast<uint4 *>(s_cl)[s] = zero;
+		}
 		lw12_barrier();
 		uint32_t adds = 0, radds = 0;
 #pragma unroll
@@ -532,7 +545,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				s_wlast[p][wave] = bal ? wave_last : 0u;
 			lw12_barrier();
 			{
-				const uint32_t x = lane < LW_THREADS / 64 ? s_wlast[p][lane] : 0u;
+				uint32_t ln = lane;
+				asm volatile("" : "+v"(ln));	/* (the slot's address: worked out here, not reloaded from scratch behind vmcnt(0)) */
+				const uint32_t x = ln < LW_THREADS / 64 ? s_wlast[p][ln] : 0u;
 				const uint64_t ball = __ballot(x != 0u), earlier = ball & ((1ull << wave) - 1ull);
 				const uint32_t carried = s_carry[p];
 				const uint32_t from_waves = (uint32_t)__builtin_amdgcn_readlane((int)x, earlier ? 63 - __clzll((long long)earlier) : 0);
@@ -646,7 +661,9 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 				t += (uint32_t)__shfl_xor((int)t, o, MDB_WAVE);
 			run = base + t;		/* (base = ~0: nothing is written) */
 		}
-		const uint32_t nib = (lane & 7u) * 4u, s_begin = wave * per_wave + lane;
+		uint32_t el = lane;
+		asm volatile("" : "+v"(el));	/* (addresses worked out now: a reload from scratch would wait for the words just asked for) */
+		const uint32_t nib = (el & 7u) * 4u, s_begin = wave * per_wave + el;
 		uint32_t cmax = 0, jsum = 0, clmax = 0;
 		/* FMT 0: 8-byte records, 1: 4-byte records, 2: keyed 8-byte records */
 #define LW12_EMIT(FMT)                                                                                                                  \
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 			/* no list to write, so no position to work out: a lane takes FOUR consecutive values - one 16-byte read of the table, one word of
 			 * 4-bit fields - instead of one value in 64 (two LDS reads and a ballot a value, round 6: the pass 0.1 ms of the kernel's 0.35) */
 			if (base != 0xFFFFFFFFu)
-				for (uint32_t q = lane; q < per_wave / 4u; q += MDB_WAVE) {
+				for (uint32_t q = el; q < per_wave / 4u; q += MDB_WAVE) {
 					const uint32_t sl0 = wave * per_wave + 4u * q;
 					const uint4 fq = *reinterpret_cast<const uint4 *>(s_fc + sl0);
 					const uint32_t cw = s_cl[sl0 >> 3] >> (16u * (q & 1u)), f[4] = { fq.x, fq.y, fq.z, fq.w };
@@ -724,7 +741,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_leaf_wide12(gc_args a, uint32_t 
 					}
 				}
 			else
-				for (uint32_t q = lane; q < per_wave / 4u; q += MDB_WAVE) {	/* (no group in the digit: the right rows are still checked) */
+				for (uint32_t q = el; q < per_wave / 4u; q += MDB_WAVE) {	/* (no group in the digit: the right rows are still checked) */
 					const uint4 fq = *reinterpret_cast<const uint4 *>(s_fc + wave * per_wave + 4u * q);
 					sum_cr += (fq.x >> 27) + (fq.y >> 27) + (fq.z >> 27) + (fq.w >> 27);
 				}
