@@ -113,6 +113,7 @@ struct sort_pack_args {
 	uint32_t kb[SORT_PACK_MAX_KEYS];		/* bits of (largest image - lo) */
 	int nkeys;
 	uint32_t rb, up;				/* bits of a stream position; left shift that aligns the word */
+	int nopos;					/* the composite value alone (group_multi_packed: a key column, not a sort word) */
 };
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, uint64_t n, uint64_t *__restrict__ w)
@@ -132,8 +133,114 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_pack(sort_pack_args a, ui
 				v = (v << a.kb[c]) | (sort_image(values[row], key.type, key.desc) - a.lo[c]);
 			}
 		}
-		w[k] = ((v << a.rb) | k) << a.up;
+		w[k] = a.nopos ? v : ((v << a.rb) | k) << a.up;
 	}
+}
+
+/* the image ranges of all columns of a packed word in ONE pass and one host round trip (a pass and a round trip per column before):
+ * mm[3 c] = smallest image, mm[3 c + 1] = largest, over the non-NULL rows of column c (min > max: none) */
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_ranges(sort_pack_args a, uint64_t n, unsigned long long *mm)
+{
+	__shared__ unsigned long long s_min[SORT_PACK_MAX_KEYS], s_max[SORT_PACK_MAX_KEYS];
+	if (threadIdx.x < SORT_PACK_MAX_KEYS) {
+		s_min[threadIdx.x] = ~0ull;
+		s_max[threadIdx.x] = 0ull;
+	}
+	__syncthreads();
+	unsigned long long lo[SORT_PACK_MAX_KEYS], hi[SORT_PACK_MAX_KEYS];
+#pragma unroll
+	for (int c = 0; c < SORT_PACK_MAX_KEYS; c++) {
+		lo[c] = ~0ull;
+		hi[c] = 0ull;
+	}
+	const uint64_t stride = (uint64_t)gridDim.x * SORT_THREADS;
+	for (uint64_t k0 = (uint64_t)blockIdx.x * SORT_THREADS + threadIdx.x; k0 < n; k0 += 2 * stride) {	/* (two rows a turn: 2 x nkeys loads in flight) */
+		uint64_t u[2][SORT_PACK_MAX_KEYS];
+		bool have[2][SORT_PACK_MAX_KEYS];
+#pragma unroll
+		for (int r = 0; r < 2; r++) {
+			const uint64_t k = k0 + (uint64_t)r * stride;
+#pragma unroll
+			for (int c = 0; c < SORT_PACK_MAX_KEYS; c++) {
+				have[r][c] = false;
+				u[r][c] = 0;
+				if (c < a.nkeys && k < n) {
+					const struct mdb_sort_key &key = a.key[c];
+					const uint64_t row = key.rid ? (uint64_t)key.rid[k] : k;
+					if (!(key.nullbits && mdb_bit_is_set(key.nullbits, row))) {
+						have[r][c] = true;
+						u[r][c] = ((const uint64_t *)key.values)[row];
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < 2; r++)
+#pragma unroll
+			for (int c = 0; c < SORT_PACK_MAX_KEYS; c++)
+				if (have[r][c]) {
+					const uint64_t im = sort_image(u[r][c], a.key[c].type, a.key[c].desc);
+					lo[c] = im < lo[c] ? im : lo[c];
+					hi[c] = im > hi[c] ? im : hi[c];
+				}
+	}
+#pragma unroll
+	for (int c = 0; c < SORT_PACK_MAX_KEYS; c++) {
+		if (c >= a.nkeys)
+			break;
+#pragma unroll
+		for (int o = 32; o; o >>= 1) {
+			const unsigned long long ol = __shfl_xor(lo[c], o, MDB_WAVE), oh = __shfl_xor(hi[c], o, MDB_WAVE);
+			lo[c] = ol < lo[c] ? ol : lo[c];
+			hi[c] = oh > hi[c] ? oh : hi[c];
+		}
+		if (mdb_lane() == 0 && lo[c] <= hi[c]) {
+			atomicMin(&s_min[c], lo[c]);
+			atomicMax(&s_max[c], hi[c]);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < (uint32_t)a.nkeys && s_min[threadIdx.x] <= s_max[threadIdx.x]) {
+		atomicMin(&mm[3 * threadIdx.x], s_min[threadIdx.x]);
+		atomicMax(&mm[3 * threadIdx.x + 1], s_max[threadIdx.x]);
+	}
+}
+
+/* the columns' image ranges into pa.lo / pa.kb (one launch, one synchronisation); *total += the bits of the composite value.
+ * 0 = done, 1 = a column type the packed word does not take, < 0 = error */
+static int sort_pack_ranges(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, unsigned long long *mm /* 12 words */,
+			    sort_pack_args *pa, uint32_t *total, uint32_t limit, uint64_t *vmax)
+{
+	uint64_t *h = ctx->h_pinned;
+	for (int c = 0; c < nkeys; c++) {
+		if (keys[c].type != MDB_T_INT64 && keys[c].type != MDB_T_DOUBLE)
+			return 1;	/* the general path reports it */
+		pa->key[c] = keys[c];
+		h[3 * c] = ~0ull;
+		h[3 * c + 1] = 0ull;
+		h[3 * c + 2] = 0ull;
+	}
+	pa->nkeys = nkeys;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	MDB_HIP(ctx, hipMemcpyAsync(mm, h, 24 * (size_t)nkeys, hipMemcpyHostToDevice, ctx->stream));
+	MDB_LAUNCH(ctx, "orderby_range", k_sort_ranges, grid ? grid : 1, SORT_THREADS, *pa, n, mm);
+	MDB_HIP(ctx, hipMemcpyAsync(h, mm, 24 * (size_t)nkeys, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int c = 0; c < nkeys; c++) {
+		const uint64_t lo = h[3 * c] <= h[3 * c + 1] ? h[3 * c] : 0, hi = h[3 * c] <= h[3 * c + 1] ? h[3 * c + 1] : 0;
+		uint32_t kb = 0;
+		if (hi != lo)
+			kb = 64u - (uint32_t)__builtin_clzll(hi - lo);
+		const uint32_t width = kb + (keys[c].nullbits ? 1u : 0u);	/* the flag bit is spent whenever the column can hold NULLs */
+		*total += width;
+		if (*total > limit)
+			return 1;
+		pa->lo[c] = lo;
+		pa->kb[c] = kb;
+		if (vmax)
+			*vmax = (*vmax << width) | ((keys[c].nullbits ? (1ull << kb) : 0ull) | (hi - lo));
+	}
+	return 0;
 }
 
 __global__ __launch_bounds__(SORT_LEAF_THREADS) void k_sort_leaf(const uint64_t *__restrict__ w, const uint32_t *__restrict__ cnt,
@@ -273,31 +380,10 @@ static int sort_perm_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, i
 		pa.rb++;
 	uint32_t total = pa.rb;
 	uint64_t vmax = 0;	/* the largest composite value: every field at its maximum */
-	for (int c = 0; c < nkeys; c++) {
-		const struct mdb_sort_key *key = &keys[c];
-		if (key->type != MDB_T_INT64 && key->type != MDB_T_DOUBLE)
-			return 1;	/* the general path reports it */
-		/* one read-only pass per column for the range of its images */
-		h[0] = ~0ull;
-		h[1] = 0ull;
-		h[2] = 0ull;
-		MDB_HIP(ctx, hipMemcpyAsync(mm, h, 24, hipMemcpyHostToDevice, ctx->stream));
-		MDB_LAUNCH(ctx, "orderby_range", k_sort_load, grid, SORT_THREADS, (const uint64_t *)key->values, key->nullbits, key->rid,
-			   (const uint32_t *)NULL, n, key->type, key->desc, (uint64_t *)NULL, mm);
-		MDB_HIP(ctx, hipMemcpyAsync(h, mm, 24, hipMemcpyDeviceToHost, ctx->stream));
-		MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		const uint64_t lo = h[0] <= h[1] ? h[0] : 0, hi = h[0] <= h[1] ? h[1] : 0;
-		uint32_t kb = 0;
-		if (hi != lo)
-			kb = 64u - (uint32_t)__builtin_clzll(hi - lo);
-		const uint32_t width = kb + (key->nullbits ? 1u : 0u);	/* the flag bit is spent whenever the column can hold NULLs */
-		total += width;
-		if (total > 64)
-			return 1;
-		pa.key[c] = *key;
-		pa.lo[c] = lo;
-		pa.kb[c] = kb;
-		vmax = (vmax << width) | ((key->nullbits ? (1ull << kb) : 0ull) | (hi - lo));
+	{
+		const int rrc = sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 64, &vmax);
+		if (rrc)
+			return rrc;
 	}
 	pa.up = 64 - total;
 	const uint32_t up = pa.up, rb = pa.rb;
@@ -465,7 +551,7 @@ static size_t sort_arena_bytes(uint64_t n)
 {
 	const size_t hist_words = mdb_sort_pass_hist_words(n);
 	return 2 * mdb_align_up(n * 8) + 2 * mdb_align_up(n * 4) + mdb_align_up(hist_words * 4) +
-	       mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(64) + 4096 + sort_packed_arena_bytes(n);
+	       mdb_align_up(mdb_scan_scratch_words(hist_words) * 4) + mdb_align_up(128) + 4096 + sort_packed_arena_bytes(n);
 }
 
 /* sorts inside an arena the caller has begun (sort_arena_bytes(n) available); *perm = the arena buffer that holds
@@ -481,7 +567,7 @@ static int sort_perm_impl(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int
 	uint32_t *pm[2] = { (uint32_t *)mdb_arena_take(ctx, n * 4), (uint32_t *)mdb_arena_take(ctx, n * 4) };
 	uint32_t *hist = (uint32_t *)mdb_arena_take(ctx, hist_words * 4);
 	uint32_t *scan_tmp = (uint32_t *)mdb_arena_take(ctx, mdb_scan_scratch_words(hist_words) * 4);
-	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 64);
+	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 128);
 	if (!u[0] || !u[1] || !pm[0] || !pm[1] || !hist || !scan_tmp || !mm)
 		return -MIDORIDB_INTERNAL;
 	if (n <= SORT_TINY_ROWS && nkeys <= SORT_PACK_MAX_KEYS) {
@@ -900,6 +986,50 @@ __global__ __launch_bounds__(SORT_THREADS) void k_group_records(const uint32_t *
 	}
 }
 
+/* GROUP BY over columns whose value ranges fit one word TOGETHER: a row's composite value - [NULL flag | image - min] per column, as the
+ * packed sort builds it - is a key like any other.  It is written into an 8-byte column and handed to the single-column operator (LDS
+ * tables, band sort or partition passes, by the composite's range; groups in first-occurrence order is what that operator delivers)
+ * instead of sorting the whole stream and looking for run heads: 10^8 rows in 512 x 300 combinations 2.70 -> 0.9 ms.
+ * 0 = served, 1 = not applicable (wider than 63 bits, a column type the sort reports), < 0 = error.  MDB_GROUP_MULTI_PACKED=0: never. */
+static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_first,
+			      int64_t *out_count, uint64_t cap, uint64_t *out_groups)
+{
+	const char *knob = mdb_knob("MDB_GROUP_MULTI_PACKED");
+	if ((knob && knob[0] == '0') || nkeys > SORT_PACK_MAX_KEYS)
+		return 1;
+	for (int c = 0; c < nkeys; c++)
+		if (keys[c].type != MDB_T_INT64 && keys[c].type != MDB_T_DOUBLE)
+			return 1;
+	int rc = mdb_arena_begin(ctx, 8192);
+	if (rc)
+		return rc;
+	unsigned long long *mm = (unsigned long long *)mdb_arena_take(ctx, 128);
+	if (!mm)
+		return -MIDORIDB_INTERNAL;
+	const uint32_t grid = (uint32_t)(((n + SORT_THREADS - 1) / SORT_THREADS) < 2048 ? ((n + SORT_THREADS - 1) / SORT_THREADS) : 2048);
+	sort_pack_args pa;
+	memset(&pa, 0, sizeof(pa));
+	pa.nkeys = nkeys;
+	pa.nopos = 1;
+	uint32_t total = 0;
+	if ((rc = sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 63, NULL)))
+		return rc;
+	void *comp = NULL;
+	if ((rc = mdb_dev_alloc(ctx, (n ? n : 1) * 8, &comp)))
+		return rc;
+	auto pack = [&]() -> int {
+		MDB_LAUNCH(ctx, "groupby_pack", k_sort_pack, grid, SORT_THREADS, pa, n, (uint64_t *)comp);
+		return MIDORIDB_OK;
+	};
+	if ((rc = pack())) {
+		mdb_dev_free(ctx, comp);
+		return rc;
+	}
+	rc = mdb_dev_group_count(ctx, (const int64_t *)comp, NULL, n, MDB_ORDER_FIRST, out_first, out_count, cap, out_groups);	/* (synchronous) */
+	mdb_dev_free(ctx, comp);
+	return rc;
+}
+
 extern "C" int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_first,
 					 int64_t *out_count, uint64_t cap, uint64_t *out_groups)
 {
@@ -907,6 +1037,10 @@ extern "C" int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort
 	int rc = sort_check(ctx, "group_count_multi", nkeys, n);
 	if (rc || n == 0)
 		return rc;
+	rc = group_multi_packed(ctx, keys, nkeys, n, out_first, out_count, cap, out_groups);
+	if (rc <= 0)
+		return rc;
+	*out_groups = 0;
 	uint32_t kbits = 0;
 	const size_t order_bytes = mdb_order_records_arena_bytes(n, n, &kbits);
 	if (!order_bytes)

@@ -1176,8 +1176,11 @@ def test_join_group_count_huge_count_takes_the_dense_ordering(dev):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("n", [1, 2, 65, 4097, 80_000])
-def test_group_count_multi_unpinned(dev, n):
+def test_group_count_multi_unpinned(dev, n, packed, monkeypatch):
+    """packed = 1: the columns' composite value as ONE key column through the single-column operator (round 6); 0: the sort of the stream."""
+    monkeypatch.setenv("MDB_GROUP_MULTI_PACKED", packed)
     rng = np.random.default_rng(n + 21)
     a = rng.integers(-2, 3, n, dtype=np.int64)
     b = rng.integers(0, 4, n, dtype=np.int64)
@@ -1193,6 +1196,48 @@ def test_group_count_multi_unpinned(dev, n):
         first, cnt = dev.group_count_multi(keys_dev, n)
         ef, ec = orc.group_count_multi(keys_np, n)
         assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
+
+
+@pytest.mark.parametrize("shape", ["wide_int64", "two_doubles", "63_bits", "64_bits", "unique_pairs", "one_hot_combination", "all_null_column", "five_columns",
+                                   "doubles_one_binade"])
+def test_group_count_multi_composite_key_forms(dev, shape):
+    """GROUP BY over several columns, the composite value handed to the single-column operator where the ranges fit 63 bits together and
+    sorted where they do not: ranges at the limit, DOUBLE columns (bits compared), every row its own group, one combination holding half
+    the rows, a column of NULLs only, more columns than the packed form takes - against the numpy oracle."""
+    n = 300_000
+    rng = np.random.default_rng(len(shape))
+    I, Dbl = D.T_INT64, D.T_DOUBLE
+    if shape == "wide_int64":       # full-range values: the general path
+        cols = [(rng.integers(-2**62, 2**62, n, dtype=np.int64) // 2**40 * 2**40, None, False), (rng.integers(-2**62, 2**62, n, dtype=np.int64) // 2**50 * 2**50, None, False)]
+    elif shape == "two_doubles":
+        cols = [(np.round(rng.normal(0, 2, n), 0), rng.random(n) < 0.05, True), (rng.choice(np.array([-0.0, 0.0, 1.5, -1.5, np.inf, -np.inf]), n), None, True)]
+    elif shape == "63_bits":        # 31 + 32 bits
+        cols = [(rng.integers(0, 2**31, n, dtype=np.int64) // 2**14 * 2**14, None, False), (rng.integers(0, 2**32, n, dtype=np.int64) // 2**16 * 2**16, None, False)]
+        cols[0][0][:2] = [0, 2**31 - 1]
+        cols[1][0][:2] = [0, 2**32 - 1]
+    elif shape == "64_bits":        # 32 + 32 bits: one too many
+        cols = [(rng.integers(0, 2**32, n, dtype=np.int64) // 2**15 * 2**15, None, False), (rng.integers(0, 2**32, n, dtype=np.int64) // 2**16 * 2**16, None, False)]
+        cols[0][0][:2] = [0, 2**32 - 1]
+        cols[1][0][:2] = [0, 2**32 - 1]
+    elif shape == "unique_pairs":
+        i = rng.permutation(n).astype(np.int64)
+        cols = [(i // 1000 - 77, None, False), (i % 1000 + 10**15, None, False)]
+    elif shape == "one_hot_combination":
+        a, b = rng.integers(0, 700, n, dtype=np.int64), rng.integers(-5, 5, n, dtype=np.int64)
+        hot = rng.random(n) < 0.5
+        a[hot], b[hot] = 123, 4
+        cols = [(a, rng.random(n) < 0.01, False), (b, None, False)]
+    elif shape == "doubles_one_binade":     # DOUBLE images that differ in their low bits only: packed
+        cols = [(1.0 + rng.integers(0, 1000, n) * 2.0**-20, rng.random(n) < 0.1, True), (rng.integers(0, 100, n, dtype=np.int64), None, False)]
+    elif shape == "all_null_column":
+        cols = [(rng.integers(0, 9, n, dtype=np.int64), np.ones(n, dtype=bool), False), (rng.integers(0, 50, n, dtype=np.int64), rng.random(n) < 0.5, False)]
+    else:
+        cols = [(rng.integers(0, 3, n, dtype=np.int64), None, False) for _ in range(5)]
+    keys_np = [(v, nl, None, dbl, False) for v, nl, dbl in cols]
+    keys_dev = [(dev.to_dev(v), dev.nullbits_dev(nl) if nl is not None else None, None, Dbl if dbl else I, False) for v, nl, dbl in cols]
+    first, cnt = dev.group_count_multi(keys_dev, n)
+    ef, ec = orc.group_count_multi(keys_np, n)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
 
 
 def test_group_count_multi_large_property_unpinned(dev):
@@ -2190,11 +2235,13 @@ def test_min_max_pruning_at_scale_matches_the_unpruned_operator(dev, narrow_mode
     assert dev.last_join_form() == 2 and dev.last_join_filter() == (0, False) and j == n and k.numel() == n	# same key range: nothing to prune
 
 
+@pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("n", [262_144, 600_001])
-def test_group_count_multi_and_distinct_on_the_packed_sort_path_unpinned(dev, n):
+def test_group_count_multi_and_distinct_on_the_packed_sort_path_unpinned(dev, n, packed, monkeypatch):
     """From 2^18 rows on, INT64 columns whose ranges fit one word are sorted by the packed path and the group / distinct
     run heads come from its sorted composite values (no per-row column gathers): against the numpy oracle with NULLs,
     negative values, a row-id vector, many and few groups; a DOUBLE column keeps the general path."""
+    monkeypatch.setenv("MDB_GROUP_MULTI_PACKED", packed)
     rng = np.random.default_rng(n + 31)
     a = rng.integers(-50, 50, n, dtype=np.int64)
     b = rng.integers(10**12, 10**12 + 300, n, dtype=np.int64)
