@@ -259,7 +259,8 @@ def main():
                                           "note": "GROUP BY over 512 distinct values + COUNT(*): one streaming pass, per-workgroup LDS tables "
                                                   "(3.8 ms through the partitioned path's hot-key kernels)"}
 
-    # GROUP BY two columns + COUNT(*) (composite-key semantics; sort, run heads, run lengths)
+    # GROUP BY two columns + COUNT(*) (composite-key semantics; round 6: the columns' composite value as one key column through the
+    # single-column operator where the ranges fit 63 bits together - sort, run heads, run lengths before and otherwise)
     k3 = dev.gen_keys(n, 0, n, 79, 300)
 
     def group_by2():
@@ -267,6 +268,12 @@ def main():
     ms, kern, groups2 = timed(dev, group_by2, reps=3, warmup=1)
     res["group_by_two_columns_1e8"] = {"rows": n, "groups": groups2, "ms": ms, "rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
                                        "note": "GROUP BY k2, k3 (512 x 300 value combinations) + COUNT(*), first-occurrence order"}
+
+    def distinct2():
+        return dev.distinct_sel([(k2, None, None, D.T_INT64, False), (k3, None, None, D.T_INT64, False)], n).numel()
+    ms, kern, groups2 = timed(dev, distinct2, reps=3, warmup=1)
+    res["distinct_two_columns_1e8"] = {"rows": n, "distinct": groups2, "ms": ms, "rows_per_s": n / (ms * 1e-3), "kernels_ms": kern,
+                                       "note": "SELECT DISTINCT k2, k3: first rows of the combinations, ascending"}
     del k3
     del k2
     del k1

@@ -1616,6 +1616,54 @@ def test_sort_perm_multi_key_packed_path_unpinned(dev, specs):
     _sort_case(dev, rng, 300_000, specs, with_rid=True)
 
 
+@pytest.mark.parametrize("shape", ["even", "outlier_above_unsampled", "outlier_below_unsampled", "nulls_in_every_sampled_row", "widened_does_not_fit",
+                                   "at_int64_min", "at_int64_max"])
+@pytest.mark.parametrize("mode", ["2", "0"])
+def test_packed_words_with_ranges_from_a_sample(dev, shape, mode, monkeypatch):
+    """The packed word's column ranges come from a sample of 2^17 rows first (MDB_SORT_RANGE_SAMPLE=2: from 2^18 rows on; by default from 2^22),
+    widened by a 1024th; the packing kernel checks every row and the ranges are measured when one lies outside: an extreme value on a row
+    the sample skips, a column that is NULL wherever the sample looks, ranges that fit the word only unwidened, values at either end of
+    int64 (the widening must not wrap) - ORDER BY, GROUP BY over two columns and DISTINCT against the numpy oracle, sample on and off."""
+    monkeypatch.setenv("MDB_SORT_RANGE_SAMPLE", mode)
+    n = 600_001
+    step = n // 2**17
+
+    def sampled(r):     # k_sort_ranges: the row looked at in the k-th stretch of `step` rows
+        k = r // step
+        return k < 2**17 and r == k * step + (((k * 0x9E3779B97F4A7C15) % 2**64) >> 32) % step
+    unsampled = [r for r in range(4000, 4400) if not sampled(r)]
+    rng = np.random.default_rng(len(shape) + 3)
+    a = rng.integers(-50, 50, n, dtype=np.int64)
+    b = rng.integers(10**12, 10**12 + 300, n, dtype=np.int64)
+    na = None
+    if shape == "outlier_above_unsampled":
+        a[unsampled[0]] = 10**6
+    elif shape == "outlier_below_unsampled":
+        b[unsampled[1]] = -(10**9)
+    elif shape == "nulls_in_every_sampled_row":
+        na = np.ones(n, dtype=bool)
+        na[unsampled[:50]] = False
+    elif shape == "widened_does_not_fit":       # 22 + 22 value bits + 20 position bits = 64: one more bit per column does not fit
+        a = rng.integers(0, 2**22, n, dtype=np.int64)
+        b = rng.integers(0, 2**22, n, dtype=np.int64)
+        a[:2] = [0, 2**22 - 1]
+        b[:2] = [0, 2**22 - 1]
+    elif shape == "at_int64_min":
+        a = np.iinfo(np.int64).min + rng.integers(0, 100, n, dtype=np.int64)
+    elif shape == "at_int64_max":
+        a = np.iinfo(np.int64).max - rng.integers(0, 100, n, dtype=np.int64)
+    ad, bd, nad = dev.to_dev(a), dev.to_dev(b), dev.nullbits_dev(na) if na is not None else None
+    for desc in (False, True):
+        got = _np(dev.sort_perm([(ad, nad, None, D.T_INT64, desc), (bd, None, None, D.T_INT64, not desc)], n)).view(np.uint32)
+        assert np.array_equal(got, orc.sort_perm([(a, na, None, False, desc), (b, None, None, False, not desc)], n))
+    keys_np, keys_dev = [(a, na, None, False, False), (b, None, None, False, False)], [(ad, nad, None, D.T_INT64, False), (bd, None, None, D.T_INT64, False)]
+    if shape != "widened_does_not_fit":          # (the python oracle walks every row; 4 x 10^12 combinations: 600 001 groups)
+        first, cnt = dev.group_count_multi(keys_dev, n)
+        ef, ec = orc.group_count_multi(keys_np, n)
+        assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
+        assert np.array_equal(_np(dev.distinct_sel(keys_dev, n)).view(np.uint32), orc.distinct_sel(keys_np, n))
+
+
 @pytest.mark.parametrize("shape", ["high_window", "negative_window", "outlier_above", "outlier_below", "too_wide", "int64_extremes"])
 def test_narrow_form_window_anywhere_in_the_int64_range(dev, narrow_mode, shape):
     """Keys inside a 2^32-wide window far from zero (surrogate keys from 10^12 on, negative timestamps) take the narrow
