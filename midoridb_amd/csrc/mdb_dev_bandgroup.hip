@@ -47,6 +47,7 @@ struct bg_sort_args {
 	uint32_t cap, bstride, nfull /* full tiles */, ntiles;
 	uint32_t ablate;	/* measurement only (MDB_BG_ABLATE): 1 no cursor atomics, 2 no words written, 4 words written in tile order (no walk) */
 	uint32_t *status;
+	struct mdb_bg_comp comp;	/* k_bg_band_sort<., true>: the key is the composite value of these columns (keys, base unused) */
 };
 
 /* block -> tile: workgroups are dealt to the 8 XCDs round-robin; XCD x takes the bands x, x + 8, ... and runs a band's tiles one after
@@ -57,7 +58,14 @@ __device__ static inline uint32_t bg_tile_of_block(uint32_t b)
 	return ((k / BG_BAND_TILES) * 8u + xcd) * BG_BAND_TILES + (k % BG_BAND_TILES);
 }
 
-template <bool FULL>
+/* (the image of mdb_dev_sort.hip's sort_image: order does not matter here, equality does - the same bits as the packed sort's fields) */
+__device__ static inline uint64_t bg_image(uint64_t bits, int is_double, int desc)
+{
+	const uint64_t u = (is_double && (bits >> 63)) ? ~bits : (bits ^ 0x8000000000000000ull);
+	return desc ? ~u : u;
+}
+
+template <bool FULL, bool COMP = false>
 __global__ __launch_bounds__(BG_THREADS) void k_bg_band_sort(bg_sort_args a)
 {
 	extern __shared__ uint32_t bg_lds[];
@@ -82,6 +90,65 @@ __global__ __launch_bounds__(BG_THREADS) void k_bg_band_sort(bg_sort_args a)
 	uint32_t hr[BG_ITEMS];
 	uint32_t bad = 0;
 	const uint32_t kmask = (1u << a.kbits) - 1u;
+	if (COMP) {
+		/* the composite value of a row, column by column (most significant first): 4 x 16 bytes of a column in flight per thread, the
+		 * fields shifted into a 32-bit word (kbits <= 25) - two workgroups per CU as for a single key column */
+		constexpr int CL = 4;
+#pragma unroll
+		for (int jb = 0; jb < (int)BG_ITEMS / 2; jb += CL) {
+			uint32_t acc[CL][2];
+#pragma unroll
+			for (int jj = 0; jj < CL; jj++)
+				acc[jj][0] = acc[jj][1] = 0u;
+#pragma unroll
+			for (int c = 0; c < MDB_BG_COMP_MAX; c++) {
+				if (c >= a.comp.nkeys)
+					break;
+				const uint64_t *const col = a.comp.values[c] + row0;
+				const uint64_t *const nb = a.comp.nullbits[c];
+				const uint32_t kb = a.comp.kb[c];
+				ulonglong2 pre[CL];
+#pragma unroll
+				for (int jj = 0; jj < CL; jj++) {
+					const uint32_t p = (uint32_t)(jb + jj) * BG_THREADS + threadIdx.x;
+					if (FULL) {
+						pre[jj] = reinterpret_cast<const ulonglong2 *>(col)[p];
+					} else {
+						pre[jj] = make_ulonglong2(0ull, 0ull);
+						if (2u * p < cnt)
+							pre[jj].x = col[2u * p];
+						if (2u * p + 1u < cnt)
+							pre[jj].y = col[2u * p + 1u];
+					}
+				}
+#pragma unroll
+				for (int jj = 0; jj < CL; jj++)
+#pragma unroll
+					for (int e = 0; e < 2; e++) {
+						const uint32_t r = 2u * ((uint32_t)(jb + jj) * BG_THREADS + threadIdx.x) + (uint32_t)e;
+						const bool live = FULL || r < cnt;
+						const bool isnull = nb && live && mdb_bit_is_set(nb, row0 + r);
+						uint64_t d = bg_image(e ? pre[jj].y : pre[jj].x, a.comp.is_double[c], a.comp.desc[c]) - a.comp.lo[c];
+						d = (isnull || !live) ? 0ull : d;
+						bad |= d > a.comp.span[c] ? 1u : 0u;
+						const uint32_t flag = nb ? (uint32_t)(isnull == (a.comp.desc[c] != 0)) : 0u;
+						acc[jj][e] = nb ? (acc[jj][e] << (kb + 1u)) | (flag << kb) | (uint32_t)d : (acc[jj][e] << kb) | (uint32_t)d;
+					}
+			}
+#pragma unroll
+			for (int jj = 0; jj < CL; jj++)
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const uint32_t r = 2u * ((uint32_t)(jb + jj) * BG_THREADS + threadIdx.x) + (uint32_t)e;
+					const uint32_t h = mdb_mixk(acc[jj][e] & kmask, a.kbits);
+					hr[2 * (jb + jj) + e] = h;
+					if (FULL || r < cnt) {
+						const uint32_t d = h >> rem;
+						atomicAdd(&s_cnt[d >> 1], 1u << (16u * (d & 1u)));
+					}
+				}
+		}
+	} else {
 #pragma unroll
 	for (int jb = 0; jb < (int)BG_ITEMS / 2; jb += BG_LOADS) {
 		ulonglong2 pre[BG_LOADS];
@@ -114,6 +181,7 @@ __global__ __launch_bounds__(BG_THREADS) void k_bg_band_sort(bg_sort_args a)
 				}
 			}
 		}
+	}
 	}
 	if (bad)
 		mdb_raise(a.status, 128u);
@@ -421,9 +489,16 @@ static uint32_t bg_dbits(uint32_t kbits)
 /* 0 = done: out_first[g] / out_count[g] = the first row and the rows of group g, groups in first-row order; 1 = not served (the caller's
  * other forms answer; *outside: a key lay outside the window); < 0 = error.  Synchronises. */
 int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
-			   uint64_t cap, uint64_t *out_groups, bool *outside)
+			   uint64_t cap, uint64_t *out_groups, bool *outside, const struct mdb_bg_comp *comp)
 {
 	*outside = false;
+	if (comp) {
+		if (comp->nkeys < 1 || comp->nkeys > MDB_BG_COMP_MAX || ctx->explain)
+			return 1;
+		for (int c = 0; c < comp->nkeys; c++)
+			if ((uintptr_t)comp->values[c] & 15u)
+				return 1;
+	}
 	if (kbits < 18u || kbits > 14u + BG_MAX_DBITS || n < ((uint64_t)1 << 21) || n >= 0xF0000000ull || ((uintptr_t)keys & 15u) ||
 	    (mdb_knob("MDB_GROUP_BANDED") && mdb_knob("MDB_GROUP_BANDED")[0] == '0'))
 		return 1;
@@ -447,7 +522,7 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	size_t need = mdb_align_up((size_t)nbands * bstride * 4 + 64) + mdb_align_up((size_t)D * nbands * 4) + mdb_align_up(most * 8) +
 		      order_records_arena_bytes(most, n, row_bits, sb1, sb2) + 16384;
 	/* (nearly unique keys need nearly as many key values as rows: a window with fewer cannot hold them - no pilot) */
-	const bool dense_ok = n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(mdb_knob("MDB_GROUP_DENSE") && mdb_knob("MDB_GROUP_DENSE")[0] == '0');
+	const bool dense_ok = !comp && n >= ((uint64_t)1 << 22) && values >= n - n / 16 && !(mdb_knob("MDB_GROUP_DENSE") && mdb_knob("MDB_GROUP_DENSE")[0] == '0');
 	if (dense_ok)
 		need += mdb_dense_arena_bytes(n) + mdb_align_up((n / 8 + 4096) * 8);
 	if (ctx->explain) {	/* (mdb_dev_explain_group_count: the band sort serves - nothing is launched; nearly unique keys: a pilot decides) */
@@ -484,15 +559,27 @@ int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, in
 	sa.ntiles = ntiles;
 	sa.status = ctx->d_status;
 	sa.ablate = mdb_knob("MDB_BG_ABLATE") ? (uint32_t)atoi(mdb_knob("MDB_BG_ABLATE")) : 0u;
+	if (comp)
+		sa.comp = *comp;
 	const size_t lds_sort = ((size_t)(D >> 1) + D + BG_TILE / 32u + BG_TILE) * 4;
 	if (nfull) {
 		const uint32_t full_bands = (nfull + BG_BAND_TILES - 1u) / BG_BAND_TILES, grid = ((full_bands + 7u) & ~7u) * BG_BAND_TILES;	/* (8 XCDs x bands per XCD x tiles per band) */
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-		MDB_LAUNCH_LDS(ctx, "group_band_sort", k_bg_band_sort<true>, grid, BG_THREADS, lds_sort, sa);
+		if (comp) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+			MDB_LAUNCH_LDS(ctx, "group_band_sort_columns", (k_bg_band_sort<true, true>), grid, BG_THREADS, lds_sort, sa);
+		} else {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+			MDB_LAUNCH_LDS(ctx, "group_band_sort", k_bg_band_sort<true>, grid, BG_THREADS, lds_sort, sa);
+		}
 	}
 	if (ntiles > nfull) {
-		MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-		MDB_LAUNCH_LDS(ctx, "group_band_sort", k_bg_band_sort<false>, 1, BG_THREADS, lds_sort, sa);
+		if (comp) {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+			MDB_LAUNCH_LDS(ctx, "group_band_sort_columns", (k_bg_band_sort<false, true>), 1, BG_THREADS, lds_sort, sa);
+		} else {
+			MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bg_band_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+			MDB_LAUNCH_LDS(ctx, "group_band_sort", k_bg_band_sort<false>, 1, BG_THREADS, lds_sort, sa);
+		}
 	}
 	bg_leaf_args la;
 	memset(&la, 0, sizeof(la));

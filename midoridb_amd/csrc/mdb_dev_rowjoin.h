@@ -36,9 +36,23 @@ int mdb_rowjoin_run_multi(mdb_dev_ctx *ctx, const int64_t *keys_l, uint64_t n_l,
 int mdb_group_count_tiled(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
 			  uint64_t cap, uint64_t *out_groups, bool *outside);
 
-/* ... through the band sort (mdb_dev_bandgroup.hip): windows of 2^18 ... 2^25 values, tables of 2^21 rows and more; same contract */
+/* a key that is the composite value of up to four columns (GROUP BY k2, k3: mdb_dev_sort.hip, group_multi_packed) - most significant first:
+ * field c = [NULL flag, where the column has a NULL bitmap | image of the value - lo[c]], kb[c] value bits; an image outside
+ * [lo[c], lo[c] + span[c]] is a key outside the window.  The band sort reads the columns itself: no composite column is written. */
+#define MDB_BG_COMP_MAX 4
+struct mdb_bg_comp {
+	const uint64_t *values[MDB_BG_COMP_MAX];	/* 16-byte aligned */
+	const uint64_t *nullbits[MDB_BG_COMP_MAX];	/* or NULL */
+	uint64_t lo[MDB_BG_COMP_MAX], span[MDB_BG_COMP_MAX];
+	uint32_t kb[MDB_BG_COMP_MAX];
+	int32_t is_double[MDB_BG_COMP_MAX], desc[MDB_BG_COMP_MAX];
+	int32_t nkeys;
+};
+
+/* ... through the band sort (mdb_dev_bandgroup.hip): windows of 2^18 ... 2^25 values, tables of 2^21 rows and more; same contract
+ * (comp != NULL: the key is that composite value, keys = its first column, win_lo = 0, kbits = the bits of all fields) */
 int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
-			   uint64_t cap, uint64_t *out_groups, bool *outside);
+			   uint64_t cap, uint64_t *out_groups, bool *outside, const struct mdb_bg_comp *comp = NULL);
 
 /* ---- groups of nearly unique keys as one bit per row + exceptions (mdb_dev_dense.hip) */
 size_t mdb_dense_arena_bytes(uint64_t n);

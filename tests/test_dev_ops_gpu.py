@@ -1240,6 +1240,77 @@ def test_group_count_multi_composite_key_forms(dev, shape):
     assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
 
 
+def _group_multi_numpy(cols, n):
+    """first rows (ascending) and COUNTs of the combinations of `cols` = [(values, nulls or None)], vectorised: NULL = NULL, values by their bits"""
+    parts = []
+    for v, nl in cols:
+        bits = np.ascontiguousarray(v).view(np.uint64).copy()
+        if nl is not None:
+            bits[nl] = 0
+            parts.append(nl.astype(np.uint64))
+        parts.append(bits)
+    _, first, cnt = np.unique(np.stack(parts, axis=1), axis=0, return_index=True, return_counts=True)
+    order = np.argsort(first, kind="stable")
+    return first[order].astype(np.int64), cnt[order].astype(np.int64)
+
+
+@pytest.mark.parametrize("shape", ["512x300", "nulls", "three_columns", "double_one_binade", "outlier_on_an_unsampled_row", "hot_combination", "17_bits", "26_bits",
+                                   "desc_and_nulls", "unaligned_column"])
+@pytest.mark.parametrize("sample", ["2", "0"])
+def test_group_count_multi_band_sort_reads_the_columns_itself(dev, shape, sample, monkeypatch):
+    """GROUP BY over columns of 18 ... 25 bits together, 2^21 rows and more, no row-id vector: k_bg_band_sort<., true> builds the composite value from
+    the columns (no composite column written).  Against numpy and against the form that writes the column (MDB_GROUP_MULTI_FUSED=0): NULLs, three
+    columns, a DOUBLE column, a value outside the sampled ranges (the band sort reports it, the ranges are measured), a combination that holds
+    half the rows (its region overflows: the other forms), 17 and 26 bits (not this form), a column that is not 16-byte aligned."""
+    monkeypatch.setenv("MDB_SORT_RANGE_SAMPLE", sample)
+    n = 2_300_001
+    rng = np.random.default_rng(len(shape) + 11)
+    I, Dbl = D.T_INT64, D.T_DOUBLE
+    a = rng.integers(0, 512, n, dtype=np.int64)
+    b = rng.integers(-150, 150, n, dtype=np.int64)
+    cols, types, descs = [(a, None), (b, None)], [I, I], [False, False]
+    if shape == "nulls":
+        cols = [(a, rng.random(n) < 0.1), (b, rng.random(n) < 0.3)]
+    elif shape == "three_columns":
+        cols = [(a, None), (rng.integers(10**12, 10**12 + 40, n, dtype=np.int64), rng.random(n) < 0.05), (rng.integers(-3, 4, n, dtype=np.int64), None)]
+        types, descs = [I, I, I], [False, False, False]
+    elif shape == "double_one_binade":
+        cols = [(1.0 + rng.integers(0, 1000, n) * 2.0**-52, None), (b, None)]
+        types = [Dbl, I]
+    elif shape == "outlier_on_an_unsampled_row":
+        step = n // 2**17
+        r = next(r for r in range(5000, 5400) if r != (r // step) * step + ((((r // step) * 0x9E3779B97F4A7C15) % 2**64) >> 32) % step)
+        b[r] = 10**7
+    elif shape == "hot_combination":
+        hot = rng.random(n) < 0.5
+        a[hot], b[hot] = 77, -3
+    elif shape == "17_bits":
+        cols = [(a, None), (rng.integers(0, 200, n, dtype=np.int64), None)]
+    elif shape == "26_bits":
+        cols = [(rng.integers(0, 2**13, n, dtype=np.int64), None), (rng.integers(0, 2**13, n, dtype=np.int64), None)]
+    elif shape == "desc_and_nulls":
+        cols = [(a, rng.random(n) < 0.02), (b, None)]
+        descs = [True, True]
+    dev_cols = []
+    for (v, nl), t in zip(cols, types):
+        vd = dev.to_dev(v)
+        if shape == "unaligned_column" and len(dev_cols) == 1:      # 8 bytes past a 16-byte boundary
+            big = torch.empty(n + 1, dtype=vd.dtype, device=dev.device)
+            big[1:] = vd
+            vd = big[1:]
+        dev_cols.append((vd, dev.nullbits_dev(nl) if nl is not None else None))
+    keys_dev = [(vd, nd, None, t, d) for (vd, nd), t, d in zip(dev_cols, types, descs)]
+    first, cnt = dev.group_count_multi(keys_dev, n)
+    ef, ec = _group_multi_numpy(cols, n)
+    assert np.array_equal(_np(first).view(np.uint32).astype(np.int64), ef) and np.array_equal(_np(cnt), ec)
+    monkeypatch.setenv("MDB_GROUP_MULTI_FUSED", "0")
+    first0, cnt0 = dev.group_count_multi(keys_dev, n)
+    assert torch.equal(first0, first) and torch.equal(cnt0, cnt)
+    monkeypatch.delenv("MDB_GROUP_MULTI_FUSED")
+    sel = dev.distinct_sel(keys_dev, n)
+    assert np.array_equal(_np(sel).view(np.uint32).astype(np.int64), ef)
+
+
 def test_group_count_multi_large_property_unpinned(dev):
     """10^7 rows, key = (i mod 1000, i mod 7): 7000 groups (1000 and 7 are coprime), counts n/7000 +- 1, firsts = 0..6999."""
     n = 10_000_000
