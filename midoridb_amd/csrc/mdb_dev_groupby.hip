@@ -4,6 +4,7 @@
  * integer work: no MFMA.
  */
 #include "mdb_dev_join_internal.h"
+#include "mdb_dev_rowjoin.h"	/* (struct mdb_bg_comp: a key that is the composite value of several columns) */
 
 /* ------------------------------------------------------------------ GROUP BY over a small value range
  *
@@ -35,8 +36,10 @@ struct gd_args {
 	unsigned long long *g_cnt;	/* [GD_TABLE_MAX + 1] */
 	uint32_t *g_first;		/* [GD_TABLE_MAX + 1] */
 	uint32_t *status;		/* bit 10: a value outside the window */
+	struct mdb_bg_comp comp;	/* k_group_direct<true>: slot = the composite value of these columns (keys, nullbits, base unused) */
 };
 
+template <bool COMP = false>
 __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t gd_lds[];
@@ -56,6 +59,45 @@ __global__ __launch_bounds__(GD_THREADS) void k_group_direct(gd_args a)
 	bool bad = false;
 	for (uint64_t row0 = (uint64_t)blockIdx.x * (2 * GD_THREADS); row0 < a.n; row0 += (uint64_t)gridDim.x * (2 * GD_THREADS)) {
 		const uint64_t i0 = row0 + 2 * (uint64_t)threadIdx.x;
+		if (COMP) {
+			/* GROUP BY over several columns of few values each (group_multi_packed, mdb_dev_sort.hip): the slot is built from the columns,
+			 * most significant first - [NULL flag | image - lo] per column; a value outside its field is a value outside the window */
+			uint32_t acc[2] = { 0u, 0u };
+#pragma unroll
+			for (int c = 0; c < MDB_BG_COMP_MAX; c++) {
+				if (c >= a.comp.nkeys)
+					break;
+				const uint64_t *const col = a.comp.values[c], *const nb = a.comp.nullbits[c];
+				const uint32_t kb = a.comp.kb[c];
+				uint64_t q[2] = { 0ull, 0ull };
+				if (i0 + 1 < a.n) {
+					const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(col + i0);
+					q[0] = t.x;
+					q[1] = t.y;
+				} else if (i0 < a.n) {
+					q[0] = col[i0];
+				}
+#pragma unroll
+				for (int u = 0; u < 2; u++) {
+					const uint64_t row = i0 + (uint64_t)u;
+					const bool valid = row < a.n, isnull = valid && nb && mdb_bit_is_set(nb, row);
+					const uint64_t bits = q[u], im0 = (a.comp.is_double[c] && (bits >> 63)) ? ~bits : (bits ^ 0x8000000000000000ull);
+					uint64_t d = (a.comp.desc[c] ? ~im0 : im0) - a.comp.lo[c];
+					d = (isnull || !valid) ? 0ull : d;
+					bad = bad || d > a.comp.span[c];
+					const uint32_t flag = nb ? (uint32_t)(isnull == (a.comp.desc[c] != 0)) : 0u;
+					acc[u] = nb ? (acc[u] << (kb + 1u)) | (flag << kb) | (uint32_t)d : (acc[u] << kb) | (uint32_t)d;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 2; u++)
+				if (i0 + (uint64_t)u < a.n && acc[u] < a.range) {
+					const uint32_t idx = acc[u] | copy;
+					atomicAdd(&s_cnt[idx], 1u);
+					atomicMin(&s_first[idx], (uint32_t)(i0 + (uint64_t)u));
+				}
+			continue;
+		}
 		int64_t k[2] = { 0, 0 };
 		if (i0 + 1 < a.n) {
 			const longlong2 q = *reinterpret_cast<const longlong2 *>(a.keys + i0);
@@ -143,6 +185,73 @@ __global__ void k_group_direct_counts(int64_t *out_count, uint64_t G, const unsi
 	out_count[g] = (int64_t)(g_cnt_r ? g_cnt[slot] * g_cnt_r[slot] : g_cnt[slot]);
 }
 
+/* GROUP BY over several columns whose composite value has at most 14 bits (mdb_dev_sort.hip, group_multi_packed): the same LDS tables, the slot
+ * built from the columns as they are loaded.  0 = done (groups in first-row order), 1 = not served (too many bits, too few rows, a value outside
+ * its field - ranges from a sample), < 0 = error.  Synchronises. */
+int mdb_group_count_direct_comp(mdb_dev_ctx *ctx, const struct mdb_bg_comp *comp, uint64_t n, uint32_t bits, uint32_t *out_first, int64_t *out_count,
+				uint64_t cap, uint64_t *out_groups)
+{
+	if (bits > 14u || n < GD_MIN_ROWS || n >= 0xFFFFFFFFull || comp->nkeys < 1 || comp->nkeys > MDB_BG_COMP_MAX || ctx->explain)
+		return 1;
+	for (int c = 0; c < comp->nkeys; c++)
+		if ((uintptr_t)comp->values[c] & 15u)
+			return 1;
+	const uint32_t shift = bits < 6u ? 6u : bits, range = 1u << shift;
+	uint32_t copies = GD_RANGE >> shift;
+	copies = copies > 64 ? 64 : (copies < 1 ? 1 : copies);
+	uint32_t kbits = 0;
+	const size_t order_bytes = mdb_order_records_arena_bytes(GD_TABLE_MAX + 1, n, &kbits);
+	if (!order_bytes)
+		return 1;
+	int rc = mdb_arena_begin(ctx, order_bytes + 4 * mdb_align_up((GD_TABLE_MAX + 1) * 8) + 8192);
+	if (rc)
+		return rc;
+	gd_args a;
+	memset(&a, 0, sizeof(a));
+	a.n = n;
+	a.range = range;
+	a.copy_shift = shift;
+	a.copy_mask = copies - 1;
+	a.table = copies << shift;
+	a.comp = *comp;
+	a.g_cnt = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
+	a.g_first = (uint32_t *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 4);
+	a.status = ctx->d_status;
+	unsigned long long *rec = (unsigned long long *)mdb_arena_take(ctx, (GD_TABLE_MAX + 1) * 8);
+	if (!a.g_cnt || !a.g_first || !rec)
+		return -MIDORIDB_INTERNAL;
+	uint32_t *rec_n = ctx->d_status + 1;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_cnt, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
+	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
+	const size_t lds = (size_t)a.table * 8;
+	const uint32_t resident = (lds > 80 * 1024 ? 1u : 2u) * (uint32_t)ctx->num_cus;
+	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group_direct<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
+	MDB_LAUNCH_LDS(ctx, "group_direct_columns", k_group_direct<true>, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, a);
+	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, (const unsigned long long *)NULL, kbits, rec, rec_n,
+		   (unsigned long long *)(ctx->d_status + 2));
+	uint32_t *h32 = (uint32_t *)ctx->h_pinned;
+	MDB_HIP(ctx, hipMemcpyAsync(h32, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h32[0] & 1024u)
+		return 1;	/* a value outside its field */
+	const uint64_t G = h32[1];
+	if (G > cap)
+		return mdb_set_err(ctx, -MIDORIDB_ERROR, "group output capacity %llu too small for %llu groups", (unsigned long long)cap,
+				   (unsigned long long)G);
+	*out_groups = G;
+	if (G == 0)
+		return 0;
+	MDB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+	rc = mdb_order_records_by_rowid(ctx, rec, G, n, kbits, out_first, out_count);
+	if (rc)
+		return rc < 0 ? rc : -MIDORIDB_INTERNAL;
+	MDB_LAUNCH(ctx, "group_direct_counts", k_group_direct_counts, (uint32_t)((G + 255) / 256), 256, out_count, G, (const unsigned long long *)a.g_cnt,
+		   (const unsigned long long *)NULL);
+	return mdb_dev_sync(ctx);
+}
+
 /* 0 = done, 1 = not applicable (use the partitioned path), < 0 = error.  keys_r != NULL: the join form (both key columns
  * inside one window; NULL keys never join) - also the cheap way through joins on a handful of hot values. */
 int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *nullbits, uint64_t n, const int64_t *keys_r,
@@ -209,10 +318,10 @@ int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 	MDB_HIP(ctx, hipMemsetAsync(a.g_first, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
 	const size_t lds = (size_t)a.table * 8;
 	const uint32_t resident = (lds > 80 * 1024 ? 1u : 2u) * (uint32_t)ctx->num_cus;
-	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	MDB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group_direct<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	{
 		const uint64_t chunks = (n + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, a);
+		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct<false>, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, a);
 	}
 	if (keys_r) {
 		gd_args b = a;
@@ -224,7 +333,7 @@ int group_direct_try(mdb_dev_ctx *ctx, const int64_t *keys, const uint64_t *null
 		MDB_HIP(ctx, hipMemsetAsync(g_cnt_r, 0, (GD_TABLE_MAX + 1) * 8, ctx->stream));
 		MDB_HIP(ctx, hipMemsetAsync(g_first_r, 0xFF, (GD_TABLE_MAX + 1) * 4, ctx->stream));
 		const uint64_t chunks = (n_r + 2 * GD_THREADS - 1) / (2 * GD_THREADS);
-		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, b);
+		MDB_LAUNCH_LDS(ctx, "group_direct", k_group_direct<false>, (uint32_t)(chunks < resident ? chunks : resident), GD_THREADS, lds, b);
 	}
 	MDB_LAUNCH(ctx, "group_direct_emit", k_group_direct_emit, (range + 1 + 255) / 256, 256, a, (const unsigned long long *)g_cnt_r, kbits, rec, rec_n,
 		   d_joined);

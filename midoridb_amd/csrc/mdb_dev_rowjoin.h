@@ -54,6 +54,10 @@ struct mdb_bg_comp {
 int mdb_group_count_banded(mdb_dev_ctx *ctx, const int64_t *keys, uint64_t n, int64_t win_lo, uint32_t kbits, uint32_t *out_first, int64_t *out_count,
 			   uint64_t cap, uint64_t *out_groups, bool *outside, const struct mdb_bg_comp *comp = NULL);
 
+/* ... through per-workgroup LDS tables (mdb_dev_groupby.hip): composite values of at most 14 bits; 1 = not served */
+int mdb_group_count_direct_comp(mdb_dev_ctx *ctx, const struct mdb_bg_comp *comp, uint64_t n, uint32_t bits, uint32_t *out_first, int64_t *out_count,
+				uint64_t cap, uint64_t *out_groups);
+
 /* ---- groups of nearly unique keys as one bit per row + exceptions (mdb_dev_dense.hip) */
 size_t mdb_dense_arena_bytes(uint64_t n);
 int mdb_dense_bits_begin(mdb_dev_ctx *ctx, uint64_t n, unsigned long long **bits);

@@ -1076,12 +1076,13 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 	memset(&pa, 0, sizeof(pa));
 	pa.nkeys = nkeys;
 	pa.nopos = 1;
+	bool pa_measured = false;
 	/* 18 ... 25 bits in all, no row-id vector: the band sort reads the columns itself (k_bg_band_sort<., true>) - no composite column is
 	 * written and read back (0.45 ms per 10^8 rows and two columns).  A row outside the sampled ranges, a hot combination that overflows
 	 * a region: the composite column below.  MDB_GROUP_MULTI_FUSED=0: never. */
 	{
 		const char *fk = mdb_knob("MDB_GROUP_MULTI_FUSED");
-		bool plain = !(fk && fk[0] == '0') && n >= ((uint64_t)1 << 21);
+		bool plain = !(fk && fk[0] == '0') && n >= ((uint64_t)1 << 18);	/* (the band sort: from 2^21 rows on - it says so itself) */
 		for (int c = 0; c < nkeys; c++)
 			plain = plain && !keys[c].rid && !((uintptr_t)keys[c].values & 15u);
 		if (plain) {
@@ -1089,7 +1090,8 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 			rc = sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 25, NULL, sort_ranges_sampled(n));
 			if (rc < 0)
 				return rc;
-			if (rc == 0 && total >= 18) {
+			pa_measured = rc == 0 && !sort_ranges_sampled(n);	/* (measured ranges of every column: good for the composite column below as well) */
+			if (rc == 0 && (total >= 18 || total <= 14)) {
 				struct mdb_bg_comp bc;
 				memset(&bc, 0, sizeof(bc));
 				bc.nkeys = nkeys;
@@ -1103,7 +1105,10 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 					bc.desc[c] = keys[c].desc;
 				}
 				bool outside = false;
-				rc = mdb_group_count_banded(ctx, (const int64_t *)keys[0].values, n, 0, total, out_first, out_count, cap, out_groups, &outside, &bc);
+				if (total <= 14)	/* (few combinations: per-workgroup LDS tables, k_group_direct<true>) */
+					rc = mdb_group_count_direct_comp(ctx, &bc, n, total, out_first, out_count, cap, out_groups);
+				else
+					rc = mdb_group_count_banded(ctx, (const int64_t *)keys[0].values, n, 0, total, out_first, out_count, cap, out_groups, &outside, &bc);
 				if (rc <= 0)
 					return rc;
 				*out_groups = 0;
@@ -1120,9 +1125,9 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 		return rc;
 	uint64_t *h = ctx->h_pinned;
 	auto pack = [&]() -> int {	/* 0 = comp holds the composite values, 1 = they do not fit 63 bits */
-		for (bool sampled = sort_ranges_sampled(n);; sampled = false) {
+		for (bool sampled = !pa_measured && sort_ranges_sampled(n);; sampled = false) {
 			uint32_t total = 0;
-			const int rrc = sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 63, NULL, sampled);
+			const int rrc = pa_measured ? 0 : sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 63, NULL, sampled);
 			if (rrc == 1 && sampled)
 				continue;
 			if (rrc)

@@ -38,3 +38,14 @@ os.environ["MDB_GROUP_MULTI_PACKED"] = "1"
 keys = [(k2, None, None, D.T_INT64, False), (k3, None, None, D.T_INT64, False)]
 dev.prof_enable(True); dev.prof_reset(); run(); prof = dev.prof_read(); dev.prof_enable(False)
 print({k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]})
+# few combinations: 16 x 50
+a = torch.randint(0, 16, (n,), device=dev.device, generator=g, dtype=torch.int64)
+b = torch.randint(100, 150, (n,), device=dev.device, generator=g, dtype=torch.int64)
+keys = [(a, None, None, D.T_INT64, False), (b, None, None, D.T_INT64, False)]
+for fused in ("1", "0"):
+    os.environ["MDB_GROUP_MULTI_FUSED"] = fused
+    f, c = run(); torch.cuda.synchronize()
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter(); f, c = run(); torch.cuda.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
+    print("16 x 50 combinations, fused", fused, "groups", f.numel(), "sum", int(c.sum()), "ms", [round(x, 3) for x in t])

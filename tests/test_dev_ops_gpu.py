@@ -1255,7 +1255,7 @@ def _group_multi_numpy(cols, n):
 
 
 @pytest.mark.parametrize("shape", ["512x300", "nulls", "three_columns", "double_one_binade", "outlier_on_an_unsampled_row", "hot_combination", "17_bits", "26_bits",
-                                   "desc_and_nulls", "unaligned_column"])
+                                   "desc_and_nulls", "unaligned_column", "16x50", "16x50_nulls", "14_bits", "four_flags", "16x50_outlier"])
 @pytest.mark.parametrize("sample", ["2", "0"])
 def test_group_count_multi_band_sort_reads_the_columns_itself(dev, shape, sample, monkeypatch):
     """GROUP BY over columns of 18 ... 25 bits together, 2^21 rows and more, no row-id vector: k_bg_band_sort<., true> builds the composite value from
@@ -1291,6 +1291,18 @@ def test_group_count_multi_band_sort_reads_the_columns_itself(dev, shape, sample
     elif shape == "desc_and_nulls":
         cols = [(a, rng.random(n) < 0.02), (b, None)]
         descs = [True, True]
+    elif shape in ("16x50", "16x50_nulls", "16x50_outlier"):       # at most 14 bits: per-workgroup LDS tables, the slot built from the columns
+        c1, c2 = rng.integers(-8, 8, n, dtype=np.int64), rng.integers(10**9, 10**9 + 50, n, dtype=np.int64)
+        if shape == "16x50_outlier":
+            step = n // 2**17
+            r = next(r for r in range(9000, 9400) if r != (r // step) * step + ((((r // step) * 0x9E3779B97F4A7C15) % 2**64) >> 32) % step)
+            c2[r] = 7
+        cols = [(c1, rng.random(n) < 0.2 if shape == "16x50_nulls" else None), (c2, rng.random(n) < 0.01 if shape == "16x50_nulls" else None)]
+    elif shape == "14_bits":
+        cols = [(a, None), (rng.integers(0, 32, n, dtype=np.int64), None)]
+    elif shape == "four_flags":
+        cols = [(rng.integers(0, 2, n, dtype=np.int64), rng.random(n) < 0.3) for _ in range(4)]
+        types, descs = [I] * 4, [False, True, False, True]
     dev_cols = []
     for (v, nl), t in zip(cols, types):
         vd = dev.to_dev(v)
