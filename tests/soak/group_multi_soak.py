@@ -70,8 +70,9 @@ for seed in range(seeds):
     first, cnt = dev.group_count_multi(keys_dev, n)
     prof = dev.prof_read()
     dev.prof_enable(False)
-    form = ("columns->band sort" if "group_band_sort_columns" in prof else "columns->LDS tables" if "group_direct_columns" in prof
-            else "composite column" if "groupby_pack" in prof else "sort of the stream")
+    ran = lambda name: name in prof and prof[name][1] > 0
+    form = "+".join(f for f, k in (("columns->band sort", "group_band_sort_columns"), ("columns->LDS tables", "group_direct_columns"),
+                                   ("composite column", "groupby_pack"), ("sort of the stream", "groupby_heads")) if ran(k))
     forms[form] = forms.get(form, 0) + 1
     ef, ec = numpy_groups(cols, rid.astype(np.int64) if rid is not None else None, n)
     ok = np.array_equal(first.cpu().numpy().view(np.uint32).astype(np.int64), ef) and np.array_equal(cnt.cpu().numpy(), ec)
