@@ -377,7 +377,11 @@ int mdb_dev_distinct_sel(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int 
 /* GROUP BY col_1, ..., col_k + COUNT(*) with composite-key semantics (rows are one group when they agree on every
  * column, NULL = NULL): the reference instead applies its single-field loop once per field
  * (executor_select.c:1537-1541), which is not a grouping by the combination - see DESIGN.md 2.  Output as
- * mdb_dev_group_count(): out_first[g] = stream position of the group's first row (ascending), out_count[g]. */
+ * mdb_dev_group_count(): out_first[g] = stream position of the group's first row (ascending), out_count[g].
+ * Columns whose value ranges fit 63 bits together are ONE key for mdb_dev_group_count's forms (round 6): built from the
+ * columns as they are loaded where the composite has at most 14 or 18 ... 25 bits and there is no row-id vector, written
+ * as a composite column otherwise; wider combinations, or more than four columns: a stable sort of the stream and its
+ * run heads.  mdb_dev_distinct_sel() above takes the same road. */
 int mdb_dev_group_count_multi(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys, int nkeys, uint64_t n, uint32_t *out_first,
 			      int64_t *out_count, uint64_t cap, uint64_t *out_groups);
 
