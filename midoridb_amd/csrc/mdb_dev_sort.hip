@@ -1076,7 +1076,7 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 	memset(&pa, 0, sizeof(pa));
 	pa.nkeys = nkeys;
 	pa.nopos = 1;
-	bool pa_measured = false;
+	bool pa_measured = false, sample_failed = false;
 	/* 18 ... 25 bits in all, no row-id vector: the band sort reads the columns itself (k_bg_band_sort<., true>) - no composite column is
 	 * written and read back (0.45 ms per 10^8 rows and two columns).  A row outside the sampled ranges, a hot combination that overflows
 	 * a region: the composite column below.  MDB_GROUP_MULTI_FUSED=0: never. */
@@ -1112,6 +1112,7 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 				if (rc <= 0)
 					return rc;
 				*out_groups = 0;
+				sample_failed = outside || total <= 14;	/* (a value outside the sampled ranges: the composite column starts from measured ones) */
 			}
 			/* (the band sort began an arena of its own) */
 			if ((rc = mdb_arena_begin(ctx, 8192)))
@@ -1125,7 +1126,7 @@ static int group_multi_packed(mdb_dev_ctx *ctx, const struct mdb_sort_key *keys,
 		return rc;
 	uint64_t *h = ctx->h_pinned;
 	auto pack = [&]() -> int {	/* 0 = comp holds the composite values, 1 = they do not fit 63 bits */
-		for (bool sampled = !pa_measured && sort_ranges_sampled(n);; sampled = false) {
+		for (bool sampled = !pa_measured && !sample_failed && sort_ranges_sampled(n);; sampled = false) {
 			uint32_t total = 0;
 			const int rrc = pa_measured ? 0 : sort_pack_ranges(ctx, keys, nkeys, n, mm, &pa, &total, 63, NULL, sampled);
 			if (rrc == 1 && sampled)
