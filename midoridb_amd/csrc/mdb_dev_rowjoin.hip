@@ -297,7 +297,9 @@ __device__ static inline uint32_t rj_digit_of_block(uint32_t b, uint32_t D)
  * has in flight: `load(unit, i)` is called for UNITS pieces' words first (it only ISSUES loads into the caller's registers), then
  * `use(unit, i)` for each of them; words beyond a piece's first LPP take the same two calls, tier by tier (below).
  * All lanes of the wave call it together. */
-template <int LPP, int UNITS, typename FL, typename FU, typename FD>
+template <int LPP, int UNITS, bool PER_SWEEP = false /* the lane-derived terms are worked out again in every sweep (callers whose own state leaves them no registers: kept across the
+							  * sweeps they are spilled and reloaded BETWEEN the loads of a batch, behind s_waitcnt vmcnt(0) - each such load waits for the one before) */,
+	  typename FL, typename FU, typename FD>
 __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, FD done /* after the `use`s of a batch */,
 					    bool skip_slow = false /* measurement only: pieces are cut off after LPP words */)
 {
@@ -311,6 +313,8 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 	const uint32_t *const o0 = offT + (size_t)d * tstride;
 #pragma unroll 1
 	for (uint32_t t0 = wave * 64u; t0 < ntiles; t0 += nwaves * 64u * RJ_G) {
+		if (PER_SWEEP)
+			asm volatile("" : "+v"(lane));
 		/* a piece's start | end << 16 stays ONE word until the lanes that walk the piece have it: one crossbar read per step, not two - the
 		 * leaf is bound by what it asks of the LDS pipeline (~20 cycles per wave-instruction and CU, profiles/r06/lds_atomics.txt: crossbar
 		 * reads, table atomics, cell reads), round 6 */
@@ -399,10 +403,10 @@ __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstri
 	}
 }
 
-template <int LPP, int UNITS, typename FL, typename FU>
+template <int LPP, int UNITS, bool PER_SWEEP = false, typename FL, typename FU>
 __device__ static inline void rj_for_pieces(const uint32_t *offT, uint32_t tstride, uint32_t ntiles, uint32_t d, FL load, FU use, bool skip_slow = false)
 {
-	rj_for_pieces<LPP, UNITS>(offT, tstride, ntiles, d, load, use, [] {}, skip_slow);
+	rj_for_pieces<LPP, UNITS, PER_SWEEP>(offT, tstride, ntiles, d, load, use, [] {}, skip_slow);
 }
 
 /* The same for pieces of 32 words and more (windows of up to 2^24 values: 1024 digits and fewer): the whole wave walks one piece after
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 				if (LPP == 64)
 					rj_for_long_pieces<UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us);
 				else
-					rj_for_pieces<LP, UB>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, (a.ablate & 16u) != 0);
+					rj_for_pieces<LP, UB, (LPP != 8)>(a.offT_r[s], a.tstride_r[s], a.ntiles_r[s], d, ld, us, (a.ablate & 16u) != 0);
 			}
 		}
 		RJ_STAMP();	/* 2: this wave's share of the build done */
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_leaf(rj_leaf_args a)
 			if (LONG)
 				rj_for_long_pieces<UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us);
 			else
-				rj_for_pieces<LPP, UP>(a.offT_l, a.tstride, a.ntiles, d, ld, us, (a.ablate & 16u) != 0);
+				rj_for_pieces<LPP, UP, (LPP != 8)>(a.offT_l, a.tstride, a.ntiles, d, ld, us, (a.ablate & 16u) != 0);
 		}
 		RJ_STAMP();	/* 4: this wave's share of the probe done */
 	}
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf_dense(rg_grou
 			atomicAdd(&s_count[slot], 1u);
 			live |= 1u << u;
 		};
-		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
+		rj_for_pieces<LPP, UG, true>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
 				       [&](int u, uint32_t idx) { ask(u, w[u], idx); },
 				       [&] {
 #pragma unroll
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(RJ_LEAF_THREADS) void k_rj_group_leaf(rg_group_args
 			atomicMin(&s_first[slot], row);
 			atomicAdd(&s_count[slot], 1u);
 		};
-		rj_for_pieces<LPP, UG>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
+		rj_for_pieces<LPP, UG, true>(a.offT, a.tstride, a.ntiles, d, [&](int u, uint32_t idx) { w[u] = a.words[idx]; },
 				       [&](int u, uint32_t idx) { take(w[u], idx); });
 	}
 	__syncthreads();
