@@ -17,6 +17,12 @@
  *   NULL pass       one extra 1-bit pass when the column holds NULLs (first for ASC, last for DESC)
  *
  * HBM traffic per 8-bit pass and row: 8 B (histogram read) + 12 B read + 12 B written.
+ *
+ * Round 6: the packed word's column ranges come from a jittered sample of 2^17 rows first (sort_pack_ranges; the packing kernel checks
+ * every row, measured ranges - all columns in one pass, k_sort_ranges - when one lies outside); and GROUP BY / SELECT DISTINCT over several
+ * columns do not sort at all where the columns' ranges fit 63 bits together (group_multi_packed): the composite value is a key for
+ * mdb_dev_group_count's forms - built from the columns by the band sort (18 ... 25 bits, mdb_dev_bandgroup.hip) or the per-workgroup LDS
+ * tables (at most 14 bits, mdb_dev_groupby.hip) as they load them, written as an 8-byte column otherwise.
  */
 #include "mdb_dev_internal.h"
 #include "mdb_dev_rowjoin.h"	/* (mdb_group_count_banded: the band sort reads the columns of a composite key itself) */
